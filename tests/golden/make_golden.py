@@ -1,0 +1,188 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+    python tests/golden/make_golden.py            # needs /root/reference (read-only import)
+
+The reference is imported, never copied: only inputs, weights and the outputs it produced are
+written (as .npz).  The GPU box has no /root/reference; the tests read the .npz files only.
+Shims: thop stub (utils.py:17 imports it, never calls it on this path),
+torchvision stub (dataloader.py:4), np.Inf alias.  Nothing in the reference tree is modified.
+"""
+import os
+import sys
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("RUL_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+import numpy as np
+import torch
+
+if "thop" not in sys.modules:
+    thop = types.ModuleType("thop")
+    thop.profile = lambda *a, **k: (0, 0)
+    sys.modules["thop"] = thop
+if "torchvision" not in sys.modules:
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tv.transforms
+if not hasattr(np, "Inf"):
+    np.Inf = np.inf
+
+from models.ST_GCN import Model as ref_model          # noqa: E402
+from algorithms.algorithms import get_algorithm_class  # noqa: E402
+import utils as ref_utils                              # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)
+
+
+# nn.Dropout(0.0) in train mode returns its input, and the reference then does ``out += res``
+# in place on a ReLU output (models/ST_GCN/Model.py:193-194) -> autograd raises.  The reference
+# therefore cannot train with dropout exactly 0; p = 1e-12 keeps every element (keep-prob
+# 1 - 1e-12, scale 1/(1-p) == 1.0f) but makes dropout out-of-place, i.e. it is "dropout off".
+DROPOUT_OFF = 1e-12
+
+
+def perturbed_model(num_patch, patch_size, seed, dropout=DROPOUT_OFF):
+    """Reference model with weights moved away from init and non-trivial BN statistics
+    (SURVEY.md section 4 hazard 5)."""
+    torch.manual_seed(seed)
+    m = ref_model.ST_GCN_model(num_patch, patch_size, dropout=dropout)
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if ".net0." in name or ".net1." in name:
+                continue
+            if name.endswith("conv_block1.2.weight") or name.endswith("conv_block2.2.weight"):
+                p.copy_(torch.empty_like(p).uniform_(0.5, 1.5, generator=g))
+            elif name.endswith(".2.bias"):
+                p.copy_(torch.empty_like(p).uniform_(-0.3, 0.3, generator=g))
+            else:
+                p.add_(torch.empty_like(p).uniform_(-0.1, 0.1, generator=g))
+        for name, b in m.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.empty_like(b).uniform_(-0.2, 0.2, generator=g))
+            elif name.endswith("running_var"):
+                b.copy_(torch.empty_like(b).uniform_(0.5, 1.5, generator=g))
+    return m
+
+
+def state_np(m, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+
+
+def intermediates(m, x):
+    """Re-walk the reference forward with the reference's own sub-modules, keeping taps."""
+    bs = x.size(0)
+    f = ref_model.segment_and_compute_features(x.reshape(bs * m.num_patch, m.patch_size))
+    f = f.reshape(bs, m.num_patch, -1).transpose(-1, -2)
+    adj = ref_model.pcc_graph_construction(f)
+    out = f
+    per_layer = []
+    for mpnn, tcn, drop in m.sg_tcn.layers:
+        res = out
+        out = drop(tcn(mpnn(out, adj))) + res
+        per_layer.append(out.detach().numpy().copy())
+    return f.detach().numpy().copy(), adj.detach().numpy().copy(), per_layer
+
+
+def case_forward_backward(name, num_patch, patch_size, bs, seed, x_shape=None, make_nan=False):
+    m = perturbed_model(num_patch, patch_size, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    x = torch.rand(bs, num_patch, patch_size, generator=g)
+    if make_nan:
+        x[1, 3, :] = 0.25            # constant patch -> std = 0 -> skew/kurt NaN -> whole sample NaN
+    if x_shape is not None:
+        x = x.reshape(x_shape)
+    y = torch.rand(bs, 1, generator=g)
+    out = {"x": x.numpy().copy(), "y": y.numpy().copy(),
+           "num_patch": np.int64(num_patch), "patch_size": np.int64(patch_size)}
+    for k, v in state_np(m, "sd:").items():
+        out[k] = v
+    # eval forward + taps
+    m.eval()
+    with torch.no_grad():
+        out["eval_pred"] = m(x).numpy().copy()
+        f, adj, per_layer = intermediates(m, x)
+    out["feat"], out["adj"] = f, adj
+    for l, t in enumerate(per_layer):
+        out[f"eval_layer{l}"] = t
+    # train-mode forward/backward (dropout p = 0 -> deterministic), MSE loss
+    if not make_nan:
+        m.train()
+        pred = m(x)
+        loss = torch.nn.functional.mse_loss(pred, y)
+        m.zero_grad()
+        loss.backward()
+        out["train_pred"] = pred.detach().numpy().copy()
+        out["train_loss"] = np.float64(loss.item())
+        for n_, p in m.named_parameters():
+            if p.grad is not None:
+                out["grad:" + n_] = p.grad.numpy().copy()
+            else:
+                assert ".net0." in n_ or ".net1." in n_, n_
+        for k, v in state_np(m, "sd_after:").items():
+            if "running_" in k or "num_batches" in k:
+                out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items() if k in ("x", "eval_pred")})
+
+
+def case_training_curve(name, num_patch, patch_size, bs, steps, seed, lr, wd):
+    """K calls of the reference's own ST_GCN.update (algorithms/algorithms.py:481-490)."""
+    ref_utils.fix_randomness(seed)
+    algo_cls = get_algorithm_class("ST_GCN")
+    algo = algo_cls({"num_patch": num_patch, "patch_size": patch_size, "dropout": DROPOUT_OFF},
+                    {"learning_rate": lr, "weight_decay": wd, "num_epochs": 1, "batch_size": bs}, "cpu")
+    src = perturbed_model(num_patch, patch_size, seed)
+    algo.model.load_state_dict(src.state_dict())
+    out = {"num_patch": np.int64(num_patch), "patch_size": np.int64(patch_size),
+           "lr": np.float64(lr), "wd": np.float64(wd), "steps": np.int64(steps)}
+    for k, v in state_np(algo, "sd0:").items():
+        out[k] = v
+    g = torch.Generator().manual_seed(seed + 11)
+    xs = torch.rand(steps, bs, num_patch, patch_size, generator=g)
+    ys = torch.rand(steps, bs, 1, generator=g)
+    out["xs"], out["ys"] = xs.numpy().copy(), ys.numpy().copy()
+    algo.train()
+    losses = []
+    for s in range(steps):
+        losses.append(algo.update(xs[s], ys[s], 1)["loss"])
+    out["losses"] = np.asarray(losses, np.float64)
+    for k, v in state_np(algo, "sdK:").items():
+        out[k] = v
+    algo.model.eval()
+    with torch.no_grad():
+        out["eval_pred_after"] = algo.model(xs[0]).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, losses[:3], "...", losses[-1])
+
+
+def case_metrics(name, seed):
+    rng = np.random.default_rng(seed)
+    pred = rng.uniform(0, 1, 257)
+    real = rng.uniform(0.05, 1, 257)
+    s1, s2, mae, rmse = ref_utils._calc_metrics(pred, real, 125)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), pred=pred, real=real, max_rul=np.float64(125),
+                        score_v1=np.float64(s1), score_v2=np.float64(s2), mae=np.float64(mae),
+                        rmse=np.float64(rmse))
+    print("wrote", name, s1, s2, mae, rmse)
+
+
+if __name__ == "__main__":
+    # BASELINE.json configs[0]: ST_GCN, C-MAPSS FD001-shaped, 14 sensors x window 30, batch 32
+    case_forward_backward("stgcn_cmapss_14x30_bs32", 14, 30, 32, seed=1)
+    case_forward_backward("stgcn_cmapss_14x50_bs8", 14, 50, 8, seed=2)
+    # ragged: batch not a multiple of any tile, input given flat [bs, N*P] like the bearing loaders
+    case_forward_backward("stgcn_16x16_bs5_flat", 16, 16, 5, seed=3, x_shape=(5, 256))
+    case_forward_backward("stgcn_9x21_bs7", 9, 21, 7, seed=4)
+    # reference-wired PHM2012 shape (configs/hparams.py:238), [bs, 1, 2560]
+    case_forward_backward("stgcn_phm_40x64_bs4", 40, 64, 4, seed=5, x_shape=(4, 1, 2560))
+    # constant patch -> NaN propagation parity
+    case_forward_backward("stgcn_nan_14x30_bs4", 14, 30, 4, seed=6, make_nan=True)
+    case_training_curve("stgcn_train_curve_14x30_bs32", 14, 30, 32, steps=24, seed=8, lr=1e-3, wd=1e-4)
+    case_metrics("metrics_case", 9)
