@@ -1,0 +1,76 @@
+"""ctypes binding of librulgnn.so -- the only door between Python and the HIP kernels.
+
+There is deliberately no fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  Signatures mirror include/rulgnn.h one to one."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "librulgnn.so")
+
+OK = 0
+NUM_STATS = 10
+
+
+class StgcnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_patch", C.c_int32), ("patch_size", C.c_int32),
+                ("num_layers", C.c_int32), ("mpnn_k", C.c_int32)]
+
+
+class StgcnTrainArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p),
+                ("grads", C.c_void_p), ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_batch", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("global_batch", C.c_int64), ("sample_offset", C.c_int64),
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64)]
+
+
+_SIGNATURES = {
+    "rulgnn_version": (C.c_int, []),
+    "rulgnn_strerror": (C.c_char_p, [C.c_int]),
+    "rulgnn_stgcn_param_count": (C.c_int64, [C.c_int32, C.c_int32]),
+    "rulgnn_stgcn_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
+    "rulgnn_stgcn_train_workspace_bytes": (C.c_size_t, [C.POINTER(StgcnShape)]),
+    "rulgnn_stgcn_train_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_backward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_fwdbwd_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.c_void_p]),
+    "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
+                                                C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load librulgnn.so (built by ``python -m gnn_rul_benchmarking_amd.build``); raise if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -m gnn_rul_benchmarking_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU). "
+            "There is no CPU fallback for the ST_GCN path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().rulgnn_strerror(code).decode()
+
+
+def check(code: int, what: str) -> None:
+    if code != OK:
+        raise RuntimeError(f"{what} failed: rulgnn error {code} ({strerror(code)})")

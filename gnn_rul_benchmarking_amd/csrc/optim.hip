@@ -1,0 +1,56 @@
+// Optimizer-side kernels over the flat parameter buffer.
+//   adam_step:          torch.optim.Adam as the reference configures it (algorithms/algorithms.py:474-478):
+//                       L2 weight decay folded into the gradient, bias-corrected, no amsgrad.
+//   bn_running_update:  nn.BatchNorm1d running statistics (momentum 0.1, unbiased running variance).
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
+                                 float beta2, float eps, float wd, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i] * gscale);
+        const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
+        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - lr_over_bc1 * (mi / denom);
+    }
+}
+
+__global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
+                                         float unbias) {
+    // layout [n_bn][2 (mean, var)][F]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bn * 2 * F) return;
+    const bool is_var = (i / F) % 2 == 1;
+    const float b = is_var ? batch[i] * unbias : batch[i];
+    bn[i] = (1.f - momentum) * bn[i] + momentum * b;
+}
+
+int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
+              float eps, float wd, float gscale, hipStream_t stream) {
+    if (n <= 0) return RULGNN_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int block = 256;
+    int64_t grid = (n + block - 1) / block;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, p, g, m, v, n,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, hipStream_t stream) {
+    const int n_bn = num_layers * 2;
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    const int total = n_bn * 2 * F;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
+                       momentum, unbias);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+}  // namespace rulgnn

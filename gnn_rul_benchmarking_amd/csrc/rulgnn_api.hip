@@ -1,0 +1,111 @@
+// extern "C" surface of librulgnn.so (declared in include/rulgnn.h).
+#include <initializer_list>
+
+#include "stgcn_host.hpp"
+
+using namespace rulgnn;
+
+extern "C" {
+
+int rulgnn_version(void) { return 100; }   // 0.1.0
+
+const char* rulgnn_strerror(int code) {
+    switch (code) {
+        case RULGNN_OK: return "ok";
+        case RULGNN_EINVAL: return "invalid argument (shape, null pointer or hyper-parameter)";
+        case RULGNN_EUNSUPPORTED: return "shape not covered by the fused gfx950 kernels";
+        case RULGNN_EWORKSPACE: return "workspace too small";
+        case RULGNN_EHIP: return "HIP runtime error";
+        case RULGNN_EALIGN: return "pointer not 4-byte aligned";
+        default: return "unknown rulgnn error";
+    }
+}
+
+int64_t rulgnn_stgcn_param_count(int32_t num_patch, int32_t num_layers) {
+    if (num_patch < 1 || num_layers < 1) return -1;
+    return param_count(num_patch, num_layers);
+}
+
+static int check_ptrs(std::initializer_list<const void*> ps) {
+    for (const void* p : ps) {
+        if (!p) return RULGNN_EINVAL;
+        if (reinterpret_cast<uintptr_t>(p) & 3) return RULGNN_EALIGN;
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
+                             const float* bn_stats, float* pred, void* stream) {
+    int rc = validate_shape(shape);
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch == 0) return RULGNN_OK;
+    rc = check_ptrs({x, params, bn_stats, pred});
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream));
+}
+
+size_t rulgnn_stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* shape) {
+    if (validate_shape(shape) != RULGNN_OK) return 0;
+    return stgcn_train_workspace_bytes(shape);
+}
+
+static int check_train(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* a, bool need_grads) {
+    int rc = validate_shape(shape);
+    if (rc != RULGNN_OK) return rc;
+    if (!a) return RULGNN_EINVAL;
+    if (shape->batch < 1) return RULGNN_EINVAL;                 // BatchNorm needs a batch
+    if (a->global_batch < shape->batch || a->sample_offset < 0) return RULGNN_EINVAL;
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return RULGNN_EINVAL;
+    rc = check_ptrs({a->x, a->params, a->pred, a->bn_batch, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (need_grads) {
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->dpred) {
+            rc = check_ptrs({a->y, a->loss});
+            if (rc != RULGNN_OK) return rc;
+        } else if (reinterpret_cast<uintptr_t>(a->dpred) & 3) {
+            return RULGNN_EALIGN;
+        }
+    }
+    if (a->workspace_bytes < stgcn_train_workspace_bytes(shape)) return RULGNN_EWORKSPACE;
+    return RULGNN_OK;
+}
+
+int rulgnn_stgcn_train_forward_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
+    const int rc = check_train(shape, args, false);
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_train_forward(shape, args, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_train_backward(shape, args, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                         void* stream) {
+    if (n < 0 || step < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({params, grads, exp_avg, exp_avg_sq});
+    if (rc != RULGNN_OK) return rc;
+    return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                     static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_bn_running_update_f32(float* bn_stats, const float* bn_batch, int32_t num_layers, int64_t count,
+                                 float momentum, void* stream) {
+    if (num_layers < 1 || num_layers > 8 || count < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({bn_stats, bn_batch});
+    if (rc != RULGNN_OK) return rc;
+    return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

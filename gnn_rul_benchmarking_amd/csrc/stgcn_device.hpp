@@ -1,0 +1,354 @@
+// Device-side building blocks of the fused ST_GCN kernels (gfx950 / CDNA4, wave64).
+//
+// Work decomposition ("row" mapping): a wavefront holds 64/RW samples, one per RW-lane row;
+// lane t of a row owns patch t (the axis the TCN convolves over and theta mixes).  The ten
+// statistic channels of a patch live in ten VGPRs of that lane.  With RW = 16 every cross-lane
+// step is a DPP modifier on a VALU instruction: the causal shift is `row_shr`, the A.X.W
+// projection broadcasts lane k with `row_newbcast`, and row sums are quad_perm / row_mirror
+// butterflies -- no LDS traffic and no barriers inside a sample.
+//
+// Math follows reference models/ST_GCN/Model.py (line numbers cited at each block).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rulgnn {
+
+constexpr int F = 10;          // statistic channels == graph nodes (Model.py:201 in_features = 10)
+constexpr int NPAIR = 55;      // upper triangle of the symmetric 10x10 Pearson adjacency
+constexpr int CONVW = 2 * F * F;   // Conv1d(10,10,k=2) weights
+constexpr float LEAKY = 0.01f;
+constexpr float BN_EPS = 1e-5f;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = 64 * WAVES_PER_BLOCK;
+
+// packed upper-triangular index of a symmetric 10x10 matrix
+__host__ __device__ constexpr int sym(int a, int b) {
+    return (a < b ? a : b) * F - (a < b ? a : b) * ((a < b ? a : b) - 1) / 2 + ((a < b ? b : a) - (a < b ? a : b));
+}
+
+// flat parameter layout (see include/rulgnn.h)
+__host__ __device__ constexpr int layer_stride(int N) { return N * N + N + 2 * (CONVW + 2 * F); }
+__host__ __device__ constexpr int off_theta_w(int) { return 0; }
+__host__ __device__ constexpr int off_theta_b(int N) { return N * N; }
+__host__ __device__ constexpr int off_conv_w(int N, int blk) { return N * N + N + blk * (CONVW + 2 * F); }
+__host__ __device__ constexpr int off_bn_g(int N, int blk) { return off_conv_w(N, blk) + CONVW; }
+__host__ __device__ constexpr int off_bn_b(int N, int blk) { return off_conv_w(N, blk) + CONVW + F; }
+__host__ __device__ constexpr int off_fc1_w(int N, int L) { return L * layer_stride(N); }
+__host__ __device__ constexpr int off_fc1_b(int N, int L) { return off_fc1_w(N, L) + N * N; }
+__host__ __device__ constexpr int off_fc2_w(int N, int L) { return off_fc1_b(N, L) + N; }
+__host__ __device__ constexpr int off_fc2_b(int N, int L) { return off_fc2_w(N, L) + N; }
+__host__ __device__ constexpr int param_count(int N, int L) { return off_fc2_b(N, L) + 1; }
+
+// ---------------------------------------------------------------------------------------------
+// DPP primitives.  bound_ctrl = true: lanes shifted in from outside the 16-lane row read 0,
+// which is exactly the causal zero padding of Conv1d(padding=(k-1)d)+Chomp1d (Model.py:92-98).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_SHL = 0x100;
+constexpr int DPP_ROW_SHR = 0x110;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_NEWBCAST = 0x150;  // gfx90a+: broadcast lane n of each row to the row
+
+// acc[c] += src[c]@(lane K of my row) * w  for the ten channels: ten v_fmac_f32_dpp.
+// hipcc's DPP combiner folds v_mov_dpp into add/mul but not into fmac, hence the asm.
+// The leading s_nop covers the VALU-write -> DPP-read hazard (2 wait states) for whatever
+// instruction the scheduler placed in front (hipcc pads nothing inside an asm statement).
+template <int K>
+__device__ __forceinline__ void fmac10_rowbcast(float (&acc)[F], const float (&src)[F], float w) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %10, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %11, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %12, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %13, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %14, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %15, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %16, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %17, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %8, %18, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %9, %19, %20 row_newbcast:%21 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+          "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9])
+        : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]),
+          "v"(src[8]), "v"(src[9]), "v"(w), "n"(K));
+}
+// single-channel form (fc1: pooled[t] broadcast)
+template <int K>
+__device__ __forceinline__ void fmac1_rowbcast(float& acc, float src, float w) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(src), "v"(w), "n"(K));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row<RW>: cross-lane operations inside one RW-lane row (= one sample)
+// ---------------------------------------------------------------------------------------------
+template <int RW>
+struct Row {
+    static_assert(RW == 16 || RW == 32 || RW == 64, "row width");
+    static constexpr int SPW = 64 / RW;   // samples per wavefront
+
+    // sum over the row, result in every lane of the row
+    static __device__ __forceinline__ float allsum(float v) {
+        v += dpp<DPP_QUAD_XOR1>(v);
+        v += dpp<DPP_QUAD_XOR2>(v);
+        v += dpp<DPP_ROW_HALF_MIRROR>(v);
+        v += dpp<DPP_ROW_MIRROR>(v);
+        if constexpr (RW >= 32) v += __shfl_xor(v, 16, 64);
+        if constexpr (RW >= 64) v += __shfl_xor(v, 32, 64);
+        return v;
+    }
+    // value of lane (t - D) of my row, 0 for t < D      (causal tap, Model.py:134-160)
+    template <int D>
+    static __device__ __forceinline__ float shr(float v, int t) {
+        if constexpr (RW == 16) {
+            return dpp<DPP_ROW_SHR + D>(v);
+        } else {
+            float r = __shfl_up(v, D, RW);
+            return t >= D ? r : 0.f;
+        }
+    }
+    // value of lane (t + D) of my row, 0 past the end of the row  (transpose of the causal tap)
+    template <int D>
+    static __device__ __forceinline__ float shl(float v, int t) {
+        if constexpr (RW == 16) {
+            return dpp<DPP_ROW_SHL + D>(v);
+        } else {
+            float r = __shfl_down(v, D, RW);
+            return t + D < RW ? r : 0.f;
+        }
+    }
+    // acc[c] += (src[c] of lane k) * wrow[k], k = 0..RW-1 (RW == 16: unrolled DPP broadcast;
+    // wider rows: ds_bpermute).  wrow points at this lane's zero-padded weight row in LDS.
+    static __device__ __forceinline__ void project10(float (&acc)[F], const float (&src)[F], const float* wrow, int n) {
+        if constexpr (RW == 16) {
+            const float4* w4 = reinterpret_cast<const float4*>(wrow);
+            float4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];
+            fmac10_rowbcast<0>(acc, src, a.x);
+            fmac10_rowbcast<1>(acc, src, a.y);
+            fmac10_rowbcast<2>(acc, src, a.z);
+            fmac10_rowbcast<3>(acc, src, a.w);
+            fmac10_rowbcast<4>(acc, src, b.x);
+            fmac10_rowbcast<5>(acc, src, b.y);
+            fmac10_rowbcast<6>(acc, src, b.z);
+            fmac10_rowbcast<7>(acc, src, b.w);
+            fmac10_rowbcast<8>(acc, src, c.x);
+            fmac10_rowbcast<9>(acc, src, c.y);
+            fmac10_rowbcast<10>(acc, src, c.z);
+            fmac10_rowbcast<11>(acc, src, c.w);
+            fmac10_rowbcast<12>(acc, src, d.x);
+            fmac10_rowbcast<13>(acc, src, d.y);
+            fmac10_rowbcast<14>(acc, src, d.z);
+            fmac10_rowbcast<15>(acc, src, d.w);
+        } else {
+            for (int k = 0; k < n; ++k) {
+                const float w = wrow[k];
+#pragma unroll
+                for (int c = 0; c < F; ++c) acc[c] = fmaf(__shfl(src[c], k, RW), w, acc[c]);
+            }
+        }
+    }
+    static __device__ __forceinline__ void project1(float& acc, float src, const float* wrow, int n) {
+        if constexpr (RW == 16) {
+            const float4* w4 = reinterpret_cast<const float4*>(wrow);
+            float4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];
+            fmac1_rowbcast<0>(acc, src, a.x);
+            fmac1_rowbcast<1>(acc, src, a.y);
+            fmac1_rowbcast<2>(acc, src, a.z);
+            fmac1_rowbcast<3>(acc, src, a.w);
+            fmac1_rowbcast<4>(acc, src, b.x);
+            fmac1_rowbcast<5>(acc, src, b.y);
+            fmac1_rowbcast<6>(acc, src, b.z);
+            fmac1_rowbcast<7>(acc, src, b.w);
+            fmac1_rowbcast<8>(acc, src, c.x);
+            fmac1_rowbcast<9>(acc, src, c.y);
+            fmac1_rowbcast<10>(acc, src, c.z);
+            fmac1_rowbcast<11>(acc, src, c.w);
+            fmac1_rowbcast<12>(acc, src, d.x);
+            fmac1_rowbcast<13>(acc, src, d.y);
+            fmac1_rowbcast<14>(acc, src, d.z);
+            fmac1_rowbcast<15>(acc, src, d.w);
+        } else {
+            for (int k = 0; k < n; ++k) acc = fmaf(__shfl(src, k, RW), wrow[k], acc);
+        }
+    }
+};
+
+// LDS row stride (floats) of a zero-padded [RW][RW] weight matrix: RW + 4 keeps 16-B alignment
+// and makes the per-lane ds_read_b128 of consecutive rows hit distinct bank groups.
+template <int RW>
+__host__ __device__ constexpr int wstride() { return RW + 4; }
+
+// NaN-propagating activations (torch.relu / F.leaky_relu propagate NaN; fmaxf would not)
+__device__ __forceinline__ float relu(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : v * LEAKY; }
+
+// ---------------------------------------------------------------------------------------------
+// Patch statistics -- Model.py:7-52.  `pp` = this lane's patch in LDS (P floats).
+// Two passes like the reference (mean first, then central moments).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void patch_statistics(const float* pp, int P, float (&st)[F]) {
+    float s = 0.f, sq = 0.f, sa = 0.f, mx = -INFINITY, mn = INFINITY;
+    if ((P & 1) == 0) {
+        const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll 5
+        for (int i = 0; i < P / 2; ++i) {
+            const float2 v = p2[i];
+            s += v.x + v.y;
+            sq = fmaf(v.x, v.x, sq);
+            sq = fmaf(v.y, v.y, sq);
+            sa += fabsf(v.x) + fabsf(v.y);
+            mx = fmaxf(mx, fmaxf(v.x, v.y));
+            mn = fminf(mn, fminf(v.x, v.y));
+        }
+    } else {
+        for (int i = 0; i < P; ++i) {
+            const float v = pp[i];
+            s += v;
+            sq = fmaf(v, v, sq);
+            sa += fabsf(v);
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+        }
+    }
+    const float invP = 1.0f / (float)P;
+    const float mean = s * invP;
+    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
+    if ((P & 1) == 0) {
+        const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll 5
+        for (int i = 0; i < P / 2; ++i) {
+            const float2 v = p2[i];
+            const float d0 = v.x - mean, d1 = v.y - mean;
+            const float q0 = d0 * d0, q1 = d1 * d1;
+            m2 += q0 + q1;
+            m3 = fmaf(q0, d0, m3);
+            m3 = fmaf(q1, d1, m3);
+            m4 = fmaf(q0, q0, m4);
+            m4 = fmaf(q1, q1, m4);
+        }
+    } else {
+        for (int i = 0; i < P; ++i) {
+            const float d = pp[i] - mean;
+            const float q = d * d;
+            m2 += q;
+            m3 = fmaf(q, d, m3);
+            m4 = fmaf(q, q, m4);
+        }
+    }
+    const float var = m2 / (float)(P - 1);      // torch.var default: unbiased
+    const float sd = sqrtf(var);
+    const float isd = 1.0f / sd;                // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
+    const float isd2 = isd * isd;
+    st[0] = mx;
+    st[1] = mn;
+    st[2] = mx - mn;
+    st[3] = var;
+    st[4] = sd;
+    st[5] = mean;
+    st[6] = sqrtf(sq * invP);
+    st[7] = sa * invP;
+    st[8] = (m3 * invP) * (isd2 * isd);            // mean(((x-mu)/sd)^3)
+    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;    // mean(((x-mu)/sd)^4) - 3
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pearson adjacency between the ten statistic rows -- Model.py:53-71.
+// X0[c] is zero in padded lanes (t >= N).  Output: packed symmetric A, uniform over the row.
+// ---------------------------------------------------------------------------------------------
+template <int RW>
+__device__ __forceinline__ void pearson_adjacency(const float (&X0)[F], bool lane_valid, int N, float (&A)[NPAIR]) {
+    float C[F];
+    const float invN = 1.0f / (float)N;
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const float mean = Row<RW>::allsum(X0[c]) * invN;
+        C[c] = lane_valid ? X0[c] - mean : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < F; ++a)
+#pragma unroll
+        for (int b = a; b < F; ++b) A[sym(a, b)] = Row<RW>::allsum(C[a] * C[b]);
+    float nrm[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) nrm[c] = sqrtf(A[sym(c, c)]);
+#pragma unroll
+    for (int a = 0; a < F; ++a)
+#pragma unroll
+        for (int b = a; b < F; ++b) A[sym(a, b)] = A[sym(a, b)] / (nrm[a] * nrm[b]);   // 0/0 -> NaN as reference
+}
+
+// AX[c] = sum_c' A[c][c'] X[c']   (torch.bmm(A, X), Model.py:87)
+__device__ __forceinline__ void adj_aggregate(const float (&A)[NPAIR], const float (&X)[F], float (&AX)[F]) {
+#pragma unroll
+    for (int a = 0; a < F; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < F; ++b) acc = fmaf(A[sym(a, b)], X[b], acc);
+        AX[a] = acc;
+    }
+}
+
+// z[co] = sum_ci w[co][ci][0] h[ci][t-D] + w[co][ci][1] h[ci][t]; weights are wave-uniform
+// (scalar loads -> SGPR operands of v_fmac).
+template <int RW, int D>
+__device__ __forceinline__ void causal_conv(const float (&h)[F], const float* __restrict__ w, int t, float (&z)[F]) {
+    float hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) hs[c] = Row<RW>::template shr<D>(h[c], t);
+#pragma unroll
+    for (int co = 0; co < F; ++co) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < F; ++ci) {
+            acc = fmaf(w[(co * F + ci) * 2 + 0], hs[ci], acc);
+            acc = fmaf(w[(co * F + ci) * 2 + 1], h[ci], acc);
+        }
+        z[co] = acc;
+    }
+}
+
+// 32-bit mix shared bit-for-bit with oracle/stgcn_oracle.py::_lowbias32
+__device__ __forceinline__ uint32_t lowbias32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+// exact i / d for i < 2^20 given magic = ceil(2^32 / d)
+__device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t magic) { return __umulhi(i, magic); }
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative, coalesced copy of one wavefront's tile (ns samples = ns*N patches of P floats,
+// contiguous in HBM) into LDS with patch stride Ppad.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_tile(const float* __restrict__ g, float* stage, int total, int P, int Ppad,
+                                           uint32_t magicP, bool vec4, int lane) {
+    if (Ppad == P) {
+        if (vec4) {
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+            float4* s4 = reinterpret_cast<float4*>(stage);
+            const int n4 = total >> 2;
+            for (int i = lane; i < n4; i += 64) s4[i] = g4[i];
+        } else {
+            for (int i = lane; i < total; i += 64) stage[i] = g[i];
+        }
+    } else {
+        for (int i = lane; i < total; i += 64) {
+            const uint32_t m = fastdiv((uint32_t)i, magicP);
+            stage[m * Ppad + (i - m * P)] = g[i];
+        }
+    }
+}
+
+}  // namespace rulgnn

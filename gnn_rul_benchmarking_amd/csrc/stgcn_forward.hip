@@ -1,0 +1,148 @@
+// Fused eval-mode ST_GCN forward for gfx950: ONE kernel from raw windows to the RUL prediction.
+// Reference path replaced: ST_GCN_model.forward under model.eval() -- models/ST_GCN/Model.py:208-222
+// (~90 ATen dispatches per call in the reference; here x is read once from HBM and 4 bytes per
+// sample are written back).
+#include "stgcn_device.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+struct FwdArgs {
+    const float* x;
+    const float* prm;
+    const float* bn;
+    float* out;
+    int64_t B;
+    int64_t ntiles;
+    int N, P, Ppad, L;
+    uint32_t magicP;
+    int vec4;
+    int stage_floats;   // per-wave LDS staging floats
+};
+
+template <int RW>
+__global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int WS = wstride<RW>();
+    constexpr int SPW = Row<RW>::SPW;
+    const int N = a.N, L = a.L, LS = layer_stride(N);
+    float* wlds = smem;                          // [L+1][RW][WS] theta rows per layer, then fc1 rows
+    float* bnf = wlds + (L + 1) * RW * WS;       // [L][2][2][F]   folded BatchNorm scale / shift
+    float* vecs = bnf + L * 4 * F;               // [L+2][RW]      theta bias per layer, fc1 bias, fc2 weight
+    float* stage_all = vecs + (L + 2) * RW;
+
+    // ---- block prologue: weights that vary per lane go to LDS, zero padded to the row width ----
+    for (int i = threadIdx.x; i < (L + 1) * RW * RW; i += BLOCK) {
+        const int m = i / (RW * RW), j = (i / RW) % RW, k = i % RW;
+        const float* src = m < L ? a.prm + m * LS + off_theta_w(N) : a.prm + off_fc1_w(N, L);
+        wlds[(m * RW + j) * WS + k] = (j < N && k < N) ? src[j * N + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < (L + 2) * RW; i += BLOCK) {
+        const int m = i / RW, j = i % RW;
+        const float* src = m < L ? a.prm + m * LS + off_theta_b(N) : (m == L ? a.prm + off_fc1_b(N, L) : a.prm + off_fc2_w(N, L));
+        vecs[i] = j < N ? src[j] : 0.f;
+    }
+    for (int i = threadIdx.x; i < L * 2 * F; i += BLOCK) {
+        const int l = i / (2 * F), blk = (i / F) % 2, c = i % F;
+        const float mean = a.bn[((l * 2 + blk) * 2 + 0) * F + c];
+        const float var = a.bn[((l * 2 + blk) * 2 + 1) * F + c];
+        const float g = a.prm[l * LS + off_bn_g(N, blk) + c], b = a.prm[l * LS + off_bn_b(N, blk) + c];
+        const float sc = g / sqrtf(var + BN_EPS);
+        bnf[((l * 2 + blk) * 2 + 0) * F + c] = sc;
+        bnf[((l * 2 + blk) * 2 + 1) * F + c] = b - mean * sc;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int srow = lane / RW, t = lane % RW;
+    float* stage = stage_all + wave * a.stage_floats;
+    const float fc2_b = a.prm[off_fc2_b(N, L)];
+    const int64_t sampleNP = (int64_t)N * a.P;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
+         tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t s0 = tile * SPW;
+        const int ns = (int)((a.B - s0) < SPW ? (a.B - s0) : SPW);
+        __builtin_amdgcn_wave_barrier();
+        stage_tile(a.x + s0 * sampleNP, stage, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
+        __builtin_amdgcn_wave_barrier();
+
+        const bool valid = (srow < ns) && (t < N);
+        float X[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) X[c] = 0.f;
+        if (valid) patch_statistics(stage + (srow * N + t) * a.Ppad, a.P, X);
+
+        float A[NPAIR];
+        pearson_adjacency<RW>(X, valid, N, A);
+
+        for (int l = 0; l < L; ++l) {
+            const float* lp = a.prm + l * LS;
+            const float* bl = bnf + l * 4 * F;
+            float AX[F], H[F], z[F], o0[F];
+            adj_aggregate(A, X, AX);
+            const float tb = vecs[l * RW + t];
+#pragma unroll
+            for (int c = 0; c < F; ++c) H[c] = tb;
+            Row<RW>::project10(H, AX, wlds + (l * RW + t) * WS, N);     // theta(A.X), Model.py:87
+#pragma unroll
+            for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
+            causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);         // conv_block1, Model.py:134-146
+#pragma unroll
+            for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z[c], bl[c], bl[F + c])) + H[c]);
+            causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);        // conv_block2 (dilation 2), Model.py:148-160
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float o1 = relu(relu(fmaf(z[c], bl[2 * F + c], bl[3 * F + c])) + o0[c]);
+                X[c] = valid ? o1 + X[c] : 0.f;                          // Dropout is identity in eval; out += res
+            }
+        }
+        // AdaptiveMaxPool1d over the ten channels (NaN-propagating like torch), Model.py:218-219
+        float pooled = X[0];
+#pragma unroll
+        for (int c = 1; c < F; ++c) pooled = (X[c] > pooled || X[c] != X[c]) ? X[c] : pooled;
+        pooled = valid ? pooled : 0.f;
+        float y1 = vecs[L * RW + t];
+        Row<RW>::project1(y1, pooled, wlds + (L * RW + t) * WS, N);     // fc1, Model.py:220
+        y1 = relu(y1);
+        const float pred = Row<RW>::allsum(y1 * vecs[(L + 1) * RW + t]) + fc2_b;   // fc2, Model.py:221
+        if (t == 0 && srow < ns) a.out[s0 + srow] = pred;
+    }
+}
+
+template <int RW>
+static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
+                          const float* bn, float* out, hipStream_t stream) {
+    FwdArgs a;
+    a.x = x; a.prm = prm; a.bn = bn; a.out = out;
+    a.B = s->batch; a.ntiles = g.ntiles; a.N = s->num_patch; a.P = s->patch_size; a.Ppad = g.Ppad; a.L = s->num_layers;
+    a.magicP = g.magicP; a.vec4 = g.vec4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    a.stage_floats = g.stage_floats;
+    constexpr int WS = wstride<RW>();
+    const size_t lds = sizeof(float) * ((size_t)(a.L + 1) * RW * WS + (size_t)a.L * 4 * F + (size_t)(a.L + 2) * RW +
+                                        (size_t)WAVES_PER_BLOCK * g.stage_floats);
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stgcn_forward_eval_kernel<RW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+    }
+    const int grid = grid_for_tiles(g.ntiles, lds);
+    hipLaunchKernelGGL(stgcn_forward_eval_kernel<RW>, dim3(grid), dim3(BLOCK), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
+                       hipStream_t stream) {
+    TileGeom g;
+    const int rc = tile_geometry(s, &g);
+    if (rc != RULGNN_OK) return rc;
+    if (s->batch == 0) return RULGNN_OK;
+    switch (g.RW) {
+        case 16: return launch_forward<16>(g, s, x, prm, bn, out, stream);
+        case 32: return launch_forward<32>(g, s, x, prm, bn, out, stream);
+        default: return launch_forward<64>(g, s, x, prm, bn, out, stream);
+    }
+}
+
+}  // namespace rulgnn

@@ -1,0 +1,87 @@
+"""Flat-buffer layout of the ST_GCN parameters (mirror of csrc/stgcn_device.hpp / include/rulgnn.h).
+
+The reference model (models/ST_GCN/Model.py:197-207) owns 52 state_dict entries; 20 of them are
+the live parameters that receive gradients, 16 are BatchNorm buffers and 16 belong to the dead
+``net0``/``net1`` branches (Model.py:110-131, constructed but never called).  The HIP kernels read
+the live parameters from ONE contiguous fp32 buffer and the BatchNorm running statistics from
+another; this module maps reference key names <-> offsets in those buffers."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+NUM_STATS = 10       # channels / graph nodes
+TCN_KERNEL = 2
+
+
+def layer_stride(num_patch: int) -> int:
+    return num_patch * num_patch + num_patch + 2 * (NUM_STATS * NUM_STATS * TCN_KERNEL + 2 * NUM_STATS)
+
+
+def param_count(num_patch: int, num_layers: int) -> int:
+    return num_layers * layer_stride(num_patch) + num_patch * num_patch + 2 * num_patch + 1
+
+
+def live_param_layout(num_patch: int, num_layers: int) -> "OrderedDict[str, tuple[int, tuple[int, ...]]]":
+    """name (reference key without ``model.``) -> (offset in floats, shape), in buffer order."""
+    N, F, K = num_patch, NUM_STATS, TCN_KERNEL
+    out: "OrderedDict[str, tuple[int, tuple[int, ...]]]" = OrderedDict()
+    off = 0
+
+    def add(name, shape):
+        nonlocal off
+        n = 1
+        for s in shape:
+            n *= s
+        out[name] = (off, tuple(shape))
+        off += n
+
+    for l in range(num_layers):
+        p = f"sg_tcn.layers.{l}"
+        add(f"{p}.0.theta.0.weight", (N, N))
+        add(f"{p}.0.theta.0.bias", (N,))
+        for blk in (1, 2):
+            add(f"{p}.1.conv_block{blk}.0.weight", (F, F, K))
+            add(f"{p}.1.conv_block{blk}.2.weight", (F,))
+            add(f"{p}.1.conv_block{blk}.2.bias", (F,))
+    add("fc1.weight", (N, N))
+    add("fc1.bias", (N,))
+    add("fc2.weight", (1, N))
+    add("fc2.bias", (1,))
+    assert off == param_count(N, num_layers)
+    return out
+
+
+def bn_buffer_layout(num_layers: int) -> "OrderedDict[str, tuple[int, tuple[int, ...]]]":
+    """running_mean / running_var keys -> offset in the [L][2][2][10] BatchNorm buffer."""
+    out: "OrderedDict[str, tuple[int, tuple[int, ...]]]" = OrderedDict()
+    for l in range(num_layers):
+        for b, blk in enumerate((1, 2)):
+            base = ((l * 2 + b) * 2) * NUM_STATS
+            q = f"sg_tcn.layers.{l}.1.conv_block{blk}.2"
+            out[f"{q}.running_mean"] = (base, (NUM_STATS,))
+            out[f"{q}.running_var"] = (base + NUM_STATS, (NUM_STATS,))
+    return out
+
+
+def bn_buffer_count(num_layers: int) -> int:
+    return num_layers * 2 * 2 * NUM_STATS
+
+
+def pack_numpy(state: dict, num_patch: int, num_layers: int, prefix: str = ""):
+    """state_dict-like mapping of numpy arrays -> (flat params, flat bn) float32 numpy arrays."""
+    import numpy as np
+
+    flat = np.zeros(param_count(num_patch, num_layers), np.float32)
+    for name, (off, shape) in live_param_layout(num_patch, num_layers).items():
+        a = np.asarray(state[prefix + name], np.float32)
+        assert tuple(a.shape) == shape, (name, a.shape, shape)
+        flat[off:off + a.size] = a.reshape(-1)
+    bn = np.zeros(bn_buffer_count(num_layers), np.float32)
+    for name, (off, shape) in bn_buffer_layout(num_layers).items():
+        bn[off:off + NUM_STATS] = np.asarray(state[prefix + name], np.float32)
+    return flat, bn
+
+
+def unpack_numpy(flat, num_patch: int, num_layers: int) -> dict:
+    return {name: flat[off:off + int(__import__("numpy").prod(shape))].reshape(shape)
+            for name, (off, shape) in live_param_layout(num_patch, num_layers).items()}

@@ -1,0 +1,121 @@
+/* rulgnn.h -- C-ABI of the MI355X (gfx950) ST_GCN hot path.
+ *
+ * The reference (Frank-Wang-oss/GNN_RUL_Benchmarking) is pure Python/PyTorch: it has no native
+ * boundary of its own.  The functions below are what a binding for its hot path would call
+ * instead of the ATen op chains cited per entry point; INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer borrowed from the caller
+ *     (e.g. torch `tensor.data_ptr()`), fp32 unless stated; nothing is allocated or freed here;
+ *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, no host synchronisation, safe under stream capture;
+ *   - return value: RULGNN_OK (0) or a negative RULGNN_E* code; rulgnn_strerror() names it;
+ *   - no global mutable state: re-entrant across streams and devices.
+ *
+ * Flat parameter buffer ("live" parameters, the ones that receive gradients), N = num_patch,
+ * per layer l (stride N*N + N + 440 floats):
+ *     theta.weight[N][N] | theta.bias[N] | conv_block1.0.weight[10][10][2] | bn1.weight[10] |
+ *     bn1.bias[10] | conv_block2.0.weight[10][10][2] | bn2.weight[10] | bn2.bias[10]
+ * then fc1.weight[N][N] | fc1.bias[N] | fc2.weight[N] | fc2.bias[1].
+ * Gradient, Adam-m and Adam-v buffers use the same layout.
+ * BatchNorm buffer: [num_layers][2 (conv_block1, conv_block2)][2 (mean, var)][10].
+ */
+#ifndef RULGNN_H
+#define RULGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RULGNN_OK            0
+#define RULGNN_EINVAL       -1   /* bad shape / null pointer / unsupported hyper-parameter */
+#define RULGNN_EUNSUPPORTED -2   /* shape outside what the fused kernels cover (e.g. num_patch > 64) */
+#define RULGNN_EWORKSPACE   -3   /* workspace too small (see *_workspace_bytes) */
+#define RULGNN_EHIP         -4   /* a HIP runtime call failed */
+#define RULGNN_EALIGN       -5   /* pointer not 4-byte aligned */
+
+#define RULGNN_NUM_STATS 10      /* statistics per patch == graph nodes == TCN channels */
+
+typedef struct rulgnn_stgcn_shape {
+    int64_t batch;        /* samples in this call (this rank's shard) */
+    int32_t num_patch;    /* N: patches per sample (C-MAPSS view: sensors), 2..64 */
+    int32_t patch_size;   /* P: samples per patch (C-MAPSS view: window), 2..4096 */
+    int32_t num_layers;   /* L: SG_TCN layers, 1..8 (reference default 2) */
+    int32_t mpnn_k;       /* MPNN order k; only 1 is implemented (the reference's default) */
+} rulgnn_stgcn_shape;
+
+/* Library / ABI version: major*10000 + minor*100 + patch. */
+int rulgnn_version(void);
+const char *rulgnn_strerror(int code);
+
+/* Number of floats in the flat live-parameter buffer for (num_patch, num_layers). */
+int64_t rulgnn_stgcn_param_count(int32_t num_patch, int32_t num_layers);
+
+/* Eval-mode forward: replaces ST_GCN_model.forward under model.eval()/no_grad
+ * (reference models/ST_GCN/Model.py:208-222, called from trainer.py:144).
+ *   x        [batch, num_patch*patch_size]  input windows, contiguous
+ *   params   flat live parameters (layout above)
+ *   bn_stats BatchNorm running statistics (layout above)
+ *   pred     [batch] output (the reference returns [batch, 1])
+ * One fused kernel: patch statistics -> Pearson adjacency -> L x (A.X.W, causal TCN, folded BN,
+ * residuals) -> channel max-pool -> fc1 -> fc2.  No workspace. */
+int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape *shape, const float *x, const float *params,
+                             const float *bn_stats, float *pred, void *stream);
+
+/* Bytes of scratch the training entry points need for `shape` (features/adjacency cache,
+ * per-block gradient partials, BatchNorm reduction cells).  Independent of pointer values. */
+size_t rulgnn_stgcn_train_workspace_bytes(const rulgnn_stgcn_shape *shape);
+
+typedef struct rulgnn_stgcn_train_args {
+    const float *x;          /* [batch, N*P] */
+    const float *y;          /* [batch] regression targets (RUL / max_rul); may be NULL if dpred given */
+    const float *dpred;      /* optional [batch] upstream gradient d(loss)/d(pred); NULL -> MSE vs y */
+    const float *params;     /* flat live parameters */
+    float *grads;            /* out: flat gradient, same layout (overwritten, not accumulated) */
+    float *pred;             /* out: [batch] train-mode predictions */
+    float *loss;             /* out: 1 float, sum over this shard of (pred-y)^2 / global_batch */
+    float *bn_batch;         /* out: batch statistics [L][2][2][10] = (mean, biased var) of this shard */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;    /* MSE normaliser: batch summed over all data-parallel ranks (>= batch) */
+    int64_t sample_offset;   /* index of this shard's first sample in the global batch (dropout stream) */
+    float dropout_p;         /* 0 disables dropout */
+    uint64_t seed;           /* dropout stream: (seed, step) -> per-layer keys */
+    uint64_t step;
+} rulgnn_stgcn_train_args;
+
+/* Train-mode forward only (BatchNorm batch statistics, dropout): fills pred, bn_batch and the
+ * workspace cache.  Replaces model(X) under model.train() (algorithms/algorithms.py:482). */
+int rulgnn_stgcn_train_forward_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                   void *stream);
+
+/* Backward of the train-mode forward: gradient of sum(pred * dpred) (or of the MSE loss when
+ * args->dpred is NULL) w.r.t. every live parameter.  Must follow rulgnn_stgcn_train_forward_f32
+ * with the same args/workspace.  Replaces loss.backward() (algorithms/algorithms.py:488). */
+int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                    void *stream);
+
+/* Fused forward + MSE + backward: what ST_GCN.update does before optimizer.step()
+ * (algorithms/algorithms.py:482-488), in one call with the loss kept on the device. */
+int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                  void *stream);
+
+/* torch.optim.Adam step over a flat buffer (L2 weight decay folded into the gradient, no amsgrad),
+ * as configured at algorithms/algorithms.py:474-478.  `step` is the 1-based step count AFTER this
+ * update.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
+int rulgnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                         int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         float grad_scale, void *stream);
+
+/* nn.BatchNorm1d running-statistics update (momentum, unbiased running variance) from the batch
+ * statistics produced by the training forward.  count = batch*num_patch values per channel. */
+int rulgnn_bn_running_update_f32(float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count,
+                                 float momentum, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RULGNN_H */

@@ -1,0 +1,52 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/rulgnn.h declares,
+and its host-only entry points behave (no kernels are launched here)."""
+import ctypes as C
+import os
+import re
+
+from gnn_rul_benchmarking_amd import _lib, build, params as PL
+
+from conftest import ROOT
+
+
+def test_library_builds_and_loads():
+    build.build()
+    lib = _lib.load()
+    assert lib.rulgnn_version() >= 100
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "rulgnn.h")).read()
+    declared = set(re.findall(r"\b(rulgnn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_param_count_and_layout_agree_with_library():
+    lib = _lib.load()
+    for N, L in [(14, 2), (40, 2), (16, 3), (2, 1)]:
+        assert lib.rulgnn_stgcn_param_count(N, L) == PL.param_count(N, L)
+        lay = PL.live_param_layout(N, L)
+        last_off, last_shape = list(lay.values())[-1]
+        assert last_off + 1 == PL.param_count(N, L)
+    assert PL.param_count(14, 2) == 1525       # 1,525 live parameters
+
+
+def test_error_codes_have_messages():
+    for code in (0, -1, -2, -3, -4, -5):
+        assert "unknown" not in _lib.strerror(code)
+    assert "unknown" in _lib.strerror(-99)
+
+
+def test_shape_validation_without_gpu():
+    lib = _lib.load()
+    bad = _lib.StgcnShape(4, 1024, 32, 2, 1)          # XJTU-sized num_patch: outside the fused kernels
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None) == -2
+    bad = _lib.StgcnShape(4, 14, 30, 2, 3)            # MPNN order k != 1
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None) == -2
+    ok = _lib.StgcnShape(4, 14, 30, 2, 1)
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(ok), None, None, None, None, None) == -1   # null pointers
+    empty = _lib.StgcnShape(0, 14, 30, 2, 1)
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(empty), None, None, None, None, None) == 0  # empty batch is a no-op

@@ -1,0 +1,69 @@
+"""-m gpu: the fused HIP eval forward (through the C-ABI) vs the reference's golden outputs and
+vs the numpy oracle on seeded inputs.  Tolerance: 1e-4 relative fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from gnn_rul_benchmarking_amd import params as PL
+from oracle import stgcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", __import__("gpu_util").FB_CASES)
+def test_forward_matches_reference_golden(name):
+    import gpu_util as G
+    z, sd = G.load_case(name)
+    N, P = int(z["num_patch"]), int(z["patch_size"])
+    flat, bn = PL.pack_numpy(sd, N, 2)
+    pred = G.abi_forward(z["x"], flat, bn, N, P)
+    ref = z["eval_pred"][:, 0]
+    assert np.array_equal(np.isnan(pred), np.isnan(ref)), "NaN must appear in exactly the reference's places"
+    ok = ~np.isnan(ref)
+    assert G.rel_err(pred[ok], ref[ok]) < TOL
+
+
+@pytest.mark.parametrize("N,P,B", [(14, 30, 1), (14, 30, 3), (14, 30, 4), (14, 30, 1027), (14, 50, 257),
+                                   (16, 30, 65), (2, 2, 9), (5, 7, 33), (14, 31, 19), (16, 16, 40),
+                                   (24, 20, 37), (32, 8, 11), (40, 64, 9), (64, 10, 6)])
+def test_forward_matches_oracle_seeded(N, P, B):
+    import gpu_util as G
+    rng = np.random.default_rng(N * 1000 + P * 10 + B)
+    prm = O.random_params(N, 2, seed=B)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    flat, bn = PL.pack_numpy(prm, N, 2)
+    pred = G.abi_forward(x, flat, bn, N, P)
+    ref = O.forward(prm, x.astype(np.float64), N, P).pred[:, 0]
+    assert np.isfinite(ref).all()
+    assert G.rel_err(pred, ref) < TOL
+
+
+def test_forward_full_size_batch_split_invariance():
+    """BASELINE-size batch: the eval forward is per-sample, so any split of the batch must give
+    bit-identical predictions (size-independent property; the oracle checks a slice)."""
+    import gpu_util as G
+    N, P, B = 14, 30, 65536 + 3
+    rng = np.random.default_rng(7)
+    prm = O.random_params(N, 2, seed=3)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    flat, bn = PL.pack_numpy(prm, N, 2)
+    full = G.abi_forward(x, flat, bn, N, P)
+    parts = np.concatenate([G.abi_forward(x[:1001], flat, bn, N, P), G.abi_forward(x[1001:], flat, bn, N, P)])
+    assert np.array_equal(full, parts)
+    ref = O.forward(prm, x[:512].astype(np.float64), N, P).pred[:, 0]
+    assert G.rel_err(full[:512], ref) < TOL
+
+
+def test_forward_rejects_unsupported():
+    import ctypes as C
+    import torch
+    import gpu_util as G
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(16, device="cuda:0")
+    for shp in (G.shape_struct(4, 1024, 32), G.shape_struct(4, 14, 30, 2, k=2)):
+        rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), G.stream_ptr())
+        assert rc == -2
+    shp = G.shape_struct(4, 14, 30)
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(shp), None, t.data_ptr(), t.data_ptr(), t.data_ptr(), G.stream_ptr()) == -1
