@@ -282,7 +282,8 @@ __device__ __forceinline__ void pearson_adjacency(const float (&X0)[F], bool lan
 #pragma unroll
     for (int a = 0; a < F; ++a)
 #pragma unroll
-        for (int b = a; b < F; ++b) A[sym(a, b)] = A[sym(a, b)] / (nrm[a] * nrm[b]);   // 0/0 -> NaN as reference
+        for (int b = a; b < F; ++b)      // dot / (|a||b|): v_rcp_f32 (1 ulp); 0 * rcp(0) = 0 * inf = NaN like the reference's 0/0
+            A[sym(a, b)] = A[sym(a, b)] * __builtin_amdgcn_rcpf(nrm[a] * nrm[b]);
 }
 
 // AX[c] = sum_c' A[c][c'] X[c']   (torch.bmm(A, X), Model.py:87)

@@ -8,10 +8,6 @@
 namespace rulgnn {
 
 struct FwdArgs {
-    const float* x;
-    const float* prm;
-    const float* bn;
-    float* out;
     int64_t B;
     int64_t ntiles;
     int N, P, Ppad, L;
@@ -21,7 +17,12 @@ struct FwdArgs {
 };
 
 template <int RW>
-__global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
+__global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* __restrict__ gx,
+                                                                   const float* __restrict__ prm,
+                                                                   const float* __restrict__ bn,
+                                                                   float* __restrict__ out, FwdArgs a) {
+    // prm / bn are separate __restrict__ kernel arguments so that wave-uniform weight reads
+    // become scalar loads (s_load_dwordx16 -> SGPR operands) instead of per-lane VMEM loads.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WS = wstride<RW>();
     constexpr int SPW = Row<RW>::SPW;
@@ -34,19 +35,19 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
     // ---- block prologue: weights that vary per lane go to LDS, zero padded to the row width ----
     for (int i = threadIdx.x; i < (L + 1) * RW * RW; i += BLOCK) {
         const int m = i / (RW * RW), j = (i / RW) % RW, k = i % RW;
-        const float* src = m < L ? a.prm + m * LS + off_theta_w(N) : a.prm + off_fc1_w(N, L);
+        const float* src = m < L ? prm + m * LS + off_theta_w(N) : prm + off_fc1_w(N, L);
         wlds[(m * RW + j) * WS + k] = (j < N && k < N) ? src[j * N + k] : 0.f;
     }
     for (int i = threadIdx.x; i < (L + 2) * RW; i += BLOCK) {
         const int m = i / RW, j = i % RW;
-        const float* src = m < L ? a.prm + m * LS + off_theta_b(N) : (m == L ? a.prm + off_fc1_b(N, L) : a.prm + off_fc2_w(N, L));
+        const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
         vecs[i] = j < N ? src[j] : 0.f;
     }
     for (int i = threadIdx.x; i < L * 2 * F; i += BLOCK) {
         const int l = i / (2 * F), blk = (i / F) % 2, c = i % F;
-        const float mean = a.bn[((l * 2 + blk) * 2 + 0) * F + c];
-        const float var = a.bn[((l * 2 + blk) * 2 + 1) * F + c];
-        const float g = a.prm[l * LS + off_bn_g(N, blk) + c], b = a.prm[l * LS + off_bn_b(N, blk) + c];
+        const float mean = bn[((l * 2 + blk) * 2 + 0) * F + c];
+        const float var = bn[((l * 2 + blk) * 2 + 1) * F + c];
+        const float g = prm[l * LS + off_bn_g(N, blk) + c], b = prm[l * LS + off_bn_b(N, blk) + c];
         const float sc = g / sqrtf(var + BN_EPS);
         bnf[((l * 2 + blk) * 2 + 0) * F + c] = sc;
         bnf[((l * 2 + blk) * 2 + 1) * F + c] = b - mean * sc;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int srow = lane / RW, t = lane % RW;
     float* stage = stage_all + wave * a.stage_floats;
-    const float fc2_b = a.prm[off_fc2_b(N, L)];
+    const float fc2_b = prm[off_fc2_b(N, L)];
     const int64_t sampleNP = (int64_t)N * a.P;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
         const int64_t s0 = tile * SPW;
         const int ns = (int)((a.B - s0) < SPW ? (a.B - s0) : SPW);
         __builtin_amdgcn_wave_barrier();
-        stage_tile(a.x + s0 * sampleNP, stage, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
+        stage_tile(gx + s0 * sampleNP, stage, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
         __builtin_amdgcn_wave_barrier();
 
         const bool valid = (srow < ns) && (t < N);
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
         pearson_adjacency<RW>(X, valid, N, A);
 
         for (int l = 0; l < L; ++l) {
-            const float* lp = a.prm + l * LS;
+            const float* lp = prm + l * LS;
             const float* bl = bnf + l * 4 * F;
             float AX[F], H[F], z[F], o0[F];
             adj_aggregate(A, X, AX);
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(FwdArgs a) {
         Row<RW>::project1(y1, pooled, wlds + (L * RW + t) * WS, N);     // fc1, Model.py:220
         y1 = relu(y1);
         const float pred = Row<RW>::allsum(y1 * vecs[(L + 1) * RW + t]) + fc2_b;   // fc2, Model.py:221
-        if (t == 0 && srow < ns) a.out[s0 + srow] = pred;
+        if (t == 0 && srow < ns) out[s0 + srow] = pred;
     }
 }
 
@@ -114,7 +115,6 @@ template <int RW>
 static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
                           const float* bn, float* out, hipStream_t stream) {
     FwdArgs a;
-    a.x = x; a.prm = prm; a.bn = bn; a.out = out;
     a.B = s->batch; a.ntiles = g.ntiles; a.N = s->num_patch; a.P = s->patch_size; a.Ppad = g.Ppad; a.L = s->num_layers;
     a.magicP = g.magicP; a.vec4 = g.vec4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.stage_floats = g.stage_floats;
@@ -127,8 +127,8 @@ static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RULGNN_EHIP;
     }
-    const int grid = grid_for_tiles(g.ntiles, lds);
-    hipLaunchKernelGGL(stgcn_forward_eval_kernel<RW>, dim3(grid), dim3(BLOCK), lds, stream, a);
+    const int grid = persistent_grid(stgcn_forward_eval_kernel<RW>, g.ntiles, lds);
+    hipLaunchKernelGGL(stgcn_forward_eval_kernel<RW>, dim3(grid), dim3(BLOCK), lds, stream, x, prm, bn, out, a);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

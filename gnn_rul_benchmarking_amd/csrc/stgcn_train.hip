@@ -1,8 +1,815 @@
-// placeholder: training kernels land here next
+// Train-mode ST_GCN forward + backward for gfx950 (row width 16: num_patch <= 16).
+//
+// Reference path replaced: ST_GCN.update up to optimizer.step() -- algorithms/algorithms.py:481-488
+// (model(X) under model.train(), MSE, loss.backward()).
+//
+// Train-mode BatchNorm couples all samples of the batch: each of the 2L BatchNorm layers needs a
+// batch-wide mean/var in the forward and two batch-wide sums in the backward before anything
+// behind it can proceed.  The step is therefore a chain of 4L+1 phase kernels separated by
+// grid-wide reductions (fp64 atomics into "cells"):
+//
+//     F_0 .. F_{2L-1}   forward up to the input of BatchNorm i, accumulate sum(z), sum(z^2)
+//     TOP               full forward -> pred, loss; backward of fc2/fc1/max-pool down to dy of
+//                       BatchNorm 2L-1, accumulate sum(dy), sum(dy*xhat)
+//     G_{2L-1} .. G_0   BatchNorm-i backward -> dz_i, weight gradients of conv_i (and theta of the
+//                       layer when i is even), data gradient down to dy_{i-1}, accumulate its sums
+//
+// Nothing per-sample is stored between phases except the input-only quantities (patch statistics
+// X0 and the Pearson adjacency A: 896 B/sample, written by F_0): every phase RECOMPUTES the
+// activations it needs from that cache, in registers.  Activations never touch HBM, which keeps
+// the whole step VALU-bound instead of HBM-bound (saving activations would cost ~25 KB/sample).
+//
+// Matrix-core use: the contraction of the weight gradients runs over (sample, patch) or
+// (sample, channel), i.e. over lanes/registers of the row mapping:
+//   d theta[j][k] = sum_{s,c} dHpre[s,c,j] * AX[s,c,k]  -> v_mfma_f32_16x16x4_f32 fed DIRECTLY from
+//       the row-mapped registers (lane>>4 = sample = k-slice, lane&15 = patch = matrix row/col);
+//   d convW[co][ci,tap] = sum_{s,t} dz[co][s,t] * h[ci][s,t-d*tap'] -> same MFMA after an in-wave
+//       LDS transpose ([channel][lane] tile, ds_read_b128 fragments).
+// Accumulators stay in the MFMA accumulator registers across the whole persistent tile loop.
+#include "stgcn_device.hpp"
 #include "stgcn_host.hpp"
+
 namespace rulgnn {
-size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape*) { return 0; }
-int stgcn_train_forward(const rulgnn_stgcn_shape*, const rulgnn_stgcn_train_args*, hipStream_t) { return RULGNN_EUNSUPPORTED; }
-int stgcn_train_backward(const rulgnn_stgcn_shape*, const rulgnn_stgcn_train_args*, hipStream_t) { return RULGNN_EUNSUPPORTED; }
-int stgcn_train_fwdbwd(const rulgnn_stgcn_shape*, const rulgnn_stgcn_train_args*, hipStream_t) { return RULGNN_EUNSUPPORTED; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TRW = 16;                     // row width of the training kernels
+using R16 = Row<TRW>;
+constexpr int TSPW = 4;                     // samples per wavefront
+constexpr int AQ = 4;                       // ceil(NPAIR / 16): adjacency cache slots per lane
+constexpr int TWS = wstride<TRW>();         // LDS row stride of a padded 16x16 weight matrix
+constexpr int TT_STRIDE = 68;               // LDS row stride of the [channel][lane] transpose tile
+constexpr int TT_ROWS = 30;
+constexpr int BNC = 7;                      // per-BatchNorm constants: mean, istd, scale, shift, gamma*istd, k1, k2
+
+enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
+
+struct TrainK {
+    // workspace regions
+    float* cacheX;        // [ntiles][F][64]
+    float* cacheA;        // [ntiles][AQ][64]
+    double* cells_fwd;    // [2L][2][F]   sum z, sum z^2
+    double* cells_bwd;    // [2L][2][F]   sum dy, sum dy*xhat
+    double* cell_loss;    // [1]
+    float* gpart;         // [grid][param_count] per-block partial gradients
+    // outputs
+    float* pred;
+    // sizes
+    int64_t B, ntiles, global_batch, sample_offset;
+    int N, P, Ppad, vec4, stage_floats;
+    uint32_t magicP;
+    int do_backward;      // TOP: 0 = forward only
+    int has_dpred;        // 1: gy is d(loss)/d(pred); 0: gy is y (MSE); 2: neither (forward only)
+    float dropout_p, drop_scale;
+    uint32_t drop_thr;
+    uint32_t drop_key[8];
+    int pcount;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {      // total over 64 lanes, valid in every lane
+    v = R16::allsum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
 }
+
+template <int D>
+__device__ __forceinline__ void causal_conv_T(const float (&dz)[F], const float* __restrict__ w, int t, float (&dh)[F]) {
+    // transpose of causal_conv: dh[ci][t] = sum_co w[co][ci][1] dz[co][t] + w[co][ci][0] dz[co][t + D]
+    float dzs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) dzs[c] = R16::template shl<D>(dz[c], t);
+#pragma unroll
+    for (int ci = 0; ci < F; ++ci) {
+        float acc = 0.f;
+#pragma unroll
+        for (int co = 0; co < F; ++co) {
+            acc = fmaf(w[(co * F + ci) * 2 + 1], dz[co], acc);
+            acc = fmaf(w[(co * F + ci) * 2 + 0], dzs[co], acc);
+        }
+        dh[ci] = acc;
+    }
+}
+
+// In-wave LDS transpose + MFMA: acc0/acc1 += dz (10 x 64 lanes) . [h | hs]^T (64 lanes x 20).
+// T: this wavefront's [TT_ROWS][TT_STRIDE] tile.  Row r of the tile holds one channel for all 64
+// lanes; the A/B fragments of v_mfma_f32_16x16x4_f32 are ds_read_b128 of 4 consecutive lanes
+// (the k index is permuted identically for A and B, which a contraction does not see).
+__device__ __forceinline__ void conv_wgrad_mfma(float* T, const float (&dz)[F], const float (&h)[F], const float (&hs)[F],
+                                                int lane, f32x4& acc0, f32x4& acc1) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        T[c * TT_STRIDE + lane] = dz[c];
+        T[(F + c) * TT_STRIDE + lane] = h[c];
+        T[(2 * F + c) * TT_STRIDE + lane] = hs[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        const float4 a = *reinterpret_cast<const float4*>(&T[i * TT_STRIDE + 16 * kq + 4 * jp]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&T[(F + i) * TT_STRIDE + 16 * kq + 4 * jp]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&T[(i < 4 ? 2 * F + 6 + i : 3 * F - 1) * TT_STRIDE + 16 * kq + 4 * jp]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the phase kernel
+// ------------------------------------------------------------------------------------------------
+// IDX: BatchNorm index (0 .. 2L-1) for F and G kernels; unused for TOP.
+template <int L, int KIND, int IDX>
+__global__ __launch_bounds__(BLOCK) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+                                                                  const float* __restrict__ prm,
+                                                                  const float* __restrict__ gy,   // y or dpred (TOP only)
+                                                                  TrainK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NBN = 2 * L;
+    constexpr bool BACKWARD = KIND != PH_F;
+    // BatchNorm layers whose forward statistics this kernel needs: F_i applies BN 0..i-1.
+    constexpr int NFWD = KIND == PH_F ? IDX : NBN;
+    const int N = a.N, LS = layer_stride(N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int srow = lane >> 4, t = lane & 15;
+
+    // ---- LDS carve --------------------------------------------------------------------------------
+    float* wlds = smem;                                   // [L+1][16][TWS]   theta rows / fc1 rows
+    float* wldsT = wlds + (L + 1) * TRW * TWS;            // [L+1][16][TWS]   transposes (backward)
+    float* vecs = wldsT + (L + 1) * TRW * TWS;            // [L+2][16]        theta bias, fc1 bias, fc2 weight
+    float* bnc = vecs + (L + 2) * TRW;                    // [NBN][BNC][F] (+pad to 4)
+    float* abuf = bnc + ((NBN * BNC * F + 3) & ~3);       // [4 waves][TSPW][64]  adjacency exchange
+    float* red = abuf + WAVES_PER_BLOCK * TSPW * 64;      // [RED_K][64] block reduction of the gradient accumulators
+    constexpr int RED_K = 15;
+    float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
+    float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (G)
+    const int wave_area_floats = a.stage_floats > TT_ROWS * TT_STRIDE ? a.stage_floats : TT_ROWS * TT_STRIDE;
+    float* mywave = wave_area + wave * wave_area_floats;
+
+    // ---- prologue: weights to LDS, BatchNorm constants from the reduction cells ---------------------
+    for (int i = threadIdx.x; i < (L + 1) * TRW * TRW; i += BLOCK) {
+        const int m = i / (TRW * TRW), j = (i / TRW) % TRW, k = i % TRW;
+        const float* src = m < L ? prm + m * LS + off_theta_w(N) : prm + off_fc1_w(N, L);
+        const float v = (j < N && k < N) ? src[j * N + k] : 0.f;
+        wlds[(m * TRW + j) * TWS + k] = v;
+        wldsT[(m * TRW + k) * TWS + j] = v;
+    }
+    for (int i = threadIdx.x; i < (L + 2) * TRW; i += BLOCK) {
+        const int m = i / TRW, j = i % TRW;
+        const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
+        vecs[i] = j < N ? src[j] : 0.f;
+    }
+    const double cnt = (double)a.B * (double)N;           // values per channel in this shard's batch
+    for (int i = threadIdx.x; i < NBN * F; i += BLOCK) {
+        const int b = i / F, c = i % F;
+        const int l = b / 2, blk = b % 2;
+        float* o = bnc + b * BNC * F;
+        if (b < NFWD) {
+            const double s1 = a.cells_fwd[(b * 2 + 0) * F + c], s2 = a.cells_fwd[(b * 2 + 1) * F + c];
+            const double mean = s1 / cnt;
+            double var = s2 / cnt - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+            const double g = prm[l * LS + off_bn_g(N, blk) + c], be = prm[l * LS + off_bn_b(N, blk) + c];
+            o[0 * F + c] = (float)mean;
+            o[1 * F + c] = (float)istd;
+            o[2 * F + c] = (float)(g * istd);
+            o[3 * F + c] = (float)(be - mean * g * istd);
+            o[4 * F + c] = (float)(g * istd);
+            if (KIND == PH_G && b >= IDX) {                // BatchNorm backward constants, known for b >= IDX
+                o[5 * F + c] = (float)(a.cells_bwd[(b * 2 + 0) * F + c] / cnt);
+                o[6 * F + c] = (float)(a.cells_bwd[(b * 2 + 1) * F + c] / cnt);
+            } else {
+                o[5 * F + c] = 0.f;
+                o[6 * F + c] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- persistent per-wave accumulators ------------------------------------------------------------
+    float s_a[F], s_b[F];                 // BatchNorm reduction pair (fwd: z, z^2; bwd: dy, dy*xhat)
+#pragma unroll
+    for (int c = 0; c < F; ++c) s_a[c] = s_b[c] = 0.f;
+    f32x4 acc_c0 = {0.f, 0.f, 0.f, 0.f}, acc_c1 = {0.f, 0.f, 0.f, 0.f};   // conv weight gradient (MFMA)
+    f32x4 acc_th = {0.f, 0.f, 0.f, 0.f};                                   // theta / fc1 weight gradient (MFMA)
+    float acc_b = 0.f, acc_w2 = 0.f, acc_b2 = 0.f, acc_loss = 0.f;         // theta/fc1 bias, fc2 weight, fc2 bias, loss
+
+    const float fc2_b = prm[off_fc2_b(N, L)];
+    const int64_t sampleNP = (int64_t)N * a.P;
+    const float inv_gb = 1.0f / (float)a.global_batch;
+
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
+         tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t s0 = tile * TSPW;
+        const int ns = (int)((a.B - s0) < TSPW ? (a.B - s0) : TSPW);
+        const bool rowok = srow < ns;
+        const bool valid = rowok && (t < N);
+        float X[F], A[NPAIR];
+
+        // ---- input-only part: patch statistics + Pearson adjacency (F_0 computes and caches) -------
+        if constexpr (KIND == PH_F && IDX == 0) {
+            __builtin_amdgcn_wave_barrier();
+            stage_tile(gx + s0 * sampleNP, mywave, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < F; ++c) X[c] = 0.f;
+            if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, a.P, X);
+            pearson_adjacency<TRW>(X, valid, N, A);
+            // padding rows (beyond the batch) would give 0/0 = NaN: keep them finite
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) A[i] = rowok ? A[i] : 0.f;
+            float* cx = a.cacheX + tile * (F * 64) + lane;
+#pragma unroll
+            for (int c = 0; c < F; ++c) cx[c * 64] = X[c];
+            float aq[AQ] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NPAIR; ++i) aq[i / 16] = (t == (i % 16)) ? A[i] : aq[i / 16];
+            float* ca = a.cacheA + tile * (AQ * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) ca[q * 64] = aq[q];
+        } else {
+            const float* cx = a.cacheX + tile * (F * 64) + lane;
+#pragma unroll
+            for (int c = 0; c < F; ++c) X[c] = cx[c * 64];
+            const float* ca = a.cacheA + tile * (AQ * 64) + lane;
+            float* ab = abuf + (wave * TSPW + srow) * 64;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < AQ; ++q) ab[q * 16 + t] = ca[q * 64];
+            __builtin_amdgcn_wave_barrier();
+            const float4* ab4 = reinterpret_cast<const float4*>(ab);
+#pragma unroll
+            for (int i4 = 0; i4 < (NPAIR + 3) / 4; ++i4) {
+                const float4 v = ab4[i4];
+                A[i4 * 4 + 0] = v.x;
+                if (i4 * 4 + 1 < NPAIR) A[i4 * 4 + 1] = v.y;
+                if (i4 * 4 + 2 < NPAIR) A[i4 * 4 + 2] = v.z;
+                if (i4 * 4 + 3 < NPAIR) A[i4 * 4 + 3] = v.w;
+            }
+        }
+
+        // ---- forward recompute, keeping what the backward needs in registers ---------------------------
+        float Xin[L][F], Hs[L][F], z1s[L][F], o0s[L][F], z2s[L][F];
+        const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
+        bool stopped = false;
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            if (stopped) break;
+            const float* lp = prm + l * LS;
+            float AX[F];
+#pragma unroll
+            for (int c = 0; c < F; ++c) Xin[l][c] = X[c];
+            adj_aggregate(A, X, AX);
+            const float tb = vecs[l * TRW + t];
+#pragma unroll
+            for (int c = 0; c < F; ++c) Hs[l][c] = tb;
+            R16::project10(Hs[l], AX, wlds + (l * TRW + t) * TWS, N);
+#pragma unroll
+            for (int c = 0; c < F; ++c) Hs[l][c] = leaky(Hs[l][c]);
+            causal_conv<TRW, 1>(Hs[l], lp + off_conv_w(N, 0), t, z1s[l]);
+            if constexpr (KIND == PH_F) {
+                if (IDX == 2 * l) {                       // F_{2l}: statistics of conv_block1's output
+#pragma unroll
+                    for (int c = 0; c < F; ++c) {
+                        const float z = valid ? z1s[l][c] : 0.f;
+                        s_a[c] += z;
+                        s_b[c] = fmaf(z, z, s_b[c]);
+                    }
+                    stopped = true;
+                    continue;
+                }
+            }
+            const float* b1 = bnc + (2 * l) * BNC * F;
+#pragma unroll
+            for (int c = 0; c < F; ++c)
+                o0s[l][c] = relu(relu(fmaf(z1s[l][c], b1[2 * F + c], b1[3 * F + c])) + Hs[l][c]);
+            causal_conv<TRW, 2>(o0s[l], lp + off_conv_w(N, 1), t, z2s[l]);
+            if constexpr (KIND == PH_F) {
+                if (IDX == 2 * l + 1) {                   // F_{2l+1}: statistics of conv_block2's output
+#pragma unroll
+                    for (int c = 0; c < F; ++c) {
+                        const float z = valid ? z2s[l][c] : 0.f;
+                        s_a[c] += z;
+                        s_b[c] = fmaf(z, z, s_b[c]);
+                    }
+                    stopped = true;
+                    continue;
+                }
+            }
+            const float* b2 = bnc + (2 * l + 1) * BNC * F;
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                float o1 = relu(relu(fmaf(z2s[l][c], b2[2 * F + c], b2[3 * F + c])) + o0s[l][c]);
+                if (a.dropout_p > 0.f) {
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[l]);
+                    o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
+                }
+                X[c] = valid ? o1 + X[c] : 0.f;
+            }
+        }
+        if constexpr (KIND == PH_F) continue;             // F kernels are done with this tile
+
+        if constexpr (BACKWARD) {
+            // ---- head: max-pool over channels, fc1, fc2 (Model.py:218-221) ----------------------------------
+            float pooled = X[0];
+            int arg = 0;
+#pragma unroll
+            for (int c = 1; c < F; ++c) {
+                const bool take = (X[c] > pooled) || (X[c] != X[c] && pooled == pooled);
+                pooled = take ? X[c] : pooled;
+                arg = take ? c : arg;
+            }
+            pooled = valid ? pooled : 0.f;
+            float y1 = vecs[L * TRW + t];
+            R16::project1(y1, pooled, wlds + (L * TRW + t) * TWS, N);
+            y1 = relu(y1);
+            const float w2 = vecs[(L + 1) * TRW + t];
+            const float pred = R16::allsum(y1 * w2) + fc2_b;
+            float dpred = 0.f;
+            if (rowok) {
+                if (a.has_dpred == 1) {
+                    dpred = gy[s0 + srow];
+                } else if (a.has_dpred == 0) {
+                    const float diff = pred - gy[s0 + srow];
+                    dpred = 2.f * diff * inv_gb;
+                    if (KIND == PH_TOP && t == 0) acc_loss = fmaf(diff, diff, acc_loss);
+                }
+            }
+            if constexpr (KIND == PH_TOP) {
+                if (t == 0 && rowok) a.pred[s0 + srow] = pred;
+                if (!a.do_backward) continue;
+            }
+            // fc2 / fc1 backward
+            const float dy1 = (y1 > 0.f) ? dpred * w2 : 0.f;                       // d(fc1 pre-activation), lane j
+            float dpool = 0.f;
+            R16::project1(dpool, dy1, wldsT + (L * TRW + t) * TWS, N);             // sum_j dy1[j] fc1.w[j][t]
+            if constexpr (KIND == PH_TOP) {
+                acc_w2 = fmaf(dpred, y1, acc_w2);
+                acc_b2 += (t == 0) ? dpred : 0.f;
+                acc_b += dy1;
+                acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dy1, pooled, acc_th, 0, 0, 0);   // d fc1.w[j][t]
+            }
+            float dX[F];
+#pragma unroll
+            for (int c = 0; c < F; ++c) dX[c] = (valid && c == arg) ? dpool : 0.f;
+
+            // ---- layers, top down ---------------------------------------------------------------------------
+            bool done = false;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l) {
+                if (done) break;
+                const float* lp = prm + l * LS;
+                const float* b1 = bnc + (2 * l) * BNC * F;
+                const float* b2 = bnc + (2 * l + 1) * BNC * F;
+                // recompute the cheap pieces
+                float gsum[F], dy[F], xh[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float x1 = relu(fmaf(z2s[l][c], b2[2 * F + c], b2[3 * F + c]));
+                    const float o1 = relu(x1 + o0s[l][c]);
+                    float g = dX[c];
+                    if (a.dropout_p > 0.f) {
+                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[l]);
+                        g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
+                    }
+                    g = (o1 > 0.f) ? g : 0.f;
+                    gsum[c] = g;                                   // d(x1 + o0)
+                    dy[c] = (x1 > 0.f && valid) ? g : 0.f;         // d(BatchNorm 2l+1 output)
+                    xh[c] = (z2s[l][c] - b2[0 * F + c]) * b2[1 * F + c];
+                }
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int bn_hi = 2 * l + 1;
+                if ((KIND == PH_TOP && bn_hi == NBN - 1) || (KIND == PH_G && bn_hi == IDX - 1)) {
+#pragma unroll
+                    for (int c = 0; c < F; ++c) {
+                        s_a[c] += dy[c];
+                        s_b[c] = fmaf(dy[c], xh[c], s_b[c]);
+                    }
+                    done = true;
+                    continue;
+                }
+                // BatchNorm 2l+1 backward
+                float dz[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float v = b2[4 * F + c] * (dy[c] - b2[5 * F + c] - xh[c] * b2[6 * F + c]);
+                    dz[c] = valid ? v : 0.f;
+                }
+                if (KIND == PH_G && bn_hi == IDX) {                 // weight gradient of conv_block2
+                    float hs[F];
+#pragma unroll
+                    for (int c = 0; c < F; ++c) hs[c] = R16::template shr<2>(o0s[l][c], t);
+                    conv_wgrad_mfma(mywave, dz, o0s[l], hs, lane, acc_c0, acc_c1);
+                }
+                float d_o0[F];
+                causal_conv_T<2>(dz, lp + off_conv_w(N, 1), t, d_o0);
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float x0 = relu(fmaf(z1s[l][c], b1[2 * F + c], b1[3 * F + c]));
+                    float g = d_o0[c] + gsum[c];
+                    g = (o0s[l][c] > 0.f) ? g : 0.f;
+                    gsum[c] = g;                                   // d(x0 + H)
+                    dy[c] = (x0 > 0.f && valid) ? g : 0.f;         // d(BatchNorm 2l output)
+                    xh[c] = (z1s[l][c] - b1[0 * F + c]) * b1[1 * F + c];
+                }
+                const int bn_lo = 2 * l;
+                if (KIND == PH_G && bn_lo == IDX - 1) {
+#pragma unroll
+                    for (int c = 0; c < F; ++c) {
+                        s_a[c] += dy[c];
+                        s_b[c] = fmaf(dy[c], xh[c], s_b[c]);
+                    }
+                    done = true;
+                    continue;
+                }
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float v = b1[4 * F + c] * (dy[c] - b1[5 * F + c] - xh[c] * b1[6 * F + c]);
+                    dz[c] = valid ? v : 0.f;
+                }
+                const bool grads_here = (KIND == PH_G && bn_lo == IDX);
+                if (grads_here) {                                   // weight gradient of conv_block1
+                    float hs[F];
+#pragma unroll
+                    for (int c = 0; c < F; ++c) hs[c] = R16::template shr<1>(Hs[l][c], t);
+                    conv_wgrad_mfma(mywave, dz, Hs[l], hs, lane, acc_c0, acc_c1);
+                }
+                float dH[F];
+                causal_conv_T<1>(dz, lp + off_conv_w(N, 0), t, dH);
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float g = dH[c] + gsum[c];
+                    dH[c] = valid ? (Hs[l][c] > 0.f ? g : g * LEAKY) : 0.f;      // d(theta pre-activation)
+                }
+                if (grads_here) {                                   // theta gradient: MFMA straight from registers
+                    float AX[F];
+                    adj_aggregate(A, Xin[l], AX);
+#pragma unroll
+                    for (int c = 0; c < F; ++c) {
+                        acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AX[c], acc_th, 0, 0, 0);
+                        acc_b += dH[c];
+                    }
+                }
+                if (l > 0) {
+                    float dAX[F];
+#pragma unroll
+                    for (int c = 0; c < F; ++c) dAX[c] = 0.f;
+                    R16::project10(dAX, dH, wldsT + (l * TRW + t) * TWS, N);       // dHpre . theta
+                    float dXl[F];
+                    adj_aggregate(A, dAX, dXl);                                     // A is symmetric: A^T = A
+#pragma unroll
+                    for (int c = 0; c < F; ++c) dX[c] = valid ? dXl[c] + dX[c] : 0.f;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: block reduction, then ONE fp64 atomic per cell / one partial row per block -------------
+    // (1) BatchNorm pair: every F kernel, TOP (if backward) and G_i with i > 0
+    const bool has_pair = (KIND == PH_F) || (KIND == PH_TOP && a.do_backward) || (KIND == PH_G && IDX > 0);
+    if (has_pair) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const float va = wave_sum(s_a[c]), vb = wave_sum(s_b[c]);
+            if (lane == 0) {
+                redp[wave * 24 + c] = va;
+                redp[wave * 24 + F + c] = vb;
+            }
+        }
+    }
+    if (KIND == PH_TOP) {
+        const float vl = wave_sum(acc_loss);
+        if (lane == 0) redp[wave * 24 + 2 * F] = vl;
+    }
+    __syncthreads();
+    if (has_pair && threadIdx.x < 2 * F) {
+        double v = 0.0;
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) v += (double)redp[w * 24 + threadIdx.x];
+        const int which = threadIdx.x / F, c = threadIdx.x % F;
+        double* cell;
+        if (KIND == PH_F) cell = a.cells_fwd + (IDX * 2 + which) * F + c;
+        else if (KIND == PH_TOP) cell = a.cells_bwd + ((NBN - 1) * 2 + which) * F + c;
+        else cell = a.cells_bwd + ((IDX - 1) * 2 + which) * F + c;
+        atomicAdd(cell, v);
+    }
+    if (KIND == PH_TOP && threadIdx.x == 2 * F && a.has_dpred == 0) {
+        double v = 0.0;
+        for (int w = 0; w < WAVES_PER_BLOCK; ++w) v += (double)redp[w * 24 + 2 * F];
+        atomicAdd(a.cell_loss, v);
+    }
+    if constexpr (KIND == PH_F) return;
+    if (KIND == PH_TOP && !a.do_backward) return;
+
+    // (2) weight-gradient accumulators -> per-block partial row (waves add in a fixed order: deterministic)
+    float* row = a.gpart + (size_t)blockIdx.x * a.pcount;
+    for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
+        if (wave == w) {
+            float* r = red + lane;
+            const float v[RED_K] = {acc_th[0], acc_th[1], acc_th[2], acc_th[3], acc_c0[0], acc_c0[1], acc_c0[2], acc_c0[3],
+                                    acc_c1[0], acc_c1[1], acc_c1[2], acc_c1[3], acc_b, acc_w2, acc_b2};
+#pragma unroll
+            for (int k = 0; k < RED_K; ++k) r[k * 64] = (w == 0) ? v[k] : r[k * 64] + v[k];
+        }
+        __syncthreads();
+    }
+    if (KIND == PH_TOP) {
+        // fc1.weight[j][k]: MFMA D layout -> row j = 4*(lane>>4) + reg, column k = lane & 15
+        for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
+            const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
+            if (j < N && k < N) row[off_fc1_w(N, L) + j * N + k] = red[rg * 64 + ln];
+        }
+        if (threadIdx.x < N) {
+            const int j = threadIdx.x;
+            float vb = 0.f, vw = 0.f;
+            for (int s = 0; s < TSPW; ++s) { vb += red[12 * 64 + s * 16 + j]; vw += red[13 * 64 + s * 16 + j]; }
+            row[off_fc1_b(N, L) + j] = vb;
+            row[off_fc2_w(N, L) + j] = vw;
+        }
+        if (threadIdx.x == 0) {
+            float v = 0.f;
+            for (int s = 0; s < TSPW; ++s) v += red[14 * 64 + s * 16];
+            row[off_fc2_b(N, L)] = v;
+        }
+    }
+    if (KIND == PH_G) {
+        constexpr int l = IDX / 2, blk = IDX % 2;
+        float* lrow = row + l * LS;
+        // conv weight [co][ci][tap]: acc0 column j<10 -> (ci=j, tap 1); 10..15 -> (ci=j-10, tap 0); acc1 column j<4 -> (ci=6+j, tap 0)
+        for (int i = threadIdx.x; i < 8 * 64; i += BLOCK) {
+            const int rg = (i / 64) % 4, which = i / 256, ln = i % 64;
+            const int co = 4 * (ln >> 4) + rg, j = ln & 15;
+            int ci, tap;
+            if (which == 0) { ci = j < F ? j : j - F; tap = j < F ? 1 : 0; }
+            else { ci = 6 + j; tap = 0; }
+            if (co < F && ci < F && (which == 0 || j < 4))
+                lrow[off_conv_w(N, blk) + (co * F + ci) * 2 + tap] = red[(4 + which * 4 + rg) * 64 + ln];
+        }
+        if (blk == 0) {
+            for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
+                const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
+                if (j < N && k < N) lrow[off_theta_w(N) + j * N + k] = red[rg * 64 + ln];
+            }
+            if (threadIdx.x < N) {
+                float vb = 0.f;
+                for (int s = 0; s < TSPW; ++s) vb += red[12 * 64 + s * 16 + threadIdx.x];
+                lrow[off_theta_b(N) + threadIdx.x] = vb;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: per-block partial rows + BatchNorm cells -> flat gradient, loss, batch statistics
+// ------------------------------------------------------------------------------------------------
+struct FinalizeK {
+    const float* gpart;
+    const double* cells_fwd;
+    const double* cells_bwd;
+    const double* cell_loss;
+    float* grads;
+    float* loss;
+    float* bn_batch;
+    int grid_top;
+    int grid_g[16];       // grid of G_i, i = BatchNorm index
+    int N, L, pcount;
+    int64_t B, global_batch;
+    int write_grads, write_loss;
+};
+
+__global__ void stgcn_train_finalize_kernel(FinalizeK f) {
+    const int N = f.N, L = f.L, LS = layer_stride(N);
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    const double cnt = (double)f.B * (double)N;
+    if (f.write_grads) {
+        for (int p = wid; p < f.pcount; p += nw) {        // one wavefront per parameter
+            int nblk;
+            bool from_cells = false;
+            int bn = 0, which = 0, c = 0;
+            if (p >= L * LS) {
+                nblk = f.grid_top;
+            } else {
+                const int l = p / LS, o = p % LS;
+                if (o < off_conv_w(N, 0)) nblk = f.grid_g[2 * l];                     // theta w/b
+                else {
+                    const int blk = o >= off_conv_w(N, 1) ? 1 : 0;
+                    const int oo = o - off_conv_w(N, blk);
+                    nblk = f.grid_g[2 * l + blk];
+                    if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
+                }
+            }
+            if (from_cells) {
+                // d gamma = sum dy*xhat, d beta = sum dy
+                if (lane == 0) f.grads[p] = (float)f.cells_bwd[(bn * 2 + (which == 0 ? 1 : 0)) * F + c];
+                continue;
+            }
+            float v = 0.f;
+            for (int b = lane; b < nblk; b += 64) v += f.gpart[(size_t)b * f.pcount + p];
+            v = wave_sum(v);
+            if (lane == 0) f.grads[p] = v;
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(f.cell_loss[0] / (double)f.global_batch);
+        for (int i = threadIdx.x; i < 2 * L * F; i += blockDim.x) {
+            const int b = i / F, c = i % F;
+            const double mean = f.cells_fwd[(b * 2 + 0) * F + c] / cnt;
+            double var = f.cells_fwd[(b * 2 + 1) * F + c] / cnt - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
+            f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct WsLayout {
+    size_t off_cacheX, off_cacheA, off_cells, off_gpart, total;
+    size_t cells_bytes;
+    int max_grid;
+};
+
+static int max_resident_blocks() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus * 8;
+}
+
+static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* w) {
+    const int L = s->num_layers, N = s->num_patch;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
+    w->off_cacheA = o; o = al(o + (size_t)g.ntiles * AQ * 64 * sizeof(float));
+    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
+    w->off_cells = o; o = al(o + w->cells_bytes);
+    w->max_grid = 2048;
+    w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
+    w->total = o;
+}
+
+size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
+    rulgnn_stgcn_shape tmp = *s;
+    TileGeom g;
+    if (tile_geometry(&tmp, &g) != RULGNN_OK) return 0;
+    if (g.RW != TRW || s->num_layers > 3) return 0;
+    g.ntiles = (s->batch + TSPW - 1) / TSPW;
+    WsLayout w;
+    ws_layout(s, g, &w);
+    return w.total;
+}
+
+static size_t train_lds_bytes(int L, const TileGeom& g) {
+    const int wave_area = g.stage_floats > TT_ROWS * TT_STRIDE ? g.stage_floats : TT_ROWS * TT_STRIDE;
+    const size_t fl = (size_t)2 * (L + 1) * TRW * TWS + (size_t)(L + 2) * TRW + (size_t)((2 * L * BNC * F + 3) & ~3) +
+                      (size_t)WAVES_PER_BLOCK * TSPW * 64 + (size_t)15 * 64 + (size_t)WAVES_PER_BLOCK * 24 +
+                      (size_t)WAVES_PER_BLOCK * wave_area;
+    return fl * sizeof(float);
+}
+
+template <int L, int KIND, int IDX>
+static int launch_phase(const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int max_grid,
+                        hipStream_t stream, int* grid_out) {
+    auto kern = stgcn_train_phase_kernel<L, KIND, IDX>;
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return RULGNN_EHIP;
+    }
+    int grid = persistent_grid(kern, k.ntiles, lds);
+    if (grid > max_grid) grid = max_grid;
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, x, prm, gy, k);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+template <int L, int I>
+struct PhaseChain {
+    static int forward_stats(const TrainK& k, const float* x, const float* prm, size_t lds, int mg, hipStream_t st) {
+        if constexpr (I > 0) {
+            const int rc = PhaseChain<L, I - 1>::forward_stats(k, x, prm, lds, mg, st);
+            if (rc != RULGNN_OK) return rc;
+        }
+        return launch_phase<L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
+    }
+    static int backward(const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int mg, hipStream_t st,
+                        int* grids) {
+        const int rc = launch_phase<L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
+        if (rc != RULGNN_OK) return rc;
+        if constexpr (I > 0) return PhaseChain<L, I - 1>::backward(k, x, prm, gy, lds, mg, st, grids);
+        return RULGNN_OK;
+    }
+};
+
+enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
+
+template <int L>
+static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+    TileGeom g;
+    int rc = tile_geometry(s, &g);
+    if (rc != RULGNN_OK) return rc;
+    if (g.RW != TRW) return RULGNN_EUNSUPPORTED;            // training kernels cover num_patch <= 16 (C-MAPSS shapes)
+    g.ntiles = (s->batch + TSPW - 1) / TSPW;
+    WsLayout w;
+    ws_layout(s, g, &w);
+    if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    const int N = s->num_patch;
+
+    TrainK k;
+    k.cacheX = reinterpret_cast<float*>(ws + w.off_cacheX);
+    k.cacheA = reinterpret_cast<float*>(ws + w.off_cacheA);
+    double* cells = reinterpret_cast<double*>(ws + w.off_cells);
+    k.cells_fwd = cells;
+    k.cells_bwd = cells + 2 * L * 2 * F;
+    k.cell_loss = cells + 2 * (2 * L * 2 * F);
+    k.gpart = reinterpret_cast<float*>(ws + w.off_gpart);
+    k.pred = a->pred;
+    k.B = s->batch; k.ntiles = g.ntiles; k.global_batch = a->global_batch; k.sample_offset = a->sample_offset;
+    k.N = N; k.P = s->patch_size; k.Ppad = g.Ppad;
+    k.vec4 = g.vec4 && ((reinterpret_cast<uintptr_t>(a->x) & 15) == 0);
+    k.stage_floats = g.stage_floats; k.magicP = g.magicP;
+    k.do_backward = mode != TM_FORWARD;
+    k.has_dpred = a->dpred ? 1 : (a->y ? 0 : 2);
+    k.dropout_p = a->dropout_p;
+    k.drop_scale = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
+    {
+        double thr = (double)a->dropout_p * 4294967296.0;
+        thr = thr < 0 ? 0 : thr;
+        uint64_t ti = (uint64_t)(thr + 0.5);
+        // match python round-half-even on exact .5 (only p with 33+ significant bits could differ)
+        k.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
+    }
+    for (int l = 0; l < 8; ++l) k.drop_key[l] = l < L ? dropout_layer_key(a->seed, a->step, l) : 0u;
+    k.pcount = param_count(N, L);
+    const size_t lds = train_lds_bytes(L, g);
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    const float* gy = a->dpred ? a->dpred : a->y;
+
+    if (mode == TM_FORWARD || mode == TM_FWDBWD) {
+        if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        rc = PhaseChain<L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
+        if (rc != RULGNN_OK) return rc;
+    } else {
+        // backward after a separate forward: forward cells are valid, clear the backward ones + loss
+        if (hipMemsetAsync(k.cells_bwd, 0, sizeof(double) * (2 * L * 2 * F + 8), stream) != hipSuccess) return RULGNN_EHIP;
+    }
+    int grid_top = 0;
+    int grids[16] = {0};
+    rc = launch_phase<L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);
+    if (rc != RULGNN_OK) return rc;
+    if (mode != TM_FORWARD) {
+        rc = PhaseChain<L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids);
+        if (rc != RULGNN_OK) return rc;
+    }
+    FinalizeK f;
+    f.gpart = k.gpart; f.cells_fwd = k.cells_fwd; f.cells_bwd = k.cells_bwd; f.cell_loss = k.cell_loss;
+    f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
+    f.grid_top = grid_top;
+    for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
+    f.N = N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.write_grads = mode != TM_FORWARD;
+    f.write_loss = (k.has_dpred == 0) && a->loss;
+    const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;
+    hipLaunchKernelGGL(stgcn_train_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, f);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+    switch (s->num_layers) {
+        case 1: return run_train<1>(s, a, mode, stream);
+        case 2: return run_train<2>(s, a, mode, stream);
+        case 3: return run_train<3>(s, a, mode, stream);
+        default: return RULGNN_EUNSUPPORTED;
+    }
+}
+
+int stgcn_train_forward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {
+    return dispatch_train(s, a, TM_FORWARD, st);
+}
+int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {
+    return dispatch_train(s, a, TM_BACKWARD, st);
+}
+int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {
+    return dispatch_train(s, a, TM_FWDBWD, st);
+}
+
+}  // namespace rulgnn

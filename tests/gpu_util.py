@@ -49,3 +49,42 @@ def abi_forward(x_np, flat_np, bn_np, N, P, L=2):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def abi_train(x_np, y_np, flat_np, N, P, L=2, mode="fwdbwd", dropout=0.0, seed=0, step=1, dpred_np=None,
+              global_batch=None, sample_offset=0):
+    """Train-mode entry points on cuda:0.  Returns dict(pred, loss, grads, bn_batch) as numpy."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B = x_np.shape[0]
+    x = torch.from_numpy(np.ascontiguousarray(x_np.reshape(B, -1), np.float32)).to(dev)
+    y = torch.from_numpy(np.ascontiguousarray(y_np.reshape(B), np.float32)).to(dev) if y_np is not None else None
+    dp = torch.from_numpy(np.ascontiguousarray(dpred_np.reshape(B), np.float32)).to(dev) if dpred_np is not None else None
+    prm = torch.from_numpy(flat_np).to(dev)
+    grads = torch.full_like(prm, float("nan"))
+    pred = torch.full((B,), float("nan"), device=dev)
+    loss = torch.full((1,), float("nan"), device=dev)
+    bnb = torch.full((L * 2 * 2 * 10,), float("nan"), device=dev)
+    shp = shape_struct(B, N, P, L)
+    nbytes = lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a = _lib.StgcnTrainArgs()
+    a.x = x.data_ptr(); a.y = y.data_ptr() if y is not None else None
+    a.dpred = dp.data_ptr() if dp is not None else None
+    a.params = prm.data_ptr(); a.grads = grads.data_ptr(); a.pred = pred.data_ptr(); a.loss = loss.data_ptr()
+    a.bn_batch = bnb.data_ptr(); a.workspace = ws.data_ptr(); a.workspace_bytes = nbytes
+    a.global_batch = B if global_batch is None else global_batch
+    a.sample_offset = sample_offset
+    a.dropout_p = dropout; a.seed = seed; a.step = step
+    st = stream_ptr()
+    if mode == "fwdbwd":
+        _lib.check(lib.rulgnn_stgcn_train_fwdbwd_f32(C.byref(shp), C.byref(a), st), "train_fwdbwd")
+    elif mode == "split":
+        _lib.check(lib.rulgnn_stgcn_train_forward_f32(C.byref(shp), C.byref(a), st), "train_forward")
+        _lib.check(lib.rulgnn_stgcn_train_backward_f32(C.byref(shp), C.byref(a), st), "train_backward")
+    elif mode == "forward":
+        _lib.check(lib.rulgnn_stgcn_train_forward_f32(C.byref(shp), C.byref(a), st), "train_forward")
+    torch.cuda.synchronize()
+    return {"pred": pred.cpu().numpy(), "loss": float(loss.item()), "grads": grads.cpu().numpy(),
+            "bn_batch": bnb.cpu().numpy()}

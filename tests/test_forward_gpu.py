@@ -25,7 +25,7 @@ def test_forward_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("N,P,B", [(14, 30, 1), (14, 30, 3), (14, 30, 4), (14, 30, 1027), (14, 50, 257),
-                                   (16, 30, 65), (2, 2, 9), (5, 7, 33), (14, 31, 19), (16, 16, 40),
+                                   (16, 30, 65), (3, 6, 9), (5, 7, 33), (14, 31, 19), (16, 16, 40),
                                    (24, 20, 37), (32, 8, 11), (40, 64, 9), (64, 10, 6)])
 def test_forward_matches_oracle_seeded(N, P, B):
     import gpu_util as G
