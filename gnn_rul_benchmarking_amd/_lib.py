@@ -24,7 +24,8 @@ class StgcnTrainArgs(C.Structure):
                 ("grads", C.c_void_p), ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_batch", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("global_batch", C.c_int64), ("sample_offset", C.c_int64),
-                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64)]
+                ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
+                ("bn_moment_weight", C.c_float)]
 
 
 _SIGNATURES = {
@@ -41,7 +42,7 @@ _SIGNATURES = {
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_void_p]),
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
-                                                C.c_void_p]),
+                                                C.c_int32, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,0 +1,81 @@
+"""Plugin registry: ``--GNN_method NAME`` -> Algorithm class, as the reference's
+algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
+``NotImplementedError("Algorithm not found: ...")`` otherwise).
+
+Only the ST_GCN wrapper (reference algorithms/algorithms.py:465-490) is implemented: it is the
+hot path this package accelerates.  The class keeps the reference contract -- constructor
+``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
+``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .optim import FusedAdam
+from .stgcn import ST_GCN_model
+
+
+def get_algorithm_class(algorithm_name):
+    """Return the algorithm class with the given name."""
+    if algorithm_name not in globals() or algorithm_name.startswith("_") or algorithm_name in _NOT_ALGORITHMS:
+        raise NotImplementedError("Algorithm not found: {}".format(algorithm_name))
+    return globals()[algorithm_name]
+
+
+class Algorithm(torch.nn.Module):
+    """Base class (reference algorithms/algorithms.py:36-48): subclasses define ``update``."""
+
+    def __init__(self, configs):
+        super(Algorithm, self).__init__()
+        self.configs = configs
+        self.mse = nn.MSELoss()
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError
+
+
+class ST_GCN(Algorithm):
+    """ST_GCN training wrapper.  ``update`` = forward + MSE + backward + Adam, as the reference
+    (algorithms.py:481-490), executed as one fused HIP forward/backward call plus one fused Adam
+    kernel; with a ``DataParallel`` context attached (dp.py) the gradient bucket is all-reduced
+    over RCCL in between.
+
+    ``sync_loss``: the reference returns ``loss.item()`` (a host sync every step).  That stays the
+    default; ``sync_loss=False`` returns the 0-d device tensor instead so a training loop can read
+    it once per epoch."""
+
+    def __init__(self, configs, hparams, device):
+        super(ST_GCN, self).__init__(configs)
+        self.model = ST_GCN_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None            # optional dp.DataParallel
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None):
+        model = self.model
+        if not model.training:
+            raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
+        if self.dp is None:
+            _, loss = model.fused_mse_step(X, y)
+            self.optimizer.step(from_bucket=True)
+        else:
+            loss = self.dp.step(model, self.optimizer, X, y)
+        return {'loss': loss.item() if self.sync_loss else loss}
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd (slower: ~20 tiny accumulate ops);
+        kept for API parity and tested to give the same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "get_algorithm_class", "torch", "nn", "annotations"}

@@ -22,12 +22,19 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
 }
 
 __global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
-                                         float unbias) {
+                                         float unbias, int from_moments) {
     // layout [n_bn][2 (mean, var)][F]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bn * 2 * F) return;
     const bool is_var = (i / F) % 2 == 1;
-    const float b = is_var ? batch[i] * unbias : batch[i];
+    float b = batch[i];
+    if (is_var) {
+        if (from_moments) {
+            const float m = batch[i - F];
+            b = fmaxf(b - m * m, 0.f);
+        }
+        b *= unbias;
+    }
     bn[i] = (1.f - momentum) * bn[i] + momentum * b;
 }
 
@@ -44,12 +51,13 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t s
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
-int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, hipStream_t stream) {
+int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
+                      hipStream_t stream) {
     const int n_bn = num_layers * 2;
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int total = n_bn * 2 * F;
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
-                       momentum, unbias);
+                       momentum, unbias, from_moments);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

@@ -56,6 +56,7 @@ static int check_train(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train
     if (shape->batch < 1) return RULGNN_EINVAL;                 // BatchNorm needs a batch
     if (a->global_batch < shape->batch || a->sample_offset < 0) return RULGNN_EINVAL;
     if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return RULGNN_EINVAL;
+    if (!(a->bn_moment_weight >= 0.f)) return RULGNN_EINVAL;
     rc = check_ptrs({a->x, a->params, a->pred, a->bn_batch, a->workspace});
     if (rc != RULGNN_OK) return rc;
     if (need_grads) {
@@ -101,11 +102,11 @@ int rulgnn_adam_step_f32(float* params, const float* grads, float* exp_avg, floa
 }
 
 int rulgnn_bn_running_update_f32(float* bn_stats, const float* bn_batch, int32_t num_layers, int64_t count,
-                                 float momentum, void* stream) {
+                                 float momentum, int32_t from_moments, void* stream) {
     if (num_layers < 1 || num_layers > 8 || count < 1) return RULGNN_EINVAL;
     const int rc = check_ptrs({bn_stats, bn_batch});
     if (rc != RULGNN_OK) return rc;
-    return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, static_cast<hipStream_t>(stream));
+    return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, from_moments, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -586,6 +586,7 @@ struct FinalizeK {
     int N, L, pcount;
     int64_t B, global_batch;
     int write_grads, write_loss;
+    float moment_weight;
 };
 
 __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
@@ -629,8 +630,13 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
             const double mean = f.cells_fwd[(b * 2 + 0) * F + c] / cnt;
             double var = f.cells_fwd[(b * 2 + 1) * F + c] / cnt - mean * mean;
             var = var < 0.0 ? 0.0 : var;
-            f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
-            f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
+            if (f.moment_weight > 0.f) {
+                f.bn_batch[(b * 2 + 0) * F + c] = (float)(mean * (double)f.moment_weight);
+                f.bn_batch[(b * 2 + 1) * F + c] = (float)(f.cells_fwd[(b * 2 + 1) * F + c] / cnt * (double)f.moment_weight);
+            } else {
+                f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
+                f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
+            }
         }
     }
 }
@@ -786,6 +792,7 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     f.grid_top = grid_top;
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
     f.N = N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.moment_weight = a->bn_moment_weight;
     f.write_grads = mode != TM_FORWARD;
     f.write_loss = (k.has_dpred == 0) && a->loss;
     const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;

@@ -1,0 +1,63 @@
+"""Data parallelism for the ST_GCN path: one process per GPU, gradients all-reduced over RCCL.
+
+The reference is single-process (no torch.distributed anywhere); this is the
+new part.  Training samples are independent except for BatchNorm's batch statistics, so the
+global batch is sharded by sample with NO data-path collective; per step there is exactly ONE
+all-reduce, over a single flat fp32 bucket:
+
+    [ gradient of the live parameters (P floats) | loss (1) | BatchNorm batch moments (2L*2*10) ]
+
+* gradient: every rank's kernels already scale d(loss)/d(pred) by 1/global_batch, so a SUM over
+  ranks is the gradient of the global-batch MSE -- no division afterwards;
+* loss: sum over ranks of sum_i (pred_i - y_i)^2 / global_batch;
+* BatchNorm: normalisation uses each rank's LOCAL batch statistics (the torch DDP default); the
+  running statistics are updated from the all-reduced global-batch moments, so replicas stay
+  bit-identical without a separate buffer broadcast.
+
+For C-MAPSS shapes the bucket is 6.4 KB: the collective is latency-bound, so
+it is issued once, on the compute stream, directly on the kernels' output buffer (no copy)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Contiguous shard [lo, hi) of n samples for `rank`; the first n % world_size ranks get one extra
+    (ragged last batch, drop_last=False in the reference's loaders)."""
+    base, extra = divmod(n, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class DataParallel:
+    def __init__(self, process_group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = process_group
+        self.rank = dist.get_rank(process_group)
+        self.world_size = dist.get_world_size(process_group)
+
+    def broadcast_model(self, model) -> None:
+        """Make every replica identical to rank 0 (parameters and BatchNorm statistics)."""
+        dist.broadcast(model.flat_params, 0, group=self.group)
+        dist.broadcast(model._bn, 0, group=self.group)
+        dist.broadcast(model._nbt, 0, group=self.group)
+
+    def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+
+    def step(self, model, optimizer, X_shard, y_shard, global_batch=None, sample_offset=None):
+        """One data-parallel ST_GCN.update on this rank's shard.  ``global_batch`` defaults to
+        world_size * len(shard) (equal shards); pass it (and ``sample_offset``) for ragged batches."""
+        b = X_shard.size(0)
+        if global_batch is None:
+            global_batch = b * self.world_size
+        if sample_offset is None:
+            sample_offset = b * self.rank
+        model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
+                             update_running_stats=False, moments_to_bucket=True)
+        self.all_reduce_bucket(model.bucket)
+        optimizer.step(from_bucket=True)
+        model._after_train_forward(global_batch, from_bucket_moments=True)
+        return model.bucket[model.num_live]

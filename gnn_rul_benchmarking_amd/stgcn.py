@@ -1,0 +1,305 @@
+"""Drop-in ``ST_GCN_model`` whose forward/backward run in the gfx950 HIP kernels.
+
+Mirrors the reference class (models/ST_GCN/Model.py:197-222): same constructor kwargs
+``(num_patch, patch_size, num_layers=2, dropout=0.5, k=1)``, same ``forward(x) -> [bs, 1]``, same 52
+``state_dict`` keys (including the dead ``net0``/``net1`` branches, Model.py:110-131) and -- because
+the parameter-holding sub-modules are created in the reference's order -- the same initial weights
+for a given torch seed.  None of those sub-modules is ever *called*: the live parameters are views
+into one flat fp32 buffer that the kernels read directly (gnn_rul_benchmarking_amd/params.py).
+
+There is no CPU path: calling the model with a non-CUDA tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+from torch.nn.utils import weight_norm
+
+from . import _lib, params as PL
+
+NUM_STATS = PL.NUM_STATS
+
+
+# --------------------------------------------------------------------------------------------
+# parameter-holding module tree (names follow the reference so that state_dict keys match)
+# --------------------------------------------------------------------------------------------
+class MPNN_mk(nn.Module):
+    """Holder of theta_k = Linear(N, N), k < K (Model.py:74-79)."""
+
+    def __init__(self, input_dimension, output_dimension, k):
+        super().__init__()
+        self.k = k
+        self.theta = nn.ModuleList([nn.Linear(input_dimension, output_dimension) for _ in range(k)])
+
+
+class TemporalConvNet(nn.Module):
+    """Holder of the TCN block's tensors (Model.py:99-160).  ``net0``/``net1`` exist only so that
+    checkpoints round-trip with the reference; they carry no gradient and are never updated."""
+
+    def __init__(self, num_inputs, num_channels, kernel_size):
+        super().__init__()
+        c0, c1 = num_channels[1], num_channels[1]
+        self.net0 = nn.Sequential(
+            weight_norm(nn.Conv1d(num_inputs, c0, kernel_size, padding=kernel_size - 1)), nn.ReLU(),
+            weight_norm(nn.Conv1d(c0, c0, kernel_size, padding=kernel_size - 1)), nn.ReLU())
+        self.net1 = nn.Sequential(
+            nn.Conv1d(num_inputs, c1, kernel_size, padding=2 * (kernel_size - 1), dilation=2), nn.ReLU(),
+            nn.Conv1d(c1, c1, kernel_size, padding=2 * (kernel_size - 1), dilation=2), nn.ReLU())
+        self.conv_block1 = nn.Sequential(
+            nn.Conv1d(num_inputs, c0, kernel_size, bias=False, padding=kernel_size - 1), nn.Identity(),
+            nn.BatchNorm1d(c0), nn.ReLU())
+        self.conv_block2 = nn.Sequential(
+            nn.Conv1d(c0, c1, kernel_size, bias=False, padding=2 * (kernel_size - 1), dilation=2), nn.Identity(),
+            nn.BatchNorm1d(c1), nn.ReLU())
+
+
+class SG_TCN(nn.Module):
+    def __init__(self, in_features, num_patch, num_layers, dropout, k):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        for _ in range(num_layers):
+            self.layers.append(nn.ModuleList([
+                MPNN_mk(num_patch, num_patch, k),
+                TemporalConvNet(in_features, [in_features, in_features], kernel_size=PL.TCN_KERNEL),
+                nn.Dropout(dropout)]))
+
+
+# --------------------------------------------------------------------------------------------
+# autograd bridge
+# --------------------------------------------------------------------------------------------
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _TrainFunction(torch.autograd.Function):
+    """model(X) in train mode: forward = rulgnn_stgcn_train_forward_f32, backward =
+    rulgnn_stgcn_train_backward_f32 with the incoming d(loss)/d(pred)."""
+
+    @staticmethod
+    def forward(ctx, model, x2d, *live):
+        pred = model._train_forward(x2d)
+        ctx.model = model
+        ctx.x2d = x2d
+        ctx.step = model._step
+        return pred.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, dpred):
+        model = ctx.model
+        grads = model._train_backward(ctx.x2d, dpred.contiguous().view(-1).float(), ctx.step)
+        out = [grads[off:off + n].view(shape).clone() for (off, n, shape) in model._live_slices]
+        return (None, None, *out)
+
+
+class ST_GCN_model(nn.Module):
+    def __init__(self, num_patch, patch_size, num_layers=2, dropout=0.5, k=1):
+        super().__init__()
+        self.num_patch = int(num_patch)
+        self.patch_size = int(patch_size)
+        self.num_layers = int(num_layers)
+        self.dropout_p = float(dropout)
+        self.k = int(k)
+        in_features = NUM_STATS
+        # same construction order as the reference => same RNG consumption => same initial weights
+        self.sg_tcn = SG_TCN(in_features, self.num_patch, self.num_layers, dropout, k)
+        self.global_max_pool = nn.AdaptiveMaxPool1d(1)
+        self.fc1 = nn.Linear(self.num_patch, self.num_patch)
+        self.fc2 = nn.Linear(self.num_patch, 1)
+
+        self._layout = PL.live_param_layout(self.num_patch, self.num_layers)
+        self._bn_layout = PL.bn_buffer_layout(self.num_layers)
+        self._live_slices = []
+        for name, (off, shape) in self._layout.items():
+            n = 1
+            for s in shape:
+                n *= s
+            self._live_slices.append((off, n, shape))
+        self._flat = None           # flat live parameters (the tensors in state_dict are views of it)
+        self._bn = None             # [L][2][2][10] running statistics
+        self._nbt = None            # [2L] num_batches_tracked
+        self._grad_flat = None      # gradient / all-reduce bucket (see dp.py): [P | loss | 4L*10 BN moments]
+        self._bn_batch = None
+        self._loss = None
+        self._ws = None
+        self._ws_key = None
+        self._step = 0              # training forwards so far (dropout stream position)
+        self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._reflatten()
+
+    # ---- flat storage --------------------------------------------------------------------------
+    def _named_live(self):
+        table = dict(self.named_parameters())
+        return [(name, table[name]) for name in self._layout]
+
+    def _reflatten(self):
+        """(Re)build the flat buffers on the parameters' current device and re-point every live
+        parameter / BatchNorm buffer at its slice."""
+        live = self._named_live()
+        dev = live[0][1].device
+        flat = torch.empty(PL.param_count(self.num_patch, self.num_layers), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for (name, p), (off, n, shape) in zip(live, self._live_slices):
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        bufs = dict(self.named_buffers())
+        bn = torch.empty(PL.bn_buffer_count(self.num_layers), dtype=torch.float32, device=dev)
+        nbt = torch.zeros(2 * self.num_layers, dtype=torch.int64, device=dev)
+        for i, (name, (off, shape)) in enumerate(self._bn_layout.items()):
+            bn[off:off + NUM_STATS].copy_(bufs[name].detach().float())
+            self._set_buffer(name, bn[off:off + NUM_STATS])
+            if name.endswith("running_mean"):
+                cname = name[:-len("running_mean")] + "num_batches_tracked"
+                nbt[i // 2].copy_(bufs[cname])
+                self._set_buffer(cname, nbt[i // 2])
+        self._bn, self._nbt = bn, nbt
+        nb = PL.param_count(self.num_patch, self.num_layers) + 1 + PL.bn_buffer_count(self.num_layers)
+        self._grad_flat = torch.zeros(nb, dtype=torch.float32, device=dev)
+        self._bn_batch = torch.zeros(PL.bn_buffer_count(self.num_layers), dtype=torch.float32, device=dev)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._pred_buf = None
+        self._ws, self._ws_key = None, None
+
+    def _set_buffer(self, dotted, tensor):
+        mod = self
+        parts = dotted.split(".")
+        for a in parts[:-1]:
+            mod = getattr(mod, a)
+        mod._buffers[parts[-1]] = tensor
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._reflatten()          # .to(device)/.float() move tensors one by one: restore the views
+        return self
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    @property
+    def bucket(self) -> torch.Tensor:
+        """[gradient (P) | loss (1) | BatchNorm batch moments (2L*2*10)]: what one all-reduce carries."""
+        return self._grad_flat
+
+    @property
+    def num_live(self) -> int:
+        return self._flat.numel()
+
+    # ---- C-ABI calls ---------------------------------------------------------------------------------
+    def _shape(self, batch):
+        return _lib.StgcnShape(batch, self.num_patch, self.patch_size, self.num_layers, self.k)
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("ST_GCN_model runs on the HIP kernels only: input must be a CUDA (ROCm) tensor; "
+                               "there is no CPU fallback")
+        if x.device != self._flat.device:
+            raise RuntimeError(f"input on {x.device} but model on {self._flat.device}")
+        bs = x.size(0)
+        if x.numel() != bs * self.num_patch * self.patch_size:
+            raise RuntimeError(f"shape '[{bs}, {self.num_patch}, {self.patch_size}]' is invalid for input of size {x.numel()}")
+        return x.reshape(bs, self.num_patch * self.patch_size).contiguous().float()
+
+    def _workspace(self, shp, batch):
+        key = (batch, self._flat.device)
+        if self._ws_key != key:
+            nbytes = _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
+            if nbytes == 0:
+                raise RuntimeError(
+                    f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
+                    "(train path: num_patch <= 16, num_layers <= 3); eval-mode forward covers num_patch <= 64")
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
+            self._ws_key = key
+        return self._ws
+
+    def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False):
+        B = x2d.size(0)
+        ws = self._workspace(shp, B)
+        if self._pred_buf is None or self._pred_buf.numel() != B:
+            self._pred_buf = torch.empty(B, dtype=torch.float32, device=x2d.device)
+        a = _lib.StgcnTrainArgs()
+        a.x = x2d.data_ptr()
+        a.y = y.data_ptr() if y is not None else None
+        a.dpred = dpred.data_ptr() if dpred is not None else None
+        a.params = self._flat.data_ptr()
+        a.grads = self._grad_flat.data_ptr()
+        a.pred = self._pred_buf.data_ptr()
+        a.loss = self._grad_flat.data_ptr() + 4 * self.num_live      # loss lands right behind the gradient
+        gb = B if global_batch is None else int(global_batch)
+        if moments_to_bucket:      # data parallel: w*(E[z], E[z^2]) behind the loss, summed by the all-reduce
+            a.bn_batch = self._grad_flat.data_ptr() + 4 * (self.num_live + 1)
+            a.bn_moment_weight = B / float(gb)
+        else:
+            a.bn_batch = self._bn_batch.data_ptr()
+            a.bn_moment_weight = 0.0
+        a.workspace = ws.data_ptr()
+        a.workspace_bytes = ws.numel()
+        a.global_batch = gb
+        a.sample_offset = int(sample_offset)
+        a.dropout_p = self.dropout_p
+        a.seed = self._seed
+        a.step = step
+        return a
+
+    def _after_train_forward(self, batch, from_bucket_moments=False):
+        """BatchNorm side effects of a training forward (running stats, num_batches_tracked).
+        ``from_bucket_moments``: use the all-reduced global-batch moments in the bucket tail."""
+        src = self._grad_flat.data_ptr() + 4 * (self.num_live + 1) if from_bucket_moments else self._bn_batch.data_ptr()
+        _lib.check(_lib.load().rulgnn_bn_running_update_f32(self._bn.data_ptr(), src, self.num_layers,
+                                                            batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
+                                                            _stream()),
+                   "rulgnn_bn_running_update_f32")
+        self._nbt += 1
+
+    def _train_forward(self, x2d):
+        self._step += 1
+        shp = self._shape(x2d.size(0))
+        a = self._train_args(shp, x2d, None, None, self._step)
+        _lib.check(_lib.load().rulgnn_stgcn_train_forward_f32(C.byref(shp), C.byref(a), _stream()),
+                   "rulgnn_stgcn_train_forward_f32")
+        self._after_train_forward(x2d.size(0))
+        return self._pred_buf.clone()
+
+    def _train_backward(self, x2d, dpred, step):
+        shp = self._shape(x2d.size(0))
+        a = self._train_args(shp, x2d, None, dpred, step)
+        _lib.check(_lib.load().rulgnn_stgcn_train_backward_f32(C.byref(shp), C.byref(a), _stream()),
+                   "rulgnn_stgcn_train_backward_f32")
+        return self._grad_flat
+
+    def fused_mse_step(self, x, y, global_batch=None, sample_offset=0, update_running_stats=True,
+                       moments_to_bucket=False):
+        """forward + MSE + backward in one C call (what ``ST_GCN.update`` needs before the optimizer):
+        fills ``self.bucket`` = [grad | loss | ...] and returns (pred [B], loss 0-d tensor), all on
+        the device, no host synchronisation."""
+        x2d = self._check_input(x)
+        yv = y.reshape(-1).contiguous().float()
+        if yv.numel() != x2d.size(0):
+            raise RuntimeError("target size mismatch")
+        self._step += 1
+        shp = self._shape(x2d.size(0))
+        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket)
+        _lib.check(_lib.load().rulgnn_stgcn_train_fwdbwd_f32(C.byref(shp), C.byref(a), _stream()),
+                   "rulgnn_stgcn_train_fwdbwd_f32")
+        if update_running_stats:
+            self._after_train_forward(x2d.size(0))
+        return self._pred_buf, self._grad_flat[self.num_live]
+
+    # ---- nn.Module surface -------------------------------------------------------------------------------
+    def forward(self, x):
+        x2d = self._check_input(x)
+        B = x2d.size(0)
+        if self.training:
+            if B == 0:
+                raise RuntimeError("training forward needs a non-empty batch")
+            if torch.is_grad_enabled():
+                return _TrainFunction.apply(self, x2d, *[p for _, p in self._named_live()])
+            return self._train_forward(x2d).view(-1, 1)
+        out = torch.empty(B, dtype=torch.float32, device=x2d.device)
+        shp = self._shape(B)
+        _lib.check(_lib.load().rulgnn_stgcn_forward_f32(C.byref(shp), x2d.data_ptr(), self._flat.data_ptr(),
+                                                        self._bn.data_ptr(), out.data_ptr(), _stream()),
+                   "rulgnn_stgcn_forward_f32")
+        return out.view(-1, 1)

@@ -77,7 +77,8 @@ typedef struct rulgnn_stgcn_train_args {
     float *grads;            /* out: flat gradient, same layout (overwritten, not accumulated) */
     float *pred;             /* out: [batch] train-mode predictions */
     float *loss;             /* out: 1 float, sum over this shard of (pred-y)^2 / global_batch */
-    float *bn_batch;         /* out: batch statistics [L][2][2][10] = (mean, biased var) of this shard */
+    float *bn_batch;         /* out: batch statistics [L][2][2][10] = (mean, biased var) of this shard;
+                                if bn_moment_weight > 0: w*(mean, mean of squares) instead */
     void *workspace;
     size_t workspace_bytes;
     int64_t global_batch;    /* MSE normaliser: batch summed over all data-parallel ranks (>= batch) */
@@ -85,6 +86,8 @@ typedef struct rulgnn_stgcn_train_args {
     float dropout_p;         /* 0 disables dropout */
     uint64_t seed;           /* dropout stream: (seed, step) -> per-layer keys */
     uint64_t step;
+    float bn_moment_weight;  /* 0: plain statistics. w > 0 (data parallel, w = batch/global_batch): bn_batch holds
+                                w*(E[z], E[z^2]) so that a SUM all-reduce over ranks yields the global-batch moments */
 } rulgnn_stgcn_train_args;
 
 /* Train-mode forward only (BatchNorm batch statistics, dropout): fills pred, bn_batch and the
@@ -111,9 +114,10 @@ int rulgnn_adam_step_f32(float *params, const float *grads, float *exp_avg, floa
                          float grad_scale, void *stream);
 
 /* nn.BatchNorm1d running-statistics update (momentum, unbiased running variance) from the batch
- * statistics produced by the training forward.  count = batch*num_patch values per channel. */
+ * statistics produced by the training forward.  count = batch*num_patch values per channel.
+ * from_moments != 0: bn_batch holds (E[z], E[z^2]) (the all-reduced form above) instead of (mean, var). */
 int rulgnn_bn_running_update_f32(float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count,
-                                 float momentum, void *stream);
+                                 float momentum, int32_t from_moments, void *stream);
 
 #ifdef __cplusplus
 }

@@ -162,6 +162,19 @@ def case_training_curve(name, num_patch, patch_size, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_init(name, num_patch, patch_size, seed):
+    """Freshly constructed reference model under fix_randomness(seed): pins key names, shapes, order
+    and the initial values (the drop-in consumes the torch RNG in the same order)."""
+    ref_utils.fix_randomness(seed)
+    m = ref_model.ST_GCN_model(num_patch, patch_size, dropout=0.2)
+    out = {"num_patch": np.int64(num_patch), "patch_size": np.int64(patch_size), "seed": np.int64(seed),
+           "key_order": np.array(list(m.state_dict().keys()))}
+    for k, v in state_np(m, "sd:").items():
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, len(m.state_dict()))
+
+
 def case_metrics(name, seed):
     rng = np.random.default_rng(seed)
     pred = rng.uniform(0, 1, 257)
@@ -186,3 +199,4 @@ if __name__ == "__main__":
     case_forward_backward("stgcn_nan_14x30_bs4", 14, 30, 4, seed=6, make_nan=True)
     case_training_curve("stgcn_train_curve_14x30_bs32", 14, 30, 32, steps=24, seed=8, lr=1e-3, wd=1e-4)
     case_metrics("metrics_case", 9)
+    case_init("stgcn_init_14x30_seed3", 14, 30, 3)
