@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: ST_GCN training samples/s on C-MAPSS FD004-shaped batches.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one ``ST_GCN.update`` (reference algorithms/algorithms.py:481-490): train-mode forward
+(BatchNorm batch statistics, dropout), MSE, backward, Adam -- on one synthetic batch already
+resident in HBM.  For N > 1 each rank owns a fixed per-GPU batch (weak scaling) and the gradient
+bucket is all-reduced over RCCL once per step (gnn_rul_benchmarking_amd/dp.py).
+
+Rank 0 prints ONE JSON line.  Besides the driver contract it carries
+  roofline       dominant kernel of the step (picked live by HIP-event timing of each phase kernel)
+  roofline_forward   the fused eval forward kernel (the north-star kernel), same measurement
+  cpu_baseline   the numpy oracle's train step timed on this box's host cores (bounded sample)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+NUM_PATCH = 14                 # C-MAPSS: 14 sensors kept (Data_read_CMAPSS.py:76)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--patch-size", type=int, default=30, help="window length (BASELINE.json: 30)")
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sync-loss", action="store_true", help="loss.item() every step like the reference")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def phase_names(L):
+    return [f"F{i}" for i in range(2 * L)] + ["TOP"] + [f"G{2 * L - 1 - j}" for j in range(2 * L)]
+
+
+def roofline_measurements(model, X, y, iters=10):
+    """HIP-event timing (on torch's current stream = the stream the kernels are launched on) of every
+    phase kernel of the training step and of the fused eval forward kernel."""
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    B, N, P, L = X.size(0), model.num_patch, model.patch_size, model.num_layers
+    x2d = X.reshape(B, -1).contiguous()
+    yv = y.reshape(-1).contiguous()
+    shp = model._shape(B)
+    model.fused_mse_step(X, y)                       # leaves a valid cache / cells in the workspace
+    a = model._train_args(shp, x2d, yv, None, model._step)
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    names = phase_names(L)
+    per = {}
+    for ph, name in enumerate(names):
+        def run(ph=ph):
+            _lib.check(lib.rulgnn_stgcn_train_phase_f32(C.byref(shp), C.byref(a), ph, st()), "phase")
+        ms = event_time_ms(run, iters)
+        # algorithmic HBM bytes per sample: F0 reads the window and writes the statistics/adjacency cache
+        # (10 + 4 floats per lane-slot, 64 slots per 4 samples); every other phase reads that cache; TOP writes pred
+        cache_b = (10 + 4) * 64 * 4 / 4.0
+        byts = (N * P * 4 + cache_b) if name == "F0" else (cache_b + (4 if name == "TOP" else 0))
+        per[name] = {"ms": ms, "bytes_per_sample": byts}
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    ach = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": f"stgcn_train_phase_kernel<{dom}>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "us_per_launch": round(d["ms"] * 1e3, 1), "bytes_per_sample": d["bytes_per_sample"],
+            "phase_us": {k: round(v["ms"] * 1e3, 1) for k, v in per.items()}}
+    # the north-star kernel: fused eval forward, one launch per call
+    model.eval()
+    with torch.no_grad():
+        fms = event_time_ms(lambda: model(X), iters)
+    model.train()
+    fb = N * P * 4 + 4
+    fach = fb * B / (fms * 1e-3) / 1e9
+    roof_f = {"bound": "hbm", "kernel": "stgcn_forward_eval_kernel", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": None,
+              "us_per_launch": round(fms * 1e3, 1), "bytes_per_sample": fb,
+              "samples_per_s": round(B / (fms * 1e-3), 1)}
+    return roof, roof_f
+
+
+def cpu_baseline(num_patch, patch_size, dropout, budget_s=12.0):
+    """The numpy oracle's full train step (forward + MSE + backward + Adam, fp32) on the host, single
+    thread, on a bounded sample of the same workload."""
+    import numpy as np
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                   # pragma: no cover
+        threadpool_limits = None
+    from oracle import stgcn_oracle as O
+    B = 4096
+    rng = np.random.default_rng(0)
+    prm = O.random_params(num_patch, 2, seed=0, dtype=np.float32)
+    x = rng.uniform(0, 1, (B, num_patch, patch_size)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    opt = {"step": 0, "m": {}, "v": {}}
+
+    def run():
+        nonlocal prm, opt
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            _, prm, opt, _, _ = O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or (steps >= 3 and el > budget_s / 2):
+                return steps, el
+
+    if threadpool_limits is not None:
+        with threadpool_limits(limits=1):
+            O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)      # warm-up
+            steps, el = run()
+    else:
+        O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)
+        steps, el = run()
+    return {"value": round(steps * B / el, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} train steps of batch {B} ({num_patch}x{patch_size}), numpy fp32 oracle, 1 thread, {el:.1f}s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ST_GCN path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    from gnn_rul_benchmarking_amd.dp import DataParallel
+    from gnn_rul_benchmarking_amd import hparams as HP
+
+    hp = HP.get_hparams_class("CMAPSS")("FD004")
+    train_cfg = hp.train_params["ST_GCN"]
+    model_cfg = dict(hp.alg_hparams["ST_GCN"], patch_size=args.patch_size, dropout=args.dropout)
+    torch.manual_seed(0)
+    algo = ST_GCN(model_cfg, train_cfg, dev)
+    algo.to(dev)
+    algo.train()
+    algo.sync_loss = bool(args.sync_loss)
+    if world > 1:
+        algo.attach_data_parallel(DataParallel())
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    nbuf = 4                                            # distinct batches, cycled (all resident in HBM)
+    Xs = [torch.rand(B, NUM_PATCH, args.patch_size, device=dev, generator=g) for _ in range(nbuf)]
+    ys = [torch.rand(B, 1, device=dev, generator=g) for _ in range(nbuf)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for i in range(args.warmup):
+        last = algo.update(Xs[i % nbuf], ys[i % nbuf], 1)["loss"]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = algo.update(Xs[i % nbuf], ys[i % nbuf], 1)["loss"]
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    final_loss = float(last)
+    if not (final_loss == final_loss):
+        raise SystemExit("training diverged to NaN")
+
+    if rank == 0:
+        total = world * B * args.steps
+        out = {
+            "metric": "training samples/sec, C-MAPSS FD004-shaped ST_GCN", "value": round(total / el, 1),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ST_GCN.update (fwd+MSE+bwd+Adam), C-MAPSS FD004-shaped windows "
+                                   f"[{NUM_PATCH} sensors x {args.patch_size}], per-GPU batch {B}, dropout {args.dropout}, "
+                                   f"lr {train_cfg['learning_rate']}, wd {train_cfg['weight_decay']}",
+                       "per_gpu_batch": B, "global_batch": world * B, "num_patch": NUM_PATCH,
+                       "patch_size": args.patch_size, "parallelism": f"dp{world}",
+                       "loss_readback": "every step" if args.sync_loss else "end of run (device-side loss each step)"},
+            "final_loss": round(final_loss, 6),
+        }
+        if not args.no_roofline:
+            roof, roof_f = roofline_measurements(algo.model, Xs[0], ys[0])
+            out["roofline"] = roof
+            out["roofline_forward"] = roof_f
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(NUM_PATCH, args.patch_size, args.dropout)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

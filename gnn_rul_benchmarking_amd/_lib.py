@@ -38,6 +38,8 @@ _SIGNATURES = {
     "rulgnn_stgcn_train_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_backward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_fwdbwd_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
+    "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.c_void_p]),

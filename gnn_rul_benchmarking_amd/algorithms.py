@@ -56,7 +56,9 @@ class ST_GCN(Algorithm):
         self.dp = dp
         dp.broadcast_model(self.model)
 
-    def update(self, X, y, epoch=None):
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        """``global_batch`` / ``sample_offset`` (data parallel only): size of the whole batch this shard
+        belongs to and the shard's first index in it; default = equal shards, rank-ordered."""
         model = self.model
         if not model.training:
             raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
@@ -64,7 +66,7 @@ class ST_GCN(Algorithm):
             _, loss = model.fused_mse_step(X, y)
             self.optimizer.step(from_bucket=True)
         else:
-            loss = self.dp.step(model, self.optimizer, X, y)
+            loss = self.dp.step(model, self.optimizer, X, y, global_batch, sample_offset)
         return {'loss': loss.item() if self.sync_loss else loss}
 
     def update_reference_style(self, X, y, epoch=None):

@@ -91,6 +91,15 @@ int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_
     return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
 }
 
+int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }
+
+int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, int32_t phase,
+                                 void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_train_phase(shape, args, phase, static_cast<hipStream_t>(stream));
+}
+
 int rulgnn_adam_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
                          float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                          void* stream) {

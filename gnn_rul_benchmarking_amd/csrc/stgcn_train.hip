@@ -707,6 +707,8 @@ static int launch_phase(const TrainK& k, const float* x, const float* prm, const
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
+enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
+
 template <int L, int I>
 struct PhaseChain {
     static int forward_stats(const TrainK& k, const float* x, const float* prm, size_t lds, int mg, hipStream_t st) {
@@ -725,22 +727,20 @@ struct PhaseChain {
     }
 };
 
-enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
-
 template <int L>
-static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, TrainK* kp, WsLayout* wp,
+                       size_t* ldsp) {
     TileGeom g;
     int rc = tile_geometry(s, &g);
     if (rc != RULGNN_OK) return rc;
     if (g.RW != TRW) return RULGNN_EUNSUPPORTED;            // training kernels cover num_patch <= 16 (C-MAPSS shapes)
     g.ntiles = (s->batch + TSPW - 1) / TSPW;
-    WsLayout w;
+    WsLayout& w = *wp;
     ws_layout(s, g, &w);
     if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
     char* ws = static_cast<char*>(a->workspace);
     const int N = s->num_patch;
-
-    TrainK k;
+    TrainK& k = *kp;
     k.cacheX = reinterpret_cast<float*>(ws + w.off_cacheX);
     k.cacheA = reinterpret_cast<float*>(ws + w.off_cacheA);
     double* cells = reinterpret_cast<double*>(ws + w.off_cells);
@@ -760,18 +760,27 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     {
         double thr = (double)a->dropout_p * 4294967296.0;
         thr = thr < 0 ? 0 : thr;
-        uint64_t ti = (uint64_t)(thr + 0.5);
-        // match python round-half-even on exact .5 (only p with 33+ significant bits could differ)
+        const uint64_t ti = (uint64_t)(thr + 0.5);
         k.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
     }
     for (int l = 0; l < 8; ++l) k.drop_key[l] = l < L ? dropout_layer_key(a->seed, a->step, l) : 0u;
     k.pcount = param_count(N, L);
-    const size_t lds = train_lds_bytes(L, g);
-    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    *ldsp = train_lds_bytes(L, g);
+    if (*ldsp > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    return RULGNN_OK;
+}
+
+template <int L>
+static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+    TrainK k;
+    WsLayout w;
+    size_t lds = 0;
+    int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
+    if (rc != RULGNN_OK) return rc;
     const float* gy = a->dpred ? a->dpred : a->y;
 
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
-        if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        if (hipMemsetAsync(k.cells_fwd, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
         rc = PhaseChain<L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
         if (rc != RULGNN_OK) return rc;
     } else {
@@ -791,13 +800,50 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
     f.grid_top = grid_top;
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
-    f.N = N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.write_grads = mode != TM_FORWARD;
     f.write_loss = (k.has_dpred == 0) && a->loss;
     const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;
     hipLaunchKernelGGL(stgcn_train_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, f);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+// One phase kernel alone (profiling / roofline timing): the reduction cells are NOT cleared, so
+// repeated launches keep accumulating into them -- durations are valid, results are not.
+template <int L, int PHASE>
+struct SinglePhase {
+    static int run(int phase, const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int mg,
+                   hipStream_t st) {
+        if (phase == PHASE) {
+            if constexpr (PHASE < 2 * L) return launch_phase<L, PH_F, PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
+            else if constexpr (PHASE == 2 * L) return launch_phase<L, PH_TOP, 0>(k, x, prm, gy, lds, mg, st, nullptr);
+            else return launch_phase<L, PH_G, 4 * L - PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
+        }
+        if constexpr (PHASE > 0) return SinglePhase<L, PHASE - 1>::run(phase, k, x, prm, gy, lds, mg, st);
+        return RULGNN_EINVAL;
+    }
+};
+
+template <int L>
+static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {
+    TrainK k;
+    WsLayout w;
+    size_t lds = 0;
+    const int rc = setup_train<L>(s, a, TM_FWDBWD, &k, &w, &lds);
+    if (rc != RULGNN_OK) return rc;
+    if (phase < 0 || phase > 4 * L) return RULGNN_EINVAL;
+    const float* gy = a->dpred ? a->dpred : a->y;
+    return SinglePhase<L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
+}
+
+int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {
+    switch (s->num_layers) {
+        case 1: return run_phase<1>(s, a, phase, stream);
+        case 2: return run_phase<2>(s, a, phase, stream);
+        case 3: return run_phase<3>(s, a, phase, stream);
+        default: return RULGNN_EUNSUPPORTED;
+    }
 }
 
 static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {

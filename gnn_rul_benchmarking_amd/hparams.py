@@ -1,0 +1,60 @@
+"""Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
+configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
+``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
+ValueError).  Only the ST_GCN rows are restated (the method this package implements).
+
+PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...).
+The CMAPSS / NCMAPSS rows are a BUILD EXTENSION: the reference never pairs ST_GCN with the aero-engine
+datasets although the model only needs numel/bs == num_patch*patch_size.  Here each
+sensor's window is one patch: num_patch = sensors (14 / 20), patch_size = window length (30 per
+BASELINE.json; the reference's preprocessed C-MAPSS windows are 50 long -- pass ``window=50``), with the
+reference's ST_GCN training parameters (lr 1e-4, wd 1e-4, 81 epochs, batch 100) and dropout 0.2."""
+from __future__ import annotations
+
+_ST_GCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-4}
+
+
+def get_hparams_class(dataset_name):
+    """Return the hparams class with the given name."""
+    if dataset_name not in _DATASETS:
+        raise NotImplementedError("Dataset not found: {}".format(dataset_name))
+    return _DATASETS[dataset_name]
+
+
+class _Table:
+    _rows: dict = {}
+
+    def __init__(self, dataset_id=None, **overrides):
+        if dataset_id not in self._rows:
+            raise ValueError(f"No hparams found for dataset: {dataset_id}")
+        self.train_params = {'ST_GCN': dict(_ST_GCN_TRAIN)}
+        self.alg_hparams = {'ST_GCN': dict(self._rows[dataset_id])}
+        self.alg_hparams['ST_GCN'].update(overrides)
+
+
+class CMAPSS(_Table):
+    def __init__(self, dataset_id, window=30):
+        self._rows = {fd: {'num_patch': 14, 'patch_size': int(window), 'dropout': 0.2}
+                      for fd in ('FD001', 'FD002', 'FD003', 'FD004')}
+        super().__init__(dataset_id)
+
+
+class NCMAPSS(_Table):
+    def __init__(self, dataset_id=None, window=50):
+        self._rows = {None: {'num_patch': 20, 'patch_size': int(window), 'dropout': 0.2}}
+        super().__init__(None)
+
+
+class PHM2012(_Table):
+    _rows = {'Condition_1': {'num_patch': 40, 'patch_size': 64, 'dropout': 0.2},
+             'Condition_2': {'num_patch': 160, 'patch_size': 16, 'dropout': 0.2},
+             'Condition_3': {'num_patch': 40, 'patch_size': 64, 'dropout': 0.2}}
+
+
+class XJTU_SY(_Table):
+    _rows = {'Condition_1': {'num_patch': 1024, 'patch_size': 32, 'dropout': 0.3},
+             'Condition_2': {'num_patch': 2048, 'patch_size': 16, 'dropout': 0.2},
+             'Condition_3': {'num_patch': 2048, 'patch_size': 16, 'dropout': 0.2}}
+
+
+_DATASETS = {'CMAPSS': CMAPSS, 'NCMAPSS': NCMAPSS, 'PHM2012': PHM2012, 'XJTU_SY': XJTU_SY}

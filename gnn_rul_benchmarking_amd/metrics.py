@@ -1,0 +1,42 @@
+"""RUL metrics with the reference's formulas (utils.py:136-201), vectorised instead of per-sample
+Python loops.  ``_calc_metrics`` returns (Score_v1, Score_v2, MAE, RMSE) like utils.py:191-201."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def scoring_function(predicted, real, max_rul):
+    """utils.py:136-146: late predictions (pred >= real) cost exp(d/10)-1, early ones exp(d/13)-1."""
+    predicted, real = np.asarray(predicted, np.float64), np.asarray(real, np.float64)
+    late = real <= predicted
+    e = np.where(late, np.exp((predicted - real) * max_rul / 10.0) - 1.0, np.exp((real - predicted) * max_rul / 13.0) - 1.0)
+    score = float(e.sum())
+    return score, score / predicted.shape[0]
+
+
+def scoring_function_v2(predicted, real):
+    """utils.py:157-169."""
+    predicted, real = np.asarray(predicted, np.float64), np.asarray(real, np.float64)
+    err = (real - predicted) / (real + 1e-8) * 100.0
+    e = np.where(err <= 0, np.exp(-math.log(0.5) * (err / 5.0)), np.exp(math.log(0.5) * (err / 20.0)))
+    return float(e.mean())
+
+
+def rmse_value(predicted, real, max_rul):
+    """utils.py:148-151: sqrt(mean squared error) * max_rul."""
+    predicted, real = np.asarray(predicted, np.float64), np.asarray(real, np.float64)
+    return math.sqrt(float(np.mean((real - predicted) ** 2))) * max_rul
+
+
+def mae_value(predicted, real, max_rul):
+    predicted, real = np.asarray(predicted, np.float64), np.asarray(real, np.float64)
+    return float(np.mean(np.abs(real - predicted))) * max_rul
+
+
+def _calc_metrics(pred_labels, true_labels, max_rul):
+    pred_labels, true_labels = np.array(pred_labels), np.array(true_labels)
+    score_v1, _ = scoring_function(pred_labels, true_labels, max_rul)
+    return score_v1, scoring_function_v2(pred_labels, true_labels), mae_value(pred_labels, true_labels, max_rul), \
+        rmse_value(pred_labels, true_labels, max_rul)

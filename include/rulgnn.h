@@ -106,6 +106,16 @@ int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape *shape, const rulgn
 int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                   void *stream);
 
+/* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
+ * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
+ * backward), 2L+1+j = G_{2L-1-j} (BatchNorm/conv/theta backward).  rulgnn_stgcn_train_phase_f32 launches
+ * exactly ONE of them on `stream` with the state a previous full step left in the workspace, so a
+ * harness can time a single kernel with HIP events.  The reduction cells are not cleared: timings
+ * are valid, numerical outputs are not. */
+int rulgnn_stgcn_train_phase_count(int32_t num_layers);
+int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                 int32_t phase, void *stream);
+
 /* torch.optim.Adam step over a flat buffer (L2 weight decay folded into the gradient, no amsgrad),
  * as configured at algorithms/algorithms.py:474-478.  `step` is the 1-based step count AFTER this
  * update.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce). */
