@@ -51,6 +51,17 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  The kernels must run on THE SAME HIP
+    runtime instance that owns torch's streams and allocations, so torch's copy has to be mapped
+    before librulgnn.so resolves its libamdhip64 dependency (otherwise /opt/rocm's copy is loaded as
+    a second runtime and every launch on a torch stream fails with hipErrorInvalidValue-class errors)."""
+    import torch  # noqa: F401  (maps torch/lib/libamdhip64.so via libtorch_hip)
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load librulgnn.so (built by ``python -m gnn_rul_benchmarking_amd.build``); raise if absent."""
     global _lib
@@ -61,6 +72,7 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -m gnn_rul_benchmarking_amd.build` (needs hipcc; cross-compiles gfx950 without a GPU). "
             "There is no CPU fallback for the ST_GCN path.")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design

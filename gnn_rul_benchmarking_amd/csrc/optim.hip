@@ -46,6 +46,7 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t s
     const int block = 256;
     int64_t grid = (n + block - 1) / block;
     if (grid > 1024) grid = 1024;
+    (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, p, g, m, v, n,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
@@ -56,6 +57,7 @@ int bn_running_update(float* bn, const float* batch, int num_layers, int64_t cou
     const int n_bn = num_layers * 2;
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int total = n_bn * 2 * F;
+    (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
                        momentum, unbias, from_moments);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;

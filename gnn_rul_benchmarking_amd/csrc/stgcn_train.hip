@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_wgrad_mfma(float* T, const float (&dz)[F], 
 // ------------------------------------------------------------------------------------------------
 // IDX: BatchNorm index (0 .. 2L-1) for F and G kernels; unused for TOP.
 template <int L, int KIND, int IDX>
-__global__ __launch_bounds__(BLOCK) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+__global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy,   // y or dpred (TOP only)
                                                                   TrainK a) {
@@ -703,6 +703,7 @@ static int launch_phase(const TrainK& k, const float* x, const float* prm, const
     int grid = persistent_grid(kern, k.ntiles, lds);
     if (grid > max_grid) grid = max_grid;
     if (grid_out) *grid_out = grid;
+    (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, stream, x, prm, gy, k);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
@@ -805,6 +806,7 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     f.write_grads = mode != TM_FORWARD;
     f.write_loss = (k.has_dpred == 0) && a->loss;
     const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;
+    (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(stgcn_train_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, f);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -50,3 +50,20 @@ def test_shape_validation_without_gpu():
     assert lib.rulgnn_stgcn_forward_f32(C.byref(ok), None, None, None, None, None) == -1   # null pointers
     empty = _lib.StgcnShape(0, 14, 30, 2, 1)
     assert lib.rulgnn_stgcn_forward_f32(C.byref(empty), None, None, None, None, None) == 0  # empty batch is a no-op
+
+
+def test_single_hip_runtime_even_when_library_is_loaded_before_torch():
+    """Regression: loading librulgnn.so before torch used to map /opt/rocm's libamdhip64 next to the
+    one bundled with torch (two HIP runtimes -> every launch on a torch stream failed)."""
+    import subprocess
+    import sys
+    code = "\n".join([
+        "import sys, os; sys.path.insert(0, %r)" % ROOT,
+        "from gnn_rul_benchmarking_amd import _lib",
+        "_lib.load()",
+        "import torch",
+        "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}",
+        "print(len({os.path.realpath(p) for p in libs}))"])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
