@@ -52,6 +52,9 @@ struct TrainK {
     double* cells_bwd;    // [2L][2][F]   sum dy, sum dy*xhat
     double* cell_loss;    // [1]
     float* gpart;         // [grid][param_count] per-block partial gradients
+    float* xsave;         // [L-1][ntiles][F][64]  X_l = input of layer l (l >= 1), written by F_{2l}
+    float* rbuf;          // [ntiles][F][64]  d X_{l+1}: gradient entering layer l's backward (TOP / G_{2l+2} -> G_{2l+1}, G_{2l})
+    float* sbuf;          // [ntiles][F][64]  d(x0 + H) of layer l (G_{2l+1} -> G_{2l})
     // outputs
     float* pred;
     // sizes
@@ -59,6 +62,7 @@ struct TrainK {
     int N, P, Ppad, vec4, stage_floats;
     uint32_t magicP;
     int do_backward;      // TOP: 0 = forward only
+    int write_pred;
     int has_dpred;        // 1: gy is d(loss)/d(pred); 0: gy is y (MSE); 2: neither (forward only)
     float dropout_p, drop_scale;
     uint32_t drop_thr;
@@ -136,7 +140,6 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                                                                   TrainK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NBN = 2 * L;
-    constexpr bool BACKWARD = KIND != PH_F;
     // BatchNorm layers whose forward statistics this kernel needs: F_i applies BN 0..i-1.
     constexpr int NFWD = KIND == PH_F ? IDX : NBN;
     const int N = a.N, LS = layer_stride(N);
@@ -209,6 +212,15 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
     const int64_t sampleNP = (int64_t)N * a.P;
     const float inv_gb = 1.0f / (float)a.global_batch;
 
+    // Which layer does this kernel work in, and where does its forward start?
+    //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
+    //   G_{2l}, l >= 1 : needs layer l-1's conv_block2 activations for the next BatchNorm's sums -> also starts at l-1
+    constexpr int LY = KIND == PH_TOP ? L - 1 : IDX / 2;
+    constexpr int BLK = KIND == PH_TOP ? 1 : IDX % 2;
+    constexpr bool WITH_PREV = (KIND != PH_TOP) && (BLK == 0) && (LY >= 1);
+    constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
+    const size_t tile_floats = (size_t)F * 64;
+
     for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
          tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int64_t s0 = tile * TSPW;
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         const bool valid = rowok && (t < N);
         float X[F], A[NPAIR];
 
-        // ---- input-only part: patch statistics + Pearson adjacency (F_0 computes and caches) -------
+        // ---- inputs: patch statistics + Pearson adjacency (F_0 computes and caches), or the saved X_l ----
         if constexpr (KIND == PH_F && IDX == 0) {
             __builtin_amdgcn_wave_barrier();
             stage_tile(gx + s0 * sampleNP, mywave, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
             // padding rows (beyond the batch) would give 0/0 = NaN: keep them finite
 #pragma unroll
             for (int i = 0; i < NPAIR; ++i) A[i] = rowok ? A[i] : 0.f;
-            float* cx = a.cacheX + tile * (F * 64) + lane;
+            float* cx = a.cacheX + tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) cx[c * 64] = X[c];
             float aq[AQ] = {0.f, 0.f, 0.f, 0.f};
@@ -239,7 +251,8 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
             for (int q = 0; q < AQ; ++q) ca[q * 64] = aq[q];
         } else {
-            const float* cx = a.cacheX + tile * (F * 64) + lane;
+            const float* cx = (LSTART == 0 ? a.cacheX : a.xsave + (size_t)(LSTART - 1) * a.ntiles * tile_floats) +
+                              tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = cx[c * 64];
             const float* ca = a.cacheA + tile * (AQ * 64) + lane;
@@ -258,70 +271,157 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 if (i4 * 4 + 3 < NPAIR) A[i4 * 4 + 3] = v.w;
             }
         }
-
-        // ---- forward recompute, keeping what the backward needs in registers ---------------------------
-        float Xin[L][F], Hs[L][F], z1s[L][F], o0s[L][F], z2s[L][F];
         const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
-        bool stopped = false;
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            if (stopped) break;
-            const float* lp = prm + l * LS;
-            float AX[F];
-#pragma unroll
-            for (int c = 0; c < F; ++c) Xin[l][c] = X[c];
+
+        // ---- previous layer in full (F_{2l}, G_{2l} with l >= 1) -------------------------------------------
+        float pz2[F], po0[F];                         // layer LY-1: conv_block2 pre-BN output and input (G_{2l} only)
+        if constexpr (WITH_PREV) {
+            constexpr int lq = LY - 1;
+            const float* lp = prm + lq * LS;
+            const float* b1 = bnc + (2 * lq) * BNC * F;
+            const float* b2 = bnc + (2 * lq + 1) * BNC * F;
+            float AX[F], H[F], z[F];
             adj_aggregate(A, X, AX);
-            const float tb = vecs[l * TRW + t];
+            const float tb = vecs[lq * TRW + t];
 #pragma unroll
-            for (int c = 0; c < F; ++c) Hs[l][c] = tb;
-            R16::project10(Hs[l], AX, wlds + (l * TRW + t) * TWS, N);
+            for (int c = 0; c < F; ++c) H[c] = tb;
+            R16::project10(H, AX, wlds + (lq * TRW + t) * TWS, N);
 #pragma unroll
-            for (int c = 0; c < F; ++c) Hs[l][c] = leaky(Hs[l][c]);
-            causal_conv<TRW, 1>(Hs[l], lp + off_conv_w(N, 0), t, z1s[l]);
-            if constexpr (KIND == PH_F) {
-                if (IDX == 2 * l) {                       // F_{2l}: statistics of conv_block1's output
+            for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
+            causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z);
 #pragma unroll
-                    for (int c = 0; c < F; ++c) {
-                        const float z = valid ? z1s[l][c] : 0.f;
-                        s_a[c] += z;
-                        s_b[c] = fmaf(z, z, s_b[c]);
-                    }
-                    stopped = true;
-                    continue;
-                }
-            }
-            const float* b1 = bnc + (2 * l) * BNC * F;
-#pragma unroll
-            for (int c = 0; c < F; ++c)
-                o0s[l][c] = relu(relu(fmaf(z1s[l][c], b1[2 * F + c], b1[3 * F + c])) + Hs[l][c]);
-            causal_conv<TRW, 2>(o0s[l], lp + off_conv_w(N, 1), t, z2s[l]);
-            if constexpr (KIND == PH_F) {
-                if (IDX == 2 * l + 1) {                   // F_{2l+1}: statistics of conv_block2's output
-#pragma unroll
-                    for (int c = 0; c < F; ++c) {
-                        const float z = valid ? z2s[l][c] : 0.f;
-                        s_a[c] += z;
-                        s_b[c] = fmaf(z, z, s_b[c]);
-                    }
-                    stopped = true;
-                    continue;
-                }
-            }
-            const float* b2 = bnc + (2 * l + 1) * BNC * F;
+            for (int c = 0; c < F; ++c) po0[c] = relu(relu(fmaf(z[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
+            causal_conv<TRW, 2>(po0, lp + off_conv_w(N, 1), t, pz2);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
-                float o1 = relu(relu(fmaf(z2s[l][c], b2[2 * F + c], b2[3 * F + c])) + o0s[l][c]);
+                float o1 = relu(relu(fmaf(pz2[c], b2[2 * F + c], b2[3 * F + c])) + po0[c]);
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[l]);
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
             }
+            if constexpr (KIND == PH_F) {              // X_l is final from here on: store it for the later phases
+                float* xs = a.xsave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
+#pragma unroll
+                for (int c = 0; c < F; ++c) xs[c * 64] = X[c];
+            }
         }
-        if constexpr (KIND == PH_F) continue;             // F kernels are done with this tile
 
-        if constexpr (BACKWARD) {
-            // ---- head: max-pool over channels, fc1, fc2 (Model.py:218-221) ----------------------------------
+        // ---- layer LY forward, as far as this phase needs it ---------------------------------------------------
+        const float* lp = prm + LY * LS;
+        const float* b1 = bnc + (2 * LY) * BNC * F;
+        const float* b2 = bnc + (2 * LY + 1) * BNC * F;
+        float AX[F], H[F], z1[F];
+        adj_aggregate(A, X, AX);
+        {
+            const float tb = vecs[LY * TRW + t];
+#pragma unroll
+            for (int c = 0; c < F; ++c) H[c] = tb;
+        }
+        R16::project10(H, AX, wlds + (LY * TRW + t) * TWS, N);
+#pragma unroll
+        for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
+        causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z1);
+
+        if constexpr (KIND == PH_F && BLK == 0) {       // F_{2l}: statistics of conv_block1's output
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float z = valid ? z1[c] : 0.f;
+                s_a[c] += z;
+                s_b[c] = fmaf(z, z, s_b[c]);
+            }
+            continue;
+        }
+
+        if constexpr (KIND == PH_G && BLK == 0) {
+            // ---- G_{2l}: BatchNorm 2l backward, conv_block1 + theta gradients, dX_l ------------------------------
+            const float* sb = a.sbuf + tile * tile_floats + lane;
+            float g0[F], dz[F];
+#pragma unroll
+            for (int c = 0; c < F; ++c) g0[c] = sb[c * 64];                       // d(x0 + H), written by G_{2l+1}
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float x0 = relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c]));
+                const float dy = (x0 > 0.f && valid) ? g0[c] : 0.f;
+                const float xh = (z1[c] - b1[0 * F + c]) * b1[1 * F + c];
+                const float v = b1[4 * F + c] * (dy - b1[5 * F + c] - xh * b1[6 * F + c]);
+                dz[c] = valid ? v : 0.f;
+            }
+            {
+                float hs[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) hs[c] = R16::template shr<1>(H[c], t);
+                conv_wgrad_mfma(mywave, dz, H, hs, lane, acc_c0, acc_c1);
+            }
+            float dH[F];
+            causal_conv_T<1>(dz, lp + off_conv_w(N, 0), t, dH);
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float g = dH[c] + g0[c];
+                dH[c] = valid ? (H[c] > 0.f ? g : g * LEAKY) : 0.f;               // d(theta pre-activation)
+                acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AX[c], acc_th, 0, 0, 0);
+                acc_b += dH[c];
+            }
+            if constexpr (LY > 0) {
+                float dAX[F], dXl[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) dAX[c] = 0.f;
+                R16::project10(dAX, dH, wldsT + (LY * TRW + t) * TWS, N);        // dHpre . theta
+                adj_aggregate(A, dAX, dXl);                                        // A is symmetric: A^T = A
+                float* rb = a.rbuf + tile * tile_floats + lane;
+                constexpr int lq = LY - 1;
+                const float* q2 = bnc + (2 * lq + 1) * BNC * F;
+#pragma unroll
+                for (int c = 0; c < F; ++c) {
+                    const float dX = valid ? dXl[c] + rb[c * 64] : 0.f;           // + residual branch: d X_{l+1}
+                    rb[c * 64] = dX;                                               // = d X_l, read by G_{2l-1}
+                    // top of layer l-1: sums for BatchNorm 2l-1
+                    const float x1 = relu(fmaf(pz2[c], q2[2 * F + c], q2[3 * F + c]));
+                    const float o1 = relu(x1 + po0[c]);
+                    float g = dX;
+                    if (a.dropout_p > 0.f) {
+                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
+                        g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
+                    }
+                    const float dy = (o1 > 0.f && x1 > 0.f && valid) ? g : 0.f;
+                    const float xh = (pz2[c] - q2[0 * F + c]) * q2[1 * F + c];
+                    s_a[c] += dy;
+                    s_b[c] = fmaf(dy, xh, s_b[c]);
+                }
+            }
+            continue;
+        }
+
+        float o0[F], z2[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
+        causal_conv<TRW, 2>(o0, lp + off_conv_w(N, 1), t, z2);
+
+        if constexpr (KIND == PH_F && BLK == 1) {       // F_{2l+1}: statistics of conv_block2's output
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float z = valid ? z2[c] : 0.f;
+                s_a[c] += z;
+                s_b[c] = fmaf(z, z, s_b[c]);
+            }
+            continue;
+        }
+
+        if constexpr (KIND == PH_TOP) {
+            // ---- layer L-1 output, head forward (Model.py:218-221), head backward --------------------------------
+            float x1v[F], o1v[F];
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                x1v[c] = relu(fmaf(z2[c], b2[2 * F + c], b2[3 * F + c]));
+                o1v[c] = relu(x1v[c] + o0[c]);
+                float o1 = o1v[c];
+                if (a.dropout_p > 0.f) {
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
+                }
+                X[c] = valid ? o1 + X[c] : 0.f;
+            }
             float pooled = X[0];
             int arg = 0;
 #pragma unroll
@@ -343,136 +443,77 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 } else if (a.has_dpred == 0) {
                     const float diff = pred - gy[s0 + srow];
                     dpred = 2.f * diff * inv_gb;
-                    if (KIND == PH_TOP && t == 0) acc_loss = fmaf(diff, diff, acc_loss);
+                    if (t == 0) acc_loss = fmaf(diff, diff, acc_loss);
                 }
+                if (t == 0 && a.write_pred) a.pred[s0 + srow] = pred;
             }
-            if constexpr (KIND == PH_TOP) {
-                if (t == 0 && rowok) a.pred[s0 + srow] = pred;
-                if (!a.do_backward) continue;
-            }
-            // fc2 / fc1 backward
+            if (!a.do_backward) continue;
             const float dy1 = (y1 > 0.f) ? dpred * w2 : 0.f;                       // d(fc1 pre-activation), lane j
             float dpool = 0.f;
             R16::project1(dpool, dy1, wldsT + (L * TRW + t) * TWS, N);             // sum_j dy1[j] fc1.w[j][t]
-            if constexpr (KIND == PH_TOP) {
-                acc_w2 = fmaf(dpred, y1, acc_w2);
-                acc_b2 += (t == 0) ? dpred : 0.f;
-                acc_b += dy1;
-                acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dy1, pooled, acc_th, 0, 0, 0);   // d fc1.w[j][t]
-            }
-            float dX[F];
+            acc_w2 = fmaf(dpred, y1, acc_w2);
+            acc_b2 += (t == 0) ? dpred : 0.f;
+            acc_b += dy1;
+            acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dy1, pooled, acc_th, 0, 0, 0);   // d fc1.w[j][t]
+            float* rb = a.rbuf + tile * tile_floats + lane;
 #pragma unroll
-            for (int c = 0; c < F; ++c) dX[c] = (valid && c == arg) ? dpool : 0.f;
+            for (int c = 0; c < F; ++c) {
+                const float dX = (valid && c == arg) ? dpool : 0.f;                 // d X_L (max-pool routes to the arg-max channel)
+                rb[c * 64] = dX;
+                float g = dX;
+                if (a.dropout_p > 0.f) {
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
+                }
+                const float dy = (o1v[c] > 0.f && x1v[c] > 0.f && valid) ? g : 0.f;
+                const float xh = (z2[c] - b2[0 * F + c]) * b2[1 * F + c];
+                s_a[c] += dy;
+                s_b[c] = fmaf(dy, xh, s_b[c]);
+            }
+            continue;
+        }
 
-            // ---- layers, top down ---------------------------------------------------------------------------
-            bool done = false;
+        if constexpr (KIND == PH_G && BLK == 1) {
+            // ---- G_{2l+1}: BatchNorm 2l+1 backward, conv_block2 gradient, d(x0 + H) -----------------------------------
+            const float* rb = a.rbuf + tile * tile_floats + lane;
+            float gsum[F], dz[F];
 #pragma unroll
-            for (int l = L - 1; l >= 0; --l) {
-                if (done) break;
-                const float* lp = prm + l * LS;
-                const float* b1 = bnc + (2 * l) * BNC * F;
-                const float* b2 = bnc + (2 * l + 1) * BNC * F;
-                // recompute the cheap pieces
-                float gsum[F], dy[F], xh[F];
-#pragma unroll
-                for (int c = 0; c < F; ++c) {
-                    const float x1 = relu(fmaf(z2s[l][c], b2[2 * F + c], b2[3 * F + c]));
-                    const float o1 = relu(x1 + o0s[l][c]);
-                    float g = dX[c];
-                    if (a.dropout_p > 0.f) {
-                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[l]);
-                        g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
-                    }
-                    g = (o1 > 0.f) ? g : 0.f;
-                    gsum[c] = g;                                   // d(x1 + o0)
-                    dy[c] = (x1 > 0.f && valid) ? g : 0.f;         // d(BatchNorm 2l+1 output)
-                    xh[c] = (z2s[l][c] - b2[0 * F + c]) * b2[1 * F + c];
+            for (int c = 0; c < F; ++c) {
+                const float x1 = relu(fmaf(z2[c], b2[2 * F + c], b2[3 * F + c]));
+                const float o1 = relu(x1 + o0[c]);
+                float g = rb[c * 64];                                               // d X_{l+1}
+                if (a.dropout_p > 0.f) {
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                 }
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int bn_hi = 2 * l + 1;
-                if ((KIND == PH_TOP && bn_hi == NBN - 1) || (KIND == PH_G && bn_hi == IDX - 1)) {
-#pragma unroll
-                    for (int c = 0; c < F; ++c) {
-                        s_a[c] += dy[c];
-                        s_b[c] = fmaf(dy[c], xh[c], s_b[c]);
-                    }
-                    done = true;
-                    continue;
-                }
-                // BatchNorm 2l+1 backward
-                float dz[F];
-#pragma unroll
-                for (int c = 0; c < F; ++c) {
-                    const float v = b2[4 * F + c] * (dy[c] - b2[5 * F + c] - xh[c] * b2[6 * F + c]);
-                    dz[c] = valid ? v : 0.f;
-                }
-                if (KIND == PH_G && bn_hi == IDX) {                 // weight gradient of conv_block2
-                    float hs[F];
-#pragma unroll
-                    for (int c = 0; c < F; ++c) hs[c] = R16::template shr<2>(o0s[l][c], t);
-                    conv_wgrad_mfma(mywave, dz, o0s[l], hs, lane, acc_c0, acc_c1);
-                }
-                float d_o0[F];
-                causal_conv_T<2>(dz, lp + off_conv_w(N, 1), t, d_o0);
-#pragma unroll
-                for (int c = 0; c < F; ++c) {
-                    const float x0 = relu(fmaf(z1s[l][c], b1[2 * F + c], b1[3 * F + c]));
-                    float g = d_o0[c] + gsum[c];
-                    g = (o0s[l][c] > 0.f) ? g : 0.f;
-                    gsum[c] = g;                                   // d(x0 + H)
-                    dy[c] = (x0 > 0.f && valid) ? g : 0.f;         // d(BatchNorm 2l output)
-                    xh[c] = (z1s[l][c] - b1[0 * F + c]) * b1[1 * F + c];
-                }
-                const int bn_lo = 2 * l;
-                if (KIND == PH_G && bn_lo == IDX - 1) {
-#pragma unroll
-                    for (int c = 0; c < F; ++c) {
-                        s_a[c] += dy[c];
-                        s_b[c] = fmaf(dy[c], xh[c], s_b[c]);
-                    }
-                    done = true;
-                    continue;
-                }
-#pragma unroll
-                for (int c = 0; c < F; ++c) {
-                    const float v = b1[4 * F + c] * (dy[c] - b1[5 * F + c] - xh[c] * b1[6 * F + c]);
-                    dz[c] = valid ? v : 0.f;
-                }
-                const bool grads_here = (KIND == PH_G && bn_lo == IDX);
-                if (grads_here) {                                   // weight gradient of conv_block1
-                    float hs[F];
-#pragma unroll
-                    for (int c = 0; c < F; ++c) hs[c] = R16::template shr<1>(Hs[l][c], t);
-                    conv_wgrad_mfma(mywave, dz, Hs[l], hs, lane, acc_c0, acc_c1);
-                }
-                float dH[F];
-                causal_conv_T<1>(dz, lp + off_conv_w(N, 0), t, dH);
-#pragma unroll
-                for (int c = 0; c < F; ++c) {
-                    const float g = dH[c] + gsum[c];
-                    dH[c] = valid ? (Hs[l][c] > 0.f ? g : g * LEAKY) : 0.f;      // d(theta pre-activation)
-                }
-                if (grads_here) {                                   // theta gradient: MFMA straight from registers
-                    float AX[F];
-                    adj_aggregate(A, Xin[l], AX);
-#pragma unroll
-                    for (int c = 0; c < F; ++c) {
-                        acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AX[c], acc_th, 0, 0, 0);
-                        acc_b += dH[c];
-                    }
-                }
-                if (l > 0) {
-                    float dAX[F];
-#pragma unroll
-                    for (int c = 0; c < F; ++c) dAX[c] = 0.f;
-                    R16::project10(dAX, dH, wldsT + (l * TRW + t) * TWS, N);       // dHpre . theta
-                    float dXl[F];
-                    adj_aggregate(A, dAX, dXl);                                     // A is symmetric: A^T = A
-#pragma unroll
-                    for (int c = 0; c < F; ++c) dX[c] = valid ? dXl[c] + dX[c] : 0.f;
-                }
+                g = (o1 > 0.f && valid) ? g : 0.f;
+                gsum[c] = g;                                                        // d(x1 + o0)
+                const float dy = (x1 > 0.f) ? g : 0.f;
+                const float xh = (z2[c] - b2[0 * F + c]) * b2[1 * F + c];
+                const float v = b2[4 * F + c] * (dy - b2[5 * F + c] - xh * b2[6 * F + c]);
+                dz[c] = valid ? v : 0.f;
             }
+            {
+                float hs[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) hs[c] = R16::template shr<2>(o0[c], t);
+                conv_wgrad_mfma(mywave, dz, o0, hs, lane, acc_c0, acc_c1);
+            }
+            float d_o0[F];
+            causal_conv_T<2>(dz, lp + off_conv_w(N, 1), t, d_o0);
+            float* sb = a.sbuf + tile * tile_floats + lane;
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                const float x0 = relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c]));
+                float g = d_o0[c] + gsum[c];
+                g = (o0[c] > 0.f && valid) ? g : 0.f;
+                sb[c * 64] = g;                                                     // d(x0 + H), read by G_{2l}
+                const float dy = (x0 > 0.f) ? g : 0.f;
+                const float xh = (z1[c] - b1[0 * F + c]) * b1[1 * F + c];
+                s_a[c] += dy;
+                s_b[c] = fmaf(dy, xh, s_b[c]);
+            }
+            continue;
         }
     }
 
@@ -645,7 +686,7 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
 // host side
 // ------------------------------------------------------------------------------------------------
 struct WsLayout {
-    size_t off_cacheX, off_cacheA, off_cells, off_gpart, total;
+    size_t off_cacheX, off_cacheA, off_cells, off_gpart, off_xsave, off_rbuf, off_sbuf, total;
     size_t cells_bytes;
     int max_grid;
 };
@@ -669,6 +710,10 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
+    const size_t tile_bytes = (size_t)g.ntiles * F * 64 * sizeof(float);
+    w->off_xsave = o; o = al(o + (size_t)(L > 1 ? L - 1 : 1) * tile_bytes);
+    w->off_rbuf = o; o = al(o + tile_bytes);
+    w->off_sbuf = o; o = al(o + tile_bytes);
     w->total = o;
 }
 
@@ -749,6 +794,10 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     k.cells_bwd = cells + 2 * L * 2 * F;
     k.cell_loss = cells + 2 * (2 * L * 2 * F);
     k.gpart = reinterpret_cast<float*>(ws + w.off_gpart);
+    k.xsave = reinterpret_cast<float*>(ws + w.off_xsave);
+    k.rbuf = reinterpret_cast<float*>(ws + w.off_rbuf);
+    k.sbuf = reinterpret_cast<float*>(ws + w.off_sbuf);
+    k.write_pred = 1;
     k.pred = a->pred;
     k.B = s->batch; k.ntiles = g.ntiles; k.global_batch = a->global_batch; k.sample_offset = a->sample_offset;
     k.N = N; k.P = s->patch_size; k.Ppad = g.Ppad;
