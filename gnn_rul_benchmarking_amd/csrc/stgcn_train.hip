@@ -62,6 +62,7 @@ struct TrainK {
     int N, P, Ppad, vec4, stage_floats;
     uint32_t magicP;
     int do_backward;      // TOP: 0 = forward only
+    int wave_area_floats;
     int write_pred;
     int has_dpred;        // 1: gy is d(loss)/d(pred); 0: gy is y (MSE); 2: neither (forward only)
     float dropout_p, drop_scale;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
     constexpr int RED_K = 15;
     float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
     float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (G)
-    const int wave_area_floats = a.stage_floats > TT_ROWS * TT_STRIDE ? a.stage_floats : TT_ROWS * TT_STRIDE;
+    const int wave_area_floats = a.wave_area_floats;     // staging (F_0), transpose tile (G), nothing otherwise
     float* mywave = wave_area + wave * wave_area_floats;
 
     // ---- prologue: weights to LDS, BatchNorm constants from the reduction cells ---------------------
@@ -728,8 +729,13 @@ size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
     return w.total;
 }
 
-static size_t train_lds_bytes(int L, const TileGeom& g) {
-    const int wave_area = g.stage_floats > TT_ROWS * TT_STRIDE ? g.stage_floats : TT_ROWS * TT_STRIDE;
+static int wave_area_for(int kind, int idx, const TileGeom& g) {
+    if (kind == PH_F) return idx == 0 ? g.stage_floats : 0;
+    if (kind == PH_G) return TT_ROWS * TT_STRIDE;
+    return 0;
+}
+
+static size_t train_lds_bytes(int L, int wave_area) {
     const size_t fl = (size_t)2 * (L + 1) * TRW * TWS + (size_t)(L + 2) * TRW + (size_t)((2 * L * BNC * F + 3) & ~3) +
                       (size_t)WAVES_PER_BLOCK * TSPW * 64 + (size_t)15 * 64 + (size_t)WAVES_PER_BLOCK * 24 +
                       (size_t)WAVES_PER_BLOCK * wave_area;
@@ -737,9 +743,13 @@ static size_t train_lds_bytes(int L, const TileGeom& g) {
 }
 
 template <int L, int KIND, int IDX>
-static int launch_phase(const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int max_grid,
+static int launch_phase(const TrainK& k_in, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                         hipStream_t stream, int* grid_out) {
     auto kern = stgcn_train_phase_kernel<L, KIND, IDX>;
+    TrainK k = k_in;
+    k.wave_area_floats = wave_area_for(KIND, IDX, g);
+    const size_t lds = train_lds_bytes(L, k.wave_area_floats);
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
@@ -757,14 +767,14 @@ enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
 
 template <int L, int I>
 struct PhaseChain {
-    static int forward_stats(const TrainK& k, const float* x, const float* prm, size_t lds, int mg, hipStream_t st) {
+    static int forward_stats(const TrainK& k, const float* x, const float* prm, const TileGeom& lds, int mg, hipStream_t st) {
         if constexpr (I > 0) {
             const int rc = PhaseChain<L, I - 1>::forward_stats(k, x, prm, lds, mg, st);
             if (rc != RULGNN_OK) return rc;
         }
         return launch_phase<L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
     }
-    static int backward(const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int mg, hipStream_t st,
+    static int backward(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& lds, int mg, hipStream_t st,
                         int* grids) {
         const int rc = launch_phase<L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
         if (rc != RULGNN_OK) return rc;
@@ -775,8 +785,8 @@ struct PhaseChain {
 
 template <int L>
 static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, TrainK* kp, WsLayout* wp,
-                       size_t* ldsp) {
-    TileGeom g;
+                       TileGeom* ldsp) {
+    TileGeom& g = *ldsp;
     int rc = tile_geometry(s, &g);
     if (rc != RULGNN_OK) return rc;
     if (g.RW != TRW) return RULGNN_EUNSUPPORTED;            // training kernels cover num_patch <= 16 (C-MAPSS shapes)
@@ -815,8 +825,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     }
     for (int l = 0; l < 8; ++l) k.drop_key[l] = l < L ? dropout_layer_key(a->seed, a->step, l) : 0u;
     k.pcount = param_count(N, L);
-    *ldsp = train_lds_bytes(L, g);
-    if (*ldsp > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    k.wave_area_floats = 0;
     return RULGNN_OK;
 }
 
@@ -824,7 +833,7 @@ template <int L>
 static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
     TrainK k;
     WsLayout w;
-    size_t lds = 0;
+    TileGeom lds;
     int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
     const float* gy = a->dpred ? a->dpred : a->y;
@@ -864,7 +873,7 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
 // repeated launches keep accumulating into them -- durations are valid, results are not.
 template <int L, int PHASE>
 struct SinglePhase {
-    static int run(int phase, const TrainK& k, const float* x, const float* prm, const float* gy, size_t lds, int mg,
+    static int run(int phase, const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& lds, int mg,
                    hipStream_t st) {
         if (phase == PHASE) {
             if constexpr (PHASE < 2 * L) return launch_phase<L, PH_F, PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
@@ -880,7 +889,7 @@ template <int L>
 static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {
     TrainK k;
     WsLayout w;
-    size_t lds = 0;
+    TileGeom lds;
     const int rc = setup_train<L>(s, a, TM_FWDBWD, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
     if (phase < 0 || phase > 4 * L) return RULGNN_EINVAL;
