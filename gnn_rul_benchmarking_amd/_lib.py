@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "librulgnn.so")
+LIB_PATH = os.environ.get("RULGNN_LIB") or os.path.join(_PKG_DIR, "librulgnn.so")    # RULGNN_LIB: development override
 
 OK = 0
 NUM_STATS = 10

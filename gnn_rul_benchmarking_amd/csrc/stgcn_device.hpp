@@ -316,6 +316,145 @@ __device__ __forceinline__ void causal_conv(const float (&h)[F], const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Causal conv on the matrix cores (row width 16 only).
+//
+// v_mfma_f32_16x16x1_4b_f32 computes, for each of the four 16-lane blocks b INDEPENDENTLY,
+// D_b[i][j] += A_b[i] * B_b[j].  With one sample per 16-lane row that is exactly one tap of the
+// conv for all four samples of the wavefront at once:
+//     A = column k of the weight matrix laid along the lanes (lane i of every row holds W[i][k]),
+//     B = the row-mapped activation register of input channel ci (tap 1) or its row_shr copy (tap 0),
+// and the 20 (ci, tap) products accumulate in the MFMA accumulator -- no wave-uniform weights (no
+// scalar loads to wait for), no VALU FMAs.  Measured layout (tools/probe_mfma4b.hip): acc[4b + r] in
+// lane (g = lane>>4, j = lane&15) is D_b[4g + r][j]; bringing it back to the row mapping (sample b in
+// lane row b, channel in the register index) is a 4x4 transpose between register index and lane row,
+// done with v_permlane32_swap + v_permlane16_swap (4 swaps per group of four registers).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void transpose_rows4(float& v0, float& v1, float& v2, float& v3) {
+    // in: register b, lane row g  ->  out: register g, lane row b.
+    // Inline asm on purpose: with __builtin_amdgcn_permlane{16,32}_swap hipcc (ROCm 7.2) returned the
+    // FIRST result for both elements of the second-stage swaps (tools/probe: stores v2 twice).  The
+    // s_nops cover the VALU-write -> permlane-read wait states hipcc itself inserts around these ops.
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %2\n\t"
+        "v_permlane32_swap_b32 %1, %3\n\t"
+        "s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3\n\t"
+        "s_nop 1"
+        : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pearson adjacency and A.X on the matrix cores (row width 16).
+//
+// The adjacency of a sample is kept LANE-DISTRIBUTED: ten registers, Arow[c] holding A[c][c'] in lane
+// c' of the sample's 16-lane row (instead of 55 row-uniform registers).  That form is exactly the
+// A operand of v_mfma_f32_16x16x1_4b_f32, so
+//     AX[c][t] = sum_c' A[c'][c] X[c'][t]   (A symmetric)
+// is ten 4-block MFMAs (A = Arow[c'], B = the row-mapped X[c']) plus the register<->lane-row transpose,
+// and the Pearson Gram matrix itself is G[c][c'] = sum_t C[c][t] C[c'][t] = sixteen MFMAs with
+// A = B = CT[t], the centred statistics TRANSPOSED inside the row (lane = channel, register = patch;
+// one pass through a per-wave LDS tile).  Row means become in-lane sums.  This replaces 65 four-step
+// DPP butterflies (4 cycles per DPP op on gfx950) and frees 45 VGPRs.
+// ---------------------------------------------------------------------------------------------
+constexpr int PT_STRIDE = 20;                       // LDS row stride of the [sample*10 + c][t] transpose tile
+constexpr int PT_FLOATS = 4 * F * PT_STRIDE;        // per wavefront
+
+__device__ __forceinline__ void acc_to_rows(const f32x16& acc, float (&out)[F]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v0 = acc[r], v1 = acc[4 + r], v2 = acc[8 + r], v3 = acc[12 + r];
+        transpose_rows4(v0, v1, v2, v3);
+        out[r] = v0;
+        out[4 + r] = v1;
+        if (8 + r < F) out[8 + r] = v2;
+    }
+}
+
+// X0[c]: row-mapped statistics, zero in padded lanes / padded sample rows.  pt: per-wave LDS tile.
+__device__ __forceinline__ void pearson_rows_mfma(const float (&X0)[F], bool rowok, int N, float* pt, int lane, float (&Arow)[F]) {
+    const int srow = lane >> 4, cl = lane & 15;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < F; ++c) pt[(srow * F + c) * PT_STRIDE + cl] = X0[c];
+    __builtin_amdgcn_wave_barrier();
+    // lane (sample, channel cl) reads its channel's 16 patch values
+    const float4* r4 = reinterpret_cast<const float4*>(pt + (srow * F + (cl < F ? cl : 0)) * PT_STRIDE);
+    const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+    float CT[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += CT[k];                 // patches >= N are zero
+    const float mean = sum * (1.0f / (float)N);
+    const bool chan_ok = cl < F;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) CT[k] = (chan_ok && k < N) ? CT[k] - mean : 0.f;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(CT[k], CT[k], acc, 0, 0, 0);
+    acc_to_rows(acc, Arow);                                     // Arow[c] lane c' = G[c][c']
+    float diag = 0.f;
+#pragma unroll
+    for (int c = 0; c < F; ++c) diag = (cl == c) ? Arow[c] : diag;
+    const float nl = sqrtf(diag);                               // |C_c'| in lane c'
+    float nb[F];
+    nb[0] = dpp<DPP_ROW_NEWBCAST + 0>(nl); nb[1] = dpp<DPP_ROW_NEWBCAST + 1>(nl); nb[2] = dpp<DPP_ROW_NEWBCAST + 2>(nl);
+    nb[3] = dpp<DPP_ROW_NEWBCAST + 3>(nl); nb[4] = dpp<DPP_ROW_NEWBCAST + 4>(nl); nb[5] = dpp<DPP_ROW_NEWBCAST + 5>(nl);
+    nb[6] = dpp<DPP_ROW_NEWBCAST + 6>(nl); nb[7] = dpp<DPP_ROW_NEWBCAST + 7>(nl); nb[8] = dpp<DPP_ROW_NEWBCAST + 8>(nl);
+    nb[9] = dpp<DPP_ROW_NEWBCAST + 9>(nl);
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        // dot / (|a||b|): v_rcp_f32 (1 ulp); 0 * rcp(0) = 0 * inf = NaN like the reference's 0/0.
+        const float v = Arow[c] * __builtin_amdgcn_rcpf(nb[c] * nl);
+        Arow[c] = (chan_ok && rowok) ? v : 0.f;                 // padded channels / padded sample rows stay finite
+    }
+}
+
+// AX[c] = sum_c' A[c][c'] X[c']  (torch.bmm(A, X), Model.py:87) with the lane-distributed adjacency
+__device__ __forceinline__ void adj_aggregate_mfma(const float (&Arow)[F], const float (&X)[F], float (&AX)[F]) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < F; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(Arow[c], X[c], acc, 0, 0, 0);
+    acc_to_rows(acc, AX);
+}
+
+constexpr int CONV_ROW = 2 * F;   // one LDS weight row: 20 floats, index 2*c + tap
+
+// Forward (TRANSPOSED = false): out[co][t] = sum_ci w[co][ci][0] h[ci][t-D] + w[co][ci][1] h[ci][t];
+//   wrow = this lane's row (lane&15 = co) of the [16][20] table  W[co][2*ci + tap]   (rows >= 10 zero).
+// Transposed (backward data): out[ci][t] = sum_co w[co][ci][1] dz[co][t] + w[co][ci][0] dz[co][t+D];
+//   wrow = row (lane&15 = ci) of the table  WT[ci][2*co + tap] = w[co][ci][tap].
+template <int D, bool TRANSPOSED>
+__device__ __forceinline__ void causal_conv_mfma(const float (&h)[F], const float* wrow, float (&out)[F]) {
+    const float4* w4 = reinterpret_cast<const float4*>(wrow);
+    const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3], we = w4[4];
+    const float w[CONV_ROW] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y,
+                               wc.z, wc.w, wd.x, wd.y, wd.z, wd.w, we.x, we.y, we.z, we.w};
+    float hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) hs[c] = TRANSPOSED ? dpp<DPP_ROW_SHL + D>(h[c]) : dpp<DPP_ROW_SHR + D>(h[c]);
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w[2 * c + 0], hs[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w[2 * c + 1], h[c], acc, 0, 0, 0);
+    }
+    acc_to_rows(acc, out);
+}
+
+// fill one [16][CONV_ROW] LDS table from a [10][10][2] conv weight (block-cooperative)
+__device__ __forceinline__ void stage_conv_table(float* tab, const float* __restrict__ w, bool transposed, int tid, int nthreads) {
+    for (int i = tid; i < 16 * CONV_ROW; i += nthreads) {
+        const int row = i / CONV_ROW, k = i % CONV_ROW, c = k >> 1, tap = k & 1;
+        float v = 0.f;
+        if (row < F) v = transposed ? w[(c * F + row) * 2 + tap] : w[(row * F + c) * 2 + tap];
+        tab[i] = v;
+    }
+}
+
 // 32-bit mix shared bit-for-bit with oracle/stgcn_oracle.py::_lowbias32
 __device__ __forceinline__ uint32_t lowbias32(uint32_t h) {
     h ^= h >> 16;

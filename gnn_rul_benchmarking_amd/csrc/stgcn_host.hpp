@@ -39,6 +39,7 @@ inline int tile_geometry(const rulgnn_stgcn_shape* s, TileGeom* g) {
     g->vec4 = (g->Ppad == P) && (((int64_t)N * P) % 4 == 0);
     const int raw = g->SPW * N * g->Ppad;
     g->stage_floats = (raw + 3) & ~3;
+    if (g->RW == 16 && g->stage_floats < PT_FLOATS) g->stage_floats = PT_FLOATS;   // the staging area doubles as the Pearson transpose tile
     if ((size_t)g->stage_floats * sizeof(float) > 36 * 1024) return RULGNN_EUNSUPPORTED;
     g->magicP = (uint32_t)((((uint64_t)1 << 32) + (uint64_t)P - 1) / (uint64_t)P);
     g->ntiles = (s->batch + g->SPW - 1) / g->SPW;
