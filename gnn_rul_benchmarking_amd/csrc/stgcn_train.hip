@@ -36,7 +36,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TRW = 16;                     // row width of the training kernels
 using R16 = Row<TRW>;
 constexpr int TSPW = 4;                     // samples per wavefront
-constexpr int AQ = 4;                       // ceil(NPAIR / 16): adjacency cache slots per lane
 constexpr int TWS = wstride<TRW>();         // LDS row stride of a padded 16x16 weight matrix
 constexpr int TT_STRIDE = 68;               // LDS row stride of the [channel][lane] transpose tile
 constexpr int TT_ROWS = 30;
@@ -47,7 +46,7 @@ enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
 struct TrainK {
     // workspace regions
     float* cacheX;        // [ntiles][F][64]
-    float* cacheA;        // [ntiles][AQ][64]
+    float* cacheA;        // [ntiles][F][64]  lane-distributed adjacency rows
     double* cells_fwd;    // [2L][2][F]   sum z, sum z^2
     double* cells_bwd;    // [2L][2][F]   sum dy, sum dy*xhat
     double* cell_loss;    // [1]
@@ -152,8 +151,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
     float* wldsT = wlds + (L + 1) * TRW * TWS;            // [L+1][16][TWS]   transposes (backward)
     float* vecs = wldsT + (L + 1) * TRW * TWS;            // [L+2][16]        theta bias, fc1 bias, fc2 weight
     float* bnc = vecs + (L + 2) * TRW;                    // [NBN][BNC][F] (+pad to 4)
-    float* abuf = bnc + ((NBN * BNC * F + 3) & ~3);       // [4 waves][TSPW][64]  adjacency exchange
-    float* red = abuf + WAVES_PER_BLOCK * TSPW * 64;      // [RED_K][64] block reduction of the gradient accumulators
+    float* red = bnc + ((NBN * BNC * F + 3) & ~3);        // [RED_K][64] block reduction of the gradient accumulators
     constexpr int RED_K = 15;
     float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
     float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (G)
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         const int ns = (int)((a.B - s0) < TSPW ? (a.B - s0) : TSPW);
         const bool rowok = srow < ns;
         const bool valid = rowok && (t < N);
-        float X[F], A[NPAIR];
+        float X[F], A[F];       // A: lane-distributed adjacency rows (stgcn_device.hpp, pearson_rows_mfma)
 
         // ---- inputs: patch statistics + Pearson adjacency (F_0 computes and caches), or the saved X_l ----
         if constexpr (KIND == PH_F && IDX == 0) {
@@ -238,39 +236,21 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = 0.f;
             if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, a.P, X);
-            pearson_adjacency<TRW>(X, valid, N, A);
-            // padding rows (beyond the batch) would give 0/0 = NaN: keep them finite
-#pragma unroll
-            for (int i = 0; i < NPAIR; ++i) A[i] = rowok ? A[i] : 0.f;
+            pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
             float* cx = a.cacheX + tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) cx[c * 64] = X[c];
-            float aq[AQ] = {0.f, 0.f, 0.f, 0.f};
+            float* ca = a.cacheA + tile * tile_floats + lane;
 #pragma unroll
-            for (int i = 0; i < NPAIR; ++i) aq[i / 16] = (t == (i % 16)) ? A[i] : aq[i / 16];
-            float* ca = a.cacheA + tile * (AQ * 64) + lane;
-#pragma unroll
-            for (int q = 0; q < AQ; ++q) ca[q * 64] = aq[q];
+            for (int c = 0; c < F; ++c) ca[c * 64] = A[c];
         } else {
             const float* cx = (LSTART == 0 ? a.cacheX : a.xsave + (size_t)(LSTART - 1) * a.ntiles * tile_floats) +
                               tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = cx[c * 64];
-            const float* ca = a.cacheA + tile * (AQ * 64) + lane;
-            float* ab = abuf + (wave * TSPW + srow) * 64;
-            __builtin_amdgcn_wave_barrier();
+            const float* ca = a.cacheA + tile * tile_floats + lane;
 #pragma unroll
-            for (int q = 0; q < AQ; ++q) ab[q * 16 + t] = ca[q * 64];
-            __builtin_amdgcn_wave_barrier();
-            const float4* ab4 = reinterpret_cast<const float4*>(ab);
-#pragma unroll
-            for (int i4 = 0; i4 < (NPAIR + 3) / 4; ++i4) {
-                const float4 v = ab4[i4];
-                A[i4 * 4 + 0] = v.x;
-                if (i4 * 4 + 1 < NPAIR) A[i4 * 4 + 1] = v.y;
-                if (i4 * 4 + 2 < NPAIR) A[i4 * 4 + 2] = v.z;
-                if (i4 * 4 + 3 < NPAIR) A[i4 * 4 + 3] = v.w;
-            }
+            for (int c = 0; c < F; ++c) A[c] = ca[c * 64];
         }
         const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
 
@@ -282,7 +262,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
             const float* b1 = bnc + (2 * lq) * BNC * F;
             const float* b2 = bnc + (2 * lq + 1) * BNC * F;
             float AX[F], H[F], z[F];
-            adj_aggregate(A, X, AX);
+            adj_aggregate_mfma(A, X, AX);
             const float tb = vecs[lq * TRW + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
@@ -314,7 +294,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         const float* b1 = bnc + (2 * LY) * BNC * F;
         const float* b2 = bnc + (2 * LY + 1) * BNC * F;
         float AX[F], H[F], z1[F];
-        adj_aggregate(A, X, AX);
+        adj_aggregate_mfma(A, X, AX);
         {
             const float tb = vecs[LY * TRW + t];
 #pragma unroll
@@ -369,7 +349,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
                 for (int c = 0; c < F; ++c) dAX[c] = 0.f;
                 R16::project10(dAX, dH, wldsT + (LY * TRW + t) * TWS, N);        // dHpre . theta
-                adj_aggregate(A, dAX, dXl);                                        // A is symmetric: A^T = A
+                adj_aggregate_mfma(A, dAX, dXl);                                   // A is symmetric: A^T = A
                 float* rb = a.rbuf + tile * tile_floats + lane;
                 constexpr int lq = LY - 1;
                 const float* q2 = bnc + (2 * lq + 1) * BNC * F;
@@ -706,7 +686,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
-    w->off_cacheA = o; o = al(o + (size_t)g.ntiles * AQ * 64 * sizeof(float));
+    w->off_cacheA = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
@@ -737,7 +717,7 @@ static int wave_area_for(int kind, int idx, const TileGeom& g) {
 
 static size_t train_lds_bytes(int L, int wave_area) {
     const size_t fl = (size_t)2 * (L + 1) * TRW * TWS + (size_t)(L + 2) * TRW + (size_t)((2 * L * BNC * F + 3) & ~3) +
-                      (size_t)WAVES_PER_BLOCK * TSPW * 64 + (size_t)15 * 64 + (size_t)WAVES_PER_BLOCK * 24 +
+                      (size_t)15 * 64 + (size_t)WAVES_PER_BLOCK * 24 +
                       (size_t)WAVES_PER_BLOCK * wave_area;
     return fl * sizeof(float);
 }
