@@ -476,10 +476,25 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ g, float* s
                                            uint32_t magicP, bool vec4, int lane) {
     if (Ppad == P) {
         if (vec4) {
+            // CH loads are issued back to back (clamped index, no branch around the load) before the
+            // first LDS store: the rolled load->wait->store loop exposed one HBM latency per float4.
+            constexpr int CH = 4;
             const float4* g4 = reinterpret_cast<const float4*>(g);
             float4* s4 = reinterpret_cast<float4*>(stage);
             const int n4 = total >> 2;
-            for (int i = lane; i < n4; i += 64) s4[i] = g4[i];
+            for (int base = lane; base < n4; base += CH * 64) {
+                float4 r[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = base + u * 64;
+                    r[u] = g4[i < n4 ? i : n4 - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = base + u * 64;
+                    if (i < n4) s4[i] = r[u];
+                }
+            }
         } else {
             for (int i = lane; i < total; i += 64) stage[i] = g[i];
         }

@@ -179,7 +179,7 @@ static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RULGNN_EHIP;
     }
-    const int grid = persistent_grid(stgcn_forward_eval_kernel<RW>, g.ntiles, lds);
+    const int grid = persistent_grid(stgcn_forward_eval_kernel<RW>, g.ntiles, lds, 4);
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(stgcn_forward_eval_kernel<RW>, dim3(grid), dim3(BLOCK), lds, stream, x, prm, bn, out, a);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
