@@ -52,6 +52,7 @@ struct TrainK {
     double* cell_loss;    // [1]
     float* gpart;         // [grid][param_count] per-block partial gradients
     float* xsave;         // [L-1][ntiles][F][64]  X_l = input of layer l (l >= 1), written by F_{2l}
+    float* psave;         // [L-1][ntiles][F][64]  layer l-1: x-hat of BatchNorm 2l-1 where the gradient passes, else +inf
     float* rbuf;          // [ntiles][F][64]  d X_{l+1}: gradient entering layer l's backward (TOP / G_{2l+2} -> G_{2l+1}, G_{2l})
     float* sbuf;          // [ntiles][F][64]  d(x0 + H) of layer l (G_{2l+1} -> G_{2l})
     // outputs
@@ -213,10 +214,11 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 
     // Which layer does this kernel work in, and where does its forward start?
     //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
-    //   G_{2l}, l >= 1 : needs layer l-1's conv_block2 activations for the next BatchNorm's sums -> also starts at l-1
+    //                    and, per element, "x-hat of BatchNorm 2l-1 if the gradient passes both ReLUs, else +inf"
+    //                    (psave) -- all that G_{2l} needs from layer l-1 to form that BatchNorm's backward sums
     constexpr int LY = KIND == PH_TOP ? L - 1 : IDX / 2;
     constexpr int BLK = KIND == PH_TOP ? 1 : IDX % 2;
-    constexpr bool WITH_PREV = (KIND != PH_TOP) && (BLK == 0) && (LY >= 1);
+    constexpr bool WITH_PREV = (KIND == PH_F) && (BLK == 0) && (LY >= 1);
     constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
     const size_t tile_floats = (size_t)F * 64;
 
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         }
         const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
 
-        // ---- previous layer in full (F_{2l}, G_{2l} with l >= 1) -------------------------------------------
-        float pz2[F], po0[F];                         // layer LY-1: conv_block2 pre-BN output and input (G_{2l} only)
+        // ---- previous layer in full (F_{2l} with l >= 1) ---------------------------------------------------
         if constexpr (WITH_PREV) {
+            float pz2[F], po0[F];
             constexpr int lq = LY - 1;
             const float* lp = prm + lq * LS;
             const float* b1 = bnc + (2 * lq) * BNC * F;
@@ -273,19 +275,20 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
             for (int c = 0; c < F; ++c) po0[c] = relu(relu(fmaf(z[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
             causal_conv<TRW, 2>(po0, lp + off_conv_w(N, 1), t, pz2);
+            float* xs = a.xsave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
+            float* ps = a.psave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) {
-                float o1 = relu(relu(fmaf(pz2[c], b2[2 * F + c], b2[3 * F + c])) + po0[c]);
+                const float x1 = relu(fmaf(pz2[c], b2[2 * F + c], b2[3 * F + c]));
+                float o1 = relu(x1 + po0[c]);
+                const bool pass = o1 > 0.f && x1 > 0.f && valid;
+                ps[c * 64] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
                 if (a.dropout_p > 0.f) {
                     const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
-            }
-            if constexpr (KIND == PH_F) {              // X_l is final from here on: store it for the later phases
-                float* xs = a.xsave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
-#pragma unroll
-                for (int c = 0; c < F; ++c) xs[c * 64] = X[c];
+                xs[c * 64] = X[c];                     // X_l is final from here on: stored for the later phases
             }
         }
 
@@ -352,23 +355,22 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 adj_aggregate_mfma(A, dAX, dXl);                                   // A is symmetric: A^T = A
                 float* rb = a.rbuf + tile * tile_floats + lane;
                 constexpr int lq = LY - 1;
-                const float* q2 = bnc + (2 * lq + 1) * BNC * F;
+                const float* ps = a.psave + (size_t)lq * a.ntiles * tile_floats + tile * tile_floats + lane;
 #pragma unroll
                 for (int c = 0; c < F; ++c) {
                     const float dX = valid ? dXl[c] + rb[c * 64] : 0.f;           // + residual branch: d X_{l+1}
                     rb[c * 64] = dX;                                               // = d X_l, read by G_{2l-1}
-                    // top of layer l-1: sums for BatchNorm 2l-1
-                    const float x1 = relu(fmaf(pz2[c], q2[2 * F + c], q2[3 * F + c]));
-                    const float o1 = relu(x1 + po0[c]);
+                    // top of layer l-1: sums for BatchNorm 2l-1 from the saved "x-hat or +inf (gradient blocked)"
+                    const float xh = ps[c * 64];
                     float g = dX;
                     if (a.dropout_p > 0.f) {
                         const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
                         g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                     }
-                    const float dy = (o1 > 0.f && x1 > 0.f && valid) ? g : 0.f;
-                    const float xh = (pz2[c] - q2[0 * F + c]) * q2[1 * F + c];
+                    const bool pass = xh < INFINITY;
+                    const float dy = pass ? g : 0.f;
                     s_a[c] += dy;
-                    s_b[c] = fmaf(dy, xh, s_b[c]);
+                    s_b[c] = fmaf(dy, pass ? xh : 0.f, s_b[c]);
                 }
             }
             continue;
@@ -667,7 +669,7 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
 // host side
 // ------------------------------------------------------------------------------------------------
 struct WsLayout {
-    size_t off_cacheX, off_cacheA, off_cells, off_gpart, off_xsave, off_rbuf, off_sbuf, total;
+    size_t off_cacheX, off_cacheA, off_cells, off_gpart, off_xsave, off_psave, off_rbuf, off_sbuf, total;
     size_t cells_bytes;
     int max_grid;
 };
@@ -693,6 +695,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
     const size_t tile_bytes = (size_t)g.ntiles * F * 64 * sizeof(float);
     w->off_xsave = o; o = al(o + (size_t)(L > 1 ? L - 1 : 1) * tile_bytes);
+    w->off_psave = o; o = al(o + (size_t)(L > 1 ? L - 1 : 1) * tile_bytes);
     w->off_rbuf = o; o = al(o + tile_bytes);
     w->off_sbuf = o; o = al(o + tile_bytes);
     w->total = o;
@@ -785,6 +788,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     k.cell_loss = cells + 2 * (2 * L * 2 * F);
     k.gpart = reinterpret_cast<float*>(ws + w.off_gpart);
     k.xsave = reinterpret_cast<float*>(ws + w.off_xsave);
+    k.psave = reinterpret_cast<float*>(ws + w.off_psave);
     k.rbuf = reinterpret_cast<float*>(ws + w.off_rbuf);
     k.sbuf = reinterpret_cast<float*>(ws + w.off_sbuf);
     k.write_pred = 1;
