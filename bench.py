@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true", help="loss.item() every step like the reference")
+    ap.add_argument("--force-dp", action="store_true", help="use the data-parallel step even for world_size 1 (exercises RCCL)")
     return ap.parse_args()
 
 
@@ -164,8 +165,12 @@ def main():
     if rank == 0:
         entry.build()
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or args.force_dp
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
@@ -181,7 +186,7 @@ def main():
     algo.to(dev)
     algo.train()
     algo.sync_loss = bool(args.sync_loss)
-    if world > 1:
+    if use_dist:
         algo.attach_data_parallel(DataParallel())
 
     B = args.batch
@@ -191,7 +196,7 @@ def main():
     ys = [torch.rand(B, 1, device=dev, generator=g) for _ in range(nbuf)]
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +209,7 @@ def main():
         last = algo.update(Xs[i % nbuf], ys[i % nbuf], 1)["loss"]
     sync()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -234,7 +239,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(NUM_PATCH, args.patch_size, args.dropout)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -42,6 +42,8 @@ class DataParallel:
         """Make every replica identical to rank 0 (parameters and BatchNorm statistics)."""
         dist.broadcast(model.flat_params, 0, group=self.group)
         dist.broadcast(model._bn, 0, group=self.group)
+        if hasattr(model, "_flush_nbt"):
+            model._flush_nbt()
         dist.broadcast(model._nbt, 0, group=self.group)
 
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:

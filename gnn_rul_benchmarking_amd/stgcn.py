@@ -125,6 +125,8 @@ class ST_GCN_model(nn.Module):
         self._ws = None
         self._ws_key = None
         self._step = 0              # training forwards so far (dropout stream position)
+        self._nbt_pending = 0       # BatchNorm num_batches_tracked increments not yet written to the buffers
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._reflatten()
 
@@ -136,6 +138,7 @@ class ST_GCN_model(nn.Module):
     def _reflatten(self):
         """(Re)build the flat buffers on the parameters' current device and re-point every live
         parameter / BatchNorm buffer at its slice."""
+        self._flush_nbt()
         live = self._named_live()
         dev = live[0][1].device
         flat = torch.empty(PL.param_count(self.num_patch, self.num_layers), dtype=torch.float32, device=dev)
@@ -161,6 +164,11 @@ class ST_GCN_model(nn.Module):
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pred_buf = None
         self._ws, self._ws_key = None, None
+
+    def _flush_nbt(self):
+        if self._nbt_pending and self._nbt is not None:
+            self._nbt += self._nbt_pending
+            self._nbt_pending = 0
 
     def _set_buffer(self, dotted, tensor):
         mod = self
@@ -251,7 +259,7 @@ class ST_GCN_model(nn.Module):
                                                             batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
                                                             _stream()),
                    "rulgnn_bn_running_update_f32")
-        self._nbt += 1
+        self._nbt_pending += 1      # folded into the num_batches_tracked buffers lazily (state_dict / .to())
 
     def _train_forward(self, x2d):
         self._step += 1
