@@ -65,6 +65,23 @@ def phase_names(L):
     return [f"F{i}" for i in range(2 * L)] + ["TOP"] + [f"G{2 * L - 1 - j}" for j in range(2 * L)]
 
 
+def phase_bytes_per_sample(name, N, P, L):
+    """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, 16-lane]
+    fp32 state tensor per sample = 640 B: X0 / adjacency rows (cache), X_l, x-hat mask, dX, d(x0+H)."""
+    T = 10 * 16 * 4
+    if name == "F0":
+        return N * P * 4 + 2 * T                       # read the window, write X0 + adjacency rows
+    if name == "TOP":
+        return 3 * T + 8                               # X_{L-1}, A; write dX_L; y in, pred out
+    i = int(name[1:])
+    l, blk = divmod(i, 2)
+    if name[0] == "F":
+        return 2 * T + (2 * T if (blk == 0 and l >= 1) else 0)        # X, A (+ write X_l and the x-hat mask)
+    if blk == 1:
+        return 4 * T                                   # G_{2l+1}: X_l, A, dX_{l+1}; write d(x0+H)
+    return (3 * T) if l == 0 else (6 * T)              # G_{2l}: X_l, A, d(x0+H) (+ dX in/out, x-hat mask)
+
+
 def roofline_measurements(model, X, y, iters=10):
     """HIP-event timing (on torch's current stream = the stream the kernels are launched on) of every
     phase kernel of the training step and of the fused eval forward kernel."""
@@ -83,11 +100,7 @@ def roofline_measurements(model, X, y, iters=10):
         def run(ph=ph):
             _lib.check(lib.rulgnn_stgcn_train_phase_f32(C.byref(shp), C.byref(a), ph, st()), "phase")
         ms = event_time_ms(run, iters)
-        # algorithmic HBM bytes per sample: F0 reads the window and writes the statistics/adjacency cache
-        # (10 + 4 floats per lane-slot, 64 slots per 4 samples); every other phase reads that cache; TOP writes pred
-        cache_b = (10 + 4) * 64 * 4 / 4.0
-        byts = (N * P * 4 + cache_b) if name == "F0" else (cache_b + (4 if name == "TOP" else 0))
-        per[name] = {"ms": ms, "bytes_per_sample": byts}
+        per[name] = {"ms": ms, "bytes_per_sample": phase_bytes_per_sample(name, N, P, L)}
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
     ach = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9
