@@ -82,6 +82,19 @@ def phase_bytes_per_sample(name, N, P, L):
     return (3 * T) if l == 0 else (6 * T)              # G_{2l}: X_l, A, d(x0+H) (+ dX in/out, x-hat mask)
 
 
+def measured_traffic(kernel_key, N, P, B):
+    """HBM bytes per launch from the committed PMC summary (profiles/r01_hbm_traffic.json), scaled to this
+    batch; None when the profiled workload does not match."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        w = t["workload"]
+        if (w["num_patch"], w["patch_size"]) != (N, P) or kernel_key not in t["kernels"]:
+            return None
+        return round(t["kernels"][kernel_key]["hbm_bytes_per_sample"] * B)
+    except Exception:
+        return None
+
+
 def roofline_measurements(model, X, y, iters=10):
     """HIP-event timing (on torch's current stream = the stream the kernels are launched on) of every
     phase kernel of the training step and of the fused eval forward kernel."""
@@ -105,7 +118,7 @@ def roofline_measurements(model, X, y, iters=10):
     d = per[dom]
     ach = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": f"stgcn_train_phase_kernel<{dom}>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, N, P, B),
             "us_per_launch": round(d["ms"] * 1e3, 1), "bytes_per_sample": d["bytes_per_sample"],
             "phase_us": {k: round(v["ms"] * 1e3, 1) for k, v in per.items()}}
     # the north-star kernel: fused eval forward, one launch per call
@@ -116,7 +129,7 @@ def roofline_measurements(model, X, y, iters=10):
     fb = N * P * 4 + 4
     fach = fb * B / (fms * 1e-3) / 1e9
     roof_f = {"bound": "hbm", "kernel": "stgcn_forward_eval_kernel", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": None,
+              "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("EVAL", N, P, B),
               "us_per_launch": round(fms * 1e3, 1), "bytes_per_sample": fb,
               "samples_per_s": round(B / (fms * 1e-3), 1)}
     return roof, roof_f
