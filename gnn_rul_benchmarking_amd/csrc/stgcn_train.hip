@@ -33,10 +33,9 @@ namespace rulgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TRW = 16;                     // row width of the training kernels
-using R16 = Row<TRW>;
-constexpr int TSPW = 4;                     // samples per wavefront
-constexpr int TWS = wstride<TRW>();         // LDS row stride of a padded 16x16 weight matrix
+// Row widths of the training kernels: 16 (num_patch <= 16: four samples per wavefront, DPP + MFMA tricks
+// that rely on 16-lane rows) and 64 (num_patch <= 64: one sample per wavefront, generic cross-lane
+// primitives; correctness path for the reference-wired PHM2012 40x64 shape).
 constexpr int TT_STRIDE = 68;               // LDS row stride of the [channel][lane] transpose tile
 constexpr int TT_ROWS = 30;
 constexpr int BNC = 7;                      // per-BatchNorm constants: mean, istd, scale, shift, gamma*istd, k1, k2
@@ -75,18 +74,18 @@ struct TrainK {
 // small device helpers
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {      // total over 64 lanes, valid in every lane
-    v = R16::allsum(v);
+    v = Row<16>::allsum(v);
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     return v;
 }
 
-template <int D>
+template <int RW, int D>
 __device__ __forceinline__ void causal_conv_T(const float (&dz)[F], const float* __restrict__ w, int t, float (&dh)[F]) {
     // transpose of causal_conv: dh[ci][t] = sum_co w[co][ci][1] dz[co][t] + w[co][ci][0] dz[co][t + D]
     float dzs[F];
 #pragma unroll
-    for (int c = 0; c < F; ++c) dzs[c] = R16::template shl<D>(dz[c], t);
+    for (int c = 0; c < F; ++c) dzs[c] = Row<RW>::template shl<D>(dz[c], t);
 #pragma unroll
     for (int ci = 0; ci < F; ++ci) {
         float acc = 0.f;
@@ -130,42 +129,96 @@ __device__ __forceinline__ void conv_wgrad_mfma(float* T, const float (&dz)[F], 
     }
 }
 
+// Generic (any row width) weight gradient of a [N][N] matrix: D[j][k] += sum_{sample, c} P[c][sample, j] * Q[c][sample, k]
+// by the same in-wave LDS transpose + v_mfma_f32_16x16x4_f32, tiled (RW/16)^2.  Used by the RW = 64 kernels
+// for theta (NC = 10) and fc1 (NC = 1); the RW = 16 kernels feed the MFMA straight from registers instead.
+template <int RW, int NC>
+__device__ __forceinline__ void outer_grad_mfma(float* T, const float (&P)[NC], const float (&Q)[NC], int lane,
+                                                f32x4 (&acc)[(RW / 16) * (RW / 16)]) {
+    constexpr int NT = RW / 16, KS = (NC + 3) / 4, ROWS = KS * 4, SPW = 64 / RW;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < ROWS; ++c) {
+        T[c * TT_STRIDE + lane] = c < NC ? P[c < NC ? c : 0] : 0.f;
+        T[(ROWS + c) * TT_STRIDE + lane] = c < NC ? Q[c < NC ? c : 0] : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < SPW; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float av[NT], bv[NT];
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                av[m] = T[(4 * ks + kq) * TT_STRIDE + s * RW + 16 * m + i];
+                bv[m] = T[(ROWS + 4 * ks + kq) * TT_STRIDE + s * RW + 16 * m + i];
+            }
+#pragma unroll
+            for (int m = 0; m < NT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m * NT + n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m * NT + n], 0, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // the phase kernel
 // ------------------------------------------------------------------------------------------------
 // IDX: BatchNorm index (0 .. 2L-1) for F and G kernels; unused for TOP.
-template <int L, int KIND, int IDX>
-__global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+template <int RW, int L, int KIND, int IDX>
+__global__ __launch_bounds__(BLOCK, RW == 16 ? 2 : 1) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy,   // y or dpred (TOP only)
                                                                   TrainK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TRW = RW, TSPW = 64 / RW, TWS = wstride<RW>();
+    using R16 = Row<RW>;                       // (name kept from the first, 16-lane-only version)
+    constexpr int NTH = RW == 16 ? 1 : (RW / 16) * (RW / 16);     // theta-gradient MFMA tiles (generic path)
     constexpr int NBN = 2 * L;
     // BatchNorm layers whose forward statistics this kernel needs: F_i applies BN 0..i-1.
     constexpr int NFWD = KIND == PH_F ? IDX : NBN;
     const int N = a.N, LS = layer_stride(N);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int srow = lane >> 4, t = lane & 15;
+    const int srow = lane / RW, t = lane % RW;
+
+    // Which layer does this kernel work in, and where does its forward start?
+    //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
+    //                    and, per element, "x-hat of BatchNorm 2l-1 if the gradient passes both ReLUs, else +inf"
+    //                    (psave) -- all that G_{2l} needs from layer l-1 to form that BatchNorm's backward sums
+    constexpr int LY = KIND == PH_TOP ? L - 1 : IDX / 2;
+    constexpr int BLK = KIND == PH_TOP ? 1 : IDX % 2;
+    constexpr bool WITH_PREV = (KIND == PH_F) && (BLK == 0) && (LY >= 1);
+    constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
 
     // ---- LDS carve --------------------------------------------------------------------------------
-    float* wlds = smem;                                   // [L+1][16][TWS]   theta rows / fc1 rows
-    float* wldsT = wlds + (L + 1) * TRW * TWS;            // [L+1][16][TWS]   transposes (backward)
-    float* vecs = wldsT + (L + 1) * TRW * TWS;            // [L+2][16]        theta bias, fc1 bias, fc2 weight
+    // three zero-padded [RW][TWS] weight slots: theta of layer LY | theta of layer LY-1 (F_{2l}) or fc1 (TOP) |
+    // the transposed matrix the backward needs (theta^T for G_{2l}, fc1^T for TOP)
+    float* w_cur = smem;
+    float* w_aux = w_cur + TRW * TWS;
+    float* w_tr = w_aux + TRW * TWS;
+    float* vecs = w_tr + TRW * TWS;                       // [L+2][RW]        theta bias, fc1 bias, fc2 weight
     float* bnc = vecs + (L + 2) * TRW;                    // [NBN][BNC][F] (+pad to 4)
+    constexpr int RED_K = 15 + (RW == 16 ? 0 : 4 * NTH);
     float* red = bnc + ((NBN * BNC * F + 3) & ~3);        // [RED_K][64] block reduction of the gradient accumulators
-    constexpr int RED_K = 15;
     float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
-    float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (G)
-    const int wave_area_floats = a.wave_area_floats;     // staging (F_0), transpose tile (G), nothing otherwise
+    float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (TOP / G)
+    const int wave_area_floats = a.wave_area_floats;
     float* mywave = wave_area + wave * wave_area_floats;
 
     // ---- prologue: weights to LDS, BatchNorm constants from the reduction cells ---------------------
-    for (int i = threadIdx.x; i < (L + 1) * TRW * TRW; i += BLOCK) {
-        const int m = i / (TRW * TRW), j = (i / TRW) % TRW, k = i % TRW;
-        const float* src = m < L ? prm + m * LS + off_theta_w(N) : prm + off_fc1_w(N, L);
-        const float v = (j < N && k < N) ? src[j * N + k] : 0.f;
-        wlds[(m * TRW + j) * TWS + k] = v;
-        wldsT[(m * TRW + k) * TWS + j] = v;
+    {
+        const float* th_cur = prm + LY * LS + off_theta_w(N);
+        const float* aux = KIND == PH_TOP ? prm + off_fc1_w(N, L) : prm + (LY >= 1 ? LY - 1 : 0) * LS + off_theta_w(N);
+        const float* trs = KIND == PH_TOP ? prm + off_fc1_w(N, L) : th_cur;
+        for (int i = threadIdx.x; i < TRW * TRW; i += BLOCK) {
+            const int j = i / TRW, k = i % TRW;
+            const bool in = j < N && k < N;
+            w_cur[j * TWS + k] = in ? th_cur[j * N + k] : 0.f;
+            w_aux[j * TWS + k] = in ? aux[j * N + k] : 0.f;
+            w_tr[k * TWS + j] = in ? trs[j * N + k] : 0.f;
+        }
     }
     for (int i = threadIdx.x; i < (L + 2) * TRW; i += BLOCK) {
         const int m = i / TRW, j = i % TRW;
@@ -205,21 +258,16 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
     for (int c = 0; c < F; ++c) s_a[c] = s_b[c] = 0.f;
     f32x4 acc_c0 = {0.f, 0.f, 0.f, 0.f}, acc_c1 = {0.f, 0.f, 0.f, 0.f};   // conv weight gradient (MFMA)
-    f32x4 acc_th = {0.f, 0.f, 0.f, 0.f};                                   // theta / fc1 weight gradient (MFMA)
+    f32x4 acc_th = {0.f, 0.f, 0.f, 0.f};                                   // theta / fc1 weight gradient (MFMA, RW 16)
+    f32x4 acc_thg[NTH];                                                    // same, tiled, for the generic row width
+#pragma unroll
+    for (int i = 0; i < NTH; ++i) acc_thg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float acc_b = 0.f, acc_w2 = 0.f, acc_b2 = 0.f, acc_loss = 0.f;         // theta/fc1 bias, fc2 weight, fc2 bias, loss
 
     const float fc2_b = prm[off_fc2_b(N, L)];
     const int64_t sampleNP = (int64_t)N * a.P;
     const float inv_gb = 1.0f / (float)a.global_batch;
 
-    // Which layer does this kernel work in, and where does its forward start?
-    //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
-    //                    and, per element, "x-hat of BatchNorm 2l-1 if the gradient passes both ReLUs, else +inf"
-    //                    (psave) -- all that G_{2l} needs from layer l-1 to form that BatchNorm's backward sums
-    constexpr int LY = KIND == PH_TOP ? L - 1 : IDX / 2;
-    constexpr int BLK = KIND == PH_TOP ? 1 : IDX % 2;
-    constexpr bool WITH_PREV = (KIND == PH_F) && (BLK == 0) && (LY >= 1);
-    constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
     const size_t tile_floats = (size_t)F * 64;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
@@ -228,7 +276,8 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         const int ns = (int)((a.B - s0) < TSPW ? (a.B - s0) : TSPW);
         const bool rowok = srow < ns;
         const bool valid = rowok && (t < N);
-        float X[F], A[F];       // A: lane-distributed adjacency rows (stgcn_device.hpp, pearson_rows_mfma)
+        constexpr int NA = RW == 16 ? F : NPAIR;   // RW 16: lane-distributed adjacency rows (MFMA); else 55 row-uniform values
+        float X[F], A[NA];
 
         // ---- inputs: patch statistics + Pearson adjacency (F_0 computes and caches), or the saved X_l ----
         if constexpr (KIND == PH_F && IDX == 0) {
@@ -238,21 +287,38 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = 0.f;
             if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, a.P, X);
-            pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
             float* cx = a.cacheX + tile * tile_floats + lane;
+            if constexpr (RW == 16) {
+                pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
+                float* ca = a.cacheA + tile * tile_floats + lane;
+#pragma unroll
+                for (int c = 0; c < F; ++c) ca[c * 64] = A[c];
+            } else {
+                pearson_adjacency<RW>(X, valid, N, A);
+                float v = 0.f;                              // one sample per wavefront: lane i keeps entry i
+#pragma unroll
+                for (int i = 0; i < NPAIR; ++i) {
+                    A[i] = rowok ? A[i] : 0.f;
+                    v = (lane == i) ? A[i] : v;
+                }
+                a.cacheA[tile * 64 + lane] = v;
+            }
 #pragma unroll
             for (int c = 0; c < F; ++c) cx[c * 64] = X[c];
-            float* ca = a.cacheA + tile * tile_floats + lane;
-#pragma unroll
-            for (int c = 0; c < F; ++c) ca[c * 64] = A[c];
         } else {
             const float* cx = (LSTART == 0 ? a.cacheX : a.xsave + (size_t)(LSTART - 1) * a.ntiles * tile_floats) +
                               tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = cx[c * 64];
-            const float* ca = a.cacheA + tile * tile_floats + lane;
+            if constexpr (RW == 16) {
+                const float* ca = a.cacheA + tile * tile_floats + lane;
 #pragma unroll
-            for (int c = 0; c < F; ++c) A[c] = ca[c * 64];
+                for (int c = 0; c < F; ++c) A[c] = ca[c * 64];
+            } else {
+                const int v = __builtin_bit_cast(int, a.cacheA[tile * 64 + lane]);
+#pragma unroll
+                for (int i = 0; i < NPAIR; ++i) A[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, i));
+            }
         }
         const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
 
@@ -264,11 +330,11 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
             const float* b1 = bnc + (2 * lq) * BNC * F;
             const float* b2 = bnc + (2 * lq + 1) * BNC * F;
             float AX[F], H[F], z[F];
-            adj_aggregate_mfma(A, X, AX);
+            if constexpr (RW == 16) adj_aggregate_mfma(A, X, AX); else adj_aggregate(A, X, AX);
             const float tb = vecs[lq * TRW + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
-            R16::project10(H, AX, wlds + (lq * TRW + t) * TWS, N);
+            R16::project10(H, AX, w_aux + t * TWS, N);
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
             causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z);
@@ -297,13 +363,13 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
         const float* b1 = bnc + (2 * LY) * BNC * F;
         const float* b2 = bnc + (2 * LY + 1) * BNC * F;
         float AX[F], H[F], z1[F];
-        adj_aggregate_mfma(A, X, AX);
+        if constexpr (RW == 16) adj_aggregate_mfma(A, X, AX); else adj_aggregate(A, X, AX);
         {
             const float tb = vecs[LY * TRW + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
         }
-        R16::project10(H, AX, wlds + (LY * TRW + t) * TWS, N);
+        R16::project10(H, AX, w_cur + t * TWS, N);
 #pragma unroll
         for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
         causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z1);
@@ -339,20 +405,21 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 conv_wgrad_mfma(mywave, dz, H, hs, lane, acc_c0, acc_c1);
             }
             float dH[F];
-            causal_conv_T<1>(dz, lp + off_conv_w(N, 0), t, dH);
+            causal_conv_T<RW, 1>(dz, lp + off_conv_w(N, 0), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float g = dH[c] + g0[c];
                 dH[c] = valid ? (H[c] > 0.f ? g : g * LEAKY) : 0.f;               // d(theta pre-activation)
-                acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AX[c], acc_th, 0, 0, 0);
+                if constexpr (RW == 16) acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AX[c], acc_th, 0, 0, 0);
                 acc_b += dH[c];
             }
+            if constexpr (RW != 16) outer_grad_mfma<RW, F>(mywave, dH, AX, lane, acc_thg);
             if constexpr (LY > 0) {
                 float dAX[F], dXl[F];
 #pragma unroll
                 for (int c = 0; c < F; ++c) dAX[c] = 0.f;
-                R16::project10(dAX, dH, wldsT + (LY * TRW + t) * TWS, N);        // dHpre . theta
-                adj_aggregate_mfma(A, dAX, dXl);                                   // A is symmetric: A^T = A
+                R16::project10(dAX, dH, w_tr + t * TWS, N);                         // dHpre . theta
+                if constexpr (RW == 16) adj_aggregate_mfma(A, dAX, dXl); else adj_aggregate(A, dAX, dXl);   // A is symmetric: A^T = A
                 float* rb = a.rbuf + tile * tile_floats + lane;
                 constexpr int lq = LY - 1;
                 const float* ps = a.psave + (size_t)lq * a.ntiles * tile_floats + tile * tile_floats + lane;
@@ -415,7 +482,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
             }
             pooled = valid ? pooled : 0.f;
             float y1 = vecs[L * TRW + t];
-            R16::project1(y1, pooled, wlds + (L * TRW + t) * TWS, N);
+            R16::project1(y1, pooled, w_aux + t * TWS, N);
             y1 = relu(y1);
             const float w2 = vecs[(L + 1) * TRW + t];
             const float pred = R16::allsum(y1 * w2) + fc2_b;
@@ -433,11 +500,16 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
             if (!a.do_backward) continue;
             const float dy1 = (y1 > 0.f) ? dpred * w2 : 0.f;                       // d(fc1 pre-activation), lane j
             float dpool = 0.f;
-            R16::project1(dpool, dy1, wldsT + (L * TRW + t) * TWS, N);             // sum_j dy1[j] fc1.w[j][t]
+            R16::project1(dpool, dy1, w_tr + t * TWS, N);                          // sum_j dy1[j] fc1.w[j][t]
             acc_w2 = fmaf(dpred, y1, acc_w2);
             acc_b2 += (t == 0) ? dpred : 0.f;
             acc_b += dy1;
-            acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dy1, pooled, acc_th, 0, 0, 0);   // d fc1.w[j][t]
+            if constexpr (RW == 16) {
+                acc_th = __builtin_amdgcn_mfma_f32_16x16x4f32(dy1, pooled, acc_th, 0, 0, 0);   // d fc1.w[j][t]
+            } else {
+                const float p1[1] = {dy1}, q1[1] = {pooled};
+                outer_grad_mfma<RW, 1>(mywave, p1, q1, lane, acc_thg);
+            }
             float* rb = a.rbuf + tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) {
@@ -483,7 +555,7 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 conv_wgrad_mfma(mywave, dz, o0, hs, lane, acc_c0, acc_c1);
             }
             float d_o0[F];
-            causal_conv_T<2>(dz, lp + off_conv_w(N, 1), t, d_o0);
+            causal_conv_T<RW, 2>(dz, lp + off_conv_w(N, 1), t, d_o0);
             float* sb = a.sbuf + tile * tile_floats + lane;
 #pragma unroll
             for (int c = 0; c < F; ++c) {
@@ -541,29 +613,50 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
     for (int w = 0; w < WAVES_PER_BLOCK; ++w) {
         if (wave == w) {
             float* r = red + lane;
-            const float v[RED_K] = {acc_th[0], acc_th[1], acc_th[2], acc_th[3], acc_c0[0], acc_c0[1], acc_c0[2], acc_c0[3],
-                                    acc_c1[0], acc_c1[1], acc_c1[2], acc_c1[3], acc_b, acc_w2, acc_b2};
+            const float v[15] = {acc_th[0], acc_th[1], acc_th[2], acc_th[3], acc_c0[0], acc_c0[1], acc_c0[2], acc_c0[3],
+                                 acc_c1[0], acc_c1[1], acc_c1[2], acc_c1[3], acc_b, acc_w2, acc_b2};
 #pragma unroll
-            for (int k = 0; k < RED_K; ++k) r[k * 64] = (w == 0) ? v[k] : r[k * 64] + v[k];
+            for (int k = 0; k < 15; ++k) r[k * 64] = (w == 0) ? v[k] : r[k * 64] + v[k];
+            if constexpr (RW != 16) {
+#pragma unroll
+                for (int q = 0; q < NTH; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 15 + q * 4 + e;
+                        r[k * 64] = (w == 0) ? acc_thg[q][e] : r[k * 64] + acc_thg[q][e];
+                    }
+            }
         }
         __syncthreads();
     }
-    if (KIND == PH_TOP) {
-        // fc1.weight[j][k]: MFMA D layout -> row j = 4*(lane>>4) + reg, column k = lane & 15
-        for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
-            const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
-            if (j < N && k < N) row[off_fc1_w(N, L) + j * N + k] = red[rg * 64 + ln];
+    // [N][N] matrix gradient (theta or fc1): MFMA D layout -> row j = 16m + 4*(lane>>4) + reg, column k = 16n + (lane & 15)
+    auto write_matrix = [&](float* dst) {
+        if constexpr (RW == 16) {
+            for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
+                const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
+                if (j < N && k < N) dst[j * N + k] = red[rg * 64 + ln];
+            }
+        } else {
+            constexpr int NT = RW / 16;
+            for (int i = threadIdx.x; i < NTH * 4 * 64; i += BLOCK) {
+                const int q = i / 256, rg = (i / 64) % 4, ln = i % 64;
+                const int j = 16 * (q / NT) + 4 * (ln >> 4) + rg, k = 16 * (q % NT) + (ln & 15);
+                if (j < N && k < N) dst[j * N + k] = red[(15 + q * 4 + rg) * 64 + ln];
+            }
         }
+    };
+    if (KIND == PH_TOP) {
+        write_matrix(row + off_fc1_w(N, L));
         if (threadIdx.x < N) {
             const int j = threadIdx.x;
             float vb = 0.f, vw = 0.f;
-            for (int s = 0; s < TSPW; ++s) { vb += red[12 * 64 + s * 16 + j]; vw += red[13 * 64 + s * 16 + j]; }
+            for (int s = 0; s < TSPW; ++s) { vb += red[12 * 64 + s * TRW + j]; vw += red[13 * 64 + s * TRW + j]; }
             row[off_fc1_b(N, L) + j] = vb;
             row[off_fc2_w(N, L) + j] = vw;
         }
         if (threadIdx.x == 0) {
             float v = 0.f;
-            for (int s = 0; s < TSPW; ++s) v += red[14 * 64 + s * 16];
+            for (int s = 0; s < TSPW; ++s) v += red[14 * 64 + s * TRW];
             row[off_fc2_b(N, L)] = v;
         }
     }
@@ -581,13 +674,10 @@ __global__ __launch_bounds__(BLOCK, 2) void stgcn_train_phase_kernel(const float
                 lrow[off_conv_w(N, blk) + (co * F + ci) * 2 + tap] = red[(4 + which * 4 + rg) * 64 + ln];
         }
         if (blk == 0) {
-            for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
-                const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
-                if (j < N && k < N) lrow[off_theta_w(N) + j * N + k] = red[rg * 64 + ln];
-            }
+            write_matrix(lrow + off_theta_w(N));
             if (threadIdx.x < N) {
                 float vb = 0.f;
-                for (int s = 0; s < TSPW; ++s) vb += red[12 * 64 + s * 16 + threadIdx.x];
+                for (int s = 0; s < TSPW; ++s) vb += red[12 * 64 + s * TRW + threadIdx.x];
                 lrow[off_theta_b(N) + threadIdx.x] = vb;
             }
         }
@@ -683,12 +773,26 @@ static int max_resident_blocks() {
     return cus * 8;
 }
 
+// training geometry: RW 16 for num_patch <= 16, else one sample per wavefront (RW 64)
+static int train_geometry(const rulgnn_stgcn_shape* s, TileGeom* g) {
+    const int rc = tile_geometry(s, g);
+    if (rc != RULGNN_OK) return rc;
+    if (g->RW != 16) {
+        g->RW = 64;
+        g->SPW = 1;
+        const int raw = s->num_patch * g->Ppad;
+        g->stage_floats = (raw + 3) & ~3;
+    }
+    g->ntiles = (s->batch + g->SPW - 1) / g->SPW;
+    return RULGNN_OK;
+}
+
 static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* w) {
     const int L = s->num_layers, N = s->num_patch;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
-    w->off_cacheA = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
+    w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
     w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
@@ -702,11 +806,9 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
 }
 
 size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
-    rulgnn_stgcn_shape tmp = *s;
     TileGeom g;
-    if (tile_geometry(&tmp, &g) != RULGNN_OK) return 0;
-    if (g.RW != TRW || s->num_layers > 3) return 0;
-    g.ntiles = (s->batch + TSPW - 1) / TSPW;
+    if (train_geometry(s, &g) != RULGNN_OK) return 0;
+    if (s->num_layers > 3 || (g.RW != 16 && s->num_layers > 2)) return 0;
     WsLayout w;
     ws_layout(s, g, &w);
     return w.total;
@@ -715,23 +817,23 @@ size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
 static int wave_area_for(int kind, int idx, const TileGeom& g) {
     if (kind == PH_F) return idx == 0 ? g.stage_floats : 0;
     if (kind == PH_G) return TT_ROWS * TT_STRIDE;
-    return 0;
+    return g.RW == 16 ? 0 : TT_ROWS * TT_STRIDE;          // TOP, generic row width: fc1 gradient through the transpose tile
 }
 
-static size_t train_lds_bytes(int L, int wave_area) {
-    const size_t fl = (size_t)2 * (L + 1) * TRW * TWS + (size_t)(L + 2) * TRW + (size_t)((2 * L * BNC * F + 3) & ~3) +
-                      (size_t)15 * 64 + (size_t)WAVES_PER_BLOCK * 24 +
-                      (size_t)WAVES_PER_BLOCK * wave_area;
+static size_t train_lds_bytes(int RW, int L, int wave_area) {
+    const int tws = RW + 4, nth = RW == 16 ? 0 : (RW / 16) * (RW / 16);
+    const size_t fl = (size_t)3 * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
+                      (size_t)(15 + 4 * nth) * 64 + (size_t)WAVES_PER_BLOCK * 24 + (size_t)WAVES_PER_BLOCK * wave_area;
     return fl * sizeof(float);
 }
 
-template <int L, int KIND, int IDX>
+template <int RW, int L, int KIND, int IDX>
 static int launch_phase(const TrainK& k_in, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                         hipStream_t stream, int* grid_out) {
-    auto kern = stgcn_train_phase_kernel<L, KIND, IDX>;
+    auto kern = stgcn_train_phase_kernel<RW, L, KIND, IDX>;
     TrainK k = k_in;
     k.wave_area_floats = wave_area_for(KIND, IDX, g);
-    const size_t lds = train_lds_bytes(L, k.wave_area_floats);
+    const size_t lds = train_lds_bytes(RW, L, k.wave_area_floats);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -748,20 +850,20 @@ static int launch_phase(const TrainK& k_in, const float* x, const float* prm, co
 
 enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
 
-template <int L, int I>
+template <int RW, int L, int I>
 struct PhaseChain {
     static int forward_stats(const TrainK& k, const float* x, const float* prm, const TileGeom& lds, int mg, hipStream_t st) {
         if constexpr (I > 0) {
-            const int rc = PhaseChain<L, I - 1>::forward_stats(k, x, prm, lds, mg, st);
+            const int rc = PhaseChain<RW, L, I - 1>::forward_stats(k, x, prm, lds, mg, st);
             if (rc != RULGNN_OK) return rc;
         }
-        return launch_phase<L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
+        return launch_phase<RW, L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
     }
     static int backward(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& lds, int mg, hipStream_t st,
                         int* grids) {
-        const int rc = launch_phase<L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
+        const int rc = launch_phase<RW, L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
         if (rc != RULGNN_OK) return rc;
-        if constexpr (I > 0) return PhaseChain<L, I - 1>::backward(k, x, prm, gy, lds, mg, st, grids);
+        if constexpr (I > 0) return PhaseChain<RW, L, I - 1>::backward(k, x, prm, gy, lds, mg, st, grids);
         return RULGNN_OK;
     }
 };
@@ -770,10 +872,9 @@ template <int L>
 static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, TrainK* kp, WsLayout* wp,
                        TileGeom* ldsp) {
     TileGeom& g = *ldsp;
-    int rc = tile_geometry(s, &g);
+    int rc = train_geometry(s, &g);
     if (rc != RULGNN_OK) return rc;
-    if (g.RW != TRW) return RULGNN_EUNSUPPORTED;            // training kernels cover num_patch <= 16 (C-MAPSS shapes)
-    g.ntiles = (s->batch + TSPW - 1) / TSPW;
+    if (g.RW != 16 && L > 2) return RULGNN_EUNSUPPORTED;
     WsLayout& w = *wp;
     ws_layout(s, g, &w);
     if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
@@ -813,18 +914,15 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     return RULGNN_OK;
 }
 
-template <int L>
-static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
-    TrainK k;
-    WsLayout w;
-    TileGeom lds;
-    int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
-    if (rc != RULGNN_OK) return rc;
+template <int RW, int L>
+static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
+                        TrainK& k, WsLayout& w, TileGeom& lds) {
+    int rc = RULGNN_OK;
     const float* gy = a->dpred ? a->dpred : a->y;
 
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
         if (hipMemsetAsync(k.cells_fwd, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
-        rc = PhaseChain<L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
+        rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
         if (rc != RULGNN_OK) return rc;
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
@@ -832,10 +930,10 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     }
     int grid_top = 0;
     int grids[16] = {0};
-    rc = launch_phase<L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);
+    rc = launch_phase<RW, L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);
     if (rc != RULGNN_OK) return rc;
     if (mode != TM_FORWARD) {
-        rc = PhaseChain<L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids);
+        rc = PhaseChain<RW, L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids);
         if (rc != RULGNN_OK) return rc;
     }
     FinalizeK f;
@@ -853,18 +951,30 @@ static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
+template <int L>
+static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+    TrainK k;
+    WsLayout w;
+    TileGeom lds;
+    const int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
+    if (rc != RULGNN_OK) return rc;
+    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds);
+    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds);
+    return RULGNN_EUNSUPPORTED;
+}
+
 // One phase kernel alone (profiling / roofline timing): the reduction cells are NOT cleared, so
 // repeated launches keep accumulating into them -- durations are valid, results are not.
-template <int L, int PHASE>
+template <int RW, int L, int PHASE>
 struct SinglePhase {
     static int run(int phase, const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& lds, int mg,
                    hipStream_t st) {
         if (phase == PHASE) {
-            if constexpr (PHASE < 2 * L) return launch_phase<L, PH_F, PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
-            else if constexpr (PHASE == 2 * L) return launch_phase<L, PH_TOP, 0>(k, x, prm, gy, lds, mg, st, nullptr);
-            else return launch_phase<L, PH_G, 4 * L - PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
+            if constexpr (PHASE < 2 * L) return launch_phase<RW, L, PH_F, PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
+            else if constexpr (PHASE == 2 * L) return launch_phase<RW, L, PH_TOP, 0>(k, x, prm, gy, lds, mg, st, nullptr);
+            else return launch_phase<RW, L, PH_G, 4 * L - PHASE>(k, x, prm, gy, lds, mg, st, nullptr);
         }
-        if constexpr (PHASE > 0) return SinglePhase<L, PHASE - 1>::run(phase, k, x, prm, gy, lds, mg, st);
+        if constexpr (PHASE > 0) return SinglePhase<RW, L, PHASE - 1>::run(phase, k, x, prm, gy, lds, mg, st);
         return RULGNN_EINVAL;
     }
 };
@@ -878,7 +988,9 @@ static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     if (rc != RULGNN_OK) return rc;
     if (phase < 0 || phase > 4 * L) return RULGNN_EINVAL;
     const float* gy = a->dpred ? a->dpred : a->y;
-    return SinglePhase<L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
+    if (lds.RW == 16) return SinglePhase<16, L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
+    if constexpr (L <= 2) return SinglePhase<64, L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
+    return RULGNN_EUNSUPPORTED;
 }
 
 int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {

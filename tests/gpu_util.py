@@ -25,7 +25,7 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def shape_struct(batch, N, P, L=2, k=1):
+def shape_struct(batch, N, P, L=2, k=1):  # noqa: E741
     return _lib.StgcnShape(batch, N, P, L, k)
 
 

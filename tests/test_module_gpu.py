@@ -101,10 +101,16 @@ def test_sync_loss_false_returns_device_tensor_and_train_mode_is_required():
     assert torch.isfinite(out)
 
 
-def test_training_unsupported_shape_raises_clearly():
-    m = ST_GCN_model(40, 64).to(DEV).train()          # PHM2012 shape: eval is covered, training is not yet
-    with pytest.raises(RuntimeError, match="num_patch"):
-        m(torch.rand(8, 1, 2560, device=DEV))
-    m.eval()
+def test_phm2012_shape_trains_and_unsupported_shape_raises_clearly():
+    """Reference-wired PHM2012 Condition_1 hparams (configs/hparams.py:238): [bs, 1, 2560] -> 40 patches of 64."""
+    algo = ST_GCN({"num_patch": 40, "patch_size": 64, "dropout": 0.2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, DEV)
+    algo.to(DEV).train()
+    x, y = torch.rand(50, 1, 2560, device=DEV), torch.rand(50, 1, device=DEV)
+    losses = [algo.update(x, y, 1)["loss"] for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    algo.eval()
     with torch.no_grad():
-        assert m(torch.rand(8, 1, 2560, device=DEV)).shape == (8, 1)
+        assert algo.model(x).shape == (50, 1)
+    big = ST_GCN_model(160, 16).to(DEV).train()       # PHM2012 Condition_2: num_patch > 64 is not covered
+    with pytest.raises(RuntimeError, match="num_patch"):
+        big(torch.rand(8, 1, 2560, device=DEV))
