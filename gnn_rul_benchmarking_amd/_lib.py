@@ -28,6 +28,12 @@ class StgcnTrainArgs(C.Structure):
                 ("bn_moment_weight", C.c_float)]
 
 
+class AdamArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("bn_stats", C.c_void_p),
+                ("step", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("bn_momentum", C.c_float)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -38,6 +44,8 @@ _SIGNATURES = {
     "rulgnn_stgcn_train_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_backward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_fwdbwd_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_step_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs),
+                                               C.c_void_p]),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
     "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,

@@ -63,8 +63,7 @@ class ST_GCN(Algorithm):
         if not model.training:
             raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
         if self.dp is None:
-            _, loss = model.fused_mse_step(X, y)
-            self.optimizer.step(from_bucket=True)
+            _, loss = model.fused_train_step(X, y, self.optimizer)      # one C call: fwd + MSE + bwd + Adam + BN stats
         else:
             loss = self.dp.step(model, self.optimizer, X, y, global_batch, sample_offset)
         return {'loss': loss.item() if self.sync_loss else loss}

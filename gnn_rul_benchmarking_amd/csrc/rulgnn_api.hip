@@ -91,6 +91,18 @@ int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_
     return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
 }
 
+int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
+                                const rulgnn_adam_args* opt, void* stream) {
+    int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (!opt || opt->step < 1 || args->dpred) return RULGNN_EINVAL;
+    if (opt->params != args->params) return RULGNN_EINVAL;
+    rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+    if (rc != RULGNN_OK) return rc;
+    if (opt->bn_stats && (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3)) return RULGNN_EALIGN;
+    return stgcn_train_step(shape, args, opt, static_cast<hipStream_t>(stream));
+}
+
 int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }
 
 int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, int32_t phase,

@@ -168,7 +168,7 @@ __device__ __forceinline__ void outer_grad_mfma(float* T, const float (&P)[NC], 
 // ------------------------------------------------------------------------------------------------
 // IDX: BatchNorm index (0 .. 2L-1) for F and G kernels; unused for TOP.
 template <int RW, int L, int KIND, int IDX>
-__global__ __launch_bounds__(BLOCK, RW == 16 ? 2 : 1) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+__global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy,   // y or dpred (TOP only)
                                                                   TrainK a) {
@@ -701,6 +701,14 @@ struct FinalizeK {
     int64_t B, global_batch;
     int write_grads, write_loss;
     float moment_weight;
+    // optional fused optimizer (single-GPU step): Adam on the parameter this wavefront just reduced, BatchNorm
+    // running statistics from the batch statistics block 0 just finished
+    float* params;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* bn_running;
+    float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, bn_momentum;
+    int fused_opt;
 };
 
 __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
@@ -726,15 +734,26 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
                     if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
                 }
             }
+            float v = 0.f;
             if (from_cells) {
                 // d gamma = sum dy*xhat, d beta = sum dy
-                if (lane == 0) f.grads[p] = (float)f.cells_bwd[(bn * 2 + (which == 0 ? 1 : 0)) * F + c];
-                continue;
+                v = (float)f.cells_bwd[(bn * 2 + (which == 0 ? 1 : 0)) * F + c];
+            } else {
+                for (int b = lane; b < nblk; b += 64) v += f.gpart[(size_t)b * f.pcount + p];
+                v = wave_sum(v);
             }
-            float v = 0.f;
-            for (int b = lane; b < nblk; b += 64) v += f.gpart[(size_t)b * f.pcount + p];
-            v = wave_sum(v);
-            if (lane == 0) f.grads[p] = v;
+            if (lane == 0) {
+                f.grads[p] = v;
+                if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
+                    const float pi = f.params[p];
+                    const float gi = fmaf(f.weight_decay, pi, v);
+                    const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
+                    const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
+                    f.exp_avg[p] = mi;
+                    f.exp_avg_sq[p] = vi;
+                    f.params[p] = pi - f.lr_over_bc1 * (mi / (sqrtf(vi) * f.inv_sqrt_bc2 + f.eps));
+                }
+            }
         }
     }
     if (blockIdx.x == 0) {
@@ -750,6 +769,13 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
             } else {
                 f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
                 f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
+            }
+            if (f.fused_opt && f.bn_running) {          // nn.BatchNorm1d running statistics (unbiased running variance)
+                const float unbias = cnt > 1.0 ? (float)(cnt / (cnt - 1.0)) : 1.f;
+                float* rm = f.bn_running + (b * 2 + 0) * F + c;
+                float* rv = f.bn_running + (b * 2 + 1) * F + c;
+                *rm = (1.f - f.bn_momentum) * *rm + f.bn_momentum * (float)mean;
+                *rv = (1.f - f.bn_momentum) * *rv + f.bn_momentum * ((float)var * unbias);
             }
         }
     }
@@ -916,7 +942,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 
 template <int RW, int L>
 static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                        TrainK& k, WsLayout& w, TileGeom& lds) {
+                        TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt) {
     int rc = RULGNN_OK;
     const float* gy = a->dpred ? a->dpred : a->y;
 
@@ -943,6 +969,18 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
+    f.fused_opt = 0;
+    f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
+    f.lr_over_bc1 = f.inv_sqrt_bc2 = f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
+    if (opt && mode == TM_FWDBWD) {
+        const double bc1 = 1.0 - pow((double)opt->beta1, (double)opt->step);
+        const double bc2 = 1.0 - pow((double)opt->beta2, (double)opt->step);
+        f.fused_opt = 1;
+        f.params = opt->params; f.exp_avg = opt->exp_avg; f.exp_avg_sq = opt->exp_avg_sq; f.bn_running = opt->bn_stats;
+        f.lr_over_bc1 = (float)((double)opt->lr / bc1); f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        f.beta1 = opt->beta1; f.beta2 = opt->beta2; f.eps = opt->eps; f.weight_decay = opt->weight_decay;
+        f.bn_momentum = opt->bn_momentum;
+    }
     f.write_grads = mode != TM_FORWARD;
     f.write_loss = (k.has_dpred == 0) && a->loss;
     const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;
@@ -952,14 +990,15 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
 }
 
 template <int L>
-static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
+                     const rulgnn_adam_args* opt) {
     TrainK k;
     WsLayout w;
     TileGeom lds;
     const int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
-    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds);
-    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds);
+    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds, opt);
+    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds, opt);
     return RULGNN_EUNSUPPORTED;
 }
 
@@ -1002,13 +1041,19 @@ int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     }
 }
 
-static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream) {
+static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
+                          const rulgnn_adam_args* opt = nullptr) {
     switch (s->num_layers) {
-        case 1: return run_train<1>(s, a, mode, stream);
-        case 2: return run_train<2>(s, a, mode, stream);
-        case 3: return run_train<3>(s, a, mode, stream);
+        case 1: return run_train<1>(s, a, mode, stream, opt);
+        case 2: return run_train<2>(s, a, mode, stream, opt);
+        case 3: return run_train<3>(s, a, mode, stream, opt);
         default: return RULGNN_EUNSUPPORTED;
     }
+}
+
+int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const rulgnn_adam_args* opt,
+                     hipStream_t st) {
+    return dispatch_train(s, a, TM_FWDBWD, st, opt);
 }
 
 int stgcn_train_forward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {

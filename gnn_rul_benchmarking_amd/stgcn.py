@@ -295,6 +295,27 @@ class ST_GCN_model(nn.Module):
             self._after_train_forward(x2d.size(0))
         return self._pred_buf, self._grad_flat[self.num_live]
 
+    def fused_train_step(self, x, y, optimizer):
+        """The whole ``ST_GCN.update`` body in ONE C call (single GPU): forward, MSE, backward, and -- inside the
+        kernel that finalises the gradient -- Adam and the BatchNorm running statistics."""
+        x2d = self._check_input(x)
+        yv = y.reshape(-1).contiguous().float()
+        if yv.numel() != x2d.size(0):
+            raise RuntimeError("target size mismatch")
+        self._step += 1
+        shp = self._shape(x2d.size(0))
+        a = self._train_args(shp, x2d, yv, None, self._step)
+        m, v = optimizer._state_buffers()
+        optimizer._steps += 1
+        g = optimizer.param_groups[0]
+        o = _lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
+                          float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                          float(g["weight_decay"]), 0.1)
+        _lib.check(_lib.load().rulgnn_stgcn_train_step_f32(C.byref(shp), C.byref(a), C.byref(o), _stream()),
+                   "rulgnn_stgcn_train_step_f32")
+        self._nbt_pending += 1
+        return self._pred_buf, self._grad_flat[self.num_live]
+
     # ---- nn.Module surface -------------------------------------------------------------------------------
     def forward(self, x):
         x2d = self._check_input(x)

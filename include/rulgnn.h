@@ -106,6 +106,22 @@ int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape *shape, const rulgn
 int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                   void *stream);
 
+/* Single-GPU fast path: rulgnn_stgcn_train_fwdbwd_f32 with the optimizer folded into its last kernel --
+ * the whole body of ST_GCN.update (algorithms/algorithms.py:482-489) in one call: the kernel that
+ * reduces the per-block gradient partials applies torch.optim.Adam to each parameter as its gradient
+ * becomes final, and updates the BatchNorm running statistics.  args->grads still receives the gradient. */
+typedef struct rulgnn_adam_args {
+    float *params;           /* flat live parameters, updated in place (same buffer as args->params) */
+    float *exp_avg;          /* Adam first moment, flat */
+    float *exp_avg_sq;       /* Adam second moment, flat */
+    float *bn_stats;         /* BatchNorm running statistics, updated in place (may be NULL) */
+    int64_t step;            /* 1-based step count after this update */
+    float lr, beta1, beta2, eps, weight_decay;
+    float bn_momentum;       /* 0.1 for nn.BatchNorm1d */
+} rulgnn_adam_args;
+int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                const rulgnn_adam_args *opt, void *stream);
+
 /* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
  * backward), 2L+1+j = G_{2L-1-j} (BatchNorm/conv/theta backward).  rulgnn_stgcn_train_phase_f32 launches
