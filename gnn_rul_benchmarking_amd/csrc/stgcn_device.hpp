@@ -317,18 +317,16 @@ __device__ __forceinline__ void causal_conv(const float (&h)[F], const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// Causal conv on the matrix cores (row width 16 only).
+// 4-block MFMA building blocks (row width 16 only).
 //
 // v_mfma_f32_16x16x1_4b_f32 computes, for each of the four 16-lane blocks b INDEPENDENTLY,
-// D_b[i][j] += A_b[i] * B_b[j].  With one sample per 16-lane row that is exactly one tap of the
-// conv for all four samples of the wavefront at once:
-//     A = column k of the weight matrix laid along the lanes (lane i of every row holds W[i][k]),
-//     B = the row-mapped activation register of input channel ci (tap 1) or its row_shr copy (tap 0),
-// and the 20 (ci, tap) products accumulate in the MFMA accumulator -- no wave-uniform weights (no
-// scalar loads to wait for), no VALU FMAs.  Measured layout (tools/probe_mfma4b.hip): acc[4b + r] in
-// lane (g = lane>>4, j = lane&15) is D_b[4g + r][j]; bringing it back to the row mapping (sample b in
-// lane row b, channel in the register index) is a 4x4 transpose between register index and lane row,
-// done with v_permlane32_swap + v_permlane16_swap (4 swaps per group of four registers).
+// D_b[i][j] += A_b[i] * B_b[j]: with one sample per 16-lane row, one instruction is an outer-product
+// update for all four samples of the wavefront at once.  Measured layout (tools/probe_mfma4b.hip):
+// acc[4b + r] in lane (g = lane>>4, j = lane&15) is D_b[4g + r][j]; bringing it back to the row mapping
+// (sample b in lane row b, matrix row in the register index) is a 4x4 transpose between register index
+// and lane row, done with v_permlane32_swap + v_permlane16_swap (4 swaps per group of four registers).
+// (A conv and a theta projection built on this were measured slower than the DPP/scalar-weight
+// versions and are not kept: profiles/r01_ubench_gfx950.md.)
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -419,40 +417,6 @@ __device__ __forceinline__ void adj_aggregate_mfma(const float (&Arow)[F], const
 #pragma unroll
     for (int c = 0; c < F; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(Arow[c], X[c], acc, 0, 0, 0);
     acc_to_rows(acc, AX);
-}
-
-constexpr int CONV_ROW = 2 * F;   // one LDS weight row: 20 floats, index 2*c + tap
-
-// Forward (TRANSPOSED = false): out[co][t] = sum_ci w[co][ci][0] h[ci][t-D] + w[co][ci][1] h[ci][t];
-//   wrow = this lane's row (lane&15 = co) of the [16][20] table  W[co][2*ci + tap]   (rows >= 10 zero).
-// Transposed (backward data): out[ci][t] = sum_co w[co][ci][1] dz[co][t] + w[co][ci][0] dz[co][t+D];
-//   wrow = row (lane&15 = ci) of the table  WT[ci][2*co + tap] = w[co][ci][tap].
-template <int D, bool TRANSPOSED>
-__device__ __forceinline__ void causal_conv_mfma(const float (&h)[F], const float* wrow, float (&out)[F]) {
-    const float4* w4 = reinterpret_cast<const float4*>(wrow);
-    const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3], we = w4[4];
-    const float w[CONV_ROW] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x, wc.y,
-                               wc.z, wc.w, wd.x, wd.y, wd.z, wd.w, we.x, we.y, we.z, we.w};
-    float hs[F];
-#pragma unroll
-    for (int c = 0; c < F; ++c) hs[c] = TRANSPOSED ? dpp<DPP_ROW_SHL + D>(h[c]) : dpp<DPP_ROW_SHR + D>(h[c]);
-    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < F; ++c) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w[2 * c + 0], hs[c], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x1f32(w[2 * c + 1], h[c], acc, 0, 0, 0);
-    }
-    acc_to_rows(acc, out);
-}
-
-// fill one [16][CONV_ROW] LDS table from a [10][10][2] conv weight (block-cooperative)
-__device__ __forceinline__ void stage_conv_table(float* tab, const float* __restrict__ w, bool transposed, int tid, int nthreads) {
-    for (int i = tid; i < 16 * CONV_ROW; i += nthreads) {
-        const int row = i / CONV_ROW, k = i % CONV_ROW, c = k >> 1, tap = k & 1;
-        float v = 0.f;
-        if (row < F) v = transposed ? w[(c * F + row) * 2 + tap] : w[(row * F + c) * 2 + tap];
-        tab[i] = v;
-    }
 }
 
 // 32-bit mix shared bit-for-bit with oracle/stgcn_oracle.py::_lowbias32

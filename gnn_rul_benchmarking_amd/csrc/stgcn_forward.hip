@@ -5,9 +5,6 @@
 #include "stgcn_device.hpp"
 #include "stgcn_host.hpp"
 
-#ifndef RULGNN_CONV_MFMA
-#define RULGNN_CONV_MFMA 0  // bit0: conv_block1 on the matrix cores, bit1: conv_block2 (row width 16)
-#endif
 #ifndef RULGNN_ABLATE
 #define RULGNN_ABLATE 0     // development only: bit0 skip stats, bit1 skip Pearson, bit2 skip theta, bit3 skip convs, bit4 skip A.X
 #endif
@@ -37,8 +34,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     float* wlds = smem;                          // [L+1][RW][WS] theta rows per layer, then fc1 rows
     float* bnf = wlds + (L + 1) * RW * WS;       // [L][2][2][F]   folded BatchNorm scale / shift
     float* vecs = bnf + L * 4 * F;               // [L+2][RW]      theta bias per layer, fc1 bias, fc2 weight
-    float* convt = vecs + (L + 2) * RW;          // [L][2][16][CONV_ROW] conv weight rows for the MFMA conv (RW == 16)
-    float* stage_all = convt + (RW == 16 ? L * 2 * 16 * CONV_ROW : 0);
+    float* stage_all = vecs + (L + 2) * RW;
 
     // ---- block prologue: weights that vary per lane go to LDS, zero padded to the row width ----
     for (int i = threadIdx.x; i < (L + 1) * RW * RW; i += BLOCK) {
@@ -59,10 +55,6 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
         const float sc = g / sqrtf(var + BN_EPS);
         bnf[((l * 2 + blk) * 2 + 0) * F + c] = sc;
         bnf[((l * 2 + blk) * 2 + 1) * F + c] = b - mean * sc;
-    }
-    if constexpr (RW == 16) {
-        for (int m = 0; m < L * 2; ++m)
-            stage_conv_table(convt + m * 16 * CONV_ROW, prm + (m / 2) * LS + off_conv_w(N, m % 2), false, threadIdx.x, BLOCK);
     }
     __syncthreads();
 
@@ -128,8 +120,6 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
             if constexpr (RULGNN_ABLATE & 8) {
 #pragma unroll
                 for (int c = 0; c < F; ++c) z[c] = H[c] * lp[off_conv_w(N, 0) + c];
-            } else if constexpr (RW == 16 && (RULGNN_CONV_MFMA & 1)) {
-                causal_conv_mfma<1, false>(H, convt + ((l * 2 + 0) * 16 + t) * CONV_ROW, z);
             } else {
                 causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);         // conv_block1, Model.py:134-146
             }
@@ -138,8 +128,6 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
             if constexpr (RULGNN_ABLATE & 8) {
 #pragma unroll
                 for (int c = 0; c < F; ++c) z[c] = o0[c] * lp[off_conv_w(N, 1) + c];
-            } else if constexpr (RW == 16 && (RULGNN_CONV_MFMA & 2)) {
-                causal_conv_mfma<2, false>(o0, convt + ((l * 2 + 1) * 16 + t) * CONV_ROW, z);
             } else {
                 causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);        // conv_block2 (dilation 2), Model.py:148-160
             }
@@ -171,7 +159,6 @@ static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const 
     a.stage_floats = g.stage_floats;
     constexpr int WS = wstride<RW>();
     const size_t lds = sizeof(float) * ((size_t)(a.L + 1) * RW * WS + (size_t)a.L * 4 * F + (size_t)(a.L + 2) * RW +
-                                        (size_t)(RW == 16 ? a.L * 2 * 16 * CONV_ROW : 0) +
                                         (size_t)WAVES_PER_BLOCK * g.stage_floats);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
