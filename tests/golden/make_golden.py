@@ -37,6 +37,8 @@ from algorithms.algorithms import get_algorithm_class  # noqa: E402
 import utils as ref_utils                              # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from synth import synthetic_phm2012  # noqa: E402
 torch.set_num_threads(1)
 
 
@@ -175,6 +177,85 @@ def case_init(name, num_patch, patch_size, seed):
     print("wrote", name, len(m.state_dict()))
 
 
+def case_trainer_phm2012(name, seed, n_train=200, n_test=60, epochs=3):
+    """The reference's OWN harness (main.py -> trainer.GNN_RUL_trainer) on a synthetic PHM2012/Condition_1
+    dataset with its own ST_GCN hparams (configs/hparams.py:223,238); only num_epochs and dropout are
+    patched on the in-memory dicts (dropout 1e-12 = off, see DROPOUT_OFF).  Records every epoch's test metrics."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    import dataloader.dataloader as ref_dl
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "PHM2012", "Condition_1")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="ST_GCN", data_path=os.path.join(tmp, "data"), dataset="PHM2012",
+                                      dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            tr.model_configs["dropout"] = DROPOUT_OFF
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "ST_GCN_run_0", "results.csv")).read()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum()), "x_test_checksum": np.float64(xte.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.fc1.weight", "model.sg_tcn.layers.0.0.theta.0.weight", "model.sg_tcn.layers.1.1.conv_block2.2.running_var"):
+        out["final:" + k] = final[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
+def case_layers(name, num_layers, seed):
+    """num_layers != 2 (the reference constructor accepts it, Model.py:198): eval + train-mode gradients."""
+    torch.manual_seed(seed)
+    m = ref_model.ST_GCN_model(14, 30, num_layers=num_layers, dropout=DROPOUT_OFF)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n_, b in m.named_buffers():
+            if n_.endswith("running_mean"):
+                b.copy_(torch.empty_like(b).uniform_(-0.2, 0.2, generator=g))
+            elif n_.endswith("running_var"):
+                b.copy_(torch.empty_like(b).uniform_(0.5, 1.5, generator=g))
+    x = torch.rand(21, 14, 30, generator=g)
+    y = torch.rand(21, 1, generator=g)
+    out = {"x": x.numpy().copy(), "y": y.numpy().copy(), "num_layers": np.int64(num_layers)}
+    for k, v in state_np(m, "sd:").items():
+        out[k] = v
+    m.eval()
+    with torch.no_grad():
+        out["eval_pred"] = m(x).numpy().copy()
+    m.train()
+    pred = m(x)
+    loss = torch.nn.functional.mse_loss(pred, y)
+    loss.backward()
+    out["train_pred"], out["train_loss"] = pred.detach().numpy().copy(), np.float64(loss.item())
+    for n_, p in m.named_parameters():
+        if p.grad is not None:
+            out["grad:" + n_] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name)
+
+
 def case_metrics(name, seed):
     rng = np.random.default_rng(seed)
     pred = rng.uniform(0, 1, 257)
@@ -200,3 +281,6 @@ if __name__ == "__main__":
     case_training_curve("stgcn_train_curve_14x30_bs32", 14, 30, 32, steps=24, seed=8, lr=1e-3, wd=1e-4)
     case_metrics("metrics_case", 9)
     case_init("stgcn_init_14x30_seed3", 14, 30, 3)
+    case_layers("stgcn_layers1_14x30_bs21", 1, 21)
+    case_layers("stgcn_layers3_14x30_bs21", 3, 22)
+    case_trainer_phm2012("trainer_phm2012_c1_reference_run", 5)

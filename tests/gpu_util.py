@@ -18,7 +18,7 @@ def load_case(name):
 
 
 FB_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stgcn_*x*_bs*.npz"))
-                  if "train_curve" not in p)
+                  if "train_curve" not in p and "layers" not in p)
 
 
 def stream_ptr():

@@ -13,7 +13,7 @@ from oracle import stgcn_oracle as O
 from conftest import GOLDEN
 
 FB_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stgcn_*x*_bs*.npz"))
-                  if "train_curve" not in p)
+                  if "train_curve" not in p and "layers" not in p)
 
 
 def load_case(name):
@@ -69,6 +69,21 @@ def test_train_forward_backward_matches_reference_autograd(name):
     new = O.bn_running_update(sd, fc, 2)
     for k, v in new.items():
         assert rel_err(v, z["sd_after:" + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("name,L", [("stgcn_layers1_14x30_bs21", 1), ("stgcn_layers3_14x30_bs21", 3)])
+def test_other_layer_counts_match_reference(name, L):
+    z, sd = load_case(name)
+    x = z["x"].astype(np.float64)
+    fc = O.forward(sd, x, 14, 30, L, train=False)
+    assert rel_err(fc.pred, z["eval_pred"]) < 1e-5
+    fc = O.forward(sd, x, 14, 30, L, train=True)
+    assert rel_err(fc.pred, z["train_pred"]) < 1e-5
+    loss, dpred = O.mse_loss_and_grad(fc.pred, z["y"].astype(np.float64))
+    assert abs(loss - float(z["train_loss"])) < 1e-5 * abs(float(z["train_loss"]))
+    g = O.backward(sd, fc, dpred)
+    for n in O.live_param_names(L):
+        assert rel_err(g[n].reshape(z["grad:" + n].shape), z["grad:" + n]) < 2e-4, n
 
 
 def test_training_curve_matches_reference_update():

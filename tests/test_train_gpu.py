@@ -78,6 +78,21 @@ def test_train_matches_oracle_seeded(N, P, B, L, p):
     check_grads(r["grads"], gref, N, L)
 
 
+@pytest.mark.parametrize("name,L", [("stgcn_layers1_14x30_bs21", 1), ("stgcn_layers3_14x30_bs21", 3)])
+def test_other_layer_counts_match_reference_autograd(name, L):
+    import gpu_util as G
+    z, sd = G.load_case(name)
+    flat, bn = PL.pack_numpy(sd, 14, L)
+    assert G.rel_err(G.abi_forward(z["x"], flat, bn, 14, 30, L=L), z["eval_pred"][:, 0]) < TOL
+    r = G.abi_train(z["x"], z["y"], flat, 14, 30, L=L)
+    assert G.rel_err(r["pred"], z["train_pred"][:, 0]) < TOL
+    assert abs(r["loss"] - float(z["train_loss"])) < TOL * abs(float(z["train_loss"]))
+    ref = np.zeros_like(flat)
+    for pname, (off, shape) in PL.live_param_layout(14, L).items():
+        ref[off:off + int(np.prod(shape))] = z["grad:" + pname].reshape(-1)
+    check_grads(r["grads"], ref, 14, L)
+
+
 def test_train_forward_only_and_upstream_gradient():
     """The autograd-style split: forward alone, then backward with an arbitrary d(loss)/d(pred)."""
     import gpu_util as G

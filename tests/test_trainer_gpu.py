@@ -83,3 +83,53 @@ def test_unknown_method_and_dataset_errors(tmp_path):
         GNN_RUL_trainer(argparse.Namespace(GNN_method="ST_GCN", **dict(base, dataset_id="FD009")))
     with pytest.raises(NotImplementedError):
         GNN_RUL_trainer(argparse.Namespace(GNN_method="ST_GCN", **dict(base, dataset="NOPE")))
+
+
+def test_trainer_matches_reference_harness_run_on_phm2012(tmp_path, monkeypatch):
+    """End-to-end RMSE parity: the reference's own harness (trainer.GNN_RUL_trainer, run on CPU by
+    tests/golden/make_golden.py::case_trainer_phm2012) vs this package's harness on the GPU, same synthetic
+    PHM2012 Condition_1 dataset, same seed (=> same initial weights), same batches (shuffle off), dropout off.
+    BASELINE.json asks for RMSE within 1e-3 of the reference."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_phm2012
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "trainer_phm2012_c1_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "PHM2012" / "Condition_1"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="ST_GCN", data_path=str(tmp_path / "data"), dataset="PHM2012",
+                              dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    tr.model_configs["dropout"] = 1e-12
+    assert tr.train_configs["batch_size"] == int(z["batch_size"]) and tr.train_configs["learning_rate"] == float(z["lr"])
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 3] - ref[:, 3])) < 1e-3                  # RMSE, absolute (north star)
+    assert np.max(np.abs(got - ref) / np.abs(ref)) < 2e-4                # Score_v1, Score_v2, MAE, RMSE, relative
+    sd = tr.algorithm.state_dict()
+    for k in z.files:
+        if k.startswith("final:"):
+            a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
+            assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 2e-4, k
+    # the results CSV has the same rows (first row inf, then one row per RMSE improvement)
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "ST_GCN_run_0" / "results.csv")
+    import io
+    ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
+    assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
+    assert np.allclose(csv.iloc[1:].to_numpy(), ref_csv.iloc[1:].to_numpy(), rtol=2e-4)
