@@ -34,13 +34,22 @@ static int check_ptrs(std::initializer_list<const void*> ps) {
     return RULGNN_OK;
 }
 
+size_t rulgnn_stgcn_forward_workspace_bytes(const rulgnn_stgcn_shape* shape) {
+    if (validate_shape(shape) != RULGNN_OK) return 0;
+    return shape->num_patch > 64 ? stgcn_tiled_forward_workspace_bytes(shape) : 0;
+}
+
 int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
-                             const float* bn_stats, float* pred, void* stream) {
+                             const float* bn_stats, float* pred, void* workspace, size_t workspace_bytes,
+                             void* stream) {
     int rc = validate_shape(shape);
     if (rc != RULGNN_OK) return rc;
     if (shape->batch == 0) return RULGNN_OK;
     rc = check_ptrs({x, params, bn_stats, pred});
     if (rc != RULGNN_OK) return rc;
+    if (shape->num_patch > 64)
+        return stgcn_tiled_forward_eval(shape, x, params, bn_stats, pred, workspace, workspace_bytes,
+                                        static_cast<hipStream_t>(stream));
     return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream));
 }
 

@@ -22,7 +22,7 @@ inline int validate_shape(const rulgnn_stgcn_shape* s) {
     if (!s) return RULGNN_EINVAL;
     if (s->batch < 0 || s->num_patch < 2 || s->patch_size < 2 || s->num_layers < 1) return RULGNN_EINVAL;
     if (s->mpnn_k != 1) return RULGNN_EUNSUPPORTED;          // only the reference default k = 1
-    if (s->num_patch > 64 || s->num_layers > 8 || s->patch_size > 4096) return RULGNN_EUNSUPPORTED;
+    if (s->num_patch > 4096 || s->num_layers > 8 || s->patch_size > 4096) return RULGNN_EUNSUPPORTED;
     if (s->batch > (int64_t)400000000 / ((int64_t)F * s->num_patch)) return RULGNN_EUNSUPPORTED;  // 32-bit dropout counter
     return RULGNN_OK;
 }
@@ -31,6 +31,7 @@ inline int tile_geometry(const rulgnn_stgcn_shape* s, TileGeom* g) {
     const int rc = validate_shape(s);
     if (rc != RULGNN_OK) return rc;
     const int N = s->num_patch, P = s->patch_size;
+    if (N > 64) return RULGNN_EUNSUPPORTED;                 // fused row-mapped kernels; larger num_patch -> tiled path
     g->RW = N <= 16 ? 16 : (N <= 32 ? 32 : 64);
     g->SPW = 64 / g->RW;
     // even P: patches are read with ds_read_b64, conflict-free iff (stride/2) is odd.
@@ -82,6 +83,9 @@ inline int persistent_grid(K kernel, int64_t ntiles, size_t lds_bytes, int overs
 
 int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
                        hipStream_t stream);
+size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s);
+int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* pred,
+                             void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s);
 int stgcn_train_forward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream);
 int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream);

@@ -164,6 +164,7 @@ class ST_GCN_model(nn.Module):
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pred_buf = None
         self._ws, self._ws_key = None, None
+        self._fwd_ws = None
 
     def _flush_nbt(self):
         if self._nbt_pending and self._nbt is not None:
@@ -328,7 +329,11 @@ class ST_GCN_model(nn.Module):
             return self._train_forward(x2d).view(-1, 1)
         out = torch.empty(B, dtype=torch.float32, device=x2d.device)
         shp = self._shape(B)
+        nbytes = _lib.load().rulgnn_stgcn_forward_workspace_bytes(C.byref(shp))       # 0 for num_patch <= 64
+        if nbytes and (self._fwd_ws is None or self._fwd_ws.numel() < nbytes or self._fwd_ws.device != x2d.device):
+            self._fwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
         _lib.check(_lib.load().rulgnn_stgcn_forward_f32(C.byref(shp), x2d.data_ptr(), self._flat.data_ptr(),
-                                                        self._bn.data_ptr(), out.data_ptr(), _stream()),
+                                                        self._bn.data_ptr(), out.data_ptr(),
+                                                        self._fwd_ws.data_ptr() if nbytes else None, nbytes, _stream()),
                    "rulgnn_stgcn_forward_f32")
         return out.view(-1, 1)

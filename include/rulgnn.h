@@ -41,7 +41,7 @@ extern "C" {
 
 typedef struct rulgnn_stgcn_shape {
     int64_t batch;        /* samples in this call (this rank's shard) */
-    int32_t num_patch;    /* N: patches per sample (C-MAPSS view: sensors), 2..64 */
+    int32_t num_patch;    /* N: patches per sample (C-MAPSS view: sensors), 2..4096 (fused kernels up to 64) */
     int32_t patch_size;   /* P: samples per patch (C-MAPSS view: window), 2..4096 */
     int32_t num_layers;   /* L: SG_TCN layers, 1..8 (reference default 2) */
     int32_t mpnn_k;       /* MPNN order k; only 1 is implemented (the reference's default) */
@@ -60,10 +60,15 @@ int64_t rulgnn_stgcn_param_count(int32_t num_patch, int32_t num_layers);
  *   params   flat live parameters (layout above)
  *   bn_stats BatchNorm running statistics (layout above)
  *   pred     [batch] output (the reference returns [batch, 1])
- * One fused kernel: patch statistics -> Pearson adjacency -> L x (A.X.W, causal TCN, folded BN,
- * residuals) -> channel max-pool -> fc1 -> fc2.  No workspace. */
+ *   workspace  rulgnn_stgcn_forward_workspace_bytes(shape) bytes of scratch: 0 (NULL allowed) for
+ *              num_patch <= 64, activation tensors for the tiled path (num_patch > 64)
+ * num_patch <= 64: ONE fused kernel: patch statistics -> Pearson adjacency -> L x (A.X.W, causal TCN,
+ * folded BN, residuals) -> channel max-pool -> fc1 -> fc2.  num_patch > 64 (PHM2012 Condition_2, XJTU-SY):
+ * tiled path, theta / fc1 as MFMA GEMMs over [batch][10][num_patch] tensors in the workspace. */
+size_t rulgnn_stgcn_forward_workspace_bytes(const rulgnn_stgcn_shape *shape);
 int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape *shape, const float *x, const float *params,
-                             const float *bn_stats, float *pred, void *stream);
+                             const float *bn_stats, float *pred, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 /* Bytes of scratch the training entry points need for `shape` (features/adjacency cache,
  * per-block gradient partials, BatchNorm reduction cells).  Independent of pointer values. */

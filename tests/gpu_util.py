@@ -39,8 +39,10 @@ def abi_forward(x_np, flat_np, bn_np, N, P, L=2):
     bn = torch.from_numpy(bn_np).to(dev)
     out = torch.full((B,), float("nan"), device=dev)
     shp = shape_struct(B, N, P, L)
+    nbytes = lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(shp))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(),
-                                      stream_ptr())
+                                      ws.data_ptr() if nbytes else None, nbytes, stream_ptr())
     _lib.check(rc, "rulgnn_stgcn_forward_f32")
     torch.cuda.synchronize()
     return out.cpu().numpy()

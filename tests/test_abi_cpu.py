@@ -42,14 +42,17 @@ def test_error_codes_have_messages():
 
 def test_shape_validation_without_gpu():
     lib = _lib.load()
-    bad = _lib.StgcnShape(4, 1024, 32, 2, 1)          # XJTU-sized num_patch: outside the fused kernels
-    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None) == -2
+    bad = _lib.StgcnShape(4, 8192, 32, 2, 1)          # beyond every path
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None, 0, None) == -2
+    big = _lib.StgcnShape(4, 1024, 32, 2, 1)          # XJTU-sized num_patch: tiled path, needs a workspace
+    assert lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(big)) > 0
+    assert lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(_lib.StgcnShape(4, 14, 30, 2, 1))) == 0
     bad = _lib.StgcnShape(4, 14, 30, 2, 3)            # MPNN order k != 1
-    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None) == -2
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None, 0, None) == -2
     ok = _lib.StgcnShape(4, 14, 30, 2, 1)
-    assert lib.rulgnn_stgcn_forward_f32(C.byref(ok), None, None, None, None, None) == -1   # null pointers
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(ok), None, None, None, None, None, 0, None) == -1   # null pointers
     empty = _lib.StgcnShape(0, 14, 30, 2, 1)
-    assert lib.rulgnn_stgcn_forward_f32(C.byref(empty), None, None, None, None, None) == 0  # empty batch is a no-op
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(empty), None, None, None, None, None, 0, None) == 0  # empty batch is a no-op
 
 
 def test_single_hip_runtime_even_when_library_is_loaded_before_torch():

@@ -26,7 +26,9 @@ def test_forward_matches_reference_golden(name):
 
 @pytest.mark.parametrize("N,P,B", [(14, 30, 1), (14, 30, 3), (14, 30, 4), (14, 30, 1027), (14, 50, 257),
                                    (16, 30, 65), (3, 6, 9), (5, 7, 33), (14, 31, 19), (16, 16, 40),
-                                   (24, 20, 37), (32, 8, 11), (40, 64, 9), (64, 10, 6)])
+                                   (24, 20, 37), (32, 8, 11), (40, 64, 9), (64, 10, 6),
+                                   # num_patch > 64: tiled path (PHM2012 Condition_2, XJTU-SY shapes)
+                                   (65, 8, 5), (160, 16, 7), (200, 6, 3), (1024, 32, 4), (2048, 16, 2)])
 def test_forward_matches_oracle_seeded(N, P, B):
     import gpu_util as G
     rng = np.random.default_rng(N * 1000 + P * 10 + B)
@@ -62,8 +64,10 @@ def test_forward_rejects_unsupported():
     from gnn_rul_benchmarking_amd import _lib
     lib = _lib.load()
     t = torch.zeros(16, device="cuda:0")
-    for shp in (G.shape_struct(4, 1024, 32), G.shape_struct(4, 14, 30, 2, k=2)):
-        rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), G.stream_ptr())
+    for shp in (G.shape_struct(4, 8192, 32), G.shape_struct(4, 14, 30, 2, k=2)):
+        rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, G.stream_ptr())
         assert rc == -2
+    rc = lib.rulgnn_stgcn_forward_f32(C.byref(G.shape_struct(4, 1024, 32)), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, G.stream_ptr())
+    assert rc == -3          # tiled path without its workspace
     shp = G.shape_struct(4, 14, 30)
-    assert lib.rulgnn_stgcn_forward_f32(C.byref(shp), None, t.data_ptr(), t.data_ptr(), t.data_ptr(), G.stream_ptr()) == -1
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(shp), None, t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, G.stream_ptr()) == -1

@@ -19,7 +19,7 @@ for B in [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["65
     shp = _lib.StgcnShape(B, N, P, L, 1)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     def run():
-        _lib.check(lib.rulgnn_stgcn_forward_f32(C.byref(shp), x.data_ptr(), fp.data_ptr(), bp.data_ptr(), out.data_ptr(), st), "fwd")
+        _lib.check(lib.rulgnn_stgcn_forward_f32(C.byref(shp), x.data_ptr(), fp.data_ptr(), bp.data_ptr(), out.data_ptr(), None, 0, st), "fwd")
     for _ in range(5): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
