@@ -53,9 +53,15 @@ int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, co
     return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream));
 }
 
+static bool tiled(const rulgnn_stgcn_shape* shape) { return shape->num_patch > 64; }
+
+static size_t train_ws_bytes(const rulgnn_stgcn_shape* shape) {
+    return tiled(shape) ? stgcn_tiled_train_workspace_bytes(shape) : stgcn_train_workspace_bytes(shape);
+}
+
 size_t rulgnn_stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* shape) {
     if (validate_shape(shape) != RULGNN_OK) return 0;
-    return stgcn_train_workspace_bytes(shape);
+    return train_ws_bytes(shape);
 }
 
 static int check_train(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* a, bool need_grads) {
@@ -78,25 +84,30 @@ static int check_train(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train
             return RULGNN_EALIGN;
         }
     }
-    if (a->workspace_bytes < stgcn_train_workspace_bytes(shape)) return RULGNN_EWORKSPACE;
+    const size_t need = train_ws_bytes(shape);
+    if (need == 0) return RULGNN_EUNSUPPORTED;
+    if (a->workspace_bytes < need) return RULGNN_EWORKSPACE;
     return RULGNN_OK;
 }
 
 int rulgnn_stgcn_train_forward_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
     const int rc = check_train(shape, args, false);
     if (rc != RULGNN_OK) return rc;
+    if (tiled(shape)) return stgcn_tiled_train(shape, args, 0, static_cast<hipStream_t>(stream));
     return stgcn_train_forward(shape, args, static_cast<hipStream_t>(stream));
 }
 
 int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
     const int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
+    if (tiled(shape)) return stgcn_tiled_train(shape, args, 1, static_cast<hipStream_t>(stream));
     return stgcn_train_backward(shape, args, static_cast<hipStream_t>(stream));
 }
 
 int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, void* stream) {
     const int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
+    if (tiled(shape)) return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream));
     return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
 }
 
@@ -109,7 +120,18 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_st
     rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
     if (rc != RULGNN_OK) return rc;
     if (opt->bn_stats && (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3)) return RULGNN_EALIGN;
-    return stgcn_train_step(shape, args, opt, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (tiled(shape)) {                                    // tiled path: same call, optimizer as separate kernels
+        rc = stgcn_tiled_train(shape, args, 2, st);
+        if (rc != RULGNN_OK) return rc;
+        rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq,
+                       param_count(shape->num_patch, shape->num_layers), opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                       opt->weight_decay, 1.0f, st);
+        if (rc != RULGNN_OK || !opt->bn_stats) return rc;
+        return bn_running_update(opt->bn_stats, args->bn_batch, shape->num_layers, shape->batch * (int64_t)shape->num_patch,
+                                 opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
+    }
+    return stgcn_train_step(shape, args, opt, st);
 }
 
 int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }
@@ -118,6 +140,7 @@ int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape* shape, const rulgnn_s
                                  void* stream) {
     const int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
+    if (tiled(shape)) return RULGNN_EUNSUPPORTED;          // the tiled path is not a phase chain
     return stgcn_train_phase(shape, args, phase, static_cast<hipStream_t>(stream));
 }
 

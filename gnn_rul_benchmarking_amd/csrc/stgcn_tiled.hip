@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X
 }
 
 // out[b][c][t] = sum_c' A[b][c][c'] in[b][c'][t] (+ add[b][c][t])          (torch.bmm(A, X), Model.py:87)
-__global__ void t_aggregate_kernel(const float* __restrict__ A, const float* __restrict__ in, const float* __restrict__ add,
-                                   float* __restrict__ out, TArgs a) {
+__global__ void t_aggregate_kernel(const float* __restrict__ A, const float* __restrict__ in, const float* add, float* out,
+                                   TArgs a) {      // add may alias out (in-place residual accumulation)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.B * a.N) return;
     const int64_t b = i / a.N;
@@ -345,6 +345,665 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     if (rc != RULGNN_OK) return rc;
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_head_kernel, dim3((unsigned)B), dim3(256), 0, stream, y1pre, prm, pred, a);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+
+// ================================================================================================
+// training (tiled path): activations of every layer are kept in the workspace, the backward reads them
+// ================================================================================================
+typedef float f32x4tt __attribute__((ext_vector_type(4)));
+constexpr int TTS = 68, TTR = 30;       // per-wave LDS transpose tile of the conv weight gradient (see stgcn_train.hip)
+
+struct TBn {            // BatchNorm constants of one layer-block, computed by every block from the reduction cells
+    float mean[F], istd[F], sc[F], sh[F], gi[F], k1[F], k2[F];
+};
+
+__device__ __forceinline__ void t_bn_consts(const double* cells_fwd, const double* cells_bwd, const float* __restrict__ prm_l,
+                                            int N, int blk, int bn_index, double cnt, bool with_bwd, float* lds /* [7][F] */) {
+    if (threadIdx.x < F) {
+        const int c = threadIdx.x;
+        const double mean = cells_fwd[(bn_index * 2 + 0) * F + c] / cnt;
+        double var = cells_fwd[(bn_index * 2 + 1) * F + c] / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double istd = 1.0 / sqrt(var + (double)BN_EPS);
+        const double g = prm_l[off_bn_g(N, blk) + c], be = prm_l[off_bn_b(N, blk) + c];
+        lds[0 * F + c] = (float)mean;
+        lds[1 * F + c] = (float)istd;
+        lds[2 * F + c] = (float)(g * istd);
+        lds[3 * F + c] = (float)(be - mean * g * istd);
+        lds[4 * F + c] = (float)(g * istd);
+        lds[5 * F + c] = with_bwd ? (float)(cells_bwd[(bn_index * 2 + 0) * F + c] / cnt) : 0.f;
+        lds[6 * F + c] = with_bwd ? (float)(cells_bwd[(bn_index * 2 + 1) * F + c] / cnt) : 0.f;
+    }
+}
+
+// block-wide sum of ten per-thread pairs -> one fp64 atomic per channel and pair member
+__device__ __forceinline__ void t_pair_reduce(const float (&sa)[F], const float (&sb)[F], double* cell /* [2][F] */, float* lds /* [4][2F] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        float va = sa[c], vb = sb[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { va += __shfl_xor(va, o, 64); vb += __shfl_xor(vb, o, 64); }
+        if (lane == 0) { lds[wave * 2 * F + c] = va; lds[wave * 2 * F + F + c] = vb; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * F) {
+        double v = 0.0;
+        for (int w = 0; w < 4; ++w) v += (double)lds[w * 2 * F + threadIdx.x];
+        atomicAdd(cell + threadIdx.x, v);
+    }
+}
+
+struct TTrain {
+    int64_t B, sample_offset, global_batch;
+    int N, P, L;
+    float dropout_p, drop_scale;
+    uint32_t drop_thr, drop_key;
+    double cnt;
+    double* cells_fwd;
+    double* cells_bwd;
+    double* cell_loss;
+};
+
+__device__ __forceinline__ void t_ld10(const float* __restrict__ T, int64_t b, int t, int N, float (&v)[F]) {
+    if (t < 0 || t >= N) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[c] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) v[c] = T[(b * F + c) * N + t];
+}
+__device__ __forceinline__ void t_st10(float* __restrict__ T, int64_t b, int t, int N, const float (&v)[F]) {
+#pragma unroll
+    for (int c = 0; c < F; ++c) T[(b * F + c) * N + t] = v[c];
+}
+
+// ---- forward --------------------------------------------------------------------------------------
+// H = leaky(Hpre + bias); z1 = conv1(H); sums of z1
+__global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restrict__ Hpre, const float* __restrict__ prm_l, float* __restrict__ H,
+                                                            float* __restrict__ z1, int bn_index, TTrain a) {
+    __shared__ float lds[4 * 2 * F];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < a.B * a.N;
+    const int64_t b = ok ? i / a.N : 0;
+    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    float sa[F], sb[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
+    if (ok) {
+        float h[F], hm[F], z[F];
+        t_load_H(Hpre, prm_l + off_theta_b(N), b, t, N, h);
+        t_load_H(Hpre, prm_l + off_theta_b(N), b, t - 1, N, hm);
+        t_conv_point(hm, h, prm_l + off_conv_w(N, 0), z);
+        t_st10(H, b, t, N, h);
+        t_st10(z1, b, t, N, z);
+#pragma unroll
+        for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
+    }
+    t_pair_reduce(sa, sb, a.cells_fwd + bn_index * 2 * F, lds);
+}
+
+// o0 = relu(relu(bn1(z1)) + H); z2 = conv2(o0); sums of z2
+__device__ __forceinline__ void t_o0_from(const float* __restrict__ z1, const float* __restrict__ H, const float* bnc, int64_t b, int t, int N,
+                                          float (&o0)[F]) {
+    if (t < 0 || t >= N) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) o0[c] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c)
+        o0[c] = relu(relu(fmaf(z1[(b * F + c) * N + t], bnc[2 * F + c], bnc[3 * F + c])) + H[(b * F + c) * N + t]);
+}
+
+__global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restrict__ z1, const float* __restrict__ H, const float* __restrict__ prm_l,
+                                                            float* __restrict__ o0, float* __restrict__ z2, int bn_index, TTrain a) {
+    __shared__ float lds[4 * 2 * F];
+    __shared__ float bnc[7 * F];
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index - 1, a.cnt, false, bnc);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < a.B * a.N;
+    const int64_t b = ok ? i / a.N : 0;
+    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    float sa[F], sb[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
+    if (ok) {
+        float v[F], vm[F], z[F];
+        t_o0_from(z1, H, bnc, b, t, N, v);
+        t_o0_from(z1, H, bnc, b, t - 2, N, vm);
+        t_conv_point(vm, v, prm_l + off_conv_w(N, 1), z);
+        t_st10(o0, b, t, N, v);
+        t_st10(z2, b, t, N, z);
+#pragma unroll
+        for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
+    }
+    t_pair_reduce(sa, sb, a.cells_fwd + bn_index * 2 * F, lds);
+}
+
+// Xout = dropout(relu(relu(bn2(z2)) + o0)) + Xin
+__global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ Xin,
+                                                           const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a) {
+    __shared__ float bnc[7 * F];
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, false, bnc);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.N) return;
+    const int64_t b = i / a.N;
+    const int t = (int)(i % a.N), N = a.N;
+    const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const int64_t idx = (b * F + c) * N + t;
+        float o1 = relu(relu(fmaf(z2[idx], bnc[2 * F + c], bnc[3 * F + c])) + o0[idx]);
+        if (a.dropout_p > 0.f) {
+            const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ a.drop_key);
+            o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
+        }
+        Xout[idx] = o1 + Xin[idx];
+    }
+}
+
+// head: y1 = relu(y1pre + b1) (stored), pred, loss, dpred, dy1pre.  One block per sample.
+__global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restrict__ y1pre, const float* __restrict__ prm, const float* __restrict__ gy,
+                                                           int has_dpred, float* __restrict__ y1, float* __restrict__ pred,
+                                                           float* __restrict__ dpred_out, float* __restrict__ dy1pre, TTrain a) {
+    __shared__ float red[4];
+    __shared__ float dp;
+    const int64_t b = blockIdx.x;
+    const int N = a.N, L = a.L, tid = threadIdx.x;
+    const float* b1 = prm + off_fc1_b(N, L);
+    const float* w2 = prm + off_fc2_w(N, L);
+    float s = 0.f;
+    for (int j = tid; j < N; j += 256) {
+        const float v = relu(y1pre[b * N + j] + b1[j]);
+        y1[b * N + j] = v;
+        s = fmaf(v, w2[j], s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float p = red[0] + red[1] + red[2] + red[3] + prm[off_fc2_b(N, L)];
+        pred[b] = p;
+        float d = 0.f;
+        if (has_dpred == 1) d = gy[b];
+        else if (has_dpred == 0) {
+            const float diff = p - gy[b];
+            d = 2.f * diff / (float)a.global_batch;
+            atomicAdd(a.cell_loss, (double)diff * (double)diff);
+        }
+        dpred_out[b] = d;
+        dp = d;
+    }
+    __syncthreads();
+    const float d = dp;
+    for (int j = tid; j < N; j += 256) dy1pre[b * N + j] = (y1[b * N + j] > 0.f) ? d * w2[j] : 0.f;
+}
+
+// ---- backward --------------------------------------------------------------------------------------
+// gradient entering the layer: top layer: dXn = scatter of dpooled to the arg-max channel; else dXn = dX buffer.
+// gsum = dropmask(dXn) * [o1 > 0]; dy2 = gsum * [x1 > 0]; BatchNorm (conv_block2) backward sums
+__global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ Xout, float* __restrict__ dXn,
+                                                         const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ prm_l,
+                                                         float* __restrict__ gsum, int bn_index, int top, TTrain a) {
+    __shared__ float lds[4 * 2 * F];
+    __shared__ float bnc[7 * F];
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, false, bnc);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < a.B * a.N;
+    const int64_t b = ok ? i / a.N : 0;
+    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    float sa[F], sb[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
+    if (ok) {
+        int arg = 0;
+        float dp = 0.f;
+        if (top) {
+            float m = Xout[(b * F) * N + t];
+#pragma unroll
+            for (int c = 1; c < F; ++c) {
+                const float v = Xout[(b * F + c) * N + t];
+                const bool take = (v > m) || (v != v && m == m);
+                m = take ? v : m;
+                arg = take ? c : arg;
+            }
+            dp = dpooled[b * N + t];
+        }
+        const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const int64_t idx = (b * F + c) * N + t;
+            float g;
+            if (top) { g = (c == arg) ? dp : 0.f; dXn[idx] = g; }
+            else g = dXn[idx];
+            const float zz = z2[idx];
+            const float x1 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
+            const float o1 = relu(x1 + o0[idx]);
+            if (a.dropout_p > 0.f) {
+                const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ a.drop_key);
+                g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
+            }
+            g = (o1 > 0.f) ? g : 0.f;
+            gsum[idx] = g;
+            const float dy = (x1 > 0.f) ? g : 0.f;
+            sa[c] = dy;
+            sb[c] = dy * ((zz - bnc[0 * F + c]) * bnc[1 * F + c]);
+        }
+    }
+    t_pair_reduce(sa, sb, a.cells_bwd + bn_index * 2 * F, lds);
+}
+
+__device__ __forceinline__ void t_wgrad_mfma(float* T, const float (&dz)[F], const float (&h)[F], const float (&hs)[F], int lane,
+                                             f32x4tt& acc0, f32x4tt& acc1) {
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        T[c * TTS + lane] = dz[c];
+        T[(F + c) * TTS + lane] = h[c];
+        T[(2 * F + c) * TTS + lane] = hs[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+        const float4 av = *reinterpret_cast<const float4*>(&T[i * TTS + 16 * kq + 4 * jp]);
+        const float4 b0 = *reinterpret_cast<const float4*>(&T[(F + i) * TTS + 16 * kq + 4 * jp]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&T[(i < 4 ? 2 * F + 6 + i : 3 * F - 1) * TTS + 16 * kq + 4 * jp]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// per-block partial conv weight gradient row [200] from the four wavefronts' MFMA accumulators
+__device__ __forceinline__ void t_wgrad_store(float* red /* [8][64] */, const f32x4tt& acc0, const f32x4tt& acc1, float* row) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[e * 64 + lane] = (w == 0 ? 0.f : red[e * 64 + lane]) + acc0[e];
+                red[(4 + e) * 64 + lane] = (w == 0 ? 0.f : red[(4 + e) * 64 + lane]) + acc1[e];
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+        const int rg = (i / 64) % 4, which = i / 256, ln = i % 64;
+        const int co = 4 * (ln >> 4) + rg, j = ln & 15;
+        int ci, tap;
+        if (which == 0) { ci = j < F ? j : j - F; tap = j < F ? 1 : 0; }
+        else { ci = 6 + j; tap = 0; }
+        if (co < F && ci < F && (which == 0 || j < 4)) row[(co * F + ci) * 2 + tap] = red[(which * 4 + rg) * 64 + ln];
+    }
+}
+
+// dz2 at position t from the stored gsum / z2 (BatchNorm conv_block2 backward)
+__device__ __forceinline__ void t_dz2_at(const float* __restrict__ gsum, const float* __restrict__ z2, const float* bnc, int64_t b, int t, int N,
+                                         float (&dz)[F]) {
+    if (t < 0 || t >= N) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) dz[c] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const int64_t idx = (b * F + c) * N + t;
+        const float zz = z2[idx];
+        const float x1 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
+        const float dy = (x1 > 0.f) ? gsum[idx] : 0.f;
+        const float xh = (zz - bnc[0 * F + c]) * bnc[1 * F + c];
+        dz[c] = bnc[4 * F + c] * (dy - bnc[5 * F + c] - xh * bnc[6 * F + c]);
+    }
+}
+
+__device__ __forceinline__ void t_convT_point(const float (&dz0)[F], const float (&dzs)[F], const float* __restrict__ w, float (&dh)[F]) {
+    // dh[ci] = sum_co w[co][ci][1] dz0[co] + w[co][ci][0] dzs[co]      (dz0 at t, dzs at t + d)
+#pragma unroll
+    for (int ci = 0; ci < F; ++ci) {
+        float acc = 0.f;
+#pragma unroll
+        for (int co = 0; co < F; ++co) {
+            acc = fmaf(w[(co * F + ci) * 2 + 1], dz0[co], acc);
+            acc = fmaf(w[(co * F + ci) * 2 + 0], dzs[co], acc);
+        }
+        dh[ci] = acc;
+    }
+}
+
+// conv_block2 backward: weight gradient partials, gsum0 = (convT2(dz2) + gsum) * [o0 > 0], BatchNorm (conv_block1) backward sums
+__global__ __launch_bounds__(256) void t_conv2_bwd_kernel(const float* __restrict__ gsum, const float* __restrict__ z2, const float* __restrict__ o0,
+                                                          const float* __restrict__ z1, const float* __restrict__ prm_l,
+                                                          float* __restrict__ gsum0, float* __restrict__ gpart, int bn_index, TTrain a) {
+    __shared__ __attribute__((aligned(16))) float tile[4][TTR * TTS];
+    __shared__ float lds[4 * 2 * F];
+    __shared__ float bnc2[7 * F], bnc1[7 * F];
+    __shared__ float red[8 * 64];
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, true, bnc2);
+    __syncthreads();
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index - 1, a.cnt, false, bnc1);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < a.B * a.N;
+    const int64_t b = ok ? i / a.N : 0;
+    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float sa[F], sb[F], dz[F], dzs[F], h[F], hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) sa[c] = sb[c] = dz[c] = h[c] = hs[c] = 0.f;
+    if (ok) {
+        t_dz2_at(gsum, z2, bnc2, b, t, N, dz);
+        t_dz2_at(gsum, z2, bnc2, b, t + 2, N, dzs);
+        t_ld10(o0, b, t, N, h);
+        t_ld10(o0, b, t - 2, N, hs);
+    }
+    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    t_wgrad_mfma(tile[wave], dz, h, hs, lane, acc0, acc1);
+    if (ok) {
+        float d_o0[F];
+        t_convT_point(dz, dzs, prm_l + off_conv_w(N, 1), d_o0);
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const int64_t idx = (b * F + c) * N + t;
+            float g = d_o0[c] + gsum[idx];
+            g = (h[c] > 0.f) ? g : 0.f;                          // h = o0
+            gsum0[idx] = g;
+            const float zz = z1[idx];
+            const float x0 = relu(fmaf(zz, bnc1[2 * F + c], bnc1[3 * F + c]));
+            const float dy = (x0 > 0.f) ? g : 0.f;
+            sa[c] = dy;
+            sb[c] = dy * ((zz - bnc1[0 * F + c]) * bnc1[1 * F + c]);
+        }
+    }
+    t_pair_reduce(sa, sb, a.cells_bwd + (bn_index - 1) * 2 * F, lds);
+    __syncthreads();
+    t_wgrad_store(red, acc0, acc1, gpart + (size_t)blockIdx.x * CONVW);
+}
+
+__device__ __forceinline__ void t_dz1_at(const float* __restrict__ gsum0, const float* __restrict__ z1, const float* bnc, int64_t b, int t, int N,
+                                         float (&dz)[F]) {
+    if (t < 0 || t >= N) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) dz[c] = 0.f;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const int64_t idx = (b * F + c) * N + t;
+        const float zz = z1[idx];
+        const float x0 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
+        const float dy = (x0 > 0.f) ? gsum0[idx] : 0.f;
+        const float xh = (zz - bnc[0 * F + c]) * bnc[1 * F + c];
+        dz[c] = bnc[4 * F + c] * (dy - bnc[5 * F + c] - xh * bnc[6 * F + c]);
+    }
+}
+
+// conv_block1 backward: weight gradient partials, dHpre = (convT1(dz1) + gsum0) * leaky'(H)
+__global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restrict__ gsum0, const float* __restrict__ z1, const float* __restrict__ H,
+                                                          const float* __restrict__ prm_l, float* __restrict__ dHpre, float* __restrict__ gpart,
+                                                          int bn_index, TTrain a) {
+    __shared__ __attribute__((aligned(16))) float tile[4][TTR * TTS];
+    __shared__ float bnc[7 * F];
+    __shared__ float red[8 * 64];
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index, a.cnt, true, bnc);
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < a.B * a.N;
+    const int64_t b = ok ? i / a.N : 0;
+    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dz[F], dzs[F], h[F], hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) dz[c] = h[c] = hs[c] = 0.f;
+    if (ok) {
+        t_dz1_at(gsum0, z1, bnc, b, t, N, dz);
+        t_dz1_at(gsum0, z1, bnc, b, t + 1, N, dzs);
+        t_ld10(H, b, t, N, h);
+        t_ld10(H, b, t - 1, N, hs);
+    }
+    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    t_wgrad_mfma(tile[wave], dz, h, hs, lane, acc0, acc1);
+    if (ok) {
+        float dH[F];
+        t_convT_point(dz, dzs, prm_l + off_conv_w(N, 0), dH);
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const int64_t idx = (b * F + c) * N + t;
+            const float g = dH[c] + gsum0[idx];
+            dHpre[idx] = h[c] > 0.f ? g : g * LEAKY;
+        }
+    }
+    t_wgrad_store(red, acc0, acc1, gpart + (size_t)blockIdx.x * CONVW);
+}
+
+// finalize (tiled path): conv weight partial rows, BatchNorm gamma/beta from the cells, loss, batch statistics
+struct TFin {
+    const float* gpart;       // [2L][grid][200]
+    const double* cells_fwd;
+    const double* cells_bwd;
+    const double* cell_loss;
+    float* grads;
+    float* loss;
+    float* bn_batch;
+    int grid, N, L;
+    int64_t global_batch;
+    double cnt;
+    float moment_weight;
+    int write_loss, write_grads;
+};
+__global__ __launch_bounds__(256) void t_finalize_kernel(TFin f) {
+    const int N = f.N, L = f.L, LS = layer_stride(N);
+    // one block per (layer, conv block): 200 conv weights + 20 BatchNorm parameters
+    const int l = blockIdx.x / 2, blk = blockIdx.x % 2, bnidx = blockIdx.x;
+    const float* gp = f.gpart + (size_t)bnidx * f.grid * CONVW;
+    if (f.write_grads) {
+        for (int p = threadIdx.x; p < CONVW; p += 256) {
+            float v = 0.f;
+            for (int b = 0; b < f.grid; ++b) v += gp[(size_t)b * CONVW + p];
+            f.grads[l * LS + off_conv_w(N, blk) + p] = v;
+        }
+    }
+    if (threadIdx.x < F) {
+        const int c = threadIdx.x;
+        if (f.write_grads) {
+            f.grads[l * LS + off_bn_g(N, blk) + c] = (float)f.cells_bwd[(bnidx * 2 + 1) * F + c];
+            f.grads[l * LS + off_bn_b(N, blk) + c] = (float)f.cells_bwd[(bnidx * 2 + 0) * F + c];
+        }
+        const double mean = f.cells_fwd[(bnidx * 2 + 0) * F + c] / f.cnt;
+        const double ex2 = f.cells_fwd[(bnidx * 2 + 1) * F + c] / f.cnt;
+        double var = ex2 - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        if (f.moment_weight > 0.f) {
+            f.bn_batch[(bnidx * 2 + 0) * F + c] = (float)(mean * (double)f.moment_weight);
+            f.bn_batch[(bnidx * 2 + 1) * F + c] = (float)(ex2 * (double)f.moment_weight);
+        } else {
+            f.bn_batch[(bnidx * 2 + 0) * F + c] = (float)mean;
+            f.bn_batch[(bnidx * 2 + 1) * F + c] = (float)var;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(f.cell_loss[0] / (double)f.global_batch);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: training forward / backward
+// ------------------------------------------------------------------------------------------------
+struct TWs {
+    size_t T, total;
+    size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
+    size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
+    size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one;
+    size_t cells_bytes;
+    int grid;
+};
+
+static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
+    const int N = s->num_patch, L = s->num_layers;
+    const int64_t B = s->batch;
+    w->T = al256((size_t)B * F * N * sizeof(float));
+    w->grid = (int)((B * N + 255) / 256);
+    size_t o = 0;
+    w->off_X = o; o += (size_t)(L + 1) * w->T;
+    w->off_AX = o; o += (size_t)L * w->T;
+    w->off_H = o; o += (size_t)L * w->T;
+    w->off_z1 = o; o += (size_t)L * w->T;
+    w->off_o0 = o; o += (size_t)L * w->T;
+    w->off_z2 = o; o += (size_t)L * w->T;
+    w->off_Hpre = o; o += w->T;
+    w->off_gsum = o; o += w->T;
+    w->off_gsum0 = o; o += w->T;
+    w->off_dH = o; o += w->T;
+    w->off_dAX = o; o += w->T;
+    w->off_dX = o; o += w->T;
+    const size_t BNb = al256((size_t)B * N * 4);
+    w->off_A = o; o += al256((size_t)B * F * F * 4);
+    w->off_pooled = o; o += BNb;
+    w->off_y1pre = o; o += BNb;
+    w->off_y1 = o; o += BNb;
+    w->off_dy1 = o; o += BNb;
+    w->off_dpool = o; o += BNb;
+    w->off_dpred = o; o += al256((size_t)B * 4);
+    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
+    w->off_cells = o; o += al256(w->cells_bytes);
+    w->off_gpart = o; o += al256((size_t)2 * L * w->grid * CONVW * 4);
+    w->off_one = o; o += 256;
+    w->total = o;
+}
+
+size_t stgcn_tiled_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
+    TWs w;
+    tws_layout(s, &w);
+    return w.total;
+}
+
+__global__ void t_fill_one_kernel(float* p) { p[0] = 1.f; }
+
+int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* ar, int mode /* 0 fwd, 1 bwd, 2 both */,
+                      hipStream_t stream) {
+    TWs w;
+    tws_layout(s, &w);
+    if (ar->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    const int N = s->num_patch, L = s->num_layers, LS = layer_stride(N);
+    const int64_t B = s->batch, BN_ = B * N;
+    char* ws = static_cast<char*>(ar->workspace);
+    auto TP = [&](size_t off, int l) { return reinterpret_cast<float*>(ws + off + (size_t)l * w.T); };
+    float* Hpre = TP(w.off_Hpre, 0); float* gsum = TP(w.off_gsum, 0); float* gsum0 = TP(w.off_gsum0, 0);
+    float* dHp = TP(w.off_dH, 0); float* dAX = TP(w.off_dAX, 0); float* dX = TP(w.off_dX, 0);
+    float* A = reinterpret_cast<float*>(ws + w.off_A);
+    float* pooled = reinterpret_cast<float*>(ws + w.off_pooled);
+    float* y1pre = reinterpret_cast<float*>(ws + w.off_y1pre);
+    float* y1 = reinterpret_cast<float*>(ws + w.off_y1);
+    float* dy1 = reinterpret_cast<float*>(ws + w.off_dy1);
+    float* dpool = reinterpret_cast<float*>(ws + w.off_dpool);
+    float* dpredb = reinterpret_cast<float*>(ws + w.off_dpred);
+    double* cells = reinterpret_cast<double*>(ws + w.off_cells);
+    float* gpart = reinterpret_cast<float*>(ws + w.off_gpart);
+    float* one = reinterpret_cast<float*>(ws + w.off_one);
+    const float* prm = ar->params;
+
+    TArgs a{B, N, s->patch_size, L};
+    TTrain t;
+    t.B = B; t.sample_offset = ar->sample_offset; t.global_batch = ar->global_batch; t.N = N; t.P = s->patch_size; t.L = L;
+    t.dropout_p = ar->dropout_p;
+    t.drop_scale = ar->dropout_p > 0.f ? 1.0f / (1.0f - ar->dropout_p) : 1.0f;
+    {
+        double thr = (double)ar->dropout_p * 4294967296.0;
+        const uint64_t ti = (uint64_t)((thr < 0 ? 0 : thr) + 0.5);
+        t.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
+    }
+    t.drop_key = 0;
+    t.cnt = (double)B * (double)N;
+    t.cells_fwd = cells; t.cells_bwd = cells + 2 * L * 2 * F; t.cell_loss = cells + 2 * (2 * L * 2 * F);
+    const int has_dpred = ar->dpred ? 1 : (ar->y ? 0 : 2);
+    const float* gy = ar->dpred ? ar->dpred : ar->y;
+    int rc;
+
+    if (mode == 0 || mode == 2) {
+        if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        T_LAUNCH(t_stats_kernel, BN_, ar->x, TP(w.off_X, 0), a);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, TP(w.off_X, 0), A, a);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        for (int l = 0; l < L; ++l) {
+            const float* pl = prm + l * LS;
+            t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
+            T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
+            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);
+            if (rc != RULGNN_OK) return rc;
+            T_LAUNCH(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
+            T_LAUNCH(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
+            T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t);
+        }
+        T_LAUNCH(t_pool_kernel, BN_, TP(w.off_X, L), pooled, a);
+        rc = sgemm(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, stream);
+        if (rc != RULGNN_OK) return rc;
+    } else {
+        if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * (2 * L * 2 * F + 8), stream) != hipSuccess) return RULGNN_EHIP;
+    }
+    // head (also recomputed by a backward-only call: cheap, gives dpred for the incoming gradient)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(t_head_train_kernel, dim3((unsigned)B), dim3(256), 0, stream, y1pre, prm, gy, has_dpred, y1, ar->pred, dpredb,
+                       dy1, t);
+    if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+
+    if (mode != 0) {
+        float* g = ar->grads;
+        T_LAUNCH(t_fill_one_kernel, 1, one);
+        // fc2: dW2[j] = sum_b dpred[b] y1[b][j];  db2 = sum_b dpred[b]
+        rc = sgemm(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, stream);
+        if (rc != RULGNN_OK) return rc;
+        rc = sgemm(dpredb, 0, 1, one, 0, 0, g + off_fc2_b(N, L), 1, 1, 1, (int)B, false, stream);
+        if (rc != RULGNN_OK) return rc;
+        // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
+        rc = sgemm(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, stream);
+        if (rc != RULGNN_OK) return rc;
+        rc = sgemm(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, stream);
+        if (rc != RULGNN_OK) return rc;
+        rc = sgemm(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, stream);
+        if (rc != RULGNN_OK) return rc;
+        for (int l = L - 1; l >= 0; --l) {
+            const float* pl = prm + l * LS;
+            float* gl = g + l * LS;
+            t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
+            T_LAUNCH(t_tail_bwd_kernel, BN_, dpool, TP(w.off_X, l + 1), dX, TP(w.off_z2, l), TP(w.off_o0, l), pl, gsum, 2 * l + 1,
+                     l == L - 1 ? 1 : 0, t);
+            T_LAUNCH(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,
+                     gpart + (size_t)(2 * l + 1) * w.grid * CONVW, 2 * l + 1, t);
+            T_LAUNCH(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
+                     gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t);
+            // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
+            rc = sgemm(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, stream);
+            if (rc != RULGNN_OK) return rc;
+            rc = sgemm(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, stream);
+            if (rc != RULGNN_OK) return rc;
+            if (l > 0) {
+                rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream);      // dHpre . theta
+                if (rc != RULGNN_OK) return rc;
+                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a);                                              // A^T dAX + dXn (A symmetric)
+            }
+        }
+    }
+    TFin f;
+    f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd; f.cell_loss = t.cell_loss;
+    f.grads = ar->grads; f.loss = ar->loss; f.bn_batch = ar->bn_batch;
+    f.grid = w.grid; f.N = N; f.L = L; f.global_batch = ar->global_batch; f.cnt = t.cnt;
+    f.moment_weight = ar->bn_moment_weight;
+    f.write_loss = (has_dpred == 0) && ar->loss && mode != 0;
+    f.write_grads = mode != 0;          // forward only: just the batch statistics for the running-stat update
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L), dim3(256), 0, stream, f);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

@@ -218,7 +218,7 @@ class ST_GCN_model(nn.Module):
             if nbytes == 0:
                 raise RuntimeError(
                     f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
-                    "(train path: num_patch <= 16 with num_layers <= 3, or num_patch <= 64 with num_layers <= 2)")
+                    "(fused kernels: num_patch <= 16 with num_layers <= 3, or <= 64 with <= 2 layers; tiled path: num_patch 65..4096)")
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._ws_key = key
         return self._ws

@@ -111,6 +111,25 @@ def test_phm2012_shape_trains_and_unsupported_shape_raises_clearly():
     algo.eval()
     with torch.no_grad():
         assert algo.model(x).shape == (50, 1)
-    big = ST_GCN_model(160, 16).to(DEV).train()       # PHM2012 Condition_2: num_patch > 64 is not covered
-    with pytest.raises(RuntimeError, match="num_patch"):
-        big(torch.rand(8, 1, 2560, device=DEV))
+    with pytest.raises(RuntimeError):                 # MPNN order k = 2 is not implemented: loud, no fallback
+        ST_GCN_model(14, 30, k=2).to(DEV).eval()(torch.rand(8, 14, 30, device=DEV))
+
+
+def test_xjtu_and_phm_c2_shapes_train_on_the_tiled_path():
+    """Reference-wired bearing configs with num_patch > 64 (configs/hparams.py:271,349): tiled path."""
+    for cfg, seq in (({"num_patch": 160, "patch_size": 16, "dropout": 0.2}, 2560), ({"num_patch": 1024, "patch_size": 32, "dropout": 0.3}, 32768)):
+        torch.manual_seed(1)
+        algo = ST_GCN(cfg, {"learning_rate": 1e-4, "weight_decay": 1e-4}, DEV)
+        algo.to(DEV).train()
+        x, y = torch.rand(20, 1, seq, device=DEV), torch.rand(20, 1, device=DEV)
+        losses = [algo.update(x, y, 1)["loss"] for _ in range(6)]
+        assert all(np.isfinite(losses)), (cfg, losses)
+        if cfg["num_patch"] == 160:          # (with 3M parameters and 20 random samples Adam's first steps are not monotone)
+            assert losses[-1] < losses[0], (cfg, losses)
+        algo.eval()
+        with torch.no_grad():
+            assert algo.model(x).shape == (20, 1)
+        # the autograd path goes through the same kernels
+        algo.train()
+        l2 = algo.update_reference_style(x, y, 1)["loss"]
+        assert np.isfinite(l2)

@@ -62,7 +62,10 @@ def test_train_matches_reference_autograd(name, mode):
                                        (9, 21, 35, 2, 0.2), (3, 6, 18, 2, 0.0), (14, 30, 77, 1, 0.2), (14, 30, 41, 3, 0.2),
                                        # num_patch > 16: one sample per wavefront (row width 64), PHM2012-like shapes
                                        (40, 64, 9, 2, 0.0), (40, 64, 33, 2, 0.2), (17, 30, 21, 2, 0.2), (24, 20, 37, 2, 0.3),
-                                       (64, 10, 6, 2, 0.2), (33, 16, 5, 1, 0.2)])
+                                       (64, 10, 6, 2, 0.2), (33, 16, 5, 1, 0.2),
+                                       # num_patch > 64: tiled path (PHM2012 Condition_2 160x16, XJTU-SY 1024x32 / 2048x16)
+                                       (65, 8, 5, 2, 0.0), (160, 16, 7, 2, 0.2), (200, 6, 3, 1, 0.3), (300, 5, 4, 3, 0.2),
+                                       (1024, 32, 3, 2, 0.3), (2048, 16, 2, 2, 0.2)])
 def test_train_matches_oracle_seeded(N, P, B, L, p):
     import gpu_util as G
     rng = np.random.default_rng(N * 1000 + P * 10 + B)
@@ -153,6 +156,7 @@ def test_train_rejects_unsupported_shapes():
     from gnn_rul_benchmarking_amd import _lib
     lib = _lib.load()
     assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 40, 64))) > 0      # PHM2012 c1/c3: covered
-    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 160, 16))) == 0    # PHM2012 c2: num_patch > 64
-    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 1024, 32))) == 0   # XJTU
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 160, 16))) > 0     # PHM2012 c2: tiled path
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 1024, 32))) > 0    # XJTU: tiled path
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 8192, 4))) == 0    # beyond every path
     assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 40, 64, L=3))) == 0  # 3 layers only for num_patch <= 16
