@@ -276,6 +276,8 @@ if __name__ == "__main__":
     case_forward_backward("stgcn_9x21_bs7", 9, 21, 7, seed=4)
     # reference-wired PHM2012 shape (configs/hparams.py:238), [bs, 1, 2560]
     case_forward_backward("stgcn_phm_40x64_bs4", 40, 64, 4, seed=5, x_shape=(4, 1, 2560))
+    # reference-wired PHM2012 Condition_2 shape (configs/hparams.py:271): 160 patches -> tiled path
+    case_forward_backward("stgcn_phm2_160x16_bs4", 160, 16, 4, seed=7, x_shape=(4, 1, 2560))
     # constant patch -> NaN propagation parity
     case_forward_backward("stgcn_nan_14x30_bs4", 14, 30, 4, seed=6, make_nan=True)
     case_training_curve("stgcn_train_curve_14x30_bs32", 14, 30, 32, steps=24, seed=8, lr=1e-3, wd=1e-4)
