@@ -34,9 +34,18 @@ static int check_ptrs(std::initializer_list<const void*> ps) {
     return RULGNN_OK;
 }
 
+// Path selection.  The fused row-mapped kernels cover num_patch <= 64 as long as one wavefront's input tile
+// fits its LDS staging area (and, for training, num_layers <= 3 / <= 2); everything else valid goes to the
+// tiled path, which has no such limits.
+static bool tiled_eval(const rulgnn_stgcn_shape* shape) {
+    TileGeom g;
+    return tile_geometry(shape, &g) != RULGNN_OK;
+}
+static bool tiled(const rulgnn_stgcn_shape* shape) { return stgcn_train_workspace_bytes(shape) == 0; }
+
 size_t rulgnn_stgcn_forward_workspace_bytes(const rulgnn_stgcn_shape* shape) {
     if (validate_shape(shape) != RULGNN_OK) return 0;
-    return shape->num_patch > 64 ? stgcn_tiled_forward_workspace_bytes(shape) : 0;
+    return tiled_eval(shape) ? stgcn_tiled_forward_workspace_bytes(shape) : 0;
 }
 
 int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
@@ -47,13 +56,11 @@ int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, co
     if (shape->batch == 0) return RULGNN_OK;
     rc = check_ptrs({x, params, bn_stats, pred});
     if (rc != RULGNN_OK) return rc;
-    if (shape->num_patch > 64)
+    if (tiled_eval(shape))
         return stgcn_tiled_forward_eval(shape, x, params, bn_stats, pred, workspace, workspace_bytes,
                                         static_cast<hipStream_t>(stream));
     return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream));
 }
-
-static bool tiled(const rulgnn_stgcn_shape* shape) { return shape->num_patch > 64; }
 
 static size_t train_ws_bytes(const rulgnn_stgcn_shape* shape) {
     return tiled(shape) ? stgcn_tiled_train_workspace_bytes(shape) : stgcn_train_workspace_bytes(shape);

@@ -218,7 +218,7 @@ class ST_GCN_model(nn.Module):
             if nbytes == 0:
                 raise RuntimeError(
                     f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
-                    "(fused kernels: num_patch <= 16 with num_layers <= 3, or <= 64 with <= 2 layers; tiled path: num_patch 65..4096)")
+                    "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)")
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._ws_key = key
         return self._ws
@@ -329,7 +329,7 @@ class ST_GCN_model(nn.Module):
             return self._train_forward(x2d).view(-1, 1)
         out = torch.empty(B, dtype=torch.float32, device=x2d.device)
         shp = self._shape(B)
-        nbytes = _lib.load().rulgnn_stgcn_forward_workspace_bytes(C.byref(shp))       # 0 for num_patch <= 64
+        nbytes = _lib.load().rulgnn_stgcn_forward_workspace_bytes(C.byref(shp))       # 0 on the fused path
         if nbytes and (self._fwd_ws is None or self._fwd_ws.numel() < nbytes or self._fwd_ws.device != x2d.device):
             self._fwd_ws = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
         _lib.check(_lib.load().rulgnn_stgcn_forward_f32(C.byref(shp), x2d.data_ptr(), self._flat.data_ptr(),

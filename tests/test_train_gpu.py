@@ -159,4 +159,34 @@ def test_train_rejects_unsupported_shapes():
     assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 160, 16))) > 0     # PHM2012 c2: tiled path
     assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 1024, 32))) > 0    # XJTU: tiled path
     assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 8192, 4))) == 0    # beyond every path
-    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 40, 64, L=3))) == 0  # 3 layers only for num_patch <= 16
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 40, 64, L=3))) > 0  # beyond the fused kernels' layer limit: tiled path
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(G.shape_struct(8, 14, 30, L=9))) == 0  # num_layers > 8
+
+
+def test_randomised_shape_sweep_forward_and_training():
+    """Seeded random (num_patch, patch_size, batch, layers, dropout) across all three kernel paths, incl. shapes
+    whose input tile does not fit the fused kernels' LDS staging (routed to the tiled path)."""
+    import gpu_util as G
+    rng = np.random.default_rng(2024)
+    shapes = [(14, 200, 9, 2, 0.2), (16, 160, 5, 2, 0.0), (40, 300, 3, 2, 0.2), (14, 30, 6, 4, 0.2), (40, 16, 5, 3, 0.1)]
+    for _ in range(14):
+        N = int(rng.choice([2, 3, 7, 13, 16, 17, 31, 48, 64, 65, 96, 130]))
+        P = int(rng.integers(3, 70))
+        shapes.append((N, P, int(rng.integers(1, 40)), int(rng.integers(1, 3)), float(rng.choice([0.0, 0.2, 0.5]))))
+    checked = 0
+    for (N, P, B, L, p) in shapes:
+        prm = O.random_params(N, L, seed=N + P)
+        x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+        y = rng.uniform(0, 1, (B,)).astype(np.float32)
+        ref = O.forward(prm, x.astype(np.float64), N, P, L).pred[:, 0]
+        if not np.isfinite(ref).all():
+            continue                                  # degenerate statistics (e.g. num_patch 2): covered by the NaN fixture
+        flat, bn = PL.pack_numpy(prm, N, L)
+        assert G.rel_err(G.abi_forward(x, flat, bn, N, P, L=L), ref) < TOL, (N, P, B, L)
+        r = G.abi_train(x, y, flat, N, P, L=L, dropout=p, seed=5, step=3)
+        pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, 5, 3)
+        assert G.rel_err(r["pred"], pred) < TOL, (N, P, B, L, p)
+        assert abs(r["loss"] - loss) < TOL * abs(loss)
+        check_grads(r["grads"], gref, N, L)
+        checked += 1
+    assert checked >= 12
