@@ -34,6 +34,21 @@ class AdamArgs(C.Structure):
                 ("weight_decay", C.c_float), ("bn_momentum", C.c_float)]
 
 
+STMSGCN_MAX_LAYERS = 6
+
+
+class StmsgcnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_patch", C.c_int32), ("patch_size", C.c_int32), ("interval", C.c_int32),
+                ("band_width", C.c_int32), ("num_gcn_layers", C.c_int32), ("gcn_dims", C.c_int32 * STMSGCN_MAX_LAYERS),
+                ("gru_hidden", C.c_int32)]
+
+
+class StmsgcnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p),
+                ("grads", C.c_void_p), ("pred", C.c_void_p), ("loss", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -54,6 +69,13 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
+    "rulgnn_stmsgcn_param_count": (C.c_int64, [C.POINTER(StmsgcnShape)]),
+    "rulgnn_stmsgcn_workspace_bytes": (C.c_size_t, [C.POINTER(StmsgcnShape)]),
+    "rulgnn_stmsgcn_features_f32": (C.c_int, [C.POINTER(StmsgcnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rulgnn_stmsgcn_forward_f32": (C.c_int, [C.POINTER(StmsgcnShape), C.POINTER(StmsgcnArgs), C.c_void_p]),
+    "rulgnn_stmsgcn_backward_f32": (C.c_int, [C.POINTER(StmsgcnShape), C.POINTER(StmsgcnArgs), C.c_void_p]),
+    "rulgnn_stmsgcn_fwdbwd_f32": (C.c_int, [C.POINTER(StmsgcnShape), C.POINTER(StmsgcnArgs), C.POINTER(AdamArgs),
+                                             C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

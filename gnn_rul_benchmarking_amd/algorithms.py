@@ -2,8 +2,8 @@
 algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
 ``NotImplementedError("Algorithm not found: ...")`` otherwise).
 
-Only the ST_GCN wrapper (reference algorithms/algorithms.py:465-490) is implemented: it is the
-hot path this package accelerates.  The class keeps the reference contract -- constructor
+The ST_GCN (reference algorithms/algorithms.py:465-490) and STMSGCN (:546-571) wrappers are implemented:
+the hot paths this package accelerates.  The classes keep the reference contract -- constructor
 ``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
 ``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
 from __future__ import annotations
@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .optim import FusedAdam
 from .stgcn import ST_GCN_model
+from .stmsgcn import STMSGCN_model
 
 
 def get_algorithm_class(algorithm_name):
@@ -79,4 +80,38 @@ class ST_GCN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class STMSGCN(Algorithm):
+    """STMSGCN training wrapper (reference algorithms.py:546-571): ``update`` = forward + MSE + backward + Adam in one
+    C call (SED/GCN/GRU kernels of csrc/stmsgcn.hip + the fused Adam kernel).  The model has neither BatchNorm nor
+    dropout, so train and eval mode compute the same function."""
+
+    def __init__(self, configs, hparams, device):
+        super(STMSGCN, self).__init__(configs)
+        self.model = STMSGCN_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if self.dp is None:
+            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        else:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        return {'loss': loss.item() if self.sync_loss else loss}
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd; same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "get_algorithm_class", "torch", "nn", "annotations"}

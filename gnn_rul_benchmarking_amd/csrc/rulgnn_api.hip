@@ -169,4 +169,67 @@ int rulgnn_bn_running_update_f32(float* bn_stats, const float* bn_batch, int32_t
     return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, from_moments, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- STMSGCN ------------------------------------------------------------------------------------------
+int64_t rulgnn_stmsgcn_param_count(const rulgnn_stmsgcn_shape* shape) { return stmsgcn_param_count(shape); }
+
+size_t rulgnn_stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* shape) { return stmsgcn_workspace_bytes(shape); }
+
+int rulgnn_stmsgcn_features_f32(const rulgnn_stmsgcn_shape* shape, const float* x, const float* params, float* features,
+                                void* stream) {
+    if (!shape) return RULGNN_EINVAL;
+    if (stmsgcn_param_count(shape) >= 0 && shape->batch == 0) return RULGNN_OK;
+    const int rc = check_ptrs({x, params, features});
+    if (rc != RULGNN_OK) return rc;
+    return stmsgcn_features(shape, x, params, features, static_cast<hipStream_t>(stream));
+}
+
+static int check_stmsgcn(const rulgnn_stmsgcn_shape* shape, const rulgnn_stmsgcn_args* a, bool backward, bool need_target) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (shape->batch < 1 || a->global_batch < shape->batch) return RULGNN_EINVAL;
+    int rc = check_ptrs({a->x, a->params, a->pred, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (a->y && (reinterpret_cast<uintptr_t>(a->y) & 3)) return RULGNN_EALIGN;
+    if (backward) {
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (a->dpred) {
+            if (reinterpret_cast<uintptr_t>(a->dpred) & 3) return RULGNN_EALIGN;
+        } else if (need_target) {
+            rc = check_ptrs({a->y, a->loss});
+            if (rc != RULGNN_OK) return rc;
+        }
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_stmsgcn_forward_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_stmsgcn_args* args, void* stream) {
+    const int rc = check_stmsgcn(shape, args, false, false);
+    if (rc != RULGNN_OK) return rc;
+    return stmsgcn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stmsgcn_backward_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_stmsgcn_args* args, void* stream) {
+    const int rc = check_stmsgcn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    return stmsgcn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_stmsgcn_args* args, const rulgnn_adam_args* opt,
+                              void* stream) {
+    int rc = check_stmsgcn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred) return RULGNN_EINVAL;                 // the fused call is the MSE step
+    if (opt) {
+        if (opt->step < 1 || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = stmsgcn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stmsgcn_param_count(shape), opt->step, opt->lr,
+                     opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st);
+}
+
 }  // extern "C"

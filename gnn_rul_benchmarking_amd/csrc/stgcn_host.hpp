@@ -95,6 +95,10 @@ int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const rulgnn_adam_args* opt,
                      hipStream_t stream);
 int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream);
+int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s);
+size_t stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* s);
+int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float* prm, float* features, hipStream_t stream);
+int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream);
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,

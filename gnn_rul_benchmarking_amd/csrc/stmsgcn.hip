@@ -1,0 +1,792 @@
+// STMSGCN path for gfx950: SED features -> GCN stack -> GRU -> node mean -> Linear, forward and backward.
+//
+// Reference: models/STMSGCN/Model.py (SED_features :7-31, GCNLayer :34-49, GRULayer :52-60,
+// STMSGCN_model.forward :84-112) and algorithms/algorithms.py:546-571 (MSE + Adam).
+//
+// Decomposition.  A sample is num_patch independent small graphs (nodes = spectral
+// bands of one patch, <= 32) followed by a GRU that runs over the patches for every (sample, node) pair:
+//   features   one workgroup per graph: direct DFT of the patch in LDS -> SED -> the GCN layers with all
+//              operands (features, adjacency, weights) in LDS -> writes the concatenated features `cat`
+//              [graph][node][C] and, fused, the GRU input projection gi = cat W_ih^T + b_ih;
+//   gru_fwd    one lane per (sequence, hidden unit): the recurrence over num_patch steps;
+//   head       one workgroup per sample: mean over nodes, Linear, squared error and d loss / d pred;
+//   gru_bwd    BPTT with the gates recomputed from gi and h; writes d gi;
+//   gcn_bwd    one workgroup per graph: d cat = d gi W_ih, then the GCN layers backwards (through the
+//              linear map, both D^-1/2 factors, the row sums and the Gram matrix), weight gradients
+//              accumulated in LDS per workgroup;
+//   finalize   fixed-order reduction of the per-workgroup partial gradients, fc gradients, loss.
+// Everything is fp32; reductions have a fixed order, so results are run-to-run reproducible.
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+constexpr int MB = 256;             // threads per workgroup
+constexpr int MAXN = 32;            // graph nodes
+constexpr int MAXL = RULGNN_STMSGCN_MAX_LAYERS;
+constexpr float LEAKY = 0.01f;      // F.leaky_relu default slope (Model.py:47)
+
+struct MsgGeom {
+    int64_t B, G;                   // samples, graphs = B * NP
+    int NP, P, interval, bw, n, L, C, H, H3;
+    int dims[MAXL + 1];             // [1, gcn_dims...]
+    int coff[MAXL + 2];             // column offset of each layer's features inside cat
+    int woff[MAXL], boff[MAXL];     // parameter offsets
+    int gcn_params;                 // floats in the GCN layers (prefix of the flat buffer)
+    int off_wih, off_whh, off_bih, off_bhh, off_fcw, off_fcb, nparam;
+    int CS, AXS, maxf;              // LDS strides (odd) and the widest layer input
+};
+
+__host__ int msg_geometry(const rulgnn_stmsgcn_shape* s, MsgGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->batch < 0 || s->num_patch < 1 || s->patch_size < 2 || s->interval < 1 || s->band_width < 1 ||
+        s->num_gcn_layers < 1 || s->gru_hidden < 1)
+        return RULGNN_EINVAL;
+    if (s->interval >= s->patch_size || (s->patch_size - s->interval) % s->band_width != 0) return RULGNN_EINVAL;
+    if (s->num_gcn_layers > MAXL || s->patch_size > 512 || s->num_patch > 4096 || s->gru_hidden > 16)
+        return RULGNN_EUNSUPPORTED;
+    g->n = (s->patch_size - s->interval) / s->band_width;
+    if (g->n > MAXN) return RULGNN_EUNSUPPORTED;
+    g->B = s->batch;
+    g->NP = s->num_patch;
+    g->G = s->batch * (int64_t)s->num_patch;
+    if (g->G * g->n > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
+    g->P = s->patch_size;
+    g->interval = s->interval;
+    g->bw = s->band_width;
+    g->L = s->num_gcn_layers;
+    g->H = s->gru_hidden;
+    g->H3 = 3 * g->H;
+    g->dims[0] = 1;
+    g->coff[0] = 0;
+    g->coff[1] = 1;
+    int off = 0, maxf = 1;
+    for (int l = 0; l < g->L; ++l) {
+        const int f = s->gcn_dims[l];
+        if (f < 1) return RULGNN_EINVAL;
+        if (f > 64) return RULGNN_EUNSUPPORTED;
+        g->dims[l + 1] = f;
+        g->coff[l + 2] = g->coff[l + 1] + f;
+        g->woff[l] = off;
+        off += f * g->dims[l];
+        g->boff[l] = off;
+        off += f;
+        if (g->dims[l] > maxf) maxf = g->dims[l];
+    }
+    g->C = g->coff[g->L + 1];
+    if (g->C > 128) return RULGNN_EUNSUPPORTED;
+    g->gcn_params = off;
+    g->off_wih = off; off += g->H3 * g->C;
+    g->off_whh = off; off += g->H3 * g->H;
+    g->off_bih = off; off += g->H3;
+    g->off_bhh = off; off += g->H3;
+    g->off_fcw = off; off += g->NP * g->H;
+    g->off_fcb = off; off += 1;
+    g->nparam = off;
+    g->CS = g->C | 1;
+    g->maxf = maxf;
+    g->AXS = maxf | 1;
+    return RULGNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// shared per-graph stages (block-cooperative; all operands in LDS)
+// ---------------------------------------------------------------------------------------------------
+// A' = x x^T + I for the feature slice [off, off+f) of cat  (Model.py:98 and :41).
+__device__ inline void gram_plus_identity(const float* cat, int CS, int off, int f, int n, float* araw) {
+    for (int e = threadIdx.x; e < n * n; e += MB) {
+        const int i = e / n, j = e - i * n;
+        const float* xi = cat + i * CS + off;
+        const float* xj = cat + j * CS + off;
+        float a = 0.f;
+        for (int c = 0; c < f; ++c) a = fmaf(xi[c], xj[c], a);
+        araw[i * (n + 1) + j] = a + (i == j ? 1.f : 0.f);
+    }
+}
+// r = rowsum(A')^-1/2 (Model.py:43; a negative row sum gives NaN exactly like torch's pow).
+__device__ inline void inv_sqrt_degree(const float* araw, int n, float* rv) {
+    if (threadIdx.x < n) {
+        const float* row = araw + threadIdx.x * (n + 1);
+        float d = 0.f;
+        for (int j = 0; j < n; ++j) d += row[j];
+        rv[threadIdx.x] = 1.0f / sqrtf(d);
+    }
+}
+// ahat = D (A' D)  (Model.py:44)
+__device__ inline void normalise(const float* araw, const float* rv, int n, float* ahat) {
+    for (int e = threadIdx.x; e < n * n; e += MB) {
+        const int i = e / n, j = e - i * n;
+        ahat[i * (n + 1) + j] = (araw[i * (n + 1) + j] * rv[j]) * rv[i];
+    }
+}
+// AX = ahat x  (Model.py:45)
+__device__ inline void aggregate(const float* ahat, const float* cat, int CS, int off, int f, int n, float* ax, int AXS) {
+    for (int e = threadIdx.x; e < n * f; e += MB) {
+        const int i = e / f, c = e - i * f;
+        const float* ar = ahat + i * (n + 1);
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a = fmaf(ar[j], cat[j * CS + off + c], a);
+        ax[i * AXS + c] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// features: SED + GCN stack (+ GRU input projection)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float* __restrict__ x,
+                                                          const float* __restrict__ prm, float* __restrict__ cat_out,
+                                                          float* __restrict__ gi_out) {
+    extern __shared__ float smem[];
+    const int n = g.n, P = g.P, C = g.C, CS = g.CS, AXS = g.AXS, H3 = g.H3;
+    float* wt = smem;                              // per layer: Wt[k][o] (transposed) | b[o]
+    float* wih = wt + g.gcn_params;                // WihT[c][3H] | b_ih[3H]
+    float* tw = wih + (C + 1) * H3;                // (cos, sin)(2 pi k / P)
+    float* xs = tw + 2 * P;
+    float* fre = xs + P;
+    float* fim = fre + P;
+    float* cat = fim + P;                          // [n][CS]
+    float* araw = cat + n * CS;                    // [n][n+1]
+    float* rv = araw + n * (n + 1);                // [32]
+    float* ax = rv + MAXN;                         // [n][AXS]
+    const int tid = threadIdx.x;
+
+    for (int l = 0; l < g.L; ++l) {
+        const int fi = g.dims[l], fo = g.dims[l + 1];
+        for (int e = tid; e < fi * fo; e += MB) {
+            const int o = e / fi, k = e - o * fi;
+            wt[g.woff[l] + k * fo + o] = prm[g.woff[l] + e];
+        }
+        for (int e = tid; e < fo; e += MB) wt[g.boff[l] + e] = prm[g.boff[l] + e];
+    }
+    if (gi_out) {
+        for (int e = tid; e < H3 * C; e += MB) {
+            const int q = e / C, c = e - q * C;
+            wih[c * H3 + q] = prm[g.off_wih + e];
+        }
+        for (int e = tid; e < H3; e += MB) wih[C * H3 + e] = prm[g.off_bih + e];
+    }
+    for (int k = tid; k < P; k += MB) {
+        float sn, cs;
+        sincospif(2.0f * (float)k / (float)P, &sn, &cs);
+        tw[2 * k] = cs;
+        tw[2 * k + 1] = sn;
+    }
+    __syncthreads();
+
+    for (int64_t gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
+        // ---- SED_features (Model.py:7-31): full DFT of the patch, lagged difference, band energies ----
+        const float* xp = x + gi * P;
+        for (int k = tid; k < P; k += MB) xs[k] = xp[k];
+        __syncthreads();
+        for (int j = tid; j < P; j += MB) {
+            float re = 0.f, im = 0.f;
+            int idx = 0;
+            for (int t = 0; t < P; ++t) {
+                const float v = xs[t];
+                re = fmaf(v, tw[2 * idx], re);
+                im = fmaf(-v, tw[2 * idx + 1], im);
+                idx += j;
+                if (idx >= P) idx -= P;
+            }
+            fre[j] = re;
+            fim[j] = im;
+        }
+        __syncthreads();
+        float en[2] = {0.f, 0.f};
+        for (int j = tid, r = 0; j < P - g.interval; j += MB, ++r) {
+            const float dr = fre[j + g.interval] - fre[j], di = fim[j + g.interval] - fim[j];
+            en[r] = dr * dr + di * di;
+        }
+        __syncthreads();
+        for (int j = tid, r = 0; j < P - g.interval; j += MB, ++r) fre[j] = en[r];
+        __syncthreads();
+        if (tid < n) {
+            float s = 0.f;
+            for (int q = 0; q < g.bw; ++q) s += fre[tid * g.bw + q];
+            cat[tid * CS] = s;
+        }
+        __syncthreads();
+        // ---- GCN stack (Model.py:96-100) ----
+        for (int l = 0; l < g.L; ++l) {
+            const int fi = g.dims[l], fo = g.dims[l + 1], off = g.coff[l], offo = g.coff[l + 1];
+            gram_plus_identity(cat, CS, off, fi, n, araw);
+            __syncthreads();
+            inv_sqrt_degree(araw, n, rv);
+            __syncthreads();
+            normalise(araw, rv, n, araw);
+            __syncthreads();
+            aggregate(araw, cat, CS, off, fi, n, ax, AXS);
+            __syncthreads();
+            const float* w = wt + g.woff[l];
+            const float* b = wt + g.boff[l];
+            for (int e = tid; e < n * fo; e += MB) {
+                const int i = e / fo, o = e - i * fo;
+                float z = 0.f;
+                for (int k = 0; k < fi; ++k) z = fmaf(ax[i * AXS + k], w[k * fo + o], z);
+                z += b[o];
+                cat[i * CS + offo + o] = z > 0.f ? z : LEAKY * z;
+            }
+            __syncthreads();
+        }
+        if (cat_out) {
+            float* dst = cat_out + gi * (int64_t)(n * C);
+            for (int e = tid; e < n * C; e += MB) {
+                const int i = e / C, c = e - i * C;
+                dst[e] = cat[i * CS + c];
+            }
+        }
+        if (gi_out) {                              // GRU input projection, fused (nn.GRU: x W_ih^T + b_ih)
+            float* dst = gi_out + gi * (int64_t)(n * H3);
+            for (int e = tid; e < n * H3; e += MB) {
+                const int i = e / H3, q = e - i * H3;
+                float a = 0.f;
+                for (int c = 0; c < C; ++c) a = fmaf(cat[i * CS + c], wih[c * H3 + q], a);
+                dst[e] = a + wih[C * H3 + q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t features_lds_bytes(const MsgGeom& g) {
+    return sizeof(float) * ((size_t)g.gcn_params + (g.C + 1) * g.H3 + 5 * g.P + g.n * g.CS + g.n * (g.n + 1) + MAXN +
+                            g.n * g.AXS);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GRU (nn.GRU, one layer, batch_first, h0 = 0; gate order r, z, n)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// One lane per (sequence, hidden unit); HG = lanes per sequence (power of two >= H).
+template <int HG>
+__global__ __launch_bounds__(MB) void msg_gru_forward_kernel(MsgGeom g, const float* __restrict__ gi,
+                                                             const float* __restrict__ prm, float* __restrict__ hseq) {
+    __shared__ float hs[MB];
+    const int tid = threadIdx.x, j = tid % HG, H = g.H, n = g.n;
+    const int64_t s = ((int64_t)blockIdx.x * MB + tid) / HG;           // sequence = b * n + node
+    const bool live = s < g.B * n && j < H;
+    const int64_t b = live ? s / n : 0;
+    const int node = live ? (int)(s - b * n) : 0;
+    const int jj = j < H ? j : 0;
+    float wr[HG], wz[HG], wn[HG];
+#pragma unroll
+    for (int k = 0; k < HG; ++k) {
+        const bool ok = k < H;
+        wr[k] = ok ? prm[g.off_whh + (jj) * H + k] : 0.f;
+        wz[k] = ok ? prm[g.off_whh + (H + jj) * H + k] : 0.f;
+        wn[k] = ok ? prm[g.off_whh + (2 * H + jj) * H + k] : 0.f;
+    }
+    const float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
+    const int base = tid - j;
+    float h = 0.f;
+    hs[tid] = 0.f;
+    __syncthreads();
+    int64_t row = (b * g.NP) * n + node;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (live) {
+        gr = gi[row * g.H3 + j];
+        gz = gi[row * g.H3 + H + j];
+        gn = gi[row * g.H3 + 2 * H + j];
+    }
+    for (int t = 0; t < g.NP; ++t) {
+        float nr = 0.f, nz = 0.f, nn = 0.f;
+        if (live && t + 1 < g.NP) {                                   // next step's inputs, ahead of the gate math
+            const int64_t r2 = (row + n) * g.H3;
+            nr = gi[r2 + j];
+            nz = gi[r2 + H + j];
+            nn = gi[r2 + 2 * H + j];
+        }
+        float ar = br, az = bz, an = bn;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) {
+            const float hk = hs[base + k];
+            ar = fmaf(wr[k], hk, ar);
+            az = fmaf(wz[k], hk, az);
+            an = fmaf(wn[k], hk, an);
+        }
+        const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
+        const float c = tanhf(gn + r * an);
+        h = (1.0f - z) * c + z * h;
+        __syncthreads();
+        hs[tid] = j < H ? h : 0.f;
+        __syncthreads();
+        if (live) hseq[row * H + j] = h;
+        row += n;
+        gr = nr; gz = nz; gn = nn;
+    }
+}
+
+// BPTT.  d out[t][j] = dpred[b] * fc.weight[t*H + j] / n  (mean over nodes + Linear, Model.py:109-111).
+// Gates are recomputed from gi and h[t-1]; per-lane accumulators for d W_hh / d b_hh are reduced in a
+// fixed order and written as one partial row per workgroup.
+template <int HG>
+__global__ __launch_bounds__(MB) void msg_gru_backward_kernel(MsgGeom g, const float* __restrict__ gi,
+                                                              const float* __restrict__ hseq, const float* __restrict__ prm,
+                                                              const float* __restrict__ dpred, float* __restrict__ dgi,
+                                                              float* __restrict__ gpart) {
+    __shared__ float hp[MB];
+    __shared__ float dg[3][MB];
+    __shared__ float red[MB / 64][3 * 16 * 16 + 3 * 16];
+    const int tid = threadIdx.x, j = tid % HG, H = g.H, n = g.n;
+    const int64_t s = ((int64_t)blockIdx.x * MB + tid) / HG;
+    const bool live = s < g.B * n && j < H;
+    const int64_t b = live ? s / n : 0;
+    const int node = live ? (int)(s - b * n) : 0;
+    const int jj = j < H ? j : 0;
+    float wr[HG], wz[HG], wn[HG], tr[HG], tz[HG], tn[HG], ar_[HG], az_[HG], an_[HG];
+#pragma unroll
+    for (int k = 0; k < HG; ++k) {
+        const bool ok = k < H;
+        wr[k] = ok ? prm[g.off_whh + (jj) * H + k] : 0.f;             // row jj of each gate block
+        wz[k] = ok ? prm[g.off_whh + (H + jj) * H + k] : 0.f;
+        wn[k] = ok ? prm[g.off_whh + (2 * H + jj) * H + k] : 0.f;
+        tr[k] = ok ? prm[g.off_whh + (k) * H + jj] : 0.f;              // column jj
+        tz[k] = ok ? prm[g.off_whh + (H + k) * H + jj] : 0.f;
+        tn[k] = ok ? prm[g.off_whh + (2 * H + k) * H + jj] : 0.f;
+        ar_[k] = az_[k] = an_[k] = 0.f;
+    }
+    const float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
+    float abr = 0.f, abz = 0.f, abn = 0.f;
+    const int base = tid - j;
+    const float dscale = live ? dpred[b] / (float)n : 0.f;
+    float dh = 0.f;
+    for (int t = g.NP - 1; t >= 0; --t) {
+        const int64_t row = (b * g.NP + t) * n + node;
+        float hprev = 0.f, gr = 0.f, gz = 0.f, gn = 0.f;
+        if (live) {
+            if (t > 0) hprev = hseq[(row - n) * H + j];
+            gr = gi[row * g.H3 + j];
+            gz = gi[row * g.H3 + H + j];
+            gn = gi[row * g.H3 + 2 * H + j];
+        }
+        __syncthreads();
+        hp[tid] = hprev;
+        __syncthreads();
+        float ar = br, az = bz, an = bn;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) {
+            const float hk = hp[base + k];
+            ar = fmaf(wr[k], hk, ar);
+            az = fmaf(wz[k], hk, az);
+            an = fmaf(wn[k], hk, an);
+        }
+        const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
+        const float c = tanhf(gn + r * an);
+        dh += live ? dscale * prm[g.off_fcw + t * H + j] : 0.f;
+        const float dn_pre = dh * (1.0f - z) * (1.0f - c * c);
+        const float dz_pre = dh * (hprev - c) * z * (1.0f - z);
+        const float dr_pre = dn_pre * an * r * (1.0f - r);
+        const float dgn = dn_pre * r;
+        if (live) {
+            dgi[row * g.H3 + j] = dr_pre;
+            dgi[row * g.H3 + H + j] = dz_pre;
+            dgi[row * g.H3 + 2 * H + j] = dn_pre;
+        }
+        dg[0][tid] = live ? dr_pre : 0.f;
+        dg[1][tid] = live ? dz_pre : 0.f;
+        dg[2][tid] = live ? dgn : 0.f;
+        __syncthreads();
+        float acc = dh * z;
+#pragma unroll
+        for (int k = 0; k < HG; ++k) {
+            const float hk = hp[base + k];
+            ar_[k] = fmaf(live ? dr_pre : 0.f, hk, ar_[k]);
+            az_[k] = fmaf(live ? dz_pre : 0.f, hk, az_[k]);
+            an_[k] = fmaf(live ? dgn : 0.f, hk, an_[k]);
+            acc = fmaf(dg[0][base + k], tr[k], acc);
+            acc = fmaf(dg[1][base + k], tz[k], acc);
+            acc = fmaf(dg[2][base + k], tn[k], acc);
+        }
+        abr += live ? dr_pre : 0.f;
+        abz += live ? dz_pre : 0.f;
+        abn += live ? dgn : 0.f;
+        dh = acc;
+    }
+    // reduce the per-lane accumulators over the sequences of this workgroup: butterfly across the lanes that hold the
+    // same unit, then the four wavefronts in order.
+    const int wave = tid / 64, lane = tid % 64;
+    auto wave_sum = [&](float v) {
+#pragma unroll
+        for (int m = HG; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+        return v;
+    };
+    const int nW = 3 * H * H;
+#pragma unroll
+    for (int k = 0; k < HG; ++k) {
+        const float a = wave_sum(ar_[k]), c = wave_sum(az_[k]), d = wave_sum(an_[k]);
+        if (lane < HG && j < H && k < H) {
+            red[wave][(j) * H + k] = a;
+            red[wave][(H + j) * H + k] = c;
+            red[wave][(2 * H + j) * H + k] = d;
+        }
+    }
+    {
+        const float a = wave_sum(abr), c = wave_sum(abz), d = wave_sum(abn);
+        if (lane < HG && j < H) {
+            red[wave][nW + j] = a;
+            red[wave][nW + H + j] = c;
+            red[wave][nW + 2 * H + j] = d;
+        }
+    }
+    __syncthreads();
+    float* dst = gpart + (int64_t)blockIdx.x * (nW + 3 * H);
+    for (int e = tid; e < nW + 3 * H; e += MB) dst[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// head: mean over nodes, fc, squared error
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __restrict__ hseq, const float* __restrict__ prm,
+                                                      const float* __restrict__ y, float* __restrict__ pred,
+                                                      float* __restrict__ pooled, float* __restrict__ dpred,
+                                                      float* __restrict__ sqerr, float inv_gb) {
+    __shared__ float red[MB];
+    const int64_t b = blockIdx.x;
+    const int H = g.H, n = g.n, Q = g.NP * H;
+    float acc = 0.f;
+    for (int q = threadIdx.x; q < Q; q += MB) {
+        const int p = q / H, j = q - p * H;
+        const float* src = hseq + ((b * g.NP + p) * n) * H + j;
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += src[i * H];
+        s = s / (float)n;
+        pooled[b * Q + q] = s;
+        acc = fmaf(s, prm[g.off_fcw + q], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int m = MB / 2; m > 0; m >>= 1) {
+        if (threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float pr = red[0] + prm[g.off_fcb];
+        pred[b] = pr;
+        if (y) {
+            const float d = pr - y[b];
+            dpred[b] = 2.0f * d * inv_gb;
+            sqerr[b] = d * d * inv_gb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GCN stack backward (+ GRU input projection backward)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const float* __restrict__ cat_in,
+                                                              const float* __restrict__ dgi_in, const float* __restrict__ prm,
+                                                              float* __restrict__ gpart) {
+    extern __shared__ float smem[];
+    const int n = g.n, C = g.C, CS = g.CS, AXS = g.AXS, H3 = g.H3, n1 = n + 1;
+    const int nacc = g.gcn_params + H3 * C + H3;
+    float* w = smem;                               // GCN weights, row-major as in the flat buffer
+    float* wih = w + g.gcn_params;                 // W_ih[3H][C]
+    float* acc = wih + H3 * C;                     // gradient accumulators: GCN | W_ih | b_ih
+    float* cat = acc + nacc;                       // [n][CS]
+    float* dcat = cat + n * CS;                    // [n][CS]
+    float* dgi = dcat + n * CS;                    // [n][3H]
+    float* araw = dgi + n * H3;                    // [n][n+1]
+    float* ahat = araw + n * n1;
+    float* dah = ahat + n * n1;
+    float* rv = dah + n * n1;                      // [32]
+    float* ddv = rv + MAXN;                        // [32]
+    float* ax = ddv + MAXN;                        // [n][AXS]  (AX, then dAX)
+    const int tid = threadIdx.x;
+
+    for (int e = tid; e < g.gcn_params; e += MB) w[e] = prm[e];
+    for (int e = tid; e < H3 * C; e += MB) wih[e] = prm[g.off_wih + e];
+    for (int e = tid; e < nacc; e += MB) acc[e] = 0.f;
+    __syncthreads();
+
+    for (int64_t gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
+        const float* csrc = cat_in + gi * (int64_t)(n * C);
+        for (int e = tid; e < n * C; e += MB) {
+            const int i = e / C, c = e - i * C;
+            cat[i * CS + c] = csrc[e];
+        }
+        const float* gsrc = dgi_in + gi * (int64_t)(n * H3);
+        for (int e = tid; e < n * H3; e += MB) dgi[e] = gsrc[e];
+        __syncthreads();
+        // d cat = d gi W_ih ; d W_ih += d gi^T cat ; d b_ih += sum d gi
+        for (int e = tid; e < n * C; e += MB) {
+            const int i = e / C, c = e - i * C;
+            float a = 0.f;
+            for (int q = 0; q < H3; ++q) a = fmaf(dgi[i * H3 + q], wih[q * C + c], a);
+            dcat[i * CS + c] = a;
+        }
+        for (int e = tid; e < H3 * C; e += MB) {
+            const int q = e / C, c = e - q * C;
+            float a = 0.f;
+            for (int i = 0; i < n; ++i) a = fmaf(dgi[i * H3 + q], cat[i * CS + c], a);
+            acc[g.gcn_params + e] += a;
+        }
+        for (int q = tid; q < H3; q += MB) {
+            float a = 0.f;
+            for (int i = 0; i < n; ++i) a += dgi[i * H3 + q];
+            acc[g.gcn_params + H3 * C + q] += a;
+        }
+        __syncthreads();
+        for (int l = g.L - 1; l >= 0; --l) {
+            const int fi = g.dims[l], fo = g.dims[l + 1], off = g.coff[l], offo = g.coff[l + 1];
+            // dz = d out * leaky'(out), in place in the d cat slice of this layer's output
+            for (int e = tid; e < n * fo; e += MB) {
+                const int i = e / fo, o = e - i * fo;
+                const float out = cat[i * CS + offo + o];
+                dcat[i * CS + offo + o] *= (out > 0.f ? 1.f : LEAKY);
+            }
+            gram_plus_identity(cat, CS, off, fi, n, araw);
+            __syncthreads();
+            inv_sqrt_degree(araw, n, rv);
+            __syncthreads();
+            normalise(araw, rv, n, ahat);
+            __syncthreads();
+            aggregate(ahat, cat, CS, off, fi, n, ax, AXS);
+            __syncthreads();
+            // d W[o][k] += sum_i dz[i][o] AX[i][k] ; d b[o] += sum_i dz[i][o]
+            for (int e = tid; e < fo * fi; e += MB) {
+                const int o = e / fi, k = e - o * fi;
+                float a = 0.f;
+                for (int i = 0; i < n; ++i) a = fmaf(dcat[i * CS + offo + o], ax[i * AXS + k], a);
+                acc[g.woff[l] + e] += a;
+            }
+            for (int o = tid; o < fo; o += MB) {
+                float a = 0.f;
+                for (int i = 0; i < n; ++i) a += dcat[i * CS + offo + o];
+                acc[g.boff[l] + o] += a;
+            }
+            if (l == 0) {                           // the SED features carry no gradient
+                __syncthreads();
+                break;
+            }
+            __syncthreads();
+            // d AX = dz W   (overwrites AX)
+            for (int e = tid; e < n * fi; e += MB) {
+                const int i = e / fi, k = e - i * fi;
+                const float* wl = w + g.woff[l];
+                float a = 0.f;
+                for (int o = 0; o < fo; ++o) a = fmaf(dcat[i * CS + offo + o], wl[o * fi + k], a);
+                ax[i * AXS + k] = a;
+            }
+            __syncthreads();
+            // d ahat = d AX x^T
+            for (int e = tid; e < n * n; e += MB) {
+                const int i = e / n, j = e - i * n;
+                float a = 0.f;
+                for (int k = 0; k < fi; ++k) a = fmaf(ax[i * AXS + k], cat[j * CS + off + k], a);
+                dah[i * n1 + j] = a;
+            }
+            __syncthreads();
+            // d r (both D factors), then d(row sum): dd = -1/2 d^-3/2 dr = -1/2 r^3 dr
+            if (tid < n) {
+                const int i = tid;
+                float a = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    a = fmaf(dah[i * n1 + j] * araw[i * n1 + j], rv[j], a);
+                    a = fmaf(dah[j * n1 + i] * araw[j * n1 + i], rv[j], a);
+                }
+                const float r = rv[i];
+                ddv[i] = -0.5f * a * r * r * r;
+            }
+            __syncthreads();
+            // M = dA' + dA'^T with dA'[i][j] = r_i d ahat[i][j] r_j + dd_i   (stored over A')
+            for (int e = tid; e < n * n; e += MB) {
+                const int i = e / n, j = e - i * n;
+                araw[i * n1 + j] = rv[i] * rv[j] * (dah[i * n1 + j] + dah[j * n1 + i]) + ddv[i] + ddv[j];
+            }
+            __syncthreads();
+            // d x = ahat^T d AX + M x, accumulated into the d cat slice of this layer's input
+            for (int e = tid; e < n * fi; e += MB) {
+                const int i = e / fi, c = e - i * fi;
+                float a = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    a = fmaf(ahat[j * n1 + i], ax[j * AXS + c], a);
+                    a = fmaf(araw[i * n1 + j], cat[j * CS + off + c], a);
+                }
+                dcat[i * CS + off + c] += a;
+            }
+            __syncthreads();
+        }
+    }
+    float* dst = gpart + (int64_t)blockIdx.x * nacc;
+    for (int e = tid; e < nacc; e += MB) dst[e] = acc[e];
+}
+
+static size_t gcn_backward_lds_bytes(const MsgGeom& g) {
+    const size_t nacc = (size_t)g.gcn_params + g.H3 * g.C + g.H3;
+    return sizeof(float) * ((size_t)g.gcn_params + g.H3 * g.C + nacc + 2 * g.n * g.CS + g.n * g.H3 + 3 * g.n * (g.n + 1) +
+                            2 * MAXN + g.n * g.AXS);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finalize: partial rows -> flat gradient; fc gradients; loss
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MB) void msg_finalize_kernel(MsgGeom g, const float* __restrict__ gpart_gcn, int rows_gcn,
+                                                          const float* __restrict__ gpart_gru, int rows_gru,
+                                                          const float* __restrict__ dpred, const float* __restrict__ pooled,
+                                                          const float* __restrict__ sqerr, float* __restrict__ grads,
+                                                          float* __restrict__ loss) {
+    const int e = blockIdx.x * MB + threadIdx.x;
+    const int nacc = g.gcn_params + g.H3 * g.C + g.H3;
+    const int ngru = g.H3 * g.H + g.H3;
+    if (e < g.nparam) {
+        float a = 0.f;
+        if (e < g.off_whh) {                                   // GCN layers | W_ih
+            for (int r = 0; r < rows_gcn; ++r) a += gpart_gcn[(int64_t)r * nacc + e];
+        } else if (e < g.off_bih) {                            // W_hh
+            for (int r = 0; r < rows_gru; ++r) a += gpart_gru[(int64_t)r * ngru + (e - g.off_whh)];
+        } else if (e < g.off_bhh) {                            // b_ih
+            for (int r = 0; r < rows_gcn; ++r) a += gpart_gcn[(int64_t)r * nacc + g.gcn_params + g.H3 * g.C + (e - g.off_bih)];
+        } else if (e < g.off_fcw) {                            // b_hh
+            for (int r = 0; r < rows_gru; ++r) a += gpart_gru[(int64_t)r * ngru + g.H3 * g.H + (e - g.off_bhh)];
+        } else if (e < g.off_fcb) {                            // fc.weight
+            const int q = e - g.off_fcw, Q = g.NP * g.H;
+            for (int64_t b = 0; b < g.B; ++b) a = fmaf(dpred[b], pooled[b * Q + q], a);
+        } else {                                               // fc.bias
+            for (int64_t b = 0; b < g.B; ++b) a += dpred[b];
+        }
+        grads[e] = a;
+    }
+    if (loss && sqerr && e == g.nparam) {
+        float a = 0.f;
+        for (int64_t b = 0; b < g.B; ++b) a += sqerr[b];
+        *loss = a;
+    }
+}
+
+struct MsgWs {
+    size_t cat, gi, hseq, dgi, pooled, dpred, sqerr, gpart_gcn, gpart_gru, total;
+    int rows_gcn_max, rows_gru, HG;
+};
+
+static void msg_ws_layout(const MsgGeom& g, MsgWs* w) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t rows = (size_t)g.G * g.n;
+    size_t o = 0;
+    w->cat = o; o = al(o + rows * g.C * sizeof(float));
+    w->gi = o; o = al(o + rows * g.H3 * sizeof(float));
+    w->hseq = o; o = al(o + rows * g.H * sizeof(float));
+    w->dgi = o; o = al(o + rows * g.H3 * sizeof(float));
+    w->pooled = o; o = al(o + (size_t)g.B * g.NP * g.H * sizeof(float));
+    w->dpred = o; o = al(o + (size_t)g.B * sizeof(float));
+    w->sqerr = o; o = al(o + (size_t)g.B * sizeof(float));
+    w->HG = g.H <= 4 ? 4 : (g.H <= 8 ? 8 : 16);
+    w->rows_gcn_max = 1024;
+    w->rows_gru = (int)(((size_t)g.B * g.n * w->HG + MB - 1) / MB);
+    if (w->rows_gru < 1) w->rows_gru = 1;
+    w->gpart_gcn = o; o = al(o + (size_t)w->rows_gcn_max * (g.gcn_params + g.H3 * g.C + g.H3) * sizeof(float));
+    w->gpart_gru = o; o = al(o + (size_t)w->rows_gru * (g.H3 * g.H + g.H3) * sizeof(float));
+    w->total = o;
+}
+
+template <typename K>
+static int resident_grid(K kernel, int64_t items, size_t lds, int cap_rows) {
+    int dev = 0, cus = 256, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, MB, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    int64_t want = (int64_t)cus * per_cu;
+    if (want > items) want = items;
+    if (want > cap_rows) want = cap_rows;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+static int launch_features(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
+    const size_t lds = features_lds_bytes(g);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(msg_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    const int grid = resident_grid(msg_features_kernel, g.G, lds, 1 << 20);
+    hipLaunchKernelGGL(msg_features_kernel, dim3(grid), dim3(MB), lds, st, g, x, prm, cat, gi);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+template <int HG>
+static void launch_gru(const MsgGeom& g, const MsgWs& w, char* ws, const float* prm, bool backward, hipStream_t st) {
+    const int grid = w.rows_gru;
+    if (!backward)
+        hipLaunchKernelGGL(msg_gru_forward_kernel<HG>, dim3(grid), dim3(MB), 0, st, g, (const float*)(ws + w.gi), prm,
+                           (float*)(ws + w.hseq));
+    else
+        hipLaunchKernelGGL(msg_gru_backward_kernel<HG>, dim3(grid), dim3(MB), 0, st, g, (const float*)(ws + w.gi),
+                           (const float*)(ws + w.hseq), prm, (const float*)(ws + w.dpred), (float*)(ws + w.dgi),
+                           (float*)(ws + w.gpart_gru));
+}
+
+static void dispatch_gru(const MsgGeom& g, const MsgWs& w, char* ws, const float* prm, bool backward, hipStream_t st) {
+    if (w.HG == 4) launch_gru<4>(g, w, ws, prm, backward, st);
+    else if (w.HG == 8) launch_gru<8>(g, w, ws, prm, backward, st);
+    else launch_gru<16>(g, w, ws, prm, backward, st);
+}
+
+}  // namespace
+
+int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s) {
+    MsgGeom g;
+    return msg_geometry(s, &g) == RULGNN_OK ? g.nparam : -1;
+}
+
+size_t stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* s) {
+    MsgGeom g;
+    if (msg_geometry(s, &g) != RULGNN_OK) return 0;
+    MsgWs w;
+    msg_ws_layout(g, &w);
+    return w.total;
+}
+
+int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float* prm, float* features, hipStream_t st) {
+    MsgGeom g;
+    const int rc = msg_geometry(s, &g);
+    if (rc != RULGNN_OK) return rc;
+    if (g.B == 0) return RULGNN_OK;
+    (void)hipGetLastError();
+    return launch_features(g, x, prm, features, nullptr, st);
+}
+
+// mode bit 0: forward, bit 1: backward
+int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t st) {
+    MsgGeom g;
+    int rc = msg_geometry(s, &g);
+    if (rc != RULGNN_OK) return rc;
+    MsgWs w;
+    msg_ws_layout(g, &w);
+    if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    (void)hipGetLastError();
+    const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+    if (mode & 1) {
+        rc = launch_features(g, a->x, a->params, (float*)(ws + w.cat), (float*)(ws + w.gi), st);
+        if (rc != RULGNN_OK) return rc;
+        dispatch_gru(g, w, ws, a->params, false, st);
+        hipLaunchKernelGGL(msg_head_kernel, dim3((unsigned)g.B), dim3(MB), 0, st, g, (const float*)(ws + w.hseq), a->params,
+                           a->y, a->pred, (float*)(ws + w.pooled), (float*)(ws + w.dpred), (float*)(ws + w.sqerr), inv_gb);
+    }
+    if (mode & 2) {
+        if (a->dpred) {
+            if (hipMemcpyAsync(ws + w.dpred, a->dpred, sizeof(float) * g.B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return RULGNN_EHIP;
+        }
+        dispatch_gru(g, w, ws, a->params, true, st);
+        const size_t lds = gcn_backward_lds_bytes(g);
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(msg_gcn_backward_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+        const int rows = resident_grid(msg_gcn_backward_kernel, g.G, lds, w.rows_gcn_max);
+        hipLaunchKernelGGL(msg_gcn_backward_kernel, dim3(rows), dim3(MB), lds, st, g, (const float*)(ws + w.cat),
+                           (const float*)(ws + w.dgi), a->params, (float*)(ws + w.gpart_gcn));
+        const bool mse = a->dpred == nullptr;
+        hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + 1 + MB - 1) / MB), dim3(MB), 0, st, g,
+                           (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
+                           (const float*)(ws + w.dpred), (const float*)(ws + w.pooled),
+                           mse ? (const float*)(ws + w.sqerr) : nullptr, a->grads, mse ? a->loss : nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+}  // namespace rulgnn

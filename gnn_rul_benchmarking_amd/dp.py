@@ -50,16 +50,21 @@ class DataParallel:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
 
     def step(self, model, optimizer, X_shard, y_shard, global_batch=None, sample_offset=None):
-        """One data-parallel ST_GCN.update on this rank's shard.  ``global_batch`` defaults to
+        """One data-parallel ``Algorithm.update`` on this rank's shard.  ``global_batch`` defaults to
         world_size * len(shard) (equal shards); pass it (and ``sample_offset``) for ragged batches."""
         b = X_shard.size(0)
         if global_batch is None:
             global_batch = b * self.world_size
         if sample_offset is None:
             sample_offset = b * self.rank
-        model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
-                             update_running_stats=False, moments_to_bucket=True)
+        batch_coupled = hasattr(model, "_after_train_forward")      # BatchNorm / dropout state (ST_GCN); STMSGCN has none
+        if batch_coupled:
+            model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
+                                 update_running_stats=False, moments_to_bucket=True)
+        else:
+            model.fused_mse_step(X_shard, y_shard, global_batch=global_batch)
         self.all_reduce_bucket(model.bucket)
         optimizer.step(from_bucket=True)
-        model._after_train_forward(global_batch, from_bucket_moments=True)
+        if batch_coupled:
+            model._after_train_forward(global_batch, from_bucket_moments=True)
         return model.bucket[model.num_live]

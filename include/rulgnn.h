@@ -150,6 +150,68 @@ int rulgnn_adam_step_f32(float *params, const float *grads, float *exp_avg, floa
 int rulgnn_bn_running_update_f32(float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count,
                                  float momentum, int32_t from_moments, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * STMSGCN path (reference models/STMSGCN/Model.py, algorithms/algorithms.py:546-571).
+ *
+ * Per sample: num_patch patches of patch_size points -> per patch a graph of
+ * nodes = (patch_size - interval) / band_width spectral bands (SED_features, Model.py:7-31) ->
+ * stack of GCN layers with the adjacency x x^T of the current features (Model.py:34-49,96-100) ->
+ * GRU over the patches per (sample, node) (Model.py:52-60) -> mean over nodes -> Linear.
+ *
+ * Flat parameter buffer (floats), dims = [1, gcn_dims...], C = sum(dims), H = gru_hidden:
+ *     for each GCN layer l: linear.weight[dims[l+1]][dims[l]] | linear.bias[dims[l+1]]
+ *     gru.weight_ih_l0[3H][C] | gru.weight_hh_l0[3H][H] | gru.bias_ih_l0[3H] | gru.bias_hh_l0[3H]
+ *     fc.weight[num_patch*H] | fc.bias[1]
+ * (6,818 floats for the reference's gcn_dims [16,64,16,1], H 8, num_patch 256.)
+ */
+#define RULGNN_STMSGCN_MAX_LAYERS 6
+
+typedef struct rulgnn_stmsgcn_shape {
+    int64_t batch;            /* samples in this call */
+    int32_t num_patch;        /* patches per sample = GRU sequence length, 1..4096 */
+    int32_t patch_size;       /* points per patch = DFT length, 2..512 */
+    int32_t interval;         /* spectral-difference lag (Model.py:17-18) */
+    int32_t band_width;       /* bins per band; (patch_size - interval) % band_width == 0; nodes <= 32 */
+    int32_t num_gcn_layers;   /* 1..RULGNN_STMSGCN_MAX_LAYERS */
+    int32_t gcn_dims[RULGNN_STMSGCN_MAX_LAYERS];   /* output width of each GCN layer, each 1..64, C <= 128 */
+    int32_t gru_hidden;       /* H, 1..16 */
+} rulgnn_stmsgcn_shape;
+
+typedef struct rulgnn_stmsgcn_args {
+    const float *x;           /* [batch, num_patch*patch_size] */
+    const float *y;           /* [batch] targets; NULL when dpred is given / forward only */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;      /* flat parameters (layout above) */
+    float *grads;             /* flat gradient out (same layout) */
+    float *pred;              /* [batch] */
+    float *loss;              /* [1]: sum((pred - y)^2) / global_batch; may be NULL */
+    void *workspace;          /* >= rulgnn_stmsgcn_workspace_bytes(shape) */
+    size_t workspace_bytes;
+    int64_t global_batch;     /* MSE denominator (data parallel: the global batch; else = batch) */
+} rulgnn_stmsgcn_args;
+
+int64_t rulgnn_stmsgcn_param_count(const rulgnn_stmsgcn_shape *shape);     /* < 0: invalid shape */
+size_t rulgnn_stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape *shape);   /* 0: invalid / unsupported shape */
+
+/* SED features + GCN stack only: features[batch*num_patch][nodes][C], the tensor the reference feeds to
+ * its GRU before the transpose (Model.py:92-103).  No workspace. */
+int rulgnn_stmsgcn_features_f32(const rulgnn_stmsgcn_shape *shape, const float *x, const float *params,
+                                float *features, void *stream);
+
+/* model(X): STMSGCN_model.forward (Model.py:84-112; trainer.py:144 in eval, algorithms.py:560 in training --
+ * the model has no train/eval difference).  Uses x, params, pred, workspace; keeps in the workspace what
+ * rulgnn_stmsgcn_backward_f32 needs. */
+int rulgnn_stmsgcn_forward_f32(const rulgnn_stmsgcn_shape *shape, const rulgnn_stmsgcn_args *args, void *stream);
+
+/* loss.backward() (algorithms.py:565): gradient of sum(pred*dpred), or of the MSE loss when dpred is NULL,
+ * w.r.t. every parameter.  Must follow rulgnn_stmsgcn_forward_f32 with the same args/workspace. */
+int rulgnn_stmsgcn_backward_f32(const rulgnn_stmsgcn_shape *shape, const rulgnn_stmsgcn_args *args, void *stream);
+
+/* forward + MSE + backward in one call: STMSGCN.update up to optimizer.step() (algorithms.py:560-565).
+ * With `opt` non-NULL also applies torch.optim.Adam (algorithms.py:566; opt->bn_stats is ignored). */
+int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape *shape, const rulgnn_stmsgcn_args *args,
+                              const rulgnn_adam_args *opt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
