@@ -80,7 +80,57 @@ def case_training_curve(name, cfg, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_trainer_phm2012(name, seed, n_train=200, n_test=60, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method STMSGCN on the synthetic
+    PHM2012/Condition_1 dataset of synth.py, its own hparams (configs/hparams.py:226,242); only num_epochs is
+    patched.  Records every epoch's test metrics, the results CSV and a few final tensors."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_phm2012
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "PHM2012", "Condition_1")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="STMSGCN", data_path=os.path.join(tmp, "data"), dataset="PHM2012",
+                                      dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "STMSGCN_run_0", "results.csv")).read()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.fc.weight", "model.gcn_layers.1.linear.weight", "model.gru_layer.gru.weight_hh_l0"):
+        out["final:" + k] = final[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_phm2012("stmsgcn_trainer_phm2012_c1_reference_run", 5)
+        sys.exit(0)
     dims = {"gcn_dims": [16, 64, 16, 1], "gru_hidden_dim": 8}
     # PHM2012 Condition_1/3 wiring (patch 16, interval 6, band 5 -> 2 nodes), fewer patches
     case_forward_backward("stmsgcn_phm1_12x16_bs5", dict(num_patch=12, patch_size=16, interval=6, band_width=5, **dims), 5, seed=31)
@@ -98,3 +148,4 @@ if __name__ == "__main__":
                                                         gru_hidden_dim=6), 4, seed=35, scale=0.2)
     case_training_curve("stmsgcn_train_curve_9x20_bs6", dict(num_patch=9, patch_size=20, interval=2, band_width=3, **dims),
                         6, steps=12, seed=36, lr=1e-2, wd=0.0)
+    case_trainer_phm2012("stmsgcn_trainer_phm2012_c1_reference_run", 5)

@@ -153,3 +153,60 @@ def test_loader_shards_partition_every_batch():
     torch.manual_seed(5)
     single = [yb.view(-1).tolist() for _, yb, _, _ in DeviceBatchLoader(X, y, 25, True, False, "cpu")]
     assert sum(single, []) == allv                               # same global batches as a single process
+
+
+# ---- STMSGCN: no BatchNorm / dropout, so the sharded step must reproduce the single-process step exactly ----
+from oracle import stmsgcn_oracle as MO   # noqa: E402
+
+MCFG = MO.Config(4, 20, 2, 3, [6, 9, 2], 4)
+
+
+class StmsgcnOracleModel:
+    """Duck-types the slice of STMSGCN_model that dp.DataParallel touches (no _after_train_forward: not batch-coupled)."""
+
+    def __init__(self, prm):
+        self.prm = {k: np.asarray(v, np.float64) for k, v in prm.items()}
+        self.names = MO.param_names(MCFG)
+        self.num_live = sum(self.prm[k].size for k in self.names)
+        self.bucket = torch.zeros(self.num_live + 1, dtype=torch.float32)
+        self.flat_params = torch.from_numpy(np.concatenate([self.prm[k].reshape(-1) for k in self.names]).astype(np.float32))
+
+    def fused_mse_step(self, X, y, optimizer=None, global_batch=None):
+        x, yy = X.numpy().astype(np.float64).reshape(X.size(0), -1), y.numpy().astype(np.float64).reshape(-1)
+        loss, grads, _ = MO.loss_and_grads(self.prm, x, yy, MCFG)
+        scale = x.shape[0] / float(global_batch)               # the kernels divide by the global batch
+        self.bucket[:self.num_live] = torch.from_numpy(
+            (scale * np.concatenate([grads[k].reshape(-1) for k in self.names])).astype(np.float32))
+        self.bucket[self.num_live] = scale * loss
+        return None, self.bucket[self.num_live]
+
+
+def _stmsgcn_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(1)
+        x = torch.from_numpy(rng.uniform(0, 0.5, (B, 1, MCFG.num_patch * MCFG.patch_size)).astype(np.float32))
+        y = torch.from_numpy(rng.uniform(0, 1, (B, 1)).astype(np.float32))
+        model = StmsgcnOracleModel(MO.random_params(MCFG, seed=5))
+        dp = DataParallel()
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "flat": model.flat_params.clone().numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stmsgcn_data_parallel_step_equals_single_process_world2_gloo():
+    B, world = 7, 2
+    out = mp.Manager().dict()
+    mp.spawn(_stmsgcn_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    assert np.array_equal(out[0]["bucket"], out[1]["bucket"]) and np.array_equal(out[0]["flat"], out[1]["flat"])
+    rng = np.random.default_rng(1)
+    x = rng.uniform(0, 0.5, (B, 1, MCFG.num_patch * MCFG.patch_size)).astype(np.float32).astype(np.float64).reshape(B, -1)
+    y = rng.uniform(0, 1, (B, 1)).astype(np.float32).astype(np.float64).reshape(-1)
+    prm = MO.random_params(MCFG, seed=5)
+    loss, grads, _ = MO.loss_and_grads(prm, x, y, MCFG)
+    full = np.concatenate([grads[k].reshape(-1) for k in MO.param_names(MCFG)])
+    assert abs(out[0]["loss"] - loss) < 1e-6 * abs(loss)
+    assert np.allclose(out[0]["bucket"][:-1], full, rtol=1e-5, atol=1e-9)

@@ -81,3 +81,22 @@ def test_cpu_tensor_is_rejected_loudly():
         STMSGCN_model(num_patch=5, patch_size=20, interval=3, band_width=3, gcn_dims=[4], gru_hidden_dim=3)
     with pytest.raises(NotImplementedError):
         get_algorithm_class("STMSGCN_model")
+
+
+def test_hparams_rows_are_the_reference_tables():
+    """configs/hparams.py:226,242,275,311,355,390,424 of the reference, restated."""
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    d = {"gcn_dims": [16, 64, 16, 1], "gru_hidden_dim": 8}
+    want = {("PHM2012", "Condition_1"): dict(num_patch=160, patch_size=16, interval=6, band_width=5, **d),
+            ("PHM2012", "Condition_2"): dict(num_patch=128, patch_size=20, interval=2, band_width=3, **d),
+            ("PHM2012", "Condition_3"): dict(num_patch=160, patch_size=16, interval=6, band_width=5, **d),
+            ("XJTU_SY", "Condition_1"): dict(num_patch=256, patch_size=128, interval=3, band_width=5, **d),
+            ("XJTU_SY", "Condition_2"): dict(num_patch=128, patch_size=256, interval=6, band_width=10, **d),
+            ("XJTU_SY", "Condition_3"): dict(num_patch=256, patch_size=128, interval=3, band_width=5, **d)}
+    for (ds, cond), cfg in want.items():
+        h = get_hparams_class(ds)(cond)
+        assert h.alg_hparams["STMSGCN"] == cfg
+        assert h.train_params["STMSGCN"] == {"num_epochs": 81, "batch_size": 100, "weight_decay": 0, "learning_rate": 1e-2}
+        STMSGCN_model(**h.alg_hparams["STMSGCN"])            # constructible
+    with pytest.raises(KeyError):
+        get_hparams_class("CMAPSS")("FD001").alg_hparams["STMSGCN"]      # the reference has no such row either

@@ -133,3 +133,51 @@ def test_trainer_matches_reference_harness_run_on_phm2012(tmp_path, monkeypatch)
     ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
     assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
     assert np.allclose(csv.iloc[1:].to_numpy(), ref_csv.iloc[1:].to_numpy(), rtol=2e-4)
+
+
+def test_stmsgcn_trainer_matches_reference_harness_run_on_phm2012(tmp_path, monkeypatch):
+    """Same as above for --GNN_method STMSGCN (reference hparams: lr 1e-2, wd 0, batch 100, 160 patches of 16 points):
+    the reference's own harness, run on CPU by tests/golden/make_golden_stmsgcn.py::case_trainer_phm2012, vs this
+    package's harness on the GPU."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_phm2012
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "stmsgcn_trainer_phm2012_c1_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "PHM2012" / "Condition_1"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="STMSGCN", data_path=str(tmp_path / "data"), dataset="PHM2012",
+                              dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.train_configs["batch_size"] == int(z["batch_size"]) and tr.train_configs["learning_rate"] == float(z["lr"])
+    assert tr.model_configs["num_patch"] == 160 and tr.model_configs["interval"] == 6
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("STMSGCN harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 3] - ref[:, 3])) < 1e-3                  # RMSE, absolute (north star)
+    assert np.max(np.abs(got[:, 2:] - ref[:, 2:]) / np.abs(ref[:, 2:])) < 1e-3      # MAE, RMSE relative
+    sd = tr.algorithm.state_dict()
+    for k in z.files:
+        if k.startswith("final:"):
+            a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
+            assert np.max(np.abs(a - b)) / np.max(np.abs(b)) < 2e-3, k
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "STMSGCN_run_0" / "results.csv")
+    import io
+    ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
+    assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
