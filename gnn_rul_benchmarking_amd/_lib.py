@@ -49,6 +49,18 @@ class StmsgcnArgs(C.Structure):
                 ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64)]
 
 
+class AstgcnnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("output_dim", C.c_int32),
+                ("K", C.c_int32)]
+
+
+class AstgcnnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_batch", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64),
+                ("bn_moment_weight", C.c_float), ("training", C.c_int32)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -69,6 +81,13 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
+    "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
+    "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
+    "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
+    "rulgnn_astgcnn_backward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
+    "rulgnn_astgcnn_fwdbwd_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_astgcnn_bn_running_update_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                                        C.c_int32, C.c_void_p]),
     "rulgnn_stmsgcn_param_count": (C.c_int64, [C.POINTER(StmsgcnShape)]),
     "rulgnn_stmsgcn_workspace_bytes": (C.c_size_t, [C.POINTER(StmsgcnShape)]),
     "rulgnn_stmsgcn_features_f32": (C.c_int, [C.POINTER(StmsgcnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -2,7 +2,8 @@
 algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
 ``NotImplementedError("Algorithm not found: ...")`` otherwise).
 
-The ST_GCN (reference algorithms/algorithms.py:465-490) and STMSGCN (:546-571) wrappers are implemented:
+The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571) and ASTGCNN (:139-163) wrappers are
+implemented:
 the hot paths this package accelerates.  The classes keep the reference contract -- constructor
 ``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
 ``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
@@ -12,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .optim import FusedAdam
+from .astgcnn import ASTGCNN_model
 from .stgcn import ST_GCN_model
 from .stmsgcn import STMSGCN_model
 
@@ -114,4 +116,40 @@ class STMSGCN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class ASTGCNN(Algorithm):
+    """ASTGCNN training wrapper (reference algorithms.py:139-163): ``update`` = train-mode forward + MSE + backward +
+    Adam + BatchNorm running statistics in one C call (csrc/astgcnn.hip + the fused Adam kernel); with a ``DataParallel``
+    context attached the gradient bucket is all-reduced in between."""
+
+    def __init__(self, configs, hparams, device):
+        super(ASTGCNN, self).__init__(configs)
+        self.model = ASTGCNN_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if not self.model.training:
+            raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics)")
+        if self.dp is None:
+            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        else:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        return {'loss': loss.item() if self.sync_loss else loss}
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd; same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "get_algorithm_class", "torch", "nn", "annotations"}

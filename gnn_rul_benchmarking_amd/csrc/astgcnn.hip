@@ -1,0 +1,723 @@
+// ASTGCNN path for gfx950: TCN (two causal Conv1d k=6 + BatchNorm + ReLU blocks with residuals) -> tanh gate ->
+// exp(-cdist) graph -> Chebyshev graph convolution (K <= 3) -> node mean -> Linear; forward and backward.
+//
+// Reference: models/ASTGCNN/Model.py (TemporalConvNet :72-146, GatingMechanism :169-181, construct_graph :184-195,
+// ChebNet :198-230, ASTGCNN_model :233-254) and algorithms/algorithms.py:139-163 (MSE + Adam).
+//
+// Decomposition.  Per sample the operands are [nodes<=25] x [time<=64] tiles; the dense
+// projections (gate theta, P, Chebyshev filters and their weight gradients) are batched over all samples as
+// [batch*nodes, .] GEMMs on the matrix cores (sgemm_mfma.hpp); everything else is one workgroup per sample with the
+// tile in LDS.  BatchNorm batch statistics cut the step into phases (fp64 reduction cells, like the ST_GCN chain):
+//   conv1 | conv2 | gate -> graph -> head | gate_bwd (BN2 sums) | conv2_bwd (BN1 sums) | conv1_bwd | finalize.
+// Node mean and Chebyshev projection commute, so the [batch*nodes, K*E] x [K*E, O] product is done on the node sums
+// ([batch, K*E]) -- nodes times less work, same result up to summation order.
+#include "sgemm_mfma.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+constexpr int AB = 256;            // threads per workgroup
+constexpr int KT = 6;              // TCN kernel size (Model.py:236)
+constexpr int MAXN = 25;           // nodes: torch.cdist takes its exact path up to 25 rows (what the reference wires)
+constexpr int MAXT = 64;
+constexpr float BN_EPS = 1e-5f;
+
+struct AstGeom {
+    int64_t B;
+    int N, T, E, O, K, KE;
+    int o_w1, o_g1, o_b1, o_w2, o_g2, o_b2, o_thw, o_thb, o_gb, o_pw, o_f, o_fcw, o_fcb, nparam;
+};
+
+__host__ int ast_geometry(const rulgnn_astgcnn_shape* s, AstGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->batch < 0 || s->num_nodes < 1 || s->time_length < 1 || s->output_dim < 1 || s->K < 1) return RULGNN_EINVAL;
+    if (s->num_nodes > MAXN || s->time_length > MAXT || s->output_dim > 256 || s->K > 3) return RULGNN_EUNSUPPORTED;
+    if (s->batch * (int64_t)s->num_nodes > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
+    g->B = s->batch;
+    g->N = s->num_nodes;
+    g->T = g->E = s->time_length;          // the gate multiplies [N, E] by [N, T] elementwise: E == T (Model.py:181)
+    g->O = s->output_dim;
+    g->K = s->K;
+    g->KE = g->K * g->E;
+    const int N = g->N, T = g->T, E = g->E;
+    int o = 0;
+    g->o_w1 = o; o += N * N * KT;
+    g->o_g1 = o; o += N;
+    g->o_b1 = o; o += N;
+    g->o_w2 = o; o += N * N * KT;
+    g->o_g2 = o; o += N;
+    g->o_b2 = o; o += N;
+    g->o_thw = o; o += E * T;
+    g->o_thb = o; o += E;
+    g->o_gb = o; o += E;
+    g->o_pw = o; o += E * E;
+    g->o_f = o; o += g->K * E * g->O;
+    g->o_fcw = o; o += g->O;
+    g->o_fcb = o; o += 1;
+    g->nparam = o;
+    return RULGNN_OK;
+}
+
+// reduction cells (fp64): forward sums [2 blocks][N][sum, sumsq], backward sums [2][N][sum dy, sum dy*xhat]
+struct Cells {
+    double fwd[2][MAXN][2];
+    double bwd[2][MAXN][2];
+};
+
+// BatchNorm scale/shift of block `blk` for channel c: y = z * sc + sh; xhat = (z - mean) * inv
+struct BnCoef {
+    float mean, inv, sc, sh;
+};
+__device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, int training, int blk, int c, int N, double count,
+                                 float gamma, float beta) {
+    BnCoef r;
+    float var;
+    if (training) {
+        const double m = cells->fwd[blk][c][0] / count;
+        double v = cells->fwd[blk][c][1] / count - m * m;
+        if (v < 0.0) v = 0.0;
+        r.mean = (float)m;
+        var = (float)v;
+    } else {
+        r.mean = bn_running[(blk * 2 + 0) * N + c];
+        var = bn_running[(blk * 2 + 1) * N + c];
+    }
+    r.inv = 1.0f / sqrtf(var + BN_EPS);
+    r.sc = gamma * r.inv;
+    r.sh = beta - r.mean * r.sc;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
+// One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
+// ---------------------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(AB) void ast_conv_kernel(AstGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                     const float* __restrict__ bn_running, int training, const float* __restrict__ z1,
+                                                     float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
+    constexpr int D = STAGE == 1 ? 1 : 2;
+    constexpr int PADL = (KT - 1) * D;
+    __shared__ float w[MAXN * MAXN * KT];
+    __shared__ float xs[MAXN][MAXT + PADL];
+    __shared__ float zs[MAXN][MAXT + 1];
+    __shared__ BnCoef co1[MAXN];
+    const int N = g.N, T = g.T, tid = threadIdx.x;
+    const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
+    for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
+    for (int e = tid; e < N * PADL; e += AB) xs[e / PADL][e % PADL] = 0.f;
+    if (STAGE == 2 && tid < N)
+        co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.B * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
+    float s1 = 0.f, s2 = 0.f;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        const float* xb = x + b * N * T;
+        for (int e = tid; e < N * T; e += AB) {
+            const int c = e / T, t = e - c * T;
+            float v = xb[e];
+            if (STAGE == 2) {
+                const float y = fmaf(z1[b * N * T + e], co1[c].sc, co1[c].sh);
+                v = fmaxf(fmaxf(y, 0.f) + v, 0.f);
+                out0[b * N * T + e] = v;
+            }
+            xs[c][PADL + t] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < N * T; e += AB) {
+            const int co = e / T, t = e - co * T;
+            float a = 0.f;
+            for (int ci = 0; ci < N; ++ci) {
+                const float* wr = w + (co * N + ci) * KT;
+                const float* xr = &xs[ci][t + PADL - (KT - 1) * D];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) a = fmaf(wr[k], xr[k * D], a);
+            }
+            zout[b * N * T + e] = a;
+            zs[co][t] = a;
+        }
+        __syncthreads();
+        if (training && tid < N) {
+            for (int t = 0; t < T; ++t) {
+                const float v = zs[tid][t];
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        __syncthreads();
+    }
+    if (training && tid < N) {
+        atomicAdd(&cells->fwd[STAGE - 1][tid][0], (double)s1);
+        atomicAdd(&cells->fwd[STAGE - 1][tid][1], (double)s2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gate: out1 = relu(relu(bn2(z2)) + out0); zg = tanh(Zpre + theta.bias + gate.bias); G = zg * out1
+// (Zpre = x theta^T from the GEMM).  Writes out1, zg (over Zpre) and G into columns [0, E) of Tcat.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AB) void ast_gate_kernel(AstGeom g, const float* __restrict__ prm, const float* __restrict__ bn_running,
+                                                     int training, const Cells* cells, const float* __restrict__ z2,
+                                                     const float* __restrict__ out0, float* __restrict__ zpre, float* __restrict__ out1,
+                                                     float* __restrict__ tcat) {
+    const int N = g.N, T = g.T;
+    const int64_t total = g.B * N * T;
+    for (int64_t e = (int64_t)blockIdx.x * AB + threadIdx.x; e < total; e += (int64_t)gridDim.x * AB) {
+        const int64_t row = e / T;
+        const int t = (int)(e - row * T), c = (int)(row % N);
+        const BnCoef k = bn_coef(cells, bn_running, training, 1, c, N, (double)g.B * T, prm[g.o_g2 + c], prm[g.o_b2 + c]);
+        const float y = fmaf(z2[e], k.sc, k.sh);
+        const float o1 = fmaxf(fmaxf(y, 0.f) + out0[e], 0.f);
+        const float zg = tanhf(zpre[e] + prm[g.o_thb + t] + prm[g.o_gb + t]);
+        out1[e] = o1;
+        zpre[e] = zg;
+        tcat[row * g.KE + t] = zg * o1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph: A = exp(-cdist(PX, PX)); T1 = A G; T2 = 2 A T1 - G; node sums of [G | T1 | T2]  (one sample per workgroup)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AB) void ast_graph_kernel(AstGeom g, const float* __restrict__ px, float* __restrict__ tcat,
+                                                      float* __restrict__ adj, float* __restrict__ distm, float* __restrict__ scat) {
+    __shared__ float P[MAXN][MAXT + 1];
+    __shared__ float G[MAXN][MAXT + 1];
+    __shared__ float T1[MAXN][MAXT + 1];
+    __shared__ float A[MAXN][MAXN + 1];
+    const int N = g.N, E = g.E, KE = g.KE, tid = threadIdx.x;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        float* tc = tcat + b * N * KE;
+        for (int e = tid; e < N * E; e += AB) {
+            const int i = e / E, c = e - i * E;
+            P[i][c] = px[b * N * E + e];
+            G[i][c] = tc[i * KE + c];
+        }
+        __syncthreads();
+        for (int e = tid; e < N * N; e += AB) {
+            const int i = e / N, j = e - i * N;
+            float d2 = 0.f;
+            for (int c = 0; c < E; ++c) {
+                const float d = P[i][c] - P[j][c];
+                d2 = fmaf(d, d, d2);
+            }
+            const float ds = sqrtf(d2);
+            const float a = expf(-ds);
+            A[i][j] = a;
+            adj[b * N * N + e] = a;
+            distm[b * N * N + e] = ds;
+        }
+        __syncthreads();
+        if (g.K > 1) {
+            for (int e = tid; e < N * E; e += AB) {
+                const int i = e / E, c = e - i * E;
+                float a = 0.f;
+                for (int j = 0; j < N; ++j) a = fmaf(A[i][j], G[j][c], a);
+                T1[i][c] = a;
+                tc[i * KE + E + c] = a;
+            }
+            __syncthreads();
+        }
+        if (g.K > 2) {
+            for (int e = tid; e < N * E; e += AB) {
+                const int i = e / E, c = e - i * E;
+                float a = 0.f;
+                for (int j = 0; j < N; ++j) a = fmaf(A[i][j], T1[j][c], a);
+                tc[i * KE + 2 * E + c] = 2.0f * a - G[i][c];
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < KE; e += AB) {                    // node sums (tc rows were written by this workgroup)
+            float s = 0.f;
+            for (int i = 0; i < N; ++i) s += tc[i * KE + e];
+            scat[b * KE + e] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// head: pooled = (Scat Fcat) / N (from the GEMM, in `pooled`), pred = pooled fc^T + b; MSE pieces; D = dpred * fc.weight / N
+__global__ __launch_bounds__(AB) void ast_head_kernel(AstGeom g, const float* __restrict__ prm, float* __restrict__ pooled,
+                                                     const float* __restrict__ y, const float* __restrict__ dpred_in,
+                                                     float* __restrict__ pred, float* __restrict__ dpred, float* __restrict__ sqerr,
+                                                     float* __restrict__ dmat, float inv_gb, int backward_only) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, O = g.O;
+    const float inv_n = 1.0f / (float)g.N;
+    for (int64_t b = (int64_t)blockIdx.x * (AB / 64) + wave; b < g.B; b += (int64_t)gridDim.x * (AB / 64)) {
+        float dp;
+        if (!backward_only) {
+            float a = 0.f;
+            for (int o = lane; o < O; o += 64) {
+                const float v = pooled[b * O + o] / (float)g.N;
+                pooled[b * O + o] = v;
+                a = fmaf(v, prm[g.o_fcw + o], a);
+            }
+            for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+            const float pr = a + prm[g.o_fcb];
+            if (lane == 0) pred[b] = pr;
+            if (!y) continue;
+            const float d = pr - y[b];
+            dp = 2.0f * d * inv_gb;
+            if (lane == 0) {
+                dpred[b] = dp;
+                sqerr[b] = d * d * inv_gb;
+            }
+        } else {
+            dp = dpred_in[b];
+            if (lane == 0) dpred[b] = dp;
+        }
+        for (int o = lane; o < O; o += 64) dmat[b * O + o] = dp * prm[g.o_fcw + o] * inv_n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph backward (one sample per workgroup).  d cheb is the same row dm/N for every node, so the three d T_k are
+// rows dt0, dt1, dt2 (from DT = D Fcat^T) broadcast over the nodes, which collapses most products to vectors:
+//   u_j = dt2.T1_j, v_j = dt1.G_j, w_j = dt2.G_j, cs_i = sum_j A[j][i]
+//   dA[i][j] = 2 u_j + v_j + 2 cs_i w_j
+//   dG_cheb[i] = dt0 - dt2 + cs_i dt1 + 2 (sum_j A[j][i] cs_j) dt2
+//   d dist = -A dA;  dPX_i = sum_j (d dist_ij + d dist_ji) (PX_i - PX_j) / dist_ij   (0 where dist = 0, as torch)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const float* __restrict__ px, const float* __restrict__ tcat,
+                                                          const float* __restrict__ adj, const float* __restrict__ distm,
+                                                          const float* __restrict__ dt, float* __restrict__ dpx,
+                                                          float* __restrict__ dg) {
+    __shared__ float P[MAXN][MAXT + 1];
+    __shared__ float A[MAXN][MAXN + 1];
+    __shared__ float Ds[MAXN][MAXN + 1];
+    __shared__ float Cf[MAXN][MAXN + 1];
+    __shared__ float d0[MAXT], d1[MAXT], d2v[MAXT];
+    __shared__ float u[MAXN], v[MAXN], w[MAXN], cs[MAXN], acs[MAXN];
+    const int N = g.N, E = g.E, KE = g.KE, tid = threadIdx.x;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        const float* tc = tcat + b * N * KE;
+        for (int e = tid; e < N * E; e += AB) P[e / E][e % E] = px[b * N * E + e];
+        for (int e = tid; e < N * N; e += AB) {
+            A[e / N][e % N] = adj[b * N * N + e];
+            Ds[e / N][e % N] = distm[b * N * N + e];
+        }
+        for (int e = tid; e < E; e += AB) {
+            d0[e] = dt[b * KE + e];
+            d1[e] = g.K > 1 ? dt[b * KE + E + e] : 0.f;
+            d2v[e] = g.K > 2 ? dt[b * KE + 2 * E + e] : 0.f;
+        }
+        __syncthreads();
+        if (tid < N) {
+            const int j = tid;
+            float uu = 0.f, vv = 0.f, ww = 0.f, c = 0.f;
+            for (int e = 0; e < E; ++e) {
+                const float gj = tc[j * KE + e];
+                vv = fmaf(d1[e], gj, vv);
+                ww = fmaf(d2v[e], gj, ww);
+                if (g.K > 2) uu = fmaf(d2v[e], tc[j * KE + E + e], uu);
+            }
+            for (int i = 0; i < N; ++i) c += A[i][j];
+            u[j] = uu; v[j] = vv; w[j] = ww; cs[j] = c;
+        }
+        __syncthreads();
+        if (tid < N) {
+            float a = 0.f;
+            for (int j = 0; j < N; ++j) a = fmaf(A[j][tid], cs[j], a);
+            acs[tid] = a;
+        }
+        // d dist (unsymmetrised) into Cf
+        for (int e = tid; e < N * N; e += AB) {
+            const int i = e / N, j = e - i * N;
+            const float dA = g.K > 1 ? 2.0f * u[j] + v[j] + 2.0f * cs[i] * w[j] : 0.f;
+            Cf[i][j] = -A[i][j] * dA;
+        }
+        __syncthreads();
+        for (int e = tid; e < N * E; e += AB) {
+            const int i = e / E, c = e - i * E;
+            float a = 0.f;
+            for (int j = 0; j < N; ++j) {
+                const float dist = Ds[i][j];
+                const float cf = dist > 0.f ? (Cf[i][j] + Cf[j][i]) / dist : 0.f;
+                a = fmaf(cf, P[i][c] - P[j][c], a);
+            }
+            dpx[b * N * E + e] = a;
+            float gch = d0[c];
+            if (g.K > 1) gch += cs[i] * d1[c];
+            if (g.K > 2) gch += (2.0f * acs[i] - 1.0f) * d2v[c];
+            dg[b * N * E + e] = gch;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gate backward + tail of the TCN backward (one sample per workgroup):
+//   dzg = dG out1; dZpre = dzg (1 - zg^2) (over zg); dout1 = dG zg; ds1 = dout1 [out1 > 0];
+//   dy2 = ds1 [bn2(z2) > 0]; BN2 backward sums.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float* __restrict__ prm, Cells* cells,
+                                                         const float* __restrict__ z2, const float* __restrict__ out1,
+                                                         const float* __restrict__ dg, float* __restrict__ zg_dzpre,
+                                                         float* __restrict__ ds1, float* __restrict__ dy2) {
+    __shared__ float sy[MAXN][MAXT + 1];
+    __shared__ float sx[MAXN][MAXT + 1];
+    __shared__ BnCoef co2[MAXN];
+    const int N = g.N, T = g.T, tid = threadIdx.x;
+    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.B * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    float a1 = 0.f, a2 = 0.f;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int e = tid; e < N * T; e += AB) {
+            const int c = e / T, t = e - c * T;
+            const int64_t idx = b * N * T + e;
+            const float gg = dg[idx], zg = zg_dzpre[idx], o1 = out1[idx];
+            zg_dzpre[idx] = gg * o1 * (1.0f - zg * zg);
+            const float s = o1 > 0.f ? gg * zg : 0.f;
+            ds1[idx] = s;
+            const float zz = z2[idx];
+            const float y = fmaf(zz, co2[c].sc, co2[c].sh);
+            const float dy = y > 0.f ? s : 0.f;
+            dy2[idx] = dy;
+            sy[c][t] = dy;
+            sx[c][t] = dy * (zz - co2[c].mean) * co2[c].inv;
+        }
+        __syncthreads();
+        if (tid < N)
+            for (int t = 0; t < T; ++t) {
+                a1 += sy[tid][t];
+                a2 += sx[tid][t];
+            }
+        __syncthreads();
+    }
+    if (tid < N) {
+        atomicAdd(&cells->bwd[1][tid][0], (double)a1);
+        atomicAdd(&cells->bwd[1][tid][1], (double)a2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv backward.  STAGE 2: dz2 = BN2'(dy2); dW2 += dz2 (*) out0; dout0 = ds1 + conv2^T(dz2); ds0 = dout0 [out0 > 0];
+// dy1 = ds0 [bn1(z1) > 0]; BN1 backward sums.   STAGE 1: dz1 = BN1'(dy1); dW1 += dz1 (*) x.
+// Weight-gradient accumulators are thread-owned registers (fixed order), one partial row per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(AB) void ast_conv_bwd_kernel(AstGeom g, const float* __restrict__ prm, Cells* cells,
+                                                         const float* __restrict__ zin, const float* __restrict__ dyin,
+                                                         const float* __restrict__ src, const float* __restrict__ ds1,
+                                                         const float* __restrict__ z1, float* __restrict__ dy1,
+                                                         float* __restrict__ gpart) {
+    constexpr int D = STAGE == 1 ? 1 : 2;
+    constexpr int PAD = (KT - 1) * D;
+    constexpr int NACC = (MAXN * MAXN * KT + AB - 1) / AB;
+    __shared__ float w[MAXN * MAXN * KT];
+    __shared__ float xs[MAXN][MAXT + PAD];        // conv input (x or out0), left-padded with zeros
+    __shared__ float dz[MAXN][MAXT + PAD];        // d z, right-padded with zeros
+    __shared__ float sy[MAXN][MAXT + 1];
+    __shared__ float sx[MAXN][MAXT + 1];
+    __shared__ BnCoef cz[MAXN], c1[MAXN];
+    __shared__ float bsum[MAXN][2];
+    const int N = g.N, T = g.T, tid = threadIdx.x, blk = STAGE - 1;
+    const double count = (double)g.B * T;
+    const int nW = N * N * KT;
+    if (STAGE == 2)
+        for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_w2 + e];
+    for (int e = tid; e < N * PAD; e += AB) {
+        xs[e / PAD][e % PAD] = 0.f;
+        dz[e / PAD][T + e % PAD] = 0.f;
+    }
+    if (tid < N) {
+        cz[tid] = bn_coef(cells, nullptr, 1, blk, tid, N, count, prm[(STAGE == 1 ? g.o_g1 : g.o_g2) + tid],
+                          prm[(STAGE == 1 ? g.o_b1 : g.o_b2) + tid]);
+        if (STAGE == 2) c1[tid] = bn_coef(cells, nullptr, 1, 0, tid, N, count, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
+        bsum[tid][0] = (float)(cells->bwd[blk][tid][0] / count);
+        bsum[tid][1] = (float)(cells->bwd[blk][tid][1] / count);
+    }
+    float acc[NACC];
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
+    float a1 = 0.f, a2 = 0.f;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int e = tid; e < N * T; e += AB) {
+            const int c = e / T, t = e - c * T;
+            const int64_t idx = b * N * T + e;
+            const float xh = (zin[idx] - cz[c].mean) * cz[c].inv;
+            dz[c][t] = cz[c].sc * (dyin[idx] - bsum[c][0] - xh * bsum[c][1]);
+            xs[c][PAD + t] = src[idx];
+        }
+        __syncthreads();
+        // d W[co][ci][k] += sum_t dz[co][t] * in[ci][t - (KT-1-k) D]
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int e = tid + r * AB;
+            if (e < nW) {
+                const int k = e % KT, ci = (e / KT) % N, co = e / (KT * N);
+                const float* xr = &xs[ci][PAD - (KT - 1 - k) * D];
+                float a = 0.f;
+                for (int t = 0; t < T; ++t) a = fmaf(dz[co][t], xr[t], a);
+                acc[r] += a;
+            }
+        }
+        if (STAGE == 2) {
+            // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
+            for (int e = tid; e < N * T; e += AB) {
+                const int ci = e / T, t = e - ci * T;
+                const int64_t idx = b * N * T + e;
+                float a = ds1[idx];
+                for (int co = 0; co < N; ++co) {
+                    const float* wr = w + (co * N + ci) * KT;
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) a = fmaf(wr[k], dz[co][t + (KT - 1 - k) * D], a);
+                }
+                const float o0 = xs[ci][PAD + t];
+                const float s0 = o0 > 0.f ? a : 0.f;
+                const float zz = z1[idx];
+                const float y = fmaf(zz, c1[ci].sc, c1[ci].sh);
+                const float dy = y > 0.f ? s0 : 0.f;
+                dy1[idx] = dy;
+                sy[ci][t] = dy;
+                sx[ci][t] = dy * (zz - c1[ci].mean) * c1[ci].inv;
+            }
+            __syncthreads();
+            if (tid < N)
+                for (int t = 0; t < T; ++t) {
+                    a1 += sy[tid][t];
+                    a2 += sx[tid][t];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = gpart + (int64_t)blockIdx.x * nW;
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+        const int e = tid + r * AB;
+        if (e < nW) dst[e] = acc[r];
+    }
+    if (STAGE == 2 && tid < N) {
+        atomicAdd(&cells->bwd[0][tid][0], (double)a1);
+        atomicAdd(&cells->bwd[0][tid][1], (double)a2);
+    }
+}
+
+// finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
+__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2,
+                                                         int rows, const Cells* cells, const float* __restrict__ sqerr,
+                                                         float* __restrict__ grads, float* __restrict__ loss) {
+    const int e = blockIdx.x * AB + threadIdx.x, N = g.N, nW = N * N * KT;
+    if (e < nW) {
+        float a = 0.f, c = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            a += gp1[(int64_t)r * nW + e];
+            c += gp2[(int64_t)r * nW + e];
+        }
+        grads[g.o_w1 + e] = a;
+        grads[g.o_w2 + e] = c;
+    } else if (e < nW + N) {
+        const int c = e - nW;
+        grads[g.o_g1 + c] = (float)cells->bwd[0][c][1];
+        grads[g.o_b1 + c] = (float)cells->bwd[0][c][0];
+        grads[g.o_g2 + c] = (float)cells->bwd[1][c][1];
+        grads[g.o_b2 + c] = (float)cells->bwd[1][c][0];
+    } else if (e == nW + N && loss && sqerr) {
+        float a = 0.f;
+        for (int64_t b = 0; b < g.B; ++b) a += sqerr[b];
+        *loss = a;
+    }
+}
+
+// BatchNorm batch statistics out: (mean, biased var) per block/channel, or weight * (E[z], E[z^2]) for data parallel
+__global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __restrict__ bn_batch, float weight) {
+    const int e = threadIdx.x;
+    if (e >= 2 * g.N) return;
+    const int blk = e / g.N, c = e % g.N;
+    const double count = (double)g.B * g.T;
+    const double m = cells->fwd[blk][c][0] / count, q = cells->fwd[blk][c][1] / count;
+    if (weight > 0.f) {
+        bn_batch[(blk * 2 + 0) * g.N + c] = (float)(weight * m);
+        bn_batch[(blk * 2 + 1) * g.N + c] = (float)(weight * q);
+    } else {
+        double v = q - m * m;
+        bn_batch[(blk * 2 + 0) * g.N + c] = (float)m;
+        bn_batch[(blk * 2 + 1) * g.N + c] = (float)(v < 0.0 ? 0.0 : v);
+    }
+}
+
+__global__ void ast_bn_running_kernel(float* __restrict__ bn, const float* __restrict__ batch, int N, double count, float momentum,
+                                      int from_moments) {
+    const int e = threadIdx.x;
+    if (e >= 2 * N) return;
+    const int blk = e / N, c = e % N;
+    float mean = batch[(blk * 2 + 0) * N + c], var = batch[(blk * 2 + 1) * N + c];
+    if (from_moments) {
+        var = var - mean * mean;
+        if (var < 0.f) var = 0.f;
+    }
+    const float unbiased = count > 1.0 ? (float)(var * (count / (count - 1.0))) : var;
+    float* rm = bn + (blk * 2 + 0) * N + c;
+    float* rv = bn + (blk * 2 + 1) * N + c;
+    *rm = (1.0f - momentum) * *rm + momentum * mean;
+    *rv = (1.0f - momentum) * *rv + momentum * unbiased;
+}
+
+__global__ void ast_fill_one_kernel(float* p) { p[0] = 1.f; }
+
+struct AstWs {
+    size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dt, dpx, dg, ds1, dy2, dy1, gp1, gp2,
+        split, total;
+    int rows;
+};
+
+void ast_ws_layout(const AstGeom& g, AstWs* w) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t BNT = (size_t)g.B * g.N * g.T * sizeof(float);
+    size_t o = 0;
+    w->cells = o; o = al(o + sizeof(Cells));
+    w->one = o; o = al(o + 256);
+    w->z1 = o; o = al(o + BNT);
+    w->out0 = o; o = al(o + BNT);
+    w->z2 = o; o = al(o + BNT);
+    w->zpre = o; o = al(o + BNT);
+    w->out1 = o; o = al(o + BNT);
+    w->tcat = o; o = al(o + BNT * g.K);
+    w->px = o; o = al(o + BNT);
+    w->adj = o; o = al(o + (size_t)g.B * g.N * g.N * sizeof(float));
+    w->dist = o; o = al(o + (size_t)g.B * g.N * g.N * sizeof(float));
+    w->scat = o; o = al(o + (size_t)g.B * g.KE * sizeof(float));
+    w->pooled = o; o = al(o + (size_t)g.B * g.O * sizeof(float));
+    w->dpred = o; o = al(o + (size_t)g.B * sizeof(float));
+    w->sqerr = o; o = al(o + (size_t)g.B * sizeof(float));
+    w->dmat = o; o = al(o + (size_t)g.B * g.O * sizeof(float));
+    w->dt = o; o = al(o + (size_t)g.B * g.KE * sizeof(float));
+    w->dpx = o; o = al(o + BNT);
+    w->dg = o; o = al(o + BNT);
+    w->ds1 = o; o = al(o + BNT);
+    w->dy2 = o; o = al(o + BNT);
+    w->dy1 = o; o = al(o + BNT);
+    w->rows = 1024;
+    w->gp1 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
+    w->gp2 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
+    const int mx = g.KE > g.E ? g.KE : g.E;
+    w->split = o; o = al(o + sgemm_splitk_partial_floats(mx, g.O > g.E ? g.O : g.E) * sizeof(float));
+    w->total = o;
+}
+
+template <typename K>
+int resident_rows(K kernel, int64_t items, int cap) {
+    int dev = 0, cus = 256, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, AB, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    int64_t want = (int64_t)cus * per_cu;
+    if (want > items) want = items;
+    if (want > cap) want = cap;
+    return want < 1 ? 1 : (int)want;
+}
+
+}  // namespace
+
+int64_t astgcnn_param_count(const rulgnn_astgcnn_shape* s) {
+    AstGeom g;
+    return ast_geometry(s, &g) == RULGNN_OK ? g.nparam : -1;
+}
+
+size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
+    AstGeom g;
+    if (ast_geometry(s, &g) != RULGNN_OK) return 0;
+    AstWs w;
+    ast_ws_layout(g, &w);
+    return w.total;
+}
+
+#define AST_RC(call)                  \
+    do {                              \
+        const int rc_ = (call);       \
+        if (rc_ != RULGNN_OK) return rc_; \
+    } while (0)
+
+// mode bit 0: forward (training != 0: batch statistics), bit 1: backward
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st) {
+    AstGeom g;
+    AST_RC(ast_geometry(s, &g));
+    AstWs w;
+    ast_ws_layout(g, &w);
+    if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    auto F = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    Cells* cells = reinterpret_cast<Cells*>(ws + w.cells);
+    const float* prm = a->params;
+    const int training = a->training ? 1 : 0;
+    const int N = g.N, T = g.T, E = g.E, O = g.O, KE = g.KE;
+    const int M = (int)(g.B * N);
+    const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+    (void)hipGetLastError();
+    if (mode & 1) {
+        if (hipMemsetAsync(cells, 0, sizeof(Cells), st) != hipSuccess) return RULGNN_EHIP;
+        const int rows = resident_rows(ast_conv_kernel<1>, g.B, 1 << 20);
+        hipLaunchKernelGGL(ast_conv_kernel<1>, dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
+                           F(w.z1), (float*)nullptr, cells);
+        hipLaunchKernelGGL(ast_conv_kernel<2>, dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
+                           F(w.z2), F(w.out0), cells);
+        // Zpre = x theta^T
+        AST_RC(sgemm(a->x, T, 1, prm + g.o_thw, T, 1, F(w.zpre), E, M, E, T, false, st));
+        {
+            int64_t blocks = (g.B * N * T + AB - 1) / AB;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(ast_gate_kernel, dim3((unsigned)blocks), dim3(AB), 0, st, g, prm, a->bn_stats, training, (const Cells*)cells,
+                               (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat));
+        }
+        // PX = G P^T  (G = columns [0, E) of Tcat)
+        AST_RC(sgemm(F(w.tcat), KE, 1, prm + g.o_pw, E, 1, F(w.px), E, M, E, E, false, st));
+        hipLaunchKernelGGL(ast_graph_kernel, dim3(resident_rows(ast_graph_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g,
+                           (const float*)F(w.px), F(w.tcat), F(w.adj), F(w.dist), F(w.scat));
+        // pooled * N = Scat Fcat   (Fcat = filters viewed as [K*E, O])
+        AST_RC(sgemm(F(w.scat), KE, 1, prm + g.o_f, 1, O, F(w.pooled), O, (int)g.B, O, KE, false, st));
+        hipLaunchKernelGGL(ast_head_kernel, dim3((unsigned)((g.B + 3) / 4 > 2048 ? 2048 : (g.B + 3) / 4)), dim3(AB), 0, st, g, prm,
+                           F(w.pooled), a->y, (const float*)nullptr, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 0);
+        if (training && a->bn_batch)
+            hipLaunchKernelGGL(ast_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
+    }
+    if (mode & 2) {
+        if (a->dpred)          // external d loss / d pred (autograd): D = dpred fc.weight / N
+            hipLaunchKernelGGL(ast_head_kernel, dim3((unsigned)((g.B + 3) / 4 > 2048 ? 2048 : (g.B + 3) / 4)), dim3(AB), 0, st, g, prm,
+                               F(w.pooled), (const float*)nullptr, a->dpred, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 1);
+        float* gr = a->grads;
+        float* split = F(w.split);
+        hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
+        // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
+        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, st));
+        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, st));
+        // d filters = Scat^T D ; DT = D Fcat^T
+        AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, st));
+        AST_RC(sgemm(F(w.dmat), O, 1, prm + g.o_f, O, 1, F(w.dt), KE, (int)g.B, KE, O, false, st));
+        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g,
+                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dt),
+                           F(w.dpx), F(w.dg));
+        // d P = dPX^T G ; dG += dPX P
+        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, st));
+        AST_RC(sgemm(F(w.dpx), E, 1, prm + g.o_pw, 1, E, F(w.dg), E, M, E, E, true, st));
+        const int rows = resident_rows(ast_conv_bwd_kernel<2>, g.B, w.rows);
+        hipLaunchKernelGGL(ast_gate_bwd_kernel, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.out1),
+                           (const float*)F(w.dg), F(w.zpre), F(w.ds1), F(w.dy2));
+        // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
+        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, st));
+        AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, st));
+        if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, st) != hipSuccess) return RULGNN_EHIP;
+        hipLaunchKernelGGL(ast_conv_bwd_kernel<2>, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
+                           (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
+        hipLaunchKernelGGL(ast_conv_bwd_kernel<1>, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
+                           a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
+        const bool mse = a->dpred == nullptr;
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N * N * KT + N + 1 + AB - 1) / AB), dim3(AB), 0, st, g, (const float*)F(w.gp1),
+                           (const float*)F(w.gp2), rows, (const Cells*)cells, mse ? (const float*)F(w.sqerr) : nullptr, gr,
+                           mse ? a->loss : nullptr);
+    }
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
+                              int from_moments, hipStream_t st) {
+    AstGeom g;
+    AST_RC(ast_geometry(s, &g));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ast_bn_running_kernel, dim3(1), dim3(64), 0, st, bn_stats, bn_batch, g.N, (double)count, momentum, from_moments);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+}  // namespace rulgnn

@@ -232,4 +232,75 @@ int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_st
                      opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st);
 }
 
+
+// ---- ASTGCNN ------------------------------------------------------------------------------------------
+int64_t rulgnn_astgcnn_param_count(const rulgnn_astgcnn_shape* shape) { return astgcnn_param_count(shape); }
+
+size_t rulgnn_astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* shape) { return astgcnn_workspace_bytes(shape); }
+
+static int check_astgcnn(const rulgnn_astgcnn_shape* shape, const rulgnn_astgcnn_args* a, bool forward, bool backward) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (shape->batch < 1 || a->global_batch < shape->batch) return RULGNN_EINVAL;
+    if (!(a->bn_moment_weight >= 0.f)) return RULGNN_EINVAL;
+    int rc = check_ptrs({a->x, a->params, a->pred, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (forward && !a->training) {
+        rc = check_ptrs({a->bn_stats});
+        if (rc != RULGNN_OK) return rc;
+    }
+    for (const void* p : {(const void*)a->y, (const void*)a->dpred, (const void*)a->bn_batch, (const void*)a->loss})
+        if (p && (reinterpret_cast<uintptr_t>(p) & 3)) return RULGNN_EALIGN;
+    if (backward) {
+        if (!a->training) return RULGNN_EINVAL;            // the backward is the train-mode (batch-statistics) one
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->dpred) {
+            rc = check_ptrs({a->y, a->loss});
+            if (rc != RULGNN_OK) return rc;
+        }
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_astgcnn_forward_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_astgcnn_args* args, void* stream) {
+    const int rc = check_astgcnn(shape, args, true, false);
+    if (rc != RULGNN_OK) return rc;
+    return astgcnn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_astgcnn_backward_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_astgcnn_args* args, void* stream) {
+    const int rc = check_astgcnn(shape, args, false, true);
+    if (rc != RULGNN_OK) return rc;
+    return astgcnn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_astgcnn_args* args, const rulgnn_adam_args* opt,
+                              void* stream) {
+    int rc = check_astgcnn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred) return RULGNN_EINVAL;
+    if (opt) {
+        if (opt->step < 1 || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+        if (opt->bn_stats && (!args->bn_batch || (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3))) return RULGNN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = astgcnn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, astgcnn_param_count(shape), opt->step, opt->lr,
+                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st);
+    if (rc != RULGNN_OK || !opt->bn_stats) return rc;
+    return astgcnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, shape->batch * (int64_t)shape->time_length,
+                                     opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
+}
+
+int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape* shape, float* bn_stats, const float* bn_batch, int64_t count,
+                                         float momentum, int32_t from_moments, void* stream) {
+    if (!shape || count < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({bn_stats, bn_batch});
+    if (rc != RULGNN_OK) return rc;
+    return astgcnn_bn_running_update(shape, bn_stats, bn_batch, count, momentum, from_moments, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

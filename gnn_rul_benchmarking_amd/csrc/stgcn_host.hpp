@@ -99,6 +99,11 @@ int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s);
 size_t stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* s);
 int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float* prm, float* features, hipStream_t stream);
 int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t stream);
+int64_t astgcnn_param_count(const rulgnn_astgcnn_shape* s);
+size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s);
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream);
+int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
+                              int from_moments, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream);
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,

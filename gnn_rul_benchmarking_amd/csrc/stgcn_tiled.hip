@@ -9,84 +9,9 @@
 // column in memory (coalesced along t).  Reference: models/ST_GCN/Model.py:7-222.
 #include "stgcn_device.hpp"
 #include "stgcn_host.hpp"
+#include "sgemm_mfma.hpp"
 
 namespace rulgnn {
-
-typedef float f32x4t __attribute__((ext_vector_type(4)));
-
-// ------------------------------------------------------------------------------------------------
-// SGEMM on the matrix cores: C[m][n] (+)= sum_k A(m,k) * B(n,k), generic strides, fp32 MFMA 16x16x4.
-// 64x64 block tile, K step 16, 4 wavefronts each owning a 32x32 quadrant (2x2 MFMA tiles).
-// ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* A; int64_t sAm, sAk;
-    const float* B; int64_t sBn, sBk;
-    float* C; int64_t ldc;
-    int M, N, K;
-    int accumulate;      // C += instead of C =
-};
-
-__global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
-    __shared__ float As[16][64 + 4];      // [k][m]
-    __shared__ float Bs[16][64 + 4];      // [k][n]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x4t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
-    const int li = lane & 15, kq = lane >> 4;
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        // cooperative load: 64 x 16 elements of A and of B (4 + 4 per thread)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = tid + e * 256, mm = idx & 63, kk = idx >> 6;
-            const int gm = m0 + mm, gn = n0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < g.M && gk < g.K) ? g.A[gm * g.sAm + gk * g.sAk] : 0.f;
-            Bs[kk][mm] = (gn < g.N && gk < g.K) ? g.B[gn * g.sBn + gk * g.sBk] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[4 * ks + kq][wm + 16 * i + li];
-                b[i] = Bs[4 * ks + kq][wn + 16 * i + li];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // D layout: lane (g4 = lane>>4, col = lane&15), reg r -> row 4*g4 + r
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wm + 16 * i + 4 * kq + r, gn = n0 + wn + 16 * j + li;
-                if (gm < g.M && gn < g.N) {
-                    float* c = g.C + (int64_t)gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-}
-
-static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, hipStream_t st) {
-    if (M <= 0 || N <= 0) return RULGNN_OK;
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0};
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-}
 
 // ------------------------------------------------------------------------------------------------
 // position-parallel kernels: thread = (sample b, patch t); tensors are [B][10][N]

@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN and STMSGCN rows are restated (the methods this package implements).
+ValueError).  Only the ST_GCN, STMSGCN and ASTGCNN rows are restated (the methods this package implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
 :226,242,275,311,355,390,424).
@@ -15,6 +15,7 @@ from __future__ import annotations
 _ST_GCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-4}
 _STMSGCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 0, 'learning_rate': 1e-2}
 _MSG = {'gcn_dims': [16, 64, 16, 1], 'gru_hidden_dim': 8}
+_ASTGCNN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
 
 
 def get_hparams_class(dataset_name):
@@ -27,6 +28,7 @@ def get_hparams_class(dataset_name):
 class _Table:
     _rows: dict = {}
     _stmsgcn_rows: dict = {}          # the reference wires STMSGCN to the bearing datasets only
+    _astgcnn_nodes = None             # ... and ASTGCNN to the aero-engine datasets only (configs/hparams.py:38,202)
 
     def __init__(self, dataset_id=None, **overrides):
         if dataset_id not in self._rows:
@@ -34,6 +36,10 @@ class _Table:
         self.train_params = {'ST_GCN': dict(_ST_GCN_TRAIN)}
         self.alg_hparams = {'ST_GCN': dict(self._rows[dataset_id])}
         self.alg_hparams['ST_GCN'].update(overrides)
+        if self._astgcnn_nodes:
+            self.train_params['ASTGCNN'] = dict(_ASTGCNN_TRAIN)
+            self.alg_hparams['ASTGCNN'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'encoder_out_dim': 50,
+                                           'output_dim': 64, 'K': 3}
         if dataset_id in self._stmsgcn_rows:
             self.train_params['STMSGCN'] = dict(_STMSGCN_TRAIN)
             self.alg_hparams['STMSGCN'] = dict(self._stmsgcn_rows[dataset_id], gcn_dims=list(_MSG['gcn_dims']),
@@ -41,6 +47,8 @@ class _Table:
 
 
 class CMAPSS(_Table):
+    _astgcnn_nodes = 14
+
     def __init__(self, dataset_id, window=30):
         self._rows = {fd: {'num_patch': 14, 'patch_size': int(window), 'dropout': 0.2}
                       for fd in ('FD001', 'FD002', 'FD003', 'FD004')}
@@ -48,6 +56,8 @@ class CMAPSS(_Table):
 
 
 class NCMAPSS(_Table):
+    _astgcnn_nodes = 20
+
     def __init__(self, dataset_id=None, window=50):
         self._rows = {None: {'num_patch': 20, 'patch_size': int(window), 'dropout': 0.2}}
         super().__init__(None)

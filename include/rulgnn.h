@@ -212,6 +212,62 @@ int rulgnn_stmsgcn_backward_f32(const rulgnn_stmsgcn_shape *shape, const rulgnn_
 int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape *shape, const rulgnn_stmsgcn_args *args,
                               const rulgnn_adam_args *opt, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ASTGCNN path (reference models/ASTGCNN/Model.py, algorithms/algorithms.py:139-163): the model the reference
+ * wires to C-MAPSS (14 sensors x 50 steps, configs/hparams.py:38) and N-CMAPSS (20 x 50, :202).
+ *
+ * x [batch, num_nodes, time_length] -> TCN over time with the nodes as channels (two causal Conv1d(k=6, dilation 1|2,
+ * no bias) + BatchNorm1d + ReLU blocks with residuals, Model.py:72-146) -> tanh gate (Linear(T->E) + bias) times the TCN
+ * output (:169-181; needs E == T) -> A = exp(-cdist(P x_i, P x_j)) (:184-195) -> Chebyshev graph convolution of order
+ * K <= 3 with filters[K][E][O] (:198-230) -> mean over nodes -> Linear(O -> 1).
+ *
+ * Flat parameter buffer (floats), N = num_nodes, T = E = time_length, O = output_dim:
+ *     conv_block1.0.weight[N][N][6] | bn1.weight[N] | bn1.bias[N] | conv_block2.0.weight[N][N][6] | bn2.weight[N] |
+ *     bn2.bias[N] | gate.theta.weight[E][T] | gate.theta.bias[E] | gate.bias[E] | distance_module.P.weight[E][E] |
+ *     chebnet.filters[K][E][O] | fc.weight[O] | fc.bias[1]
+ * BatchNorm buffer: [2 (conv_block1, conv_block2)][2 (mean, var)][N].
+ */
+typedef struct rulgnn_astgcnn_shape {
+    int64_t batch;
+    int32_t num_nodes;        /* N, 1..25 (torch.cdist's exact path) */
+    int32_t time_length;      /* T = encoder_out_dim, 1..64 */
+    int32_t output_dim;       /* O, 1..256 */
+    int32_t K;                /* Chebyshev order, 1..3 */
+} rulgnn_astgcnn_shape;
+
+typedef struct rulgnn_astgcnn_args {
+    const float *x;           /* [batch, num_nodes*time_length] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;      /* flat parameters */
+    float *grads;             /* flat gradient out */
+    float *pred;              /* [batch] */
+    float *loss;              /* [1]: sum((pred - y)^2) / global_batch; may be NULL */
+    const float *bn_stats;    /* running statistics (read when training == 0) */
+    float *bn_batch;          /* out, training: batch (mean, biased var) per BatchNorm/channel, or, with
+                               * bn_moment_weight > 0, weight * (E[z], E[z^2]) (summable over ranks); may be NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;     /* MSE denominator */
+    float bn_moment_weight;
+    int32_t training;         /* != 0: BatchNorm batch statistics (model.train()), else running statistics */
+} rulgnn_astgcnn_args;
+
+int64_t rulgnn_astgcnn_param_count(const rulgnn_astgcnn_shape *shape);      /* < 0: invalid / unsupported */
+size_t rulgnn_astgcnn_workspace_bytes(const rulgnn_astgcnn_shape *shape);    /* 0: invalid / unsupported */
+
+/* model(X): ASTGCNN_model.forward (Model.py:241-254) in eval (trainer.py:144) or train mode (algorithms.py:153). */
+int rulgnn_astgcnn_forward_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_astgcnn_args *args, void *stream);
+/* loss.backward() (algorithms.py:159) after a train-mode forward with the same args/workspace. */
+int rulgnn_astgcnn_backward_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_astgcnn_args *args, void *stream);
+/* ASTGCNN.update body (algorithms.py:153-161): train forward + MSE + backward; with `opt` also torch.optim.Adam and the
+ * BatchNorm running-statistics update (opt->bn_stats, opt->bn_momentum). */
+int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_astgcnn_args *args,
+                              const rulgnn_adam_args *opt, void *stream);
+/* nn.BatchNorm1d running-statistics update for this model's two BatchNorm layers (count = batch * time_length). */
+int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape *shape, float *bn_stats, const float *bn_batch,
+                                         int64_t count, float momentum, int32_t from_moments, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
