@@ -496,8 +496,7 @@ __global__ __launch_bounds__(AB) void ast_conv_bwd_kernel(AstGeom g, const float
 
 // finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
 __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2,
-                                                         int rows, const Cells* cells, const float* __restrict__ sqerr,
-                                                         float* __restrict__ grads, float* __restrict__ loss) {
+                                                         int rows, const Cells* cells, float* __restrict__ grads) {
     const int e = blockIdx.x * AB + threadIdx.x, N = g.N, nW = N * N * KT;
     if (e < nW) {
         float a = 0.f, c = 0.f;
@@ -513,10 +512,6 @@ __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const float
         grads[g.o_b1 + c] = (float)cells->bwd[0][c][0];
         grads[g.o_g2 + c] = (float)cells->bwd[1][c][1];
         grads[g.o_b2 + c] = (float)cells->bwd[1][c][0];
-    } else if (e == nW + N && loss && sqerr) {
-        float a = 0.f;
-        for (int64_t b = 0; b < g.B; ++b) a += sqerr[b];
-        *loss = a;
     }
 }
 
@@ -704,9 +699,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         hipLaunchKernelGGL(ast_conv_bwd_kernel<1>, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         const bool mse = a->dpred == nullptr;
-        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N * N * KT + N + 1 + AB - 1) / AB), dim3(AB), 0, st, g, (const float*)F(w.gp1),
-                           (const float*)F(w.gp2), rows, (const Cells*)cells, mse ? (const float*)F(w.sqerr) : nullptr, gr,
-                           mse ? a->loss : nullptr);
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N * N * KT + N + AB - 1) / AB), dim3(AB), 0, st, g, (const float*)F(w.gp1),
+                           (const float*)F(w.gp2), rows, (const Cells*)cells, gr);
+        if (mse && a->loss)
+            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)F(w.sqerr), (int64_t)g.B, a->loss);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

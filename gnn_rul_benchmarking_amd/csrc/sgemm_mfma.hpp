@@ -123,6 +123,20 @@ static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
+// out[0] = sum(v[0..n)) with one workgroup: strided partial sums, then a fixed-order tree (deterministic).
+static __global__ __launch_bounds__(1024) void block_sum_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float a = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int m = 512; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 // floats the caller must provide as `partial` for sgemm_splitk(M, N, any K)
 static inline size_t sgemm_splitk_partial_floats(int M, int N) { return (size_t)256 * M * N; }
 

@@ -16,6 +16,7 @@
 //              accumulated in LDS per workgroup;
 //   finalize   fixed-order reduction of the per-workgroup partial gradients, fc gradients, loss.
 // Everything is fp32; reductions have a fixed order, so results are run-to-run reproducible.
+#include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
 namespace rulgnn {
@@ -625,8 +626,7 @@ static size_t gcn_backward_lds_bytes(const MsgGeom& g) {
 __global__ __launch_bounds__(MB) void msg_finalize_kernel(MsgGeom g, const float* __restrict__ gpart_gcn, int rows_gcn,
                                                           const float* __restrict__ gpart_gru, int rows_gru,
                                                           const float* __restrict__ dpred, const float* __restrict__ pooled,
-                                                          const float* __restrict__ sqerr, float* __restrict__ grads,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ grads) {
     const int e = blockIdx.x * MB + threadIdx.x;
     const int nacc = g.gcn_params + g.H3 * g.C + g.H3;
     const int ngru = g.H3 * g.H + g.H3;
@@ -647,11 +647,6 @@ __global__ __launch_bounds__(MB) void msg_finalize_kernel(MsgGeom g, const float
             for (int64_t b = 0; b < g.B; ++b) a += dpred[b];
         }
         grads[e] = a;
-    }
-    if (loss && sqerr && e == g.nparam) {
-        float a = 0.f;
-        for (int64_t b = 0; b < g.B; ++b) a += sqerr[b];
-        *loss = a;
     }
 }
 
@@ -781,10 +776,11 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
         hipLaunchKernelGGL(msg_gcn_backward_kernel, dim3(rows), dim3(MB), lds, st, g, (const float*)(ws + w.cat),
                            (const float*)(ws + w.dgi), a->params, (float*)(ws + w.gpart_gcn));
         const bool mse = a->dpred == nullptr;
-        hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + 1 + MB - 1) / MB), dim3(MB), 0, st, g,
+        hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + MB - 1) / MB), dim3(MB), 0, st, g,
                            (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
-                           (const float*)(ws + w.dpred), (const float*)(ws + w.pooled),
-                           mse ? (const float*)(ws + w.sqerr) : nullptr, a->grads, mse ? a->loss : nullptr);
+                           (const float*)(ws + w.dpred), (const float*)(ws + w.pooled), a->grads);
+        if (mse && a->loss)
+            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + w.sqerr), (int64_t)g.B, a->loss);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -50,6 +50,10 @@ class DeviceBatchLoader:
 
     def __iter__(self):
         from .dp import shard_bounds
+        # torch's DataLoader iterator draws its `_base_seed` from the global RNG before the sampler draws anything
+        # (torch/utils/data/dataloader.py, _BaseDataLoaderIter.__init__); drawing it here too keeps the global RNG -- and
+        # with it every later shuffle -- in lockstep with the reference's DataLoader for a given seed.
+        torch.empty((), dtype=torch.int64).random_()
         for idx in self.index_batches():
             gb = len(idx)
             lo, hi = shard_bounds(gb, self.world_size, self.rank) if self.world_size > 1 else (0, gb)

@@ -114,7 +114,59 @@ def case_training_curve(name, cfg, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_trainer_cmapss(name, seed, n_train=250, n_test=80, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method ASTGCNN on the synthetic C-MAPSS FD001
+    dataset of synth.py, its own hparams (configs/hparams.py:19,38: batch 100, lr 1e-3, wd 1e-4) and its own shuffling
+    DataLoader (data_model_configs.py:13); only num_epochs is patched.  Records every epoch's test metrics, the results
+    CSV and a few final tensors."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_cmapss
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "CMAPSS", "FD001")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="ASTGCNN", data_path=os.path.join(tmp, "data"), dataset="CMAPSS",
+                                      dataset_id="FD001", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "ASTGCNN_run_0", "results.csv")).read()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.fc.weight", "model.chebnet.filters", "model.tcn.conv_block2.0.weight", "model.tcn.conv_block2.2.running_var",
+              "model.tcn.conv_block1.2.num_batches_tracked"):
+        out["final:" + k] = final[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_cmapss("astgcnn_trainer_cmapss_fd001_reference_run", 6)
+        sys.exit(0)
     cm = dict(num_nodes=14, time_length=50, encoder_out_dim=50, output_dim=64, K=3)
     case_forward_backward("astgcnn_cmapss_14x50_bs16", cm, 16, seed=41)
     # N-CMAPSS is scaled to [-1, 1] (Data_read_NCMAPSS.py:230)
@@ -122,3 +174,4 @@ if __name__ == "__main__":
     case_forward_backward("astgcnn_small_5x12_bs9", dict(num_nodes=5, time_length=12, encoder_out_dim=12, output_dim=8, K=3), 9, seed=43)
     case_forward_backward("astgcnn_k2_7x20_bs4", dict(num_nodes=7, time_length=20, encoder_out_dim=20, output_dim=16, K=2), 4, seed=44)
     case_training_curve("astgcnn_train_curve_14x50_bs20", cm, 20, steps=16, seed=45, lr=1e-3, wd=1e-4)
+    case_trainer_cmapss("astgcnn_trainer_cmapss_fd001_reference_run", 6)
