@@ -160,3 +160,30 @@ def test_eval_batch_split_invariance_and_abi_errors():
     assert lib.rulgnn_astgcnn_forward_f32(C.byref(shp), C.byref(a), None) == -3
     a = m._args(shp, x[:4].reshape(4, -1), False)          # backward needs the train-mode forward
     assert lib.rulgnn_astgcnn_backward_f32(C.byref(shp), C.byref(a), None) == -1
+
+
+def test_shard_step_fills_the_data_parallel_bucket():
+    """What dp.DataParallel.step asks of the kernels: gradient and loss scaled by the GLOBAL batch, BatchNorm normalised
+    with the shard's own statistics, and weight * (E[z], E[z^2]) behind the loss for the all-reduce."""
+    rng = np.random.default_rng(5)
+    N, T = 14, 50
+    p = O.random_params(N, T, seed=2)
+    x, y = rng.uniform(0, 1, (10, N, T)), rng.uniform(0, 1, 10)
+    m = build_model(dict(num_nodes=N, time_length=T, encoder_out_dim=T, output_dim=64, K=3), p).train()
+    before = m._bn.clone()
+    for lo, hi in ((0, 4), (4, 10)):
+        xs, ys = x[lo:hi], y[lo:hi]
+        loss, grads, fw = O.loss_and_grads(p, xs, ys, global_batch=10)
+        m.fused_mse_step(torch.from_numpy(xs.astype(np.float32)).to(DEV), torch.from_numpy(ys.astype(np.float32)).to(DEV),
+                         global_batch=10, sample_offset=lo, update_running_stats=False, moments_to_bucket=True)
+        b = m.bucket.cpu().numpy().astype(np.float64)
+        assert abs(b[m.num_live] - loss) < TOL * abs(loss)
+        g = grads_of(m)
+        for k in O.live_param_names():
+            assert rel(g[k], grads[k]) < GTOL, k
+        w = (hi - lo) / 10.0
+        tail = b[m.num_live + 1:]
+        for i, zz in enumerate((fw.z1, fw.z2)):
+            assert np.allclose(tail[(2 * i) * N:(2 * i + 1) * N], w * zz.mean(axis=(0, 2)), rtol=1e-4, atol=1e-6)
+            assert np.allclose(tail[(2 * i + 1) * N:(2 * i + 2) * N], w * (zz * zz).mean(axis=(0, 2)), rtol=1e-4, atol=1e-6)
+    assert torch.equal(m._bn, before)                      # running statistics wait for the all-reduced moments

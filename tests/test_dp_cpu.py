@@ -210,3 +210,74 @@ def test_stmsgcn_data_parallel_step_equals_single_process_world2_gloo():
     full = np.concatenate([grads[k].reshape(-1) for k in MO.param_names(MCFG)])
     assert abs(out[0]["loss"] - loss) < 1e-6 * abs(loss)
     assert np.allclose(out[0]["bucket"][:-1], full, rtol=1e-5, atol=1e-9)
+
+
+# ---- ASTGCNN: BatchNorm-coupled like ST_GCN (local normalisation, global moments for the running statistics) ----
+from oracle import astgcnn_oracle as AO   # noqa: E402
+
+AN, AT, AOUT = 5, 12, 8
+
+
+class AstgcnnOracleModel:
+    """Duck-types the slice of ASTGCNN_model that dp.DataParallel touches."""
+
+    def __init__(self, prm):
+        self.prm = {k: np.asarray(v, np.float64) for k, v in prm.items()}
+        self.names = AO.live_param_names()
+        self.num_live = sum(self.prm[k].size for k in self.names)
+        self.bucket = torch.zeros(self.num_live + 1 + 4 * AN, dtype=torch.float32)
+        self.flat_params = torch.from_numpy(np.concatenate([self.prm[k].reshape(-1) for k in self.names]).astype(np.float32))
+        self.global_moments = None
+
+    def fused_mse_step(self, X, y, optimizer=None, global_batch=None, sample_offset=0, update_running_stats=True,
+                       moments_to_bucket=False):
+        assert moments_to_bucket and not update_running_stats
+        x, yy = X.numpy().astype(np.float64), y.numpy().astype(np.float64).reshape(-1)
+        loss, grads, fw = AO.loss_and_grads(self.prm, x, yy, global_batch=global_batch)
+        self.bucket[:self.num_live] = torch.from_numpy(np.concatenate([grads[k].reshape(-1) for k in self.names]).astype(np.float32))
+        self.bucket[self.num_live] = loss
+        w = x.shape[0] / float(global_batch)
+        tail = self.bucket[self.num_live + 1:]
+        for i, z in enumerate((fw.z1, fw.z2)):
+            tail[(2 * i) * AN:(2 * i + 1) * AN] = torch.from_numpy((w * z.mean(axis=(0, 2))).astype(np.float32))
+            tail[(2 * i + 1) * AN:(2 * i + 2) * AN] = torch.from_numpy((w * (z * z).mean(axis=(0, 2))).astype(np.float32))
+        self.last = fw
+        return None, self.bucket[self.num_live]
+
+    def _after_train_forward(self, batch, from_bucket_moments=False):
+        assert from_bucket_moments
+        self.global_moments = self.bucket[self.num_live + 1:].clone()
+
+
+def _astgcnn_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(2)
+        x = torch.from_numpy(rng.uniform(0, 1, (B, AN, AT)).astype(np.float32))
+        y = torch.from_numpy(rng.uniform(0, 1, (B, 1)).astype(np.float32))
+        model = AstgcnnOracleModel(AO.random_params(AN, AT, output_dim=AOUT, seed=9))
+        dp = DataParallel()
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "flat": model.flat_params.clone().numpy(),
+                     "moments": model.global_moments.numpy(), "pred": model.last.pred.copy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_astgcnn_data_parallel_step_world2_gloo():
+    B, world = 11, 2
+    out = mp.Manager().dict()
+    mp.spawn(_astgcnn_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    assert np.array_equal(out[0]["bucket"], out[1]["bucket"]) and np.array_equal(out[0]["flat"], out[1]["flat"])
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0, 1, (B, AN, AT)).astype(np.float32).astype(np.float64)
+    y = rng.uniform(0, 1, (B, 1)).astype(np.float32).astype(np.float64)
+    # the reduced loss is the global-batch MSE of the (locally normalised) shard predictions
+    pred = np.concatenate([out[0]["pred"], out[1]["pred"]])
+    assert abs(out[0]["loss"] - float(np.mean((pred - y) ** 2))) < 1e-5
+    # BatchNorm 1 sees the same conv output in every sharding: its reduced moments equal the single-process statistics
+    fw = AO.forward(AO.random_params(AN, AT, output_dim=AOUT, seed=9), x, train=True)
+    assert np.allclose(out[0]["moments"][:AN], fw.z1.mean(axis=(0, 2)), rtol=1e-5, atol=1e-6)
+    assert np.allclose(out[0]["moments"][AN:2 * AN], (fw.z1 ** 2).mean(axis=(0, 2)), rtol=1e-5, atol=1e-6)
