@@ -25,16 +25,17 @@ class StgcnTrainArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("global_batch", C.c_int64), ("sample_offset", C.c_int64),
                 ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
-                ("bn_moment_weight", C.c_float)]
+                ("bn_moment_weight", C.c_float), ("step_state", C.c_void_p)]
 
 
 class AdamArgs(C.Structure):
     _fields_ = [("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("bn_stats", C.c_void_p),
                 ("step", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("weight_decay", C.c_float), ("bn_momentum", C.c_float)]
+                ("weight_decay", C.c_float), ("bn_momentum", C.c_float), ("step_state", C.c_void_p)]
 
 
 STMSGCN_MAX_LAYERS = 6
+STEP_STATE_BYTES = 64
 
 
 class StmsgcnShape(C.Structure):
@@ -81,6 +82,9 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
+    "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
+    "rulgnn_adam_step_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                                            C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),

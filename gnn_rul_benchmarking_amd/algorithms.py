@@ -36,6 +36,16 @@ class Algorithm(torch.nn.Module):
     def update(self, *args, **kwargs):
         raise NotImplementedError
 
+    def enable_graphs(self, warmup=2):
+        """Replay ``update`` from a hipGraph per input shape (graphs.py): one launch per step instead of dozens --
+        for launch-bound batch sizes such as the reference protocol's 100.  Single process only."""
+        from .graphs import GraphedUpdate
+        self._graphed = GraphedUpdate(self, warmup=warmup)
+        return self
+
+    def _finish(self, loss):
+        return {'loss': loss.item() if self.sync_loss else loss}
+
 
 class ST_GCN(Algorithm):
     """ST_GCN training wrapper.  ``update`` = forward + MSE + backward + Adam, as the reference
@@ -65,11 +75,17 @@ class ST_GCN(Algorithm):
         model = self.model
         if not model.training:
             raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
-        if self.dp is None:
-            _, loss = model.fused_train_step(X, y, self.optimizer)      # one C call: fwd + MSE + bwd + Adam + BN stats
-        else:
+        if self.dp is not None:
             loss = self.dp.step(model, self.optimizer, X, y, global_batch, sample_offset)
-        return {'loss': loss.item() if self.sync_loss else loss}
+        elif getattr(self, "_graphed", None) is not None:
+            loss = self._graphed.update(X, y)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_train_step(X, y, self.optimizer)      # one C call: fwd + MSE + bwd + Adam + BN stats
+        return loss
 
     def update_reference_style(self, X, y, epoch=None):
         """The reference's literal sequence through autograd (slower: ~20 tiny accumulate ops);
@@ -100,11 +116,17 @@ class STMSGCN(Algorithm):
         dp.broadcast_model(self.model)
 
     def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
-        if self.dp is None:
-            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
-        else:
+        if self.dp is not None:
             loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
-        return {'loss': loss.item() if self.sync_loss else loss}
+        elif getattr(self, "_graphed", None) is not None:
+            loss = self._graphed.update(X, y)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return loss
 
     def update_reference_style(self, X, y, epoch=None):
         """The reference's literal sequence through autograd; same result as ``update``."""
@@ -136,11 +158,17 @@ class ASTGCNN(Algorithm):
     def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
         if not self.model.training:
             raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics)")
-        if self.dp is None:
-            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
-        else:
+        if self.dp is not None:
             loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
-        return {'loss': loss.item() if self.sync_loss else loss}
+        elif getattr(self, "_graphed", None) is not None:
+            loss = self._graphed.update(X, y)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return loss
 
     def update_reference_style(self, X, y, epoch=None):
         """The reference's literal sequence through autograd; same result as ``update``."""

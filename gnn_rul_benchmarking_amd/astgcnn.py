@@ -107,7 +107,7 @@ class ASTGCNN_model(nn.Module):
             self._slices.append((off, n, shape))
         self._bn_names = [f"tcn.conv_block{b}.2.running_{k}" for b in (1, 2) for k in ("mean", "var")]
         self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
-        self._ws_key = None
+        self._bufs, self._pin_bufs, self._step_state = {}, False, None
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
         self._reflatten()
@@ -153,7 +153,7 @@ class ASTGCNN_model(nn.Module):
         self._bn, self._nbt = bn, nbt
         self._grad_flat = torch.zeros(self._count + 1 + 4 * N, dtype=torch.float32, device=dev)   # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(4 * N, dtype=torch.float32, device=dev)
-        self._pred_buf, self._ws, self._ws_key = None, None, None
+        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
@@ -192,15 +192,18 @@ class ASTGCNN_model(nn.Module):
 
     def _args(self, shp, x2d, training, y=None, dpred=None, global_batch=None, moments_to_bucket=False):
         B = x2d.size(0)
-        key = (B, self._flat.device)
-        if self._ws_key != key:
+        ent = self._bufs.get(B)
+        if ent is None:
             nbytes = _lib.load().rulgnn_astgcnn_workspace_bytes(C.byref(shp))
             if nbytes == 0:
                 raise RuntimeError("ASTGCNN kernels do not cover this configuration (num_nodes <= 25, time_length <= 64, "
                                    "output_dim <= 256, K <= 3)")
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
-            self._pred_buf = torch.empty(B, dtype=torch.float32, device=self._flat.device)
-            self._ws_key = key
+            if len(self._bufs) >= 4 and not self._pin_bufs:
+                self._bufs.pop(next(iter(self._bufs)))
+            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
+                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
+            self._bufs[B] = ent
+        self._ws, self._pred_buf = ent
         a = _lib.AstgcnnArgs()
         a.x = x2d.data_ptr()
         a.y = y.data_ptr() if y is not None else None
@@ -262,7 +265,8 @@ class ASTGCNN_model(nn.Module):
             g = optimizer.param_groups[0]
             o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
                                       float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), 0.1))
+                                      float(g["weight_decay"]), 0.1,
+                                      self._step_state.data_ptr() if self._step_state is not None else None))
         _lib.check(_lib.load().rulgnn_astgcnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_astgcnn_fwdbwd_f32")
         if optimizer is not None:
             self._nbt_pending += 1

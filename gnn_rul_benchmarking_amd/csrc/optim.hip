@@ -8,7 +8,11 @@ namespace rulgnn {
 
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
-                                 float beta2, float eps, float wd, float gscale) {
+                                 float beta2, float eps, float wd, float gscale, const StepState* __restrict__ st) {
+    if (st) {                      // device step state: bias corrections of the step the prepare kernel just advanced to
+        lr_over_bc1 = st->lr_over_bc1;
+        inv_sqrt_bc2 = st->inv_sqrt_bc2;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float pi = p[i];
         const float gi = fmaf(wd, pi, g[i] * gscale);
@@ -38,9 +42,55 @@ __global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __
     bn[i] = (1.f - momentum) * bn[i] + momentum * b;
 }
 
+__global__ void step_state_set_kernel(StepState* s, uint64_t dropout_step, int64_t adam_step) {
+    s->dropout_step = dropout_step;
+    s->adam_step = adam_step;
+    s->lr_over_bc1 = s->inv_sqrt_bc2 = 0.f;
+    for (int l = 0; l < 8; ++l) s->drop_key[l] = 0u;
+    s->pad[0] = s->pad[1] = 0u;
+}
+
+__global__ void step_prepare_dropout_kernel(StepState* s, uint64_t seed, int num_layers) {
+    const uint64_t step = s->dropout_step + 1;
+    s->dropout_step = step;
+    for (int l = 0; l < 8; ++l) s->drop_key[l] = l < num_layers ? dropout_layer_key(seed, step, l) : 0u;
+}
+
+__global__ void step_prepare_adam_kernel(StepState* s, float lr, float beta1, float beta2) {
+    const int64_t step = s->adam_step + 1;
+    s->adam_step = step;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    s->lr_over_bc1 = (float)((double)lr / bc1);
+    s->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(step_state_set_kernel, dim3(1), dim3(1), 0, stream, static_cast<StepState*>(state), dropout_step, adam_step);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int step_prepare_dropout(void* state, uint64_t seed, int num_layers, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(step_prepare_dropout_kernel, dim3(1), dim3(1), 0, stream, static_cast<StepState*>(state), seed, num_layers);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(step_prepare_adam_kernel, dim3(1), dim3(1), 0, stream, static_cast<StepState*>(state), lr, beta1, beta2);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t stream) {
+              float eps, float wd, float gscale, hipStream_t stream, void* step_state) {
     if (n <= 0) return RULGNN_OK;
+    if (step_state) {
+        const int rc = step_prepare_adam(step_state, lr, beta1, beta2, stream);
+        if (rc != RULGNN_OK) return rc;
+        step = 1;                  // placeholder: the kernel takes the corrections from the state
+    }
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const int block = 256;
@@ -48,7 +98,8 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t s
     if (grid > 1024) grid = 1024;
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, p, g, m, v, n,
-                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale);
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale,
+                       static_cast<const StepState*>(step_state));
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

@@ -122,7 +122,7 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_st
                                 const rulgnn_adam_args* opt, void* stream) {
     int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
-    if (!opt || opt->step < 1 || args->dpred) return RULGNN_EINVAL;
+    if (!opt || (opt->step < 1 && !opt->step_state) || args->dpred) return RULGNN_EINVAL;
     if (opt->params != args->params) return RULGNN_EINVAL;
     rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
     if (rc != RULGNN_OK) return rc;
@@ -133,7 +133,7 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_st
         if (rc != RULGNN_OK) return rc;
         rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq,
                        param_count(shape->num_patch, shape->num_layers), opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps,
-                       opt->weight_decay, 1.0f, st);
+                       opt->weight_decay, 1.0f, st, opt->step_state);
         if (rc != RULGNN_OK || !opt->bn_stats) return rc;
         return bn_running_update(opt->bn_stats, args->bn_batch, shape->num_layers, shape->batch * (int64_t)shape->num_patch,
                                  opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
@@ -221,7 +221,7 @@ int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_st
     if (rc != RULGNN_OK) return rc;
     if (args->dpred) return RULGNN_EINVAL;                 // the fused call is the MSE step
     if (opt) {
-        if (opt->step < 1 || opt->params != args->params) return RULGNN_EINVAL;
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
         rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
         if (rc != RULGNN_OK) return rc;
     }
@@ -229,7 +229,7 @@ int rulgnn_stmsgcn_fwdbwd_f32(const rulgnn_stmsgcn_shape* shape, const rulgnn_st
     rc = stmsgcn_run(shape, args, 3, st);
     if (rc != RULGNN_OK || !opt) return rc;
     return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stmsgcn_param_count(shape), opt->step, opt->lr,
-                     opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st);
+                     opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
 }
 
 
@@ -280,7 +280,7 @@ int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_as
     if (rc != RULGNN_OK) return rc;
     if (args->dpred) return RULGNN_EINVAL;
     if (opt) {
-        if (opt->step < 1 || opt->params != args->params) return RULGNN_EINVAL;
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
         rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
         if (rc != RULGNN_OK) return rc;
         if (opt->bn_stats && (!args->bn_batch || (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3))) return RULGNN_EINVAL;
@@ -289,7 +289,7 @@ int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_as
     rc = astgcnn_run(shape, args, 3, st);
     if (rc != RULGNN_OK || !opt) return rc;
     rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, astgcnn_param_count(shape), opt->step, opt->lr,
-                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st);
+                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
     if (rc != RULGNN_OK || !opt->bn_stats) return rc;
     return astgcnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, shape->batch * (int64_t)shape->time_length,
                                      opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
@@ -301,6 +301,23 @@ int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape* shape, floa
     const int rc = check_ptrs({bn_stats, bn_batch});
     if (rc != RULGNN_OK) return rc;
     return astgcnn_bn_running_update(shape, bn_stats, bn_batch, count, momentum, from_moments, static_cast<hipStream_t>(stream));
+}
+
+
+// ---- device step state (hipGraph-capturable training steps) -----------------------------------------------
+int rulgnn_step_state_set(void* step_state, uint64_t dropout_step, int64_t adam_step, void* stream) {
+    if (!step_state || adam_step < 0) return RULGNN_EINVAL;
+    if (reinterpret_cast<uintptr_t>(step_state) & 7) return RULGNN_EALIGN;
+    return step_state_set(step_state, dropout_step, adam_step, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_adam_step_dev_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, void* step_state,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream) {
+    if (n < 0 || !step_state) return RULGNN_EINVAL;
+    const int rc = check_ptrs({params, grads, exp_avg, exp_avg_sq});
+    if (rc != RULGNN_OK) return rc;
+    return adam_step(params, grads, exp_avg, exp_avg_sq, n, 1, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                     static_cast<hipStream_t>(stream), step_state);
 }
 
 }  // extern "C"

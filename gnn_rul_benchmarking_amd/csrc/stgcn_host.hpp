@@ -47,14 +47,25 @@ inline int tile_geometry(const rulgnn_stgcn_shape* s, TileGeom* g) {
     return RULGNN_OK;
 }
 
+// Device-resident step state (include/rulgnn.h, RULGNN_STEP_STATE_BYTES): counters advanced on the device, plus what the
+// compute kernels derive from them, so that a captured hipGraph replays with fresh dropout keys / Adam bias corrections.
+struct StepState {
+    uint64_t dropout_step;
+    int64_t adam_step;
+    float lr_over_bc1, inv_sqrt_bc2;
+    uint32_t drop_key[8];
+    uint32_t pad[2];
+};
+static_assert(sizeof(StepState) == RULGNN_STEP_STATE_BYTES, "step state layout");
+
 // (seed, step, layer) -> 32-bit dropout key; bit-identical to oracle/stgcn_oracle.py::dropout_layer_key
-inline uint64_t splitmix64(uint64_t z) {
+__host__ __device__ inline uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-inline uint32_t dropout_layer_key(uint64_t seed, uint64_t step, int layer) {
+__host__ __device__ inline uint32_t dropout_layer_key(uint64_t seed, uint64_t step, int layer) {
     return (uint32_t)(splitmix64(seed ^ splitmix64(step * 64 + (uint64_t)layer + 1)) & 0xFFFFFFFFull);
 }
 
@@ -105,7 +116,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
                               int from_moments, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t stream);
+              float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
+int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);
+int step_prepare_dropout(void* state, uint64_t seed, int num_layers, hipStream_t stream);   // ++dropout_step, keys
+int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream_t stream); // ++adam_step, bias corrections
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
                       hipStream_t stream);
 

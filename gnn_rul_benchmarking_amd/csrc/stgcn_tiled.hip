@@ -326,6 +326,7 @@ struct TTrain {
     int N, P, L;
     float dropout_p, drop_scale;
     uint32_t drop_thr, drop_key;
+    const uint32_t* key_dev;    // device step state: this layer's key (else drop_key)
     double cnt;
     double* cells_fwd;
     double* cells_bwd;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
         const int64_t idx = (b * F + c) * N + t;
         float o1 = relu(relu(fmaf(z2[idx], bnc[2 * F + c], bnc[3 * F + c])) + o0[idx]);
         if (a.dropout_p > 0.f) {
-            const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ a.drop_key);
+            const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ (a.key_dev ? *a.key_dev : a.drop_key));
             o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
         }
         Xout[idx] = o1 + Xin[idx];
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
             const float x1 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
             const float o1 = relu(x1 + o0[idx]);
             if (a.dropout_p > 0.f) {
-                const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ a.drop_key);
+                const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ (a.key_dev ? *a.key_dev : a.drop_key));
                 g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
             }
             g = (o1 > 0.f) ? g : 0.f;
@@ -849,6 +850,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         t.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
     }
     t.drop_key = 0;
+    t.key_dev = nullptr;
+    const StepState* sstate = static_cast<const StepState*>(ar->step_state);
     t.cnt = (double)B * (double)N;
     t.cells_fwd = cells; t.cells_bwd = cells + 2 * L * 2 * F; t.cell_loss = cells + 2 * (2 * L * 2 * F);
     const int has_dpred = ar->dpred ? 1 : (ar->y ? 0 : 2);
@@ -856,6 +859,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     int rc;
 
     if (mode == 0 || mode == 2) {
+        if (ar->step_state) {
+            rc = step_prepare_dropout(ar->step_state, ar->seed, L, stream);
+            if (rc != RULGNN_OK) return rc;
+        }
         if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
         T_LAUNCH(t_stats_kernel, BN_, ar->x, TP(w.off_X, 0), a);
         (void)hipGetLastError();
@@ -864,6 +871,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         for (int l = 0; l < L; ++l) {
             const float* pl = prm + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
+            t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
             T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
             rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);
             if (rc != RULGNN_OK) return rc;
@@ -902,6 +910,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             const float* pl = prm + l * LS;
             float* gl = g + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
+            t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
             T_LAUNCH(t_tail_bwd_kernel, BN_, dpool, TP(w.off_X, l + 1), dX, TP(w.off_z2, l), TP(w.off_o0, l), pl, gsum, 2 * l + 1,
                      l == L - 1 ? 1 : 0, t);
             T_LAUNCH(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,

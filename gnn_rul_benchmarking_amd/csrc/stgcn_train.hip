@@ -67,8 +67,11 @@ struct TrainK {
     float dropout_p, drop_scale;
     uint32_t drop_thr;
     uint32_t drop_key[8];
+    const uint32_t* keys_dev;   // device step state: per-layer keys written by step_prepare_dropout (else drop_key[])
     int pcount;
 };
+
+__device__ __forceinline__ uint32_t drop_key_of(const TrainK& a, int l) { return a.keys_dev ? a.keys_dev[l] : a.drop_key[l]; }
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 const bool pass = o1 > 0.f && x1 > 0.f && valid;
                 ps[c * 64] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, lq));
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                     const float xh = ps[c * 64];
                     float g = dX;
                     if (a.dropout_p > 0.f) {
-                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[lq]);
+                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, lq));
                         g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                     }
                     const bool pass = xh < INFINITY;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 o1v[c] = relu(x1v[c] + o0[c]);
                 float o1 = o1v[c];
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 rb[c * 64] = dX;
                 float g = dX;
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
                     g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                 }
                 const float dy = (o1v[c] > 0.f && x1v[c] > 0.f && valid) ? g : 0.f;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 const float o1 = relu(x1 + o0[c]);
                 float g = rb[c * 64];                                               // d X_{l+1}
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ a.drop_key[LY]);
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
                     g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                 }
                 g = (o1 > 0.f && valid) ? g : 0.f;
@@ -709,10 +712,15 @@ struct FinalizeK {
     float* bn_running;
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, bn_momentum;
     int fused_opt;
+    const StepState* state;   // device step state: Adam bias corrections come from here when non-null
 };
 
 __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
+    if (f.state) {
+        f.lr_over_bc1 = f.state->lr_over_bc1;
+        f.inv_sqrt_bc2 = f.state->inv_sqrt_bc2;
+    }
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nw = (gridDim.x * blockDim.x) >> 6;
@@ -935,6 +943,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
         k.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
     }
     for (int l = 0; l < 8; ++l) k.drop_key[l] = l < L ? dropout_layer_key(a->seed, a->step, l) : 0u;
+    k.keys_dev = a->step_state ? static_cast<const StepState*>(a->step_state)->drop_key : nullptr;
     k.pcount = param_count(N, L);
     k.wave_area_floats = 0;
     return RULGNN_OK;
@@ -947,6 +956,10 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     const float* gy = a->dpred ? a->dpred : a->y;
 
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
+        if (a->step_state) {       // advance the dropout stream on the device (a backward-only call reuses the keys)
+            rc = step_prepare_dropout(a->step_state, a->seed, L, stream);
+            if (rc != RULGNN_OK) return rc;
+        }
         if (hipMemsetAsync(k.cells_fwd, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
         rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
         if (rc != RULGNN_OK) return rc;
@@ -970,12 +983,18 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.fused_opt = 0;
+    f.state = nullptr;
     f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
     f.lr_over_bc1 = f.inv_sqrt_bc2 = f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
     if (opt && mode == TM_FWDBWD) {
         const double bc1 = 1.0 - pow((double)opt->beta1, (double)opt->step);
         const double bc2 = 1.0 - pow((double)opt->beta2, (double)opt->step);
         f.fused_opt = 1;
+        if (opt->step_state) {
+            rc = step_prepare_adam(opt->step_state, opt->lr, opt->beta1, opt->beta2, stream);
+            if (rc != RULGNN_OK) return rc;
+            f.state = static_cast<const StepState*>(opt->step_state);
+        }
         f.params = opt->params; f.exp_avg = opt->exp_avg; f.exp_avg_sq = opt->exp_avg_sq; f.bn_running = opt->bn_stats;
         f.lr_over_bc1 = (float)((double)opt->lr / bc1); f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
         f.beta1 = opt->beta1; f.beta2 = opt->beta2; f.eps = opt->eps; f.weight_decay = opt->weight_decay;

@@ -56,6 +56,13 @@ class FusedAdam(torch.optim.Optimizer):
         m, v = self._state_buffers()
         g = self.param_groups[0]
         self._steps += 1
+        state = getattr(model, "_step_state", None)
+        if state is not None:          # device-resident step (hipGraph-capturable, see graphs.py)
+            _lib.check(_lib.load().rulgnn_adam_step_dev_f32(
+                flat.data_ptr(), model.bucket.data_ptr(), m.data_ptr(), v.data_ptr(), n, state.data_ptr(),
+                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(grad_scale), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_adam_step_dev_f32")
+            return None
         _lib.check(_lib.load().rulgnn_adam_step_f32(
             flat.data_ptr(), model.bucket.data_ptr(), m.data_ptr(), v.data_ptr(), n, self._steps,
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),

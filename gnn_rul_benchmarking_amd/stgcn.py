@@ -123,7 +123,9 @@ class ST_GCN_model(nn.Module):
         self._bn_batch = None
         self._loss = None
         self._ws = None
-        self._ws_key = None
+        self._bufs = {}             # batch size -> (training workspace, prediction buffer); several sizes stay alive
+        self._pin_bufs = False      # graphs.py: captured hipGraphs hold these pointers, never evict
+        self._step_state = None     # device step state (graphs.py), else the host counters are used
         self._step = 0              # training forwards so far (dropout stream position)
         self._nbt_pending = 0       # BatchNorm num_batches_tracked increments not yet written to the buffers
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
@@ -163,7 +165,8 @@ class ST_GCN_model(nn.Module):
         self._bn_batch = torch.zeros(PL.bn_buffer_count(self.num_layers), dtype=torch.float32, device=dev)
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pred_buf = None
-        self._ws, self._ws_key = None, None
+        self._ws, self._bufs = None, {}
+        self._step_state = None
         self._fwd_ws = None
 
     def _flush_nbt(self):
@@ -212,22 +215,24 @@ class ST_GCN_model(nn.Module):
         return x.reshape(bs, self.num_patch * self.patch_size).contiguous().float()
 
     def _workspace(self, shp, batch):
-        key = (batch, self._flat.device)
-        if self._ws_key != key:
+        ent = self._bufs.get(batch)
+        if ent is None:
             nbytes = _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
             if nbytes == 0:
                 raise RuntimeError(
                     f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
                     "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)")
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
-            self._ws_key = key
+            if len(self._bufs) >= 4 and not self._pin_bufs:
+                self._bufs.pop(next(iter(self._bufs)))
+            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
+                   torch.empty(batch, dtype=torch.float32, device=self._flat.device))
+            self._bufs[batch] = ent
+        self._ws, self._pred_buf = ent
         return self._ws
 
     def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False):
         B = x2d.size(0)
         ws = self._workspace(shp, B)
-        if self._pred_buf is None or self._pred_buf.numel() != B:
-            self._pred_buf = torch.empty(B, dtype=torch.float32, device=x2d.device)
         a = _lib.StgcnTrainArgs()
         a.x = x2d.data_ptr()
         a.y = y.data_ptr() if y is not None else None
@@ -250,6 +255,7 @@ class ST_GCN_model(nn.Module):
         a.dropout_p = self.dropout_p
         a.seed = self._seed
         a.step = step
+        a.step_state = self._step_state.data_ptr() if self._step_state is not None else None
         return a
 
     def _after_train_forward(self, batch, from_bucket_moments=False):
@@ -311,7 +317,7 @@ class ST_GCN_model(nn.Module):
         g = optimizer.param_groups[0]
         o = _lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
                           float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                          float(g["weight_decay"]), 0.1)
+                          float(g["weight_decay"]), 0.1, self._step_state.data_ptr() if self._step_state is not None else None)
         _lib.check(_lib.load().rulgnn_stgcn_train_step_f32(C.byref(shp), C.byref(a), C.byref(o), _stream()),
                    "rulgnn_stgcn_train_step_f32")
         self._nbt_pending += 1

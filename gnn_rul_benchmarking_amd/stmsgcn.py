@@ -107,7 +107,7 @@ class STMSGCN_model(nn.Module):
                 n *= s
             self._slices.append((off, n, shape))
         self._flat = self._grad_flat = self._loss = self._pred_buf = self._ws = None
-        self._ws_key = None
+        self._bufs, self._pin_bufs, self._step_state = {}, False, None
         self._reflatten()
 
     # ---- flat storage ----------------------------------------------------------------------------------
@@ -128,7 +128,7 @@ class STMSGCN_model(nn.Module):
                 p.data = flat[off:off + n].view(shape)
         self._flat = flat
         self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._pred_buf, self._ws, self._ws_key = None, None, None
+        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
@@ -174,15 +174,18 @@ class STMSGCN_model(nn.Module):
 
     def _args(self, shp, x2d, y=None, dpred=None, global_batch=None):
         B = x2d.size(0)
-        key = (B, self._flat.device)
-        if self._ws_key != key:
+        ent = self._bufs.get(B)
+        if ent is None:
             nbytes = _lib.load().rulgnn_stmsgcn_workspace_bytes(C.byref(shp))
             if nbytes == 0:
                 raise RuntimeError("STMSGCN kernels do not cover this configuration (nodes <= 32, patch_size <= 512, "
                                    "GCN widths <= 64 with sum <= 128, gru_hidden_dim <= 16, num_patch <= 4096)")
-            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device)
-            self._pred_buf = torch.empty(B, dtype=torch.float32, device=self._flat.device)
-            self._ws_key = key
+            if len(self._bufs) >= 4 and not self._pin_bufs:
+                self._bufs.pop(next(iter(self._bufs)))
+            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
+                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
+            self._bufs[B] = ent
+        self._ws, self._pred_buf = ent
         a = _lib.StmsgcnArgs()
         a.x = x2d.data_ptr()
         a.y = y.data_ptr() if y is not None else None
@@ -235,7 +238,7 @@ class STMSGCN_model(nn.Module):
             g = optimizer.param_groups[0]
             o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
                                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                      0.1))
+                                      0.1, self._step_state.data_ptr() if self._step_state is not None else None))
         _lib.check(_lib.load().rulgnn_stmsgcn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stmsgcn_fwdbwd_f32")
         return self._pred_buf, self._grad_flat[self._count]
 

@@ -93,6 +93,7 @@ typedef struct rulgnn_stgcn_train_args {
     uint64_t step;
     float bn_moment_weight;  /* 0: plain statistics. w > 0 (data parallel, w = batch/global_batch): bn_batch holds
                                 w*(E[z], E[z^2]) so that a SUM all-reduce over ranks yields the global-batch moments */
+    void *step_state;        /* optional device step state (see rulgnn_step_state_set); NULL = use `step` above */
 } rulgnn_stgcn_train_args;
 
 /* Train-mode forward only (BatchNorm batch statistics, dropout): fills pred, bn_batch and the
@@ -123,6 +124,7 @@ typedef struct rulgnn_adam_args {
     int64_t step;            /* 1-based step count after this update */
     float lr, beta1, beta2, eps, weight_decay;
     float bn_momentum;       /* 0.1 for nn.BatchNorm1d */
+    void *step_state;        /* optional device step state; NULL = use `step` above */
 } rulgnn_adam_args;
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                 const rulgnn_adam_args *opt, void *stream);
@@ -267,6 +269,24 @@ int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_as
 /* nn.BatchNorm1d running-statistics update for this model's two BatchNorm layers (count = batch * time_length). */
 int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape *shape, float *bn_stats, const float *bn_batch,
                                          int64_t count, float momentum, int32_t from_moments, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-resident step state, for capturing a whole training step in a hipGraph.
+ *
+ * A captured graph bakes its kernel arguments, so whatever changes from step to step (the dropout stream position, the
+ * Adam step used for the bias corrections) must live in device memory.  The state is a caller-owned device buffer of
+ * RULGNN_STEP_STATE_BYTES bytes.  When a call receives it (args->step_state / opt->step_state non-NULL) the host-side
+ * `step` fields are ignored: a one-thread kernel at the head of the call advances the counter on the device and derives
+ * the per-layer dropout keys / the Adam bias corrections, and the compute kernels read them from the buffer.  Every
+ * such call therefore has identical arguments step after step and can be replayed from a graph.
+ */
+#define RULGNN_STEP_STATE_BYTES 64
+/* (Re)initialise the counters: `dropout_step` training forwards and `adam_step` optimizer steps have happened so far. */
+int rulgnn_step_state_set(void *step_state, uint64_t dropout_step, int64_t adam_step, void *stream);
+/* rulgnn_adam_step_f32 with the step taken from (and advanced in) the device step state. */
+int rulgnn_adam_step_dev_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                             void *step_state, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,89 @@
+"""hipGraph-replayed training steps (graphs.py) must be the eager steps: same kernels, same order, with the dropout stream
+position and the Adam step advanced on the device instead of passed as kernel arguments."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make(name, seed):
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    torch.manual_seed(seed)
+    if name == "ST_GCN":
+        cfg, hp, shape = {"num_patch": 14, "patch_size": 30, "dropout": 0.2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 30)
+    elif name == "ASTGCNN":
+        cfg = dict(num_nodes=14, time_length=50, encoder_out_dim=50, output_dim=64, K=3)
+        hp, shape = {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 50)
+    else:
+        cfg = dict(num_patch=12, patch_size=20, interval=2, band_width=3, gcn_dims=[16, 64, 16, 1], gru_hidden_dim=8)
+        hp, shape = {"learning_rate": 1e-3, "weight_decay": 0.0}, (1, 240)
+    algo = get_algorithm_class(name)(cfg, hp, DEV)
+    algo.to(DEV).train()
+    return algo, shape
+
+
+@pytest.mark.parametrize("name", ["ST_GCN", "ASTGCNN", "STMSGCN"])
+def test_graph_replay_equals_eager_steps(name):
+    eager, shape = make(name, 3)
+    graphed, _ = make(name, 3)
+    graphed.enable_graphs(warmup=1)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    sizes = [100, 100, 100, 37, 100, 100, 37, 37, 100, 100]         # a full batch and the ragged last batch of an epoch
+    le, lg = [], []
+    for bs in sizes:
+        x = torch.rand(bs, *shape, device=DEV, generator=g)
+        y = torch.rand(bs, 1, device=DEV, generator=g)
+        le.append(eager.update(x, y, 1)["loss"])
+        lg.append(graphed.update(x, y, 1)["loss"])
+    assert graphed._graphed.num_graphs == 2
+    assert np.allclose(le, lg, rtol=2e-6, atol=0), (le, lg)
+    assert torch.allclose(eager.model.flat_params, graphed.model.flat_params, rtol=1e-5, atol=1e-7)
+    a, b = eager.state_dict(), graphed.state_dict()
+    for k in a:
+        if "running_" in k:
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), k
+        if "num_batches_tracked" in k:
+            assert int(a[k]) == int(b[k]) == len(sizes), k
+    assert eager.optimizer._steps == graphed.optimizer._steps == len(sizes)
+    # evaluation after graphed training uses the same parameters
+    eager.eval(), graphed.eval()
+    x = torch.rand(16, *shape, device=DEV, generator=g)
+    with torch.no_grad():
+        assert torch.allclose(eager.model(x), graphed.model(x), rtol=1e-5, atol=1e-6)
+
+
+def test_graph_replay_timing_at_the_reference_batch_size():
+    res = {}
+    for name in ("ST_GCN", "ASTGCNN"):
+        for mode in ("eager", "graph"):
+            algo, shape = make(name, 1)
+            algo.sync_loss = False
+            if mode == "graph":
+                algo.enable_graphs(warmup=1)
+            x, y = torch.rand(100, *shape, device=DEV), torch.rand(100, 1, device=DEV)
+            for _ in range(5):
+                algo.update(x, y, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                algo.update(x, y, 1)
+            torch.cuda.synchronize()
+            res[(name, mode)] = (time.perf_counter() - t0) / 200 * 1e3
+    print("ms/step at batch 100:", {f"{k[0]}/{k[1]}": round(v, 4) for k, v in res.items()})
+    for name in ("ST_GCN", "ASTGCNN"):
+        assert res[(name, "graph")] < 1.5 * res[(name, "eager")]       # recorded in DESIGN.md; not a regression gate on speed
+
+
+def test_enable_graphs_rejects_data_parallel_and_cpu():
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    algo = ST_GCN({"num_patch": 14, "patch_size": 30, "dropout": 0.2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, "cpu")
+    with pytest.raises(RuntimeError):
+        algo.enable_graphs()
+    algo.to(DEV)
+    algo.dp = object()
+    with pytest.raises(RuntimeError):
+        algo.enable_graphs()
