@@ -62,6 +62,20 @@ class AstgcnnArgs(C.Structure):
                 ("bn_moment_weight", C.c_float), ("training", C.c_int32)]
 
 
+class FcstgnnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64)] + [(k, C.c_int32) for k in (
+        "patch_size", "num_patch", "encoder_time_out", "encoder_hidden_dim", "encoder_out_dim", "encoder_conv_kernel",
+        "hidden_dim", "num_sequential", "num_node", "num_windows")]
+
+
+class FcstgnnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_batch", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64),
+                ("sample_offset", C.c_int64), ("bn_moment_weight", C.c_float), ("dropout_p", C.c_float),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32), ("step_state", C.c_void_p)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -85,6 +99,14 @@ _SIGNATURES = {
     "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
     "rulgnn_adam_step_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "rulgnn_fcstgnn_param_count": (C.c_int64, [C.POINTER(FcstgnnShape)]),
+    "rulgnn_fcstgnn_bn_count": (C.c_int64, [C.POINTER(FcstgnnShape)]),
+    "rulgnn_fcstgnn_workspace_bytes": (C.c_size_t, [C.POINTER(FcstgnnShape)]),
+    "rulgnn_fcstgnn_forward_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.c_void_p]),
+    "rulgnn_fcstgnn_backward_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.c_void_p]),
+    "rulgnn_fcstgnn_fwdbwd_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_fcstgnn_bn_running_update_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                                        C.c_void_p]),
     "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),

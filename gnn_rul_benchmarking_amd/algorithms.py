@@ -2,8 +2,8 @@
 algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
 ``NotImplementedError("Algorithm not found: ...")`` otherwise).
 
-The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571) and ASTGCNN (:139-163) wrappers are
-implemented:
+The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571), ASTGCNN (:139-163) and FC_STGNN (:51-76)
+wrappers are implemented:
 the hot paths this package accelerates.  The classes keep the reference contract -- constructor
 ``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
 ``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .optim import FusedAdam
 from .astgcnn import ASTGCNN_model
+from .fcstgnn import FC_STGNN_RUL
 from .stgcn import ST_GCN_model
 from .stmsgcn import STMSGCN_model
 
@@ -180,4 +181,45 @@ class ASTGCNN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class FC_STGNN(Algorithm):
+    """FC_STGNN training wrapper (reference algorithms.py:51-76): ``update`` = train-mode forward + MSE + backward + Adam +
+    BatchNorm running statistics in one C call (csrc/fcstgnn.hip + the fused Adam kernel)."""
+
+    def __init__(self, configs, hparams, device):
+        super(FC_STGNN, self).__init__(configs)
+        self.model = FC_STGNN_RUL(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if not self.model.training:
+            raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        elif getattr(self, "_graphed", None) is not None:
+            loss = self._graphed.update(X, y)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return loss
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd; same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "get_algorithm_class", "torch", "nn", "annotations"}

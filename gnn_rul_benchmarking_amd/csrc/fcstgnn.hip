@@ -1,0 +1,1011 @@
+// FC_STGNN path for gfx950: per-(sample, patch, sensor) 1D-CNN encoder -> Linear + BatchNorm -> positional encoding
+// (+ dropout) -> two windowed fully-connected space-time graph blocks (dot-product graph with softmax and decay mask,
+// BatchNorm, MPNN, BatchNorm, mean over the window) -> 4-layer MLP; forward and backward.
+//
+// Reference: models/FC_STGNN/Model.py (FC_STGNN_RUL :5-84), Model_Base.py (Feature_extractor_1DCNN_RUL :12-41,
+// Dot_Graph_Construction_weights :44-67, MPNN_mk_v2 :72-107, PositionalEncoding :111-134, Conv_GraphST :137-148,
+// Mask_Matrix :150-170, GraphConvpoolMPNN_block_v6 :175-225) and algorithms/algorithms.py:51-76 (MSE + Adam).
+//
+// Decomposition.  Rows m = (sample, patch t, sensor) carry the encoder; the unfold of
+// Conv_GraphST is index arithmetic (window w of block b covers patches w*stride + {0,1}; graph node q = tau*N + sensor),
+// so the mapping Linear of the graph construction runs once per row, not per window copy.  Dense projections are
+// [rows, .] GEMMs on the matrix cores (sgemm_mfma.hpp), one workgroup per window graph (<= 40 nodes) does the
+// adjacency / softmax / aggregation in LDS, the rest is elementwise.  Seven BatchNorms cut the step into phases; batch
+// statistics go through fp64 reduction cells in stream order.  BatchNorms on the unfolded windows are computed on the
+// rows with multiplicity weights (how many windows contain a patch).
+#include "sgemm_mfma.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+constexpr int FB = 256;
+constexpr int MAXC = 64;            // BatchNorm channels
+constexpr int MAXQ = 40;            // graph nodes = 2 * sensors
+constexpr int MAXD = 64;            // graph feature width 2 * hidden_dim
+constexpr int NBN = 7;
+constexpr float BN_EPS = 1e-5f;
+constexpr float LEAKY = 0.01f;
+constexpr float DECAY = 0.7f;       // Model.py:13
+constexpr float PE_P = 0.1f;        // Model.py:25
+
+struct FcGeom {
+    int64_t B, M;                   // samples; rows = B * NP * N
+    int N, NP, PS, TL, H1, CO, K, L1, L2, CL, D2, HD, Q, FIN;
+    int W[2], S[2], foff[2];
+    int64_t G[2];
+    int o_w1, o_ga, o_ba, o_w2, o_gb, o_bb, o_W3, o_b3, o_gc, o_bc;
+    int o_map[2], o_bmap[2], o_gd[2], o_bd[2], o_th[2], o_thb[2], o_ge[2], o_be[2];
+    int o_f1w, o_f1b, o_f2w, o_f2b, o_f3w, o_f3b, o_f4w, o_f4b, nparam;
+    int bn_ch[NBN], bn_off[NBN], bn_g[NBN], bn_b[NBN], bn_total;
+    double cnt[NBN];
+};
+
+__host__ int fc_geometry(const rulgnn_fcstgnn_shape* s, FcGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->batch < 0 || s->patch_size < 1 || s->num_patch < 2 || s->encoder_hidden_dim < 1 || s->encoder_out_dim < 1 ||
+        s->encoder_conv_kernel < 1 || s->hidden_dim < 1 || s->num_node < 1)
+        return RULGNN_EINVAL;
+    g->K = s->encoder_conv_kernel;
+    g->PS = s->patch_size;
+    g->L1 = g->PS + 2 * (g->K / 2) - g->K + 1;
+    g->L2 = g->L1 + 2 - g->K + 1;
+    if (g->L1 < 1 || g->L2 < 1 || s->encoder_time_out != g->L2) return RULGNN_EINVAL;
+    g->NP = s->num_patch;
+    g->W[0] = g->NP - 1;
+    g->W[1] = (g->NP - 2) / 2 + 1;
+    if (s->num_windows != g->W[0] + g->W[1]) return RULGNN_EINVAL;
+    if (s->num_node * 2 > MAXQ || s->hidden_dim * 2 > MAXD || s->encoder_hidden_dim > 16 || s->encoder_out_dim > MAXC ||
+        g->K > 4 || g->PS > 64 || g->NP > 128)
+        return RULGNN_EUNSUPPORTED;
+    g->B = s->batch;
+    g->N = s->num_node;
+    g->TL = g->NP * g->PS;
+    g->H1 = s->encoder_hidden_dim;
+    g->CO = s->encoder_out_dim;
+    g->CL = g->CO * g->L2;
+    g->HD = s->hidden_dim;
+    g->D2 = 2 * g->HD;
+    g->Q = 2 * g->N;
+    g->S[0] = 1;
+    g->S[1] = 2;
+    g->M = g->B * g->NP * g->N;
+    if (g->M * (int64_t)(g->CL > g->D2 ? g->CL : g->D2) > ((int64_t)1 << 31) - 1) return RULGNN_EUNSUPPORTED;
+    g->G[0] = g->B * g->W[0];
+    g->G[1] = g->B * g->W[1];
+    g->foff[0] = 0;
+    g->foff[1] = g->W[0] * g->N * g->HD;
+    g->FIN = g->HD * (g->W[0] + g->W[1]) * g->N;
+    int o = 0;
+    auto take = [&](int n) { const int r = o; o += n; return r; };
+    g->o_w1 = take(g->H1 * g->K); g->o_ga = take(g->H1); g->o_ba = take(g->H1);
+    g->o_w2 = take(g->CO * g->H1 * g->K); g->o_gb = take(g->CO); g->o_bb = take(g->CO);
+    g->o_W3 = take(g->D2 * g->CL); g->o_b3 = take(g->D2); g->o_gc = take(g->D2); g->o_bc = take(g->D2);
+    for (int b = 0; b < 2; ++b) {
+        g->o_map[b] = take(g->D2 * g->D2); g->o_bmap[b] = take(g->D2); g->o_gd[b] = take(g->D2); g->o_bd[b] = take(g->D2);
+        g->o_th[b] = take(g->HD * g->D2); g->o_thb[b] = take(g->HD); g->o_ge[b] = take(g->HD); g->o_be[b] = take(g->HD);
+    }
+    g->o_f1w = take(g->D2 * g->FIN); g->o_f1b = take(g->D2);
+    g->o_f2w = take(g->D2 * g->D2); g->o_f2b = take(g->D2);
+    g->o_f3w = take(g->HD * g->D2); g->o_f3b = take(g->HD);
+    g->o_f4w = take(g->HD); g->o_f4b = take(1);
+    g->nparam = o;
+    const int ch[NBN] = {g->H1, g->CO, g->D2, g->D2, g->HD, g->D2, g->HD};
+    const int og[NBN] = {g->o_ga, g->o_gb, g->o_gc, g->o_gd[0], g->o_ge[0], g->o_gd[1], g->o_ge[1]};
+    const int ob[NBN] = {g->o_ba, g->o_bb, g->o_bc, g->o_bd[0], g->o_be[0], g->o_bd[1], g->o_be[1]};
+    int bo = 0;
+    for (int i = 0; i < NBN; ++i) {
+        g->bn_ch[i] = ch[i]; g->bn_g[i] = og[i]; g->bn_b[i] = ob[i];
+        g->bn_off[i] = bo;
+        bo += 2 * ch[i];
+    }
+    g->bn_total = bo;
+    g->cnt[0] = (double)g->M * g->L1;
+    g->cnt[1] = (double)g->M * g->L2;
+    g->cnt[2] = (double)g->M;
+    for (int b = 0; b < 2; ++b) g->cnt[3 + 2 * b] = g->cnt[4 + 2 * b] = (double)g->G[b] * g->Q;
+    return RULGNN_OK;
+}
+
+struct Cells {
+    double fwd[NBN][MAXC][2];       // sum, sum of squares
+    double bwd[NBN][MAXC][2];       // sum dy, sum dy * xhat
+};
+
+struct BnCoef {
+    float mean, inv, sc, sh;
+};
+__device__ inline BnCoef fbn(const FcGeom& g, const Cells* cells, const float* prm, const float* running, int training, int id, int c) {
+    BnCoef r;
+    float var;
+    if (training) {
+        const double m = cells->fwd[id][c][0] / g.cnt[id];
+        double v = cells->fwd[id][c][1] / g.cnt[id] - m * m;
+        if (v < 0.0) v = 0.0;
+        r.mean = (float)m;
+        var = (float)v;
+    } else {
+        r.mean = running[g.bn_off[id] + c];
+        var = running[g.bn_off[id] + g.bn_ch[id] + c];
+    }
+    r.inv = 1.0f / sqrtf(var + BN_EPS);
+    r.sc = prm[g.bn_g[id] + c] * r.inv;
+    r.sh = prm[g.bn_b[id] + c] - r.mean * r.sc;
+    return r;
+}
+
+// per-workgroup (sum, sumsq) accumulators in LDS doubles, flushed to the cells with one atomic per channel
+struct BlockStats {
+    double* s;                      // [C][2] in LDS
+    __device__ void init(double* lds, int C) {
+        s = lds;
+        for (int i = threadIdx.x; i < 2 * C; i += FB) s[i] = 0.0;
+        __syncthreads();
+    }
+    __device__ void add(int c, float a, float b) {
+        atomicAdd(&s[2 * c], (double)a);
+        atomicAdd(&s[2 * c + 1], (double)b);
+    }
+    __device__ void flush(double (*dst)[2], int C) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += FB)
+            if (s[i] != 0.0) atomicAdd(&dst[i >> 1][i & 1], s[i]);
+    }
+};
+
+__device__ inline float leaky(float v) { return v > 0.f ? v : LEAKY * v; }
+// multiplicity of patch t in the unfolded windows of block b (how many window graphs contain it)
+__device__ inline float mult(const FcGeom& g, int b, int t) {
+    if (b == 0) return (g.W[0] > 1 && t > 0 && t < g.NP - 1) ? 2.f : 1.f;
+    return t < 2 * g.W[1] ? 1.f : 0.f;
+}
+__device__ inline float pos_enc(int t, int d, int D2) {     // PositionalEncoding table entry (Model_Base.py:117-125), base 100
+    const float div = expf((float)(d & ~1) * -(4.605170185988092f / (float)D2));
+    const float ang = (float)t * div;
+    return (d & 1) ? cosf(ang) : sinf(ang);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// encoder
+// ---------------------------------------------------------------------------------------------------
+// z1[m][c][p] = sum_k w1[c][k] * v[m][p + k - K/2]   (Conv1d(1 -> H1, K, padding K/2), Model_Base.py:17-18)
+__global__ __launch_bounds__(FB) void fc_conv1_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                     float* __restrict__ z1, Cells* cells, int training) {
+    __shared__ double sl[2 * MAXC];
+    BlockStats st;
+    st.init(sl, g.H1);
+    const int64_t total = g.M * g.H1 * g.L1;
+    const int pad = g.K / 2;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int p = (int)(e % g.L1), c = (int)((e / g.L1) % g.H1);
+        const int64_t m = e / ((int64_t)g.L1 * g.H1);
+        const int node = (int)(m % g.N), t = (int)((m / g.N) % g.NP);
+        const int64_t b = m / ((int64_t)g.N * g.NP);
+        const float* v = x + (b * g.N + node) * g.TL + t * g.PS;
+        float a = 0.f;
+        for (int k = 0; k < g.K; ++k) {
+            const int j = p + k - pad;
+            if (j >= 0 && j < g.PS) a = fmaf(prm[g.o_w1 + c * g.K + k], v[j], a);
+        }
+        z1[e] = a;
+        if (training) st.add(c, a, a * a);
+    }
+    if (training) st.flush(cells->fwd[0], g.H1);
+}
+
+// z2[m][co][p] = sum_ci sum_k w2[co][ci][k] * relu(bn_a(z1))[m][ci][p + k - 1]   (padding 1, Model_Base.py:27-28)
+__global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
+                                                     const float* __restrict__ z1, float* __restrict__ z2, Cells* cells, int training) {
+    __shared__ double sl[2 * MAXC];
+    __shared__ BnCoef ca[16];
+    if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, running, training, 0, threadIdx.x);
+    BlockStats st;
+    st.init(sl, g.CO);
+    const int64_t total = g.M * g.CL;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int p = (int)(e % g.L2), co = (int)((e / g.L2) % g.CO);
+        const int64_t m = e / g.CL;
+        const float* zr = z1 + m * g.H1 * g.L1;
+        float a = 0.f;
+        for (int ci = 0; ci < g.H1; ++ci)
+            for (int k = 0; k < g.K; ++k) {
+                const int q = p + k - 1;
+                if (q >= 0 && q < g.L1) {
+                    const float a1 = fmaxf(fmaf(zr[ci * g.L1 + q], ca[ci].sc, ca[ci].sh), 0.f);
+                    a = fmaf(prm[g.o_w2 + (co * g.H1 + ci) * g.K + k], a1, a);
+                }
+            }
+        z2[e] = a;
+        if (training) st.add(co, a, a * a);
+    }
+    if (training) st.flush(cells->fwd[1], g.CO);
+}
+
+// a2 = relu(bn_b(z2)), flattened [m][CO * L2]
+__global__ __launch_bounds__(FB) void fc_act2_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
+                                                    const Cells* cells, int training, const float* __restrict__ z2, float* __restrict__ a2) {
+    __shared__ BnCoef cb[MAXC];
+    if (threadIdx.x < g.CO) cb[threadIdx.x] = fbn(g, cells, prm, running, training, 1, threadIdx.x);
+    __syncthreads();
+    const int64_t total = g.M * g.CL;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int co = (int)((e / g.L2) % g.CO);
+        a2[e] = fmaxf(fmaf(z2[e], cb[co].sc, cb[co].sh), 0.f);
+    }
+}
+
+// z[r][c] += bias[c] in place; per-column (sum, sumsq) into cells->fwd[id]
+__global__ __launch_bounds__(FB) void fc_bias_stats_kernel(float* __restrict__ z, const float* __restrict__ bias, int64_t rows, int C,
+                                                          Cells* cells, int id, int training) {
+    __shared__ double sl[2 * MAXC];
+    BlockStats st;
+    st.init(sl, C);
+    const int64_t total = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int c = (int)(e % C);
+        const float v = z[e] + bias[c];
+        z[e] = v;
+        if (training) st.add(c, v, v * v);
+    }
+    if (training) st.flush(cells->fwd[id], C);
+}
+
+// F = dropout(bn_c(z3) + pe[t]); weighted column statistics for the two window BatchNorms
+__global__ __launch_bounds__(FB) void fc_pe_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
+                                                  Cells* cells, int training, const float* __restrict__ z3, float* __restrict__ F,
+                                                  uint32_t drop_thr, float drop_scale, uint32_t drop_key, const uint32_t* key_dev,
+                                                  int64_t row_offset) {
+    __shared__ double sl[4 * MAXC];
+    __shared__ BnCoef cc[MAXC];
+    if (threadIdx.x < g.D2) cc[threadIdx.x] = fbn(g, cells, prm, running, training, 2, threadIdx.x);
+    BlockStats s0, s1;
+    s0.init(sl, g.D2);
+    s1.init(sl + 2 * MAXC, g.D2);
+    const uint32_t key = key_dev ? *key_dev : drop_key;
+    const int64_t total = g.M * g.D2;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int d = (int)(e % g.D2);
+        const int64_t m = e / g.D2;
+        const int t = (int)((m / g.N) % g.NP);
+        float y = fmaf(z3[e], cc[d].sc, cc[d].sh) + pos_enc(t, d, g.D2);
+        if (training && drop_thr) {
+            const uint32_t ctr = (uint32_t)((m + row_offset) * g.D2 + d);
+            y = lowbias32(ctr ^ key) >= drop_thr ? y * drop_scale : 0.f;
+        }
+        F[e] = y;
+        if (training) {
+            const float c0 = mult(g, 0, t), c1 = mult(g, 1, t);
+            s0.add(d, c0 * y, c0 * y * y);
+            if (c1 != 0.f) s1.add(d, y, y * y);
+        }
+    }
+    if (training) {
+        s0.flush(cells->fwd[3], g.D2);
+        s1.flush(cells->fwd[5], g.D2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// window graphs (one workgroup per graph)
+// ---------------------------------------------------------------------------------------------------
+__device__ inline int64_t graph_row(const FcGeom& g, int blk, int64_t gi, int q) {      // F row of node q of graph gi
+    const int64_t b = gi / g.W[blk];
+    const int w = (int)(gi - b * g.W[blk]);
+    const int tau = q >= g.N ? 1 : 0;
+    return (b * g.NP + w * g.S[blk] + tau) * g.N + (q - tau * g.N);
+}
+
+__global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
+                                                     const Cells* cells, int training, const float* __restrict__ F,
+                                                     const float* __restrict__ Mm, float* __restrict__ P, float* __restrict__ AX) {
+    __shared__ float mm[MAXQ][MAXD + 1];
+    __shared__ float xb[MAXQ][MAXD + 1];
+    __shared__ float A[MAXQ][MAXQ + 1];
+    __shared__ BnCoef cd[MAXD];
+    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x;
+    if (tid < D2) cd[tid] = fbn(g, cells, prm, running, training, 3 + 2 * blk, tid);
+    __syncthreads();
+    for (int64_t gi = blockIdx.x; gi < g.G[blk]; gi += gridDim.x) {
+        for (int e = tid; e < Q * D2; e += FB) {
+            const int q = e / D2, d = e - q * D2;
+            const int64_t r = graph_row(g, blk, gi, q);
+            mm[q][d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
+            xb[q][d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
+        }
+        __syncthreads();
+        for (int e = tid; e < Q * Q; e += FB) {
+            const int i = e / Q, j = e - i * Q;
+            float s = 0.f;
+            for (int d = 0; d < D2; ++d) s = fmaf(mm[i][d], mm[j][d], s);
+            if (i == j) s -= 1e8f;
+            A[i][j] = leaky(s);
+        }
+        __syncthreads();
+        if (tid < Q) {                                   // softmax over the row, then + I and the decay mask
+            float mx = -INFINITY;
+            for (int j = 0; j < Q; ++j) mx = fmaxf(mx, A[tid][j]);
+            float sum = 0.f;
+            for (int j = 0; j < Q; ++j) {
+                const float ev = expf(A[tid][j] - mx);
+                A[tid][j] = ev;
+                sum += ev;
+            }
+            float* pr = P + (gi * Q + tid) * Q;
+            for (int j = 0; j < Q; ++j) {
+                const float pv = A[tid][j] / sum;
+                pr[j] = pv;
+                A[tid][j] = (pv + (tid == j ? 1.f : 0.f)) * (((tid < N) == (j < N)) ? 1.f : DECAY);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < Q * D2; e += FB) {
+            const int i = e / D2, d = e - i * D2;
+            float a = 0.f;
+            for (int j = 0; j < Q; ++j) a = fmaf(A[i][j], xb[j][d], a);
+            AX[(gi * Q + i) * D2 + d] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// features = mean over the two window steps of leaky(bn_e(z5))
+__global__ __launch_bounds__(FB) void fc_pool_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
+                                                    const Cells* cells, int training, const float* __restrict__ z5,
+                                                    float* __restrict__ feat) {
+    __shared__ BnCoef ce[MAXC];
+    if (threadIdx.x < g.HD) ce[threadIdx.x] = fbn(g, cells, prm, running, training, 4 + 2 * blk, threadIdx.x);
+    __syncthreads();
+    const int HD = g.HD, N = g.N, W = g.W[blk];
+    const int64_t total = g.G[blk] * N * HD;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int h = (int)(e % HD), node = (int)((e / HD) % N);
+        const int64_t gi = e / ((int64_t)HD * N), b = gi / W;
+        const int w = (int)(gi - b * W);
+        const float y0 = leaky(fmaf(z5[(gi * g.Q + node) * HD + h], ce[h].sc, ce[h].sh));
+        const float y1 = leaky(fmaf(z5[(gi * g.Q + N + node) * HD + h], ce[h].sc, ce[h].sh));
+        feat[b * g.FIN + g.foff[blk] + (w * N + node) * HD + h] = (y0 + y1) / 2.0f;
+    }
+}
+
+// z = relu(z + bias) in place, [rows][C]
+__global__ void fc_bias_relu_kernel(float* __restrict__ z, const float* __restrict__ bias, int64_t rows, int C) {
+    const int64_t total = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+        z[e] = fmaxf(z[e] + bias[e % C], 0.f);
+}
+
+// head: pred = h3 . w4 + b4; MSE pieces; dh3 = dpred * w4 * [h3 > 0]
+__global__ void fc_head_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ h3, const float* __restrict__ y,
+                               const float* __restrict__ dpred_in, float* __restrict__ pred, float* __restrict__ dpred,
+                               float* __restrict__ sqerr, float* __restrict__ dh3, float inv_gb, int backward_only) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.B) return;
+    float dp;
+    if (!backward_only) {
+        float a = prm[g.o_f4b];
+        for (int j = 0; j < g.HD; ++j) a = fmaf(h3[b * g.HD + j], prm[g.o_f4w + j], a);
+        pred[b] = a;
+        if (!y) return;
+        const float d = a - y[b];
+        dp = 2.0f * d * inv_gb;
+        sqerr[b] = d * d * inv_gb;
+    } else {
+        dp = dpred_in[b];
+    }
+    dpred[b] = dp;
+    for (int j = 0; j < g.HD; ++j) dh3[b * g.HD + j] = h3[b * g.HD + j] > 0.f ? dp * prm[g.o_f4w + j] : 0.f;
+}
+
+// dz *= [h > 0]
+__global__ void fc_relu_mask_kernel(float* __restrict__ dz, const float* __restrict__ h, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        if (!(h[e] > 0.f)) dz[e] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+// d(bn_e output) from d features; BatchNorm-e backward sums
+__global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, const float* __restrict__ prm, Cells* cells,
+                                                        const float* __restrict__ z5, const float* __restrict__ dfeat,
+                                                        float* __restrict__ dy5) {
+    __shared__ double sl[2 * MAXC];
+    __shared__ BnCoef ce[MAXC];
+    const int id = 4 + 2 * blk;
+    if (threadIdx.x < g.HD) ce[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
+    BlockStats st;
+    st.init(sl, g.HD);
+    const int HD = g.HD, N = g.N, Q = g.Q, W = g.W[blk];
+    const int64_t total = g.G[blk] * Q * HD;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int h = (int)(e % HD), q = (int)((e / HD) % Q);
+        const int64_t gi = e / ((int64_t)HD * Q), b = gi / W;
+        const int w = (int)(gi - b * W), node = q >= N ? q - N : q;
+        const float zz = z5[e];
+        const float yv = fmaf(zz, ce[h].sc, ce[h].sh);
+        const float dy = dfeat[b * g.FIN + g.foff[blk] + (w * N + node) * HD + h] * 0.5f * (yv > 0.f ? 1.f : LEAKY);
+        dy5[e] = dy;
+        st.add(h, dy, dy * (zz - ce[h].mean) * ce[h].inv);
+    }
+    st.flush(cells->bwd[id], HD);
+}
+
+// BatchNorm backward, row-major [rows][C]: dz = sc * (dy - sum_dy/m - xhat * sum_dyxhat/m), in place
+__global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id, const float* __restrict__ prm, const Cells* cells,
+                                                           const float* __restrict__ z, float* __restrict__ dy, int64_t rows) {
+    __shared__ BnCoef cf[MAXC];
+    __shared__ float s1[MAXC], s2[MAXC];
+    const int C = g.bn_ch[id];
+    if (threadIdx.x < C) {
+        cf[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
+        s1[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][0] / g.cnt[id]);
+        s2[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][1] / g.cnt[id]);
+    }
+    __syncthreads();
+    const int64_t total = rows * C;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int c = (int)(e % C);
+        const float xh = (z[e] - cf[c].mean) * cf[c].inv;
+        dy[e] = cf[c].sc * (dy[e] - s1[c] - xh * s2[c]);
+    }
+}
+
+// the same for channel-major rows [m][C][L]
+__global__ __launch_bounds__(FB) void fc_bn_chan_bwd_kernel(FcGeom g, int id, int L, const float* __restrict__ prm, const Cells* cells,
+                                                           const float* __restrict__ z, float* __restrict__ dy, int64_t total) {
+    __shared__ BnCoef cf[MAXC];
+    __shared__ float s1[MAXC], s2[MAXC];
+    const int C = g.bn_ch[id];
+    if (threadIdx.x < C) {
+        cf[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
+        s1[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][0] / g.cnt[id]);
+        s2[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][1] / g.cnt[id]);
+    }
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int c = (int)((e / L) % C);
+        const float xh = (z[e] - cf[c].mean) * cf[c].inv;
+        dy[e] = cf[c].sc * (dy[e] - s1[c] - xh * s2[c]);
+    }
+}
+
+// graph backward: d adjacency, softmax / leaky backward, d mapping, d normalised features (scatter-added onto the rows)
+__global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
+                                                         const float* __restrict__ F, const float* __restrict__ Mm,
+                                                         const float* __restrict__ P, const float* __restrict__ dAX,
+                                                         float* __restrict__ gX, float* __restrict__ gM) {
+    __shared__ float mm[MAXQ][MAXD + 1];
+    __shared__ float xb[MAXQ][MAXD + 1];
+    __shared__ float da[MAXQ][MAXD + 1];
+    __shared__ float Pm[MAXQ][MAXQ + 1];
+    __shared__ float T[MAXQ][MAXQ + 1];
+    __shared__ float Sm[MAXQ][MAXQ + 1];          // pre-activation M M^T - 1e8 I (for the leaky slope)
+    __shared__ BnCoef cd[MAXD];
+    __shared__ int64_t rows[MAXQ];
+    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x;
+    if (tid < D2) cd[tid] = fbn(g, cells, prm, nullptr, 1, 3 + 2 * blk, tid);
+    __syncthreads();
+    for (int64_t gi = blockIdx.x; gi < g.G[blk]; gi += gridDim.x) {
+        if (tid < Q) rows[tid] = graph_row(g, blk, gi, tid);
+        __syncthreads();
+        for (int e = tid; e < Q * D2; e += FB) {
+            const int q = e / D2, d = e - q * D2;
+            const int64_t r = rows[q];
+            mm[q][d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
+            xb[q][d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
+            da[q][d] = dAX[(gi * Q + q) * D2 + d];
+        }
+        for (int e = tid; e < Q * Q; e += FB) Pm[e / Q][e % Q] = P[gi * Q * Q + e];
+        __syncthreads();
+        // d Adj -> d P (masked) ; d Xbn = Adj^T dAX
+        for (int e = tid; e < Q * Q; e += FB) {
+            const int i = e / Q, j = e - i * Q;
+            float s = 0.f, sm = 0.f;
+            for (int d = 0; d < D2; ++d) {
+                s = fmaf(da[i][d], xb[j][d], s);
+                sm = fmaf(mm[i][d], mm[j][d], sm);
+            }
+            T[i][j] = s * (((i < N) == (j < N)) ? 1.f : DECAY);
+            Sm[i][j] = i == j ? sm - 1e8f : sm;
+        }
+        for (int e = tid; e < Q * D2; e += FB) {
+            const int j = e / D2, d = e - j * D2;
+            float s = 0.f;
+            for (int i = 0; i < Q; ++i)
+                s = fmaf((Pm[i][j] + (i == j ? 1.f : 0.f)) * (((i < N) == (j < N)) ? 1.f : DECAY), da[i][d], s);
+            atomicAdd(&gX[rows[j] * D2 + d], s);
+        }
+        __syncthreads();
+        if (tid < Q) {                                   // softmax backward per row, then the leaky slope of the pre-activation
+            float dot = 0.f;
+            for (int j = 0; j < Q; ++j) dot = fmaf(T[tid][j], Pm[tid][j], dot);
+            for (int j = 0; j < Q; ++j) T[tid][j] = Pm[tid][j] * (T[tid][j] - dot) * (Sm[tid][j] > 0.f ? 1.f : LEAKY);
+        }
+        __syncthreads();
+        for (int e = tid; e < Q * D2; e += FB) {          // d Mm = (dS + dS^T) Mm
+            const int i = e / D2, d = e - i * D2;
+            float s = 0.f;
+            for (int j = 0; j < Q; ++j) s = fmaf(T[i][j] + T[j][i], mm[j][d], s);
+            atomicAdd(&gM[rows[i] * D2 + d], s);
+        }
+        __syncthreads();
+    }
+}
+
+// sums for the window BatchNorms' backward from the row-accumulated gradients gX_b:  sum g, sum g * xhat
+__global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
+                                                          const float* __restrict__ F, const float* __restrict__ gX0,
+                                                          const float* __restrict__ gX1) {
+    __shared__ double sl[4 * MAXC];
+    __shared__ BnCoef c0[MAXD], c1[MAXD];
+    if (threadIdx.x < g.D2) {
+        c0[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 3, threadIdx.x);
+        c1[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 5, threadIdx.x);
+    }
+    BlockStats s0, s1;
+    s0.init(sl, g.D2);
+    s1.init(sl + 2 * MAXC, g.D2);
+    const int64_t total = g.M * g.D2;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int d = (int)(e % g.D2);
+        const float f = F[e], a = gX0[e], b = gX1[e];
+        s0.add(d, a, a * (f - c0[d].mean) * c0[d].inv);
+        s1.add(d, b, b * (f - c1[d].mean) * c1[d].inv);
+    }
+    s0.flush(cells->bwd[3], g.D2);
+    s1.flush(cells->bwd[5], g.D2);
+}
+
+// dF = sum over the two blocks of the window-BatchNorm backward (row form, multiplicity-weighted)
+__global__ __launch_bounds__(FB) void fc_feat_bwd_kernel(FcGeom g, const float* __restrict__ prm, const Cells* cells,
+                                                        const float* __restrict__ F, const float* __restrict__ gX0,
+                                                        const float* __restrict__ gX1, float* __restrict__ dF) {
+    __shared__ BnCoef c0[MAXD], c1[MAXD];
+    __shared__ float m0[MAXD][2], m1[MAXD][2];
+    if (threadIdx.x < g.D2) {
+        const int d = threadIdx.x;
+        c0[d] = fbn(g, cells, prm, nullptr, 1, 3, d);
+        c1[d] = fbn(g, cells, prm, nullptr, 1, 5, d);
+        m0[d][0] = (float)(cells->bwd[3][d][0] / g.cnt[3]); m0[d][1] = (float)(cells->bwd[3][d][1] / g.cnt[3]);
+        m1[d][0] = (float)(cells->bwd[5][d][0] / g.cnt[5]); m1[d][1] = (float)(cells->bwd[5][d][1] / g.cnt[5]);
+    }
+    __syncthreads();
+    const int64_t total = g.M * g.D2;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int d = (int)(e % g.D2);
+        const int t = (int)(((e / g.D2) / g.N) % g.NP);
+        const float f = F[e];
+        const float k0 = mult(g, 0, t), k1 = mult(g, 1, t);
+        const float x0 = (f - c0[d].mean) * c0[d].inv, x1 = (f - c1[d].mean) * c1[d].inv;
+        dF[e] = c0[d].sc * (gX0[e] - k0 * (m0[d][0] + x0 * m0[d][1])) + c1[d].sc * (gX1[e] - k1 * (m1[d][0] + x1 * m1[d][1]));
+    }
+}
+
+// dy3 = dF * dropout keep (in place); BatchNorm-c backward sums
+__global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
+                                                      const float* __restrict__ z3, float* __restrict__ dF, uint32_t drop_thr,
+                                                      float drop_scale, uint32_t drop_key, const uint32_t* key_dev, int64_t row_offset) {
+    __shared__ double sl[2 * MAXC];
+    __shared__ BnCoef cc[MAXC];
+    if (threadIdx.x < g.D2) cc[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 2, threadIdx.x);
+    BlockStats st;
+    st.init(sl, g.D2);
+    const uint32_t key = key_dev ? *key_dev : drop_key;
+    const int64_t total = g.M * g.D2;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int d = (int)(e % g.D2);
+        float dy = dF[e];
+        if (drop_thr) {
+            const uint32_t ctr = (uint32_t)(((e / g.D2) + row_offset) * g.D2 + d);
+            dy = lowbias32(ctr ^ key) >= drop_thr ? dy * drop_scale : 0.f;
+        }
+        dF[e] = dy;
+        st.add(d, dy, dy * (z3[e] - cc[d].mean) * cc[d].inv);
+    }
+    st.flush(cells->bwd[2], g.D2);
+}
+
+// dy2 = da2 * [a2 > 0] (in place); BatchNorm-b backward sums
+__global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
+                                                        const float* __restrict__ z2, const float* __restrict__ a2,
+                                                        float* __restrict__ da2) {
+    __shared__ double sl[2 * MAXC];
+    __shared__ BnCoef cb[MAXC];
+    if (threadIdx.x < g.CO) cb[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 1, threadIdx.x);
+    BlockStats st;
+    st.init(sl, g.CO);
+    const int64_t total = g.M * g.CL;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int co = (int)((e / g.L2) % g.CO);
+        const float dy = a2[e] > 0.f ? da2[e] : 0.f;
+        da2[e] = dy;
+        st.add(co, dy, dy * (z2[e] - cb[co].mean) * cb[co].inv);
+    }
+    st.flush(cells->bwd[1], g.CO);
+}
+
+// dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums
+__global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
+                                                        const float* __restrict__ z1, const float* __restrict__ dz2,
+                                                        float* __restrict__ dy1) {
+    __shared__ double sl[2 * MAXC];
+    __shared__ BnCoef ca[16];
+    if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
+    BlockStats st;
+    st.init(sl, g.H1);
+    const int64_t total = g.M * g.H1 * g.L1;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int q = (int)(e % g.L1), ci = (int)((e / g.L1) % g.H1);
+        const int64_t m = e / ((int64_t)g.L1 * g.H1);
+        const float zz = z1[e];
+        float dy = 0.f;
+        if (fmaf(zz, ca[ci].sc, ca[ci].sh) > 0.f) {
+            const float* dr = dz2 + m * g.CL;
+            for (int co = 0; co < g.CO; ++co)
+                for (int k = 0; k < g.K; ++k) {
+                    const int p = q + 1 - k;
+                    if (p >= 0 && p < g.L2) dy = fmaf(prm[g.o_w2 + (co * g.H1 + ci) * g.K + k], dr[co * g.L2 + p], dy);
+                }
+        }
+        dy1[e] = dy;
+        st.add(ci, dy, dy * (zz - ca[ci].mean) * ca[ci].inv);
+    }
+    st.flush(cells->bwd[0], g.H1);
+}
+
+// conv weight gradients: WHICH 2: dw2[co][ci][k] = sum_m sum_p dz2[m][co][p] * a1[m][ci][p + k - 1]
+//                        WHICH 1: dw1[c][k]      = sum_m sum_p dz1[m][c][p]  * v[m][p + k - K/2]
+// each workgroup reduces a contiguous chunk of rows; thread-owned outputs, one partial row per workgroup
+template <int WHICH>
+__global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                          const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
+                                                          float* __restrict__ gpart) {
+    __shared__ BnCoef ca[16];
+    if (WHICH == 2 && threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
+    __syncthreads();
+    const int nout = WHICH == 2 ? g.CO * g.H1 * g.K : g.H1 * g.K;
+    const int64_t per = (g.M + gridDim.x - 1) / gridDim.x;
+    const int64_t m0 = per * blockIdx.x, m1 = m0 + per < g.M ? m0 + per : g.M;
+    for (int o = threadIdx.x; o < nout; o += FB) {
+        float acc = 0.f;
+        if (WHICH == 2) {
+            const int k = o % g.K, ci = (o / g.K) % g.H1, co = o / (g.K * g.H1);
+            for (int64_t m = m0; m < m1; ++m) {
+                const float* dr = dz + m * g.CL + co * g.L2;
+                const float* zr = z1 + (m * g.H1 + ci) * g.L1;
+                for (int p = 0; p < g.L2; ++p) {
+                    const int q = p + k - 1;
+                    if (q >= 0 && q < g.L1) acc = fmaf(dr[p], fmaxf(fmaf(zr[q], ca[ci].sc, ca[ci].sh), 0.f), acc);
+                }
+            }
+        } else {
+            const int k = o % g.K, c = o / g.K, pad = g.K / 2;
+            for (int64_t m = m0; m < m1; ++m) {
+                const int node = (int)(m % g.N), t = (int)((m / g.N) % g.NP);
+                const int64_t b = m / ((int64_t)g.N * g.NP);
+                const float* v = x + (b * g.N + node) * g.TL + t * g.PS;
+                const float* dr = dz + (m * g.H1 + c) * g.L1;
+                for (int p = 0; p < g.L1; ++p) {
+                    const int j = p + k - pad;
+                    if (j >= 0 && j < g.PS) acc = fmaf(dr[p], v[j], acc);
+                }
+            }
+        }
+        gpart[(int64_t)blockIdx.x * nout + o] = acc;
+    }
+}
+
+// conv partial rows -> gradients; BatchNorm gamma / beta gradients from the cells
+__global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2, int rows,
+                                                        const Cells* cells, float* __restrict__ grads) {
+    const int e = blockIdx.x * FB + threadIdx.x;
+    const int n1 = g.H1 * g.K, n2 = g.CO * g.H1 * g.K;
+    if (e < n1) {
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += gp1[(int64_t)r * n1 + e];
+        grads[g.o_w1 + e] = a;
+    } else if (e < n1 + n2) {
+        const int o = e - n1;
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += gp2[(int64_t)r * n2 + o];
+        grads[g.o_w2 + o] = a;
+    } else {
+        int c = e - n1 - n2;
+        for (int id = 0; id < NBN; ++id) {
+            if (c < g.bn_ch[id]) {
+                grads[g.bn_g[id] + c] = (float)cells->bwd[id][c][1];
+                grads[g.bn_b[id] + c] = (float)cells->bwd[id][c][0];
+                return;
+            }
+            c -= g.bn_ch[id];
+        }
+    }
+}
+
+// BatchNorm batch statistics out: (mean, biased var) per layer/channel, or weight * (E[z], E[z^2]) for data parallel
+__global__ void fc_bn_batch_kernel(FcGeom g, const Cells* cells, float* __restrict__ bn_batch, float weight) {
+    for (int id = 0; id < NBN; ++id)
+        for (int c = threadIdx.x; c < g.bn_ch[id]; c += blockDim.x) {
+            const double m = cells->fwd[id][c][0] / g.cnt[id], q = cells->fwd[id][c][1] / g.cnt[id];
+            float* mean = bn_batch + g.bn_off[id] + c;
+            float* var = mean + g.bn_ch[id];
+            if (weight > 0.f) {
+                *mean = (float)(weight * m);
+                *var = (float)(weight * q);
+            } else {
+                const double v = q - m * m;
+                *mean = (float)m;
+                *var = (float)(v < 0.0 ? 0.0 : v);
+            }
+        }
+}
+
+// running statistics update for all seven layers; count[id] values per channel went into the batch statistics
+__global__ void fc_bn_running_kernel(FcGeom g, float* __restrict__ bn, const float* __restrict__ batch, float momentum, int from_moments) {
+    for (int id = 0; id < NBN; ++id)
+        for (int c = threadIdx.x; c < g.bn_ch[id]; c += blockDim.x) {
+            float mean = batch[g.bn_off[id] + c], var = batch[g.bn_off[id] + g.bn_ch[id] + c];
+            if (from_moments) {
+                var = var - mean * mean;
+                if (var < 0.f) var = 0.f;
+            }
+            const double n = g.cnt[id];
+            const float unbiased = n > 1.0 ? (float)(var * (n / (n - 1.0))) : var;
+            float* rm = bn + g.bn_off[id] + c;
+            float* rv = rm + g.bn_ch[id];
+            *rm = (1.0f - momentum) * *rm + momentum * mean;
+            *rv = (1.0f - momentum) * *rv + momentum * unbiased;
+        }
+}
+
+__global__ void fc_fill_one_kernel(float* p) { p[0] = 1.f; }
+
+struct FcWs {
+    size_t cells, one, z1, z2, a2, z3, F, Mm[2], P[2], AX[2], z5[2], feat, h1, h2, h3, dpred, sqerr;
+    size_t dh3, dh2, dh1, dfeat, dAX[2], dz5[2], gX[2], gM[2], dF, da2, dy1, gp1, gp2, split, total;
+    int rows;
+};
+
+void fc_ws_layout(const FcGeom& g, FcWs* w) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t o = 0;
+    auto take = [&](size_t floats) { const size_t r = o; o = al(o + floats * sizeof(float)); return r; };
+    w->cells = o; o = al(o + sizeof(Cells));
+    w->one = take(64);
+    const size_t M = (size_t)g.M, B = (size_t)g.B;
+    w->z1 = take(M * g.H1 * g.L1);
+    w->z2 = take(M * g.CL);
+    w->a2 = take(M * g.CL);
+    w->z3 = take(M * g.D2);
+    w->F = take(M * g.D2);
+    for (int b = 0; b < 2; ++b) {
+        const size_t GQ = (size_t)g.G[b] * g.Q;
+        w->Mm[b] = take(M * g.D2);
+        w->P[b] = take(GQ * g.Q);
+        w->AX[b] = take(GQ * g.D2);
+        w->z5[b] = take(GQ * g.HD);
+        w->dAX[b] = take(GQ * g.D2);
+        w->dz5[b] = take(GQ * g.HD);
+        w->gX[b] = take(M * g.D2);
+        w->gM[b] = take(M * g.D2);
+    }
+    w->feat = take(B * g.FIN);
+    w->h1 = take(B * g.D2);
+    w->h2 = take(B * g.D2);
+    w->h3 = take(B * g.HD);
+    w->dpred = take(B);
+    w->sqerr = take(B);
+    w->dh3 = take(B * g.HD);
+    w->dh2 = take(B * g.D2);
+    w->dh1 = take(B * g.D2);
+    w->dfeat = take(B * g.FIN);
+    w->dF = take(M * g.D2);
+    w->da2 = take(M * g.CL);
+    w->dy1 = take(M * g.H1 * g.L1);
+    w->rows = 512;
+    w->gp1 = take((size_t)w->rows * g.H1 * g.K);
+    w->gp2 = take((size_t)w->rows * g.CO * g.H1 * g.K);
+    // split-K scratch: max over the weight-gradient GEMMs of slices * M * N
+    size_t mx = 1;
+    auto need = [&](int Mo, int No, int64_t K) {
+        const size_t v = (size_t)sgemm_splitk_slices(Mo, No, (int)K) * Mo * No;
+        if (v > mx) mx = v;
+    };
+    need(1, g.HD, g.B); need(g.HD, g.D2, g.B); need(g.D2, g.D2, g.B); need(g.D2, g.FIN, g.B); need(1, g.D2, g.B);
+    for (int b = 0; b < 2; ++b) { need(g.HD, g.D2, g.G[b] * g.Q); need(1, g.HD, g.G[b] * g.Q); }
+    need(g.D2, g.D2, g.M); need(1, g.D2, g.M); need(g.D2, g.CL, g.M);
+    w->split = take(mx);
+    w->total = o;
+}
+
+inline unsigned grid_for(int64_t total) {
+    int64_t b = (total + FB - 1) / FB;
+    if (b > 4096) b = 4096;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+int64_t fcstgnn_param_count(const rulgnn_fcstgnn_shape* s) {
+    FcGeom g;
+    return fc_geometry(s, &g) == RULGNN_OK ? g.nparam : -1;
+}
+
+int64_t fcstgnn_bn_count(const rulgnn_fcstgnn_shape* s) {
+    FcGeom g;
+    return fc_geometry(s, &g) == RULGNN_OK ? g.bn_total : -1;
+}
+
+size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s) {
+    FcGeom g;
+    if (fc_geometry(s, &g) != RULGNN_OK) return 0;
+    FcWs w;
+    fc_ws_layout(g, &w);
+    return w.total;
+}
+
+#define FC_RC(call)                        \
+    do {                                   \
+        const int rc_ = (call);            \
+        if (rc_ != RULGNN_OK) return rc_;  \
+    } while (0)
+
+// mode bit 0: forward (args->training selects batch / running statistics), bit 1: backward
+int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st) {
+    FcGeom g;
+    FC_RC(fc_geometry(s, &g));
+    FcWs w;
+    fc_ws_layout(g, &w);
+    if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    char* ws = static_cast<char*>(a->workspace);
+    auto P_ = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    Cells* cells = reinterpret_cast<Cells*>(ws + w.cells);
+    const float* prm = a->params;
+    const float* run = a->bn_stats;
+    const int training = a->training ? 1 : 0;
+    const int D2 = g.D2, HD = g.HD, CL = g.CL, FIN = g.FIN;
+    const int Mi = (int)g.M, Bi = (int)g.B;
+    const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+    // positional-encoding dropout (train mode only)
+    const float p = training ? a->dropout_p : 0.f;
+    uint32_t thr = 0;
+    if (p > 0.f) {
+        const double t = (double)p * 4294967296.0;
+        const uint64_t ti = (uint64_t)(t + 0.5);
+        thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
+    }
+    const float dscale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_layer_key(a->seed, a->step, 0);
+    const uint32_t* key_dev = a->step_state ? static_cast<const StepState*>(a->step_state)->drop_key : nullptr;
+    const int64_t row_off = a->sample_offset * g.NP * g.N;
+    (void)hipGetLastError();
+
+    if (mode & 1) {
+        if (training && a->step_state) FC_RC(step_prepare_dropout(a->step_state, a->seed, 1, st));
+        if (hipMemsetAsync(cells, 0, sizeof(Cells), st) != hipSuccess) return RULGNN_EHIP;
+        hipLaunchKernelGGL(fc_conv1_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
+        hipLaunchKernelGGL(fc_conv2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2), cells,
+                           training);
+        hipLaunchKernelGGL(fc_act2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
+                           (const float*)P_(w.z2), P_(w.a2));
+        FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st));
+        hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, P_(w.z3), prm + g.o_b3, g.M, D2, cells, 2, training);
+        hipLaunchKernelGGL(fc_pe_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, run, cells, training, (const float*)P_(w.z3),
+                           P_(w.F), thr, dscale, key, key_dev, row_off);
+        for (int b = 0; b < 2; ++b) {
+            const int GQ = (int)(g.G[b] * g.Q);
+            FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st));
+            hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm, run,
+                               (const Cells*)cells, training, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
+            FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st));
+            hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
+                               (int64_t)GQ, HD, cells, 4 + 2 * b, training);
+        }
+        for (int b = 0; b < 2; ++b)
+            hipLaunchKernelGGL(fc_pool_kernel, dim3(grid_for(g.G[b] * g.N * HD)), dim3(FB), 0, st, g, b, prm, run, (const Cells*)cells,
+                               training, (const float*)P_(w.z5[b]), P_(w.feat));
+        FC_RC(sgemm(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, st));
+        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h1), prm + g.o_f1b, g.B, D2);
+        FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st));
+        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h2), prm + g.o_f2b, g.B, D2);
+        FC_RC(sgemm(P_(w.h2), D2, 1, prm + g.o_f3w, D2, 1, P_(w.h3), HD, Bi, HD, D2, false, st));
+        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * HD)), dim3(FB), 0, st, P_(w.h3), prm + g.o_f3b, g.B, HD);
+        hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3), a->y,
+                           (const float*)nullptr, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 0);
+        if (training && a->bn_batch)
+            hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
+    }
+    if (mode & 2) {
+        float* gr = a->grads;
+        float* split = P_(w.split);
+        float* one = P_(w.one);
+        hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
+        if (a->dpred)
+            hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3),
+                               (const float*)nullptr, a->dpred, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 1);
+        auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
+            return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, st);
+        };
+        // ---- MLP ----
+        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, st));
+        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, st));
+        FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, st));
+        FC_RC(colsum(P_(w.dh3), g.B, HD, gr + g.o_f3b));
+        FC_RC(sgemm(P_(w.dh3), HD, 1, prm + g.o_f3w, 1, D2, P_(w.dh2), D2, Bi, D2, HD, false, st));
+        hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh2), (const float*)P_(w.h2), g.B * D2);
+        FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, st));
+        FC_RC(colsum(P_(w.dh2), g.B, D2, gr + g.o_f2b));
+        FC_RC(sgemm(P_(w.dh2), D2, 1, prm + g.o_f2w, 1, D2, P_(w.dh1), D2, Bi, D2, D2, false, st));
+        hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh1), (const float*)P_(w.h1), g.B * D2);
+        FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, st));
+        FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
+        FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st));
+        // ---- graph blocks ----
+        for (int b = 0; b < 2; ++b) {
+            const int GQ = (int)(g.G[b] * g.Q);
+            float* dz5 = P_(w.dz5[b]);
+            hipLaunchKernelGGL(fc_pool_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, b, prm, cells,
+                               (const float*)P_(w.z5[b]), (const float*)P_(w.dfeat), dz5);
+            hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
+                               (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
+            FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, st));
+            FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
+            FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st));
+            if (hipMemsetAsync(P_(w.gX[b]), 0, sizeof(float) * g.M * D2, st) != hipSuccess) return RULGNN_EHIP;
+            if (hipMemsetAsync(P_(w.gM[b]), 0, sizeof(float) * g.M * D2, st) != hipSuccess) return RULGNN_EHIP;
+            hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm,
+                               (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
+                               (const float*)P_(w.dAX[b]), P_(w.gX[b]), P_(w.gM[b]));
+        }
+        hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
+                           (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
+        hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
+                           (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
+        for (int b = 0; b < 2; ++b) {
+            FC_RC(sgemm_splitk(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, false, split, st));
+            FC_RC(colsum(P_(w.gM[b]), g.M, D2, gr + g.o_bmap[b]));
+            FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st));
+        }
+        // ---- positional encoding / dropout, Linear + BatchNorm ----
+        hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
+                           dscale, key, key_dev, row_off);
+        hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
+                           (const float*)P_(w.z3), P_(w.dF), g.M);
+        FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, st));
+        FC_RC(colsum(P_(w.dF), g.M, D2, gr + g.o_b3));
+        FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st));
+        // ---- encoder convolutions ----
+        hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
+                           (const float*)P_(w.a2), P_(w.da2));
+        hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, 1, g.L2, prm, (const Cells*)cells,
+                           (const float*)P_(w.z2), P_(w.da2), g.M * CL);
+        hipLaunchKernelGGL(fc_conv2_dx_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z1),
+                           (const float*)P_(w.da2), P_(w.dy1));
+        const int rows = (int)(g.M < w.rows ? g.M : w.rows);
+        hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
+                           (const float*)P_(w.da2), P_(w.gp2));
+        hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, 0, g.L1, prm, (const Cells*)cells,
+                           (const float*)P_(w.z1), P_(w.dy1), g.M * g.H1 * g.L1);
+        hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
+                           (const float*)P_(w.dy1), P_(w.gp1));
+        int nbn = 0;
+        for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
+        hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + FB - 1) / FB), dim3(FB), 0, st, g,
+                           (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr);
+        if (!a->dpred && a->loss)
+            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)P_(w.sqerr), (int64_t)g.B, a->loss);
+    }
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int fcstgnn_bn_running_update(const rulgnn_fcstgnn_shape* s, float* bn_stats, const float* bn_batch, float momentum, int from_moments,
+                              hipStream_t st) {
+    FcGeom g;
+    FC_RC(fc_geometry(s, &g));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fc_bn_running_kernel, dim3(1), dim3(64), 0, st, g, bn_stats, bn_batch, momentum, from_moments);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+}  // namespace rulgnn

@@ -320,4 +320,74 @@ int rulgnn_adam_step_dev_f32(float* params, const float* grads, float* exp_avg, 
                      static_cast<hipStream_t>(stream), step_state);
 }
 
+
+// ---- FC_STGNN -----------------------------------------------------------------------------------------
+int64_t rulgnn_fcstgnn_param_count(const rulgnn_fcstgnn_shape* shape) { return fcstgnn_param_count(shape); }
+int64_t rulgnn_fcstgnn_bn_count(const rulgnn_fcstgnn_shape* shape) { return fcstgnn_bn_count(shape); }
+size_t rulgnn_fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* shape) { return fcstgnn_workspace_bytes(shape); }
+
+static int check_fcstgnn(const rulgnn_fcstgnn_shape* shape, const rulgnn_fcstgnn_args* a, bool forward, bool backward) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (shape->batch < 1 || a->global_batch < shape->batch || a->sample_offset < 0) return RULGNN_EINVAL;
+    if (!(a->bn_moment_weight >= 0.f) || !(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return RULGNN_EINVAL;
+    int rc = check_ptrs({a->x, a->params, a->pred, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (forward && !a->training) {
+        rc = check_ptrs({a->bn_stats});
+        if (rc != RULGNN_OK) return rc;
+    }
+    for (const void* p : {(const void*)a->y, (const void*)a->dpred, (const void*)a->bn_batch, (const void*)a->loss})
+        if (p && (reinterpret_cast<uintptr_t>(p) & 3)) return RULGNN_EALIGN;
+    if (backward) {
+        if (!a->training) return RULGNN_EINVAL;
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->dpred) {
+            rc = check_ptrs({a->y, a->loss});
+            if (rc != RULGNN_OK) return rc;
+        }
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_fcstgnn_forward_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fcstgnn_args* args, void* stream) {
+    const int rc = check_fcstgnn(shape, args, true, false);
+    if (rc != RULGNN_OK) return rc;
+    return fcstgnn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_fcstgnn_backward_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fcstgnn_args* args, void* stream) {
+    const int rc = check_fcstgnn(shape, args, false, true);
+    if (rc != RULGNN_OK) return rc;
+    return fcstgnn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fcstgnn_args* args, const rulgnn_adam_args* opt,
+                              void* stream) {
+    int rc = check_fcstgnn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+        if (opt->bn_stats && (!args->bn_batch || (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3))) return RULGNN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = fcstgnn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, fcstgnn_param_count(shape), opt->step, opt->lr,
+                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+    if (rc != RULGNN_OK || !opt->bn_stats) return rc;
+    return fcstgnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
+}
+
+int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape* shape, float* bn_stats, const float* bn_batch, float momentum,
+                                         int32_t from_moments, void* stream) {
+    if (!shape) return RULGNN_EINVAL;
+    const int rc = check_ptrs({bn_stats, bn_batch});
+    if (rc != RULGNN_OK) return rc;
+    return fcstgnn_bn_running_update(shape, bn_stats, bn_batch, momentum, from_moments, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -115,6 +115,12 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s);
 int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream);
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
                               int from_moments, hipStream_t stream);
+int64_t fcstgnn_param_count(const rulgnn_fcstgnn_shape* s);
+int64_t fcstgnn_bn_count(const rulgnn_fcstgnn_shape* s);
+size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s);
+int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t stream);
+int fcstgnn_bn_running_update(const rulgnn_fcstgnn_shape* s, float* bn_stats, const float* bn_batch, float momentum, int from_moments,
+                              hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
 int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);

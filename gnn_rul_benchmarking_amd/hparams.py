@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN and ASTGCNN rows are restated (the methods this package implements).
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN and FC_STGNN rows are restated (the methods this package implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
 :226,242,275,311,355,390,424).
@@ -16,6 +16,20 @@ _ST_GCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'lea
 _STMSGCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 0, 'learning_rate': 1e-2}
 _MSG = {'gcn_dims': [16, 64, 16, 1], 'gru_hidden_dim': 8}
 _ASTGCNN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
+_FC_STGNN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
+# configs/hparams.py:32,69,109,149 (C-MAPSS FD001-4) and :196 (N-CMAPSS)
+_FC_STGNN_ROWS = {
+    'FD001': {'patch_size': 25, 'num_patch': 2, 'encoder_time_out': 27, 'encoder_hidden_dim': 8, 'encoder_out_dim': 32,
+              'encoder_conv_kernel': 2, 'hidden_dim': 8, 'num_sequential': 6, 'num_node': 14, 'num_windows': 2},
+    'FD002': {'patch_size': 1, 'num_patch': 50, 'encoder_time_out': 3, 'encoder_hidden_dim': 8, 'encoder_out_dim': 12,
+              'encoder_conv_kernel': 2, 'hidden_dim': 8, 'num_sequential': 10, 'num_node': 14, 'num_windows': 74},
+    'FD003': {'patch_size': 1, 'num_patch': 50, 'encoder_time_out': 3, 'encoder_hidden_dim': 8, 'encoder_out_dim': 6,
+              'encoder_conv_kernel': 2, 'hidden_dim': 24, 'num_sequential': 25, 'num_node': 14, 'num_windows': 74},
+    'FD004': {'patch_size': 2, 'num_patch': 25, 'encoder_time_out': 4, 'encoder_hidden_dim': 8, 'encoder_out_dim': 6,
+              'encoder_conv_kernel': 2, 'hidden_dim': 8, 'num_sequential': 10, 'num_node': 14, 'num_windows': 36},
+    None: {'patch_size': 2, 'num_patch': 25, 'encoder_time_out': 4, 'encoder_hidden_dim': 8, 'encoder_out_dim': 32,
+           'encoder_conv_kernel': 2, 'hidden_dim': 8, 'num_sequential': 6, 'num_node': 20, 'num_windows': 36},
+}
 
 
 def get_hparams_class(dataset_name):
@@ -40,6 +54,8 @@ class _Table:
             self.train_params['ASTGCNN'] = dict(_ASTGCNN_TRAIN)
             self.alg_hparams['ASTGCNN'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'encoder_out_dim': 50,
                                            'output_dim': 64, 'K': 3}
+            self.train_params['FC_STGNN'] = dict(_FC_STGNN_TRAIN)
+            self.alg_hparams['FC_STGNN'] = dict(_FC_STGNN_ROWS[dataset_id])
         if dataset_id in self._stmsgcn_rows:
             self.train_params['STMSGCN'] = dict(_STMSGCN_TRAIN)
             self.alg_hparams['STMSGCN'] = dict(self._stmsgcn_rows[dataset_id], gcn_dims=list(_MSG['gcn_dims']),

@@ -288,6 +288,64 @@ int rulgnn_adam_step_dev_f32(float *params, const float *grads, float *exp_avg, 
                              void *step_state, float lr, float beta1, float beta2, float eps, float weight_decay,
                              float grad_scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FC_STGNN path (reference models/FC_STGNN/Model.py + Model_Base.py, algorithms/algorithms.py:51-76): the model the
+ * reference wires to C-MAPSS FD001-4 and N-CMAPSS with five different patchings (configs/hparams.py:32,69,109,149,196).
+ *
+ * x [batch, num_node, num_patch*patch_size] -> per (sample, patch, sensor) row: Conv1d(1->H1, k, pad k/2) + BN + ReLU ->
+ * Conv1d(H1->CO, k, pad 1) + BN + ReLU -> Linear(CO*encoder_time_out -> 2*hidden) + BN -> + positional encoding, dropout
+ * 0.1 (train) -> two window blocks (window 2, stride 1 and 2): per window a graph of 2*num_node nodes,
+ * A = (softmax(leaky(M M^T - 1e8 I)) + I) * decay mask with M = Linear(X), X' = BN(X), leaky(BN(Linear(A X'))), mean
+ * over the window -> concat -> MLP (2h, 2h, h, 1).
+ *
+ * Flat parameter buffer: the tensors in the order of the reference's named_parameters():
+ *   conv1.weight[H1][1][k] | bn_a.weight | bn_a.bias | conv2.weight[CO][H1][k] | bn_b.{weight,bias} |
+ *   nonlin_map2.0.{weight[2h][CO*TO], bias} | bn_c.{weight,bias} |
+ *   for MPNN1, MPNN2: mapping.{weight[2h][2h], bias} | BN.{weight,bias} | theta.{weight[h][2h], bias} | bn1.{weight,bias} |
+ *   fc1.{weight[2h][h*num_windows*num_node], bias} | fc2.{weight[2h][2h], bias} | fc3.{weight[h][2h], bias} | fc4.{weight[h], bias}
+ * BatchNorm buffer: for the seven layers in that order: running_mean[C] | running_var[C].
+ */
+typedef struct rulgnn_fcstgnn_shape {
+    int64_t batch;
+    int32_t patch_size, num_patch, encoder_time_out, encoder_hidden_dim, encoder_out_dim, encoder_conv_kernel;
+    int32_t hidden_dim, num_sequential, num_node, num_windows;   /* the reference's constructor arguments, Model.py:6-8 */
+} rulgnn_fcstgnn_shape;
+
+typedef struct rulgnn_fcstgnn_args {
+    const float *x;           /* [batch, num_node * num_patch * patch_size] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;
+    float *grads;
+    float *pred;              /* [batch] */
+    float *loss;              /* [1]; may be NULL */
+    const float *bn_stats;    /* running statistics (read when training == 0) */
+    float *bn_batch;          /* out, training: batch statistics in the BatchNorm-buffer layout (mean | biased var), or with
+                               * bn_moment_weight > 0: weight * (E[z], E[z^2]); may be NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;
+    int64_t sample_offset;    /* index of this shard's first sample in the global batch (dropout stream) */
+    float bn_moment_weight;
+    float dropout_p;          /* positional-encoding dropout, 0.1 in the reference (Model.py:25); train mode only */
+    uint64_t seed, step;      /* dropout stream: mask = f(seed, step, element index) */
+    int32_t training;
+    void *step_state;         /* optional device step state (rulgnn_step_state_set) */
+} rulgnn_fcstgnn_args;
+
+int64_t rulgnn_fcstgnn_param_count(const rulgnn_fcstgnn_shape *shape);     /* < 0: invalid / unsupported */
+int64_t rulgnn_fcstgnn_bn_count(const rulgnn_fcstgnn_shape *shape);        /* floats in the BatchNorm buffer */
+size_t rulgnn_fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape *shape);
+/* model(X): FC_STGNN_RUL.forward (Model.py:46-84), eval (trainer.py:144) or train mode (algorithms.py:67). */
+int rulgnn_fcstgnn_forward_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fcstgnn_args *args, void *stream);
+/* loss.backward() (algorithms.py:72) after a train-mode forward with the same args/workspace. */
+int rulgnn_fcstgnn_backward_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fcstgnn_args *args, void *stream);
+/* FC_STGNN.update body (algorithms.py:67-74); with `opt` also Adam and the running statistics (opt->bn_stats). */
+int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fcstgnn_args *args,
+                              const rulgnn_adam_args *opt, void *stream);
+int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape *shape, float *bn_stats, const float *bn_batch,
+                                         float momentum, int32_t from_moments, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
