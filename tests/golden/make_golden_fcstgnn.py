@@ -143,7 +143,70 @@ def case_training_curve(name, cfg, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_trainer_cmapss(name, seed, n_train=250, n_test=80, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method FC_STGNN on the synthetic C-MAPSS FD004
+    dataset of synth.py, its own hparams (configs/hparams.py:133,149: batch 100, lr 1e-3, wd 1e-4, 25 patches of 2) and its own
+    shuffling DataLoader.  num_epochs is patched, and the algorithm class handed to the trainer switches the hard-coded
+    positional-encoding dropout off after construction (torch's Bernoulli stream cannot be reproduced by any other
+    implementation); nothing in the reference tree is modified."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_cmapss
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    base = get_algorithm_class("FC_STGNN")
+
+    class NoDropout(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.model.positional_encoding.dropout.p = 0.0
+    NoDropout.__name__ = "FC_STGNN"
+    _orig_get = ref_trainer.get_algorithm_class
+    ref_trainer.get_algorithm_class = lambda n: NoDropout if n == "FC_STGNN" else _orig_get(n)
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "CMAPSS", "FD004")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="FC_STGNN", data_path=os.path.join(tmp, "data"), dataset="CMAPSS",
+                                      dataset_id="FD004", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "FC_STGNN_run_0", "results.csv")).read()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+            ref_trainer.get_algorithm_class = _orig_get
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.fc.fc4.weight", "model.MPNN1.graph_construction.mapping.weight", "model.nonlin_map.conv_block2.0.weight",
+              "model.MPNN2.MPNN.bn1.running_var", "model.nonlin_map2.1.num_batches_tracked"):
+        out["final:" + k] = final[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_cmapss("fcstgnn_trainer_cmapss_fd004_reference_run", 7)
+        sys.exit(0)
     case_forward_backward("fcstgnn_fd004_bs6", WIRINGS["fd004"], 6, seed=51)
     case_forward_backward("fcstgnn_fd001_bs5", WIRINGS["fd001"], 5, seed=52)
     case_forward_backward("fcstgnn_fd002_bs3", WIRINGS["fd002"], 3, seed=53)
@@ -151,3 +214,4 @@ if __name__ == "__main__":
     case_forward_backward("fcstgnn_fd003like_6p_bs2", dict(WIRINGS["fd003"], num_patch=6, num_windows=8), 2, seed=54)
     case_forward_backward("fcstgnn_ncmapss_bs3", WIRINGS["ncmapss"], 3, seed=55, lo=-1.0, hi=1.0)
     case_training_curve("fcstgnn_train_curve_fd004_bs10", WIRINGS["fd004"], 10, steps=12, seed=56, lr=1e-3, wd=1e-4)
+    case_trainer_cmapss("fcstgnn_trainer_cmapss_fd004_reference_run", 7)

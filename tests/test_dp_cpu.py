@@ -281,3 +281,76 @@ def test_astgcnn_data_parallel_step_world2_gloo():
     fw = AO.forward(AO.random_params(AN, AT, output_dim=AOUT, seed=9), x, train=True)
     assert np.allclose(out[0]["moments"][:AN], fw.z1.mean(axis=(0, 2)), rtol=1e-5, atol=1e-6)
     assert np.allclose(out[0]["moments"][AN:2 * AN], (fw.z1 ** 2).mean(axis=(0, 2)), rtol=1e-5, atol=1e-6)
+
+
+# ---- FC_STGNN: seven BatchNorms + dropout stream offset, same bucket scheme ----
+from oracle import fcstgnn_oracle as FO   # noqa: E402
+
+FCFG = FO.Config(patch_size=2, num_patch=5, encoder_time_out=4, encoder_hidden_dim=3, encoder_out_dim=2, encoder_conv_kernel=2,
+                 hidden_dim=2, num_sequential=1, num_node=3, num_windows=6)
+
+
+class FcstgnnOracleModel:
+    """Duck-types the slice of FC_STGNN_RUL that dp.DataParallel touches."""
+
+    def __init__(self, prm):
+        self.prm = {k: np.asarray(v, np.float64) for k, v in prm.items()}
+        self.names = FO.param_names(FCFG)
+        self.num_live = sum(self.prm[k].size for k in self.names)
+        self.nbn = 2 * sum(FO.bn_channels(FCFG).values())
+        self.bucket = torch.zeros(self.num_live + 1 + self.nbn, dtype=torch.float32)
+        self.flat_params = torch.from_numpy(np.concatenate([self.prm[k].reshape(-1) for k in self.names]).astype(np.float32))
+        self.global_moments = None
+
+    def fused_mse_step(self, X, y, optimizer=None, global_batch=None, sample_offset=0, update_running_stats=True,
+                       moments_to_bucket=False):
+        assert moments_to_bucket and not update_running_stats
+        x, yy = X.numpy().astype(np.float64), y.numpy().astype(np.float64).reshape(-1)
+        loss, grads, fw = FO.loss_and_grads(self.prm, x, yy, FCFG, global_batch=global_batch)
+        self.bucket[:self.num_live] = torch.from_numpy(np.concatenate([grads[k].reshape(-1) for k in self.names]).astype(np.float32))
+        self.bucket[self.num_live] = loss
+        w = x.shape[0] / float(global_batch)
+        tail, o = self.bucket[self.num_live + 1:], 0
+        for name, t in FO.bn_tapes(fw).items():
+            c = t.mean.size
+            tail[o:o + c] = torch.from_numpy((w * t.mean).astype(np.float32))
+            tail[o + c:o + 2 * c] = torch.from_numpy((w * (t.var + t.mean ** 2)).astype(np.float32))
+            o += 2 * c
+        self.sample_offset = sample_offset
+        return None, self.bucket[self.num_live]
+
+    def _after_train_forward(self, batch, from_bucket_moments=False):
+        assert from_bucket_moments
+        self.global_moments = self.bucket[self.num_live + 1:].clone()
+
+
+def _fcstgnn_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(4)
+        x = torch.from_numpy(rng.uniform(0, 1, (B, FCFG.num_node, FCFG.num_patch * FCFG.patch_size)).astype(np.float32))
+        y = torch.from_numpy(rng.uniform(0, 1, (B, 1)).astype(np.float32))
+        model = FcstgnnOracleModel(FO.random_params(FCFG, seed=6))
+        dp = DataParallel()
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "flat": model.flat_params.clone().numpy(),
+                     "moments": model.global_moments.numpy(), "offset": model.sample_offset, "lo": lo}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fcstgnn_data_parallel_step_world2_gloo():
+    B, world = 9, 2
+    out = mp.Manager().dict()
+    mp.spawn(_fcstgnn_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    assert np.array_equal(out[0]["bucket"], out[1]["bucket"]) and np.array_equal(out[0]["flat"], out[1]["flat"])
+    assert out[1]["offset"] == out[1]["lo"] > 0                         # the dropout stream of shard 1 starts at its first sample
+    # the first BatchNorm sees the same conv output in every sharding: reduced moments == single-process batch statistics
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 1, (B, FCFG.num_node, FCFG.num_patch * FCFG.patch_size)).astype(np.float32).astype(np.float64)
+    fw = FO.forward(FO.random_params(FCFG, seed=6), x, FCFG, train=True)
+    c = FCFG.encoder_hidden_dim
+    assert np.allclose(out[0]["moments"][:c], fw.bna.mean, rtol=1e-5, atol=1e-6)
+    assert np.allclose(out[0]["moments"][c:2 * c], fw.bna.var + fw.bna.mean ** 2, rtol=1e-5, atol=1e-6)

@@ -18,6 +18,10 @@ def make(name, seed):
     elif name == "ASTGCNN":
         cfg = dict(num_nodes=14, time_length=50, encoder_out_dim=50, output_dim=64, K=3)
         hp, shape = {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 50)
+    elif name == "FC_STGNN":
+        from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+        cfg = get_hparams_class("CMAPSS")("FD004").alg_hparams["FC_STGNN"]
+        hp, shape = {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 50)
     else:
         cfg = dict(num_patch=12, patch_size=20, interval=2, band_width=3, gcn_dims=[16, 64, 16, 1], gru_hidden_dim=8)
         hp, shape = {"learning_rate": 1e-3, "weight_decay": 0.0}, (1, 240)
@@ -26,7 +30,7 @@ def make(name, seed):
     return algo, shape
 
 
-@pytest.mark.parametrize("name", ["ST_GCN", "ASTGCNN", "STMSGCN"])
+@pytest.mark.parametrize("name", ["ST_GCN", "ASTGCNN", "STMSGCN", "FC_STGNN"])
 def test_graph_replay_equals_eager_steps(name):
     eager, shape = make(name, 3)
     graphed, _ = make(name, 3)

@@ -78,7 +78,7 @@ def test_unknown_method_and_dataset_errors(tmp_path):
     base = dict(save_dir=str(tmp_path / "logs"), experiment_description="e", run_description="r", data_path=str(tmp_path),
                 dataset="CMAPSS", dataset_id="FD004", bearing_id="b", num_runs=1, device="cuda:0")
     with pytest.raises(KeyError):                             # trainer.py:60: method not listed for the dataset
-        GNN_RUL_trainer(argparse.Namespace(GNN_method="FC_STGNN", **base))
+        GNN_RUL_trainer(argparse.Namespace(GNN_method="HAGCN", **base))
     with pytest.raises(ValueError):                           # hparams.py:172
         GNN_RUL_trainer(argparse.Namespace(GNN_method="ST_GCN", **dict(base, dataset_id="FD009")))
     with pytest.raises(NotImplementedError):
@@ -231,3 +231,55 @@ def test_astgcnn_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monke
     import io
     ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
     assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
+
+
+def test_fcstgnn_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monkeypatch):
+    """--GNN_method FC_STGNN on C-MAPSS FD004 as the reference wires it (configs/hparams.py:133,149; shuffling DataLoader):
+    the reference's own harness, run on CPU by tests/golden/make_golden_fcstgnn.py::case_trainer_cmapss with the
+    positional-encoding dropout switched off on the constructed model, vs this package's harness on the GPU with the same
+    switch."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_cmapss
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "fcstgnn_trainer_cmapss_fd004_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "CMAPSS" / "FD004"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    base = T.get_algorithm_class("FC_STGNN")
+
+    class NoDropout(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.model.dropout_p = 0.0
+    monkeypatch.setattr(T, "get_algorithm_class", lambda n: NoDropout)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="FC_STGNN", data_path=str(tmp_path / "data"), dataset="CMAPSS",
+                              dataset_id="FD004", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.train_configs["batch_size"] == int(z["batch_size"]) and tr.train_configs["learning_rate"] == float(z["lr"])
+    assert tr.model_configs["num_patch"] == 25 and tr.model_configs["num_windows"] == 36
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("FC_STGNN harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 2:] - ref[:, 2:]) / np.abs(ref[:, 2:])) < 1e-3      # MAE, RMSE (in RUL cycles), relative
+    assert np.max(np.abs(got[:, 3] - ref[:, 3]) / 125.0) < 1e-3                      # RMSE on the normalised scale, absolute
+    sd = tr.algorithm.state_dict()
+    for k in z.files:
+        if k.startswith("final:"):
+            a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
+            assert np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30) < 3e-3, k
