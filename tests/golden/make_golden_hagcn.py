@@ -1,0 +1,113 @@
+"""Golden fixtures for the HAGCN path, produced by RUNNING THE REFERENCE in this container.
+
+    python tests/golden/make_golden_hagcn.py     # needs /root/reference (read-only import)
+
+Only data is written (inputs, weights, the outputs/gradients the reference produced); see make_golden.py for the shims.
+Shapes: the reference's wirings (configs/hparams.py:41 FD001: 5 patches of 10; :79,119 FD002/3 and :204 N-CMAPSS: 2 of 25;
+:159 FD004: 1 of 50).  The two Dropout(0.2) modules of the LSTM stack are switched off on the instantiated module so that
+train-mode outputs are deterministic; nothing in the reference tree is modified.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg                                   # noqa: E402  (installs the shims, sets sys.path)
+from models.HAGCN import Model as ref_model                # noqa: E402
+
+ALPHA = 100.0                                              # configs/hparams.py:22
+
+
+def build(cfg, seed):
+    torch.manual_seed(seed)
+    m = ref_model.HAGCN_model(**cfg)
+    for d in (m.TD.drop1, m.TD.drop2, m.TD.drop3):
+        d.p = 0.0
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.startswith("TD."):
+                continue
+            p.add_(torch.empty_like(p).uniform_(-0.05, 0.05, generator=g))
+            if ".rank." in name or (name.startswith("gnn") and ".mlp.2." in name):
+                p.mul_(3.0)                                # spread the node scores: well separated top-k selections
+    return m
+
+
+def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False):
+    m = build(cfg, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    x = torch.rand(bs, num_node, cfg["patch_size"] * cfg["num_patch"], generator=g) * (hi - lo) + lo
+    y = torch.rand(bs, 1, generator=g)
+    out = {"x": x.numpy().copy(), "y": y.numpy().copy(), "alpha": np.float64(ALPHA)}
+    for k, v in cfg.items():
+        out["cfg:" + k] = np.int64(v)
+    for k, v in mg.state_np(m, "sd:").items():
+        if keep_td or not k.startswith("sd:TD."):          # the LSTM stack is 320k of the 366k weights: kept in one fixture only
+            out[k] = v
+    t = {}
+
+    def gin1(mod, i, o):
+        t["nodes"] = i[0]
+        t["adj0"] = i[1].detach().numpy().copy()
+        t["gin1"] = o.detach().numpy().copy()
+
+    def sag(l):
+        def f(mod, i, o):
+            t[f"xo{l}"] = o[0].detach().numpy().copy()
+            t[f"adj{l}"] = o[1].detach().numpy().copy()
+            t[f"kl{l}"] = np.float64(o[2].item())
+        return f
+    hs = [m.gin1.register_forward_hook(gin1), m.gnn1.register_forward_hook(sag(1)), m.gnn2.register_forward_hook(sag(2)),
+          m.gnn3.register_forward_hook(sag(3))]
+    m.eval()
+    with torch.no_grad():
+        out["eval_pred"] = m(x).numpy().copy()
+    m.train()
+    # record the indices torch.sort hands to the three SAGPool layers (Model.py:106-107): on these inputs the node scores
+    # are equal to within fp32 rounding, so WHICH nodes are kept is decided by rounding noise and has to be part of the fixture
+    sorted_idx = []
+    _sort = torch.sort
+
+    def recording_sort(*a, **k):
+        r = _sort(*a, **k)
+        sorted_idx.append(r[1].detach().numpy().copy())
+        return r
+    torch.sort = recording_sort
+    try:
+        pred, kl = m(x, train=True)
+    finally:
+        torch.sort = _sort
+    assert len(sorted_idx) == 3
+    for l, idx in enumerate(sorted_idx):
+        out[f"order{l + 1}"] = idx.astype(np.int64)
+    nodes = t["nodes"]
+    nodes.retain_grad()
+    loss = torch.nn.functional.mse_loss(pred, y) + ALPHA * kl
+    m.zero_grad()
+    loss.backward()
+    for h in hs:
+        h.remove()
+    out["nodes"] = nodes.detach().numpy().copy()
+    out["grad_nodes"] = nodes.grad.numpy().copy()
+    for k in ("adj0", "gin1", "xo1", "adj1", "kl1", "xo2", "adj2", "kl2", "xo3", "adj3", "kl3"):
+        out[k] = t[k]
+    out["train_pred"] = pred.detach().numpy().copy()
+    out["train_kl"] = np.float64(kl.item())
+    out["train_loss"] = np.float64(loss.item())
+    for n_, p in m.named_parameters():
+        if not n_.startswith("TD."):                       # the LSTM gradients belong to the delegated library path
+            out["grad:" + n_] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, out["eval_pred"].ravel()[:3], "kl", out["train_kl"], "loss", out["train_loss"])
+
+
+if __name__ == "__main__":
+    dims = dict(hidden_dim=64, encoder_hidden_dim=60, output_dim=32)
+    case("hagcn_fd001_5x10_bs6", dict(patch_size=10, num_patch=5, **dims), 6, 14, seed=61, keep_td=True)
+    case("hagcn_fd002_2x25_bs5", dict(patch_size=25, num_patch=2, **dims), 5, 14, seed=62)
+    case("hagcn_fd004_1x50_bs7", dict(patch_size=50, num_patch=1, **dims), 7, 14, seed=63)
+    case("hagcn_ncmapss_2x25_bs3", dict(patch_size=25, num_patch=2, **dims), 3, 20, seed=64, lo=-1.0, hi=1.0)
