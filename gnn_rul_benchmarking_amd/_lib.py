@@ -76,6 +76,19 @@ class FcstgnnArgs(C.Structure):
                 ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32), ("step_state", C.c_void_p)]
 
 
+HAGCN_TOPK_SLOTS = 16
+
+
+class HagcnShape(C.Structure):
+    _fields_ = [("graphs", C.c_int64), ("num_node", C.c_int32), ("enc_dim", C.c_int32), ("hidden_dim", C.c_int32)]
+
+
+class HagcnArgs(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("params", C.c_void_p), ("feats", C.c_void_p), ("kl", C.c_void_p), ("topk", C.c_void_p),
+                ("forced_topk", C.c_void_p), ("dfeats", C.c_void_p), ("dkl", C.c_void_p), ("dnodes", C.c_void_p),
+                ("grads", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -107,6 +120,10 @@ _SIGNATURES = {
     "rulgnn_fcstgnn_fwdbwd_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_fcstgnn_bn_running_update_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
                                                         C.c_void_p]),
+    "rulgnn_hagcn_graph_param_count": (C.c_int64, [C.POINTER(HagcnShape)]),
+    "rulgnn_hagcn_workspace_bytes": (C.c_size_t, [C.POINTER(HagcnShape)]),
+    "rulgnn_hagcn_graph_forward_f32": (C.c_int, [C.POINTER(HagcnShape), C.POINTER(HagcnArgs), C.c_void_p]),
+    "rulgnn_hagcn_graph_backward_f32": (C.c_int, [C.POINTER(HagcnShape), C.POINTER(HagcnArgs), C.c_void_p]),
     "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),

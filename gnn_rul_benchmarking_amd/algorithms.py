@@ -2,8 +2,8 @@
 algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
 ``NotImplementedError("Algorithm not found: ...")`` otherwise).
 
-The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571), ASTGCNN (:139-163) and FC_STGNN (:51-76)
-wrappers are implemented:
+The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571), ASTGCNN (:139-163), FC_STGNN (:51-76) and HAGCN
+(:222-248) wrappers are implemented:
 the hot paths this package accelerates.  The classes keep the reference contract -- constructor
 ``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
 ``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
@@ -15,6 +15,7 @@ import torch.nn as nn
 from .optim import FusedAdam
 from .astgcnn import ASTGCNN_model
 from .fcstgnn import FC_STGNN_RUL
+from .hagcn import HAGCN_model
 from .stgcn import ST_GCN_model
 from .stmsgcn import STMSGCN_model
 
@@ -222,4 +223,33 @@ class FC_STGNN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "get_algorithm_class", "torch", "nn", "annotations"}
+class HAGCN(Algorithm):
+    """HAGCN training wrapper (reference algorithms.py:222-248): ``loss = mse + alpha * KL`` with the reference's literal
+    autograd sequence.  The graph stack is one HIP autograd function (csrc/hagcn.hip); the Bi-LSTM stack and ``fc`` are
+    torch modules on the vendor libraries, so the optimizer is ``torch.optim.Adam`` exactly as in the reference.  The LSTM
+    recurs along batch*nodes (Model.py:153-157): every sample depends on the whole batch, hence replicas only -- no
+    data-parallel sharding for this model."""
+
+    def __init__(self, configs, hparams, device):
+        super(HAGCN, self).__init__(configs)
+        self.model = HAGCN_model(**configs)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.alpha = hparams["alpha"]
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        raise RuntimeError("HAGCN is not sample-shardable (its LSTM recurs along batch*nodes): run independent replicas")
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        predicted_RUL, KL_Loss = self.model(X, train=True)
+        loss_mse = self.mse(predicted_RUL, y)
+        loss = loss_mse + self.alpha * KL_Loss
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return self._finish(loss.detach())
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "get_algorithm_class", "torch", "nn", "annotations"}

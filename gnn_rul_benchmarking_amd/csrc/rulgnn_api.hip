@@ -390,4 +390,25 @@ int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape* shape, floa
     return fcstgnn_bn_running_update(shape, bn_stats, bn_batch, momentum, from_moments, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- HAGCN graph stack ----------------------------------------------------------------------------------
+int64_t rulgnn_hagcn_graph_param_count(const rulgnn_hagcn_shape* shape) { return hagcn_graph_param_count(shape); }
+size_t rulgnn_hagcn_workspace_bytes(const rulgnn_hagcn_shape* shape) { return hagcn_workspace_bytes(shape); }
+
+int rulgnn_hagcn_graph_forward_f32(const rulgnn_hagcn_shape* shape, const rulgnn_hagcn_args* a, void* stream) {
+    if (!shape || !a || shape->graphs < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({a->nodes, a->params, a->feats, a->kl, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    for (const void* p : {(const void*)a->topk, (const void*)a->forced_topk})
+        if (p && (reinterpret_cast<uintptr_t>(p) & 3)) return RULGNN_EALIGN;
+    return hagcn_graph_forward(shape, a, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_hagcn_graph_backward_f32(const rulgnn_hagcn_shape* shape, const rulgnn_hagcn_args* a, void* stream) {
+    if (!shape || !a || shape->graphs < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({a->params, a->dfeats, a->dkl, a->dnodes, a->grads, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    return hagcn_graph_backward(shape, a, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -121,6 +121,10 @@ size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s);
 int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t stream);
 int fcstgnn_bn_running_update(const rulgnn_fcstgnn_shape* s, float* bn_stats, const float* bn_batch, float momentum, int from_moments,
                               hipStream_t stream);
+int64_t hagcn_graph_param_count(const rulgnn_hagcn_shape* s);
+size_t hagcn_workspace_bytes(const rulgnn_hagcn_shape* s);
+int hagcn_graph_forward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
+int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
 int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);

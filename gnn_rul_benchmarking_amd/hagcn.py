@@ -1,0 +1,233 @@
+"""Drop-in ``HAGCN_model``: the graph stack (cosine adjacency, three GIN + SAGPool levels with top-k node selection and the
+KL prior, node means) runs in the gfx950 HIP kernels of csrc/hagcn.hip through one autograd function; the Bi-LSTM stack in
+front of it and the two-layer ``fc`` behind it are ``torch.nn`` modules on the vendor libraries (MIOpen / rocBLAS).
+
+Mirrors the reference class (models/HAGCN/Model.py:129-195): same constructor kwargs
+``(patch_size, num_patch, encoder_hidden_dim, hidden_dim, output_dim)``, same ``forward(X, train=False)`` returning the
+prediction or ``(prediction, total_kl)``, the same 67 ``state_dict`` keys and -- sub-modules being created in the
+reference's order -- the same initial weights for a torch seed.  The LSTM stack keeps the reference's axis convention
+(sequence axis = batch*nodes, batch axis = num_patch, Model.py:153-157), which couples all samples of a batch: data
+parallelism for this model is replicas only.
+
+The graph-stack parameters are views into one flat fp32 buffer that the kernels read directly (layout in
+include/rulgnn.h).  There is no CPU path for the graph stack: a non-CUDA input raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class GINLayer(nn.Module):
+    """Holder of ``eps`` and ``mlp`` (Model.py:6-14)."""
+
+    def __init__(self, input_dim, hidden_dim):
+        super().__init__()
+        self.eps = nn.Parameter(torch.Tensor([0]))
+        self.mlp = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, hidden_dim))
+
+
+class SAGPool(nn.Module):
+    """Holder of ``rank``, ``model`` and ``mlp`` (Model.py:75-87)."""
+
+    def __init__(self, input_dimension, output_dimension, n):
+        super().__init__()
+        self.rank = nn.Linear(input_dimension, 1)
+        self.model = nn.Linear(input_dimension, output_dimension)
+        self.n = n
+        self.mlp = nn.Sequential(nn.Linear(input_dimension, input_dimension // 2), nn.ReLU(), nn.Linear(input_dimension // 2, 1))
+
+
+class Bi_LSTM_Standard(nn.Module):
+    """The reference's LSTM stack (Model.py:26-73), executed by torch (MIOpen on ROCm)."""
+
+    def __init__(self, input_dim, num_hidden, time_length):
+        super().__init__()
+        self.bi_lstm1 = nn.LSTM(input_size=input_dim, hidden_size=num_hidden, num_layers=1, batch_first=True, dropout=0,
+                                bidirectional=True)
+        self.drop1 = nn.Dropout(p=0.2)
+        self.bi_lstm2 = nn.LSTM(input_size=num_hidden, hidden_size=num_hidden * 2, num_layers=1, batch_first=True, dropout=0,
+                                bidirectional=True)
+        self.drop2 = nn.Dropout(p=0.2)
+        self.bi_lstm3 = nn.LSTM(input_size=num_hidden * 2, hidden_size=num_hidden, num_layers=1, batch_first=True,
+                                bidirectional=True)
+        self.drop3 = nn.Dropout(p=0.2)
+
+    def forward(self, x):
+        x, _ = self.bi_lstm1(x)
+        a, b = torch.split(x, x.shape[2] // 2, 2)
+        x = a + b
+        x, _ = self.bi_lstm2(x)
+        a, b = torch.split(x, x.shape[2] // 2, 2)
+        x = self.drop2(a + b)
+        x2, _ = self.bi_lstm3(x)
+        a, b = torch.split(x2, x2.shape[2] // 2, 2)
+        return F.leaky_relu(self.drop3(a + b))
+
+
+GRAPH_LEAVES = ("eps", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias")
+POOL_LEAVES = ("rank.weight", "rank.bias", "model.weight", "model.bias", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias")
+
+
+def graph_param_names():
+    names = []
+    for l in (1, 2, 3):
+        names += [f"gin{l}.{leaf}" for leaf in GRAPH_LEAVES] + [f"gnn{l}.{leaf}" for leaf in POOL_LEAVES]
+    return names
+
+
+class _GraphFunction(torch.autograd.Function):
+    """(nodes [G, N, enc], graph parameters) -> (feats [G, 3h], kl []) on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, model, nodes, *params):
+        feats, kl = model._graph_forward(nodes)
+        ctx.model = model
+        ctx.shape = tuple(nodes.shape)
+        ctx.ws = model._ws                      # the tape lives in the workspace: keep it until backward
+        return feats, kl
+
+    @staticmethod
+    def backward(ctx, dfeats, dkl):
+        model = ctx.model
+        dnodes, grads = model._graph_backward(ctx.shape, ctx.ws, dfeats.contiguous().float(), dkl.reshape(1).contiguous().float())
+        out = [grads[off:off + n].view(shape).clone() for (off, n, shape) in model._slices]
+        return (None, dnodes, *out)
+
+
+class HAGCN_model(nn.Module):
+    def __init__(self, patch_size, num_patch, encoder_hidden_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.patch_size, self.num_patch = int(patch_size), int(num_patch)
+        self.enc_dim, self.hidden_dim = int(encoder_hidden_dim), int(hidden_dim)
+        # same construction order as the reference (Model.py:135-147) => same RNG consumption => same initial weights
+        self.TD = Bi_LSTM_Standard(patch_size, encoder_hidden_dim, None)
+        self.gin1 = GINLayer(encoder_hidden_dim, hidden_dim)
+        self.gnn1 = SAGPool(hidden_dim, hidden_dim, 10)
+        self.gin2 = GINLayer(hidden_dim, hidden_dim)
+        self.gnn2 = SAGPool(hidden_dim, hidden_dim, 5)
+        self.gin3 = GINLayer(hidden_dim, hidden_dim)
+        self.gnn3 = SAGPool(hidden_dim, hidden_dim, 1)
+        self.fc = nn.Sequential(nn.Linear(hidden_dim * 3 * num_patch, output_dim), nn.ReLU(inplace=True), nn.Linear(output_dim, 1))
+
+        table = dict(self.named_parameters())
+        self._layout, self._slices, off = {}, [], 0
+        for name in graph_param_names():
+            p = table[name]
+            self._layout[name] = (off, tuple(p.shape))
+            self._slices.append((off, p.numel(), tuple(p.shape)))
+            off += p.numel()
+        self._count = off
+        self._flat = self._grad_flat = self._ws = None
+        self.last_topk = None                   # [G, 16] int32: node indices the last forward kept (10 | 5 | 1)
+        self.forced_topk = None                 # optional [G, 16] int32 imposed on the next forwards (parity checks under ties)
+        self._reflatten()
+
+    # ---- flat storage of the graph-stack parameters ----------------------------------------------------
+    def _graph_params(self):
+        table = dict(self.named_parameters())
+        return [table[name] for name in self._layout]
+
+    def _reflatten(self):
+        ps = self._graph_params()
+        dev = ps[0].device
+        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, (off, n, shape) in zip(ps, self._slices):
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        self._grad_flat = torch.zeros(self._count, dtype=torch.float32, device=dev)
+        self._ws = None
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._reflatten()
+        return self
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    # ---- C-ABI calls -----------------------------------------------------------------------------------
+    def _shape(self, graphs, num_node):
+        return _lib.HagcnShape(graphs, num_node, self.enc_dim, self.hidden_dim)
+
+    def _graph_forward(self, nodes):
+        if not nodes.is_cuda:
+            raise RuntimeError("HAGCN_model's graph stack runs on the HIP kernels only: tensors must be on a CUDA (ROCm) device; "
+                               "there is no CPU fallback")
+        nodes = nodes.contiguous().float()
+        G, N, _ = nodes.shape
+        shp = self._shape(G, N)
+        nbytes = _lib.load().rulgnn_hagcn_workspace_bytes(C.byref(shp))
+        if nbytes == 0:
+            raise RuntimeError("HAGCN graph kernels do not cover this configuration (10 <= num_node <= 20, encoder_hidden_dim <= 64, "
+                               "hidden_dim even and <= 64)")
+        # a fresh workspace per forward: it carries the tape to this forward's backward
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=nodes.device)
+        feats = torch.empty(G, 3 * self.hidden_dim, dtype=torch.float32, device=nodes.device)
+        kl = torch.empty(1, dtype=torch.float32, device=nodes.device)
+        topk = torch.zeros(G, _lib.HAGCN_TOPK_SLOTS, dtype=torch.int32, device=nodes.device)
+        a = _lib.HagcnArgs()
+        a.nodes, a.params, a.feats, a.kl, a.topk = nodes.data_ptr(), self._flat.data_ptr(), feats.data_ptr(), kl.data_ptr(), topk.data_ptr()
+        if self.forced_topk is not None:
+            f = self.forced_topk.to(device=nodes.device, dtype=torch.int32).contiguous()
+            if tuple(f.shape) != (G, _lib.HAGCN_TOPK_SLOTS):
+                raise RuntimeError("forced_topk must be [graphs, 16] int32")
+            a.forced_topk = f.data_ptr()
+            self._forced_keepalive = f
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        _lib.check(_lib.load().rulgnn_hagcn_graph_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_hagcn_graph_forward_f32")
+        self.last_topk = topk
+        return feats, kl.reshape(())
+
+    def _graph_backward(self, shape, ws, dfeats, dkl):
+        G, N, enc = shape
+        shp = self._shape(G, N)
+        dnodes = torch.empty(G, N, enc, dtype=torch.float32, device=dfeats.device)
+        a = _lib.HagcnArgs()
+        a.params, a.dfeats, a.dkl, a.dnodes, a.grads = (self._flat.data_ptr(), dfeats.data_ptr(), dkl.data_ptr(), dnodes.data_ptr(),
+                                                        self._grad_flat.data_ptr())
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(_lib.load().rulgnn_hagcn_graph_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_hagcn_graph_backward_f32")
+        return dnodes, self._grad_flat
+
+    def graph_stack(self, nodes):
+        """(feats [G, 3h], kl) of the graph part for given node features [G, N, enc] (what Model.py:164-183 computes)."""
+        if torch.is_grad_enabled() and (nodes.requires_grad or any(p.requires_grad for p in self._graph_params())):
+            return _GraphFunction.apply(self, nodes, *self._graph_params())
+        return self._graph_forward(nodes)
+
+    # ---- nn.Module surface -----------------------------------------------------------------------------
+    def forward(self, X, train=False):
+        if not X.is_cuda:
+            raise RuntimeError("HAGCN_model's graph stack runs on the HIP kernels only: input must be a CUDA (ROCm) tensor; "
+                               "there is no CPU fallback")
+        bs, num_node, _ = X.size()
+        X = torch.reshape(X.float(), [bs, num_node, self.num_patch, self.patch_size])
+        X = torch.transpose(X, 1, 2)
+        bs, tlen, num_node, dimension = X.size()
+        X = torch.transpose(X, 1, 2)
+        X = torch.reshape(X, [bs * num_node, tlen, dimension])
+        X = torch.transpose(X, 1, 0)                        # LSTM "batch" = patches, "sequence" = batch*nodes (Model.py:153-157)
+        TD_output = self.TD(X)
+        X = torch.transpose(TD_output, 1, 0)
+        X = torch.reshape(X, [bs, num_node, tlen, -1])
+        X = torch.transpose(X, 1, 2)
+        nodes = torch.reshape(X, [bs * tlen, num_node, -1])
+        feats, total_kl_div = self.graph_stack(nodes)
+        out = torch.reshape(feats, [bs, -1])
+        output = self.fc(out)
+        if train:
+            return output, total_kl_div
+        return output

@@ -1,7 +1,8 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN and FC_STGNN rows are restated (the methods this package implements).
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN and HAGCN rows are restated (the methods this package
+implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
 :226,242,275,311,355,390,424).
@@ -16,6 +17,9 @@ _ST_GCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'lea
 _STMSGCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 0, 'learning_rate': 1e-2}
 _MSG = {'gcn_dims': [16, 64, 16, 1], 'gru_hidden_dim': 8}
 _ASTGCNN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
+_HAGCN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3, 'alpha': 100}
+# configs/hparams.py:41,79,119,159 (C-MAPSS FD001-4) and :204 (N-CMAPSS)
+_HAGCN_PATCH = {'FD001': (10, 5), 'FD002': (25, 2), 'FD003': (25, 2), 'FD004': (50, 1), None: (25, 2)}
 _FC_STGNN_TRAIN = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
 # configs/hparams.py:32,69,109,149 (C-MAPSS FD001-4) and :196 (N-CMAPSS)
 _FC_STGNN_ROWS = {
@@ -54,6 +58,10 @@ class _Table:
             self.train_params['ASTGCNN'] = dict(_ASTGCNN_TRAIN)
             self.alg_hparams['ASTGCNN'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'encoder_out_dim': 50,
                                            'output_dim': 64, 'K': 3}
+            ps, npatch = _HAGCN_PATCH[dataset_id]
+            self.train_params['HAGCN'] = dict(_HAGCN_TRAIN)
+            self.alg_hparams['HAGCN'] = {'patch_size': ps, 'num_patch': npatch, 'hidden_dim': 64, 'encoder_hidden_dim': 60,
+                                         'output_dim': 32}
             self.train_params['FC_STGNN'] = dict(_FC_STGNN_TRAIN)
             self.alg_hparams['FC_STGNN'] = dict(_FC_STGNN_ROWS[dataset_id])
         if dataset_id in self._stmsgcn_rows:

@@ -346,6 +346,53 @@ int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fc
 int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape *shape, float *bn_stats, const float *bn_batch,
                                          float momentum, int32_t from_moments, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
+ * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
+ * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).
+ *
+ * One graph = one (sample, patch): nodes [num_node, enc_dim] -> A = cosine similarity -> three levels of
+ *   GIN: g = MLP(A x + (1 + eps) x);  SAGPool: xo = leaky(Linear(A g)), P = softmax_nodes(mlp(g)),
+ *   score = softmax_nodes(rank(A g)), kl += KL(score || P), keep the k = 10, 5, 1 best-scored nodes (rows of xo, rows and
+ *   columns of A)
+ * -> feats = [mean of the kept nodes of level 1 | level 2 | level 3]  (3 * hidden_dim), kl = sum of the three terms with
+ * 'batchmean' over the graphs.
+ *
+ * Flat parameter buffer, per level l = 1..3 (fin = enc_dim for l = 1, hidden_dim after), h = hidden_dim:
+ *   gin.eps[1] | gin.mlp.0.weight[h][fin] | gin.mlp.0.bias[h] | gin.mlp.2.weight[h][h] | gin.mlp.2.bias[h] |
+ *   gnn.rank.weight[h] | gnn.rank.bias[1] | gnn.model.weight[h][h] | gnn.model.bias[h] |
+ *   gnn.mlp.0.weight[h/2][h] | gnn.mlp.0.bias[h/2] | gnn.mlp.2.weight[h/2] | gnn.mlp.2.bias[1]
+ */
+#define RULGNN_HAGCN_TOPK_SLOTS 16   /* ints per graph in the index arrays: 10 (level 1) | 5 (level 2) | 1 (level 3) */
+
+typedef struct rulgnn_hagcn_shape {
+    int64_t graphs;           /* batch * num_patch */
+    int32_t num_node;         /* 10..20 */
+    int32_t enc_dim;          /* LSTM output width (encoder_hidden_dim), <= 64 */
+    int32_t hidden_dim;       /* even, <= 64 */
+} rulgnn_hagcn_shape;
+
+typedef struct rulgnn_hagcn_args {
+    const float *nodes;       /* [graphs, num_node, enc_dim] */
+    const float *params;      /* flat graph-stack parameters */
+    float *feats;             /* out [graphs, 3 * hidden_dim] */
+    float *kl;                /* out [1] */
+    int32_t *topk;            /* out, optional: node indices kept per level [graphs, RULGNN_HAGCN_TOPK_SLOTS] */
+    const int32_t *forced_topk; /* optional: impose these selections instead of the kernel's own ranking (parity checks
+                               * under score ties: the scores of this model are equal to within fp32 rounding) */
+    const float *dfeats;      /* backward in  [graphs, 3 * hidden_dim] */
+    const float *dkl;         /* backward in  [1] (device scalar): d loss / d kl */
+    float *dnodes;            /* backward out [graphs, num_node, enc_dim] */
+    float *grads;             /* backward out, flat (parameter layout) */
+    void *workspace;          /* >= rulgnn_hagcn_workspace_bytes; carries the tape from forward to backward */
+    size_t workspace_bytes;
+} rulgnn_hagcn_args;
+
+int64_t rulgnn_hagcn_graph_param_count(const rulgnn_hagcn_shape *shape);   /* < 0: invalid / unsupported */
+size_t rulgnn_hagcn_workspace_bytes(const rulgnn_hagcn_shape *shape);
+int rulgnn_hagcn_graph_forward_f32(const rulgnn_hagcn_shape *shape, const rulgnn_hagcn_args *args, void *stream);
+int rulgnn_hagcn_graph_backward_f32(const rulgnn_hagcn_shape *shape, const rulgnn_hagcn_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,9 +105,25 @@ def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False):
     print("wrote", name, out["eval_pred"].ravel()[:3], "kl", out["train_kl"], "loss", out["train_loss"])
 
 
+def case_init(name, cfg, seed):
+    """Key order and per-tensor checksums of a freshly constructed reference model (initial-weight parity for a seed)."""
+    torch.manual_seed(seed)
+    m = ref_model.HAGCN_model(**cfg)
+    sd = m.state_dict()
+    out = {"keys": np.array(list(sd.keys())), "seed": np.int64(seed),
+           "sums": np.array([float(v.double().sum()) for v in sd.values()]),
+           "abssums": np.array([float(v.double().abs().sum()) for v in sd.values()]),
+           "numel": np.array([v.numel() for v in sd.values()], dtype=np.int64)}
+    for k, v in cfg.items():
+        out["cfg:" + k] = np.int64(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, len(sd), "keys")
+
+
 if __name__ == "__main__":
     dims = dict(hidden_dim=64, encoder_hidden_dim=60, output_dim=32)
     case("hagcn_fd001_5x10_bs6", dict(patch_size=10, num_patch=5, **dims), 6, 14, seed=61, keep_td=True)
     case("hagcn_fd002_2x25_bs5", dict(patch_size=25, num_patch=2, **dims), 5, 14, seed=62)
     case("hagcn_fd004_1x50_bs7", dict(patch_size=50, num_patch=1, **dims), 7, 14, seed=63)
     case("hagcn_ncmapss_2x25_bs3", dict(patch_size=25, num_patch=2, **dims), 3, 20, seed=64, lo=-1.0, hi=1.0)
+    case_init("hagcn_init_fd004_seed65", dict(patch_size=50, num_patch=1, **dims), 65)

@@ -1,0 +1,144 @@
+"""HAGCN graph stack (HIP) vs the reference's golden outputs and vs the oracle; whole model with the LSTM stack on torch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hagcn_oracle as O
+from test_hagcn_oracle_golden import CASES, load_case, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+TOL = 1e-4
+GTOL = 1e-3
+
+
+def build(cfg, sd):
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    m = HAGCN_model(**cfg)
+    missing = m.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("TD.") for k in missing.missing_keys)
+    for d in (m.TD.drop1, m.TD.drop2, m.TD.drop3):
+        d.p = 0.0
+    return m.to(DEV)
+
+
+def cfg_of(z):
+    return {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg:")}
+
+
+def forced_of(z):
+    G = z["order1"].shape[0]
+    f = np.zeros((G, 16), dtype=np.int32)
+    f[:, 0:10], f[:, 10:15], f[:, 15:16] = z["order1"][:, :10], z["order2"][:, :5], z["order3"][:, :1]
+    return torch.from_numpy(f)
+
+
+def kernel_topk(m):
+    t = m.last_topk.cpu().numpy()
+    return [t[:, 0:10], t[:, 10:15], t[:, 15:16]]
+
+
+def check_param_grads(m, ref, scale_keys):
+    gmax = max(np.abs(ref[k]).max() for k in scale_keys)
+    table = dict(m.named_parameters())
+    for k in scale_keys:
+        got = table[k].grad.cpu().numpy().astype(np.float64)
+        if k.endswith("rank.bias") or (k.startswith("gnn") and k.endswith("mlp.2.bias")):
+            assert np.abs(got).max() < 1e-4 * gmax, k            # exactly zero in exact arithmetic
+            continue
+        r = np.asarray(ref[k], np.float64)
+        assert np.abs(got - r).max() / max(np.abs(r).max(), 1e-2 * gmax) < GTOL, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_graph_stack_matches_reference_golden_under_the_reference_selection(name):
+    """The reference's node scores are equal to within fp32 rounding, so its top-k selection is rounding noise; with the
+    reference's own sort indices imposed, the HIP graph stack + fc reproduce its outputs and gradients."""
+    z, _ = load_case(name)
+    m = build(cfg_of(z), {k[3:]: z[k] for k in z.files if k.startswith("sd:")})
+    m.forced_topk = forced_of(z)
+    nodes = torch.from_numpy(z["nodes"]).to(DEV).requires_grad_(True)
+    y = torch.from_numpy(z["y"]).to(DEV)
+    feats, kl = m.graph_stack(nodes)
+    pred = m.fc(feats.reshape(y.size(0), -1))
+    assert rel(pred.detach().cpu().numpy(), z["train_pred"]) < TOL
+    assert abs(float(kl.detach()) - float(z["train_kl"])) < 1e-3 * abs(float(z["train_kl"])) + 2e-6
+    loss = torch.nn.functional.mse_loss(pred, y) + float(z["alpha"]) * kl
+    assert abs(float(loss) - float(z["train_loss"])) < 1e-3 * abs(float(z["train_loss"]))
+    loss.backward()
+    ref = {k[5:]: z[k] for k in z.files if k.startswith("grad:")}
+    check_param_grads(m, ref, O.graph_param_names())
+    for k in ("fc.0.weight", "fc.2.weight"):
+        assert rel(dict(m.named_parameters())[k].grad.cpu().numpy(), ref[k]) < GTOL, k
+    g = nodes.grad.cpu().numpy()
+    assert np.abs(g - z["grad_nodes"]).max() / np.abs(z["grad_nodes"]).max() < GTOL
+
+
+@pytest.mark.parametrize("N,enc,hid,G", [(14, 60, 64, 37), (20, 60, 64, 9), (10, 7, 8, 5), (17, 64, 32, 300)])
+def test_free_running_graph_stack_matches_oracle_with_its_own_selection(N, enc, hid, G):
+    """No imposed selection: the kernel ranks the nodes itself; the oracle is then run with the kernel's selection, which must be
+    a valid top-k of the oracle's own scores (up to fp32 rounding), and everything else must agree."""
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    rng = np.random.default_rng(N * 7 + G)
+    p = O.random_graph_params(enc, hid, seed=G)
+    m = HAGCN_model(patch_size=5, num_patch=1, encoder_hidden_dim=enc, hidden_dim=hid, output_dim=4)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in p.items()}, strict=False)
+    m = m.to(DEV)
+    x0 = rng.normal(size=(G, N, enc))
+    w = rng.normal(size=(G, 3 * hid))
+    nodes = torch.from_numpy(x0.astype(np.float32)).to(DEV).requires_grad_(True)
+    feats, kl = m.graph_stack(nodes)
+    (feats * torch.from_numpy(w.astype(np.float32)).to(DEV)).sum().add(7.0 * kl).backward()
+    fw = O.graph_forward(p, x0, forced_topk=kernel_topk(m))
+    for lv in fw.levels:
+        assert O.selection_slack(lv) < 2e-5
+        assert (np.sort(lv.topk, axis=1)[:, 1:] != np.sort(lv.topk, axis=1)[:, :-1]).all()     # distinct nodes
+    assert rel(feats.detach().cpu().numpy(), fw.feats) < TOL
+    assert abs(float(kl) - fw.kl) < TOL * abs(fw.kl) + 1e-7
+    grads, dx0 = O.graph_backward(p, fw, w, 7.0)
+    check_param_grads(m, grads, O.graph_param_names())
+    assert rel(nodes.grad.cpu().numpy(), dx0) < GTOL
+
+
+def test_whole_model_with_lstm_on_the_vendor_library():
+    """End to end (LSTM stack on torch/MIOpen, graph stack on HIP, fc on torch) vs the reference's eval prediction; the
+    reference's selection is imposed (see above) and the LSTM output is compared first."""
+    z, _ = load_case("hagcn_fd001_5x10_bs6")
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    m = HAGCN_model(**cfg_of(z))
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")})
+    m = m.to(DEV).eval()
+    m.forced_topk = forced_of(z)
+    x = torch.from_numpy(z["x"]).to(DEV)
+    taps = {}
+    h = m.TD.register_forward_hook(lambda mod, i, o: taps.__setitem__("td", o.detach()))
+    with torch.no_grad():
+        pred = m(x)
+    h.remove()
+    bs, N = x.size(0), x.size(1)
+    nodes = taps["td"].transpose(1, 0).reshape(bs, N, 5, -1).transpose(1, 2).reshape(bs * 5, N, -1)
+    assert rel(nodes.cpu().numpy(), z["nodes"]) < 1e-4
+    assert pred.shape == (bs, 1) and rel(pred.cpu().numpy(), z["eval_pred"]) < 2e-4
+    out = m(x, train=True)
+    assert isinstance(out, tuple) and out[1].dim() == 0
+
+
+def test_algorithm_update_trains():
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    h = get_hparams_class("CMAPSS")("FD002")
+    torch.manual_seed(0)
+    algo = get_algorithm_class("HAGCN")(h.alg_hparams["HAGCN"], h.train_params["HAGCN"], DEV)
+    algo.to(DEV).train()
+    x = torch.rand(40, 14, 50, device=DEV)
+    y = x.mean(dim=(1, 2)).reshape(-1, 1)
+    losses = [algo.update(x, y, 1)["loss"] for _ in range(25)]
+    assert all(np.isfinite(losses)) and min(losses[-5:]) < losses[0]
+    algo.eval()
+    with torch.no_grad():
+        assert algo.model(x).shape == (40, 1)
+    sd = algo.state_dict()
+    assert len(sd) == 67 and all(k.startswith("model.") for k in sd)
