@@ -89,6 +89,16 @@ class HagcnArgs(C.Structure):
                 ("grads", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class BilstmShape(C.Structure):
+    _fields_ = [("seq_len", C.c_int64), ("num_seq", C.c_int32), ("input_dim", C.c_int32), ("hidden_dim", C.c_int32)]
+
+
+class BilstmArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
+                ("out", C.c_void_p), ("dout", C.c_void_p), ("dx", C.c_void_p), ("dw_ih", C.c_void_p * 2), ("dw_hh", C.c_void_p * 2),
+                ("db_ih", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -124,6 +134,9 @@ _SIGNATURES = {
     "rulgnn_hagcn_workspace_bytes": (C.c_size_t, [C.POINTER(HagcnShape)]),
     "rulgnn_hagcn_graph_forward_f32": (C.c_int, [C.POINTER(HagcnShape), C.POINTER(HagcnArgs), C.c_void_p]),
     "rulgnn_hagcn_graph_backward_f32": (C.c_int, [C.POINTER(HagcnShape), C.POINTER(HagcnArgs), C.c_void_p]),
+    "rulgnn_bilstm_workspace_bytes": (C.c_size_t, [C.POINTER(BilstmShape)]),
+    "rulgnn_bilstm_forward_f32": (C.c_int, [C.POINTER(BilstmShape), C.POINTER(BilstmArgs), C.c_void_p]),
+    "rulgnn_bilstm_backward_f32": (C.c_int, [C.POINTER(BilstmShape), C.POINTER(BilstmArgs), C.c_void_p]),
     "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),

@@ -1,0 +1,251 @@
+// Persistent bidirectional LSTM layer for gfx950 (the HAGCN encoder): out = h_forward + h_backward, forward and BPTT.
+//
+// Reference: Bi_LSTM_Standard, models/HAGCN/Model.py:26-73 (three nn.LSTM(bidirectional=True) whose two halves are
+// summed), called with the reference's axis convention (Model.py:153-157): "batch" = num_patch (1..5 sequences), sequence
+// length T = batch_size * num_node (1 400 .. 5 000 steps).  That is the worst case for a library RNN (a handful of kernel
+// launches per time step); here the recurrence is ONE persistent workgroup per (direction, sequence):
+//   * the input projection x W_ih^T of all time steps is one MFMA GEMM up front (sgemm_mfma.hpp);
+//   * each of the 4H threads keeps its row of W_hh in registers for the whole sequence, reads h from LDS (broadcast),
+//     and the H cell threads apply the gate non-linearities -- two workgroup barriers per time step, no launches;
+//   * BPTT mirrors it with the transposed rows in registers; the per-step gate gradients are written out and the weight
+//     gradients are split-K GEMMs over the whole sequence (dW_ih = dG^T x, dW_hh = dG^T h_prev), dx = dG W_ih.
+// The 2 * num_patch recurrences of a layer run concurrently on different CUs; layers are sequentially dependent.
+#include <utility>
+
+#include "sgemm_mfma.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+struct LstmGeom {
+    int64_t T;                  // time steps (batch_size * num_node)
+    int Bq, I, H, H4;           // sequences, input width, hidden width
+    int64_t rows;               // Bq * T
+    // workspace offsets (floats); every per-direction tensor is [dir][q][t][.]
+    int64_t o_gi, o_gates, o_c, o_h, o_hprev, o_dgates, o_one, o_split, total;
+};
+
+__host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->seq_len < 1 || s->num_seq < 1 || s->input_dim < 1 || s->hidden_dim < 1) return RULGNN_EINVAL;
+    if (s->hidden_dim > 128 || s->input_dim > 1024 || s->num_seq > 64) return RULGNN_EUNSUPPORTED;
+    if (s->seq_len * (int64_t)s->num_seq * 4 * s->hidden_dim > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
+    g->T = s->seq_len;
+    g->Bq = s->num_seq;
+    g->I = s->input_dim;
+    g->H = s->hidden_dim;
+    g->H4 = 4 * g->H;
+    g->rows = g->T * g->Bq;
+    int64_t o = 0;
+    auto tk = [&](int64_t n) { const int64_t r = o; o += (n + 63) & ~(int64_t)63; return r; };
+    g->o_gi = tk(2 * g->rows * g->H4);
+    g->o_gates = tk(2 * g->rows * g->H4);
+    g->o_c = tk(2 * g->rows * g->H);
+    g->o_h = tk(2 * g->rows * g->H);
+    g->o_hprev = tk(2 * g->rows * g->H);
+    g->o_dgates = tk(2 * g->rows * g->H4);
+    g->o_one = tk(64);
+    int64_t mx = 1;
+    for (const auto& mn : {std::pair<int, int>(g->H4, g->I), std::pair<int, int>(g->H4, g->H), std::pair<int, int>(1, g->H4)}) {
+        const int64_t v = (int64_t)sgemm_splitk_slices(mn.first, mn.second, (int)g->rows) * mn.first * mn.second;
+        if (v > mx) mx = v;
+    }
+    g->o_split = tk(mx);
+    g->total = o;
+    return RULGNN_OK;
+}
+
+__device__ inline float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------------
+// forward recurrence: workgroup = (direction, sequence); thread j < 4H owns gate row j of W_hh
+// ---------------------------------------------------------------------------------------------------
+template <int HMAX>
+__global__ void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
+                                    const float* __restrict__ w_hh1, const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
+                                    const float* __restrict__ b_ih1, const float* __restrict__ b_hh1, float* __restrict__ gates,
+                                    float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev) {
+    __shared__ __attribute__((aligned(16))) float hs[HMAX];
+    __shared__ float gl[4 * HMAX];
+    const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
+    const int j = threadIdx.x, H = g.H, H4 = g.H4;
+    const bool live = j < H4;
+    const float* w_hh = dir ? w_hh1 : w_hh0;
+    float w[HMAX];
+#pragma unroll
+    for (int k = 0; k < HMAX; ++k) w[k] = (live && k < H) ? w_hh[j * H + k] : 0.f;
+    const float bias = live ? (dir ? b_ih1[j] + b_hh1[j] : b_ih0[j] + b_hh0[j]) : 0.f;
+    const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;          // row of (dir, q, t = 0)
+    if (j < HMAX) hs[j] = 0.f;
+    float c = 0.f;
+    __syncthreads();
+    int64_t t = dir ? g.T - 1 : 0;
+    const int64_t dt = dir ? -1 : 1;
+    float nxt = live ? gi[(base + t) * H4 + j] : 0.f;
+    for (int64_t s = 0; s < g.T; ++s, t += dt) {
+        float acc = nxt + bias;
+        if (live && s + 1 < g.T) nxt = gi[(base + t + dt) * H4 + j];       // next step's input projection, ahead of the matvec
+#pragma unroll
+        for (int k = 0; k < HMAX; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
+            acc = fmaf(w[k], hv.x, acc);
+            acc = fmaf(w[k + 1], hv.y, acc);
+            acc = fmaf(w[k + 2], hv.z, acc);
+            acc = fmaf(w[k + 3], hv.w, acc);
+        }
+        if (live) gl[j] = acc;
+        if (j < H) hprev[(base + t) * H + j] = hs[j];
+        __syncthreads();
+        if (j < H) {
+            const float ig = sigm(gl[j]), fg = sigm(gl[H + j]), gg = tanhf(gl[2 * H + j]), og = sigm(gl[3 * H + j]);
+            c = fmaf(fg, c, ig * gg);
+            const float h = og * tanhf(c);
+            float* gr = gates + (base + t) * H4;
+            gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = gg; gr[3 * H + j] = og;
+            cseq[(base + t) * H + j] = c;
+            hseq[(base + t) * H + j] = h;
+            hs[j] = h;
+        }
+        __syncthreads();
+    }
+}
+
+// out[q][t][:] = h_fwd + h_bwd   (Model.py:59-61)
+__global__ void lstm_sum_kernel(LstmGeom g, const float* __restrict__ hseq, float* __restrict__ out) {
+    const int64_t n = g.rows * g.H;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = hseq[e] + hseq[n + e];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BPTT: thread tid < 4H = (part p, unit k) keeps W_hh[p*H + :, k] in registers
+// ---------------------------------------------------------------------------------------------------
+template <int HMAX>
+__global__ void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
+                                     const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ dout,
+                                     float* __restrict__ dgates) {
+    __shared__ __attribute__((aligned(16))) float dgl[4 * HMAX];
+    __shared__ float part[4][HMAX];
+    const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
+    const int tid = threadIdx.x, H = g.H, H4 = g.H4;
+    const bool live = tid < H4;
+    const int p = live ? tid / H : 0, k = live ? tid - p * H : 0;
+    const float* w_hh = dir ? w_hh1 : w_hh0;
+    float wt[HMAX];
+#pragma unroll
+    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && jj < H) ? w_hh[(p * H + jj) * H + k] : 0.f;
+    for (int e = tid; e < 4 * HMAX; e += blockDim.x) dgl[e] = 0.f;
+    const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;
+    const int64_t obase = (int64_t)q * g.T;                          // dout is [q][t][H], shared by both directions
+    float dh = 0.f, dc = 0.f;
+    __syncthreads();
+    // opposite to the forward order of this direction
+    int64_t t = dir ? 0 : g.T - 1;
+    const int64_t dt = dir ? 1 : -1;
+    for (int64_t s = 0; s < g.T; ++s, t += dt) {
+        if (tid < H) {
+            const float* gr = gates + (base + t) * H4;
+            const float ig = gr[tid], fg = gr[H + tid], gg = gr[2 * H + tid], og = gr[3 * H + tid];
+            const float ct = cseq[(base + t) * H + tid];
+            // cell state entering step t: the forward visited t - dt_fwd before t, i.e. t + dt in this loop's direction
+            const bool first = dir ? (t == g.T - 1) : (t == 0);
+            const float cp = first ? 0.f : cseq[(base + t + dt) * H + tid];
+            const float dht = dout[(obase + t) * H + tid] + dh;
+            const float tc = tanhf(ct);
+            const float dct = fmaf(dht * og, 1.0f - tc * tc, dc);
+            const float di = dct * gg * ig * (1.0f - ig), df = dct * cp * fg * (1.0f - fg);
+            const float dg = dct * ig * (1.0f - gg * gg), dov = dht * tc * og * (1.0f - og);
+            dc = dct * fg;
+            dgl[tid] = di; dgl[H + tid] = df; dgl[2 * H + tid] = dg; dgl[3 * H + tid] = dov;
+            float* dr = dgates + (base + t) * H4;
+            dr[tid] = di; dr[H + tid] = df; dr[2 * H + tid] = dg; dr[3 * H + tid] = dov;
+        }
+        __syncthreads();
+        if (live) {                                   // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate
+            float a = 0.f;
+            const float* dsrc = dgl + p * H;
+#pragma unroll
+            for (int jj = 0; jj < HMAX; ++jj) a = fmaf(dsrc[jj], wt[jj], a);      // wt is zero beyond H; dsrc stays inside dgl
+            part[p][k] = a;
+        }
+        __syncthreads();
+        if (tid < H) dh = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    }
+}
+
+__global__ void lstm_fill_one_kernel(float* p) { p[0] = 1.f; }
+// db_ih = db_hh: copy
+__global__ void lstm_copy_kernel(const float* __restrict__ a, float* __restrict__ b, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) b[e] = a[e];
+}
+
+}  // namespace
+
+size_t bilstm_workspace_bytes(const rulgnn_bilstm_shape* s) {
+    LstmGeom g;
+    if (lstm_geometry(s, &g) != RULGNN_OK) return 0;
+    return (size_t)g.total * sizeof(float);
+}
+
+#define LS_RC(call)                        \
+    do {                                   \
+        const int rc_ = (call);            \
+        if (rc_ != RULGNN_OK) return rc_;  \
+    } while (0)
+
+int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st) {
+    LstmGeom g;
+    LS_RC(lstm_geometry(s, &g));
+    if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
+    float* ws = static_cast<float*>(a->workspace);
+    (void)hipGetLastError();
+    const int R = (int)g.rows;
+    // input projections of both directions: gi[dir] = x W_ih[dir]^T   ([rows, I] x [I, 4H])
+    for (int d = 0; d < 2; ++d)
+        LS_RC(sgemm(a->x, g.I, 1, a->w_ih[d], g.I, 1, ws + g.o_gi + (int64_t)d * g.rows * g.H4, g.H4, R, g.H4, g.I, false, st));
+    const int threads = (g.H4 + 63) & ~63;
+    if (g.H <= 64)
+        hipLaunchKernelGGL(lstm_forward_kernel<64>, dim3(2 * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
+                           a->w_hh[1], a->b_ih[0], a->b_hh[0], a->b_ih[1], a->b_hh[1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
+                           ws + g.o_hprev);
+    else
+        hipLaunchKernelGGL(lstm_forward_kernel<128>, dim3(2 * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
+                           a->w_hh[1], a->b_ih[0], a->b_hh[0], a->b_ih[1], a->b_hh[1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
+                           ws + g.o_hprev);
+    hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st) {
+    LstmGeom g;
+    LS_RC(lstm_geometry(s, &g));
+    if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
+    float* ws = static_cast<float*>(a->workspace);
+    (void)hipGetLastError();
+    const int R = (int)g.rows, H = g.H, H4 = g.H4, I = g.I;
+    const int threads = (H4 + 63) & ~63;
+    if (H <= 64)
+        hipLaunchKernelGGL(lstm_backward_kernel<64>, dim3(2 * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[1],
+                           (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
+    else
+        hipLaunchKernelGGL(lstm_backward_kernel<128>, dim3(2 * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[1],
+                           (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
+    float* one = ws + g.o_one;
+    float* split = ws + g.o_split;
+    hipLaunchKernelGGL(lstm_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
+    for (int d = 0; d < 2; ++d) {
+        const float* dg = ws + g.o_dgates + (int64_t)d * g.rows * H4;
+        // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db = column sums ; dx (+)= dG W_ih
+        LS_RC(sgemm_splitk(dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R, false, split, st));
+        LS_RC(sgemm_splitk(dg, 1, H4, ws + g.o_hprev + (int64_t)d * g.rows * H, 1, H, a->dw_hh[d], H, H4, H, R, false, split, st));
+        LS_RC(sgemm_splitk(one, 0, 0, dg, 1, H4, a->db_ih[d], H4, 1, H4, R, false, split, st));
+        hipLaunchKernelGGL(lstm_copy_kernel, dim3((H4 + 255) / 256), dim3(256), 0, st, (const float*)a->db_ih[d], a->db_hh[d], H4);
+        if (a->dx) LS_RC(sgemm(dg, H4, 1, a->w_ih[d], 1, I, a->dx, I, R, I, H4, d == 1, st));
+    }
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+}  // namespace rulgnn

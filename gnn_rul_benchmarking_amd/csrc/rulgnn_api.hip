@@ -411,4 +411,25 @@ int rulgnn_hagcn_graph_backward_f32(const rulgnn_hagcn_shape* shape, const rulgn
     return hagcn_graph_backward(shape, a, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- bidirectional LSTM layer (HAGCN encoder) ---------------------------------------------------------------
+size_t rulgnn_bilstm_workspace_bytes(const rulgnn_bilstm_shape* shape) { return bilstm_workspace_bytes(shape); }
+
+int rulgnn_bilstm_forward_f32(const rulgnn_bilstm_shape* shape, const rulgnn_bilstm_args* a, void* stream) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    const int rc = check_ptrs({a->x, a->w_ih[0], a->w_ih[1], a->w_hh[0], a->w_hh[1], a->b_ih[0], a->b_ih[1], a->b_hh[0], a->b_hh[1],
+                               a->out, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    return bilstm_forward(shape, a, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_bilstm_backward_f32(const rulgnn_bilstm_shape* shape, const rulgnn_bilstm_args* a, void* stream) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    const int rc = check_ptrs({a->x, a->w_ih[0], a->w_ih[1], a->w_hh[0], a->w_hh[1], a->dout, a->dw_ih[0], a->dw_ih[1], a->dw_hh[0],
+                               a->dw_hh[1], a->db_ih[0], a->db_ih[1], a->db_hh[0], a->db_hh[1], a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (a->dx && (reinterpret_cast<uintptr_t>(a->dx) & 3)) return RULGNN_EALIGN;
+    return bilstm_backward(shape, a, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

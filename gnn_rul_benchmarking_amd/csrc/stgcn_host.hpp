@@ -125,6 +125,9 @@ int64_t hagcn_graph_param_count(const rulgnn_hagcn_shape* s);
 size_t hagcn_workspace_bytes(const rulgnn_hagcn_shape* s);
 int hagcn_graph_forward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
 int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
+size_t bilstm_workspace_bytes(const rulgnn_bilstm_shape* s);
+int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
+int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
 int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);

@@ -1,6 +1,9 @@
 """Drop-in ``HAGCN_model``: the graph stack (cosine adjacency, three GIN + SAGPool levels with top-k node selection and the
-KL prior, node means) runs in the gfx950 HIP kernels of csrc/hagcn.hip through one autograd function; the Bi-LSTM stack in
-front of it and the two-layer ``fc`` behind it are ``torch.nn`` modules on the vendor libraries (MIOpen / rocBLAS).
+KL prior, node means) runs in the gfx950 HIP kernels of csrc/hagcn.hip through one autograd function, and each of the three
+bidirectional LSTM layers in front of it in the persistent-recurrence kernels of csrc/bilstm.hip (the reference's axis
+convention gives the LSTMs 1-5 sequences of batch*nodes = thousands of steps: a per-step-launch library RNN is slower than the
+reference's CPU there).  The ``nn.LSTM`` modules only hold the parameters; dropout, LeakyReLU and the two-layer ``fc`` are
+plain torch ops.
 
 Mirrors the reference class (models/HAGCN/Model.py:129-195): same constructor kwargs
 ``(patch_size, num_patch, encoder_hidden_dim, hidden_dim, output_dim)``, same ``forward(X, train=False)`` returning the
@@ -47,8 +50,59 @@ class SAGPool(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(input_dimension, input_dimension // 2), nn.ReLU(), nn.Linear(input_dimension // 2, 1))
 
 
+class _BiLstmSum(torch.autograd.Function):
+    """out = LSTM_forward(x) + LSTM_reverse(x) for one nn.LSTM(bidirectional=True, batch_first=True) (Model.py:58-61)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        if not x.is_cuda:
+            raise RuntimeError("the bidirectional LSTM layers run on the HIP kernels only: tensors must be on a CUDA (ROCm) device")
+        x = x.contiguous().float()
+        Bq, T, I = x.shape
+        H = w_hh.shape[1]
+        shp = _lib.BilstmShape(T, Bq, I, H)
+        nbytes = _lib.load().rulgnn_bilstm_workspace_bytes(C.byref(shp))
+        if nbytes == 0:
+            raise RuntimeError("bidirectional LSTM kernels do not cover this configuration (hidden <= 128, <= 64 sequences)")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty(Bq, T, H, dtype=torch.float32, device=x.device)
+        a = _lib.BilstmArgs()
+        a.x, a.out = x.data_ptr(), out.data_ptr()
+        for d, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+            a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = wi.data_ptr(), wh.data_ptr(), bi.data_ptr(), bh.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        _lib.check(_lib.load().rulgnn_bilstm_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_bilstm_forward_f32")
+        ctx.save_for_backward(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        ctx.ws, ctx.shp = ws, (T, Bq, I, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r = ctx.saved_tensors
+        T, Bq, I, H = ctx.shp
+        shp = _lib.BilstmShape(T, Bq, I, H)
+        dout = dout.contiguous().float()
+        grads = [torch.empty_like(t) for t in (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        a = _lib.BilstmArgs()
+        a.x, a.dout, a.dx = x.data_ptr(), dout.data_ptr(), dx.data_ptr() if dx is not None else None
+        for d, (wi, wh) in enumerate(((w_ih, w_hh), (w_ih_r, w_hh_r))):
+            a.w_ih[d], a.w_hh[d] = wi.data_ptr(), wh.data_ptr()
+            a.dw_ih[d], a.dw_hh[d], a.db_ih[d], a.db_hh[d] = (grads[4 * d].data_ptr(), grads[4 * d + 1].data_ptr(),
+                                                              grads[4 * d + 2].data_ptr(), grads[4 * d + 3].data_ptr())
+        a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
+        _lib.check(_lib.load().rulgnn_bilstm_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_bilstm_backward_f32")
+        return (dx, *grads)
+
+
+def bilstm_sum(lstm: nn.LSTM, x):
+    """The two halves of a bidirectional ``nn.LSTM`` output, summed -- on the persistent-recurrence kernels."""
+    return _BiLstmSum.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, lstm.weight_ih_l0_reverse,
+                            lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
+
+
 class Bi_LSTM_Standard(nn.Module):
-    """The reference's LSTM stack (Model.py:26-73), executed by torch (MIOpen on ROCm)."""
+    """The reference's LSTM stack (Model.py:26-73); the nn.LSTM modules hold the parameters, csrc/bilstm.hip runs them."""
 
     def __init__(self, input_dim, num_hidden, time_length):
         super().__init__()
@@ -63,15 +117,9 @@ class Bi_LSTM_Standard(nn.Module):
         self.drop3 = nn.Dropout(p=0.2)
 
     def forward(self, x):
-        x, _ = self.bi_lstm1(x)
-        a, b = torch.split(x, x.shape[2] // 2, 2)
-        x = a + b
-        x, _ = self.bi_lstm2(x)
-        a, b = torch.split(x, x.shape[2] // 2, 2)
-        x = self.drop2(a + b)
-        x2, _ = self.bi_lstm3(x)
-        a, b = torch.split(x2, x2.shape[2] // 2, 2)
-        return F.leaky_relu(self.drop3(a + b))
+        x = bilstm_sum(self.bi_lstm1, x)
+        x = self.drop2(bilstm_sum(self.bi_lstm2, x))
+        return F.leaky_relu(self.drop3(bilstm_sum(self.bi_lstm3, x)))
 
 
 GRAPH_LEAVES = ("eps", "mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias")

@@ -393,6 +393,37 @@ size_t rulgnn_hagcn_workspace_bytes(const rulgnn_hagcn_shape *shape);
 int rulgnn_hagcn_graph_forward_f32(const rulgnn_hagcn_shape *shape, const rulgnn_hagcn_args *args, void *stream);
 int rulgnn_hagcn_graph_backward_f32(const rulgnn_hagcn_shape *shape, const rulgnn_hagcn_args *args, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Bidirectional LSTM layer with summed halves: out = LSTM_forward(x) + LSTM_backward(x)
+ * (reference Bi_LSTM_Standard, models/HAGCN/Model.py:58-61,64-66: nn.LSTM(bidirectional=True, batch_first=True) followed by
+ * split + add; torch gate order i, f, g, o; h0 = c0 = 0).  HAGCN calls it with num_seq = num_patch and
+ * seq_len = batch_size * num_node (Model.py:153-157): a few very long sequences -- one persistent workgroup per
+ * (direction, sequence) runs the whole recurrence without per-step launches.
+ * Tensors: x [num_seq, seq_len, input_dim]; w_ih[d] [4H, input_dim]; w_hh[d] [4H, H]; b_ih[d], b_hh[d] [4H] (d = 0 forward,
+ * 1 reverse: torch's *_l0 and *_l0_reverse); out, dout [num_seq, seq_len, H]; gradients in the shapes of their tensors.
+ */
+typedef struct rulgnn_bilstm_shape {
+    int64_t seq_len;
+    int32_t num_seq;          /* <= 64 */
+    int32_t input_dim;        /* <= 1024 */
+    int32_t hidden_dim;       /* H <= 128 */
+} rulgnn_bilstm_shape;
+
+typedef struct rulgnn_bilstm_args {
+    const float *x;
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];
+    float *out;               /* forward out */
+    const float *dout;        /* backward in */
+    float *dx;                /* backward out; may be NULL (first layer) */
+    float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
+    void *workspace;          /* carries the tape (gates, cell states) from forward to backward */
+    size_t workspace_bytes;
+} rulgnn_bilstm_args;
+
+size_t rulgnn_bilstm_workspace_bytes(const rulgnn_bilstm_shape *shape);     /* 0: invalid / unsupported */
+int rulgnn_bilstm_forward_f32(const rulgnn_bilstm_shape *shape, const rulgnn_bilstm_args *args, void *stream);
+int rulgnn_bilstm_backward_f32(const rulgnn_bilstm_shape *shape, const rulgnn_bilstm_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ def build(cfg, seed):
     return m
 
 
-def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False):
+def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False, keep_td_grads=False):
     m = build(cfg, seed)
     g = torch.Generator().manual_seed(seed + 7)
     x = torch.rand(bs, num_node, cfg["patch_size"] * cfg["num_patch"], generator=g) * (hi - lo) + lo
@@ -99,7 +99,7 @@ def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False):
     out["train_kl"] = np.float64(kl.item())
     out["train_loss"] = np.float64(loss.item())
     for n_, p in m.named_parameters():
-        if not n_.startswith("TD."):                       # the LSTM gradients belong to the delegated library path
+        if keep_td_grads or not n_.startswith("TD."):      # LSTM gradients: kept in the small-LSTM fixture only
             out["grad:" + n_] = p.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("wrote", name, out["eval_pred"].ravel()[:3], "kl", out["train_kl"], "loss", out["train_loss"])
@@ -126,4 +126,7 @@ if __name__ == "__main__":
     case("hagcn_fd002_2x25_bs5", dict(patch_size=25, num_patch=2, **dims), 5, 14, seed=62)
     case("hagcn_fd004_1x50_bs7", dict(patch_size=50, num_patch=1, **dims), 7, 14, seed=63)
     case("hagcn_ncmapss_2x25_bs3", dict(patch_size=25, num_patch=2, **dims), 3, 20, seed=64, lo=-1.0, hi=1.0)
+    # a narrow LSTM stack (hidden 8 / 16 / 8) so that its weights AND gradients fit a small fixture: pins the BPTT of the oracle
+    case("hagcn_smalllstm_3x6_bs4", dict(patch_size=6, num_patch=3, hidden_dim=16, encoder_hidden_dim=8, output_dim=4), 4, 12, seed=66,
+         keep_td=True, keep_td_grads=True)
     case_init("hagcn_init_fd004_seed65", dict(patch_size=50, num_patch=1, **dims), 65)

@@ -142,3 +142,47 @@ def test_algorithm_update_trains():
         assert algo.model(x).shape == (40, 1)
     sd = algo.state_dict()
     assert len(sd) == 67 and all(k.startswith("model.") for k in sd)
+
+
+@pytest.mark.parametrize("Bq,T,I,H", [(3, 48, 6, 8), (5, 1400, 10, 60), (2, 700, 60, 120), (1, 33, 50, 60), (4, 9, 7, 5)])
+def test_persistent_bilstm_layer_matches_oracle(Bq, T, I, H):
+    """Forward and BPTT of one summed bidirectional layer (csrc/bilstm.hip) vs the numpy oracle, incl. the reference's
+    long-sequence shapes (1 400 steps = batch 100 x 14 nodes)."""
+    from gnn_rul_benchmarking_amd.hagcn import bilstm_sum
+    rng = np.random.default_rng(T + H)
+    lstm = torch.nn.LSTM(I, H, 1, batch_first=True, bidirectional=True).to(DEV)
+    p = {"L." + k: v.detach().cpu().numpy().astype(np.float64) for k, v in lstm.state_dict().items()}
+    x = rng.normal(size=(Bq, T, I))
+    w = rng.normal(size=(Bq, T, H))
+    xt = torch.from_numpy(x.astype(np.float32)).to(DEV).requires_grad_(True)
+    out = bilstm_sum(lstm, xt)
+    ref = O.bilstm_sum(x, p, "L")
+    assert rel(out.detach().cpu().numpy(), ref) < TOL
+    (out * torch.from_numpy(w.astype(np.float32)).to(DEV)).sum().backward()
+    dx, grads = O.bilstm_sum_backward(x, p, "L", w)
+    assert rel(xt.grad.cpu().numpy(), dx) < GTOL
+    for k, v in lstm.named_parameters():
+        assert rel(v.grad.cpu().numpy(), grads["L." + k]) < GTOL, k
+
+
+def test_lstm_stack_gradients_match_reference_golden():
+    """The three-layer stack through the persistent kernels: LSTM parameter gradients vs the reference's autograd
+    (small-LSTM fixture), with the reference's d loss / d nodes fed in."""
+    z, _ = load_case("hagcn_smalllstm_3x6_bs4")
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    m = HAGCN_model(**cfg_of(z))
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")})
+    m = m.to(DEV).train()
+    for d in (m.TD.drop1, m.TD.drop2, m.TD.drop3):
+        d.p = 0.0
+    x = torch.from_numpy(z["x"]).to(DEV)
+    bs, N = x.size(0), x.size(1)
+    ps, npatch = int(z["cfg:patch_size"]), int(z["cfg:num_patch"])
+    v = x.reshape(bs, N, npatch, ps).transpose(1, 2).transpose(1, 2).reshape(bs * N, npatch, ps).transpose(1, 0)
+    td = m.TD(v)
+    nodes = td.transpose(1, 0).reshape(bs, N, npatch, -1).transpose(1, 2).reshape(bs * npatch, N, -1)
+    assert rel(nodes.detach().cpu().numpy(), z["nodes"]) < TOL
+    nodes.backward(torch.from_numpy(z["grad_nodes"]).to(DEV))
+    for k, p in m.named_parameters():
+        if k.startswith("TD."):
+            assert rel(p.grad.cpu().numpy(), z["grad:" + k]) < GTOL, k
