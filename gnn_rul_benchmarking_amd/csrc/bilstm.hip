@@ -63,7 +63,7 @@ __device__ inline float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
 // forward recurrence: workgroup = (direction, sequence); thread j < 4H owns gate row j of W_hh
 // ---------------------------------------------------------------------------------------------------
 template <int HMAX>
-__global__ void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
+__global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
                                     const float* __restrict__ w_hh1, const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
                                     const float* __restrict__ b_ih1, const float* __restrict__ b_hh1, float* __restrict__ gates,
                                     float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev) {
@@ -123,7 +123,7 @@ __global__ void lstm_sum_kernel(LstmGeom g, const float* __restrict__ hseq, floa
 // BPTT: thread tid < 4H = (part p, unit k) keeps W_hh[p*H + :, k] in registers
 // ---------------------------------------------------------------------------------------------------
 template <int HMAX>
-__global__ void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
+__global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
                                      const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ dout,
                                      float* __restrict__ dgates) {
     __shared__ __attribute__((aligned(16))) float dgl[4 * HMAX];
