@@ -120,7 +120,65 @@ def case_init(name, cfg, seed):
     print("wrote", name, len(sd), "keys")
 
 
+def case_trainer_cmapss(name, seed, n_train=250, n_test=80, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method HAGCN on the synthetic C-MAPSS FD004 dataset of
+    synth.py, its own hparams (configs/hparams.py:140,159: batch 100, lr 1e-3, wd 1e-4, alpha 100, one patch of 50) and its
+    shuffling DataLoader.  num_epochs is patched and the algorithm class handed to the trainer switches the LSTM-stack dropout
+    off after construction (torch's Bernoulli stream cannot be reproduced elsewhere)."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from algorithms.algorithms import get_algorithm_class
+    from synth import synthetic_cmapss
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    base = get_algorithm_class("HAGCN")
+
+    class NoDropout(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            for d in (self.model.TD.drop1, self.model.TD.drop2, self.model.TD.drop3):
+                d.p = 0.0
+    NoDropout.__name__ = "HAGCN"
+    _orig_get = ref_trainer.get_algorithm_class
+    ref_trainer.get_algorithm_class = lambda n: NoDropout if n == "HAGCN" else _orig_get(n)
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "CMAPSS", "FD004")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="HAGCN", data_path=os.path.join(tmp, "data"), dataset="CMAPSS",
+                                      dataset_id="FD004", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+            ref_trainer.get_algorithm_class = _orig_get
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_cmapss("hagcn_trainer_cmapss_fd004_reference_run", 8)
+        sys.exit(0)
     dims = dict(hidden_dim=64, encoder_hidden_dim=60, output_dim=32)
     case("hagcn_fd001_5x10_bs6", dict(patch_size=10, num_patch=5, **dims), 6, 14, seed=61, keep_td=True)
     case("hagcn_fd002_2x25_bs5", dict(patch_size=25, num_patch=2, **dims), 5, 14, seed=62)
@@ -130,3 +188,4 @@ if __name__ == "__main__":
     case("hagcn_smalllstm_3x6_bs4", dict(patch_size=6, num_patch=3, hidden_dim=16, encoder_hidden_dim=8, output_dim=4), 4, 12, seed=66,
          keep_td=True, keep_td_grads=True)
     case_init("hagcn_init_fd004_seed65", dict(patch_size=50, num_patch=1, **dims), 65)
+    case_trainer_cmapss("hagcn_trainer_cmapss_fd004_reference_run", 8)

@@ -283,3 +283,55 @@ def test_fcstgnn_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monke
         if k.startswith("final:"):
             a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
             assert np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30) < 3e-3, k
+
+
+def test_hagcn_trainer_runs_the_reference_protocol_on_cmapss(tmp_path, monkeypatch):
+    """--GNN_method HAGCN on C-MAPSS FD004 (configs/hparams.py:140,159), reference harness on CPU vs this package's on the GPU,
+    LSTM-stack dropout off on both sides.  Unlike the other models this one cannot be matched step for step: its top-k node
+    selection is decided by fp32 rounding noise, so two implementations keep different -- equally valid --
+    nodes from the first step on, and Adam amplifies that: perturbing the inputs of THIS package's run by 1e-7 moves its epoch-2
+    test RMSE from 44.7 to 67.8 cycles (measured).  Single-step parity is covered in test_hagcn_gpu.py; here the
+    harness must run the reference's protocol end to end and land in the same regime after the first epoch."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_cmapss
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "hagcn_trainer_cmapss_fd004_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "CMAPSS" / "FD004"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    base = T.get_algorithm_class("HAGCN")
+
+    class NoDropout(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            for dr in (self.model.TD.drop1, self.model.TD.drop2, self.model.TD.drop3):
+                dr.p = 0.0
+    monkeypatch.setattr(T, "get_algorithm_class", lambda n: NoDropout)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="HAGCN", data_path=str(tmp_path / "data"), dataset="CMAPSS",
+                              dataset_id="FD004", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.train_configs["alpha"] == 100 and tr.model_configs["patch_size"] == 50
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("HAGCN harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.isfinite(got).all()
+    assert abs(got[0, 3] - ref[0, 3]) / ref[0, 3] < 0.2                     # after 3 steps: same regime as the reference (8 % measured)
+    assert got[1:, 3].max() < 0.5 * got[0, 3]                               # and it trains: RMSE drops like the reference's (365 -> 45 -> 34)
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "HAGCN_run_0" / "results.csv")
+    assert list(csv.columns) == ["Score_v1", "Score_v2", "MAE", "RMSE"]
