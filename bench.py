@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true", help="loss.item() every step like the reference")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel step even for world_size 1 (exercises RCCL)")
+    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN"],
+                    help="ST_GCN (default) is the headline benchmark; the others run the same contract on the SURVEY section 8d "
+                         "configuration of that model family")
     return ap.parse_args()
 
 
@@ -173,6 +176,114 @@ def cpu_baseline(num_patch, patch_size, dropout, budget_s=12.0):
             "host_cpus": os.cpu_count()}
 
 
+# SURVEY section 8d measurement configurations of the other hot-path families: (dataset, id, per-GPU batch, input shape,
+# forward matmul/conv FLOPs per sample as counted there)
+FAMILY_CONFIGS = {
+    "ASTGCNN": ("NCMAPSS", None, 512, (20, 50), 1.22e6),
+    "FC_STGNN": ("CMAPSS", "FD004", 256, (14, 50), 3.28e6),
+    "HAGCN": ("CMAPSS", "FD004", 256, (14, 50), 0.99e6 + 8.7e6),
+    "STMSGCN": ("XJTU_SY", "Condition_1", 128, (1, 32768), 185e6),
+}
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
+
+
+def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
+    """The family's numpy oracle (train-step restatement) timed on this box's host cores, bounded sample."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    if family == "ASTGCNN":
+        from oracle import astgcnn_oracle as O
+        p = O.random_params(cfg["num_nodes"], cfg["time_length"], cfg["output_dim"], cfg["K"])
+        bs = 64
+        x, y = rng.uniform(-1, 1, (bs,) + shape), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y)
+    elif family == "FC_STGNN":
+        from oracle import fcstgnn_oracle as O
+        c = O.Config(**cfg)
+        p = O.random_params(c)
+        bs = 32
+        x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, c)
+    elif family == "STMSGCN":
+        from oracle import stmsgcn_oracle as O
+        c = O.Config(cfg["num_patch"], cfg["patch_size"], cfg["interval"], cfg["band_width"], cfg["gcn_dims"], cfg["gru_hidden_dim"])
+        p = O.random_params(c)
+        bs = 2
+        x, y = rng.uniform(0, 1, (bs, shape[1])), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, c)
+    else:
+        return None                    # HAGCN: the oracle restates forward + per-block backward, not one timed train step
+    run()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s and n < 50:
+        run()
+        n += 1
+    el = time.perf_counter() - t0
+    return {"value": round(bs * n / el, 2), "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{n} train steps (forward + loss + backward, no optimizer) of oracle/{family.lower()}_oracle.py, batch {bs}, fp64, "
+                      f"numpy with its BLAS threads"}
+
+
+def family_main(args, world, rank, dev, use_dist, dist):
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    from gnn_rul_benchmarking_amd.dp import DataParallel
+    from gnn_rul_benchmarking_amd import hparams as HP
+    ds, did, B, shape, fwd_flops = FAMILY_CONFIGS[args.family]
+    if args.batch != 65536:
+        B = args.batch
+    hp = HP.get_hparams_class(ds)(did)
+    cfg, train_cfg = hp.alg_hparams[args.family], hp.train_params[args.family]
+    torch.manual_seed(0)
+    algo = get_algorithm_class(args.family)(cfg, train_cfg, dev)
+    algo.to(dev)
+    algo.train()
+    algo.sync_loss = bool(args.sync_loss)
+    replicas = args.family == "HAGCN"                  # its LSTM recurs along batch*nodes: not sample-shardable
+    if use_dist and not replicas:
+        algo.attach_data_parallel(DataParallel())
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    Xs = [torch.rand(B, *shape, device=dev, generator=g) for _ in range(2)]
+    ys = [torch.rand(B, 1, device=dev, generator=g) for _ in range(2)]
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    last = None
+    for i in range(args.warmup):
+        last = algo.update(Xs[i % 2], ys[i % 2], 1)["loss"]
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = algo.update(Xs[i % 2], ys[i % 2], 1)["loss"]
+    sync()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    rate = world * B * args.steps / el
+    tf = 3.0 * fwd_flops * rate / 1e12
+    out = {"metric": f"training samples/sec, {args.family} ({ds} {did or ''} wiring)".replace("  ", " "), "value": round(rate, 1),
+           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.family}.update (fwd+loss+bwd+Adam), input [{B}, {shape[0]}, {shape[1]}], hparams {cfg}",
+                      "per_gpu_batch": B, "global_batch": world * B,
+                      "parallelism": f"replicas{world}" if replicas else f"dp{world}"},
+           "final_loss": round(float(last), 6),
+           "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                        "note": "whole step: 3 x SURVEY section 8d forward FLOPs per sample x samples/s (not one kernel)"}}
+    if world == 1 and not args.no_cpu_baseline:
+        cb = family_cpu_baseline(args.family, cfg, shape)
+        if cb:
+            out["cpu_baseline"] = cb
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,6 +310,13 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
+
+    if args.family != "ST_GCN":
+        family_main(args, world, rank, dev, use_dist, dist)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
     from gnn_rul_benchmarking_amd.dp import DataParallel

@@ -66,12 +66,20 @@ struct TrainK {
     int has_dpred;        // 1: gy is d(loss)/d(pred); 0: gy is y (MSE); 2: neither (forward only)
     float dropout_p, drop_scale;
     uint32_t drop_thr;
-    uint32_t drop_key[8];
-    const uint32_t* keys_dev;   // device step state: per-layer keys written by step_prepare_dropout (else drop_key[])
     int pcount;
 };
 
-__device__ __forceinline__ uint32_t drop_key_of(const TrainK& a, int l) { return a.keys_dev ? a.keys_dev[l] : a.drop_key[l]; }
+// Per-step scalars that change from step to step live in the workspace right behind the loss cell (8 doubles), written by
+// stgcn_prepare_kernel at the head of the step -- not in the kernel arguments: that keeps the argument block small (the
+// phase kernels are SGPR-bound) and lets a captured hipGraph replay with fresh values.
+struct StepScratch {
+    uint32_t drop_key[8];
+    float lr_over_bc1, inv_sqrt_bc2;
+    uint32_t pad[6];
+};
+__device__ __forceinline__ const StepScratch* step_scratch(const double* cell_loss) {
+    return reinterpret_cast<const StepScratch*>(cell_loss + 8);
+}
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -185,6 +193,11 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
     const int N = a.N, LS = layer_stride(N);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int srow = lane / RW, t = lane % RW;
+    // dropout keys, read ONCE from the step scratch (kept out of the tile loops: the compiler will not hoist a load through a
+    // plain pointer)
+    uint32_t dkey[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) dkey[l] = step_scratch(a.cell_loss)->drop_key[l];
 
     // Which layer does this kernel work in, and where does its forward start?
     //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
@@ -353,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 const bool pass = o1 > 0.f && x1 > 0.f && valid;
                 ps[c * 64] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, lq));
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                     const float xh = ps[c * 64];
                     float g = dX;
                     if (a.dropout_p > 0.f) {
-                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, lq));
+                        const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
                         g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                     }
                     const bool pass = xh < INFINITY;
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 o1v[c] = relu(x1v[c] + o0[c]);
                 float o1 = o1v[c];
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[LY]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 rb[c * 64] = dX;
                 float g = dX;
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[LY]);
                     g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                 }
                 const float dy = (o1v[c] > 0.f && x1v[c] > 0.f && valid) ? g : 0.f;
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 const float o1 = relu(x1 + o0[c]);
                 float g = rb[c * 64];                                               // d X_{l+1}
                 if (a.dropout_p > 0.f) {
-                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ drop_key_of(a, LY));
+                    const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[LY]);
                     g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
                 }
                 g = (o1 > 0.f && valid) ? g : 0.f;
@@ -710,17 +723,13 @@ struct FinalizeK {
     float* exp_avg;
     float* exp_avg_sq;
     float* bn_running;
-    float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, bn_momentum;
+    float beta1, beta2, eps, weight_decay, bn_momentum;
     int fused_opt;
-    const StepState* state;   // device step state: Adam bias corrections come from here when non-null
 };
 
 __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
-    if (f.state) {
-        f.lr_over_bc1 = f.state->lr_over_bc1;
-        f.inv_sqrt_bc2 = f.state->inv_sqrt_bc2;
-    }
+    const float lr_over_bc1 = step_scratch(f.cell_loss)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cell_loss)->inv_sqrt_bc2;
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nw = (gridDim.x * blockDim.x) >> 6;
@@ -759,7 +768,7 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
                     const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
                     f.exp_avg[p] = mi;
                     f.exp_avg_sq[p] = vi;
-                    f.params[p] = pi - f.lr_over_bc1 * (mi / (sqrtf(vi) * f.inv_sqrt_bc2 + f.eps));
+                    f.params[p] = pi - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + f.eps));
                 }
             }
         }
@@ -827,7 +836,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
-    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
+    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8) + sizeof(StepScratch);
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
@@ -942,11 +951,29 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
         const uint64_t ti = (uint64_t)(thr + 0.5);
         k.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
     }
-    for (int l = 0; l < 8; ++l) k.drop_key[l] = l < L ? dropout_layer_key(a->seed, a->step, l) : 0u;
-    k.keys_dev = a->step_state ? static_cast<const StepState*>(a->step_state)->drop_key : nullptr;
     k.pcount = param_count(N, L);
     k.wave_area_floats = 0;
     return RULGNN_OK;
+}
+
+// Head of every step: clears the reduction cells (what a memset did before) and writes the step scratch -- dropout keys of
+// (seed, step) and, for the fused optimizer, Adam's bias corrections.  With a device step state the counters are advanced and
+// read there (hipGraph replay), else they come from the arguments.
+__global__ void stgcn_prepare_kernel(double* zero_from, int nzero, StepScratch* sc, StepState* st, uint64_t seed, uint64_t step,
+                                     int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1, float beta2) {
+    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero_from[i] = 0.0;
+    if (threadIdx.x != 0) return;
+    if (new_forward) {
+        if (st) step = ++st->dropout_step;
+        for (int l = 0; l < 8; ++l) sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
+    }
+    if (has_adam) {
+        if (st) adam_step = ++st->adam_step;
+        const double bc1 = 1.0 - pow((double)beta1, (double)adam_step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)adam_step);
+        sc->lr_over_bc1 = (float)((double)lr / bc1);
+        sc->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
 }
 
 template <int RW, int L>
@@ -955,17 +982,25 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     int rc = RULGNN_OK;
     const float* gy = a->dpred ? a->dpred : a->y;
 
+    StepScratch* sc = reinterpret_cast<StepScratch*>(k.cell_loss + 8);
+    const bool fused_adam = opt && mode == TM_FWDBWD;
+    void* adam_state = fused_adam ? opt->step_state : nullptr;
+    if (adam_state && a->step_state && adam_state != a->step_state) return RULGNN_EINVAL;
+    StepState* st = static_cast<StepState*>(a->step_state ? a->step_state : adam_state);
+    (void)hipGetLastError();
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
-        if (a->step_state) {       // advance the dropout stream on the device (a backward-only call reuses the keys)
-            rc = step_prepare_dropout(a->step_state, a->seed, L, stream);
-            if (rc != RULGNN_OK) return rc;
-        }
-        if (hipMemsetAsync(k.cells_fwd, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        // a new forward: all cells, fresh dropout keys (a backward-only call below reuses the keys of its forward)
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells_fwd, 2 * (2 * L * 2 * F) + 8, sc,
+                           a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
+                           fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
         if (rc != RULGNN_OK) return rc;
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
-        if (hipMemsetAsync(k.cells_bwd, 0, sizeof(double) * (2 * L * 2 * F + 8), stream) != hipSuccess) return RULGNN_EHIP;
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells_bwd, 2 * L * 2 * F + 8, sc, (StepState*)nullptr,
+                           a->seed, a->step, L, 0, 0, (int64_t)0, 0.f, 0.f, 0.f);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
     int grid_top = 0;
     int grids[16] = {0};
@@ -983,20 +1018,11 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.fused_opt = 0;
-    f.state = nullptr;
     f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
-    f.lr_over_bc1 = f.inv_sqrt_bc2 = f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
-    if (opt && mode == TM_FWDBWD) {
-        const double bc1 = 1.0 - pow((double)opt->beta1, (double)opt->step);
-        const double bc2 = 1.0 - pow((double)opt->beta2, (double)opt->step);
+    f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
+    if (fused_adam) {                      // the bias corrections are in the step scratch (stgcn_prepare_kernel)
         f.fused_opt = 1;
-        if (opt->step_state) {
-            rc = step_prepare_adam(opt->step_state, opt->lr, opt->beta1, opt->beta2, stream);
-            if (rc != RULGNN_OK) return rc;
-            f.state = static_cast<const StepState*>(opt->step_state);
-        }
         f.params = opt->params; f.exp_avg = opt->exp_avg; f.exp_avg_sq = opt->exp_avg_sq; f.bn_running = opt->bn_stats;
-        f.lr_over_bc1 = (float)((double)opt->lr / bc1); f.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
         f.beta1 = opt->beta1; f.beta2 = opt->beta2; f.eps = opt->eps; f.weight_decay = opt->weight_decay;
         f.bn_momentum = opt->bn_momentum;
     }
