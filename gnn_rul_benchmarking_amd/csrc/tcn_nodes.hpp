@@ -1,0 +1,218 @@
+// The node-channel temporal convolution block shared by ASTGCNN and ST_Conv (both instantiate the reference's
+// TemporalConvNet(num_nodes, [num_nodes, num_nodes], kernel_size=6): models/ASTGCNN/Model.py:72-146, models/ST_Conv/Model.py:81-155):
+// two causal Conv1d(N -> N, k = 6, dilation 1 | 2, no bias) + BatchNorm1d(N) + ReLU blocks with residuals over [N nodes] x [T steps].
+// One sample per workgroup iteration, tile in LDS, BatchNorm sums through fp64 cells.  `Geom` provides
+// B, N, T and the parameter offsets o_w1, o_g1, o_b1, o_w2, o_g2, o_b2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rulgnn {
+namespace tcn {
+
+constexpr int AB = 256;            // threads per workgroup
+constexpr int KT = 6;              // TCN kernel size
+constexpr int MAXN = 25;           // nodes
+constexpr int MAXT = 64;
+constexpr float BN_EPS = 1e-5f;
+
+// reduction cells (fp64): forward sums [2 blocks][N][sum, sumsq], backward sums [2][N][sum dy, sum dy*xhat]
+struct Cells {
+    double fwd[2][MAXN][2];
+    double bwd[2][MAXN][2];
+};
+
+// BatchNorm scale/shift of block `blk` for channel c: y = z * sc + sh; xhat = (z - mean) * inv
+struct BnCoef {
+    float mean, inv, sc, sh;
+};
+__device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, int training, int blk, int c, int N, double count,
+                                 float gamma, float beta) {
+    BnCoef r;
+    float var;
+    if (training) {
+        const double m = cells->fwd[blk][c][0] / count;
+        double v = cells->fwd[blk][c][1] / count - m * m;
+        if (v < 0.0) v = 0.0;
+        r.mean = (float)m;
+        var = (float)v;
+    } else {
+        r.mean = bn_running[(blk * 2 + 0) * N + c];
+        var = bn_running[(blk * 2 + 1) * N + c];
+    }
+    r.inv = 1.0f / sqrtf(var + BN_EPS);
+    r.sc = gamma * r.inv;
+    r.sh = beta - r.mean * r.sc;
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
+// One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
+// ---------------------------------------------------------------------------------------------------
+template <int STAGE, typename Geom>
+static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                     const float* __restrict__ bn_running, int training, const float* __restrict__ z1,
+                                                     float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
+    constexpr int D = STAGE == 1 ? 1 : 2;
+    constexpr int PADL = (KT - 1) * D;
+    __shared__ float w[MAXN * MAXN * KT];
+    __shared__ float xs[MAXN][MAXT + PADL];
+    __shared__ float zs[MAXN][MAXT + 1];
+    __shared__ BnCoef co1[MAXN];
+    const int N = g.N, T = g.T, tid = threadIdx.x;
+    const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
+    for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
+    for (int e = tid; e < N * PADL; e += AB) xs[e / PADL][e % PADL] = 0.f;
+    if (STAGE == 2 && tid < N)
+        co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.B * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
+    float s1 = 0.f, s2 = 0.f;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        const float* xb = x + b * N * T;
+        for (int e = tid; e < N * T; e += AB) {
+            const int c = e / T, t = e - c * T;
+            float v = xb[e];
+            if (STAGE == 2) {
+                const float y = fmaf(z1[b * N * T + e], co1[c].sc, co1[c].sh);
+                v = fmaxf(fmaxf(y, 0.f) + v, 0.f);
+                out0[b * N * T + e] = v;
+            }
+            xs[c][PADL + t] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < N * T; e += AB) {
+            const int co = e / T, t = e - co * T;
+            float a = 0.f;
+            for (int ci = 0; ci < N; ++ci) {
+                const float* wr = w + (co * N + ci) * KT;
+                const float* xr = &xs[ci][t + PADL - (KT - 1) * D];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) a = fmaf(wr[k], xr[k * D], a);
+            }
+            zout[b * N * T + e] = a;
+            zs[co][t] = a;
+        }
+        __syncthreads();
+        if (training && tid < N) {
+            for (int t = 0; t < T; ++t) {
+                const float v = zs[tid][t];
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+        }
+        __syncthreads();
+    }
+    if (training && tid < N) {
+        atomicAdd(&cells->fwd[STAGE - 1][tid][0], (double)s1);
+        atomicAdd(&cells->fwd[STAGE - 1][tid][1], (double)s2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv backward.  STAGE 2: dz2 = BN2'(dy2); dW2 += dz2 (*) out0; dout0 = ds1 + conv2^T(dz2); ds0 = dout0 [out0 > 0];
+// dy1 = ds0 [bn1(z1) > 0]; BN1 backward sums.   STAGE 1: dz1 = BN1'(dy1); dW1 += dz1 (*) x.
+// Weight-gradient accumulators are thread-owned registers (fixed order), one partial row per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int STAGE, typename Geom>
+static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
+                                                         const float* __restrict__ zin, const float* __restrict__ dyin,
+                                                         const float* __restrict__ src, const float* __restrict__ ds1,
+                                                         const float* __restrict__ z1, float* __restrict__ dy1,
+                                                         float* __restrict__ gpart) {
+    constexpr int D = STAGE == 1 ? 1 : 2;
+    constexpr int PAD = (KT - 1) * D;
+    constexpr int NACC = (MAXN * MAXN * KT + AB - 1) / AB;
+    __shared__ float w[MAXN * MAXN * KT];
+    __shared__ float xs[MAXN][MAXT + PAD];        // conv input (x or out0), left-padded with zeros
+    __shared__ float dz[MAXN][MAXT + PAD];        // d z, right-padded with zeros
+    __shared__ float sy[MAXN][MAXT + 1];
+    __shared__ float sx[MAXN][MAXT + 1];
+    __shared__ BnCoef cz[MAXN], c1[MAXN];
+    __shared__ float bsum[MAXN][2];
+    const int N = g.N, T = g.T, tid = threadIdx.x, blk = STAGE - 1;
+    const double count = (double)g.B * T;
+    const int nW = N * N * KT;
+    if (STAGE == 2)
+        for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_w2 + e];
+    for (int e = tid; e < N * PAD; e += AB) {
+        xs[e / PAD][e % PAD] = 0.f;
+        dz[e / PAD][T + e % PAD] = 0.f;
+    }
+    if (tid < N) {
+        cz[tid] = bn_coef(cells, nullptr, 1, blk, tid, N, count, prm[(STAGE == 1 ? g.o_g1 : g.o_g2) + tid],
+                          prm[(STAGE == 1 ? g.o_b1 : g.o_b2) + tid]);
+        if (STAGE == 2) c1[tid] = bn_coef(cells, nullptr, 1, 0, tid, N, count, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
+        bsum[tid][0] = (float)(cells->bwd[blk][tid][0] / count);
+        bsum[tid][1] = (float)(cells->bwd[blk][tid][1] / count);
+    }
+    float acc[NACC];
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
+    float a1 = 0.f, a2 = 0.f;
+    __syncthreads();
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int e = tid; e < N * T; e += AB) {
+            const int c = e / T, t = e - c * T;
+            const int64_t idx = b * N * T + e;
+            const float xh = (zin[idx] - cz[c].mean) * cz[c].inv;
+            dz[c][t] = cz[c].sc * (dyin[idx] - bsum[c][0] - xh * bsum[c][1]);
+            xs[c][PAD + t] = src[idx];
+        }
+        __syncthreads();
+        // d W[co][ci][k] += sum_t dz[co][t] * in[ci][t - (KT-1-k) D]
+#pragma unroll
+        for (int r = 0; r < NACC; ++r) {
+            const int e = tid + r * AB;
+            if (e < nW) {
+                const int k = e % KT, ci = (e / KT) % N, co = e / (KT * N);
+                const float* xr = &xs[ci][PAD - (KT - 1 - k) * D];
+                float a = 0.f;
+                for (int t = 0; t < T; ++t) a = fmaf(dz[co][t], xr[t], a);
+                acc[r] += a;
+            }
+        }
+        if (STAGE == 2) {
+            // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
+            for (int e = tid; e < N * T; e += AB) {
+                const int ci = e / T, t = e - ci * T;
+                const int64_t idx = b * N * T + e;
+                float a = ds1[idx];
+                for (int co = 0; co < N; ++co) {
+                    const float* wr = w + (co * N + ci) * KT;
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) a = fmaf(wr[k], dz[co][t + (KT - 1 - k) * D], a);
+                }
+                const float o0 = xs[ci][PAD + t];
+                const float s0 = o0 > 0.f ? a : 0.f;
+                const float zz = z1[idx];
+                const float y = fmaf(zz, c1[ci].sc, c1[ci].sh);
+                const float dy = y > 0.f ? s0 : 0.f;
+                dy1[idx] = dy;
+                sy[ci][t] = dy;
+                sx[ci][t] = dy * (zz - c1[ci].mean) * c1[ci].inv;
+            }
+            __syncthreads();
+            if (tid < N)
+                for (int t = 0; t < T; ++t) {
+                    a1 += sy[tid][t];
+                    a2 += sx[tid][t];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = gpart + (int64_t)blockIdx.x * nW;
+#pragma unroll
+    for (int r = 0; r < NACC; ++r) {
+        const int e = tid + r * AB;
+        if (e < nW) dst[e] = acc[r];
+    }
+    if (STAGE == 2 && tid < N) {
+        atomicAdd(&cells->bwd[0][tid][0], (double)a1);
+        atomicAdd(&cells->bwd[0][tid][1], (double)a2);
+    }
+}
+
+
+}  // namespace tcn
+}  // namespace rulgnn
