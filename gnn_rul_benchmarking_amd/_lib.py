@@ -62,6 +62,10 @@ class AstgcnnArgs(C.Structure):
                 ("bn_moment_weight", C.c_float), ("training", C.c_int32)]
 
 
+class StconvShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("kernel_size", C.c_int32)]
+
+
 class FcstgnnShape(C.Structure):
     _fields_ = [("batch", C.c_int64)] + [(k, C.c_int32) for k in (
         "patch_size", "num_patch", "encoder_time_out", "encoder_hidden_dim", "encoder_out_dim", "encoder_conv_kernel",
@@ -137,6 +141,13 @@ _SIGNATURES = {
     "rulgnn_bilstm_workspace_bytes": (C.c_size_t, [C.POINTER(BilstmShape)]),
     "rulgnn_bilstm_forward_f32": (C.c_int, [C.POINTER(BilstmShape), C.POINTER(BilstmArgs), C.c_void_p]),
     "rulgnn_bilstm_backward_f32": (C.c_int, [C.POINTER(BilstmShape), C.POINTER(BilstmArgs), C.c_void_p]),
+    "rulgnn_stconv_param_count": (C.c_int64, [C.POINTER(StconvShape)]),
+    "rulgnn_stconv_workspace_bytes": (C.c_size_t, [C.POINTER(StconvShape)]),
+    "rulgnn_stconv_forward_f32": (C.c_int, [C.POINTER(StconvShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
+    "rulgnn_stconv_backward_f32": (C.c_int, [C.POINTER(StconvShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
+    "rulgnn_stconv_fwdbwd_f32": (C.c_int, [C.POINTER(StconvShape), C.POINTER(AstgcnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_stconv_bn_running_update_f32": (C.c_int, [C.POINTER(StconvShape), C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                                       C.c_int32, C.c_void_p]),
     "rulgnn_astgcnn_param_count": (C.c_int64, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_workspace_bytes": (C.c_size_t, [C.POINTER(AstgcnnShape)]),
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),

@@ -2,8 +2,8 @@
 algorithms/algorithms.py:29-48 does it (lookup by name in this module's globals,
 ``NotImplementedError("Algorithm not found: ...")`` otherwise).
 
-The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571), ASTGCNN (:139-163), FC_STGNN (:51-76) and HAGCN
-(:222-248) wrappers are implemented:
+The ST_GCN (reference algorithms/algorithms.py:465-490), STMSGCN (:546-571), ASTGCNN (:139-163), FC_STGNN (:51-76), HAGCN (:222-248)
+and ST_Conv (:195-220) wrappers are implemented:
 the hot paths this package accelerates.  The classes keep the reference contract -- constructor
 ``(configs, hparams, device)``, attributes ``model`` / ``optimizer`` / ``hparams`` / ``mse``,
 ``update(X, y, epoch) -> {'loss': float}`` -- so the reference's trainer can drive it unchanged."""
@@ -16,6 +16,7 @@ from .optim import FusedAdam
 from .astgcnn import ASTGCNN_model
 from .fcstgnn import FC_STGNN_RUL
 from .hagcn import HAGCN_model
+from .stconv import ST_Conv_model
 from .stgcn import ST_GCN_model
 from .stmsgcn import STMSGCN_model
 
@@ -182,6 +183,47 @@ class ASTGCNN(Algorithm):
         return {'loss': loss.item()}
 
 
+class ST_Conv(Algorithm):
+    """ST_Conv training wrapper (reference algorithms.py:195-220): ``update`` = train-mode forward + MSE + backward + Adam +
+    BatchNorm running statistics in one C call (csrc/stconv.hip + the fused Adam kernel)."""
+
+    def __init__(self, configs, hparams, device):
+        super(ST_Conv, self).__init__(configs)
+        self.model = ST_Conv_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if not self.model.training:
+            raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics)")
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        elif getattr(self, "_graphed", None) is not None:
+            loss = self._graphed.update(X, y)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return loss
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd; same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
 class FC_STGNN(Algorithm):
     """FC_STGNN training wrapper (reference algorithms.py:51-76): ``update`` = train-mode forward + MSE + backward + Adam +
     BatchNorm running statistics in one C call (csrc/fcstgnn.hip + the fused Adam kernel)."""
@@ -252,4 +294,4 @@ class HAGCN(Algorithm):
         return self._finish(loss.detach())
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "get_algorithm_class", "torch", "nn", "annotations"}

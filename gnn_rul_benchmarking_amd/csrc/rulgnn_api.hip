@@ -432,4 +432,56 @@ int rulgnn_bilstm_backward_f32(const rulgnn_bilstm_shape* shape, const rulgnn_bi
     return bilstm_backward(shape, a, static_cast<hipStream_t>(stream));
 }
 
+
+// ---- ST_Conv ------------------------------------------------------------------------------------------
+int64_t rulgnn_stconv_param_count(const rulgnn_stconv_shape* shape) { return stconv_param_count(shape); }
+size_t rulgnn_stconv_workspace_bytes(const rulgnn_stconv_shape* shape) { return stconv_workspace_bytes(shape); }
+
+static int check_stconv(const rulgnn_stconv_shape* shape, const rulgnn_astgcnn_args* a, bool forward, bool backward) {
+    if (!shape) return RULGNN_EINVAL;
+    rulgnn_astgcnn_shape probe{shape->batch, 1, 1, 1, 1};          // the argument checks do not depend on the model dimensions
+    return check_astgcnn(&probe, a, forward, backward);
+}
+
+int rulgnn_stconv_forward_f32(const rulgnn_stconv_shape* shape, const rulgnn_astgcnn_args* args, void* stream) {
+    const int rc = check_stconv(shape, args, true, false);
+    if (rc != RULGNN_OK) return rc;
+    return stconv_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stconv_backward_f32(const rulgnn_stconv_shape* shape, const rulgnn_astgcnn_args* args, void* stream) {
+    const int rc = check_stconv(shape, args, false, true);
+    if (rc != RULGNN_OK) return rc;
+    return stconv_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stconv_fwdbwd_f32(const rulgnn_stconv_shape* shape, const rulgnn_astgcnn_args* args, const rulgnn_adam_args* opt,
+                             void* stream) {
+    int rc = check_stconv(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+        if (opt->bn_stats && (!args->bn_batch || (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3))) return RULGNN_EINVAL;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = stconv_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stconv_param_count(shape), opt->step, opt->lr, opt->beta1,
+                   opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+    if (rc != RULGNN_OK || !opt->bn_stats) return rc;
+    return stconv_bn_running_update(shape, opt->bn_stats, args->bn_batch, shape->batch * (int64_t)shape->time_length, opt->bn_momentum,
+                                    args->bn_moment_weight > 0.f ? 1 : 0, st);
+}
+
+int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape* shape, float* bn_stats, const float* bn_batch, int64_t count,
+                                        float momentum, int32_t from_moments, void* stream) {
+    if (!shape || count < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({bn_stats, bn_batch});
+    if (rc != RULGNN_OK) return rc;
+    return stconv_bn_running_update(shape, bn_stats, bn_batch, count, momentum, from_moments, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -128,6 +128,11 @@ int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a
 size_t bilstm_workspace_bytes(const rulgnn_bilstm_shape* s);
 int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
 int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
+int64_t stconv_param_count(const rulgnn_stconv_shape* s);
+size_t stconv_workspace_bytes(const rulgnn_stconv_shape* s);
+int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream);
+int stconv_bn_running_update(const rulgnn_stconv_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
+                             int from_moments, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
               float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
 int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);

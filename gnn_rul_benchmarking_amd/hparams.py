@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN and HAGCN rows are restated (the methods this package
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN and ST_Conv rows are restated (the methods this package
 implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
@@ -58,6 +58,8 @@ class _Table:
             self.train_params['ASTGCNN'] = dict(_ASTGCNN_TRAIN)
             self.alg_hparams['ASTGCNN'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'encoder_out_dim': 50,
                                            'output_dim': 64, 'K': 3}
+            self.train_params['ST_Conv'] = dict(_ASTGCNN_TRAIN)            # configs/hparams.py:21,40,... : same values
+            self.alg_hparams['ST_Conv'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'kernel_size': 6}
             ps, npatch = _HAGCN_PATCH[dataset_id]
             self.train_params['HAGCN'] = dict(_HAGCN_TRAIN)
             self.alg_hparams['HAGCN'] = {'patch_size': ps, 'num_patch': npatch, 'hidden_dim': 64, 'encoder_hidden_dim': 60,

@@ -424,6 +424,39 @@ size_t rulgnn_bilstm_workspace_bytes(const rulgnn_bilstm_shape *shape);     /* 0
 int rulgnn_bilstm_forward_f32(const rulgnn_bilstm_shape *shape, const rulgnn_bilstm_args *args, void *stream);
 int rulgnn_bilstm_backward_f32(const rulgnn_bilstm_shape *shape, const rulgnn_bilstm_args *args, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ST_Conv path (reference models/ST_Conv/Model.py, algorithms/algorithms.py:195-220): the
+ * reference's natively C-MAPSS / N-CMAPSS wired spatio-temporal convolution (configs/hparams.py:40,203).
+ *
+ * x [batch, num_nodes, time_length] -> g = leaky(Linear_T->T(pcc(x) x)) -> c = relu(BN(Conv1d_same(g, k=6))) and, in
+ * parallel, t = TemporalConvNet(x) (the block of ASTGCNN) -> tanh(th1 t + th2 c) * sigmoid(th3 t + th4 c) + x ->
+ * Linear(num_nodes*time_length -> 1).  The reference evaluates both branches with the "_1" modules (Model.py:196-206);
+ * the "_2" modules are dead parameters and every BatchNorm runs twice per training forward.
+ *
+ * Flat parameter buffer: theta1..4 [4] | gcn_layer_1.theta.0.weight[T][T] | .bias[T] | cnn_layer_1.conv.weight[N][N][6] |
+ *   .bias[N] | cnn_layer_1.bn.weight[N] | .bias[N] | tcn conv_block1.0.weight[N][N][6] | bn1.weight | bn1.bias |
+ *   conv_block2.0.weight | bn2.weight | bn2.bias | fc.weight[N*T] | fc.bias[1]
+ * BatchNorm buffer: [3 (tcn conv_block1, tcn conv_block2, cnn)][2 (mean, var)][N].
+ * The argument struct is rulgnn_astgcnn_args (same fields, same meaning).
+ */
+typedef struct rulgnn_stconv_shape {
+    int64_t batch;
+    int32_t num_nodes;        /* N <= 25 */
+    int32_t time_length;      /* T <= 64 */
+    int32_t kernel_size;      /* 6 (every reference wiring) */
+} rulgnn_stconv_shape;
+
+int64_t rulgnn_stconv_param_count(const rulgnn_stconv_shape *shape);
+size_t rulgnn_stconv_workspace_bytes(const rulgnn_stconv_shape *shape);
+int rulgnn_stconv_forward_f32(const rulgnn_stconv_shape *shape, const rulgnn_astgcnn_args *args, void *stream);
+int rulgnn_stconv_backward_f32(const rulgnn_stconv_shape *shape, const rulgnn_astgcnn_args *args, void *stream);
+int rulgnn_stconv_fwdbwd_f32(const rulgnn_stconv_shape *shape, const rulgnn_astgcnn_args *args, const rulgnn_adam_args *opt,
+                             void *stream);
+/* running statistics of the three BatchNorms after one training forward (the momentum update is applied twice, as the
+ * reference's double use of each module does); count = batch * time_length. */
+int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape *shape, float *bn_stats, const float *bn_batch, int64_t count,
+                                        float momentum, int32_t from_moments, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
