@@ -437,7 +437,7 @@ int rulgnn_bilstm_backward_f32(const rulgnn_bilstm_shape *shape, const rulgnn_bi
  *   .bias[N] | cnn_layer_1.bn.weight[N] | .bias[N] | tcn conv_block1.0.weight[N][N][6] | bn1.weight | bn1.bias |
  *   conv_block2.0.weight | bn2.weight | bn2.bias | fc.weight[N*T] | fc.bias[1]
  * BatchNorm buffer: [3 (tcn conv_block1, tcn conv_block2, cnn)][2 (mean, var)][N].
- * The argument struct is rulgnn_astgcnn_args (same fields, same meaning).
+ * The argument struct is the ASTGCNN one, rulgnn_astgcnn_args: same fields, same meaning.
  */
 typedef struct rulgnn_stconv_shape {
     int64_t batch;

@@ -115,9 +115,58 @@ def case_training_curve(name, cfg, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_trainer_cmapss(name, seed, n_train=250, n_test=80, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method ST_Conv on the synthetic C-MAPSS FD002 dataset of
+    synth.py, its own hparams (configs/hparams.py:59,78) and its shuffling DataLoader; only num_epochs is patched."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_cmapss
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "CMAPSS", "FD002")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="ST_Conv", data_path=os.path.join(tmp, "data"), dataset="CMAPSS",
+                                      dataset_id="FD002", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.theta1", "model.fc.weight", "model.cnn_layer_1.conv.weight", "model.tcn_layer_1.conv_block2.2.running_var",
+              "model.cnn_layer_1.bn.num_batches_tracked"):
+        out["final:" + k] = final[k]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_cmapss("stconv_trainer_cmapss_fd002_reference_run", 9)
+        sys.exit(0)
     cm = dict(num_nodes=14, time_length=50, kernel_size=6)
     case_forward_backward("stconv_cmapss_14x50_bs12", cm, 12, seed=71)
     case_forward_backward("stconv_ncmapss_20x50_bs5", dict(cm, num_nodes=20), 5, seed=72, lo=-1.0, hi=1.0)
     case_forward_backward("stconv_small_6x11_bs9", dict(num_nodes=6, time_length=11, kernel_size=6), 9, seed=73)
     case_training_curve("stconv_train_curve_14x50_bs20", cm, 20, steps=12, seed=74, lr=1e-3, wd=1e-4)
+    case_trainer_cmapss("stconv_trainer_cmapss_fd002_reference_run", 9)

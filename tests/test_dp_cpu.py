@@ -354,3 +354,66 @@ def test_fcstgnn_data_parallel_step_world2_gloo():
     c = FCFG.encoder_hidden_dim
     assert np.allclose(out[0]["moments"][:c], fw.bna.mean, rtol=1e-5, atol=1e-6)
     assert np.allclose(out[0]["moments"][c:2 * c], fw.bna.var + fw.bna.mean ** 2, rtol=1e-5, atol=1e-6)
+
+
+# ---- ST_Conv: three BatchNorms, same bucket scheme as ASTGCNN ----
+from oracle import stconv_oracle as CO   # noqa: E402
+
+CN, CT = 5, 9
+
+
+class StconvOracleModel:
+    def __init__(self, prm):
+        self.prm = {k: np.asarray(v, np.float64) for k, v in prm.items()}
+        self.names = CO.live_param_names()
+        self.num_live = sum(self.prm[k].size for k in self.names)
+        self.bucket = torch.zeros(self.num_live + 1 + 6 * CN, dtype=torch.float32)
+        self.flat_params = torch.from_numpy(np.concatenate([self.prm[k].reshape(-1) for k in self.names]).astype(np.float32))
+
+    def fused_mse_step(self, X, y, optimizer=None, global_batch=None, sample_offset=0, update_running_stats=True,
+                       moments_to_bucket=False):
+        assert moments_to_bucket and not update_running_stats
+        x, yy = X.numpy().astype(np.float64), y.numpy().astype(np.float64).reshape(-1)
+        loss, grads, fw = CO.loss_and_grads(self.prm, x, yy, global_batch=global_batch)
+        self.bucket[:self.num_live] = torch.from_numpy(np.concatenate([grads[k].reshape(-1) for k in self.names]).astype(np.float32))
+        self.bucket[self.num_live] = loss
+        w = x.shape[0] / float(global_batch)
+        tail = self.bucket[self.num_live + 1:]
+        for i, t in enumerate((fw.bn1, fw.bn2, fw.bnc)):
+            tail[(2 * i) * CN:(2 * i + 1) * CN] = torch.from_numpy((w * t.mean).astype(np.float32))
+            tail[(2 * i + 1) * CN:(2 * i + 2) * CN] = torch.from_numpy((w * (t.var + t.mean ** 2)).astype(np.float32))
+        return None, self.bucket[self.num_live]
+
+    def _after_train_forward(self, batch, from_bucket_moments=False):
+        assert from_bucket_moments
+        self.global_moments = self.bucket[self.num_live + 1:].clone()
+
+
+def _stconv_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        x = torch.from_numpy(rng.uniform(0, 1, (B, CN, CT)).astype(np.float32))
+        y = torch.from_numpy(rng.uniform(0, 1, (B, 1)).astype(np.float32))
+        model = StconvOracleModel(CO.random_params(CN, CT, seed=8))
+        dp = DataParallel()
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "flat": model.flat_params.clone().numpy(),
+                     "moments": model.global_moments.numpy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stconv_data_parallel_step_world2_gloo():
+    B, world = 9, 2
+    out = mp.Manager().dict()
+    mp.spawn(_stconv_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    assert np.array_equal(out[0]["bucket"], out[1]["bucket"]) and np.array_equal(out[0]["flat"], out[1]["flat"])
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 1, (B, CN, CT)).astype(np.float32).astype(np.float64)
+    fw = CO.forward(CO.random_params(CN, CT, seed=8), x, train=True)
+    # the first TCN BatchNorm and the CNN BatchNorm see sharding-independent inputs: reduced moments == single-process statistics
+    assert np.allclose(out[0]["moments"][:CN], fw.bn1.mean, rtol=1e-5, atol=1e-6)
+    assert np.allclose(out[0]["moments"][4 * CN:5 * CN], fw.bnc.mean, rtol=1e-5, atol=1e-6)
