@@ -52,8 +52,8 @@ def test_graph_replay_equals_eager_steps(name):
     for k in a:
         if "running_" in k:
             assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-7), k
-        if "num_batches_tracked" in k:
-            assert int(a[k]) == int(b[k]) == len(sizes) * (2 if name == "ST_Conv" else 1), k     # ST_Conv: each BN runs twice per step
+        if "num_batches_tracked" in k and "_layer_2." not in k:      # ST_Conv: the "_2" layers never run; each live BN runs twice per step
+            assert int(a[k]) == int(b[k]) == len(sizes) * (2 if name == "ST_Conv" else 1), k
     assert eager.optimizer._steps == graphed.optimizer._steps == len(sizes)
     # evaluation after graphed training uses the same parameters
     eager.eval(), graphed.eval()
