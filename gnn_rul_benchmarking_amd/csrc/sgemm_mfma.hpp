@@ -36,16 +36,37 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
     const int li = lane & 15, kq = lane >> 4;
     const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        // cooperative load: 64 x 16 elements of A and of B (4 + 4 per thread)
+    // Cooperative tile load: 64 x 16 elements of A and of B (4 + 4 per thread).  The lane -> element mapping follows the
+    // operand's contiguous dimension (k-fastest when the k stride is 1, else m-fastest) so that wavefront loads coalesce, and
+    // the next k-step's elements are fetched into registers while the matrix cores work on the current one.
+    const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
+    int am[4], ak[4], bm[4], bk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = tid + e * 256;
+        am[e] = a_kfast ? idx >> 4 : idx & 63;
+        ak[e] = a_kfast ? idx & 15 : idx >> 6;
+        bm[e] = b_kfast ? idx >> 4 : idx & 63;
+        bk[e] = b_kfast ? idx & 15 : idx >> 6;
+    }
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int idx = tid + e * 256, mm = idx & 63, kk = idx >> 6;
-            const int gm = m0 + mm, gn = n0 + mm, gk = k0 + kk;
-            As[kk][mm] = (gm < g.M && gk < kend) ? g.A[gm * g.sAm + gk * g.sAk] : 0.f;
-            Bs[kk][mm] = (gn < g.N && gk < kend) ? g.B[gn * g.sBn + gk * g.sBk] : 0.f;
+            const int gm = m0 + am[e], gka = k0 + ak[e], gn = n0 + bm[e], gkb = k0 + bk[e];
+            ra[e] = (gm < g.M && gka < kend) ? g.A[gm * g.sAm + gka * g.sAk] : 0.f;
+            rb[e] = (gn < g.N && gkb < kend) ? g.B[gn * g.sBn + gkb * g.sBk] : 0.f;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            As[ak[e]][am[e]] = ra[e];
+            Bs[bk[e]][bm[e]] = rb[e];
         }
         __syncthreads();
+        if (k0 + 16 < kend) fetch(k0 + 16);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             float a[2], b[2];
@@ -88,14 +109,22 @@ static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
 
 // Split-K for reductions over a long K (weight gradients: K = batch * nodes) with few output tiles: `slices` partial
 // products into `partial` ([slices][M][N], caller-provided), then a fixed-order sum -- deterministic, no atomics.
-static __global__ void sgemm_reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ C, int64_t ldc, int M, int N,
-                                                  int slices, int accumulate) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= M * N) return;
+static __global__ __launch_bounds__(256) void sgemm_reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                                         int64_t ldc, int M, int N, int slices, int accumulate) {
+    // 64 outputs per workgroup, four threads per output each summing every fourth slice, combined in a fixed order
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     float a = 0.f;
-    for (int z = 0; z < slices; ++z) a += partial[(int64_t)z * M * N + e];
-    float* c = C + (int64_t)(e / N) * ldc + (e % N);
-    *c = accumulate ? *c + a : a;
+    if (e < M * N)
+        for (int z = q; z < slices; z += 4) a += partial[(int64_t)z * M * N + e];
+    part[q][lane] = a;
+    __syncthreads();
+    if (q == 0 && e < M * N) {
+        const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float* c = C + (int64_t)(e / N) * ldc + (e % N);
+        *c = accumulate ? *c + v : v;
+    }
 }
 
 static inline int sgemm_splitk_slices(int M, int N, int K) {
@@ -118,7 +147,7 @@ static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B
     GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
     (void)hipGetLastError();
     hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64, used), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, partial, C, ldc, M, N, used,
+    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, partial, C, ldc, M, N, used,
                        accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
