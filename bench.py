@@ -70,19 +70,22 @@ def phase_names(L):
 
 def phase_bytes_per_sample(name, N, P, L):
     """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, 16-lane]
-    fp32 state tensor per sample = 640 B: X0 / adjacency rows (cache), X_l, x-hat mask, dX, d(x0+H)."""
+    fp32 state tensor per sample = 640 B: X0 / adjacency rows (cache), X_l, x-hat mask, dX, d(x0+H) and the
+    activations H, z1, o0, z2 each layer hands from phase to phase (stgcn_train.hip::SavedSlot)."""
     T = 10 * 16 * 4
     if name == "F0":
-        return N * P * 4 + 2 * T                       # read the window, write X0 + adjacency rows
+        return N * P * 4 + 4 * T                       # read the window; write X0, adjacency rows, H, z1
     if name == "TOP":
-        return 3 * T + 8                               # X_{L-1}, A; write dX_L; y in, pred out
+        return 4 * T + 8                               # X_{L-1}, o0, z2; write dX_L; y in, pred out
     i = int(name[1:])
     l, blk = divmod(i, 2)
     if name[0] == "F":
-        return 2 * T + (2 * T if (blk == 0 and l >= 1) else 0)        # X, A (+ write X_l and the x-hat mask)
+        if blk == 1:
+            return 4 * T                               # F_{2l+1}: H, z1; write o0, z2
+        return 8 * T                                   # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, x-hat mask, H, z1
     if blk == 1:
-        return 4 * T                                   # G_{2l+1}: X_l, A, dX_{l+1}; write d(x0+H)
-    return (3 * T) if l == 0 else (6 * T)              # G_{2l}: X_l, A, d(x0+H) (+ dX in/out, x-hat mask)
+        return 5 * T                                   # G_{2l+1}: z1, o0, z2, dX_{l+1}; write d(x0+H)
+    return (5 * T) if l == 0 else (8 * T)              # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
 
 
 def measured_traffic(kernel_key, N, P, B):

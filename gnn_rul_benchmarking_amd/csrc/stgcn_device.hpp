@@ -297,10 +297,29 @@ __device__ __forceinline__ void adj_aggregate(const float (&A)[NPAIR], const flo
     }
 }
 
+// Wave-uniform weights are read with scalar loads.  Left alone the compiler hoists those loads out of the persistent tile loop
+// and shares them between the forward recompute and the transposed convolution of a G phase; 200 live scalars do not fit the
+// 106-SGPR file, so they end up in VGPR lanes (v_writelane / v_readlane: up to 20 % of a tile iteration).  scalar_fresh makes one
+// use site re-load instead: the pointer passes through an opaque scalar asm that depends on a loop-variant token (no hoisting;
+// the ID keeps two sites from being merged) and is read in the constant address space, which keeps the loads on the scalar
+// unit without the read-only proof that the laundering throws away.
+typedef const float __attribute__((address_space(4)))* scalar_f32p;
+template <int ID>
+__device__ __forceinline__ scalar_f32p scalar_fresh(const float* p, int token) {
+    unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    asm("; scalar_fresh %2" : "+s"(a) : "v"(token), "n"(ID));
+    return (scalar_f32p)a;
+}
+
+template <bool FRESH, int ID>
+__device__ __forceinline__ auto conv_weights(const float* p, int token) {
+    if constexpr (FRESH) return scalar_fresh<ID>(p, token); else return p;
+}
+
 // z[co] = sum_ci w[co][ci][0] h[ci][t-D] + w[co][ci][1] h[ci][t]; weights are wave-uniform
 // (scalar loads -> SGPR operands of v_fmac).
-template <int RW, int D>
-__device__ __forceinline__ void causal_conv(const float (&h)[F], const float* __restrict__ w, int t, float (&z)[F]) {
+template <int RW, int D, typename WP>
+__device__ __forceinline__ void causal_conv(const float (&h)[F], WP w, int t, float (&z)[F]) {
     float hs[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) hs[c] = Row<RW>::template shr<D>(h[c], t);

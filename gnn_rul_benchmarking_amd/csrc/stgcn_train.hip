@@ -14,10 +14,10 @@
 //     G_{2L-1} .. G_0   BatchNorm-i backward -> dz_i, weight gradients of conv_i (and theta of the
 //                       layer when i is even), data gradient down to dy_{i-1}, accumulate its sums
 //
-// Nothing per-sample is stored between phases except the input-only quantities (patch statistics
-// X0 and the Pearson adjacency A: 896 B/sample, written by F_0): every phase RECOMPUTES the
-// activations it needs from that cache, in registers.  Activations never touch HBM, which keeps
-// the whole step VALU-bound instead of HBM-bound (saving activations would cost ~25 KB/sample).
+// Per sample the phases hand each other 640-byte [10][N] tensors through HBM: the input-only statistics X0 and Pearson
+// adjacency (written by F_0), and per layer the tensors listed at SavedSlot.  The first versions recomputed activations from
+// the cache in every phase; the kernels turned out VALU-issue-bound with HBM two thirds idle, so each phase now reads what an
+// earlier phase already had in registers instead of redoing a theta projection and up to two convolutions.
 //
 // Matrix-core use: the contraction of the weight gradients runs over (sample, patch) or
 // (sample, channel), i.e. over lanes/registers of the row mapping:
@@ -41,6 +41,37 @@ constexpr int TT_ROWS = 30;
 constexpr int BNC = 7;                      // per-BatchNorm constants: mean, istd, scale, shift, gamma*istd, k1, k2
 
 enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
+#ifndef PHASE_WAVES_F1
+#define PHASE_WAVES_F1 5
+#define PHASE_WAVES_F2 4
+#define PHASE_WAVES_TOP 3
+#define PHASE_WAVES_G1 3
+#define PHASE_WAVES_G0 3
+#endif
+#ifndef FRESH_G1
+#define FRESH_G1 true
+#define FRESH_G0 false
+#endif
+
+// Activations carried from phase to phase through HBM, one [ntiles][F][64] lane-major tensor per slot (ONE base pointer in the
+// kernel arguments: the phase kernels are SGPR-bound).  Every tensor is written once per step by the phase that first has it
+// and read by the phases that would otherwise recompute it (theta projection + two convolutions per layer):
+//   X(l)   input of layer l >= 1                                       F_{2l}   -> F_{2l} (next use), TOP, G_{2l}
+//   P(l)   x-hat of BatchNorm 2l+1 where the gradient passes, else inf  F_{2l+2} -> G_{2l+2}
+//   H(l)   leaky(theta(A X_l))                                          F_{2l}   -> F_{2l+1}, G_{2l}
+//   Z1(l)  conv_block1 output (BatchNorm 2l input)                      F_{2l}   -> F_{2l+1}, G_{2l+1}, G_{2l}
+//   O0(l)  relu(relu(BN(z1)) + H): conv_block2 input                    F_{2l+1} -> F_{2l+2} / TOP, G_{2l+1}
+//   Z2(l)  conv_block2 output (BatchNorm 2l+1 input)                    F_{2l+1} -> F_{2l+2} / TOP, G_{2l+1}
+template <int L>
+struct SavedSlot {
+    static constexpr int X(int l) { return l - 1; }
+    static constexpr int P(int l) { return (L - 1) + l; }
+    static constexpr int H(int l) { return 2 * (L - 1) + l; }
+    static constexpr int Z1(int l) { return 2 * (L - 1) + L + l; }
+    static constexpr int O0(int l) { return 2 * (L - 1) + 2 * L + l; }
+    static constexpr int Z2(int l) { return 2 * (L - 1) + 3 * L + l; }
+};
+static inline int saved_slots(int L) { return 6 * L - 2; }
 
 struct TrainK {
     // workspace regions
@@ -50,8 +81,7 @@ struct TrainK {
     double* cells_bwd;    // [2L][2][F]   sum dy, sum dy*xhat
     double* cell_loss;    // [1]
     float* gpart;         // [grid][param_count] per-block partial gradients
-    float* xsave;         // [L-1][ntiles][F][64]  X_l = input of layer l (l >= 1), written by F_{2l}
-    float* psave;         // [L-1][ntiles][F][64]  layer l-1: x-hat of BatchNorm 2l-1 where the gradient passes, else +inf
+    float* saved;         // [6L-2][ntiles][F][64]  activations carried between phases, see SavedSlot
     float* rbuf;          // [ntiles][F][64]  d X_{l+1}: gradient entering layer l's backward (TOP / G_{2l+2} -> G_{2l+1}, G_{2l})
     float* sbuf;          // [ntiles][F][64]  d(x0 + H) of layer l (G_{2l+1} -> G_{2l})
     // outputs
@@ -91,8 +121,8 @@ __device__ __forceinline__ float wave_sum(float v) {      // total over 64 lanes
     return v;
 }
 
-template <int RW, int D>
-__device__ __forceinline__ void causal_conv_T(const float (&dz)[F], const float* __restrict__ w, int t, float (&dh)[F]) {
+template <int RW, int D, typename WP>
+__device__ __forceinline__ void causal_conv_T(const float (&dz)[F], WP w, int t, float (&dh)[F]) {
     // transpose of causal_conv: dh[ci][t] = sum_co w[co][ci][1] dz[co][t] + w[co][ci][0] dz[co][t + D]
     float dzs[F];
 #pragma unroll
@@ -178,8 +208,17 @@ __device__ __forceinline__ void outer_grad_mfma(float* T, const float (&P)[NC], 
 // the phase kernel
 // ------------------------------------------------------------------------------------------------
 // IDX: BatchNorm index (0 .. 2L-1) for F and G kernels; unused for TOP.
+// Wavefronts per SIMD the register allocation aims for (second __launch_bounds__ argument).  The phases that only stream
+// saved activations through a convolution or the head want more wavefronts in flight; the gradient phases need the registers.
+constexpr int phase_min_waves(int RW, int KIND, int IDX) {
+    if (RW != 16) return 1;
+    if (KIND == PH_F) return IDX % 2 == 1 ? PHASE_WAVES_F1 : (IDX == 0 ? 4 : PHASE_WAVES_F2);
+    if (KIND == PH_TOP) return PHASE_WAVES_TOP;
+    return IDX % 2 == 1 ? PHASE_WAVES_G1 : PHASE_WAVES_G0;
+}
+
 template <int RW, int L, int KIND, int IDX>
-__global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+__global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy,   // y or dpred (TOP only)
                                                                   TrainK a) {
@@ -207,6 +246,11 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
     constexpr int BLK = KIND == PH_TOP ? 1 : IDX % 2;
     constexpr bool WITH_PREV = (KIND == PH_F) && (BLK == 0) && (LY >= 1);
     constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
+    using SV = SavedSlot<L>;
+    // what this phase reads besides the saved activations: the layer input (F_{2l}: aggregation, G_{2l}: theta gradient,
+    // TOP: last residual) and the adjacency (F_{2l}, G_{2l})
+    constexpr bool NEED_A = KIND != PH_TOP && BLK == 0;
+    constexpr bool NEED_X = NEED_A || KIND == PH_TOP;
 
     // ---- LDS carve --------------------------------------------------------------------------------
     // three zero-padded [RW][TWS] weight slots: theta of layer LY | theta of layer LY-1 (F_{2l}) or fc1 (TOP) |
@@ -284,7 +328,29 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
     const int64_t sampleNP = (int64_t)N * a.P;
     const float inv_gb = 1.0f / (float)a.global_batch;
 
-    const size_t tile_floats = (size_t)F * 64;
+    // Saved tensors are packed: of each RW-lane row only the N patch lanes are stored (element (c, sample row, patch t) of a
+    // tile at c * pitch + row * N + t), padded lanes read back as zero -- 12.5 % less traffic at N = 14.  The lane-distributed
+    // adjacency rows (RW 16) use F of the 16 lanes.
+    const int pitch = TSPW * N, loff = srow * N + t;
+    const bool lane_ok = t < N;
+    const size_t tile_floats = (size_t)F * pitch;
+    auto load_tile = [&](const float* p, float (&v)[F]) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[c] = 0.f;
+        if (lane_ok) {
+#pragma unroll
+            for (int c = 0; c < F; ++c) v[c] = p[c * pitch];
+        }
+    };
+    auto store_tile = [&](float* p, const float (&v)[F]) {
+        if (lane_ok) {
+#pragma unroll
+            for (int c = 0; c < F; ++c) p[c * pitch] = v[c];
+        }
+    };
+    constexpr int pitch_a = TSPW * F;
+    const int loff_a = srow * F + t;
+    const bool lane_ok_a = t < F;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
          tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
@@ -294,6 +360,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
         const bool valid = rowok && (t < N);
         constexpr int NA = RW == 16 ? F : NPAIR;   // RW 16: lane-distributed adjacency rows (MFMA); else 55 row-uniform values
         float X[F], A[NA];
+        auto slot = [&](int k) { return a.saved + ((size_t)k * a.ntiles + tile) * tile_floats + loff; };
 
         // ---- inputs: patch statistics + Pearson adjacency (F_0 computes and caches), or the saved X_l ----
         if constexpr (KIND == PH_F && IDX == 0) {
@@ -303,12 +370,13 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = 0.f;
             if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, a.P, X);
-            float* cx = a.cacheX + tile * tile_floats + lane;
             if constexpr (RW == 16) {
                 pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
-                float* ca = a.cacheA + tile * tile_floats + lane;
+                float* ca = a.cacheA + tile * (size_t)(F * pitch_a) + loff_a;
+                if (lane_ok_a) {
 #pragma unroll
-                for (int c = 0; c < F; ++c) ca[c * 64] = A[c];
+                    for (int c = 0; c < F; ++c) ca[c * pitch_a] = A[c];
+                }
             } else {
                 pearson_adjacency<RW>(X, valid, N, A);
                 float v = 0.f;                              // one sample per wavefront: lane i keeps entry i
@@ -319,21 +387,25 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 }
                 a.cacheA[tile * 64 + lane] = v;
             }
-#pragma unroll
-            for (int c = 0; c < F; ++c) cx[c * 64] = X[c];
+            store_tile(a.cacheX + tile * tile_floats + loff, X);
         } else {
-            const float* cx = (LSTART == 0 ? a.cacheX : a.xsave + (size_t)(LSTART - 1) * a.ntiles * tile_floats) +
-                              tile * tile_floats + lane;
+            if constexpr (NEED_X) {
+                load_tile(LSTART == 0 ? a.cacheX + tile * tile_floats + loff : slot(SV::X(LSTART)), X);
+            }
+            if constexpr (NEED_A) {
+                if constexpr (RW == 16) {
+                    const float* ca = a.cacheA + tile * (size_t)(F * pitch_a) + loff_a;
 #pragma unroll
-            for (int c = 0; c < F; ++c) X[c] = cx[c * 64];
-            if constexpr (RW == 16) {
-                const float* ca = a.cacheA + tile * tile_floats + lane;
+                    for (int c = 0; c < F; ++c) A[c] = 0.f;
+                    if (lane_ok_a) {
 #pragma unroll
-                for (int c = 0; c < F; ++c) A[c] = ca[c * 64];
-            } else {
-                const int v = __builtin_bit_cast(int, a.cacheA[tile * 64 + lane]);
+                        for (int c = 0; c < F; ++c) A[c] = ca[c * pitch_a];
+                    }
+                } else {
+                    const int v = __builtin_bit_cast(int, a.cacheA[tile * 64 + lane]);
 #pragma unroll
-                for (int i = 0; i < NPAIR; ++i) A[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, i));
+                    for (int i = 0; i < NPAIR; ++i) A[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(v, i));
+                }
             }
         }
         const uint32_t ctr_base = (uint32_t)((a.sample_offset + s0 + srow) * F) * (uint32_t)N + (uint32_t)t;
@@ -342,36 +414,24 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
         if constexpr (WITH_PREV) {
             float pz2[F], po0[F];
             constexpr int lq = LY - 1;
-            const float* lp = prm + lq * LS;
-            const float* b1 = bnc + (2 * lq) * BNC * F;
             const float* b2 = bnc + (2 * lq + 1) * BNC * F;
-            float AX[F], H[F], z[F];
-            if constexpr (RW == 16) adj_aggregate_mfma(A, X, AX); else adj_aggregate(A, X, AX);
-            const float tb = vecs[lq * TRW + t];
-#pragma unroll
-            for (int c = 0; c < F; ++c) H[c] = tb;
-            R16::project10(H, AX, w_aux + t * TWS, N);
-#pragma unroll
-            for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
-            causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z);
-#pragma unroll
-            for (int c = 0; c < F; ++c) po0[c] = relu(relu(fmaf(z[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
-            causal_conv<TRW, 2>(po0, lp + off_conv_w(N, 1), t, pz2);
-            float* xs = a.xsave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
-            float* ps = a.psave + (size_t)(LY - 1) * a.ntiles * tile_floats + tile * tile_floats + lane;
+            load_tile(slot(SV::O0(lq)), po0);
+            load_tile(slot(SV::Z2(lq)), pz2);
+            float psv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x1 = relu(fmaf(pz2[c], b2[2 * F + c], b2[3 * F + c]));
                 float o1 = relu(x1 + po0[c]);
                 const bool pass = o1 > 0.f && x1 > 0.f && valid;
-                ps[c * 64] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
+                psv[c] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
                 if (a.dropout_p > 0.f) {
                     const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
-                xs[c * 64] = X[c];                     // X_l is final from here on: stored for the later phases
             }
+            store_tile(slot(SV::P(lq)), psv);
+            store_tile(slot(SV::X(LY)), X);            // X_l is final from here on: stored for the later phases
         }
 
         // ---- layer LY forward, as far as this phase needs it ---------------------------------------------------
@@ -379,18 +439,18 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
         const float* b1 = bnc + (2 * LY) * BNC * F;
         const float* b2 = bnc + (2 * LY + 1) * BNC * F;
         float AX[F], H[F], z1[F];
-        if constexpr (RW == 16) adj_aggregate_mfma(A, X, AX); else adj_aggregate(A, X, AX);
-        {
+        if constexpr (NEED_A) { if constexpr (RW == 16) adj_aggregate_mfma(A, X, AX); else adj_aggregate(A, X, AX); }
+
+        if constexpr (KIND == PH_F && BLK == 0) {       // F_{2l}: theta projection, conv_block1, its statistics
             const float tb = vecs[LY * TRW + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
-        }
-        R16::project10(H, AX, w_cur + t * TWS, N);
+            R16::project10(H, AX, w_cur + t * TWS, N);
 #pragma unroll
-        for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
-        causal_conv<TRW, 1>(H, lp + off_conv_w(N, 0), t, z1);
-
-        if constexpr (KIND == PH_F && BLK == 0) {       // F_{2l}: statistics of conv_block1's output
+            for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
+            causal_conv<TRW, 1>(H, conv_weights<true, 5>(lp + off_conv_w(N, 0), (int)tile), t, z1);
+            store_tile(slot(SV::H(LY)), H);
+            store_tile(slot(SV::Z1(LY)), z1);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float z = valid ? z1[c] : 0.f;
@@ -399,13 +459,17 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
             }
             continue;
         }
+        if constexpr (KIND != PH_TOP) {                  // F_{2l+1}, G_{2l+1}, G_{2l}: conv_block1 output as F_{2l} left it
+            load_tile(slot(SV::Z1(LY)), z1);
+        }
+        if constexpr (KIND != PH_TOP && !(KIND == PH_G && BLK == 1)) {
+            load_tile(slot(SV::H(LY)), H);
+        }
 
         if constexpr (KIND == PH_G && BLK == 0) {
             // ---- G_{2l}: BatchNorm 2l backward, conv_block1 + theta gradients, dX_l ------------------------------
-            const float* sb = a.sbuf + tile * tile_floats + lane;
             float g0[F], dz[F];
-#pragma unroll
-            for (int c = 0; c < F; ++c) g0[c] = sb[c * 64];                       // d(x0 + H), written by G_{2l+1}
+            load_tile(a.sbuf + tile * tile_floats + loff, g0);                    // d(x0 + H), written by G_{2l+1}
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x0 = relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c]));
@@ -421,7 +485,7 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 conv_wgrad_mfma(mywave, dz, H, hs, lane, acc_c0, acc_c1);
             }
             float dH[F];
-            causal_conv_T<RW, 1>(dz, lp + off_conv_w(N, 0), t, dH);
+            causal_conv_T<RW, 1>(dz, conv_weights<FRESH_G0, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float g = dH[c] + g0[c];
@@ -436,15 +500,17 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 for (int c = 0; c < F; ++c) dAX[c] = 0.f;
                 R16::project10(dAX, dH, w_tr + t * TWS, N);                         // dHpre . theta
                 if constexpr (RW == 16) adj_aggregate_mfma(A, dAX, dXl); else adj_aggregate(A, dAX, dXl);   // A is symmetric: A^T = A
-                float* rb = a.rbuf + tile * tile_floats + lane;
+                float* rb = a.rbuf + tile * tile_floats + loff;
                 constexpr int lq = LY - 1;
-                const float* ps = a.psave + (size_t)lq * a.ntiles * tile_floats + tile * tile_floats + lane;
+                float rbv[F], psv[F];
+                load_tile(rb, rbv);
+                load_tile(slot(SV::P(lq)), psv);
 #pragma unroll
                 for (int c = 0; c < F; ++c) {
-                    const float dX = valid ? dXl[c] + rb[c * 64] : 0.f;           // + residual branch: d X_{l+1}
-                    rb[c * 64] = dX;                                               // = d X_l, read by G_{2l-1}
+                    const float dX = valid ? dXl[c] + rbv[c] : 0.f;               // + residual branch: d X_{l+1}
+                    rbv[c] = dX;                                                   // = d X_l, read by G_{2l-1}
                     // top of layer l-1: sums for BatchNorm 2l-1 from the saved "x-hat or +inf (gradient blocked)"
-                    const float xh = ps[c * 64];
+                    const float xh = lane_ok ? psv[c] : INFINITY;
                     float g = dX;
                     if (a.dropout_p > 0.f) {
                         const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
@@ -455,16 +521,18 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                     s_a[c] += dy;
                     s_b[c] = fmaf(dy, pass ? xh : 0.f, s_b[c]);
                 }
+                store_tile(rb, rbv);
             }
             continue;
         }
 
         float o0[F], z2[F];
+        if constexpr (KIND == PH_F && BLK == 1) {       // F_{2l+1}: conv_block2 and its statistics
 #pragma unroll
-        for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
-        causal_conv<TRW, 2>(o0, lp + off_conv_w(N, 1), t, z2);
-
-        if constexpr (KIND == PH_F && BLK == 1) {       // F_{2l+1}: statistics of conv_block2's output
+            for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
+            causal_conv<TRW, 2>(o0, conv_weights<true, 6>(lp + off_conv_w(N, 1), (int)tile), t, z2);
+            store_tile(slot(SV::O0(LY)), o0);
+            store_tile(slot(SV::Z2(LY)), z2);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float z = valid ? z2[c] : 0.f;
@@ -473,6 +541,8 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
             }
             continue;
         }
+        load_tile(slot(SV::O0(LY)), o0);
+        load_tile(slot(SV::Z2(LY)), z2);
 
         if constexpr (KIND == PH_TOP) {
             // ---- layer L-1 output, head forward (Model.py:218-221), head backward --------------------------------
@@ -526,11 +596,11 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 const float p1[1] = {dy1}, q1[1] = {pooled};
                 outer_grad_mfma<RW, 1>(mywave, p1, q1, lane, acc_thg);
             }
-            float* rb = a.rbuf + tile * tile_floats + lane;
+            float rbv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float dX = (valid && c == arg) ? dpool : 0.f;                 // d X_L (max-pool routes to the arg-max channel)
-                rb[c * 64] = dX;
+                rbv[c] = dX;
                 float g = dX;
                 if (a.dropout_p > 0.f) {
                     const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[LY]);
@@ -541,18 +611,19 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 s_a[c] += dy;
                 s_b[c] = fmaf(dy, xh, s_b[c]);
             }
+            store_tile(a.rbuf + tile * tile_floats + loff, rbv);
             continue;
         }
 
         if constexpr (KIND == PH_G && BLK == 1) {
             // ---- G_{2l+1}: BatchNorm 2l+1 backward, conv_block2 gradient, d(x0 + H) -----------------------------------
-            const float* rb = a.rbuf + tile * tile_floats + lane;
-            float gsum[F], dz[F];
+            float gsum[F], dz[F], rbv[F];
+            load_tile(a.rbuf + tile * tile_floats + loff, rbv);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x1 = relu(fmaf(z2[c], b2[2 * F + c], b2[3 * F + c]));
                 const float o1 = relu(x1 + o0[c]);
-                float g = rb[c * 64];                                               // d X_{l+1}
+                float g = rbv[c];                                                   // d X_{l+1}
                 if (a.dropout_p > 0.f) {
                     const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[LY]);
                     g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
@@ -571,19 +642,20 @@ __global__ __launch_bounds__(BLOCK, RW == 16 ? 3 : 1) void stgcn_train_phase_ker
                 conv_wgrad_mfma(mywave, dz, o0, hs, lane, acc_c0, acc_c1);
             }
             float d_o0[F];
-            causal_conv_T<RW, 2>(dz, lp + off_conv_w(N, 1), t, d_o0);
-            float* sb = a.sbuf + tile * tile_floats + lane;
+            causal_conv_T<RW, 2>(dz, conv_weights<FRESH_G1, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
+            float sbv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x0 = relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c]));
                 float g = d_o0[c] + gsum[c];
                 g = (o0[c] > 0.f && valid) ? g : 0.f;
-                sb[c * 64] = g;                                                     // d(x0 + H), read by G_{2l}
+                sbv[c] = g;                                                         // d(x0 + H), read by G_{2l}
                 const float dy = (x0 > 0.f) ? g : 0.f;
                 const float xh = (z1[c] - b1[0 * F + c]) * b1[1 * F + c];
                 s_a[c] += dy;
                 s_b[c] = fmaf(dy, xh, s_b[c]);
             }
+            store_tile(a.sbuf + tile * tile_floats + loff, sbv);
             continue;
         }
     }
@@ -802,7 +874,7 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
 // host side
 // ------------------------------------------------------------------------------------------------
 struct WsLayout {
-    size_t off_cacheX, off_cacheA, off_cells, off_gpart, off_xsave, off_psave, off_rbuf, off_sbuf, total;
+    size_t off_cacheX, off_cacheA, off_cells, off_gpart, off_saved, off_rbuf, off_sbuf, total;
     size_t cells_bytes;
     int max_grid;
 };
@@ -841,8 +913,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
     const size_t tile_bytes = (size_t)g.ntiles * F * 64 * sizeof(float);
-    w->off_xsave = o; o = al(o + (size_t)(L > 1 ? L - 1 : 1) * tile_bytes);
-    w->off_psave = o; o = al(o + (size_t)(L > 1 ? L - 1 : 1) * tile_bytes);
+    w->off_saved = o; o = al(o + (size_t)saved_slots(L) * tile_bytes);
     w->off_rbuf = o; o = al(o + tile_bytes);
     w->off_sbuf = o; o = al(o + tile_bytes);
     w->total = o;
@@ -931,8 +1002,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     k.cells_bwd = cells + 2 * L * 2 * F;
     k.cell_loss = cells + 2 * (2 * L * 2 * F);
     k.gpart = reinterpret_cast<float*>(ws + w.off_gpart);
-    k.xsave = reinterpret_cast<float*>(ws + w.off_xsave);
-    k.psave = reinterpret_cast<float*>(ws + w.off_psave);
+    k.saved = reinterpret_cast<float*>(ws + w.off_saved);
     k.rbuf = reinterpret_cast<float*>(ws + w.off_rbuf);
     k.sbuf = reinterpret_cast<float*>(ws + w.off_sbuf);
     k.write_pred = 1;
