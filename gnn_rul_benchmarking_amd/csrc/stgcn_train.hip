@@ -48,6 +48,9 @@ enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
 #define PHASE_WAVES_G1 3
 #define PHASE_WAVES_G0 3
 #endif
+#ifndef PHASE_ALTERNATE
+#define PHASE_ALTERNATE true
+#endif
 #ifndef FRESH_G1
 #define FRESH_G1 true
 #define FRESH_G0 false
@@ -77,9 +80,7 @@ struct TrainK {
     // workspace regions
     float* cacheX;        // [ntiles][F][64]
     float* cacheA;        // [ntiles][F][64]  lane-distributed adjacency rows
-    double* cells_fwd;    // [2L][2][F]   sum z, sum z^2
-    double* cells_bwd;    // [2L][2][F]   sum dy, sum dy*xhat
-    double* cell_loss;    // [1]
+    double* cells;        // [CELL_REPLICAS][cell_stride(L)] reduction cells (see CellLayout), step scratch behind them
     float* gpart;         // [grid][param_count] per-block partial gradients
     float* saved;         // [6L-2][ntiles][F][64]  activations carried between phases, see SavedSlot
     float* rbuf;          // [ntiles][F][64]  d X_{l+1}: gradient entering layer l's backward (TOP / G_{2l+2} -> G_{2l+1}, G_{2l})
@@ -107,8 +108,24 @@ struct StepScratch {
     float lr_over_bc1, inv_sqrt_bc2;
     uint32_t pad[6];
 };
-__device__ __forceinline__ const StepScratch* step_scratch(const double* cell_loss) {
-    return reinterpret_cast<const StepScratch*>(cell_loss + 8);
+
+// Reduction cells (fp64): per BatchNorm the forward pair (sum z, sum z^2) and the backward pair (sum dy, sum dy*xhat), then
+// the loss.  Every block adds its partial sums with one atomic per cell; 1280 blocks hitting the same 20 addresses serialise
+// (measured: ~10 us per phase kernel), so the cells exist CELL_REPLICAS times, block b adds into replica b % CELL_REPLICAS and
+// the consumers sum the replicas in a fixed order.
+constexpr int CELL_REPLICAS = 16;
+__host__ __device__ constexpr int cell_fwd(int L) { (void)L; return 0; }
+__host__ __device__ constexpr int cell_bwd(int L) { return 2 * L * 2 * F; }
+__host__ __device__ constexpr int cell_loss(int L) { return 2 * (2 * L * 2 * F); }
+__host__ __device__ constexpr int cell_stride(int L) { return 2 * (2 * L * 2 * F) + 8; }
+__host__ __device__ __forceinline__ StepScratch* step_scratch(double* cells, int L) {
+    return reinterpret_cast<StepScratch*>(cells + CELL_REPLICAS * cell_stride(L));
+}
+__device__ __forceinline__ double cell_sum(const double* cells, int L, int i) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < CELL_REPLICAS; ++r) v += cells[r * cell_stride(L) + i];
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     // plain pointer)
     uint32_t dkey[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) dkey[l] = step_scratch(a.cell_loss)->drop_key[l];
+    for (int l = 0; l < L; ++l) dkey[l] = step_scratch(a.cells, L)->drop_key[l];
 
     // Which layer does this kernel work in, and where does its forward start?
     //   F_{2l}, l >= 1 : first finishes layer l-1 (its BatchNorm statistics are complete now) and stores X_l
@@ -255,7 +272,9 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     // ---- LDS carve --------------------------------------------------------------------------------
     // three zero-padded [RW][TWS] weight slots: theta of layer LY | theta of layer LY-1 (F_{2l}) or fc1 (TOP) |
     // the transposed matrix the backward needs (theta^T for G_{2l}, fc1^T for TOP)
-    float* w_cur = smem;
+    constexpr int CS = cell_stride(L);
+    double* cellsum = reinterpret_cast<double*>(smem);     // [CS] the reduction cells, replicas summed
+    float* w_cur = smem + 2 * CS;
     float* w_aux = w_cur + TRW * TWS;
     float* w_tr = w_aux + TRW * TWS;
     float* vecs = w_tr + TRW * TWS;                       // [L+2][RW]        theta bias, fc1 bias, fc2 weight
@@ -285,13 +304,17 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
         vecs[i] = j < N ? src[j] : 0.f;
     }
+    for (int i = threadIdx.x; i < CS; i += BLOCK) cellsum[i] = cell_sum(a.cells, L, i);
+    __syncthreads();
+    const double* cells_fwd = cellsum + cell_fwd(L);
+    const double* cells_bwd = cellsum + cell_bwd(L);
     const double cnt = (double)a.B * (double)N;           // values per channel in this shard's batch
     for (int i = threadIdx.x; i < NBN * F; i += BLOCK) {
         const int b = i / F, c = i % F;
         const int l = b / 2, blk = b % 2;
         float* o = bnc + b * BNC * F;
         if (b < NFWD) {
-            const double s1 = a.cells_fwd[(b * 2 + 0) * F + c], s2 = a.cells_fwd[(b * 2 + 1) * F + c];
+            const double s1 = cells_fwd[(b * 2 + 0) * F + c], s2 = cells_fwd[(b * 2 + 1) * F + c];
             const double mean = s1 / cnt;
             double var = s2 / cnt - mean * mean;
             var = var < 0.0 ? 0.0 : var;
@@ -303,8 +326,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
             o[3 * F + c] = (float)(be - mean * g * istd);
             o[4 * F + c] = (float)(g * istd);
             if (KIND == PH_G && b >= IDX) {                // BatchNorm backward constants, known for b >= IDX
-                o[5 * F + c] = (float)(a.cells_bwd[(b * 2 + 0) * F + c] / cnt);
-                o[6 * F + c] = (float)(a.cells_bwd[(b * 2 + 1) * F + c] / cnt);
+                o[5 * F + c] = (float)(cells_bwd[(b * 2 + 0) * F + c] / cnt);
+                o[6 * F + c] = (float)(cells_bwd[(b * 2 + 1) * F + c] / cnt);
             } else {
                 o[5 * F + c] = 0.f;
                 o[6 * F + c] = 0.f;
@@ -352,8 +375,12 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     const int loff_a = srow * F + t;
     const bool lane_ok_a = t < F;
 
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
-         tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+    // Successive phases walk the tiles in opposite directions: what a phase wrote (or read) last is what the next one
+    // touches first, while it is still in the 256 MB Infinity Cache.
+    constexpr int CHAIN_POS = KIND == PH_F ? IDX : (KIND == PH_TOP ? NBN : NBN + 1 + (NBN - 1 - IDX));
+    constexpr bool REVERSED = PHASE_ALTERNATE && (CHAIN_POS % 2 == 1);
+    for (int64_t it = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; it < a.ntiles; it += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int64_t tile = REVERSED ? a.ntiles - 1 - it : it;
         const int64_t s0 = tile * TSPW;
         const int ns = (int)((a.B - s0) < TSPW ? (a.B - s0) : TSPW);
         const bool rowok = srow < ns;
@@ -682,16 +709,16 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         double v = 0.0;
         for (int w = 0; w < WAVES_PER_BLOCK; ++w) v += (double)redp[w * 24 + threadIdx.x];
         const int which = threadIdx.x / F, c = threadIdx.x % F;
-        double* cell;
-        if (KIND == PH_F) cell = a.cells_fwd + (IDX * 2 + which) * F + c;
-        else if (KIND == PH_TOP) cell = a.cells_bwd + ((NBN - 1) * 2 + which) * F + c;
-        else cell = a.cells_bwd + ((IDX - 1) * 2 + which) * F + c;
+        double* cell = a.cells + (blockIdx.x % CELL_REPLICAS) * CS;
+        if (KIND == PH_F) cell += cell_fwd(L) + (IDX * 2 + which) * F + c;
+        else if (KIND == PH_TOP) cell += cell_bwd(L) + ((NBN - 1) * 2 + which) * F + c;
+        else cell += cell_bwd(L) + ((IDX - 1) * 2 + which) * F + c;
         atomicAdd(cell, v);
     }
     if (KIND == PH_TOP && threadIdx.x == 2 * F && a.has_dpred == 0) {
         double v = 0.0;
         for (int w = 0; w < WAVES_PER_BLOCK; ++w) v += (double)redp[w * 24 + 2 * F];
-        atomicAdd(a.cell_loss, v);
+        atomicAdd(a.cells + (blockIdx.x % CELL_REPLICAS) * CS + cell_loss(L), v);
     }
     if constexpr (KIND == PH_F) return;
     if (KIND == PH_TOP && !a.do_backward) return;
@@ -777,9 +804,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
 // ------------------------------------------------------------------------------------------------
 struct FinalizeK {
     const float* gpart;
-    const double* cells_fwd;
-    const double* cells_bwd;
-    const double* cell_loss;
+    double* cells;
     float* grads;
     float* loss;
     float* bn_batch;
@@ -801,7 +826,7 @@ struct FinalizeK {
 
 __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
-    const float lr_over_bc1 = step_scratch(f.cell_loss)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cell_loss)->inv_sqrt_bc2;
+    const float lr_over_bc1 = step_scratch(f.cells, L)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cells, L)->inv_sqrt_bc2;
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nw = (gridDim.x * blockDim.x) >> 6;
@@ -826,7 +851,7 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
             float v = 0.f;
             if (from_cells) {
                 // d gamma = sum dy*xhat, d beta = sum dy
-                v = (float)f.cells_bwd[(bn * 2 + (which == 0 ? 1 : 0)) * F + c];
+                v = (float)cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c);
             } else {
                 for (int b = lane; b < nblk; b += 64) v += f.gpart[(size_t)b * f.pcount + p];
                 v = wave_sum(v);
@@ -846,15 +871,16 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
         }
     }
     if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(f.cell_loss[0] / (double)f.global_batch);
+        if (threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
         for (int i = threadIdx.x; i < 2 * L * F; i += blockDim.x) {
             const int b = i / F, c = i % F;
-            const double mean = f.cells_fwd[(b * 2 + 0) * F + c] / cnt;
-            double var = f.cells_fwd[(b * 2 + 1) * F + c] / cnt - mean * mean;
+            const double s2 = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 1) * F + c);
+            const double mean = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 0) * F + c) / cnt;
+            double var = s2 / cnt - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             if (f.moment_weight > 0.f) {
                 f.bn_batch[(b * 2 + 0) * F + c] = (float)(mean * (double)f.moment_weight);
-                f.bn_batch[(b * 2 + 1) * F + c] = (float)(f.cells_fwd[(b * 2 + 1) * F + c] / cnt * (double)f.moment_weight);
+                f.bn_batch[(b * 2 + 1) * F + c] = (float)(s2 / cnt * (double)f.moment_weight);
             } else {
                 f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
                 f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
@@ -908,7 +934,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
-    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8) + sizeof(StepScratch);
+    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch);
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
@@ -936,7 +962,7 @@ static int wave_area_for(int kind, int idx, const TileGeom& g) {
 
 static size_t train_lds_bytes(int RW, int L, int wave_area) {
     const int tws = RW + 4, nth = RW == 16 ? 0 : (RW / 16) * (RW / 16);
-    const size_t fl = (size_t)3 * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
+    const size_t fl = (size_t)2 * cell_stride(L) + (size_t)3 * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
                       (size_t)(15 + 4 * nth) * 64 + (size_t)WAVES_PER_BLOCK * 24 + (size_t)WAVES_PER_BLOCK * wave_area;
     return fl * sizeof(float);
 }
@@ -997,10 +1023,7 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     TrainK& k = *kp;
     k.cacheX = reinterpret_cast<float*>(ws + w.off_cacheX);
     k.cacheA = reinterpret_cast<float*>(ws + w.off_cacheA);
-    double* cells = reinterpret_cast<double*>(ws + w.off_cells);
-    k.cells_fwd = cells;
-    k.cells_bwd = cells + 2 * L * 2 * F;
-    k.cell_loss = cells + 2 * (2 * L * 2 * F);
+    k.cells = reinterpret_cast<double*>(ws + w.off_cells);
     k.gpart = reinterpret_cast<float*>(ws + w.off_gpart);
     k.saved = reinterpret_cast<float*>(ws + w.off_saved);
     k.rbuf = reinterpret_cast<float*>(ws + w.off_rbuf);
@@ -1029,9 +1052,10 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 // Head of every step: clears the reduction cells (what a memset did before) and writes the step scratch -- dropout keys of
 // (seed, step) and, for the fused optimizer, Adam's bias corrections.  With a device step state the counters are advanced and
 // read there (hipGraph replay), else they come from the arguments.
-__global__ void stgcn_prepare_kernel(double* zero_from, int nzero, StepScratch* sc, StepState* st, uint64_t seed, uint64_t step,
-                                     int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1, float beta2) {
-    for (int i = threadIdx.x; i < nzero; i += blockDim.x) zero_from[i] = 0.0;
+__global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st, uint64_t seed,
+                                     uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1,
+                                     float beta2) {
+    for (int i = threadIdx.x; i < nzero * CELL_REPLICAS; i += blockDim.x) cells[(i / nzero) * stride + zero_from + i % nzero] = 0.0;
     if (threadIdx.x != 0) return;
     if (new_forward) {
         if (st) step = ++st->dropout_step;
@@ -1052,7 +1076,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     int rc = RULGNN_OK;
     const float* gy = a->dpred ? a->dpred : a->y;
 
-    StepScratch* sc = reinterpret_cast<StepScratch*>(k.cell_loss + 8);
+    StepScratch* sc = step_scratch(k.cells, L);
     const bool fused_adam = opt && mode == TM_FWDBWD;
     void* adam_state = fused_adam ? opt->step_state : nullptr;
     if (adam_state && a->step_state && adam_state != a->step_state) return RULGNN_EINVAL;
@@ -1060,7 +1084,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     (void)hipGetLastError();
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
         // a new forward: all cells, fresh dropout keys (a backward-only call below reuses the keys of its forward)
-        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells_fwd, 2 * (2 * L * 2 * F) + 8, sc,
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), sc,
                            a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
                            fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -1068,7 +1092,8 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         if (rc != RULGNN_OK) return rc;
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
-        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells_bwd, 2 * L * 2 * F + 8, sc, (StepState*)nullptr,
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, cell_bwd(L), cell_stride(L) - cell_bwd(L),
+                           cell_stride(L), sc, (StepState*)nullptr,
                            a->seed, a->step, L, 0, 0, (int64_t)0, 0.f, 0.f, 0.f);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
@@ -1081,7 +1106,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         if (rc != RULGNN_OK) return rc;
     }
     FinalizeK f;
-    f.gpart = k.gpart; f.cells_fwd = k.cells_fwd; f.cells_bwd = k.cells_bwd; f.cell_loss = k.cell_loss;
+    f.gpart = k.gpart; f.cells = k.cells;
     f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
     f.grid_top = grid_top;
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];

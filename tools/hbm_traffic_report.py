@@ -1,0 +1,32 @@
+"""HBM bytes per launch of the ST_GCN phase kernels from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh.
+    python tools/hbm_traffic_report.py gpurun_out/<tag> profiles/<name>.json [batch]
+Counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B),
+WRITE_SIZE is taken as is."""
+import csv, collections, glob, json, re, sys
+tag, out = sys.argv[1], sys.argv[2]
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+def collect(sub, counter):
+    res = collections.defaultdict(list)
+    for f in glob.glob(f"{tag}/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)>", r["Kernel_Name"])
+            if m:
+                name = {"0": "F", "1": "TOP", "2": "G"}[m.group(3)] + (m.group(4) if m.group(3) != "1" else "")
+            elif "stgcn_forward_eval" in r["Kernel_Name"]:
+                name = "EVAL"
+            else:
+                continue
+            res[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in res.items()}
+fetch, write = collect("fetch", "FETCH_SIZE"), collect("write", "WRITE_SIZE")
+kern = {}
+for k in fetch:
+    b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+    kern[k] = {"fetch_kb_raw": fetch[k], "write_kb_raw": write.get(k, 0.0), "hbm_bytes_per_launch": b, "hbm_bytes_per_sample": b / batch}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); counters are in KB; "
+                   "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE taken as is",
+           "workload": {"num_patch": 14, "patch_size": 30, "batch": batch}, "kernels": kern}, open(out, "w"), indent=1)
+for k, v in kern.items():
+    print(f"{k:5s} {v['hbm_bytes_per_sample']:8.0f} B/sample")
