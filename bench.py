@@ -69,12 +69,14 @@ def phase_names(L):
 
 
 def phase_bytes_per_sample(name, N, P, L):
-    """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, 16-lane]
-    fp32 state tensor per sample = 640 B: X0 / adjacency rows (cache), X_l, x-hat mask, dX, d(x0+H) and the
-    activations H, z1, o0, z2 each layer hands from phase to phase (stgcn_train.hip::SavedSlot)."""
-    T = 10 * 16 * 4
+    """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, N] fp32 state
+    tensor per sample (packed: only the N patch lanes of a row are stored) = 560 B at N = 14: X0, X_l, x-hat mask, dX,
+    d(x0+H) and the activations H, z1, o0, z2 each layer hands from phase to phase (stgcn_train.hip::SavedSlot);
+    A = the [10, 10] adjacency = 400 B."""
+    T = 10 * N * 4
+    A = 10 * 10 * 4
     if name == "F0":
-        return N * P * 4 + 4 * T                       # read the window; write X0, adjacency rows, H, z1
+        return N * P * 4 + 3 * T + A                   # read the window; write X0, adjacency, H, z1
     if name == "TOP":
         return 4 * T + 8                               # X_{L-1}, o0, z2; write dX_L; y in, pred out
     i = int(name[1:])
@@ -82,17 +84,17 @@ def phase_bytes_per_sample(name, N, P, L):
     if name[0] == "F":
         if blk == 1:
             return 4 * T                               # F_{2l+1}: H, z1; write o0, z2
-        return 8 * T                                   # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, x-hat mask, H, z1
+        return 7 * T + A                               # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, x-hat mask, H, z1
     if blk == 1:
         return 5 * T                                   # G_{2l+1}: z1, o0, z2, dX_{l+1}; write d(x0+H)
-    return (5 * T) if l == 0 else (8 * T)              # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
+    return (4 * T + A) if l == 0 else (7 * T + A)      # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
 
 
 def measured_traffic(kernel_key, N, P, B):
     """HBM bytes per launch from the committed PMC summary (profiles/r01_hbm_traffic.json), scaled to this
     batch; None when the profiled workload does not match."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")))
         w = t["workload"]
         if (w["num_patch"], w["patch_size"]) != (N, P) or kernel_key not in t["kernels"]:
             return None
