@@ -124,6 +124,8 @@ _SIGNATURES = {
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
     "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
+    "rulgnn_rul_metrics_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "rulgnn_rul_metrics_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rulgnn_adam_step_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "rulgnn_fcstgnn_param_count": (C.c_int64, [C.POINTER(FcstgnnShape)]),

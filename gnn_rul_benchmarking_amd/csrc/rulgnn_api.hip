@@ -484,4 +484,14 @@ int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape* shape, float*
     return stconv_bn_running_update(shape, bn_stats, bn_batch, count, momentum, from_moments, static_cast<hipStream_t>(stream));
 }
 
+size_t rulgnn_rul_metrics_workspace_bytes(int64_t n) { return rul_metrics_workspace_bytes(n); }
+
+int rulgnn_rul_metrics_f32(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (n < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({pred, real, out, workspace});
+    if (rc != RULGNN_OK) return rc;
+    return rul_metrics(pred, real, n, max_rul, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

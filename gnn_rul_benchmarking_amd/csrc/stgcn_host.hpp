@@ -141,4 +141,8 @@ int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
                       hipStream_t stream);
 
+size_t rul_metrics_workspace_bytes(int64_t n);
+int rul_metrics(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace, size_t workspace_bytes,
+                hipStream_t st);
+
 }  // namespace rulgnn

@@ -1,5 +1,7 @@
-"""RUL metrics with the reference's formulas (utils.py:136-201), vectorised instead of per-sample
-Python loops.  ``_calc_metrics`` returns (Score_v1, Score_v2, MAE, RMSE) like utils.py:191-201."""
+"""RUL metrics with the reference's formulas (utils.py:136-201).  ``_calc_metrics`` returns (Score_v1, Score_v2, MAE, RMSE)
+like utils.py:191-201.  Host arrays go through the vectorised numpy forms below (instead of per-sample Python loops); CUDA
+tensors go through ``device_metrics`` -- one reduction kernel over the predictions where the eval forward left them
+(``rulgnn_rul_metrics_f32``), 32 bytes to the host."""
 from __future__ import annotations
 
 import math
@@ -36,7 +38,33 @@ def mae_value(predicted, real, max_rul):
 
 
 def _calc_metrics(pred_labels, true_labels, max_rul):
+    if getattr(pred_labels, "is_cuda", False):          # predictions still on the GPU: reduce them there
+        return device_metrics(pred_labels, true_labels, max_rul)
     pred_labels, true_labels = np.array(pred_labels), np.array(true_labels)
     score_v1, _ = scoring_function(pred_labels, true_labels, max_rul)
     return score_v1, scoring_function_v2(pred_labels, true_labels), mae_value(pred_labels, true_labels, max_rul), \
         rmse_value(pred_labels, true_labels, max_rul)
+
+
+def device_metrics(pred, real, max_rul):
+    """(Score_v1, Score_v2, MAE, RMSE) of two float32 CUDA tensors, computed on the device in fp64.
+    Raises if the HIP library is missing: there is no host fallback behind this entry."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    if not (pred.is_cuda and real.is_cuda):
+        raise RuntimeError("device_metrics needs CUDA tensors; use _calc_metrics for host arrays")
+    lib = _lib.load()
+    p = pred.detach().reshape(-1).float().contiguous()
+    r = real.detach().reshape(-1).float().contiguous()
+    if p.numel() != r.numel() or p.numel() < 1:
+        raise RuntimeError(f"device_metrics: {p.numel()} predictions vs {r.numel()} labels")
+    n = p.numel()
+    ws = torch.empty(int(lib.rulgnn_rul_metrics_workspace_bytes(n)) // 8, dtype=torch.float64, device=p.device)
+    out = torch.empty(4, dtype=torch.float64, device=p.device)
+    st = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+    _lib.check(lib.rulgnn_rul_metrics_f32(p.data_ptr(), r.data_ptr(), n, float(max_rul), out.data_ptr(), ws.data_ptr(),
+                                          ws.numel() * 8, st), "rul_metrics")
+    return tuple(float(v) for v in out.cpu())

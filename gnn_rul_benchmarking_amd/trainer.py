@@ -131,10 +131,15 @@ class GNN_RUL_trainer(object):
                 loss_total.append(F.mse_loss(predictions, labels))
                 preds.append(predictions.detach())
                 trues.append(labels)
-        # one device->host copy per test set instead of one per batch (trainer.py:148-152)
-        pred_labels = torch.cat(preds).cpu().numpy().astype(np.float64) if preds else np.array([])
-        true_labels = torch.cat(trues).cpu().numpy().astype(np.float64) if trues else np.array([])
-        return pred_labels, true_labels, [float(v) for v in torch.stack(loss_total).cpu()] if loss_total else []
+        losses = [float(v) for v in torch.stack(loss_total).cpu()] if loss_total else []
+        if not preds:
+            return np.array([]), np.array([]), losses
+        pred_labels, true_labels = torch.cat(preds), torch.cat(trues)
+        if pred_labels.is_cuda:
+            # the predictions stay on the GPU: the metrics are reduced there (metrics.device_metrics) and they only travel
+            # to the host when a best row is saved -- instead of one copy per batch (trainer.py:148-152)
+            return pred_labels, true_labels, losses
+        return pred_labels.numpy().astype(np.float64), true_labels.numpy().astype(np.float64), losses
 
     def test_prediction(self, algorithm):
         model = algorithm.model.to(self.device)
@@ -158,7 +163,8 @@ class GNN_RUL_trainer(object):
             if ind[3] < best[3][-1]:
                 for i in range(4):
                     best[i].append(ind[i])
-                torch.save({'pre': pred, 'real': real, 'max_rul': max_rul}, os.path.join(save_path, f"{stem}results.pt"))
+                host = lambda v: v.cpu().numpy().astype(np.float64) if torch.is_tensor(v) else v
+                torch.save({'pre': host(pred), 'real': host(real), 'max_rul': max_rul}, os.path.join(save_path, f"{stem}results.pt"))
             pd.DataFrame({n: best[i] for i, n in enumerate(names)}).to_csv(os.path.join(save_path, f"{stem}results.csv"),
                                                                           index=False)
             self.logger.debug(f'Testing{label}, ' + ', '.join(f'{n}: {best[i][-1]}' for i, n in enumerate(names)))

@@ -457,6 +457,17 @@ int rulgnn_stconv_fwdbwd_f32(const rulgnn_stconv_shape *shape, const rulgnn_astg
 int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape *shape, float *bn_stats, const float *bn_batch, int64_t count,
                                         float momentum, int32_t from_moments, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * RUL test metrics on the device.
+ *
+ * Replaces _calc_metrics (utils.py:191-201) and the per-batch device-to-host copies in front of it (trainer.py:148-152):
+ * out[0..3] = Score_v1 (utils.py:136-146, sum), Score_v2 (utils.py:157-169, mean), MAE * max_rul, RMSE * max_rul, all
+ * accumulated in fp64 with a fixed summation order.  pred / real: n floats in device memory; out: 4 doubles in device memory.
+ */
+size_t rulgnn_rul_metrics_workspace_bytes(int64_t n);
+int rulgnn_rul_metrics_f32(const float *pred, const float *real, int64_t n, float max_rul, double *out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
