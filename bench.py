@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true", help="loss.item() every step like the reference")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel step even for world_size 1 (exercises RCCL)")
-    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN"],
+    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN"],
                     help="ST_GCN (default) is the headline benchmark; the others run the same contract on the SURVEY section 8d "
                          "configuration of that model family")
     return ap.parse_args()
@@ -188,6 +188,9 @@ FAMILY_CONFIGS = {
     "FC_STGNN": ("CMAPSS", "FD004", 256, (14, 50), 3.28e6),
     "HAGCN": ("CMAPSS", "FD004", 256, (14, 50), 0.99e6 + 8.7e6),
     "STMSGCN": ("XJTU_SY", "Condition_1", 128, (1, 32768), 185e6),
+    # SURVEY 8f rank 3; forward FLOPs per sample: ChebNet projection 14*150*64*2, graph terms 2*14*14*50*2 + cdist 14*14*50*3,
+    # GRU input projection 14*64*192*2 (one step, h0 = 0), fc 896*2
+    "STGNN": ("CMAPSS", "FD004", 256, (14, 50), 0.68e6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
 
@@ -216,6 +219,12 @@ def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
         bs = 2
         x, y = rng.uniform(0, 1, (bs, shape[1])), rng.uniform(0, 1, bs)
         run = lambda: O.loss_and_grads(p, x, y, c)
+    elif family == "STGNN":
+        from oracle import stgnn_oracle as O
+        p = O.random_params(cfg["num_patch"], cfg["patch_size"], cfg["num_nodes"], cfg["hidden_dim"], cfg["K"])
+        bs = 256
+        x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
+        run = lambda: O.forward_backward(x, y, p, cfg["num_patch"], cfg["patch_size"], cfg["top_k"])
     else:
         return None                    # HAGCN: the oracle restates forward + per-block backward, not one timed train step
     run()

@@ -66,6 +66,19 @@ class StconvShape(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("kernel_size", C.c_int32)]
 
 
+class StgnnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64)] + [(k, C.c_int32) for k in ("num_nodes", "num_patch", "patch_size", "hidden_dim", "K", "top_k")]
+
+
+class GruShape(C.Structure):
+    _fields_ = [("num_seq", C.c_int64), ("seq_len", C.c_int32), ("input_dim", C.c_int32), ("hidden_dim", C.c_int32)]
+
+
+class GruArgs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("x", "w_ih", "w_hh", "b_ih", "b_hh", "out", "dout", "dx", "dw_ih", "dw_hh", "db_ih", "db_hh",
+                                          "workspace")] + [("workspace_bytes", C.c_size_t)]
+
+
 class FcstgnnShape(C.Structure):
     _fields_ = [("batch", C.c_int64)] + [(k, C.c_int32) for k in (
         "patch_size", "num_patch", "encoder_time_out", "encoder_hidden_dim", "encoder_out_dim", "encoder_conv_kernel",
@@ -124,6 +137,14 @@ _SIGNATURES = {
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
     "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
+    "rulgnn_stgnn_workspace_bytes": (C.c_size_t, [C.POINTER(StgnnShape)]),
+    "rulgnn_stgnn_terms_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rulgnn_stgnn_cheb_forward_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rulgnn_stgnn_cheb_backward_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p]),
+    "rulgnn_gru_workspace_bytes": (C.c_size_t, [C.POINTER(GruShape)]),
+    "rulgnn_gru_forward_f32": (C.c_int, [C.POINTER(GruShape), C.POINTER(GruArgs), C.c_void_p]),
+    "rulgnn_gru_backward_f32": (C.c_int, [C.POINTER(GruShape), C.POINTER(GruArgs), C.c_void_p]),
     "rulgnn_rul_metrics_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "rulgnn_rul_metrics_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rulgnn_adam_step_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,

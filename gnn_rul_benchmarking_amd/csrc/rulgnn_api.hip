@@ -484,6 +484,64 @@ int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape* shape, float*
     return stconv_bn_running_update(shape, bn_stats, bn_batch, count, momentum, from_moments, static_cast<hipStream_t>(stream));
 }
 
+size_t rulgnn_stgnn_workspace_bytes(const rulgnn_stgnn_shape* shape) { return stgnn_workspace_bytes(shape); }
+
+int rulgnn_stgnn_terms_f32(const rulgnn_stgnn_shape* shape, const float* x, float* terms, float* adj, void* stream) {
+    if (!shape) return RULGNN_EINVAL;
+    if (shape->batch > 0) {
+        const int rc = check_ptrs({x, terms});
+        if (rc != RULGNN_OK) return rc;
+    }
+    return stgnn_terms(shape, x, terms, adj, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgnn_cheb_forward_f32(const rulgnn_stgnn_shape* shape, const float* terms, const float* filters, float* out,
+                                  void* stream) {
+    if (!shape) return RULGNN_EINVAL;
+    if (shape->batch > 0) {
+        const int rc = check_ptrs({terms, filters, out});
+        if (rc != RULGNN_OK) return rc;
+    }
+    return stgnn_cheb_forward(shape, terms, filters, out, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgnn_cheb_backward_f32(const rulgnn_stgnn_shape* shape, const float* terms, const float* dout, float* dfilters,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (!shape) return RULGNN_EINVAL;
+    int rc = check_ptrs({dfilters, workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch > 0) {
+        rc = check_ptrs({terms, dout});
+        if (rc != RULGNN_OK) return rc;
+    }
+    return stgnn_cheb_backward(shape, terms, dout, dfilters, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t rulgnn_gru_workspace_bytes(const rulgnn_gru_shape* shape) { return gru_workspace_bytes(shape); }
+
+int rulgnn_gru_forward_f32(const rulgnn_gru_shape* shape, const rulgnn_gru_args* args, void* stream) {
+    if (!shape || !args) return RULGNN_EINVAL;
+    int rc = check_ptrs({args->w_ih, args->w_hh, args->b_ih, args->b_hh, args->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->num_seq > 0) {
+        rc = check_ptrs({args->x, args->out});
+        if (rc != RULGNN_OK) return rc;
+    }
+    return gru_forward(shape, args, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_gru_backward_f32(const rulgnn_gru_shape* shape, const rulgnn_gru_args* args, void* stream) {
+    if (!shape || !args) return RULGNN_EINVAL;
+    int rc = check_ptrs({args->w_ih, args->w_hh, args->b_ih, args->b_hh, args->workspace, args->dw_ih, args->dw_hh, args->db_ih,
+                         args->db_hh});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->num_seq > 0) {
+        rc = check_ptrs({args->x, args->dout});
+        if (rc != RULGNN_OK) return rc;
+    }
+    return gru_backward(shape, args, static_cast<hipStream_t>(stream));
+}
+
 size_t rulgnn_rul_metrics_workspace_bytes(int64_t n) { return rul_metrics_workspace_bytes(n); }
 
 int rulgnn_rul_metrics_f32(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace,

@@ -141,6 +141,14 @@ int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
                       hipStream_t stream);
 
+size_t stgnn_workspace_bytes(const rulgnn_stgnn_shape* s);
+int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float* adj, hipStream_t st);
+int stgnn_cheb_forward(const rulgnn_stgnn_shape* s, const float* terms, const float* filters, float* out, hipStream_t st);
+int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const float* dout, float* dfilters, void* workspace,
+                        size_t workspace_bytes, hipStream_t st);
+size_t gru_workspace_bytes(const rulgnn_gru_shape* s);
+int gru_forward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t st);
+int gru_backward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t st);
 size_t rul_metrics_workspace_bytes(int64_t n);
 int rul_metrics(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace, size_t workspace_bytes,
                 hipStream_t st);

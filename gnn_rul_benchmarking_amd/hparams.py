@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN and ST_Conv rows are restated (the methods this package
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN, ST_Conv and STGNN rows are restated (the methods this package
 implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
@@ -64,6 +64,11 @@ class _Table:
             self.train_params['HAGCN'] = dict(_HAGCN_TRAIN)
             self.alg_hparams['HAGCN'] = {'patch_size': ps, 'num_patch': npatch, 'hidden_dim': 64, 'encoder_hidden_dim': 60,
                                          'output_dim': 32}
+            # configs/hparams.py:27,47,88,128,168 (C-MAPSS: one patch of 50) and :191,211 (N-CMAPSS: 5 patches of 10)
+            self.train_params['STGNN'] = dict(_ASTGCNN_TRAIN)
+            self.alg_hparams['STGNN'] = {'patch_size': 50 if self._astgcnn_nodes == 14 else 10,
+                                         'num_patch': 1 if self._astgcnn_nodes == 14 else 5, 'num_nodes': self._astgcnn_nodes,
+                                         'hidden_dim': 64, 'K': 3, 'top_k': 10}
             self.train_params['FC_STGNN'] = dict(_FC_STGNN_TRAIN)
             self.alg_hparams['FC_STGNN'] = dict(_FC_STGNN_ROWS[dataset_id])
         if dataset_id in self._stmsgcn_rows:

@@ -458,6 +458,64 @@ int rulgnn_stconv_bn_running_update_f32(const rulgnn_stconv_shape *shape, float 
                                         float momentum, int32_t from_moments, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * STGNN graph path -- models/STGNN/Model.py.
+ *
+ * The model input carries no gradient and the adjacency depends on the input alone: graph construction is forward-only,
+ * ChebNet's backward is the filter gradient.  G = batch * num_patch graphs of num_nodes nodes with patch_size features.
+ */
+typedef struct rulgnn_stgnn_shape {
+    int64_t batch;
+    int32_t num_nodes;   /* <= 32 */
+    int32_t num_patch;
+    int32_t patch_size;  /* <= 128 */
+    int32_t hidden_dim;
+    int32_t K;           /* Chebyshev order, <= 4 */
+    int32_t top_k;       /* <= num_nodes */
+} rulgnn_stgnn_shape;
+
+size_t rulgnn_stgnn_workspace_bytes(const rulgnn_stgnn_shape *shape);      /* 0: invalid / unsupported */
+/* compute_adjacency_matrix (Model.py:8-25) + the Chebyshev terms of ChebNet.forward (:49-59) for x [batch, num_nodes,
+ * num_patch*patch_size]: terms [G*num_nodes, K*patch_size] (row = graph*num_nodes + node, column = k*patch_size + j);
+ * adj [G, num_nodes, num_nodes] is optional (NULL to skip). */
+int rulgnn_stgnn_terms_f32(const rulgnn_stgnn_shape *shape, const float *x, float *terms, float *adj, void *stream);
+/* ChebNet.forward (:52-61): out [G*num_nodes, hidden_dim] = sum_k T_k filters[k], filters [K, patch_size, hidden_dim]. */
+int rulgnn_stgnn_cheb_forward_f32(const rulgnn_stgnn_shape *shape, const float *terms, const float *filters, float *out,
+                                  void *stream);
+/* Its backward: dfilters [K, patch_size, hidden_dim] = T_k^T dout (deterministic split-K reduction). */
+int rulgnn_stgnn_cheb_backward_f32(const rulgnn_stgnn_shape *shape, const float *terms, const float *dout, float *dfilters,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One-layer GRU over many short sequences -- nn.GRU(input_dim, hidden_dim, batch_first=True), h0 = 0, gate order (r, z, n);
+ * STGNN's recurrent part (models/STGNN/Model.py:71,97-98: batch*nodes sequences of num_patch steps).
+ *
+ * Tensors: x [num_seq, seq_len, input_dim]; w_ih [3H, input_dim]; w_hh [3H, H]; b_ih, b_hh [3H] (torch's *_l0);
+ * out, dout [num_seq, seq_len, H]; gradients in the shapes of their tensors.  The workspace carries the tape (input and
+ * recurrent projections, previous states) from forward to backward.
+ */
+typedef struct rulgnn_gru_shape {
+    int64_t num_seq;
+    int32_t seq_len;
+    int32_t input_dim;
+    int32_t hidden_dim;
+} rulgnn_gru_shape;
+
+typedef struct rulgnn_gru_args {
+    const float *x;
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    float *out;               /* forward out */
+    const float *dout;        /* backward in */
+    float *dx;                /* backward out; may be NULL */
+    float *dw_ih, *dw_hh, *db_ih, *db_hh;
+    void *workspace;
+    size_t workspace_bytes;
+} rulgnn_gru_args;
+
+size_t rulgnn_gru_workspace_bytes(const rulgnn_gru_shape *shape);           /* 0: invalid / unsupported */
+int rulgnn_gru_forward_f32(const rulgnn_gru_shape *shape, const rulgnn_gru_args *args, void *stream);
+int rulgnn_gru_backward_f32(const rulgnn_gru_shape *shape, const rulgnn_gru_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RUL test metrics on the device.
  *
  * Replaces _calc_metrics (utils.py:191-201) and the per-batch device-to-host copies in front of it (trainer.py:148-152):

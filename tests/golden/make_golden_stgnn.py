@@ -106,7 +106,58 @@ def case_training_curve(name, cfg, bs, steps, seed, lr, wd):
     print("wrote", name, losses[:3], "...", losses[-1])
 
 
+def case_trainer_cmapss(name, seed, n_train=250, n_test=80, epochs=3):
+    """The reference's OWN harness (trainer.GNN_RUL_trainer) with --GNN_method STGNN on the synthetic C-MAPSS FD003 dataset
+    of synth.py, its own hparams (configs/hparams.py:105,128: batch 100, lr 1e-3, wd 1e-4) and its own shuffling DataLoader;
+    only num_epochs is patched.  Records every epoch's test metrics, the results CSV and a few final tensors."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_cmapss
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "CMAPSS", "FD003")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="STGNN", data_path=os.path.join(tmp, "data"), dataset="CMAPSS",
+                                      dataset_id="FD003", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "STGNN_run_0", "results.csv")).read()
+            final = {k: v.detach().numpy().copy() for k, v in tr.algorithm.state_dict().items()}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum()),
+           "batch_size": np.int64(tr.train_configs["batch_size"]), "lr": np.float64(tr.train_configs["learning_rate"])}
+    for k in ("model.fc.weight", "model.fc.bias", "model.gru.bias_hh_l0", "model.gru.weight_ih_l0"):
+        out["final:" + k] = final[k]
+    out["final_mean:model.chebnet.filters"] = final["model.chebnet.filters"].mean(axis=1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "trainer":
+        case_trainer_cmapss("stgnn_trainer_cmapss_fd003_reference_run", 8)
+        sys.exit(0)
     cmapss = dict(patch_size=50, num_patch=1, num_nodes=14, hidden_dim=64, K=3, top_k=10)
     ncmapss = dict(patch_size=10, num_patch=5, num_nodes=20, hidden_dim=64, K=3, top_k=10)
     small = dict(patch_size=7, num_patch=3, num_nodes=6, hidden_dim=12, K=2, top_k=4)
@@ -115,3 +166,4 @@ if __name__ == "__main__":
     case_forward_backward("stgnn_small_3x7_bs6", small, 6, 13)
     case_init("stgnn_init_cmapss_seed5", cmapss, 5)
     case_training_curve("stgnn_train_curve_1x50_bs16", cmapss, 16, 20, 3, 1e-3, 1e-4)
+    case_trainer_cmapss("stgnn_trainer_cmapss_fd003_reference_run", 8)

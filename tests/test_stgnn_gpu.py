@@ -1,0 +1,120 @@
+"""STGNN on the GPU: the HIP graph path + library GRU/fc against the reference's own outputs (tests/golden/stgnn_*.npz),
+against the numpy oracle on random shapes, and the reference's training curve.  Tolerances: 1e-4 relative on the forward
+(SURVEY section 8d), gradients 2e-3 of the tensor's scale."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+from gnn_rul_benchmarking_amd.stgnn import STGNN_model
+from oracle import stgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "stgnn_*.npz")) if "init" not in p and "curve" not in p and "trainer" not in p)
+DEV = "cuda:0"
+
+
+def model_from(z, cfg):
+    m = STGNN_model(**cfg)
+    m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_forward_and_gradients_match_the_reference(path):
+    z = np.load(path)
+    cfg = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg:")}
+    m = model_from(z, cfg)
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    m.train()
+    pred = m(x, return_adjacency=True)
+    adj = m.last_adjacency.reshape(-1, cfg["num_nodes"], cfg["num_nodes"]).cpu().numpy()
+    assert ((adj != 0) == (z["adj"] != 0)).all()                     # same top-k selection
+    assert np.allclose(adj, z["adj"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(pred.detach().cpu().numpy(), z["pred"], rtol=1e-4, atol=1e-5)
+    loss = torch.nn.functional.mse_loss(pred, y)
+    loss.backward()
+    assert abs(loss.item() - float(z["loss"])) <= 1e-4 * abs(float(z["loss"]))
+    for n_, p in m.named_parameters():
+        g = z["grad:" + n_]
+        assert np.allclose(p.grad.cpu().numpy(), g, rtol=2e-3, atol=1e-6 + 2e-4 * np.abs(g).max()), n_
+    m.eval()
+    with torch.no_grad():
+        assert np.allclose(m(x).cpu().numpy(), z["eval_pred"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("cfg,bs", [(dict(patch_size=5, num_patch=4, num_nodes=9, hidden_dim=16, K=1, top_k=9), 7),
+                                    (dict(patch_size=128, num_patch=2, num_nodes=32, hidden_dim=40, K=4, top_k=5), 3),
+                                    (dict(patch_size=50, num_patch=1, num_nodes=14, hidden_dim=64, K=3, top_k=10), 100),
+                                    (dict(patch_size=3, num_patch=1, num_nodes=2, hidden_dim=5, K=2, top_k=1), 1)])
+def test_matches_the_oracle_on_random_shapes(cfg, bs):
+    torch.manual_seed(bs)
+    m = STGNN_model(**cfg).to(DEV)
+    x = torch.rand(bs, cfg["num_nodes"], cfg["num_patch"] * cfg["patch_size"], device=DEV) * (0.4 if cfg["patch_size"] > 60 else 1.0)
+    y = torch.rand(bs, 1, device=DEV)
+    pred = m(x)
+    loss = torch.nn.functional.mse_loss(pred, y)
+    loss.backward()
+    p = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    oloss, grads, out, _ = O.forward_backward(x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64), p, cfg["num_patch"],
+                                              cfg["patch_size"], cfg["top_k"])
+    assert np.allclose(pred.detach().cpu().numpy(), out, rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - oloss) <= 1e-4 * abs(oloss) + 1e-7
+    for n_, prm in m.named_parameters():
+        assert np.allclose(prm.grad.cpu().numpy(), grads[n_], rtol=2e-3, atol=1e-6 + 2e-4 * np.abs(grads[n_]).max()), n_
+
+
+def test_empty_batch_and_determinism():
+    cfg = dict(patch_size=10, num_patch=5, num_nodes=20, hidden_dim=64, K=3, top_k=10)
+    torch.manual_seed(0)
+    m = STGNN_model(**cfg).to(DEV)
+    x = torch.rand(33, 20, 50, device=DEV) * 2 - 1
+    y = torch.rand(33, 1, device=DEV)
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        torch.nn.functional.mse_loss(m(x), y).backward()
+        grads.append(m.chebnet.filters.grad.clone())
+    assert torch.equal(grads[0], grads[1])                            # split-K reduction in a fixed order
+    with torch.no_grad(), pytest.raises(RuntimeError):                # like the reference: reshape(0, -1) is ambiguous (Model.py:101)
+        m(torch.empty(0, 20, 50, device=DEV))
+
+
+def test_training_curve_follows_the_reference():
+    z = np.load(os.path.join(GOLD, "stgnn_train_curve_1x50_bs16.npz"))
+    cfg = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg:")}
+    torch.manual_seed(int(z["seed"]))
+    algo = get_algorithm_class("STGNN")(cfg, {"learning_rate": float(z["lr"]), "weight_decay": float(z["wd"])}, DEV)
+    algo.to(DEV).train()
+    xs, ys = torch.from_numpy(z["xs"]).to(DEV), torch.from_numpy(z["ys"]).to(DEV)
+    losses = [algo.update(xs[s], ys[s], 1)["loss"] for s in range(xs.size(0))]
+    assert np.allclose(losses, z["losses"], rtol=2e-3)
+    algo.eval()
+    with torch.no_grad():
+        assert np.allclose(algo.model(xs[0]).cpu().numpy(), z["eval_pred_end"], rtol=2e-3, atol=2e-4)
+    for k, v in algo.state_dict().items():
+        assert np.allclose(v.cpu().numpy(), z["sd_end:" + k], rtol=2e-3, atol=3e-4), k
+
+
+@pytest.mark.parametrize("S,L,I,H", [(37, 1, 16, 16), (1400, 1, 64, 64), (500, 5, 64, 64), (3, 7, 10, 33), (2000, 3, 20, 130)])
+def test_gru_kernels_match_torch_cpu_gru(S, L, I, H):
+    """csrc/gru.hip against nn.GRU on the CPU in float64 (forward, input gradient and the four parameter gradients)."""
+    from gnn_rul_benchmarking_amd.stgnn import _GruFunction
+    torch.manual_seed(S + L)
+    ref = torch.nn.GRU(I, H, batch_first=True).double()
+    x = torch.randn(S, L, I, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(S, L, H, dtype=torch.float64)
+    out, _ = ref(x)
+    (out * w).sum().backward()
+    prm = [p.detach().float().to(DEV).requires_grad_(True) for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xg = x.detach().float().to(DEV).requires_grad_(True)
+    og = _GruFunction.apply(xg, *prm)
+    (og * w.float().to(DEV)).sum().backward()
+    assert np.allclose(og.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-4, atol=1e-5)
+    assert np.allclose(xg.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-3, atol=1e-5 + 1e-4 * x.grad.abs().max().item())
+    for p, r in zip(prm, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
+        assert np.allclose(p.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=1e-5 + 2e-4 * r.grad.abs().max().item())

@@ -10,7 +10,7 @@ import pytest
 from oracle import stgnn_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "stgnn_*.npz")) if "init" not in p and "curve" not in p)
+CASES = sorted(p for p in glob.glob(os.path.join(GOLD, "stgnn_*.npz")) if "init" not in p and "curve" not in p and "trainer" not in p)
 
 
 def load(path):

@@ -377,3 +377,53 @@ def test_stconv_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monkey
         if k.startswith("final:"):
             a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
             assert np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30) < 2e-3, k
+
+
+def test_stgnn_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monkeypatch):
+    """--GNN_method STGNN on C-MAPSS FD003 as the reference wires it (configs/hparams.py:105,128; shuffling DataLoader): the
+    reference's own harness, run on CPU by tests/golden/make_golden_stgnn.py::case_trainer_cmapss, vs this package's harness
+    on the GPU (HIP graph function + HIP GRU through autograd, torch.optim.Adam like the reference)."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_cmapss
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "stgnn_trainer_cmapss_fd003_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "CMAPSS" / "FD003"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 125}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 125}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="STGNN", data_path=str(tmp_path / "data"), dataset="CMAPSS",
+                              dataset_id="FD003", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.train_configs["batch_size"] == int(z["batch_size"]) and tr.train_configs["learning_rate"] == float(z["lr"])
+    assert tr.model_configs == dict(patch_size=50, num_patch=1, num_nodes=14, hidden_dim=64, K=3, top_k=10)
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("STGNN harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 2:] - ref[:, 2:]) / np.abs(ref[:, 2:])) < 2e-3      # MAE, RMSE (in RUL cycles), relative
+    sd = tr.algorithm.state_dict()
+    for k in z.files:
+        if k.startswith("final:"):
+            a, b = sd[k[6:]].cpu().numpy().astype(np.float64), z[k].astype(np.float64)
+            assert np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30) < 3e-3, k
+    a = sd["model.chebnet.filters"].cpu().numpy().astype(np.float64).mean(axis=1)
+    assert np.max(np.abs(a - z["final_mean:model.chebnet.filters"])) / np.max(np.abs(z["final_mean:model.chebnet.filters"])) < 3e-3
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "STGNN_run_0" / "results.csv")
+    import io
+    ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
+    assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
+    assert np.allclose(csv.iloc[1:].to_numpy()[:, 2:], ref_csv.iloc[1:].to_numpy()[:, 2:], rtol=2e-3)
