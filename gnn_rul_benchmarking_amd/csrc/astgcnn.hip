@@ -289,8 +289,8 @@ __global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float
         __syncthreads();
     }
     if (tid < N) {
-        atomicAdd(&cells->bwd[1][tid][0], (double)a1);
-        atomicAdd(&cells->bwd[1][tid][1], (double)a2);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][0], (double)a1);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][1], (double)a2);
     }
 }
 
@@ -308,10 +308,10 @@ __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const float
         grads[g.o_w2 + e] = c;
     } else if (e < nW + N) {
         const int c = e - nW;
-        grads[g.o_g1 + c] = (float)cells->bwd[0][c][1];
-        grads[g.o_b1 + c] = (float)cells->bwd[0][c][0];
-        grads[g.o_g2 + c] = (float)cells->bwd[1][c][1];
-        grads[g.o_b2 + c] = (float)cells->bwd[1][c][0];
+        grads[g.o_g1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
+        grads[g.o_b1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
+        grads[g.o_g2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
+        grads[g.o_b2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
     }
 }
 
@@ -321,7 +321,7 @@ __global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __rest
     if (e >= 2 * g.N) return;
     const int blk = e / g.N, c = e % g.N;
     const double count = (double)g.B * g.T;
-    const double m = cells->fwd[blk][c][0] / count, q = cells->fwd[blk][c][1] / count;
+    const double m = cell_sum(cells, &Cells::fwd, blk, c, 0) / count, q = cell_sum(cells, &Cells::fwd, blk, c, 1) / count;
     if (weight > 0.f) {
         bn_batch[(blk * 2 + 0) * g.N + c] = (float)(weight * m);
         bn_batch[(blk * 2 + 1) * g.N + c] = (float)(weight * q);
@@ -361,7 +361,7 @@ void ast_ws_layout(const AstGeom& g, AstWs* w) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t BNT = (size_t)g.B * g.N * g.T * sizeof(float);
     size_t o = 0;
-    w->cells = o; o = al(o + sizeof(Cells));
+    w->cells = o; o = al(o + sizeof(Cells) * CELL_REP);
     w->one = o; o = al(o + 256);
     w->z1 = o; o = al(o + BNT);
     w->out0 = o; o = al(o + BNT);
@@ -443,7 +443,7 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
     (void)hipGetLastError();
     if (mode & 1) {
-        if (hipMemsetAsync(cells, 0, sizeof(Cells), st) != hipSuccess) return RULGNN_EHIP;
+        if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
         const int rows = resident_rows((tcn_conv_kernel<1, AstGeom>), g.B, 1 << 20);
         hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
                            F(w.z1), (float*)nullptr, cells);

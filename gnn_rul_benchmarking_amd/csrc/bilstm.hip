@@ -49,7 +49,7 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
     g->o_one = tk(64);
     int64_t mx = 1;
     for (const auto& mn : {std::pair<int, int>(g->H4, g->I), std::pair<int, int>(g->H4, g->H), std::pair<int, int>(1, g->H4)}) {
-        const int64_t v = (int64_t)sgemm_splitk_slices(mn.first, mn.second, (int)g->rows) * mn.first * mn.second;
+        const int64_t v = (int64_t)sgemm_splitk_need_floats(mn.first, mn.second, (int)g->rows);
         if (v > mx) mx = v;
     }
     g->o_split = tk(mx);

@@ -113,6 +113,23 @@ struct Cells {
     double bwd[NBN][MAXC][2];       // sum dy, sum dy * xhat
 };
 
+// Every workgroup adds its partial sums with one atomic per channel; thousands of workgroups hitting the same addresses
+// serialise (~10 ns each: 40-50 us per streaming kernel at 4096 workgroups), so the cells exist CELL_REP times, workgroup b
+// adds into replica b % CELL_REP and the readers sum the replicas in a fixed order.
+constexpr int CELL_REP = 16;
+__device__ inline double cell_fwd(const Cells* cells, int id, int c, int j) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < CELL_REP; ++r) v += cells[r].fwd[id][c][j];
+    return v;
+}
+__device__ inline double cell_bwd(const Cells* cells, int id, int c, int j) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < CELL_REP; ++r) v += cells[r].bwd[id][c][j];
+    return v;
+}
+
 struct BnCoef {
     float mean, inv, sc, sh;
 };
@@ -120,8 +137,8 @@ __device__ inline BnCoef fbn(const FcGeom& g, const Cells* cells, const float* p
     BnCoef r;
     float var;
     if (training) {
-        const double m = cells->fwd[id][c][0] / g.cnt[id];
-        double v = cells->fwd[id][c][1] / g.cnt[id] - m * m;
+        const double m = cell_fwd(cells, id, c, 0) / g.cnt[id];
+        double v = cell_fwd(cells, id, c, 1) / g.cnt[id] - m * m;
         if (v < 0.0) v = 0.0;
         r.mean = (float)m;
         var = (float)v;
@@ -135,22 +152,49 @@ __device__ inline BnCoef fbn(const FcGeom& g, const Cells* cells, const float* p
     return r;
 }
 
-// per-workgroup (sum, sumsq) accumulators in LDS doubles, flushed to the cells with one atomic per channel
+// per-workgroup (sum, sumsq) accumulators in LDS doubles, flushed to the cells with one atomic per channel.  Two measures
+// against same-address LDS atomics (they serialise: the streaming kernels spent 50-90 us in them at FD004 / batch 256):
+// a thread keeps a private running pair while consecutive elements fall into the same channel, and the LDS slots exist
+// BS_REP times, picked by lane bits, so lanes of one wavefront that do share a channel rarely share an address.
+constexpr int BS_REP = 8;
+constexpr int BS_DOUBLES = BS_REP * 2 * MAXC;
 struct BlockStats {
-    double* s;                      // [C][2] in LDS
-    __device__ void init(double* lds, int C) {
+    double* s;                      // [BS_REP][C][2] in LDS
+    int C, cur;
+    float pa, pb;
+    __device__ void init(double* lds, int C_) {
         s = lds;
-        for (int i = threadIdx.x; i < 2 * C; i += FB) s[i] = 0.0;
+        C = C_;
+        cur = -1;
+        pa = pb = 0.f;
+        for (int i = threadIdx.x; i < BS_REP * 2 * C; i += FB) s[i] = 0.0;
         __syncthreads();
+    }
+    __device__ void spill() {
+        if (cur >= 0) {
+            const int rep = (threadIdx.x ^ (threadIdx.x >> 3)) & (BS_REP - 1);
+            atomicAdd(&s[(rep * C + cur) * 2], (double)pa);
+            atomicAdd(&s[(rep * C + cur) * 2 + 1], (double)pb);
+        }
     }
     __device__ void add(int c, float a, float b) {
-        atomicAdd(&s[2 * c], (double)a);
-        atomicAdd(&s[2 * c + 1], (double)b);
+        if (c != cur) {
+            spill();
+            cur = c;
+            pa = pb = 0.f;
+        }
+        pa += a;
+        pb += b;
     }
-    __device__ void flush(double (*dst)[2], int C) {
+    __device__ void flush(double (*dst)[2], int C_) {
+        spill();
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * C; i += FB)
-            if (s[i] != 0.0) atomicAdd(&dst[i >> 1][i & 1], s[i]);
+        for (int i = threadIdx.x; i < 2 * C_; i += FB) {
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < BS_REP; ++r) v += s[r * 2 * C_ + i];
+            if (v != 0.0) atomicAdd(&dst[i >> 1][i & 1], v);
+        }
     }
 };
 
@@ -172,7 +216,7 @@ __device__ inline float pos_enc(int t, int d, int D2) {     // PositionalEncodin
 // z1[m][c][p] = sum_k w1[c][k] * v[m][p + k - K/2]   (Conv1d(1 -> H1, K, padding K/2), Model_Base.py:17-18)
 __global__ __launch_bounds__(FB) void fc_conv1_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                      float* __restrict__ z1, Cells* cells, int training) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     BlockStats st;
     st.init(sl, g.H1);
     const int64_t total = g.M * g.H1 * g.L1;
@@ -191,13 +235,13 @@ __global__ __launch_bounds__(FB) void fc_conv1_kernel(FcGeom g, const float* __r
         z1[e] = a;
         if (training) st.add(c, a, a * a);
     }
-    if (training) st.flush(cells->fwd[0], g.H1);
+    if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[0], g.H1);
 }
 
 // z2[m][co][p] = sum_ci sum_k w2[co][ci][k] * relu(bn_a(z1))[m][ci][p + k - 1]   (padding 1, Model_Base.py:27-28)
 __global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
                                                      const float* __restrict__ z1, float* __restrict__ z2, Cells* cells, int training) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ca[16];
     if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, running, training, 0, threadIdx.x);
     BlockStats st;
@@ -219,7 +263,7 @@ __global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __r
         z2[e] = a;
         if (training) st.add(co, a, a * a);
     }
-    if (training) st.flush(cells->fwd[1], g.CO);
+    if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[1], g.CO);
 }
 
 // a2 = relu(bn_b(z2)), flattened [m][CO * L2]
@@ -238,7 +282,7 @@ __global__ __launch_bounds__(FB) void fc_act2_kernel(FcGeom g, const float* __re
 // z[r][c] += bias[c] in place; per-column (sum, sumsq) into cells->fwd[id]
 __global__ __launch_bounds__(FB) void fc_bias_stats_kernel(float* __restrict__ z, const float* __restrict__ bias, int64_t rows, int C,
                                                           Cells* cells, int id, int training) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     BlockStats st;
     st.init(sl, C);
     const int64_t total = rows * C;
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(FB) void fc_bias_stats_kernel(float* __restrict__ z
         z[e] = v;
         if (training) st.add(c, v, v * v);
     }
-    if (training) st.flush(cells->fwd[id], C);
+    if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[id], C);
 }
 
 // F = dropout(bn_c(z3) + pe[t]); weighted column statistics for the two window BatchNorms
@@ -256,12 +300,12 @@ __global__ __launch_bounds__(FB) void fc_pe_kernel(FcGeom g, const float* __rest
                                                   Cells* cells, int training, const float* __restrict__ z3, float* __restrict__ F,
                                                   uint32_t drop_thr, float drop_scale, uint32_t drop_key, const uint32_t* key_dev,
                                                   int64_t row_offset) {
-    __shared__ double sl[4 * MAXC];
+    __shared__ double sl[2 * BS_DOUBLES];
     __shared__ BnCoef cc[MAXC];
     if (threadIdx.x < g.D2) cc[threadIdx.x] = fbn(g, cells, prm, running, training, 2, threadIdx.x);
     BlockStats s0, s1;
     s0.init(sl, g.D2);
-    s1.init(sl + 2 * MAXC, g.D2);
+    s1.init(sl + BS_DOUBLES, g.D2);
     const uint32_t key = key_dev ? *key_dev : drop_key;
     const int64_t total = g.M * g.D2;
     for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
@@ -281,8 +325,8 @@ __global__ __launch_bounds__(FB) void fc_pe_kernel(FcGeom g, const float* __rest
         }
     }
     if (training) {
-        s0.flush(cells->fwd[3], g.D2);
-        s1.flush(cells->fwd[5], g.D2);
+        s0.flush(cells[blockIdx.x % CELL_REP].fwd[3], g.D2);
+        s1.flush(cells[blockIdx.x % CELL_REP].fwd[5], g.D2);
     }
 }
 
@@ -410,7 +454,7 @@ __global__ void fc_relu_mask_kernel(float* __restrict__ dz, const float* __restr
 __global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z5, const float* __restrict__ dfeat,
                                                         float* __restrict__ dy5) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ce[MAXC];
     const int id = 4 + 2 * blk;
     if (threadIdx.x < g.HD) ce[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
@@ -428,7 +472,7 @@ __global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, cons
         dy5[e] = dy;
         st.add(h, dy, dy * (zz - ce[h].mean) * ce[h].inv);
     }
-    st.flush(cells->bwd[id], HD);
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[id], HD);
 }
 
 // BatchNorm backward, row-major [rows][C]: dz = sc * (dy - sum_dy/m - xhat * sum_dyxhat/m), in place
@@ -439,8 +483,8 @@ __global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id, co
     const int C = g.bn_ch[id];
     if (threadIdx.x < C) {
         cf[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
-        s1[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][0] / g.cnt[id]);
-        s2[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][1] / g.cnt[id]);
+        s1[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 0) / g.cnt[id]);
+        s2[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 1) / g.cnt[id]);
     }
     __syncthreads();
     const int64_t total = rows * C;
@@ -459,8 +503,8 @@ __global__ __launch_bounds__(FB) void fc_bn_chan_bwd_kernel(FcGeom g, int id, in
     const int C = g.bn_ch[id];
     if (threadIdx.x < C) {
         cf[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
-        s1[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][0] / g.cnt[id]);
-        s2[threadIdx.x] = (float)(cells->bwd[id][threadIdx.x][1] / g.cnt[id]);
+        s1[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 0) / g.cnt[id]);
+        s2[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 1) / g.cnt[id]);
     }
     __syncthreads();
     for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
@@ -537,7 +581,7 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
 __global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                           const float* __restrict__ F, const float* __restrict__ gX0,
                                                           const float* __restrict__ gX1) {
-    __shared__ double sl[4 * MAXC];
+    __shared__ double sl[2 * BS_DOUBLES];
     __shared__ BnCoef c0[MAXD], c1[MAXD];
     if (threadIdx.x < g.D2) {
         c0[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 3, threadIdx.x);
@@ -545,7 +589,7 @@ __global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float
     }
     BlockStats s0, s1;
     s0.init(sl, g.D2);
-    s1.init(sl + 2 * MAXC, g.D2);
+    s1.init(sl + BS_DOUBLES, g.D2);
     const int64_t total = g.M * g.D2;
     for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
         const int d = (int)(e % g.D2);
@@ -553,8 +597,8 @@ __global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float
         s0.add(d, a, a * (f - c0[d].mean) * c0[d].inv);
         s1.add(d, b, b * (f - c1[d].mean) * c1[d].inv);
     }
-    s0.flush(cells->bwd[3], g.D2);
-    s1.flush(cells->bwd[5], g.D2);
+    s0.flush(cells[blockIdx.x % CELL_REP].bwd[3], g.D2);
+    s1.flush(cells[blockIdx.x % CELL_REP].bwd[5], g.D2);
 }
 
 // dF = sum over the two blocks of the window-BatchNorm backward (row form, multiplicity-weighted)
@@ -567,8 +611,8 @@ __global__ __launch_bounds__(FB) void fc_feat_bwd_kernel(FcGeom g, const float* 
         const int d = threadIdx.x;
         c0[d] = fbn(g, cells, prm, nullptr, 1, 3, d);
         c1[d] = fbn(g, cells, prm, nullptr, 1, 5, d);
-        m0[d][0] = (float)(cells->bwd[3][d][0] / g.cnt[3]); m0[d][1] = (float)(cells->bwd[3][d][1] / g.cnt[3]);
-        m1[d][0] = (float)(cells->bwd[5][d][0] / g.cnt[5]); m1[d][1] = (float)(cells->bwd[5][d][1] / g.cnt[5]);
+        m0[d][0] = (float)(cell_bwd(cells, 3, d, 0) / g.cnt[3]); m0[d][1] = (float)(cell_bwd(cells, 3, d, 1) / g.cnt[3]);
+        m1[d][0] = (float)(cell_bwd(cells, 5, d, 0) / g.cnt[5]); m1[d][1] = (float)(cell_bwd(cells, 5, d, 1) / g.cnt[5]);
     }
     __syncthreads();
     const int64_t total = g.M * g.D2;
@@ -586,7 +630,7 @@ __global__ __launch_bounds__(FB) void fc_feat_bwd_kernel(FcGeom g, const float* 
 __global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                       const float* __restrict__ z3, float* __restrict__ dF, uint32_t drop_thr,
                                                       float drop_scale, uint32_t drop_key, const uint32_t* key_dev, int64_t row_offset) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef cc[MAXC];
     if (threadIdx.x < g.D2) cc[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 2, threadIdx.x);
     BlockStats st;
@@ -603,14 +647,14 @@ __global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __
         dF[e] = dy;
         st.add(d, dy, dy * (z3[e] - cc[d].mean) * cc[d].inv);
     }
-    st.flush(cells->bwd[2], g.D2);
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[2], g.D2);
 }
 
 // dy2 = da2 * [a2 > 0] (in place); BatchNorm-b backward sums
 __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z2, const float* __restrict__ a2,
                                                         float* __restrict__ da2) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef cb[MAXC];
     if (threadIdx.x < g.CO) cb[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 1, threadIdx.x);
     BlockStats st;
@@ -622,14 +666,14 @@ __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* 
         da2[e] = dy;
         st.add(co, dy, dy * (z2[e] - cb[co].mean) * cb[co].inv);
     }
-    st.flush(cells->bwd[1], g.CO);
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[1], g.CO);
 }
 
 // dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums
 __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z1, const float* __restrict__ dz2,
                                                         float* __restrict__ dy1) {
-    __shared__ double sl[2 * MAXC];
+    __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ca[16];
     if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
     BlockStats st;
@@ -651,7 +695,7 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
         dy1[e] = dy;
         st.add(ci, dy, dy * (zz - ca[ci].mean) * ca[ci].inv);
     }
-    st.flush(cells->bwd[0], g.H1);
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[0], g.H1);
 }
 
 // conv weight gradients: WHICH 2: dw2[co][ci][k] = sum_m sum_p dz2[m][co][p] * a1[m][ci][p + k - 1]
@@ -667,11 +711,12 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
     const int nout = WHICH == 2 ? g.CO * g.H1 * g.K : g.H1 * g.K;
     const int64_t per = (g.M + gridDim.x - 1) / gridDim.x;
     const int64_t m0 = per * blockIdx.x, m1 = m0 + per < g.M ? m0 + per : g.M;
-    for (int o = threadIdx.x; o < nout; o += FB) {
+    // output o over rows m = mb, mb + step, ... of this workgroup's chunk
+    auto partial = [&](int o, int64_t mb, int step) {
         float acc = 0.f;
         if (WHICH == 2) {
             const int k = o % g.K, ci = (o / g.K) % g.H1, co = o / (g.K * g.H1);
-            for (int64_t m = m0; m < m1; ++m) {
+            for (int64_t m = mb; m < m1; m += step) {
                 const float* dr = dz + m * g.CL + co * g.L2;
                 const float* zr = z1 + (m * g.H1 + ci) * g.L1;
                 for (int p = 0; p < g.L2; ++p) {
@@ -681,7 +726,7 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
             }
         } else {
             const int k = o % g.K, c = o / g.K, pad = g.K / 2;
-            for (int64_t m = m0; m < m1; ++m) {
+            for (int64_t m = mb; m < m1; m += step) {
                 const int node = (int)(m % g.N), t = (int)((m / g.N) % g.NP);
                 const int64_t b = m / ((int64_t)g.N * g.NP);
                 const float* v = x + (b * g.N + node) * g.TL + t * g.PS;
@@ -692,30 +737,44 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
                 }
             }
         }
-        gpart[(int64_t)blockIdx.x * nout + o] = acc;
+        return acc;
+    };
+    if (nout * 2 <= FB) {
+        // few outputs: FB / nout thread slices share each output (rows interleaved), combined in a fixed order through LDS
+        __shared__ float red[FB];
+        const int nsl = FB / nout, o = threadIdx.x % nout, sl = threadIdx.x / nout;
+        red[threadIdx.x] = sl < nsl ? partial(o, m0 + sl, nsl) : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < nout) {
+            float acc = 0.f;
+            for (int q = 0; q < nsl; ++q) acc += red[q * nout + threadIdx.x];
+            gpart[(int64_t)blockIdx.x * nout + threadIdx.x] = acc;
+        }
+    } else {
+        for (int o = threadIdx.x; o < nout; o += FB) gpart[(int64_t)blockIdx.x * nout + o] = partial(o, m0, 1);
     }
 }
 
 // conv partial rows -> gradients; BatchNorm gamma / beta gradients from the cells
 __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2, int rows,
                                                         const Cells* cells, float* __restrict__ grads) {
-    const int e = blockIdx.x * FB + threadIdx.x;
+    // one wavefront per value: lanes stride over the partial rows, then a fixed-order butterfly (deterministic)
+    const int e = (blockIdx.x * FB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int n1 = g.H1 * g.K, n2 = g.CO * g.H1 * g.K;
-    if (e < n1) {
+    if (e < n1 + n2) {
+        const float* src = e < n1 ? gp1 + e : gp2 + (e - n1);
+        const int n = e < n1 ? n1 : n2;
         float a = 0.f;
-        for (int r = 0; r < rows; ++r) a += gp1[(int64_t)r * n1 + e];
-        grads[g.o_w1 + e] = a;
-    } else if (e < n1 + n2) {
-        const int o = e - n1;
-        float a = 0.f;
-        for (int r = 0; r < rows; ++r) a += gp2[(int64_t)r * n2 + o];
-        grads[g.o_w2 + o] = a;
-    } else {
+        for (int r = lane; r < rows; r += 64) a += src[(int64_t)r * n];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+        if (lane == 0) grads[(e < n1 ? g.o_w1 + e : g.o_w2 + (e - n1))] = a;
+    } else if (lane == 0) {
         int c = e - n1 - n2;
         for (int id = 0; id < NBN; ++id) {
             if (c < g.bn_ch[id]) {
-                grads[g.bn_g[id] + c] = (float)cells->bwd[id][c][1];
-                grads[g.bn_b[id] + c] = (float)cells->bwd[id][c][0];
+                grads[g.bn_g[id] + c] = (float)cell_bwd(cells, id, c, 1);
+                grads[g.bn_b[id] + c] = (float)cell_bwd(cells, id, c, 0);
                 return;
             }
             c -= g.bn_ch[id];
@@ -727,7 +786,7 @@ __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* 
 __global__ void fc_bn_batch_kernel(FcGeom g, const Cells* cells, float* __restrict__ bn_batch, float weight) {
     for (int id = 0; id < NBN; ++id)
         for (int c = threadIdx.x; c < g.bn_ch[id]; c += blockDim.x) {
-            const double m = cells->fwd[id][c][0] / g.cnt[id], q = cells->fwd[id][c][1] / g.cnt[id];
+            const double m = cell_fwd(cells, id, c, 0) / g.cnt[id], q = cell_fwd(cells, id, c, 1) / g.cnt[id];
             float* mean = bn_batch + g.bn_off[id] + c;
             float* var = mean + g.bn_ch[id];
             if (weight > 0.f) {
@@ -771,7 +830,7 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t o = 0;
     auto take = [&](size_t floats) { const size_t r = o; o = al(o + floats * sizeof(float)); return r; };
-    w->cells = o; o = al(o + sizeof(Cells));
+    w->cells = o; o = al(o + sizeof(Cells) * CELL_REP);
     w->one = take(64);
     const size_t M = (size_t)g.M, B = (size_t)g.B;
     w->z1 = take(M * g.H1 * g.L1);
@@ -809,12 +868,13 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
     // split-K scratch: max over the weight-gradient GEMMs of slices * M * N
     size_t mx = 1;
     auto need = [&](int Mo, int No, int64_t K) {
-        const size_t v = (size_t)sgemm_splitk_slices(Mo, No, (int)K) * Mo * No;
+        const size_t v = sgemm_splitk_need_floats(Mo, No, (int)K);
         if (v > mx) mx = v;
     };
     need(1, g.HD, g.B); need(g.HD, g.D2, g.B); need(g.D2, g.D2, g.B); need(g.D2, g.FIN, g.B); need(1, g.D2, g.B);
     for (int b = 0; b < 2; ++b) { need(g.HD, g.D2, g.G[b] * g.Q); need(1, g.HD, g.G[b] * g.Q); }
     need(g.D2, g.D2, g.M); need(1, g.D2, g.M); need(g.D2, g.CL, g.M);
+    need((int)g.B, g.D2, g.FIN);                        // fc1 forward
     w->split = take(mx);
     w->total = o;
 }
@@ -883,7 +943,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
 
     if (mode & 1) {
         if (training && a->step_state) FC_RC(step_prepare_dropout(a->step_state, a->seed, 1, st));
-        if (hipMemsetAsync(cells, 0, sizeof(Cells), st) != hipSuccess) return RULGNN_EHIP;
+        if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL(fc_conv1_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
         hipLaunchKernelGGL(fc_conv2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2), cells,
                            training);
@@ -905,7 +965,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int b = 0; b < 2; ++b)
             hipLaunchKernelGGL(fc_pool_kernel, dim3(grid_for(g.G[b] * g.N * HD)), dim3(FB), 0, st, g, b, prm, run, (const Cells*)cells,
                                training, (const float*)P_(w.z5[b]), P_(w.feat));
-        FC_RC(sgemm(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, st));
+        // K = FIN (4032 at FD004) against a [batch x 16] output: split the reduction, or four workgroups walk it alone (250 us)
+        FC_RC(sgemm_splitk(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, P_(w.split), st));
         hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h1), prm + g.o_f1b, g.B, D2);
         FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st));
         hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h2), prm + g.o_f2b, g.B, D2);
@@ -991,7 +1052,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.dy1), P_(w.gp1));
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
-        hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + FB - 1) / FB), dim3(FB), 0, st, g,
+        hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
                            (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr);
         if (!a->dpred && a->loss)
             hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)P_(w.sqerr), (int64_t)g.B, a->loss);

@@ -86,7 +86,7 @@ __host__ int hg_geometry(const rulgnn_hagcn_shape* s, HgGeom* g) {
     size_t mx = 1;
     for (int l = 0; l < NLV; ++l) {
         const int widest = g->fin[l] > g->Hd ? g->fin[l] : g->Hd;          // gin.mlp.0.weight is [Hd x fin]
-        const size_t v = (size_t)sgemm_splitk_slices(g->Hd, widest, (int)g->rows[l]) * g->Hd * widest;
+        const size_t v = sgemm_splitk_bound_floats(g->Hd, widest, (int)g->rows[l]);
         if (v > mx) mx = v;
     }
     g->t_split = tk((int64_t)mx);

@@ -98,9 +98,65 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall-and-skinny case: many rows, a small [K x N] weight matrix (the per-row projections of the graph models:
+// [batch*patches*nodes, 16..64] x [16..64, 8..64]).  A 64x64 MFMA tile wastes most of its columns there and the launch is
+// bandwidth-bound anyway: one thread per output row, the weights in LDS (broadcast reads), the row streamed with 16-byte
+// loads, N accumulators in registers.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+static __global__ __launch_bounds__(256) void sgemm_skinny_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float Bsk[];      // [K][NT]
+    for (int i = threadIdx.x; i < g.K * NT; i += 256) {
+        const int k = i / NT, n = i % NT;
+        Bsk[i] = n < g.N ? g.B[n * g.sBn + k * g.sBk] : 0.f;
+    }
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= g.M) return;
+    float acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+    const float* a = g.A + m * g.sAm;
+    const bool vec = ((g.sAm & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+    int k = 0;
+    if (vec) {
+        for (; k + 4 <= g.K; k += 4) {
+            const f32x4t av = *reinterpret_cast<const f32x4t*>(a + k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = fmaf(av[q], Bsk[(k + q) * NT + n], acc[n]);
+        }
+    }
+    for (; k < g.K; ++k) {
+        const float av = a[k];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = fmaf(av, Bsk[k * NT + n], acc[n]);
+    }
+    float* c = g.C + m * g.ldc;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        if (n < g.N) c[n] = g.accumulate ? c[n] + acc[n] : acc[n];
+}
+
+// (measured: at N = 50..64 the LDS broadcast reads bind and the MFMA tile wins -- ASTGCNN batch 65536: 8.5 vs 10.6 ms/step)
+static inline bool sgemm_is_skinny(int64_t sAk, int M, int N, int K) { return sAk == 1 && N <= 32 && K <= 128 && M >= 2048; }
+
 static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                  int M, int N, int K, bool accumulate, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if (sgemm_is_skinny(sAk, M, N, K)) {
+        GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? K : 1};
+        const int NT = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
+        const size_t lds = (size_t)(K > 0 ? K : 1) * NT * sizeof(float);
+        const dim3 grid((unsigned)((M + 255) / 256));
+        (void)hipGetLastError();
+        if (NT == 8) hipLaunchKernelGGL(sgemm_skinny_kernel<8>, grid, dim3(256), lds, st, g);
+        else if (NT == 16) hipLaunchKernelGGL(sgemm_skinny_kernel<16>, grid, dim3(256), lds, st, g);
+        else hipLaunchKernelGGL(sgemm_skinny_kernel<32>, grid, dim3(256), lds, st, g);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
     GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? K : 1};
     (void)hipGetLastError();
     hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
@@ -136,9 +192,114 @@ static inline int sgemm_splitk_slices(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Long reduction into a small output (the weight gradients of the per-row projections: M x N <= 1024 outputs, K = all rows
+// of the batch).  The generic split-K path launches a 64x64 MFMA tile per slice for a handful of useful columns and then
+// walks the slices; here every workgroup owns a contiguous run of k, stages 32 k-rows of both operands in LDS with
+// coalesced loads, each thread keeps <= 4 outputs in registers, and one wavefront per output adds the per-workgroup
+// partials in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+constexpr int SKT_ROWS = 128;
+static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int kper) {
+    extern __shared__ float sk_lds[];                 // As[SKT_ROWS][M] | Bs[SKT_ROWS][N] | red[256] (few outputs only)
+    float* As = sk_lds;
+    float* Bs = sk_lds + SKT_ROWS * g.M;
+    const int O = g.M * g.N;
+    // O >= 256: thread t owns outputs t, t + 256, ... (<= 4), every k-row.  O < 256: 256 / O thread slices share each output,
+    // slice s taking rows s, s + S, ... of a tile; the slices are combined through LDS in a fixed order at the end.
+    const int S = O >= 256 ? 1 : 256 / O;
+    const int sl = O >= 256 ? 0 : threadIdx.x / O;
+    const bool active = O >= 256 || sl < S;
+    int oi[4], oj[4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int o = O >= 256 ? threadIdx.x + q * 256 : (q == 0 ? threadIdx.x % O : O);
+        oi[q] = o < O ? o / g.N : 0;
+        oj[q] = o < O ? o % g.N : 0;
+    }
+    const int kbeg = blockIdx.x * kper, kend = min(g.K, kbeg + kper);
+    for (int k0 = kbeg; k0 < kend; k0 += SKT_ROWS) {
+        const int nr = min(SKT_ROWS, kend - k0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < SKT_ROWS * g.M; e += 256)
+            As[e] = e < nr * g.M ? g.A[(e % g.M) * g.sAm + (int64_t)(k0 + e / g.M) * g.sAk] : 0.f;
+        for (int e = threadIdx.x; e < SKT_ROWS * g.N; e += 256)
+            Bs[e] = e < nr * g.N ? g.B[(e % g.N) * g.sBn + (int64_t)(k0 + e / g.N) * g.sBk] : 0.f;
+        __syncthreads();
+        if (!active) continue;
+        if (O >= 256) {
+#pragma unroll 4
+            for (int r = 0; r < SKT_ROWS; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = fmaf(As[r * g.M + oi[q]], Bs[r * g.N + oj[q]], acc[q]);
+            }
+        } else {
+            // rows past nr are zero-filled: no bounds in the loop; four independent chains hide the LDS latency
+            for (int r = sl; r < SKT_ROWS; r += 4 * S) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rr = r + q * S;
+                    if (rr < SKT_ROWS) acc[q] = fmaf(As[rr * g.M + oi[0]], Bs[rr * g.N + oj[0]], acc[q]);
+                }
+            }
+        }
+    }
+    if (O >= 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = threadIdx.x + q * 256;
+            if (o < O) g.C[(int64_t)blockIdx.x * O + o] = acc[q];      // g.C = the partial buffer here
+        }
+    } else {
+        float* red = Bs + SKT_ROWS * g.N;
+        __syncthreads();
+        red[threadIdx.x] = active ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < O) {
+            float a = 0.f;
+            for (int q = 0; q < S; ++q) a += red[q * O + threadIdx.x];
+            g.C[(int64_t)blockIdx.x * O + threadIdx.x] = a;
+        }
+    }
+}
+
+static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                                        int64_t ldc, int M, int N, int nblk, int accumulate) {
+    const int o = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (o >= M * N) return;
+    float a = 0.f;
+    for (int b = lane; b < nblk; b += 64) a += partial[(int64_t)b * M * N + o];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) {
+        float* c = C + (int64_t)(o / N) * ldc + (o % N);
+        *c = accumulate ? *c + a : a;
+    }
+}
+
+// workgroups of the long-k path for this shape, 0 if it does not apply
+static inline int sgemm_longk_blocks(int M, int N, int K) {
+    if (!(M * N <= 1024 && K >= 2048 && ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float) <= 48 * 1024)) return 0;
+    const int nblk = (K + SKT_ROWS - 1) / SKT_ROWS;     // one k tile per workgroup while the partial buffer (1024 rows) allows
+    return nblk > 1024 ? 1024 : nblk;
+}
+
 static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if (sgemm_longk_blocks(M, N, K) > 0) {
+        int nblk = sgemm_longk_blocks(M, N, K);
+        int kper = (K + nblk - 1) / nblk;
+        kper = (kper + SKT_ROWS - 1) / SKT_ROWS * SKT_ROWS;
+        nblk = (K + kper - 1) / kper;
+        GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kper};
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float), st, g, kper);
+        hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, N, nblk,
+                           accumulate ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
     const int slices = sgemm_splitk_slices(M, N, K);
     if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st);
     int kchunk = (K + slices - 1) / slices;
@@ -167,6 +328,17 @@ static __global__ __launch_bounds__(1024) void block_sum_kernel(const float* __r
 }
 
 // floats the caller must provide as `partial` for sgemm_splitk(M, N, any K)
-static inline size_t sgemm_splitk_partial_floats(int M, int N) { return (size_t)256 * M * N; }
+static inline size_t sgemm_splitk_partial_floats(int M, int N) { return (size_t)(M * N <= 1024 ? 1024 : 256) * M * N; }
+// ... and the exact need for one known K
+static inline size_t sgemm_splitk_need_floats(int M, int N, int K) {
+    const int lb = sgemm_longk_blocks(M, N, K);
+    return (size_t)(lb > 0 ? lb : sgemm_splitk_slices(M, N, K)) * M * N;
+}
+// ... and for every output of at most M x Nmax values (the two paths do not grow monotonically with the output size)
+static inline size_t sgemm_splitk_bound_floats(int M, int Nmax, int K) {
+    size_t v = sgemm_splitk_need_floats(M, Nmax, K);
+    const size_t small = (size_t)sgemm_longk_blocks(1, 1, K) * (M * Nmax < 1024 ? M * Nmax : 1024);
+    return small > v ? small : v;
+}
 
 }  // namespace rulgnn

@@ -56,13 +56,28 @@ struct Cells3 {                      // the CNN BatchNorm (slot 2 of the BatchNo
     double th[4];
 };
 
+__device__ inline double cell3_fwd(const Cells3* c3, int c, int j) {
+    double v = 0.0;
+    for (int r = 0; r < CELL_REP; ++r) v += c3[r].fwd[c][j];
+    return v;
+}
+__device__ inline double cell3_bwd(const Cells3* c3, int c, int j) {
+    double v = 0.0;
+    for (int r = 0; r < CELL_REP; ++r) v += c3[r].bwd[c][j];
+    return v;
+}
+__device__ inline double cell3_th(const Cells3* c3, int q) {
+    double v = 0.0;
+    for (int r = 0; r < CELL_REP; ++r) v += c3[r].th[q];
+    return v;
+}
 __device__ inline BnCoef bnc_coef(const Cells3* c3, const float* bn_running, int training, int c, int N, double count, float gamma,
                                   float beta) {
     BnCoef r;
     float var;
     if (training) {
-        const double m = c3->fwd[c][0] / count;
-        double v = c3->fwd[c][1] / count - m * m;
+        const double m = cell3_fwd(c3, c, 0) / count;
+        double v = cell3_fwd(c3, c, 1) / count - m * m;
         if (v < 0.0) v = 0.0;
         r.mean = (float)m;
         var = (float)v;
@@ -159,8 +174,8 @@ __global__ __launch_bounds__(AB) void sc_cnn_kernel(ScGeom g, const float* __res
         __syncthreads();
     }
     if (training && tid < N) {
-        atomicAdd(&c3->fwd[tid][0], (double)s1);
-        atomicAdd(&c3->fwd[tid][1], (double)s2);
+        atomicAdd(&c3[blockIdx.x % CELL_REP].fwd[tid][0], (double)s1);
+        atomicAdd(&c3[blockIdx.x % CELL_REP].fwd[tid][1], (double)s2);
     }
 }
 
@@ -252,10 +267,10 @@ __global__ __launch_bounds__(AB) void sc_head_kernel(ScGeom g, const float* __re
     }
     if (BACKWARD) {
         if (tid < N) {
-            atomicAdd(&cells->bwd[1][tid][0], (double)b0);
-            atomicAdd(&cells->bwd[1][tid][1], (double)b1);
-            atomicAdd(&c3->bwd[tid][0], (double)b2);
-            atomicAdd(&c3->bwd[tid][1], (double)b3);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][0], (double)b0);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][1], (double)b1);
+            atomicAdd(&c3[blockIdx.x % CELL_REP].bwd[tid][0], (double)b2);
+            atomicAdd(&c3[blockIdx.x % CELL_REP].bwd[tid][1], (double)b3);
         }
         const float av[4] = {a1, a2, a3, a4};
         for (int q = 0; q < 4; ++q) {                 // block tree reduction of each theta gradient, one atomic per workgroup
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(AB) void sc_head_kernel(ScGeom g, const float* __re
                 if (tid < m) red[tid] += red[tid + m];
                 __syncthreads();
             }
-            if (tid == 0) atomicAdd(&c3->th[q], (double)red[0]);
+            if (tid == 0) atomicAdd(&c3[blockIdx.x % CELL_REP].th[q], (double)red[0]);
         }
     }
 }
@@ -292,8 +307,8 @@ __global__ __launch_bounds__(AB) void sc_cnn_bwd_kernel(ScGeom g, const float* _
     }
     if (tid < N) {
         cc[tid] = bnc_coef(c3, nullptr, 1, tid, N, count, prm[g.o_gc + tid], prm[g.o_bc + tid]);
-        bsum[tid][0] = (float)(c3->bwd[tid][0] / count);
-        bsum[tid][1] = (float)(c3->bwd[tid][1] / count);
+        bsum[tid][0] = (float)(cell3_bwd(c3, tid, 0) / count);
+        bsum[tid][1] = (float)(cell3_bwd(c3, tid, 1) / count);
     }
     float acc[NACC];
 #pragma unroll
@@ -365,14 +380,14 @@ __global__ __launch_bounds__(AB) void sc_finalize_kernel(ScGeom g, const float* 
         float d = 0.f;
         for (int r = 0; r < rows; ++r) d += gp3[(int64_t)r * (nW + N) + e];
         grads[g.o_cb + c] = d;
-        grads[g.o_g1 + c] = (float)cells->bwd[0][c][1];
-        grads[g.o_b1 + c] = (float)cells->bwd[0][c][0];
-        grads[g.o_g2 + c] = (float)cells->bwd[1][c][1];
-        grads[g.o_b2 + c] = (float)cells->bwd[1][c][0];
-        grads[g.o_gc + c] = (float)c3->bwd[c][1];
-        grads[g.o_bc + c] = (float)c3->bwd[c][0];
+        grads[g.o_g1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
+        grads[g.o_b1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
+        grads[g.o_g2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
+        grads[g.o_b2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
+        grads[g.o_gc + c] = (float)cell3_bwd(c3, c, 1);
+        grads[g.o_bc + c] = (float)cell3_bwd(c3, c, 0);
     } else if (e < nW + N + 4) {
-        grads[g.o_th + (e - nW - N)] = (float)c3->th[e - nW - N];
+        grads[g.o_th + (e - nW - N)] = (float)cell3_th(c3, e - nW - N);
     }
 }
 
@@ -382,7 +397,7 @@ __global__ void sc_bn_batch_kernel(ScGeom g, const Cells* cells, const Cells3* c
     if (e >= 3 * g.N) return;
     const int blk = e / g.N, c = e % g.N;
     const double count = (double)g.B * g.T;
-    const double s = blk < 2 ? cells->fwd[blk][c][0] : c3->fwd[c][0], q2 = blk < 2 ? cells->fwd[blk][c][1] : c3->fwd[c][1];
+    const double s = blk < 2 ? cell_sum(cells, &Cells::fwd, blk, c, 0) : cell3_fwd(c3, c, 0), q2 = blk < 2 ? cell_sum(cells, &Cells::fwd, blk, c, 1) : cell3_fwd(c3, c, 1);
     const double m = s / count, q = q2 / count;
     if (weight > 0.f) {
         bn_batch[(blk * 2 + 0) * g.N + c] = (float)(weight * m);
@@ -426,8 +441,8 @@ void sc_ws_layout(const ScGeom& g, ScWs* w) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t BNT = (size_t)g.B * g.NT * sizeof(float);
     size_t o = 0;
-    w->cells = o; o = al(o + sizeof(Cells));
-    w->c3 = o; o = al(o + sizeof(Cells3));
+    w->cells = o; o = al(o + sizeof(Cells) * CELL_REP);
+    w->c3 = o; o = al(o + sizeof(Cells3) * CELL_REP);
     w->one = o; o = al(o + 256);
     for (size_t* p : {&w->ax, &w->gpre, &w->zc, &w->z1, &w->out0, &w->z2, &w->res, &w->ds1, &w->dy2, &w->dyc, &w->dy1}) {
         *p = o;
@@ -442,7 +457,7 @@ void sc_ws_layout(const ScGeom& g, ScWs* w) {
     w->gp3 = o; o = al(o + w->rows * (nW + g.N) * sizeof(float));
     size_t mx = 1;
     auto need = [&](int M, int Nn, int64_t K) {
-        const size_t v = (size_t)sgemm_splitk_slices(M, Nn, (int)K) * M * Nn;
+        const size_t v = sgemm_splitk_need_floats(M, Nn, (int)K);
         if (v > mx) mx = v;
     };
     need(g.T, g.T, g.B * g.N); need(1, g.T, g.B * g.N); need(1, g.NT, g.B); need(1, 1, g.B);

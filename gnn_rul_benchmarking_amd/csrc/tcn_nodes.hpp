@@ -22,6 +22,17 @@ struct Cells {
     double bwd[2][MAXN][2];
 };
 
+// Every workgroup adds its partial sums with one atomic per channel; with one workgroup per sample thousands of them hit
+// the same addresses and serialise (~10 ns each), so the cells exist CELL_REP times: workgroup b adds into replica
+// b % CELL_REP, the readers sum the replicas in a fixed order.
+constexpr int CELL_REP = 16;
+__device__ inline double cell_sum(const Cells* cells, double (Cells::*field)[2][MAXN][2], int blk, int c, int j) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < CELL_REP; ++r) v += (cells[r].*field)[blk][c][j];
+    return v;
+}
+
 // BatchNorm scale/shift of block `blk` for channel c: y = z * sc + sh; xhat = (z - mean) * inv
 struct BnCoef {
     float mean, inv, sc, sh;
@@ -31,8 +42,8 @@ __device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, in
     BnCoef r;
     float var;
     if (training) {
-        const double m = cells->fwd[blk][c][0] / count;
-        double v = cells->fwd[blk][c][1] / count - m * m;
+        const double m = cell_sum(cells, &Cells::fwd, blk, c, 0) / count;
+        double v = cell_sum(cells, &Cells::fwd, blk, c, 1) / count - m * m;
         if (v < 0.0) v = 0.0;
         r.mean = (float)m;
         var = (float)v;
@@ -104,8 +115,8 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
         __syncthreads();
     }
     if (training && tid < N) {
-        atomicAdd(&cells->fwd[STAGE - 1][tid][0], (double)s1);
-        atomicAdd(&cells->fwd[STAGE - 1][tid][1], (double)s2);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][0], (double)s1);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][1], (double)s2);
     }
 }
 
@@ -143,8 +154,8 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         cz[tid] = bn_coef(cells, nullptr, 1, blk, tid, N, count, prm[(STAGE == 1 ? g.o_g1 : g.o_g2) + tid],
                           prm[(STAGE == 1 ? g.o_b1 : g.o_b2) + tid]);
         if (STAGE == 2) c1[tid] = bn_coef(cells, nullptr, 1, 0, tid, N, count, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
-        bsum[tid][0] = (float)(cells->bwd[blk][tid][0] / count);
-        bsum[tid][1] = (float)(cells->bwd[blk][tid][1] / count);
+        bsum[tid][0] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 0) / count);
+        bsum[tid][1] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 1) / count);
     }
     float acc[NACC];
 #pragma unroll
@@ -208,8 +219,8 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         if (e < nW) dst[e] = acc[r];
     }
     if (STAGE == 2 && tid < N) {
-        atomicAdd(&cells->bwd[0][tid][0], (double)a1);
-        atomicAdd(&cells->bwd[0][tid][1], (double)a2);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][0], (double)a1);
+        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][1], (double)a2);
     }
 }
 
