@@ -95,14 +95,29 @@ __host__ int msg_geometry(const rulgnn_stmsgcn_shape* s, MsgGeom* g) {
 // shared per-graph stages (block-cooperative; all operands in LDS)
 // ---------------------------------------------------------------------------------------------------
 // A' = x x^T + I for the feature slice [off, off+f) of cat  (Model.py:98 and :41).
+// (All per-graph products below keep a 2x2 or 1x4 block of outputs per thread: on the vector ALUs every FMA of a
+// one-output-per-thread loop costs two LDS reads, and the LDS pipe is what binds these kernels.)
+template <int TW>
 __device__ inline void gram_plus_identity(const float* cat, int CS, int off, int f, int n, float* araw) {
-    for (int e = threadIdx.x; e < n * n; e += MB) {
-        const int i = e / n, j = e - i * n;
+    constexpr int TS = TW > 1 ? 2 : 1;
+    const int nb = TW > 1 ? (n + 1) >> 1 : n;
+    for (int e = threadIdx.x; e < nb * nb; e += MB) {
+        const int i = TS * (e / nb), j = TS * (e % nb);
+        const int i1 = (TS > 1 && i + 1 < n) ? i + 1 : i, j1 = (TS > 1 && j + 1 < n) ? j + 1 : j;
         const float* xi = cat + i * CS + off;
+        const float* xi1 = cat + i1 * CS + off;
         const float* xj = cat + j * CS + off;
-        float a = 0.f;
-        for (int c = 0; c < f; ++c) a = fmaf(xi[c], xj[c], a);
-        araw[i * (n + 1) + j] = a + (i == j ? 1.f : 0.f);
+        const float* xj1 = cat + j1 * CS + off;
+        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+        for (int c = 0; c < f; ++c) {
+            const float u0 = xi[c], u1 = xi1[c], v0 = xj[c], v1 = xj1[c];
+            a00 = fmaf(u0, v0, a00); a01 = fmaf(u0, v1, a01);
+            a10 = fmaf(u1, v0, a10); a11 = fmaf(u1, v1, a11);
+        }
+        araw[i * (n + 1) + j] = a00 + (i == j ? 1.f : 0.f);
+        if (TS > 1 && j + 1 < n) araw[i * (n + 1) + j + 1] = a01 + (i == j + 1 ? 1.f : 0.f);
+        if (TS > 1 && i + 1 < n) araw[(i + 1) * (n + 1) + j] = a10 + (i + 1 == j ? 1.f : 0.f);
+        if (TS > 1 && i + 1 < n && j + 1 < n) araw[(i + 1) * (n + 1) + j + 1] = a11 + (i == j ? 1.f : 0.f);
     }
 }
 // r = rowsum(A')^-1/2 (Model.py:43; a negative row sum gives NaN exactly like torch's pow).
@@ -122,19 +137,36 @@ __device__ inline void normalise(const float* araw, const float* rv, int n, floa
     }
 }
 // AX = ahat x  (Model.py:45)
+template <int TW>
 __device__ inline void aggregate(const float* ahat, const float* cat, int CS, int off, int f, int n, float* ax, int AXS) {
-    for (int e = threadIdx.x; e < n * f; e += MB) {
-        const int i = e / f, c = e - i * f;
+    const int fq = (f + TW - 1) / TW;
+    for (int e = threadIdx.x; e < n * fq; e += MB) {
+        const int i = e / fq, c = TW * (e - i * fq);
         const float* ar = ahat + i * (n + 1);
-        float a = 0.f;
-        for (int j = 0; j < n; ++j) a = fmaf(ar[j], cat[j * CS + off + c], a);
-        ax[i * AXS + c] = a;
+        const float* xc = cat + off + c;
+        const bool k1 = TW > 1 && c + 1 < f, k2 = TW > 1 && c + 2 < f, k3 = TW > 1 && c + 3 < f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float w = ar[j];
+            const float* xr = xc + j * CS;
+            a0 = fmaf(w, xr[0], a0);
+            a1 = fmaf(w, k1 ? xr[1] : 0.f, a1);
+            a2 = fmaf(w, k2 ? xr[2] : 0.f, a2);
+            a3 = fmaf(w, k3 ? xr[3] : 0.f, a3);
+        }
+        float* o = ax + i * AXS + c;
+        o[0] = a0;
+        if (k1) o[1] = a1;
+        if (k2) o[2] = a2;
+        if (k3) o[3] = a3;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // features: SED + GCN stack (+ GRU input projection)
 // ---------------------------------------------------------------------------------------------------
+// TW: register-block width of the per-graph products (4 for graphs of >= 12 nodes, 1 = one output per thread for small ones)
+template <int TW>
 __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float* __restrict__ x,
                                                           const float* __restrict__ prm, float* __restrict__ cat_out,
                                                           float* __restrict__ gi_out) {
@@ -211,22 +243,35 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
         // ---- GCN stack (Model.py:96-100) ----
         for (int l = 0; l < g.L; ++l) {
             const int fi = g.dims[l], fo = g.dims[l + 1], off = g.coff[l], offo = g.coff[l + 1];
-            gram_plus_identity(cat, CS, off, fi, n, araw);
+            gram_plus_identity<TW>(cat, CS, off, fi, n, araw);
             __syncthreads();
             inv_sqrt_degree(araw, n, rv);
             __syncthreads();
             normalise(araw, rv, n, araw);
             __syncthreads();
-            aggregate(araw, cat, CS, off, fi, n, ax, AXS);
+            aggregate<TW>(araw, cat, CS, off, fi, n, ax, AXS);
             __syncthreads();
             const float* w = wt + g.woff[l];
             const float* b = wt + g.boff[l];
-            for (int e = tid; e < n * fo; e += MB) {
-                const int i = e / fo, o = e - i * fo;
-                float z = 0.f;
-                for (int k = 0; k < fi; ++k) z = fmaf(ax[i * AXS + k], w[k * fo + o], z);
-                z += b[o];
-                cat[i * CS + offo + o] = z > 0.f ? z : LEAKY * z;
+            const int foq = (fo + TW - 1) / TW;
+            for (int e = tid; e < n * foq; e += MB) {
+                const int i = e / foq, o = TW * (e - i * foq);
+                const bool k1 = TW > 1 && o + 1 < fo, k2 = TW > 1 && o + 2 < fo, k3 = TW > 1 && o + 3 < fo;
+                float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+                for (int k = 0; k < fi; ++k) {
+                    const float av = ax[i * AXS + k];
+                    const float* wr = w + k * fo + o;
+                    z0 = fmaf(av, wr[0], z0);
+                    z1 = fmaf(av, k1 ? wr[1] : 0.f, z1);
+                    z2 = fmaf(av, k2 ? wr[2] : 0.f, z2);
+                    z3 = fmaf(av, k3 ? wr[3] : 0.f, z3);
+                }
+                float* dst = cat + i * CS + offo + o;
+                z0 += b[o];
+                dst[0] = z0 > 0.f ? z0 : LEAKY * z0;
+                if (k1) { z1 += b[o + 1]; dst[1] = z1 > 0.f ? z1 : LEAKY * z1; }
+                if (k2) { z2 += b[o + 2]; dst[2] = z2 > 0.f ? z2 : LEAKY * z2; }
+                if (k3) { z3 += b[o + 3]; dst[3] = z3 > 0.f ? z3 : LEAKY * z3; }
             }
             __syncthreads();
         }
@@ -476,6 +521,7 @@ __global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __
 // ---------------------------------------------------------------------------------------------------
 // GCN stack backward (+ GRU input projection backward)
 // ---------------------------------------------------------------------------------------------------
+template <int TW>
 __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const float* __restrict__ cat_in,
                                                               const float* __restrict__ dgi_in, const float* __restrict__ prm,
                                                               float* __restrict__ gpart) {
@@ -511,17 +557,47 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
         for (int e = tid; e < n * H3; e += MB) dgi[e] = gsrc[e];
         __syncthreads();
         // d cat = d gi W_ih ; d W_ih += d gi^T cat ; d b_ih += sum d gi
-        for (int e = tid; e < n * C; e += MB) {
-            const int i = e / C, c = e - i * C;
-            float a = 0.f;
-            for (int q = 0; q < H3; ++q) a = fmaf(dgi[i * H3 + q], wih[q * C + c], a);
-            dcat[i * CS + c] = a;
+        {
+            const int cq = (C + TW - 1) / TW;
+            for (int e = tid; e < n * cq; e += MB) {
+                const int i = e / cq, c = TW * (e - i * cq);
+                const bool k1 = TW > 1 && c + 1 < C, k2 = TW > 1 && c + 2 < C, k3 = TW > 1 && c + 3 < C;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int q = 0; q < H3; ++q) {
+                    const float d = dgi[i * H3 + q];
+                    const float* wr = wih + q * C + c;
+                    a0 = fmaf(d, wr[0], a0);
+                    a1 = fmaf(d, k1 ? wr[1] : 0.f, a1);
+                    a2 = fmaf(d, k2 ? wr[2] : 0.f, a2);
+                    a3 = fmaf(d, k3 ? wr[3] : 0.f, a3);
+                }
+                float* o = dcat + i * CS + c;
+                o[0] = a0;
+                if (k1) o[1] = a1;
+                if (k2) o[2] = a2;
+                if (k3) o[3] = a3;
+            }
         }
-        for (int e = tid; e < H3 * C; e += MB) {
-            const int q = e / C, c = e - q * C;
-            float a = 0.f;
-            for (int i = 0; i < n; ++i) a = fmaf(dgi[i * H3 + q], cat[i * CS + c], a);
-            acc[g.gcn_params + e] += a;
+        {
+            const int cq = (C + TW - 1) / TW;
+            for (int e = tid; e < H3 * cq; e += MB) {
+                const int q = e / cq, c = TW * (e - q * cq);
+                const bool k1 = TW > 1 && c + 1 < C, k2 = TW > 1 && c + 2 < C, k3 = TW > 1 && c + 3 < C;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int i = 0; i < n; ++i) {
+                    const float d = dgi[i * H3 + q];
+                    const float* xr = cat + i * CS + c;
+                    a0 = fmaf(d, xr[0], a0);
+                    a1 = fmaf(d, k1 ? xr[1] : 0.f, a1);
+                    a2 = fmaf(d, k2 ? xr[2] : 0.f, a2);
+                    a3 = fmaf(d, k3 ? xr[3] : 0.f, a3);
+                }
+                float* o = acc + g.gcn_params + q * C + c;
+                o[0] += a0;
+                if (k1) o[1] += a1;
+                if (k2) o[2] += a2;
+                if (k3) o[3] += a3;
+            }
         }
         for (int q = tid; q < H3; q += MB) {
             float a = 0.f;
@@ -537,20 +613,35 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
                 const float out = cat[i * CS + offo + o];
                 dcat[i * CS + offo + o] *= (out > 0.f ? 1.f : LEAKY);
             }
-            gram_plus_identity(cat, CS, off, fi, n, araw);
+            gram_plus_identity<TW>(cat, CS, off, fi, n, araw);
             __syncthreads();
             inv_sqrt_degree(araw, n, rv);
             __syncthreads();
             normalise(araw, rv, n, ahat);
             __syncthreads();
-            aggregate(ahat, cat, CS, off, fi, n, ax, AXS);
+            aggregate<TW>(ahat, cat, CS, off, fi, n, ax, AXS);
             __syncthreads();
             // d W[o][k] += sum_i dz[i][o] AX[i][k] ; d b[o] += sum_i dz[i][o]
-            for (int e = tid; e < fo * fi; e += MB) {
-                const int o = e / fi, k = e - o * fi;
-                float a = 0.f;
-                for (int i = 0; i < n; ++i) a = fmaf(dcat[i * CS + offo + o], ax[i * AXS + k], a);
-                acc[g.woff[l] + e] += a;
+            {
+                const int fq = (fi + TW - 1) / TW;
+                for (int e = tid; e < fo * fq; e += MB) {
+                    const int o = e / fq, k = TW * (e - o * fq);
+                    const bool k1 = TW > 1 && k + 1 < fi, k2 = TW > 1 && k + 2 < fi, k3 = TW > 1 && k + 3 < fi;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int i = 0; i < n; ++i) {
+                        const float d = dcat[i * CS + offo + o];
+                        const float* xr = ax + i * AXS + k;
+                        a0 = fmaf(d, xr[0], a0);
+                        a1 = fmaf(d, k1 ? xr[1] : 0.f, a1);
+                        a2 = fmaf(d, k2 ? xr[2] : 0.f, a2);
+                        a3 = fmaf(d, k3 ? xr[3] : 0.f, a3);
+                    }
+                    float* dst = acc + g.woff[l] + o * fi + k;
+                    dst[0] += a0;
+                    if (k1) dst[1] += a1;
+                    if (k2) dst[2] += a2;
+                    if (k3) dst[3] += a3;
+                }
             }
             for (int o = tid; o < fo; o += MB) {
                 float a = 0.f;
@@ -563,20 +654,52 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
             }
             __syncthreads();
             // d AX = dz W   (overwrites AX)
-            for (int e = tid; e < n * fi; e += MB) {
-                const int i = e / fi, k = e - i * fi;
+            {
+                const int fq = (fi + TW - 1) / TW;
                 const float* wl = w + g.woff[l];
-                float a = 0.f;
-                for (int o = 0; o < fo; ++o) a = fmaf(dcat[i * CS + offo + o], wl[o * fi + k], a);
-                ax[i * AXS + k] = a;
+                for (int e = tid; e < n * fq; e += MB) {
+                    const int i = e / fq, k = TW * (e - i * fq);
+                    const bool k1 = TW > 1 && k + 1 < fi, k2 = TW > 1 && k + 2 < fi, k3 = TW > 1 && k + 3 < fi;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int o = 0; o < fo; ++o) {
+                        const float d = dcat[i * CS + offo + o];
+                        const float* wr = wl + o * fi + k;
+                        a0 = fmaf(d, wr[0], a0);
+                        a1 = fmaf(d, k1 ? wr[1] : 0.f, a1);
+                        a2 = fmaf(d, k2 ? wr[2] : 0.f, a2);
+                        a3 = fmaf(d, k3 ? wr[3] : 0.f, a3);
+                    }
+                    // AX of this graph is no longer needed (the d W loop above finished before the barrier)
+                    float* dst = ax + i * AXS + k;
+                    dst[0] = a0;
+                    if (k1) dst[1] = a1;
+                    if (k2) dst[2] = a2;
+                    if (k3) dst[3] = a3;
+                }
             }
             __syncthreads();
             // d ahat = d AX x^T
-            for (int e = tid; e < n * n; e += MB) {
-                const int i = e / n, j = e - i * n;
-                float a = 0.f;
-                for (int k = 0; k < fi; ++k) a = fmaf(ax[i * AXS + k], cat[j * CS + off + k], a);
-                dah[i * n1 + j] = a;
+            {
+                constexpr int TS = TW > 1 ? 2 : 1;
+    const int nb = TW > 1 ? (n + 1) >> 1 : n;
+                for (int e = tid; e < nb * nb; e += MB) {
+                    const int i = TS * (e / nb), j = TS * (e % nb);
+                    const int i1 = (TS > 1 && i + 1 < n) ? i + 1 : i, j1 = (TS > 1 && j + 1 < n) ? j + 1 : j;
+                    const float* u0p = ax + i * AXS;
+                    const float* u1p = ax + i1 * AXS;
+                    const float* v0p = cat + j * CS + off;
+                    const float* v1p = cat + j1 * CS + off;
+                    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+                    for (int k = 0; k < fi; ++k) {
+                        const float u0 = u0p[k], u1 = u1p[k], v0 = v0p[k], v1 = v1p[k];
+                        a00 = fmaf(u0, v0, a00); a01 = fmaf(u0, v1, a01);
+                        a10 = fmaf(u1, v0, a10); a11 = fmaf(u1, v1, a11);
+                    }
+                    dah[i * n1 + j] = a00;
+                    if (TS > 1 && j + 1 < n) dah[i * n1 + j + 1] = a01;
+                    if (TS > 1 && i + 1 < n) dah[(i + 1) * n1 + j] = a10;
+                    if (TS > 1 && i + 1 < n && j + 1 < n) dah[(i + 1) * n1 + j + 1] = a11;
+                }
             }
             __syncthreads();
             // d r (both D factors), then d(row sum): dd = -1/2 d^-3/2 dr = -1/2 r^3 dr
@@ -598,14 +721,27 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
             }
             __syncthreads();
             // d x = ahat^T d AX + M x, accumulated into the d cat slice of this layer's input
-            for (int e = tid; e < n * fi; e += MB) {
-                const int i = e / fi, c = e - i * fi;
-                float a = 0.f;
-                for (int j = 0; j < n; ++j) {
-                    a = fmaf(ahat[j * n1 + i], ax[j * AXS + c], a);
-                    a = fmaf(araw[i * n1 + j], cat[j * CS + off + c], a);
+            {
+                const int fq = (fi + TW - 1) / TW;
+                for (int e = tid; e < n * fq; e += MB) {
+                    const int i = e / fq, c = TW * (e - i * fq);
+                    const bool k1 = TW > 1 && c + 1 < fi, k2 = TW > 1 && c + 2 < fi, k3 = TW > 1 && c + 3 < fi;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int j = 0; j < n; ++j) {
+                        const float h = ahat[j * n1 + i], m = araw[i * n1 + j];
+                        const float* dr = ax + j * AXS + c;
+                        const float* xr = cat + j * CS + off + c;
+                        a0 = fmaf(h, dr[0], a0);               a0 = fmaf(m, xr[0], a0);
+                        a1 = fmaf(h, k1 ? dr[1] : 0.f, a1);    a1 = fmaf(m, k1 ? xr[1] : 0.f, a1);
+                        a2 = fmaf(h, k2 ? dr[2] : 0.f, a2);    a2 = fmaf(m, k2 ? xr[2] : 0.f, a2);
+                        a3 = fmaf(h, k3 ? dr[3] : 0.f, a3);    a3 = fmaf(m, k3 ? xr[3] : 0.f, a3);
+                    }
+                    float* dst = dcat + i * CS + off + c;
+                    dst[0] += a0;
+                    if (k1) dst[1] += a1;
+                    if (k2) dst[2] += a2;
+                    if (k3) dst[3] += a3;
                 }
-                dcat[i * CS + off + c] += a;
             }
             __syncthreads();
         }
@@ -690,15 +826,33 @@ static int resident_grid(K kernel, int64_t items, size_t lds, int cap_rows) {
     return (int)want;
 }
 
-static int launch_features(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
+template <int TW>
+static int launch_features_tw(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
     const size_t lds = features_lds_bytes(g);
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(msg_features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(msg_features_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
         return RULGNN_EHIP;
-    const int grid = resident_grid(msg_features_kernel, g.G, lds, 1 << 20);
-    hipLaunchKernelGGL(msg_features_kernel, dim3(grid), dim3(MB), lds, st, g, x, prm, cat, gi);
+    const int grid = resident_grid(msg_features_kernel<TW>, g.G, lds, 1 << 20);
+    hipLaunchKernelGGL(msg_features_kernel<TW>, dim3(grid), dim3(MB), lds, st, g, x, prm, cat, gi);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+static int launch_features(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
+    return g.n >= 12 ? launch_features_tw<4>(g, x, prm, cat, gi, st) : launch_features_tw<1>(g, x, prm, cat, gi, st);
+}
+
+template <int TW>
+static int launch_gcn_backward(const MsgGeom& g, int rows_max, const float* cat, const float* dgi, const float* prm, float* gpart,
+                               hipStream_t st, int* rows_out) {
+    const size_t lds = gcn_backward_lds_bytes(g);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(msg_gcn_backward_kernel<TW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    const int rows = resident_grid(msg_gcn_backward_kernel<TW>, g.G, lds, rows_max);
+    hipLaunchKernelGGL(msg_gcn_backward_kernel<TW>, dim3(rows), dim3(MB), lds, st, g, cat, dgi, prm, gpart);
+    *rows_out = rows;
+    return RULGNN_OK;
 }
 
 template <int HG>
@@ -767,14 +921,12 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
                 return RULGNN_EHIP;
         }
         dispatch_gru(g, w, ws, a->params, true, st);
-        const size_t lds = gcn_backward_lds_bytes(g);
-        if (lds > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(msg_gcn_backward_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return RULGNN_EHIP;
-        const int rows = resident_grid(msg_gcn_backward_kernel, g.G, lds, w.rows_gcn_max);
-        hipLaunchKernelGGL(msg_gcn_backward_kernel, dim3(rows), dim3(MB), lds, st, g, (const float*)(ws + w.cat),
-                           (const float*)(ws + w.dgi), a->params, (float*)(ws + w.gpart_gcn));
+        int rows = 0;
+        const int rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dgi), a->params,
+                                                           (float*)(ws + w.gpart_gcn), st, &rows)
+                                  : launch_gcn_backward<1>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dgi), a->params,
+                                                           (float*)(ws + w.gpart_gcn), st, &rows);
+        if (rcb != RULGNN_OK) return rcb;
         const bool mse = a->dpred == nullptr;
         hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + MB - 1) / MB), dim3(MB), 0, st, g,
                            (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
