@@ -523,18 +523,18 @@ __global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __
 // ---------------------------------------------------------------------------------------------------
 template <int TW>
 __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const float* __restrict__ cat_in,
-                                                              const float* __restrict__ dgi_in, const float* __restrict__ prm,
+                                                              const float* __restrict__ dcat_in, const float* __restrict__ prm,
                                                               float* __restrict__ gpart) {
+    // d cat = d gi W_ih arrives from a GEMM over all graphs (and d W_ih, d b_ih are GEMMs too, see msg_run): that keeps 19 KB
+    // of weights / accumulators out of the LDS -- three workgroups per CU instead of two -- and a quarter of the per-graph FMAs.
     extern __shared__ float smem[];
-    const int n = g.n, C = g.C, CS = g.CS, AXS = g.AXS, H3 = g.H3, n1 = n + 1;
-    const int nacc = g.gcn_params + H3 * C + H3;
+    const int n = g.n, C = g.C, CS = g.CS, AXS = g.AXS, n1 = n + 1;
+    const int nacc = g.gcn_params;
     float* w = smem;                               // GCN weights, row-major as in the flat buffer
-    float* wih = w + g.gcn_params;                 // W_ih[3H][C]
-    float* acc = wih + H3 * C;                     // gradient accumulators: GCN | W_ih | b_ih
+    float* acc = w + g.gcn_params;                 // gradient accumulators of the GCN layers
     float* cat = acc + nacc;                       // [n][CS]
     float* dcat = cat + n * CS;                    // [n][CS]
-    float* dgi = dcat + n * CS;                    // [n][3H]
-    float* araw = dgi + n * H3;                    // [n][n+1]
+    float* araw = dcat + n * CS;                   // [n][n+1]
     float* ahat = araw + n * n1;
     float* dah = ahat + n * n1;
     float* rv = dah + n * n1;                      // [32]
@@ -543,66 +543,16 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
     const int tid = threadIdx.x;
 
     for (int e = tid; e < g.gcn_params; e += MB) w[e] = prm[e];
-    for (int e = tid; e < H3 * C; e += MB) wih[e] = prm[g.off_wih + e];
     for (int e = tid; e < nacc; e += MB) acc[e] = 0.f;
     __syncthreads();
 
     for (int64_t gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
         const float* csrc = cat_in + gi * (int64_t)(n * C);
+        const float* dsrc = dcat_in + gi * (int64_t)(n * C);
         for (int e = tid; e < n * C; e += MB) {
             const int i = e / C, c = e - i * C;
             cat[i * CS + c] = csrc[e];
-        }
-        const float* gsrc = dgi_in + gi * (int64_t)(n * H3);
-        for (int e = tid; e < n * H3; e += MB) dgi[e] = gsrc[e];
-        __syncthreads();
-        // d cat = d gi W_ih ; d W_ih += d gi^T cat ; d b_ih += sum d gi
-        {
-            const int cq = (C + TW - 1) / TW;
-            for (int e = tid; e < n * cq; e += MB) {
-                const int i = e / cq, c = TW * (e - i * cq);
-                const bool k1 = TW > 1 && c + 1 < C, k2 = TW > 1 && c + 2 < C, k3 = TW > 1 && c + 3 < C;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int q = 0; q < H3; ++q) {
-                    const float d = dgi[i * H3 + q];
-                    const float* wr = wih + q * C + c;
-                    a0 = fmaf(d, wr[0], a0);
-                    a1 = fmaf(d, k1 ? wr[1] : 0.f, a1);
-                    a2 = fmaf(d, k2 ? wr[2] : 0.f, a2);
-                    a3 = fmaf(d, k3 ? wr[3] : 0.f, a3);
-                }
-                float* o = dcat + i * CS + c;
-                o[0] = a0;
-                if (k1) o[1] = a1;
-                if (k2) o[2] = a2;
-                if (k3) o[3] = a3;
-            }
-        }
-        {
-            const int cq = (C + TW - 1) / TW;
-            for (int e = tid; e < H3 * cq; e += MB) {
-                const int q = e / cq, c = TW * (e - q * cq);
-                const bool k1 = TW > 1 && c + 1 < C, k2 = TW > 1 && c + 2 < C, k3 = TW > 1 && c + 3 < C;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                for (int i = 0; i < n; ++i) {
-                    const float d = dgi[i * H3 + q];
-                    const float* xr = cat + i * CS + c;
-                    a0 = fmaf(d, xr[0], a0);
-                    a1 = fmaf(d, k1 ? xr[1] : 0.f, a1);
-                    a2 = fmaf(d, k2 ? xr[2] : 0.f, a2);
-                    a3 = fmaf(d, k3 ? xr[3] : 0.f, a3);
-                }
-                float* o = acc + g.gcn_params + q * C + c;
-                o[0] += a0;
-                if (k1) o[1] += a1;
-                if (k2) o[2] += a2;
-                if (k3) o[3] += a3;
-            }
-        }
-        for (int q = tid; q < H3; q += MB) {
-            float a = 0.f;
-            for (int i = 0; i < n; ++i) a += dgi[i * H3 + q];
-            acc[g.gcn_params + H3 * C + q] += a;
+            dcat[i * CS + c] = dsrc[e];
         }
         __syncthreads();
         for (int l = g.L - 1; l >= 0; --l) {
@@ -751,9 +701,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
 }
 
 static size_t gcn_backward_lds_bytes(const MsgGeom& g) {
-    const size_t nacc = (size_t)g.gcn_params + g.H3 * g.C + g.H3;
-    return sizeof(float) * ((size_t)g.gcn_params + g.H3 * g.C + nacc + 2 * g.n * g.CS + g.n * g.H3 + 3 * g.n * (g.n + 1) +
-                            2 * MAXN + g.n * g.AXS);
+    return sizeof(float) * ((size_t)2 * g.gcn_params + 2 * g.n * g.CS + 3 * g.n * (g.n + 1) + 2 * MAXN + g.n * g.AXS);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -763,31 +711,35 @@ __global__ __launch_bounds__(MB) void msg_finalize_kernel(MsgGeom g, const float
                                                           const float* __restrict__ gpart_gru, int rows_gru,
                                                           const float* __restrict__ dpred, const float* __restrict__ pooled,
                                                           float* __restrict__ grads) {
-    const int e = blockIdx.x * MB + threadIdx.x;
-    const int nacc = g.gcn_params + g.H3 * g.C + g.H3;
+    // one wavefront per value: lanes stride over the partial rows (or the batch), fixed-order butterfly (deterministic).
+    // W_ih and b_ih are written by the GEMMs of msg_run and skipped here.
+    const int e = (blockIdx.x * MB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int ngru = g.H3 * g.H + g.H3;
-    if (e < g.nparam) {
-        float a = 0.f;
-        if (e < g.off_whh) {                                   // GCN layers | W_ih
-            for (int r = 0; r < rows_gcn; ++r) a += gpart_gcn[(int64_t)r * nacc + e];
-        } else if (e < g.off_bih) {                            // W_hh
-            for (int r = 0; r < rows_gru; ++r) a += gpart_gru[(int64_t)r * ngru + (e - g.off_whh)];
-        } else if (e < g.off_bhh) {                            // b_ih
-            for (int r = 0; r < rows_gcn; ++r) a += gpart_gcn[(int64_t)r * nacc + g.gcn_params + g.H3 * g.C + (e - g.off_bih)];
-        } else if (e < g.off_fcw) {                            // b_hh
-            for (int r = 0; r < rows_gru; ++r) a += gpart_gru[(int64_t)r * ngru + g.H3 * g.H + (e - g.off_bhh)];
-        } else if (e < g.off_fcb) {                            // fc.weight
-            const int q = e - g.off_fcw, Q = g.NP * g.H;
-            for (int64_t b = 0; b < g.B; ++b) a = fmaf(dpred[b], pooled[b * Q + q], a);
-        } else {                                               // fc.bias
-            for (int64_t b = 0; b < g.B; ++b) a += dpred[b];
-        }
-        grads[e] = a;
+    if (e >= g.nparam || (e >= g.off_wih && e < g.off_whh) || (e >= g.off_bih && e < g.off_bhh)) return;
+    float a = 0.f;
+    if (e < g.off_wih) {                                       // GCN layers
+        for (int r = lane; r < rows_gcn; r += 64) a += gpart_gcn[(int64_t)r * g.gcn_params + e];
+    } else if (e < g.off_bih) {                                // W_hh
+        for (int r = lane; r < rows_gru; r += 64) a += gpart_gru[(int64_t)r * ngru + (e - g.off_whh)];
+    } else if (e < g.off_fcw) {                                // b_hh
+        for (int r = lane; r < rows_gru; r += 64) a += gpart_gru[(int64_t)r * ngru + g.H3 * g.H + (e - g.off_bhh)];
+    } else if (e < g.off_fcb) {                                // fc.weight
+        const int q = e - g.off_fcw, Q = g.NP * g.H;
+        for (int64_t b = lane; b < g.B; b += 64) a = fmaf(dpred[b], pooled[b * Q + q], a);
+    } else {                                                   // fc.bias
+        for (int64_t b = lane; b < g.B; b += 64) a += dpred[b];
     }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) grads[e] = a;
+}
+
+__global__ void msg_fill_kernel(float* p, int n, float v) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = v;
 }
 
 struct MsgWs {
-    size_t cat, gi, hseq, dgi, pooled, dpred, sqerr, gpart_gcn, gpart_gru, total;
+    size_t cat, gi, hseq, dgi, dcat, one, split, pooled, dpred, sqerr, gpart_gcn, gpart_gru, total;
     int rows_gcn_max, rows_gru, HG;
 };
 
@@ -799,6 +751,12 @@ static void msg_ws_layout(const MsgGeom& g, MsgWs* w) {
     w->gi = o; o = al(o + rows * g.H3 * sizeof(float));
     w->hseq = o; o = al(o + rows * g.H * sizeof(float));
     w->dgi = o; o = al(o + rows * g.H3 * sizeof(float));
+    w->dcat = o; o = al(o + rows * g.C * sizeof(float));
+    w->one = o; o = al(o + 64 * sizeof(float));
+    {
+        const size_t s1 = sgemm_splitk_need_floats(g.H3, g.C, (int)rows), s2 = sgemm_splitk_need_floats(g.H3, 1, (int)rows);
+        w->split = o; o = al(o + (s1 > s2 ? s1 : s2) * sizeof(float));
+    }
     w->pooled = o; o = al(o + (size_t)g.B * g.NP * g.H * sizeof(float));
     w->dpred = o; o = al(o + (size_t)g.B * sizeof(float));
     w->sqerr = o; o = al(o + (size_t)g.B * sizeof(float));
@@ -806,7 +764,7 @@ static void msg_ws_layout(const MsgGeom& g, MsgWs* w) {
     w->rows_gcn_max = 1024;
     w->rows_gru = (int)(((size_t)g.B * g.n * w->HG + MB - 1) / MB);
     if (w->rows_gru < 1) w->rows_gru = 1;
-    w->gpart_gcn = o; o = al(o + (size_t)w->rows_gcn_max * (g.gcn_params + g.H3 * g.C + g.H3) * sizeof(float));
+    w->gpart_gcn = o; o = al(o + (size_t)w->rows_gcn_max * g.gcn_params * sizeof(float));
     w->gpart_gru = o; o = al(o + (size_t)w->rows_gru * (g.H3 * g.H + g.H3) * sizeof(float));
     w->total = o;
 }
@@ -842,7 +800,7 @@ static int launch_features(const MsgGeom& g, const float* x, const float* prm, f
 }
 
 template <int TW>
-static int launch_gcn_backward(const MsgGeom& g, int rows_max, const float* cat, const float* dgi, const float* prm, float* gpart,
+static int launch_gcn_backward(const MsgGeom& g, int rows_max, const float* cat, const float* dcat, const float* prm, float* gpart,
                                hipStream_t st, int* rows_out) {
     const size_t lds = gcn_backward_lds_bytes(g);
     if (lds > 64 * 1024 &&
@@ -850,7 +808,7 @@ static int launch_gcn_backward(const MsgGeom& g, int rows_max, const float* cat,
                             (int)lds) != hipSuccess)
         return RULGNN_EHIP;
     const int rows = resident_grid(msg_gcn_backward_kernel<TW>, g.G, lds, rows_max);
-    hipLaunchKernelGGL(msg_gcn_backward_kernel<TW>, dim3(rows), dim3(MB), lds, st, g, cat, dgi, prm, gpart);
+    hipLaunchKernelGGL(msg_gcn_backward_kernel<TW>, dim3(rows), dim3(MB), lds, st, g, cat, dcat, prm, gpart);
     *rows_out = rows;
     return RULGNN_OK;
 }
@@ -921,14 +879,30 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
                 return RULGNN_EHIP;
         }
         dispatch_gru(g, w, ws, a->params, true, st);
+        // GRU input projection backward as GEMMs over all (graph, node) rows:
+        //   d cat = d gi W_ih,  d W_ih = d gi^T cat,  d b_ih = column sums of d gi
+        {
+            const int R = (int)(g.G * g.n);
+            const float* dgi = (const float*)(ws + w.dgi);
+            const float* wih = a->params + g.off_wih;
+            float* one = (float*)(ws + w.one);
+            float* split = (float*)(ws + w.split);
+            hipLaunchKernelGGL(msg_fill_kernel, dim3(1), dim3(64), 0, st, one, 64, 1.0f);
+            rc = sgemm(dgi, g.H3, 1, wih, 1, g.C, (float*)(ws + w.dcat), g.C, R, g.C, g.H3, false, st);
+            if (rc != RULGNN_OK) return rc;
+            rc = sgemm_splitk(dgi, 1, g.H3, (const float*)(ws + w.cat), 1, g.C, a->grads + g.off_wih, g.C, g.H3, g.C, R, false, split, st);
+            if (rc != RULGNN_OK) return rc;
+            rc = sgemm_splitk(dgi, 1, g.H3, one, 0, 0, a->grads + g.off_bih, 1, g.H3, 1, R, false, split, st);
+            if (rc != RULGNN_OK) return rc;
+        }
         int rows = 0;
-        const int rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dgi), a->params,
+        const int rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
                                                            (float*)(ws + w.gpart_gcn), st, &rows)
-                                  : launch_gcn_backward<1>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dgi), a->params,
+                                  : launch_gcn_backward<1>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
                                                            (float*)(ws + w.gpart_gcn), st, &rows);
         if (rcb != RULGNN_OK) return rcb;
         const bool mse = a->dpred == nullptr;
-        hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + MB - 1) / MB), dim3(MB), 0, st, g,
+        hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + 3) / 4), dim3(MB), 0, st, g,
                            (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
                            (const float*)(ws + w.dpred), (const float*)(ws + w.pooled), a->grads);
         if (mse && a->loss)
