@@ -284,12 +284,25 @@ struct TBn {            // BatchNorm constants of one layer-block, computed by e
     float mean[F], istd[F], sc[F], sh[F], gi[F], k1[F], k2[F];
 };
 
+// Reduction cells of the tiled path, replicated like the fused path's (4096 workgroups per kernel adding into the same 20
+// addresses serialise for ~40 us): forward cells [T_REP][tc_sf(L)], then backward cells + loss [T_REP][tc_sb(L)] (loss at
+// offset tc_sf(L) of a backward replica).  Workgroup b adds into replica b % T_REP; readers sum the replicas in a fixed order.
+constexpr int T_REP = 16;
+__host__ __device__ constexpr int tc_sf(int L) { return 2 * L * 2 * F; }
+__host__ __device__ constexpr int tc_sb(int L) { return 2 * L * 2 * F + 8; }
+__device__ __forceinline__ double tc_sum(const double* base, int stride, int idx) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < T_REP; ++r) v += base[r * stride + idx];
+    return v;
+}
+
 __device__ __forceinline__ void t_bn_consts(const double* cells_fwd, const double* cells_bwd, const float* __restrict__ prm_l,
-                                            int N, int blk, int bn_index, double cnt, bool with_bwd, float* lds /* [7][F] */) {
+                                            int N, int L, int blk, int bn_index, double cnt, bool with_bwd, float* lds /* [7][F] */) {
     if (threadIdx.x < F) {
         const int c = threadIdx.x;
-        const double mean = cells_fwd[(bn_index * 2 + 0) * F + c] / cnt;
-        double var = cells_fwd[(bn_index * 2 + 1) * F + c] / cnt - mean * mean;
+        const double mean = tc_sum(cells_fwd, tc_sf(L), (bn_index * 2 + 0) * F + c) / cnt;
+        double var = tc_sum(cells_fwd, tc_sf(L), (bn_index * 2 + 1) * F + c) / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         const double istd = 1.0 / sqrt(var + (double)BN_EPS);
         const double g = prm_l[off_bn_g(N, blk) + c], be = prm_l[off_bn_b(N, blk) + c];
@@ -298,8 +311,8 @@ __device__ __forceinline__ void t_bn_consts(const double* cells_fwd, const doubl
         lds[2 * F + c] = (float)(g * istd);
         lds[3 * F + c] = (float)(be - mean * g * istd);
         lds[4 * F + c] = (float)(g * istd);
-        lds[5 * F + c] = with_bwd ? (float)(cells_bwd[(bn_index * 2 + 0) * F + c] / cnt) : 0.f;
-        lds[6 * F + c] = with_bwd ? (float)(cells_bwd[(bn_index * 2 + 1) * F + c] / cnt) : 0.f;
+        lds[5 * F + c] = with_bwd ? (float)(tc_sum(cells_bwd, tc_sb(L), (bn_index * 2 + 0) * F + c) / cnt) : 0.f;
+        lds[6 * F + c] = with_bwd ? (float)(tc_sum(cells_bwd, tc_sb(L), (bn_index * 2 + 1) * F + c) / cnt) : 0.f;
     }
 }
 
@@ -328,9 +341,8 @@ struct TTrain {
     uint32_t drop_thr, drop_key;
     const uint32_t* key_dev;    // device step state: this layer's key (else drop_key)
     double cnt;
-    double* cells_fwd;
-    double* cells_bwd;
-    double* cell_loss;
+    double* cells_fwd;          // [T_REP][tc_sf(L)]
+    double* cells_bwd;          // [T_REP][tc_sb(L)], the loss cell at offset tc_sf(L) of every replica
 };
 
 __device__ __forceinline__ void t_ld10(const float* __restrict__ T, int64_t b, int t, int N, float (&v)[F]) {
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
     }
-    t_pair_reduce(sa, sb, a.cells_fwd + bn_index * 2 * F, lds);
+    t_pair_reduce(sa, sb, a.cells_fwd + (blockIdx.x % T_REP) * tc_sf(a.L) + bn_index * 2 * F, lds);
 }
 
 // o0 = relu(relu(bn1(z1)) + H); z2 = conv2(o0); sums of z2
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
                                                             float* __restrict__ o0, float* __restrict__ z2, int bn_index, TTrain a) {
     __shared__ float lds[4 * 2 * F];
     __shared__ float bnc[7 * F];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index - 1, a.cnt, false, bnc);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index - 1, a.cnt, false, bnc);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < a.B * a.N;
@@ -408,14 +420,14 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
     }
-    t_pair_reduce(sa, sb, a.cells_fwd + bn_index * 2 * F, lds);
+    t_pair_reduce(sa, sb, a.cells_fwd + (blockIdx.x % T_REP) * tc_sf(a.L) + bn_index * 2 * F, lds);
 }
 
 // Xout = dropout(relu(relu(bn2(z2)) + o0)) + Xin
 __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ Xin,
                                                            const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a) {
     __shared__ float bnc[7 * F];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, false, bnc);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.B * a.N) return;
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restri
         else if (has_dpred == 0) {
             const float diff = p - gy[b];
             d = 2.f * diff / (float)a.global_batch;
-            atomicAdd(a.cell_loss, (double)diff * (double)diff);
+            atomicAdd(a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + tc_sf(a.L), (double)diff * (double)diff);
         }
         dpred_out[b] = d;
         dp = d;
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
                                                          float* __restrict__ gsum, int bn_index, int top, TTrain a) {
     __shared__ float lds[4 * 2 * F];
     __shared__ float bnc[7 * F];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, false, bnc);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < a.B * a.N;
@@ -524,7 +536,7 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
             sb[c] = dy * ((zz - bnc[0 * F + c]) * bnc[1 * F + c]);
         }
     }
-    t_pair_reduce(sa, sb, a.cells_bwd + bn_index * 2 * F, lds);
+    t_pair_reduce(sa, sb, a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + bn_index * 2 * F, lds);
 }
 
 __device__ __forceinline__ void t_wgrad_mfma(float* T, const float (&dz)[F], const float (&h)[F], const float (&hs)[F], int lane,
@@ -618,9 +630,9 @@ __global__ __launch_bounds__(256) void t_conv2_bwd_kernel(const float* __restric
     __shared__ float lds[4 * 2 * F];
     __shared__ float bnc2[7 * F], bnc1[7 * F];
     __shared__ float red[8 * 64];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 1, bn_index, a.cnt, true, bnc2);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, true, bnc2);
     __syncthreads();
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index - 1, a.cnt, false, bnc1);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index - 1, a.cnt, false, bnc1);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < a.B * a.N;
@@ -654,7 +666,7 @@ __global__ __launch_bounds__(256) void t_conv2_bwd_kernel(const float* __restric
             sb[c] = dy * ((zz - bnc1[0 * F + c]) * bnc1[1 * F + c]);
         }
     }
-    t_pair_reduce(sa, sb, a.cells_bwd + (bn_index - 1) * 2 * F, lds);
+    t_pair_reduce(sa, sb, a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + (bn_index - 1) * 2 * F, lds);
     __syncthreads();
     t_wgrad_store(red, acc0, acc1, gpart + (size_t)blockIdx.x * CONVW);
 }
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float tile[4][TTR * TTS];
     __shared__ float bnc[7 * F];
     __shared__ float red[8 * 64];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, 0, bn_index, a.cnt, true, bnc);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index, a.cnt, true, bnc);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i < a.B * a.N;
@@ -720,7 +732,6 @@ struct TFin {
     const float* gpart;       // [2L][grid][200]
     const double* cells_fwd;
     const double* cells_bwd;
-    const double* cell_loss;
     float* grads;
     float* loss;
     float* bn_batch;
@@ -730,26 +741,33 @@ struct TFin {
     float moment_weight;
     int write_loss, write_grads;
 };
+constexpr int TFIN_SUB = (CONVW + 3) / 4;      // workgroups per (layer, conv block): four weights each, one per wavefront
 __global__ __launch_bounds__(256) void t_finalize_kernel(TFin f) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
-    // one block per (layer, conv block): 200 conv weights + 20 BatchNorm parameters
-    const int l = blockIdx.x / 2, blk = blockIdx.x % 2, bnidx = blockIdx.x;
+    // (layer, conv block) x sub: 200 conv weights -- a wavefront per weight, lanes striding over the partial rows (one thread
+    // walking all of them took 1.5 ms at XJTU batch 1024), fixed-order butterfly -- and, in sub 0, the 20 BatchNorm parameters
+    const int bnidx = blockIdx.x / TFIN_SUB, sub = blockIdx.x % TFIN_SUB;
+    const int l = bnidx / 2, blk = bnidx % 2;
     const float* gp = f.gpart + (size_t)bnidx * f.grid * CONVW;
     if (f.write_grads) {
-        for (int p = threadIdx.x; p < CONVW; p += 256) {
+        const int p = sub * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (p < CONVW) {
             float v = 0.f;
-            for (int b = 0; b < f.grid; ++b) v += gp[(size_t)b * CONVW + p];
-            f.grads[l * LS + off_conv_w(N, blk) + p] = v;
+            for (int b = lane; b < f.grid; b += 64) v += gp[(size_t)b * CONVW + p];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+            if (lane == 0) f.grads[l * LS + off_conv_w(N, blk) + p] = v;
         }
     }
+    if (sub != 0) return;
     if (threadIdx.x < F) {
         const int c = threadIdx.x;
         if (f.write_grads) {
-            f.grads[l * LS + off_bn_g(N, blk) + c] = (float)f.cells_bwd[(bnidx * 2 + 1) * F + c];
-            f.grads[l * LS + off_bn_b(N, blk) + c] = (float)f.cells_bwd[(bnidx * 2 + 0) * F + c];
+            f.grads[l * LS + off_bn_g(N, blk) + c] = (float)tc_sum(f.cells_bwd, tc_sb(L), (bnidx * 2 + 1) * F + c);
+            f.grads[l * LS + off_bn_b(N, blk) + c] = (float)tc_sum(f.cells_bwd, tc_sb(L), (bnidx * 2 + 0) * F + c);
         }
-        const double mean = f.cells_fwd[(bnidx * 2 + 0) * F + c] / f.cnt;
-        const double ex2 = f.cells_fwd[(bnidx * 2 + 1) * F + c] / f.cnt;
+        const double mean = tc_sum(f.cells_fwd, tc_sf(L), (bnidx * 2 + 0) * F + c) / f.cnt;
+        const double ex2 = tc_sum(f.cells_fwd, tc_sf(L), (bnidx * 2 + 1) * F + c) / f.cnt;
         double var = ex2 - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         if (f.moment_weight > 0.f) {
@@ -760,7 +778,8 @@ __global__ __launch_bounds__(256) void t_finalize_kernel(TFin f) {
             f.bn_batch[(bnidx * 2 + 1) * F + c] = (float)var;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(f.cell_loss[0] / (double)f.global_batch);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.write_loss)
+        f.loss[0] = (float)(tc_sum(f.cells_bwd, tc_sb(L), tc_sf(L)) / (double)f.global_batch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -801,7 +820,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_dy1 = o; o += BNb;
     w->off_dpool = o; o += BNb;
     w->off_dpred = o; o += al256((size_t)B * 4);
-    w->cells_bytes = sizeof(double) * ((size_t)2 * L * 2 * F * 2 + 8);
+    w->cells_bytes = sizeof(double) * (size_t)T_REP * (tc_sf(L) + tc_sb(L));
     w->off_cells = o; o += al256(w->cells_bytes);
     w->off_gpart = o; o += al256((size_t)2 * L * w->grid * CONVW * 4);
     w->off_one = o; o += 256;
@@ -853,7 +872,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     t.key_dev = nullptr;
     const StepState* sstate = static_cast<const StepState*>(ar->step_state);
     t.cnt = (double)B * (double)N;
-    t.cells_fwd = cells; t.cells_bwd = cells + 2 * L * 2 * F; t.cell_loss = cells + 2 * (2 * L * 2 * F);
+    t.cells_fwd = cells; t.cells_bwd = cells + T_REP * tc_sf(L);
     const int has_dpred = ar->dpred ? 1 : (ar->y ? 0 : 2);
     const float* gy = ar->dpred ? ar->dpred : ar->y;
     int rc;
@@ -883,7 +902,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         rc = sgemm(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, stream);
         if (rc != RULGNN_OK) return rc;
     } else {
-        if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * (2 * L * 2 * F + 8), stream) != hipSuccess) return RULGNN_EHIP;
+        if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * T_REP * tc_sb(L), stream) != hipSuccess) return RULGNN_EHIP;
     }
     // head (also recomputed by a backward-only call: cheap, gives dpred for the incoming gradient)
     (void)hipGetLastError();
@@ -930,14 +949,14 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         }
     }
     TFin f;
-    f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd; f.cell_loss = t.cell_loss;
+    f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd;
     f.grads = ar->grads; f.loss = ar->loss; f.bn_batch = ar->bn_batch;
     f.grid = w.grid; f.N = N; f.L = L; f.global_batch = ar->global_batch; f.cnt = t.cnt;
     f.moment_weight = ar->bn_moment_weight;
     f.write_loss = (has_dpred == 0) && ar->loss && mode != 0;
     f.write_grads = mode != 0;          // forward only: just the batch statistics for the running-stat update
     (void)hipGetLastError();
-    hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L * TFIN_SUB), dim3(256), 0, stream, f);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
