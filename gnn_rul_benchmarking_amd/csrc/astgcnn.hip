@@ -295,19 +295,9 @@ __global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float
 }
 
 // finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
-__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2,
-                                                         int rows, const Cells* cells, float* __restrict__ grads) {
-    const int e = blockIdx.x * AB + threadIdx.x, N = g.N, nW = N * N * KT;
-    if (e < nW) {
-        float a = 0.f, c = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            a += gp1[(int64_t)r * nW + e];
-            c += gp2[(int64_t)r * nW + e];
-        }
-        grads[g.o_w1 + e] = a;
-        grads[g.o_w2 + e] = c;
-    } else if (e < nW + N) {
-        const int c = e - nW;
+__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads) {
+    const int c = blockIdx.x * AB + threadIdx.x;
+    if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
         grads[g.o_g1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
         grads[g.o_b1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
         grads[g.o_g2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
@@ -499,8 +489,9 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         const bool mse = a->dpred == nullptr;
-        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N * N * KT + N + AB - 1) / AB), dim3(AB), 0, st, g, (const float*)F(w.gp1),
-                           (const float*)F(w.gp2), rows, (const Cells*)cells, gr);
+        AST_RC(rows_sum(F(w.gp1), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w1, st));
+        AST_RC(rows_sum(F(w.gp2), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w2, st));
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr);
         if (mse && a->loss)
             hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)F(w.sqerr), (int64_t)g.B, a->loss);
     }

@@ -313,6 +313,33 @@ static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
+// out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 64 columns x 16 row slices per
+// workgroup, the slices combined through LDS in a fixed order (deterministic).  One thread per column walking every row alone
+// was 140-190 us in the finalize kernels of three families.
+static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ part, int rows, int64_t ld, int n,
+                                                               float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    float a = 0.f;
+    if (e < n)
+        for (int r = sl; r < rows; r += 16) a += part[(int64_t)r * ld + e];
+    red[sl][lane] = a;
+    __syncthreads();
+    if (sl == 0 && e < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][lane];
+        out[e] = v;
+    }
+}
+static inline int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {
+    if (n <= 0) return RULGNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, part, rows, ld, n, out);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
 // out[0] = sum(v[0..n)) with one workgroup: strided partial sums, then a fixed-order tree (deterministic).
 static __global__ __launch_bounds__(1024) void block_sum_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
     __shared__ float red[1024];

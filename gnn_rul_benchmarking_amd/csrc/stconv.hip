@@ -361,33 +361,17 @@ __global__ __launch_bounds__(AB) void sc_cnn_bwd_kernel(ScGeom g, const float* _
     }
 }
 
-__global__ __launch_bounds__(AB) void sc_finalize_kernel(ScGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2,
-                                                        const float* __restrict__ gp3, int rows, const Cells* cells, const Cells3* c3,
-                                                        float* __restrict__ grads) {
-    const int e = blockIdx.x * AB + threadIdx.x, N = g.N, nW = N * N * KT;
-    if (e < nW) {
-        float a = 0.f, c = 0.f, d = 0.f;
-        for (int r = 0; r < rows; ++r) {
-            a += gp1[(int64_t)r * nW + e];
-            c += gp2[(int64_t)r * nW + e];
-            d += gp3[(int64_t)r * (nW + N) + e];
-        }
-        grads[g.o_w1 + e] = a;
-        grads[g.o_w2 + e] = c;
-        grads[g.o_cw + e] = d;
-    } else if (e < nW + N) {
-        const int c = e - nW;
-        float d = 0.f;
-        for (int r = 0; r < rows; ++r) d += gp3[(int64_t)r * (nW + N) + e];
-        grads[g.o_cb + c] = d;
+__global__ __launch_bounds__(AB) void sc_finalize_kernel(ScGeom g, const Cells* cells, const Cells3* c3, float* __restrict__ grads) {
+    const int c = blockIdx.x * AB + threadIdx.x, N = g.N;
+    if (c < N) {            // the conv weight / bias rows are summed by rows_sum (sgemm_mfma.hpp)
         grads[g.o_g1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
         grads[g.o_b1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
         grads[g.o_g2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
         grads[g.o_b2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
         grads[g.o_gc + c] = (float)cell3_bwd(c3, c, 1);
         grads[g.o_bc + c] = (float)cell3_bwd(c3, c, 0);
-    } else if (e < nW + N + 4) {
-        grads[g.o_th + (e - nW - N)] = (float)cell3_th(c3, e - nW - N);
+    } else if (c < N + 4) {
+        grads[g.o_th + (c - N)] = (float)cell3_th(c3, c - N);
     }
 }
 
@@ -556,8 +540,14 @@ int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int m
         // theta of the MPNN: d weight = dgpre^T (A X) ; d bias = column sums
         SC_RC(sgemm_splitk(F(w.gpre), 1, T, F(w.ax), 1, T, gr + g.o_gw, T, T, T, M, false, split, st));
         SC_RC(sgemm_splitk(one, 0, 0, F(w.gpre), 1, T, gr + g.o_gb, T, 1, T, M, false, split, st));
-        hipLaunchKernelGGL(sc_finalize_kernel, dim3((N * N * KT + N + 4 + AB - 1) / AB), dim3(AB), 0, st, g, (const float*)F(w.gp1),
-                           (const float*)F(w.gp2), (const float*)F(w.gp3), rows, (const Cells*)cells, (const Cells3*)c3, gr);
+        {
+            const int nW = N * N * KT;
+            SC_RC(rows_sum(F(w.gp1), rows, nW, nW, gr + g.o_w1, st));
+            SC_RC(rows_sum(F(w.gp2), rows, nW, nW, gr + g.o_w2, st));
+            SC_RC(rows_sum(F(w.gp3), rows, nW + N, nW, gr + g.o_cw, st));
+            SC_RC(rows_sum(F(w.gp3) + nW, rows, nW + N, N, gr + g.o_cb, st));
+        }
+        hipLaunchKernelGGL(sc_finalize_kernel, dim3((N + 4 + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, (const Cells3*)c3, gr);
         if (!a->dpred && a->loss)
             hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)F(w.sqerr), (int64_t)g.B, a->loss);
     }
