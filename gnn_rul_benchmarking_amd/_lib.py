@@ -142,6 +142,11 @@ _SIGNATURES = {
     "rulgnn_stgnn_cheb_forward_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rulgnn_stgnn_cheb_backward_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                  C.c_void_p]),
+    "rulgnn_stgnn_param_count": (C.c_int64, [C.POINTER(StgnnShape)]),
+    "rulgnn_stgnn_step_workspace_bytes": (C.c_size_t, [C.POINTER(StgnnShape)]),
+    "rulgnn_stgnn_forward_f32": (C.c_int, [C.POINTER(StgnnShape), C.POINTER(StmsgcnArgs), C.c_void_p]),
+    "rulgnn_stgnn_backward_f32": (C.c_int, [C.POINTER(StgnnShape), C.POINTER(StmsgcnArgs), C.c_void_p]),
+    "rulgnn_stgnn_fwdbwd_f32": (C.c_int, [C.POINTER(StgnnShape), C.POINTER(StmsgcnArgs), C.c_void_p, C.c_void_p]),
     "rulgnn_gru_workspace_bytes": (C.c_size_t, [C.POINTER(GruShape)]),
     "rulgnn_gru_forward_f32": (C.c_int, [C.POINTER(GruShape), C.POINTER(GruArgs), C.c_void_p]),
     "rulgnn_gru_backward_f32": (C.c_int, [C.POINTER(GruShape), C.POINTER(GruArgs), C.c_void_p]),

@@ -296,46 +296,41 @@ class HAGCN(Algorithm):
 
 
 class STGNN(Algorithm):
-    """STGNN training wrapper (reference algorithms.py:383-408), the reference's literal autograd sequence: the graph part is
-    one HIP autograd function (csrc/stgnn.hip), the GRU and ``fc`` are torch modules, so the optimizer is
-    ``torch.optim.Adam`` exactly as in the reference.  Samples are independent (no BatchNorm, no dropout): under data
-    parallelism each rank back-propagates ``sum (pred - y)^2 / global_batch`` of its shard and ONE all-reduce over the flat
-    ``[gradients | loss]`` bucket gives every rank the global-batch gradient."""
+    """STGNN training wrapper (reference algorithms.py:383-408): ``update`` = forward + MSE + backward + Adam in one C call
+    (graph / ChebNet kernels of csrc/stgnn.hip, the GRU of csrc/gru.hip, the fused Adam kernel).  The model has neither
+    BatchNorm nor dropout: samples are independent and data parallelism is the plain ``[gradient | loss]`` bucket."""
 
     def __init__(self, configs, hparams, device):
         super(STGNN, self).__init__(configs)
         self.model = STGNN_model(**configs)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
         self.hparams = hparams
         self.dp = None
         self.sync_loss = True
 
     def attach_data_parallel(self, dp):
         self.dp = dp
-        for t in list(self.model.parameters()) + list(self.model.buffers()):
-            torch.distributed.broadcast(t.data, src=0, group=dp.group)
+        dp.broadcast_model(self.model)
 
     def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        else:
+            loss = self._eager_update(X, y)
+        return self._finish(loss)
+
+    def _eager_update(self, X, y):
+        _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return loss
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd; same result as ``update``."""
         predicted_RUL = self.model(X)
-        if self.dp is None:
-            loss = self.mse(predicted_RUL, y)
-            self.optimizer.zero_grad()
-            loss.backward()
-            self.optimizer.step()
-            return self._finish(loss.detach())
-        gb = int(global_batch) if global_batch is not None else X.size(0) * self.dp.world_size
-        loss = ((predicted_RUL - y) ** 2).sum() / gb
+        loss = self.mse(predicted_RUL, y)
         self.optimizer.zero_grad()
         loss.backward()
-        params = [p for p in self.model.parameters()]
-        bucket = torch.cat([p.grad.reshape(-1) for p in params] + [loss.detach().reshape(1)])
-        self.dp.all_reduce_bucket(bucket)
-        o = 0
-        for p in params:
-            p.grad.copy_(bucket[o:o + p.numel()].view_as(p))
-            o += p.numel()
         self.optimizer.step()
-        return self._finish(bucket[o])
+        return {'loss': loss.item()}
 
 
 _NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}

@@ -517,6 +517,54 @@ int rulgnn_stgnn_cheb_backward_f32(const rulgnn_stgnn_shape* shape, const float*
     return stgnn_cheb_backward(shape, terms, dout, dfilters, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int64_t rulgnn_stgnn_param_count(const rulgnn_stgnn_shape* shape) { return stgnn_param_count(shape); }
+size_t rulgnn_stgnn_step_workspace_bytes(const rulgnn_stgnn_shape* shape) { return stgnn_step_workspace_bytes(shape); }
+
+static int check_stgnn(const rulgnn_stgnn_shape* shape, const rulgnn_stmsgcn_args* a, bool fwd, bool bwd) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (stgnn_param_count(shape) < 0) return stgnn_step_workspace_bytes(shape) == 0 && shape->batch >= 0 ? RULGNN_EUNSUPPORTED : RULGNN_EINVAL;
+    int rc = check_ptrs({a->params, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch > 0) {
+        rc = check_ptrs({a->x});
+        if (rc != RULGNN_OK) return rc;
+        if (fwd && (rc = check_ptrs({a->pred})) != RULGNN_OK) return rc;
+    }
+    if (bwd) {
+        if ((rc = check_ptrs({a->grads})) != RULGNN_OK) return rc;
+        if (shape->batch > 0 && !a->dpred && !(fwd && a->y)) return RULGNN_EINVAL;     // needs d pred, or targets with a forward
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_stgnn_forward_f32(const rulgnn_stgnn_shape* shape, const rulgnn_stmsgcn_args* args, void* stream) {
+    const int rc = check_stgnn(shape, args, true, false);
+    if (rc != RULGNN_OK) return rc;
+    return stgnn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgnn_backward_f32(const rulgnn_stgnn_shape* shape, const rulgnn_stmsgcn_args* args, void* stream) {
+    const int rc = check_stgnn(shape, args, false, true);
+    if (rc != RULGNN_OK) return rc;
+    return stgnn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgnn_fwdbwd_f32(const rulgnn_stgnn_shape* shape, const rulgnn_stmsgcn_args* args, const rulgnn_adam_args* opt, void* stream) {
+    int rc = check_stgnn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = stgnn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stgnn_param_count(shape), opt->step, opt->lr, opt->beta1,
+                     opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
 size_t rulgnn_gru_workspace_bytes(const rulgnn_gru_shape* shape) { return gru_workspace_bytes(shape); }
 
 int rulgnn_gru_forward_f32(const rulgnn_gru_shape* shape, const rulgnn_gru_args* args, void* stream) {

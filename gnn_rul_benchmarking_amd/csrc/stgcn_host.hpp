@@ -146,6 +146,9 @@ int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float
 int stgnn_cheb_forward(const rulgnn_stgnn_shape* s, const float* terms, const float* filters, float* out, hipStream_t st);
 int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const float* dout, float* dfilters, void* workspace,
                         size_t workspace_bytes, hipStream_t st);
+int64_t stgnn_param_count(const rulgnn_stgnn_shape* s);
+size_t stgnn_step_workspace_bytes(const rulgnn_stgnn_shape* s);
+int stgnn_run(const rulgnn_stgnn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t st);
 size_t gru_workspace_bytes(const rulgnn_gru_shape* s);
 int gru_forward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t st);
 int gru_backward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t st);

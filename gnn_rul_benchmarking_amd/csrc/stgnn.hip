@@ -170,4 +170,193 @@ int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const f
     return sgemm_splitk(terms, 1, g.KF, dout, 1, g.H, dfilters, g.H, g.KF, g.H, (int)M, false, static_cast<float*>(workspace), st);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// whole model: forward / backward / both, flat parameters
+//   chebnet.filters [K, f, H] | gru.weight_ih_l0 [3H, H] | gru.weight_hh_l0 [3H, H] | gru.bias_ih_l0 [3H] | gru.bias_hh_l0 [3H] |
+//   fc.weight [N*L*H] | fc.bias [1]        (the reference's state_dict order, Model.py:69-72)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct GnOff {
+    int filters, wih, whh, bih, bhh, fcw, fcb, total;
+};
+GnOff gn_offsets(const GnGeom& g) {
+    GnOff o;
+    int t = 0;
+    o.filters = t; t += g.KF * g.H;
+    o.wih = t; t += 3 * g.H * g.H;
+    o.whh = t; t += 3 * g.H * g.H;
+    o.bih = t; t += 3 * g.H;
+    o.bhh = t; t += 3 * g.H;
+    o.fcw = t; t += g.H * g.L * g.N;
+    o.fcb = t; t += 1;
+    o.total = t;
+    return o;
+}
+
+// rows (b, l, n) <-> (b, n, l) of an [*, H] tensor (Model.py:93-95: view(bs, L, N, H).permute(0, 2, 1, 3))
+__global__ __launch_bounds__(GB) void stgnn_permute_kernel(GnGeom g, const float* __restrict__ src, float* __restrict__ dst, int to_seq) {
+    const int64_t total = g.G * g.N * g.H;
+    for (int64_t e = (int64_t)blockIdx.x * GB + threadIdx.x; e < total; e += (int64_t)gridDim.x * GB) {
+        const int h = (int)(e % g.H);
+        const int64_t r = e / g.H;                           // source row
+        int64_t b, l, n;
+        if (to_seq) { n = r % g.N; l = (r / g.N) % g.L; b = r / ((int64_t)g.N * g.L); }
+        else { l = r % g.L; n = (r / g.L) % g.N; b = r / ((int64_t)g.N * g.L); }
+        const int64_t d = to_seq ? (b * g.N + n) * g.L + l : (b * g.L + l) * g.N + n;
+        dst[d * g.H + h] = src[e];
+    }
+}
+
+// pred[b] = flat[b] . fc_w + fc_b (Model.py:101-104); d loss / d pred and the squared error for the MSE
+__global__ __launch_bounds__(GB) void stgnn_head_kernel(GnGeom g, const float* __restrict__ flat, const float* __restrict__ fcw,
+                                                        const float* __restrict__ fcb, const float* __restrict__ y,
+                                                        float* __restrict__ pred, float* __restrict__ dpred, float* __restrict__ sqerr,
+                                                        float inv_gb) {
+    __shared__ float red[GB];
+    const int64_t b = blockIdx.x;
+    const int Q = g.N * g.L * g.H;
+    float a = 0.f;
+    for (int q = threadIdx.x; q < Q; q += GB) a = fmaf(flat[b * Q + q], fcw[q], a);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int m = GB / 2; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float p = red[0] + fcb[0];
+        pred[b] = p;
+        if (y) {
+            const float d = p - y[b];
+            dpred[b] = 2.f * d * inv_gb;
+            sqerr[b] = d * d * inv_gb;
+        }
+    }
+}
+
+// d flat[b][q] = dpred[b] * fc_w[q]
+__global__ __launch_bounds__(GB) void stgnn_dflat_kernel(GnGeom g, const float* __restrict__ dpred, const float* __restrict__ fcw,
+                                                         float* __restrict__ dflat) {
+    const int Q = g.N * g.L * g.H;
+    const int64_t total = g.B * Q;
+    for (int64_t e = (int64_t)blockIdx.x * GB + threadIdx.x; e < total; e += (int64_t)gridDim.x * GB) dflat[e] = dpred[e / Q] * fcw[e % Q];
+}
+
+__global__ void stgnn_fill_kernel(float* p, int n, float v) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = v;
+}
+
+struct GnWs {
+    size_t terms, cheb, seq, hs, dhs, dseq, dcheb, dpred, sqerr, one, gru, split, total;
+    size_t gru_bytes;
+};
+void gn_ws(const GnGeom& g, GnWs* w) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t R = (size_t)g.G * g.N;
+    size_t o = 0;
+    w->terms = o; o = al(o + R * g.KF * sizeof(float));
+    w->cheb = o; o = al(o + R * g.H * sizeof(float));
+    w->seq = o; o = al(o + R * g.H * sizeof(float));
+    w->hs = o; o = al(o + R * g.H * sizeof(float));
+    w->dhs = o; o = al(o + R * g.H * sizeof(float));
+    w->dseq = o; o = al(o + R * g.H * sizeof(float));
+    w->dcheb = o; o = al(o + R * g.H * sizeof(float));
+    w->dpred = o; o = al(o + (size_t)(g.B > 0 ? g.B : 1) * sizeof(float));
+    w->sqerr = o; o = al(o + (size_t)(g.B > 0 ? g.B : 1) * sizeof(float));
+    w->one = o; o = al(o + 64 * sizeof(float));
+    rulgnn_gru_shape gs{(int64_t)(g.B * g.N), g.L, g.H, g.H};
+    w->gru_bytes = gru_workspace_bytes(&gs);
+    w->gru = o; o = al(o + w->gru_bytes);
+    const int Q = g.N * g.L * g.H;
+    size_t sp = sgemm_splitk_partial_floats(g.KF, g.H);
+    const size_t s2 = sgemm_splitk_need_floats(1, Q, (int)g.B), s3 = sgemm_splitk_need_floats(1, 1, (int)g.B);
+    if (s2 > sp) sp = s2;
+    if (s3 > sp) sp = s3;
+    w->split = o; o = al(o + sp * sizeof(float));
+    w->total = o;
+}
+
+inline unsigned gn_blocks(int64_t n) {
+    int64_t b = (n + GB - 1) / GB;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+int64_t stgnn_param_count(const rulgnn_stgnn_shape* s) {
+    GnGeom g;
+    if (gn_geometry(s, &g) != RULGNN_OK) return -1;
+    return gn_offsets(g).total;
+}
+
+size_t stgnn_step_workspace_bytes(const rulgnn_stgnn_shape* s) {
+    GnGeom g;
+    if (gn_geometry(s, &g) != RULGNN_OK) return 0;
+    GnWs w;
+    gn_ws(g, &w);
+    return w.gru_bytes == 0 && g.B > 0 ? 0 : w.total;
+}
+
+#define GN_RC(x) do { const int rc_ = (x); if (rc_ != RULGNN_OK) return rc_; } while (0)
+
+// mode bit 0: forward (pred; with y also d pred and the loss terms), bit 1: backward (gradients; d pred from args->dpred or
+// from the forward of this call)
+int stgnn_run(const rulgnn_stgnn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t st) {
+    GnGeom g;
+    GN_RC(gn_geometry(s, &g));
+    GnWs w;
+    gn_ws(g, &w);
+    if (!a->workspace || a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
+    const GnOff o = gn_offsets(g);
+    if (g.B == 0) {
+        if ((mode & 2) && hipMemsetAsync(a->grads, 0, sizeof(float) * o.total, st) != hipSuccess) return RULGNN_EHIP;
+        if ((mode & 2) && a->loss && hipMemsetAsync(a->loss, 0, sizeof(float), st) != hipSuccess) return RULGNN_EHIP;
+        return RULGNN_OK;
+    }
+    char* ws = static_cast<char*>(a->workspace);
+    auto Fp = [&](size_t off) { return reinterpret_cast<float*>(ws + off); };
+    const float* prm = a->params;
+    const int64_t R = g.G * g.N;
+    const int Q = g.N * g.L * g.H;
+    rulgnn_gru_shape gs{(int64_t)(g.B * g.N), g.L, g.H, g.H};
+    rulgnn_gru_args ga{};
+    ga.w_ih = prm + o.wih; ga.w_hh = prm + o.whh; ga.b_ih = prm + o.bih; ga.b_hh = prm + o.bhh;
+    ga.workspace = ws + w.gru; ga.workspace_bytes = w.gru_bytes;
+    float* seq = g.L == 1 ? Fp(w.cheb) : Fp(w.seq);          // one patch: the permutation is the identity
+    float* dseq = Fp(w.dseq);
+    float* dcheb = g.L == 1 ? dseq : Fp(w.dcheb);
+    (void)hipGetLastError();
+    if (mode & 1) {
+        GN_RC(stgnn_terms(s, a->x, Fp(w.terms), nullptr, st));
+        GN_RC(stgnn_cheb_forward(s, Fp(w.terms), prm + o.filters, Fp(w.cheb), st));
+        if (g.L > 1) hipLaunchKernelGGL(stgnn_permute_kernel, dim3(gn_blocks(R * g.H)), dim3(GB), 0, st, g, (const float*)Fp(w.cheb), seq, 1);
+        ga.x = seq; ga.out = Fp(w.hs);
+        GN_RC(gru_forward(&gs, &ga, st));
+        const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+        hipLaunchKernelGGL(stgnn_head_kernel, dim3((unsigned)g.B), dim3(GB), 0, st, g, (const float*)Fp(w.hs), prm + o.fcw, prm + o.fcb, a->y,
+                           a->pred, Fp(w.dpred), Fp(w.sqerr), inv_gb);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    }
+    if (mode & 2) {
+        const float* dpred = a->dpred ? a->dpred : Fp(w.dpred);
+        float* gr = a->grads;
+        float* split = Fp(w.split);
+        hipLaunchKernelGGL(stgnn_fill_kernel, dim3(1), dim3(64), 0, st, Fp(w.one), 64, 1.0f);
+        // fc: d w[q] = sum_b dpred[b] flat[b][q], d b = sum_b dpred[b], d flat = dpred (x) w
+        GN_RC(sgemm_splitk(dpred, 0, 1, Fp(w.hs), 1, Q, gr + o.fcw, Q, 1, Q, (int)g.B, false, split, st));
+        GN_RC(sgemm_splitk(dpred, 0, 1, Fp(w.one), 0, 0, gr + o.fcb, 1, 1, 1, (int)g.B, false, split, st));
+        hipLaunchKernelGGL(stgnn_dflat_kernel, dim3(gn_blocks(g.B * Q)), dim3(GB), 0, st, g, dpred, prm + o.fcw, Fp(w.dhs));
+        ga.x = seq; ga.dout = Fp(w.dhs); ga.dx = dseq;
+        ga.dw_ih = gr + o.wih; ga.dw_hh = gr + o.whh; ga.db_ih = gr + o.bih; ga.db_hh = gr + o.bhh;
+        GN_RC(gru_backward(&gs, &ga, st));
+        if (g.L > 1) hipLaunchKernelGGL(stgnn_permute_kernel, dim3(gn_blocks(R * g.H)), dim3(GB), 0, st, g, (const float*)dseq, dcheb, 0);
+        GN_RC(stgnn_cheb_backward(s, Fp(w.terms), dcheb, gr + o.filters, split, sgemm_splitk_partial_floats(g.KF, g.H) * sizeof(float), st));
+        if (!a->dpred && a->loss)
+            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)Fp(w.sqerr), (int64_t)g.B, a->loss);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    }
+    return RULGNN_OK;
+}
+
 }  // namespace rulgnn

@@ -41,10 +41,12 @@ class DataParallel:
     def broadcast_model(self, model) -> None:
         """Make every replica identical to rank 0 (parameters and BatchNorm statistics)."""
         dist.broadcast(model.flat_params, 0, group=self.group)
-        dist.broadcast(model._bn, 0, group=self.group)
+        if getattr(model, "_bn", None) is not None:            # models without BatchNorm (STMSGCN, STGNN) have no such buffers
+            dist.broadcast(model._bn, 0, group=self.group)
         if hasattr(model, "_flush_nbt"):
             model._flush_nbt()
-        dist.broadcast(model._nbt, 0, group=self.group)
+        if getattr(model, "_nbt", None) is not None:
+            dist.broadcast(model._nbt, 0, group=self.group)
 
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)

@@ -1,6 +1,8 @@
-"""Drop-in ``STGNN_model`` (the first of the ChebNet users): the graph part -- Gaussian-kernel
-top-k adjacency of every (sample, patch) graph, the Chebyshev terms, the ChebNet projection and its filter gradient -- runs
-in the gfx950 HIP kernels of csrc/stgnn.hip through one autograd function, the one-layer GRU over the (1-5) patches of every
+"""Drop-in ``STGNN_model`` (the first of the ChebNet users).  The whole model runs behind three C
+entries on one flat parameter buffer (``rulgnn_stgnn_{forward,backward,fwdbwd}_f32``: ``fused_mse_step`` is forward + MSE +
+backward + Adam in one call); the autograd pieces ``_ChebFunction`` / ``_GruFunction`` expose the same kernels op by op.
+The graph part -- Gaussian-kernel top-k adjacency of every (sample, patch) graph, the Chebyshev terms, the ChebNet projection
+and its filter gradient -- runs in the gfx950 HIP kernels of csrc/stgnn.hip, the one-layer GRU over the (1-5) patches of every
 (sample, node) pair in the kernels of csrc/gru.hip (the vendor RNN's backward took 6 ms at batch 4096 for this many short
 sequences; the ``nn.GRU`` module only holds the parameters); the final ``Linear`` is a library op on the same stream.
 
@@ -121,28 +123,189 @@ class ChebNet(nn.Module):
         nn.init.xavier_uniform_(self.filters)
 
 
+class _Function(torch.autograd.Function):
+    """model(x) through the C entries rulgnn_stgnn_forward_f32 / rulgnn_stgnn_backward_f32 (flat parameters)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        pred = model._forward(x).clone()
+        ctx.model, ctx.x = model, x
+        return pred.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        grads = model._backward(ctx.x, dout.reshape(-1).contiguous().float())
+        outs = [grads[off:off + n].view(shape).clone() for off, n, shape in model._slices]
+        return (None, None, *outs)
+
+
+def param_layout(patch_size, num_patch, num_nodes, hidden_dim, K):
+    """name -> (offset, shape) in the flat buffer the kernels read (include/rulgnn.h), in state_dict order."""
+    H = hidden_dim
+    layout, off = {}, 0
+    for name, shape in (("chebnet.filters", (K, patch_size, H)), ("gru.weight_ih_l0", (3 * H, H)), ("gru.weight_hh_l0", (3 * H, H)),
+                        ("gru.bias_ih_l0", (3 * H,)), ("gru.bias_hh_l0", (3 * H,)), ("fc.weight", (1, H * num_patch * num_nodes)),
+                        ("fc.bias", (1,))):
+        n = 1
+        for d in shape:
+            n *= d
+        layout[name] = (off, shape)
+        off += n
+    return layout, off
+
+
 class STGNN_model(nn.Module):
     def __init__(self, patch_size, num_patch, num_nodes, hidden_dim, K, top_k):
         super().__init__()
         self.num_patch, self.patch_size = int(num_patch), int(patch_size)
         self.num_nodes, self.hidden_dim = int(num_nodes), int(hidden_dim)
         self.top_k = int(top_k)
+        # same construction order as the reference => same RNG consumption => same initial weights; the sub-modules only hold
+        # the parameters (views into one flat buffer), none of them is ever called
         self.chebnet = ChebNet(self.patch_size, self.hidden_dim, int(K))
         self.gru = nn.GRU(self.hidden_dim, self.hidden_dim, batch_first=True)
         self.fc = nn.Linear(self.hidden_dim * self.num_patch * self.num_nodes, 1)
         self.last_adjacency = None          # filled by forward(x, return_adjacency=True)
+        self._layout, self._count = param_layout(self.patch_size, self.num_patch, self.num_nodes, self.hidden_dim, int(K))
+        self._slices = []
+        for _, (off, shape) in self._layout.items():
+            n = 1
+            for d in shape:
+                n *= d
+            self._slices.append((off, n, shape))
+        self._flat = self._grad_flat = None
+        self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._reflatten()
 
+    # ---- flat storage ----------------------------------------------------------------------------------
+    def _named(self):
+        table = dict(self.named_parameters())
+        return [table[name] for name in self._layout]
+
+    def _named_live(self):
+        return list(zip(self._layout, self._named()))
+
+    def _reflatten(self):
+        ps = self._named()
+        dev = ps[0].device
+        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, (off, n, shape) in zip(ps, self._slices):
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
+        self._bufs, self._step_state = {}, None
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._reflatten()
+        return self
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def bucket(self):
+        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
+        return self._grad_flat
+
+    @property
+    def num_live(self):
+        return self._count
+
+    # ---- C-ABI calls -----------------------------------------------------------------------------------
+    def _shape(self, batch):
+        return _lib.StgnnShape(batch, self.num_nodes, self.num_patch, self.patch_size, self.hidden_dim, self.chebnet.K, self.top_k)
+
+    def _check_input(self, x):
+        if x.dim() != 3 or x.size(1) != self.num_nodes or x.size(2) != self.num_patch * self.patch_size:
+            raise RuntimeError(f"STGNN_model expects [bs, {self.num_nodes}, {self.num_patch * self.patch_size}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("STGNN_model runs on the HIP path only: input must be a CUDA (ROCm) tensor; there is no CPU fallback")
+        if x.device != self._flat.device:
+            raise RuntimeError(f"input on {x.device} but model on {self._flat.device}")
+        return x.contiguous().float()
+
+    def _args(self, shp, x, y=None, dpred=None, global_batch=None):
+        B = x.size(0)
+        ent = self._bufs.get(B)
+        if ent is None:
+            nbytes = _lib.load().rulgnn_stgnn_step_workspace_bytes(C.byref(shp))
+            if nbytes == 0:
+                raise RuntimeError("STGNN HIP kernels do not cover this configuration (num_nodes <= 32, patch_size <= 128, K <= 4, "
+                                   "top_k <= num_nodes)")
+            if len(self._bufs) >= 4 and not self._pin_bufs:
+                self._bufs.pop(next(iter(self._bufs)))
+            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
+                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
+            self._bufs[B] = ent
+        ws, pred = ent
+        a = _lib.StmsgcnArgs()
+        a.x = x.data_ptr()
+        a.y = y.data_ptr() if y is not None else None
+        a.dpred = dpred.data_ptr() if dpred is not None else None
+        a.params, a.grads = self._flat.data_ptr(), self._grad_flat.data_ptr()
+        a.pred = pred.data_ptr()
+        a.loss = self._grad_flat.data_ptr() + 4 * self._count
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.global_batch = B if global_batch is None else int(global_batch)
+        return a, pred
+
+    def _forward(self, x):
+        shp = self._shape(x.size(0))
+        a, pred = self._args(shp, x)
+        _lib.check(_lib.load().rulgnn_stgnn_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stgnn_forward_f32")
+        return pred[:x.size(0)]
+
+    def _backward(self, x, dpred):
+        shp = self._shape(x.size(0))
+        a, _ = self._args(shp, x, dpred=dpred)
+        _lib.check(_lib.load().rulgnn_stgnn_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stgnn_backward_f32")
+        return self._grad_flat
+
+    def fused_mse_step(self, x, y, optimizer=None, global_batch=None):
+        """forward + MSE + backward (+ Adam when ``optimizer`` is a FusedAdam over this model) in one C call; fills
+        ``self.bucket`` = [grad | loss]; returns (pred [B], loss 0-d tensor) on the device, no host sync."""
+        x = self._check_input(x)
+        yv = y.reshape(-1).contiguous().float()
+        if yv.numel() != x.size(0):
+            raise RuntimeError("target size mismatch")
+        shp = self._shape(x.size(0))
+        a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
+        o = None
+        if optimizer is not None:
+            m, v = optimizer._state_buffers()
+            optimizer._steps += 1
+            g = optimizer.param_groups[0]
+            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
+                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                                      0.1, self._step_state.data_ptr() if self._step_state is not None else None))
+        _lib.check(_lib.load().rulgnn_stgnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stgnn_fwdbwd_f32")
+        return pred[:x.size(0)], self._grad_flat[self._count]
+
+    def adjacency(self, x):
+        """[bs, num_patch, N, N]: compute_adjacency_matrix of the reference (Model.py:8-25), for inspection / tests."""
+        x = self._check_input(x)
+        bs = x.size(0)
+        shp = self._shape(bs)
+        G = bs * self.num_patch
+        terms = torch.empty(G * self.num_nodes, self.chebnet.K * self.patch_size, dtype=torch.float32, device=x.device)
+        adj = torch.empty(G, self.num_nodes, self.num_nodes, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().rulgnn_stgnn_terms_f32(C.byref(shp), x.data_ptr(), terms.data_ptr(), adj.data_ptr(), _stream()),
+                   "rulgnn_stgnn_terms_f32")
+        return adj.view(bs, self.num_patch, self.num_nodes, self.num_nodes)
+
+    # ---- nn.Module surface -----------------------------------------------------------------------------
     def forward(self, x, return_adjacency=False):
-        bs, num_node, time_length = x.shape
-        L, f, H = self.num_patch, self.patch_size, self.hidden_dim
-        if num_node != self.num_nodes or time_length != L * f:
-            raise RuntimeError(f"STGNN_model expects [bs, {self.num_nodes}, {L * f}], got {tuple(x.shape)}")
-        shape = (bs, num_node, L, f, H, self.chebnet.K, self.top_k)
-        cheb, adj = _ChebFunction.apply(x, self.chebnet.filters, shape, bool(return_adjacency))
+        x = self._check_input(x)
+        if x.size(0) == 0:              # like the reference: reshape(0, -1) is ambiguous (Model.py:101)
+            raise RuntimeError("cannot reshape tensor of 0 elements into shape [0, -1] because the unspecified dimension size -1 can be "
+                               "any value and is ambiguous")
         if return_adjacency:
-            self.last_adjacency = adj.view(bs, L, num_node, num_node)
-        # [bs*L*N, H] -> one sequence of L patches per (sample, node)  (Model.py:93-95)
-        seq = cheb.view(bs, L, num_node, H).permute(0, 2, 1, 3).reshape(bs * num_node, L, H)
-        g = self.gru                       # the nn.GRU module only holds the parameters
-        gru_output = _GruFunction.apply(seq, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)
-        return self.fc(gru_output.reshape(bs, -1))
+            self.last_adjacency = self.adjacency(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._named()):
+            return _Function.apply(self, x, *self._named())
+        return self._forward(x).clone().view(-1, 1)

@@ -485,6 +485,19 @@ int rulgnn_stgnn_cheb_forward_f32(const rulgnn_stgnn_shape *shape, const float *
 int rulgnn_stgnn_cheb_backward_f32(const rulgnn_stgnn_shape *shape, const float *terms, const float *dout, float *dfilters,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* The whole model on one flat parameter buffer -- chebnet.filters [K, patch_size, H] | gru.weight_ih_l0 [3H, H] |
+ * gru.weight_hh_l0 [3H, H] | gru.bias_ih_l0 [3H] | gru.bias_hh_l0 [3H] | fc.weight [num_nodes*num_patch*H] | fc.bias [1]
+ * (the reference's state_dict order, Model.py:69-72).  The argument struct is STMSGCN's (rulgnn_stmsgcn_args: same fields,
+ * same meaning; x is [batch, num_nodes, num_patch*patch_size]).  forward = STGNN_model.forward (Model.py:75-107);
+ * backward needs the workspace of the forward of the same batch; fwdbwd = STGNN.update up to and, with opt, including
+ * optimizer.step() (algorithms.py:399-408). */
+int64_t rulgnn_stgnn_param_count(const rulgnn_stgnn_shape *shape);          /* < 0: invalid / unsupported */
+size_t rulgnn_stgnn_step_workspace_bytes(const rulgnn_stgnn_shape *shape);  /* 0: invalid / unsupported */
+int rulgnn_stgnn_forward_f32(const rulgnn_stgnn_shape *shape, const rulgnn_stmsgcn_args *args, void *stream);
+int rulgnn_stgnn_backward_f32(const rulgnn_stgnn_shape *shape, const rulgnn_stmsgcn_args *args, void *stream);
+int rulgnn_stgnn_fwdbwd_f32(const rulgnn_stgnn_shape *shape, const rulgnn_stmsgcn_args *args, const rulgnn_adam_args *opt,
+                            void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * One-layer GRU over many short sequences -- nn.GRU(input_dim, hidden_dim, batch_first=True), h0 = 0, gate order (r, z, n);
  * STGNN's recurrent part (models/STGNN/Model.py:71,97-98: batch*nodes sequences of num_patch steps).

@@ -419,46 +419,50 @@ def test_stconv_data_parallel_step_world2_gloo():
     assert np.allclose(out[0]["moments"][4 * CN:5 * CN], fw.bnc.mean, rtol=1e-5, atol=1e-6)
 
 
-# ---- STGNN: autograd path (HIP graph function + HIP GRU), gradient bucket assembled from the parameters' .grad ----
+# ---- STGNN: no BatchNorm, no dropout -- the plain [gradient | loss] bucket, through the Algorithm class ----
+from oracle import stgnn_oracle as GO   # noqa: E402
+
 SG_CFG = dict(patch_size=6, num_patch=3, num_nodes=5, hidden_dim=8, K=3, top_k=3)
 
 
-class StgnnTorchDouble(torch.nn.Module):
-    """CPU stand-in with STGNN_model's parameters and function (plain torch ops), so that STGNN.update's data-parallel branch
-    can run without a GPU: same state_dict keys, same forward(x) -> [bs, 1]."""
+class StgnnOracleModel:
+    """Duck-types the slice of STGNN_model that STGNN.update / dp.DataParallel touch (oracle-backed: the HIP path needs a GPU)."""
 
-    def __init__(self, cfg):
-        super().__init__()
-        from gnn_rul_benchmarking_amd.stgnn import ChebNet
-        self.cfg = cfg
-        self.chebnet = ChebNet(cfg["patch_size"], cfg["hidden_dim"], cfg["K"])
-        self.gru = torch.nn.GRU(cfg["hidden_dim"], cfg["hidden_dim"], batch_first=True)
-        self.fc = torch.nn.Linear(cfg["hidden_dim"] * cfg["num_patch"] * cfg["num_nodes"], 1)
+    def __init__(self, prm):
+        self.prm = {k: np.asarray(v, np.float64) for k, v in prm.items()}
+        self.names = GO.param_names()
+        self.num_live = sum(self.prm[k].size for k in self.names)
+        self.bucket = torch.zeros(self.num_live + 1, dtype=torch.float32)
+        self.flat_params = torch.from_numpy(np.concatenate([self.prm[k].reshape(-1) for k in self.names]).astype(np.float32))
 
-    def forward(self, x):
-        c = self.cfg
-        bs, N, L, f = x.size(0), c["num_nodes"], c["num_patch"], c["patch_size"]
-        xg = x.reshape(bs, N, L, f).transpose(1, 2).reshape(bs * L, N, f)
-        d = torch.cdist(xg, xg)
-        sim = torch.exp(-d ** 2)
-        adj = sim * torch.zeros_like(sim).scatter_(-1, sim.topk(c["top_k"], dim=-1).indices, 1.0)
-        t0, t1 = xg, adj @ xg
-        out = t0 @ self.chebnet.filters[0] + t1 @ self.chebnet.filters[1]
-        for k in range(2, c["K"]):
-            t0, t1 = t1, 2 * (adj @ t1) - t0
-            out = out + t1 @ self.chebnet.filters[k]
-        seq = out.view(bs, L, N, -1).permute(0, 2, 1, 3).reshape(bs * N, L, -1)
-        return self.fc(self.gru(seq)[0].reshape(bs, -1))
+    def _sync(self):
+        o = 0
+        for k in self.names:
+            n = self.prm[k].size
+            self.prm[k] = self.flat_params[o:o + n].numpy().astype(np.float64).reshape(self.prm[k].shape)
+            o += n
+
+    def fused_mse_step(self, X, y, optimizer=None, global_batch=None):
+        self._sync()
+        x, yy = X.numpy().astype(np.float64), y.numpy().astype(np.float64)
+        loss, grads, _, _ = GO.forward_backward(x, yy, self.prm, SG_CFG["num_patch"], SG_CFG["patch_size"], SG_CFG["top_k"])
+        scale = x.shape[0] / float(global_batch if global_batch is not None else x.shape[0])    # the kernels divide by the global batch
+        self.bucket[:self.num_live] = torch.from_numpy((scale * np.concatenate([grads[k].reshape(-1) for k in self.names])).astype(np.float32))
+        self.bucket[self.num_live] = scale * loss
+        return None, self.bucket[self.num_live]
 
 
-def _stgnn_algo():
+def _stgnn_algo(perturb=0.0):
+    """The package's STGNN Algorithm with its model / optimizer swapped for the CPU doubles."""
     from gnn_rul_benchmarking_amd.algorithms import STGNN
     torch.manual_seed(4)
     algo = STGNN(SG_CFG, {"learning_rate": 1e-2, "weight_decay": 1e-4}, "cpu")
-    double = StgnnTorchDouble(SG_CFG)
-    double.load_state_dict(algo.model.state_dict())
-    algo.model = double
-    algo.optimizer = torch.optim.Adam(double.parameters(), lr=1e-2, weight_decay=1e-4)
+    prm = GO.random_params(SG_CFG["num_patch"], SG_CFG["patch_size"], SG_CFG["num_nodes"], SG_CFG["hidden_dim"], SG_CFG["K"], seed=8)
+    double = StgnnOracleModel(prm)
+    double.flat_params += perturb
+    del algo.model                                        # registered sub-module: replace it with the plain-object double
+    object.__setattr__(algo, "model", double)
+    algo.optimizer = SgdFromBucket(double)
     return algo
 
 
@@ -471,16 +475,12 @@ def _stgnn_worker(rank, world, port, B, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        algo = _stgnn_algo()
-        if rank == 1:                                   # replicas start different: attach must broadcast rank 0's weights
-            with torch.no_grad():
-                for p in algo.model.parameters():
-                    p.add_(0.5)
+        algo = _stgnn_algo(perturb=0.5 * rank)            # replicas start different: attach must broadcast rank 0's weights
         algo.attach_data_parallel(DataParallel())
         x, y = _stgnn_batch(B)
         lo, hi = shard_bounds(B, world, rank)
-        losses = [algo.update(x[lo:hi], y[lo:hi], 1, global_batch=B, sample_offset=lo)["loss"] for _ in range(3)]
-        out[rank] = {"losses": losses, "sd": {k: v.clone().numpy() for k, v in algo.model.state_dict().items()}}
+        losses = [float(algo.update(x[lo:hi], y[lo:hi], 1, global_batch=B, sample_offset=lo)["loss"]) for _ in range(3)]
+        out[rank] = {"losses": losses, "flat": algo.model.flat_params.clone().numpy()}
     finally:
         dist.destroy_process_group()
 
@@ -489,10 +489,13 @@ def test_stgnn_data_parallel_steps_equal_single_process_world2_gloo():
     B, world = 9, 2
     out = mp.Manager().dict()
     mp.spawn(_stgnn_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    assert np.array_equal(out[0]["flat"], out[1]["flat"])                  # replicas stay bit-identical
     algo = _stgnn_algo()
     x, y = _stgnn_batch(B)
-    single = [algo.update(x, y, 1)["loss"] for _ in range(3)]
+    single = []
+    for _ in range(3):                                                     # the single-process reference: same double, full batch
+        _, loss = algo.model.fused_mse_step(x, y, global_batch=B)
+        single.append(float(loss))
+        algo.optimizer.step(from_bucket=True)
     assert np.allclose(out[0]["losses"], single, rtol=1e-5) and np.allclose(out[1]["losses"], single, rtol=1e-5)
-    for k, v in algo.model.state_dict().items():
-        assert np.array_equal(out[0]["sd"][k], out[1]["sd"][k]), k                   # replicas stay bit-identical
-        assert np.allclose(out[0]["sd"][k], v.numpy(), rtol=1e-4, atol=1e-6), k      # and follow the single-process run
+    assert np.allclose(out[0]["flat"], algo.model.flat_params.numpy(), rtol=1e-4, atol=1e-6)

@@ -118,3 +118,39 @@ def test_gru_kernels_match_torch_cpu_gru(S, L, I, H):
     assert np.allclose(xg.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-3, atol=1e-5 + 1e-4 * x.grad.abs().max().item())
     for p, r in zip(prm, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)):
         assert np.allclose(p.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-3, atol=1e-5 + 2e-4 * r.grad.abs().max().item())
+
+
+def test_fused_step_equals_the_autograd_path_and_follows_the_reference_curve():
+    """STGNN.update (one C call: forward + MSE + backward + Adam) against the reference's literal autograd sequence through the
+    same kernels, and both against the reference's recorded losses."""
+    z = np.load(os.path.join(GOLD, "stgnn_train_curve_1x50_bs16.npz"))
+    cfg = {k[4:]: int(z[k]) for k in z.files if k.startswith("cfg:")}
+    hp = {"learning_rate": float(z["lr"]), "weight_decay": float(z["wd"])}
+    xs, ys = torch.from_numpy(z["xs"]).to(DEV), torch.from_numpy(z["ys"]).to(DEV)
+    runs = []
+    for style in ("fused", "autograd"):
+        torch.manual_seed(int(z["seed"]))
+        algo = get_algorithm_class("STGNN")(cfg, hp, DEV)
+        algo.to(DEV).train()
+        step = algo.update if style == "fused" else algo.update_reference_style
+        losses = [step(xs[s], ys[s], 1)["loss"] for s in range(8)]
+        runs.append((losses, {k: v.clone() for k, v in algo.state_dict().items()}))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-5)
+    assert np.allclose(runs[0][0], z["losses"][:8], rtol=2e-3)
+    for k in runs[0][1]:
+        assert torch.allclose(runs[0][1][k], runs[1][1][k], rtol=1e-4, atol=1e-6), k
+
+
+def test_separate_forward_and_backward_calls_and_ragged_global_batch():
+    cfg = dict(patch_size=10, num_patch=5, num_nodes=20, hidden_dim=64, K=3, top_k=10)
+    torch.manual_seed(1)
+    m = STGNN_model(**cfg).to(DEV)
+    x, y = torch.rand(7, 20, 50, device=DEV) * 2 - 1, torch.rand(7, 1, device=DEV)
+    # autograd: forward call, then backward call with d loss / d pred
+    pred = m(x)
+    (((pred - y) ** 2).sum() / 11.0).backward()
+    g_auto = torch.cat([p.grad.reshape(-1) for _, p in m._named_live()])
+    # fused: the kernels divide by global_batch themselves
+    _, loss = m.fused_mse_step(x, y, global_batch=11)
+    assert torch.allclose(m.bucket[:m.num_live], g_auto, rtol=1e-4, atol=1e-7)
+    assert abs(float(loss) - float(((pred - y) ** 2).sum() / 11.0)) < 1e-5 * float(loss)
