@@ -189,8 +189,19 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
         if (live) {                                   // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate
             float a = 0.f;
             const float* dsrc = dgl + p * H;
+            if ((H & 3) == 0) {                                                   // 16-byte LDS reads (p * H floats is a multiple of 16 B)
 #pragma unroll
-            for (int jj = 0; jj < HMAX; ++jj) a = fmaf(dsrc[jj], wt[jj], a);      // wt is zero beyond H; dsrc stays inside dgl
+                for (int jj = 0; jj < HMAX; jj += 4) {                            // wt is zero beyond H; dsrc stays inside dgl
+                    const float4 dv = *reinterpret_cast<const float4*>(dsrc + jj);
+                    a = fmaf(dv.x, wt[jj], a);
+                    a = fmaf(dv.y, wt[jj + 1], a);
+                    a = fmaf(dv.z, wt[jj + 2], a);
+                    a = fmaf(dv.w, wt[jj + 3], a);
+                }
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < HMAX; ++jj) a = fmaf(dsrc[jj], wt[jj], a);
+            }
             part[p][k] = a;
         }
         __syncthreads();
