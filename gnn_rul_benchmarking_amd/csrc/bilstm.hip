@@ -167,15 +167,24 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
     // opposite to the forward order of this direction
     int64_t t = dir ? 0 : g.T - 1;
     const int64_t dt = dir ? 1 : -1;
+    // The tape of a step (gates, cell states, incoming gradient) does not depend on the recurrence: it is fetched one step
+    // ahead, so that a step does not start with a global-memory round trip.
+    float n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_ct = 0.f, n_cp = 0.f, n_do = 0.f;
+    auto fetch = [&](int64_t tt) {
+        const float* gr = gates + (base + tt) * H4;
+        n_ig = gr[tid]; n_fg = gr[H + tid]; n_gg = gr[2 * H + tid]; n_og = gr[3 * H + tid];
+        n_ct = cseq[(base + tt) * H + tid];
+        // cell state entering step tt: the forward visited tt - dt_fwd before tt, i.e. tt + dt in this loop's direction
+        const bool first = dir ? (tt == g.T - 1) : (tt == 0);
+        n_cp = first ? 0.f : cseq[(base + tt + dt) * H + tid];
+        n_do = dout[(obase + tt) * H + tid];
+    };
+    if (tid < H && g.T > 0) fetch(t);
     for (int64_t s = 0; s < g.T; ++s, t += dt) {
         if (tid < H) {
-            const float* gr = gates + (base + t) * H4;
-            const float ig = gr[tid], fg = gr[H + tid], gg = gr[2 * H + tid], og = gr[3 * H + tid];
-            const float ct = cseq[(base + t) * H + tid];
-            // cell state entering step t: the forward visited t - dt_fwd before t, i.e. t + dt in this loop's direction
-            const bool first = dir ? (t == g.T - 1) : (t == 0);
-            const float cp = first ? 0.f : cseq[(base + t + dt) * H + tid];
-            const float dht = dout[(obase + t) * H + tid] + dh;
+            const float ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, ct = n_ct, cp = n_cp;
+            const float dht = n_do + dh;
+            if (s + 1 < g.T) fetch(t + dt);
             const float tc = tanh_gate(ct);
             const float dct = fmaf(dht * og, 1.0f - tc * tc, dc);
             const float di = dct * gg * ig * (1.0f - ig), df = dct * cp * fg * (1.0f - fg);
