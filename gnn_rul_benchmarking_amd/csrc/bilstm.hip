@@ -179,17 +179,28 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
         n_cp = first ? 0.f : cseq[(base + tt + dt) * H + tid];
         n_do = dout[(obase + tt) * H + tid];
     };
-    if (tid < H && g.T > 0) fetch(t);
+    // ... and everything of a step that does not involve dh / dc is folded into six coefficients while the tape is in
+    // registers, off the recurrence's critical path (they are prepared behind the matvec of the step before):
+    //   dct = dht * k_c + dc;  (di, df, dg) = dct * (k_i, k_f, k_g);  do = dht * k_o;  dc' = dct * k_fg
+    float k_c = 0.f, k_i = 0.f, k_f = 0.f, k_g = 0.f, k_o = 0.f, k_fg = 0.f, k_do = 0.f;
+    auto prepare = [&]() {
+        const float tc = tanh_gate(n_ct);
+        k_c = n_og * (1.0f - tc * tc);
+        k_i = n_gg * n_ig * (1.0f - n_ig);
+        k_f = n_cp * n_fg * (1.0f - n_fg);
+        k_g = n_ig * (1.0f - n_gg * n_gg);
+        k_o = tc * n_og * (1.0f - n_og);
+        k_fg = n_fg;
+        k_do = n_do;
+    };
+    if (tid < H && g.T > 0) { fetch(t); prepare(); }
     for (int64_t s = 0; s < g.T; ++s, t += dt) {
         if (tid < H) {
-            const float ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, ct = n_ct, cp = n_cp;
-            const float dht = n_do + dh;
+            const float dht = k_do + dh;
+            const float dct = fmaf(dht, k_c, dc);
+            const float di = dct * k_i, df = dct * k_f, dg = dct * k_g, dov = dht * k_o;
+            dc = dct * k_fg;
             if (s + 1 < g.T) fetch(t + dt);
-            const float tc = tanh_gate(ct);
-            const float dct = fmaf(dht * og, 1.0f - tc * tc, dc);
-            const float di = dct * gg * ig * (1.0f - ig), df = dct * cp * fg * (1.0f - fg);
-            const float dg = dct * ig * (1.0f - gg * gg), dov = dht * tc * og * (1.0f - og);
-            dc = dct * fg;
             dgl[tid] = di; dgl[H + tid] = df; dgl[2 * H + tid] = dg; dgl[3 * H + tid] = dov;
             float* dr = dgates + (base + t) * H4;
             dr[tid] = di; dr[H + tid] = df; dr[2 * H + tid] = dg; dr[3 * H + tid] = dov;
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
             }
             part[p][k] = a;
         }
+        if (tid < H && s + 1 < g.T) prepare();        // the next step's coefficients (its tape was requested at the top of this step)
         __syncthreads();
         if (tid < H) dh = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     }
