@@ -38,6 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // primitives; correctness path for the reference-wired PHM2012 40x64 shape).
 constexpr int TT_STRIDE = 68;               // LDS row stride of the [channel][lane] transpose tile
 constexpr int TT_ROWS = 30;
+constexpr int CONVT_FLOATS = F * 2 * F;     // one transposed conv weight block in LDS (multiple of 4 floats)
 constexpr int BNC = 7;                      // per-BatchNorm constants: mean, istd, scale, shift, gamma*istd, k1, k2
 
 enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
@@ -50,6 +51,9 @@ enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
 #endif
 #ifndef PHASE_ALTERNATE
 #define PHASE_ALTERNATE true
+#endif
+#ifndef LDS_CONVT
+#define LDS_CONVT true
 #endif
 #ifndef FRESH_G1
 #define FRESH_G1 true
@@ -154,6 +158,41 @@ __device__ __forceinline__ void causal_conv_T(const float (&dz)[F], WP w, int t,
         }
         dh[ci] = acc;
     }
+}
+
+// The same with the weights in LDS as [ci][co][tap]: the 20 weights of one input channel are fetched by one inline-asm batch
+// of five uniform-address ds_read_b128 + one wait.  Written as asm on purpose: as plain loads the compiler lifts all 50
+// loop-invariant reads out of the persistent tile loop (+200 live VGPRs -> scratch spills, profiles/r01_ubench_gfx950.md).
+template <int RW, int D>
+__device__ __forceinline__ void causal_conv_T_lds(const float (&dz)[F], const float* wT, int t, float (&dh)[F]) {
+    static_assert(F == 10, "five 16-byte reads per input channel");
+    float dzs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) dzs[c] = Row<RW>::template shl<D>(dz[c], t);
+    const uint32_t base = (uint32_t)(uintptr_t)wT;        // LDS byte address (low 32 bits of the shared-window pointer)
+    float chain = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < F; ++ci) {
+        f32x4 w0, w1, w2, w3, w4;
+        const uint32_t addr = base + ci * 2 * F * 4;
+        asm volatile("ds_read_b128 %[w0], %[ad]\n\t"
+                     "ds_read_b128 %[w1], %[ad] offset:16\n\t"
+                     "ds_read_b128 %[w2], %[ad] offset:32\n\t"
+                     "ds_read_b128 %[w3], %[ad] offset:48\n\t"
+                     "ds_read_b128 %[w4], %[ad] offset:64\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [ch] "+v"(chain)
+                     : [ad] "v"(addr));             // `chain` = the previous channel's result: keeps the batches from bunching up
+        float acc = 0.f;
+        acc = fmaf(w0[0], dzs[0], acc); acc = fmaf(w0[1], dz[0], acc); acc = fmaf(w0[2], dzs[1], acc); acc = fmaf(w0[3], dz[1], acc);
+        acc = fmaf(w1[0], dzs[2], acc); acc = fmaf(w1[1], dz[2], acc); acc = fmaf(w1[2], dzs[3], acc); acc = fmaf(w1[3], dz[3], acc);
+        acc = fmaf(w2[0], dzs[4], acc); acc = fmaf(w2[1], dz[4], acc); acc = fmaf(w2[2], dzs[5], acc); acc = fmaf(w2[3], dz[5], acc);
+        acc = fmaf(w3[0], dzs[6], acc); acc = fmaf(w3[1], dz[6], acc); acc = fmaf(w3[2], dzs[7], acc); acc = fmaf(w3[3], dz[7], acc);
+        acc = fmaf(w4[0], dzs[8], acc); acc = fmaf(w4[1], dz[8], acc); acc = fmaf(w4[2], dzs[9], acc); acc = fmaf(w4[3], dz[9], acc);
+        dh[ci] = acc;
+        chain = acc;
+    }
+    dh[F - 1] = chain;
 }
 
 // In-wave LDS transpose + MFMA: acc0/acc1 += dz (10 x 64 lanes) . [h | hs]^T (64 lanes x 20).
@@ -285,7 +324,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     constexpr int RED_K = 15 + (RW == 16 ? 0 : 4 * NTH);
     float* red = bnc + ((NBN * BNC * F + 3) & ~3);        // [RED_K][64] block reduction of the gradient accumulators
     float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
-    float* wave_area = redp + WAVES_PER_BLOCK * 24;       // per-wave: staging (F_0) or transpose tile (TOP / G)
+    float* convT = redp + WAVES_PER_BLOCK * 24;           // [F][2F] conv_block1 weights of layer LY as [ci][co][tap] (G_{2l} only)
+    float* wave_area = convT + CONVT_FLOATS;              // per-wave: staging (F_0) or transpose tile (TOP / G)
     const int wave_area_floats = a.wave_area_floats;
     float* mywave = wave_area + wave * wave_area_floats;
 
@@ -306,6 +346,13 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         const int m = i / TRW, j = i % TRW;
         const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
         vecs[i] = j < N ? src[j] : 0.f;
+    }
+    if constexpr (LDS_CONVT && KIND == PH_G && (IDX % 2) == 0) {     // the transposed convolution of G_{2l} reads its weights from LDS
+        const float* cw = prm + (IDX / 2) * LS + off_conv_w(N, 0);
+        for (int i = threadIdx.x; i < F * F * 2; i += BLOCK) {
+            const int tap = i & 1, ci = (i >> 1) % F, co = (i >> 1) / F;
+            convT[ci * 2 * F + co * 2 + tap] = cw[i];
+        }
     }
     for (int i = threadIdx.x; i < CS; i += BLOCK) cellsum[i] = cell_sum(a.cells, L, i);
     __syncthreads();
@@ -515,7 +562,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 conv_wgrad_mfma(mywave, dz, H, hs, lane, acc_c0, acc_c1);
             }
             float dH[F];
-            causal_conv_T<RW, 1>(dz, conv_weights<FRESH_G0, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
+            if constexpr (LDS_CONVT) causal_conv_T_lds<RW, 1>(dz, convT, t, dH);
+            else causal_conv_T<RW, 1>(dz, conv_weights<FRESH_G0, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float g = dH[c] + g0[c];
@@ -966,7 +1014,7 @@ static int wave_area_for(int kind, int idx, const TileGeom& g) {
 static size_t train_lds_bytes(int RW, int L, int wave_area) {
     const int tws = RW + 4, nth = RW == 16 ? 0 : (RW / 16) * (RW / 16);
     const size_t fl = (size_t)2 * cell_stride(L) + (size_t)3 * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
-                      (size_t)(15 + 4 * nth) * 64 + (size_t)WAVES_PER_BLOCK * 24 + (size_t)WAVES_PER_BLOCK * wave_area;
+                      (size_t)(15 + 4 * nth) * 64 + (size_t)WAVES_PER_BLOCK * 24 + CONVT_FLOATS + (size_t)WAVES_PER_BLOCK * wave_area;
     return fl * sizeof(float);
 }
 
