@@ -335,6 +335,50 @@ __device__ __forceinline__ void causal_conv(const float (&h)[F], WP w, int t, fl
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Convolution rows with the weights in LDS: out[r] = sum_q w[r][2q] * sh[q] + w[r][2q + 1] * pl[q], 20 weights per row.
+//   forward conv (block's natural layout [co][ci][tap]):  r = co, sh = input shifted right by the dilation, pl = input;
+//   transposed conv (layout [ci][co][tap], built in the prologue): r = ci, sh = dz shifted left, pl = dz.
+// The 20 weights of a row arrive through one inline-asm batch of five uniform-address ds_read_b128 + one wait, chained on the
+// previous row's result.  Asm on purpose: as plain loads the compiler lifts all 50 loop-invariant reads out of the persistent
+// tile loop (+200 live VGPRs -> scratch), and unchained batches bunch up with the same effect (profiles/r01_ubench_gfx950.md).
+// Versus scalar-operand weights: no SGPR pressure (a third of the G_{2l} tile loop was v_readlane / v_writelane spill traffic)
+// and VGPR-operand FMAs issue at twice the rate of SGPR-operand ones.
+__device__ __forceinline__ void conv_rows_lds(const float (&sh)[F], const float (&pl)[F], const float* wl, float (&out)[F]) {
+    static_assert(F == 10, "five 16-byte reads per row");
+    const uint32_t base = (uint32_t)(uintptr_t)wl;        // LDS byte address (low 32 bits of the shared-window pointer)
+    float chain = 0.f;
+#pragma unroll
+    for (int r = 0; r < F; ++r) {
+        f32x4 w0, w1, w2, w3, w4;
+        const uint32_t addr = base + r * 2 * F * 4;
+        asm volatile("ds_read_b128 %[w0], %[ad]\n\t"
+                     "ds_read_b128 %[w1], %[ad] offset:16\n\t"
+                     "ds_read_b128 %[w2], %[ad] offset:32\n\t"
+                     "ds_read_b128 %[w3], %[ad] offset:48\n\t"
+                     "ds_read_b128 %[w4], %[ad] offset:64\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [ch] "+v"(chain)
+                     : [ad] "v"(addr));
+        float acc = 0.f;
+        acc = fmaf(w0[0], sh[0], acc); acc = fmaf(w0[1], pl[0], acc); acc = fmaf(w0[2], sh[1], acc); acc = fmaf(w0[3], pl[1], acc);
+        acc = fmaf(w1[0], sh[2], acc); acc = fmaf(w1[1], pl[2], acc); acc = fmaf(w1[2], sh[3], acc); acc = fmaf(w1[3], pl[3], acc);
+        acc = fmaf(w2[0], sh[4], acc); acc = fmaf(w2[1], pl[4], acc); acc = fmaf(w2[2], sh[5], acc); acc = fmaf(w2[3], pl[5], acc);
+        acc = fmaf(w3[0], sh[6], acc); acc = fmaf(w3[1], pl[6], acc); acc = fmaf(w3[2], sh[7], acc); acc = fmaf(w3[3], pl[7], acc);
+        acc = fmaf(w4[0], sh[8], acc); acc = fmaf(w4[1], pl[8], acc); acc = fmaf(w4[2], sh[9], acc); acc = fmaf(w4[3], pl[9], acc);
+        out[r] = acc;
+        chain = acc;
+    }
+    out[F - 1] = chain;
+}
+template <int RW, int D>
+__device__ __forceinline__ void causal_conv_lds(const float (&h)[F], const float* wl, int t, float (&z)[F]) {
+    float hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) hs[c] = Row<RW>::template shr<D>(h[c], t);
+    conv_rows_lds(hs, h, wl, z);
+}
 // ---------------------------------------------------------------------------------------------
 // 4-block MFMA building blocks (row width 16 only).
 //

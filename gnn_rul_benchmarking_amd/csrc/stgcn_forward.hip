@@ -3,6 +3,9 @@
 // (~90 ATen dispatches per call in the reference; here x is read once from HBM and 4 bytes per
 // sample are written back).
 #include "stgcn_device.hpp"
+#ifndef EVAL_LDS_CONV
+#define EVAL_LDS_CONV false   // measured: 93-94 us vs 87-88 us with scalar-operand weights (batch 65536): the eval kernel has no spill problem
+#endif
 #include "stgcn_host.hpp"
 
 #ifndef RULGNN_ABLATE
@@ -34,7 +37,8 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     float* wlds = smem;                          // [L+1][RW][WS] theta rows per layer, then fc1 rows
     float* bnf = wlds + (L + 1) * RW * WS;       // [L][2][2][F]   folded BatchNorm scale / shift
     float* vecs = bnf + L * 4 * F;               // [L+2][RW]      theta bias per layer, fc1 bias, fc2 weight
-    float* stage_all = vecs + (L + 2) * RW;
+    float* convw = vecs + (L + 2) * RW;          // [L][2][F][2F]  conv weights as stored ([co][ci][tap])
+    float* stage_all = convw + (EVAL_LDS_CONV ? L * 2 * F * F * 2 : 0);
 
     // ---- block prologue: weights that vary per lane go to LDS, zero padded to the row width ----
     for (int i = threadIdx.x; i < (L + 1) * RW * RW; i += BLOCK) {
@@ -46,6 +50,12 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
         const int m = i / RW, j = i % RW;
         const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
         vecs[i] = j < N ? src[j] : 0.f;
+    }
+    if constexpr (EVAL_LDS_CONV) {
+        for (int i = threadIdx.x; i < L * 2 * F * F * 2; i += BLOCK) {
+            const int l = i / (2 * F * F * 2), r = i % (2 * F * F * 2);
+            convw[i] = prm[l * LS + off_conv_w(N, r / (F * F * 2)) + r % (F * F * 2)];
+        }
     }
     for (int i = threadIdx.x; i < L * 2 * F; i += BLOCK) {
         const int l = i / (2 * F), blk = (i / F) % 2, c = i % F;
@@ -121,7 +131,8 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
 #pragma unroll
                 for (int c = 0; c < F; ++c) z[c] = H[c] * lp[off_conv_w(N, 0) + c];
             } else {
-                causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);         // conv_block1, Model.py:134-146
+                if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 1>(H, convw + (l * 2 + 0) * F * F * 2, t, z);
+                else causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);         // conv_block1, Model.py:134-146
             }
 #pragma unroll
             for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z[c], bl[c], bl[F + c])) + H[c]);
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
 #pragma unroll
                 for (int c = 0; c < F; ++c) z[c] = o0[c] * lp[off_conv_w(N, 1) + c];
             } else {
-                causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);        // conv_block2 (dilation 2), Model.py:148-160
+                if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 2>(o0, convw + (l * 2 + 1) * F * F * 2, t, z);
+                else causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);        // conv_block2 (dilation 2), Model.py:148-160
             }
 #pragma unroll
             for (int c = 0; c < F; ++c) {
@@ -159,6 +171,7 @@ static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const 
     a.stage_floats = g.stage_floats;
     constexpr int WS = wstride<RW>();
     const size_t lds = sizeof(float) * ((size_t)(a.L + 1) * RW * WS + (size_t)a.L * 4 * F + (size_t)(a.L + 2) * RW +
+                                        (EVAL_LDS_CONV ? (size_t)a.L * 2 * F * F * 2 : 0) +
                                         (size_t)WAVES_PER_BLOCK * g.stage_floats);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {

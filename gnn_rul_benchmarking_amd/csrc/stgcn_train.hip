@@ -31,7 +31,6 @@
 
 namespace rulgnn {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Row widths of the training kernels: 16 (num_patch <= 16: four samples per wavefront, DPP + MFMA tricks
 // that rely on 16-lane rows) and 64 (num_patch <= 64: one sample per wavefront, generic cross-lane
@@ -160,39 +159,12 @@ __device__ __forceinline__ void causal_conv_T(const float (&dz)[F], WP w, int t,
     }
 }
 
-// The same with the weights in LDS as [ci][co][tap]: the 20 weights of one input channel are fetched by one inline-asm batch
-// of five uniform-address ds_read_b128 + one wait.  Written as asm on purpose: as plain loads the compiler lifts all 50
-// loop-invariant reads out of the persistent tile loop (+200 live VGPRs -> scratch spills, profiles/r01_ubench_gfx950.md).
 template <int RW, int D>
 __device__ __forceinline__ void causal_conv_T_lds(const float (&dz)[F], const float* wT, int t, float (&dh)[F]) {
-    static_assert(F == 10, "five 16-byte reads per input channel");
     float dzs[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) dzs[c] = Row<RW>::template shl<D>(dz[c], t);
-    const uint32_t base = (uint32_t)(uintptr_t)wT;        // LDS byte address (low 32 bits of the shared-window pointer)
-    float chain = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < F; ++ci) {
-        f32x4 w0, w1, w2, w3, w4;
-        const uint32_t addr = base + ci * 2 * F * 4;
-        asm volatile("ds_read_b128 %[w0], %[ad]\n\t"
-                     "ds_read_b128 %[w1], %[ad] offset:16\n\t"
-                     "ds_read_b128 %[w2], %[ad] offset:32\n\t"
-                     "ds_read_b128 %[w3], %[ad] offset:48\n\t"
-                     "ds_read_b128 %[w4], %[ad] offset:64\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [ch] "+v"(chain)
-                     : [ad] "v"(addr));             // `chain` = the previous channel's result: keeps the batches from bunching up
-        float acc = 0.f;
-        acc = fmaf(w0[0], dzs[0], acc); acc = fmaf(w0[1], dz[0], acc); acc = fmaf(w0[2], dzs[1], acc); acc = fmaf(w0[3], dz[1], acc);
-        acc = fmaf(w1[0], dzs[2], acc); acc = fmaf(w1[1], dz[2], acc); acc = fmaf(w1[2], dzs[3], acc); acc = fmaf(w1[3], dz[3], acc);
-        acc = fmaf(w2[0], dzs[4], acc); acc = fmaf(w2[1], dz[4], acc); acc = fmaf(w2[2], dzs[5], acc); acc = fmaf(w2[3], dz[5], acc);
-        acc = fmaf(w3[0], dzs[6], acc); acc = fmaf(w3[1], dz[6], acc); acc = fmaf(w3[2], dzs[7], acc); acc = fmaf(w3[3], dz[7], acc);
-        acc = fmaf(w4[0], dzs[8], acc); acc = fmaf(w4[1], dz[8], acc); acc = fmaf(w4[2], dzs[9], acc); acc = fmaf(w4[3], dz[9], acc);
-        dh[ci] = acc;
-        chain = acc;
-    }
-    dh[F - 1] = chain;
+    conv_rows_lds(dzs, dz, wT, dh);
 }
 
 // In-wave LDS transpose + MFMA: acc0/acc1 += dz (10 x 64 lanes) . [h | hs]^T (64 lanes x 20).
@@ -306,6 +278,9 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     constexpr bool WITH_PREV = (KIND == PH_F) && (BLK == 0) && (LY >= 1);
     constexpr int LSTART = WITH_PREV ? LY - 1 : LY;
     using SV = SavedSlot<L>;
+    // where the LDS weights pay (measured per phase, batch 65536): G_{2l} (86 -> 64 us, 46 -> 40 us: the scalar path spilled),
+    // F_{2l+1} (29 -> 28 us); G_{2l+1} and F_{2l} are 1-2 us better on scalar-operand weights
+    constexpr bool CONV_FROM_LDS = LDS_CONVT && ((KIND == PH_G && IDX % 2 == 0) || (KIND == PH_F && IDX % 2 == 1));
     // what this phase reads besides the saved activations: the layer input (F_{2l}: aggregation, G_{2l}: theta gradient,
     // TOP: last residual) and the adjacency (F_{2l}, G_{2l})
     constexpr bool NEED_A = KIND != PH_TOP && BLK == 0;
@@ -347,11 +322,11 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
         vecs[i] = j < N ? src[j] : 0.f;
     }
-    if constexpr (LDS_CONVT && KIND == PH_G && (IDX % 2) == 0) {     // the transposed convolution of G_{2l} reads its weights from LDS
-        const float* cw = prm + (IDX / 2) * LS + off_conv_w(N, 0);
+    if constexpr (CONV_FROM_LDS) {                        // this phase's ONE convolution reads its weights from LDS
+        const float* cw = prm + (IDX / 2) * LS + off_conv_w(N, IDX % 2);
         for (int i = threadIdx.x; i < F * F * 2; i += BLOCK) {
             const int tap = i & 1, ci = (i >> 1) % F, co = (i >> 1) / F;
-            convT[ci * 2 * F + co * 2 + tap] = cw[i];
+            convT[KIND == PH_G ? ci * 2 * F + co * 2 + tap : i] = cw[i];      // backward: [ci][co][tap]; forward: as stored
         }
     }
     for (int i = threadIdx.x; i < CS; i += BLOCK) cellsum[i] = cell_sum(a.cells, L, i);
@@ -525,7 +500,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
             R16::project10(H, AX, w_cur + t * TWS, N);
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
-            causal_conv<TRW, 1>(H, conv_weights<true, 5>(lp + off_conv_w(N, 0), (int)tile), t, z1);
+            if constexpr (CONV_FROM_LDS) causal_conv_lds<TRW, 1>(H, convT, t, z1);
+            else causal_conv<TRW, 1>(H, conv_weights<true, 5>(lp + off_conv_w(N, 0), (int)tile), t, z1);
             store_tile(slot(SV::H(LY)), H);
             store_tile(slot(SV::Z1(LY)), z1);
 #pragma unroll
@@ -562,7 +538,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 conv_wgrad_mfma(mywave, dz, H, hs, lane, acc_c0, acc_c1);
             }
             float dH[F];
-            if constexpr (LDS_CONVT) causal_conv_T_lds<RW, 1>(dz, convT, t, dH);
+            if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 1>(dz, convT, t, dH);
             else causal_conv_T<RW, 1>(dz, conv_weights<FRESH_G0, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
@@ -608,7 +584,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         if constexpr (KIND == PH_F && BLK == 1) {       // F_{2l+1}: conv_block2 and its statistics
 #pragma unroll
             for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
-            causal_conv<TRW, 2>(o0, conv_weights<true, 6>(lp + off_conv_w(N, 1), (int)tile), t, z2);
+            if constexpr (CONV_FROM_LDS) causal_conv_lds<TRW, 2>(o0, convT, t, z2);
+            else causal_conv<TRW, 2>(o0, conv_weights<true, 6>(lp + off_conv_w(N, 1), (int)tile), t, z2);
             store_tile(slot(SV::O0(LY)), o0);
             store_tile(slot(SV::Z2(LY)), z2);
 #pragma unroll
@@ -720,7 +697,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 conv_wgrad_mfma(mywave, dz, o0, hs, lane, acc_c0, acc_c1);
             }
             float d_o0[F];
-            causal_conv_T<RW, 2>(dz, conv_weights<FRESH_G1, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
+            if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 2>(dz, convT, t, d_o0);
+            else causal_conv_T<RW, 2>(dz, conv_weights<FRESH_G1, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
             float sbv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
