@@ -94,7 +94,7 @@ def measured_traffic(kernel_key, N, P, B):
     """HBM bytes per launch from the committed PMC summary (profiles/r01_hbm_traffic.json), scaled to this
     batch; None when the profiled workload does not match."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_f_hbm_traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")))
         w = t["workload"]
         if (w["num_patch"], w["patch_size"]) != (N, P) or kernel_key not in t["kernels"]:
             return None
