@@ -23,7 +23,9 @@ struct FwdArgs {
     int stage_floats;   // per-wave LDS staging floats
 };
 
-template <int RW>
+// NFIX / PFIX / LFIX: num_patch, patch_size, num_layers known at compile time (0 = from the arguments): the C-MAPSS shapes
+// (14 sensors x 30 or 50 points, two layers) get immediate offsets, fully unrolled statistics passes and a flat layer loop.
+template <int RW, int NFIX = 0, int PFIX = 0, int LFIX = 0>
 __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* __restrict__ gx,
                                                                    const float* __restrict__ prm,
                                                                    const float* __restrict__ bn,
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WS = wstride<RW>();
     constexpr int SPW = Row<RW>::SPW;
-    const int N = a.N, L = a.L, LS = layer_stride(N);
+    const int N = NFIX ? NFIX : a.N, L = LFIX ? LFIX : a.L, P = PFIX ? PFIX : a.P, LS = layer_stride(N);
     float* wlds = smem;                          // [L+1][RW][WS] theta rows per layer, then fc1 rows
     float* bnf = wlds + (L + 1) * RW * WS;       // [L][2][2][F]   folded BatchNorm scale / shift
     float* vecs = bnf + L * 4 * F;               // [L+2][RW]      theta bias per layer, fc1 bias, fc2 weight
@@ -72,14 +74,14 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     const int srow = lane / RW, t = lane % RW;
     float* stage = stage_all + wave * a.stage_floats;
     const float fc2_b = prm[off_fc2_b(N, L)];
-    const int64_t sampleNP = (int64_t)N * a.P;
+    const int64_t sampleNP = (int64_t)N * P;
 
     for (int64_t tile = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; tile < a.ntiles;
          tile += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int64_t s0 = tile * SPW;
         const int ns = (int)((a.B - s0) < SPW ? (a.B - s0) : SPW);
         __builtin_amdgcn_wave_barrier();
-        stage_tile(gx + s0 * sampleNP, stage, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
+        stage_tile(gx + s0 * sampleNP, stage, ns * (int)sampleNP, P, a.Ppad, a.magicP, a.vec4, lane);
         __builtin_amdgcn_wave_barrier();
 
         const bool valid = (srow < ns) && (t < N);
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = valid ? stage[(srow * N + t) * a.Ppad + c] + 0.1f * c : 0.f;
         } else {
-            if (valid) patch_statistics(stage + (srow * N + t) * a.Ppad, a.P, X);
+            if (valid) patch_statistics(stage + (srow * N + t) * a.Ppad, P, X);
         }
 
         constexpr int NA = RW == 16 ? F : NPAIR;      // RW 16: lane-distributed adjacency rows (MFMA path)
@@ -162,8 +164,8 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     }
 }
 
-template <int RW>
-static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
+template <int RW, int NFIX, int PFIX, int LFIX>
+static int launch_forward_fix(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
                           const float* bn, float* out, hipStream_t stream) {
     FwdArgs a;
     a.B = s->batch; a.ntiles = g.ntiles; a.N = s->num_patch; a.P = s->patch_size; a.Ppad = g.Ppad; a.L = s->num_layers;
@@ -175,14 +177,24 @@ static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const 
                                         (size_t)WAVES_PER_BLOCK * g.stage_floats);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stgcn_forward_eval_kernel<RW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stgcn_forward_eval_kernel<RW, NFIX, PFIX, LFIX>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RULGNN_EHIP;
     }
-    const int grid = persistent_grid(stgcn_forward_eval_kernel<RW>, g.ntiles, lds, 4);
+    const int grid = persistent_grid(stgcn_forward_eval_kernel<RW, NFIX, PFIX, LFIX>, g.ntiles, lds, 4);
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
-    hipLaunchKernelGGL(stgcn_forward_eval_kernel<RW>, dim3(grid), dim3(BLOCK), lds, stream, x, prm, bn, out, a);
+    hipLaunchKernelGGL((stgcn_forward_eval_kernel<RW, NFIX, PFIX, LFIX>), dim3(grid), dim3(BLOCK), lds, stream, x, prm, bn, out, a);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+template <int RW>
+static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
+                          const float* bn, float* out, hipStream_t stream) {
+    if constexpr (RW == 16) {
+        if (s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 30) return launch_forward_fix<RW, 14, 30, 2>(g, s, x, prm, bn, out, stream);
+        if (s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 50) return launch_forward_fix<RW, 14, 50, 2>(g, s, x, prm, bn, out, stream);
+    }
+    return launch_forward_fix<RW, 0, 0, 0>(g, s, x, prm, bn, out, stream);
 }
 
 int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,

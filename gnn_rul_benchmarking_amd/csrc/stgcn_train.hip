@@ -248,7 +248,7 @@ constexpr int phase_min_waves(int RW, int KIND, int IDX) {
 // NFIX: num_patch known at compile time (14 = C-MAPSS, the headline shape; 0 = read it from the arguments).  With a constant
 // pitch the 10 element addresses of a saved tensor become immediate offsets of one base: ~60 64-bit address computations per
 // tile and the scalar registers that carried them disappear.
-template <int RW, int L, int KIND, int IDX, int NFIX = 0>
+template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0>
 __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy,   // y or dpred (TOP only)
@@ -373,7 +373,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     float acc_b = 0.f, acc_w2 = 0.f, acc_b2 = 0.f, acc_loss = 0.f;         // theta/fc1 bias, fc2 weight, fc2 bias, loss
 
     const float fc2_b = prm[off_fc2_b(N, L)];
-    const int64_t sampleNP = (int64_t)N * a.P;
+    const int P = PFIX ? PFIX : a.P;                      // compile-time window length: the F_0 statistics passes unroll fully
+    const int64_t sampleNP = (int64_t)N * P;
     const float inv_gb = 1.0f / (float)a.global_batch;
 
     // Saved tensors are packed: of each RW-lane row only the N patch lanes are stored (element (c, sample row, patch t) of a
@@ -417,11 +418,11 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
         // ---- inputs: patch statistics + Pearson adjacency (F_0 computes and caches), or the saved X_l ----
         if constexpr (KIND == PH_F && IDX == 0) {
             __builtin_amdgcn_wave_barrier();
-            stage_tile(gx + s0 * sampleNP, mywave, ns * (int)sampleNP, a.P, a.Ppad, a.magicP, a.vec4, lane);
+            stage_tile(gx + s0 * sampleNP, mywave, ns * (int)sampleNP, P, a.Ppad, a.magicP, a.vec4, lane);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = 0.f;
-            if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, a.P, X);
+            if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, P, X);
             if constexpr (RW == 16) {
                 pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
                 float* ca = a.cacheA + tile * (size_t)(F * pitch_a) + loff_a;
@@ -996,10 +997,10 @@ static size_t train_lds_bytes(int RW, int L, int wave_area) {
     return fl * sizeof(float);
 }
 
-template <int RW, int L, int KIND, int IDX, int NFIX>
+template <int RW, int L, int KIND, int IDX, int NFIX, int PFIX = 0>
 static int launch_phase_n(const TrainK& k_in, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                           hipStream_t stream, int* grid_out) {
-    auto kern = stgcn_train_phase_kernel<RW, L, KIND, IDX, NFIX>;
+    auto kern = stgcn_train_phase_kernel<RW, L, KIND, IDX, NFIX, PFIX>;
     TrainK k = k_in;
     k.wave_area_floats = wave_area_for(KIND, IDX, g);
     const size_t lds = train_lds_bytes(RW, L, k.wave_area_floats);
@@ -1021,6 +1022,10 @@ template <int RW, int L, int KIND, int IDX>
 static int launch_phase(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                         hipStream_t stream, int* grid_out) {
     if constexpr (RW == 16 && L == 2) {
+        if constexpr (KIND == PH_F && IDX == 0) {          // the only phase that reads the windows
+            if (k.N == 14 && k.P == 30) return launch_phase_n<RW, L, KIND, IDX, 14, 30>(k, x, prm, gy, g, max_grid, stream, grid_out);
+            if (k.N == 14 && k.P == 50) return launch_phase_n<RW, L, KIND, IDX, 14, 50>(k, x, prm, gy, g, max_grid, stream, grid_out);
+        }
         if (k.N == 14) return launch_phase_n<RW, L, KIND, IDX, 14>(k, x, prm, gy, g, max_grid, stream, grid_out);
     }
     return launch_phase_n<RW, L, KIND, IDX, 0>(k, x, prm, gy, g, max_grid, stream, grid_out);
