@@ -514,11 +514,14 @@ __global__ __launch_bounds__(FB) void fc_bn_chan_bwd_kernel(FcGeom g, int id, in
     }
 }
 
-// graph backward: d adjacency, softmax / leaky backward, d mapping, d normalised features (scatter-added onto the rows)
+// graph backward: d adjacency, softmax / leaky backward, d mapping, d normalised features.  Every graph writes its own
+// [Q, D2] contribution blocks (cX over its dAX block, which it has consumed; cM); fc_graph_gather_kernel adds the <= 2 graphs
+// that contain a row -- no atomics: the first version scatter-added 5.5 M fp32 atomics per step onto the rows (slow, and the
+// summation order of overlapping windows was not reproducible).
 __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
                                                          const float* __restrict__ F, const float* __restrict__ Mm,
-                                                         const float* __restrict__ P, const float* __restrict__ dAX,
-                                                         float* __restrict__ gX, float* __restrict__ gM) {
+                                                         const float* __restrict__ P, float* dAX /* in: d AX, out: cX */,
+                                                         float* __restrict__ cM) {
     __shared__ float mm[MAXQ][MAXD + 1];
     __shared__ float xb[MAXQ][MAXD + 1];
     __shared__ float da[MAXQ][MAXD + 1];
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
             float s = 0.f;
             for (int i = 0; i < Q; ++i)
                 s = fmaf((Pm[i][j] + (i == j ? 1.f : 0.f)) * (((i < N) == (j < N)) ? 1.f : DECAY), da[i][d], s);
-            atomicAdd(&gX[rows[j] * D2 + d], s);
+            dAX[(gi * Q + j) * D2 + d] = s;               // (this graph's dAX block is in LDS since the barrier above)
         }
         __syncthreads();
         if (tid < Q) {                                   // softmax backward per row, then the leaky slope of the pre-activation
@@ -571,9 +574,35 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
             const int i = e / D2, d = e - i * D2;
             float s = 0.f;
             for (int j = 0; j < Q; ++j) s = fmaf(T[i][j] + T[j][i], mm[j][d], s);
-            atomicAdd(&gM[rows[i] * D2 + d], s);
+            cM[(gi * Q + i) * D2 + d] = s;
         }
         __syncthreads();
+    }
+}
+
+// gX[r][d] = sum over the graphs that contain row r = (b, t, n) of their contribution; the same for gM.  Windows hold two
+// consecutive patches (tau = 0, 1) and start every S[blk] patches: row t is node tau*N + n of window w = (t - tau) / S.
+__global__ __launch_bounds__(FB) void fc_graph_gather_kernel(FcGeom g, int blk, const float* __restrict__ cX, const float* __restrict__ cM,
+                                                            float* __restrict__ gX, float* __restrict__ gM) {
+    const int64_t total = g.M * g.D2;
+    const int S = g.S[blk], W = g.W[blk];
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+        const int d = (int)(e % g.D2);
+        const int64_t r = e / g.D2;
+        const int n = (int)(r % g.N), t = (int)((r / g.N) % g.NP);
+        const int64_t b = r / ((int64_t)g.N * g.NP);
+        float ax = 0.f, am = 0.f;
+#pragma unroll
+        for (int tau = 0; tau < 2; ++tau) {
+            const int tt = t - tau;
+            if (tt >= 0 && tt % S == 0 && tt / S < W) {
+                const int64_t src = ((b * W + tt / S) * g.Q + tau * g.N + n) * g.D2 + d;
+                ax += cX[src];
+                am += cM[src];
+            }
+        }
+        gX[e] = ax;
+        gM[e] = am;
     }
 }
 
@@ -1013,11 +1042,12 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, st));
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
             FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st));
-            if (hipMemsetAsync(P_(w.gX[b]), 0, sizeof(float) * g.M * D2, st) != hipSuccess) return RULGNN_EHIP;
-            if (hipMemsetAsync(P_(w.gM[b]), 0, sizeof(float) * g.M * D2, st) != hipSuccess) return RULGNN_EHIP;
+            // AX[b] is free from here on (its last reader was the theta gradient above): it takes the per-graph d mapping blocks
             hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
-                               (const float*)P_(w.dAX[b]), P_(w.gX[b]), P_(w.gM[b]));
+                               P_(w.dAX[b]), P_(w.AX[b]));
+            hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
+                               (const float*)P_(w.AX[b]), P_(w.gX[b]), P_(w.gM[b]));
         }
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));

@@ -105,6 +105,9 @@ def test_autograd_path_equals_fused_path():
     m = build_model(cfg, sd0).train()
     m.fused_mse_step(x, y)
     fused = m.bucket[:m.num_live].clone()
+    m3 = build_model(cfg, sd0).train()                   # no atomics on the data path: the gradient is reproducible bit for bit
+    m3.fused_mse_step(x, y)
+    assert torch.equal(m3.bucket[:m3.num_live], fused)
     m2 = build_model(cfg, sd0).train()
     pred = m2(x)
     torch.nn.functional.mse_loss(pred, y).backward()
