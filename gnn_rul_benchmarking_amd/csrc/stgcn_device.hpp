@@ -9,6 +9,9 @@
 //
 // Math follows reference models/ST_GCN/Model.py (line numbers cited at each block).
 #pragma once
+#ifndef STAGE_NT
+#define STAGE_NT 1   // the windows are read once per step: nontemporal loads (F0 alone 64 -> 60 us)
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -518,7 +521,12 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ g, float* s
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
                     const int i = base + u * 64;
+#if STAGE_NT
+                    const f32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + (i < n4 ? i : n4 - 1));
+                    r[u] = make_float4(nv[0], nv[1], nv[2], nv[3]);
+#else
                     r[u] = g4[i < n4 ? i : n4 - 1];
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
