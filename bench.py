@@ -75,19 +75,21 @@ def phase_bytes_per_sample(name, N, P, L):
     A = the [10, 10] adjacency = 400 B."""
     T = 10 * N * 4
     A = 10 * 10 * 4
+    TOPG = 2 * N * 4                                   # d X_L: (value, arg-max channel) per (sample, patch) instead of ten rows
     if name == "F0":
         return N * P * 4 + 3 * T + A                   # read the window; write X0, adjacency, H, z1
     if name == "TOP":
-        return 4 * T + 8                               # X_{L-1}, o0, z2; write dX_L; y in, pred out
+        return 3 * T + TOPG + 8                        # X_{L-1}, o0, z2; write dX_L; y in, pred out
     i = int(name[1:])
     l, blk = divmod(i, 2)
+    din = TOPG if l == L - 1 else T                    # the gradient entering the top layer is the sparse one
     if name[0] == "F":
         if blk == 1:
             return 4 * T                               # F_{2l+1}: H, z1; write o0, z2
         return 7 * T + A                               # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, x-hat mask, H, z1
     if blk == 1:
-        return 5 * T                                   # G_{2l+1}: z1, o0, z2, dX_{l+1}; write d(x0+H)
-    return (4 * T + A) if l == 0 else (7 * T + A)      # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
+        return 4 * T + din                             # G_{2l+1}: z1, o0, z2, dX_{l+1}; write d(x0+H)
+    return (4 * T + A) if l == 0 else (6 * T + A + din)   # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
 
 
 def measured_traffic(kernel_key, N, P, B):

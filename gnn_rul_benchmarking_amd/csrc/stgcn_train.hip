@@ -397,6 +397,24 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
             for (int c = 0; c < F; ++c) p[c * pitch] = v[c];
         }
     };
+    // d X_L out of TOP is one value per (sample, patch): the max-pool routes the gradient to the arg-max channel.  It travels as
+    // (value, channel) in the first two channel rows of rbuf instead of ten rows, nine of them zero.
+    auto store_top_grad = [&](float* p, float v, int arg) {
+        if (lane_ok) {
+            p[0] = v;
+            p[pitch] = __builtin_bit_cast(float, arg);
+        }
+    };
+    auto load_top_grad = [&](const float* p, float (&v)[F]) {
+        float val = 0.f;
+        int arg = -1;
+        if (lane_ok) {
+            val = p[0];
+            arg = __builtin_bit_cast(int, p[pitch]);
+        }
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[c] = c == arg ? val : 0.f;
+    };
     constexpr int pitch_a = TSPW * F;
     const int loff_a = srow * F + t;
     const bool lane_ok_a = t < F;
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 float* rb = a.rbuf + tile * tile_floats + loff;
                 constexpr int lq = LY - 1;
                 float rbv[F], psv[F];
-                load_tile(rb, rbv);
+                if constexpr (LY == L - 1) load_top_grad(rb, rbv); else load_tile(rb, rbv);
                 load_tile(slot(SV::P(lq)), psv);
 #pragma unroll
                 for (int c = 0; c < F; ++c) {
@@ -667,14 +685,15 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 s_a[c] += dy;
                 s_b[c] = fmaf(dy, xh, s_b[c]);
             }
-            store_tile(a.rbuf + tile * tile_floats + loff, rbv);
+            store_top_grad(a.rbuf + tile * tile_floats + loff, valid ? dpool : 0.f, arg);
             continue;
         }
 
         if constexpr (KIND == PH_G && BLK == 1) {
             // ---- G_{2l+1}: BatchNorm 2l+1 backward, conv_block2 gradient, d(x0 + H) -----------------------------------
             float gsum[F], dz[F], rbv[F];
-            load_tile(a.rbuf + tile * tile_floats + loff, rbv);
+            if constexpr (LY == L - 1) load_top_grad(a.rbuf + tile * tile_floats + loff, rbv);
+            else load_tile(a.rbuf + tile * tile_floats + loff, rbv);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x1 = relu(fmaf(z2[c], b2[2 * F + c], b2[3 * F + c]));
