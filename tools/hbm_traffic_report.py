@@ -11,7 +11,7 @@ def collect(sub, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)?>", r["Kernel_Name"])
+            m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)*>", r["Kernel_Name"])
             if m:
                 name = {"0": "F", "1": "TOP", "2": "G"}[m.group(3)] + (m.group(4) if m.group(3) != "1" else "")
             elif "stgcn_forward_eval" in r["Kernel_Name"]:

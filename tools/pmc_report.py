@@ -2,7 +2,7 @@ import csv, collections, re, sys
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in ['gpurun_out/pmcA/p_counter_collection.csv','gpurun_out/pmcB/p_counter_collection.csv']:
     for r in csv.DictReader(open(f)):
-        m = re.search(r'stgcn_train_phase_kernel<\d+, (\d), (\d), (\d)(?:, \d+)?>', r['Kernel_Name'])
+        m = re.search(r'stgcn_train_phase_kernel<\d+, (\d), (\d), (\d)(?:, \d+)*>', r['Kernel_Name'])
         if m: name = {'0':'F','1':'TOP','2':'G'}[m.group(2)] + m.group(3)
         elif 'stgcn_forward_eval' in r['Kernel_Name']: name = 'EVAL'
         else: continue
