@@ -303,7 +303,13 @@ static size_t features_lds_bytes(const MsgGeom& g) {
 // ---------------------------------------------------------------------------------------------------
 // GRU (nn.GRU, one layer, batch_first, h0 = 0; gate order r, z, n)
 // ---------------------------------------------------------------------------------------------------
-__device__ inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+// hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm expf / tanhf + IEEE division: the gate
+// non-linearities sit on the critical path of every sequential GRU step (same finding as in the HAGCN LSTM)
+__device__ inline float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+__device__ inline float tanhf_(float v) {
+    const float a = fabsf(v);
+    return copysignf(1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a)), v);
+}
 
 // One lane per (sequence, hidden unit); HG = lanes per sequence (power of two >= H).
 template <int HG>
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(MB) void msg_gru_forward_kernel(MsgGeom g, const fl
             an = fmaf(wn[k], hk, an);
         }
         const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
-        const float c = tanhf(gn + r * an);
+        const float c = tanhf_(gn + r * an);
         h = (1.0f - z) * c + z * h;
         __syncthreads();
         hs[tid] = j < H ? h : 0.f;
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(MB) void msg_gru_backward_kernel(MsgGeom g, const f
             an = fmaf(wn[k], hk, an);
         }
         const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
-        const float c = tanhf(gn + r * an);
+        const float c = tanhf_(gn + r * an);
         dh += live ? dscale * prm[g.off_fcw + t * H + j] : 0.f;
         const float dn_pre = dh * (1.0f - z) * (1.0f - c * c);
         const float dz_pre = dh * (hprev - c) * z * (1.0f - z);
