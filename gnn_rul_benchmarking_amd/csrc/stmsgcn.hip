@@ -182,6 +182,8 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
     float* araw = cat + n * CS;                    // [n][n+1]
     float* rv = araw + n * (n + 1);                // [32]
     float* ax = rv + MAXN;                         // [n][AXS]
+    float* pre = ax;                               // partial DFT sums (real | imaginary) borrow the AX tile: it is idle until the GCN stack
+    float* pim = ax + MB;
     const int tid = threadIdx.x;
 
     for (int l = 0; l < g.L; ++l) {
@@ -212,18 +214,45 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
         const float* xp = x + gi * P;
         for (int k = tid; k < P; k += MB) xs[k] = xp[k];
         __syncthreads();
-        for (int j = tid; j < P; j += MB) {
+        if (P * 2 <= MB && n * AXS >= 2 * MB) {
+            // short patches: MB / P threads share one frequency, each summing a contiguous run of the time index (the patch of
+            // 128 points left half of the workgroup idle for 128 dependent iterations); partial sums meet in LDS
+            const int S = MB / P, j = tid % P, h = tid / P;
+            const int per = (P + S - 1) / S, t0 = h * per, t1 = t0 + per < P ? t0 + per : P;
             float re = 0.f, im = 0.f;
-            int idx = 0;
-            for (int t = 0; t < P; ++t) {
-                const float v = xs[t];
-                re = fmaf(v, tw[2 * idx], re);
-                im = fmaf(-v, tw[2 * idx + 1], im);
-                idx += j;
-                if (idx >= P) idx -= P;
+            if (h < S) {
+                int idx = (int)(((int64_t)j * t0) % P);
+                for (int t = t0; t < t1; ++t) {
+                    const float v = xs[t];
+                    re = fmaf(v, tw[2 * idx], re);
+                    im = fmaf(-v, tw[2 * idx + 1], im);
+                    idx += j;
+                    if (idx >= P) idx -= P;
+                }
             }
-            fre[j] = re;
-            fim[j] = im;
+            pre[tid] = re;
+            pim[tid] = im;
+            __syncthreads();
+            if (tid < P) {
+                float a = 0.f, b = 0.f;
+                for (int q = 0; q < S; ++q) { a += pre[q * P + tid]; b += pim[q * P + tid]; }
+                fre[tid] = a;
+                fim[tid] = b;
+            }
+        } else {
+            for (int j = tid; j < P; j += MB) {
+                float re = 0.f, im = 0.f;
+                int idx = 0;
+                for (int t = 0; t < P; ++t) {
+                    const float v = xs[t];
+                    re = fmaf(v, tw[2 * idx], re);
+                    im = fmaf(-v, tw[2 * idx + 1], im);
+                    idx += j;
+                    if (idx >= P) idx -= P;
+                }
+                fre[j] = re;
+                fim[j] = im;
+            }
         }
         __syncthreads();
         float en[2] = {0.f, 0.f};
