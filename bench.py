@@ -279,7 +279,7 @@ def family_main(args, world, rank, dev, use_dist, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     if rank != 0:
-        return
+        return None
     rate = world * B * args.steps / el
     tf = 3.0 * fwd_flops * rate / 1e12
     out = {"metric": f"training samples/sec, {args.family} ({ds} {did or ''} wiring)".replace("  ", " "), "value": round(rate, 1),
@@ -297,7 +297,19 @@ def family_main(args, world, rank, dev, use_dist, dist):
         cb = family_cpu_baseline(args.family, cfg, shape)
         if cb:
             out["cpu_baseline"] = cb
-    print(json.dumps(out), flush=True)
+    return json.dumps(out)
+
+
+def finish(line, use_dist, dist):
+    """Tear the process group down, then print rank 0's JSON line as the LAST thing on stdout: RCCL's version banner
+    (NCCL_DEBUG=VERSION is exported in this image) sits in the C stdio buffer and would otherwise land after the line."""
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(line, flush=True)
 
 
 def main():
@@ -328,10 +340,8 @@ def main():
         dist.barrier()
 
     if args.family != "ST_GCN":
-        family_main(args, world, rank, dev, use_dist, dist)
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
+        line = family_main(args, world, rank, dev, use_dist, dist)
+        finish(line, use_dist, dist)
         return
 
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
@@ -377,6 +387,7 @@ def main():
     if not (final_loss == final_loss):
         raise SystemExit("training diverged to NaN")
 
+    line = None
     if rank == 0:
         total = world * B * args.steps
         out = {
@@ -398,10 +409,8 @@ def main():
             out["roofline_forward"] = roof_f
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(NUM_PATCH, args.patch_size, args.dropout)
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        line = json.dumps(out)
+    finish(line, use_dist, dist)
 
 
 if __name__ == "__main__":
