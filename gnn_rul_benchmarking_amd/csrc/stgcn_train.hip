@@ -51,6 +51,12 @@ enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
 #ifndef PHASE_ALTERNATE
 #define PHASE_ALTERNATE true
 #endif
+#ifndef NT_ALL_STORES
+#define NT_ALL_STORES false
+#endif
+#ifndef NT_COLD_STORES
+#define NT_COLD_STORES true
+#endif
 #ifndef LDS_CONVT
 #define LDS_CONVT true
 #endif
@@ -394,7 +400,20 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     auto store_tile = [&](float* p, const float (&v)[F]) {
         if (lane_ok) {
 #pragma unroll
-            for (int c = 0; c < F; ++c) p[c * pitch] = v[c];
+            for (int c = 0; c < F; ++c) {
+                if constexpr (NT_ALL_STORES) __builtin_nontemporal_store(v[c], p + c * pitch);
+                else p[c * pitch] = v[c];
+            }
+        }
+    };
+    // tensors whose next reader is several phases away (X_l, the x-hat mask): optionally stored past the caches
+    auto store_tile_cold = [&](float* p, const float (&v)[F]) {
+        if (lane_ok) {
+#pragma unroll
+            for (int c = 0; c < F; ++c) {
+                if constexpr (NT_COLD_STORES) __builtin_nontemporal_store(v[c], p + c * pitch);
+                else p[c * pitch] = v[c];
+            }
         }
     };
     // d X_L out of TOP is one value per (sample, patch): the max-pool routes the gradient to the arg-max channel.  It travels as
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 }
                 a.cacheA[tile * 64 + lane] = v;
             }
-            store_tile(a.cacheX + tile * tile_floats + loff, X);
+            store_tile_cold(a.cacheX + tile * tile_floats + loff, X);
         } else {
             if constexpr (NEED_X) {
                 load_tile(LSTART == 0 ? a.cacheX + tile * tile_floats + loff : slot(SV::X(LSTART)), X);
@@ -501,8 +520,8 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
             }
-            store_tile(slot(SV::P(lq)), psv);
-            store_tile(slot(SV::X(LY)), X);            // X_l is final from here on: stored for the later phases
+            store_tile_cold(slot(SV::P(lq)), psv);
+            store_tile_cold(slot(SV::X(LY)), X);            // X_l is final from here on: stored for the later phases
         }
 
         // ---- layer LY forward, as far as this phase needs it ---------------------------------------------------
