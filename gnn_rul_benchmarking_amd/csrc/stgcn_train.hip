@@ -892,18 +892,24 @@ struct FinalizeK {
     int fused_opt;
 };
 
-__global__ void stgcn_train_finalize_kernel(FinalizeK f) {
+// Gradient rows of the phase kernels' workgroups -> gradient (+ Adam): a workgroup owns FIN_COLS consecutive parameters (lane =
+// parameter, so every row read is one coalesced 256-byte line) and its FIN_SLICES wavefronts split the rows; the slices are
+// combined in a fixed order (bit-reproducible).  One wavefront per parameter, as before round-1h, read the rows with a
+// 6-KB stride: 12 us for 7.8 MB.
+constexpr int FIN_COLS = 64, FIN_SLICES = 16;
+__global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_kernel(FinalizeK f) {
+    __shared__ float part[FIN_SLICES][FIN_COLS];
     const int N = f.N, L = f.L, LS = layer_stride(N);
     const float lr_over_bc1 = step_scratch(f.cells, L)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cells, L)->inv_sqrt_bc2;
-    const int lane = threadIdx.x & 63;
-    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nw = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const double cnt = (double)f.B * (double)N;
     if (f.write_grads) {
-        for (int p = wid; p < f.pcount; p += nw) {        // one wavefront per parameter
-            int nblk;
-            bool from_cells = false;
-            int bn = 0, which = 0, c = 0;
+        const int p = blockIdx.x * FIN_COLS + lane;
+        const bool valid = p < f.pcount;
+        int nblk = 0;
+        bool from_cells = false;
+        int bn = 0, which = 0, c = 0;
+        if (valid) {
             if (p >= L * LS) {
                 nblk = f.grid_top;
             } else {
@@ -916,25 +922,42 @@ __global__ void stgcn_train_finalize_kernel(FinalizeK f) {
                     if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
                 }
             }
-            float v = 0.f;
+        }
+        float v = 0.f;
+        if (valid && !from_cells) {
+            // latency-bound: sixteen independent row reads in flight per lane, then the tail
+            const float* col = f.gpart + p;
+            const size_t rs = (size_t)f.pcount * FIN_SLICES;
+            int b = slice;
+            for (; b + 15 * FIN_SLICES < nblk; b += 16 * FIN_SLICES) {
+                float r[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) r[u] = col[(size_t)b * f.pcount + u * rs];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v += r[u];
+            }
+            for (; b < nblk; b += FIN_SLICES) v += col[(size_t)b * f.pcount];
+        }
+        part[slice][lane] = v;
+        __syncthreads();
+        if (slice == 0 && valid) {
             if (from_cells) {
                 // d gamma = sum dy*xhat, d beta = sum dy
                 v = (float)cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c);
             } else {
-                for (int b = lane; b < nblk; b += 64) v += f.gpart[(size_t)b * f.pcount + p];
-                v = wave_sum(v);
+                v = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < FIN_SLICES; ++sl) v += part[sl][lane];
             }
-            if (lane == 0) {
-                f.grads[p] = v;
-                if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
-                    const float pi = f.params[p];
-                    const float gi = fmaf(f.weight_decay, pi, v);
-                    const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
-                    const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
-                    f.exp_avg[p] = mi;
-                    f.exp_avg_sq[p] = vi;
-                    f.params[p] = pi - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + f.eps));
-                }
+            f.grads[p] = v;
+            if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
+                const float pi = f.params[p];
+                const float gi = fmaf(f.weight_decay, pi, v);
+                const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
+                const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
+                f.exp_avg[p] = mi;
+                f.exp_avg_sq[p] = vi;
+                f.params[p] = pi - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + f.eps));
             }
         }
     }
@@ -1204,9 +1227,9 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     }
     f.write_grads = mode != TM_FORWARD;
     f.write_loss = (k.has_dpred == 0) && a->loss;
-    const int fgrid = f.write_grads ? (k.pcount + 3) / 4 : 1;
+    const int fgrid = f.write_grads ? (k.pcount + FIN_COLS - 1) / FIN_COLS : 1;
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
-    hipLaunchKernelGGL(stgcn_train_finalize_kernel, dim3(fgrid), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(stgcn_train_finalize_kernel, dim3(fgrid), dim3(FIN_COLS * FIN_SLICES), 0, stream, f);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
