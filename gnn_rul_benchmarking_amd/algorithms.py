@@ -37,6 +37,8 @@ class Algorithm(torch.nn.Module):
         self.configs = configs
         self.mse = nn.MSELoss()
 
+    supports_graphs = True       # HAGCN (torch Adam + selection bookkeeping) and STGNN opt out
+
     def update(self, *args, **kwargs):
         raise NotImplementedError
 
@@ -44,6 +46,9 @@ class Algorithm(torch.nn.Module):
         """Replay ``update`` from a hipGraph per input shape (graphs.py): one launch per step instead of dozens --
         for launch-bound batch sizes such as the reference protocol's 100.  Single process only."""
         from .graphs import GraphedUpdate
+        if not self.supports_graphs:
+            raise RuntimeError(f"{type(self).__name__}.update cannot be captured in a hipGraph "
+                               "(its step has host-side control flow); it stays eager")
         self._graphed = GraphedUpdate(self, warmup=warmup)
         return self
 
@@ -273,6 +278,8 @@ class HAGCN(Algorithm):
     recurs along batch*nodes (Model.py:153-157): every sample depends on the whole batch, hence replicas only -- no
     data-parallel sharding for this model."""
 
+    supports_graphs = False
+
     def __init__(self, configs, hparams, device):
         super(HAGCN, self).__init__(configs)
         self.model = HAGCN_model(**configs)
@@ -299,6 +306,8 @@ class STGNN(Algorithm):
     """STGNN training wrapper (reference algorithms.py:383-408): ``update`` = forward + MSE + backward + Adam in one C call
     (graph / ChebNet kernels of csrc/stgnn.hip, the GRU of csrc/gru.hip, the fused Adam kernel).  The model has neither
     BatchNorm nor dropout: samples are independent and data parallelism is the plain ``[gradient | loss]`` bucket."""
+
+    supports_graphs = False      # update() does not consult a captured graph
 
     def __init__(self, configs, hparams, device):
         super(STGNN, self).__init__(configs)

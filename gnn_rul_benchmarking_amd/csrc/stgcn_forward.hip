@@ -8,10 +8,6 @@
 #endif
 #include "stgcn_host.hpp"
 
-#ifndef RULGNN_ABLATE
-#define RULGNN_ABLATE 0     // development only: bit0 skip stats, bit1 skip Pearson, bit2 skip theta, bit3 skip convs, bit4 skip A.X
-#endif
-
 namespace rulgnn {
 
 struct FwdArgs {
@@ -88,19 +84,11 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
         float X[F];
 #pragma unroll
         for (int c = 0; c < F; ++c) X[c] = 0.f;
-        if constexpr (RULGNN_ABLATE & 1) {
-#pragma unroll
-            for (int c = 0; c < F; ++c) X[c] = valid ? stage[(srow * N + t) * a.Ppad + c] + 0.1f * c : 0.f;
-        } else {
-            if (valid) patch_statistics(stage + (srow * N + t) * a.Ppad, P, X);
-        }
+        if (valid) patch_statistics(stage + (srow * N + t) * a.Ppad, P, X);
 
         constexpr int NA = RW == 16 ? F : NPAIR;      // RW 16: lane-distributed adjacency rows (MFMA path)
         float A[NA];
-        if constexpr (RULGNN_ABLATE & 2) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) A[i] = X[i % F] * 0.01f;
-        } else if constexpr (RW == 16) {
+        if constexpr (RW == 16) {
             pearson_rows_mfma(X, srow < ns, N, stage, lane, A);
         } else {
             pearson_adjacency<RW>(X, valid, N, A);
@@ -110,10 +98,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
             const float* lp = prm + l * LS;
             const float* bl = bnf + l * 4 * F;
             float AX[F], H[F], z[F], o0[F];
-            if constexpr (RULGNN_ABLATE & 16) {
-#pragma unroll
-                for (int c = 0; c < F; ++c) AX[c] = X[c] * A[c];
-            } else if constexpr (RW == 16) {
+            if constexpr (RW == 16) {
                 adj_aggregate_mfma(A, X, AX);
             } else {
                 adj_aggregate(A, X, AX);
@@ -121,30 +106,15 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
             const float tb = vecs[l * RW + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
-            if constexpr (RULGNN_ABLATE & 4) {
-#pragma unroll
-                for (int c = 0; c < F; ++c) H[c] += AX[c];
-            } else {
-                Row<RW>::project10(H, AX, wlds + (l * RW + t) * WS, N);     // theta(A.X), Model.py:87
-            }
+            Row<RW>::project10(H, AX, wlds + (l * RW + t) * WS, N);     // theta(A.X), Model.py:87
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
-            if constexpr (RULGNN_ABLATE & 8) {
-#pragma unroll
-                for (int c = 0; c < F; ++c) z[c] = H[c] * lp[off_conv_w(N, 0) + c];
-            } else {
-                if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 1>(H, convw + (l * 2 + 0) * F * F * 2, t, z);
-                else causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);         // conv_block1, Model.py:134-146
-            }
+            if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 1>(H, convw + (l * 2 + 0) * F * F * 2, t, z);
+            else causal_conv<RW, 1>(H, lp + off_conv_w(N, 0), t, z);             // conv_block1, Model.py:134-146
 #pragma unroll
             for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z[c], bl[c], bl[F + c])) + H[c]);
-            if constexpr (RULGNN_ABLATE & 8) {
-#pragma unroll
-                for (int c = 0; c < F; ++c) z[c] = o0[c] * lp[off_conv_w(N, 1) + c];
-            } else {
-                if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 2>(o0, convw + (l * 2 + 1) * F * F * 2, t, z);
-                else causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);        // conv_block2 (dilation 2), Model.py:148-160
-            }
+            if constexpr (EVAL_LDS_CONV) causal_conv_lds<RW, 2>(o0, convw + (l * 2 + 1) * F * F * 2, t, z);
+            else causal_conv<RW, 2>(o0, lp + off_conv_w(N, 1), t, z);            // conv_block2 (dilation 2), Model.py:148-160
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float o1 = relu(relu(fmaf(z[c], bl[2 * F + c], bl[3 * F + c])) + o0[c]);

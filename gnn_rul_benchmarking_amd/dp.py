@@ -60,7 +60,14 @@ class DataParallel:
         if sample_offset is None:
             sample_offset = b * self.rank
         batch_coupled = hasattr(model, "_after_train_forward")      # BatchNorm / dropout state (ST_GCN); STMSGCN has none
-        if batch_coupled:
+        if b == 0:
+            # Ragged last batch smaller than the world (drop_last=False: n % batch_size can be 1..world_size-1): this rank's
+            # shard is empty.  It launches no kernel, contributes a zero bucket, and still takes part in the all-reduce, the
+            # optimizer step and the running-statistics update, so that replicas stay identical and nobody waits forever.
+            model.bucket.zero_()
+            if hasattr(model, "_step"):
+                model._step += 1                                     # dropout stream position: in lockstep with the other ranks
+        elif batch_coupled:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
                                  update_running_stats=False, moments_to_bucket=True)
         else:

@@ -21,7 +21,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, params as PL
 
 PE_DROPOUT = 0.1
 
@@ -187,10 +187,12 @@ class FC_STGNN_RUL(nn.Module):
         self._grad_flat = torch.zeros(self._count + 1 + total, dtype=torch.float32, device=dev)      # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(total, dtype=torch.float32, device=dev)
         self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
+        PL.mark_flat_views(self)
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
-        self._reflatten()
+        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
+            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
         return self
 
     @property

@@ -38,9 +38,28 @@ class GraphedUpdate:
         if not model.flat_params.is_cuda:
             raise RuntimeError("enable_graphs() needs the algorithm on a CUDA (ROCm) device: call .to(device) first")
         model._pin_bufs = True
+        self._bind_step_state()
+        # A REAL move of the model (other device / dtype) rebuilds its flat buffers: every pointer baked into the captured
+        # graphs is then stale.  Drop the graphs and re-create the step state; the next updates re-warm and re-capture.
+        # (A no-op ``model.to(device)``, which the trainers issue every epoch, keeps the buffers: params.flat_views_intact.)
+        listeners = getattr(model, "_reflatten_listeners", None)
+        if listeners is None:
+            listeners = model._reflatten_listeners = []
+        listeners.append(self._invalidate)
+
+    def _bind_step_state(self):
+        model, opt = self.algorithm.model, self.algorithm.optimizer
         model._step_state = torch.zeros(_lib.STEP_STATE_BYTES, dtype=torch.uint8, device=model.flat_params.device)
         _lib.check(_lib.load().rulgnn_step_state_set(model._step_state.data_ptr(), int(getattr(model, "_step", 0)), int(opt._steps),
                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_step_state_set")
+
+    def _invalidate(self):
+        self._graphs.clear()
+        self._seen.clear()
+        model = self.algorithm.model
+        model._pin_bufs = True
+        if model.flat_params.is_cuda:
+            self._bind_step_state()
 
     # host-side counters that the eager code advances; a captured step must leave them where they were
     def _counters(self):

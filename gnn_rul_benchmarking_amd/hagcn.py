@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, params as PL
 
 
 def _stream():
@@ -196,10 +196,12 @@ class HAGCN_model(nn.Module):
         self._flat = flat
         self._grad_flat = torch.zeros(self._count, dtype=torch.float32, device=dev)
         self._ws = None
+        PL.mark_flat_views(self)
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
-        self._reflatten()
+        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
+            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
         return self
 
     @property

@@ -85,3 +85,36 @@ def pack_numpy(state: dict, num_patch: int, num_layers: int, prefix: str = ""):
 def unpack_numpy(flat, num_patch: int, num_layers: int) -> dict:
     return {name: flat[off:off + int(__import__("numpy").prod(shape))].reshape(shape)
             for name, (off, shape) in live_param_layout(num_patch, num_layers).items()}
+
+
+# ---- flat-buffer view bookkeeping shared by every model module --------------------------------------------------------
+def count_flat_views(module) -> int:
+    """How many of the module's parameters / buffers are still views into its flat device buffers
+    (``_flat``: parameters, ``_bn``: BatchNorm statistics, ``_nbt``: BatchNorm counters)."""
+    owners = {}
+    for name in ("_flat", "_bn", "_nbt"):
+        t = getattr(module, name, None)
+        if t is not None:
+            owners[t.untyped_storage().data_ptr()] = t
+    n = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        o = owners.get(t.untyped_storage().data_ptr())
+        if o is not None and t.device == o.device and t.dtype == o.dtype:
+            n += 1
+    return n
+
+
+def flat_views_intact(module) -> bool:
+    """True when an ``nn.Module._apply`` (``.to()``, ``.cuda()``, ``.float()`` ...) left every view where ``_reflatten`` put it
+    -- the per-epoch ``model.to(device)`` of the trainers is such a no-op and must not reallocate the buffers
+    (captured hipGraphs and the optimizer state point into them)."""
+    want = getattr(module, "_flat_view_count", None)
+    return want is not None and getattr(module, "_flat", None) is not None and count_flat_views(module) == want
+
+
+def mark_flat_views(module) -> None:
+    """Call at the end of ``_reflatten``: remembers the view census and tells listeners (graphs.GraphedUpdate) that every
+    device pointer of the module changed."""
+    module._flat_view_count = count_flat_views(module)
+    for hook in list(getattr(module, "_reflatten_listeners", ())):
+        hook()

@@ -17,7 +17,7 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, params as PL
 from .stgcn import MPNN_mk, TemporalConvNet
 
 LIVE = ("theta1", "theta2", "theta3", "theta4", "gcn_layer_1.theta.0.weight", "gcn_layer_1.theta.0.bias",
@@ -130,10 +130,12 @@ class ST_Conv_model(nn.Module):
         self._grad_flat = torch.zeros(self._count + 1 + 6 * N, dtype=torch.float32, device=dev)   # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(6 * N, dtype=torch.float32, device=dev)
         self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
+        PL.mark_flat_views(self)
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
-        self._reflatten()
+        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
+            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
         return self
 
     @property

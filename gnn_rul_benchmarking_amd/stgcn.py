@@ -168,6 +168,7 @@ class ST_GCN_model(nn.Module):
         self._ws, self._bufs = None, {}
         self._step_state = None
         self._fwd_ws = None
+        PL.mark_flat_views(self)
 
     def _flush_nbt(self):
         if self._nbt_pending and self._nbt is not None:
@@ -183,7 +184,8 @@ class ST_GCN_model(nn.Module):
 
     def _apply(self, fn, recurse=True):
         super()._apply(fn)
-        self._reflatten()          # .to(device)/.float() move tensors one by one: restore the views
+        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
+            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
         return self
 
     @property

@@ -197,8 +197,9 @@ def _stmsgcn_worker(rank, world, port, B, out):
         dist.destroy_process_group()
 
 
-def test_stmsgcn_data_parallel_step_equals_single_process_world2_gloo():
-    B, world = 7, 2
+@pytest.mark.parametrize("B", [7, 1])       # B = 1: the ragged last batch is smaller than the world, rank 1's shard is EMPTY
+def test_stmsgcn_data_parallel_step_equals_single_process_world2_gloo(B):
+    world = 2
     out = mp.Manager().dict()
     mp.spawn(_stmsgcn_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
     assert np.array_equal(out[0]["bucket"], out[1]["bucket"]) and np.array_equal(out[0]["flat"], out[1]["flat"])

@@ -103,7 +103,7 @@ def test_free_running_graph_stack_matches_oracle_with_its_own_selection(N, enc, 
     assert rel(nodes.grad.cpu().numpy(), dx0) < GTOL
 
 
-def test_whole_model_with_lstm_on_the_vendor_library():
+def test_whole_model_with_persistent_bilstm_kernels():
     """End to end (LSTM stack on torch/MIOpen, graph stack on HIP, fc on torch) vs the reference's eval prediction; the
     reference's selection is imposed (see above) and the LSTM output is compared first."""
     z, _ = load_case("hagcn_fd001_5x10_bs6")
