@@ -11,6 +11,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RULGNN_LIB") or os.path.join(_PKG_DIR, "librulgnn.so")    # RULGNN_LIB: development override
 
 OK = 0
+EVAL_AUTO, EVAL_EXACT, EVAL_MX = 0, 1, 2      # include/rulgnn.h RULGNN_EVAL_*
 NUM_STATS = 10
 
 
@@ -121,6 +122,11 @@ _SIGNATURES = {
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
     "rulgnn_stgcn_param_count": (C.c_int64, [C.c_int32, C.c_int32]),
     "rulgnn_stgcn_forward_workspace_bytes": (C.c_size_t, [C.POINTER(StgcnShape)]),
+    "rulgnn_stgcn_forward_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "rulgnn_stgcn_forward_mx_tap_floats": (C.c_int, []),
+    "rulgnn_stgcn_forward_mx_taps_f32": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "rulgnn_stgcn_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rulgnn_stgcn_train_workspace_bytes": (C.c_size_t, [C.POINTER(StgcnShape)]),

@@ -14,8 +14,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librulgnn.so")
-SOURCES = ["stgcn_forward.hip", "stgcn_train.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc"]
+SOURCES = ["stgcn_forward.hip", "stgcn_forward_mx.hip", "stgcn_train.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
 
 
 def _hipcc() -> str:
@@ -39,21 +38,51 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source into one shared library; returns its path."""
-    if not force and not needs_build():
-        return LIB_PATH
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    missing = [s for s in srcs if not os.path.exists(s)]
-    if missing:
-        raise RuntimeError(f"missing HIP sources: {missing}")
-    tmp = LIB_PATH + ".tmp"
-    cmd = [_hipcc()] + FLAGS + srcs + ["-o", tmp]
+OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
+COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
+
+
+def _compile_one(hipcc: str, src: str, obj: str, verbose: bool) -> None:
+    cmd = [hipcc] + COMPILE_FLAGS + [src, "-o", obj + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError(f"hipcc failed on {os.path.basename(src)}:\n" + res.stdout + res.stderr)
+    os.replace(obj + ".tmp", obj)
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """Compile every HIP source to an object (in parallel, only what is out of date) and link one shared library;
+    returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    missing = [s for s in srcs if not os.path.exists(s)]
+    if missing:
+        raise RuntimeError(f"missing HIP sources: {missing}")
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [d for d in _deps() if not d.endswith(".hip")]
+    newest_header = max(os.path.getmtime(h) for h in headers if os.path.exists(h))
+    objs, todo = [], []
+    for src in srcs:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
+        if stale:
+            todo.append((src, obj))
+    with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as pool:
+        for fut in [pool.submit(_compile_one, hipcc, src, obj, verbose) for src, obj in todo]:
+            fut.result()
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", tmp]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

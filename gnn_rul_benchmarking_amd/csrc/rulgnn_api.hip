@@ -48,18 +48,36 @@ size_t rulgnn_stgcn_forward_workspace_bytes(const rulgnn_stgcn_shape* shape) {
     return tiled_eval(shape) ? stgcn_tiled_forward_workspace_bytes(shape) : 0;
 }
 
-int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
-                             const float* bn_stats, float* pred, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+int rulgnn_stgcn_forward_path_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
+                                  const float* bn_stats, float* pred, void* workspace, size_t workspace_bytes,
+                                  int path, void* stream) {
     int rc = validate_shape(shape);
     if (rc != RULGNN_OK) return rc;
+    if (path != RULGNN_EVAL_AUTO && path != RULGNN_EVAL_EXACT && path != RULGNN_EVAL_MX) return RULGNN_EINVAL;
     if (shape->batch == 0) return RULGNN_OK;
     rc = check_ptrs({x, params, bn_stats, pred});
     if (rc != RULGNN_OK) return rc;
     if (tiled_eval(shape))
         return stgcn_tiled_forward_eval(shape, x, params, bn_stats, pred, workspace, workspace_bytes,
                                         static_cast<hipStream_t>(stream));
-    return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream));
+    return stgcn_forward_eval(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream), path);
+}
+
+int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
+                             const float* bn_stats, float* pred, void* workspace, size_t workspace_bytes,
+                             void* stream) {
+    return rulgnn_stgcn_forward_path_f32(shape, x, params, bn_stats, pred, workspace, workspace_bytes, RULGNN_EVAL_AUTO, stream);
+}
+
+int rulgnn_stgcn_forward_mx_tap_floats(void) { return stgcn_forward_mx_tap_floats(); }
+
+int rulgnn_stgcn_forward_mx_taps_f32(const rulgnn_stgcn_shape* shape, const float* x, const float* params,
+                                     const float* bn_stats, float* pred, float* taps, void* stream) {
+    int rc = validate_shape(shape);
+    if (rc != RULGNN_OK) return rc;
+    rc = check_ptrs({x, params, bn_stats, pred, taps});
+    if (rc != RULGNN_OK) return rc;
+    return stgcn_forward_eval_mx(shape, x, params, bn_stats, pred, static_cast<hipStream_t>(stream), taps);
 }
 
 static size_t train_ws_bytes(const rulgnn_stgcn_shape* shape) {

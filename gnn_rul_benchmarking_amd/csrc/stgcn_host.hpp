@@ -92,8 +92,15 @@ inline int persistent_grid(K kernel, int64_t ntiles, size_t lds_bytes, int overs
     return (int)want;
 }
 
+// Eval-forward path selection (include/rulgnn.h: RULGNN_EVAL_*): AUTO = matrix-core kernel when the shape qualifies.
+enum { STGCN_EVAL_AUTO = RULGNN_EVAL_AUTO, STGCN_EVAL_EXACT = RULGNN_EVAL_EXACT, STGCN_EVAL_MX = RULGNN_EVAL_MX };
 int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
-                       hipStream_t stream);
+                       hipStream_t stream, int path = STGCN_EVAL_AUTO);
+// Matrix-core kernel (stgcn_forward_mx.hip); RULGNN_EUNSUPPORTED when the shape does not qualify (nothing launched).
+// `taps`: optional debug buffer, MX_TAP_FLOATS floats (raw register dumps of the first tile, see the kernel).
+int stgcn_forward_eval_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
+                          hipStream_t stream, float* taps = nullptr);
+int stgcn_forward_mx_tap_floats();
 size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s);
 int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* pred,
                              void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -70,6 +70,33 @@ int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape *shape, const float *x, co
                              const float *bn_stats, float *pred, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* Same call with the kernel chosen by the caller (the default entry above is RULGNN_EVAL_AUTO).  For num_patch <= 64 there
+ * are two fused kernels:
+ *   RULGNN_EVAL_EXACT  every contraction in fp32 (VALU / DPP FMAs, f32 MFMA for the Pearson matrix): any num_patch <= 64;
+ *   RULGNN_EVAL_MX     the contractions of the layers on the f16 matrix cores with 2-way split operands
+ *                      (hi + lo, fp32 accumulate: fp32-class accuracy, measured 5e-8 of sum|a.b| per product); requires
+ *                      num_patch <= 15, num_layers <= 3, num_patch*patch_size a multiple of 4 and a 16-byte aligned x
+ *                      (else RULGNN_EUNSUPPORTED).  Samples whose
+ *                      arithmetic leaves the f16 range, or whose statistics are NaN / Inf, are recomputed inside the same
+ *                      launch by the EXACT arithmetic, so both paths agree on where NaN appears.
+ *   RULGNN_EVAL_AUTO   MX when the shape qualifies, EXACT otherwise.
+ * num_patch > 64 ignores `path` (tiled kernels). */
+#define RULGNN_EVAL_AUTO  0
+#define RULGNN_EVAL_EXACT 1
+#define RULGNN_EVAL_MX    2
+int rulgnn_stgcn_forward_path_f32(const rulgnn_stgcn_shape *shape, const float *x, const float *params,
+                                  const float *bn_stats, float *pred, void *workspace, size_t workspace_bytes,
+                                  int path, void *stream);
+
+/* Verification aid for the MX kernel (tests/test_forward_mx_gpu.py): runs it on `shape` and additionally dumps the raw
+ * registers of the FIRST 4-sample tile after every stage into `taps` (rulgnn_stgcn_forward_mx_tap_floats() floats,
+ * [slot][64 lanes]; slot map in csrc/stgcn_forward_mx.hip), so that each layout conversion and each matrix-core product can
+ * be checked against the oracle's intermediates separately.  Separate template instance: the production kernel carries
+ * no tap code. */
+int rulgnn_stgcn_forward_mx_tap_floats(void);
+int rulgnn_stgcn_forward_mx_taps_f32(const rulgnn_stgcn_shape *shape, const float *x, const float *params,
+                                     const float *bn_stats, float *pred, float *taps, void *stream);
+
 /* Bytes of scratch the training entry points need for `shape` (features/adjacency cache,
  * per-block gradient partials, BatchNorm reduction cells).  Independent of pointer values. */
 size_t rulgnn_stgcn_train_workspace_bytes(const rulgnn_stgcn_shape *shape);
