@@ -98,6 +98,63 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     return r;
 }
 
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Patch statistics (Model.py:7-52) with the patch held in registers: one pass of LDS reads serves both passes of the
+// arithmetic, and max / min take two elements per (half-rate) instruction.  Same formulas as patch_statistics().
+template <int P>
+__device__ __forceinline__ void patch_statistics_regs(const float* pp, float (&st)[F]) {
+    // No contraction: fused into fma(-s, 1/P, x) the deviation from the mean of a CONSTANT patch is a rounding residue instead of
+    // the exact 0 that makes the reference's skew / kurtosis 0/0 = NaN (Model.py:41-52) -- caught by the NaN fixture.
+#pragma clang fp contract(off)
+    static_assert(P % 2 == 0 && P <= 64, "even patch sizes that fit the register budget");
+    float v[P];
+    const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) { const float2 q = p2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+    float s = 0.f, sq = 0.f, sa = 0.f, mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        s += v[i] + v[i + 1];
+        sq = fmaf(v[i], v[i], sq);
+        sq = fmaf(v[i + 1], v[i + 1], sq);
+        sa += __builtin_fabsf(v[i]) + __builtin_fabsf(v[i + 1]);
+        mx = vmax3(mx, v[i], v[i + 1]);
+        mn = vmin3(mn, v[i], v[i + 1]);
+    }
+    const float invP = 1.0f / (float)P;
+    const float mean = s * invP;
+    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        const float d0 = v[i] - mean, d1 = v[i + 1] - mean;
+        const float q0 = d0 * d0, q1 = d1 * d1;
+        m2 += q0 + q1;
+        m3 = fmaf(q0, d0, m3);
+        m3 = fmaf(q1, d1, m3);
+        m4 = fmaf(q0, q0, m4);
+        m4 = fmaf(q1, q1, m4);
+    }
+    const float var = m2 / (float)(P - 1);
+    const float sd = sqrtf(var);
+    const float isd = 1.0f / sd;                // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
+    const float isd2 = isd * isd;
+    st[0] = mx;
+    st[1] = mn;
+    st[2] = mx - mn;
+    st[3] = var;
+    st[4] = sd;
+    st[5] = mean;
+    st[6] = sqrtf(sq * invP);
+    st[7] = sa * invP;
+    st[8] = (m3 * invP) * (isd2 * isd);
+    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
+}
+
 __device__ __forceinline__ float relu2(float v) { return __builtin_fabsf(v) + v; }     // 2 relu(v); NaN / +Inf preserving
 
 // ---- LDS-DMA --------------------------------------------------------------------------------------------------------
@@ -252,7 +309,10 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
         float X0[F];
 #pragma unroll
         for (int c = 0; c < F; ++c) X0[c] = 0.f;
-        if (valid) patch_statistics(cur + (g * N + col) * P, P, X0);
+        if (valid) {
+            if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) patch_statistics_regs<PFIX>(cur + (g * N + col) * P, X0);
+            else patch_statistics(cur + (g * N + col) * P, P, X0);
+        }
 #pragma unroll
         for (int c = 0; c < F; ++c) tap<TAPS>(a.taps, tapon, c, lane, X0[c]);
 
@@ -265,22 +325,30 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
         {
             // lane (sample row g, slot col) reads its channel's patch series; normalised BEFORE the Gram product
             // (dot / (|a| |b|) == (a / |a|) . (b / |b|)); a constant series gives 0 * Inf = NaN like the reference's 0 / 0
+            // Lanes whose slot is padding read slot 0's series and scale it by 0 (one select instead of thirty).
             const bool slot_ok = slot_chan(col) >= 0 && g < ns;
-            const float4* r4 = reinterpret_cast<const float4*>(cur + (g * 16 + col) * PT_STRIDE);
+            const float4* r4 = reinterpret_cast<const float4*>(cur + (g * 16 + (slot_chan(col) >= 0 ? col : 0)) * PT_STRIDE);
             const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
             float CT[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            float sum = 0.f;
+            float sum = 0.f;                           // columns t >= N were written as zeros
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { CT[k] = (slot_ok && k < N) ? CT[k] : 0.f; sum += CT[k]; }
+            for (int k = 0; k < 16; ++k) sum += CT[k];
             const float mean = sum * (1.0f / (float)N);
             float ss = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { CT[k] = (slot_ok && k < N) ? CT[k] - mean : 0.f; ss = fmaf(CT[k], CT[k], ss); }
+            for (int k = 0; k < 16; ++k) {
+                if (NFIX ? k < NFIX : true) {
+                    CT[k] = (NFIX || k < N) ? CT[k] - mean : 0.f;
+                    ss = fmaf(CT[k], CT[k], ss);
+                }
+            }
             const float rn = slot_ok ? __builtin_amdgcn_rcpf(sqrtf(ss)) : 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float y = CT[k] * rn;
-                if (k < N) gram = __builtin_amdgcn_mfma_f32_16x16x1f32(y, y, gram, 0, 0, 0);
+                if (k < N) {
+                    const float y = CT[k] * rn;
+                    gram = __builtin_amdgcn_mfma_f32_16x16x1f32(y, y, gram, 0, 0, 0);
+                }
             }
         }
         // gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]: the D layout of sample b's adjacency
@@ -313,10 +381,14 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
         }
 
         // ---- the layers, four samples in flight ---------------------------------------------------------------------
+        // Scheduling barriers between the five stages of a layer: inside a stage the samples follow one another (operands of
+        // sample s, then its MFMA chain), so the results of sample 0 are three samples old when the next stage reads them.
+        // Left alone the scheduler groups the whole layer by sample and pays an s_nop 7 after every MFMA chain.
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             const int tb = 38 + MX_TAPS_PER_LAYER * l;
             f32x4 T[4], Hp[4], z[4];
+            __builtin_amdgcn_sched_barrier(0);
             // T = (A.X)^T : rows t, columns c
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -325,6 +397,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 T[s] = mfma16(ah, adjB[s], t_init);
                 T[s] = mfma16(al, adjB[s], T[s]);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // Hp = theta(A.X) + b : rows c, columns j
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -337,6 +410,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 Hp[s] = mfma16(ta, ops[l].theta_lo, Hp[s]);
             }
             float H[4][3], V[4][3];
+            __builtin_amdgcn_sched_barrier(0);
             // conv_block1 on H = leaky(Hp)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -353,6 +427,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 z[s] = mfma16(ops[l].w_hi[0], bl, z[s]);
                 z[s] = mfma16(ops[l].w_lo[0], bh, z[s]);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // o0 = relu(relu(z1) + H), carried as V = 4 o0;  conv_block2 (dilation 2)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -371,6 +446,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 z[s] = mfma16(ops[l].w_hi[1], bl, z[s]);
                 z[s] = mfma16(ops[l].w_lo[1], bh, z[s]);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // o1 = relu(z2) + o0 (both >= 0: the outer ReLU is the identity); out = dropout_eval(o1) + X
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -415,9 +491,15 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
     if (any_bad) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        // Cold path: hide the parameter pointers' uniformity so that its ~800 conv weights arrive through per-lane loads instead
+        // of scalar loads -- the scalar form makes the whole kernel spill SGPRs (106 live at once here), which the hot loop
+        // would pay for in v_readlane traffic.
+        const float* prm_cold = prm;
+        const float* bn_cold = bn;
+        asm volatile("" : "+v"(prm_cold), "+v"(bn_cold));
         EvalWeightsLds<16> w;
         w.bind(smem + a.buf_floats, L);
-        eval_weights_fill<16>(w, prm, bn, N, L, lane, 64);
+        eval_weights_fill<16>(w, prm_cold, bn_cold, N, L, lane, 64);
         __builtin_amdgcn_wave_barrier();
         for (tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
             const int64_t s0 = tile * 4;
@@ -428,7 +510,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             __builtin_amdgcn_wave_barrier();
             stage_tile(gx + s0 * tileNP, smem, ns * tileNP, P, P, 0u, true, lane);
             __builtin_amdgcn_wave_barrier();
-            const float pred = eval_tile_valu<16>(smem, ns, N, P, P, L, w, prm, lane);
+            const float pred = eval_tile_valu<16>(smem, ns, N, P, P, L, w, prm_cold, lane);
             // only the samples that need it: the others keep the matrix-core result, bit for bit independent of their tile mates
             if (mine && !(__builtin_fabsf(have) <= 3.0e38f)) out[s0 + g] = pred;
         }
