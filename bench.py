@@ -10,10 +10,20 @@ A "step" is one ``ST_GCN.update`` (reference algorithms/algorithms.py:481-490): 
 resident in HBM.  For N > 1 each rank owns a fixed per-GPU batch (weak scaling) and the gradient
 bucket is all-reduced over RCCL once per step (gnn_rul_benchmarking_amd/dp.py).
 
+`--gpus N` from a bare shell (no WORLD_SIZE in the environment) re-launches itself under torch.distributed.run with N
+processes on 127.0.0.1.  The step loop is timed `--reps` times (each repetition = EXACTLY `--steps` steps between barriers +
+synchronize, max over ranks) and the MEDIAN repetition is reported.  For N > 1 the weak-scaling run (fixed per-GPU batch) is the
+headline and a strong-scaling run (the same global batch as N = 1, split over the ranks) is reported beside it.
+
 Rank 0 prints ONE JSON line.  Besides the driver contract it carries
-  roofline       dominant kernel of the step (picked live by HIP-event timing of each phase kernel)
-  roofline_forward   the fused eval forward kernel (the north-star kernel), same measurement
-  cpu_baseline   the numpy oracle's train step timed on this box's host cores (bounded sample)
+  roofline       dominant kernel of the step (picked live by HIP-event timing of each phase kernel).  `achieved` / `frac` are on
+                 SURVEY section 8(d)'s ALGORITHMIC bytes (4 N P + 4 = 1684 B per sample at 14x30: the window in, one float out);
+                 `frac_traffic` is the same launch priced on the bytes the phase really moves (its inter-phase tensors included);
+                 `step_algorithmic_frac` prices the whole step on the algorithmic bytes, `traffic_over_algorithmic` = PMC bytes of
+                 all phases / algorithmic bytes
+  roofline_forward   the fused eval forward kernel (the north-star kernel), same measurement, at the bench batch and at 1M
+  cpu_baseline   the reference's CPU path restated on torch-CPU (oracle/stgcn_torch_cpu.py, pinned to the reference's own
+                 training curve) timed on this box's host cores at 1 and all threads, 20 warm-up + 100 iterations
 """
 from __future__ import annotations
 
@@ -38,7 +48,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed step loop; the median is reported")
+    ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling) = global batch of the strong-scaling run")
+    ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
+                    help="N > 1: weak = fixed per-GPU batch (headline), strong = fixed global batch split over the ranks")
     ap.add_argument("--patch-size", type=int, default=30, help="window length (BASELINE.json: 30)")
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,25 +106,51 @@ def phase_bytes_per_sample(name, N, P, L):
     return (4 * T + A) if l == 0 else (6 * T + A + din)   # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
 
 
+def _traffic_profile():
+    """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh): newest round first."""
+    for name in ("r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            t["file"] = "profiles/" + name
+            return t
+        except Exception:
+            continue
+    return None
+
+
 def measured_traffic(kernel_key, N, P, B):
-    """HBM bytes per launch from the committed PMC summary (profiles/r01_hbm_traffic.json), scaled to this
-    batch; None when the profiled workload does not match."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_g_hbm_traffic.json")))
-        w = t["workload"]
-        if (w["num_patch"], w["patch_size"]) != (N, P) or kernel_key not in t["kernels"]:
-            return None
-        return round(t["kernels"][kernel_key]["hbm_bytes_per_sample"] * B)
-    except Exception:
+    """HBM bytes per launch from the committed PMC summary, scaled to this batch; None when the profiled workload does not match."""
+    t = _traffic_profile()
+    if not t:
         return None
+    w = t["workload"]
+    if (w["num_patch"], w["patch_size"]) != (N, P) or kernel_key not in t["kernels"]:
+        return None
+    return round(t["kernels"][kernel_key]["hbm_bytes_per_sample"] * B)
 
 
-def roofline_measurements(model, X, y, iters=10, isolated=False):
+def algorithmic_bytes_per_sample(N, P):
+    """the window is read once and one float is written; the 6.1 KB of weights amortise over the batch."""
+    return 4 * N * P + 4
+
+
+def time_eval_forward(model, X, iters=20, reps=5):
+    """Median over `reps` event-timed groups of `iters` launches of the fused eval forward (one kernel per call)."""
+    import statistics
+    model.eval()
+    with torch.no_grad():
+        ts = [event_time_ms(lambda: model(X), iters) for _ in range(reps)]
+    model.train()
+    return statistics.median(ts)
+
+
+def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_forward=True):
     """HIP-event timing (on torch's current stream = the stream the kernels are launched on) of every
     phase kernel of the training step and of the fused eval forward kernel."""
     from gnn_rul_benchmarking_amd import _lib
     lib = _lib.load()
     B, N, P, L = X.size(0), model.num_patch, model.patch_size, model.num_layers
+    alg = algorithmic_bytes_per_sample(N, P)
     x2d = X.reshape(B, -1).contiguous()
     yv = y.reshape(-1).contiguous()
     shp = model._shape(B)
@@ -148,64 +187,65 @@ def roofline_measurements(model, X, y, iters=10, isolated=False):
             iso[name] = round(event_time_ms(run, iters) * 1e3, 1)
     dom = max(per, key=lambda k: per[k]["ms"])
     d = per[dom]
-    ach = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9
+    ach = alg * B / (d["ms"] * 1e-3) / 1e9                               # algorithmic bytes of the launch / its duration
+    ach_traffic = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9      # the bytes this phase really moves
+    prof = _traffic_profile()
+    total_traffic = None
+    if prof and (prof["workload"]["num_patch"], prof["workload"]["patch_size"]) == (N, P):
+        total_traffic = sum(k["hbm_bytes_per_sample"] for n_, k in prof["kernels"].items() if n_ in names)
     roof = {"bound": "hbm", "kernel": f"stgcn_train_phase_kernel<{dom}>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, N, P, B),
-            "us_per_launch": round(d["ms"] * 1e3, 1), "bytes_per_sample": d["bytes_per_sample"],
+            "algorithmic_bytes_per_sample": alg,
+            "frac_traffic": round(ach_traffic / HBM_PEAK_GBS, 4), "phase_bytes_per_sample": d["bytes_per_sample"],
+            "step_algorithmic_frac": round(alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic_over_algorithmic": round(total_traffic / alg, 2) if total_traffic else None,
+            "step_traffic_bytes_per_sample": round(total_traffic, 1) if total_traffic else None,
+            "traffic_source": prof["file"] if prof else None,
+            "us_per_launch": round(d["ms"] * 1e3, 1),
             "phase_us": {k: round(v["ms"] * 1e3, 1) for k, v in per.items()},
             "timing": "HIP events between consecutive phases of the step (in-step cache state)"}
     if iso:
         roof["phase_us_isolated"] = iso
     # the north-star kernel: fused eval forward, one launch per call
-    model.eval()
-    with torch.no_grad():
-        fms = event_time_ms(lambda: model(X), iters)
-    model.train()
-    fb = N * P * 4 + 4
-    fach = fb * B / (fms * 1e-3) / 1e9
-    roof_f = {"bound": "hbm", "kernel": "stgcn_forward_eval_kernel", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
+    fms = time_eval_forward(model, X)
+    fach = alg * B / (fms * 1e-3) / 1e9
+    roof_f = {"bound": "hbm", "kernel": "stgcn_forward_mx_kernel", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("EVAL", N, P, B),
-              "us_per_launch": round(fms * 1e3, 1), "bytes_per_sample": fb,
-              "samples_per_s": round(B / (fms * 1e-3), 1)}
+              "algorithmic_bytes_per_sample": alg, "batch": B,
+              "us_per_launch": round(fms * 1e3, 1), "samples_per_s": round(B / (fms * 1e-3), 1)}
+    if big_forward:
+        BB = 1 << 20
+        g = torch.Generator(device=X.device).manual_seed(99)
+        Xb = torch.rand(BB, N, P, device=X.device, generator=g)
+        bms = time_eval_forward(model, Xb, iters=5)
+        bach = alg * BB / (bms * 1e-3) / 1e9
+        roof_f["at_1M"] = {"batch": BB, "us_per_launch": round(bms * 1e3, 1), "achieved": round(bach, 1),
+                           "frac": round(bach / HBM_PEAK_GBS, 4), "samples_per_s": round(BB / (bms * 1e-3), 1)}
+        del Xb
     return roof, roof_f
 
 
-def cpu_baseline(num_patch, patch_size, dropout, budget_s=12.0):
-    """The numpy oracle's full train step (forward + MSE + backward + Adam, fp32) on the host, single
-    thread, on a bounded sample of the same workload."""
-    import numpy as np
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:                                   # pragma: no cover
-        threadpool_limits = None
-    from oracle import stgcn_oracle as O
-    B = 4096
-    rng = np.random.default_rng(0)
-    prm = O.random_params(num_patch, 2, seed=0, dtype=np.float32)
-    x = rng.uniform(0, 1, (B, num_patch, patch_size)).astype(np.float32)
-    y = rng.uniform(0, 1, (B,)).astype(np.float32)
-    opt = {"step": 0, "m": {}, "v": {}}
-
-    def run():
-        nonlocal prm, opt
-        steps, t0 = 0, time.perf_counter()
-        while True:
-            _, prm, opt, _, _ = O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)
-            steps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or (steps >= 3 and el > budget_s / 2):
-                return steps, el
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)      # warm-up
-            steps, el = run()
-    else:
-        O.train_step(prm, opt, x, y, num_patch, patch_size, dropout=dropout, seed=1)
-        steps, el = run()
-    return {"value": round(steps * B / el, 1), "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} train steps of batch {B} ({num_patch}x{patch_size}), numpy fp32 oracle, 1 thread, {el:.1f}s",
-            "host_cpus": os.cpu_count()}
+def cpu_baseline(num_patch, patch_size, dropout):
+    """The reference's CPU path restated on torch-CPU (oracle/stgcn_torch_cpu.py: the same ATen kernels the reference runs,
+    pinned to the reference's own training curve in tests/test_torch_cpu_baseline.py), SURVEY section 8(d) protocol:
+    torch.set_num_threads(n) for n = 1 and n = all host cores (plus 16 and 64 where the host has more), 20 warm-up + 100 timed
+    iterations of ST_GCN.update each, same input distribution as the GPU run; bounded sample: batch 4096 (the reference's CPU
+    throughput saturates there) and the reference protocol's own batch 32 (BASELINE.json configs[0])."""
+    from oracle import stgcn_torch_cpu as T
+    cores = os.cpu_count() or 1
+    thread_counts = sorted({1, min(16, cores), min(64, cores), cores})
+    runs = []
+    for n in thread_counts:
+        runs.append(dict(T.time_update(num_patch, patch_size, 4096, n, dropout, warmup=20, iters=100, budget_s=14.0), what="train"))
+    best = max(runs, key=lambda r: r["samples_per_s"])
+    runs.append(dict(T.time_update(num_patch, patch_size, 32, 1, dropout, warmup=20, iters=100, budget_s=3.0), what="train, BASELINE.json configs[0] batch"))
+    runs.append(dict(T.time_update(num_patch, patch_size, 4096, best["threads"], dropout, warmup=20, iters=100, budget_s=6.0,
+                                   eval_forward=True), what="eval forward"))
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['iterations']} ST_GCN.update iterations (after 20 warm-up) of batch 4096 ({num_patch}x{patch_size}, dropout {dropout}), "
+                      f"torch-CPU restatement of the reference (oracle/stgcn_torch_cpu.py), fp32, best of thread counts {thread_counts}",
+            "cpu_model": T.cpu_model_name(), "host_cpus": cores, "torch": torch.__version__, "runs": runs,
+            "reference_on_survey_container": "8 vCPU Xeon 2.1 GHz: train 5.8 k samples/s at batch 32, 44.6 k/s best (BASELINE.md)"}
 
 
 # SURVEY section 8d measurement configurations of the other hot-path families: (dataset, id, per-GPU batch, input shape,
@@ -337,17 +377,60 @@ def finish(line, use_dist, dist):
         print(line, flush=True)
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` from a bare shell: re-launch under torch.distributed.run, one process per GPU, rendezvous
+    on 127.0.0.1 (the container hostname may not resolve); returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_repetitions(step_fn, steps, warmup, reps, use_dist, dist, dev):
+    """`warmup` untimed steps, then `reps` repetitions of EXACTLY `steps` steps, each bracketed by barrier + synchronize on both
+    sides, the MAX over ranks taken per repetition; returns the list of per-repetition seconds (same on every rank)."""
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    k = 0
+    for _ in range(warmup):
+        step_fn(k)
+        k += 1
+    out = []
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn(k)
+            k += 1
+        sync()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        out.append(el)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_spawn(args))
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ST_GCN path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -369,6 +452,7 @@ def main():
         finish(line, use_dist, dist)
         return
 
+    import statistics
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
     from gnn_rul_benchmarking_amd.dp import DataParallel
     from gnn_rul_benchmarking_amd import hparams as HP
@@ -384,52 +468,58 @@ def main():
     if use_dist:
         algo.attach_data_parallel(DataParallel())
 
+    def run(B):
+        """Per-rank batch B: returns (per-repetition seconds, last loss, the batches)."""
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        nbuf = 4                                        # distinct batches, cycled (all resident in HBM)
+        Xs = [torch.rand(B, NUM_PATCH, args.patch_size, device=dev, generator=g) for _ in range(nbuf)]
+        ys = [torch.rand(B, 1, device=dev, generator=g) for _ in range(nbuf)]
+        last = [None]
+
+        def step(k):
+            last[0] = algo.update(Xs[k % nbuf], ys[k % nbuf], 1)["loss"]
+        els = timed_repetitions(step, args.steps, args.warmup, max(1, args.reps), use_dist, dist, dev)
+        loss = float(last[0])
+        if not (loss == loss):
+            raise SystemExit("training diverged to NaN")
+        return els, loss, Xs, ys
+
     B = args.batch
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    nbuf = 4                                            # distinct batches, cycled (all resident in HBM)
-    Xs = [torch.rand(B, NUM_PATCH, args.patch_size, device=dev, generator=g) for _ in range(nbuf)]
-    ys = [torch.rand(B, 1, device=dev, generator=g) for _ in range(nbuf)]
-
-    def sync():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    last = None
-    for i in range(args.warmup):
-        last = algo.update(Xs[i % nbuf], ys[i % nbuf], 1)["loss"]
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = algo.update(Xs[i % nbuf], ys[i % nbuf], 1)["loss"]
-    sync()
-    el = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    final_loss = float(last)
-    if not (final_loss == final_loss):
-        raise SystemExit("training diverged to NaN")
+    weak = args.scaling != "strong" or world == 1
+    els, final_loss, Xs, ys = run(B if weak else max(1, B // world))
+    per_rank = B if weak else max(1, B // world)
+    el = statistics.median(els)
+    strong = None
+    if world > 1 and args.scaling == "both":
+        sb = max(1, B // world)
+        sels, _, _, _ = run(sb)
+        sel = statistics.median(sels)
+        strong = {"global_batch": sb * world, "per_gpu_batch": sb, "value": round(world * sb * args.steps / sel, 1), "unit": "samples/s",
+                  "ms_per_step": round(sel / args.steps * 1e3, 4), "ms_per_step_repetitions": [round(e / args.steps * 1e3, 4) for e in sels]}
 
     line = None
     if rank == 0:
-        total = world * B * args.steps
+        total = world * per_rank * args.steps
         out = {
             "metric": "training samples/sec, C-MAPSS FD004-shaped ST_GCN", "value": round(total / el, 1),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ST_GCN.update (fwd+MSE+bwd+Adam), C-MAPSS FD004-shaped windows "
-                                   f"[{NUM_PATCH} sensors x {args.patch_size}], per-GPU batch {B}, dropout {args.dropout}, "
+                                   f"[{NUM_PATCH} sensors x {args.patch_size}], per-GPU batch {per_rank}, dropout {args.dropout}, "
                                    f"lr {train_cfg['learning_rate']}, wd {train_cfg['weight_decay']}",
-                       "per_gpu_batch": B, "global_batch": world * B, "num_patch": NUM_PATCH,
+                       "per_gpu_batch": per_rank, "global_batch": world * per_rank, "num_patch": NUM_PATCH,
                        "patch_size": args.patch_size, "parallelism": f"dp{world}",
+                       "batchnorm": "local per-rank statistics (DDP default)" if use_dist else "single process",
                        "loss_readback": "every step" if args.sync_loss else "end of run (device-side loss each step)"},
+            "repetitions": len(els), "ms_per_step_repetitions": [round(e / args.steps * 1e3, 4) for e in els],
+            "timing": f"median of {len(els)} repetitions of {args.steps} steps, each between barrier + synchronize, max over ranks",
             "final_loss": round(final_loss, 6),
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if not args.no_roofline:
-            roof, roof_f = roofline_measurements(algo.model, Xs[0], ys[0], isolated=args.isolated_phases)
+            roof, roof_f = roofline_measurements(algo.model, Xs[0], ys[0], el / args.steps * 1e3, isolated=args.isolated_phases)
             out["roofline"] = roof
             out["roofline_forward"] = roof_f
         if world == 1 and not args.no_cpu_baseline:
