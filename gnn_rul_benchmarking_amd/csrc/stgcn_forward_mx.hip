@@ -139,9 +139,12 @@ __device__ __forceinline__ void patch_statistics_regs(const float* pp, float (&s
         m4 = fmaf(q0, q0, m4);
         m4 = fmaf(q1, q1, m4);
     }
-    const float var = m2 / (float)(P - 1);
-    const float sd = sqrtf(var);
-    const float isd = 1.0f / sd;                // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
+    // Hardware sqrt / rcp (1 ulp) and a reciprocal constant instead of the IEEE sequences (~45 instructions per patch).  They flush
+    // denormal inputs: a variance below 1e-38 becomes sd = 0 -> isd = Inf -> non-finite skew / kurtosis, which the safety net
+    // turns into the exact kernel's answer.
+    const float var = m2 * (1.0f / (float)(P - 1));
+    const float sd = __builtin_amdgcn_sqrtf(var);
+    const float isd = __builtin_amdgcn_rcpf(sd);   // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
     const float isd2 = isd * isd;
     st[0] = mx;
     st[1] = mn;
@@ -149,7 +152,7 @@ __device__ __forceinline__ void patch_statistics_regs(const float* pp, float (&s
     st[3] = var;
     st[4] = sd;
     st[5] = mean;
-    st[6] = sqrtf(sq * invP);
+    st[6] = __builtin_amdgcn_sqrtf(sq * invP);
     st[7] = sa * invP;
     st[8] = (m3 * invP) * (isd2 * isd);
     st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                     ss = fmaf(CT[k], CT[k], ss);
                 }
             }
-            const float rn = slot_ok ? __builtin_amdgcn_rcpf(sqrtf(ss)) : 0.f;
+            const float rn = slot_ok ? __builtin_amdgcn_rsqf(ss) : 0.f;      // ss == 0 -> Inf: 0 * Inf = NaN like the reference
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 if (k < N) {
@@ -417,7 +420,8 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 16 + 4 * s + r, lane, Hp[s][r]);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) H[s][r] = vmax(Hp[s][r], LEAKY * Hp[s][r]);      // both operands NaN when Hp is
+                // leaky(x) = (1 + a)/2 x + (1 - a)/2 |x|: two full-rate instructions (v_max is half rate); NaN stays NaN
+                for (int r = 0; r < 3; ++r) H[s][r] = fmaf(0.5f * (1.f - LEAKY), __builtin_fabsf(Hp[s][r]), (0.5f * (1.f + LEAKY)) * Hp[s][r]);
                 const Split2 p01 = split2(H[s][0], H[s][1]), p2 = split2(H[s][2], 0.f);
                 const unsigned h2 = p2.hi | one_hi;                                           // slot 3 = 1: the BatchNorm shift's partner
                 const u32x4 bh = {p01.hi, h2, shr_packed<1>(p01.hi), shr_packed<1>(p2.hi)};
