@@ -1,0 +1,236 @@
+"""-m gpu: every configuration BASELINE.json names, at its REAL size, HIP path vs the fp64 numpy oracles (which are pinned to
+the reference by tests/test_*oracle_golden.py).  One test per config string; sizes come from the reference's hparams rows
+(configs/hparams.py:149-151 ST_GCN, :202 ASTGCNN N-CMAPSS, :159 FC_STGNN FD004, HAGCN FD004 row, :355-356 STMSGCN XJTU-SY).
+
+Tolerances as everywhere else: 1e-4 relative for predictions / loss / BatchNorm statistics (north_star), 5e-4 for gradients
+(1e-3 where a 3 584-step fp32 recurrence feeds them)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+GTOL = 5e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---- BASELINE.json metric: "training samples/sec ... C-MAPSS FD004 ST_GCN" at the bench batch (65 536 per GPU) ---------------------------
+def test_config_ST_GCN_cmapss_fd004_shaped_14x30_train_batch_65536_matches_fp64_oracle():
+    """The headline workload of bench.py, whole batch: train-mode predictions, loss, the four BatchNorm batch statistics and EVERY
+    gradient tensor vs the fp64 oracle -- exercises the multi-tile persistent loop, the 16 cell replicas and the [grid][1525]
+    partial rows at the size they are benchmarked at; then the eval forward (matrix-core kernel) of the same batch."""
+    import gpu_util as G
+    from gnn_rul_benchmarking_amd import params as PL
+    from oracle import stgcn_oracle as O
+    from test_train_gpu import check_grads, oracle_step
+    N, P, B, L, p = 14, 30, 65536, 2, 0.2
+    rng = np.random.default_rng(65536)
+    prm = O.random_params(N, L, seed=21)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    flat, bn = PL.pack_numpy(prm, N, L)
+    r = G.abi_train(x, y, flat, N, P, L=L, dropout=p, seed=7, step=3)
+    pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, 7, 3)
+    assert G.rel_err(r["pred"], pred) < TOL
+    assert abs(r["loss"] - loss) < TOL * abs(loss)
+    assert G.rel_err(r["bn_batch"], bnb) < TOL
+    check_grads(r["grads"], gref, N, L)
+    ev = O.forward(prm, x.astype(np.float64), N, P, L, train=False).pred[:, 0]
+    assert G.rel_err(G.abi_forward(x, flat, bn, N, P, L=L), ev) < TOL
+
+
+# ---- configs[0]: "ST_GCN on C-MAPSS FD001 (14 sensors, window=30), batch=32, PyTorch CPU reference path" -----------------------------------
+def test_config_ST_GCN_cmapss_fd001_14x30_batch_32_matches_the_reference_cpu_run():
+    """The reference's own CPU run of this config is the golden fixture (tests/golden/make_golden.py): eval and train forward,
+    every gradient, and the first steps of its training curve."""
+    import os
+    import gpu_util as G
+    from gnn_rul_benchmarking_amd import params as PL
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    z, sd = G.load_case("stgcn_cmapss_14x30_bs32")
+    assert z["x"].shape == (32, 14, 30)
+    flat, bn = PL.pack_numpy(sd, 14, 2)
+    assert G.rel_err(G.abi_forward(z["x"], flat, bn, 14, 30), z["eval_pred"][:, 0]) < TOL
+    r = G.abi_train(z["x"], z["y"], flat, 14, 30)
+    assert G.rel_err(r["pred"], z["train_pred"][:, 0]) < TOL
+    for name, (off, shape) in PL.live_param_layout(14, 2).items():
+        n = int(np.prod(shape))
+        assert G.rel_err(r["grads"][off:off + n], z["grad:" + name].reshape(-1)) < GTOL, name
+    c = np.load(os.path.join(os.path.dirname(__file__), "golden", "stgcn_train_curve_14x30_bs32.npz"))
+    algo = ST_GCN({"num_patch": 14, "patch_size": 30, "dropout": 1e-12}, {"learning_rate": float(c["lr"]), "weight_decay": float(c["wd"])}, DEV)
+    algo.load_state_dict({k[4:]: torch.from_numpy(c[k]) for k in c.files if k.startswith("sd0:")})
+    algo.to(DEV).train()
+    losses = [algo.update(torch.from_numpy(c["xs"][i]).to(DEV), torch.from_numpy(c["ys"][i]).to(DEV), 1)["loss"] for i in range(8)]
+    assert np.allclose(losses[:4], c["losses"][:4], rtol=1e-4)
+    assert np.allclose(losses, c["losses"][:8], rtol=5e-3)
+
+
+# ---- configs[1]: "FC_STGNN on C-MAPSS FD004, batch=256" (fp32 leg; the bf16 leg is reported separately) --------------------------------
+def test_config_FC_STGNN_cmapss_fd004_batch_256_fp32_matches_fp64_oracle():
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    from oracle import fcstgnn_oracle as O
+    from test_fcstgnn_gpu import build_model, check_grads, grads_of, keep_mask
+    cfg = O.Config(**get_hparams_class("CMAPSS")("FD004").alg_hparams["FC_STGNN"])
+    bs = 256
+    rng = np.random.default_rng(256)
+    p = O.random_params(cfg, seed=4)
+    x = rng.uniform(0, 1, (bs, cfg.num_node, cfg.num_patch * cfg.patch_size))
+    y = rng.uniform(0, 1, bs)
+    assert x.shape == (256, 14, 50)
+    m = build_model(cfg, p, dropout=0.1).train()
+    keep = keep_mask(cfg, bs, m._seed, m._step + 1, 0.1).astype(np.float64)
+    loss, grads, fw = O.loss_and_grads(p, x, y, cfg, keep_mask=keep)
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    pred, l = m.fused_mse_step(xt, yt)
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    # 89 600 encoder rows: the BatchNorm scale gradients are sums of 358 400 cancelling fp32 terms (|gradient| ~ 1e-3 of the summed
+    # magnitudes); measured 5.5e-4 on conv_block2's gamma against fp64, every other tensor below 5e-4
+    check_grads(grads_of(m), grads, cfg, tol=1e-3)
+    m.eval()
+    with torch.no_grad():
+        after = {**p, **O.bn_running_update(p, fw)}
+        assert rel(m(xt).cpu().numpy(), O.forward(after, x, cfg, train=False).pred) < TOL
+
+
+# ---- configs[2]: "ASTGCNN on N-CMAPSS DS02, batch=512" (per-rank step; the data-parallel wiring is tests/test_dp_cpu.py) ---------------------
+def test_config_ASTGCNN_ncmapss_ds02_batch_512_matches_fp64_oracle():
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    from oracle import astgcnn_oracle as O
+    from test_astgcnn_gpu import build_model, grads_of
+    cfg = get_hparams_class("NCMAPSS")(None).alg_hparams["ASTGCNN"]
+    N, T, bs = cfg["num_nodes"], cfg["time_length"], 512
+    assert (N, T) == (20, 50)
+    rng = np.random.default_rng(512)
+    p = O.random_params(N, T, output_dim=cfg["output_dim"], K=cfg["K"], seed=9)
+    x = rng.uniform(-1, 1, (bs, N, T))                       # N-CMAPSS is scaled to [-1, 1]
+    y = rng.uniform(0, 1, (bs,))
+    loss, grads, fw = O.loss_and_grads(p, x, y)
+    m = build_model(cfg, p)
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        assert rel(m(xt).cpu().numpy(), O.forward(p, x, train=False).pred) < TOL
+    m.train()
+    pred, l = m.fused_mse_step(xt, yt)
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    g = grads_of(m)
+    for k in O.live_param_names():
+        assert rel(g[k], grads[k]) < GTOL, k
+
+
+# ---- configs[3]: "HAGCN ..., batch=256" (the reference wires HAGCN to C-MAPSS / N-CMAPSS only: FD004 row, one 50-point patch) ---------------
+def test_config_HAGCN_cmapss_fd004_batch_256_lstm_sequence_3584_matches_fp64_oracle():
+    """Whole model at the real shape: the three Bi-LSTM layers recur over batch x nodes = 3 584 steps.  Forward (LSTM output, pooled
+    features, KL, prediction) and the full backward (graph stack, fc, all LSTM weights through 3 584 steps of BPTT) vs the oracle, with
+    the oracle's own top-k selection imposed on the kernels (score ties are structural) after checking that it
+    is a valid selection of the kernels' scores."""
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    from oracle import hagcn_oracle as O
+    from test_hagcn_gpu import check_param_grads
+    cfg = get_hparams_class("CMAPSS")("FD004").alg_hparams["HAGCN"]
+    ps, npatch, bs, N = cfg["patch_size"], cfg["num_patch"], 256, 14
+    assert bs * N == 3584 and ps * npatch == 50
+    torch.manual_seed(11)
+    m = HAGCN_model(**cfg)
+    for d in (m.TD.drop1, m.TD.drop2, m.TD.drop3):
+        d.p = 0.0
+    m = m.to(DEV).train()
+    p = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    rng = np.random.default_rng(3584)
+    x = rng.uniform(0, 1, (bs, N, ps * npatch))
+    y = rng.uniform(0, 1, (bs, 1))
+    alpha = 100.0
+
+    nodes_ref = O.td_forward(p, x, ps, npatch)
+    fw = O.graph_forward(p, nodes_ref)
+    forced = np.zeros((nodes_ref.shape[0], 16), dtype=np.int32)
+    forced[:, 0:10], forced[:, 10:15], forced[:, 15:16] = fw.levels[0].topk, fw.levels[1].topk, fw.levels[2].topk
+    m.forced_topk = torch.from_numpy(forced)
+
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    taps = {}
+    h = m.TD.register_forward_hook(lambda mod, i, o: taps.__setitem__("td", o))
+    pred, kl = m(xt, train=True)
+    h.remove()
+    nodes = taps["td"].detach().transpose(1, 0).reshape(bs, N, npatch, -1).transpose(1, 2).reshape(bs * npatch, N, -1)
+    assert rel(nodes.cpu().numpy(), nodes_ref) < TOL                       # 3 x 3 584 recurrent steps in fp32
+    pred_ref = O.head_forward(p, fw.feats, bs)
+    assert rel(pred.detach().cpu().numpy(), pred_ref) < 2e-4
+    assert abs(float(kl.detach()) - fw.kl) < 1e-3 * abs(fw.kl) + 2e-6
+    loss = torch.nn.functional.mse_loss(pred, yt) + alpha * kl
+    loss_ref = float(np.mean((pred_ref - y) ** 2) + alpha * fw.kl)
+    assert abs(float(loss.detach()) - loss_ref) < 1e-3 * abs(loss_ref)
+    loss.backward()
+
+    # backward of the head by hand (two Linear layers, Model.py:185-187), then the oracle's graph and LSTM backward
+    dpred = 2.0 * (pred_ref - y) / bs
+    f2 = fw.feats.reshape(bs, -1)
+    hpre = f2 @ p["fc.0.weight"].T + p["fc.0.bias"]
+    dh = (dpred @ p["fc.2.weight"]) * (hpre > 0)
+    ref = {"fc.2.weight": dpred.T @ np.maximum(hpre, 0), "fc.0.weight": dh.T @ f2}
+    dfeats = (dh @ p["fc.0.weight"]).reshape(fw.feats.shape)
+    ggraph, dnodes = O.graph_backward(p, fw, dfeats, alpha)
+    check_param_grads(m, ggraph, O.graph_param_names())
+    table = dict(m.named_parameters())
+    for k in ("fc.0.weight", "fc.2.weight"):
+        assert rel(table[k].grad.cpu().numpy(), ref[k]) < 1e-3, k
+    glstm = O.td_backward(p, x, ps, npatch, dnodes)
+    gmax = max(np.abs(v).max() for v in glstm.values())
+    for k, v in glstm.items():
+        got = table[k].grad.cpu().numpy().astype(np.float64)
+        assert np.abs(got - v).max() / max(np.abs(v).max(), 1e-2 * gmax) < 2e-3, k
+
+
+# ---- configs[4]: "STMSGCN multi-scale graph on XJTU-SY bearing_1, batch=128" at its real 256 patches x 128 points ---------------------------
+def test_config_STMSGCN_xjtu_sy_condition_1_256x128_matches_fp64_oracle_and_batch_128_is_split_invariant():
+    """256-step GRU BPTT, fc input 2048, 25-node graphs x 256 per sample: forward (features, prediction, loss) and every gradient vs
+    the oracle on 3 samples; then the config's batch (128): predictions equal those of its two halves bit for bit, and the
+    half-batch gradients (scaled by the global batch) add up to the full-batch gradient -- the data-parallel invariant."""
+    from gnn_rul_benchmarking_amd.hparams import get_hparams_class
+    from oracle import stmsgcn_oracle as O
+    from test_stmsgcn_gpu import build_model, grads_of
+    h = get_hparams_class("XJTU_SY")("Condition_1").alg_hparams["STMSGCN"]
+    cfg = O.Config(h["num_patch"], h["patch_size"], h["interval"], h["band_width"], h["gcn_dims"], h["gru_hidden_dim"])
+    assert (cfg.num_patch, cfg.patch_size) == (256, 128) and O.num_nodes(cfg.patch_size, cfg.interval, cfg.band_width) == 25
+    rng = np.random.default_rng(128)
+    params = O.random_params(cfg, seed=3)
+    bs = 3
+    x = rng.uniform(0, 1, (bs, cfg.num_patch * cfg.patch_size))        # XJTU-SY is min-max scaled to [0, 1]
+    y = rng.uniform(0, 1, (bs,))
+    loss, grads, fw = O.loss_and_grads(params, x, y, cfg)
+    m = build_model(cfg, params)
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    assert rel(m.features(xt).cpu().numpy(), fw.cat) < TOL
+    pred, l = m.fused_mse_step(xt, yt)
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    g = grads_of(m)
+    for k in O.param_names(cfg):
+        assert rel(g[k], grads[k]) < GTOL, k
+
+    B = 128
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    X, Y = torch.rand(B, 1, cfg.num_patch * cfg.patch_size, device=DEV, generator=gen), torch.rand(B, device=DEV, generator=gen)
+    pred, loss = m.fused_mse_step(X, Y)
+    full_pred, full_loss, full_grad = pred.clone(), float(loss), m.bucket[:m.num_live].clone()
+    assert torch.isfinite(full_pred).all() and torch.isfinite(full_grad).all()
+    acc, lsum, preds = torch.zeros_like(full_grad), 0.0, []
+    for lo, hi in ((0, 64), (64, 128)):
+        pp, ll = m.fused_mse_step(X[lo:hi], Y[lo:hi], global_batch=B)
+        preds.append(pp.clone())
+        acc += m.bucket[:m.num_live]
+        lsum += float(ll)
+    assert torch.equal(torch.cat(preds), full_pred)
+    assert abs(lsum - full_loss) < 1e-6 * abs(full_loss)
+    assert torch.allclose(acc, full_grad, rtol=1e-4, atol=1e-7 * float(full_grad.abs().max()))
+    # a sample of the big batch against the oracle (the kernels see it inside a 128-sample launch)
+    xs = X[5:6, 0].cpu().numpy().astype(np.float64)
+    assert rel(full_pred[5:6].cpu().numpy().reshape(-1, 1), O.forward(params, xs, cfg).pred) < TOL
