@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed step loop; the median is reported")
     ap.add_argument("--batch", type=int, default=65536, help="per-GPU batch (weak scaling) = global batch of the strong-scaling run")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="data parallel with synchronised BatchNorm: the N-GPU step is the 1-GPU function of the global batch "
+                         "(8 more 160-byte all-reduces per step); default = local statistics like torch DDP")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
                     help="N > 1: weak = fixed per-GPU batch (headline), strong = fixed global batch split over the ranks")
     ap.add_argument("--patch-size", type=int, default=30, help="window length (BASELINE.json: 30)")
@@ -466,7 +469,7 @@ def main():
     algo.train()
     algo.sync_loss = bool(args.sync_loss)
     if use_dist:
-        algo.attach_data_parallel(DataParallel())
+        algo.attach_data_parallel(DataParallel(sync_bn=args.sync_bn))
 
     def run(B):
         """Per-rank batch B: returns (per-repetition seconds, last loss, the batches)."""
@@ -509,8 +512,9 @@ def main():
                                    f"[{NUM_PATCH} sensors x {args.patch_size}], per-GPU batch {per_rank}, dropout {args.dropout}, "
                                    f"lr {train_cfg['learning_rate']}, wd {train_cfg['weight_decay']}",
                        "per_gpu_batch": per_rank, "global_batch": world * per_rank, "num_patch": NUM_PATCH,
-                       "patch_size": args.patch_size, "parallelism": f"dp{world}",
-                       "batchnorm": "local per-rank statistics (DDP default)" if use_dist else "single process",
+                       "patch_size": args.patch_size, "parallelism": f"dp{world}" + ("+syncbn" if args.sync_bn and use_dist else ""),
+                       "batchnorm": ("synchronised over the ranks (global-batch statistics: the 1-GPU function)" if args.sync_bn
+                                     else "local per-rank statistics (DDP default)") if use_dist else "single process",
                        "loss_readback": "every step" if args.sync_loss else "end of run (device-side loss each step)"},
             "repetitions": len(els), "ms_per_step_repetitions": [round(e / args.steps * 1e3, 4) for e in els],
             "timing": f"median of {len(els)} repetitions of {args.steps} steps, each between barrier + synchronize, max over ranks",

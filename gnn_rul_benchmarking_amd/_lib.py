@@ -11,6 +11,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RULGNN_LIB") or os.path.join(_PKG_DIR, "librulgnn.so")    # RULGNN_LIB: development override
 
 OK = 0
+EINVAL, EUNSUPPORTED, EWORKSPACE, EHIP, EALIGN, ECALLBACK = -1, -2, -3, -4, -5, -6      # include/rulgnn.h RULGNN_E*
 EVAL_AUTO, EVAL_EXACT, EVAL_MX = 0, 1, 2      # include/rulgnn.h RULGNN_EVAL_*
 NUM_STATS = 10
 
@@ -117,6 +118,9 @@ class BilstmArgs(C.Structure):
                 ("db_ih", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+# rulgnn_allreduce_f64_fn: int (*)(void *user, double *device_buf, int32_t count, void *stream)
+ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
 _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
@@ -133,6 +137,8 @@ _SIGNATURES = {
     "rulgnn_stgcn_train_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_backward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_fwdbwd_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_fwdbwd_syncbn_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_float, ALLREDUCE_F64_FN,
+                                                        C.c_void_p, C.c_void_p]),
     "rulgnn_stgcn_train_step_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs),
                                                C.c_void_p]),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),

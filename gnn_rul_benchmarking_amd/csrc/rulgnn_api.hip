@@ -17,6 +17,7 @@ const char* rulgnn_strerror(int code) {
         case RULGNN_EWORKSPACE: return "workspace too small";
         case RULGNN_EHIP: return "HIP runtime error";
         case RULGNN_EALIGN: return "pointer not 4-byte aligned";
+        case RULGNN_ECALLBACK: return "caller-supplied callback failed";
         default: return "unknown rulgnn error";
     }
 }
@@ -134,6 +135,15 @@ int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_
     if (rc != RULGNN_OK) return rc;
     if (tiled(shape)) return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream));
     return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
+                                         float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void* user, void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (!(bn_param_grad_scale >= 0.f && bn_param_grad_scale <= 1.f) || !allreduce || args->bn_moment_weight != 0.f) return RULGNN_EINVAL;
+    if (tiled(shape)) return RULGNN_EUNSUPPORTED;          // the tiled path keeps local statistics
+    return stgcn_train_fwdbwd_syncbn(shape, args, bn_param_grad_scale, allreduce, user, static_cast<hipStream_t>(stream));
 }
 
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,

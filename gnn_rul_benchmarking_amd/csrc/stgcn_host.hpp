@@ -113,6 +113,8 @@ int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const rulgnn_adam_args* opt,
                      hipStream_t stream);
 int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream);
+int stgcn_train_fwdbwd_syncbn(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, float bn_param_grad_scale,
+                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t stream);
 int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s);
 size_t stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* s);
 int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float* prm, float* features, hipStream_t stream);

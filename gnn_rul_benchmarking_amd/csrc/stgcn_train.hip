@@ -115,8 +115,11 @@ struct TrainK {
 struct StepScratch {
     uint32_t drop_key[8];
     float lr_over_bc1, inv_sqrt_bc2;
-    uint32_t pad[6];
+    double bn_count;      // values per channel behind the BatchNorm cells: batch * N of this shard, or of the GLOBAL batch when the
+                          // cells are all-reduced between the phases (synchronised BatchNorm, stgcn_train_fwdbwd_syncbn)
+    uint32_t pad[4];
 };
+static_assert(sizeof(StepScratch) == 64, "step scratch layout");
 
 // Reduction cells (fp64): per BatchNorm the forward pair (sum z, sum z^2) and the backward pair (sum dy, sum dy*xhat), then
 // the loss.  Every block adds its partial sums with one atomic per cell; 1280 blocks hitting the same 20 addresses serialise
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     __syncthreads();
     const double* cells_fwd = cellsum + cell_fwd(L);
     const double* cells_bwd = cellsum + cell_bwd(L);
-    const double cnt = (double)a.B * (double)N;           // values per channel in this shard's batch
+    const double cnt = step_scratch(a.cells, L)->bn_count;   // values per channel behind the cells (shard, or global batch under SyncBN)
     for (int i = threadIdx.x; i < NBN * F; i += BLOCK) {
         const int b = i / F, c = i % F;
         const int l = b / 2, blk = b % 2;
@@ -882,6 +885,8 @@ struct FinalizeK {
     int64_t B, global_batch;
     int write_grads, write_loss;
     float moment_weight;
+    float cell_grad_scale;   // 1; under SyncBN the caller's factor: the cells then hold GLOBAL sums on every rank and the gradient
+                             // bucket is summed over the ranks afterwards (1 on one rank and 0 elsewhere, or 1 / world_size)
     // optional fused optimizer (single-GPU step): Adam on the parameter this wavefront just reduced, BatchNorm
     // running statistics from the batch statistics block 0 just finished
     float* params;
@@ -902,7 +907,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_ke
     const int N = f.N, L = f.L, LS = layer_stride(N);
     const float lr_over_bc1 = step_scratch(f.cells, L)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cells, L)->inv_sqrt_bc2;
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const double cnt = (double)f.B * (double)N;
+    const double cnt = step_scratch(f.cells, L)->bn_count;
     if (f.write_grads) {
         const int p = blockIdx.x * FIN_COLS + lane;
         const bool valid = p < f.pcount;
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_ke
         if (slice == 0 && valid) {
             if (from_cells) {
                 // d gamma = sum dy*xhat, d beta = sum dy
-                v = (float)cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c);
+                v = (float)(cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c) * (double)f.cell_grad_scale);
             } else {
                 v = 0.f;
 #pragma unroll
@@ -1094,20 +1099,56 @@ static int launch_phase(const TrainK& k, const float* x, const float* prm, const
 
 enum TrainMode { TM_FORWARD = 0, TM_BACKWARD = 1, TM_FWDBWD = 2 };
 
+// Synchronised BatchNorm ("per-BN all-reduce of [sum x, sum x^2, count] in forward and the matching [sum dy, sum dy xhat]
+// in backward"): after every phase that completes a reduction pair its 16 replicas are collapsed into replica 0 (the others
+// zeroed, so that the consumers' replica sum is unchanged) and the caller's all-reduce runs on those 2 F contiguous doubles.
+struct SyncHook {
+    float bn_param_grad_scale;
+    rulgnn_allreduce_f64_fn fn;
+    void* user;
+};
+
+__global__ void stgcn_cells_collapse_kernel(double* cells, int off, int n, int stride) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    double v = 0.0;
+    for (int r = 0; r < CELL_REPLICAS; ++r) {          // same fixed order as cell_sum()
+        v += cells[r * stride + off + i];
+        if (r) cells[r * stride + off + i] = 0.0;
+    }
+    cells[off + i] = v;
+}
+
+template <int L>
+static int sync_pair(const TrainK& k, int off, const SyncHook* h, hipStream_t st) {
+    if (!h) return RULGNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(stgcn_cells_collapse_kernel, dim3(1), dim3(64), 0, st, k.cells, off, 2 * F, cell_stride(L));
+    if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    return h->fn(h->user, k.cells + off, 2 * F, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
+}
+
 template <int RW, int L, int I>
 struct PhaseChain {
-    static int forward_stats(const TrainK& k, const float* x, const float* prm, const TileGeom& lds, int mg, hipStream_t st) {
+    static int forward_stats(const TrainK& k, const float* x, const float* prm, const TileGeom& lds, int mg, hipStream_t st,
+                             const SyncHook* h) {
         if constexpr (I > 0) {
-            const int rc = PhaseChain<RW, L, I - 1>::forward_stats(k, x, prm, lds, mg, st);
+            const int rc = PhaseChain<RW, L, I - 1>::forward_stats(k, x, prm, lds, mg, st, h);
             if (rc != RULGNN_OK) return rc;
         }
-        return launch_phase<RW, L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
+        const int rc = launch_phase<RW, L, PH_F, I>(k, x, prm, nullptr, lds, mg, st, nullptr);
+        if (rc != RULGNN_OK) return rc;
+        return sync_pair<L>(k, cell_fwd(L) + I * 2 * F, h, st);          // sum z, sum z^2 of BatchNorm I
     }
     static int backward(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& lds, int mg, hipStream_t st,
-                        int* grids) {
-        const int rc = launch_phase<RW, L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
+                        int* grids, const SyncHook* h) {
+        int rc = launch_phase<RW, L, PH_G, I>(k, x, prm, gy, lds, mg, st, &grids[I]);
         if (rc != RULGNN_OK) return rc;
-        if constexpr (I > 0) return PhaseChain<RW, L, I - 1>::backward(k, x, prm, gy, lds, mg, st, grids);
+        if constexpr (I > 0) {
+            rc = sync_pair<L>(k, cell_bwd(L) + (I - 1) * 2 * F, h, st);  // G_I leaves sum dy, sum dy xhat of BatchNorm I - 1
+            if (rc != RULGNN_OK) return rc;
+            return PhaseChain<RW, L, I - 1>::backward(k, x, prm, gy, lds, mg, st, grids, h);
+        }
         return RULGNN_OK;
     }
 };
@@ -1158,9 +1199,10 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 // read there (hipGraph replay), else they come from the arguments.
 __global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st, uint64_t seed,
                                      uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1,
-                                     float beta2) {
+                                     float beta2, double bn_count) {
     for (int i = threadIdx.x; i < nzero * CELL_REPLICAS; i += blockDim.x) cells[(i / nzero) * stride + zero_from + i % nzero] = 0.0;
     if (threadIdx.x != 0) return;
+    sc->bn_count = bn_count;
     if (new_forward) {
         if (st) step = ++st->dropout_step;
         for (int l = 0; l < 8; ++l) sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
@@ -1176,8 +1218,9 @@ __global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, in
 
 template <int RW, int L>
 static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                        TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt) {
+                        TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt, const SyncHook* hook) {
     int rc = RULGNN_OK;
+    const double bn_count = (double)(hook ? a->global_batch : s->batch) * (double)s->num_patch;
     const float* gy = a->dpred ? a->dpred : a->y;
 
     StepScratch* sc = step_scratch(k.cells, L);
@@ -1190,15 +1233,15 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         // a new forward: all cells, fresh dropout keys (a backward-only call below reuses the keys of its forward)
         hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), sc,
                            a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
-                           fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f);
+                           fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f, bn_count);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
-        rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream);
+        rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream, hook);
         if (rc != RULGNN_OK) return rc;
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
         hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, cell_bwd(L), cell_stride(L) - cell_bwd(L),
                            cell_stride(L), sc, (StepState*)nullptr,
-                           a->seed, a->step, L, 0, 0, (int64_t)0, 0.f, 0.f, 0.f);
+                           a->seed, a->step, L, 0, 0, (int64_t)0, 0.f, 0.f, 0.f, bn_count);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
     int grid_top = 0;
@@ -1206,7 +1249,9 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     rc = launch_phase<RW, L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);
     if (rc != RULGNN_OK) return rc;
     if (mode != TM_FORWARD) {
-        rc = PhaseChain<RW, L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids);
+        rc = sync_pair<L>(k, cell_bwd(L) + (2 * L - 1) * 2 * F, hook, stream);      // TOP leaves the pair of the last BatchNorm
+        if (rc != RULGNN_OK) return rc;
+        rc = PhaseChain<RW, L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids, hook);
         if (rc != RULGNN_OK) return rc;
     }
     FinalizeK f;
@@ -1216,6 +1261,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
+    f.cell_grad_scale = hook ? hook->bn_param_grad_scale : 1.0f;
     f.fused_opt = 0;
     f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
     f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
@@ -1235,14 +1281,14 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
 
 template <int L>
 static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                     const rulgnn_adam_args* opt) {
+                     const rulgnn_adam_args* opt, const SyncHook* hook) {
     TrainK k;
     WsLayout w;
     TileGeom lds;
     const int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
-    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds, opt);
-    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds, opt);
+    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds, opt, hook);
+    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds, opt, hook);
     return RULGNN_EUNSUPPORTED;
 }
 
@@ -1286,11 +1332,11 @@ int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
 }
 
 static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                          const rulgnn_adam_args* opt = nullptr) {
+                          const rulgnn_adam_args* opt = nullptr, const SyncHook* hook = nullptr) {
     switch (s->num_layers) {
-        case 1: return run_train<1>(s, a, mode, stream, opt);
-        case 2: return run_train<2>(s, a, mode, stream, opt);
-        case 3: return run_train<3>(s, a, mode, stream, opt);
+        case 1: return run_train<1>(s, a, mode, stream, opt, hook);
+        case 2: return run_train<2>(s, a, mode, stream, opt, hook);
+        case 3: return run_train<3>(s, a, mode, stream, opt, hook);
         default: return RULGNN_EUNSUPPORTED;
     }
 }
@@ -1308,6 +1354,11 @@ int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_a
 }
 int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {
     return dispatch_train(s, a, TM_FWDBWD, st);
+}
+int stgcn_train_fwdbwd_syncbn(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, float bn_param_grad_scale,
+                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t st) {
+    const SyncHook hook{bn_param_grad_scale, allreduce, user};
+    return dispatch_train(s, a, TM_FWDBWD, st, nullptr, &hook);
 }
 
 }  // namespace rulgnn

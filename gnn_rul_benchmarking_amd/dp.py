@@ -13,6 +13,10 @@ all-reduce, over a single flat fp32 bucket:
 * BatchNorm: normalisation uses each rank's LOCAL batch statistics (the torch DDP default); the
   running statistics are updated from the all-reduced global-batch moments, so replicas stay
   bit-identical without a separate buffer broadcast.
+* ``DataParallel(sync_bn=True)`` (ST_GCN, num_patch <= 64): SYNCHRONISED BatchNorm -- SURVEY.md section 8e's "per-BN
+  all-reduce of [sum x, sum x^2, count] in forward and the matching [sum dy, sum dy*xhat] in backward".  The step then
+  computes exactly the single-GPU function of the concatenated batch (tests/test_dp_cpu.py, tests/test_syncbn_gpu.py),
+  at the price of 4 L more latency-bound all-reduces of 20 doubles between the phase kernels (8 at L = 2).
 
 For C-MAPSS shapes the bucket is 6.4 KB: the collective is latency-bound, so
 it is issued once, on the compute stream, directly on the kernels' output buffer (no copy)."""
@@ -31,10 +35,11 @@ def shard_bounds(n: int, world_size: int, rank: int) -> tuple[int, int]:
 
 
 class DataParallel:
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, sync_bn=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = process_group
+        self.sync_bn = bool(sync_bn)
         self.rank = dist.get_rank(process_group)
         self.world_size = dist.get_world_size(process_group)
 
@@ -51,6 +56,36 @@ class DataParallel:
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _sync_bn_step(self, model, optimizer, X_shard, y_shard, global_batch, sample_offset):
+        """Synchronised-BatchNorm step: the model's phase chain calls back for every BatchNorm reduction pair; an empty shard
+        joins the same collectives with zeros."""
+        b = X_shard.size(0)
+        if not hasattr(model, "fused_mse_step_syncbn"):
+            raise RuntimeError(f"{type(model).__name__} has no synchronised-BatchNorm step (ST_GCN only); use sync_bn=False")
+        n_pairs = model.SYNC_BN_PAIRS_PER_LAYER * model.num_layers
+        if b == 0 and self.rank == 0 and global_batch > 0:
+            raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
+        if b == 0:
+            zero = torch.zeros(20, dtype=torch.float64, device=model.bucket.device)
+            for _ in range(n_pairs):
+                dist.all_reduce(zero, op=dist.ReduceOp.SUM, group=self.group)
+                zero.zero_()
+            model.bucket.zero_()
+            model._step += 1
+        else:
+            # the BatchNorm scale / shift gradients come out of the all-reduced cells, i.e. they are already the global sums on every
+            # rank: rank 0 (never empty under shard_bounds) contributes them to the bucket, the others contribute zero
+            model.fused_mse_step_syncbn(X_shard, y_shard, global_batch, sample_offset, 1.0 if self.rank == 0 else 0.0,
+                                        lambda cells: dist.all_reduce(cells, op=dist.ReduceOp.SUM, group=self.group))
+            # every rank holds the same global (mean, variance); weighted by the shard fraction they SUM to themselves over the
+            # ranks, which also hands them to a rank whose shard was empty -- one bucket all-reduce as in the local-BN step
+            tail = model.bucket[model.num_live + 1:model.num_live + 1 + model._bn_batch.numel()]
+            torch.mul(model._bn_batch.reshape(-1), float(b) / float(global_batch), out=tail)
+        self.all_reduce_bucket(model.bucket)
+        optimizer.step(from_bucket=True)
+        model._after_train_forward(global_batch, from_bucket_stats=True)
+        return model.bucket[model.num_live]
+
     def step(self, model, optimizer, X_shard, y_shard, global_batch=None, sample_offset=None):
         """One data-parallel ``Algorithm.update`` on this rank's shard.  ``global_batch`` defaults to
         world_size * len(shard) (equal shards); pass it (and ``sample_offset``) for ragged batches."""
@@ -60,6 +95,8 @@ class DataParallel:
         if sample_offset is None:
             sample_offset = b * self.rank
         batch_coupled = hasattr(model, "_after_train_forward")      # BatchNorm / dropout state (ST_GCN); STMSGCN has none
+        if self.sync_bn and batch_coupled:
+            return self._sync_bn_step(model, optimizer, X_shard, y_shard, global_batch, sample_offset)
         if b == 0:
             # Ragged last batch smaller than the world (drop_last=False: n % batch_size can be 1..world_size-1): this rank's
             # shard is empty.  It launches no kernel, contributes a zero bucket, and still takes part in the all-reduce, the

@@ -260,10 +260,12 @@ class ST_GCN_model(nn.Module):
         a.step_state = self._step_state.data_ptr() if self._step_state is not None else None
         return a
 
-    def _after_train_forward(self, batch, from_bucket_moments=False):
+    def _after_train_forward(self, batch, from_bucket_moments=False, from_bucket_stats=False):
         """BatchNorm side effects of a training forward (running stats, num_batches_tracked).
-        ``from_bucket_moments``: use the all-reduced global-batch moments in the bucket tail."""
-        src = self._grad_flat.data_ptr() + 4 * (self.num_live + 1) if from_bucket_moments else self._bn_batch.data_ptr()
+        ``from_bucket_moments``: use the all-reduced global-batch moments (E[z], E[z^2]) in the bucket tail;
+        ``from_bucket_stats``: the bucket tail holds the global (mean, biased variance) themselves (synchronised BatchNorm)."""
+        in_bucket = from_bucket_moments or from_bucket_stats
+        src = self._grad_flat.data_ptr() + 4 * (self.num_live + 1) if in_bucket else self._bn_batch.data_ptr()
         _lib.check(_lib.load().rulgnn_bn_running_update_f32(self._bn.data_ptr(), src, self.num_layers,
                                                             batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
                                                             _stream()),
@@ -302,6 +304,40 @@ class ST_GCN_model(nn.Module):
                    "rulgnn_stgcn_train_fwdbwd_f32")
         if update_running_stats:
             self._after_train_forward(x2d.size(0))
+        return self._pred_buf, self._grad_flat[self.num_live]
+
+    SYNC_BN_PAIRS_PER_LAYER = 4      # all-reduces per layer and step under synchronised BatchNorm: 2 forward + 2 backward pairs
+
+    def fused_mse_step_syncbn(self, x, y, global_batch, sample_offset, bn_param_grad_scale, allreduce):
+        """``fused_mse_step`` on this rank's shard with every BatchNorm normalising by the GLOBAL batch's statistics (dp.py,
+        ``DataParallel(sync_bn=True)``).  ``allreduce(view)`` is called 4 L times with a float64 view of 20 reduction cells inside
+        the workspace and must SUM it over the ranks in place, in stream order.  Fills ``self.bucket`` = [grad | loss | ...] such
+        that a SUM over the ranks is the global-batch gradient / loss (the BatchNorm scale / shift gradients are global sums on every
+        rank and enter multiplied by ``bn_param_grad_scale``: 1 on one rank, 0 elsewhere), and ``self._bn_batch`` with the global
+        (mean, var)."""
+        x2d = self._check_input(x)
+        yv = y.reshape(-1).contiguous().float()
+        if yv.numel() != x2d.size(0):
+            raise RuntimeError("target size mismatch")
+        self._step += 1
+        shp = self._shape(x2d.size(0))
+        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, False)
+        ws = self._ws
+        base, failure = ws.data_ptr(), []
+
+        def hook(_user, buf, count, _stream):
+            try:
+                off = int(buf) - base
+                allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
+                return 0
+            except BaseException as e:          # never let an exception cross the C frame
+                failure.append(e)
+                return 1
+        cb = _lib.ALLREDUCE_F64_FN(hook)
+        rc = _lib.load().rulgnn_stgcn_train_fwdbwd_syncbn_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None, _stream())
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "rulgnn_stgcn_train_fwdbwd_syncbn_f32")
         return self._pred_buf, self._grad_flat[self.num_live]
 
     def fused_train_step(self, x, y, optimizer):

@@ -36,6 +36,7 @@ extern "C" {
 #define RULGNN_EWORKSPACE   -3   /* workspace too small (see *_workspace_bytes) */
 #define RULGNN_EHIP         -4   /* a HIP runtime call failed */
 #define RULGNN_EALIGN       -5   /* pointer not 4-byte aligned */
+#define RULGNN_ECALLBACK    -6   /* a caller-supplied callback (rulgnn_allreduce_f64_fn) returned non-zero */
 
 #define RULGNN_NUM_STATS 10      /* statistics per patch == graph nodes == TCN channels */
 
@@ -138,6 +139,26 @@ int rulgnn_stgcn_train_backward_f32(const rulgnn_stgcn_shape *shape, const rulgn
  * (algorithms/algorithms.py:482-488), in one call with the loss kept on the device. */
 int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                   void *stream);
+
+/* Data parallel with SYNCHRONISED BatchNorm: rulgnn_stgcn_train_fwdbwd_f32 on this rank's shard, with every BatchNorm
+ * normalising by the statistics of the GLOBAL batch -- the function the single-GPU step computes on the concatenated
+ * batch (the reference has no data parallelism; this is what keeps an N-GPU run the same function as
+ * algorithms/algorithms.py:481-490 on the whole batch).  After each of the 2L forward phases
+ * ([sum z, sum z^2] of one BatchNorm) and each of the 2L backward phases that produce one ([sum dy, sum dy*xhat]) the
+ * library calls `allreduce(user, buf, count, stream)` with a DEVICE pointer to `count` (= 20) contiguous doubles inside
+ * args->workspace; the callback must enqueue (or perform) an in-place SUM over all ranks that is ordered after the
+ * work already queued on `stream` and before anything queued on it later, and return 0.  4L callbacks per step, in the
+ * same order on every rank.  Differences to the plain call: counts are global_batch * num_patch; args->bn_batch
+ * receives the (mean, biased variance) of the GLOBAL batch (bn_moment_weight must be 0); the BatchNorm scale / shift
+ * gradients, which come out of the all-reduced cells and are therefore already GLOBAL sums on every rank, are written to
+ * args->grads multiplied by `bn_param_grad_scale` (in [0, 1]): pass 1 on exactly one rank and 0 on the others (or
+ * 1/world_size everywhere when no shard is empty), so that a SUM of args->grads over the ranks is the gradient of the
+ * global-batch loss for every parameter.  A rank with an empty shard makes no call; it must still take part in the 4L
+ * all-reduces (with zeros).  num_patch <= 64 only (RULGNN_EUNSUPPORTED otherwise). */
+typedef int (*rulgnn_allreduce_f64_fn)(void *user, double *device_buf, int32_t count, void *stream);
+int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                         float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void *user,
+                                         void *stream);
 
 /* Single-GPU fast path: rulgnn_stgcn_train_fwdbwd_f32 with the optimizer folded into its last kernel --
  * the whole body of ST_GCN.update (algorithms/algorithms.py:482-489) in one call: the kernel that

@@ -214,10 +214,18 @@ class FwdCache:
     pred: np.ndarray = None
 
 
-def _bn(z, prm, prefix, train, cache_mean, cache_var):
+def _bn(z, prm, prefix, train, cache_mean, cache_var, stat_reduce=None, stat_count=None):
     g = prm[f"{prefix}.weight"][None, :, None]
     b = prm[f"{prefix}.bias"][None, :, None]
-    if train:
+    if train and stat_reduce is not None:
+        # synchronised BatchNorm: [sum z | sum z^2] summed over the data-parallel ranks by the caller's
+        # ``stat_reduce``; ``stat_count`` = values per channel in the GLOBAL batch
+        s = stat_reduce(np.concatenate([z.sum(axis=(0, 2)), (z * z).sum(axis=(0, 2))]))
+        mean = s[:z.shape[1]] / stat_count
+        var = np.maximum(s[z.shape[1]:] / stat_count - mean * mean, 0)
+        cache_mean.append(mean)
+        cache_var.append(var)
+    elif train:
         mean = z.mean(axis=(0, 2))
         var = z.var(axis=(0, 2))            # biased, used for normalisation
         cache_mean.append(mean)
@@ -232,7 +240,7 @@ def _bn(z, prm, prefix, train, cache_mean, cache_var):
 
 def forward(prm: dict, x: np.ndarray, num_patch: int, patch_size: int, num_layers: int = 2,
             train: bool = False, dropout: float = 0.0, dropout_keys=None,
-            sample_offset: int = 0) -> FwdCache:
+            sample_offset: int = 0, stat_reduce=None, stat_count=None) -> FwdCache:
     """Full ST_GCN forward -- Model.py:208-222.  ``x`` is any array with ``x.size ==
     B * num_patch * patch_size`` per the reference's reshape.  ``train`` selects batch-stat
     BatchNorm and (if ``dropout`` > 0) the hash-RNG dropout mask with one key per layer."""
@@ -253,11 +261,11 @@ def forward(prm: dict, x: np.ndarray, num_patch: int, patch_size: int, num_layer
         lc.Hpre = lc.AX @ prm[f"{p}.0.theta.0.weight"].T + prm[f"{p}.0.theta.0.bias"]
         lc.H = _leaky(lc.Hpre)
         lc.z1 = causal_conv(lc.H, prm[f"{p}.1.conv_block1.0.weight"], 1)
-        y, lc.xhat1, lc.istd1 = _bn(lc.z1, prm, f"{p}.1.conv_block1.2", train, lc.bn_mean, lc.bn_var)
+        y, lc.xhat1, lc.istd1 = _bn(lc.z1, prm, f"{p}.1.conv_block1.2", train, lc.bn_mean, lc.bn_var, stat_reduce, stat_count)
         lc.x0 = _relu(y)
         lc.o0 = _relu(lc.x0 + lc.H)
         lc.z2 = causal_conv(lc.o0, prm[f"{p}.1.conv_block2.0.weight"], 2)
-        y, lc.xhat2, lc.istd2 = _bn(lc.z2, prm, f"{p}.1.conv_block2.2", train, lc.bn_mean, lc.bn_var)
+        y, lc.xhat2, lc.istd2 = _bn(lc.z2, prm, f"{p}.1.conv_block2.2", train, lc.bn_mean, lc.bn_var, stat_reduce, stat_count)
         lc.x1 = _relu(y)
         lc.o1 = _relu(lc.x1 + lc.o0)
         if train and dropout > 0.0:
@@ -280,10 +288,13 @@ def forward(prm: dict, x: np.ndarray, num_patch: int, patch_size: int, num_layer
 # ----------------------------------------------------------------------------------------
 # backward (manual; checked against torch autograd of the reference via the golden fixtures)
 # ----------------------------------------------------------------------------------------
-def _bn_backward(dy, xhat, istd, gamma):
+def _bn_backward(dy, xhat, istd, gamma, stat_reduce=None, stat_count=None):
     n = dy.shape[0] * dy.shape[2]
     dgamma = (dy * xhat).sum(axis=(0, 2))
     dbeta = dy.sum(axis=(0, 2))
+    if stat_reduce is not None:             # synchronised BatchNorm: [sum dy | sum dy*xhat] over all ranks, global count
+        s = stat_reduce(np.concatenate([dbeta, dgamma]))
+        dbeta, dgamma, n = s[:dy.shape[1]], s[dy.shape[1]:], stat_count
     dz = (gamma * istd)[None, :, None] * (dy - dbeta[None, :, None] / n - xhat * (dgamma[None, :, None] / n))
     return dz, dgamma, dbeta
 
@@ -298,8 +309,9 @@ def _conv_backward(dz, h, w, dil):
     return dh, dw
 
 
-def backward(prm: dict, fc: FwdCache, dpred: np.ndarray, dropout: float = 0.0) -> dict:
-    """Gradients of sum(pred * dpred) w.r.t. every live parameter (train-mode BN)."""
+def backward(prm: dict, fc: FwdCache, dpred: np.ndarray, dropout: float = 0.0, stat_reduce=None, stat_count=None) -> dict:
+    """Gradients of sum(pred * dpred) w.r.t. every live parameter (train-mode BN).  With ``stat_reduce`` (synchronised
+    BatchNorm) the BatchNorm scale / shift gradients returned are the GLOBAL sums (identical on every rank)."""
     dt = fc.pred.dtype
     prm = {k: np.asarray(v, dtype=dt) for k, v in prm.items()}
     g = {}
@@ -319,12 +331,12 @@ def backward(prm: dict, fc: FwdCache, dpred: np.ndarray, dropout: float = 0.0) -
         d_o1 = dX if lc.keep is None else np.where(lc.keep, dX * dt.type(1.0 / (1.0 - dropout)), dt.type(0))
         gsum = d_o1 * (lc.o1 > 0)                                     # d(x1 + o0)
         dz2, g[f"{p}.1.conv_block2.2.weight"], g[f"{p}.1.conv_block2.2.bias"] = _bn_backward(
-            gsum * (lc.x1 > 0), lc.xhat2, lc.istd2, prm[f"{p}.1.conv_block2.2.weight"])
+            gsum * (lc.x1 > 0), lc.xhat2, lc.istd2, prm[f"{p}.1.conv_block2.2.weight"], stat_reduce, stat_count)
         d_o0, g[f"{p}.1.conv_block2.0.weight"] = _conv_backward(dz2, lc.o0, prm[f"{p}.1.conv_block2.0.weight"], 2)
         d_o0 = d_o0 + gsum
         gsum0 = d_o0 * (lc.o0 > 0)                                    # d(x0 + H)
         dz1, g[f"{p}.1.conv_block1.2.weight"], g[f"{p}.1.conv_block1.2.bias"] = _bn_backward(
-            gsum0 * (lc.x0 > 0), lc.xhat1, lc.istd1, prm[f"{p}.1.conv_block1.2.weight"])
+            gsum0 * (lc.x0 > 0), lc.xhat1, lc.istd1, prm[f"{p}.1.conv_block1.2.weight"], stat_reduce, stat_count)
         dH, g[f"{p}.1.conv_block1.0.weight"] = _conv_backward(dz1, lc.H, prm[f"{p}.1.conv_block1.0.weight"], 1)
         dH = dH + gsum0
         dHpre = dH * np.where(lc.Hpre > 0, dt.type(1), dt.type(LEAKY_SLOPE))

@@ -500,3 +500,103 @@ def test_stgnn_data_parallel_steps_equal_single_process_world2_gloo():
         algo.optimizer.step(from_bucket=True)
     assert np.allclose(out[0]["losses"], single, rtol=1e-5) and np.allclose(out[1]["losses"], single, rtol=1e-5)
     assert np.allclose(out[0]["flat"], algo.model.flat_params.numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- synchronised BatchNorm: the data-parallel step IS the single-process full-batch step ------------------------------------
+class SyncOracleModel(OracleModel):
+    """Test double of ST_GCN_model.fused_mse_step_syncbn: the oracle with its BatchNorm reductions routed through the caller's
+    all-reduce, in the order the phase kernels issue them (2 L forward pairs, then 2 L backward pairs)."""
+    SYNC_BN_PAIRS_PER_LAYER = 4
+    num_layers = L
+
+    def __init__(self, prm, dropout=0.2, seed=7):
+        super().__init__(prm, dropout, seed)
+        self._bn_batch = torch.zeros(PL.bn_buffer_count(L), dtype=torch.float32)
+        self.reductions = 0
+
+    def fused_mse_step_syncbn(self, X, y, global_batch, sample_offset, bn_param_grad_scale, allreduce):
+        self._step += 1
+        keys = [O.dropout_layer_key(self.seed, self._step, l) for l in range(L)]
+
+        def reduce(v):
+            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+            assert t.numel() == 20
+            allreduce(t)
+            self.reductions += 1
+            return t.numpy()
+        cnt = float(global_batch * N)
+        x = X.numpy().astype(np.float64)
+        fc = O.forward(self.prm, x, N, P, L, train=True, dropout=self.dropout, dropout_keys=keys, sample_offset=sample_offset,
+                       stat_reduce=reduce, stat_count=cnt)
+        loss, dpred = O.mse_loss_and_grad(fc.pred, y.numpy().astype(np.float64), global_batch)
+        g = O.backward(self.prm, fc, dpred, self.dropout, stat_reduce=reduce, stat_count=cnt)
+        for name, (off, shape) in PL.live_param_layout(N, L).items():
+            v = g[name].reshape(-1)
+            if name.endswith(".2.weight") or name.endswith(".2.bias"):
+                v = v * bn_param_grad_scale        # global sums on every rank: one rank contributes them (rulgnn.h)
+            self.bucket[off:off + int(np.prod(shape))] = torch.from_numpy(v.astype(np.float32))
+        self.bucket[self.num_live] = loss
+        for l in range(L):
+            for b in range(2):
+                base = ((l * 2 + b) * 2) * 10
+                self._bn_batch[base:base + 10] = torch.from_numpy(fc.layers[l].bn_mean[b].astype(np.float32))
+                self._bn_batch[base + 10:base + 20] = torch.from_numpy(fc.layers[l].bn_var[b].astype(np.float32))
+        self.last_fc = fc
+        return None, self.bucket[self.num_live]
+
+    def _after_train_forward(self, batch, from_bucket_moments=False, from_bucket_stats=False):
+        assert from_bucket_stats and not from_bucket_moments
+        self.global_stats = self.bucket[self.num_live + 1:].clone()
+        self._nbt += 1
+
+
+def _sync_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(0)
+        x = torch.from_numpy(rng.uniform(0, 1, (B, N, P)).astype(np.float32))
+        y = torch.from_numpy(rng.uniform(0, 1, (B, 1)).astype(np.float32))
+        model = SyncOracleModel(O.random_params(N, L, seed=0))
+        dp = DataParallel(sync_bn=True)
+        dp.broadcast_model(model)
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "flat": model.flat_params.clone().numpy(),
+                     "stats": model.global_stats.numpy(), "pred": getattr(model, "last_fc", None) and model.last_fc.pred.copy(),
+                     "reductions": model.reductions, "step": model._step}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [64, 65, 1])
+def test_sync_batchnorm_step_equals_the_single_process_full_batch_step_world2_gloo(B):
+    """B = 1: the second rank's shard is empty and it still joins every collective."""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_sync_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert np.array_equal(r0["bucket"], r1["bucket"]) and np.array_equal(r0["flat"], r1["flat"])
+    assert r0["step"] == r1["step"] == 1
+    assert r0["reductions"] == 4 * L and r1["reductions"] == (4 * L if B > 1 else 0)
+    # the single-process step on the whole batch
+    prm = O.random_params(N, L, seed=0)
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32).astype(np.float64)
+    y = rng.uniform(0, 1, (B, 1)).astype(np.float32).astype(np.float64)
+    keys = [O.dropout_layer_key(7, 1, l) for l in range(L)]
+    fc = O.forward(prm, x, N, P, L, train=True, dropout=0.2, dropout_keys=keys)
+    loss, dpred = O.mse_loss_and_grad(fc.pred, y)
+    g = O.backward(prm, fc, dpred, 0.2)
+    pred = np.concatenate([r["pred"] for r in (r0, r1) if r["pred"] is not None])
+    assert np.allclose(pred, fc.pred, rtol=1e-9, atol=1e-12)            # same function, not just the same loss
+    assert abs(r0["loss"] - loss) < 1e-6 * max(abs(loss), 1e-3)
+    for name, (off, shape) in PL.live_param_layout(N, L).items():
+        ref = g[name].reshape(-1)
+        got = r0["bucket"][off:off + ref.size]
+        assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * max(np.abs(ref).max(), 1e-6)), name
+    for l in range(L):
+        for b in range(2):
+            base = ((l * 2 + b) * 2) * 10
+            assert np.allclose(r0["stats"][base:base + 10], fc.layers[l].bn_mean[b], rtol=1e-5, atol=1e-7)
+            assert np.allclose(r0["stats"][base + 10:base + 20], fc.layers[l].bn_var[b], rtol=1e-5, atol=1e-7)
