@@ -4,7 +4,7 @@ for f in ['gpurun_out/pmcA/p_counter_collection.csv','gpurun_out/pmcB/p_counter_
     for r in csv.DictReader(open(f)):
         m = re.search(r'stgcn_train_phase_kernel<\d+, (\d), (\d), (\d)(?:, \d+)*>', r['Kernel_Name'])
         if m: name = {'0':'F','1':'TOP','2':'G'}[m.group(2)] + m.group(3)
-        elif 'stgcn_forward_eval' in r['Kernel_Name']: name = 'EVAL'
+        elif 'stgcn_forward_mx_kernel' in r['Kernel_Name'] or 'stgcn_forward_eval' in r['Kernel_Name']: name = 'EVAL'
         else: continue
         res[name][r['Counter_Name']].append(float(r['Counter_Value']))
 tiles = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
