@@ -225,6 +225,64 @@ def case_trainer_phm2012(name, seed, n_train=200, n_test=60, epochs=3):
     print("wrote", name, "per-epoch (Score_v1, Score_v2, MAE, RMSE):\n", np.asarray(per_epoch))
 
 
+def case_trainer_phm2012_dict(name, seed, n_train=200, n_tests=(40, 55), epochs=3):
+    """Dict-of-test-sets protocol (dataloader/dataloader.py:83-90, trainer.py:89-90,159-177,206-231): test.pt holds
+    {'samples': {key: array}, 'labels': {key: array}}, train.pt['max_ruls'] is a dict with the same keys (float bearing ids, saved as
+    "<int(key)>_results.csv/.pt").  The reference's own harness, as in case_trainer_phm2012."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(seed, n_train, sum(n_tests))
+    keys = [3.0, 4.0]
+    cut = n_tests[0]
+    tx = {keys[0]: xte[:cut], keys[1]: xte[cut:]}
+    ty = {keys[0]: yte[:cut], keys[1]: yte[cut:]}
+    max_ruls = {keys[0]: 1.0, keys[1]: 2.5}
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "PHM2012", "Condition_1")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": max_ruls}, os.path.join(d, "train.pt"))
+        torch.save({"samples": tx, "labels": ty, "max_ruls": max_ruls}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="ST_GCN", data_path=os.path.join(tmp, "data"), dataset="PHM2012",
+                                      dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            tr.model_configs["dropout"] = DROPOUT_OFF
+            per_epoch = {k: [] for k in keys}
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                for k in keys:
+                    per_epoch[k].append(ref_utils._calc_metrics(tr.pred_labels[k], tr.true_labels[k], tr.max_ruls[k]))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            run_dir = os.path.join(tmp, "logs", "exp", "r", "ST_GCN_run_0")
+            files = sorted(f for f in os.listdir(run_dir) if f.endswith(("results.csv", "results.pt")))
+            csv_text = {k: open(os.path.join(run_dir, f"{int(k)}_results.csv")).read() for k in keys}
+            saved = {k: _orig_load(os.path.join(run_dir, f"{int(k)}_results.pt"), weights_only=False) for k in keys}
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_tests": np.asarray(n_tests, np.int64), "epochs": np.int64(epochs),
+           "keys": np.asarray(keys, np.float64), "max_ruls": np.asarray([max_ruls[k] for k in keys], np.float64),
+           "files": np.array("|".join(files)),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum())}
+    for k in keys:
+        out[f"per_epoch:{int(k)}"] = np.asarray(per_epoch[k], np.float64)
+        out[f"csv_text:{int(k)}"] = np.array(csv_text[k])
+        out[f"saved_pre:{int(k)}"] = np.asarray(saved[k]["pre"], np.float64)
+        out[f"saved_max_rul:{int(k)}"] = np.float64(saved[k]["max_rul"])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, files, {k: np.asarray(v)[:, 3] for k, v in per_epoch.items()})
+
+
 def case_layers(name, num_layers, seed):
     """num_layers != 2 (the reference constructor accepts it, Model.py:198): eval + train-mode gradients."""
     torch.manual_seed(seed)
@@ -286,3 +344,4 @@ if __name__ == "__main__":
     case_layers("stgcn_layers1_14x30_bs21", 1, 21)
     case_layers("stgcn_layers3_14x30_bs21", 3, 22)
     case_trainer_phm2012("trainer_phm2012_c1_reference_run", 5)
+    case_trainer_phm2012_dict("trainer_phm2012_c1_dict_reference_run", 6)
