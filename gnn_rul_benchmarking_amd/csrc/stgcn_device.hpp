@@ -262,6 +262,86 @@ __device__ __forceinline__ void patch_statistics(const float* pp, int P, float (
     st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;    // mean(((x-mu)/sd)^4) - 3
 }
 
+// v_max_f32 / v_max3_f32 as written: fmaxf() adds a canonicalising v_max x, x, x per operand (IEEE mode), and these run at
+// half rate.  NaN is dropped by the hardware max unless every operand is NaN; callers deal with that where it matters.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Patch statistics (Model.py:7-52) with the patch held in registers: one pass of LDS reads serves both passes of the
+// arithmetic, and max / min take two elements per (half-rate) instruction.  Same formulas as patch_statistics().
+// FAST: hardware sqrt / rcp (1 ulp; denormal inputs flush, so a variance below 1e-38 gives sd = 0 -> non-finite skew / kurtosis --
+// only for callers that recompute non-finite results exactly); otherwise the IEEE sequences of patch_statistics().
+template <int P, bool FAST>
+__device__ __forceinline__ void patch_statistics_regs(const float* pp, float (&st)[F]) {
+    // No contraction: fused into fma(-s, 1/P, x) the deviation from the mean of a CONSTANT patch is a rounding residue instead of
+    // the exact 0 that makes the reference's skew / kurtosis 0/0 = NaN (Model.py:41-52) -- caught by the NaN fixture.
+#pragma clang fp contract(off)
+    static_assert(P % 2 == 0 && P <= 64, "even patch sizes that fit the register budget");
+    float v[P];
+    const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) { const float2 q = p2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+    float s = 0.f, sq = 0.f, sa = 0.f, mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        s += v[i] + v[i + 1];
+        sq = fmaf(v[i], v[i], sq);
+        sq = fmaf(v[i + 1], v[i + 1], sq);
+        sa += __builtin_fabsf(v[i]) + __builtin_fabsf(v[i + 1]);
+        mx = vmax3(mx, v[i], v[i + 1]);
+        mn = vmin3(mn, v[i], v[i + 1]);
+    }
+    const float invP = 1.0f / (float)P;
+    const float mean = s * invP;
+    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        const float d0 = v[i] - mean, d1 = v[i + 1] - mean;
+        const float q0 = d0 * d0, q1 = d1 * d1;
+        m2 += q0 + q1;
+        m3 = fmaf(q0, d0, m3);
+        m3 = fmaf(q1, d1, m3);
+        m4 = fmaf(q0, q0, m4);
+        m4 = fmaf(q1, q1, m4);
+    }
+    float var, sd, isd;                            // sd == 0 -> isd = inf; 0 * inf = NaN like the reference's 0/0
+    if constexpr (FAST) {
+        var = m2 * (1.0f / (float)(P - 1));
+        sd = __builtin_amdgcn_sqrtf(var);
+        isd = __builtin_amdgcn_rcpf(sd);
+    } else {
+        var = m2 / (float)(P - 1);
+        sd = sqrtf(var);
+        isd = 1.0f / sd;
+    }
+    const float isd2 = isd * isd;
+    st[0] = mx;
+    st[1] = mn;
+    st[2] = mx - mn;
+    st[3] = var;
+    st[4] = sd;
+    st[5] = mean;
+    st[6] = FAST ? __builtin_amdgcn_sqrtf(sq * invP) : sqrtf(sq * invP);
+    st[7] = sa * invP;
+    st[8] = (m3 * invP) * (isd2 * isd);
+    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Pearson adjacency between the ten statistic rows -- Model.py:53-71.
 // X0[c] is zero in padded lanes (t >= N).  Output: packed symmetric A, uniform over the row.

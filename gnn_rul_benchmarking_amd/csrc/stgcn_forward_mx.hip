@@ -85,78 +85,10 @@ __device__ __forceinline__ unsigned shr_packed(unsigned v) {     // operand regi
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + D, 0xf, 0xf, true);
 }
 
-// v_max_f32 / v_max3_f32 as written: fmaxf() adds a canonicalising v_max x, x, x per operand (IEEE mode), and these run at
-// half rate.  NaN is dropped by the hardware max unless every operand is NaN; callers deal with that where it matters.
-__device__ __forceinline__ float vmax(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-__device__ __forceinline__ float vmin3(float a, float b, float c) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// Patch statistics (Model.py:7-52) with the patch held in registers: one pass of LDS reads serves both passes of the
-// arithmetic, and max / min take two elements per (half-rate) instruction.  Same formulas as patch_statistics().
-template <int P>
-__device__ __forceinline__ void patch_statistics_regs(const float* pp, float (&st)[F]) {
-    // No contraction: fused into fma(-s, 1/P, x) the deviation from the mean of a CONSTANT patch is a rounding residue instead of
-    // the exact 0 that makes the reference's skew / kurtosis 0/0 = NaN (Model.py:41-52) -- caught by the NaN fixture.
-#pragma clang fp contract(off)
-    static_assert(P % 2 == 0 && P <= 64, "even patch sizes that fit the register budget");
-    float v[P];
-    const float2* p2 = reinterpret_cast<const float2*>(pp);
-#pragma unroll
-    for (int i = 0; i < P / 2; ++i) { const float2 q = p2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
-    float s = 0.f, sq = 0.f, sa = 0.f, mx = -INFINITY, mn = INFINITY;
-#pragma unroll
-    for (int i = 0; i < P; i += 2) {
-        s += v[i] + v[i + 1];
-        sq = fmaf(v[i], v[i], sq);
-        sq = fmaf(v[i + 1], v[i + 1], sq);
-        sa += __builtin_fabsf(v[i]) + __builtin_fabsf(v[i + 1]);
-        mx = vmax3(mx, v[i], v[i + 1]);
-        mn = vmin3(mn, v[i], v[i + 1]);
-    }
-    const float invP = 1.0f / (float)P;
-    const float mean = s * invP;
-    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
-#pragma unroll
-    for (int i = 0; i < P; i += 2) {
-        const float d0 = v[i] - mean, d1 = v[i + 1] - mean;
-        const float q0 = d0 * d0, q1 = d1 * d1;
-        m2 += q0 + q1;
-        m3 = fmaf(q0, d0, m3);
-        m3 = fmaf(q1, d1, m3);
-        m4 = fmaf(q0, q0, m4);
-        m4 = fmaf(q1, q1, m4);
-    }
-    // Hardware sqrt / rcp (1 ulp) and a reciprocal constant instead of the IEEE sequences (~45 instructions per patch).  They flush
-    // denormal inputs: a variance below 1e-38 becomes sd = 0 -> isd = Inf -> non-finite skew / kurtosis, which the safety net
-    // turns into the exact kernel's answer.
-    const float var = m2 * (1.0f / (float)(P - 1));
-    const float sd = __builtin_amdgcn_sqrtf(var);
-    const float isd = __builtin_amdgcn_rcpf(sd);   // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
-    const float isd2 = isd * isd;
-    st[0] = mx;
-    st[1] = mn;
-    st[2] = mx - mn;
-    st[3] = var;
-    st[4] = sd;
-    st[5] = mean;
-    st[6] = __builtin_amdgcn_sqrtf(sq * invP);
-    st[7] = sa * invP;
-    st[8] = (m3 * invP) * (isd2 * isd);
-    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
-}
+// Row 3 of every lane group is padding, so element 3 of a D-layout accumulator is dead on arrival -- and the register allocator
+// hands it out as a scratch register while the MFMA that writes it is still in flight: a write-after-write hazard the
+// compiler pads with s_nop 7.  Naming the element at the point where its siblings are consumed keeps it reserved until then.
+__device__ __forceinline__ void keep_until_here(float v) { asm volatile("" ::"v"(v)); }
 
 __device__ __forceinline__ float relu2(float v) { return __builtin_fabsf(v) + v; }     // 2 relu(v); NaN / +Inf preserving
 
@@ -313,7 +245,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
         for (int c = 0; c < F; ++c) X0[c] = 0.f;
         if (valid) {
-            if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) patch_statistics_regs<PFIX>(cur + (g * N + col) * P, X0);
+            if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) patch_statistics_regs<PFIX, true>(cur + (g * N + col) * P, X0);
             else patch_statistics(cur + (g * N + col) * P, P, X0);
         }
 #pragma unroll
@@ -419,6 +351,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 16 + 4 * s + r, lane, Hp[s][r]);
+                keep_until_here(Hp[s][3]);
 #pragma unroll
                 // leaky(x) = (1 + a)/2 x + (1 - a)/2 |x|: two full-rate instructions (v_max is half rate); NaN stays NaN
                 for (int r = 0; r < 3; ++r) H[s][r] = fmaf(0.5f * (1.f - LEAKY), __builtin_fabsf(Hp[s][r]), (0.5f * (1.f + LEAKY)) * Hp[s][r]);
@@ -437,6 +370,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 32 + 4 * s + r, lane, z[s][r]);
+                keep_until_here(z[s][3]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) V[s][r] = relu2(fmaf(2.f, H[s][r], relu2(z[s][r])));
 #pragma unroll
@@ -456,6 +390,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 60 + 4 * s + r, lane, z[s][r]);
+                keep_until_here(z[s][3]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) X[s][r] = fmaf(half_ok, relu2(z[s][r]), fmaf(quarter_ok, V[s][r], X[s][r]));
 #pragma unroll

@@ -462,7 +462,12 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = 0; c < F; ++c) X[c] = 0.f;
-            if (valid) patch_statistics(mywave + (srow * N + t) * a.Ppad, P, X);
+            if (valid) {
+                // even compile-time window: the patch is read from LDS once and held in registers for both passes (Ppad is even
+                // whenever P is, so the 8-byte reads stay aligned)
+                if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) patch_statistics_regs<PFIX, false>(mywave + (srow * N + t) * a.Ppad, X);
+                else patch_statistics(mywave + (srow * N + t) * a.Ppad, P, X);
+            }
             if constexpr (RW == 16) {
                 pearson_rows_mfma(X, rowok, N, mywave, lane, A);   // padded sample rows are kept finite (zero) inside
                 float* ca = a.cacheA + tile * (size_t)(F * pitch_a) + loff_a;
