@@ -92,9 +92,11 @@ class FcstgnnArgs(C.Structure):
                 ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_batch", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64),
                 ("sample_offset", C.c_int64), ("bn_moment_weight", C.c_float), ("dropout_p", C.c_float),
-                ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32), ("step_state", C.c_void_p)]
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32), ("step_state", C.c_void_p),
+                ("compute_dtype", C.c_int32)]
 
 
+DTYPE_F32, DTYPE_BF16 = 0, 1      # include/rulgnn.h RULGNN_DTYPE_*
 HAGCN_TOPK_SLOTS = 16
 
 

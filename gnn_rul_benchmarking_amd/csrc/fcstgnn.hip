@@ -953,6 +953,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const float* prm = a->params;
     const float* run = a->bn_stats;
     const int training = a->training ? 1 : 0;
+    const int bf = a->compute_dtype == RULGNN_DTYPE_BF16 ? 1 : 0;     // bf16 operands on the row-projection GEMMs (forward + data gradient)
     const int D2 = g.D2, HD = g.HD, CL = g.CL, FIN = g.FIN;
     const int Mi = (int)g.M, Bi = (int)g.B;
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
@@ -978,16 +979,16 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            training);
         hipLaunchKernelGGL(fc_act2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
                            (const float*)P_(w.z2), P_(w.a2));
-        FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st));
+        FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st, bf));
         hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, P_(w.z3), prm + g.o_b3, g.M, D2, cells, 2, training);
         hipLaunchKernelGGL(fc_pe_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, run, cells, training, (const float*)P_(w.z3),
                            P_(w.F), thr, dscale, key, key_dev, row_off);
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
-            FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st));
+            FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
             hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm, run,
                                (const Cells*)cells, training, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
-            FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st));
+            FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
             hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
                                (int64_t)GQ, HD, cells, 4 + 2 * b, training);
         }
@@ -997,9 +998,9 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // K = FIN (4032 at FD004) against a [batch x 16] output: split the reduction, or four workgroups walk it alone (250 us)
         FC_RC(sgemm_splitk(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, P_(w.split), st));
         hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h1), prm + g.o_f1b, g.B, D2);
-        FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st));
+        FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st, bf));
         hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h2), prm + g.o_f2b, g.B, D2);
-        FC_RC(sgemm(P_(w.h2), D2, 1, prm + g.o_f3w, D2, 1, P_(w.h3), HD, Bi, HD, D2, false, st));
+        FC_RC(sgemm(P_(w.h2), D2, 1, prm + g.o_f3w, D2, 1, P_(w.h3), HD, Bi, HD, D2, false, st, bf));
         hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * HD)), dim3(FB), 0, st, P_(w.h3), prm + g.o_f3b, g.B, HD);
         hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3), a->y,
                            (const float*)nullptr, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 0);
@@ -1022,15 +1023,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, st));
         FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, st));
         FC_RC(colsum(P_(w.dh3), g.B, HD, gr + g.o_f3b));
-        FC_RC(sgemm(P_(w.dh3), HD, 1, prm + g.o_f3w, 1, D2, P_(w.dh2), D2, Bi, D2, HD, false, st));
+        FC_RC(sgemm(P_(w.dh3), HD, 1, prm + g.o_f3w, 1, D2, P_(w.dh2), D2, Bi, D2, HD, false, st, bf));
         hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh2), (const float*)P_(w.h2), g.B * D2);
         FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, st));
         FC_RC(colsum(P_(w.dh2), g.B, D2, gr + g.o_f2b));
-        FC_RC(sgemm(P_(w.dh2), D2, 1, prm + g.o_f2w, 1, D2, P_(w.dh1), D2, Bi, D2, D2, false, st));
+        FC_RC(sgemm(P_(w.dh2), D2, 1, prm + g.o_f2w, 1, D2, P_(w.dh1), D2, Bi, D2, D2, false, st, bf));
         hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh1), (const float*)P_(w.h1), g.B * D2);
         FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, st));
         FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
-        FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st));
+        FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         // ---- graph blocks ----
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
@@ -1041,7 +1042,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
             FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, st));
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
-            FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st));
+            FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // AX[b] is free from here on (its last reader was the theta gradient above): it takes the per-graph d mapping blocks
             hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
@@ -1056,7 +1057,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int b = 0; b < 2; ++b) {
             FC_RC(sgemm_splitk(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, false, split, st));
             FC_RC(colsum(P_(w.gM[b]), g.M, D2, gr + g.o_bmap[b]));
-            FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st));
+            FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
         }
         // ---- positional encoding / dropout, Linear + BatchNorm ----
         hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
@@ -1065,7 +1066,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.z3), P_(w.dF), g.M);
         FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, st));
         FC_RC(colsum(P_(w.dF), g.M, D2, gr + g.o_b3));
-        FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st));
+        FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st, bf));
         // ---- encoder convolutions ----
         hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
                            (const float*)P_(w.a2), P_(w.da2));

@@ -140,12 +140,112 @@ static __global__ __launch_bounds__(256) void sgemm_skinny_kernel(GemmArgs g) {
         if (n < g.N) c[n] = g.accumulate ? c[n] + acc[n] : acc[n];
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 variant of the tall-and-skinny case (BASELINE.json config "FC_STGNN ... bf16"): C[m][n] (+)= sum_k A[m][k] * B(n,k) with both
+// operands ROUNDED TO bf16 (v_cvt_pk_bf16_f32, round to nearest even) and fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+// One wavefront per 16-row tile: lane (kg = lane >> 4, m = lane & 15) reads the 8 consecutive k of its row (two 16-byte loads),
+// the weight operand (N <= 32, K <= 128: NT x KS MFMA operands) stays in registers for the whole grid-stride loop, each of the
+// 4 result registers is one 64-byte row segment.  The kernel streams: [M, K] in, [M, N] out, nothing else.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ unsigned gemm_pk_bf16(float a, float b) {
+    unsigned u;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b));
+    return u;
+}
+
+template <int NT, int KS>
+static __global__ __launch_bounds__(256) void sgemm_rows_bf16_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, kg = lane >> 4, mi = lane & 15;
+    gemm_u32x4 bop[NT][KS];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            float w[8];
+            const int n = nt * 16 + mi;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = ks * 32 + 8 * kg + i;
+                w[i] = (n < g.N && k < g.K) ? g.B[n * g.sBn + k * g.sBk] : 0.f;
+            }
+            bop[nt][ks] = gemm_u32x4{gemm_pk_bf16(w[0], w[1]), gemm_pk_bf16(w[2], w[3]), gemm_pk_bf16(w[4], w[5]), gemm_pk_bf16(w[6], w[7])};
+        }
+    const bool vec = ((g.sAm & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.K & 7) == 0);
+    const int64_t tiles = ((int64_t)g.M + 15) / 16;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t tile = wave0; tile < tiles; tile += nwaves) {
+        const int64_t row = tile * 16 + mi;
+        f32x4t acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k0 = ks * 32 + 8 * kg;
+            float a[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = 0.f;
+            if (row < g.M && k0 < g.K) {
+                const float* ap = g.A + row * g.sAm + k0;
+                if (vec) {
+                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(ap), v1 = *reinterpret_cast<const f32x4t*>(ap + 4);
+                    a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3]; a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a[i] = (k0 + i < g.K) ? ap[i] : 0.f;
+                }
+            }
+            const gemm_u32x4 aop = {gemm_pk_bf16(a[0], a[1]), gemm_pk_bf16(a[2], a[3]), gemm_pk_bf16(a[4], a[5]), gemm_pk_bf16(a[6], a[7])};
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gemm_bf16x8, aop), __builtin_bit_cast(gemm_bf16x8, bop[nt][ks]),
+                                                                  acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gm = tile * 16 + 4 * kg + r;
+                const int gn = nt * 16 + mi;
+                if (gm < g.M && gn < g.N) {
+                    float* c = g.C + gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[nt][r] : acc[nt][r];
+                }
+            }
+    }
+}
+
+static inline bool sgemm_rows_bf16_ok(int64_t sAk, int M, int N, int K) { return sAk == 1 && N <= 32 && K <= 128 && K >= 1 && M >= 16; }
+
+template <int NT, int KS>
+static int sgemm_rows_bf16_launch(const GemmArgs& g, hipStream_t st) {
+    const int64_t tiles = ((int64_t)g.M + 15) / 16;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 4096) blocks = 4096;                   // 16 waves per CU worth of persistent workgroups
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((sgemm_rows_bf16_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+static int sgemm_rows_bf16(const GemmArgs& g, hipStream_t st) {
+    const int NT = g.N <= 16 ? 1 : 2, KS = g.K <= 32 ? 1 : (g.K <= 64 ? 2 : 4);
+    if (NT == 1) return KS == 1 ? sgemm_rows_bf16_launch<1, 1>(g, st) : (KS == 2 ? sgemm_rows_bf16_launch<1, 2>(g, st) : sgemm_rows_bf16_launch<1, 4>(g, st));
+    return KS == 1 ? sgemm_rows_bf16_launch<2, 1>(g, st) : (KS == 2 ? sgemm_rows_bf16_launch<2, 2>(g, st) : sgemm_rows_bf16_launch<2, 4>(g, st));
+}
+
 // (measured: at N = 50..64 the LDS broadcast reads bind and the MFMA tile wins -- ASTGCNN batch 65536: 8.5 vs 10.6 ms/step)
 static inline bool sgemm_is_skinny(int64_t sAk, int M, int N, int K) { return sAk == 1 && N <= 32 && K <= 128 && M >= 2048; }
 
+// `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies (sgemm_rows_bf16_ok), fp32 paths otherwise
 static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, hipStream_t st) {
+                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if (bf16 && sgemm_rows_bf16_ok(sAk, M, N, K)) {
+        const GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K};
+        return sgemm_rows_bf16(g, st);
+    }
     if (sgemm_is_skinny(sAk, M, N, K)) {
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? K : 1};
         const int NT = N <= 8 ? 8 : (N <= 16 ? 16 : 32);

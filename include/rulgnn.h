@@ -379,7 +379,14 @@ typedef struct rulgnn_fcstgnn_args {
     uint64_t seed, step;      /* dropout stream: mask = f(seed, step, element index) */
     int32_t training;
     void *step_state;         /* optional device step state (rulgnn_step_state_set) */
+    int32_t compute_dtype;    /* RULGNN_DTYPE_F32 (0, default): everything fp32.  RULGNN_DTYPE_BF16: the row projections (Linear layers
+                               * over the [rows, 8..24] activations, forward and data gradient) round both operands to bf16 and run
+                               * on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; BatchNorm statistics, the window graphs, the
+                               * weight gradients, the loss and the optimizer stay fp32.  BASELINE.json config "FC_STGNN ... bf16":
+                               * reported separately, it does NOT meet the 1e-4 gate (tests/test_fcstgnn_gpu.py bounds its error) */
 } rulgnn_fcstgnn_args;
+#define RULGNN_DTYPE_F32  0
+#define RULGNN_DTYPE_BF16 1
 
 int64_t rulgnn_fcstgnn_param_count(const rulgnn_fcstgnn_shape *shape);     /* < 0: invalid / unsupported */
 int64_t rulgnn_fcstgnn_bn_count(const rulgnn_fcstgnn_shape *shape);        /* floats in the BatchNorm buffer */
