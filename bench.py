@@ -268,6 +268,72 @@ FAMILY_CONFIGS = {
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
 
 
+def kernel_short_name(name):
+    """'void rulgnn::(anonymous namespace)::fc_graph_bwd_kernel<2>(rulgnn::...)' -> 'fc_graph_bwd_kernel<2>'"""
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("rulgnn::", "").strip()
+
+
+def family_traffic(family, kernel_short):
+    """HBM bytes per launch of a family's kernel from the committed PMC summary (profiles/r02_family_hbm_traffic.json, written by
+    tools/family_traffic_report.py from separate FETCH_SIZE / WRITE_SIZE passes), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r02_family_hbm_traffic.json")))
+        for k, v in t["families"][family]["kernels"].items():
+            if k == kernel_short:
+                return round(v["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def kernel_times(step_fn, steps=10):
+    """Per-kernel device time of `steps` calls of step_fn, measured live through the HIP activity tracer (torch.profiler / roctracer;
+    it records every kernel this process launches, the library's included): {kernel name: (launches per step, average us)}."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for i in range(steps):
+            step_fn(i)
+        torch.cuda.synchronize()
+    out = {}
+    for e in prof.key_averages():
+        if e.device_time_total > 0 and e.count > 0:
+            out[e.key] = (e.count / steps, e.device_time_total / e.count)
+    return out
+
+
+def _gcn_stack_flops(n, dims):
+    """Forward matmul FLOPs of STMSGCN's GCN stack for ONE graph of n nodes (models/STMSGCN/Model.py:84-112 without the dense
+    diag products): per layer the Gram matrix x x^T and A.x (2 n^2 f each) and the Linear (2 n f_in f_out)."""
+    f = [1] + list(dims)
+    return sum(2 * 2 * n * n * f[l] + 2 * n * f[l] * f[l + 1] for l in range(len(dims)))
+
+
+# Work model of the kernel that dominates each family's step: substring of the kernel name -> f(cfg, batch, launches per step)
+# = (algorithmic FLOPs of ONE launch, how they are counted).  Matmul-type FLOPs only, as SURVEY 8(d) counts them.
+def dominant_kernel_work(family, name, cfg, B, shape, per_step):
+    if family == "FC_STGNN" and "fc_graph_bwd_kernel" in name:
+        Q, D2 = 2 * cfg["num_node"], 2 * cfg["hidden_dim"]
+        graphs = B * ((cfg["num_patch"] - 1) + (cfg["num_patch"] - 2) // 2 + 1)            # window 2, stride 1 and 2 (Model_Base.py:175-225)
+        return graphs / per_step * 6 * Q * Q * D2, ("backward of one window graph: dA = dAX X'^T, dX' = A^T dAX, dM = (dS + dS^T) M, "
+                                                    "2 Q^2 D FLOPs each (Q = 28 nodes, D = 16); averaged over the two window blocks")
+    if family == "HAGCN" and "lstm_forward_kernel" in name:
+        T = B * shape[0]
+        H = cfg["encoder_hidden_dim"]
+        return T * 2 * cfg["num_patch"] * (2 * 4 * H * H), ("recurrent matvec 4H x H per step, direction and sequence over batch x nodes = "
+                                                            f"{T} SEQUENTIAL steps (H = {H}): a latency-bound recurrence, not a throughput kernel")
+    if family == "STMSGCN" and "msg_gcn_backward_kernel" in name:
+        from oracle.stmsgcn_oracle import num_nodes
+        n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])
+        return B * cfg["num_patch"] * 2 * _gcn_stack_flops(n, cfg["gcn_dims"]), (f"backward of the 4-layer GCN stack of every (sample, patch) graph ({n} nodes): "
+                                                                                  "2 x its forward FLOPs (Gram matrix, A.x and Linear per layer)")
+    if family == "STMSGCN" and "msg_features_kernel" in name:
+        from oracle.stmsgcn_oracle import num_nodes
+        n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])
+        return B * cfg["num_patch"] * _gcn_stack_flops(n, cfg["gcn_dims"]), "forward of the GCN stack per graph (the DFT is not counted)"
+    return None, None
+
+
 def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
     """The family's numpy oracle (train-step restatement) timed on this box's host cores, bounded sample."""
     import numpy as np
@@ -370,17 +436,43 @@ def family_main(args, world, rank, dev, use_dist, dist):
         return None
     rate = world * B * args.steps / el
     tf = 3.0 * fwd_flops * rate / 1e12
+    step_ms = el / args.steps * 1e3
+    roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+            "note": "whole step: 3 x SURVEY section 8d forward FLOPs per sample x samples/s (not one kernel)"}
+    if not args.no_roofline:
+        # the dominant kernel of the step, measured live (per-kernel device time over 10 more steps), priced on its own matmul FLOPs
+        kt = kernel_times(lambda i: algo.update(Xs[i % 2], ys[i % 2], 1))
+        tot = sum(c * us for c, us in kt.values())
+        dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
+        per_step, us = kt[dom]
+        work, how = dominant_kernel_work(args.family, dom, cfg, B, shape, per_step)
+        short = kernel_short_name(dom)
+        top = sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:5]
+        whole = roof
+        roof = {"bound": "mfma", "kernel": short, "launches_per_step": round(per_step, 2), "us_per_launch": round(us, 2),
+                "share_of_step_kernel_time": round(per_step * us / tot, 4), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "traffic": family_traffic(args.family, short),
+                "timing": "per-kernel device time from the HIP activity tracer over 10 steps inside bench.py",
+                "step_kernel_time_us": round(tot, 1), "launches_in_step": round(sum(c for c, _ in kt.values()), 1),
+                "top_kernels": [{"kernel": kernel_short_name(k),
+                                 "launches_per_step": round(c, 2), "us_per_launch": round(u, 2)} for k, (c, u) in top],
+                "whole_step_estimate": {"achieved": whole["achieved"], "frac": whole["frac"], "note": whole["note"]}}
+        if work:
+            ach = work / (us * 1e-6) / 1e12
+            roof.update({"achieved": round(ach, 4), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 5), "flops_per_launch": round(work), "work_model": how})
+        else:
+            roof.update({"achieved": whole["achieved"], "frac": whole["frac"],
+                         "work_model": "no per-kernel FLOP model for this kernel (a generic GEMM serving several shapes): the whole-step estimate is quoted"})
     out = {"metric": f"training samples/sec, {args.family} ({ds} {did or ''} wiring)".replace("  ", " "), "value": round(rate, 1),
            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": f"{args.family}.update (fwd+loss+bwd+Adam), input [{B}, {shape[0]}, {shape[1]}], hparams {cfg}",
                       "per_gpu_batch": B, "global_batch": world * B,
                       "parallelism": f"replicas{world}" if replicas else f"dp{world}"},
            "final_loss": round(float(last), 6),
-           "roofline": {"bound": "mfma", "achieved": round(tf, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 5), "traffic": None,
-                        "note": "whole step: 3 x SURVEY section 8d forward FLOPs per sample x samples/s (not one kernel)"}}
+           "roofline": roof}
     if variant_error is not None:
         out["variant_error"] = variant_error
     if world == 1 and not args.no_cpu_baseline:
