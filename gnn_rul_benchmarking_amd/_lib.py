@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("RULGNN_LIB") or os.path.join(_PKG_DIR, "librulgnn.so"
 OK = 0
 EINVAL, EUNSUPPORTED, EWORKSPACE, EHIP, EALIGN, ECALLBACK = -1, -2, -3, -4, -5, -6      # include/rulgnn.h RULGNN_E*
 EVAL_AUTO, EVAL_EXACT, EVAL_MX = 0, 1, 2      # include/rulgnn.h RULGNN_EVAL_*
+STEP_AUTO, STEP_CHAIN, STEP_COOP = 0, 1, 2    # include/rulgnn.h RULGNN_STEP_*
 NUM_STATS = 10
 
 
@@ -143,6 +144,8 @@ _SIGNATURES = {
                                                         C.c_void_p, C.c_void_p]),
     "rulgnn_stgcn_train_step_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs),
                                                C.c_void_p]),
+    "rulgnn_stgcn_train_step_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs), C.c_int32,
+                                                    C.c_void_p]),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
     "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,

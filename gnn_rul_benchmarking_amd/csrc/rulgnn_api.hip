@@ -148,9 +148,20 @@ int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape* shape, const 
 
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
                                 const rulgnn_adam_args* opt, void* stream) {
+    if (!opt) return RULGNN_EINVAL;
+    return rulgnn_stgcn_train_step_path_f32(shape, args, opt, RULGNN_STEP_AUTO, stream);
+}
+
+int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
+                                     const rulgnn_adam_args* opt, int32_t path, void* stream) {
     int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
-    if (!opt || (opt->step < 1 && !opt->step_state) || args->dpred) return RULGNN_EINVAL;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_COOP) return RULGNN_EINVAL;
+    if (!opt) {                                            // forward + backward only
+        if (tiled(shape)) return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream));
+        return stgcn_train_step(shape, args, nullptr, static_cast<hipStream_t>(stream), path);
+    }
+    if ((opt->step < 1 && !opt->step_state) || args->dpred) return RULGNN_EINVAL;
     if (opt->params != args->params) return RULGNN_EINVAL;
     rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
     if (rc != RULGNN_OK) return rc;
@@ -166,7 +177,7 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_st
         return bn_running_update(opt->bn_stats, args->bn_batch, shape->num_layers, shape->batch * (int64_t)shape->num_patch,
                                  opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
     }
-    return stgcn_train_step(shape, args, opt, st);
+    return stgcn_train_step(shape, args, opt, st, path);
 }
 
 int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }

@@ -257,11 +257,12 @@ constexpr int phase_min_waves(int RW, int KIND, int IDX) {
 // NFIX: num_patch known at compile time (14 = C-MAPSS, the headline shape; 0 = read it from the arguments).  With a constant
 // pitch the 10 element addresses of a saved tensor become immediate offsets of one base: ~60 64-bit address computations per
 // tile and the scalar registers that carried them disappear.
+// The body is a device function so that the same code runs as one kernel per phase (the chain, below) and as the stages of the
+// single cooperative launch that small batches use (stgcn_train_coop_kernel).
 template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0>
-__global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
-                                                                  const float* __restrict__ prm,
-                                                                  const float* __restrict__ gy,   // y or dpred (TOP only)
-                                                                  TrainK a) {
+__device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, const float* __restrict__ prm,
+                                                 const float* __restrict__ gy,   // y or dpred (TOP only)
+                                                 const TrainK& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TRW = RW, TSPW = 64 / RW, TWS = wstride<RW>();
     using R16 = Row<RW>;                       // (name kept from the first, 16-lane-only version)
@@ -875,6 +876,13 @@ __global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_t
     }
 }
 
+template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0>
+__global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+                                                                  const float* __restrict__ prm,
+                                                                  const float* __restrict__ gy, TrainK a) {
+    train_phase_body<RW, L, KIND, IDX, NFIX, PFIX>(gx, prm, gy, a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // finalize: per-block partial rows + BatchNorm cells -> flat gradient, loss, batch statistics
 // ------------------------------------------------------------------------------------------------
@@ -907,32 +915,37 @@ struct FinalizeK {
 // combined in a fixed order (bit-reproducible).  One wavefront per parameter, as before round-1h, read the rows with a
 // 6-KB stride: 12 us for 7.8 MB.
 constexpr int FIN_COLS = 64, FIN_SLICES = 16;
-__global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_kernel(FinalizeK f) {
-    __shared__ float part[FIN_SLICES][FIN_COLS];
+
+// One unit = FIN_COLS consecutive parameters.  `part` is a [FIN_SLICES][FIN_COLS] LDS scratch; the calling workgroup's wavefronts
+// split the FIN_SLICES row slices among themselves (SPW slices per wavefront: 1 in the finalize kernel with its 16 wavefronts, 4 in
+// the cooperative kernel with its 4) -- every slice is summed in the same order by whoever owns it and the slices are combined in a
+// fixed order, so both launch forms produce the same bits.
+template <int SPW>
+__device__ __forceinline__ void finalize_unit(const FinalizeK& f, int unit, float (*part)[FIN_COLS], int lane, int wave) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
     const float lr_over_bc1 = step_scratch(f.cells, L)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cells, L)->inv_sqrt_bc2;
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const double cnt = step_scratch(f.cells, L)->bn_count;
-    if (f.write_grads) {
-        const int p = blockIdx.x * FIN_COLS + lane;
-        const bool valid = p < f.pcount;
-        int nblk = 0;
-        bool from_cells = false;
-        int bn = 0, which = 0, c = 0;
-        if (valid) {
-            if (p >= L * LS) {
-                nblk = f.grid_top;
-            } else {
-                const int l = p / LS, o = p % LS;
-                if (o < off_conv_w(N, 0)) nblk = f.grid_g[2 * l];                     // theta w/b
-                else {
-                    const int blk = o >= off_conv_w(N, 1) ? 1 : 0;
-                    const int oo = o - off_conv_w(N, blk);
-                    nblk = f.grid_g[2 * l + blk];
-                    if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
-                }
+    const int p = unit * FIN_COLS + lane;
+    const bool valid = p < f.pcount;
+    int nblk = 0;
+    bool from_cells = false;
+    int bn = 0, which = 0, c = 0;
+    if (valid) {
+        if (p >= L * LS) {
+            nblk = f.grid_top;
+        } else {
+            const int l = p / LS, o = p % LS;
+            if (o < off_conv_w(N, 0)) nblk = f.grid_g[2 * l];                     // theta w/b
+            else {
+                const int blk = o >= off_conv_w(N, 1) ? 1 : 0;
+                const int oo = o - off_conv_w(N, blk);
+                nblk = f.grid_g[2 * l + blk];
+                if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
             }
         }
+    }
+#pragma unroll
+    for (int q = 0; q < SPW; ++q) {
+        const int slice = wave * SPW + q;
         float v = 0.f;
         if (valid && !from_cells) {
             // latency-bound: sixteen independent row reads in flight per lane, then the tail
@@ -949,52 +962,65 @@ __global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_ke
             for (; b < nblk; b += FIN_SLICES) v += col[(size_t)b * f.pcount];
         }
         part[slice][lane] = v;
-        __syncthreads();
-        if (slice == 0 && valid) {
-            if (from_cells) {
-                // d gamma = sum dy*xhat, d beta = sum dy
-                v = (float)(cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c) * (double)f.cell_grad_scale);
-            } else {
-                v = 0.f;
+    }
+    __syncthreads();
+    if (wave == 0 && valid) {
+        float v;
+        if (from_cells) {
+            // d gamma = sum dy*xhat, d beta = sum dy
+            v = (float)(cell_sum(f.cells, L, cell_bwd(L) + (bn * 2 + (which == 0 ? 1 : 0)) * F + c) * (double)f.cell_grad_scale);
+        } else {
+            v = 0.f;
 #pragma unroll
-                for (int sl = 0; sl < FIN_SLICES; ++sl) v += part[sl][lane];
-            }
-            f.grads[p] = v;
-            if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
-                const float pi = f.params[p];
-                const float gi = fmaf(f.weight_decay, pi, v);
-                const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
-                const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
-                f.exp_avg[p] = mi;
-                f.exp_avg_sq[p] = vi;
-                f.params[p] = pi - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + f.eps));
-            }
+            for (int sl = 0; sl < FIN_SLICES; ++sl) v += part[sl][lane];
+        }
+        f.grads[p] = v;
+        if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
+            const float pi = f.params[p];
+            const float gi = fmaf(f.weight_decay, pi, v);
+            const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
+            const float vi = fmaf(f.beta2, f.exp_avg_sq[p], (1.f - f.beta2) * gi * gi);
+            f.exp_avg[p] = mi;
+            f.exp_avg_sq[p] = vi;
+            f.params[p] = pi - lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + f.eps));
         }
     }
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0 && f.write_loss) f.loss[0] = (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
-        for (int i = threadIdx.x; i < 2 * L * F; i += blockDim.x) {
-            const int b = i / F, c = i % F;
-            const double s2 = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 1) * F + c);
-            const double mean = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 0) * F + c) / cnt;
-            double var = s2 / cnt - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            if (f.moment_weight > 0.f) {
-                f.bn_batch[(b * 2 + 0) * F + c] = (float)(mean * (double)f.moment_weight);
-                f.bn_batch[(b * 2 + 1) * F + c] = (float)(s2 / cnt * (double)f.moment_weight);
-            } else {
-                f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
-                f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
-            }
-            if (f.fused_opt && f.bn_running) {          // nn.BatchNorm1d running statistics (unbiased running variance)
-                const float unbias = cnt > 1.0 ? (float)(cnt / (cnt - 1.0)) : 1.f;
-                float* rm = f.bn_running + (b * 2 + 0) * F + c;
-                float* rv = f.bn_running + (b * 2 + 1) * F + c;
-                *rm = (1.f - f.bn_momentum) * *rm + f.bn_momentum * (float)mean;
-                *rv = (1.f - f.bn_momentum) * *rv + f.bn_momentum * ((float)var * unbias);
-            }
+    __syncthreads();
+}
+
+// loss, batch statistics and (fused optimizer) the BatchNorm running statistics: one workgroup
+__device__ __forceinline__ void finalize_stats(const FinalizeK& f, int tid, int nthreads) {
+    const int N = f.N, L = f.L;
+    (void)N;
+    const double cnt = step_scratch(f.cells, L)->bn_count;
+    if (tid == 0 && f.write_loss) f.loss[0] = (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
+    for (int i = tid; i < 2 * L * F; i += nthreads) {
+        const int b = i / F, c = i % F;
+        const double s2 = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 1) * F + c);
+        const double mean = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 0) * F + c) / cnt;
+        double var = s2 / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        if (f.moment_weight > 0.f) {
+            f.bn_batch[(b * 2 + 0) * F + c] = (float)(mean * (double)f.moment_weight);
+            f.bn_batch[(b * 2 + 1) * F + c] = (float)(s2 / cnt * (double)f.moment_weight);
+        } else {
+            f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
+            f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
+        }
+        if (f.fused_opt && f.bn_running) {          // nn.BatchNorm1d running statistics (unbiased running variance)
+            const float unbias = cnt > 1.0 ? (float)(cnt / (cnt - 1.0)) : 1.f;
+            float* rm = f.bn_running + (b * 2 + 0) * F + c;
+            float* rv = f.bn_running + (b * 2 + 1) * F + c;
+            *rm = (1.f - f.bn_momentum) * *rm + f.bn_momentum * (float)mean;
+            *rv = (1.f - f.bn_momentum) * *rv + f.bn_momentum * ((float)var * unbias);
         }
     }
+}
+
+__global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_kernel(FinalizeK f) {
+    __shared__ float part[FIN_SLICES][FIN_COLS];
+    if (f.write_grads) finalize_unit<1>(f, blockIdx.x, part, threadIdx.x & 63, threadIdx.x >> 6);
+    if (blockIdx.x == 0) finalize_stats(f, threadIdx.x, blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1035,7 +1061,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
-    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch);
+    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64;   // + grid-barrier counter
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
@@ -1202,9 +1228,9 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 // Head of every step: clears the reduction cells (what a memset did before) and writes the step scratch -- dropout keys of
 // (seed, step) and, for the fused optimizer, Adam's bias corrections.  With a device step state the counters are advanced and
 // read there (hipGraph replay), else they come from the arguments.
-__global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st, uint64_t seed,
-                                     uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1,
-                                     float beta2, double bn_count) {
+__device__ __forceinline__ void prepare_body(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st,
+                                             uint64_t seed, uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step,
+                                             float lr, float beta1, float beta2, double bn_count) {
     for (int i = threadIdx.x; i < nzero * CELL_REPLICAS; i += blockDim.x) cells[(i / nzero) * stride + zero_from + i % nzero] = 0.0;
     if (threadIdx.x != 0) return;
     sc->bn_count = bn_count;
@@ -1221,11 +1247,172 @@ __global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, in
     }
 }
 
+__global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st, uint64_t seed,
+                                     uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1,
+                                     float beta2, double bn_count) {
+    prepare_body(cells, zero_from, nzero, stride, sc, st, seed, step, L, new_forward, has_adam, adam_step, lr, beta1, beta2, bn_count);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small batches: the whole step as ONE launch (RULGNN_STEP_COOP; an experiment kept as an explicit, tested option -- it does NOT pay).
+// At the reference protocol's batch size (100; configs/hparams.py:223) the chain is eleven dependent kernels of ~9 us each.  When
+// every tile of the batch has its own resident wavefront the same phase bodies run back to back inside one kernel, the BatchNorm
+// reductions behind device-side grid barriers instead of kernel boundaries: prepare | F_0 .. F_{2L-1} | TOP | G_{2L-1} .. G_0 |
+// finalize (+Adam, running statistics).  Same grid in every stage as the chain uses for such a batch (one tile per wavefront), same
+// per-workgroup partial rows, same finalize arithmetic: bit-identical to the chain (tests/test_coop_step_gpu.py).  Measured: 97 us
+// against the chain's 89 us at batch 100 -- the ~9 us of a phase are its prologue and one single-wavefront pass, not its launch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float* coop_smem() {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    return smem;
+}
+
+struct CoopK {
+    unsigned* barrier;          // one zeroed 32-bit counter in the workspace
+    int wa_f0, wa_g, wa_top;    // per-wavefront LDS area of F_0 / the G phases / TOP (wave_area_for)
+    StepState* st;              // optional device step state
+    uint64_t seed, step;
+    int has_adam;
+    int64_t adam_step;
+    float lr, beta1, beta2;
+    double bn_count;
+    FinalizeK fin;
+};
+
+__device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned& epoch) {
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * gridDim.x;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+}
+
+template <int RW, int L, int NFIX, int PFIX, int I>
+struct CoopChain {
+    static __device__ __forceinline__ void forward(const float* gx, const float* prm, const TrainK& a, const CoopK& c, unsigned& epoch) {
+        if constexpr (I > 0) CoopChain<RW, L, NFIX, PFIX, I - 1>::forward(gx, prm, a, c, epoch);
+        TrainK b = a;
+        b.wave_area_floats = I == 0 ? c.wa_f0 : 0;
+        train_phase_body<RW, L, PH_F, I, NFIX, (I == 0 ? PFIX : 0)>(gx, prm, nullptr, b);
+        grid_barrier(c.barrier, epoch);
+    }
+    static __device__ __forceinline__ void backward(const float* gx, const float* prm, const float* gy, const TrainK& a, const CoopK& c,
+                                                    unsigned& epoch) {
+        TrainK b = a;
+        b.wave_area_floats = c.wa_g;
+        train_phase_body<RW, L, PH_G, I, NFIX, 0>(gx, prm, gy, b);
+        grid_barrier(c.barrier, epoch);
+        if constexpr (I > 0) CoopChain<RW, L, NFIX, PFIX, I - 1>::backward(gx, prm, gy, a, c, epoch);
+    }
+};
+
+template <int RW, int L, int NFIX, int PFIX>
+__global__ __launch_bounds__(BLOCK) void stgcn_train_coop_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+                                                                 const float* __restrict__ gy, TrainK a, CoopK c) {
+    unsigned epoch = 0;
+    if (blockIdx.x == 0)
+        prepare_body(a.cells, 0, cell_stride(L), cell_stride(L), step_scratch(a.cells, L), c.st, c.seed, c.step, L, 1, c.has_adam,
+                     c.adam_step, c.lr, c.beta1, c.beta2, c.bn_count);
+    grid_barrier(c.barrier, epoch);
+    CoopChain<RW, L, NFIX, PFIX, 2 * L - 1>::forward(gx, prm, a, c, epoch);
+    {
+        TrainK b = a;
+        b.wave_area_floats = c.wa_top;
+        train_phase_body<RW, L, PH_TOP, 0, NFIX, 0>(gx, prm, gy, b);
+        grid_barrier(c.barrier, epoch);
+    }
+    CoopChain<RW, L, NFIX, PFIX, 2 * L - 1>::backward(gx, prm, gy, a, c, epoch);
+    // finalize: the parameter units over the workgroups, then the statistics on workgroup 0
+    float(*part)[FIN_COLS] = reinterpret_cast<float(*)[FIN_COLS]>(coop_smem());
+    const int units = (c.fin.pcount + FIN_COLS - 1) / FIN_COLS;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) finalize_unit<FIN_SLICES / WAVES_PER_BLOCK>(c.fin, u, part, threadIdx.x & 63, threadIdx.x >> 6);
+    if (blockIdx.x == 0) finalize_stats(c.fin, threadIdx.x, blockDim.x);
+}
+
+// Host side of the cooperative step: applicable when every tile gets its own co-resident wavefront.
+template <int RW, int L, int NFIX, int PFIX>
+static int launch_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream, const TrainK& k,
+                       const WsLayout& w, const TileGeom& g, const rulgnn_adam_args* opt, double bn_count) {
+    auto kern = stgcn_train_coop_kernel<RW, L, NFIX, PFIX>;
+    CoopK c;
+    c.wa_f0 = wave_area_for(PH_F, 0, g);
+    c.wa_g = wave_area_for(PH_G, 0, g);
+    c.wa_top = wave_area_for(PH_TOP, 0, g);
+    int wa = c.wa_f0 > c.wa_g ? c.wa_f0 : c.wa_g;
+    wa = wa > c.wa_top ? wa : c.wa_top;
+    size_t lds = train_lds_bytes(RW, L, wa);
+    if (lds < sizeof(float) * FIN_SLICES * FIN_COLS) lds = sizeof(float) * FIN_SLICES * FIN_COLS;
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    const int64_t grid = (k.ntiles + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (grid > w.max_grid) return RULGNN_EUNSUPPORTED;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RULGNN_EHIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds) != hipSuccess || per_cu < 1) return RULGNN_EUNSUPPORTED;
+    // every workgroup must be resident for the grid barriers; one workgroup per CU keeps them evenly spread as well
+    if (grid > (int64_t)cus) return RULGNN_EUNSUPPORTED;
+    const bool fused_adam = opt != nullptr;
+    void* adam_state = fused_adam ? opt->step_state : nullptr;
+    if (adam_state && a->step_state && adam_state != a->step_state) return RULGNN_EINVAL;
+    StepScratch* sc = step_scratch(k.cells, L);
+    c.barrier = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sc) + sizeof(StepScratch));
+    c.st = a->step_state ? static_cast<StepState*>(a->step_state) : nullptr;      // as the chain's prepare kernel
+    c.seed = a->seed; c.step = a->step;
+    c.has_adam = fused_adam ? 1 : 0;
+    c.adam_step = fused_adam ? opt->step : 0;
+    c.lr = fused_adam ? opt->lr : 0.f; c.beta1 = fused_adam ? opt->beta1 : 0.f; c.beta2 = fused_adam ? opt->beta2 : 0.f;
+    c.bn_count = bn_count;
+    FinalizeK& f = c.fin;
+    f.gpart = k.gpart; f.cells = k.cells;
+    f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
+    f.grid_top = (int)grid;
+    for (int i = 0; i < 16; ++i) f.grid_g[i] = (int)grid;
+    f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.moment_weight = a->bn_moment_weight;
+    f.cell_grad_scale = 1.0f;
+    f.fused_opt = fused_adam ? 1 : 0;
+    f.params = fused_adam ? opt->params : nullptr; f.exp_avg = fused_adam ? opt->exp_avg : nullptr;
+    f.exp_avg_sq = fused_adam ? opt->exp_avg_sq : nullptr; f.bn_running = fused_adam ? opt->bn_stats : nullptr;
+    f.beta1 = fused_adam ? opt->beta1 : 0.f; f.beta2 = fused_adam ? opt->beta2 : 0.f; f.eps = fused_adam ? opt->eps : 0.f;
+    f.weight_decay = fused_adam ? opt->weight_decay : 0.f; f.bn_momentum = fused_adam ? opt->bn_momentum : 0.f;
+    f.write_grads = 1;
+    f.write_loss = (k.has_dpred == 0) && a->loss;
+    const float* gy = a->dpred ? a->dpred : a->y;
+    if (hipMemsetAsync(c.barrier, 0, sizeof(unsigned), stream) != hipSuccess) return RULGNN_EHIP;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds, stream, a->x, a->params, gy, k, c);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+template <int RW, int L>
+static int run_train_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream, const TrainK& k,
+                          const WsLayout& w, const TileGeom& g, const rulgnn_adam_args* opt, double bn_count) {
+    if constexpr (RW == 16 && L == 2) {
+        if (k.N == 14 && k.P == 30) return launch_coop<RW, L, 14, 30>(s, a, stream, k, w, g, opt, bn_count);
+        if (k.N == 14 && k.P == 50) return launch_coop<RW, L, 14, 50>(s, a, stream, k, w, g, opt, bn_count);
+    }
+    return launch_coop<RW, L, 0, 0>(s, a, stream, k, w, g, opt, bn_count);
+}
+
 template <int RW, int L>
 static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                        TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt, const SyncHook* hook) {
+                        TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt, const SyncHook* hook, int path) {
     int rc = RULGNN_OK;
     const double bn_count = (double)(hook ? a->global_batch : s->batch) * (double)s->num_patch;
+    // RULGNN_STEP_AUTO is the chain: measured on MI355X the cooperative launch is SLOWER at every batch it applies to (batch 100:
+    // 97 vs 89 us, batch 4096: 275 vs 104 us) -- a phase costs its prologue plus one single-wavefront pass (~2000 instructions at one
+    // issue per ~5 cycles), not its launch, and eleven grid barriers cost more than the ten launches they replace
+    if (path == RULGNN_STEP_COOP) {
+        if (mode != TM_FWDBWD || hook) return RULGNN_EUNSUPPORTED;
+        return run_train_coop<RW, L>(s, a, stream, k, w, lds, opt, bn_count);
+    }
     const float* gy = a->dpred ? a->dpred : a->y;
 
     StepScratch* sc = step_scratch(k.cells, L);
@@ -1286,14 +1473,14 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
 
 template <int L>
 static int run_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                     const rulgnn_adam_args* opt, const SyncHook* hook) {
+                     const rulgnn_adam_args* opt, const SyncHook* hook, int path) {
     TrainK k;
     WsLayout w;
     TileGeom lds;
     const int rc = setup_train<L>(s, a, mode, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
-    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds, opt, hook);
-    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds, opt, hook);
+    if (lds.RW == 16) return run_train_rw<16, L>(s, a, mode, stream, k, w, lds, opt, hook, path);
+    if constexpr (L <= 2) return run_train_rw<64, L>(s, a, mode, stream, k, w, lds, opt, hook, path);
     return RULGNN_EUNSUPPORTED;
 }
 
@@ -1337,18 +1524,18 @@ int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
 }
 
 static int dispatch_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
-                          const rulgnn_adam_args* opt = nullptr, const SyncHook* hook = nullptr) {
+                          const rulgnn_adam_args* opt = nullptr, const SyncHook* hook = nullptr, int path = RULGNN_STEP_AUTO) {
     switch (s->num_layers) {
-        case 1: return run_train<1>(s, a, mode, stream, opt, hook);
-        case 2: return run_train<2>(s, a, mode, stream, opt, hook);
-        case 3: return run_train<3>(s, a, mode, stream, opt, hook);
+        case 1: return run_train<1>(s, a, mode, stream, opt, hook, path);
+        case 2: return run_train<2>(s, a, mode, stream, opt, hook, path);
+        case 3: return run_train<3>(s, a, mode, stream, opt, hook, path);
         default: return RULGNN_EUNSUPPORTED;
     }
 }
 
 int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const rulgnn_adam_args* opt,
-                     hipStream_t st) {
-    return dispatch_train(s, a, TM_FWDBWD, st, opt);
+                     hipStream_t st, int path) {
+    return dispatch_train(s, a, TM_FWDBWD, st, opt, nullptr, path);
 }
 
 int stgcn_train_forward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {

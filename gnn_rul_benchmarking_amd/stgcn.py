@@ -100,6 +100,9 @@ class ST_GCN_model(nn.Module):
         self.patch_size = int(patch_size)
         self.num_layers = int(num_layers)
         self.dropout_p = float(dropout)
+        # launch form of the training step (rulgnn.h RULGNN_STEP_*): AUTO = the phase chain; STEP_COOP = one launch with device-side
+        # grid barriers for batches of at most 4 x #CUs tiles (same bits, measured slower: kept as an explicit option)
+        self.step_path = _lib.STEP_AUTO
         self.k = int(k)
         in_features = NUM_STATS
         # same construction order as the reference => same RNG consumption => same initial weights
@@ -300,8 +303,8 @@ class ST_GCN_model(nn.Module):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket)
-        _lib.check(_lib.load().rulgnn_stgcn_train_fwdbwd_f32(C.byref(shp), C.byref(a), _stream()),
-                   "rulgnn_stgcn_train_fwdbwd_f32")
+        _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), None, int(self.step_path), _stream()),
+                   "rulgnn_stgcn_train_step_path_f32")
         if update_running_stats:
             self._after_train_forward(x2d.size(0))
         return self._pred_buf, self._grad_flat[self.num_live]
@@ -356,8 +359,8 @@ class ST_GCN_model(nn.Module):
         o = _lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
                           float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                           float(g["weight_decay"]), 0.1, self._step_state.data_ptr() if self._step_state is not None else None)
-        _lib.check(_lib.load().rulgnn_stgcn_train_step_f32(C.byref(shp), C.byref(a), C.byref(o), _stream()),
-                   "rulgnn_stgcn_train_step_f32")
+        _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), C.byref(o), int(self.step_path), _stream()),
+                   "rulgnn_stgcn_train_step_path_f32")
         self._nbt_pending += 1
         return self._pred_buf, self._grad_flat[self.num_live]
 

@@ -177,6 +177,25 @@ typedef struct rulgnn_adam_args {
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                 const rulgnn_adam_args *opt, void *stream);
 
+/* The step with the launch form chosen by the caller (the entries above are RULGNN_STEP_AUTO); `opt` may be NULL (= forward +
+ * backward only, rulgnn_stgcn_train_fwdbwd_f32).  For num_patch <= 64 there are two forms of the same arithmetic:
+ *   RULGNN_STEP_CHAIN  prepare | 2L forward phase kernels | head | 2L backward phase kernels | finalize: 4L + 3 launches; any batch;
+ *   RULGNN_STEP_COOP   the same phase bodies inside ONE launch, the BatchNorm reductions behind device-side grid barriers -- for
+ *                      batches whose every 4-sample tile (1-sample for num_patch > 16) gets its own resident wavefront: at most
+ *                      4 x #CUs tiles (4096 samples on an MI355X at num_patch <= 16); RULGNN_EUNSUPPORTED otherwise.  Bit-identical
+ *                      results to the chain (same per-workgroup partial sums, same finalize order).  Built for the reference
+ *                      protocol's regime (batch_size 100, configs/hparams.py:223) and measured SLOWER there (97 vs 89 us per step:
+ *                      a phase costs its prologue and one single-wavefront pass, not its launch), so it is an explicit option
+ *                      only.  The workgroups spin on a counter in the workspace: do not share the device with a kernel that
+ *                      waits on this stream.
+ *   RULGNN_STEP_AUTO   = RULGNN_STEP_CHAIN.
+ * num_patch > 64 (tiled path) ignores `path`. */
+#define RULGNN_STEP_AUTO  0
+#define RULGNN_STEP_CHAIN 1
+#define RULGNN_STEP_COOP  2
+int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                     const rulgnn_adam_args *opt, int32_t path, void *stream);
+
 /* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
  * backward), 2L+1+j = G_{2L-1-j} (BatchNorm/conv/theta backward).  rulgnn_stgcn_train_phase_f32 launches

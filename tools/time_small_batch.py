@@ -1,0 +1,36 @@
+"""ST_GCN.update at small batches: phase chain vs the cooperative single launch (us per step)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from gnn_rul_benchmarking_amd import _lib                      # noqa: E402
+from gnn_rul_benchmarking_amd.algorithms import ST_GCN         # noqa: E402
+
+dev = torch.device("cuda:0")
+for B in [int(v) for v in sys.argv[1:]] or [100, 256, 1024, 2048, 4096]:
+    row = []
+    for name, path in (("chain", _lib.STEP_CHAIN), ("coop", _lib.STEP_COOP)):
+        torch.manual_seed(0)
+        a = ST_GCN({"num_patch": 14, "patch_size": 30, "dropout": 0.2}, {"learning_rate": 1e-4, "weight_decay": 1e-4}, dev)
+        a.to(dev).train()
+        a.sync_loss = False
+        a.model.step_path = path
+        X, y = torch.rand(B, 14, 30, device=dev), torch.rand(B, 1, device=dev)
+        try:
+            for _ in range(20):
+                a.update(X, y, 1)
+        except RuntimeError as e:
+            row.append(f"{name}: n/a")
+            continue
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                a.update(X, y, 1)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 200 * 1e6)
+        row.append(f"{name}: {sorted(ts)[2]:7.1f} us")
+    print(f"batch {B:6d}  " + "   ".join(row), flush=True)
