@@ -80,7 +80,9 @@ class _Table:
 class CMAPSS(_Table):
     _astgcnn_nodes = 14
 
-    def __init__(self, dataset_id, window=30):
+    def __init__(self, dataset_id, window=50):
+        # default window = the reference's preprocessed C-MAPSS windows (data_model_configs.CMAPSS.sequence_len = 50); bench.py and
+        # BASELINE.json config 0 use window 30 and pass it explicitly (--window 30 / patch_size)
         self._rows = {fd: {'num_patch': 14, 'patch_size': int(window), 'dropout': 0.2}
                       for fd in ('FD001', 'FD002', 'FD003', 'FD004')}
         super().__init__(dataset_id)

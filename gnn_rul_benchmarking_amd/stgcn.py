@@ -88,6 +88,11 @@ class _TrainFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpred):
         model = ctx.model
+        B = ctx.x2d.size(0)
+        if model._tape_step.get(B) != ctx.step or B not in model._bufs:
+            raise RuntimeError("ST_GCN_model: another training forward of this batch size ran between this forward and its backward "
+                               "(or its workspace was evicted); the saved activations live in one workspace per batch size, not per "
+                               "call, and were overwritten. Call backward() before the next model(x), or use Algorithm.update.")
         grads = model._train_backward(ctx.x2d, dpred.contiguous().view(-1).float(), ctx.step)
         out = [grads[off:off + n].view(shape).clone() for (off, n, shape) in model._live_slices]
         return (None, None, *out)
@@ -103,6 +108,7 @@ class ST_GCN_model(nn.Module):
         # launch form of the training step (rulgnn.h RULGNN_STEP_*): AUTO = the phase chain; STEP_COOP = one launch with device-side
         # grid barriers for batches of at most 4 x #CUs tiles (same bits, measured slower: kept as an explicit option)
         self.step_path = _lib.STEP_AUTO
+        self._tape_step = {}            # batch size -> step whose activations its workspace holds (autograd-path hazard check)
         self.k = int(k)
         in_features = NUM_STATS
         # same construction order as the reference => same RNG consumption => same initial weights
@@ -238,6 +244,7 @@ class ST_GCN_model(nn.Module):
     def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False):
         B = x2d.size(0)
         ws = self._workspace(shp, B)
+        self._tape_step[B] = int(step)
         a = _lib.StgcnTrainArgs()
         a.x = x2d.data_ptr()
         a.y = y.data_ptr() if y is not None else None
