@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="--family FC_STGNN only: bf16 = BASELINE.json's 'FC_STGNN ... bf16' variant (bf16 operands on the row-projection "
                          "matrix-core GEMMs, fp32 accumulate / BatchNorm / graphs / weight gradients); reported separately, it does not meet 1e-4")
-    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN"],
+    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN", "RGCNU"],
                     help="ST_GCN (default) is the headline benchmark; the others run the same contract on the SURVEY section 8d "
                          "configuration of that model family")
     return ap.parse_args()
@@ -264,6 +264,9 @@ FAMILY_CONFIGS = {
     # SURVEY 8f rank 3; forward FLOPs per sample: ChebNet projection 14*150*64*2, graph terms 2*14*14*50*2 + cdist 14*14*50*3,
     # GRU input projection 14*64*192*2 (one step, h0 = 0), fc 896*2
     "STGNN": ("CMAPSS", "FD004", 256, (14, 50), 0.68e6),
+    # SURVEY 8f rank 3; forward FLOPs per sample: adjacency 2*(2*14*14*50) + 2*(2*14*14*14), 50 graphs x (2*14*14*(1+32) + 2*14*32*32),
+    # LSTM 50 steps x 2*4*32*(14+32), fusion 2*32*14*50 + 2*32*32*3*50 + 2*2*1600
+    "RGCNU": ("CMAPSS", "FD004", 256, (14, 50), 0.09e6 + 2.08e6 + 0.59e6 + 0.36e6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
 

@@ -97,6 +97,18 @@ class FcstgnnArgs(C.Structure):
                 ("compute_dtype", C.c_int32)]
 
 
+class RgcnuShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("hidden_dim", C.c_int32),
+                ("encoder_hidden_dim", C.c_int32), ("kernel_size", C.c_int32), ("alpha", C.c_float)]
+
+
+class RgcnuArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("std_pred", C.c_void_p), ("loss", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64), ("sample_offset", C.c_int64), ("dropout_p", C.c_float),
+                ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32)]
+
+
 DTYPE_F32, DTYPE_BF16 = 0, 1      # include/rulgnn.h RULGNN_DTYPE_*
 HAGCN_TOPK_SLOTS = 16
 
@@ -125,6 +137,11 @@ class BilstmArgs(C.Structure):
 ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _SIGNATURES = {
+    "rulgnn_rgcnu_param_count": (C.c_int64, [C.POINTER(RgcnuShape)]),
+    "rulgnn_rgcnu_workspace_bytes": (C.c_size_t, [C.POINTER(RgcnuShape)]),
+    "rulgnn_rgcnu_forward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),
+    "rulgnn_rgcnu_backward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),
+    "rulgnn_rgcnu_fwdbwd_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
     "rulgnn_stgcn_param_count": (C.c_int64, [C.c_int32, C.c_int32]),

@@ -16,6 +16,7 @@ from .optim import FusedAdam
 from .astgcnn import ASTGCNN_model
 from .fcstgnn import FC_STGNN_RUL
 from .hagcn import HAGCN_model
+from .rgcnu import RGCNU_model
 from .stconv import ST_Conv_model
 from .stgcn import ST_GCN_model
 from .stgnn import STGNN_model
@@ -342,4 +343,46 @@ class STGNN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class RGCNU(Algorithm):
+    """RGCNU training wrapper (reference algorithms.py:250-296): ``update`` = train-mode forward of both heads + MSE of the first
+    head + backward + Adam in one C call (kernels of csrc/rgcnu.hip, the one-direction LSTM of csrc/bilstm.hip, the fused Adam
+    kernel).  ``lambda`` (the weight of the reference's commented-out uncertainty loss, :266-282) is kept as ``lambda_hy`` and,
+    like there, unused.  No BatchNorm: samples are independent except for the adjacency-tiling quirk (rgcnu.py), which couples the
+    samples of one call -- data parallelism shards the batch like the other families and therefore pairs graphs with the adjacencies
+    of the SHARD (a different, equally arbitrary pairing than the single-process batch; stated, not hidden)."""
+
+    supports_graphs = False
+
+    def __init__(self, configs, hparams, device):
+        super(RGCNU, self).__init__(configs)
+        self.model = RGCNU_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.lambda_hy = hparams.get("lambda", 0.1)
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if not self.model.training:
+            raise RuntimeError("update() needs algorithm.train() (SCL's dropout)")
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        else:
+            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return self._finish(loss)
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd (algorithms.py:284-296); same result as ``update``."""
+        predicted_RUL, std_RUL = self.model(X, train=True)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}

@@ -33,7 +33,7 @@ struct LstmGeom {
 __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
     if (!s) return RULGNN_EINVAL;
     if (s->seq_len < 1 || s->num_seq < 1 || s->input_dim < 1 || s->hidden_dim < 1) return RULGNN_EINVAL;
-    if (s->hidden_dim > 128 || s->input_dim > 1024 || s->num_seq > 64) return RULGNN_EUNSUPPORTED;
+    if (s->hidden_dim > 128 || s->input_dim > 1024 || s->num_seq > 65535) return RULGNN_EUNSUPPORTED;
     if (s->seq_len * (int64_t)s->num_seq * 4 * s->hidden_dim > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
     g->T = s->seq_len;
     g->Bq = s->num_seq;
@@ -251,7 +251,9 @@ size_t bilstm_workspace_bytes(const rulgnn_bilstm_shape* s) {
         if (rc_ != RULGNN_OK) return rc_;  \
     } while (0)
 
-int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st) {
+// ndir = 2: the bidirectional layer of the ABI; ndir = 1: the forward direction alone (nn.LSTM(bidirectional=False), e.g. RGCNU's
+// TDL, models/RGCNU/Model.py:46-53) -- same kernels, half the workgroups, out = h of direction 0
+int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st, int ndir) {
     LstmGeom g;
     LS_RC(lstm_geometry(s, &g));
     if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
@@ -259,22 +261,25 @@ int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hi
     (void)hipGetLastError();
     const int R = (int)g.rows;
     // input projections of both directions: gi[dir] = x W_ih[dir]^T   ([rows, I] x [I, 4H])
-    for (int d = 0; d < 2; ++d)
+    if (ndir != 1 && ndir != 2) return RULGNN_EINVAL;
+    for (int d = 0; d < ndir; ++d)
         LS_RC(sgemm(a->x, g.I, 1, a->w_ih[d], g.I, 1, ws + g.o_gi + (int64_t)d * g.rows * g.H4, g.H4, R, g.H4, g.I, false, st));
     const int threads = (g.H4 + 63) & ~63;
+    const int d1 = ndir == 2 ? 1 : 0;                 // the one-direction launch never selects direction 1
     if (g.H <= 64)
-        hipLaunchKernelGGL(lstm_forward_kernel<64>, dim3(2 * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
-                           a->w_hh[1], a->b_ih[0], a->b_hh[0], a->b_ih[1], a->b_hh[1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
+        hipLaunchKernelGGL(lstm_forward_kernel<64>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
+                           a->w_hh[d1], a->b_ih[0], a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
                            ws + g.o_hprev);
     else
-        hipLaunchKernelGGL(lstm_forward_kernel<128>, dim3(2 * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
-                           a->w_hh[1], a->b_ih[0], a->b_hh[0], a->b_ih[1], a->b_hh[1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
+        hipLaunchKernelGGL(lstm_forward_kernel<128>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
+                           a->w_hh[d1], a->b_ih[0], a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
                            ws + g.o_hprev);
-    hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
+    if (ndir == 2) hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
+    else hipLaunchKernelGGL(lstm_copy_kernel, dim3((unsigned)((g.rows * g.H + 255) / 256)), dim3(256), 0, st, (const float*)(ws + g.o_h), a->out, (int)(g.rows * g.H));
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
-int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st) {
+int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t st, int ndir) {
     LstmGeom g;
     LS_RC(lstm_geometry(s, &g));
     if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
@@ -282,16 +287,18 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
     (void)hipGetLastError();
     const int R = (int)g.rows, H = g.H, H4 = g.H4, I = g.I;
     const int threads = (H4 + 63) & ~63;
+    if (ndir != 1 && ndir != 2) return RULGNN_EINVAL;
+    const int d1 = ndir == 2 ? 1 : 0;
     if (H <= 64)
-        hipLaunchKernelGGL(lstm_backward_kernel<64>, dim3(2 * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[1],
+        hipLaunchKernelGGL(lstm_backward_kernel<64>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1],
                            (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
     else
-        hipLaunchKernelGGL(lstm_backward_kernel<128>, dim3(2 * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[1],
+        hipLaunchKernelGGL(lstm_backward_kernel<128>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1],
                            (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
     float* one = ws + g.o_one;
     float* split = ws + g.o_split;
     hipLaunchKernelGGL(lstm_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
-    for (int d = 0; d < 2; ++d) {
+    for (int d = 0; d < ndir; ++d) {
         const float* dg = ws + g.o_dgates + (int64_t)d * g.rows * H4;
         // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db = column sums ; dx (+)= dG W_ih
         LS_RC(sgemm_splitk(dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R, false, split, st));

@@ -1,0 +1,626 @@
+// RGCNU on gfx950 (a GCNLayer user).
+// Reference path replaced: RGCNU_model.forward -- models/RGCNU/Model.py:96-119 (adj_construction :80-93, SCL :25-43 with GCNLayer :7-22,
+// TDL :46-53, FusionModule :56-78) -- and RGCNU.update, algorithms/algorithms.py:284-296 (MSE of the first head, backward, Adam).
+//
+// Everything per sample is small (N <= 32 sensor nodes, L <= 64 time steps, hidden widths <= 64), so the step is a handful of
+// one-workgroup-per-sample kernels with their operands in LDS plus the persistent LSTM kernels of bilstm.hip in their one-direction
+// form:
+//   rg_adj        x -> A1, A2 = tanh(alpha (x W^T + b)); S = alpha (A1 A2^T - A2 A1^T); A = relu(tanh S); A_hat = D^-1/2 (A + I) D^-1/2
+//   rg_scl        per (sample b, step l): graph convolutions with the adjacency of sample (b L + l) % batch -- the reference tiles the
+//                 adjacency batch L times along the batch axis while the node signals are sample-major (Model.py:104-106); two GCN
+//                 layers (1 -> H -> H), dropout, 1x1 convolution -> the LSTM's input sequence
+//   lstm          nn.LSTM(N -> E) over the L steps of every sample (bilstm.hip, ndir = 1)
+//   rg_fusion     1x1 convolution of x + LSTM output, 'same' convolution (k taps), the two linear heads, squared error
+// and their mirror images backwards.  Parameter gradients: every workgroup owns fixed gradient entries in registers over its
+// grid-stride loop over samples and writes one partial row; rows are summed in a fixed order (rows_sum) -- reproducible bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgemm_mfma.hpp"
+#include "stgcn_device.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+constexpr int RB = 256;                 // threads per workgroup
+constexpr int RG_MAXN = 32, RG_MAXL = 64, RG_MAXH = 64, RG_MAXE = 64, RG_MAXK = 7;
+constexpr int RG_OWN = 16;              // gradient entries a thread owns per tensor (RB * RG_OWN >= the largest tensor)
+
+struct RgGeom {
+    int64_t B, G;                       // samples, graphs = B * L
+    int N, L, H, E, K, pad;
+    float alpha;
+    // flat parameter offsets (floats), the reference's named_parameters() order
+    int o_t1w, o_t1b, o_t2w, o_t2b, o_g1w, o_g1b, o_g2w, o_g2b, o_cw, o_cb, o_wih, o_whh, o_bih, o_bhh, o_c1w, o_c1b, o_c2w, o_c2b,
+        o_f1w, o_f1b, o_f2w, o_f2b, pcount;
+    int nA, nS, nF;                     // gradient entries of the adjacency / SCL / fusion groups
+    int blocks;                         // workgroups of the per-sample kernels (= their partial rows)
+    int gblocks;                        // workgroups of the per-graph kernels (= partial rows of rg_scl_bwd)
+    // workspace offsets (floats)
+    int64_t w_A1, w_A2, w_T, w_dinv, w_Ahat, w_ax1, w_ah1, w_z2, w_sp, w_hseq, w_M, w_M2, w_dpred, w_sq, w_dM, w_dsp, w_dAg,
+        w_partA, w_partS, w_partF, w_lstm, total;
+};
+
+int rg_geometry(const rulgnn_rgcnu_shape* s, RgGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->batch < 0 || s->num_nodes < 1 || s->time_length < 1 || s->hidden_dim < 1 || s->encoder_hidden_dim < 1 || s->kernel_size < 1)
+        return RULGNN_EINVAL;
+    if (s->num_nodes > RG_MAXN || s->time_length > RG_MAXL || s->hidden_dim > RG_MAXH || s->encoder_hidden_dim > RG_MAXE ||
+        s->kernel_size > RG_MAXK || (s->kernel_size & 1) == 0)
+        return RULGNN_EUNSUPPORTED;          // padding='same' with an even kernel pads asymmetrically: not wired by the reference
+    const int N = s->num_nodes, L = s->time_length, H = s->hidden_dim, E = s->encoder_hidden_dim, K = s->kernel_size;
+    if (E * E * K > RB * RG_OWN || H * H > RB * RG_OWN || E * L > RB * RG_OWN || N * L > RB * RG_OWN || E * N > RB * RG_OWN)
+        return RULGNN_EUNSUPPORTED;
+    g->B = s->batch; g->G = s->batch * L;
+    g->N = N; g->L = L; g->H = H; g->E = E; g->K = K; g->pad = (K - 1) / 2; g->alpha = s->alpha;
+    int o = 0;
+    auto tk = [&](int n) { const int r = o; o += n; return r; };
+    g->o_t1w = tk(N * L); g->o_t1b = tk(N); g->o_t2w = tk(N * L); g->o_t2b = tk(N);
+    g->nA = o;
+    g->o_g1w = tk(H); g->o_g1b = tk(H); g->o_g2w = tk(H * H); g->o_g2b = tk(H); g->o_cw = tk(H); g->o_cb = tk(1);
+    g->nS = o - g->nA;
+    g->o_wih = tk(4 * E * N); g->o_whh = tk(4 * E * E); g->o_bih = tk(4 * E); g->o_bhh = tk(4 * E);
+    g->o_c1w = tk(E * N); g->o_c1b = tk(E); g->o_c2w = tk(E * E * K); g->o_c2b = tk(E); g->o_f1w = tk(E * L); g->o_f1b = tk(1);
+    g->nF = o - g->o_c1w;
+    g->o_f2w = tk(E * L); g->o_f2b = tk(1);
+    g->pcount = o;
+    g->blocks = (int)(g->B < 512 ? (g->B > 0 ? g->B : 1) : 512);
+    g->gblocks = (int)(g->G < 2048 ? (g->G > 0 ? g->G : 1) : 2048);
+    int64_t w = 0;
+    auto wk = [&](int64_t n) { const int64_t r = w; w += (n + 63) & ~(int64_t)63; return r; };
+    const int64_t B = g->B, G = g->G;
+    g->w_A1 = wk(B * N * N); g->w_A2 = wk(B * N * N); g->w_T = wk(B * N * N); g->w_dinv = wk(B * N); g->w_Ahat = wk(B * N * N);
+    g->w_ax1 = wk(G * N); g->w_ah1 = wk(G * N * H); g->w_z2 = wk(G * N * H);
+    g->w_sp = wk(G * N); g->w_hseq = wk(G * E); g->w_M = wk(B * E * L); g->w_M2 = wk(B * E * L);
+    g->w_dpred = wk(B); g->w_sq = wk(B); g->w_dM = wk(G * E); g->w_dsp = wk(G * N); g->w_dAg = wk(G * N * N);
+    g->w_partA = wk((int64_t)g->blocks * g->nA); g->w_partS = wk((int64_t)g->gblocks * g->nS); g->w_partF = wk((int64_t)g->blocks * g->nF);
+    rulgnn_bilstm_shape ls{L, (int32_t)(B > 0 ? B : 1), N, E};
+    const size_t lb = bilstm_workspace_bytes(&ls);
+    if (lb == 0) return RULGNN_EUNSUPPORTED;
+    g->w_lstm = wk((int64_t)(lb / sizeof(float)) + 64);
+    g->total = w;
+    return RULGNN_OK;
+}
+
+__device__ __forceinline__ float rg_tanh(float v) { return tanhf(v); }
+
+// ---- adjacency ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_adj_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
+    __shared__ float xs[RG_MAXN * RG_MAXL], a1[RG_MAXN * RG_MAXN], a2[RG_MAXN * RG_MAXN], tt[RG_MAXN * RG_MAXN], dv[RG_MAXN];
+    const int N = g.N, L = g.L, tid = threadIdx.x;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int i = tid; i < N * L; i += RB) xs[i] = x[b * N * L + i];
+        __syncthreads();
+        for (int i = tid; i < N * N; i += RB) {
+            const int n = i / N, m = i % N;
+            float u1 = prm[g.o_t1b + m], u2 = prm[g.o_t2b + m];
+            for (int l = 0; l < L; ++l) {
+                const float xv = xs[n * L + l];
+                u1 = fmaf(xv, prm[g.o_t1w + m * L + l], u1);
+                u2 = fmaf(xv, prm[g.o_t2w + m * L + l], u2);
+            }
+            a1[i] = rg_tanh(g.alpha * u1);
+            a2[i] = rg_tanh(g.alpha * u2);
+        }
+        __syncthreads();
+        for (int i = tid; i < N * N; i += RB) {
+            const int r = i / N, c = i % N;
+            float sacc = 0.f;
+            for (int m = 0; m < N; ++m) sacc += a1[r * N + m] * a2[c * N + m] - a2[r * N + m] * a1[c * N + m];
+            tt[i] = rg_tanh(g.alpha * sacc);
+        }
+        __syncthreads();
+        if (tid < N) {
+            float r = 1.0f;                                    // the self loop
+            for (int c = 0; c < N; ++c) r += fmaxf(tt[tid * N + c], 0.f);
+            dv[tid] = 1.0f / sqrtf(r);
+        }
+        __syncthreads();
+        for (int i = tid; i < N * N; i += RB) {
+            const int r = i / N, c = i % N;
+            const float at = fmaxf(tt[i], 0.f) + (r == c ? 1.f : 0.f);
+            ws[g.w_A1 + b * N * N + i] = a1[i];
+            ws[g.w_A2 + b * N * N + i] = a2[i];
+            ws[g.w_T + b * N * N + i] = tt[i];
+            ws[g.w_Ahat + b * N * N + i] = dv[r] * at * dv[c];
+        }
+        if (tid < N) ws[g.w_dinv + b * N + tid] = dv[tid];
+        __syncthreads();
+    }
+}
+
+// dropout keep-scale of element (global sample, step, node, channel); counter-based hash shared with the oracle
+__device__ __forceinline__ float rg_keep(uint32_t key, uint32_t thr, float scale, int64_t sample, int l, int n, int h, const RgGeom& g) {
+    if (thr == 0u) return 1.f;
+    const uint32_t ctr = (uint32_t)(((sample * g.L + l) * g.N + n) * g.H + h);
+    return lowbias32(ctr ^ key) >= thr ? scale : 0.f;
+}
+
+// ---- spatial correlation layer --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_scl_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws,
+                                                    uint32_t key, uint32_t thr, float scale, int64_t sample_offset) {
+    // LDS sized by the actual widths (the static worst case, 45 KB, allowed three workgroups per CU: 124 us at batch 256)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = g.N, L = g.L, H = g.H, tid = threadIdx.x;
+    float* ah = sm;                       // [N][N]
+    float* xs = ah + N * N;               // [N]
+    float* ax = xs + N;                   // [N]
+    float* h1 = ax + N;                   // [N][H]
+    float* a1 = h1 + N * H;               // [N][H]
+    float* h2 = a1 + N * H;               // [N][H]
+    float* w2t = h2 + N * H;              // [H][H + 1]: W2[h][k] -> [k][h], padded rows
+    for (int i = tid; i < H * H; i += RB) w2t[(i % H) * (H + 1) + i / H] = prm[g.o_g2w + i];
+    __syncthreads();
+    for (int64_t gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
+        const int64_t b = gi / L;
+        const int l = (int)(gi % L);
+        const int64_t a = gi % g.B;                             // the adjacency this graph convolves with (Model.py:104-106)
+        for (int i = tid; i < N * N; i += RB) ah[i] = ws[g.w_Ahat + a * N * N + i];
+        if (tid < N) xs[tid] = x[(b * N + tid) * L + l];
+        __syncthreads();
+        if (tid < N) {
+            float v = 0.f;
+            for (int j = 0; j < N; ++j) v = fmaf(ah[tid * N + j], xs[j], v);
+            ax[tid] = v;
+            ws[g.w_ax1 + gi * N + tid] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < N * H; i += RB) {
+            const int n = i / H, h = i % H;
+            h1[i] = fmaxf(fmaf(ax[n], prm[g.o_g1w + h], prm[g.o_g1b + h]), 0.f);
+        }
+        __syncthreads();
+        for (int i = tid; i < N * H; i += RB) {
+            const int n = i / H, h = i % H;
+            float v = 0.f;
+            for (int j = 0; j < N; ++j) v = fmaf(ah[n * N + j], h1[j * H + h], v);
+            a1[i] = v;
+            ws[g.w_ah1 + gi * N * H + i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < N * H; i += RB) {
+            const int n = i / H, h = i % H;
+            float v = prm[g.o_g2b + h];
+            for (int k = 0; k < H; ++k) v = fmaf(a1[n * H + k], w2t[k * (H + 1) + h], v);
+            ws[g.w_z2 + gi * N * H + i] = v;
+            h2[i] = fmaxf(v, 0.f) * rg_keep(key, thr, scale, sample_offset + b, l, n, h, g);
+        }
+        __syncthreads();
+        if (tid < N) {
+            float v = prm[g.o_cb];
+            for (int h = 0; h < H; ++h) v = fmaf(h2[tid * H + h], prm[g.o_cw + h], v);
+            ws[g.w_sp + (b * L + l) * N + tid] = v;             // [sample][step][node]: the LSTM's batch-first input
+        }
+        __syncthreads();
+    }
+}
+
+// ---- fusion module, heads, squared error ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_fusion_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ prm,
+                                                       float* __restrict__ ws, float* __restrict__ pred, float* __restrict__ stdv, float inv_gb) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = g.N, L = g.L, E = g.E, K = g.K, pad = g.pad, LP = L + K - 1, tid = threadIdx.x;
+    float* Mp = sm;                       // [E][LP] zero-padded
+    float* xs = Mp + E * LP;              // [N][L]
+    float* w2 = xs + N * L;               // [E][E][K]
+    float* red = w2 + E * E * K;          // [2][RB]
+    for (int i = tid; i < E * E * K; i += RB) w2[i] = prm[g.o_c2w + i];
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int i = tid; i < E * LP; i += RB) Mp[i] = 0.f;
+        for (int i = tid; i < N * L; i += RB) xs[i] = x[b * N * L + i];
+        __syncthreads();
+        for (int i = tid; i < E * L; i += RB) {
+            const int e = i / L, l = i % L;
+            float v = prm[g.o_c1b + e];
+            for (int n = 0; n < N; ++n) v = fmaf(prm[g.o_c1w + e * N + n], xs[n * L + l], v);
+            v += ws[g.w_hseq + (b * L + l) * E + e];
+            Mp[e * LP + pad + l] = v;
+            ws[g.w_M + b * E * L + i] = v;
+        }
+        __syncthreads();
+        float p1 = 0.f, p2 = 0.f;
+        for (int i = tid; i < E * L; i += RB) {
+            const int o = i / L, l = i % L;
+            float v = prm[g.o_c2b + o];
+            for (int e = 0; e < E; ++e)
+                for (int j = 0; j < K; ++j) v = fmaf(w2[(o * E + e) * K + j], Mp[e * LP + l + j], v);
+            ws[g.w_M2 + b * E * L + i] = v;
+            p1 = fmaf(v, prm[g.o_f1w + i], p1);
+            p2 = fmaf(v, prm[g.o_f2w + i], p2);
+        }
+        red[tid] = p1;
+        red[RB + tid] = p2;
+        __syncthreads();
+        for (int m = RB / 2; m > 0; m >>= 1) {
+            if (tid < m) { red[tid] += red[tid + m]; red[RB + tid] += red[RB + tid + m]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float pr = red[0] + prm[g.o_f1b];
+            pred[b] = pr;
+            if (stdv) stdv[b] = red[RB] + prm[g.o_f2b];
+            if (y) {
+                const float d = pr - y[b];
+                ws[g.w_sq + b] = d * d * inv_gb;
+                ws[g.w_dpred + b] = 2.f * d * inv_gb;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// thread-owned gradient entries: entry e of a tensor of n values belongs to thread e % RB, slot e / RB
+#define RG_FOR_OWNED(n, e, s) _Pragma("unroll") for (int s = 0, e = threadIdx.x; s < RG_OWN; ++s, e += RB) if (e < (n))
+
+// ---- fusion backward ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_fusion_bwd_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ dpred_in,
+                                                           const float* __restrict__ prm, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = g.N, L = g.L, E = g.E, K = g.K, pad = g.pad, LP = L + K - 1, tid = threadIdx.x;
+    float* Mp = sm;                       // [E][LP]  forward M, zero padded
+    float* d2 = Mp + E * LP;              // [E][LP]  d M2, zero padded by pad' = K - 1 - pad on the left (transposed convolution)
+    float* xs = d2 + E * LP;              // [N][L]
+    float* w2 = xs + N * L;               // [E][E][K]
+    float* dMs = w2 + E * E * K;          // [E][L]
+    for (int i = tid; i < E * E * K; i += RB) w2[i] = prm[g.o_c2w + i];
+    float gc1w[RG_OWN], gc1b[RG_OWN], gc2w[RG_OWN], gc2b[RG_OWN], gf1w[RG_OWN], gf1b = 0.f;
+#pragma unroll
+    for (int s = 0; s < RG_OWN; ++s) gc1w[s] = gc1b[s] = gc2w[s] = gc2b[s] = gf1w[s] = 0.f;
+    const float* dpred = dpred_in ? dpred_in : ws + g.w_dpred;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        const float dp = dpred[b];
+        for (int i = tid; i < E * LP; i += RB) { Mp[i] = 0.f; d2[i] = 0.f; }
+        for (int i = tid; i < N * L; i += RB) xs[i] = x[b * N * L + i];
+        __syncthreads();
+        for (int i = tid; i < E * L; i += RB) {
+            const int e = i / L, l = i % L;
+            Mp[e * LP + pad + l] = ws[g.w_M + b * E * L + i];
+            d2[e * LP + (K - 1 - pad) + l] = dp * prm[g.o_f1w + i];
+        }
+        RG_FOR_OWNED(E * L, e, s) gf1w[s] = fmaf(dp, ws[g.w_M2 + b * E * L + e], gf1w[s]);
+        if (tid == 0) gf1b += dp;
+        __syncthreads();
+        // d M[e][l] = sum_{o, j} W2[o][e][j] dM2[o][l - j + pad]
+        for (int i = tid; i < E * L; i += RB) {
+            const int e = i / L, l = i % L;
+            float v = 0.f;
+            for (int o = 0; o < E; ++o)
+                for (int j = 0; j < K; ++j) v = fmaf(w2[(o * E + e) * K + j], d2[o * LP + (K - 1 - pad) + l - j + pad], v);
+            dMs[i] = v;
+            ws[g.w_dM + (b * L + l) * E + e] = v;               // [sample][step][E]: d (LSTM output)
+        }
+        // d W2[o][e][j] = sum_l dM2[o][l] M[e][l + j - pad]
+        RG_FOR_OWNED(E * E * K, e_, s) {
+            const int o = e_ / (E * K), e = (e_ / K) % E, j = e_ % K;
+            float v = 0.f;
+            for (int l = 0; l < L; ++l) v = fmaf(d2[o * LP + (K - 1 - pad) + l], Mp[e * LP + l + j], v);
+            gc2w[s] += v;
+        }
+        RG_FOR_OWNED(E, o, s) {
+            float v = 0.f;
+            for (int l = 0; l < L; ++l) v += d2[o * LP + (K - 1 - pad) + l];
+            gc2b[s] += v;
+        }
+        __syncthreads();
+        RG_FOR_OWNED(E * N, e_, s) {
+            const int e = e_ / N, n = e_ % N;
+            float v = 0.f;
+            for (int l = 0; l < L; ++l) v = fmaf(dMs[e * L + l], xs[n * L + l], v);
+            gc1w[s] += v;
+        }
+        RG_FOR_OWNED(E, e, s) {
+            float v = 0.f;
+            for (int l = 0; l < L; ++l) v += dMs[e * L + l];
+            gc1b[s] += v;
+        }
+        __syncthreads();
+    }
+    float* row = ws + g.w_partF + (int64_t)blockIdx.x * g.nF;
+    const int base = g.o_c1w;
+    RG_FOR_OWNED(E * N, e, s) row[g.o_c1w - base + e] = gc1w[s];
+    RG_FOR_OWNED(E, e, s) row[g.o_c1b - base + e] = gc1b[s];
+    RG_FOR_OWNED(E * E * K, e, s) row[g.o_c2w - base + e] = gc2w[s];
+    RG_FOR_OWNED(E, e, s) row[g.o_c2b - base + e] = gc2b[s];
+    RG_FOR_OWNED(E * L, e, s) row[g.o_f1w - base + e] = gf1w[s];
+    if (tid == 0) row[g.o_f1b - base] = gf1b;
+}
+
+// ---- spatial correlation layer backward -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_scl_bwd_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws,
+                                                        uint32_t key, uint32_t thr, float scale, int64_t sample_offset) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = g.N, L = g.L, H = g.H, tid = threadIdx.x;
+    float* ah = sm;                       // [N][N]
+    float* xs = ah + N * N;               // [N] x 4: xs, ax, dsp, dax
+    float* ax = xs + N;
+    float* dsp = ax + N;
+    float* dax = dsp + N;
+    float* h1 = dax + N;                  // [N][H] x 5
+    float* a1 = h1 + N * H;
+    float* dz2 = a1 + N * H;
+    float* da1 = dz2 + N * H;
+    float* dz1 = da1 + N * H;
+    float* w2 = dz1 + N * H;              // [H][H + 1]: W2[h][k], padded rows
+    for (int i = tid; i < H * H; i += RB) w2[(i / H) * (H + 1) + i % H] = prm[g.o_g2w + i];
+    float gg2w[RG_OWN], gg1w = 0.f, gg1b = 0.f, gg2b = 0.f, gcw = 0.f, gcb = 0.f;
+#pragma unroll
+    for (int s = 0; s < RG_OWN; ++s) gg2w[s] = 0.f;
+    __syncthreads();
+    // graphs over the workgroups in a fixed stride (grid = rg_graph_blocks(), a function of the shape alone): every partial row
+    // sums the same graphs on every run
+    for (int64_t gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
+        {
+            const int64_t b = gi / L, a = gi % g.B;
+            const int l = (int)(gi % L);
+            for (int i = tid; i < N * N; i += RB) ah[i] = ws[g.w_Ahat + a * N * N + i];
+            if (tid < N) {
+                xs[tid] = x[(b * N + tid) * L + l];
+                ax[tid] = ws[g.w_ax1 + gi * N + tid];
+                dsp[tid] = ws[g.w_dsp + gi * N + tid];
+            }
+            __syncthreads();
+            for (int i = tid; i < N * H; i += RB) {
+                const int n = i / H, h = i % H;
+                h1[i] = fmaxf(fmaf(ax[n], prm[g.o_g1w + h], prm[g.o_g1b + h]), 0.f);
+                a1[i] = ws[g.w_ah1 + gi * N * H + i];
+                const float z = ws[g.w_z2 + gi * N * H + i];
+                const float kp = rg_keep(key, thr, scale, sample_offset + b, l, n, h, g);
+                dz2[i] = z > 0.f ? dsp[n] * prm[g.o_cw + h] * kp : 0.f;
+                dz1[i] = fmaxf(z, 0.f) * kp;                     // the dropped-out hidden features (dz1 is free until gcn1's backward)
+            }
+            __syncthreads();
+            // conv1d (1x1) and gcn2 parameter gradients
+            if (tid < H) {
+                float vw = 0.f, vb = 0.f;
+                for (int n = 0; n < N; ++n) {
+                    vw = fmaf(dsp[n], dz1[n * H + tid], vw);
+                    vb += dz2[n * H + tid];
+                }
+                gcw += vw;
+                gg2b += vb;
+            }
+            if (tid == 0) {
+                float v = 0.f;
+                for (int n = 0; n < N; ++n) v += dsp[n];
+                gcb += v;
+            }
+            RG_FOR_OWNED(H * H, e, s) {
+                const int h = e / H, k = e % H;
+                float v = 0.f;
+                for (int n = 0; n < N; ++n) v = fmaf(dz2[n * H + h], a1[n * H + k], v);
+                gg2w[s] += v;
+            }
+            // d (A_hat h1)[n][k] = sum_h dz2[n][h] W2[h][k]
+            for (int i = tid; i < N * H; i += RB) {
+                const int n = i / H, k = i % H;
+                float v = 0.f;
+                for (int h = 0; h < H; ++h) v = fmaf(dz2[n * H + h], w2[h * (H + 1) + k], v);
+                da1[i] = v;
+            }
+            __syncthreads();
+            // d h1[j][h] = sum_i A_hat[i][j] da1[i][h];  gcn1
+            for (int i = tid; i < N * H; i += RB) {
+                const int j = i / H, h = i % H;
+                float v = 0.f;
+                for (int r = 0; r < N; ++r) v = fmaf(ah[r * N + j], da1[r * H + h], v);
+                dz1[i] = h1[i] > 0.f ? v : 0.f;
+            }
+            __syncthreads();
+            if (tid < H) {
+                float vw = 0.f, vb = 0.f;
+                for (int n = 0; n < N; ++n) {
+                    vw = fmaf(dz1[n * H + tid], ax[n], vw);
+                    vb += dz1[n * H + tid];
+                }
+                gg1w += vw;
+                gg1b += vb;
+            }
+            if (tid < N) {
+                float v = 0.f;
+                for (int h = 0; h < H; ++h) v = fmaf(dz1[tid * H + h], prm[g.o_g1w + h], v);
+                dax[tid] = v;
+            }
+            __syncthreads();
+            // d A_hat of this graph: da1 h1^T + dax x^T
+            for (int i = tid; i < N * N; i += RB) {
+                const int r = i / N, c = i % N;
+                float v = dax[r] * xs[c];
+                for (int h = 0; h < H; ++h) v = fmaf(da1[r * H + h], h1[c * H + h], v);
+                ws[g.w_dAg + gi * N * N + i] = v;
+            }
+            __syncthreads();
+        }
+    }
+    float* row = ws + g.w_partS + (int64_t)blockIdx.x * g.nS;
+    const int base = g.o_g1w;
+    if (tid < H) {
+        row[g.o_g1w - base + tid] = gg1w;
+        row[g.o_g1b - base + tid] = gg1b;
+        row[g.o_g2b - base + tid] = gg2b;
+        row[g.o_cw - base + tid] = gcw;
+    }
+    RG_FOR_OWNED(H * H, e, s) row[g.o_g2w - base + e] = gg2w[s];
+    if (tid == 0) row[g.o_cb - base] = gcb;
+}
+
+// ---- adjacency backward ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void rg_adj_bwd_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
+    __shared__ float xs[RG_MAXN * RG_MAXL], a1[RG_MAXN * RG_MAXN], a2[RG_MAXN * RG_MAXN], tt[RG_MAXN * RG_MAXN], dh[RG_MAXN * RG_MAXN],
+        ds[RG_MAXN * RG_MAXN], du1[RG_MAXN * RG_MAXN], du2[RG_MAXN * RG_MAXN], dv[RG_MAXN], dd[RG_MAXN];
+    const int N = g.N, L = g.L, tid = threadIdx.x;
+    float gw1[RG_OWN], gw2[RG_OWN], gb1 = 0.f, gb2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < RG_OWN; ++s) gw1[s] = gw2[s] = 0.f;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        for (int i = tid; i < N * L; i += RB) xs[i] = x[b * N * L + i];
+        for (int i = tid; i < N * N; i += RB) {
+            a1[i] = ws[g.w_A1 + b * N * N + i];
+            a2[i] = ws[g.w_A2 + b * N * N + i];
+            tt[i] = ws[g.w_T + b * N * N + i];
+            float v = 0.f;                                       // the graphs that used this sample's adjacency: b, b + B, b + 2B, ...
+            for (int j = 0; j < L; ++j) v += ws[g.w_dAg + (b + (int64_t)j * g.B) * N * N + i];
+            dh[i] = v;
+        }
+        if (tid < N) dv[tid] = ws[g.w_dinv + b * N + tid];
+        __syncthreads();
+        // A_hat_ij = d_i At_ij d_j, d = rowsum(At)^-1/2
+        if (tid < N) {
+            float v = 0.f;
+            for (int c = 0; c < N; ++c) {
+                const float at_rc = fmaxf(tt[tid * N + c], 0.f) + (tid == c ? 1.f : 0.f);
+                const float at_cr = fmaxf(tt[c * N + tid], 0.f) + (tid == c ? 1.f : 0.f);
+                v = fmaf(dh[tid * N + c] * at_rc, dv[c], v);
+                v = fmaf(dh[c * N + tid] * at_cr, dv[c], v);
+            }
+            dd[tid] = v * (-0.5f) * dv[tid] * dv[tid] * dv[tid];
+        }
+        __syncthreads();
+        for (int i = tid; i < N * N; i += RB) {
+            const int r = i / N, c = i % N;
+            const float dA = dv[r] * dh[i] * dv[c] + dd[r];
+            const float t = tt[i];
+            ds[i] = t > 0.f ? dA * (1.f - t * t) * g.alpha : 0.f;
+        }
+        __syncthreads();
+        // dA1 = dS A2 - dS^T A2;  dA2 = dS^T A1 - dS A1;  through tanh(alpha u)
+        for (int i = tid; i < N * N; i += RB) {
+            const int n = i / N, m = i % N;
+            float v1 = 0.f, v2 = 0.f;
+            for (int c = 0; c < N; ++c) {
+                const float sd = ds[n * N + c] - ds[c * N + n];
+                v1 = fmaf(sd, a2[c * N + m], v1);
+                v2 = fmaf(-sd, a1[c * N + m], v2);
+            }
+            du1[i] = v1 * (1.f - a1[i] * a1[i]) * g.alpha;
+            du2[i] = v2 * (1.f - a2[i] * a2[i]) * g.alpha;
+        }
+        __syncthreads();
+        RG_FOR_OWNED(N * L, e, s) {
+            const int m = e / L, l = e % L;
+            float v1 = 0.f, v2 = 0.f;
+            for (int n = 0; n < N; ++n) {
+                v1 = fmaf(du1[n * N + m], xs[n * L + l], v1);
+                v2 = fmaf(du2[n * N + m], xs[n * L + l], v2);
+            }
+            gw1[s] += v1;
+            gw2[s] += v2;
+        }
+        if (tid < N) {
+            float v1 = 0.f, v2 = 0.f;
+            for (int n = 0; n < N; ++n) { v1 += du1[n * N + tid]; v2 += du2[n * N + tid]; }
+            gb1 += v1;
+            gb2 += v2;
+        }
+        __syncthreads();
+    }
+    float* row = ws + g.w_partA + (int64_t)blockIdx.x * g.nA;
+    RG_FOR_OWNED(N * L, e, s) { row[g.o_t1w + e] = gw1[s]; row[g.o_t2w + e] = gw2[s]; }
+    if (tid < N) { row[g.o_t1b + tid] = gb1; row[g.o_t2b + tid] = gb2; }
+}
+
+__global__ void rg_zero_kernel(float* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+size_t rg_fusion_lds(const RgGeom& g, bool bwd) {
+    const int LP = g.L + g.K - 1;
+    size_t fl = (size_t)g.E * LP + (size_t)g.N * g.L + (size_t)g.E * g.E * g.K;
+    fl += bwd ? (size_t)g.E * LP + (size_t)g.E * g.L : (size_t)2 * RB;
+    return fl * sizeof(float);
+}
+
+}  // namespace
+
+int64_t rgcnu_param_count(const rulgnn_rgcnu_shape* s) {
+    RgGeom g;
+    return rg_geometry(s, &g) == RULGNN_OK ? g.pcount : -1;
+}
+
+size_t rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* s) {
+    RgGeom g;
+    return rg_geometry(s, &g) == RULGNN_OK ? (size_t)g.total * sizeof(float) : 0;
+}
+
+#define RG_RC(call)                        \
+    do {                                   \
+        const int rc_ = (call);            \
+        if (rc_ != RULGNN_OK) return rc_;  \
+    } while (0)
+
+// mode bit 0: forward, bit 1: backward (after a forward with the same args / workspace)
+int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode, hipStream_t st) {
+    RgGeom g;
+    RG_RC(rg_geometry(s, &g));
+    if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
+    if (g.B == 0) return RULGNN_OK;
+    float* ws = static_cast<float*>(a->workspace);
+    const float* prm = a->params;
+    const float p = a->training ? a->dropout_p : 0.f;
+    uint32_t thr = 0;
+    if (p > 0.f) {
+        const uint64_t ti = (uint64_t)((double)p * 4294967296.0 + 0.5);
+        thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
+    }
+    const float scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t key = dropout_layer_key(a->seed, a->step, 0);
+    const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+    rulgnn_bilstm_shape ls{g.L, (int32_t)g.B, g.N, g.E};
+    rulgnn_bilstm_args la{};
+    la.x = ws + g.w_sp;
+    la.w_ih[0] = prm + g.o_wih; la.w_hh[0] = prm + g.o_whh; la.b_ih[0] = prm + g.o_bih; la.b_hh[0] = prm + g.o_bhh;
+    la.w_ih[1] = la.w_ih[0]; la.w_hh[1] = la.w_hh[0]; la.b_ih[1] = la.b_ih[0]; la.b_hh[1] = la.b_hh[0];      // unused (ndir = 1)
+    la.out = ws + g.w_hseq;
+    la.workspace = ws + g.w_lstm;
+    la.workspace_bytes = bilstm_workspace_bytes(&ls);
+    const int blocks = g.blocks, gblocks = g.gblocks;
+    const size_t lds_scl = sizeof(float) * ((size_t)g.N * g.N + 2 * g.N + 3 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
+    const size_t lds_sclb = sizeof(float) * ((size_t)g.N * g.N + 4 * g.N + 5 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
+    (void)hipGetLastError();
+    if (mode & 1) {
+        hipLaunchKernelGGL(rg_adj_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
+        hipLaunchKernelGGL(rg_scl_kernel, dim3((unsigned)gblocks), dim3(RB), lds_scl, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        RG_RC(bilstm_forward(&ls, &la, st, 1));
+        const size_t lds = rg_fusion_lds(g, false);
+        if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_fusion_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+        hipLaunchKernelGGL(rg_fusion_kernel, dim3(blocks), dim3(RB), lds, st, g, a->x, a->y, prm, ws, a->pred, a->std_pred, inv_gb);
+        if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    }
+    if (mode & 2) {
+        if (!a->grads) return RULGNN_EINVAL;
+        const size_t lds = rg_fusion_lds(g, true);
+        if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+        if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_fusion_bwd_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+        hipLaunchKernelGGL(rg_fusion_bwd_kernel, dim3(blocks), dim3(RB), lds, st, g, a->x, a->dpred, prm, ws);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        la.dout = ws + g.w_dM;
+        la.dx = ws + g.w_dsp;
+        la.dw_ih[0] = a->grads + g.o_wih; la.dw_hh[0] = a->grads + g.o_whh; la.db_ih[0] = a->grads + g.o_bih; la.db_hh[0] = a->grads + g.o_bhh;
+        la.dw_ih[1] = la.dw_ih[0]; la.dw_hh[1] = la.dw_hh[0]; la.db_ih[1] = la.db_ih[0]; la.db_hh[1] = la.db_hh[0];
+        RG_RC(bilstm_backward(&ls, &la, st, 1));
+        if (lds_sclb > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_scl_bwd_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sclb) != hipSuccess)
+            return RULGNN_EHIP;
+        hipLaunchKernelGGL(rg_scl_bwd_kernel, dim3((unsigned)gblocks), dim3(RB), lds_sclb, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+        hipLaunchKernelGGL(rg_adj_bwd_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        RG_RC(rows_sum(ws + g.w_partA, blocks, g.nA, g.nA, a->grads, st));
+        RG_RC(rows_sum(ws + g.w_partS, gblocks, g.nS, g.nS, a->grads + g.o_g1w, st));
+        RG_RC(rows_sum(ws + g.w_partF, blocks, g.nF, g.nF, a->grads + g.o_c1w, st));
+        const int nz = g.E * g.L + 1;                                    // the `std` head is not in the loss (algorithms.py:287-290)
+        hipLaunchKernelGGL(rg_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, st, a->grads + g.o_f2w, nz);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    }
+    return RULGNN_OK;
+}
+
+}  // namespace rulgnn

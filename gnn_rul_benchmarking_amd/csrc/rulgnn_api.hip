@@ -604,6 +604,63 @@ int rulgnn_stgnn_fwdbwd_f32(const rulgnn_stgnn_shape* shape, const rulgnn_stmsgc
                      opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
 }
 
+// ---- RGCNU ----------------------------------------------------------------------------------------------------------------------
+int64_t rulgnn_rgcnu_param_count(const rulgnn_rgcnu_shape* shape) { return rgcnu_param_count(shape); }
+size_t rulgnn_rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* shape) { return rgcnu_workspace_bytes(shape); }
+
+static int check_rgcnu(const rulgnn_rgcnu_shape* shape, const rulgnn_rgcnu_args* a, bool fwd, bool bwd) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (rgcnu_param_count(shape) < 0) return rgcnu_workspace_bytes(shape) == 0 && shape->batch >= 0 && shape->num_nodes >= 1 &&
+                                                     shape->time_length >= 1 && shape->hidden_dim >= 1 && shape->encoder_hidden_dim >= 1 &&
+                                                     shape->kernel_size >= 1
+                                                 ? RULGNN_EUNSUPPORTED
+                                                 : RULGNN_EINVAL;
+    if (!(a->dropout_p >= 0.f && a->dropout_p < 1.f)) return RULGNN_EINVAL;
+    int rc = check_ptrs({a->params, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch > 0) {
+        rc = check_ptrs({a->x, a->pred});
+        if (rc != RULGNN_OK) return rc;
+    }
+    if (bwd) {
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->dpred && !a->y && shape->batch > 0) return RULGNN_EINVAL;
+    }
+    (void)fwd;
+    return RULGNN_OK;
+}
+
+int rulgnn_rgcnu_forward_f32(const rulgnn_rgcnu_shape* shape, const rulgnn_rgcnu_args* args, void* stream) {
+    const int rc = check_rgcnu(shape, args, true, false);
+    if (rc != RULGNN_OK) return rc;
+    return rgcnu_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_rgcnu_backward_f32(const rulgnn_rgcnu_shape* shape, const rulgnn_rgcnu_args* args, void* stream) {
+    const int rc = check_rgcnu(shape, args, false, true);
+    if (rc != RULGNN_OK) return rc;
+    return rgcnu_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_rgcnu_fwdbwd_f32(const rulgnn_rgcnu_shape* shape, const rulgnn_rgcnu_args* args, const rulgnn_adam_args* opt, void* stream) {
+    int rc = check_rgcnu(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred || (!args->y && shape->batch > 0)) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = rgcnu_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    // the second head (fc2, the last E*L + 1 entries) has no gradient in the reference (`grad is None`): torch's Adam leaves it untouched
+    const int64_t live = rgcnu_param_count(shape) - ((int64_t)shape->encoder_hidden_dim * shape->time_length + 1);
+    return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, live, opt->step, opt->lr, opt->beta1,
+                     opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
 size_t rulgnn_gru_workspace_bytes(const rulgnn_gru_shape* shape) { return gru_workspace_bytes(shape); }
 
 int rulgnn_gru_forward_f32(const rulgnn_gru_shape* shape, const rulgnn_gru_args* args, void* stream) {

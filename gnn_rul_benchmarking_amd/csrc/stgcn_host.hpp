@@ -135,8 +135,8 @@ size_t hagcn_workspace_bytes(const rulgnn_hagcn_shape* s);
 int hagcn_graph_forward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
 int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a, hipStream_t stream);
 size_t bilstm_workspace_bytes(const rulgnn_bilstm_shape* s);
-int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
-int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream);
+int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream, int ndir = 2);
+int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hipStream_t stream, int ndir = 2);
 int64_t stconv_param_count(const rulgnn_stconv_shape* s);
 size_t stconv_workspace_bytes(const rulgnn_stconv_shape* s);
 int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream);
@@ -155,6 +155,9 @@ int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float
 int stgnn_cheb_forward(const rulgnn_stgnn_shape* s, const float* terms, const float* filters, float* out, hipStream_t st);
 int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const float* dout, float* dfilters, void* workspace,
                         size_t workspace_bytes, hipStream_t st);
+int64_t rgcnu_param_count(const rulgnn_rgcnu_shape* s);
+size_t rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* s);
+int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode, hipStream_t st);
 int64_t stgnn_param_count(const rulgnn_stgnn_shape* s);
 size_t stgnn_step_workspace_bytes(const rulgnn_stgnn_shape* s);
 int stgnn_run(const rulgnn_stgnn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t st);

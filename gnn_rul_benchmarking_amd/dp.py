@@ -107,6 +107,8 @@ class DataParallel:
         elif batch_coupled:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
                                  update_running_stats=False, moments_to_bucket=True)
+        elif getattr(model, "dropout_by_sample_offset", False):      # dropout without BatchNorm (RGCNU): masks indexed by global sample
+            model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset)
         else:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch)
         self.all_reduce_bucket(model.bucket)

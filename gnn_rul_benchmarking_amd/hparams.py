@@ -64,6 +64,10 @@ class _Table:
             self.train_params['HAGCN'] = dict(_HAGCN_TRAIN)
             self.alg_hparams['HAGCN'] = {'patch_size': ps, 'num_patch': npatch, 'hidden_dim': 64, 'encoder_hidden_dim': 60,
                                          'output_dim': 32}
+            # configs/hparams.py:23,42,80,120,160 (C-MAPSS FD001-4) and :187,205 (N-CMAPSS): one row everywhere
+            self.train_params['RGCNU'] = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3, 'lambda': 0.1}
+            self.alg_hparams['RGCNU'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50, 'hidden_dim': 32, 'encoder_hidden_dim': 32,
+                                         'kernel_size': 3, 'alpha': 1}
             # configs/hparams.py:27,47,88,128,168 (C-MAPSS: one patch of 50) and :191,211 (N-CMAPSS: 5 patches of 10)
             self.train_params['STGNN'] = dict(_ASTGCNN_TRAIN)
             self.alg_hparams['STGNN'] = {'patch_size': 50 if self._astgcnn_nodes == 14 else 10,

@@ -47,12 +47,19 @@ class FusedAdam(torch.optim.Optimizer):
         flat = model.flat_params
         if not flat.is_cuda:
             raise RuntimeError("FusedAdam runs on the HIP kernel only: move the model to a CUDA (ROCm) device")
-        n = flat.numel()
+        # parameters that never receive a gradient sit at the END of some flat buffers (RGCNU's second head): torch.optim.Adam
+        # leaves `grad is None` parameters untouched -- no update, no weight decay -- so the kernel stops in front of them
+        n = int(getattr(model, "num_optimized", flat.numel()))
         if not from_bucket:
             grads = [p.grad for p in self.param_groups[0]["params"]]
-            if any(g is None for g in grads):
-                raise RuntimeError("FusedAdam.step(): a live parameter has no gradient")
-            model.bucket[:n].copy_(torch.cat([g.reshape(-1) for g in grads]))
+            live, off = [], 0
+            for p_, g_ in zip(self.param_groups[0]["params"], grads):
+                if off < n and g_ is None:
+                    raise RuntimeError("FusedAdam.step(): a live parameter has no gradient")
+                if off < n:
+                    live.append(g_.reshape(-1))
+                off += p_.numel()
+            model.bucket[:n].copy_(torch.cat(live))
         m, v = self._state_buffers()
         g = self.param_groups[0]
         self._steps += 1

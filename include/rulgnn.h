@@ -421,6 +421,61 @@ int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape *shape, floa
                                          float momentum, int32_t from_moments, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RGCNU path (reference models/RGCNU/Model.py:96-119, algorithms/algorithms.py:250-296; SURVEY section 8f rank 3: a GCNLayer user
+ * the reference wires to C-MAPSS FD001-4 and N-CMAPSS, configs/hparams.py:42,80,120,160,205).
+ *
+ * x [batch, num_nodes, time_length] -> learned adjacency A = relu(tanh(alpha (A1 A2^T - A2 A1^T))), A1/2 = tanh(alpha Linear(x))
+ * (adj_construction :80-93) -> per (sample, time step) a graph of the num_nodes sensors with ONE feature, two GCN layers
+ * (symmetric normalisation of A + I; 1 -> hidden -> hidden, ReLU), Dropout(0.5), 1x1 convolution back to one feature (SCL
+ * :25-43) -> nn.LSTM(num_nodes -> encoder_hidden) over the time steps (TDL :46-53) -> 1x1 convolution of x + the LSTM output,
+ * Conv1d(kernel_size, padding='same'), two Linear heads (FusionModule :56-78): pred [batch] and std [batch].  The loss of
+ * RGCNU.update is the MSE of pred alone (:287-290): the std head (fc2) receives no gradient.
+ * Quirk kept: the adjacency batch is tiled time_length times along the batch axis while the node signals are sample-major
+ * (Model.py:104-106): graph (b, l) is convolved with the adjacency of sample (b * time_length + l) % batch.
+ *
+ * Flat parameter buffer in the order of the reference's named_parameters():
+ *   adj.trainable_theta1.{weight[N][L], bias[N]} | adj.trainable_theta2.{...} | scl.gcn1.linear.{weight[H][1], bias[H]} |
+ *   scl.gcn2.linear.{weight[H][H], bias[H]} | scl.conv1d.{weight[1][H][1], bias[1]} |
+ *   tdl.lstm.{weight_ih_l0[4E][N], weight_hh_l0[4E][E], bias_ih_l0[4E], bias_hh_l0[4E]} |
+ *   fusion.cnn1.{weight[E][N][1], bias[E]} | fusion.cnn2.{weight[E][E][k], bias[E]} | fusion.fc1.{weight[E*L], bias[1]} |
+ *   fusion.fc2.{weight[E*L], bias[1]}
+ * Limits: num_nodes <= 32, time_length <= 64, hidden_dim, encoder_hidden_dim <= 64, odd kernel_size <= 7, every tensor <= 4096
+ * values (RULGNN_EUNSUPPORTED beyond; every wiring of the reference is 14|20 x 50, 32, 32, 3).
+ */
+typedef struct rulgnn_rgcnu_shape {
+    int64_t batch;
+    int32_t num_nodes, time_length, hidden_dim, encoder_hidden_dim, kernel_size;
+    float alpha;
+} rulgnn_rgcnu_shape;
+
+typedef struct rulgnn_rgcnu_args {
+    const float *x;           /* [batch, num_nodes * time_length] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;
+    float *grads;             /* same layout as params; the fc2 entries are written as zeros */
+    float *pred;              /* [batch] */
+    float *std_pred;          /* [batch] second head (model(X, train=True)[1]); may be NULL */
+    float *loss;              /* [1] sum over the shard of (pred - y)^2 / global_batch; may be NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;
+    int64_t sample_offset;    /* index of this shard's first sample in the global batch (dropout stream) */
+    float dropout_p;          /* SCL's Dropout, 0.5 in the reference (Model.py:31); applied when training != 0 */
+    uint64_t seed, step;      /* dropout stream: mask = f(seed, step, element index) */
+    int32_t training;
+} rulgnn_rgcnu_args;
+
+int64_t rulgnn_rgcnu_param_count(const rulgnn_rgcnu_shape *shape);         /* < 0: invalid / unsupported */
+size_t rulgnn_rgcnu_workspace_bytes(const rulgnn_rgcnu_shape *shape);
+/* model(X) / model(X, train=True): RGCNU_model.forward (Model.py:104-119). */
+int rulgnn_rgcnu_forward_f32(const rulgnn_rgcnu_shape *shape, const rulgnn_rgcnu_args *args, void *stream);
+/* loss.backward() (algorithms.py:294) after a forward with the same args / workspace. */
+int rulgnn_rgcnu_backward_f32(const rulgnn_rgcnu_shape *shape, const rulgnn_rgcnu_args *args, void *stream);
+/* RGCNU.update body (algorithms.py:285-295); with `opt` also Adam on the flat parameter buffer. */
+int rulgnn_rgcnu_fwdbwd_f32(const rulgnn_rgcnu_shape *shape, const rulgnn_rgcnu_args *args, const rulgnn_adam_args *opt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
  * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
  * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).
