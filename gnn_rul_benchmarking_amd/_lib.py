@@ -97,6 +97,18 @@ class FcstgnnArgs(C.Structure):
                 ("compute_dtype", C.c_int32)]
 
 
+class StnetShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_patch", C.c_int32), ("patch_size", C.c_int32), ("num_nodes", C.c_int32), ("nperseg", C.c_int32),
+                ("input_dim", C.c_int32), ("num_cheb", C.c_int32), ("cheb_layers", C.c_int32 * 4), ("lstm_hidden_dim", C.c_int32),
+                ("autoencoder_hidden_dim", C.c_int32)]
+
+
+class StnetArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("recon", C.c_void_p), ("loss", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64)]
+
+
 class RgcnuShape(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("hidden_dim", C.c_int32),
                 ("encoder_hidden_dim", C.c_int32), ("kernel_size", C.c_int32), ("alpha", C.c_float)]
@@ -137,6 +149,11 @@ class BilstmArgs(C.Structure):
 ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 _SIGNATURES = {
+    "rulgnn_stnet_param_count": (C.c_int64, [C.POINTER(StnetShape)]),
+    "rulgnn_stnet_workspace_bytes": (C.c_size_t, [C.POINTER(StnetShape)]),
+    "rulgnn_stnet_forward_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.c_void_p]),
+    "rulgnn_stnet_backward_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.c_void_p]),
+    "rulgnn_stnet_fwdbwd_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_rgcnu_param_count": (C.c_int64, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_workspace_bytes": (C.c_size_t, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_forward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),

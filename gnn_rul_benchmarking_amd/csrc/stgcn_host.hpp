@@ -155,6 +155,9 @@ int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float
 int stgnn_cheb_forward(const rulgnn_stgnn_shape* s, const float* terms, const float* filters, float* out, hipStream_t st);
 int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const float* dout, float* dfilters, void* workspace,
                         size_t workspace_bytes, hipStream_t st);
+int64_t stnet_param_count(const rulgnn_stnet_shape* s);
+size_t stnet_workspace_bytes(const rulgnn_stnet_shape* s);
+int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode, hipStream_t st);
 int64_t rgcnu_param_count(const rulgnn_rgcnu_shape* s);
 size_t rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* s);
 int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode, hipStream_t st);

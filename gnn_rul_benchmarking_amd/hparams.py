@@ -46,6 +46,7 @@ def get_hparams_class(dataset_name):
 class _Table:
     _rows: dict = {}
     _stmsgcn_rows: dict = {}          # the reference wires STMSGCN to the bearing datasets only
+    _stnet_rows: dict = {}            # ... and STNet (configs/hparams.py:222,236,267,303 and :333,347,382,416)
     _astgcnn_nodes = None             # ... and ASTGCNN to the aero-engine datasets only (configs/hparams.py:38,202)
 
     def __init__(self, dataset_id=None, **overrides):
@@ -75,6 +76,12 @@ class _Table:
                                          'hidden_dim': 64, 'K': 3, 'top_k': 10}
             self.train_params['FC_STGNN'] = dict(_FC_STGNN_TRAIN)
             self.alg_hparams['FC_STGNN'] = dict(_FC_STGNN_ROWS[dataset_id])
+        if dataset_id in self._stnet_rows:
+            self.train_params['STNet'] = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-2, 'learning_rate': 1e-2}
+            num_patch, patch_size, num_nodes, nperseg, input_dim = self._stnet_rows[dataset_id]
+            self.alg_hparams['STNet'] = {'num_patch': num_patch, 'patch_size': patch_size, 'num_nodes': num_nodes, 'nperseg': nperseg,
+                                         'input_dim': input_dim, 'Cheb_layers': [300, 200, 100], 'lstm_hidden_dim': 10,
+                                         'autoencoder_hidden_dim': 50}
         if dataset_id in self._stmsgcn_rows:
             self.train_params['STMSGCN'] = dict(_STMSGCN_TRAIN)
             self.alg_hparams['STMSGCN'] = dict(self._stmsgcn_rows[dataset_id], gcn_dims=list(_MSG['gcn_dims']),
@@ -107,6 +114,7 @@ class PHM2012(_Table):
     _stmsgcn_rows = {'Condition_1': {'num_patch': 160, 'patch_size': 16, 'interval': 6, 'band_width': 5},
                      'Condition_2': {'num_patch': 128, 'patch_size': 20, 'interval': 2, 'band_width': 3},
                      'Condition_3': {'num_patch': 160, 'patch_size': 16, 'interval': 6, 'band_width': 5}}
+    _stnet_rows = {'Condition_1': (20, 128, 9, 16, 9), 'Condition_2': (20, 128, 9, 16, 9), 'Condition_3': (80, 32, 5, 8, 5)}
 
 
 class XJTU_SY(_Table):
@@ -116,6 +124,7 @@ class XJTU_SY(_Table):
     _stmsgcn_rows = {'Condition_1': {'num_patch': 256, 'patch_size': 128, 'interval': 3, 'band_width': 5},
                      'Condition_2': {'num_patch': 128, 'patch_size': 256, 'interval': 6, 'band_width': 10},
                      'Condition_3': {'num_patch': 256, 'patch_size': 128, 'interval': 3, 'band_width': 5}}
+    _stnet_rows = {'Condition_1': (128, 256, 9, 16, 17), 'Condition_2': (32, 1024, 17, 32, 33), 'Condition_3': (64, 512, 17, 32, 17)}
 
 
 _DATASETS = {'CMAPSS': CMAPSS, 'NCMAPSS': NCMAPSS, 'PHM2012': PHM2012, 'XJTU_SY': XJTU_SY}

@@ -47,31 +47,35 @@ class FusedAdam(torch.optim.Optimizer):
         flat = model.flat_params
         if not flat.is_cuda:
             raise RuntimeError("FusedAdam runs on the HIP kernel only: move the model to a CUDA (ROCm) device")
-        # parameters that never receive a gradient sit at the END of some flat buffers (RGCNU's second head): torch.optim.Adam
-        # leaves `grad is None` parameters untouched -- no update, no weight decay -- so the kernel stops in front of them
-        n = int(getattr(model, "num_optimized", flat.numel()))
+        # parameters that never receive a gradient sit at one END of some flat buffers (RGCNU's second head at the tail, STNet's
+        # thresholded 1x1 convolution at the head): torch.optim.Adam leaves `grad is None` parameters untouched -- no update, no
+        # weight decay -- so the kernel runs over [start, end) only
+        start, end = getattr(model, "optimized_range", (0, int(getattr(model, "num_optimized", flat.numel()))))
+        n = end - start
         if not from_bucket:
             grads = [p.grad for p in self.param_groups[0]["params"]]
             live, off = [], 0
             for p_, g_ in zip(self.param_groups[0]["params"], grads):
-                if off < n and g_ is None:
+                inside = start <= off < end
+                if inside and g_ is None:
                     raise RuntimeError("FusedAdam.step(): a live parameter has no gradient")
-                if off < n:
+                if inside:
                     live.append(g_.reshape(-1))
                 off += p_.numel()
-            model.bucket[:n].copy_(torch.cat(live))
+            model.bucket[start:end].copy_(torch.cat(live))
         m, v = self._state_buffers()
         g = self.param_groups[0]
         self._steps += 1
         state = getattr(model, "_step_state", None)
+        o = 4 * start
         if state is not None:          # device-resident step (hipGraph-capturable, see graphs.py)
             _lib.check(_lib.load().rulgnn_adam_step_dev_f32(
-                flat.data_ptr(), model.bucket.data_ptr(), m.data_ptr(), v.data_ptr(), n, state.data_ptr(),
+                flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, state.data_ptr(),
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                 float(grad_scale), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_adam_step_dev_f32")
             return None
         _lib.check(_lib.load().rulgnn_adam_step_f32(
-            flat.data_ptr(), model.bucket.data_ptr(), m.data_ptr(), v.data_ptr(), n, self._steps,
+            flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, self._steps,
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
             float(grad_scale), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_adam_step_f32")
         return None

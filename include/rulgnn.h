@@ -476,6 +476,55 @@ int rulgnn_rgcnu_backward_f32(const rulgnn_rgcnu_shape *shape, const rulgnn_rgcn
 int rulgnn_rgcnu_fwdbwd_f32(const rulgnn_rgcnu_shape *shape, const rulgnn_rgcnu_args *args, const rulgnn_adam_args *opt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * STNet path (reference models/STNet/Model.py:44-169, algorithms/algorithms.py:438-463; SURVEY section 8f rank 3: a ChebNet user the
+ * reference wires to the bearing datasets, configs/hparams.py:236,267,303,347,382,416).
+ *
+ * x [batch, num_patch * patch_size] -> per (sample, patch): |STFT| with n_fft = hop = win = nperseg, periodic Hann window,
+ * reflect-centred (torch.stft's defaults; Model.py:84-92) = num_nodes = nperseg/2 + 1 frequency nodes x input_dim = 1 +
+ * patch_size/nperseg frames -> node weight = cnn(mean, max over the frames) (1x1 Conv2d, 2 -> 1) -> nodes above 0.7 are fully
+ * connected (:104-110) -> num_cheb ChebNets, K = 3, no non-linearity in between (:114-115) -> Y_o [batch, num_patch,
+ * num_nodes * C_last] -> encoder (Linear + ReLU x3, Linear) -> H [.., autoencoder_hidden] -> decoder (mirror) -> reconstruction
+ * MSE(Y_o, decoder(H)) (:141) ; LSTM(autoencoder_hidden -> lstm_hidden) over the patches -> Linear(lstm_hidden * num_patch -> 1).
+ * STNet.update: loss = MSE(pred, y) + reconstruction.  The threshold passes no gradient: cnn.{weight, bias} have grad None in the
+ * reference (their entries of `grads` are written as zeros, and the optimizer must leave them alone -- they are the FIRST 3 floats).
+ *
+ * Flat parameter buffer in the order of the reference's named_parameters():
+ *   cnn.weight[2] | cnn.bias[1] | chebnets.i.filters[3][C_i][C_i+1] ... | encoder.{0,2,4,6}.{weight[out][in], bias} |
+ *   decoder.{0,2,4,6}.{weight, bias} | lstm.{weight_ih_l0[4E][A], weight_hh_l0[4E][E], bias_ih_l0[4E], bias_hh_l0[4E]} |
+ *   linear.{weight[E * num_patch], bias[1]}
+ * Limits: even nperseg <= 64 dividing patch_size, <= 64 frames, <= 4 ChebNets of <= 4096 channels, lstm_hidden <= 128,
+ * autoencoder_hidden <= 1024 (RULGNN_EUNSUPPORTED beyond); num_nodes / input_dim must equal the STFT's shape (RULGNN_EINVAL).
+ */
+typedef struct rulgnn_stnet_shape {
+    int64_t batch;
+    int32_t num_patch, patch_size, num_nodes, nperseg, input_dim;
+    int32_t num_cheb, cheb_layers[4];
+    int32_t lstm_hidden_dim, autoencoder_hidden_dim;
+} rulgnn_stnet_shape;
+
+typedef struct rulgnn_stnet_args {
+    const float *x;           /* [batch, num_patch * patch_size] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y.  The reconstruction term always
+                               * enters the backward with weight 1 (it is part of the reference's loss) */
+    const float *params;
+    float *grads;
+    float *pred;              /* [batch] */
+    float *recon;             /* [1] reconstruction MSE, averaged over the GLOBAL batch's elements (this shard's share); may be NULL */
+    float *loss;              /* [1] this shard's share of MSE(pred, y) + reconstruction; may be NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;
+} rulgnn_stnet_args;
+
+int64_t rulgnn_stnet_param_count(const rulgnn_stnet_shape *shape);         /* < 0: invalid / unsupported */
+size_t rulgnn_stnet_workspace_bytes(const rulgnn_stnet_shape *shape);
+int rulgnn_stnet_forward_f32(const rulgnn_stnet_shape *shape, const rulgnn_stnet_args *args, void *stream);
+int rulgnn_stnet_backward_f32(const rulgnn_stnet_shape *shape, const rulgnn_stnet_args *args, void *stream);
+/* STNet.update body (algorithms.py:455-462); with `opt` also Adam on the flat parameter buffer behind the cnn entries. */
+int rulgnn_stnet_fwdbwd_f32(const rulgnn_stnet_shape *shape, const rulgnn_stnet_args *args, const rulgnn_adam_args *opt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
  * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
  * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).

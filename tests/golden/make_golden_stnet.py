@@ -129,3 +129,45 @@ if __name__ == "__main__":
     case_forward_backward("stnet_small_3x24_bs6", CS, 6, 3)
     case_init("stnet_init_c1like_seed4", C1, 4)
     case_training_curve("stnet_train_curve_6x128_bs8", C1, 8, 10, 5, 1e-2, 1e-2)
+
+
+def case_trainer_phm2012(name, seed, n_train=200, n_test=60, epochs=3):
+    """The reference's OWN harness with --GNN_method STNet on the synthetic PHM2012 Condition_1 dataset of synth.py with its own hparams
+    (configs/hparams.py:222,236: 20 patches of 128, ChebNets [300, 200, 100], batch 100, lr 1e-2, wd 1e-2; no shuffling); num_epochs patched."""
+    import argparse
+    import tempfile
+    import trainer as ref_trainer
+    from synth import synthetic_phm2012
+    _orig_load = torch.load
+    torch.load = lambda *a, **k: _orig_load(*a, **{**k, "weights_only": False})
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(seed, n_train, n_test)
+    with tempfile.TemporaryDirectory() as tmp:
+        d = os.path.join(tmp, "data", "PHM2012", "Condition_1")
+        os.makedirs(d)
+        torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, os.path.join(d, "train.pt"))
+        torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, os.path.join(d, "test.pt"))
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            args = argparse.Namespace(save_dir=os.path.join(tmp, "logs"), experiment_description="exp", run_description="r",
+                                      GNN_method="STNet", data_path=os.path.join(tmp, "data"), dataset="PHM2012",
+                                      dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cpu")
+            tr = ref_trainer.GNN_RUL_trainer(args)
+            tr.train_configs["num_epochs"] = epochs
+            per_epoch = []
+            orig = tr.calc_results_per_run
+
+            def spy(run_id):
+                per_epoch.append(mg.ref_utils._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+                return orig(run_id)
+            tr.calc_results_per_run = spy
+            tr.train()
+            csv_text = open(os.path.join(tmp, "logs", "exp", "r", "STNet_run_0", "results.csv")).read()
+        finally:
+            os.chdir(cwd)
+            torch.load = _orig_load
+    out = {"seed": np.int64(seed), "n_train": np.int64(n_train), "n_test": np.int64(n_test), "epochs": np.int64(epochs),
+           "per_epoch": np.asarray(per_epoch, np.float64), "csv_text": np.array(csv_text),
+           "x_train_checksum": np.float64(xtr.astype(np.float64).sum())}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, np.asarray(per_epoch))

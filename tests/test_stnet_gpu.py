@@ -1,0 +1,153 @@
+"""STNet HIP path vs the reference's golden outputs and vs the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stnet_oracle as O
+from test_stnet_oracle_golden import CASES, load_case, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+TOL = 1e-4
+GTOL = 1e-3            # gradients through three un-normalised Chebyshev layers: values of 1e4..1e8, sums of O(rows) fp32 products
+
+
+def build_model(cfg, p):
+    from gnn_rul_benchmarking_amd.stnet import STNet_model
+    m = STNet_model(**cfg)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v, np.float32)) for k, v in p.items()})
+    return m.to(DEV)
+
+
+def grads_of(m):
+    flat = m._grad_flat[:m.num_live].detach().cpu().numpy().astype(np.float64)
+    return {name: flat[off:off + int(np.prod(shape))].reshape(shape) for name, (off, shape) in m._layout.items()}
+
+
+def signal(bs, n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)[None, :]
+    x = np.zeros((bs, n))
+    for _ in range(4):
+        fr = rng.uniform(0.02, 0.45, (bs, 1))
+        x += rng.uniform(0.0, 1.2, (bs, 1)) * np.sin(2 * np.pi * fr * t + rng.uniform(0, 6.28, (bs, 1)))
+    return x + 0.3 * rng.standard_normal((bs, n))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_reconstruction_and_gradients_match_reference_golden(name):
+    z, cfg, p = load_case(name)
+    m = build_model(cfg, p)
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        pred = m(x)
+    assert pred.shape == (x.size(0), 1) and rel(pred.cpu().numpy(), z["eval_pred"]) < TOL
+    m.train()
+    pr, rc = m(x, train=True)
+    assert rel(pr.detach().cpu().numpy(), z["pred"]) < TOL
+    assert abs(float(rc) - float(z["recon"])) < TOL * float(z["recon"])
+    pred2, loss = m.fused_mse_step(x, y)
+    assert rel(pred2.cpu().numpy().reshape(-1, 1), z["pred"]) < TOL
+    assert abs(float(loss) - float(z["loss"])) < TOL * abs(float(z["loss"]))
+    g = grads_of(m)
+    for k in O.param_names(len(cfg["Cheb_layers"])):
+        if k.startswith("cnn."):
+            assert not g[k].any()
+            continue
+        assert rel(g[k], z["grad:" + k]) < GTOL, k
+
+
+@pytest.mark.parametrize("T,P,ns,cheb,E,A,bs", [(20, 128, 16, [300, 200, 100], 10, 50, 16), (80, 32, 8, [300, 200, 100], 10, 50, 3),
+                                               (4, 256, 16, [33, 17], 10, 50, 5), (2, 64, 32, [8, 8, 8, 8], 4, 6, 7), (3, 24, 6, [7, 5], 3, 6, 1)])
+def test_training_step_matches_oracle(T, P, ns, cheb, E, A, bs):
+    N, f = ns // 2 + 1, 1 + P // ns
+    cfg = dict(num_patch=T, patch_size=P, num_nodes=N, nperseg=ns, input_dim=f, Cheb_layers=cheb, lstm_hidden_dim=E, autoencoder_hidden_dim=A)
+    p = O.random_params(T, N, f, cheb, E, A, seed=bs)
+    y = np.random.default_rng(bs).uniform(0, 1, bs)
+    for attempt in range(20):        # inputs without a node weight within 5e-5 of the 0.7 threshold (a discrete decision: fp32 vs fp64)
+        x = signal(bs, T * P, T * 10 + bs + 1000 * attempt)
+        mag = O.stft_magnitude(x.reshape(bs * T, P), ns)
+        nw = 0.3 * mag.mean(-1) + 0.1 * mag.max(-1) + 0.1
+        if np.abs(nw - O.NODE_THRESHOLD).min() > 5e-5:
+            break
+    loss, grads, fw = O.loss_and_grads(p, x, y, T, P, ns)
+    assert 0.0 < fw.mask.mean() < 1.0 and np.abs(fw.node_w - O.NODE_THRESHOLD).min() > 5e-5       # a mixed graph, no knife-edge node
+    m = build_model(cfg, p).train()
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    pred, l = m.fused_mse_step(xt, yt)
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    g = grads_of(m)
+    for k in O.param_names(len(cheb)):
+        if not k.startswith("cnn."):
+            assert rel(g[k], grads[k]) < GTOL, k
+
+
+def test_autograd_path_equals_fused_path_and_the_thresholded_convolution_stays_untouched():
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    z, cfg, p = load_case("stnet_phm_c3like_7x32_bs4")
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    m = build_model(cfg, p).train()
+    m.fused_mse_step(x, y)
+    fused = m._grad_flat[:m.num_live].clone()
+    m2 = build_model(cfg, p).train()
+    pred, recon = m2(x, train=True)
+    (torch.nn.functional.mse_loss(pred, y) + recon).backward()
+    table = dict(m2.named_parameters())
+    assert table["cnn.weight"].grad is None and table["cnn.bias"].grad is None
+    auto = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in m2._named()])
+    assert torch.equal(auto, fused)
+    with pytest.raises(RuntimeError, match="weight 1"):
+        pr, rc = m2(x, train=True)
+        (pr.sum() + 0.5 * rc).backward()
+    algo = get_algorithm_class("STNet")(cfg, {"learning_rate": 1e-2, "weight_decay": 1e-2}, DEV)
+    algo.to(DEV).train()
+    before = {k: v.clone() for k, v in algo.model.state_dict().items()}
+    a = algo.update(x, y, 1)["loss"]
+    b = algo.update_reference_style(x, y, 1)["loss"]
+    assert np.isfinite(a) and np.isfinite(b)
+    after = algo.model.state_dict()
+    assert torch.equal(after["cnn.weight"], before["cnn.weight"]) and torch.equal(after["cnn.bias"], before["cnn.bias"])
+    assert not torch.equal(after["linear.weight"], before["linear.weight"])
+
+
+def test_training_curve_matches_reference_algorithm():
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    z = np.load(os.path.join(GOLD, "stnet_train_curve_6x128_bs8.npz"))
+    cfg = {k[4:]: (z[k].tolist() if z[k].ndim else int(z[k])) for k in z.files if k.startswith("cfg:")}
+    algo = get_algorithm_class("STNet")(cfg, {"learning_rate": float(z["lr"]), "weight_decay": float(z["wd"])}, DEV)
+    algo.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0:")})
+    algo.to(DEV).train()
+    xs, ys = torch.from_numpy(z["xs"]).to(DEV), torch.from_numpy(z["ys"]).to(DEV)
+    losses = [algo.update(xs[s], ys[s], 1)["loss"] for s in range(xs.size(0))]
+    assert np.allclose(losses[:3], z["losses"][:3], rtol=1e-3)
+    assert np.allclose(losses, z["losses"], rtol=5e-2), (losses, z["losses"].tolist())
+    sd = algo.state_dict()
+    for k in ("model.cnn.weight", "model.cnn.bias"):
+        assert np.array_equal(sd[k].cpu().numpy(), z["sd_end:" + k])
+
+
+def test_abi_rejects_what_it_documents():
+    import ctypes as C
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+
+    def shape(**kw):
+        s = _lib.StnetShape()
+        base = dict(batch=4, num_patch=20, patch_size=128, num_nodes=9, nperseg=16, input_dim=9, num_cheb=3, lstm_hidden_dim=10, autoencoder_hidden_dim=50)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(s, k, v)
+        for i, c in enumerate((300, 200, 100)):
+            s.cheb_layers[i] = c
+        return s
+    from gnn_rul_benchmarking_amd.stnet import STNet_model
+    n = sum(p.numel() for p in STNet_model(20, 128, 9, 16, 9, [300, 200, 100], 10, 50).parameters())
+    assert lib.rulgnn_stnet_param_count(C.byref(shape())) == n
+    assert lib.rulgnn_stnet_param_count(C.byref(shape(num_nodes=8))) < 0            # does not describe the STFT's shape
+    assert lib.rulgnn_stnet_workspace_bytes(C.byref(shape(nperseg=15))) == 0
+    assert lib.rulgnn_stnet_workspace_bytes(C.byref(shape(patch_size=130))) == 0

@@ -531,3 +531,47 @@ def test_rgcnu_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monkeyp
     ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
     assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
     assert np.allclose(csv.iloc[1:].to_numpy()[:, 2:], ref_csv.iloc[1:].to_numpy()[:, 2:], rtol=2e-3)
+
+
+def test_stnet_trainer_matches_reference_harness_run_on_phm2012(tmp_path, monkeypatch):
+    """--GNN_method STNet on PHM2012 Condition_1 as the reference wires it (configs/hparams.py:222,236: 20 patches of 128 points, STFT
+    9 x 9, ChebNets [300, 200, 100], batch 100, lr 1e-2, wd 1e-2): the reference's own harness, run on CPU by
+    tests/golden/make_golden_stnet.py::case_trainer_phm2012, vs this package's harness on the GPU (measured agreement: RMSE to 6e-7)."""
+    import io
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_phm2012
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "stnet_trainer_phm2012_c1_reference_run.npz"))
+    (xtr, ytr), (xte, yte) = synthetic_phm2012(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "PHM2012" / "Condition_1"
+    os.makedirs(d)
+    torch.save({"samples": xtr, "labels": ytr, "max_ruls": 1.0}, d / "train.pt")
+    torch.save({"samples": xte, "labels": yte, "max_ruls": 1.0}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="STNet", data_path=str(tmp_path / "data"), dataset="PHM2012",
+                              dataset_id="Condition_1", bearing_id="Testing_bearing_1", num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.model_configs == dict(num_patch=20, patch_size=128, num_nodes=9, nperseg=16, input_dim=9, Cheb_layers=[300, 200, 100],
+                                    lstm_hidden_dim=10, autoencoder_hidden_dim=50)
+    assert tr.train_configs == {'num_epochs': 3, 'batch_size': 100, 'weight_decay': 1e-2, 'learning_rate': 1e-2}
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("STNet harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 3] - ref[:, 3])) < 1e-4                  # RMSE on the normalised scale (north star: 1e-3)
+    assert np.max(np.abs(got[:, 2:] - ref[:, 2:]) / np.abs(ref[:, 2:])) < 1e-4
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "STNet_run_0" / "results.csv")
+    ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
+    assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
