@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="--family FC_STGNN only: bf16 = BASELINE.json's 'FC_STGNN ... bf16' variant (bf16 operands on the row-projection "
                          "matrix-core GEMMs, fp32 accumulate / BatchNorm / graphs / weight gradients); reported separately, it does not meet 1e-4")
-    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN", "RGCNU", "STNet"],
+    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN", "RGCNU", "STNet", "SAGCN"],
                     help="ST_GCN (default) is the headline benchmark; the others run the same contract on the SURVEY section 8d "
                          "configuration of that model family")
     return ap.parse_args()
@@ -270,6 +270,9 @@ FAMILY_CONFIGS = {
     # SURVEY 8f rank 3 (PHM2012 Condition_1 wiring at the reference protocol's batch); forward FLOPs per sample: the three ChebNet GEMMs
     # over 20 x 9 node rows 180 * 2 * (27*300 + 900*200 + 600*100), auto-encoder 20 * 2 * (2*900*50 + 6*50*50), LSTM, head
     "STNet": ("PHM2012", "Condition_1", 100, (1, 2560), 89.3e6 + 4.2e6 + 0.05e6),
+    # SURVEY 8f rank 3 (PHM2012 Condition_2 wiring: 128 patches of 20 points, hidden 1000 / 200, the reference protocol's batch); forward
+    # FLOPs per sample: gcn1 2*128*40*1000, two projection layers 2 * (2*128*128*1000 + 2*128*1000*1000), attention 2 * 2*200*128*1000
+    "SAGCN": ("PHM2012", "Condition_2", 100, (1, 2560), 10.2e6 + 2 * (32.8e6 + 256e6) + 102.4e6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
 
@@ -370,6 +373,12 @@ def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
         bs = 256
         x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
         run = lambda: O.forward_backward(x, y, p, cfg["num_patch"], cfg["patch_size"], cfg["top_k"])
+    elif family == "SAGCN":
+        from oracle import sagcn_oracle as O
+        p = O.random_params(cfg["num_patch"], cfg["gcn_hidden_dim"], cfg["attention_hidden_dim"])
+        bs = 8
+        x, y = rng.uniform(-0.5, 0.5, (bs, shape[1])), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, cfg["num_patch"], cfg["patch_size"])
     else:
         return None                    # HAGCN: the oracle restates forward + per-block backward, not one timed train step
     run()

@@ -109,6 +109,17 @@ class StnetArgs(C.Structure):
                 ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64)]
 
 
+class SagcnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_patch", C.c_int32), ("patch_size", C.c_int32), ("gcn_hidden_dim", C.c_int32),
+                ("attention_hidden_dim", C.c_int32)]
+
+
+class SagcnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("loss", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("global_batch", C.c_int64)]
+
+
 class RgcnuShape(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("hidden_dim", C.c_int32),
                 ("encoder_hidden_dim", C.c_int32), ("kernel_size", C.c_int32), ("alpha", C.c_float)]
@@ -154,6 +165,12 @@ _SIGNATURES = {
     "rulgnn_stnet_forward_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.c_void_p]),
     "rulgnn_stnet_backward_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.c_void_p]),
     "rulgnn_stnet_fwdbwd_f32": (C.c_int, [C.POINTER(StnetShape), C.POINTER(StnetArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_sagcn_param_count": (C.c_int64, [C.POINTER(SagcnShape)]),
+    "rulgnn_sagcn_workspace_bytes": (C.c_size_t, [C.POINTER(SagcnShape)]),
+    "rulgnn_sagcn_tap_offset": (C.c_int64, [C.POINTER(SagcnShape), C.c_int32]),
+    "rulgnn_sagcn_forward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
+    "rulgnn_sagcn_backward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
+    "rulgnn_sagcn_fwdbwd_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_rgcnu_param_count": (C.c_int64, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_workspace_bytes": (C.c_size_t, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_forward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),

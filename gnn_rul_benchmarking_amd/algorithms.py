@@ -22,6 +22,7 @@ from .stgcn import ST_GCN_model
 from .stgnn import STGNN_model
 from .stmsgcn import STMSGCN_model
 from .stnet import STNet_model
+from .sagcn import SAGCN_model
 
 
 def get_algorithm_class(algorithm_name):
@@ -423,4 +424,40 @@ class STNet(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class SAGCN(Algorithm):
+    """SAGCN training wrapper (reference algorithms.py:412-436): ``update`` = forward + MSE + backward + Adam in one C call
+    (csrc/sagcn.hip, matrix-core GEMMs, the fused Adam kernel).  No BatchNorm, no dropout: samples are independent and data
+    parallelism is the plain ``[gradient | loss]`` bucket."""
+
+    supports_graphs = False
+
+    def __init__(self, configs, hparams, device):
+        super(SAGCN, self).__init__(configs)
+        self.model = SAGCN_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        else:
+            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return self._finish(loss)
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd (algorithms.py:427-436); same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "SAGCN_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}

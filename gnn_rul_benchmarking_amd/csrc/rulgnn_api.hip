@@ -654,6 +654,56 @@ int rulgnn_stnet_fwdbwd_f32(const rulgnn_stnet_shape* shape, const rulgnn_stnet_
                      opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
 }
 
+// ---- SAGCN ----------------------------------------------------------------------------------------------------------------------
+int64_t rulgnn_sagcn_param_count(const rulgnn_sagcn_shape* shape) { return sagcn_param_count(shape); }
+size_t rulgnn_sagcn_workspace_bytes(const rulgnn_sagcn_shape* shape) { return sagcn_workspace_bytes(shape); }
+int64_t rulgnn_sagcn_tap_offset(const rulgnn_sagcn_shape* shape, int32_t which) { return sagcn_tap_offset(shape, which); }
+
+static int check_sagcn(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_args* a, bool bwd) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (sagcn_param_count(shape) < 0) return RULGNN_EUNSUPPORTED;
+    int rc = check_ptrs({a->params, a->workspace});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch > 0) {
+        rc = check_ptrs({a->x, a->pred});
+        if (rc != RULGNN_OK) return rc;
+    }
+    if (bwd) {
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->dpred && !a->y && shape->batch > 0) return RULGNN_EINVAL;
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_sagcn_forward_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_args* args, void* stream) {
+    const int rc = check_sagcn(shape, args, false);
+    if (rc != RULGNN_OK) return rc;
+    return sagcn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_sagcn_backward_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_args* args, void* stream) {
+    const int rc = check_sagcn(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    return sagcn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_args* args, const rulgnn_adam_args* opt, void* stream) {
+    int rc = check_sagcn(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred || (!args->y && shape->batch > 0)) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = sagcn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, sagcn_param_count(shape), opt->step, opt->lr, opt->beta1,
+                     opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
 // ---- RGCNU ----------------------------------------------------------------------------------------------------------------------
 int64_t rulgnn_rgcnu_param_count(const rulgnn_rgcnu_shape* shape) { return rgcnu_param_count(shape); }
 size_t rulgnn_rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* shape) { return rgcnu_workspace_bytes(shape); }

@@ -158,6 +158,10 @@ int stgnn_cheb_backward(const rulgnn_stgnn_shape* s, const float* terms, const f
 int64_t stnet_param_count(const rulgnn_stnet_shape* s);
 size_t stnet_workspace_bytes(const rulgnn_stnet_shape* s);
 int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode, hipStream_t st);
+int64_t sagcn_param_count(const rulgnn_sagcn_shape* s);
+size_t sagcn_workspace_bytes(const rulgnn_sagcn_shape* s);
+int64_t sagcn_tap_offset(const rulgnn_sagcn_shape* s, int which);
+int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode, hipStream_t st);
 int64_t rgcnu_param_count(const rulgnn_rgcnu_shape* s);
 size_t rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* s);
 int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode, hipStream_t st);

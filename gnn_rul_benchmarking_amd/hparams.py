@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN, ST_Conv and STGNN rows are restated (the methods this package
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN, ST_Conv, STGNN, RGCNU, STNet and SAGCN rows are restated (the methods this package
 implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
@@ -47,6 +47,7 @@ class _Table:
     _rows: dict = {}
     _stmsgcn_rows: dict = {}          # the reference wires STMSGCN to the bearing datasets only
     _stnet_rows: dict = {}            # ... and STNet (configs/hparams.py:222,236,267,303 and :333,347,382,416)
+    _sagcn_rows: dict = {}            # ... and SAGCN (configs/hparams.py:221,235,266,302 and :332,346,381,415)
     _astgcnn_nodes = None             # ... and ASTGCNN to the aero-engine datasets only (configs/hparams.py:38,202)
 
     def __init__(self, dataset_id=None, **overrides):
@@ -82,6 +83,11 @@ class _Table:
             self.alg_hparams['STNet'] = {'num_patch': num_patch, 'patch_size': patch_size, 'num_nodes': num_nodes, 'nperseg': nperseg,
                                          'input_dim': input_dim, 'Cheb_layers': [300, 200, 100], 'lstm_hidden_dim': 10,
                                          'autoencoder_hidden_dim': 50}
+        if dataset_id in self._sagcn_rows:
+            self.train_params['SAGCN'] = {'num_epochs': 81, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-4}
+            num_patch, patch_size, gcn_hidden, attention_hidden = self._sagcn_rows[dataset_id]
+            self.alg_hparams['SAGCN'] = {'num_patch': num_patch, 'patch_size': patch_size, 'gcn_hidden_dim': gcn_hidden,
+                                         'attention_hidden_dim': attention_hidden}
         if dataset_id in self._stmsgcn_rows:
             self.train_params['STMSGCN'] = dict(_STMSGCN_TRAIN)
             self.alg_hparams['STMSGCN'] = dict(self._stmsgcn_rows[dataset_id], gcn_dims=list(_MSG['gcn_dims']),
@@ -115,6 +121,7 @@ class PHM2012(_Table):
                      'Condition_2': {'num_patch': 128, 'patch_size': 20, 'interval': 2, 'band_width': 3},
                      'Condition_3': {'num_patch': 160, 'patch_size': 16, 'interval': 6, 'band_width': 5}}
     _stnet_rows = {'Condition_1': (20, 128, 9, 16, 9), 'Condition_2': (20, 128, 9, 16, 9), 'Condition_3': (80, 32, 5, 8, 5)}
+    _sagcn_rows = {'Condition_1': (160, 16, 100, 100), 'Condition_2': (128, 20, 1000, 200), 'Condition_3': (128, 20, 1000, 200)}
 
 
 class XJTU_SY(_Table):
@@ -125,6 +132,7 @@ class XJTU_SY(_Table):
                      'Condition_2': {'num_patch': 128, 'patch_size': 256, 'interval': 6, 'band_width': 10},
                      'Condition_3': {'num_patch': 256, 'patch_size': 128, 'interval': 3, 'band_width': 5}}
     _stnet_rows = {'Condition_1': (128, 256, 9, 16, 17), 'Condition_2': (32, 1024, 17, 32, 33), 'Condition_3': (64, 512, 17, 32, 17)}
+    _sagcn_rows = {'Condition_1': (32, 1024, 1000, 100), 'Condition_2': (32, 1024, 1000, 200), 'Condition_3': (32, 1024, 1000, 200)}
 
 
 _DATASETS = {'CMAPSS': CMAPSS, 'NCMAPSS': NCMAPSS, 'PHM2012': PHM2012, 'XJTU_SY': XJTU_SY}

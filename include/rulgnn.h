@@ -525,6 +525,54 @@ int rulgnn_stnet_backward_f32(const rulgnn_stnet_shape *shape, const rulgnn_stne
 int rulgnn_stnet_fwdbwd_f32(const rulgnn_stnet_shape *shape, const rulgnn_stnet_args *args, const rulgnn_adam_args *opt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SAGCN path (reference models/SAGCN/Model.py:6-156, algorithms/algorithms.py:412-436; the reference wires
+ * it to the bearing datasets, configs/hparams.py:235,266,302,346,381,415).
+ *
+ * x [batch, num_patch * patch_size] -> per patch 12 temporal statistics (Model.py:17-34: max, min, std, rms, mean, peak-to-peak, var,
+ * entropy of softmax, std of arcsin / arctan, kurtosis, skewness; std / var unbiased) + 8 spectral ones (:37-52: mean frequency,
+ * frequency at the median rank of the sorted power, band power, occupied bandwidth, power bandwidth, max power, max amplitude, its
+ * frequency; fs = 1) -> their cumulative form along the patches (:6-14) appended -> [num_patch, 40] scaled to unit Frobenius norm
+ * (:66-69) -> cosine adjacency (:73-79) -> gcn1: ReLU(Linear_40->H(D^-1/2 (A + I) D^-1/2 X)) -> proj1, proj2: ReLU(Linear_H->H(
+ * Linear_P->P over the node axis)) (:99-112) -> attention = softmax over the nodes of Linear_Ah->P(tanh(Linear_P->Ah(x^T))) (:115-125)
+ * -> x * attention -> Linear(H * num_patch -> 1).  SAGCN.update: plain MSE.
+ *
+ * Tie rule of the two index-valued statistics (the spectrum of a real signal is mirrored exactly): the largest amplitude's bin is the
+ * first one (torch.argmax); the bin at rank patch_size / 2 is taken from a STABLE ascending sort of the power (the reference's
+ * torch.argsort is unstable: its CPU sort agrees for patch_size <= 16, beyond that its order among equal keys is unspecified).
+ *
+ * Flat parameter buffer in the order of the reference's named_parameters():
+ *   gcn1.linear.{weight[H][40], bias[H]} | proj1.linear.{weight[H][H], bias[H]} | proj1.project_matrices.{weight[P][P], bias[P]} |
+ *   proj2.(same) | attn.tanh_layer.{weight[Ah][P], bias[Ah]} | attn.softmax_layer.{weight[P][Ah], bias[P]} | fc.{weight[H * P], bias[1]}
+ * Limits: num_patch <= 256, 2 <= patch_size <= 2048, hidden sizes <= 4096, batch * H * num_patch < 2^31 (RULGNN_EUNSUPPORTED beyond).
+ */
+typedef struct rulgnn_sagcn_shape {
+    int64_t batch;
+    int32_t num_patch, patch_size, gcn_hidden_dim, attention_hidden_dim;
+} rulgnn_sagcn_shape;
+
+typedef struct rulgnn_sagcn_args {
+    const float *x;           /* [batch, num_patch * patch_size] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;
+    float *grads;
+    float *pred;              /* [batch] */
+    float *loss;              /* [1] this shard's share of MSE(pred, y) over the GLOBAL batch; may be NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;
+} rulgnn_sagcn_args;
+
+int64_t rulgnn_sagcn_param_count(const rulgnn_sagcn_shape *shape);         /* < 0: invalid / unsupported */
+size_t rulgnn_sagcn_workspace_bytes(const rulgnn_sagcn_shape *shape);
+/* workspace taps for the parity tests: float offsets of the normalised features [batch][P][40] and of A_hat X [P][batch][40] */
+int64_t rulgnn_sagcn_tap_offset(const rulgnn_sagcn_shape *shape, int32_t which);   /* 0 features, 1 A_hat X, 2 h3 [P][batch][H], 3 attention */
+int rulgnn_sagcn_forward_f32(const rulgnn_sagcn_shape *shape, const rulgnn_sagcn_args *args, void *stream);
+int rulgnn_sagcn_backward_f32(const rulgnn_sagcn_shape *shape, const rulgnn_sagcn_args *args, void *stream);
+/* SAGCN.update body (algorithms.py:427-435); with `opt` also Adam on the flat parameter buffer. */
+int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape *shape, const rulgnn_sagcn_args *args, const rulgnn_adam_args *opt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
  * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
  * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).
