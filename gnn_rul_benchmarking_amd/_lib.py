@@ -120,6 +120,17 @@ class SagcnArgs(C.Structure):
                 ("global_batch", C.c_int64)]
 
 
+class StagnnShape(C.Structure):
+    _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("hidden_dim", C.c_int32),
+                ("output_dim", C.c_int32), ("num_heads", C.c_int32), ("threshold", C.c_float)]
+
+
+class StagnnArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
+                ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_state", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64), ("training", C.c_int32), ("update_running_stats", C.c_int32)]
+
+
 class RgcnuShape(C.Structure):
     _fields_ = [("batch", C.c_int64), ("num_nodes", C.c_int32), ("time_length", C.c_int32), ("hidden_dim", C.c_int32),
                 ("encoder_hidden_dim", C.c_int32), ("kernel_size", C.c_int32), ("alpha", C.c_float)]
@@ -171,6 +182,13 @@ _SIGNATURES = {
     "rulgnn_sagcn_forward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
     "rulgnn_sagcn_backward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
     "rulgnn_sagcn_fwdbwd_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_stagnn_param_count": (C.c_int64, [C.POINTER(StagnnShape)]),
+    "rulgnn_stagnn_bn_state_count": (C.c_int64, [C.POINTER(StagnnShape)]),
+    "rulgnn_stagnn_workspace_bytes": (C.c_size_t, [C.POINTER(StagnnShape)]),
+    "rulgnn_stagnn_tap_offset": (C.c_int64, [C.POINTER(StagnnShape), C.c_int32]),
+    "rulgnn_stagnn_forward_f32": (C.c_int, [C.POINTER(StagnnShape), C.POINTER(StagnnArgs), C.c_void_p]),
+    "rulgnn_stagnn_backward_f32": (C.c_int, [C.POINTER(StagnnShape), C.POINTER(StagnnArgs), C.c_void_p]),
+    "rulgnn_stagnn_fwdbwd_f32": (C.c_int, [C.POINTER(StagnnShape), C.POINTER(StagnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_rgcnu_param_count": (C.c_int64, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_workspace_bytes": (C.c_size_t, [C.POINTER(RgcnuShape)]),
     "rulgnn_rgcnu_forward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),

@@ -23,6 +23,7 @@ from .stgnn import STGNN_model
 from .stmsgcn import STMSGCN_model
 from .stnet import STNet_model
 from .sagcn import SAGCN_model
+from .stagnn import STAGNN_model
 
 
 def get_algorithm_class(algorithm_name):
@@ -460,4 +461,42 @@ class SAGCN(Algorithm):
         return {'loss': loss.item()}
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "SAGCN_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}
+class STAGNN(Algorithm):
+    """STAGNN training wrapper (reference algorithms.py:298-323): ``update`` = train-mode forward (batch statistics in the four
+    BatchNorm1d layers, running statistics updated) + MSE + backward + Adam in one C call (csrc/stagnn.hip, the fused Adam kernel).
+    Data parallelism: the plain ``[gradient | loss]`` bucket with rank-local BatchNorm statistics."""
+
+    supports_graphs = False
+
+    def __init__(self, configs, hparams, device):
+        super(STAGNN, self).__init__(configs)
+        self.model = STAGNN_model(**configs)
+        self.optimizer = FusedAdam(self.model, lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        self.hparams = hparams
+        self.dp = None
+        self.sync_loss = True
+
+    def attach_data_parallel(self, dp):
+        self.dp = dp
+        dp.broadcast_model(self.model)
+
+    def update(self, X, y, epoch=None, global_batch=None, sample_offset=None):
+        if not self.model.training:
+            raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics)")
+        if self.dp is not None:
+            loss = self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        else:
+            _, loss = self.model.fused_mse_step(X, y, self.optimizer)
+        return self._finish(loss)
+
+    def update_reference_style(self, X, y, epoch=None):
+        """The reference's literal sequence through autograd (algorithms.py:314-323); same result as ``update``."""
+        predicted_RUL = self.model(X)
+        loss = self.mse(predicted_RUL, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'loss': loss.item()}
+
+
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "SAGCN_model", "STAGNN_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations"}

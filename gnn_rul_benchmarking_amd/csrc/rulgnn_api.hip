@@ -704,6 +704,58 @@ int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_
                      opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
 }
 
+// ---- STAGNN ---------------------------------------------------------------------------------------------------------------------
+int64_t rulgnn_stagnn_param_count(const rulgnn_stagnn_shape* shape) { return stagnn_param_count(shape); }
+int64_t rulgnn_stagnn_bn_state_count(const rulgnn_stagnn_shape* shape) { return stagnn_bn_state_count(shape); }
+size_t rulgnn_stagnn_workspace_bytes(const rulgnn_stagnn_shape* shape) { return stagnn_workspace_bytes(shape); }
+int64_t rulgnn_stagnn_tap_offset(const rulgnn_stagnn_shape* shape, int32_t which) { return stagnn_tap_offset(shape, which); }
+
+static int check_stagnn(const rulgnn_stagnn_shape* shape, const rulgnn_stagnn_args* a, bool bwd) {
+    if (!shape || !a) return RULGNN_EINVAL;
+    if (stagnn_param_count(shape) < 0) return RULGNN_EUNSUPPORTED;
+    int rc = check_ptrs({a->params, a->workspace, a->bn_state});
+    if (rc != RULGNN_OK) return rc;
+    if (shape->batch > 0) {
+        rc = check_ptrs({a->x, a->pred});
+        if (rc != RULGNN_OK) return rc;
+    }
+    if (bwd) {
+        rc = check_ptrs({a->grads});
+        if (rc != RULGNN_OK) return rc;
+        if (!a->training) return RULGNN_EINVAL;
+        if (!a->dpred && !a->y && shape->batch > 0) return RULGNN_EINVAL;
+    }
+    return RULGNN_OK;
+}
+
+int rulgnn_stagnn_forward_f32(const rulgnn_stagnn_shape* shape, const rulgnn_stagnn_args* args, void* stream) {
+    const int rc = check_stagnn(shape, args, false);
+    if (rc != RULGNN_OK) return rc;
+    return stagnn_run(shape, args, 1, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stagnn_backward_f32(const rulgnn_stagnn_shape* shape, const rulgnn_stagnn_args* args, void* stream) {
+    const int rc = check_stagnn(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    return stagnn_run(shape, args, 2, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape* shape, const rulgnn_stagnn_args* args, const rulgnn_adam_args* opt, void* stream) {
+    int rc = check_stagnn(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred || (!args->y && shape->batch > 0)) return RULGNN_EINVAL;
+    if (opt) {
+        if ((opt->step < 1 && !opt->step_state) || opt->params != args->params) return RULGNN_EINVAL;
+        rc = check_ptrs({opt->params, opt->exp_avg, opt->exp_avg_sq});
+        if (rc != RULGNN_OK) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = stagnn_run(shape, args, 3, st);
+    if (rc != RULGNN_OK || !opt) return rc;
+    return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stagnn_param_count(shape), opt->step, opt->lr, opt->beta1,
+                     opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
 // ---- RGCNU ----------------------------------------------------------------------------------------------------------------------
 int64_t rulgnn_rgcnu_param_count(const rulgnn_rgcnu_shape* shape) { return rgcnu_param_count(shape); }
 size_t rulgnn_rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* shape) { return rgcnu_workspace_bytes(shape); }

@@ -1,0 +1,968 @@
+// STAGNN on gfx950 (the last of the GCNLayer users).
+// Reference path replaced: STAGNN_model.forward -- models/STAGNN/Model.py:184-230 (GCNLayer :8-22, GraphAttentionLayer :26-61, GAT
+// :63-74, TemporalConvNet :85-159, MultiHeadTemporalEncoder :163-180) -- and STAGNN.update, algorithms/algorithms.py:314-323.
+//
+//   x [bs, N, L] -> adj = (covariance of the sensor rows > threshold) -> gcn1 (L -> h, leaky 0.01) -> gat1 (mean of `heads`
+//   attention layers: softmax over ALL neighbours, then masked by adj) -> gcn2 -> gat2 -> [N, h] read as N channels of length T = h
+//   -> tcn1 (causal k = 2 convolutions, dilation 1 and 2, each + BatchNorm1d + ReLU, residuals; N -> h -> h channels) -> temporal
+//   encoder 1 (softmax over the length of sigmoid(Linear over the channels), mean over the heads, x scaled) -> tcn2 (h -> out -> out)
+//   -> temporal encoder 2 -> Linear(out * h -> 1).
+//
+// A sample is a few [<= 64, <= 64] matrices: one workgroup per sample and stage, everything of the sample in LDS.  The four train-mode
+// BatchNorms need the statistics of the whole batch before they can be applied, so the model is cut at them: graph | conv1 | BN,
+// residual, conv2 | BN, residual, encoder (| the same three for tcn2, the last one with the head) forward, and the mirror image
+// backward (each BatchNorm backward needs two more batch-wide sums).  Per-workgroup fp64 partial sums are combined by every consumer
+// in a fixed order; weight gradients accumulate in per-workgroup rows (each slot owned by one thread) that one kernel adds in a fixed
+// order: the step is deterministic.  Eval mode normalises with the running statistics (no cut needed, same kernels).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgemm_mfma.hpp"
+#include "stgcn_host.hpp"
+
+namespace rulgnn {
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int TG_MAXN = 32, TG_MAXL = 128, TG_MAXH = 64, TG_MAXOUT = 16, TG_MAXHEADS = 4, TG_CMAX = 64;
+constexpr float TG_BN_EPS = 1e-5f, TG_GCN_SLOPE = 0.01f, TG_GAT_SLOPE = 0.1f, TG_BN_MOMENTUM = 0.1f;
+
+struct TgGeom {
+    int64_t B;
+    int N, L, h, out, heads, T, nblk;
+    float thr;
+    int Ci[2], Co[2];
+    // flat parameter offsets (reference named_parameters() order, live parameters only)
+    int o_gcn_w[2], o_gcn_b[2], o_gat_w[2][TG_MAXHEADS], o_gat_b[2][TG_MAXHEADS], o_gat_a[2][TG_MAXHEADS], o_gat_ab[2][TG_MAXHEADS];
+    int o_ds_w[2], o_ds_b[2], o_c1_w[2], o_bn_g[4], o_bn_b[4], o_c2_w[2], o_enc_w[2][TG_MAXHEADS], o_enc_b[2][TG_MAXHEADS], o_fc_w, o_fc_b, pcount;
+    int bn_off[4], bn_total;                    // running_mean at bn_off[k], running_var at bn_off[k] + channels
+    // workspace (float offsets; per-sample arrays are [B][stride])
+    int64_t w_adj, w_ahat, w_ax1, w_pre1, w_wh[2], w_gpre[2], w_att[2], w_g1, w_ax2, w_pre2, w_G;
+    int64_t w_z1[2], w_o0[2], w_z2[2], w_o1[2], w_es[2], w_ew[2], w_e[2];
+    int64_t w_dy2[2], w_dres[2], w_dy1[2], w_dxin[2], w_dpred, w_sq, w_bnpart, w_dbnpart, w_gpart, total;
+};
+
+int tg_geometry(const rulgnn_stagnn_shape* s, TgGeom* g) {
+    if (!s) return RULGNN_EINVAL;
+    if (s->batch < 0 || s->num_nodes < 1 || s->time_length < 2 || s->hidden_dim < 1 || s->output_dim < 1 || s->num_heads < 1) return RULGNN_EINVAL;
+    if (s->num_nodes > TG_MAXN || s->time_length > TG_MAXL || s->hidden_dim > TG_MAXH || s->output_dim > TG_MAXOUT || s->num_heads > TG_MAXHEADS)
+        return RULGNN_EUNSUPPORTED;
+    // the residual branches: downsample0 exists when the channel counts differ (Model.py:104); downsample1 never (both widths equal)
+    if (s->num_nodes == s->hidden_dim || s->hidden_dim == s->output_dim) return RULGNN_EUNSUPPORTED;
+    if (s->hidden_dim < 3) return RULGNN_EUNSUPPORTED;          // the dilation-2 convolution runs along a length of hidden_dim
+    g->B = s->batch; g->N = s->num_nodes; g->L = s->time_length; g->h = s->hidden_dim; g->out = s->output_dim; g->heads = s->num_heads;
+    g->T = g->h; g->thr = s->threshold;
+    g->Ci[0] = g->N; g->Co[0] = g->h; g->Ci[1] = g->h; g->Co[1] = g->out;
+    g->nblk = (int)(g->B < 256 ? (g->B > 0 ? g->B : 1) : 256);
+    const int N = g->N, L = g->L, h = g->h, T = g->T, Hd = g->heads;
+    int o = 0;
+    for (int l = 0; l < 2; ++l) {
+        g->o_gcn_w[l] = o; o += h * (l == 0 ? L : h);
+        g->o_gcn_b[l] = o; o += h;
+        for (int i = 0; i < Hd; ++i) {
+            g->o_gat_w[l][i] = o; o += h * h;
+            g->o_gat_b[l][i] = o; o += h;
+            g->o_gat_a[l][i] = o; o += 2 * h;
+            g->o_gat_ab[l][i] = o; o += 1;
+        }
+    }
+    int bo = 0;
+    for (int l = 0; l < 2; ++l) {
+        const int Ci = g->Ci[l], Co = g->Co[l];
+        g->o_ds_w[l] = o; o += Co * Ci;
+        g->o_ds_b[l] = o; o += Co;
+        g->o_c1_w[l] = o; o += Co * Ci * 2;
+        g->o_bn_g[2 * l] = o; o += Co;
+        g->o_bn_b[2 * l] = o; o += Co;
+        g->o_c2_w[l] = o; o += Co * Co * 2;
+        g->o_bn_g[2 * l + 1] = o; o += Co;
+        g->o_bn_b[2 * l + 1] = o; o += Co;
+        for (int i = 0; i < Hd; ++i) {
+            g->o_enc_w[l][i] = o; o += Co;
+            g->o_enc_b[l][i] = o; o += 1;
+        }
+        g->bn_off[2 * l] = bo; bo += 2 * Co;
+        g->bn_off[2 * l + 1] = bo; bo += 2 * Co;
+    }
+    g->o_fc_w = o; o += g->out * h;
+    g->o_fc_b = o; o += 1;
+    g->pcount = o;
+    g->bn_total = bo;
+    int64_t w = 0;
+    const int64_t B = g->B;
+    auto take = [&w](int64_t nfl) { const int64_t at = w; w += (nfl + 63) & ~(int64_t)63; return at; };
+    g->w_adj = take(B * N * N); g->w_ahat = take(B * N * N);
+    g->w_ax1 = take(B * N * L); g->w_pre1 = take(B * N * h);
+    for (int l = 0; l < 2; ++l) { g->w_wh[l] = take(B * Hd * N * h); g->w_gpre[l] = take(B * Hd * N * N); g->w_att[l] = take(B * Hd * N * N); }
+    g->w_g1 = take(B * N * h); g->w_ax2 = take(B * N * h); g->w_pre2 = take(B * N * h); g->w_G = take(B * N * h);
+    for (int l = 0; l < 2; ++l) {
+        const int64_t ct = (int64_t)g->Co[l] * T;
+        g->w_z1[l] = take(B * ct); g->w_o0[l] = take(B * ct); g->w_z2[l] = take(B * ct); g->w_o1[l] = take(B * ct);
+        g->w_es[l] = take(B * Hd * T); g->w_ew[l] = take(B * Hd * T); g->w_e[l] = take(B * ct);
+        g->w_dy2[l] = take(B * ct); g->w_dres[l] = take(B * ct); g->w_dy1[l] = take(B * ct); g->w_dxin[l] = take(B * g->Ci[l] * T);
+    }
+    g->w_dpred = take(B); g->w_sq = take(B);
+    g->w_bnpart = take((int64_t)2 * 4 * g->nblk * 2 * TG_CMAX);          // doubles: two floats each
+    g->w_dbnpart = take((int64_t)2 * 4 * g->nblk * 2 * TG_CMAX);
+    g->w_gpart = take((int64_t)g->nblk * g->pcount);
+    g->total = w;
+    return RULGNN_OK;
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+// ---- BatchNorm constants of one layer, by every workgroup in the same fixed order ------------------------------------------------
+__device__ void bn_consts(int Co, const double* __restrict__ part, int nblk, const float* __restrict__ running, int training, double cnt,
+                          float* mu, float* istd) {
+    for (int c = threadIdx.x; c < Co; c += TB) {
+        double mean, var;
+        if (training) {
+            double s = 0.0, q = 0.0;
+            for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+            mean = s / cnt;
+            var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+        } else {
+            mean = running[c];
+            var = running[Co + c];
+        }
+        mu[c] = (float)mean;
+        istd[c] = (float)(1.0 / sqrt(var + (double)TG_BN_EPS));
+    }
+}
+
+// mean over the batch of dy and of dy * xhat (the two sums of the BatchNorm backward)
+__device__ void bn_bwd_means(int Co, const double* __restrict__ part, int nblk, double cnt, float* m1, float* m2) {
+    for (int c = threadIdx.x; c < Co; c += TB) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+        m1[c] = (float)(s / cnt);
+        m2[c] = (float)(q / cnt);
+    }
+}
+
+// ---- graph part, forward ---------------------------------------------------------------------------------------------------------
+// LDS: X[N*L] | adj[N*N] | ah[N*N] | AX[N*max(L,h)] | H0[N*h] | H1[N*h] | Wh[N*h] | att[N*N] | f1[N] | f2[N]
+__global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
+    const int Lh = L > h ? L : h;
+    float* X = lds;
+    float* adj = X + N * L;
+    float* ah = adj + N * N;
+    float* AX = ah + N * N;
+    float* H0 = AX + N * Lh;
+    float* H1 = H0 + N * h;
+    float* Wh = H1 + N * h;
+    float* att = Wh + N * h;
+    float* f1 = att + N * N;
+    float* f2 = f1 + N;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < N * L; i += TB) X[i] = x[b * N * L + i];
+        __syncthreads();
+        if (tid < N) {
+            float s = 0.f;
+            for (int l = 0; l < L; ++l) s += X[tid * L + l];
+            f1[tid] = s / (float)L;
+        }
+        __syncthreads();
+        for (int e = tid; e < N * N; e += TB) {
+            const int i = e / N, j = e % N;
+            float c = 0.f;
+            for (int l = 0; l < L; ++l) c = fmaf(X[i * L + l] - f1[i], X[j * L + l] - f1[j], c);
+            adj[e] = c / (float)(L - 1) > g.thr ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (tid < N) {
+            float d = 1.f;
+            for (int j = 0; j < N; ++j) d += adj[tid * N + j];
+            f2[tid] = 1.0f / sqrtf(d);
+        }
+        __syncthreads();
+        for (int e = tid; e < N * N; e += TB) {
+            const int i = e / N, j = e % N;
+            const float v = f2[i] * (adj[e] + (i == j ? 1.f : 0.f)) * f2[j];
+            ah[e] = v;
+            ws[g.w_adj + b * N * N + e] = adj[e];
+            ws[g.w_ahat + b * N * N + e] = v;
+        }
+        __syncthreads();
+        for (int layer = 0; layer < 2; ++layer) {
+            const int K = layer == 0 ? L : h;                       // input width of this GCN layer
+            const float* in = layer == 0 ? X : H1;
+            // AX = A_hat in
+            for (int e = tid; e < N * K; e += TB) {
+                const int i = e / K, k = e % K;
+                float a = 0.f;
+                for (int j = 0; j < N; ++j) a = fmaf(ah[i * N + j], in[j * K + k], a);
+                AX[e] = a;
+                ws[(layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K + e] = a;
+            }
+            __syncthreads();
+            const float* W = prm + g.o_gcn_w[layer];
+            for (int e = tid; e < N * h; e += TB) {
+                const int i = e / h, o = e % h;
+                float a = prm[g.o_gcn_b[layer] + o];
+                for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], W[o * K + k], a);
+                ws[(layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h + e] = a;
+                H0[e] = lrelu(a, TG_GCN_SLOPE);
+                H1[e] = 0.f;
+            }
+            __syncthreads();
+            for (int hd = 0; hd < Hd; ++hd) {
+                const float* Wl = prm + g.o_gat_w[layer][hd];
+                const float* av = prm + g.o_gat_a[layer][hd];
+                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
+                for (int e = tid; e < N * h; e += TB) {
+                    const int i = e / h, o = e % h;
+                    float a = prm[g.o_gat_b[layer][hd] + o];
+                    for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wl[o * h + k], a);
+                    Wh[e] = a;
+                    ws[at_wh + e] = a;
+                }
+                __syncthreads();
+                if (tid < 2 * N) {
+                    const int i = tid % N, half = tid / N;
+                    float a = 0.f;
+                    for (int o = 0; o < h; ++o) a = fmaf(av[half * h + o], Wh[i * h + o], a);
+                    (half ? f2 : f1)[i] = a;
+                }
+                __syncthreads();
+                const float ab = prm[g.o_gat_ab[layer][hd]];
+                if (tid < N) {
+                    const int i = tid;
+                    float m = -INFINITY;
+                    for (int j = 0; j < N; ++j) {
+                        const float pre = f1[i] + f2[j] + ab;
+                        ws[g.w_gpre[layer] + at_nn + i * N + j] = pre;
+                        m = fmaxf(m, lrelu(pre, TG_GAT_SLOPE));
+                    }
+                    float s = 0.f;
+                    for (int j = 0; j < N; ++j) {
+                        const float ev = expf(lrelu(f1[i] + f2[j] + ab, TG_GAT_SLOPE) - m);
+                        att[i * N + j] = ev;
+                        s += ev;
+                    }
+                    const float inv = 1.0f / s;
+                    for (int j = 0; j < N; ++j) {
+                        const float a = att[i * N + j] * inv;
+                        att[i * N + j] = a;
+                        ws[g.w_att[layer] + at_nn + i * N + j] = a;
+                    }
+                }
+                __syncthreads();
+                const float ih = 1.0f / (float)Hd;
+                for (int e = tid; e < N * h; e += TB) {
+                    const int i = e / h, o = e % h;
+                    float a = 0.f;
+                    for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * h + o], a);
+                    H1[e] = fmaf(a, ih, H1[e]);
+                }
+                __syncthreads();
+            }
+            for (int e = tid; e < N * h; e += TB) ws[(layer == 0 ? g.w_g1 : g.w_G) + b * N * h + e] = H1[e];
+            __syncthreads();
+        }
+    }
+}
+
+// ---- TCN stage 1: z1 = causal conv (dilation 1) of the input; BatchNorm partial sums -----------------------------------------------
+// LDS: xin[Ci*T] | z[Co*T]
+__global__ __launch_bounds__(TB) void tg_conv1_fwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                          float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    float* xin = lds;
+    float* z = xin + Ci * T;
+    const float* W = prm + g.o_c1_w[l];
+    double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s = 0.0, q = 0.0;                                       // thread c < Co: sums of channel c over this workgroup's samples
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T, t = e % T;
+            float a = 0.f;
+            for (int ci = 0; ci < Ci; ++ci) {
+                a = fmaf(W[(c * Ci + ci) * 2 + 1], xin[ci * T + t], a);
+                if (t >= 1) a = fmaf(W[(c * Ci + ci) * 2], xin[ci * T + t - 1], a);
+            }
+            z[e] = a;
+            ws[g.w_z1[l] + b * Co * T + e] = a;
+        }
+        __syncthreads();
+        if (tid < Co)
+            for (int t = 0; t < T; ++t) { const double v = z[tid * T + t]; s += v; q += v * v; }
+    }
+    if (tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
+}
+
+// ---- TCN stage 2: BN1, ReLU, + residual (1x1 convolution of the input), ReLU -> out0; z2 = causal conv (dilation 2); BN partials --
+// LDS: xin[Ci*T] | o0[Co*T] | z[Co*T] | mu[Co] | istd[Co]
+__global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                        const float* __restrict__ bnstate, float* __restrict__ ws, int training) {
+    extern __shared__ float lds[];
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    float* xin = lds;
+    float* o0 = xin + Ci * T;
+    float* z = o0 + Co * T;
+    float* mu = z + Co * T;
+    float* istd = mu + Co;
+    const double cnt = (double)g.B * T;
+    bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], training,
+              cnt, mu, istd);
+    const float* Wd = prm + g.o_ds_w[l];
+    const float* W2 = prm + g.o_c2_w[l];
+    const float* gam = prm + g.o_bn_g[2 * l];
+    const float* bet = prm + g.o_bn_b[2 * l];
+    double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l + 1) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s = 0.0, q = 0.0;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T, t = e % T;
+            const float y1 = fmaf((ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
+            float r = prm[g.o_ds_b[l] + c];
+            for (int ci = 0; ci < Ci; ++ci) r = fmaf(Wd[c * Ci + ci], xin[ci * T + t], r);
+            const float v = fmaxf(fmaxf(y1, 0.f) + r, 0.f);
+            o0[e] = v;
+            ws[g.w_o0[l] + b * Co * T + e] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T, t = e % T;
+            float a = 0.f;
+            for (int ci = 0; ci < Co; ++ci) {
+                a = fmaf(W2[(c * Co + ci) * 2 + 1], o0[ci * T + t], a);
+                if (t >= 2) a = fmaf(W2[(c * Co + ci) * 2], o0[ci * T + t - 2], a);
+            }
+            z[e] = a;
+            ws[g.w_z2[l] + b * Co * T + e] = a;
+        }
+        __syncthreads();
+        if (training && tid < Co)
+            for (int t = 0; t < T; ++t) { const double v = z[tid * T + t]; s += v; q += v * v; }
+    }
+    if (training && tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
+}
+
+// ---- TCN stage 3: BN2, ReLU, + out0, ReLU -> out1; temporal encoder -> e; for the second TCN also the head and the loss terms -------
+// LDS: o1[Co*T] | u[heads*T] | m[T] | mu[Co] | istd[Co] | red[TB]
+__global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const float* __restrict__ prm, const float* __restrict__ bnstate,
+                                                        float* __restrict__ ws, int training, const float* __restrict__ y, float* __restrict__ pred,
+                                                        float inv_gb) {
+    extern __shared__ float lds[];
+    const int Co = g.Co[l], T = g.T, Hd = g.heads, tid = threadIdx.x;
+    float* o1 = lds;
+    float* u = o1 + Co * T;
+    float* m = u + Hd * T;
+    float* mu = m + T;
+    float* istd = mu + Co;
+    float* red = istd + Co;
+    const double cnt = (double)g.B * T;
+    bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1],
+              training, cnt, mu, istd);
+    const float* gam = prm + g.o_bn_g[2 * l + 1];
+    const float* bet = prm + g.o_bn_b[2 * l + 1];
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T;
+            const float y2 = fmaf((ws[g.w_z2[l] + b * Co * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
+            const float v = fmaxf(fmaxf(y2, 0.f) + ws[g.w_o0[l] + b * Co * T + e], 0.f);
+            o1[e] = v;
+            ws[g.w_o1[l] + b * Co * T + e] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < Hd * T; e += TB) {
+            const int hd = e / T, t = e % T;
+            float a = prm[g.o_enc_b[l][hd]];
+            for (int c = 0; c < Co; ++c) a = fmaf(prm[g.o_enc_w[l][hd] + c], o1[c * T + t], a);
+            const float sg = 1.0f / (1.0f + expf(-a));
+            u[e] = sg;
+            ws[g.w_es[l] + (b * Hd + hd) * T + t] = sg;
+        }
+        __syncthreads();
+        if (tid < Hd) {
+            float mx = -INFINITY;
+            for (int t = 0; t < T; ++t) mx = fmaxf(mx, u[tid * T + t]);
+            float sum = 0.f;
+            for (int t = 0; t < T; ++t) sum += expf(u[tid * T + t] - mx);
+            const float inv = 1.0f / sum;
+            for (int t = 0; t < T; ++t) {
+                const float w = expf(u[tid * T + t] - mx) * inv;
+                u[tid * T + t] = w;
+                ws[g.w_ew[l] + (b * Hd + tid) * T + t] = w;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += TB) {
+            float a = 0.f;
+            for (int hd = 0; hd < Hd; ++hd) a += u[hd * T + t];
+            m[t] = a / (float)Hd;
+        }
+        __syncthreads();
+        float acc = 0.f;
+        for (int e = tid; e < Co * T; e += TB) {
+            const float v = o1[e] * m[e % T];
+            ws[g.w_e[l] + b * Co * T + e] = v;
+            if (l == 1) acc = fmaf(v, prm[g.o_fc_w + e], acc);
+        }
+        if (l == 1) {
+            red[tid] = acc;
+            __syncthreads();
+            for (int k = TB / 2; k > 0; k >>= 1) {
+                if (tid < k) red[tid] += red[tid + k];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const float pr = red[0] + prm[g.o_fc_b];
+                pred[b] = pr;
+                if (y) {
+                    const float d = pr - y[b];
+                    ws[g.w_sq + b] = d * d * inv_gb;
+                    ws[g.w_dpred + b] = 2.f * d * inv_gb;
+                }
+            }
+        }
+    }
+}
+
+// running statistics after a train-mode forward (BatchNorm1d: momentum 0.1, unbiased variance)
+__global__ void tg_running_kernel(TgGeom g, const float* __restrict__ ws, float* __restrict__ bnstate) {
+    const int k = blockIdx.x, Co = g.Co[k / 2];
+    const double cnt = (double)g.B * g.T;
+    const double* part = reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)k * g.nblk * 2 * TG_CMAX;
+    for (int c = threadIdx.x; c < Co; c += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < g.nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        float* rm = bnstate + g.bn_off[k];
+        rm[c] = (float)((1.0 - TG_BN_MOMENTUM) * rm[c] + TG_BN_MOMENTUM * mean);
+        rm[Co + c] = (float)((1.0 - TG_BN_MOMENTUM) * rm[Co + c] + TG_BN_MOMENTUM * unb);
+    }
+}
+
+// ---- backward of stage 3: (head,) encoder, ReLU, residual split, ReLU of the BN2 branch; BN2-backward partial sums ----------------
+// LDS: o1[Co*T] | de[Co*T] | s[heads*T] | w[heads*T] | dm[T] | du[heads*T] | mu[Co] | istd[Co] | dot[heads]
+__global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const float* __restrict__ prm, const float* __restrict__ bnstate,
+                                                        float* __restrict__ ws, const float* __restrict__ dpred, const float* __restrict__ de_g) {
+    extern __shared__ float lds[];
+    const int Co = g.Co[l], T = g.T, Hd = g.heads, tid = threadIdx.x;
+    float* o1 = lds;
+    float* de = o1 + Co * T;
+    float* sg = de + Co * T;
+    float* wv = sg + Hd * T;
+    float* dm = wv + Hd * T;
+    float* du = dm + T;
+    float* mu = du + Hd * T;
+    float* istd = mu + Co;
+    float* dot = istd + Co;
+    const double cnt = (double)g.B * T;
+    bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1], 1,
+              cnt, mu, istd);
+    const float* gam = prm + g.o_bn_g[2 * l + 1];
+    const float* bet = prm + g.o_bn_b[2 * l + 1];
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    double* part = reinterpret_cast<double*>(ws + g.w_dbnpart) + ((int64_t)(2 * l + 1) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const float v = ws[g.w_o1[l] + b * Co * T + e];
+            o1[e] = v;
+            if (l == 1) {
+                const float dp = dpred[b];
+                de[e] = dp * prm[g.o_fc_w + e];
+                gp[g.o_fc_w + e] += dp * ws[g.w_e[l] + b * Co * T + e];
+            } else {
+                de[e] = de_g[b * Co * T + e];
+            }
+        }
+        if (l == 1 && tid == 0) gp[g.o_fc_b] += dpred[b];
+        for (int e = tid; e < Hd * T; e += TB) {
+            sg[e] = ws[g.w_es[l] + b * Hd * T + e];
+            wv[e] = ws[g.w_ew[l] + b * Hd * T + e];
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += TB) {
+            float a = 0.f;
+            for (int c = 0; c < Co; ++c) a = fmaf(de[c * T + t], o1[c * T + t], a);
+            dm[t] = a / (float)Hd;                               // d w_i[t], the same for every head
+        }
+        __syncthreads();
+        if (tid < Hd) {
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a = fmaf(dm[t], wv[tid * T + t], a);
+            dot[tid] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < Hd * T; e += TB) {
+            const int hd = e / T, t = e % T;
+            const float s = sg[e];
+            du[e] = wv[e] * (dm[t] - dot[hd]) * s * (1.f - s);
+        }
+        __syncthreads();
+        // encoder parameter gradients: thread (hd, c) owns linears.hd.weight[c]; thread hd owns its bias
+        for (int e = tid; e < Hd * Co; e += TB) {
+            const int hd = e / Co, c = e % Co;
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a = fmaf(du[hd * T + t], o1[c * T + t], a);
+            gp[g.o_enc_w[l][hd] + c] += a;
+        }
+        if (tid < Hd) {
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a += du[tid * T + t];
+            gp[g.o_enc_b[l][tid]] += a;
+        }
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T, t = e % T;
+            float mt = 0.f, dx = 0.f;
+            for (int hd = 0; hd < Hd; ++hd) {
+                mt += wv[hd * T + t];
+                dx = fmaf(du[hd * T + t], prm[g.o_enc_w[l][hd] + c], dx);
+            }
+            dx = fmaf(de[e], mt / (float)Hd, dx);
+            const float d = o1[e] > 0.f ? dx : 0.f;              // through the last ReLU
+            const float xh = (ws[g.w_z2[l] + b * Co * T + e] - mu[c]) * istd[c];
+            const float y2 = fmaf(xh, gam[c], bet[c]);
+            const float dy = y2 > 0.f ? d : 0.f;
+            ws[g.w_dres[l] + b * Co * T + e] = d;
+            ws[g.w_dy2[l] + b * Co * T + e] = dy;
+            de[e] = dy;                                          // (every thread rewrites only its own elements)
+            o1[e] = dy * xh;
+        }
+        __syncthreads();
+        if (tid < Co)
+            for (int t = 0; t < T; ++t) { s1 += (double)de[tid * T + t]; s2 += (double)o1[tid * T + t]; }
+    }
+    if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
+}
+
+// ---- backward of stage 2: BN2 backward, conv2 backward, residual, ReLU(out0), 1x1 convolution backward, ReLU of the BN1 branch ------
+// LDS: xin[Ci*T] | o0[Co*T] | dz[Co*T] | d[Co*T] | mu1,istd1,mu2,istd2,m1,m2 [6*Co]
+__global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                        const float* __restrict__ bnstate, float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    float* xin = lds;
+    float* o0 = xin + Ci * T;
+    float* dz = o0 + Co * T;
+    float* d = dz + Co * T;
+    float* mu1 = d + Co * T;
+    float* istd1 = mu1 + Co;
+    float* mu2 = istd1 + Co;
+    float* istd2 = mu2 + Co;
+    float* m1 = istd2 + Co;
+    float* m2 = m1 + Co;
+    const double cnt = (double)g.B * T;
+    const double* bp = reinterpret_cast<const double*>(ws + g.w_bnpart);
+    bn_consts(Co, bp + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu1, istd1);
+    bn_consts(Co, bp + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1], 1, cnt, mu2, istd2);
+    bn_bwd_means(Co, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    __syncthreads();
+    const float* Wd = prm + g.o_ds_w[l];
+    const float* W2 = prm + g.o_c2_w[l];
+    const float* gam1 = prm + g.o_bn_g[2 * l];
+    const float* bet1 = prm + g.o_bn_b[2 * l];
+    const float* gam2 = prm + g.o_bn_g[2 * l + 1];
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    if (blockIdx.x == 0)                                         // BatchNorm affine gradients are the batch sums themselves
+        for (int c = tid; c < Co; c += TB) {
+            gp[g.o_bn_g[2 * l + 1] + c] += (float)((double)m2[c] * cnt);
+            gp[g.o_bn_b[2 * l + 1] + c] += (float)((double)m1[c] * cnt);
+        }
+    double* part = reinterpret_cast<double*>(ws + g.w_dbnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T;
+            o0[e] = ws[g.w_o0[l] + b * Co * T + e];
+            const float xh = (ws[g.w_z2[l] + b * Co * T + e] - mu2[c]) * istd2[c];
+            dz[e] = gam2[c] * istd2[c] * (ws[g.w_dy2[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
+        }
+        __syncthreads();
+        // conv2 weight gradient: thread owns (c, ci, k)
+        for (int e = tid; e < Co * Co * 2; e += TB) {
+            const int k = e & 1, ci = (e >> 1) % Co, c = (e >> 1) / Co;
+            const int sh = k ? 0 : 2;
+            float a = 0.f;
+            for (int t = sh; t < T; ++t) a = fmaf(dz[c * T + t], o0[ci * T + t - sh], a);
+            gp[g.o_c2_w[l] + e] += a;
+        }
+        // d out0 = residual path + conv2 backward; through ReLU(out0)
+        for (int e = tid; e < Co * T; e += TB) {
+            const int ci = e / T, t = e % T;
+            float a = ws[g.w_dres[l] + b * Co * T + e];
+            for (int c = 0; c < Co; ++c) {
+                a = fmaf(W2[(c * Co + ci) * 2 + 1], dz[c * T + t], a);
+                if (t + 2 < T) a = fmaf(W2[(c * Co + ci) * 2], dz[c * T + t + 2], a);
+            }
+            d[e] = o0[e] > 0.f ? a : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < Co * Ci; e += TB) {
+            const int c = e / Ci, ci = e % Ci;
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a = fmaf(d[c * T + t], xin[ci * T + t], a);
+            gp[g.o_ds_w[l] + e] += a;
+        }
+        if (tid < Co) {
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a += d[tid * T + t];
+            gp[g.o_ds_b[l] + tid] += a;
+        }
+        for (int e = tid; e < Ci * T; e += TB) {
+            const int ci = e / T, t = e % T;
+            float a = 0.f;
+            for (int c = 0; c < Co; ++c) a = fmaf(Wd[c * Ci + ci], d[c * T + t], a);
+            ws[g.w_dxin[l] + b * Ci * T + e] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T;
+            const float xh = (ws[g.w_z1[l] + b * Co * T + e] - mu1[c]) * istd1[c];
+            const float y1 = fmaf(xh, gam1[c], bet1[c]);
+            const float dy = y1 > 0.f ? d[e] : 0.f;
+            ws[g.w_dy1[l] + b * Co * T + e] = dy;
+            dz[e] = dy;
+            o0[e] = dy * xh;
+        }
+        __syncthreads();
+        if (tid < Co)
+            for (int t = 0; t < T; ++t) { s1 += (double)dz[tid * T + t]; s2 += (double)o0[tid * T + t]; }
+    }
+    if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
+}
+
+// ---- backward of stage 1: BN1 backward, conv1 backward -> gradient of the stage's input ---------------------------------------------
+// LDS: xin[Ci*T] | dz[Co*T] | mu,istd,m1,m2 [4*Co]
+__global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                          const float* __restrict__ bnstate, float* __restrict__ ws, float* __restrict__ dxin_out) {
+    extern __shared__ float lds[];
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    float* xin = lds;
+    float* dz = xin + Ci * T;
+    float* mu = dz + Co * T;
+    float* istd = mu + Co;
+    float* m1 = istd + Co;
+    float* m2 = m1 + Co;
+    const double cnt = (double)g.B * T;
+    bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu,
+              istd);
+    bn_bwd_means(Co, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    __syncthreads();
+    const float* W1 = prm + g.o_c1_w[l];
+    const float* gam = prm + g.o_bn_g[2 * l];
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    if (blockIdx.x == 0)
+        for (int c = tid; c < Co; c += TB) {
+            gp[g.o_bn_g[2 * l] + c] += (float)((double)m2[c] * cnt);
+            gp[g.o_bn_b[2 * l] + c] += (float)((double)m1[c] * cnt);
+        }
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T;
+            const float xh = (ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c];
+            dz[e] = gam[c] * istd[c] * (ws[g.w_dy1[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
+        }
+        __syncthreads();
+        for (int e = tid; e < Co * Ci * 2; e += TB) {
+            const int k = e & 1, ci = (e >> 1) % Ci, c = (e >> 1) / Ci;
+            const int sh = k ? 0 : 1;
+            float a = 0.f;
+            for (int t = sh; t < T; ++t) a = fmaf(dz[c * T + t], xin[ci * T + t - sh], a);
+            gp[g.o_c1_w[l] + e] += a;
+        }
+        for (int e = tid; e < Ci * T; e += TB) {
+            const int ci = e / T, t = e % T;
+            float a = ws[g.w_dxin[l] + b * Ci * T + e];
+            for (int c = 0; c < Co; ++c) {
+                a = fmaf(W1[(c * Ci + ci) * 2 + 1], dz[c * T + t], a);
+                if (t + 1 < T) a = fmaf(W1[(c * Ci + ci) * 2], dz[c * T + t + 1], a);
+            }
+            dxin_out[b * Ci * T + e] = a;
+        }
+    }
+}
+
+// ---- graph part, backward --------------------------------------------------------------------------------------------------------
+// LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | Wh[N*h] | dWh[N*h] | dhp[N*h] | att[N*N] | dpre[N*N] | AX[N*max(L,h)] | f1[N] | f2[N]
+__global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float* __restrict__ prm, float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
+    const int Lh = L > h ? L : h;
+    float* adj = lds;
+    float* ah = adj + N * N;
+    float* dH = ah + N * N;          // gradient arriving at the GAT output / the GCN output
+    float* dN = dH + N * h;          // gradient w.r.t. the GAT input (accumulated over the heads)
+    float* H = dN + N * h;           // GAT input = leaky(pre) of the GCN below
+    float* Wh = H + N * h;
+    float* dWh = Wh + N * h;
+    float* dhp = dWh + N * h;
+    float* att = dhp + N * h;
+    float* dpre = att + N * N;
+    float* AX = dpre + N * N;
+    float* f1 = AX + N * Lh;
+    float* f2 = f1 + N;
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    const float ih = 1.0f / (float)Hd;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < N * N; e += TB) { adj[e] = ws[g.w_adj + b * N * N + e]; ah[e] = ws[g.w_ahat + b * N * N + e]; }
+        for (int e = tid; e < N * h; e += TB) dH[e] = ws[g.w_dxin[0] + b * N * h + e];          // d G from tcn1's first stage (written in place)
+        __syncthreads();
+        for (int layer = 1; layer >= 0; --layer) {
+            const int K = layer == 0 ? L : h;
+            const float* pre_g = ws + (layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h;
+            for (int e = tid; e < N * h; e += TB) { H[e] = lrelu(pre_g[e], TG_GCN_SLOPE); dN[e] = 0.f; dhp[e] = dH[e] * ih; }
+            __syncthreads();
+            for (int hd = 0; hd < Hd; ++hd) {
+                const float* Wl = prm + g.o_gat_w[layer][hd];
+                const float* av = prm + g.o_gat_a[layer][hd];
+                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
+                for (int e = tid; e < N * h; e += TB) Wh[e] = ws[at_wh + e];
+                for (int e = tid; e < N * N; e += TB) att[e] = ws[g.w_att[layer] + at_nn + e];
+                __syncthreads();
+                // d att (masked), then the softmax backward with one thread per row
+                for (int e = tid; e < N * N; e += TB) {
+                    const int i = e / N, j = e % N;
+                    float a = 0.f;
+                    for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * h + o], a);
+                    dpre[e] = a * adj[e];
+                }
+                __syncthreads();
+                if (tid < N) {
+                    const int i = tid;
+                    float dot = 0.f;
+                    for (int j = 0; j < N; ++j) dot = fmaf(dpre[i * N + j], att[i * N + j], dot);
+                    float r = 0.f;
+                    for (int j = 0; j < N; ++j) {
+                        const float de = att[i * N + j] * (dpre[i * N + j] - dot);
+                        const float v = ws[g.w_gpre[layer] + at_nn + i * N + j] > 0.f ? de : TG_GAT_SLOPE * de;
+                        dpre[i * N + j] = v;
+                        r += v;
+                    }
+                    f1[i] = r;                                    // d f1[i] = row sum
+                }
+                __syncthreads();
+                if (tid < N) {
+                    float cs = 0.f;
+                    for (int i = 0; i < N; ++i) cs += dpre[i * N + tid];
+                    f2[tid] = cs;                                 // d f2[j] = column sum
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float a = 0.f;
+                    for (int i = 0; i < N; ++i) a += f1[i];
+                    gp[g.o_gat_ab[layer][hd]] += a;
+                }
+                if (tid < 2 * h) {
+                    const int half = tid / h, o = tid % h;
+                    const float* df = half ? f2 : f1;
+                    float a = 0.f;
+                    for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * h + o], a);
+                    gp[g.o_gat_a[layer][hd] + tid] += a;
+                }
+                for (int e = tid; e < N * h; e += TB) {
+                    const int j = e / h, o = e % h;
+                    float a = fmaf(f1[j], av[o], f2[j] * av[h + o]);
+                    for (int i = 0; i < N; ++i) a = fmaf(att[i * N + j] * adj[i * N + j], dhp[i * h + o], a);
+                    dWh[e] = a;
+                }
+                __syncthreads();
+                for (int e = tid; e < h * h; e += TB) {
+                    const int o = e / h, k = e % h;
+                    float a = 0.f;
+                    for (int i = 0; i < N; ++i) a = fmaf(dWh[i * h + o], H[i * h + k], a);
+                    gp[g.o_gat_w[layer][hd] + e] += a;
+                }
+                if (tid < h) {
+                    float a = 0.f;
+                    for (int i = 0; i < N; ++i) a += dWh[i * h + tid];
+                    gp[g.o_gat_b[layer][hd] + tid] += a;
+                }
+                for (int e = tid; e < N * h; e += TB) {
+                    const int i = e / h, k = e % h;
+                    float a = dN[e];
+                    for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wl[o * h + k], a);
+                    dN[e] = a;
+                }
+                __syncthreads();
+            }
+            // GCN backward: d pre = dN * leaky'(pre)
+            for (int e = tid; e < N * h; e += TB) dN[e] = pre_g[e] > 0.f ? dN[e] : TG_GCN_SLOPE * dN[e];
+            const float* ax_g = ws + (layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K;
+            for (int e = tid; e < N * K; e += TB) AX[e] = ax_g[e];
+            __syncthreads();
+            const float* W = prm + g.o_gcn_w[layer];
+            for (int e = tid; e < h * K; e += TB) {
+                const int o = e / K, k = e % K;
+                float a = 0.f;
+                for (int i = 0; i < N; ++i) a = fmaf(dN[i * h + o], AX[i * K + k], a);
+                gp[g.o_gcn_w[layer] + e] += a;
+            }
+            if (tid < h) {
+                float a = 0.f;
+                for (int i = 0; i < N; ++i) a += dN[i * h + tid];
+                gp[g.o_gcn_b[layer] + tid] += a;
+            }
+            __syncthreads();
+            if (layer == 1) {
+                // d AX = d pre W ; d (gat1 output) = A_hat^T d AX
+                for (int e = tid; e < N * h; e += TB) {
+                    const int i = e / h, k = e % h;
+                    float a = 0.f;
+                    for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], W[o * h + k], a);
+                    AX[e] = a;
+                }
+                __syncthreads();
+                for (int e = tid; e < N * h; e += TB) {
+                    const int j = e / h, k = e % h;
+                    float a = 0.f;
+                    for (int i = 0; i < N; ++i) a = fmaf(ah[i * N + j], AX[i * h + k], a);
+                    dH[e] = a;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+inline size_t tg_lds_graph_fwd(const TgGeom& g) {
+    const int Lh = g.L > g.h ? g.L : g.h;
+    return sizeof(float) * ((size_t)g.N * g.L + 3 * g.N * g.N + (size_t)g.N * Lh + 3 * (size_t)g.N * g.h + 2 * g.N);
+}
+inline size_t tg_lds_graph_bwd(const TgGeom& g) {
+    const int Lh = g.L > g.h ? g.L : g.h;
+    return sizeof(float) * (4 * (size_t)g.N * g.N + 6 * (size_t)g.N * g.h + (size_t)g.N * Lh + 2 * g.N);
+}
+
+template <typename K>
+inline int tg_allow_lds(K kernel, size_t lds) {
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    return RULGNN_OK;
+}
+
+}  // namespace
+
+int64_t stagnn_param_count(const rulgnn_stagnn_shape* s) {
+    TgGeom g;
+    return tg_geometry(s, &g) == RULGNN_OK ? g.pcount : -1;
+}
+
+int64_t stagnn_bn_state_count(const rulgnn_stagnn_shape* s) {
+    TgGeom g;
+    return tg_geometry(s, &g) == RULGNN_OK ? g.bn_total : -1;
+}
+
+size_t stagnn_workspace_bytes(const rulgnn_stagnn_shape* s) {
+    TgGeom g;
+    return tg_geometry(s, &g) == RULGNN_OK ? (size_t)g.total * sizeof(float) : 0;
+}
+
+int64_t stagnn_tap_offset(const rulgnn_stagnn_shape* s, int which) {
+    TgGeom g;
+    if (tg_geometry(s, &g) != RULGNN_OK) return -1;
+    switch (which) {
+        case 0: return g.w_adj;
+        case 1: return g.w_G;
+        case 2: return g.w_o1[0];
+        case 3: return g.w_e[0];
+        case 4: return g.w_o1[1];
+        case 5: return g.w_e[1];
+        default: return -1;
+    }
+}
+
+#define TG_RC(call)                        \
+    do {                                   \
+        const int rc_ = (call);            \
+        if (rc_ != RULGNN_OK) return rc_;  \
+    } while (0)
+#define TG_LAUNCH_OK()                                           \
+    do {                                                         \
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP; \
+    } while (0)
+
+// mode bit 0: forward, bit 1: backward (after a TRAINING forward with the same args / workspace)
+int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mode, hipStream_t st) {
+    TgGeom g;
+    TG_RC(tg_geometry(s, &g));
+    if (a->workspace_bytes < (size_t)g.total * sizeof(float)) return RULGNN_EWORKSPACE;
+    if (g.B == 0) return RULGNN_OK;
+    float* ws = static_cast<float*>(a->workspace);
+    const float* prm = a->params;
+    const int64_t gb = a->global_batch > 0 ? a->global_batch : g.B;
+    const float inv_gb = 1.0f / (float)gb;
+    const int training = a->training ? 1 : 0;
+    const int T = g.T, Hd = g.heads;
+    const dim3 grid((unsigned)g.nblk), blk(TB);
+    const float* stage_in[2] = {ws + g.w_G, ws + g.w_e[0]};
+    (void)hipGetLastError();
+    if (mode & 1) {
+        const size_t lg = tg_lds_graph_fwd(g);
+        TG_RC(tg_allow_lds(tg_graph_fwd_kernel, lg));
+        hipLaunchKernelGGL(tg_graph_fwd_kernel, grid, blk, lg, st, g, a->x, prm, ws);
+        TG_LAUNCH_OK();
+        for (int l = 0; l < 2; ++l) {
+            const int Ci = g.Ci[l], Co = g.Co[l];
+            const size_t l1 = sizeof(float) * ((size_t)Ci * T + (size_t)Co * T);
+            const size_t l2 = sizeof(float) * ((size_t)Ci * T + 2 * (size_t)Co * T + 2 * Co);
+            const size_t l3 = sizeof(float) * ((size_t)Co * T + (size_t)Hd * T + T + 2 * Co + TB);
+            TG_RC(tg_allow_lds(tg_conv1_fwd_kernel, l1));
+            TG_RC(tg_allow_lds(tg_mid_fwd_kernel, l2));
+            TG_RC(tg_allow_lds(tg_end_fwd_kernel, l3));
+            hipLaunchKernelGGL(tg_conv1_fwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, ws);
+            hipLaunchKernelGGL(tg_mid_fwd_kernel, grid, blk, l2, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, training);
+            hipLaunchKernelGGL(tg_end_fwd_kernel, grid, blk, l3, st, g, l, prm, (const float*)a->bn_state, ws, training, a->y, a->pred, inv_gb);
+            TG_LAUNCH_OK();
+        }
+        if (training && a->update_running_stats) hipLaunchKernelGGL(tg_running_kernel, dim3(4), dim3(64), 0, st, g, (const float*)ws, a->bn_state);
+        if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
+        TG_LAUNCH_OK();
+    }
+    if (mode & 2) {
+        if (!a->grads) return RULGNN_EINVAL;
+        if (!training) return RULGNN_EINVAL;                      // the backward differentiates the batch statistics
+        const float* dpred = a->dpred ? a->dpred : ws + g.w_dpred;
+        if (hipMemsetAsync(ws + g.w_gpart, 0, (size_t)g.nblk * g.pcount * sizeof(float), st) != hipSuccess) return RULGNN_EHIP;
+        for (int l = 1; l >= 0; --l) {
+            const int Ci = g.Ci[l], Co = g.Co[l];
+            const size_t l3 = sizeof(float) * (2 * (size_t)Co * T + 3 * (size_t)Hd * T + T + 2 * Co + Hd);
+            const size_t l2 = sizeof(float) * ((size_t)Ci * T + 3 * (size_t)Co * T + 6 * Co);
+            const size_t l1 = sizeof(float) * ((size_t)Ci * T + (size_t)Co * T + 4 * Co);
+            TG_RC(tg_allow_lds(tg_mid_bwd_kernel, l2));
+            TG_RC(tg_allow_lds(tg_end_bwd_kernel, l3));
+            TG_RC(tg_allow_lds(tg_conv1_bwd_kernel, l1));
+            // (the gradient w.r.t. a stage's input is written over w_dxin[l], which the next kernel down the chain reads)
+            hipLaunchKernelGGL(tg_end_bwd_kernel, grid, blk, l3, st, g, l, prm, (const float*)a->bn_state, ws, dpred, (const float*)(ws + g.w_dxin[1]));
+            hipLaunchKernelGGL(tg_mid_bwd_kernel, grid, blk, l2, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws);
+            hipLaunchKernelGGL(tg_conv1_bwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, ws + g.w_dxin[l]);
+            TG_LAUNCH_OK();
+        }
+        const size_t lg = tg_lds_graph_bwd(g);
+        TG_RC(tg_allow_lds(tg_graph_bwd_kernel, lg));
+        hipLaunchKernelGGL(tg_graph_bwd_kernel, grid, blk, lg, st, g, prm, ws);
+        TG_LAUNCH_OK();
+        TG_RC(rows_sum(ws + g.w_gpart, g.nblk, g.pcount, g.pcount, a->grads, st));
+    }
+    return RULGNN_OK;
+}
+
+}  // namespace rulgnn

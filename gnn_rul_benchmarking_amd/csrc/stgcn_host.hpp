@@ -162,6 +162,11 @@ int64_t sagcn_param_count(const rulgnn_sagcn_shape* s);
 size_t sagcn_workspace_bytes(const rulgnn_sagcn_shape* s);
 int64_t sagcn_tap_offset(const rulgnn_sagcn_shape* s, int which);
 int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode, hipStream_t st);
+int64_t stagnn_param_count(const rulgnn_stagnn_shape* s);
+int64_t stagnn_bn_state_count(const rulgnn_stagnn_shape* s);
+size_t stagnn_workspace_bytes(const rulgnn_stagnn_shape* s);
+int64_t stagnn_tap_offset(const rulgnn_stagnn_shape* s, int which);
+int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mode, hipStream_t st);
 int64_t rgcnu_param_count(const rulgnn_rgcnu_shape* s);
 size_t rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* s);
 int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode, hipStream_t st);

@@ -1,7 +1,7 @@
 """Hyper-parameter tables, looked up by dataset name then dataset id, like the reference's
 configs/hparams.py:3-7 (``get_hparams_class(name)(dataset_id)`` -> object with ``train_params`` and
 ``alg_hparams`` dicts keyed by ``--GNN_method``; unknown dataset -> NotImplementedError, unknown id ->
-ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN, ST_Conv, STGNN, RGCNU, STNet and SAGCN rows are restated (the methods this package
+ValueError).  Only the ST_GCN, STMSGCN, ASTGCNN, FC_STGNN, HAGCN, ST_Conv, STGNN, RGCNU, STNet, SAGCN and STAGNN rows are restated (the methods this package
 implements).
 
 PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :334,349,...; STMSGCN
@@ -75,6 +75,11 @@ class _Table:
             self.alg_hparams['STGNN'] = {'patch_size': 50 if self._astgcnn_nodes == 14 else 10,
                                          'num_patch': 1 if self._astgcnn_nodes == 14 else 5, 'num_nodes': self._astgcnn_nodes,
                                          'hidden_dim': 64, 'K': 3, 'top_k': 10}
+            # configs/hparams.py:24,43,82,122,162 (C-MAPSS FD001-4: hidden 64 / 16 / 32 / 32) and :188,206 (N-CMAPSS: hidden 32)
+            self.train_params['STAGNN'] = dict(_ASTGCNN_TRAIN)
+            self.alg_hparams['STAGNN'] = {'num_nodes': self._astgcnn_nodes, 'time_length': 50,
+                                          'hidden_dim': {'FD001': 64, 'FD002': 16, 'FD003': 32, 'FD004': 32, None: 32}[dataset_id],
+                                          'output_dim': 10, 'num_heads': 3, 'threshold': 0}
             self.train_params['FC_STGNN'] = dict(_FC_STGNN_TRAIN)
             self.alg_hparams['FC_STGNN'] = dict(_FC_STGNN_ROWS[dataset_id])
         if dataset_id in self._stnet_rows:

@@ -573,6 +573,66 @@ int rulgnn_sagcn_backward_f32(const rulgnn_sagcn_shape *shape, const rulgnn_sagc
 int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape *shape, const rulgnn_sagcn_args *args, const rulgnn_adam_args *opt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * STAGNN path (reference models/STAGNN/Model.py:8-230, algorithms/algorithms.py:298-323; the reference wires
+ * it to the aero-engine datasets, configs/hparams.py:43,82,122,162,206).
+ *
+ * x [batch, num_nodes, time_length] -> adj = (covariance of the sensor rows over the window, / (L - 1)) > threshold (Model.py:199-206;
+ * forward-only) -> gcn1: leaky_relu_0.01(Linear_L->h(D^-1/2 (adj + I) D^-1/2 x)) -> gat1: mean over num_heads of
+ * (softmax_j(leaky_relu_0.1(a . [Wh_i, Wh_j] + b)) * adj) Wh -- the mask is applied AFTER the softmax (:40-47) -> gcn2 (h -> h) -> gat2
+ * -> [num_nodes, h] read as num_nodes channels of length h -> tcn1 (:85-159: Conv1d k=2 dilation 1, causal, no bias -> BatchNorm1d ->
+ * ReLU; + downsample0 (1x1 Conv1d) of the input -> ReLU; Conv1d k=2 dilation 2 -> BatchNorm1d -> ReLU; + previous -> ReLU; channels
+ * num_nodes -> h -> h) -> temporal_encoder1 (:163-180: per head softmax over the length of sigmoid(Linear over the channels); the mean
+ * of the heads scales x) -> tcn2 (h -> output_dim -> output_dim) -> temporal_encoder2 -> Linear(output_dim * h -> 1).
+ * The four BatchNorm1d layers use batch statistics when `training` (their backward is differentiated through those statistics) and
+ * the running statistics otherwise.  The weight-normed `net0` / plain `net1` branches of TemporalConvNet are never called: dead
+ * parameters, not part of the flat buffer.  STAGNN.update: plain MSE.
+ *
+ * Flat parameter buffer = the parameters that receive a gradient, in the order of the reference's named_parameters():
+ *   gcn1.linear.{weight[h][L], bias[h]} | gat1.attention_i.{linear.weight[h][h], linear.bias[h], attention.weight[2h], attention.bias[1]}
+ *   (i < num_heads) | gcn2.linear.{weight[h][h], bias} | gat2.(same) | tcn1.{downsample0.weight[h][N], downsample0.bias[h],
+ *   conv_block1.0.weight[h][N][2], conv_block1.2.{weight, bias}[h], conv_block2.0.weight[h][h][2], conv_block2.2.{weight, bias}[h]} |
+ *   temporal_encoder1.linears.i.{weight[h], bias[1]} | tcn2.(same with N -> h, h -> output_dim) | temporal_encoder2.linears.i.{weight[out],
+ *   bias[1]} | fc.{weight[out * h], bias[1]}
+ * bn_state: [running_mean | running_var] of tcn1.conv_block1.2, tcn1.conv_block2.2, tcn2.conv_block1.2, tcn2.conv_block2.2.
+ * Limits: num_nodes <= 32, time_length <= 128, 3 <= hidden_dim <= 64, output_dim <= 16, num_heads <= 4, num_nodes != hidden_dim !=
+ * output_dim (the residual 1x1 convolutions exist) -- RULGNN_EUNSUPPORTED beyond; every wiring of the reference is 14|20 x 50, 16|32|64,
+ * 10, 3.
+ */
+typedef struct rulgnn_stagnn_shape {
+    int64_t batch;
+    int32_t num_nodes, time_length, hidden_dim, output_dim, num_heads;
+    float threshold;
+} rulgnn_stagnn_shape;
+
+typedef struct rulgnn_stagnn_args {
+    const float *x;           /* [batch, num_nodes, time_length] */
+    const float *y;           /* [batch] targets, or NULL */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y */
+    const float *params;
+    float *grads;
+    float *pred;              /* [batch] */
+    float *loss;              /* [1] this shard's share of MSE(pred, y) over the GLOBAL batch; may be NULL */
+    float *bn_state;          /* running statistics, see above; read in eval mode, updated by a training forward when asked to */
+    void *workspace;
+    size_t workspace_bytes;
+    int64_t global_batch;
+    int32_t training;              /* != 0: batch statistics (model.train()) */
+    int32_t update_running_stats;  /* != 0 with training: momentum-0.1 update of bn_state, unbiased variance (BatchNorm1d's defaults) */
+} rulgnn_stagnn_args;
+
+int64_t rulgnn_stagnn_param_count(const rulgnn_stagnn_shape *shape);         /* < 0: invalid / unsupported */
+int64_t rulgnn_stagnn_bn_state_count(const rulgnn_stagnn_shape *shape);
+size_t rulgnn_stagnn_workspace_bytes(const rulgnn_stagnn_shape *shape);
+/* workspace taps for the parity tests (float offsets): 0 adjacency [batch][N][N], 1 graph output [batch][N][h], 2 tcn1 output, 3
+ * temporal_encoder1 output [batch][h][h], 4 tcn2 output, 5 temporal_encoder2 output [batch][out][h] */
+int64_t rulgnn_stagnn_tap_offset(const rulgnn_stagnn_shape *shape, int32_t which);
+int rulgnn_stagnn_forward_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stagnn_args *args, void *stream);
+/* loss.backward() after a TRAINING forward with the same args / workspace (RULGNN_EINVAL when args->training == 0). */
+int rulgnn_stagnn_backward_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stagnn_args *args, void *stream);
+/* STAGNN.update body (algorithms.py:314-322); with `opt` also Adam on the flat parameter buffer. */
+int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stagnn_args *args, const rulgnn_adam_args *opt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
  * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
  * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).

@@ -1,0 +1,153 @@
+"""STAGNN HIP path vs the reference's golden outputs and vs the oracle (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stagnn_oracle as O
+from test_stagnn_oracle_golden import CASES, grad_floor, load_case, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def build_model(cfg, p):
+    from gnn_rul_benchmarking_amd.stagnn import STAGNN_model
+    m = STAGNN_model(**cfg)
+    sd = m.state_dict()
+    for k, v in p.items():
+        sd[k] = torch.from_numpy(np.asarray(v, np.float32))
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def grads_of(m):
+    flat = m._grad_flat[:m.num_live].detach().cpu().numpy().astype(np.float64)
+    return {name: flat[off:off + int(np.prod(shape))].reshape(shape) for name, (off, shape) in m._layout.items()}
+
+
+def check_grads(g, ref, tol=5e-4):
+    floor = grad_floor(ref)
+    for k, r in ref.items():
+        r = np.asarray(r, np.float64)
+        assert np.abs(g[k] - r).max() < tol * max(np.abs(r).max(), 1e4 * floor), k
+
+
+def windows(bs, N, L, seed):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0, 1, L)[None, None, :]
+    x = 0.5 + rng.uniform(-0.5, 0.5, (bs, N, 1)) * (t - 0.5) + 0.08 * rng.standard_normal((bs, N, L))
+    return np.clip(x, 0, 1)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_and_gradients_match_reference_golden(name):
+    z, cfg, p = load_case(name)
+    m = build_model(cfg, p)
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    bs = x.size(0)
+    m.eval()
+    with torch.no_grad():
+        pred = m(x)
+    assert pred.shape == (bs, 1) and rel(pred.cpu().numpy(), z["eval_pred"]) < TOL            # running statistics as loaded
+    assert np.array_equal(m.tap(bs, "adjacency").cpu().numpy(), z["adj"])
+    m.train()
+    pred2, loss = m.fused_mse_step(x, y)
+    for tap, ref in (("graph", "gat2"), ("tcn1", "tcn1"), ("encoder1", "enc1"), ("tcn2", "tcn2"), ("encoder2", "enc2")):
+        assert rel(m.tap(bs, tap).cpu().numpy(), z[ref]) < TOL, tap
+    assert rel(pred2.cpu().numpy().reshape(-1, 1), z["pred"]) < TOL
+    assert abs(float(loss) - float(z["loss"])) < TOL * abs(float(z["loss"]))
+    live = [k[8:] for k in z.files if k.startswith("hasgrad:") and bool(z[k])]
+    check_grads(grads_of(m), {k: z["grad:" + k] for k in live})
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith("sd_after:") and "running" in k:
+            assert rel(sd[k[9:]].cpu().numpy(), z[k]) < TOL, k
+        if k.startswith("sd_after:") and "num_batches" in k:
+            assert int(sd[k[9:]]) == int(z[k]) == 1, k
+
+
+@pytest.mark.parametrize("N,L,h,out,heads,thr,bs", [(14, 50, 64, 10, 3, 0.0, 100), (14, 50, 16, 10, 3, 0.0, 33), (20, 50, 32, 10, 3, 0.0, 300),
+                                                   (32, 128, 64, 16, 4, 0.001, 3), (3, 5, 4, 2, 1, 0.0, 7), (5, 12, 9, 4, 2, 0.002, 1)])
+def test_training_step_matches_oracle(N, L, h, out, heads, thr, bs):
+    cfg = dict(num_nodes=N, time_length=L, hidden_dim=h, output_dim=out, num_heads=heads, threshold=thr)
+    p = O.random_params(N, L, h, out, heads, seed=bs)
+    y = np.random.default_rng(bs).uniform(0, 1, bs)
+    for attempt in range(50):          # inputs without a covariance within 3e-8 of the threshold (fp32 rounding of these sums is ~1e-9) (a discrete decision: fp32 vs fp64)
+        x = windows(bs, N, L, N * 10 + bs + 1000 * attempt)
+        if np.abs(O.adjacency(x, thr)[1] - thr).min() > 3e-8:
+            break
+    else:
+        pytest.fail("no input away from the threshold")
+    loss, grads, fw = O.loss_and_grads(p, x, y, heads, thr)
+    m = build_model(cfg, p).train()
+    xt, yt = torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV)
+    pred, l = m.fused_mse_step(xt, yt)
+    assert np.array_equal(m.tap(bs, "adjacency").cpu().numpy(), fw.adj)
+    for tap, ref in (("graph", fw.graph_out), ("tcn1", fw.tcn1_out), ("encoder1", fw.enc1_out), ("tcn2", fw.tcn2_out), ("encoder2", fw.enc2_out)):
+        assert rel(m.tap(bs, tap).cpu().numpy(), ref) < TOL, tap
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    if bs > 1:          # (one sample: BatchNorm over h points only; the conditioning of its backward is that of 1 / var)
+        check_grads(grads_of(m), {k: grads[k] for k in O.live_param_names(heads)}, tol=1e-3)
+    sd = m.state_dict()
+    for k, v in O.running_stats_after(p, fw).items():
+        assert rel(sd[k].cpu().numpy(), v) < TOL, k
+    m.eval()
+    with torch.no_grad():
+        ev = m(xt)
+    q = dict(p)
+    q.update(O.running_stats_after(p, fw))
+    assert rel(ev.cpu().numpy(), O.forward(q, x, heads, thr, training=False).pred) < TOL
+
+
+def test_autograd_path_equals_fused_path_and_dead_branches_stay_untouched():
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    z, cfg, p = load_case("stagnn_cmapss_fd002_h16_bs7")
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    m = build_model(cfg, p).train()
+    m.fused_mse_step(x, y)
+    fused = m._grad_flat[:m.num_live].clone()
+    m2 = build_model(cfg, p).train()
+    torch.nn.functional.mse_loss(m2(x), y).backward()
+    auto = torch.cat([t.grad.reshape(-1) for t in m2._named()])
+    assert torch.equal(auto, fused)
+    table = dict(m2.named_parameters())
+    assert table["tcn1.net0.0.weight_v"].grad is None and table["tcn2.net1.2.bias"].grad is None
+    assert torch.equal(m2.state_dict()["tcn1.conv_block1.2.running_mean"], m.state_dict()["tcn1.conv_block1.2.running_mean"])
+    algo = get_algorithm_class("STAGNN")(cfg, {"learning_rate": 1e-3, "weight_decay": 1e-4}, DEV)
+    algo.to(DEV).train()
+    before = {k: v.clone() for k, v in algo.model.state_dict().items()}
+    a = algo.update(x, y, 1)["loss"]
+    b = algo.update_reference_style(x, y, 1)["loss"]
+    assert np.isfinite(a) and np.isfinite(b)
+    after = algo.model.state_dict()
+    assert torch.equal(after["tcn1.net0.0.weight_v"], before["tcn1.net0.0.weight_v"]) and torch.equal(after["tcn2.net1.0.weight"], before["tcn2.net1.0.weight"])
+    assert not torch.equal(after["fc.weight"], before["fc.weight"]) and int(after["tcn2.conv_block2.2.num_batches_tracked"]) == 2
+    algo.eval()
+    with pytest.raises(RuntimeError, match="algorithm.train"):
+        algo.update(x, y, 1)
+
+
+def test_training_curve_matches_reference_algorithm():
+    from gnn_rul_benchmarking_amd.algorithms import get_algorithm_class
+    z = np.load(os.path.join(GOLD, "stagnn_train_curve_fd002_bs20.npz"))
+    cfg = {k[4:]: (float(z[k]) if k == "cfg:threshold" else int(z[k])) for k in z.files if k.startswith("cfg:")}
+    algo = get_algorithm_class("STAGNN")(cfg, {"learning_rate": float(z["lr"]), "weight_decay": float(z["wd"])}, DEV)
+    algo.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0:")})
+    algo.to(DEV).train()
+    xs, ys = torch.from_numpy(z["xs"]).to(DEV), torch.from_numpy(z["ys"]).to(DEV)
+    losses = [algo.update(xs[s], ys[s], 1)["loss"] for s in range(xs.size(0))]
+    assert np.allclose(losses, z["losses"], rtol=2e-3), (losses, z["losses"].tolist())
+    algo.eval()
+    with torch.no_grad():
+        assert rel(algo.model(xs[0]).cpu().numpy(), z["eval_pred_end"]) < 5e-3
+    sd = algo.state_dict()
+    for k in ("model.tcn1.conv_block2.2.running_var", "model.tcn2.conv_block1.2.running_mean", "model.fc.weight", "model.gat1.attention_1.linear.weight"):
+        assert rel(sd[k].cpu().numpy(), z["sd_end:" + k]) < 5e-3, k
+    assert int(sd["model.tcn1.conv_block1.2.num_batches_tracked"]) == int(z["sd_end:model.tcn1.conv_block1.2.num_batches_tracked"]) == 10
+    for k in ("model.tcn1.net0.0.weight_g", "model.tcn2.net1.2.weight"):
+        assert np.array_equal(sd[k].cpu().numpy(), z["sd_end:" + k])          # dead branches: untouched, as in the reference
