@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="--family FC_STGNN only: bf16 = BASELINE.json's 'FC_STGNN ... bf16' variant (bf16 operands on the row-projection "
                          "matrix-core GEMMs, fp32 accumulate / BatchNorm / graphs / weight gradients); reported separately, it does not meet 1e-4")
-    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN", "RGCNU", "STNet", "SAGCN"],
+    ap.add_argument("--family", default="ST_GCN", choices=["ST_GCN", "ASTGCNN", "FC_STGNN", "STMSGCN", "HAGCN", "STGNN", "RGCNU", "STNet", "SAGCN", "STAGNN"],
                     help="ST_GCN (default) is the headline benchmark; the others run the same contract on the SURVEY section 8d "
                          "configuration of that model family")
     return ap.parse_args()
@@ -273,6 +273,10 @@ FAMILY_CONFIGS = {
     # SURVEY 8f rank 3 (PHM2012 Condition_2 wiring: 128 patches of 20 points, hidden 1000 / 200, the reference protocol's batch); forward
     # FLOPs per sample: gcn1 2*128*40*1000, two projection layers 2 * (2*128*128*1000 + 2*128*1000*1000), attention 2 * 2*200*128*1000
     "SAGCN": ("PHM2012", "Condition_2", 100, (1, 2560), 10.2e6 + 2 * (32.8e6 + 256e6) + 102.4e6),
+    # SURVEY 8f rank 3 (C-MAPSS FD001 wiring: hidden 64, 3 heads); forward FLOPs per sample: covariance 2*14*14*50, GCNs 2*14*14*(50+64) +
+    # 2*14*64*(50+64), six attention heads 6 * (2*14*64*64 + 2*14*14*64), tcn1 2*64*64*(2*14 + 14 + 2*64), encoder 2*3*64*64, tcn2
+    # 2*10*64*(2*64 + 64 + 2*10), head
+    "STAGNN": ("CMAPSS", "FD001", 256, (14, 50), 0.02e6 + 0.25e6 + 0.84e6 + 1.39e6 + 0.03e6 + 0.27e6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
 
@@ -373,6 +377,12 @@ def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
         bs = 256
         x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
         run = lambda: O.forward_backward(x, y, p, cfg["num_patch"], cfg["patch_size"], cfg["top_k"])
+    elif family == "STAGNN":
+        from oracle import stagnn_oracle as O
+        p = O.random_params(cfg["num_nodes"], cfg["time_length"], cfg["hidden_dim"], cfg["output_dim"], cfg["num_heads"])
+        bs = 64
+        x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, cfg["num_heads"], cfg["threshold"])
     elif family == "SAGCN":
         from oracle import sagcn_oracle as O
         p = O.random_params(cfg["num_patch"], cfg["gcn_hidden_dim"], cfg["attention_hidden_dim"])

@@ -618,3 +618,49 @@ def test_sagcn_trainer_matches_reference_harness_run_on_phm2012(tmp_path, monkey
     csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "SAGCN_run_0" / "results.csv")
     ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
     assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
+
+
+
+def test_stagnn_trainer_matches_reference_harness_run_on_cmapss(tmp_path, monkeypatch):
+    """--GNN_method STAGNN on C-MAPSS FD002 as the reference wires it (configs/hparams.py:62,82: hidden 16, 3 heads, threshold 0, batch
+    100, lr 1e-3, wd 1e-4, shuffling DataLoader): the reference's own harness, run on CPU by
+    tests/golden/make_golden_stagnn.py::case_trainer_cmapss, vs this package's harness on the GPU -- train-mode BatchNorm statistics in
+    the steps, running statistics in the per-epoch test passes, a ragged last batch (300 % 100 == 0 here; the test set's 80 is)."""
+    import io
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from synth import synthetic_cmapss
+    from gnn_rul_benchmarking_amd import trainer as T
+    z = np.load(os.path.join(GOLDEN, "stagnn_trainer_cmapss_fd002_reference_run.npz"))
+    fd = str(z["fd"])
+    (xtr, ytr), (xte, yte) = synthetic_cmapss(int(z["seed"]), int(z["n_train"]), int(z["n_test"]))
+    assert abs(xtr.astype(np.float64).sum() - float(z["x_train_checksum"])) < 1e-6
+    d = tmp_path / "data" / "CMAPSS" / fd
+    os.makedirs(d)
+    torch.save({"samples": torch.from_numpy(xtr), "labels": torch.from_numpy(ytr), "max_ruls": 125.0}, d / "train.pt")
+    torch.save({"samples": torch.from_numpy(xte), "labels": torch.from_numpy(yte), "max_ruls": 125.0}, d / "test.pt")
+    monkeypatch.chdir(tmp_path)
+    args = argparse.Namespace(save_dir=str(tmp_path / "logs"), experiment_description="exp", run_description="r",
+                              GNN_method="STAGNN", data_path=str(tmp_path / "data"), dataset="CMAPSS",
+                              dataset_id=fd, bearing_id=None, num_runs=1, device="cuda:0")
+    tr = T.GNN_RUL_trainer(args)
+    tr.train_configs["num_epochs"] = int(z["epochs"])
+    assert tr.model_configs == dict(num_nodes=14, time_length=50, hidden_dim=16, output_dim=10, num_heads=3, threshold=0)
+    assert tr.train_configs == {'num_epochs': 3, 'batch_size': 100, 'weight_decay': 1e-4, 'learning_rate': 1e-3}
+    per_epoch = []
+    orig = tr.calc_results_per_run
+
+    def spy(run_id):
+        per_epoch.append(T._calc_metrics(tr.pred_labels, tr.true_labels, tr.max_ruls))
+        return orig(run_id)
+    tr.calc_results_per_run = spy
+    tr.train()
+    got, ref = np.asarray(per_epoch, np.float64), z["per_epoch"]
+    print("STAGNN harness per-epoch got/ref:\n", got, "\n", ref)
+    assert got.shape == ref.shape == (3, 4)
+    assert np.max(np.abs(got[:, 3] - ref[:, 3]) / 125.0) < 1e-3          # RMSE on the normalised scale (north star: 1e-3)
+    assert np.max(np.abs(got[:, 2:] - ref[:, 2:]) / np.abs(ref[:, 2:])) < 2e-3
+    csv = pd.read_csv(tmp_path / "logs" / "exp" / "r" / "STAGNN_run_0" / "results.csv")
+    ref_csv = pd.read_csv(io.StringIO(str(z["csv_text"])))
+    assert list(csv.columns) == list(ref_csv.columns) and len(csv) == len(ref_csv)
