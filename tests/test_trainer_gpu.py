@@ -78,7 +78,7 @@ def test_unknown_method_and_dataset_errors(tmp_path):
     base = dict(save_dir=str(tmp_path / "logs"), experiment_description="e", run_description="r", data_path=str(tmp_path),
                 dataset="CMAPSS", dataset_id="FD004", bearing_id="b", num_runs=1, device="cuda:0")
     with pytest.raises(KeyError):                             # trainer.py:60: method not listed for the dataset
-        GNN_RUL_trainer(argparse.Namespace(GNN_method="RGCNU", **base))
+        GNN_RUL_trainer(argparse.Namespace(GNN_method="SAGCN", **base))
     with pytest.raises(ValueError):                           # hparams.py:172
         GNN_RUL_trainer(argparse.Namespace(GNN_method="ST_GCN", **dict(base, dataset_id="FD009")))
     with pytest.raises(NotImplementedError):
