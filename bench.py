@@ -135,6 +135,20 @@ def measured_traffic(kernel_key, N, P, B):
     return round(t["kernels"][kernel_key]["hbm_bytes_per_sample"] * B)
 
 
+def forward_traffic(N, P, B):
+    """HBM bytes per launch of the fused eval forward from its own PMC passes (tools/profile_forward.sh ->
+    profiles/r02_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
+    the bench's other launches of that name), or None when this batch was not profiled."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", f"r02_forward_bs{B}_hbm_traffic.json")))
+        w = t["workload"]
+        if (w["num_patch"], w["patch_size"], w["batch"]) == (N, P, B):
+            return round(t["kernels"]["EVAL"]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def algorithmic_bytes_per_sample(N, P):
     """the window is read once and one float is written; the 6.1 KB of weights amortise over the batch."""
     return 4 * N * P + 4
@@ -216,7 +230,7 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
     fms = time_eval_forward(model, X)
     fach = alg * B / (fms * 1e-3) / 1e9
     roof_f = {"bound": "hbm", "kernel": "stgcn_forward_mx_kernel", "achieved": round(fach, 1), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": measured_traffic("EVAL", N, P, B),
+              "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": forward_traffic(N, P, B),
               "algorithmic_bytes_per_sample": alg, "batch": B,
               "us_per_launch": round(fms * 1e3, 1), "samples_per_s": round(B / (fms * 1e-3), 1)}
     if big_forward:
@@ -226,7 +240,8 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
         bms = time_eval_forward(model, Xb, iters=5)
         bach = alg * BB / (bms * 1e-3) / 1e9
         roof_f["at_1M"] = {"batch": BB, "us_per_launch": round(bms * 1e3, 1), "achieved": round(bach, 1),
-                           "frac": round(bach / HBM_PEAK_GBS, 4), "samples_per_s": round(BB / (bms * 1e-3), 1)}
+                           "frac": round(bach / HBM_PEAK_GBS, 4), "samples_per_s": round(BB / (bms * 1e-3), 1),
+                           "traffic": forward_traffic(N, P, BB)}
         del Xb
     return roof, roof_f
 
