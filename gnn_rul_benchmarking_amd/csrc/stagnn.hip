@@ -112,14 +112,43 @@ int tg_geometry(const rulgnn_stagnn_shape* s, TgGeom* g) {
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-// ---- BatchNorm constants of one layer, by every workgroup in the same fixed order ------------------------------------------------
+// ---- per-workgroup fp64 partial sums -> batch totals, by every workgroup in the same fixed order ----------------------------------
+// part[b][0..CMAX) and part[b][CMAX..2 CMAX) hold two sums per channel of workgroup b.  The TB threads split the workgroups four ways
+// (independent loads in flight instead of one dependent chain per channel), the four slices are added in a fixed order.
+__device__ void reduce_partials(int Co, const double* __restrict__ part, int nblk, double* tot0, double* tot1) {
+    __shared__ double slice[4][2 * TG_CMAX];
+    const int c = threadIdx.x & (TG_CMAX - 1), q = threadIdx.x / TG_CMAX;
+    __syncthreads();
+    if (c < Co) {
+        double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+        int b = q;
+        for (; b + 4 < nblk; b += 8) {
+            s0 += part[(int64_t)b * 2 * TG_CMAX + c];
+            s1 += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c];
+            t0 += part[(int64_t)(b + 4) * 2 * TG_CMAX + c];
+            t1 += part[(int64_t)(b + 4) * 2 * TG_CMAX + TG_CMAX + c];
+        }
+        if (b < nblk) { s0 += part[(int64_t)b * 2 * TG_CMAX + c]; s1 += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+        slice[q][c] = s0 + t0;
+        slice[q][TG_CMAX + c] = s1 + t1;
+    }
+    __syncthreads();
+    if (threadIdx.x < Co) {
+        const int k = threadIdx.x;
+        *tot0 = (slice[0][k] + slice[1][k]) + (slice[2][k] + slice[3][k]);
+        *tot1 = (slice[0][TG_CMAX + k] + slice[1][TG_CMAX + k]) + (slice[2][TG_CMAX + k] + slice[3][TG_CMAX + k]);
+    }
+}
+
+// BatchNorm constants of one layer (batch statistics when training, the running ones otherwise)
 __device__ void bn_consts(int Co, const double* __restrict__ part, int nblk, const float* __restrict__ running, int training, double cnt,
                           float* mu, float* istd) {
-    for (int c = threadIdx.x; c < Co; c += TB) {
+    double s = 0.0, q = 0.0;
+    if (training) reduce_partials(Co, part, nblk, &s, &q);
+    if ((int)threadIdx.x < Co) {
+        const int c = threadIdx.x;
         double mean, var;
         if (training) {
-            double s = 0.0, q = 0.0;
-            for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
             mean = s / cnt;
             var = q / cnt - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -134,44 +163,55 @@ __device__ void bn_consts(int Co, const double* __restrict__ part, int nblk, con
 
 // mean over the batch of dy and of dy * xhat (the two sums of the BatchNorm backward)
 __device__ void bn_bwd_means(int Co, const double* __restrict__ part, int nblk, double cnt, float* m1, float* m2) {
-    for (int c = threadIdx.x; c < Co; c += TB) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
-        m1[c] = (float)(s / cnt);
-        m2[c] = (float)(q / cnt);
+    double s = 0.0, q = 0.0;
+    reduce_partials(Co, part, nblk, &s, &q);
+    if ((int)threadIdx.x < Co) {
+        m1[threadIdx.x] = (float)(s / cnt);
+        m2[threadIdx.x] = (float)(q / cnt);
     }
 }
 
+// LDS rows get an odd stride wherever the lanes of a wavefront walk DIFFERENT rows at the same column (weight-gradient loops, the
+// attention scores): a row stride of 64 floats puts all of them in one bank.
+__device__ __forceinline__ int odd(int v) { return v | 1; }
+
+// coalesced copy of a [rows][cols] matrix from global memory into LDS rows of stride ld (weights are staged once per use: read from
+// global memory inside the inner loops, every product waited for its own L2 round trip)
+__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int rows, int cols, int ld) {
+    for (int i = threadIdx.x; i < rows * cols; i += TB) dst[(i / cols) * ld + i % cols] = src[i];
+}
+
 // ---- graph part, forward ---------------------------------------------------------------------------------------------------------
-// LDS: X[N*L] | adj[N*N] | ah[N*N] | AX[N*max(L,h)] | H0[N*h] | H1[N*h] | Wh[N*h] | att[N*N] | f1[N] | f2[N]
+// LDS: X[N*LP] | adj[N*N] | ah[N*N] | AX[N*Lh] | H0[N*h] | H1[N*h] | Wh[N*hp] | att[N*N] | f1[N] | f2[N] | Wb[h*odd(Lh)]
 __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
     extern __shared__ float lds[];
     const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
-    const int Lh = L > h ? L : h;
+    const int Lh = L > h ? L : h, LP = odd(L), hp = odd(h);
     float* X = lds;
-    float* adj = X + N * L;
+    float* adj = X + N * LP;
     float* ah = adj + N * N;
     float* AX = ah + N * N;
     float* H0 = AX + N * Lh;
     float* H1 = H0 + N * h;
     float* Wh = H1 + N * h;
-    float* att = Wh + N * h;
+    float* att = Wh + N * hp;
     float* f1 = att + N * N;
     float* f2 = f1 + N;
+    float* Wb = f2 + N;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < N * L; i += TB) X[i] = x[b * N * L + i];
+        for (int i = tid; i < N * L; i += TB) X[(i / L) * LP + i % L] = x[b * N * L + i];
         __syncthreads();
         if (tid < N) {
             float s = 0.f;
-            for (int l = 0; l < L; ++l) s += X[tid * L + l];
+            for (int l = 0; l < L; ++l) s += X[tid * LP + l];
             f1[tid] = s / (float)L;
         }
         __syncthreads();
         for (int e = tid; e < N * N; e += TB) {
             const int i = e / N, j = e % N;
             float c = 0.f;
-            for (int l = 0; l < L; ++l) c = fmaf(X[i * L + l] - f1[i], X[j * L + l] - f1[j], c);
+            for (int l = 0; l < L; ++l) c = fmaf(X[i * LP + l] - f1[i], X[j * LP + l] - f1[j], c);
             adj[e] = c / (float)(L - 1) > g.thr ? 1.f : 0.f;
         }
         __syncthreads();
@@ -190,43 +230,45 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
         }
         __syncthreads();
         for (int layer = 0; layer < 2; ++layer) {
-            const int K = layer == 0 ? L : h;                       // input width of this GCN layer
+            const int K = layer == 0 ? L : h, KP = odd(K);          // input width of this GCN layer
             const float* in = layer == 0 ? X : H1;
+            const int inld = layer == 0 ? LP : h;
+            stage(Wb, prm + g.o_gcn_w[layer], h, K, KP);
             // AX = A_hat in
             for (int e = tid; e < N * K; e += TB) {
                 const int i = e / K, k = e % K;
                 float a = 0.f;
-                for (int j = 0; j < N; ++j) a = fmaf(ah[i * N + j], in[j * K + k], a);
+                for (int j = 0; j < N; ++j) a = fmaf(ah[i * N + j], in[j * inld + k], a);
                 AX[e] = a;
                 ws[(layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K + e] = a;
             }
             __syncthreads();
-            const float* W = prm + g.o_gcn_w[layer];
             for (int e = tid; e < N * h; e += TB) {
                 const int i = e / h, o = e % h;
                 float a = prm[g.o_gcn_b[layer] + o];
-                for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], W[o * K + k], a);
+                for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], Wb[o * KP + k], a);
                 ws[(layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h + e] = a;
                 H0[e] = lrelu(a, TG_GCN_SLOPE);
                 H1[e] = 0.f;
             }
             __syncthreads();
             for (int hd = 0; hd < Hd; ++hd) {
-                const float* Wl = prm + g.o_gat_w[layer][hd];
                 const float* av = prm + g.o_gat_a[layer][hd];
                 const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
+                stage(Wb, prm + g.o_gat_w[layer][hd], h, h, hp);
+                __syncthreads();
                 for (int e = tid; e < N * h; e += TB) {
                     const int i = e / h, o = e % h;
                     float a = prm[g.o_gat_b[layer][hd] + o];
-                    for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wl[o * h + k], a);
-                    Wh[e] = a;
+                    for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wb[o * hp + k], a);
+                    Wh[i * hp + o] = a;
                     ws[at_wh + e] = a;
                 }
                 __syncthreads();
                 if (tid < 2 * N) {
                     const int i = tid % N, half = tid / N;
                     float a = 0.f;
-                    for (int o = 0; o < h; ++o) a = fmaf(av[half * h + o], Wh[i * h + o], a);
+                    for (int o = 0; o < h; ++o) a = fmaf(av[half * h + o], Wh[i * hp + o], a);
                     (half ? f2 : f1)[i] = a;
                 }
                 __syncthreads();
@@ -257,7 +299,7 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
                 for (int e = tid; e < N * h; e += TB) {
                     const int i = e / h, o = e % h;
                     float a = 0.f;
-                    for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * h + o], a);
+                    for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * hp + o], a);
                     H1[e] = fmaf(a, ih, H1[e]);
                 }
                 __syncthreads();
@@ -269,68 +311,71 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
 }
 
 // ---- TCN stage 1: z1 = causal conv (dilation 1) of the input; BatchNorm partial sums -----------------------------------------------
-// LDS: xin[Ci*T] | z[Co*T]
+// LDS: xin[Ci*TP] | z[Co*TP] | W[Co*Ci*2]
 __global__ __launch_bounds__(TB) void tg_conv1_fwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
                                                           float* __restrict__ ws) {
     extern __shared__ float lds[];
-    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, TP = odd(T), tid = threadIdx.x;
     float* xin = lds;
-    float* z = xin + Ci * T;
-    const float* W = prm + g.o_c1_w[l];
+    float* z = xin + Ci * TP;
+    float* W = z + Co * TP;
+    stage(W, prm + g.o_c1_w[l], 1, Co * Ci * 2, 0);
     double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
     double s = 0.0, q = 0.0;                                       // thread c < Co: sums of channel c over this workgroup's samples
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
             const int c = e / T, t = e % T;
             float a = 0.f;
             for (int ci = 0; ci < Ci; ++ci) {
-                a = fmaf(W[(c * Ci + ci) * 2 + 1], xin[ci * T + t], a);
-                if (t >= 1) a = fmaf(W[(c * Ci + ci) * 2], xin[ci * T + t - 1], a);
+                a = fmaf(W[(c * Ci + ci) * 2 + 1], xin[ci * TP + t], a);
+                if (t >= 1) a = fmaf(W[(c * Ci + ci) * 2], xin[ci * TP + t - 1], a);
             }
-            z[e] = a;
+            z[c * TP + t] = a;
             ws[g.w_z1[l] + b * Co * T + e] = a;
         }
         __syncthreads();
         if (tid < Co)
-            for (int t = 0; t < T; ++t) { const double v = z[tid * T + t]; s += v; q += v * v; }
+            for (int t = 0; t < T; ++t) { const double v = z[tid * TP + t]; s += v; q += v * v; }
     }
     if (tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
 }
 
 // ---- TCN stage 2: BN1, ReLU, + residual (1x1 convolution of the input), ReLU -> out0; z2 = causal conv (dilation 2); BN partials --
-// LDS: xin[Ci*T] | o0[Co*T] | z[Co*T] | mu[Co] | istd[Co]
+// LDS: xin[Ci*TP] | o0[Co*TP] | z[Co*TP] | mu[Co] | istd[Co] | Wd[Co*Ci] | W2[Co*Co*2]
 __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
                                                         const float* __restrict__ bnstate, float* __restrict__ ws, int training) {
     extern __shared__ float lds[];
-    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, TP = odd(T), tid = threadIdx.x;
     float* xin = lds;
-    float* o0 = xin + Ci * T;
-    float* z = o0 + Co * T;
-    float* mu = z + Co * T;
+    float* o0 = xin + Ci * TP;
+    float* z = o0 + Co * TP;
+    float* mu = z + Co * TP;
     float* istd = mu + Co;
+    float* Wd = istd + Co;
+    float* W2 = Wd + Co * Ci;
     const double cnt = (double)g.B * T;
     bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], training,
               cnt, mu, istd);
-    const float* Wd = prm + g.o_ds_w[l];
-    const float* W2 = prm + g.o_c2_w[l];
+    stage(Wd, prm + g.o_ds_w[l], 1, Co * Ci, 0);
+    stage(W2, prm + g.o_c2_w[l], 1, Co * Co * 2, 0);
     const float* gam = prm + g.o_bn_g[2 * l];
     const float* bet = prm + g.o_bn_b[2 * l];
     double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l + 1) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
     double s = 0.0, q = 0.0;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
             const int c = e / T, t = e % T;
             const float y1 = fmaf((ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
             float r = prm[g.o_ds_b[l] + c];
-            for (int ci = 0; ci < Ci; ++ci) r = fmaf(Wd[c * Ci + ci], xin[ci * T + t], r);
+            for (int ci = 0; ci < Ci; ++ci) r = fmaf(Wd[c * Ci + ci], xin[ci * TP + t], r);
             const float v = fmaxf(fmaxf(y1, 0.f) + r, 0.f);
-            o0[e] = v;
+            o0[c * TP + t] = v;
             ws[g.w_o0[l] + b * Co * T + e] = v;
         }
         __syncthreads();
@@ -338,51 +383,53 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
             const int c = e / T, t = e % T;
             float a = 0.f;
             for (int ci = 0; ci < Co; ++ci) {
-                a = fmaf(W2[(c * Co + ci) * 2 + 1], o0[ci * T + t], a);
-                if (t >= 2) a = fmaf(W2[(c * Co + ci) * 2], o0[ci * T + t - 2], a);
+                a = fmaf(W2[(c * Co + ci) * 2 + 1], o0[ci * TP + t], a);
+                if (t >= 2) a = fmaf(W2[(c * Co + ci) * 2], o0[ci * TP + t - 2], a);
             }
-            z[e] = a;
+            z[c * TP + t] = a;
             ws[g.w_z2[l] + b * Co * T + e] = a;
         }
         __syncthreads();
         if (training && tid < Co)
-            for (int t = 0; t < T; ++t) { const double v = z[tid * T + t]; s += v; q += v * v; }
+            for (int t = 0; t < T; ++t) { const double v = z[tid * TP + t]; s += v; q += v * v; }
     }
     if (training && tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
 }
 
 // ---- TCN stage 3: BN2, ReLU, + out0, ReLU -> out1; temporal encoder -> e; for the second TCN also the head and the loss terms -------
-// LDS: o1[Co*T] | u[heads*T] | m[T] | mu[Co] | istd[Co] | red[TB]
+// LDS: o1[Co*TP] | u[heads*T] | m[T] | mu[Co] | istd[Co] | red[TB] | ew[heads*Co]
 __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const float* __restrict__ prm, const float* __restrict__ bnstate,
                                                         float* __restrict__ ws, int training, const float* __restrict__ y, float* __restrict__ pred,
                                                         float inv_gb) {
     extern __shared__ float lds[];
-    const int Co = g.Co[l], T = g.T, Hd = g.heads, tid = threadIdx.x;
+    const int Co = g.Co[l], T = g.T, TP = odd(T), Hd = g.heads, tid = threadIdx.x;
     float* o1 = lds;
-    float* u = o1 + Co * T;
+    float* u = o1 + Co * TP;
     float* m = u + Hd * T;
     float* mu = m + T;
     float* istd = mu + Co;
     float* red = istd + Co;
+    float* ew = red + TB;
     const double cnt = (double)g.B * T;
     bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1],
               training, cnt, mu, istd);
+    for (int e = tid; e < Hd * Co; e += TB) ew[e] = prm[g.o_enc_w[l][e / Co] + e % Co];
     const float* gam = prm + g.o_bn_g[2 * l + 1];
     const float* bet = prm + g.o_bn_b[2 * l + 1];
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
-            const int c = e / T;
+            const int c = e / T, t = e % T;
             const float y2 = fmaf((ws[g.w_z2[l] + b * Co * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
             const float v = fmaxf(fmaxf(y2, 0.f) + ws[g.w_o0[l] + b * Co * T + e], 0.f);
-            o1[e] = v;
+            o1[c * TP + t] = v;
             ws[g.w_o1[l] + b * Co * T + e] = v;
         }
         __syncthreads();
         for (int e = tid; e < Hd * T; e += TB) {
             const int hd = e / T, t = e % T;
             float a = prm[g.o_enc_b[l][hd]];
-            for (int c = 0; c < Co; ++c) a = fmaf(prm[g.o_enc_w[l][hd] + c], o1[c * T + t], a);
+            for (int c = 0; c < Co; ++c) a = fmaf(ew[hd * Co + c], o1[c * TP + t], a);
             const float sg = 1.0f / (1.0f + expf(-a));
             u[e] = sg;
             ws[g.w_es[l] + (b * Hd + hd) * T + t] = sg;
@@ -409,7 +456,7 @@ __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const f
         __syncthreads();
         float acc = 0.f;
         for (int e = tid; e < Co * T; e += TB) {
-            const float v = o1[e] * m[e % T];
+            const float v = o1[(e / T) * TP + e % T] * m[e % T];
             ws[g.w_e[l] + b * Co * T + e] = v;
             if (l == 1) acc = fmaf(v, prm[g.o_fc_w + e], acc);
         }
@@ -433,14 +480,14 @@ __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const f
     }
 }
 
-// running statistics after a train-mode forward (BatchNorm1d: momentum 0.1, unbiased variance)
-__global__ void tg_running_kernel(TgGeom g, const float* __restrict__ ws, float* __restrict__ bnstate) {
+// running statistics after a train-mode forward (BatchNorm1d: momentum 0.1, unbiased variance); one workgroup of TB threads per layer
+__global__ __launch_bounds__(TB) void tg_running_kernel(TgGeom g, const float* __restrict__ ws, float* __restrict__ bnstate) {
     const int k = blockIdx.x, Co = g.Co[k / 2];
     const double cnt = (double)g.B * g.T;
-    const double* part = reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)k * g.nblk * 2 * TG_CMAX;
-    for (int c = threadIdx.x; c < Co; c += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < g.nblk; ++b) { s += part[(int64_t)b * 2 * TG_CMAX + c]; q += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+    double s = 0.0, q = 0.0;
+    reduce_partials(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)k * g.nblk * 2 * TG_CMAX, g.nblk, &s, &q);
+    if ((int)threadIdx.x < Co) {
+        const int c = threadIdx.x;
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -452,23 +499,25 @@ __global__ void tg_running_kernel(TgGeom g, const float* __restrict__ ws, float*
 }
 
 // ---- backward of stage 3: (head,) encoder, ReLU, residual split, ReLU of the BN2 branch; BN2-backward partial sums ----------------
-// LDS: o1[Co*T] | de[Co*T] | s[heads*T] | w[heads*T] | dm[T] | du[heads*T] | mu[Co] | istd[Co] | dot[heads]
+// LDS: o1[Co*TP] | de[Co*TP] | s[heads*T] | w[heads*T] | dm[T] | du[heads*T] | mu[Co] | istd[Co] | dot[heads] | ew[heads*Co]
 __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const float* __restrict__ prm, const float* __restrict__ bnstate,
                                                         float* __restrict__ ws, const float* __restrict__ dpred, const float* __restrict__ de_g) {
     extern __shared__ float lds[];
-    const int Co = g.Co[l], T = g.T, Hd = g.heads, tid = threadIdx.x;
+    const int Co = g.Co[l], T = g.T, TP = odd(T), Hd = g.heads, tid = threadIdx.x;
     float* o1 = lds;
-    float* de = o1 + Co * T;
-    float* sg = de + Co * T;
+    float* de = o1 + Co * TP;
+    float* sg = de + Co * TP;
     float* wv = sg + Hd * T;
     float* dm = wv + Hd * T;
     float* du = dm + T;
     float* mu = du + Hd * T;
     float* istd = mu + Co;
     float* dot = istd + Co;
+    float* ew = dot + Hd;
     const double cnt = (double)g.B * T;
     bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1], 1,
               cnt, mu, istd);
+    for (int e = tid; e < Hd * Co; e += TB) ew[e] = prm[g.o_enc_w[l][e / Co] + e % Co];
     const float* gam = prm + g.o_bn_g[2 * l + 1];
     const float* bet = prm + g.o_bn_b[2 * l + 1];
     float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
@@ -477,14 +526,14 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
-            const float v = ws[g.w_o1[l] + b * Co * T + e];
-            o1[e] = v;
+            const int at = (e / T) * TP + e % T;
+            o1[at] = ws[g.w_o1[l] + b * Co * T + e];
             if (l == 1) {
                 const float dp = dpred[b];
-                de[e] = dp * prm[g.o_fc_w + e];
+                de[at] = dp * prm[g.o_fc_w + e];
                 gp[g.o_fc_w + e] += dp * ws[g.w_e[l] + b * Co * T + e];
             } else {
-                de[e] = de_g[b * Co * T + e];
+                de[at] = de_g[b * Co * T + e];
             }
         }
         if (l == 1 && tid == 0) gp[g.o_fc_b] += dpred[b];
@@ -495,7 +544,7 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         __syncthreads();
         for (int t = tid; t < T; t += TB) {
             float a = 0.f;
-            for (int c = 0; c < Co; ++c) a = fmaf(de[c * T + t], o1[c * T + t], a);
+            for (int c = 0; c < Co; ++c) a = fmaf(de[c * TP + t], o1[c * TP + t], a);
             dm[t] = a / (float)Hd;                               // d w_i[t], the same for every head
         }
         __syncthreads();
@@ -515,7 +564,7 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         for (int e = tid; e < Hd * Co; e += TB) {
             const int hd = e / Co, c = e % Co;
             float a = 0.f;
-            for (int t = 0; t < T; ++t) a = fmaf(du[hd * T + t], o1[c * T + t], a);
+            for (int t = 0; t < T; ++t) a = fmaf(du[hd * T + t], o1[c * TP + t], a);
             gp[g.o_enc_w[l][hd] + c] += a;
         }
         if (tid < Hd) {
@@ -525,53 +574,55 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         }
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
-            const int c = e / T, t = e % T;
+            const int c = e / T, t = e % T, at = c * TP + t;
             float mt = 0.f, dx = 0.f;
             for (int hd = 0; hd < Hd; ++hd) {
                 mt += wv[hd * T + t];
-                dx = fmaf(du[hd * T + t], prm[g.o_enc_w[l][hd] + c], dx);
+                dx = fmaf(du[hd * T + t], ew[hd * Co + c], dx);
             }
-            dx = fmaf(de[e], mt / (float)Hd, dx);
-            const float d = o1[e] > 0.f ? dx : 0.f;              // through the last ReLU
+            dx = fmaf(de[at], mt / (float)Hd, dx);
+            const float d = o1[at] > 0.f ? dx : 0.f;             // through the last ReLU
             const float xh = (ws[g.w_z2[l] + b * Co * T + e] - mu[c]) * istd[c];
             const float y2 = fmaf(xh, gam[c], bet[c]);
             const float dy = y2 > 0.f ? d : 0.f;
             ws[g.w_dres[l] + b * Co * T + e] = d;
             ws[g.w_dy2[l] + b * Co * T + e] = dy;
-            de[e] = dy;                                          // (every thread rewrites only its own elements)
-            o1[e] = dy * xh;
+            de[at] = dy;                                         // (every thread rewrites only its own elements)
+            o1[at] = dy * xh;
         }
         __syncthreads();
         if (tid < Co)
-            for (int t = 0; t < T; ++t) { s1 += (double)de[tid * T + t]; s2 += (double)o1[tid * T + t]; }
+            for (int t = 0; t < T; ++t) { s1 += (double)de[tid * TP + t]; s2 += (double)o1[tid * TP + t]; }
     }
     if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
 }
 
 // ---- backward of stage 2: BN2 backward, conv2 backward, residual, ReLU(out0), 1x1 convolution backward, ReLU of the BN1 branch ------
-// LDS: xin[Ci*T] | o0[Co*T] | dz[Co*T] | d[Co*T] | mu1,istd1,mu2,istd2,m1,m2 [6*Co]
+// LDS: xin[Ci*TP] | o0[Co*TP] | dz[Co*TP] | d[Co*TP] | mu1,istd1,mu2,istd2,m1,m2 [6*Co] | Wd[Co*Ci] | W2[Co*Co*2]
 __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
                                                         const float* __restrict__ bnstate, float* __restrict__ ws) {
     extern __shared__ float lds[];
-    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, TP = odd(T), tid = threadIdx.x;
     float* xin = lds;
-    float* o0 = xin + Ci * T;
-    float* dz = o0 + Co * T;
-    float* d = dz + Co * T;
-    float* mu1 = d + Co * T;
+    float* o0 = xin + Ci * TP;
+    float* dz = o0 + Co * TP;
+    float* d = dz + Co * TP;
+    float* mu1 = d + Co * TP;
     float* istd1 = mu1 + Co;
     float* mu2 = istd1 + Co;
     float* istd2 = mu2 + Co;
     float* m1 = istd2 + Co;
     float* m2 = m1 + Co;
+    float* Wd = m2 + Co;
+    float* W2 = Wd + Co * Ci;
     const double cnt = (double)g.B * T;
     const double* bp = reinterpret_cast<const double*>(ws + g.w_bnpart);
     bn_consts(Co, bp + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu1, istd1);
     bn_consts(Co, bp + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1], 1, cnt, mu2, istd2);
     bn_bwd_means(Co, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    stage(Wd, prm + g.o_ds_w[l], 1, Co * Ci, 0);
+    stage(W2, prm + g.o_c2_w[l], 1, Co * Co * 2, 0);
     __syncthreads();
-    const float* Wd = prm + g.o_ds_w[l];
-    const float* W2 = prm + g.o_c2_w[l];
     const float* gam1 = prm + g.o_bn_g[2 * l];
     const float* bet1 = prm + g.o_bn_b[2 * l];
     const float* gam2 = prm + g.o_bn_g[2 * l + 1];
@@ -585,12 +636,12 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
     double s1 = 0.0, s2 = 0.0;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
         for (int e = tid; e < Co * T; e += TB) {
-            const int c = e / T;
-            o0[e] = ws[g.w_o0[l] + b * Co * T + e];
+            const int c = e / T, at = c * TP + e % T;
+            o0[at] = ws[g.w_o0[l] + b * Co * T + e];
             const float xh = (ws[g.w_z2[l] + b * Co * T + e] - mu2[c]) * istd2[c];
-            dz[e] = gam2[c] * istd2[c] * (ws[g.w_dy2[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
+            dz[at] = gam2[c] * istd2[c] * (ws[g.w_dy2[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
         }
         __syncthreads();
         // conv2 weight gradient: thread owns (c, ci, k)
@@ -598,7 +649,7 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             const int k = e & 1, ci = (e >> 1) % Co, c = (e >> 1) / Co;
             const int sh = k ? 0 : 2;
             float a = 0.f;
-            for (int t = sh; t < T; ++t) a = fmaf(dz[c * T + t], o0[ci * T + t - sh], a);
+            for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], o0[ci * TP + t - sh], a);
             gp[g.o_c2_w[l] + e] += a;
         }
         // d out0 = residual path + conv2 backward; through ReLU(out0)
@@ -606,64 +657,65 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             const int ci = e / T, t = e % T;
             float a = ws[g.w_dres[l] + b * Co * T + e];
             for (int c = 0; c < Co; ++c) {
-                a = fmaf(W2[(c * Co + ci) * 2 + 1], dz[c * T + t], a);
-                if (t + 2 < T) a = fmaf(W2[(c * Co + ci) * 2], dz[c * T + t + 2], a);
+                a = fmaf(W2[(c * Co + ci) * 2 + 1], dz[c * TP + t], a);
+                if (t + 2 < T) a = fmaf(W2[(c * Co + ci) * 2], dz[c * TP + t + 2], a);
             }
-            d[e] = o0[e] > 0.f ? a : 0.f;
+            d[ci * TP + t] = o0[ci * TP + t] > 0.f ? a : 0.f;
         }
         __syncthreads();
         for (int e = tid; e < Co * Ci; e += TB) {
             const int c = e / Ci, ci = e % Ci;
             float a = 0.f;
-            for (int t = 0; t < T; ++t) a = fmaf(d[c * T + t], xin[ci * T + t], a);
+            for (int t = 0; t < T; ++t) a = fmaf(d[c * TP + t], xin[ci * TP + t], a);
             gp[g.o_ds_w[l] + e] += a;
         }
         if (tid < Co) {
             float a = 0.f;
-            for (int t = 0; t < T; ++t) a += d[tid * T + t];
+            for (int t = 0; t < T; ++t) a += d[tid * TP + t];
             gp[g.o_ds_b[l] + tid] += a;
         }
         for (int e = tid; e < Ci * T; e += TB) {
             const int ci = e / T, t = e % T;
             float a = 0.f;
-            for (int c = 0; c < Co; ++c) a = fmaf(Wd[c * Ci + ci], d[c * T + t], a);
+            for (int c = 0; c < Co; ++c) a = fmaf(Wd[c * Ci + ci], d[c * TP + t], a);
             ws[g.w_dxin[l] + b * Ci * T + e] = a;
         }
         __syncthreads();
         for (int e = tid; e < Co * T; e += TB) {
-            const int c = e / T;
+            const int c = e / T, at = c * TP + e % T;
             const float xh = (ws[g.w_z1[l] + b * Co * T + e] - mu1[c]) * istd1[c];
             const float y1 = fmaf(xh, gam1[c], bet1[c]);
-            const float dy = y1 > 0.f ? d[e] : 0.f;
+            const float dy = y1 > 0.f ? d[at] : 0.f;
             ws[g.w_dy1[l] + b * Co * T + e] = dy;
-            dz[e] = dy;
-            o0[e] = dy * xh;
+            dz[at] = dy;
+            o0[at] = dy * xh;
         }
         __syncthreads();
         if (tid < Co)
-            for (int t = 0; t < T; ++t) { s1 += (double)dz[tid * T + t]; s2 += (double)o0[tid * T + t]; }
+            for (int t = 0; t < T; ++t) { s1 += (double)dz[tid * TP + t]; s2 += (double)o0[tid * TP + t]; }
     }
     if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
 }
 
 // ---- backward of stage 1: BN1 backward, conv1 backward -> gradient of the stage's input ---------------------------------------------
-// LDS: xin[Ci*T] | dz[Co*T] | mu,istd,m1,m2 [4*Co]
+// LDS: xin[Ci*TP] | dz[Co*TP] | mu,istd,m1,m2 [4*Co] | W1[Co*Ci*2]
 __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
                                                           const float* __restrict__ bnstate, float* __restrict__ ws, float* __restrict__ dxin_out) {
     extern __shared__ float lds[];
-    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, tid = threadIdx.x;
+    const int Ci = g.Ci[l], Co = g.Co[l], T = g.T, TP = odd(T), tid = threadIdx.x;
     float* xin = lds;
-    float* dz = xin + Ci * T;
-    float* mu = dz + Co * T;
+    float* dz = xin + Ci * TP;
+    float* mu = dz + Co * TP;
     float* istd = mu + Co;
     float* m1 = istd + Co;
     float* m2 = m1 + Co;
+    float* W1 = m2 + Co;
     const double cnt = (double)g.B * T;
     bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu,
               istd);
     bn_bwd_means(Co, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    stage(W1, prm + g.o_c1_w[l], 1, Co * Ci * 2, 0);
     __syncthreads();
-    const float* W1 = prm + g.o_c1_w[l];
     const float* gam = prm + g.o_bn_g[2 * l];
     float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
     if (blockIdx.x == 0)
@@ -673,26 +725,26 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
         }
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < Ci * T; i += TB) xin[i] = xin_g[b * Ci * T + i];
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
         for (int e = tid; e < Co * T; e += TB) {
             const int c = e / T;
             const float xh = (ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c];
-            dz[e] = gam[c] * istd[c] * (ws[g.w_dy1[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
+            dz[c * TP + e % T] = gam[c] * istd[c] * (ws[g.w_dy1[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
         }
         __syncthreads();
         for (int e = tid; e < Co * Ci * 2; e += TB) {
             const int k = e & 1, ci = (e >> 1) % Ci, c = (e >> 1) / Ci;
             const int sh = k ? 0 : 1;
             float a = 0.f;
-            for (int t = sh; t < T; ++t) a = fmaf(dz[c * T + t], xin[ci * T + t - sh], a);
+            for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], xin[ci * TP + t - sh], a);
             gp[g.o_c1_w[l] + e] += a;
         }
         for (int e = tid; e < Ci * T; e += TB) {
             const int ci = e / T, t = e % T;
             float a = ws[g.w_dxin[l] + b * Ci * T + e];
             for (int c = 0; c < Co; ++c) {
-                a = fmaf(W1[(c * Ci + ci) * 2 + 1], dz[c * T + t], a);
-                if (t + 1 < T) a = fmaf(W1[(c * Ci + ci) * 2], dz[c * T + t + 1], a);
+                a = fmaf(W1[(c * Ci + ci) * 2 + 1], dz[c * TP + t], a);
+                if (t + 1 < T) a = fmaf(W1[(c * Ci + ci) * 2], dz[c * TP + t + 1], a);
             }
             dxin_out[b * Ci * T + e] = a;
         }
@@ -700,24 +752,25 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
 }
 
 // ---- graph part, backward --------------------------------------------------------------------------------------------------------
-// LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | Wh[N*h] | dWh[N*h] | dhp[N*h] | att[N*N] | dpre[N*N] | AX[N*max(L,h)] | f1[N] | f2[N]
+// LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | Wh[N*hp] | dWh[N*h] | dhp[N*h] | att[N*N] | dpre[N*N] | AX[N*Lh] | f1[N] | f2[N] | Wb[h*hp]
 __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float* __restrict__ prm, float* __restrict__ ws) {
     extern __shared__ float lds[];
     const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
-    const int Lh = L > h ? L : h;
+    const int Lh = L > h ? L : h, hp = odd(h);
     float* adj = lds;
     float* ah = adj + N * N;
     float* dH = ah + N * N;          // gradient arriving at the GAT output / the GCN output
     float* dN = dH + N * h;          // gradient w.r.t. the GAT input (accumulated over the heads)
     float* H = dN + N * h;           // GAT input = leaky(pre) of the GCN below
     float* Wh = H + N * h;
-    float* dWh = Wh + N * h;
+    float* dWh = Wh + N * hp;
     float* dhp = dWh + N * h;
     float* att = dhp + N * h;
     float* dpre = att + N * N;
     float* AX = dpre + N * N;
     float* f1 = AX + N * Lh;
     float* f2 = f1 + N;
+    float* Wb = f2 + N;
     float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
     const float ih = 1.0f / (float)Hd;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -731,17 +784,17 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
             for (int e = tid; e < N * h; e += TB) { H[e] = lrelu(pre_g[e], TG_GCN_SLOPE); dN[e] = 0.f; dhp[e] = dH[e] * ih; }
             __syncthreads();
             for (int hd = 0; hd < Hd; ++hd) {
-                const float* Wl = prm + g.o_gat_w[layer][hd];
                 const float* av = prm + g.o_gat_a[layer][hd];
                 const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
-                for (int e = tid; e < N * h; e += TB) Wh[e] = ws[at_wh + e];
+                for (int e = tid; e < N * h; e += TB) Wh[(e / h) * hp + e % h] = ws[at_wh + e];
                 for (int e = tid; e < N * N; e += TB) att[e] = ws[g.w_att[layer] + at_nn + e];
+                stage(Wb, prm + g.o_gat_w[layer][hd], h, h, hp);
                 __syncthreads();
                 // d att (masked), then the softmax backward with one thread per row
                 for (int e = tid; e < N * N; e += TB) {
                     const int i = e / N, j = e % N;
                     float a = 0.f;
-                    for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * h + o], a);
+                    for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * hp + o], a);
                     dpre[e] = a * adj[e];
                 }
                 __syncthreads();
@@ -774,7 +827,7 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
                     const int half = tid / h, o = tid % h;
                     const float* df = half ? f2 : f1;
                     float a = 0.f;
-                    for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * h + o], a);
+                    for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * hp + o], a);
                     gp[g.o_gat_a[layer][hd] + tid] += a;
                 }
                 for (int e = tid; e < N * h; e += TB) {
@@ -798,7 +851,7 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
                 for (int e = tid; e < N * h; e += TB) {
                     const int i = e / h, k = e % h;
                     float a = dN[e];
-                    for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wl[o * h + k], a);
+                    for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wb[o * hp + k], a);
                     dN[e] = a;
                 }
                 __syncthreads();
@@ -807,8 +860,8 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
             for (int e = tid; e < N * h; e += TB) dN[e] = pre_g[e] > 0.f ? dN[e] : TG_GCN_SLOPE * dN[e];
             const float* ax_g = ws + (layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K;
             for (int e = tid; e < N * K; e += TB) AX[e] = ax_g[e];
+            if (layer == 1) stage(Wb, prm + g.o_gcn_w[1], h, h, hp);
             __syncthreads();
-            const float* W = prm + g.o_gcn_w[layer];
             for (int e = tid; e < h * K; e += TB) {
                 const int o = e / K, k = e % K;
                 float a = 0.f;
@@ -826,7 +879,7 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
                 for (int e = tid; e < N * h; e += TB) {
                     const int i = e / h, k = e % h;
                     float a = 0.f;
-                    for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], W[o * h + k], a);
+                    for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], Wb[o * hp + k], a);
                     AX[e] = a;
                 }
                 __syncthreads();
@@ -844,11 +897,12 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
 
 inline size_t tg_lds_graph_fwd(const TgGeom& g) {
     const int Lh = g.L > g.h ? g.L : g.h;
-    return sizeof(float) * ((size_t)g.N * g.L + 3 * g.N * g.N + (size_t)g.N * Lh + 3 * (size_t)g.N * g.h + 2 * g.N);
+    return sizeof(float) * ((size_t)g.N * (g.L | 1) + 3 * g.N * g.N + (size_t)g.N * Lh + 2 * (size_t)g.N * g.h + (size_t)g.N * (g.h | 1) + 2 * g.N +
+                            (size_t)g.h * (Lh | 1));
 }
 inline size_t tg_lds_graph_bwd(const TgGeom& g) {
     const int Lh = g.L > g.h ? g.L : g.h;
-    return sizeof(float) * (4 * (size_t)g.N * g.N + 6 * (size_t)g.N * g.h + (size_t)g.N * Lh + 2 * g.N);
+    return sizeof(float) * (4 * (size_t)g.N * g.N + 5 * (size_t)g.N * g.h + (size_t)g.N * (g.h | 1) + (size_t)g.N * Lh + 2 * g.N + (size_t)g.h * (g.h | 1));
 }
 
 template <typename K>
@@ -911,7 +965,7 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
     const int64_t gb = a->global_batch > 0 ? a->global_batch : g.B;
     const float inv_gb = 1.0f / (float)gb;
     const int training = a->training ? 1 : 0;
-    const int T = g.T, Hd = g.heads;
+    const int T = g.T, TP = g.T | 1, Hd = g.heads;
     const dim3 grid((unsigned)g.nblk), blk(TB);
     const float* stage_in[2] = {ws + g.w_G, ws + g.w_e[0]};
     (void)hipGetLastError();
@@ -922,9 +976,9 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
         TG_LAUNCH_OK();
         for (int l = 0; l < 2; ++l) {
             const int Ci = g.Ci[l], Co = g.Co[l];
-            const size_t l1 = sizeof(float) * ((size_t)Ci * T + (size_t)Co * T);
-            const size_t l2 = sizeof(float) * ((size_t)Ci * T + 2 * (size_t)Co * T + 2 * Co);
-            const size_t l3 = sizeof(float) * ((size_t)Co * T + (size_t)Hd * T + T + 2 * Co + TB);
+            const size_t l1 = sizeof(float) * ((size_t)Ci * TP + (size_t)Co * TP + 2 * (size_t)Co * Ci);
+            const size_t l2 = sizeof(float) * ((size_t)Ci * TP + 2 * (size_t)Co * TP + 2 * Co + (size_t)Co * Ci + 2 * (size_t)Co * Co);
+            const size_t l3 = sizeof(float) * ((size_t)Co * TP + (size_t)Hd * T + T + 2 * Co + TB + (size_t)Hd * Co);
             TG_RC(tg_allow_lds(tg_conv1_fwd_kernel, l1));
             TG_RC(tg_allow_lds(tg_mid_fwd_kernel, l2));
             TG_RC(tg_allow_lds(tg_end_fwd_kernel, l3));
@@ -933,7 +987,7 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             hipLaunchKernelGGL(tg_end_fwd_kernel, grid, blk, l3, st, g, l, prm, (const float*)a->bn_state, ws, training, a->y, a->pred, inv_gb);
             TG_LAUNCH_OK();
         }
-        if (training && a->update_running_stats) hipLaunchKernelGGL(tg_running_kernel, dim3(4), dim3(64), 0, st, g, (const float*)ws, a->bn_state);
+        if (training && a->update_running_stats) hipLaunchKernelGGL(tg_running_kernel, dim3(4), dim3(TB), 0, st, g, (const float*)ws, a->bn_state);
         if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
         TG_LAUNCH_OK();
     }
@@ -944,9 +998,9 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
         if (hipMemsetAsync(ws + g.w_gpart, 0, (size_t)g.nblk * g.pcount * sizeof(float), st) != hipSuccess) return RULGNN_EHIP;
         for (int l = 1; l >= 0; --l) {
             const int Ci = g.Ci[l], Co = g.Co[l];
-            const size_t l3 = sizeof(float) * (2 * (size_t)Co * T + 3 * (size_t)Hd * T + T + 2 * Co + Hd);
-            const size_t l2 = sizeof(float) * ((size_t)Ci * T + 3 * (size_t)Co * T + 6 * Co);
-            const size_t l1 = sizeof(float) * ((size_t)Ci * T + (size_t)Co * T + 4 * Co);
+            const size_t l3 = sizeof(float) * (2 * (size_t)Co * TP + 3 * (size_t)Hd * T + T + 2 * Co + Hd + (size_t)Hd * Co);
+            const size_t l2 = sizeof(float) * ((size_t)Ci * TP + 3 * (size_t)Co * TP + 6 * Co + (size_t)Co * Ci + 2 * (size_t)Co * Co);
+            const size_t l1 = sizeof(float) * ((size_t)Ci * TP + (size_t)Co * TP + 4 * Co + 2 * (size_t)Co * Ci);
             TG_RC(tg_allow_lds(tg_mid_bwd_kernel, l2));
             TG_RC(tg_allow_lds(tg_end_bwd_kernel, l3));
             TG_RC(tg_allow_lds(tg_conv1_bwd_kernel, l1));
