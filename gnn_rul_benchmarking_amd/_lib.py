@@ -182,6 +182,8 @@ _SIGNATURES = {
     "rulgnn_sagcn_forward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
     "rulgnn_sagcn_backward_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.c_void_p]),
     "rulgnn_sagcn_fwdbwd_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p]),
     "rulgnn_stagnn_param_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_bn_state_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_workspace_bytes": (C.c_size_t, [C.POINTER(StagnnShape)]),

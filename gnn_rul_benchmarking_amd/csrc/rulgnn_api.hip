@@ -1,6 +1,7 @@
 // extern "C" surface of librulgnn.so (declared in include/rulgnn.h).
 #include <initializer_list>
 
+#include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
 using namespace rulgnn;
@@ -754,6 +755,15 @@ int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape* shape, const rulgnn_stag
     if (rc != RULGNN_OK || !opt) return rc;
     return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, stagnn_param_count(shape), opt->step, opt->lr, opt->beta1,
                      opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
+// ---- plain GEMM -------------------------------------------------------------------------------------------------------------------
+int rulgnn_sgemm_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int32_t M,
+                     int32_t N, int32_t K, int32_t accumulate, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldc < N) return RULGNN_EINVAL;
+    if (M == 0 || N == 0) return RULGNN_OK;
+    if (!A || !B || !C) return RULGNN_EINVAL;
+    return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, static_cast<hipStream_t>(stream));
 }
 
 // ---- RGCNU ----------------------------------------------------------------------------------------------------------------------

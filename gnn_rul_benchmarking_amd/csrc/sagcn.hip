@@ -37,7 +37,7 @@ struct SgGeom {
     int64_t B, R, BH;                           // samples, node rows = P * B, columns of the node-major matrices = B * H
     int P, n, H, Ah, nh;                        // nh = n / 2 + 1 bins of the half spectrum
     int o_w1, o_b1, o_wl[2], o_bl[2], o_wp[2], o_bp[2], o_wt, o_bt, o_ws, o_bs, o_wfc, o_bfc, pcount;
-    int64_t w_raw, w_feat, w_ax, w_h1, w_u[2], w_h[2], w_s, w_attn, w_dpred, w_sq, w_one, w_dA, w_dB, w_ds, w_split, total;
+    int64_t w_raw, w_feat, w_ax, w_h1, w_u[2], w_h[2], w_s, w_attn, w_dpred, w_sq, w_one, w_dA, w_dB, w_ds, w_split, w_rowpart, w_headpart, total;
 };
 
 int sg_geometry(const rulgnn_sagcn_shape* s, SgGeom* g) {
@@ -92,6 +92,8 @@ int sg_geometry(const rulgnn_sagcn_shape* s, SgGeom* g) {
         for (size_t v : need) sp = v > sp ? v : sp;
     }
     g->w_split = take((int64_t)sp);
+    g->w_rowpart = take((int64_t)SG_MAXH * 16);
+    g->w_headpart = take(g->B * ((H + 63) / 64));
     g->total = w;
     return RULGNN_OK;
 }
@@ -347,49 +349,79 @@ __global__ void sg_tanh_bwd_kernel(float* __restrict__ d, const float* __restric
         d[i] *= 1.f - s[i] * s[i];
 }
 
-// out[r] = sum_c v[r][c]: one workgroup per row, fixed order
-__global__ __launch_bounds__(GB) void sg_rowsum_kernel(const float* __restrict__ v, int64_t cols, float* __restrict__ out) {
+// out[r] = sum_c v[r][c], fixed order: workgroup (r, s) adds slice s of row r, sg_rowsum_finish adds the slices in order
+// (one workgroup per row left 128-200 workgroups walking 400 KB each: 100 us per call)
+constexpr int SG_ROW_SLICES = 16;
+__global__ __launch_bounds__(GB) void sg_rowsum_kernel(const float* __restrict__ v, int64_t cols, float* __restrict__ part) {
     __shared__ float red[GB];
+    const int64_t per = (cols + SG_ROW_SLICES - 1) / SG_ROW_SLICES;
+    const int64_t c0 = (int64_t)blockIdx.y * per, c1 = c0 + per < cols ? c0 + per : cols;
     const float* row = v + (int64_t)blockIdx.x * cols;
     float a[1] = {0.f};
-    for (int64_t c = threadIdx.x; c < cols; c += GB) a[0] += row[c];
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += GB) a[0] += row[c];
     block_sum<1>(a, red);
-    if (threadIdx.x == 0) out[blockIdx.x] = a[0];
+    if (threadIdx.x == 0) part[blockIdx.x * SG_ROW_SLICES + blockIdx.y] = a[0];
+}
+__global__ void sg_rowsum_finish_kernel(const float* __restrict__ part, int rows, float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float a = 0.f;
+    for (int s = 0; s < SG_ROW_SLICES; ++s) a += part[r * SG_ROW_SLICES + s];
+    out[r] = a;
 }
 
-// One workgroup per sample: softmax over the nodes of every feature channel (logits [P][B*H] + bias[p], in place -> attention),
-// x * attention, the final Linear, and the loss terms.
-__global__ __launch_bounds__(GB) void sg_attn_head_kernel(SgGeom g, float* __restrict__ attn, const float* __restrict__ h3,
-                                                          const float* __restrict__ prm, const float* __restrict__ y, float* __restrict__ pred,
-                                                          float* __restrict__ ws, float inv_gb) {
-    __shared__ float red[GB];
-    const int P = g.P, H = g.H;
+// Softmax over the nodes of every feature channel (logits [P][B*H] + bias[p], in place -> attention), x * attention and the final
+// Linear: one wavefront per (sample, 64 channels), one thread per column -- an online max / sum pass, then one pass that writes the
+// attention and accumulates the column's share of the prediction (two strided passes over the logits instead of three, 1600 wavefronts
+// instead of 100 workgroups).  The per-chunk shares are added per sample in a fixed order by sg_head_finish_kernel.
+__global__ __launch_bounds__(64) void sg_attn_head_kernel(SgGeom g, float* __restrict__ attn, const float* __restrict__ h3,
+                                                         const float* __restrict__ prm, float* __restrict__ part) {
+    __shared__ float red[64];
+    const int P = g.P, H = g.H, chunks = (H + 63) / 64;
     const float* bs = prm + g.o_bs;
     const float* wfc = prm + g.o_wfc;
-    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
-        float acc[1] = {0.f};
-        for (int h = threadIdx.x; h < H; h += GB) {
+    for (int64_t w = blockIdx.x; w < g.B * chunks; w += gridDim.x) {
+        const int64_t b = w / chunks;
+        const int h = (int)(w % chunks) * 64 + threadIdx.x;
+        float acc = 0.f;
+        if (h < H) {
             const int64_t c = b * H + h;
-            float m = -INFINITY;
-            for (int p = 0; p < P; ++p) m = fmaxf(m, attn[p * g.BH + c] + bs[p]);
-            float sum = 0.f;
-            for (int p = 0; p < P; ++p) sum += expf(attn[p * g.BH + c] + bs[p] - m);
+            float m = -INFINITY, sum = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float v = attn[p * g.BH + c] + bs[p];
+                const float mn = fmaxf(m, v);
+                sum = sum * expf(m - mn) + expf(v - mn);
+                m = mn;
+            }
             const float inv = 1.0f / sum;
             for (int p = 0; p < P; ++p) {
                 const float a = expf(attn[p * g.BH + c] + bs[p] - m) * inv;
                 attn[p * g.BH + c] = a;
-                acc[0] = fmaf(h3[p * g.BH + c] * a, wfc[p * H + h], acc[0]);
+                acc = fmaf(h3[p * g.BH + c] * a, wfc[p * H + h], acc);
             }
         }
-        block_sum<1>(acc, red);
-        if (threadIdx.x == 0) {
-            const float pr = acc[0] + prm[g.o_bfc];
-            pred[b] = pr;
-            if (y) {
-                const float d = pr - y[b];
-                ws[g.w_sq + b] = d * d * inv_gb;
-                ws[g.w_dpred + b] = 2.f * d * inv_gb;
-            }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int k = 32; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) part[w] = red[0];
+        __syncthreads();
+    }
+}
+
+__global__ void sg_head_finish_kernel(SgGeom g, const float* __restrict__ part, const float* __restrict__ prm, const float* __restrict__ y,
+                                      float* __restrict__ pred, float* __restrict__ ws, float inv_gb) {
+    const int chunks = (g.H + 63) / 64;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < g.B; b += (int64_t)gridDim.x * blockDim.x) {
+        float a = prm[g.o_bfc];
+        for (int k = 0; k < chunks; ++k) a += part[b * chunks + k];
+        pred[b] = a;
+        if (y) {
+            const float d = a - y[b];
+            ws[g.w_sq + b] = d * d * inv_gb;
+            ws[g.w_dpred + b] = 2.f * d * inv_gb;
         }
     }
 }
@@ -518,8 +550,13 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
         SG_RC(sgemm(prm + g.o_wt, P, 1, hh[2], 1, BH, S, BH, Ah, BH, P, false, st));
         hipLaunchKernelGGL(sg_bias_rows_kernel, dim3(sg_grid((int64_t)Ah * BH)), dim3(GB), 0, st, S, prm + g.o_bt, Ah, (int64_t)BH, 2);
         SG_RC(sgemm(prm + g.o_ws, Ah, 1, S, 1, BH, attn, BH, P, BH, Ah, false, st));
-        hipLaunchKernelGGL(sg_attn_head_kernel, dim3((unsigned)(g.B < 4096 ? g.B : 4096)), dim3(GB), 0, st, g, attn, (const float*)hh[2], prm, a->y,
-                           a->pred, ws, inv_gb);
+        {
+            const int64_t waves = g.B * ((H + 63) / 64);
+            hipLaunchKernelGGL(sg_attn_head_kernel, dim3((unsigned)(waves < 65536 ? waves : 65536)), dim3(64), 0, st, g, attn, (const float*)hh[2], prm,
+                               ws + g.w_headpart);
+            hipLaunchKernelGGL(sg_head_finish_kernel, dim3(sg_grid(g.B)), dim3(GB), 0, st, g, (const float*)(ws + g.w_headpart), prm, a->y, a->pred, ws,
+                               inv_gb);
+        }
         if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
         SG_LAUNCH_OK();
     }
@@ -539,12 +576,14 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
         hipLaunchKernelGGL(sg_attn_head_bwd_kernel, dim3(sg_grid(BH)), dim3(GB), 0, st, g, (const float*)attn, (const float*)hh[2], prm, dpred, dA, dB);
         SG_LAUNCH_OK();
         SG_RC(sgemm_splitk(dB, BH, 1, S, BH, 1, gr + g.o_ws, Ah, P, Ah, BH, false, split, st));
-        hipLaunchKernelGGL(sg_rowsum_kernel, dim3(P), dim3(GB), 0, st, (const float*)dB, (int64_t)BH, gr + g.o_bs);
+        hipLaunchKernelGGL(sg_rowsum_kernel, dim3(P, SG_ROW_SLICES), dim3(GB), 0, st, (const float*)dB, (int64_t)BH, ws + g.w_rowpart);
+        hipLaunchKernelGGL(sg_rowsum_finish_kernel, dim3((P + GB - 1) / GB), dim3(GB), 0, st, (const float*)(ws + g.w_rowpart), P, gr + g.o_bs);
         // d S [Ah, B*H] = Ws^T x d logits ; through tanh
         SG_RC(sgemm(prm + g.o_ws, 1, Ah, dB, 1, BH, ds, BH, Ah, BH, P, false, st));
         hipLaunchKernelGGL(sg_tanh_bwd_kernel, dim3(sg_grid((int64_t)Ah * BH)), dim3(GB), 0, st, ds, (const float*)S, (int64_t)Ah * BH);
         SG_RC(sgemm_splitk(ds, BH, 1, hh[2], BH, 1, gr + g.o_wt, P, Ah, P, BH, false, split, st));
-        hipLaunchKernelGGL(sg_rowsum_kernel, dim3(Ah), dim3(GB), 0, st, (const float*)ds, (int64_t)BH, gr + g.o_bt);
+        hipLaunchKernelGGL(sg_rowsum_kernel, dim3(Ah, SG_ROW_SLICES), dim3(GB), 0, st, (const float*)ds, (int64_t)BH, ws + g.w_rowpart);
+        hipLaunchKernelGGL(sg_rowsum_finish_kernel, dim3((Ah + GB - 1) / GB), dim3(GB), 0, st, (const float*)(ws + g.w_rowpart), Ah, gr + g.o_bt);
         // d h3 += Wt^T x d(tanh input)
         SG_RC(sgemm(prm + g.o_wt, 1, P, ds, 1, BH, dA, BH, P, BH, Ah, true, st));
         SG_LAUNCH_OK();
@@ -557,7 +596,8 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
             // d U [R, H] = d V [R, H] x Wl
             SG_RC(sgemm(d, H, 1, prm + g.o_wl[i], 1, H, other, H, R, H, H, false, st));
             SG_RC(sgemm_splitk(other, BH, 1, hh[i], BH, 1, gr + g.o_wp[i], P, P, P, BH, false, split, st));
-            hipLaunchKernelGGL(sg_rowsum_kernel, dim3(P), dim3(GB), 0, st, (const float*)other, (int64_t)BH, gr + g.o_bp[i]);
+            hipLaunchKernelGGL(sg_rowsum_kernel, dim3(P, SG_ROW_SLICES), dim3(GB), 0, st, (const float*)other, (int64_t)BH, ws + g.w_rowpart);
+            hipLaunchKernelGGL(sg_rowsum_finish_kernel, dim3((P + GB - 1) / GB), dim3(GB), 0, st, (const float*)(ws + g.w_rowpart), P, gr + g.o_bp[i]);
             // d h_in [P, B*H] = Wp^T x d U
             SG_RC(sgemm(prm + g.o_wp[i], 1, P, other, 1, BH, d, BH, P, BH, P, false, st));
             SG_LAUNCH_OK();

@@ -99,6 +99,154 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large outputs (the hidden-1000 layers of SAGCN, the Chebyshev layers of STNet, the tiled ST_GCN path): 128x128 block tile, K step
+// 16, 4 wavefronts each owning a 64x64 quadrant (4x4 MFMA tiles, 64 accumulator registers).  The 64x64 kernel above moves 8 KB
+// through LDS per 131 kFLOP -- 16 FLOP per byte, i.e. the fp32 matrix peak would need ~10 TB/s out of L2 --; this one 32 FLOP per byte,
+// with 16-byte global loads along whichever dimension of the operand is contiguous (template flags), the next K step's loads in
+// flight under the 64 MFMAs of the current one, double-buffered LDS (one barrier per K step) and an LDS row stride of 128 + 16 floats
+// (the four k-rows a wavefront's operand read touches land in disjoint bank halves).  Same k order per accumulator as the 64x64
+// kernel.  Requirements (checked by sgemm_big_ok): each operand contiguous along k or along its row index, 16-byte aligned base,
+// the other stride a multiple of 4.
+// ------------------------------------------------------------------------------------------------
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g) {
+    constexpr int LD = 128 + 16;
+    __shared__ __attribute__((aligned(16))) float As[2][16][LD];      // [buffer][k][m]
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][LD];      // [buffer][k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x4t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, kq = lane >> 4;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    f32x4t ra[2], rb[2];
+    // one operand tile = 128 x 16 floats = 512 float4, two per thread: along k (row = idx >> 2, k = 4 (idx & 3)) when k is the
+    // contiguous dimension, else along the row index (k = idx >> 5, row = 4 (idx & 31))
+    auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int idx, bool kfast) -> f32x4t {
+        f32x4t v = {0.f, 0.f, 0.f, 0.f};
+        if (kfast) {
+            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+            if (r < rows) {
+                const float* p = P + (int64_t)r * s_row + k;
+                if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (k < kend) v[0] = p[0];
+                    if (k + 1 < kend) v[1] = p[1];
+                    if (k + 2 < kend) v[2] = p[2];
+                }
+            }
+        } else {
+            const int k = k0 + (idx >> 5), r = r0 + 4 * (idx & 31);
+            if (k < kend) {
+                const float* p = P + (int64_t)k * s_k + r;
+                if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (r < rows) v[0] = p[0];
+                    if (r + 1 < rows) v[1] = p[1];
+                    if (r + 2 < rows) v[2] = p[2];
+                }
+            }
+        }
+        return v;
+    };
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, tid + e * 256, A_KFAST);
+            rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, tid + e * 256, B_KFAST);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = tid + e * 256;
+            if (A_KFAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[buf][4 * (idx & 3) + j][idx >> 2] = ra[e][j];
+            } else {
+                *reinterpret_cast<f32x4t*>(&As[buf][idx >> 5][4 * (idx & 31)]) = ra[e];
+            }
+            if (B_KFAST) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[buf][4 * (idx & 3) + j][idx >> 2] = rb[e][j];
+            } else {
+                *reinterpret_cast<f32x4t*>(&Bs[buf][idx >> 5][4 * (idx & 31)]) = rb[e];
+            }
+        }
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        if (more) fetch(k0 + 16);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = As[buf][4 * ks + kq][wm + 16 * i + li];
+                b[i] = Bs[buf][4 * ks + kq][wn + 16 * i + li];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int gm = m0 + wm + 16 * i + 4 * kq + r, gn = n0 + wn + 16 * j + li;
+                if (gm < g.M && gn < g.N) {
+                    float* c = g.C + (int64_t)gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+}
+
+// the 128x128 kernel pays when both output dimensions fill most of a tile and there are enough tiles for the chip
+static inline bool sgemm_big_ok(const GemmArgs& g, int slices) {
+    if (g.M <= 96 || g.N <= 96 || g.K < 16) return false;
+    const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * slices;
+    if (tiles < 96) return false;
+    const bool ak = g.sAk == 1, am = g.sAm == 1, bk = g.sBk == 1, bn = g.sBn == 1;
+    if (!(ak || am) || !(bk || bn)) return false;
+    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) return false;
+    if ((ak ? g.sAm : g.sAk) % 4 != 0 || (bk ? g.sBn : g.sBk) % 4 != 0) return false;
+    return g.kchunk % 4 == 0;
+}
+
+// the matrix-core GEMM of a (possibly split-K) problem: the 128x128 kernel where it pays, the 64x64 one otherwise
+static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t st) {
+    if (sgemm_big_ok(g, slices)) {
+        const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, slices);
+        const bool ak = g.sAk == 1, bk = g.sBk == 1;
+        if (ak && bk) hipLaunchKernelGGL((sgemm_mfma128_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (ak) hipLaunchKernelGGL((sgemm_mfma128_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (bk) hipLaunchKernelGGL((sgemm_mfma128_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((sgemm_mfma128_kernel<false, false>), grid, dim3(256), 0, st, g);
+        return;
+    }
+    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, slices), dim3(256), 0, st, g);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tall-and-skinny case: many rows, a small [K x N] weight matrix (the per-row projections of the graph models:
 // [batch*patches*nodes, 16..64] x [16..64, 8..64]).  A 64x64 MFMA tile wastes most of its columns there and the launch is
 // bandwidth-bound anyway: one thread per output row, the weights in LDS (broadcast reads), the row streamed with 16-byte
@@ -257,9 +405,9 @@ static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         else hipLaunchKernelGGL(sgemm_skinny_kernel<32>, grid, dim3(256), lds, st, g);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? K : 1};
+    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? (K + 15) & ~15 : 16};
     (void)hipGetLastError();
-    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, st, g);
+    sgemm_launch_tiles(g, 1, st);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
@@ -284,8 +432,11 @@ static __global__ __launch_bounds__(256) void sgemm_reduce_slices_kernel(const f
 }
 
 static inline int sgemm_splitk_slices(int M, int N, int K) {
-    const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    int s = 1024 / (tiles > 0 ? tiles : 1);          // aim at ~1024 workgroups
+    // outputs that fill 128x128 tiles run on the big kernel (sgemm_big_ok): count its tiles, two workgroups per CU
+    const bool big = M > 96 && N > 96;
+    const int t = big ? 128 : 64;
+    const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t);
+    int s = (big ? 768 : 1024) / (tiles > 0 ? tiles : 1);          // aim at ~768 / ~1024 workgroups
     const int maxs = (K + 255) / 256;                // at least 256 k per slice
     if (s > maxs) s = maxs;
     if (s > 256) s = 256;
@@ -407,7 +558,7 @@ static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B
     const int used = (K + kchunk - 1) / kchunk;
     GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
     (void)hipGetLastError();
-    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((N + 63) / 64, (M + 63) / 64, used), dim3(256), 0, st, g);
+    sgemm_launch_tiles(g, used, st);
     hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, partial, C, ldc, M, N, used,
                        accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;

@@ -633,6 +633,15 @@ int rulgnn_stagnn_backward_f32(const rulgnn_stagnn_shape *shape, const rulgnn_st
 int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stagnn_args *args, const rulgnn_adam_args *opt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The fp32 matrix product behind every nn.Linear / torch.matmul / torch.bmm of the reference models that runs as a GEMM here
+ * (e.g. models/SAGCN/Model.py:107-108, models/STNet/Model.py:31-38, models/ST_GCN/Model.py:88): C[m][n] (+)= sum_k A(m,k) B(n,k) with
+ * element strides (A(m,k) = A[m * sAm + k * sAk], B(n,k) = B[n * sBn + k * sBk], C row stride ldc), exact fp32 on the matrix cores
+ * (v_mfma_f32_16x16x4_f32), fixed summation order.  Exposed for the parity tests and for timing the kernel alone.
+ */
+int rulgnn_sgemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
+                     int32_t M, int32_t N, int32_t K, int32_t accumulate, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).
  * The Bi-LSTM stack in front of it (Model.py:26-73) and the two-layer fc behind it stay with the vendor libraries on the
  * Python side (strictly sequential recurrence over batch*nodes, not a graph kernel).

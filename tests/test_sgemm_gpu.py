@@ -1,0 +1,59 @@
+"""The fp32 matrix-core GEMM (csrc/sgemm_mfma.hpp: 64x64 and 128x128 tile kernels, generic strides) against numpy fp64 (GPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run(A, B, M, N, K, a_layout, b_layout, accumulate=False, C0=None):
+    """A given as the logical [M, K] array, B as the logical [N, K] array; layouts 'k' (k contiguous) or 'r' (row index contiguous)."""
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    At = torch.from_numpy(np.ascontiguousarray(A if a_layout == "k" else A.T)).to(DEV)
+    Bt = torch.from_numpy(np.ascontiguousarray(B if b_layout == "k" else B.T)).to(DEV)
+    sAm, sAk = (K, 1) if a_layout == "k" else (1, M)
+    sBn, sBk = (K, 1) if b_layout == "k" else (1, N)
+    Ct = torch.zeros(M, N, device=DEV) if C0 is None else torch.from_numpy(C0.copy()).to(DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rulgnn_sgemm_f32(At.data_ptr(), sAm, sAk, Bt.data_ptr(), sBn, sBk, Ct.data_ptr(), N, M, N, K, 1 if accumulate else 0, st), "sgemm")
+    return Ct.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 1000, 1000), (128, 25600, 128), (200, 12800, 128), (1024, 1024, 16), (777, 515, 133), (129, 97 * 128, 40),
+                                   (12800, 1000, 40), (64, 64, 64), (5, 3, 7), (300, 200, 19)])
+@pytest.mark.parametrize("a_layout,b_layout", [("k", "k"), ("k", "r"), ("r", "k"), ("r", "r")])
+def test_matches_numpy(M, N, K, a_layout, b_layout):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got = run(A, B, M, N, K, a_layout, b_layout)
+    assert np.abs(got - ref).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-6
+    if M * N <= 1 << 20:
+        C0 = rng.standard_normal((M, N)).astype(np.float32)
+        got = run(A, B, M, N, K, a_layout, b_layout, accumulate=True, C0=C0)
+        assert np.abs(got - (ref + C0)).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-5
+
+
+def test_both_tile_kernels_give_the_same_bits_and_unaligned_operands_are_handled():
+    """Same k order per accumulator in the 64x64 and the 128x128 kernel: a sub-block computed alone (small problem -> 64x64 kernel) equals
+    the same block of the big product; an operand whose base is not 16-byte aligned takes the 64x64 kernel."""
+    from gnn_rul_benchmarking_amd import _lib
+    rng = np.random.default_rng(1)
+    M, N, K = 1024, 2048, 200
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    big = run(A, B, M, N, K, "k", "k")
+    small = run(A[:64], B[:64], 64, 64, K, "k", "k")
+    assert np.array_equal(big[:64, :64], small)
+    lib = _lib.load()
+    buf = torch.from_numpy(np.concatenate([[0.0], A.reshape(-1)]).astype(np.float32)).to(DEV)      # A starts 4 bytes into the allocation
+    Bt = torch.from_numpy(B).to(DEV)
+    Ct = torch.zeros(M, N, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rulgnn_sgemm_f32(buf.data_ptr() + 4, K, 1, Bt.data_ptr(), K, 1, Ct.data_ptr(), N, M, N, K, 0, st), "sgemm")
+    assert np.array_equal(Ct.cpu().numpy(), big)
