@@ -350,6 +350,19 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
         H = cfg["encoder_hidden_dim"]
         return T * 2 * cfg["num_patch"] * (2 * 4 * H * H), ("recurrent matvec 4H x H per step, direction and sequence over batch x nodes = "
                                                             f"{T} SEQUENTIAL steps (H = {H}): a latency-bound recurrence, not a throughput kernel")
+    if family == "SAGCN" and "sgemm_mfma128_kernel" in name:
+        # the matrix products of one step by operand layout (csrc/sagcn.hip::sagcn_run): which template instance serves which GEMM
+        P, H, Ah = cfg["num_patch"], cfg["gcn_hidden_dim"], cfg["attention_hidden_dim"]
+        R, BH = P * B, B * H
+        node, feat, att = 2.0 * P * P * BH, 2.0 * R * H * H, 2.0 * P * Ah * BH
+        variants = {"<true, true": (2.0 * R * H * 40 + 2 * feat + 2 * att + 2 * node,
+                                    "gcn1, the two feature-axis Linear layers, the split-K gradients of the attention and node-axis weights"),
+                    "<true, false": (2 * node + 2 * att + 2 * feat, "the two node-axis Linear layers, the attention's two products, d(node-mixed) of both projections"),
+                    "<false, false": (2 * att + 2 * feat + 2 * node, "d tanh-input, d h3, the feature-axis weight gradients, d(input) of both projections")}
+        for key, (flops, what) in variants.items():
+            if key in name:
+                return flops / per_step, (f"fp32 MFMA GEMMs of one step served by this instance ({what}): {flops / 1e9:.1f} GFLOP over "
+                                          f"{per_step:.0f} launches (P = {P}, H = {H}, Ah = {Ah}, batch {B})")
     if family == "STMSGCN" and "msg_gcn_backward_kernel" in name:
         from oracle.stmsgcn_oracle import num_nodes
         n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])

@@ -108,11 +108,12 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
 // kernel.  Requirements (checked by sgemm_big_ok): each operand contiguous along k or along its row index, 16-byte aligned base,
 // the other stride a multiple of 4.
 // ------------------------------------------------------------------------------------------------
-template <bool A_KFAST, bool B_KFAST>
+template <bool A_KFAST, bool B_KFAST, int KT>
 static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g) {
     constexpr int LD = 128 + 16;
-    __shared__ __attribute__((aligned(16))) float As[2][16][LD];      // [buffer][k][m]
-    __shared__ __attribute__((aligned(16))) float Bs[2][16][LD];      // [buffer][k][n]
+    extern __shared__ __attribute__((aligned(16))) float sgemm_big_lds[];
+    float (*As)[KT][LD] = reinterpret_cast<float (*)[KT][LD]>(sgemm_big_lds);                    // [buffer][k][m]
+    float (*Bs)[KT][LD] = reinterpret_cast<float (*)[KT][LD]>(sgemm_big_lds + 2 * KT * LD);      // [buffer][k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -124,13 +125,14 @@ static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g
     const int li = lane & 15, kq = lane >> 4;
     const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    f32x4t ra[2], rb[2];
+    constexpr int NF = KT / 8;          // float4 per thread and operand: 128 x KT floats over 256 threads
+    f32x4t ra[NF], rb[NF];
     // one operand tile = 128 x 16 floats = 512 float4, two per thread: along k (row = idx >> 2, k = 4 (idx & 3)) when k is the
     // contiguous dimension, else along the row index (k = idx >> 5, row = 4 (idx & 31))
     auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int idx, bool kfast) -> f32x4t {
         f32x4t v = {0.f, 0.f, 0.f, 0.f};
         if (kfast) {
-            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+            const int r = r0 + idx / (KT / 4), k = k0 + 4 * (idx % (KT / 4));
             if (r < rows) {
                 const float* p = P + (int64_t)r * s_row + k;
                 if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
@@ -156,24 +158,24 @@ static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g
     };
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NF; ++e) {
             ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, tid + e * 256, A_KFAST);
             rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, tid + e * 256, B_KFAST);
         }
     };
     auto stash = [&](int buf) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NF; ++e) {
             const int idx = tid + e * 256;
             if (A_KFAST) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) As[buf][4 * (idx & 3) + j][idx >> 2] = ra[e][j];
+                for (int j = 0; j < 4; ++j) As[buf][4 * (idx % (KT / 4)) + j][idx / (KT / 4)] = ra[e][j];
             } else {
                 *reinterpret_cast<f32x4t*>(&As[buf][idx >> 5][4 * (idx & 31)]) = ra[e];
             }
             if (B_KFAST) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[buf][4 * (idx & 3) + j][idx >> 2] = rb[e][j];
+                for (int j = 0; j < 4; ++j) Bs[buf][4 * (idx % (KT / 4)) + j][idx / (KT / 4)] = rb[e][j];
             } else {
                 *reinterpret_cast<f32x4t*>(&Bs[buf][idx >> 5][4 * (idx & 31)]) = rb[e];
             }
@@ -185,11 +187,11 @@ static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g
         stash(0);
     }
     __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const bool more = k0 + 16 < kend;
-        if (more) fetch(k0 + 16);
+    for (int k0 = kbeg; k0 < kend; k0 += KT) {
+        const bool more = k0 + KT < kend;
+        if (more) fetch(k0 + KT);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KT / 4; ++ks) {
             float a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -220,6 +222,9 @@ static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g
             }
 }
 
+#ifndef SGEMM_BIG_KT
+#define SGEMM_BIG_KT 16
+#endif
 // the 128x128 kernel pays when both output dimensions fill most of a tile and there are enough tiles for the chip
 static inline bool sgemm_big_ok(const GemmArgs& g, int slices) {
     if (g.M <= 96 || g.N <= 96 || g.K < 16) return false;
@@ -237,10 +242,19 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
     if (sgemm_big_ok(g, slices)) {
         const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, slices);
         const bool ak = g.sAk == 1, bk = g.sBk == 1;
-        if (ak && bk) hipLaunchKernelGGL((sgemm_mfma128_kernel<true, true>), grid, dim3(256), 0, st, g);
-        else if (ak) hipLaunchKernelGGL((sgemm_mfma128_kernel<true, false>), grid, dim3(256), 0, st, g);
-        else if (bk) hipLaunchKernelGGL((sgemm_mfma128_kernel<false, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((sgemm_mfma128_kernel<false, false>), grid, dim3(256), 0, st, g);
+        constexpr size_t lds = (size_t)4 * SGEMM_BIG_KT * (128 + 16) * sizeof(float);
+        auto go = [&](auto kernel) {
+            static bool raised = false;                              // once per instantiation and process
+            if (lds > 48 * 1024 && !raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                raised = true;
+            }
+            hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g);
+        };
+        if (ak && bk) go(sgemm_mfma128_kernel<true, true, SGEMM_BIG_KT>);
+        else if (ak) go(sgemm_mfma128_kernel<true, false, SGEMM_BIG_KT>);
+        else if (bk) go(sgemm_mfma128_kernel<false, true, SGEMM_BIG_KT>);
+        else go(sgemm_mfma128_kernel<false, false, SGEMM_BIG_KT>);
         return;
     }
     hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, slices), dim3(256), 0, st, g);
