@@ -294,6 +294,7 @@ FAMILY_CONFIGS = {
     "STAGNN": ("CMAPSS", "FD001", 256, (14, 50), 0.02e6 + 0.25e6 + 0.84e6 + 1.39e6 + 0.03e6 + 0.27e6),
 }
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 matrix peak (MI355X_MICROARCH.md)
 
 
 def kernel_short_name(name):
@@ -350,7 +351,7 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
         H = cfg["encoder_hidden_dim"]
         return T * 2 * cfg["num_patch"] * (2 * 4 * H * H), ("recurrent matvec 4H x H per step, direction and sequence over batch x nodes = "
                                                             f"{T} SEQUENTIAL steps (H = {H}): a latency-bound recurrence, not a throughput kernel")
-    if family == "SAGCN" and "sgemm_mfma128_kernel" in name:
+    if family == "SAGCN" and ("sgemm_mfma128_kernel" in name or "sgemm_bf16x3_kernel" in name):
         # the matrix products of one step by operand layout (csrc/sagcn.hip::sagcn_run): which template instance serves which GEMM
         P, H, Ah = cfg["num_patch"], cfg["gcn_hidden_dim"], cfg["attention_hidden_dim"]
         R, BH = P * B, B * H
@@ -361,7 +362,7 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
                     "<false, false": (2 * att + 2 * feat + 2 * node, "d tanh-input, d h3, the feature-axis weight gradients, d(input) of both projections")}
         for key, (flops, what) in variants.items():
             if key in name:
-                return flops / per_step, (f"fp32 MFMA GEMMs of one step served by this instance ({what}): {flops / 1e9:.1f} GFLOP over "
+                return flops / per_step, (f"matrix-core GEMMs of one step served by this instance ({what}): {flops / 1e9:.1f} GFLOP over "
                                           f"{per_step:.0f} launches (P = {P}, H = {H}, Ah = {Ah}, batch {B})")
     if family == "STMSGCN" and "msg_gcn_backward_kernel" in name:
         from oracle.stmsgcn_oracle import num_nodes
@@ -513,7 +514,12 @@ def family_main(args, world, rank, dev, use_dist, dist):
                 "whole_step_estimate": {"achieved": whole["achieved"], "frac": whole["frac"], "note": whole["note"]}}
         if work:
             ach = work / (us * 1e-6) / 1e12
-            roof.update({"achieved": round(ach, 4), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 5), "flops_per_launch": round(work), "work_model": how})
+            peak = FP32_MFMA_PEAK_TFLOPS
+            if "bf16x3" in short:
+                # fp32-class products out of six bf16 matrix instructions each (csrc/sgemm_mfma.hpp): the ceiling is a sixth of the dense bf16 peak
+                peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
+                roof["peak_note"] = "dense bf16 matrix peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 products per fp32-class product; FLOPs counted once"
+            roof.update({"achieved": round(ach, 4), "peak": peak, "frac": round(ach / peak, 5), "flops_per_launch": round(work), "work_model": how})
         else:
             roof.update({"achieved": whole["achieved"], "frac": whole["frac"],
                          "work_model": "no per-kernel FLOP model for this kernel (a generic GEMM serving several shapes): the whole-step estimate is quoted"})

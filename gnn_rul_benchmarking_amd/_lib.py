@@ -144,6 +144,7 @@ class RgcnuArgs(C.Structure):
 
 
 DTYPE_F32, DTYPE_BF16 = 0, 1      # include/rulgnn.h RULGNN_DTYPE_*
+GEMM_F32, GEMM_BF16X3 = 0, 1      # include/rulgnn.h RULGNN_GEMM_*
 HAGCN_TOPK_SLOTS = 16
 
 
@@ -184,6 +185,7 @@ _SIGNATURES = {
     "rulgnn_sagcn_fwdbwd_f32": (C.c_int, [C.POINTER(SagcnShape), C.POINTER(SagcnArgs), C.POINTER(AdamArgs), C.c_void_p]),
     "rulgnn_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p]),
+    "rulgnn_sgemm_mode": (C.c_int, [C.c_int32]),
     "rulgnn_stagnn_param_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_bn_state_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_workspace_bytes": (C.c_size_t, [C.POINTER(StagnnShape)]),

@@ -6,6 +6,13 @@
 
 using namespace rulgnn;
 
+namespace rulgnn {
+int& sgemm_big_mode() {
+    static int mode = RULGNN_GEMM_BF16X3;
+    return mode;
+}
+}  // namespace rulgnn
+
 extern "C" {
 
 int rulgnn_version(void) { return 100; }   // 0.1.0
@@ -703,6 +710,12 @@ int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_
     if (rc != RULGNN_OK || !opt) return rc;
     return adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, sagcn_param_count(shape), opt->step, opt->lr, opt->beta1,
                      opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+}
+
+int rulgnn_sgemm_mode(int32_t mode) {
+    const int prev = sgemm_big_mode();
+    if (mode == RULGNN_GEMM_F32 || mode == RULGNN_GEMM_BF16X3) sgemm_big_mode() = mode;
+    return prev;
 }
 
 // ---- STAGNN ---------------------------------------------------------------------------------------------------------------------

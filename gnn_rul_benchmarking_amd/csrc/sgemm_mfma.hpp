@@ -222,6 +222,187 @@ static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g
             }
 }
 
+typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
+// ------------------------------------------------------------------------------------------------
+// The same 128x128 tile on the bf16 matrix cores with fp32-class accuracy ("bf16 x 3").  Every fp32 operand is split EXACTLY into
+// three bf16 parts, x = h + m + l (h = the top 8 significant bits, m = the top 8 of x - h, l = x - h - m: 24 bits in all; the
+// subtractions are exact in fp32), when its tile is written to LDS -- once per element, amortised over the 128 products it takes part
+// in.  a b = ah bh + ah bm + am bh + ah bl + am bm + al bh + (terms below 2^-23 |a b|): six v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, each bf16 x bf16 product exact.  The error per product is that of ONE fp32 rounding; the rate is a sixth of the bf16
+// matrix peak = 2.6x the fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the VALU FMA rate).  bf16 keeps fp32's exponent range, so no
+// scaling is needed (an f16 split would need two parts and three products but underflows on gradient-sized values).
+// LDS: per buffer three bf16 planes per operand, rows of 16 k = 32 bytes padded to 48 (eight consecutive rows x 16-byte reads cover
+// the 32 banks exactly once); a lane's MFMA operand is one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+// one fp32 pair -> one dword (first value in the low half) of each of the three planes
+static __device__ __forceinline__ void split_pair_bf16x3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned ha = __builtin_bit_cast(unsigned, a) & 0xFFFF0000u, hb = __builtin_bit_cast(unsigned, b) & 0xFFFF0000u;
+    const float ra = a - __builtin_bit_cast(float, ha), rb = b - __builtin_bit_cast(float, hb);
+    const unsigned ma = __builtin_bit_cast(unsigned, ra) & 0xFFFF0000u, mb = __builtin_bit_cast(unsigned, rb) & 0xFFFF0000u;
+    const float la = ra - __builtin_bit_cast(float, ma), lb = rb - __builtin_bit_cast(float, mb);
+    h = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+    m = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, lb), __builtin_bit_cast(unsigned, la), 0x07060302u);
+}
+
+// LDS layouts of one operand plane (6 KB reserved each):
+//   operand contiguous along k   : [row][16 k] bf16, rows padded to 48 bytes; a thread's float4 (4 k of one row) is one 8-byte store,
+//                                  a lane's MFMA operand (8 k of its row) one 16-byte read;
+//   operand contiguous along rows: [k pair][128 rows] dwords (k even in the low half); a thread holds 4 rows x 2 k (two float4, k and
+//                                  k + 1) = one 16-byte store, a lane's MFMA operand four 4-byte reads, consecutive lanes consecutive
+//                                  dwords.  (Two-byte stores into the row-major form were 16-way bank conflicts: 56 TFLOP/s.)
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g) {
+    constexpr int ROWB = 48;                       // bytes per LDS row of the k-contiguous form
+    constexpr int PLANE = 128 * ROWB;              // one bf16 plane of one operand tile
+    constexpr int BUF = 6 * PLANE;                 // A: h, m, l ; B: h, m, l
+    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    f32x4t ra[2], rb[2];
+    // k-contiguous: float4 e of a thread = row (tid + 256 e) >> 2, k = 4 ((tid + 256 e) & 3)
+    // row-contiguous: float4 e of a thread = rows 4 (tid & 31) .. + 3 at k = 2 (tid >> 5) + e
+    auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int e, bool kfast) -> f32x4t {
+        f32x4t v = {0.f, 0.f, 0.f, 0.f};
+        if (kfast) {
+            const int idx = tid + e * 256;
+            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+            if (r < rows) {
+                const float* p = P + (int64_t)r * s_row + k;
+                if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (k < kend) v[0] = p[0];
+                    if (k + 1 < kend) v[1] = p[1];
+                    if (k + 2 < kend) v[2] = p[2];
+                }
+            }
+        } else {
+            const int k = k0 + 2 * (tid >> 5) + e, r = r0 + 4 * (tid & 31);
+            if (k < kend) {
+                const float* p = P + (int64_t)k * s_k + r;
+                if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (r < rows) v[0] = p[0];
+                    if (r + 1 < rows) v[1] = p[1];
+                    if (r + 2 < rows) v[2] = p[2];
+                }
+            }
+        }
+        return v;
+    };
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, e, A_KFAST);
+            rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, e, B_KFAST);
+        }
+    };
+    auto stash_one = [&](unsigned char* base, const f32x4t (&v)[2], bool kfast) {
+        if (kfast) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = tid + e * 256;
+                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split_pair_bf16x3(x0, x1, h0, m0_, l0);
+                split_pair_bf16x3(x2, x3, h1, m1, l1);
+                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+            }
+        } else {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[0][j], x1 = v[1][j];
+                split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
+            }
+            unsigned char* p = base + ((tid >> 5) * 128 + 4 * (tid & 31)) * 4;
+            *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned char* b = sgemm_x3_lds + buf * BUF;
+        stash_one(b, ra, A_KFAST);
+        stash_one(b + 3 * PLANE, rb, B_KFAST);
+    };
+    // the MFMA operand of this lane: 8 consecutive k (k half lane >> 5) of row `row0 + (lane & 31)` of one plane
+    auto operand = [&](const unsigned char* plane, int row0, bool kfast) -> gemm_bf16x8 {
+        if (kfast) return *reinterpret_cast<const gemm_bf16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * 128 + row0 + (lane & 31);
+        const gemm_u32x4 v = {q[0], q[128], q[256], q[384]};
+        return __builtin_bit_cast(gemm_bf16x8, v);
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        if (more) fetch(k0 + 16);
+        const unsigned char* b = sgemm_x3_lds + buf * BUF;
+        gemm_bf16x8 a[2][3], bb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
+                bb[i][p] = operand(b + (3 + p) * PLANE, wn + 32 * i, B_KFAST);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16t c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], c, 0, 0, 0);     // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D layout of the 32x32 result: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
+                if (gm < g.M && gn < g.N) {
+                    float* c = g.C + (int64_t)gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+}
+
+// process-wide arithmetic of the big-tile GEMM: 1 = bf16 x 3 (default), 0 = fp32 matrix instructions (bit-compatible with the 64x64 kernel)
+// (defined once, in rulgnn_api.hip: this header is included by several translation units)
+int& sgemm_big_mode();
+
 #ifndef SGEMM_BIG_KT
 #define SGEMM_BIG_KT 16
 #endif
@@ -242,6 +423,22 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
     if (sgemm_big_ok(g, slices)) {
         const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, slices);
         const bool ak = g.sAk == 1, bk = g.sBk == 1;
+        if (sgemm_big_mode() == 1) {
+            constexpr size_t lx = (size_t)2 * 6 * 128 * 48;
+            auto gox = [&](auto kernel) {
+                static bool raised = false;                          // once per instantiation and process
+                if (!raised) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx);
+                    raised = true;
+                }
+                hipLaunchKernelGGL(kernel, grid, dim3(256), lx, st, g);
+            };
+            if (ak && bk) gox(sgemm_bf16x3_kernel<true, true>);
+            else if (ak) gox(sgemm_bf16x3_kernel<true, false>);
+            else if (bk) gox(sgemm_bf16x3_kernel<false, true>);
+            else gox(sgemm_bf16x3_kernel<false, false>);
+            return;
+        }
         constexpr size_t lds = (size_t)4 * SGEMM_BIG_KT * (128 + 16) * sizeof(float);
         auto go = [&](auto kernel) {
             static bool raised = false;                              // once per instantiation and process
@@ -309,8 +506,6 @@ static __global__ __launch_bounds__(256) void sgemm_skinny_kernel(GemmArgs g) {
 // the weight operand (N <= 32, K <= 128: NT x KS MFMA operands) stays in registers for the whole grid-stride loop, each of the
 // 4 result registers is one 64-byte row segment.  The kernel streams: [M, K] in, [M, N] out, nothing else.
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ unsigned gemm_pk_bf16(float a, float b) {
     unsigned u;

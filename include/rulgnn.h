@@ -640,6 +640,14 @@ int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stag
  */
 int rulgnn_sgemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t accumulate, void *stream);
+/* Arithmetic of the large-tile GEMM (outputs of at least ~100 x 100 with enough tiles to fill the chip), process-wide:
+ * RULGNN_GEMM_BF16X3 (default): every fp32 operand split exactly into three bf16 parts, six bf16 matrix instructions per product
+ * block with fp32 accumulation -- the error per product is that of one fp32 rounding (terms below 2^-23 relative are dropped), at up
+ * to 2.6x the fp32 matrix peak; RULGNN_GEMM_F32: fp32 matrix instructions (v_mfma_f32_16x16x4_f32), bit-compatible with the small-tile
+ * kernel.  Returns the previous mode; any other value only queries. */
+#define RULGNN_GEMM_F32 0
+#define RULGNN_GEMM_BF16X3 1
+int rulgnn_sgemm_mode(int32_t mode);
 
 /* ------------------------------------------------------------------------------------------------
  * HAGCN graph stack (reference models/HAGCN/Model.py:164-183: cosine_distance, GINLayer x3, SAGPool x3, node means).

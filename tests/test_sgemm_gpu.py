@@ -33,6 +33,9 @@ def test_matches_numpy(M, N, K, a_layout, b_layout):
     ref = A.astype(np.float64) @ B.astype(np.float64).T
     got = run(A, B, M, N, K, a_layout, b_layout)
     assert np.abs(got - ref).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-6
+    # fp32-class accuracy whichever kernel served the shape: compare with what fp32 accumulation itself does to this product
+    f32 = (A @ B.T).astype(np.float64)
+    assert np.abs(got - ref).max() <= 4 * np.abs(f32 - ref).max() + 1e-6 * np.abs(ref).max()
     if M * N <= 1 << 20:
         C0 = rng.standard_normal((M, N)).astype(np.float32)
         got = run(A, B, M, N, K, a_layout, b_layout, accumulate=True, C0=C0)
@@ -42,6 +45,16 @@ def test_matches_numpy(M, N, K, a_layout, b_layout):
 def test_both_tile_kernels_give_the_same_bits_and_unaligned_operands_are_handled():
     """Same k order per accumulator in the 64x64 and the 128x128 kernel: a sub-block computed alone (small problem -> 64x64 kernel) equals
     the same block of the big product; an operand whose base is not 16-byte aligned takes the 64x64 kernel."""
+    from gnn_rul_benchmarking_amd import _lib
+    prev = _lib.load().rulgnn_sgemm_mode(_lib.GEMM_F32)          # the fp32-instruction mode of the large-tile kernel
+    assert prev == _lib.GEMM_BF16X3                                # (the default)
+    try:
+        _check_f32_tiles_bitwise()
+    finally:
+        _lib.load().rulgnn_sgemm_mode(prev)
+
+
+def _check_f32_tiles_bitwise():
     from gnn_rul_benchmarking_amd import _lib
     rng = np.random.default_rng(1)
     M, N, K = 1024, 2048, 200
@@ -57,3 +70,21 @@ def test_both_tile_kernels_give_the_same_bits_and_unaligned_operands_are_handled
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.rulgnn_sgemm_f32(buf.data_ptr() + 4, K, 1, Bt.data_ptr(), K, 1, Ct.data_ptr(), N, M, N, K, 0, st), "sgemm")
     assert np.array_equal(Ct.cpu().numpy(), big)
+
+
+def test_bf16x3_is_fp32_class_on_hard_inputs():
+    """Operands spanning twelve orders of magnitude (gradient-sized values beside O(1e3) activations) and exactly representable
+    integers: the three-way bf16 split is exact, so integer products come out exact and tiny values keep their relative accuracy."""
+    rng = np.random.default_rng(7)
+    M, N, K = 512, 640, 96
+    A = (rng.standard_normal((M, K)) * 10.0 ** rng.uniform(-9, 3, (M, 1))).astype(np.float32)
+    B = (rng.standard_normal((N, K)) * 10.0 ** rng.uniform(-9, 3, (N, 1))).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got = run(A, B, M, N, K, "k", "r")
+    scale = np.abs(A.astype(np.float64)) @ np.abs(B.astype(np.float64)).T          # per-output magnitude of the summed products
+    assert (np.abs(got - ref) / scale).max() < 4e-7
+    Ai = rng.integers(-300, 300, (M, K)).astype(np.float32)
+    Bi = rng.integers(-300, 300, (N, K)).astype(np.float32)
+    exact = Ai.astype(np.float64) @ Bi.astype(np.float64).T                        # |sum| <= 96 * 9e4 < 2^24: every partial sum is an exact fp32
+    got = run(Ai, Bi, M, N, K, "r", "k")
+    assert np.array_equal(got, exact)
