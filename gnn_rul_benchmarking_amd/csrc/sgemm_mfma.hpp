@@ -254,8 +254,8 @@ static __device__ __forceinline__ void split_pair_bf16x3(float a, float b, unsig
 //   operand contiguous along rows: [k pair][128 rows] dwords (k even in the low half); a thread holds 4 rows x 2 k (two float4, k and
 //                                  k + 1) = one 16-byte store, a lane's MFMA operand four 4-byte reads, consecutive lanes consecutive
 //                                  dwords.  (Two-byte stores into the row-major form were 16-way bank conflicts: 56 TFLOP/s.)
-template <bool A_KFAST, bool B_KFAST>
-static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g) {
+template <bool A_KFAST, bool B_KFAST, bool GUARD>
+static __device__ __forceinline__ void sgemm_bf16x3_body(GemmArgs g) {
     constexpr int ROWB = 48;                       // bytes per LDS row of the k-contiguous form
     constexpr int PLANE = 128 * ROWB;              // one bf16 plane of one operand tile
     constexpr int BUF = 6 * PLANE;                 // A: h, m, l ; B: h, m, l
@@ -277,6 +277,13 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
     // row-contiguous: float4 e of a thread = rows 4 (tid & 31) .. + 3 at k = 2 (tid >> 5) + e
     auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int e, bool kfast) -> f32x4t {
         f32x4t v = {0.f, 0.f, 0.f, 0.f};
+        if (!GUARD && k0 + 16 <= kend) {          // interior tile, whole K step (wave-uniform): every 16-byte load is in bounds
+            if (kfast) {
+                const int idx = tid + e * 256;
+                return *reinterpret_cast<const f32x4t*>(P + (int64_t)(r0 + (idx >> 2)) * s_row + k0 + 4 * (idx & 3));
+            }
+            return *reinterpret_cast<const f32x4t*>(P + (int64_t)(k0 + 2 * (tid >> 5) + e) * s_k + r0 + 4 * (tid & 31));
+        }
         if (kfast) {
             const int idx = tid + e * 256;
             const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
@@ -349,15 +356,23 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
         const gemm_u32x4 v = {q[0], q[128], q[256], q[384]};
         return __builtin_bit_cast(gemm_bf16x8, v);
     };
+    // Software pipeline, two K steps deep: while the matrix cores work on tile k (LDS buffer `buf`), the registers loaded during the
+    // PREVIOUS iteration (tile k + 1: a full iteration of latency cover) are split and written to the other buffer, and the loads of
+    // tile k + 2 are issued.  The split's VALU work is interleaved with the MFMAs by the scheduling hints at the end of the body: an
+    // in-order wavefront hides ~5 other instructions behind each 32-cycle MFMA, or none at all if they sit behind the whole chain.
     int buf = 0;
     if (kbeg < kend) {
         fetch(kbeg);
         stash(0);
+        fetch(kbeg + 16);                     // tile 1 (past the end the guarded loads return zeros)
     }
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
         const bool more = k0 + 16 < kend;
-        if (more) fetch(k0 + 16);
+        f32x4t na[2], nb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { na[e] = ra[e]; nb[e] = rb[e]; }          // tile k + 1, loaded one iteration ago
+        if (k0 + 32 < kend) fetch(k0 + 32);                                      // tile k + 2 into ra / rb
         const unsigned char* b = sgemm_x3_lds + buf * BUF;
         gemm_bf16x8 a[2][3], bb[2][3];
 #pragma unroll
@@ -367,20 +382,26 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
                 a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
                 bb[i][p] = operand(b + (3 + p) * PLANE, wn + 32 * i, B_KFAST);
             }
+        // the six product terms, smallest first; consecutive MFMAs go to different accumulators (independent: back-to-back issue)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f32x16t c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], bb[j][0], c, 0, 0, 0);     // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], bb[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][1], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], bb[j][0], c, 0, 0, 0);
-                acc[i][j] = c;
-            }
-        if (more) stash(buf ^ 1);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], bb[j][PB[t]], acc[i][j], 0, 0, 0);
+        if (more) {
+            unsigned char* nbuf = sgemm_x3_lds + (buf ^ 1) * BUF;
+            stash_one(nbuf, na, A_KFAST);
+            stash_one(nbuf + 3 * PLANE, nb, B_KFAST);
+        }
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // five VALU (the split)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one LDS write
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -392,11 +413,20 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
-                if (gm < g.M && gn < g.N) {
+                if (!GUARD || (gm < g.M && gn < g.N)) {
                     float* c = g.C + (int64_t)gm * g.ldc + gn;
                     *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
                 }
             }
+}
+
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g) {
+    // interior tiles take the body whose whole K steps load without bounds checks (a third of its non-MFMA instructions were guards)
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const bool interior = (int)blockIdx.y * 128 + 128 <= g.M && (int)blockIdx.x * 128 + 128 <= g.N && kend > kbeg;
+    if (interior) sgemm_bf16x3_body<A_KFAST, B_KFAST, false>(g);
+    else sgemm_bf16x3_body<A_KFAST, B_KFAST, true>(g);
 }
 
 // process-wide arithmetic of the big-tile GEMM: 1 = bf16 x 3 (default), 0 = fp32 matrix instructions (bit-compatible with the 64x64 kernel)
