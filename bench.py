@@ -351,19 +351,36 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
         H = cfg["encoder_hidden_dim"]
         return T * 2 * cfg["num_patch"] * (2 * 4 * H * H), ("recurrent matvec 4H x H per step, direction and sequence over batch x nodes = "
                                                             f"{T} SEQUENTIAL steps (H = {H}): a latency-bound recurrence, not a throughput kernel")
-    if family == "SAGCN" and ("sgemm_mfma128_kernel" in name or "sgemm_bf16x3_kernel" in name):
-        # the matrix products of one step by operand layout (csrc/sagcn.hip::sagcn_run): which template instance serves which GEMM
+    if family == "SAGCN" and "sgemm_" in name and "reduce" not in name:
+        # every matrix product of one step (csrc/sagcn.hip::sagcn_run) as (what, M, N, K, A contiguous along k, B contiguous along k, split-K),
+        # mapped to the kernel instance that serves it by the dispatch rules of csrc/sgemm_mfma.hpp (restated here)
         P, H, Ah = cfg["num_patch"], cfg["gcn_hidden_dim"], cfg["attention_hidden_dim"]
         R, BH = P * B, B * H
-        node, feat, att = 2.0 * P * P * BH, 2.0 * R * H * H, 2.0 * P * Ah * BH
-        variants = {"<true, true": (2.0 * R * H * 40 + 2 * feat + 2 * att + 2 * node,
-                                    "gcn1, the two feature-axis Linear layers, the split-K gradients of the attention and node-axis weights"),
-                    "<true, false": (2 * node + 2 * att + 2 * feat, "the two node-axis Linear layers, the attention's two products, d(node-mixed) of both projections"),
-                    "<false, false": (2 * att + 2 * feat + 2 * node, "d tanh-input, d h3, the feature-axis weight gradients, d(input) of both projections")}
-        for key, (flops, what) in variants.items():
-            if key in name:
-                return flops / per_step, (f"matrix-core GEMMs of one step served by this instance ({what}): {flops / 1e9:.1f} GFLOP over "
-                                          f"{per_step:.0f} launches (P = {P}, H = {H}, Ah = {Ah}, batch {B})")
+        gemms = [("gcn1", R, H, 40, 1, 1, 0)]
+        for _ in range(2):
+            gemms += [("node axis", P, BH, P, 1, 0, 0), ("feature axis", R, H, H, 1, 1, 0), ("d node-mixed", R, H, H, 1, 0, 0),
+                      ("feature-axis weight gradient", H, H, R, 0, 0, 1), ("node-axis weight gradient", P, P, BH, 1, 1, 1), ("d input", P, BH, P, 0, 0, 0)]
+        gemms += [("attention tanh layer", Ah, BH, P, 1, 0, 0), ("attention logits", P, BH, Ah, 1, 0, 0), ("softmax-layer weight gradient", P, Ah, BH, 1, 1, 1),
+                  ("d tanh", Ah, BH, P, 0, 0, 0), ("tanh-layer weight gradient", Ah, P, BH, 1, 1, 1), ("d h3", P, BH, Ah, 0, 0, 0)]
+
+        def instance(M, N, K, ak, bk, split):
+            slices = 1
+            if split:
+                big = M > 96 and N > 96
+                t = 128 if big else 64
+                tiles = -(-M // t) * -(-N // t)
+                slices = max(1, min((768 if big else 1024) // tiles, -(-K // 256), 256))
+            fl = f"<{'true' if ak else 'false'}, {'true' if bk else 'false'}"
+            if M > 192 and N > 192 and -(-M // 256) * -(-N // 256) * slices >= 160:
+                return "sgemm_bf16x3w_kernel" + fl
+            if M > 96 and N > 96 and K >= 16 and -(-M // 128) * -(-N // 128) * slices >= 96:
+                return "sgemm_bf16x3_kernel" + fl
+            return "other"
+        mine = [(w, 2.0 * M * N * K) for (w, M, N, K, ak, bk, sp) in gemms if name.replace("rulgnn::", "").replace("void ", "").startswith(instance(M, N, K, ak, bk, sp))]
+        if mine:
+            flops = sum(f for _, f in mine)
+            return flops / per_step, (f"matrix products of one step served by this kernel instance ({', '.join(sorted(set(w for w, _ in mine)))}): "
+                                      f"{flops / 1e9:.1f} GFLOP over {len(mine)} products, {per_step:.0f} launches counted (P = {P}, H = {H}, Ah = {Ah}, batch {B})")
     if family == "STMSGCN" and "msg_gcn_backward_kernel" in name:
         from oracle.stmsgcn_oracle import num_nodes
         n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])

@@ -429,6 +429,172 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
     else sgemm_bf16x3_body<A_KFAST, B_KFAST, true>(g);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same arithmetic on a 256x256 block tile, 16 wavefronts (4 per SIMD, one workgroup per CU).  SQ counters of the 128x128 kernel:
+// per K step a wavefront issues 154 VALU + 37 scalar + 20 LDS instructions for its 24 MFMAs -- 1044 issue cycles against 768 MFMA
+// cycles, two wavefronts per SIMD: the split is re-done by every tile that loads an element and the kernel is ISSUE-bound.  Doubling
+// both tile dimensions halves the elements loaded (and split) per MFMA; a thread serves ONE operand (wavefronts 0-7: A, 8-15: B).
+// ------------------------------------------------------------------------------------------------
+template <bool A_KFAST, bool B_KFAST, bool GUARD>
+static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
+    constexpr int T = 256;                         // tile rows / columns
+    constexpr int ROWB = 48;
+    constexpr int PLANE = T * ROWB;                // 12 KB
+    constexpr int BUF = 6 * PLANE;                 // 72 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
+    f32x16t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    // this thread's operand
+    const bool mine_b = tid >= 512;
+    const int t = tid & 511;
+    const float* __restrict__ P = mine_b ? g.B : g.A;
+    const int64_t s_row = mine_b ? g.sBn : g.sAm, s_k = mine_b ? g.sBk : g.sAk;
+    const int rows = mine_b ? g.N : g.M, r0 = mine_b ? n0 : m0;
+    const bool kfast = mine_b ? B_KFAST : A_KFAST;                  // wave-uniform
+    f32x4t rr[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            f32x4t v = {0.f, 0.f, 0.f, 0.f};
+            if (kfast) {
+                const int idx = t + e * 512;
+                const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+                const float* p = P + (int64_t)r * s_row + k;
+                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else if (r < rows) {
+                    if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
+                    else {
+                        if (k < kend) v[0] = p[0];
+                        if (k + 1 < kend) v[1] = p[1];
+                        if (k + 2 < kend) v[2] = p[2];
+                    }
+                }
+            } else {
+                const int k = k0 + 2 * (t >> 6) + e, r = r0 + 4 * (t & 63);
+                const float* p = P + (int64_t)k * s_k + r;
+                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else if (k < kend) {
+                    if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
+                    else {
+                        if (r < rows) v[0] = p[0];
+                        if (r + 1 < rows) v[1] = p[1];
+                        if (r + 2 < rows) v[2] = p[2];
+                    }
+                }
+            }
+            rr[e] = v;
+        }
+    };
+    auto stash = [&](unsigned char* bufp, const f32x4t (&v)[2]) {
+        unsigned char* base = bufp + (mine_b ? 3 * PLANE : 0);
+        if (kfast) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = t + e * 512;
+                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split_pair_bf16x3(x0, x1, h0, m0_, l0);
+                split_pair_bf16x3(x2, x3, h1, m1, l1);
+                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0_, m1);
+                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
+            }
+        } else {
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[0][j], x1 = v[1][j];
+                split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
+            }
+            unsigned char* p = base + ((t >> 6) * T + 4 * (t & 63)) * 4;
+            *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    auto operand = [&](const unsigned char* plane, int row0, bool kf) -> gemm_bf16x8 {
+        if (kf) return *reinterpret_cast<const gemm_bf16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * T + row0 + (lane & 31);
+        const gemm_u32x4 v = {q[0], q[T], q[2 * T], q[3 * T]};
+        return __builtin_bit_cast(gemm_bf16x8, v);
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(sgemm_x3_lds, rr);
+        fetch(kbeg + 16);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        f32x4t nn[2] = {rr[0], rr[1]};                                         // tile k + 1, loaded one iteration ago
+        if (k0 + 32 < kend) fetch(k0 + 32);
+        const unsigned char* b = sgemm_x3_lds + buf * BUF;
+        gemm_bf16x8 a[2][3], bb[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
+                bb[i][p] = operand(b + (3 + p) * PLANE, wn + 32 * i, B_KFAST);
+            }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[tt]], bb[j][PB[tt]], acc[i][j], 0, 0, 0);
+        if (more) stash(sgemm_x3_lds + (buf ^ 1) * BUF, nn);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
+                if (!GUARD || (gm < g.M && gn < g.N)) {
+                    float* c = g.C + (int64_t)gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+}
+
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(1024) void sgemm_bf16x3w_kernel(GemmArgs g) {
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const bool interior = (int)blockIdx.y * 256 + 256 <= g.M && (int)blockIdx.x * 256 + 256 <= g.N && kend > kbeg;
+    if (interior) sgemm_bf16x3w_body<A_KFAST, B_KFAST, false>(g);
+    else sgemm_bf16x3w_body<A_KFAST, B_KFAST, true>(g);
+}
+
+// 256x256 tiles when both output dimensions fill them and there are enough of them for one per CU
+static inline bool sgemm_wide_ok(const GemmArgs& g, int slices) {
+    if (g.M <= 192 || g.N <= 192) return false;
+    return (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * slices >= 160;
+}
+
 // process-wide arithmetic of the big-tile GEMM: 1 = bf16 x 3 (default), 0 = fp32 matrix instructions (bit-compatible with the 64x64 kernel)
 // (defined once, in rulgnn_api.hip: this header is included by several translation units)
 int& sgemm_big_mode();
@@ -463,6 +629,23 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
                 }
                 hipLaunchKernelGGL(kernel, grid, dim3(256), lx, st, g);
             };
+            if (sgemm_wide_ok(g, slices)) {
+                const dim3 wgrid((g.N + 255) / 256, (g.M + 255) / 256, slices);
+                constexpr size_t lw = (size_t)2 * 6 * 256 * 48;
+                auto gow = [&](auto kernel) {
+                    static bool raised = false;
+                    if (!raised) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+                        raised = true;
+                    }
+                    hipLaunchKernelGGL(kernel, wgrid, dim3(1024), lw, st, g);
+                };
+                if (ak && bk) gow(sgemm_bf16x3w_kernel<true, true>);
+                else if (ak) gow(sgemm_bf16x3w_kernel<true, false>);
+                else if (bk) gow(sgemm_bf16x3w_kernel<false, true>);
+                else gow(sgemm_bf16x3w_kernel<false, false>);
+                return;
+            }
             if (ak && bk) gox(sgemm_bf16x3_kernel<true, true>);
             else if (ak) gox(sgemm_bf16x3_kernel<true, false>);
             else if (bk) gox(sgemm_bf16x3_kernel<false, true>);

@@ -24,7 +24,7 @@ def run(A, B, M, N, K, a_layout, b_layout, accumulate=False, C0=None):
 
 
 @pytest.mark.parametrize("M,N,K", [(1280, 1000, 1000), (128, 25600, 128), (200, 12800, 128), (1024, 1024, 16), (777, 515, 133), (129, 97 * 128, 40),
-                                   (12800, 1000, 40), (64, 64, 64), (5, 3, 7), (300, 200, 19)])
+                                   (12800, 1000, 40), (64, 64, 64), (5, 3, 7), (300, 200, 19), (3000, 3500, 77)])
 @pytest.mark.parametrize("a_layout,b_layout", [("k", "k"), ("k", "r"), ("r", "k"), ("r", "r")])
 def test_matches_numpy(M, N, K, a_layout, b_layout):
     rng = np.random.default_rng(M + N + K)
