@@ -26,6 +26,7 @@ namespace {
 
 constexpr int TB = 256;
 constexpr int TG_MAXN = 32, TG_MAXL = 128, TG_MAXH = 64, TG_MAXOUT = 16, TG_MAXHEADS = 4, TG_CMAX = 64;
+constexpr int TG_WREG = 2 * TG_MAXH * TG_MAXH / TB;      // convolution-weight gradients a thread owns (<= 64 x 64 x 2 over TB threads)
 constexpr float TG_BN_EPS = 1e-5f, TG_GCN_SLOPE = 0.01f, TG_GAT_SLOPE = 0.1f, TG_BN_MOMENTUM = 0.1f;
 
 struct TgGeom {
@@ -181,11 +182,30 @@ __device__ __forceinline__ void stage(float* dst, const float* __restrict__ src,
     for (int i = threadIdx.x; i < rows * cols; i += TB) dst[(i / cols) * ld + i % cols] = src[i];
 }
 
+// group-strided variant of stage(): the TB threads of one head group copy a [rows][cols] matrix into LDS rows of stride ld
+__device__ __forceinline__ void stage_group(float* dst, const float* __restrict__ src, int rows, int cols, int ld, int gt) {
+    for (int i = gt; i < rows * cols; i += TB) dst[(i / cols) * ld + i % cols] = src[i];
+}
+
+// floats of one head group's private LDS region (forward / backward) and the whole dynamic LDS of the two graph kernels
+__host__ __device__ inline int tg_fwd_group_floats(int N, int h) {
+    const int hp = h | 1, wb = h * hp > N * h ? h * hp : N * h;
+    return N * hp + N * N + 2 * N + wb;
+}
+__host__ __device__ inline int tg_bwd_group_floats(int N, int h) {
+    const int hp = h | 1;
+    return N * hp + N * h + 2 * N * N + 2 * N + h * hp;
+}
+
 // ---- graph part, forward ---------------------------------------------------------------------------------------------------------
-// LDS: X[N*LP] | adj[N*N] | ah[N*N] | AX[N*Lh] | H0[N*h] | H1[N*h] | Wh[N*hp] | att[N*N] | f1[N] | f2[N] | Wb[h*odd(Lh)]
-__global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
+// The heads of an attention layer are independent until their mean: G of them run side by side, one group of TB threads each
+// (blockDim = TB * G; with one head after the other the kernel was a chain of ~40 barrier-separated phases on one sample).
+// LDS: X[N*LP] | adj[N*N] | ah[N*N] | AX[N*Lh] | H0[N*h] | H1[N*h] | Wg[h*odd(Lh)] | G x { Wh[N*hp] | att[N*N] | f1[N] | f2[N] | Wb }
+__global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, const float* __restrict__ x, const float* __restrict__ prm,
+                                                            float* __restrict__ ws) {
     extern __shared__ float lds[];
-    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
+    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x, NT = blockDim.x;
+    const int grp = tid / TB, gt = tid % TB;
     const int Lh = L > h ? L : h, LP = odd(L), hp = odd(h);
     float* X = lds;
     float* adj = X + N * LP;
@@ -193,25 +213,30 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
     float* AX = ah + N * N;
     float* H0 = AX + N * Lh;
     float* H1 = H0 + N * h;
-    float* Wh = H1 + N * h;
+    float* Wg = H1 + N * h;
+    float* groups = Wg + h * odd(Lh);
+    const int gsz = tg_fwd_group_floats(N, h);
+    float* Wh = groups + grp * gsz;
     float* att = Wh + N * hp;
     float* f1 = att + N * N;
     float* f2 = f1 + N;
-    float* Wb = f2 + N;
+    float* Wb = f2 + N;                        // the head's weights, then its output [N][h]
+    const int wb_off = N * hp + N * N + 2 * N;
+    const float ih = 1.0f / (float)Hd;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < N * L; i += TB) X[(i / L) * LP + i % L] = x[b * N * L + i];
+        for (int i = tid; i < N * L; i += NT) X[(i / L) * LP + i % L] = x[b * N * L + i];
         __syncthreads();
         if (tid < N) {
             float s = 0.f;
             for (int l = 0; l < L; ++l) s += X[tid * LP + l];
-            f1[tid] = s / (float)L;
+            f1[tid] = s / (float)L;            // (group 0's f1 / f2 double as scratch here)
         }
         __syncthreads();
-        for (int e = tid; e < N * N; e += TB) {
+        for (int e = tid; e < N * N; e += NT) {
             const int i = e / N, j = e % N;
             float c = 0.f;
-            for (int l = 0; l < L; ++l) c = fmaf(X[i * LP + l] - f1[i], X[j * LP + l] - f1[j], c);
+            for (int l = 0; l < L; ++l) c = fmaf(X[i * LP + l] - groups[N * hp + N * N + i], X[j * LP + l] - groups[N * hp + N * N + j], c);
             adj[e] = c / (float)(L - 1) > g.thr ? 1.f : 0.f;
         }
         __syncthreads();
@@ -221,9 +246,10 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
             f2[tid] = 1.0f / sqrtf(d);
         }
         __syncthreads();
-        for (int e = tid; e < N * N; e += TB) {
+        for (int e = tid; e < N * N; e += NT) {
             const int i = e / N, j = e % N;
-            const float v = f2[i] * (adj[e] + (i == j ? 1.f : 0.f)) * f2[j];
+            const float* dinv = groups + N * hp + N * N + N;          // group 0's f2
+            const float v = dinv[i] * (adj[e] + (i == j ? 1.f : 0.f)) * dinv[j];
             ah[e] = v;
             ws[g.w_adj + b * N * N + e] = adj[e];
             ws[g.w_ahat + b * N * N + e] = v;
@@ -233,9 +259,8 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
             const int K = layer == 0 ? L : h, KP = odd(K);          // input width of this GCN layer
             const float* in = layer == 0 ? X : H1;
             const int inld = layer == 0 ? LP : h;
-            stage(Wb, prm + g.o_gcn_w[layer], h, K, KP);
-            // AX = A_hat in
-            for (int e = tid; e < N * K; e += TB) {
+            for (int i = tid; i < h * K; i += NT) Wg[(i / K) * KP + i % K] = prm[g.o_gcn_w[layer] + i];
+            for (int e = tid; e < N * K; e += NT) {                   // AX = A_hat in
                 const int i = e / K, k = e % K;
                 float a = 0.f;
                 for (int j = 0; j < N; ++j) a = fmaf(ah[i * N + j], in[j * inld + k], a);
@@ -243,38 +268,42 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
                 ws[(layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K + e] = a;
             }
             __syncthreads();
-            for (int e = tid; e < N * h; e += TB) {
+            for (int e = tid; e < N * h; e += NT) {
                 const int i = e / h, o = e % h;
                 float a = prm[g.o_gcn_b[layer] + o];
-                for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], Wb[o * KP + k], a);
+                for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], Wg[o * KP + k], a);
                 ws[(layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h + e] = a;
                 H0[e] = lrelu(a, TG_GCN_SLOPE);
                 H1[e] = 0.f;
             }
             __syncthreads();
-            for (int hd = 0; hd < Hd; ++hd) {
-                const float* av = prm + g.o_gat_a[layer][hd];
-                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
-                stage(Wb, prm + g.o_gat_w[layer][hd], h, h, hp);
+            for (int hd0 = 0; hd0 < Hd; hd0 += G) {
+                const int hd = hd0 + grp;
+                const bool act = hd < Hd;
+                const int hdc = act ? hd : 0;
+                const float* av = prm + g.o_gat_a[layer][hdc];
+                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hdc) * N * h, at_nn = (b * Hd + hdc) * N * N;
+                if (act) stage_group(Wb, prm + g.o_gat_w[layer][hdc], h, h, hp, gt);
                 __syncthreads();
-                for (int e = tid; e < N * h; e += TB) {
-                    const int i = e / h, o = e % h;
-                    float a = prm[g.o_gat_b[layer][hd] + o];
-                    for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wb[o * hp + k], a);
-                    Wh[i * hp + o] = a;
-                    ws[at_wh + e] = a;
-                }
+                if (act)
+                    for (int e = gt; e < N * h; e += TB) {
+                        const int i = e / h, o = e % h;
+                        float a = prm[g.o_gat_b[layer][hdc] + o];
+                        for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wb[o * hp + k], a);
+                        Wh[i * hp + o] = a;
+                        ws[at_wh + e] = a;
+                    }
                 __syncthreads();
-                if (tid < 2 * N) {
-                    const int i = tid % N, half = tid / N;
+                if (act && gt < 2 * N) {
+                    const int i = gt % N, half = gt / N;
                     float a = 0.f;
                     for (int o = 0; o < h; ++o) a = fmaf(av[half * h + o], Wh[i * hp + o], a);
                     (half ? f2 : f1)[i] = a;
                 }
                 __syncthreads();
-                const float ab = prm[g.o_gat_ab[layer][hd]];
-                if (tid < N) {
-                    const int i = tid;
+                if (act && gt < N) {
+                    const float ab = prm[g.o_gat_ab[layer][hdc]];
+                    const int i = gt;
                     float m = -INFINITY;
                     for (int j = 0; j < N; ++j) {
                         const float pre = f1[i] + f2[j] + ab;
@@ -295,16 +324,22 @@ __global__ __launch_bounds__(TB) void tg_graph_fwd_kernel(TgGeom g, const float*
                     }
                 }
                 __syncthreads();
-                const float ih = 1.0f / (float)Hd;
-                for (int e = tid; e < N * h; e += TB) {
-                    const int i = e / h, o = e % h;
-                    float a = 0.f;
-                    for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * hp + o], a);
-                    H1[e] = fmaf(a, ih, H1[e]);
+                if (act)
+                    for (int e = gt; e < N * h; e += TB) {             // the head's output over its (no longer needed) weights
+                        const int i = e / h, o = e % h;
+                        float a = 0.f;
+                        for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * hp + o], a);
+                        Wb[e] = a * ih;
+                    }
+                __syncthreads();
+                for (int e = tid; e < N * h; e += NT) {                // mean over the heads, in head order
+                    float a = H1[e];
+                    for (int q = 0; q < G && hd0 + q < Hd; ++q) a += groups[q * gsz + wb_off + e];
+                    H1[e] = a;
                 }
                 __syncthreads();
             }
-            for (int e = tid; e < N * h; e += TB) ws[(layer == 0 ? g.w_g1 : g.w_G) + b * N * h + e] = H1[e];
+            for (int e = tid; e < N * h; e += NT) ws[(layer == 0 ? g.w_g1 : g.w_G) + b * N * h + e] = H1[e];
             __syncthreads();
         }
     }
@@ -634,6 +669,11 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
         }
     double* part = reinterpret_cast<double*>(ws + g.w_dbnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
     double s1 = 0.0, s2 = 0.0;
+    float gw2[TG_WREG], gwd[TG_WREG / 2];
+#pragma unroll
+    for (int q = 0; q < TG_WREG; ++q) gw2[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < TG_WREG / 2; ++q) gwd[q] = 0.f;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
         for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
@@ -644,13 +684,18 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             dz[at] = gam2[c] * istd2[c] * (ws[g.w_dy2[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
         }
         __syncthreads();
-        // conv2 weight gradient: thread owns (c, ci, k)
-        for (int e = tid; e < Co * Co * 2; e += TB) {
-            const int k = e & 1, ci = (e >> 1) % Co, c = (e >> 1) / Co;
-            const int sh = k ? 0 : 2;
-            float a = 0.f;
-            for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], o0[ci * TP + t - sh], a);
-            gp[g.o_c2_w[l] + e] += a;
+        // conv2 weight gradient: thread owns (c, ci, k); summed in registers over the workgroup's samples (a read-modify-write of
+        // the partial row per sample was a chain of dependent global round trips: 32 per thread)
+#pragma unroll
+        for (int q = 0; q < TG_WREG; ++q) {
+            const int e = tid + q * TB;
+            if (e < Co * Co * 2) {
+                const int k = e & 1, ci = (e >> 1) % Co, c = (e >> 1) / Co;
+                const int sh = k ? 0 : 2;
+                float a = 0.f;
+                for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], o0[ci * TP + t - sh], a);
+                gw2[q] += a;
+            }
         }
         // d out0 = residual path + conv2 backward; through ReLU(out0)
         for (int e = tid; e < Co * T; e += TB) {
@@ -663,11 +708,15 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             d[ci * TP + t] = o0[ci * TP + t] > 0.f ? a : 0.f;
         }
         __syncthreads();
-        for (int e = tid; e < Co * Ci; e += TB) {
-            const int c = e / Ci, ci = e % Ci;
-            float a = 0.f;
-            for (int t = 0; t < T; ++t) a = fmaf(d[c * TP + t], xin[ci * TP + t], a);
-            gp[g.o_ds_w[l] + e] += a;
+#pragma unroll
+        for (int q = 0; q < TG_WREG / 2; ++q) {
+            const int e = tid + q * TB;
+            if (e < Co * Ci) {
+                const int c = e / Ci, ci = e % Ci;
+                float a = 0.f;
+                for (int t = 0; t < T; ++t) a = fmaf(d[c * TP + t], xin[ci * TP + t], a);
+                gwd[q] += a;
+            }
         }
         if (tid < Co) {
             float a = 0.f;
@@ -695,6 +744,12 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             for (int t = 0; t < T; ++t) { s1 += (double)dz[tid * TP + t]; s2 += (double)o0[tid * TP + t]; }
     }
     if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
+#pragma unroll
+    for (int q = 0; q < TG_WREG; ++q)
+        if (tid + q * TB < Co * Co * 2) gp[g.o_c2_w[l] + tid + q * TB] = gw2[q];
+#pragma unroll
+    for (int q = 0; q < TG_WREG / 2; ++q)
+        if (tid + q * TB < Co * Ci) gp[g.o_ds_w[l] + tid + q * TB] = gwd[q];
 }
 
 // ---- backward of stage 1: BN1 backward, conv1 backward -> gradient of the stage's input ---------------------------------------------
@@ -723,6 +778,9 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
             gp[g.o_bn_g[2 * l] + c] += (float)((double)m2[c] * cnt);
             gp[g.o_bn_b[2 * l] + c] += (float)((double)m1[c] * cnt);
         }
+    float gw1[TG_WREG];
+#pragma unroll
+    for (int q = 0; q < TG_WREG; ++q) gw1[q] = 0.f;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
         for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * TP + i % T] = xin_g[b * Ci * T + i];
@@ -732,12 +790,16 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
             dz[c * TP + e % T] = gam[c] * istd[c] * (ws[g.w_dy1[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
         }
         __syncthreads();
-        for (int e = tid; e < Co * Ci * 2; e += TB) {
-            const int k = e & 1, ci = (e >> 1) % Ci, c = (e >> 1) / Ci;
-            const int sh = k ? 0 : 1;
-            float a = 0.f;
-            for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], xin[ci * TP + t - sh], a);
-            gp[g.o_c1_w[l] + e] += a;
+#pragma unroll
+        for (int q = 0; q < TG_WREG; ++q) {
+            const int e = tid + q * TB;
+            if (e < Co * Ci * 2) {
+                const int k = e & 1, ci = (e >> 1) % Ci, c = (e >> 1) / Ci;
+                const int sh = k ? 0 : 1;
+                float a = 0.f;
+                for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], xin[ci * TP + t - sh], a);
+                gw1[q] += a;
+            }
         }
         for (int e = tid; e < Ci * T; e += TB) {
             const int ci = e / T, t = e % T;
@@ -749,57 +811,70 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
             dxin_out[b * Ci * T + e] = a;
         }
     }
+#pragma unroll
+    for (int q = 0; q < TG_WREG; ++q)
+        if (tid + q * TB < Co * Ci * 2) gp[g.o_c1_w[l] + tid + q * TB] = gw1[q];
 }
 
 // ---- graph part, backward --------------------------------------------------------------------------------------------------------
-// LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | Wh[N*hp] | dWh[N*h] | dhp[N*h] | att[N*N] | dpre[N*N] | AX[N*Lh] | f1[N] | f2[N] | Wb[h*hp]
-__global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float* __restrict__ prm, float* __restrict__ ws) {
+// LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | dhp[N*h] | AX[N*Lh] | Wg[h*hp] |
+//      G x { Wh[N*hp] | dWh[N*h] | att[N*N] | dpre[N*N] | f1[N] | f2[N] | Wb[h*hp] }
+__global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, const float* __restrict__ prm, float* __restrict__ ws) {
     extern __shared__ float lds[];
-    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x;
+    const int N = g.N, L = g.L, h = g.h, Hd = g.heads, tid = threadIdx.x, NT = blockDim.x;
+    const int grp = tid / TB, gt = tid % TB;
     const int Lh = L > h ? L : h, hp = odd(h);
     float* adj = lds;
     float* ah = adj + N * N;
     float* dH = ah + N * N;          // gradient arriving at the GAT output / the GCN output
-    float* dN = dH + N * h;          // gradient w.r.t. the GAT input (accumulated over the heads)
+    float* dN = dH + N * h;          // gradient w.r.t. the GAT input (summed over the heads)
     float* H = dN + N * h;           // GAT input = leaky(pre) of the GCN below
-    float* Wh = H + N * h;
+    float* dhp = H + N * h;
+    float* AX = dhp + N * h;
+    float* Wg = AX + N * Lh;
+    float* groups = Wg + h * hp;
+    const int gsz = tg_bwd_group_floats(N, h);
+    float* Wh = groups + grp * gsz;   // the head's Wh, later its share of dN ([N][h])
     float* dWh = Wh + N * hp;
-    float* dhp = dWh + N * h;
-    float* att = dhp + N * h;
+    float* att = dWh + N * h;
     float* dpre = att + N * N;
-    float* AX = dpre + N * N;
-    float* f1 = AX + N * Lh;
+    float* f1 = dpre + N * N;
     float* f2 = f1 + N;
     float* Wb = f2 + N;
     float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
     const float ih = 1.0f / (float)Hd;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int e = tid; e < N * N; e += TB) { adj[e] = ws[g.w_adj + b * N * N + e]; ah[e] = ws[g.w_ahat + b * N * N + e]; }
-        for (int e = tid; e < N * h; e += TB) dH[e] = ws[g.w_dxin[0] + b * N * h + e];          // d G from tcn1's first stage (written in place)
+        for (int e = tid; e < N * N; e += NT) { adj[e] = ws[g.w_adj + b * N * N + e]; ah[e] = ws[g.w_ahat + b * N * N + e]; }
+        for (int e = tid; e < N * h; e += NT) dH[e] = ws[g.w_dxin[0] + b * N * h + e];          // d G from tcn1's first stage (written in place)
         __syncthreads();
         for (int layer = 1; layer >= 0; --layer) {
             const int K = layer == 0 ? L : h;
             const float* pre_g = ws + (layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h;
-            for (int e = tid; e < N * h; e += TB) { H[e] = lrelu(pre_g[e], TG_GCN_SLOPE); dN[e] = 0.f; dhp[e] = dH[e] * ih; }
+            for (int e = tid; e < N * h; e += NT) { H[e] = lrelu(pre_g[e], TG_GCN_SLOPE); dN[e] = 0.f; dhp[e] = dH[e] * ih; }
             __syncthreads();
-            for (int hd = 0; hd < Hd; ++hd) {
-                const float* av = prm + g.o_gat_a[layer][hd];
-                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hd) * N * h, at_nn = (b * Hd + hd) * N * N;
-                for (int e = tid; e < N * h; e += TB) Wh[(e / h) * hp + e % h] = ws[at_wh + e];
-                for (int e = tid; e < N * N; e += TB) att[e] = ws[g.w_att[layer] + at_nn + e];
-                stage(Wb, prm + g.o_gat_w[layer][hd], h, h, hp);
-                __syncthreads();
-                // d att (masked), then the softmax backward with one thread per row
-                for (int e = tid; e < N * N; e += TB) {
-                    const int i = e / N, j = e % N;
-                    float a = 0.f;
-                    for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * hp + o], a);
-                    dpre[e] = a * adj[e];
+            for (int hd0 = 0; hd0 < Hd; hd0 += G) {
+                const int hd = hd0 + grp;
+                const bool act = hd < Hd;
+                const int hdc = act ? hd : 0;
+                const float* av = prm + g.o_gat_a[layer][hdc];
+                const int64_t at_wh = g.w_wh[layer] + (b * Hd + hdc) * N * h, at_nn = (b * Hd + hdc) * N * N;
+                if (act) {
+                    for (int e = gt; e < N * h; e += TB) Wh[(e / h) * hp + e % h] = ws[at_wh + e];
+                    for (int e = gt; e < N * N; e += TB) att[e] = ws[g.w_att[layer] + at_nn + e];
+                    stage_group(Wb, prm + g.o_gat_w[layer][hdc], h, h, hp, gt);
                 }
                 __syncthreads();
-                if (tid < N) {
-                    const int i = tid;
+                if (act)                                            // d att (masked)
+                    for (int e = gt; e < N * N; e += TB) {
+                        const int i = e / N, j = e % N;
+                        float a = 0.f;
+                        for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * hp + o], a);
+                        dpre[e] = a * adj[e];
+                    }
+                __syncthreads();
+                if (act && gt < N) {                                // softmax backward, one thread per row
+                    const int i = gt;
                     float dot = 0.f;
                     for (int j = 0; j < N; ++j) dot = fmaf(dpre[i * N + j], att[i * N + j], dot);
                     float r = 0.f;
@@ -809,60 +884,71 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
                         dpre[i * N + j] = v;
                         r += v;
                     }
-                    f1[i] = r;                                    // d f1[i] = row sum
+                    f1[i] = r;                                      // d f1[i] = row sum
                 }
                 __syncthreads();
-                if (tid < N) {
+                if (act && gt < N) {
                     float cs = 0.f;
-                    for (int i = 0; i < N; ++i) cs += dpre[i * N + tid];
-                    f2[tid] = cs;                                 // d f2[j] = column sum
+                    for (int i = 0; i < N; ++i) cs += dpre[i * N + gt];
+                    f2[gt] = cs;                                    // d f2[j] = column sum
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    float a = 0.f;
-                    for (int i = 0; i < N; ++i) a += f1[i];
-                    gp[g.o_gat_ab[layer][hd]] += a;
-                }
-                if (tid < 2 * h) {
-                    const int half = tid / h, o = tid % h;
-                    const float* df = half ? f2 : f1;
-                    float a = 0.f;
-                    for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * hp + o], a);
-                    gp[g.o_gat_a[layer][hd] + tid] += a;
-                }
-                for (int e = tid; e < N * h; e += TB) {
-                    const int j = e / h, o = e % h;
-                    float a = fmaf(f1[j], av[o], f2[j] * av[h + o]);
-                    for (int i = 0; i < N; ++i) a = fmaf(att[i * N + j] * adj[i * N + j], dhp[i * h + o], a);
-                    dWh[e] = a;
+                if (act) {
+                    if (gt == 0) {
+                        float a = 0.f;
+                        for (int i = 0; i < N; ++i) a += f1[i];
+                        gp[g.o_gat_ab[layer][hdc]] += a;
+                    }
+                    if (gt < 2 * h) {
+                        const int half = gt / h, o = gt % h;
+                        const float* df = half ? f2 : f1;
+                        float a = 0.f;
+                        for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * hp + o], a);
+                        gp[g.o_gat_a[layer][hdc] + gt] += a;
+                    }
+                    for (int e = gt; e < N * h; e += TB) {
+                        const int j = e / h, o = e % h;
+                        float a = fmaf(f1[j], av[o], f2[j] * av[h + o]);
+                        for (int i = 0; i < N; ++i) a = fmaf(att[i * N + j] * adj[i * N + j], dhp[i * h + o], a);
+                        dWh[e] = a;
+                    }
                 }
                 __syncthreads();
-                for (int e = tid; e < h * h; e += TB) {
-                    const int o = e / h, k = e % h;
-                    float a = 0.f;
-                    for (int i = 0; i < N; ++i) a = fmaf(dWh[i * h + o], H[i * h + k], a);
-                    gp[g.o_gat_w[layer][hd] + e] += a;
+                if (act) {
+                    for (int e = gt; e < h * h; e += TB) {
+                        const int o = e / h, k = e % h;
+                        float a = 0.f;
+                        for (int i = 0; i < N; ++i) a = fmaf(dWh[i * h + o], H[i * h + k], a);
+                        gp[g.o_gat_w[layer][hdc] + e] += a;
+                    }
+                    if (gt < h) {
+                        float a = 0.f;
+                        for (int i = 0; i < N; ++i) a += dWh[i * h + gt];
+                        gp[g.o_gat_b[layer][hdc] + gt] += a;
+                    }
+                    for (int e = gt; e < N * h; e += TB) {             // this head's share of dN, over its Wh (no longer needed)
+                        const int i = e / h, k = e % h;
+                        float a = 0.f;
+                        for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wb[o * hp + k], a);
+                        Wh[e] = a;
+                    }
                 }
-                if (tid < h) {
-                    float a = 0.f;
-                    for (int i = 0; i < N; ++i) a += dWh[i * h + tid];
-                    gp[g.o_gat_b[layer][hd] + tid] += a;
-                }
-                for (int e = tid; e < N * h; e += TB) {
-                    const int i = e / h, k = e % h;
+                __syncthreads();
+                for (int e = tid; e < N * h; e += NT) {                // summed in head order
                     float a = dN[e];
-                    for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wb[o * hp + k], a);
+                    for (int q = 0; q < G && hd0 + q < Hd; ++q) a += groups[q * gsz + e];
                     dN[e] = a;
                 }
                 __syncthreads();
             }
             // GCN backward: d pre = dN * leaky'(pre)
-            for (int e = tid; e < N * h; e += TB) dN[e] = pre_g[e] > 0.f ? dN[e] : TG_GCN_SLOPE * dN[e];
+            for (int e = tid; e < N * h; e += NT) dN[e] = pre_g[e] > 0.f ? dN[e] : TG_GCN_SLOPE * dN[e];
             const float* ax_g = ws + (layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K;
-            for (int e = tid; e < N * K; e += TB) AX[e] = ax_g[e];
-            if (layer == 1) stage(Wb, prm + g.o_gcn_w[1], h, h, hp);
+            for (int e = tid; e < N * K; e += NT) AX[e] = ax_g[e];
+            if (layer == 1)
+                for (int i = tid; i < h * h; i += NT) Wg[(i / h) * hp + i % h] = prm[g.o_gcn_w[1] + i];
             __syncthreads();
-            for (int e = tid; e < h * K; e += TB) {
+            for (int e = tid; e < h * K; e += NT) {
                 const int o = e / K, k = e % K;
                 float a = 0.f;
                 for (int i = 0; i < N; ++i) a = fmaf(dN[i * h + o], AX[i * K + k], a);
@@ -876,14 +962,14 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
             __syncthreads();
             if (layer == 1) {
                 // d AX = d pre W ; d (gat1 output) = A_hat^T d AX
-                for (int e = tid; e < N * h; e += TB) {
+                for (int e = tid; e < N * h; e += NT) {
                     const int i = e / h, k = e % h;
                     float a = 0.f;
-                    for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], Wb[o * hp + k], a);
+                    for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], Wg[o * hp + k], a);
                     AX[e] = a;
                 }
                 __syncthreads();
-                for (int e = tid; e < N * h; e += TB) {
+                for (int e = tid; e < N * h; e += NT) {
                     const int j = e / h, k = e % h;
                     float a = 0.f;
                     for (int i = 0; i < N; ++i) a = fmaf(ah[i * N + j], AX[i * h + k], a);
@@ -895,14 +981,21 @@ __global__ __launch_bounds__(TB) void tg_graph_bwd_kernel(TgGeom g, const float*
     }
 }
 
-inline size_t tg_lds_graph_fwd(const TgGeom& g) {
+inline size_t tg_lds_graph_fwd(const TgGeom& g, int G) {
     const int Lh = g.L > g.h ? g.L : g.h;
-    return sizeof(float) * ((size_t)g.N * (g.L | 1) + 3 * g.N * g.N + (size_t)g.N * Lh + 2 * (size_t)g.N * g.h + (size_t)g.N * (g.h | 1) + 2 * g.N +
-                            (size_t)g.h * (Lh | 1));
+    return sizeof(float) * ((size_t)g.N * (g.L | 1) + 2 * g.N * g.N + (size_t)g.N * Lh + 2 * (size_t)g.N * g.h + (size_t)g.h * (Lh | 1) +
+                            (size_t)G * tg_fwd_group_floats(g.N, g.h));
 }
-inline size_t tg_lds_graph_bwd(const TgGeom& g) {
+inline size_t tg_lds_graph_bwd(const TgGeom& g, int G) {
     const int Lh = g.L > g.h ? g.L : g.h;
-    return sizeof(float) * (4 * (size_t)g.N * g.N + 5 * (size_t)g.N * g.h + (size_t)g.N * (g.h | 1) + (size_t)g.N * Lh + 2 * g.N + (size_t)g.h * (g.h | 1));
+    return sizeof(float) * (2 * (size_t)g.N * g.N + 4 * (size_t)g.N * g.h + (size_t)g.N * Lh + (size_t)g.h * (g.h | 1) +
+                            (size_t)G * tg_bwd_group_floats(g.N, g.h));
+}
+// head groups run side by side: as many as fit in the CU's LDS (<= 4 x TB threads)
+inline int tg_head_groups(const TgGeom& g, bool bwd) {
+    int G = g.heads < 4 ? g.heads : 4;
+    while (G > 1 && (bwd ? tg_lds_graph_bwd(g, G) : tg_lds_graph_fwd(g, G)) > 160 * 1024) --G;
+    return G;
 }
 
 template <typename K>
@@ -970,9 +1063,10 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
     const float* stage_in[2] = {ws + g.w_G, ws + g.w_e[0]};
     (void)hipGetLastError();
     if (mode & 1) {
-        const size_t lg = tg_lds_graph_fwd(g);
+        const int G = tg_head_groups(g, false);
+        const size_t lg = tg_lds_graph_fwd(g, G);
         TG_RC(tg_allow_lds(tg_graph_fwd_kernel, lg));
-        hipLaunchKernelGGL(tg_graph_fwd_kernel, grid, blk, lg, st, g, a->x, prm, ws);
+        hipLaunchKernelGGL(tg_graph_fwd_kernel, grid, dim3(TB * G), lg, st, g, G, a->x, prm, ws);
         TG_LAUNCH_OK();
         for (int l = 0; l < 2; ++l) {
             const int Ci = g.Ci[l], Co = g.Co[l];
@@ -1010,9 +1104,10 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             hipLaunchKernelGGL(tg_conv1_bwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, ws + g.w_dxin[l]);
             TG_LAUNCH_OK();
         }
-        const size_t lg = tg_lds_graph_bwd(g);
+        const int G = tg_head_groups(g, true);
+        const size_t lg = tg_lds_graph_bwd(g, G);
         TG_RC(tg_allow_lds(tg_graph_bwd_kernel, lg));
-        hipLaunchKernelGGL(tg_graph_bwd_kernel, grid, blk, lg, st, g, prm, ws);
+        hipLaunchKernelGGL(tg_graph_bwd_kernel, grid, dim3(TB * G), lg, st, g, G, prm, ws);
         TG_LAUNCH_OK();
         TG_RC(rows_sum(ws + g.w_gpart, g.nblk, g.pcount, g.pcount, a->grads, st));
     }
