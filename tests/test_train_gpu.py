@@ -129,9 +129,10 @@ def test_train_shard_semantics_for_data_parallel():
     check_grads(r["grads"], gref, N, 2)
 
 
-def test_train_full_size_linearity_and_determinism():
-    """BASELINE-size batch (65536): gradients are deterministic run to run, and scaling the
-    upstream gradient by 2 scales every parameter gradient by exactly 2 (linearity of backward)."""
+def test_train_full_size_linearity_and_run_to_run_reproducibility():
+    """BASELINE-size batch (65536): gradients agree run to run to 1e-6 -- NOT bit for bit: the BatchNorm reductions end in fp64 atomics
+    whose order varies; everything else is summed in a fixed order -- and scaling the upstream gradient by 2
+    scales every parameter gradient by 2 (linearity of backward)."""
     import gpu_util as G
     N, P, B = 14, 30, 65536
     rng = np.random.default_rng(8)
