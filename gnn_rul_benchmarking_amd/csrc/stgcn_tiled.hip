@@ -789,7 +789,7 @@ struct TWs {
     size_t T, total;
     size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
     size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
-    size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one;
+    size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split;
     size_t cells_bytes;
     int grid;
 };
@@ -824,6 +824,16 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_cells = o; o += al256(w->cells_bytes);
     w->off_gpart = o; o += al256((size_t)2 * L * w->grid * CONVW * 4);
     w->off_one = o; o += 256;
+    // partial products of the split-K weight / bias gradient GEMMs (reductions over batch * 10 or batch rows)
+    {
+        const int R = (int)(B * F), Bi = (int)B;
+        size_t need = 1024;
+        if (B > 0)
+            for (size_t v : {sgemm_splitk_need_floats(N, N, R), sgemm_splitk_need_floats(1, N, R), sgemm_splitk_need_floats(N, N, Bi),
+                             sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi)})
+                need = v > need ? v : need;
+        w->off_split = o; o += al256(need * sizeof(float));
+    }
     w->total = o;
 }
 
@@ -856,6 +866,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     double* cells = reinterpret_cast<double*>(ws + w.off_cells);
     float* gpart = reinterpret_cast<float*>(ws + w.off_gpart);
     float* one = reinterpret_cast<float*>(ws + w.off_one);
+    float* split = reinterpret_cast<float*>(ws + w.off_split);
     const float* prm = ar->params;
 
     TArgs a{B, N, s->patch_size, L};
@@ -914,14 +925,14 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         float* g = ar->grads;
         T_LAUNCH(t_fill_one_kernel, 1, one);
         // fc2: dW2[j] = sum_b dpred[b] y1[b][j];  db2 = sum_b dpred[b]
-        rc = sgemm(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, stream);
+        rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
-        rc = sgemm(dpredb, 0, 1, one, 0, 0, g + off_fc2_b(N, L), 1, 1, 1, (int)B, false, stream);
+        rc = sgemm_splitk(dpredb, 0, 1, one, 0, 0, g + off_fc2_b(N, L), 1, 1, 1, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
         // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
-        rc = sgemm(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, stream);
+        rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
-        rc = sgemm(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, stream);
+        rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
         rc = sgemm(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, stream);
         if (rc != RULGNN_OK) return rc;
@@ -937,9 +948,9 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             T_LAUNCH(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
                      gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t);
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
-            rc = sgemm(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, stream);
+            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream);
             if (rc != RULGNN_OK) return rc;
-            rc = sgemm(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, stream);
+            rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
             if (rc != RULGNN_OK) return rc;
             if (l > 0) {
                 rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream);      // dHpre . theta
