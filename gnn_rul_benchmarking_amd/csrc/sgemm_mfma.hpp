@@ -953,7 +953,7 @@ static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const fl
 
 // workgroups of the long-k path for this shape, 0 if it does not apply
 static inline int sgemm_longk_blocks(int M, int N, int K) {
-    if (!(M * N <= 1024 && K >= 2048 && ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float) <= 48 * 1024)) return 0;
+    if (!(M * N <= 1024 && K >= 512 && ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float) <= 48 * 1024)) return 0;
     const int nblk = (K + SKT_ROWS - 1) / SKT_ROWS;     // one k tile per workgroup while the partial buffer (1024 rows) allows
     return nblk > 1024 ? 1024 : nblk;
 }
