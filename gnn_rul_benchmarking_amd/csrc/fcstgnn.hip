@@ -21,6 +21,7 @@ namespace rulgnn {
 namespace {
 
 constexpr int FB = 256;
+constexpr int FC_GRAPH_FWD_THREADS = 128, FC_GRAPH_BWD_THREADS = 256;     // workgroups of the per-graph kernels (measured: 46 -> 42 us, 74 -> 70 us)
 constexpr int MAXC = 64;            // BatchNorm channels
 constexpr int MAXQ = 40;            // graph nodes = 2 * sensors
 constexpr int MAXD = 64;            // graph feature width 2 * hidden_dim
@@ -343,50 +344,53 @@ __device__ inline int64_t graph_row(const FcGeom& g, int blk, int64_t gi, int q)
 __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
                                                      const Cells* cells, int training, const float* __restrict__ F,
                                                      const float* __restrict__ Mm, float* __restrict__ P, float* __restrict__ AX) {
-    __shared__ float mm[MAXQ][MAXD + 1];
-    __shared__ float xb[MAXQ][MAXD + 1];
-    __shared__ float A[MAXQ][MAXQ + 1];
+    // dynamic LDS sized for THIS wiring's Q x D2 (sized for the limits, 40 x 64, the arrays took 28 KB and held the CU to 5 workgroups)
+    extern __shared__ float fc_graph_lds[];
     __shared__ BnCoef cd[MAXD];
-    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x;
+    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x, FT = blockDim.x;
+    const int DP = D2 + 1, QP = Q + 1;
+    float* mm = fc_graph_lds;               // [Q][DP]
+    float* xb = mm + Q * DP;                // [Q][DP]
+    float* A = xb + Q * DP;                 // [Q][QP]
     if (tid < D2) cd[tid] = fbn(g, cells, prm, running, training, 3 + 2 * blk, tid);
     __syncthreads();
     for (int64_t gi = blockIdx.x; gi < g.G[blk]; gi += gridDim.x) {
-        for (int e = tid; e < Q * D2; e += FB) {
+        for (int e = tid; e < Q * D2; e += FT) {
             const int q = e / D2, d = e - q * D2;
             const int64_t r = graph_row(g, blk, gi, q);
-            mm[q][d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
-            xb[q][d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
+            mm[q * DP + d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
+            xb[q * DP + d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
         }
         __syncthreads();
-        for (int e = tid; e < Q * Q; e += FB) {
+        for (int e = tid; e < Q * Q; e += FT) {
             const int i = e / Q, j = e - i * Q;
             float s = 0.f;
-            for (int d = 0; d < D2; ++d) s = fmaf(mm[i][d], mm[j][d], s);
+            for (int d = 0; d < D2; ++d) s = fmaf(mm[i * DP + d], mm[j * DP + d], s);
             if (i == j) s -= 1e8f;
-            A[i][j] = leaky(s);
+            A[i * QP + j] = leaky(s);
         }
         __syncthreads();
         if (tid < Q) {                                   // softmax over the row, then + I and the decay mask
             float mx = -INFINITY;
-            for (int j = 0; j < Q; ++j) mx = fmaxf(mx, A[tid][j]);
+            for (int j = 0; j < Q; ++j) mx = fmaxf(mx, A[tid * QP + j]);
             float sum = 0.f;
             for (int j = 0; j < Q; ++j) {
-                const float ev = expf(A[tid][j] - mx);
-                A[tid][j] = ev;
+                const float ev = expf(A[tid * QP + j] - mx);
+                A[tid * QP + j] = ev;
                 sum += ev;
             }
             float* pr = P + (gi * Q + tid) * Q;
             for (int j = 0; j < Q; ++j) {
-                const float pv = A[tid][j] / sum;
+                const float pv = A[tid * QP + j] / sum;
                 pr[j] = pv;
-                A[tid][j] = (pv + (tid == j ? 1.f : 0.f)) * (((tid < N) == (j < N)) ? 1.f : DECAY);
+                A[tid * QP + j] = (pv + (tid == j ? 1.f : 0.f)) * (((tid < N) == (j < N)) ? 1.f : DECAY);
             }
         }
         __syncthreads();
-        for (int e = tid; e < Q * D2; e += FB) {
+        for (int e = tid; e < Q * D2; e += FT) {
             const int i = e / D2, d = e - i * D2;
             float a = 0.f;
-            for (int j = 0; j < Q; ++j) a = fmaf(A[i][j], xb[j][d], a);
+            for (int j = 0; j < Q; ++j) a = fmaf(A[i * QP + j], xb[j * DP + d], a);
             AX[(gi * Q + i) * D2 + d] = a;
         }
         __syncthreads();
@@ -522,58 +526,61 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
                                                          const float* __restrict__ F, const float* __restrict__ Mm,
                                                          const float* __restrict__ P, float* dAX /* in: d AX, out: cX */,
                                                          float* __restrict__ cM) {
-    __shared__ float mm[MAXQ][MAXD + 1];
-    __shared__ float xb[MAXQ][MAXD + 1];
-    __shared__ float da[MAXQ][MAXD + 1];
-    __shared__ float Pm[MAXQ][MAXQ + 1];
-    __shared__ float T[MAXQ][MAXQ + 1];
-    __shared__ float Sm[MAXQ][MAXQ + 1];          // pre-activation M M^T - 1e8 I (for the leaky slope)
+    // dynamic LDS sized for this wiring's Q x D2 (51 KB at the limits: three workgroups per CU)
+    extern __shared__ float fc_graph_lds[];
     __shared__ BnCoef cd[MAXD];
     __shared__ int64_t rows[MAXQ];
-    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x;
+    const int Q = g.Q, D2 = g.D2, N = g.N, tid = threadIdx.x, FT = blockDim.x;
+    const int DP = D2 + 1, QP = Q + 1;
+    float* mm = fc_graph_lds;               // [Q][DP]
+    float* xb = mm + Q * DP;
+    float* da = xb + Q * DP;
+    float* Pm = da + Q * DP;                // [Q][QP]
+    float* T = Pm + Q * QP;
+    float* Sm = T + Q * QP;                 // pre-activation M M^T - 1e8 I (for the leaky slope)
     if (tid < D2) cd[tid] = fbn(g, cells, prm, nullptr, 1, 3 + 2 * blk, tid);
     __syncthreads();
     for (int64_t gi = blockIdx.x; gi < g.G[blk]; gi += gridDim.x) {
         if (tid < Q) rows[tid] = graph_row(g, blk, gi, tid);
         __syncthreads();
-        for (int e = tid; e < Q * D2; e += FB) {
+        for (int e = tid; e < Q * D2; e += FT) {
             const int q = e / D2, d = e - q * D2;
             const int64_t r = rows[q];
-            mm[q][d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
-            xb[q][d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
-            da[q][d] = dAX[(gi * Q + q) * D2 + d];
+            mm[q * DP + d] = Mm[r * D2 + d] + prm[g.o_bmap[blk] + d];
+            xb[q * DP + d] = fmaf(F[r * D2 + d], cd[d].sc, cd[d].sh);
+            da[q * DP + d] = dAX[(gi * Q + q) * D2 + d];
         }
-        for (int e = tid; e < Q * Q; e += FB) Pm[e / Q][e % Q] = P[gi * Q * Q + e];
+        for (int e = tid; e < Q * Q; e += FT) Pm[(e / Q) * QP + e % Q] = P[gi * Q * Q + e];
         __syncthreads();
         // d Adj -> d P (masked) ; d Xbn = Adj^T dAX
-        for (int e = tid; e < Q * Q; e += FB) {
+        for (int e = tid; e < Q * Q; e += FT) {
             const int i = e / Q, j = e - i * Q;
             float s = 0.f, sm = 0.f;
             for (int d = 0; d < D2; ++d) {
-                s = fmaf(da[i][d], xb[j][d], s);
-                sm = fmaf(mm[i][d], mm[j][d], sm);
+                s = fmaf(da[i * DP + d], xb[j * DP + d], s);
+                sm = fmaf(mm[i * DP + d], mm[j * DP + d], sm);
             }
-            T[i][j] = s * (((i < N) == (j < N)) ? 1.f : DECAY);
-            Sm[i][j] = i == j ? sm - 1e8f : sm;
+            T[i * QP + j] = s * (((i < N) == (j < N)) ? 1.f : DECAY);
+            Sm[i * QP + j] = i == j ? sm - 1e8f : sm;
         }
-        for (int e = tid; e < Q * D2; e += FB) {
+        for (int e = tid; e < Q * D2; e += FT) {
             const int j = e / D2, d = e - j * D2;
             float s = 0.f;
             for (int i = 0; i < Q; ++i)
-                s = fmaf((Pm[i][j] + (i == j ? 1.f : 0.f)) * (((i < N) == (j < N)) ? 1.f : DECAY), da[i][d], s);
+                s = fmaf((Pm[i * QP + j] + (i == j ? 1.f : 0.f)) * (((i < N) == (j < N)) ? 1.f : DECAY), da[i * DP + d], s);
             dAX[(gi * Q + j) * D2 + d] = s;               // (this graph's dAX block is in LDS since the barrier above)
         }
         __syncthreads();
         if (tid < Q) {                                   // softmax backward per row, then the leaky slope of the pre-activation
             float dot = 0.f;
-            for (int j = 0; j < Q; ++j) dot = fmaf(T[tid][j], Pm[tid][j], dot);
-            for (int j = 0; j < Q; ++j) T[tid][j] = Pm[tid][j] * (T[tid][j] - dot) * (Sm[tid][j] > 0.f ? 1.f : LEAKY);
+            for (int j = 0; j < Q; ++j) dot = fmaf(T[tid * QP + j], Pm[tid * QP + j], dot);
+            for (int j = 0; j < Q; ++j) T[tid * QP + j] = Pm[tid * QP + j] * (T[tid * QP + j] - dot) * (Sm[tid * QP + j] > 0.f ? 1.f : LEAKY);
         }
         __syncthreads();
-        for (int e = tid; e < Q * D2; e += FB) {          // d Mm = (dS + dS^T) Mm
+        for (int e = tid; e < Q * D2; e += FT) {          // d Mm = (dS + dS^T) Mm
             const int i = e / D2, d = e - i * D2;
             float s = 0.f;
-            for (int j = 0; j < Q; ++j) s = fmaf(T[i][j] + T[j][i], mm[j][d], s);
+            for (int j = 0; j < Q; ++j) s = fmaf(T[i * QP + j] + T[j * QP + i], mm[j * DP + d], s);
             cM[(gi * Q + i) * D2 + d] = s;
         }
         __syncthreads();
@@ -986,7 +993,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
             FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
-            hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm, run,
+            hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_FWD_THREADS), sizeof(float) * (2 * g.Q * (g.D2 + 1) + g.Q * (g.Q + 1)), st, g, b, prm, run,
                                (const Cells*)cells, training, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
             FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
             hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
@@ -1044,7 +1051,13 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
             FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // AX[b] is free from here on (its last reader was the theta gradient above): it takes the per-graph d mapping blocks
-            hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FB), 0, st, g, b, prm,
+            {
+                const size_t lds_b = sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1));
+                if (lds_b > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_graph_bwd_kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess)
+                    return RULGNN_EHIP;
+            }
+            hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_BWD_THREADS), sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1)), st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
                                P_(w.dAX[b]), P_(w.AX[b]));
             hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
