@@ -423,6 +423,18 @@ def family_cpu_baseline(family, cfg, shape, budget_s=10.0):
         bs = 256
         x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
         run = lambda: O.forward_backward(x, y, p, cfg["num_patch"], cfg["patch_size"], cfg["top_k"])
+    elif family == "RGCNU":
+        from oracle import rgcnu_oracle as O
+        p = O.random_params(cfg["num_nodes"], cfg["time_length"], cfg["hidden_dim"], cfg["encoder_hidden_dim"], cfg["kernel_size"])
+        bs = 32
+        x, y = rng.uniform(0, 1, (bs,) + shape), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, cfg["alpha"])
+    elif family == "STNet":
+        from oracle import stnet_oracle as O
+        p = O.random_params(cfg["num_patch"], cfg["num_nodes"], cfg["input_dim"], cfg["Cheb_layers"], cfg["lstm_hidden_dim"], cfg["autoencoder_hidden_dim"])
+        bs = 8
+        x, y = rng.normal(0, 1, (bs, shape[1])), rng.uniform(0, 1, bs)
+        run = lambda: O.loss_and_grads(p, x, y, cfg["num_patch"], cfg["patch_size"], cfg["nperseg"])
     elif family == "STAGNN":
         from oracle import stagnn_oracle as O
         p = O.random_params(cfg["num_nodes"], cfg["time_length"], cfg["hidden_dim"], cfg["output_dim"], cfg["num_heads"])
