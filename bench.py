@@ -372,7 +372,7 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
                 slices = max(1, min((768 if big else 1024) // tiles, -(-K // 256), 256))
             fl = f"<{'true' if ak else 'false'}, {'true' if bk else 'false'}"
             if M > 192 and N > 192 and -(-M // 256) * -(-N // 256) * slices >= 160:
-                return "sgemm_bf16x3w_kernel" + fl
+                return "sgemm_bf16x3v_kernel" + fl
             if M > 96 and N > 96 and K >= 16 and -(-M // 128) * -(-N // 128) * slices >= 96:
                 return "sgemm_bf16x3_kernel" + fl
             return "other"

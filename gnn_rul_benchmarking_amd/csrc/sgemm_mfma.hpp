@@ -430,13 +430,16 @@ static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same arithmetic on a 256x256 block tile, 16 wavefronts (4 per SIMD, one workgroup per CU).  SQ counters of the 128x128 kernel:
-// per K step a wavefront issues 154 VALU + 37 scalar + 20 LDS instructions for its 24 MFMAs -- 1044 issue cycles against 768 MFMA
-// cycles, two wavefronts per SIMD: the split is re-done by every tile that loads an element and the kernel is ISSUE-bound.  Doubling
-// both tile dimensions halves the elements loaded (and split) per MFMA; a thread serves ONE operand (wavefronts 0-7: A, 8-15: B).
+// The same arithmetic on a 256x256 block tile.  SQ counters of the 128x128 kernel: per K step a wavefront issues 154 VALU + 37
+// scalar + 20 LDS instructions for its 24 MFMAs -- 1044 issue cycles against 768 MFMA cycles, two wavefronts per SIMD: the split is
+// re-done by every tile that loads an element.  Doubling both tile dimensions halves the elements loaded (and split) per MFMA; a
+// thread serves ONE operand (wavefronts 0-3: A, 4-7: B).  First built with 16 wavefronts of 64 x 64 (193 TFLOP/s at 4096^3): that
+// form is bound by LDS READ bandwidth -- 12 KB of operand planes per 24 MFMAs = 512 B per MFMA, 64 B/clk per CU of the LDS's 128 B/clk
+// before bank conflicts (a variant that split every operand once, in a pre-pass, ran no faster).  This one has 8 wavefronts of
+// 64 x 128 (128 accumulator registers): 18 KB per 48 MFMAs = 384 B per MFMA, 203 TFLOP/s.
 // ------------------------------------------------------------------------------------------------
 template <bool A_KFAST, bool B_KFAST, bool GUARD>
-static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
+static __device__ __forceinline__ void sgemm_bf16x3v_body(GemmArgs g) {
     constexpr int T = 256;                         // tile rows / columns
     constexpr int ROWB = 48;
     constexpr int PLANE = T * ROWB;                // 12 KB
@@ -444,30 +447,30 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
-    f32x16t acc[2][2];
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;          // 8 wavefronts, each 64 rows x 128 columns
+    f32x16t acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     g.C += (int64_t)blockIdx.z * g.M * g.ldc;
     // this thread's operand
-    const bool mine_b = tid >= 512;
-    const int t = tid & 511;
+    const bool mine_b = tid >= 256;
+    const int t = tid & 255;
     const float* __restrict__ P = mine_b ? g.B : g.A;
     const int64_t s_row = mine_b ? g.sBn : g.sAm, s_k = mine_b ? g.sBk : g.sAk;
     const int rows = mine_b ? g.N : g.M, r0 = mine_b ? n0 : m0;
     const bool kfast = mine_b ? B_KFAST : A_KFAST;                  // wave-uniform
-    f32x4t rr[2];
+    f32x4t rr[4];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 4; ++e) {
             f32x4t v = {0.f, 0.f, 0.f, 0.f};
             if (kfast) {
-                const int idx = t + e * 512;
+                const int idx = t + e * 256;
                 const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
                 const float* p = P + (int64_t)r * s_row + k;
                 if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
@@ -480,7 +483,7 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
                     }
                 }
             } else {
-                const int k = k0 + 2 * (t >> 6) + e, r = r0 + 4 * (t & 63);
+                const int k = k0 + 4 * (t >> 6) + e, r = r0 + 4 * (t & 63);
                 const float* p = P + (int64_t)k * s_k + r;
                 if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
                 else if (k < kend) {
@@ -495,12 +498,12 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
             rr[e] = v;
         }
     };
-    auto stash = [&](unsigned char* bufp, const f32x4t (&v)[2]) {
+    auto stash = [&](unsigned char* bufp, const f32x4t (&v)[4]) {
         unsigned char* base = bufp + (mine_b ? 3 * PLANE : 0);
         if (kfast) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int idx = t + e * 512;
+            for (int e = 0; e < 4; ++e) {
+                const int idx = t + e * 256;
                 const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
                 unsigned h0, m0_, l0, h1, m1, l1;
                 split_pair_bf16x3(x0, x1, h0, m0_, l0);
@@ -511,16 +514,19 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
                 *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
             }
         } else {
-            unsigned h[4], m[4], l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x0 = v[0][j], x1 = v[1][j];
-                split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
+            for (int pp = 0; pp < 2; ++pp) {                       // two k pairs per thread: (4 kq, 4 kq + 1) and (4 kq + 2, 4 kq + 3)
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = v[2 * pp][j], x1 = v[2 * pp + 1][j];
+                    split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
+                }
+                unsigned char* p = base + ((2 * (t >> 6) + pp) * T + 4 * (t & 63)) * 4;
+                *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+                *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
             }
-            unsigned char* p = base + ((t >> 6) * T + 4 * (t & 63)) * 4;
-            *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
-            *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
         }
     };
     auto operand = [&](const unsigned char* plane, int row0, bool kf) -> gemm_bf16x8 {
@@ -538,28 +544,28 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
     __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
         const bool more = k0 + 16 < kend;
-        f32x4t nn[2] = {rr[0], rr[1]};                                         // tile k + 1, loaded one iteration ago
+        f32x4t nn[4] = {rr[0], rr[1], rr[2], rr[3]};                                         // tile k + 1, loaded one iteration ago
         if (k0 + 32 < kend) fetch(k0 + 32);
         const unsigned char* b = sgemm_x3_lds + buf * BUF;
-        gemm_bf16x8 a[2][3], bb[2][3];
+        gemm_bf16x8 a[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
-                bb[i][p] = operand(b + (3 + p) * PLANE, wn + 32 * i, B_KFAST);
-            }
+            for (int p = 0; p < 3; ++p) a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int tt = 0; tt < 6; ++tt)
+        for (int j = 0; j < 4; ++j) {
+            gemm_bf16x8 bb[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int p = 0; p < 3; ++p) bb[p] = operand(b + (3 + p) * PLANE, wn + 32 * j, B_KFAST);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[tt]], bb[j][PB[tt]], acc[i][j], 0, 0, 0);
+            for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[tt]], bb[PB[tt]], acc[i][j], 0, 0, 0);
+        }
         if (more) stash(sgemm_x3_lds + (buf ^ 1) * BUF, nn);
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
+        for (int q = 0; q < 48; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -570,7 +576,7 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
@@ -582,11 +588,11 @@ static __device__ __forceinline__ void sgemm_bf16x3w_body(GemmArgs g) {
 }
 
 template <bool A_KFAST, bool B_KFAST>
-static __global__ __launch_bounds__(1024) void sgemm_bf16x3w_kernel(GemmArgs g) {
+static __global__ __launch_bounds__(512) void sgemm_bf16x3v_kernel(GemmArgs g) {
     const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const bool interior = (int)blockIdx.y * 256 + 256 <= g.M && (int)blockIdx.x * 256 + 256 <= g.N && kend > kbeg;
-    if (interior) sgemm_bf16x3w_body<A_KFAST, B_KFAST, false>(g);
-    else sgemm_bf16x3w_body<A_KFAST, B_KFAST, true>(g);
+    if (interior) sgemm_bf16x3v_body<A_KFAST, B_KFAST, false>(g);
+    else sgemm_bf16x3v_body<A_KFAST, B_KFAST, true>(g);
 }
 
 // 256x256 tiles when both output dimensions fill them and there are enough of them for one per CU
@@ -638,12 +644,12 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
                         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
                         raised = true;
                     }
-                    hipLaunchKernelGGL(kernel, wgrid, dim3(1024), lw, st, g);
+                    hipLaunchKernelGGL(kernel, wgrid, dim3(512), lw, st, g);
                 };
-                if (ak && bk) gow(sgemm_bf16x3w_kernel<true, true>);
-                else if (ak) gow(sgemm_bf16x3w_kernel<true, false>);
-                else if (bk) gow(sgemm_bf16x3w_kernel<false, true>);
-                else gow(sgemm_bf16x3w_kernel<false, false>);
+                if (ak && bk) gow(sgemm_bf16x3v_kernel<true, true>);
+                else if (ak) gow(sgemm_bf16x3v_kernel<true, false>);
+                else if (bk) gow(sgemm_bf16x3v_kernel<false, true>);
+                else gow(sgemm_bf16x3v_kernel<false, false>);
                 return;
             }
             if (ak && bk) gox(sgemm_bf16x3_kernel<true, true>);
