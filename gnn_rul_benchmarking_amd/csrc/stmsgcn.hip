@@ -109,6 +109,7 @@ __device__ inline void gram_plus_identity(const float* cat, int CS, int off, int
         const float* xj = cat + j * CS + off;
         const float* xj1 = cat + j1 * CS + off;
         float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 8
         for (int c = 0; c < f; ++c) {
             const float u0 = xi[c], u1 = xi1[c], v0 = xj[c], v1 = xj1[c];
             a00 = fmaf(u0, v0, a00); a01 = fmaf(u0, v1, a01);
@@ -146,6 +147,7 @@ __device__ inline void aggregate(const float* ahat, const float* cat, int CS, in
         const float* xc = cat + off + c;
         const bool k1 = TW > 1 && c + 1 < f, k2 = TW > 1 && c + 2 < f, k3 = TW > 1 && c + 3 < f;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
         for (int j = 0; j < n; ++j) {
             const float w = ar[j];
             const float* xr = xc + j * CS;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
             for (int j = tid; j < P; j += MB) {
                 float re = 0.f, im = 0.f;
                 int idx = 0;
+#pragma unroll 8
                 for (int t = 0; t < P; ++t) {
                     const float v = xs[t];
                     re = fmaf(v, tw[2 * idx], re);
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
                 const int i = e / foq, o = TW * (e - i * foq);
                 const bool k1 = TW > 1 && o + 1 < fo, k2 = TW > 1 && o + 2 < fo, k3 = TW > 1 && o + 3 < fo;
                 float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+#pragma unroll 8
                 for (int k = 0; k < fi; ++k) {
                     const float av = ax[i * AXS + k];
                     const float* wr = w + k * fo + o;
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
                     const int o = e / fq, k = TW * (e - o * fq);
                     const bool k1 = TW > 1 && k + 1 < fi, k2 = TW > 1 && k + 2 < fi, k3 = TW > 1 && k + 3 < fi;
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
                     for (int i = 0; i < n; ++i) {
                         const float d = dcat[i * CS + offo + o];
                         const float* xr = ax + i * AXS + k;
@@ -646,6 +651,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
                     const int i = e / fq, k = TW * (e - i * fq);
                     const bool k1 = TW > 1 && k + 1 < fi, k2 = TW > 1 && k + 2 < fi, k3 = TW > 1 && k + 3 < fi;
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
                     for (int o = 0; o < fo; ++o) {
                         const float d = dcat[i * CS + offo + o];
                         const float* wr = wl + o * fi + k;
@@ -675,6 +681,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
                     const float* v0p = cat + j * CS + off;
                     const float* v1p = cat + j1 * CS + off;
                     float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 8
                     for (int k = 0; k < fi; ++k) {
                         const float u0 = u0p[k], u1 = u1p[k], v0 = v0p[k], v1 = v1p[k];
                         a00 = fmaf(u0, v0, a00); a01 = fmaf(u0, v1, a01);
@@ -712,6 +719,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
                     const int i = e / fq, c = TW * (e - i * fq);
                     const bool k1 = TW > 1 && c + 1 < fi, k2 = TW > 1 && c + 2 < fi, k3 = TW > 1 && c + 3 < fi;
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
                     for (int j = 0; j < n; ++j) {
                         const float h = ahat[j * n1 + i], m = araw[i * n1 + j];
                         const float* dr = ax + j * AXS + c;
