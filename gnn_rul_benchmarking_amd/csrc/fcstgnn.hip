@@ -365,6 +365,7 @@ __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const f
         for (int e = tid; e < Q * Q; e += FT) {
             const int i = e / Q, j = e - i * Q;
             float s = 0.f;
+#pragma unroll 8
             for (int d = 0; d < D2; ++d) s = fmaf(mm[i * DP + d], mm[j * DP + d], s);
             if (i == j) s -= 1e8f;
             A[i * QP + j] = leaky(s);
@@ -372,14 +373,17 @@ __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const f
         __syncthreads();
         if (tid < Q) {                                   // softmax over the row, then + I and the decay mask
             float mx = -INFINITY;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) mx = fmaxf(mx, A[tid * QP + j]);
             float sum = 0.f;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) {
                 const float ev = expf(A[tid * QP + j] - mx);
                 A[tid * QP + j] = ev;
                 sum += ev;
             }
             float* pr = P + (gi * Q + tid) * Q;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) {
                 const float pv = A[tid * QP + j] / sum;
                 pr[j] = pv;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const f
         for (int e = tid; e < Q * D2; e += FT) {
             const int i = e / D2, d = e - i * D2;
             float a = 0.f;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) a = fmaf(A[i * QP + j], xb[j * DP + d], a);
             AX[(gi * Q + i) * D2 + d] = a;
         }
@@ -556,6 +561,7 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
         for (int e = tid; e < Q * Q; e += FT) {
             const int i = e / Q, j = e - i * Q;
             float s = 0.f, sm = 0.f;
+#pragma unroll 8
             for (int d = 0; d < D2; ++d) {
                 s = fmaf(da[i * DP + d], xb[j * DP + d], s);
                 sm = fmaf(mm[i * DP + d], mm[j * DP + d], sm);
@@ -566,6 +572,7 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
         for (int e = tid; e < Q * D2; e += FT) {
             const int j = e / D2, d = e - j * D2;
             float s = 0.f;
+#pragma unroll 8
             for (int i = 0; i < Q; ++i)
                 s = fmaf((Pm[i * QP + j] + (i == j ? 1.f : 0.f)) * (((i < N) == (j < N)) ? 1.f : DECAY), da[i * DP + d], s);
             dAX[(gi * Q + j) * D2 + d] = s;               // (this graph's dAX block is in LDS since the barrier above)
@@ -573,13 +580,16 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
         __syncthreads();
         if (tid < Q) {                                   // softmax backward per row, then the leaky slope of the pre-activation
             float dot = 0.f;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) dot = fmaf(T[tid * QP + j], Pm[tid * QP + j], dot);
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) T[tid * QP + j] = Pm[tid * QP + j] * (T[tid * QP + j] - dot) * (Sm[tid * QP + j] > 0.f ? 1.f : LEAKY);
         }
         __syncthreads();
         for (int e = tid; e < Q * D2; e += FT) {          // d Mm = (dS + dS^T) Mm
             const int i = e / D2, d = e - i * D2;
             float s = 0.f;
+#pragma unroll 8
             for (int j = 0; j < Q; ++j) s = fmaf(T[i * QP + j] + T[j * QP + i], mm[j * DP + d], s);
             cM[(gi * Q + i) * D2 + d] = s;
         }

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
         __syncthreads();
         if (tid < N) {
             float s = 0.f;
+#pragma unroll 8
             for (int l = 0; l < L; ++l) s += X[tid * LP + l];
             f1[tid] = s / (float)L;            // (group 0's f1 / f2 double as scratch here)
         }
@@ -236,12 +237,14 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
         for (int e = tid; e < N * N; e += NT) {
             const int i = e / N, j = e % N;
             float c = 0.f;
+#pragma unroll 8
             for (int l = 0; l < L; ++l) c = fmaf(X[i * LP + l] - groups[N * hp + N * N + i], X[j * LP + l] - groups[N * hp + N * N + j], c);
             adj[e] = c / (float)(L - 1) > g.thr ? 1.f : 0.f;
         }
         __syncthreads();
         if (tid < N) {
             float d = 1.f;
+#pragma unroll 8
             for (int j = 0; j < N; ++j) d += adj[tid * N + j];
             f2[tid] = 1.0f / sqrtf(d);
         }
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
             for (int e = tid; e < N * K; e += NT) {                   // AX = A_hat in
                 const int i = e / K, k = e % K;
                 float a = 0.f;
+#pragma unroll 8
                 for (int j = 0; j < N; ++j) a = fmaf(ah[i * N + j], in[j * inld + k], a);
                 AX[e] = a;
                 ws[(layer == 0 ? g.w_ax1 : g.w_ax2) + b * N * K + e] = a;
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
             for (int e = tid; e < N * h; e += NT) {
                 const int i = e / h, o = e % h;
                 float a = prm[g.o_gcn_b[layer] + o];
+#pragma unroll 8
                 for (int k = 0; k < K; ++k) a = fmaf(AX[i * K + k], Wg[o * KP + k], a);
                 ws[(layer == 0 ? g.w_pre1 : g.w_pre2) + b * N * h + e] = a;
                 H0[e] = lrelu(a, TG_GCN_SLOPE);
@@ -289,6 +294,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
                     for (int e = gt; e < N * h; e += TB) {
                         const int i = e / h, o = e % h;
                         float a = prm[g.o_gat_b[layer][hdc] + o];
+#pragma unroll 8
                         for (int k = 0; k < h; ++k) a = fmaf(H0[i * h + k], Wb[o * hp + k], a);
                         Wh[i * hp + o] = a;
                         ws[at_wh + e] = a;
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
                 if (act && gt < 2 * N) {
                     const int i = gt % N, half = gt / N;
                     float a = 0.f;
+#pragma unroll 8
                     for (int o = 0; o < h; ++o) a = fmaf(av[half * h + o], Wh[i * hp + o], a);
                     (half ? f2 : f1)[i] = a;
                 }
@@ -305,18 +312,21 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
                     const float ab = prm[g.o_gat_ab[layer][hdc]];
                     const int i = gt;
                     float m = -INFINITY;
+#pragma unroll 8
                     for (int j = 0; j < N; ++j) {
                         const float pre = f1[i] + f2[j] + ab;
                         ws[g.w_gpre[layer] + at_nn + i * N + j] = pre;
                         m = fmaxf(m, lrelu(pre, TG_GAT_SLOPE));
                     }
                     float s = 0.f;
+#pragma unroll 8
                     for (int j = 0; j < N; ++j) {
                         const float ev = expf(lrelu(f1[i] + f2[j] + ab, TG_GAT_SLOPE) - m);
                         att[i * N + j] = ev;
                         s += ev;
                     }
                     const float inv = 1.0f / s;
+#pragma unroll 8
                     for (int j = 0; j < N; ++j) {
                         const float a = att[i * N + j] * inv;
                         att[i * N + j] = a;
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(1024) void tg_graph_fwd_kernel(TgGeom g, int G, con
                     for (int e = gt; e < N * h; e += TB) {             // the head's output over its (no longer needed) weights
                         const int i = e / h, o = e % h;
                         float a = 0.f;
+#pragma unroll 8
                         for (int j = 0; j < N; ++j) a = fmaf(att[i * N + j] * adj[i * N + j], Wh[j * hp + o], a);
                         Wb[e] = a * ih;
                     }
@@ -364,6 +375,7 @@ __global__ __launch_bounds__(TB) void tg_conv1_fwd_kernel(TgGeom g, int l, const
         for (int e = tid; e < Co * T; e += TB) {
             const int c = e / T, t = e % T;
             float a = 0.f;
+#pragma unroll 8
             for (int ci = 0; ci < Ci; ++ci) {
                 a = fmaf(W[(c * Ci + ci) * 2 + 1], xin[ci * TP + t], a);
                 if (t >= 1) a = fmaf(W[(c * Ci + ci) * 2], xin[ci * TP + t - 1], a);
@@ -373,6 +385,7 @@ __global__ __launch_bounds__(TB) void tg_conv1_fwd_kernel(TgGeom g, int l, const
         }
         __syncthreads();
         if (tid < Co)
+#pragma unroll 8
             for (int t = 0; t < T; ++t) { const double v = z[tid * TP + t]; s += v; q += v * v; }
     }
     if (tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
             const int c = e / T, t = e % T;
             const float y1 = fmaf((ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
             float r = prm[g.o_ds_b[l] + c];
+#pragma unroll 8
             for (int ci = 0; ci < Ci; ++ci) r = fmaf(Wd[c * Ci + ci], xin[ci * TP + t], r);
             const float v = fmaxf(fmaxf(y1, 0.f) + r, 0.f);
             o0[c * TP + t] = v;
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
         for (int e = tid; e < Co * T; e += TB) {
             const int c = e / T, t = e % T;
             float a = 0.f;
+#pragma unroll 8
             for (int ci = 0; ci < Co; ++ci) {
                 a = fmaf(W2[(c * Co + ci) * 2 + 1], o0[ci * TP + t], a);
                 if (t >= 2) a = fmaf(W2[(c * Co + ci) * 2], o0[ci * TP + t - 2], a);
@@ -426,6 +441,7 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
         }
         __syncthreads();
         if (training && tid < Co)
+#pragma unroll 8
             for (int t = 0; t < T; ++t) { const double v = z[tid * TP + t]; s += v; q += v * v; }
     }
     if (training && tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
@@ -464,6 +480,7 @@ __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const f
         for (int e = tid; e < Hd * T; e += TB) {
             const int hd = e / T, t = e % T;
             float a = prm[g.o_enc_b[l][hd]];
+#pragma unroll 8
             for (int c = 0; c < Co; ++c) a = fmaf(ew[hd * Co + c], o1[c * TP + t], a);
             const float sg = 1.0f / (1.0f + expf(-a));
             u[e] = sg;
@@ -472,10 +489,13 @@ __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const f
         __syncthreads();
         if (tid < Hd) {
             float mx = -INFINITY;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) mx = fmaxf(mx, u[tid * T + t]);
             float sum = 0.f;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) sum += expf(u[tid * T + t] - mx);
             const float inv = 1.0f / sum;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) {
                 const float w = expf(u[tid * T + t] - mx) * inv;
                 u[tid * T + t] = w;
@@ -579,12 +599,14 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         __syncthreads();
         for (int t = tid; t < T; t += TB) {
             float a = 0.f;
+#pragma unroll 8
             for (int c = 0; c < Co; ++c) a = fmaf(de[c * TP + t], o1[c * TP + t], a);
             dm[t] = a / (float)Hd;                               // d w_i[t], the same for every head
         }
         __syncthreads();
         if (tid < Hd) {
             float a = 0.f;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) a = fmaf(dm[t], wv[tid * T + t], a);
             dot[tid] = a;
         }
@@ -599,11 +621,13 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         for (int e = tid; e < Hd * Co; e += TB) {
             const int hd = e / Co, c = e % Co;
             float a = 0.f;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) a = fmaf(du[hd * T + t], o1[c * TP + t], a);
             gp[g.o_enc_w[l][hd] + c] += a;
         }
         if (tid < Hd) {
             float a = 0.f;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) a += du[tid * T + t];
             gp[g.o_enc_b[l][tid]] += a;
         }
@@ -627,6 +651,7 @@ __global__ __launch_bounds__(TB) void tg_end_bwd_kernel(TgGeom g, int l, const f
         }
         __syncthreads();
         if (tid < Co)
+#pragma unroll 8
             for (int t = 0; t < T; ++t) { s1 += (double)de[tid * TP + t]; s2 += (double)o1[tid * TP + t]; }
     }
     if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
@@ -693,6 +718,7 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
                 const int k = e & 1, ci = (e >> 1) % Co, c = (e >> 1) / Co;
                 const int sh = k ? 0 : 2;
                 float a = 0.f;
+#pragma unroll 8
                 for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], o0[ci * TP + t - sh], a);
                 gw2[q] += a;
             }
@@ -701,6 +727,7 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
         for (int e = tid; e < Co * T; e += TB) {
             const int ci = e / T, t = e % T;
             float a = ws[g.w_dres[l] + b * Co * T + e];
+#pragma unroll 8
             for (int c = 0; c < Co; ++c) {
                 a = fmaf(W2[(c * Co + ci) * 2 + 1], dz[c * TP + t], a);
                 if (t + 2 < T) a = fmaf(W2[(c * Co + ci) * 2], dz[c * TP + t + 2], a);
@@ -714,18 +741,21 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
             if (e < Co * Ci) {
                 const int c = e / Ci, ci = e % Ci;
                 float a = 0.f;
+#pragma unroll 8
                 for (int t = 0; t < T; ++t) a = fmaf(d[c * TP + t], xin[ci * TP + t], a);
                 gwd[q] += a;
             }
         }
         if (tid < Co) {
             float a = 0.f;
+#pragma unroll 8
             for (int t = 0; t < T; ++t) a += d[tid * TP + t];
             gp[g.o_ds_b[l] + tid] += a;
         }
         for (int e = tid; e < Ci * T; e += TB) {
             const int ci = e / T, t = e % T;
             float a = 0.f;
+#pragma unroll 8
             for (int c = 0; c < Co; ++c) a = fmaf(Wd[c * Ci + ci], d[c * TP + t], a);
             ws[g.w_dxin[l] + b * Ci * T + e] = a;
         }
@@ -741,6 +771,7 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
         }
         __syncthreads();
         if (tid < Co)
+#pragma unroll 8
             for (int t = 0; t < T; ++t) { s1 += (double)dz[tid * TP + t]; s2 += (double)o0[tid * TP + t]; }
     }
     if (tid < Co) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
@@ -797,6 +828,7 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
                 const int k = e & 1, ci = (e >> 1) % Ci, c = (e >> 1) / Ci;
                 const int sh = k ? 0 : 1;
                 float a = 0.f;
+#pragma unroll 8
                 for (int t = sh; t < T; ++t) a = fmaf(dz[c * TP + t], xin[ci * TP + t - sh], a);
                 gw1[q] += a;
             }
@@ -804,6 +836,7 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
         for (int e = tid; e < Ci * T; e += TB) {
             const int ci = e / T, t = e % T;
             float a = ws[g.w_dxin[l] + b * Ci * T + e];
+#pragma unroll 8
             for (int c = 0; c < Co; ++c) {
                 a = fmaf(W1[(c * Ci + ci) * 2 + 1], dz[c * TP + t], a);
                 if (t + 1 < T) a = fmaf(W1[(c * Ci + ci) * 2], dz[c * TP + t + 1], a);
@@ -869,6 +902,7 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                     for (int e = gt; e < N * N; e += TB) {
                         const int i = e / N, j = e % N;
                         float a = 0.f;
+#pragma unroll 8
                         for (int o = 0; o < h; ++o) a = fmaf(dhp[i * h + o], Wh[j * hp + o], a);
                         dpre[e] = a * adj[e];
                     }
@@ -876,8 +910,10 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                 if (act && gt < N) {                                // softmax backward, one thread per row
                     const int i = gt;
                     float dot = 0.f;
+#pragma unroll 8
                     for (int j = 0; j < N; ++j) dot = fmaf(dpre[i * N + j], att[i * N + j], dot);
                     float r = 0.f;
+#pragma unroll 8
                     for (int j = 0; j < N; ++j) {
                         const float de = att[i * N + j] * (dpre[i * N + j] - dot);
                         const float v = ws[g.w_gpre[layer] + at_nn + i * N + j] > 0.f ? de : TG_GAT_SLOPE * de;
@@ -889,6 +925,7 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                 __syncthreads();
                 if (act && gt < N) {
                     float cs = 0.f;
+#pragma unroll 8
                     for (int i = 0; i < N; ++i) cs += dpre[i * N + gt];
                     f2[gt] = cs;                                    // d f2[j] = column sum
                 }
@@ -896,6 +933,7 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                 if (act) {
                     if (gt == 0) {
                         float a = 0.f;
+#pragma unroll 8
                         for (int i = 0; i < N; ++i) a += f1[i];
                         gp[g.o_gat_ab[layer][hdc]] += a;
                     }
@@ -903,12 +941,14 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                         const int half = gt / h, o = gt % h;
                         const float* df = half ? f2 : f1;
                         float a = 0.f;
+#pragma unroll 8
                         for (int i = 0; i < N; ++i) a = fmaf(df[i], Wh[i * hp + o], a);
                         gp[g.o_gat_a[layer][hdc] + gt] += a;
                     }
                     for (int e = gt; e < N * h; e += TB) {
                         const int j = e / h, o = e % h;
                         float a = fmaf(f1[j], av[o], f2[j] * av[h + o]);
+#pragma unroll 8
                         for (int i = 0; i < N; ++i) a = fmaf(att[i * N + j] * adj[i * N + j], dhp[i * h + o], a);
                         dWh[e] = a;
                     }
@@ -918,17 +958,20 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                     for (int e = gt; e < h * h; e += TB) {
                         const int o = e / h, k = e % h;
                         float a = 0.f;
+#pragma unroll 8
                         for (int i = 0; i < N; ++i) a = fmaf(dWh[i * h + o], H[i * h + k], a);
                         gp[g.o_gat_w[layer][hdc] + e] += a;
                     }
                     if (gt < h) {
                         float a = 0.f;
+#pragma unroll 8
                         for (int i = 0; i < N; ++i) a += dWh[i * h + gt];
                         gp[g.o_gat_b[layer][hdc] + gt] += a;
                     }
                     for (int e = gt; e < N * h; e += TB) {             // this head's share of dN, over its Wh (no longer needed)
                         const int i = e / h, k = e % h;
                         float a = 0.f;
+#pragma unroll 8
                         for (int o = 0; o < h; ++o) a = fmaf(dWh[i * h + o], Wb[o * hp + k], a);
                         Wh[e] = a;
                     }
@@ -951,11 +994,13 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
             for (int e = tid; e < h * K; e += NT) {
                 const int o = e / K, k = e % K;
                 float a = 0.f;
+#pragma unroll 8
                 for (int i = 0; i < N; ++i) a = fmaf(dN[i * h + o], AX[i * K + k], a);
                 gp[g.o_gcn_w[layer] + e] += a;
             }
             if (tid < h) {
                 float a = 0.f;
+#pragma unroll 8
                 for (int i = 0; i < N; ++i) a += dN[i * h + tid];
                 gp[g.o_gcn_b[layer] + tid] += a;
             }
@@ -965,6 +1010,7 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                 for (int e = tid; e < N * h; e += NT) {
                     const int i = e / h, k = e % h;
                     float a = 0.f;
+#pragma unroll 8
                     for (int o = 0; o < h; ++o) a = fmaf(dN[i * h + o], Wg[o * hp + k], a);
                     AX[e] = a;
                 }
@@ -972,6 +1018,7 @@ __global__ __launch_bounds__(1024) void tg_graph_bwd_kernel(TgGeom g, int G, con
                 for (int e = tid; e < N * h; e += NT) {
                     const int j = e / h, k = e % h;
                     float a = 0.f;
+#pragma unroll 8
                     for (int i = 0; i < N; ++i) a = fmaf(ah[i * N + j], AX[i * h + k], a);
                     dH[e] = a;
                 }
