@@ -493,7 +493,7 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         AST_RC(rows_sum(F(w.gp2), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w2, st));
         hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr);
         if (mse && a->loss)
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)F(w.sqerr), (int64_t)g.B, a->loss);
+            (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -1109,7 +1109,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
                            (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr);
         if (!a->dpred && a->loss)
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)P_(w.sqerr), (int64_t)g.B, a->loss);
+            (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -556,7 +556,7 @@ int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a
         HG_RC(wgrad(ws + g.d_zp0[l], Hh, ws + g.t_g[l], Hd, gr + g.o_pw0[l], gr + g.o_pb0[l]));
         HG_RC(wgrad(ws + g.d_zp1[l], 1, ws + g.t_pm[l], Hh, gr + g.o_pw2[l], gr + g.o_pb2[l]));
         HG_RC(wgrad(ws + g.d_zr[l], 1, ws + g.t_axs[l], Hd, gr + g.o_rw[l], gr + g.o_rb[l]));
-        hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.d_eps[l]), g.G, gr + g.o_eps[l]);
+        (void)block_sum((const float*)(ws + g.d_eps[l]), g.G, gr + g.o_eps[l], st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

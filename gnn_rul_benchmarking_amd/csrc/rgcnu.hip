@@ -590,7 +590,7 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
                                                    (int)lds) != hipSuccess)
             return RULGNN_EHIP;
         hipLaunchKernelGGL(rg_fusion_kernel, dim3(blocks), dim3(RB), lds, st, g, a->x, a->y, prm, ws, a->pred, a->std_pred, inv_gb);
-        if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
+        if (a->y && a->loss) (void)block_sum((const float*)(ws + g.w_sq), g.B, a->loss, st);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
     if (mode & 2) {

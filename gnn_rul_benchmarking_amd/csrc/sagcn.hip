@@ -557,7 +557,7 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
             hipLaunchKernelGGL(sg_head_finish_kernel, dim3(sg_grid(g.B)), dim3(GB), 0, st, g, (const float*)(ws + g.w_headpart), prm, a->y, a->pred, ws,
                                inv_gb);
         }
-        if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
+        if (a->y && a->loss) (void)block_sum((const float*)(ws + g.w_sq), g.B, a->loss, st);
         SG_LAUNCH_OK();
     }
     if (mode & 2) {

@@ -1,4 +1,4 @@
-// SGEMM on the gfx950 matrix cores, shared by the tiled ST_GCN path and the ASTGCNN path.
+// Interface of the shared matrix-core SGEMM (csrc/sgemm.hip) and the small deterministic reductions next to it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -9,856 +9,26 @@ namespace rulgnn {
 
 typedef float f32x4t __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------------
-// SGEMM on the matrix cores: C[m][n] (+)= sum_k A(m,k) * B(n,k), generic strides, fp32 MFMA 16x16x4.
-// 64x64 block tile, K step 16, 4 wavefronts each owning a 32x32 quadrant (2x2 MFMA tiles).
-// ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* A; int64_t sAm, sAk;
-    const float* B; int64_t sBn, sBk;
-    float* C; int64_t ldc;
-    int M, N, K;
-    int accumulate;      // C += instead of C =
-    int kchunk;          // split-K: blockIdx.z owns k in [z*kchunk, (z+1)*kchunk) and writes slice z of C (stride M*ldc)
-};
-
-static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
-    __shared__ float As[16][64 + 4];      // [k][m]
-    __shared__ float Bs[16][64 + 4];      // [k][n]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x4t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
-    const int li = lane & 15, kq = lane >> 4;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    // Cooperative tile load: 64 x 16 elements of A and of B (4 + 4 per thread).  The lane -> element mapping follows the
-    // operand's contiguous dimension (k-fastest when the k stride is 1, else m-fastest) so that wavefront loads coalesce, and
-    // the next k-step's elements are fetched into registers while the matrix cores work on the current one.
-    const bool a_kfast = g.sAk == 1, b_kfast = g.sBk == 1;
-    int am[4], ak[4], bm[4], bk[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = tid + e * 256;
-        am[e] = a_kfast ? idx >> 4 : idx & 63;
-        ak[e] = a_kfast ? idx & 15 : idx >> 6;
-        bm[e] = b_kfast ? idx >> 4 : idx & 63;
-        bk[e] = b_kfast ? idx & 15 : idx >> 6;
-    }
-    float ra[4], rb[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int gm = m0 + am[e], gka = k0 + ak[e], gn = n0 + bm[e], gkb = k0 + bk[e];
-            ra[e] = (gm < g.M && gka < kend) ? g.A[gm * g.sAm + gka * g.sAk] : 0.f;
-            rb[e] = (gn < g.N && gkb < kend) ? g.B[gn * g.sBn + gkb * g.sBk] : 0.f;
-        }
-    };
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            As[ak[e]][am[e]] = ra[e];
-            Bs[bk[e]][bm[e]] = rb[e];
-        }
-        __syncthreads();
-        if (k0 + 16 < kend) fetch(k0 + 16);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[4 * ks + kq][wm + 16 * i + li];
-                b[i] = Bs[4 * ks + kq][wn + 16 * i + li];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // D layout: lane (g4 = lane>>4, col = lane&15), reg r -> row 4*g4 + r
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wm + 16 * i + 4 * kq + r, gn = n0 + wn + 16 * j + li;
-                if (gm < g.M && gn < g.N) {
-                    float* c = g.C + (int64_t)gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Large outputs (the hidden-1000 layers of SAGCN, the Chebyshev layers of STNet, the tiled ST_GCN path): 128x128 block tile, K step
-// 16, 4 wavefronts each owning a 64x64 quadrant (4x4 MFMA tiles, 64 accumulator registers).  The 64x64 kernel above moves 8 KB
-// through LDS per 131 kFLOP -- 16 FLOP per byte, i.e. the fp32 matrix peak would need ~10 TB/s out of L2 --; this one 32 FLOP per byte,
-// with 16-byte global loads along whichever dimension of the operand is contiguous (template flags), the next K step's loads in
-// flight under the 64 MFMAs of the current one, double-buffered LDS (one barrier per K step) and an LDS row stride of 128 + 16 floats
-// (the four k-rows a wavefront's operand read touches land in disjoint bank halves).  Same k order per accumulator as the 64x64
-// kernel.  Requirements (checked by sgemm_big_ok): each operand contiguous along k or along its row index, 16-byte aligned base,
-// the other stride a multiple of 4.
-// ------------------------------------------------------------------------------------------------
-template <bool A_KFAST, bool B_KFAST, int KT>
-static __global__ __launch_bounds__(256, 2) void sgemm_mfma128_kernel(GemmArgs g) {
-    constexpr int LD = 128 + 16;
-    extern __shared__ __attribute__((aligned(16))) float sgemm_big_lds[];
-    float (*As)[KT][LD] = reinterpret_cast<float (*)[KT][LD]>(sgemm_big_lds);                    // [buffer][k][m]
-    float (*Bs)[KT][LD] = reinterpret_cast<float (*)[KT][LD]>(sgemm_big_lds + 2 * KT * LD);      // [buffer][k][n]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x4t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
-    const int li = lane & 15, kq = lane >> 4;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    constexpr int NF = KT / 8;          // float4 per thread and operand: 128 x KT floats over 256 threads
-    f32x4t ra[NF], rb[NF];
-    // one operand tile = 128 x 16 floats = 512 float4, two per thread: along k (row = idx >> 2, k = 4 (idx & 3)) when k is the
-    // contiguous dimension, else along the row index (k = idx >> 5, row = 4 (idx & 31))
-    auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int idx, bool kfast) -> f32x4t {
-        f32x4t v = {0.f, 0.f, 0.f, 0.f};
-        if (kfast) {
-            const int r = r0 + idx / (KT / 4), k = k0 + 4 * (idx % (KT / 4));
-            if (r < rows) {
-                const float* p = P + (int64_t)r * s_row + k;
-                if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
-                else {
-                    if (k < kend) v[0] = p[0];
-                    if (k + 1 < kend) v[1] = p[1];
-                    if (k + 2 < kend) v[2] = p[2];
-                }
-            }
-        } else {
-            const int k = k0 + (idx >> 5), r = r0 + 4 * (idx & 31);
-            if (k < kend) {
-                const float* p = P + (int64_t)k * s_k + r;
-                if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
-                else {
-                    if (r < rows) v[0] = p[0];
-                    if (r + 1 < rows) v[1] = p[1];
-                    if (r + 2 < rows) v[2] = p[2];
-                }
-            }
-        }
-        return v;
-    };
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < NF; ++e) {
-            ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, tid + e * 256, A_KFAST);
-            rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, tid + e * 256, B_KFAST);
-        }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int e = 0; e < NF; ++e) {
-            const int idx = tid + e * 256;
-            if (A_KFAST) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) As[buf][4 * (idx % (KT / 4)) + j][idx / (KT / 4)] = ra[e][j];
-            } else {
-                *reinterpret_cast<f32x4t*>(&As[buf][idx >> 5][4 * (idx & 31)]) = ra[e];
-            }
-            if (B_KFAST) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Bs[buf][4 * (idx % (KT / 4)) + j][idx / (KT / 4)] = rb[e][j];
-            } else {
-                *reinterpret_cast<f32x4t*>(&Bs[buf][idx >> 5][4 * (idx & 31)]) = rb[e];
-            }
-        }
-    };
-    int buf = 0;
-    if (kbeg < kend) {
-        fetch(kbeg);
-        stash(0);
-    }
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += KT) {
-        const bool more = k0 + KT < kend;
-        if (more) fetch(k0 + KT);
-#pragma unroll
-        for (int ks = 0; ks < KT / 4; ++ks) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = As[buf][4 * ks + kq][wm + 16 * i + li];
-                b[i] = Bs[buf][4 * ks + kq][wn + 16 * i + li];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) stash(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int gm = m0 + wm + 16 * i + 4 * kq + r, gn = n0 + wn + 16 * j + li;
-                if (gm < g.M && gn < g.N) {
-                    float* c = g.C + (int64_t)gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-}
-
-typedef __bf16 gemm_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned gemm_u32x4 __attribute__((ext_vector_type(4)));
-// ------------------------------------------------------------------------------------------------
-// The same 128x128 tile on the bf16 matrix cores with fp32-class accuracy ("bf16 x 3").  Every fp32 operand is split EXACTLY into
-// three bf16 parts, x = h + m + l (h = the top 8 significant bits, m = the top 8 of x - h, l = x - h - m: 24 bits in all; the
-// subtractions are exact in fp32), when its tile is written to LDS -- once per element, amortised over the 128 products it takes part
-// in.  a b = ah bh + ah bm + am bh + ah bl + am bm + al bh + (terms below 2^-23 |a b|): six v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation, each bf16 x bf16 product exact.  The error per product is that of ONE fp32 rounding; the rate is a sixth of the bf16
-// matrix peak = 2.6x the fp32 matrix peak (v_mfma_f32_16x16x4_f32 runs at the VALU FMA rate).  bf16 keeps fp32's exponent range, so no
-// scaling is needed (an f16 split would need two parts and three products but underflows on gradient-sized values).
-// LDS: per buffer three bf16 planes per operand, rows of 16 k = 32 bytes padded to 48 (eight consecutive rows x 16-byte reads cover
-// the 32 banks exactly once); a lane's MFMA operand is one ds_read_b128.
-// ------------------------------------------------------------------------------------------------
-typedef float f32x16t __attribute__((ext_vector_type(16)));
-
-// one fp32 pair -> one dword (first value in the low half) of each of the three planes
-static __device__ __forceinline__ void split_pair_bf16x3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    const unsigned ha = __builtin_bit_cast(unsigned, a) & 0xFFFF0000u, hb = __builtin_bit_cast(unsigned, b) & 0xFFFF0000u;
-    const float ra = a - __builtin_bit_cast(float, ha), rb = b - __builtin_bit_cast(float, hb);
-    const unsigned ma = __builtin_bit_cast(unsigned, ra) & 0xFFFF0000u, mb = __builtin_bit_cast(unsigned, rb) & 0xFFFF0000u;
-    const float la = ra - __builtin_bit_cast(float, ma), lb = rb - __builtin_bit_cast(float, mb);
-    h = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
-    m = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
-    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, lb), __builtin_bit_cast(unsigned, la), 0x07060302u);
-}
-
-// LDS layouts of one operand plane (6 KB reserved each):
-//   operand contiguous along k   : [row][16 k] bf16, rows padded to 48 bytes; a thread's float4 (4 k of one row) is one 8-byte store,
-//                                  a lane's MFMA operand (8 k of its row) one 16-byte read;
-//   operand contiguous along rows: [k pair][128 rows] dwords (k even in the low half); a thread holds 4 rows x 2 k (two float4, k and
-//                                  k + 1) = one 16-byte store, a lane's MFMA operand four 4-byte reads, consecutive lanes consecutive
-//                                  dwords.  (Two-byte stores into the row-major form were 16-way bank conflicts: 56 TFLOP/s.)
-template <bool A_KFAST, bool B_KFAST, bool GUARD>
-static __device__ __forceinline__ void sgemm_bf16x3_body(GemmArgs g) {
-    constexpr int ROWB = 48;                       // bytes per LDS row of the k-contiguous form
-    constexpr int PLANE = 128 * ROWB;              // one bf16 plane of one operand tile
-    constexpr int BUF = 6 * PLANE;                 // A: h, m, l ; B: h, m, l
-    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    f32x4t ra[2], rb[2];
-    // k-contiguous: float4 e of a thread = row (tid + 256 e) >> 2, k = 4 ((tid + 256 e) & 3)
-    // row-contiguous: float4 e of a thread = rows 4 (tid & 31) .. + 3 at k = 2 (tid >> 5) + e
-    auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int e, bool kfast) -> f32x4t {
-        f32x4t v = {0.f, 0.f, 0.f, 0.f};
-        if (!GUARD && k0 + 16 <= kend) {          // interior tile, whole K step (wave-uniform): every 16-byte load is in bounds
-            if (kfast) {
-                const int idx = tid + e * 256;
-                return *reinterpret_cast<const f32x4t*>(P + (int64_t)(r0 + (idx >> 2)) * s_row + k0 + 4 * (idx & 3));
-            }
-            return *reinterpret_cast<const f32x4t*>(P + (int64_t)(k0 + 2 * (tid >> 5) + e) * s_k + r0 + 4 * (tid & 31));
-        }
-        if (kfast) {
-            const int idx = tid + e * 256;
-            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
-            if (r < rows) {
-                const float* p = P + (int64_t)r * s_row + k;
-                if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
-                else {
-                    if (k < kend) v[0] = p[0];
-                    if (k + 1 < kend) v[1] = p[1];
-                    if (k + 2 < kend) v[2] = p[2];
-                }
-            }
-        } else {
-            const int k = k0 + 2 * (tid >> 5) + e, r = r0 + 4 * (tid & 31);
-            if (k < kend) {
-                const float* p = P + (int64_t)k * s_k + r;
-                if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
-                else {
-                    if (r < rows) v[0] = p[0];
-                    if (r + 1 < rows) v[1] = p[1];
-                    if (r + 2 < rows) v[2] = p[2];
-                }
-            }
-        }
-        return v;
-    };
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, e, A_KFAST);
-            rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, e, B_KFAST);
-        }
-    };
-    auto stash_one = [&](unsigned char* base, const f32x4t (&v)[2], bool kfast) {
-        if (kfast) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int idx = tid + e * 256;
-                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split_pair_bf16x3(x0, x1, h0, m0_, l0);
-                split_pair_bf16x3(x2, x3, h1, m1, l1);
-                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
-                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0_, m1);
-                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
-            }
-        } else {
-            unsigned h[4], m[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x0 = v[0][j], x1 = v[1][j];
-                split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
-            }
-            unsigned char* p = base + ((tid >> 5) * 128 + 4 * (tid & 31)) * 4;
-            *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
-            *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
-        }
-    };
-    auto stash = [&](int buf) {
-        unsigned char* b = sgemm_x3_lds + buf * BUF;
-        stash_one(b, ra, A_KFAST);
-        stash_one(b + 3 * PLANE, rb, B_KFAST);
-    };
-    // the MFMA operand of this lane: 8 consecutive k (k half lane >> 5) of row `row0 + (lane & 31)` of one plane
-    auto operand = [&](const unsigned char* plane, int row0, bool kfast) -> gemm_bf16x8 {
-        if (kfast) return *reinterpret_cast<const gemm_bf16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
-        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * 128 + row0 + (lane & 31);
-        const gemm_u32x4 v = {q[0], q[128], q[256], q[384]};
-        return __builtin_bit_cast(gemm_bf16x8, v);
-    };
-    // Software pipeline, two K steps deep: while the matrix cores work on tile k (LDS buffer `buf`), the registers loaded during the
-    // PREVIOUS iteration (tile k + 1: a full iteration of latency cover) are split and written to the other buffer, and the loads of
-    // tile k + 2 are issued.  The split's VALU work is interleaved with the MFMAs by the scheduling hints at the end of the body: an
-    // in-order wavefront hides ~5 other instructions behind each 32-cycle MFMA, or none at all if they sit behind the whole chain.
-    int buf = 0;
-    if (kbeg < kend) {
-        fetch(kbeg);
-        stash(0);
-        fetch(kbeg + 16);                     // tile 1 (past the end the guarded loads return zeros)
-    }
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const bool more = k0 + 16 < kend;
-        f32x4t na[2], nb[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { na[e] = ra[e]; nb[e] = rb[e]; }          // tile k + 1, loaded one iteration ago
-        if (k0 + 32 < kend) fetch(k0 + 32);                                      // tile k + 2 into ra / rb
-        const unsigned char* b = sgemm_x3_lds + buf * BUF;
-        gemm_bf16x8 a[2][3], bb[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
-                bb[i][p] = operand(b + (3 + p) * PLANE, wn + 32 * i, B_KFAST);
-            }
-        // the six product terms, smallest first; consecutive MFMAs go to different accumulators (independent: back-to-back issue)
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], bb[j][PB[t]], acc[i][j], 0, 0, 0);
-        if (more) {
-            unsigned char* nbuf = sgemm_x3_lds + (buf ^ 1) * BUF;
-            stash_one(nbuf, na, A_KFAST);
-            stash_one(nbuf + 3 * PLANE, nb, B_KFAST);
-        }
-#pragma unroll
-        for (int q = 0; q < 24; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // five VALU (the split)
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one LDS write
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-    // D layout of the 32x32 result: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
-                if (!GUARD || (gm < g.M && gn < g.N)) {
-                    float* c = g.C + (int64_t)gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-}
-
-template <bool A_KFAST, bool B_KFAST>
-static __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(GemmArgs g) {
-    // interior tiles take the body whose whole K steps load without bounds checks (a third of its non-MFMA instructions were guards)
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    const bool interior = (int)blockIdx.y * 128 + 128 <= g.M && (int)blockIdx.x * 128 + 128 <= g.N && kend > kbeg;
-    if (interior) sgemm_bf16x3_body<A_KFAST, B_KFAST, false>(g);
-    else sgemm_bf16x3_body<A_KFAST, B_KFAST, true>(g);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same arithmetic on a 256x256 block tile.  SQ counters of the 128x128 kernel: per K step a wavefront issues 154 VALU + 37
-// scalar + 20 LDS instructions for its 24 MFMAs -- 1044 issue cycles against 768 MFMA cycles, two wavefronts per SIMD: the split is
-// re-done by every tile that loads an element.  Doubling both tile dimensions halves the elements loaded (and split) per MFMA; a
-// thread serves ONE operand (wavefronts 0-3: A, 4-7: B).  First built with 16 wavefronts of 64 x 64 (193 TFLOP/s at 4096^3): that
-// form is bound by LDS READ bandwidth -- 12 KB of operand planes per 24 MFMAs = 512 B per MFMA, 64 B/clk per CU of the LDS's 128 B/clk
-// before bank conflicts (a variant that split every operand once, in a pre-pass, ran no faster).  This one has 8 wavefronts of
-// 64 x 128 (128 accumulator registers): 18 KB per 48 MFMAs = 384 B per MFMA, 203 TFLOP/s.
-// ------------------------------------------------------------------------------------------------
-template <bool A_KFAST, bool B_KFAST, bool GUARD>
-static __device__ __forceinline__ void sgemm_bf16x3v_body(GemmArgs g) {
-    constexpr int T = 256;                         // tile rows / columns
-    constexpr int ROWB = 48;
-    constexpr int PLANE = T * ROWB;                // 12 KB
-    constexpr int BUF = 6 * PLANE;                 // 72 KB
-    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;          // 8 wavefronts, each 64 rows x 128 columns
-    f32x16t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
-    // this thread's operand
-    const bool mine_b = tid >= 256;
-    const int t = tid & 255;
-    const float* __restrict__ P = mine_b ? g.B : g.A;
-    const int64_t s_row = mine_b ? g.sBn : g.sAm, s_k = mine_b ? g.sBk : g.sAk;
-    const int rows = mine_b ? g.N : g.M, r0 = mine_b ? n0 : m0;
-    const bool kfast = mine_b ? B_KFAST : A_KFAST;                  // wave-uniform
-    f32x4t rr[4];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f32x4t v = {0.f, 0.f, 0.f, 0.f};
-            if (kfast) {
-                const int idx = t + e * 256;
-                const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
-                const float* p = P + (int64_t)r * s_row + k;
-                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
-                else if (r < rows) {
-                    if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
-                    else {
-                        if (k < kend) v[0] = p[0];
-                        if (k + 1 < kend) v[1] = p[1];
-                        if (k + 2 < kend) v[2] = p[2];
-                    }
-                }
-            } else {
-                const int k = k0 + 4 * (t >> 6) + e, r = r0 + 4 * (t & 63);
-                const float* p = P + (int64_t)k * s_k + r;
-                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
-                else if (k < kend) {
-                    if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
-                    else {
-                        if (r < rows) v[0] = p[0];
-                        if (r + 1 < rows) v[1] = p[1];
-                        if (r + 2 < rows) v[2] = p[2];
-                    }
-                }
-            }
-            rr[e] = v;
-        }
-    };
-    auto stash = [&](unsigned char* bufp, const f32x4t (&v)[4]) {
-        unsigned char* base = bufp + (mine_b ? 3 * PLANE : 0);
-        if (kfast) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int idx = t + e * 256;
-                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split_pair_bf16x3(x0, x1, h0, m0_, l0);
-                split_pair_bf16x3(x2, x3, h1, m1, l1);
-                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
-                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0_, m1);
-                *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
-            }
-        } else {
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {                       // two k pairs per thread: (4 kq, 4 kq + 1) and (4 kq + 2, 4 kq + 3)
-                unsigned h[4], m[4], l[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = v[2 * pp][j], x1 = v[2 * pp + 1][j];
-                    split_pair_bf16x3(x0, x1, h[j], m[j], l[j]);
-                }
-                unsigned char* p = base + ((2 * (t >> 6) + pp) * T + 4 * (t & 63)) * 4;
-                *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
-                *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
-                *reinterpret_cast<uint4*>(p + 2 * PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
-            }
-        }
-    };
-    auto operand = [&](const unsigned char* plane, int row0, bool kf) -> gemm_bf16x8 {
-        if (kf) return *reinterpret_cast<const gemm_bf16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
-        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * T + row0 + (lane & 31);
-        const gemm_u32x4 v = {q[0], q[T], q[2 * T], q[3 * T]};
-        return __builtin_bit_cast(gemm_bf16x8, v);
-    };
-    int buf = 0;
-    if (kbeg < kend) {
-        fetch(kbeg);
-        stash(sgemm_x3_lds, rr);
-        fetch(kbeg + 16);
-    }
-    __syncthreads();
-    for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        const bool more = k0 + 16 < kend;
-        f32x4t nn[4] = {rr[0], rr[1], rr[2], rr[3]};                                         // tile k + 1, loaded one iteration ago
-        if (k0 + 32 < kend) fetch(k0 + 32);
-        const unsigned char* b = sgemm_x3_lds + buf * BUF;
-        gemm_bf16x8 a[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            gemm_bf16x8 bb[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bb[p] = operand(b + (3 + p) * PLANE, wn + 32 * j, B_KFAST);
-#pragma unroll
-            for (int tt = 0; tt < 6; ++tt)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[tt]], bb[PB[tt]], acc[i][j], 0, 0, 0);
-        }
-        if (more) stash(sgemm_x3_lds + (buf ^ 1) * BUF, nn);
-#pragma unroll
-        for (int q = 0; q < 48; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
-                if (!GUARD || (gm < g.M && gn < g.N)) {
-                    float* c = g.C + (int64_t)gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
-                }
-            }
-}
-
-template <bool A_KFAST, bool B_KFAST>
-static __global__ __launch_bounds__(512) void sgemm_bf16x3v_kernel(GemmArgs g) {
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    const bool interior = (int)blockIdx.y * 256 + 256 <= g.M && (int)blockIdx.x * 256 + 256 <= g.N && kend > kbeg;
-    if (interior) sgemm_bf16x3v_body<A_KFAST, B_KFAST, false>(g);
-    else sgemm_bf16x3v_body<A_KFAST, B_KFAST, true>(g);
-}
-
-// 256x256 tiles when both output dimensions fill them and there are enough of them for one per CU
-static inline bool sgemm_wide_ok(const GemmArgs& g, int slices) {
-    if (g.M <= 192 || g.N <= 192) return false;
-    return (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256) * slices >= 160;
-}
-
-// process-wide arithmetic of the big-tile GEMM: 1 = bf16 x 3 (default), 0 = fp32 matrix instructions (bit-compatible with the 64x64 kernel)
-// (defined once, in rulgnn_api.hip: this header is included by several translation units)
+// process-wide arithmetic of the big-tile GEMM: 1 = bf16 x 3 (default), 0 = fp32 matrix instructions (bit-compatible with the 64x64
+// kernel); defined in rulgnn_api.hip (rulgnn_sgemm_mode)
 int& sgemm_big_mode();
 
-#ifndef SGEMM_BIG_KT
-#define SGEMM_BIG_KT 16
-#endif
-// the 128x128 kernel pays when both output dimensions fill most of a tile and there are enough tiles for the chip
-static inline bool sgemm_big_ok(const GemmArgs& g, int slices) {
-    if (g.M <= 96 || g.N <= 96 || g.K < 16) return false;
-    const int64_t tiles = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * slices;
-    if (tiles < 96) return false;
-    const bool ak = g.sAk == 1, am = g.sAm == 1, bk = g.sBk == 1, bn = g.sBn == 1;
-    if (!(ak || am) || !(bk || bn)) return false;
-    if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B)) & 15) return false;
-    if ((ak ? g.sAm : g.sAk) % 4 != 0 || (bk ? g.sBn : g.sBk) % 4 != 0) return false;
-    return g.kchunk % 4 == 0;
-}
+// C[m][n] (+)= sum_k A(m,k) * B(n,k) with element strides (sAm, sAk), (sBn, sBk); picks the tile / tall-and-skinny / big-tile kernel.
+// `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies, fp32 paths otherwise.
+int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
+          int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0);
 
-// the matrix-core GEMM of a (possibly split-K) problem: the 128x128 kernel where it pays, the 64x64 one otherwise
-static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t st) {
-    if (sgemm_big_ok(g, slices)) {
-        const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, slices);
-        const bool ak = g.sAk == 1, bk = g.sBk == 1;
-        if (sgemm_big_mode() == 1) {
-            constexpr size_t lx = (size_t)2 * 6 * 128 * 48;
-            auto gox = [&](auto kernel) {
-                static bool raised = false;                          // once per instantiation and process
-                if (!raised) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx);
-                    raised = true;
-                }
-                hipLaunchKernelGGL(kernel, grid, dim3(256), lx, st, g);
-            };
-            if (sgemm_wide_ok(g, slices)) {
-                const dim3 wgrid((g.N + 255) / 256, (g.M + 255) / 256, slices);
-                constexpr size_t lw = (size_t)2 * 6 * 256 * 48;
-                auto gow = [&](auto kernel) {
-                    static bool raised = false;
-                    if (!raised) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-                        raised = true;
-                    }
-                    hipLaunchKernelGGL(kernel, wgrid, dim3(512), lw, st, g);
-                };
-                if (ak && bk) gow(sgemm_bf16x3v_kernel<true, true>);
-                else if (ak) gow(sgemm_bf16x3v_kernel<true, false>);
-                else if (bk) gow(sgemm_bf16x3v_kernel<false, true>);
-                else gow(sgemm_bf16x3v_kernel<false, false>);
-                return;
-            }
-            if (ak && bk) gox(sgemm_bf16x3_kernel<true, true>);
-            else if (ak) gox(sgemm_bf16x3_kernel<true, false>);
-            else if (bk) gox(sgemm_bf16x3_kernel<false, true>);
-            else gox(sgemm_bf16x3_kernel<false, false>);
-            return;
-        }
-        constexpr size_t lds = (size_t)4 * SGEMM_BIG_KT * (128 + 16) * sizeof(float);
-        auto go = [&](auto kernel) {
-            static bool raised = false;                              // once per instantiation and process
-            if (lds > 48 * 1024 && !raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                raised = true;
-            }
-            hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, g);
-        };
-        if (ak && bk) go(sgemm_mfma128_kernel<true, true, SGEMM_BIG_KT>);
-        else if (ak) go(sgemm_mfma128_kernel<true, false, SGEMM_BIG_KT>);
-        else if (bk) go(sgemm_mfma128_kernel<false, true, SGEMM_BIG_KT>);
-        else go(sgemm_mfma128_kernel<false, false, SGEMM_BIG_KT>);
-        return;
-    }
-    hipLaunchKernelGGL(sgemm_mfma_kernel, dim3((g.N + 63) / 64, (g.M + 63) / 64, slices), dim3(256), 0, st, g);
-}
+// The same product as a deterministic split-K reduction (weight gradients: K = all rows of the batch); `partial` is caller-provided
+// scratch of sgemm_splitk_need_floats(M, N, K) floats.
+int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
+                 int M, int N, int K, bool accumulate, float* partial, hipStream_t st);
 
-// ------------------------------------------------------------------------------------------------
-// Tall-and-skinny case: many rows, a small [K x N] weight matrix (the per-row projections of the graph models:
-// [batch*patches*nodes, 16..64] x [16..64, 8..64]).  A 64x64 MFMA tile wastes most of its columns there and the launch is
-// bandwidth-bound anyway: one thread per output row, the weights in LDS (broadcast reads), the row streamed with 16-byte
-// loads, N accumulators in registers.
-// ------------------------------------------------------------------------------------------------
-template <int NT>
-static __global__ __launch_bounds__(256) void sgemm_skinny_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float Bsk[];      // [K][NT]
-    for (int i = threadIdx.x; i < g.K * NT; i += 256) {
-        const int k = i / NT, n = i % NT;
-        Bsk[i] = n < g.N ? g.B[n * g.sBn + k * g.sBk] : 0.f;
-    }
-    __syncthreads();
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= g.M) return;
-    float acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = 0.f;
-    const float* a = g.A + m * g.sAm;
-    const bool vec = ((g.sAm & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-    int k = 0;
-    if (vec) {
-        for (; k + 4 <= g.K; k += 4) {
-            const f32x4t av = *reinterpret_cast<const f32x4t*>(a + k);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[n] = fmaf(av[q], Bsk[(k + q) * NT + n], acc[n]);
-        }
-    }
-    for (; k < g.K; ++k) {
-        const float av = a[k];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = fmaf(av, Bsk[k * NT + n], acc[n]);
-    }
-    float* c = g.C + m * g.ldc;
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-        if (n < g.N) c[n] = g.accumulate ? c[n] + acc[n] : acc[n];
-}
+// out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
+int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
+int block_sum(const float* v, int64_t n, float* out, hipStream_t st);
 
-// ------------------------------------------------------------------------------------------------
-// bf16 variant of the tall-and-skinny case (BASELINE.json config "FC_STGNN ... bf16"): C[m][n] (+)= sum_k A[m][k] * B(n,k) with both
-// operands ROUNDED TO bf16 (v_cvt_pk_bf16_f32, round to nearest even) and fp32 accumulation on v_mfma_f32_16x16x32_bf16.
-// One wavefront per 16-row tile: lane (kg = lane >> 4, m = lane & 15) reads the 8 consecutive k of its row (two 16-byte loads),
-// the weight operand (N <= 32, K <= 128: NT x KS MFMA operands) stays in registers for the whole grid-stride loop, each of the
-// 4 result registers is one 64-byte row segment.  The kernel streams: [M, K] in, [M, N] out, nothing else.
-// ------------------------------------------------------------------------------------------------
-
-static __device__ __forceinline__ unsigned gemm_pk_bf16(float a, float b) {
-    unsigned u;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b));
-    return u;
-}
-
-template <int NT, int KS>
-static __global__ __launch_bounds__(256) void sgemm_rows_bf16_kernel(GemmArgs g) {
-    const int lane = threadIdx.x & 63, kg = lane >> 4, mi = lane & 15;
-    gemm_u32x4 bop[NT][KS];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            float w[8];
-            const int n = nt * 16 + mi;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = ks * 32 + 8 * kg + i;
-                w[i] = (n < g.N && k < g.K) ? g.B[n * g.sBn + k * g.sBk] : 0.f;
-            }
-            bop[nt][ks] = gemm_u32x4{gemm_pk_bf16(w[0], w[1]), gemm_pk_bf16(w[2], w[3]), gemm_pk_bf16(w[4], w[5]), gemm_pk_bf16(w[6], w[7])};
-        }
-    const bool vec = ((g.sAm & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.K & 7) == 0);
-    const int64_t tiles = ((int64_t)g.M + 15) / 16;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t tile = wave0; tile < tiles; tile += nwaves) {
-        const int64_t row = tile * 16 + mi;
-        f32x4t acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k0 = ks * 32 + 8 * kg;
-            float a[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = 0.f;
-            if (row < g.M && k0 < g.K) {
-                const float* ap = g.A + row * g.sAm + k0;
-                if (vec) {
-                    const f32x4t v0 = *reinterpret_cast<const f32x4t*>(ap), v1 = *reinterpret_cast<const f32x4t*>(ap + 4);
-                    a[0] = v0[0]; a[1] = v0[1]; a[2] = v0[2]; a[3] = v0[3]; a[4] = v1[0]; a[5] = v1[1]; a[6] = v1[2]; a[7] = v1[3];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) a[i] = (k0 + i < g.K) ? ap[i] : 0.f;
-                }
-            }
-            const gemm_u32x4 aop = {gemm_pk_bf16(a[0], a[1]), gemm_pk_bf16(a[2], a[3]), gemm_pk_bf16(a[4], a[5]), gemm_pk_bf16(a[6], a[7])};
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gemm_bf16x8, aop), __builtin_bit_cast(gemm_bf16x8, bop[nt][ks]),
-                                                                  acc[nt], 0, 0, 0);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t gm = tile * 16 + 4 * kg + r;
-                const int gn = nt * 16 + mi;
-                if (gm < g.M && gn < g.N) {
-                    float* c = g.C + gm * g.ldc + gn;
-                    *c = g.accumulate ? *c + acc[nt][r] : acc[nt][r];
-                }
-            }
-    }
-}
-
-static inline bool sgemm_rows_bf16_ok(int64_t sAk, int M, int N, int K) { return sAk == 1 && N <= 32 && K <= 128 && K >= 1 && M >= 16; }
-
-template <int NT, int KS>
-static int sgemm_rows_bf16_launch(const GemmArgs& g, hipStream_t st) {
-    const int64_t tiles = ((int64_t)g.M + 15) / 16;
-    int64_t blocks = (tiles + 3) / 4;
-    if (blocks > 4096) blocks = 4096;                   // 16 waves per CU worth of persistent workgroups
-    (void)hipGetLastError();
-    hipLaunchKernelGGL((sgemm_rows_bf16_kernel<NT, KS>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-}
-
-static int sgemm_rows_bf16(const GemmArgs& g, hipStream_t st) {
-    const int NT = g.N <= 16 ? 1 : 2, KS = g.K <= 32 ? 1 : (g.K <= 64 ? 2 : 4);
-    if (NT == 1) return KS == 1 ? sgemm_rows_bf16_launch<1, 1>(g, st) : (KS == 2 ? sgemm_rows_bf16_launch<1, 2>(g, st) : sgemm_rows_bf16_launch<1, 4>(g, st));
-    return KS == 1 ? sgemm_rows_bf16_launch<2, 1>(g, st) : (KS == 2 ? sgemm_rows_bf16_launch<2, 2>(g, st) : sgemm_rows_bf16_launch<2, 4>(g, st));
-}
-
-// (measured: at N = 50..64 the LDS broadcast reads bind and the MFMA tile wins -- ASTGCNN batch 65536: 8.5 vs 10.6 ms/step)
-static inline bool sgemm_is_skinny(int64_t sAk, int M, int N, int K) { return sAk == 1 && N <= 32 && K <= 128 && M >= 2048; }
-
-// `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies (sgemm_rows_bf16_ok), fp32 paths otherwise
-static int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0) {
-    if (M <= 0 || N <= 0) return RULGNN_OK;
-    if (bf16 && sgemm_rows_bf16_ok(sAk, M, N, K)) {
-        const GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K};
-        return sgemm_rows_bf16(g, st);
-    }
-    if (sgemm_is_skinny(sAk, M, N, K)) {
-        GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? K : 1};
-        const int NT = N <= 8 ? 8 : (N <= 16 ? 16 : 32);
-        const size_t lds = (size_t)(K > 0 ? K : 1) * NT * sizeof(float);
-        const dim3 grid((unsigned)((M + 255) / 256));
-        (void)hipGetLastError();
-        if (NT == 8) hipLaunchKernelGGL(sgemm_skinny_kernel<8>, grid, dim3(256), lds, st, g);
-        else if (NT == 16) hipLaunchKernelGGL(sgemm_skinny_kernel<16>, grid, dim3(256), lds, st, g);
-        else hipLaunchKernelGGL(sgemm_skinny_kernel<32>, grid, dim3(256), lds, st, g);
-        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-    }
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? (K + 15) & ~15 : 16};
-    (void)hipGetLastError();
-    sgemm_launch_tiles(g, 1, st);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-}
-
-// Split-K for reductions over a long K (weight gradients: K = batch * nodes) with few output tiles: `slices` partial
-// products into `partial` ([slices][M][N], caller-provided), then a fixed-order sum -- deterministic, no atomics.
-static __global__ __launch_bounds__(256) void sgemm_reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                                         int64_t ldc, int M, int N, int slices, int accumulate) {
-    // 64 outputs per workgroup, four threads per output each summing every fourth slice, combined in a fixed order
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    float a = 0.f;
-    if (e < M * N)
-        for (int z = q; z < slices; z += 4) a += partial[(int64_t)z * M * N + e];
-    part[q][lane] = a;
-    __syncthreads();
-    if (q == 0 && e < M * N) {
-        const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-        float* c = C + (int64_t)(e / N) * ldc + (e % N);
-        *c = accumulate ? *c + v : v;
-    }
-}
-
+// ---- scratch sizing (host) ----------------------------------------------------------------------------------------------------
+constexpr int SKT_ROWS = 128;
 static inline int sgemm_splitk_slices(int M, int N, int K) {
     // outputs that fill 128x128 tiles run on the big kernel (sgemm_big_ok): count its tiles, two workgroups per CU
     const bool big = M > 96 && N > 96;
@@ -871,166 +41,11 @@ static inline int sgemm_splitk_slices(int M, int N, int K) {
     return s < 1 ? 1 : s;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Long reduction into a small output (the weight gradients of the per-row projections: M x N <= 1024 outputs, K = all rows
-// of the batch).  The generic split-K path launches a 64x64 MFMA tile per slice for a handful of useful columns and then
-// walks the slices; here every workgroup owns a contiguous run of k, stages 32 k-rows of both operands in LDS with
-// coalesced loads, each thread keeps <= 4 outputs in registers, and one wavefront per output adds the per-workgroup
-// partials in a fixed order (deterministic).
-// ------------------------------------------------------------------------------------------------
-constexpr int SKT_ROWS = 128;
-static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int kper) {
-    extern __shared__ float sk_lds[];                 // As[SKT_ROWS][M] | Bs[SKT_ROWS][N] | red[256] (few outputs only)
-    float* As = sk_lds;
-    float* Bs = sk_lds + SKT_ROWS * g.M;
-    const int O = g.M * g.N;
-    // O >= 256: thread t owns outputs t, t + 256, ... (<= 4), every k-row.  O < 256: 256 / O thread slices share each output,
-    // slice s taking rows s, s + S, ... of a tile; the slices are combined through LDS in a fixed order at the end.
-    const int S = O >= 256 ? 1 : 256 / O;
-    const int sl = O >= 256 ? 0 : threadIdx.x / O;
-    const bool active = O >= 256 || sl < S;
-    int oi[4], oj[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int o = O >= 256 ? threadIdx.x + q * 256 : (q == 0 ? threadIdx.x % O : O);
-        oi[q] = o < O ? o / g.N : 0;
-        oj[q] = o < O ? o % g.N : 0;
-    }
-    const int kbeg = blockIdx.x * kper, kend = min(g.K, kbeg + kper);
-    for (int k0 = kbeg; k0 < kend; k0 += SKT_ROWS) {
-        const int nr = min(SKT_ROWS, kend - k0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < SKT_ROWS * g.M; e += 256)
-            As[e] = e < nr * g.M ? g.A[(e % g.M) * g.sAm + (int64_t)(k0 + e / g.M) * g.sAk] : 0.f;
-        for (int e = threadIdx.x; e < SKT_ROWS * g.N; e += 256)
-            Bs[e] = e < nr * g.N ? g.B[(e % g.N) * g.sBn + (int64_t)(k0 + e / g.N) * g.sBk] : 0.f;
-        __syncthreads();
-        if (!active) continue;
-        if (O >= 256) {
-#pragma unroll 4
-            for (int r = 0; r < SKT_ROWS; ++r) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = fmaf(As[r * g.M + oi[q]], Bs[r * g.N + oj[q]], acc[q]);
-            }
-        } else {
-            // rows past nr are zero-filled: no bounds in the loop; four independent chains hide the LDS latency
-            for (int r = sl; r < SKT_ROWS; r += 4 * S) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rr = r + q * S;
-                    if (rr < SKT_ROWS) acc[q] = fmaf(As[rr * g.M + oi[0]], Bs[rr * g.N + oj[0]], acc[q]);
-                }
-            }
-        }
-    }
-    if (O >= 256) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = threadIdx.x + q * 256;
-            if (o < O) g.C[(int64_t)blockIdx.x * O + o] = acc[q];      // g.C = the partial buffer here
-        }
-    } else {
-        float* red = Bs + SKT_ROWS * g.N;
-        __syncthreads();
-        red[threadIdx.x] = active ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.f;
-        __syncthreads();
-        if ((int)threadIdx.x < O) {
-            float a = 0.f;
-            for (int q = 0; q < S; ++q) a += red[q * O + threadIdx.x];
-            g.C[(int64_t)blockIdx.x * O + threadIdx.x] = a;
-        }
-    }
-}
-
-static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                                        int64_t ldc, int M, int N, int nblk, int accumulate) {
-    const int o = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (o >= M * N) return;
-    float a = 0.f;
-    for (int b = lane; b < nblk; b += 64) a += partial[(int64_t)b * M * N + o];
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
-    if (lane == 0) {
-        float* c = C + (int64_t)(o / N) * ldc + (o % N);
-        *c = accumulate ? *c + a : a;
-    }
-}
-
 // workgroups of the long-k path for this shape, 0 if it does not apply
 static inline int sgemm_longk_blocks(int M, int N, int K) {
     if (!(M * N <= 1024 && K >= 512 && ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float) <= 48 * 1024)) return 0;
     const int nblk = (K + SKT_ROWS - 1) / SKT_ROWS;     // one k tile per workgroup while the partial buffer (1024 rows) allows
     return nblk > 1024 ? 1024 : nblk;
-}
-
-static int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                        int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
-    if (M <= 0 || N <= 0) return RULGNN_OK;
-    if (sgemm_longk_blocks(M, N, K) > 0) {
-        int nblk = sgemm_longk_blocks(M, N, K);
-        int kper = (K + nblk - 1) / nblk;
-        kper = (kper + SKT_ROWS - 1) / SKT_ROWS * SKT_ROWS;
-        nblk = (K + kper - 1) / kper;
-        GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kper};
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float), st, g, kper);
-        hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, N, nblk,
-                           accumulate ? 1 : 0);
-        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-    }
-    const int slices = sgemm_splitk_slices(M, N, K);
-    if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st);
-    int kchunk = (K + slices - 1) / slices;
-    kchunk = (kchunk + 15) & ~15;
-    const int used = (K + kchunk - 1) / kchunk;
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
-    (void)hipGetLastError();
-    sgemm_launch_tiles(g, used, st);
-    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, partial, C, ldc, M, N, used,
-                       accumulate ? 1 : 0);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-}
-
-// out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 64 columns x 16 row slices per
-// workgroup, the slices combined through LDS in a fixed order (deterministic).  One thread per column walking every row alone
-// was 140-190 us in the finalize kernels of three families.
-static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ part, int rows, int64_t ld, int n,
-                                                               float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    float a = 0.f;
-    if (e < n)
-        for (int r = sl; r < rows; r += 16) a += part[(int64_t)r * ld + e];
-    red[sl][lane] = a;
-    __syncthreads();
-    if (sl == 0 && e < n) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v += red[q][lane];
-        out[e] = v;
-    }
-}
-static inline int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {
-    if (n <= 0) return RULGNN_OK;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, part, rows, ld, n, out);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
-}
-
-// out[0] = sum(v[0..n)) with one workgroup: strided partial sums, then a fixed-order tree (deterministic).
-static __global__ __launch_bounds__(1024) void block_sum_kernel(const float* __restrict__ v, int64_t n, float* __restrict__ out) {
-    __shared__ float red[1024];
-    float a = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int m = 512; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // floats the caller must provide as `partial` for sgemm_splitk(M, N, any K)

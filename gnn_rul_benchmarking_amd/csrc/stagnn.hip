@@ -1129,7 +1129,7 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             TG_LAUNCH_OK();
         }
         if (training && a->update_running_stats) hipLaunchKernelGGL(tg_running_kernel, dim3(4), dim3(TB), 0, st, g, (const float*)ws, a->bn_state);
-        if (a->y && a->loss) hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, a->loss);
+        if (a->y && a->loss) (void)block_sum((const float*)(ws + g.w_sq), g.B, a->loss, st);
         TG_LAUNCH_OK();
     }
     if (mode & 2) {

@@ -549,7 +549,7 @@ int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int m
         }
         hipLaunchKernelGGL(sc_finalize_kernel, dim3((N + 4 + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, (const Cells3*)c3, gr);
         if (!a->dpred && a->loss)
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)F(w.sqerr), (int64_t)g.B, a->loss);
+            (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -353,7 +353,7 @@ int stgnn_run(const rulgnn_stgnn_shape* s, const rulgnn_stmsgcn_args* a, int mod
         if (g.L > 1) hipLaunchKernelGGL(stgnn_permute_kernel, dim3(gn_blocks(R * g.H)), dim3(GB), 0, st, g, (const float*)dseq, dcheb, 0);
         GN_RC(stgnn_cheb_backward(s, Fp(w.terms), dcheb, gr + o.filters, split, sgemm_splitk_partial_floats(g.KF, g.H) * sizeof(float), st));
         if (!a->dpred && a->loss)
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)Fp(w.sqerr), (int64_t)g.B, a->loss);
+            (void)block_sum((const float*)Fp(w.sqerr), (int64_t)g.B, a->loss, st);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
     return RULGNN_OK;

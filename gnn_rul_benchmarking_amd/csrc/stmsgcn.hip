@@ -949,7 +949,7 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
                            (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
                            (const float*)(ws + w.dpred), (const float*)(ws + w.pooled), a->grads);
         if (mse && a->loss)
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + w.sqerr), (int64_t)g.B, a->loss);
+            (void)block_sum((const float*)(ws + w.sqerr), (int64_t)g.B, a->loss, st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

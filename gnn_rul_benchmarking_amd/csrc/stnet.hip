@@ -368,7 +368,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
         // reconstruction error (and, when a backward follows, its gradients w.r.t. both of its arguments)
         hipLaunchKernelGGL(sn_recon_kernel, dim3(g.rblocks), dim3(SB), 0, st, (const float*)cur, (const float*)(ws + g.w_dec[3]), (int64_t)BT * D,
                            rscale, ws + g.w_dD1, ws + g.w_dD2, ws + g.w_rsq);
-        hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_rsq), (int64_t)g.rblocks, ws + g.w_one + 1);
+        (void)block_sum((const float*)(ws + g.w_rsq), (int64_t)g.rblocks, ws + g.w_one + 1, st);
         SN_LAUNCH_OK();
         SN_RC(bilstm_forward(&ls, &la, st, 1));
         hipLaunchKernelGGL(sn_head_kernel, dim3((unsigned)(g.B < 1024 ? g.B : 1024)), dim3(SB), 0, st, g, (const float*)(ws + g.w_hseq), prm, a->y,
@@ -376,7 +376,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
         if (a->recon) hipLaunchKernelGGL(sn_loss_kernel, dim3(1), dim3(1), 0, st, (const float*)(ws + g.w_one + 1), (const float*)(ws + g.w_one + 3),
                                          a->recon);          // w_one + 3 holds 0
         if (a->y && a->loss) {
-            hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)(ws + g.w_sq), g.B, ws + g.w_one + 2);
+            (void)block_sum((const float*)(ws + g.w_sq), g.B, ws + g.w_one + 2, st);
             hipLaunchKernelGGL(sn_loss_kernel, dim3(1), dim3(1), 0, st, (const float*)(ws + g.w_one + 1), (const float*)(ws + g.w_one + 2), a->loss);
         }
         SN_LAUNCH_OK();
