@@ -154,11 +154,16 @@ def algorithmic_bytes_per_sample(N, P):
     return 4 * N * P + 4
 
 
-def time_eval_forward(model, X, iters=20, reps=5):
-    """Median over `reps` event-timed groups of `iters` launches of the fused eval forward (one kernel per call)."""
+def time_eval_forward(model, X, iters=20, reps=5, settle_ms=20.0):
+    """Median over `reps` event-timed groups of `iters` launches of the fused eval forward (one kernel per call), taken in steady
+    state: the kernel is launched back to back for `settle_ms` first.  The clock of an MI355X that was idle (or in another kernel
+    mix) takes 5-10 ms of this kernel to settle: the first 1-2 ms of launches run ~10 % slower (tools/time_forward_steady.py:
+    55 us -> 50.3 us at batch 65536 after 100 launches, flat from there to 1000)."""
     import statistics
     model.eval()
     with torch.no_grad():
+        one = event_time_ms(lambda: model(X), 3)
+        event_time_ms(lambda: model(X), max(3, int(settle_ms / max(one, 1e-3))), warm=0)
         ts = [event_time_ms(lambda: model(X), iters) for _ in range(reps)]
     model.train()
     return statistics.median(ts)

@@ -16,19 +16,29 @@
 // k-slots 4 (lane >> 4) + r of an operand, so a layer chains through the matrix cores with no data movement at all:
 //   T  = X^T-as-A-operand x Adj            (A.X, Model.py:87; rows t, columns c: the transposed tile)       2 MFMAs
 //   Hp = T-as-A-operand x theta^T + b      (theta(A.X); rows c, columns j: D layout again)                  2 MFMAs
-//   z1 = W1 x [H ; H shifted by 1]         (conv_block1 with BatchNorm folded in; the causal tap is a DPP row_shr of
-//                                           the PACKED operand registers, zero fill = the causal padding)    3 MFMAs
+//   z1 = W1 x [H ; H shifted by 1]         (conv_block1 with BatchNorm folded in; the causal tap is the PACKED operand
+//                                           registers of column t - 1, fetched through an LDS tile on the LDS port;
+//                                           lanes t < d read a zero slot = the causal padding)                3 MFMAs
 //   z2 = W2 x [o0 ; o0 shifted by 2]       (conv_block2, dilation 2)                                        3 MFMAs
 // Biases ride in spare k-slots against a constant 1 (theta: k = 15, so num_patch <= 15; conv: slot 3 of lane group 0).
 // ReLU is |x| + x = 2 relu(x) (one full-rate op, NaN-preserving where v_max is neither); the powers of two are folded
-// into the next weights.  Four samples are in flight per wavefront so that dependent MFMAs never wait.
+// into the next weights; LeakyReLU is one fma, (1 + a)/2 folded into theta.  Four samples are in flight per wavefront so that
+// dependent MFMAs never wait.
+//
+// What the SIMD's issue port costs (tools/probe_issue.hip, round 3): everything adds up -- an f16 MFMA holds the port for its
+// 16 cycles (10 with an inline-zero C operand), also against the OTHER wavefront of the SIMD; v_cvt_pk_f16_f32, any DPP form,
+// v_max/min and every packed-f16 op are 4 cycles, plain fp32 ops 2.4.  So the kernel is shaped by instruction count, and by keeping
+// a wavefront's own stalls (LDS round trips, LDS-DMA issue, dependent chains) from coinciding with the other wavefront's.
 //
 // Around the layers: the patch statistics (Model.py:7-52) and the Pearson Gram matrix (Model.py:53-71, f32 4-block MFMAs,
 // exact) run in the row mapping of the exact kernel and are converted through the wavefront's LDS tile; the head
 // (channel max-pool, fc1, fc2) returns to the row mapping with one 4x4 register/row transpose.
 //
-// Memory: windows arrive by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double buffered one tile ahead; 4 bytes per
-// sample leave.  One wavefront per workgroup (wavefronts never synchronise), 2 x 6.7 KB of LDS each at 14x30.
+// Memory: windows arrive by LDS-DMA (global_load_lds_dwordx4, no VGPRs) into ONE 6.7-KB buffer per wavefront: the patches go to
+// registers at the top of a tile and the next tile is requested right behind them, a whole iteration ahead of its use; M0 is
+// written once per 4 KB (the immediate offset advances both addresses): an LDS-DMA piece with its own M0 round trip keeps the
+// issuing wavefront busy for ~190 cycles, back to back ~85.  4 bytes per sample leave, one tile late (s_waitcnt vmcnt also counts
+// stores).  One wavefront per workgroup (wavefronts never synchronise), 12.9 KB of LDS each at 14x30.
 //
 // Safety net.  f16 overflows at 65504.  Every pointwise step here preserves NaN / Inf, so a sample whose arithmetic
 // left the f16 range (or whose input statistics are NaN: constant patch, Model.py:41-52) ends up non-finite; such
@@ -47,8 +57,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MX_MAX_LAYERS = 3;
-constexpr int MX_BLOCKS_PER_CU = 8;
+constexpr int MX_WAVES_PER_SIMD = 2;          // a third one (168 VGPRs, 12.9 KB of LDS each: it fits) is 7 % SLOWER: 688 vs 641 us at 1M samples
+constexpr int MX_BLOCKS_PER_CU = 4 * MX_WAVES_PER_SIMD;
 constexpr int MX_MIN_BUF_BYTES = 5120;        // [64][20] floats: layout-conversion tile (both uses)
+constexpr int MX_SHIFT_TILE_BYTES = 2 * 65 * 8;  // hi pairs and lo pairs of [64 lanes + the zero slot], behind the conversion tile
 constexpr int MX_TAPS_PER_LAYER = 88;
 constexpr int MX_TAP_SLOTS = 38 + MX_TAPS_PER_LAYER * MX_MAX_LAYERS + 2;
 
@@ -85,12 +97,89 @@ __device__ __forceinline__ unsigned shr_packed(unsigned v) {     // operand regi
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + D, 0xf, 0xf, true);
 }
 
+// The causal tap of a convolution is the operand registers of column t - d: a lane shift inside the 16-lane row.  As four DPP moves
+// it costs 17 cycles of the VALU port per sample and convolution (a DPP move issues at half rate); through the wavefront's LDS tile it
+// is one ds_write_b128 + one ds_read_b128 on the LDS port, which nothing else here keeps busy.  Lanes t < d read the zero slot (index
+// 64) = the causal padding.  LDS operations of one wavefront execute in order, so one tile serves the samples back to back.
+// 8-byte pieces on purpose: the hi pair and the lo pair of the shifted column land straight in the upper halves of the two MFMA
+// operands they belong to (a 16-byte read would need four register moves to get them there).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct Shifted { u32x2 hi, lo; };
+// (rd_lo = rd + 65 arrives through an opaque register: seeing the constant distance the compiler fuses the two reads into one
+// ds_read2_b64, whose four consecutive result registers then have to be moved apart.)
+__device__ __forceinline__ Shifted shift_columns(u32x2* tile, int rd, int rd_lo, int lane, const u32x2& hi, const u32x2& lo) {
+    tile[lane] = hi;
+    tile[65 + lane] = lo;
+    Shifted r;
+    r.hi = tile[rd];
+    r.lo = tile[rd_lo];
+    return r;
+}
+
 // Row 3 of every lane group is padding, so element 3 of a D-layout accumulator is dead on arrival -- and the register allocator
 // hands it out as a scratch register while the MFMA that writes it is still in flight: a write-after-write hazard the
 // compiler pads with s_nop 7.  Naming the element at the point where its siblings are consumed keeps it reserved until then.
 __device__ __forceinline__ void keep_until_here(float v) { asm volatile("" ::"v"(v)); }
 
 __device__ __forceinline__ float relu2(float v) { return __builtin_fabsf(v) + v; }     // 2 relu(v); NaN / +Inf preserving
+
+// ---- patch statistics, lean form -------------------------------------------------------------------------------------
+// Same ten statistics as patch_statistics_regs<P, true> (Model.py:7-52) with two of the per-element accumulations removed:
+//  * sum x^2 = sum (x - mean)^2 + P mean^2 (both terms non-negative: no cancellation), so rms comes from the second pass;
+//  * sum |x| = +-sum x when the patch does not change sign (min >= 0 or max <= 0: every dataset the reference wires is scaled to
+//    [0, 1]); a wavefront with a mixed-sign patch takes the explicit sum (wave-uniform branch).
+template <int P>
+__device__ __forceinline__ void patch_load(const float* pp, float (&v)[P]) {
+    static_assert(P % 2 == 0 && P <= 64, "even patch sizes that fit the register budget");
+    const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) { const float2 q = p2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+}
+template <int P>
+__device__ __forceinline__ void patch_statistics_lean(const float (&v)[P], float (&st)[F]) {
+#pragma clang fp contract(off)          // see patch_statistics_regs: a constant patch must give the exact 0 deviation
+    float s = 0.f, mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        s += v[i] + v[i + 1];
+        mx = vmax3(mx, v[i], v[i + 1]);
+        mn = vmin3(mn, v[i], v[i + 1]);
+    }
+    float sa = mn >= 0.f ? s : -s;
+    if (__builtin_amdgcn_ballot_w64(mn < 0.f && mx > 0.f) != 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < P; i += 2) t += __builtin_fabsf(v[i]) + __builtin_fabsf(v[i + 1]);
+        sa = t;
+    }
+    const float invP = 1.0f / (float)P;
+    const float mean = s * invP;
+    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        const float d0 = v[i] - mean, d1 = v[i + 1] - mean;
+        const float q0 = d0 * d0, q1 = d1 * d1;
+        m2 += q0 + q1;
+        m3 = fmaf(q0, d0, m3);
+        m3 = fmaf(q1, d1, m3);
+        m4 = fmaf(q0, q0, m4);
+        m4 = fmaf(q1, q1, m4);
+    }
+    const float var = m2 * (1.0f / (float)(P - 1));
+    const float sd = __builtin_amdgcn_sqrtf(var);
+    const float isd = __builtin_amdgcn_rcpf(sd);       // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
+    const float isd2 = isd * isd;
+    st[0] = mx;
+    st[1] = mn;
+    st[2] = mx - mn;
+    st[3] = var;
+    st[4] = sd;
+    st[5] = mean;
+    st[6] = __builtin_amdgcn_sqrtf(fmaf(mean, mean, m2 * invP));
+    st[7] = sa * invP;
+    st[8] = (m3 * invP) * (isd2 * isd);
+    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
+}
 
 // ---- LDS-DMA --------------------------------------------------------------------------------------------------------
 // Copies `bytes` (multiple of 16) from global memory to the wavefront's LDS buffer; every instruction moves 1 KB
@@ -115,12 +204,41 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ g, float* lds
         }
     }
 }
+// The same copy for a byte count known at compile time: M0 is written once per 4 KB (the instruction's immediate offset advances the
+// global AND the LDS address), so the pieces go out back to back instead of one M0 round trip each.
+template <int BYTES>
+__device__ __forceinline__ void dma_tile_fixed(const float* __restrict__ g, float* lds_dst, int lane) {
+    static_assert(BYTES % 16 == 0 && BYTES <= 16384, "16-byte pieces, at most four M0 windows");
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst);
+    const float* src = g + lane * 4;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep) :: "memory");
+#pragma unroll
+    for (int win = 0; win < BYTES; win += 4096) {
+        const float* s4 = src + win / 4;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(base + (unsigned)win) : "memory");
+        if (win + 1024 <= BYTES) asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(s4) : "memory");
+        if (win + 2048 <= BYTES) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" :: "v"(s4) : "memory");
+        if (win + 3072 <= BYTES) asm volatile("global_load_lds_dwordx4 %0, off offset:2048" :: "v"(s4) : "memory");
+        if (win + 4096 <= BYTES) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" :: "v"(s4) : "memory");
+        constexpr int full = BYTES / 1024 * 1024;          // the last, partial piece: the lanes below the end
+        if (win <= full && full < win + 4096 && full < BYTES) {
+            if (lane * 16 < BYTES - full) {
+                if (full - win == 0) asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(s4) : "memory");
+                if (full - win == 1024) asm volatile("global_load_lds_dwordx4 %0, off offset:1024" :: "v"(s4) : "memory");
+                if (full - win == 2048) asm volatile("global_load_lds_dwordx4 %0, off offset:2048" :: "v"(s4) : "memory");
+                if (full - win == 3072) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" :: "v"(s4) : "memory");
+            }
+        }
+    }
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep) : "memory");
+}
 
 struct MxArgs {
     int64_t B;
     int64_t ntiles;
     int N, P, L;
-    int buf_floats;        // one of the two LDS buffers of a wavefront
+    int buf_floats;        // the window buffer of a wavefront (the conversion region follows it)
     float* taps;           // debug: raw register dumps of tile 0 (TAPS builds only)
 };
 
@@ -140,7 +258,7 @@ __device__ __forceinline__ void tap(float* taps, bool on, int slot, int lane, fl
 }
 
 template <int LFIX, int NFIX, int PFIX, bool TAPS>
-__global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+__global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
                                                                  const float* __restrict__ bn, float* __restrict__ out, MxArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int L = LFIX;
@@ -173,7 +291,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 const bool ok = col < N && (k < N || k == 15);
                 const int idx = k == 15 ? off_theta_b(N) + col : off_theta_w(N) + col * N + k;
                 const float v = lp[ok ? idx : 0];
-                w[r] = ok ? v : 0.f;
+                w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;      // Hp arrives as (1 + a)/2 Hp: leaky() is then ONE fma
             }
             const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
             ops[l].theta_hi = u32x4{p01.hi, p23.hi, p01.hi, p23.hi};
@@ -216,37 +334,68 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
     const float fc1b = col < N ? fc1b_raw : 0.f;
     const float fc2w_half = col < N ? 0.5f * fc2w_raw : 0.f;                         // fc1's ReLU arrives as 2 relu
     const float fc2b = prm[off_fc2_b(N, L)];
-    // T's accumulator starts with row t = 15 at 1: the k = 15 slot of theta^T is the bias
-    const f32x4 t_init = {0.f, 0.f, 0.f, g == 3 ? 1.f : 0.f};
+    // row t = 15 of T is 1 (the k = 15 slot of theta^T is the bias): OR-ed into the hi operand of T (column 15 of X is zero, so
+    // the matrix cores leave an exact 0 there) -- an MFMA with C = 0 issues in 10 cycles, with a register C in 16 (tools/probe_issue.hip)
+    const unsigned t_bias = g == 3 ? 0x3C00u << 16 : 0u;
     const float half_ok = col < N ? 0.5f : 0.f, quarter_ok = col < N ? 0.25f : 0.f;  // residual scales; padded columns stay 0
-    const unsigned one_hi = 0x3C00u << 16;                                            // f16 1.0 in the upper half
 
-    bool any_bad = false;
+    const int sh_rd1 = col >= 1 ? lane - 1 : 64, sh_rd2 = col >= 2 ? lane - 2 : 64;     // shift tile: column t - d, or the zero slot
+    int sh_rd1_lo = sh_rd1 + 65, sh_rd2_lo = sh_rd2 + 65;
+    asm volatile("" : "+v"(sh_rd1_lo), "+v"(sh_rd2_lo));
+
+    bool any_bad = false, pend_mine = false;
+    int64_t pend_idx = 0;
+    float pend_pred = 0.f;
     for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
-        float* cur = smem + (it & 1) * a.buf_floats;     // plain arithmetic on the __shared__ base keeps these LDS (not flat) accesses
+        float* const tileA = smem;                       // this tile's windows (LDS-DMA target); free again once the patches are in registers
+        float* const cur = smem + a.buf_floats;          // layout-conversion tile + shift tile (plain arithmetic on the __shared__ base
+                                                         // keeps these LDS, not flat, accesses)
         const int64_t s0 = tile * 4;
         const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
         const bool tapon = TAPS && a.taps != nullptr && tile == 0;
         // this tile's windows have landed; every LDS access of the previous tile has retired
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        {
-            const int64_t nt = tile + gridDim.x;
-            if (nt < a.ntiles) {
-                const int64_t n0 = nt * 4;
-                const int nns = (int)((a.B - n0) < 4 ? (a.B - n0) : 4);
-                dma_tile(gx + n0 * tileNP, smem + ((it + 1) & 1) * a.buf_floats, nns * tileNP * 4, lane);
-            }
-        }
+        // The previous tile's predictions leave HERE, not at the end of their own iteration: the wait above also counts stores, and a
+        // store issued just in front of it kept the wavefront parked for the write acknowledgement (~1600 cycles per tile, s_memtime).
+        if (pend_mine) out[pend_idx] = pend_pred;
+
+        u32x2* sh_tile = reinterpret_cast<u32x2*>(cur + MX_MIN_BUF_BYTES / 4);      // behind the layout-conversion tile
 
         // ---- patch statistics, row mapping: lane (sample row g, patch col) ------------------------------------------
         const bool valid = (g < ns) && (col < N);
         float X0[F];
 #pragma unroll
         for (int c = 0; c < F; ++c) X0[c] = 0.f;
-        if (valid) {
-            if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) patch_statistics_regs<PFIX, true>(cur + (g * N + col) * P, X0);
-            else patch_statistics(cur + (g * N + col) * P, P, X0);
+        // The next tile is requested as soon as this one has left the LDS: ONE window buffer per wavefront (12.9 KB with the conversion
+        // tile at 14x30 -> twelve wavefronts per CU, three per SIMD), and the copy has the rest of the iteration to land.
+        auto request_next = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t nt = tile + gridDim.x;
+            if (nt < a.ntiles) {
+                const int64_t n0 = nt * 4;
+                const int nns = (int)((a.B - n0) < 4 ? (a.B - n0) : 4);
+                if constexpr (NFIX != 0 && PFIX != 0) {
+                    if (nns == 4) dma_tile_fixed<16 * NFIX * PFIX>(gx + n0 * tileNP, tileA, lane);
+                    else dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
+                } else {
+                    dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
+                }
+            }
+        };
+        if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) {
+            // every lane loads (padding lanes: a patch that exists; their statistics are never computed): the copy below must run
+            // with all 64 lanes enabled -- a lane transfers ITS 16 bytes -- so nothing in front of it may tempt the compiler into
+            // one divergent region around the loads, the copy and the arithmetic
+            float v[PFIX];
+            patch_load<PFIX>(tileA + ((g < ns ? g : 0) * N + (col < N ? col : 0)) * P, v);
+            request_next();
+            if (valid) patch_statistics_lean<PFIX>(v, X0);
+
+        } else {
+            if (valid) patch_statistics(tileA + (g * N + col) * P, P, X0);
+            request_next();
         }
 #pragma unroll
         for (int c = 0; c < F; ++c) tap<TAPS>(a.taps, tapon, c, lane, X0[c]);
@@ -314,7 +463,12 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 3; ++r) tap<TAPS>(a.taps, tapon, 26 + 3 * s + r, lane, X[s][r]);
         }
+        if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};      // the padding slot of the shift tile (hi and lo halves)
 
+        // The layers are the dense part of a tile; statistics, Pearson and the head are chains of LDS round trips and dependent
+        // instructions.  The wavefront that is in a sparse stage goes first whenever it has something to issue; the other one fills the
+        // gaps from its dense stage (s_setprio 1 / 0: 665 -> 648 us at 1M samples).
+        __builtin_amdgcn_s_setprio(0);
         // ---- the layers, four samples in flight ---------------------------------------------------------------------
         // Scheduling barriers between the five stages of a layer: inside a stage the samples follow one another (operands of
         // sample s, then its MFMA chain), so the results of sample 0 are three samples old when the next stage reads them.
@@ -329,7 +483,8 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             for (int s = 0; s < 4; ++s) {
                 const Split2 p01 = split2(X[s][0], X[s][1]), p2 = split2(X[s][2], 0.f);
                 const u32x4 ah = {p01.hi, p2.hi, p01.hi, p2.hi}, al = {p01.lo, p2.lo, p01.lo, p2.lo};
-                T[s] = mfma16(ah, adjB[s], t_init);
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                T[s] = mfma16(ah, adjB[s], zero);
                 T[s] = mfma16(al, adjB[s], T[s]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -339,30 +494,38 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 4 * s + r, lane, T[s][r]);
                 const Split2 p01 = split2(T[s][0], T[s][1]), p23 = split2(T[s][2], T[s][3]);
-                const u32x4 ta = {p01.hi, p23.hi, p01.lo, p23.lo};
+                const u32x4 ta = {p01.hi, p23.hi | t_bias, p01.lo, p23.lo};
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                 Hp[s] = mfma16(ta, ops[l].theta_hi, zero);
                 Hp[s] = mfma16(ta, ops[l].theta_lo, Hp[s]);
             }
             float H[4][3], V[4][3];
+            u32x4 bh[4], bl[4];
             __builtin_amdgcn_sched_barrier(0);
             // conv_block1 on H = leaky(Hp)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 16 + 4 * s + r, lane, Hp[s][r]);
+                for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, tb + 16 + 4 * s + r, lane, Hp[s][r] * (2.f / (1.f + LEAKY)));
                 keep_until_here(Hp[s][3]);
+                // Hp carries the factor (1 + a)/2 (folded into theta): leaky(x) = x' + (1 - a)/(1 + a) |x'|, one full-rate fma; NaN stays NaN
 #pragma unroll
-                // leaky(x) = (1 + a)/2 x + (1 - a)/2 |x|: two full-rate instructions (v_max is half rate); NaN stays NaN
-                for (int r = 0; r < 3; ++r) H[s][r] = fmaf(0.5f * (1.f - LEAKY), __builtin_fabsf(Hp[s][r]), (0.5f * (1.f + LEAKY)) * Hp[s][r]);
-                const Split2 p01 = split2(H[s][0], H[s][1]), p2 = split2(H[s][2], 0.f);
-                const unsigned h2 = p2.hi | one_hi;                                           // slot 3 = 1: the BatchNorm shift's partner
-                const u32x4 bh = {p01.hi, h2, shr_packed<1>(p01.hi), shr_packed<1>(p2.hi)};
-                const u32x4 bl = {p01.lo, p2.lo, shr_packed<1>(p01.lo), shr_packed<1>(p2.lo)};
+                for (int r = 0; r < 3; ++r) H[s][r] = fmaf((1.f - LEAKY) / (1.f + LEAKY), __builtin_fabsf(Hp[s][r]), Hp[s][r]);
+                // slot 3 = 1: the BatchNorm shift's partner rides through the split (its lo part is 0)
+                const Split2 p01 = split2(H[s][0], H[s][1]), p2 = split2(H[s][2], 1.0f);
+                const Shifted prev = shift_columns(sh_tile, sh_rd1, sh_rd1_lo, lane, u32x2{p01.hi, p2.hi}, u32x2{p01.lo, p2.lo});   // column t - 1
+                bh[s] = u32x4{p01.hi, p2.hi, prev.hi.x, prev.hi.y};
+                bl[s] = u32x4{p01.lo, p2.lo, prev.lo.x, prev.lo.y};
+                __builtin_amdgcn_sched_barrier(0);          // keep each sample's LDS round trip behind ITS arithmetic, not behind all four
+            }
+            // the shifted columns of all four samples are in flight through the LDS before the first product needs one
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                z[s] = mfma16(ops[l].w_hi[0], bh, zero);
-                z[s] = mfma16(ops[l].w_hi[0], bl, z[s]);
-                z[s] = mfma16(ops[l].w_lo[0], bh, z[s]);
+                z[s] = mfma16(ops[l].w_hi[0], bh[s], zero);
+                z[s] = mfma16(ops[l].w_hi[0], bl[s], z[s]);
+                z[s] = mfma16(ops[l].w_lo[0], bh[s], z[s]);
             }
             __builtin_amdgcn_sched_barrier(0);
             // o0 = relu(relu(z1) + H), carried as V = 4 o0;  conv_block2 (dilation 2)
@@ -375,14 +538,19 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
                 for (int r = 0; r < 3; ++r) V[s][r] = relu2(fmaf(2.f, H[s][r], relu2(z[s][r])));
 #pragma unroll
                 for (int r = 0; r < 3; ++r) tap<TAPS>(a.taps, tapon, tb + 48 + 3 * s + r, lane, V[s][r]);
-                const Split2 p01 = split2(V[s][0], V[s][1]), p2 = split2(V[s][2], 0.f);
-                const unsigned h2 = p2.hi | one_hi;
-                const u32x4 bh = {p01.hi, h2, shr_packed<2>(p01.hi), shr_packed<2>(p2.hi)};
-                const u32x4 bl = {p01.lo, p2.lo, shr_packed<2>(p01.lo), shr_packed<2>(p2.lo)};
+                const Split2 p01 = split2(V[s][0], V[s][1]), p2 = split2(V[s][2], 1.0f);
+                const Shifted prev = shift_columns(sh_tile, sh_rd2, sh_rd2_lo, lane, u32x2{p01.hi, p2.hi}, u32x2{p01.lo, p2.lo});   // column t - 2
+                bh[s] = u32x4{p01.hi, p2.hi, prev.hi.x, prev.hi.y};
+                bl[s] = u32x4{p01.lo, p2.lo, prev.lo.x, prev.lo.y};
+                __builtin_amdgcn_sched_barrier(0);          // keep each sample's LDS round trip behind ITS arithmetic, not behind all four
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
                 const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                z[s] = mfma16(ops[l].w_hi[1], bh, zero);
-                z[s] = mfma16(ops[l].w_hi[1], bl, z[s]);
-                z[s] = mfma16(ops[l].w_lo[1], bh, z[s]);
+                z[s] = mfma16(ops[l].w_hi[1], bh[s], zero);
+                z[s] = mfma16(ops[l].w_hi[1], bl[s], z[s]);
+                z[s] = mfma16(ops[l].w_lo[1], bh[s], z[s]);
             }
             __builtin_amdgcn_sched_barrier(0);
             // o1 = relu(z2) + o0 (both >= 0: the outer ReLU is the identity); out = dropout_eval(o1) + X
@@ -398,6 +566,7 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
             }
         }
 
+        __builtin_amdgcn_s_setprio(1);
         // ---- head: max over the ten channels (Model.py:218-219), fc1, fc2 -------------------------------------------
         float pm[4];
 #pragma unroll
@@ -422,10 +591,11 @@ __global__ __launch_bounds__(64, 2) void stgcn_forward_mx_kernel(const float* __
         const float pred = Row<16>::allsum(relu2(y1) * fc2w_half) + fc2b;
         tap<TAPS>(a.taps, tapon, 38 + MX_TAPS_PER_LAYER * MX_MAX_LAYERS + 1, lane, pred);
         const bool mine = col == 0 && g < ns;
-        if (mine) out[s0 + g] = pred;
+        pend_mine = mine; pend_idx = s0 + g; pend_pred = pred;
         any_bad |= __any(mine && !(__builtin_fabsf(pred) <= 3.0e38f)) != 0;
     }
 
+    if (pend_mine) out[pend_idx] = pend_pred;
     // ---- safety net: recompute non-finite samples with the exact fp32 tile routine ----------------------------------
     if (any_bad) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -464,11 +634,13 @@ static bool mx_shape_ok(const rulgnn_stgcn_shape* s, const float* x) {
     return true;
 }
 
+// LDS of a wavefront: [window buffer: 4 samples | conversion tile + shift tile].  The safety net stages its tile (and its transpose
+// scratch, PT_FLOATS) in the first region and keeps its weights in the second.
+constexpr int MX_CONV_BYTES = MX_MIN_BUF_BYTES + MX_SHIFT_TILE_BYTES;
+static_assert(EvalWeightsLds<16>::floats(MX_MAX_LAYERS) * 4 <= MX_CONV_BYTES, "the safety net's weights live in the conversion region");
 static int mx_buf_floats(const rulgnn_stgcn_shape* s) {
     int bytes = 4 * s->num_patch * s->patch_size * 4;
-    if (bytes < MX_MIN_BUF_BYTES) bytes = MX_MIN_BUF_BYTES;
-    const int fb = EvalWeightsLds<16>::floats(s->num_layers) * 4;        // the safety net's weights live in buffer 1
-    if (bytes < fb) bytes = fb;
+    if (bytes < PT_FLOATS * 4) bytes = PT_FLOATS * 4;
     return ((bytes + 15) & ~15) / 4;
 }
 
@@ -479,7 +651,7 @@ static int mx_launch(const rulgnn_stgcn_shape* s, const float* x, const float* p
     a.B = s->batch; a.ntiles = (s->batch + 3) / 4; a.N = s->num_patch; a.P = s->patch_size; a.L = s->num_layers;
     a.buf_floats = mx_buf_floats(s);
     a.taps = taps;
-    const size_t lds = (size_t)2 * a.buf_floats * sizeof(float);
+    const size_t lds = (size_t)a.buf_floats * sizeof(float) + MX_CONV_BYTES;
     if (lds > 64 * 1024) return RULGNN_EUNSUPPORTED;
     auto kern = &stgcn_forward_mx_kernel<L, NFIX, PFIX, TAPS>;
     if (lds > 48 * 1024 &&
@@ -491,10 +663,10 @@ static int mx_launch(const rulgnn_stgcn_shape* s, const float* x, const float* p
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    // The kernel is issue-bound, not latency-bound: two wavefronts per SIMD (8 one-wave workgroups per CU) saturate it, and an
-    // even spread over the four SIMDs matters more than a third wavefront (measured at 1M samples: 8 per CU 806 us, 9: 981,
-    // 10: 912, 11: 850, 12 -- which the occupancy API grants but the LDS granule does not fit -- 1044).
+    // Wavefronts per CU: as many as fit, in whole multiples of the four SIMDs (an uneven spread costs more than the extra
+    // wavefront brings: at 1M samples 8 per CU 806 us, 9: 981, 10: 912, 11: 850 -- round 2's kernel).  Three per SIMD at 14x30.
     if (per_cu > MX_BLOCKS_PER_CU) per_cu = MX_BLOCKS_PER_CU;
+    if (per_cu > 4) per_cu -= per_cu % 4;
     if (const char* e = getenv("RULGNN_MX_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) per_cu = v; }   // tuning aid
     int64_t grid = (int64_t)cus * per_cu;
     if (grid > a.ntiles) grid = a.ntiles;

@@ -117,7 +117,7 @@ def test_every_stage_of_the_first_tile_matches_the_oracle(N, P, L, B):
                     if t < N and c >= 0:
                         want[lane], m[lane] = lc.AX[s, c, t], True
                     elif t == 15:
-                        want[lane], m[lane] = 1.0, True           # the bias partner
+                        want[lane], m[lane] = 0.0, True           # exact zero: the bias partner (1.0) is OR-ed into the split operand
                 close(taps[tb + 4 * s + r][m], want[m], f"layer {l} A.X sample {s} register {r}")
             bnout = []
             for blk, (zz, xhat) in enumerate(((lc.z1, lc.xhat1), (lc.z2, lc.xhat2))):
