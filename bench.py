@@ -90,7 +90,7 @@ def phase_names(L):
 
 def phase_bytes_per_sample(name, N, P, L):
     """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, N] fp32 state
-    tensor per sample (packed: only the N patch lanes of a row are stored) = 560 B at N = 14: X0, X_l, x-hat mask, dX,
+    tensor per sample (packed: only the N patch lanes of a row are stored) = 560 B at N = 14: X0, X_l, dX,
     d(x0+H) and the activations H, z1, o0, z2 each layer hands from phase to phase (stgcn_train.hip::SavedSlot);
     A = the [10, 10] adjacency = 400 B."""
     T = 10 * N * 4
@@ -106,10 +106,10 @@ def phase_bytes_per_sample(name, N, P, L):
     if name[0] == "F":
         if blk == 1:
             return 4 * T                               # F_{2l+1}: H, z1; write o0, z2
-        return 7 * T + A                               # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, x-hat mask, H, z1
+        return 6 * T + A                               # F_{2l}, l >= 1: X_{l-1}, A, o0, z2; write X_l, H, z1
     if blk == 1:
         return 4 * T + din                             # G_{2l+1}: z1, o0, z2, dX_{l+1}; write d(x0+H)
-    return (4 * T + A) if l == 0 else (6 * T + A + din)   # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, x-hat mask)
+    return (4 * T + A) if l == 0 else (6 * T + A + din)   # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, z2 of the layer below)
 
 
 def _traffic_profile():

@@ -69,21 +69,20 @@ enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
 // kernel arguments: the phase kernels are SGPR-bound).  Every tensor is written once per step by the phase that first has it
 // and read by the phases that would otherwise recompute it (theta projection + two convolutions per layer):
 //   X(l)   input of layer l >= 1                                       F_{2l}   -> F_{2l} (next use), TOP, G_{2l}
-//   P(l)   x-hat of BatchNorm 2l+1 where the gradient passes, else inf  F_{2l+2} -> G_{2l+2}
 //   H(l)   leaky(theta(A X_l))                                          F_{2l}   -> F_{2l+1}, G_{2l}
 //   Z1(l)  conv_block1 output (BatchNorm 2l input)                      F_{2l}   -> F_{2l+1}, G_{2l+1}, G_{2l}
 //   O0(l)  relu(relu(BN(z1)) + H): conv_block2 input                    F_{2l+1} -> F_{2l+2} / TOP, G_{2l+1}
-//   Z2(l)  conv_block2 output (BatchNorm 2l+1 input)                    F_{2l+1} -> F_{2l+2} / TOP, G_{2l+1}
+//   Z2(l)  conv_block2 output (BatchNorm 2l+1 input)                    F_{2l+1} -> F_{2l+2} / TOP, G_{2l+1}, G_{2l+2} (x-hat and
+//          the ReLU gate of BatchNorm 2l+1 for its backward sums: round 2 carried them in a tensor of their own)
 template <int L>
 struct SavedSlot {
     static constexpr int X(int l) { return l - 1; }
-    static constexpr int P(int l) { return (L - 1) + l; }
-    static constexpr int H(int l) { return 2 * (L - 1) + l; }
-    static constexpr int Z1(int l) { return 2 * (L - 1) + L + l; }
-    static constexpr int O0(int l) { return 2 * (L - 1) + 2 * L + l; }
-    static constexpr int Z2(int l) { return 2 * (L - 1) + 3 * L + l; }
+    static constexpr int H(int l) { return (L - 1) + l; }
+    static constexpr int Z1(int l) { return (L - 1) + L + l; }
+    static constexpr int O0(int l) { return (L - 1) + 2 * L + l; }
+    static constexpr int Z2(int l) { return (L - 1) + 3 * L + l; }
 };
-static inline int saved_slots(int L) { return 6 * L - 2; }
+static inline int saved_slots(int L) { return 5 * L - 1; }
 
 struct TrainK {
     // workspace regions
@@ -91,7 +90,7 @@ struct TrainK {
     float* cacheA;        // [ntiles][F][64]  lane-distributed adjacency rows
     double* cells;        // [CELL_REPLICAS][cell_stride(L)] reduction cells (see CellLayout), step scratch behind them
     float* gpart;         // [grid][param_count] per-block partial gradients
-    float* saved;         // [6L-2][ntiles][F][64]  activations carried between phases, see SavedSlot
+    float* saved;         // [5L-1][ntiles][F][64]  activations carried between phases, see SavedSlot
     float* rbuf;          // [ntiles][F][64]  d X_{l+1}: gradient entering layer l's backward (TOP / G_{2l+2} -> G_{2l+1}, G_{2l})
     float* sbuf;          // [ntiles][F][64]  d(x0 + H) of layer l (G_{2l+1} -> G_{2l})
     // outputs
@@ -516,20 +515,16 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             const float* b2 = bnc + (2 * lq + 1) * BNC * F;
             load_tile(slot(SV::O0(lq)), po0);
             load_tile(slot(SV::Z2(lq)), pz2);
-            float psv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float x1 = relu(fmaf(pz2[c], b2[2 * F + c], b2[3 * F + c]));
                 float o1 = relu(x1 + po0[c]);
-                const bool pass = o1 > 0.f && x1 > 0.f && valid;
-                psv[c] = pass ? (pz2[c] - b2[0 * F + c]) * b2[1 * F + c] : INFINITY;
                 if (a.dropout_p > 0.f) {
                     const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
                     o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
                 }
                 X[c] = valid ? o1 + X[c] : 0.f;
             }
-            store_tile_cold(slot(SV::P(lq)), psv);
             store_tile_cold(slot(SV::X(LY)), X);            // X_l is final from here on: stored for the later phases
         }
 
@@ -603,15 +598,18 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
                 if constexpr (RW == 16) adj_aggregate_mfma(A, dAX, dXl); else adj_aggregate(A, dAX, dXl);   // A is symmetric: A^T = A
                 float* rb = a.rbuf + tile * tile_floats + loff;
                 constexpr int lq = LY - 1;
-                float rbv[F], psv[F];
+                float rbv[F], pz2[F];
                 if constexpr (LY == L - 1) load_top_grad(rb, rbv); else load_tile(rb, rbv);
-                load_tile(slot(SV::P(lq)), psv);
+                // top of layer l-1: the sums of BatchNorm 2l-1 need its x-hat where the gradient passes.  Both come from the stored
+                // conv_block2 output: the gradient passes where x1 = relu(BN(z2)) > 0 (then o1 = relu(x1 + o0) > 0 as well, o0 >= 0)
+                load_tile(slot(SV::Z2(lq)), pz2);
+                const float* q2 = bnc + (2 * lq + 1) * BNC * F;
 #pragma unroll
                 for (int c = 0; c < F; ++c) {
                     const float dX = valid ? dXl[c] + rbv[c] : 0.f;               // + residual branch: d X_{l+1}
                     rbv[c] = dX;                                                   // = d X_l, read by G_{2l-1}
-                    // top of layer l-1: sums for BatchNorm 2l-1 from the saved "x-hat or +inf (gradient blocked)"
-                    const float xh = lane_ok ? psv[c] : INFINITY;
+                    const bool open = valid && fmaf(pz2[c], q2[2 * F + c], q2[3 * F + c]) > 0.f;
+                    const float xh = open ? (pz2[c] - q2[0 * F + c]) * q2[1 * F + c] : INFINITY;
                     float g = dX;
                     if (a.dropout_p > 0.f) {
                         const uint32_t h = lowbias32((ctr_base + (uint32_t)(c * N)) ^ dkey[lq]);
