@@ -257,6 +257,115 @@ __device__ __forceinline__ void tap(float* taps, bool on, int slot, int lane, fl
     }
 }
 
+// ---- front end of a tile (shared by the eval kernel and the training phase F_0) ------------------------------------------------------
+// Patch statistics (row mapping), the request for the next tile's windows, the Pearson adjacency as split B operands, and the statistics
+// in the D layout.  `gram` keeps the fp32 adjacency (gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]).
+template <int NFIX, int PFIX, bool TAPS>
+__device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const MxArgs& a, float* tileA, float* cur, int64_t tile, int ns,
+                                             int N, int P, int lane, bool tapon, float (&X0)[F], f32x16& gram, u32x4 (&adjB)[4],
+                                             float (&X)[4][3]) {
+    const int g = lane >> 4, col = lane & 15;
+    const int tileNP = N * P;
+    // ---- patch statistics, row mapping: lane (sample row g, patch col) ------------------------------------------
+    const bool valid = (g < ns) && (col < N);
+#pragma unroll
+    for (int c = 0; c < F; ++c) X0[c] = 0.f;
+    // The next tile is requested as soon as this one has left the LDS: ONE window buffer per wavefront (12.9 KB with the conversion
+    // tile at 14x30 -> twelve wavefronts per CU, three per SIMD), and the copy has the rest of the iteration to land.
+    auto request_next = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t nt = tile + gridDim.x;
+        if (nt < a.ntiles) {
+            const int64_t n0 = nt * 4;
+            const int nns = (int)((a.B - n0) < 4 ? (a.B - n0) : 4);
+            if constexpr (NFIX != 0 && PFIX != 0) {
+                if (nns == 4) dma_tile_fixed<16 * NFIX * PFIX>(gx + n0 * tileNP, tileA, lane);
+                else dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
+            } else {
+                dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
+            }
+        }
+    };
+    if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) {
+        // every lane loads (padding lanes: a patch that exists; their statistics are never computed): the copy below must run
+        // with all 64 lanes enabled -- a lane transfers ITS 16 bytes -- so nothing in front of it may tempt the compiler into
+        // one divergent region around the loads, the copy and the arithmetic
+        float v[PFIX];
+        patch_load<PFIX>(tileA + ((g < ns ? g : 0) * N + (col < N ? col : 0)) * P, v);
+        request_next();
+        if (valid) patch_statistics_lean<PFIX>(v, X0);
+
+    } else {
+        if (valid) patch_statistics(tileA + (g * N + col) * P, P, X0);
+        request_next();
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) tap<TAPS>(a.taps, tapon, c, lane, X0[c]);
+
+    // ---- Pearson adjacency: rows = channel slots, one 16x16 block per sample (f32 4-block MFMA, exact) ---------
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < F; ++c) cur[(g * 16 + chan_slot(c)) * PT_STRIDE + col] = X0[c];
+    __builtin_amdgcn_wave_barrier();
+    gram = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        // lane (sample row g, slot col) reads its channel's patch series; normalised BEFORE the Gram product
+        // (dot / (|a| |b|) == (a / |a|) . (b / |b|)); a constant series gives 0 * Inf = NaN like the reference's 0 / 0
+        // Lanes whose slot is padding read slot 0's series and scale it by 0 (one select instead of thirty).
+        const bool slot_ok = slot_chan(col) >= 0 && g < ns;
+        const float4* r4 = reinterpret_cast<const float4*>(cur + (g * 16 + (slot_chan(col) >= 0 ? col : 0)) * PT_STRIDE);
+        const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
+        float CT[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        float sum = 0.f;                           // columns t >= N were written as zeros
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += CT[k];
+        const float mean = sum * (1.0f / (float)N);
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (NFIX ? k < NFIX : true) {
+                CT[k] = (NFIX || k < N) ? CT[k] - mean : 0.f;
+                ss = fmaf(CT[k], CT[k], ss);
+            }
+        }
+        const float rn = slot_ok ? __builtin_amdgcn_rsqf(ss) : 0.f;      // ss == 0 -> Inf: 0 * Inf = NaN like the reference
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < N) {
+                const float y = CT[k] * rn;
+                gram = __builtin_amdgcn_mfma_f32_16x16x1f32(y, y, gram, 0, 0, 0);
+            }
+        }
+    }
+    // gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]: the D layout of sample b's adjacency
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, 10 + 4 * b + r, lane, gram[4 * b + r]);
+        const Split2 p01 = split2(gram[4 * b + 0], gram[4 * b + 1]), p23 = split2(gram[4 * b + 2], gram[4 * b + 3]);
+        adjB[b] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
+    }
+
+    // ---- statistics into the D layout: [row-mapped lane][16 slots] through the LDS tile ------------------------
+    __builtin_amdgcn_wave_barrier();
+    {
+        float4* w4 = reinterpret_cast<float4*>(cur + lane * PT_STRIDE);
+        w4[0] = make_float4(X0[0], X0[1], X0[2], 0.f);
+        w4[1] = make_float4(X0[3], X0[4], X0[5], 0.f);
+        w4[2] = make_float4(X0[6], X0[7], X0[8], 0.f);
+        w4[3] = make_float4(X0[9], 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(cur + (16 * s + col) * PT_STRIDE + 4 * g);
+        X[s][0] = v.x; X[s][1] = v.y; X[s][2] = v.z;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) tap<TAPS>(a.taps, tapon, 26 + 3 * s + r, lane, X[s][r]);
+    }
+}
+
 template <int LFIX, int NFIX, int PFIX, bool TAPS>
 __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
                                                                  const float* __restrict__ bn, float* __restrict__ out, MxArgs a) {
@@ -362,107 +471,11 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
 
         u32x2* sh_tile = reinterpret_cast<u32x2*>(cur + MX_MIN_BUF_BYTES / 4);      // behind the layout-conversion tile
 
-        // ---- patch statistics, row mapping: lane (sample row g, patch col) ------------------------------------------
         const bool valid = (g < ns) && (col < N);
-        float X0[F];
-#pragma unroll
-        for (int c = 0; c < F; ++c) X0[c] = 0.f;
-        // The next tile is requested as soon as this one has left the LDS: ONE window buffer per wavefront (12.9 KB with the conversion
-        // tile at 14x30 -> twelve wavefronts per CU, three per SIMD), and the copy has the rest of the iteration to land.
-        auto request_next = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const int64_t nt = tile + gridDim.x;
-            if (nt < a.ntiles) {
-                const int64_t n0 = nt * 4;
-                const int nns = (int)((a.B - n0) < 4 ? (a.B - n0) : 4);
-                if constexpr (NFIX != 0 && PFIX != 0) {
-                    if (nns == 4) dma_tile_fixed<16 * NFIX * PFIX>(gx + n0 * tileNP, tileA, lane);
-                    else dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
-                } else {
-                    dma_tile(gx + n0 * tileNP, tileA, nns * tileNP * 4, lane);
-                }
-            }
-        };
-        if constexpr (PFIX != 0 && PFIX % 2 == 0 && PFIX <= 64) {
-            // every lane loads (padding lanes: a patch that exists; their statistics are never computed): the copy below must run
-            // with all 64 lanes enabled -- a lane transfers ITS 16 bytes -- so nothing in front of it may tempt the compiler into
-            // one divergent region around the loads, the copy and the arithmetic
-            float v[PFIX];
-            patch_load<PFIX>(tileA + ((g < ns ? g : 0) * N + (col < N ? col : 0)) * P, v);
-            request_next();
-            if (valid) patch_statistics_lean<PFIX>(v, X0);
-
-        } else {
-            if (valid) patch_statistics(tileA + (g * N + col) * P, P, X0);
-            request_next();
-        }
-#pragma unroll
-        for (int c = 0; c < F; ++c) tap<TAPS>(a.taps, tapon, c, lane, X0[c]);
-
-        // ---- Pearson adjacency: rows = channel slots, one 16x16 block per sample (f32 4-block MFMA, exact) ---------
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < F; ++c) cur[(g * 16 + chan_slot(c)) * PT_STRIDE + col] = X0[c];
-        __builtin_amdgcn_wave_barrier();
-        f32x16 gram = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        {
-            // lane (sample row g, slot col) reads its channel's patch series; normalised BEFORE the Gram product
-            // (dot / (|a| |b|) == (a / |a|) . (b / |b|)); a constant series gives 0 * Inf = NaN like the reference's 0 / 0
-            // Lanes whose slot is padding read slot 0's series and scale it by 0 (one select instead of thirty).
-            const bool slot_ok = slot_chan(col) >= 0 && g < ns;
-            const float4* r4 = reinterpret_cast<const float4*>(cur + (g * 16 + (slot_chan(col) >= 0 ? col : 0)) * PT_STRIDE);
-            const float4 q0 = r4[0], q1 = r4[1], q2 = r4[2], q3 = r4[3];
-            float CT[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            float sum = 0.f;                           // columns t >= N were written as zeros
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += CT[k];
-            const float mean = sum * (1.0f / (float)N);
-            float ss = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (NFIX ? k < NFIX : true) {
-                    CT[k] = (NFIX || k < N) ? CT[k] - mean : 0.f;
-                    ss = fmaf(CT[k], CT[k], ss);
-                }
-            }
-            const float rn = slot_ok ? __builtin_amdgcn_rsqf(ss) : 0.f;      // ss == 0 -> Inf: 0 * Inf = NaN like the reference
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                if (k < N) {
-                    const float y = CT[k] * rn;
-                    gram = __builtin_amdgcn_mfma_f32_16x16x1f32(y, y, gram, 0, 0, 0);
-                }
-            }
-        }
-        // gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]: the D layout of sample b's adjacency
+        float X0[F], X[4][3];
+        f32x16 gram;
         u32x4 adjB[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tap<TAPS>(a.taps, tapon, 10 + 4 * b + r, lane, gram[4 * b + r]);
-            const Split2 p01 = split2(gram[4 * b + 0], gram[4 * b + 1]), p23 = split2(gram[4 * b + 2], gram[4 * b + 3]);
-            adjB[b] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
-        }
-
-        // ---- statistics into the D layout: [row-mapped lane][16 slots] through the LDS tile ------------------------
-        __builtin_amdgcn_wave_barrier();
-        {
-            float4* w4 = reinterpret_cast<float4*>(cur + lane * PT_STRIDE);
-            w4[0] = make_float4(X0[0], X0[1], X0[2], 0.f);
-            w4[1] = make_float4(X0[3], X0[4], X0[5], 0.f);
-            w4[2] = make_float4(X0[6], X0[7], X0[8], 0.f);
-            w4[3] = make_float4(X0[9], 0.f, 0.f, 0.f);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float X[4][3];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(cur + (16 * s + col) * PT_STRIDE + 4 * g);
-            X[s][0] = v.x; X[s][1] = v.y; X[s][2] = v.z;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) tap<TAPS>(a.taps, tapon, 26 + 3 * s + r, lane, X[s][r]);
-        }
+        mx_front_end<NFIX, PFIX, TAPS>(gx, a, tileA, cur, tile, ns, N, P, lane, tapon, X0, gram, adjB, X);
         if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};      // the padding slot of the shift tile (hi and lo halves)
 
         // The layers are the dense part of a tile; statistics, Pearson and the head are chains of LDS round trips and dependent
@@ -626,6 +639,228 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
     }
 }
 
+// =====================================================================================================================
+// Training phase F_0 on the same arithmetic (stgcn_train.hip: "forward up to the input of BatchNorm 0").
+// Reference path: ST_GCN_model.forward under model.train() up to conv_block1 of layer 0 -- models/ST_GCN/Model.py:208-216,
+// :74-90 (MPNN_mk), :134-146 (conv_block1).  Writes what the later phases read (the packed [10][4 N] tiles of stgcn_train.hip):
+// the statistics X0, the Pearson adjacency, H = leaky(theta(A X0)), z1 = conv_block1(H), and adds sum z1, sum z1^2 per channel
+// to the BatchNorm-0 reduction cells (fp64 atomics, replica blockIdx % 16).
+//
+// No safety net is needed here: up to z1 the layer is positively homogeneous in (X0, bias), so every sample is scaled by a power of
+// two 2^-k that brings its largest statistic below 128 (the bias partner of theta becomes 2^-k, an exact f16 down to k = 24) and
+// H, z1 are scaled back exactly: statistics up to ~1e9 stay inside the f16 range, NaN (constant patch) stays NaN.
+struct MxF0Out {
+    float* cacheX;         // [ntiles][10][4 N]
+    float* cacheA;         // [ntiles][10][40]
+    float* H0;             // [ntiles][10][4 N]   SavedSlot::H(0)
+    float* Z1;             // [ntiles][10][4 N]   SavedSlot::Z1(0)
+    double* cells;         // replica 0 of the BatchNorm-0 forward pair: [sum z (10) | sum z^2 (10)]
+    int cell_stride;       // doubles from one replica to the next
+    int replicas;
+};
+
+template <int NFIX, int PFIX>
+__global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+                                                                               MxArgs a, MxF0Out o) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = NFIX ? NFIX : a.N, P = PFIX ? PFIX : a.P;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, col = lane & 15;
+    const int tileNP = N * P;
+
+    int64_t tile = blockIdx.x;
+    if (tile >= a.ntiles) return;
+    {
+        const int64_t s0 = tile * 4;
+        const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
+        dma_tile(gx + s0 * tileNP, smem, ns * tileNP * 4, lane);
+    }
+
+    // ---- prologue: theta^T (leaky's (1 + a)/2 folded in) and the RAW conv_block1 weights of layer 0 as split operands ----------------
+    u32x4 theta_hi, theta_lo, w_hi, w_lo;
+    {
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g + r;
+            const bool ok = col < N && (k < N || k == 15);
+            const int idx = k == 15 ? off_theta_b(N) + col : off_theta_w(N) + col * N + k;
+            const float v = prm[ok ? idx : 0];
+            w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
+        }
+        const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
+        theta_hi = u32x4{p01.hi, p23.hi, p01.hi, p23.hi};
+        theta_lo = u32x4{p01.lo, p23.lo, p01.lo, p23.lo};
+        const int co = slot_chan(col), coc = co >= 0 ? co : 0;
+        float wc[4], wd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = slot_chan(4 * g + r);
+            const bool ok = co >= 0 && ci >= 0;
+            const float2 taps2 = *reinterpret_cast<const float2*>(prm + off_conv_w(N, 0) + (coc * F + (ci >= 0 ? ci : 0)) * 2);
+            wc[r] = ok ? taps2.y : 0.f;
+            wd[r] = ok ? taps2.x : 0.f;
+        }
+        const Split2 c01 = split2(wc[0], wc[1]), c23 = split2(wc[2], wc[3]), d01 = split2(wd[0], wd[1]), d23 = split2(wd[2], wd[3]);
+        w_hi = u32x4{c01.hi, c23.hi, d01.hi, d23.hi};
+        w_lo = u32x4{c01.lo, c23.lo, d01.lo, d23.lo};
+    }
+    const int sh_rd1 = col >= 1 ? lane - 1 : 64;
+    int sh_rd1_lo = sh_rd1 + 65;
+    asm volatile("" : "+v"(sh_rd1_lo));
+
+    // where this lane's values go in a packed [10][4 N] tile: row mapping (sample g, patch col), and D layout (channel of slot 4 g + r)
+    const int pitch = 4 * N, tile_floats = F * pitch;
+    const bool col_ok = col < N;
+    int d_off[3];
+    bool d_ok[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int c = slot_chan(4 * g + r);
+        d_ok[r] = c >= 0 && col_ok;
+        d_off[r] = (c >= 0 ? c : 0) * pitch + col;
+    }
+    const int ca_col = slot_chan(col);                    // adjacency: gram[4 b + r] of lane (g, col) = A_b[slot 4 g + r][slot col]
+    float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+
+    for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
+        float* const tileA = smem;
+        float* const cur = smem + a.buf_floats;
+        const int64_t s0 = tile * 4;
+        const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        u32x2* sh_tile = reinterpret_cast<u32x2*>(cur + MX_MIN_BUF_BYTES / 4);
+
+        float X0[F], X[4][3];
+        f32x16 gram;
+        u32x4 adjB[4];
+        mx_front_end<NFIX, PFIX, false>(gx, a, tileA, cur, tile, ns, N, P, lane, false, X0, gram, adjB, X);
+        if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};
+
+        // ---- what the later phases read of the inputs: statistics (row mapping) and adjacency -----------------------------
+        if (g < ns && col_ok) {
+            float* px = o.cacheX + tile * (int64_t)tile_floats + g * N + col;
+#pragma unroll
+            for (int c = 0; c < F; ++c) __builtin_nontemporal_store(X0[c], px + c * pitch);
+        }
+        if (ca_col >= 0) {
+            float* pa = o.cacheA + tile * (int64_t)(F * 40) + ca_col;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int c = slot_chan(4 * g + r);
+                    if (c >= 0) pa[c * 40 + b * 10] = gram[4 * b + r];
+                }
+            }
+        }
+
+        // ---- per-sample power-of-two scale: the largest |statistic| of the sample below 128 ------------------------------------
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < F; ++c) m = fmaxf(m, __builtin_fabsf(X0[c]));
+        m = fmaxf(m, dpp<DPP_QUAD_XOR1>(m));
+        m = fmaxf(m, dpp<DPP_QUAD_XOR2>(m));
+        m = fmaxf(m, dpp<DPP_ROW_HALF_MIRROR>(m));
+        m = fmaxf(m, dpp<DPP_ROW_MIRROR>(m));
+        int kexp = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu) - (127 + 6);
+        kexp = kexp < 0 ? 0 : (kexp > 24 ? 24 : kexp);
+        float sc[4], isc[4];
+        unsigned t_bias[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = __builtin_amdgcn_readlane(kexp, 16 * s);
+            sc[s] = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+            isc[s] = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+            t_bias[s] = g == 3 ? (pk_f16(0.f, sc[s]) & 0xFFFF0000u) : 0u;      // the bias partner of theta: 2^-k instead of 1
+        }
+
+        __builtin_amdgcn_s_setprio(0);
+        f32x4 T[4], Hp[4], z[4];
+        float H[4][3];
+        u32x4 bh[4], bl[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const Split2 p01 = split2(X[s][0] * sc[s], X[s][1] * sc[s]), p2 = split2(X[s][2] * sc[s], 0.f);
+            const u32x4 ah = {p01.hi, p2.hi, p01.hi, p2.hi}, al = {p01.lo, p2.lo, p01.lo, p2.lo};
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            T[s] = mfma16(ah, adjB[s], zero);
+            T[s] = mfma16(al, adjB[s], T[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const Split2 p01 = split2(T[s][0], T[s][1]), p23 = split2(T[s][2], T[s][3]);
+            const u32x4 ta = {p01.hi, p23.hi | t_bias[s], p01.lo, p23.lo};
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            Hp[s] = mfma16(ta, theta_hi, zero);
+            Hp[s] = mfma16(ta, theta_lo, Hp[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            keep_until_here(Hp[s][3]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) H[s][r] = fmaf((1.f - LEAKY) / (1.f + LEAKY), __builtin_fabsf(Hp[s][r]), Hp[s][r]);
+            const Split2 p01 = split2(H[s][0], H[s][1]), p2 = split2(H[s][2], 0.f);
+            const Shifted prev = shift_columns(sh_tile, sh_rd1, sh_rd1_lo, lane, u32x2{p01.hi, p2.hi}, u32x2{p01.lo, p2.lo});
+            bh[s] = u32x4{p01.hi, p2.hi, prev.hi.x, prev.hi.y};
+            bl[s] = u32x4{p01.lo, p2.lo, prev.lo.x, prev.lo.y};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            z[s] = mfma16(w_hi, bh[s], zero);
+            z[s] = mfma16(w_hi, bl[s], z[s]);
+            z[s] = mfma16(w_lo, bh[s], z[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- H and z1 back to their true scale, out to the phases behind, z1 into the BatchNorm sums ----------------------------
+        {
+            float* ph = o.H0 + tile * (int64_t)tile_floats;
+            float* pz = o.Z1 + tile * (int64_t)tile_floats;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                keep_until_here(z[s][3]);
+                if (s < ns) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        if (d_ok[r]) {
+                            const float hv = H[s][r] * isc[s], zv = z[s][r] * isc[s];
+                            ph[d_off[r] + s * N] = hv;
+                            pz[d_off[r] + s * N] = zv;
+                            sa[r] += zv;
+                            sb[r] = fmaf(zv, zv, sb[r]);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+    }
+
+    // ---- epilogue: this wavefront's share of sum z1, sum z1^2 (fp64 from here on), one atomic per channel and cell -------------------
+    double* cell = o.cells + (int64_t)(blockIdx.x % o.replicas) * o.cell_stride;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double da = (double)sa[r], db = (double)sb[r];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) {
+            da += __shfl_xor(da, off, 16);
+            db += __shfl_xor(db, off, 16);
+        }
+        const int c = slot_chan(4 * g + r);
+        if (col == 0 && c >= 0) {
+            atomicAdd(cell + c, da);
+            atomicAdd(cell + F + c, db);
+        }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static bool mx_shape_ok(const rulgnn_stgcn_shape* s, const float* x) {
     const int N = s->num_patch, P = s->patch_size, L = s->num_layers;
@@ -703,6 +938,43 @@ int stgcn_forward_eval_mx(const rulgnn_stgcn_shape* s, const float* x, const flo
         case 2: return mx_dispatch_shape<2, false>(s, x, prm, bn, out, stream, taps);
         default: return mx_dispatch_shape<3, false>(s, x, prm, bn, out, stream, taps);
     }
+}
+
+// Training phase F_0 (see stgcn_train_f0_mx_kernel): same shape rules as the eval kernel; RULGNN_EUNSUPPORTED -> the caller runs the
+// row-mapped fp32 phase kernel.
+int stgcn_train_f0_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* cacheX, float* cacheA, float* H0, float* Z1,
+                      double* cells_bn0, int cell_stride_doubles, int replicas, hipStream_t stream) {
+    if (!mx_shape_ok(s, x)) return RULGNN_EUNSUPPORTED;
+    if (s->batch == 0) return RULGNN_OK;
+    MxArgs a;
+    a.B = s->batch; a.ntiles = (s->batch + 3) / 4; a.N = s->num_patch; a.P = s->patch_size; a.L = s->num_layers;
+    a.buf_floats = mx_buf_floats(s);
+    a.taps = nullptr;
+    MxF0Out o;
+    o.cacheX = cacheX; o.cacheA = cacheA; o.H0 = H0; o.Z1 = Z1; o.cells = cells_bn0; o.cell_stride = cell_stride_doubles; o.replicas = replicas;
+    const size_t lds = (size_t)a.buf_floats * sizeof(float) + MX_CONV_BYTES;
+    if (lds > 64 * 1024) return RULGNN_EUNSUPPORTED;
+    auto launch = [&](auto kern) -> int {
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+        int dev = 0, cus = 256, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > MX_BLOCKS_PER_CU) per_cu = MX_BLOCKS_PER_CU;
+        if (per_cu > 4) per_cu -= per_cu % 4;
+        int64_t grid = (int64_t)cus * per_cu;
+        if (grid > a.ntiles) grid = a.ntiles;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, x, prm, a, o);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    };
+    if (s->num_patch == 14 && s->patch_size == 30) return launch(&stgcn_train_f0_mx_kernel<14, 30>);
+    if (s->num_patch == 14 && s->patch_size == 50) return launch(&stgcn_train_f0_mx_kernel<14, 50>);
+    return launch(&stgcn_train_f0_mx_kernel<0, 0>);
 }
 
 int stgcn_forward_mx_tap_floats() { return MX_TAP_SLOTS * 64; }

@@ -101,6 +101,9 @@ int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float*
 int stgcn_forward_eval_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
                           hipStream_t stream, float* taps = nullptr);
 int stgcn_forward_mx_tap_floats();
+// Training phase F_0 on the matrix cores (stgcn_forward_mx.hip); RULGNN_EUNSUPPORTED when the shape is outside its rules
+int stgcn_train_f0_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* cacheX, float* cacheA, float* H0, float* Z1,
+                      double* cells_bn0, int cell_stride_doubles, int replicas, hipStream_t stream);
 size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s);
 int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* pred,
                              void* workspace, size_t workspace_bytes, hipStream_t stream);

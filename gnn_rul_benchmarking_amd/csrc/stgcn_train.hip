@@ -1116,6 +1116,20 @@ static int launch_phase_n(const TrainK& k_in, const float* x, const float* prm, 
 template <int RW, int L, int KIND, int IDX>
 static int launch_phase(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                         hipStream_t stream, int* grid_out) {
+    if constexpr (RW == 16 && KIND == PH_F && IDX == 0) {
+        // F_0 on the f16 matrix cores (stgcn_forward_mx.hip: the eval kernel's front end and the first half of layer 0) where its
+        // shape rules hold (num_patch <= 15, 16-byte pieces); the row-mapped fp32 phase kernel below otherwise
+        rulgnn_stgcn_shape shp;
+        shp.batch = k.B; shp.num_patch = k.N; shp.patch_size = k.P; shp.num_layers = L; shp.mpnn_k = 1;
+        const size_t tile_floats = (size_t)F * (64 / RW) * k.N;
+        const int rc = stgcn_train_f0_mx(&shp, x, prm, k.cacheX, k.cacheA, k.saved + (size_t)SavedSlot<L>::H(0) * k.ntiles * tile_floats,
+                                         k.saved + (size_t)SavedSlot<L>::Z1(0) * k.ntiles * tile_floats, k.cells + cell_fwd(L), cell_stride(L),
+                                         CELL_REPLICAS, stream);
+        if (rc != RULGNN_EUNSUPPORTED) {
+            if (grid_out) *grid_out = 0;
+            return rc;
+        }
+    }
     if constexpr (RW == 16 && L == 2) {
         if constexpr (KIND == PH_F && IDX == 0) {          // the only phase that reads the windows
             if (k.N == 14 && k.P == 30) return launch_phase_n<RW, L, KIND, IDX, 14, 30>(k, x, prm, gy, g, max_grid, stream, grid_out);

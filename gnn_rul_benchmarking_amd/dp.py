@@ -63,8 +63,10 @@ class DataParallel:
         if not hasattr(model, "fused_mse_step_syncbn"):
             raise RuntimeError(f"{type(model).__name__} has no synchronised-BatchNorm step (ST_GCN only); use sync_bn=False")
         n_pairs = model.SYNC_BN_PAIRS_PER_LAYER * model.num_layers
-        if b == 0 and self.rank == 0 and global_batch > 0:
-            raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
+        # rank 0 must hold data whenever the batch is not empty (shard_bounds()): it alone contributes the BatchNorm scale / shift
+        # gradients.  A violation is raised AFTER this rank has joined every collective of the step with zeros -- raising here would
+        # leave the other ranks waiting in theirs forever.
+        violated = b == 0 and self.rank == 0 and global_batch > 0
         if b == 0:
             zero = torch.zeros(20, dtype=torch.float64, device=model.bucket.device)
             for _ in range(n_pairs):
@@ -82,6 +84,8 @@ class DataParallel:
             tail = model.bucket[model.num_live + 1:model.num_live + 1 + model._bn_batch.numel()]
             torch.mul(model._bn_batch.reshape(-1), float(b) / float(global_batch), out=tail)
         self.all_reduce_bucket(model.bucket)
+        if violated:
+            raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
         optimizer.step(from_bucket=True)
         model._after_train_forward(global_batch, from_bucket_stats=True)
         return model.bucket[model.num_live]

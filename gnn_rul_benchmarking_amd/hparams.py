@@ -8,8 +8,8 @@ PHM2012 / XJTU_SY rows are the reference's (configs/hparams.py:223,238,... and :
 :226,242,275,311,355,390,424).
 The CMAPSS / NCMAPSS rows are a BUILD EXTENSION: the reference never pairs ST_GCN with the aero-engine
 datasets although the model only needs numel/bs == num_patch*patch_size.  Here each
-sensor's window is one patch: num_patch = sensors (14 / 20), patch_size = window length (30 per
-BASELINE.json; the reference's preprocessed C-MAPSS windows are 50 long -- pass ``window=50``), with the
+sensor's window is one patch: num_patch = sensors (14 / 20), patch_size = window length (default 50, the
+reference's preprocessed C-MAPSS windows; BASELINE.json's config 0 and bench.py use 30 -- pass ``window=30``), with the
 reference's ST_GCN training parameters (lr 1e-4, wd 1e-4, 81 epochs, batch 100) and dropout 0.2."""
 from __future__ import annotations
 

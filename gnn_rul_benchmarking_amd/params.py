@@ -118,3 +118,24 @@ def mark_flat_views(module) -> None:
     module._flat_view_count = count_flat_views(module)
     for hook in list(getattr(module, "_reflatten_listeners", ())):
         hook()
+
+
+class ForwardTape:
+    """Hazard check of the autograd path of the flat-parameter models.  The activations a backward needs live in ONE workspace per
+    batch size (``model._bufs[B]``), written by every forward of that size: a second ``model(x)`` between a forward and its backward
+    (two-view losses, an evaluation inside a step) or an eviction of the workspace would silently give wrong gradients.  Every forward
+    that writes a workspace calls ``mark(B)``; the autograd Function keeps the token and ``check`` raises when it is stale."""
+
+    def __init__(self):
+        self.tokens, self.count = {}, 0
+
+    def mark(self, batch: int) -> int:
+        self.count += 1
+        self.tokens[int(batch)] = self.count
+        return self.count
+
+    def check(self, batch: int, token: int, bufs: dict, name: str) -> None:
+        if self.tokens.get(int(batch)) != token or int(batch) not in bufs:
+            raise RuntimeError(f"{name}: another forward of this batch size ran between this forward and its backward (or its workspace "
+                               "was evicted); the saved activations live in one workspace per batch size, not per call, and were "
+                               "overwritten. Call backward() before the next model(x), or use Algorithm.update.")

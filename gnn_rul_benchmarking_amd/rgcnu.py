@@ -81,14 +81,16 @@ class _Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, training, *params):
         pred, std = model._forward(x, training)
-        ctx.model, ctx.x, ctx.step = model, x, model._step
+        ctx.model, ctx.x, ctx.step, ctx.training = model, x, model._step, bool(training)
+        ctx.tape = model._tape.tokens[x.size(0)]
         ctx.mark_non_differentiable(std)
         return pred.clone().view(-1, 1), std.clone().view(-1, 1)
 
     @staticmethod
     def backward(ctx, dpred, _dstd):
         model = ctx.model
-        grads = model._backward(ctx.x, dpred.reshape(-1).contiguous().float(), ctx.step)
+        model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "RGCNU_model")
+        grads = model._backward(ctx.x, dpred.reshape(-1).contiguous().float(), ctx.step, ctx.training)
         outs = [grads[off:off + n].view(shape).clone() for off, n, shape in model._slices]
         return (None, None, None, *outs)
 
@@ -122,6 +124,7 @@ class RGCNU_model(nn.Module):
         self.num_optimized = self._layout["fusion.fc2.weight"][0]
         self._flat = self._grad_flat = None
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._tape = PL.ForwardTape()
         self._reflatten()
 
     # ---- flat storage ----------------------------------------------------------------------------------
@@ -211,13 +214,15 @@ class RGCNU_model(nn.Module):
         if training:
             self._step += 1
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred, std = self._args(shp, x, training, self._step)
         _lib.check(_lib.load().rulgnn_rgcnu_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_rgcnu_forward_f32")
         return pred[:x.size(0)], std[:x.size(0)]
 
-    def _backward(self, x, dpred, step):
+    def _backward(self, x, dpred, step, training=True):
+        """``training`` must be the flag of the forward this backward belongs to: the dropout mask of rg_scl_bwd is applied only then."""
         shp = self._shape(x.size(0))
-        a, _, _ = self._args(shp, x, True, step, dpred=dpred)
+        a, _, _ = self._args(shp, x, training, step, dpred=dpred)
         _lib.check(_lib.load().rulgnn_rgcnu_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_rgcnu_backward_f32")
         return self._grad_flat
 
@@ -230,6 +235,7 @@ class RGCNU_model(nn.Module):
             raise RuntimeError("target size mismatch")
         self._step += 1
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred, _ = self._args(shp, x, True, self._step, y=yv, global_batch=global_batch, sample_offset=sample_offset)
         o = None
         if optimizer is not None:

@@ -54,11 +54,13 @@ class _Function(torch.autograd.Function):
     def forward(ctx, model, x, *params):
         pred = model._forward(x)
         ctx.model, ctx.x = model, x
+        ctx.tape = model._tape.tokens[x.size(0)]
         return pred.clone().view(-1, 1)
 
     @staticmethod
     def backward(ctx, dpred):
         model = ctx.model
+        model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "SAGCN_model")
         grads = model._backward(ctx.x, dpred.reshape(-1).contiguous().float())
         return (None, None, *[grads[off:off + n].view(shape).clone() for off, n, shape in model._slices])
 
@@ -82,6 +84,7 @@ class SAGCN_model(nn.Module):
         self._count = off
         self._flat = self._grad_flat = None
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._tape = PL.ForwardTape()
         self._reflatten()
 
     # ---- flat storage ----------------------------------------------------------------------------------
@@ -165,6 +168,7 @@ class SAGCN_model(nn.Module):
 
     def _forward(self, x):
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x)
         _lib.check(_lib.load().rulgnn_sagcn_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_sagcn_forward_f32")
         return pred[:x.size(0)]
@@ -196,6 +200,7 @@ class SAGCN_model(nn.Module):
         if yv.numel() != x.size(0):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
         o = None
         if optimizer is not None:

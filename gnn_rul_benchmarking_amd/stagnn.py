@@ -106,11 +106,13 @@ class _TrainFunction(torch.autograd.Function):
         pred = model._run_forward(x, training=True)
         model._nbt_pending += 1
         ctx.model, ctx.x = model, x
+        ctx.tape = model._tape.tokens[x.size(0)]
         return pred.clone().view(-1, 1)
 
     @staticmethod
     def backward(ctx, dpred):
         model = ctx.model
+        model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "STAGNN_model")
         grads = model._run_backward(ctx.x, dpred.reshape(-1).contiguous().float())
         return (None, None, *[grads[off:off + n].view(shape).clone() for off, n, shape in model._slices])
 
@@ -144,6 +146,7 @@ class STAGNN_model(nn.Module):
         self._bn_channels = (h, h, self.output_dim, self.output_dim)
         self._flat = self._bn = self._nbt = self._grad_flat = None
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._tape = PL.ForwardTape()
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
         self._reflatten()
@@ -256,6 +259,7 @@ class STAGNN_model(nn.Module):
 
     def _run_forward(self, x, training):
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, training)
         _lib.check(_lib.load().rulgnn_stagnn_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stagnn_forward_f32")
         return pred[:x.size(0)]
@@ -283,6 +287,7 @@ class STAGNN_model(nn.Module):
         if yv.numel() != x.size(0):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, True, y=yv, global_batch=global_batch, update_running_stats=update_running_stats)
         o = None
         if optimizer is not None:

@@ -41,11 +41,13 @@ class _Function(torch.autograd.Function):
     def forward(ctx, model, x, *params):
         pred, recon = model._forward(x)
         ctx.model, ctx.x = model, x
+        ctx.tape = model._tape.tokens[x.size(0)]
         return pred.clone().view(-1, 1), recon.clone()
 
     @staticmethod
     def backward(ctx, dpred, drecon):
         model = ctx.model
+        model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "STNet_model")
         if drecon is None or abs(float(drecon) - 1.0) > 1e-6:
             raise RuntimeError("STNet_model: the reconstruction loss must enter the objective with weight 1 (algorithms.py:458); "
                                f"got d loss / d reconstruction = {None if drecon is None else float(drecon)}")
@@ -81,6 +83,7 @@ class STNet_model(nn.Module):
         self.optimized_range = (3, off)          # cnn.weight [2] + cnn.bias [1] come first and have no gradient
         self._flat = self._grad_flat = None
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._tape = PL.ForwardTape()
         self._reflatten()
 
     # ---- flat storage ----------------------------------------------------------------------------------
@@ -173,6 +176,7 @@ class STNet_model(nn.Module):
 
     def _forward(self, x):
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x)
         _lib.check(_lib.load().rulgnn_stnet_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stnet_forward_f32")
         return pred[:x.size(0)], self._grad_flat[self._count + 1]
@@ -191,6 +195,7 @@ class STNet_model(nn.Module):
         if yv.numel() != x.size(0):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x.size(0))
+        self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
         o = None
         if optimizer is not None:

@@ -114,3 +114,21 @@ def test_noop_to_keeps_the_flat_buffers_and_a_real_move_notifies_listeners(famil
     assert model.flat_params is not flat and calls == [1]
     after = model.state_dict()
     assert list(after) == list(before) and all(torch.equal(after[k], before[k]) for k in before)
+
+
+def test_forward_tape_tokens():
+    """params.ForwardTape: the token of a batch size changes with every forward that writes its workspace; a stale token or an evicted
+    workspace raises (the four flat-parameter models of round 2 use it in their autograd Functions)."""
+    from gnn_rul_benchmarking_amd.params import ForwardTape
+    tape, bufs = ForwardTape(), {8: object(), 4: object()}
+    t8 = tape.mark(8)
+    t4 = tape.mark(4)
+    tape.check(8, t8, bufs, "M")
+    tape.check(4, t4, bufs, "M")
+    tape.mark(8)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        tape.check(8, t8, bufs, "M")
+    tape.check(4, t4, bufs, "M")
+    del bufs[4]
+    with pytest.raises(RuntimeError, match="evicted"):
+        tape.check(4, t4, bufs, "M")

@@ -153,3 +153,21 @@ def test_median_rank_tie_rule_on_exactly_mirrored_spectra():
         ref = O.extract_features(x, P, n)
         assert rel(feat[:, :, 13], ref[:, :, 13]) < TOL and rel(feat[:, :, 19], ref[:, :, 19]) < TOL
         assert (ref[:, :, 13] < 0).any() and (ref[:, :, 13] > 0).any()
+
+
+def test_autograd_backward_after_a_second_forward_raises_instead_of_using_overwritten_activations():
+    """One workspace per batch size holds the saved activations (params.ForwardTape, advisor finding of round 2): a second forward of
+    the same size between a forward and its backward must raise; the latest forward still owns the workspace."""
+    z, cfg, p = load_case("sagcn_phm_c2like_9x20_bs4")
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    m = build_model(cfg, p).train()
+    p1 = m(x)
+    with torch.no_grad():
+        m(x * 0.5)                                       # e.g. an evaluation inside the step
+    with pytest.raises(RuntimeError, match="overwritten"):
+        p1.sum().backward()
+    p2 = m(x)
+    torch.nn.functional.mse_loss(p2, y).backward()
+    m2 = build_model(cfg, p).train()
+    m2.fused_mse_step(x, y)
+    assert torch.equal(torch.cat([t.grad.reshape(-1) for t in m._named()]), m2._grad_flat[:m2.num_live])
