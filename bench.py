@@ -114,7 +114,7 @@ def phase_bytes_per_sample(name, N, P, L):
 
 def _traffic_profile():
     """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh): newest round first."""
-    for name in ("r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             t["file"] = "profiles/" + name
@@ -137,15 +137,16 @@ def measured_traffic(kernel_key, N, P, B):
 
 def forward_traffic(N, P, B):
     """HBM bytes per launch of the fused eval forward from its own PMC passes (tools/profile_forward.sh ->
-    profiles/r02_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
+    profiles/r0N_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
     the bench's other launches of that name), or None when this batch was not profiled."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", f"r02_forward_bs{B}_hbm_traffic.json")))
-        w = t["workload"]
-        if (w["num_patch"], w["patch_size"], w["batch"]) == (N, P, B):
-            return round(t["kernels"]["EVAL"]["hbm_bytes_per_launch"])
-    except Exception:
-        pass
+    for rnd in ("r03", "r02"):                     # newest round first
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_forward_bs{B}_hbm_traffic.json")))
+            w = t["workload"]
+            if (w["num_patch"], w["patch_size"], w["batch"]) == (N, P, B):
+                return round(t["kernels"]["EVAL"]["hbm_bytes_per_launch"])
+        except Exception:
+            continue
     return None
 
 

@@ -12,9 +12,6 @@
 // The 2 * num_patch recurrences of a layer run concurrently on different CUs; layers are sequentially dependent.
 #include <utility>
 
-#ifndef LSTM_FAST_GATES
-#define LSTM_FAST_GATES 1
-#endif
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
@@ -62,17 +59,12 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
 
 // The gate non-linearities sit on the critical path of every sequential step (0.27 us of 0.95 with libm's expf / tanhf and
 // IEEE division): hardware exp2 and reciprocal instead (v_exp_f32, v_rcp_f32: ~1 ulp each, ~2e-7 absolute on the outputs).
-#if LSTM_FAST_GATES
 __device__ inline float sigm(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ inline float tanh_gate(float v) {
     const float a = fabsf(v);
     const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a));        // exp overflow -> rcp(inf) = 0 -> 1
     return copysignf(t, v);
 }
-#else
-__device__ inline float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
-__device__ inline float tanh_gate(float v) { return tanhf(v); }
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // forward recurrence: workgroup = (direction, sequence); thread j < 4H owns gate row j of W_hh

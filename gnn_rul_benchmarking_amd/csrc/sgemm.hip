@@ -600,9 +600,7 @@ static inline bool sgemm_wide_ok(const GemmArgs& g, int slices) {
 // (defined once, in rulgnn_api.hip: this header is included by several translation units)
 int& sgemm_big_mode();
 
-#ifndef SGEMM_BIG_KT
-#define SGEMM_BIG_KT 16
-#endif
+constexpr int SGEMM_BIG_KT = 16;      // k depth of an LDS stage of the 128x128 kernel
 // the 128x128 kernel pays when both output dimensions fill most of a tile and there are enough tiles for the chip
 static inline bool sgemm_big_ok(const GemmArgs& g, int slices) {
     if (g.M <= 96 || g.N <= 96 || g.K < 16) return false;

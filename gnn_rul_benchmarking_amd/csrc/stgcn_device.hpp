@@ -9,9 +9,6 @@
 //
 // Math follows reference models/ST_GCN/Model.py (line numbers cited at each block).
 #pragma once
-#ifndef STAGE_NT
-#define STAGE_NT 1   // the windows are read once per step: nontemporal loads (F0 alone 64 -> 60 us)
-#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -593,7 +590,6 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ g, float* s
             // CH loads are issued back to back (clamped index, no branch around the load) before the
             // first LDS store: the rolled load->wait->store loop exposed one HBM latency per float4.
             constexpr int CH = 4;
-            const float4* g4 = reinterpret_cast<const float4*>(g);
             float4* s4 = reinterpret_cast<float4*>(stage);
             const int n4 = total >> 2;
             for (int base = lane; base < n4; base += CH * 64) {
@@ -601,12 +597,9 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ g, float* s
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
                     const int i = base + u * 64;
-#if STAGE_NT
+                    // the windows are read once per step: nontemporal loads (F0 alone 64 -> 60 us)
                     const f32x4 nv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + (i < n4 ? i : n4 - 1));
                     r[u] = make_float4(nv[0], nv[1], nv[2], nv[3]);
-#else
-                    r[u] = g4[i < n4 ? i : n4 - 1];
-#endif
                 }
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {

@@ -41,29 +41,8 @@ constexpr int CONVT_FLOATS = F * 2 * F;     // one transposed conv weight block 
 constexpr int BNC = 7;                      // per-BatchNorm constants: mean, istd, scale, shift, gamma*istd, k1, k2
 
 enum PhaseKind { PH_F = 0, PH_TOP = 1, PH_G = 2 };
-#ifndef PHASE_WAVES_F1
-#define PHASE_WAVES_F1 5
-#define PHASE_WAVES_F2 4
-#define PHASE_WAVES_TOP 3
-#define PHASE_WAVES_G1 3
-#define PHASE_WAVES_G0 3
-#endif
-#ifndef PHASE_ALTERNATE
-#define PHASE_ALTERNATE true
-#endif
-#ifndef NT_ALL_STORES
-#define NT_ALL_STORES false
-#endif
-#ifndef NT_COLD_STORES
-#define NT_COLD_STORES true
-#endif
-#ifndef LDS_CONVT
-#define LDS_CONVT true
-#endif
-#ifndef FRESH_G1
-#define FRESH_G1 true
-#define FRESH_G0 false
-#endif
+// Wavefronts per SIMD the phase kernels are compiled for (launch bounds; measured per phase at batch 65536: tighter bounds spill)
+constexpr int PHASE_WAVES_F1 = 5, PHASE_WAVES_F2 = 4, PHASE_WAVES_TOP = 3, PHASE_WAVES_G1 = 3, PHASE_WAVES_G0 = 3;
 
 // Activations carried from phase to phase through HBM, one [ntiles][F][64] lane-major tensor per slot (ONE base pointer in the
 // kernel arguments: the phase kernels are SGPR-bound).  Every tensor is written once per step by the phase that first has it
@@ -289,7 +268,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     using SV = SavedSlot<L>;
     // where the LDS weights pay (measured per phase, batch 65536): G_{2l} (86 -> 64 us, 46 -> 40 us: the scalar path spilled),
     // F_{2l+1} (29 -> 28 us); G_{2l+1} and F_{2l} are 1-2 us better on scalar-operand weights
-    constexpr bool CONV_FROM_LDS = LDS_CONVT && ((KIND == PH_G && IDX % 2 == 0) || (KIND == PH_F && IDX % 2 == 1));
+    constexpr bool CONV_FROM_LDS = (KIND == PH_G && IDX % 2 == 0) || (KIND == PH_F && IDX % 2 == 1);
     // what this phase reads besides the saved activations: the layer input (F_{2l}: aggregation, G_{2l}: theta gradient,
     // TOP: last residual) and the adjacency (F_{2l}, G_{2l})
     constexpr bool NEED_A = KIND != PH_TOP && BLK == 0;
@@ -404,8 +383,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
         if (lane_ok) {
 #pragma unroll
             for (int c = 0; c < F; ++c) {
-                if constexpr (NT_ALL_STORES) __builtin_nontemporal_store(v[c], p + c * pitch);
-                else p[c * pitch] = v[c];
+                p[c * pitch] = v[c];
             }
         }
     };
@@ -414,8 +392,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
         if (lane_ok) {
 #pragma unroll
             for (int c = 0; c < F; ++c) {
-                if constexpr (NT_COLD_STORES) __builtin_nontemporal_store(v[c], p + c * pitch);
-                else p[c * pitch] = v[c];
+                __builtin_nontemporal_store(v[c], p + c * pitch);
             }
         }
     };
@@ -444,7 +421,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     // Successive phases walk the tiles in opposite directions: what a phase wrote (or read) last is what the next one
     // touches first, while it is still in the 256 MB Infinity Cache.
     constexpr int CHAIN_POS = KIND == PH_F ? IDX : (KIND == PH_TOP ? NBN : NBN + 1 + (NBN - 1 - IDX));
-    constexpr bool REVERSED = PHASE_ALTERNATE && (CHAIN_POS % 2 == 1);
+    constexpr bool REVERSED = CHAIN_POS % 2 == 1;
     for (int64_t it = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave; it < a.ntiles; it += (int64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int64_t tile = REVERSED ? a.ntiles - 1 - it : it;
         const int64_t s0 = tile * TSPW;
@@ -581,7 +558,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             }
             float dH[F];
             if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 1>(dz, convT, t, dH);
-            else causal_conv_T<RW, 1>(dz, conv_weights<FRESH_G0, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
+            else causal_conv_T<RW, 1>(dz, conv_weights<false, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float g = dH[c] + g0[c];
@@ -744,7 +721,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             }
             float d_o0[F];
             if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 2>(dz, convT, t, d_o0);
-            else causal_conv_T<RW, 2>(dz, conv_weights<FRESH_G1, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
+            else causal_conv_T<RW, 2>(dz, conv_weights<true, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
             float sbv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {

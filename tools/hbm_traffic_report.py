@@ -14,6 +14,8 @@ def collect(sub, counter):
             m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)*>", r["Kernel_Name"])
             if m:
                 name = {"0": "F", "1": "TOP", "2": "G"}[m.group(3)] + (m.group(4) if m.group(3) != "1" else "")
+            elif "stgcn_train_f0_mx_kernel" in r["Kernel_Name"]:      # phase F_0 on the matrix cores (round 3)
+                name = "F0"
             elif "stgcn_forward_mx_kernel<2, 14, 30" in r["Kernel_Name"] or "stgcn_forward_eval" in r["Kernel_Name"]:
                 name = "EVAL"
             else:

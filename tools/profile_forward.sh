@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/profile_forward.sh <tag>   -- the fused eval forward kernels alone, batch 65536 and 1M:
 # rocprofv3 kernel stats, then FETCH_SIZE / WRITE_SIZE in separate passes (HBM traffic per launch), then the SQ counter passes
-tag=${1:-r02}
+tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for B in 65536 1048576; do
   d=gpurun_out/$tag/fwd_$B
