@@ -1,5 +1,6 @@
 """-m gpu: the cooperative single-launch training step (RULGNN_STEP_COOP: all phases inside one kernel, BatchNorm reductions behind
-device-side grid barriers) against the phase chain (RULGNN_STEP_CHAIN) -- bit for bit -- and against the fp64 oracle."""
+device-side grid barriers) against the phase chain (RULGNN_STEP_CHAIN) -- bit for bit where both run the same arithmetic -- and
+against the fp64 oracle."""
 import ctypes as C
 
 import numpy as np
@@ -26,7 +27,7 @@ def _algo(N, P, L, p, path, seed=3):
 @pytest.mark.parametrize("N,P,L,B,p", [(14, 30, 2, 100, 0.2), (14, 30, 2, 1, 0.0), (14, 30, 2, 1024, 0.2), (14, 50, 2, 100, 0.2),
                                        (14, 30, 3, 77, 0.1), (14, 30, 1, 33, 0.2), (9, 21, 2, 130, 0.2), (40, 64, 2, 100, 0.2),
                                        (40, 64, 1, 17, 0.0)])
-def test_cooperative_step_is_bit_identical_to_the_phase_chain(N, P, L, B, p):
+def test_cooperative_step_equals_the_phase_chain(N, P, L, B, p):
     g = torch.Generator(device=DEV).manual_seed(B)
     xs = [torch.rand(B, N, P, device=DEV, generator=g) for _ in range(3)]
     ys = [torch.rand(B, 1, device=DEV, generator=g) for _ in range(3)]
@@ -36,9 +37,23 @@ def test_cooperative_step_is_bit_identical_to_the_phase_chain(N, P, L, B, p):
         losses = [a.update(x, y, 1)["loss"].clone() for x, y in zip(xs, ys)]           # fused Adam inside the step
         pred = a.model._pred_buf.clone()
         out[path] = (torch.stack(losses), a.model.flat_params.clone(), a.model.bucket[:a.model.num_live].clone(), a.model._bn.clone(), pred)
+    # The chain runs phase F_0 on the f16 matrix cores where that kernel's shape rules hold (round 3: num_patch <= 15, 16-byte pieces;
+    # split-operand products, ~1e-7 relative); the cooperative kernel keeps the row-mapped fp32 body for every phase.  Bit equality
+    # therefore holds where both run the same arithmetic (num_patch 40); elsewhere the two agree to fp32 rounding through three
+    # Adam steps.
+    same_arithmetic = N > 15 or (N * P) % 4 != 0
     for c, k in zip(out[_lib.STEP_CHAIN], out[_lib.STEP_COOP]):
         assert torch.isfinite(c).all()
-        assert torch.equal(c, k)
+        if same_arithmetic:
+            assert torch.equal(c, k)
+    if not same_arithmetic:
+        (lc, pc, gc, bc, qc), (lk, pk, gk, bk, qk) = out[_lib.STEP_CHAIN], out[_lib.STEP_COOP]
+        assert abs(float(lc[0] - lk[0])) <= 1e-6 + 1e-5 * abs(float(lc[0]))        # first step: same weights, predictions differ by ~1e-7
+        assert torch.allclose(lc, lk, rtol=1e-3, atol=1e-5)                         # Adam (lr 1e-3, sign-like for tiny gradients) in between
+        assert float((gc - gk).abs().max()) <= 2e-3 * float(gc.abs().max())         # third step's gradient, norm-wise
+        assert float((qc - qk).abs().max()) <= 1e-3 * float(qc.abs().max())
+        assert float((bc - bk).abs().max()) <= 1e-4 * float(bc.abs().max())         # BatchNorm running statistics
+        assert float((pc - pk).abs().max()) <= 3 * 1e-3 + 1e-6                      # three Adam steps move a weight by at most 3 lr
 
 
 def test_cooperative_forward_backward_matches_fp64_oracle_and_rejects_large_batches():
