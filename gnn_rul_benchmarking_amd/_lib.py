@@ -250,6 +250,8 @@ _SIGNATURES = {
     "rulgnn_fcstgnn_forward_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.c_void_p]),
     "rulgnn_fcstgnn_backward_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.c_void_p]),
     "rulgnn_fcstgnn_fwdbwd_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_fcstgnn_fwdbwd_syncbn_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.POINTER(FcstgnnArgs), C.c_float, ALLREDUCE_F64_FN,
+                                                    C.c_void_p, C.c_void_p]),
     "rulgnn_fcstgnn_bn_running_update_f32": (C.c_int, [C.POINTER(FcstgnnShape), C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
                                                         C.c_void_p]),
     "rulgnn_hagcn_graph_param_count": (C.c_int64, [C.POINTER(HagcnShape)]),
@@ -271,6 +273,8 @@ _SIGNATURES = {
     "rulgnn_astgcnn_forward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
     "rulgnn_astgcnn_backward_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_void_p]),
     "rulgnn_astgcnn_fwdbwd_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_astgcnn_fwdbwd_syncbn_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.POINTER(AstgcnnArgs), C.c_float, ALLREDUCE_F64_FN,
+                                                    C.c_void_p, C.c_void_p]),
     "rulgnn_astgcnn_bn_running_update_f32": (C.c_int, [C.POINTER(AstgcnnShape), C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
                                                         C.c_int32, C.c_void_p]),
     "rulgnn_stmsgcn_param_count": (C.c_int64, [C.POINTER(StmsgcnShape)]),

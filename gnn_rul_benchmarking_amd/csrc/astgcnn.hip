@@ -23,6 +23,7 @@ using namespace tcn;               // AB, KT (Model.py:236), MAXN (torch.cdist's
 
 struct AstGeom {
     int64_t B;
+    int64_t BG;             // samples behind the BatchNorm statistics: B, or the GLOBAL batch under synchronised BatchNorm
     int N, T, E, O, K, KE;
     int o_w1, o_g1, o_b1, o_w2, o_g2, o_b2, o_thw, o_thb, o_gb, o_pw, o_f, o_fcw, o_fcb, nparam;
 };
@@ -33,6 +34,7 @@ __host__ int ast_geometry(const rulgnn_astgcnn_shape* s, AstGeom* g) {
     if (s->num_nodes > MAXN || s->time_length > MAXT || s->output_dim > 256 || s->K > 3) return RULGNN_EUNSUPPORTED;
     if (s->batch * (int64_t)s->num_nodes > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
     g->B = s->batch;
+    g->BG = s->batch;
     g->N = s->num_nodes;
     g->T = g->E = s->time_length;          // the gate multiplies [N, E] by [N, T] elementwise: E == T (Model.py:181)
     g->O = s->output_dim;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(AB) void ast_gate_kernel(AstGeom g, const float* __
     for (int64_t e = (int64_t)blockIdx.x * AB + threadIdx.x; e < total; e += (int64_t)gridDim.x * AB) {
         const int64_t row = e / T;
         const int t = (int)(e - row * T), c = (int)(row % N);
-        const BnCoef k = bn_coef(cells, bn_running, training, 1, c, N, (double)g.B * T, prm[g.o_g2 + c], prm[g.o_b2 + c]);
+        const BnCoef k = bn_coef(cells, bn_running, training, 1, c, N, (double)g.BG * T, prm[g.o_g2 + c], prm[g.o_b2 + c]);
         const float y = fmaf(z2[e], k.sc, k.sh);
         const float o1 = fmaxf(fmaxf(y, 0.f) + out0[e], 0.f);
         const float zg = tanhf(zpre[e] + prm[g.o_thb + t] + prm[g.o_gb + t]);
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float
     __shared__ float sx[MAXN][MAXT + 1];
     __shared__ BnCoef co2[MAXN];
     const int N = g.N, T = g.T, tid = threadIdx.x;
-    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.B * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
     float a1 = 0.f, a2 = 0.f;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -295,13 +297,28 @@ __global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float
 }
 
 // finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
-__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads) {
+// (x bn_scale: under synchronised BatchNorm the cells hold GLOBAL sums on every rank and only one rank may contribute them)
+__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads, float bn_scale) {
     const int c = blockIdx.x * AB + threadIdx.x;
     if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
-        grads[g.o_g1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
-        grads[g.o_b1 + c] = (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
-        grads[g.o_g2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
-        grads[g.o_b2 + c] = (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
+        grads[g.o_g1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
+        grads[g.o_b1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
+        grads[g.o_g2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
+        grads[g.o_b2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
+    }
+}
+
+// Synchronised BatchNorm: the 16 replicas of one reduction pair (2 MAXN contiguous doubles) collapsed into replica 0, the
+// others zeroed (the readers' replica sum is unchanged): the caller's all-reduce runs on one contiguous buffer.
+__global__ void ast_cells_collapse_kernel(Cells* cells, int bwd, int blk) {
+    for (int i = threadIdx.x; i < 2 * MAXN; i += blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < CELL_REP; ++r) {
+            double* p = bwd ? &cells[r].bwd[blk][0][0] : &cells[r].fwd[blk][0][0];
+            v += p[i];
+            if (r) p[i] = 0.0;
+        }
+        (bwd ? &cells[0].bwd[blk][0][0] : &cells[0].fwd[blk][0][0])[i] = v;
     }
 }
 
@@ -310,7 +327,7 @@ __global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __rest
     const int e = threadIdx.x;
     if (e >= 2 * g.N) return;
     const int blk = e / g.N, c = e % g.N;
-    const double count = (double)g.B * g.T;
+    const double count = (double)g.BG * g.T;
     const double m = cell_sum(cells, &Cells::fwd, blk, c, 0) / count, q = cell_sum(cells, &Cells::fwd, blk, c, 1) / count;
     if (weight > 0.f) {
         bn_batch[(blk * 2 + 0) * g.N + c] = (float)(weight * m);
@@ -417,9 +434,13 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
     } while (0)
 
 // mode bit 0: forward (training != 0: batch statistics), bit 1: backward
-int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st) {
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync) {
     AstGeom g;
     AST_RC(ast_geometry(s, &g));
+    if (sync) {          // both BatchNorm layers normalise by the statistics of the GLOBAL batch (cells all-reduced between the kernels)
+        if (mode != 3 || !a->training || a->global_batch < g.B || g.B < 1 || a->bn_moment_weight > 0.f) return RULGNN_EINVAL;
+        g.BG = a->global_batch;
+    }
     AstWs w;
     ast_ws_layout(g, &w);
     if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
@@ -432,13 +453,22 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
     const int M = (int)(g.B * N);
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
     (void)hipGetLastError();
+    auto sync_pair = [&](int bwd, int blk) -> int {
+        if (!sync) return RULGNN_OK;
+        hipLaunchKernelGGL(ast_cells_collapse_kernel, dim3(1), dim3(64), 0, st, cells, bwd, blk);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        double* buf = bwd ? &cells[0].bwd[blk][0][0] : &cells[0].fwd[blk][0][0];
+        return sync->fn(sync->user, buf, 2 * MAXN, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
+    };
     if (mode & 1) {
         if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
         const int rows = resident_rows((tcn_conv_kernel<1, AstGeom>), g.B, 1 << 20);
         hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
                            F(w.z1), (float*)nullptr, cells);
+        AST_RC(sync_pair(0, 0));
         hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
                            F(w.z2), F(w.out0), cells);
+        AST_RC(sync_pair(0, 1));
         // Zpre = x theta^T
         AST_RC(sgemm(a->x, T, 1, prm + g.o_thw, T, 1, F(w.zpre), E, M, E, T, false, st));
         {
@@ -480,18 +510,20 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
         hipLaunchKernelGGL(ast_gate_bwd_kernel, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.out1),
                            (const float*)F(w.dg), F(w.zpre), F(w.ds1), F(w.dy2));
+        AST_RC(sync_pair(1, 1));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, st));
         AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, st));
         if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, st) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
+        AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         const bool mse = a->dpred == nullptr;
         AST_RC(rows_sum(F(w.gp1), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w1, st));
         AST_RC(rows_sum(F(w.gp2), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w2, st));
-        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr);
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
         if (mse && a->loss)
             (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);
     }

@@ -801,9 +801,25 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
     }
 }
 
-// conv partial rows -> gradients; BatchNorm gamma / beta gradients from the cells
+// Synchronised BatchNorm: the 16 replicas of ONE reduction pair (forward: sum z, sum z^2; backward: sum dy, sum dy x-hat;
+// 2 MAXC contiguous doubles) are collapsed into replica 0 and the others zeroed -- the readers' replica sum is unchanged -- so that
+// the caller's all-reduce runs on one contiguous buffer.
+__global__ void fc_cells_collapse_kernel(Cells* cells, int bwd, int id) {
+    for (int i = threadIdx.x; i < 2 * MAXC; i += blockDim.x) {
+        double v = 0.0;
+        for (int r = 0; r < CELL_REP; ++r) {
+            double* p = bwd ? &cells[r].bwd[id][0][0] : &cells[r].fwd[id][0][0];
+            v += p[i];
+            if (r) p[i] = 0.0;
+        }
+        (bwd ? &cells[0].bwd[id][0][0] : &cells[0].fwd[id][0][0])[i] = v;
+    }
+}
+
+// conv partial rows -> gradients; BatchNorm gamma / beta gradients from the cells (x bn_scale: under synchronised BatchNorm the
+// cells hold GLOBAL sums on every rank and only one rank may contribute them to the all-reduced gradient)
 __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2, int rows,
-                                                        const Cells* cells, float* __restrict__ grads) {
+                                                        const Cells* cells, float* __restrict__ grads, float bn_scale) {
     // one wavefront per value: lanes stride over the partial rows, then a fixed-order butterfly (deterministic)
     const int e = (blockIdx.x * FB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     const int n1 = g.H1 * g.K, n2 = g.CO * g.H1 * g.K;
@@ -819,8 +835,8 @@ __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* 
         int c = e - n1 - n2;
         for (int id = 0; id < NBN; ++id) {
             if (c < g.bn_ch[id]) {
-                grads[g.bn_g[id] + c] = (float)cell_bwd(cells, id, c, 1);
-                grads[g.bn_b[id] + c] = (float)cell_bwd(cells, id, c, 0);
+                grads[g.bn_g[id] + c] = bn_scale * (float)cell_bwd(cells, id, c, 1);
+                grads[g.bn_b[id] + c] = bn_scale * (float)cell_bwd(cells, id, c, 0);
                 return;
             }
             c -= g.bn_ch[id];
@@ -958,9 +974,16 @@ size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s) {
     } while (0)
 
 // mode bit 0: forward (args->training selects batch / running statistics), bit 1: backward
-int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st) {
+int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st, const FcstgnnSync* sync) {
     FcGeom g;
     FC_RC(fc_geometry(s, &g));
+    if (sync) {
+        // every BatchNorm normalises by the statistics of the GLOBAL batch: the cells are all-reduced between the kernel that
+        // completes a pair and its first reader, and the element counts are those of the global batch
+        if (mode != 3 || !a->training || a->global_batch < g.B || g.B < 1 || a->bn_moment_weight > 0.f) return RULGNN_EINVAL;
+        const double scale = (double)a->global_batch / (double)g.B;
+        for (int i = 0; i < NBN; ++i) g.cnt[i] *= scale;
+    }
     FcWs w;
     fc_ws_layout(g, &w);
     if (a->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
@@ -987,19 +1010,31 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const uint32_t* key_dev = a->step_state ? static_cast<const StepState*>(a->step_state)->drop_key : nullptr;
     const int64_t row_off = a->sample_offset * g.NP * g.N;
     (void)hipGetLastError();
+    auto sync_pair = [&](int bwd, int id) -> int {
+        if (!sync) return RULGNN_OK;
+        hipLaunchKernelGGL(fc_cells_collapse_kernel, dim3(1), dim3(128), 0, st, cells, bwd, id);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        double* buf = bwd ? &cells[0].bwd[id][0][0] : &cells[0].fwd[id][0][0];
+        return sync->fn(sync->user, buf, 2 * MAXC, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
+    };
 
     if (mode & 1) {
         if (training && a->step_state) FC_RC(step_prepare_dropout(a->step_state, a->seed, 1, st));
         if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL(fc_conv1_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
+        FC_RC(sync_pair(0, 0));
         hipLaunchKernelGGL(fc_conv2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2), cells,
                            training);
+        FC_RC(sync_pair(0, 1));
         hipLaunchKernelGGL(fc_act2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
                            (const float*)P_(w.z2), P_(w.a2));
         FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st, bf));
         hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, P_(w.z3), prm + g.o_b3, g.M, D2, cells, 2, training);
+        FC_RC(sync_pair(0, 2));
         hipLaunchKernelGGL(fc_pe_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, run, cells, training, (const float*)P_(w.z3),
                            P_(w.F), thr, dscale, key, key_dev, row_off);
+        FC_RC(sync_pair(0, 3));
+        FC_RC(sync_pair(0, 5));
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
             FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
@@ -1008,6 +1043,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
             hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
                                (int64_t)GQ, HD, cells, 4 + 2 * b, training);
+            FC_RC(sync_pair(0, 4 + 2 * b));
         }
         for (int b = 0; b < 2; ++b)
             hipLaunchKernelGGL(fc_pool_kernel, dim3(grid_for(g.G[b] * g.N * HD)), dim3(FB), 0, st, g, b, prm, run, (const Cells*)cells,
@@ -1055,6 +1091,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             float* dz5 = P_(w.dz5[b]);
             hipLaunchKernelGGL(fc_pool_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, b, prm, cells,
                                (const float*)P_(w.z5[b]), (const float*)P_(w.dfeat), dz5);
+            FC_RC(sync_pair(1, 4 + 2 * b));
             hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
                                (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
             FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, st));
@@ -1075,6 +1112,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         }
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
+        FC_RC(sync_pair(1, 3));
+        FC_RC(sync_pair(1, 5));
         hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
                            (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
         for (int b = 0; b < 2; ++b) {
@@ -1085,6 +1124,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // ---- positional encoding / dropout, Linear + BatchNorm ----
         hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
                            dscale, key, key_dev, row_off);
+        FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);
         FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, st));
@@ -1093,10 +1133,12 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // ---- encoder convolutions ----
         hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
                            (const float*)P_(w.a2), P_(w.da2));
+        FC_RC(sync_pair(1, 1));
         hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, 1, g.L2, prm, (const Cells*)cells,
                            (const float*)P_(w.z2), P_(w.da2), g.M * CL);
         hipLaunchKernelGGL(fc_conv2_dx_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z1),
                            (const float*)P_(w.da2), P_(w.dy1));
+        FC_RC(sync_pair(1, 0));
         const int rows = (int)(g.M < w.rows ? g.M : w.rows);
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
                            (const float*)P_(w.da2), P_(w.gp2));
@@ -1107,7 +1149,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
         hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
-                           (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr);
+                           (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
         if (!a->dpred && a->loss)
             (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, st);
     }

@@ -342,6 +342,15 @@ int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_as
                                      opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
 }
 
+int rulgnn_astgcnn_fwdbwd_syncbn_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_astgcnn_args* args, float bn_param_grad_scale,
+                                     rulgnn_allreduce_f64_fn allreduce, void* user, void* stream) {
+    const int rc = check_astgcnn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred || !allreduce || !(bn_param_grad_scale >= 0.f && bn_param_grad_scale <= 1.f)) return RULGNN_EINVAL;
+    const BnSyncHook hook = {allreduce, user, bn_param_grad_scale};
+    return astgcnn_run(shape, args, 3, static_cast<hipStream_t>(stream), &hook);
+}
+
 int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape* shape, float* bn_stats, const float* bn_batch, int64_t count,
                                          float momentum, int32_t from_moments, void* stream) {
     if (!shape || count < 1) return RULGNN_EINVAL;
@@ -427,6 +436,15 @@ int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fc
                    opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
     if (rc != RULGNN_OK || !opt->bn_stats) return rc;
     return fcstgnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
+}
+
+int rulgnn_fcstgnn_fwdbwd_syncbn_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fcstgnn_args* args, float bn_param_grad_scale,
+                                     rulgnn_allreduce_f64_fn allreduce, void* user, void* stream) {
+    const int rc = check_fcstgnn(shape, args, true, true);
+    if (rc != RULGNN_OK) return rc;
+    if (args->dpred || !allreduce || !(bn_param_grad_scale >= 0.f && bn_param_grad_scale <= 1.f)) return RULGNN_EINVAL;
+    const BnSyncHook hook = {allreduce, user, bn_param_grad_scale};
+    return fcstgnn_run(shape, args, 3, static_cast<hipStream_t>(stream), &hook);
 }
 
 int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape* shape, float* bn_stats, const float* bn_batch, float momentum,

@@ -24,6 +24,7 @@ constexpr int PADR = KT - 1 - PADL;
 
 struct ScGeom {
     int64_t B;
+    int64_t BG;             // samples behind the BatchNorm statistics: B, or the GLOBAL batch under synchronised BatchNorm
     int N, T, NT;
     int o_th, o_gw, o_gb, o_cw, o_cb, o_gc, o_bc, o_w1, o_g1, o_b1, o_w2, o_g2, o_b2, o_fcw, o_fcb, nparam;
 };
@@ -34,6 +35,7 @@ __host__ int sc_geometry(const rulgnn_stconv_shape* s, ScGeom* g) {
     if (s->kernel_size != KT || s->num_nodes > MAXN || s->time_length > MAXT) return RULGNN_EUNSUPPORTED;
     if (s->batch * (int64_t)s->num_nodes > ((int64_t)1 << 30)) return RULGNN_EUNSUPPORTED;
     g->B = s->batch;
+    g->BG = s->batch;
     g->N = s->num_nodes;
     g->T = s->time_length;
     g->NT = g->N * g->T;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(AB) void sc_head_kernel(ScGeom g, const float* __re
     __shared__ float red[AB];
     __shared__ float sums[BACKWARD ? 4 : 1][MAXN][MAXT + 1];     // per-element BatchNorm backward terms of one sample
     const int N = g.N, T = g.T, tid = threadIdx.x;
-    const double count = (double)g.B * T;
+    const double count = (double)g.BG * T;
     if (tid < N) {
         c2[tid] = bn_coef(cells, bn_running, training, 1, tid, N, count, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
         cc[tid] = bnc_coef(c3, bn_running, training, tid, N, count, prm[g.o_gc + tid], prm[g.o_bc + tid]);
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(AB) void sc_cnn_bwd_kernel(ScGeom g, const float* _
     __shared__ BnCoef cc[MAXN];
     __shared__ float bsum[MAXN][2];
     const int N = g.N, T = g.T, tid = threadIdx.x;
-    const double count = (double)g.B * T;
+    const double count = (double)g.BG * T;
     const int nW = N * N * KT, nOut = nW + N;
     for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_cw + e];
     for (int e = tid; e < N * (KT - 1); e += AB) {
@@ -380,7 +382,7 @@ __global__ void sc_bn_batch_kernel(ScGeom g, const Cells* cells, const Cells3* c
     const int e = threadIdx.x;
     if (e >= 3 * g.N) return;
     const int blk = e / g.N, c = e % g.N;
-    const double count = (double)g.B * g.T;
+    const double count = (double)g.BG * g.T;
     const double s = blk < 2 ? cell_sum(cells, &Cells::fwd, blk, c, 0) : cell3_fwd(c3, c, 0), q2 = blk < 2 ? cell_sum(cells, &Cells::fwd, blk, c, 1) : cell3_fwd(c3, c, 1);
     const double m = s / count, q = q2 / count;
     if (weight > 0.f) {

@@ -124,13 +124,21 @@ int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float*
 int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int mode, hipStream_t stream);
 int64_t astgcnn_param_count(const rulgnn_astgcnn_shape* s);
 size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s);
-int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream);
+struct BnSyncHook;
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream, const BnSyncHook* sync = nullptr);
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
                               int from_moments, hipStream_t stream);
 int64_t fcstgnn_param_count(const rulgnn_fcstgnn_shape* s);
 int64_t fcstgnn_bn_count(const rulgnn_fcstgnn_shape* s);
 size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s);
-int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t stream);
+// synchronised BatchNorm hook of the FC_STGNN / ASTGCNN steps (include/rulgnn.h: rulgnn_*_fwdbwd_syncbn_f32)
+struct BnSyncHook {
+    rulgnn_allreduce_f64_fn fn;
+    void* user;
+    float bn_param_grad_scale;
+};
+typedef BnSyncHook FcstgnnSync;
+int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t stream, const FcstgnnSync* sync = nullptr);
 int fcstgnn_bn_running_update(const rulgnn_fcstgnn_shape* s, float* bn_stats, const float* bn_batch, float momentum, int from_moments,
                               hipStream_t stream);
 int64_t hagcn_graph_param_count(const rulgnn_hagcn_shape* s);

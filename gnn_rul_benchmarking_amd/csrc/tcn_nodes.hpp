@@ -2,7 +2,8 @@
 // TemporalConvNet(num_nodes, [num_nodes, num_nodes], kernel_size=6): models/ASTGCNN/Model.py:72-146, models/ST_Conv/Model.py:81-155):
 // two causal Conv1d(N -> N, k = 6, dilation 1 | 2, no bias) + BatchNorm1d(N) + ReLU blocks with residuals over [N nodes] x [T steps].
 // One sample per workgroup iteration, tile in LDS, BatchNorm sums through fp64 cells.  `Geom` provides
-// B, N, T and the parameter offsets o_w1, o_g1, o_b1, o_w2, o_g2, o_b2.
+// B, BG (the samples behind the BatchNorm statistics: B, or the global batch under synchronised BatchNorm), N, T and the parameter
+// offsets o_w1, o_g1, o_b1, o_w2, o_g2, o_b2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -76,7 +77,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
     for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
     for (int e = tid; e < N * PADL; e += AB) xs[e / PADL][e % PADL] = 0.f;
     if (STAGE == 2 && tid < N)
-        co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.B * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
+        co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.BG * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
     float s1 = 0.f, s2 = 0.f;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -142,7 +143,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     __shared__ BnCoef cz[MAXN], c1[MAXN];
     __shared__ float bsum[MAXN][2];
     const int N = g.N, T = g.T, tid = threadIdx.x, blk = STAGE - 1;
-    const double count = (double)g.B * T;
+    const double count = (double)g.BG * T;
     const int nW = N * N * KT;
     if (STAGE == 2)
         for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_w2 + e];

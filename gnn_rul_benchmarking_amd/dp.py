@@ -61,19 +61,20 @@ class DataParallel:
         joins the same collectives with zeros."""
         b = X_shard.size(0)
         if not hasattr(model, "fused_mse_step_syncbn"):
-            raise RuntimeError(f"{type(model).__name__} has no synchronised-BatchNorm step (ST_GCN only); use sync_bn=False")
-        n_pairs = model.SYNC_BN_PAIRS_PER_LAYER * model.num_layers
+            raise RuntimeError(f"{type(model).__name__} has no synchronised-BatchNorm step (ST_GCN, FC_STGNN and ASTGCNN do); "
+                               "use sync_bn=False")
+        schedule = model.sync_bn_schedule()
         # rank 0 must hold data whenever the batch is not empty (shard_bounds()): it alone contributes the BatchNorm scale / shift
         # gradients.  A violation is raised AFTER this rank has joined every collective of the step with zeros -- raising here would
         # leave the other ranks waiting in theirs forever.
         violated = b == 0 and self.rank == 0 and global_batch > 0
         if b == 0:
-            zero = torch.zeros(20, dtype=torch.float64, device=model.bucket.device)
-            for _ in range(n_pairs):
+            for n in schedule:
+                zero = torch.zeros(n, dtype=torch.float64, device=model.bucket.device)
                 dist.all_reduce(zero, op=dist.ReduceOp.SUM, group=self.group)
-                zero.zero_()
             model.bucket.zero_()
-            model._step += 1
+            if hasattr(model, "_step"):
+                model._step += 1
         else:
             # the BatchNorm scale / shift gradients come out of the all-reduced cells, i.e. they are already the global sums on every
             # rank: rank 0 (never empty under shard_bounds) contributes them to the bucket, the others contribute zero

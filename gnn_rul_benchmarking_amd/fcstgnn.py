@@ -287,10 +287,12 @@ class FC_STGNN_RUL(nn.Module):
         _lib.check(_lib.load().rulgnn_fcstgnn_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_fcstgnn_backward_f32")
         return self._grad_flat
 
-    def _after_train_forward(self, batch=None, from_bucket_moments=False):
+    def _after_train_forward(self, batch=None, from_bucket_moments=False, from_bucket_stats=False):
         """BatchNorm side effects of a training forward.  ``batch``: the (global) batch the statistics were taken over;
-        only needed when it differs from the last forward's (data parallel)."""
-        src = self._grad_flat.data_ptr() + 4 * (self._count + 1) if from_bucket_moments else self._bn_batch.data_ptr()
+        only needed when it differs from the last forward's (data parallel).  ``from_bucket_moments``: the bucket tail holds
+        the all-reduced (E[z], E[z^2]) (local BatchNorm); ``from_bucket_stats``: it holds the global (mean, var) (synchronised)."""
+        in_bucket = from_bucket_moments or from_bucket_stats
+        src = self._grad_flat.data_ptr() + 4 * (self._count + 1) if in_bucket else self._bn_batch.data_ptr()
         shp = self._shape(int(batch) if batch is not None else self._pred_buf.numel())
         _lib.check(_lib.load().rulgnn_fcstgnn_bn_running_update_f32(C.byref(shp), self._bn.data_ptr(), src, 0.1,
                                                                     1 if from_bucket_moments else 0, _stream()),
@@ -322,6 +324,42 @@ class FC_STGNN_RUL(nn.Module):
             self._nbt_pending += 1
         elif update_running_stats:
             self._after_train_forward(x2d.size(0))
+        return self._pred_buf, self._grad_flat[self._count]
+
+    def sync_bn_schedule(self):
+        """float64 counts of the all-reduces one synchronised-BatchNorm step issues, in order (dp.py: a rank with an empty shard joins
+        them with zeros)."""
+        return [128] * 14
+
+    def fused_mse_step_syncbn(self, x, y, global_batch, sample_offset, bn_param_grad_scale, allreduce):
+        """``fused_mse_step`` on this rank's shard with every BatchNorm normalising by the GLOBAL batch's statistics (dp.py,
+        ``DataParallel(sync_bn=True)``; rulgnn_fcstgnn_fwdbwd_syncbn_f32).  ``allreduce(view)`` is called 14 times with a float64 view of 128 reduction cells
+        inside the workspace and must SUM it over the ranks in place, in stream order.  Fills ``self.bucket`` such that a SUM over the
+        ranks is the global-batch gradient / loss (the BatchNorm scale / shift gradients are global sums on every rank and enter
+        multiplied by ``bn_param_grad_scale``), and ``self._bn_batch`` with the global (mean, biased variance)."""
+        x2d = self._check_input(x)
+        yv = y.reshape(-1).contiguous().float()
+        if yv.numel() != x2d.size(0):
+            raise RuntimeError("target size mismatch")
+        self._step += 1
+        shp = self._shape(x2d.size(0))
+        a = self._args(shp, x2d, True, self._step, y=yv, global_batch=global_batch, sample_offset=sample_offset)
+        ws = self._ws
+        base, failure = ws.data_ptr(), []
+
+        def hook(_user, buf, count, _stream):
+            try:
+                off = int(buf) - base
+                allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
+                return 0
+            except BaseException as e:          # never let an exception cross the C frame
+                failure.append(e)
+                return 1
+        cb = _lib.ALLREDUCE_F64_FN(hook)
+        rc = _lib.load().rulgnn_fcstgnn_fwdbwd_syncbn_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None, _stream())
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "rulgnn_fcstgnn_fwdbwd_syncbn_f32")
         return self._pred_buf, self._grad_flat[self._count]
 
     # ---- nn.Module surface -----------------------------------------------------------------------------

@@ -318,6 +318,10 @@ class ST_GCN_model(nn.Module):
 
     SYNC_BN_PAIRS_PER_LAYER = 4      # all-reduces per layer and step under synchronised BatchNorm: 2 forward + 2 backward pairs
 
+    def sync_bn_schedule(self):
+        """float64 counts of the all-reduces one synchronised-BatchNorm step issues, in order (dp.py)."""
+        return [20] * (self.SYNC_BN_PAIRS_PER_LAYER * self.num_layers)
+
     def fused_mse_step_syncbn(self, x, y, global_batch, sample_offset, bn_param_grad_scale, allreduce):
         """``fused_mse_step`` on this rank's shard with every BatchNorm normalising by the GLOBAL batch's statistics (dp.py,
         ``DataParallel(sync_bn=True)``).  ``allreduce(view)`` is called 4 L times with a float64 view of 20 reduction cells inside

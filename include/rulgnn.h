@@ -334,6 +334,14 @@ int rulgnn_astgcnn_backward_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_
 int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_astgcnn_args *args,
                               const rulgnn_adam_args *opt, void *stream);
 /* nn.BatchNorm1d running-statistics update for this model's two BatchNorm layers (count = batch * time_length). */
+/* rulgnn_astgcnn_fwdbwd_f32 on this rank's shard with both BatchNorm layers of the TemporalConvNet (Model.py:72-146) normalising by
+ * the statistics of the GLOBAL batch, the contract of rulgnn_stgcn_train_fwdbwd_syncbn_f32: `allreduce` is
+ * called 4 times per step (forward pairs of block 1, block 2, then backward pairs of block 2, block 1) with a device pointer to
+ * 50 contiguous doubles inside args->workspace; counts are global_batch * time_length; args->bn_batch receives the global (mean,
+ * biased variance) (bn_moment_weight must be 0); the BatchNorm scale / shift gradients are written multiplied by bn_param_grad_scale.
+ * A rank with an empty shard makes no call and joins the 4 all-reduces with zeros.  training != 0, no dpred. */
+int rulgnn_astgcnn_fwdbwd_syncbn_f32(const rulgnn_astgcnn_shape *shape, const rulgnn_astgcnn_args *args, float bn_param_grad_scale,
+                                     rulgnn_allreduce_f64_fn allreduce, void *user, void *stream);
 int rulgnn_astgcnn_bn_running_update_f32(const rulgnn_astgcnn_shape *shape, float *bn_stats, const float *bn_batch,
                                          int64_t count, float momentum, int32_t from_moments, void *stream);
 
@@ -417,6 +425,15 @@ int rulgnn_fcstgnn_backward_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_
 /* FC_STGNN.update body (algorithms.py:67-74); with `opt` also Adam and the running statistics (opt->bn_stats). */
 int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fcstgnn_args *args,
                               const rulgnn_adam_args *opt, void *stream);
+/* rulgnn_fcstgnn_fwdbwd_f32 on this rank's shard with all SEVEN BatchNorm layers (Model_Base.py:12-41,72-107,175-225; Model.py:19-22)
+ * normalising by the statistics of the GLOBAL batch, the contract of rulgnn_stgcn_train_fwdbwd_syncbn_f32:
+ * `allreduce` is called 14 times per step (forward pairs of layers 0,1,2,3,5,4,6, then backward pairs of 4,6,3,5,2,1,0, the same
+ * order on every rank) with a device pointer to 128 contiguous doubles inside args->workspace; element counts are those of
+ * args->global_batch; args->bn_batch receives the global (mean, biased variance) (bn_moment_weight must be 0); the BatchNorm scale /
+ * shift gradients are written multiplied by bn_param_grad_scale.  A rank with an empty shard makes no call and joins the 14
+ * all-reduces with zeros.  training != 0, no dpred. */
+int rulgnn_fcstgnn_fwdbwd_syncbn_f32(const rulgnn_fcstgnn_shape *shape, const rulgnn_fcstgnn_args *args, float bn_param_grad_scale,
+                                     rulgnn_allreduce_f64_fn allreduce, void *user, void *stream);
 int rulgnn_fcstgnn_bn_running_update_f32(const rulgnn_fcstgnn_shape *shape, float *bn_stats, const float *bn_batch,
                                          float momentum, int32_t from_moments, void *stream);
 

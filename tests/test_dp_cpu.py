@@ -509,6 +509,9 @@ class SyncOracleModel(OracleModel):
     SYNC_BN_PAIRS_PER_LAYER = 4
     num_layers = L
 
+    def sync_bn_schedule(self):
+        return [20] * (self.SYNC_BN_PAIRS_PER_LAYER * self.num_layers)
+
     def __init__(self, prm, dropout=0.2, seed=7):
         super().__init__(prm, dropout, seed)
         self._bn_batch = torch.zeros(PL.bn_buffer_count(L), dtype=torch.float32)

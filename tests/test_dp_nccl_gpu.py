@@ -79,3 +79,28 @@ def test_family_data_parallel_step_over_rccl_equals_the_single_process_step(nccl
     for (k, va), vb in zip(ref.model.state_dict().items(), dp.model.state_dict().values()):
         if va.dtype.is_floating_point:
             assert torch.allclose(va, vb, rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("name,ds,did,shape", [("FC_STGNN", "CMAPSS", "FD004", (14, 50)), ("ASTGCNN", "NCMAPSS", "DS02", (20, 50))])
+def test_family_synchronised_batchnorm_step_over_rccl_equals_the_single_process_step(nccl_world_of_one, name, ds, did, shape):
+    """DataParallel(sync_bn=True) for the two other BatchNorm families (round 3): 14 / 4 all-reduces of reduction cells + the bucket."""
+    from gnn_rul_benchmarking_amd import hparams as HP
+    from gnn_rul_benchmarking_amd.dp import DataParallel
+    hp = HP.get_hparams_class(ds)(did)
+    cfg, tc = hp.alg_hparams[name], hp.train_params[name]
+    ref, dp = _algo(name, cfg, tc), _algo(name, cfg, tc)
+    dp.model.load_state_dict(ref.model.state_dict())
+    if hasattr(ref.model, "_seed"):
+        dp.model._seed = ref.model._seed
+    dp.attach_data_parallel(DataParallel(sync_bn=True))
+    g = torch.Generator(device=DEV).manual_seed(7)
+    for step in range(2):
+        x = torch.rand(32, *shape, device=DEV, generator=g)
+        y = torch.rand(32, 1, device=DEV, generator=g)
+        la, lb = ref.update(x, y, step)["loss"], dp.update(x, y, step)["loss"]
+        assert abs(la - lb) <= 1e-5 * abs(la), (step, la, lb)
+    for (k, va), vb in zip(ref.model.state_dict().items(), dp.model.state_dict().values()):
+        if va.dtype.is_floating_point:
+            assert torch.allclose(va, vb, rtol=1e-4, atol=1e-6), k
+        else:
+            assert torch.equal(va, vb), k
