@@ -170,6 +170,7 @@ class BilstmArgs(C.Structure):
 
 # rulgnn_allreduce_f64_fn: int (*)(void *user, double *device_buf, int32_t count, void *stream)
 ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+GRAD_READY_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
 
 _SIGNATURES = {
     "rulgnn_stnet_param_count": (C.c_int64, [C.POINTER(StnetShape)]),
@@ -213,6 +214,7 @@ _SIGNATURES = {
     "rulgnn_stgcn_train_forward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_backward_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
     "rulgnn_stgcn_train_fwdbwd_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_void_p]),
+    "rulgnn_stgcn_train_fwdbwd_ready_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), GRAD_READY_FN, C.c_void_p, C.c_void_p]),
     "rulgnn_stgcn_train_fwdbwd_syncbn_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_float, ALLREDUCE_F64_FN,
                                                         C.c_void_p, C.c_void_p]),
     "rulgnn_stgcn_train_step_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs),

@@ -145,6 +145,18 @@ int rulgnn_stgcn_train_fwdbwd_f32(const rulgnn_stgcn_shape* shape, const rulgnn_
     return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));
 }
 
+int rulgnn_stgcn_train_fwdbwd_ready_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, rulgnn_grad_ready_fn ready,
+                                        void* user, void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (!ready) return RULGNN_EINVAL;
+    if (tiled(shape)) {
+        const GradReadyHook hook = {ready, user};
+        return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream), &hook);
+    }
+    return stgcn_train_fwdbwd(shape, args, static_cast<hipStream_t>(stream));     // buckets of a few KB: nothing to overlap
+}
+
 int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
                                          float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void* user, void* stream) {
     const int rc = check_train(shape, args, true);

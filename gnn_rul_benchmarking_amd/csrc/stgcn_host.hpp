@@ -108,7 +108,13 @@ size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s);
 int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* pred,
                              void* workspace, size_t workspace_bytes, hipStream_t stream);
 size_t stgcn_tiled_train_workspace_bytes(const rulgnn_stgcn_shape* s);
-int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream);
+// optional "these gradients are final" callback of the tiled training step (include/rulgnn.h: rulgnn_grad_ready_fn)
+struct GradReadyHook {
+    rulgnn_grad_ready_fn fn;
+    void* user;
+};
+int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
+                      const GradReadyHook* ready = nullptr);
 size_t stgcn_train_workspace_bytes(const rulgnn_stgcn_shape* s);
 int stgcn_train_forward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream);
 int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream);

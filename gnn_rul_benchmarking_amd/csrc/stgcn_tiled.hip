@@ -846,7 +846,7 @@ size_t stgcn_tiled_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
 __global__ void t_fill_one_kernel(float* p) { p[0] = 1.f; }
 
 int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* ar, int mode /* 0 fwd, 1 bwd, 2 both */,
-                      hipStream_t stream) {
+                      hipStream_t stream, const GradReadyHook* ready) {
     TWs w;
     tws_layout(s, &w);
     if (ar->workspace_bytes < w.total) return RULGNN_EWORKSPACE;
@@ -934,6 +934,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         if (rc != RULGNN_OK) return rc;
         rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
+        // data parallel with overlap: the head's gradients (fc1 is N x N: 4 MB at XJTU-SY) are final here, with the whole layer
+        // stack still to run -- the caller may start their all-reduce on another stream (include/rulgnn.h: rulgnn_grad_ready_fn)
+        if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(param_count(N, L) - off_fc1_w(N, L)), stream) != 0)
+            return RULGNN_ECALLBACK;
         rc = sgemm(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, stream);
         if (rc != RULGNN_OK) return rc;
         for (int l = L - 1; l >= 0; --l) {
@@ -952,6 +956,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (rc != RULGNN_OK) return rc;
             rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
             if (rc != RULGNN_OK) return rc;
+            // theta of this layer (weight + bias, contiguous at the head of the layer's block) is final; the convolution and
+            // BatchNorm gradients behind it (2 x 220 floats) come out of t_finalize_kernel at the end of the step
+            if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, stream) != 0)
+                return RULGNN_ECALLBACK;
             if (l > 0) {
                 rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;

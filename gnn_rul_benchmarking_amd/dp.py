@@ -56,6 +56,49 @@ class DataParallel:
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
 
+    # ---- large buckets: all-reduce in gradient-ready order, overlapped with the rest of the backward -------------------------
+    OVERLAP_MIN_BYTES = 1 << 20          # below this one blocking all-reduce is latency-bound either way
+
+    def _overlapped_step(self, model, X_shard, y_shard, global_batch, sample_offset):
+        """``fused_mse_step`` of a model whose backward reports final gradient regions (ST_GCN's tiled path: theta / fc1 are
+        num_patch x num_patch, a 12.6 MB bucket at XJTU-SY).  Each reported region is all-reduced on a side stream as soon as the
+        kernels that finalise it have been enqueued -- behind an event recorded on the compute stream -- while the compute stream
+        carries on with the layers below; whatever was not reported goes out when the step has been enqueued; the compute stream
+        then waits for the side stream.  Every bucket element is summed over the ranks exactly once."""
+        bucket = model.bucket
+        compute = torch.cuda.current_stream()
+        if getattr(self, "_comm_stream", None) is None or self._comm_stream.device != bucket.device:
+            self._comm_stream = torch.cuda.Stream(device=bucket.device)
+        comm = self._comm_stream
+        done = []
+
+        def launch(offset, count):
+            ev = torch.cuda.Event()
+            ev.record(compute)
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                dist.all_reduce(bucket[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
+            done.append((offset, offset + count))
+
+        model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset, update_running_stats=False,
+                             moments_to_bucket=True, grad_ready=launch)
+        # the complement of the reported regions, in ascending order
+        pos, rest = 0, []
+        for lo, hi in sorted(done):
+            if lo < pos:
+                raise RuntimeError("overlapping gradient-ready regions")
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = hi
+        if pos < bucket.numel():
+            rest.append((pos, bucket.numel()))
+        for lo, hi in rest:
+            launch(lo, hi - lo)
+        fin = torch.cuda.Event()
+        fin.record(comm)
+        compute.wait_event(fin)
+        self.last_overlap_regions = sorted(done)      # (tests / diagnostics)
+
     def _sync_bn_step(self, model, optimizer, X_shard, y_shard, global_batch, sample_offset):
         """Synchronised-BatchNorm step: the model's phase chain calls back for every BatchNorm reduction pair; an empty shard
         joins the same collectives with zeros."""
@@ -109,6 +152,12 @@ class DataParallel:
             model.bucket.zero_()
             if hasattr(model, "_step"):
                 model._step += 1                                     # dropout stream position: in lockstep with the other ranks
+        elif batch_coupled and getattr(model, "reports_ready_gradients", False) and model.bucket.is_cuda and \
+                model.bucket.numel() * 4 >= self.OVERLAP_MIN_BYTES:
+            self._overlapped_step(model, X_shard, y_shard, global_batch, sample_offset)
+            optimizer.step(from_bucket=True)
+            model._after_train_forward(global_batch, from_bucket_moments=True)
+            return model.bucket[model.num_live]
         elif batch_coupled:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
                                  update_running_stats=False, moments_to_bucket=True)

@@ -299,10 +299,15 @@ class ST_GCN_model(nn.Module):
         return self._grad_flat
 
     def fused_mse_step(self, x, y, global_batch=None, sample_offset=0, update_running_stats=True,
-                       moments_to_bucket=False):
+                       moments_to_bucket=False, grad_ready=None):
         """forward + MSE + backward in one C call (what ``ST_GCN.update`` needs before the optimizer):
         fills ``self.bucket`` = [grad | loss | ...] and returns (pred [B], loss 0-d tensor), all on
-        the device, no host synchronisation."""
+        the device, no host synchronisation.
+
+        ``grad_ready(offset, count)`` (data parallel, dp.py): called while the backward is still being enqueued, each time a region
+        ``bucket[offset:offset + count]`` has become final in stream order (rulgnn_stgcn_train_fwdbwd_ready_f32: the head and the
+        theta blocks of the tiled path, num_patch > 64, whose bucket is megabytes); the callee starts that region's all-reduce on
+        another stream.  What is not reported is final when the call's work has drained."""
         x2d = self._check_input(x)
         yv = y.reshape(-1).contiguous().float()
         if yv.numel() != x2d.size(0):
@@ -310,11 +315,33 @@ class ST_GCN_model(nn.Module):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket)
-        _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), None, int(self.step_path), _stream()),
-                   "rulgnn_stgcn_train_step_path_f32")
+        if grad_ready is not None:
+            failure = []
+
+            def hook(_user, _grads, offset, count, _stream):
+                try:
+                    grad_ready(int(offset), int(count))
+                    return 0
+                except BaseException as e:          # never let an exception cross the C frame
+                    failure.append(e)
+                    return 1
+            cb = _lib.GRAD_READY_FN(hook)
+            rc = _lib.load().rulgnn_stgcn_train_fwdbwd_ready_f32(C.byref(shp), C.byref(a), cb, None, _stream())
+            if failure:
+                raise failure[0]
+            _lib.check(rc, "rulgnn_stgcn_train_fwdbwd_ready_f32")
+        else:
+            _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), None, int(self.step_path), _stream()),
+                       "rulgnn_stgcn_train_step_path_f32")
         if update_running_stats:
             self._after_train_forward(x2d.size(0))
         return self._pred_buf, self._grad_flat[self.num_live]
+
+    @property
+    def reports_ready_gradients(self):
+        """True where ``fused_mse_step(grad_ready=...)`` reports regions (the tiled path: num_patch > 64); dp.py overlaps their
+        all-reduce with the rest of the backward when the bucket is large enough."""
+        return self.num_patch > 64
 
     SYNC_BN_PAIRS_PER_LAYER = 4      # all-reduces per layer and step under synchronised BatchNorm: 2 forward + 2 backward pairs
 

@@ -160,6 +160,20 @@ int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape *shape, const 
                                          float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void *user,
                                          void *stream);
 
+/* Data parallel with a LARGE gradient bucket (num_patch > 64: theta and fc1 are num_patch x num_patch -- 12.6 MB at the reference's
+ * XJTU-SY wiring, configs/hparams.py:349): rulgnn_stgcn_train_fwdbwd_f32 that reports gradient regions as they become final, so
+ * that the caller can all-reduce them on another stream while the rest of the backward runs ("overlap with
+ * backward").  `ready(user, grads, offset, count, stream)` is called from the launching thread right after the kernels that finalise
+ * args->grads[offset, offset + count) were enqueued on `stream`; the callback must order whatever it starts after the work queued
+ * on `stream` so far (record an event there and make its own stream wait for it) and must not touch the rest of args->grads.  Regions
+ * are disjoint and reported in backward order: the head (fc1 | fc2 at the tail of the flat buffer) first, then theta (weight | bias) of
+ * every layer but the first; everything that is not reported (the first layer, the convolution and BatchNorm gradients, the loss) is
+ * final when the call returns and its work has drained, as with the plain entry.  Shapes of the fused kernels (num_patch <= 64:
+ * buckets of a few KB) make no callback.  Returns RULGNN_ECALLBACK when `ready` returns non-zero. */
+typedef int (*rulgnn_grad_ready_fn)(void *user, float *grads, int64_t offset, int64_t count, void *stream);
+int rulgnn_stgcn_train_fwdbwd_ready_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                        rulgnn_grad_ready_fn ready, void *user, void *stream);
+
 /* Single-GPU fast path: rulgnn_stgcn_train_fwdbwd_f32 with the optimizer folded into its last kernel --
  * the whole body of ST_GCN.update (algorithms/algorithms.py:482-489) in one call: the kernel that
  * reduces the per-block gradient partials applies torch.optim.Adam to each parameter as its gradient

@@ -104,3 +104,37 @@ def test_family_synchronised_batchnorm_step_over_rccl_equals_the_single_process_
             assert torch.allclose(va, vb, rtol=1e-4, atol=1e-6), k
         else:
             assert torch.equal(va, vb), k
+
+
+def test_large_bucket_step_overlaps_the_all_reduce_in_gradient_ready_order(nccl_world_of_one):
+    """ST_GCN at a tiled shape (num_patch 512 > 64: theta and fc1 are 512 x 512, a 3.2 MB bucket): dp.step() takes the overlapped
+    path -- the head's and the upper layers' theta regions are all-reduced on a side stream while the backward continues
+    (rulgnn_stgcn_train_fwdbwd_ready_f32) -- and is the single-process step; the reported regions are what the header documents."""
+    from gnn_rul_benchmarking_amd.dp import DataParallel
+    N, P, L = 512, 8, 2
+    cfg = {"num_patch": N, "patch_size": P, "num_layers": L, "dropout": 0.2}
+    tc = {"learning_rate": 1e-3, "weight_decay": 1e-4}
+    ref, dp = _algo("ST_GCN", cfg, tc), _algo("ST_GCN", cfg, tc)
+    dp.model.load_state_dict(ref.model.state_dict())
+    dp.model._seed = ref.model._seed
+    ctx = DataParallel()
+    dp.attach_data_parallel(ctx)
+    assert dp.model.reports_ready_gradients and dp.model.bucket.numel() * 4 >= ctx.OVERLAP_MIN_BYTES
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for step in range(3):
+        x = torch.rand(24, N, P, device=DEV, generator=g)
+        y = torch.rand(24, 1, device=DEV, generator=g)
+        la, lb = ref.update(x, y, step)["loss"], dp.update(x, y, step)["loss"]
+        assert abs(la - lb) <= 1e-6 * abs(la), (step, la, lb)
+    LS = N * N + N + 2 * (200 + 20)
+    fc1 = L * LS
+    total = dp.model.bucket.numel()
+    regs = ctx.last_overlap_regions
+    assert (fc1, fc1 + N * N + N + N + 1) in regs                        # the head: fc1 | fc2, reported first
+    assert (1 * LS, 1 * LS + N * N + N) in regs                           # theta of layer 1
+    assert regs[0][0] == 0 and regs[-1][1] == total                      # and the complement: every element exactly once
+    assert all(a[1] == b[0] for a, b in zip(regs, regs[1:]))
+    sa, sb = ref.model.state_dict(), dp.model.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert torch.allclose(sa[k], sb[k], rtol=2e-5, atol=1e-7), k
