@@ -337,6 +337,11 @@ def kernel_times(step_fn, steps=10):
     return out
 
 
+def _stmsgcn_nodes(cfg):
+    """Graph nodes of STMSGCN = energy bands of a patch's lagged spectrum (models/STMSGCN/Model.py:7-31)."""
+    return (cfg["patch_size"] - cfg["interval"]) // cfg["band_width"]
+
+
 def _gcn_stack_flops(n, dims):
     """Forward matmul FLOPs of STMSGCN's GCN stack for ONE graph of n nodes (models/STMSGCN/Model.py:84-112 without the dense
     diag products): per layer the Gram matrix x x^T and A.x (2 n^2 f each) and the Linear (2 n f_in f_out)."""
@@ -388,13 +393,11 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
             return flops / per_step, (f"matrix products of one step served by this kernel instance ({', '.join(sorted(set(w for w, _ in mine)))}): "
                                       f"{flops / 1e9:.1f} GFLOP over {len(mine)} products, {per_step:.0f} launches counted (P = {P}, H = {H}, Ah = {Ah}, batch {B})")
     if family == "STMSGCN" and "msg_gcn_backward_kernel" in name:
-        from oracle.stmsgcn_oracle import num_nodes
-        n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])
+        n = _stmsgcn_nodes(cfg)
         return B * cfg["num_patch"] * 2 * _gcn_stack_flops(n, cfg["gcn_dims"]), (f"backward of the 4-layer GCN stack of every (sample, patch) graph ({n} nodes): "
                                                                                   "2 x its forward FLOPs (Gram matrix, A.x and Linear per layer)")
     if family == "STMSGCN" and "msg_features_kernel" in name:
-        from oracle.stmsgcn_oracle import num_nodes
-        n = num_nodes(cfg["patch_size"], cfg["interval"], cfg["band_width"])
+        n = _stmsgcn_nodes(cfg)
         return B * cfg["num_patch"] * _gcn_stack_flops(n, cfg["gcn_dims"]), "forward of the GCN stack per graph (the DFT is not counted)"
     return None, None
 
