@@ -328,6 +328,257 @@ __global__ __launch_bounds__(MB) void msg_features_kernel(MsgGeom g, const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// features on the fp32 matrix cores: ONE WAVEFRONT PER GRAPH (graphs of >= 12 nodes; round 3)
+// ---------------------------------------------------------------------------------------------------
+// msg_features_kernel above spends ~97 % of a graph's 70 us waiting: 256 threads share one graph, every product is a loop of
+// dependent LDS reads behind a workgroup barrier (~30 barriers per graph).  Here a graph belongs to one wavefront and lives in its
+// registers; every product of the GCN stack is a chain of v_mfma_f32_32x32x2_f32 (exact fp32: an fmaf chain, bitwise) on the graph
+// padded to 32 nodes, and two register forms of a [node, feature] matrix are enough to chain them without ever transposing:
+//   NL ("node on lanes"):    register m, lane (h, i)  = M[node i][feature f(m, h)]     f(m, h) = 32 (m / 16) + krow(m % 16, h)
+//   FL ("feature on lanes"): register r, lane (h, c)  = M[node krow(r, h)][feature c]  (one set of 16 registers per 32 features)
+// with krow(r, h) = 8 (r / 4) + 4 h + r % 4 -- the row a 32x32 MFMA result keeps in accumulator register r of lane half h, so that
+// an MFMA result IS one of the two forms: rows = features gives NL, rows = nodes gives FL.  Per layer (Model.py:34-49, :96-100):
+//   A' = X X^T + I            A = B = X in NL form (the contraction runs over the features)                    f_in / 2 MFMAs
+//   r = rowsum(A')^-1/2, A^ = r_i A'_ij r_j     in the result layout; the row factors come back through 32 floats of LDS
+//   (A^ X)^T = X^T A^         A = X in FL form, B = A^ as it stands (symmetric): the result is A^ X in NL form         16 per 32 features
+//   Z = (A^ X) W^T            A = A^X (NL), B = W as an operand table -> FL form;  the SAME two registers swapped -> NL form
+// so a layer hands the next one both forms (the Linear layer runs twice; no transposes, no barriers), the FL form goes out to `cat`
+// with coalesced stores, and the GRU input projection accumulates from every layer's NL form as it appears.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MXW = 4;                   // wavefronts = graphs in flight per workgroup
+__host__ __device__ constexpr int krow(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+__host__ __device__ constexpr int nl_feat(int m, int h) { return 32 * (m >> 4) + krow(m & 15, h); }
+
+struct MxLds {                           // float offsets of the workgroup's LDS
+    int tw, bias, bih, wop[MAXL], wih[MAXL + 1], wave, wave_floats, total;
+};
+__host__ __device__ inline void mx_lds_layout(const MsgGeom& g, MxLds* o) {
+    int p = 0;
+    o->tw = p; p += 2 * g.P;
+    o->bias = p; p += 64 * g.L;
+    o->bih = p; p += 32;
+    for (int l = 0; l < g.L; ++l) {
+        const int nbi = (g.dims[l] + 31) / 32, nbo = (g.dims[l + 1] + 31) / 32;
+        o->wop[l] = p; p += nbo * nbi * 16 * 64;
+    }
+    o->wih[0] = p; p += 64;
+    for (int l = 0; l < g.L; ++l) { o->wih[l + 1] = p; p += ((g.dims[l + 1] + 31) / 32) * 16 * 64; }
+    o->wave = p;
+    o->wave_floats = 3 * g.P + 64;       // xs | re | im | row-factor scratch, one set per wavefront
+    p += MXW * o->wave_floats;
+    o->total = p;
+}
+static bool mx_features_ok(const MsgGeom& g, size_t* lds_bytes) {
+    if (g.n < 12 || g.H3 > 32) return false;
+    MxLds o;
+    mx_lds_layout(g, &o);
+    *lds_bytes = sizeof(float) * (size_t)o.total;
+    return *lds_bytes <= 64 * 1024;
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// the 16 values v[krow(r, h)] of a per-node vector in this wavefront's LDS scratch (four 16-byte reads: krow runs in fours)
+__device__ __forceinline__ void row_values(const float* vec, int h, float (&out)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(vec + 8 * q + 4 * h);
+        out[4 * q] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+    }
+}
+
+__global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                                    float* __restrict__ cat_out, float* __restrict__ gi_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    MxLds L_;
+    mx_lds_layout(g, &L_);
+    const int n = g.n, P = g.P, C = g.C, H3 = g.H3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    float* tw = smem + L_.tw;
+
+    // ---- operand tables (once per workgroup) ----------------------------------------------------------------------------
+    for (int k = tid; k < P; k += 64 * MXW) {
+        float sn, cs;
+        sincospif(2.0f * (float)k / (float)P, &sn, &cs);
+        tw[2 * k] = cs;
+        tw[2 * k + 1] = sn;
+    }
+    for (int e = tid; e < 64 * g.L; e += 64 * MXW) {
+        const int l = e >> 6, o = e & 63;
+        smem[L_.bias + e] = o < g.dims[l + 1] ? prm[g.boff[l] + o] : 0.f;
+    }
+    for (int e = tid; e < 32; e += 64 * MXW) smem[L_.bih + e] = gi_out && e < H3 ? prm[g.off_bih + e] : 0.f;
+    for (int l = 0; l < g.L; ++l) {
+        const int fi = g.dims[l], fo = g.dims[l + 1], nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
+        for (int e = tid; e < nbo * nbi * 16 * 64; e += 64 * MXW) {          // Linear: lane (hh, o) of register m: W[32 ob + o][f(m, hh)]
+            const int ln = e & 63, m = (e >> 6) % (nbi * 16), ob = (e >> 6) / (nbi * 16);
+            const int o = 32 * ob + (ln & 31), f = nl_feat(m, ln >> 5);
+            smem[L_.wop[l] + e] = (o < fo && f < fi) ? prm[g.woff[l] + o * fi + f] : 0.f;
+        }
+        for (int e = tid; e < nbo * 16 * 64; e += 64 * MXW) {                 // GRU input projection of this layer's output columns
+            const int ln = e & 63, m = e >> 6;
+            const int q = ln & 31, f = nl_feat(m, ln >> 5);
+            smem[L_.wih[l + 1] + e] = (gi_out && q < H3 && f < fo) ? prm[g.off_wih + q * C + g.coff[l + 1] + f] : 0.f;
+        }
+    }
+    for (int e = tid; e < 64; e += 64 * MXW)                                   // ... and of the input column (the SED feature)
+        smem[L_.wih[0] + e] = (gi_out && (e & 31) < H3 && (e >> 5) == 0) ? prm[g.off_wih + (e & 31) * C] : 0.f;
+    __syncthreads();
+
+    float* xs = smem + L_.wave + wave * L_.wave_floats;        // this wavefront's scratch
+    float* fre = xs + P;
+    float* fim = fre + P;
+    float* rowv = fim + P;                                     // [64]: two per-node vectors for row_values()
+    const bool node_ok = j < n;
+
+    for (int64_t gi = (int64_t)blockIdx.x * MXW + wave; gi < g.G; gi += (int64_t)gridDim.x * MXW) {
+        // ---- SED_features (Model.py:7-31): DFT of the patch, lagged difference, band energies -------------------------------
+        const float* xp = x + gi * P;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < P; k += 64) xs[k] = xp[k];
+        __builtin_amdgcn_wave_barrier();
+        for (int j0 = lane; j0 < P; j0 += 128) {               // two frequencies per pass share the reads of the patch
+            const int j1 = j0 + 64 < P ? j0 + 64 : j0;
+            float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
+            int i0 = 0, i1 = 0;
+#pragma unroll 4
+            for (int t = 0; t < P; ++t) {
+                const float v = xs[t];
+                const float2 w0 = *reinterpret_cast<const float2*>(tw + 2 * i0), w1 = *reinterpret_cast<const float2*>(tw + 2 * i1);
+                re0 = fmaf(v, w0.x, re0); im0 = fmaf(-v, w0.y, im0);
+                re1 = fmaf(v, w1.x, re1); im1 = fmaf(-v, w1.y, im1);
+                i0 += j0; if (i0 >= P) i0 -= P;
+                i1 += j1; if (i1 >= P) i1 -= P;
+            }
+            fre[j0] = re0; fim[j0] = im0;
+            if (j0 + 64 < P) { fre[j1] = re1; fim[j1] = im1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < P - g.interval; k += 64) {
+            const float dr = fre[k + g.interval] - fre[k], di = fim[k + g.interval] - fim[k];
+            xs[k] = dr * dr + di * di;                         // (the patch itself is no longer needed)
+        }
+        __builtin_amdgcn_wave_barrier();
+        float x0 = 0.f;
+        if (node_ok)
+            for (int q = 0; q < g.bw; ++q) x0 += xs[j * g.bw + q];
+        if (cat_out && node_ok && h == 0) cat_out[gi * (int64_t)(n * C) + j * C] = x0;
+
+        // ---- GCN stack (Model.py:96-100) ---------------------------------------------------------------------------------
+        float Xn[32], Xf[2][16];
+#pragma unroll
+        for (int m = 0; m < 32; ++m) Xn[m] = 0.f;
+        Xn[0] = h == 0 ? x0 : 0.f;                             // NL form of the one input feature (f(0, 0) = 0, f(0, 1) = 4)
+        f32x16 giacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        giacc = mfma32(Xn[0], smem[L_.wih[0] + lane], giacc);
+        for (int l = 0; l < g.L; ++l) {
+            const int fi = g.dims[l], fo = g.dims[l + 1], nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
+            // A' = X X^T + I
+            f32x16 G = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+                if (nl_feat(m, 0) < fi) G = mfma32(Xn[m], Xn[m], G);
+            float d = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                G[r] += (krow(r, 0) + 4 * h == j) ? 1.f : 0.f;
+                d += G[r];
+            }
+            d += __shfl_xor(d, 32, 64);
+            const float rj = 1.0f / sqrtf(d);                  // rowsum^-1/2 (Model.py:43); A' is symmetric: column sum = row sum
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0) { rowv[j] = rj; rowv[32 + j] = Xn[0]; }
+            __builtin_amdgcn_wave_barrier();
+            float rr[16];
+            row_values(rowv, h, rr);
+            float Ah[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ah[r] = (G[r] * rj) * rr[r];          // A^[krow(r, h)][j]
+            // A^ X in NL form
+            float AXn[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) AXn[m] = 0.f;
+            if (fi == 1) {                                     // one feature: a matrix-vector product on the vector ALUs
+                float xr[16], s1 = 0.f;
+                row_values(rowv + 32, h, xr);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1 = fmaf(Ah[r], xr[r], s1);
+                s1 += __shfl_xor(s1, 32, 64);
+                AXn[0] = h == 0 ? s1 : 0.f;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (b < nbi) {
+                        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc = mfma32(Xf[b][r], Ah[r], acc);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) AXn[16 * b + r] = acc[r];
+                    }
+                }
+            }
+            // Z = leaky((A^ X) W^T + b) in both forms; the FL form goes out to cat, the NL form feeds the GRU projection
+            float Zn[32], Zf[2][16];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) Zn[m] = 0.f;
+            const float* wl = smem + L_.wop[l];
+            const float* bl = smem + L_.bias + 64 * l;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Zf[ob][r] = 0.f;
+                if (ob < nbo) {
+                    f32x16 aF = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, aN = aF;
+#pragma unroll
+                    for (int m = 0; m < 32; ++m) {
+                        if (nl_feat(m, 0) < fi) {
+                            const float w = wl[(ob * nbi * 16 + m) * 64 + lane];
+                            aF = mfma32(AXn[m], w, aF);
+                            aN = mfma32(w, AXn[m], aN);
+                        }
+                    }
+                    const float bF = bl[32 * ob + j];
+                    float bN[16];
+                    row_values(bl + 32 * ob, h, bN);
+                    float* dst = cat_out ? cat_out + gi * (int64_t)(n * C) + g.coff[l + 1] + 32 * ob + j : nullptr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int node = krow(r, 0) + 4 * h;
+                        float zf = aF[r] + bF, zn = aN[r] + bN[r];
+                        zf = zf > 0.f ? zf : LEAKY * zf;
+                        zn = zn > 0.f ? zn : LEAKY * zn;
+                        const bool okf = node < n && 32 * ob + j < fo;
+                        Zf[ob][r] = okf ? zf : 0.f;
+                        Zn[16 * ob + r] = node_ok ? zn : 0.f;        // (features >= f_out: zero weights and zero bias give 0)
+                        if (dst && okf) dst[node * C] = zf;
+                    }
+                }
+            }
+            if (gi_out) {
+                const float* wq = smem + L_.wih[l + 1];
+#pragma unroll
+                for (int m = 0; m < 32; ++m)
+                    if (nl_feat(m, 0) < fo) giacc = mfma32(Zn[m], wq[m * 64 + lane], giacc);
+            }
+#pragma unroll
+            for (int m = 0; m < 32; ++m) Xn[m] = Zn[m];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xf[b][r] = Zf[b][r];
+        }
+        if (gi_out && j < H3) {                                // nn.GRU: x W_ih^T + b_ih, [graph][node][3H]
+            float* dst = gi_out + gi * (int64_t)(n * H3) + j;
+            const float bq = smem[L_.bih + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int node = krow(r, 0) + 4 * h;
+                if (node < n) dst[node * H3] = giacc[r] + bq;
+            }
+        }
+    }
+}
+
 static size_t features_lds_bytes(const MsgGeom& g) {
     return sizeof(float) * ((size_t)g.gcn_params + (g.C + 1) * g.H3 + 5 * g.P + g.n * g.CS + g.n * (g.n + 1) + MAXN +
                             g.n * g.AXS);
@@ -839,6 +1090,25 @@ static int launch_features_tw(const MsgGeom& g, const float* x, const float* prm
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 static int launch_features(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
+    size_t lds = 0;
+    if (mx_features_ok(g, &lds)) {                  // graphs of >= 12 nodes: one wavefront per graph on the fp32 matrix cores
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(msg_features_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return RULGNN_EHIP;
+        int dev = 0, cus = 256, per_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int v = 0;
+            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msg_features_mx_kernel, 64 * MXW, lds) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        int64_t grid = (int64_t)cus * per_cu;
+        const int64_t need = (g.G + MXW - 1) / MXW;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL(msg_features_mx_kernel, dim3((unsigned)grid), dim3(64 * MXW), lds, st, g, x, prm, cat, gi);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
     return g.n >= 12 ? launch_features_tw<4>(g, x, prm, cat, gi, st) : launch_features_tw<1>(g, x, prm, cat, gi, st);
 }
 
