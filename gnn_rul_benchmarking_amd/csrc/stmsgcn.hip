@@ -994,6 +994,260 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
     for (int e = tid; e < nacc; e += MB) dst[e] = acc[e];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GCN backward on the fp32 matrix cores: ONE WAVEFRONT PER GRAPH (graphs of >= 12 nodes; round 3)
+// ---------------------------------------------------------------------------------------------------
+// Same two register forms as msg_features_mx_kernel.  What arrives from memory arrives in the FL form (coalesced rows of cat / d cat);
+// the NL form of a matrix is its product with the identity on the matrix cores (exact: x 1 + 0s).  Per layer, top down:
+//   dz = d out * leaky'(out)                          FL (loaded), NL = dz^T-as-rows x I
+//   A', r, A^ recomputed from X (NL: Gram)            as in the forward
+//   AX = A^ X                                          A = A^ (symmetric: rows on lanes), B = X (FL)          -> FL
+//   d W = dz^T AX, d b = column sums                   A = dz (FL: rows = out features, k = nodes), B = AX (FL) -> into this wavefront's
+//                                                      LDS accumulator (plain read-add-write: fixed order, reproducible)
+//   d AX = dz W                                        A/B = dz (NL) and the W^T operand table, both orders   -> NL and FL
+//   d A^ = d AX X^T and its transpose                  A/B = d AX (NL), X (NL), both orders
+//   d r, d(row sum), M = d A' + d A'^T                 in the result layout, row factors through 32 floats of LDS
+//   d x = A^ d AX + M X                                A = A^ / M (symmetric), B = d AX / X (FL)               -> FL, added to the d cat
+//                                                      slice of the layer below when that layer loads it
+struct MxBwdLds {
+    int wt[MAXL], acc, wave, total;      // W^T operand tables (layers >= 1), per-wavefront gradient accumulators, per-wavefront scratch
+};
+__host__ __device__ inline void mx_bwd_lds_layout(const MsgGeom& g, MxBwdLds* o) {
+    int p = 0;
+    for (int l = 0; l < g.L; ++l) {
+        o->wt[l] = p;
+        if (l > 0) p += ((g.dims[l] + 31) / 32) * ((g.dims[l + 1] + 31) / 32) * 16 * 64;
+    }
+    o->acc = p; p += MXW * g.gcn_params;
+    o->wave = p; p += MXW * 64;
+    o->total = p;
+}
+static bool mx_backward_ok(const MsgGeom& g, size_t* lds_bytes) {
+    if (g.n < 12) return false;
+    MxBwdLds o;
+    mx_bwd_lds_layout(g, &o);
+    *lds_bytes = sizeof(float) * (size_t)o.total;
+    return *lds_bytes <= 64 * 1024;
+}
+
+__global__ __launch_bounds__(64 * MXW, 2) void msg_gcn_backward_mx_kernel(MsgGeom g, const float* __restrict__ cat_in,
+                                                                        const float* __restrict__ dcat_in, const float* __restrict__ prm,
+                                                                        float* __restrict__ gpart) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    MxBwdLds L_;
+    mx_bwd_lds_layout(g, &L_);
+    const int n = g.n, C = g.C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
+    for (int l = 1; l < g.L; ++l) {                // d AX = dz W: lane (hh, k) of register m: W[o = f(m, hh)][32 ib + k]
+        const int fi = g.dims[l], fo = g.dims[l + 1], nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
+        for (int e = tid; e < nbi * nbo * 16 * 64; e += 64 * MXW) {
+            const int ln = e & 63, m = (e >> 6) % (nbo * 16), ib = (e >> 6) / (nbo * 16);
+            const int o = nl_feat(m, ln >> 5), k = 32 * ib + (ln & 31);
+            smem[L_.wt[l] + e] = (o < fo && k < fi) ? prm[g.woff[l] + o * fi + k] : 0.f;
+        }
+    }
+    for (int e = tid; e < MXW * g.gcn_params; e += 64 * MXW) smem[L_.acc + e] = 0.f;
+    __syncthreads();
+    float* acc = smem + L_.acc + wave * g.gcn_params;      // this wavefront's gradient accumulator
+    float* rowv = smem + L_.wave + wave * 64;
+
+    float ident[16];                                         // I[krow(r, h)][j]: the B operand that turns FL into NL
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ident[r] = (krow(r, 0) + 4 * h == j) ? 1.f : 0.f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t gi = (int64_t)blockIdx.x * MXW + wave; gi < g.G; gi += (int64_t)gridDim.x * MXW) {
+        const float* cg = cat_in + gi * (int64_t)(n * C);
+        const float* dg = dcat_in + gi * (int64_t)(n * C);
+        // FL-form load of `width` columns starting at column `col0` of a [n][C] matrix (zero outside)
+        auto load_fl = [&](const float* base, int col0, int width, float (&dst)[2][16]) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int node = krow(r, 0) + 4 * h, c = 32 * b + j;
+                    dst[b][r] = (node < n && c < width) ? base[node * C + col0 + c] : 0.f;
+                }
+        };
+        float dxF[2][16];                                   // d x of the layer above, FL form of the current layer's OUTPUT columns
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dxF[b][r] = 0.f;
+
+        for (int l = g.L - 1; l >= 0; --l) {
+            const int fi = g.dims[l], fo = g.dims[l + 1], off = g.coff[l], offo = g.coff[l + 1];
+            const int nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
+            // dz (FL) = (d cat slice + d x from above) * leaky'(out)
+            float dzF[2][16];
+            {
+                float outF[2][16];
+                load_fl(cg, offo, fo, outF);
+                load_fl(dg, offo, fo, dzF);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // (d x of a PADDED node row is not zero -- M[pad][j] = dd_j -- so the mask is applied here, not only in the loads)
+                        const bool ok = krow(r, 0) + 4 * h < n && 32 * b + j < fo;
+                        dzF[b][r] = ok ? (dzF[b][r] + dxF[b][r]) * (outF[b][r] > 0.f ? 1.f : LEAKY) : 0.f;
+                    }
+            }
+            // X in both forms
+            float XF[2][16], XN[32];
+            load_fl(cg, off, fi, XF);
+#pragma unroll
+            for (int m = 0; m < 32; ++m) XN[m] = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b < nbi) {
+                    f32x16 t = zero16;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t = mfma32(XF[b][r], ident[r], t);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) XN[16 * b + r] = t[r];
+                }
+            }
+            // A' = X X^T + I, r, A^
+            f32x16 G = zero16;
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+                if (nl_feat(m, 0) < fi) G = mfma32(XN[m], XN[m], G);
+            float d = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                G[r] += ident[r];
+                d += G[r];
+            }
+            d += __shfl_xor(d, 32, 64);
+            const float rj = 1.0f / sqrtf(d);
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0) rowv[j] = rj;
+            __builtin_amdgcn_wave_barrier();
+            float rr[16], Ah[16];
+            row_values(rowv, h, rr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ah[r] = (G[r] * rj) * rr[r];
+            // AX (FL), d W, d b
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                if (ib < nbi) {
+                    f32x16 ax = zero16;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ax = mfma32(Ah[r], XF[ib][r], ax);          // rows = nodes: FL form
+#pragma unroll
+                    for (int ob = 0; ob < 2; ++ob) {
+                        if (ob < nbo) {
+                            f32x16 dw = zero16;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) dw = mfma32(dzF[ob][r], ax[r], dw);  // rows = out features, columns = in features
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int o = 32 * ob + krow(r, 0) + 4 * h, k = 32 * ib + j;
+                                if (o < fo && k < fi) acc[g.woff[l] + o * fi + k] += dw[r];
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                if (ob < nbo) {
+                    float sb = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sb += dzF[ob][r];
+                    sb += __shfl_xor(sb, 32, 64);
+                    if (h == 0 && 32 * ob + j < fo) acc[g.boff[l] + 32 * ob + j] += sb;
+                }
+            }
+            if (l == 0) break;                               // the SED features carry no gradient
+            // dz in NL form
+            float dzN[32];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) dzN[m] = 0.f;
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                if (ob < nbo) {
+                    f32x16 t = zero16;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t = mfma32(dzF[ob][r], ident[r], t);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dzN[16 * ob + r] = t[r];
+                }
+            }
+            // d AX = dz W in both forms
+            float dAXN[32], dAXF[2][16];
+#pragma unroll
+            for (int m = 0; m < 32; ++m) dAXN[m] = 0.f;
+            const float* wt = smem + L_.wt[l];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dAXF[ib][r] = 0.f;
+                if (ib < nbi) {
+                    f32x16 aN = zero16, aF = zero16;
+#pragma unroll
+                    for (int m = 0; m < 32; ++m) {
+                        if (nl_feat(m, 0) < fo) {
+                            const float w = wt[(ib * nbo * 16 + m) * 64 + lane];
+                            aN = mfma32(w, dzN[m], aN);        // rows = in features, columns = nodes: NL
+                            aF = mfma32(dzN[m], w, aF);        // rows = nodes, columns = in features: FL
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { dAXN[16 * ib + r] = aN[r]; dAXF[ib][r] = aF[r]; }
+                }
+            }
+            // S = d A^ + d A^^T
+            f32x16 S = zero16;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                if (nl_feat(m, 0) < fi) {
+                    S = mfma32(dAXN[m], XN[m], S);
+                    S = mfma32(XN[m], dAXN[m], S);
+                }
+            }
+            // d r (both D factors) and d(row sum): dd = -1/2 r^3 sum_j A'[i][j] r_j S[i][j]   (A', S symmetric)
+            float a1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1 = fmaf(G[r] * rr[r], S[r], a1);
+            a1 += __shfl_xor(a1, 32, 64);
+            const float ddj = -0.5f * a1 * rj * rj * rj;
+            __builtin_amdgcn_wave_barrier();
+            if (h == 0) rowv[32 + j] = ddj;
+            __builtin_amdgcn_wave_barrier();
+            float ddr[16], Mm[16];
+            row_values(rowv + 32, h, ddr);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Mm[r] = (rr[r] * rj) * S[r] + ddr[r] + ddj;
+            // d x = A^ d AX + M X  (FL), handed to the layer below
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dxF[ib][r] = 0.f;
+                if (ib < nbi) {
+                    f32x16 t = zero16;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        t = mfma32(Ah[r], dAXF[ib][r], t);
+                        t = mfma32(Mm[r], XF[ib][r], t);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dxF[ib][r] = t[r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = gpart + (int64_t)blockIdx.x * g.gcn_params;
+    for (int e = tid; e < g.gcn_params; e += 64 * MXW) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < MXW; ++w) v += smem[L_.acc + w * g.gcn_params + e];
+        dst[e] = v;
+    }
+}
+
 static size_t gcn_backward_lds_bytes(const MsgGeom& g) {
     return sizeof(float) * ((size_t)2 * g.gcn_params + 2 * g.n * g.CS + 3 * g.n * (g.n + 1) + 2 * MAXN + g.n * g.AXS);
 }
@@ -1209,7 +1463,30 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
             if (rc != RULGNN_OK) return rc;
         }
         int rows = 0;
-        const int rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
+        size_t lds_mx = 0;
+        int rcb;
+        if (mx_backward_ok(g, &lds_mx)) {                  // graphs of >= 12 nodes: one wavefront per graph on the fp32 matrix cores
+            if (lds_mx > 48 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(msg_gcn_backward_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_mx) != hipSuccess)
+                return RULGNN_EHIP;
+            int dev = 0, cus = 256, per_cu = 0;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msg_gcn_backward_mx_kernel, 64 * MXW, lds_mx) != hipSuccess || per_cu < 1)
+                per_cu = 1;
+            int64_t grid = (int64_t)cus * per_cu;
+            const int64_t need = (g.G + MXW - 1) / MXW;
+            if (grid > need) grid = need;
+            if (grid > w.rows_gcn_max) grid = w.rows_gcn_max;
+            rows = (int)grid;
+            hipLaunchKernelGGL(msg_gcn_backward_mx_kernel, dim3((unsigned)grid), dim3(64 * MXW), lds_mx, st, g, (const float*)(ws + w.cat),
+                               (const float*)(ws + w.dcat), a->params, (float*)(ws + w.gpart_gcn));
+            rcb = hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+        } else
+        rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
                                                            (float*)(ws + w.gpart_gcn), st, &rows)
                                   : launch_gcn_backward<1>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
                                                            (float*)(ws + w.gpart_gcn), st, &rows);
