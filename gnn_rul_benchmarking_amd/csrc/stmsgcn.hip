@@ -1084,6 +1084,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
             }
         };
         float dxF[2][16];                                   // d x of the layer above, FL form of the current layer's OUTPUT columns
+        float outF[2][16];                                  // the current layer's output (= the X of the layer above)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1095,8 +1096,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
             // dz (FL) = (d cat slice + d x from above) * leaky'(out)
             float dzF[2][16];
             {
-                float outF[2][16];
-                load_fl(cg, offo, fo, outF);
+                if (l == g.L - 1) load_fl(cg, offo, fo, outF);        // (below the top layer: the X of the layer above, already here)
                 load_fl(dg, offo, fo, dzF);
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
@@ -1250,6 +1250,10 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
                     for (int r = 0; r < 16; ++r) dxF[ib][r] = t[r];
                 }
             }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) outF[b][r] = XF[b][r];
         }
     }
     __syncthreads();
