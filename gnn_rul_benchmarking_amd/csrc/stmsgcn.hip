@@ -437,21 +437,48 @@ __global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g,
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < P; k += 64) xs[k] = xp[k];
         __builtin_amdgcn_wave_barrier();
-        for (int j0 = lane; j0 < P; j0 += 128) {               // two frequencies per pass share the reads of the patch
-            const int j1 = j0 + 64 < P ? j0 + 64 : j0;
-            float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
-            int i0 = 0, i1 = 0;
-#pragma unroll 4
-            for (int t = 0; t < P; ++t) {
-                const float v = xs[t];
-                const float2 w0 = *reinterpret_cast<const float2*>(tw + 2 * i0), w1 = *reinterpret_cast<const float2*>(tw + 2 * i1);
-                re0 = fmaf(v, w0.x, re0); im0 = fmaf(-v, w0.y, im0);
-                re1 = fmaf(v, w1.x, re1); im1 = fmaf(-v, w1.y, im1);
-                i0 += j0; if (i0 >= P) i0 -= P;
-                i1 += j1; if (i1 >= P) i1 -= P;
+        // The patch is real: F[P - k] = conj(F[k]).  Frequencies 0 .. P/2 - 1 are summed directly (two per pass share the reads of
+        // the patch), F[P/2] = sum (-1)^t x[t] is a wavefront reduction, the upper half is mirrored.  (Odd P: all frequencies directly.)
+        const int half = (P & 1) ? P : P / 2;
+        if (half <= 64) {                                    // one frequency per lane
+            if (lane < half) {
+                float re0 = 0.f, im0 = 0.f;
+                int i0 = 0;
+#pragma unroll 8
+                for (int t = 0; t < P; ++t) {
+                    const float v = xs[t];
+                    const float2 w0 = *reinterpret_cast<const float2*>(tw + 2 * i0);
+                    re0 = fmaf(v, w0.x, re0); im0 = fmaf(-v, w0.y, im0);
+                    i0 += lane; if (i0 >= P) i0 -= P;
+                }
+                fre[lane] = re0; fim[lane] = im0;
             }
-            fre[j0] = re0; fim[j0] = im0;
-            if (j0 + 64 < P) { fre[j1] = re1; fim[j1] = im1; }
+        } else {
+            for (int j0 = lane; j0 < half; j0 += 128) {
+                const int j1 = j0 + 64 < half ? j0 + 64 : j0;
+                float re0 = 0.f, im0 = 0.f, re1 = 0.f, im1 = 0.f;
+                int i0 = 0, i1 = 0;
+#pragma unroll 4
+                for (int t = 0; t < P; ++t) {
+                    const float v = xs[t];
+                    const float2 w0 = *reinterpret_cast<const float2*>(tw + 2 * i0), w1 = *reinterpret_cast<const float2*>(tw + 2 * i1);
+                    re0 = fmaf(v, w0.x, re0); im0 = fmaf(-v, w0.y, im0);
+                    re1 = fmaf(v, w1.x, re1); im1 = fmaf(-v, w1.y, im1);
+                    i0 += j0; if (i0 >= P) i0 -= P;
+                    i1 += j1; if (i1 >= P) i1 -= P;
+                }
+                fre[j0] = re0; fim[j0] = im0;
+                if (j0 + 64 < half) { fre[j1] = re1; fim[j1] = im1; }
+            }
+        }
+        if (!(P & 1)) {
+            float alt = 0.f;
+            for (int t = lane; t < P; t += 64) alt += (t & 1) ? -xs[t] : xs[t];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) alt += __shfl_xor(alt, m, 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { fre[P / 2] = alt; fim[P / 2] = 0.f; }
+            for (int k = P / 2 + 1 + lane; k < P; k += 64) { fre[k] = fre[P - k]; fim[k] = -fim[P - k]; }
         }
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < P - g.interval; k += 64) {
