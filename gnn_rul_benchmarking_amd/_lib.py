@@ -62,7 +62,7 @@ class AstgcnnArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
                 ("pred", C.c_void_p), ("loss", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_batch", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64),
-                ("bn_moment_weight", C.c_float), ("training", C.c_int32)]
+                ("bn_moment_weight", C.c_float), ("training", C.c_int32), ("aux_stream", C.c_void_p)]
 
 
 class StconvShape(C.Structure):
@@ -94,7 +94,7 @@ class FcstgnnArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64),
                 ("sample_offset", C.c_int64), ("bn_moment_weight", C.c_float), ("dropout_p", C.c_float),
                 ("seed", C.c_uint64), ("step", C.c_uint64), ("training", C.c_int32), ("step_state", C.c_void_p),
-                ("compute_dtype", C.c_int32)]
+                ("compute_dtype", C.c_int32), ("aux_stream", C.c_void_p)]
 
 
 class StnetShape(C.Structure):

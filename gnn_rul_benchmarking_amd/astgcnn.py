@@ -108,6 +108,7 @@ class ASTGCNN_model(nn.Module):
         self._bn_names = [f"tcn.conv_block{b}.2.running_{k}" for b in (1, 2) for k in ("mean", "var")]
         self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self.side_stream = PL.SideStream()
         self._nbt_pending = 0
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
         self._reflatten()
@@ -226,6 +227,7 @@ class ASTGCNN_model(nn.Module):
         a.workspace_bytes = self._ws.numel()
         a.global_batch = gb
         a.training = 1 if training else 0
+        a.aux_stream = self.side_stream.pointer(self._flat.device, training)
         return a
 
     def _run_forward(self, x2d, training):

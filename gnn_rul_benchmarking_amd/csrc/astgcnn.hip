@@ -11,6 +11,7 @@
 //   conv1 | conv2 | gate -> graph -> head | gate_bwd (BN2 sums) | conv2_bwd (BN1 sums) | conv1_bwd | finalize.
 // Node mean and Chebyshev projection commute, so the [batch*nodes, K*E] x [K*E, O] product is done on the node sums
 // ([batch, K*E]) -- nodes times less work, same result up to summation order.
+#include "aux_stream.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 #include "tcn_nodes.hpp"
@@ -495,26 +496,33 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         float* gr = a->grads;
         float* split = F(w.split);
         hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
+        // The parameter-gradient GEMMs feed nothing in this call: with a second stream of the caller (args->aux_stream, aux_stream.hpp)
+        // they run beside the data-gradient chain.  They share the split-K scratch and therefore one stream.
+        AuxFork fk(st, a->aux_stream);
+        hipStream_t wst = fk.side();
+        fk.fork();
         // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
-        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, st));
-        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, st));
+        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
+        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
         // d filters = Scat^T D ; DT = D Fcat^T
-        AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, st));
+        AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         AST_RC(sgemm(F(w.dmat), O, 1, prm + g.o_f, O, 1, F(w.dt), KE, (int)g.B, KE, O, false, st));
         hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g,
                            (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dt),
                            F(w.dpx), F(w.dg));
         // d P = dPX^T G ; dG += dPX P
-        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, st));
+        fk.fork();
+        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
         AST_RC(sgemm(F(w.dpx), E, 1, prm + g.o_pw, 1, E, F(w.dg), E, M, E, E, true, st));
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
         hipLaunchKernelGGL(ast_gate_bwd_kernel, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.out1),
                            (const float*)F(w.dg), F(w.zpre), F(w.ds1), F(w.dy2));
         AST_RC(sync_pair(1, 1));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
-        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, st));
-        AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, st));
-        if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, st) != hipSuccess) return RULGNN_EHIP;
+        fk.fork();
+        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
+        AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, wst));
+        if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, wst) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
         AST_RC(sync_pair(1, 0));
@@ -523,6 +531,7 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         const bool mse = a->dpred == nullptr;
         AST_RC(rows_sum(F(w.gp1), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w1, st));
         AST_RC(rows_sum(F(w.gp2), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w2, st));
+        AST_RC(fk.join());
         hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
         if (mse && a->loss)
             (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);

@@ -1,0 +1,45 @@
+// Fork / join of an optional second stream of the caller (the `aux_stream` field of a family's argument struct, include/rulgnn.h).
+// The backward passes of the small-batch families are chains of launches at their 5-19 us latency floor; the weight / bias gradient
+// GEMMs among them feed nothing downstream in the same call.  With a second stream they leave the critical path:
+//     AuxFork fk(stream, args->aux_stream);
+//     ...            fk.fork();                 // the aux stream waits for everything enqueued on `stream` so far
+//     ...            gemm(..., fk.side());      // = the aux stream, or `stream` itself when the caller gave none
+//     ...            rc = fk.join();            // `stream` waits for the aux stream; in front of the call's last kernel
+// Same launches, same results.  Events come from a small per-thread ring, created on first use and kept: an event may be re-recorded
+// once the waits enqueued on it have been issued to their streams, which hipStreamWaitEvent does before it returns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/rulgnn.h"
+
+namespace rulgnn {
+
+inline hipEvent_t aux_pooled_event() {
+    constexpr int N = 32;
+    static thread_local hipEvent_t ring[N] = {};
+    static thread_local int next = 0;
+    hipEvent_t& e = ring[next];
+    next = (next + 1) % N;
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    return e;
+}
+
+struct AuxFork {
+    hipStream_t st, wst;
+    int rc = RULGNN_OK;
+    AuxFork(hipStream_t stream, void* aux) : st(stream), wst(aux ? static_cast<hipStream_t>(aux) : stream) {}
+    bool active() const { return wst != st; }
+    hipStream_t side() const { return wst; }
+    void order(hipStream_t after, hipStream_t waiter) {
+        if (!active() || rc != RULGNN_OK) return;
+        hipEvent_t ev = aux_pooled_event();
+        if (!ev || hipEventRecord(ev, after) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) rc = RULGNN_EHIP;
+    }
+    void fork() { order(st, wst); }
+    int join() {
+        order(wst, st);
+        return rc;
+    }
+};
+
+}  // namespace rulgnn

@@ -59,71 +59,155 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
 
 // The gate non-linearities sit on the critical path of every sequential step (0.27 us of 0.95 with libm's expf / tanhf and
 // IEEE division): hardware exp2 and reciprocal instead (v_exp_f32, v_rcp_f32: ~1 ulp each, ~2e-7 absolute on the outputs).
-__device__ inline float sigm(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 __device__ inline float tanh_gate(float v) {
     const float a = fabsf(v);
-    const float t = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a));        // exp overflow -> rcp(inf) = 0 -> 1
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * a));        // exp overflow -> rcp(inf) = 0 -> 1
     return copysignf(t, v);
 }
 
+// One sequential step used to cost 1.6 us (H = 64) although its arithmetic is ~0.2 us: __syncthreads() waits for vmcnt(0), i.e. for the
+// step's global stores (and the prefetched input row) to complete -- two HBM round trips per step.  Here the step barrier only waits
+// for the LDS (lgkmcnt) and global traffic is asynchronous: tape stores drain behind the recurrence, and the rows a step reads are
+// requested LSTM_AHEAD steps earlier by LDS-DMA (global_load_lds_dword: no destination register the compiler could touch early) into a
+// ring each wavefront reads back itself.  The compiler would wait for vmcnt(0) in front of every use (it cannot count through the
+// loop), so every vector-memory instruction of the loops is written out and counted by hand: vmcnt decrements in issue order on gfx9,
+// a step issues the same instructions in every wavefront that has a live lane, and the wait in front of a ring read names exactly the
+// instructions issued after that row's request.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void store_async(float* dst, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(v) : "memory"); }
+// one dword per lane to lds_wave_base[lane]; all 64 lanes enabled; M0 carries the LDS base and is compiler-reserved: saved and restored
+__device__ __forceinline__ void dma_dword(const float* src, const float* lds_wave_base) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(base)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+constexpr int LSTM_AHEAD = 8;       // even (the LDS vectors of the recurrence are double-buffered by step parity)
+
+// acc += w * (lane N of this lane's row of 16 in hc): the matvec's broadcast.  Reading the whole vector in every lane (LDS broadcast
+// reads) is bound by the LDS return path -- 4H lanes x H floats at 128 B/clk: 0.24 us per step at H = 64, 0.98 us at H = 128, what the
+// recurrence measured -- so a lane reads H/16 floats (lane l: element 16c + l % 16 of chunk c) and the DPP row broadcast of gfx90a+
+// feeds the FMA: 16x less LDS traffic, 4 issue cycles per FMA.
+template <int N>
+__device__ __forceinline__ void fma_row_bcast(float& acc, float hc, float w) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(hc), "v"(w), "n"(N));
+}
+template <int HMAX>
+__device__ __forceinline__ void chunks_load(float (&hc)[HMAX / 16], const float* vec, int lane16) {
+#pragma unroll
+    for (int c = 0; c < HMAX / 16; ++c) hc[c] = vec[16 * c + lane16];
+}
+template <int HMAX>
+__device__ __forceinline__ float matvec_row_bcast(const float (&w)[HMAX], const float (&hc)[HMAX / 16], float a0) {
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < HMAX / 16; ++c) {
+        fma_row_bcast<0>(a0, hc[c], w[16 * c + 0]);   fma_row_bcast<1>(a1, hc[c], w[16 * c + 1]);
+        fma_row_bcast<2>(a2, hc[c], w[16 * c + 2]);   fma_row_bcast<3>(a3, hc[c], w[16 * c + 3]);
+        fma_row_bcast<4>(a0, hc[c], w[16 * c + 4]);   fma_row_bcast<5>(a1, hc[c], w[16 * c + 5]);
+        fma_row_bcast<6>(a2, hc[c], w[16 * c + 6]);   fma_row_bcast<7>(a3, hc[c], w[16 * c + 7]);
+        fma_row_bcast<8>(a0, hc[c], w[16 * c + 8]);   fma_row_bcast<9>(a1, hc[c], w[16 * c + 9]);
+        fma_row_bcast<10>(a2, hc[c], w[16 * c + 10]); fma_row_bcast<11>(a3, hc[c], w[16 * c + 11]);
+        fma_row_bcast<12>(a0, hc[c], w[16 * c + 12]); fma_row_bcast<13>(a1, hc[c], w[16 * c + 13]);
+        fma_row_bcast<14>(a2, hc[c], w[16 * c + 14]); fma_row_bcast<15>(a3, hc[c], w[16 * c + 15]);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+// sum over the four rows of 16 lanes of a wavefront, in every lane (v_permlane32_swap / v_permlane16_swap of gfx950)
+__device__ __forceinline__ float rows_sum4(float a) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    const float b = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(b), __float_as_uint(b), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 // ---------------------------------------------------------------------------------------------------
-// forward recurrence: workgroup = (direction, sequence); thread j < 4H owns gate row j of W_hh
+// forward recurrence: workgroup = (direction, sequence); thread 4u + p owns gate row p*H + u of W_hh (gate order i, f, g, o), so the
+// four gates of a unit sit in one quad of lanes: they are combined by DPP quad permutes (no LDS, no barrier), every lane of the quad
+// carries the unit's cell state, and the new h goes to the other half of a double-buffered LDS vector -- ONE workgroup barrier per step
 // ---------------------------------------------------------------------------------------------------
 template <int HMAX>
 __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
                                     const float* __restrict__ w_hh1, const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
                                     const float* __restrict__ b_ih1, const float* __restrict__ b_hh1, float* __restrict__ gates,
                                     float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev) {
-    __shared__ __attribute__((aligned(16))) float hs[HMAX];
-    __shared__ float gl[4 * HMAX];
+    __shared__ __attribute__((aligned(16))) float hs[2][HMAX];
+    __shared__ float ring[LSTM_AHEAD][4 * HMAX];
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
-    const int j = threadIdx.x, H = g.H, H4 = g.H4;
-    const bool live = j < H4;
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, H = g.H, H4 = g.H4;
+    const bool live = u < H;
+    const int row = live ? p * H + u : 0;
     const float* w_hh = dir ? w_hh1 : w_hh0;
     float w[HMAX];
 #pragma unroll
-    for (int k = 0; k < HMAX; ++k) w[k] = (live && k < H) ? w_hh[j * H + k] : 0.f;
-    const float bias = live ? (dir ? b_ih1[j] + b_hh1[j] : b_ih0[j] + b_hh0[j]) : 0.f;
-    const bool is_tanh = j >= 2 * H && j < 3 * H;                      // gate order (i, f, g, o): g is the tanh row
+    for (int k = 0; k < HMAX; ++k) w[k] = (live && k < H) ? w_hh[(int64_t)row * H + k] : 0.f;
+    float bias_v = live ? (dir ? b_ih1[row] + b_hh1[row] : b_ih0[row] + b_hh0[row]) : 0.f;
+    const bool is_tanh = p == 2;                                       // gate order (i, f, g, o): g is the tanh row
     const float gate_in = is_tanh ? 1.0f : 0.5f;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;          // row of (dir, q, t = 0)
-    if (j < HMAX) hs[j] = 0.f;
-    float c = 0.f;
-    __syncthreads();
-    int64_t t = dir ? g.T - 1 : 0;
+    for (int e = tid; e < 2 * HMAX; e += blockDim.x) (&hs[0][0])[e] = 0.f;
+    float c = 0.f, hlast = 0.f;
+    const int64_t t0 = dir ? g.T - 1 : 0;
     const int64_t dt = dir ? -1 : 1;
-    float nxt = live ? gi[(base + t) * H4 + j] : 0.f;
-    for (int64_t s = 0; s < g.T; ++s, t += dt) {
-        float acc = nxt + bias;
-        if (live && s + 1 < g.T) nxt = gi[(base + t + dt) * H4 + j];       // next step's input projection, ahead of the matvec
+    const int wave0 = tid & ~63;
+    // running pointers (a step moves them by one row in this direction's order): the row to request, the tape rows to store
+    const float* gsrc = gi + (base + t0) * H4 + row;
+    const int64_t gstep = dt * H4, xstep = dt * H;
+    int64_t requested = 0;                                            // steps whose input projection has been requested
+    auto request = [&](int slot) {                                     // clamped at the end: the instruction count must not vary
+        dma_dword(gsrc, &ring[slot][wave0]);
+        if (++requested < g.T) gsrc += gstep;
+    };
+    // every lane stores its gate; lanes p = 0, 1, 2 of a unit share its (c, h, h entering the step)
+    float* gdst = gates + (base + t0) * H4 + row;
+    float* xdst = (p == 0 ? cseq : (p == 1 ? hseq : hprev)) + (base + t0) * H + (live ? u : 0);
+    // the weight rows above are the compiler's own loads: a use in front of the loop makes it wait for them HERE, not (conservatively,
+    // every step) at their first use inside
 #pragma unroll
-        for (int k = 0; k < HMAX; k += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(&hs[k]);
-            acc = fmaf(w[k], hv.x, acc);
-            acc = fmaf(w[k + 1], hv.y, acc);
-            acc = fmaf(w[k + 2], hv.z, acc);
-            acc = fmaf(w[k + 3], hv.w, acc);
-        }
-        // every gate row applies its own non-linearity before the barrier (all four wavefronts busy; sigmoid written as
-        // 0.5 + 0.5 tanh(x / 2) so that the tanh row and the sigmoid rows run the same instructions): behind the barrier a
-        // unit only combines its four gates and takes tanh(c)
-        if (live) {
-            const float tt = tanh_gate(acc * gate_in);
-            gl[j] = is_tanh ? tt : fmaf(0.5f, tt, 0.5f);
-        }
-        if (j < H) hprev[(base + t) * H + j] = hs[j];
-        __syncthreads();
-        if (j < H) {
-            const float ig = gl[j], fg = gl[H + j], gg = gl[2 * H + j], og = gl[3 * H + j];
+    for (int k = 0; k < HMAX; ++k) asm volatile("" : "+v"(w[k]));
+    asm volatile("" : "+v"(bias_v));
+    for (int i = 0; i < LSTM_AHEAD; ++i) request(i);
+    wait_vm<0>();
+    __syncthreads();
+    for (int64_t s0 = 0; s0 < g.T; s0 += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (s0 + i >= g.T) break;
+            const int slot = (int)((s0 + i) & (LSTM_AHEAD - 1));
+            const float* hv = hs[i];                                   // step s reads half s & 1
+            // issued after this row's request: the two stores of that step and (request, store, store) of the LSTM_AHEAD - 1 steps since
+            wait_vm<2 + 3 * (LSTM_AHEAD - 1)>();
+            float hc[HMAX / 16];
+            chunks_load<HMAX>(hc, hv, tid & 15);
+            const float pre = matvec_row_bcast<HMAX>(w, hc, ring[slot][tid] + bias_v);
+            // sigmoid written as 0.5 + 0.5 tanh(x / 2): the tanh row and the sigmoid rows run the same instructions
+            const float tt = tanh_gate(pre * gate_in);
+            const float gate = is_tanh ? tt : fmaf(0.5f, tt, 0.5f);
+            const float ig = quad_perm<0x00>(gate), fg = quad_perm<0x55>(gate), gg = quad_perm<0xAA>(gate), og = quad_perm<0xFF>(gate);
             c = fmaf(fg, c, ig * gg);
             const float h = og * tanh_gate(c);
-            float* gr = gates + (base + t) * H4;
-            gr[j] = ig; gr[H + j] = fg; gr[2 * H + j] = gg; gr[3 * H + j] = og;
-            cseq[(base + t) * H + j] = c;
-            hseq[(base + t) * H + j] = h;
-            hs[j] = h;
+            if (live && p == 3) hs[i ^ 1][u] = h;
+            request(slot);                                             // the slot's row was read in front of the matvec
+            if (live) store_async(gdst, gate);
+            if (live && p < 3) store_async(xdst, p == 0 ? c : (p == 1 ? h : hlast));
+            gdst += gstep;
+            xdst += xstep;
+            hlast = h;
+            lds_barrier();
         }
-        __syncthreads();
     }
 }
 
@@ -135,90 +219,103 @@ __global__ void lstm_sum_kernel(LstmGeom g, const float* __restrict__ hseq, floa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// BPTT: thread tid < 4H = (part p, unit k) keeps W_hh[p*H + :, k] in registers
+// BPTT: a wavefront owns 16 units; lane 16p + kl keeps W_hh[p*H + :, k] (gate block p, unit k = 16 wave + kl) in registers, so a row of
+// 16 lanes shares its gate block: the block's gate gradients are broadcast along the row by DPP (matvec_row_bcast), the four partial
+// sums of d h_prev[k] sit in the four rows (rows_sum4), every lane carries its unit's (dh, dc) and computes ITS gate's gradient: one
+// LDS vector of 4H gate gradients, double-buffered, one workgroup barrier per step.  The tape of a step (gates, cell states, incoming
+// gradient) does not depend on the recurrence: it is requested LSTM_AHEAD steps ahead (lane 16p + kl: gate p and one of c_t, c
+// entering, d out, read back from the wavefront's own ring segment) and folded into four coefficients one step ahead, in the shadow
+// of the matvec:   dct = dht * k_c + dc;  d gate_p = (p < 3 ? dct : dht) * k_p;  dc' = dct * k_fg
 // ---------------------------------------------------------------------------------------------------
 template <int HMAX>
 __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
                                      const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ dout,
                                      float* __restrict__ dgates) {
-    __shared__ __attribute__((aligned(16))) float dgl[4 * HMAX];
-    __shared__ float part[4][HMAX];
+    __shared__ __attribute__((aligned(16))) float dgl[2][4 * HMAX];           // [gate block][HMAX]
+    __shared__ float ring[LSTM_AHEAD][2][4 * HMAX];
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
-    const int tid = threadIdx.x, H = g.H, H4 = g.H4;
-    const bool live = tid < H4;
-    const int p = live ? tid / H : 0, k = live ? tid - p * H : 0;
+    const int tid = threadIdx.x, wave0 = tid & ~63, kl = tid & 15, p = (tid >> 4) & 3, k = (wave0 >> 2) + kl, H = g.H, H4 = g.H4;
+    const bool live = k < H;
+    const int kk = live ? k : 0;
     const float* w_hh = dir ? w_hh1 : w_hh0;
     float wt[HMAX];
 #pragma unroll
-    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && jj < H) ? w_hh[(p * H + jj) * H + k] : 0.f;
-    for (int e = tid; e < 4 * HMAX; e += blockDim.x) dgl[e] = 0.f;
+    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && jj < H) ? w_hh[((int64_t)p * H + jj) * H + kk] : 0.f;
+    for (int e = tid; e < 8 * HMAX; e += blockDim.x) (&dgl[0][0])[e] = 0.f;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;
     const int64_t obase = (int64_t)q * g.T;                          // dout is [q][t][H], shared by both directions
+    // opposite to the forward order of this direction
+    const int64_t t0 = dir ? 0 : g.T - 1;
+    const int64_t dt = dir ? 1 : -1;
+    // running pointers, one row per step in this loop's order.  The cell state entering step t is the one the forward left at t + dt
+    // (this loop's direction) -- the forward's first step (this loop's last) has none: its address is clamped and the value replaced
+    // by 0 in prepare
+    const float* gptr = gates + (base + t0) * H4 + p * H + kk;
+    const float* xptr = p == 2 ? dout + (obase + t0) * H + kk : cseq + (base + t0 + (p == 1 && g.T > 1 ? dt : 0)) * H + kk;
+    const int64_t gstep = dt * H4, xstep = dt * H;
+    int64_t requested = 0;
+    auto request = [&](int slot) {                                     // clamped at the end: the instruction count must not vary
+        dma_dword(gptr, &ring[slot][0][wave0]);
+        dma_dword(xptr, &ring[slot][1][wave0]);
+        ++requested;
+        if (requested < g.T) gptr += gstep;
+        if (requested + (p == 1 ? 1 : 0) < g.T) xptr += xstep;
+    };
+    // a step's tape, read back from this wavefront's ring segment (rows of 16: gate blocks i, f, g, o / c_t, c entering, d out) ...
+    struct Tape { float ig, fg, gg, og, ct, cp, d; };
+    auto tape_read = [&](int slot) {
+        const float* gr = &ring[slot][0][wave0 + kl];
+        const float* xr = &ring[slot][1][wave0 + kl];
+        return Tape{gr[0], gr[16], gr[32], gr[48], xr[0], xr[16], xr[32]};
+    };
+    // ... and folded into the step's coefficients
+    float k_c = 0.f, k_p = 0.f, k_fg = 0.f, k_do = 0.f;
+    auto prepare = [&](const Tape& r, bool forward_first) {
+        const float cp = forward_first ? 0.f : r.cp;
+        const float tc = tanh_gate(r.ct);
+        k_c = r.og * (1.0f - tc * tc);
+        const float ki = r.gg * r.ig * (1.0f - r.ig), kf = cp * r.fg * (1.0f - r.fg), kg = r.ig * (1.0f - r.gg * r.gg),
+                    ko = tc * r.og * (1.0f - r.og);
+        k_p = p == 0 ? ki : (p == 1 ? kf : (p == 2 ? kg : ko));
+        k_fg = r.fg;
+        k_do = r.d;
+    };
+    float* ddst = dgates + (base + t0) * H4 + p * H + kk;
+#pragma unroll
+    for (int jj = 0; jj < HMAX; ++jj) asm volatile("" : "+v"(wt[jj]));        // the compiler waits for its weight loads here (see the forward)
+    for (int i = 0; i < LSTM_AHEAD; ++i) request(i);
+    wait_vm<0>();
+    prepare(tape_read(0), g.T == 1);
     float dh = 0.f, dc = 0.f;
     __syncthreads();
-    // opposite to the forward order of this direction
-    int64_t t = dir ? 0 : g.T - 1;
-    const int64_t dt = dir ? 1 : -1;
-    // The tape of a step (gates, cell states, incoming gradient) does not depend on the recurrence: it is fetched one step
-    // ahead, so that a step does not start with a global-memory round trip.
-    float n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_ct = 0.f, n_cp = 0.f, n_do = 0.f;
-    auto fetch = [&](int64_t tt) {
-        const float* gr = gates + (base + tt) * H4;
-        n_ig = gr[tid]; n_fg = gr[H + tid]; n_gg = gr[2 * H + tid]; n_og = gr[3 * H + tid];
-        n_ct = cseq[(base + tt) * H + tid];
-        // cell state entering step tt: the forward visited tt - dt_fwd before tt, i.e. tt + dt in this loop's direction
-        const bool first = dir ? (tt == g.T - 1) : (tt == 0);
-        n_cp = first ? 0.f : cseq[(base + tt + dt) * H + tid];
-        n_do = dout[(obase + tt) * H + tid];
-    };
-    // ... and everything of a step that does not involve dh / dc is folded into six coefficients while the tape is in
-    // registers, off the recurrence's critical path (they are prepared behind the matvec of the step before):
-    //   dct = dht * k_c + dc;  (di, df, dg) = dct * (k_i, k_f, k_g);  do = dht * k_o;  dc' = dct * k_fg
-    float k_c = 0.f, k_i = 0.f, k_f = 0.f, k_g = 0.f, k_o = 0.f, k_fg = 0.f, k_do = 0.f;
-    auto prepare = [&]() {
-        const float tc = tanh_gate(n_ct);
-        k_c = n_og * (1.0f - tc * tc);
-        k_i = n_gg * n_ig * (1.0f - n_ig);
-        k_f = n_cp * n_fg * (1.0f - n_fg);
-        k_g = n_ig * (1.0f - n_gg * n_gg);
-        k_o = tc * n_og * (1.0f - n_og);
-        k_fg = n_fg;
-        k_do = n_do;
-    };
-    if (tid < H && g.T > 0) { fetch(t); prepare(); }
-    for (int64_t s = 0; s < g.T; ++s, t += dt) {
-        if (tid < H) {
+    for (int64_t s0 = 0; s0 < g.T; s0 += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t s = s0 + i;
+            if (s >= g.T) break;
+            const int slot = (int)(s & (LSTM_AHEAD - 1));
+            float* dcur = dgl[i];
             const float dht = k_do + dh;
             const float dct = fmaf(dht, k_c, dc);
-            const float di = dct * k_i, df = dct * k_f, dg = dct * k_g, dov = dht * k_o;
+            const float dval = (p == 3 ? dht : dct) * k_p;
             dc = dct * k_fg;
-            if (s + 1 < g.T) fetch(t + dt);
-            dgl[tid] = di; dgl[H + tid] = df; dgl[2 * H + tid] = dg; dgl[3 * H + tid] = dov;
-            float* dr = dgates + (base + t) * H4;
-            dr[tid] = di; dr[H + tid] = df; dr[2 * H + tid] = dg; dr[3 * H + tid] = dov;
+            if (live) dcur[p * HMAX + k] = dval;
+            if (live) store_async(ddst, dval);
+            ddst += gstep;
+            lds_barrier();
+            // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate: this row's block, then the four rows.  A wavefront
+            // issues in order and is alone on its SIMD at H = 64: the next step's tape (independent of the recurrence) is read from the
+            // ring in front of the matvec and folded behind it, so that the LDS latency hides under the FMAs.  Issued after that tape's
+            // requests (LSTM_AHEAD - 1 steps ago): (store, two requests) of the LSTM_AHEAD - 2 steps in between and this step's store
+            float dchunk[HMAX / 16];
+            chunks_load<HMAX>(dchunk, dcur + p * HMAX, kl);           // wt is zero beyond H; the LDS vector is zero there
+            wait_vm<3 * (LSTM_AHEAD - 2) + 1>();
+            const Tape nxt = tape_read((slot + 1) & (LSTM_AHEAD - 1));
+            const float part = matvec_row_bcast<HMAX>(wt, dchunk, 0.f);
+            request(slot);                                             // slot held this step's tape, folded into the coefficients a step ago
+            prepare(nxt, s + 2 >= g.T);
+            dh = rows_sum4(part);
         }
-        __syncthreads();
-        if (live) {                                   // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate
-            float a = 0.f;
-            const float* dsrc = dgl + p * H;
-            if ((H & 3) == 0) {                                                   // 16-byte LDS reads (p * H floats is a multiple of 16 B)
-#pragma unroll
-                for (int jj = 0; jj < HMAX; jj += 4) {                            // wt is zero beyond H; dsrc stays inside dgl
-                    const float4 dv = *reinterpret_cast<const float4*>(dsrc + jj);
-                    a = fmaf(dv.x, wt[jj], a);
-                    a = fmaf(dv.y, wt[jj + 1], a);
-                    a = fmaf(dv.z, wt[jj + 2], a);
-                    a = fmaf(dv.w, wt[jj + 3], a);
-                }
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < HMAX; ++jj) a = fmaf(dsrc[jj], wt[jj], a);
-            }
-            part[p][k] = a;
-        }
-        if (tid < H && s + 1 < g.T) prepare();        // the next step's coefficients (its tape was requested at the top of this step)
-        __syncthreads();
-        if (tid < H) dh = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
     }
 }
 

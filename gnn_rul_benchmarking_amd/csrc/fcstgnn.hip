@@ -13,6 +13,7 @@
 // adjacency / softmax / aggregation in LDS, the rest is elementwise.  Seven BatchNorms cut the step into phases; batch
 // statistics go through fp64 reduction cells in stream order.  BatchNorms on the unfolded windows are computed on the
 // rows with multiplicity weights (how many windows contain a patch).
+#include "aux_stream.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
@@ -884,7 +885,7 @@ __global__ void fc_fill_one_kernel(float* p) { p[0] = 1.f; }
 
 struct FcWs {
     size_t cells, one, z1, z2, a2, z3, F, Mm[2], P[2], AX[2], z5[2], feat, h1, h2, h3, dpred, sqerr;
-    size_t dh3, dh2, dh1, dfeat, dAX[2], dz5[2], gX[2], gM[2], dF, da2, dy1, gp1, gp2, split, total;
+    size_t dh3, dh2, dh1, dfeat, dAX[2], dz5[2], gX[2], gM[2], dMb[2], dF, da2, dy1, gp1, gp2, split, total;
     int rows;
 };
 
@@ -910,6 +911,7 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
         w->dz5[b] = take(GQ * g.HD);
         w->gX[b] = take(M * g.D2);
         w->gM[b] = take(M * g.D2);
+        w->dMb[b] = take(GQ * g.D2);     // per-graph d mapping blocks (their own buffer: AX[b] is still being read by the theta gradient)
     }
     w->feat = take(B * g.FIN);
     w->h1 = take(B * g.D2);
@@ -1065,24 +1067,33 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         float* split = P_(w.split);
         float* one = P_(w.one);
         hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
+        // Weight / bias gradient GEMMs: nothing in this call reads their results, and each is a ~6-19 us launch at its latency floor.
+        // With a second stream of the caller (args->aux_stream, aux_stream.hpp) they leave the critical path; they share the split-K
+        // scratch and therefore one stream.
+        AuxFork fk(st, a->aux_stream);
+        hipStream_t wst = fk.side();
+        auto fork = [&]() { fk.fork(); };
+        fork();
         if (a->dpred)
             hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3),
                                (const float*)nullptr, a->dpred, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 1);
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
-            return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, st);
+            return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, wst);
         };
         // ---- MLP ----
-        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, st));
-        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, st));
-        FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, st));
+        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
+        FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, wst));
+        FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, wst));
         FC_RC(colsum(P_(w.dh3), g.B, HD, gr + g.o_f3b));
         FC_RC(sgemm(P_(w.dh3), HD, 1, prm + g.o_f3w, 1, D2, P_(w.dh2), D2, Bi, D2, HD, false, st, bf));
         hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh2), (const float*)P_(w.h2), g.B * D2);
-        FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, st));
+        fork();
+        FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, wst));
         FC_RC(colsum(P_(w.dh2), g.B, D2, gr + g.o_f2b));
         FC_RC(sgemm(P_(w.dh2), D2, 1, prm + g.o_f2w, 1, D2, P_(w.dh1), D2, Bi, D2, D2, false, st, bf));
         hipLaunchKernelGGL(fc_relu_mask_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.dh1), (const float*)P_(w.h1), g.B * D2);
-        FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, st));
+        fork();
+        FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, wst));
         FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
         FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         // ---- graph blocks ----
@@ -1094,10 +1105,11 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(sync_pair(1, 4 + 2 * b));
             hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
                                (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
-            FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, st));
+            fork();
+            FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, wst));
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
             FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
-            // AX[b] is free from here on (its last reader was the theta gradient above): it takes the per-graph d mapping blocks
+            // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
             {
                 const size_t lds_b = sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1));
                 if (lds_b > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_graph_bwd_kernel),
@@ -1106,10 +1118,11 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             }
             hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_BWD_THREADS), sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1)), st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
-                               P_(w.dAX[b]), P_(w.AX[b]));
+                               P_(w.dAX[b]), P_(w.dMb[b]));
             hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
-                               (const float*)P_(w.AX[b]), P_(w.gX[b]), P_(w.gM[b]));
+                               (const float*)P_(w.dMb[b]), P_(w.gX[b]), P_(w.gM[b]));
         }
+        fork();
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
         FC_RC(sync_pair(1, 3));
@@ -1117,7 +1130,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
                            (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
         for (int b = 0; b < 2; ++b) {
-            FC_RC(sgemm_splitk(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, false, split, st));
+            FC_RC(sgemm_splitk(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, false, split, wst));
             FC_RC(colsum(P_(w.gM[b]), g.M, D2, gr + g.o_bmap[b]));
             FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
         }
@@ -1127,7 +1140,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);
-        FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, st));
+        fork();
+        FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, wst));
         FC_RC(colsum(P_(w.dF), g.M, D2, gr + g.o_b3));
         FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st, bf));
         // ---- encoder convolutions ----
@@ -1146,6 +1160,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.z1), P_(w.dy1), g.M * g.H1 * g.L1);
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
                            (const float*)P_(w.dy1), P_(w.gp1));
+        FC_RC(fk.join());                                    // the gradient GEMMs are done before the call's last kernel
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
         hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,

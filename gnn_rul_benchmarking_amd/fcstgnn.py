@@ -132,6 +132,7 @@ class FC_STGNN_RUL(nn.Module):
         self._count = off
         self._bn_ch = [dict(self.named_buffers())[n + ".running_mean"].numel() for n in BN_NAMES]
         self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
+        self.side_stream = PL.SideStream()
         self._bufs, self._pin_bufs, self._step_state = {}, False, None
         self._nbt_pending = 0
         self._step = 0
@@ -270,6 +271,7 @@ class FC_STGNN_RUL(nn.Module):
         a.step = int(step)
         a.training = 1 if training else 0
         a.step_state = self._step_state.data_ptr() if self._step_state is not None else None
+        a.aux_stream = self.side_stream.pointer(self._flat.device, training)       # the backward's weight / bias gradient GEMMs
         if self.compute_dtype not in ("f32", "bf16"):
             raise RuntimeError(f"compute_dtype must be 'f32' or 'bf16', not {self.compute_dtype!r}")
         a.compute_dtype = _lib.DTYPE_BF16 if self.compute_dtype == "bf16" else _lib.DTYPE_F32

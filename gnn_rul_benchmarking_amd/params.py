@@ -120,6 +120,24 @@ def mark_flat_views(module) -> None:
         hook()
 
 
+class SideStream:
+    """Second HIP stream a model hands to its training calls (``aux_stream`` of the argument structs, include/rulgnn.h): the backward's
+    parameter-gradient GEMMs run on it beside the data-gradient chain and are joined before the call returns its last kernel, so the
+    caller's stream semantics do not change.  ``enabled = False`` keeps everything on the current stream; a stream being captured into
+    a hipGraph never gets one (the fork / join events come from a pool the graph would pin)."""
+
+    def __init__(self):
+        self.enabled, self._stream = True, None
+
+    def pointer(self, device, training: bool = True):
+        import torch
+        if not (self.enabled and training) or torch.cuda.is_current_stream_capturing():
+            return None
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream.cuda_stream
+
+
 class ForwardTape:
     """Hazard check of the autograd path of the flat-parameter models.  The activations a backward needs live in ONE workspace per
     batch size (``model._bufs[B]``), written by every forward of that size: a second ``model(x)`` between a forward and its backward

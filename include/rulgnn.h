@@ -334,6 +334,7 @@ typedef struct rulgnn_astgcnn_args {
     int64_t global_batch;     /* MSE denominator */
     float bn_moment_weight;
     int32_t training;         /* != 0: BatchNorm batch statistics (model.train()), else running statistics */
+    void *aux_stream;         /* optional second HIP stream of the caller for the parameter-gradient GEMMs (see rulgnn_fcstgnn_args) */
 } rulgnn_astgcnn_args;
 
 int64_t rulgnn_astgcnn_param_count(const rulgnn_astgcnn_shape *shape);      /* < 0: invalid / unsupported */
@@ -425,6 +426,10 @@ typedef struct rulgnn_fcstgnn_args {
                                * on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; BatchNorm statistics, the window graphs, the
                                * weight gradients, the loss and the optimizer stay fp32.  BASELINE.json config "FC_STGNN ... bf16":
                                * reported separately, it does NOT meet the 1e-4 gate (tests/test_fcstgnn_gpu.py bounds its error) */
+    void *aux_stream;         /* optional second HIP stream of the caller (NULL: everything on `stream`).  The backward then runs its
+                               * weight / bias gradient GEMMs -- 17 latency-bound launches that nothing downstream waits for -- on it,
+                               * forked behind events recorded on `stream` and joined before the call's last kernel, while the
+                               * data-gradient chain continues on `stream`.  Same results (the GEMMs are the same launches). */
 } rulgnn_fcstgnn_args;
 #define RULGNN_DTYPE_F32  0
 #define RULGNN_DTYPE_BF16 1
