@@ -287,7 +287,10 @@ class HAGCN(Algorithm):
     def __init__(self, configs, hparams, device):
         super(HAGCN, self).__init__(configs)
         self.model = HAGCN_model(**configs)
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+        # the reference's torch.optim.Adam (algorithms.py:226-230) in its fused (one multi-tensor kernel) form: same update rule,
+        # ~2 launches per step instead of ~14 foreach kernels over the model's ~45 parameter tensors
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"],
+                                          fused=True)
         self.hparams = hparams
         self.alpha = hparams["alpha"]
         self.dp = None

@@ -24,7 +24,7 @@ struct LstmGeom {
     int Bq, I, H, H4;           // sequences, input width, hidden width
     int64_t rows;               // Bq * T
     // workspace offsets (floats); every per-direction tensor is [dir][q][t][.]
-    int64_t o_gi, o_gates, o_c, o_h, o_hprev, o_dgates, o_one, o_split, total;
+    int64_t o_gi, o_gates, o_c, o_tc, o_h, o_hprev, o_dgates, o_one, o_split, total;
 };
 
 __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
@@ -43,6 +43,7 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
     g->o_gi = tk(2 * g->rows * g->H4);
     g->o_gates = tk(2 * g->rows * g->H4);
     g->o_c = tk(2 * g->rows * g->H);
+    g->o_tc = tk(2 * g->rows * g->H);
     g->o_h = tk(2 * g->rows * g->H);
     g->o_hprev = tk(2 * g->rows * g->H);
     g->o_dgates = tk(2 * g->rows * g->H4);
@@ -57,13 +58,13 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
     return RULGNN_OK;
 }
 
-// The gate non-linearities sit on the critical path of every sequential step (0.27 us of 0.95 with libm's expf / tanhf and
-// IEEE division): hardware exp2 and reciprocal instead (v_exp_f32, v_rcp_f32: ~1 ulp each, ~2e-7 absolute on the outputs).
-__device__ inline float tanh_gate(float v) {
-    const float a = fabsf(v);
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * a));        // exp overflow -> rcp(inf) = 0 -> 1
-    return copysignf(t, v);
-}
+// The gate non-linearities sit on the critical path of every sequential step: hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp
+// each, ~2e-7 absolute on the outputs), and the argument scaling folded into the weights.  With e = 2^(k x):
+//   sigmoid(x) = 1 / (1 + e), k = -log2(e);     tanh(x) = 1 - 2 / (1 + e), k = 2 log2(e)   (e = inf -> rcp = 0 -> 1, e = 0 -> -1)
+// i.e. gate = fma(rcp(1 + exp2(k x)), m, b) with (m, b) = (1, 0) / (-2, 1): one instruction sequence for all four gate rows.
+constexpr float LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ float rcp1p_exp2(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v)); }
+__device__ __forceinline__ float tanh_fast(float v) { return fmaf(-2.0f, rcp1p_exp2(v * (2.0f * LOG2E)), 1.0f); }
 
 // One sequential step used to cost 1.6 us (H = 64) although its arithmetic is ~0.2 us: __syncthreads() waits for vmcnt(0), i.e. for the
 // step's global stores (and the prefetched input row) to complete -- two HBM round trips per step.  Here the step barrier only waits
@@ -75,17 +76,14 @@ __device__ inline float tanh_gate(float v) {
 // instructions issued after that row's request.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void store_async(float* dst, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(v) : "memory"); }
-// one dword per lane to lds_wave_base[lane]; all 64 lanes enabled; M0 carries the LDS base and is compiler-reserved: saved and restored
-__device__ __forceinline__ void dma_dword(const float* src, const float* lds_wave_base) {
-    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %2\n\t"
+// one dword per lane to LDS byte address lds_wave + 4 lane; all 64 lanes enabled.  M0 carries the LDS base: nothing else in these
+// kernels uses it (LDS instructions do not need M0 on gfx9), so it is neither saved nor restored.
+__device__ __forceinline__ void dma_dword(const float* src, unsigned lds_wave) {
+    asm volatile("s_mov_b32 m0, %1\n\t"
                  "s_nop 0\n\t"
-                 "global_load_lds_dword %1, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(src), "s"(base)
+                 "global_load_lds_dword %0, off"
+                 :
+                 : "v"(src), "s"(lds_wave)
                  : "memory");
 }
 template <int N>
@@ -137,72 +135,78 @@ __device__ __forceinline__ float quad_perm(float v) {
 // ---------------------------------------------------------------------------------------------------
 // forward recurrence: workgroup = (direction, sequence); thread 4u + p owns gate row p*H + u of W_hh (gate order i, f, g, o), so the
 // four gates of a unit sit in one quad of lanes: they are combined by DPP quad permutes (no LDS, no barrier), every lane of the quad
-// carries the unit's cell state, and the new h goes to the other half of a double-buffered LDS vector -- ONE workgroup barrier per step
+// carries the unit's cell state, and the new h goes to the other half of a double-buffered LDS vector -- ONE workgroup barrier per step.
+// A wavefront is alone on its SIMD at H = 64 and issues one instruction per ~4 cycles whatever its type, so the step is written for
+// instruction count: FULL (H == HMAX, HAGCN's layers) has no lane masks, every lane of a quad stores (its gate and one of c, h,
+// h entering, tanh c -- the last saves the BPTT an exp and a reciprocal per step), ring slots and LDS halves are immediates.
 // ---------------------------------------------------------------------------------------------------
-template <int HMAX>
+template <int HMAX, bool FULL>
 __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
                                     const float* __restrict__ w_hh1, const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
                                     const float* __restrict__ b_ih1, const float* __restrict__ b_hh1, float* __restrict__ gates,
-                                    float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev) {
-    __shared__ __attribute__((aligned(16))) float hs[2][HMAX];
+                                    float* __restrict__ cseq, float* __restrict__ hseq, float* __restrict__ hprev, float* __restrict__ tseq) {
+    __shared__ float hs[2][4 * HMAX];                                  // element 4u + p: every lane of a unit's quad writes its copy of h
     __shared__ float ring[LSTM_AHEAD][4 * HMAX];
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
-    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, H = g.H, H4 = g.H4;
-    const bool live = u < H;
+    const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, H = g.H, H4 = g.H4, T = (int)g.T;
+    const bool live = FULL || u < H;
     const int row = live ? p * H + u : 0;
     const float* w_hh = dir ? w_hh1 : w_hh0;
+    const float scale = p == 2 ? 2.0f * LOG2E : -LOG2E;                // gate order (i, f, g, o): g is the tanh row
+    const float gm = p == 2 ? -2.0f : 1.0f, gb = p == 2 ? 1.0f : 0.0f;
     float w[HMAX];
 #pragma unroll
-    for (int k = 0; k < HMAX; ++k) w[k] = (live && k < H) ? w_hh[(int64_t)row * H + k] : 0.f;
-    float bias_v = live ? (dir ? b_ih1[row] + b_hh1[row] : b_ih0[row] + b_hh0[row]) : 0.f;
-    const bool is_tanh = p == 2;                                       // gate order (i, f, g, o): g is the tanh row
-    const float gate_in = is_tanh ? 1.0f : 0.5f;
+    for (int k = 0; k < HMAX; ++k) w[k] = (live && (FULL || k < H)) ? w_hh[(int64_t)row * H + k] * scale : 0.f;
+    float bias_s = live ? (dir ? b_ih1[row] + b_hh1[row] : b_ih0[row] + b_hh0[row]) * scale : 0.f;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;          // row of (dir, q, t = 0)
-    for (int e = tid; e < 2 * HMAX; e += blockDim.x) (&hs[0][0])[e] = 0.f;
+    for (int e = tid; e < 8 * HMAX; e += blockDim.x) (&hs[0][0])[e] = 0.f;
     float c = 0.f, hlast = 0.f;
     const int64_t t0 = dir ? g.T - 1 : 0;
     const int64_t dt = dir ? -1 : 1;
-    const int wave0 = tid & ~63;
+    const unsigned ring_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&ring[0][tid & ~63]);   // LDS byte address
     // running pointers (a step moves them by one row in this direction's order): the row to request, the tape rows to store
     const float* gsrc = gi + (base + t0) * H4 + row;
     const int64_t gstep = dt * H4, xstep = dt * H;
-    int64_t requested = 0;                                            // steps whose input projection has been requested
+    int requested = 0;                                                 // steps whose input projection has been requested
     auto request = [&](int slot) {                                     // clamped at the end: the instruction count must not vary
-        dma_dword(gsrc, &ring[slot][wave0]);
-        if (++requested < g.T) gsrc += gstep;
+        dma_dword(gsrc, ring_wave + (unsigned)slot * (4 * HMAX * 4));
+        if (++requested < T) gsrc += gstep;
     };
-    // every lane stores its gate; lanes p = 0, 1, 2 of a unit share its (c, h, h entering the step)
     float* gdst = gates + (base + t0) * H4 + row;
-    float* xdst = (p == 0 ? cseq : (p == 1 ? hseq : hprev)) + (base + t0) * H + (live ? u : 0);
+    float* xdst = (p == 0 ? cseq : (p == 1 ? hseq : (p == 2 ? hprev : tseq))) + (base + t0) * H + (live ? u : 0);
     // the weight rows above are the compiler's own loads: a use in front of the loop makes it wait for them HERE, not (conservatively,
     // every step) at their first use inside
 #pragma unroll
     for (int k = 0; k < HMAX; ++k) asm volatile("" : "+v"(w[k]));
-    asm volatile("" : "+v"(bias_v));
+    asm volatile("" : "+v"(bias_s));
+#pragma unroll
     for (int i = 0; i < LSTM_AHEAD; ++i) request(i);
     wait_vm<0>();
     __syncthreads();
-    for (int64_t s0 = 0; s0 < g.T; s0 += 2) {
+    for (int s0 = 0; s0 < T; s0 += LSTM_AHEAD) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (s0 + i >= g.T) break;
-            const int slot = (int)((s0 + i) & (LSTM_AHEAD - 1));
-            const float* hv = hs[i];                                   // step s reads half s & 1
+        for (int i = 0; i < LSTM_AHEAD; ++i) {
+            if (s0 + i >= T) break;
+            const float* hv = hs[i & 1];                               // step s reads half s & 1 (LSTM_AHEAD is even)
             // issued after this row's request: the two stores of that step and (request, store, store) of the LSTM_AHEAD - 1 steps since
             wait_vm<2 + 3 * (LSTM_AHEAD - 1)>();
             float hc[HMAX / 16];
-            chunks_load<HMAX>(hc, hv, tid & 15);
-            const float pre = matvec_row_bcast<HMAX>(w, hc, ring[slot][tid] + bias_v);
-            // sigmoid written as 0.5 + 0.5 tanh(x / 2): the tanh row and the sigmoid rows run the same instructions
-            const float tt = tanh_gate(pre * gate_in);
-            const float gate = is_tanh ? tt : fmaf(0.5f, tt, 0.5f);
+#pragma unroll
+            for (int cc = 0; cc < HMAX / 16; ++cc) hc[cc] = hv[64 * cc + 4 * (tid & 15)];
+            const float pre = matvec_row_bcast<HMAX>(w, hc, fmaf(ring[i][tid], scale, bias_s));
+            const float gate = fmaf(rcp1p_exp2(pre), gm, gb);
             const float ig = quad_perm<0x00>(gate), fg = quad_perm<0x55>(gate), gg = quad_perm<0xAA>(gate), og = quad_perm<0xFF>(gate);
             c = fmaf(fg, c, ig * gg);
-            const float h = og * tanh_gate(c);
-            if (live && p == 3) hs[i ^ 1][u] = h;
-            request(slot);                                             // the slot's row was read in front of the matvec
-            if (live) store_async(gdst, gate);
-            if (live && p < 3) store_async(xdst, p == 0 ? c : (p == 1 ? h : hlast));
+            const float tc = tanh_fast(c);
+            float h = og * tc;
+            if (!FULL && !live) h = 0.f;                               // a dead unit's slot is read (times a zero weight)
+            hs[(i & 1) ^ 1][tid] = h;
+            request(i);                                                // the slot's row was read in front of the matvec
+            const float xv = p == 0 ? c : (p == 1 ? h : (p == 2 ? hlast : tc));
+            if (FULL || live) {
+                store_async(gdst, gate);
+                store_async(xdst, xv);
+            }
             gdst += gstep;
             xdst += xstep;
             hlast = h;
@@ -222,26 +226,29 @@ __global__ void lstm_sum_kernel(LstmGeom g, const float* __restrict__ hseq, floa
 // BPTT: a wavefront owns 16 units; lane 16p + kl keeps W_hh[p*H + :, k] (gate block p, unit k = 16 wave + kl) in registers, so a row of
 // 16 lanes shares its gate block: the block's gate gradients are broadcast along the row by DPP (matvec_row_bcast), the four partial
 // sums of d h_prev[k] sit in the four rows (rows_sum4), every lane carries its unit's (dh, dc) and computes ITS gate's gradient: one
-// LDS vector of 4H gate gradients, double-buffered, one workgroup barrier per step.  The tape of a step (gates, cell states, incoming
-// gradient) does not depend on the recurrence: it is requested LSTM_AHEAD steps ahead (lane 16p + kl: gate p and one of c_t, c
-// entering, d out, read back from the wavefront's own ring segment) and folded into four coefficients one step ahead, in the shadow
-// of the matvec:   dct = dht * k_c + dc;  d gate_p = (p < 3 ? dct : dht) * k_p;  dc' = dct * k_fg
+// LDS vector of 4H gate gradients, double-buffered, one workgroup barrier per step.  The tape of a step (gates, tanh c, cell state
+// entering, incoming gradient) does not depend on the recurrence: it is requested LSTM_AHEAD steps ahead (lane 16p + kl: gate p and
+// one of tanh c_t, c entering, d out; read back from the wavefront's own ring segment) and folded into four coefficients one step
+// ahead, interleaved with the matvec:   dct = dht * k_c + dc;  d gate_p = (p < 3 ? dct : dht) * k_p;  dc' = dct * k_fg
+//   k_c = o (1 - tc^2);   k_p = A (E (m - E) + b) with (A, E, m, b) = (g, i, 1, 0), (c entering, f, 1, 0), (i, g, 0, 1), (tc, o, 1, 0):
+// the same three instructions in every row, A and E read through per-lane LDS offsets.
 // ---------------------------------------------------------------------------------------------------
-template <int HMAX>
+template <int HMAX, bool FULL>
 __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
-                                     const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ dout,
-                                     float* __restrict__ dgates) {
-    __shared__ __attribute__((aligned(16))) float dgl[2][4 * HMAX];           // [gate block][HMAX]
-    __shared__ float ring[LSTM_AHEAD][2][4 * HMAX];
+                                     const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ tseq,
+                                     const float* __restrict__ dout, float* __restrict__ dgates) {
+    constexpr int ROW = 4 * HMAX;                                              // floats per ring row
+    __shared__ float dgl[2][ROW];                                              // [gate block][HMAX]
+    __shared__ float ring[LSTM_AHEAD][2][ROW];                                 // [slot][gates | tanh c, c entering, d out, -][lane of the workgroup]
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
-    const int tid = threadIdx.x, wave0 = tid & ~63, kl = tid & 15, p = (tid >> 4) & 3, k = (wave0 >> 2) + kl, H = g.H, H4 = g.H4;
-    const bool live = k < H;
+    const int tid = threadIdx.x, wave0 = tid & ~63, kl = tid & 15, p = (tid >> 4) & 3, k = (wave0 >> 2) + kl, H = g.H, H4 = g.H4, T = (int)g.T;
+    const bool live = FULL || k < H;
     const int kk = live ? k : 0;
     const float* w_hh = dir ? w_hh1 : w_hh0;
     float wt[HMAX];
 #pragma unroll
-    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && jj < H) ? w_hh[((int64_t)p * H + jj) * H + kk] : 0.f;
-    for (int e = tid; e < 8 * HMAX; e += blockDim.x) (&dgl[0][0])[e] = 0.f;
+    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && (FULL || jj < H)) ? w_hh[((int64_t)p * H + jj) * H + kk] : 0.f;
+    for (int e = tid; e < 2 * ROW; e += blockDim.x) (&dgl[0][0])[e] = 0.f;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;
     const int64_t obase = (int64_t)q * g.T;                          // dout is [q][t][H], shared by both directions
     // opposite to the forward order of this direction
@@ -249,71 +256,76 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
     const int64_t dt = dir ? 1 : -1;
     // running pointers, one row per step in this loop's order.  The cell state entering step t is the one the forward left at t + dt
     // (this loop's direction) -- the forward's first step (this loop's last) has none: its address is clamped and the value replaced
-    // by 0 in prepare
+    // by 0 when it is folded.  The second request of a step carries the row offset as the instruction's immediate (it moves the LDS
+    // AND the global address), hence the pointer ROW floats back.
     const float* gptr = gates + (base + t0) * H4 + p * H + kk;
-    const float* xptr = p == 2 ? dout + (obase + t0) * H + kk : cseq + (base + t0 + (p == 1 && g.T > 1 ? dt : 0)) * H + kk;
+    const float* xptr = (p == 2 ? dout + (obase + t0) * H : (p == 1 ? cseq + (base + t0 + (T > 1 ? dt : 0)) * H : tseq + (base + t0) * H)) + kk - ROW;
     const int64_t gstep = dt * H4, xstep = dt * H;
-    int64_t requested = 0;
+    const unsigned ring_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&ring[0][0][wave0]);   // LDS byte address
+    int requested = 0;
     auto request = [&](int slot) {                                     // clamped at the end: the instruction count must not vary
-        dma_dword(gptr, &ring[slot][0][wave0]);
-        dma_dword(xptr, &ring[slot][1][wave0]);
+        asm volatile("s_mov_b32 m0, %2\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dword %0, off\n\t"
+                     "global_load_lds_dword %1, off offset:%3"
+                     :
+                     : "v"(gptr), "v"(xptr), "s"(ring_wave + (unsigned)slot * (2 * ROW * 4)), "n"(ROW * 4)
+                     : "memory");
         ++requested;
-        if (requested < g.T) gptr += gstep;
-        if (requested + (p == 1 ? 1 : 0) < g.T) xptr += xstep;
+        if (requested < T) gptr += gstep;
+        if (requested + (p == 1 ? 1 : 0) < T) xptr += xstep;
     };
-    // a step's tape, read back from this wavefront's ring segment (rows of 16: gate blocks i, f, g, o / c_t, c entering, d out) ...
-    struct Tape { float ig, fg, gg, og, ct, cp, d; };
-    auto tape_read = [&](int slot) {
-        const float* gr = &ring[slot][0][wave0 + kl];
-        const float* xr = &ring[slot][1][wave0 + kl];
-        return Tape{gr[0], gr[16], gr[32], gr[48], xr[0], xr[16], xr[32]};
-    };
-    // ... and folded into the step's coefficients
+    // per-lane ring offsets (floats from the slot's start)
+    const int o_g = wave0 + kl;                                        // gates of this unit: + 0, 16, 32, 48 = i, f, g, o
+    const int o_x = ROW + wave0 + kl;                                  // + 0, 16, 32 = tanh c_t, c entering, d out
+    const int o_A = p == 0 ? o_g + 32 : (p == 1 ? o_x + 16 : (p == 2 ? o_g : o_x));
+    const int o_E = p == 0 ? o_g : (p == 1 ? o_g + 16 : (p == 2 ? o_g + 32 : o_g + 48));
+    const float km = p == 2 ? 0.0f : 1.0f, kb = p == 2 ? 1.0f : 0.0f;
+    const int no_entering = p == 1 ? T - 1 : -1;                       // the loop step whose "c entering" does not exist (lanes of row 1)
     float k_c = 0.f, k_p = 0.f, k_fg = 0.f, k_do = 0.f;
-    auto prepare = [&](const Tape& r, bool forward_first) {
-        const float cp = forward_first ? 0.f : r.cp;
-        const float tc = tanh_gate(r.ct);
-        k_c = r.og * (1.0f - tc * tc);
-        const float ki = r.gg * r.ig * (1.0f - r.ig), kf = cp * r.fg * (1.0f - r.fg), kg = r.ig * (1.0f - r.gg * r.gg),
-                    ko = tc * r.og * (1.0f - r.og);
-        k_p = p == 0 ? ki : (p == 1 ? kf : (p == 2 ? kg : ko));
-        k_fg = r.fg;
-        k_do = r.d;
+    auto prepare = [&](int slot, int step) {                           // the coefficients of loop step `step` from ring slot `slot`
+        const float* r = &ring[slot][0][0];
+        const float og = r[o_g + 48], tc = r[o_x], fg = r[o_g + 16], d = r[o_x + 32], E = r[o_E];
+        const float A = step == no_entering ? 0.f : r[o_A];
+        k_c = fmaf(-og * tc, tc, og);
+        k_p = A * fmaf(E, km - E, kb);
+        k_fg = fg;
+        k_do = d;
     };
     float* ddst = dgates + (base + t0) * H4 + p * H + kk;
 #pragma unroll
     for (int jj = 0; jj < HMAX; ++jj) asm volatile("" : "+v"(wt[jj]));        // the compiler waits for its weight loads here (see the forward)
+#pragma unroll
     for (int i = 0; i < LSTM_AHEAD; ++i) request(i);
     wait_vm<0>();
-    prepare(tape_read(0), g.T == 1);
+    prepare(0, 0);
     float dh = 0.f, dc = 0.f;
     __syncthreads();
-    for (int64_t s0 = 0; s0 < g.T; s0 += 2) {
+    for (int s0 = 0; s0 < T; s0 += LSTM_AHEAD) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t s = s0 + i;
-            if (s >= g.T) break;
-            const int slot = (int)(s & (LSTM_AHEAD - 1));
-            float* dcur = dgl[i];
+        for (int i = 0; i < LSTM_AHEAD; ++i) {
+            const int s = s0 + i;
+            if (s >= T) break;
+            float* dcur = dgl[i & 1];                                  // LSTM_AHEAD is even
             const float dht = k_do + dh;
             const float dct = fmaf(dht, k_c, dc);
             const float dval = (p == 3 ? dht : dct) * k_p;
             dc = dct * k_fg;
-            if (live) dcur[p * HMAX + k] = dval;
-            if (live) store_async(ddst, dval);
+            if (FULL || live) {
+                dcur[p * HMAX + k] = dval;
+                store_async(ddst, dval);
+            }
             ddst += gstep;
             lds_barrier();
-            // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate: this row's block, then the four rows.  A wavefront
-            // issues in order and is alone on its SIMD at H = 64: the next step's tape (independent of the recurrence) is read from the
-            // ring in front of the matvec and folded behind it, so that the LDS latency hides under the FMAs.  Issued after that tape's
-            // requests (LSTM_AHEAD - 1 steps ago): (store, two requests) of the LSTM_AHEAD - 2 steps in between and this step's store
+            // d h_prev[k] = sum over the four gate blocks of W_hh[block]^T d gate: this row's block, then the four rows.  The next
+            // step's tape is folded meanwhile; issued after its requests (LSTM_AHEAD - 1 steps ago): (store, two requests) of the
+            // LSTM_AHEAD - 2 steps in between and this step's store
             float dchunk[HMAX / 16];
             chunks_load<HMAX>(dchunk, dcur + p * HMAX, kl);           // wt is zero beyond H; the LDS vector is zero there
             wait_vm<3 * (LSTM_AHEAD - 2) + 1>();
-            const Tape nxt = tape_read((slot + 1) & (LSTM_AHEAD - 1));
+            prepare((i + 1) % LSTM_AHEAD, s + 1);
             const float part = matvec_row_bcast<HMAX>(wt, dchunk, 0.f);
-            request(slot);                                             // slot held this step's tape, folded into the coefficients a step ago
-            prepare(nxt, s + 2 >= g.T);
+            request(i);                                                // the slot held this step's tape, folded a step ago
             dh = rows_sum4(part);
         }
     }
@@ -355,14 +367,14 @@ int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hi
         LS_RC(sgemm(a->x, g.I, 1, a->w_ih[d], g.I, 1, ws + g.o_gi + (int64_t)d * g.rows * g.H4, g.H4, R, g.H4, g.I, false, st));
     const int threads = (g.H4 + 63) & ~63;
     const int d1 = ndir == 2 ? 1 : 0;                 // the one-direction launch never selects direction 1
-    if (g.H <= 64)
-        hipLaunchKernelGGL(lstm_forward_kernel<64>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
-                           a->w_hh[d1], a->b_ih[0], a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
-                           ws + g.o_hprev);
-    else
-        hipLaunchKernelGGL(lstm_forward_kernel<128>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0],
-                           a->w_hh[d1], a->b_ih[0], a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h,
-                           ws + g.o_hprev);
+    auto fwd = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0], a->w_hh[d1], a->b_ih[0],
+                           a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h, ws + g.o_hprev, ws + g.o_tc);
+    };
+    if (g.H == 64) fwd(lstm_forward_kernel<64, true>);                // no lane masks when the hidden width fills the kernel's
+    else if (g.H < 64) fwd(lstm_forward_kernel<64, false>);
+    else if (g.H == 128) fwd(lstm_forward_kernel<128, true>);
+    else fwd(lstm_forward_kernel<128, false>);
     if (ndir == 2) hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
     else hipLaunchKernelGGL(lstm_copy_kernel, dim3((unsigned)((g.rows * g.H + 255) / 256)), dim3(256), 0, st, (const float*)(ws + g.o_h), a->out, (int)(g.rows * g.H));
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
@@ -378,12 +390,14 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
     const int threads = (H4 + 63) & ~63;
     if (ndir != 1 && ndir != 2) return RULGNN_EINVAL;
     const int d1 = ndir == 2 ? 1 : 0;
-    if (H <= 64)
-        hipLaunchKernelGGL(lstm_backward_kernel<64>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1],
-                           (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
-    else
-        hipLaunchKernelGGL(lstm_backward_kernel<128>, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1],
-                           (const float*)(ws + g.o_gates), (const float*)(ws + g.o_c), a->dout, ws + g.o_dgates);
+    auto bwd = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1], (const float*)(ws + g.o_gates),
+                           (const float*)(ws + g.o_c), (const float*)(ws + g.o_tc), a->dout, ws + g.o_dgates);
+    };
+    if (H == 64) bwd(lstm_backward_kernel<64, true>);
+    else if (H < 64) bwd(lstm_backward_kernel<64, false>);
+    else if (H == 128) bwd(lstm_backward_kernel<128, true>);
+    else bwd(lstm_backward_kernel<128, false>);
     float* one = ws + g.o_one;
     float* split = ws + g.o_split;
     hipLaunchKernelGGL(lstm_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
