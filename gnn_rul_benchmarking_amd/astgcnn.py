@@ -17,13 +17,10 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
+from .flat import FlatModule, current_stream as _stream
 from .stgcn import TemporalConvNet
 
 TCN_KERNEL = 6          # Model.py:236
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class GatingMechanism(nn.Module):
@@ -86,7 +83,7 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, *out)
 
 
-class ASTGCNN_model(nn.Module):
+class ASTGCNN_model(FlatModule):
     def __init__(self, num_nodes, time_length, encoder_out_dim, output_dim, K):
         super().__init__()
         self.num_nodes, self.time_length = int(num_nodes), int(time_length)
@@ -98,49 +95,20 @@ class ASTGCNN_model(nn.Module):
         self.chebnet = ChebNet(self.encoder_out_dim, self.output_dim, self.K)
         self.fc = nn.Linear(self.output_dim, 1)
 
-        self._layout, self._count = live_layout(self.num_nodes, self.time_length, self.output_dim, self.K)
-        self._slices = []
-        for name, (off, shape) in self._layout.items():
-            n = 1
-            for s in shape:
-                n *= s
-            self._slices.append((off, n, shape))
         self._bn_names = [f"tcn.conv_block{b}.2.running_{k}" for b in (1, 2) for k in ("mean", "var")]
-        self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._bn = self._bn_batch = self._pred_buf = self._ws = None
         self.side_stream = PL.SideStream()
-        self._nbt_pending = 0
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
-        self._reflatten()
+        self._track_batchnorm_counters()
+        self._init_flat(*live_layout(self.num_nodes, self.time_length, self.output_dim, self.K))
 
     # ---- flat storage ----------------------------------------------------------------------------------
-    def _named_live(self):
-        table = dict(self.named_parameters())
-        return [(name, table[name]) for name in self._layout]
+    workspace_slots = 4
 
-    def _set_buffer(self, dotted, tensor):
-        mod = self
-        parts = dotted.split(".")
-        for a in parts[:-1]:
-            mod = getattr(mod, a)
-        mod._buffers[parts[-1]] = tensor
+    def _bucket_floats(self):
+        return self._count + 1 + 4 * self.num_nodes                   # [gradient | loss | BatchNorm batch moments]
 
-    def _flush_nbt(self):
-        if self._nbt_pending and self._nbt is not None:
-            self._nbt += self._nbt_pending
-            self._nbt_pending = 0
-
-    def _reflatten(self):
-        self._flush_nbt()
-        live = self._named_live()
-        dev = live[0][1].device
+    def _reflatten_buffers(self, dev):
         N = self.num_nodes
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for (name, p), (off, n, shape) in zip(live, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
         bufs = dict(self.named_buffers())
         bn = torch.empty(4 * N, dtype=torch.float32, device=dev)
         nbt = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -152,29 +120,11 @@ class ASTGCNN_model(nn.Module):
             nbt[b - 1].copy_(bufs[cname])
             self._set_buffer(cname, nbt[b - 1])
         self._bn, self._nbt = bn, nbt
-        self._grad_flat = torch.zeros(self._count + 1 + 4 * N, dtype=torch.float32, device=dev)   # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(4 * N, dtype=torch.float32, device=dev)
-        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
-        PL.mark_flat_views(self)
 
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss | BatchNorm batch moments]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    def _reset_caches(self):
+        super()._reset_caches()
+        self._pred_buf = self._ws = None
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -195,17 +145,9 @@ class ASTGCNN_model(nn.Module):
 
     def _args(self, shp, x2d, training, y=None, dpred=None, global_batch=None, moments_to_bucket=False):
         B = x2d.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_astgcnn_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("ASTGCNN kernels do not cover this configuration (num_nodes <= 25, time_length <= 64, "
-                                   "output_dim <= 256, K <= 3)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_astgcnn_workspace_bytes(C.byref(shp)),
+                                    "ASTGCNN kernels do not cover this configuration (num_nodes <= 25, time_length <= 64, "
+                                    "output_dim <= 256, K <= 3)", make=lambda dev: (torch.empty(B, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         a = _lib.AstgcnnArgs()
         a.x = x2d.data_ptr()
@@ -264,15 +206,7 @@ class ASTGCNN_model(nn.Module):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x2d.size(0))
         a = self._args(shp, x2d, True, y=yv, global_batch=global_batch, moments_to_bucket=moments_to_bucket)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
-                                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), 0.1,
-                                      self._step_state.data_ptr() if self._step_state is not None else None))
+        o = self._adam_args(optimizer, bn=self._bn)
         _lib.check(_lib.load().rulgnn_astgcnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_astgcnn_fwdbwd_f32")
         if optimizer is not None:
             self._nbt_pending += 1

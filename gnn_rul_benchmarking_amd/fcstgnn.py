@@ -22,12 +22,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
+from .flat import FlatModule, current_stream as _stream
 
 PE_DROPOUT = 0.1
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class Feature_extractor_1DCNN_RUL(nn.Module):
@@ -101,7 +98,7 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, *out)
 
 
-class FC_STGNN_RUL(nn.Module):
+class FC_STGNN_RUL(FlatModule):
     def __init__(self, patch_size, num_patch, encoder_time_out, encoder_hidden_dim, encoder_out_dim, encoder_conv_kernel,
                  hidden_dim, num_sequential, num_node, num_windows):
         super().__init__()
@@ -123,18 +120,9 @@ class FC_STGNN_RUL(nn.Module):
             ('fc4', nn.Linear(hidden_dim, 1))]))
 
         # flat layout = named_parameters() order (the order include/rulgnn.h documents)
-        self._layout, off = OrderedDict(), 0
-        self._slices = []
-        for name, p in self.named_parameters():
-            self._layout[name] = (off, tuple(p.shape))
-            self._slices.append((off, p.numel(), tuple(p.shape)))
-            off += p.numel()
-        self._count = off
         self._bn_ch = [dict(self.named_buffers())[n + ".running_mean"].numel() for n in BN_NAMES]
-        self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
+        self._bn = self._bn_batch = self._pred_buf = self._ws = None
         self.side_stream = PL.SideStream()
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
-        self._nbt_pending = 0
         self._step = 0
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.dropout_p = PE_DROPOUT
@@ -142,39 +130,19 @@ class FC_STGNN_RUL(nn.Module):
         # accumulation / BatchNorm / graphs / weight gradients / optimizer -- BASELINE.json's "FC_STGNN ... bf16" variant, reported
         # separately (rulgnn.h: rulgnn_fcstgnn_args.compute_dtype)
         self.compute_dtype = "f32"
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
-        self._reflatten()
+        self._track_batchnorm_counters()
+        self._init_flat()
         lib_count = _lib.load().rulgnn_fcstgnn_param_count(C.byref(self._shape(1)))
         if lib_count >= 0 and lib_count != self._count:
             raise RuntimeError(f"flat parameter layout mismatch: module {self._count} vs kernels {lib_count}")
 
     # ---- flat storage ----------------------------------------------------------------------------------
-    def _named_live(self):
-        table = dict(self.named_parameters())
-        return [(name, table[name]) for name in self._layout]
+    workspace_slots = 4
 
-    def _set_buffer(self, dotted, tensor):
-        mod = self
-        parts = dotted.split(".")
-        for a in parts[:-1]:
-            mod = getattr(mod, a)
-        mod._buffers[parts[-1]] = tensor
+    def _bucket_floats(self):
+        return self._count + 1 + 2 * sum(self._bn_ch)                 # [gradient | loss | BatchNorm batch moments]
 
-    def _flush_nbt(self):
-        if self._nbt_pending and self._nbt is not None:
-            self._nbt += self._nbt_pending
-            self._nbt_pending = 0
-
-    def _reflatten(self):
-        self._flush_nbt()
-        live = self._named_live()
-        dev = live[0][1].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for (name, p), (off, n, shape) in zip(live, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
+    def _reflatten_buffers(self, dev):
         bufs = dict(self.named_buffers())
         total = 2 * sum(self._bn_ch)
         bn = torch.empty(total, dtype=torch.float32, device=dev)
@@ -189,28 +157,11 @@ class FC_STGNN_RUL(nn.Module):
             self._set_buffer(name + ".num_batches_tracked", nbt[i])
             o += 2 * c
         self._bn, self._nbt = bn, nbt
-        self._grad_flat = torch.zeros(self._count + 1 + total, dtype=torch.float32, device=dev)      # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(total, dtype=torch.float32, device=dev)
-        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
-        PL.mark_flat_views(self)
 
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    def _reset_caches(self):
+        super()._reset_caches()
+        self._pred_buf = self._ws = None
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -233,18 +184,11 @@ class FC_STGNN_RUL(nn.Module):
 
     def _args(self, shp, x2d, training, step, y=None, dpred=None, global_batch=None, sample_offset=0, moments_to_bucket=False):
         B = x2d.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_fcstgnn_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("FC_STGNN kernels do not cover this configuration (encoder_time_out must be the second conv's "
-                                   "output length, num_windows the windows of the two blocks; num_node <= 20, hidden_dim <= 32, "
-                                   "encoder_out_dim <= 64, encoder_hidden_dim <= 16, encoder_conv_kernel <= 4)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_fcstgnn_workspace_bytes(C.byref(shp)),
+                                    "FC_STGNN kernels do not cover this configuration (encoder_time_out must be the second conv's "
+                                    "output length, num_windows the windows of the two blocks; num_node <= 20, hidden_dim <= 32, "
+                                    "encoder_out_dim <= 64, encoder_hidden_dim <= 16, encoder_conv_kernel <= 4)",
+                                    make=lambda dev: (torch.empty(B, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         a = _lib.FcstgnnArgs()
         a.x = x2d.data_ptr()
@@ -312,15 +256,7 @@ class FC_STGNN_RUL(nn.Module):
         shp = self._shape(x2d.size(0))
         a = self._args(shp, x2d, True, self._step, y=yv, global_batch=global_batch, sample_offset=sample_offset,
                        moments_to_bucket=moments_to_bucket)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
-                                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), 0.1,
-                                      self._step_state.data_ptr() if self._step_state is not None else None))
+        o = self._adam_args(optimizer, bn=self._bn)
         _lib.check(_lib.load().rulgnn_fcstgnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_fcstgnn_fwdbwd_f32")
         if optimizer is not None:
             self._nbt_pending += 1

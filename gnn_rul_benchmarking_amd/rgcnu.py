@@ -19,12 +19,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
+from .flat import FlatModule, current_stream as _stream
 
 SCL_DROPOUT = 0.5          # models/RGCNU/Model.py:31
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 # ---- parameter holders: created in the reference's order so that a seed gives the reference's initial weights; never called ----
@@ -95,7 +92,7 @@ class _Function(torch.autograd.Function):
         return (None, None, None, *outs)
 
 
-class RGCNU_model(nn.Module):
+class RGCNU_model(FlatModule):
     dropout_by_sample_offset = True          # dp.py: pass the shard's first global sample index to fused_mse_step
 
     def __init__(self, num_nodes, time_length, hidden_dim, encoder_hidden_dim, kernel_size, alpha):
@@ -109,63 +106,15 @@ class RGCNU_model(nn.Module):
         self.fusion = FusionModule(self.num_nodes, self.encoder_hidden_dim, self.kernel_size, self.time_length)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._step = 0
-        table = dict(self.named_parameters())
-        if list(table) != PARAM_ORDER:
+        if [n for n, _ in self.named_parameters()] != PARAM_ORDER:
             raise RuntimeError("parameter order differs from the flat layout of include/rulgnn.h")
-        self._slices, off = [], 0
-        self._layout = {}
-        for name in PARAM_ORDER:
-            shape, n = tuple(table[name].shape), table[name].numel()
-            self._layout[name] = (off, shape)
-            self._slices.append((off, n, shape))
-            off += n
-        self._count = off
+        self._tape = PL.ForwardTape()
+        self._init_flat()
         # fusion.fc2 (the `std` head) is not in the loss: its gradient is None in the reference and torch's Adam never touches it
         self.num_optimized = self._layout["fusion.fc2.weight"][0]
-        self._flat = self._grad_flat = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
-        self._tape = PL.ForwardTape()
-        self._reflatten()
 
-    # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in PARAM_ORDER]
-
-    def _named_live(self):
-        return list(zip(PARAM_ORDER, self._named()))
-
-    def _reflatten(self):
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
-        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._bufs, self._step_state = {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):
-            self._reflatten()
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    flat_order = PARAM_ORDER
+    workspace_slots = 4
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -182,18 +131,10 @@ class RGCNU_model(nn.Module):
 
     def _args(self, shp, x, training, step, y=None, dpred=None, global_batch=None, sample_offset=0):
         B = x.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_rgcnu_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("RGCNU HIP kernels do not cover this configuration (num_nodes <= 32, time_length <= 64, hidden widths "
-                                   "<= 64, odd kernel_size <= 7)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_rgcnu_workspace_bytes(C.byref(shp)),
+                                    "RGCNU HIP kernels do not cover this configuration (num_nodes <= 32, time_length <= 64, hidden widths "
+                                    "<= 64, odd kernel_size <= 7)",
+                                    make=lambda dev: tuple(torch.empty(max(B, 1), dtype=torch.float32, device=dev) for _ in range(2)))
         ws, pred, std = ent
         a = _lib.RgcnuArgs()
         a.x = x.data_ptr()
@@ -237,14 +178,7 @@ class RGCNU_model(nn.Module):
         shp = self._shape(x.size(0))
         self._tape.mark(x.size(0))
         a, pred, _ = self._args(shp, x, True, self._step, y=yv, global_batch=global_batch, sample_offset=sample_offset)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                      0.1, None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_rgcnu_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_rgcnu_fwdbwd_f32")
         return pred[:x.size(0)], self._grad_flat[self._count]
 

@@ -21,10 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .flat import FlatModule, current_stream as _stream
 
 
 class GCNLayer(nn.Module):
@@ -65,7 +62,7 @@ class _Function(torch.autograd.Function):
         return (None, None, *[grads[off:off + n].view(shape).clone() for off, n, shape in model._slices])
 
 
-class SAGCN_model(nn.Module):
+class SAGCN_model(FlatModule):
     def __init__(self, num_patch, patch_size, gcn_hidden_dim, attention_hidden_dim):
         super().__init__()
         self.num_patch, self.patch_size = int(num_patch), int(patch_size)
@@ -76,56 +73,8 @@ class SAGCN_model(nn.Module):
         self.proj2 = GraphProjectionLayer(self.gcn_hidden_dim, self.gcn_hidden_dim, self.num_patch)
         self.attn = SelfAttentionLayer(self.num_patch, self.attention_hidden_dim)
         self.fc = nn.Linear(self.gcn_hidden_dim * self.num_patch, 1)
-        self._slices, self._layout, off = [], {}, 0
-        for name, p in self.named_parameters():
-            self._layout[name] = (off, tuple(p.shape))
-            self._slices.append((off, p.numel(), tuple(p.shape)))
-            off += p.numel()
-        self._count = off
-        self._flat = self._grad_flat = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
         self._tape = PL.ForwardTape()
-        self._reflatten()
-
-    # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in self._layout]
-
-    def _named_live(self):
-        return list(zip(self._layout, self._named()))
-
-    def _reflatten(self):
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
-        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._bufs, self._step_state = {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):
-            self._reflatten()
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+        self._init_flat()
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -143,17 +92,9 @@ class SAGCN_model(nn.Module):
 
     def _args(self, shp, x, y=None, dpred=None, global_batch=None):
         B = x.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_sagcn_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("SAGCN HIP kernels do not cover this configuration (num_patch <= 256, 2 <= patch_size <= 2048, hidden "
-                                   "sizes <= 4096, batch * gcn_hidden_dim * num_patch < 2^31)")
-            if len(self._bufs) >= 2 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_sagcn_workspace_bytes(C.byref(shp)),
+                                    "SAGCN HIP kernels do not cover this configuration (num_patch <= 256, 2 <= patch_size <= 2048, hidden "
+                                    "sizes <= 4096, batch * gcn_hidden_dim * num_patch < 2^31)")
         ws, pred = ent
         a = _lib.SagcnArgs()
         a.x = x.data_ptr()
@@ -202,13 +143,7 @@ class SAGCN_model(nn.Module):
         shp = self._shape(x.size(0))
         self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), 0.1, None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_sagcn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_sagcn_fwdbwd_f32")
         return pred[:x.size(0)], self._grad_flat[self._count]
 

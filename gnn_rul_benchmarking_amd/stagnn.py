@@ -19,10 +19,7 @@ import torch.nn as nn
 from torch.nn.utils import weight_norm
 
 from . import _lib, params as PL
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .flat import FlatModule, current_stream as _stream
 
 
 class GCNLayer(nn.Module):
@@ -117,7 +114,7 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, *[grads[off:off + n].view(shape).clone() for off, n, shape in model._slices])
 
 
-class STAGNN_model(nn.Module):
+class STAGNN_model(FlatModule):
     def __init__(self, num_nodes, time_length, hidden_dim, output_dim, num_heads, threshold):
         super().__init__()
         self.num_nodes, self.time_length, self.hidden_dim = int(num_nodes), int(time_length), int(hidden_dim)
@@ -134,53 +131,20 @@ class STAGNN_model(nn.Module):
         self.temporal_encoder2 = MultiHeadTemporalEncoder(self.num_heads, self.output_dim)
         self.fc = nn.Linear(h * self.output_dim, 1)
         table = dict(self.named_parameters())
-        self._slices, self._layout, off = [], {}, 0
         for name in live_parameter_names(self.num_heads):
             if name not in table:
                 raise RuntimeError(f"STAGNN HIP kernels need the residual 1x1 convolutions (num_nodes != hidden_dim != output_dim): no '{name}'")
-            p = table[name]
-            self._layout[name] = (off, tuple(p.shape))
-            self._slices.append((off, p.numel(), tuple(p.shape)))
-            off += p.numel()
-        self._count = off
+        self.flat_order = live_parameter_names(self.num_heads)
         self._bn_channels = (h, h, self.output_dim, self.output_dim)
-        self._flat = self._bn = self._nbt = self._grad_flat = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
+        self._bn = self._nbt = None
         self._tape = PL.ForwardTape()
-        self._nbt_pending = 0
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
-        self._reflatten()
+        self._track_batchnorm_counters()
+        self._init_flat()
 
     # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in self._layout]
+    workspace_slots = 3
 
-    def _named_live(self):
-        return list(zip(self._layout, self._named()))
-
-    def _set_buffer(self, dotted, tensor):
-        mod = self
-        parts = dotted.split(".")
-        for a in parts[:-1]:
-            mod = getattr(mod, a)
-        mod._buffers[parts[-1]] = tensor
-
-    def _flush_nbt(self):
-        if self._nbt_pending and self._nbt is not None:
-            self._nbt += self._nbt_pending
-            self._nbt_pending = 0
-
-    def _reflatten(self):
-        self._flush_nbt()
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
+    def _reflatten_buffers(self, dev):
         bufs = dict(self.named_buffers())
         bn = torch.empty(2 * sum(self._bn_channels), dtype=torch.float32, device=dev)
         nbt = torch.zeros(4, dtype=torch.int64, device=dev)
@@ -193,28 +157,6 @@ class STAGNN_model(nn.Module):
             nbt[k].copy_(bufs[f"{layer}.num_batches_tracked"])
             self._set_buffer(f"{layer}.num_batches_tracked", nbt[k])
         self._bn, self._nbt = bn, nbt
-        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._bufs, self._step_state = {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):
-            self._reflatten()
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -231,17 +173,9 @@ class STAGNN_model(nn.Module):
 
     def _args(self, shp, x, training, y=None, dpred=None, global_batch=None, update_running_stats=True):
         B = x.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stagnn_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("STAGNN HIP kernels do not cover this configuration (num_nodes <= 32, time_length <= 128, 3 <= hidden_dim "
-                                   "<= 64, output_dim <= 16, num_heads <= 4, num_nodes != hidden_dim != output_dim)")
-            if len(self._bufs) >= 3 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_stagnn_workspace_bytes(C.byref(shp)),
+                                    "STAGNN HIP kernels do not cover this configuration (num_nodes <= 32, time_length <= 128, 3 <= hidden_dim "
+                                    "<= 64, output_dim <= 16, num_heads <= 4, num_nodes != hidden_dim != output_dim)")
         ws, pred = ent
         a = _lib.StagnnArgs()
         a.x = x.data_ptr()
@@ -289,13 +223,7 @@ class STAGNN_model(nn.Module):
         shp = self._shape(x.size(0))
         self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, True, y=yv, global_batch=global_batch, update_running_stats=update_running_stats)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), 0.1, None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_stagnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stagnn_fwdbwd_f32")
         if update_running_stats:
             self._nbt_pending += 1

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
+from .flat import FlatModule, current_stream as _stream
 from .stgcn import MPNN_mk, TemporalConvNet
 
 LIVE = ("theta1", "theta2", "theta3", "theta4", "gcn_layer_1.theta.0.weight", "gcn_layer_1.theta.0.bias",
@@ -26,10 +27,6 @@ LIVE = ("theta1", "theta2", "theta3", "theta4", "gcn_layer_1.theta.0.weight", "g
         "tcn_layer_1.conv_block2.0.weight", "tcn_layer_1.conv_block2.2.weight", "tcn_layer_1.conv_block2.2.bias",
         "fc.weight", "fc.bias")
 BN_NAMES = ("tcn_layer_1.conv_block1.2", "tcn_layer_1.conv_block2.2", "cnn_layer_1.bn")
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class CNNLayer(nn.Module):
@@ -57,7 +54,7 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, *out)
 
 
-class ST_Conv_model(nn.Module):
+class ST_Conv_model(FlatModule):
     def __init__(self, num_nodes, time_length, kernel_size):
         super().__init__()
         self.num_nodes, self.time_length, self.kernel_size = int(num_nodes), int(time_length), int(kernel_size)
@@ -74,48 +71,24 @@ class ST_Conv_model(nn.Module):
         self.theta4 = nn.Parameter(torch.randn(1))
         self.fc = nn.Linear(num_nodes * time_length, 1)
 
-        table = dict(self.named_parameters())
-        self._layout, self._slices, off = {}, [], 0
-        for name in LIVE:
-            p = table[name]
-            self._layout[name] = (off, tuple(p.shape))
-            self._slices.append((off, p.numel(), tuple(p.shape)))
-            off += p.numel()
-        self._count = off
-        self._flat = self._bn = self._nbt = self._grad_flat = self._bn_batch = self._pred_buf = self._ws = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
-        self._nbt_pending = 0
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
-        self._reflatten()
+        self._bn = self._bn_batch = self._pred_buf = self._ws = None
+        self._track_batchnorm_counters()
+        self._init_flat()
 
     # ---- flat storage ----------------------------------------------------------------------------------
-    def _named_live(self):
-        table = dict(self.named_parameters())
-        return [(name, table[name]) for name in self._layout]
-
-    def _set_buffer(self, dotted, tensor):
-        mod = self
-        parts = dotted.split(".")
-        for a in parts[:-1]:
-            mod = getattr(mod, a)
-        mod._buffers[parts[-1]] = tensor
+    flat_order = LIVE                                                  # the parameters the forward uses; the rest stay ordinary tensors
+    workspace_slots = 4
 
     def _flush_nbt(self):
         if self._nbt_pending and self._nbt is not None:
             self._nbt += 2 * self._nbt_pending          # every live BatchNorm runs twice per training forward (Model.py:196-206)
             self._nbt_pending = 0
 
-    def _reflatten(self):
-        self._flush_nbt()
-        live = self._named_live()
-        dev = live[0][1].device
+    def _bucket_floats(self):
+        return self._count + 1 + 6 * self.num_nodes                   # [gradient | loss | BatchNorm batch moments]
+
+    def _reflatten_buffers(self, dev):
         N = self.num_nodes
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for (name, p), (off, n, shape) in zip(live, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
         bufs = dict(self.named_buffers())
         bn = torch.empty(6 * N, dtype=torch.float32, device=dev)
         nbt = torch.zeros(3, dtype=torch.int64, device=dev)
@@ -127,28 +100,11 @@ class ST_Conv_model(nn.Module):
             nbt[i].copy_(bufs[name + ".num_batches_tracked"])
             self._set_buffer(name + ".num_batches_tracked", nbt[i])
         self._bn, self._nbt = bn, nbt
-        self._grad_flat = torch.zeros(self._count + 1 + 6 * N, dtype=torch.float32, device=dev)   # [grad | loss | BN moments]
         self._bn_batch = torch.zeros(6 * N, dtype=torch.float32, device=dev)
-        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
-        PL.mark_flat_views(self)
 
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    def _reset_caches(self):
+        super()._reset_caches()
+        self._pred_buf = self._ws = None
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -166,16 +122,9 @@ class ST_Conv_model(nn.Module):
 
     def _args(self, shp, x2d, training, y=None, dpred=None, global_batch=None, moments_to_bucket=False):
         B = x2d.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stconv_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("ST_Conv kernels do not cover this configuration (kernel_size 6, num_nodes <= 25, time_length <= 64)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_stconv_workspace_bytes(C.byref(shp)),
+                                    "ST_Conv kernels do not cover this configuration (kernel_size 6, num_nodes <= 25, time_length <= 64)",
+                                    make=lambda dev: (torch.empty(B, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         a = _lib.AstgcnnArgs()
         a.x = x2d.data_ptr()
@@ -228,15 +177,7 @@ class ST_Conv_model(nn.Module):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x2d.size(0))
         a = self._args(shp, x2d, True, y=yv, global_batch=global_batch, moments_to_bucket=moments_to_bucket)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
-                                      float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                      float(g["weight_decay"]), 0.1,
-                                      self._step_state.data_ptr() if self._step_state is not None else None))
+        o = self._adam_args(optimizer, bn=self._bn)
         _lib.check(_lib.load().rulgnn_stconv_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stconv_fwdbwd_f32")
         if optimizer is not None:
             self._nbt_pending += 1

@@ -18,6 +18,7 @@ import torch.nn as nn
 from torch.nn.utils import weight_norm
 
 from . import _lib, params as PL
+from .flat import FlatModule, current_stream as _stream
 
 NUM_STATS = PL.NUM_STATS
 
@@ -69,10 +70,6 @@ class SG_TCN(nn.Module):
 # --------------------------------------------------------------------------------------------
 # autograd bridge
 # --------------------------------------------------------------------------------------------
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
 class _TrainFunction(torch.autograd.Function):
     """model(X) in train mode: forward = rulgnn_stgcn_train_forward_f32, backward =
     rulgnn_stgcn_train_backward_f32 with the incoming d(loss)/d(pred)."""
@@ -98,7 +95,7 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, *out)
 
 
-class ST_GCN_model(nn.Module):
+class ST_GCN_model(FlatModule):
     def __init__(self, num_patch, patch_size, num_layers=2, dropout=0.5, k=1):
         super().__init__()
         self.num_patch = int(num_patch)
@@ -117,47 +114,24 @@ class ST_GCN_model(nn.Module):
         self.fc1 = nn.Linear(self.num_patch, self.num_patch)
         self.fc2 = nn.Linear(self.num_patch, 1)
 
-        self._layout = PL.live_param_layout(self.num_patch, self.num_layers)
         self._bn_layout = PL.bn_buffer_layout(self.num_layers)
-        self._live_slices = []
-        for name, (off, shape) in self._layout.items():
-            n = 1
-            for s in shape:
-                n *= s
-            self._live_slices.append((off, n, shape))
-        self._flat = None           # flat live parameters (the tensors in state_dict are views of it)
-        self._bn = None             # [L][2][2][10] running statistics
-        self._nbt = None            # [2L] num_batches_tracked
-        self._grad_flat = None      # gradient / all-reduce bucket (see dp.py): [P | loss | 4L*10 BN moments]
-        self._bn_batch = None
-        self._loss = None
-        self._ws = None
-        self._bufs = {}             # batch size -> (training workspace, prediction buffer); several sizes stay alive
-        self._pin_bufs = False      # graphs.py: captured hipGraphs hold these pointers, never evict
-        self._step_state = None     # device step state (graphs.py), else the host counters are used
+        self._bn = None             # [L][2][2][10] running statistics; _nbt: [2L] num_batches_tracked
+        self._bn_batch = self._loss = self._ws = self._pred_buf = self._fwd_ws = None
         self._step = 0              # training forwards so far (dropout stream position)
-        self._nbt_pending = 0       # BatchNorm num_batches_tracked increments not yet written to the buffers
-        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._flush_nbt())
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        self._reflatten()
+        self._track_batchnorm_counters()
+        # _bufs: batch size -> (training workspace, prediction buffer), several sizes stay alive; _pin_bufs (graphs.py): captured
+        # hipGraphs hold these pointers, never evict; _step_state: device step state (graphs.py), else the host counters are used
+        self._init_flat(PL.live_param_layout(self.num_patch, self.num_layers), PL.param_count(self.num_patch, self.num_layers))
+        self._live_slices = self._slices
 
     # ---- flat storage --------------------------------------------------------------------------
-    def _named_live(self):
-        table = dict(self.named_parameters())
-        return [(name, table[name]) for name in self._layout]
+    workspace_slots = 4
 
-    def _reflatten(self):
-        """(Re)build the flat buffers on the parameters' current device and re-point every live
-        parameter / BatchNorm buffer at its slice."""
-        self._flush_nbt()
-        live = self._named_live()
-        dev = live[0][1].device
-        flat = torch.empty(PL.param_count(self.num_patch, self.num_layers), dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for (name, p), (off, n, shape) in zip(live, self._live_slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
+    def _bucket_floats(self):                                          # [gradient (P) | loss (1) | BatchNorm batch moments (2L*2*10)]
+        return self._count + 1 + PL.bn_buffer_count(self.num_layers)
+
+    def _reflatten_buffers(self, dev):
         bufs = dict(self.named_buffers())
         bn = torch.empty(PL.bn_buffer_count(self.num_layers), dtype=torch.float32, device=dev)
         nbt = torch.zeros(2 * self.num_layers, dtype=torch.int64, device=dev)
@@ -169,46 +143,12 @@ class ST_GCN_model(nn.Module):
                 nbt[i // 2].copy_(bufs[cname])
                 self._set_buffer(cname, nbt[i // 2])
         self._bn, self._nbt = bn, nbt
-        nb = PL.param_count(self.num_patch, self.num_layers) + 1 + PL.bn_buffer_count(self.num_layers)
-        self._grad_flat = torch.zeros(nb, dtype=torch.float32, device=dev)
         self._bn_batch = torch.zeros(PL.bn_buffer_count(self.num_layers), dtype=torch.float32, device=dev)
         self._loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._pred_buf = None
-        self._ws, self._bufs = None, {}
-        self._step_state = None
-        self._fwd_ws = None
-        PL.mark_flat_views(self)
 
-    def _flush_nbt(self):
-        if self._nbt_pending and self._nbt is not None:
-            self._nbt += self._nbt_pending
-            self._nbt_pending = 0
-
-    def _set_buffer(self, dotted, tensor):
-        mod = self
-        parts = dotted.split(".")
-        for a in parts[:-1]:
-            mod = getattr(mod, a)
-        mod._buffers[parts[-1]] = tensor
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self) -> torch.Tensor:
-        return self._flat
-
-    @property
-    def bucket(self) -> torch.Tensor:
-        """[gradient (P) | loss (1) | BatchNorm batch moments (2L*2*10)]: what one all-reduce carries."""
-        return self._grad_flat
-
-    @property
-    def num_live(self) -> int:
-        return self._flat.numel()
+    def _reset_caches(self):
+        super()._reset_caches()
+        self._pred_buf = self._ws = self._fwd_ws = None
 
     # ---- C-ABI calls ---------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -226,18 +166,10 @@ class ST_GCN_model(nn.Module):
         return x.reshape(bs, self.num_patch * self.patch_size).contiguous().float()
 
     def _workspace(self, shp, batch):
-        ent = self._bufs.get(batch)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError(
-                    f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
-                    "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(batch, dtype=torch.float32, device=self._flat.device))
-            self._bufs[batch] = ent
+        ent = self._workspace_entry(batch, lambda: _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp)),
+                                    f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
+                                    "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)",
+                                    make=lambda dev: (torch.empty(batch, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         return self._ws
 
@@ -391,13 +323,8 @@ class ST_GCN_model(nn.Module):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step)
-        m, v = optimizer._state_buffers()
-        optimizer._steps += 1
-        g = optimizer.param_groups[0]
-        o = _lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), self._bn.data_ptr(), optimizer._steps,
-                          float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                          float(g["weight_decay"]), 0.1, self._step_state.data_ptr() if self._step_state is not None else None)
-        _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), C.byref(o), int(self.step_path), _stream()),
+        o = self._adam_args(optimizer, bn=self._bn)
+        _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), o, int(self.step_path), _stream()),
                    "rulgnn_stgcn_train_step_path_f32")
         self._nbt_pending += 1
         return self._pred_buf, self._grad_flat[self.num_live]

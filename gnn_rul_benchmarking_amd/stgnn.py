@@ -20,10 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .flat import FlatModule, current_stream as _stream
 
 
 class _ChebFunction(torch.autograd.Function):
@@ -155,7 +152,7 @@ def param_layout(patch_size, num_patch, num_nodes, hidden_dim, K):
     return layout, off
 
 
-class STGNN_model(nn.Module):
+class STGNN_model(FlatModule):
     def __init__(self, patch_size, num_patch, num_nodes, hidden_dim, K, top_k):
         super().__init__()
         self.num_patch, self.patch_size = int(num_patch), int(patch_size)
@@ -167,56 +164,9 @@ class STGNN_model(nn.Module):
         self.gru = nn.GRU(self.hidden_dim, self.hidden_dim, batch_first=True)
         self.fc = nn.Linear(self.hidden_dim * self.num_patch * self.num_nodes, 1)
         self.last_adjacency = None          # filled by forward(x, return_adjacency=True)
-        self._layout, self._count = param_layout(self.patch_size, self.num_patch, self.num_nodes, self.hidden_dim, int(K))
-        self._slices = []
-        for _, (off, shape) in self._layout.items():
-            n = 1
-            for d in shape:
-                n *= d
-            self._slices.append((off, n, shape))
-        self._flat = self._grad_flat = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
-        self._reflatten()
+        self._init_flat(*param_layout(self.patch_size, self.num_patch, self.num_nodes, self.hidden_dim, int(K)))
 
-    # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in self._layout]
-
-    def _named_live(self):
-        return list(zip(self._layout, self._named()))
-
-    def _reflatten(self):
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
-        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._bufs, self._step_state = {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    workspace_slots = 4
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -233,17 +183,9 @@ class STGNN_model(nn.Module):
 
     def _args(self, shp, x, y=None, dpred=None, global_batch=None):
         B = x.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stgnn_step_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("STGNN HIP kernels do not cover this configuration (num_nodes <= 32, patch_size <= 128, K <= 4, "
-                                   "top_k <= num_nodes)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_stgnn_step_workspace_bytes(C.byref(shp)),
+                                    "STGNN HIP kernels do not cover this configuration (num_nodes <= 32, patch_size <= 128, K <= 4, "
+                                    "top_k <= num_nodes)")
         ws, pred = ent
         a = _lib.StmsgcnArgs()
         a.x = x.data_ptr()
@@ -277,14 +219,7 @@ class STGNN_model(nn.Module):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x.size(0))
         a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                      0.1, self._step_state.data_ptr() if self._step_state is not None else None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_stgnn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stgnn_fwdbwd_f32")
         return pred[:x.size(0)], self._grad_flat[self._count]
 

@@ -17,10 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .flat import FlatModule, current_stream as _stream
 
 
 class GCNLayer(nn.Module):
@@ -84,7 +81,7 @@ class _Function(torch.autograd.Function):
         return (None, None, *out)
 
 
-class STMSGCN_model(nn.Module):
+class STMSGCN_model(FlatModule):
     def __init__(self, num_patch, patch_size, interval, band_width, gcn_dims, gru_hidden_dim):
         super().__init__()
         self.num_patch, self.patch_size = int(num_patch), int(patch_size)
@@ -99,56 +96,14 @@ class STMSGCN_model(nn.Module):
         self.gru_layer = GRULayer(sum(dims), self.gru_hidden_dim, 1)
         self.fc = nn.Linear(self.gru_hidden_dim * self.num_patch, 1)
 
-        self._layout, self._count = param_layout(self.num_patch, dims[1:], self.gru_hidden_dim)
-        self._slices = []
-        for name, (off, shape) in self._layout.items():
-            n = 1
-            for s in shape:
-                n *= s
-            self._slices.append((off, n, shape))
-        self._flat = self._grad_flat = self._loss = self._pred_buf = self._ws = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
-        self._reflatten()
+        self._loss = self._pred_buf = self._ws = None
+        self._init_flat(*param_layout(self.num_patch, dims[1:], self.gru_hidden_dim))
 
-    # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in self._layout]
+    workspace_slots = 4
 
-    def _named_live(self):
-        return list(zip(self._layout, self._named()))
-
-    def _reflatten(self):
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
-        self._grad_flat = torch.zeros(self._count + 1, dtype=torch.float32, device=dev)     # [gradient | loss]
-        self._pred_buf, self._ws, self._bufs, self._step_state = None, None, {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):      # a no-op .to(device) (every epoch in the trainers) keeps the buffers
-            self._reflatten()                   # a real move converts tensors one by one: rebuild the flat views
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
-
-    @property
-    def bucket(self):
-        """[gradient | loss]: what one all-reduce carries in data-parallel training."""
-        return self._grad_flat
-
-    @property
-    def num_live(self):
-        return self._count
+    def _reset_caches(self):
+        super()._reset_caches()
+        self._pred_buf = self._ws = None
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -176,17 +131,10 @@ class STMSGCN_model(nn.Module):
 
     def _args(self, shp, x2d, y=None, dpred=None, global_batch=None):
         B = x2d.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stmsgcn_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("STMSGCN kernels do not cover this configuration (nodes <= 32, patch_size <= 512, "
-                                   "GCN widths <= 64 with sum <= 128, gru_hidden_dim <= 16, num_patch <= 4096)")
-            if len(self._bufs) >= 4 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(B, dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_stmsgcn_workspace_bytes(C.byref(shp)),
+                                    "STMSGCN kernels do not cover this configuration (nodes <= 32, patch_size <= 512, "
+                                    "GCN widths <= 64 with sum <= 128, gru_hidden_dim <= 16, num_patch <= 4096)",
+                                    make=lambda dev: (torch.empty(B, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         a = _lib.StmsgcnArgs()
         a.x = x2d.data_ptr()
@@ -233,14 +181,7 @@ class STMSGCN_model(nn.Module):
             raise RuntimeError("target size mismatch")
         shp = self._shape(x2d.size(0))
         a = self._args(shp, x2d, y=yv, global_batch=global_batch)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                                      0.1, self._step_state.data_ptr() if self._step_state is not None else None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_stmsgcn_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stmsgcn_fwdbwd_f32")
         return self._pred_buf, self._grad_flat[self._count]
 

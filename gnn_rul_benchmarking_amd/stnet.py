@@ -17,10 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, params as PL
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .flat import FlatModule, current_stream as _stream
 
 
 class ChebNet(nn.Module):
@@ -56,7 +53,7 @@ class _Function(torch.autograd.Function):
         return (None, None, *outs)
 
 
-class STNet_model(nn.Module):
+class STNet_model(FlatModule):
     def __init__(self, num_patch, patch_size, num_nodes, nperseg, input_dim, Cheb_layers, lstm_hidden_dim, autoencoder_hidden_dim):
         super().__init__()
         self.num_patch, self.patch_size, self.nperseg = int(num_patch), int(patch_size), int(nperseg)
@@ -74,57 +71,16 @@ class STNet_model(nn.Module):
                                      nn.Linear(A, dims[-1] * self.num_nodes))
         self.lstm = nn.LSTM(input_size=A, hidden_size=self.lstm_hidden_dim, batch_first=True)
         self.linear = nn.Linear(self.lstm_hidden_dim * self.num_patch, 1)
-        self._slices, self._layout, off = [], {}, 0
-        for name, p in self.named_parameters():
-            self._layout[name] = (off, tuple(p.shape))
-            self._slices.append((off, p.numel(), tuple(p.shape)))
-            off += p.numel()
-        self._count = off
-        self.optimized_range = (3, off)          # cnn.weight [2] + cnn.bias [1] come first and have no gradient
-        self._flat = self._grad_flat = None
-        self._bufs, self._pin_bufs, self._step_state = {}, False, None
         self._tape = PL.ForwardTape()
-        self._reflatten()
+        self._init_flat()
+        self.optimized_range = (3, self._count)  # cnn.weight [2] + cnn.bias [1] come first and have no gradient
 
-    # ---- flat storage ----------------------------------------------------------------------------------
-    def _named(self):
-        table = dict(self.named_parameters())
-        return [table[name] for name in self._layout]
-
-    def _named_live(self):
-        return list(zip(self._layout, self._named()))
-
-    def _reflatten(self):
-        ps = self._named()
-        dev = ps[0].device
-        flat = torch.empty(self._count, dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            for p, (off, n, shape) in zip(ps, self._slices):
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + n].view(shape)
-        self._flat = flat
-        self._grad_flat = torch.zeros(self._count + 2, dtype=torch.float32, device=dev)     # [gradient | loss | reconstruction]
-        self._bufs, self._step_state = {}, None
-        PL.mark_flat_views(self)
-
-    def _apply(self, fn, recurse=True):
-        super()._apply(fn)
-        if not PL.flat_views_intact(self):
-            self._reflatten()
-        return self
-
-    @property
-    def flat_params(self):
-        return self._flat
+    bucket_tail = 2            # [gradient | loss | reconstruction]
 
     @property
     def bucket(self):
         """[gradient | loss]: what one all-reduce carries in data-parallel training (the reconstruction term sits behind it)."""
         return self._grad_flat[:self._count + 1]
-
-    @property
-    def num_live(self):
-        return self._count
 
     # ---- C-ABI calls -----------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -150,17 +106,9 @@ class STNet_model(nn.Module):
 
     def _args(self, shp, x, y=None, dpred=None, global_batch=None):
         B = x.size(0)
-        ent = self._bufs.get(B)
-        if ent is None:
-            nbytes = _lib.load().rulgnn_stnet_workspace_bytes(C.byref(shp))
-            if nbytes == 0:
-                raise RuntimeError("STNet HIP kernels do not cover this configuration (num_nodes = nperseg / 2 + 1, input_dim = 1 + "
-                                   "patch_size / nperseg, even nperseg <= 64, <= 4 ChebNets)")
-            if len(self._bufs) >= 2 and not self._pin_bufs:
-                self._bufs.pop(next(iter(self._bufs)))
-            ent = (torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device),
-                   torch.empty(max(B, 1), dtype=torch.float32, device=self._flat.device))
-            self._bufs[B] = ent
+        ent = self._workspace_entry(B, lambda: _lib.load().rulgnn_stnet_workspace_bytes(C.byref(shp)),
+                                    "STNet HIP kernels do not cover this configuration (num_nodes = nperseg / 2 + 1, input_dim = 1 + "
+                                    "patch_size / nperseg, even nperseg <= 64, <= 4 ChebNets)")
         ws, pred = ent
         a = _lib.StnetArgs()
         a.x = x.data_ptr()
@@ -197,13 +145,7 @@ class STNet_model(nn.Module):
         shp = self._shape(x.size(0))
         self._tape.mark(x.size(0))
         a, pred = self._args(shp, x, y=yv, global_batch=global_batch)
-        o = None
-        if optimizer is not None:
-            m, v = optimizer._state_buffers()
-            optimizer._steps += 1
-            g = optimizer.param_groups[0]
-            o = C.byref(_lib.AdamArgs(self._flat.data_ptr(), m.data_ptr(), v.data_ptr(), None, optimizer._steps, float(g["lr"]),
-                                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), 0.1, None))
+        o = self._adam_args(optimizer)
         _lib.check(_lib.load().rulgnn_stnet_fwdbwd_f32(C.byref(shp), C.byref(a), o, _stream()), "rulgnn_stnet_fwdbwd_f32")
         return pred[:x.size(0)], self._grad_flat[self._count]
 
