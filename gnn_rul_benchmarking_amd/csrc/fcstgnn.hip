@@ -372,23 +372,42 @@ __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const f
             A[i * QP + j] = leaky(s);
         }
         __syncthreads();
-        if (tid < Q) {                                   // softmax over the row, then + I and the decay mask
+        {
+            // softmax over the row, then + I and the decay mask: four lanes per row (a quad: DPP reductions), seven columns each --
+            // one lane per row left 100 of the 128 threads idle behind 3 x Q dependent LDS round trips with a libm exp and a division
+            // per element, and was 60 % of this kernel
+            const int part = tid & 3;
+            for (int row = tid >> 2; row < ((Q + FT / 4 - 1) / (FT / 4)) * (FT / 4); row += FT / 4) {       // uniform trip count
+            const bool on = row < Q;
+            const float* ar = A + (on ? row : 0) * QP;
             float mx = -INFINITY;
-#pragma unroll 8
-            for (int j = 0; j < Q; ++j) mx = fmaxf(mx, A[tid * QP + j]);
+            for (int j = part; j < Q; j += 4) mx = fmaxf(mx, ar[j]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            float ev[(MAXQ + 3) / 4];
             float sum = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < Q; ++j) {
-                const float ev = expf(A[tid * QP + j] - mx);
-                A[tid * QP + j] = ev;
-                sum += ev;
+#pragma unroll
+            for (int c = 0; c < (MAXQ + 3) / 4; ++c) {
+                const int j = part + 4 * c;
+                ev[c] = j < Q ? __expf(ar[j] - mx) : 0.f;
+                sum += ev[c];
             }
-            float* pr = P + (gi * Q + tid) * Q;
-#pragma unroll 8
-            for (int j = 0; j < Q; ++j) {
-                const float pv = A[tid * QP + j] / sum;
-                pr[j] = pv;
-                A[tid * QP + j] = (pv + (tid == j ? 1.f : 0.f)) * (((tid < N) == (j < N)) ? 1.f : DECAY);
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const float inv = 1.0f / sum;
+            if (on) {
+                float* pr = P + (gi * Q + row) * Q;
+                float* aw = A + row * QP;
+#pragma unroll
+                for (int c = 0; c < (MAXQ + 3) / 4; ++c) {
+                    const int j = part + 4 * c;
+                    if (j < Q) {
+                        const float pv = ev[c] * inv;
+                        pr[j] = pv;
+                        aw[j] = (pv + (row == j ? 1.f : 0.f)) * (((row < N) == (j < N)) ? 1.f : DECAY);
+                    }
+                }
+            }
             }
         }
         __syncthreads();
@@ -449,6 +468,89 @@ __global__ void fc_head_kernel(FcGeom g, const float* __restrict__ prm, const fl
     }
     dpred[b] = dp;
     for (int j = 0; j < g.HD; ++j) dh3[b * g.HD + j] = h3[b * g.HD + j] > 0.f ? dp * prm[g.o_f4w + j] : 0.f;
+}
+
+// The MLP behind the first (split-K) projection in ONE launch: bias + ReLU of fc1, fc2, fc3, the head, and -- when the loss is formed
+// here (y) or its gradient comes in (dpred_in) -- the data gradients back to d h1.  Eight launches of the chain (bias-ReLU x 3, two
+// [batch x 16 x 16] products, head; backward: head, two products, two masks) at their 5-7 us latency floor each; a thread owns a sample
+// row, the 16..64-wide weights sit in LDS (broadcast reads).  mode bit 0: forward (h1 holds fc1's product without the bias), bit 1: backward.
+template <int D2T>
+__global__ __launch_bounds__(64) void fc_mlp_tail_kernel(FcGeom g, const float* __restrict__ prm, float* __restrict__ h1, float* __restrict__ h2,
+                                                         float* __restrict__ h3, const float* __restrict__ y, const float* __restrict__ dpred_in,
+                                                         float* __restrict__ pred, float* __restrict__ dpred, float* __restrict__ sqerr,
+                                                         float* __restrict__ dh3, float* __restrict__ dh2, float* __restrict__ dh1, float inv_gb,
+                                                         int mode) {
+    constexpr int HDT = D2T / 2;
+    __shared__ float w2[D2T * D2T], w3[HDT * D2T], w4[HDT], b1[D2T], b2[D2T], b3[HDT];
+    for (int e = threadIdx.x; e < D2T * D2T; e += 64) w2[e] = prm[g.o_f2w + e];
+    for (int e = threadIdx.x; e < HDT * D2T; e += 64) w3[e] = prm[g.o_f3w + e];
+    for (int e = threadIdx.x; e < D2T; e += 64) { b1[e] = prm[g.o_f1b + e]; b2[e] = prm[g.o_f2b + e]; }
+    for (int e = threadIdx.x; e < HDT; e += 64) { b3[e] = prm[g.o_f3b + e]; w4[e] = prm[g.o_f4w + e]; }
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= g.B) return;
+    float v1[D2T], v2[D2T], v3[HDT];
+    float* r1 = h1 + b * D2T;
+    float* r2 = h2 + b * D2T;
+    float* r3 = h3 + b * HDT;
+    float out = 0.f;
+    if (mode & 1) {
+#pragma unroll
+        for (int i = 0; i < D2T; ++i) { v1[i] = fmaxf(r1[i] + b1[i], 0.f); r1[i] = v1[i]; }
+#pragma unroll
+        for (int o = 0; o < D2T; ++o) {
+            float a = b2[o];
+#pragma unroll
+            for (int i = 0; i < D2T; ++i) a = fmaf(v1[i], w2[o * D2T + i], a);
+            v2[o] = fmaxf(a, 0.f);
+            r2[o] = v2[o];
+        }
+#pragma unroll
+        for (int o = 0; o < HDT; ++o) {
+            float a = b3[o];
+#pragma unroll
+            for (int i = 0; i < D2T; ++i) a = fmaf(v2[i], w3[o * D2T + i], a);
+            v3[o] = fmaxf(a, 0.f);
+            r3[o] = v3[o];
+        }
+        out = prm[g.o_f4b];
+#pragma unroll
+        for (int j = 0; j < HDT; ++j) out = fmaf(v3[j], w4[j], out);
+        pred[b] = out;
+        if (!y) return;
+    } else {
+#pragma unroll
+        for (int i = 0; i < D2T; ++i) { v1[i] = r1[i]; v2[i] = r2[i]; }
+#pragma unroll
+        for (int i = 0; i < HDT; ++i) v3[i] = r3[i];
+    }
+    float dp;
+    if (mode & 1) {
+        const float d = out - y[b];
+        dp = 2.0f * d * inv_gb;
+        sqerr[b] = d * d * inv_gb;
+    } else {
+        dp = dpred_in[b];
+    }
+    dpred[b] = dp;
+    float d3[HDT], d2[D2T];
+#pragma unroll
+    for (int j = 0; j < HDT; ++j) { d3[j] = v3[j] > 0.f ? dp * w4[j] : 0.f; dh3[b * HDT + j] = d3[j]; }
+#pragma unroll
+    for (int j = 0; j < D2T; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < HDT; ++o) a = fmaf(d3[o], w3[o * D2T + j], a);
+        d2[j] = v2[j] > 0.f ? a : 0.f;
+        dh2[b * D2T + j] = d2[j];
+    }
+#pragma unroll
+    for (int j = 0; j < D2T; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int o = 0; o < D2T; ++o) a = fmaf(d2[o], w2[o * D2T + j], a);
+        dh1[b * D2T + j] = v1[j] > 0.f ? a : 0.f;
+    }
 }
 
 // dz *= [h > 0]
@@ -999,6 +1101,17 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const int D2 = g.D2, HD = g.HD, CL = g.CL, FIN = g.FIN;
     const int Mi = (int)g.M, Bi = (int)g.B;
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
+    // the MLP behind fc1 in one launch (fc_mlp_tail_kernel) for the fp32 path at the widths it is instantiated for
+    const bool mlp_fused = !bf && g.D2 == 2 * g.HD && (g.D2 == 16 || g.D2 == 32 || g.D2 == 64);
+    auto mlp_tail = [&](int tail_mode, const float* y, const float* dpred_in) {
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)((g.B + 63) / 64)), dim3(64), 0, st, g, prm, P_(w.h1), P_(w.h2), P_(w.h3), y, dpred_in, a->pred,
+                               P_(w.dpred), P_(w.sqerr), P_(w.dh3), P_(w.dh2), P_(w.dh1), inv_gb, tail_mode);
+        };
+        if (g.D2 == 16) go(fc_mlp_tail_kernel<16>);
+        else if (g.D2 == 32) go(fc_mlp_tail_kernel<32>);
+        else go(fc_mlp_tail_kernel<64>);
+    };
     // positional-encoding dropout (train mode only)
     const float p = training ? a->dropout_p : 0.f;
     uint32_t thr = 0;
@@ -1052,13 +1165,17 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                training, (const float*)P_(w.z5[b]), P_(w.feat));
         // K = FIN (4032 at FD004) against a [batch x 16] output: split the reduction, or four workgroups walk it alone (250 us)
         FC_RC(sgemm_splitk(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, P_(w.split), st));
-        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h1), prm + g.o_f1b, g.B, D2);
-        FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st, bf));
-        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h2), prm + g.o_f2b, g.B, D2);
-        FC_RC(sgemm(P_(w.h2), D2, 1, prm + g.o_f3w, D2, 1, P_(w.h3), HD, Bi, HD, D2, false, st, bf));
-        hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * HD)), dim3(FB), 0, st, P_(w.h3), prm + g.o_f3b, g.B, HD);
-        hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3), a->y,
-                           (const float*)nullptr, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 0);
+        if (mlp_fused) {
+            mlp_tail(1, a->y, nullptr);
+        } else {
+            hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h1), prm + g.o_f1b, g.B, D2);
+            FC_RC(sgemm(P_(w.h1), D2, 1, prm + g.o_f2w, D2, 1, P_(w.h2), D2, Bi, D2, D2, false, st, bf));
+            hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * D2)), dim3(FB), 0, st, P_(w.h2), prm + g.o_f2b, g.B, D2);
+            FC_RC(sgemm(P_(w.h2), D2, 1, prm + g.o_f3w, D2, 1, P_(w.h3), HD, Bi, HD, D2, false, st, bf));
+            hipLaunchKernelGGL(fc_bias_relu_kernel, dim3(grid_for(g.B * HD)), dim3(FB), 0, st, P_(w.h3), prm + g.o_f3b, g.B, HD);
+            hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3), a->y,
+                               (const float*)nullptr, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 0);
+        }
         if (training && a->bn_batch)
             hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
     }
@@ -1073,14 +1190,28 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         AuxFork fk(st, a->aux_stream);
         hipStream_t wst = fk.side();
         auto fork = [&]() { fk.fork(); };
-        fork();
-        if (a->dpred)
-            hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3),
-                               (const float*)nullptr, a->dpred, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 1);
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
             return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, wst);
         };
         // ---- MLP ----
+        if (mlp_fused) {
+            // d h3, d h2, d h1 are there (formed with the loss in the forward's fused MLP kernel, or here from the incoming gradient):
+            // one fork, every parameter gradient of the MLP on the side
+            if (a->dpred) mlp_tail(2, nullptr, a->dpred);
+            fork();
+            FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
+            FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, wst));
+            FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, wst));
+            FC_RC(colsum(P_(w.dh3), g.B, HD, gr + g.o_f3b));
+            FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, wst));
+            FC_RC(colsum(P_(w.dh2), g.B, D2, gr + g.o_f2b));
+            FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, wst));
+            FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
+        } else {
+        fork();
+        if (a->dpred)
+            hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3),
+                               (const float*)nullptr, a->dpred, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 1);
         FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
         FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, wst));
         FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, wst));
@@ -1095,6 +1226,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         fork();
         FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, wst));
         FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
+        }
         FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         // ---- graph blocks ----
         for (int b = 0; b < 2; ++b) {
@@ -1150,12 +1282,14 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sync_pair(1, 1));
         hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, 1, g.L2, prm, (const Cells*)cells,
                            (const float*)P_(w.z2), P_(w.da2), g.M * CL);
+        // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain
+        const int rows = (int)(g.M < w.rows ? g.M : w.rows);
+        fork();
+        hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
+                           (const float*)P_(w.da2), P_(w.gp2));
         hipLaunchKernelGGL(fc_conv2_dx_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z1),
                            (const float*)P_(w.da2), P_(w.dy1));
         FC_RC(sync_pair(1, 0));
-        const int rows = (int)(g.M < w.rows ? g.M : w.rows);
-        hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.da2), P_(w.gp2));
         hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, 0, g.L1, prm, (const Cells*)cells,
                            (const float*)P_(w.z1), P_(w.dy1), g.M * g.H1 * g.L1);
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),

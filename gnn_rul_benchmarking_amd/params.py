@@ -123,15 +123,15 @@ def mark_flat_views(module) -> None:
 class SideStream:
     """Second HIP stream a model hands to its training calls (``aux_stream`` of the argument structs, include/rulgnn.h): the backward's
     parameter-gradient GEMMs run on it beside the data-gradient chain and are joined before the call returns its last kernel, so the
-    caller's stream semantics do not change.  ``enabled = False`` keeps everything on the current stream; a stream being captured into
-    a hipGraph never gets one (the fork / join events come from a pool the graph would pin)."""
+    caller's stream semantics do not change.  ``enabled = False`` keeps everything on the current stream.  Under hipGraph capture the
+    fork / join events become edges of the graph: the replayed step keeps the two branches."""
 
     def __init__(self):
         self.enabled, self._stream = True, None
 
     def pointer(self, device, training: bool = True):
         import torch
-        if not (self.enabled and training) or torch.cuda.is_current_stream_capturing():
+        if not (self.enabled and training):
             return None
         if self._stream is None or self._stream.device != device:
             self._stream = torch.cuda.Stream(device=device)
