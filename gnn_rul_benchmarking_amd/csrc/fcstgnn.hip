@@ -422,6 +422,108 @@ __global__ __launch_bounds__(FB) void fc_graph_kernel(FcGeom g, int blk, const f
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// window graphs on the fp32 matrix cores: ONE WAVEFRONT per graph, no LDS staging, no workgroup barriers
+// ---------------------------------------------------------------------------------------------------
+// The workgroup-per-graph kernels above spend their time in LDS reads (two per FMA in the Q x Q x D products) and barriers.  A graph
+// (Q = 2 x sensors <= 32 nodes, D = 2 x hidden = 16 or 32 features) fits the 32x32x2 fp32 MFMA tile, and its rows are consecutive in
+// F / Mm (row of node q = first row + q): a wavefront keeps the whole graph in registers.
+//   v_mfma_f32_32x32x2_f32: a-operand lane l = A[l & 31][l >> 5], b-operand lane l = B[l >> 5][l & 31], and of the result lane l holds
+//   column l & 31, register r row krow(r, l >> 5) = 8 (r >> 2) + 4 (l >> 5) + (r & 3).
+// A product sums over k in ANY order as long as both operands agree, so k runs in the order the registers already hold it: a result
+// (register -> row, lane -> column) is fed back as the a-operand of the next product with k = krow(step, half) -- no transposition.
+typedef float fc_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ fc_f32x16 fc_mfma(float a, float b, const fc_f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__host__ __device__ constexpr int fc_krow(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+__device__ __forceinline__ float fc_swap32(float v) {                 // the value of the lane 32 away
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+constexpr int FC_MX_WAVES = 4;
+
+// forward: S = M' M'^T, P = softmax(leaky(S - 1e8 I)) by rows, AX = ((P + I) o decay mask) X'   (Model_Base.py:44-78)
+template <int D2T>
+__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
+                                                                       const Cells* cells, int training, const float* __restrict__ F,
+                                                                       const float* __restrict__ Mm, float* __restrict__ P, float* __restrict__ AX) {
+    constexpr int HK = D2T / 2;                                        // k of a half-wave in the products over the features
+    __shared__ BnCoef cd[D2T];
+    __shared__ float bm[D2T];
+    if (threadIdx.x < D2T) {
+        cd[threadIdx.x] = fbn(g, cells, prm, running, training, 3 + 2 * blk, threadIdx.x);
+        bm[threadIdx.x] = prm[g.o_bmap[blk] + threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, Q = g.Q, N = g.N;
+    const float sc = c < D2T ? cd[c < D2T ? c : 0].sc : 0.f, sh = c < D2T ? cd[c < D2T ? c : 0].sh : 0.f;
+    const int cq = c < Q ? c : Q - 1;                                  // lanes beyond the graph repeat its last node (never stored)
+    for (int64_t gi = (int64_t)blockIdx.x * FC_MX_WAVES + (threadIdx.x >> 6); gi < g.G[blk]; gi += (int64_t)gridDim.x * FC_MX_WAVES) {
+        const int64_t b = gi / g.W[blk];
+        const int64_t row0 = (b * g.NP + (gi - b * g.W[blk]) * g.S[blk]) * g.N;       // rows row0 .. row0 + Q - 1 of F / Mm
+        // S: both operands are node c's half row of the mapped features (k = HK h + step)
+        float mh[HK];
+        {
+            const float4* src = reinterpret_cast<const float4*>(Mm + (row0 + cq) * D2T + HK * h);
+#pragma unroll
+            for (int v = 0; v < HK / 4; ++v) {
+                const float4 t = src[v];
+                mh[4 * v] = t.x + bm[HK * h + 4 * v];         mh[4 * v + 1] = t.y + bm[HK * h + 4 * v + 1];
+                mh[4 * v + 2] = t.z + bm[HK * h + 4 * v + 2]; mh[4 * v + 3] = t.w + bm[HK * h + 4 * v + 3];
+            }
+        }
+        // the normalised features by node for the second product: lane = feature, k = node krow(step, half)
+        float xk[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int node = fc_krow(s, h);
+            xk[s] = (c < D2T && node < Q) ? fmaf(F[(row0 + node) * D2T + c], sc, sh) : 0.f;
+        }
+        fc_f32x16 S = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < HK; ++s) S = fc_mfma(mh[s], mh[s], S);
+        // S is symmetric: the softmax over row c is the softmax over column c, which this lane and its partner 32 lanes away hold
+        float t[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = fc_krow(r, h);
+            const float v = leaky(i == c ? S[r] - 1e8f : S[r]);
+            t[r] = i < Q ? v : -INFINITY;
+            mx = fmaxf(mx, t[r]);
+        }
+        mx = fmaxf(mx, fc_swap32(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[r] = __expf(t[r] - mx);
+            sum += t[r];
+        }
+        sum += fc_swap32(sum);
+        const float inv = 1.0f / sum;
+        // t[r] = P[c][krow(r, h)]: four consecutive columns per register group
+        if (c < Q) {
+            float* pr = P + (gi * Q + c) * Q + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (8 * m + 4 * h < Q)
+                    *reinterpret_cast<float4*>(pr + 8 * m) = make_float4(t[4 * m] * inv, t[4 * m + 1] * inv, t[4 * m + 2] * inv, t[4 * m + 3] * inv);
+        }
+        // AX^T = X'^T Adj^T: a-operand the features by node (lane = feature), b-operand this lane's adjacency row -> lane = node,
+        // register = feature krow(r, h): float4 stores of the node's row
+        fc_f32x16 A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int j = fc_krow(s, h);
+            const float adj = (t[s] * inv + (j == c ? 1.f : 0.f)) * (((c < N) == (j < N)) ? 1.f : DECAY);
+            A = fc_mfma(xk[s], j < Q ? adj : 0.f, A);
+        }
+        if (c < Q) {
+            float* ar = AX + (gi * Q + c) * D2T + 4 * h;
+#pragma unroll
+            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(ar + 8 * m) = make_float4(A[4 * m], A[4 * m + 1], A[4 * m + 2], A[4 * m + 3]);
+        }
+    }
+}
+
 // features = mean over the two window steps of leaky(bn_e(z5))
 __global__ __launch_bounds__(FB) void fc_pool_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
                                                     const Cells* cells, int training, const float* __restrict__ z5,
@@ -697,6 +799,116 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
             cM[(gi * Q + i) * D2 + d] = s;
         }
         __syncthreads();
+    }
+}
+
+// graph backward, one wavefront per graph on the fp32 matrix cores (see fc_graph_mx_kernel for the register forms):
+//   T = (dAX X'^T) o mask, softmax backward by rows with the leaky slope of S = M' M'^T - 1e8 I, cX = Adj^T dAX, cM = (dS + dS^T) M'.
+// The softmax reductions run inside a lane when the lane is the ROW: T is computed transposed (a-operand X', b-operand dAX), P is read
+// in both orientations, and dS^T comes from one product with the identity (a-operand dS: the result's register <-> lane roles swap).
+template <int D2T>
+__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
+                                                                           const float* __restrict__ F, const float* __restrict__ Mm,
+                                                                           const float* __restrict__ P, float* dAX /* in: d AX, out: cX */,
+                                                                           float* __restrict__ cM) {
+    constexpr int HK = D2T / 2;
+    __shared__ BnCoef cd[D2T];
+    __shared__ float bm[D2T];
+    if (threadIdx.x < D2T) {
+        cd[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 3 + 2 * blk, threadIdx.x);
+        bm[threadIdx.x] = prm[g.o_bmap[blk] + threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, Q = g.Q, N = g.N;
+    const int cf = c < D2T ? c : 0;
+    const float bc = bm[cf];
+    const int cq = c < Q ? c : Q - 1;
+    const fc_f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t gi = (int64_t)blockIdx.x * FC_MX_WAVES + (threadIdx.x >> 6); gi < g.G[blk]; gi += (int64_t)gridDim.x * FC_MX_WAVES) {
+        const int64_t b = gi / g.W[blk];
+        const int64_t row0 = (b * g.NP + (gi - b * g.W[blk]) * g.S[blk]) * g.N;
+        // half rows of node c (k = HK h + step): mapped features, normalised features, incoming gradient
+        float mh[HK], xh[HK], dh[HK];
+        {
+            const float4* ms = reinterpret_cast<const float4*>(Mm + (row0 + cq) * D2T + HK * h);
+            const float4* fs = reinterpret_cast<const float4*>(F + (row0 + cq) * D2T + HK * h);
+            const float4* ds = reinterpret_cast<const float4*>(dAX + (gi * Q + cq) * D2T + HK * h);
+#pragma unroll
+            for (int v = 0; v < HK / 4; ++v) {
+                const float4 m4 = ms[v], f4 = fs[v], d4 = ds[v];
+                const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = HK * h + 4 * v + e;
+                    mh[4 * v + e] = mv[e] + bm[k];
+                    xh[4 * v + e] = fmaf(fv[e], cd[k].sc, cd[k].sh);
+                    dh[4 * v + e] = dv[e];
+                }
+            }
+        }
+        // by node (lane = feature c, k = node krow(step, half)): mapped features and incoming gradient; P by rows and by columns
+        float mk[16], dk[16], pl[16], pc[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int node = fc_krow(s, h);
+            const bool on = c < D2T && node < Q;
+            mk[s] = on ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
+            dk[s] = on ? dAX[(gi * Q + node) * D2T + c] : 0.f;
+            pc[s] = node < Q ? P[(gi * Q + node) * Q + cq] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (8 * m + 4 * h < Q) t4 = *reinterpret_cast<const float4*>(P + (gi * Q + cq) * Q + 8 * m + 4 * h);
+            pl[4 * m] = t4.x; pl[4 * m + 1] = t4.y; pl[4 * m + 2] = t4.z; pl[4 * m + 3] = t4.w;
+        }
+        fc_f32x16 Tt = zero, Sm = zero;
+#pragma unroll
+        for (int s = 0; s < HK; ++s) {
+            Tt = fc_mfma(xh[s], dh[s], Tt);                             // (register -> j, lane -> i): sum_d X'[j][d] dAX[i][d]
+            Sm = fc_mfma(mh[s], mh[s], Sm);
+        }
+        // cX^T = dAX^T Adj: a-operand the gradient by node (lane = feature), b-operand column c of the adjacency -> lane = node j
+        fc_f32x16 CX = zero;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int i = fc_krow(s, h);
+            const float adj = (pc[s] + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
+            CX = fc_mfma(dk[s], i < Q ? adj : 0.f, CX);
+        }
+        // softmax backward of row c, then the leaky slope of the pre-activation
+        float ds_[16], dot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = fc_krow(r, h);
+            ds_[r] = Tt[r] * (((c < N) == (j < N)) ? 1.f : DECAY);
+            dot = fmaf(ds_[r], pl[r], dot);                             // pl is 0 beyond the graph
+        }
+        dot += fc_swap32(dot);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = fc_krow(r, h);
+            const float pre = j == c ? Sm[r] - 1e8f : Sm[r];
+            ds_[r] = (j < Q && c < Q) ? pl[r] * (ds_[r] - dot) * (pre > 0.f ? 1.f : LEAKY) : 0.f;
+        }
+        if (c < Q) {                                                    // (all loads of this graph's dAX block are behind us)
+            float* xr = dAX + (gi * Q + c) * D2T + 4 * h;
+#pragma unroll
+            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(xr + 8 * m) = make_float4(CX[4 * m], CX[4 * m + 1], CX[4 * m + 2], CX[4 * m + 3]);
+        }
+        // dS^T: the product with the identity swaps the roles of register and lane
+        fc_f32x16 St = zero;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) St = fc_mfma(ds_[s], fc_krow(s, h) == c ? 1.f : 0.f, St);
+        // cM^T = M'^T (dS + dS^T)^T: a-operand the mapped features by node (lane = feature), b-operand row c of dS + dS^T
+        fc_f32x16 CM = zero;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) CM = fc_mfma(mk[s], ds_[s] + St[s], CM);
+        if (c < Q) {
+            float* mr = cM + (gi * Q + c) * D2T + 4 * h;
+#pragma unroll
+            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(mr + 8 * m) = make_float4(CM[4 * m], CM[4 * m + 1], CM[4 * m + 2], CM[4 * m + 3]);
+        }
     }
 }
 
@@ -1102,6 +1314,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const int Mi = (int)g.M, Bi = (int)g.B;
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
     // the MLP behind fc1 in one launch (fc_mlp_tail_kernel) for the fp32 path at the widths it is instantiated for
+    // the window graphs one wavefront each on the fp32 matrix cores where a graph fits the 32 x 32 tile
+    const bool graph_mx = g.Q <= 32 && g.Q % 4 == 0 && (g.D2 == 16 || g.D2 == 32);
     const bool mlp_fused = !bf && g.D2 == 2 * g.HD && (g.D2 == 16 || g.D2 == 32 || g.D2 == 64);
     auto mlp_tail = [&](int tail_mode, const float* y, const float* dpred_in) {
         auto go = [&](auto kernel) {
@@ -1153,6 +1367,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
             FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
+            if (graph_mx) {
+                const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
+                auto go = [&](auto kernel) {
+                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, (const Cells*)cells, training,
+                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
+                };
+                if (D2 == 16) go(fc_graph_mx_kernel<16>);
+                else go(fc_graph_mx_kernel<32>);
+            } else
             hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_FWD_THREADS), sizeof(float) * (2 * g.Q * (g.D2 + 1) + g.Q * (g.Q + 1)), st, g, b, prm, run,
                                (const Cells*)cells, training, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
             FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
@@ -1242,6 +1465,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
             FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
+            if (graph_mx) {
+                const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
+                auto go = [&](auto kernel) {
+                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, (const Cells*)cells,
+                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]), P_(w.dAX[b]), P_(w.dMb[b]));
+                };
+                if (D2 == 16) go(fc_graph_bwd_mx_kernel<16>);
+                else go(fc_graph_bwd_mx_kernel<32>);
+            } else {
             {
                 const size_t lds_b = sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1));
                 if (lds_b > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_graph_bwd_kernel),
@@ -1251,6 +1483,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_BWD_THREADS), sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1)), st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
                                P_(w.dAX[b]), P_(w.dMb[b]));
+            }
             hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
                                (const float*)P_(w.dMb[b]), P_(w.gX[b]), P_(w.gM[b]));
         }

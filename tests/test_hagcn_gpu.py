@@ -144,7 +144,8 @@ def test_algorithm_update_trains():
     assert len(sd) == 67 and all(k.startswith("model.") for k in sd)
 
 
-@pytest.mark.parametrize("Bq,T,I,H", [(3, 48, 6, 8), (5, 1400, 10, 60), (2, 700, 60, 120), (1, 33, 50, 60), (4, 9, 7, 5)])
+@pytest.mark.parametrize("Bq,T,I,H", [(3, 48, 6, 8), (5, 1400, 10, 60), (2, 700, 60, 120), (1, 33, 50, 60), (4, 9, 7, 5), (2, 61, 9, 64), (1, 45, 64, 128),
+                                      (1, 1, 4, 64), (2, 7, 3, 16)])
 def test_persistent_bilstm_layer_matches_oracle(Bq, T, I, H):
     """Forward and BPTT of one summed bidirectional layer (csrc/bilstm.hip) vs the numpy oracle, incl. the reference's
     long-sequence shapes (1 400 steps = batch 100 x 14 nodes)."""
