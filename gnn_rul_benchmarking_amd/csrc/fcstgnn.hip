@@ -802,16 +802,163 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
     }
 }
 
+// The whole window block of the forward in the same wavefront: the mapping M = F W_map^T in front (result lane = node, register = mapped
+// feature krow(r, h): exactly the operand form of S = M' M'^T, whose k order is free because both operands are the same registers) and
+// the block's Linear z5 = AX W_theta^T + b with its BatchNorm statistics behind (AX^T is already the a-operand form).  Replaces
+// [mapping GEMM, graph kernel, theta GEMM, bias + statistics kernel]: three launches and the Mm / AX round trips less per block.
+template <int D2T>
+__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
+                                                                       Cells* cells, int training, const float* __restrict__ F, float* __restrict__ Mm,
+                                                                       float* __restrict__ P, float* __restrict__ AX, float* __restrict__ z5) {
+    constexpr int HK = D2T / 2, HDT = D2T / 2;                         // hidden width of the block's Linear = D2 / 2
+    __shared__ BnCoef cd[D2T];
+    __shared__ float bm[D2T];
+    if (threadIdx.x < D2T) {
+        cd[threadIdx.x] = fbn(g, cells, prm, running, training, 3 + 2 * blk, threadIdx.x);
+        bm[threadIdx.x] = prm[g.o_bmap[blk] + threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5, Q = g.Q, N = g.N;
+    const float sc = c < D2T ? cd[c < D2T ? c : 0].sc : 0.f, sh = c < D2T ? cd[c < D2T ? c : 0].sh : 0.f;
+    const int cq = c < Q ? c : Q - 1;
+    // constant operands: row c of W_map over this half's k, row c of W_theta over k = krow(step, half), the Linear's bias by register
+    float wm[HK], wt[HK], bt[HDT / 2];
+#pragma unroll
+    for (int s = 0; s < HK; ++s) {
+        wm[s] = c < D2T ? prm[g.o_map[blk] + c * D2T + HK * h + s] : 0.f;
+        wt[s] = c < HDT ? prm[g.o_th[blk] + c * D2T + fc_krow(s, h)] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < HDT / 2; ++r) bt[r] = prm[g.o_thb[blk] + fc_krow(r, h)];
+    float st_s[HDT / 2], st_q[HDT / 2];                                // this lane's share of the statistics: channel krow(r, h)
+#pragma unroll
+    for (int r = 0; r < HDT / 2; ++r) st_s[r] = st_q[r] = 0.f;
+    const fc_f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t gi = (int64_t)blockIdx.x * FC_MX_WAVES + (threadIdx.x >> 6); gi < g.G[blk]; gi += (int64_t)gridDim.x * FC_MX_WAVES) {
+        const int64_t b = gi / g.W[blk];
+        const int64_t row0 = (b * g.NP + (gi - b * g.W[blk]) * g.S[blk]) * g.N;
+        float fh[HK];                                                  // node c's half row of F (k = HK h + step)
+        {
+            const float4* src = reinterpret_cast<const float4*>(F + (row0 + cq) * D2T + HK * h);
+#pragma unroll
+            for (int v = 0; v < HK / 4; ++v) {
+                const float4 t = src[v];
+                fh[4 * v] = t.x; fh[4 * v + 1] = t.y; fh[4 * v + 2] = t.z; fh[4 * v + 3] = t.w;
+            }
+        }
+        float xk[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int node = fc_krow(s, h);
+            xk[s] = (c < D2T && node < Q) ? fmaf(F[(row0 + node) * D2T + c], sc, sh) : 0.f;
+        }
+        // M^T = W_map F^T: lane = node, register = mapped feature krow(r, h)
+        fc_f32x16 M = zero;
+#pragma unroll
+        for (int s = 0; s < HK; ++s) M = fc_mfma(wm[s], fh[s], M);
+        if (c < Q) {                                                   // the backward reads the mapping (overlapping windows write the same values)
+            float* mr = Mm + (row0 + c) * D2T + 4 * h;
+#pragma unroll
+            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(mr + 8 * m) = make_float4(M[4 * m], M[4 * m + 1], M[4 * m + 2], M[4 * m + 3]);
+        }
+        fc_f32x16 S = zero;
+#pragma unroll
+        for (int s = 0; s < HK; ++s) {
+            const float v = M[s] + bm[fc_krow(s, h)];
+            S = fc_mfma(v, v, S);
+        }
+        float t[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = fc_krow(r, h);
+            const float v = leaky(i == c ? S[r] - 1e8f : S[r]);
+            t[r] = i < Q ? v : -INFINITY;
+            mx = fmaxf(mx, t[r]);
+        }
+        mx = fmaxf(mx, fc_swap32(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[r] = __expf(t[r] - mx);
+            sum += t[r];
+        }
+        sum += fc_swap32(sum);
+        const float inv = 1.0f / sum;
+        if (c < Q) {
+            float* pr = P + (gi * Q + c) * Q + 4 * h;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                if (8 * m + 4 * h < Q)
+                    *reinterpret_cast<float4*>(pr + 8 * m) = make_float4(t[4 * m] * inv, t[4 * m + 1] * inv, t[4 * m + 2] * inv, t[4 * m + 3] * inv);
+        }
+        fc_f32x16 A = zero;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int j = fc_krow(s, h);
+            const float adj = (t[s] * inv + (j == c ? 1.f : 0.f)) * (((c < N) == (j < N)) ? 1.f : DECAY);
+            A = fc_mfma(xk[s], j < Q ? adj : 0.f, A);
+        }
+        if (c < Q) {
+            float* ar = AX + (gi * Q + c) * D2T + 4 * h;
+#pragma unroll
+            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(ar + 8 * m) = make_float4(A[4 * m], A[4 * m + 1], A[4 * m + 2], A[4 * m + 3]);
+        }
+        // z5^T = W_theta AX^T: lane = node, register = output channel krow(r, h)
+        fc_f32x16 Z = zero;
+#pragma unroll
+        for (int s = 0; s < HK; ++s) Z = fc_mfma(wt[s], A[s], Z);
+        if (c < Q) {
+            float zv[HDT / 2];
+#pragma unroll
+            for (int r = 0; r < HDT / 2; ++r) {
+                zv[r] = Z[r] + bt[r];
+                st_s[r] += zv[r];
+                st_q[r] = fmaf(zv[r], zv[r], st_q[r]);
+            }
+            float* zr = z5 + (gi * Q + c) * HDT + 4 * h;
+#pragma unroll
+            for (int m = 0; m < HDT / 8; ++m) *reinterpret_cast<float4*>(zr + 8 * m) = make_float4(zv[4 * m], zv[4 * m + 1], zv[4 * m + 2], zv[4 * m + 3]);
+        }
+    }
+    if (training) {
+        // BatchNorm statistics of z5: the 32 node lanes of a half, the workgroup's wavefronts through LDS, then ONE atomic per channel and
+        // workgroup (same-address fp64 atomics serialise in L2: per wavefront they cost more than the products above)
+        __shared__ double red[FC_MX_WAVES][HDT][2];
+#pragma unroll
+        for (int r = 0; r < HDT / 2; ++r) {
+            double a = (double)st_s[r], q2 = (double)st_q[r];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {
+                a += __shfl_xor(a, o);
+                q2 += __shfl_xor(q2, o);
+            }
+            if (c == 0) {
+                red[threadIdx.x >> 6][fc_krow(r, h)][0] = a;
+                red[threadIdx.x >> 6][fc_krow(r, h)][1] = q2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * HDT) {
+            double v = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < FC_MX_WAVES; ++wv) v += red[wv][threadIdx.x >> 1][threadIdx.x & 1];
+            if (v != 0.0) atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[4 + 2 * blk][threadIdx.x >> 1][threadIdx.x & 1], v);
+        }
+    }
+}
+
 // graph backward, one wavefront per graph on the fp32 matrix cores (see fc_graph_mx_kernel for the register forms):
 //   T = (dAX X'^T) o mask, softmax backward by rows with the leaky slope of S = M' M'^T - 1e8 I, cX = Adj^T dAX, cM = (dS + dS^T) M'.
 // The softmax reductions run inside a lane when the lane is the ROW: T is computed transposed (a-operand X', b-operand dAX), P is read
 // in both orientations, and dS^T comes from one product with the identity (a-operand dS: the result's register <-> lane roles swap).
-template <int D2T>
+// FUSED: the gradient arrives as d z5 and d AX = d z5 W_theta is formed here in both register forms (eight more products, K = D2 / 2)
+// instead of a GEMM launch and two reads of its result; the half rows of X' are then read in the order krow(step, half) of that form.
+template <int D2T, bool FUSED>
 __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
                                                                            const float* __restrict__ F, const float* __restrict__ Mm,
-                                                                           const float* __restrict__ P, float* dAX /* in: d AX, out: cX */,
-                                                                           float* __restrict__ cM) {
-    constexpr int HK = D2T / 2;
+                                                                           const float* __restrict__ P, const float* __restrict__ dz5,
+                                                                           float* dAX /* in (not FUSED): d AX; out: cX */, float* __restrict__ cM) {
+    constexpr int HK = D2T / 2, HO = D2T / 4;                          // HO: k of a half-wave in the product over the Linear's D2 / 2 outputs
     __shared__ BnCoef cd[D2T];
     __shared__ float bm[D2T];
     if (threadIdx.x < D2T) {
@@ -824,36 +971,63 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeo
     const float bc = bm[cf];
     const int cq = c < Q ? c : Q - 1;
     const fc_f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float wth[HO];                                                     // FUSED: W_theta[HO h + step][c]
+#pragma unroll
+    for (int s = 0; s < HO; ++s) wth[s] = (FUSED && c < D2T) ? prm[g.o_th[blk] + (HO * h + s) * D2T + c] : 0.f;
     for (int64_t gi = (int64_t)blockIdx.x * FC_MX_WAVES + (threadIdx.x >> 6); gi < g.G[blk]; gi += (int64_t)gridDim.x * FC_MX_WAVES) {
         const int64_t b = gi / g.W[blk];
         const int64_t row0 = (b * g.NP + (gi - b * g.W[blk]) * g.S[blk]) * g.N;
-        // half rows of node c (k = HK h + step): mapped features, normalised features, incoming gradient
-        float mh[HK], xh[HK], dh[HK];
+        // half rows of node c: mapped features (k = HK h + step), normalised features and incoming gradient (k = HK h + step, or
+        // krow(step, half) when the gradient is formed here)
+        float mh[HK], xh[HK], dh[HK], dk[16];
         {
             const float4* ms = reinterpret_cast<const float4*>(Mm + (row0 + cq) * D2T + HK * h);
-            const float4* fs = reinterpret_cast<const float4*>(F + (row0 + cq) * D2T + HK * h);
-            const float4* ds = reinterpret_cast<const float4*>(dAX + (gi * Q + cq) * D2T + HK * h);
 #pragma unroll
             for (int v = 0; v < HK / 4; ++v) {
-                const float4 m4 = ms[v], f4 = fs[v], d4 = ds[v];
-                const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                const int k0 = FUSED ? 8 * v + 4 * h : HK * h + 4 * v;
+                const float4 m4 = ms[v], f4 = *reinterpret_cast<const float4*>(F + (row0 + cq) * D2T + k0);
+                const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = HK * h + 4 * v + e;
-                    mh[4 * v + e] = mv[e] + bm[k];
-                    xh[4 * v + e] = fmaf(fv[e], cd[k].sc, cd[k].sh);
-                    dh[4 * v + e] = dv[e];
+                    mh[4 * v + e] = mv[e] + bm[HK * h + 4 * v + e];
+                    xh[4 * v + e] = fmaf(fv[e], cd[k0 + e].sc, cd[k0 + e].sh);
                 }
             }
         }
-        // by node (lane = feature c, k = node krow(step, half)): mapped features and incoming gradient; P by rows and by columns
-        float mk[16], dk[16], pl[16], pc[16];
+        if constexpr (FUSED) {
+            float zo[HO];                                              // node c's half row of d z5 (k = HO h + step)
+            const float4* zs = reinterpret_cast<const float4*>(dz5 + (gi * Q + cq) * HK + HO * h);
+#pragma unroll
+            for (int v = 0; v < HO / 4; ++v) {
+                const float4 z4 = zs[v];
+                zo[4 * v] = z4.x; zo[4 * v + 1] = z4.y; zo[4 * v + 2] = z4.z; zo[4 * v + 3] = z4.w;
+            }
+            fc_f32x16 DH = zero, DK = zero;
+#pragma unroll
+            for (int s = 0; s < HO; ++s) {
+                DH = fc_mfma(wth[s], zo[s], DH);                        // (register -> feature krow, lane -> node)
+                DK = fc_mfma(zo[s], wth[s], DK);                        // (register -> node krow, lane -> feature)
+            }
+#pragma unroll
+            for (int s = 0; s < HK; ++s) dh[s] = DH[s];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dk[s] = DK[s];
+        } else {
+            const float4* ds = reinterpret_cast<const float4*>(dAX + (gi * Q + cq) * D2T + HK * h);
+#pragma unroll
+            for (int v = 0; v < HK / 4; ++v) {
+                const float4 d4 = ds[v];
+                dh[4 * v] = d4.x; dh[4 * v + 1] = d4.y; dh[4 * v + 2] = d4.z; dh[4 * v + 3] = d4.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) dk[s] = (c < D2T && fc_krow(s, h) < Q) ? dAX[(gi * Q + fc_krow(s, h)) * D2T + c] : 0.f;
+        }
+        // by node (lane = feature c, k = node krow(step, half)): mapped features; P by rows and by columns
+        float mk[16], pl[16], pc[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int node = fc_krow(s, h);
-            const bool on = c < D2T && node < Q;
-            mk[s] = on ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
-            dk[s] = on ? dAX[(gi * Q + node) * D2T + c] : 0.f;
+            mk[s] = (c < D2T && node < Q) ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
             pc[s] = node < Q ? P[(gi * Q + node) * Q + cq] : 0.f;
         }
 #pragma unroll
@@ -1257,9 +1431,12 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
     w->total = o;
 }
 
+// streaming kernels: at most this many workgroups (each ends in one fp64 atomic per channel onto the statistics cells; 4096 workgroups
+// spent longer in those than 1024 spend looping: 0.755 -> 0.736 ms per step at batch 256)
+constexpr int FC_GRID_CAP = 1024;
 inline unsigned grid_for(int64_t total) {
     int64_t b = (total + FB - 1) / FB;
-    if (b > 4096) b = 4096;
+    if (b > FC_GRID_CAP) b = FC_GRID_CAP;
     return (unsigned)(b < 1 ? 1 : b);
 }
 
@@ -1366,21 +1543,33 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sync_pair(0, 5));
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
-            FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
-            if (graph_mx) {
-                const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
+            const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
+            if (graph_mx && !bf && D2 == 2 * HD) {
+                // mapping, window graphs, the block's Linear and its BatchNorm statistics in one launch
                 auto go = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, (const Cells*)cells, training,
-                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
+                    hipLaunchKernelGGL(kernel, dim3(wgs < 1024 ? wgs : 1024), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, cells, training,
+                                       (const float*)P_(w.F), P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]), P_(w.z5[b]));
                 };
-                if (D2 == 16) go(fc_graph_mx_kernel<16>);
-                else go(fc_graph_mx_kernel<32>);
-            } else
-            hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_FWD_THREADS), sizeof(float) * (2 * g.Q * (g.D2 + 1) + g.Q * (g.Q + 1)), st, g, b, prm, run,
-                               (const Cells*)cells, training, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
-            FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
-            hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
-                               (int64_t)GQ, HD, cells, 4 + 2 * b, training);
+                if (D2 == 16) go(fc_block_mx_kernel<16>);
+                else go(fc_block_mx_kernel<32>);
+            } else {
+                FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
+                if (graph_mx) {
+                    auto go = [&](auto kernel) {
+                        hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, (const Cells*)cells, training,
+                                           (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
+                    };
+                    if (D2 == 16) go(fc_graph_mx_kernel<16>);
+                    else go(fc_graph_mx_kernel<32>);
+                } else {
+                    hipLaunchKernelGGL(fc_graph_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_FWD_THREADS),
+                                       sizeof(float) * (2 * g.Q * (g.D2 + 1) + g.Q * (g.Q + 1)), st, g, b, prm, run, (const Cells*)cells, training,
+                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]));
+                }
+                FC_RC(sgemm(P_(w.AX[b]), D2, 1, prm + g.o_th[b], D2, 1, P_(w.z5[b]), HD, GQ, HD, D2, false, st, bf));
+                hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, P_(w.z5[b]), prm + g.o_thb[b],
+                                   (int64_t)GQ, HD, cells, 4 + 2 * b, training);
+            }
             FC_RC(sync_pair(0, 4 + 2 * b));
         }
         for (int b = 0; b < 2; ++b)
@@ -1463,16 +1652,23 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             fork();
             FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, wst));
             FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
-            FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
+            const bool bwd_fused = graph_mx && !bf && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
+            if (!bwd_fused) FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
             if (graph_mx) {
                 const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
                 auto go = [&](auto kernel) {
                     hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, (const Cells*)cells,
-                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]), P_(w.dAX[b]), P_(w.dMb[b]));
+                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]), (const float*)dz5, P_(w.dAX[b]),
+                                       P_(w.dMb[b]));
                 };
-                if (D2 == 16) go(fc_graph_bwd_mx_kernel<16>);
-                else go(fc_graph_bwd_mx_kernel<32>);
+                if (bwd_fused) {
+                    if (D2 == 16) go(fc_graph_bwd_mx_kernel<16, true>);
+                    else go(fc_graph_bwd_mx_kernel<32, true>);
+                } else {
+                    if (D2 == 16) go(fc_graph_bwd_mx_kernel<16, false>);
+                    else go(fc_graph_bwd_mx_kernel<32, false>);
+                }
             } else {
             {
                 const size_t lds_b = sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1));
