@@ -309,15 +309,16 @@ def kernel_short_name(name):
 
 
 def family_traffic(family, kernel_short):
-    """HBM bytes per launch of a family's kernel from the committed PMC summary (profiles/r02_family_hbm_traffic.json, written by
-    tools/family_traffic_report.py from separate FETCH_SIZE / WRITE_SIZE passes), or None."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_family_hbm_traffic.json")))
-        for k, v in t["families"][family]["kernels"].items():
-            if k == kernel_short:
-                return round(v["hbm_bytes_per_launch"])
-    except Exception:
-        pass
+    """HBM bytes per launch of a family's kernel from the committed PMC summary (profiles/r0N_family_hbm_traffic.json, the newest round
+    that has the kernel; written by tools/family_traffic_report.py from separate FETCH_SIZE / WRITE_SIZE passes), or None."""
+    for tag in ("r03", "r02"):
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_family_hbm_traffic.json")))
+            for k, v in t["families"][family]["kernels"].items():
+                if k == kernel_short:
+                    return round(v["hbm_bytes_per_launch"])
+        except Exception:
+            pass
     return None
 
 
@@ -352,16 +353,18 @@ def _gcn_stack_flops(n, dims):
 # Work model of the kernel that dominates each family's step: substring of the kernel name -> f(cfg, batch, launches per step)
 # = (algorithmic FLOPs of ONE launch, how they are counted).  Matmul-type FLOPs only, as SURVEY 8(d) counts them.
 def dominant_kernel_work(family, name, cfg, B, shape, per_step):
-    if family == "FC_STGNN" and "fc_graph_bwd_kernel" in name:
+    if family == "FC_STGNN" and "fc_graph_bwd" in name:
         Q, D2 = 2 * cfg["num_node"], 2 * cfg["hidden_dim"]
         graphs = B * ((cfg["num_patch"] - 1) + (cfg["num_patch"] - 2) // 2 + 1)            # window 2, stride 1 and 2 (Model_Base.py:175-225)
         return graphs / per_step * 6 * Q * Q * D2, ("backward of one window graph: dA = dAX X'^T, dX' = A^T dAX, dM = (dS + dS^T) M, "
                                                     "2 Q^2 D FLOPs each (Q = 28 nodes, D = 16); averaged over the two window blocks")
-    if family == "FC_STGNN" and "fc_graph_kernel" in name:
+    if family == "FC_STGNN" and ("fc_graph_kernel" in name or "fc_graph_mx" in name or "fc_block_mx" in name):
         Q, D2 = 2 * cfg["num_node"], 2 * cfg["hidden_dim"]
         graphs = B * ((cfg["num_patch"] - 1) + (cfg["num_patch"] - 2) // 2 + 1)
-        return graphs / per_step * 4 * Q * Q * D2, ("forward of one window graph: S = M M^T and A X', 2 Q^2 D FLOPs each (Q = 28 nodes, D = 16); "
-                                                    "averaged over the two window blocks")
+        extra = (2 * Q * D2 * D2 + 2 * Q * D2 * (D2 // 2)) if "fc_block_mx" in name else 0            # mapping + the block's Linear
+        return graphs / per_step * (4 * Q * Q * D2 + extra), ("forward of one window graph: S = M M^T and A X', 2 Q^2 D FLOPs each (Q = 28 nodes, D = 16)"
+                                                              + ("; plus the mapping F W_map^T and the block's Linear" if extra else "")
+                                                              + "; averaged over the two window blocks")
     if family == "HAGCN" and ("lstm_forward_kernel" in name or "lstm_backward_kernel" in name):
         T = B * shape[0]
         H = cfg["encoder_hidden_dim"] * (2 if "<128" in name else 1)                          # layers 1, 3: H; layer 2: 2H (Model.py:41-56)
