@@ -1298,20 +1298,138 @@ static size_t gcn_backward_lds_bytes(const MsgGeom& g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// backward of the GRU input projection gi = cat W_ih^T + b_ih over all (graph, node) rows in ONE pass:
+//   d cat = d gi W_ih,   d W_ih = d gi^T cat,   d b_ih = column sums of d gi.
+// Two generic GEMM launches read d gi and the 318-MB cat twice at 2.3 TB/s (172 us each + 80 us of reductions at XJTU-SY c1 / batch
+// 128).  Here a lane owns TWO columns of cat (W_ih's columns in 2 x 3H registers for the whole kernel, coalesced row loads / stores,
+// packed FMAs) and a wavefront walks rows; the row of d gi every lane needs comes as LDS broadcast reads from a block the workgroup
+// staged with coalesced loads (a first version fed it through the scalar cache: 412 us -- streaming data misses that cache line by
+// line).  The column behind the last carries the constant 1: its accumulators are d b_ih.  One partial row per workgroup, reduced in
+// fixed order by msg_finalize.
+// ---------------------------------------------------------------------------------------------------
+typedef float gi_f2 __attribute__((ext_vector_type(2)));
+// acc.xy += a.xy * s.x  /  a.xy * s.y : the packed FMA with one half of its second source feeding both lanes (op_sel) -- written out
+// because the compiler builds the (s, s) pair with moves instead
+__device__ __forceinline__ void pk_fma_lo(gi_f2& acc, gi_f2 a, gi_f2 s) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(a), "v"(s)); }
+__device__ __forceinline__ void pk_fma_hi(gi_f2& acc, gi_f2 a, gi_f2 s) { asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(a), "v"(s)); }
+constexpr int GIB = 256;                 // four wavefronts = four row streams
+constexpr int GI_ROWS = 64;              // rows of d gi per staged block (16 per wavefront)
+constexpr int GI_MAX_PARTS = 1024;
+template <int H3T>
+__global__ __launch_bounds__(GIB) void msg_gi_backward_kernel(int C, const float* __restrict__ dgi, const float* __restrict__ cat,
+                                                              const float* __restrict__ wih, float* __restrict__ dcat, float* __restrict__ gpart,
+                                                              int64_t rows) {
+    constexpr int BLK4 = GI_ROWS * H3T / 4;                            // float4s per block
+    __shared__ float4 blk[2][BLK4];
+    __shared__ float red[3][2 * H3T][64];                              // the other wavefronts' accumulators at the end
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: row addresses stay scalar)
+    const int c0 = 2 * lane, c1 = c0 + 1;
+    // columns beyond the matrix: loads are clamped to a valid column and x = v * keep + one  (the column behind the last is the constant 1)
+    const int l0 = c0 < C ? c0 : C - 1, l1 = c1 < C ? c1 : C - 1;
+    const float k0 = c0 < C ? 1.f : 0.f, k1 = c1 < C ? 1.f : 0.f, o0 = c0 == C ? 1.f : 0.f, o1 = c1 == C ? 1.f : 0.f;
+    gi_f2 w[H3T], acc[H3T];
+#pragma unroll
+    for (int h = 0; h < H3T; ++h) {
+        w[h] = gi_f2{c0 < C ? wih[h * C + c0] : 0.f, c1 < C ? wih[h * C + c1] : 0.f};
+        acc[h] = gi_f2{0.f, 0.f};
+    }
+    const int64_t per = ((rows + gridDim.x - 1) / gridDim.x + GI_ROWS - 1) / GI_ROWS * GI_ROWS;       // whole blocks per workgroup
+    const int64_t R0 = (int64_t)blockIdx.x * per, R1 = R0 + per < rows ? R0 + per : rows;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t base, int k) {                            // float4 number tid + 256 k of the block that starts at row `base`
+        const int i = tid + GIB * k;
+        const int64_t e = base * H3T + 4 * (int64_t)i;                 // rows are contiguous: the block is one span of floats
+        return (i < BLK4 && e + 3 < R1 * H3T) ? *reinterpret_cast<const float4*>(dgi + e)
+                                              : (i < BLK4 && e < R1 * H3T ? make_float4(dgi[e], e + 1 < R1 * H3T ? dgi[e + 1] : 0.f,
+                                                                                       e + 2 < R1 * H3T ? dgi[e + 2] : 0.f, 0.f) : zero4);
+    };
+    constexpr int NF = (BLK4 + GIB - 1) / GIB;
+    float4 nxt[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) nxt[k] = fetch(R0, k);
+    int buf = 0;
+    for (int64_t base = R0; base < R1; base += GI_ROWS, buf ^= 1) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+            if (tid + GIB * k < BLK4) blk[buf][tid + GIB * k] = nxt[k];
+        __syncthreads();                                               // (the other buffer was read two blocks ago: one barrier per block)
+        if (base + GI_ROWS < R1) {
+#pragma unroll
+            for (int k = 0; k < NF; ++k) nxt[k] = fetch(base + GI_ROWS, k);
+        }
+        // this wavefront's 16 rows: their cat pairs first (16 loads in flight), then row by row
+        const int64_t r0 = base + 16 * wave;
+        gi_f2 x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float* rp = cat + (r0 + j < R1 ? r0 + j : R1 - 1) * C;        // uniform
+            x[j] = gi_f2{fmaf(rp[l0], k0, o0), fmaf(rp[l1], k1, o1)};
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (r0 + j >= R1) break;
+            const float4* sr = &blk[buf][(16 * wave + j) * (H3T / 4)];
+            gi_f2 d = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < H3T / 4; ++q) {
+                const float4 s4 = sr[q];                               // the same address in every lane: a broadcast read
+                const gi_f2 s01 = {s4.x, s4.y}, s23 = {s4.z, s4.w};
+                pk_fma_lo(d, w[4 * q], s01);      pk_fma_lo(acc[4 * q], x[j], s01);
+                pk_fma_hi(d, w[4 * q + 1], s01);  pk_fma_hi(acc[4 * q + 1], x[j], s01);
+                pk_fma_lo(d, w[4 * q + 2], s23);  pk_fma_lo(acc[4 * q + 2], x[j], s23);
+                pk_fma_hi(d, w[4 * q + 3], s23);  pk_fma_hi(acc[4 * q + 3], x[j], s23);
+            }
+            float* dr = dcat + (r0 + j) * C;
+            if (c0 < C) dr[c0] = d.x;
+            if (c1 < C) dr[c1] = d.y;
+            asm volatile("" ::: "memory");                             // one row's broadcast reads at a time (hoisted, they take 24 registers a row)
+        }
+    }
+    // the four row streams of the workgroup -> one partial row  [d W_ih (3H x C) | d b_ih (3H)]
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int h = 0; h < H3T; ++h) {
+            red[wave - 1][2 * h][lane] = acc[h].x;
+            red[wave - 1][2 * h + 1][lane] = acc[h].y;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = gpart + (int64_t)blockIdx.x * (H3T * C + H3T);
+#pragma unroll
+        for (int h = 0; h < H3T; ++h) {
+            const float ax = ((acc[h].x + red[0][2 * h][lane]) + red[1][2 * h][lane]) + red[2][2 * h][lane];
+            const float ay = ((acc[h].y + red[0][2 * h + 1][lane]) + red[1][2 * h + 1][lane]) + red[2][2 * h + 1][lane];
+            if (c0 < C) dst[h * C + c0] = ax;
+            else if (c0 == C) dst[H3T * C + h] = ax;
+            if (c1 < C) dst[h * C + c1] = ay;
+            else if (c1 == C) dst[H3T * C + h] = ay;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // finalize: partial rows -> flat gradient; fc gradients; loss
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MB) void msg_finalize_kernel(MsgGeom g, const float* __restrict__ gpart_gcn, int rows_gcn,
                                                           const float* __restrict__ gpart_gru, int rows_gru,
+                                                          const float* __restrict__ gpart_gi, int rows_gi,
                                                           const float* __restrict__ dpred, const float* __restrict__ pooled,
                                                           float* __restrict__ grads) {
     // one wavefront per value: lanes stride over the partial rows (or the batch), fixed-order butterfly (deterministic).
-    // W_ih and b_ih are written by the GEMMs of msg_run and skipped here.
+    // W_ih and b_ih come from msg_gi_backward_kernel's partial rows, or (rows_gi == 0) were written by the GEMMs of msg_run.
     const int e = (blockIdx.x * MB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int ngru = g.H3 * g.H + g.H3;
-    if (e >= g.nparam || (e >= g.off_wih && e < g.off_whh) || (e >= g.off_bih && e < g.off_bhh)) return;
+    const int ngru = g.H3 * g.H + g.H3, ngi = g.H3 * g.C + g.H3;
+    const bool is_wih = e >= g.off_wih && e < g.off_whh, is_bih = e >= g.off_bih && e < g.off_bhh;
+    if (e >= g.nparam || ((is_wih || is_bih) && rows_gi == 0)) return;
     float a = 0.f;
     if (e < g.off_wih) {                                       // GCN layers
         for (int r = lane; r < rows_gcn; r += 64) a += gpart_gcn[(int64_t)r * g.gcn_params + e];
+    } else if (is_wih) {
+        for (int r = lane; r < rows_gi; r += 64) a += gpart_gi[(int64_t)r * ngi + (e - g.off_wih)];
+    } else if (is_bih) {
+        for (int r = lane; r < rows_gi; r += 64) a += gpart_gi[(int64_t)r * ngi + g.H3 * g.C + (e - g.off_bih)];
     } else if (e < g.off_bih) {                                // W_hh
         for (int r = lane; r < rows_gru; r += 64) a += gpart_gru[(int64_t)r * ngru + (e - g.off_whh)];
     } else if (e < g.off_fcw) {                                // b_hh
@@ -1332,7 +1450,7 @@ __global__ void msg_fill_kernel(float* p, int n, float v) {
 }
 
 struct MsgWs {
-    size_t cat, gi, hseq, dgi, dcat, one, split, pooled, dpred, sqerr, gpart_gcn, gpart_gru, total;
+    size_t cat, gi, hseq, dgi, dcat, one, split, pooled, dpred, sqerr, gpart_gcn, gpart_gru, gpart_gi, total;
     int rows_gcn_max, rows_gru, HG;
 };
 
@@ -1359,6 +1477,7 @@ static void msg_ws_layout(const MsgGeom& g, MsgWs* w) {
     if (w->rows_gru < 1) w->rows_gru = 1;
     w->gpart_gcn = o; o = al(o + (size_t)w->rows_gcn_max * g.gcn_params * sizeof(float));
     w->gpart_gru = o; o = al(o + (size_t)w->rows_gru * (g.H3 * g.H + g.H3) * sizeof(float));
+    w->gpart_gi = o; o = al(o + (size_t)GI_MAX_PARTS * (g.H3 * g.C + g.H3) * sizeof(float));
     w->total = o;
 }
 
@@ -1491,21 +1610,29 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
                 return RULGNN_EHIP;
         }
         dispatch_gru(g, w, ws, a->params, true, st);
-        // GRU input projection backward as GEMMs over all (graph, node) rows:
-        //   d cat = d gi W_ih,  d W_ih = d gi^T cat,  d b_ih = column sums of d gi
+        // GRU input projection backward over all (graph, node) rows: d cat = d gi W_ih, d W_ih = d gi^T cat, d b_ih = column sums of d gi
+        int rows_gi = 0;
         {
-            const int R = (int)(g.G * g.n);
+            const int64_t R = g.G * g.n;
             const float* dgi = (const float*)(ws + w.dgi);
-            const float* wih = a->params + g.off_wih;
-            float* one = (float*)(ws + w.one);
-            float* split = (float*)(ws + w.split);
-            hipLaunchKernelGGL(msg_fill_kernel, dim3(1), dim3(64), 0, st, one, 64, 1.0f);
-            rc = sgemm(dgi, g.H3, 1, wih, 1, g.C, (float*)(ws + w.dcat), g.C, R, g.C, g.H3, false, st);
-            if (rc != RULGNN_OK) return rc;
-            rc = sgemm_splitk(dgi, 1, g.H3, (const float*)(ws + w.cat), 1, g.C, a->grads + g.off_wih, g.C, g.H3, g.C, R, false, split, st);
-            if (rc != RULGNN_OK) return rc;
-            rc = sgemm_splitk(dgi, 1, g.H3, one, 0, 0, a->grads + g.off_bih, 1, g.H3, 1, R, false, split, st);
-            if (rc != RULGNN_OK) return rc;
+            if (g.H3 == 24 && g.C < 128) {                          // the reference's GRU width (hidden 8): one streaming pass
+                int64_t parts = (R + 4 * GI_ROWS - 1) / (4 * GI_ROWS);
+                if (parts > GI_MAX_PARTS) parts = GI_MAX_PARTS;
+                rows_gi = (int)parts;
+                hipLaunchKernelGGL(msg_gi_backward_kernel<24>, dim3((unsigned)parts), dim3(GIB), 0, st, g.C, dgi, (const float*)(ws + w.cat),
+                                   a->params + g.off_wih, (float*)(ws + w.dcat), (float*)(ws + w.gpart_gi), R);
+            } else {
+                const float* wih = a->params + g.off_wih;
+                float* one = (float*)(ws + w.one);
+                float* split = (float*)(ws + w.split);
+                hipLaunchKernelGGL(msg_fill_kernel, dim3(1), dim3(64), 0, st, one, 64, 1.0f);
+                rc = sgemm(dgi, g.H3, 1, wih, 1, g.C, (float*)(ws + w.dcat), g.C, (int)R, g.C, g.H3, false, st);
+                if (rc != RULGNN_OK) return rc;
+                rc = sgemm_splitk(dgi, 1, g.H3, (const float*)(ws + w.cat), 1, g.C, a->grads + g.off_wih, g.C, g.H3, g.C, (int)R, false, split, st);
+                if (rc != RULGNN_OK) return rc;
+                rc = sgemm_splitk(dgi, 1, g.H3, one, 0, 0, a->grads + g.off_bih, 1, g.H3, 1, (int)R, false, split, st);
+                if (rc != RULGNN_OK) return rc;
+            }
         }
         int rows = 0;
         size_t lds_mx = 0;
@@ -1539,7 +1666,7 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
         const bool mse = a->dpred == nullptr;
         hipLaunchKernelGGL(msg_finalize_kernel, dim3((g.nparam + 3) / 4), dim3(MB), 0, st, g,
                            (const float*)(ws + w.gpart_gcn), rows, (const float*)(ws + w.gpart_gru), w.rows_gru,
-                           (const float*)(ws + w.dpred), (const float*)(ws + w.pooled), a->grads);
+                           (const float*)(ws + w.gpart_gi), rows_gi, (const float*)(ws + w.dpred), (const float*)(ws + w.pooled), a->grads);
         if (mse && a->loss)
             (void)block_sum((const float*)(ws + w.sqerr), (int64_t)g.B, a->loss, st);
     }
