@@ -503,7 +503,8 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         fk.fork();
         // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
         AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
-        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
+        if (cols_sum_small_ok(g.B, 1)) AST_RC(cols_sum_small(F(w.dpred), (int)g.B, 1, gr + g.o_fcb, wst));
+        else AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         AST_RC(sgemm(F(w.dmat), O, 1, prm + g.o_f, O, 1, F(w.dt), KE, (int)g.B, KE, O, false, st));
@@ -521,7 +522,8 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
         fk.fork();
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
-        AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, wst));
+        if (cols_sum_small_ok(M, E)) AST_RC(cols_sum_small(F(w.zpre), M, E, gr + g.o_thb, wst));
+        else AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, wst));
         if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, wst) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));

@@ -1603,6 +1603,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipStream_t wst = fk.side();
         auto fork = [&]() { fk.fork(); };
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
+            if (cols_sum_small_ok(rows, C)) return cols_sum_small(src, (int)rows, C, dst, wst);
             return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, wst);
         };
         // ---- MLP ----
@@ -1612,7 +1613,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             if (a->dpred) mlp_tail(2, nullptr, a->dpred);
             fork();
             FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
-            FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, one, 0, 0, gr + g.o_f4b, 1, 1, 1, Bi, false, split, wst));
+            FC_RC(colsum(P_(w.dpred), g.B, 1, gr + g.o_f4b));
             FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, wst));
             FC_RC(colsum(P_(w.dh3), g.B, HD, gr + g.o_f3b));
             FC_RC(sgemm_splitk(P_(w.dh2), 1, D2, P_(w.h1), 1, D2, gr + g.o_f2w, D2, D2, D2, Bi, false, split, wst));
