@@ -1588,20 +1588,26 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_head_kernel, dim3((unsigned)((g.B + FB - 1) / FB)), dim3(FB), 0, st, g, prm, (const float*)P_(w.h3), a->y,
                                (const float*)nullptr, a->pred, P_(w.dpred), P_(w.sqerr), P_(w.dh3), inv_gb, 0);
         }
-        if (training && a->bn_batch)
+        if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
             hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
     }
     if (mode & 2) {
         float* gr = a->grads;
         float* split = P_(w.split);
         float* one = P_(w.one);
-        hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
         // Weight / bias gradient GEMMs: nothing in this call reads their results, and each is a ~6-19 us launch at its latency floor.
         // With a second stream of the caller (args->aux_stream, aux_stream.hpp) they leave the critical path; they share the split-K
         // scratch and therefore one stream.
         AuxFork fk(st, a->aux_stream);
         hipStream_t wst = fk.side();
         auto fork = [&]() { fk.fork(); };
+        // ... and so do the other launches nothing on the chain waits for: the constant for the column sums, the batch moments for the
+        // bucket, the loss sum
+        fork();
+        hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, wst, one);
+        if ((mode & 1) && training && a->bn_batch)
+            hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, wst, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
+        if (!a->dpred && a->loss) (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, wst);
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
             if (cols_sum_small_ok(rows, C)) return cols_sum_small(src, (int)rows, C, dst, wst);
             return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, wst);
@@ -1729,8 +1735,6 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
         hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
                            (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
-        if (!a->dpred && a->loss)
-            (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, st);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
