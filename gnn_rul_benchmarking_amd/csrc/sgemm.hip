@@ -939,9 +939,38 @@ static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const fl
 }
 
 
+// C[m][n] (+)= sum_k A[m][k] B[n][k] for a SMALL output over a SHORT reduction (M N <= 1024, K <= 2048: the weight gradients of the
+// families' MLP heads over a batch): one workgroup, 1024 / (M N) threads per output over interleaved k, combined in fixed order through
+// LDS -- one launch of ~6 us instead of a split-K pair (two launches, 16-19 + 5-7 us).
+static __global__ __launch_bounds__(1024) void sgemm_tiny_kernel(GemmArgs g, int accumulate) {
+    __shared__ float red[1024];
+    const int O = g.M * g.N, stripes = 1024 / O, e = threadIdx.x % O, sidx = threadIdx.x / O;
+    const int m = e / g.N, n = e - m * g.N;
+    float a = 0.f;
+    if (sidx < stripes) {
+        const float* ap = g.A + (int64_t)m * g.sAm;
+        const float* bp = g.B + (int64_t)n * g.sBn;
+        for (int k = sidx; k < g.K; k += stripes) a = fmaf(ap[(int64_t)k * g.sAk], bp[(int64_t)k * g.sBk], a);
+    }
+    red[threadIdx.x] = sidx < stripes ? a : 0.f;
+    __syncthreads();
+    if ((int)threadIdx.x < O) {
+        float v = 0.f;
+        for (int q = 0; q < stripes; ++q) v += red[q * O + threadIdx.x];
+        float* c = g.C + (int64_t)m * g.ldc + n;
+        *c = accumulate ? *c + v : v;
+    }
+}
+
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if ((int64_t)M * N <= 1024 && K <= 2048) {
+        GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, 0, K};
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(sgemm_tiny_kernel, dim3(1), dim3(1024), 0, st, g, accumulate ? 1 : 0);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
     if (sgemm_longk_blocks(M, N, K) > 0) {
         int nblk = sgemm_longk_blocks(M, N, K);
         int kper = (K + nblk - 1) / nblk;
