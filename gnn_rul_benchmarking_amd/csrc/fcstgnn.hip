@@ -954,7 +954,7 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
 // FUSED: the gradient arrives as d z5 and d AX = d z5 W_theta is formed here in both register forms (eight more products, K = D2 / 2)
 // instead of a GEMM launch and two reads of its result; the half rows of X' are then read in the order krow(step, half) of that form.
 template <int D2T, bool FUSED>
-__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
+__global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
                                                                            const float* __restrict__ F, const float* __restrict__ Mm,
                                                                            const float* __restrict__ P, const float* __restrict__ dz5,
                                                                            float* dAX /* in (not FUSED): d AX; out: cX */, float* __restrict__ cM) {
@@ -1022,54 +1022,59 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeo
 #pragma unroll
             for (int s = 0; s < 16; ++s) dk[s] = (c < D2T && fc_krow(s, h) < Q) ? dAX[(gi * Q + fc_krow(s, h)) * D2T + c] : 0.f;
         }
-        // by node (lane = feature c, k = node krow(step, half)): mapped features; P by rows and by columns
-        float mk[16], pl[16], pc[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int node = fc_krow(s, h);
-            mk[s] = (c < D2T && node < Q) ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
-            pc[s] = node < Q ? P[(gi * Q + node) * Q + cq] : 0.f;
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (8 * m + 4 * h < Q) t4 = *reinterpret_cast<const float4*>(P + (gi * Q + cq) * Q + 8 * m + 4 * h);
-            pl[4 * m] = t4.x; pl[4 * m + 1] = t4.y; pl[4 * m + 2] = t4.z; pl[4 * m + 3] = t4.w;
-        }
+        // The products below are ordered so that an operand is loaded right before its product and dies behind it, with a compiler
+        // barrier between the stages: hoisted to the top (what the scheduler does on its own) the operands of all five products are
+        // live at once -- 308 registers, one wavefront per SIMD and nothing to hide its ~70 loads per graph behind.  This way two fit
+        // (205 registers; three spill and are slower): 0.692 -> 0.681 ms per step.
         fc_f32x16 Tt = zero, Sm = zero;
 #pragma unroll
         for (int s = 0; s < HK; ++s) {
             Tt = fc_mfma(xh[s], dh[s], Tt);                             // (register -> j, lane -> i): sum_d X'[j][d] dAX[i][d]
             Sm = fc_mfma(mh[s], mh[s], Sm);
         }
-        // cX^T = dAX^T Adj: a-operand the gradient by node (lane = feature), b-operand column c of the adjacency -> lane = node j
-        fc_f32x16 CX = zero;
+        asm volatile("" ::: "memory");
+        // softmax backward of row c (P by rows: this lane's row), then the leaky slope of the pre-activation
+        float ds_[16];
+        {
+            float pl[16], dot = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int i = fc_krow(s, h);
-            const float adj = (pc[s] + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
-            CX = fc_mfma(dk[s], i < Q ? adj : 0.f, CX);
-        }
-        // softmax backward of row c, then the leaky slope of the pre-activation
-        float ds_[16], dot = 0.f;
+            for (int m = 0; m < 4; ++m) {
+                float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (8 * m + 4 * h < Q) t4 = *reinterpret_cast<const float4*>(P + (gi * Q + cq) * Q + 8 * m + 4 * h);
+                pl[4 * m] = t4.x; pl[4 * m + 1] = t4.y; pl[4 * m + 2] = t4.z; pl[4 * m + 3] = t4.w;
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = fc_krow(r, h);
-            ds_[r] = Tt[r] * (((c < N) == (j < N)) ? 1.f : DECAY);
-            dot = fmaf(ds_[r], pl[r], dot);                             // pl is 0 beyond the graph
-        }
-        dot += fc_swap32(dot);
+            for (int r = 0; r < 16; ++r) {
+                const int j = fc_krow(r, h);
+                ds_[r] = Tt[r] * (((c < N) == (j < N)) ? 1.f : DECAY);
+                dot = fmaf(ds_[r], pl[r], dot);                         // pl is 0 beyond the graph
+            }
+            dot += fc_swap32(dot);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = fc_krow(r, h);
-            const float pre = j == c ? Sm[r] - 1e8f : Sm[r];
-            ds_[r] = (j < Q && c < Q) ? pl[r] * (ds_[r] - dot) * (pre > 0.f ? 1.f : LEAKY) : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int j = fc_krow(r, h);
+                const float pre = j == c ? Sm[r] - 1e8f : Sm[r];
+                ds_[r] = (j < Q && c < Q) ? pl[r] * (ds_[r] - dot) * (pre > 0.f ? 1.f : LEAKY) : 0.f;
+            }
         }
-        if (c < Q) {                                                    // (all loads of this graph's dAX block are behind us)
-            float* xr = dAX + (gi * Q + c) * D2T + 4 * h;
+        asm volatile("" ::: "memory");
+        // cX^T = dAX^T Adj: a-operand the gradient by node (lane = feature), b-operand column c of the adjacency (P by columns) -> lane = node j
+        {
+            fc_f32x16 CX = zero;
 #pragma unroll
-            for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(xr + 8 * m) = make_float4(CX[4 * m], CX[4 * m + 1], CX[4 * m + 2], CX[4 * m + 3]);
+            for (int s = 0; s < 16; ++s) {
+                const int i = fc_krow(s, h);
+                const float pcs = i < Q ? P[(gi * Q + i) * Q + cq] : 0.f;
+                const float adj = (pcs + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
+                CX = fc_mfma(dk[s], i < Q ? adj : 0.f, CX);
+            }
+            if (c < Q) {                                                // (all loads of this graph's dAX block are behind us)
+                float* xr = dAX + (gi * Q + c) * D2T + 4 * h;
+#pragma unroll
+                for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(xr + 8 * m) = make_float4(CX[4 * m], CX[4 * m + 1], CX[4 * m + 2], CX[4 * m + 3]);
+            }
         }
+        asm volatile("" ::: "memory");
         // dS^T: the product with the identity swaps the roles of register and lane
         fc_f32x16 St = zero;
 #pragma unroll
@@ -1077,7 +1082,11 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_bwd_mx_kernel(FcGeo
         // cM^T = M'^T (dS + dS^T)^T: a-operand the mapped features by node (lane = feature), b-operand row c of dS + dS^T
         fc_f32x16 CM = zero;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) CM = fc_mfma(mk[s], ds_[s] + St[s], CM);
+        for (int s = 0; s < 16; ++s) {
+            const int node = fc_krow(s, h);
+            const float mks = (c < D2T && node < Q) ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
+            CM = fc_mfma(mks, ds_[s] + St[s], CM);
+        }
         if (c < Q) {
             float* mr = cM + (gi * Q + c) * D2T + 4 * h;
 #pragma unroll
