@@ -12,6 +12,7 @@
 // The 2 * num_patch recurrences of a layer run concurrently on different CUs; layers are sequentially dependent.
 #include <utility>
 
+#include "async_mem.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
@@ -68,26 +69,8 @@ __device__ __forceinline__ float tanh_fast(float v) { return fmaf(-2.0f, rcp1p_e
 
 // One sequential step used to cost 1.6 us (H = 64) although its arithmetic is ~0.2 us: __syncthreads() waits for vmcnt(0), i.e. for the
 // step's global stores (and the prefetched input row) to complete -- two HBM round trips per step.  Here the step barrier only waits
-// for the LDS (lgkmcnt) and global traffic is asynchronous: tape stores drain behind the recurrence, and the rows a step reads are
-// requested LSTM_AHEAD steps earlier by LDS-DMA (global_load_lds_dword: no destination register the compiler could touch early) into a
-// ring each wavefront reads back itself.  The compiler would wait for vmcnt(0) in front of every use (it cannot count through the
-// loop), so every vector-memory instruction of the loops is written out and counted by hand: vmcnt decrements in issue order on gfx9,
-// a step issues the same instructions in every wavefront that has a live lane, and the wait in front of a ring read names exactly the
-// instructions issued after that row's request.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void store_async(float* dst, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(v) : "memory"); }
-// one dword per lane to LDS byte address lds_wave + 4 lane; all 64 lanes enabled.  M0 carries the LDS base: nothing else in these
-// kernels uses it (LDS instructions do not need M0 on gfx9), so it is neither saved nor restored.
-__device__ __forceinline__ void dma_dword(const float* src, unsigned lds_wave) {
-    asm volatile("s_mov_b32 m0, %1\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dword %0, off"
-                 :
-                 : "v"(src), "s"(lds_wave)
-                 : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// for the LDS (lgkmcnt) and global traffic is asynchronous and counted by hand (async_mem.hpp): tape stores drain behind the
+// recurrence, and the rows a step reads are requested LSTM_AHEAD steps earlier by LDS-DMA into a ring each wavefront reads back itself.
 constexpr int LSTM_AHEAD = 8;       // even (the LDS vectors of the recurrence are double-buffered by step parity)
 
 // acc += w * (lane N of this lane's row of 16 in hc): the matvec's broadcast.  Reading the whole vector in every lane (LDS broadcast

@@ -16,6 +16,7 @@
 //              accumulated in LDS per workgroup;
 //   finalize   fixed-order reduction of the per-workgroup partial gradients, fc gradients, loss.
 // Everything is fp32; reductions have a fixed order, so results are run-to-run reproducible.
+#include "async_mem.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
@@ -616,12 +617,11 @@ static size_t features_lds_bytes(const MsgGeom& g) {
 // ---------------------------------------------------------------------------------------------------
 // hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm expf / tanhf + IEEE division: the gate
 // non-linearities sit on the critical path of every sequential GRU step (same finding as in the HAGCN LSTM)
-__device__ inline float sigmoidf_(float v) { return __frcp_rn(1.0f + __expf(-v)); }
-__device__ inline float tanhf_(float v) {
-    const float a = fabsf(v);
-    return copysignf(1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * a)), v);
-}
+// (__frcp_rn compiles to the IEEE division sequence with this compiler: the builtin is the single v_rcp_f32)
+__device__ inline float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ inline float tanhf_(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }     // exp -> inf: 1; -> 0: -1
 
+constexpr int GRU_AHEAD = 4;             // steps a step's inputs are requested ahead
 // One lane per (sequence, hidden unit); HG = lanes per sequence (power of two >= H).
 template <int HG>
 __global__ __launch_bounds__(MB) void msg_gru_forward_kernel(MsgGeom g, const float* __restrict__ gi,
@@ -641,49 +641,61 @@ __global__ __launch_bounds__(MB) void msg_gru_forward_kernel(MsgGeom g, const fl
         wz[k] = ok ? prm[g.off_whh + (H + jj) * H + k] : 0.f;
         wn[k] = ok ? prm[g.off_whh + (2 * H + jj) * H + k] : 0.f;
     }
-    const float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
+    float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
+    asm volatile("" : "+v"(br), "+v"(bz), "+v"(bn));
     const int base = tid - j;
     float h = 0.f;
     hs[tid] = 0.f;
-    __syncthreads();
-    int64_t row = (b * g.NP) * n + node;
-    float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (live) {
-        gr = gi[row * g.H3 + j];
-        gz = gi[row * g.H3 + H + j];
-        gn = gi[row * g.H3 + 2 * H + j];
-    }
-    for (int t = 0; t < g.NP; ++t) {
-        float nr = 0.f, nz = 0.f, nn = 0.f;
-        if (live && t + 1 < g.NP) {                                   // next step's inputs, ahead of the gate math
-            const int64_t r2 = (row + n) * g.H3;
-            nr = gi[r2 + j];
-            nz = gi[r2 + H + j];
-            nn = gi[r2 + 2 * H + j];
-        }
-        float ar = br, az = bz, an = bn;
 #pragma unroll
-        for (int k = 0; k < HG; ++k) {
-            const float hk = hs[base + k];
-            ar = fmaf(wr[k], hk, ar);
-            az = fmaf(wz[k], hk, az);
-            an = fmaf(wn[k], hk, an);
+    for (int k = 0; k < HG; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]));   // the compiler waits for its weight loads here
+    // The HG lanes of a sequence sit in ONE wavefront: its LDS operations execute in order, so the exchange of h needs no workgroup
+    // barrier -- and __syncthreads() also waits for vmcnt(0), i.e. for the step's store and the prefetched inputs: two memory round
+    // trips per sequential step (0.75 us per step of 256).  Global traffic is asynchronous and counted by hand (async_mem.hpp): the
+    // three gate inputs of a step are requested GRU_AHEAD steps ahead into a ring the wavefront reads back itself.
+    __shared__ float ring[GRU_AHEAD][3][MB];
+    const unsigned ring_wave = lds_address(&ring[0][0][tid & ~63]);
+    const float* gsrc = gi + ((b * g.NP) * n + node) * g.H3 + jj;      // (lanes without work request sequence 0: the count must not vary)
+    const int64_t gstep = (int64_t)n * g.H3;
+    float* hdst = hseq + ((b * g.NP) * n + node) * H + jj;
+    const int64_t hstep = (int64_t)n * H;
+    int requested = 0;
+    auto request = [&](int slot) {
+        const unsigned dst = ring_wave + (unsigned)slot * (3 * MB * 4);
+        dma_dword(gsrc, dst);
+        dma_dword(gsrc + H, dst + MB * 4);
+        dma_dword(gsrc + 2 * H, dst + 2 * MB * 4);
+        if (++requested < g.NP) gsrc += gstep;
+    };
+    asm volatile("" : "+v"(h));
+    wait_vm<0>();                                                      // (the weights above: the compiler's own loads)
+#pragma unroll
+    for (int i = 0; i < GRU_AHEAD; ++i) request(i);
+    wait_vm<0>();
+    for (int t0 = 0; t0 < g.NP; t0 += GRU_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < GRU_AHEAD; ++i) {
+            if (t0 + i >= g.NP) break;
+            // issued after this step's requests: that step's store and (three requests, store) of the GRU_AHEAD - 1 steps since
+            wait_vm<1 + 4 * (GRU_AHEAD - 1)>();
+            const float gr = ring[i][0][tid], gz = ring[i][1][tid], gn = ring[i][2][tid];
+            float ar = br, az = bz, an = bn;
+#pragma unroll
+            for (int k = 0; k < HG; ++k) {
+                const float hk = hs[base + k];
+                ar = fmaf(wr[k], hk, ar);
+                az = fmaf(wz[k], hk, az);
+                an = fmaf(wn[k], hk, an);
+            }
+            const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
+            const float c = tanhf_(gn + r * an);
+            h = (1.0f - z) * c + z * h;
+            hs[tid] = j < H ? h : 0.f;
+            request(i);
+            if (live) store_async(hdst, h);
+            hdst += hstep;
         }
-        const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
-        const float c = tanhf_(gn + r * an);
-        h = (1.0f - z) * c + z * h;
-        __syncthreads();
-        hs[tid] = j < H ? h : 0.f;
-        __syncthreads();
-        if (live) hseq[row * H + j] = h;
-        row += n;
-        gr = nr; gz = nz; gn = nn;
     }
 }
-
-// BPTT.  d out[t][j] = dpred[b] * fc.weight[t*H + j] / n  (mean over nodes + Linear, Model.py:109-111).
-// Gates are recomputed from gi and h[t-1]; per-lane accumulators for d W_hh / d b_hh are reduced in a
-// fixed order and written as one partial row per workgroup.
 template <int HG>
 __global__ __launch_bounds__(MB) void msg_gru_backward_kernel(MsgGeom g, const float* __restrict__ gi,
                                                               const float* __restrict__ hseq, const float* __restrict__ prm,
@@ -710,63 +722,92 @@ __global__ __launch_bounds__(MB) void msg_gru_backward_kernel(MsgGeom g, const f
         tn[k] = ok ? prm[g.off_whh + (2 * H + k) * H + jj] : 0.f;
         ar_[k] = az_[k] = an_[k] = 0.f;
     }
-    const float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
+    float br = prm[g.off_bhh + jj], bz = prm[g.off_bhh + H + jj], bn = prm[g.off_bhh + 2 * H + jj];
     float abr = 0.f, abz = 0.f, abn = 0.f;
     const int base = tid - j;
-    const float dscale = live ? dpred[b] / (float)n : 0.f;
+    float dscale = live ? dpred[b] / (float)n : 0.f;
     float dh = 0.f;
-    for (int t = g.NP - 1; t >= 0; --t) {
-        const int64_t row = (b * g.NP + t) * n + node;
-        float hprev = 0.f, gr = 0.f, gz = 0.f, gn = 0.f;
-        if (live) {
-            if (t > 0) hprev = hseq[(row - n) * H + j];
-            gr = gi[row * g.H3 + j];
-            gz = gi[row * g.H3 + H + j];
-            gn = gi[row * g.H3 + 2 * H + j];
-        }
-        __syncthreads();
-        hp[tid] = hprev;
-        __syncthreads();
-        float ar = br, az = bz, an = bn;
+    // (see the forward: the lanes of a sequence share a wavefront, no workgroup barrier; global traffic counted by hand.)  The tape of a
+    // step -- h entering it, its three gate inputs, the head's weight for this unit -- is requested GRU_AHEAD steps ahead.
+    __shared__ float ring[GRU_AHEAD][5][MB];
+    const unsigned ring_wave = lds_address(&ring[0][0][tid & ~63]);
+    const int64_t seq0 = (b * g.NP) * n + node;                        // row of (sequence, t = 0); lanes without work use sequence 0
+    const int64_t gstep = (int64_t)n * g.H3, hstep = (int64_t)n * H;
+    const float* gsrc = gi + (seq0 + (int64_t)(g.NP - 1) * n) * g.H3 + jj;
+    const float* hsrc = hseq + (seq0 + (int64_t)(g.NP > 1 ? g.NP - 2 : 0) * n) * H + jj;      // h entering step t = h of step t - 1 (t = 0: unused)
+    const float* fsrc = prm + g.off_fcw + (int64_t)(g.NP - 1) * H + jj;
+    float* ddst = dgi + (seq0 + (int64_t)(g.NP - 1) * n) * g.H3 + jj;
+    int requested = 0;
+    auto request = [&](int slot) {                                     // the tape of step NP - 1 - requested (clamped at the end)
+        const unsigned dst = ring_wave + (unsigned)slot * (5 * MB * 4);
+        dma_dword(hsrc, dst);
+        dma_dword(gsrc, dst + MB * 4);
+        dma_dword(gsrc + H, dst + 2 * MB * 4);
+        dma_dword(gsrc + 2 * H, dst + 3 * MB * 4);
+        dma_dword(fsrc, dst + 4 * MB * 4);
+        ++requested;
+        if (requested < g.NP) { gsrc -= gstep; fsrc -= H; }
+        if (requested + 1 < g.NP) hsrc -= hstep;
+    };
 #pragma unroll
-        for (int k = 0; k < HG; ++k) {
-            const float hk = hp[base + k];
-            ar = fmaf(wr[k], hk, ar);
-            az = fmaf(wz[k], hk, az);
-            an = fmaf(wn[k], hk, an);
-        }
-        const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
-        const float c = tanhf_(gn + r * an);
-        dh += live ? dscale * prm[g.off_fcw + t * H + j] : 0.f;
-        const float dn_pre = dh * (1.0f - z) * (1.0f - c * c);
-        const float dz_pre = dh * (hprev - c) * z * (1.0f - z);
-        const float dr_pre = dn_pre * an * r * (1.0f - r);
-        const float dgn = dn_pre * r;
-        if (live) {
-            dgi[row * g.H3 + j] = dr_pre;
-            dgi[row * g.H3 + H + j] = dz_pre;
-            dgi[row * g.H3 + 2 * H + j] = dn_pre;
-        }
-        dg[0][tid] = live ? dr_pre : 0.f;
-        dg[1][tid] = live ? dz_pre : 0.f;
-        dg[2][tid] = live ? dgn : 0.f;
-        __syncthreads();
-        float acc = dh * z;
+    for (int k = 0; k < HG; ++k) asm volatile("" : "+v"(wr[k]), "+v"(wz[k]), "+v"(wn[k]), "+v"(tr[k]), "+v"(tz[k]), "+v"(tn[k]));
+    asm volatile("" : "+v"(br), "+v"(bz), "+v"(bn), "+v"(dscale));       // the compiler waits for its own loads here
 #pragma unroll
-        for (int k = 0; k < HG; ++k) {
-            const float hk = hp[base + k];
-            ar_[k] = fmaf(live ? dr_pre : 0.f, hk, ar_[k]);
-            az_[k] = fmaf(live ? dz_pre : 0.f, hk, az_[k]);
-            an_[k] = fmaf(live ? dgn : 0.f, hk, an_[k]);
-            acc = fmaf(dg[0][base + k], tr[k], acc);
-            acc = fmaf(dg[1][base + k], tz[k], acc);
-            acc = fmaf(dg[2][base + k], tn[k], acc);
+    for (int i = 0; i < GRU_AHEAD; ++i) request(i);
+    wait_vm<0>();
+    for (int t0 = g.NP - 1; t0 >= 0; t0 -= GRU_AHEAD) {
+#pragma unroll
+        for (int i = 0; i < GRU_AHEAD; ++i) {
+            const int t = t0 - i;
+            if (t < 0) break;
+            // issued after this step's requests: that step's three stores and (five requests, three stores) of the GRU_AHEAD - 1 steps since
+            wait_vm<3 + 8 * (GRU_AHEAD - 1)>();
+            const float hprev = t > 0 ? ring[i][0][tid] : 0.f, gr = ring[i][1][tid], gz = ring[i][2][tid], gn = ring[i][3][tid];
+            const float fw = ring[i][4][tid];
+            hp[tid] = hprev;
+            float ar = br, az = bz, an = bn;
+#pragma unroll
+            for (int k = 0; k < HG; ++k) {
+                const float hk = hp[base + k];
+                ar = fmaf(wr[k], hk, ar);
+                az = fmaf(wz[k], hk, az);
+                an = fmaf(wn[k], hk, an);
+            }
+            const float r = sigmoidf_(gr + ar), z = sigmoidf_(gz + az);
+            const float c = tanhf_(gn + r * an);
+            dh += live ? dscale * fw : 0.f;
+            const float dn_pre = dh * (1.0f - z) * (1.0f - c * c);
+            const float dz_pre = dh * (hprev - c) * z * (1.0f - z);
+            const float dr_pre = dn_pre * an * r * (1.0f - r);
+            const float dgn = dn_pre * r;
+            request(i);
+            if (live) {
+                store_async(ddst, dr_pre);
+                store_async(ddst + H, dz_pre);
+                store_async(ddst + 2 * H, dn_pre);
+            }
+            ddst -= gstep;
+            dg[0][tid] = live ? dr_pre : 0.f;
+            dg[1][tid] = live ? dz_pre : 0.f;
+            dg[2][tid] = live ? dgn : 0.f;
+            float acc = dh * z;
+#pragma unroll
+            for (int k = 0; k < HG; ++k) {
+                const float hk = hp[base + k];
+                ar_[k] = fmaf(live ? dr_pre : 0.f, hk, ar_[k]);
+                az_[k] = fmaf(live ? dz_pre : 0.f, hk, az_[k]);
+                an_[k] = fmaf(live ? dgn : 0.f, hk, an_[k]);
+                acc = fmaf(dg[0][base + k], tr[k], acc);
+                acc = fmaf(dg[1][base + k], tz[k], acc);
+                acc = fmaf(dg[2][base + k], tn[k], acc);
+            }
+            abr += live ? dr_pre : 0.f;
+            abz += live ? dz_pre : 0.f;
+            abn += live ? dgn : 0.f;
+            dh = acc;
         }
-        abr += live ? dr_pre : 0.f;
-        abz += live ? dz_pre : 0.f;
-        abn += live ? dgn : 0.f;
-        dh = acc;
     }
+    wait_vm<0>();
     // reduce the per-lane accumulators over the sequences of this workgroup: butterfly across the lanes that hold the
     // same unit, then the four wavefronts in order.
     const int wave = tid / 64, lane = tid % 64;
