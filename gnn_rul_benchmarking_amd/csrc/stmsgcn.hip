@@ -842,15 +842,20 @@ __global__ __launch_bounds__(MB) void msg_gru_backward_kernel(MsgGeom g, const f
 // ---------------------------------------------------------------------------------------------------
 // head: mean over nodes, fc, squared error
 // ---------------------------------------------------------------------------------------------------
+constexpr int HEAD_MAX_PARTS = 16;
 __global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __restrict__ hseq, const float* __restrict__ prm,
                                                       const float* __restrict__ y, float* __restrict__ pred,
                                                       float* __restrict__ pooled, float* __restrict__ dpred,
-                                                      float* __restrict__ sqerr, float inv_gb) {
+                                                      float* __restrict__ sqerr, float inv_gb, int parts, float* __restrict__ hpart) {
+    // `parts` workgroups per sample (a sample's 26 MB / batch of hidden states walked by ONE workgroup was 57 us at batch 128): each
+    // takes a slice of the (patch, unit) pairs and leaves its share of the dot product; msg_head_finish_kernel adds them in order
     __shared__ float red[MB];
-    const int64_t b = blockIdx.x;
+    const int64_t b = blockIdx.x / parts;
+    const int part = blockIdx.x - (int)b * parts;
     const int H = g.H, n = g.n, Q = g.NP * H;
+    const int qper = (Q + parts - 1) / parts, q0 = part * qper, q1 = q0 + qper < Q ? q0 + qper : Q;
     float acc = 0.f;
-    for (int q = threadIdx.x; q < Q; q += MB) {
+    for (int q = q0 + threadIdx.x; q < q1; q += MB) {
         const int p = q / H, j = q - p * H;
         const float* src = hseq + ((b * g.NP + p) * n) * H + j;
         float s = 0.f;
@@ -866,6 +871,10 @@ __global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        if (parts > 1) {
+            hpart[blockIdx.x] = red[0];
+            return;
+        }
         const float pr = red[0] + prm[g.off_fcb];
         pred[b] = pr;
         if (y) {
@@ -873,6 +882,21 @@ __global__ __launch_bounds__(MB) void msg_head_kernel(MsgGeom g, const float* __
             dpred[b] = 2.0f * d * inv_gb;
             sqerr[b] = d * d * inv_gb;
         }
+    }
+}
+__global__ void msg_head_finish_kernel(MsgGeom g, const float* __restrict__ prm, const float* __restrict__ hpart, int parts,
+                                       const float* __restrict__ y, float* __restrict__ pred, float* __restrict__ dpred,
+                                       float* __restrict__ sqerr, float inv_gb) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.B) return;
+    float pr = 0.f;
+    for (int k = 0; k < parts; ++k) pr += hpart[b * parts + k];
+    pr += prm[g.off_fcb];
+    pred[b] = pr;
+    if (y) {
+        const float d = pr - y[b];
+        dpred[b] = 2.0f * d * inv_gb;
+        sqerr[b] = d * d * inv_gb;
     }
 }
 
@@ -1491,7 +1515,7 @@ __global__ void msg_fill_kernel(float* p, int n, float v) {
 }
 
 struct MsgWs {
-    size_t cat, gi, hseq, dgi, dcat, one, split, pooled, dpred, sqerr, gpart_gcn, gpart_gru, gpart_gi, total;
+    size_t cat, gi, hseq, dgi, dcat, one, split, pooled, dpred, sqerr, hpart, gpart_gcn, gpart_gru, gpart_gi, total;
     int rows_gcn_max, rows_gru, HG;
 };
 
@@ -1512,6 +1536,7 @@ static void msg_ws_layout(const MsgGeom& g, MsgWs* w) {
     w->pooled = o; o = al(o + (size_t)g.B * g.NP * g.H * sizeof(float));
     w->dpred = o; o = al(o + (size_t)g.B * sizeof(float));
     w->sqerr = o; o = al(o + (size_t)g.B * sizeof(float));
+    w->hpart = o; o = al(o + (size_t)g.B * HEAD_MAX_PARTS * sizeof(float));
     w->HG = g.H <= 4 ? 4 : (g.H <= 8 ? 8 : 16);
     w->rows_gcn_max = 1024;
     w->rows_gru = (int)(((size_t)g.B * g.n * w->HG + MB - 1) / MB);
@@ -1642,8 +1667,17 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
         rc = launch_features(g, a->x, a->params, (float*)(ws + w.cat), (float*)(ws + w.gi), st);
         if (rc != RULGNN_OK) return rc;
         dispatch_gru(g, w, ws, a->params, false, st);
-        hipLaunchKernelGGL(msg_head_kernel, dim3((unsigned)g.B), dim3(MB), 0, st, g, (const float*)(ws + w.hseq), a->params,
-                           a->y, a->pred, (float*)(ws + w.pooled), (float*)(ws + w.dpred), (float*)(ws + w.sqerr), inv_gb);
+        {
+            // enough workgroups to fill the chip: a sample's (patch, unit) pairs in up to HEAD_MAX_PARTS slices
+            int parts = 1;
+            while (parts < HEAD_MAX_PARTS && g.B * parts < 1024 && g.NP * g.H / (2 * parts) >= MB) parts *= 2;
+            hipLaunchKernelGGL(msg_head_kernel, dim3((unsigned)(g.B * parts)), dim3(MB), 0, st, g, (const float*)(ws + w.hseq), a->params,
+                               a->y, a->pred, (float*)(ws + w.pooled), (float*)(ws + w.dpred), (float*)(ws + w.sqerr), inv_gb, parts,
+                               (float*)(ws + w.hpart));
+            if (parts > 1)
+                hipLaunchKernelGGL(msg_head_finish_kernel, dim3((unsigned)((g.B + 255) / 256)), dim3(256), 0, st, g, a->params,
+                                   (const float*)(ws + w.hpart), parts, a->y, a->pred, (float*)(ws + w.dpred), (float*)(ws + w.sqerr), inv_gb);
+        }
     }
     if (mode & 2) {
         if (a->dpred) {
