@@ -13,6 +13,7 @@
 // adjacency / softmax / aggregation in LDS, the rest is elementwise.  Seven BatchNorms cut the step into phases; batch
 // statistics go through fp64 reduction cells in stream order.  BatchNorms on the unfolded windows are computed on the
 // rows with multiplicity weights (how many windows contain a patch).
+#include "async_mem.hpp"
 #include "aux_stream.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
@@ -240,30 +241,86 @@ __global__ __launch_bounds__(FB) void fc_conv1_kernel(FcGeom g, const float* __r
     if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[0], g.H1);
 }
 
+// Row-group mapping of the encoder kernels: a thread keeps ONE position of the per-row tile ((channel, time) = tid % tile) and walks
+// rows; FB / tile rows are in flight per workgroup.  The element-per-thread form paid three 64-bit divisions per output, read every
+// weight from global memory inside the innermost loop and changed its BatchNorm channel with every element (one LDS fp64 atomic pair
+// per output): 33 us for the 2.1 M outputs of the second convolution at FD004 / batch 256.
+struct RowGroup {
+    int tile, rows_per, sub, pos;
+    bool on;
+    __device__ RowGroup(int tile_) : tile(tile_) {
+        rows_per = FB / tile;                      // 0 when the tile is wider than the workgroup: see wide()
+        sub = rows_per ? (int)threadIdx.x / tile : 0;
+        pos = rows_per ? (int)threadIdx.x % tile : (int)threadIdx.x;
+        on = rows_per ? sub < rows_per : true;
+    }
+    __device__ bool wide() const { return rows_per == 0; }
+};
+constexpr int FC_W2_MAX = 64 * 16 * 4;      // CO x H1 x K at the limits of fc_geometry
+
 // z2[m][co][p] = sum_ci sum_k w2[co][ci][k] * relu(bn_a(z1))[m][ci][p + k - 1]   (padding 1, Model_Base.py:27-28)
 __global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
                                                      const float* __restrict__ z1, float* __restrict__ z2, Cells* cells, int training) {
     __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ca[16];
+    __shared__ float wl[FC_W2_MAX];
     if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, running, training, 0, threadIdx.x);
+    for (int e = threadIdx.x; e < g.CO * g.H1 * g.K; e += FB) wl[e] = prm[g.o_w2 + e];
     BlockStats st;
-    st.init(sl, g.CO);
-    const int64_t total = g.M * g.CL;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
-        const int p = (int)(e % g.L2), co = (int)((e / g.L2) % g.CO);
-        const int64_t m = e / g.CL;
-        const float* zr = z1 + m * g.H1 * g.L1;
+    st.init(sl, g.CO);                                                 // (ends in a barrier)
+    const int H1 = g.H1, K = g.K, L1 = g.L1, L2 = g.L2, CL = g.CL;
+    auto one = [&](int64_t m, int cl) {
+        const int co = cl / L2, p = cl - co * L2;
+        const float* zr = z1 + m * H1 * L1;
+        const float* wr = wl + co * H1 * K;
         float a = 0.f;
-        for (int ci = 0; ci < g.H1; ++ci)
-            for (int k = 0; k < g.K; ++k) {
+        for (int ci = 0; ci < H1; ++ci)
+            for (int k = 0; k < K; ++k) {
                 const int q = p + k - 1;
-                if (q >= 0 && q < g.L1) {
-                    const float a1 = fmaxf(fmaf(zr[ci * g.L1 + q], ca[ci].sc, ca[ci].sh), 0.f);
-                    a = fmaf(prm[g.o_w2 + (co * g.H1 + ci) * g.K + k], a1, a);
-                }
+                if (q >= 0 && q < L1) a = fmaf(wr[ci * K + k], fmaxf(fmaf(zr[ci * L1 + q], ca[ci].sc, ca[ci].sh), 0.f), a);
             }
-        z2[e] = a;
+        z2[m * CL + cl] = a;
         if (training) st.add(co, a, a * a);
+    };
+    const int T1 = H1 * L1;
+    const RowGroup rg(T1 > CL ? T1 : CL);
+    if (rg.wide()) {
+        for (int64_t m = blockIdx.x; m < g.M; m += gridDim.x)
+            for (int cl = threadIdx.x; cl < CL; cl += FB) one(m, cl);
+    } else {
+        // the row's activated input a1 = relu(bn_a(z1)) goes through LDS (one coalesced load per thread; read from global inside the
+        // (channel, tap) loop the 16 loads of an output were served one after the other: 33 us of latency), double-buffered: one
+        // barrier per group of rows
+        __shared__ float tile[2][FB];
+        const int co = rg.pos < CL ? rg.pos / L2 : 0, p = rg.pos - co * L2;
+        const float* wr = wl + co * H1 * K;
+        const int64_t stride = (int64_t)gridDim.x * rg.rows_per;
+        int buf = 0;
+        const int cis = rg.pos < T1 ? rg.pos / L1 : 0;
+        auto fetch = [&](int64_t m0) {                                  // this thread's element of the row group that starts at m0
+            const int64_t m = m0 + rg.sub;
+            return (rg.on && m < g.M && rg.pos < T1) ? z1[m * T1 + rg.pos] : 0.f;
+        };
+        float nxt = fetch((int64_t)blockIdx.x * rg.rows_per);
+        for (int64_t m0 = (int64_t)blockIdx.x * rg.rows_per; m0 < g.M; m0 += stride, buf ^= 1) {
+            const int64_t m = m0 + rg.sub;
+            const bool row_on = rg.on && m < g.M;
+            const float cur = nxt;
+            nxt = fetch(m0 + stride);                                  // the next group's element is in flight under this one's products
+            if (row_on && rg.pos < T1) tile[buf][rg.sub * rg.tile + rg.pos] = fmaxf(fmaf(cur, ca[cis].sc, ca[cis].sh), 0.f);
+            lds_barrier();                                             // LDS only: __syncthreads() would also wait for the stores of the group before
+            if (row_on && rg.pos < CL) {
+                const float* ar = &tile[buf][rg.sub * rg.tile];
+                float a = 0.f;
+                for (int ci = 0; ci < H1; ++ci)
+                    for (int k = 0; k < K; ++k) {
+                        const int q = p + k - 1;
+                        if (q >= 0 && q < L1) a = fmaf(wr[ci * K + k], ar[ci * L1 + q], a);
+                    }
+                z2[m * CL + rg.pos] = a;
+                if (training) st.add(co, a, a * a);
+            }
+        }
     }
     if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[1], g.CO);
 }
@@ -1213,31 +1270,73 @@ __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* 
     st.flush(cells[blockIdx.x % CELL_REP].bwd[1], g.CO);
 }
 
-// dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums
+// dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums  (row-group mapping, see fc_conv2_kernel)
 __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z1, const float* __restrict__ dz2,
                                                         float* __restrict__ dy1) {
     __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ca[16];
+    __shared__ float wl[FC_W2_MAX];
     if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
+    for (int e = threadIdx.x; e < g.CO * g.H1 * g.K; e += FB) wl[e] = prm[g.o_w2 + e];
     BlockStats st;
     st.init(sl, g.H1);
-    const int64_t total = g.M * g.H1 * g.L1;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
-        const int q = (int)(e % g.L1), ci = (int)((e / g.L1) % g.H1);
-        const int64_t m = e / ((int64_t)g.L1 * g.H1);
-        const float zz = z1[e];
+    const int H1 = g.H1, K = g.K, L1 = g.L1, L2 = g.L2, CL = g.CL, CO = g.CO, T1 = g.H1 * g.L1;
+    auto one = [&](int64_t m, int pos) {
+        const int ci = pos / L1, q = pos - ci * L1;
+        const float zz = z1[m * T1 + pos];
         float dy = 0.f;
         if (fmaf(zz, ca[ci].sc, ca[ci].sh) > 0.f) {
-            const float* dr = dz2 + m * g.CL;
-            for (int co = 0; co < g.CO; ++co)
-                for (int k = 0; k < g.K; ++k) {
+            const float* dr = dz2 + m * CL;
+            for (int co = 0; co < CO; ++co)
+                for (int k = 0; k < K; ++k) {
                     const int p = q + 1 - k;
-                    if (p >= 0 && p < g.L2) dy = fmaf(prm[g.o_w2 + (co * g.H1 + ci) * g.K + k], dr[co * g.L2 + p], dy);
+                    if (p >= 0 && p < L2) dy = fmaf(wl[(co * H1 + ci) * K + k], dr[co * L2 + p], dy);
                 }
         }
-        dy1[e] = dy;
+        dy1[m * T1 + pos] = dy;
         st.add(ci, dy, dy * (zz - ca[ci].mean) * ca[ci].inv);
+    };
+    const RowGroup rg(T1 > CL ? T1 : CL);
+    if (rg.wide()) {
+        for (int64_t m = blockIdx.x; m < g.M; m += gridDim.x)
+            for (int pos = threadIdx.x; pos < T1; pos += FB) one(m, pos);
+    } else {
+        __shared__ float tile[2][FB];                                  // the row of d z2, staged as in fc_conv2_kernel
+        const int ci = rg.pos < T1 ? rg.pos / L1 : 0, q = rg.pos - ci * L1;
+        const int64_t stride = (int64_t)gridDim.x * rg.rows_per;
+        int buf = 0;
+        auto fetch_d = [&](int64_t m0) {
+            const int64_t m = m0 + rg.sub;
+            return (rg.on && m < g.M && rg.pos < CL) ? dz2[m * CL + rg.pos] : 0.f;
+        };
+        auto fetch_z = [&](int64_t m0) {
+            const int64_t m = m0 + rg.sub;
+            return (rg.on && m < g.M && rg.pos < T1) ? z1[m * T1 + rg.pos] : 0.f;
+        };
+        float nd = fetch_d((int64_t)blockIdx.x * rg.rows_per), nz = fetch_z((int64_t)blockIdx.x * rg.rows_per);
+        for (int64_t m0 = (int64_t)blockIdx.x * rg.rows_per; m0 < g.M; m0 += stride, buf ^= 1) {
+            const int64_t m = m0 + rg.sub;
+            const bool row_on = rg.on && m < g.M;
+            const float dcur = nd, zz = nz;
+            nd = fetch_d(m0 + stride);                                 // the next group's elements are in flight under this one's products
+            nz = fetch_z(m0 + stride);
+            if (row_on && rg.pos < CL) tile[buf][rg.sub * rg.tile + rg.pos] = dcur;
+            lds_barrier();
+            if (row_on && rg.pos < T1) {
+                float dy = 0.f;
+                if (fmaf(zz, ca[ci].sc, ca[ci].sh) > 0.f) {
+                    const float* dr = &tile[buf][rg.sub * rg.tile];
+                    for (int co = 0; co < CO; ++co)
+                        for (int k = 0; k < K; ++k) {
+                            const int p = q + 1 - k;
+                            if (p >= 0 && p < L2) dy = fmaf(wl[(co * H1 + ci) * K + k], dr[co * L2 + p], dy);
+                        }
+                }
+                dy1[m * T1 + rg.pos] = dy;
+                st.add(ci, dy, dy * (zz - ca[ci].mean) * ca[ci].inv);
+            }
+        }
     }
     st.flush(cells[blockIdx.x % CELL_REP].bwd[0], g.H1);
 }
