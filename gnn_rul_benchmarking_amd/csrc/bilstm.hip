@@ -132,15 +132,18 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, cons
     __shared__ float ring[LSTM_AHEAD][4 * HMAX];
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
     const int tid = threadIdx.x, u = tid >> 2, p = tid & 3, H = g.H, H4 = g.H4, T = (int)g.T;
+    // FULL: no lane masks.  Lanes beyond the hidden width (H < HMAX) repeat unit H - 1: same values to the same addresses -- benign --
+    // and their slots of the h vector meet zero weights.
+    const int uc = u < H ? u : H - 1;
     const bool live = FULL || u < H;
-    const int row = live ? p * H + u : 0;
+    const int row = p * H + uc;
     const float* w_hh = dir ? w_hh1 : w_hh0;
     const float scale = p == 2 ? 2.0f * LOG2E : -LOG2E;                // gate order (i, f, g, o): g is the tanh row
     const float gm = p == 2 ? -2.0f : 1.0f, gb = p == 2 ? 1.0f : 0.0f;
     float w[HMAX];
 #pragma unroll
-    for (int k = 0; k < HMAX; ++k) w[k] = (live && (FULL || k < H)) ? w_hh[(int64_t)row * H + k] * scale : 0.f;
-    float bias_s = live ? (dir ? b_ih1[row] + b_hh1[row] : b_ih0[row] + b_hh0[row]) * scale : 0.f;
+    for (int k = 0; k < HMAX; ++k) w[k] = k < H ? w_hh[(int64_t)row * H + k] * scale : 0.f;
+    float bias_s = (dir ? b_ih1[row] + b_hh1[row] : b_ih0[row] + b_hh0[row]) * scale;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;          // row of (dir, q, t = 0)
     for (int e = tid; e < 8 * HMAX; e += blockDim.x) (&hs[0][0])[e] = 0.f;
     float c = 0.f, hlast = 0.f;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, cons
         if (++requested < T) gsrc += gstep;
     };
     float* gdst = gates + (base + t0) * H4 + row;
-    float* xdst = (p == 0 ? cseq : (p == 1 ? hseq : (p == 2 ? hprev : tseq))) + (base + t0) * H + (live ? u : 0);
+    float* xdst = (p == 0 ? cseq : (p == 1 ? hseq : (p == 2 ? hprev : tseq))) + (base + t0) * H + uc;
     // the weight rows above are the compiler's own loads: a use in front of the loop makes it wait for them HERE, not (conservatively,
     // every step) at their first use inside
 #pragma unroll
@@ -226,11 +229,11 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
     const int dir = blockIdx.x / g.Bq, q = blockIdx.x % g.Bq;
     const int tid = threadIdx.x, wave0 = tid & ~63, kl = tid & 15, p = (tid >> 4) & 3, k = (wave0 >> 2) + kl, H = g.H, H4 = g.H4, T = (int)g.T;
     const bool live = FULL || k < H;
-    const int kk = live ? k : 0;
+    const int kk = k < H ? k : H - 1;                                   // (lanes beyond the hidden width repeat unit H - 1, see the forward)
     const float* w_hh = dir ? w_hh1 : w_hh0;
     float wt[HMAX];
 #pragma unroll
-    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = (live && (FULL || jj < H)) ? w_hh[((int64_t)p * H + jj) * H + kk] : 0.f;
+    for (int jj = 0; jj < HMAX; ++jj) wt[jj] = jj < H ? w_hh[((int64_t)p * H + jj) * H + kk] : 0.f;
     for (int e = tid; e < 2 * ROW; e += blockDim.x) (&dgl[0][0])[e] = 0.f;
     const int64_t base = ((int64_t)dir * g.Bq + q) * g.T;
     const int64_t obase = (int64_t)q * g.T;                          // dout is [q][t][H], shared by both directions
@@ -354,10 +357,8 @@ int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hi
         hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0], a->w_hh[d1], a->b_ih[0],
                            a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h, ws + g.o_hprev, ws + g.o_tc);
     };
-    if (g.H == 64) fwd(lstm_forward_kernel<64, true>);                // no lane masks when the hidden width fills the kernel's
-    else if (g.H < 64) fwd(lstm_forward_kernel<64, false>);
-    else if (g.H == 128) fwd(lstm_forward_kernel<128, true>);
-    else fwd(lstm_forward_kernel<128, false>);
+    if (g.H <= 64) fwd(lstm_forward_kernel<64, true>);                // (the mask-free form serves every width: lanes beyond it repeat unit H - 1)
+    else fwd(lstm_forward_kernel<128, true>);
     if (ndir == 2) hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
     else hipLaunchKernelGGL(lstm_copy_kernel, dim3((unsigned)((g.rows * g.H + 255) / 256)), dim3(256), 0, st, (const float*)(ws + g.o_h), a->out, (int)(g.rows * g.H));
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
@@ -377,10 +378,8 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
         hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1], (const float*)(ws + g.o_gates),
                            (const float*)(ws + g.o_c), (const float*)(ws + g.o_tc), a->dout, ws + g.o_dgates);
     };
-    if (H == 64) bwd(lstm_backward_kernel<64, true>);
-    else if (H < 64) bwd(lstm_backward_kernel<64, false>);
-    else if (H == 128) bwd(lstm_backward_kernel<128, true>);
-    else bwd(lstm_backward_kernel<128, false>);
+    if (H <= 64) bwd(lstm_backward_kernel<64, true>);
+    else bwd(lstm_backward_kernel<128, true>);
     float* one = ws + g.o_one;
     float* split = ws + g.o_split;
     hipLaunchKernelGGL(lstm_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
