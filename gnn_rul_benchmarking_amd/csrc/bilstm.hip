@@ -86,19 +86,31 @@ __device__ __forceinline__ void chunks_load(float (&hc)[HMAX / 16], const float*
 #pragma unroll
     for (int c = 0; c < HMAX / 16; ++c) hc[c] = vec[16 * c + lane16];
 }
-template <int HMAX>
+// (KLIVE <= HMAX: the hidden width when it is known at compile time -- the products beyond it meet zero weights and are not issued)
+// (Measured and rejected at H = 120, two wavefronts per SIMD: a part of the products as plain FMAs on values every lane reads from LDS
+// itself -- 2.4 VALU cycles instead of 4, the LDS return path being idle -- is SLOWER: HAGCN step 11.25 ms all-DPP, 11.5 / 11.8 /
+// 12.2 ms with 24 / 40 / 56 products moved.)
+template <int HMAX, int KLIVE>
 __device__ __forceinline__ float matvec_row_bcast(const float (&w)[HMAX], const float (&hc)[HMAX / 16], float a0) {
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-    for (int c = 0; c < HMAX / 16; ++c) {
-        fma_row_bcast<0>(a0, hc[c], w[16 * c + 0]);   fma_row_bcast<1>(a1, hc[c], w[16 * c + 1]);
-        fma_row_bcast<2>(a2, hc[c], w[16 * c + 2]);   fma_row_bcast<3>(a3, hc[c], w[16 * c + 3]);
-        fma_row_bcast<4>(a0, hc[c], w[16 * c + 4]);   fma_row_bcast<5>(a1, hc[c], w[16 * c + 5]);
-        fma_row_bcast<6>(a2, hc[c], w[16 * c + 6]);   fma_row_bcast<7>(a3, hc[c], w[16 * c + 7]);
-        fma_row_bcast<8>(a0, hc[c], w[16 * c + 8]);   fma_row_bcast<9>(a1, hc[c], w[16 * c + 9]);
-        fma_row_bcast<10>(a2, hc[c], w[16 * c + 10]); fma_row_bcast<11>(a3, hc[c], w[16 * c + 11]);
-        fma_row_bcast<12>(a0, hc[c], w[16 * c + 12]); fma_row_bcast<13>(a1, hc[c], w[16 * c + 13]);
-        fma_row_bcast<14>(a2, hc[c], w[16 * c + 14]); fma_row_bcast<15>(a3, hc[c], w[16 * c + 15]);
+    for (int c = 0; c < (KLIVE + 15) / 16; ++c) {
+        if (16 * c + 0 < KLIVE) fma_row_bcast<0>(a0, hc[c], w[16 * c + 0]);
+        if (16 * c + 1 < KLIVE) fma_row_bcast<1>(a1, hc[c], w[16 * c + 1]);
+        if (16 * c + 2 < KLIVE) fma_row_bcast<2>(a2, hc[c], w[16 * c + 2]);
+        if (16 * c + 3 < KLIVE) fma_row_bcast<3>(a3, hc[c], w[16 * c + 3]);
+        if (16 * c + 4 < KLIVE) fma_row_bcast<4>(a0, hc[c], w[16 * c + 4]);
+        if (16 * c + 5 < KLIVE) fma_row_bcast<5>(a1, hc[c], w[16 * c + 5]);
+        if (16 * c + 6 < KLIVE) fma_row_bcast<6>(a2, hc[c], w[16 * c + 6]);
+        if (16 * c + 7 < KLIVE) fma_row_bcast<7>(a3, hc[c], w[16 * c + 7]);
+        if (16 * c + 8 < KLIVE) fma_row_bcast<8>(a0, hc[c], w[16 * c + 8]);
+        if (16 * c + 9 < KLIVE) fma_row_bcast<9>(a1, hc[c], w[16 * c + 9]);
+        if (16 * c + 10 < KLIVE) fma_row_bcast<10>(a2, hc[c], w[16 * c + 10]);
+        if (16 * c + 11 < KLIVE) fma_row_bcast<11>(a3, hc[c], w[16 * c + 11]);
+        if (16 * c + 12 < KLIVE) fma_row_bcast<12>(a0, hc[c], w[16 * c + 12]);
+        if (16 * c + 13 < KLIVE) fma_row_bcast<13>(a1, hc[c], w[16 * c + 13]);
+        if (16 * c + 14 < KLIVE) fma_row_bcast<14>(a2, hc[c], w[16 * c + 14]);
+        if (16 * c + 15 < KLIVE) fma_row_bcast<15>(a3, hc[c], w[16 * c + 15]);
     }
     return (a0 + a1) + (a2 + a3);
 }
@@ -123,7 +135,7 @@ __device__ __forceinline__ float quad_perm(float v) {
 // instruction count: FULL (H == HMAX, HAGCN's layers) has no lane masks, every lane of a quad stores (its gate and one of c, h,
 // h entering, tanh c -- the last saves the BPTT an exp and a reciprocal per step), ring slots and LDS halves are immediates.
 // ---------------------------------------------------------------------------------------------------
-template <int HMAX, bool FULL>
+template <int HMAX, bool FULL, int KLIVE = HMAX>
 __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, const float* __restrict__ gi, const float* __restrict__ w_hh0,
                                     const float* __restrict__ w_hh1, const float* __restrict__ b_ih0, const float* __restrict__ b_hh0,
                                     const float* __restrict__ b_ih1, const float* __restrict__ b_hh1, float* __restrict__ gates,
@@ -178,8 +190,8 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_forward_kernel(LstmGeom g, cons
             wait_vm<2 + 3 * (LSTM_AHEAD - 1)>();
             float hc[HMAX / 16];
 #pragma unroll
-            for (int cc = 0; cc < HMAX / 16; ++cc) hc[cc] = hv[64 * cc + 4 * (tid & 15)];
-            const float pre = matvec_row_bcast<HMAX>(w, hc, fmaf(ring[i][tid], scale, bias_s));
+            for (int cc = 0; cc < (KLIVE + 15) / 16; ++cc) hc[cc] = hv[64 * cc + 4 * (tid & 15)];
+            const float pre = matvec_row_bcast<HMAX, KLIVE>(w, hc, fmaf(ring[i][tid], scale, bias_s));
             const float gate = fmaf(rcp1p_exp2(pre), gm, gb);
             const float ig = quad_perm<0x00>(gate), fg = quad_perm<0x55>(gate), gg = quad_perm<0xAA>(gate), og = quad_perm<0xFF>(gate);
             c = fmaf(fg, c, ig * gg);
@@ -219,7 +231,7 @@ __global__ void lstm_sum_kernel(LstmGeom g, const float* __restrict__ hseq, floa
 //   k_c = o (1 - tc^2);   k_p = A (E (m - E) + b) with (A, E, m, b) = (g, i, 1, 0), (c entering, f, 1, 0), (i, g, 0, 1), (tc, o, 1, 0):
 // the same three instructions in every row, A and E read through per-lane LDS offsets.
 // ---------------------------------------------------------------------------------------------------
-template <int HMAX, bool FULL>
+template <int HMAX, bool FULL, int KLIVE = HMAX>
 __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, const float* __restrict__ w_hh0, const float* __restrict__ w_hh1,
                                      const float* __restrict__ gates, const float* __restrict__ cseq, const float* __restrict__ tseq,
                                      const float* __restrict__ dout, float* __restrict__ dgates) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(4 * HMAX) void lstm_backward_kernel(LstmGeom g, con
             chunks_load<HMAX>(dchunk, dcur + p * HMAX, kl);           // wt is zero beyond H; the LDS vector is zero there
             wait_vm<3 * (LSTM_AHEAD - 2) + 1>();
             prepare((i + 1) % LSTM_AHEAD, s + 1);
-            const float part = matvec_row_bcast<HMAX>(wt, dchunk, 0.f);
+            const float part = matvec_row_bcast<HMAX, KLIVE>(wt, dchunk, 0.f);
             request(i);                                                // the slot held this step's tape, folded a step ago
             dh = rows_sum4(part);
         }
@@ -357,7 +369,10 @@ int bilstm_forward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, hi
         hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, (const float*)(ws + g.o_gi), a->w_hh[0], a->w_hh[d1], a->b_ih[0],
                            a->b_hh[0], a->b_ih[d1], a->b_hh[d1], ws + g.o_gates, ws + g.o_c, ws + g.o_h, ws + g.o_hprev, ws + g.o_tc);
     };
-    if (g.H <= 64) fwd(lstm_forward_kernel<64, true>);                // (the mask-free form serves every width: lanes beyond it repeat unit H - 1)
+    // (the mask-free form serves every width: lanes beyond it repeat unit H - 1; HAGCN's widths also skip the products beyond them)
+    if (g.H == 60) fwd(lstm_forward_kernel<64, true, 60>);
+    else if (g.H <= 64) fwd(lstm_forward_kernel<64, true>);
+    else if (g.H == 120) fwd(lstm_forward_kernel<128, true, 120>);
     else fwd(lstm_forward_kernel<128, true>);
     if (ndir == 2) hipLaunchKernelGGL(lstm_sum_kernel, dim3(1024), dim3(256), 0, st, g, (const float*)(ws + g.o_h), a->out);
     else hipLaunchKernelGGL(lstm_copy_kernel, dim3((unsigned)((g.rows * g.H + 255) / 256)), dim3(256), 0, st, (const float*)(ws + g.o_h), a->out, (int)(g.rows * g.H));
@@ -378,7 +393,9 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
         hipLaunchKernelGGL(kernel, dim3(ndir * g.Bq), dim3(threads), 0, st, g, a->w_hh[0], a->w_hh[d1], (const float*)(ws + g.o_gates),
                            (const float*)(ws + g.o_c), (const float*)(ws + g.o_tc), a->dout, ws + g.o_dgates);
     };
-    if (H <= 64) bwd(lstm_backward_kernel<64, true>);
+    if (H == 60) bwd(lstm_backward_kernel<64, true, 60>);
+    else if (H <= 64) bwd(lstm_backward_kernel<64, true>);
+    else if (H == 120) bwd(lstm_backward_kernel<128, true, 120>);
     else bwd(lstm_backward_kernel<128, true>);
     float* one = ws + g.o_one;
     float* split = ws + g.o_split;
