@@ -1569,8 +1569,8 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
         if (v > mx) mx = v;
     };
     need(1, g.HD, g.B); need(g.HD, g.D2, g.B); need(g.D2, g.D2, g.B); need(g.D2, g.FIN, g.B); need(1, g.D2, g.B);
-    for (int b = 0; b < 2; ++b) { need(g.HD, g.D2, g.G[b] * g.Q); need(1, g.HD, g.G[b] * g.Q); }
-    need(g.D2, g.D2, g.M); need(1, g.D2, g.M); need(g.D2, g.CL, g.M);
+    for (int b = 0; b < 2; ++b) { need(g.HD, g.D2, g.G[b] * g.Q); need(g.HD, g.D2 + 1, g.G[b] * g.Q); need(1, g.HD, g.G[b] * g.Q); }
+    need(g.D2, g.D2, g.M); need(g.D2, g.D2 + 1, g.M); need(1, g.D2, g.M); need(g.D2, g.CL, g.M); need(g.D2, g.CL + 1, g.M);
     need((int)g.B, g.D2, g.FIN);                        // fc1 forward
     w->split = take(mx);
     w->total = o;
@@ -1802,8 +1802,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
                                (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
             fork();
-            FC_RC(sgemm_splitk(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, false, split, wst));
-            FC_RC(colsum(dz5, GQ, HD, gr + g.o_thb[b]));
+            // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum)
+            FC_RC(sgemm_splitk_colsum(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, gr + g.o_thb[b], one, split, wst));
             const bool bwd_fused = graph_mx && !bf && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
             if (!bwd_fused) FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
@@ -1843,8 +1843,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
                            (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
         for (int b = 0; b < 2; ++b) {
-            FC_RC(sgemm_splitk(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, false, split, wst));
-            FC_RC(colsum(P_(w.gM[b]), g.M, D2, gr + g.o_bmap[b]));
+            FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
             FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
         }
         // ---- positional encoding / dropout, Linear + BatchNorm ----
@@ -1854,8 +1853,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);
         fork();
-        FC_RC(sgemm_splitk(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, false, split, wst));
-        FC_RC(colsum(P_(w.dF), g.M, D2, gr + g.o_b3));
+        FC_RC(sgemm_splitk_colsum(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3, one, split, wst));
         FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st, bf));
         // ---- encoder convolutions ----
         hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),

@@ -860,11 +860,13 @@ static __global__ __launch_bounds__(256) void sgemm_reduce_slices_kernel(const f
 // coalesced loads, each thread keeps <= 4 outputs in registers, and one wavefront per output adds the per-workgroup
 // partials in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int kper) {
+// `ones` = 1: B gains a virtual last column of ones, i.e. output column N is the sum over k of A(m, k) -- the bias gradient that goes
+// with a weight gradient over the same rows, in the same launch (g.N already counts that column; it is not read from memory).
+static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int kper, int ones) {
     extern __shared__ float sk_lds[];                 // As[SKT_ROWS][M] | Bs[SKT_ROWS][N] | red[256] (few outputs only)
     float* As = sk_lds;
     float* Bs = sk_lds + SKT_ROWS * g.M;
-    const int O = g.M * g.N;
+    const int O = g.M * g.N, NB = g.N - ones;          // NB: the columns B really has
     // O >= 256: thread t owns outputs t, t + 256, ... (<= 4), every k-row.  O < 256: 256 / O thread slices share each output,
     // slice s taking rows s, s + S, ... of a tile; the slices are combined through LDS in a fixed order at the end.
     const int S = O >= 256 ? 1 : 256 / O;
@@ -884,8 +886,10 @@ static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int
         __syncthreads();
         for (int e = threadIdx.x; e < SKT_ROWS * g.M; e += 256)
             As[e] = e < nr * g.M ? g.A[(e % g.M) * g.sAm + (int64_t)(k0 + e / g.M) * g.sAk] : 0.f;
-        for (int e = threadIdx.x; e < SKT_ROWS * g.N; e += 256)
-            Bs[e] = e < nr * g.N ? g.B[(e % g.N) * g.sBn + (int64_t)(k0 + e / g.N) * g.sBk] : 0.f;
+        for (int e = threadIdx.x; e < SKT_ROWS * g.N; e += 256) {
+            const int col = e % g.N;
+            Bs[e] = e < nr * g.N ? (col < NB ? g.B[col * g.sBn + (int64_t)(k0 + e / g.N) * g.sBk] : 1.f) : 0.f;
+        }
         __syncthreads();
         if (!active) continue;
         if (O >= 256) {
@@ -924,8 +928,10 @@ static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int
     }
 }
 
+// (N counts the virtual ones column when colsum != nullptr: its sums go to colsum[m], not into C)
 static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                                        int64_t ldc, int M, int N, int nblk, int accumulate) {
+                                                                        int64_t ldc, int M, int N, int nblk, int accumulate,
+                                                                        float* __restrict__ colsum) {
     const int o = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (o >= M * N) return;
     float a = 0.f;
@@ -933,8 +939,13 @@ static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const fl
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
     if (lane == 0) {
-        float* c = C + (int64_t)(o / N) * ldc + (o % N);
-        *c = accumulate ? *c + a : a;
+        const int mi = o / N, nj = o % N;
+        if (colsum && nj == N - 1) {
+            colsum[mi] = a;
+        } else {
+            float* c = C + (int64_t)mi * ldc + nj;
+            *c = accumulate ? *c + a : a;
+        }
     }
 }
 
@@ -978,9 +989,9 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         nblk = (K + kper - 1) / kper;
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kper};
         (void)hipGetLastError();
-        hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float), st, g, kper);
+        hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float), st, g, kper, 0);
         hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, N, nblk,
-                           accumulate ? 1 : 0);
+                           accumulate ? 1 : 0, (float*)nullptr);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
     const int slices = sgemm_splitk_slices(M, N, K);
@@ -994,6 +1005,29 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
     hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, partial, C, ldc, M, N, used,
                        accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+// sgemm_splitk plus colsum[m] = sum_k A(m, k) from the same pass (a weight gradient and the bias gradient that goes with it): on the
+// long-k path the sums are one more output column against a virtual column of ones; elsewhere two calls (`ones`: K ones, stride 0).
+int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
+                        int M, int N, int K, float* colsum, const float* ones, float* partial, hipStream_t st) {
+    if (M <= 0 || N <= 0) return RULGNN_OK;
+    const int NE = N + 1;
+    if (!((int64_t)M * N <= 1024 && K <= 2048) && sgemm_longk_blocks(M, NE, K) > 0) {
+        int nblk = sgemm_longk_blocks(M, NE, K);
+        int kper = (K + nblk - 1) / nblk;
+        kper = (kper + SKT_ROWS - 1) / SKT_ROWS * SKT_ROWS;
+        nblk = (K + kper - 1) / kper;
+        GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, NE, M, NE, K, 0, kper};
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + NE) + 256) * sizeof(float), st, g, kper, 1);
+        hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * NE + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, NE, nblk, 0,
+                           colsum);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
+    const int rc = sgemm_splitk(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, false, partial, st);
+    if (rc != RULGNN_OK) return rc;
+    return sgemm_splitk(ones, 0, 0, A, sAm, sAk, colsum, M, 1, M, K, false, partial, st);
 }
 
 // out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 64 columns x 16 row slices per

@@ -23,6 +23,11 @@ int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn,
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                  int M, int N, int K, bool accumulate, float* partial, hipStream_t st);
 
+// ... and colsum[m] = sum_k A(m, k) from the same pass (weight gradient + the bias gradient over the same rows); `ones`: K ones for
+// the shapes that take two calls; `partial`: sgemm_splitk_need_floats(M, N + 1, K) floats
+int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
+                        int M, int N, int K, float* colsum, const float* ones, float* partial, hipStream_t st);
+
 // out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
 // dst[c] = sum_r src[r][c] of a short row-major matrix with ONE workgroup.  A thread walks rows * C / 1024 elements alone: beyond
