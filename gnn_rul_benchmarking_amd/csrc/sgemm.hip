@@ -1074,6 +1074,7 @@ static __global__ __launch_bounds__(1024) void cols_sum_small_kernel(const float
     }
 }
 int cols_sum_small(const float* src, int rows, int C, float* dst, hipStream_t st) {
+    if (C == 1) return block_sum(src, rows, dst, st);              // (one column: a tree, not one thread adding 1024 stripes)
     (void)hipGetLastError();
     hipLaunchKernelGGL(cols_sum_small_kernel, dim3(1), dim3(1024), 0, st, src, rows, C, dst);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
