@@ -326,15 +326,26 @@ def kernel_times(step_fn, steps=10):
     """Per-kernel device time of `steps` calls of step_fn, measured live through the HIP activity tracer (torch.profiler / roctracer;
     it records every kernel this process launches, the library's included): {kernel name: (launches per step, average us)}."""
     from torch.profiler import ProfilerActivity, profile
-    torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        for i in range(steps):
-            step_fn(i)
+
+    def once():
         torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(steps):
+                step_fn(i)
+            torch.cuda.synchronize()
+        out = {}
+        for e in prof.key_averages():
+            if e.device_time_total > 0 and e.count > 0:
+                out[e.key] = (e.count / steps, e.device_time_total / e.count)
+        return out
+
+    # the tracer now and then hands back a fraction of a short run's records (seen with two streams: 0.2 launches per step of a kernel
+    # that runs once per step): a capture in which a kernel's count is not a whole number of launches per step is taken again
     out = {}
-    for e in prof.key_averages():
-        if e.device_time_total > 0 and e.count > 0:
-            out[e.key] = (e.count / steps, e.device_time_total / e.count)
+    for _ in range(3):
+        out = once()
+        if out and all(abs(c - round(c)) < 1e-9 and c >= 1 for c, _ in out.values()):
+            break
     return out
 
 
