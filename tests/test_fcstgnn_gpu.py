@@ -195,3 +195,27 @@ def test_bf16_variant_error_is_bounded_and_does_not_meet_the_fp32_gate():
     with pytest.raises(RuntimeError):
         m.compute_dtype = "fp8"
         m(xt)
+
+
+@pytest.mark.parametrize("hidden,nodes,npatch,bs", [(16, 14, 5, 9), (8, 16, 4, 6), (8, 6, 6, 11), (4, 7, 5, 5), (32, 14, 4, 4), (16, 9, 3, 3)])
+def test_kernel_variants_beyond_the_reference_wirings_match_oracle(hidden, nodes, npatch, bs):
+    """The reference wires hidden_dim 8 / 24 with 14 or 20 sensors.  The matrix-core window kernels exist for feature widths 16 and 32 and
+    graphs of at most 32 nodes in multiples of four, the one-launch MLP for widths 16 / 32 / 64; every other shape takes the general
+    kernels: one case per instantiation and per fallback."""
+    cfg = O.Config(patch_size=2, num_patch=npatch, encoder_time_out=4, encoder_hidden_dim=8, encoder_out_dim=6, encoder_conv_kernel=2,
+                   hidden_dim=hidden, num_sequential=10, num_node=nodes, num_windows=(npatch - 1) + ((npatch - 2) // 2 + 1))
+    rng = np.random.default_rng(hidden * 100 + nodes)
+    p = O.random_params(cfg, seed=hidden + nodes)
+    x = rng.uniform(0, 1, (bs, cfg.num_node, cfg.num_patch * cfg.patch_size))
+    y = rng.uniform(0, 1, bs)
+    m = build_model(cfg, p, dropout=0.0).train()
+    loss, grads, fw = O.loss_and_grads(p, x, y, cfg)
+    pred, l = m.fused_mse_step(torch.from_numpy(x.astype(np.float32)).to(DEV), torch.from_numpy(y.astype(np.float32)).to(DEV))
+    assert rel(pred.cpu().numpy().reshape(-1, 1), fw.pred) < TOL
+    assert abs(float(l) - loss) < TOL * abs(loss)
+    check_grads(grads_of(m), grads, cfg)
+    m.eval()
+    with torch.no_grad():
+        after = {**p, **O.bn_running_update(p, fw)}
+        ev = O.forward(after, x, cfg, train=False).pred
+        assert rel(m(torch.from_numpy(x.astype(np.float32)).to(DEV)).cpu().numpy(), ev) < TOL
