@@ -106,7 +106,7 @@ class StnetShape(C.Structure):
 class StnetArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("dpred", C.c_void_p), ("params", C.c_void_p), ("grads", C.c_void_p),
                 ("pred", C.c_void_p), ("recon", C.c_void_p), ("loss", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64)]
+                ("workspace_bytes", C.c_size_t), ("global_batch", C.c_int64), ("recon_weight", C.c_void_p)]
 
 
 class SagcnShape(C.Structure):

@@ -217,6 +217,14 @@ __global__ void sn_relu_bwd_kernel(float* __restrict__ d, const float* __restric
         d[i] = h[i] > 0.f ? d[i] : 0.f;
 }
 
+// a *= w[0], b *= w[0]: the reconstruction term's gradients under a weight other than 1 (autograd path)
+__global__ void sn_scale2_kernel(float* __restrict__ a, float* __restrict__ b, int64_t n, const float* __restrict__ w) {
+    const float s = w[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        a[i] *= s;
+        b[i] *= s;
+    }
+}
 __global__ void sn_add_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) a[i] += b[i];
 }
@@ -399,6 +407,9 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
         la.dw_ih[1] = la.dw_ih[0]; la.dw_hh[1] = la.dw_hh[0]; la.db_ih[1] = la.db_ih[0]; la.db_hh[1] = la.db_hh[0];
         SN_RC(bilstm_backward(&ls, &la, st, 1));
         // decoder, from d Yp = w_dD1 (the reconstruction scale of a data-parallel shard is the global one: recon is in the loss with weight 1)
+        if (a->recon_weight)
+            hipLaunchKernelGGL(sn_scale2_kernel, dim3(sn_grid((int64_t)BT * D)), dim3(SB), 0, st, ws + g.w_dD1, ws + g.w_dD2, (int64_t)BT * D,
+                               a->recon_weight);
         float* d = ws + g.w_dD1;
         float* dA[2] = {ws + g.w_dA1, ws + g.w_dA2};
         for (int i = 3; i >= 0; --i) {

@@ -39,16 +39,20 @@ class _Function(torch.autograd.Function):
         pred, recon = model._forward(x)
         ctx.model, ctx.x = model, x
         ctx.tape = model._tape.tokens[x.size(0)]
+        ctx.set_materialize_grads(False)
         return pred.clone().view(-1, 1), recon.clone()
 
     @staticmethod
     def backward(ctx, dpred, drecon):
+        # The reconstruction term enters with whatever weight the objective gave it (the reference: 1, algorithms.py:458; a loss on the
+        # prediction alone: none) -- handed to the kernels as a device scalar, no host round trip.  A backward of the forward's own
+        # workspace: run once per forward (the reconstruction gradients are scaled in place).
         model = ctx.model
         model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "STNet_model")
-        if drecon is None or abs(float(drecon) - 1.0) > 1e-6:
-            raise RuntimeError("STNet_model: the reconstruction loss must enter the objective with weight 1 (algorithms.py:458); "
-                               f"got d loss / d reconstruction = {None if drecon is None else float(drecon)}")
-        grads = model._backward(ctx.x, dpred.reshape(-1).contiguous().float())
+        B = ctx.x.size(0)
+        dp = dpred.reshape(-1).contiguous().float() if dpred is not None else torch.zeros(B, dtype=torch.float32, device=ctx.x.device)
+        w = drecon.reshape(1).contiguous().float() if drecon is not None else torch.zeros(1, dtype=torch.float32, device=ctx.x.device)
+        grads = model._backward(ctx.x, dp, recon_weight=w)
         outs = [grads[off:off + n].view(shape).clone() if i >= 2 else None for i, (off, n, shape) in enumerate(model._slices)]
         return (None, None, *outs)
 
@@ -129,9 +133,10 @@ class STNet_model(FlatModule):
         _lib.check(_lib.load().rulgnn_stnet_forward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stnet_forward_f32")
         return pred[:x.size(0)], self._grad_flat[self._count + 1]
 
-    def _backward(self, x, dpred):
+    def _backward(self, x, dpred, recon_weight=None):
         shp = self._shape(x.size(0))
         a, _ = self._args(shp, x, dpred=dpred)
+        a.recon_weight = recon_weight.data_ptr() if recon_weight is not None else None
         _lib.check(_lib.load().rulgnn_stnet_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_stnet_backward_f32")
         return self._grad_flat
 

@@ -541,8 +541,8 @@ typedef struct rulgnn_stnet_shape {
 typedef struct rulgnn_stnet_args {
     const float *x;           /* [batch, num_patch * patch_size] */
     const float *y;           /* [batch] targets, or NULL */
-    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y.  The reconstruction term always
-                               * enters the backward with weight 1 (it is part of the reference's loss) */
+    const float *dpred;       /* [batch] d loss / d pred (autograd backward); NULL = MSE against y.  The reconstruction term enters the
+                               * backward with weight 1 (it is part of the reference's loss) unless recon_weight says otherwise */
     const float *params;
     float *grads;
     float *pred;              /* [batch] */
@@ -551,6 +551,8 @@ typedef struct rulgnn_stnet_args {
     void *workspace;
     size_t workspace_bytes;
     int64_t global_batch;
+    const float *recon_weight; /* backward only: [1] device scalar d loss / d reconstruction (autograd: the reconstruction term may enter the
+                               * objective with any weight, 0 when it is not used); NULL = 1, the reference's loss (algorithms.py:458) */
 } rulgnn_stnet_args;
 
 int64_t rulgnn_stnet_param_count(const rulgnn_stnet_shape *shape);         /* < 0: invalid / unsupported */

@@ -101,9 +101,22 @@ def test_autograd_path_equals_fused_path_and_the_thresholded_convolution_stays_u
     assert table["cnn.weight"].grad is None and table["cnn.bias"].grad is None
     auto = torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in m2._named()])
     assert torch.equal(auto, fused)
-    with pytest.raises(RuntimeError, match="weight 1"):
-        pr, rc = m2(x, train=True)
-        (pr.sum() + 0.5 * rc).backward()
+
+    # the reconstruction term under any weight, or unused (the gradient is linear in that weight; w = 1 is the fused path above)
+    def grads(weight):
+        mm = build_model(cfg, p).train()
+        pr, rc = mm(x, train=True)
+        loss = torch.nn.functional.mse_loss(pr, y)
+        (loss if weight is None else loss + weight * rc).backward()
+        return torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in mm._named()])
+    g0, g1, gh = grads(None), grads(1.0), grads(0.5)
+    assert torch.equal(g1, fused)
+    assert torch.equal(g0, grads(0.0))
+    scale = float(g1.abs().max())
+    assert float((gh - 0.5 * (g0 + g1)).abs().max()) < 1e-5 * scale
+    assert float((g1 - g0).abs().max()) > 1e-3 * scale              # the term does contribute
+    enc = m._layout["encoder.0.weight"][0]
+    assert float(g0[enc:enc + 8].abs().max()) > 0                    # ... and the encoder still learns from the prediction alone
     algo = get_algorithm_class("STNet")(cfg, {"learning_rate": 1e-2, "weight_decay": 1e-2}, DEV)
     algo.to(DEV).train()
     before = {k: v.clone() for k, v in algo.model.state_dict().items()}
