@@ -338,6 +338,55 @@ __global__ __launch_bounds__(FB) void fc_act2_kernel(FcGeom g, const float* __re
     }
 }
 
+// a2 = relu(bn_b(z2)), z3 = a2 W3^T + b3 and the BatchNorm-c statistics of z3 in ONE launch (row-group mapping, see fc_conv2_kernel):
+// the activation kernel, the [M x CL] x [CL x D2] projection and the bias / statistics kernel were three launches of 8 + 12 + 6 us
+// around a product of 24 MACs per output.  W3 sits in LDS with an odd row stride (lanes differ in the output: no bank conflicts).
+__global__ __launch_bounds__(FB) void fc_proj3_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running, Cells* cells,
+                                                     int training, const float* __restrict__ z2, float* __restrict__ a2,
+                                                     float* __restrict__ z3) {
+    extern __shared__ float proj_lds[];                                // W3s[D2][CL + 1] | tile[2][FB]
+    __shared__ double sl[BS_DOUBLES];
+    __shared__ BnCoef cb[MAXC];
+    const int CL = g.CL, D2 = g.D2, L2 = g.L2, WS = CL + 1;
+    float* w3 = proj_lds;
+    float* tile = proj_lds + D2 * WS;
+    if (threadIdx.x < g.CO) cb[threadIdx.x] = fbn(g, cells, prm, running, training, 1, threadIdx.x);
+    for (int e = threadIdx.x; e < D2 * CL; e += FB) w3[(e / CL) * WS + e % CL] = prm[g.o_W3 + e];
+    BlockStats st;
+    st.init(sl, D2);                                                   // (ends in a barrier)
+    const RowGroup rg(CL > D2 ? CL : D2);
+    const int co = rg.pos < CL ? rg.pos / L2 : 0;
+    const float bias = rg.pos < D2 ? prm[g.o_b3 + rg.pos] : 0.f;
+    const float* wr = w3 + (rg.pos < D2 ? rg.pos : 0) * WS;
+    const int64_t stride = (int64_t)gridDim.x * rg.rows_per;
+    auto fetch = [&](int64_t m0) {
+        const int64_t m = m0 + rg.sub;
+        return (rg.on && m < g.M && rg.pos < CL) ? z2[m * CL + rg.pos] : 0.f;
+    };
+    float nxt = fetch((int64_t)blockIdx.x * rg.rows_per);
+    int buf = 0;
+    for (int64_t m0 = (int64_t)blockIdx.x * rg.rows_per; m0 < g.M; m0 += stride, buf ^= 1) {
+        const int64_t m = m0 + rg.sub;
+        const bool row_on = rg.on && m < g.M;
+        const float cur = nxt;
+        nxt = fetch(m0 + stride);
+        if (row_on && rg.pos < CL) {
+            const float a = fmaxf(fmaf(cur, cb[co].sc, cb[co].sh), 0.f);
+            a2[m * CL + rg.pos] = a;
+            tile[buf * FB + rg.sub * rg.tile + rg.pos] = a;
+        }
+        lds_barrier();
+        if (row_on && rg.pos < D2) {
+            const float* ar = tile + buf * FB + rg.sub * rg.tile;
+            float v = bias;
+            for (int c = 0; c < CL; ++c) v = fmaf(ar[c], wr[c], v);
+            z3[m * D2 + rg.pos] = v;
+            if (training) st.add(rg.pos, v, v * v);
+        }
+    }
+    if (training) st.flush(cells[blockIdx.x % CELL_REP].fwd[2], D2);
+}
+
 // z[r][c] += bias[c] in place; per-column (sum, sumsq) into cells->fwd[id]
 __global__ __launch_bounds__(FB) void fc_bias_stats_kernel(float* __restrict__ z, const float* __restrict__ bias, int64_t rows, int C,
                                                           Cells* cells, int id, int training) {
@@ -1251,6 +1300,52 @@ __global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __
     st.flush(cells[blockIdx.x % CELL_REP].bwd[2], g.D2);
 }
 
+// d a2 = d z3 W3 and the activation's backward with the BatchNorm-b sums in one launch (the counterpart of fc_proj3_kernel):
+// dy2 = d a2 [a2 > 0], sums of dy2 and dy2 * xhat(z2) per channel
+__global__ __launch_bounds__(FB) void fc_proj3_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells, const float* __restrict__ z2,
+                                                         const float* __restrict__ a2, const float* __restrict__ dz3,
+                                                         float* __restrict__ da2) {
+    extern __shared__ float proj_lds[];                                // W3s[D2][CL + 1] | tile[2][FB]
+    __shared__ double sl[BS_DOUBLES];
+    __shared__ BnCoef cb[MAXC];
+    const int CL = g.CL, D2 = g.D2, L2 = g.L2, WS = CL + 1;
+    float* w3 = proj_lds;
+    float* tile = proj_lds + D2 * WS;
+    if (threadIdx.x < g.CO) cb[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 1, threadIdx.x);
+    for (int e = threadIdx.x; e < D2 * CL; e += FB) w3[(e / CL) * WS + e % CL] = prm[g.o_W3 + e];
+    BlockStats st;
+    st.init(sl, g.CO);
+    const RowGroup rg(CL > D2 ? CL : D2);
+    const int co = rg.pos < CL ? rg.pos / L2 : 0;
+    const float* wc = w3 + (rg.pos < CL ? rg.pos : 0);                 // column rg.pos of W3: lanes consecutive
+    const int64_t stride = (int64_t)gridDim.x * rg.rows_per;
+    auto fetch_d = [&](int64_t m0) {
+        const int64_t m = m0 + rg.sub;
+        return (rg.on && m < g.M && rg.pos < D2) ? dz3[m * D2 + rg.pos] : 0.f;
+    };
+    float nd = fetch_d((int64_t)blockIdx.x * rg.rows_per);
+    int buf = 0;
+    for (int64_t m0 = (int64_t)blockIdx.x * rg.rows_per; m0 < g.M; m0 += stride, buf ^= 1) {
+        const int64_t m = m0 + rg.sub;
+        const bool row_on = rg.on && m < g.M;
+        const float dcur = nd;
+        nd = fetch_d(m0 + stride);
+        float av = 0.f, zv = 0.f;
+        if (row_on && rg.pos < CL) { av = a2[m * CL + rg.pos]; zv = z2[m * CL + rg.pos]; }
+        if (row_on && rg.pos < D2) tile[buf * FB + rg.sub * rg.tile + rg.pos] = dcur;
+        lds_barrier();
+        if (row_on && rg.pos < CL) {
+            const float* dr = tile + buf * FB + rg.sub * rg.tile;
+            float d = 0.f;
+            for (int o = 0; o < D2; ++o) d = fmaf(dr[o], wc[o * WS], d);
+            const float dy = av > 0.f ? d : 0.f;
+            da2[m * CL + rg.pos] = dy;
+            st.add(co, dy, dy * (zv - cb[co].mean) * cb[co].inv);
+        }
+    }
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[1], g.CO);
+}
+
 // dy2 = da2 * [a2 > 0] (in place); BatchNorm-b backward sums
 __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z2, const float* __restrict__ a2,
@@ -1638,6 +1733,9 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     // the MLP behind fc1 in one launch (fc_mlp_tail_kernel) for the fp32 path at the widths it is instantiated for
     // the window graphs one wavefront each on the fp32 matrix cores where a graph fits the 32 x 32 tile
     const bool graph_mx = g.Q <= 32 && g.Q % 4 == 0 && (g.D2 == 16 || g.D2 == 32);
+    // activation + projection + statistics of the encoder's last Linear in one launch (fc_proj3_kernel) where a row's tile fits a workgroup
+    const size_t proj_lds = sizeof(float) * ((size_t)g.D2 * (g.CL + 1) + 2 * FB);
+    const bool proj_fused = !bf && g.CL <= FB && g.D2 <= FB && proj_lds <= 40 * 1024;
     const bool mlp_fused = !bf && g.D2 == 2 * g.HD && (g.D2 == 16 || g.D2 == 32 || g.D2 == 64);
     auto mlp_tail = [&](int tail_mode, const float* y, const float* dpred_in) {
         auto go = [&](auto kernel) {
@@ -1677,10 +1775,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         hipLaunchKernelGGL(fc_conv2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2), cells,
                            training);
         FC_RC(sync_pair(0, 1));
-        hipLaunchKernelGGL(fc_act2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
-                           (const float*)P_(w.z2), P_(w.a2));
-        FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st, bf));
-        hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, P_(w.z3), prm + g.o_b3, g.M, D2, cells, 2, training);
+        if (proj_fused) {
+            hipLaunchKernelGGL(fc_proj3_kernel, dim3(grid_for(g.M * CL)), dim3(FB), proj_lds, st, g, prm, run, cells, training,
+                               (const float*)P_(w.z2), P_(w.a2), P_(w.z3));
+        } else {
+            hipLaunchKernelGGL(fc_act2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
+                               (const float*)P_(w.z2), P_(w.a2));
+            FC_RC(sgemm(P_(w.a2), CL, 1, prm + g.o_W3, CL, 1, P_(w.z3), D2, Mi, D2, CL, false, st, bf));
+            hipLaunchKernelGGL(fc_bias_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, P_(w.z3), prm + g.o_b3, g.M, D2, cells, 2, training);
+        }
         FC_RC(sync_pair(0, 2));
         hipLaunchKernelGGL(fc_pe_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, run, cells, training, (const float*)P_(w.z3),
                            P_(w.F), thr, dscale, key, key_dev, row_off);
@@ -1854,10 +1957,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.z3), P_(w.dF), g.M);
         fork();
         FC_RC(sgemm_splitk_colsum(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3, one, split, wst));
-        FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st, bf));
         // ---- encoder convolutions ----
-        hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
-                           (const float*)P_(w.a2), P_(w.da2));
+        if (proj_fused) {
+            hipLaunchKernelGGL(fc_proj3_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), proj_lds, st, g, prm, cells, (const float*)P_(w.z2),
+                               (const float*)P_(w.a2), (const float*)P_(w.dF), P_(w.da2));
+        } else {
+            FC_RC(sgemm(P_(w.dF), D2, 1, prm + g.o_W3, 1, CL, P_(w.da2), CL, Mi, CL, D2, false, st, bf));
+            hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
+                               (const float*)P_(w.a2), P_(w.da2));
+        }
         FC_RC(sync_pair(1, 1));
         hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, 1, g.L2, prm, (const Cells*)cells,
                            (const float*)P_(w.z2), P_(w.da2), g.M * CL);
