@@ -1300,6 +1300,71 @@ __global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __
     st.flush(cells[blockIdx.x % CELL_REP].bwd[2], g.D2);
 }
 
+// The window BatchNorms' backward, both blocks' d M W_map products and the positional-encoding / dropout backward with the BatchNorm-c
+// sums in ONE launch (row-group mapping: D2 lanes per row): d F = bn'(gX_0) + bn'(gX_1) + gM_0 W_map0 + gM_1 W_map1, then the dropout
+// mask and the sums of dy and dy * xhat(z3).  Four launches of 17 + 16 + 18 + 9 us before.
+__global__ __launch_bounds__(FB) void fc_feat_pe_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells, const float* __restrict__ F,
+                                                           const float* __restrict__ gX0, const float* __restrict__ gX1,
+                                                           const float* __restrict__ gM0, const float* __restrict__ gM1,
+                                                           const float* __restrict__ z3, float* __restrict__ dF, uint32_t drop_thr,
+                                                           float drop_scale, uint32_t drop_key, const uint32_t* key_dev, int64_t row_offset) {
+    __shared__ double sl[BS_DOUBLES];
+    __shared__ BnCoef c0[MAXD], c1[MAXD], cc[MAXD];
+    __shared__ float m0[MAXD][2], m1[MAXD][2];
+    __shared__ float wl[2][MAXD * MAXD];
+    __shared__ float tile[2][2][FB];
+    const int D2 = g.D2;
+    if ((int)threadIdx.x < D2) {
+        const int d = threadIdx.x;
+        c0[d] = fbn(g, cells, prm, nullptr, 1, 3, d);
+        c1[d] = fbn(g, cells, prm, nullptr, 1, 5, d);
+        cc[d] = fbn(g, cells, prm, nullptr, 1, 2, d);
+        m0[d][0] = (float)(cell_bwd(cells, 3, d, 0) / g.cnt[3]); m0[d][1] = (float)(cell_bwd(cells, 3, d, 1) / g.cnt[3]);
+        m1[d][0] = (float)(cell_bwd(cells, 5, d, 0) / g.cnt[5]); m1[d][1] = (float)(cell_bwd(cells, 5, d, 1) / g.cnt[5]);
+    }
+    for (int e = threadIdx.x; e < D2 * D2; e += FB) { wl[0][e] = prm[g.o_map[0] + e]; wl[1][e] = prm[g.o_map[1] + e]; }
+    BlockStats st;
+    st.init(sl, D2);
+    const uint32_t key = key_dev ? *key_dev : drop_key;
+    const RowGroup rg(D2);
+    const int d = rg.pos;
+    const int64_t stride = (int64_t)gridDim.x * rg.rows_per;
+    int buf = 0;
+    for (int64_t mb = (int64_t)blockIdx.x * rg.rows_per; mb < g.M; mb += stride, buf ^= 1) {
+        const int64_t m = mb + rg.sub;
+        const bool row_on = rg.on && m < g.M;
+        const int64_t e = m * D2 + d;
+        float f = 0.f, a0 = 0.f, a1 = 0.f, zz = 0.f;
+        if (row_on) {
+            tile[buf][0][rg.sub * D2 + d] = gM0[e];
+            tile[buf][1][rg.sub * D2 + d] = gM1[e];
+            f = F[e]; a0 = gX0[e]; a1 = gX1[e]; zz = z3[e];
+        }
+        lds_barrier();
+        if (row_on) {
+            const int t = (int)((m / g.N) % g.NP);
+            const float k0 = mult(g, 0, t), k1 = mult(g, 1, t);
+            const float x0 = (f - c0[d].mean) * c0[d].inv, x1 = (f - c1[d].mean) * c1[d].inv;
+            float v = c0[d].sc * (a0 - k0 * (m0[d][0] + x0 * m0[d][1])) + c1[d].sc * (a1 - k1 * (m1[d][0] + x1 * m1[d][1]));
+            const float* r0 = &tile[buf][0][rg.sub * D2];
+            const float* r1 = &tile[buf][1][rg.sub * D2];
+            float p0 = 0.f, p1 = 0.f;
+            for (int o = 0; o < D2; ++o) {
+                p0 = fmaf(r0[o], wl[0][o * D2 + d], p0);
+                p1 = fmaf(r1[o], wl[1][o * D2 + d], p1);
+            }
+            v = (v + p0) + p1;                                         // (the order of the unfused path: block 0's product, then block 1's)
+            if (drop_thr) {
+                const uint32_t ctr = (uint32_t)((m + row_offset) * D2 + d);
+                v = lowbias32(ctr ^ key) >= drop_thr ? v * drop_scale : 0.f;
+            }
+            dF[e] = v;
+            st.add(d, v, v * (zz - cc[d].mean) * cc[d].inv);
+        }
+    }
+    st.flush(cells[blockIdx.x % CELL_REP].bwd[2], D2);
+}
+
 // d a2 = d z3 W3 and the activation's backward with the BatchNorm-b sums in one launch (the counterpart of fc_proj3_kernel):
 // dy2 = d a2 [a2 > 0], sums of dy2 and dy2 * xhat(z2) per channel
 __global__ __launch_bounds__(FB) void fc_proj3_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells, const float* __restrict__ z2,
@@ -1943,15 +2008,21 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
         FC_RC(sync_pair(1, 3));
         FC_RC(sync_pair(1, 5));
-        hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
-                           (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 2; ++b)
             FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
-            FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
+        if (!bf) {
+            // window BatchNorms' backward + both d M W_map products + positional encoding / dropout backward: one launch
+            hipLaunchKernelGGL(fc_feat_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
+                               (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), (const float*)P_(w.gM[0]), (const float*)P_(w.gM[1]),
+                               (const float*)P_(w.z3), P_(w.dF), thr, dscale, key, key_dev, row_off);
+        } else {
+            hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
+                               (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
+            for (int b = 0; b < 2; ++b) FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
+            // ---- positional encoding / dropout, Linear + BatchNorm ----
+            hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
+                               dscale, key, key_dev, row_off);
         }
-        // ---- positional encoding / dropout, Linear + BatchNorm ----
-        hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
-                           dscale, key, key_dev, row_off);
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);

@@ -861,6 +861,354 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
     }
 }
 
+// =====================================================================================================================
+// The same arithmetic for 16 <= num_patch <= 47 -- PHM2012's 40 patches of 64 points is the reference's own ST_GCN wiring
+// (configs/hparams.py:238); the row-mapped kernel runs it at 0.05 of the HBM roofline.  ONE sample per wavefront iteration, its patch
+// axis in NT = 2 | 3 column tiles of 16: a [10, N] tensor is NT x 3 registers, the tiles of a sample are the independent MFMA chains
+// that the four samples are in the narrow kernel.  What changes against it:
+//  * theta is N x N: the projection contracts over NT k-tiles into NT column tiles (2 NT^2 products per layer); its 2 NT^2 operands
+//    per layer (the distinct halves only: 8 bytes per lane) live in LDS, shared by the EIGHT wavefronts of a workgroup (one
+//    workgroup per CU: 18 KB of operands + 8 x 13.6 KB at 40 x 64);
+//  * the causal taps cross tile boundaries: the shift tile is indexed [row group][column 0 .. 16 NT);
+//  * the patch (64 points = 256 bytes) is read from the linearly copied window in a per-lane ROTATED chunk order -- lane p reads its
+//    16-byte chunks (k + p) mod 16, k = 0..15: every statistic is a symmetric function of the patch, and a 256-byte lane stride
+//    would put all lanes on the same four banks;
+//  * Pearson on v_mfma_f32_16x16x4_f32 (one sample: A = B = the normalised series, lane (g, slot) holding patches 4 NT g .. + 4 NT),
+//    whose result IS the adjacency's D layout; the statistics reach the D layout from the same LDS tile (one write, two reads);
+//  * head: the pooled patch vector goes through LDS (broadcast reads) against fc1 rows in registers;
+//  * non-finite predictions (f16 range, NaN statistics) are recomputed by a second, scanning launch of the exact kernel
+//    (stgcn_forward.hip: stgcn_forward_fixup) instead of inside this one.
+constexpr int MXW_WAVES = 8;
+template <int NT> struct MxwGeom {
+    static constexpr int W = 16 * NT, PT = W + 4, TG = 4 * NT;
+    static constexpr int conv_bytes = 16 * PT * 4 + 256;                   // [16 slots][PT] + 64 floats of head scratch
+    static constexpr int shift_bytes = 2 * (4 * W + 1) * 8;                // hi plane and lo plane: [4 row groups][W] + the zero slot
+    static constexpr int region_bytes = ((conv_bytes > shift_bytes ? conv_bytes : shift_bytes) + 15) & ~15;
+    static constexpr int theta_bytes(int L) { return L * NT * NT * 2 * 64 * 8; }
+};
+
+template <int LFIX, int NT, int NFIX, int PFIX>
+__global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+                                                                             const float* __restrict__ bn, float* __restrict__ out, MxArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef MxwGeom<NT> G;
+    constexpr int L = LFIX, W = G::W, PT = G::PT, TG = G::TG;
+    const int N = NFIX ? NFIX : a.N, P = PFIX ? PFIX : a.P;
+    const int LS = layer_stride(N);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    const int NP = N * P;
+    u32x2* const theta_lds = reinterpret_cast<u32x2*>(smem);
+    float* const win = smem + G::theta_bytes(L) / 4 + wave * (a.buf_floats + G::region_bytes / 4);
+    float* const cur = win + a.buf_floats;
+    const int64_t stride = (int64_t)gridDim.x * MXW_WAVES;
+    int64_t smp = (int64_t)blockIdx.x * MXW_WAVES + wave;
+
+    if (smp < a.B) dma_tile(gx + smp * NP, win, NP * 4, lane);          // first window on its way before the weights are touched
+
+    // ---- prologue ------------------------------------------------------------------------------------------------------
+    // theta^T as B operands, tile (ct, jt): column j = 16 jt + col, k-slot 4 g + r <-> patch 16 ct + 4 g + r; k-slot 15 of the last
+    // k-tile carries the bias (its A side is the constant 1: num_patch <= 16 NT - 1)
+    for (int idx = wave; idx < L * NT * NT; idx += MXW_WAVES) {
+        const int l = idx / (NT * NT), ct = (idx / NT) % NT, jt = idx % NT;
+        const float* lp = prm + l * LS;
+        const int j = 16 * jt + col;
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 16 * ct + 4 * g + r;
+            const bool bias = ct == NT - 1 && 4 * g + r == 15;
+            const bool ok = j < N && (k < N || bias);
+            const float v = lp[ok ? (bias ? off_theta_b(N) + j : off_theta_w(N) + j * N + k) : 0];
+            w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
+        }
+        const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
+        theta_lds[(idx * 2 + 0) * 64 + lane] = u32x2{p01.hi, p23.hi};
+        theta_lds[(idx * 2 + 1) * 64 + lane] = u32x2{p01.lo, p23.lo};
+    }
+    u32x4 w_hi[L][2], w_lo[L][2];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float* lp = prm + l * LS;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {                              // see the narrow kernel: BatchNorm and the ReLU form's 2^k folded in
+            const int co = slot_chan(col), coc = co >= 0 ? co : 0;
+            const float mean = bn[((l * 2 + blk) * 2 + 0) * F + coc], var = bn[((l * 2 + blk) * 2 + 1) * F + coc];
+            const float gam = lp[off_bn_g(N, blk) + coc], bet = lp[off_bn_b(N, blk) + coc];
+            const float sc = gam / sqrtf(var + BN_EPS);
+            const float shift = bet - mean * sc;
+            const float wsc = (blk == 0 ? 1.f : 0.25f) * sc;
+            float wc[4], wd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = slot_chan(4 * g + r);
+                const bool ok = co >= 0 && ci >= 0;
+                const float2 taps2 = *reinterpret_cast<const float2*>(lp + off_conv_w(N, blk) + (coc * F + (ci >= 0 ? ci : 0)) * 2);
+                wc[r] = ok ? taps2.y * wsc : 0.f;
+                wd[r] = ok ? taps2.x * wsc : 0.f;
+            }
+            if (g == 0) wc[3] = co >= 0 ? shift : 0.f;
+            const Split2 c01 = split2(wc[0], wc[1]), c23 = split2(wc[2], wc[3]), d01 = split2(wd[0], wd[1]), d23 = split2(wd[2], wd[3]);
+            w_hi[l][blk] = u32x4{c01.hi, c23.hi, d01.hi, d23.hi};
+            w_lo[l][blk] = u32x4{c01.lo, c23.lo, d01.lo, d23.lo};
+        }
+    }
+    // head, row mapping: lane j holds row j of fc1
+    float fc1w[W];
+    const int jc = lane < N ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const float v = prm[off_fc1_w(N, L) + jc * N + (k < N ? k : 0)];
+        fc1w[k] = (lane < N && k < N) ? v : 0.f;
+    }
+    const float fc1b_raw = prm[off_fc1_b(N, L) + jc], fc2w_raw = prm[off_fc2_w(N, L) + jc];
+    const float fc1b = lane < N ? fc1b_raw : 0.f;
+    const float fc2w_half = lane < N ? 0.5f * fc2w_raw : 0.f;
+    const float fc2b = prm[off_fc2_b(N, L)];
+    const unsigned t_bias = g == 3 ? 0x3C00u << 16 : 0u;
+    float half_ok[NT], quarter_ok[NT];
+    int sh_wr[NT], sh_rd1[NT], sh_rd2[NT];
+    constexpr int SH_ZERO = 4 * W, SH_LO = 4 * W + 1;                    // index of the zero slot; offset of the lo plane
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+        const int t = 16 * jt + col;
+        half_ok[jt] = t < N ? 0.5f : 0.f;
+        quarter_ok[jt] = t < N ? 0.25f : 0.f;
+        sh_wr[jt] = g * W + t;
+        sh_rd1[jt] = t >= 1 ? g * W + t - 1 : SH_ZERO;
+        sh_rd2[jt] = t >= 2 ? g * W + t - 2 : SH_ZERO;
+    }
+    // rows 13, 14 of the conversion tile are the padding rows lane group 3 reads as its registers 1, 2: zero, once
+    for (int e = lane; e < 2 * PT; e += 64) cur[13 * PT + e] = 0.f;
+    __syncthreads();
+
+    bool pend_mine = false;
+    int64_t pend_idx = 0;
+    float pend_pred = 0.f;
+    for (; smp < a.B; smp += stride) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (pend_mine) out[pend_idx] = pend_pred;
+
+        // ---- patch statistics, row mapping: lane = patch ---------------------------------------------------------------
+        float X0[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) X0[c] = 0.f;
+        auto request_next = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t nx = smp + stride;
+            if (nx < a.B) {
+                if constexpr (NFIX != 0 && PFIX != 0) dma_tile_fixed<4 * NFIX * PFIX>(gx + nx * NP, win, lane);
+                else dma_tile(gx + nx * NP, win, NP * 4, lane);
+            }
+        };
+        if constexpr (PFIX == 64) {
+            float v[64];
+            const float4* p4 = reinterpret_cast<const float4*>(win + jc * 64);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 q = p4[(k + lane) & 15];
+                v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+            }
+            request_next();
+            if (lane < N) patch_statistics_lean<64>(v, X0);
+        } else {
+            if (lane < N) patch_statistics(win + lane * P, P, X0);
+            request_next();
+        }
+
+        // ---- Pearson adjacency (Model.py:53-71) and the statistics in the D layout --------------------------------------
+        __builtin_amdgcn_wave_barrier();
+        if (lane < W) {
+#pragma unroll
+            for (int c = 0; c < F; ++c) cur[chan_slot(c) * PT + lane] = X0[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 gram = {0.f, 0.f, 0.f, 0.f};
+        {
+            const bool slot_ok = slot_chan(col) >= 0;
+            const float4* r4 = reinterpret_cast<const float4*>(cur + (slot_ok ? col : 0) * PT + TG * g);
+            float CT[TG];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const float4 v = r4[q];
+                CT[4 * q] = v.x; CT[4 * q + 1] = v.y; CT[4 * q + 2] = v.z; CT[4 * q + 3] = v.w;
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < TG; ++k) sum += CT[k];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.0f / (float)N);
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < TG; ++k) {
+                CT[k] = (TG * g + k < N) ? CT[k] - mean : 0.f;
+                ss = fmaf(CT[k], CT[k], ss);
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rn = slot_ok ? __builtin_amdgcn_rsqf(ss) : 0.f;
+#pragma unroll
+            for (int k = 0; k < TG; ++k) {
+                const float y = CT[k] * rn;
+                gram = __builtin_amdgcn_mfma_f32_16x16x4f32(y, y, gram, 0, 0, 0);
+            }
+        }
+        u32x4 adjB;
+        {
+            const Split2 p01 = split2(gram[0], gram[1]), p23 = split2(gram[2], gram[3]);
+            adjB = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
+        }
+        float X[NT][3];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) X[ct][r] = cur[(4 * g + r) * PT + 16 * ct + col];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        u32x2* const sh_tile = reinterpret_cast<u32x2*>(cur);             // the shift tile reuses the conversion tile's bytes
+        if (lane < 2) sh_tile[SH_ZERO + SH_LO * lane] = u32x2{0u, 0u};
+
+        // ---- the layers -----------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            f32x4 T[NT], Hp[NT], z[NT];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const Split2 p01 = split2(X[ct][0], X[ct][1]), p2 = split2(X[ct][2], 0.f);
+                const u32x4 ah = {p01.hi, p2.hi, p01.hi, p2.hi}, al = {p01.lo, p2.lo, p01.lo, p2.lo};
+                T[ct] = mfma16(ah, adjB, zero);
+                T[ct] = mfma16(al, adjB, T[ct]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 ta[NT];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const Split2 p01 = split2(T[ct][0], T[ct][1]), p23 = split2(T[ct][2], T[ct][3]);
+                ta[ct] = u32x4{p01.hi, ct == NT - 1 ? p23.hi | t_bias : p23.hi, p01.lo, p23.lo};
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) Hp[jt] = zero;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) {
+                    const int idx = (l * NT + ct) * NT + jt;
+                    const u32x2 th = theta_lds[(idx * 2 + 0) * 64 + lane], tl = theta_lds[(idx * 2 + 1) * 64 + lane];
+                    Hp[jt] = mfma16(ta[ct], u32x4{th.x, th.y, th.x, th.y}, Hp[jt]);
+                    Hp[jt] = mfma16(ta[ct], u32x4{tl.x, tl.y, tl.x, tl.y}, Hp[jt]);
+                }
+            }
+            float H[NT][3], V[NT][3];
+            u32x2 ch[NT], cl[NT];
+            u32x4 bh[NT], bl[NT];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                keep_until_here(Hp[jt][3]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) H[jt][r] = fmaf((1.f - LEAKY) / (1.f + LEAKY), __builtin_fabsf(Hp[jt][r]), Hp[jt][r]);
+                const Split2 p01 = split2(H[jt][0], H[jt][1]), p2 = split2(H[jt][2], 1.0f);
+                ch[jt] = u32x2{p01.hi, p2.hi};
+                cl[jt] = u32x2{p01.lo, p2.lo};
+                sh_tile[sh_wr[jt]] = ch[jt];
+                sh_tile[SH_LO + sh_wr[jt]] = cl[jt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const u32x2 ph = sh_tile[sh_rd1[jt]], pl = sh_tile[SH_LO + sh_rd1[jt]];
+                bh[jt] = u32x4{ch[jt].x, ch[jt].y, ph.x, ph.y};
+                bl[jt] = u32x4{cl[jt].x, cl[jt].y, pl.x, pl.y};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                z[jt] = mfma16(w_hi[l][0], bh[jt], zero);
+                z[jt] = mfma16(w_hi[l][0], bl[jt], z[jt]);
+                z[jt] = mfma16(w_lo[l][0], bh[jt], z[jt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                keep_until_here(z[jt][3]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) V[jt][r] = relu2(fmaf(2.f, H[jt][r], relu2(z[jt][r])));
+                const Split2 p01 = split2(V[jt][0], V[jt][1]), p2 = split2(V[jt][2], 1.0f);
+                ch[jt] = u32x2{p01.hi, p2.hi};
+                cl[jt] = u32x2{p01.lo, p2.lo};
+                sh_tile[sh_wr[jt]] = ch[jt];
+                sh_tile[SH_LO + sh_wr[jt]] = cl[jt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const u32x2 ph = sh_tile[sh_rd2[jt]], pl = sh_tile[SH_LO + sh_rd2[jt]];
+                bh[jt] = u32x4{ch[jt].x, ch[jt].y, ph.x, ph.y};
+                bl[jt] = u32x4{cl[jt].x, cl[jt].y, pl.x, pl.y};
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                z[jt] = mfma16(w_hi[l][1], bh[jt], zero);
+                z[jt] = mfma16(w_hi[l][1], bl[jt], z[jt]);
+                z[jt] = mfma16(w_lo[l][1], bh[jt], z[jt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                keep_until_here(z[jt][3]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) X[jt][r] = fmaf(half_ok[jt], relu2(z[jt][r]), fmaf(quarter_ok[jt], V[jt][r], X[jt][r]));
+            }
+        }
+
+        // ---- head: max over the ten channels (Model.py:218-219), fc1, fc2 ---------------------------------------------------
+        float pm[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct < NT) {
+                const float x1 = g == 3 ? X[ct][0] : X[ct][1], x2 = g == 3 ? X[ct][0] : X[ct][2];
+                const float m = vmax3(X[ct][0], x1, x2);
+                pm[ct] = fmaf(X[ct][0] + x1 + x2, 0.f, m);               // v_max drops NaN: put it (and Inf) back
+            } else {
+                pm[ct] = 0.f;
+            }
+        }
+        transpose_rows4(pm[0], pm[1], pm[2], pm[3]);                      // in: register = column tile, row = group; out: the reverse
+        float pooled = vmax(vmax3(pm[0], pm[1], pm[2]), pm[3]);
+        pooled = fmaf((pm[0] + pm[1]) + (pm[2] + pm[3]), 0.f, pooled);
+        pooled = lane < N ? pooled : 0.f;                                 // lane (row ct, col) = patch 16 ct + col = lane
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        float* const scratch = cur + 16 * PT;
+        scratch[lane] = pooled;
+        __builtin_amdgcn_wave_barrier();
+        float y1 = fc1b, y1b = 0.f;
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const float4 pv = *reinterpret_cast<const float4*>(scratch + 4 * q);
+            y1 = fmaf(fc1w[4 * q], pv.x, y1);
+            y1b = fmaf(fc1w[4 * q + 1], pv.y, y1b);
+            y1 = fmaf(fc1w[4 * q + 2], pv.z, y1);
+            y1b = fmaf(fc1w[4 * q + 3], pv.w, y1b);
+        }
+        y1 += y1b;
+        const float pred = Row<64>::allsum(relu2(y1) * fc2w_half) + fc2b;
+        pend_mine = lane == 0; pend_idx = smp; pend_pred = pred;
+        // the conversion tile's padding rows were overwritten by the shift tile: restore them for the next sample
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < 2 * PT; e += 64) cur[13 * PT + e] = 0.f;
+    }
+    if (pend_mine) out[pend_idx] = pend_pred;
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 static bool mx_shape_ok(const rulgnn_stgcn_shape* s, const float* x) {
     const int N = s->num_patch, P = s->patch_size, L = s->num_layers;
@@ -975,6 +1323,54 @@ int stgcn_train_f0_mx(const rulgnn_stgcn_shape* s, const float* x, const float* 
     if (s->num_patch == 14 && s->patch_size == 30) return launch(&stgcn_train_f0_mx_kernel<14, 30>);
     if (s->num_patch == 14 && s->patch_size == 50) return launch(&stgcn_train_f0_mx_kernel<14, 50>);
     return launch(&stgcn_train_f0_mx_kernel<0, 0>);
+}
+
+// ---- wide shapes ---------------------------------------------------------------------------------------------------------
+template <int L, int NT, int NFIX, int PFIX>
+static int mxw_launch(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out, hipStream_t stream) {
+    typedef MxwGeom<NT> G;
+    MxArgs a;
+    a.B = s->batch; a.ntiles = s->batch; a.N = s->num_patch; a.P = s->patch_size; a.L = s->num_layers;
+    a.buf_floats = (s->num_patch * s->patch_size + 3) & ~3;
+    a.taps = nullptr;
+    const size_t lds = (size_t)G::theta_bytes(L) + (size_t)MXW_WAVES * ((size_t)a.buf_floats * 4 + G::region_bytes);
+    if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
+    auto kern = &stgcn_forward_mxw_kernel<L, NT, NFIX, PFIX>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    int64_t grid = (s->batch + MXW_WAVES - 1) / MXW_WAVES;
+    if (grid > cus) grid = cus;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXW_WAVES), lds, stream, x, prm, bn, out, a);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+template <int L>
+static int mxw_dispatch(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out, hipStream_t stream) {
+    if (s->num_patch == 40 && s->patch_size == 64) return mxw_launch<L, 3, 40, 64>(s, x, prm, bn, out, stream);
+    if (s->num_patch <= 31) return mxw_launch<L, 2, 0, 0>(s, x, prm, bn, out, stream);
+    return mxw_launch<L, 3, 0, 0>(s, x, prm, bn, out, stream);
+}
+
+// 16 <= num_patch <= 47.  The caller follows a successful launch with stgcn_forward_fixup (non-finite predictions -> exact kernel).
+int stgcn_forward_eval_mxw(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out, hipStream_t stream) {
+    const int rc = validate_shape(s);
+    if (rc != RULGNN_OK) return rc;
+    const int N = s->num_patch, P = s->patch_size, L = s->num_layers;
+    if (N < 16 || N > 47 || L < 1 || L > MX_MAX_LAYERS || s->mpnn_k != 1) return RULGNN_EUNSUPPORTED;
+    if (((int64_t)N * P) % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) return RULGNN_EUNSUPPORTED;
+    if (s->batch == 0) return RULGNN_OK;
+    switch (L) {
+        case 1: return mxw_dispatch<1>(s, x, prm, bn, out, stream);
+        case 2: return mxw_dispatch<2>(s, x, prm, bn, out, stream);
+        default: return mxw_dispatch<3>(s, x, prm, bn, out, stream);
+    }
 }
 
 int stgcn_forward_mx_tap_floats() { return MX_TAP_SLOTS * 64; }

@@ -101,6 +101,10 @@ int stgcn_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const float*
 int stgcn_forward_eval_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out,
                           hipStream_t stream, float* taps = nullptr);
 int stgcn_forward_mx_tap_floats();
+// The matrix-core eval forward for 16 <= num_patch <= 47 (stgcn_forward_mx.hip) and the scanning launch that follows it: every
+// non-finite prediction is recomputed by the exact row-mapped routine (stgcn_forward.hip).
+int stgcn_forward_eval_mxw(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out, hipStream_t stream);
+int stgcn_forward_fixup(const rulgnn_stgcn_shape* s, const float* x, const float* prm, const float* bn, float* out, hipStream_t stream);
 // Training phase F_0 on the matrix cores (stgcn_forward_mx.hip); RULGNN_EUNSUPPORTED when the shape is outside its rules
 int stgcn_train_f0_mx(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* cacheX, float* cacheA, float* H0, float* Z1,
                       double* cells_bn0, int cell_stride_doubles, int replicas, hipStream_t stream);

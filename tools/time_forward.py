@@ -12,7 +12,8 @@ from oracle import stgcn_oracle as O                       # noqa: E402
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-N, P, L = 14, 30, 2
+import os
+N, P, L = int(os.environ.get("NP", 14)), int(os.environ.get("PS", 30)), 2
 prm_np, bn_np = PL.pack_numpy(O.random_params(N, L, seed=1), N, L)
 prm, bn = torch.from_numpy(prm_np).to(dev), torch.from_numpy(bn_np).to(dev)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -21,7 +22,7 @@ for B in [int(a) for a in sys.argv[1:]] or [4096, 65536, 1048576]:
     out = torch.empty(B, device=dev)
     shp = _lib.StgcnShape(B, N, P, L, 1)
     res = {}
-    for name, path in (("exact", _lib.EVAL_EXACT), ("mx", _lib.EVAL_MX)):
+    for name, path in (("exact", _lib.EVAL_EXACT), ("mx", _lib.EVAL_MX))[:2 if N <= 47 else 1]:
         def call():
             _lib.check(lib.rulgnn_stgcn_forward_path_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(), None, 0,
                                                          path, st), name)
