@@ -249,6 +249,20 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
                            "frac": round(bach / HBM_PEAK_GBS, 4), "samples_per_s": round(BB / (bms * 1e-3), 1),
                            "traffic": forward_traffic(N, P, BB)}
         del Xb
+        # the reference's own ST_GCN wiring on PHM2012 (configs/hparams.py:238: 40 patches of 64 points): the wide matrix-core kernel
+        # (stgcn_forward_mxw_kernel) followed by the scanning launch of the exact kernel, both inside the timed region
+        from gnn_rul_benchmarking_amd.stgcn import ST_GCN_model
+        WN, WP, WB = 40, 64, 1 << 17
+        torch.manual_seed(1)
+        wide = ST_GCN_model(num_patch=WN, patch_size=WP).to(X.device)
+        Xw = torch.rand(WB, WN, WP, device=X.device, generator=g)
+        wms = time_eval_forward(wide, Xw, iters=5)
+        walg = algorithmic_bytes_per_sample(WN, WP)
+        wach = walg * WB / (wms * 1e-3) / 1e9
+        roof_f["phm2012_40x64"] = {"kernel": "stgcn_forward_mxw_kernel + stgcn_forward_fixup_kernel", "batch": WB,
+                                   "algorithmic_bytes_per_sample": walg, "us_per_call": round(wms * 1e3, 1), "achieved": round(wach, 1),
+                                   "frac": round(wach / HBM_PEAK_GBS, 4), "samples_per_s": round(WB / (wms * 1e-3), 1)}
+        del Xw, wide
     return roof, roof_f
 
 

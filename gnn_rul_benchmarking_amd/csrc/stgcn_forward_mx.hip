@@ -866,9 +866,9 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
 // (configs/hparams.py:238); the row-mapped kernel runs it at 0.05 of the HBM roofline.  ONE sample per wavefront iteration, its patch
 // axis in NT = 2 | 3 column tiles of 16: a [10, N] tensor is NT x 3 registers, the tiles of a sample are the independent MFMA chains
 // that the four samples are in the narrow kernel.  What changes against it:
-//  * theta is N x N: the projection contracts over NT k-tiles into NT column tiles (2 NT^2 products per layer); its 2 NT^2 operands
-//    per layer (the distinct halves only: 8 bytes per lane) live in LDS, shared by the EIGHT wavefronts of a workgroup (one
-//    workgroup per CU: 18 KB of operands + 8 x 13.6 KB at 40 x 64);
+//  * theta is N x N: the projection contracts over NT k-tiles into NT column tiles (2 NT^2 products per layer); its operands
+//    -- NT^2 per layer, (hi | lo) halves, each against the data's (hi | hi) and (lo | lo) -- live in LDS, shared by the EIGHT
+//    wavefronts of a workgroup (one workgroup per CU: 18 KB of operands + 8 x 13.6 KB at 40 x 64);
 //  * the causal taps cross tile boundaries: the shift tile is indexed [row group][column 0 .. 16 NT);
 //  * the patch (64 points = 256 bytes) is read from the linearly copied window in a per-lane ROTATED chunk order -- lane p reads its
 //    16-byte chunks (k + p) mod 16, k = 0..15: every statistic is a symmetric function of the patch, and a 256-byte lane stride
@@ -884,7 +884,7 @@ template <int NT> struct MxwGeom {
     static constexpr int conv_bytes = 16 * PT * 4 + 256;                   // [16 slots][PT] + 64 floats of head scratch
     static constexpr int shift_bytes = 2 * (4 * W + 1) * 8;                // hi plane and lo plane: [4 row groups][W] + the zero slot
     static constexpr int region_bytes = ((conv_bytes > shift_bytes ? conv_bytes : shift_bytes) + 15) & ~15;
-    static constexpr int theta_bytes(int L) { return L * NT * NT * 2 * 64 * 8; }
+    static constexpr int theta_bytes(int L) { return L * NT * NT * 64 * 16; }
 };
 
 template <int LFIX, int NT, int NFIX, int PFIX>
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, col = lane & 15;
     const int NP = N * P;
-    u32x2* const theta_lds = reinterpret_cast<u32x2*>(smem);
+    u32x4* const theta_lds = reinterpret_cast<u32x4*>(smem);
     float* const win = smem + G::theta_bytes(L) / 4 + wave * (a.buf_floats + G::region_bytes / 4);
     float* const cur = win + a.buf_floats;
     const int64_t stride = (int64_t)gridDim.x * MXW_WAVES;
@@ -923,8 +923,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
             w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
         }
         const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
-        theta_lds[(idx * 2 + 0) * 64 + lane] = u32x2{p01.hi, p23.hi};
-        theta_lds[(idx * 2 + 1) * 64 + lane] = u32x2{p01.lo, p23.lo};
+        theta_lds[idx * 64 + lane] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};      // (hi | lo) against the data's (hi | hi) and (lo | lo)
     }
     u32x4 w_hi[L][2], w_lo[L][2];
 #pragma unroll
@@ -967,7 +966,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
     const float fc2b = prm[off_fc2_b(N, L)];
     const unsigned t_bias = g == 3 ? 0x3C00u << 16 : 0u;
     float half_ok[NT], quarter_ok[NT];
-    int sh_wr[NT], sh_rd1[NT], sh_rd2[NT];
+    int sh_wr[NT], sh_rd1[NT], sh_rd2[NT], sh_rd1_lo[NT], sh_rd2_lo[NT];
     constexpr int SH_ZERO = 4 * W, SH_LO = 4 * W + 1;                    // index of the zero slot; offset of the lo plane
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
@@ -977,6 +976,11 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
         sh_wr[jt] = g * W + t;
         sh_rd1[jt] = t >= 1 ? g * W + t - 1 : SH_ZERO;
         sh_rd2[jt] = t >= 2 ? g * W + t - 2 : SH_ZERO;
+        // through opaque registers: seeing the constant distance the compiler fuses the hi and the lo read into one ds_read2_b64, whose four
+        // consecutive result registers then have to be moved apart into the two MFMA operands they belong to
+        sh_rd1_lo[jt] = sh_rd1[jt] + SH_LO;
+        sh_rd2_lo[jt] = sh_rd2[jt] + SH_LO;
+        asm volatile("" : "+v"(sh_rd1_lo[jt]), "+v"(sh_rd2_lo[jt]));
     }
     // rows 13, 14 of the conversion tile are the padding rows lane group 3 reads as its registers 1, 2: zero, once
     for (int e = lane; e < 2 * PT; e += 64) cur[13 * PT + e] = 0.f;
@@ -1072,7 +1076,8 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
         u32x2* const sh_tile = reinterpret_cast<u32x2*>(cur);             // the shift tile reuses the conversion tile's bytes
         if (lane < 2) sh_tile[SH_ZERO + SH_LO * lane] = u32x2{0u, 0u};
 
-        // ---- the layers -----------------------------------------------------------------------------------------------
+        // ---- the layers (the dense stage: the wavefront in a sparse stage goes first, see the narrow kernel) -------------------
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int l = 0; l < L; ++l) {
             f32x4 T[NT], Hp[NT], z[NT];
@@ -1086,11 +1091,13 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
                 T[ct] = mfma16(al, adjB, T[ct]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            u32x4 ta[NT];
+            u32x4 tah[NT], tal[NT];
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const Split2 p01 = split2(T[ct][0], T[ct][1]), p23 = split2(T[ct][2], T[ct][3]);
-                ta[ct] = u32x4{p01.hi, ct == NT - 1 ? p23.hi | t_bias : p23.hi, p01.lo, p23.lo};
+                const unsigned h23 = ct == NT - 1 ? p23.hi | t_bias : p23.hi;
+                tah[ct] = u32x4{p01.hi, h23, p01.hi, h23};
+                tal[ct] = u32x4{p01.lo, p23.lo, p01.lo, p23.lo};
             }
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) Hp[jt] = zero;
@@ -1098,10 +1105,9 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
             for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) {
-                    const int idx = (l * NT + ct) * NT + jt;
-                    const u32x2 th = theta_lds[(idx * 2 + 0) * 64 + lane], tl = theta_lds[(idx * 2 + 1) * 64 + lane];
-                    Hp[jt] = mfma16(ta[ct], u32x4{th.x, th.y, th.x, th.y}, Hp[jt]);
-                    Hp[jt] = mfma16(ta[ct], u32x4{tl.x, tl.y, tl.x, tl.y}, Hp[jt]);
+                    const u32x4 th = theta_lds[((l * NT + ct) * NT + jt) * 64 + lane];
+                    Hp[jt] = mfma16(tah[ct], th, Hp[jt]);
+                    Hp[jt] = mfma16(tal[ct], th, Hp[jt]);
                 }
             }
             float H[NT][3], V[NT][3];
@@ -1122,7 +1128,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const u32x2 ph = sh_tile[sh_rd1[jt]], pl = sh_tile[SH_LO + sh_rd1[jt]];
+                const u32x2 ph = sh_tile[sh_rd1[jt]], pl = sh_tile[sh_rd1_lo[jt]];
                 bh[jt] = u32x4{ch[jt].x, ch[jt].y, ph.x, ph.y};
                 bl[jt] = u32x4{cl[jt].x, cl[jt].y, pl.x, pl.y};
             }
@@ -1148,7 +1154,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
-                const u32x2 ph = sh_tile[sh_rd2[jt]], pl = sh_tile[SH_LO + sh_rd2[jt]];
+                const u32x2 ph = sh_tile[sh_rd2[jt]], pl = sh_tile[sh_rd2_lo[jt]];
                 bh[jt] = u32x4{ch[jt].x, ch[jt].y, ph.x, ph.y};
                 bl[jt] = u32x4{cl[jt].x, cl[jt].y, pl.x, pl.y};
             }
@@ -1168,6 +1174,7 @@ __global__ __launch_bounds__(64 * MXW_WAVES, 2) void stgcn_forward_mxw_kernel(co
             }
         }
 
+        __builtin_amdgcn_s_setprio(1);
         // ---- head: max over the ten channels (Model.py:218-219), fc1, fc2 ---------------------------------------------------
         float pm[4];
 #pragma unroll

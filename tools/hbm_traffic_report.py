@@ -2,7 +2,7 @@
     python tools/hbm_traffic_report.py gpurun_out/<tag> profiles/<name>.json [batch]
 Counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B),
 WRITE_SIZE is taken as is."""
-import csv, collections, glob, json, re, sys
+import csv, collections, glob, json, os, re, sys
 tag, out = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 def collect(sub, counter):
@@ -18,6 +18,10 @@ def collect(sub, counter):
                 name = "F0"
             elif "stgcn_forward_mx_kernel<2, 14, 30" in r["Kernel_Name"] or "stgcn_forward_eval" in r["Kernel_Name"]:
                 name = "EVAL"
+            elif "stgcn_forward_mxw_kernel" in r["Kernel_Name"]:       # wide matrix-core eval forward (16 <= num_patch <= 47)
+                name = "EVAL_WIDE"
+            elif "stgcn_forward_fixup_kernel" in r["Kernel_Name"]:
+                name = "EVAL_WIDE_SCAN"
             else:
                 continue
             res[name].append(float(r["Counter_Value"]))
@@ -29,6 +33,6 @@ for k in fetch:
     kern[k] = {"fetch_kb_raw": fetch[k], "write_kb_raw": write.get(k, 0.0), "hbm_bytes_per_launch": b, "hbm_bytes_per_sample": b / batch}
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_round.sh); counters are in KB; "
                    "FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE taken as is",
-           "workload": {"num_patch": 14, "patch_size": 30, "batch": batch}, "kernels": kern}, open(out, "w"), indent=1)
+           "workload": {"num_patch": int(os.environ.get("NP", 14)), "patch_size": int(os.environ.get("PS", 30)), "batch": batch}, "kernels": kern}, open(out, "w"), indent=1)
 for k, v in kern.items():
     print(f"{k:5s} {v['hbm_bytes_per_sample']:8.0f} B/sample")

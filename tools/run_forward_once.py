@@ -1,4 +1,4 @@
-"""Launches of each fused eval-forward kernel at one batch size (for rocprofv3 passes): python tools/run_forward_once.py [B]"""
+"""Launches of each fused eval-forward kernel at one batch size (for rocprofv3 passes): [NP=40 PS=64] python tools/run_forward_once.py [B]"""
 import ctypes as C
 import sys
 
@@ -10,7 +10,8 @@ from oracle import stgcn_oracle as O                       # noqa: E402
 
 lib = _lib.load()
 dev = torch.device("cuda:0")
-N, P, L = 14, 30, 2
+import os
+N, P, L = int(os.environ.get("NP", 14)), int(os.environ.get("PS", 30)), 2     # NP=40 PS=64: the PHM2012 wiring (wide kernel)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 prm_np, bn_np = PL.pack_numpy(O.random_params(N, L, seed=1), N, L)
 prm, bn = torch.from_numpy(prm_np).to(dev), torch.from_numpy(bn_np).to(dev)
