@@ -77,7 +77,8 @@ __device__ __forceinline__ unsigned pk_f16(float a, float b) {
 }
 // a = hi + lo with hi = the top 11 significant bits of a (mask: exactly representable in f16, so its conversion is exact) and
 // lo = f16(a - hi), the difference being exact in fp32: 22 significant bits in all.  Per PAIR of values: two v_and, two
-// subtractions, two packing conversions (the form with hi = f16(a) rounded needs two v_cvt_f32_f16 on top).
+// subtractions, two packing conversions (the form with hi = f16(a) rounded needs two v_cvt_f32_f16 on top; with the residuals from
+// v_fma_mixlo/mixhi_f16 -- three instructions per pair instead of six -- it passes every test and is NOT faster: 686 vs 684 us at 1M).
 struct Split2 { unsigned hi, lo; };
 __device__ __forceinline__ Split2 split2(float a, float b) {
     const float ha = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
@@ -347,23 +348,19 @@ __device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const
         adjB[b] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
     }
 
-    // ---- statistics into the D layout: [row-mapped lane][16 slots] through the LDS tile ------------------------
-    __builtin_amdgcn_wave_barrier();
-    {
-        float4* w4 = reinterpret_cast<float4*>(cur + lane * PT_STRIDE);
-        w4[0] = make_float4(X0[0], X0[1], X0[2], 0.f);
-        w4[1] = make_float4(X0[3], X0[4], X0[5], 0.f);
-        w4[2] = make_float4(X0[6], X0[7], X0[8], 0.f);
-        w4[3] = make_float4(X0[9], 0.f, 0.f, 0.f);
-    }
-    __builtin_amdgcn_wave_barrier();
+    // ---- statistics in the D layout: the SAME tile read by (slot row, column) -- rows 13, 14 of a sample's block are the padding
+    // rows lane group 3 reads as its registers 1, 2: zeroed once by the caller (mx_zero_padding_rows), never written here
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(cur + (16 * s + col) * PT_STRIDE + 4 * g);
-        X[s][0] = v.x; X[s][1] = v.y; X[s][2] = v.z;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) tap<TAPS>(a.taps, tapon, 26 + 3 * s + r, lane, X[s][r]);
+        for (int r = 0; r < 3; ++r) {
+            X[s][r] = cur[(16 * s + 4 * g + r) * PT_STRIDE + col];
+            tap<TAPS>(a.taps, tapon, 26 + 3 * s + r, lane, X[s][r]);
+        }
     }
+}
+__device__ __forceinline__ void mx_zero_padding_rows(float* cur, int lane) {
+    for (int e = lane; e < 4 * 2 * PT_STRIDE; e += 64) cur[((e / (2 * PT_STRIDE)) * 16 + 13) * PT_STRIDE + e % (2 * PT_STRIDE)] = 0.f;
 }
 
 template <int LFIX, int NFIX, int PFIX, bool TAPS>
@@ -452,6 +449,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
     int sh_rd1_lo = sh_rd1 + 65, sh_rd2_lo = sh_rd2 + 65;
     asm volatile("" : "+v"(sh_rd1_lo), "+v"(sh_rd2_lo));
 
+    mx_zero_padding_rows(smem + a.buf_floats, lane);
     bool any_bad = false, pend_mine = false;
     int64_t pend_idx = 0;
     float pend_pred = 0.f;
@@ -722,6 +720,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
     }
     const int ca_col = slot_chan(col);                    // adjacency: gram[4 b + r] of lane (g, col) = A_b[slot 4 g + r][slot col]
     float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+    mx_zero_padding_rows(smem + a.buf_floats, lane);
 
     for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
         float* const tileA = smem;
