@@ -1030,30 +1030,41 @@ int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B
     return sgemm_splitk(ones, 0, 0, A, sAm, sAk, colsum, M, 1, M, K, false, partial, st);
 }
 
-// out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 64 columns x 16 row slices per
-// workgroup, the slices combined through LDS in a fixed order (deterministic).  One thread per column walking every row alone
-// was 140-190 us in the finalize kernels of three families.
+// out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 32 columns x 32 row slices per
+// workgroup (twice the workgroups of the 64 x 16 form: 118 instead of 59 for the 3 750 TCN weights of ASTGCNN, which left three
+// quarters of the CUs idle), four independent partial sums per thread so that four loads are in flight, the slices combined through
+// LDS in a fixed order (deterministic).  One thread per column walking every row alone was 140-190 us in the finalize kernels of
+// three families.
 static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __restrict__ part, int rows, int64_t ld, int n,
                                                                float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    float a = 0.f;
-    if (e < n)
-        for (int r = sl; r < rows; r += 16) a += part[(int64_t)r * ld + e];
-    red[sl][lane] = a;
+    __shared__ float red[32][33];
+    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n) {
+        const float* p = part + e;
+        int r = sl;
+        for (; r + 96 < rows; r += 128) {
+            a0 += p[(int64_t)r * ld];
+            a1 += p[(int64_t)(r + 32) * ld];
+            a2 += p[(int64_t)(r + 64) * ld];
+            a3 += p[(int64_t)(r + 96) * ld];
+        }
+        for (; r < rows; r += 32) a0 += p[(int64_t)r * ld];
+    }
+    red[sl][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (sl == 0 && e < n) {
         float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v += red[q][lane];
+        for (int q = 0; q < 32; ++q) v += red[q][lane];
         out[e] = v;
     }
 }
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {
     if (n <= 0) return RULGNN_OK;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, part, rows, ld, n, out);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((n + 31) / 32), dim3(1024), 0, st, part, rows, ld, n, out);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
