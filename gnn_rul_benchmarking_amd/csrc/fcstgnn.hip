@@ -1251,55 +1251,6 @@ __global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float
     s1.flush(cells[blockIdx.x % CELL_REP].bwd[5], g.D2);
 }
 
-// dF = sum over the two blocks of the window-BatchNorm backward (row form, multiplicity-weighted)
-__global__ __launch_bounds__(FB) void fc_feat_bwd_kernel(FcGeom g, const float* __restrict__ prm, const Cells* cells,
-                                                        const float* __restrict__ F, const float* __restrict__ gX0,
-                                                        const float* __restrict__ gX1, float* __restrict__ dF) {
-    __shared__ BnCoef c0[MAXD], c1[MAXD];
-    __shared__ float m0[MAXD][2], m1[MAXD][2];
-    if (threadIdx.x < g.D2) {
-        const int d = threadIdx.x;
-        c0[d] = fbn(g, cells, prm, nullptr, 1, 3, d);
-        c1[d] = fbn(g, cells, prm, nullptr, 1, 5, d);
-        m0[d][0] = (float)(cell_bwd(cells, 3, d, 0) / g.cnt[3]); m0[d][1] = (float)(cell_bwd(cells, 3, d, 1) / g.cnt[3]);
-        m1[d][0] = (float)(cell_bwd(cells, 5, d, 0) / g.cnt[5]); m1[d][1] = (float)(cell_bwd(cells, 5, d, 1) / g.cnt[5]);
-    }
-    __syncthreads();
-    const int64_t total = g.M * g.D2;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
-        const int d = (int)(e % g.D2);
-        const int t = (int)(((e / g.D2) / g.N) % g.NP);
-        const float f = F[e];
-        const float k0 = mult(g, 0, t), k1 = mult(g, 1, t);
-        const float x0 = (f - c0[d].mean) * c0[d].inv, x1 = (f - c1[d].mean) * c1[d].inv;
-        dF[e] = c0[d].sc * (gX0[e] - k0 * (m0[d][0] + x0 * m0[d][1])) + c1[d].sc * (gX1[e] - k1 * (m1[d][0] + x1 * m1[d][1]));
-    }
-}
-
-// dy3 = dF * dropout keep (in place); BatchNorm-c backward sums
-__global__ __launch_bounds__(FB) void fc_pe_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
-                                                      const float* __restrict__ z3, float* __restrict__ dF, uint32_t drop_thr,
-                                                      float drop_scale, uint32_t drop_key, const uint32_t* key_dev, int64_t row_offset) {
-    __shared__ double sl[BS_DOUBLES];
-    __shared__ BnCoef cc[MAXC];
-    if (threadIdx.x < g.D2) cc[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 2, threadIdx.x);
-    BlockStats st;
-    st.init(sl, g.D2);
-    const uint32_t key = key_dev ? *key_dev : drop_key;
-    const int64_t total = g.M * g.D2;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
-        const int d = (int)(e % g.D2);
-        float dy = dF[e];
-        if (drop_thr) {
-            const uint32_t ctr = (uint32_t)(((e / g.D2) + row_offset) * g.D2 + d);
-            dy = lowbias32(ctr ^ key) >= drop_thr ? dy * drop_scale : 0.f;
-        }
-        dF[e] = dy;
-        st.add(d, dy, dy * (z3[e] - cc[d].mean) * cc[d].inv);
-    }
-    st.flush(cells[blockIdx.x % CELL_REP].bwd[2], g.D2);
-}
-
 // The window BatchNorms' backward, both blocks' d M W_map products and the positional-encoding / dropout backward with the BatchNorm-c
 // sums in ONE launch (row-group mapping: D2 lanes per row): d F = bn'(gX_0) + bn'(gX_1) + gM_0 W_map0 + gM_1 W_map1, then the dropout
 // mask and the sums of dy and dy * xhat(z3).  Four launches of 17 + 16 + 18 + 9 us before.
@@ -1791,7 +1742,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const float* prm = a->params;
     const float* run = a->bn_stats;
     const int training = a->training ? 1 : 0;
-    const int bf = a->compute_dtype == RULGNN_DTYPE_BF16 ? 1 : 0;     // bf16 operands on the row-projection GEMMs (forward + data gradient)
+    const int bf = a->compute_dtype == RULGNN_DTYPE_BF16 ? 1 : 0;     // bf16 operands on the row projections that run as GEMM launches
     const int D2 = g.D2, HD = g.HD, CL = g.CL, FIN = g.FIN;
     const int Mi = (int)g.M, Bi = (int)g.B;
     const float inv_gb = 1.0f / (float)(a->global_batch > 0 ? a->global_batch : g.B);
@@ -1800,8 +1751,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     const bool graph_mx = g.Q <= 32 && g.Q % 4 == 0 && (g.D2 == 16 || g.D2 == 32);
     // activation + projection + statistics of the encoder's last Linear in one launch (fc_proj3_kernel) where a row's tile fits a workgroup
     const size_t proj_lds = sizeof(float) * ((size_t)g.D2 * (g.CL + 1) + 2 * FB);
-    const bool proj_fused = !bf && g.CL <= FB && g.D2 <= FB && proj_lds <= 40 * 1024;
-    const bool mlp_fused = !bf && g.D2 == 2 * g.HD && (g.D2 == 16 || g.D2 == 32 || g.D2 == 64);
+    const bool proj_fused = g.CL <= FB && g.D2 <= FB && proj_lds <= 40 * 1024;
+    const bool mlp_fused = g.D2 == 2 * g.HD && (g.D2 == 16 || g.D2 == 32 || g.D2 == 64);
     auto mlp_tail = [&](int tail_mode, const float* y, const float* dpred_in) {
         auto go = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3((unsigned)((g.B + 63) / 64)), dim3(64), 0, st, g, prm, P_(w.h1), P_(w.h2), P_(w.h3), y, dpred_in, a->pred,
@@ -1857,7 +1808,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
             const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
-            if (graph_mx && !bf && D2 == 2 * HD) {
+            if (graph_mx && D2 == 2 * HD) {
                 // mapping, window graphs, the block's Linear and its BatchNorm statistics in one launch
                 auto go = [&](auto kernel) {
                     hipLaunchKernelGGL(kernel, dim3(wgs < 1024 ? wgs : 1024), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, cells, training,
@@ -1972,7 +1923,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             fork();
             // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum)
             FC_RC(sgemm_splitk_colsum(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, gr + g.o_thb[b], one, split, wst));
-            const bool bwd_fused = graph_mx && !bf && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
+            const bool bwd_fused = graph_mx && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
             if (!bwd_fused) FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
             if (graph_mx) {
@@ -2010,19 +1961,10 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sync_pair(1, 5));
         for (int b = 0; b < 2; ++b)
             FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
-        if (!bf) {
-            // window BatchNorms' backward + both d M W_map products + positional encoding / dropout backward: one launch
-            hipLaunchKernelGGL(fc_feat_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
-                               (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), (const float*)P_(w.gM[0]), (const float*)P_(w.gM[1]),
-                               (const float*)P_(w.z3), P_(w.dF), thr, dscale, key, key_dev, row_off);
-        } else {
-            hipLaunchKernelGGL(fc_feat_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, (const Cells*)cells,
-                               (const float*)P_(w.F), (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), P_(w.dF));
-            for (int b = 0; b < 2; ++b) FC_RC(sgemm(P_(w.gM[b]), D2, 1, prm + g.o_map[b], 1, D2, P_(w.dF), D2, Mi, D2, D2, true, st, bf));
-            // ---- positional encoding / dropout, Linear + BatchNorm ----
-            hipLaunchKernelGGL(fc_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z3), P_(w.dF), thr,
-                               dscale, key, key_dev, row_off);
-        }
+        // window BatchNorms' backward + both d M W_map products + positional encoding / dropout backward: one launch
+        hipLaunchKernelGGL(fc_feat_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
+                           (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), (const float*)P_(w.gM[0]), (const float*)P_(w.gM[1]),
+                           (const float*)P_(w.z3), P_(w.dF), thr, dscale, key, key_dev, row_off);
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);

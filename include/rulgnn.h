@@ -421,11 +421,13 @@ typedef struct rulgnn_fcstgnn_args {
     uint64_t seed, step;      /* dropout stream: mask = f(seed, step, element index) */
     int32_t training;
     void *step_state;         /* optional device step state (rulgnn_step_state_set) */
-    int32_t compute_dtype;    /* RULGNN_DTYPE_F32 (0, default): everything fp32.  RULGNN_DTYPE_BF16: the row projections (Linear layers
-                               * over the [rows, 8..24] activations, forward and data gradient) round both operands to bf16 and run
-                               * on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; BatchNorm statistics, the window graphs, the
-                               * weight gradients, the loss and the optimizer stay fp32.  BASELINE.json config "FC_STGNN ... bf16":
-                               * reported separately, it does NOT meet the 1e-4 gate (tests/test_fcstgnn_gpu.py bounds its error) */
+    int32_t compute_dtype;    /* RULGNN_DTYPE_F32 (0, default): everything fp32.  RULGNN_DTYPE_BF16: the row projections that run as
+                               * GEMM launches (Linear layers over the [rows, 8..24] activations, forward and data gradient) round
+                               * both operands to bf16 and run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the projections
+                               * fused into other kernels (round 3: the encoder's last Linear, the MLP behind fc1, the theta Linear
+                               * and the map products of the window blocks), BatchNorm statistics, the window graphs, the weight
+                               * gradients, the loss and the optimizer stay fp32.  BASELINE.json config "FC_STGNN ... bf16":
+                               * reported separately; tests/test_fcstgnn_gpu.py bounds its error (the parity claims are fp32) */
     void *aux_stream;         /* optional second HIP stream of the caller (NULL: everything on `stream`).  The backward then runs its
                                * weight / bias gradient GEMMs -- 17 latency-bound launches that nothing downstream waits for -- on it,
                                * forked behind events recorded on `stream` and joined before the call's last kernel, while the

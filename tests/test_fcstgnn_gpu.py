@@ -157,11 +157,12 @@ def test_eval_batch_split_invariance_and_abi_errors():
     assert lib.rulgnn_fcstgnn_backward_f32(C.byref(shp), C.byref(a), None) == -1
 
 
-def test_bf16_variant_error_is_bounded_and_does_not_meet_the_fp32_gate():
+def test_bf16_variant_error_is_bounded():
     """BASELINE.json config "FC_STGNN on C-MAPSS FD004, batch=256, bf16": compute_dtype="bf16" rounds the operands of the row
-    projections to bf16 (fp32 accumulate, fp32 BatchNorm / graphs / weight gradients).  It is a separate, reported variant: its error
-    against the fp64 oracle is bounded here (1e-2 on predictions and loss, gradients within 5 % and pointing the same way) and is
-    ABOVE the 1e-4 gate the fp32 path meets -- the default stays fp32."""
+    projections that run as GEMM launches to bf16 (fp32 accumulate; fp32 BatchNorm / graphs / weight gradients / fused projections).
+    It is a separate, reported variant: its error against the fp64 oracle is bounded here (1e-2 on predictions and loss, gradients
+    within 5 % and pointing the same way).  Since round 3 every forward projection of this wiring is fused into an fp32 kernel, so the
+    predictions sit at fp32 level; the default and every parity claim stay fp32."""
     from gnn_rul_benchmarking_amd.hparams import get_hparams_class
     cfg = O.Config(**get_hparams_class("CMAPSS")("FD004").alg_hparams["FC_STGNN"])
     bs = 256
@@ -186,7 +187,7 @@ def test_bf16_variant_error_is_bounded_and_does_not_meet_the_fp32_gate():
     ref_flat = np.concatenate([np.asarray(grads[k], np.float64).reshape(-1) for k in O.param_names(cfg) if k not in ZERO_GRAD])
     e32, e16 = rel(res["f32"][0], fw.pred), rel(res["bf16"][0], fw.pred)
     assert e32 < TOL
-    assert 1e-4 < e16 < 1e-2, e16                                   # a different arithmetic, and a bounded one
+    assert e16 < 1e-2, e16
     assert abs(res["bf16"][1] - loss) < 1e-2 * abs(loss)
     gerr = np.abs(res["bf16"][2] - ref_flat).max() / np.abs(ref_flat).max()
     cos = float(res["bf16"][2] @ ref_flat / (np.linalg.norm(res["bf16"][2]) * np.linalg.norm(ref_flat)))
