@@ -148,7 +148,7 @@ class _GraphFunction(torch.autograd.Function):
     def backward(ctx, dfeats, dkl):
         model = ctx.model
         dnodes, grads = model._graph_backward(ctx.shape, ctx.ws, dfeats.contiguous().float(), dkl.reshape(1).contiguous().float())
-        out = [grads[off:off + n].view(shape).clone() for (off, n, shape) in model._slices]
+        out = [grads[off:off + n].view(shape) for (off, n, shape) in model._slices]        # views of this backward's own buffer
         return (None, dnodes, *out)
 
 
@@ -246,11 +246,13 @@ class HAGCN_model(nn.Module):
         shp = self._shape(G, N)
         dnodes = torch.empty(G, N, enc, dtype=torch.float32, device=dfeats.device)
         a = _lib.HagcnArgs()
+        # a fresh gradient buffer per backward (the kernels write every slot): autograd gets views of it instead of ~30 copies
+        grads = torch.empty(self._count, dtype=torch.float32, device=dfeats.device)
         a.params, a.dfeats, a.dkl, a.dnodes, a.grads = (self._flat.data_ptr(), dfeats.data_ptr(), dkl.data_ptr(), dnodes.data_ptr(),
-                                                        self._grad_flat.data_ptr())
+                                                        grads.data_ptr())
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         _lib.check(_lib.load().rulgnn_hagcn_graph_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_hagcn_graph_backward_f32")
-        return dnodes, self._grad_flat
+        return dnodes, grads
 
     def graph_stack(self, nodes):
         """(feats [G, 3h], kl) of the graph part for given node features [G, N, enc] (what Model.py:164-183 computes)."""
