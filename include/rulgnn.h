@@ -76,10 +76,13 @@ int rulgnn_stgcn_forward_f32(const rulgnn_stgcn_shape *shape, const float *x, co
  *   RULGNN_EVAL_EXACT  every contraction in fp32 (VALU / DPP FMAs, f32 MFMA for the Pearson matrix): any num_patch <= 64;
  *   RULGNN_EVAL_MX     the contractions of the layers on the f16 matrix cores with 2-way split operands
  *                      (hi + lo, fp32 accumulate: fp32-class accuracy, measured 5e-8 of sum|a.b| per product); requires
- *                      num_patch <= 15, num_layers <= 3, num_patch*patch_size a multiple of 4 and a 16-byte aligned x
- *                      (else RULGNN_EUNSUPPORTED).  Samples whose
- *                      arithmetic leaves the f16 range, or whose statistics are NaN / Inf, are recomputed inside the same
- *                      launch by the EXACT arithmetic, so both paths agree on where NaN appears.
+ *                      num_patch <= 47, num_layers <= 3, num_patch*patch_size a multiple of 4 and a 16-byte aligned x
+ *                      (else RULGNN_EUNSUPPORTED).  num_patch <= 15 (the C-MAPSS shapes): four samples per wavefront;
+ *                      16 <= num_patch <= 47 (PHM2012: 40 x 64, reference configs/hparams.py:238): one sample per
+ *                      wavefront in 2-3 column tiles, when its LDS need fits (else RULGNN_EUNSUPPORTED).  Samples whose
+ *                      arithmetic leaves the f16 range, or whose statistics are NaN / Inf, are recomputed by the EXACT
+ *                      arithmetic -- inside the same launch (num_patch <= 15) or by a second, scanning launch enqueued
+ *                      behind the first (16..47) -- so both paths agree on where NaN appears.
  *   RULGNN_EVAL_AUTO   MX when the shape qualifies, EXACT otherwise.
  * num_patch > 64 ignores `path` (tiled kernels). */
 #define RULGNN_EVAL_AUTO  0
