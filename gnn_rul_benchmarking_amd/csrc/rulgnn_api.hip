@@ -176,7 +176,7 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape* shape, const rulg
                                      const rulgnn_adam_args* opt, int32_t path, void* stream) {
     int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
-    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_COOP) return RULGNN_EINVAL;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_COOP && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
     if (!opt) {                                            // forward + backward only
         if (tiled(shape)) return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream));
         return stgcn_train_step(shape, args, nullptr, static_cast<hipStream_t>(stream), path);

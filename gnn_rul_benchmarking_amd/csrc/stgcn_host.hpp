@@ -125,7 +125,8 @@ int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_a
 int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream);
 int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const rulgnn_adam_args* opt,
                      hipStream_t stream, int path = RULGNN_STEP_AUTO);     // opt == nullptr: forward + backward only
-int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream);
+int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream,
+                      int path = RULGNN_STEP_AUTO);
 int stgcn_train_fwdbwd_syncbn(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, float bn_param_grad_scale,
                               rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t stream);
 int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s);

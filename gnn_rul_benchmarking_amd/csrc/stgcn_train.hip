@@ -28,6 +28,8 @@
 // Accumulators stay in the MFMA accumulator registers across the whole persistent tile loop.
 #include "stgcn_device.hpp"
 #include "stgcn_host.hpp"
+#include "stgcn_train_layout.hpp"
+#include "stgcn_train_mx.hpp"
 
 namespace rulgnn {
 
@@ -86,37 +88,6 @@ struct TrainK {
     uint32_t drop_thr;
     int pcount;
 };
-
-// Per-step scalars that change from step to step live in the workspace right behind the loss cell (8 doubles), written by
-// stgcn_prepare_kernel at the head of the step -- not in the kernel arguments: that keeps the argument block small (the
-// phase kernels are SGPR-bound) and lets a captured hipGraph replay with fresh values.
-struct StepScratch {
-    uint32_t drop_key[8];
-    float lr_over_bc1, inv_sqrt_bc2;
-    double bn_count;      // values per channel behind the BatchNorm cells: batch * N of this shard, or of the GLOBAL batch when the
-                          // cells are all-reduced between the phases (synchronised BatchNorm, stgcn_train_fwdbwd_syncbn)
-    uint32_t pad[4];
-};
-static_assert(sizeof(StepScratch) == 64, "step scratch layout");
-
-// Reduction cells (fp64): per BatchNorm the forward pair (sum z, sum z^2) and the backward pair (sum dy, sum dy*xhat), then
-// the loss.  Every block adds its partial sums with one atomic per cell; 1280 blocks hitting the same 20 addresses serialise
-// (measured: ~10 us per phase kernel), so the cells exist CELL_REPLICAS times, block b adds into replica b % CELL_REPLICAS and
-// the consumers sum the replicas in a fixed order.
-constexpr int CELL_REPLICAS = 16;
-__host__ __device__ constexpr int cell_fwd(int L) { (void)L; return 0; }
-__host__ __device__ constexpr int cell_bwd(int L) { return 2 * L * 2 * F; }
-__host__ __device__ constexpr int cell_loss(int L) { return 2 * (2 * L * 2 * F); }
-__host__ __device__ constexpr int cell_stride(int L) { return 2 * (2 * L * 2 * F) + 8; }
-__host__ __device__ __forceinline__ StepScratch* step_scratch(double* cells, int L) {
-    return reinterpret_cast<StepScratch*>(cells + CELL_REPLICAS * cell_stride(L));
-}
-__device__ __forceinline__ double cell_sum(const double* cells, int L, int i) {
-    double v = 0.0;
-#pragma unroll
-    for (int r = 0; r < CELL_REPLICAS; ++r) v += cells[r * cell_stride(L) + i];
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers
@@ -371,10 +342,13 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     const int pitch = TSPW * N, loff = srow * N + t;
     const bool lane_ok = t < N;
     const size_t tile_floats = (size_t)F * pitch;
+    // rows of samples beyond the batch (last tile) read as zero, whatever an earlier step -- or the matrix-core chain, which shares the
+    // workspace and keeps +inf sentinels in it -- left there: 0 x inf would poison the MFMA weight-gradient accumulators
+    bool tile_row_ok = true;
     auto load_tile = [&](const float* p, float (&v)[F]) {
 #pragma unroll
         for (int c = 0; c < F; ++c) v[c] = 0.f;
-        if (lane_ok) {
+        if (lane_ok && tile_row_ok) {
 #pragma unroll
             for (int c = 0; c < F; ++c) v[c] = p[c * pitch];
         }
@@ -407,7 +381,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     auto load_top_grad = [&](const float* p, float (&v)[F]) {
         float val = 0.f;
         int arg = -1;
-        if (lane_ok) {
+        if (lane_ok && tile_row_ok) {
             val = p[0];
             arg = __builtin_bit_cast(int, p[pitch]);
         }
@@ -428,6 +402,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
         const int ns = (int)((a.B - s0) < TSPW ? (a.B - s0) : TSPW);
         const bool rowok = srow < ns;
         const bool valid = rowok && (t < N);
+        tile_row_ok = rowok;
         constexpr int NA = RW == 16 ? F : NPAIR;   // RW 16: lane-distributed adjacency rows (MFMA); else 55 row-uniform values
         float X[F], A[NA];
         auto slot = [&](int k) { return a.saved + ((size_t)k * a.ntiles + tile) * tile_floats + loff; };
@@ -883,6 +858,8 @@ struct FinalizeK {
     float* bn_running;
     float beta1, beta2, eps, weight_decay, bn_momentum;
     int fused_opt;
+    int guard;               // matrix-core chain: a raised status word (a value left the f16 range, stgcn_train_mx.hip) leaves parameters,
+                             // optimizer state and running statistics untouched and reports a NaN loss
 };
 
 // Gradient rows of the phase kernels' workgroups -> gradient (+ Adam): a workgroup owns FIN_COLS consecutive parameters (lane =
@@ -950,7 +927,7 @@ __device__ __forceinline__ void finalize_unit(const FinalizeK& f, int unit, floa
             for (int sl = 0; sl < FIN_SLICES; ++sl) v += part[sl][lane];
         }
         f.grads[p] = v;
-        if (f.fused_opt) {                     // torch.optim.Adam, same arithmetic as adam_step_kernel
+        if (f.fused_opt && !(f.guard && step_scratch(f.cells, L)->pad[0] != 0u)) {     // torch.optim.Adam, same arithmetic as adam_step_kernel
             const float pi = f.params[p];
             const float gi = fmaf(f.weight_decay, pi, v);
             const float mi = fmaf(f.beta1, f.exp_avg[p], (1.f - f.beta1) * gi);
@@ -968,7 +945,8 @@ __device__ __forceinline__ void finalize_stats(const FinalizeK& f, int tid, int 
     const int N = f.N, L = f.L;
     (void)N;
     const double cnt = step_scratch(f.cells, L)->bn_count;
-    if (tid == 0 && f.write_loss) f.loss[0] = (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
+    const bool tripped = f.guard && step_scratch(f.cells, L)->pad[0] != 0u;
+    if (tid == 0 && f.write_loss) f.loss[0] = tripped ? __builtin_nanf("") : (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
     for (int i = tid; i < 2 * L * F; i += nthreads) {
         const int b = i / F, c = i % F;
         const double s2 = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 1) * F + c);
@@ -982,7 +960,7 @@ __device__ __forceinline__ void finalize_stats(const FinalizeK& f, int tid, int 
             f.bn_batch[(b * 2 + 0) * F + c] = (float)mean;
             f.bn_batch[(b * 2 + 1) * F + c] = (float)var;
         }
-        if (f.fused_opt && f.bn_running) {          // nn.BatchNorm1d running statistics (unbiased running variance)
+        if (f.fused_opt && f.bn_running && !tripped) {          // nn.BatchNorm1d running statistics (unbiased running variance)
             const float unbias = cnt > 1.0 ? (float)(cnt / (cnt - 1.0)) : 1.f;
             float* rm = f.bn_running + (b * 2 + 0) * F + c;
             float* rv = f.bn_running + (b * 2 + 1) * F + c;
@@ -1036,7 +1014,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
-    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64;   // + grid-barrier counter
+    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64 + BN_TABLE_BYTES;   // + grid-barrier counter + BatchNorm table
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
@@ -1224,6 +1202,8 @@ __device__ __forceinline__ void prepare_body(double* cells, int zero_from, int n
     if (threadIdx.x != 0) return;
     sc->bn_count = bn_count;
     if (new_forward) {
+        sc->pad[0] = 0u;                               // status word of the matrix-core chain (stgcn_train_mx.hip)
+        sc->pad[1] = 0u;                               // its BatchNorm-table sequence number (bn_table_sync)
         if (st) step = ++st->dropout_step;
         for (int l = 0; l < 8; ++l) sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
     }
@@ -1366,6 +1346,7 @@ static int launch_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.cell_grad_scale = 1.0f;
+    f.guard = 0;
     f.fused_opt = fused_adam ? 1 : 0;
     f.params = fused_adam ? opt->params : nullptr; f.exp_avg = fused_adam ? opt->exp_avg : nullptr;
     f.exp_avg_sq = fused_adam ? opt->exp_avg_sq : nullptr; f.bn_running = fused_adam ? opt->bn_stats : nullptr;
@@ -1390,6 +1371,39 @@ static int run_train_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_
     return launch_coop<RW, L, 0, 0>(s, a, stream, k, w, g, opt, bn_count);
 }
 
+// ---- the matrix-core chain's view of the workspace (stgcn_train_mx.hip): X_0 tiles in cacheX, packed adjacency tiles in cacheA, X_l in
+// the saved slots X(l), TOP's sparse gradient in slot H(0), d(x0 + H) in sbuf, d X_l in rbuf ---------------------------------------------
+template <int L>
+static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k) {
+    MxTrainArgs m;
+    const size_t tile_floats = (size_t)F * 4 * k.N;
+    m.prm = a->params; m.y = a->y; m.pred = a->pred; m.cells = k.cells; m.gpart = k.gpart;
+    m.xrec[0] = k.cacheX;
+    m.qrec[0] = nullptr;
+    for (int l = 1; l < 3; ++l) {
+        m.xrec[l] = l < L ? k.saved + (size_t)SavedSlot<L>::X(l) * k.ntiles * tile_floats : nullptr;
+        m.qrec[l] = l < L ? k.saved + (size_t)SavedSlot<L>::Z2(l - 1) * k.ntiles * tile_floats : nullptr;
+    }
+    m.arec = k.cacheA;
+    m.sb = k.sbuf; m.dx = k.rbuf;
+    m.dtop = k.saved + (size_t)SavedSlot<L>::H(0) * k.ntiles * tile_floats;
+    m.B = s->batch; m.global_batch = a->global_batch; m.sample_offset = a->sample_offset;
+    m.N = k.N; m.L = L; m.pcount = k.pcount;
+    m.dropout_p = k.dropout_p; m.drop_scale = k.drop_scale; m.drop_thr = k.drop_thr;
+    m.do_backward = k.do_backward;
+    return m;
+}
+// phase numbering of rulgnn_stgcn_train_phase_f32: 0 .. 2L-1 = F_i, 2L = TOP, 2L+1+j = G_{2L-1-j}
+template <int L>
+static int mx_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k, const MxTrainArgs& m, int ph,
+                    hipStream_t stream, int max_grid, int* grid_out) {
+    if (ph == 0)
+        return stgcn_train_f0_mx_packed(s, a->x, a->params, m.xrec[0], m.arec, k.cells + cell_fwd(L), cell_stride(L), CELL_REPLICAS, stream);
+    if (ph < 2 * L) return stgcn_train_mx_phase(m, PH_F, ph, stream, max_grid, grid_out);
+    if (ph == 2 * L) return stgcn_train_mx_phase(m, PH_TOP, 0, stream, max_grid, grid_out);
+    return stgcn_train_mx_phase(m, PH_G, 4 * L - ph, stream, max_grid, grid_out);
+}
+
 template <int RW, int L>
 static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int mode, hipStream_t stream,
                         TrainK& k, WsLayout& w, TileGeom& lds, const rulgnn_adam_args* opt, const SyncHook* hook, int path) {
@@ -1403,6 +1417,10 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         return run_train_coop<RW, L>(s, a, stream, k, w, lds, opt, bn_count);
     }
     const float* gy = a->dpred ? a->dpred : a->y;
+    // The matrix-core chain (stgcn_train_mx.hip): same prepare / cells / finalize, phases that recompute instead of reading saved
+    // activations.  Whole MSE steps only (the autograd split and upstream gradients of unknown magnitude stay on the fp32 phases).
+    const bool use_mx = RW == 16 && path != RULGNN_STEP_CHAIN && mode == TM_FWDBWD && k.has_dpred == 0 && stgcn_train_mx_shape_ok(s, a->x);
+    if (path == RULGNN_STEP_MX && !use_mx) return RULGNN_EUNSUPPORTED;
 
     StepScratch* sc = step_scratch(k.cells, L);
     const bool fused_adam = opt && mode == TM_FWDBWD;
@@ -1416,8 +1434,10 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
                            a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
                            fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f, bn_count);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
-        rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream, hook);
-        if (rc != RULGNN_OK) return rc;
+        if (!use_mx) {
+            rc = PhaseChain<RW, L, 2 * L - 1>::forward_stats(k, a->x, a->params, lds, w.max_grid, stream, hook);
+            if (rc != RULGNN_OK) return rc;
+        }
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
         hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, cell_bwd(L), cell_stride(L) - cell_bwd(L),
@@ -1427,9 +1447,28 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     }
     int grid_top = 0;
     int grids[16] = {0};
+    if (use_mx) {
+        const MxTrainArgs m = mx_args<L>(s, a, k);
+        for (int ph = 0; ph <= 4 * L; ++ph) {
+            int grid = 0;
+            rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid);
+            if (rc != RULGNN_OK) return rc;
+            // the reduction pair a phase completes (all-reduced here under synchronised BatchNorm; the NEXT phase's workgroup 0 finishes
+            // the BatchNorm table from it either way): F_i -> forward pair i, TOP -> backward pair 2L-1, G_i -> backward pair i-1
+            if (ph < 2 * L) rc = sync_pair<L>(k, cell_fwd(L) + ph * 2 * F, hook, stream);
+            else if (ph == 2 * L) { grid_top = grid; rc = sync_pair<L>(k, cell_bwd(L) + (2 * L - 1) * 2 * F, hook, stream); }
+            else {
+                const int i = 4 * L - ph;
+                grids[i] = grid;
+                if (i > 0) rc = sync_pair<L>(k, cell_bwd(L) + (i - 1) * 2 * F, hook, stream);
+            }
+            if (rc != RULGNN_OK) return rc;
+        }
+    } else {
     rc = launch_phase<RW, L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);
     if (rc != RULGNN_OK) return rc;
-    if (mode != TM_FORWARD) {
+    }
+    if (mode != TM_FORWARD && !use_mx) {
         rc = sync_pair<L>(k, cell_bwd(L) + (2 * L - 1) * 2 * F, hook, stream);      // TOP leaves the pair of the last BatchNorm
         if (rc != RULGNN_OK) return rc;
         rc = PhaseChain<RW, L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids, hook);
@@ -1443,6 +1482,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.cell_grad_scale = hook ? hook->bn_param_grad_scale : 1.0f;
+    f.guard = use_mx ? 1 : 0;
     f.fused_opt = 0;
     f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
     f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;
@@ -1490,24 +1530,37 @@ struct SinglePhase {
 };
 
 template <int L>
-static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {
+static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream, int path) {
     TrainK k;
     WsLayout w;
     TileGeom lds;
     const int rc = setup_train<L>(s, a, TM_FWDBWD, &k, &w, &lds);
     if (rc != RULGNN_OK) return rc;
+    if (phase == -1) {
+        // the step's prepare kernel alone: clears the reduction cells (same dropout step) so that a harness timing the phases one by one
+        // runs them on valid BatchNorm statistics -- cells that keep accumulating from launch to launch drive the statistics out of range
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), step_scratch(k.cells, L),
+                           (StepState*)nullptr, a->seed, a->step, L, 1, 0, (int64_t)0, 0.f, 0.f, 0.f, (double)s->batch * (double)s->num_patch);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    }
     if (phase < 0 || phase > 4 * L) return RULGNN_EINVAL;
     const float* gy = a->dpred ? a->dpred : a->y;
+    if (lds.RW == 16 && path != RULGNN_STEP_CHAIN && k.has_dpred == 0 && stgcn_train_mx_shape_ok(s, a->x)) {
+        const MxTrainArgs m = mx_args<L>(s, a, k);
+        return mx_phase<L>(s, a, k, m, phase, stream, w.max_grid, nullptr);
+    }
+    if (path == RULGNN_STEP_MX) return RULGNN_EUNSUPPORTED;
     if (lds.RW == 16) return SinglePhase<16, L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
     if constexpr (L <= 2) return SinglePhase<64, L, 4 * L>::run(phase, k, a->x, a->params, gy, lds, w.max_grid, stream);
     return RULGNN_EUNSUPPORTED;
 }
 
-int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream) {
+int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream, int path) {
     switch (s->num_layers) {
-        case 1: return run_phase<1>(s, a, phase, stream);
-        case 2: return run_phase<2>(s, a, phase, stream);
-        case 3: return run_phase<3>(s, a, phase, stream);
+        case 1: return run_phase<1>(s, a, phase, stream, path);
+        case 2: return run_phase<2>(s, a, phase, stream, path);
+        case 3: return run_phase<3>(s, a, phase, stream, path);
         default: return RULGNN_EUNSUPPORTED;
     }
 }

@@ -195,7 +195,8 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
                                 const rulgnn_adam_args *opt, void *stream);
 
 /* The step with the launch form chosen by the caller (the entries above are RULGNN_STEP_AUTO); `opt` may be NULL (= forward +
- * backward only, rulgnn_stgcn_train_fwdbwd_f32).  For num_patch <= 64 there are two forms of the same arithmetic:
+ * backward only, rulgnn_stgcn_train_fwdbwd_f32).  For num_patch <= 64 there are two forms of the same fp32 arithmetic and, for the
+ * C-MAPSS shapes, a matrix-core form:
  *   RULGNN_STEP_CHAIN  prepare | 2L forward phase kernels | head | 2L backward phase kernels | finalize: 4L + 3 launches; any batch;
  *   RULGNN_STEP_COOP   the same phase bodies inside ONE launch, the BatchNorm reductions behind device-side grid barriers -- for
  *                      batches whose every 4-sample tile (1-sample for num_patch > 16) gets its own resident wavefront: at most
@@ -205,11 +206,22 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
  *                      a phase costs its prologue and one single-wavefront pass, not its launch), so it is an explicit option
  *                      only.  The workgroups spin on a counter in the workspace: do not share the device with a kernel that
  *                      waits on this stream.
- *   RULGNN_STEP_AUTO   = RULGNN_STEP_CHAIN.
+ *   RULGNN_STEP_MX     the chain with every phase on the f16 matrix cores (2-way split operands, fp32 accumulation:
+ *                      csrc/stgcn_train_mx.hip) and RECOMPUTATION instead of saved activations: a phase re-derives what it needs from
+ *                      the layer input (X_l + the 55-entry adjacency), so only layer inputs and two gradient tensors cross HBM between
+ *                      phases (13.5 KB per sample at 14 x 30 against 26.0 KB).  num_patch <= 15, num_layers <= 3, num_patch x patch_size a
+ *                      multiple of 4, 16-byte aligned x, MSE steps (args->y; not args->dpred): RULGNN_EUNSUPPORTED otherwise.  fp32-class
+ *                      results (same gates as the fp32 chain), not bit-identical to it.  f16 RANGE GUARD: activations are not
+ *                      rescaled; a value beyond the f16 range (inputs far from O(1): every dataset the reference wires is scaled to
+ *                      [0, 1] or [-1, 1]) ends as Inf / NaN in a sum or a gradient row, the step's status word is raised and the
+ *                      finalize kernel then leaves parameters, optimizer state and running statistics UNTOUCHED and reports a NaN
+ *                      loss (and NaN-free untouched state): repeat that step with RULGNN_STEP_CHAIN.
+ *   RULGNN_STEP_AUTO   = RULGNN_STEP_MX where it applies, else RULGNN_STEP_CHAIN.
  * num_patch > 64 (tiled path) ignores `path`. */
 #define RULGNN_STEP_AUTO  0
 #define RULGNN_STEP_CHAIN 1
 #define RULGNN_STEP_COOP  2
+#define RULGNN_STEP_MX    3
 int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                      const rulgnn_adam_args *opt, int32_t path, void *stream);
 
@@ -217,8 +229,9 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulg
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
  * backward), 2L+1+j = G_{2L-1-j} (BatchNorm/conv/theta backward).  rulgnn_stgcn_train_phase_f32 launches
  * exactly ONE of them on `stream` with the state a previous full step left in the workspace, so a
- * harness can time a single kernel with HIP events.  The reduction cells are not cleared: timings
- * are valid, numerical outputs are not. */
+ * harness can time a single kernel with HIP events.  The reduction cells are not cleared by a phase;
+ * phase -1 launches the step's prepare kernel (clears them): a harness that runs -1, 0, 1, ... 4L in
+ * order executes a numerically valid step, one launch at a time (with RULGNN_STEP_AUTO's choice of chain). */
 int rulgnn_stgcn_train_phase_count(int32_t num_layers);
 int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                  int32_t phase, void *stream);

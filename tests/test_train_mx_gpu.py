@@ -1,0 +1,145 @@
+"""-m gpu: the matrix-core training chain (RULGNN_STEP_MX, csrc/stgcn_train_mx.hip: every phase on the f16 matrix cores with split
+operands, activations recomputed from the layer input instead of saved) against the fp64 oracle and against the fp32 phase chain
+(RULGNN_STEP_CHAIN), through the C-ABI.  Same gates as tests/test_train_gpu.py: 1e-4 for predictions / loss / batch statistics,
+5e-4 for gradients, relative to the largest entry of each tensor.  Reference step: algorithms/algorithms.py:481-488."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gnn_rul_benchmarking_amd import _lib, params as PL
+from oracle import stgcn_oracle as O
+from test_train_gpu import oracle_step, check_grads, TOL, GTOL
+
+pytestmark = pytest.mark.gpu
+
+
+def abi_step(x_np, y_np, flat_np, N, P, L, path, dropout=0.0, seed=0, step=1, global_batch=None, sample_offset=0, adam=False):
+    """rulgnn_stgcn_train_step_path_f32 on cuda:0 (opt = NULL: forward + backward only, or a fused Adam step)."""
+    import gpu_util as G
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B = x_np.shape[0]
+    x = torch.from_numpy(np.ascontiguousarray(x_np.reshape(B, -1), np.float32)).to(dev)
+    y = torch.from_numpy(np.ascontiguousarray(y_np.reshape(B), np.float32)).to(dev)
+    prm = torch.from_numpy(flat_np.copy()).to(dev)
+    grads = torch.full_like(prm, float("nan"))
+    pred = torch.full((B,), float("nan"), device=dev)
+    loss = torch.full((1,), float("nan"), device=dev)
+    bnb = torch.full((L * 2 * 2 * 10,), float("nan"), device=dev)
+    shp = G.shape_struct(B, N, P, L)
+    nbytes = lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a = _lib.StgcnTrainArgs()
+    a.x = x.data_ptr(); a.y = y.data_ptr(); a.dpred = None
+    a.params = prm.data_ptr(); a.grads = grads.data_ptr(); a.pred = pred.data_ptr(); a.loss = loss.data_ptr()
+    a.bn_batch = bnb.data_ptr(); a.workspace = ws.data_ptr(); a.workspace_bytes = nbytes
+    a.global_batch = B if global_batch is None else global_batch
+    a.sample_offset = sample_offset
+    a.dropout_p = dropout; a.seed = seed; a.step = step
+    opt = None
+    m = v = bn = None
+    if adam:
+        m, v = torch.zeros_like(prm), torch.zeros_like(prm)
+        bn = torch.zeros(L * 2 * 2 * 10, device=dev)
+        opt = C.byref(_lib.AdamArgs(prm.data_ptr(), m.data_ptr(), v.data_ptr(), bn.data_ptr(), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0.1, None))
+    rc = lib.rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), opt, path, G.stream_ptr())
+    torch.cuda.synchronize()
+    return rc, {"pred": pred.cpu().numpy(), "loss": float(loss.item()), "grads": grads.cpu().numpy(), "bn_batch": bnb.cpu().numpy(),
+                "params": prm.cpu().numpy(), "m": None if m is None else m.cpu().numpy()}
+
+
+CASES = [(14, 30, 32, 2, 0.0), (14, 30, 1, 2, 0.0), (14, 30, 3, 2, 0.0), (14, 30, 5, 2, 0.2), (14, 30, 1027, 2, 0.0), (14, 30, 257, 2, 0.2),
+         (14, 50, 130, 2, 0.5), (14, 30, 77, 1, 0.2), (14, 30, 41, 3, 0.2), (14, 30, 8192, 2, 0.2),
+         (15, 16, 67, 2, 0.3), (12, 21, 35, 2, 0.2), (2, 6, 18, 2, 0.0), (8, 10, 19, 3, 0.1), (10, 10, 23, 1, 0.0)]
+
+
+@pytest.mark.parametrize("N,P,B,L,p", CASES)
+def test_mx_chain_matches_oracle_and_fp32_chain(N, P, B, L, p):
+    import gpu_util as G
+    rng = np.random.default_rng(N * 1000 + P * 10 + B)
+    prm = O.random_params(N, L, seed=B)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    flat, _ = PL.pack_numpy(prm, N, L)
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=99, step=5)
+    assert rc == 0, rc
+    pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, 99, 5)
+    assert G.rel_err(r["pred"], pred) < TOL
+    assert abs(r["loss"] - loss) < TOL * abs(loss)
+    assert G.rel_err(r["bn_batch"], bnb) < TOL
+    check_grads(r["grads"], gref, N, L)
+    # the fp32 phase chain on the same inputs: same function, different arithmetic (so not the same bits)
+    rc, c = abi_step(x, y, flat, N, P, L, _lib.STEP_CHAIN, dropout=p, seed=99, step=5)
+    assert rc == 0
+    assert G.rel_err(r["pred"], c["pred"]) < TOL
+    check_grads(r["grads"], c["grads"], N, L)
+    assert not np.array_equal(r["grads"], c["grads"])
+    # AUTO is the matrix-core chain where it applies: bit-identical to the explicit choice up to the order of the fp64 atomics
+    rc, u = abi_step(x, y, flat, N, P, L, _lib.STEP_AUTO, dropout=p, seed=99, step=5)
+    assert rc == 0
+    assert G.rel_err(u["grads"], r["grads"]) < 1e-6
+
+
+def test_mx_chain_shard_semantics():
+    """A rank's shard: MSE normalised by the global batch, dropout counters offset by the shard's first sample."""
+    import gpu_util as G
+    N, P, B = 14, 30, 96
+    rng = np.random.default_rng(6)
+    prm = O.random_params(N, 2, seed=7)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    flat, _ = PL.pack_numpy(prm, N, 2)
+    rc, r = abi_step(x, y, flat, N, P, 2, _lib.STEP_MX, dropout=0.3, seed=4, step=2, global_batch=4 * B, sample_offset=B)
+    assert rc == 0
+    pred, loss, gref, _ = oracle_step(prm, x, y, N, P, 2, 0.3, 4, 2, global_batch=4 * B, sample_offset=B)
+    assert G.rel_err(r["pred"], pred) < TOL
+    check_grads(r["grads"], gref, N, 2)
+
+
+def test_mx_chain_shape_rules():
+    import gpu_util as G
+    rng = np.random.default_rng(1)
+    for N, P in [(16, 16), (14, 31), (40, 64)]:            # num_patch > 15; num_patch x patch_size not a multiple of 4
+        prm = O.random_params(N, 2, seed=1)
+        flat, _ = PL.pack_numpy(prm, N, 2)
+        x = rng.uniform(0, 1, (8, N, P)).astype(np.float32)
+        y = rng.uniform(0, 1, (8,)).astype(np.float32)
+        rc, _ = abi_step(x, y, flat, N, P, 2, _lib.STEP_MX)
+        assert rc == _lib.EUNSUPPORTED
+        rc, _ = abi_step(x, y, flat, N, P, 2, _lib.STEP_AUTO)      # falls to the fp32 chain
+        assert rc == 0
+
+
+def test_mx_chain_range_guard_leaves_state_untouched():
+    """Inputs far outside O(1): the f16 operands overflow, the status word is raised, and the fused step reports a NaN loss with
+    parameters and optimizer state untouched; the fp32 chain takes the same step with finite results."""
+    N, P, B, L = 14, 30, 64, 2
+    rng = np.random.default_rng(3)
+    prm = O.random_params(N, L, seed=3)
+    flat, _ = PL.pack_numpy(prm, N, L)
+    x = (rng.uniform(0, 1, (B, N, P)) * 3.0e4).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, adam=True)
+    assert rc == 0
+    assert np.isnan(r["loss"])
+    assert np.array_equal(r["params"], flat) and not np.any(r["m"])
+    rc, c = abi_step(x, y, flat, N, P, L, _lib.STEP_CHAIN, adam=True)
+    assert rc == 0 and np.isfinite(c["loss"]) and not np.array_equal(c["params"], flat)
+
+
+def test_mx_chain_fused_adam_step_matches_fp32_chain():
+    import gpu_util as G
+    N, P, B, L = 14, 30, 500, 2
+    rng = np.random.default_rng(8)
+    prm = O.random_params(N, L, seed=8)
+    flat, _ = PL.pack_numpy(prm, N, L)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=0.2, seed=1, step=1, adam=True)
+    rc2, c = abi_step(x, y, flat, N, P, L, _lib.STEP_CHAIN, dropout=0.2, seed=1, step=1, adam=True)
+    assert rc == 0 and rc2 == 0
+    assert abs(r["loss"] - c["loss"]) < TOL * abs(c["loss"])
+    # Adam's first step moves every parameter by lr * sign(g): identical unless a gradient is ~0
+    assert np.mean(np.abs(r["params"] - c["params"]) < 1e-6) > 0.99
