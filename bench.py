@@ -88,14 +88,30 @@ def phase_names(L):
     return [f"F{i}" for i in range(2 * L)] + ["TOP"] + [f"G{2 * L - 1 - j}" for j in range(2 * L)]
 
 
-def phase_bytes_per_sample(name, N, P, L):
-    """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, N] fp32 state
-    tensor per sample (packed: only the N patch lanes of a row are stored) = 560 B at N = 14: X0, X_l, dX,
-    d(x0+H) and the activations H, z1, o0, z2 each layer hands from phase to phase (stgcn_train.hip::SavedSlot);
-    A = the [10, 10] adjacency = 400 B."""
+def phase_bytes_per_sample(name, N, P, L, chain="mx"):
+    """Algorithmic HBM bytes per sample of one phase kernel.  T = one [10, N] fp32 state tensor per sample
+    (packed: only the N patch lanes of a row are stored) = 560 B at N = 14; t = d X_L as (value, arg-max channel) per (sample, patch).
+
+    chain "mx" (matrix-core chain, csrc/stgcn_train_mx.hip: every phase recomputes from the layer input): A = the adjacency's 55
+    unique entries = 220 B; what crosses HBM between phases is X_l, the gated x-hat Q_l of BatchNorm 2l-1 (l >= 1), d(x0 + H) and d X_l.
+    chain "fp32" (row-mapped chain, csrc/stgcn_train.hip): A = 400 B lane layout, plus the saved H, z1, o0, z2 of every layer."""
     T = 10 * N * 4
-    A = 10 * 10 * 4
     TOPG = 2 * N * 4                                   # d X_L: (value, arg-max channel) per (sample, patch) instead of ten rows
+    if chain == "mx":
+        A = 55 * 4
+        if name == "F0":
+            return N * P * 4 + T + A                   # read the window; write X_0, adjacency
+        if name == "TOP":
+            return T + A + TOPG + 8                    # X_{L-1}, A; write d X_L; y in, pred out
+        i = int(name[1:])
+        l, blk = divmod(i, 2)
+        din = TOPG if l == L - 1 else T
+        if name[0] == "F":
+            return (T + A) if blk == 1 else (T + A + 2 * T)        # F_{2l+1}: X_l, A;  F_{2l}, l >= 1: X_{l-1}, A; write X_l, Q_l
+        if blk == 1:
+            return T + A + din + T                     # G_{2l+1}: X_l, A, d X_{l+1}; write d(x0 + H)
+        return (T + A + T) if l == 0 else (T + A + T + din + T + T)   # G_{2l}: X_l, A, d(x0 + H) (+ d X_{l+1}, Q_l in; d X_l out)
+    A = 10 * 10 * 4
     if name == "F0":
         return N * P * 4 + 3 * T + A                   # read the window; write X0, adjacency, H, z1
     if name == "TOP":
@@ -112,11 +128,14 @@ def phase_bytes_per_sample(name, N, P, L):
     return (4 * T + A) if l == 0 else (6 * T + A + din)   # G_{2l}: X_l, A, H, z1, d(x0+H) (+ dX in/out, z2 of the layer below)
 
 
-def _traffic_profile():
-    """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh): newest round first."""
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
+def _traffic_profile(chain="mx"):
+    """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh) of the given phase chain ("mx" = the
+    matrix-core chain of round 4, "fp32" = the row-mapped chain; summaries without a "chain" entry predate the former): newest round first."""
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if t.get("chain", "fp32") != chain:
+                continue
             t["file"] = "profiles/" + name
             return t
         except Exception:
@@ -124,9 +143,9 @@ def _traffic_profile():
     return None
 
 
-def measured_traffic(kernel_key, N, P, B):
+def measured_traffic(kernel_key, N, P, B, chain="mx"):
     """HBM bytes per launch from the committed PMC summary, scaled to this batch; None when the profiled workload does not match."""
-    t = _traffic_profile()
+    t = _traffic_profile(chain)
     if not t:
         return None
     w = t["workload"]
@@ -139,7 +158,7 @@ def forward_traffic(N, P, B):
     """HBM bytes per launch of the fused eval forward from its own PMC passes (tools/profile_forward.sh ->
     profiles/r0N_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
     the bench's other launches of that name), or None when this batch was not profiled."""
-    for rnd in ("r03", "r02"):                     # newest round first
+    for rnd in ("r04", "r03", "r02"):              # newest round first
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_forward_bs{B}_hbm_traffic.json")))
             w = t["workload"]
@@ -184,10 +203,16 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
     a = model._train_args(shp, x2d, yv, None, model._step)
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
     names = phase_names(L)
+    resolved = lib.rulgnn_stgcn_train_step_resolve(C.byref(shp), C.c_void_p(x2d.data_ptr()), int(model.step_path))
+    chain_kind = "mx" if resolved == _lib.STEP_MX else "fp32"
     # in-step timing: the phases run in the order of the real step with an event between each, so every kernel sees the
     # cache state its predecessor leaves (re-running ONE phase back to back keeps its ~250 MB working set warm in the
-    # 256-MB MALL and reads 8-15 % faster than the same kernel does inside the step)
+    # 256-MB MALL and reads 8-15 % faster than the same kernel does inside the step).  Phase -1 = the step's prepare kernel: the
+    # reduction cells are cleared, so the phases run on valid BatchNorm statistics.
     def chain(evs=None):
+        _lib.check(lib.rulgnn_stgcn_train_phase_f32(C.byref(shp), C.byref(a), -1, st()), "prepare")
+        if evs is not None:
+            evs[0].record()
         for ph in range(len(names)):
             _lib.check(lib.rulgnn_stgcn_train_phase_f32(C.byref(shp), C.byref(a), ph, st()), "phase")
             if evs is not None:
@@ -198,12 +223,11 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
     acc = [0.0] * len(names)
     for _ in range(iters):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
-        evs[0].record()
         chain(evs)
         torch.cuda.synchronize()
         for ph in range(len(names)):
             acc[ph] += evs[ph].elapsed_time(evs[ph + 1])
-    per = {name: {"ms": acc[ph] / iters, "bytes_per_sample": phase_bytes_per_sample(name, N, P, L)} for ph, name in enumerate(names)}
+    per = {name: {"ms": acc[ph] / iters, "bytes_per_sample": phase_bytes_per_sample(name, N, P, L, chain_kind)} for ph, name in enumerate(names)}
     iso = None
     if isolated:
         iso = {}
@@ -215,15 +239,23 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
     d = per[dom]
     ach = alg * B / (d["ms"] * 1e-3) / 1e9                               # algorithmic bytes of the launch / its duration
     ach_traffic = d["bytes_per_sample"] * B / (d["ms"] * 1e-3) / 1e9      # the bytes this phase really moves
-    prof = _traffic_profile()
+    prof = _traffic_profile(chain_kind)
     total_traffic = None
     if prof and (prof["workload"]["num_patch"], prof["workload"]["patch_size"]) == (N, P):
         total_traffic = sum(k["hbm_bytes_per_sample"] for n_, k in prof["kernels"].items() if n_ in names)
-    roof = {"bound": "hbm", "kernel": f"stgcn_train_phase_kernel<{dom}>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, N, P, B),
+    if chain_kind == "mx":
+        kname = "stgcn_train_f0_mx_kernel (F0)" if dom == "F0" else f"stgcn_train_mx_kernel<{dom}>"
+    else:
+        kname = f"stgcn_train_phase_kernel<{dom}>"
+    algorithmic_step = sum(v["bytes_per_sample"] for v in per.values())
+    roof = {"bound": "hbm", "kernel": kname, "chain": "matrix-core chain, activations recomputed (RULGNN_STEP_MX)" if chain_kind == "mx"
+            else "row-mapped fp32 chain (RULGNN_STEP_CHAIN)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(dom, N, P, B, chain_kind),
             "algorithmic_bytes_per_sample": alg,
             "frac_traffic": round(ach_traffic / HBM_PEAK_GBS, 4), "phase_bytes_per_sample": d["bytes_per_sample"],
             "step_algorithmic_frac": round(alg * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "step_accounted_bytes_per_sample": algorithmic_step,
+            "accounted_over_algorithmic": round(algorithmic_step / alg, 2),
             "traffic_over_algorithmic": round(total_traffic / alg, 2) if total_traffic else None,
             "step_traffic_bytes_per_sample": round(total_traffic, 1) if total_traffic else None,
             "traffic_source": prof["file"] if prof else None,

@@ -221,6 +221,7 @@ _SIGNATURES = {
                                                C.c_void_p]),
     "rulgnn_stgcn_train_step_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs), C.c_int32,
                                                     C.c_void_p]),
+    "rulgnn_stgcn_train_step_resolve": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_int32]),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
     "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
@@ -228,6 +229,11 @@ _SIGNATURES = {
                                         C.c_void_p]),
     "rulgnn_bn_running_update_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                 C.c_int32, C.c_void_p]),
+    "rulgnn_adam_step_guarded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                C.c_void_p, C.c_void_p]),
+    "rulgnn_bn_running_update_guarded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
+                                                        C.c_int32, C.c_void_p, C.c_void_p]),
     "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),
     "rulgnn_stgnn_workspace_bytes": (C.c_size_t, [C.POINTER(StgnnShape)]),
     "rulgnn_stgnn_terms_f32": (C.c_int, [C.POINTER(StgnnShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -88,13 +88,22 @@ class ST_GCN(Algorithm):
         model = self.model
         if not model.training:
             raise RuntimeError("update() needs algorithm.train() (BatchNorm batch statistics, dropout)")
-        if self.dp is not None:
-            loss = self.dp.step(model, self.optimizer, X, y, global_batch, sample_offset)
-        elif getattr(self, "_graphed", None) is not None:
-            loss = self._graphed.update(X, y)
-        else:
-            loss = self._eager_update(X, y)
+        graphed = self.dp is None and getattr(self, "_graphed", None) is not None
+        loss = self._one_step(X, y, global_batch, sample_offset)
+        # f16 range guard of the matrix-core chain (RULGNN_STEP_MX): a NaN loss with every piece of state untouched.  With the
+        # reference's per-step loss read-back the step is repeated on the fp32 chain and the model stays there (data parallel: the
+        # NaN is part of the all-reduced bucket, so every rank takes this branch).  A captured hipGraph replays one path: no retry.
+        if self.sync_loss and not graphed and getattr(model, "guard_tensor", None) is not None and not bool(torch.isfinite(loss)):
+            model.retry_on_fp32_chain(self.optimizer)
+            loss = self._one_step(X, y, global_batch, sample_offset)
         return self._finish(loss)
+
+    def _one_step(self, X, y, global_batch=None, sample_offset=None):
+        if self.dp is not None:
+            return self.dp.step(self.model, self.optimizer, X, y, global_batch, sample_offset)
+        if getattr(self, "_graphed", None) is not None:
+            return self._graphed.update(X, y)
+        return self._eager_update(X, y)
 
     def _eager_update(self, X, y):
         _, loss = self.model.fused_train_step(X, y, self.optimizer)      # one C call: fwd + MSE + bwd + Adam + BN stats

@@ -8,7 +8,11 @@ namespace rulgnn {
 
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
-                                 float beta2, float eps, float wd, float gscale, const StepState* __restrict__ st) {
+                                 float beta2, float eps, float wd, float gscale, const StepState* __restrict__ st,
+                                 const float* __restrict__ guard) {
+    // guarded step (rulgnn_adam_step_guarded_f32): a non-finite *guard -- the loss behind the gradient in the bucket, NaN when the
+    // matrix-core training chain raised its f16 range status (stgcn_train_mx.hip) -- leaves parameters and moments untouched
+    if (guard && !(fabsf(*guard) <= 3.0e38f)) return;
     if (st) {                      // device step state: bias corrections of the step the prepare kernel just advanced to
         lr_over_bc1 = st->lr_over_bc1;
         inv_sqrt_bc2 = st->inv_sqrt_bc2;
@@ -26,10 +30,11 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
 }
 
 __global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
-                                         float unbias, int from_moments) {
+                                         float unbias, int from_moments, const float* __restrict__ guard) {
     // layout [n_bn][2 (mean, var)][F]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bn * 2 * F) return;
+    if (guard && !(fabsf(*guard) <= 3.0e38f)) return;
     const bool is_var = (i / F) % 2 == 1;
     float b = batch[i];
     if (is_var) {
@@ -84,7 +89,7 @@ int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream
 }
 
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t stream, void* step_state) {
+              float eps, float wd, float gscale, hipStream_t stream, void* step_state, const float* guard) {
     if (n <= 0) return RULGNN_OK;
     if (step_state) {
         const int rc = step_prepare_adam(step_state, lr, beta1, beta2, stream);
@@ -99,18 +104,18 @@ int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t s
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)grid), dim3(block), 0, stream, p, g, m, v, n,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale,
-                       static_cast<const StepState*>(step_state));
+                       static_cast<const StepState*>(step_state), guard);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
-                      hipStream_t stream) {
+                      hipStream_t stream, const float* guard) {
     const int n_bn = num_layers * 2;
     const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
     const int total = n_bn * 2 * F;
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
-                       momentum, unbias, from_moments);
+                       momentum, unbias, from_moments, guard);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

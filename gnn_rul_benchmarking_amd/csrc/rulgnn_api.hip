@@ -3,6 +3,7 @@
 
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
+#include "stgcn_train_mx.hpp"
 
 using namespace rulgnn;
 
@@ -200,6 +201,16 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape* shape, const rulg
     return stgcn_train_step(shape, args, opt, st, path);
 }
 
+int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape* shape, const float* x, int32_t path) {
+    const int rc = validate_shape(shape);
+    if (rc != RULGNN_OK) return rc;
+    if (tiled(shape)) return RULGNN_EUNSUPPORTED;
+    if (path == RULGNN_STEP_CHAIN || path == RULGNN_STEP_COOP) return path;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
+    if (stgcn_train_mx_shape_ok(shape, x)) return RULGNN_STEP_MX;
+    return path == RULGNN_STEP_MX ? RULGNN_EUNSUPPORTED : RULGNN_STEP_CHAIN;
+}
+
 int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }
 
 int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args, int32_t phase,
@@ -218,6 +229,24 @@ int rulgnn_adam_step_f32(float* params, const float* grads, float* exp_avg, floa
     if (rc != RULGNN_OK) return rc;
     return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
                      static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_adam_step_guarded_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                                 const float* guard, void* stream) {
+    if (n < 0 || step < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({params, grads, exp_avg, exp_avg_sq, guard});
+    if (rc != RULGNN_OK) return rc;
+    return adam_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                     static_cast<hipStream_t>(stream), nullptr, guard);
+}
+
+int rulgnn_bn_running_update_guarded_f32(float* bn_stats, const float* bn_batch, int32_t num_layers, int64_t count,
+                                         float momentum, int32_t from_moments, const float* guard, void* stream) {
+    if (num_layers < 1 || num_layers > 8 || count < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({bn_stats, bn_batch, guard});
+    if (rc != RULGNN_OK) return rc;
+    return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, from_moments, static_cast<hipStream_t>(stream), guard);
 }
 
 int rulgnn_bn_running_update_f32(float* bn_stats, const float* bn_batch, int32_t num_layers, int64_t count,

@@ -631,7 +631,10 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         const int c = slot_chan(4 * g + r);
-                        if (c >= 0 && c <= ca_col) pa[b * NPAIR + sym(c, ca_col)] = gram[4 * b + r];
+                        // the entry as its (hi | lo << 16) f16 pair, as the front end split it: the later phases permute bytes instead of splitting
+                        const unsigned ph = r < 2 ? adjB[b][0] : adjB[b][1], pl = r < 2 ? adjB[b][2] : adjB[b][3];
+                        const unsigned pair = (r & 1) ? ((ph >> 16) | (pl & 0xFFFF0000u)) : ((ph & 0xFFFFu) | (pl << 16));
+                        if (c >= 0 && c <= ca_col) pa[b * NPAIR + sym(c, ca_col)] = __builtin_bit_cast(float, pair);
                     }
                 }
             }

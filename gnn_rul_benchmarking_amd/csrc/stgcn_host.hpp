@@ -165,12 +165,12 @@ int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int m
 int stconv_bn_running_update(const rulgnn_stconv_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
                              int from_moments, hipStream_t stream);
 int adam_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2,
-              float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr);
+              float eps, float wd, float gscale, hipStream_t stream, void* step_state = nullptr, const float* guard = nullptr);
 int step_state_set(void* state, uint64_t dropout_step, int64_t adam_step, hipStream_t stream);
 int step_prepare_dropout(void* state, uint64_t seed, int num_layers, hipStream_t stream);   // ++dropout_step, keys
 int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream_t stream); // ++adam_step, bias corrections
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
-                      hipStream_t stream);
+                      hipStream_t stream, const float* guard = nullptr);
 
 size_t stgnn_workspace_bytes(const rulgnn_stgnn_shape* s);
 int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float* adj, hipStream_t st);

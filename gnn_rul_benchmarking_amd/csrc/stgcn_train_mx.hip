@@ -40,6 +40,7 @@
 // Memory.  Inputs arrive by LDS-DMA one tile ahead (each record is requested again as soon as its last LDS read has retired), outputs
 // leave one tile late, right behind the s_waitcnt vmcnt(0) that also counts stores (stgcn_forward_mx.hip, round 3).
 #include <cstdlib>
+#include <type_traits>
 
 #include "stgcn_host.hpp"
 #include "stgcn_mx.hpp"
@@ -194,7 +195,6 @@ struct MxTrainK {
     uint32_t drop_thr;
     float gscale, inv_gscale;
     int do_backward;
-    int debug_skip;
 };
 
 // =====================================================================================================================
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     const bool col_ok = col < N;
     const float colm = col_ok ? 1.f : 0.f;
     const int pitch = 4 * N;
-    int xoff[3], aoff[4], chan[3];
+    int xoff[3], aoff[3], chan[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int c = slot_chan(4 * g + r);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     {
         const int cc = slot_chan(col);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 3; ++r) {
             const int c = slot_chan(4 * g + r);
             aoff[r] = (c >= 0 && cc >= 0) ? sym(c, cc) : -1;
         }
@@ -385,20 +385,24 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
     // ---- building blocks of a tile ------------------------------------------------------------------------------------------------------
     // T = (A X)^T, Hp' = (1 + a)/2 (theta (A X) + b), H = leaky(Hp)
-    auto stage_T = [&](const float (&X)[4][3], const u32x4 (&adjB)[4], f32x4 (&T)[4], Op2 (*xo)[4]) {
+    // (generic in the number of samples in flight: four in the forward phases, two per half tile in the backward phases, whose working set
+    // does not fit 256 registers at four)
+    auto stage_T = [&](const auto& X, const auto& adjB, auto& T, auto& xo) {
+        constexpr int NS = std::extent_v<std::remove_reference_t<decltype(T)>>;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const Split2 p01 = split2(X[s][0], X[s][1]), p2 = split2(X[s][2], 0.f);
             const Op2 o = {u32x4{p01.hi, p2.hi, p01.hi, p2.hi}, u32x4{p01.lo, p2.lo, p01.lo, p2.lo}};
-            if (xo) (*xo)[s] = o;
+            xo[s] = o;
             T[s] = mfma16z(o.h, adjB[s]);
             T[s] = mfma16(o.l, adjB[s], T[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto stage_Hp = [&](const f32x4 (&T)[4], const ThetaOp& th, f32x4 (&Hp)[4]) {
+    auto stage_Hp = [&](const auto& T, const ThetaOp& th, auto& Hp) {
+        constexpr int NS = std::extent_v<std::remove_reference_t<decltype(Hp)>>;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const Split2 p01 = split2(T[s][0], T[s][1]), p23 = split2(T[s][2], T[s][3]);
             const u32x4 ta = {p01.hi, p23.hi | t_bias, p01.lo, p23.lo};
             Hp[s] = mfma16z(ta, th.hi);
@@ -407,30 +411,32 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         __builtin_amdgcn_sched_barrier(0);
     };
     // z = W x [D ; D of column t - d] (+ shift x partner); keeps the packed operand halves of D and of the shifted column
-    auto stage_conv = [&](const float (&D)[4][3], float partner, const ConvOp& w, int rd, int rd_lo, f32x4 (&z)[4], Pk (*keep)[4], Shifted (*keep_sh)[4]) {
-        u32x4 bh[4], bl[4];
+    auto stage_conv = [&](const auto& D, float partner, const ConvOp& w, int rd, int rd_lo, auto& z, auto& keep, auto& keep_sh) {
+        constexpr int NS = std::extent_v<std::remove_reference_t<decltype(z)>>;
+        u32x4 bh[NS], bl[NS];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const Pk p = pack3(D[s][0], D[s][1], D[s][2], partner);
             const Shifted prev = shift_read(sh_tile, rd, rd_lo, lane, p);
             bh[s] = cat(p.hi, prev.hi);
             bl[s] = cat(p.lo, prev.lo);
-            if (keep) (*keep)[s] = p;
-            if (keep_sh) (*keep_sh)[s] = prev;
+            keep[s] = p;
+            keep_sh[s] = prev;
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             z[s] = mfma16z(w.hi, bh[s]);
             z[s] = mfma16(w.hi, bl[s], z[s]);
             z[s] = mfma16(w.lo, bh[s], z[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto leaky_of = [&](const f32x4 (&Hp)[4], float (&H)[4][3]) {
+    auto leaky_of = [&](const auto& Hp, auto& H) {
+        constexpr int NS = std::extent_v<std::remove_reference_t<decltype(H)>>;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             keep_until_here(Hp[s][3]);
 #pragma unroll
             for (int r = 0; r < 3; ++r) H[s][r] = fmaf((1.f - LEAKY) / (1.f + LEAKY), __builtin_fabsf(Hp[s][r]), Hp[s][r]);
@@ -441,10 +447,13 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                           float (*xh1_out)[4][3], float (*y2_out)[4][3], float (*q_out)[4][3]) {
         f32x4 T[4], Hp[4], z[4];
         float H[4][3], V[4][3];
-        stage_T(X, adjB, T, nullptr);
+        Op2 xo[4];
+        Pk pk[4];
+        Shifted ps[4];
+        stage_T(X, adjB, T, xo);
         stage_Hp(T, k.th, Hp);
         leaky_of(Hp, H);
-        stage_conv(H, 1.0f, k.w[0], sh_rd1, sh_rd1_lo, z, nullptr, nullptr);
+        stage_conv(H, 1.0f, k.w[0], sh_rd1, sh_rd1_lo, z, pk, ps);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             keep_until_here(z[s][3]);
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 V[s][r] = relu2(fmaf(2.f, H[s][r], relu2(y1)));                  // 4 o0
             }
         }
-        stage_conv(V, 1.0f, k.w[1], sh_rd2, sh_rd2_lo, z, nullptr, nullptr);
+        stage_conv(V, 1.0f, k.w[1], sh_rd2, sh_rd2_lo, z, pk, ps);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             keep_until_here(z[s][3]);
@@ -515,12 +524,17 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                float q[4];
+                // F_0 left every entry as its (hi | lo << 16) f16 pair: the operand is four byte permutes, no split (slot 3 of every
+                // lane group is padding: always zero)
+                unsigned q[3];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q[r] = smem[(aoff[r] >= 0 ? off_A + aoff[r] : off_zero) + s * 55];
-                if (s >= ns) { q[0] = q[1] = q[2] = q[3] = 0.f; X[s][0] = X[s][1] = X[s][2] = 0.f; }
-                const Split2 p01 = split2(q[0], q[1]), p23 = split2(q[2], q[3]);
-                adjB[s] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
+                for (int r = 0; r < 3; ++r) q[r] = __builtin_bit_cast(unsigned, smem[(aoff[r] >= 0 ? off_A + aoff[r] : off_zero) + s * 55]);
+                adjB[s] = u32x4{__builtin_amdgcn_perm(q[1], q[0], 0x05040100u), q[2] & 0xFFFFu, __builtin_amdgcn_perm(q[1], q[0], 0x07060302u), q[2] >> 16};
+            }
+            if (ns < 4) {                       // samples beyond the batch (last tile): whatever the workspace holds there must not reach an accumulator
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if (s >= ns) { adjB[s] = u32x4{0u, 0u, 0u, 0u}; X[s][0] = X[s][1] = X[s][2] = 0.f; }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -543,13 +557,16 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             }
             f32x4 T[4], Hp[4], z[4];
             float H[4][3];
-            stage_T(X, adjB, T, nullptr);
+            Op2 xo[4];
+            Pk pk[4];
+            Shifted ps[4];
+            stage_T(X, adjB, T, xo);
             stage_Hp(T, kc.th, Hp);
             leaky_of(Hp, H);
             if constexpr (BLK == 0) {
-                stage_conv(H, 0.f, kc.w[0], sh_rd1, sh_rd1_lo, z, nullptr, nullptr);          // raw z1
+                stage_conv(H, 0.f, kc.w[0], sh_rd1, sh_rd1_lo, z, pk, ps);          // raw z1
             } else {
-                stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, nullptr, nullptr);         // x-hat of BatchNorm 2l
+                stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, pk, ps);         // x-hat of BatchNorm 2l
                 float V[4][3];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 #pragma unroll
                     for (int r = 0; r < 3; ++r) V[s][r] = relu2(fmaf(2.f, H[s][r], relu2(fmaf(kc.gam[0][r], z[s][r], kc.bet[0][r]))));
                 }
-                stage_conv(V, 0.f, kc.w[1], sh_rd2, sh_rd2_lo, z, nullptr, nullptr);          // raw z2
+                stage_conv(V, 0.f, kc.w[1], sh_rd2, sh_rd2_lo, z, pk, ps);          // raw z2
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -675,251 +692,229 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 }
             } else if constexpr (GRAD_IN) {
                 ld_tile(off_DX, gin);
+                if (ns < 4) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s >= ns) gin[s][0] = gin[s][1] = gin[s][2] = 0.f;
+                    for (int s = 0; s < 4; ++s)
+                        if (s >= ns) gin[s][0] = gin[s][1] = gin[s][2] = 0.f;
+                }
             }
             float SB[4][3];
             if constexpr (NEED_SB) {
                 ld_tile(off_SB, SB);
+                if (ns < 4) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s >= ns) SB[s][0] = SB[s][1] = SB[s][2] = 0.f;
+                    for (int s = 0; s < 4; ++s)
+                        if (s >= ns) SB[s][0] = SB[s][1] = SB[s][2] = 0.f;
+                }
             }
             float Q[4][3];
             if constexpr (BWD_PREV) {
                 ld_tile(off_XP, Q);
+                if (ns < 4) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    if (s >= ns) Q[s][0] = Q[s][1] = Q[s][2] = INFINITY;
+                    for (int s = 0; s < 4; ++s)
+                        if (s >= ns) Q[s][0] = Q[s][1] = Q[s][2] = INFINITY;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             if (nt < a.ntiles) { req_SB(nt); req_DX(nt); req_XP(nt); }
 
-            // ---- layer LY forward again, as far as this phase needs it -------------------------------------------------------------------
-            f32x4 T[4], Hp[4], z[4];
-            float H[4][3];
-            Op2 xo[4];
-            stage_T(X, adjB, T, &xo);
-            stage_Hp(T, kc.th, Hp);
-            leaky_of(Hp, H);
-            Pk hk[4];
-            Shifted hks[4];
-            stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, &hk, &hks);                    // x-hat of BatchNorm 2l
-            float xh0[4][3], y1[4][3];
+            // ---- two samples at a time (the working set of four does not fit the register file) ------------------------------------------------
+            auto g_half = [&](auto HS_) {
+                constexpr int HS = decltype(HS_)::value;
+                constexpr int NS = 2;
+                float Xh[NS][3];
+                u32x4 ad[NS];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                keep_until_here(z[s][3]);
+                for (int e = 0; e < NS; ++e) {
+                    ad[e] = adjB[HS + e];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    xh0[s][r] = z[s][r];
-                    y1[s][r] = fmaf(kc.gam[0][r], z[s][r], kc.bet[0][r]);
+                    for (int r = 0; r < 3; ++r) Xh[e][r] = X[HS + e][r];
                 }
-            }
-
-            if constexpr (BLK == 1) {
-                // ---- G_{2l+1}: BatchNorm 2l+1 backward, conv_block2 gradient, d(x0 + H) -------------------------------------------------------
-                float V[4][3];
+                // layer LY forward again, as far as this phase needs it
+                f32x4 T[NS], Hp[NS], z[NS], AXd[NS];
+                float H[NS][3];
+                Op2 xo[NS];
+                stage_T(Xh, ad, T, xo);
+                if constexpr (BLK == 0) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+                    for (int e = 0; e < NS; ++e) {
+                        AXd[e] = mfma16z(ad[e], xo[e].h);                                    // (A X) in the D layout: rows c, columns k
+                        AXd[e] = mfma16(ad[e], xo[e].l, AXd[e]);
+                    }
+                }
+                stage_Hp(T, kc.th, Hp);
+                leaky_of(Hp, H);
+                Pk hk[NS];
+                Shifted hks[NS];
+                stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, hk, hks);                  // x-hat of BatchNorm 2l
+                float xh0[NS][3], y1[NS][3];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) V[s][r] = relu2(fmaf(2.f, H[s][r], relu2(y1[s][r])));
-                Pk vk[4];
-                Shifted vks[4];
-                stage_conv(V, 1.0f, kc.w[1], sh_rd2, sh_rd2_lo, z, &vk, &vks);                 // x-hat of BatchNorm 2l+1
-                float gsum[4][3], dz[4][3];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    keep_until_here(z[s][3]);
+                for (int e = 0; e < NS; ++e) {
+                    keep_until_here(z[e][3]);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const float xh = z[s][r];
-                        const float y2 = fmaf(kc.gam[1][r], xh, kc.bet[1][r]);
-                        float gq = gin[s][r];
-                        if (use_drop) {
-                            const uint32_t h = lowbias32((sbase[s] + dro[r]) ^ dkey[LY]);
-                            gq = h >= a.drop_thr ? gq * a.drop_scale : 0.f;
-                        }
-                        const bool x1pos = y2 > 0.f;
-                        gsum[s][r] = (x1pos || V[s][r] > 0.f) ? gq : 0.f;                    // d(x1 + o0): o1 = relu(x1 + o0) > 0
-                        const float dy = x1pos ? gq : 0.f;
-                        const float v = bA[r] * (fmaf(-xh, bk2[r], dy) - bk1[r]);
-                        dz[s][r] = (s < ns) ? v * colm : 0.f;
+                        xh0[e][r] = z[e][r];
+                        y1[e][r] = fmaf(kc.gam[0][r], z[e][r], kc.bet[0][r]);
                     }
                 }
-                // d o0 = W2^T-conv(d z2); weight gradient from the transposed tiles
-                f32x4 dzT[4], hT[4], hsT[4], dI[4];
-                {
-                    u32x4 bh[4], bl[4];
+                // the operand the weight gradient transposes: conv_block1: H; conv_block2: V = 4 o0
+                Pk dk[NS];                              // packed d z (BLK 1) -- later the packed d Hp (BLK 0)
+                float dz[NS][3], gsum[NS][3], V[NS][3];
+                if constexpr (BLK == 1) {
+                    // ---- G_{2l+1}: BatchNorm 2l+1 backward, conv_block2 gradient, d(x0 + H) ---------------------------------------------------
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const Pk p = pack3(dz[s][0], dz[s][1], dz[s][2], 0.f);
-                        const Shifted nx = shift_read(sh_tile, sh_bk, sh_bk_lo, lane, p);
-                        bh[s] = cat(p.hi, nx.hi);
-                        bl[s] = cat(p.lo, nx.lo);
-                        dzT[s] = mfma16z(cat(p.hi, p.lo), ident);
-                        hT[s] = mfma16z(cat(vk[s].hi, vk[s].lo), ident);
-                        hsT[s] = mfma16z(cat(vks[s].hi, vks[s].lo), ident);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int e = 0; e < NS; ++e)
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        dI[s] = mfma16z(wT.hi, bh[s]);
-                        dI[s] = mfma16(wT.hi, bl[s], dI[s]);
-                        dI[s] = mfma16(wT.lo, bh[s], dI[s]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // weight gradient: acc += dzT x [hT | hsT]  (contraction over the columns t = 4 g + r of the transposed tiles)
+                        for (int r = 0; r < 3; ++r) V[e][r] = relu2(fmaf(2.f, H[e][r], relu2(y1[e][r])));
+                    stage_conv(V, 1.0f, kc.w[1], sh_rd2, sh_rd2_lo, z, hk, hks);              // x-hat of BatchNorm 2l+1; hk, hks <- V
 #pragma unroll
-                for (int sp = 0; sp < 4; sp += 2) {
-                    Pk q[2], u[2], us[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int s = sp + e;
-                        q[e] = pack3(dzT[s][0], dzT[s][1], dzT[s][2], dzT[s][3]);
-                        u[e] = pack3(hT[s][0], hT[s][1], hT[s][2], hT[s][3]);
-                        us[e] = pack3(hsT[s][0], hsT[s][1], hsT[s][2], hsT[s][3]);
-                        acc_w0 = mfma16(cat(q[e].hi, q[e].lo), cat(u[e].hi, u[e].hi), acc_w0);
-                        acc_w1 = mfma16(cat(q[e].hi, q[e].lo), cat(us[e].hi, us[e].hi), acc_w1);
-                    }
-                    acc_w0 = mfma16(cat(q[0].hi, q[1].hi), cat(u[0].lo, u[1].lo), acc_w0);
-                    acc_w1 = mfma16(cat(q[0].hi, q[1].hi), cat(us[0].lo, us[1].lo), acc_w1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // d(x0 + H) and the sums of BatchNorm 2l
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    keep_until_here(dI[s][3]);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        float gq = dI[s][r] + gsum[s][r];
-                        gq = (V[s][r] > 0.f && s < ns) ? gq * colm : 0.f;
-                        pend_v[s][r] = gq;
-                        const float dy = y1[s][r] > 0.f ? gq : 0.f;
-                        s_a[r] += dy;
-                        s_b[r] = fmaf(dy, xh0[s][r], s_b[r]);
-                    }
-                }
-                pend = true; pend_tile = tile; pend_ns = ns;
-                continue;
-            } else {
-                // ---- G_{2l}: BatchNorm 2l backward, conv_block1 + theta gradients, d X_l -----------------------------------------------------
-                float dz[4][3];
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float dy = y1[s][r] > 0.f ? SB[s][r] : 0.f;
-                        const float v = bA[r] * (fmaf(-xh0[s][r], bk2[r], dy) - bk1[r]);
-                        dz[s][r] = (s < ns) ? v * colm : 0.f;
-                    }
-                f32x4 dzT[4], hT[4], hsT[4], dI[4], AXd[4];
-                {
-                    u32x4 bh[4], bl[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const Pk p = pack3(dz[s][0], dz[s][1], dz[s][2], 0.f);
-                        const Shifted nx = shift_read(sh_tile, sh_bk, sh_bk_lo, lane, p);
-                        bh[s] = cat(p.hi, nx.hi);
-                        bl[s] = cat(p.lo, nx.lo);
-                        dzT[s] = mfma16z(cat(p.hi, p.lo), ident);
-                        hT[s] = mfma16z(cat(hk[s].hi, hk[s].lo), ident);
-                        hsT[s] = mfma16z(cat(hks[s].hi, hks[s].lo), ident);
-                        AXd[s] = mfma16z(adjB[s], xo[s].h);                                  // (A X) in the D layout: rows c, columns k
-                        AXd[s] = mfma16(adjB[s], xo[s].l, AXd[s]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        dI[s] = mfma16z(wT.hi, bh[s]);
-                        dI[s] = mfma16(wT.hi, bl[s], dI[s]);
-                        dI[s] = mfma16(wT.lo, bh[s], dI[s]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int sp = 0; sp < 4; sp += 2) {
-                    Pk q[2], u[2], us[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int s = sp + e;
-                        q[e] = pack3(dzT[s][0], dzT[s][1], dzT[s][2], dzT[s][3]);
-                        u[e] = pack3(hT[s][0], hT[s][1], hT[s][2], hT[s][3]);
-                        us[e] = pack3(hsT[s][0], hsT[s][1], hsT[s][2], hsT[s][3]);
-                        acc_w0 = mfma16(cat(q[e].hi, q[e].lo), cat(u[e].hi, u[e].hi), acc_w0);
-                        acc_w1 = mfma16(cat(q[e].hi, q[e].lo), cat(us[e].hi, us[e].hi), acc_w1);
-                    }
-                    acc_w0 = mfma16(cat(q[0].hi, q[1].hi), cat(u[0].lo, u[1].lo), acc_w0);
-                    acc_w1 = mfma16(cat(q[0].hi, q[1].hi), cat(us[0].lo, us[1].lo), acc_w1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // d Hp = leaky'(Hp) (d H + d(x0 + H)); theta gradient: contraction over the channel slots
-                Pk dk[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    keep_until_here(dI[s][3]);
-                    float dHp[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float gq = dI[s][r] + SB[s][r];
-                        const float v = Hp[s][r] > 0.f ? gq : gq * LEAKY;
-                        dHp[r] = (s < ns) ? v * colm : 0.f;
-                        acc_b += dHp[r];
-                    }
-                    dk[s] = pack3(dHp[0], dHp[1], dHp[2], 0.f);
-                }
-#pragma unroll
-                for (int sp = 0; sp < 4; sp += 2) {
-                    Pk ax[2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int s = sp + e;
-                        keep_until_here(AXd[s][3]);
-                        ax[e] = pack3(AXd[s][0], AXd[s][1], AXd[s][2], 0.f);
-                        acc_th = mfma16(cat(dk[s].hi, dk[s].lo), cat(ax[e].hi, ax[e].hi), acc_th);
-                    }
-                    acc_th = mfma16(cat(dk[sp].hi, dk[sp + 1].hi), cat(ax[0].lo, ax[1].lo), acc_th);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (LY >= 1) {
-                    // d X_l = A (d Hp theta) + d X_{l+1}: U = (A d Hp)^T, then U x theta
-                    f32x4 U[4], dXl[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        U[s] = mfma16z(cat(dk[s].hi, dk[s].hi), adjB[s]);
-                        U[s] = mfma16(cat(dk[s].lo, dk[s].lo), adjB[s], U[s]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const Split2 p01 = split2(U[s][0], U[s][1]), p23 = split2(U[s][2], U[s][3]);
-                        const u32x4 ua = {p01.hi, p23.hi, p01.lo, p23.lo};
-                        dXl[s] = mfma16z(ua, thN.hi);
-                        dXl[s] = mfma16(ua, thN.lo, dXl[s]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the sums of BatchNorm 2l-1: F_{2l} left its x-hat where the gradient passes (ReLU gate, dropout), +inf elsewhere
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        keep_until_here(dXl[s][3]);
+                    for (int e = 0; e < NS; ++e) {
+                        keep_until_here(z[e][3]);
 #pragma unroll
                         for (int r = 0; r < 3; ++r) {
-                            const float dX = (s < ns) ? (dXl[s][r] + gin[s][r]) * colm : 0.f;
-                            pend_v[s][r] = dX;
-                            const bool open = Q[s][r] < INFINITY;
-                            const float dy = open ? dX * a.drop_scale : 0.f;
-                            s_a[r] += dy;
-                            s_b[r] = fmaf(dy, open ? Q[s][r] : 0.f, s_b[r]);
+                            const float xh = z[e][r];
+                            const float y2 = fmaf(kc.gam[1][r], xh, kc.bet[1][r]);
+                            float gq = gin[HS + e][r];
+                            if (use_drop) {
+                                const uint32_t h = lowbias32((sbase[HS + e] + dro[r]) ^ dkey[LY]);
+                                gq = h >= a.drop_thr ? gq * a.drop_scale : 0.f;
+                            }
+                            const bool x1pos = y2 > 0.f;
+                            gsum[e][r] = (x1pos || V[e][r] > 0.f) ? gq : 0.f;                // d(x1 + o0): o1 = relu(x1 + o0) > 0
+                            const float dy = x1pos ? gq : 0.f;
+                            const float v = bA[r] * (fmaf(-xh, bk2[r], dy) - bk1[r]);
+                            dz[e][r] = (HS + e < ns) ? v * colm : 0.f;
                         }
                     }
-                    pend = true; pend_tile = tile; pend_ns = ns;
+                } else {
+                    // ---- G_{2l}: BatchNorm 2l backward, conv_block1 + theta gradients, d X_l -------------------------------------------------
+#pragma unroll
+                    for (int e = 0; e < NS; ++e)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const float dy = y1[e][r] > 0.f ? SB[HS + e][r] : 0.f;
+                            const float v = bA[r] * (fmaf(-xh0[e][r], bk2[r], dy) - bk1[r]);
+                            dz[e][r] = (HS + e < ns) ? v * colm : 0.f;
+                        }
                 }
-                continue;
-            }
+                // d(input of the convolution) = W^T-conv(d z); weight gradient from the transposed tiles: acc += dzT x [hT | hsT]
+                // (contraction over the columns t = 4 g + r of the transposed tiles)
+                f32x4 dI[NS];
+                {
+                    u32x4 bh[NS], bl[NS];
+                    f32x4 dzT[NS], hT[NS], hsT[NS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const Pk p = pack3(dz[e][0], dz[e][1], dz[e][2], 0.f);
+                        const Shifted nx = shift_read(sh_tile, sh_bk, sh_bk_lo, lane, p);
+                        bh[e] = cat(p.hi, nx.hi);
+                        bl[e] = cat(p.lo, nx.lo);
+                        dzT[e] = mfma16z(cat(p.hi, p.lo), ident);
+                        hT[e] = mfma16z(cat(hk[e].hi, hk[e].lo), ident);
+                        hsT[e] = mfma16z(cat(hks[e].hi, hks[e].lo), ident);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        dI[e] = mfma16z(wT.hi, bh[e]);
+                        dI[e] = mfma16(wT.hi, bl[e], dI[e]);
+                        dI[e] = mfma16(wT.lo, bh[e], dI[e]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    Pk q[NS], u[NS], us[NS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        q[e] = pack3(dzT[e][0], dzT[e][1], dzT[e][2], dzT[e][3]);
+                        u[e] = pack3(hT[e][0], hT[e][1], hT[e][2], hT[e][3]);
+                        us[e] = pack3(hsT[e][0], hsT[e][1], hsT[e][2], hsT[e][3]);
+                        acc_w0 = mfma16(cat(q[e].hi, q[e].lo), cat(u[e].hi, u[e].hi), acc_w0);
+                        acc_w1 = mfma16(cat(q[e].hi, q[e].lo), cat(us[e].hi, us[e].hi), acc_w1);
+                    }
+                    acc_w0 = mfma16(cat(q[0].hi, q[1].hi), cat(u[0].lo, u[1].lo), acc_w0);
+                    acc_w1 = mfma16(cat(q[0].hi, q[1].hi), cat(us[0].lo, us[1].lo), acc_w1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (BLK == 1) {
+                    // d(x0 + H) and the sums of BatchNorm 2l
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        keep_until_here(dI[e][3]);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            float gq = dI[e][r] + gsum[e][r];
+                            gq = (V[e][r] > 0.f && HS + e < ns) ? gq * colm : 0.f;
+                            pend_v[HS + e][r] = gq;
+                            const float dy = y1[e][r] > 0.f ? gq : 0.f;
+                            s_a[r] += dy;
+                            s_b[r] = fmaf(dy, xh0[e][r], s_b[r]);
+                        }
+                    }
+                } else {
+                    // d Hp = leaky'(Hp) (d H + d(x0 + H)); theta gradient: contraction over the channel slots
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        keep_until_here(dI[e][3]);
+                        float dHp[3];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const float gq = dI[e][r] + SB[HS + e][r];
+                            const float v = Hp[e][r] > 0.f ? gq : gq * LEAKY;
+                            dHp[r] = (HS + e < ns) ? v * colm : 0.f;
+                            acc_b += dHp[r];
+                        }
+                        dk[e] = pack3(dHp[0], dHp[1], dHp[2], 0.f);
+                    }
+                    {
+                        Pk ax[NS];
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            keep_until_here(AXd[e][3]);
+                            ax[e] = pack3(AXd[e][0], AXd[e][1], AXd[e][2], 0.f);
+                            acc_th = mfma16(cat(dk[e].hi, dk[e].lo), cat(ax[e].hi, ax[e].hi), acc_th);
+                        }
+                        acc_th = mfma16(cat(dk[0].hi, dk[1].hi), cat(ax[0].lo, ax[1].lo), acc_th);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (LY >= 1) {
+                        // d X_l = A (d Hp theta) + d X_{l+1}: U = (A d Hp)^T, then U x theta
+                        f32x4 U[NS], dXl[NS];
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            U[e] = mfma16z(cat(dk[e].hi, dk[e].hi), ad[e]);
+                            U[e] = mfma16(cat(dk[e].lo, dk[e].lo), ad[e], U[e]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            const Split2 p01 = split2(U[e][0], U[e][1]), p23 = split2(U[e][2], U[e][3]);
+                            const u32x4 ua = {p01.hi, p23.hi, p01.lo, p23.lo};
+                            dXl[e] = mfma16z(ua, thN.hi);
+                            dXl[e] = mfma16(ua, thN.lo, dXl[e]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        // the sums of BatchNorm 2l-1: F_{2l} left its x-hat where the gradient passes (ReLU gate, dropout), +inf elsewhere
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            keep_until_here(dXl[e][3]);
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) {
+                                const float dX = (HS + e < ns) ? (dXl[e][r] + gin[HS + e][r]) * colm : 0.f;
+                                pend_v[HS + e][r] = dX;
+                                const bool open = Q[HS + e][r] < INFINITY;
+                                const float dy = open ? dX * a.drop_scale : 0.f;
+                                s_a[r] += dy;
+                                s_b[r] = fmaf(dy, open ? Q[HS + e][r] : 0.f, s_b[r]);
+                            }
+                        }
+                    }
+                }
+            };
+            g_half(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            g_half(std::integral_constant<int, 2>{});
+            if constexpr (BLK == 1 || LY >= 1) { pend = true; pend_tile = tile; pend_ns = ns; }
         }
     }
 
@@ -991,7 +986,6 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
     // ---- the workgroup's row of partial gradients: the wavefronts add their accumulators into an LDS image of the phase's contiguous
     // parameter range in a fixed order, then the image leaves in coalesced stores -------------------------------------------------------------
-    if (a.debug_skip == 4) return;
     const float us = a.inv_gscale;
     const int NN = N * N;
     int rbase = 0, rlen = 0;
@@ -1042,13 +1036,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     else if constexpr (BLK == 0) { rbase = LY * LS + off_theta_w(N); rlen = NN + N + CONVW; }
     else { rbase = LY * LS + off_conv_w(N, 1); rlen = CONVW; }
     float* row = a.gpart + (size_t)blockIdx.x * a.pcount + rbase;
-    if (a.debug_skip == 6) return;
     for (int i = threadIdx.x; i < rlen; i += 64 * MXT_WAVES) {
         const float v = red[i] * us;
         row[i] = v;
         bad |= !finite_f(v);
     }
-    if (a.debug_skip == 7) return;
     if (__any(bad) && lane == 0) atomicOr(&sc->pad[0], 1u);
 }
 
@@ -1136,8 +1128,6 @@ int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t st
     k.gscale = stgcn_train_mx_grad_scale(m.global_batch);
     k.inv_gscale = 1.0f / k.gscale;
     k.do_backward = m.do_backward;
-    k.debug_skip = 0;
-    if (const char* e = getenv("RULGNN_MXT_SKIP")) k.debug_skip = atoi(e);
     if (m.B == 0) { if (grid_out) *grid_out = 0; return RULGNN_OK; }
     const int L = m.L;
     if (kind == PH_TOP) {

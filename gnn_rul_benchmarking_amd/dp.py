@@ -53,6 +53,17 @@ class DataParallel:
         if getattr(model, "_nbt", None) is not None:
             dist.broadcast(model._nbt, 0, group=self.group)
 
+    @staticmethod
+    def _optimizer_step(model, optimizer) -> None:
+        """The optimizer over the all-reduced bucket.  ST_GCN's matrix-core training chain reports an f16 range violation as a NaN
+        loss (include/rulgnn.h, RULGNN_STEP_MX): summed over the ranks it makes every rank skip this step (and the running-statistics
+        update) alike -- guarded kernels -- and ``ST_GCN.update`` then repeats the step on the fp32 chain."""
+        guard = getattr(model, "guard_tensor", None)
+        if guard is not None:
+            optimizer.step(from_bucket=True, guard=guard)
+        else:
+            optimizer.step(from_bucket=True)
+
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -130,7 +141,7 @@ class DataParallel:
         self.all_reduce_bucket(model.bucket)
         if violated:
             raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
-        optimizer.step(from_bucket=True)
+        self._optimizer_step(model, optimizer)
         model._after_train_forward(global_batch, from_bucket_stats=True)
         return model.bucket[model.num_live]
 
@@ -166,7 +177,7 @@ class DataParallel:
         else:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch)
         self.all_reduce_bucket(model.bucket)
-        optimizer.step(from_bucket=True)
+        self._optimizer_step(model, optimizer)
         if batch_coupled:
             model._after_train_forward(global_batch, from_bucket_moments=True)
         return model.bucket[model.num_live]

@@ -40,9 +40,11 @@ class FusedAdam(torch.optim.Optimizer):
             p.grad = None
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0, from_bucket: bool = False):
+    def step(self, closure=None, grad_scale: float = 1.0, from_bucket: bool = False, guard=None):
         """``from_bucket=True``: the gradient is already in ``model.bucket`` (fused path);
-        otherwise it is gathered from the parameters' ``.grad`` (autograd path)."""
+        otherwise it is gathered from the parameters' ``.grad`` (autograd path).
+        ``guard``: a one-element device tensor (the loss in the bucket); when it is not finite the kernel leaves parameters and
+        moments untouched (the f16 range guard of ST_GCN's matrix-core training chain, see ``ST_GCN_model.guard_tensor``)."""
         model = self.model
         flat = model.flat_params
         if not flat.is_cuda:
@@ -73,6 +75,12 @@ class FusedAdam(torch.optim.Optimizer):
                 flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, state.data_ptr(),
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
                 float(grad_scale), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_adam_step_dev_f32")
+            return None
+        if guard is not None:
+            _lib.check(_lib.load().rulgnn_adam_step_guarded_f32(
+                flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, self._steps,
+                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(grad_scale), guard.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rulgnn_adam_step_guarded_f32")
             return None
         _lib.check(_lib.load().rulgnn_adam_step_f32(
             flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, self._steps,

@@ -102,9 +102,11 @@ class ST_GCN_model(FlatModule):
         self.patch_size = int(patch_size)
         self.num_layers = int(num_layers)
         self.dropout_p = float(dropout)
-        # launch form of the training step (rulgnn.h RULGNN_STEP_*): AUTO = the phase chain; STEP_COOP = one launch with device-side
-        # grid barriers for batches of at most 4 x #CUs tiles (same bits, measured slower: kept as an explicit option)
+        # launch form of the training step (rulgnn.h RULGNN_STEP_*): AUTO = the matrix-core chain with recomputed activations
+        # (STEP_MX, csrc/stgcn_train_mx.hip) where it applies (num_patch <= 15), else the fp32 phase chain (STEP_CHAIN); STEP_COOP = the
+        # fp32 phases in one launch with device-side grid barriers (same bits as the chain, measured slower: an explicit option)
         self.step_path = _lib.STEP_AUTO
+        self._last_chain = _lib.STEP_CHAIN   # what the latest whole step resolved to (guard_tensor / retry_on_fp32_chain)
         self._tape_step = {}            # batch size -> step whose activations its workspace holds (autograd-path hazard check)
         self.k = int(k)
         in_features = NUM_STATS
@@ -202,16 +204,45 @@ class ST_GCN_model(FlatModule):
         a.step_state = self._step_state.data_ptr() if self._step_state is not None else None
         return a
 
+    # ---- f16 range guard of the matrix-core chain -------------------------------------------------------------------------
+    # The chain reports a value beyond the f16 range (inputs far from O(1)) as a NaN loss with parameters, optimizer state and
+    # running statistics untouched (include/rulgnn.h, RULGNN_STEP_MX).  The separate optimizer / running-statistics kernels of the
+    # data-parallel step take the bucket's loss as their guard; the Algorithm wrapper repeats such a step on the fp32 chain.
+    def _resolve_chain(self, shp, x2d):
+        self._last_chain = _lib.load().rulgnn_stgcn_train_step_resolve(C.byref(shp), C.c_void_p(x2d.data_ptr()), int(self.step_path))
+        return self._last_chain
+
+    @property
+    def guard_tensor(self):
+        """The loss slot of the bucket when the latest step ran on the matrix-core chain, else None."""
+        return self._grad_flat[self.num_live:self.num_live + 1] if self._last_chain == _lib.STEP_MX else None
+
+    def retry_on_fp32_chain(self, optimizer=None):
+        """Undo the counters of a step the guard rejected and route this model's later steps through the fp32 phase chain."""
+        self.step_path = _lib.STEP_CHAIN
+        self._last_chain = _lib.STEP_CHAIN
+        self._step -= 1
+        self._nbt_pending -= 1
+        if optimizer is not None:
+            optimizer._steps -= 1
+
     def _after_train_forward(self, batch, from_bucket_moments=False, from_bucket_stats=False):
         """BatchNorm side effects of a training forward (running stats, num_batches_tracked).
         ``from_bucket_moments``: use the all-reduced global-batch moments (E[z], E[z^2]) in the bucket tail;
         ``from_bucket_stats``: the bucket tail holds the global (mean, biased variance) themselves (synchronised BatchNorm)."""
         in_bucket = from_bucket_moments or from_bucket_stats
         src = self._grad_flat.data_ptr() + 4 * (self.num_live + 1) if in_bucket else self._bn_batch.data_ptr()
-        _lib.check(_lib.load().rulgnn_bn_running_update_f32(self._bn.data_ptr(), src, self.num_layers,
-                                                            batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
-                                                            _stream()),
-                   "rulgnn_bn_running_update_f32")
+        guard = self.guard_tensor
+        if guard is not None:
+            _lib.check(_lib.load().rulgnn_bn_running_update_guarded_f32(self._bn.data_ptr(), src, self.num_layers,
+                                                                        batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
+                                                                        guard.data_ptr(), _stream()),
+                       "rulgnn_bn_running_update_guarded_f32")
+        else:
+            _lib.check(_lib.load().rulgnn_bn_running_update_f32(self._bn.data_ptr(), src, self.num_layers,
+                                                                batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0,
+                                                                _stream()),
+                       "rulgnn_bn_running_update_f32")
         self._nbt_pending += 1      # folded into the num_batches_tracked buffers lazily (state_dict / .to())
 
     def _train_forward(self, x2d):
@@ -247,6 +278,7 @@ class ST_GCN_model(FlatModule):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket)
+        self._resolve_chain(shp, x2d)
         if grad_ready is not None:
             failure = []
 
@@ -295,6 +327,7 @@ class ST_GCN_model(FlatModule):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, False)
+        self._resolve_chain(shp, x2d)
         ws = self._ws
         base, failure = ws.data_ptr(), []
 
@@ -323,6 +356,7 @@ class ST_GCN_model(FlatModule):
         self._step += 1
         shp = self._shape(x2d.size(0))
         a = self._train_args(shp, x2d, yv, None, self._step)
+        self._resolve_chain(shp, x2d)
         o = self._adam_args(optimizer, bn=self._bn)
         _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), o, int(self.step_path), _stream()),
                    "rulgnn_stgcn_train_step_path_f32")

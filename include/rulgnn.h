@@ -224,6 +224,9 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
 #define RULGNN_STEP_MX    3
 int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                      const rulgnn_adam_args *opt, int32_t path, void *stream);
+/* Which form a whole MSE step (args->y) with `path` runs for this shape and input pointer: RULGNN_STEP_CHAIN, RULGNN_STEP_COOP or
+ * RULGNN_STEP_MX; RULGNN_EUNSUPPORTED for the tiled path (num_patch > 64) and for an explicit form the shape does not allow.  No launch. */
+int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape *shape, const float *x, int32_t path);
 
 /* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
@@ -242,6 +245,15 @@ int rulgnn_stgcn_train_phase_f32(const rulgnn_stgcn_shape *shape, const rulgnn_s
 int rulgnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
                          int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                          float grad_scale, void *stream);
+
+/* The same step behind a guard: when *guard (a device float: the loss that follows the gradient in a data-parallel bucket) is not
+ * finite, nothing is touched.  The matrix-core training chain (RULGNN_STEP_MX) reports an f16 range violation as a NaN loss; after the
+ * bucket's all-reduce every rank then skips the optimizer step consistently and the caller repeats the step with RULGNN_STEP_CHAIN. */
+int rulgnn_adam_step_guarded_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                 int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 float grad_scale, const float *guard, void *stream);
+int rulgnn_bn_running_update_guarded_f32(float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count,
+                                         float momentum, int32_t from_moments, const float *guard, void *stream);
 
 /* nn.BatchNorm1d running-statistics update (momentum, unbiased running variance) from the batch
  * statistics produced by the training forward.  count = batch*num_patch values per channel.
