@@ -140,8 +140,8 @@ __device__ __forceinline__ void tap(float* taps, bool on, int slot, int lane, fl
 // Patch statistics (row mapping), the request for the next tile's windows, the Pearson adjacency as split B operands, and the statistics
 // in the D layout.  `gram` keeps the fp32 adjacency (gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]).
 template <int NFIX, int PFIX, bool TAPS>
-__device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const MxArgs& a, float* tileA, float* cur, int64_t tile, int ns,
-                                             int N, int P, int lane, bool tapon, float (&X0)[F], f32x16& gram, u32x4 (&adjB)[4],
+__device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const MxArgs& a, float* tileA, float* cur, int64_t tile, int64_t tstride,
+                                             int ns, int N, int P, int lane, bool tapon, float (&X0)[F], f32x16& gram, u32x4 (&adjB)[4],
                                              float (&X)[4][3]) {
     const int g = lane >> 4, col = lane & 15;
     const int tileNP = N * P;
@@ -154,7 +154,7 @@ __device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const
     auto request_next = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const int64_t nt = tile + gridDim.x;
+        const int64_t nt = tile + tstride;
         if (nt < a.ntiles) {
             const int64_t n0 = nt * 4;
             const int nns = (int)((a.B - n0) < 4 ? (a.B - n0) : 4);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
         float X0[F], X[4][3];
         f32x16 gram;
         u32x4 adjB[4];
-        mx_front_end<NFIX, PFIX, TAPS>(gx, a, tileA, cur, tile, ns, N, P, lane, tapon, X0, gram, adjB, X);
+        mx_front_end<NFIX, PFIX, TAPS>(gx, a, tileA, cur, tile, gridDim.x, ns, N, P, lane, tapon, X0, gram, adjB, X);
         if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};      // the padding slot of the shift tile (hi and lo halves)
 
         // The layers are the dense part of a tile; statistics, Pearson and the head are chains of LDS round trips and dependent
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
 // No safety net is needed here: up to z1 the layer is positively homogeneous in (X0, bias), so every sample is scaled by a power of
 // two 2^-k that brings its largest statistic below 128 (the bias partner of theta becomes 2^-k, an exact f16 down to k = 24) and
 // H, z1 are scaled back exactly: statistics up to ~1e9 stay inside the f16 range, NaN (constant patch) stays NaN.
+constexpr int MXF0_WAVES = 4;
 struct MxF0Out {
     float* cacheX;         // [ntiles][10][4 N]
     float* cacheA;         // [ntiles][10][40]
@@ -538,17 +539,22 @@ struct MxF0Out {
 // PACKED (the matrix-core chain of stgcn_train_mx.hip): the adjacency leaves as its 55 unique entries per sample ([tile][4][55], 220
 // bytes instead of the 400-byte lane layout of the row-mapped phases) and H, z1 are not written at all -- the later phases recompute.
 template <int NFIX, int PFIX, bool PACKED>
-__global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
-                                                                               MxArgs a, MxF0Out o) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__global__ __launch_bounds__(64 * MXF0_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
+                                                                                             MxArgs a, MxF0Out o) {
+    // Four wavefronts per workgroup, each on its own tiles with its own LDS region; they meet once, in the epilogue, where their BatchNorm
+    // sums are combined in LDS: one fp64 atomic per channel and WORKGROUP (2048 single-wavefront workgroups adding into 16 replicas of
+    // the same two lines cost ~4 us of serialised atomics at the end of the kernel).
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int N = NFIX ? NFIX : a.N, P = PFIX ? PFIX : a.P;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, col = lane & 15;
     const int tileNP = N * P;
+    double* const pairbuf = reinterpret_cast<double*>(smem_all);                       // [MXF0_WAVES][2 F]
+    float* const smem = smem_all + 2 * MXF0_WAVES * 2 * F + wave * (a.buf_floats + (MX_MIN_BUF_BYTES + MX_SHIFT_TILE_BYTES) / 4);
 
-    int64_t tile = blockIdx.x;
-    if (tile >= a.ntiles) return;
-    {
+    int64_t tile = (int64_t)blockIdx.x * MXF0_WAVES + wave;
+    const int64_t tstride = (int64_t)gridDim.x * MXF0_WAVES;
+    if (tile < a.ntiles) {
         const int64_t s0 = tile * 4;
         const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
         dma_tile(gx + s0 * tileNP, smem, ns * tileNP * 4, lane);
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
     float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
     mx_zero_padding_rows(smem + a.buf_floats, lane);
 
-    for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
+    for (int it = 0; tile < a.ntiles; ++it, tile += tstride) {
         float* const tileA = smem;
         float* const cur = smem + a.buf_floats;
         const int64_t s0 = tile * 4;
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
         float X0[F], X[4][3];
         f32x16 gram;
         u32x4 adjB[4];
-        mx_front_end<NFIX, PFIX, false>(gx, a, tileA, cur, tile, ns, N, P, lane, false, X0, gram, adjB, X);
+        mx_front_end<NFIX, PFIX, false>(gx, a, tileA, cur, tile, tstride, ns, N, P, lane, false, X0, gram, adjB, X);
         if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};
 
         // ---- what the later phases read of the inputs: statistics (row mapping) and adjacency -----------------------------
@@ -739,8 +745,8 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
         __builtin_amdgcn_s_setprio(1);
     }
 
-    // ---- epilogue: this wavefront's share of sum z1, sum z1^2 (fp64 from here on), one atomic per channel and cell -------------------
-    double* cell = o.cells + (int64_t)(blockIdx.x % o.replicas) * o.cell_stride;
+    // ---- epilogue: sum z1, sum z1^2 (fp64 from the 16-lane reduction on), the wavefronts' shares combined in a fixed order, one atomic
+    // per channel and workgroup ---------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         double da = (double)sa[r], db = (double)sb[r];
@@ -751,9 +757,16 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kerne
         }
         const int c = slot_chan(4 * g + r);
         if (col == 0 && c >= 0) {
-            atomicAdd(cell + c, da);
-            atomicAdd(cell + F + c, db);
+            pairbuf[wave * 2 * F + c] = da;
+            pairbuf[wave * 2 * F + F + c] = db;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * F) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < MXF0_WAVES; ++w) v += pairbuf[w * 2 * F + threadIdx.x];
+        atomicAdd(o.cells + (int64_t)(blockIdx.x % o.replicas) * o.cell_stride + threadIdx.x, v);
     }
 }
 
@@ -1204,8 +1217,8 @@ static int train_f0_mx_launch(const rulgnn_stgcn_shape* s, const float* x, const
     a.taps = nullptr;
     MxF0Out o;
     o.cacheX = cacheX; o.cacheA = cacheA; o.H0 = H0; o.Z1 = Z1; o.cells = cells_bn0; o.cell_stride = cell_stride_doubles; o.replicas = replicas;
-    const size_t lds = (size_t)a.buf_floats * sizeof(float) + MX_CONV_BYTES;
-    if (lds > 64 * 1024) return RULGNN_EUNSUPPORTED;
+    const size_t lds = MXF0_WAVES * ((size_t)a.buf_floats * sizeof(float) + MX_CONV_BYTES) + sizeof(double) * MXF0_WAVES * 2 * F;
+    if (lds > 80 * 1024) return RULGNN_EUNSUPPORTED;
     auto launch = [&](auto kern) -> int {
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1215,13 +1228,13 @@ static int train_f0_mx_launch(const rulgnn_stgcn_shape* s, const float* x, const
             int v = 0;
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (per_cu > MX_BLOCKS_PER_CU) per_cu = MX_BLOCKS_PER_CU;
-        if (per_cu > 4) per_cu -= per_cu % 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * MXF0_WAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > MX_WAVES_PER_SIMD) per_cu = MX_WAVES_PER_SIMD;         // a workgroup is one wavefront per SIMD
         int64_t grid = (int64_t)cus * per_cu;
-        if (grid > a.ntiles) grid = a.ntiles;
+        const int64_t want = (a.ntiles + MXF0_WAVES - 1) / MXF0_WAVES;
+        if (grid > want) grid = want;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, x, prm, a, o);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXF0_WAVES), lds, stream, x, prm, a, o);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     };
     if (s->num_patch == 14 && s->patch_size == 30) return launch(&stgcn_train_f0_mx_kernel<14, 30, PACKED>);

@@ -1014,7 +1014,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     size_t o = 0;
     w->off_cacheX = o; o = al(o + (size_t)g.ntiles * F * 64 * sizeof(float));
     w->off_cacheA = o; o = al(o + (size_t)g.ntiles * (g.RW == 16 ? F : 1) * 64 * sizeof(float));
-    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64 + BN_TABLE_BYTES;   // + grid-barrier counter + BatchNorm table
+    w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64;   // + grid-barrier counter
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
     w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
@@ -1203,7 +1203,6 @@ __device__ __forceinline__ void prepare_body(double* cells, int zero_from, int n
     sc->bn_count = bn_count;
     if (new_forward) {
         sc->pad[0] = 0u;                               // status word of the matrix-core chain (stgcn_train_mx.hip)
-        sc->pad[1] = 0u;                               // its BatchNorm-table sequence number (bn_table_sync)
         if (st) step = ++st->dropout_step;
         for (int l = 0; l < 8; ++l) sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
     }
@@ -1380,6 +1379,8 @@ static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train
     m.prm = a->params; m.y = a->y; m.pred = a->pred; m.cells = k.cells; m.gpart = k.gpart;
     m.xrec[0] = k.cacheX;
     m.qrec[0] = nullptr;
+    for (int l = 0; l < 3; ++l)
+        m.mrec[l] = l < L ? reinterpret_cast<uint32_t*>(k.saved + (size_t)SavedSlot<L>::O0(l) * k.ntiles * tile_floats) : nullptr;
     for (int l = 1; l < 3; ++l) {
         m.xrec[l] = l < L ? k.saved + (size_t)SavedSlot<L>::X(l) * k.ntiles * tile_floats : nullptr;
         m.qrec[l] = l < L ? k.saved + (size_t)SavedSlot<L>::Z2(l - 1) * k.ntiles * tile_floats : nullptr;
@@ -1453,8 +1454,8 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
             int grid = 0;
             rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid);
             if (rc != RULGNN_OK) return rc;
-            // the reduction pair a phase completes (all-reduced here under synchronised BatchNorm; the NEXT phase's workgroup 0 finishes
-            // the BatchNorm table from it either way): F_i -> forward pair i, TOP -> backward pair 2L-1, G_i -> backward pair i-1
+            // the reduction pair a phase completes (all-reduced here under synchronised BatchNorm; the later phases read the cells):
+            // F_i -> forward pair i, TOP -> backward pair 2L-1, G_i -> backward pair i-1
             if (ph < 2 * L) rc = sync_pair<L>(k, cell_fwd(L) + ph * 2 * F, hook, stream);
             else if (ph == 2 * L) { grid_top = grid; rc = sync_pair<L>(k, cell_bwd(L) + (2 * L - 1) * 2 * F, hook, stream); }
             else {

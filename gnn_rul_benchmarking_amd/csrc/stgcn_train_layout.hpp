@@ -36,38 +36,30 @@ __device__ __forceinline__ double cell_sum(const double* cells, int L, int i) {
     return v;
 }
 
-// ---- BatchNorm table (matrix-core chain) -----------------------------------------------------------------------------------------------
-// 2048 wavefronts each summing 16 replicas of every cell and finishing the BatchNorm constants in fp64 cost ~10 us of L2 traffic per
-// phase kernel (50 MB against the same 170 lines).  In the matrix-core chain a reduction pair is finished ONCE, by workgroup 0 of the
-// NEXT phase kernel (the pair is final when that kernel starts -- also under synchronised BatchNorm, where the all-reduce sits between the
-// two kernels): it sums the pair's replicas, writes the constants into a table of 7 x F floats per BatchNorm behind the step scratch and
-// then publishes the kernel's sequence number in StepScratch::pad[1]; the other workgroups build the operands that do not depend on a
-// BatchNorm meanwhile and wait for the number.  Workgroup 0 is dispatched first, so whoever waits waits for a resident wavefront.
-// (A last-arriver ticket at the END of the producing kernel was tried first: its device-scope release fence writes the L2 back --
-// the XCDs' L2s are not coherent with each other -- and cost ~40 us per kernel.)  Table and flag travel by device-scope atomic
-// stores / loads, which bypass the per-XCD L2.
+// ---- BatchNorm constants of a phase (matrix-core chain) ------------------------------------------------------------------------------------
+// One row block of BN_TABLE_ROWS x F floats per BatchNorm in the workgroup's LDS: mean, istd, gamma, beta, gamma istd (from the forward
+// pair sum z, sum z^2) and mean(dy), mean(dy xhat) (from the backward pair).  A phase needs at most three reduction pairs; wavefront w of
+// the workgroup finishes pair w: lane j < 2 F sums the 16 replicas of cell j (sixteen independent loads: ONE memory round trip; the
+// same fixed order as cell_sum()), lane c < F then holds both sums of channel c and does the fp64 arithmetic.  The cells are final when the
+// kernel starts (kernel boundary; under synchronised BatchNorm the all-reduce sits in between), so plain loads do.
+// History (round 4): every lane summing every cell cost three dependent rounds of loads per kernel; a table finished ONCE by workgroup 0
+// and published through a flag cost four round trips on the critical path of every workgroup (device-scope stores / loads: the XCDs' L2s
+// are not coherent with each other); a last-arriver ticket at the end of the producing kernel needs a device-scope release fence, which
+// writes the L2 back: ~40 us per kernel.
 constexpr int BN_TABLE_ROWS = 7;        // mean, istd, gamma, beta, gamma istd, mean(dy), mean(dy xhat)
-constexpr int BN_TABLE_BYTES = 4608;    // 2 * 8 layers * 7 * F floats, rounded up
-__host__ __device__ __forceinline__ float* bn_table(double* cells, int L) {
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(step_scratch(cells, L)) + sizeof(StepScratch) + 64);
-}
-__device__ __forceinline__ void table_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float table_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// One wavefront finishes BatchNorm b's forward (rows 0..4 from sum z, sum z^2) or backward (rows 5, 6) constants: lane j < 2 F sums the
-// replicas of cell j of the pair (same fixed order as cell_sum()), lane c < F then holds both sums of channel c.
-__device__ __forceinline__ void bn_pair_finish(double* cells, const float* prm, int L, int N, bool fwd, int b, int lane) {
+__device__ __forceinline__ void bn_pair_to_lds(const double* cells, const float* prm, float* bnc, int L, int N, bool fwd, int b, int lane) {
     const int CS = cell_stride(L);
     const int base = (fwd ? cell_fwd(L) : cell_bwd(L)) + b * 2 * F;
     double v = 0.0;
     if (lane < 2 * F) {
 #pragma unroll
-        for (int r = 0; r < CELL_REPLICAS; ++r) v += __hip_atomic_load(cells + r * CS + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < CELL_REPLICAS; ++r) v += cells[r * CS + base + lane];
     }
     const double s1 = v, s2 = __shfl(v, (lane + F) & 63, 64);
     if (lane < F) {
         const int c = lane;
-        const double cnt = step_scratch(cells, L)->bn_count;
-        float* o = bn_table(cells, L) + b * BN_TABLE_ROWS * F;
+        const double cnt = step_scratch(const_cast<double*>(cells), L)->bn_count;
+        float* o = bnc + b * BN_TABLE_ROWS * F;
         if (fwd) {
             const double mean = s1 / cnt;
             double var = s2 / cnt - mean * mean;
@@ -75,31 +67,16 @@ __device__ __forceinline__ void bn_pair_finish(double* cells, const float* prm, 
             const double istd = 1.0 / sqrt(var + (double)BN_EPS);
             const int LS = layer_stride(N);
             const double g = prm[(b / 2) * LS + off_bn_g(N, b % 2) + c];
-            table_store(o + 0 * F + c, (float)mean);
-            table_store(o + 1 * F + c, (float)istd);
-            table_store(o + 2 * F + c, (float)g);
-            table_store(o + 3 * F + c, prm[(b / 2) * LS + off_bn_b(N, b % 2) + c]);
-            table_store(o + 4 * F + c, (float)(g * istd));
+            o[0 * F + c] = (float)mean;
+            o[1 * F + c] = (float)istd;
+            o[2 * F + c] = (float)g;
+            o[3 * F + c] = prm[(b / 2) * LS + off_bn_b(N, b % 2) + c];
+            o[4 * F + c] = (float)(g * istd);
         } else {
-            table_store(o + 5 * F + c, (float)(s1 / cnt));
-            table_store(o + 6 * F + c, (float)(s2 / cnt));
+            o[5 * F + c] = (float)(s1 / cnt);
+            o[6 * F + c] = (float)(s2 / cnt);
         }
     }
-}
-// prologue of a phase kernel: the leader (wavefront 0 of workgroup 0) finishes the pair its predecessor completed and publishes `seq`;
-// every other wavefront waits for it
-__device__ __forceinline__ void bn_table_sync(double* cells, const float* prm, int L, int N, bool fwd, int b, unsigned seq, bool leader, int lane) {
-    unsigned* flag = &step_scratch(cells, L)->pad[1];
-    if (leader) {
-        bn_pair_finish(cells, prm, L, N, fwd, b, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the table's stores have been acknowledged
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) __builtin_amdgcn_s_sleep(8);
-    }
-    __builtin_amdgcn_wave_barrier();
 }
 
 }  // namespace rulgnn

@@ -83,17 +83,29 @@ struct ConvOp { u32x4 hi, lo; };
 
 // A operand of a forward convolution: row m = col <-> output channel; k-slots [0..3] = tap at t, [4..7] = tap at t - d, each x input
 // slot 4 g + r; `scale` multiplies the weights of this lane's output channel, `pre` undoes a factor carried by the data (V = 4 o0),
-// `shift` rides in slot 3 of lane group 0 against the constant 1 of the data operand.
-__device__ __forceinline__ ConvOp conv_fwd_operand(const float* cw, float scale, float shift, float pre, int g, int col) {
+// `shift` rides in slot 3 of lane group 0 against the constant 1 of the data operand.  In two steps: the raw taps are loaded in front of
+// the BatchNorm-table hand-over of the prologue (they do not depend on it), scaled and split behind it.
+struct ConvRaw { float wc[4], wd[4]; };
+__device__ __forceinline__ ConvRaw conv_fwd_raw(const float* cw, int g, int col) {
     const int co = slot_chan(col), coc = co >= 0 ? co : 0;
-    float wc[4], wd[4];
+    ConvRaw w;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int ci = slot_chan(4 * g + r);
         const bool ok = co >= 0 && ci >= 0;
         const float2 taps2 = *reinterpret_cast<const float2*>(cw + (coc * F + (ci >= 0 ? ci : 0)) * 2);
-        wc[r] = ok ? taps2.y * (scale * pre) : 0.f;
-        wd[r] = ok ? taps2.x * (scale * pre) : 0.f;
+        w.wc[r] = ok ? taps2.y : 0.f;
+        w.wd[r] = ok ? taps2.x : 0.f;
+    }
+    return w;
+}
+__device__ __forceinline__ ConvOp conv_fwd_operand(const ConvRaw& w, float scale, float shift, float pre, int g, int col) {
+    const int co = slot_chan(col);
+    float wc[4], wd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        wc[r] = w.wc[r] * (scale * pre);
+        wd[r] = w.wd[r] * (scale * pre);
     }
     if (g == 0) wc[3] = co >= 0 ? shift : 0.f;
     const Split2 c01 = split2(wc[0], wc[1]), c23 = split2(wc[2], wc[3]), d01 = split2(wd[0], wd[1]), d23 = split2(wd[2], wd[3]);
@@ -154,9 +166,21 @@ struct LayerK {
 
 // `mode[blk]`: 0 = convolution not needed, 1 = raw weights (its BatchNorm statistics are what this phase computes), 2 = x-hat fold
 // (weights x istd, shift -mean istd: the product IS x-hat, y = gamma x-hat + beta one fma behind it)
-__device__ __forceinline__ void layer_constants(LayerK& k, const float* prm, const float* bnc, int l, int N, int g, int col, int mode0, int mode1) {
+struct LayerRaw {
+    ThetaOp th;
+    ConvRaw w[2];
+};
+__device__ __forceinline__ void layer_raw(LayerRaw& k, const float* prm, int l, int N, int g, int col, int mode0, int mode1) {
     const float* lp = prm + l * layer_stride(N);
     k.th = theta_t_operand(lp, N, g, col);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        if ((blk == 0 ? mode0 : mode1) != 0) k.w[blk] = conv_fwd_raw(lp + off_conv_w(N, blk), g, col);
+        else k.w[blk] = ConvRaw{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    }
+}
+__device__ __forceinline__ void layer_constants(LayerK& k, const LayerRaw& raw, const float* bnc, int l, int g, int col, int mode0, int mode1) {
+    k.th = raw.th;
     const int co = slot_chan(col), coc = co >= 0 ? co : 0;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
@@ -164,7 +188,7 @@ __device__ __forceinline__ void layer_constants(LayerK& k, const float* prm, con
         const float* q = bnc + (2 * l + blk) * MXT_BNC * F;
         const float istd = mode == 2 ? q[1 * F + coc] : 1.f;
         const float shift = mode == 2 ? -q[0 * F + coc] * istd : 0.f;
-        if (mode != 0) k.w[blk] = conv_fwd_operand(lp + off_conv_w(N, blk), istd, shift, blk == 0 ? 1.f : 0.25f, g, col);
+        if (mode != 0) k.w[blk] = conv_fwd_operand(raw.w[blk], istd, shift, blk == 0 ? 1.f : 0.25f, g, col);
         else k.w[blk] = ConvOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -185,6 +209,8 @@ struct MxTrainK {
     float* gpart;
     float* xrec[MX_MAX_LAYERS];   // X_l tiles: [ntiles][10][4 N]
     float* qrec[MX_MAX_LAYERS];   // l >= 1: x-hat of BatchNorm 2l-1 where the gradient passes (ReLU gate and dropout), else +inf
+    uint32_t* mrec[MX_MAX_LAYERS];   // dropout masks of layer l, one word per lane and tile (bit 3 s + r = keep of sample s, register r):
+                                     // hashed once, by the phase that first applies them (F_{2l+2} / TOP), read by G_{2l+1}
     float* arec;                  // adjacency tiles: [ntiles][4][55]
     float* sb;                    // d(x0 + H): [ntiles][10][4 N]
     float* dx;                    // d X_l: [ntiles][10][4 N]
@@ -225,7 +251,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     // workgroup: [BatchNorm table | gradient row image | pair partials]; then one region per wavefront (the wavefronts only meet in the
     // prologue and the epilogue)
     constexpr int SH_BNC = (NBN * MXT_BNC * F + 3) & ~3;
-    float* const bnc = smem_all;
+    float* const bnc = smem_all;                                                 // [NBN][BN_TABLE_ROWS][F], the rows this phase uses
     float* const red = smem_all + SH_BNC;                                       // [MXT_RED_FLOATS]
     double* const pairbuf = reinterpret_cast<double*>(red + MXT_RED_FLOATS);    // [MXT_WAVES][2 F + 1]
     const int off_zero = 0;
@@ -264,43 +290,45 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     auto req_XP = [&](int64_t t) { if constexpr (BWD_PREV) dma(a.qrec[LY] + t * XF, off_XP, 4 * XF); };
     if (tile < a.ntiles) { req_XA(tile); req_SB(tile); req_DX(tile); req_XP(tile); }
 
-    // ---- prologue: the BatchNorm table (workgroup 0 finishes the pair the previous phase completed), constant operands ----------------------
+    // ---- prologue.  First everything that does not depend on a BatchNorm (parameter loads, theta / transposed-convolution / identity
+    // operands); then the BatchNorm constants from the reduction cells (one pair per wavefront, stgcn_train_layout.hpp); then the operands
+    // that fold a BatchNorm in ----------------------------------------------------------------------------------------------------
     for (int i = lane; i < MXT_ZERO_FLOATS; i += 64) smem[off_zero + i] = 0.f;
     if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};
-    {
-        // previous phase: F_{i-1} (forward pair i-1) in front of F_i and TOP; TOP / G_{i+1} (backward pair IDX) in front of G_i
-        constexpr bool PFWD = KIND != PH_G;
-        constexpr int PB = KIND == PH_F ? IDX - 1 : (KIND == PH_TOP ? NBN - 1 : IDX);
-        constexpr unsigned SEQ = KIND == PH_F ? IDX : (KIND == PH_TOP ? 2 * L : 4 * L - IDX);
-        bn_table_sync(a.cells, a.prm, L, N, PFWD, PB, SEQ, blockIdx.x == 0 && wave == 0, lane);
-        const float* tab = bn_table(a.cells, L);
-        for (int i = threadIdx.x; i < NBN * MXT_BNC * F; i += 64 * MXT_WAVES) bnc[i] = table_load(tab + i);
-        __syncthreads();
-    }
-
     // which convolutions of the main layer / the previous layer this phase runs, and how
     constexpr int M0_LY = (KIND == PH_F && BLK == 0) ? 1 : 2;                          // conv_block1 of layer LY
     constexpr int M1_LY = (KIND == PH_F && BLK == 0) ? 0 : ((KIND == PH_F) ? 1 : ((KIND == PH_G && BLK == 0) ? 0 : 2));   // conv_block2
-    LayerK kc;                                   // layer LY
-    layer_constants(kc, a.prm, bnc, LY, N, g, col, M0_LY, M1_LY);
-    LayerK kp;                                   // layer LY - 1 (F_{2l}, l >= 1)
-    if constexpr (WITH_PREV) layer_constants(kp, a.prm, bnc, LY - 1, N, g, col, 2, 2);
-
-    // backward-only constants
+    LayerRaw rc, rp;
+    layer_raw(rc, a.prm, LY, N, g, col, M0_LY, M1_LY);
+    if constexpr (WITH_PREV) layer_raw(rp, a.prm, LY - 1, N, g, col, 2, 2);
     ConvOp wT = ConvOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     ThetaOp thN = ThetaOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     u32x4 ident = u32x4{0u, 0u, 0u, 0u};
-    float bA[3] = {0.f, 0.f, 0.f}, bk1[3] = {0.f, 0.f, 0.f}, bk2[3] = {0.f, 0.f, 0.f};     // BatchNorm IDX backward: gamma istd, S mean(dy), S mean(dy xhat)
     if constexpr (KIND == PH_G) {
         wT = conv_bwd_operand(a.prm + LY * LS + off_conv_w(N, BLK), g, col);
         if constexpr (BLK == 0 && LY >= 1) thN = theta_n_operand(a.prm + LY * LS, N, g, col);
-        {
-            unsigned w[4];
+        unsigned w[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w[r] = (4 * g + r == col) ? 0x3C00u : 0u;      // f16 1.0
-            const unsigned p01 = w[0] | (w[1] << 16), p23 = w[2] | (w[3] << 16);
-            ident = u32x4{p01, p23, p01, p23};
-        }
+        for (int r = 0; r < 4; ++r) w[r] = (4 * g + r == col) ? 0x3C00u : 0u;      // f16 1.0
+        const unsigned p01 = w[0] | (w[1] << 16), p23 = w[2] | (w[3] << 16);
+        ident = u32x4{p01, p23, p01, p23};
+    }
+    {
+        // the reduction pairs this phase's BatchNorm constants come from, one per wavefront: the forward pairs of the layers it runs
+        // (F_{2l+1}: 2l; F_{2l}, l >= 1: 2l-2, 2l-1; TOP, G_{2l+1}: 2l, 2l+1; G_{2l}: 2l) and the backward pair of BatchNorm IDX (G)
+        constexpr int FW0 = WITH_PREV ? 2 * LY - 2 : 2 * LY;                       // first forward pair
+        constexpr int NFW = (KIND == PH_F && BLK == 1) || (KIND == PH_G && BLK == 0) ? 1 : 2;
+        static_assert(NFW + (KIND == PH_G ? 1 : 0) <= MXT_WAVES, "one reduction pair per wavefront");
+        if (wave < NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
+        if (KIND == PH_G && wave == NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, false, IDX, lane);
+        __syncthreads();
+    }
+    LayerK kc;                                   // layer LY
+    layer_constants(kc, rc, bnc, LY, g, col, M0_LY, M1_LY);
+    LayerK kp;                                   // layer LY - 1 (F_{2l}, l >= 1)
+    if constexpr (WITH_PREV) layer_constants(kp, rp, bnc, LY - 1, g, col, 2, 2);
+    float bA[3] = {0.f, 0.f, 0.f}, bk1[3] = {0.f, 0.f, 0.f}, bk2[3] = {0.f, 0.f, 0.f};     // BatchNorm IDX backward: gamma istd, S mean(dy), S mean(dy xhat)
+    if constexpr (KIND == PH_G) {
         const float* q = bnc + IDX * MXT_BNC * F;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     };
     // One layer in full (both BatchNorms known): X <- dropout(relu(BN(z2)) + o0) + X.  `sbase[s]`: dropout counter of (sample s, channel 0, patch 0).
     auto layer_full = [&](float (&X)[4][3], const u32x4 (&adjB)[4], const LayerK& k, uint32_t key, const uint32_t (&sbase)[4],
-                          float (*xh1_out)[4][3], float (*y2_out)[4][3], float (*q_out)[4][3]) {
+                          float (*xh1_out)[4][3], float (*y2_out)[4][3], float (*q_out)[4][3], uint32_t* mbits_out) {
         f32x4 T[4], Hp[4], z[4];
         float H[4][3], V[4][3];
         Op2 xo[4];
@@ -464,6 +492,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             }
         }
         stage_conv(V, 1.0f, k.w[1], sh_rd2, sh_rd2_lo, z, pk, ps);
+        uint32_t mbits = 0u;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             keep_until_here(z[s][3]);
@@ -479,12 +508,14 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     const uint32_t h = lowbias32((sbase[s] + dro[r]) ^ key);
                     keep = h >= a.drop_thr;
                     o1 = keep ? o1 * a.drop_scale : 0.f;
+                    mbits |= keep ? 1u << (3 * s + r) : 0u;
                 }
                 // what the backward sums of this BatchNorm need: x-hat where the gradient passes the ReLU and the dropout, else +inf
                 if (q_out) (*q_out)[s][r] = (keep && y2 > 0.f) ? xh : INFINITY;
                 X[s][r] = fmaf(colm, o1, X[s][r]);
             }
         }
+        *mbits_out = mbits;
     };
 
     bool pend = false;
@@ -492,6 +523,12 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     int pend_ns = 0;
     float pend_v[4][3], pend_q[4][3];
     float pend_top0 = 0.f, pend_top1 = 0.f, pend_pred = 0.f;
+    uint32_t pend_m = 0u;                       // dropout mask bits of the tile (F_{2l}, TOP: written; G_{2l+1}: this tile's, read one tile ahead)
+    uint32_t mask_next = 0u;
+    constexpr bool MASK_IN = KIND == PH_G && BLK == 1;
+    if constexpr (MASK_IN) {
+        if (use_drop && tile < a.ntiles) mask_next = a.mrec[LY][tile * 64 + lane];
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -505,7 +542,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         __builtin_amdgcn_wave_barrier();
         // ---- what the previous tile leaves: stored HERE, behind the wait that also counts stores ------------------------------------
         if (pend) {
-            if constexpr (WITH_PREV) { st_tile(a.xrec[LY] + pend_tile * XF, pend_v, pend_ns); st_tile(a.qrec[LY] + pend_tile * XF, pend_q, pend_ns); }
+            if constexpr (WITH_PREV) {
+                st_tile(a.xrec[LY] + pend_tile * XF, pend_v, pend_ns);
+                st_tile(a.qrec[LY] + pend_tile * XF, pend_q, pend_ns);
+                if (use_drop) a.mrec[LY - 1][pend_tile * 64 + lane] = pend_m;
+            }
             if constexpr (KIND == PH_G && BLK == 1) st_tile(a.sb + pend_tile * XF, pend_v, pend_ns);
             if constexpr (BWD_PREV) st_tile(a.dx + pend_tile * XF, pend_v, pend_ns);
             if constexpr (KIND == PH_TOP) {
@@ -515,6 +556,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     p[pitch] = pend_top1;
                 }
                 if (g < pend_ns && col == 0) a.pred[pend_tile * 4 + g] = pend_pred;
+                if (use_drop && a.do_backward) a.mrec[LY][pend_tile * 64 + lane] = pend_m;
             }
         }
         // ---- inputs ------------------------------------------------------------------------------------------------------------------
@@ -549,7 +591,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         if constexpr (KIND == PH_F) {
             // ===== forward statistics phases ==============================================================================================
             if constexpr (WITH_PREV) {
-                layer_full(X, adjB, kp, dkey[LY - 1], sbase, nullptr, nullptr, &pend_q);
+                layer_full(X, adjB, kp, dkey[LY - 1], sbase, nullptr, nullptr, &pend_q, &pend_m);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -595,7 +637,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         if constexpr (KIND == PH_TOP) {
             // ===== last layer, head, loss, head backward ===================================================================================
             float xh1[4][3], y2[4][3];
-            layer_full(X, adjB, kc, dkey[LY], sbase, &xh1, &y2, nullptr);
+            layer_full(X, adjB, kc, dkey[LY], sbase, &xh1, &y2, nullptr, &pend_m);
             // max over the ten channels with its arg-max: per lane over its (up to three) channels, then across the four lane groups
             float pm[4], pa[4];
 #pragma unroll
@@ -665,10 +707,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     float gq = (chan[r] == da) ? dv : 0.f;
-                    if (use_drop) {
-                        const uint32_t h = lowbias32((sbase[s] + dro[r]) ^ dkey[LY]);
-                        gq = h >= a.drop_thr ? gq * a.drop_scale : 0.f;
-                    }
+                    if (use_drop) gq = (pend_m >> (3 * s + r)) & 1u ? gq * a.drop_scale : 0.f;       // the mask layer_full hashed
                     const float dy = y2[s][r] > 0.f ? gq : 0.f;
                     s_a[r] += dy;
                     s_b[r] = fmaf(dy, xh1[s][r], s_b[r]);
@@ -720,6 +759,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             __builtin_amdgcn_wave_barrier();
             if (nt < a.ntiles) { req_SB(nt); req_DX(nt); req_XP(nt); }
 
+            uint32_t mask_cur = 0u;
+            if constexpr (MASK_IN) {
+                mask_cur = mask_next;
+                if (use_drop && nt < a.ntiles) mask_next = a.mrec[LY][nt * 64 + lane];
+            }
             // ---- two samples at a time (the working set of four does not fit the register file) ------------------------------------------------
             auto g_half = [&](auto HS_) {
                 constexpr int HS = decltype(HS_)::value;
@@ -777,10 +821,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                             const float xh = z[e][r];
                             const float y2 = fmaf(kc.gam[1][r], xh, kc.bet[1][r]);
                             float gq = gin[HS + e][r];
-                            if (use_drop) {
-                                const uint32_t h = lowbias32((sbase[HS + e] + dro[r]) ^ dkey[LY]);
-                                gq = h >= a.drop_thr ? gq * a.drop_scale : 0.f;
-                            }
+                            if (use_drop) gq = (mask_cur >> (3 * (HS + e) + r)) & 1u ? gq * a.drop_scale : 0.f;   // hashed by F_{2l+2} / TOP
                             const bool x1pos = y2 > 0.f;
                             gsum[e][r] = (x1pos || V[e][r] > 0.f) ? gq : 0.f;                // d(x1 + o0): o1 = relu(x1 + o0) > 0
                             const float dy = x1pos ? gq : 0.f;
@@ -920,7 +961,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
     // ---- the last tile's outputs ---------------------------------------------------------------------------------------------------------
     if (pend) {
-        if constexpr (WITH_PREV) { st_tile(a.xrec[LY] + pend_tile * XF, pend_v, pend_ns); st_tile(a.qrec[LY] + pend_tile * XF, pend_q, pend_ns); }
+        if constexpr (WITH_PREV) {
+            st_tile(a.xrec[LY] + pend_tile * XF, pend_v, pend_ns);
+            st_tile(a.qrec[LY] + pend_tile * XF, pend_q, pend_ns);
+            if (use_drop) a.mrec[LY - 1][pend_tile * 64 + lane] = pend_m;
+        }
         if constexpr (KIND == PH_G && BLK == 1) st_tile(a.sb + pend_tile * XF, pend_v, pend_ns);
         if constexpr (BWD_PREV) st_tile(a.dx + pend_tile * XF, pend_v, pend_ns);
         if constexpr (KIND == PH_TOP) {
@@ -930,6 +975,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 p[pitch] = pend_top1;
             }
             if (g < pend_ns && col == 0) a.pred[pend_tile * 4 + g] = pend_pred;
+            if (use_drop && a.do_backward) a.mrec[LY][pend_tile * 64 + lane] = pend_m;
         }
     }
 
@@ -1120,7 +1166,7 @@ float stgcn_train_mx_grad_scale(int64_t global_batch) {
 int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out) {
     MxTrainK k;
     k.prm = m.prm; k.y = m.y; k.pred = m.pred; k.cells = m.cells; k.gpart = m.gpart;
-    for (int l = 0; l < MX_MAX_LAYERS; ++l) { k.xrec[l] = m.xrec[l]; k.qrec[l] = m.qrec[l]; }
+    for (int l = 0; l < MX_MAX_LAYERS; ++l) { k.xrec[l] = m.xrec[l]; k.qrec[l] = m.qrec[l]; k.mrec[l] = m.mrec[l]; }
     k.arec = m.arec; k.sb = m.sb; k.dx = m.dx; k.dtop = m.dtop;
     k.B = m.B; k.ntiles = (m.B + 3) / 4; k.global_batch = m.global_batch; k.sample_offset = m.sample_offset;
     k.N = m.N; k.pcount = m.pcount;

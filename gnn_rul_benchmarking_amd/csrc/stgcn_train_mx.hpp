@@ -15,6 +15,7 @@ struct MxTrainArgs {
     float* gpart;          // [grid][pcount] partial gradient rows
     float* xrec[3];        // X_l tiles [ntiles][10][4 N]; xrec[0] is written by F_0
     float* qrec[3];        // l >= 1: gated x-hat of BatchNorm 2l-1 (F_{2l} -> G_{2l})
+    uint32_t* mrec[3];     // dropout mask bits of layer l, one word per lane and tile (F_{2l+2} / TOP -> G_{2l+1})
     float* arec;           // adjacency tiles [ntiles][4][55], written by F_0
     float* sb;             // d(x0 + H)
     float* dx;             // d X_l
