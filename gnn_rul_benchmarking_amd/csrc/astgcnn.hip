@@ -502,8 +502,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         AuxFork fk(st, a->aux_stream);
         hipStream_t wst = fk.side();
         const bool mse = a->dpred == nullptr;
-        fk.fork();
+        // the constant 1 the side stream's bias reductions read: written IN FRONT of the fork (behind it the side stream's split-K over
+        // `one` was ordered against nothing that wrote it -- garbage from a fresh workspace on the first step)
         hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
+        fk.fork();
         if ((mode & 1) && training && a->bn_batch)
             hipLaunchKernelGGL(ast_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
         if (mse && a->loss) (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);

@@ -14,12 +14,16 @@
 
 namespace rulgnn {
 
+// One ring per (thread, device): an event belongs to the device that was current when it was created, and recording it on another
+// device's stream fails -- a thread that drives training on several GPUs (torch.cuda.device(1): ...) gets a ring for each.
 inline hipEvent_t aux_pooled_event() {
-    constexpr int N = 32;
-    static thread_local hipEvent_t ring[N] = {};
-    static thread_local int next = 0;
-    hipEvent_t& e = ring[next];
-    next = (next + 1) % N;
+    constexpr int N = 32, MAX_DEV = 16;
+    static thread_local hipEvent_t ring[MAX_DEV][N] = {};
+    static thread_local int next[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    hipEvent_t& e = ring[dev][next[dev]];
+    next[dev] = (next[dev] + 1) % N;
     if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
     return e;
 }
@@ -27,17 +31,30 @@ inline hipEvent_t aux_pooled_event() {
 struct AuxFork {
     hipStream_t st, wst;
     int rc = RULGNN_OK;
+    bool forked = false;        // the side stream carries work the main stream has not waited for yet
     AuxFork(hipStream_t stream, void* aux) : st(stream), wst(aux ? static_cast<hipStream_t>(aux) : stream) {}
+    AuxFork(const AuxFork&) = delete;
+    AuxFork& operator=(const AuxFork&) = delete;
+    // An early return between fork() and join() (a failed launch, RULGNN_EHIP) must not leave the side stream un-joined: a hipGraph
+    // capture in progress would be invalidated, and the next call could reuse scratch the side stream is still working on.
+    ~AuxFork() {
+        if (forked) (void)join();
+    }
     bool active() const { return wst != st; }
     hipStream_t side() const { return wst; }
     void order(hipStream_t after, hipStream_t waiter) {
-        if (!active() || rc != RULGNN_OK) return;
+        if (!active()) return;
         hipEvent_t ev = aux_pooled_event();
         if (!ev || hipEventRecord(ev, after) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess) rc = RULGNN_EHIP;
     }
-    void fork() { order(st, wst); }
+    void fork() {
+        if (rc != RULGNN_OK) return;
+        order(st, wst);
+        forked = active();
+    }
     int join() {
-        order(wst, st);
+        if (forked) order(wst, st);        // also after an error elsewhere: the join itself must still happen
+        forked = false;
         return rc;
     }
 };

@@ -70,44 +70,70 @@ class DataParallel:
     # ---- large buckets: all-reduce in gradient-ready order, overlapped with the rest of the backward -------------------------
     OVERLAP_MIN_BYTES = 1 << 20          # below this one blocking all-reduce is latency-bound either way
 
-    def _overlapped_step(self, model, X_shard, y_shard, global_batch, sample_offset):
-        """``fused_mse_step`` of a model whose backward reports final gradient regions (ST_GCN's tiled path: theta / fc1 are
-        num_patch x num_patch, a 12.6 MB bucket at XJTU-SY).  Each reported region is all-reduced on a side stream as soon as the
-        kernels that finalise it have been enqueued -- behind an event recorded on the compute stream -- while the compute stream
-        carries on with the layers below; whatever was not reported goes out when the step has been enqueued; the compute stream
-        then waits for the side stream.  Every bucket element is summed over the ranks exactly once."""
-        bucket = model.bucket
-        compute = torch.cuda.current_stream()
-        if getattr(self, "_comm_stream", None) is None or self._comm_stream.device != bucket.device:
-            self._comm_stream = torch.cuda.Stream(device=bucket.device)
-        comm = self._comm_stream
-        done = []
-
-        def launch(offset, count):
-            ev = torch.cuda.Event()
-            ev.record(compute)
-            comm.wait_event(ev)
-            with torch.cuda.stream(comm):
-                dist.all_reduce(bucket[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
-            done.append((offset, offset + count))
-
-        model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset, update_running_stats=False,
-                             moments_to_bucket=True, grad_ready=launch)
-        # the complement of the reported regions, in ascending order
+    @staticmethod
+    def _complement(regions, numel):
+        """What ``regions`` ((lo, hi) pairs, disjoint) leave of [0, numel), in ascending order."""
         pos, rest = 0, []
-        for lo, hi in sorted(done):
+        for lo, hi in sorted(regions):
             if lo < pos:
                 raise RuntimeError("overlapping gradient-ready regions")
             if lo > pos:
                 rest.append((pos, lo))
             pos = hi
-        if pos < bucket.numel():
-            rest.append((pos, bucket.numel()))
-        for lo, hi in rest:
+        if pos < numel:
+            rest.append((pos, numel))
+        return rest
+
+    def _overlapped_step(self, model, X_shard, y_shard, global_batch, sample_offset):
+        """``fused_mse_step`` of a model whose backward reports final gradient regions (ST_GCN's tiled path: theta / fc1 are
+        num_patch x num_patch, a 12.6 MB bucket at XJTU-SY).  Each reported region is all-reduced on a side stream as soon as the
+        kernels that finalise it have been enqueued -- behind an event recorded on the compute stream -- while the compute stream
+        carries on with the layers below; whatever was not reported goes out when the step has been enqueued; the compute stream
+        then waits for the side stream.  Every bucket element is summed over the ranks exactly once.
+
+        Every rank must issue the SAME collectives in the same order: the regions are ``model.ready_regions()`` -- a function of the
+        shape alone, checked against what the kernels report -- followed by their complement, and a rank whose shard is empty (ragged
+        last batch smaller than the world, ``drop_last=False`` in the reference's loaders) replays exactly that sequence on a zero
+        bucket instead of one all-reduce over the whole bucket (which would pair its single collective with the first slice of the
+        others: a hang, or silently wrong sums)."""
+        bucket = model.bucket
+        on_gpu = bucket.is_cuda
+        expected = [(int(o), int(o) + int(c)) for o, c in model.ready_regions()]
+        if on_gpu:
+            compute = torch.cuda.current_stream()
+            if getattr(self, "_comm_stream", None) is None or self._comm_stream.device != bucket.device:
+                self._comm_stream = torch.cuda.Stream(device=bucket.device)
+            comm = self._comm_stream
+        done = []
+
+        def launch(offset, count):
+            if on_gpu:
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                comm.wait_event(ev)
+                with torch.cuda.stream(comm):
+                    dist.all_reduce(bucket[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                dist.all_reduce(bucket[offset:offset + count], op=dist.ReduceOp.SUM, group=self.group)
+            done.append((offset, offset + count))
+
+        if X_shard.size(0) == 0:
+            bucket.zero_()
+            if hasattr(model, "_step"):
+                model._step += 1                                     # dropout stream position: in lockstep with the other ranks
+            for lo, hi in expected:
+                launch(lo, hi - lo)
+        else:
+            model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset, update_running_stats=False,
+                                 moments_to_bucket=True, grad_ready=launch)
+            if done != expected:
+                raise RuntimeError(f"gradient-ready regions {done} differ from the model's schedule {expected}")
+        for lo, hi in self._complement(done, bucket.numel()):
             launch(lo, hi - lo)
-        fin = torch.cuda.Event()
-        fin.record(comm)
-        compute.wait_event(fin)
+        if on_gpu:
+            fin = torch.cuda.Event()
+            fin.record(comm)
+            compute.wait_event(fin)
         self.last_overlap_regions = sorted(done)      # (tests / diagnostics)
 
     def _sync_bn_step(self, model, optimizer, X_shard, y_shard, global_batch, sample_offset):
@@ -156,6 +182,15 @@ class DataParallel:
         batch_coupled = hasattr(model, "_after_train_forward")      # BatchNorm / dropout state (ST_GCN); STMSGCN has none
         if self.sync_bn and batch_coupled:
             return self._sync_bn_step(model, optimizer, X_shard, y_shard, global_batch, sample_offset)
+        # decided from what every rank shares (the model and its bucket), never from this rank's shard: ranks that disagreed would issue
+        # different collectives
+        overlap = batch_coupled and getattr(model, "reports_ready_gradients", False) and \
+            model.bucket.numel() * 4 >= self.OVERLAP_MIN_BYTES
+        if overlap:
+            self._overlapped_step(model, X_shard, y_shard, global_batch, sample_offset)      # an empty shard replays the same collectives
+            self._optimizer_step(model, optimizer)
+            model._after_train_forward(global_batch, from_bucket_moments=True)
+            return model.bucket[model.num_live]
         if b == 0:
             # Ragged last batch smaller than the world (drop_last=False: n % batch_size can be 1..world_size-1): this rank's
             # shard is empty.  It launches no kernel, contributes a zero bucket, and still takes part in the all-reduce, the
@@ -163,12 +198,6 @@ class DataParallel:
             model.bucket.zero_()
             if hasattr(model, "_step"):
                 model._step += 1                                     # dropout stream position: in lockstep with the other ranks
-        elif batch_coupled and getattr(model, "reports_ready_gradients", False) and model.bucket.is_cuda and \
-                model.bucket.numel() * 4 >= self.OVERLAP_MIN_BYTES:
-            self._overlapped_step(model, X_shard, y_shard, global_batch, sample_offset)
-            optimizer.step(from_bucket=True)
-            model._after_train_forward(global_batch, from_bucket_moments=True)
-            return model.bucket[model.num_live]
         elif batch_coupled:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
                                  update_running_stats=False, moments_to_bucket=True)

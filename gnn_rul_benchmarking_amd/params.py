@@ -152,7 +152,17 @@ class ForwardTape:
         self.tokens[int(batch)] = self.count
         return self.count
 
+    def consume(self, batch: int, token: int) -> None:
+        """For backwards that rework the saved buffers in place (STNet scales the reconstruction gradients, RGCNU its gate tape): after
+        one backward the forward's activations are gone; a second one (``retain_graph=True``, two losses backpropagated separately)
+        must raise instead of silently applying the in-place step twice."""
+        if self.tokens.get(int(batch)) == token:
+            self.tokens[int(batch)] = ("consumed", token)
+
     def check(self, batch: int, token: int, bufs: dict, name: str) -> None:
+        if self.tokens.get(int(batch)) == ("consumed", token):
+            raise RuntimeError(f"{name}: backward() ran twice for the same forward; its saved activations were reworked in place by the "
+                               "first one. Run the forward again (or sum the losses and call backward() once).")
         if self.tokens.get(int(batch)) != token or int(batch) not in bufs:
             raise RuntimeError(f"{name}: another forward of this batch size ran between this forward and its backward (or its workspace "
                                "was evicted); the saved activations live in one workspace per batch size, not per call, and were "

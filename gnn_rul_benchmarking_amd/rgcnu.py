@@ -88,6 +88,7 @@ class _Function(torch.autograd.Function):
         model = ctx.model
         model._tape.check(ctx.x.size(0), ctx.tape, model._bufs, "RGCNU_model")
         grads = model._backward(ctx.x, dpred.reshape(-1).contiguous().float(), ctx.step, ctx.training)
+        model._tape.consume(ctx.x.size(0), ctx.tape)
         outs = [grads[off:off + n].view(shape).clone() for off, n, shape in model._slices]
         return (None, None, None, *outs)
 

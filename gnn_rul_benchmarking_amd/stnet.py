@@ -53,6 +53,7 @@ class _Function(torch.autograd.Function):
         dp = dpred.reshape(-1).contiguous().float() if dpred is not None else torch.zeros(B, dtype=torch.float32, device=ctx.x.device)
         w = drecon.reshape(1).contiguous().float() if drecon is not None else torch.zeros(1, dtype=torch.float32, device=ctx.x.device)
         grads = model._backward(ctx.x, dp, recon_weight=w)
+        model._tape.consume(ctx.x.size(0), ctx.tape)
         outs = [grads[off:off + n].view(shape).clone() if i >= 2 else None for i, (off, n, shape) in enumerate(model._slices)]
         return (None, None, *outs)
 

@@ -791,3 +791,73 @@ def test_bucket_families_data_parallel_step_world2_gloo(family):
         loss = float(single.update(x, y, 1)["loss"])
         single.optimizer.step(from_bucket=True)          # (the oracle-backed double leaves the optimizer to the caller)
         assert abs(loss - r0["loss"]) < 1e-6 and np.allclose(single.model.flat_params.numpy(), r0["flat"], rtol=1e-5, atol=1e-7)
+
+
+# ---- large-bucket overlap: every rank issues the same collectives, also with an empty shard (ragged last batch smaller than the world) ----
+class ReadyRegionsModel:
+    """Duck-types a model whose backward reports final gradient regions (ST_GCN's tiled path): a bucket of 4096 'gradients' + loss +
+    8 moments, two reported regions (in backward order) and what they leave."""
+    reports_ready_gradients = True
+
+    def __init__(self):
+        self.num_live = 4096
+        self.bucket = torch.zeros(self.num_live + 1 + 8, dtype=torch.float32)
+        self.flat_params = torch.zeros(self.num_live)
+        self._bn = torch.zeros(8)
+        self._nbt = torch.zeros(2, dtype=torch.int64)
+        self._step = 0
+
+    def ready_regions(self):
+        return [(3000, 1096), (1000, 500)]
+
+    def fused_mse_step(self, X, y, global_batch=None, sample_offset=0, update_running_stats=True, moments_to_bucket=False, grad_ready=None):
+        assert moments_to_bucket and not update_running_stats and grad_ready is not None
+        self._step += 1
+        b = X.shape[0]
+        self.bucket[:self.num_live] = float(X.sum()) + torch.arange(self.num_live, dtype=torch.float32) * 1e-3
+        for off, cnt in self.ready_regions():
+            grad_ready(off, cnt)
+        self.bucket[self.num_live] = float(b)
+        self.bucket[self.num_live + 1:] = b / float(global_batch)
+        return None, self.bucket[self.num_live]
+
+    def _after_train_forward(self, batch, from_bucket_moments=False):
+        assert from_bucket_moments
+        self._nbt += 1
+
+
+def _overlap_worker(rank, world, port, B, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.arange(B * 3, dtype=torch.float32).reshape(B, 3) + 1.0
+        y = torch.zeros(B, 1)
+        model = ReadyRegionsModel()
+        dp = DataParallel()
+        dp.OVERLAP_MIN_BYTES = 1024
+        lo, hi = shard_bounds(B, world, rank)
+        loss = dp.step(model, SgdFromBucket(model), x[lo:hi], y[lo:hi], global_batch=B, sample_offset=lo)
+        out[rank] = {"loss": float(loss), "bucket": model.bucket.clone().numpy(), "regions": list(dp.last_overlap_regions),
+                     "step": model._step, "shard": hi - lo}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_overlapped_all_reduce_issues_the_same_collectives_on_every_rank_world2_gloo(B):
+    """with B = 1 rank 1's shard is empty; it used to issue ONE all-reduce over the whole bucket against rank 0's
+    per-region all-reduces.  Both ranks now walk the model's region schedule and its complement."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, _free_port(), B, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r1["shard"] == B // 2 and r0["step"] == r1["step"] == 1
+    assert r0["regions"] == r1["regions"] == [(0, 1000), (1000, 1500), (1500, 3000), (3000, 4096), (4096, 4105)]
+    assert np.array_equal(r0["bucket"], r1["bucket"])
+    assert r0["loss"] == float(B) and np.allclose(r0["bucket"][4097:], 1.0)
+    # every element was summed exactly once
+    x = np.arange(B * 3, dtype=np.float32).reshape(B, 3) + 1.0
+    n0 = (B + 1) // 2
+    want = sum(float(part.sum()) + np.arange(4096, dtype=np.float32) * 1e-3 for part in (x[:n0], x[n0:]) if part.shape[0] > 0)
+    assert np.allclose(r0["bucket"][:4096], want, rtol=1e-6)

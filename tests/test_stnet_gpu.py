@@ -109,6 +109,13 @@ def test_autograd_path_equals_fused_path_and_the_thresholded_convolution_stays_u
         loss = torch.nn.functional.mse_loss(pr, y)
         (loss if weight is None else loss + weight * rc).backward()
         return torch.cat([(t.grad if t.grad is not None else torch.zeros_like(t)).reshape(-1) for t in mm._named()])
+    # a second backward of the same forward must raise: the first one reworked the saved reconstruction gradients in place
+    mm = build_model(cfg, p).train()
+    pr, rc = mm(x, train=True)
+    loss = torch.nn.functional.mse_loss(pr, y) + rc
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ran twice"):
+        loss.backward()
     g0, g1, gh = grads(None), grads(1.0), grads(0.5)
     assert torch.equal(g1, fused)
     assert torch.equal(g0, grads(0.0))
