@@ -1,0 +1,18 @@
+"""-m gpu: the RMSE half of BASELINE.json's metric ("training samples/sec + RMSE"), gated.  SURVEY.md section 8(d)'s synthetic task -- a
+fixed random teacher ST_GCN labels uniform C-MAPSS-shaped windows -- trained through the HIP path (ST_GCN.update: the matrix-core chain)
+and through the torch-CPU restatement of the reference's update (oracle/stgcn_torch_cpu.py, pinned to the reference's own training curve)
+from the same initial weights on the same batches; scored with the reference's formula (utils.py:148-151: RMSE x max_rul 125).
+North star: RMSE within 1e-3 of the reference.  bench.py reports the same quantity at ~49 k windows in its JSON line."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_teacher_task_rmse_within_1e_3_of_the_torch_cpu_restatement():
+    import bench
+    r = bench.rmse_teacher_task(torch.device("cuda:0"), epochs=2, n_train=16384, n_test=4096, batch=2048)
+    assert r["steps"] == 16
+    assert r["abs_diff"] <= 1e-3, r
+    assert r["rmse_hip"] < r["rmse_of_predicting_the_mean"], r              # the student did learn something in sixteen steps
+    assert abs(r["final_train_loss_hip"] - r["final_train_loss_torch_cpu"]) <= 1e-4 * abs(r["final_train_loss_torch_cpu"]) + 1e-7, r
