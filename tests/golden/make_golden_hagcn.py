@@ -105,6 +105,50 @@ def case(name, cfg, bs, num_node, seed, lo=0.0, hi=1.0, keep_td=False, keep_td_g
     print("wrote", name, out["eval_pred"].ravel()[:3], "kl", out["train_kl"], "loss", out["train_loss"])
 
 
+def case_margins(name, dims, G, num_node, seed0, min_gap=1e-3):
+    """Graph stack alone (GIN + SAGPool x 3, Model.py:165-176) on node features whose scores are NOT tied: standard-normal nodes instead
+    of LSTM outputs (whose cosine adjacency is ~1 everywhere), seeds searched until every RELATIVE gap between consecutive sorted scores
+    among the first k + 1 of every graph and level is >= min_gap.  There the reference's selection is a function of the arithmetic, not of
+    rounding noise, and an implementation must reproduce its sort indices EXACTLY (bit-exact index work)."""
+    for seed in range(seed0, seed0 + 500):
+        m = build(dict(patch_size=10, num_patch=1, **dims), seed)
+        g = torch.Generator().manual_seed(seed + 7)
+        nodes = torch.randn(G, num_node, dims["encoder_hidden_dim"], generator=g)
+        rec = []
+        _sort = torch.sort
+
+        def recording_sort(*a, **k):
+            r = _sort(*a, **k)
+            rec.append((r[0].detach().numpy().copy(), r[1].detach().numpy().copy()))
+            return r
+        torch.sort = recording_sort
+        try:
+            with torch.no_grad():
+                adj0 = ref_model.cosine_distance(nodes)
+                o1, a1, k1 = m.gnn1(m.gin1(nodes, adj0), adj0)
+                o2, a2, k2 = m.gnn2(m.gin2(o1, a1), a1)
+                o3, a3, k3 = m.gnn3(m.gin3(o2, a2), a2)
+        finally:
+            torch.sort = _sort
+        # relative gaps (= gaps of the logits the softmax scores come from): 1e-3 is a thousand times their fp32 rounding noise
+        gaps = [float(np.min((v[:, :k] - v[:, 1:k + 1]) / v[:, :k])) for (v, _), k in zip(rec, (10, 5, 1))]
+        if min(gaps) < min_gap:
+            continue
+        out = {"nodes": nodes.numpy().copy(), "seed": np.int64(seed), "gaps": np.array(gaps),
+               "feats": torch.cat([o1.mean(1), o2.mean(1), o3.mean(1)], -1).numpy().copy(), "kl": np.float64((k1 + k2 + k3).item())}
+        for k, v in dims.items():
+            out["cfg:" + k] = np.int64(v)
+        for k, v in mg.state_np(m, "sd:").items():
+            if not k.startswith("sd:TD.") and not k.startswith("sd:fc."):
+                out[k] = v
+        for l, (_, idx) in enumerate(rec):
+            out[f"order{l + 1}"] = idx.astype(np.int64)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print("wrote", name, "seed", seed, "smallest gaps per level", gaps)
+        return
+    raise RuntimeError("no seed with separated scores found")
+
+
 def case_init(name, cfg, seed):
     """Key order and per-tensor checksums of a freshly constructed reference model (initial-weight parity for a seed)."""
     torch.manual_seed(seed)
@@ -180,6 +224,9 @@ if __name__ == "__main__":
         case_trainer_cmapss("hagcn_trainer_cmapss_fd004_reference_run", 8)
         sys.exit(0)
     dims = dict(hidden_dim=64, encoder_hidden_dim=60, output_dim=32)
+    if len(sys.argv) > 1 and sys.argv[1] == "margins":
+        case_margins("hagcn_margins_14x60_g6", dims, 6, 14, 300)
+        sys.exit(0)
     case("hagcn_fd001_5x10_bs6", dict(patch_size=10, num_patch=5, **dims), 6, 14, seed=61, keep_td=True)
     case("hagcn_fd002_2x25_bs5", dict(patch_size=25, num_patch=2, **dims), 5, 14, seed=62)
     case("hagcn_fd004_1x50_bs7", dict(patch_size=50, num_patch=1, **dims), 7, 14, seed=63)
@@ -188,4 +235,5 @@ if __name__ == "__main__":
     case("hagcn_smalllstm_3x6_bs4", dict(patch_size=6, num_patch=3, hidden_dim=16, encoder_hidden_dim=8, output_dim=4), 4, 12, seed=66,
          keep_td=True, keep_td_grads=True)
     case_init("hagcn_init_fd004_seed65", dict(patch_size=50, num_patch=1, **dims), 65)
+    case_margins("hagcn_margins_14x60_g6", dims, 6, 14, 300)
     case_trainer_cmapss("hagcn_trainer_cmapss_fd004_reference_run", 8)

@@ -53,6 +53,16 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
 
 
+def elem_gate(got, ref, rtol=1e-4, floor=1e-6):
+    """Per-element form of the 1e-4 gate: the largest |got - ref| / (rtol |ref| + floor max|ref|) over the tensor.
+    The max-norm ratio of rel_err() lets a prediction near zero be 100 % off when the batch's largest |prediction| is 1; this one holds
+    every element to 1e-4 of ITS OWN magnitude plus an absolute floor of 1e-6 of the tensor's scale (the depth of fp32 accumulation).
+    <= 1 passes."""
+    a, b = np.asarray(got, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
+    tol = rtol * np.abs(b) + floor * (np.max(np.abs(b)) + 1e-30)
+    return float(np.max(np.abs(a - b) / tol))
+
+
 def abi_train(x_np, y_np, flat_np, N, P, L=2, mode="fwdbwd", dropout=0.0, seed=0, step=1, dpred_np=None,
               global_batch=None, sample_offset=0):
     """Train-mode entry points on cuda:0.  Returns dict(pred, loss, grads, bn_batch) as numpy."""

@@ -187,3 +187,28 @@ def test_lstm_stack_gradients_match_reference_golden():
     for k, p in m.named_parameters():
         if k.startswith("TD."):
             assert rel(p.grad.cpu().numpy(), z["grad:" + k]) < GTOL, k
+
+
+def test_free_running_selection_equals_the_reference_sort_indices_where_scores_are_separated():
+    """Bit-exact index parity: where the node scores are separated the selection is a function of the arithmetic,
+    and the kernel's own top-k -- nothing imposed -- must BE the reference's torch.sort indices (and the oracle's), exactly, in order.
+    Fixture: the reference's GIN / SAGPool stack on standard-normal node features (tests/golden/make_golden_hagcn.py::case_margins)."""
+    z = np.load(os.path.join(GOLD, "hagcn_margins_14x60_g6.npz"))
+    assert float(z["gaps"].min()) >= 1e-3
+    from gnn_rul_benchmarking_amd.hagcn import HAGCN_model
+    m = HAGCN_model(patch_size=10, num_patch=1, **cfg_of(z))
+    missing = m.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")}, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith(("TD.", "fc.")) for k in missing.missing_keys)      # the graph stack alone
+    m = m.to(DEV)
+    assert m.forced_topk is None
+    nodes = torch.from_numpy(z["nodes"]).to(DEV)
+    feats, kl = m.graph_stack(nodes)
+    got = kernel_topk(m)
+    p = {k[3:]: z[k].astype(np.float64) for k in z.files if k.startswith("sd:")}
+    fw = O.graph_forward(p, z["nodes"].astype(np.float64))
+    for l, k in enumerate((10, 5, 1)):
+        ref = z[f"order{l + 1}"][:, :k]
+        assert np.array_equal(got[l], ref), (l, got[l], ref)
+        assert np.array_equal(fw.levels[l].topk, ref)
+    assert rel(feats.detach().cpu().numpy(), z["feats"]) < TOL
+    assert abs(float(kl) - float(z["kl"])) < 1e-4 * abs(float(z["kl"])) + 1e-7
