@@ -536,7 +536,12 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
     for (; tile < a.ntiles; tile += tstride) {
         const int64_t s0 = tile * 4;
-        const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
+        const int ns_tile = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
+        // Two instantiations of the tile body: every tile but (at most) the last one is FULL -- there `ns` is the constant 4 and the
+        // per-sample guards of the partial tile (selects on every gradient element, scalar branches around the sums) compile away.
+        auto tile_body = [&](auto FULL_) {
+        constexpr bool FULL = decltype(FULL_)::value;
+        const int ns = FULL ? 4 : ns_tile;
         const int64_t nt = tile + tstride;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 }
             }
             if constexpr (WITH_PREV) { pend = true; pend_tile = tile; pend_ns = ns; }
-            continue;
+            return;
         }
 
         if constexpr (KIND == PH_TOP) {
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 if (col == 0) acc_loss = fmaf(diff, diff, acc_loss);
             }
             pend = true; pend_tile = tile; pend_ns = ns; pend_pred = pred;
-            if (!a.do_backward) continue;
+            if (!a.do_backward) return;
             const float dy1 = (y1 > 0.f) ? dpred * fc2w : 0.f;            // d(fc1 pre-activation), lane j
             float dpool = 0.f;
             fmac1_rowbcast<0>(dpool, dy1, fc1wT[0]);   fmac1_rowbcast<1>(dpool, dy1, fc1wT[1]);   fmac1_rowbcast<2>(dpool, dy1, fc1wT[2]);
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            continue;
+            return;
         }
 
         if constexpr (KIND == PH_G) {
@@ -957,6 +962,9 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             g_half(std::integral_constant<int, 2>{});
             if constexpr (BLK == 1 || LY >= 1) { pend = true; pend_tile = tile; pend_ns = ns; }
         }
+        };
+        if (ns_tile == 4) tile_body(std::true_type{});
+        else tile_body(std::false_type{});
     }
 
     // ---- the last tile's outputs ---------------------------------------------------------------------------------------------------------
