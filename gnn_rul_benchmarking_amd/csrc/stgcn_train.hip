@@ -900,10 +900,18 @@ __device__ __forceinline__ void finalize_unit(const FinalizeK& f, int unit, floa
         const int slice = wave * SPW + q;
         float v = 0.f;
         if (valid && !from_cells) {
-            // latency-bound: sixteen independent row reads in flight per lane, then the tail
+            // latency-bound: thirty-two (then sixteen) independent row reads in flight per lane, then the tail -- the 512 rows of the
+            // matrix-core chain are ONE round trip per lane; the order of the additions is the row order either way
             const float* col = f.gpart + p;
             const size_t rs = (size_t)f.pcount * FIN_SLICES;
             int b = slice;
+            for (; b + 31 * FIN_SLICES < nblk; b += 32 * FIN_SLICES) {
+                float r[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) r[u] = col[(size_t)b * f.pcount + u * rs];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v += r[u];
+            }
             for (; b + 15 * FIN_SLICES < nblk; b += 16 * FIN_SLICES) {
                 float r[16];
 #pragma unroll
@@ -1198,21 +1206,29 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
 __device__ __forceinline__ void prepare_body(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st,
                                              uint64_t seed, uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step,
                                              float lr, float beta1, float beta2, double bn_count) {
-    for (int i = threadIdx.x; i < nzero * CELL_REPLICAS; i += blockDim.x) cells[(i / nzero) * stride + zero_from + i % nzero] = 0.0;
-    if (threadIdx.x != 0) return;
-    sc->bn_count = bn_count;
-    if (new_forward) {
-        sc->pad[0] = 0u;                               // status word of the matrix-core chain (stgcn_train_mx.hip)
-        if (st) step = ++st->dropout_step;
-        for (int l = 0; l < 8; ++l) sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
+    // the scalar pieces on different wavefronts, beside the zeroing (one lane doing keys, two fp64 pow() and the stores in sequence was
+    // most of this kernel's 5 us)
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        sc->bn_count = bn_count;
+        if (new_forward) sc->pad[0] = 0u;              // status word of the matrix-core chain (stgcn_train_mx.hip)
     }
-    if (has_adam) {
+    if (new_forward && tid >= 64 && tid < 72) {        // one dropout key per lane
+        const int l = tid - 64;
+        if (st) {
+            if (l == 0) step = ++st->dropout_step;
+            step = __shfl(step, 0, 64);
+        }
+        sc->drop_key[l] = l < L ? dropout_layer_key(seed, step, l) : 0u;
+    }
+    if (has_adam && tid == 128) {
         if (st) adam_step = ++st->adam_step;
         const double bc1 = 1.0 - pow((double)beta1, (double)adam_step);
         const double bc2 = 1.0 - pow((double)beta2, (double)adam_step);
         sc->lr_over_bc1 = (float)((double)lr / bc1);
         sc->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     }
+    for (int i = tid; i < nzero * CELL_REPLICAS; i += blockDim.x) cells[(i / nzero) * stride + zero_from + i % nzero] = 0.0;
 }
 
 __global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, int stride, StepScratch* sc, StepState* st, uint64_t seed,
@@ -1431,7 +1447,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     (void)hipGetLastError();
     if (mode == TM_FORWARD || mode == TM_FWDBWD) {
         // a new forward: all cells, fresh dropout keys (a backward-only call below reuses the keys of its forward)
-        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), sc,
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(1024), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), sc,
                            a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
                            fused_adam ? opt->lr : 0.f, fused_adam ? opt->beta1 : 0.f, fused_adam ? opt->beta2 : 0.f, bn_count);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -1441,7 +1457,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         }
     } else {
         // backward after a separate forward: forward cells are valid, clear the backward ones + loss
-        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, cell_bwd(L), cell_stride(L) - cell_bwd(L),
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(1024), 0, stream, k.cells, cell_bwd(L), cell_stride(L) - cell_bwd(L),
                            cell_stride(L), sc, (StepState*)nullptr,
                            a->seed, a->step, L, 0, 0, (int64_t)0, 0.f, 0.f, 0.f, bn_count);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -1541,7 +1557,7 @@ static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
         // the step's prepare kernel alone: clears the reduction cells (same dropout step) so that a harness timing the phases one by one
         // runs them on valid BatchNorm statistics -- cells that keep accumulating from launch to launch drive the statistics out of range
         (void)hipGetLastError();
-        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(256), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), step_scratch(k.cells, L),
+        hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(1024), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), step_scratch(k.cells, L),
                            (StepState*)nullptr, a->seed, a->step, L, 1, 0, (int64_t)0, 0.f, 0.f, 0.f, (double)s->batch * (double)s->num_patch);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
