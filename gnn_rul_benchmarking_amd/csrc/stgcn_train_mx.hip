@@ -850,7 +850,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 f32x4 dI[NS];
                 {
                     u32x4 bh[NS], bl[NS];
-                    f32x4 dzT[NS], hT[NS], hsT[NS];
+                    f32x4 dzT[NS], hT[NS];
 #pragma unroll
                     for (int e = 0; e < NS; ++e) {
                         const Pk p = pack3(dz[e][0], dz[e][1], dz[e][2], 0.f);
@@ -859,7 +859,6 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                         bl[e] = cat(p.lo, nx.lo);
                         dzT[e] = mfma16z(cat(p.hi, p.lo), ident);
                         hT[e] = mfma16z(cat(hk[e].hi, hk[e].lo), ident);
-                        hsT[e] = mfma16z(cat(hks[e].hi, hks[e].lo), ident);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -874,7 +873,18 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     for (int e = 0; e < NS; ++e) {
                         q[e] = pack3(dzT[e][0], dzT[e][1], dzT[e][2], dzT[e][3]);
                         u[e] = pack3(hT[e][0], hT[e][1], hT[e][2], hT[e][3]);
-                        us[e] = pack3(hsT[e][0], hsT[e][1], hsT[e][2], hsT[e][3]);
+                        // The operand of the tap at t - d is the SAME transposed tile shifted by d columns.  In this arrangement lane
+                        // (g, slot) holds columns 4 g .. 4 g + 3 as two packed pairs, so the shift is a move between registers plus the
+                        // last pair of the row above (lane - 16; nothing above row 0 = the causal zeros): no third transposing MFMA, no
+                        // third split.  d = 2 (conv_block2): pairs move whole; d = 1 (conv_block1): halves recombine (two byte permutes).
+                        const unsigned uh = __builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u[e].hi.y), ul = __builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u[e].lo.y);
+                        const unsigned ah = g == 0 ? 0u : uh, al = g == 0 ? 0u : ul;
+                        if constexpr (BLK == 1) {
+                            us[e] = Pk{u32x2{ah, u[e].hi.x}, u32x2{al, u[e].lo.x}};
+                        } else {
+                            us[e] = Pk{u32x2{__builtin_amdgcn_perm(u[e].hi.x, ah, 0x05040302u), __builtin_amdgcn_perm(u[e].hi.y, u[e].hi.x, 0x05040302u)},
+                                       u32x2{__builtin_amdgcn_perm(u[e].lo.x, al, 0x05040302u), __builtin_amdgcn_perm(u[e].lo.y, u[e].lo.x, 0x05040302u)}};
+                        }
                         acc_w0 = mfma16(cat(q[e].hi, q[e].lo), cat(u[e].hi, u[e].hi), acc_w0);
                         acc_w1 = mfma16(cat(q[e].hi, q[e].lo), cat(us[e].hi, us[e].hi), acc_w1);
                     }
