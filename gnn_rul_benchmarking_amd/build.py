@@ -14,7 +14,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librulgnn.so")
-SOURCES = ["sgemm.hip", "stgcn_forward.hip", "stgcn_forward_mx.hip", "stgcn_train.hip", "stgcn_train_mx.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "rgcnu.hip", "stnet.hip", "sagcn.hip", "stagnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
+SOURCES = ["sgemm.hip", "stgcn_forward.hip", "stgcn_forward_mx.hip", "stgcn_train.hip", "stgcn_train_mx.hip", "stgcn_train_mxw.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "rgcnu.hip", "stnet.hip", "sagcn.hip", "stagnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
 
 
 def _hipcc() -> str:
@@ -42,7 +42,7 @@ OBJ_DIR = os.path.join(PKG_DIR, "..", "build", "obj")
 COMPILE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c"]
 # per-source additions.  stgcn_forward_mx.hip: the SLP vectoriser pairs scalar fp32 adds into v_pk_add_f32 and pays for it in
 # v_mov register shuffles (same FLOP rate on gfx950): measured 80 -> 73 us at batch 65536.
-EXTRA_FLAGS = {"stgcn_forward_mx.hip": ["-fno-slp-vectorize"], "stgcn_train_mx.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"stgcn_forward_mx.hip": ["-fno-slp-vectorize"], "stgcn_train_mx.hip": ["-fno-slp-vectorize"], "stgcn_train_mxw.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile_one(hipcc: str, src: str, obj: str, verbose: bool) -> None:

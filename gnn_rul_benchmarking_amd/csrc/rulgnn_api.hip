@@ -207,7 +207,7 @@ int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape* shape, const float
     if (tiled(shape)) return RULGNN_EUNSUPPORTED;
     if (path == RULGNN_STEP_CHAIN || path == RULGNN_STEP_COOP) return path;
     if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
-    if (stgcn_train_mx_shape_ok(shape, x)) return RULGNN_STEP_MX;
+    if (stgcn_train_mx_shape_ok(shape, x) || (shape->num_layers <= 2 && stgcn_train_mxw_shape_ok(shape, x))) return RULGNN_STEP_MX;
     return path == RULGNN_STEP_MX ? RULGNN_EUNSUPPORTED : RULGNN_STEP_CHAIN;
 }
 

@@ -132,4 +132,64 @@ __device__ __forceinline__ void dma_tile_fixed(const float* __restrict__ g, floa
     asm volatile("s_mov_b32 m0, %0" :: "s"(keep) : "memory");
 }
 
+
+
+// ---- patch statistics, lean form -------------------------------------------------------------------------------------
+// Same ten statistics as patch_statistics_regs<P, true> (Model.py:7-52) with two of the per-element accumulations removed:
+//  * sum x^2 = sum (x - mean)^2 + P mean^2 (both terms non-negative: no cancellation), so rms comes from the second pass;
+//  * sum |x| = +-sum x when the patch does not change sign (min >= 0 or max <= 0: every dataset the reference wires is scaled to
+//    [0, 1]); a wavefront with a mixed-sign patch takes the explicit sum (wave-uniform branch).
+template <int P>
+__device__ __forceinline__ void patch_load(const float* pp, float (&v)[P]) {
+    static_assert(P % 2 == 0 && P <= 64, "even patch sizes that fit the register budget");
+    const float2* p2 = reinterpret_cast<const float2*>(pp);
+#pragma unroll
+    for (int i = 0; i < P / 2; ++i) { const float2 q = p2[i]; v[2 * i] = q.x; v[2 * i + 1] = q.y; }
+}
+template <int P>
+__device__ __forceinline__ void patch_statistics_lean(const float (&v)[P], float (&st)[F]) {
+#pragma clang fp contract(off)          // see patch_statistics_regs: a constant patch must give the exact 0 deviation
+    float s = 0.f, mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        s += v[i] + v[i + 1];
+        mx = vmax3(mx, v[i], v[i + 1]);
+        mn = vmin3(mn, v[i], v[i + 1]);
+    }
+    float sa = mn >= 0.f ? s : -s;
+    if (__builtin_amdgcn_ballot_w64(mn < 0.f && mx > 0.f) != 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < P; i += 2) t += __builtin_fabsf(v[i]) + __builtin_fabsf(v[i + 1]);
+        sa = t;
+    }
+    const float invP = 1.0f / (float)P;
+    const float mean = s * invP;
+    float m2 = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+    for (int i = 0; i < P; i += 2) {
+        const float d0 = v[i] - mean, d1 = v[i + 1] - mean;
+        const float q0 = d0 * d0, q1 = d1 * d1;
+        m2 += q0 + q1;
+        m3 = fmaf(q0, d0, m3);
+        m3 = fmaf(q1, d1, m3);
+        m4 = fmaf(q0, q0, m4);
+        m4 = fmaf(q1, q1, m4);
+    }
+    const float var = m2 * (1.0f / (float)(P - 1));
+    const float sd = __builtin_amdgcn_sqrtf(var);
+    const float isd = __builtin_amdgcn_rcpf(sd);       // sd == 0 -> inf; 0 * inf = NaN like the reference's 0/0
+    const float isd2 = isd * isd;
+    st[0] = mx;
+    st[1] = mn;
+    st[2] = mx - mn;
+    st[3] = var;
+    st[4] = sd;
+    st[5] = mean;
+    st[6] = __builtin_amdgcn_sqrtf(fmaf(mean, mean, m2 * invP));
+    st[7] = sa * invP;
+    st[8] = (m3 * invP) * (isd2 * isd);
+    st[9] = (m4 * invP) * (isd2 * isd2) - 3.0f;
+}
+
 }  // namespace rulgnn

@@ -1388,10 +1388,12 @@ static int run_train_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_
 
 // ---- the matrix-core chain's view of the workspace (stgcn_train_mx.hip): X_0 tiles in cacheX, packed adjacency tiles in cacheA, X_l in
 // the saved slots X(l), TOP's sparse gradient in slot H(0), d(x0 + H) in sbuf, d X_l in rbuf ---------------------------------------------
+// The wide chain (stgcn_train_mxw.hip, 16 <= num_patch <= 47) keeps per-SAMPLE records in the same slots (a slot is ntiles x 640 floats in
+// either geometry: >= 160 floats per sample, which holds its largest record, 10 x 47 floats, whenever the geometry is one sample per tile).
 template <int L>
-static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k) {
+static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k, bool wide = false) {
     MxTrainArgs m;
-    const size_t tile_floats = (size_t)F * 4 * k.N;
+    const size_t tile_floats = wide ? (size_t)F * 64 : (size_t)F * 4 * k.N;
     m.prm = a->params; m.y = a->y; m.pred = a->pred; m.cells = k.cells; m.gpart = k.gpart;
     m.xrec[0] = k.cacheX;
     m.qrec[0] = nullptr;
@@ -1413,7 +1415,13 @@ static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train
 // phase numbering of rulgnn_stgcn_train_phase_f32: 0 .. 2L-1 = F_i, 2L = TOP, 2L+1+j = G_{2L-1-j}
 template <int L>
 static int mx_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k, const MxTrainArgs& m, int ph,
-                    hipStream_t stream, int max_grid, int* grid_out) {
+                    hipStream_t stream, int max_grid, int* grid_out, bool wide = false) {
+    if (wide) {
+        if (ph == 0) return stgcn_train_mxw_f0(m, a->x, s->patch_size, stream);
+        if (ph < 2 * L) return stgcn_train_mxw_phase(m, PH_F, ph, stream, max_grid, grid_out);
+        if (ph == 2 * L) return stgcn_train_mxw_phase(m, PH_TOP, 0, stream, max_grid, grid_out);
+        return stgcn_train_mxw_phase(m, PH_G, 4 * L - ph, stream, max_grid, grid_out);
+    }
     if (ph == 0)
         return stgcn_train_f0_mx_packed(s, a->x, a->params, m.xrec[0], m.arec, k.cells + cell_fwd(L), cell_stride(L), CELL_REPLICAS, stream);
     if (ph < 2 * L) return stgcn_train_mx_phase(m, PH_F, ph, stream, max_grid, grid_out);
@@ -1436,7 +1444,9 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     const float* gy = a->dpred ? a->dpred : a->y;
     // The matrix-core chain (stgcn_train_mx.hip): same prepare / cells / finalize, phases that recompute instead of reading saved
     // activations.  Whole MSE steps only (the autograd split and upstream gradients of unknown magnitude stay on the fp32 phases).
-    const bool use_mx = RW == 16 && path != RULGNN_STEP_CHAIN && mode == TM_FWDBWD && k.has_dpred == 0 && stgcn_train_mx_shape_ok(s, a->x);
+    const bool mx_step = path != RULGNN_STEP_CHAIN && mode == TM_FWDBWD && k.has_dpred == 0;
+    const bool use_mxw = mx_step && L <= 2 && stgcn_train_mxw_shape_ok(s, a->x);           // 16 <= num_patch <= 47: the wide chain
+    const bool use_mx = use_mxw || (RW == 16 && mx_step && stgcn_train_mx_shape_ok(s, a->x));
     if (path == RULGNN_STEP_MX && !use_mx) return RULGNN_EUNSUPPORTED;
 
     StepScratch* sc = step_scratch(k.cells, L);
@@ -1465,10 +1475,10 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     int grid_top = 0;
     int grids[16] = {0};
     if (use_mx) {
-        const MxTrainArgs m = mx_args<L>(s, a, k);
+        const MxTrainArgs m = mx_args<L>(s, a, k, use_mxw);
         for (int ph = 0; ph <= 4 * L; ++ph) {
             int grid = 0;
-            rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid);
+            rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid, use_mxw);
             if (rc != RULGNN_OK) return rc;
             // the reduction pair a phase completes (all-reduced here under synchronised BatchNorm; the later phases read the cells):
             // F_i -> forward pair i, TOP -> backward pair 2L-1, G_i -> backward pair i-1
@@ -1563,6 +1573,10 @@ static int run_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
     }
     if (phase < 0 || phase > 4 * L) return RULGNN_EINVAL;
     const float* gy = a->dpred ? a->dpred : a->y;
+    if (path != RULGNN_STEP_CHAIN && k.has_dpred == 0 && L <= 2 && stgcn_train_mxw_shape_ok(s, a->x)) {
+        const MxTrainArgs m = mx_args<L>(s, a, k, true);
+        return mx_phase<L>(s, a, k, m, phase, stream, w.max_grid, nullptr, true);
+    }
     if (lds.RW == 16 && path != RULGNN_STEP_CHAIN && k.has_dpred == 0 && stgcn_train_mx_shape_ok(s, a->x)) {
         const MxTrainArgs m = mx_args<L>(s, a, k);
         return mx_phase<L>(s, a, k, m, phase, stream, w.max_grid, nullptr);

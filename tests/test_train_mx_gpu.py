@@ -53,6 +53,9 @@ def abi_step(x_np, y_np, flat_np, N, P, L, path, dropout=0.0, seed=0, step=1, gl
 CASES = [(14, 30, 32, 2, 0.0), (14, 30, 1, 2, 0.0), (14, 30, 3, 2, 0.0), (14, 30, 5, 2, 0.2), (14, 30, 1027, 2, 0.0), (14, 30, 257, 2, 0.2),
          (14, 50, 130, 2, 0.5), (14, 30, 77, 1, 0.2), (14, 30, 41, 3, 0.2), (14, 30, 8192, 2, 0.2),
          (15, 16, 67, 2, 0.3), (12, 21, 35, 2, 0.2), (2, 6, 18, 2, 0.0), (8, 10, 19, 3, 0.1), (10, 10, 23, 1, 0.0)]
+# the wide chain (csrc/stgcn_train_mxw.hip): 16 <= num_patch <= 47 in two or three column tiles; PHM2012's 40 x 64 is the reference's wiring
+CASES += [(40, 64, 9, 2, 0.0), (40, 64, 33, 2, 0.2), (40, 64, 1, 2, 0.0), (40, 64, 700, 2, 0.2), (16, 16, 21, 2, 0.2), (17, 28, 19, 2, 0.3),
+          (24, 20, 37, 1, 0.2), (31, 12, 11, 2, 0.0), (32, 8, 13, 2, 0.5), (33, 16, 29, 2, 0.2), (47, 4, 15, 1, 0.0), (47, 12, 25, 2, 0.1)]
 
 
 @pytest.mark.parametrize("N,P,B,L,p", CASES)
@@ -101,7 +104,7 @@ def test_mx_chain_shard_semantics():
 def test_mx_chain_shape_rules():
     import gpu_util as G
     rng = np.random.default_rng(1)
-    for N, P in [(16, 16), (14, 31), (40, 64)]:            # num_patch > 15; num_patch x patch_size not a multiple of 4
+    for N, P in [(48, 16), (14, 31), (41, 7), (64, 8)]:    # num_patch > 47; num_patch x patch_size not a multiple of 4
         prm = O.random_params(N, 2, seed=1)
         flat, _ = PL.pack_numpy(prm, N, 2)
         x = rng.uniform(0, 1, (8, N, P)).astype(np.float32)
