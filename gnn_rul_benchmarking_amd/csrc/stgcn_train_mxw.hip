@@ -296,6 +296,9 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     constexpr bool GRAD_IN = KIND == PH_G && (BLK == 1 || LY >= 1);
     constexpr bool GRAD_TOP = GRAD_IN && LY == L - 1;
     constexpr bool NEED_SB = KIND == PH_G && BLK == 0;
+    // G_{2l} carries the most state (the theta-gradient tiles): its records are read from LDS where they are used instead of being held in
+    // registers across the sample, the next sample's records are requested once the region is free, and d X_l is stored without the delay
+    constexpr bool LATE = KIND == PH_G && BLK == 0;
     constexpr int NTH = 1 + (WITH_PREV ? 1 : 0) + (BWD_PREV ? 1 : 0);          // theta operand tables: theta^T(LY) | theta^T(LY-1) | theta(LY)
     static_assert(!(KIND == PH_F && IDX == 0), "F_0 is stgcn_train_f0_mxw_kernel");
     const int XS = mxw_xstride(N), DS = mxw_dstride(N);
@@ -303,16 +306,21 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     // ---- LDS: workgroup [theta tables | fc1 tables (TOP) | BatchNorm constants | row image | pair partials], then one region per wavefront
     constexpr int SH_BNC = (NBN * MXT_BNC * F + 3) & ~3;
     constexpr int TH_FLOATS = NTH * NT * NT * 64 * 4;
-    constexpr int FC_FLOATS = KIND == PH_TOP ? 2 * W * W : 0;
+    constexpr int FCP = W + 4;                                  // row pitch of the fc1 tables: 16-byte row reads of 16 lanes fall on distinct banks
+    constexpr int FC_FLOATS = KIND == PH_TOP ? 2 * W * FCP : 0;
     constexpr int RED_FLOATS = (W * W + W + CONVW + 3) & ~3;
     u32x4* const theta_lds = reinterpret_cast<u32x4*>(smem_all);
-    float* const fc1T = smem_all + TH_FLOATS;                  // [k][W]: fc1.w[j][k] at k W + j
-    float* const fc1N = fc1T + W * W;                          // [j][W]: fc1.w[j][k] at j W + k
+    float* const fc1N = smem_all + TH_FLOATS;                  // fc1.w[j][k] at j FCP + k: lane j reads its row (y1 = fc1 x pooled)
+    float* const fc1T = fc1N + W * FCP;                        // fc1.w[j][k] at k FCP + j: lane k reads its column (d pooled = fc1^T x d y1)
+    constexpr int COPS_FLOATS = LATE ? 31 * 64 : 0;           // G_{2l}: per-lane constant operands kept out of the register file
     float* const bnc = smem_all + TH_FLOATS + FC_FLOATS;
-    float* const red = bnc + SH_BNC;
-    double* const pairbuf = reinterpret_cast<double*>(red + RED_FLOATS);
-    constexpr int SH_ZERO = 4 * W, SH_LO = 4 * W + 1;
-    constexpr int SHIFT_FLOATS = ((2 * (4 * W + 1) * 2) + 3) & ~3;
+    double* const pairbuf = reinterpret_cast<double*>(bnc + SH_BNC);
+    float* const cops = bnc + SH_BNC + 2 * MXT_WAVES * (2 * F + 2);
+    float* const red = cops + COPS_FLOATS;                     // the epilogue's row image lies over the wavefronts' regions (all done by then)
+    // shift tile: [hi | lo][row group][2 zero entries | column 0 .. W): a tap at t - d (d <= 2) of column 0 / 1 reads the zeros in front of its
+    // row, a tap at t + d past the last column the zeros in front of the next row (two more behind the last): every tap is base + constant
+    constexpr int WP = W + 2, SH_LO = 4 * WP + 2;
+    constexpr int SHIFT_FLOATS = ((2 * SH_LO * 2) + 3) & ~3;
     const int off_zero = 0;                                    // 64 zero words
     const int off_scr = 64;                                    // 4 W floats: pooled | d y1 | d pool | arg-max
     const int off_sh = off_scr + 4 * W;
@@ -322,7 +330,8 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     const int off_DX = off_SB + (NEED_SB ? XS : 0);
     const int off_Q = off_DX + (GRAD_IN ? XS : 0);
     const int wave_floats = off_Q + (BWD_PREV ? XS : 0);
-    float* const smem = smem_all + TH_FLOATS + FC_FLOATS + SH_BNC + RED_FLOATS + 2 * MXT_WAVES * (2 * F + 2) + wave * wave_floats;
+    float* const smem = red + wave * wave_floats;
+    static_assert(RED_FLOATS <= MXT_WAVES * (64 + 4 * W + SHIFT_FLOATS + 160 + MXW_ASTRIDE), "row image fits the wavefronts' regions");
     u32x2* const sh_tile = reinterpret_cast<u32x2*>(smem + off_sh);
 
     int64_t smp = (int64_t)blockIdx.x * MXT_WAVES + wave;
@@ -343,41 +352,47 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------
     for (int i = lane; i < 64; i += 64) smem[off_zero + i] = 0.f;
-    if (lane < 2) sh_tile[SH_ZERO + SH_LO * lane] = u32x2{0u, 0u};
+    for (int i = lane; i < 2 * SH_LO; i += 64) sh_tile[i] = u32x2{0u, 0u};
     // theta tables.  Table 0 (and 1): theta^T of layer LY (LY - 1) as B operands of Hp = T x theta^T + b: tile (ct, jt), column j = 16 jt + col,
     // k-slot 4 g + r <-> patch 16 ct + 4 g + r, k-slot 15 of the last k-tile = the bias, (1 + a)/2 folded in.  Last table (G_{2l}, l >= 1):
     // theta itself as B operands of d X = U x theta: tile (jt, kt), column k = 16 kt + col, k-slot <-> row j = 16 jt + 4 g + r.
-    for (int idx = wave; idx < NTH * NT * NT; idx += MXT_WAVES) {
+    // (all loads of the prologue are issued before the first conversion: the tables cost one memory round trip, not one per tile)
+    constexpr int TT = NTH * NT * NT, TIT = (TT + MXT_WAVES - 1) / MXT_WAVES;
+    float tw[TIT][4];
+    bool tok[TIT][4];
+#pragma unroll
+    for (int it = 0; it < TIT; ++it) {
+        const int idx = (wave + MXT_WAVES * it < TT) ? wave + MXT_WAVES * it : TT - 1;        // (the surplus slots of the last round load tile TT - 1 again)
         const int tab = idx / (NT * NT), ct = (idx / NT) % NT, jt = idx % NT;
         const bool plain = BWD_PREV && tab == NTH - 1;
         const int layer = plain ? LY : (tab == 0 ? LY : LY - 1);
         const float* lp = a.prm + layer * LS;
-        float w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            int off;
             if (plain) {
                 const int j = 16 * ct + 4 * g + r, k = 16 * jt + col;
-                const bool ok = j < N && k < N;
-                const float v = lp[ok ? off_theta_w(N) + j * N + k : 0];
-                w[r] = ok ? v : 0.f;
+                tok[it][r] = j < N && k < N;
+                off = off_theta_w(N) + j * N + k;
             } else {
                 const int j = 16 * jt + col, k = 16 * ct + 4 * g + r;
                 const bool bias = ct == NT - 1 && 4 * g + r == 15;
-                const bool ok = j < N && (k < N || bias);
-                const float v = lp[ok ? (bias ? off_theta_b(N) + j : off_theta_w(N) + j * N + k) : 0];
-                w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
+                tok[it][r] = j < N && (k < N || bias);
+                off = bias ? off_theta_b(N) + j : off_theta_w(N) + j * N + k;
             }
+            tw[it][r] = lp[tok[it][r] ? off : 0] * (plain ? 1.f : 0.5f * (1.f + LEAKY));
         }
-        const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
-        theta_lds[idx * 64 + lane] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
     }
+    constexpr int FIT = KIND == PH_TOP ? (W * W) / (64 * MXT_WAVES) : 0;
+    static_assert((W * W) % (64 * MXT_WAVES) == 0, "fc1 table elements per thread");
+    float fv[FIT > 0 ? FIT : 1];
     if constexpr (KIND == PH_TOP) {
-        for (int i = threadIdx.x; i < W * W; i += 64 * MXT_WAVES) {
-            const int j = i / W, k = i % W;
+#pragma unroll
+        for (int q = 0; q < FIT; ++q) {
+            const int i = threadIdx.x + 64 * MXT_WAVES * q, j = i / W, k = i % W;
             const bool ok = j < N && k < N;
             const float v = a.prm[off_fc1_w(N, L) + (ok ? j * N + k : 0)];
-            fc1N[j * W + k] = ok ? v : 0.f;
-            fc1T[k * W + j] = ok ? v : 0.f;
+            fv[q] = ok ? v : 0.f;
         }
     }
     constexpr int M0_LY = (KIND == PH_F && BLK == 0) ? 1 : 2;
@@ -396,12 +411,30 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         ident = u32x4{p01, p23, p01, p23};
     }
     {
+        // (the BatchNorm pairs' loads go out behind the table loads, their fp64 arithmetic runs under those)
         constexpr int FW0 = WITH_PREV ? 2 * LY - 2 : 2 * LY;
         constexpr int NFW = (KIND == PH_F && BLK == 1) || (KIND == PH_G && BLK == 0) ? 1 : 2;
         if (wave < NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
         if (KIND == PH_G && wave == NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, false, IDX, lane);
-        __syncthreads();
     }
+#pragma unroll
+    for (int it = 0; it < TIT; ++it) {
+        const int idx = wave + MXT_WAVES * it;
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = tok[it][r] ? tw[it][r] : 0.f;
+        const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
+        if (idx < TT) theta_lds[idx * 64 + lane] = u32x4{p01.hi, p23.hi, p01.lo, p23.lo};
+    }
+    if constexpr (KIND == PH_TOP) {
+#pragma unroll
+        for (int q = 0; q < FIT; ++q) {
+            const int i = threadIdx.x + 64 * MXT_WAVES * q, j = i / W, k = i % W;
+            fc1N[j * FCP + k] = fv[q];
+            fc1T[k * FCP + j] = fv[q];
+        }
+    }
+    __syncthreads();
     LayerK kc, kp;
     layer_constants(kc, rc, bnc, LY, g, col, M0_LY, M1_LY);
     if constexpr (WITH_PREV) layer_constants(kp, rp, bnc, LY - 1, g, col, 2, 2);
@@ -416,6 +449,31 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             bk2[r] = c >= 0 ? q[6 * F + c] * a.gscale : 0.f;
         }
     }
+    if constexpr (LATE) {
+        // [0..3] x 64 x 16 bytes: conv_block1 forward operand (hi, lo), its transposed operand (hi, lo); then 9 x 64 floats: the BatchNorm
+        // backward constants per register row
+        if (wave == 0) {
+            u32x4* c4 = reinterpret_cast<u32x4*>(cops);
+            c4[lane] = kc.w[0].hi; c4[64 + lane] = kc.w[0].lo; c4[128 + lane] = wT.hi; c4[192 + lane] = wT.lo;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                cops[(16 + r) * 64 + lane] = bA[r];
+                cops[(19 + r) * 64 + lane] = bk1[r];
+                cops[(22 + r) * 64 + lane] = bk2[r];
+                cops[(25 + r) * 64 + lane] = kc.gam[0][r];
+                cops[(28 + r) * 64 + lane] = kc.bet[0][r];
+            }
+        }
+        __syncthreads();
+    }
+    auto conv_fwd0 = [&]() -> ConvOp {
+        if constexpr (LATE) { const u32x4* c4 = reinterpret_cast<const u32x4*>(cops); return ConvOp{c4[lane], c4[64 + lane]}; }
+        else return kc.w[0];
+    };
+    auto conv_bwd = [&]() -> ConvOp {
+        if constexpr (LATE) { const u32x4* c4 = reinterpret_cast<const u32x4*>(cops); return ConvOp{c4[128 + lane], c4[192 + lane]}; }
+        else return wT;
+    };
     float fc1b = 0.f, fc2w = 0.f, fc2b = 0.f;
     if constexpr (KIND == PH_TOP) {
         const int jc = lane < N ? lane : 0;
@@ -436,7 +494,8 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         }
     }
     float colm[NT];
-    int xoff[NT][3], sh_wr[NT], sh_rd1[NT], sh_rd2[NT], sh_rd1_lo[NT], sh_rd2_lo[NT], sh_bk[NT], sh_bk_lo[NT];
+    int xoff[NT][3];
+    const int shb = g * WP + 2 + col;
     uint32_t dro[NT][3];
     constexpr int DB = BLK == 0 ? 1 : 2;                       // dilation of this phase's backward convolution
 #pragma unroll
@@ -448,14 +507,6 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             xoff[ct][r] = (chan[r] >= 0 && t < N) ? chan[r] * N + t : -1;
             dro[ct][r] = (uint32_t)((chan[r] >= 0 ? chan[r] : 0) * N + t);
         }
-        sh_wr[ct] = g * W + t;
-        sh_rd1[ct] = t >= 1 ? g * W + t - 1 : SH_ZERO;
-        sh_rd2[ct] = t >= 2 ? g * W + t - 2 : SH_ZERO;
-        sh_bk[ct] = t + DB < W ? g * W + t + DB : SH_ZERO;
-        sh_rd1_lo[ct] = sh_rd1[ct] + SH_LO;
-        sh_rd2_lo[ct] = sh_rd2[ct] + SH_LO;
-        sh_bk_lo[ct] = sh_bk[ct] + SH_LO;
-        asm volatile("" : "+v"(sh_rd1_lo[ct]), "+v"(sh_rd2_lo[ct]), "+v"(sh_bk_lo[ct]));
     }
     auto ld_rec = [&](int base, float (&v)[NT][3]) {
 #pragma unroll
@@ -532,19 +583,19 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         }
     };
     // z = W x [D ; D shifted] over the whole patch axis (the shift crosses tile boundaries); `rd` picks the direction / distance
-    auto stage_conv = [&](const float (&D)[NT][3], float partner, const ConvOp& w, const int (&rd)[NT], const int (&rd_lo)[NT], f32x4 (&z)[NT],
-                          Pk (&keep)[NT]) {
+    auto stage_conv = [&](const float (&D)[NT][3], float partner, const ConvOp& w, auto tap, f32x4 (&z)[NT], Pk (&keep)[NT]) {
+        constexpr int TAP = decltype(tap)::value;                  // -1 | -2: the causal taps; +1 | +2: the transposed convolution's
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             keep[jt] = pack3(D[jt][0], D[jt][1], D[jt][2], partner);
-            sh_tile[sh_wr[jt]] = keep[jt].hi;
-            sh_tile[SH_LO + sh_wr[jt]] = keep[jt].lo;
+            sh_tile[shb + 16 * jt] = keep[jt].hi;
+            sh_tile[shb + 16 * jt + SH_LO] = keep[jt].lo;
         }
         __builtin_amdgcn_wave_barrier();
         u32x4 bh[NT], bl[NT];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
-            const u32x2 ph = sh_tile[rd[jt]], pl = sh_tile[rd_lo[jt]];
+            const u32x2 ph = sh_tile[shb + 16 * jt + TAP], pl = sh_tile[shb + 16 * jt + TAP + SH_LO];
             bh[jt] = cat(keep[jt].hi, ph);
             bl[jt] = cat(keep[jt].lo, pl);
         }
@@ -567,14 +618,14 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         stage_T(X, adjB, T, xo);
         stage_theta(T, tab, true, Hp);
         leaky_of(Hp, H);
-        stage_conv(H, 1.0f, k.w[0], sh_rd1, sh_rd1_lo, z, pk);
+        stage_conv(H, 1.0f, k.w[0], std::integral_constant<int, -1>{}, z, pk);
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             keep_until_here(z[jt][3]);
 #pragma unroll
             for (int r = 0; r < 3; ++r) V[jt][r] = relu2(fmaf(2.f, H[jt][r], relu2(fmaf(k.gam[0][r], z[jt][r], k.bet[0][r]))));
         }
-        stage_conv(V, 1.0f, k.w[1], sh_rd2, sh_rd2_lo, z, pk);
+        stage_conv(V, 1.0f, k.w[1], std::integral_constant<int, -2>{}, z, pk);
         uint32_t mbits = 0u;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
@@ -625,7 +676,6 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 if (use_drop) a.mrec[LY - 1][pend_smp * 64 + lane] = pend_m;
             }
             if constexpr (KIND == PH_G && BLK == 1) st_rec(a.sb + pend_smp * XS, pend_v);
-            if constexpr (BWD_PREV) st_rec(a.dx + pend_smp * XS, pend_v);
             if constexpr (KIND == PH_TOP) {
                 if (lane < N && a.do_backward) {
                     float* p = a.dtop + pend_smp * DS + lane;
@@ -648,7 +698,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (nx < a.B) req_XA(nx);
+        if (!LATE && nx < a.B) req_XA(nx);
         const uint32_t sbase = (uint32_t)((a.sample_offset + smp) * F) * (uint32_t)N;
 
         if constexpr (KIND == PH_F) {
@@ -667,9 +717,9 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             stage_theta(T, 0, true, Hp);
             leaky_of(Hp, H);
             if constexpr (BLK == 0) {
-                stage_conv(H, 0.f, kc.w[0], sh_rd1, sh_rd1_lo, z, pk);
+                stage_conv(H, 0.f, kc.w[0], std::integral_constant<int, -1>{}, z, pk);
             } else {
-                stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, pk);
+                stage_conv(H, 1.0f, kc.w[0], std::integral_constant<int, -1>{}, z, pk);
                 float V[NT][3];
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) {
@@ -677,7 +727,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 #pragma unroll
                     for (int r = 0; r < 3; ++r) V[jt][r] = relu2(fmaf(2.f, H[jt][r], relu2(fmaf(kc.gam[0][r], z[jt][r], kc.bet[0][r]))));
                 }
-                stage_conv(V, 0.f, kc.w[1], sh_rd2, sh_rd2_lo, z, pk);
+                stage_conv(V, 0.f, kc.w[1], std::integral_constant<int, -2>{}, z, pk);
             }
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
@@ -729,11 +779,19 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             float* scr = smem + off_scr;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            scr[lane] = pooled;                                        // lanes >= W do not exist as patches: W <= 48 < 64, their zeros are harmless
+            if (lane < W) scr[lane] = pooled;
             __builtin_amdgcn_wave_barrier();
             float y1 = fc1b;
             const int jl = lane < W ? lane : 0;
-            for (int k = 0; k < N; ++k) y1 = fmaf(fc1T[k * W + jl], scr[k], y1);
+            {
+                const float4* row = reinterpret_cast<const float4*>(fc1N + jl * FCP);
+                const float4* vec = reinterpret_cast<const float4*>(scr);
+#pragma unroll
+                for (int k4 = 0; k4 < W / 4; ++k4) {
+                    const float4 wv = row[k4], pv = vec[k4];
+                    y1 = fmaf(wv.x, pv.x, y1); y1 = fmaf(wv.y, pv.y, y1); y1 = fmaf(wv.z, pv.z, y1); y1 = fmaf(wv.w, pv.w, y1);
+                }
+            }
             y1 = valid ? relu(y1) : 0.f;
             const float pred = Row<64>::allsum(y1 * fc2w) + fc2b;
             const float diff = pred - a.y[smp];
@@ -742,10 +800,18 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             pend = true; pend_smp = smp; pend_pred = pred;
             if (!a.do_backward) continue;
             const float dy1 = (y1 > 0.f) ? dpred * fc2w : 0.f;         // lane j
-            scr[W + lane] = dy1;
+            if (lane < W) scr[W + lane] = dy1;
             __builtin_amdgcn_wave_barrier();
             float dpool = 0.f;
-            for (int j = 0; j < N; ++j) dpool = fmaf(fc1N[j * W + jl], scr[W + j], dpool);
+            {
+                const float4* row = reinterpret_cast<const float4*>(fc1T + jl * FCP);
+                const float4* vec = reinterpret_cast<const float4*>(scr + W);
+#pragma unroll
+                for (int j4 = 0; j4 < W / 4; ++j4) {
+                    const float4 wv = row[j4], dv = vec[j4];
+                    dpool = fmaf(wv.x, dv.x, dpool); dpool = fmaf(wv.y, dv.y, dpool); dpool = fmaf(wv.z, dv.z, dpool); dpool = fmaf(wv.w, dv.w, dpool);
+                }
+            }
             dpool = valid ? dpool : 0.f;
             acc_w2 = fmaf(dpred, y1, acc_w2);
             acc_b2 += lane == 0 ? dpred : 0.f;
@@ -767,8 +833,10 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             pend_top0 = dpool;
             pend_top1 = __builtin_bit_cast(float, arg);
             // the sums of the last BatchNorm want d X_L in the D layout
-            scr[2 * W + lane] = dpool;
-            scr[3 * W + lane] = __builtin_bit_cast(float, arg);
+            if (lane < W) {
+                scr[2 * W + lane] = dpool;
+                scr[3 * W + lane] = __builtin_bit_cast(float, arg);
+            }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
@@ -789,7 +857,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 
         if constexpr (KIND == PH_G) {
             float gin[NT][3];
-            if constexpr (GRAD_TOP) {
+            if constexpr (GRAD_TOP && !LATE) {
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct) {
                     const int t = 16 * ct + col;
@@ -798,15 +866,14 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 #pragma unroll
                     for (int r = 0; r < 3; ++r) gin[ct][r] = (chan[r] == da) ? dv : 0.f;
                 }
-            } else if constexpr (GRAD_IN) {
+            } else if constexpr (GRAD_IN && !LATE) {
                 ld_rec(off_DX, gin);
             }
-            float SB[NT][3], Q[NT][3];
-            if constexpr (NEED_SB) ld_rec(off_SB, SB);
-            if constexpr (BWD_PREV) ld_rec(off_Q, Q);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            if (nx < a.B) { req_SB(nx); req_DX(nx); req_Q(nx); }
+            if constexpr (!LATE) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if (nx < a.B) req_DX(nx);
+            }
             uint32_t mask_cur = 0u;
             if constexpr (MASK_IN) {
                 mask_cur = mask_next;
@@ -818,25 +885,29 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             float H[NT][3];
             Op2 xo[NT];
             stage_T(X, adjB, T, xo);
-            if constexpr (BLK == 0) {
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) {
-                    AXd[ct] = mfma16z(adjB, xo[ct].h);
-                    AXd[ct] = mfma16(adjB, xo[ct].l, AXd[ct]);
-                }
-            }
             stage_theta(T, 0, true, Hp);
             leaky_of(Hp, H);
+            uint32_t hp_pos = 0u;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) hp_pos |= Hp[jt][r] > 0.f ? 1u << (3 * jt + r) : 0u;
             Pk hk[NT];
-            stage_conv(H, 1.0f, kc.w[0], sh_rd1, sh_rd1_lo, z, hk);
+            stage_conv(H, 1.0f, conv_fwd0(), std::integral_constant<int, -1>{}, z, hk);
             float xh0[NT][3], y1[NT][3];
+            float gam0[3], bet0[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                gam0[r] = LATE ? cops[(25 + r) * 64 + lane] : kc.gam[0][r];
+                bet0[r] = LATE ? cops[(28 + r) * 64 + lane] : kc.bet[0][r];
+            }
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 keep_until_here(z[jt][3]);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     xh0[jt][r] = z[jt][r];
-                    y1[jt][r] = fmaf(kc.gam[0][r], z[jt][r], kc.bet[0][r]);
+                    y1[jt][r] = fmaf(gam0[r], z[jt][r], bet0[r]);
                 }
             }
             float dz[NT][3], gsum[NT][3], V[NT][3];
@@ -845,7 +916,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                 for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) V[jt][r] = relu2(fmaf(2.f, H[jt][r], relu2(y1[jt][r])));
-                stage_conv(V, 1.0f, kc.w[1], sh_rd2, sh_rd2_lo, z, hk);             // hk <- V
+                stage_conv(V, 1.0f, kc.w[1], std::integral_constant<int, -2>{}, z, hk);             // hk <- V
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) {
                     keep_until_here(z[jt][3]);
@@ -862,63 +933,72 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     }
                 }
             } else {
+                float cA[3], c1[3], c2[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    cA[r] = cops[(16 + r) * 64 + lane];
+                    c1[r] = cops[(19 + r) * 64 + lane];
+                    c2[r] = cops[(22 + r) * 64 + lane];
+                }
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const float dy = y1[jt][r] > 0.f ? SB[jt][r] : 0.f;
-                        dz[jt][r] = bA[r] * (fmaf(-xh0[jt][r], bk2[r], dy) - bk1[r]) * colm[jt];
+                        const float sbv = smem[xoff[jt][r] >= 0 ? off_SB + xoff[jt][r] : off_zero];
+                        const float dy = y1[jt][r] > 0.f ? sbv : 0.f;
+                        dz[jt][r] = cA[r] * (fmaf(-xh0[jt][r], c2[r], dy) - c1[r]) * colm[jt];
                     }
             }
             // d(input of the convolution) = W^T-conv(d z); weight gradient from the transposed tiles
             f32x4 dI[NT];
             {
                 Pk dzp[NT];
-                stage_conv(dz, 0.f, wT, sh_bk, sh_bk_lo, dI, dzp);
-                Pk q[NT], u[NT], us[NT];
+                stage_conv(dz, 0.f, conv_bwd(), std::integral_constant<int, DB>{}, dI, dzp);
+                // per column tile: both tiles transposed (one identity product each), the tap at t - d built in the transposed arrangement --
+                // lane group g of tile ct holds columns 16 ct + 4 g .. + 3 as two packed pairs; the pair above comes from lane - 16, or from
+                // row group 3 of the tile before -- and the weight-gradient products; the hi . lo cross terms go two tiles per instruction
+                const u32x2 z2 = u32x2{0u, 0u};
+                Pk qp = Pk{z2, z2}, up = Pk{z2, z2}, usp = Pk{z2, z2};
+                unsigned prev_hy = 0u, prev_ly = 0u;
 #pragma unroll
                 for (int ct = 0; ct < NT; ++ct) {
                     const f32x4 dzT = mfma16z(cat(dzp[ct].hi, dzp[ct].lo), ident);
                     const f32x4 hT = mfma16z(cat(hk[ct].hi, hk[ct].lo), ident);
-                    q[ct] = pack3(dzT[0], dzT[1], dzT[2], dzT[3]);
-                    u[ct] = pack3(hT[0], hT[1], hT[2], hT[3]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // the tap at t - d: the transposed tile shifted by d columns -- lane group g of tile ct holds columns 16 ct + 4 g .. + 3 as two
-                // packed pairs; the pair above comes from lane - 16, or from row group 3 of the tile before
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) {
-                    unsigned ah = (unsigned)__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u[ct].hi.y);
-                    unsigned al = (unsigned)__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u[ct].lo.y);
+                    const Pk q = pack3(dzT[0], dzT[1], dzT[2], dzT[3]);
+                    const Pk u = pack3(hT[0], hT[1], hT[2], hT[3]);
+                    unsigned ah = (unsigned)__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u.hi.y);
+                    unsigned al = (unsigned)__builtin_amdgcn_ds_bpermute((lane - 16) << 2, (int)u.lo.y);
                     if (ct > 0) {
-                        const unsigned bh2 = (unsigned)__builtin_amdgcn_ds_bpermute((lane + 48) << 2, (int)u[ct - 1].hi.y);
-                        const unsigned bl2 = (unsigned)__builtin_amdgcn_ds_bpermute((lane + 48) << 2, (int)u[ct - 1].lo.y);
+                        const unsigned bh2 = (unsigned)__builtin_amdgcn_ds_bpermute((lane + 48) << 2, (int)prev_hy);
+                        const unsigned bl2 = (unsigned)__builtin_amdgcn_ds_bpermute((lane + 48) << 2, (int)prev_ly);
                         ah = g == 0 ? bh2 : ah;
                         al = g == 0 ? bl2 : al;
                     } else {
                         ah = g == 0 ? 0u : ah;
                         al = g == 0 ? 0u : al;
                     }
+                    Pk us;
                     if constexpr (BLK == 1) {
-                        us[ct] = Pk{u32x2{ah, u[ct].hi.x}, u32x2{al, u[ct].lo.x}};
+                        us = Pk{u32x2{ah, u.hi.x}, u32x2{al, u.lo.x}};
                     } else {
-                        us[ct] = Pk{u32x2{__builtin_amdgcn_perm(u[ct].hi.x, ah, 0x05040302u), __builtin_amdgcn_perm(u[ct].hi.y, u[ct].hi.x, 0x05040302u)},
-                                    u32x2{__builtin_amdgcn_perm(u[ct].lo.x, al, 0x05040302u), __builtin_amdgcn_perm(u[ct].lo.y, u[ct].lo.x, 0x05040302u)}};
+                        us = Pk{u32x2{__builtin_amdgcn_perm(u.hi.x, ah, 0x05040302u), __builtin_amdgcn_perm(u.hi.y, u.hi.x, 0x05040302u)},
+                                u32x2{__builtin_amdgcn_perm(u.lo.x, al, 0x05040302u), __builtin_amdgcn_perm(u.lo.y, u.lo.x, 0x05040302u)}};
                     }
+                    acc_w0 = mfma16(cat(q.hi, q.lo), cat(u.hi, u.hi), acc_w0);
+                    acc_w1 = mfma16(cat(q.hi, q.lo), cat(us.hi, us.hi), acc_w1);
+                    if (ct % 2 == 1) {
+                        acc_w0 = mfma16(cat(qp.hi, q.hi), cat(up.lo, u.lo), acc_w0);
+                        acc_w1 = mfma16(cat(qp.hi, q.hi), cat(usp.lo, us.lo), acc_w1);
+                    } else if (ct == NT - 1) {
+                        acc_w0 = mfma16(cat(q.hi, z2), cat(u.lo, z2), acc_w0);
+                        acc_w1 = mfma16(cat(q.hi, z2), cat(us.lo, z2), acc_w1);
+                    } else {
+                        qp = q; up = u; usp = us;
+                    }
+                    prev_hy = u.hi.y;
+                    prev_ly = u.lo.y;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct) {
-                    acc_w0 = mfma16(cat(q[ct].hi, q[ct].lo), cat(u[ct].hi, u[ct].hi), acc_w0);
-                    acc_w1 = mfma16(cat(q[ct].hi, q[ct].lo), cat(us[ct].hi, us[ct].hi), acc_w1);
-                }
-                const u32x2 z2 = u32x2{0u, 0u};
-#pragma unroll
-                for (int ct = 0; ct < NT; ct += 2) {                  // the hi . lo cross terms, two tiles per instruction
-                    const bool two = ct + 1 < NT;
-                    acc_w0 = mfma16(cat(q[ct].hi, two ? q[ct + 1 < NT ? ct + 1 : ct].hi : z2), cat(u[ct].lo, two ? u[ct + 1 < NT ? ct + 1 : ct].lo : z2), acc_w0);
-                    acc_w1 = mfma16(cat(q[ct].hi, two ? q[ct + 1 < NT ? ct + 1 : ct].hi : z2), cat(us[ct].lo, two ? us[ct + 1 < NT ? ct + 1 : ct].lo : z2), acc_w1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (BLK == 1) {
 #pragma unroll
@@ -943,15 +1023,30 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     float dHp[3];
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
-                        const float gq = dI[jt][r] + SB[jt][r];
-                        dHp[r] = (Hp[jt][r] > 0.f ? gq : gq * LEAKY) * colm[jt];
+                        const float gq = dI[jt][r] + smem[xoff[jt][r] >= 0 ? off_SB + xoff[jt][r] : off_zero];
+                        dHp[r] = ((hp_pos >> (3 * jt + r)) & 1u ? gq : gq * LEAKY) * colm[jt];
                         acc_b[jt] += dHp[r];
                     }
                     dk[jt] = pack3(dHp[0], dHp[1], dHp[2], 0.f);
                 }
                 {
+                    // A x X (the other operand of the theta gradient) from the X record, which is still in LDS
                     Pk ax[NT];
                     const u32x2 z2 = u32x2{0u, 0u};
+                    {
+                        float X2[NT][3];
+                        ld_rec(off_X, X2);
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) {
+                            const Split2 p01 = split2(X2[ct][0], X2[ct][1]), p2 = split2(X2[ct][2], 0.f);
+                            AXd[ct] = mfma16z(adjB, u32x4{p01.hi, p2.hi, p01.hi, p2.hi});
+                            AXd[ct] = mfma16(adjB, u32x4{p01.lo, p2.lo, p01.lo, p2.lo}, AXd[ct]);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        if (nx < a.B) { req_XA(nx); req_SB(nx); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int kt = 0; kt < NT; ++kt) {
                         keep_until_here(AXd[kt][3]);
@@ -975,20 +1070,37 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     stage_theta(U, NTH - 1, false, dXl);
+                    float Q[NT][3], dXo[NT][3];
+                    if constexpr (GRAD_TOP) {
+#pragma unroll
+                        for (int ct = 0; ct < NT; ++ct) {
+                            const int t = 16 * ct + col;
+                            const float dv = smem[t < N ? off_DX + t : off_zero];
+                            const int da = __builtin_bit_cast(int, smem[t < N ? off_DX + N + t : off_zero]);
+#pragma unroll
+                            for (int r = 0; r < 3; ++r) gin[ct][r] = (chan[r] == da) ? dv : 0.f;
+                        }
+                    } else {
+                        ld_rec(off_DX, gin);
+                    }
+                    ld_rec(off_Q, Q);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (nx < a.B) { req_DX(nx); req_Q(nx); }
 #pragma unroll
                     for (int kt = 0; kt < NT; ++kt) {
                         keep_until_here(dXl[kt][3]);
 #pragma unroll
                         for (int r = 0; r < 3; ++r) {
                             const float dX = (dXl[kt][r] + gin[kt][r]) * colm[kt];
-                            pend_v[kt][r] = dX;
+                            dXo[kt][r] = dX;
                             const bool open = Q[kt][r] < INFINITY;
                             const float dy = open ? dX * a.drop_scale : 0.f;
                             s_a[r] += dy;
                             s_b[r] = fmaf(dy, open ? Q[kt][r] : 0.f, s_b[r]);
                         }
                     }
-                    pend = true; pend_smp = smp;
+                    st_rec(a.dx + smp * XS, dXo);
                 }
             }
         }
@@ -1002,7 +1114,6 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             if (use_drop) a.mrec[LY - 1][pend_smp * 64 + lane] = pend_m;
         }
         if constexpr (KIND == PH_G && BLK == 1) st_rec(a.sb + pend_smp * XS, pend_v);
-        if constexpr (BWD_PREV) st_rec(a.dx + pend_smp * XS, pend_v);
         if constexpr (KIND == PH_TOP) {
             if (lane < N && a.do_backward) {
                 float* p = a.dtop + pend_smp * DS + lane;
@@ -1067,9 +1178,12 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     // ---- the workgroup's row of partial gradients (LDS image of the phase's contiguous parameter range) --------------------------------
     const float us = a.inv_gscale;
     const int NN = N * N;
-    for (int w = 0; w < MXT_WAVES; ++w) {
-        if (wave == w) {
-            auto put = [&](int idx, float v) { red[idx] = (w == 0) ? v : red[idx] + v; };
+    // two images (wavefronts 0 | 1 store, then 2 | 3 add), summed on the way out: two rounds, a fixed order of additions
+    static_assert(2 * RED_FLOATS <= MXT_WAVES * (64 + 4 * W + SHIFT_FLOATS + 160 + MXW_ASTRIDE), "two row images fit the wavefronts' regions");
+    for (int w = 0; w < 2; ++w) {
+        if ((wave >> 1) == w) {
+            float* const img = red + (wave & 1) * RED_FLOATS;
+            auto put = [&](int idx, float v) { img[idx] = (w == 0) ? v : img[idx] + v; };
             // [N][N] matrix (theta or fc1): tile (jt, kt) in the MFMA D layout, row j = 16 jt + 4 g + r, column k = 16 kt + col
             if (KIND == PH_TOP || BLK == 0) {
 #pragma unroll
@@ -1119,7 +1233,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     else { rbase = LY * LS + off_conv_w(N, 1); rlen = CONVW; }
     float* row = a.gpart + (size_t)blockIdx.x * a.pcount + rbase;
     for (int i = threadIdx.x; i < rlen; i += 64 * MXT_WAVES) {
-        const float v = red[i] * us;
+        const float v = (red[i] + red[RED_FLOATS + i]) * us;
         row[i] = v;
         bad |= !finite_f(v);
     }
@@ -1136,10 +1250,12 @@ static size_t mxtw_lds_bytes(int L, int kind, int idx, int N, int NT) {
     const bool need_sb = kind == PH_G && blk == 0, grad_in = kind == PH_G && (blk == 1 || ly >= 1);
     const int nth = 1 + (with_prev ? 1 : 0) + (bwd_prev ? 1 : 0);
     const int XS = mxw_xstride(N);
-    const size_t shared = (size_t)nth * NT * NT * 64 * 4 + (kind == PH_TOP ? 2 * W * W : 0) + ((2 * L * MXT_BNC * F + 3) & ~3) + ((W * W + W + CONVW + 3) & ~3) +
-                          2 * MXT_WAVES * (2 * F + 2);
-    const size_t wave = 64 + 4 * W + (((2 * (4 * W + 1) * 2) + 3) & ~3) + XS + MXW_ASTRIDE + (need_sb ? XS : 0) + (grad_in ? XS : 0) + (bwd_prev ? XS : 0);
-    return (shared + MXT_WAVES * wave) * sizeof(float);
+    const bool late = kind == PH_G && blk == 0;
+    const size_t shared = (size_t)nth * NT * NT * 64 * 4 + (kind == PH_TOP ? 2 * W * (W + 4) : 0) + ((2 * L * MXT_BNC * F + 3) & ~3) + 2 * MXT_WAVES * (2 * F + 2) +
+                          (late ? 31 * 64 : 0);
+    const size_t red = (W * W + W + CONVW + 3) & ~3;
+    const size_t wave = 64 + 4 * W + (((2 * (4 * (W + 2) + 2) * 2) + 3) & ~3) + XS + MXW_ASTRIDE + (need_sb ? XS : 0) + (grad_in ? XS : 0) + (bwd_prev ? XS : 0);
+    return (shared + (MXT_WAVES * wave > red ? MXT_WAVES * wave : red)) * sizeof(float);
 }
 
 template <typename K>
