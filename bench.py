@@ -425,23 +425,36 @@ def rmse_teacher_task(dev, epochs=3, n_train=49152, n_test=8192, batch=4096, max
             "max_pred_diff": round(float((ph.double() - pc.double()).abs().max()), 8)}
 
 
-def stgcn_train_other_shape(dev, N, P, batches, steps=10):
-    """ST_GCN.update at another wiring (the reference's own PHM2012 40 x 64, configs/hparams.py:223,238): ms per step and samples/s per batch."""
+def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
+    """ST_GCN.update at another wiring (the reference's own PHM2012 40 x 64, configs/hparams.py:223,238): ms per step and samples/s per batch
+    on the chain AUTO resolves to (the wide matrix-core chain, csrc/stgcn_train_mxw.hip), and -- for ``fp32_batches`` -- on the fp32 phase chain
+    (RULGNN_STEP_CHAIN, the row-mapped path of rounds 1-3) in the same run."""
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    from gnn_rul_benchmarking_amd import _lib
     out = {}
     for B in batches:
-        torch.manual_seed(0)
-        algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=0.2), {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
-        algo.to(dev)
-        algo.train()
-        algo.sync_loss = False
         g = torch.Generator(device=dev).manual_seed(5)
         X, y = torch.rand(B, N, P, device=dev, generator=g), torch.rand(B, 1, device=dev, generator=g)
-        ms = event_time_ms(lambda: algo.update(X, y, 1), steps, warm=3)
+        entry = {}
+        for name, path in (("auto", _lib.STEP_AUTO), ("fp32_chain", _lib.STEP_CHAIN)):
+            if name == "fp32_chain" and B not in fp32_batches:
+                continue
+            torch.manual_seed(0)
+            algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=0.2), {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
+            algo.to(dev)
+            algo.train()
+            algo.sync_loss = False
+            algo.model.step_path = path
+            ms = event_time_ms(lambda: algo.update(X, y, 1), steps, warm=3)
+            entry[name] = ms
+            del algo
+        ms = entry["auto"]
         alg = algorithmic_bytes_per_sample(N, P)
         out[f"batch_{B}"] = {"ms_per_step": round(ms, 4), "samples_per_s": round(B / (ms * 1e-3), 1),
                              "step_algorithmic_frac": round(alg * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        del algo, X, y
+        if "fp32_chain" in entry:
+            out[f"batch_{B}"].update(fp32_chain_ms_per_step=round(entry["fp32_chain"], 4), vs_fp32_chain=round(entry["fp32_chain"] / ms, 2))
+        del X, y
     return out
 
 
@@ -1028,9 +1041,10 @@ def main():
             algo.sync_loss = bool(args.sync_loss)
             out["with_per_step_loss_readback"] = {"ms_per_step": round(sl / args.steps * 1e3, 4), "value": round(per_rank * args.steps / sl, 1),
                                                   "unit": "samples/s", "note": "ST_GCN.update returning loss.item() every step like the reference"}
-            out["train_phm2012_40x64"] = dict(stgcn_train_other_shape(dev, 40, 64, [100, 16384]),
+            out["train_phm2012_40x64"] = dict(stgcn_train_other_shape(dev, 40, 64, [100, 16384, 65536], fp32_batches=(16384, 65536)),
                                               workload="ST_GCN.update at the reference's own PHM2012 wiring (40 patches x 64 points, configs/hparams.py:223,238): "
-                                                       "row-mapped fp32 phase chain, one sample per wavefront",
+                                                       "wide matrix-core chain (one sample per wavefront in three column tiles, activations recomputed), the "
+                                                       "fp32 phase chain of rounds 1-3 timed beside it",
                                               algorithmic_bytes_per_sample=algorithmic_bytes_per_sample(40, 64))
         if world == 1 and not args.no_rmse:
             out["rmse"] = rmse_teacher_task(dev)

@@ -1258,8 +1258,11 @@ static size_t mxtw_lds_bytes(int L, int kind, int idx, int N, int NT) {
     return (shared + (MXT_WAVES * wave > red ? MXT_WAVES * wave : red)) * sizeof(float);
 }
 
+// Two workgroups per CU: the backward phases hold > 128 registers; a third and fourth workgroup of the forward phases (~110 registers)
+// were measured (F_1 / F_3 at 40 x 64, batch 16384: 23.7 / 23.1 / 23.7 us with 2 / 3 / 4) -- the issue port is the limit, not latency
 template <typename K>
 static int mxtw_grid(K kern, size_t lds, int64_t B, int max_grid, int* grid_out) {
+    constexpr int cap = MX_WAVES_PER_SIMD;
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1270,7 +1273,7 @@ static int mxtw_grid(K kern, size_t lds, int64_t B, int max_grid, int* grid_out)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * MXT_WAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > MX_WAVES_PER_SIMD) per_cu = MX_WAVES_PER_SIMD;
+    if (per_cu > cap) per_cu = cap;
     int64_t grid = (int64_t)cus * per_cu;
     const int64_t want = (B + MXT_WAVES - 1) / MXT_WAVES;
     if (grid > want) grid = want;

@@ -103,7 +103,7 @@ class ST_GCN_model(FlatModule):
         self.num_layers = int(num_layers)
         self.dropout_p = float(dropout)
         # launch form of the training step (rulgnn.h RULGNN_STEP_*): AUTO = the matrix-core chain with recomputed activations
-        # (STEP_MX, csrc/stgcn_train_mx.hip) where it applies (num_patch <= 15), else the fp32 phase chain (STEP_CHAIN); STEP_COOP = the
+        # (STEP_MX, csrc/stgcn_train_mx.hip / stgcn_train_mxw.hip) where it applies (num_patch <= 47), else the fp32 phase chain (STEP_CHAIN); STEP_COOP = the
         # fp32 phases in one launch with device-side grid barriers (same bits as the chain, measured slower: an explicit option)
         self.step_path = _lib.STEP_AUTO
         self._last_chain = _lib.STEP_CHAIN   # what the latest whole step resolved to (guard_tensor / retry_on_fp32_chain)

@@ -209,8 +209,10 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
  *   RULGNN_STEP_MX     the chain with every phase on the f16 matrix cores (2-way split operands, fp32 accumulation:
  *                      csrc/stgcn_train_mx.hip) and RECOMPUTATION instead of saved activations: a phase re-derives what it needs from
  *                      the layer input (X_l + the 55-entry adjacency), so only layer inputs and two gradient tensors cross HBM between
- *                      phases (13.5 KB per sample at 14 x 30 against 26.0 KB).  num_patch <= 15, num_layers <= 3, num_patch x patch_size a
- *                      multiple of 4, 16-byte aligned x, MSE steps (args->y; not args->dpred): RULGNN_EUNSUPPORTED otherwise.  fp32-class
+ *                      phases (13.5 KB per sample at 14 x 30 against 26.0 KB).  num_patch <= 15 and num_layers <= 3 (four samples per
+ *                      wavefront), or 16 <= num_patch <= 47 and num_layers <= 2 (csrc/stgcn_train_mxw.hip: one sample per wavefront in
+ *                      two or three column tiles -- PHM2012's 40 x 64); num_patch x patch_size a multiple of 4 (and at most 10240),
+ *                      16-byte aligned x, MSE steps (args->y; not args->dpred): RULGNN_EUNSUPPORTED otherwise.  fp32-class
  *                      results (same gates as the fp32 chain), not bit-identical to it.  f16 RANGE GUARD: activations are not
  *                      rescaled; a value beyond the f16 range (inputs far from O(1): every dataset the reference wires is scaled to
  *                      [0, 1] or [-1, 1]) ends as Inf / NaN in a sum or a gradient row, the step's status word is raised and the

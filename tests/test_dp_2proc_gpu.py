@@ -5,7 +5,7 @@ scale (rank 0 only), zero joins of an empty shard, the order of the collectives 
 
 * synchronised BatchNorm: the two-rank step IS the single-process step of the concatenated batch (SURVEY.md section 8e);
 * local statistics (DDP default): the two-rank step is the sum of the two shards' single-process ``fused_mse_step`` buckets;
-* ST_GCN (matrix-core chain at 14 x 30, fp32 chain at 20 x 30, tiled path with the overlapped all-reduce at 72 x 8), FC_STGNN, ASTGCNN."""
+* ST_GCN (matrix-core chain at 14 x 30, its wide form at 20 x 30 and 40 x 64, fp32 chain at 21 x 30, tiled path with the overlapped all-reduce at 72 x 8), FC_STGNN, ASTGCNN."""
 import os
 import socket
 
@@ -96,7 +96,9 @@ def _single_process(family, cfg, shape, B, sync_bn, world=2):
 
 
 STGCN_MX = ("ST_GCN", dict(num_patch=14, patch_size=30, dropout=0.2), (14, 30))
-STGCN_FP32 = ("ST_GCN", dict(num_patch=20, patch_size=30, dropout=0.2), (20, 30))
+STGCN_MXW = ("ST_GCN", dict(num_patch=20, patch_size=30, dropout=0.2), (20, 30))          # the wide matrix-core chain (two column tiles)
+STGCN_MXW40 = ("ST_GCN", dict(num_patch=40, patch_size=64, dropout=0.2), (40, 64))        # PHM2012's wiring (three column tiles)
+STGCN_FP32 = ("ST_GCN", dict(num_patch=21, patch_size=30, dropout=0.2), (21, 30))         # 630 floats per window: not 16-byte pieces -> fp32 chain
 STGCN_TILED = ("ST_GCN", dict(num_patch=72, patch_size=8, dropout=0.2), (72, 8))
 def _hp_case(family):
     """The reference's FD004 wiring of the family (configs/hparams.py), as this package restates it."""
@@ -133,6 +135,13 @@ def test_stgcn_two_processes_equal_the_single_process_step(B, sync_bn):
 @pytest.mark.parametrize("sync_bn", [False, True])
 def test_stgcn_fp32_chain_two_processes(sync_bn):
     r0, r1, ref = _run(STGCN_FP32, 23, sync_bn)
+    _check(r0, r1, ref, 2e-4)
+
+
+@pytest.mark.parametrize("case,B", [(STGCN_MXW, 23), (STGCN_MXW40, 13), (STGCN_MXW40, 1)])
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_stgcn_wide_matrix_core_chain_two_processes(case, B, sync_bn):
+    r0, r1, ref = _run(case, B, sync_bn)
     _check(r0, r1, ref, 2e-4)
 
 
