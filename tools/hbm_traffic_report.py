@@ -13,7 +13,14 @@ def collect(sub, counter):
                 continue
             m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)*>", r["Kernel_Name"])
             mx = re.search(r"stgcn_train_mx_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])      # matrix-core chain (round 4): <L, KIND, IDX, NFIX>
-            if mx:
+            mxw = re.search(r"stgcn_train_mxw_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])    # its wide form: <L, KIND, IDX, NT>
+            if mxw:
+                CHAIN.add("mx")
+                name = {"0": "F", "1": "TOP", "2": "G"}[mxw.group(2)] + (mxw.group(3) if mxw.group(2) != "1" else "")
+            elif "stgcn_train_f0_mxw_kernel" in r["Kernel_Name"]:
+                CHAIN.add("mx")
+                name = "F0"
+            elif mx:
                 CHAIN.add("mx")
                 name = {"0": "F", "1": "TOP", "2": "G"}[mx.group(2)] + (mx.group(3) if mx.group(2) != "1" else "")
             elif m:
