@@ -880,9 +880,12 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     const float us = a.inv_gscale;
     const int NN = N * N;
     int rbase = 0, rlen = 0;
-    for (int w = 0; w < MXT_WAVES; ++w) {
-        if (wave == w) {
-            auto put = [&](int idx, float v) { red[idx] = (w == 0) ? v : red[idx] + v; };
+    // (two images -- the second over the wavefronts' regions, dead by now: wavefronts 0 | 1 store, then 2 | 3 add: two rounds, fixed order)
+    float* const red2 = smem_all + SH_BNC + MXT_RED_FLOATS + 2 * MXT_WAVES * (2 * F + 2);
+    for (int w = 0; w < 2; ++w) {
+        if ((wave >> 1) == w) {
+            float* const img = (wave & 1) ? red2 : red;
+            auto put = [&](int idx, float v) { img[idx] = (w == 0) ? v : img[idx] + v; };
             if constexpr (KIND == PH_TOP) {
                 // [fc1.w | fc1.b | fc2.w | fc2.b]; fc1.w in the fp32 MFMA's D layout: row j = 4 g + r, column k = col
 #pragma unroll
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     else { rbase = LY * LS + off_conv_w(N, 1); rlen = CONVW; }
     float* row = a.gpart + (size_t)blockIdx.x * a.pcount + rbase;
     for (int i = threadIdx.x; i < rlen; i += 64 * MXT_WAVES) {
-        const float v = red[i] * us;
+        const float v = (red[i] + red2[i]) * us;
         row[i] = v;
         bad |= !finite_f(v);
     }
