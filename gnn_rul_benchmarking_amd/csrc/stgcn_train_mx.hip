@@ -131,9 +131,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     ConvOp wT = ConvOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     ThetaOp thN = ThetaOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     u32x4 ident = u32x4{0u, 0u, 0u, 0u};
+    ConvRaw wT_raw = ConvRaw{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};          // (converted behind the BatchNorm cells' loads: one round trip)
+    ThetaRaw thN_raw = ThetaRaw{{0.f, 0.f, 0.f, 0.f}};
     if constexpr (KIND == PH_G) {
-        wT = conv_bwd_operand(a.prm + LY * LS + off_conv_w(N, BLK), g, col);
-        if constexpr (BLK == 0 && LY >= 1) thN = theta_n_operand(a.prm + LY * LS, N, g, col);
+        wT_raw = conv_bwd_raw(a.prm + LY * LS + off_conv_w(N, BLK), g, col);
+        if constexpr (BLK == 0 && LY >= 1) thN_raw = theta_n_raw(a.prm + LY * LS, N, g, col);
         unsigned w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = (4 * g + r == col) ? 0x3C00u : 0u;      // f16 1.0
@@ -148,6 +150,10 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         static_assert(NFW + (KIND == PH_G ? 1 : 0) <= MXT_WAVES, "one reduction pair per wavefront");
         if (wave < NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
         if (KIND == PH_G && wave == NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, false, IDX, lane);
+        if constexpr (KIND == PH_G) {
+            wT = conv_bwd_pack(wT_raw);
+            if constexpr (BLK == 0 && LY >= 1) thN = theta_pack(thN_raw);
+        }
         __syncthreads();
     }
     LayerK kc;                                   // layer LY

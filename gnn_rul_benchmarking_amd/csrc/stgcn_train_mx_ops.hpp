@@ -72,49 +72,59 @@ __device__ __forceinline__ ConvOp conv_fwd_operand(const ConvRaw& w, float scale
 }
 // A operand of the TRANSPOSED convolution: row m = col <-> input channel ci; k-slots [0..3] = w[co][ci][tap at t] against d z of
 // column t, [4..7] = w[co][ci][tap at t - d] against d z of column t + d, co = slot 4 g + r.
-__device__ __forceinline__ ConvOp conv_bwd_operand(const float* cw, int g, int col) {
+// (loads and conversion apart: a prologue issues every load before it converts anything -- one memory round trip)
+__device__ __forceinline__ ConvRaw conv_bwd_raw(const float* cw, int g, int col) {
     const int ci = slot_chan(col), cic = ci >= 0 ? ci : 0;
-    float w1[4], w0[4];
+    ConvRaw w;                               // wc: tap at t, wd: tap at t - d
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int co = slot_chan(4 * g + r);
         const bool ok = co >= 0 && ci >= 0;
         const float2 taps2 = *reinterpret_cast<const float2*>(cw + ((co >= 0 ? co : 0) * F + cic) * 2);
-        w1[r] = ok ? taps2.y : 0.f;
-        w0[r] = ok ? taps2.x : 0.f;
+        w.wc[r] = ok ? taps2.y : 0.f;
+        w.wd[r] = ok ? taps2.x : 0.f;
     }
-    const Split2 c01 = split2(w1[0], w1[1]), c23 = split2(w1[2], w1[3]), d01 = split2(w0[0], w0[1]), d23 = split2(w0[2], w0[3]);
+    return w;
+}
+__device__ __forceinline__ ConvOp conv_bwd_pack(const ConvRaw& w) {
+    const Split2 c01 = split2(w.wc[0], w.wc[1]), c23 = split2(w.wc[2], w.wc[3]), d01 = split2(w.wd[0], w.wd[1]), d23 = split2(w.wd[2], w.wd[3]);
     return ConvOp{u32x4{c01.hi, c23.hi, d01.hi, d23.hi}, u32x4{c01.lo, c23.lo, d01.lo, d23.lo}};
 }
+__device__ __forceinline__ ConvOp conv_bwd_operand(const float* cw, int g, int col) { return conv_bwd_pack(conv_bwd_raw(cw, g, col)); }
 
 struct ThetaOp { u32x4 hi, lo; };
+struct ThetaRaw { float w[4]; };
+__device__ __forceinline__ ThetaOp theta_pack(const ThetaRaw& t) {
+    const Split2 p01 = split2(t.w[0], t.w[1]), p23 = split2(t.w[2], t.w[3]);
+    return ThetaOp{u32x4{p01.hi, p23.hi, p01.hi, p23.hi}, u32x4{p01.lo, p23.lo, p01.lo, p23.lo}};
+}
 // theta^T as B operand of Hp = T x theta^T + b: column j = col, k-slot 4 g + r <-> patch k, k = 15 <-> bias; (1 + a)/2 folded in
-__device__ __forceinline__ ThetaOp theta_t_operand(const float* lp, int N, int g, int col) {
-    float w[4];
+__device__ __forceinline__ ThetaRaw theta_t_raw(const float* lp, int N, int g, int col) {
+    ThetaRaw t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = 4 * g + r;
         const bool ok = col < N && (k < N || k == 15);
         const int idx = k == 15 ? off_theta_b(N) + col : off_theta_w(N) + col * N + k;
         const float v = lp[ok ? idx : 0];
-        w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
+        t.w[r] = ok ? v * (0.5f * (1.f + LEAKY)) : 0.f;
     }
-    const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
-    return ThetaOp{u32x4{p01.hi, p23.hi, p01.hi, p23.hi}, u32x4{p01.lo, p23.lo, p01.lo, p23.lo}};
+    return t;
 }
+__device__ __forceinline__ ThetaOp theta_t_operand(const float* lp, int N, int g, int col) { return theta_pack(theta_t_raw(lp, N, g, col)); }
 // theta as B operand of d X = U x theta: column k' = col, k-slot 4 g + r <-> row j of theta
-__device__ __forceinline__ ThetaOp theta_n_operand(const float* lp, int N, int g, int col) {
-    float w[4];
+__device__ __forceinline__ ThetaRaw theta_n_raw(const float* lp, int N, int g, int col) {
+    ThetaRaw t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int j = 4 * g + r;
         const bool ok = col < N && j < N;
         const float v = lp[ok ? off_theta_w(N) + j * N + col : 0];
-        w[r] = ok ? v : 0.f;
+        t.w[r] = ok ? v : 0.f;
     }
-    const Split2 p01 = split2(w[0], w[1]), p23 = split2(w[2], w[3]);
-    return ThetaOp{u32x4{p01.hi, p23.hi, p01.hi, p23.hi}, u32x4{p01.lo, p23.lo, p01.lo, p23.lo}};
+    return t;
 }
+__device__ __forceinline__ ThetaOp theta_n_operand(const float* lp, int N, int g, int col) { return theta_pack(theta_n_raw(lp, N, g, col)); }
 
 // Everything one layer's forward needs as constants: theta^T, the two convolutions, the affine part of its BatchNorms per D register
 struct LayerK {
@@ -126,12 +136,12 @@ struct LayerK {
 // `mode[blk]`: 0 = convolution not needed, 1 = raw weights (its BatchNorm statistics are what this phase computes), 2 = x-hat fold
 // (weights x istd, shift -mean istd: the product IS x-hat, y = gamma x-hat + beta one fma behind it)
 struct LayerRaw {
-    ThetaOp th;
+    ThetaRaw th;
     ConvRaw w[2];
 };
 __device__ __forceinline__ void layer_raw(LayerRaw& k, const float* prm, int l, int N, int g, int col, int mode0, int mode1) {
     const float* lp = prm + l * layer_stride(N);
-    k.th = theta_t_operand(lp, N, g, col);
+    k.th = theta_t_raw(lp, N, g, col);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
         if ((blk == 0 ? mode0 : mode1) != 0) k.w[blk] = conv_fwd_raw(lp + off_conv_w(N, blk), g, col);
@@ -139,7 +149,7 @@ __device__ __forceinline__ void layer_raw(LayerRaw& k, const float* prm, int l, 
     }
 }
 __device__ __forceinline__ void layer_constants(LayerK& k, const LayerRaw& raw, const float* bnc, int l, int g, int col, int mode0, int mode1) {
-    k.th = raw.th;
+    k.th = theta_pack(raw.th);
     const int co = slot_chan(col), coc = co >= 0 ? co : 0;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {

@@ -402,8 +402,9 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     if constexpr (WITH_PREV) layer_raw(rp, a.prm, LY - 1, N, g, col, 2, 2);
     ConvOp wT = ConvOp{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
     u32x4 ident = u32x4{0u, 0u, 0u, 0u};
+    ConvRaw wT_raw = ConvRaw{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (KIND == PH_G) {
-        wT = conv_bwd_operand(a.prm + LY * LS + off_conv_w(N, BLK), g, col);
+        wT_raw = conv_bwd_raw(a.prm + LY * LS + off_conv_w(N, BLK), g, col);
         unsigned w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = (4 * g + r == col) ? 0x3C00u : 0u;
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         if (wave < NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
         if (KIND == PH_G && wave == NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, false, IDX, lane);
     }
+    if constexpr (KIND == PH_G) wT = conv_bwd_pack(wT_raw);
 #pragma unroll
     for (int it = 0; it < TIT; ++it) {
         const int idx = wave + MXT_WAVES * it;
