@@ -14,6 +14,7 @@ OK = 0
 EINVAL, EUNSUPPORTED, EWORKSPACE, EHIP, EALIGN, ECALLBACK = -1, -2, -3, -4, -5, -6      # include/rulgnn.h RULGNN_E*
 EVAL_AUTO, EVAL_EXACT, EVAL_MX = 0, 1, 2      # include/rulgnn.h RULGNN_EVAL_*
 STEP_AUTO, STEP_CHAIN, STEP_COOP, STEP_MX = 0, 1, 2, 3    # include/rulgnn.h RULGNN_STEP_*
+TRAIN_WS_CLEAN = 1                                        # include/rulgnn.h RULGNN_TRAIN_WS_CLEAN
 NUM_STATS = 10
 
 
@@ -28,7 +29,7 @@ class StgcnTrainArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("global_batch", C.c_int64), ("sample_offset", C.c_int64),
                 ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
-                ("bn_moment_weight", C.c_float), ("step_state", C.c_void_p)]
+                ("bn_moment_weight", C.c_float), ("step_state", C.c_void_p), ("flags", C.c_uint32)]
 
 
 class AdamArgs(C.Structure):

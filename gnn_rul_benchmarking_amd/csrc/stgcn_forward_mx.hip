@@ -49,6 +49,7 @@
 #include "stgcn_eval_tile.hpp"
 #include "stgcn_host.hpp"
 #include "stgcn_mx.hpp"
+#include "stgcn_train_layout.hpp"
 #include "stgcn_train_mx.hpp"
 
 namespace rulgnn {
@@ -479,7 +480,8 @@ struct MxF0Out {
 // bytes instead of the 400-byte lane layout of the row-mapped phases) and H, z1 are not written at all -- the later phases recompute.
 template <int NFIX, int PFIX, bool PACKED>
 __global__ __launch_bounds__(64 * MXF0_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_f0_mx_kernel(const float* __restrict__ gx, const float* __restrict__ prm,
-                                                                                             MxArgs a, MxF0Out o) {
+                                                                                             MxArgs a, MxF0Out o, HeadScalars hs) {
+    if (PACKED && hs.sc != nullptr && blockIdx.x == 0) head_scalars(hs, threadIdx.x);       // a step without its prepare launch
     // Four wavefronts per workgroup, each on its own tiles with its own LDS region; they meet once, in the epilogue, where their BatchNorm
     // sums are combined in LDS: one fp64 atomic per channel and WORKGROUP (2048 single-wavefront workgroups adding into 16 replicas of
     // the same two lines cost ~4 us of serialised atomics at the end of the kernel).
@@ -1147,7 +1149,9 @@ int stgcn_forward_eval_mx(const rulgnn_stgcn_shape* s, const float* x, const flo
 // row-mapped fp32 phase kernel.
 template <bool PACKED>
 static int train_f0_mx_launch(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* cacheX, float* cacheA, float* H0, float* Z1,
-                              double* cells_bn0, int cell_stride_doubles, int replicas, hipStream_t stream) {
+                              double* cells_bn0, int cell_stride_doubles, int replicas, hipStream_t stream, const HeadScalars* head = nullptr) {
+    HeadScalars hs{};
+    if (head) hs = *head;
     if (!mx_shape_ok(s, x)) return RULGNN_EUNSUPPORTED;
     if (s->batch == 0) return RULGNN_OK;
     MxArgs a;
@@ -1173,7 +1177,7 @@ static int train_f0_mx_launch(const rulgnn_stgcn_shape* s, const float* x, const
         const int64_t want = (a.ntiles + MXF0_WAVES - 1) / MXF0_WAVES;
         if (grid > want) grid = want;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXF0_WAVES), lds, stream, x, prm, a, o);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXF0_WAVES), lds, stream, x, prm, a, o, hs);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     };
     if (s->num_patch == 14 && s->patch_size == 30) return launch(&stgcn_train_f0_mx_kernel<14, 30, PACKED>);
@@ -1186,8 +1190,8 @@ int stgcn_train_f0_mx(const rulgnn_stgcn_shape* s, const float* x, const float* 
     return train_f0_mx_launch<false>(s, x, prm, cacheX, cacheA, H0, Z1, cells_bn0, cell_stride_doubles, replicas, stream);
 }
 int stgcn_train_f0_mx_packed(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* xrec0, float* arec, double* cells_bn0,
-                             int cell_stride_doubles, int replicas, hipStream_t stream) {
-    return train_f0_mx_launch<true>(s, x, prm, xrec0, arec, nullptr, nullptr, cells_bn0, cell_stride_doubles, replicas, stream);
+                             int cell_stride_doubles, int replicas, hipStream_t stream, const HeadScalars* head) {
+    return train_f0_mx_launch<true>(s, x, prm, xrec0, arec, nullptr, nullptr, cells_bn0, cell_stride_doubles, replicas, stream, head);
 }
 
 // ---- wide shapes ---------------------------------------------------------------------------------------------------------

@@ -860,6 +860,7 @@ struct FinalizeK {
     int fused_opt;
     int guard;               // matrix-core chain: a raised status word (a value left the f16 range, stgcn_train_mx.hip) leaves parameters,
                              // optimizer state and running statistics untouched and reports a NaN loss
+    int clean;               // matrix-core chain: the last workgroup zeroes the cells and the status word and sets the clean token
 };
 
 // Gradient rows of the phase kernels' workgroups -> gradient (+ Adam): a workgroup owns FIN_COLS consecutive parameters (lane =
@@ -982,6 +983,21 @@ __global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_ke
     __shared__ float part[FIN_SLICES][FIN_COLS];
     if (f.write_grads) finalize_unit<1>(f, blockIdx.x, part, threadIdx.x & 63, threadIdx.x >> 6);
     if (blockIdx.x == 0) finalize_stats(f, threadIdx.x, blockDim.x);
+    if (f.clean) {
+        // A matrix-core step leaves its workspace ready for a step WITHOUT a prepare launch (RULGNN_TRAIN_WS_CLEAN): the workgroup that
+        // finishes last -- every other one has read the cells and the status word by then -- zeroes them and sets the clean token.
+        __shared__ int last;
+        StepScratch* sc = step_scratch(f.cells, f.L);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) last = atomicAdd(&sc->pad[2], 1u) == gridDim.x - 1 ? 1 : 0;
+        __syncthreads();
+        if (last) {
+            const int stride = cell_stride(f.L);
+            for (int i = threadIdx.x; i < stride * CELL_REPLICAS; i += blockDim.x) f.cells[i] = 0.0;
+            if (threadIdx.x == 0) { sc->pad[0] = 0u; sc->pad[2] = 0u; sc->pad[1] = WS_CLEAN_TOKEN; }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1211,7 +1227,11 @@ __device__ __forceinline__ void prepare_body(double* cells, int zero_from, int n
     const int tid = threadIdx.x;
     if (tid == 0) {
         sc->bn_count = bn_count;
-        if (new_forward) sc->pad[0] = 0u;              // status word of the matrix-core chain (stgcn_train_mx.hip)
+        if (new_forward) {                             // status word of the matrix-core chain (stgcn_train_mx.hip), its clean token and
+            sc->pad[0] = 0u;                           // the finalize kernel's ticket (stgcn_train_layout.hpp)
+            sc->pad[1] = 0u;
+            sc->pad[2] = 0u;
+        }
     }
     if (new_forward && tid >= 64 && tid < 72) {        // one dropout key per lane
         const int l = tid - 64;
@@ -1415,15 +1435,15 @@ static MxTrainArgs mx_args(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train
 // phase numbering of rulgnn_stgcn_train_phase_f32: 0 .. 2L-1 = F_i, 2L = TOP, 2L+1+j = G_{2L-1-j}
 template <int L>
 static int mx_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, const TrainK& k, const MxTrainArgs& m, int ph,
-                    hipStream_t stream, int max_grid, int* grid_out, bool wide = false) {
+                    hipStream_t stream, int max_grid, int* grid_out, bool wide = false, const HeadScalars* head = nullptr) {
     if (wide) {
-        if (ph == 0) return stgcn_train_mxw_f0(m, a->x, s->patch_size, stream);
+        if (ph == 0) return stgcn_train_mxw_f0(m, a->x, s->patch_size, stream, head);
         if (ph < 2 * L) return stgcn_train_mxw_phase(m, PH_F, ph, stream, max_grid, grid_out);
         if (ph == 2 * L) return stgcn_train_mxw_phase(m, PH_TOP, 0, stream, max_grid, grid_out);
         return stgcn_train_mxw_phase(m, PH_G, 4 * L - ph, stream, max_grid, grid_out);
     }
     if (ph == 0)
-        return stgcn_train_f0_mx_packed(s, a->x, a->params, m.xrec[0], m.arec, k.cells + cell_fwd(L), cell_stride(L), CELL_REPLICAS, stream);
+        return stgcn_train_f0_mx_packed(s, a->x, a->params, m.xrec[0], m.arec, k.cells + cell_fwd(L), cell_stride(L), CELL_REPLICAS, stream, head);
     if (ph < 2 * L) return stgcn_train_mx_phase(m, PH_F, ph, stream, max_grid, grid_out);
     if (ph == 2 * L) return stgcn_train_mx_phase(m, PH_TOP, 0, stream, max_grid, grid_out);
     return stgcn_train_mx_phase(m, PH_G, 4 * L - ph, stream, max_grid, grid_out);
@@ -1455,7 +1475,18 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     if (adam_state && a->step_state && adam_state != a->step_state) return RULGNN_EINVAL;
     StepState* st = static_cast<StepState*>(a->step_state ? a->step_state : adam_state);
     (void)hipGetLastError();
-    if (mode == TM_FORWARD || mode == TM_FWDBWD) {
+    // RULGNN_TRAIN_WS_CLEAN: the caller vouches that the previous matrix-core step on this workspace was the last thing to touch it -- its
+    // finalize kernel left the cells zero, F_0's workgroup 0 writes the head-of-step scalars (and checks the clean token)
+    const bool skip_prepare = use_mx && (a->flags & RULGNN_TRAIN_WS_CLEAN) != 0 && !a->step_state && !adam_state && s->batch > 0;
+    HeadScalars head{};
+    if (skip_prepare) {
+        head.sc = sc; head.seed = a->seed; head.step = a->step; head.L = L; head.has_adam = fused_adam ? 1 : 0;
+        head.adam_step = fused_adam ? opt->step : 0;
+        head.lr = fused_adam ? opt->lr : 0.f; head.beta1 = fused_adam ? opt->beta1 : 0.f; head.beta2 = fused_adam ? opt->beta2 : 0.f;
+        head.bn_count = bn_count;
+    }
+    if (skip_prepare) {
+    } else if (mode == TM_FORWARD || mode == TM_FWDBWD) {
         // a new forward: all cells, fresh dropout keys (a backward-only call below reuses the keys of its forward)
         hipLaunchKernelGGL(stgcn_prepare_kernel, dim3(1), dim3(1024), 0, stream, k.cells, 0, cell_stride(L), cell_stride(L), sc,
                            a->step_state ? st : nullptr, a->seed, a->step, L, 1, fused_adam ? 1 : 0, fused_adam ? opt->step : 0,
@@ -1478,7 +1509,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         const MxTrainArgs m = mx_args<L>(s, a, k, use_mxw);
         for (int ph = 0; ph <= 4 * L; ++ph) {
             int grid = 0;
-            rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid, use_mxw);
+            rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid, use_mxw, ph == 0 && skip_prepare ? &head : nullptr);
             if (rc != RULGNN_OK) return rc;
             // the reduction pair a phase completes (all-reduced here under synchronised BatchNorm; the later phases read the cells):
             // F_i -> forward pair i, TOP -> backward pair 2L-1, G_i -> backward pair i-1
@@ -1510,6 +1541,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     f.moment_weight = a->bn_moment_weight;
     f.cell_grad_scale = hook ? hook->bn_param_grad_scale : 1.0f;
     f.guard = use_mx ? 1 : 0;
+    f.clean = use_mx && mode == TM_FWDBWD ? 1 : 0;
     f.fused_opt = 0;
     f.params = nullptr; f.exp_avg = nullptr; f.exp_avg_sq = nullptr; f.bn_running = nullptr;
     f.beta1 = f.beta2 = f.eps = f.weight_decay = f.bn_momentum = 0.f;

@@ -2,6 +2,7 @@
 // matrix-core chain (stgcn_train_mx.hip): both chains are bracketed by the same prepare / finalize kernels.
 #pragma once
 #include "stgcn_device.hpp"
+#include "stgcn_host.hpp"
 
 namespace rulgnn {
 
@@ -13,9 +14,43 @@ struct StepScratch {
     float lr_over_bc1, inv_sqrt_bc2;
     double bn_count;      // values per channel behind the BatchNorm cells: batch * N of this shard, or of the GLOBAL batch when the
                           // cells are all-reduced between the phases (synchronised BatchNorm, stgcn_train_fwdbwd_syncbn)
-    uint32_t pad[4];
+    uint32_t pad[4];      // [0] status word of the matrix-core chain (f16 range guard; bit 1: a step claimed clean cells that were not),
+                          // [1] clean token: the finalize kernel of a matrix-core step left every cell and the status word zero,
+                          // [2] ticket of that finalize kernel's workgroups
 };
 static_assert(sizeof(StepScratch) == 64, "step scratch layout");
+constexpr uint32_t WS_CLEAN_TOKEN = 0x52554C43u;
+
+// The head-of-step scalars (dropout keys, Adam bias corrections, the BatchNorm count) for a step that SKIPS its prepare launch
+// (RULGNN_TRAIN_WS_CLEAN: the previous matrix-core step's finalize kernel left the cells zero): F_0's workgroup 0 writes them -- nothing
+// reads them before the next kernel -- and consumes the clean token; a missing token raises the status word, so that the step ends like
+// one the range guard rejected (NaN loss, state untouched) instead of running on stale sums.
+struct HeadScalars {
+    StepScratch* sc;      // nullptr: the prepare kernel ran
+    uint64_t seed, step;
+    int L, has_adam;
+    int64_t adam_step;
+    float lr, beta1, beta2;
+    double bn_count;
+};
+__device__ __forceinline__ void head_scalars(const HeadScalars& h, int tid) {
+    StepScratch* sc = h.sc;
+    if (tid == 0) {
+        sc->bn_count = h.bn_count;
+        if (sc->pad[1] != WS_CLEAN_TOKEN) {            // not clean: reject the step; the finalize kernel's ticket starts from zero, so that
+            sc->pad[0] = 2u;                           // it can leave the workspace clean for the next one
+            sc->pad[2] = 0u;
+        }
+        sc->pad[1] = 0u;
+    }
+    if (tid >= 64 && tid < 72) sc->drop_key[tid - 64] = tid - 64 < h.L ? dropout_layer_key(h.seed, h.step, tid - 64) : 0u;
+    if (h.has_adam && tid == 128) {
+        const double bc1 = 1.0 - pow((double)h.beta1, (double)h.adam_step);
+        const double bc2 = 1.0 - pow((double)h.beta2, (double)h.adam_step);
+        sc->lr_over_bc1 = (float)((double)h.lr / bc1);
+        sc->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    }
+}
 
 // Reduction cells (fp64): per BatchNorm the forward pair (sum z, sum z^2) and the backward pair (sum dy, sum dy*xhat), then
 // the loss.  Every block adds its partial sums with one atomic per cell; 1280 blocks hitting the same 20 addresses serialise

@@ -34,14 +34,16 @@ float stgcn_train_mx_grad_scale(int64_t global_batch);
 // one phase: kind 0 = F_idx (idx >= 1), 1 = TOP, 2 = G_idx
 int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out);
 // F_0 of the chain (stgcn_forward_mx.hip): windows -> X_0 tiles, packed adjacency tiles, BatchNorm-0 sums
+// (`head` != nullptr: the step runs without its prepare launch, workgroup 0 writes the head-of-step scalars: stgcn_train_layout.hpp)
+struct HeadScalars;
 int stgcn_train_f0_mx_packed(const rulgnn_stgcn_shape* s, const float* x, const float* prm, float* xrec0, float* arec, double* cells_bn0,
-                             int cell_stride_doubles, int replicas, hipStream_t stream);
+                             int cell_stride_doubles, int replicas, hipStream_t stream, const HeadScalars* head = nullptr);
 
 
 // ---- the wide chain (stgcn_train_mxw.hip): 16 <= num_patch <= 47, one sample per wavefront iteration, records per SAMPLE:
 // X_l / Q_l / sb / dx [10][N] at a stride of (10 N + 3) & ~3 floats, adjacency 56 floats, d X_L [2][N] at (2 N + 3) & ~3, mask bits 64 words
 bool stgcn_train_mxw_shape_ok(const rulgnn_stgcn_shape* s, const float* x);
-int stgcn_train_mxw_f0(const MxTrainArgs& m, const float* x, int patch_size, hipStream_t stream);
+int stgcn_train_mxw_f0(const MxTrainArgs& m, const float* x, int patch_size, hipStream_t stream, const HeadScalars* head = nullptr);
 int stgcn_train_mxw_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out);
 
 }  // namespace rulgnn

@@ -37,7 +37,8 @@ __host__ __device__ constexpr int mxw_dstride(int N) { return (2 * N + 3) & ~3; 
 // F_0: windows -> X_0 record, adjacency pairs, sum z1, sum z1^2 of BatchNorm 0 (front end of the wide eval kernel + half a layer)
 // =====================================================================================================================
 template <int NT, int NFIX, int PFIX>
-__global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_f0_mxw_kernel(const float* __restrict__ gx, MxTrainK a, int P_, int buf_floats, int cells_stride) {
+__global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_f0_mxw_kernel(const float* __restrict__ gx, MxTrainK a, int P_, int buf_floats, int cells_stride, HeadScalars hs) {
+    if (hs.sc != nullptr && blockIdx.x == 0) head_scalars(hs, threadIdx.x);                   // a step without its prepare launch
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     constexpr int W = 16 * NT, PT = W + 4, TG = 4 * NT;
     const int N = NFIX ? NFIX : a.N, P = PFIX ? PFIX : P_;
@@ -1334,8 +1335,10 @@ static MxTrainK mxtw_args(const MxTrainArgs& m) {
     return k;
 }
 
-int stgcn_train_mxw_f0(const MxTrainArgs& m, const float* x, int P, hipStream_t stream) {
+int stgcn_train_mxw_f0(const MxTrainArgs& m, const float* x, int P, hipStream_t stream, const HeadScalars* head) {
     const MxTrainK k = mxtw_args(m);
+    HeadScalars hs{};
+    if (head) hs = *head;
     if (m.B == 0) return RULGNN_OK;
     const int NT = m.N <= 31 ? 2 : 3, W = 16 * NT, PT = W + 4;
     const int buf_floats = (m.N * P + 3) & ~3;
@@ -1346,7 +1349,7 @@ int stgcn_train_mxw_f0(const MxTrainArgs& m, const float* x, int P, hipStream_t 
         const int rc = mxtw_grid(kern, lds, m.B, 1 << 30, &grid);
         if (rc != RULGNN_OK) return rc;
         (void)hipGetLastError();
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXT_WAVES), lds, stream, x, k, P, buf_floats, cell_stride(m.L));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXT_WAVES), lds, stream, x, k, P, buf_floats, cell_stride(m.L), hs);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     };
     if (m.N == 40 && P == 64) return go(&stgcn_train_f0_mxw_kernel<3, 40, 64>);

@@ -107,6 +107,7 @@ class ST_GCN_model(FlatModule):
         # fp32 phases in one launch with device-side grid barriers (same bits as the chain, measured slower: an explicit option)
         self.step_path = _lib.STEP_AUTO
         self._last_chain = _lib.STEP_CHAIN   # what the latest whole step resolved to (guard_tensor / retry_on_fp32_chain)
+        self._clean_ws = None                # the workspace a matrix-core whole step left clean (see _train_args)
         self._tape_step = {}            # batch size -> step whose activations its workspace holds (autograd-path hazard check)
         self.k = int(k)
         in_features = NUM_STATS
@@ -151,6 +152,7 @@ class ST_GCN_model(FlatModule):
     def _reset_caches(self):
         super()._reset_caches()
         self._pred_buf = self._ws = self._fwd_ws = None
+        self._clean_ws = None
 
     # ---- C-ABI calls ---------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -175,7 +177,7 @@ class ST_GCN_model(FlatModule):
         self._ws, self._pred_buf = ent
         return self._ws
 
-    def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False):
+    def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False, whole_step=False):
         B = x2d.size(0)
         ws = self._workspace(shp, B)
         self._tape_step[B] = int(step)
@@ -202,7 +204,14 @@ class ST_GCN_model(FlatModule):
         a.seed = self._seed
         a.step = step
         a.step_state = self._step_state.data_ptr() if self._step_state is not None else None
+        # RULGNN_TRAIN_WS_CLEAN: a whole step on the matrix-core chain leaves the reduction cells zero; when the LAST use of this very
+        # workspace was such a step, the next one runs without its prepare launch (any other use of the workspace drops the claim)
+        a.flags = _lib.TRAIN_WS_CLEAN if (whole_step and self._clean_ws is ws and self._step_state is None) else 0
+        self._clean_ws = None
         return a
+
+    def _whole_step_done(self):
+        self._clean_ws = self._ws if self._last_chain == _lib.STEP_MX else None
 
     # ---- f16 range guard of the matrix-core chain -------------------------------------------------------------------------
     # The chain reports a value beyond the f16 range (inputs far from O(1)) as a NaN loss with parameters, optimizer state and
@@ -277,7 +286,7 @@ class ST_GCN_model(FlatModule):
             raise RuntimeError("target size mismatch")
         self._step += 1
         shp = self._shape(x2d.size(0))
-        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket)
+        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, moments_to_bucket, whole_step=True)
         self._resolve_chain(shp, x2d)
         if grad_ready is not None:
             failure = []
@@ -297,6 +306,7 @@ class ST_GCN_model(FlatModule):
         else:
             _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), None, int(self.step_path), _stream()),
                        "rulgnn_stgcn_train_step_path_f32")
+            self._whole_step_done()
         if update_running_stats:
             self._after_train_forward(x2d.size(0))
         return self._pred_buf, self._grad_flat[self.num_live]
@@ -337,7 +347,7 @@ class ST_GCN_model(FlatModule):
             raise RuntimeError("target size mismatch")
         self._step += 1
         shp = self._shape(x2d.size(0))
-        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, False)
+        a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, False, whole_step=True)
         self._resolve_chain(shp, x2d)
         ws = self._ws
         base, failure = ws.data_ptr(), []
@@ -355,6 +365,7 @@ class ST_GCN_model(FlatModule):
         if failure:
             raise failure[0]
         _lib.check(rc, "rulgnn_stgcn_train_fwdbwd_syncbn_f32")
+        self._whole_step_done()
         return self._pred_buf, self._grad_flat[self.num_live]
 
     def fused_train_step(self, x, y, optimizer):
@@ -366,11 +377,12 @@ class ST_GCN_model(FlatModule):
             raise RuntimeError("target size mismatch")
         self._step += 1
         shp = self._shape(x2d.size(0))
-        a = self._train_args(shp, x2d, yv, None, self._step)
+        a = self._train_args(shp, x2d, yv, None, self._step, whole_step=True)
         self._resolve_chain(shp, x2d)
         o = self._adam_args(optimizer, bn=self._bn)
         _lib.check(_lib.load().rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), o, int(self.step_path), _stream()),
                    "rulgnn_stgcn_train_step_path_f32")
+        self._whole_step_done()
         self._nbt_pending += 1
         return self._pred_buf, self._grad_flat[self.num_live]
 

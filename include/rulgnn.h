@@ -125,7 +125,16 @@ typedef struct rulgnn_stgcn_train_args {
     float bn_moment_weight;  /* 0: plain statistics. w > 0 (data parallel, w = batch/global_batch): bn_batch holds
                                 w*(E[z], E[z^2]) so that a SUM all-reduce over ranks yields the global-batch moments */
     void *step_state;        /* optional device step state (see rulgnn_step_state_set); NULL = use `step` above */
+    uint32_t flags;          /* RULGNN_TRAIN_* bits, 0 = none */
 } rulgnn_stgcn_train_args;
+/* rulgnn_stgcn_train_step*_f32 / _fwdbwd*_f32 on the matrix-core chain (RULGNN_STEP_MX, also through RULGNN_STEP_AUTO) end with a finalize
+ * kernel that leaves the workspace's reduction cells ZERO.  A caller that sets this bit vouches that the previous call that used
+ * args->workspace was such a step (same shape) and that nothing else has touched the workspace since: the step then runs without its
+ * prepare launch (~5 us), the head-of-step scalars being written by its first phase.  Ignored where it does not apply (other chains,
+ * a device step state, an empty shard).  Safety net: the first phase checks a token the finalize kernel left; without it the step ends
+ * like one the f16 range guard rejected (NaN loss, parameters / optimizer state / running statistics untouched) and the workspace is
+ * clean again afterwards. */
+#define RULGNN_TRAIN_WS_CLEAN 1u
 
 /* Train-mode forward only (BatchNorm batch statistics, dropout): fills pred, bn_batch and the
  * workspace cache.  Replaces model(X) under model.train() (algorithms/algorithms.py:482). */
