@@ -61,52 +61,89 @@ __host__ int ast_geometry(const rulgnn_astgcnn_shape* s, AstGeom* g) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gate: out1 = relu(relu(bn2(z2)) + out0); zg = tanh(Zpre + theta.bias + gate.bias); G = zg * out1
-// (Zpre = x theta^T from the GEMM).  Writes out1, zg (over Zpre) and G into columns [0, E) of Tcat.
+// front: gate -> P projection -> graph -> Chebyshev terms -> node sums -> filter product, ONE sample per workgroup iteration (round 4:
+// the three [batch*nodes, .] GEMM launches and the gate launch around the graph kernel were 11 + 9 + 11 + 11 us of a 260-us step for 100 k
+// multiply-adds per sample; here they are loops over the LDS tiles the graph stage needs anyway):
+//   out1 = relu(relu(bn2(z2)) + out0);  zg = tanh(x theta^T + theta.bias + gate.bias);  G = zg * out1          (Model.py:169-181)
+//   PX = G P^T;  A = exp(-cdist(PX, PX));  T1 = A G;  T2 = 2 A T1 - G;  node sums of [G | T1 | T2]               (Model.py:184-230)
+//   pooled N = Scat Fcat   (Fcat = filters viewed as [K E, O]; the head kernel divides by N)
+// Writes what the backward reads: out1, zg (`zg_out`), Tcat = [G | T1 | T2], PX, A, dist, Scat.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB) void ast_gate_kernel(AstGeom g, const float* __restrict__ prm, const float* __restrict__ bn_running,
-                                                     int training, const Cells* cells, const float* __restrict__ z2,
-                                                     const float* __restrict__ out0, float* __restrict__ zpre, float* __restrict__ out1,
-                                                     float* __restrict__ tcat) {
-    const int N = g.N, T = g.T;
-    const int64_t total = g.B * N * T;
-    for (int64_t e = (int64_t)blockIdx.x * AB + threadIdx.x; e < total; e += (int64_t)gridDim.x * AB) {
-        const int64_t row = e / T;
-        const int t = (int)(e - row * T), c = (int)(row % N);
-        const BnCoef k = bn_coef(cells, bn_running, training, 1, c, N, (double)g.BG * T, prm[g.o_g2 + c], prm[g.o_b2 + c]);
-        const float y = fmaf(z2[e], k.sc, k.sh);
-        const float o1 = fmaxf(fmaxf(y, 0.f) + out0[e], 0.f);
-        const float zg = tanhf(zpre[e] + prm[g.o_thb + t] + prm[g.o_gb + t]);
-        out1[e] = o1;
-        zpre[e] = zg;
-        tcat[row * g.KE + t] = zg * o1;
-    }
+// Every product runs four output columns per thread: the operand along the output's contiguous dimension comes as one 16-byte LDS read
+// per four multiply-adds (tiles at a row pitch of MAXT + 4 floats, the weight tables stored k-major).
+constexpr int TP = MAXT + 4;
+__device__ __forceinline__ void fma4(float (&acc)[4], float a, const float4& b) {
+    acc[0] = fmaf(a, b.x, acc[0]); acc[1] = fmaf(a, b.y, acc[1]); acc[2] = fmaf(a, b.z, acc[2]); acc[3] = fmaf(a, b.w, acc[3]);
 }
-
-// ---------------------------------------------------------------------------------------------------
-// graph: A = exp(-cdist(PX, PX)); T1 = A G; T2 = 2 A T1 - G; node sums of [G | T1 | T2]  (one sample per workgroup)
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB) void ast_graph_kernel(AstGeom g, const float* __restrict__ px, float* __restrict__ tcat,
-                                                      float* __restrict__ adj, float* __restrict__ distm, float* __restrict__ scat) {
-    __shared__ float P[MAXN][MAXT + 1];
-    __shared__ float G[MAXN][MAXT + 1];
-    __shared__ float T1[MAXN][MAXT + 1];
+__global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                      const float* __restrict__ bn_running, int training, const Cells* cells,
+                                                      const float* __restrict__ z2, const float* __restrict__ out0,
+                                                      float* __restrict__ zg_out, float* __restrict__ out1, float* __restrict__ tcat,
+                                                      float* __restrict__ px, float* __restrict__ adj, float* __restrict__ distm,
+                                                      float* __restrict__ scat, float* __restrict__ pooled) {
+    __shared__ __attribute__((aligned(16))) float THt[MAXT][TP];         // theta.weight^T: [k = time][t = gate column]
+    __shared__ __attribute__((aligned(16))) float PWt[MAXT][TP];         // P.weight^T: [k][c]
+    __shared__ __attribute__((aligned(16))) float P[MAXN][TP];
+    __shared__ __attribute__((aligned(16))) float G[MAXN][TP];
+    __shared__ __attribute__((aligned(16))) float T1[MAXN][TP];          // the x tile first, T1 later
     __shared__ float A[MAXN][MAXN + 1];
-    const int N = g.N, E = g.E, KE = g.KE, tid = threadIdx.x;
+    __shared__ float SC[3 * MAXT];
+    __shared__ float gbias[MAXT];
+    __shared__ BnCoef co2[MAXN];
+    const int N = g.N, T = g.T, E = g.E, KE = g.KE, O = g.O, tid = threadIdx.x;
+    const int Q = (E + 3) / 4;                    // column quads (E == T)
+    for (int e = tid; e < MAXT * TP; e += AB) { (&THt[0][0])[e] = 0.f; (&PWt[0][0])[e] = 0.f; }
+    for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&G[0][0])[e] = 0.f; (&T1[0][0])[e] = 0.f; }
+    __syncthreads();
+    for (int e = tid; e < E * T; e += AB) THt[e % T][e / T] = prm[g.o_thw + e];
+    for (int e = tid; e < E * E; e += AB) PWt[e % E][e / E] = prm[g.o_pw + e];
+    for (int e = tid; e < E; e += AB) gbias[e] = prm[g.o_thb + e] + prm[g.o_gb + e];
+    if (tid < N) co2[tid] = bn_coef(cells, bn_running, training, 1, tid, N, (double)g.BG * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         float* tc = tcat + b * N * KE;
-        for (int e = tid; e < N * E; e += AB) {
-            const int i = e / E, c = e - i * E;
-            P[i][c] = px[b * N * E + e];
-            G[i][c] = tc[i * KE + c];
+        for (int e = tid; e < N * T; e += AB) T1[e / T][e % T] = x[b * N * T + e];
+        __syncthreads();
+        for (int w = tid; w < N * Q; w += AB) {                  // gate: four columns t per thread
+            const int c = w / Q, t0 = 4 * (w - c * Q);
+            float zp[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < T; ++k) fma4(zp, T1[c][k], *reinterpret_cast<const float4*>(&THt[k][t0]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = t0 + r;
+                if (t < T) {
+                    const int64_t idx = b * N * T + c * T + t;
+                    const float y = fmaf(z2[idx], co2[c].sc, co2[c].sh);
+                    const float o1 = fmaxf(fmaxf(y, 0.f) + out0[idx], 0.f);
+                    const float zg = tanhf(zp[r] + gbias[t]);
+                    out1[idx] = o1;
+                    zg_out[idx] = zg;
+                    const float gv = zg * o1;
+                    G[c][t] = gv;
+                    tc[c * KE + t] = gv;
+                }
+            }
         }
         __syncthreads();
-        for (int e = tid; e < N * N; e += AB) {
+        for (int w = tid; w < N * Q; w += AB) {                  // PX = G P^T
+            const int i = w / Q, c0 = 4 * (w - i * Q);
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < E; ++k) fma4(a, G[i][k], *reinterpret_cast<const float4*>(&PWt[k][c0]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c0 + r < E) {
+                    P[i][c0 + r] = a[r];
+                    px[b * N * E + i * E + c0 + r] = a[r];
+                }
+        }
+        __syncthreads();
+        for (int e = tid; e < N * N; e += AB) {                  // (columns >= E of the P rows are zero: whole quads)
             const int i = e / N, j = e - i * N;
             float d2 = 0.f;
-            for (int c = 0; c < E; ++c) {
-                const float d = P[i][c] - P[j][c];
-                d2 = fmaf(d, d, d2);
+            for (int q = 0; q < Q; ++q) {
+                const float4 pi = *reinterpret_cast<const float4*>(&P[i][4 * q]), pj = *reinterpret_cast<const float4*>(&P[j][4 * q]);
+                const float dx = pi.x - pj.x, dy = pi.y - pj.y, dz = pi.z - pj.z, dw = pi.w - pj.w;
+                d2 = fmaf(dx, dx, d2); d2 = fmaf(dy, dy, d2); d2 = fmaf(dz, dz, d2); d2 = fmaf(dw, dw, d2);
             }
             const float ds = sqrtf(d2);
             const float a = expf(-ds);
@@ -116,28 +153,51 @@ __global__ __launch_bounds__(AB) void ast_graph_kernel(AstGeom g, const float* _
         }
         __syncthreads();
         if (g.K > 1) {
-            for (int e = tid; e < N * E; e += AB) {
-                const int i = e / E, c = e - i * E;
-                float a = 0.f;
-                for (int j = 0; j < N; ++j) a = fmaf(A[i][j], G[j][c], a);
-                T1[i][c] = a;
-                tc[i * KE + E + c] = a;
+            for (int w = tid; w < N * Q; w += AB) {
+                const int i = w / Q, c0 = 4 * (w - i * Q);
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < N; ++j) fma4(a, A[i][j], *reinterpret_cast<const float4*>(&G[j][c0]));
+                // (T1 aliases the x tile, which nobody reads any more)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < E) {
+                        T1[i][c0 + r] = a[r];
+                        tc[i * KE + E + c0 + r] = a[r];
+                    } else {
+                        T1[i][c0 + r] = 0.f;
+                    }
             }
             __syncthreads();
         }
         if (g.K > 2) {
-            for (int e = tid; e < N * E; e += AB) {
-                const int i = e / E, c = e - i * E;
-                float a = 0.f;
-                for (int j = 0; j < N; ++j) a = fmaf(A[i][j], T1[j][c], a);
-                tc[i * KE + 2 * E + c] = 2.0f * a - G[i][c];
+            for (int w = tid; w < N * Q; w += AB) {
+                const int i = w / Q, c0 = 4 * (w - i * Q);
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < N; ++j) fma4(a, A[i][j], *reinterpret_cast<const float4*>(&T1[j][c0]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c0 + r < E) tc[i * KE + 2 * E + c0 + r] = 2.0f * a[r] - G[i][c0 + r];
             }
             __syncthreads();
         }
         for (int e = tid; e < KE; e += AB) {                    // node sums (tc rows were written by this workgroup)
-            float s = 0.f;
-            for (int i = 0; i < N; ++i) s += tc[i * KE + e];
-            scat[b * KE + e] = s;
+            float sum = 0.f;
+            for (int i = 0; i < N; ++i) sum += tc[i * KE + e];
+            scat[b * KE + e] = sum;
+            SC[e] = sum;
+        }
+        __syncthreads();
+        {                                                        // pooled N = Scat Fcat: four k-stripes per output, combined in fixed order
+            float* PL = &T1[0][0];                               // [4][O] partial sums over the T1 tile (dead by now; O <= 256 <= MAXN TP / 4)
+            for (int it = tid; it < 4 * O; it += AB) {
+                const int st = it / O, o = it - st * O;
+                float a = 0.f;
+#pragma unroll 8
+                for (int k = st; k < KE; k += 4) a = fmaf(SC[k], prm[g.o_f + k * O + o], a);
+                PL[st * O + o] = a;
+            }
+            __syncthreads();
+            for (int o = tid; o < O; o += AB) pooled[b * O + o] = (PL[o] + PL[O + o]) + (PL[2 * O + o] + PL[3 * O + o]);
         }
         __syncthreads();
     }
@@ -184,29 +244,52 @@ __global__ __launch_bounds__(AB) void ast_head_kernel(AstGeom g, const float* __
 //   dA[i][j] = 2 u_j + v_j + 2 cs_i w_j
 //   dG_cheb[i] = dt0 - dt2 + cs_i dt1 + 2 (sum_j A[j][i] cs_j) dt2
 //   d dist = -A dA;  dPX_i = sum_j (d dist_ij + d dist_ji) (PX_i - PX_j) / dist_ij   (0 where dist = 0, as torch)
+// Round 4: the two GEMM launches around it live here -- DT = D Fcat^T (one row of K E values per sample) in front, and behind it the
+// projection's share of the gate gradient, dG = dG_cheb + dPX P, from the dPX tile in LDS.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const float* __restrict__ px, const float* __restrict__ tcat,
-                                                          const float* __restrict__ adj, const float* __restrict__ distm,
-                                                          const float* __restrict__ dt, float* __restrict__ dpx,
-                                                          float* __restrict__ dg) {
-    __shared__ float P[MAXN][MAXT + 1];
+__global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const float* __restrict__ prm, const float* __restrict__ px,
+                                                          const float* __restrict__ tcat, const float* __restrict__ adj,
+                                                          const float* __restrict__ distm, const float* __restrict__ dmat,
+                                                          float* __restrict__ dpx, float* __restrict__ dg) {
+    __shared__ __attribute__((aligned(16))) float PW[MAXT][TP];           // P.weight [k][c]
+    __shared__ __attribute__((aligned(16))) float DPX[MAXN][TP];
+    __shared__ __attribute__((aligned(16))) float P[MAXN][TP];
+    __shared__ float DM[256];
+    __shared__ float DTP[4][3 * MAXT];
     __shared__ float A[MAXN][MAXN + 1];
-    __shared__ float Ds[MAXN][MAXN + 1];
+    __shared__ float Cs[MAXN][MAXN + 1];          // (d dist_ij + d dist_ji) / dist_ij
     __shared__ float Cf[MAXN][MAXN + 1];
     __shared__ float d0[MAXT], d1[MAXT], d2v[MAXT];
     __shared__ float u[MAXN], v[MAXN], w[MAXN], cs[MAXN], acs[MAXN];
-    const int N = g.N, E = g.E, KE = g.KE, tid = threadIdx.x;
+    const int N = g.N, E = g.E, KE = g.KE, O = g.O, tid = threadIdx.x;
+    const int Q = (E + 3) / 4;
+    for (int e = tid; e < MAXT * TP; e += AB) (&PW[0][0])[e] = 0.f;
+    for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&DPX[0][0])[e] = 0.f; }
+    __syncthreads();
+    for (int e = tid; e < E * E; e += AB) PW[e / E][e % E] = prm[g.o_pw + e];
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* tc = tcat + b * N * KE;
         for (int e = tid; e < N * E; e += AB) P[e / E][e % E] = px[b * N * E + e];
         for (int e = tid; e < N * N; e += AB) {
             A[e / N][e % N] = adj[b * N * N + e];
-            Ds[e / N][e % N] = distm[b * N * N + e];
+            Cs[e / N][e % N] = distm[b * N * N + e];
         }
-        for (int e = tid; e < E; e += AB) {
-            d0[e] = dt[b * KE + e];
-            d1[e] = g.K > 1 ? dt[b * KE + E + e] : 0.f;
-            d2v[e] = g.K > 2 ? dt[b * KE + 2 * E + e] : 0.f;
+        for (int e = tid; e < O; e += AB) DM[e] = dmat[b * O + e];
+        __syncthreads();
+        for (int it = tid; it < 4 * KE; it += AB) {             // DT = D Fcat^T: row e of the filters viewed as [K E, O], four o-stripes
+            const int st = it / KE, e = it - st * KE;
+            const float* fr = prm + g.o_f + e * O;
+            float a = 0.f;
+#pragma unroll 8
+            for (int o = st; o < O; o += 4) a = fmaf(DM[o], fr[o], a);
+            DTP[st][e] = a;
+        }
+        __syncthreads();
+        for (int e = tid; e < 3 * E; e += AB) {
+            const float a = e < KE ? (DTP[0][e] + DTP[1][e]) + (DTP[2][e] + DTP[3][e]) : 0.f;
+            if (e < E) d0[e] = a;
+            else if (e < 2 * E) d1[e - E] = a;
+            else d2v[e - 2 * E] = a;
         }
         __syncthreads();
         if (tid < N) {
@@ -234,19 +317,44 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
             Cf[i][j] = -A[i][j] * dA;
         }
         __syncthreads();
-        for (int e = tid; e < N * E; e += AB) {
-            const int i = e / E, c = e - i * E;
-            float a = 0.f;
+        for (int e = tid; e < N * N; e += AB) {                  // the symmetrised coefficient once per pair (it used to be once per output)
+            const int i = e / N, j = e - i * N;
+            const float dist = Cs[i][j];
+            A[i][j] = dist > 0.f ? (Cf[i][j] + Cf[j][i]) / dist : 0.f;        // (A itself is no longer needed)
+        }
+        __syncthreads();
+        for (int wk = tid; wk < N * Q; wk += AB) {
+            const int i = wk / Q, c0 = 4 * (wk - i * Q);
+            const float4 pi = *reinterpret_cast<const float4*>(&P[i][c0]);
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < N; ++j) {
-                const float dist = Ds[i][j];
-                const float cf = dist > 0.f ? (Cf[i][j] + Cf[j][i]) / dist : 0.f;
-                a = fmaf(cf, P[i][c] - P[j][c], a);
+                const float cf = A[i][j];
+                const float4 pj = *reinterpret_cast<const float4*>(&P[j][c0]);
+                a[0] = fmaf(cf, pi.x - pj.x, a[0]); a[1] = fmaf(cf, pi.y - pj.y, a[1]);
+                a[2] = fmaf(cf, pi.z - pj.z, a[2]); a[3] = fmaf(cf, pi.w - pj.w, a[3]);
             }
-            dpx[b * N * E + e] = a;
-            float gch = d0[c];
-            if (g.K > 1) gch += cs[i] * d1[c];
-            if (g.K > 2) gch += (2.0f * acs[i] - 1.0f) * d2v[c];
-            dg[b * N * E + e] = gch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c0 + r < E) {
+                    dpx[b * N * E + i * E + c0 + r] = a[r];
+                    DPX[i][c0 + r] = a[r];
+                }
+        }
+        __syncthreads();
+        for (int wk = tid; wk < N * Q; wk += AB) {               // dG = dG_cheb + dPX P
+            const int i = wk / Q, c0 = 4 * (wk - i * Q);
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < E; ++k) fma4(a, DPX[i][k], *reinterpret_cast<const float4*>(&PW[k][c0]));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + r;
+                if (c < E) {
+                    float gch = d0[c];
+                    if (g.K > 1) gch += cs[i] * d1[c];
+                    if (g.K > 2) gch += (2.0f * acs[i] - 1.0f) * d2v[c];
+                    dg[b * N * E + i * E + c] = gch + a[r];
+                }
+            }
         }
         __syncthreads();
     }
@@ -299,13 +407,30 @@ __global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float
 
 // finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
 // (x bn_scale: under synchronised BatchNorm the cells hold GLOBAL sums on every rank and only one rank may contribute them)
-__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads, float bn_scale) {
-    const int c = blockIdx.x * AB + threadIdx.x;
+// (one workgroup; round 4: also the batch statistics out and the loss sum -- two launches less on the chain)
+__device__ __forceinline__ void ast_bn_batch_body(const AstGeom& g, const Cells* cells, float* __restrict__ bn_batch, float weight, int e);
+__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads, float bn_scale,
+                                                         float* __restrict__ bn_batch, float bn_weight, const float* __restrict__ sqerr,
+                                                         float* __restrict__ loss) {
+    __shared__ float red[AB];
+    const int c = threadIdx.x;
     if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
         grads[g.o_g1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
         grads[g.o_b1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
         grads[g.o_g2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
         grads[g.o_b2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
+    }
+    if (bn_batch && c >= 64 && c < 64 + 2 * g.N) ast_bn_batch_body(g, cells, bn_batch, bn_weight, c - 64);
+    if (loss) {             // strided partial sums, then a fixed-order tree (block_sum's arithmetic at 256 threads)
+        float a = 0.f;
+        for (int64_t i = threadIdx.x; i < g.B; i += AB) a += sqerr[i];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int m = AB / 2; m > 0; m >>= 1) {
+            if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss[0] = red[0];
     }
 }
 
@@ -324,9 +449,7 @@ __global__ void ast_cells_collapse_kernel(Cells* cells, int bwd, int blk) {
 }
 
 // BatchNorm batch statistics out: (mean, biased var) per block/channel, or weight * (E[z], E[z^2]) for data parallel
-__global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __restrict__ bn_batch, float weight) {
-    const int e = threadIdx.x;
-    if (e >= 2 * g.N) return;
+__device__ __forceinline__ void ast_bn_batch_body(const AstGeom& g, const Cells* cells, float* __restrict__ bn_batch, float weight, int e) {
     const int blk = e / g.N, c = e % g.N;
     const double count = (double)g.BG * g.T;
     const double m = cell_sum(cells, &Cells::fwd, blk, c, 0) / count, q = cell_sum(cells, &Cells::fwd, blk, c, 1) / count;
@@ -338,6 +461,9 @@ __global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __rest
         bn_batch[(blk * 2 + 0) * g.N + c] = (float)m;
         bn_batch[(blk * 2 + 1) * g.N + c] = (float)(v < 0.0 ? 0.0 : v);
     }
+}
+__global__ void ast_bn_batch_kernel(AstGeom g, const Cells* cells, float* __restrict__ bn_batch, float weight) {
+    if ((int)threadIdx.x < 2 * g.N) ast_bn_batch_body(g, cells, bn_batch, weight, threadIdx.x);
 }
 
 __global__ void ast_bn_running_kernel(float* __restrict__ bn, const float* __restrict__ batch, int N, double count, float momentum,
@@ -358,6 +484,12 @@ __global__ void ast_bn_running_kernel(float* __restrict__ bn, const float* __res
 }
 
 __global__ void ast_fill_one_kernel(float* p) { p[0] = 1.f; }
+// head of a call with a forward: the reduction cells cleared and the constant 1 of the bias reductions, one launch
+__global__ void ast_prepare_kernel(Cells* cells, float* one) {
+    double* p = reinterpret_cast<double*>(cells);
+    for (int i = threadIdx.x; i < (int)(sizeof(Cells) * CELL_REP / sizeof(double)); i += blockDim.x) p[i] = 0.0;
+    if (threadIdx.x == 0) one[0] = 1.f;
+}
 
 struct AstWs {
     size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dt, dpx, dg, ds1, dy2, dy1, gp1, gp2,
@@ -462,7 +594,7 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         return sync->fn(sync->user, buf, 2 * MAXN, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
     };
     if (mode & 1) {
-        if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
+        hipLaunchKernelGGL(ast_prepare_kernel, dim3(1), dim3(1024), 0, st, cells, F(w.one));
         const int rows = resident_rows((tcn_conv_kernel<1, AstGeom>), g.B, 1 << 20);
         hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
                            F(w.z1), (float*)nullptr, cells);
@@ -470,20 +602,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
-        // Zpre = x theta^T
-        AST_RC(sgemm(a->x, T, 1, prm + g.o_thw, T, 1, F(w.zpre), E, M, E, T, false, st));
-        {
-            int64_t blocks = (g.B * N * T + AB - 1) / AB;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(ast_gate_kernel, dim3((unsigned)blocks), dim3(AB), 0, st, g, prm, a->bn_stats, training, (const Cells*)cells,
-                               (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat));
-        }
-        // PX = G P^T  (G = columns [0, E) of Tcat)
-        AST_RC(sgemm(F(w.tcat), KE, 1, prm + g.o_pw, E, 1, F(w.px), E, M, E, E, false, st));
-        hipLaunchKernelGGL(ast_graph_kernel, dim3(resident_rows(ast_graph_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g,
-                           (const float*)F(w.px), F(w.tcat), F(w.adj), F(w.dist), F(w.scat));
-        // pooled * N = Scat Fcat   (Fcat = filters viewed as [K*E, O])
-        AST_RC(sgemm(F(w.scat), KE, 1, prm + g.o_f, 1, O, F(w.pooled), O, (int)g.B, O, KE, false, st));
+        // gate, P projection, graph, Chebyshev terms, node sums and the filter product: one launch (ast_front_kernel)
+        hipLaunchKernelGGL(ast_front_kernel, dim3(resident_rows(ast_front_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
+                           (const Cells*)cells, (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat), F(w.px), F(w.adj),
+                           F(w.dist), F(w.scat), F(w.pooled));
         hipLaunchKernelGGL(ast_head_kernel, dim3((unsigned)((g.B + 3) / 4 > 2048 ? 2048 : (g.B + 3) / 4)), dim3(AB), 0, st, g, prm,
                            F(w.pooled), a->y, (const float*)nullptr, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 0);
         if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
@@ -504,25 +626,22 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         const bool mse = a->dpred == nullptr;
         // the constant 1 the side stream's bias reductions read: written IN FRONT of the fork (behind it the side stream's split-K over
         // `one` was ordered against nothing that wrote it -- garbage from a fresh workspace on the first step)
-        hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
+        // (with a forward in the same call ast_prepare_kernel wrote it; batch statistics and the loss sum ride in the finalize kernel)
+        if (!(mode & 1)) hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
         fk.fork();
-        if ((mode & 1) && training && a->bn_batch)
-            hipLaunchKernelGGL(ast_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
-        if (mse && a->loss) (void)block_sum((const float*)F(w.sqerr), (int64_t)g.B, a->loss, st);
         // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
         AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
         if (cols_sum_small_ok(g.B, 1)) AST_RC(cols_sum_small(F(w.dpred), (int)g.B, 1, gr + g.o_fcb, wst));
         else AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
-        AST_RC(sgemm(F(w.dmat), O, 1, prm + g.o_f, O, 1, F(w.dt), KE, (int)g.B, KE, O, false, st));
-        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g,
-                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dt),
+        // DT = D Fcat^T, the graph backward and dG = dG_cheb + dPX P: one launch
+        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, prm,
+                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
                            F(w.dpx), F(w.dg));
-        // d P = dPX^T G ; dG += dPX P
+        // d P = dPX^T G
         fk.fork();
         AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
-        AST_RC(sgemm(F(w.dpx), E, 1, prm + g.o_pw, 1, E, F(w.dg), E, M, E, E, true, st));
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
         hipLaunchKernelGGL(ast_gate_bwd_kernel, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.out1),
                            (const float*)F(w.dg), F(w.zpre), F(w.ds1), F(w.dy2));
@@ -535,13 +654,15 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, wst) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
-        AST_RC(rows_sum(F(w.gp2), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w2, st));   // (on the side stream: 0.270 vs 0.263 ms)
         AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
-        AST_RC(rows_sum(F(w.gp1), rows, (int64_t)N * N * KT, N * N * KT, gr + g.o_w1, st));
+        // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
+        AST_RC(rows_sum2(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, st));
         AST_RC(fk.join());
-        hipLaunchKernelGGL(ast_finalize_kernel, dim3((N + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
+                           ((mode & 1) && training) ? a->bn_batch : (float*)nullptr, a->bn_moment_weight, (const float*)F(w.sqerr),
+                           (mse && a->loss) ? a->loss : (float*)nullptr);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -1061,6 +1061,41 @@ static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __re
         out[e] = v;
     }
 }
+// two sums of the same shape in one launch (blockIdx.y picks the pair)
+static __global__ __launch_bounds__(1024) void rows_sum2_kernel(const float* __restrict__ partA, float* __restrict__ outA,
+                                                                const float* __restrict__ partB, float* __restrict__ outB, int rows, int64_t ld, int n) {
+    __shared__ float red[32][33];
+    const float* part = blockIdx.y ? partB : partA;
+    float* out = blockIdx.y ? outB : outA;
+    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < n) {
+        const float* p = part + e;
+        int r = sl;
+        for (; r + 96 < rows; r += 128) {
+            a0 += p[(int64_t)r * ld];
+            a1 += p[(int64_t)(r + 32) * ld];
+            a2 += p[(int64_t)(r + 64) * ld];
+            a3 += p[(int64_t)(r + 96) * ld];
+        }
+        for (; r < rows; r += 32) a0 += p[(int64_t)r * ld];
+    }
+    red[sl][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sl == 0 && e < n) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v += red[q][lane];
+        out[e] = v;
+    }
+}
+int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st) {
+    if (n <= 0) return RULGNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_sum2_kernel, dim3((n + 31) / 32, 2), dim3(1024), 0, st, partA, outA, partB, outB, rows, ld, n);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {
     if (n <= 0) return RULGNN_OK;
     (void)hipGetLastError();
