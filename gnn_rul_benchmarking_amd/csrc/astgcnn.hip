@@ -80,7 +80,9 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                                                       const float* __restrict__ z2, const float* __restrict__ out0,
                                                       float* __restrict__ zg_out, float* __restrict__ out1, float* __restrict__ tcat,
                                                       float* __restrict__ px, float* __restrict__ adj, float* __restrict__ distm,
-                                                      float* __restrict__ scat, float* __restrict__ pooled) {
+                                                      float* __restrict__ scat, float* __restrict__ pooled, const float* __restrict__ y,
+                                                      float* __restrict__ pred, float* __restrict__ dpred, float* __restrict__ sqerr,
+                                                      float* __restrict__ dmat, float inv_gb) {
     __shared__ __attribute__((aligned(16))) float THt[MAXT][TP];         // theta.weight^T: [k = time][t = gate column]
     __shared__ __attribute__((aligned(16))) float PWt[MAXT][TP];         // P.weight^T: [k][c]
     __shared__ __attribute__((aligned(16))) float P[MAXN][TP];
@@ -197,7 +199,28 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                 PL[st * O + o] = a;
             }
             __syncthreads();
-            for (int o = tid; o < O; o += AB) pooled[b * O + o] = (PL[o] + PL[O + o]) + (PL[2 * O + o] + PL[3 * O + o]);
+            // head (ast_head_kernel's arithmetic, wavefront 0): pooled / N, pred = pooled fc^T + b, MSE pieces, D = dpred fc.weight / N
+            if (tid < 64) {
+                const float inv_n = 1.0f / (float)N;
+                float a = 0.f;
+                for (int o = tid; o < O; o += 64) {
+                    const float v = ((PL[o] + PL[O + o]) + (PL[2 * O + o] + PL[3 * O + o])) / (float)N;
+                    pooled[b * O + o] = v;
+                    a = fmaf(v, prm[g.o_fcw + o], a);
+                }
+                for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+                const float pr = a + prm[g.o_fcb];
+                if (tid == 0) pred[b] = pr;
+                if (y) {
+                    const float d = pr - y[b];
+                    const float dp = 2.0f * d * inv_gb;
+                    if (tid == 0) {
+                        dpred[b] = dp;
+                        sqerr[b] = d * d * inv_gb;
+                    }
+                    for (int o = tid; o < O; o += 64) dmat[b * O + o] = dp * prm[g.o_fcw + o] * inv_n;
+                }
+            }
         }
         __syncthreads();
     }
@@ -250,7 +273,14 @@ __global__ __launch_bounds__(AB) void ast_head_kernel(AstGeom g, const float* __
 __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const float* __restrict__ prm, const float* __restrict__ px,
                                                           const float* __restrict__ tcat, const float* __restrict__ adj,
                                                           const float* __restrict__ distm, const float* __restrict__ dmat,
-                                                          float* __restrict__ dpx, float* __restrict__ dg) {
+                                                          float* __restrict__ dpx, Cells* cells, const float* __restrict__ z2,
+                                                          const float* __restrict__ out1, float* __restrict__ zg_dzpre,
+                                                          float* __restrict__ ds1, float* __restrict__ dy2) {
+    // ... and the gate backward with the tail of the TCN backward (it consumed d G element by element, one sample per workgroup as well):
+    //   dzg = dG out1; dZpre = dzg (1 - zg^2) (over zg); dout1 = dG zg; ds1 = dout1 [out1 > 0]; dy2 = ds1 [bn2(z2) > 0]; BN2 backward sums
+    __shared__ float sy[MAXN][MAXT + 1];
+    __shared__ float sx[MAXN][MAXT + 1];
+    __shared__ BnCoef co2[MAXN];
     __shared__ __attribute__((aligned(16))) float PW[MAXT][TP];           // P.weight [k][c]
     __shared__ __attribute__((aligned(16))) float DPX[MAXN][TP];
     __shared__ __attribute__((aligned(16))) float P[MAXN][TP];
@@ -267,6 +297,8 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
     for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&DPX[0][0])[e] = 0.f; }
     __syncthreads();
     for (int e = tid; e < E * E; e += AB) PW[e / E][e % E] = prm[g.o_pw + e];
+    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * g.T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    float a1 = 0.f, a2 = 0.f;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* tc = tcat + b * N * KE;
         for (int e = tid; e < N * E; e += AB) P[e / E][e % E] = px[b * N * E + e];
@@ -352,48 +384,24 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
                     float gch = d0[c];
                     if (g.K > 1) gch += cs[i] * d1[c];
                     if (g.K > 2) gch += (2.0f * acs[i] - 1.0f) * d2v[c];
-                    dg[b * N * E + i * E + c] = gch + a[r];
+                    const float gg = gch + a[r];
+                    const int64_t idx = b * N * E + i * E + c;               // (E == T: node i is the BatchNorm channel, c the time step)
+                    const float zg = zg_dzpre[idx], o1 = out1[idx];
+                    zg_dzpre[idx] = gg * o1 * (1.0f - zg * zg);
+                    const float sv = o1 > 0.f ? gg * zg : 0.f;
+                    ds1[idx] = sv;
+                    const float zz = z2[idx];
+                    const float yv = fmaf(zz, co2[i].sc, co2[i].sh);
+                    const float dy = yv > 0.f ? sv : 0.f;
+                    dy2[idx] = dy;
+                    sy[i][c] = dy;
+                    sx[i][c] = dy * (zz - co2[i].mean) * co2[i].inv;
                 }
             }
         }
         __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// gate backward + tail of the TCN backward (one sample per workgroup):
-//   dzg = dG out1; dZpre = dzg (1 - zg^2) (over zg); dout1 = dG zg; ds1 = dout1 [out1 > 0];
-//   dy2 = ds1 [bn2(z2) > 0]; BN2 backward sums.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(AB) void ast_gate_bwd_kernel(AstGeom g, const float* __restrict__ prm, Cells* cells,
-                                                         const float* __restrict__ z2, const float* __restrict__ out1,
-                                                         const float* __restrict__ dg, float* __restrict__ zg_dzpre,
-                                                         float* __restrict__ ds1, float* __restrict__ dy2) {
-    __shared__ float sy[MAXN][MAXT + 1];
-    __shared__ float sx[MAXN][MAXT + 1];
-    __shared__ BnCoef co2[MAXN];
-    const int N = g.N, T = g.T, tid = threadIdx.x;
-    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
-    float a1 = 0.f, a2 = 0.f;
-    __syncthreads();
-    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
-        for (int e = tid; e < N * T; e += AB) {
-            const int c = e / T, t = e - c * T;
-            const int64_t idx = b * N * T + e;
-            const float gg = dg[idx], zg = zg_dzpre[idx], o1 = out1[idx];
-            zg_dzpre[idx] = gg * o1 * (1.0f - zg * zg);
-            const float s = o1 > 0.f ? gg * zg : 0.f;
-            ds1[idx] = s;
-            const float zz = z2[idx];
-            const float y = fmaf(zz, co2[c].sc, co2[c].sh);
-            const float dy = y > 0.f ? s : 0.f;
-            dy2[idx] = dy;
-            sy[c][t] = dy;
-            sx[c][t] = dy * (zz - co2[c].mean) * co2[c].inv;
-        }
-        __syncthreads();
         if (tid < N)
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < E; ++t) {
                 a1 += sy[tid][t];
                 a2 += sx[tid][t];
             }
@@ -602,12 +610,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
-        // gate, P projection, graph, Chebyshev terms, node sums and the filter product: one launch (ast_front_kernel)
+        // gate, P projection, graph, Chebyshev terms, node sums, the filter product and the head: one launch (ast_front_kernel)
         hipLaunchKernelGGL(ast_front_kernel, dim3(resident_rows(ast_front_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
                            (const Cells*)cells, (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat), F(w.px), F(w.adj),
-                           F(w.dist), F(w.scat), F(w.pooled));
-        hipLaunchKernelGGL(ast_head_kernel, dim3((unsigned)((g.B + 3) / 4 > 2048 ? 2048 : (g.B + 3) / 4)), dim3(AB), 0, st, g, prm,
-                           F(w.pooled), a->y, (const float*)nullptr, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 0);
+                           F(w.dist), F(w.scat), F(w.pooled), a->y, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb);
         if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
             hipLaunchKernelGGL(ast_bn_batch_kernel, dim3(1), dim3(64), 0, st, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
     }
@@ -635,19 +641,16 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         else AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
-        // DT = D Fcat^T, the graph backward and dG = dG_cheb + dPX P: one launch
+        // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
         hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, prm,
                            (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
-                           F(w.dpx), F(w.dg));
+                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2));
         // d P = dPX^T G
         fk.fork();
         AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
-        hipLaunchKernelGGL(ast_gate_bwd_kernel, dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.out1),
-                           (const float*)F(w.dg), F(w.zpre), F(w.ds1), F(w.dy2));
         AST_RC(sync_pair(1, 1));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
-        fk.fork();
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         if (cols_sum_small_ok(M, E)) AST_RC(cols_sum_small(F(w.zpre), M, E, gr + g.o_thb, wst));
         else AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, wst));

@@ -834,19 +834,22 @@ int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn,
 
 // Split-K for reductions over a long K (weight gradients: K = batch * nodes) with few output tiles: `slices` partial
 // products into `partial` ([slices][M][N], caller-provided), then a fixed-order sum -- deterministic, no atomics.
-static __global__ __launch_bounds__(256) void sgemm_reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ C,
-                                                                         int64_t ldc, int M, int N, int slices, int accumulate) {
-    // 64 outputs per workgroup, four threads per output each summing every fourth slice, combined in a fixed order
-    __shared__ float part[4][64];
+static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                                          int64_t ldc, int M, int N, int slices, int accumulate) {
+    // 64 outputs per workgroup, sixteen threads per output each summing every sixteenth slice (up to 256 slices: sixteen loads in a
+    // thread's chain), combined in a fixed order
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;
     float a = 0.f;
     if (e < M * N)
-        for (int z = q; z < slices; z += 4) a += partial[(int64_t)z * M * N + e];
+        for (int z = q; z < slices; z += 16) a += partial[(int64_t)z * M * N + e];
     part[q][lane] = a;
     __syncthreads();
     if (q == 0 && e < M * N) {
-        const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) v += (part[r][lane] + part[r + 1][lane]) + (part[r + 2][lane] + part[r + 3][lane]);
         float* c = C + (int64_t)(e / N) * ldc + (e % N);
         *c = accumulate ? *c + v : v;
     }
@@ -1002,7 +1005,7 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
     GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
     (void)hipGetLastError();
     sgemm_launch_tiles(g, used, st);
-    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(256), 0, st, partial, C, ldc, M, N, used,
+    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(1024), 0, st, partial, C, ldc, M, N, used,
                        accumulate ? 1 : 0);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

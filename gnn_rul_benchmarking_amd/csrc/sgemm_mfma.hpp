@@ -45,7 +45,9 @@ static inline int sgemm_splitk_slices(int M, int N, int K) {
     const int t = big ? 128 : 64;
     const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t);
     int s = (big ? 768 : 1024) / (tiles > 0 ? tiles : 1);          // aim at ~768 / ~1024 workgroups
-    const int maxs = (K + 255) / 256;                // at least 256 k per slice
+    // at least 64 k per slice for the 64 x 64 tile kernel: a slice costs ~1 us per 16-k step (one tile load in flight), so a [50 x 50] output
+    // over 10 240 rows took 20 us in 40 slices of 256 and takes a third of that in 160 of 64; 256 for the big tiles
+    const int maxs = big ? (K + 255) / 256 : (K + 63) / 64;
     if (s > maxs) s = maxs;
     if (s > 256) s = 256;
     return s < 1 ? 1 : s;
