@@ -419,7 +419,7 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
 __device__ __forceinline__ void ast_bn_batch_body(const AstGeom& g, const Cells* cells, float* __restrict__ bn_batch, float weight, int e);
 __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads, float bn_scale,
                                                          float* __restrict__ bn_batch, float bn_weight, const float* __restrict__ sqerr,
-                                                         float* __restrict__ loss) {
+                                                         float* __restrict__ loss, float* __restrict__ bn_running, float bn_momentum) {
     __shared__ float red[AB];
     const int c = threadIdx.x;
     if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
@@ -428,7 +428,19 @@ __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells
         grads[g.o_g2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
         grads[g.o_b2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
     }
-    if (bn_batch && c >= 64 && c < 64 + 2 * g.N) ast_bn_batch_body(g, cells, bn_batch, bn_weight, c - 64);
+    if (bn_batch && c >= 64 && c < 64 + 2 * g.N) {
+        ast_bn_batch_body(g, cells, bn_batch, bn_weight, c - 64);
+        if (bn_running) {       // nn.BatchNorm1d's running statistics (ast_bn_running_kernel's arithmetic on the values just written)
+            const int blk = (c - 64) / g.N, ch = (c - 64) % g.N;
+            const double count = (double)g.BG * g.T;
+            const float mean = bn_batch[(blk * 2 + 0) * g.N + ch], var = bn_batch[(blk * 2 + 1) * g.N + ch];
+            const float unbiased = count > 1.0 ? (float)(var * (count / (count - 1.0))) : var;
+            float* rm = bn_running + (blk * 2 + 0) * g.N + ch;
+            float* rv = bn_running + (blk * 2 + 1) * g.N + ch;
+            *rm = (1.0f - bn_momentum) * *rm + bn_momentum * mean;
+            *rv = (1.0f - bn_momentum) * *rv + bn_momentum * unbiased;
+        }
+    }
     if (loss) {             // strided partial sums, then a fixed-order tree (block_sum's arithmetic at 256 threads)
         float a = 0.f;
         for (int64_t i = threadIdx.x; i < g.B; i += AB) a += sqerr[i];
@@ -575,7 +587,8 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
     } while (0)
 
 // mode bit 0: forward (training != 0: batch statistics), bit 1: backward
-int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync) {
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync, float* bn_running_out,
+                float bn_momentum) {
     AstGeom g;
     AST_RC(ast_geometry(s, &g));
     if (sync) {          // both BatchNorm layers normalise by the statistics of the GLOBAL batch (cells all-reduced between the kernels)
@@ -665,7 +678,8 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         AST_RC(fk.join());
         hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
                            ((mode & 1) && training) ? a->bn_batch : (float*)nullptr, a->bn_moment_weight, (const float*)F(w.sqerr),
-                           (mse && a->loss) ? a->loss : (float*)nullptr);
+                           (mse && a->loss) ? a->loss : (float*)nullptr,
+                           ((mode & 1) && training && a->bn_batch && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr, bn_momentum);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
