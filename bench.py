@@ -588,11 +588,16 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
         H = cfg["encoder_hidden_dim"] * (2 if "<128" in name else 1)                          # layers 1, 3: H; layer 2: 2H (Model.py:41-56)
         return T * 2 * cfg["num_patch"] * (2 * 4 * H * H), ("recurrent matvec 4H x H per step, direction and sequence over batch x nodes = "
                                                             f"{T} SEQUENTIAL steps (H = {H}): a latency-bound recurrence, not a throughput kernel")
-    if family == "ASTGCNN" and ("ast_graph_kernel" in name or "ast_graph_bwd_kernel" in name):
-        N, E, K = cfg["num_nodes"], cfg["encoder_out_dim"], cfg["K"]
-        fwd = 3 * N * N * E + 2 * N * N * N + (K - 1) * 2 * N * N * E                           # cdist, one N^3 Laplacian term, Chebyshev recursion
-        return B * fwd * (2 if "bwd" in name else 1), (f"per sample graph ({N} nodes, {E} features, K = {K}): pairwise distances 3 N^2 E, "
-                                                       "(K - 1) Chebyshev products 2 N^2 E" + ("; backward = 2 x forward" if "bwd" in name else ""))
+    if family == "ASTGCNN" and ("ast_front_kernel" in name or "ast_graph_bwd_kernel" in name):
+        # round 4: the GEMM launches around the graph stage live inside these two kernels (csrc/astgcnn.hip): gate projection x theta^T and
+        # P projection (2 N E^2 each), the filter product (2 K E O per sample) -- and their backward counterparts d G += d PX P, DT = D Fcat^T
+        N, E, K, O = cfg["num_nodes"], cfg["encoder_out_dim"], cfg["K"], cfg["output_dim"]
+        graph = 3 * N * N * E + 2 * N * N * N + (K - 1) * 2 * N * N * E                         # cdist, one N^3 Laplacian term, Chebyshev recursion
+        if "bwd" in name:
+            return B * (2 * graph + 2 * N * E * E + 2 * K * E * O), (f"per sample ({N} nodes, {E} features, K = {K}): graph backward = 2 x (pairwise distances 3 N^2 E + "
+                                                                     "(K - 1) Chebyshev products 2 N^2 E), d G += d PX P 2 N E^2, DT = D Fcat^T 2 K E O")
+        return B * (graph + 4 * N * E * E + 2 * K * E * O), (f"per sample ({N} nodes, {E} features, K = {K}): gate and P projections 2 x 2 N E^2, pairwise "
+                                                             "distances 3 N^2 E, (K - 1) Chebyshev products 2 N^2 E, filter product 2 K E O")
     if family == "ASTGCNN" and "tcn_conv" in name:
         N, T = cfg["num_nodes"], cfg["time_length"]
         taps = 6                                                                                # kernel_size of the reference TCN (models/ASTGCNN/Model.py:236)
