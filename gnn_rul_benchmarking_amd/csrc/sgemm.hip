@@ -931,6 +931,66 @@ static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int
     }
 }
 
+// The same partial products on the fp32 matrix cores, straight from global memory, for the layout every weight gradient of the families
+// has: A = [K][M] and B = [K][N] row-major (sAm = sBn = 1), M <= 32, N <= 64.  One WAVEFRONT per k-range (what a workgroup was above:
+// same number of partial rows, same reduce kernel), v_mfma_f32_16x16x4f32 over four rows per step -- lane (kq, li) reads A[k + kq][16 mt + li]
+// and B[k + kq][16 nt + li], i.e. a wavefront's load is four rows of 64 contiguous bytes -- eight steps of loads in flight, no LDS, no
+// barrier.  The LDS kernel above ran 18-44 us per launch beside the families' backward chains (FC_STGNN: five of them were the step's
+// critical path); this one is bound by the rows it reads.
+template <int MT, int NT>
+static __global__ __launch_bounds__(256) void sgemm_longk_mfma_kernel(GemmArgs g, int kper, int ones, int nwaves) {
+    const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= nwaves) return;
+    const int li = lane & 15, kq = lane >> 4;
+    const int NB = g.N - ones;
+    f32x4t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    bool am[MT], bn[NT], b1[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) am[i] = 16 * i + li < g.M;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { bn[j] = 16 * j + li < NB; b1[j] = ones && 16 * j + li == NB; }
+    const int kbeg = wv * kper, kend = min(g.K, kbeg + kper);
+    const float* pa = g.A + li;
+    const float* pb = g.B + li;
+#pragma unroll 8
+    for (int k0 = kbeg; k0 < kend; k0 += 4) {
+        const int k = k0 + kq;
+        const bool kok = k < kend;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = (kok && am[i]) ? pa[(int64_t)k * g.sAk + 16 * i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[j] = (kok && bn[j]) ? pb[(int64_t)k * g.sBk + 16 * j] : ((kok && b1[j]) ? 1.f : 0.f);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float* out = g.C + (int64_t)wv * g.M * g.N;                 // g.C = the partial buffer: one row of M N values per wavefront
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * i + 4 * kq + r, n = 16 * j + li;
+                if (m < g.M && n < g.N) out[m * g.N + n] = acc[i][j][r];
+            }
+}
+static bool sgemm_longk_mfma_ok(const GemmArgs& g) { return g.sAm == 1 && g.sBn == 1 && g.M <= 32 && g.N <= 64; }
+static void sgemm_longk_mfma_launch(const GemmArgs& g, int kper, int ones, int nwaves, hipStream_t st) {
+    const int MT = (g.M + 15) / 16, NT = (g.N + 15) / 16;
+    const dim3 grid((nwaves + 3) / 4), block(256);
+#define RULGNN_LK(mt, nt) hipLaunchKernelGGL((sgemm_longk_mfma_kernel<mt, nt>), grid, block, 0, st, g, kper, ones, nwaves)
+    if (MT == 1) { if (NT == 1) RULGNN_LK(1, 1); else if (NT == 2) RULGNN_LK(1, 2); else if (NT == 3) RULGNN_LK(1, 3); else RULGNN_LK(1, 4); }
+    else { if (NT == 1) RULGNN_LK(2, 1); else if (NT == 2) RULGNN_LK(2, 2); else if (NT == 3) RULGNN_LK(2, 3); else RULGNN_LK(2, 4); }
+#undef RULGNN_LK
+}
+
 // (N counts the virtual ones column when colsum != nullptr: its sums go to colsum[m], not into C)
 static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
                                                                         int64_t ldc, int M, int N, int nblk, int accumulate,
@@ -992,6 +1052,8 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         nblk = (K + kper - 1) / kper;
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kper};
         (void)hipGetLastError();
+        if (sgemm_longk_mfma_ok(g)) sgemm_longk_mfma_launch(g, kper, 0, nblk, st);
+        else
         hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + N) + 256) * sizeof(float), st, g, kper, 0);
         hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, N, nblk,
                            accumulate ? 1 : 0, (float*)nullptr);
@@ -1023,6 +1085,8 @@ int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B
         nblk = (K + kper - 1) / kper;
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, NE, M, NE, K, 0, kper};
         (void)hipGetLastError();
+        if (sgemm_longk_mfma_ok(g)) sgemm_longk_mfma_launch(g, kper, 1, nblk, st);
+        else
         hipLaunchKernelGGL(sgemm_longk_kernel, dim3(nblk), dim3(256), ((size_t)SKT_ROWS * (M + NE) + 256) * sizeof(float), st, g, kper, 1);
         hipLaunchKernelGGL(sgemm_longk_reduce_kernel, dim3((M * NE + 3) / 4), dim3(256), 0, st, (const float*)partial, C, ldc, M, NE, nblk, 0,
                            colsum);
