@@ -1723,7 +1723,8 @@ size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s) {
     } while (0)
 
 // mode bit 0: forward (args->training selects batch / running statistics), bit 1: backward
-int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st, const FcstgnnSync* sync) {
+int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st, const FcstgnnSync* sync, float* bn_running_out,
+                float bn_momentum) {
     FcGeom g;
     FC_RC(fc_geometry(s, &g));
     if (sync) {
@@ -1867,10 +1868,15 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         auto fork = [&]() { fk.fork(); };
         // ... and so do the other launches nothing on the chain waits for: the constant for the column sums, the batch moments for the
         // bucket, the loss sum
+        // (one fork for everything that is ready when the backward starts: with an incoming gradient the MLP's d h first)
+        if (mlp_fused && a->dpred) mlp_tail(2, nullptr, a->dpred);
         fork();
         hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, wst, one);
-        if ((mode & 1) && training && a->bn_batch)
+        if ((mode & 1) && training && a->bn_batch) {
             hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, wst, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
+            if (bn_running_out && a->bn_moment_weight == 0.f)
+                hipLaunchKernelGGL(fc_bn_running_kernel, dim3(1), dim3(64), 0, wst, g, bn_running_out, (const float*)a->bn_batch, bn_momentum, 0);
+        }
         if (!a->dpred && a->loss) (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, wst);
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
             if (cols_sum_small_ok(rows, C)) return cols_sum_small(src, (int)rows, C, dst, wst);
@@ -1880,8 +1886,6 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         if (mlp_fused) {
             // d h3, d h2, d h1 are there (formed with the loss in the forward's fused MLP kernel, or here from the incoming gradient):
             // one fork, every parameter gradient of the MLP on the side
-            if (a->dpred) mlp_tail(2, nullptr, a->dpred);
-            fork();
             FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
             FC_RC(colsum(P_(w.dpred), g.B, 1, gr + g.o_f4b));
             FC_RC(sgemm_splitk(P_(w.dh3), 1, HD, P_(w.h2), 1, D2, gr + g.o_f3w, D2, HD, D2, Bi, false, split, wst));

@@ -473,11 +473,12 @@ int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fc
         if (opt->bn_stats && (!args->bn_batch || (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3))) return RULGNN_EINVAL;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = fcstgnn_run(shape, args, 3, st);
+    const bool tail_bn = opt && opt->bn_stats && args->training && args->bn_moment_weight == 0.f;
+    rc = fcstgnn_run(shape, args, 3, st, nullptr, tail_bn ? opt->bn_stats : nullptr, tail_bn ? opt->bn_momentum : 0.f);
     if (rc != RULGNN_OK || !opt) return rc;
     rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, fcstgnn_param_count(shape), opt->step, opt->lr,
                    opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
-    if (rc != RULGNN_OK || !opt->bn_stats) return rc;
+    if (rc != RULGNN_OK || !opt->bn_stats || tail_bn) return rc;
     return fcstgnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
 }
 
