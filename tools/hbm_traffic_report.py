@@ -14,6 +14,13 @@ def collect(sub, counter):
             m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)*>", r["Kernel_Name"])
             mx = re.search(r"stgcn_train_mx_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])      # matrix-core chain (round 4): <L, KIND, IDX, NFIX>
             mxw = re.search(r"stgcn_train_mxw_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])    # its wide form: <L, KIND, IDX, NT>
+            wide = int(os.environ.get("NP", 14)) >= 16                  # which chain this report is about (the default bench also runs 40 x 64 lines)
+            if (mxw or "stgcn_train_f0_mxw_kernel" in r["Kernel_Name"]) and not wide:
+                continue
+            if (mx or "stgcn_train_f0_mx_kernel" in r["Kernel_Name"]) and wide:
+                continue
+            if m and (m.group(1) == "64") != wide:                      # the fp32 chain's row width: 16 at num_patch <= 16, else 64
+                continue
             if mxw:
                 CHAIN.add("mx")
                 name = {"0": "F", "1": "TOP", "2": "G"}[mxw.group(2)] + (mxw.group(3) if mxw.group(2) != "1" else "")
