@@ -188,6 +188,9 @@ _SIGNATURES = {
     "rulgnn_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p]),
     "rulgnn_sgemm_mode": (C.c_int, [C.c_int32]),
+    "rulgnn_sgemm_splitk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rulgnn_sgemm_splitk_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rulgnn_stagnn_param_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_bn_state_count": (C.c_int64, [C.POINTER(StagnnShape)]),
     "rulgnn_stagnn_workspace_bytes": (C.c_size_t, [C.POINTER(StagnnShape)]),

@@ -512,7 +512,7 @@ __global__ void ast_prepare_kernel(Cells* cells, float* one) {
 }
 
 struct AstWs {
-    size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dt, dpx, dg, ds1, dy2, dy1, gp1, gp2,
+    size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dpx, ds1, dy2, dy1, gp1, gp2,
         split, total;
     int rows;
 };
@@ -537,9 +537,7 @@ void ast_ws_layout(const AstGeom& g, AstWs* w) {
     w->dpred = o; o = al(o + (size_t)g.B * sizeof(float));
     w->sqerr = o; o = al(o + (size_t)g.B * sizeof(float));
     w->dmat = o; o = al(o + (size_t)g.B * g.O * sizeof(float));
-    w->dt = o; o = al(o + (size_t)g.B * g.KE * sizeof(float));
     w->dpx = o; o = al(o + BNT);
-    w->dg = o; o = al(o + BNT);
     w->ds1 = o; o = al(o + BNT);
     w->dy2 = o; o = al(o + BNT);
     w->dy1 = o; o = al(o + BNT);

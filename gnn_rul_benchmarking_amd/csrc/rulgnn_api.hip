@@ -841,6 +841,34 @@ int rulgnn_sgemm_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, i
     return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, static_cast<hipStream_t>(stream));
 }
 
+static size_t splitk_part_floats(int32_t M, int32_t N, int32_t K) {
+    const size_t a = sgemm_splitk_need_floats(M, N, K), b = sgemm_splitk_need_floats(M, N + 1, K), c = sgemm_splitk_need_floats(M, 1, K);
+    const size_t v = a > b ? a : b;
+    return ((v > c ? v : c) + 63) & ~(size_t)63;
+}
+size_t rulgnn_sgemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (splitk_part_floats(M, N, K) + (size_t)K) * sizeof(float);
+}
+__global__ void splitk_ones_kernel(float* p, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 1.f;
+}
+int rulgnn_sgemm_splitk_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int32_t M,
+                            int32_t N, int32_t K, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 1 || ldc < N) return RULGNN_EINVAL;
+    if (M == 0 || N == 0) return RULGNN_OK;
+    if (!A || !B || !C || !workspace) return RULGNN_EINVAL;
+    if (workspace_bytes < rulgnn_sgemm_splitk_workspace_bytes(M, N, K)) return RULGNN_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(workspace);
+    if (!colsum) return sgemm_splitk(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, false, part, st);
+    float* ones = part + splitk_part_floats(M, N, K);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(splitk_ones_kernel, dim3(64), dim3(256), 0, st, ones, K);
+    if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    return sgemm_splitk_colsum(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, colsum, ones, part, st);
+}
+
 // ---- RGCNU ----------------------------------------------------------------------------------------------------------------------
 int64_t rulgnn_rgcnu_param_count(const rulgnn_rgcnu_shape* shape) { return rgcnu_param_count(shape); }
 size_t rulgnn_rgcnu_workspace_bytes(const rulgnn_rgcnu_shape* shape) { return rgcnu_workspace_bytes(shape); }

@@ -719,6 +719,15 @@ int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stag
  */
 int rulgnn_sgemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t accumulate, void *stream);
+/* The same product as a deterministic split-K reduction -- the weight gradients of the families: C[m][n] = sum over the K rows of the
+ * batch of dY(k, m) X(k, n), e.g. nn.Linear's weight.grad (models/FC_STGNN/Model_Base.py:44-107, models/HAGCN/Model.py:26-73) -- and,
+ * with `colsum` != NULL, colsum[m] = sum_k A(m, k) from the same pass (the bias gradient over the same rows).  `workspace`: at least
+ * rulgnn_sgemm_splitk_workspace_bytes(M, N, K) bytes (partial products and, for the column sums, K ones).  Small outputs over long
+ * reductions with row-major operands (sAm = sBn = 1, M <= 32, N <= 64) run one wavefront per k-range on the fp32 matrix cores straight from
+ * global memory; other shapes take the tile kernels.  Fixed summation order.  Exposed for the parity tests. */
+size_t rulgnn_sgemm_splitk_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int rulgnn_sgemm_splitk_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
+                            int32_t M, int32_t N, int32_t K, float *colsum, void *workspace, size_t workspace_bytes, void *stream);
 /* Arithmetic of the large-tile GEMM (outputs of at least ~100 x 100 with enough tiles to fill the chip), process-wide:
  * RULGNN_GEMM_BF16X3 (default): every fp32 operand split exactly into three bf16 parts, six bf16 matrix instructions per product
  * block with fp32 accumulation -- the error per product is that of one fp32 rounding (terms below 2^-23 relative are dropped), at up

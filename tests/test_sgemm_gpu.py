@@ -88,3 +88,49 @@ def test_bf16x3_is_fp32_class_on_hard_inputs():
     exact = Ai.astype(np.float64) @ Bi.astype(np.float64).T                        # |sum| <= 96 * 9e4 < 2^24: every partial sum is an exact fp32
     got = run(Ai, Bi, M, N, K, "r", "k")
     assert np.array_equal(got, exact)
+
+
+# ---- split-K weight gradients (rulgnn_sgemm_splitk_f32): every path of csrc/sgemm.hip::sgemm_splitk / sgemm_splitk_colsum -----------------
+def run_splitk(A, B, M, N, K, a_layout, b_layout, colsum):
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    At = torch.from_numpy(np.ascontiguousarray(A if a_layout == "k" else A.T)).to(DEV)
+    Bt = torch.from_numpy(np.ascontiguousarray(B if b_layout == "k" else B.T)).to(DEV)
+    sAm, sAk = (K, 1) if a_layout == "k" else (1, M)
+    sBn, sBk = (K, 1) if b_layout == "k" else (1, N)
+    Ct = torch.full((M, N), float("nan"), device=DEV)
+    cs = torch.full((M,), float("nan"), device=DEV) if colsum else None
+    nbytes = lib.rulgnn_sgemm_splitk_workspace_bytes(M, N, K)
+    ws = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rulgnn_sgemm_splitk_f32(At.data_ptr(), sAm, sAk, Bt.data_ptr(), sBn, sBk, Ct.data_ptr(), N, M, N, K,
+                                           cs.data_ptr() if colsum else None, ws.data_ptr(), nbytes, st), "sgemm_splitk")
+    torch.cuda.synchronize()
+    return Ct.cpu().numpy(), (cs.cpu().numpy() if colsum else None)
+
+
+# (M, N, K): the matrix-core long-k kernel in each of its tile counts (row-major operands, M <= 32, N <= 64, with the ones column pushing
+# N + 1 over a tile edge), the LDS long-k kernel (k-contiguous operands), the one-workgroup kernel (K <= 2048), 64-k slices of the tile
+# kernel with the 16-stripe reduction, a ragged last k-range
+SPLITK = [(8, 16, 93184), (16, 16, 50176), (16, 32, 7168), (16, 48, 7168), (32, 32, 10240), (24, 64, 4099), (30, 17, 131), (1, 8, 4000),
+          (16, 16, 2048), (8, 16, 600), (50, 50, 10240), (96, 72, 7168), (240, 60, 3584), (3, 5, 1)]
+
+
+@pytest.mark.parametrize("M,N,K", SPLITK)
+@pytest.mark.parametrize("layout", ["r", "k"])
+@pytest.mark.parametrize("colsum", [False, True])
+def test_splitk_weight_gradient_matches_numpy(M, N, K, layout, colsum):
+    rng = np.random.default_rng(M * 1000 + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got, cs = run_splitk(A, B, M, N, K, layout, layout, colsum)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() < 2e-6 * np.sqrt(K) * max(np.abs(ref).max(), 1.0) + 1e-6
+    if colsum:
+        cref = A.astype(np.float64).sum(axis=1)
+        assert np.isfinite(cs).all()
+        assert np.abs(cs - cref).max() < 2e-6 * np.sqrt(K) * max(np.abs(cref).max(), 1.0) + 1e-6
+    # deterministic: same bits on a second run
+    got2, cs2 = run_splitk(A, B, M, N, K, layout, layout, colsum)
+    assert np.array_equal(got, got2) and (not colsum or np.array_equal(cs, cs2))
