@@ -275,11 +275,14 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
                                                           const float* __restrict__ distm, const float* __restrict__ dmat,
                                                           float* __restrict__ dpx, Cells* cells, const float* __restrict__ z2,
                                                           const float* __restrict__ out1, float* __restrict__ zg_dzpre,
-                                                          float* __restrict__ ds1, float* __restrict__ dy2) {
+                                                          float* __restrict__ ds1, float* __restrict__ dy2, float* __restrict__ thb_part) {
+    // ... and the gate's bias gradient d theta.bias = d gate.bias = column sums of d Zpre: one partial row per workgroup (summed by the
+    // finalize kernel; it was a split-K launch pair and a copy at the END of the side chain, which had become the step's critical path)
     // ... and the gate backward with the tail of the TCN backward (it consumed d G element by element, one sample per workgroup as well):
     //   dzg = dG out1; dZpre = dzg (1 - zg^2) (over zg); dout1 = dG zg; ds1 = dout1 [out1 > 0]; dy2 = ds1 [bn2(z2) > 0]; BN2 backward sums
     __shared__ float sy[MAXN][MAXT + 1];
     __shared__ float sx[MAXN][MAXT + 1];
+    __shared__ float DPX2[MAXN][MAXT + 1];       // d Zpre of the sample (for its column sums)
     __shared__ BnCoef co2[MAXN];
     __shared__ __attribute__((aligned(16))) float PW[MAXT][TP];           // P.weight [k][c]
     __shared__ __attribute__((aligned(16))) float DPX[MAXN][TP];
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
     __syncthreads();
     for (int e = tid; e < E * E; e += AB) PW[e / E][e % E] = prm[g.o_pw + e];
     if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * g.T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
-    float a1 = 0.f, a2 = 0.f;
+    float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* tc = tcat + b * N * KE;
         for (int e = tid; e < N * E; e += AB) P[e / E][e % E] = px[b * N * E + e];
@@ -387,7 +390,9 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
                     const float gg = gch + a[r];
                     const int64_t idx = b * N * E + i * E + c;               // (E == T: node i is the BatchNorm channel, c the time step)
                     const float zg = zg_dzpre[idx], o1 = out1[idx];
-                    zg_dzpre[idx] = gg * o1 * (1.0f - zg * zg);
+                    const float dzp = gg * o1 * (1.0f - zg * zg);
+                    zg_dzpre[idx] = dzp;
+                    DPX2[i][c] = dzp;
                     const float sv = o1 > 0.f ? gg * zg : 0.f;
                     ds1[idx] = sv;
                     const float zz = z2[idx];
@@ -405,12 +410,15 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
                 a1 += sy[tid][t];
                 a2 += sx[tid][t];
             }
+        if (tid >= 64 && tid < 64 + E)
+            for (int i = 0; i < N; ++i) a3 += DPX2[i][tid - 64];
         __syncthreads();
     }
     if (tid < N) {
         atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][0], (double)a1);
         atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[1][tid][1], (double)a2);
     }
+    if (tid >= 64 && tid < 64 + E) thb_part[(int64_t)blockIdx.x * E + tid - 64] = a3;
 }
 
 // finalize: conv partial rows -> gradient; BatchNorm gamma/beta gradients and batch statistics from the cells; loss
@@ -503,6 +511,7 @@ __global__ void ast_bn_running_kernel(float* __restrict__ bn, const float* __res
     *rv = (1.0f - momentum) * *rv + momentum * unbiased;
 }
 
+constexpr int AST_BWD_ROWS = 4096;      // workgroups of the graph backward at most (one partial row of the gate's bias gradient each)
 __global__ void ast_fill_one_kernel(float* p) { p[0] = 1.f; }
 // head of a call with a forward: the reduction cells cleared and the constant 1 of the bias reductions, one launch
 __global__ void ast_prepare_kernel(Cells* cells, float* one) {
@@ -512,7 +521,7 @@ __global__ void ast_prepare_kernel(Cells* cells, float* one) {
 }
 
 struct AstWs {
-    size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dpx, ds1, dy2, dy1, gp1, gp2,
+    size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dpx, ds1, dy2, dy1, thb, gp1, gp2,
         split, total;
     int rows;
 };
@@ -542,6 +551,7 @@ void ast_ws_layout(const AstGeom& g, AstWs* w) {
     w->dy2 = o; o = al(o + BNT);
     w->dy1 = o; o = al(o + BNT);
     w->rows = 1024;
+    w->thb = o; o = al(o + (size_t)AST_BWD_ROWS * g.E * sizeof(float));
     w->gp1 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
     w->gp2 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
     const int mx = g.KE > g.E ? g.KE : g.E;
@@ -653,9 +663,10 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
-        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(resident_rows(ast_graph_bwd_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, prm,
+        const int bwd_rows = resident_rows(ast_graph_bwd_kernel, g.B, AST_BWD_ROWS);
+        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(bwd_rows), dim3(AB), 0, st, g, prm,
                            (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
-                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2));
+                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
         // d P = dPX^T G
         fk.fork();
         AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
@@ -663,16 +674,15 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         AST_RC(sync_pair(1, 1));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
-        if (cols_sum_small_ok(M, E)) AST_RC(cols_sum_small(F(w.zpre), M, E, gr + g.o_thb, wst));
-        else AST_RC(sgemm_splitk(F(w.one), 0, 0, F(w.zpre), 1, E, gr + g.o_thb, E, 1, E, M, false, split, wst));
-        if (hipMemcpyAsync(gr + g.o_gb, gr + g.o_thb, sizeof(float) * E, hipMemcpyDeviceToDevice, wst) != hipSuccess) return RULGNN_EHIP;
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
         AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
-        AST_RC(rows_sum2(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, st));
+        // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)
+        AST_RC(rows_sum3(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, F(w.thb), gr + g.o_thb, gr + g.o_gb,
+                         bwd_rows, (int64_t)E, E, st));
         AST_RC(fk.join());
         hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
                            ((mode & 1) && training) ? a->bn_batch : (float*)nullptr, a->bn_moment_weight, (const float*)F(w.sqerr),

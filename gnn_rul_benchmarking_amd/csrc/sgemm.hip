@@ -1128,14 +1128,23 @@ static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __re
         out[e] = v;
     }
 }
-// two sums of the same shape in one launch (blockIdx.y picks the pair)
-static __global__ __launch_bounds__(1024) void rows_sum2_kernel(const float* __restrict__ partA, float* __restrict__ outA,
-                                                                const float* __restrict__ partB, float* __restrict__ outB, int rows, int64_t ld, int n) {
+// up to three such sums in one launch (blockIdx.y picks the job; a job may write its result twice: out and out2)
+struct RowsSumJobs {
+    const float* part[3];
+    float* out[3];
+    float* out2[3];
+    int rows[3], n[3];
+    int64_t ld[3];
+};
+static __global__ __launch_bounds__(1024) void rows_sum_multi_kernel(RowsSumJobs jb) {
     __shared__ float red[32][33];
-    const float* part = blockIdx.y ? partB : partA;
-    float* out = blockIdx.y ? outB : outA;
+    const int job = blockIdx.y;
+    const float* part = jb.part[job];
+    const int rows = jb.rows[job], n = jb.n[job];
+    const int64_t ld = jb.ld[job];
     const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + lane;
+    if (blockIdx.x * 32 >= n) return;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (e < n) {
         const float* p = part + e;
@@ -1154,13 +1163,23 @@ static __global__ __launch_bounds__(1024) void rows_sum2_kernel(const float* __r
         float v = 0.f;
 #pragma unroll
         for (int q = 0; q < 32; ++q) v += red[q][lane];
-        out[e] = v;
+        jb.out[job][e] = v;
+        if (jb.out2[job]) jb.out2[job][e] = v;
     }
 }
 int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st) {
+    return rows_sum3(partA, outA, partB, outB, rows, ld, n, nullptr, nullptr, nullptr, 0, 0, 0, st);
+}
+int rows_sum3(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, const float* partC, float* outC,
+              float* outC2, int rowsC, int64_t ldC, int nC, hipStream_t st) {
     if (n <= 0) return RULGNN_OK;
+    RowsSumJobs jb{};
+    jb.part[0] = partA; jb.out[0] = outA; jb.rows[0] = rows; jb.n[0] = n; jb.ld[0] = ld;
+    jb.part[1] = partB; jb.out[1] = outB; jb.rows[1] = rows; jb.n[1] = n; jb.ld[1] = ld;
+    jb.part[2] = partC; jb.out[2] = outC; jb.out2[2] = outC2; jb.rows[2] = rowsC; jb.n[2] = nC; jb.ld[2] = ldC;
+    const int nmax = n > nC ? n : nC;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(rows_sum2_kernel, dim3((n + 31) / 32, 2), dim3(1024), 0, st, partA, outA, partB, outB, rows, ld, n);
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3((nmax + 31) / 32, partC && nC > 0 ? 3 : 2), dim3(1024), 0, st, jb);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {

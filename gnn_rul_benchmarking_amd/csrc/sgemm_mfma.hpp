@@ -31,6 +31,9 @@ int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B
 // out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
 int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st);
+// ... plus a third sum of another shape whose result is written twice (outC and, if given, outC2)
+int rows_sum3(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, const float* partC, float* outC,
+              float* outC2, int rowsC, int64_t ldC, int nC, hipStream_t st);
 // dst[c] = sum_r src[r][c] of a short row-major matrix with ONE workgroup.  A thread walks rows * C / 1024 elements alone: beyond
 // ~64 of them the split-K pair wins again (10 240 rows x 50 columns: > 100 us)
 inline bool cols_sum_small_ok(int64_t rows, int C) { return C >= 1 && C <= 64 && rows * C <= 65536; }

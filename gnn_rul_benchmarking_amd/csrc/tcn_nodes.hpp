@@ -15,6 +15,7 @@ constexpr int AB = 256;            // threads per workgroup
 constexpr int KT = 6;              // TCN kernel size
 constexpr int MAXN = 25;           // nodes
 constexpr int MAXT = 64;
+constexpr int XP = MAXT + 16;        // row pitch of the convolution tiles: 16-byte row reads, room for the taps' reach on both sides
 constexpr float BN_EPS = 1e-5f;
 
 // reduction cells (fp64): forward sums [2 blocks][N][sum, sumsq], backward sums [2][N][sum dy, sum dy*xhat]
@@ -68,14 +69,15 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
                                                      float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
     constexpr int D = STAGE == 1 ? 1 : 2;
     constexpr int PADL = (KT - 1) * D;
-    __shared__ float w[MAXN * MAXN * KT];
-    __shared__ float xs[MAXN][MAXT + PADL];
+    static_assert(KT == 6, "the taps of a (co, ci) pair are read as three 8-byte pieces");
+    __shared__ __attribute__((aligned(16))) float w[MAXN * MAXN * KT];
+    __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];           // left-padded with PADL zeros
     __shared__ float zs[MAXN][MAXT + 1];
     __shared__ BnCoef co1[MAXN];
     const int N = g.N, T = g.T, tid = threadIdx.x;
     const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
     for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
-    for (int e = tid; e < N * PADL; e += AB) xs[e / PADL][e % PADL] = 0.f;
+    for (int e = tid; e < MAXN * XP; e += AB) (&xs[0][0])[e] = 0.f;
     if (STAGE == 2 && tid < N)
         co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.BG * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
     float s1 = 0.f, s2 = 0.f;
@@ -93,17 +95,35 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
             xs[c][PADL + t] = v;
         }
         __syncthreads();
-        for (int e = tid; e < N * T; e += AB) {
-            const int co = e / T, t = e - co * T;
-            float a = 0.f;
+        // four consecutive steps t per thread: the six taps of a (co, ci) pair and the 4 + 5 D inputs they meet come as 16- / 8-byte LDS
+        // reads once per 24 multiply-adds (it was two 4-byte reads per multiply-add); same order of additions per output as before
+        const int Q = (T + 3) / 4;
+        for (int wi = tid; wi < N * Q; wi += AB) {
+            const int co = wi / Q, t0 = 4 * (wi - co * Q);
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
             for (int ci = 0; ci < N; ++ci) {
-                const float* wr = w + (co * N + ci) * KT;
-                const float* xr = &xs[ci][t + PADL - (KT - 1) * D];
+                const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
+                const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
+                const float wk[KT] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
+                constexpr int NX = (4 + PADL + 3) / 4;                  // xs[ci][t0 + k D + i]: PADL - (KT - 1) D = 0
+                float xv[4 * NX];
+                const float4* xr = reinterpret_cast<const float4*>(&xs[ci][t0]);
 #pragma unroll
-                for (int k = 0; k < KT; ++k) a = fmaf(wr[k], xr[k * D], a);
+                for (int q = 0; q < NX; ++q) {
+                    const float4 v = xr[q];
+                    xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = fmaf(wk[k], xv[k * D + i], a[i]);
             }
-            zout[b * N * T + e] = a;
-            zs[co][t] = a;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (t0 + i < T) {
+                    zout[b * N * T + co * T + t0 + i] = a[i];
+                    zs[co][t0 + i] = a[i];
+                }
         }
         __syncthreads();
         if (training && tid < N) {
@@ -134,10 +154,11 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
                                                          float* __restrict__ gpart) {
     constexpr int D = STAGE == 1 ? 1 : 2;
     constexpr int PAD = (KT - 1) * D;
-    constexpr int NACC = (MAXN * MAXN * KT + AB - 1) / AB;
-    __shared__ float w[MAXN * MAXN * KT];
-    __shared__ float xs[MAXN][MAXT + PAD];        // conv input (x or out0), left-padded with zeros
-    __shared__ float dz[MAXN][MAXT + PAD];        // d z, right-padded with zeros
+    constexpr int NPAIR = (MAXN * MAXN + AB - 1) / AB;      // (co, ci) pairs per thread: all six taps of a pair in one thread
+    static_assert(KT == 6, "the taps of a (co, ci) pair are read as three 8-byte pieces");
+    __shared__ __attribute__((aligned(16))) float w[MAXN * MAXN * KT];
+    __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];        // conv input (x or out0), left-padded with zeros (zero behind the row too)
+    __shared__ __attribute__((aligned(16))) float dz[MAXN][XP];        // d z, zero from column T on
     __shared__ float sy[MAXN][MAXT + 1];
     __shared__ float sx[MAXN][MAXT + 1];
     __shared__ BnCoef cz[MAXN], c1[MAXN];
@@ -147,10 +168,11 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     const int nW = N * N * KT;
     if (STAGE == 2)
         for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_w2 + e];
-    for (int e = tid; e < N * PAD; e += AB) {
-        xs[e / PAD][e % PAD] = 0.f;
-        dz[e / PAD][T + e % PAD] = 0.f;
+    for (int e = tid; e < MAXN * XP; e += AB) {
+        (&xs[0][0])[e] = 0.f;
+        (&dz[0][0])[e] = 0.f;
     }
+    __syncthreads();
     if (tid < N) {
         cz[tid] = bn_coef(cells, nullptr, 1, blk, tid, N, count, prm[(STAGE == 1 ? g.o_g1 : g.o_g2) + tid],
                           prm[(STAGE == 1 ? g.o_b1 : g.o_b2) + tid]);
@@ -158,9 +180,13 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         bsum[tid][0] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 0) / count);
         bsum[tid][1] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 1) / count);
     }
-    float acc[NACC];
+    float acc[NPAIR][KT];
 #pragma unroll
-    for (int r = 0; r < NACC; ++r) acc[r] = 0.f;
+    for (int r = 0; r < NPAIR; ++r)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[r][k] = 0.f;
+    const int Q = (T + 3) / 4;
+    constexpr int NX = (4 + PAD + 3) / 4;
     float a1 = 0.f, a2 = 0.f;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
@@ -173,28 +199,63 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         }
         __syncthreads();
         // d W[co][ci][k] += sum_t dz[co][t] * in[ci][t - (KT-1-k) D]
+        // (a thread owns all six taps of its pairs: four steps of d z and the 4 + 5 D inputs they meet per 16-byte reads, 24 multiply-adds
+        // per five or six LDS reads instead of 48; same order of additions per weight: t ascending, d z = 0 behind T)
 #pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-            const int e = tid + r * AB;
-            if (e < nW) {
-                const int k = e % KT, ci = (e / KT) % N, co = e / (KT * N);
-                const float* xr = &xs[ci][PAD - (KT - 1 - k) * D];
-                float a = 0.f;
-                for (int t = 0; t < T; ++t) a = fmaf(dz[co][t], xr[t], a);
-                acc[r] += a;
+        for (int r = 0; r < NPAIR; ++r) {
+            const int p = tid + r * AB;
+            if (p < N * N) {
+                const int ci = p % N, co = p / N;
+                float a6[KT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float4* dr = reinterpret_cast<const float4*>(&dz[co][0]);
+                for (int q4 = 0; q4 < Q; ++q4) {
+                    const float4 dv = dr[q4];
+                    const float dzv[4] = {dv.x, dv.y, dv.z, dv.w};
+                    float xv[4 * NX];
+                    const float4* xr = reinterpret_cast<const float4*>(&xs[ci][4 * q4]);       // xs[ci][t + k D]: PAD - (KT - 1 - k) D = k D
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        const float4 v = xr[q];
+                        xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) a6[k] = fmaf(dzv[i], xv[k * D + i], a6[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc[r][k] += a6[k];
             }
         }
         if (STAGE == 2) {
             // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
-            for (int e = tid; e < N * T; e += AB) {
-                const int ci = e / T, t = e - ci * T;
-                const int64_t idx = b * N * T + e;
-                float a = ds1[idx];
-                for (int co = 0; co < N; ++co) {
-                    const float* wr = w + (co * N + ci) * KT;
+            for (int wi = tid; wi < N * Q; wi += AB) {
+                const int ci = wi / Q, t0 = 4 * (wi - ci * Q);
+                float a4[4];
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) a = fmaf(wr[k], dz[co][t + (KT - 1 - k) * D], a);
+                for (int i = 0; i < 4; ++i) a4[i] = t0 + i < T ? ds1[b * N * T + ci * T + t0 + i] : 0.f;
+                for (int co = 0; co < N; ++co) {
+                    const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
+                    const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
+                    const float wk[KT] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
+                    float dv[4 * NX];
+                    const float4* dr = reinterpret_cast<const float4*>(&dz[co][t0]);
+#pragma unroll
+                    for (int q = 0; q < NX; ++q) {
+                        const float4 v = dr[q];
+                        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < KT; ++k)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a4[i] = fmaf(wk[k], dv[(KT - 1 - k) * D + i], a4[i]);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                if (t0 + i >= T) continue;
+                const int t = t0 + i;
+                const int64_t idx = b * N * T + ci * T + t;
+                const float a = a4[i];
                 const float o0 = xs[ci][PAD + t];
                 const float s0 = o0 > 0.f ? a : 0.f;
                 const float zz = z1[idx];
@@ -203,6 +264,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
                 dy1[idx] = dy;
                 sy[ci][t] = dy;
                 sx[ci][t] = dy * (zz - c1[ci].mean) * c1[ci].inv;
+                }
             }
             __syncthreads();
             if (tid < N)
@@ -215,9 +277,12 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     }
     float* dst = gpart + (int64_t)blockIdx.x * nW;
 #pragma unroll
-    for (int r = 0; r < NACC; ++r) {
-        const int e = tid + r * AB;
-        if (e < nW) dst[e] = acc[r];
+    for (int r = 0; r < NPAIR; ++r) {
+        const int p = tid + r * AB;
+        if (p < N * N) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) dst[p * KT + k] = acc[r][k];
+        }
     }
     if (STAGE == 2 && tid < N) {
         atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][0], (double)a1);
