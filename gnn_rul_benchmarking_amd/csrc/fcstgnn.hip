@@ -815,6 +815,24 @@ __global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id, co
     }
 }
 
+// ... and as a transform in the LOAD of a consumer (round 4: the two channel-major passes over [M, C, L] were 16 + 17 us launches on the
+// backward chain for 2 flops per element; the convolution gradient kernels that read their result apply it to each element they load)
+struct BnBwdLds {
+    BnCoef cf[MAXC];
+    float s1[MAXC], s2[MAXC];
+    __device__ __forceinline__ void init(const FcGeom& g, const Cells* cells, const float* prm, int id) {
+        if ((int)threadIdx.x < g.bn_ch[id]) {
+            cf[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, id, threadIdx.x);
+            s1[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 0) / g.cnt[id]);
+            s2[threadIdx.x] = (float)(cell_bwd(cells, id, threadIdx.x, 1) / g.cnt[id]);
+        }
+    }
+    __device__ __forceinline__ float apply(float dy, float z, int c) const {
+        const float xh = (z - cf[c].mean) * cf[c].inv;
+        return cf[c].sc * (dy - s1[c] - xh * s2[c]);
+    }
+};
+
 // the same for channel-major rows [m][C][L]
 __global__ __launch_bounds__(FB) void fc_bn_chan_bwd_kernel(FcGeom g, int id, int L, const float* __restrict__ prm, const Cells* cells,
                                                            const float* __restrict__ z, float* __restrict__ dy, int64_t total) {
@@ -1382,12 +1400,15 @@ __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* 
 }
 
 // dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums  (row-group mapping, see fc_conv2_kernel)
+// (`z2` != nullptr: `dz2` is still d y2 -- the gradient in front of BatchNorm 1's backward, which is applied to every element as it is loaded)
 __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z1, const float* __restrict__ dz2,
-                                                        float* __restrict__ dy1) {
+                                                        float* __restrict__ dy1, const float* __restrict__ z2) {
     __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ca[16];
     __shared__ float wl[FC_W2_MAX];
+    __shared__ BnBwdLds bb;
+    if (z2) bb.init(g, cells, prm, 1);
     if (threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
     for (int e = threadIdx.x; e < g.CO * g.H1 * g.K; e += FB) wl[e] = prm[g.o_w2 + e];
     BlockStats st;
@@ -1402,7 +1423,10 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
             for (int co = 0; co < CO; ++co)
                 for (int k = 0; k < K; ++k) {
                     const int p = q + 1 - k;
-                    if (p >= 0 && p < L2) dy = fmaf(wl[(co * H1 + ci) * K + k], dr[co * L2 + p], dy);
+                    if (p >= 0 && p < L2) {
+                        const float dv = z2 ? bb.apply(dr[co * L2 + p], z2[m * CL + co * L2 + p], co) : dr[co * L2 + p];
+                        dy = fmaf(wl[(co * H1 + ci) * K + k], dv, dy);
+                    }
                 }
         }
         dy1[m * T1 + pos] = dy;
@@ -1419,7 +1443,9 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
         int buf = 0;
         auto fetch_d = [&](int64_t m0) {
             const int64_t m = m0 + rg.sub;
-            return (rg.on && m < g.M && rg.pos < CL) ? dz2[m * CL + rg.pos] : 0.f;
+            if (!(rg.on && m < g.M && rg.pos < CL)) return 0.f;
+            const float dv = dz2[m * CL + rg.pos];
+            return z2 ? bb.apply(dv, z2[m * CL + rg.pos], rg.pos / L2) : dv;
         };
         auto fetch_z = [&](int64_t m0) {
             const int64_t m = m0 + rg.sub;
@@ -1455,11 +1481,15 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
 // conv weight gradients: WHICH 2: dw2[co][ci][k] = sum_m sum_p dz2[m][co][p] * a1[m][ci][p + k - 1]
 //                        WHICH 1: dw1[c][k]      = sum_m sum_p dz1[m][c][p]  * v[m][p + k - K/2]
 // each workgroup reduces a contiguous chunk of rows; thread-owned outputs, one partial row per workgroup
+// (`zbn` != nullptr: `dz` is still the gradient in FRONT of the convolution's BatchNorm backward -- BatchNorm WHICH - 1, pre-activations
+// `zbn` = z2 | z1 --, applied to every element as it is loaded)
 template <int WHICH>
 __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                           const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
-                                                          float* __restrict__ gpart) {
+                                                          float* __restrict__ gpart, const float* __restrict__ zbn) {
     __shared__ BnCoef ca[16];
+    __shared__ BnBwdLds bb;
+    if (zbn) bb.init(g, cells, prm, WHICH - 1);
     if (WHICH == 2 && threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
     __syncthreads();
     const int nout = WHICH == 2 ? g.CO * g.H1 * g.K : g.H1 * g.K;
@@ -1472,10 +1502,12 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
             const int k = o % g.K, ci = (o / g.K) % g.H1, co = o / (g.K * g.H1);
             for (int64_t m = mb; m < m1; m += step) {
                 const float* dr = dz + m * g.CL + co * g.L2;
+                const float* zb = zbn ? zbn + m * g.CL + co * g.L2 : nullptr;
                 const float* zr = z1 + (m * g.H1 + ci) * g.L1;
                 for (int p = 0; p < g.L2; ++p) {
                     const int q = p + k - 1;
-                    if (q >= 0 && q < g.L1) acc = fmaf(dr[p], fmaxf(fmaf(zr[q], ca[ci].sc, ca[ci].sh), 0.f), acc);
+                    if (q >= 0 && q < g.L1)
+                        acc = fmaf(zb ? bb.apply(dr[p], zb[p], co) : dr[p], fmaxf(fmaf(zr[q], ca[ci].sc, ca[ci].sh), 0.f), acc);
                 }
             }
         } else {
@@ -1485,9 +1517,10 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
                 const int64_t b = m / ((int64_t)g.N * g.NP);
                 const float* v = x + (b * g.N + node) * g.TL + t * g.PS;
                 const float* dr = dz + (m * g.H1 + c) * g.L1;
+                const float* zb = zbn ? zbn + (m * g.H1 + c) * g.L1 : nullptr;
                 for (int p = 0; p < g.L1; ++p) {
                     const int j = p + k - pad;
-                    if (j >= 0 && j < g.PS) acc = fmaf(dr[p], v[j], acc);
+                    if (j >= 0 && j < g.PS) acc = fmaf(zb ? bb.apply(dr[p], zb[p], c) : dr[p], v[j], acc);
                 }
             }
         }
@@ -1506,7 +1539,8 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float
         float acc = 0.f;
         for (int64_t mb = m0; mb < m1; mb += RB) {
             const int nr = (int)(m1 - mb < RB ? m1 - mb : RB);
-            for (int e = threadIdx.x; e < nr * CL; e += FB) sd[e] = dz[mb * CL + e];
+            for (int e = threadIdx.x; e < nr * CL; e += FB)
+                sd[e] = zbn ? bb.apply(dz[mb * CL + e], zbn[mb * CL + e], (e % CL) / L2) : dz[mb * CL + e];
             for (int e = threadIdx.x; e < nr * T1; e += FB) {
                 const int c = (e % T1) / L1;
                 sa[e] = fmaxf(fmaf(z1[mb * T1 + e], ca[c].sc, ca[c].sh), 0.f);
@@ -1984,20 +2018,17 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                (const float*)P_(w.a2), P_(w.da2));
         }
         FC_RC(sync_pair(1, 1));
-        hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, 1, g.L2, prm, (const Cells*)cells,
-                           (const float*)P_(w.z2), P_(w.da2), g.M * CL);
+        // (BatchNorm 1's and BatchNorm 0's channel-major backward passes ride in the loads of the kernels that consume them)
         // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain
         const int rows = (int)(g.M < w.rows ? g.M : w.rows);
         fork();
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.da2), P_(w.gp2));
+                           (const float*)P_(w.da2), P_(w.gp2), (const float*)P_(w.z2));
         hipLaunchKernelGGL(fc_conv2_dx_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.da2), P_(w.dy1));
+                           (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
         FC_RC(sync_pair(1, 0));
-        hipLaunchKernelGGL(fc_bn_chan_bwd_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, 0, g.L1, prm, (const Cells*)cells,
-                           (const float*)P_(w.z1), P_(w.dy1), g.M * g.H1 * g.L1);
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.dy1), P_(w.gp1));
+                           (const float*)P_(w.dy1), P_(w.gp1), (const float*)P_(w.z1));
         FC_RC(fk.join());                                    // the gradient GEMMs are done before the call's last kernel
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
