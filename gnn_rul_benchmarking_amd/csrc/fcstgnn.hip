@@ -1401,6 +1401,9 @@ __global__ __launch_bounds__(FB) void fc_act2_bwd_kernel(FcGeom g, const float* 
 
 // dy1[m][ci][q] = [a1 > 0] * sum_co sum_k w2[co][ci][k] * dz2[m][co][q + 1 - k]; BatchNorm-a backward sums  (row-group mapping, see fc_conv2_kernel)
 // (`z2` != nullptr: `dz2` is still d y2 -- the gradient in front of BatchNorm 1's backward, which is applied to every element as it is loaded)
+// <SK, SL1, SL2, SH1, SCO>: the wiring's convolution shape as compile-time constants (0 = generic): the index arithmetic of a row -- divisions
+// by L1 / L2, tap ranges, the CO x K product loop -- is most of this kernel's instructions at 2 x 3 x 4 x 8 x 6 (the reference's FD004 wiring)
+template <int SK, int SL1, int SL2, int SH1, int SCO>
 __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells,
                                                         const float* __restrict__ z1, const float* __restrict__ dz2,
                                                         float* __restrict__ dy1, const float* __restrict__ z2) {
@@ -1413,7 +1416,8 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
     for (int e = threadIdx.x; e < g.CO * g.H1 * g.K; e += FB) wl[e] = prm[g.o_w2 + e];
     BlockStats st;
     st.init(sl, g.H1);
-    const int H1 = g.H1, K = g.K, L1 = g.L1, L2 = g.L2, CL = g.CL, CO = g.CO, T1 = g.H1 * g.L1;
+    const int H1 = SH1 ? SH1 : g.H1, K = SK ? SK : g.K, L1 = SL1 ? SL1 : g.L1, L2 = SL2 ? SL2 : g.L2, CO = SCO ? SCO : g.CO;
+    const int CL = CO * L2, T1 = H1 * L1;
     auto one = [&](int64_t m, int pos) {
         const int ci = pos / L1, q = pos - ci * L1;
         const float zz = z1[m * T1 + pos];
@@ -1483,14 +1487,24 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
 // each workgroup reduces a contiguous chunk of rows; thread-owned outputs, one partial row per workgroup
 // (`zbn` != nullptr: `dz` is still the gradient in FRONT of the convolution's BatchNorm backward -- BatchNorm WHICH - 1, pre-activations
 // `zbn` = z2 | z1 --, applied to every element as it is loaded)
-template <int WHICH>
-__global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+// (<SK, SL1, SL2, SH1, SCO>: the convolution shape as compile-time constants, 0 = generic -- see fc_conv2_dx_kernel)
+template <int WHICH, int SK = 0, int SL1 = 0, int SL2 = 0, int SH1 = 0, int SCO = 0>
+__global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g_, const float* __restrict__ x, const float* __restrict__ prm,
                                                           const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
                                                           float* __restrict__ gpart, const float* __restrict__ zbn) {
+    // the shape fields this kernel reads, constants where the instantiation fixes them
+    struct Shape {
+        const FcGeom& f;
+        int K, L1, L2, H1, CO, CL;
+        int64_t M;
+        int N, NP, TL, PS;
+    };
+    const Shape g{g_, SK ? SK : g_.K, SL1 ? SL1 : g_.L1, SL2 ? SL2 : g_.L2, SH1 ? SH1 : g_.H1, SCO ? SCO : g_.CO,
+                  (SCO ? SCO : g_.CO) * (SL2 ? SL2 : g_.L2), g_.M, g_.N, g_.NP, g_.TL, g_.PS};
     __shared__ BnCoef ca[16];
     __shared__ BnBwdLds bb;
-    if (zbn) bb.init(g, cells, prm, WHICH - 1);
-    if (WHICH == 2 && threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 0, threadIdx.x);
+    if (zbn) bb.init(g_, cells, prm, WHICH - 1);
+    if (WHICH == 2 && threadIdx.x < g.H1) ca[threadIdx.x] = fbn(g_, cells, prm, nullptr, 1, 0, threadIdx.x);
     __syncthreads();
     const int nout = WHICH == 2 ? g.CO * g.H1 * g.K : g.H1 * g.K;
     const int64_t per = (g.M + gridDim.x - 1) / gridDim.x;
@@ -2022,11 +2036,24 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain
         const int rows = (int)(g.M < w.rows ? g.M : w.rows);
         fork();
+        const bool fd004_conv = g.K == 2 && g.L1 == 3 && g.L2 == 4 && g.H1 == 8 && g.CO == 6;     // the reference's C-MAPSS wiring: constants
+        if (fd004_conv)
+            hipLaunchKernelGGL((fc_conv_wgrad_kernel<2, 2, 3, 4, 8, 6>), dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.gp2), (const float*)P_(w.z2));
+        else
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
                            (const float*)P_(w.da2), P_(w.gp2), (const float*)P_(w.z2));
-        hipLaunchKernelGGL(fc_conv2_dx_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
+        if (g.K == 2 && g.L1 == 3 && g.L2 == 4 && g.H1 == 8 && g.CO == 6)
+            hipLaunchKernelGGL((fc_conv2_dx_kernel<2, 3, 4, 8, 6>), dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
+        else
+            hipLaunchKernelGGL((fc_conv2_dx_kernel<0, 0, 0, 0, 0>), dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
         FC_RC(sync_pair(1, 0));
+        if (fd004_conv)
+            hipLaunchKernelGGL((fc_conv_wgrad_kernel<1, 2, 3, 4, 8, 6>), dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.dy1), P_(w.gp1), (const float*)P_(w.z1));
+        else
         hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
                            (const float*)P_(w.dy1), P_(w.gp1), (const float*)P_(w.z1));
         FC_RC(fk.join());                                    // the gradient GEMMs are done before the call's last kernel
