@@ -217,23 +217,28 @@ __device__ inline float pos_enc(int t, int d, int D2) {     // PositionalEncodin
 // encoder
 // ---------------------------------------------------------------------------------------------------
 // z1[m][c][p] = sum_k w1[c][k] * v[m][p + k - K/2]   (Conv1d(1 -> H1, K, padding K/2), Model_Base.py:17-18)
+// (FD004: the reference's C-MAPSS wiring -- kernel 2, 3 output steps, 8 channels, 14 nodes x 25 patches of 2 points -- as compile-time
+// constants: the element index is decomposed by five divisions, which are most of this kernel's instructions)
+template <bool FD004>
 __global__ __launch_bounds__(FB) void fc_conv1_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                      float* __restrict__ z1, Cells* cells, int training) {
     __shared__ double sl[BS_DOUBLES];
     BlockStats st;
     st.init(sl, g.H1);
-    const int64_t total = g.M * g.H1 * g.L1;
-    const int pad = g.K / 2;
+    const int K = FD004 ? 2 : g.K, L1 = FD004 ? 3 : g.L1, H1 = FD004 ? 8 : g.H1, N = FD004 ? 14 : g.N, NP = FD004 ? 25 : g.NP,
+              PS = FD004 ? 2 : g.PS, TL = FD004 ? 50 : g.TL;
+    const int64_t total = g.M * H1 * L1;
+    const int pad = K / 2;
     for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
-        const int p = (int)(e % g.L1), c = (int)((e / g.L1) % g.H1);
-        const int64_t m = e / ((int64_t)g.L1 * g.H1);
-        const int node = (int)(m % g.N), t = (int)((m / g.N) % g.NP);
-        const int64_t b = m / ((int64_t)g.N * g.NP);
-        const float* v = x + (b * g.N + node) * g.TL + t * g.PS;
+        const int p = (int)(e % L1), c = (int)((e / L1) % H1);
+        const int64_t m = e / ((int64_t)L1 * H1);
+        const int node = (int)(m % N), t = (int)((m / N) % NP);
+        const int64_t b = m / ((int64_t)N * NP);
+        const float* v = x + (b * N + node) * TL + t * PS;
         float a = 0.f;
-        for (int k = 0; k < g.K; ++k) {
+        for (int k = 0; k < K; ++k) {
             const int j = p + k - pad;
-            if (j >= 0 && j < g.PS) a = fmaf(prm[g.o_w1 + c * g.K + k], v[j], a);
+            if (j >= 0 && j < PS) a = fmaf(prm[g.o_w1 + c * K + k], v[j], a);
         }
         z1[e] = a;
         if (training) st.add(c, a, a * a);
@@ -259,6 +264,7 @@ struct RowGroup {
 constexpr int FC_W2_MAX = 64 * 16 * 4;      // CO x H1 x K at the limits of fc_geometry
 
 // z2[m][co][p] = sum_ci sum_k w2[co][ci][k] * relu(bn_a(z1))[m][ci][p + k - 1]   (padding 1, Model_Base.py:27-28)
+template <int SK, int SL1, int SL2, int SH1, int SCO>
 __global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
                                                      const float* __restrict__ z1, float* __restrict__ z2, Cells* cells, int training) {
     __shared__ double sl[BS_DOUBLES];
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(FB) void fc_conv2_kernel(FcGeom g, const float* __r
     for (int e = threadIdx.x; e < g.CO * g.H1 * g.K; e += FB) wl[e] = prm[g.o_w2 + e];
     BlockStats st;
     st.init(sl, g.CO);                                                 // (ends in a barrier)
-    const int H1 = g.H1, K = g.K, L1 = g.L1, L2 = g.L2, CL = g.CL;
+    const int H1 = SH1 ? SH1 : g.H1, K = SK ? SK : g.K, L1 = SL1 ? SL1 : g.L1, L2 = SL2 ? SL2 : g.L2, CL = (SCO ? SCO : g.CO) * L2;
     auto one = [&](int64_t m, int cl) {
         const int co = cl / L2, p = cl - co * L2;
         const float* zr = z1 + m * H1 * L1;
@@ -1835,10 +1841,18 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
     if (mode & 1) {
         if (training && a->step_state) FC_RC(step_prepare_dropout(a->step_state, a->seed, 1, st));
         if (hipMemsetAsync(cells, 0, sizeof(Cells) * CELL_REP, st) != hipSuccess) return RULGNN_EHIP;
-        hipLaunchKernelGGL(fc_conv1_kernel, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
+        // (the reference's C-MAPSS wiring has its own instantiations: shapes as compile-time constants)
+        const bool fd004_conv = g.K == 2 && g.L1 == 3 && g.L2 == 4 && g.H1 == 8 && g.CO == 6;
+        const bool fd004_in = fd004_conv && g.N == 14 && g.NP == 25 && g.PS == 2 && g.TL == 50;
+        if (fd004_in) hipLaunchKernelGGL(fc_conv1_kernel<true>, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
+        else hipLaunchKernelGGL(fc_conv1_kernel<false>, dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, a->x, prm, P_(w.z1), cells, training);
         FC_RC(sync_pair(0, 0));
-        hipLaunchKernelGGL(fc_conv2_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2), cells,
-                           training);
+        if (fd004_conv)
+            hipLaunchKernelGGL((fc_conv2_kernel<2, 3, 4, 8, 6>), dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2),
+                               cells, training);
+        else
+            hipLaunchKernelGGL((fc_conv2_kernel<0, 0, 0, 0, 0>), dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, run, (const float*)P_(w.z1), P_(w.z2),
+                               cells, training);
         FC_RC(sync_pair(0, 1));
         if (proj_fused) {
             hipLaunchKernelGGL(fc_proj3_kernel, dim3(grid_for(g.M * CL)), dim3(FB), proj_lds, st, g, prm, run, cells, training,
