@@ -202,6 +202,18 @@ struct BlockStats {
 };
 
 __device__ inline float leaky(float v) { return v > 0.f ? v : LEAKY * v; }
+// Element loop of the streaming kernels with 32-BIT index arithmetic whenever the tensors are small enough (always, at the reference's
+// wirings): an element index is decomposed by two to five divisions, and a 64-bit division is ~100 instructions against ~25 -- half of
+// these kernels' time.  `body` is a generic lambda over the index type.
+template <typename Body>
+__device__ __forceinline__ void fc_walk(int64_t total, Body&& body) {
+    if (total <= (int64_t)1 << 29) {
+        const unsigned tot = (unsigned)total, step = gridDim.x * FB;
+        for (unsigned e = blockIdx.x * FB + threadIdx.x; e < tot; e += step) body(e);
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) body(e);
+    }
+}
 // multiplicity of patch t in the unfolded windows of block b (how many window graphs contain it)
 __device__ inline float mult(const FcGeom& g, int b, int t) {
     if (b == 0) return (g.W[0] > 1 && t > 0 && t < g.NP - 1) ? 2.f : 1.f;
@@ -422,13 +434,13 @@ __global__ __launch_bounds__(FB) void fc_pe_kernel(FcGeom g, const float* __rest
     s1.init(sl + BS_DOUBLES, g.D2);
     const uint32_t key = key_dev ? *key_dev : drop_key;
     const int64_t total = g.M * g.D2;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int d = (int)(e % g.D2);
-        const int64_t m = e / g.D2;
+        const auto m = e / g.D2;
         const int t = (int)((m / g.N) % g.NP);
         float y = fmaf(z3[e], cc[d].sc, cc[d].sh) + pos_enc(t, d, g.D2);
         if (training && drop_thr) {
-            const uint32_t ctr = (uint32_t)((m + row_offset) * g.D2 + d);
+            const uint32_t ctr = (uint32_t)(((int64_t)m + row_offset) * g.D2 + d);
             y = lowbias32(ctr ^ key) >= drop_thr ? y * drop_scale : 0.f;
         }
         F[e] = y;
@@ -437,7 +449,7 @@ __global__ __launch_bounds__(FB) void fc_pe_kernel(FcGeom g, const float* __rest
             s0.add(d, c0 * y, c0 * y * y);
             if (c1 != 0.f) s1.add(d, y, y * y);
         }
-    }
+    });
     if (training) {
         s0.flush(cells[blockIdx.x % CELL_REP].fwd[3], g.D2);
         s1.flush(cells[blockIdx.x % CELL_REP].fwd[5], g.D2);
@@ -645,14 +657,14 @@ __global__ __launch_bounds__(FB) void fc_pool_kernel(FcGeom g, int blk, const fl
     __syncthreads();
     const int HD = g.HD, N = g.N, W = g.W[blk];
     const int64_t total = g.G[blk] * N * HD;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int h = (int)(e % HD), node = (int)((e / HD) % N);
-        const int64_t gi = e / ((int64_t)HD * N), b = gi / W;
+        const auto gi = e / (HD * N), b = gi / W;
         const int w = (int)(gi - b * W);
         const float y0 = leaky(fmaf(z5[(gi * g.Q + node) * HD + h], ce[h].sc, ce[h].sh));
         const float y1 = leaky(fmaf(z5[(gi * g.Q + N + node) * HD + h], ce[h].sc, ce[h].sh));
         feat[b * g.FIN + g.foff[blk] + (w * N + node) * HD + h] = (y0 + y1) / 2.0f;
-    }
+    });
 }
 
 // z = relu(z + bias) in place, [rows][C]
@@ -788,16 +800,16 @@ __global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, cons
     st.init(sl, g.HD);
     const int HD = g.HD, N = g.N, Q = g.Q, W = g.W[blk];
     const int64_t total = g.G[blk] * Q * HD;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int h = (int)(e % HD), q = (int)((e / HD) % Q);
-        const int64_t gi = e / ((int64_t)HD * Q), b = gi / W;
+        const auto gi = e / (HD * Q), b = gi / W;
         const int w = (int)(gi - b * W), node = q >= N ? q - N : q;
         const float zz = z5[e];
         const float yv = fmaf(zz, ce[h].sc, ce[h].sh);
         const float dy = dfeat[b * g.FIN + g.foff[blk] + (w * N + node) * HD + h] * 0.5f * (yv > 0.f ? 1.f : LEAKY);
         dy5[e] = dy;
         st.add(h, dy, dy * (zz - ce[h].mean) * ce[h].inv);
-    }
+    });
     st.flush(cells[blockIdx.x % CELL_REP].bwd[id], HD);
 }
 
@@ -814,11 +826,11 @@ __global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id, co
     }
     __syncthreads();
     const int64_t total = rows * C;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int c = (int)(e % C);
         const float xh = (z[e] - cf[c].mean) * cf[c].inv;
         dy[e] = cf[c].sc * (dy[e] - s1[c] - xh * s2[c]);
-    }
+    });
 }
 
 // ... and as a transform in the LOAD of a consumer (round 4: the two channel-major passes over [M, C, L] were 16 + 17 us launches on the
@@ -1231,24 +1243,24 @@ __global__ __launch_bounds__(FB) void fc_graph_gather_kernel(FcGeom g, int blk, 
                                                             float* __restrict__ gX, float* __restrict__ gM) {
     const int64_t total = g.M * g.D2;
     const int S = g.S[blk], W = g.W[blk];
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int d = (int)(e % g.D2);
-        const int64_t r = e / g.D2;
+        const auto r = e / g.D2;
         const int n = (int)(r % g.N), t = (int)((r / g.N) % g.NP);
-        const int64_t b = r / ((int64_t)g.N * g.NP);
+        const auto b = r / (g.N * g.NP);
         float ax = 0.f, am = 0.f;
 #pragma unroll
         for (int tau = 0; tau < 2; ++tau) {
             const int tt = t - tau;
             if (tt >= 0 && tt % S == 0 && tt / S < W) {
-                const int64_t src = ((b * W + tt / S) * g.Q + tau * g.N + n) * g.D2 + d;
+                const auto src = ((b * W + tt / S) * g.Q + tau * g.N + n) * g.D2 + d;
                 ax += cX[src];
                 am += cM[src];
             }
         }
         gX[e] = ax;
         gM[e] = am;
-    }
+    });
 }
 
 // sums for the window BatchNorms' backward from the row-accumulated gradients gX_b:  sum g, sum g * xhat
@@ -1265,12 +1277,12 @@ __global__ __launch_bounds__(FB) void fc_feat_stats_kernel(FcGeom g, const float
     s0.init(sl, g.D2);
     s1.init(sl + BS_DOUBLES, g.D2);
     const int64_t total = g.M * g.D2;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) {
+    fc_walk(total, [&](auto e) {
         const int d = (int)(e % g.D2);
         const float f = F[e], a = gX0[e], b = gX1[e];
         s0.add(d, a, a * (f - c0[d].mean) * c0[d].inv);
         s1.add(d, b, b * (f - c1[d].mean) * c1[d].inv);
-    }
+    });
     s0.flush(cells[blockIdx.x % CELL_REP].bwd[3], g.D2);
     s1.flush(cells[blockIdx.x % CELL_REP].bwd[5], g.D2);
 }
@@ -1933,6 +1945,9 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // (one fork for everything that is ready when the backward starts: with an incoming gradient the MLP's d h first)
         if (mlp_fused && a->dpred) mlp_tail(2, nullptr, a->dpred);
         fork();
+        // (the host enqueues in program order: the MAIN stream's next kernel goes out before the dozen side-stream launches behind this fork
+        // -- with the side launches first the main queue sat empty for ~30 us while the host enqueued them; same at every fork below)
+        if (mlp_fused) FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, wst, one);
         if ((mode & 1) && training && a->bn_batch) {
             hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, wst, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
@@ -1976,7 +1991,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, wst));
         FC_RC(colsum(P_(w.dh1), g.B, D2, gr + g.o_f1b));
         }
-        FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
+        if (!mlp_fused) FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         // ---- graph blocks ----
         for (int b = 0; b < 2; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
@@ -1987,8 +2002,6 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
                                (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
             fork();
-            // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum)
-            FC_RC(sgemm_splitk_colsum(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, gr + g.o_thb[b], one, split, wst));
             const bool bwd_fused = graph_mx && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
             if (!bwd_fused) FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
@@ -2019,23 +2032,25 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             }
             hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
                                (const float*)P_(w.dMb[b]), P_(w.gX[b]), P_(w.gM[b]));
+            // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum; enqueued behind the main
+            // stream's graph kernels, which it runs beside)
+            FC_RC(sgemm_splitk_colsum(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, gr + g.o_thb[b], one, split, wst));
         }
         fork();
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
         FC_RC(sync_pair(1, 3));
         FC_RC(sync_pair(1, 5));
-        for (int b = 0; b < 2; ++b)
-            FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
         // window BatchNorms' backward + both d M W_map products + positional encoding / dropout backward: one launch
         hipLaunchKernelGGL(fc_feat_pe_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), (const float*)P_(w.gM[0]), (const float*)P_(w.gM[1]),
                            (const float*)P_(w.z3), P_(w.dF), thr, dscale, key, key_dev, row_off);
+        for (int b = 0; b < 2; ++b)
+            FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            (const float*)P_(w.z3), P_(w.dF), g.M);
         fork();
-        FC_RC(sgemm_splitk_colsum(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3, one, split, wst));
         // ---- encoder convolutions ----
         if (proj_fused) {
             hipLaunchKernelGGL(fc_proj3_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), proj_lds, st, g, prm, cells, (const float*)P_(w.z2),
@@ -2045,6 +2060,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
                                (const float*)P_(w.a2), P_(w.da2));
         }
+        FC_RC(sgemm_splitk_colsum(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3, one, split, wst));
         FC_RC(sync_pair(1, 1));
         // (BatchNorm 1's and BatchNorm 0's channel-major backward passes ride in the loads of the kernels that consume them)
         // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain
