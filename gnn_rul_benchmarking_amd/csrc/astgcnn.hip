@@ -656,26 +656,27 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         // (with a forward in the same call ast_prepare_kernel wrote it; batch statistics and the loss sum ride in the finalize kernel)
         if (!(mode & 1)) hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
         fk.fork();
+        // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
+        const int bwd_rows = resident_rows(ast_graph_bwd_kernel, g.B, AST_BWD_ROWS);
+        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(bwd_rows), dim3(AB), 0, st, g, prm,
+                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
+                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
+        // (the side stream's launches are enqueued BEHIND the main stream's kernel they run beside: the host enqueues in program order)
         // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
         AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
         if (cols_sum_small_ok(g.B, 1)) AST_RC(cols_sum_small(F(w.dpred), (int)g.B, 1, gr + g.o_fcb, wst));
         else AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
-        // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
-        const int bwd_rows = resident_rows(ast_graph_bwd_kernel, g.B, AST_BWD_ROWS);
-        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(bwd_rows), dim3(AB), 0, st, g, prm,
-                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
-                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
         // d P = dPX^T G
         fk.fork();
-        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
         AST_RC(sync_pair(1, 1));
-        // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
-        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
+        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
+        // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
+        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
