@@ -1124,13 +1124,36 @@ static bool mx_backward_ok(const MsgGeom& g, size_t* lds_bytes) {
 
 // (one workgroup per CU: the accumulator half of the unified register file then takes the spills instead of scratch memory, 3.21 -> 3.04 ms
 // per step; requesting the next layer's tiles a layer ahead needs 96 more live registers and is 1.7 x SLOWER: 865 accvgpr moves per layer)
+// XJ: the reference's XJTU-SY wiring (gcn_dims 16-64-16-1 on 25-node graphs) with its layer shapes as compile-time constants: the layer loop
+// unrolls, block counts and column offsets fold, the guards around the matrix instructions of absent feature blocks disappear
+struct MsgXJ {
+    static constexpr int L = 4, n = 25, C = 98, gcn_params = 2177;
+    __host__ __device__ static constexpr int dim(int l) { return l == 0 ? 1 : l == 1 ? 16 : l == 2 ? 64 : l == 3 ? 16 : 1; }
+    __host__ __device__ static constexpr int coff(int l) { return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 17 : l == 3 ? 81 : l == 4 ? 97 : 98; }
+    __host__ __device__ static constexpr int woff(int l) { return l == 0 ? 0 : l == 1 ? 32 : l == 2 ? 1120 : 2160; }
+    __host__ __device__ static constexpr int boff(int l) { return l == 0 ? 16 : l == 1 ? 1056 : l == 2 ? 2144 : 2176; }
+    static bool matches(const MsgGeom& g) {
+        if (g.L != L || g.n != n || g.C != C || g.gcn_params != gcn_params) return false;
+        for (int l = 0; l <= L; ++l)
+            if (g.dims[l] != dim(l) || g.coff[l] != coff(l)) return false;
+        for (int l = 0; l < L; ++l)
+            if (g.woff[l] != woff(l) || g.boff[l] != boff(l)) return false;
+        return true;
+    }
+};
+template <bool XJ>
 __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeom g, const float* __restrict__ cat_in,
                                                                         const float* __restrict__ dcat_in, const float* __restrict__ prm,
                                                                         float* __restrict__ gpart) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MxBwdLds L_;
     mx_bwd_lds_layout(g, &L_);
-    const int n = g.n, C = g.C;
+    const int n = XJ ? MsgXJ::n : g.n, C = XJ ? MsgXJ::C : g.C;
+    const int NL = XJ ? MsgXJ::L : g.L;
+    auto gdim = [&](int l) { return XJ ? MsgXJ::dim(l) : g.dims[l]; };
+    auto gcoff = [&](int l) { return XJ ? MsgXJ::coff(l) : g.coff[l]; };
+    auto gwoff = [&](int l) { return XJ ? MsgXJ::woff(l) : g.woff[l]; };
+    auto gboff = [&](int l) { return XJ ? MsgXJ::boff(l) : g.boff[l]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     for (int l = 1; l < g.L; ++l) {                // d AX = dz W: lane (hh, k) of register m: W[o = f(m, hh)][32 ib + k]
         const int fi = g.dims[l], fo = g.dims[l + 1], nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
@@ -1182,13 +1205,14 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
 #pragma unroll
             for (int r = 0; r < 16; ++r) dxF[b][r] = 0.f;
 
-        for (int l = g.L - 1; l >= 0; --l) {
-            const int fi = g.dims[l], fo = g.dims[l + 1], off = g.coff[l], offo = g.coff[l + 1];
+#pragma unroll
+        for (int l = NL - 1; l >= 0; --l) {
+            const int fi = gdim(l), fo = gdim(l + 1), off = gcoff(l), offo = gcoff(l + 1);
             const int nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
             // dz (FL) = (d cat slice + d x from above) * leaky'(out)
             float dzF[2][16];
             {
-                if (l == g.L - 1) load_fl(cg, offo, fo, outF);        // (below the top layer: the X of the layer above, already here)
+                if (l == NL - 1) load_fl(cg, offo, fo, outF);        // (below the top layer: the X of the layer above, already here)
                 load_fl(dg, offo, fo, dzF);
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
@@ -1250,7 +1274,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int o = 32 * ob + krow(r, 0) + 4 * h, k = 32 * ib + j;
-                                if (o < fo && k < fi) acc[g.woff[l] + o * fi + k] += dw[r];
+                                if (o < fo && k < fi) acc[gwoff(l) + o * fi + k] += dw[r];
                             }
                         }
                     }
@@ -1263,7 +1287,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sb += dzF[ob][r];
                     sb += __shfl_xor(sb, 32, 64);
-                    if (h == 0 && 32 * ob + j < fo) acc[g.boff[l] + 32 * ob + j] += sb;
+                    if (h == 0 && 32 * ob + j < fo) acc[gboff(l) + 32 * ob + j] += sb;
                 }
             }
             if (l == 0) break;                               // the SED features carry no gradient
@@ -1725,24 +1749,27 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
         size_t lds_mx = 0;
         int rcb;
         if (mx_backward_ok(g, &lds_mx)) {                  // graphs of >= 12 nodes: one wavefront per graph on the fp32 matrix cores
-            if (lds_mx > 48 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(msg_gcn_backward_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_mx) != hipSuccess)
-                return RULGNN_EHIP;
-            int dev = 0, cus = 256, per_cu = 0;
-            if (hipGetDevice(&dev) == hipSuccess) {
-                int v = 0;
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-            }
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msg_gcn_backward_mx_kernel, 64 * MXW, lds_mx) != hipSuccess || per_cu < 1)
-                per_cu = 1;
-            int64_t grid = (int64_t)cus * per_cu;
-            const int64_t need = (g.G + MXW - 1) / MXW;
-            if (grid > need) grid = need;
-            if (grid > w.rows_gcn_max) grid = w.rows_gcn_max;
-            rows = (int)grid;
-            hipLaunchKernelGGL(msg_gcn_backward_mx_kernel, dim3((unsigned)grid), dim3(64 * MXW), lds_mx, st, g, (const float*)(ws + w.cat),
-                               (const float*)(ws + w.dcat), a->params, (float*)(ws + w.gpart_gcn));
+            auto launch_mx = [&](auto kern) -> int {
+                if (lds_mx > 48 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mx) != hipSuccess)
+                    return RULGNN_EHIP;
+                int dev = 0, cus = 256, per_cu = 0;
+                if (hipGetDevice(&dev) == hipSuccess) {
+                    int v = 0;
+                    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+                }
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * MXW, lds_mx) != hipSuccess || per_cu < 1) per_cu = 1;
+                int64_t grid = (int64_t)cus * per_cu;
+                const int64_t need = (g.G + MXW - 1) / MXW;
+                if (grid > need) grid = need;
+                if (grid > w.rows_gcn_max) grid = w.rows_gcn_max;
+                rows = (int)grid;
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXW), lds_mx, st, g, (const float*)(ws + w.cat),
+                                   (const float*)(ws + w.dcat), a->params, (float*)(ws + w.gpart_gcn));
+                return RULGNN_OK;
+            };
+            const int rl = MsgXJ::matches(g) ? launch_mx(&msg_gcn_backward_mx_kernel<true>) : launch_mx(&msg_gcn_backward_mx_kernel<false>);
+            if (rl != RULGNN_OK) return rl;
             rcb = hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
         } else
         rcb = g.n >= 12 ? launch_gcn_backward<4>(g, w.rows_gcn_max, (const float*)(ws + w.cat), (const float*)(ws + w.dcat), a->params,
