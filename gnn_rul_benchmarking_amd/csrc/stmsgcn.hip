@@ -388,12 +388,33 @@ __device__ __forceinline__ void row_values(const float* vec, int h, float (&out)
     }
 }
 
+// XJ: the reference's XJTU-SY wiring (gcn_dims 16-64-16-1 on 25-node graphs) with its layer shapes as compile-time constants: the layer loop
+// unrolls, block counts and column offsets fold, the guards around the matrix instructions of absent feature blocks disappear
+struct MsgXJ {
+    static constexpr int L = 4, n = 25, C = 98, gcn_params = 2177;
+    __host__ __device__ static constexpr int dim(int l) { return l == 0 ? 1 : l == 1 ? 16 : l == 2 ? 64 : l == 3 ? 16 : 1; }
+    __host__ __device__ static constexpr int coff(int l) { return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 17 : l == 3 ? 81 : l == 4 ? 97 : 98; }
+    __host__ __device__ static constexpr int woff(int l) { return l == 0 ? 0 : l == 1 ? 32 : l == 2 ? 1120 : 2160; }
+    __host__ __device__ static constexpr int boff(int l) { return l == 0 ? 16 : l == 1 ? 1056 : l == 2 ? 2144 : 2176; }
+    static bool matches(const MsgGeom& g) {
+        if (g.L != L || g.n != n || g.C != C || g.gcn_params != gcn_params) return false;
+        for (int l = 0; l <= L; ++l)
+            if (g.dims[l] != dim(l) || g.coff[l] != coff(l)) return false;
+        for (int l = 0; l < L; ++l)
+            if (g.woff[l] != woff(l) || g.boff[l] != boff(l)) return false;
+        return true;
+    }
+};
+template <bool XJ>
 __global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                                     float* __restrict__ cat_out, float* __restrict__ gi_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MxLds L_;
     mx_lds_layout(g, &L_);
-    const int n = g.n, P = g.P, C = g.C, H3 = g.H3;
+    const int n = XJ ? MsgXJ::n : g.n, P = g.P, C = XJ ? MsgXJ::C : g.C, H3 = g.H3;
+    const int NL = XJ ? MsgXJ::L : g.L;
+    auto gdim = [&](int l) { return XJ ? MsgXJ::dim(l) : g.dims[l]; };
+    auto gcoff = [&](int l) { return XJ ? MsgXJ::coff(l) : g.coff[l]; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, j = lane & 31;
     float* tw = smem + L_.tw;
 
@@ -499,8 +520,9 @@ __global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g,
         Xn[0] = h == 0 ? x0 : 0.f;                             // NL form of the one input feature (f(0, 0) = 0, f(0, 1) = 4)
         f32x16 giacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         giacc = mfma32(Xn[0], smem[L_.wih[0] + lane], giacc);
-        for (int l = 0; l < g.L; ++l) {
-            const int fi = g.dims[l], fo = g.dims[l + 1], nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int fi = gdim(l), fo = gdim(l + 1), nbi = (fi + 31) / 32, nbo = (fo + 31) / 32;
             // A' = X X^T + I
             f32x16 G = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -568,7 +590,7 @@ __global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g,
                     const float bF = bl[32 * ob + j];
                     float bN[16];
                     row_values(bl + 32 * ob, h, bN);
-                    float* dst = cat_out ? cat_out + gi * (int64_t)(n * C) + g.coff[l + 1] + 32 * ob + j : nullptr;
+                    float* dst = cat_out ? cat_out + gi * (int64_t)(n * C) + gcoff(l + 1) + 32 * ob + j : nullptr;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int node = krow(r, 0) + 4 * h;
@@ -1124,23 +1146,6 @@ static bool mx_backward_ok(const MsgGeom& g, size_t* lds_bytes) {
 
 // (one workgroup per CU: the accumulator half of the unified register file then takes the spills instead of scratch memory, 3.21 -> 3.04 ms
 // per step; requesting the next layer's tiles a layer ahead needs 96 more live registers and is 1.7 x SLOWER: 865 accvgpr moves per layer)
-// XJ: the reference's XJTU-SY wiring (gcn_dims 16-64-16-1 on 25-node graphs) with its layer shapes as compile-time constants: the layer loop
-// unrolls, block counts and column offsets fold, the guards around the matrix instructions of absent feature blocks disappear
-struct MsgXJ {
-    static constexpr int L = 4, n = 25, C = 98, gcn_params = 2177;
-    __host__ __device__ static constexpr int dim(int l) { return l == 0 ? 1 : l == 1 ? 16 : l == 2 ? 64 : l == 3 ? 16 : 1; }
-    __host__ __device__ static constexpr int coff(int l) { return l == 0 ? 0 : l == 1 ? 1 : l == 2 ? 17 : l == 3 ? 81 : l == 4 ? 97 : 98; }
-    __host__ __device__ static constexpr int woff(int l) { return l == 0 ? 0 : l == 1 ? 32 : l == 2 ? 1120 : 2160; }
-    __host__ __device__ static constexpr int boff(int l) { return l == 0 ? 16 : l == 1 ? 1056 : l == 2 ? 2144 : 2176; }
-    static bool matches(const MsgGeom& g) {
-        if (g.L != L || g.n != n || g.C != C || g.gcn_params != gcn_params) return false;
-        for (int l = 0; l <= L; ++l)
-            if (g.dims[l] != dim(l) || g.coff[l] != coff(l)) return false;
-        for (int l = 0; l < L; ++l)
-            if (g.woff[l] != woff(l) || g.boff[l] != boff(l)) return false;
-        return true;
-    }
-};
 template <bool XJ>
 __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeom g, const float* __restrict__ cat_in,
                                                                         const float* __restrict__ dcat_in, const float* __restrict__ prm,
@@ -1612,22 +1617,23 @@ static int launch_features_tw(const MsgGeom& g, const float* x, const float* prm
 static int launch_features(const MsgGeom& g, const float* x, const float* prm, float* cat, float* gi, hipStream_t st) {
     size_t lds = 0;
     if (mx_features_ok(g, &lds)) {                  // graphs of >= 12 nodes: one wavefront per graph on the fp32 matrix cores
-        if (lds > 48 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(msg_features_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return RULGNN_EHIP;
-        int dev = 0, cus = 256, per_cu = 0;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int v = 0;
-            if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msg_features_mx_kernel, 64 * MXW, lds) != hipSuccess || per_cu < 1)
-            per_cu = 1;
-        int64_t grid = (int64_t)cus * per_cu;
-        const int64_t need = (g.G + MXW - 1) / MXW;
-        if (grid > need) grid = need;
-        hipLaunchKernelGGL(msg_features_mx_kernel, dim3((unsigned)grid), dim3(64 * MXW), lds, st, g, x, prm, cat, gi);
-        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+        auto go = [&](auto kern) -> int {
+            if (lds > 48 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return RULGNN_EHIP;
+            int dev = 0, cus = 256, per_cu = 0;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int v = 0;
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+            }
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64 * MXW, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            int64_t grid = (int64_t)cus * per_cu;
+            const int64_t need = (g.G + MXW - 1) / MXW;
+            if (grid > need) grid = need;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXW), lds, st, g, x, prm, cat, gi);
+            return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+        };
+        return MsgXJ::matches(g) ? go(&msg_features_mx_kernel<true>) : go(&msg_features_mx_kernel<false>);   // (the XJTU-SY layer shapes as constants)
     }
     return g.n >= 12 ? launch_features_tw<4>(g, x, prm, cat, gi, st) : launch_features_tw<1>(g, x, prm, cat, gi, st);
 }
