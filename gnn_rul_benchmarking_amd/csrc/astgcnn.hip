@@ -75,6 +75,8 @@ constexpr int TP = MAXT + 4;
 __device__ __forceinline__ void fma4(float (&acc)[4], float a, const float4& b) {
     acc[0] = fmaf(a, b.x, acc[0]); acc[1] = fmaf(a, b.y, acc[1]); acc[2] = fmaf(a, b.z, acc[2]); acc[3] = fmaf(a, b.w, acc[3]);
 }
+// (<SN, SE, SO>: nodes, time steps / features (E == T) and output width as compile-time constants, 0 = generic)
+template <int SN, int SE, int SO>
 __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                       const float* __restrict__ bn_running, int training, const Cells* cells,
                                                       const float* __restrict__ z2, const float* __restrict__ out0,
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
     __shared__ float SC[3 * MAXT];
     __shared__ float gbias[MAXT];
     __shared__ BnCoef co2[MAXN];
-    const int N = g.N, T = g.T, E = g.E, KE = g.KE, O = g.O, tid = threadIdx.x;
+    const int N = SN ? SN : g.N, T = SE ? SE : g.T, E = SE ? SE : g.E, KE = g.K * E, O = SO ? SO : g.O, tid = threadIdx.x;
     const int Q = (E + 3) / 4;                    // column quads (E == T)
     for (int e = tid; e < MAXT * TP; e += AB) { (&THt[0][0])[e] = 0.f; (&PWt[0][0])[e] = 0.f; }
     for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&G[0][0])[e] = 0.f; (&T1[0][0])[e] = 0.f; }
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(AB) void ast_head_kernel(AstGeom g, const float* __
 // Round 4: the two GEMM launches around it live here -- DT = D Fcat^T (one row of K E values per sample) in front, and behind it the
 // projection's share of the gate gradient, dG = dG_cheb + dPX P, from the dPX tile in LDS.
 // ---------------------------------------------------------------------------------------------------
+template <int SN, int SE, int SO>
 __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const float* __restrict__ prm, const float* __restrict__ px,
                                                           const float* __restrict__ tcat, const float* __restrict__ adj,
                                                           const float* __restrict__ distm, const float* __restrict__ dmat,
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
     __shared__ float Cf[MAXN][MAXN + 1];
     __shared__ float d0[MAXT], d1[MAXT], d2v[MAXT];
     __shared__ float u[MAXN], v[MAXN], w[MAXN], cs[MAXN], acs[MAXN];
-    const int N = g.N, E = g.E, KE = g.KE, O = g.O, tid = threadIdx.x;
+    const int N = SN ? SN : g.N, E = SE ? SE : g.E, KE = g.K * E, O = SO ? SO : g.O, tid = threadIdx.x;
     const int Q = (E + 3) / 4;
     for (int e = tid; e < MAXT * TP; e += AB) (&PW[0][0])[e] = 0.f;
     for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&DPX[0][0])[e] = 0.f; }
@@ -595,8 +598,11 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
     } while (0)
 
 // mode bit 0: forward (training != 0: batch statistics), bit 1: backward
-int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync, float* bn_running_out,
-                float bn_momentum) {
+// <SN, SE, SO>: the kernels' instantiation -- the reference's two wirings (N-CMAPSS: 20 nodes, C-MAPSS: 14; 50 steps, 64 outputs) have their
+// shapes as compile-time constants, anything else runs the generic <0, 0, 0>
+template <int SN, int SE, int SO>
+static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync,
+                         float* bn_running_out, float bn_momentum) {
     AstGeom g;
     AST_RC(ast_geometry(s, &g));
     if (sync) {          // both BatchNorm layers normalise by the statistics of the GLOBAL batch (cells all-reduced between the kernels)
@@ -624,15 +630,15 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
     };
     if (mode & 1) {
         hipLaunchKernelGGL(ast_prepare_kernel, dim3(1), dim3(1024), 0, st, cells, F(w.one));
-        const int rows = resident_rows((tcn_conv_kernel<1, AstGeom>), g.B, 1 << 20);
-        hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
+        const int rows = resident_rows((tcn_conv_kernel<1, AstGeom, SN, SE>), g.B, 1 << 20);
+        hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
                            F(w.z1), (float*)nullptr, cells);
         AST_RC(sync_pair(0, 0));
-        hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
+        hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
         // gate, P projection, graph, Chebyshev terms, node sums, the filter product and the head: one launch (ast_front_kernel)
-        hipLaunchKernelGGL(ast_front_kernel, dim3(resident_rows(ast_front_kernel, g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
+        hipLaunchKernelGGL((ast_front_kernel<SN, SE, SO>), dim3(resident_rows((ast_front_kernel<SN, SE, SO>), g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
                            (const Cells*)cells, (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat), F(w.px), F(w.adj),
                            F(w.dist), F(w.scat), F(w.pooled), a->y, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb);
         if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
@@ -657,8 +663,8 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         if (!(mode & 1)) hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
         fk.fork();
         // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
-        const int bwd_rows = resident_rows(ast_graph_bwd_kernel, g.B, AST_BWD_ROWS);
-        hipLaunchKernelGGL(ast_graph_bwd_kernel, dim3(bwd_rows), dim3(AB), 0, st, g, prm,
+        const int bwd_rows = resident_rows((ast_graph_bwd_kernel<SN, SE, SO>), g.B, AST_BWD_ROWS);
+        hipLaunchKernelGGL((ast_graph_bwd_kernel<SN, SE, SO>), dim3(bwd_rows), dim3(AB), 0, st, g, prm,
                            (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
                            F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
         // (the side stream's launches are enqueued BEHIND the main stream's kernel they run beside: the host enqueues in program order)
@@ -670,15 +676,15 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         // d P = dPX^T G
         fk.fork();
-        const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom>), g.B, w.rows);
+        const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom, SN, SE>), g.B, w.rows);
         AST_RC(sync_pair(1, 1));
-        hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
+        hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
         AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         AST_RC(sync_pair(1, 0));
-        hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
+        hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
         // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)
@@ -691,6 +697,15 @@ int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int
                            ((mode & 1) && training && a->bn_batch && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr, bn_momentum);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync, float* bn_running_out,
+                float bn_momentum) {
+    if (s && s->time_length == 50 && s->output_dim == 64) {
+        if (s->num_nodes == 20) return astgcnn_run_t<20, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum);
+        if (s->num_nodes == 14) return astgcnn_run_t<14, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum);
+    }
+    return astgcnn_run_t<0, 0, 0>(s, a, mode, st, sync, bn_running_out, bn_momentum);
 }
 
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,

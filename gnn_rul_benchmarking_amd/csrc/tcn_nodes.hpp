@@ -63,7 +63,8 @@ __device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, in
 // TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
 // One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
 // ---------------------------------------------------------------------------------------------------
-template <int STAGE, typename Geom>
+// (<SN, ST>: nodes and time steps as compile-time constants, 0 = generic: the element loops divide by T, the channel loops run to N)
+template <int STAGE, typename Geom, int SN = 0, int ST = 0>
 static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                      const float* __restrict__ bn_running, int training, const float* __restrict__ z1,
                                                      float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
@@ -74,7 +75,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
     __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];           // left-padded with PADL zeros
     __shared__ float zs[MAXN][MAXT + 1];
     __shared__ BnCoef co1[MAXN];
-    const int N = g.N, T = g.T, tid = threadIdx.x;
+    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x;
     const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
     for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
     for (int e = tid; e < MAXN * XP; e += AB) (&xs[0][0])[e] = 0.f;
@@ -146,7 +147,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
 // dy1 = ds0 [bn1(z1) > 0]; BN1 backward sums.   STAGE 1: dz1 = BN1'(dy1); dW1 += dz1 (*) x.
 // Weight-gradient accumulators are thread-owned registers (fixed order), one partial row per workgroup.
 // ---------------------------------------------------------------------------------------------------
-template <int STAGE, typename Geom>
+template <int STAGE, typename Geom, int SN = 0, int ST = 0>
 static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
                                                          const float* __restrict__ zin, const float* __restrict__ dyin,
                                                          const float* __restrict__ src, const float* __restrict__ ds1,
@@ -163,7 +164,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     __shared__ float sx[MAXN][MAXT + 1];
     __shared__ BnCoef cz[MAXN], c1[MAXN];
     __shared__ float bsum[MAXN][2];
-    const int N = g.N, T = g.T, tid = threadIdx.x, blk = STAGE - 1;
+    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x, blk = STAGE - 1;
     const double count = (double)g.BG * T;
     const int nW = N * N * KT;
     if (STAGE == 2)
