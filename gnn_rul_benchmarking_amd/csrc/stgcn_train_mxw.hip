@@ -279,11 +279,13 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 // =====================================================================================================================
 // the phase kernel (everything but F_0)
 // =====================================================================================================================
-template <int L, int KIND, int IDX, int NT>
+// NFIX: num_patch as a compile-time constant (40 = PHM2012's wiring; 0 = generic): record strides, LDS offsets and the byte counts of the
+// LDS-DMA requests (dma_tile_fixed: one M0 write per 4 KB instead of one per piece) fold
+template <int L, int KIND, int IDX, int NT, int NFIX>
 __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_mxw_kernel(MxTrainK a) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     constexpr int W = 16 * NT;
-    const int N = a.N;
+    const int N = NFIX ? NFIX : a.N;
     const int LS = layer_stride(N);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, col = lane & 15;
@@ -338,7 +340,14 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     int64_t smp = (int64_t)blockIdx.x * MXT_WAVES + wave;
     const int64_t stride = (int64_t)gridDim.x * MXT_WAVES;
 
-    auto dma = [&](const float* src, int off, int floats) { dma_tile(src, smem + off, floats * 4, lane); };
+    auto dma = [&](const float* src, int off, int floats) {
+        if constexpr (NFIX != 0) {
+            if (floats == mxw_xstride(NFIX)) { dma_tile_fixed<4 * mxw_xstride(NFIX)>(src, smem + off, lane); return; }
+            if (floats == mxw_dstride(NFIX)) { dma_tile_fixed<4 * mxw_dstride(NFIX)>(src, smem + off, lane); return; }
+        }
+        if (floats == MXW_ASTRIDE) { dma_tile_fixed<4 * MXW_ASTRIDE>(src, smem + off, lane); return; }
+        dma_tile(src, smem + off, floats * 4, lane);
+    };
     auto req_XA = [&](int64_t s) {
         dma(a.xrec[LIN] + s * XS, off_X, XS);
         dma(a.arec + s * MXW_ASTRIDE, off_A, MXW_ASTRIDE);
@@ -1287,15 +1296,20 @@ static int mxtw_grid(K kern, size_t lds, int64_t B, int max_grid, int* grid_out)
 
 template <int L, int KIND, int IDX, int NT>
 static int mxtw_launch(const MxTrainK& k, hipStream_t stream, int max_grid, int* grid_out) {
-    auto kern = &stgcn_train_mxw_kernel<L, KIND, IDX, NT>;
     const size_t lds = mxtw_lds_bytes(L, KIND, IDX, k.N, NT);
-    int grid = 0;
-    const int rc = mxtw_grid(kern, lds, k.B, max_grid, &grid);
-    if (rc != RULGNN_OK) return rc;
-    if (grid_out) *grid_out = grid;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXT_WAVES), lds, stream, k);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    auto go = [&](auto kern) -> int {
+        int grid = 0;
+        const int rc = mxtw_grid(kern, lds, k.B, max_grid, &grid);
+        if (rc != RULGNN_OK) return rc;
+        if (grid_out) *grid_out = grid;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXT_WAVES), lds, stream, k);
+        return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    };
+    if constexpr (NT == 3) {
+        if (k.N == 40) return go(&stgcn_train_mxw_kernel<L, KIND, IDX, NT, 40>);          // PHM2012's wiring
+    }
+    return go(&stgcn_train_mxw_kernel<L, KIND, IDX, NT, 0>);
 }
 
 template <int L, int NT, int I>
