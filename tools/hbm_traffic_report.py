@@ -13,7 +13,7 @@ def collect(sub, counter):
                 continue
             m = re.search(r"stgcn_train_phase_kernel<(\d+), (\d), (\d), (\d)(?:, \d+)*>", r["Kernel_Name"])
             mx = re.search(r"stgcn_train_mx_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])      # matrix-core chain (round 4): <L, KIND, IDX, NFIX>
-            mxw = re.search(r"stgcn_train_mxw_kernel<(\d+), (\d), (\d), (\d+)>", r["Kernel_Name"])    # its wide form: <L, KIND, IDX, NT>
+            mxw = re.search(r"stgcn_train_mxw_kernel<(\d+), (\d), (\d), (\d+)(?:, \d+)?>", r["Kernel_Name"])    # its wide form: <L, KIND, IDX, NT>
             wide = int(os.environ.get("NP", 14)) >= 16                  # which chain this report is about (the default bench also runs 40 x 64 lines)
             if (mxw or "stgcn_train_f0_mxw_kernel" in r["Kernel_Name"]) and not wide:
                 continue
