@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(MB) void msg_gcn_backward_kernel(MsgGeom g, const f
 //   d x = A^ d AX + M X                                A = A^ / M (symmetric), B = d AX / X (FL)               -> FL, added to the d cat
 //                                                      slice of the layer below when that layer loads it
 struct MxBwdLds {
-    int wt[MAXL], acc, wave, total;      // W^T operand tables (layers >= 1), per-wavefront gradient accumulators, per-wavefront scratch
+    int wt[MAXL], acc, wave, tr, total;  // W^T operand tables (layers >= 1), per-wavefront gradient accumulators, per-wavefront scratch
 };
 __host__ __device__ inline void mx_bwd_lds_layout(const MsgGeom& g, MxBwdLds* o) {
     int p = 0;
@@ -1134,6 +1134,7 @@ __host__ __device__ inline void mx_bwd_lds_layout(const MsgGeom& g, MxBwdLds* o)
     }
     o->acc = p; p += MXW * g.gcn_params;
     o->wave = p; p += MXW * 64;
+    o->tr = p; p += MXW * 32 * 33;                   // per-wavefront transpose tile (FL -> NL form of a 32 x 32 block)
     o->total = p;
 }
 static bool mx_backward_ok(const MsgGeom& g, size_t* lds_bytes) {
@@ -1141,7 +1142,7 @@ static bool mx_backward_ok(const MsgGeom& g, size_t* lds_bytes) {
     MxBwdLds o;
     mx_bwd_lds_layout(g, &o);
     *lds_bytes = sizeof(float) * (size_t)o.total;
-    return *lds_bytes <= 64 * 1024;
+    return *lds_bytes <= 96 * 1024;
 }
 
 // (one workgroup per CU: the accumulator half of the unified register file then takes the spills instead of scratch memory, 3.21 -> 3.04 ms
@@ -1172,8 +1173,19 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
     __syncthreads();
     float* acc = smem + L_.acc + wave * g.gcn_params;      // this wavefront's gradient accumulator
     float* rowv = smem + L_.wave + wave * 64;
+    float* trt = smem + L_.tr + wave * (32 * 33);            // [node][33]: the FL -> NL form of a block goes through LDS (16 writes + 16
+    // reads of a wavefront-private tile, in order: no barrier) instead of 16 matrix instructions against the identity (1024 cycles a block,
+    // nine blocks a graph at the XJTU-SY shapes)
+    auto fl_to_nl = [&](const float (&FL)[16], float* NLdst) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) trt[(krow(r, 0) + 4 * h) * 33 + j] = FL[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) NLdst[m] = trt[j * 33 + krow(m, 0) + 4 * h];
+    };
 
-    float ident[16];                                         // I[krow(r, h)][j]: the B operand that turns FL into NL
+    float ident[16];                                         // I[krow(r, h)][j]
 #pragma unroll
     for (int r = 0; r < 16; ++r) ident[r] = (krow(r, 0) + 4 * h == j) ? 1.f : 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1235,13 +1247,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
             for (int m = 0; m < 32; ++m) XN[m] = 0.f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                if (b < nbi) {
-                    f32x16 t = zero16;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t = mfma32(XF[b][r], ident[r], t);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) XN[16 * b + r] = t[r];
-                }
+                if (b < nbi) fl_to_nl(XF[b], &XN[16 * b]);
             }
             // A' = X X^T + I, r, A^
             f32x16 G = zero16;
@@ -1302,13 +1308,7 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
             for (int m = 0; m < 32; ++m) dzN[m] = 0.f;
 #pragma unroll
             for (int ob = 0; ob < 2; ++ob) {
-                if (ob < nbo) {
-                    f32x16 t = zero16;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t = mfma32(dzF[ob][r], ident[r], t);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dzN[16 * ob + r] = t[r];
-                }
+                if (ob < nbo) fl_to_nl(dzF[ob], &dzN[16 * ob]);
             }
             // d AX = dz W in both forms
             float dAXN[32], dAXF[2][16];
