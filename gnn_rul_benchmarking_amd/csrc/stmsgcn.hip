@@ -352,7 +352,7 @@ __host__ __device__ constexpr int krow(int r, int h) { return 8 * (r >> 2) + 4 *
 __host__ __device__ constexpr int nl_feat(int m, int h) { return 32 * (m >> 4) + krow(m & 15, h); }
 
 struct MxLds {                           // float offsets of the workgroup's LDS
-    int tw, bias, bih, wop[MAXL], wih[MAXL + 1], wave, wave_floats, total;
+    int tw, bias, bih, wop[MAXL], wih[MAXL + 1], wave, wave_floats, tr, total;
 };
 __host__ __device__ inline void mx_lds_layout(const MsgGeom& g, MxLds* o) {
     int p = 0;
@@ -368,6 +368,7 @@ __host__ __device__ inline void mx_lds_layout(const MsgGeom& g, MxLds* o) {
     o->wave = p;
     o->wave_floats = 3 * g.P + 64;       // xs | re | im | row-factor scratch, one set per wavefront
     p += MXW * o->wave_floats;
+    o->tr = p; p += MXW * 32 * 33;       // per-wavefront transpose tile (FL -> NL form of a layer's output block)
     o->total = p;
 }
 static bool mx_features_ok(const MsgGeom& g, size_t* lds_bytes) {
@@ -375,7 +376,7 @@ static bool mx_features_ok(const MsgGeom& g, size_t* lds_bytes) {
     MxLds o;
     mx_lds_layout(g, &o);
     *lds_bytes = sizeof(float) * (size_t)o.total;
-    return *lds_bytes <= 64 * 1024;
+    return *lds_bytes <= 80 * 1024;              // (two workgroups per CU)
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, const f32x16& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -578,30 +579,33 @@ __global__ __launch_bounds__(64 * MXW, 2) void msg_features_mx_kernel(MsgGeom g,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Zf[ob][r] = 0.f;
                 if (ob < nbo) {
-                    f32x16 aF = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, aN = aF;
+                    // (round 4: the Linear layer ran twice to leave its result in both forms -- the second form now comes from the first
+                    // through a wavefront-private LDS tile: 32 LDS operations instead of up to 32 matrix instructions per block)
+                    f32x16 aF = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int m = 0; m < 32; ++m) {
                         if (nl_feat(m, 0) < fi) {
                             const float w = wl[(ob * nbi * 16 + m) * 64 + lane];
                             aF = mfma32(AXn[m], w, aF);
-                            aN = mfma32(w, AXn[m], aN);
                         }
                     }
                     const float bF = bl[32 * ob + j];
-                    float bN[16];
-                    row_values(bl + 32 * ob, h, bN);
                     float* dst = cat_out ? cat_out + gi * (int64_t)(n * C) + gcoff(l + 1) + 32 * ob + j : nullptr;
+                    float* trt = smem + L_.tr + wave * (32 * 33);
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int node = krow(r, 0) + 4 * h;
-                        float zf = aF[r] + bF, zn = aN[r] + bN[r];
+                        float zf = aF[r] + bF;
                         zf = zf > 0.f ? zf : LEAKY * zf;
-                        zn = zn > 0.f ? zn : LEAKY * zn;
                         const bool okf = node < n && 32 * ob + j < fo;
                         Zf[ob][r] = okf ? zf : 0.f;
-                        Zn[16 * ob + r] = node_ok ? zn : 0.f;        // (features >= f_out: zero weights and zero bias give 0)
+                        trt[node * 33 + j] = okf ? zf : 0.f;
                         if (dst && okf) dst[node * C] = zf;
                     }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) Zn[16 * ob + m] = trt[j * 33 + krow(m, 0) + 4 * h];
                 }
             }
             if (gi_out) {
