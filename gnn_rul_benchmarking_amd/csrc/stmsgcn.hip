@@ -1324,17 +1324,17 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dAXF[ib][r] = 0.f;
                 if (ib < nbi) {
-                    f32x16 aN = zero16, aF = zero16;
+                    f32x16 aF = zero16;
 #pragma unroll
                     for (int m = 0; m < 32; ++m) {
                         if (nl_feat(m, 0) < fo) {
                             const float w = wt[(ib * nbo * 16 + m) * 64 + lane];
-                            aN = mfma32(w, dzN[m], aN);        // rows = in features, columns = nodes: NL
                             aF = mfma32(dzN[m], w, aF);        // rows = nodes, columns = in features: FL
                         }
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { dAXN[16 * ib + r] = aN[r]; dAXF[ib][r] = aF[r]; }
+                    for (int r = 0; r < 16; ++r) dAXF[ib][r] = aF[r];
+                    fl_to_nl(dAXF[ib], &dAXN[16 * ib]);       // (the NL form through the LDS tile: it was the same products a second time)
                 }
             }
             // S = d A^ + d A^^T
