@@ -1338,13 +1338,19 @@ __global__ __launch_bounds__(64 * MXW, 1) void msg_gcn_backward_mx_kernel(MsgGeo
                 }
             }
             // S = d A^ + d A^^T
+            // (S = T + T^T with T = d AX X^T: the transpose of the 32 x 32 result through the LDS tile -- result layout in, result layout
+            // out -- instead of the same products a second time with the operands swapped)
             f32x16 S = zero16;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                if (nl_feat(m, 0) < fi) {
-                    S = mfma32(dAXN[m], XN[m], S);
-                    S = mfma32(XN[m], dAXN[m], S);
-                }
+            for (int m = 0; m < 32; ++m)
+                if (nl_feat(m, 0) < fi) S = mfma32(dAXN[m], XN[m], S);
+            {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) trt[(krow(r, 0) + 4 * h) * 33 + j] = S[r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[r] += trt[j * 33 + krow(r, 0) + 4 * h];
             }
             // d r (both D factors) and d(row sum): dd = -1/2 r^3 sum_j A'[i][j] r_j S[i][j]   (A', S symmetric)
             float a1 = 0.f;
