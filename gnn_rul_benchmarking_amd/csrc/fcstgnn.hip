@@ -1103,6 +1103,7 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
     constexpr int HK = D2T / 2, HO = D2T / 4;                          // HO: k of a half-wave in the product over the Linear's D2 / 2 outputs
     __shared__ BnCoef cd[D2T];
     __shared__ float bm[D2T];
+    __shared__ float trt[FC_MX_WAVES][32 * 33];
     if (threadIdx.x < D2T) {
         cd[threadIdx.x] = fbn(g, cells, prm, nullptr, 1, 3 + 2 * blk, threadIdx.x);
         bm[threadIdx.x] = prm[g.o_bmap[blk] + threadIdx.x];
@@ -1217,10 +1218,18 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
             }
         }
         asm volatile("" ::: "memory");
-        // dS^T: the product with the identity swaps the roles of register and lane
-        fc_f32x16 St = zero;
+        // dS^T: register and lane swap roles through a wavefront-private LDS tile (16 writes + 16 reads, in order: no barrier; it was 16 matrix
+        // instructions against the identity)
+        fc_f32x16 St;
+        {
+            float* tt = &trt[threadIdx.x >> 6][0];
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int s = 0; s < 16; ++s) St = fc_mfma(ds_[s], fc_krow(s, h) == c ? 1.f : 0.f, St);
+            for (int s = 0; s < 16; ++s) tt[fc_krow(s, h) * 33 + c] = ds_[s];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) St[s] = tt[c * 33 + fc_krow(s, h)];
+        }
         // cM^T = M'^T (dS + dS^T)^T: a-operand the mapped features by node (lane = feature), b-operand row c of dS + dS^T
         fc_f32x16 CM = zero;
 #pragma unroll
