@@ -13,12 +13,14 @@ dev = torch.device("cuda:0")
 NP, PS = int(os.environ.get("NP", 14)), int(os.environ.get("PS", 30))      # NP=40 PS=64: the PHM2012 wiring
 for B in [int(v) for v in sys.argv[1:]] or [100, 256, 1024, 2048, 4096]:
     row = []
-    for name, path in (("chain", _lib.STEP_CHAIN), ("coop", _lib.STEP_COOP)):
+    for name, path in (("auto", _lib.STEP_AUTO), ("auto+graph", _lib.STEP_AUTO), ("chain", _lib.STEP_CHAIN), ("coop", _lib.STEP_COOP)):
         torch.manual_seed(0)
         a = ST_GCN({"num_patch": NP, "patch_size": PS, "dropout": 0.2}, {"learning_rate": 1e-4, "weight_decay": 1e-4}, dev)
         a.to(dev).train()
         a.sync_loss = False
         a.model.step_path = path
+        if name.endswith('graph'):
+            a.enable_graphs()
         X, y = torch.rand(B, NP, PS, device=dev), torch.rand(B, 1, device=dev)
         try:
             for _ in range(20):
