@@ -236,6 +236,9 @@ _SIGNATURES = {
     "rulgnn_adam_step_guarded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                                 C.c_void_p, C.c_void_p]),
+    "rulgnn_adam_bn_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "rulgnn_bn_running_update_guarded_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_float,
                                                         C.c_int32, C.c_void_p, C.c_void_p]),
     "rulgnn_step_state_set": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p]),

@@ -6,6 +6,19 @@
 
 namespace rulgnn {
 
+__device__ __forceinline__ void adam_element(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, int64_t i, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
+                                             float beta2, float eps, float wd, float gscale) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gscale);
+    const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
+    const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - lr_over_bc1 * (mi / denom);
+}
+
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
                                  float beta2, float eps, float wd, float gscale, const StepState* __restrict__ st,
@@ -17,24 +30,13 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
         lr_over_bc1 = st->lr_over_bc1;
         inv_sqrt_bc2 = st->inv_sqrt_bc2;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float pi = p[i];
-        const float gi = fmaf(wd, pi, g[i] * gscale);
-        const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
-        const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] = pi - lr_over_bc1 * (mi / denom);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        adam_element(p, g, m, v, i, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
 }
 
-__global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
-                                         float unbias, int from_moments, const float* __restrict__ guard) {
+__device__ __forceinline__ void bn_running_entry(float* __restrict__ bn, const float* __restrict__ batch, int i, float momentum,
+                                                 float unbias, int from_moments) {
     // layout [n_bn][2 (mean, var)][F]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_bn * 2 * F) return;
-    if (guard && !(fabsf(*guard) <= 3.0e38f)) return;
     const bool is_var = (i / F) % 2 == 1;
     float b = batch[i];
     if (is_var) {
@@ -45,6 +47,30 @@ __global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __
         b *= unbias;
     }
     bn[i] = (1.f - momentum) * bn[i] + momentum * b;
+}
+
+__global__ void bn_running_update_kernel(float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
+                                         float unbias, int from_moments, const float* __restrict__ guard) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bn * 2 * F) return;
+    if (guard && !(fabsf(*guard) <= 3.0e38f)) return;
+    bn_running_entry(bn, batch, i, momentum, unbias, from_moments);
+}
+
+// The optimizer step and the running-statistics update behind a data-parallel bucket all-reduce in ONE launch (rulgnn_adam_bn_step_f32):
+// the last workgroup carries the BatchNorm entries, the others the Adam elements -- each the arithmetic of its own kernel above.
+__global__ void adam_bn_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                    int64_t n, float lr_over_bc1, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
+                                    float gscale, float* __restrict__ bn, const float* __restrict__ batch, int n_bn, float momentum,
+                                    float unbias, int from_moments, const float* __restrict__ guard) {
+    if (guard && !(fabsf(*guard) <= 3.0e38f)) return;
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int i = threadIdx.x; i < n_bn * 2 * F; i += blockDim.x) bn_running_entry(bn, batch, i, momentum, unbias, from_moments);
+        return;
+    }
+    const int64_t stride = (int64_t)(gridDim.x - 1) * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        adam_element(p, g, m, v, i, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
 }
 
 __global__ void step_state_set_kernel(StepState* s, uint64_t dropout_step, int64_t adam_step) {
@@ -116,6 +142,23 @@ int bn_running_update(float* bn, const float* batch, int num_layers, int64_t cou
     (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
                        momentum, unbias, from_moments, guard);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+int adam_bn_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                 float wd, float gscale, float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
+                 const float* guard, hipStream_t stream) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float unbias = count > 1 ? (float)((double)count / (double)(count - 1)) : 1.f;
+    const int block = 256;
+    int64_t grid = (n + block - 1) / block;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    (void)hipGetLastError();   // drop any stale error of the caller's earlier HIP calls
+    hipLaunchKernelGGL(adam_bn_step_kernel, dim3((unsigned)grid + 1), dim3(block), 0, stream, p, g, m, v, n, (float)((double)lr / bc1),
+                       (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, wd, gscale, bn, batch, num_layers * 2, momentum, unbias,
+                       from_moments, guard);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

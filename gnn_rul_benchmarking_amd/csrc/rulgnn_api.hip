@@ -249,6 +249,17 @@ int rulgnn_bn_running_update_guarded_f32(float* bn_stats, const float* bn_batch,
     return bn_running_update(bn_stats, bn_batch, num_layers, count, momentum, from_moments, static_cast<hipStream_t>(stream), guard);
 }
 
+int rulgnn_adam_bn_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int64_t step, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, float grad_scale, float* bn_stats,
+                            const float* bn_batch, int32_t num_layers, int64_t count, float momentum, int32_t from_moments,
+                            const float* guard, void* stream) {
+    if (n < 0 || step < 1 || num_layers < 1 || num_layers > 8 || count < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({params, grads, exp_avg, exp_avg_sq, bn_stats, bn_batch});
+    if (rc != RULGNN_OK) return rc;
+    return adam_bn_step(params, grads, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, bn_stats,
+                        bn_batch, num_layers, count, momentum, from_moments, guard, static_cast<hipStream_t>(stream));
+}
+
 int rulgnn_bn_running_update_f32(float* bn_stats, const float* bn_batch, int32_t num_layers, int64_t count,
                                  float momentum, int32_t from_moments, void* stream) {
     if (num_layers < 1 || num_layers > 8 || count < 1) return RULGNN_EINVAL;

@@ -176,6 +176,10 @@ int step_prepare_dropout(void* state, uint64_t seed, int num_layers, hipStream_t
 int step_prepare_adam(void* state, float lr, float beta1, float beta2, hipStream_t stream); // ++adam_step, bias corrections
 int bn_running_update(float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
                       hipStream_t stream, const float* guard = nullptr);
+// adam_step + bn_running_update in one launch (what follows a data-parallel bucket all-reduce); `guard` may be null
+int adam_bn_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                 float wd, float gscale, float* bn, const float* batch, int num_layers, int64_t count, float momentum, int from_moments,
+                 const float* guard, hipStream_t stream);
 
 size_t stgnn_workspace_bytes(const rulgnn_stgnn_shape* s);
 int stgnn_terms(const rulgnn_stgnn_shape* s, const float* x, float* terms, float* adj, hipStream_t st);

@@ -64,6 +64,14 @@ class DataParallel:
         else:
             optimizer.step(from_bucket=True)
 
+    def _optimizer_and_stats(self, model, optimizer, global_batch, **source) -> None:
+        """Optimizer step + BatchNorm running statistics behind the all-reduce: one launch where the model offers it (ST_GCN)."""
+        fused = getattr(model, "fused_optimizer_and_running_stats", None)
+        if fused is not None and fused(optimizer, global_batch, **source):
+            return
+        self._optimizer_step(model, optimizer)
+        model._after_train_forward(global_batch, **source)
+
     def all_reduce_bucket(self, bucket: torch.Tensor) -> None:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -167,8 +175,7 @@ class DataParallel:
         self.all_reduce_bucket(model.bucket)
         if violated:
             raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
-        self._optimizer_step(model, optimizer)
-        model._after_train_forward(global_batch, from_bucket_stats=True)
+        self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_stats=True)
         return model.bucket[model.num_live]
 
     def step(self, model, optimizer, X_shard, y_shard, global_batch=None, sample_offset=None):
@@ -188,8 +195,7 @@ class DataParallel:
             model.bucket.numel() * 4 >= self.OVERLAP_MIN_BYTES
         if overlap:
             self._overlapped_step(model, X_shard, y_shard, global_batch, sample_offset)      # an empty shard replays the same collectives
-            self._optimizer_step(model, optimizer)
-            model._after_train_forward(global_batch, from_bucket_moments=True)
+            self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_moments=True)
             return model.bucket[model.num_live]
         if b == 0:
             # Ragged last batch smaller than the world (drop_last=False: n % batch_size can be 1..world_size-1): this rank's
@@ -206,7 +212,8 @@ class DataParallel:
         else:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch)
         self.all_reduce_bucket(model.bucket)
-        self._optimizer_step(model, optimizer)
         if batch_coupled:
-            model._after_train_forward(global_batch, from_bucket_moments=True)
+            self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_moments=True)
+        else:
+            self._optimizer_step(model, optimizer)
         return model.bucket[model.num_live]

@@ -254,6 +254,29 @@ class ST_GCN_model(FlatModule):
                        "rulgnn_bn_running_update_f32")
         self._nbt_pending += 1      # folded into the num_batches_tracked buffers lazily (state_dict / .to())
 
+    def fused_optimizer_and_running_stats(self, optimizer, batch, from_bucket_moments=False, from_bucket_stats=False) -> bool:
+        """``optimizer.step(from_bucket=True)`` and ``_after_train_forward(batch, ...)`` as ONE launch (rulgnn_adam_bn_step_f32) -- the
+        tail of a data-parallel step behind the bucket all-reduce (dp.py).  False when that does not apply (another optimizer, a
+        device-resident step state): the caller then makes the two calls."""
+        from .optim import FusedAdam
+        if not isinstance(optimizer, FusedAdam) or optimizer.model is not self or getattr(self, "_step_state", None) is not None \
+                or not (from_bucket_moments or from_bucket_stats) or not self.flat_params.is_cuda:
+            return False
+        start, end = getattr(self, "optimized_range", (0, int(getattr(self, "num_optimized", self.flat_params.numel()))))
+        m, v = optimizer._state_buffers()
+        g = optimizer.param_groups[0]
+        optimizer._steps += 1
+        o = 4 * start
+        guard = self.guard_tensor
+        _lib.check(_lib.load().rulgnn_adam_bn_step_f32(
+            self.flat_params.data_ptr() + o, self.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, end - start,
+            optimizer._steps, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+            1.0, self._bn.data_ptr(), self._grad_flat.data_ptr() + 4 * (self.num_live + 1), self.num_layers,
+            batch * self.num_patch, 0.1, 1 if from_bucket_moments else 0, guard.data_ptr() if guard is not None else None,
+            _stream()), "rulgnn_adam_bn_step_f32")
+        self._nbt_pending += 1
+        return True
+
     def _train_forward(self, x2d):
         self._step += 1
         shp = self._shape(x2d.size(0))

@@ -266,6 +266,15 @@ int rulgnn_adam_step_guarded_f32(float *params, const float *grads, float *exp_a
 int rulgnn_bn_running_update_guarded_f32(float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count,
                                          float momentum, int32_t from_moments, const float *guard, void *stream);
 
+/* rulgnn_adam_step_f32 (or its guarded form, guard != NULL) and rulgnn_bn_running_update_f32 in ONE launch: the two kernels that follow
+ * the bucket all-reduce of a data-parallel ST_GCN step (dp.py) -- same arithmetic per element, one launch latency less per step.
+ * Replaces optimizer.step() + the running-statistics side effect of the training forward (algorithms/algorithms.py:474-478,
+ * nn.BatchNorm1d in models/ST_GCN/Model.py). */
+int rulgnn_adam_bn_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                            float *bn_stats, const float *bn_batch, int32_t num_layers, int64_t count, float momentum,
+                            int32_t from_moments, const float *guard, void *stream);
+
 /* nn.BatchNorm1d running-statistics update (momentum, unbiased running variance) from the batch
  * statistics produced by the training forward.  count = batch*num_patch values per channel.
  * from_moments != 0: bn_batch holds (E[z], E[z^2]) (the all-reduced form above) instead of (mean, var). */
