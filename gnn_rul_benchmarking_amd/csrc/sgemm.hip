@@ -1013,7 +1013,7 @@ static __global__ __launch_bounds__(256) void sgemm_longk_reduce_kernel(const fl
 }
 
 
-// C[m][n] (+)= sum_k A[m][k] B[n][k] for a SMALL output over a SHORT reduction (M N <= 1024, K <= 2048: the weight gradients of the
+// C[m][n] (+)= sum_k A[m][k] B[n][k] for a SMALL output over a SHORT reduction (M N <= 1024, K M N <= 131072: the weight gradients of the
 // families' MLP heads over a batch): one workgroup, 1024 / (M N) threads per output over interleaved k, combined in fixed order through
 // LDS -- one launch of ~6 us instead of a split-K pair (two launches, 16-19 + 5-7 us).
 static __global__ __launch_bounds__(1024) void sgemm_tiny_kernel(GemmArgs g, int accumulate) {
@@ -1024,7 +1024,19 @@ static __global__ __launch_bounds__(1024) void sgemm_tiny_kernel(GemmArgs g, int
     if (sidx < stripes) {
         const float* ap = g.A + (int64_t)m * g.sAm;
         const float* bp = g.B + (int64_t)n * g.sBn;
-        for (int k = sidx; k < g.K; k += stripes) a = fmaf(ap[(int64_t)k * g.sAk], bp[(int64_t)k * g.sBk], a);
+        // eight products' operands requested before the first is used (one memory round trip per eight, same summation order)
+        int k = sidx;
+        for (; k + 7 * stripes < g.K; k += 8 * stripes) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = ap[(int64_t)(k + u * stripes) * g.sAk];
+                bv[u] = bp[(int64_t)(k + u * stripes) * g.sBk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(av[u], bv[u], a);
+        }
+        for (; k < g.K; k += stripes) a = fmaf(ap[(int64_t)k * g.sAk], bp[(int64_t)k * g.sBk], a);
     }
     red[threadIdx.x] = sidx < stripes ? a : 0.f;
     __syncthreads();
@@ -1036,10 +1048,16 @@ static __global__ __launch_bounds__(1024) void sgemm_tiny_kernel(GemmArgs g, int
     }
 }
 
+// One workgroup: a thread walks K M N / 1024 products, eight operand pairs per memory round trip.  Measured before that bound existed
+// (STNet, K = batch x patches = 2000): 29 us for 300 outputs, 240-540 us for ~1000 outputs -- far above the split-K pair it replaces.
+// Up to 128 products per thread it is a 5-11 us launch (FC_STGNN's heads at batch 256); at 224 (STGNN's head: 896 outputs x 256
+// rows) 25 us against 12 us for the pair.
+static inline bool sgemm_tiny_ok(int M, int N, int K) { return (int64_t)M * N <= 1024 && (int64_t)K * M * N <= 131072; }
+
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
-    if ((int64_t)M * N <= 1024 && K <= 2048) {
+    if (sgemm_tiny_ok(M, N, K)) {
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, 0, K};
         (void)hipGetLastError();
         hipLaunchKernelGGL(sgemm_tiny_kernel, dim3(1), dim3(1024), 0, st, g, accumulate ? 1 : 0);
@@ -1078,7 +1096,7 @@ int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B
                         int M, int N, int K, float* colsum, const float* ones, float* partial, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
     const int NE = N + 1;
-    if (!((int64_t)M * N <= 1024 && K <= 2048) && sgemm_longk_blocks(M, NE, K) > 0) {
+    if (!sgemm_tiny_ok(M, N, K) && sgemm_longk_blocks(M, NE, K) > 0) {
         int nblk = sgemm_longk_blocks(M, NE, K);
         int kper = (K + nblk - 1) / nblk;
         kper = (kper + SKT_ROWS - 1) / SKT_ROWS * SKT_ROWS;

@@ -110,7 +110,7 @@ def run_splitk(A, B, M, N, K, a_layout, b_layout, colsum):
 
 
 # (M, N, K): the matrix-core long-k kernel in each of its tile counts (row-major operands, M <= 32, N <= 64, with the ones column pushing
-# N + 1 over a tile edge), the LDS long-k kernel (k-contiguous operands), the one-workgroup kernel (K <= 2048), 64-k slices of the tile
+# N + 1 over a tile edge), the LDS long-k kernel (k-contiguous operands), the one-workgroup kernel (K M N <= 131072), 64-k slices of the tile
 # kernel with the 16-stripe reduction, a ragged last k-range
 SPLITK = [(8, 16, 93184), (16, 16, 50176), (16, 32, 7168), (16, 48, 7168), (32, 32, 10240), (24, 64, 4099), (30, 17, 131), (1, 8, 4000),
           (16, 16, 2048), (8, 16, 600), (50, 50, 10240), (96, 72, 7168), (240, 60, 3584), (3, 5, 1)]
