@@ -445,6 +445,301 @@ __global__ __launch_bounds__(RB) void rg_scl_bwd_kernel(RgGeom g, const float* _
     if (tid == 0) row[g.o_cb - base] = gcb;
 }
 
+// ---- spatial correlation layer on the fp32 matrix cores (N <= 16 nodes, H = 32: every wiring of the reference but N-CMAPSS's 20 nodes) ----
+// The kernels above give a graph to a WORKGROUP: eight barriers per graph and two LDS reads per multiply-add (89 / 203 us at batch 256,
+// half of the step).  Here a graph belongs to a WAVEFRONT -- four graphs in flight per workgroup, no workgroup barrier in the loop, LDS
+// operations of one wavefront execute in order -- and every product of the layer is v_mfma_f32_16x16x4f32 with the node axis padded to
+// 16: lane (kq, li) = (lane / 16, lane % 16) feeds A[m = li][k = 4 s + kq] and B[k = 4 s + kq][n = li] and receives
+// C[m = 4 kq + r][n = li].  Operands come from per-wavefront LDS tiles (pitch 33) or, where they are rank-one (h1 = relu(ax w1 + b1)),
+// are formed in registers; W2 sits in 16 registers per lane in the operand form of the kernel's one product with it.  Pad rows / columns
+// of A_hat are zero, so whatever the pad rows of the other operand hold never reaches a result.
+constexpr int RG_MXW = 4;                // wavefronts (graphs in flight) per workgroup
+constexpr int RG_TP = 33;                // tile pitch
+constexpr int RG_AP = 17;                // adjacency pitch
+constexpr int RG_MX_WAVE_FLOATS = 16 * RG_AP + 3 * 16 * RG_TP + 64;       // A_hat | three [16][32] tiles | four 16-vectors
+constexpr int RG_MXH = 32;
+
+__device__ __forceinline__ f32x4t rg_mfma(float a, float b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum over the 16 lanes of a row (li), every lane of the row receives it
+__device__ __forceinline__ float rg_row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64 * RG_MXW) void rg_scl_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                                float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
+                                                                int64_t sample_offset) {
+    __shared__ __attribute__((aligned(16))) float sm[RG_MXW * RG_MX_WAVE_FLOATS];
+    constexpr int H = RG_MXH;
+    const int N = g.N, L = g.L, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    float* ah = sm + wave * RG_MX_WAVE_FLOATS;      // [16][17], zero outside [N][N]
+    float* a1t = ah + 16 * RG_AP;                    // [16][33]
+    float* xs = a1t + 3 * 16 * RG_TP;                // [16]
+    float* axs = xs + 16;                            // [16]
+    float w1[2], b1[2], b2[2], cw[2], w2t[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = 16 * t + li;
+        w1[t] = prm[g.o_g1w + c]; b1[t] = prm[g.o_g1b + c]; b2[t] = prm[g.o_g2b + c]; cw[t] = prm[g.o_cw + c];
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) w2t[t][s4] = prm[g.o_g2w + c * H + 4 * s4 + kq];      // B(k, n = h) = W2[h][k]
+    }
+    const float cb = prm[g.o_cb];
+    for (int i = lane; i < 16 * RG_AP; i += 64) ah[i] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const int64_t nw = (int64_t)gridDim.x * RG_MXW;
+    for (int64_t gi = (int64_t)blockIdx.x * RG_MXW + wave; gi < g.G; gi += nw) {
+        const int64_t b = gi / L, a = gi % g.B;                 // the adjacency this graph convolves with (Model.py:104-106)
+        const int l = (int)(gi % L);
+        for (int i = lane; i < N * N; i += 64) ah[(i / N) * RG_AP + i % N] = ws[g.w_Ahat + a * N * N + i];
+        if (lane < 16) xs[lane] = lane < N ? x[(b * N + lane) * L + l] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) {
+            float v = 0.f;
+            for (int j = 0; j < N; ++j) v = fmaf(ah[lane * RG_AP + j], xs[j], v);
+            axs[lane] = v;
+            if (lane < N) ws[g.w_ax1 + gi * N + lane] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // a1 = A_hat h1, h1[k][h] = relu(ax[k] w1[h] + b1[h]) formed in the B operand
+        {
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float av = ah[li * RG_AP + 4 * s4 + kq], axk = axs[4 * s4 + kq];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, fmaxf(fmaf(axk, w1[t], b1[t]), 0.f), acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 4 * kq + r, h = 16 * t + li;
+                    a1t[n * RG_TP + h] = acc[t][r];
+                    if (n < N) ws[g.w_ah1 + gi * N * H + n * H + h] = acc[t][r];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // z2 = a1 W2^T + b2; dropout; the 1x1 convolution over the hidden axis
+        {
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float av = a1t[li * RG_TP + 4 * s4 + kq];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, w2t[t][s4], acc[t]);
+            }
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 4 * kq + r, h = 16 * t + li;
+                    const float z = acc[t][r] + b2[t];
+                    if (n < N) {
+                        ws[g.w_z2 + gi * N * H + n * H + h] = z;
+                        p[r] = fmaf(fmaxf(z, 0.f) * rg_keep(key, thr, scale, sample_offset + b, l, n, h, g), cw[t], p[r]);
+                    }
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = rg_row16_sum(p[r]) + cb;
+                const int n = 4 * kq + r;
+                if (li == 0 && n < N) ws[g.w_sp + (b * L + l) * N + n] = v;      // [sample][step][node]: the LSTM's batch-first input
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64 * RG_MXW) void rg_scl_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                                    float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
+                                                                    int64_t sample_offset) {
+    // after the loop the wavefronts' regions are reused for the fixed-order sum of their partial gradients:
+    // g2w [RG_MXW][H H] | column sums [RG_MXW][4 kinds][4 kq][H] | cb [RG_MXW][16]
+    constexpr int H = RG_MXH;
+    constexpr int RED_FLOATS = RG_MXW * (H * H + 4 * 4 * H + 16);
+    constexpr int SM_FLOATS = RG_MXW * RG_MX_WAVE_FLOATS > RED_FLOATS ? RG_MXW * RG_MX_WAVE_FLOATS : RED_FLOATS;
+    __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
+    const int N = g.N, L = g.L, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    float* ah = sm + wave * RG_MX_WAVE_FLOATS;      // [16][17], zero outside [N][N]
+    float* dz2t = ah + 16 * RG_AP;                   // [16][33] x 3: dz2, a1, da1
+    float* a1t = dz2t + 16 * RG_TP;
+    float* da1t = a1t + 16 * RG_TP;
+    float* xs = da1t + 16 * RG_TP;                   // [16] x 4: xs, ax, dsp, dax
+    float* axs = xs + 16;
+    float* dsp = axs + 16;
+    float* dax = dsp + 16;
+    float w1[2], b1[2], cw[2], w2b[2][8], w1k[8], b1k[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = 16 * t + li;
+        w1[t] = prm[g.o_g1w + c]; b1[t] = prm[g.o_g1b + c]; cw[t] = prm[g.o_cw + c];
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) w2b[t][s4] = prm[g.o_g2w + (4 * s4 + kq) * H + c];      // B(k = h, n) = W2[h][n]
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) { w1k[s4] = prm[g.o_g1w + 4 * s4 + kq]; b1k[s4] = prm[g.o_g1b + 4 * s4 + kq]; }
+    f32x4t g2w[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g2w[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    float gg1w[2] = {0.f, 0.f}, gg1b[2] = {0.f, 0.f}, gg2b[2] = {0.f, 0.f}, gcw[2] = {0.f, 0.f}, gcb = 0.f;
+    for (int i = lane; i < 16 * RG_AP; i += 64) ah[i] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    // graphs over the wavefronts in a fixed stride (the grid is a function of the shape alone): every partial row sums the same graphs
+    // in the same order on every run
+    const int64_t nw = (int64_t)gridDim.x * RG_MXW;
+    for (int64_t gi = (int64_t)blockIdx.x * RG_MXW + wave; gi < g.G; gi += nw) {
+        const int64_t b = gi / L, a = gi % g.B;
+        const int l = (int)(gi % L);
+        for (int i = lane; i < N * N; i += 64) ah[(i / N) * RG_AP + i % N] = ws[g.w_Ahat + a * N * N + i];
+        if (lane < 16) {
+            const bool in = lane < N;
+            xs[lane] = in ? x[(b * N + lane) * L + l] : 0.f;
+            axs[lane] = in ? ws[g.w_ax1 + gi * N + lane] : 0.f;
+            const float d = in ? ws[g.w_dsp + gi * N + lane] : 0.f;
+            dsp[lane] = d;
+            gcb += d;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // element-wise part in the result layout of the products: rows 4 kq + r, columns 16 t + li
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 4 * kq + r, h = 16 * t + li;
+                float dz = 0.f, av = 0.f;
+                if (n < N) {
+                    const float z = ws[g.w_z2 + gi * N * H + n * H + h];
+                    av = ws[g.w_ah1 + gi * N * H + n * H + h];
+                    const float kp = rg_keep(key, thr, scale, sample_offset + b, l, n, h, g), d = dsp[n];
+                    dz = z > 0.f ? d * cw[t] * kp : 0.f;
+                    gcw[t] = fmaf(d, fmaxf(z, 0.f) * kp, gcw[t]);          // conv1d (1x1) weight: the dropped-out hidden features
+                    gg2b[t] += dz;
+                }
+                dz2t[n * RG_TP + h] = dz;
+                a1t[n * RG_TP + h] = av;
+            }
+        __builtin_amdgcn_wave_barrier();
+        // gcn2 weight gradient: g2w[h][k] += sum_n dz2[n][h] a1[n][k] (accumulators live across the graphs)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int n = 4 * s4 + kq;
+            const float d0 = dz2t[n * RG_TP + li], d1 = dz2t[n * RG_TP + 16 + li];
+            const float e0 = a1t[n * RG_TP + li], e1 = a1t[n * RG_TP + 16 + li];
+            g2w[0][0] = rg_mfma(d0, e0, g2w[0][0]);
+            g2w[0][1] = rg_mfma(d0, e1, g2w[0][1]);
+            g2w[1][0] = rg_mfma(d1, e0, g2w[1][0]);
+            g2w[1][1] = rg_mfma(d1, e1, g2w[1][1]);
+        }
+        // d (A_hat h1) = dz2 W2
+        {
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const float av = dz2t[li * RG_TP + 4 * s4 + kq];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, w2b[t][s4], acc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) da1t[(4 * kq + r) * RG_TP + 16 * t + li] = acc[t][r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // d h1 = A_hat^T da1 through the ReLU of gcn1; its parameter gradients; d ax
+        {
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int i = 4 * s4 + kq;
+                const float av = ah[i * RG_AP + li];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, da1t[i * RG_TP + 16 * t + li], acc[t]);
+            }
+            float pd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float axj = axs[4 * kq + r];
+                    const float dz1 = fmaf(axj, w1[t], b1[t]) > 0.f ? acc[t][r] : 0.f;      // pad rows: A_hat's pad columns made acc zero
+                    gg1w[t] = fmaf(dz1, axj, gg1w[t]);
+                    gg1b[t] += dz1;
+                    pd[r] = fmaf(dz1, w1[t], pd[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = rg_row16_sum(pd[r]);
+                if (li == 0) dax[4 * kq + r] = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // d A_hat of this graph: da1 h1^T + dax x^T
+        {
+            f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
+            const float axc = axs[li];
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4)
+                acc = rg_mfma(da1t[li * RG_TP + 4 * s4 + kq], fmaxf(fmaf(axc, w1k[s4], b1k[s4]), 0.f), acc);
+            const float xc = xs[li];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 4 * kq + r;
+                if (rr < N && li < N) ws[g.w_dAg + gi * N * N + rr * N + li] = fmaf(dax[rr], xc, acc[r]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- one partial row per workgroup: the four wavefronts' partial sums in a fixed order ----
+    __syncthreads();
+    float* r2w = sm;                                 // [RG_MXW][H H]
+    float* rcol = r2w + RG_MXW * H * H;              // [RG_MXW][4][4][H]: g1w, g1b, g2b, cw by (kq, column)
+    float* rcb = rcol + RG_MXW * 4 * 4 * H;          // [RG_MXW][16]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) r2w[wave * H * H + (16 * i + 4 * kq + r) * H + 16 * j + li] = g2w[i][j][r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float* c = rcol + wave * 4 * 4 * H + kq * H + 16 * t + li;
+        c[0 * 4 * H] = gg1w[t];
+        c[1 * 4 * H] = gg1b[t];
+        c[2 * 4 * H] = gg2b[t];
+        c[3 * 4 * H] = gcw[t];
+    }
+    if (lane < 16) rcb[wave * 16 + lane] = gcb;
+    __syncthreads();
+    float* row = ws + g.w_partS + (int64_t)blockIdx.x * g.nS;
+    const int base = g.o_g1w, tid = threadIdx.x;
+    for (int e = tid; e < H * H; e += 64 * RG_MXW) {
+        float v = 0.f;
+        for (int w = 0; w < RG_MXW; ++w) v += r2w[w * H * H + e];
+        row[g.o_g2w - base + e] = v;
+    }
+    if (tid < 4 * H) {
+        const int kind = tid / H, c = tid % H;
+        float v = 0.f;
+        for (int w = 0; w < RG_MXW; ++w)
+            for (int q = 0; q < 4; ++q) v += rcol[w * 4 * 4 * H + kind * 4 * H + q * H + c];
+        const int off = kind == 0 ? g.o_g1w : kind == 1 ? g.o_g1b : kind == 2 ? g.o_g2b : g.o_cw;
+        row[off - base + c] = v;
+    }
+    if (tid == 0) {
+        float v = 0.f;
+        for (int i = 0; i < RG_MXW * 16; ++i) v += rcb[i];
+        row[g.o_cb - base] = v;
+    }
+}
+
 // ---- adjacency backward ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RB) void rg_adj_bwd_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
     __shared__ float xs[RG_MAXN * RG_MAXL], a1[RG_MAXN * RG_MAXN], a2[RG_MAXN * RG_MAXN], tt[RG_MAXN * RG_MAXN], dh[RG_MAXN * RG_MAXN],
@@ -575,12 +870,17 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
     la.out = ws + g.w_hseq;
     la.workspace = ws + g.w_lstm;
     la.workspace_bytes = bilstm_workspace_bytes(&ls);
-    const int blocks = g.blocks, gblocks = g.gblocks;
+    // the matrix-core SCL kernels give a graph to a wavefront: half the workgroups (and partial rows), twice the graphs in flight
+    const bool scl_mx = g.N <= 16 && g.H == RG_MXH;
+    const int blocks = g.blocks, gblocks = scl_mx ? (g.gblocks + 1) / 2 : g.gblocks;
     const size_t lds_scl = sizeof(float) * ((size_t)g.N * g.N + 2 * g.N + 3 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
     const size_t lds_sclb = sizeof(float) * ((size_t)g.N * g.N + 4 * g.N + 5 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
     (void)hipGetLastError();
     if (mode & 1) {
         hipLaunchKernelGGL(rg_adj_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
+        if (scl_mx)
+            hipLaunchKernelGGL(rg_scl_mx_kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), 0, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+        else
         hipLaunchKernelGGL(rg_scl_kernel, dim3((unsigned)gblocks), dim3(RB), lds_scl, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         RG_RC(bilstm_forward(&ls, &la, st, 1));
@@ -610,6 +910,9 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
         if (lds_sclb > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_scl_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sclb) != hipSuccess)
             return RULGNN_EHIP;
+        if (scl_mx)
+            hipLaunchKernelGGL(rg_scl_bwd_mx_kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), 0, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+        else
         hipLaunchKernelGGL(rg_scl_bwd_kernel, dim3((unsigned)gblocks), dim3(RB), lds_sclb, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
         hipLaunchKernelGGL(rg_adj_bwd_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
