@@ -740,6 +740,216 @@ __global__ __launch_bounds__(64 * RG_MXW) void rg_scl_bwd_mx_kernel(RgGeom g, co
     }
 }
 
+// ---- fusion module on the fp32 matrix cores (E = 32, k = 3, N <= 16, L <= 64: the reference's wirings) --------------------------------
+// The k-tap convolution of a sample is the product [E x E k] x [E k x L] over the zero-padded tile (96 x 50 at the reference's widths),
+// its transposed form the same with the weights regrouped, its weight gradient [E x L] x [L x E k]; the 1x1 convolution over the nodes
+// and its weight gradient are products over N and L.  One workgroup per sample as above, but a wavefront owns a 16-column tile of the
+// time axis (forward, d M) or three 16 x 16 tiles of d W2 (accumulated in registers over the workgroup's samples); the weights sit in
+// operand form in registers for the whole kernel (48 per lane), the tiles in LDS with odd pitches.  rg_fusion 51 -> / rg_fusion_bwd 56 ->
+// see DESIGN 3i.
+constexpr int RF_E = 32, RF_K = 3, RF_PAD = 1, RF_P = 67, RF_XP = 65, RF_KE = RF_E * RF_K;      // 96 = (e, j) pairs
+
+__host__ __device__ __forceinline__ bool rg_fusion_mx_ok(const RgGeom& g) { return g.E == RF_E && g.K == RF_K && g.N <= 16 && g.L <= 64; }
+
+__global__ __launch_bounds__(RB) void rg_fusion_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ prm, float* __restrict__ ws, float* __restrict__ pred,
+                                                          float* __restrict__ stdv, float inv_gb) {
+    __shared__ __attribute__((aligned(16))) float Mp[RF_E * RF_P];      // [E][67]: M at column pad + l, zero elsewhere
+    __shared__ __attribute__((aligned(16))) float xs[16 * RF_XP];       // [16][65]: x, zero rows beyond N
+    __shared__ float red[2 * RB];
+    constexpr int E = RF_E, P = RF_P, XP = RF_XP;
+    const int N = g.N, L = g.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float c1a[2][4], w2a[2][24], c1b[2][4], c2b[2][4];
+    int boff[24];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) c1a[i][s4] = 4 * s4 + kq < N ? prm[g.o_c1w + (16 * i + li) * N + 4 * s4 + kq] : 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 24; ++s4) w2a[i][s4] = prm[g.o_c2w + (16 * i + li) * RF_KE + 4 * s4 + kq];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { c1b[i][r] = prm[g.o_c1b + 16 * i + 4 * kq + r]; c2b[i][r] = prm[g.o_c2b + 16 * i + 4 * kq + r]; }
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 24; ++s4) boff[s4] = ((4 * s4 + kq) / RF_K) * P + (4 * s4 + kq) % RF_K;
+    for (int i = tid; i < 16 * XP; i += RB) xs[i] = 0.f;
+    for (int i = tid; i < E * P; i += RB) Mp[i] = 0.f;
+    const int l = 16 * wave + li;                 // this lane's column of the time axis (operand B and the results)
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < N * L; i += RB) xs[(i / L) * XP + i % L] = x[b * N * L + i];
+        __syncthreads();
+        {   // M = conv1x1_N(x) + LSTM output
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float bv = xs[(4 * s4 + kq) * XP + l];
+                acc[0] = rg_mfma(c1a[0][s4], bv, acc[0]);
+                acc[1] = rg_mfma(c1a[1][s4], bv, acc[1]);
+            }
+            if (l < L) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float4 hv = *reinterpret_cast<const float4*>(ws + g.w_hseq + (b * L + l) * E + 16 * i + 4 * kq);
+                    const float h4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = 16 * i + 4 * kq + r;
+                        const float v = acc[i][r] + c1b[i][r] + h4[r];
+                        Mp[e * P + RF_PAD + l] = v;
+                        ws[g.w_M + b * E * L + e * L + l] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float p1 = 0.f, p2 = 0.f;
+        {   // M2 = conv_k(M) + bias; the two heads
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 24; ++s4) {
+                const float bv = Mp[boff[s4] + l];
+                acc[0] = rg_mfma(w2a[0][s4], bv, acc[0]);
+                acc[1] = rg_mfma(w2a[1][s4], bv, acc[1]);
+            }
+            if (l < L) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (16 * i + 4 * kq + r) * L + l;
+                        const float v = acc[i][r] + c2b[i][r];
+                        ws[g.w_M2 + b * E * L + idx] = v;
+                        p1 = fmaf(v, prm[g.o_f1w + idx], p1);
+                        p2 = fmaf(v, prm[g.o_f2w + idx], p2);
+                    }
+            }
+        }
+        red[tid] = p1;
+        red[RB + tid] = p2;
+        __syncthreads();
+        for (int m = RB / 2; m > 0; m >>= 1) {
+            if (tid < m) { red[tid] += red[tid + m]; red[RB + tid] += red[RB + tid + m]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float pr = red[0] + prm[g.o_f1b];
+            pred[b] = pr;
+            if (stdv) stdv[b] = red[RB] + prm[g.o_f2b];
+            if (y) {
+                const float d = pr - y[b];
+                ws[g.w_sq + b] = d * d * inv_gb;
+                ws[g.w_dpred + b] = 2.f * d * inv_gb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RB) void rg_fusion_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ dpred_in,
+                                                              const float* __restrict__ prm, float* __restrict__ ws) {
+    __shared__ __attribute__((aligned(16))) float Mp[RF_E * RF_P];      // forward M at column pad + l
+    __shared__ __attribute__((aligned(16))) float d2[RF_E * RF_P];      // d M2 at column (k - 1 - pad) + l
+    __shared__ __attribute__((aligned(16))) float dMs[RF_E * RF_XP];    // d M at column l
+    __shared__ __attribute__((aligned(16))) float xs[16 * RF_XP];
+    constexpr int E = RF_E, P = RF_P, XP = RF_XP, K = RF_K, D2O = RF_K - 1 - RF_PAD;
+    const int N = g.N, L = g.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float w2d[2][24];                  // A(m = e, k = (o, j)) = W2[o][e][j]
+    int doff[24];                      // B(k = (o, j), n = l) = d2[o][(k - 1) + l - j]
+#pragma unroll
+    for (int s4 = 0; s4 < 24; ++s4) {
+        const int o = (4 * s4 + kq) / K, j = (4 * s4 + kq) % K;
+        doff[s4] = o * P + (K - 1) - j;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w2d[i][s4] = prm[g.o_c2w + (o * E + 16 * i + li) * K + j];
+    }
+    // d W2: wavefront w owns the row tile i = w & 1 and the column tiles 3 (w >> 1) .. + 2 of the [E][E k] gradient
+    const int wi = wave & 1, wt0 = 3 * (wave >> 1);
+    int eoff[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) eoff[t] = ((16 * (wt0 + t) + li) / K) * P + (16 * (wt0 + t) + li) % K;
+    f32x4t gw2[3] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+    f32x4t gw1 = (f32x4t){0.f, 0.f, 0.f, 0.f};                           // d W1[e][n]: wavefronts 0, 1 own the row tile i = wave
+    float gc1b[RG_OWN], gc2b[RG_OWN], gf1w[RG_OWN], gf1b = 0.f;
+#pragma unroll
+    for (int s = 0; s < RG_OWN; ++s) gc1b[s] = gc2b[s] = gf1w[s] = 0.f;
+    for (int i = tid; i < E * P; i += RB) { Mp[i] = 0.f; d2[i] = 0.f; }
+    for (int i = tid; i < E * XP; i += RB) dMs[i] = 0.f;
+    for (int i = tid; i < 16 * XP; i += RB) xs[i] = 0.f;
+    const float* dpred = dpred_in ? dpred_in : ws + g.w_dpred;
+    const int l = 16 * wave + li;
+    const int ksteps = (L + 3) / 4;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        const float dp = dpred[b];
+        __syncthreads();
+        for (int i = tid; i < N * L; i += RB) xs[(i / L) * XP + i % L] = x[b * N * L + i];
+        for (int i = tid; i < E * L; i += RB) {
+            const int e = i / L, ll = i % L;
+            Mp[e * P + RF_PAD + ll] = ws[g.w_M + b * E * L + i];
+            d2[e * P + D2O + ll] = dp * prm[g.o_f1w + i];
+        }
+        RG_FOR_OWNED(E * L, e, s) gf1w[s] = fmaf(dp, ws[g.w_M2 + b * E * L + e], gf1w[s]);
+        if (tid == 0) gf1b += dp;
+        __syncthreads();
+        {   // d M[e][l] = sum_{o, j} W2[o][e][j] dM2[o][l - j + pad]
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int s4 = 0; s4 < 24; ++s4) {
+                const float bv = d2[doff[s4] + l];
+                acc[0] = rg_mfma(w2d[0][s4], bv, acc[0]);
+                acc[1] = rg_mfma(w2d[1][s4], bv, acc[1]);
+            }
+            if (l < L) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dMs[(16 * i + 4 * kq + r) * XP + l] = acc[i][r];
+                    *reinterpret_cast<float4*>(ws + g.w_dM + (b * L + l) * E + 16 * i + 4 * kq) =
+                        make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);          // [sample][step][E]: d (LSTM output)
+                }
+            }
+        }
+        // d W2[o][(e, j)] += sum_l dM2[o][l] M[e][l + j - pad]
+        for (int s4 = 0; s4 < ksteps; ++s4) {
+            const int k = 4 * s4 + kq;
+            const float av = d2[(16 * wi + li) * P + D2O + k];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) gw2[t] = rg_mfma(av, Mp[eoff[t] + k], gw2[t]);
+        }
+        RG_FOR_OWNED(E, o, s) {
+            float v = 0.f;
+            for (int ll = 0; ll < L; ++ll) v += d2[o * P + D2O + ll];
+            gc2b[s] += v;
+        }
+        __syncthreads();
+        // d W1[e][n] += sum_l dM[e][l] x[n][l]
+        if (wave < 2)
+            for (int s4 = 0; s4 < ksteps; ++s4) {
+                const int k = 4 * s4 + kq;
+                gw1 = rg_mfma(dMs[(16 * wave + li) * XP + k], xs[li * XP + k], gw1);
+            }
+        RG_FOR_OWNED(E, e, s) {
+            float v = 0.f;
+            for (int ll = 0; ll < L; ++ll) v += dMs[e * XP + ll];
+            gc1b[s] += v;
+        }
+    }
+    float* row = ws + g.w_partF + (int64_t)blockIdx.x * g.nF;
+    const int base = g.o_c1w;
+    if (wave < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (li < N) row[g.o_c1w - base + (16 * wave + 4 * kq + r) * N + li] = gw1[r];
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[g.o_c2w - base + (16 * wi + 4 * kq + r) * RF_KE + 16 * (wt0 + t) + li] = gw2[t][r];
+    RG_FOR_OWNED(E, e, s) row[g.o_c1b - base + e] = gc1b[s];
+    RG_FOR_OWNED(E, e, s) row[g.o_c2b - base + e] = gc2b[s];
+    RG_FOR_OWNED(E * L, e, s) row[g.o_f1w - base + e] = gf1w[s];
+    if (tid == 0) row[g.o_f1b - base] = gf1b;
+}
+
 // ---- adjacency backward ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RB) void rg_adj_bwd_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm, float* __restrict__ ws) {
     __shared__ float xs[RG_MAXN * RG_MAXL], a1[RG_MAXN * RG_MAXN], a2[RG_MAXN * RG_MAXN], tt[RG_MAXN * RG_MAXN], dh[RG_MAXN * RG_MAXN],
@@ -889,6 +1099,9 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_fusion_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)lds) != hipSuccess)
             return RULGNN_EHIP;
+        if (rg_fusion_mx_ok(g))
+            hipLaunchKernelGGL(rg_fusion_mx_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, a->y, prm, ws, a->pred, a->std_pred, inv_gb);
+        else
         hipLaunchKernelGGL(rg_fusion_kernel, dim3(blocks), dim3(RB), lds, st, g, a->x, a->y, prm, ws, a->pred, a->std_pred, inv_gb);
         if (a->y && a->loss) (void)block_sum((const float*)(ws + g.w_sq), g.B, a->loss, st);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -900,6 +1113,9 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
         if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_fusion_bwd_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return RULGNN_EHIP;
+        if (rg_fusion_mx_ok(g))
+            hipLaunchKernelGGL(rg_fusion_bwd_mx_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, a->dpred, prm, ws);
+        else
         hipLaunchKernelGGL(rg_fusion_bwd_kernel, dim3(blocks), dim3(RB), lds, st, g, a->x, a->dpred, prm, ws);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         la.dout = ws + g.w_dM;
