@@ -1132,9 +1132,13 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
         hipLaunchKernelGGL(rg_scl_bwd_kernel, dim3((unsigned)gblocks), dim3(RB), lds_sclb, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
         hipLaunchKernelGGL(rg_adj_bwd_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
-        RG_RC(rows_sum(ws + g.w_partA, blocks, g.nA, g.nA, a->grads, st));
-        RG_RC(rows_sum(ws + g.w_partS, gblocks, g.nS, g.nS, a->grads + g.o_g1w, st));
-        RG_RC(rows_sum(ws + g.w_partF, blocks, g.nF, g.nF, a->grads + g.o_c1w, st));
+        {   // the three groups' partial rows in one launch
+            const float* const part[3] = {ws + g.w_partA, ws + g.w_partS, ws + g.w_partF};
+            float* const out[3] = {a->grads, a->grads + g.o_g1w, a->grads + g.o_c1w};
+            const int rows[3] = {blocks, gblocks, blocks}, n[3] = {g.nA, g.nS, g.nF};
+            const int64_t ld[3] = {g.nA, g.nS, g.nF};
+            RG_RC(rows_sum_three(part, out, rows, ld, n, st));
+        }
         const int nz = g.E * g.L + 1;                                    // the `std` head is not in the loss (algorithms.py:287-290)
         hipLaunchKernelGGL(rg_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, st, a->grads + g.o_f2w, nz);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;

@@ -1200,6 +1200,18 @@ int rows_sum3(const float* partA, float* outA, const float* partB, float* outB, 
     hipLaunchKernelGGL(rows_sum_multi_kernel, dim3((nmax + 31) / 32, partC && nC > 0 ? 3 : 2), dim3(1024), 0, st, jb);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
+int rows_sum_three(const float* const part[3], float* const out[3], const int rows[3], const int64_t ld[3], const int n[3], hipStream_t st) {
+    RowsSumJobs jb{};
+    int nmax = 0;
+    for (int j = 0; j < 3; ++j) {
+        jb.part[j] = part[j]; jb.out[j] = out[j]; jb.rows[j] = rows[j]; jb.ld[j] = ld[j]; jb.n[j] = n[j] > 0 ? n[j] : 0;
+        nmax = jb.n[j] > nmax ? jb.n[j] : nmax;
+    }
+    if (nmax <= 0) return RULGNN_OK;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(rows_sum_multi_kernel, dim3((nmax + 31) / 32, 3), dim3(1024), 0, st, jb);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st) {
     if (n <= 0) return RULGNN_OK;
     (void)hipGetLastError();

@@ -34,6 +34,8 @@ int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, 
 // ... plus a third sum of another shape whose result is written twice (outC and, if given, outC2)
 int rows_sum3(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, const float* partC, float* outC,
               float* outC2, int rowsC, int64_t ldC, int nC, hipStream_t st);
+// three sums of different shapes in one launch
+int rows_sum_three(const float* const part[3], float* const out[3], const int rows[3], const int64_t ld[3], const int n[3], hipStream_t st);
 // dst[c] = sum_r src[r][c] of a short row-major matrix with ONE workgroup.  A thread walks rows * C / 1024 elements alone: beyond
 // ~64 of them the split-K pair wins again (10 240 rows x 50 columns: > 100 us)
 inline bool cols_sum_small_ok(int64_t rows, int C) { return C >= 1 && C <= 64 && rows * C <= 65536; }
