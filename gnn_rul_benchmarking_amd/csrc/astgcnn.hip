@@ -563,13 +563,13 @@ void ast_ws_layout(const AstGeom& g, AstWs* w) {
 }
 
 template <typename K>
-int resident_rows(K kernel, int64_t items, int cap) {
+int resident_rows(K kernel, int64_t items, int cap, int block = AB) {
     int dev = 0, cus = 256, per_cu = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, AB, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     int64_t want = (int64_t)cus * per_cu;
     if (want > items) want = items;
     if (want > cap) want = cap;
@@ -603,6 +603,8 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
 template <int SN, int SE, int SO>
 static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync,
                          float* bn_running_out, float bn_momentum) {
+    // threads of the TCN kernels: 20 nodes x 50 steps are 260 / 400 work items per sample -- one round of 448 threads (tcn_nodes.hpp)
+    constexpr int TTB = SN == 20 ? 448 : AB;
     AstGeom g;
     AST_RC(ast_geometry(s, &g));
     if (sync) {          // both BatchNorm layers normalise by the statistics of the GLOBAL batch (cells all-reduced between the kernels)
@@ -630,11 +632,11 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
     };
     if (mode & 1) {
         hipLaunchKernelGGL(ast_prepare_kernel, dim3(1), dim3(1024), 0, st, cells, F(w.one));
-        const int rows = resident_rows((tcn_conv_kernel<1, AstGeom, SN, SE>), g.B, 1 << 20);
-        hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
+        const int rows = resident_rows((tcn_conv_kernel<1, AstGeom, SN, SE, TTB>), g.B, 1 << 20, TTB);
+        hipLaunchKernelGGL((tcn_conv_kernel<1, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)nullptr,
                            F(w.z1), (float*)nullptr, cells);
         AST_RC(sync_pair(0, 0));
-        hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
+        hipLaunchKernelGGL((tcn_conv_kernel<2, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, a->x, prm, a->bn_stats, training, (const float*)F(w.z1),
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
         // gate, P projection, graph, Chebyshev terms, node sums, the filter product and the head: one launch (ast_front_kernel)
@@ -676,15 +678,15 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         // d P = dPX^T G
         fk.fork();
-        const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom, SN, SE>), g.B, w.rows);
+        const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), g.B, w.rows, TTB);
         AST_RC(sync_pair(1, 1));
-        hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
+        hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
         AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
         // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
         AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         AST_RC(sync_pair(1, 0));
-        hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom, SN, SE>), dim3(rows), dim3(AB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
+        hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
         // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)

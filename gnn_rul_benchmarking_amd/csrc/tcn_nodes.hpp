@@ -17,6 +17,11 @@ constexpr int MAXN = 25;           // nodes
 constexpr int MAXT = 64;
 constexpr int XP = MAXT + 16;        // row pitch of the convolution tiles: 16-byte row reads, room for the taps' reach on both sides
 constexpr float BN_EPS = 1e-5f;
+#ifndef TCN_UNROLL_N
+#define TCN_UNROLL_N 4
+#endif
+// the (ci | co | four-step) loops: with the shapes as constants the compiler unrolled them fully -- > 256 registers, one workgroup per CU
+constexpr int TCN_UNROLL = TCN_UNROLL_N;
 
 // reduction cells (fp64): forward sums [2 blocks][N][sum, sumsq], backward sums [2][N][sum dy, sum dy*xhat]
 struct Cells {
@@ -63,9 +68,11 @@ __device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, in
 // TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
 // One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
 // ---------------------------------------------------------------------------------------------------
-// (<SN, ST>: nodes and time steps as compile-time constants, 0 = generic: the element loops divide by T, the channel loops run to N)
-template <int STAGE, typename Geom, int SN = 0, int ST = 0>
-static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ prm,
+// (<SN, ST>: nodes and time steps as compile-time constants, 0 = generic: the element loops divide by T, the channel loops run to N;
+//  TBK: threads per workgroup -- at 20 nodes x 50 steps the work lists are 260 (node, four steps) items and 400 (co, ci) pairs: 256 threads
+//  walk them in two rounds, the second nearly empty; 448 threads take each in one)
+template <int STAGE, typename Geom, int SN = 0, int ST = 0, int TBK = AB>
+static __global__ __launch_bounds__(TBK) void tcn_conv_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                      const float* __restrict__ bn_running, int training, const float* __restrict__ z1,
                                                      float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
     constexpr int D = STAGE == 1 ? 1 : 2;
@@ -77,15 +84,15 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
     __shared__ BnCoef co1[MAXN];
     const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x;
     const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
-    for (int e = tid; e < N * N * KT; e += AB) w[e] = wsrc[e];
-    for (int e = tid; e < MAXN * XP; e += AB) (&xs[0][0])[e] = 0.f;
+    for (int e = tid; e < N * N * KT; e += TBK) w[e] = wsrc[e];
+    for (int e = tid; e < MAXN * XP; e += TBK) (&xs[0][0])[e] = 0.f;
     if (STAGE == 2 && tid < N)
         co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.BG * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
     float s1 = 0.f, s2 = 0.f;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* xb = x + b * N * T;
-        for (int e = tid; e < N * T; e += AB) {
+        for (int e = tid; e < N * T; e += TBK) {
             const int c = e / T, t = e - c * T;
             float v = xb[e];
             if (STAGE == 2) {
@@ -99,9 +106,10 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
         // four consecutive steps t per thread: the six taps of a (co, ci) pair and the 4 + 5 D inputs they meet come as 16- / 8-byte LDS
         // reads once per 24 multiply-adds (it was two 4-byte reads per multiply-add); same order of additions per output as before
         const int Q = (T + 3) / 4;
-        for (int wi = tid; wi < N * Q; wi += AB) {
+        for (int wi = tid; wi < N * Q; wi += TBK) {
             const int co = wi / Q, t0 = 4 * (wi - co * Q);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll TCN_UNROLL
             for (int ci = 0; ci < N; ++ci) {
                 const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
                 const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
@@ -147,15 +155,15 @@ static __global__ __launch_bounds__(AB) void tcn_conv_kernel(Geom g, const float
 // dy1 = ds0 [bn1(z1) > 0]; BN1 backward sums.   STAGE 1: dz1 = BN1'(dy1); dW1 += dz1 (*) x.
 // Weight-gradient accumulators are thread-owned registers (fixed order), one partial row per workgroup.
 // ---------------------------------------------------------------------------------------------------
-template <int STAGE, typename Geom, int SN = 0, int ST = 0>
-static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
+template <int STAGE, typename Geom, int SN = 0, int ST = 0, int TBK = AB>
+static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
                                                          const float* __restrict__ zin, const float* __restrict__ dyin,
                                                          const float* __restrict__ src, const float* __restrict__ ds1,
                                                          const float* __restrict__ z1, float* __restrict__ dy1,
                                                          float* __restrict__ gpart) {
     constexpr int D = STAGE == 1 ? 1 : 2;
     constexpr int PAD = (KT - 1) * D;
-    constexpr int NPAIR = (MAXN * MAXN + AB - 1) / AB;      // (co, ci) pairs per thread: all six taps of a pair in one thread
+    constexpr int NPAIR = ((SN ? SN * SN : MAXN * MAXN) + TBK - 1) / TBK;      // (co, ci) pairs per thread: all six taps of a pair in one thread
     static_assert(KT == 6, "the taps of a (co, ci) pair are read as three 8-byte pieces");
     __shared__ __attribute__((aligned(16))) float w[MAXN * MAXN * KT];
     __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];        // conv input (x or out0), left-padded with zeros (zero behind the row too)
@@ -168,8 +176,8 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     const double count = (double)g.BG * T;
     const int nW = N * N * KT;
     if (STAGE == 2)
-        for (int e = tid; e < nW; e += AB) w[e] = prm[g.o_w2 + e];
-    for (int e = tid; e < MAXN * XP; e += AB) {
+        for (int e = tid; e < nW; e += TBK) w[e] = prm[g.o_w2 + e];
+    for (int e = tid; e < MAXN * XP; e += TBK) {
         (&xs[0][0])[e] = 0.f;
         (&dz[0][0])[e] = 0.f;
     }
@@ -191,7 +199,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     float a1 = 0.f, a2 = 0.f;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
-        for (int e = tid; e < N * T; e += AB) {
+        for (int e = tid; e < N * T; e += TBK) {
             const int c = e / T, t = e - c * T;
             const int64_t idx = b * N * T + e;
             const float xh = (zin[idx] - cz[c].mean) * cz[c].inv;
@@ -204,11 +212,12 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         // per five or six LDS reads instead of 48; same order of additions per weight: t ascending, d z = 0 behind T)
 #pragma unroll
         for (int r = 0; r < NPAIR; ++r) {
-            const int p = tid + r * AB;
+            const int p = tid + r * TBK;
             if (p < N * N) {
                 const int ci = p % N, co = p / N;
                 float a6[KT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const float4* dr = reinterpret_cast<const float4*>(&dz[co][0]);
+#pragma unroll TCN_UNROLL
                 for (int q4 = 0; q4 < Q; ++q4) {
                     const float4 dv = dr[q4];
                     const float dzv[4] = {dv.x, dv.y, dv.z, dv.w};
@@ -230,11 +239,12 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
         }
         if (STAGE == 2) {
             // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
-            for (int wi = tid; wi < N * Q; wi += AB) {
+            for (int wi = tid; wi < N * Q; wi += TBK) {
                 const int ci = wi / Q, t0 = 4 * (wi - ci * Q);
                 float a4[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a4[i] = t0 + i < T ? ds1[b * N * T + ci * T + t0 + i] : 0.f;
+#pragma unroll TCN_UNROLL
                 for (int co = 0; co < N; ++co) {
                     const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
                     const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
@@ -279,7 +289,7 @@ static __global__ __launch_bounds__(AB) void tcn_conv_bwd_kernel(Geom g, const f
     float* dst = gpart + (int64_t)blockIdx.x * nW;
 #pragma unroll
     for (int r = 0; r < NPAIR; ++r) {
-        const int p = tid + r * AB;
+        const int p = tid + r * TBK;
         if (p < N * N) {
 #pragma unroll
             for (int k = 0; k < KT; ++k) dst[p * KT + k] = acc[r][k];
