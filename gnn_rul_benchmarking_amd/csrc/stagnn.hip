@@ -447,6 +447,103 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
     if (training && tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
 }
 
+// ---- TCN stage 2 on the fp32 matrix cores (Co = T = 64, Ci <= 16: tcn1 of the reference's 64-wide wirings) -------------------------
+// The stage above is scalar multiply-adds with two LDS reads each (107 us at batch 256).  Here the 1x1 down-sampling convolution is the
+// product [Co x Ci] x [Ci x T] and the dilated two-tap convolution [Co x 2 Co] x [2 Co x T] over the tile padded by two zero columns
+// (tap 1 reads column t + 2, tap 0 column t), both as v_mfma_f32_16x16x4f32: wavefront w owns the 16 columns t = 16 w .. 16 w + 15 and
+// all four row tiles; lane (kq, li) = (lane / 16, lane % 16) feeds A[m = li][k = 4 s + kq], B[k = 4 s + kq][n = li] and receives
+// C[m = 4 kq + r][n = li].  W2 sits in LDS as [Co][2 Co] at pitch 129.
+// LDS: xin[16][65] | o0p[64][67] | z[64][65] | mu[64] | istd[64] | W2s[64][129]
+constexpr int TM_C = 64, TM_P = 65, TM_PP = 67, TM_WP = 129;
+constexpr size_t TM_FWD_LDS = sizeof(float) * (16 * TM_P + TM_C * TM_PP + TM_C * TM_P + 2 * TM_C + TM_C * TM_WP);
+constexpr size_t TM_BWD_LDS = sizeof(float) * (16 * TM_P + 2 * TM_C * TM_PP + TM_C * TM_P + 6 * TM_C + TM_C * TM_WP);
+
+__host__ __device__ inline bool tg_mid_mx_ok(const TgGeom& g, int l) { return g.Co[l] == TM_C && g.T == TM_C && g.Ci[l] <= 16; }
+
+__device__ __forceinline__ f32x4t tg_mfma(float a, float b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(TB) void tg_mid_fwd_mx_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                           const float* __restrict__ bnstate, float* __restrict__ ws, int training) {
+    extern __shared__ float lds[];
+    constexpr int C = TM_C, T = TM_C, P = TM_P, PP = TM_PP, WP = TM_WP;
+    const int Ci = g.Ci[l], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float* xin = lds;                     // [16][P], rows beyond Ci zero
+    float* o0p = xin + 16 * P;            // [C][PP]: out0 at column 2 + t behind two zero columns
+    float* z = o0p + C * PP;              // [C][P]
+    float* mu = z + C * P;
+    float* istd = mu + C;
+    float* W2s = istd + C;                // [C][WP]: W2[c][(ci, k)]
+    const double cnt = (double)g.B * T;
+    bn_consts(C, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], training,
+              cnt, mu, istd);
+    stage(W2s, prm + g.o_c2_w[l], C, 2 * C, WP);
+    for (int i = tid; i < 16 * P; i += TB) xin[i] = 0.f;
+    for (int i = tid; i < C * PP; i += TB) o0p[i] = 0.f;
+    float wd[4][4];                        // A(m = c, k = ci) of the 1x1 convolution
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) wd[i][s4] = 4 * s4 + kq < Ci ? prm[g.o_ds_w[l] + (16 * i + li) * Ci + 4 * s4 + kq] : 0.f;
+    const float* gam = prm + g.o_bn_g[2 * l];
+    const float* bet = prm + g.o_bn_b[2 * l];
+    const float* dsb = prm + g.o_ds_b[l];
+    double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l + 1) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s = 0.0, q = 0.0;
+    const int t = 16 * wave + li;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * P + i % T] = xin_g[b * Ci * T + i];
+        __syncthreads();
+        {   // out0 = relu(relu(bn1(z1)) + conv1x1(x) + bias)
+            f32x4t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float bv = xin[(4 * s4 + kq) * P + t];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = tg_mfma(wd[i][s4], bv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * i + 4 * kq + r, e = c * T + t;
+                    const float y1 = fmaf((ws[g.w_z1[l] + b * C * T + e] - mu[c]) * istd[c], gam[c], bet[c]);
+                    const float v = fmaxf(fmaxf(y1, 0.f) + (acc[i][r] + dsb[c]), 0.f);
+                    o0p[c * PP + 2 + t] = v;
+                    ws[g.w_o0[l] + b * C * T + e] = v;
+                }
+        }
+        __syncthreads();
+        {   // z2 = conv2_dilation2(out0)
+            f32x4t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int s4 = 0; s4 < 32; ++s4) {
+                const int kk = 4 * s4 + kq;
+                const float bv = o0p[(kk >> 1) * PP + t + 2 * (kk & 1)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = tg_mfma(W2s[(16 * i + li) * WP + kk], bv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * i + 4 * kq + r;
+                    z[c * P + t] = acc[i][r];
+                    ws[g.w_z2[l] + b * C * T + c * T + t] = acc[i][r];
+                }
+        }
+        __syncthreads();
+        if (training && tid < C)
+#pragma unroll 8
+            for (int tt = 0; tt < T; ++tt) { const double v = z[tid * P + tt]; s += v; q += v * v; }
+    }
+    if (training && tid < C) { part[tid] = s; part[TG_CMAX + tid] = q; }
+}
+
 // ---- TCN stage 3: BN2, ReLU, + out0, ReLU -> out1; temporal encoder -> e; for the second TCN also the head and the loss terms -------
 // LDS: o1[Co*TP] | u[heads*T] | m[T] | mu[Co] | istd[Co] | red[TB] | ew[heads*Co]
 __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const float* __restrict__ prm, const float* __restrict__ bnstate,
@@ -781,6 +878,143 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
 #pragma unroll
     for (int q = 0; q < TG_WREG / 2; ++q)
         if (tid + q * TB < Co * Ci) gp[g.o_ds_w[l] + tid + q * TB] = gwd[q];
+}
+
+// ---- backward of TCN stage 2 on the fp32 matrix cores (same shapes as tg_mid_fwd_mx_kernel) ------------------------------------------
+// d W2 = dz [Co x T] x out0-taps [T x 2 Co] (32 tiles of 16 x 16, eight per wavefront, accumulated in registers over the workgroup's
+// samples), d out0 = W2^T-taps [Co x 2 Co] x dz-taps [2 Co x T], d Wd = d [Co x T] x x^T [T x Ci], d x = Wd^T [Ci x Co] x d [Co x T].
+// LDS: xin[16][65] | o0p[64][67] | dzp[64][67] (two zero columns behind) | d[64][65] | six [64] constant vectors | W2T[64][129] = W2[c][ci][k] at [ci][(c, k)]
+__global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                           const float* __restrict__ bnstate, float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    constexpr int C = TM_C, T = TM_C, P = TM_P, PP = TM_PP, WP = TM_WP;
+    const int Ci = g.Ci[l], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float* xin = lds;
+    float* o0p = xin + 16 * P;
+    float* dzp = o0p + C * PP;
+    float* d = dzp + C * PP;
+    float* mu1 = d + C * P;
+    float* istd1 = mu1 + C;
+    float* mu2 = istd1 + C;
+    float* istd2 = mu2 + C;
+    float* m1 = istd2 + C;
+    float* m2 = m1 + C;
+    float* W2T = m2 + C;
+    const double cnt = (double)g.B * T;
+    const double* bp = reinterpret_cast<const double*>(ws + g.w_bnpart);
+    bn_consts(C, bp + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu1, istd1);
+    bn_consts(C, bp + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l + 1], 1, cnt, mu2, istd2);
+    bn_bwd_means(C, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l + 1) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    for (int i = tid; i < C * C * 2; i += TB) {
+        const int k = i & 1, ci = (i >> 1) % C, c = (i >> 1) / C;
+        W2T[ci * WP + 2 * c + k] = prm[g.o_c2_w[l] + i];
+    }
+    for (int i = tid; i < 16 * P; i += TB) xin[i] = 0.f;
+    for (int i = tid; i < C * PP; i += TB) { o0p[i] = 0.f; dzp[i] = 0.f; }
+    float wdT[16];                         // A(m = ci, k = c) = Wd[c][ci]
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) wdT[s4] = li < Ci ? prm[g.o_ds_w[l] + (4 * s4 + kq) * Ci + li] : 0.f;
+    __syncthreads();
+    const float* gam1 = prm + g.o_bn_g[2 * l];
+    const float* bet1 = prm + g.o_bn_b[2 * l];
+    const float* gam2 = prm + g.o_bn_g[2 * l + 1];
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    if (blockIdx.x == 0)                                         // BatchNorm affine gradients are the batch sums themselves
+        for (int c = tid; c < C; c += TB) {
+            gp[g.o_bn_g[2 * l + 1] + c] += (float)((double)m2[c] * cnt);
+            gp[g.o_bn_b[2 * l + 1] + c] += (float)((double)m1[c] * cnt);
+        }
+    double* part = reinterpret_cast<double*>(ws + g.w_dbnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s1 = 0.0, s2 = 0.0;
+    f32x4t gw2[8], gwd = (f32x4t){0.f, 0.f, 0.f, 0.f};          // rows c = 16 wave + ..: columns (ci, k) = 16 j + li | ci = li
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gw2[j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    const int t = 16 * wave + li;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xin[(i / T) * P + i % T] = xin_g[b * Ci * T + i];
+        for (int e = tid; e < C * T; e += TB) {
+            const int c = e / T, tt = e % T;
+            o0p[c * PP + 2 + tt] = ws[g.w_o0[l] + b * C * T + e];
+            const float xh = (ws[g.w_z2[l] + b * C * T + e] - mu2[c]) * istd2[c];
+            dzp[c * PP + tt] = gam2[c] * istd2[c] * (ws[g.w_dy2[l] + b * C * T + e] - m1[c] - xh * m2[c]);
+        }
+        __syncthreads();
+        // d W2[c][(ci, k)] += sum_t dz[c][t] out0[ci][t - 2 (1 - k)]
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int tt = 4 * s4 + kq;
+            const float av = dzp[(16 * wave + li) * PP + tt];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = 16 * j + li;
+                gw2[j] = tg_mfma(av, o0p[(n >> 1) * PP + tt + 2 * (n & 1)], gw2[j]);
+            }
+        }
+        {   // d out0[ci][t] = residual path + sum_{c, k} W2[c][ci][k] dz[c][t + 2 (1 - k)]; through ReLU(out0)
+            f32x4t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int s4 = 0; s4 < 32; ++s4) {
+                const int kk = 4 * s4 + kq;
+                const float bv = dzp[(kk >> 1) * PP + t + 2 * (1 - (kk & 1))];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = tg_mfma(W2T[(16 * i + li) * WP + kk], bv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 16 * i + 4 * kq + r;
+                    const float a = acc[i][r] + ws[g.w_dres[l] + b * C * T + ci * T + t];
+                    d[ci * P + t] = o0p[ci * PP + 2 + t] > 0.f ? a : 0.f;
+                }
+        }
+        __syncthreads();
+        // d Wd[c][ci] += sum_t d[c][t] x[ci][t]
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const int tt = 4 * s4 + kq;
+            gwd = tg_mfma(d[(16 * wave + li) * P + tt], xin[li * P + tt], gwd);
+        }
+        if (tid < C) {
+            float a = 0.f;
+#pragma unroll 8
+            for (int tt = 0; tt < T; ++tt) a += d[tid * P + tt];
+            gp[g.o_ds_b[l] + tid] += a;
+        }
+        {   // d x[ci][t] = sum_c Wd[c][ci] d[c][t]
+            f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < 16; ++s4) acc = tg_mfma(wdT[s4], d[(4 * s4 + kq) * P + t], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < Ci) ws[g.w_dxin[l] + b * Ci * T + (4 * kq + r) * T + t] = acc[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < C * T; e += TB) {
+            const int c = e / T, tt = e % T;
+            const float xh = (ws[g.w_z1[l] + b * C * T + e] - mu1[c]) * istd1[c];
+            const float y1 = fmaf(xh, gam1[c], bet1[c]);
+            const float dy = y1 > 0.f ? d[c * P + tt] : 0.f;
+            ws[g.w_dy1[l] + b * C * T + e] = dy;
+            dzp[c * PP + tt] = dy;
+            o0p[c * PP + 2 + tt] = dy * xh;
+        }
+        __syncthreads();
+        if (tid < C)
+#pragma unroll 8
+            for (int tt = 0; tt < T; ++tt) { s1 += (double)dzp[tid * PP + tt]; s2 += (double)o0p[tid * PP + 2 + tt]; }
+    }
+    if (tid < C) { part[tid] = s1; part[TG_CMAX + tid] = s2; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gp[g.o_c2_w[l] + (16 * wave + 4 * kq + r) * 2 * C + 16 * j + li] = gw2[j][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (li < Ci) gp[g.o_ds_w[l] + (16 * wave + 4 * kq + r) * Ci + li] = gwd[r];
 }
 
 // ---- backward of stage 1: BN1 backward, conv1 backward -> gradient of the stage's input ---------------------------------------------
@@ -1124,6 +1358,10 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             TG_RC(tg_allow_lds(tg_mid_fwd_kernel, l2));
             TG_RC(tg_allow_lds(tg_end_fwd_kernel, l3));
             hipLaunchKernelGGL(tg_conv1_fwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, ws);
+            if (tg_mid_mx_ok(g, l)) {
+                TG_RC(tg_allow_lds(tg_mid_fwd_mx_kernel, TM_FWD_LDS));
+                hipLaunchKernelGGL(tg_mid_fwd_mx_kernel, grid, blk, TM_FWD_LDS, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, training);
+            } else
             hipLaunchKernelGGL(tg_mid_fwd_kernel, grid, blk, l2, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, training);
             hipLaunchKernelGGL(tg_end_fwd_kernel, grid, blk, l3, st, g, l, prm, (const float*)a->bn_state, ws, training, a->y, a->pred, inv_gb);
             TG_LAUNCH_OK();
@@ -1147,6 +1385,10 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             TG_RC(tg_allow_lds(tg_conv1_bwd_kernel, l1));
             // (the gradient w.r.t. a stage's input is written over w_dxin[l], which the next kernel down the chain reads)
             hipLaunchKernelGGL(tg_end_bwd_kernel, grid, blk, l3, st, g, l, prm, (const float*)a->bn_state, ws, dpred, (const float*)(ws + g.w_dxin[1]));
+            if (tg_mid_mx_ok(g, l)) {
+                TG_RC(tg_allow_lds(tg_mid_bwd_mx_kernel, TM_BWD_LDS));
+                hipLaunchKernelGGL(tg_mid_bwd_mx_kernel, grid, blk, TM_BWD_LDS, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws);
+            } else
             hipLaunchKernelGGL(tg_mid_bwd_kernel, grid, blk, l2, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws);
             hipLaunchKernelGGL(tg_conv1_bwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, ws + g.w_dxin[l]);
             TG_LAUNCH_OK();
