@@ -1083,6 +1083,116 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
         if (tid + q * TB < Co * Ci * 2) gp[g.o_c1_w[l] + tid + q * TB] = gw1[q];
 }
 
+
+// ---- backward of TCN stage 1 on the fp32 matrix cores (T = 64; any Ci, Co <= 64) ------------------------------------------------------
+// d W1 = dz [Co x T] x x-taps [T x 2 Ci] (16 x 16 tiles over the wavefronts, accumulated in registers over the workgroup's samples),
+// d x += W1^T-taps [Ci x 2 Co] x dz-taps [2 Co x T].  Operand rows are padded to 16 with zeros in LDS, so no product needs a guard.
+// LDS: xinp[CiP][67] (x at column 1 + t) | dzp[CoP][67] (zero from column 64) | mu, istd, m1, m2 [4 Co] | W1T[CiP][WPT] = W1[c][ci][k] at [ci][(c, k)]
+__host__ __device__ inline int tg_pad16(int v) { return (v + 15) / 16 * 16; }
+__host__ __device__ inline int tg_c1_wpt(int Co) { return ((2 * Co + 3) / 4 * 4) | 1; }
+__host__ __device__ inline bool tg_conv1_mx_ok(const TgGeom& g, int l) { return g.T == TM_C && g.Ci[l] <= 64 && g.Co[l] <= 64; }
+inline size_t tg_conv1_bwd_mx_lds(const TgGeom& g, int l) {
+    return sizeof(float) * ((size_t)(tg_pad16(g.Ci[l]) + tg_pad16(g.Co[l])) * TM_PP + 4 * (size_t)g.Co[l] + (size_t)tg_pad16(g.Ci[l]) * tg_c1_wpt(g.Co[l]));
+}
+
+__global__ __launch_bounds__(TB) void tg_conv1_bwd_mx_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                             const float* __restrict__ bnstate, float* __restrict__ ws, float* __restrict__ dxin_out) {
+    extern __shared__ float lds[];
+    constexpr int T = TM_C, PP = TM_PP;
+    const int Ci = g.Ci[l], Co = g.Co[l], CiP = tg_pad16(Ci), CoP = tg_pad16(Co), WPT = tg_c1_wpt(Co);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float* xinp = lds;
+    float* dzp = xinp + CiP * PP;
+    float* mu = dzp + CoP * PP;
+    float* istd = mu + Co;
+    float* m1 = istd + Co;
+    float* m2 = m1 + Co;
+    float* W1T = m2 + Co;
+    const double cnt = (double)g.B * T;
+    bn_consts(Co, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], 1, cnt, mu,
+              istd);
+    bn_bwd_means(Co, reinterpret_cast<const double*>(ws + g.w_dbnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, cnt, m1, m2);
+    for (int i = tid; i < CiP * WPT; i += TB) W1T[i] = 0.f;
+    for (int i = tid; i < (CiP + CoP) * PP; i += TB) xinp[i] = 0.f;            // xinp and dzp are adjacent
+    __syncthreads();
+    for (int i = tid; i < Co * Ci * 2; i += TB) {
+        const int k = i & 1, ci = (i >> 1) % Ci, c = (i >> 1) / Ci;
+        W1T[ci * WPT + 2 * c + k] = prm[g.o_c1_w[l] + i];
+    }
+    const float* gam = prm + g.o_bn_g[2 * l];
+    float* gp = ws + g.w_gpart + (int64_t)blockIdx.x * g.pcount;
+    if (blockIdx.x == 0)
+        for (int c = tid; c < Co; c += TB) {
+            gp[g.o_bn_g[2 * l] + c] += (float)((double)m2[c] * cnt);
+            gp[g.o_bn_b[2 * l] + c] += (float)((double)m1[c] * cnt);
+        }
+    // d W1 tiles: (row tile i of Co, column tile j of the 2 Ci (ci, k) pairs), tile q of this wavefront = wave + 4 q
+    const int NT2 = (2 * Ci + 15) / 16, ntiles = (CoP / 16) * NT2, CIT = CiP / 16, ksteps = (2 * Co + 3) / 4;
+    constexpr int MAXQ = 8;                 // 4 x 8 tiles at most (Co, Ci <= 64)
+    f32x4t gw[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) gw[q] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+    const int t = 16 * wave + li;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xinp[(i / T) * PP + 1 + i % T] = xin_g[b * Ci * T + i];
+        for (int e = tid; e < Co * T; e += TB) {
+            const int c = e / T;
+            const float xh = (ws[g.w_z1[l] + b * Co * T + e] - mu[c]) * istd[c];
+            dzp[c * PP + e % T] = gam[c] * istd[c] * (ws[g.w_dy1[l] + b * Co * T + e] - m1[c] - xh * m2[c]);
+        }
+        __syncthreads();
+        // d W1[c][(ci, k)] += sum_t dz[c][t] x[ci][t - (1 - k)]
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int idx = wave + 4 * q;
+            if (idx < ntiles) {
+                const int i = idx / NT2, n = 16 * (idx - i * NT2) + li;
+                const float* ar = dzp + (16 * i + li) * PP + kq;
+                const float* br = xinp + (n >> 1) * PP + (n & 1) + kq;
+                f32x4t acc = gw[q];
+#pragma unroll 4
+                for (int s4 = 0; s4 < T / 4; ++s4) acc = tg_mfma(ar[4 * s4], br[4 * s4], acc);
+                gw[q] = acc;
+            }
+        }
+        {   // d x[ci][t] += sum_{c, k} W1[c][ci][k] dz[c][t + (1 - k)]
+            f32x4t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+            for (int s4 = 0; s4 < ksteps; ++s4) {
+                const int kk = 4 * s4 + kq;
+                const float bv = dzp[(kk >> 1) * PP + t + 1 - (kk & 1)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < CIT) acc[i] = tg_mfma(W1T[(16 * i + li) * WPT + kk], bv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = 16 * i + 4 * kq + r;
+                    if (ci < Ci) {
+                        const int64_t at = b * Ci * T + ci * T + t;
+                        dxin_out[at] = acc[i][r] + ws[g.w_dxin[l] + at];
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int idx = wave + 4 * q;
+        if (idx < ntiles) {
+            const int i = idx / NT2, n = 16 * (idx - i * NT2) + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * i + 4 * kq + r;
+                if (c < Co && n < 2 * Ci) gp[g.o_c1_w[l] + c * 2 * Ci + n] = gw[q][r];
+            }
+        }
+    }
+}
+
 // ---- graph part, backward --------------------------------------------------------------------------------------------------------
 // LDS: adj[N*N] | ah[N*N] | dH[N*h] | dN[N*h] | H[N*h] | dhp[N*h] | AX[N*Lh] | Wg[h*hp] |
 //      G x { Wh[N*hp] | dWh[N*h] | att[N*N] | dpre[N*N] | f1[N] | f2[N] | Wb[h*hp] }
@@ -1390,6 +1500,11 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
                 hipLaunchKernelGGL(tg_mid_bwd_mx_kernel, grid, blk, TM_BWD_LDS, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws);
             } else
             hipLaunchKernelGGL(tg_mid_bwd_kernel, grid, blk, l2, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws);
+            if (tg_conv1_mx_ok(g, l)) {
+                const size_t l1m = tg_conv1_bwd_mx_lds(g, l);
+                TG_RC(tg_allow_lds(tg_conv1_bwd_mx_kernel, l1m));
+                hipLaunchKernelGGL(tg_conv1_bwd_mx_kernel, grid, blk, l1m, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, ws + g.w_dxin[l]);
+            } else
             hipLaunchKernelGGL(tg_conv1_bwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, (const float*)a->bn_state, ws, ws + g.w_dxin[l]);
             TG_LAUNCH_OK();
         }
