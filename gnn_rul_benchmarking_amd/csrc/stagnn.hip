@@ -121,15 +121,26 @@ __device__ void reduce_partials(int Co, const double* __restrict__ part, int nbl
     const int c = threadIdx.x & (TG_CMAX - 1), q = threadIdx.x / TG_CMAX;
     __syncthreads();
     if (c < Co) {
-        double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+        // eight partial rows (16 loads) requested per pass (it was two: one L2 round trip per pass, 32 passes at 256 workgroups -- a fifth of
+        // the step; sixteen rows per pass measured no better); the running sums are added in a fixed order
+        constexpr int U = 8;
+        double a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a0[u] = a1[u] = 0.0;
         int b = q;
-        for (; b + 4 < nblk; b += 8) {
-            s0 += part[(int64_t)b * 2 * TG_CMAX + c];
-            s1 += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c];
-            t0 += part[(int64_t)(b + 4) * 2 * TG_CMAX + c];
-            t1 += part[(int64_t)(b + 4) * 2 * TG_CMAX + TG_CMAX + c];
+        for (; b + 4 * (U - 1) < nblk; b += 4 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a0[u] += part[(int64_t)(b + 4 * u) * 2 * TG_CMAX + c];
+                a1[u] += part[(int64_t)(b + 4 * u) * 2 * TG_CMAX + TG_CMAX + c];
+            }
         }
-        if (b < nblk) { s0 += part[(int64_t)b * 2 * TG_CMAX + c]; s1 += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+        for (; b < nblk; b += 4) { a0[0] += part[(int64_t)b * 2 * TG_CMAX + c]; a1[0] += part[(int64_t)b * 2 * TG_CMAX + TG_CMAX + c]; }
+#pragma unroll
+        for (int w = U / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) { a0[u] += a0[u + w]; a1[u] += a1[u + w]; }
+        const double s0 = a0[0], t0 = 0.0, s1 = a1[0], t1 = 0.0;
         slice[q][c] = s0 + t0;
         slice[q][TG_CMAX + c] = s1 + t1;
     }
