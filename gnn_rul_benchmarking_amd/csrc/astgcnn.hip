@@ -111,6 +111,7 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
         for (int w = tid; w < N * Q; w += AB) {                  // gate: four columns t per thread
             const int c = w / Q, t0 = 4 * (w - c * Q);
             float zp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 10
             for (int k = 0; k < T; ++k) fma4(zp, T1[c][k], *reinterpret_cast<const float4*>(&THt[k][t0]));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
         for (int w = tid; w < N * Q; w += AB) {                  // PX = G P^T
             const int i = w / Q, c0 = 4 * (w - i * Q);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 10
             for (int k = 0; k < E; ++k) fma4(a, G[i][k], *reinterpret_cast<const float4*>(&PWt[k][c0]));
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
         if (tid < N) {
             const int j = tid;
             float uu = 0.f, vv = 0.f, ww = 0.f, c = 0.f;
+#pragma unroll 10
             for (int e = 0; e < E; ++e) {
                 const float gj = tc[j * KE + e];
                 vv = fmaf(d1[e], gj, vv);
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
         for (int wk = tid; wk < N * Q; wk += AB) {               // dG = dG_cheb + dPX P
             const int i = wk / Q, c0 = 4 * (wk - i * Q);
             float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 10
             for (int k = 0; k < E; ++k) fma4(a, DPX[i][k], *reinterpret_cast<const float4*>(&PW[k][c0]));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
