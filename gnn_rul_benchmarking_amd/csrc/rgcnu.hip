@@ -470,7 +470,7 @@ __device__ __forceinline__ float rg_row16_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * RG_MXW) void rg_scl_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+__global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                                 float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
                                                                 int64_t sample_offset) {
     __shared__ __attribute__((aligned(16))) float sm[RG_MXW * RG_MX_WAVE_FLOATS];
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64 * RG_MXW) void rg_scl_mx_kernel(RgGeom g, const 
     }
 }
 
-__global__ __launch_bounds__(64 * RG_MXW) void rg_scl_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+__global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                                     float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
                                                                     int64_t sample_offset) {
     // after the loop the wavefronts' regions are reused for the fixed-order sum of their partial gradients:
