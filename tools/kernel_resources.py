@@ -11,7 +11,7 @@ for line in out.splitlines():
     m = re.search(r"remark: [^ ]+ +(Function Name|Name): (\S+)", line) or re.search(r"(Function Name|Name): (\S+)", line)
     if m:
         name = subprocess.run(["c++filt", m.group(2)], capture_output=True, text=True).stdout.strip()
-        cur = {"name": re.sub(r"\(.*", "", name)}
+        cur = {"name": re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "").replace("rulgnn::", "").replace("void ", ""))}
         rows.append(cur)
         continue
     m = re.search(r"(SGPRs|VGPRs|AGPRs|SGPRs Spill|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
