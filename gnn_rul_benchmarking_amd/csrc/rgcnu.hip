@@ -455,9 +455,15 @@ __global__ __launch_bounds__(RB) void rg_scl_bwd_kernel(RgGeom g, const float* _
 // of A_hat are zero, so whatever the pad rows of the other operand hold never reaches a result.
 constexpr int RG_MXW = 4;                // wavefronts (graphs in flight) per workgroup
 constexpr int RG_TP = 33;                // tile pitch
-constexpr int RG_AP = 17;                // adjacency pitch
-constexpr int RG_MX_WAVE_FLOATS = 16 * RG_AP + 3 * 16 * RG_TP + 64;       // A_hat | three [16][32] tiles | four 16-vectors
+// (NT: 16-row tiles of the node axis -- 1 for the 14-node wirings, 2 for N-CMAPSS's 20 nodes; LDS per wavefront: A_hat [16 NT][16 NT + 1] |
+//  three [16 NT][33] tiles | four vectors of 16 NT)
 constexpr int RG_MXH = 32;
+__host__ __device__ constexpr int rg_mx_wave_floats(int NT) { return 16 * NT * (16 * NT + 1) + 3 * 16 * NT * RG_TP + 4 * 16 * NT; }
+__host__ __device__ constexpr int rg_mx_red_floats() { return RG_MXW * (RG_MXH * RG_MXH + 4 * 4 * RG_MXH + 32); }
+inline size_t rg_scl_mx_lds(int NT, bool bwd) {
+    const int a = RG_MXW * rg_mx_wave_floats(NT), b = bwd ? rg_mx_red_floats() : 0;
+    return sizeof(float) * (size_t)(a > b ? a : b);
+}
 
 __device__ __forceinline__ f32x4t rg_mfma(float a, float b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -470,16 +476,17 @@ __device__ __forceinline__ float rg_row16_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
-                                                                float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
-                                                                int64_t sample_offset) {
-    __shared__ __attribute__((aligned(16))) float sm[RG_MXW * RG_MX_WAVE_FLOATS];
-    constexpr int H = RG_MXH;
+template <int NT>
+__global__ __launch_bounds__(64 * RG_MXW, NT == 1 ? 4 : 2) void rg_scl_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                                                   float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
+                                                                                   int64_t sample_offset) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int H = RG_MXH, NP = 16 * NT, AP = NP + 1, WF = rg_mx_wave_floats(NT);
     const int N = g.N, L = g.L, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    float* ah = sm + wave * RG_MX_WAVE_FLOATS;      // [16][17], zero outside [N][N]
-    float* a1t = ah + 16 * RG_AP;                    // [16][33]
-    float* xs = a1t + 3 * 16 * RG_TP;                // [16]
-    float* axs = xs + 16;                            // [16]
+    float* ah = sm + wave * WF;                      // [NP][AP], zero outside [N][N]
+    float* a1t = ah + NP * AP;                       // [NP][33]
+    float* xs = a1t + 3 * NP * RG_TP;                // [NP]
+    float* axs = xs + NP;                            // [NP]
     float w1[2], b1[2], b2[2], cw[2], w2t[2][8];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -489,47 +496,57 @@ __global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, con
         for (int s4 = 0; s4 < 8; ++s4) w2t[t][s4] = prm[g.o_g2w + c * H + 4 * s4 + kq];      // B(k, n = h) = W2[h][k]
     }
     const float cb = prm[g.o_cb];
-    for (int i = lane; i < 16 * RG_AP; i += 64) ah[i] = 0.f;
+    for (int i = lane; i < NP * AP; i += 64) ah[i] = 0.f;
     __builtin_amdgcn_wave_barrier();
     const int64_t nw = (int64_t)gridDim.x * RG_MXW;
     for (int64_t gi = (int64_t)blockIdx.x * RG_MXW + wave; gi < g.G; gi += nw) {
         const int64_t b = gi / L, a = gi % g.B;                 // the adjacency this graph convolves with (Model.py:104-106)
         const int l = (int)(gi % L);
-        for (int i = lane; i < N * N; i += 64) ah[(i / N) * RG_AP + i % N] = ws[g.w_Ahat + a * N * N + i];
-        if (lane < 16) xs[lane] = lane < N ? x[(b * N + lane) * L + l] : 0.f;
+        for (int i = lane; i < N * N; i += 64) ah[(i / N) * AP + i % N] = ws[g.w_Ahat + a * N * N + i];
+        if (lane < NP) xs[lane] = lane < N ? x[(b * N + lane) * L + l] : 0.f;
         __builtin_amdgcn_wave_barrier();
-        if (lane < 16) {
+        if (lane < NP) {
             float v = 0.f;
-            for (int j = 0; j < N; ++j) v = fmaf(ah[lane * RG_AP + j], xs[j], v);
+            for (int j = 0; j < N; ++j) v = fmaf(ah[lane * AP + j], xs[j], v);
             axs[lane] = v;
             if (lane < N) ws[g.w_ax1 + gi * N + lane] = v;
         }
         __builtin_amdgcn_wave_barrier();
         // a1 = A_hat h1, h1[k][h] = relu(ax[k] w1[h] + b1[h]) formed in the B operand
         {
-            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+            f32x4t acc[NT][2];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const float av = ah[li * RG_AP + 4 * s4 + kq], axk = axs[4 * s4 + kq];
+            for (int i = 0; i < NT; ++i) acc[i][0] = acc[i][1] = (f32x4t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, fmaxf(fmaf(axk, w1[t], b1[t]), 0.f), acc[t]);
+            for (int s4 = 0; s4 < 4 * NT; ++s4) {
+                const float axk = axs[4 * s4 + kq];
+                const float h0 = fmaxf(fmaf(axk, w1[0], b1[0]), 0.f), h1v = fmaxf(fmaf(axk, w1[1], b1[1]), 0.f);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const float av = ah[(16 * i + li) * AP + 4 * s4 + kq];
+                    acc[i][0] = rg_mfma(av, h0, acc[i][0]);
+                    acc[i][1] = rg_mfma(av, h1v, acc[i][1]);
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = 4 * kq + r, h = 16 * t + li;
-                    a1t[n * RG_TP + h] = acc[t][r];
-                    if (n < N) ws[g.w_ah1 + gi * N * H + n * H + h] = acc[t][r];
-                }
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = 16 * i + 4 * kq + r, h = 16 * t + li;
+                        a1t[n * RG_TP + h] = acc[i][t][r];
+                        if (n < N) ws[g.w_ah1 + gi * N * H + n * H + h] = acc[i][t][r];
+                    }
         }
         __builtin_amdgcn_wave_barrier();
         // z2 = a1 W2^T + b2; dropout; the 1x1 convolution over the hidden axis
-        {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
             f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {
-                const float av = a1t[li * RG_TP + 4 * s4 + kq];
+                const float av = a1t[(16 * i + li) * RG_TP + 4 * s4 + kq];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, w2t[t][s4], acc[t]);
             }
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, con
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = 4 * kq + r, h = 16 * t + li;
+                    const int n = 16 * i + 4 * kq + r, h = 16 * t + li;
                     const float z = acc[t][r] + b2[t];
                     if (n < N) {
                         ws[g.w_z2 + gi * N * H + n * H + h] = z;
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = rg_row16_sum(p[r]) + cb;
-                const int n = 4 * kq + r;
+                const int n = 16 * i + 4 * kq + r;
                 if (li == 0 && n < N) ws[g.w_sp + (b * L + l) * N + n] = v;      // [sample][step][node]: the LSTM's batch-first input
             }
         }
@@ -556,24 +573,23 @@ __global__ __launch_bounds__(64 * RG_MXW, 4) void rg_scl_mx_kernel(RgGeom g, con
     }
 }
 
-__global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
-                                                                    float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
-                                                                    int64_t sample_offset) {
+template <int NT>
+__global__ __launch_bounds__(64 * RG_MXW, NT == 1 ? 3 : 2) void rg_scl_bwd_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                                                       float* __restrict__ ws, uint32_t key, uint32_t thr, float scale,
+                                                                                       int64_t sample_offset) {
     // after the loop the wavefronts' regions are reused for the fixed-order sum of their partial gradients:
-    // g2w [RG_MXW][H H] | column sums [RG_MXW][4 kinds][4 kq][H] | cb [RG_MXW][16]
-    constexpr int H = RG_MXH;
-    constexpr int RED_FLOATS = RG_MXW * (H * H + 4 * 4 * H + 16);
-    constexpr int SM_FLOATS = RG_MXW * RG_MX_WAVE_FLOATS > RED_FLOATS ? RG_MXW * RG_MX_WAVE_FLOATS : RED_FLOATS;
-    __shared__ __attribute__((aligned(16))) float sm[SM_FLOATS];
+    // g2w [RG_MXW][H H] | column sums [RG_MXW][4 kinds][4 kq][H] | cb [RG_MXW][32]
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int H = RG_MXH, NP = 16 * NT, AP = NP + 1, WF = rg_mx_wave_floats(NT);
     const int N = g.N, L = g.L, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    float* ah = sm + wave * RG_MX_WAVE_FLOATS;      // [16][17], zero outside [N][N]
-    float* dz2t = ah + 16 * RG_AP;                   // [16][33] x 3: dz2, a1, da1
-    float* a1t = dz2t + 16 * RG_TP;
-    float* da1t = a1t + 16 * RG_TP;
-    float* xs = da1t + 16 * RG_TP;                   // [16] x 4: xs, ax, dsp, dax
-    float* axs = xs + 16;
-    float* dsp = axs + 16;
-    float* dax = dsp + 16;
+    float* ah = sm + wave * WF;                      // [NP][AP], zero outside [N][N]
+    float* dz2t = ah + NP * AP;                      // [NP][33] x 3: dz2, a1, da1
+    float* a1t = dz2t + NP * RG_TP;
+    float* da1t = a1t + NP * RG_TP;
+    float* xs = da1t + NP * RG_TP;                   // [NP] x 4: xs, ax, dsp, dax
+    float* axs = xs + NP;
+    float* dsp = axs + NP;
+    float* dax = dsp + NP;
     float w1[2], b1[2], cw[2], w2b[2][8], w1k[8], b1k[8];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -590,7 +606,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
 #pragma unroll
         for (int j = 0; j < 2; ++j) g2w[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
     float gg1w[2] = {0.f, 0.f}, gg1b[2] = {0.f, 0.f}, gg2b[2] = {0.f, 0.f}, gcw[2] = {0.f, 0.f}, gcb = 0.f;
-    for (int i = lane; i < 16 * RG_AP; i += 64) ah[i] = 0.f;
+    for (int i = lane; i < NP * AP; i += 64) ah[i] = 0.f;
     __builtin_amdgcn_wave_barrier();
     // graphs over the wavefronts in a fixed stride (the grid is a function of the shape alone): every partial row sums the same graphs
     // in the same order on every run
@@ -598,8 +614,8 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
     for (int64_t gi = (int64_t)blockIdx.x * RG_MXW + wave; gi < g.G; gi += nw) {
         const int64_t b = gi / L, a = gi % g.B;
         const int l = (int)(gi % L);
-        for (int i = lane; i < N * N; i += 64) ah[(i / N) * RG_AP + i % N] = ws[g.w_Ahat + a * N * N + i];
-        if (lane < 16) {
+        for (int i = lane; i < N * N; i += 64) ah[(i / N) * AP + i % N] = ws[g.w_Ahat + a * N * N + i];
+        if (lane < NP) {
             const bool in = lane < N;
             xs[lane] = in ? x[(b * N + lane) * L + l] : 0.f;
             axs[lane] = in ? ws[g.w_ax1 + gi * N + lane] : 0.f;
@@ -608,28 +624,30 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
             gcb += d;
         }
         __builtin_amdgcn_wave_barrier();
-        // element-wise part in the result layout of the products: rows 4 kq + r, columns 16 t + li
+        // element-wise part in the result layout of the products: rows 16 i + 4 kq + r, columns 16 t + li
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 4 * kq + r, h = 16 * t + li;
-                float dz = 0.f, av = 0.f;
-                if (n < N) {
-                    const float z = ws[g.w_z2 + gi * N * H + n * H + h];
-                    av = ws[g.w_ah1 + gi * N * H + n * H + h];
-                    const float kp = rg_keep(key, thr, scale, sample_offset + b, l, n, h, g), d = dsp[n];
-                    dz = z > 0.f ? d * cw[t] * kp : 0.f;
-                    gcw[t] = fmaf(d, fmaxf(z, 0.f) * kp, gcw[t]);          // conv1d (1x1) weight: the dropped-out hidden features
-                    gg2b[t] += dz;
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * i + 4 * kq + r, h = 16 * t + li;
+                    float dz = 0.f, av = 0.f;
+                    if (n < N) {
+                        const float z = ws[g.w_z2 + gi * N * H + n * H + h];
+                        av = ws[g.w_ah1 + gi * N * H + n * H + h];
+                        const float kp = rg_keep(key, thr, scale, sample_offset + b, l, n, h, g), d = dsp[n];
+                        dz = z > 0.f ? d * cw[t] * kp : 0.f;
+                        gcw[t] = fmaf(d, fmaxf(z, 0.f) * kp, gcw[t]);          // conv1d (1x1) weight: the dropped-out hidden features
+                        gg2b[t] += dz;
+                    }
+                    dz2t[n * RG_TP + h] = dz;
+                    a1t[n * RG_TP + h] = av;
                 }
-                dz2t[n * RG_TP + h] = dz;
-                a1t[n * RG_TP + h] = av;
-            }
         __builtin_amdgcn_wave_barrier();
         // gcn2 weight gradient: g2w[h][k] += sum_n dz2[n][h] a1[n][k] (accumulators live across the graphs)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
+        for (int s4 = 0; s4 < 4 * NT; ++s4) {
             const int n = 4 * s4 + kq;
             const float d0 = dz2t[n * RG_TP + li], d1 = dz2t[n * RG_TP + 16 + li];
             const float e0 = a1t[n * RG_TP + li], e1 = a1t[n * RG_TP + 16 + li];
@@ -639,27 +657,29 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
             g2w[1][1] = rg_mfma(d1, e1, g2w[1][1]);
         }
         // d (A_hat h1) = dz2 W2
-        {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
             f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int s4 = 0; s4 < 8; ++s4) {
-                const float av = dz2t[li * RG_TP + 4 * s4 + kq];
+                const float av = dz2t[(16 * i + li) * RG_TP + 4 * s4 + kq];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, w2b[t][s4], acc[t]);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) da1t[(4 * kq + r) * RG_TP + 16 * t + li] = acc[t][r];
+                for (int r = 0; r < 4; ++r) da1t[(16 * i + 4 * kq + r) * RG_TP + 16 * t + li] = acc[t][r];
         }
         __builtin_amdgcn_wave_barrier();
         // d h1 = A_hat^T da1 through the ReLU of gcn1; its parameter gradients; d ax
-        {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
             f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
+            for (int s4 = 0; s4 < 4 * NT; ++s4) {
                 const int i = 4 * s4 + kq;
-                const float av = ah[i * RG_AP + li];
+                const float av = ah[i * AP + 16 * jt + li];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[t] = rg_mfma(av, da1t[i * RG_TP + 16 * t + li], acc[t]);
             }
@@ -668,7 +688,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float axj = axs[4 * kq + r];
+                    const float axj = axs[16 * jt + 4 * kq + r];
                     const float dz1 = fmaf(axj, w1[t], b1[t]) > 0.f ? acc[t][r] : 0.f;      // pad rows: A_hat's pad columns made acc zero
                     gg1w[t] = fmaf(dz1, axj, gg1w[t]);
                     gg1b[t] += dz1;
@@ -677,22 +697,27 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = rg_row16_sum(pd[r]);
-                if (li == 0) dax[4 * kq + r] = v;
+                if (li == 0) dax[16 * jt + 4 * kq + r] = v;
             }
         }
         __builtin_amdgcn_wave_barrier();
         // d A_hat of this graph: da1 h1^T + dax x^T
-        {
-            f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
-            const float axc = axs[li];
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4)
-                acc = rg_mfma(da1t[li * RG_TP + 4 * s4 + kq], fmaxf(fmaf(axc, w1k[s4], b1k[s4]), 0.f), acc);
-            const float xc = xs[li];
+        for (int jt = 0; jt < NT; ++jt) {
+            const float axc = axs[16 * jt + li], xc = xs[16 * jt + li];
+            float hb[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 4 * kq + r;
-                if (rr < N && li < N) ws[g.w_dAg + gi * N * N + rr * N + li] = fmaf(dax[rr], xc, acc[r]);
+            for (int s4 = 0; s4 < 8; ++s4) hb[s4] = fmaxf(fmaf(axc, w1k[s4], b1k[s4]), 0.f);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s4 = 0; s4 < 8; ++s4) acc = rg_mfma(da1t[(16 * i + li) * RG_TP + 4 * s4 + kq], hb[s4], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * i + 4 * kq + r, cc = 16 * jt + li;
+                    if (rr < N && cc < N) ws[g.w_dAg + gi * N * N + rr * N + cc] = fmaf(dax[rr], xc, acc[r]);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -701,7 +726,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
     __syncthreads();
     float* r2w = sm;                                 // [RG_MXW][H H]
     float* rcol = r2w + RG_MXW * H * H;              // [RG_MXW][4][4][H]: g1w, g1b, g2b, cw by (kq, column)
-    float* rcb = rcol + RG_MXW * 4 * 4 * H;          // [RG_MXW][16]
+    float* rcb = rcol + RG_MXW * 4 * 4 * H;          // [RG_MXW][32]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -716,7 +741,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
         c[2 * 4 * H] = gg2b[t];
         c[3 * 4 * H] = gcw[t];
     }
-    if (lane < 16) rcb[wave * 16 + lane] = gcb;
+    if (lane < 32) rcb[wave * 32 + lane] = lane < NP ? gcb : 0.f;
     __syncthreads();
     float* row = ws + g.w_partS + (int64_t)blockIdx.x * g.nS;
     const int base = g.o_g1w, tid = threadIdx.x;
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
     }
     if (tid == 0) {
         float v = 0.f;
-        for (int i = 0; i < RG_MXW * 16; ++i) v += rcb[i];
+        for (int i = 0; i < RG_MXW * 32; ++i) v += rcb[i];
         row[g.o_cb - base] = v;
     }
 }
@@ -749,22 +774,22 @@ __global__ __launch_bounds__(64 * RG_MXW, 3) void rg_scl_bwd_mx_kernel(RgGeom g,
 // see DESIGN 3i.
 constexpr int RF_E = 32, RF_K = 3, RF_PAD = 1, RF_P = 67, RF_XP = 65, RF_KE = RF_E * RF_K;      // 96 = (e, j) pairs
 
-__host__ __device__ __forceinline__ bool rg_fusion_mx_ok(const RgGeom& g) { return g.E == RF_E && g.K == RF_K && g.N <= 16 && g.L <= 64; }
+__host__ __device__ __forceinline__ bool rg_fusion_mx_ok(const RgGeom& g) { return g.E == RF_E && g.K == RF_K && g.N <= 32 && g.L <= 64; }
 
 __global__ __launch_bounds__(RB) void rg_fusion_mx_kernel(RgGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ prm, float* __restrict__ ws, float* __restrict__ pred,
                                                           float* __restrict__ stdv, float inv_gb) {
     __shared__ __attribute__((aligned(16))) float Mp[RF_E * RF_P];      // [E][67]: M at column pad + l, zero elsewhere
-    __shared__ __attribute__((aligned(16))) float xs[16 * RF_XP];       // [16][65]: x, zero rows beyond N
+    __shared__ __attribute__((aligned(16))) float xs[32 * RF_XP];       // [32][65]: x, zero rows beyond N
     __shared__ float red[2 * RB];
     constexpr int E = RF_E, P = RF_P, XP = RF_XP;
     const int N = g.N, L = g.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    float c1a[2][4], w2a[2][24], c1b[2][4], c2b[2][4];
+    float c1a[2][8], w2a[2][24], c1b[2][4], c2b[2][4];
     int boff[24];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) c1a[i][s4] = 4 * s4 + kq < N ? prm[g.o_c1w + (16 * i + li) * N + 4 * s4 + kq] : 0.f;
+        for (int s4 = 0; s4 < 8; ++s4) c1a[i][s4] = 4 * s4 + kq < N ? prm[g.o_c1w + (16 * i + li) * N + 4 * s4 + kq] : 0.f;
 #pragma unroll
         for (int s4 = 0; s4 < 24; ++s4) w2a[i][s4] = prm[g.o_c2w + (16 * i + li) * RF_KE + 4 * s4 + kq];
 #pragma unroll
@@ -772,9 +797,10 @@ __global__ __launch_bounds__(RB) void rg_fusion_mx_kernel(RgGeom g, const float*
     }
 #pragma unroll
     for (int s4 = 0; s4 < 24; ++s4) boff[s4] = ((4 * s4 + kq) / RF_K) * P + (4 * s4 + kq) % RF_K;
-    for (int i = tid; i < 16 * XP; i += RB) xs[i] = 0.f;
+    for (int i = tid; i < 32 * XP; i += RB) xs[i] = 0.f;
     for (int i = tid; i < E * P; i += RB) Mp[i] = 0.f;
     const int l = 16 * wave + li;                 // this lane's column of the time axis (operand B and the results)
+    const int nsteps = N <= 16 ? 4 : 8;           // reduction steps of the 1x1 convolution over the nodes
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
         for (int i = tid; i < N * L; i += RB) xs[(i / L) * XP + i % L] = x[b * N * L + i];
@@ -782,10 +808,12 @@ __global__ __launch_bounds__(RB) void rg_fusion_mx_kernel(RgGeom g, const float*
         {   // M = conv1x1_N(x) + LSTM output
             f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const float bv = xs[(4 * s4 + kq) * XP + l];
-                acc[0] = rg_mfma(c1a[0][s4], bv, acc[0]);
-                acc[1] = rg_mfma(c1a[1][s4], bv, acc[1]);
+            for (int s4 = 0; s4 < 8; ++s4) {
+                if (s4 < nsteps) {
+                    const float bv = xs[(4 * s4 + kq) * XP + l];
+                    acc[0] = rg_mfma(c1a[0][s4], bv, acc[0]);
+                    acc[1] = rg_mfma(c1a[1][s4], bv, acc[1]);
+                }
             }
             if (l < L) {
 #pragma unroll
@@ -850,7 +878,7 @@ __global__ __launch_bounds__(RB) void rg_fusion_bwd_mx_kernel(RgGeom g, const fl
     __shared__ __attribute__((aligned(16))) float Mp[RF_E * RF_P];      // forward M at column pad + l
     __shared__ __attribute__((aligned(16))) float d2[RF_E * RF_P];      // d M2 at column (k - 1 - pad) + l
     __shared__ __attribute__((aligned(16))) float dMs[RF_E * RF_XP];    // d M at column l
-    __shared__ __attribute__((aligned(16))) float xs[16 * RF_XP];
+    __shared__ __attribute__((aligned(16))) float xs[32 * RF_XP];
     constexpr int E = RF_E, P = RF_P, XP = RF_XP, K = RF_K, D2O = RF_K - 1 - RF_PAD;
     const int N = g.N, L = g.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     float w2d[2][24];                  // A(m = e, k = (o, j)) = W2[o][e][j]
@@ -868,13 +896,14 @@ __global__ __launch_bounds__(RB) void rg_fusion_bwd_mx_kernel(RgGeom g, const fl
 #pragma unroll
     for (int t = 0; t < 3; ++t) eoff[t] = ((16 * (wt0 + t) + li) / K) * P + (16 * (wt0 + t) + li) % K;
     f32x4t gw2[3] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
-    f32x4t gw1 = (f32x4t){0.f, 0.f, 0.f, 0.f};                           // d W1[e][n]: wavefronts 0, 1 own the row tile i = wave
+    f32x4t gw1[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};      // d W1[e][n]: wavefronts 0, 1 own the row tile i = wave; column tiles of the nodes
+    const int ntn = N <= 16 ? 1 : 2;
     float gc1b[RG_OWN], gc2b[RG_OWN], gf1w[RG_OWN], gf1b = 0.f;
 #pragma unroll
     for (int s = 0; s < RG_OWN; ++s) gc1b[s] = gc2b[s] = gf1w[s] = 0.f;
     for (int i = tid; i < E * P; i += RB) { Mp[i] = 0.f; d2[i] = 0.f; }
     for (int i = tid; i < E * XP; i += RB) dMs[i] = 0.f;
-    for (int i = tid; i < 16 * XP; i += RB) xs[i] = 0.f;
+    for (int i = tid; i < 32 * XP; i += RB) xs[i] = 0.f;
     const float* dpred = dpred_in ? dpred_in : ws + g.w_dpred;
     const int l = 16 * wave + li;
     const int ksteps = (L + 3) / 4;
@@ -925,7 +954,9 @@ __global__ __launch_bounds__(RB) void rg_fusion_bwd_mx_kernel(RgGeom g, const fl
         if (wave < 2)
             for (int s4 = 0; s4 < ksteps; ++s4) {
                 const int k = 4 * s4 + kq;
-                gw1 = rg_mfma(dMs[(16 * wave + li) * XP + k], xs[li * XP + k], gw1);
+                const float av = dMs[(16 * wave + li) * XP + k];
+                gw1[0] = rg_mfma(av, xs[li * XP + k], gw1[0]);
+                if (ntn > 1) gw1[1] = rg_mfma(av, xs[(16 + li) * XP + k], gw1[1]);
             }
         RG_FOR_OWNED(E, e, s) {
             float v = 0.f;
@@ -937,8 +968,10 @@ __global__ __launch_bounds__(RB) void rg_fusion_bwd_mx_kernel(RgGeom g, const fl
     const int base = g.o_c1w;
     if (wave < 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (li < N) row[g.o_c1w - base + (16 * wave + 4 * kq + r) * N + li] = gw1[r];
+        for (int r = 0; r < 4; ++r) {
+            if (li < N) row[g.o_c1w - base + (16 * wave + 4 * kq + r) * N + li] = gw1[0][r];
+            if (16 + li < N) row[g.o_c1w - base + (16 * wave + 4 * kq + r) * N + 16 + li] = gw1[1][r];
+        }
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -1081,16 +1114,26 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
     la.workspace = ws + g.w_lstm;
     la.workspace_bytes = bilstm_workspace_bytes(&ls);
     // the matrix-core SCL kernels give a graph to a wavefront: half the workgroups (and partial rows), twice the graphs in flight
-    const bool scl_mx = g.N <= 16 && g.H == RG_MXH;
+    const bool scl_mx = g.N <= 32 && g.H == RG_MXH;
+    const int scl_nt = g.N <= 16 ? 1 : 2;
     const int blocks = g.blocks, gblocks = scl_mx ? (g.gblocks + 1) / 2 : g.gblocks;
     const size_t lds_scl = sizeof(float) * ((size_t)g.N * g.N + 2 * g.N + 3 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
     const size_t lds_sclb = sizeof(float) * ((size_t)g.N * g.N + 4 * g.N + 5 * (size_t)g.N * g.H + (size_t)g.H * (g.H + 1));
     (void)hipGetLastError();
     if (mode & 1) {
         hipLaunchKernelGGL(rg_adj_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
-        if (scl_mx)
-            hipLaunchKernelGGL(rg_scl_mx_kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), 0, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
-        else
+        if (scl_mx) {
+            const size_t lm = rg_scl_mx_lds(scl_nt, false);
+            auto go = [&](auto kernel) {
+                static bool raised = false;                          // once per instantiation and process
+                if (lm > 48 * 1024 && !raised) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+                    raised = true;
+                }
+                hipLaunchKernelGGL(kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), lm, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+            };
+            if (scl_nt == 1) go(rg_scl_mx_kernel<1>); else go(rg_scl_mx_kernel<2>);
+        } else
         hipLaunchKernelGGL(rg_scl_kernel, dim3((unsigned)gblocks), dim3(RB), lds_scl, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         RG_RC(bilstm_forward(&ls, &la, st, 1));
@@ -1126,9 +1169,18 @@ int rgcnu_run(const rulgnn_rgcnu_shape* s, const rulgnn_rgcnu_args* a, int mode,
         if (lds_sclb > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(rg_scl_bwd_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sclb) != hipSuccess)
             return RULGNN_EHIP;
-        if (scl_mx)
-            hipLaunchKernelGGL(rg_scl_bwd_mx_kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), 0, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
-        else
+        if (scl_mx) {
+            const size_t lm = rg_scl_mx_lds(scl_nt, true);
+            auto go = [&](auto kernel) {
+                static bool raised = false;                          // once per instantiation and process
+                if (lm > 48 * 1024 && !raised) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+                    raised = true;
+                }
+                hipLaunchKernelGGL(kernel, dim3((unsigned)gblocks), dim3(64 * RG_MXW), lm, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
+            };
+            if (scl_nt == 1) go(rg_scl_bwd_mx_kernel<1>); else go(rg_scl_bwd_mx_kernel<2>);
+        } else
         hipLaunchKernelGGL(rg_scl_bwd_kernel, dim3((unsigned)gblocks), dim3(RB), lds_sclb, st, g, a->x, prm, ws, key, thr, scale, a->sample_offset);
         hipLaunchKernelGGL(rg_adj_bwd_kernel, dim3(blocks), dim3(RB), 0, st, g, a->x, prm, ws);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
