@@ -464,12 +464,12 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_kernel(TgGeom g, int l, const f
 // (tap 1 reads column t + 2, tap 0 column t), both as v_mfma_f32_16x16x4f32: wavefront w owns the 16 columns t = 16 w .. 16 w + 15 and
 // all four row tiles; lane (kq, li) = (lane / 16, lane % 16) feeds A[m = li][k = 4 s + kq], B[k = 4 s + kq][n = li] and receives
 // C[m = 4 kq + r][n = li].  W2 sits in LDS as [Co][2 Co] at pitch 129.
-// LDS: xin[16][65] | o0p[64][67] | z[64][65] | mu[64] | istd[64] | W2s[64][129]
+// LDS: xin[32][65] | o0p[64][67] | z[64][65] | mu[64] | istd[64] | W2s[64][129]
 constexpr int TM_C = 64, TM_P = 65, TM_PP = 67, TM_WP = 129;
-constexpr size_t TM_FWD_LDS = sizeof(float) * (16 * TM_P + TM_C * TM_PP + TM_C * TM_P + 2 * TM_C + TM_C * TM_WP);
-constexpr size_t TM_BWD_LDS = sizeof(float) * (16 * TM_P + 2 * TM_C * TM_PP + TM_C * TM_P + 6 * TM_C + TM_C * TM_WP);
+constexpr size_t TM_FWD_LDS = sizeof(float) * (32 * TM_P + TM_C * TM_PP + TM_C * TM_P + 2 * TM_C + TM_C * TM_WP);
+constexpr size_t TM_BWD_LDS = sizeof(float) * (32 * TM_P + 2 * TM_C * TM_PP + TM_C * TM_P + 6 * TM_C + TM_C * TM_WP);
 
-__host__ __device__ inline bool tg_mid_mx_ok(const TgGeom& g, int l) { return g.Co[l] == TM_C && g.T == TM_C && g.Ci[l] <= 16; }
+__host__ __device__ inline bool tg_mid_mx_ok(const TgGeom& g, int l) { return g.Co[l] == TM_C && g.T == TM_C && g.Ci[l] <= 32; }
 
 __device__ __forceinline__ f32x4t tg_mfma(float a, float b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_mx_kernel(TgGeom g, int l, cons
     extern __shared__ float lds[];
     constexpr int C = TM_C, T = TM_C, P = TM_P, PP = TM_PP, WP = TM_WP;
     const int Ci = g.Ci[l], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    float* xin = lds;                     // [16][P], rows beyond Ci zero
-    float* o0p = xin + 16 * P;            // [C][PP]: out0 at column 2 + t behind two zero columns
+    float* xin = lds;                     // [32][P], rows beyond Ci zero
+    float* o0p = xin + 32 * P;            // [C][PP]: out0 at column 2 + t behind two zero columns
     float* z = o0p + C * PP;              // [C][P]
     float* mu = z + C * P;
     float* istd = mu + C;
@@ -488,13 +488,14 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_mx_kernel(TgGeom g, int l, cons
     bn_consts(C, reinterpret_cast<const double*>(ws + g.w_bnpart) + (int64_t)(2 * l) * g.nblk * 2 * TG_CMAX, g.nblk, bnstate + g.bn_off[2 * l], training,
               cnt, mu, istd);
     stage(W2s, prm + g.o_c2_w[l], C, 2 * C, WP);
-    for (int i = tid; i < 16 * P; i += TB) xin[i] = 0.f;
+    for (int i = tid; i < 32 * P; i += TB) xin[i] = 0.f;
     for (int i = tid; i < C * PP; i += TB) o0p[i] = 0.f;
-    float wd[4][4];                        // A(m = c, k = ci) of the 1x1 convolution
+    float wd[4][8];                        // A(m = c, k = ci) of the 1x1 convolution
+    const int dsteps = Ci <= 16 ? 4 : 8;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) wd[i][s4] = 4 * s4 + kq < Ci ? prm[g.o_ds_w[l] + (16 * i + li) * Ci + 4 * s4 + kq] : 0.f;
+        for (int s4 = 0; s4 < 8; ++s4) wd[i][s4] = 4 * s4 + kq < Ci ? prm[g.o_ds_w[l] + (16 * i + li) * Ci + 4 * s4 + kq] : 0.f;
     const float* gam = prm + g.o_bn_g[2 * l];
     const float* bet = prm + g.o_bn_b[2 * l];
     const float* dsb = prm + g.o_ds_b[l];
@@ -510,10 +511,12 @@ __global__ __launch_bounds__(TB) void tg_mid_fwd_mx_kernel(TgGeom g, int l, cons
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const float bv = xin[(4 * s4 + kq) * P + t];
+            for (int s4 = 0; s4 < 8; ++s4) {
+                if (s4 < dsteps) {
+                    const float bv = xin[(4 * s4 + kq) * P + t];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = tg_mfma(wd[i][s4], bv, acc[i]);
+                    for (int i = 0; i < 4; ++i) acc[i] = tg_mfma(wd[i][s4], bv, acc[i]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -894,14 +897,14 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_kernel(TgGeom g, int l, const f
 // ---- backward of TCN stage 2 on the fp32 matrix cores (same shapes as tg_mid_fwd_mx_kernel) ------------------------------------------
 // d W2 = dz [Co x T] x out0-taps [T x 2 Co] (32 tiles of 16 x 16, eight per wavefront, accumulated in registers over the workgroup's
 // samples), d out0 = W2^T-taps [Co x 2 Co] x dz-taps [2 Co x T], d Wd = d [Co x T] x x^T [T x Ci], d x = Wd^T [Ci x Co] x d [Co x T].
-// LDS: xin[16][65] | o0p[64][67] | dzp[64][67] (two zero columns behind) | d[64][65] | six [64] constant vectors | W2T[64][129] = W2[c][ci][k] at [ci][(c, k)]
+// LDS: xin[32][65] | o0p[64][67] | dzp[64][67] (two zero columns behind) | d[64][65] | six [64] constant vectors | W2T[64][129] = W2[c][ci][k] at [ci][(c, k)]
 __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
                                                            const float* __restrict__ bnstate, float* __restrict__ ws) {
     extern __shared__ float lds[];
     constexpr int C = TM_C, T = TM_C, P = TM_P, PP = TM_PP, WP = TM_WP;
     const int Ci = g.Ci[l], tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     float* xin = lds;
-    float* o0p = xin + 16 * P;
+    float* o0p = xin + 32 * P;
     float* dzp = o0p + C * PP;
     float* d = dzp + C * PP;
     float* mu1 = d + C * P;
@@ -920,11 +923,14 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, cons
         const int k = i & 1, ci = (i >> 1) % C, c = (i >> 1) / C;
         W2T[ci * WP + 2 * c + k] = prm[g.o_c2_w[l] + i];
     }
-    for (int i = tid; i < 16 * P; i += TB) xin[i] = 0.f;
+    for (int i = tid; i < 32 * P; i += TB) xin[i] = 0.f;
     for (int i = tid; i < C * PP; i += TB) { o0p[i] = 0.f; dzp[i] = 0.f; }
-    float wdT[16];                         // A(m = ci, k = c) = Wd[c][ci]
+    const int cit = Ci <= 16 ? 1 : 2;      // 16-row tiles of the input channels
+    float wdT[2][16];                      // A(m = ci, k = c) = Wd[c][ci]
 #pragma unroll
-    for (int s4 = 0; s4 < 16; ++s4) wdT[s4] = li < Ci ? prm[g.o_ds_w[l] + (4 * s4 + kq) * Ci + li] : 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s4 = 0; s4 < 16; ++s4) wdT[j][s4] = 16 * j + li < Ci ? prm[g.o_ds_w[l] + (4 * s4 + kq) * Ci + 16 * j + li] : 0.f;
     __syncthreads();
     const float* gam1 = prm + g.o_bn_g[2 * l];
     const float* bet1 = prm + g.o_bn_b[2 * l];
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, cons
         }
     double* part = reinterpret_cast<double*>(ws + g.w_dbnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
     double s1 = 0.0, s2 = 0.0;
-    f32x4t gw2[8], gwd = (f32x4t){0.f, 0.f, 0.f, 0.f};          // rows c = 16 wave + ..: columns (ci, k) = 16 j + li | ci = li
+    f32x4t gw2[8], gwd[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};      // rows c = 16 wave + ..: columns (ci, k) = 16 j + li | ci = 16 j + li
 #pragma unroll
     for (int j = 0; j < 8; ++j) gw2[j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
     const int t = 16 * wave + li;
@@ -987,7 +993,9 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, cons
 #pragma unroll 4
         for (int s4 = 0; s4 < 16; ++s4) {
             const int tt = 4 * s4 + kq;
-            gwd = tg_mfma(d[(16 * wave + li) * P + tt], xin[li * P + tt], gwd);
+            const float av = d[(16 * wave + li) * P + tt];
+            gwd[0] = tg_mfma(av, xin[li * P + tt], gwd[0]);
+            if (cit > 1) gwd[1] = tg_mfma(av, xin[(16 + li) * P + tt], gwd[1]);
         }
         if (tid < C) {
             float a = 0.f;
@@ -996,12 +1004,18 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, cons
             gp[g.o_ds_b[l] + tid] += a;
         }
         {   // d x[ci][t] = sum_c Wd[c][ci] d[c][t]
-            f32x4t acc = (f32x4t){0.f, 0.f, 0.f, 0.f};
+            f32x4t acc[2] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s4 = 0; s4 < 16; ++s4) acc = tg_mfma(wdT[s4], d[(4 * s4 + kq) * P + t], acc);
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const float bv = d[(4 * s4 + kq) * P + t];
+                acc[0] = tg_mfma(wdT[0][s4], bv, acc[0]);
+                if (cit > 1) acc[1] = tg_mfma(wdT[1][s4], bv, acc[1]);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * kq + r < Ci) ws[g.w_dxin[l] + b * Ci * T + (4 * kq + r) * T + t] = acc[r];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * j + 4 * kq + r < Ci) ws[g.w_dxin[l] + b * Ci * T + (16 * j + 4 * kq + r) * T + t] = acc[j][r];
         }
         __syncthreads();
         for (int e = tid; e < C * T; e += TB) {
@@ -1024,8 +1038,10 @@ __global__ __launch_bounds__(TB) void tg_mid_bwd_mx_kernel(TgGeom g, int l, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) gp[g.o_c2_w[l] + (16 * wave + 4 * kq + r) * 2 * C + 16 * j + li] = gw2[j][r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (li < Ci) gp[g.o_ds_w[l] + (16 * wave + 4 * kq + r) * Ci + li] = gwd[r];
+    for (int r = 0; r < 4; ++r) {
+        if (li < Ci) gp[g.o_ds_w[l] + (16 * wave + 4 * kq + r) * Ci + li] = gwd[0][r];
+        if (16 + li < Ci) gp[g.o_ds_w[l] + (16 * wave + 4 * kq + r) * Ci + 16 + li] = gwd[1][r];
+    }
 }
 
 // ---- backward of stage 1: BN1 backward, conv1 backward -> gradient of the stage's input ---------------------------------------------
