@@ -1111,13 +1111,71 @@ __global__ __launch_bounds__(TB) void tg_conv1_bwd_kernel(TgGeom g, int l, const
 }
 
 
+// ---- TCN stage 1 on the fp32 matrix cores (T = 64; any Ci, Co <= 64): z1 = conv1(x) as [Co x 2 Ci] x [2 Ci x T] over the tile with one zero
+// column in front (tap 1 reads column t + 1, tap 0 column t).  LDS: xinp[CiP][67] | z[CoP][65] | W1s[CoP][WPF] = W1[c][(ci, k)], zero-padded
+__host__ __device__ inline int tg_pad16(int v) { return (v + 15) / 16 * 16; }
+__host__ __device__ inline int tg_c1_wpt(int Co) { return ((2 * Co + 3) / 4 * 4) | 1; }
+__host__ __device__ inline bool tg_conv1_mx_ok(const TgGeom& g, int l) { return g.T == TM_C && g.Ci[l] <= 64 && g.Co[l] <= 64; }
+__host__ __device__ inline int tg_c1_wpf(int Ci) { return ((2 * Ci + 3) / 4 * 4) | 1; }
+inline size_t tg_conv1_fwd_mx_lds(const TgGeom& g, int l) {
+    return sizeof(float) * ((size_t)tg_pad16(g.Ci[l]) * TM_PP + (size_t)tg_pad16(g.Co[l]) * TM_P + (size_t)tg_pad16(g.Co[l]) * tg_c1_wpf(g.Ci[l]));
+}
+
+__global__ __launch_bounds__(TB) void tg_conv1_fwd_mx_kernel(TgGeom g, int l, const float* __restrict__ xin_g, const float* __restrict__ prm,
+                                                             float* __restrict__ ws) {
+    extern __shared__ float lds[];
+    constexpr int T = TM_C, P = TM_P, PP = TM_PP;
+    const int Ci = g.Ci[l], Co = g.Co[l], CiP = tg_pad16(Ci), CoP = tg_pad16(Co), WPF = tg_c1_wpf(Ci), CT = CoP / 16, ksteps = (2 * Ci + 3) / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float* xinp = lds;
+    float* z = xinp + CiP * PP;
+    float* W1s = z + CoP * P;
+    for (int i = tid; i < CiP * PP; i += TB) xinp[i] = 0.f;
+    for (int i = tid; i < CoP * WPF; i += TB) {
+        const int r = i / WPF, c = i - r * WPF;
+        W1s[i] = r < Co && c < 2 * Ci ? prm[g.o_c1_w[l] + r * 2 * Ci + c] : 0.f;
+    }
+    double* part = reinterpret_cast<double*>(ws + g.w_bnpart) + ((int64_t)(2 * l) * g.nblk + blockIdx.x) * 2 * TG_CMAX;
+    double s = 0.0, q = 0.0;                                       // thread c < Co: sums of channel c over this workgroup's samples
+    const int t = 16 * wave + li;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < Ci * T; i += TB) xinp[(i / T) * PP + 1 + i % T] = xin_g[b * Ci * T + i];
+        __syncthreads();
+        {
+            f32x4t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+            for (int s4 = 0; s4 < ksteps; ++s4) {
+                const int kk = 4 * s4 + kq;
+                const float bv = xinp[(kk >> 1) * PP + t + (kk & 1)];          // rows beyond Ci meet zero weights (and exist: CiP >= Ci + 1 or 2 Ci % 4 == 0)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < CT) acc[i] = tg_mfma(W1s[(16 * i + li) * WPF + kk], bv, acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * i + 4 * kq + r;
+                    if (c < Co) {
+                        z[c * P + t] = acc[i][r];
+                        ws[g.w_z1[l] + b * Co * T + c * T + t] = acc[i][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (tid < Co)
+#pragma unroll 8
+            for (int tt = 0; tt < T; ++tt) { const double v = z[tid * P + tt]; s += v; q += v * v; }
+    }
+    if (tid < Co) { part[tid] = s; part[TG_CMAX + tid] = q; }
+}
+
 // ---- backward of TCN stage 1 on the fp32 matrix cores (T = 64; any Ci, Co <= 64) ------------------------------------------------------
 // d W1 = dz [Co x T] x x-taps [T x 2 Ci] (16 x 16 tiles over the wavefronts, accumulated in registers over the workgroup's samples),
 // d x += W1^T-taps [Ci x 2 Co] x dz-taps [2 Co x T].  Operand rows are padded to 16 with zeros in LDS, so no product needs a guard.
 // LDS: xinp[CiP][67] (x at column 1 + t) | dzp[CoP][67] (zero from column 64) | mu, istd, m1, m2 [4 Co] | W1T[CiP][WPT] = W1[c][ci][k] at [ci][(c, k)]
-__host__ __device__ inline int tg_pad16(int v) { return (v + 15) / 16 * 16; }
-__host__ __device__ inline int tg_c1_wpt(int Co) { return ((2 * Co + 3) / 4 * 4) | 1; }
-__host__ __device__ inline bool tg_conv1_mx_ok(const TgGeom& g, int l) { return g.T == TM_C && g.Ci[l] <= 64 && g.Co[l] <= 64; }
 inline size_t tg_conv1_bwd_mx_lds(const TgGeom& g, int l) {
     return sizeof(float) * ((size_t)(tg_pad16(g.Ci[l]) + tg_pad16(g.Co[l])) * TM_PP + 4 * (size_t)g.Co[l] + (size_t)tg_pad16(g.Ci[l]) * tg_c1_wpt(g.Co[l]));
 }
@@ -1494,6 +1552,11 @@ int stagnn_run(const rulgnn_stagnn_shape* s, const rulgnn_stagnn_args* a, int mo
             TG_RC(tg_allow_lds(tg_conv1_fwd_kernel, l1));
             TG_RC(tg_allow_lds(tg_mid_fwd_kernel, l2));
             TG_RC(tg_allow_lds(tg_end_fwd_kernel, l3));
+            if (tg_conv1_mx_ok(g, l)) {
+                const size_t l1m = tg_conv1_fwd_mx_lds(g, l);
+                TG_RC(tg_allow_lds(tg_conv1_fwd_mx_kernel, l1m));
+                hipLaunchKernelGGL(tg_conv1_fwd_mx_kernel, grid, blk, l1m, st, g, l, stage_in[l], prm, ws);
+            } else
             hipLaunchKernelGGL(tg_conv1_fwd_kernel, grid, blk, l1, st, g, l, stage_in[l], prm, ws);
             if (tg_mid_mx_ok(g, l)) {
                 TG_RC(tg_allow_lds(tg_mid_fwd_mx_kernel, TM_FWD_LDS));
