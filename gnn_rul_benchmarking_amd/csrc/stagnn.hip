@@ -598,19 +598,22 @@ __global__ __launch_bounds__(TB) void tg_end_fwd_kernel(TgGeom g, int l, const f
             ws[g.w_es[l] + (b * Hd + hd) * T + t] = sg;
         }
         __syncthreads();
-        if (tid < Hd) {
-            float mx = -INFINITY;
-#pragma unroll 8
-            for (int t = 0; t < T; ++t) mx = fmaxf(mx, u[tid * T + t]);
-            float sum = 0.f;
-#pragma unroll 8
-            for (int t = 0; t < T; ++t) sum += expf(u[tid * T + t] - mx);
-            const float inv = 1.0f / sum;
-#pragma unroll 8
-            for (int t = 0; t < T; ++t) {
-                const float w = expf(u[tid * T + t] - mx) * inv;
-                u[tid * T + t] = w;
-                ws[g.w_ew[l] + (b * Hd + tid) * T + t] = w;
+        {   // softmax over the T steps of a head: one wavefront per head, a lane per step (T <= 64) -- three threads walked it alone before
+            const int hd = tid >> 6, lane = tid & 63;
+            if (hd < Hd) {
+                const float v = lane < T ? u[hd * T + lane] : -INFINITY;
+                float mx = v;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                const float ex = lane < T ? expf(v - mx) : 0.f;
+                float sum = ex;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                if (lane < T) {
+                    const float w = ex * (1.0f / sum);
+                    u[hd * T + lane] = w;
+                    ws[g.w_ew[l] + (b * Hd + hd) * T + lane] = w;
+                }
             }
         }
         __syncthreads();
