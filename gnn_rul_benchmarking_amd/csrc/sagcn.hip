@@ -99,27 +99,30 @@ int sg_geometry(const rulgnn_sagcn_shape* s, SgGeom* g) {
 }
 
 // ---- block reductions over GB threads, K values at once, fixed order ------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void block_sum(float (&v)[K], float* red) {          // red: K * GB floats
+template <int K, int TBS = GB>
+__device__ __forceinline__ void block_sum(float (&v)[K], float* red) {          // red: K * TBS floats
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) red[k * GB + threadIdx.x] = v[k];
+    for (int k = 0; k < K; ++k) red[k * TBS + threadIdx.x] = v[k];
     __syncthreads();
-    for (int m = GB / 2; m > 0; m >>= 1) {
+    for (int m = TBS / 2; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) red[k * GB + threadIdx.x] += red[k * GB + threadIdx.x + m];
+            for (int k = 0; k < K; ++k) red[k * TBS + threadIdx.x] += red[k * TBS + threadIdx.x + m];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = red[k * GB];
+    for (int k = 0; k < K; ++k) v[k] = red[k * TBS];
     __syncthreads();
 }
 
 // ---- kernel 1: the 20 statistics of every patch (Model.py:17-52) -----------------------------------------------------------------
 // dynamic LDS: s[n] | cos[n] | sin[n] | power of the half spectrum [nh] | red[7 * GB]
-__global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const float* __restrict__ x, float* __restrict__ raw) {
+// (TBS: threads per workgroup -- a patch is n <= 64 values at the reference's wirings (20): one wavefront per patch keeps four times the patches
+// in flight per CU and its barriers cost nothing; 256 threads per patch left 236 of them idle in every loop)
+template <int TBS>
+__global__ __launch_bounds__(TBS) void sg_patch_features_kernel(SgGeom g, const float* __restrict__ x, float* __restrict__ raw) {
     extern __shared__ float lds[];
     const int n = g.n, nh = g.nh, tid = threadIdx.x;
     float* s = lds;
@@ -127,8 +130,8 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
     float* ts = tc + n;
     float* pw = ts + n;
     float* red = pw + nh;
-    int* ired = reinterpret_cast<int*>(red + 6 * GB);
-    for (int j = tid; j < n; j += GB) {
+    int* ired = reinterpret_cast<int*>(red + 6 * TBS);
+    for (int j = tid; j < n; j += TBS) {
         const double a = 2.0 * (double)j / (double)n;
         tc[j] = (float)cospi(a);
         ts[j] = (float)sinpi(a);
@@ -137,30 +140,30 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
     for (int64_t patch = blockIdx.x; patch < g.R; patch += gridDim.x) {
         __syncthreads();
         const float* xp = x + patch * n;
-        for (int j = tid; j < n; j += GB) s[j] = xp[j];
+        for (int j = tid; j < n; j += TBS) s[j] = xp[j];
         __syncthreads();
         // pass A: extrema and first moments
         float mx = -INFINITY, mn = INFINITY;
         float a4[4] = {0.f, 0.f, 0.f, 0.f};                          // sum s, sum s^2, sum asin, sum atan
-        for (int j = tid; j < n; j += GB) {
+        for (int j = tid; j < n; j += TBS) {
             const float v = s[j];
             mx = fmaxf(mx, v); mn = fminf(mn, v);
             a4[0] += v; a4[1] = fmaf(v, v, a4[1]);
             a4[2] += asinf(fminf(fmaxf(v, -1.f + 1e-7f), 1.f - 1e-7f));
             a4[3] += atanf(v);
         }
-        red[tid] = mx; red[GB + tid] = mn;
+        red[tid] = mx; red[TBS + tid] = mn;
         __syncthreads();
-        for (int m = GB / 2; m > 0; m >>= 1) {
-            if (tid < m) { red[tid] = fmaxf(red[tid], red[tid + m]); red[GB + tid] = fminf(red[GB + tid], red[GB + tid + m]); }
+        for (int m = TBS / 2; m > 0; m >>= 1) {
+            if (tid < m) { red[tid] = fmaxf(red[tid], red[tid + m]); red[TBS + tid] = fminf(red[TBS + tid], red[TBS + tid + m]); }
             __syncthreads();
         }
-        mx = red[0]; mn = red[GB];
-        block_sum<4>(a4, red);
+        mx = red[0]; mn = red[TBS];
+        block_sum<4, TBS>(a4, red);
         const float mean = a4[0] * inv_n, ma = a4[2] * inv_n, mt = a4[3] * inv_n;
         // pass B: central moments, entropy of softmax(s), spread of asin / atan
         float b7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int j = tid; j < n; j += GB) {
+        for (int j = tid; j < n; j += TBS) {
             const float v = s[j], d = v - mean, d2 = d * d, z = v - mx, e = expf(z);
             b7[0] += d2; b7[1] = fmaf(d2, d, b7[1]); b7[2] = fmaf(d2, d2, b7[2]);
             b7[3] += e; b7[4] = fmaf(e, z, b7[4]);
@@ -169,9 +172,9 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
         }
         {
             float lo[4] = {b7[0], b7[1], b7[2], b7[3]};
-            block_sum<4>(lo, red);
+            block_sum<4, TBS>(lo, red);
             float hi[3] = {b7[4], b7[5], b7[6]};
-            block_sum<3>(hi, red);
+            block_sum<3, TBS>(hi, red);
             b7[0] = lo[0]; b7[1] = lo[1]; b7[2] = lo[2]; b7[3] = lo[3]; b7[4] = hi[0]; b7[5] = hi[1]; b7[6] = hi[2];
         }
         const float var = b7[0] / (fn - 1.f), sd = sqrtf(var);
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
         int kmax = 0;
         float c3[3] = {0.f, 0.f, 0.f};                               // sum of the mirrored power, of its square, and the Nyquist bin's power
         __syncthreads();
-        for (int k = tid; k < nh; k += GB) {
+        for (int k = tid; k < nh; k += TBS) {
             float re = 0.f, im = 0.f;
             int idx = 0;
             for (int t = 0; t < n; ++t) {
@@ -200,10 +203,10 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
             if (2 * k == n) c3[2] = p;
             if (amp > amax) { amax = amp; kmax = k; }
         }
-        block_sum<3>(c3, red);
+        block_sum<3, TBS>(c3, red);
         red[tid] = amax; ired[tid] = kmax;
         __syncthreads();
-        for (int m = GB / 2; m > 0; m >>= 1) {
+        for (int m = TBS / 2; m > 0; m >>= 1) {
             if (tid < m) {
                 const float o = red[tid + m];
                 const int ko = ired[tid + m];
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
         __syncthreads();
         // the bin at rank n / 2 of the stably sorted mirrored power
         int median_bin = -1;
-        for (int k = tid; k < n; k += GB) {
+        for (int k = tid; k < n; k += TBS) {
             const float p = pw[k < nh ? k : n - k];
             int rank = 0;
             for (int j = 0; j < n; ++j) {
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(GB) void sg_patch_features_kernel(SgGeom g, const f
         }
         ired[tid] = median_bin;
         __syncthreads();
-        for (int m = GB / 2; m > 0; m >>= 1) {
+        for (int m = TBS / 2; m > 0; m >>= 1) {
             if (tid < m) ired[tid] = max(ired[tid], ired[tid + m]);
             __syncthreads();
         }
@@ -530,7 +533,11 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
         const size_t lds1 = sizeof(float) * ((size_t)3 * g.n + g.nh + 7 * GB);
         const size_t lds2 = sizeof(float) * ((size_t)P * (SG_F + 1) + 2 * P + GB);
         if (lds1 > 64 * 1024 || lds2 > 64 * 1024) return RULGNN_EUNSUPPORTED;
-        hipLaunchKernelGGL(sg_patch_features_kernel, dim3((unsigned)(g.R < 16384 ? g.R : 16384)), dim3(GB), lds1, st, g, a->x, ws + g.w_raw);
+        if (g.n <= 64) {
+            const size_t lw = sizeof(float) * ((size_t)3 * g.n + g.nh + 7 * 64);
+            hipLaunchKernelGGL(sg_patch_features_kernel<64>, dim3((unsigned)(g.R < 65536 ? g.R : 65536)), dim3(64), lw, st, g, a->x, ws + g.w_raw);
+        } else
+        hipLaunchKernelGGL(sg_patch_features_kernel<GB>, dim3((unsigned)(g.R < 16384 ? g.R : 16384)), dim3(GB), lds1, st, g, a->x, ws + g.w_raw);
         hipLaunchKernelGGL(sg_graph_kernel, dim3((unsigned)(g.B < 4096 ? g.B : 4096)), dim3(GB), lds2, st, g, (const float*)(ws + g.w_raw),
                            ws + g.w_feat, ws + g.w_ax);
         SG_LAUNCH_OK();
