@@ -389,14 +389,32 @@ __global__ __launch_bounds__(64) void sg_attn_head_kernel(SgGeom g, float* __res
         float acc = 0.f;
         if (h < H) {
             const int64_t c = b * H + h;
+            // online softmax over the patches, eight rows per rescale: the eight loads are in flight together and the running sum is rescaled
+            // once per group (it was one load, two exponentials and a dependent rescale per patch)
             float m = -INFINITY, sum = 0.f;
-            for (int p = 0; p < P; ++p) {
-                const float v = attn[p * g.BH + c] + bs[p];
+            int p0 = 0;
+            for (; p0 + 7 < P; p0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = attn[(p0 + u) * g.BH + c] + bs[p0 + u];
+                float cm = v[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) cm = fmaxf(cm, v[u]);
+                const float mn = fmaxf(m, cm);
+                float e = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e += expf(v[u] - mn);
+                sum = sum * expf(m - mn) + e;
+                m = mn;
+            }
+            for (; p0 < P; ++p0) {
+                const float v = attn[p0 * g.BH + c] + bs[p0];
                 const float mn = fmaxf(m, v);
                 sum = sum * expf(m - mn) + expf(v - mn);
                 m = mn;
             }
             const float inv = 1.0f / sum;
+#pragma unroll 8
             for (int p = 0; p < P; ++p) {
                 const float a = expf(attn[p * g.BH + c] + bs[p] - m) * inv;
                 attn[p * g.BH + c] = a;
