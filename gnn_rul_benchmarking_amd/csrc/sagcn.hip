@@ -323,6 +323,126 @@ __global__ __launch_bounds__(GB) void sg_graph_kernel(SgGeom g, const float* __r
 }
 
 // v[r][c] = act(v[r][c] + bias[c])     act: 0 none, 1 ReLU
+// The same kernel with its two [P x P] passes on the fp32 matrix cores (P a multiple of 16, P <= 128: the reference's 128-patch wirings).
+// Above, 128 of the 256 threads each walked 128 x 40 multiply-adds for the degree and 128 x 80 for the aggregation, recomputing the cosine
+// matrix in between (101 us for 100 samples).  Here C = Fh Fh^T (Fh: rows scaled to unit length) is formed once, as 16 x 16 tiles of
+// v_mfma_f32_16x16x4f32, and kept in LDS; the aggregation A_hat F is a second product whose A operand is formed from C and the degrees on the
+// fly.  Lane (kq, li) = (lane / 16, lane % 16) feeds A[m = li][k = 4 s + kq] and B[k = 4 s + kq][n = li] and receives C[m = 4 kq + r][n = li].
+// LDS: F[P][41] | Fh[P][41] (+ 8 floats so that the last row's columns 40..47 exist) | nrm[P] | dinv[P] | red[GB] | C[P][P + 1]
+__device__ __forceinline__ f32x4t sg_mfma(float a, float b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+inline size_t sg_graph_mx_lds(int P) {
+    const size_t ctile = (size_t)P * (P + 1), csums = (size_t)2 * P * SG_RAW;      // the C tile also holds the fp64 running sums [P][SG_RAW] first
+    return sizeof(float) * ((size_t)2 * P * (SG_F + 1) + 8 + 2 * P + GB + (ctile > csums ? ctile : csums));
+}
+
+__global__ __launch_bounds__(GB) void sg_graph_mx_kernel(SgGeom g, const float* __restrict__ raw, float* __restrict__ feat,
+                                                         float* __restrict__ ax) {
+    extern __shared__ float lds[];
+    constexpr int LD = SG_F + 1;
+    const int P = g.P, PT = P / 16, CP = P + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    float* F = lds;
+    float* Fh = F + P * LD;
+    float* nrm = Fh + P * LD + 8;
+    float* dinv = nrm + P;
+    float* red = dinv + P;
+    float* Cm = red + GB;
+    for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        // the running sums stay a sequential fp64 chain per feature (c / sqrt|c| amplifies their rounding near the zero crossings), but only the
+        // additions: the square roots and divisions -- 128 dependent fp64 pairs on 20 threads before -- are taken by all threads afterwards
+        double* cs = reinterpret_cast<double*>(Cm);                   // [P][SG_RAW], over the (not yet used) C tile; 8-byte aligned: every term above is even
+        if (tid < SG_RAW) {
+            double c = 0.0;
+            for (int p = 0; p < P; ++p) {
+                const float v = raw[(b * P + p) * SG_RAW + tid];
+                c += (double)v;
+                F[p * LD + tid] = v;
+                cs[p * SG_RAW + tid] = c;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < P * SG_RAW; i += GB) {
+            const double c = cs[i];
+            F[(i / SG_RAW) * LD + SG_RAW + i % SG_RAW] = (float)(c / sqrt(fmax(fabs(c), 1e-12)));
+        }
+        __syncthreads();
+        float q[1] = {0.f};
+        for (int i = tid; i < P * SG_F; i += GB) { const float v = F[(i / SG_F) * LD + i % SG_F]; q[0] = fmaf(v, v, q[0]); }
+        block_sum<1>(q, red);
+        const float inv = 1.0f / sqrtf(q[0]);
+        for (int i = tid; i < P * SG_F; i += GB) {
+            const float v = F[(i / SG_F) * LD + i % SG_F] * inv;
+            F[(i / SG_F) * LD + i % SG_F] = v;
+            feat[b * P * SG_F + i] = v;
+        }
+        __syncthreads();
+        for (int p = tid; p < P; p += GB) {
+            float a = 0.f;
+            for (int f = 0; f < SG_F; ++f) a = fmaf(F[p * LD + f], F[p * LD + f], a);
+            nrm[p] = sqrtf(a);
+        }
+        __syncthreads();
+        for (int i = tid; i < P * LD + 8; i += GB) {
+            const int p = i / LD, f = i - p * LD;
+            Fh[i] = p < P && f < SG_F ? F[p * LD + f] / nrm[p] : 0.f;
+        }
+        __syncthreads();
+        // C = Fh Fh^T: row tiles wave, wave + 4 of this wavefront, every column tile
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = wave + 4 * ii;
+            if (i < PT) {
+                f32x4t acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+                for (int s4 = 0; s4 < SG_F / 4; ++s4) {
+                    const float av = Fh[(16 * i + li) * LD + 4 * s4 + kq];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < PT) acc[j] = sg_mfma(av, Fh[(16 * j + li) * LD + 4 * s4 + kq], acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < PT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Cm[(16 * i + 4 * kq + r) * CP + 16 * j + li] = acc[j][r];
+                    }
+            }
+        }
+        __syncthreads();
+        for (int p = tid; p < P; p += GB) {
+            float rs = 1.f;                                           // the self loop
+            for (int o = 0; o < P; ++o) rs += Cm[p * CP + o];
+            dinv[p] = 1.0f / sqrtf(rs);                               // a non-positive degree gives NaN, like ** -0.5
+        }
+        __syncthreads();
+        // AX = A_hat F, A_hat[p][o] = (C[p][o] + [p == o]) dinv[p] dinv[o]; feature columns 40..47 of the third tile are discarded
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = wave + 4 * ii;
+            if (i < PT) {
+                f32x4t acc[3] = {(f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}, (f32x4t){0.f, 0.f, 0.f, 0.f}};
+                const int pr = 16 * i + li;
+                const float dp = dinv[pr];
+                for (int s4 = 0; s4 < P / 4; ++s4) {
+                    const int o = 4 * s4 + kq;
+                    const float av = (Cm[pr * CP + o] + (o == pr ? 1.f : 0.f)) * dp * dinv[o];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[j] = sg_mfma(av, F[o * LD + 16 * j + li], acc[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pp = 16 * i + 4 * kq + r, f = 16 * j + li;
+                        if (f < SG_F) ax[((int64_t)pp * g.B + b) * SG_F + f] = acc[j][r];
+                    }
+            }
+        }
+    }
+}
+
 __global__ void sg_bias_cols_kernel(float* __restrict__ v, const float* __restrict__ bias, int64_t rows, int cols, int act) {
     const int64_t tot = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
@@ -556,6 +676,16 @@ int sagcn_run(const rulgnn_sagcn_shape* s, const rulgnn_sagcn_args* a, int mode,
             hipLaunchKernelGGL(sg_patch_features_kernel<64>, dim3((unsigned)(g.R < 65536 ? g.R : 65536)), dim3(64), lw, st, g, a->x, ws + g.w_raw);
         } else
         hipLaunchKernelGGL(sg_patch_features_kernel<GB>, dim3((unsigned)(g.R < 16384 ? g.R : 16384)), dim3(GB), lds1, st, g, a->x, ws + g.w_raw);
+        if (P % 16 == 0 && P <= 128) {
+            const size_t lm = sg_graph_mx_lds(P);
+            static bool raised = false;
+            if (lm > 48 * 1024 && !raised) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sg_graph_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                raised = true;
+            }
+            hipLaunchKernelGGL(sg_graph_mx_kernel, dim3((unsigned)(g.B < 4096 ? g.B : 4096)), dim3(GB), lm, st, g, (const float*)(ws + g.w_raw),
+                           ws + g.w_feat, ws + g.w_ax);
+        } else
         hipLaunchKernelGGL(sg_graph_kernel, dim3((unsigned)(g.B < 4096 ? g.B : 4096)), dim3(GB), lds2, st, g, (const float*)(ws + g.w_raw),
                            ws + g.w_feat, ws + g.w_ax);
         SG_LAUNCH_OK();
