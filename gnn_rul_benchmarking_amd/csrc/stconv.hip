@@ -544,10 +544,14 @@ int stconv_run(const rulgnn_stconv_shape* s, const rulgnn_astgcnn_args* a, int m
         SC_RC(sgemm_splitk(one, 0, 0, F(w.gpre), 1, T, gr + g.o_gb, T, 1, T, M, false, split, st));
         {
             const int nW = N * N * KT;
-            SC_RC(rows_sum(F(w.gp1), rows, nW, nW, gr + g.o_w1, st));
-            SC_RC(rows_sum(F(w.gp2), rows, nW, nW, gr + g.o_w2, st));
-            SC_RC(rows_sum(F(w.gp3), rows, nW + N, nW, gr + g.o_cw, st));
-            SC_RC(rows_sum(F(w.gp3) + nW, rows, nW + N, N, gr + g.o_cb, st));
+            if (g.o_cb == g.o_cw + nW) {       // the convolution's weight and bias are neighbours in the flat buffer as in the partial rows: one launch for all
+                SC_RC(rows_sum3(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, nW, nW, F(w.gp3), gr + g.o_cw, nullptr, rows, nW + N, nW + N, st));
+            } else {
+                SC_RC(rows_sum(F(w.gp1), rows, nW, nW, gr + g.o_w1, st));
+                SC_RC(rows_sum(F(w.gp2), rows, nW, nW, gr + g.o_w2, st));
+                SC_RC(rows_sum(F(w.gp3), rows, nW + N, nW, gr + g.o_cw, st));
+                SC_RC(rows_sum(F(w.gp3) + nW, rows, nW + N, N, gr + g.o_cb, st));
+            }
         }
         hipLaunchKernelGGL(sc_finalize_kernel, dim3((N + 4 + AB - 1) / AB), dim3(AB), 0, st, g, (const Cells*)cells, (const Cells3*)c3, gr);
         if (!a->dpred && a->loss)
