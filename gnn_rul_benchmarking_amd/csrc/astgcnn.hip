@@ -332,18 +332,24 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
             else d2v[e - 2 * E] = a;
         }
         __syncthreads();
-        if (tid < N) {
-            const int j = tid;
-            float uu = 0.f, vv = 0.f, ww = 0.f, c = 0.f;
-#pragma unroll 10
-            for (int e = 0; e < E; ++e) {
-                const float gj = tc[j * KE + e];
-                vv = fmaf(d1[e], gj, vv);
-                ww = fmaf(d2v[e], gj, ww);
-                if (g.K > 2) uu = fmaf(d2v[e], tc[j * KE + E + e], uu);
+        {   // per node j: three products over the E channels of its (global) Chebyshev rows and a column sum of A -- eight lanes per node and
+            // xor-shuffles (N threads walked 2-3 E dependent global loads each while the other 236 waited)
+            const int j = tid >> 3, l8 = tid & 7;
+            if (j < N) {
+                float uu = 0.f, vv = 0.f, ww = 0.f, c = 0.f;
+                for (int e = l8; e < E; e += 8) {
+                    const float gj = tc[j * KE + e];
+                    vv = fmaf(d1[e], gj, vv);
+                    ww = fmaf(d2v[e], gj, ww);
+                    if (g.K > 2) uu = fmaf(d2v[e], tc[j * KE + E + e], uu);
+                }
+                for (int i = l8; i < N; i += 8) c += A[i][j];
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    uu += __shfl_xor(uu, o, 64); vv += __shfl_xor(vv, o, 64); ww += __shfl_xor(ww, o, 64); c += __shfl_xor(c, o, 64);
+                }
+                if (l8 == 0) { u[j] = uu; v[j] = vv; w[j] = ww; cs[j] = c; }
             }
-            for (int i = 0; i < N; ++i) c += A[i][j];
-            u[j] = uu; v[j] = vv; w[j] = ww; cs[j] = c;
         }
         __syncthreads();
         if (tid < N) {
