@@ -70,7 +70,10 @@ def keep_mask(m, bs, cfg, step, p, offset=0):
 
 @pytest.mark.parametrize("N,L,H,E,k,alpha,bs,lo", [(14, 50, 32, 32, 3, 1.0, 100, 0.0), (20, 50, 32, 32, 3, 1.0, 33, -1.0),
                                                   (5, 12, 6, 8, 3, 0.7, 9, 0.0), (32, 64, 64, 64, 1, 0.5, 3, 0.0),
-                                                  (7, 9, 10, 12, 5, 1.3, 1, 0.0), (14, 50, 32, 32, 3, 1.0, 700, 0.0)])
+                                                  (7, 9, 10, 12, 5, 1.3, 1, 0.0), (14, 50, 32, 32, 3, 1.0, 700, 0.0),
+                                                  # the matrix-core kernels at their tile edges: 16 | 17 | 32 nodes, 64 steps, a short sequence
+                                                  (16, 50, 32, 32, 3, 1.0, 9, 0.0), (17, 20, 32, 32, 3, 0.8, 11, -1.0), (32, 64, 32, 32, 3, 0.5, 5, 0.0),
+                                                  (3, 7, 32, 32, 3, 1.0, 6, 0.0)])
 def test_training_step_with_dropout_matches_oracle(N, L, H, E, k, alpha, bs, lo):
     cfg = dict(num_nodes=N, time_length=L, hidden_dim=H, encoder_hidden_dim=E, kernel_size=k, alpha=alpha)
     rng = np.random.default_rng(N * 100 + bs)

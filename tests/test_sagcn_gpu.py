@@ -73,7 +73,7 @@ def test_forward_and_gradients_match_reference_golden(name):
 
 
 @pytest.mark.parametrize("P,n,H,Ah,bs", [(160, 16, 100, 100, 12), (128, 20, 1000, 200, 3), (32, 1024, 1000, 100, 2), (5, 33, 7, 3, 9), (256, 3, 4, 4, 1),
-                                        (1, 64, 16, 8, 4)])
+                                        (1, 64, 16, 8, 4), (16, 8, 12, 6, 4), (48, 20, 30, 10, 3), (64, 64, 24, 8, 2)])
 def test_training_step_matches_oracle(P, n, H, Ah, bs):
     # (patches of 2 points are accepted but not compared: their skewness is an exact zero whose rounding residue the cumulative
     #  feature c / sqrt|c| turns into 1e-4-sized noise -- in the reference's fp32 as much as here)

@@ -70,7 +70,7 @@ def test_forward_and_gradients_match_reference_golden(name):
             assert int(sd[k[9:]]) == int(z[k]) == 1, k
 
 
-@pytest.mark.parametrize("N,L,h,out,heads,thr,bs", [(14, 50, 64, 10, 3, 0.0, 100), (14, 50, 16, 10, 3, 0.0, 33), (20, 50, 32, 10, 3, 0.0, 300), (20, 50, 64, 10, 3, 0.0, 40),
+@pytest.mark.parametrize("N,L,h,out,heads,thr,bs", [(14, 50, 64, 10, 3, 0.0, 100), (14, 50, 16, 10, 3, 0.0, 33), (20, 50, 32, 10, 3, 0.0, 300), (20, 50, 64, 10, 3, 0.0, 40), (16, 30, 64, 10, 2, 0.0, 9), (17, 30, 64, 12, 2, 0.0, 5),
                                                    (32, 128, 64, 16, 4, 0.001, 3), (3, 5, 4, 2, 1, 0.0, 7), (5, 12, 9, 4, 2, 0.002, 1)])
 def test_training_step_matches_oracle(N, L, h, out, heads, thr, bs):
     cfg = dict(num_nodes=N, time_length=L, hidden_dim=h, output_dim=out, num_heads=heads, threshold=thr)
