@@ -34,6 +34,7 @@ struct SnGeom {
     // flat parameter offsets
     int o_cw, o_cb, o_f[SN_MAX_CHEB], o_enc_w[4], o_enc_b[4], o_dec_w[4], o_dec_b[4], o_wih, o_whh, o_bih, o_bhh, o_lw, o_lb, pcount;
     // workspace offsets (floats)
+    int64_t w_fal[SN_MAX_CHEB];          // 16-byte aligned copies of the ChebNet filters (their flat-buffer offsets are odd: the big-tile GEMM needs aligned operands)
     int64_t w_mag, w_mask, w_terms[SN_MAX_CHEB], w_out[SN_MAX_CHEB], w_enc[4], w_dec[4], w_hseq, w_dpred, w_sq, w_rsq, w_dD1, w_dD2,
         w_dA1, w_dA2, w_dterms, w_dc1, w_dc2, w_dhs, w_dH, w_one, w_split, w_lstm, total;
     int rblocks;                                // workgroups of the reconstruction-error kernel (= partial sums)
@@ -96,6 +97,7 @@ int sn_geometry(const rulgnn_stnet_shape* s, SnGeom* g) {
     g->w_dterms = wk(R * 3 * cmax); g->w_dc1 = wk(R * cmax); g->w_dc2 = wk(R * cmax);
     g->w_dhs = wk(BT * g->E); g->w_dH = wk(BT * A);
     g->w_one = wk(64);
+    for (int i = 0; i < g->ncheb; ++i) g->w_fal[i] = wk((int64_t)3 * g->C[i] * g->C[i + 1]);
     int64_t sp = 1024;
     auto need = [&](int M, int Nn, int64_t K) {
         if (K > 0x7fffffff) return;
@@ -345,6 +347,20 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
     la.workspace_bytes = bilstm_workspace_bytes(&ls);
     const unsigned ggrid = (unsigned)(g.G < 4096 ? g.G : 4096);
     (void)hipGetLastError();
+    // The filters as GEMM operands: the flat parameter buffer puts them behind three scalars, 12 bytes off a 16-byte boundary, and the
+    // large-tile GEMM (sgemm.hip: 16-byte vector loads) falls back to the 64 x 64 fp32 tiles for a misaligned operand -- 123 instead of
+    // 98 us for the [18 000 x 900] x [900 x 200] product, 98 instead of 80 us for its transpose.  A misaligned filter is copied into the
+    // workspace once per call (1 MB at the reference's widths, ~3 us a copy).
+    const float* fop[SN_MAX_CHEB];
+    for (int i = 0; i < nc; ++i) {
+        fop[i] = prm + g.o_f[i];
+        const bool used_big = i > 0 || (mode & 1);                  // layer 0's transpose product is never formed (the input carries no gradient)
+        if ((reinterpret_cast<uintptr_t>(fop[i]) & 15) && used_big) {
+            if (hipMemcpyAsync(ws + g.w_fal[i], fop[i], sizeof(float) * 3 * g.C[i] * g.C[i + 1], hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return RULGNN_EHIP;
+            fop[i] = ws + g.w_fal[i];
+        }
+    }
     if (mode & 1) {
         const size_t lds = sizeof(float) * ((size_t)g.P + g.nseg + 3 * (size_t)g.nseg + (size_t)g.N * g.f);
         if (lds > 48 * 1024) return RULGNN_EUNSUPPORTED;
@@ -355,7 +371,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
         for (int i = 0; i < nc; ++i) {
             hipLaunchKernelGGL(sn_terms_kernel, dim3(ggrid), dim3(SB), 0, st, g, g.C[i], cur, mask, ws + g.w_terms[i]);
             SN_LAUNCH_OK();
-            SN_RC(sgemm(ws + g.w_terms[i], 3 * g.C[i], 1, prm + g.o_f[i], 1, g.C[i + 1], ws + g.w_out[i], g.C[i + 1], R, g.C[i + 1], 3 * g.C[i],
+            SN_RC(sgemm(ws + g.w_terms[i], 3 * g.C[i], 1, fop[i], 1, g.C[i + 1], ws + g.w_out[i], g.C[i + 1], R, g.C[i + 1], 3 * g.C[i],
                         false, st));
             cur = ws + g.w_out[i];
         }
@@ -445,7 +461,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
             const int Ci = g.C[i], Co = g.C[i + 1];
             SN_RC(sgemm_splitk(ws + g.w_terms[i], 1, 3 * Ci, dcur, 1, Co, gr + g.o_f[i], Co, 3 * Ci, Co, R, false, split, st));
             if (i == 0) break;                        // the input carries no gradient
-            SN_RC(sgemm(dcur, Co, 1, prm + g.o_f[i], Co, 1, ws + g.w_dterms, 3 * Ci, R, 3 * Ci, Co, false, st));
+            SN_RC(sgemm(dcur, Co, 1, fop[i], Co, 1, ws + g.w_dterms, 3 * Ci, R, 3 * Ci, Co, false, st));
             float* dn = dc[i & 1];
             hipLaunchKernelGGL(sn_terms_bwd_kernel, dim3(ggrid), dim3(SB), 0, st, g, Ci, (const float*)(ws + g.w_dterms), mask, dn);
             SN_LAUNCH_OK();
