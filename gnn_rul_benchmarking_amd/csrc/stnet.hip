@@ -107,6 +107,7 @@ int sn_geometry(const rulgnn_stnet_shape* s, SnGeom* g) {
     for (int i = 0; i < g->ncheb; ++i) need(3 * g->C[i], g->C[i + 1], R);
     for (int i = 0; i < 4; ++i) { need(eout[i], ein[i], BT); need(1, eout[i], BT); need(dout[i], din[i], BT); need(1, dout[i], BT); }
     need(1, g->E * g->T, g->B);
+    for (int i = 0; i < 4; ++i) { need((int)BT, eout[i], ein[i]); need((int)BT, din[i], dout[i]); }      // activations over a long reduction: sn_gemm_rows
     g->w_split = wk(sp);
     rulgnn_bilstm_shape ls{g->T, (int32_t)(g->B > 0 ? g->B : 1), A, g->E};
     const size_t lb = bilstm_workspace_bytes(&ls);
@@ -347,6 +348,13 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
     la.workspace_bytes = bilstm_workspace_bytes(&ls);
     const unsigned ggrid = (unsigned)(g.G < 4096 ? g.G : 4096);
     (void)hipGetLastError();
+    // [BT x K] x [K x 50] with K = 900: 32 output tiles, each walking all of K alone (45 us); split over k it is a 6-us product and a
+    // 6-us fixed-order sum (the scratch need of these shapes is registered in sn_geometry)
+    auto gemm_rows = [&](const float* Am, int64_t sAm, int64_t sAk, const float* Bm, int64_t sBn, int64_t sBk, float* Cm, int64_t ldc, int M, int N,
+                         int K) -> int {
+        if (K >= 512 && (int64_t)((M + 63) / 64) * ((N + 63) / 64) < 128) return sgemm_splitk(Am, sAm, sAk, Bm, sBn, sBk, Cm, ldc, M, N, K, false, split, st);
+        return sgemm(Am, sAm, sAk, Bm, sBn, sBk, Cm, ldc, M, N, K, false, st);
+    };
     // The filters as GEMM operands: the flat parameter buffer puts them behind three scalars, 12 bytes off a 16-byte boundary, and the
     // large-tile GEMM (sgemm.hip: 16-byte vector loads) falls back to the 64 x 64 fp32 tiles for a misaligned operand -- 123 instead of
     // 98 us for the [18 000 x 900] x [900 x 200] product, 98 instead of 80 us for its transpose.  A misaligned filter is copied into the
@@ -377,7 +385,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
         }
         const float* h = cur;                         // Y_o as [BT, D] rows
         for (int i = 0; i < 4; ++i) {
-            SN_RC(sgemm(h, ein[i], 1, prm + g.o_enc_w[i], ein[i], 1, ws + g.w_enc[i], eout[i], BT, eout[i], ein[i], false, st));
+            SN_RC(gemm_rows(h, ein[i], 1, prm + g.o_enc_w[i], ein[i], 1, ws + g.w_enc[i], eout[i], BT, eout[i], ein[i]));
             hipLaunchKernelGGL(sn_bias_act_kernel, dim3(sn_grid((int64_t)BT * eout[i])), dim3(SB), 0, st, ws + g.w_enc[i], prm + g.o_enc_b[i],
                                (int64_t)BT, eout[i], i < 3 ? 1 : 0);
             h = ws + g.w_enc[i];
@@ -435,7 +443,7 @@ int stnet_run(const rulgnn_stnet_shape* s, const rulgnn_stnet_args* a, int mode,
             SN_RC(sgemm_splitk(d, 1, dout[i], hin, 1, din[i], gr + g.o_dec_w[i], din[i], dout[i], din[i], BT, false, split, st));
             SN_RC(sgemm_splitk(one, 0, 0, d, 1, dout[i], gr + g.o_dec_b[i], dout[i], 1, dout[i], BT, false, split, st));
             float* dn = dA[i & 1];
-            SN_RC(sgemm(d, dout[i], 1, prm + g.o_dec_w[i], 1, din[i], dn, din[i], BT, din[i], dout[i], false, st));
+            SN_RC(gemm_rows(d, dout[i], 1, prm + g.o_dec_w[i], 1, din[i], dn, din[i], BT, din[i], dout[i]));
             d = dn;
         }
         // d H = decoder path + LSTM path
