@@ -61,6 +61,27 @@ struct MxArgs {
     float* taps;           // debug: raw register dumps of tile 0 (TAPS builds only)
 };
 
+// Development aid (variant builds with -DMX_STAGE_CLOCKS only; tools/mx_stage_clocks.py): s_memtime stamps at the stage boundaries of
+// a tile, consumed at the END of the iteration (an SMEM result needs lgkmcnt(0): consumed in place it would serialise the LDS round
+// trips the stages overlap), summed per wavefront and added to a device array.  The product build compiles every call to nothing.
+#ifdef MX_STAGE_CLOCKS
+constexpr int MX_CLK_STAMPS = 20;
+__device__ unsigned long long g_mx_stage_clocks[MX_CLK_STAMPS + 2];
+struct StageClk {
+    unsigned long long t[MX_CLK_STAMPS];
+    template <int I> __device__ __forceinline__ void stamp() {
+        if (MX_STAGE_CLOCKS == 2 && I != 0 && I != 18) return;      // light form: only the ends of the iteration
+        __builtin_amdgcn_sched_barrier(0);
+        t[I] = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+#else
+struct StageClk {
+    template <int I> __device__ __forceinline__ void stamp() {}
+};
+#endif
+
 // Per-wavefront constant MFMA operands of one layer (built in the prologue from the flat parameter buffer).
 struct LayerOps {
     u32x4 theta_hi, theta_lo;   // B operands of Hp: lane (kg, j): theta[j][4 kg + r] as (hi | hi) and (lo | lo) against the data's
@@ -82,7 +103,7 @@ __device__ __forceinline__ void tap(float* taps, bool on, int slot, int lane, fl
 template <int NFIX, int PFIX, bool TAPS>
 __device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const MxArgs& a, float* tileA, float* cur, int64_t tile, int64_t tstride,
                                              int ns, int N, int P, int lane, bool tapon, float (&X0)[F], f32x16& gram, u32x4 (&adjB)[4],
-                                             float (&X)[4][3]) {
+                                             float (&X)[4][3], StageClk& ck) {
     const int g = lane >> 4, col = lane & 15;
     const int tileNP = N * P;
     // ---- patch statistics, row mapping: lane (sample row g, patch col) ------------------------------------------
@@ -122,6 +143,7 @@ __device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const
 #pragma unroll
     for (int c = 0; c < F; ++c) tap<TAPS>(a.taps, tapon, c, lane, X0[c]);
 
+    ck.template stamp<2>();
     // ---- Pearson adjacency: rows = channel slots, one 16x16 block per sample (f32 4-block MFMA, exact) ---------
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -157,6 +179,7 @@ __device__ __forceinline__ void mx_front_end(const float* __restrict__ gx, const
             }
         }
     }
+    ck.template stamp<3>();
     // gram[4 b + r] in lane (g, col) = Adj_b[slot 4 g + r][slot col]: the D layout of sample b's adjacency
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -194,6 +217,9 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
 
     int64_t tile = blockIdx.x;
     if (tile >= a.ntiles) return;
+#ifdef MX_STAGE_CLOCKS
+    const unsigned long long clk_entry = __builtin_readcyclecounter();
+#endif
     {   // first tile on its way before the weights are touched
         const int64_t s0 = tile * 4;
         const int ns = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
@@ -271,7 +297,13 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
     bool any_bad = false, pend_mine = false;
     int64_t pend_idx = 0;
     float pend_pred = 0.f;
+#ifdef MX_STAGE_CLOCKS
+    unsigned clk_acc[MX_CLK_STAMPS] = {};
+    unsigned clk_tiles = 0;
+#endif
     for (int it = 0; tile < a.ntiles; ++it, tile += gridDim.x) {
+        StageClk ck;
+        ck.template stamp<0>();
         float* const tileA = smem;                       // this tile's windows (LDS-DMA target); free again once the patches are in registers
         float* const cur = smem + a.buf_floats;          // layout-conversion tile + shift tile (plain arithmetic on the __shared__ base
                                                          // keeps these LDS, not flat, accesses)
@@ -284,6 +316,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
         // The previous tile's predictions leave HERE, not at the end of their own iteration: the wait above also counts stores, and a
         // store issued just in front of it kept the wavefront parked for the write acknowledgement (~1600 cycles per tile, s_memtime).
         if (pend_mine) out[pend_idx] = pend_pred;
+        ck.template stamp<1>();
 
         u32x2* sh_tile = reinterpret_cast<u32x2*>(cur + MX_MIN_BUF_BYTES / 4);      // behind the layout-conversion tile
 
@@ -291,7 +324,8 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
         float X0[F], X[4][3];
         f32x16 gram;
         u32x4 adjB[4];
-        mx_front_end<NFIX, PFIX, TAPS>(gx, a, tileA, cur, tile, gridDim.x, ns, N, P, lane, tapon, X0, gram, adjB, X);
+        mx_front_end<NFIX, PFIX, TAPS>(gx, a, tileA, cur, tile, gridDim.x, ns, N, P, lane, tapon, X0, gram, adjB, X, ck);
+        ck.template stamp<4>();
         if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};      // the padding slot of the shift tile (hi and lo halves)
 
         // The layers are the dense part of a tile; statistics, Pearson and the head are chains of LDS round trips and dependent
@@ -316,6 +350,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 T[s] = mfma16(ah, adjB[s], zero);
                 T[s] = mfma16(al, adjB[s], T[s]);
             }
+            if (l == 0) ck.template stamp<5>(); else ck.template stamp<11>();
             __builtin_amdgcn_sched_barrier(0);
             // Hp = theta(A.X) + b : rows c, columns j
 #pragma unroll
@@ -330,6 +365,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
             }
             float H[4][3], V[4][3];
             u32x4 bh[4], bl[4];
+            if (l == 0) ck.template stamp<6>(); else ck.template stamp<12>();
             __builtin_amdgcn_sched_barrier(0);
             // conv_block1 on H = leaky(Hp)
 #pragma unroll
@@ -348,6 +384,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 __builtin_amdgcn_sched_barrier(0);          // keep each sample's LDS round trip behind ITS arithmetic, not behind all four
             }
             // the shifted columns of all four samples are in flight through the LDS before the first product needs one
+            if (l == 0) ck.template stamp<7>(); else ck.template stamp<13>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -356,6 +393,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 z[s] = mfma16(ops[l].w_hi[0], bl[s], z[s]);
                 z[s] = mfma16(ops[l].w_lo[0], bh[s], z[s]);
             }
+            if (l == 0) ck.template stamp<8>(); else ck.template stamp<14>();
             __builtin_amdgcn_sched_barrier(0);
             // o0 = relu(relu(z1) + H), carried as V = 4 o0;  conv_block2 (dilation 2)
 #pragma unroll
@@ -373,6 +411,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 bl[s] = u32x4{p01.lo, p2.lo, prev.lo.x, prev.lo.y};
                 __builtin_amdgcn_sched_barrier(0);          // keep each sample's LDS round trip behind ITS arithmetic, not behind all four
             }
+            if (l == 0) ck.template stamp<9>(); else ck.template stamp<15>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -381,6 +420,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 z[s] = mfma16(ops[l].w_hi[1], bl[s], z[s]);
                 z[s] = mfma16(ops[l].w_lo[1], bh[s], z[s]);
             }
+            if (l == 0) ck.template stamp<10>(); else ck.template stamp<16>();
             __builtin_amdgcn_sched_barrier(0);
             // o1 = relu(z2) + o0 (both >= 0: the outer ReLU is the identity); out = dropout_eval(o1) + X
 #pragma unroll
@@ -395,6 +435,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
             }
         }
 
+        ck.template stamp<17>();
         __builtin_amdgcn_s_setprio(1);
         // ---- head: max over the ten channels (Model.py:218-219), fc1, fc2 -------------------------------------------
         float pm[4];
@@ -422,7 +463,31 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
         const bool mine = col == 0 && g < ns;
         pend_mine = mine; pend_idx = s0 + g; pend_pred = pred;
         any_bad |= __any(mine && !(__builtin_fabsf(pred) <= 3.0e38f)) != 0;
+#ifdef MX_STAGE_CLOCKS
+        ck.template stamp<18>();
+        if constexpr (L == 2) {
+            if (MX_STAGE_CLOCKS == 2) {
+                clk_acc[0] += (unsigned)(ck.t[18] - ck.t[0]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) {
+                    clk_acc[i] += (unsigned)(ck.t[i + 1] - ck.t[i]);
+                    asm volatile("" : "+v"(clk_acc[i]));
+                }
+            }
+            ++clk_tiles;
+        }
+#endif
     }
+#ifdef MX_STAGE_CLOCKS
+    if (lane == 0) {
+        // [0..17] stage sums, [18] wavefronts, [19] entry-to-here ticks, [20] tile passes
+        for (int i = 0; i < 18; ++i) atomicAdd(&g_mx_stage_clocks[i], (unsigned long long)clk_acc[i]);
+        atomicAdd(&g_mx_stage_clocks[18], 1ull);
+        atomicAdd(&g_mx_stage_clocks[19], __builtin_readcyclecounter() - clk_entry);
+        atomicAdd(&g_mx_stage_clocks[MX_CLK_STAMPS], (unsigned long long)clk_tiles);
+    }
+#endif
 
     if (pend_mine) out[pend_idx] = pend_pred;
     // ---- safety net: recompute non-finite samples with the exact fp32 tile routine ----------------------------------
@@ -561,7 +626,8 @@ __global__ __launch_bounds__(64 * MXF0_WAVES, MX_WAVES_PER_SIMD) void stgcn_trai
         float X0[F], X[4][3];
         f32x16 gram;
         u32x4 adjB[4];
-        mx_front_end<NFIX, PFIX, false>(gx, a, tileA, cur, tile, tstride, ns, N, P, lane, false, X0, gram, adjB, X);
+        StageClk ck;
+        mx_front_end<NFIX, PFIX, false>(gx, a, tileA, cur, tile, tstride, ns, N, P, lane, false, X0, gram, adjB, X, ck);
         if (lane < 2) sh_tile[64 + 65 * lane] = u32x2{0u, 0u};
 
         // ---- what the later phases read of the inputs: statistics (row mapping) and adjacency -----------------------------
@@ -1245,3 +1311,16 @@ int stgcn_forward_eval_mxw(const rulgnn_stgcn_shape* s, const float* x, const fl
 int stgcn_forward_mx_tap_floats() { return MX_TAP_SLOTS * 64; }
 
 }  // namespace rulgnn
+
+#ifdef MX_STAGE_CLOCKS
+// variant builds only (tools/mx_stage_clocks.py): the stage clock sums of the launches since the last reset
+extern "C" __attribute__((visibility("default"))) int rulgnn_debug_mx_stage_clocks(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rulgnn::g_mx_stage_clocks), sizeof(rulgnn::g_mx_stage_clocks)) != hipSuccess) return -2;
+    if (reset) {
+        unsigned long long z[rulgnn::MX_CLK_STAMPS + 2] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rulgnn::g_mx_stage_clocks), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+#endif
