@@ -226,6 +226,10 @@ _SIGNATURES = {
     "rulgnn_stgcn_train_step_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.POINTER(AdamArgs), C.c_int32,
                                                     C.c_void_p]),
     "rulgnn_stgcn_train_step_resolve": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_int32]),
+    "rulgnn_stgcn_train_fwdbwd_syncbn_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_float, ALLREDUCE_F64_FN,
+                                                             C.c_void_p, C.c_int32, C.c_void_p]),
+    "rulgnn_stgcn_train_guard_counter_offset": (C.c_int64, [C.POINTER(StgcnShape)]),
+    "rulgnn_stgcn_train_args_size": (C.c_size_t, []),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
     "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
@@ -257,6 +261,7 @@ _SIGNATURES = {
     "rulgnn_gru_backward_f32": (C.c_int, [C.POINTER(GruShape), C.POINTER(GruArgs), C.c_void_p]),
     "rulgnn_rul_metrics_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "rulgnn_rul_metrics_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rulgnn_rul_metric_sums_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rulgnn_adam_step_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                             C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "rulgnn_fcstgnn_param_count": (C.c_int64, [C.POINTER(FcstgnnShape)]),

@@ -38,12 +38,15 @@ __global__ __launch_bounds__(MB) void rul_metrics_partial_kernel(const float* __
     if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
+// raw != 0: out[0..3] = the four SUMS themselves (Score_v1 terms, Score_v2 terms, |d|, d^2) -- what a rank contributes when a test set
+// is sharded over the GPUs (one all-reduce of the sums and the count, then the same closing arithmetic on every rank)
 __global__ void rul_metrics_final_kernel(const double* __restrict__ partial, int nblocks, int64_t n, double max_rul,
-                                         double* __restrict__ out) {
+                                         double* __restrict__ out, int raw) {
     const int k = threadIdx.x;
     if (k >= 4) return;
     double v = 0.0;
     for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * 4 + k];
+    if (raw) { out[k] = v; return; }
     const double dn = (double)n;
     if (k == 0) out[0] = v;                                 // Score_v1 (sum)
     if (k == 1) out[1] = v / dn;                            // Score_v2 (mean)
@@ -59,14 +62,14 @@ static int metric_blocks(int64_t n) {
 size_t rul_metrics_workspace_bytes(int64_t n) { return n < 1 ? 0 : (size_t)metric_blocks(n) * 4 * sizeof(double); }
 
 int rul_metrics(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace,
-                size_t workspace_bytes, hipStream_t st) {
+                size_t workspace_bytes, hipStream_t st, int raw) {
     if (!pred || !real || !out || n < 1) return RULGNN_EINVAL;
     if (!workspace || workspace_bytes < rul_metrics_workspace_bytes(n)) return RULGNN_EWORKSPACE;
     const int nb = metric_blocks(n);
     double* partial = static_cast<double*>(workspace);
     (void)hipGetLastError();
     hipLaunchKernelGGL(rul_metrics_partial_kernel, dim3(nb), dim3(MB), 0, st, pred, real, n, (double)max_rul, partial);
-    hipLaunchKernelGGL(rul_metrics_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, nb, n, (double)max_rul, out);
+    hipLaunchKernelGGL(rul_metrics_final_kernel, dim3(1), dim3(64), 0, st, (const double*)partial, nb, n, (double)max_rul, out, raw);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 

@@ -164,8 +164,26 @@ int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape* shape, const 
     if (rc != RULGNN_OK) return rc;
     if (!(bn_param_grad_scale >= 0.f && bn_param_grad_scale <= 1.f) || !allreduce || args->bn_moment_weight != 0.f) return RULGNN_EINVAL;
     if (tiled(shape)) return RULGNN_EUNSUPPORTED;          // the tiled path keeps local statistics
-    return stgcn_train_fwdbwd_syncbn(shape, args, bn_param_grad_scale, allreduce, user, static_cast<hipStream_t>(stream));
+    return stgcn_train_fwdbwd_syncbn(shape, args, bn_param_grad_scale, allreduce, user, static_cast<hipStream_t>(stream), RULGNN_STEP_CHAIN);
 }
+
+int rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
+                                              float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void* user, int32_t path,
+                                              void* stream) {
+    const int rc = check_train(shape, args, true);
+    if (rc != RULGNN_OK) return rc;
+    if (!(bn_param_grad_scale >= 0.f && bn_param_grad_scale <= 1.f) || !allreduce || args->bn_moment_weight != 0.f) return RULGNN_EINVAL;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
+    if (tiled(shape)) return RULGNN_EUNSUPPORTED;
+    return stgcn_train_fwdbwd_syncbn(shape, args, bn_param_grad_scale, allreduce, user, static_cast<hipStream_t>(stream), path);
+}
+
+int64_t rulgnn_stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape* shape) {
+    if (validate_shape(shape) != RULGNN_OK) return -1;
+    return tiled(shape) ? -1 : stgcn_train_guard_counter_offset(shape);
+}
+
+size_t rulgnn_stgcn_train_args_size(void) { return sizeof(rulgnn_stgcn_train_args); }
 
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
                                 const rulgnn_adam_args* opt, void* stream) {
@@ -207,7 +225,7 @@ int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape* shape, const float
     if (tiled(shape)) return RULGNN_EUNSUPPORTED;
     if (path == RULGNN_STEP_CHAIN || path == RULGNN_STEP_COOP) return path;
     if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
-    if (stgcn_train_mx_shape_ok(shape, x) || (shape->num_layers <= 2 && stgcn_train_mxw_shape_ok(shape, x))) return RULGNN_STEP_MX;
+    if (stgcn_train_mx_kind(shape, x) != 0) return RULGNN_STEP_MX;
     return path == RULGNN_STEP_MX ? RULGNN_EUNSUPPORTED : RULGNN_STEP_CHAIN;
 }
 
@@ -970,6 +988,14 @@ int rulgnn_rul_metrics_f32(const float* pred, const float* real, int64_t n, floa
     const int rc = check_ptrs({pred, real, out, workspace});
     if (rc != RULGNN_OK) return rc;
     return rul_metrics(pred, real, n, max_rul, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_rul_metric_sums_f32(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (n < 1) return RULGNN_EINVAL;
+    const int rc = check_ptrs({pred, real, out, workspace});
+    if (rc != RULGNN_OK) return rc;
+    return rul_metrics(pred, real, n, max_rul, out, workspace, workspace_bytes, static_cast<hipStream_t>(stream), 1);
 }
 
 }  // extern "C"

@@ -128,7 +128,9 @@ int stgcn_train_step(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args*
 int stgcn_train_phase(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, int phase, hipStream_t stream,
                       int path = RULGNN_STEP_AUTO);
 int stgcn_train_fwdbwd_syncbn(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, float bn_param_grad_scale,
-                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t stream);
+                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t stream, int path = RULGNN_STEP_CHAIN);
+int stgcn_train_mx_kind(const rulgnn_stgcn_shape* s, const float* x);        // 0 fp32 phases, 1 matrix-core chain, 2 wide matrix-core chain
+int64_t stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape* s);
 int64_t stmsgcn_param_count(const rulgnn_stmsgcn_shape* s);
 size_t stmsgcn_workspace_bytes(const rulgnn_stmsgcn_shape* s);
 int stmsgcn_features(const rulgnn_stmsgcn_shape* s, const float* x, const float* prm, float* features, hipStream_t stream);
@@ -209,6 +211,6 @@ int gru_forward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t
 int gru_backward(const rulgnn_gru_shape* s, const rulgnn_gru_args* a, hipStream_t st);
 size_t rul_metrics_workspace_bytes(int64_t n);
 int rul_metrics(const float* pred, const float* real, int64_t n, float max_rul, double* out, void* workspace, size_t workspace_bytes,
-                hipStream_t st);
+                hipStream_t st, int raw = 0);
 
 }  // namespace rulgnn

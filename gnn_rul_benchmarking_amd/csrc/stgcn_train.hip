@@ -966,6 +966,8 @@ __device__ __forceinline__ void finalize_stats(const FinalizeK& f, int tid, int 
     const double cnt = step_scratch(f.cells, L)->bn_count;
     const bool tripped = f.guard && step_scratch(f.cells, L)->pad[0] != 0u;
     if (tid == 0 && f.write_loss) f.loss[0] = tripped ? __builtin_nanf("") : (float)(cell_sum(f.cells, L, cell_loss(L)) / (double)f.global_batch);
+    if (tid == 0 && tripped) step_scratch(f.cells, L)->pad[3] += 1u;      // sticky: a rejected step never vanishes (a caller that does not read
+                                                                          // the loss every step checks this counter instead)
     for (int i = tid; i < 2 * L * F; i += nthreads) {
         const int b = i / F, c = i % F;
         const double s2 = cell_sum(f.cells, L, cell_fwd(L) + (b * 2 + 1) * F + c);
@@ -1353,7 +1355,7 @@ template <int RW, int L, int NFIX, int PFIX>
 static int launch_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t stream, const TrainK& k,
                        const WsLayout& w, const TileGeom& g, const rulgnn_adam_args* opt, double bn_count) {
     auto kern = stgcn_train_coop_kernel<RW, L, NFIX, PFIX>;
-    CoopK c;
+    CoopK c{};
     c.wa_f0 = wave_area_for(PH_F, 0, g);
     c.wa_g = wave_area_for(PH_G, 0, g);
     c.wa_top = wave_area_for(PH_TOP, 0, g);
@@ -1475,8 +1477,9 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     // The matrix-core chain (stgcn_train_mx.hip): same prepare / cells / finalize, phases that recompute instead of reading saved
     // activations.  Whole MSE steps only (the autograd split and upstream gradients of unknown magnitude stay on the fp32 phases).
     const bool mx_step = path != RULGNN_STEP_CHAIN && mode == TM_FWDBWD && k.has_dpred == 0;
-    const bool use_mxw = mx_step && L <= 2 && stgcn_train_mxw_shape_ok(s, a->x);           // 16 <= num_patch <= 47: the wide chain
-    const bool use_mx = use_mxw || (RW == 16 && mx_step && stgcn_train_mx_shape_ok(s, a->x));
+    const int mx_kind = mx_step ? stgcn_train_mx_kind(s, a->x) : 0;                         // the ONE predicate rulgnn_stgcn_train_step_resolve uses
+    const bool use_mxw = mx_kind == 2;                                                      // 16 <= num_patch <= 47: the wide chain
+    const bool use_mx = mx_kind != 0;
     if (path == RULGNN_STEP_MX && !use_mx) return RULGNN_EUNSUPPORTED;
 
     StepScratch* sc = step_scratch(k.cells, L);
@@ -1542,7 +1545,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
         rc = PhaseChain<RW, L, 2 * L - 1>::backward(k, a->x, a->params, gy, lds, w.max_grid, stream, grids, hook);
         if (rc != RULGNN_OK) return rc;
     }
-    FinalizeK f;
+    FinalizeK f{};
     f.gpart = k.gpart; f.cells = k.cells;
     f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
     f.grid_top = grid_top;
@@ -1660,12 +1663,37 @@ int stgcn_train_backward(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_a
     return dispatch_train(s, a, TM_BACKWARD, st);
 }
 int stgcn_train_fwdbwd(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, hipStream_t st) {
-    return dispatch_train(s, a, TM_FWDBWD, st);
+    // The split entry (gradients now, the caller's own optimizer call later) stays on the fp32 phases: the matrix-core chain reports an
+    // f16 range violation as a NaN loss + untouched state, which only a caller that knows the guard protocol handles
+    // (rulgnn_stgcn_train_step_path_f32 with an explicit path is that caller's entry).
+    return dispatch_train(s, a, TM_FWDBWD, st, nullptr, nullptr, RULGNN_STEP_CHAIN);
 }
 int stgcn_train_fwdbwd_syncbn(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* a, float bn_param_grad_scale,
-                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t st) {
+                              rulgnn_allreduce_f64_fn allreduce, void* user, hipStream_t st, int path) {
     const SyncHook hook{bn_param_grad_scale, allreduce, user};
-    return dispatch_train(s, a, TM_FWDBWD, st, nullptr, &hook);
+    return dispatch_train(s, a, TM_FWDBWD, st, nullptr, &hook, path);
+}
+
+// Which matrix-core chain a whole MSE step of this shape runs on: 0 none (fp32 phases), 1 the 4-sample-tile chain (num_patch <= 15,
+// stgcn_train_mx.hip), 2 the wide chain (16 <= num_patch <= 47, stgcn_train_mxw.hip).  Shared by run_train_rw and
+// rulgnn_stgcn_train_step_resolve so that the two dispatch rules cannot drift apart.
+int stgcn_train_mx_kind(const rulgnn_stgcn_shape* s, const float* x) {
+    TileGeom g;
+    if (train_geometry(s, &g) != RULGNN_OK) return 0;
+    if (s->num_layers <= 2 && stgcn_train_mxw_shape_ok(s, x)) return 2;
+    if (g.RW == 16 && stgcn_train_mx_shape_ok(s, x)) return 1;
+    return 0;
+}
+
+// Byte offset of the sticky guard counter (StepScratch::pad[3]) inside a training workspace of this shape; -1 where the phase chain
+// does not apply (the tiled path).
+int64_t stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape* s) {
+    TileGeom g;
+    if (train_geometry(s, &g) != RULGNN_OK) return -1;
+    if (s->num_layers > 3 || (g.RW != 16 && s->num_layers > 2)) return -1;
+    WsLayout w;
+    ws_layout(s, g, &w);
+    return (int64_t)(w.off_cells + sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(s->num_layers) + offsetof(StepScratch, pad) + 3 * sizeof(uint32_t));
 }
 
 }  // namespace rulgnn

@@ -16,7 +16,9 @@ struct StepScratch {
                           // cells are all-reduced between the phases (synchronised BatchNorm, stgcn_train_fwdbwd_syncbn)
     uint32_t pad[4];      // [0] status word of the matrix-core chain (f16 range guard; bit 1: a step claimed clean cells that were not),
                           // [1] clean token: the finalize kernel of a matrix-core step left every cell and the status word zero,
-                          // [2] ticket of that finalize kernel's workgroups
+                          // [2] ticket of that finalize kernel's workgroups,
+                          // [3] STICKY count of the steps the range guard rejected (finalize_stats adds, no kernel ever clears it:
+                          //     rulgnn_stgcn_train_guard_counter_offset; the caller zeroes it when it allocates the workspace)
 };
 static_assert(sizeof(StepScratch) == 64, "step scratch layout");
 constexpr uint32_t WS_CLEAN_TOKEN = 0x52554C43u;

@@ -32,9 +32,22 @@ def _normalise(X, y):
 class DeviceBatchLoader:
     """Iterates (X[idx], y[idx]) with idx from torch's samplers; tensors live on ``device``.
     ``rank``/``world_size``: every rank walks the SAME index batches (same seed) and takes its
-    contiguous shard of each (dp.shard_bounds), so the global batch equals the single-process one."""
+    contiguous shard of each (dp.shard_bounds), so the global batch equals the single-process one.
 
-    def __init__(self, X, y, batch_size, shuffle, drop_last, device, rank=0, world_size=1):
+    ``shard_samples`` (the TEST sets under data parallelism): the rank keeps only its contiguous shard
+    ``[lo, hi)`` of the set (``dp.shard_bounds(n, world_size, rank)``: shard sizes differ by at most one) and walks it in batches of
+    ``batch_size`` -- an eval forward is per-sample independent, so the concatenation of the ranks' predictions in rank order is the
+    single-process prediction vector.  ``global_n`` / ``shard`` say where the shard sits."""
+
+    def __init__(self, X, y, batch_size, shuffle, drop_last, device, rank=0, world_size=1, shard_samples=False):
+        self.global_n, self.shard = X.shape[0], (0, X.shape[0])
+        # (a set that is shuffled or drops its ragged tail is not a fixed vector of samples: every rank then walks all of it)
+        self.shard_samples = bool(shard_samples) and world_size > 1 and not shuffle and not drop_last
+        if self.shard_samples:
+            from .dp import shard_bounds
+            lo, hi = shard_bounds(X.shape[0], world_size, rank)
+            X, y, self.shard = X[lo:hi], y[lo:hi], (lo, hi)
+            rank, world_size = 0, 1            # inside the shard this rank is on its own
         self.x_data, self.y_data = X.to(device), y.to(device)
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.device, self.rank, self.world_size = device, rank, world_size
@@ -71,8 +84,8 @@ def data_generator(data_path, dataset_configs, hparams, device="cpu", rank=0, wo
         test_loader = {}
         for key in test['samples']:
             Xt, yt = _normalise(test['samples'][key], test['labels'][key])
-            test_loader[key] = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device)
+            test_loader[key] = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, rank, world_size, shard_samples=True)
     else:
         Xt, yt = _normalise(test['samples'], test['labels'])
-        test_loader = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device)
+        test_loader = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, rank, world_size, shard_samples=True)
     return train_loader, test_loader, train['max_ruls']

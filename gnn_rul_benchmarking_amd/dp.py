@@ -54,6 +54,22 @@ class DataParallel:
             dist.broadcast(model._nbt, 0, group=self.group)
 
     @staticmethod
+    def _empty_shard_bookkeeping(model, global_batch) -> None:
+        """What a rank with an EMPTY shard must still advance so that it stays in lockstep with the ranks that ran kernels: the dropout
+        stream position, and the chain the step resolved to (a function of the shape and ``step_path`` alone): with it the guarded /
+        unguarded choice of the optimizer kernels behind the all-reduce is the same on every rank."""
+        if hasattr(model, "_step"):
+            model._step += 1
+        resolve = getattr(model, "resolve_chain_for_empty_shard", None)
+        if resolve is not None:
+            resolve(global_batch)
+
+    @staticmethod
+    def _note_guard(model, loss) -> None:
+        if getattr(model, "guard_tensor", None) is not None:
+            model.note_data_parallel_loss(loss)
+
+    @staticmethod
     def _optimizer_step(model, optimizer) -> None:
         """The optimizer over the all-reduced bucket.  ST_GCN's matrix-core training chain reports an f16 range violation as a NaN
         loss (include/rulgnn.h, RULGNN_STEP_MX): summed over the ranks it makes every rank skip this step (and the running-statistics
@@ -127,8 +143,7 @@ class DataParallel:
 
         if X_shard.size(0) == 0:
             bucket.zero_()
-            if hasattr(model, "_step"):
-                model._step += 1                                     # dropout stream position: in lockstep with the other ranks
+            self._empty_shard_bookkeeping(model, global_batch)
             for lo, hi in expected:
                 launch(lo, hi - lo)
         else:
@@ -161,8 +176,7 @@ class DataParallel:
                 zero = torch.zeros(n, dtype=torch.float64, device=model.bucket.device)
                 dist.all_reduce(zero, op=dist.ReduceOp.SUM, group=self.group)
             model.bucket.zero_()
-            if hasattr(model, "_step"):
-                model._step += 1
+            self._empty_shard_bookkeeping(model, global_batch)
         else:
             # the BatchNorm scale / shift gradients come out of the all-reduced cells, i.e. they are already the global sums on every
             # rank: rank 0 (never empty under shard_bounds) contributes them to the bucket, the others contribute zero
@@ -176,6 +190,7 @@ class DataParallel:
         if violated:
             raise RuntimeError("synchronised BatchNorm expects shard_bounds() sharding: rank 0 holds data whenever the batch is not empty")
         self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_stats=True)
+        self._note_guard(model, model.bucket[model.num_live])
         return model.bucket[model.num_live]
 
     def step(self, model, optimizer, X_shard, y_shard, global_batch=None, sample_offset=None):
@@ -196,14 +211,14 @@ class DataParallel:
         if overlap:
             self._overlapped_step(model, X_shard, y_shard, global_batch, sample_offset)      # an empty shard replays the same collectives
             self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_moments=True)
+            self._note_guard(model, model.bucket[model.num_live])
             return model.bucket[model.num_live]
         if b == 0:
             # Ragged last batch smaller than the world (drop_last=False: n % batch_size can be 1..world_size-1): this rank's
             # shard is empty.  It launches no kernel, contributes a zero bucket, and still takes part in the all-reduce, the
             # optimizer step and the running-statistics update, so that replicas stay identical and nobody waits forever.
             model.bucket.zero_()
-            if hasattr(model, "_step"):
-                model._step += 1                                     # dropout stream position: in lockstep with the other ranks
+            self._empty_shard_bookkeeping(model, global_batch)
         elif batch_coupled:
             model.fused_mse_step(X_shard, y_shard, global_batch=global_batch, sample_offset=sample_offset,
                                  update_running_stats=False, moments_to_bucket=True)
@@ -216,4 +231,5 @@ class DataParallel:
             self._optimizer_and_stats(model, optimizer, global_batch, from_bucket_moments=True)
         else:
             self._optimizer_step(model, optimizer)
+        self._note_guard(model, model.bucket[model.num_live])
         return model.bucket[model.num_live]

@@ -46,9 +46,7 @@ def _calc_metrics(pred_labels, true_labels, max_rul):
         rmse_value(pred_labels, true_labels, max_rul)
 
 
-def device_metrics(pred, real, max_rul):
-    """(Score_v1, Score_v2, MAE, RMSE) of two float32 CUDA tensors, computed on the device in fp64 (SURVEY 8f rank 4).
-    Raises if the HIP library is missing: there is no host fallback behind this entry."""
+def _device_reduce(pred, real, max_rul, entry):
     import ctypes as C
 
     import torch
@@ -65,6 +63,31 @@ def device_metrics(pred, real, max_rul):
     ws = torch.empty(int(lib.rulgnn_rul_metrics_workspace_bytes(n)) // 8, dtype=torch.float64, device=p.device)
     out = torch.empty(4, dtype=torch.float64, device=p.device)
     st = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
-    _lib.check(lib.rulgnn_rul_metrics_f32(p.data_ptr(), r.data_ptr(), n, float(max_rul), out.data_ptr(), ws.data_ptr(),
-                                          ws.numel() * 8, st), "rul_metrics")
-    return tuple(float(v) for v in out.cpu())
+    _lib.check(getattr(lib, entry)(p.data_ptr(), r.data_ptr(), n, float(max_rul), out.data_ptr(), ws.data_ptr(), ws.numel() * 8, st), entry)
+    return out
+
+
+def device_metrics(pred, real, max_rul):
+    """(Score_v1, Score_v2, MAE, RMSE) of two float32 CUDA tensors, computed on the device in fp64 (SURVEY 8f rank 4).
+    Raises if the HIP library is missing: there is no host fallback behind this entry."""
+    return tuple(float(v) for v in _device_reduce(pred, real, max_rul, "rulgnn_rul_metrics_f32").cpu())
+
+
+def device_metric_sums(pred, real, max_rul):
+    """This rank's contribution to the metrics of a test set that is SHARDED over the ranks: a float64 device tensor
+    ``[sum Score_v1 terms, sum Score_v2 terms, sum |d|, sum d^2, n]`` (``rulgnn_rul_metric_sums_f32``); zeros for an empty shard.
+    SUM it over the ranks (one 5-double all-reduce) and close with ``metrics_from_sums``."""
+    import torch
+    out = torch.zeros(5, dtype=torch.float64, device=pred.device)
+    if pred.numel():
+        out[:4] = _device_reduce(pred, real, max_rul, "rulgnn_rul_metric_sums_f32")
+        out[4] = float(pred.numel())
+    return out
+
+
+def metrics_from_sums(sums, max_rul):
+    """(Score_v1, Score_v2, MAE, RMSE) from the (all-reduced) five sums: utils.py:136-169 closes with exactly these divisions."""
+    s1, s2, sa, sq, n = (float(v) for v in (sums.cpu() if hasattr(sums, "cpu") else sums))
+    if n < 1:
+        raise RuntimeError("metrics of an empty test set")
+    return s1, s2 / n, sa / n * max_rul, math.sqrt(sq / n) * max_rul

@@ -71,6 +71,9 @@ class FusedAdam(torch.optim.Optimizer):
         state = getattr(model, "_step_state", None)
         o = 4 * start
         if state is not None:          # device-resident step (hipGraph-capturable, see graphs.py)
+            if guard is not None:
+                raise RuntimeError("FusedAdam.step(guard=...) with a device-resident step state: the guarded kernel takes the step count "
+                                   "from the host; a captured graph runs the whole-step entry, which honours the guard itself")
             _lib.check(_lib.load().rulgnn_adam_step_dev_f32(
                 flat.data_ptr() + o, model.bucket.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, n, state.data_ptr(),
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),

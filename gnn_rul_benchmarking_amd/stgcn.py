@@ -123,6 +123,7 @@ class ST_GCN_model(FlatModule):
         self._step = 0              # training forwards so far (dropout stream position)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._track_batchnorm_counters()
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.check_guard())
         # _bufs: batch size -> (training workspace, prediction buffer), several sizes stay alive; _pin_bufs (graphs.py): captured
         # hipGraphs hold these pointers, never evict; _step_state: device step state (graphs.py), else the host counters are used
         self._init_flat(PL.live_param_layout(self.num_patch, self.num_layers), PL.param_count(self.num_patch, self.num_layers))
@@ -153,6 +154,11 @@ class ST_GCN_model(FlatModule):
         super()._reset_caches()
         self._pred_buf = self._ws = self._fwd_ws = None
         self._clean_ws = None
+        self._guard_off = {}             # batch size -> byte offset of the workspace's sticky guard counter (-1: none)
+        self._guard_seen = {}            # batch size -> count already reported
+        self._guard_dp = None            # data parallel: device count of the all-reduced losses that came back NaN (dp.py)
+        self._guard_unchecked = False    # a matrix-core step ran since the counters were last read
+        self._guard_carry = 0            # counts read early (before a workspace eviction), not yet reported
 
     # ---- C-ABI calls ---------------------------------------------------------------------------------
     def _shape(self, batch):
@@ -170,11 +176,20 @@ class ST_GCN_model(FlatModule):
         return x.reshape(bs, self.num_patch * self.patch_size).contiguous().float()
 
     def _workspace(self, shp, batch):
+        fresh = batch not in self._bufs
+        if fresh and self._guard_unchecked and len(self._bufs) >= self.workspace_slots and not self._pin_bufs:
+            self._guard_carry += self.guard_trips()      # a workspace is about to be evicted: its count must not go with it
+            self._guard_unchecked = True
         ent = self._workspace_entry(batch, lambda: _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp)),
                                     f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
                                     "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)",
                                     make=lambda dev: (torch.empty(batch, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
+        if fresh:            # the sticky count of guard-rejected steps lives in the workspace and is only ever ADDED to by the kernels
+            off = int(_lib.load().rulgnn_stgcn_train_guard_counter_offset(C.byref(shp)))
+            self._guard_off[batch] = off
+            if off >= 0:
+                self._ws[off:off + 4].zero_()
         return self._ws
 
     def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False, whole_step=False):
@@ -219,7 +234,63 @@ class ST_GCN_model(FlatModule):
     # data-parallel step take the bucket's loss as their guard; the Algorithm wrapper repeats such a step on the fp32 chain.
     def _resolve_chain(self, shp, x2d):
         self._last_chain = _lib.load().rulgnn_stgcn_train_step_resolve(C.byref(shp), C.c_void_p(x2d.data_ptr()), int(self.step_path))
+        if self._last_chain == _lib.STEP_MX:
+            self._guard_unchecked = True
         return self._last_chain
+
+    def resolve_chain_for_empty_shard(self, global_batch):
+        """Data parallel, this rank's shard of the batch is empty (dp.py): the chain the OTHER ranks run is a function of the shape and
+        ``step_path`` alone (their shards are fresh 256-byte aligned allocations), so this rank resolves the same one -- and with it
+        the same guarded / unguarded optimizer kernel -- without an input of its own."""
+        shp = self._shape(max(int(global_batch), 1))
+        self._last_chain = _lib.load().rulgnn_stgcn_train_step_resolve(C.byref(shp), C.c_void_p(self._flat.data_ptr() & ~0xFF),
+                                                                       int(self.step_path))
+        return self._last_chain
+
+    def guard_trips(self):
+        """Training steps the f16 range guard rejected (NaN loss, every piece of state untouched) since the last call: the kernels count
+        them in the workspace (rulgnn_stgcn_train_guard_counter_offset), the data-parallel step in ``_guard_dp`` -- one host read-back
+        here instead of one per step.  A caller that reads the loss every step (``sync_loss=True``) sees the NaN itself and never
+        needs this; ``ST_GCN.update(sync_loss=False)`` and captured graphs rely on it."""
+        self._guard_unchecked = False
+        n, self._guard_carry = self._guard_carry, 0
+        for batch, ent in list(self._bufs.items()):
+            off = self._guard_off.get(batch, -1)
+            if off >= 0:
+                total = int(ent[0][off:off + 4].view(torch.int32).item())
+                if self._guard_dp is None:       # data parallel counts the all-reduced loss instead (every rank sees the same number)
+                    n += total - self._guard_seen.get(batch, 0)
+                self._guard_seen[batch] = total
+        if self._guard_dp is not None:
+            n += int(self._guard_dp.item())
+            self._guard_dp.zero_()
+        return n
+
+    def note_data_parallel_loss(self, loss):
+        """dp.py, after the bucket all-reduce of a step on the matrix-core chain: a NaN loss (some rank's shard tripped the guard) made
+        every rank skip the step; count it on the device."""
+        if self._guard_dp is None:
+            self._guard_dp = torch.zeros((), dtype=torch.int32, device=loss.device)
+        self._guard_dp += torch.isnan(loss).to(torch.int32)
+        self._guard_unchecked = True
+
+    def check_guard(self):
+        """Raise if a training step since the last check was rejected by the f16 range guard and nobody noticed (no per-step loss
+        read-back).  Called by ``eval()`` / ``state_dict()`` -- the points where the reference's trainer looks at the model."""
+        if not self._guard_unchecked:
+            return
+        n = self.guard_trips()
+        if n:
+            raise RuntimeError(
+                f"ST_GCN: {n} training step(s) were rejected by the f16 range guard of the matrix-core chain (inputs far from O(1): the "
+                "loss of such a step is NaN and parameters, optimizer state and running statistics were left untouched, i.e. the step "
+                "was DROPPED). The reference never drops a step (algorithms.py:486-490): train with sync_loss=True (the step is then "
+                "repeated on the fp32 chain automatically) or set model.step_path = STEP_CHAIN.")
+
+    def train(self, mode: bool = True):
+        if not mode and self.training:
+            self.check_guard()
+        return super().train(mode)
 
     @property
     def guard_tensor(self):
@@ -384,10 +455,12 @@ class ST_GCN_model(FlatModule):
                 failure.append(e)
                 return 1
         cb = _lib.ALLREDUCE_F64_FN(hook)
-        rc = _lib.load().rulgnn_stgcn_train_fwdbwd_syncbn_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None, _stream())
+        # the launch form is the model's (step_path): after a guard trip retry_on_fp32_chain() must really land on the fp32 phases
+        rc = _lib.load().rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None,
+                                                                   int(self.step_path), _stream())
         if failure:
             raise failure[0]
-        _lib.check(rc, "rulgnn_stgcn_train_fwdbwd_syncbn_f32")
+        _lib.check(rc, "rulgnn_stgcn_train_fwdbwd_syncbn_path_f32")
         self._whole_step_done()
         return self._pred_buf, self._grad_flat[self.num_live]
 

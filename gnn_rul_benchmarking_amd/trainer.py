@@ -8,7 +8,8 @@ whenever the TEST RMSE improves, CSV first row inf,inf,inf,inf (trainer.py:219-2
 checkpoint per run after the last epoch (trainer.py:125-126); same directory / file names.
 
 New: the dataset lives on the GPU (dataloader.py); under torch.distributed every rank walks the same
-batches and trains on its shard (dp.py), only rank 0 logs and writes files."""
+batches and trains on its shard (dp.py); every TEST set is sharded over the ranks too (contiguous shards, the four metric sums and
+the count travel in one 5-double all-reduce); only rank 0 logs and writes files."""
 from __future__ import annotations
 
 import collections
@@ -23,7 +24,7 @@ from .algorithms import get_algorithm_class
 from .data_model_configs import get_dataset_class
 from .dataloader import data_generator
 from .hparams import get_hparams_class
-from .metrics import _calc_metrics
+from .metrics import _calc_metrics, device_metric_sums, metrics_from_sums
 from .utils import AverageMeter, fix_randomness, save_checkpoint, starting_logs
 
 
@@ -112,8 +113,7 @@ class GNN_RUL_trainer(object):
                 for key, val in loss_avg_meters.items():
                     self.logger.debug(f'{key}\t: {float(val.avg):2.4f}')
                 self.test_prediction(algorithm)
-                if self.rank == 0:
-                    self.calc_results_per_run(run_id)
+                self.calc_results_per_run(run_id)          # every rank: the sharded metrics are a collective; rank 0 writes
                 self.logger.debug('-------------------------------------')
 
             self.algorithm = algorithm
@@ -132,7 +132,9 @@ class GNN_RUL_trainer(object):
                 preds.append(predictions.detach())
                 trues.append(labels)
         losses = [float(v) for v in torch.stack(loss_total).cpu()] if loss_total else []
-        if not preds:
+        if not preds:                 # an empty set -- or this rank's empty shard of a set smaller than the world
+            if self.device.type == "cuda":
+                return torch.empty(0, device=self.device), torch.empty(0, device=self.device), losses
             return np.array([]), np.array([]), losses
         pred_labels, true_labels = torch.cat(preds), torch.cat(trues)
         if pred_labels.is_cuda:
@@ -148,7 +150,7 @@ class GNN_RUL_trainer(object):
             test_pre, test_real, test_total_loss = {}, {}, {}
             for key, dl in self.test_dl.items():
                 pre_i, real_i, loss_i = self.test_base(model, dl)
-                test_pre[key], test_real[key], test_total_loss[key] = pre_i, real_i, torch.tensor(loss_i).mean()
+                test_pre[key], test_real[key], test_total_loss[key] = pre_i, real_i, torch.tensor(loss_i).mean()      # (of this rank's batches)
         else:
             test_pre, test_real, test_total_loss = self.test_base(model, self.test_dl)
             test_total_loss = torch.tensor(test_total_loss).mean()
@@ -158,24 +160,58 @@ class GNN_RUL_trainer(object):
         names = ('Score_v1', 'Score_v2', 'MAE', 'RMSE')
         save_path = os.path.join(self.exp_log_dir, self.GNN_method + "_run_" + str(run_id))
 
-        def one(pred, real, max_rul, best, stem, label):
-            ind = _calc_metrics(pred, real, max_rul)
-            if ind[3] < best[3][-1]:
+        def one(pred, real, max_rul, best, stem, label, loader):
+            sharded = self.dp is not None and getattr(loader, "shard_samples", False)
+            ind = sharded_metrics(pred, real, max_rul, self.dp) if sharded else _calc_metrics(pred, real, max_rul)
+            if ind[3] < best[3][-1]:          # the same decision on every rank (they hold the same all-reduced numbers)
                 for i in range(4):
                     best[i].append(ind[i])
-                host = lambda v: v.cpu().numpy().astype(np.float64) if torch.is_tensor(v) else v
-                torch.save({'pre': host(pred), 'real': host(real), 'max_rul': max_rul}, os.path.join(save_path, f"{stem}results.pt"))
-            pd.DataFrame({n: best[i] for i, n in enumerate(names)}).to_csv(os.path.join(save_path, f"{stem}results.csv"),
-                                                                          index=False)
+                if sharded:                   # a best row is saved with its predictions: collect the shards, in rank order = sample order
+                    pred, real = gather_shards(pred, loader, self.dp), gather_shards(real, loader, self.dp)
+                if self.rank == 0:
+                    host = lambda v: v.cpu().numpy().astype(np.float64) if torch.is_tensor(v) else v
+                    torch.save({'pre': host(pred), 'real': host(real), 'max_rul': max_rul}, os.path.join(save_path, f"{stem}results.pt"))
+            if self.rank == 0:
+                pd.DataFrame({n: best[i] for i, n in enumerate(names)}).to_csv(os.path.join(save_path, f"{stem}results.csv"),
+                                                                              index=False)
             self.logger.debug(f'Testing{label}, ' + ', '.join(f'{n}: {best[i][-1]}' for i, n in enumerate(names)))
 
         if isinstance(self.pred_labels, dict):
             for key in self.pred_labels.keys():
                 key_save = int(key) if isinstance(key, float) else key
                 one(self.pred_labels[key], self.true_labels[key], self.max_ruls[key], self.best_result[key],
-                    f"{key_save}_", f" {key_save}")
+                    f"{key_save}_", f" {key_save}", self.test_dl[key])
         else:
-            one(self.pred_labels, self.true_labels, self.max_ruls, self.best_result, "", "")
+            one(self.pred_labels, self.true_labels, self.max_ruls, self.best_result, "", "", self.test_dl)
+
+
+def sharded_metrics(pred, real, max_rul, dp):
+    """(Score_v1, Score_v2, MAE, RMSE) of a test set whose predictions are spread over the ranks (reference formulas utils.py:136-201):
+    each rank reduces ITS shard on the device to four fp64 sums (``rulgnn_rul_metric_sums_f32``), one all-reduce carries them and the
+    counts, every rank closes with the same divisions.  A rank whose shard is empty (fewer samples than ranks) contributes zeros."""
+    if torch.is_tensor(pred) and pred.is_cuda:
+        sums = device_metric_sums(pred, real, max_rul)
+    else:                                     # host arrays (CPU tests of the collective logic): the vectorised numpy forms, as sums
+        p, r = np.asarray(pred, np.float64).reshape(-1), np.asarray(real, np.float64).reshape(-1)
+        from .metrics import scoring_function, scoring_function_v2
+        n = p.shape[0]
+        s = [scoring_function(p, r, max_rul)[0], scoring_function_v2(p, r) * n, float(np.abs(r - p).sum()), float(((r - p) ** 2).sum()),
+             float(n)] if n else [0.0] * 5
+        sums = torch.tensor(s, dtype=torch.float64)
+    torch.distributed.all_reduce(sums, op=torch.distributed.ReduceOp.SUM, group=dp.group)
+    return metrics_from_sums(sums, max_rul)
+
+
+def gather_shards(values, loader, dp):
+    """The full vector of a sample-sharded test set on every rank: each rank writes its shard into a zero vector at its offsets and the
+    vectors are summed (exact: every element is one value plus zeros; works on every backend, unlike all_gather of ragged CUDA
+    tensors under gloo).  Only issued when a best row is saved."""
+    v = values if torch.is_tensor(values) else torch.as_tensor(np.asarray(values))
+    full = torch.zeros(loader.global_n, dtype=v.dtype, device=v.device)
+    lo, hi = loader.shard
+    full[lo:hi] = v.reshape(-1)
+    torch.distributed.all_reduce(full, op=torch.distributed.ReduceOp.SUM, group=dp.group)
+    return full
 
 
 class _NullLogger:

@@ -171,6 +171,11 @@ typedef int (*rulgnn_allreduce_f64_fn)(void *user, double *device_buf, int32_t c
 int rulgnn_stgcn_train_fwdbwd_syncbn_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                          float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void *user,
                                          void *stream);
+/* The same with the launch form chosen by the caller (RULGNN_STEP_AUTO / _CHAIN / _MX below; the entry above is RULGNN_STEP_CHAIN).
+ * On the matrix-core chain the f16 range guard applies: see RULGNN_STEP_MX. */
+int rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
+                                              float bn_param_grad_scale, rulgnn_allreduce_f64_fn allreduce, void *user,
+                                              int32_t path, void *stream);
 
 /* Data parallel with a LARGE gradient bucket (num_patch > 64: theta and fc1 are num_patch x num_patch -- 12.6 MB at the reference's
  * XJTU-SY wiring, configs/hparams.py:349): rulgnn_stgcn_train_fwdbwd_f32 that reports gradient regions as they become final, so
@@ -227,8 +232,18 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
  *                      [0, 1] or [-1, 1]) ends as Inf / NaN in a sum or a gradient row, the step's status word is raised and the
  *                      finalize kernel then leaves parameters, optimizer state and running statistics UNTOUCHED and reports a NaN
  *                      loss (and NaN-free untouched state): repeat that step with RULGNN_STEP_CHAIN.
+ *                      A rejected step also increments a STICKY counter inside the workspace
+ *                      (rulgnn_stgcn_train_guard_counter_offset) that no kernel ever clears: a caller that does not read the loss
+ *                      back every step checks it at its own pace (once per epoch) and so cannot lose a step silently.
  *   RULGNN_STEP_AUTO   = RULGNN_STEP_MX where it applies, else RULGNN_STEP_CHAIN.
- * num_patch > 64 (tiled path) ignores `path`. */
+ * num_patch > 64 (tiled path) ignores `path`.
+ *
+ * CONTRACT (round 5): only THIS entry (explicit `path`), rulgnn_stgcn_train_step_f32 (a whole step: the library owns the optimizer
+ * and honours the guard itself) and rulgnn_stgcn_train_fwdbwd_syncbn_path_f32 can run the matrix-core chain.  The split entries --
+ * rulgnn_stgcn_train_fwdbwd_f32, _fwdbwd_ready_f32, _fwdbwd_syncbn_f32, after which the CALLER runs rulgnn_adam_step_f32 /
+ * rulgnn_bn_running_update_f32 -- always run the fp32 phases, so the documented three-call flow never applies a rejected step's
+ * gradients.  A caller that passes RULGNN_STEP_AUTO / _MX with opt == NULL must use the guarded optimizer entries
+ * (rulgnn_adam_step_guarded_f32, rulgnn_bn_running_update_guarded_f32, rulgnn_adam_bn_step_f32 with guard = args->loss). */
 #define RULGNN_STEP_AUTO  0
 #define RULGNN_STEP_CHAIN 1
 #define RULGNN_STEP_COOP  2
@@ -238,6 +253,13 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulg
 /* Which form a whole MSE step (args->y) with `path` runs for this shape and input pointer: RULGNN_STEP_CHAIN, RULGNN_STEP_COOP or
  * RULGNN_STEP_MX; RULGNN_EUNSUPPORTED for the tiled path (num_patch > 64) and for an explicit form the shape does not allow.  No launch. */
 int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape *shape, const float *x, int32_t path);
+/* Byte offset, inside a training workspace of this shape, of a uint32 that counts the steps the f16 range guard rejected since the
+ * caller last zeroed it (the library only ever adds to it; a caller that wants the count zeroes these four bytes when it allocates the
+ * workspace).  -1: the shape runs on the tiled path (no matrix-core chain, no guard). */
+int64_t rulgnn_stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape *shape);
+/* sizeof(rulgnn_stgcn_train_args) as this library was built: the struct has grown by trailing fields (`flags`, round 4); a caller
+ * built against another header compares this with its own sizeof before the first call. */
+size_t rulgnn_stgcn_train_args_size(void);
 
 /* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head
@@ -938,6 +960,12 @@ int rulgnn_gru_backward_f32(const rulgnn_gru_shape *shape, const rulgnn_gru_args
 size_t rulgnn_rul_metrics_workspace_bytes(int64_t n);
 int rulgnn_rul_metrics_f32(const float *pred, const float *real, int64_t n, float max_rul, double *out, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* The same pass that stops at the four SUMS: out[0..3] = sum of the Score_v1 terms, sum of the Score_v2 terms, sum |real - pred|,
+ * sum (real - pred)^2 over this call's n samples -- one rank's contribution when a test set is sharded across the GPUs (SURVEY section 8f
+ * rank 4): SUM the four doubles and n over the ranks (one 5-double all-reduce), then Score_v1 = S0, Score_v2 = S1 / n,
+ * MAE = S2 / n * max_rul, RMSE = sqrt(S3 / n) * max_rul (utils.py:136-169).  Same workspace as rulgnn_rul_metrics_f32. */
+int rulgnn_rul_metric_sums_f32(const float *pred, const float *real, int64_t n, float max_rul, double *out, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

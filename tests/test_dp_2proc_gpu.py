@@ -36,14 +36,14 @@ def _make(family, cfg, dev):
     return algo
 
 
-def _data(cfg_shape, B, dev):
+def _data(cfg_shape, B, dev, scale=1.0):
     g = torch.Generator(device="cpu").manual_seed(17)
-    X = torch.rand((B,) + tuple(cfg_shape), generator=g).to(dev)
+    X = (torch.rand((B,) + tuple(cfg_shape), generator=g) * scale).to(dev)
     y = torch.rand((B, 1), generator=g).to(dev)
     return X, y
 
 
-def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out):
+def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out, scale=1.0, sync_loss=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,12 +56,18 @@ def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out)
         if overlap_min is not None:
             dp.OVERLAP_MIN_BYTES = overlap_min
         algo.attach_data_parallel(dp)
-        X, y = _data(shape, B, dev)
+        X, y = _data(shape, B, dev, scale)
         lo, hi = shard_bounds(B, world, rank)
+        algo.sync_loss = sync_loss
         losses = [algo.update(X[lo:hi], y[lo:hi], 1, global_batch=B, sample_offset=lo)["loss"] for _ in range(2)]
+        losses = [float(v) for v in losses]
         torch.cuda.synchronize()
-        out[rank] = {"loss": losses, "flat": algo.model.flat_params.detach().cpu().numpy(), "bn": algo.model._bn.detach().cpu().numpy(),
-                     "shard": hi - lo, "regions": getattr(dp, "last_overlap_regions", None)}
+        bn = getattr(algo.model, "_bn", None)
+        out[rank] = {"loss": losses, "flat": algo.model.flat_params.detach().cpu().numpy(),
+                     "bn": bn.detach().cpu().numpy() if bn is not None else np.zeros(1, np.float32),
+                     "shard": hi - lo, "regions": getattr(dp, "last_overlap_regions", None),
+                     "step_path": int(getattr(algo.model, "step_path", -1)),
+                     "trips": algo.model.guard_trips() if hasattr(algo.model, "guard_trips") else 0}
     finally:
         dist.destroy_process_group()
 
@@ -158,3 +164,95 @@ def test_stgcn_tiled_path_overlapped_all_reduce_two_processes(B):
 def test_synchronised_batchnorm_families_two_processes(family, B):
     r0, r1, ref = _run(_hp_case(family), B, True)
     _check(r0, r1, ref, 3e-4)
+
+
+# ---- the f16 range guard under data parallelism -------------------------------------------------------------------
+def _run_scaled(case, B, sync_bn, scale, sync_loss):
+    family, cfg, shape = case
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), family, cfg, shape, B, sync_bn, None, out, scale, sync_loss), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+@pytest.mark.parametrize("B", [37, 1])
+def test_guard_trip_retries_on_the_fp32_chain_on_every_rank(sync_bn, B):
+    """Inputs beyond the f16 range, per-step loss read-back: the NaN travels in the all-reduced bucket, EVERY rank (also one whose shard is
+    empty, B = 1) skips the guarded optimizer, repeats the step on the fp32 phases -- under synchronised BatchNorm too: the launch form
+    is passed down (rulgnn_stgcn_train_fwdbwd_syncbn_path_f32) -- and ends with finite, identical replicas that equal a model that was
+    on the fp32 chain all along."""
+    from gnn_rul_benchmarking_amd import _lib
+    r0, r1 = _run_scaled(STGCN_MX, B, sync_bn, 3.0e4, True)
+    assert r0["step_path"] == r1["step_path"] == _lib.STEP_CHAIN
+    assert np.all(np.isfinite(r0["loss"])) and r0["loss"] == r1["loss"]
+    assert np.all(np.isfinite(r0["flat"])) and np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["bn"], r1["bn"])
+    assert np.all(np.isfinite(r0["bn"]))
+    # the single-process fp32-chain run of the same global batch (synchronised BatchNorm = the function of the concatenated batch)
+    if sync_bn:
+        dev = torch.device("cuda:0")
+        ref = _make(*STGCN_MX[:2], dev)
+        ref.model.step_path = _lib.STEP_CHAIN
+        X, y = _data(STGCN_MX[2], B, dev, 3.0e4)
+        want = [ref.update(X, y, 1)["loss"] for _ in range(2)]
+        assert np.allclose(r0["loss"], want, rtol=1e-5)
+        assert np.max(np.abs(r0["flat"] - ref.model.flat_params.detach().cpu().numpy())) < 2e-4
+
+
+def test_guard_trip_without_loss_readback_is_counted_on_every_rank():
+    """``sync_loss=False``: no retry is possible; the dropped steps are counted from the all-reduced loss, the same number on both ranks."""
+    r0, r1 = _run_scaled(STGCN_MX, 37, False, 3.0e4, False)
+    assert r0["trips"] == r1["trips"] == 2 and np.all(np.isnan(r0["loss"]))
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.all(np.isfinite(r0["flat"]))
+
+
+# ---- sharded evaluation (SURVEY section 8f rank 4) -------------------------------------------------------------------------------------------
+def _eval_worker(rank, world, port, n, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_rul_benchmarking_amd.dataloader import DeviceBatchLoader
+        from gnn_rul_benchmarking_amd.dp import DataParallel
+        from gnn_rul_benchmarking_amd.trainer import gather_shards, sharded_metrics
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        algo = _make(*STGCN_MX[:2], dev)
+        X, y = _data(STGCN_MX[2], n, dev)
+        dl = DeviceBatchLoader(X.cpu(), y.cpu(), 16, False, False, dev, rank, world, shard_samples=True)
+        model = algo.model
+        model.eval()
+        preds, reals = [], []
+        with torch.no_grad():
+            for xb, yb, _, _ in dl:
+                preds.append(model(xb).view(-1)); reals.append(yb.view(-1))
+        pred = torch.cat(preds) if preds else torch.empty(0, device=dev)
+        real = torch.cat(reals) if reals else torch.empty(0, device=dev)
+        dp = DataParallel()
+        m = sharded_metrics(pred, real, 125.0, dp)
+        full = gather_shards(pred, dl, dp)
+        out[rank] = {"metrics": m, "full": full.cpu().numpy(), "shard": dl.shard}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [75, 1])
+def test_sharded_evaluation_equals_the_single_process_evaluation(n):
+    """Each rank evaluates its contiguous shard of the test set with the real eval kernel, reduces it on the device to four fp64 sums, one
+    all-reduce: the metrics equal the single-process ``device_metrics`` of the whole set to 1e-12, and the gathered predictions are the
+    single-process predictions bit for bit (an eval forward does not depend on its batch mates)."""
+    from gnn_rul_benchmarking_amd.metrics import device_metrics
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_eval_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    dev = torch.device("cuda:0")
+    algo = _make(*STGCN_MX[:2], dev)
+    X, y = _data(STGCN_MX[2], n, dev)
+    algo.model.eval()
+    with torch.no_grad():
+        pred = algo.model(X).view(-1)
+    want = device_metrics(pred, y.view(-1), 125.0)
+    assert out[0]["metrics"] == out[1]["metrics"]
+    assert np.allclose(out[0]["metrics"], want, rtol=1e-12, atol=0)
+    assert np.array_equal(out[0]["full"], pred.cpu().numpy()) and np.array_equal(out[1]["full"], out[0]["full"])
+    assert out[0]["shard"] == (0, (n + 1) // 2) and out[1]["shard"] == ((n + 1) // 2, n)

@@ -861,3 +861,45 @@ def test_overlapped_all_reduce_issues_the_same_collectives_on_every_rank_world2_
     n0 = (B + 1) // 2
     want = sum(float(part.sum()) + np.arange(4096, dtype=np.float32) * 1e-3 for part in (x[:n0], x[n0:]) if part.shape[0] > 0)
     assert np.allclose(r0["bucket"][:4096], want, rtol=1e-6)
+
+
+# ---- sharded evaluation: metrics of a test set spread over the ranks -------------------------------------------
+def _sharded_eval_worker(rank, world, port, n, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_rul_benchmarking_amd.dataloader import DeviceBatchLoader
+        from gnn_rul_benchmarking_amd.dp import DataParallel
+        from gnn_rul_benchmarking_amd.trainer import gather_shards, sharded_metrics
+        g = torch.Generator().manual_seed(5)
+        X, y = torch.rand(n, 3, 4, generator=g), torch.rand(n, 1, generator=g)
+        pred_full = (y.view(-1) + 0.05 * torch.randn(n, generator=g)).clamp_min(0.0)
+        dl = DeviceBatchLoader(X, y, 4, False, False, "cpu", rank, world, shard_samples=True)
+        lo, hi = dl.shard
+        seen = [yb for _, yb, _, _ in dl]
+        got_y = torch.cat(seen).view(-1) if seen else torch.empty(0)
+        assert torch.equal(got_y, y.view(-1)[lo:hi]) and dl.global_n == n
+        dp = DataParallel()
+        m = sharded_metrics(pred_full[lo:hi].numpy(), y.view(-1)[lo:hi].numpy(), 125.0, dp)
+        full = gather_shards(pred_full[lo:hi], dl, dp)
+        out[rank] = {"metrics": m, "full_equal": bool(torch.equal(full, pred_full)), "shard": (lo, hi)}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37, 1, 2])
+def test_sharded_test_set_metrics_equal_the_single_process_metrics_world2_gloo(n):
+    """Contiguous shards (19 + 18; 1 + 0: an EMPTY shard joins with zeros), four sums + count in one all-reduce, the reference's closing
+    divisions on every rank: equal to ``_calc_metrics`` of the whole set to 1e-12; the gathered prediction vector is the original."""
+    from gnn_rul_benchmarking_amd.metrics import _calc_metrics
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sharded_eval_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(5)
+    X, y = torch.rand(n, 3, 4, generator=g), torch.rand(n, 1, generator=g)
+    pred_full = (y.view(-1) + 0.05 * torch.randn(n, generator=g)).clamp_min(0.0)
+    want = _calc_metrics(pred_full.numpy().astype(np.float64), y.view(-1).numpy().astype(np.float64), 125.0)
+    assert out[0]["metrics"] == out[1]["metrics"]
+    assert np.allclose(out[0]["metrics"], want, rtol=1e-12, atol=0)
+    assert out[0]["full_equal"] and out[1]["full_equal"]
+    assert out[0]["shard"][1] == out[1]["shard"][0] and out[1]["shard"][1] == n

@@ -176,6 +176,67 @@ def test_update_repeats_a_rejected_step_on_the_fp32_chain():
     assert np.isfinite(lc) and c.model.step_path == _lib.STEP_AUTO and c.model.guard_tensor is not None
 
 
+def test_a_rejected_step_without_loss_readback_is_never_silent():
+    """``sync_loss=False`` (what bench.py times; no host read-back per step): a step the f16 range guard rejects is DROPPED -- NaN loss,
+    state untouched -- and must not vanish (the reference never drops a step, algorithms.py:486-490): the kernels count it in a sticky
+    workspace counter; ``check_guard()``, ``model.eval()`` and ``state_dict()`` raise; in-range steps never do."""
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    dev = torch.device("cuda:0")
+    cfg = dict(num_patch=14, patch_size=30, dropout=0.2)
+    hp = {"learning_rate": 1e-3, "weight_decay": 1e-4}
+    g = torch.Generator(device=dev).manual_seed(5)
+    X = torch.rand(300, 14, 30, device=dev, generator=g)
+    y = torch.rand(300, 1, device=dev, generator=g)
+    torch.manual_seed(11)
+    a = ST_GCN(cfg, hp, dev); a.to(dev); a.train()
+    a.sync_loss = False
+    for _ in range(3):
+        loss = a.update(X, y, 1)["loss"]
+    assert torch.is_tensor(loss) and bool(torch.isfinite(loss))
+    a.check_guard()                                   # nothing was rejected: no error, and eval() / state_dict() pass
+    a.model.eval(); a.train(); a.state_dict()
+    before = a.model.flat_params.clone()
+    l1 = a.update(X * 3.0e4, y, 1)["loss"]            # out of the f16 range: rejected
+    l2 = a.update(X, y, 1)["loss"]                    # the next in-range step runs normally (clean-workspace claim included)
+    assert bool(torch.isnan(l1)) and bool(torch.isfinite(l2))
+    assert not torch.equal(a.model.flat_params, before)
+    with pytest.raises(RuntimeError, match="rejected by the f16 range guard"):
+        a.check_guard()
+    a.check_guard()                                   # reported once; the counter is sticky on the device, consumed on the host
+    a.update(X * 3.0e4, y, 1)
+    with pytest.raises(RuntimeError, match="1 training step"):
+        a.model.eval()
+    a.update(X * 3.0e4, y, 1); a.update(X * 3.0e4, y, 1)
+    with pytest.raises(RuntimeError, match="2 training step"):
+        a.state_dict()
+    # a new batch size (another workspace) keeps counting; a model on the fp32 chain never counts
+    a.update(X[:64] * 3.0e4, y[:64], 1)
+    assert a.model.guard_trips() == 1
+    a.model.step_path = _lib.STEP_CHAIN
+    lc = a.update(X * 3.0e4, y, 1)["loss"]
+    assert bool(torch.isfinite(lc)) and a.model.guard_trips() == 0
+
+
+def test_split_fwdbwd_entry_stays_on_the_fp32_phases():
+    """include/rulgnn.h, CONTRACT (round 5): rulgnn_stgcn_train_fwdbwd_f32 -- after which a C caller runs its own rulgnn_adam_step_f32 --
+    never runs the matrix-core chain, so that flow cannot apply a rejected step's gradients: out-of-range inputs give a FINITE loss and
+    gradient there, and the library's struct size is what this binding was written against."""
+    import gpu_util as G
+    lib = _lib.load()
+    assert lib.rulgnn_stgcn_train_args_size() == C.sizeof(_lib.StgcnTrainArgs)
+    N, P, B, L = 14, 30, 64, 2
+    rng = np.random.default_rng(3)
+    flat, _ = PL.pack_numpy(O.random_params(N, L, seed=3), N, L)
+    x = (rng.uniform(0, 1, (B, N, P)) * 3.0e4).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    r = G.abi_train(x, y, flat, N, P, L)
+    assert np.isfinite(r["loss"]) and np.all(np.isfinite(r["grads"]))
+    shp = G.shape_struct(B, N, P, L)
+    off = lib.rulgnn_stgcn_train_guard_counter_offset(C.byref(shp))
+    assert 0 < off < lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp)) - 4 and off % 4 == 0
+    assert lib.rulgnn_stgcn_train_guard_counter_offset(C.byref(G.shape_struct(B, 72, 8, L))) == -1      # tiled path: no guard
+
+
 # ---- RULGNN_TRAIN_WS_CLEAN: a matrix-core step leaves the reduction cells zero, the next one may run without its prepare launch ----------
 class _Stepper:
     """Consecutive C-ABI steps (fused Adam) on ONE workspace."""
