@@ -368,13 +368,13 @@ def compute_leg(flops_per_sample, samples_per_s, what):
             "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "counts": what}
 
 
-def rmse_teacher_task(dev, epochs=3, n_train=49152, n_test=8192, batch=4096, max_rul=125.0):
+def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, max_rul=125.0, checkpoints=(36, 120, 240)):
     """The RMSE half of BASELINE.json's metric on SURVEY section 8(d)'s synthetic task: a fixed random "teacher" ST_GCN (14 x 30, eval
     mode) labels ~49 k uniform windows (about FD004's training-set size); a student with another initialisation is trained for `epochs`
     passes in batches of `batch`, dropout off, (a) on the HIP path (ST_GCN.update) and (b) by the torch-CPU restatement of the reference's
-    update (oracle/stgcn_torch_cpu.py) from the SAME initial weights on the same batches; both are then scored on held-out windows with
-    the reference's formula RMSE = sqrt(mean((pred - y)^2)) * max_rul (utils.py:148-151).  The north star asks |RMSE_hip - RMSE_cpu| <= 1e-3."""
-    import numpy as np
+    update (oracle/stgcn_torch_cpu.py) from the SAME initial weights on the same batches; both are scored on held-out windows with
+    the reference's formula RMSE = sqrt(mean((pred - y)^2)) * max_rul (utils.py:148-151) after 36, 120 and 240 optimizer steps (drift
+    shows as a growing difference).  The north star asks |RMSE_hip - RMSE_cpu| <= 1e-3."""
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
     from gnn_rul_benchmarking_amd.stgcn import ST_GCN_model
     from oracle import stgcn_torch_cpu as T
@@ -390,39 +390,93 @@ def rmse_teacher_task(dev, epochs=3, n_train=49152, n_test=8192, batch=4096, max
     algo.to(dev)
     init = {k: v.detach().cpu().numpy().copy() for k, v in algo.state_dict().items()}
     st = T.State(init, num_layers=2, lr=1e-3, weight_decay=1e-4)
-    Xd, yd = Xtr.to(dev), ytr.to(dev)
-    t0 = time.perf_counter()
+    Xd, yd, Xted = Xtr.to(dev), ytr.to(dev), Xte.to(dev)
+    yt = yte.reshape(-1).double()
+    rmse = lambda p_: float(torch.sqrt(torch.mean((p_.double() - yt) ** 2)) * max_rul)
+    threads = torch.get_num_threads()
+    t_hip = t_cpu = 0.0
+    hip_loss = cpu_loss = 0.0
+    step, marks = 0, []
+    for _ in range(epochs):
+        for lo in range(0, n_train, batch):
+            t0 = time.perf_counter()
+            algo.train()
+            hip_loss = algo.update(Xd[lo:lo + batch], yd[lo:lo + batch], 1)["loss"]
+            t_hip += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            cpu_loss = T.update(st, Xtr[lo:lo + batch], ytr[lo:lo + batch], N, P, 0.0)
+            t_cpu += time.perf_counter() - t0
+            step += 1
+            if step in checkpoints:
+                algo.eval()
+                with torch.no_grad():
+                    ph = algo.model(Xted).cpu().reshape(-1)
+                    pc = T.forward(st, Xte, N, P, False).reshape(-1)
+                marks.append({"steps": step, "rmse_hip": round(rmse(ph), 6), "rmse_torch_cpu": round(rmse(pc), 6),
+                              "abs_diff": round(abs(rmse(ph) - rmse(pc)), 7), "train_loss_hip": round(float(hip_loss), 8),
+                              "train_loss_torch_cpu": round(float(cpu_loss), 8), "max_pred_diff": round(float((ph.double() - pc.double()).abs().max()), 8)})
+    torch.set_num_threads(threads)
+    base = float(torch.sqrt(torch.mean((yt.mean() - yt) ** 2)) * max_rul)
+    last = marks[-1]
+    return {"task": f"teacher ST_GCN({N}, {P}) labels {n_train} uniform windows; student trained {epochs} epochs, batch {batch}, dropout off, "
+                    f"Adam lr 1e-3 wd 1e-4; scored on {n_test} held-out windows, RMSE x max_rul {max_rul:g} (reference utils.py:148-151)",
+            "rmse_hip": last["rmse_hip"], "rmse_torch_cpu": last["rmse_torch_cpu"], "abs_diff": last["abs_diff"],
+            "within_1e-3": bool(all(m["abs_diff"] <= 1e-3 for m in marks)), "after_steps": marks, "rmse_of_predicting_the_mean": round(base, 4),
+            "final_train_loss_hip": last["train_loss_hip"], "final_train_loss_torch_cpu": last["train_loss_torch_cpu"],
+            "steps": step, "seconds_hip": round(t_hip, 2), "seconds_torch_cpu": round(t_cpu, 2), "max_pred_diff": last["max_pred_diff"]}
+
+
+def rmse_teacher_task_stmsgcn(dev, n_train=4000, n_test=1000, batch=100, epochs=6, max_rul=1.0, checkpoints=(36, 120, 240)):
+    """The same experiment on a family WITHOUT BatchNorm and dropout (STMSGCN at the reference's PHM2012 Condition_1 wiring, 160 patches of
+    16 points, the protocol's batch 100, configs/hparams.py): teacher-labelled windows, the student trained on the HIP path and by the
+    torch-CPU restatement (oracle/families_torch_cpu.py) from the same weights on the same batches; 240 optimizer steps."""
+    from gnn_rul_benchmarking_amd.algorithms import STMSGCN
+    from gnn_rul_benchmarking_amd.stmsgcn import STMSGCN_model
+    from gnn_rul_benchmarking_amd import hparams as HP
+    from oracle import families_torch_cpu as T
+    hp = HP.get_hparams_class("PHM2012")("Condition_1")
+    cfg = dict(hp.alg_hparams["STMSGCN"])
+    L = cfg["num_patch"] * cfg["patch_size"]
+    g = torch.Generator(device="cpu").manual_seed(777)
+    Xtr, Xte = torch.rand(n_train, 1, L, generator=g), torch.rand(n_test, 1, L, generator=g)
+    torch.manual_seed(101)
+    teacher = STMSGCN_model(**cfg).to(dev).eval()
+    with torch.no_grad():
+        ytr, yte = teacher(Xtr.to(dev)).cpu(), teacher(Xte.to(dev)).cpu()
+    torch.manual_seed(8)
+    tc = {"learning_rate": 1e-3, "weight_decay": 0.0}
+    algo = STMSGCN(cfg, tc, dev)
+    algo.to(dev)
     algo.train()
-    hip_loss = 0.0
+    init = {k: v.detach().cpu().numpy().copy() for k, v in algo.state_dict().items()}
+    st = T.StmsgcnState(init, cfg, lr=tc["learning_rate"], weight_decay=tc["weight_decay"])
+    Xd, yd, Xted = Xtr.to(dev), ytr.to(dev), Xte.to(dev)
+    yt = yte.reshape(-1).double()
+    rmse = lambda p_: float(torch.sqrt(torch.mean((p_.double() - yt) ** 2)) * max_rul)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    step, marks, t_cpu = 0, [], 0.0
     for _ in range(epochs):
         for lo in range(0, n_train, batch):
             hip_loss = algo.update(Xd[lo:lo + batch], yd[lo:lo + batch], 1)["loss"]
-    algo.eval()
-    with torch.no_grad():
-        ph = algo.model(Xte.to(dev)).cpu().reshape(-1)
-    t_hip = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    threads = torch.get_num_threads()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    cpu_loss = 0.0
-    for _ in range(epochs):
-        for lo in range(0, n_train, batch):
-            cpu_loss = T.update(st, Xtr[lo:lo + batch], ytr[lo:lo + batch], N, P, 0.0)
-    with torch.no_grad():
-        pc = T.forward(st, Xte, N, P, False).reshape(-1)
+            t0 = time.perf_counter()
+            cpu_loss = T.stmsgcn_update(st, Xtr[lo:lo + batch], ytr[lo:lo + batch])
+            t_cpu += time.perf_counter() - t0
+            step += 1
+            if step in checkpoints:
+                with torch.no_grad():
+                    ph = algo.model(Xted).cpu().reshape(-1)
+                    pc = T.stmsgcn_forward(st, Xte).reshape(-1)
+                scale = float(yt.abs().max())
+                marks.append({"steps": step, "rmse_hip": round(rmse(ph), 8), "rmse_torch_cpu": round(rmse(pc), 8),
+                              "rel_diff": round(abs(rmse(ph) - rmse(pc)) / max(rmse(pc), 1e-30), 8), "train_loss_hip": float(hip_loss),
+                              "train_loss_torch_cpu": float(cpu_loss), "max_pred_diff_over_label_scale": round(float((ph.double() - pc.double()).abs().max()) / scale, 8)})
     torch.set_num_threads(threads)
-    t_cpu = time.perf_counter() - t0
-    yt = yte.reshape(-1).double()
-    rmse = lambda p_: float(torch.sqrt(torch.mean((p_.double() - yt) ** 2)) * max_rul)
-    r_hip, r_cpu = rmse(ph), rmse(pc)
-    base = float(torch.sqrt(torch.mean((yt.mean() - yt) ** 2)) * max_rul)
-    return {"task": f"teacher ST_GCN({N}, {P}) labels {n_train} uniform windows; student trained {epochs} epochs, batch {batch}, dropout off, "
-                    f"Adam lr 1e-3 wd 1e-4; scored on {n_test} held-out windows, RMSE x max_rul {max_rul:g} (reference utils.py:148-151)",
-            "rmse_hip": round(r_hip, 6), "rmse_torch_cpu": round(r_cpu, 6), "abs_diff": round(abs(r_hip - r_cpu), 7),
-            "within_1e-3": bool(abs(r_hip - r_cpu) <= 1e-3), "rmse_of_predicting_the_mean": round(base, 4),
-            "final_train_loss_hip": round(float(hip_loss), 8), "final_train_loss_torch_cpu": round(float(cpu_loss), 8),
-            "steps": epochs * ((n_train + batch - 1) // batch), "seconds_hip": round(t_hip, 2), "seconds_torch_cpu": round(t_cpu, 2),
-            "max_pred_diff": round(float((ph.double() - pc.double()).abs().max()), 8)}
+    return {"task": f"teacher STMSGCN (PHM2012 Condition_1 wiring {cfg['num_patch']} x {cfg['patch_size']}) labels {n_train} uniform windows; student "
+                    f"trained {epochs} epochs at batch {batch} (Adam lr {tc['learning_rate']}, no weight decay; no BatchNorm, no dropout in this model); "
+                    f"RMSE on {n_test} held-out windows in label units", "after_steps": marks, "steps": step, "seconds_torch_cpu": round(t_cpu, 2),
+            "within_1e-3_relative": bool(all(m["rel_diff"] <= 1e-3 for m in marks))}
 
 
 def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
@@ -643,9 +697,38 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
     return None, None
 
 
-def family_cpu_baseline(family, cfg, shape, budget_s=10.0, model=None):
-    """The family's numpy oracle (train-step restatement) timed on this box's host cores, bounded sample."""
+TORCH_CPU_FAMILIES = ("FC_STGNN", "ASTGCNN", "HAGCN", "STMSGCN")
+
+
+def family_torch_cpu_baseline(family, cfg, batch, budget_s=10.0):
+    """the path the reference itself takes on a CPU -- ATen kernels, autograd, torch.optim.Adam -- restated in
+    oracle/families_torch_cpu.py (pinned to the reference's own fixtures, tests/test_torch_cpu_families.py) and timed on this box's host
+    cores: a FULL update() at the configuration's batch, 1 thread and 16 / 64 threads, up to 100 iterations or the time budget."""
+    from oracle import families_torch_cpu as T
+    cores = os.cpu_count() or 1
+    counts = sorted({1, min(16, cores), min(64, cores)})
+    per = budget_s / len(counts)
+    runs = [T.time_update(family, dict(cfg), batch, th, warmup=3, iters=100, budget_s=per) for th in counts]
+    best = max(runs, key=lambda r: r["samples_per_s"])
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "torch-cpu restatement",
+            "cpu_model": T.cpu_model_name(), "host_cpus": cores, "torch": torch.__version__, "runs": runs,
+            "sample": f"full update() (train forward + loss + backward + torch.optim.Adam) of oracle/families_torch_cpu.py at batch {batch}, "
+                      f"fp32 ATen kernels, threads {counts}, <= {per:.1f} s or 100 iterations each (iterations timed: "
+                      f"{[r['iterations'] for r in runs]})",
+            "reference_on_survey_container": BASELINE_MD_FAMILY.get(family)}
+
+
+# BASELINE.md section 2: the reference's own update() on the survey container (8 vCPU Xeon 2.1 GHz), samples/s
+BASELINE_MD_FAMILY = {"FC_STGNN": "1 648 samples/s at batch 256", "ASTGCNN": "19 336 samples/s at batch 512", "HAGCN": "305 samples/s at batch 256 (FD001 wiring)",
+                      "STMSGCN": "67 samples/s at batch 128"}
+
+
+def family_cpu_baseline(family, cfg, shape, budget_s=10.0, model=None, batch=None):
+    """The family's CPU baseline on this box's host cores, bounded sample: the torch-CPU restatement for the BASELINE.json families,
+    the numpy oracle (train-step restatement, ``kind: port``) for the section 8(f) families."""
     import numpy as np
+    if family in TORCH_CPU_FAMILIES and batch is not None:
+        return family_torch_cpu_baseline(family, cfg, batch, budget_s)
     rng = np.random.default_rng(0)
     if family == "HAGCN" and model is None:
         return None
@@ -867,7 +950,7 @@ def family_line(args, family, world, rank, dev, use_dist, dist, batch=None, cpu_
     if variant_error is not None:
         out["variant_error"] = variant_error
     if world == 1 and not args.no_cpu_baseline:
-        cb = family_cpu_baseline(args.family, cfg, shape, budget_s=cpu_budget_s, model=algo.model)
+        cb = family_cpu_baseline(args.family, cfg, shape, budget_s=cpu_budget_s, model=algo.model, batch=B)
         if cb:
             out["cpu_baseline"] = cb
     return out
@@ -1009,6 +1092,11 @@ def main():
         strong = {"global_batch": sb * world, "per_gpu_batch": sb, "value": round(world * sb * args.steps / sel, 1), "unit": "samples/s",
                   "ms_per_step": round(sel / args.steps * 1e3, 4), "ms_per_step_repetitions": [round(e / args.steps * 1e3, 4) for e in sels]}
 
+    # a step the f16 range guard rejected would have been DROPPED (loss kept on the device): never silently
+    algo.check_guard()
+    from gnn_rul_benchmarking_amd import _lib as _L
+    on_mx = algo.model._last_chain == _L.STEP_MX
+    dtype_name = "f32 (f16x2-split MFMA operands, fp32 accumulate)" if on_mx else "f32"
     line = None
     line_out = None
     if rank == 0:
@@ -1017,7 +1105,7 @@ def main():
             "metric": "training samples/sec, C-MAPSS FD004-shaped ST_GCN", "value": round(total / el, 1),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if weak else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": f"ST_GCN.update (fwd+MSE+bwd+Adam), C-MAPSS FD004-shaped windows "
                                    f"[{NUM_PATCH} sensors x {args.patch_size}], per-GPU batch {per_rank}, dropout {args.dropout}, "
                                    f"lr {train_cfg['learning_rate']}, wd {train_cfg['weight_decay']}",
@@ -1045,6 +1133,12 @@ def main():
             algo.sync_loss = bool(args.sync_loss)
             out["with_per_step_loss_readback"] = {"ms_per_step": round(sl / args.steps * 1e3, 4), "value": round(per_rank * args.steps / sl, 1),
                                                   "unit": "samples/s", "note": "ST_GCN.update returning loss.item() every step like the reference"}
+            fp = stgcn_train_other_shape(dev, NUM_PATCH, args.patch_size, [per_rank], fp32_batches=(per_rank,))[f"batch_{per_rank}"]
+            out["fp32_chain_ms_per_step"] = fp["fp32_chain_ms_per_step"]
+            out["fp32_chain"] = {"ms_per_step": fp["fp32_chain_ms_per_step"], "value": round(per_rank / (fp["fp32_chain_ms_per_step"] * 1e-3), 1),
+                                 "unit": "samples/s", "vs_fp32_chain": fp["vs_fp32_chain"],
+                                 "note": "the same step with every product in plain fp32 FMAs (RULGNN_STEP_CHAIN, the path a guard trip falls back to), "
+                                         "same batch, dropout 0.2, timed beside the headline"}
             out["train_phm2012_40x64"] = dict(stgcn_train_other_shape(dev, 40, 64, [100, 16384, 65536], fp32_batches=(16384, 65536)),
                                               workload="ST_GCN.update at the reference's own PHM2012 wiring (40 patches x 64 points, configs/hparams.py:223,238): "
                                                        "wide matrix-core chain (one sample per wavefront in three column tiles, activations recomputed), the "
@@ -1052,6 +1146,7 @@ def main():
                                               algorithmic_bytes_per_sample=algorithmic_bytes_per_sample(40, 64))
         if world == 1 and not args.no_rmse:
             out["rmse"] = rmse_teacher_task(dev)
+            out["rmse"]["bn_free_family"] = rmse_teacher_task_stmsgcn(dev)
         line_out = out
     if world == 1 and rank == 0 and not args.no_families and args.family == "ST_GCN":
         # the other four BASELINE.json configurations, each on its SURVEY section 8d wiring: same contract, compact
@@ -1061,7 +1156,7 @@ def main():
             import copy
             fa = copy.copy(args)
             fa.steps, fa.warmup = (20, 5) if fam != "HAGCN" else (10, 3)
-            d = family_line(fa, fam, world, rank, dev, False, dist, cpu_budget_s=4.0)
+            d = family_line(fa, fam, world, rank, dev, False, dist, cpu_budget_s=9.0)
             r = d["roofline"]
             fams[fam] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
                          "workload": d["config"]["workload"], "per_gpu_batch": d["config"]["per_gpu_batch"], "final_loss": d["final_loss"],
