@@ -511,6 +511,46 @@ def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
     return out
 
 
+def stgcn_tiled_shapes(dev, steps=10):
+    """ST_GCN at the reference's own wirings with num_patch > 64 (configs/hparams.py:269,349,384,418: PHM2012 Condition_2 160 x 16, XJTU-SY 1024 x 32)
+    on the tiled path (csrc/stgcn_tiled.hip): theta / fc1 are num_patch x num_patch matrices there and theta(A.X) is a dense
+    [batch*10, N] x [N, N] contraction -- SURVEY section 8(d): 46.3 MFLOP per sample forward at 1024 x 32, 353 FLOP/B: priced on the MFMA
+    roofline (dense fp32-class products: the fp32 matrix peak; the large GEMM runs them as bf16 x 3 above that peak).
+    Full update() (forward + loss + backward + Adam + running statistics) at the reference protocol's batch (100) and at 1024, and the eval
+    forward."""
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    out = {}
+    for name, N, P, batches in (("xjtu_1024x32", 1024, 32, (100, 1024)), ("phm2012_c2_160x16", 160, 16, (100, 1024))):
+        # matmul FLOPs per sample forward: L x theta [10 x N x N] + fc1 [N x N] + A.X [10 x 10 x N] x L + conv 2 x [10 x 20 x N] x L
+        L = 2
+        fwd = 2.0 * (L * 10 * N * N + N * N + L * 100 * N + L * 2 * 200 * N)
+        entry = {"forward_matmul_flops_per_sample": fwd, "algorithmic_bytes_per_sample": algorithmic_bytes_per_sample(N, P)}
+        for B in batches:
+            g = torch.Generator(device=dev).manual_seed(5)
+            X, y = torch.rand(B, N, P, device=dev, generator=g), torch.rand(B, 1, device=dev, generator=g)
+            torch.manual_seed(0)
+            algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=0.3), {"learning_rate": 1e-5, "weight_decay": 1e-4}, dev)
+            algo.to(dev)
+            algo.train()
+            algo.sync_loss = False
+            ms = min(event_time_ms(lambda: algo.update(X, y, 1), steps, warm=3) for _ in range(3))
+            algo.eval()
+            with torch.no_grad():
+                ems = min(event_time_ms(lambda: algo.model(X), steps, warm=3) for _ in range(3))
+            tf, etf = 3.0 * fwd * B / (ms * 1e-3) / 1e12, fwd * B / (ems * 1e-3) / 1e12
+            entry[f"batch_{B}"] = {"train_ms_per_step": round(ms, 4), "train_samples_per_s": round(B / (ms * 1e-3), 1),
+                                   "eval_ms_per_batch": round(ems, 4), "eval_samples_per_s": round(B / (ems * 1e-3), 1),
+                                   "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "eval_achieved": round(etf, 2),
+                                                "eval_frac": round(etf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                                "counts": "whole step: 3 x the forward matmul FLOPs per sample x samples/s (not one kernel)"}}
+            del algo, X, y
+        out[name] = entry
+    out["profile"] = "profiles/r05_stgcn_tiled_xjtu_bs1024_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/time_tiled_one.py: 5 large GEMMs at " \
+                     "~147 TFLOP/s = 36 % of the step, the position-parallel kernels between them the rest)"
+    return out
+
+
 def cpu_baseline(num_patch, patch_size, dropout):
     """The reference's CPU path restated on torch-CPU (oracle/stgcn_torch_cpu.py: the same ATen kernels the reference runs,
     pinned to the reference's own training curve in tests/test_torch_cpu_baseline.py), SURVEY section 8(d) protocol:
@@ -1144,9 +1184,7 @@ def main():
                                                        "wide matrix-core chain (one sample per wavefront in three column tiles, activations recomputed), the "
                                                        "fp32 phase chain of rounds 1-3 timed beside it",
                                               algorithmic_bytes_per_sample=algorithmic_bytes_per_sample(40, 64))
-        if world == 1 and not args.no_rmse:
-            out["rmse"] = rmse_teacher_task(dev)
-            out["rmse"]["bn_free_family"] = rmse_teacher_task_stmsgcn(dev)
+            out["train_reference_wirings_tiled"] = stgcn_tiled_shapes(dev)
         line_out = out
     if world == 1 and rank == 0 and not args.no_families and args.family == "ST_GCN":
         # the other four BASELINE.json configurations, each on its SURVEY section 8d wiring: same contract, compact
@@ -1164,7 +1202,22 @@ def main():
                                                          "launches_in_step", "step_kernel_time_us", "share_of_step_kernel_time", "whole_step_estimate",
                                                          "work_model") if k in r},
                          "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "runs")} if "cpu_baseline" in d else None}
+        # BASELINE.json configs[1] is written "FC_STGNN ... bf16": the switch exists (bf16 operands on the row projections that run as GEMM
+        # launches, fp32 everything else) and is timed here beside the fp32 path the entry above reports; at the FD004 sizes those projections
+        # are fused kernels, so the variant is the same step -- stated, not hidden
+        fb = copy.copy(args)
+        fb.steps, fb.warmup, fb.dtype, fb.no_cpu_baseline, fb.no_roofline = 20, 5, "bf16", True, True
+        db = family_line(fb, "FC_STGNN", world, rank, dev, False, dist)
+        fams["FC_STGNN"]["bf16_variant"] = {"ms_per_step": db["ms_per_step"], "value": db["value"], "unit": db["unit"],
+                                            "error_vs_f32": db.get("variant_error"),
+                                            "note": "compute_dtype='bf16' (rulgnn_fcstgnn_args.compute_dtype): operands of the GEMM-launch row projections "
+                                                    "rounded to bf16; tests/test_fcstgnn_gpu.py bounds it against the fp64 oracle"}
         line_out["families"] = fams
+    if world == 1 and rank == 0 and not args.no_rmse:
+        # (after the family lines: the torch-CPU halves of these legs leave the host's thread pool warm and spinning, which the
+        # launch-bound FC_STGNN step right behind them paid for with 1.4 instead of 0.43 ms)
+        line_out["rmse"] = rmse_teacher_task(dev)
+        line_out["rmse"]["bn_free_family"] = rmse_teacher_task_stmsgcn(dev)
     if rank == 0:
         line = json.dumps(line_out)
     finish(line, use_dist, dist)

@@ -25,10 +25,12 @@
 // into the next weights; LeakyReLU is one fma, (1 + a)/2 folded into theta.  Four samples are in flight per wavefront so that
 // dependent MFMAs never wait.
 //
-// What the SIMD's issue port costs (tools/probe_issue.hip, round 3): everything adds up -- an f16 MFMA holds the port for its
-// 16 cycles (10 with an inline-zero C operand), also against the OTHER wavefront of the SIMD; v_cvt_pk_f16_f32, any DPP form,
-// v_max/min and every packed-f16 op are 4 cycles, plain fp32 ops 2.4.  So the kernel is shaped by instruction count, and by keeping
-// a wavefront's own stalls (LDS round trips, LDS-DMA issue, dependent chains) from coinciding with the other wavefront's.
+// What the SIMD's issue port costs (tools/probe_mixed.hip, round 5; profiles/r05_mfma_valu_overlap.md): an f16 16x16x32 MFMA is 16.3
+// cycles with either C form (round 3's "10 with an inline-zero C" came from a probe the compiler had CSE'd); against full-rate fp32 VALU
+// work it holds the port for all of them, also against the OTHER wavefront of the SIMD; beside the multi-cycle forms (v_cvt_pk_f16_f32,
+// DPP, v_max/min, packed f16: 4 cycles on the lanes, less on the port) about half of it hides.  Plain fp32 ops 2.4.  So the kernel is
+// shaped by instruction count, by spreading the MFMAs among the conversions, and by keeping a wavefront's own stalls (LDS round trips,
+// LDS-DMA issue, dependent chains) from coinciding with the other wavefront's.
 //
 // Around the layers: the patch statistics (Model.py:7-52) and the Pearson Gram matrix (Model.py:53-71, f32 4-block MFMAs,
 // exact) run in the row mapping of the exact kernel and are converted through the wavefront's LDS tile; the head
@@ -71,6 +73,8 @@ struct StageClk {
     unsigned long long t[MX_CLK_STAMPS];
     template <int I> __device__ __forceinline__ void stamp() {
         if (MX_STAGE_CLOCKS == 2 && I != 0 && I != 18) return;      // light form: only the ends of the iteration
+        if (MX_STAGE_CLOCKS == 3) return;                           // lifetime form: no stamp inside the loop at all (an outstanding SMEM
+                                                                    // result turns every LDS wait of the iteration into lgkmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
         t[I] = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
     const float fc2w_half = col < N ? 0.5f * fc2w_raw : 0.f;                         // fc1's ReLU arrives as 2 relu
     const float fc2b = prm[off_fc2_b(N, L)];
     // row t = 15 of T is 1 (the k = 15 slot of theta^T is the bias): OR-ed into the hi operand of T (column 15 of X is zero, so
-    // the matrix cores leave an exact 0 there) -- an MFMA with C = 0 issues in 10 cycles, with a register C in 16 (tools/probe_issue.hip)
+    // the matrix cores leave an exact 0 there): no separate bias add, every MFMA chain starts from C = 0
     const unsigned t_bias = g == 3 ? 0x3C00u << 16 : 0u;
     const float half_ok = col < N ? 0.5f : 0.f, quarter_ok = col < N ? 0.25f : 0.f;  // residual scales; padded columns stay 0
 
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
         any_bad |= __any(mine && !(__builtin_fabsf(pred) <= 3.0e38f)) != 0;
 #ifdef MX_STAGE_CLOCKS
         ck.template stamp<18>();
-        if constexpr (L == 2) {
+        if constexpr (L == 2 && MX_STAGE_CLOCKS != 3) {
             if (MX_STAGE_CLOCKS == 2) {
                 clk_acc[0] += (unsigned)(ck.t[18] - ck.t[0]);
             } else {

@@ -1,5 +1,6 @@
 """Stage clocks of the fused ST_GCN eval forward (development aid).
-    python tools/build_variants.py stgcn_forward_mx.hip clk:-DMX_STAGE_CLOCKS
+    python tools/build_variants.py stgcn_forward_mx.hip clk:-DMX_STAGE_CLOCKS=1 clk2:-DMX_STAGE_CLOCKS=2 clk3:-DMX_STAGE_CLOCKS=3
+    (1: a stamp per stage, 2: two per iteration, 3: wavefront lifetime only -- the one that does not perturb the loop)
     RULGNN_LIB=variants/librulgnn_clk.so python tools/mx_stage_clocks.py [batch]
 Prints, per stage of a 4-sample tile, the s_memtime ticks a wavefront spends between the stage's boundaries (issue time: a stall is
 charged to the stage whose instruction waits), averaged over all tiles of all wavefronts, beside the instruction counts of the ISA."""
@@ -41,8 +42,11 @@ names = ["wait: tile landed (vmcnt/lgkmcnt 0) + pending store", "patch load, nex
 tiles = buf[20]
 tot = sum(buf[i] for i in range(18))
 waves = buf[18]
-print(f"{tiles} tile passes by {waves} wavefronts in 10 launches; {tot / tiles:.0f} ticks per tile and wavefront inside the loop;")
+print(f"{tiles} tile passes by {waves} wavefronts in 10 launches; {tot / max(tiles, 1):.0f} ticks per tile and wavefront inside the loop;")
 print(f"a wavefront lives {buf[19] / waves:.0f} ticks from entry to its last tile = {buf[19] / waves / us:.0f} ticks per us of the launch "
       f"(the shader clock under THIS kernel if the wavefronts live for the whole launch)")
-for i, n in enumerate(names):
-    print(f"  {i:2d} {n:60s} {buf[i] / tiles:8.1f}  {100.0 * buf[i] / tot:5.1f} %")
+if tot:
+    for i, n in enumerate(names):
+        print(f"  {i:2d} {n:60s} {buf[i] / tiles:8.1f}  {100.0 * buf[i] / tot:5.1f} %")
+else:
+    print(f"lifetime form: {B // 4 / waves * 10:.1f} tiles per wavefront -> {buf[19] / waves / (B // 4 / waves * 10):.0f} ticks per tile and wavefront, prologue included")
