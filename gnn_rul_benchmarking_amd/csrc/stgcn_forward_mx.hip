@@ -47,6 +47,8 @@
 // samples are recomputed by the exact fp32 tile routine (stgcn_eval_tile.hpp) inside the same launch, which also
 // reproduces the reference's NaN placement.  Inputs scaled to [0, 1] (every dataset the reference wires) never take it.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "stgcn_eval_tile.hpp"
 #include "stgcn_host.hpp"
@@ -68,7 +70,9 @@ struct MxArgs {
 // trips the stages overlap), summed per wavefront and added to a device array.  The product build compiles every call to nothing.
 #ifdef MX_STAGE_CLOCKS
 constexpr int MX_CLK_STAMPS = 20;
-__device__ unsigned long long g_mx_stage_clocks[MX_CLK_STAMPS + 2];
+constexpr int MX_CLK_SLOTS = 4096;          // one row per workgroup (= wavefront): plain stores, no same-address atomics at the end of the kernel
+                                            // (20 480 wavefronts adding into 20 addresses cost ~150 us per launch: a first version did)
+__device__ unsigned long long g_mx_stage_clocks[MX_CLK_SLOTS][MX_CLK_STAMPS + 2];
 struct StageClk {
     unsigned long long t[MX_CLK_STAMPS];
     template <int I> __device__ __forceinline__ void stamp() {
@@ -223,6 +227,7 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
     if (tile >= a.ntiles) return;
 #ifdef MX_STAGE_CLOCKS
     const unsigned long long clk_entry = __builtin_readcyclecounter();
+    const unsigned long long wall_entry = wall_clock64();          // the constant 100 MHz counter: shader ticks / wall ticks = the clock
 #endif
     {   // first tile on its way before the weights are touched
         const int64_t s0 = tile * 4;
@@ -484,12 +489,14 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
 #endif
     }
 #ifdef MX_STAGE_CLOCKS
-    if (lane == 0) {
-        // [0..17] stage sums, [18] wavefronts, [19] entry-to-here ticks, [20] tile passes
-        for (int i = 0; i < 18; ++i) atomicAdd(&g_mx_stage_clocks[i], (unsigned long long)clk_acc[i]);
-        atomicAdd(&g_mx_stage_clocks[18], 1ull);
-        atomicAdd(&g_mx_stage_clocks[19], __builtin_readcyclecounter() - clk_entry);
-        atomicAdd(&g_mx_stage_clocks[MX_CLK_STAMPS], (unsigned long long)clk_tiles);
+    if (lane == 0 && blockIdx.x < MX_CLK_SLOTS) {
+        // [0..17] stage sums, [18] wavefronts, [19] entry-to-here ticks, [20] tile passes; accumulated over the launches since the last reset
+        unsigned long long* row = g_mx_stage_clocks[blockIdx.x];
+        for (int i = 0; i < 18; ++i) row[i] += (unsigned long long)clk_acc[i];
+        row[18] += 1ull;
+        row[19] += __builtin_readcyclecounter() - clk_entry;
+        row[MX_CLK_STAMPS] += (unsigned long long)clk_tiles;
+        row[MX_CLK_STAMPS + 1] += wall_clock64() - wall_entry;
     }
 #endif
 
@@ -1320,10 +1327,19 @@ int stgcn_forward_mx_tap_floats() { return MX_TAP_SLOTS * 64; }
 // variant builds only (tools/mx_stage_clocks.py): the stage clock sums of the launches since the last reset
 extern "C" __attribute__((visibility("default"))) int rulgnn_debug_mx_stage_clocks(unsigned long long* out, int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rulgnn::g_mx_stage_clocks), sizeof(rulgnn::g_mx_stage_clocks)) != hipSuccess) return -2;
+    constexpr int W = rulgnn::MX_CLK_STAMPS + 2;
+    static unsigned long long host[rulgnn::MX_CLK_SLOTS][W];
+    if (out) {
+        if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rulgnn::g_mx_stage_clocks), sizeof(host)) != hipSuccess) return -2;
+        for (int i = 0; i < W; ++i) {
+            out[i] = 0;
+            for (int r = 0; r < rulgnn::MX_CLK_SLOTS; ++r) out[i] += host[r][i];
+        }
+    }
     if (reset) {
-        unsigned long long z[rulgnn::MX_CLK_STAMPS + 2] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(rulgnn::g_mx_stage_clocks), z, sizeof(z)) != hipSuccess) return -3;
+        void* dptr = nullptr;
+        if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(rulgnn::g_mx_stage_clocks)) != hipSuccess) return -3;
+        if (hipMemset(dptr, 0, sizeof(host)) != hipSuccess) return -3;
     }
     return 0;
 }

@@ -43,8 +43,8 @@ tiles = buf[20]
 tot = sum(buf[i] for i in range(18))
 waves = buf[18]
 print(f"{tiles} tile passes by {waves} wavefronts in 10 launches; {tot / max(tiles, 1):.0f} ticks per tile and wavefront inside the loop;")
-print(f"a wavefront lives {buf[19] / waves:.0f} ticks from entry to its last tile = {buf[19] / waves / us:.0f} ticks per us of the launch "
-      f"(the shader clock under THIS kernel if the wavefronts live for the whole launch)")
+print(f"a wavefront lives {buf[19] / waves:.0f} shader ticks = {buf[21] / waves:.0f} ticks of the 100 MHz wall clock from entry to its last tile: "
+      f"{buf[19] / max(buf[21], 1) * 100:.0f} MHz under THIS kernel ({buf[21] / waves / 100:.1f} us of the launch's {us:.1f})")
 if tot:
     for i, n in enumerate(names):
         print(f"  {i:2d} {n:60s} {buf[i] / tiles:8.1f}  {100.0 * buf[i] / tot:5.1f} %")
