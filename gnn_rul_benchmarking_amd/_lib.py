@@ -166,7 +166,8 @@ class BilstmShape(C.Structure):
 class BilstmArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w_ih", C.c_void_p * 2), ("w_hh", C.c_void_p * 2), ("b_ih", C.c_void_p * 2), ("b_hh", C.c_void_p * 2),
                 ("out", C.c_void_p), ("dout", C.c_void_p), ("dx", C.c_void_p), ("dw_ih", C.c_void_p * 2), ("dw_hh", C.c_void_p * 2),
-                ("db_ih", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("db_ih", C.c_void_p * 2), ("db_hh", C.c_void_p * 2), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("aux_stream", C.c_void_p)]
 
 
 # rulgnn_allreduce_f64_fn: int (*)(void *user, double *device_buf, int32_t count, void *stream)

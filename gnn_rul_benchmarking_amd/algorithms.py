@@ -18,7 +18,7 @@ from . import _lib
 from .optim import FusedAdam
 from .astgcnn import ASTGCNN_model
 from .fcstgnn import FC_STGNN_RUL
-from .hagcn import HAGCN_model
+from .hagcn import HAGCN_model, deferred_weight_gradients
 from .rgcnu import RGCNU_model
 from .stconv import ST_Conv_model
 from .stgcn import ST_GCN_model
@@ -218,7 +218,8 @@ class HAGCN(Algorithm):
         loss_mse = self.mse(predicted_RUL, y)
         loss = loss_mse + self.alpha * KL_Loss
         self.optimizer.zero_grad()
-        loss.backward()
+        with deferred_weight_gradients(loss.device):      # LSTM layer l's weight-gradient GEMMs under layer l-1's BPTT (hagcn.py)
+            loss.backward()
         self.optimizer.step()
         return self._finish(loss.detach())
 
@@ -275,4 +276,4 @@ class STAGNN(_FusedAlgorithm):
     needs_train_mode = "BatchNorm batch statistics"
 
 
-_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "SAGCN_model", "STAGNN_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations", "math", "_lib"}
+_NOT_ALGORITHMS = {"Algorithm", "FusedAdam", "RGCNU_model", "STNet_model", "SAGCN_model", "STAGNN_model", "ST_GCN_model", "STMSGCN_model", "ASTGCNN_model", "FC_STGNN_RUL", "HAGCN_model", "ST_Conv_model", "STGNN_model", "get_algorithm_class", "torch", "nn", "annotations", "math", "_lib", "deferred_weight_gradients"}

@@ -13,6 +13,7 @@
 #include <utility>
 
 #include "async_mem.hpp"
+#include "aux_stream.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 
@@ -400,14 +401,26 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
     float* one = ws + g.o_one;
     float* split = ws + g.o_split;
     hipLaunchKernelGGL(lstm_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
+    // The data gradient first: the layer below waits for nothing else.  dx (+)= dG W_ih
+    if (a->dx)
+        for (int d = 0; d < ndir; ++d)
+            LS_RC(sgemm(ws + g.o_dgates + (int64_t)d * g.rows * H4, H4, 1, a->w_ih[d], 1, I, a->dx, I, R, I, H4, d == 1, st));
+    // The parameter gradients feed nothing in this call: on the caller's second stream (args->aux_stream) they run beside what the caller
+    // enqueues on `st` next -- in a stack of layers the BPTT of the layer below, a persistent recurrence on 2 * num_seq of the CUs.
+    // NOT joined here: the caller joins before it reads them (include/rulgnn.h).
+    hipStream_t wst = st;
+    if (a->aux_stream) {
+        wst = static_cast<hipStream_t>(a->aux_stream);
+        hipEvent_t ev = aux_pooled_event();
+        if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(wst, ev, 0) != hipSuccess) return RULGNN_EHIP;
+    }
     for (int d = 0; d < ndir; ++d) {
         const float* dg = ws + g.o_dgates + (int64_t)d * g.rows * H4;
-        // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db = column sums ; dx (+)= dG W_ih
-        LS_RC(sgemm_splitk(dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R, false, split, st));
-        LS_RC(sgemm_splitk(dg, 1, H4, ws + g.o_hprev + (int64_t)d * g.rows * H, 1, H, a->dw_hh[d], H, H4, H, R, false, split, st));
-        LS_RC(sgemm_splitk(one, 0, 0, dg, 1, H4, a->db_ih[d], H4, 1, H4, R, false, split, st));
-        hipLaunchKernelGGL(lstm_copy_kernel, dim3((H4 + 255) / 256), dim3(256), 0, st, (const float*)a->db_ih[d], a->db_hh[d], H4);
-        if (a->dx) LS_RC(sgemm(dg, H4, 1, a->w_ih[d], 1, I, a->dx, I, R, I, H4, d == 1, st));
+        // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db = column sums
+        LS_RC(sgemm_splitk(dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R, false, split, wst));
+        LS_RC(sgemm_splitk(dg, 1, H4, ws + g.o_hprev + (int64_t)d * g.rows * H, 1, H, a->dw_hh[d], H, H4, H, R, false, split, wst));
+        LS_RC(sgemm_splitk(one, 0, 0, dg, 1, H4, a->db_ih[d], H4, 1, H4, R, false, split, wst));
+        hipLaunchKernelGGL(lstm_copy_kernel, dim3((H4 + 255) / 256), dim3(256), 0, wst, (const float*)a->db_ih[d], a->db_hh[d], H4);
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

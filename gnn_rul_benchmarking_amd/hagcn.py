@@ -50,6 +50,34 @@ class SAGPool(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(input_dimension, input_dimension // 2), nn.ReLU(), nn.Linear(input_dimension // 2, 1))
 
 
+# The side stream that carries the LSTM layers' parameter-gradient GEMMs while a ``deferred_weight_gradients`` block is open (a plain
+# module global, not a thread-local: autograd runs the backward on its own thread).  Layer l's dW_ih / dW_hh / db GEMMs (~40 launches of
+# 5-16 us per layer) then run UNDER layer l-1's BPTT -- a persistent recurrence on two of the 256 CUs -- instead of in front of it.
+_DEFERRED = [None]
+
+
+class deferred_weight_gradients:
+    """``with deferred_weight_gradients(device): loss.backward()`` -- the Bi-LSTM layers' parameter gradients are produced on a side stream;
+    leaving the block makes the current stream wait for it, so they are final (in stream order) for whatever follows: ``optimizer.step()``
+    in ``HAGCN.update``.  Outside such a block every gradient is produced on the current stream as before."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        if self.device.type == "cuda":
+            if getattr(deferred_weight_gradients, "_stream", None) is None or deferred_weight_gradients._stream.device != self.device:
+                deferred_weight_gradients._stream = torch.cuda.Stream(device=self.device)
+            _DEFERRED[0] = deferred_weight_gradients._stream
+        return self
+
+    def __exit__(self, *exc):
+        side, _DEFERRED[0] = _DEFERRED[0], None
+        if side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(side)
+        return False
+
+
 class _BiLstmSum(torch.autograd.Function):
     """out = LSTM_forward(x) + LSTM_reverse(x) for one nn.LSTM(bidirectional=True, batch_first=True) (Model.py:58-61)."""
 
@@ -91,6 +119,11 @@ class _BiLstmSum(torch.autograd.Function):
             a.dw_ih[d], a.dw_hh[d], a.db_ih[d], a.db_hh[d] = (grads[4 * d].data_ptr(), grads[4 * d + 1].data_ptr(),
                                                               grads[4 * d + 2].data_ptr(), grads[4 * d + 3].data_ptr())
         a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
+        side = _DEFERRED[0]
+        if side is not None and side.device == x.device:
+            a.aux_stream = side.cuda_stream
+            for t in (ctx.ws, x, *grads):          # the side stream reads / writes them after this function has returned
+                t.record_stream(side)
         _lib.check(_lib.load().rulgnn_bilstm_backward_f32(C.byref(shp), C.byref(a), _stream()), "rulgnn_bilstm_backward_f32")
         return (dx, *grads)
 

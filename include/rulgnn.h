@@ -840,6 +840,11 @@ typedef struct rulgnn_bilstm_args {
     float *dw_ih[2], *dw_hh[2], *db_ih[2], *db_hh[2];
     void *workspace;          /* carries the tape (gates, cell states) from forward to backward */
     size_t workspace_bytes;
+    void *aux_stream;         /* backward, optional second stream of the caller (NULL: everything on `stream`): the parameter-gradient GEMMs
+                                 (dw_ih, dw_hh, db_ih, db_hh -- nothing downstream in the call needs them) run there beside whatever the
+                                 caller enqueues on `stream` next: in a stack of layers, layer l's weight gradients under layer l-1's BPTT,
+                                 whose persistent recurrence occupies 2 * num_seq of the 256 CUs.  The call does NOT join: the CALLER must make
+                                 `stream` wait for `aux_stream` before it reads a parameter gradient, reuses the workspace or frees either. */
 } rulgnn_bilstm_args;
 
 size_t rulgnn_bilstm_workspace_bytes(const rulgnn_bilstm_shape *shape);     /* 0: invalid / unsupported */

@@ -212,3 +212,38 @@ def test_free_running_selection_equals_the_reference_sort_indices_where_scores_a
         assert np.array_equal(fw.levels[l].topk, ref)
     assert rel(feats.detach().cpu().numpy(), z["feats"]) < TOL
     assert abs(float(kl) - float(z["kl"])) < 1e-4 * abs(float(z["kl"])) + 1e-7
+
+
+def test_deferred_lstm_weight_gradients_give_the_same_step():
+    """``HAGCN.update`` produces the Bi-LSTM layers' parameter gradients on a side stream (layer l's GEMMs under layer l - 1's BPTT,
+    ``hagcn.deferred_weight_gradients``) and joins it in front of the optimizer: the same step as with everything on one stream."""
+    import contextlib
+    from gnn_rul_benchmarking_amd import algorithms as A
+    from gnn_rul_benchmarking_amd import hparams as HP
+    dev = torch.device("cuda:0")
+    hp = HP.get_hparams_class("CMAPSS")("FD004")
+    cfg, tc = dict(hp.alg_hparams["HAGCN"]), dict(hp.train_params["HAGCN"])
+    g = torch.Generator(device="cpu").manual_seed(3)
+    X, y = torch.rand(24, 14, 50, generator=g).to(dev), torch.rand(24, 1, generator=g).to(dev)
+
+    def run(deferred):
+        torch.manual_seed(21)
+        algo = A.HAGCN(cfg, tc, dev)
+        algo.to(dev)
+        algo.train()
+        torch.manual_seed(5)                                   # the torch dropouts of the LSTM stack draw from the global generator
+        saved = A.deferred_weight_gradients
+        if not deferred:
+            A.deferred_weight_gradients = lambda device: contextlib.nullcontext()
+        try:
+            losses = [algo.update(X, y, 1)["loss"] for _ in range(3)]
+        finally:
+            A.deferred_weight_gradients = saved
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in algo.model.state_dict().items()}
+
+    la, sa = run(True)
+    lb, sb = run(False)
+    assert all(np.isfinite(la)) and np.allclose(la, lb, rtol=1e-6, atol=0)
+    for k in sa:                 # (a gradient read before the side stream had written it would be garbage, not round-off)
+        assert torch.allclose(sa[k].float(), sb[k].float(), rtol=0, atol=2e-6), k
