@@ -696,6 +696,99 @@ __global__ void fc_head_kernel(FcGeom g, const float* __restrict__ prm, const fl
     for (int j = 0; j < g.HD; ++j) dh3[b * g.HD + j] = h3[b * g.HD + j] > 0.f ? dp * prm[g.o_f4w + j] : 0.f;
 }
 
+// Every parameter gradient of the MLP (Model.py:30-40: fc1 [2h x FIN], fc2 [2h x 2h], fc3 [h x 2h], fc4 [1 x h] and their biases) and the
+// loss sum in ONE launch, for the batches the reference protocol trains at (batch <= FC_MLPW_MAXB).  As split-K GEMMs + column sums these
+// were nine latency-bound launches (sgemm_tiny / sgemm_mfma + reduce_slices / cols_sum_small / block_sum) at the head of the backward's side
+// stream -- 50 us of host enqueue time during which the main stream's queue ran empty (the step is host-launch bound, tools/trace_family_step.sh).
+// Workgroups [0, nfw): 64 columns of d fc1.weight each (thread = (column, row quarter): rows j = q, q + 4, ...; the batch walked in
+// order, d h1 staged in LDS in chunks of 64 samples); the last workgroup: the small outputs, one per thread, each a dot product over the batch
+// in order.  Fixed summation order: run-to-run reproducible.
+constexpr int FC_MLPW_MAXB = 2048;
+struct FcMlpW {
+    const float *dpred, *dh3, *dh2, *dh1, *h3, *h2, *h1, *feat, *sqerr;
+    float *f1w, *f1b, *f2w, *f2b, *f3w, *f3b, *f4w, *f4b, *loss;
+    int B, D2, HD, FIN, nfw;
+};
+__global__ __launch_bounds__(256) void fc_mlp_wgrad_kernel(FcMlpW k) {
+    __shared__ float dl[32 * (4 * 64 + 2 * 32 + 2)];                 // d fc1.weight part: [64 samples][D2 <= 64]; the small outputs: eight chunk arrays
+    const int t = threadIdx.x, B = k.B, D2 = k.D2, HD = k.HD, FIN = k.FIN;
+    if ((int)blockIdx.x < k.nfw) {
+        const int c = blockIdx.x * 64 + (t & 63), q = t >> 6;
+        float acc[16];                                               // rows q, q + 4, ..., < D2 <= 64
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            const int nb = B - b0 < 64 ? B - b0 : 64;
+            __syncthreads();
+            for (int e = t; e < nb * D2; e += 256) dl[e] = k.dh1[(int64_t)b0 * D2 + e];
+            __syncthreads();
+            if (c < FIN) {
+                for (int b = 0; b < nb; ++b) {
+                    const float f = k.feat[(int64_t)(b0 + b) * FIN + c];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (q + 4 * r < D2) acc[r] = fmaf(dl[b * D2 + q + 4 * r], f, acc[r]);
+                }
+            }
+        }
+        if (c < FIN) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (q + 4 * r < D2) k.f1w[(int64_t)(q + 4 * r) * FIN + c] = acc[r];
+        }
+        return;
+    }
+    // the small outputs: [f2w D2 x D2 | f3w HD x D2 | f4w HD | f1b D2 | f2b D2 | f3b HD | f4b 1 | loss 1], one per thread of the workgroups behind
+    // the first nfw; the batch is staged through LDS in chunks of 32 samples (coalesced loads), every output a dot product over it in order
+    const int n2 = D2 * D2, n3 = HD * D2;
+    const int total = n2 + n3 + HD + D2 + D2 + HD + 2;
+    const int o = ((int)blockIdx.x - k.nfw) * 256 + t;
+    // which dot product this thread owns: a[b * sa + ia] * c[b * sc + ic] over the chunk arrays (c == nullptr: plain sum)
+    float* const c_dh1 = dl, * const c_dh2 = c_dh1 + 32 * D2, * const c_h1 = c_dh2 + 32 * D2, * const c_h2 = c_h1 + 32 * D2;
+    float* const c_dh3 = c_h2 + 32 * D2, * const c_h3 = c_dh3 + 32 * HD, * const c_dp = c_h3 + 32 * HD, * const c_sq = c_dp + 32;
+    const float *pa = nullptr, *pc = nullptr;
+    int sa = 0, sc = 0;
+    float* dst = nullptr;
+    {
+        int i = o;
+        if (i >= 0 && i < total) {
+            if (i < n2) { pa = c_dh2 + i / D2; sa = D2; pc = c_h1 + i % D2; sc = D2; dst = k.f2w + i; }
+            else if ((i -= n2) < n3) { pa = c_dh3 + i / D2; sa = HD; pc = c_h2 + i % D2; sc = D2; dst = k.f3w + i; }
+            else if ((i -= n3) < HD) { pa = c_dp; sa = 1; pc = c_h3 + i; sc = HD; dst = k.f4w + i; }
+            else if ((i -= HD) < D2) { pa = c_dh1 + i; sa = D2; dst = k.f1b + i; }
+            else if ((i -= D2) < D2) { pa = c_dh2 + i; sa = D2; dst = k.f2b + i; }
+            else if ((i -= D2) < HD) { pa = c_dh3 + i; sa = HD; dst = k.f3b + i; }
+            else if ((i -= HD) == 0) { pa = c_dp; sa = 1; dst = k.f4b; }
+            else if (k.loss) { pa = c_sq; sa = 1; dst = k.loss; }
+        }
+    }
+    float v = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        const int nb = B - b0 < 32 ? B - b0 : 32;
+        __syncthreads();
+        for (int e = t; e < nb * D2; e += 256) {
+            c_dh1[e] = k.dh1[(int64_t)b0 * D2 + e];
+            c_dh2[e] = k.dh2[(int64_t)b0 * D2 + e];
+            c_h1[e] = k.h1[(int64_t)b0 * D2 + e];
+            c_h2[e] = k.h2[(int64_t)b0 * D2 + e];
+        }
+        for (int e = t; e < nb * HD; e += 256) {
+            c_dh3[e] = k.dh3[(int64_t)b0 * HD + e];
+            c_h3[e] = k.h3[(int64_t)b0 * HD + e];
+        }
+        if (t < nb) {
+            c_dp[t] = k.dpred[b0 + t];
+            c_sq[t] = k.sqerr[b0 + t];
+        }
+        __syncthreads();
+        if (dst) {
+            if (pc) for (int b = 0; b < nb; ++b) v = fmaf(pa[b * sa], pc[b * sc], v);
+            else for (int b = 0; b < nb; ++b) v += pa[b * sa];
+        }
+    }
+    if (dst) *dst = v;
+}
+
 // The MLP behind the first (split-K) projection in ONE launch: bias + ReLU of fc1, fc2, fc3, the head, and -- when the loss is formed
 // here (y) or its gradient comes in (dpred_in) -- the data gradients back to d h1.  Eight launches of the chain (bias-ReLU x 3, two
 // [batch x 16 x 16] products, head; backward: head, two products, two masks) at their 5-7 us latency floor each; a thread owns a sample
@@ -1963,13 +2056,28 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             if (bn_running_out && a->bn_moment_weight == 0.f)
                 hipLaunchKernelGGL(fc_bn_running_kernel, dim3(1), dim3(64), 0, wst, g, bn_running_out, (const float*)a->bn_batch, bn_momentum, 0);
         }
-        if (!a->dpred && a->loss) (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, wst);
+        // (batches of the reference protocol's size: every MLP parameter gradient and the loss sum in one launch, fc_mlp_wgrad_kernel)
+        const bool mlp_wgrad_fused = mlp_fused && g.B <= FC_MLPW_MAXB && D2 <= 64;
+        if (!a->dpred && a->loss && !mlp_wgrad_fused) (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, wst);
         auto colsum = [&](const float* src, int64_t rows, int C, float* dst) {      // dst[c] = sum_r src[r][c]
             if (cols_sum_small_ok(rows, C)) return cols_sum_small(src, (int)rows, C, dst, wst);
             return sgemm_splitk(one, 0, 0, src, 1, C, dst, C, 1, C, (int)rows, false, split, wst);
         };
         // ---- MLP ----
-        if (mlp_fused) {
+        if (mlp_wgrad_fused) {
+            FcMlpW k;
+            k.dpred = P_(w.dpred); k.dh3 = P_(w.dh3); k.dh2 = P_(w.dh2); k.dh1 = P_(w.dh1);
+            k.h3 = P_(w.h3); k.h2 = P_(w.h2); k.h1 = P_(w.h1); k.feat = P_(w.feat); k.sqerr = P_(w.sqerr);
+            k.f1w = gr + g.o_f1w; k.f1b = gr + g.o_f1b; k.f2w = gr + g.o_f2w; k.f2b = gr + g.o_f2b;
+            k.f3w = gr + g.o_f3w; k.f3b = gr + g.o_f3b; k.f4w = gr + g.o_f4w; k.f4b = gr + g.o_f4b;
+            k.loss = (!a->dpred && a->loss) ? a->loss : nullptr;
+            // (d fc1.weight [2h x FIN] stays on the split-K matrix-core pair: as 64-column workgroups walking the batch in order it took
+            // ~90 us at batch 256 -- a chain of 256 dependent-latency iterations -- and the side stream is nearly as long as the main one)
+            FC_RC(sgemm_splitk(P_(w.dh1), 1, D2, P_(w.feat), 1, FIN, gr + g.o_f1w, FIN, D2, FIN, Bi, false, split, wst));
+            k.B = Bi; k.D2 = D2; k.HD = HD; k.FIN = FIN; k.nfw = 0;
+            const int small = D2 * D2 + HD * D2 + HD + D2 + D2 + HD + 2;
+            hipLaunchKernelGGL(fc_mlp_wgrad_kernel, dim3((unsigned)(k.nfw + (small + 255) / 256)), dim3(256), 0, wst, k);
+        } else if (mlp_fused) {
             // d h3, d h2, d h1 are there (formed with the loss in the forward's fused MLP kernel, or here from the incoming gradient):
             // one fork, every parameter gradient of the MLP on the side
             FC_RC(sgemm_splitk(P_(w.dpred), 0, 1, P_(w.h3), 1, HD, gr + g.o_f4w, HD, 1, HD, Bi, false, split, wst));
