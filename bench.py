@@ -133,7 +133,7 @@ def phase_bytes_per_sample(name, N, P, L, chain="mx"):
 def _traffic_profile(chain="mx"):
     """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh) of the given phase chain ("mx" = the
     matrix-core chain of round 4, "fp32" = the row-mapped chain; summaries without a "chain" entry predate the former): newest round first."""
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             if t.get("chain", "fp32") != chain:
@@ -160,7 +160,7 @@ def forward_traffic(N, P, B):
     """HBM bytes per launch of the fused eval forward from its own PMC passes (tools/profile_forward.sh ->
     profiles/r0N_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
     the bench's other launches of that name), or None when this batch was not profiled."""
-    for rnd in ("r04", "r03", "r02"):              # newest round first
+    for rnd in ("r05", "r04", "r03", "r02"):       # newest round first
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_forward_bs{B}_hbm_traffic.json")))
             w = t["workload"]
@@ -612,7 +612,7 @@ def kernel_short_name(name):
 def family_traffic(family, kernel_short):
     """HBM bytes per launch of a family's kernel from the committed PMC summary (profiles/r0N_family_hbm_traffic.json, the newest round
     that has the kernel; written by tools/family_traffic_report.py from separate FETCH_SIZE / WRITE_SIZE passes), or None."""
-    for tag in ("r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_family_hbm_traffic.json")))
             for k, v in t["families"][family]["kernels"].items():
