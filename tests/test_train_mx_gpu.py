@@ -196,24 +196,25 @@ def test_a_rejected_step_without_loss_readback_is_never_silent():
     a.check_guard()                                   # nothing was rejected: no error, and eval() / state_dict() pass
     a.model.eval(); a.train(); a.state_dict()
     before = a.model.flat_params.clone()
-    l1 = a.update(X * 1.0e7, y, 1)["loss"]            # out of the f16 range: rejected
+    l1 = a.update(X, y * 1.0e15, 1)["loss"]            # labels of 1e15: d loss / d pred leaves the f16 range of the matrix-core backward for certain (window scaling
+                                                      # alone does not trip reliably: F0 rescales per sample, BatchNorm renormalises): rejected
     l2 = a.update(X, y, 1)["loss"]                    # the next in-range step runs normally (clean-workspace claim included)
     assert bool(torch.isnan(l1)) and bool(torch.isfinite(l2))
     assert not torch.equal(a.model.flat_params, before)
     with pytest.raises(RuntimeError, match="rejected by the f16 range guard"):
         a.check_guard()
     a.check_guard()                                   # reported once; the counter is sticky on the device, consumed on the host
-    a.update(X * 1.0e7, y, 1)
+    a.update(X, y * 1.0e15, 1)
     with pytest.raises(RuntimeError, match="1 training step"):
         a.model.eval()
-    a.update(X * 1.0e7, y, 1); a.update(X * 1.0e7, y, 1)
+    a.update(X, y * 1.0e15, 1); a.update(X, y * 1.0e15, 1)
     with pytest.raises(RuntimeError, match="2 training step"):
         a.state_dict()
     # a new batch size (another workspace) keeps counting; a model on the fp32 chain never counts
-    a.update(X[:64] * 1.0e7, y[:64], 1)
+    a.update(X[:64], y[:64] * 1.0e15, 1)
     assert a.model.guard_trips() == 1
     a.model.step_path = _lib.STEP_CHAIN
-    lc = a.update(X * 1.0e7, y, 1)["loss"]
+    lc = a.update(X, y * 1.0e15, 1)["loss"]
     assert bool(torch.isfinite(lc)) and a.model.guard_trips() == 0
 
 
