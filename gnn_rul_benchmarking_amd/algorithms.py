@@ -70,7 +70,8 @@ class _FusedAlgorithm(Algorithm):
     all-reduced over RCCL in between), through a captured hipGraph when ``enable_graphs()`` was called.
 
     ``sync_loss``: the reference returns ``loss.item()`` (a host sync every step).  That stays the default; ``sync_loss=False``
-    returns the 0-d device tensor instead so that a training loop can read it once per epoch."""
+    returns the 0-d device tensor instead so that a training loop can read it once per epoch -- a VIEW of the loss slot of the model's
+    bucket (no extra kernel per step): valid until the next ``update()``, ``clone()`` it to keep it."""
 
     model_class = None
     needs_train_mode = None      # why update() refuses a model in eval mode (None: train and eval compute the same function)

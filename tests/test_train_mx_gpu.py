@@ -196,9 +196,10 @@ def test_a_rejected_step_without_loss_readback_is_never_silent():
     a.check_guard()                                   # nothing was rejected: no error, and eval() / state_dict() pass
     a.model.eval(); a.train(); a.state_dict()
     before = a.model.flat_params.clone()
-    l1 = a.update(X, y * 1.0e15, 1)["loss"]            # labels of 1e15: d loss / d pred leaves the f16 range of the matrix-core backward for certain (window scaling
+    # (with sync_loss=False the returned loss is a VIEW of the bucket's loss slot, valid until the next step: clone to keep it)
+    l1 = a.update(X, y * 1.0e15, 1)["loss"].clone()    # labels of 1e15: d loss / d pred leaves the f16 range of the matrix-core backward for certain (window scaling
                                                       # alone does not trip reliably: F0 rescales per sample, BatchNorm renormalises): rejected
-    l2 = a.update(X, y, 1)["loss"]                    # the next in-range step runs normally (clean-workspace claim included)
+    l2 = a.update(X, y, 1)["loss"].clone()            # the next in-range step runs normally (clean-workspace claim included)
     assert bool(torch.isnan(l1)) and bool(torch.isfinite(l2))
     assert not torch.equal(a.model.flat_params, before)
     with pytest.raises(RuntimeError, match="rejected by the f16 range guard"):
