@@ -145,10 +145,15 @@ def main():
     args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ST_GCN path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
+    # Test hook (tests/test_bench_multirank_gpu.py): RULGNN_BENCH_SHARE_GPU=1 lets the ranks of an N > 1 launch share the visible GPUs
+    # over the gloo backend, so that the multi-rank path of this script (sharding, barriers, max over ranks, one JSON line) can be
+    # exercised on a one-GPU box.  Never set by the driver; the numbers of such a run are not a measurement.
+    share_gpu = os.environ.get("RULGNN_BENCH_SHARE_GPU") == "1"
+    if local_rank >= torch.cuda.device_count() and not share_gpu:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -160,7 +165,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
     if args.family != "ST_GCN":
