@@ -68,6 +68,10 @@ def _gcn_stack_flops(n, dims):
     return sum(2 * 2 * n * n * f[l] + 2 * n * f[l] * f[l + 1] for l in range(len(dims)))
 
 
+def _fc_blocks(per_step):
+    return "both window blocks in the one launch (blockIdx.y)" if per_step < 1.5 else "averaged over the two window blocks' launches"
+
+
 # Work model of the kernel that dominates each family's step: substring of the kernel name -> f(cfg, batch, launches per step)
 # = (algorithmic FLOPs of ONE launch, how they are counted).  Matmul-type FLOPs only, as SURVEY 8(d) counts them.
 def dominant_kernel_work(family, name, cfg, B, shape, per_step):
@@ -75,14 +79,14 @@ def dominant_kernel_work(family, name, cfg, B, shape, per_step):
         Q, D2 = 2 * cfg["num_node"], 2 * cfg["hidden_dim"]
         graphs = B * ((cfg["num_patch"] - 1) + (cfg["num_patch"] - 2) // 2 + 1)            # window 2, stride 1 and 2 (Model_Base.py:175-225)
         return graphs / per_step * 6 * Q * Q * D2, ("backward of one window graph: dA = dAX X'^T, dX' = A^T dAX, dM = (dS + dS^T) M, "
-                                                    "2 Q^2 D FLOPs each (Q = 28 nodes, D = 16); averaged over the two window blocks")
+                                                    "2 Q^2 D FLOPs each (Q = 28 nodes, D = 16); " + _fc_blocks(per_step))
     if family == "FC_STGNN" and ("fc_graph_kernel" in name or "fc_graph_mx" in name or "fc_block_mx" in name):
         Q, D2 = 2 * cfg["num_node"], 2 * cfg["hidden_dim"]
         graphs = B * ((cfg["num_patch"] - 1) + (cfg["num_patch"] - 2) // 2 + 1)
         extra = (2 * Q * D2 * D2 + 2 * Q * D2 * (D2 // 2)) if "fc_block_mx" in name else 0            # mapping + the block's Linear
         return graphs / per_step * (4 * Q * Q * D2 + extra), ("forward of one window graph: S = M M^T and A X', 2 Q^2 D FLOPs each (Q = 28 nodes, D = 16)"
                                                               + ("; plus the mapping F W_map^T and the block's Linear" if extra else "")
-                                                              + "; averaged over the two window blocks")
+                                                              + "; " + _fc_blocks(per_step))
     if family == "HAGCN" and ("lstm_forward_kernel" in name or "lstm_backward_kernel" in name):
         T = B * shape[0]
         H = cfg["encoder_hidden_dim"] * (2 if "<128" in name else 1)                          # layers 1, 3: H; layer 2: 2H (Model.py:41-56)

@@ -214,6 +214,11 @@ __device__ __forceinline__ void fc_walk(int64_t total, Body&& body) {
         for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += (int64_t)gridDim.x * FB) body(e);
     }
 }
+// The two window blocks (stride 1 and 2) are independent between the positional encoding and the MLP: their kernels take per-block pointers
+// in pairs and blockIdx.y picks the block, so one launch serves both (a launch less per pair on a chain of launches at their latency floor,
+// and the smaller block's workgroups fill the slots the larger one leaves).
+struct Ptr2 { float* p[2]; };
+struct CPtr2 { const float* p[2]; };
 // multiplicity of patch t in the unfolded windows of block b (how many window graphs contain it)
 __device__ inline float mult(const FcGeom& g, int b, int t) {
     if (b == 0) return (g.W[0] > 1 && t > 0 && t < g.NP - 1) ? 2.f : 1.f;
@@ -649,9 +654,10 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_mx_kernel(FcGeom g,
 }
 
 // features = mean over the two window steps of leaky(bn_e(z5))
-__global__ __launch_bounds__(FB) void fc_pool_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
-                                                    const Cells* cells, int training, const float* __restrict__ z5,
-                                                    float* __restrict__ feat) {
+__global__ __launch_bounds__(FB) void fc_pool_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
+                                                    const Cells* cells, int training, CPtr2 z5p, float* __restrict__ feat) {
+    const int blk = blockIdx.y;
+    const float* __restrict__ z5 = z5p.p[blk];
     __shared__ BnCoef ce[MAXC];
     if (threadIdx.x < g.HD) ce[threadIdx.x] = fbn(g, cells, prm, running, training, 4 + 2 * blk, threadIdx.x);
     __syncthreads();
@@ -882,9 +888,11 @@ __global__ void fc_relu_mask_kernel(float* __restrict__ dz, const float* __restr
 // backward
 // ---------------------------------------------------------------------------------------------------
 // d(bn_e output) from d features; BatchNorm-e backward sums
-__global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, const float* __restrict__ prm, Cells* cells,
-                                                        const float* __restrict__ z5, const float* __restrict__ dfeat,
-                                                        float* __restrict__ dy5) {
+__global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, const float* __restrict__ prm, Cells* cells, CPtr2 z5p,
+                                                        const float* __restrict__ dfeat, Ptr2 dy5p) {
+    const int blk = blockIdx.y;
+    const float* __restrict__ z5 = z5p.p[blk];
+    float* __restrict__ dy5 = dy5p.p[blk];
     __shared__ double sl[BS_DOUBLES];
     __shared__ BnCoef ce[MAXC];
     const int id = 4 + 2 * blk;
@@ -907,8 +915,13 @@ __global__ __launch_bounds__(FB) void fc_pool_bwd_kernel(FcGeom g, int blk, cons
 }
 
 // BatchNorm backward, row-major [rows][C]: dz = sc * (dy - sum_dy/m - xhat * sum_dyxhat/m), in place
-__global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id, const float* __restrict__ prm, const Cells* cells,
-                                                           const float* __restrict__ z, float* __restrict__ dy, int64_t rows) {
+// (blockIdx.y > 0: the second window block's tensor -- id + 2, its own rows)
+__global__ __launch_bounds__(FB) void fc_bn_rows_bwd_kernel(FcGeom g, int id0, const float* __restrict__ prm, const Cells* cells, CPtr2 zp, Ptr2 dyp,
+                                                           int64_t rows0, int64_t rows1) {
+    const int id = id0 + 2 * blockIdx.y;
+    const float* __restrict__ z = zp.p[blockIdx.y];
+    float* __restrict__ dy = dyp.p[blockIdx.y];
+    const int64_t rows = blockIdx.y ? rows1 : rows0;
     __shared__ BnCoef cf[MAXC];
     __shared__ float s1[MAXC], s2[MAXC];
     const int C = g.bn_ch[id];
@@ -1042,9 +1055,14 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
 // the block's Linear z5 = AX W_theta^T + b with its BatchNorm statistics behind (AX^T is already the a-operand form).  Replaces
 // [mapping GEMM, graph kernel, theta GEMM, bias + statistics kernel]: three launches and the Mm / AX round trips less per block.
 template <int D2T>
-__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
-                                                                       Cells* cells, int training, const float* __restrict__ F, float* __restrict__ Mm,
-                                                                       float* __restrict__ P, float* __restrict__ AX, float* __restrict__ z5) {
+__global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
+                                                                       Cells* cells, int training, const float* __restrict__ F, Ptr2 Mmp, Ptr2 Pp,
+                                                                       Ptr2 AXp, Ptr2 z5p) {
+    const int blk = blockIdx.y;
+    float* __restrict__ Mm = Mmp.p[blk];
+    float* __restrict__ P = Pp.p[blk];
+    float* __restrict__ AX = AXp.p[blk];
+    float* __restrict__ z5 = z5p.p[blk];
     constexpr int HK = D2T / 2, HDT = D2T / 2;                         // hidden width of the block's Linear = D2 / 2
     __shared__ BnCoef cd[D2T];
     __shared__ float bm[D2T];
@@ -1189,10 +1207,15 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
 // FUSED: the gradient arrives as d z5 and d AX = d z5 W_theta is formed here in both register forms (eight more products, K = D2 / 2)
 // instead of a GEMM launch and two reads of its result; the half rows of X' are then read in the order krow(step, half) of that form.
 template <int D2T, bool FUSED>
-__global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const Cells* cells,
-                                                                           const float* __restrict__ F, const float* __restrict__ Mm,
-                                                                           const float* __restrict__ P, const float* __restrict__ dz5,
-                                                                           float* dAX /* in (not FUSED): d AX; out: cX */, float* __restrict__ cM) {
+__global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(FcGeom g, const float* __restrict__ prm, const Cells* cells,
+                                                                           const float* __restrict__ F, CPtr2 Mmp, CPtr2 Pp, CPtr2 dz5p,
+                                                                           Ptr2 dAXp /* in (not FUSED): d AX; out: cX */, Ptr2 cMp) {
+    const int blk = blockIdx.y;
+    const float* __restrict__ Mm = Mmp.p[blk];
+    const float* __restrict__ P = Pp.p[blk];
+    const float* __restrict__ dz5 = dz5p.p[blk];
+    float* dAX = dAXp.p[blk];
+    float* __restrict__ cM = cMp.p[blk];
     constexpr int HK = D2T / 2, HO = D2T / 4;                          // HO: k of a half-wave in the product over the Linear's D2 / 2 outputs
     __shared__ BnCoef cd[D2T];
     __shared__ float bm[D2T];
@@ -1341,8 +1364,12 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
 
 // gX[r][d] = sum over the graphs that contain row r = (b, t, n) of their contribution; the same for gM.  Windows hold two
 // consecutive patches (tau = 0, 1) and start every S[blk] patches: row t is node tau*N + n of window w = (t - tau) / S.
-__global__ __launch_bounds__(FB) void fc_graph_gather_kernel(FcGeom g, int blk, const float* __restrict__ cX, const float* __restrict__ cM,
-                                                            float* __restrict__ gX, float* __restrict__ gM) {
+__global__ __launch_bounds__(FB) void fc_graph_gather_kernel(FcGeom g, CPtr2 cXp, CPtr2 cMp, Ptr2 gXp, Ptr2 gMp) {
+    const int blk = blockIdx.y;
+    const float* __restrict__ cX = cXp.p[blk];
+    const float* __restrict__ cM = cMp.p[blk];
+    float* __restrict__ gX = gXp.p[blk];
+    float* __restrict__ gM = gMp.p[blk];
     const int64_t total = g.M * g.D2;
     const int S = g.S[blk], W = g.W[blk];
     fc_walk(total, [&](auto e) {
@@ -1982,18 +2009,25 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            P_(w.F), thr, dscale, key, key_dev, row_off);
         FC_RC(sync_pair(0, 3));
         FC_RC(sync_pair(0, 5));
-        for (int b = 0; b < 2; ++b) {
+        const int64_t Gmax = g.G[0] > g.G[1] ? g.G[0] : g.G[1];
+        const bool block_fused = graph_mx && D2 == 2 * HD;
+        if (block_fused) {
+            // mapping, window graphs, the block's Linear and its BatchNorm statistics: one launch for both window blocks
+            const unsigned wgs = (unsigned)((Gmax + FC_MX_WAVES - 1) / FC_MX_WAVES);
+            auto go = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3(wgs < 1024 ? wgs : 1024, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, run, cells, training,
+                                   (const float*)P_(w.F), Ptr2{{P_(w.Mm[0]), P_(w.Mm[1])}}, Ptr2{{P_(w.P[0]), P_(w.P[1])}},
+                                   Ptr2{{P_(w.AX[0]), P_(w.AX[1])}}, Ptr2{{P_(w.z5[0]), P_(w.z5[1])}});
+            };
+            if (D2 == 16) go(fc_block_mx_kernel<16>);
+            else go(fc_block_mx_kernel<32>);
+            FC_RC(sync_pair(0, 4));
+            FC_RC(sync_pair(0, 6));
+        }
+        for (int b = 0; b < 2 && !block_fused; ++b) {
             const int GQ = (int)(g.G[b] * g.Q);
             const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
-            if (graph_mx && D2 == 2 * HD) {
-                // mapping, window graphs, the block's Linear and its BatchNorm statistics in one launch
-                auto go = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, dim3(wgs < 1024 ? wgs : 1024), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, run, cells, training,
-                                       (const float*)P_(w.F), P_(w.Mm[b]), P_(w.P[b]), P_(w.AX[b]), P_(w.z5[b]));
-                };
-                if (D2 == 16) go(fc_block_mx_kernel<16>);
-                else go(fc_block_mx_kernel<32>);
-            } else {
+            {
                 FC_RC(sgemm(P_(w.F), D2, 1, prm + g.o_map[b], D2, 1, P_(w.Mm[b]), D2, Mi, D2, D2, false, st, bf));
                 if (graph_mx) {
                     auto go = [&](auto kernel) {
@@ -2013,9 +2047,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             }
             FC_RC(sync_pair(0, 4 + 2 * b));
         }
-        for (int b = 0; b < 2; ++b)
-            hipLaunchKernelGGL(fc_pool_kernel, dim3(grid_for(g.G[b] * g.N * HD)), dim3(FB), 0, st, g, b, prm, run, (const Cells*)cells,
-                               training, (const float*)P_(w.z5[b]), P_(w.feat));
+        hipLaunchKernelGGL(fc_pool_kernel, dim3(grid_for(Gmax * g.N * HD), 2), dim3(FB), 0, st, g, prm, run, (const Cells*)cells, training,
+                           CPtr2{{P_(w.z5[0]), P_(w.z5[1])}}, P_(w.feat));
         // K = FIN (4032 at FD004) against a [batch x 16] output: split the reduction, or four workgroups walk it alone (250 us)
         FC_RC(sgemm_splitk(P_(w.feat), FIN, 1, prm + g.o_f1w, FIN, 1, P_(w.h1), D2, Bi, D2, FIN, false, P_(w.split), st));
         if (mlp_fused) {
@@ -2110,24 +2143,31 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         }
         if (!mlp_fused) FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
         // ---- graph blocks ----
-        for (int b = 0; b < 2; ++b) {
-            const int GQ = (int)(g.G[b] * g.Q);
-            float* dz5 = P_(w.dz5[b]);
-            hipLaunchKernelGGL(fc_pool_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, b, prm, cells,
-                               (const float*)P_(w.z5[b]), (const float*)P_(w.dfeat), dz5);
-            FC_RC(sync_pair(1, 4 + 2 * b));
-            hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for((int64_t)GQ * HD)), dim3(FB), 0, st, g, 4 + 2 * b, prm,
-                               (const Cells*)cells, (const float*)P_(w.z5[b]), dz5, (int64_t)GQ);
+        // (both window blocks in each launch: blockIdx.y)
+        {
+            const int64_t Gmax = g.G[0] > g.G[1] ? g.G[0] : g.G[1];
+            const int64_t GQ0 = g.G[0] * g.Q, GQ1 = g.G[1] * g.Q;
+            const CPtr2 z5p{{P_(w.z5[0]), P_(w.z5[1])}};
+            const Ptr2 dz5p{{P_(w.dz5[0]), P_(w.dz5[1])}};
+            hipLaunchKernelGGL(fc_pool_bwd_kernel, dim3(grid_for(Gmax * g.Q * HD), 2), dim3(FB), 0, st, g, prm, cells, z5p,
+                               (const float*)P_(w.dfeat), dz5p);
+            FC_RC(sync_pair(1, 4));
+            FC_RC(sync_pair(1, 6));
+            hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(Gmax * g.Q * HD), 2), dim3(FB), 0, st, g, 4, prm, (const Cells*)cells, z5p, dz5p,
+                               GQ0, GQ1);
             fork();
             const bool bwd_fused = graph_mx && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
-            if (!bwd_fused) FC_RC(sgemm(dz5, HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, GQ, D2, HD, false, st, bf));
+            if (!bwd_fused)
+                for (int b = 0; b < 2; ++b)
+                    FC_RC(sgemm(P_(w.dz5[b]), HD, 1, prm + g.o_th[b], 1, D2, P_(w.dAX[b]), D2, (int)(g.G[b] * g.Q), D2, HD, false, st, bf));
             // (the per-graph d mapping blocks have their own buffer: the theta gradient, possibly on the other stream, still reads AX[b])
             if (graph_mx) {
-                const unsigned wgs = (unsigned)((g.G[b] + FC_MX_WAVES - 1) / FC_MX_WAVES);
+                const unsigned wgs = (unsigned)((Gmax + FC_MX_WAVES - 1) / FC_MX_WAVES);
                 auto go = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096), dim3(64 * FC_MX_WAVES), 0, st, g, b, prm, (const Cells*)cells,
-                                       (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]), (const float*)dz5, P_(w.dAX[b]),
-                                       P_(w.dMb[b]));
+                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, (const Cells*)cells,
+                                       (const float*)P_(w.F), CPtr2{{P_(w.Mm[0]), P_(w.Mm[1])}}, CPtr2{{P_(w.P[0]), P_(w.P[1])}},
+                                       CPtr2{{P_(w.dz5[0]), P_(w.dz5[1])}}, Ptr2{{P_(w.dAX[0]), P_(w.dAX[1])}},
+                                       Ptr2{{P_(w.dMb[0]), P_(w.dMb[1])}});
                 };
                 if (bwd_fused) {
                     if (D2 == 16) go(fc_graph_bwd_mx_kernel<16, true>);
@@ -2137,21 +2177,23 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                     else go(fc_graph_bwd_mx_kernel<32, false>);
                 }
             } else {
-            {
+            for (int b = 0; b < 2; ++b) {
                 const size_t lds_b = sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1));
                 if (lds_b > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(fc_graph_bwd_kernel),
                                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b) != hipSuccess)
                     return RULGNN_EHIP;
-            }
             hipLaunchKernelGGL(fc_graph_bwd_kernel, dim3((unsigned)(g.G[b] < 8192 ? g.G[b] : 8192)), dim3(FC_GRAPH_BWD_THREADS), sizeof(float) * (3 * g.Q * (g.D2 + 1) + 3 * g.Q * (g.Q + 1)), st, g, b, prm,
                                (const Cells*)cells, (const float*)P_(w.F), (const float*)P_(w.Mm[b]), (const float*)P_(w.P[b]),
                                P_(w.dAX[b]), P_(w.dMb[b]));
             }
-            hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, b, (const float*)P_(w.dAX[b]),
-                               (const float*)P_(w.dMb[b]), P_(w.gX[b]), P_(w.gM[b]));
+            }
+            hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2), 2), dim3(FB), 0, st, g, CPtr2{{P_(w.dAX[0]), P_(w.dAX[1])}},
+                               CPtr2{{P_(w.dMb[0]), P_(w.dMb[1])}}, Ptr2{{P_(w.gX[0]), P_(w.gX[1])}}, Ptr2{{P_(w.gM[0]), P_(w.gM[1])}});
             // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum; enqueued behind the main
             // stream's graph kernels, which it runs beside)
-            FC_RC(sgemm_splitk_colsum(dz5, 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, GQ, gr + g.o_thb[b], one, split, wst));
+            for (int b = 0; b < 2; ++b)
+                FC_RC(sgemm_splitk_colsum(P_(w.dz5[b]), 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, (int)(g.G[b] * g.Q), gr + g.o_thb[b], one,
+                                          split, wst));
         }
         fork();
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
@@ -2166,7 +2208,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
-                           (const float*)P_(w.z3), P_(w.dF), g.M);
+                           CPtr2{{P_(w.z3), nullptr}}, Ptr2{{P_(w.dF), nullptr}}, g.M, (int64_t)0);
         fork();
         // ---- encoder convolutions ----
         if (proj_fused) {
