@@ -93,16 +93,25 @@ __global__ void t_aggregate_kernel(const float* __restrict__ A, const float* __r
     const int64_t b = i / a.N;
     const int t = (int)(i % a.N);
     const float* Ab = A + b * F * F;
-    float x[F];
+    float x[F], r[F];
+    // (every load before the first store: `add` may alias `out`, and a load behind a store of the same loop waits for it)
 #pragma unroll
     for (int c = 0; c < F; ++c) x[c] = in[(b * F + c) * a.N + t];
 #pragma unroll
+    for (int c = 0; c < F; ++c) r[c] = 0.f;
+    if (add) {
+#pragma unroll
+        for (int c = 0; c < F; ++c) r[c] = add[(b * F + c) * a.N + t];
+    }
+#pragma unroll
     for (int c = 0; c < F; ++c) {
-        float acc = add ? add[(b * F + c) * a.N + t] : 0.f;
+        float acc = r[c];
 #pragma unroll
         for (int q = 0; q < F; ++q) acc = fmaf(Ab[c * F + q], x[q], acc);
-        out[(b * F + c) * a.N + t] = acc;
+        r[c] = acc;
     }
+#pragma unroll
+    for (int c = 0; c < F; ++c) out[(b * F + c) * a.N + t] = r[c];
 }
 
 // eval-mode TCN block of one layer after the theta GEMM (BatchNorm folded), Model.py:134-170,187-195:
@@ -226,6 +235,13 @@ size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
            al256((size_t)s->num_layers * 4 * F * 4);
 }
 
+// (persistent kernels: at most T_PGRID workgroups)
+#define T_LAUNCH_P(kern, n, ...)                                                                            \
+    do {                                                                                                    \
+        (void)hipGetLastError();                                                                            \
+        hipLaunchKernelGGL(kern, dim3((unsigned)t_pgrid(n)), dim3(256), 0, stream, __VA_ARGS__);            \
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;                                            \
+    } while (0)
 #define T_LAUNCH(kern, n, ...)                                                                              \
     do {                                                                                                    \
         (void)hipGetLastError();                                                                            \
@@ -297,10 +313,12 @@ __device__ __forceinline__ double tc_sum(const double* base, int stride, int idx
     return v;
 }
 
+// (threads tid0 .. tid0 + F - 1 do the work: a kernel that needs two sets gives them to two wavefronts and pays the fp64 chain once)
 __device__ __forceinline__ void t_bn_consts(const double* cells_fwd, const double* cells_bwd, const float* __restrict__ prm_l,
-                                            int N, int L, int blk, int bn_index, double cnt, bool with_bwd, float* lds /* [7][F] */) {
-    if (threadIdx.x < F) {
-        const int c = threadIdx.x;
+                                            int N, int L, int blk, int bn_index, double cnt, bool with_bwd, float* lds /* [7][F] */,
+                                            int tid0 = 0) {
+    if ((int)threadIdx.x >= tid0 && (int)threadIdx.x < tid0 + F) {
+        const int c = threadIdx.x - tid0;
         const double mean = tc_sum(cells_fwd, tc_sf(L), (bn_index * 2 + 0) * F + c) / cnt;
         double var = tc_sum(cells_fwd, tc_sf(L), (bn_index * 2 + 1) * F + c) / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
@@ -334,6 +352,20 @@ __device__ __forceinline__ void t_pair_reduce(const float (&sa)[F], const float 
     }
 }
 
+// The kernels with a reduction behind them (BatchNorm sums, convolution weight-gradient partials) are PERSISTENT: at most T_PGRID
+// workgroups (four per CU, what the weight-gradient kernels' LDS tiles allow), each walking chunks of 256 positions with its sums in
+// registers, so that the BatchNorm constants (a chain of fp64 divisions and a square root over 16 cell replicas) and the block
+// reduction + atomics are paid once per workgroup instead of once per 256 positions -- at XJTU batch 1024 (4096 chunks) those two were
+// 20 and 33 us of t_conv2_bwd_kernel's 101.
+#ifndef T_PGRID_V
+#define T_PGRID_V 1024
+#endif
+constexpr int T_PGRID = T_PGRID_V;
+__host__ __device__ inline int t_pgrid(int64_t positions) {
+    const int64_t chunks = (positions + 255) / 256;
+    return (int)(chunks < T_PGRID ? chunks : T_PGRID);
+}
+
 struct TTrain {
     int64_t B, sample_offset, global_batch;
     int N, P, L;
@@ -364,14 +396,14 @@ __device__ __forceinline__ void t_st10(float* __restrict__ T, int64_t b, int t, 
 __global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restrict__ Hpre, const float* __restrict__ prm_l, float* __restrict__ H,
                                                             float* __restrict__ z1, int bn_index, TTrain a) {
     __shared__ float lds[4 * 2 * F];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < a.B * a.N;
-    const int64_t b = ok ? i / a.N : 0;
-    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int N = a.N;
+    const int64_t total = a.B * a.N;
     float sa[F], sb[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
-    if (ok) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / N;
+        const int t = (int)(i - b * N);
         float h[F], hm[F], z[F];
         t_load_H(Hpre, prm_l + off_theta_b(N), b, t, N, h);
         t_load_H(Hpre, prm_l + off_theta_b(N), b, t - 1, N, hm);
@@ -379,7 +411,7 @@ __global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restr
         t_st10(H, b, t, N, h);
         t_st10(z1, b, t, N, z);
 #pragma unroll
-        for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
+        for (int c = 0; c < F; ++c) { sa[c] += z[c]; sb[c] = fmaf(z[c], z[c], sb[c]); }
     }
     t_pair_reduce(sa, sb, a.cells_fwd + (blockIdx.x % T_REP) * tc_sf(a.L) + bn_index * 2 * F, lds);
 }
@@ -403,14 +435,14 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
     __shared__ float bnc[7 * F];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index - 1, a.cnt, false, bnc);
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < a.B * a.N;
-    const int64_t b = ok ? i / a.N : 0;
-    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int N = a.N;
+    const int64_t total = a.B * a.N;
     float sa[F], sb[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
-    if (ok) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / N;
+        const int t = (int)(i - b * N);
         float v[F], vm[F], z[F];
         t_o0_from(z1, H, bnc, b, t, N, v);
         t_o0_from(z1, H, bnc, b, t - 2, N, vm);
@@ -418,7 +450,7 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
         t_st10(o0, b, t, N, v);
         t_st10(z2, b, t, N, z);
 #pragma unroll
-        for (int c = 0; c < F; ++c) { sa[c] = z[c]; sb[c] = z[c] * z[c]; }
+        for (int c = 0; c < F; ++c) { sa[c] += z[c]; sb[c] = fmaf(z[c], z[c], sb[c]); }
     }
     t_pair_reduce(sa, sb, a.cells_fwd + (blockIdx.x % T_REP) * tc_sf(a.L) + bn_index * 2 * F, lds);
 }
@@ -434,15 +466,21 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
     const int64_t b = i / a.N;
     const int t = (int)(i % a.N), N = a.N;
     const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
+    const uint32_t key = a.key_dev ? *a.key_dev : a.drop_key;
+    float zv[F], ov[F], xv[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) {
         const int64_t idx = (b * F + c) * N + t;
-        float o1 = relu(relu(fmaf(z2[idx], bnc[2 * F + c], bnc[3 * F + c])) + o0[idx]);
+        zv[c] = z2[idx]; ov[c] = o0[idx]; xv[c] = Xin[idx];
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        float o1 = relu(relu(fmaf(zv[c], bnc[2 * F + c], bnc[3 * F + c])) + ov[c]);
         if (a.dropout_p > 0.f) {
-            const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ (a.key_dev ? *a.key_dev : a.drop_key));
+            const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ key);
             o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
         }
-        Xout[idx] = o1 + Xin[idx];
+        Xout[(b * F + c) * N + t] = o1 + xv[c];
     }
 }
 
@@ -494,46 +532,58 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
     __shared__ float bnc[7 * F];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < a.B * a.N;
-    const int64_t b = ok ? i / a.N : 0;
-    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int N = a.N;
+    const int64_t total = a.B * a.N;
     float sa[F], sb[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
-    if (ok) {
-        int arg = 0;
-        float dp = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / N;
+        const int t = (int)(i - b * N);
+        // (all loads first, then the arithmetic, then the stores: written channel by channel the compiler kept one channel's loads
+        // behind the previous channel's stores and waits -- some thirty dependent memory round trips per position)
+        float gin[F], zv[F], ov[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const int64_t idx = (b * F + c) * N + t;
+            gin[c] = top ? Xout[idx] : dXn[idx];
+            zv[c] = z2[idx];
+            ov[c] = o0[idx];
+        }
         if (top) {
-            float m = Xout[(b * F) * N + t];
+            int arg = 0;
+            float m = gin[0];
 #pragma unroll
             for (int c = 1; c < F; ++c) {
-                const float v = Xout[(b * F + c) * N + t];
+                const float v = gin[c];
                 const bool take = (v > m) || (v != v && m == m);
                 m = take ? v : m;
                 arg = take ? c : arg;
             }
-            dp = dpooled[b * N + t];
+            const float dp = dpooled[b * N + t];
+#pragma unroll
+            for (int c = 0; c < F; ++c) gin[c] = (c == arg) ? dp : 0.f;
+#pragma unroll
+            for (int c = 0; c < F; ++c) dXn[(b * F + c) * N + t] = gin[c];
         }
         const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
+        const uint32_t key = a.key_dev ? *a.key_dev : a.drop_key;
 #pragma unroll
         for (int c = 0; c < F; ++c) {
             const int64_t idx = (b * F + c) * N + t;
-            float g;
-            if (top) { g = (c == arg) ? dp : 0.f; dXn[idx] = g; }
-            else g = dXn[idx];
-            const float zz = z2[idx];
+            float g = gin[c];
+            const float zz = zv[c];
             const float x1 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
-            const float o1 = relu(x1 + o0[idx]);
+            const float o1 = relu(x1 + ov[c]);
             if (a.dropout_p > 0.f) {
-                const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ (a.key_dev ? *a.key_dev : a.drop_key));
+                const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ key);
                 g = h >= a.drop_thr ? g * a.drop_scale : 0.f;
             }
             g = (o1 > 0.f) ? g : 0.f;
             gsum[idx] = g;
             const float dy = (x1 > 0.f) ? g : 0.f;
-            sa[c] = dy;
-            sb[c] = dy * ((zz - bnc[0 * F + c]) * bnc[1 * F + c]);
+            sa[c] += dy;
+            sb[c] = fmaf(dy, (zz - bnc[0 * F + c]) * bnc[1 * F + c], sb[c]);
         }
     }
     t_pair_reduce(sa, sb, a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + bn_index * 2 * F, lds);
@@ -597,12 +647,19 @@ __device__ __forceinline__ void t_dz2_at(const float* __restrict__ gsum, const f
         for (int c = 0; c < F; ++c) dz[c] = 0.f;
         return;
     }
+    // (both tensors loaded up front: with the load inside the select, `x1 > 0 ? gsum[idx] : 0`, the compiler issued it under a branch
+    // behind the wait for z2 -- ten dependent memory round trips per call, two thirds of the kernel's wavefront time)
+    float zv[F], gv[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) {
-        const int64_t idx = (b * F + c) * N + t;
-        const float zz = z2[idx];
+        zv[c] = z2[(b * F + c) * N + t];
+        gv[c] = gsum[(b * F + c) * N + t];
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const float zz = zv[c];
         const float x1 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
-        const float dy = (x1 > 0.f) ? gsum[idx] : 0.f;
+        const float dy = (x1 > 0.f) ? gv[c] : 0.f;
         const float xh = (zz - bnc[0 * F + c]) * bnc[1 * F + c];
         dz[c] = bnc[4 * F + c] * (dy - bnc[5 * F + c] - xh * bnc[6 * F + c]);
     }
@@ -630,25 +687,30 @@ __global__ __launch_bounds__(256) void t_conv2_bwd_kernel(const float* __restric
     __shared__ float lds[4 * 2 * F];
     __shared__ float bnc2[7 * F], bnc1[7 * F];
     __shared__ float red[8 * 64];
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, true, bnc2);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, true, bnc2, 0);
+    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index - 1, a.cnt, false, bnc1, 64);
     __syncthreads();
-    t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index - 1, a.cnt, false, bnc1);
-    __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < a.B * a.N;
-    const int64_t b = ok ? i / a.N : 0;
-    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int N = a.N;
+    const int64_t total = a.B * a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float sa[F], sb[F], dz[F], dzs[F], h[F], hs[F];
+    float sa[F], sb[F];
 #pragma unroll
-    for (int c = 0; c < F; ++c) sa[c] = sb[c] = dz[c] = h[c] = hs[c] = 0.f;
+    for (int c = 0; c < F; ++c) sa[c] = sb[c] = 0.f;
+    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {       // (workgroup-uniform trip count)
+    const int64_t i = base + threadIdx.x;
+    const bool ok = i < total;
+    const int64_t b = ok ? i / N : 0;
+    const int t = ok ? (int)(i - b * N) : 0;
+    float dz[F], dzs[F], h[F], hs[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) dz[c] = dzs[c] = h[c] = hs[c] = 0.f;
     if (ok) {
         t_dz2_at(gsum, z2, bnc2, b, t, N, dz);
         t_dz2_at(gsum, z2, bnc2, b, t + 2, N, dzs);
         t_ld10(o0, b, t, N, h);
         t_ld10(o0, b, t - 2, N, hs);
     }
-    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     t_wgrad_mfma(tile[wave], dz, h, hs, lane, acc0, acc1);
     if (ok) {
         float d_o0[F];
@@ -662,9 +724,10 @@ __global__ __launch_bounds__(256) void t_conv2_bwd_kernel(const float* __restric
             const float zz = z1[idx];
             const float x0 = relu(fmaf(zz, bnc1[2 * F + c], bnc1[3 * F + c]));
             const float dy = (x0 > 0.f) ? g : 0.f;
-            sa[c] = dy;
-            sb[c] = dy * ((zz - bnc1[0 * F + c]) * bnc1[1 * F + c]);
+            sa[c] += dy;
+            sb[c] = fmaf(dy, (zz - bnc1[0 * F + c]) * bnc1[1 * F + c], sb[c]);
         }
+    }
     }
     t_pair_reduce(sa, sb, a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + (bn_index - 1) * 2 * F, lds);
     __syncthreads();
@@ -678,12 +741,17 @@ __device__ __forceinline__ void t_dz1_at(const float* __restrict__ gsum0, const 
         for (int c = 0; c < F; ++c) dz[c] = 0.f;
         return;
     }
+    float zv[F], gv[F];                     // (loaded up front: see t_dz2_at)
 #pragma unroll
     for (int c = 0; c < F; ++c) {
-        const int64_t idx = (b * F + c) * N + t;
-        const float zz = z1[idx];
+        zv[c] = z1[(b * F + c) * N + t];
+        gv[c] = gsum0[(b * F + c) * N + t];
+    }
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        const float zz = zv[c];
         const float x0 = relu(fmaf(zz, bnc[2 * F + c], bnc[3 * F + c]));
-        const float dy = (x0 > 0.f) ? gsum0[idx] : 0.f;
+        const float dy = (x0 > 0.f) ? gv[c] : 0.f;
         const float xh = (zz - bnc[0 * F + c]) * bnc[1 * F + c];
         dz[c] = bnc[4 * F + c] * (dy - bnc[5 * F + c] - xh * bnc[6 * F + c]);
     }
@@ -698,21 +766,24 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
     __shared__ float red[8 * 64];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 0, bn_index, a.cnt, true, bnc);
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool ok = i < a.B * a.N;
-    const int64_t b = ok ? i / a.N : 0;
-    const int t = ok ? (int)(i % a.N) : 0, N = a.N;
+    const int N = a.N;
+    const int64_t total = a.B * a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
+    const int64_t i = base + threadIdx.x;
+    const bool ok = i < total;
+    const int64_t b = ok ? i / N : 0;
+    const int t = ok ? (int)(i - b * N) : 0;
     float dz[F], dzs[F], h[F], hs[F];
 #pragma unroll
-    for (int c = 0; c < F; ++c) dz[c] = h[c] = hs[c] = 0.f;
+    for (int c = 0; c < F; ++c) dz[c] = dzs[c] = h[c] = hs[c] = 0.f;
     if (ok) {
         t_dz1_at(gsum0, z1, bnc, b, t, N, dz);
         t_dz1_at(gsum0, z1, bnc, b, t + 1, N, dzs);
         t_ld10(H, b, t, N, h);
         t_ld10(H, b, t - 1, N, hs);
     }
-    f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     t_wgrad_mfma(tile[wave], dz, h, hs, lane, acc0, acc1);
     if (ok) {
         float dH[F];
@@ -723,6 +794,7 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
             const float g = dH[c] + gsum0[idx];
             dHpre[idx] = h[c] > 0.f ? g : g * LEAKY;
         }
+    }
     }
     t_wgrad_store(red, acc0, acc1, gpart + (size_t)blockIdx.x * CONVW);
 }
@@ -798,7 +870,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     const int N = s->num_patch, L = s->num_layers;
     const int64_t B = s->batch;
     w->T = al256((size_t)B * F * N * sizeof(float));
-    w->grid = (int)((B * N + 255) / 256);
+    w->grid = t_pgrid(B * N);
     size_t o = 0;
     w->off_X = o; o += (size_t)(L + 1) * w->T;
     w->off_AX = o; o += (size_t)L * w->T;
@@ -905,8 +977,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
             rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);
             if (rc != RULGNN_OK) return rc;
-            T_LAUNCH(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
-            T_LAUNCH(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
+            T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
+            T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
             T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t);
         }
         T_LAUNCH(t_pool_kernel, BN_, TP(w.off_X, L), pooled, a);
@@ -945,11 +1017,11 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             float* gl = g + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
-            T_LAUNCH(t_tail_bwd_kernel, BN_, dpool, TP(w.off_X, l + 1), dX, TP(w.off_z2, l), TP(w.off_o0, l), pl, gsum, 2 * l + 1,
+            T_LAUNCH_P(t_tail_bwd_kernel, BN_, dpool, TP(w.off_X, l + 1), dX, TP(w.off_z2, l), TP(w.off_o0, l), pl, gsum, 2 * l + 1,
                      l == L - 1 ? 1 : 0, t);
-            T_LAUNCH(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,
+            T_LAUNCH_P(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,
                      gpart + (size_t)(2 * l + 1) * w.grid * CONVW, 2 * l + 1, t);
-            T_LAUNCH(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
+            T_LAUNCH_P(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
                      gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t);
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
             rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream);
