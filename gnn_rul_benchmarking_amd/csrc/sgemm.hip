@@ -856,6 +856,40 @@ static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_kernel(const 
 }
 
 
+// ... for large contiguous outputs (M N a multiple of 4, ldc == N: the [N x N] weight gradients of the tiled ST_GCN path, 4 MB per slice):
+// a thread owns four consecutive outputs and walks the slices with 16-byte loads, four slices in flight -- the form above issues one
+// 4-byte load per thread and slice and ran at ~2 TB/s (35 us for 16 slices of [1024 x 1024]).  Fixed order: slice 0, 1, 2, ...
+static __global__ __launch_bounds__(256) void sgemm_reduce_slices4_kernel(const float4* __restrict__ partial, float4* __restrict__ C, int64_t quads,
+                                                                          int slices, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= quads) return;
+    float4 v = accumulate ? C[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 3 < slices; z += 4) {
+        const float4 p0 = partial[(int64_t)z * quads + e], p1 = partial[(int64_t)(z + 1) * quads + e];
+        const float4 p2 = partial[(int64_t)(z + 2) * quads + e], p3 = partial[(int64_t)(z + 3) * quads + e];
+        v.x = (((v.x + p0.x) + p1.x) + p2.x) + p3.x;
+        v.y = (((v.y + p0.y) + p1.y) + p2.y) + p3.y;
+        v.z = (((v.z + p0.z) + p1.z) + p2.z) + p3.z;
+        v.w = (((v.w + p0.w) + p1.w) + p2.w) + p3.w;
+    }
+    for (; z < slices; ++z) {
+        const float4 p = partial[(int64_t)z * quads + e];
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    C[e] = v;
+}
+static inline int sgemm_reduce_slices(const float* partial, float* C, int64_t ldc, int M, int N, int slices, bool accumulate, hipStream_t st) {
+    const int64_t MN = (int64_t)M * N;
+    (void)hipGetLastError();
+    if (MN >= 65536 && MN % 4 == 0 && (ldc == N || M == 1) && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(C)) & 15) == 0)
+        hipLaunchKernelGGL(sgemm_reduce_slices4_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(C), MN / 4, slices, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(1024), 0, st, partial, C, ldc, M, N, slices, accumulate ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Long reduction into a small output (the weight gradients of the per-row projections: M x N <= 1024 outputs, K = all rows
 // of the batch).  The generic split-K path launches a 64x64 MFMA tile per slice for a handful of useful columns and then
@@ -1054,9 +1088,60 @@ static __global__ __launch_bounds__(1024) void sgemm_tiny_kernel(GemmArgs g, int
 // rows) 25 us against 12 us for the pair.
 static inline bool sgemm_tiny_ok(int M, int N, int K) { return (int64_t)M * N <= 1024 && (int64_t)K * M * N <= 131072; }
 
+// ------------------------------------------------------------------------------------------------
+// One output ROW over a long K with B contiguous along n: C[n] = sum_k a[k] B[k][n] -- the bias gradients (a = ones) and vector-matrix
+// weight gradients (fc2 of the tiled ST_GCN path) over batch-sized row counts.  As a 64 x 64 matrix-core tile with one useful row in 64
+// plus the slice reduction this was 27 + 15 us per product at N = 1024 (four of them per step of the XJTU-SY wiring); it is a
+// memory-bound column sum: lanes along n (coalesced), a wavefront per row slice, eight loads in flight per thread, `ks` row chunks
+// across blockIdx.y, the chunks' partial rows combined by rows_sum_kernel in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void sgemm_vecmat_kernel(const float* __restrict__ a, int64_t sAk, const float* __restrict__ B, int64_t sBk,
+                                                                  float* __restrict__ partial, int N, int K, int kper) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int k0 = blockIdx.y * kper, k1 = min(K, k0 + kper);
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    if (n < N) {
+        const float* bp = B + n;
+        int k = k0 + wave;
+        for (; k + 28 < k1; k += 32) {
+            float bv[8], av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                bv[u] = bp[(int64_t)(k + 4 * u) * sBk];
+                av[u] = a[(int64_t)(k + 4 * u) * sAk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = fmaf(av[u], bv[u], acc[u]);
+        }
+        for (; k < k1; k += 4) acc[0] = fmaf(a[(int64_t)k * sAk], bp[(int64_t)k * sBk], acc[0]);
+    }
+    red[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (wave == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+static inline bool sgemm_vecmat_ok(int M, int N, int K, int64_t sBn) { return M == 1 && sBn == 1 && N >= 64 && K >= 256; }
+
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if (!accumulate && !sgemm_tiny_ok(M, N, K) && sgemm_longk_blocks(M, N, K) == 0 && sgemm_vecmat_ok(M, N, K, sBn)) {
+        // (the row chunks fit the scratch the caller sized with sgemm_splitk_need_floats: never more chunks than the tile path's slices)
+        int ks = sgemm_splitk_slices(M, N, K);
+        const int want = (512 + (N + 63) / 64 - 1) / ((N + 63) / 64);                  // ~512 workgroups
+        ks = ks < want ? ks : want;
+        ks = ks > 32 ? 32 : ks;                                                        // (rows_sum_kernel: 32 row slices)
+        int kper = (K + ks - 1) / ks;
+        kper = (kper + 31) & ~31;
+        ks = (K + kper - 1) / kper;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(sgemm_vecmat_kernel, dim3((N + 63) / 64, ks), dim3(256), 0, st, A, sAk, B, sBk, ks > 1 ? partial : C, N, K, kper);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        return ks > 1 ? rows_sum(partial, ks, N, N, C, st) : RULGNN_OK;
+    }
     if (sgemm_tiny_ok(M, N, K)) {
         GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, 0, K};
         (void)hipGetLastError();
@@ -1085,9 +1170,8 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
     GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
     (void)hipGetLastError();
     sgemm_launch_tiles(g, used, st);
-    hipLaunchKernelGGL(sgemm_reduce_slices_kernel, dim3((M * N + 63) / 64), dim3(1024), 0, st, partial, C, ldc, M, N, used,
-                       accumulate ? 1 : 0);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    return sgemm_reduce_slices(partial, C, ldc, M, N, used, accumulate, st);
 }
 
 // sgemm_splitk plus colsum[m] = sum_k A(m, k) from the same pass (a weight gradient and the bias gradient that goes with it): on the

@@ -47,6 +47,16 @@ constexpr int SKT_ROWS = 128;
 static inline int sgemm_splitk_slices(int M, int N, int K) {
     // outputs that fill 128x128 tiles run on the big kernel (sgemm_big_ok): count its tiles, two workgroups per CU
     const bool big = M > 96 && N > 96;
+    if (M > 192 && N > 192) {
+        // outputs that fill 256 x 256 tiles (sgemm_wide_ok): one workgroup per CU (144 KB of LDS), so tiles x slices should be a whole
+        // number of rounds of the 256 CUs -- [1024 x 1024] over K = 10 240 ran as 16 x 12 = 192 workgroups (a quarter of the chip idle),
+        // as 16 x 16 it fills it
+        const int wt = ((M + 255) / 256) * ((N + 255) / 256);
+        int s = wt <= 256 ? (256 + wt / 2) / wt : 1;
+        const int maxw = (K + 255) / 256;
+        s = s > maxw ? maxw : s;
+        if (s >= 1 && wt * s >= 160) return s;
+    }
     const int t = big ? 128 : 64;
     const int tiles = ((M + t - 1) / t) * ((N + t - 1) / t);
     int s = (big ? 768 : 1024) / (tiles > 0 ? tiles : 1);          // aim at ~768 / ~1024 workgroups

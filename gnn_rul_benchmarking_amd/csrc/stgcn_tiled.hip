@@ -33,6 +33,36 @@ __global__ void t_stats_kernel(const float* __restrict__ x, float* __restrict__ 
     for (int c = 0; c < F; ++c) X0[(b * F + c) * a.N + t] = st[c];
 }
 
+// The same for the reference wirings' patch sizes (16: PHM2012 Condition_2 and XJTU-SY 2048 x 16; 32: XJTU-SY 1024 x 32).  A thread walking
+// its own patch in global memory reads 8 bytes at a stride of P floats: every load instruction touches 64 cache lines, twice over the two
+// passes (73 us for the 134 MB of XJTU batch 1024, texture-address bound).  Here a workgroup copies its 256 patches with coalesced
+// 16-byte loads into LDS (rows padded by four floats: a 16-byte read per lane is conflict-free), and a thread takes its patch from there
+// into registers once (patch_statistics_regs: same formulas, IEEE divisions and square roots).
+template <int P>
+__global__ __launch_bounds__(256) void t_stats_lds_kernel(const float* __restrict__ x, float* __restrict__ X0, TArgs a) {
+    constexpr int RS = P + 4;
+    __shared__ __attribute__((aligned(16))) float rows[256 * RS];
+    const int64_t total = a.B * a.N, p0 = (int64_t)blockIdx.x * 256;
+    const int64_t left = total - p0;
+    const int cnt = left < 256 ? (int)left : 256;
+    const float4* src = reinterpret_cast<const float4*>(x + p0 * P);
+#pragma unroll
+    for (int e = 0; e < P / 4; ++e) {
+        const int q = threadIdx.x + 256 * e;                 // float4 index inside the chunk
+        const int r = q / (P / 4), c = q % (P / 4);
+        if (r < cnt) *reinterpret_cast<float4*>(&rows[r * RS + 4 * c]) = src[q];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= cnt) return;
+    const int64_t i = p0 + threadIdx.x;
+    const int64_t b = i / a.N;
+    const int t = (int)(i - b * a.N);
+    float st[F];
+    patch_statistics_regs<P, false>(&rows[threadIdx.x * RS], st);
+#pragma unroll
+    for (int c = 0; c < F; ++c) X0[(b * F + c) * a.N + t] = st[c];
+}
+
 // Pearson adjacency -- Model.py:53-71.  One block per sample.  A: [B][10][10]
 __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X0, float* __restrict__ A, TArgs a) {
     __shared__ float red[NPAIR][4];
@@ -242,6 +272,13 @@ size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)t_pgrid(n)), dim3(256), 0, stream, __VA_ARGS__);            \
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;                                            \
     } while (0)
+// patch statistics: the LDS-staged form for the wirings' patch sizes (x 16-byte aligned), the per-thread walk otherwise
+#define T_STATS(xp, X0p)                                                                                    \
+    do {                                                                                                    \
+        if (a.P == 32 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) T_LAUNCH(t_stats_lds_kernel<32>, BN_, xp, X0p, a);      \
+        else if (a.P == 16 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) T_LAUNCH(t_stats_lds_kernel<16>, BN_, xp, X0p, a); \
+        else T_LAUNCH(t_stats_kernel, BN_, xp, X0p, a);                                                     \
+    } while (0)
 #define T_LAUNCH(kern, n, ...)                                                                              \
     do {                                                                                                    \
         (void)hipGetLastError();                                                                            \
@@ -267,7 +304,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* bnf = reinterpret_cast<float*>(w);
 
     T_LAUNCH(t_bnfold_kernel, L * 2 * F, prm, bn, bnf, N, L);
-    T_LAUNCH(t_stats_kernel, BN_, x, Xa, a);
+    T_STATS(x, Xa);
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -902,7 +939,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
         size_t need = 1024;
         if (B > 0)
             for (size_t v : {sgemm_splitk_need_floats(N, N, R), sgemm_splitk_need_floats(1, N, R), sgemm_splitk_need_floats(N, N, Bi),
-                             sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi)})
+                             sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi), sgemm_splitk_need_floats(Bi, N, N)})
                 need = v > need ? v : need;
         w->off_split = o; o += al256(need * sizeof(float));
     }
@@ -966,7 +1003,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (rc != RULGNN_OK) return rc;
         }
         if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
-        T_LAUNCH(t_stats_kernel, BN_, ar->x, TP(w.off_X, 0), a);
+        T_STATS(ar->x, TP(w.off_X, 0));
         (void)hipGetLastError();
         hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, TP(w.off_X, 0), A, a);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
@@ -982,7 +1019,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t);
         }
         T_LAUNCH(t_pool_kernel, BN_, TP(w.off_X, L), pooled, a);
-        rc = sgemm(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, stream);
+        // (through the split-K pair: [batch x N] has too few output tiles to fill the chip -- at XJTU batch 1024, 64 tiles of 128 x 128)
+        rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);
         if (rc != RULGNN_OK) return rc;
     } else {
         if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * T_REP * tc_sb(L), stream) != hipSuccess) return RULGNN_EHIP;
@@ -1010,7 +1048,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         // stack still to run -- the caller may start their all-reduce on another stream (include/rulgnn.h: rulgnn_grad_ready_fn)
         if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(param_count(N, L) - off_fc1_w(N, L)), stream) != 0)
             return RULGNN_ECALLBACK;
-        rc = sgemm(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, stream);
+        rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream);
         if (rc != RULGNN_OK) return rc;
         for (int l = L - 1; l >= 0; --l) {
             const float* pl = prm + l * LS;
