@@ -492,9 +492,11 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
     t_pair_reduce(sa, sb, a.cells_fwd + (blockIdx.x % T_REP) * tc_sf(a.L) + bn_index * 2 * F, lds);
 }
 
-// Xout = dropout(relu(relu(bn2(z2)) + o0)) + Xin
+// Xout = dropout(relu(relu(bn2(z2)) + o0)) + Xin; and what the next stage reads of it, position by position: the next layer's
+// aggregation A.Xout (AXnext) or, behind the last layer, the channel max-pool (pooled) -- both were launches that re-read Xout
 __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ Xin,
-                                                           const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a) {
+                                                           const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a,
+                                                           const float* __restrict__ A, float* __restrict__ AXnext, float* __restrict__ pooled) {
     __shared__ float bnc[7 * F];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
     __syncthreads();
@@ -517,7 +519,24 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
             const uint32_t h = lowbias32((ctr + (uint32_t)(c * N)) ^ key);
             o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
         }
-        Xout[(b * F + c) * N + t] = o1 + xv[c];
+        xv[c] = o1 + xv[c];
+        Xout[(b * F + c) * N + t] = xv[c];
+    }
+    if (AXnext) {                                                    // (same sums, in the same order, as t_aggregate_kernel)
+        const float* Ab = A + b * F * F;
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < F; ++q) acc = fmaf(Ab[c * F + q], xv[q], acc);
+            AXnext[(b * F + c) * N + t] = acc;
+        }
+    }
+    if (pooled) {                                                    // (t_pool_kernel)
+        float m = xv[0];
+#pragma unroll
+        for (int c = 1; c < F; ++c) m = (xv[c] > m || xv[c] != xv[c]) ? xv[c] : m;
+        pooled[i] = m;
     }
 }
 
@@ -1011,14 +1030,15 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             const float* pl = prm + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
-            T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
+            if (l == 0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
             rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);
             if (rc != RULGNN_OK) return rc;
             T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
             T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
-            T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t);
+            // (+ the next layer's A.X, or the channel max-pool behind the last layer)
+            T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t,
+                     (const float*)A, l + 1 < L ? TP(w.off_AX, l + 1) : (float*)nullptr, l + 1 < L ? (float*)nullptr : pooled);
         }
-        T_LAUNCH(t_pool_kernel, BN_, TP(w.off_X, L), pooled, a);
         // (through the split-K pair: [batch x N] has too few output tiles to fill the chip -- at XJTU batch 1024, 64 tiles of 128 x 128)
         rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);
         if (rc != RULGNN_OK) return rc;
@@ -1073,7 +1093,9 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (l > 0) {
                 rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;
-                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a);                                              // A^T dAX + dXn (A symmetric)
+                // (A^T dAX + dXn, A symmetric.  Folded into the tail kernel of the layer below it cost more there -- 100 adjacency loads and
+                // 100 FMAs per position inside the persistent loop: +22 us -- than this launch takes)
+                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a);
             }
         }
     }
