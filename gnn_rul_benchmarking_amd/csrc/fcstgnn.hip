@@ -605,7 +605,8 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_mx_kernel(FcGeom g,
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int node = fc_krow(s, h);
-            xk[s] = (c < D2T && node < Q) ? fmaf(F[(row0 + node) * D2T + c], sc, sh) : 0.f;
+            const float fv = F[(row0 + (node < Q ? node : Q - 1)) * D2T + (c < D2T ? c : 0)];      // (unconditional: the sixteen loads go out together)
+            xk[s] = (c < D2T && node < Q) ? fmaf(fv, sc, sh) : 0.f;
         }
         fc_f32x16 S = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -1103,7 +1104,8 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int node = fc_krow(s, h);
-            xk[s] = (c < D2T && node < Q) ? fmaf(F[(row0 + node) * D2T + c], sc, sh) : 0.f;
+            const float fv = F[(row0 + (node < Q ? node : Q - 1)) * D2T + (c < D2T ? c : 0)];      // (unconditional: the sixteen loads go out together)
+            xk[s] = (c < D2T && node < Q) ? fmaf(fv, sc, sh) : 0.f;
         }
         // M^T = W_map F^T: lane = node, register = mapped feature krow(r, h)
         fc_f32x16 M = zero;
@@ -1279,7 +1281,11 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
                 dh[4 * v] = d4.x; dh[4 * v + 1] = d4.y; dh[4 * v + 2] = d4.z; dh[4 * v + 3] = d4.w;
             }
 #pragma unroll
-            for (int s = 0; s < 16; ++s) dk[s] = (c < D2T && fc_krow(s, h) < Q) ? dAX[(gi * Q + fc_krow(s, h)) * D2T + c] : 0.f;
+            for (int s = 0; s < 16; ++s) {
+                const int i = fc_krow(s, h);
+                const float v = dAX[(gi * Q + (i < Q ? i : Q - 1)) * D2T + cf];
+                dk[s] = (c < D2T && i < Q) ? v : 0.f;
+            }
         }
         // The products below are ordered so that an operand is loaded right before its product and dies behind it, with a compiler
         // barrier between the stages: hoisted to the top (what the scheduler does on its own) the operands of all five products are
@@ -1320,11 +1326,18 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
         // cX^T = dAX^T Adj: a-operand the gradient by node (lane = feature), b-operand column c of the adjacency (P by columns) -> lane = node j
         {
             fc_f32x16 CX = zero;
+            // (the sixteen loads unconditional -- row index clamped -- and ahead of the products: as `i < Q ? P[..] : 0` each one sat in
+            // its own branch with a full wait between it and its product, sixteen dependent memory round trips per graph; same below)
+            float pc[16];
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int i = fc_krow(s, h);
-                const float pcs = i < Q ? P[(gi * Q + i) * Q + cq] : 0.f;
-                const float adj = (pcs + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
+                pc[s] = P[(gi * Q + (i < Q ? i : Q - 1)) * Q + cq];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int i = fc_krow(s, h);
+                const float adj = (pc[s] + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
                 CX = fc_mfma(dk[s], i < Q ? adj : 0.f, CX);
             }
             if (c < Q) {                                                // (all loads of this graph's dAX block are behind us)
@@ -1348,10 +1361,16 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
         }
         // cM^T = M'^T (dS + dS^T)^T: a-operand the mapped features by node (lane = feature), b-operand row c of dS + dS^T
         fc_f32x16 CM = zero;
+        float mk[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int node = fc_krow(s, h);
-            const float mks = (c < D2T && node < Q) ? Mm[(row0 + node) * D2T + c] + bc : 0.f;
+            mk[s] = Mm[(row0 + (node < Q ? node : Q - 1)) * D2T + cf];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int node = fc_krow(s, h);
+            const float mks = (c < D2T && node < Q) ? mk[s] + bc : 0.f;
             CM = fc_mfma(mks, ds_[s] + St[s], CM);
         }
         if (c < Q) {
@@ -1636,9 +1655,9 @@ __global__ __launch_bounds__(FB) void fc_conv2_dx_kernel(FcGeom g, const float* 
 // `zbn` = z2 | z1 --, applied to every element as it is loaded)
 // (<SK, SL1, SL2, SH1, SCO>: the convolution shape as compile-time constants, 0 = generic -- see fc_conv2_dx_kernel)
 template <int WHICH, int SK = 0, int SL1 = 0, int SL2 = 0, int SH1 = 0, int SCO = 0>
-__global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g_, const float* __restrict__ x, const float* __restrict__ prm,
-                                                          const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
-                                                          float* __restrict__ gpart, const float* __restrict__ zbn) {
+__device__ __forceinline__ void fc_conv_wgrad_body(const FcGeom& g_, const float* __restrict__ x, const float* __restrict__ prm,
+                                                   const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
+                                                   float* __restrict__ gpart, const float* __restrict__ zbn) {
     // the shape fields this kernel reads, constants where the instantiation fixes them
     struct Shape {
         const FcGeom& f;
@@ -1739,6 +1758,22 @@ __global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g_, const floa
     } else {
         for (int o = threadIdx.x; o < nout; o += FB) gpart[(int64_t)blockIdx.x * nout + o] = partial(o, m0, 1);
     }
+}
+template <int WHICH, int SK = 0, int SL1 = 0, int SL2 = 0, int SH1 = 0, int SCO = 0>
+__global__ __launch_bounds__(FB) void fc_conv_wgrad_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                          const Cells* cells, const float* __restrict__ z1, const float* __restrict__ dz,
+                                                          float* __restrict__ gpart, const float* __restrict__ zbn) {
+    fc_conv_wgrad_body<WHICH, SK, SL1, SL2, SH1, SCO>(g, x, prm, cells, z1, dz, gpart, zbn);
+}
+// both convolutions' weight gradients in one launch (blockIdx.y = 0: the second convolution's, the longer one): as two launches the
+// second convolution's sat at the end of the side stream, behind the five split-K pairs, and the step's last kernels waited ~40 us for it
+template <int SK = 0, int SL1 = 0, int SL2 = 0, int SH1 = 0, int SCO = 0>
+__global__ __launch_bounds__(FB) void fc_conv_wgrad_both_kernel(FcGeom g, const float* __restrict__ x, const float* __restrict__ prm,
+                                                               const Cells* cells, const float* __restrict__ z1, const float* __restrict__ z2,
+                                                               const float* __restrict__ dy1, const float* __restrict__ da2,
+                                                               float* __restrict__ gp1, float* __restrict__ gp2) {
+    if (blockIdx.y == 0) fc_conv_wgrad_body<2, SK, SL1, SL2, SH1, SCO>(g, x, prm, cells, z1, da2, gp2, z2);
+    else fc_conv_wgrad_body<1, SK, SL1, SL2, SH1, SCO>(g, x, prm, cells, z1, dy1, gp1, z1);
 }
 
 // Synchronised BatchNorm: the 16 replicas of ONE reduction pair (forward: sum z, sum z^2; backward: sum dy, sum dy x-hat;
@@ -2224,14 +2259,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // (BatchNorm 1's and BatchNorm 0's channel-major backward passes ride in the loads of the kernels that consume them)
         // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain
         const int rows = (int)(g.M < w.rows ? g.M : w.rows);
-        fork();
         const bool fd004_conv = g.K == 2 && g.L1 == 3 && g.L2 == 4 && g.H1 == 8 && g.CO == 6;     // the reference's C-MAPSS wiring: constants
-        if (fd004_conv)
-            hipLaunchKernelGGL((fc_conv_wgrad_kernel<2, 2, 3, 4, 8, 6>), dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells,
-                               (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.gp2), (const float*)P_(w.z2));
-        else
-        hipLaunchKernelGGL(fc_conv_wgrad_kernel<2>, dim3(rows), dim3(FB), 0, wst, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.da2), P_(w.gp2), (const float*)P_(w.z2));
         if (g.K == 2 && g.L1 == 3 && g.L2 == 4 && g.H1 == 8 && g.CO == 6)
             hipLaunchKernelGGL((fc_conv2_dx_kernel<2, 3, 4, 8, 6>), dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells,
                                (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
@@ -2239,12 +2267,13 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL((fc_conv2_dx_kernel<0, 0, 0, 0, 0>), dim3(grid_for(g.M * g.H1 * g.L1)), dim3(FB), 0, st, g, prm, cells,
                                (const float*)P_(w.z1), (const float*)P_(w.da2), P_(w.dy1), (const float*)P_(w.z2));
         FC_RC(sync_pair(1, 0));
+        // both convolutions' weight gradients (the second one's needs d z2 only, but the side stream is the longer one by then)
         if (fd004_conv)
-            hipLaunchKernelGGL((fc_conv_wgrad_kernel<1, 2, 3, 4, 8, 6>), dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells,
-                               (const float*)P_(w.z1), (const float*)P_(w.dy1), P_(w.gp1), (const float*)P_(w.z1));
+            hipLaunchKernelGGL((fc_conv_wgrad_both_kernel<2, 3, 4, 8, 6>), dim3(rows, 2), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.z2), (const float*)P_(w.dy1), (const float*)P_(w.da2), P_(w.gp1), P_(w.gp2));
         else
-        hipLaunchKernelGGL(fc_conv_wgrad_kernel<1>, dim3(rows), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells, (const float*)P_(w.z1),
-                           (const float*)P_(w.dy1), P_(w.gp1), (const float*)P_(w.z1));
+            hipLaunchKernelGGL((fc_conv_wgrad_both_kernel<>), dim3(rows, 2), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells,
+                               (const float*)P_(w.z1), (const float*)P_(w.z2), (const float*)P_(w.dy1), (const float*)P_(w.da2), P_(w.gp1), P_(w.gp2));
         FC_RC(fk.join());                                    // the gradient GEMMs are done before the call's last kernel
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
