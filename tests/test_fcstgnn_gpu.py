@@ -38,7 +38,8 @@ def check_grads(g, ref, cfg, tol=GTOL):
             wmax = max(np.abs(ref[k[:-4] + "weight"]).max(), 1e-12)
             assert np.abs(g[k]).max() < 1e-4 * wmax, k          # exactly zero in exact arithmetic; fp32 rounding noise here
             continue
-        assert rel(g[k], np.asarray(ref[k], np.float64)) < tol, k
+        r = rel(g[k], np.asarray(ref[k], np.float64))
+        assert r < tol, (k, r)
 
 
 @pytest.mark.parametrize("name", CASES)
