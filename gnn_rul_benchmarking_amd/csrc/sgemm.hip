@@ -45,20 +45,23 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
         bk[e] = b_kfast ? idx & 15 : idx >> 6;
     }
     float ra[4], rb[4];
+    // (unconditional loads on clamped indices; the mask is applied when the values go to LDS, one iteration later.  As `ok ? p[..] : 0` each
+    // of the eight loads sat in its own branch with waits between them, and with the select right behind the load the compiler waited for
+    // the next step's operands BEFORE the current step's products instead of behind them)
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int gm = m0 + am[e], gka = k0 + ak[e], gn = n0 + bm[e], gkb = k0 + bk[e];
-            ra[e] = (gm < g.M && gka < kend) ? g.A[gm * g.sAm + gka * g.sAk] : 0.f;
-            rb[e] = (gn < g.N && gkb < kend) ? g.B[gn * g.sBn + gkb * g.sBk] : 0.f;
+            ra[e] = g.A[(gm < g.M ? gm : g.M - 1) * g.sAm + (gka < kend ? gka : kend - 1) * g.sAk];
+            rb[e] = g.B[(gn < g.N ? gn : g.N - 1) * g.sBn + (gkb < kend ? gkb : kend - 1) * g.sBk];
         }
     };
     if (kbeg < kend) fetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            As[ak[e]][am[e]] = ra[e];
-            Bs[bk[e]][bm[e]] = rb[e];
+            As[ak[e]][am[e]] = (m0 + am[e] < g.M && k0 + ak[e] < kend) ? ra[e] : 0.f;
+            Bs[bk[e]][bm[e]] = (n0 + bm[e] < g.N && k0 + bk[e] < kend) ? rb[e] : 0.f;
         }
         __syncthreads();
         if (k0 + 16 < kend) fetch(k0 + 16);
@@ -988,21 +991,38 @@ static __global__ __launch_bounds__(256) void sgemm_longk_mfma_kernel(GemmArgs g
 #pragma unroll
     for (int j = 0; j < NT; ++j) { bn[j] = 16 * j + li < NB; b1[j] = ones && 16 * j + li == NB; }
     const int kbeg = wv * kper, kend = min(g.K, kbeg + kper);
-    const float* pa = g.A + li;
-    const float* pb = g.B + li;
-#pragma unroll 8
-    for (int k0 = kbeg; k0 < kend; k0 += 4) {
-        const int k = k0 + kq;
-        const bool kok = k < kend;
-        float a[MT], b[NT];
+    // Eight steps (32 rows) of operands are requested before the first product: every load UNCONDITIONAL, on a clamped row / column, and
+    // masked afterwards.  Written as `ok ? p[..] : 0` the compiler kept each load in its own branch with a full wait in front of the
+    // products -- one memory round trip per four rows, 15-30 us for the ~170 000 rows of FC_STGNN's window blocks (five such launches were
+    // the tail of its side stream).  Same products in the same order; the steps past kend multiply zeros.
+    const float* pa[MT];
+    const float* pb[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = (kok && am[i]) ? pa[(int64_t)k * g.sAk + 16 * i] : 0.f;
+    for (int i = 0; i < MT; ++i) pa[i] = g.A + (am[i] ? 16 * i + li : 0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[j] = (kok && bn[j]) ? pb[(int64_t)k * g.sBk + 16 * j] : ((kok && b1[j]) ? 1.f : 0.f);
+    for (int j = 0; j < NT; ++j) pb[j] = g.B + (bn[j] ? 16 * j + li : 0);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        float a[8][MT], b[8][NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq, kc = k < kend ? k : kend - 1;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) a[u][i] = pa[i][(int64_t)kc * g.sAk];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[u][j] = pb[j][(int64_t)kc * g.sBk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool kok = k0 + 4 * u + kq < kend;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) a[u][i] = (kok && am[i]) ? a[u][i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[u][j] = (kok && bn[j]) ? b[u][j] : ((kok && b1[j]) ? 1.f : 0.f);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+        }
     }
     float* out = g.C + (int64_t)wv * g.M * g.N;                 // g.C = the partial buffer: one row of M N values per wavefront
 #pragma unroll
