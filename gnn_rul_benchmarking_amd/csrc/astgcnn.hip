@@ -676,9 +676,10 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         fk.fork();
         // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
         const int bwd_rows = resident_rows((ast_graph_bwd_kernel<SN, SE, SO>), g.B, AST_BWD_ROWS);
-        hipLaunchKernelGGL((ast_graph_bwd_kernel<SN, SE, SO>), dim3(bwd_rows), dim3(AB), 0, st, g, prm,
-                           (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
-                           F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
+        hipEvent_t bwd_done = fk.stop_event();                       // (the second fork point: behind this kernel)
+        RULGNN_LAUNCH_EV(bwd_done, (ast_graph_bwd_kernel<SN, SE, SO>), dim3(bwd_rows), dim3(AB), 0, st, g, prm,
+                         (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
+                         F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
         // (the side stream's launches are enqueued BEHIND the main stream's kernel they run beside: the host enqueues in program order)
         // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
         AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
@@ -687,7 +688,7 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         // d filters = Scat^T D ; DT = D Fcat^T
         AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
         // d P = dPX^T G
-        fk.fork();
+        fk.fork_after(bwd_done);
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), g.B, w.rows, TTB);
         AST_RC(sync_pair(1, 1));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),

@@ -9,6 +9,7 @@
 // once the waits enqueued on it have been issued to their streams, which hipStreamWaitEvent does before it returns.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "../../include/rulgnn.h"
 
@@ -28,11 +29,39 @@ inline hipEvent_t aux_pooled_event() {
     return e;
 }
 
+// Events for fork_after(): signalled by a kernel's OWN completion (hipExtLaunchKernel's stopEvent).  hipEventRecord puts a barrier packet of
+// its own into the main stream's queue, and the next kernel of the chain waits for the command processor to retire it: ~6 us of bubble
+// per fork on chains whose kernels take 5-30 us (FC_STGNN: eight forks per step).  A separate ring: these carry timestamps.
+inline hipEvent_t aux_pooled_stop_event() {
+    constexpr int N = 32, MAX_DEV = 16;
+    static thread_local hipEvent_t ring[MAX_DEV][N] = {};
+    static thread_local int next[MAX_DEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    hipEvent_t& e = ring[dev][next[dev]];
+    next[dev] = (next[dev] + 1) % N;
+    if (!e && hipEventCreate(&e) != hipSuccess) e = nullptr;
+    return e;
+}
+
 struct AuxFork {
     hipStream_t st, wst;
     int rc = RULGNN_OK;
     bool forked = false;        // the side stream carries work the main stream has not waited for yet
-    AuxFork(hipStream_t stream, void* aux) : st(stream), wst(aux ? static_cast<hipStream_t>(aux) : stream) {}
+    bool capturing = false;     // a hipGraph capture is in progress on the main stream: plain event records only
+    AuxFork(hipStream_t stream, void* aux) : st(stream), wst(aux ? static_cast<hipStream_t>(aux) : stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (active() && (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)) capturing = true;
+    }
+    // The fork point is "behind THIS kernel": stop_event() before the launch, the launch through RULGNN_LAUNCH_EV with it, fork_after()
+    // behind it.  Without a side stream, or inside a capture, stop_event() is null and the three reduce to a plain launch + fork().
+    hipEvent_t stop_event() { return (active() && !capturing && rc == RULGNN_OK) ? aux_pooled_stop_event() : nullptr; }
+    void fork_after(hipEvent_t ev) {
+        if (!ev) { fork(); return; }
+        if (rc != RULGNN_OK) return;
+        if (hipStreamWaitEvent(wst, ev, 0) != hipSuccess) rc = RULGNN_EHIP;
+        forked = true;
+    }
     AuxFork(const AuxFork&) = delete;
     AuxFork& operator=(const AuxFork&) = delete;
     // An early return between fork() and join() (a failed launch, RULGNN_EHIP) must not leave the side stream un-joined: a hipGraph
@@ -58,5 +87,12 @@ struct AuxFork {
         return rc;
     }
 };
+
+// launch on `stream` with `ev` (may be null) signalled by the kernel's completion
+#define RULGNN_LAUNCH_EV(ev, kernel, grid, block, lds, stream, ...)                                                     \
+    do {                                                                                                                \
+        if (ev) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, ev, 0, __VA_ARGS__);                   \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                         \
+    } while (0)
 
 }  // namespace rulgnn
