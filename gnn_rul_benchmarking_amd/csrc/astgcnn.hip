@@ -614,7 +614,7 @@ template <int SN, int SE, int SO>
 static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync,
                          float* bn_running_out, float bn_momentum) {
     // threads of the TCN kernels: 20 nodes x 50 steps are 260 / 400 work items per sample -- one round of 448 threads (tcn_nodes.hpp)
-    constexpr int TTB = SN == 20 ? 448 : AB;
+    constexpr int TTB = AB;             // (the matrix-core convolution kernels: four wavefronts, a 16-step column tile each)
     AstGeom g;
     AST_RC(ast_geometry(s, &g));
     if (sync) {          // both BatchNorm layers normalise by the statistics of the GLOBAL batch (cells all-reduced between the kernels)

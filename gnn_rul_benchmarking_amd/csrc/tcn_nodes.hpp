@@ -65,95 +65,140 @@ __device__ inline BnCoef bn_coef(const Cells* cells, const float* bn_running, in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The convolutions on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation).
+// One sample is a small GEMM: z[co][t] = sum_k W[co][k] X[k][t], k = (ci, tap), X[(ci, tap)][t] = in[ci][t - (KT-1-tap) D] -- M = N nodes
+// (two 16-row tiles), N = T steps (a 16-column tile per wavefront, four wavefronts), K = 6 N (steps of four).  The weights are the A
+// operand and stay in registers for the whole launch (lane (i, kq) holds W[16 mt + i][4 s + kq]: contiguous in k in the parameter
+// layout); the B operand is one LDS word per step, read at (ci XP + tap D + t) of the zero-padded input tile.  As thread-per-output FMA
+// loops the two forward launches took 12 + 10 us and the two backward ones 23 + 19 us at 20 nodes x 50 steps x 512 samples -- bound by
+// LDS reads (six or seven 8/16-byte reads per 24 multiply-adds), the longest kernels of ASTGCNN's chain after the graph stage.
+// ---------------------------------------------------------------------------------------------------
+typedef float tcn_f4 __attribute__((ext_vector_type(4)));
+constexpr int MROWS = 32;                                  // tile rows padded to two 16-row matrix tiles
+constexpr int KSMAX = (MAXN * KT + 3) / 4;                 // k steps of the (channel, tap) reductions
+__device__ __forceinline__ float tcn_row16_sum(float v) {  // sum over the 16 lanes of a row (lanes l, l ^ 1, ^ 2, ^ 4, ^ 8)
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
 // One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
 // ---------------------------------------------------------------------------------------------------
-// (<SN, ST>: nodes and time steps as compile-time constants, 0 = generic: the element loops divide by T, the channel loops run to N;
-//  TBK: threads per workgroup -- at 20 nodes x 50 steps the work lists are 260 (node, four steps) items and 400 (co, ci) pairs: 256 threads
-//  walk them in two rounds, the second nearly empty; 448 threads take each in one)
+// (<SN, ST>: nodes and time steps as compile-time constants, 0 = generic; TBK: threads per workgroup, 256 = one 16-step column tile per
+//  wavefront)
 template <int STAGE, typename Geom, int SN = 0, int ST = 0, int TBK = AB>
 static __global__ __launch_bounds__(TBK) void tcn_conv_kernel(Geom g, const float* __restrict__ x, const float* __restrict__ prm,
                                                      const float* __restrict__ bn_running, int training, const float* __restrict__ z1,
                                                      float* __restrict__ zout, float* __restrict__ out0, Cells* cells) {
+    static_assert(TBK == 256, "four wavefronts: one 16-step column tile each");
     constexpr int D = STAGE == 1 ? 1 : 2;
     constexpr int PADL = (KT - 1) * D;
-    static_assert(KT == 6, "the taps of a (co, ci) pair are read as three 8-byte pieces");
-    __shared__ __attribute__((aligned(16))) float w[MAXN * MAXN * KT];
+    constexpr int KSC = SN ? (SN * KT + 3) / 4 : KSMAX;
     __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];           // left-padded with PADL zeros
-    __shared__ float zs[MAXN][MAXT + 1];
+    __shared__ float wl[MAXN * (MAXN * KT + 1)];                          // the weights, rows of NK + 1 words (odd pitch: conflict-free reads)
     __shared__ BnCoef co1[MAXN];
-    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x;
+    __shared__ float red[4][2][MROWS];
+    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x, NK = N * KT, NKP = NK + 1;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
-    for (int e = tid; e < N * N * KT; e += TBK) w[e] = wsrc[e];
+    // (through LDS with coalesced loads: fetched by the lanes straight into their operand registers every load instruction touched 16
+    // rows of the matrix -- 60 such instructions per lane took 7 of the kernel's 17 us)
+    for (int e = tid; e < N * NK; e += TBK) wl[(e / NK) * NKP + e % NK] = wsrc[e];
+    __syncthreads();
+    float wa[2][KSC];
+    int boff[KSC];
+#pragma unroll
+    for (int s = 0; s < KSC; ++s) {
+        const int k = 4 * s + kq, kc = k < NK ? k : NK - 1;
+        boff[s] = (kc / KT) * XP + (kc % KT) * D;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int co = 16 * mt + li;
+            const float v = wl[(co < N ? co : N - 1) * NKP + kc];
+            wa[mt][s] = (co < N && k < NK) ? v : 0.f;
+        }
+    }
     for (int e = tid; e < MAXN * XP; e += TBK) (&xs[0][0])[e] = 0.f;
     if (STAGE == 2 && tid < N)
         co1[tid] = bn_coef(cells, bn_running, training, 0, tid, N, (double)g.BG * T, prm[g.o_g1 + tid], prm[g.o_b1 + tid]);
-    float s1 = 0.f, s2 = 0.f;
+    float s1[2][4], s2[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[mt][r] = s2[mt][r] = 0.f;
+    const int t = 16 * wave + li;
+    const float* xsf = &xs[0][0];
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* xb = x + b * N * T;
         for (int e = tid; e < N * T; e += TBK) {
-            const int c = e / T, t = e - c * T;
+            const int c = e / T, tt = e - c * T;
             float v = xb[e];
             if (STAGE == 2) {
                 const float y = fmaf(z1[b * N * T + e], co1[c].sc, co1[c].sh);
                 v = fmaxf(fmaxf(y, 0.f) + v, 0.f);
                 out0[b * N * T + e] = v;
             }
-            xs[c][PADL + t] = v;
+            xs[c][PADL + tt] = v;
         }
         __syncthreads();
-        // four consecutive steps t per thread: the six taps of a (co, ci) pair and the 4 + 5 D inputs they meet come as 16- / 8-byte LDS
-        // reads once per 24 multiply-adds (it was two 4-byte reads per multiply-add); same order of additions per output as before
-        const int Q = (T + 3) / 4;
-        for (int wi = tid; wi < N * Q; wi += TBK) {
-            const int co = wi / Q, t0 = 4 * (wi - co * Q);
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll TCN_UNROLL
-            for (int ci = 0; ci < N; ++ci) {
-                const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
-                const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
-                const float wk[KT] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
-                constexpr int NX = (4 + PADL + 3) / 4;                  // xs[ci][t0 + k D + i]: PADL - (KT - 1) D = 0
-                float xv[4 * NX];
-                const float4* xr = reinterpret_cast<const float4*>(&xs[ci][t0]);
+        if (16 * wave < T) {                                             // (wave-uniform)
+            tcn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int q = 0; q < NX; ++q) {
-                    const float4 v = xr[q];
-                    xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
-                }
-#pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) a[i] = fmaf(wk[k], xv[k * D + i], a[i]);
+            for (int s = 0; s < KSC; ++s) {
+                const float bv = xsf[boff[s] + t];                        // in[ci][t - (KT-1-tap) D]: column PADL + that = t + tap D
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][s], bv, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][s], bv, acc[1], 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (t0 + i < T) {
-                    zout[b * N * T + co * T + t0 + i] = a[i];
-                    zs[co][t0 + i] = a[i];
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = 16 * mt + 4 * kq + r;
+                    if (co < N && t < T) {
+                        const float v = acc[mt][r];
+                        zout[b * N * T + co * T + t] = v;
+                        s1[mt][r] += v;
+                        s2[mt][r] = fmaf(v, v, s2[mt][r]);
+                    }
                 }
-        }
-        __syncthreads();
-        if (training && tid < N) {
-            for (int t = 0; t < T; ++t) {
-                const float v = zs[tid][t];
-                s1 += v;
-                s2 = fmaf(v, v, s2);
-            }
         }
         __syncthreads();
     }
-    if (training && tid < N) {
-        atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][0], (double)s1);
-        atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][1], (double)s2);
+    if (training) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = tcn_row16_sum(s1[mt][r]), q = tcn_row16_sum(s2[mt][r]);
+                if (li == 0) {
+                    red[wave][0][16 * mt + 4 * kq + r] = a;
+                    red[wave][1][16 * mt + 4 * kq + r] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < N) {
+            const float a = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
+            const float q = (red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid]);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][0], (double)a);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].fwd[STAGE - 1][tid][1], (double)q);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // conv backward.  STAGE 2: dz2 = BN2'(dy2); dW2 += dz2 (*) out0; dout0 = ds1 + conv2^T(dz2); ds0 = dout0 [out0 > 0];
 // dy1 = ds0 [bn1(z1) > 0]; BN1 backward sums.   STAGE 1: dz1 = BN1'(dy1); dW1 += dz1 (*) x.
-// Weight-gradient accumulators are thread-owned registers (fixed order), one partial row per workgroup.
+// Two more small GEMMs per sample on the matrix cores:
+//   d W[co][(ci, tap)] += sum_t dz[co][t] in[ci][t - (KT-1-tap) D]   M = co, N = (ci, tap) (two or three 16-column tiles per wavefront),
+//                                                                    K = t; the accumulators live in registers across the samples
+//   d in[ci][t]         = sum_(co, tap) W[co][ci][tap] dz[co][t + (KT-1-tap) D]   M = ci, N = t (a tile per wavefront), K = (co, tap);
+//                                                                    the A operand (W seen by input channel) in registers
+// One partial weight-gradient row per workgroup, as before.
 // ---------------------------------------------------------------------------------------------------
 template <int STAGE, typename Geom, int SN = 0, int ST = 0, int TBK = AB>
 static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
@@ -161,27 +206,50 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
                                                          const float* __restrict__ src, const float* __restrict__ ds1,
                                                          const float* __restrict__ z1, float* __restrict__ dy1,
                                                          float* __restrict__ gpart) {
+    static_assert(TBK == 256, "four wavefronts");
     constexpr int D = STAGE == 1 ? 1 : 2;
     constexpr int PAD = (KT - 1) * D;
-    constexpr int NPAIR = ((SN ? SN * SN : MAXN * MAXN) + TBK - 1) / TBK;      // (co, ci) pairs per thread: all six taps of a pair in one thread
-    static_assert(KT == 6, "the taps of a (co, ci) pair are read as three 8-byte pieces");
-    __shared__ __attribute__((aligned(16))) float w[MAXN * MAXN * KT];
-    __shared__ __attribute__((aligned(16))) float xs[MAXN][XP];        // conv input (x or out0), left-padded with zeros (zero behind the row too)
-    __shared__ __attribute__((aligned(16))) float dz[MAXN][XP];        // d z, zero from column T on
-    __shared__ float sy[MAXN][MAXT + 1];
-    __shared__ float sx[MAXN][MAXT + 1];
+    constexpr int KSC = SN ? (SN * KT + 3) / 4 : KSMAX;                   // k steps over (co, tap)
+    constexpr int TSC = ST ? (ST + 3) / 4 : MAXT / 4;                     // k steps over t
+    constexpr int NTW = ((SN ? SN : MAXN) * KT + 63) / 64;                // 16-column tiles of (ci, tap) per wavefront
+    __shared__ __attribute__((aligned(16))) float xs[MROWS][XP];       // conv input (x or out0), left-padded with zeros (zero behind the row too)
+    __shared__ __attribute__((aligned(16))) float dz[MROWS][XP];       // d z, zero from column T on and in the rows behind N
     __shared__ BnCoef cz[MAXN], c1[MAXN];
     __shared__ float bsum[MAXN][2];
-    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x, blk = STAGE - 1;
+    __shared__ float red[4][2][MROWS];
+    __shared__ float wl[STAGE == 2 ? MAXN * (MAXN * KT + 1) : 1];        // (see tcn_conv_kernel)
+    const int N = SN ? SN : g.N, T = ST ? ST : g.T, tid = threadIdx.x, blk = STAGE - 1, NK = N * KT, NKP = NK + 1;
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const double count = (double)g.BG * T;
-    const int nW = N * N * KT;
-    if (STAGE == 2)
-        for (int e = tid; e < nW; e += TBK) w[e] = prm[g.o_w2 + e];
-    for (int e = tid; e < MAXN * XP; e += TBK) {
+    for (int e = tid; e < MROWS * XP; e += TBK) {
         (&xs[0][0])[e] = 0.f;
         (&dz[0][0])[e] = 0.f;
     }
-    __syncthreads();
+    // STAGE 2: W by input channel, the A operand of the data gradient: lane (i, kq) holds W[co][16 mt + i][tap], (co, tap) = 4 s + kq
+    float wt[STAGE == 2 ? 2 : 1][STAGE == 2 ? KSC : 1];
+    int doff[STAGE == 2 ? KSC : 1];
+    if constexpr (STAGE == 2) {
+        for (int e = tid; e < N * NK; e += TBK) wl[(e / NK) * NKP + e % NK] = prm[g.o_w2 + e];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KSC; ++s) {
+            const int k = 4 * s + kq, kc = k < NK ? k : NK - 1, co = kc / KT, tap = kc % KT;
+            doff[s] = co * XP + (KT - 1 - tap) * D;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int ci = 16 * mt + li;
+                const float v = wl[co * NKP + (ci < N ? ci : N - 1) * KT + tap];
+                wt[mt][s] = (ci < N && k < NK) ? v : 0.f;
+            }
+        }
+    }
+    // this lane's (ci, tap) columns of the weight gradient: input rows at ci XP + tap D
+    int xoff[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+        const int n = 16 * (NTW * wave + j) + li, nc = n < NK ? n : NK - 1;
+        xoff[j] = (nc / KT) * XP + (nc % KT) * D;
+    }
     if (tid < N) {
         cz[tid] = bn_coef(cells, nullptr, 1, blk, tid, N, count, prm[(STAGE == 1 ? g.o_g1 : g.o_g2) + tid],
                           prm[(STAGE == 1 ? g.o_b1 : g.o_b2) + tid]);
@@ -189,115 +257,101 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
         bsum[tid][0] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 0) / count);
         bsum[tid][1] = (float)(cell_sum(cells, &Cells::bwd, blk, tid, 1) / count);
     }
-    float acc[NPAIR][KT];
+    tcn_f4 accw[2][NTW];
 #pragma unroll
-    for (int r = 0; r < NPAIR; ++r)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int k = 0; k < KT; ++k) acc[r][k] = 0.f;
-    const int Q = (T + 3) / 4;
-    constexpr int NX = (4 + PAD + 3) / 4;
-    float a1 = 0.f, a2 = 0.f;
+        for (int j = 0; j < NTW; ++j) accw[mt][j] = (tcn_f4){0.f, 0.f, 0.f, 0.f};
+    float a1[2][4], a2[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[mt][r] = a2[mt][r] = 0.f;
+    const float* xsf = &xs[0][0];
+    const float* dzf = &dz[0][0];
+    const int t = 16 * wave + li;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         for (int e = tid; e < N * T; e += TBK) {
-            const int c = e / T, t = e - c * T;
+            const int c = e / T, tt = e - c * T;
             const int64_t idx = b * N * T + e;
             const float xh = (zin[idx] - cz[c].mean) * cz[c].inv;
-            dz[c][t] = cz[c].sc * (dyin[idx] - bsum[c][0] - xh * bsum[c][1]);
-            xs[c][PAD + t] = src[idx];
+            dz[c][tt] = cz[c].sc * (dyin[idx] - bsum[c][0] - xh * bsum[c][1]);
+            xs[c][PAD + tt] = src[idx];
         }
         __syncthreads();
-        // d W[co][ci][k] += sum_t dz[co][t] * in[ci][t - (KT-1-k) D]
-        // (a thread owns all six taps of its pairs: four steps of d z and the 4 + 5 D inputs they meet per 16-byte reads, 24 multiply-adds
-        // per five or six LDS reads instead of 48; same order of additions per weight: t ascending, d z = 0 behind T)
+        // d W[co][(ci, tap)] += sum_t dz[co][t] * in[ci][t - (KT-1-tap) D]      (column PAD + that = t + tap D; d z = 0 behind T)
 #pragma unroll
-        for (int r = 0; r < NPAIR; ++r) {
-            const int p = tid + r * TBK;
-            if (p < N * N) {
-                const int ci = p % N, co = p / N;
-                float a6[KT] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                const float4* dr = reinterpret_cast<const float4*>(&dz[co][0]);
-#pragma unroll TCN_UNROLL
-                for (int q4 = 0; q4 < Q; ++q4) {
-                    const float4 dv = dr[q4];
-                    const float dzv[4] = {dv.x, dv.y, dv.z, dv.w};
-                    float xv[4 * NX];
-                    const float4* xr = reinterpret_cast<const float4*>(&xs[ci][4 * q4]);       // xs[ci][t + k D]: PAD - (KT - 1 - k) D = k D
+        for (int s = 0; s < TSC; ++s) {
+            const int tk = 4 * s + kq;
+            const float av0 = dzf[li * XP + tk], av1 = dzf[(16 + li) * XP + tk];
 #pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        const float4 v = xr[q];
-                        xv[4 * q] = v.x; xv[4 * q + 1] = v.y; xv[4 * q + 2] = v.z; xv[4 * q + 3] = v.w;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int k = 0; k < KT; ++k) a6[k] = fmaf(dzv[i], xv[k * D + i], a6[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < KT; ++k) acc[r][k] += a6[k];
+            for (int j = 0; j < NTW; ++j) {
+                const float bv = xsf[xoff[j] + tk];
+                accw[0][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0, bv, accw[0][j], 0, 0, 0);
+                accw[1][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, bv, accw[1][j], 0, 0, 0);
             }
         }
-        if (STAGE == 2) {
+        if constexpr (STAGE == 2) {
             // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
-            for (int wi = tid; wi < N * Q; wi += TBK) {
-                const int ci = wi / Q, t0 = 4 * (wi - ci * Q);
-                float a4[4];
+            if (16 * wave < T) {
+                tcn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a4[i] = t0 + i < T ? ds1[b * N * T + ci * T + t0 + i] : 0.f;
-#pragma unroll TCN_UNROLL
-                for (int co = 0; co < N; ++co) {
-                    const float2* wr = reinterpret_cast<const float2*>(w + (co * N + ci) * KT);
-                    const float2 w01 = wr[0], w23 = wr[1], w45 = wr[2];
-                    const float wk[KT] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
-                    float dv[4 * NX];
-                    const float4* dr = reinterpret_cast<const float4*>(&dz[co][t0]);
+                for (int s = 0; s < KSC; ++s) {
+                    const float bv = dzf[doff[s] + t];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[0][s], bv, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[1][s], bv, acc[1], 0, 0, 0);
+                }
 #pragma unroll
-                    for (int q = 0; q < NX; ++q) {
-                        const float4 v = dr[q];
-                        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = 16 * mt + 4 * kq + r;
+                        if (ci < N && t < T) {
+                            const int64_t idx = b * N * T + ci * T + t;
+                            const float a = acc[mt][r] + ds1[idx];
+                            const float o0 = xs[ci][PAD + t];
+                            const float s0 = o0 > 0.f ? a : 0.f;
+                            const float zz = z1[idx];
+                            const float y = fmaf(zz, c1[ci].sc, c1[ci].sh);
+                            const float dy = y > 0.f ? s0 : 0.f;
+                            dy1[idx] = dy;
+                            a1[mt][r] += dy;
+                            a2[mt][r] = fmaf(dy, (zz - c1[ci].mean) * c1[ci].inv, a2[mt][r]);
+                        }
                     }
-#pragma unroll
-                    for (int k = 0; k < KT; ++k)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) a4[i] = fmaf(wk[k], dv[(KT - 1 - k) * D + i], a4[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                if (t0 + i >= T) continue;
-                const int t = t0 + i;
-                const int64_t idx = b * N * T + ci * T + t;
-                const float a = a4[i];
-                const float o0 = xs[ci][PAD + t];
-                const float s0 = o0 > 0.f ? a : 0.f;
-                const float zz = z1[idx];
-                const float y = fmaf(zz, c1[ci].sc, c1[ci].sh);
-                const float dy = y > 0.f ? s0 : 0.f;
-                dy1[idx] = dy;
-                sy[ci][t] = dy;
-                sx[ci][t] = dy * (zz - c1[ci].mean) * c1[ci].inv;
-                }
             }
-            __syncthreads();
-            if (tid < N)
-                for (int t = 0; t < T; ++t) {
-                    a1 += sy[tid][t];
-                    a2 += sx[tid][t];
-                }
         }
         __syncthreads();
     }
-    float* dst = gpart + (int64_t)blockIdx.x * nW;
+    float* dst = gpart + (int64_t)blockIdx.x * N * NK;
 #pragma unroll
-    for (int r = 0; r < NPAIR; ++r) {
-        const int p = tid + r * TBK;
-        if (p < N * N) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int k = 0; k < KT; ++k) dst[p * KT + k] = acc[r][k];
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * mt + 4 * kq + r, n = 16 * (NTW * wave + j) + li;
+                if (co < N && n < NK) dst[co * NK + n] = accw[mt][j][r];
+            }
+    if constexpr (STAGE == 2) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = tcn_row16_sum(a1[mt][r]), q = tcn_row16_sum(a2[mt][r]);
+                if (li == 0) {
+                    red[wave][0][16 * mt + 4 * kq + r] = a;
+                    red[wave][1][16 * mt + 4 * kq + r] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < N) {
+            const float a = (red[0][0][tid] + red[1][0][tid]) + (red[2][0][tid] + red[3][0][tid]);
+            const float q = (red[0][1][tid] + red[1][1][tid]) + (red[2][1][tid] + red[3][1][tid]);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][0], (double)a);
+            atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][1], (double)q);
         }
-    }
-    if (STAGE == 2 && tid < N) {
-        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][0], (double)a1);
-        atomicAdd(&cells[blockIdx.x % CELL_REP].bwd[0][tid][1], (double)a2);
     }
 }
 
