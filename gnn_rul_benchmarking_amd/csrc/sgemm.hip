@@ -15,6 +15,12 @@ struct GemmArgs {
     int M, N, K;
     int accumulate;      // C += instead of C =
     int kchunk;          // split-K: blockIdx.z owns k in [z*kchunk, (z+1)*kchunk) and writes slice z of C (stride M*ldc)
+    // optional (both or neither): partial maxima of |A| and |B| over their finite elements (one float per workgroup of the kernels that
+    // wrote the operands; their maximum is the tensor's).  With them the 256 x 256 kernel runs the two-plane f16 split
+    // (sgemm_f16x2v_kernel) instead of the three-plane bf16 one.
+    const float* amax_a;
+    const float* amax_b;
+    int amax_na, amax_nb;
 };
 
 static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
@@ -593,6 +599,214 @@ static __global__ __launch_bounds__(512) void sgemm_bf16x3v_kernel(GemmArgs g) {
     else sgemm_bf16x3v_body<A_KFAST, B_KFAST, true>(g);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 256 x 256 kernel on TWO f16 planes per operand: a = hi + lo with hi = the top 11 significant bits of a s (exact in f16) and
+// lo = f16(a s - hi); a b = (hi hi + hi lo + lo hi) / (sa sb) + terms below 2^-22 |a b| -- three v_mfma_f32_32x32x16_f16 per fp32
+// product instead of the six of the bf16 split, the arithmetic of the fused ST_GCN kernels (stgcn_mx.hpp).  f16 has five exponent bits:
+// the caller passes max |A| and max |B| (GemmArgs::amax_*, produced by the kernels that wrote the operands) and each operand is scaled
+// by a power of two so that its largest element lands in [2^11, 2^12); elements more than 2^25 below the largest lose precision
+// (their hi part goes subnormal) -- invisible in a product that also contains the large ones, and the reason this form is opt-in:
+// the generic entry points keep the range-free bf16 split.  Same tiles, LDS layout (two planes: 96 KB double-buffered) and pipeline.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 gemm_f16x8 __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ float sgemm_f16_scale_of(float amax) {
+    const unsigned m = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((m >> 23) & 0xFFu);                          // biased exponent of the largest finite magnitude
+    if (!(amax > 0.f) || e == 0 || e == 255) return 1.0f;
+    int se = 127 + 11 - (e - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __builtin_bit_cast(float, (unsigned)se << 23);
+}
+// the two operand scales from the producers' partial maxima (512 threads; a few thousand floats out of L2: ~1 us per workgroup)
+static __device__ __forceinline__ void sgemm_f16_scales(const GemmArgs& g, float& sa, float& sb) {
+    __shared__ float part[2][8];
+    float ma = 0.f, mb = 0.f;
+    for (int i = threadIdx.x; i < g.amax_na; i += 512) ma = fmaxf(ma, g.amax_a[i]);
+    for (int i = threadIdx.x; i < g.amax_nb; i += 512) mb = fmaxf(mb, g.amax_b[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+        mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ma; part[1][threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    ma = mb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { ma = fmaxf(ma, part[0][w]); mb = fmaxf(mb, part[1][w]); }
+    sa = sgemm_f16_scale_of(ma);
+    sb = sgemm_f16_scale_of(mb);
+}
+// one fp32 pair (already scaled) -> one dword (first value in the low half) of each of the two planes
+static __device__ __forceinline__ void split_pair_f16x2(float a, float b, unsigned& h, unsigned& l) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float ha = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+    const float hb = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFFE000u);
+    const f2 hv = {ha, hb}, lv = {a - ha, b - hb};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(hv, h2));
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(lv, h2));
+}
+template <bool A_KFAST, bool B_KFAST, bool GUARD>
+static __device__ __forceinline__ void sgemm_f16x2v_body(GemmArgs g) {
+    constexpr int T = 256;                         // tile rows / columns
+    constexpr int ROWB = 48;
+    constexpr int PLANE = T * ROWB;                // 12 KB
+    constexpr int BUF = 4 * PLANE;                 // 48 KB: A hi, lo ; B hi, lo
+    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 128;          // 8 wavefronts, each 64 rows x 128 columns
+    f32x16t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    // this thread's operand
+    const bool mine_b = tid >= 256;
+    const int t = tid & 255;
+    const float* __restrict__ P = mine_b ? g.B : g.A;
+    const int64_t s_row = mine_b ? g.sBn : g.sAm, s_k = mine_b ? g.sBk : g.sAk;
+    const int rows = mine_b ? g.N : g.M, r0 = mine_b ? n0 : m0;
+    const bool kfast = mine_b ? B_KFAST : A_KFAST;                  // wave-uniform
+    // per-operand power-of-two scale: max |x| s in [2^11, 2^12) -- sixteen times below the f16 range, and an element down to 2^-25 of
+    // the tensor's largest still has a normal hi part
+    float sa, sb;
+    sgemm_f16_scales(g, sa, sb);
+    const float sc = mine_b ? sb : sa;
+    const float unscale = 1.0f / (sa * sb);                         // (exact: powers of two)
+    f32x4t rr[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4t v = {0.f, 0.f, 0.f, 0.f};
+            if (kfast) {
+                const int idx = t + e * 256;
+                const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+                const float* p = P + (int64_t)r * s_row + k;
+                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else if (r < rows) {
+                    if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
+                    else {
+                        if (k < kend) v[0] = p[0];
+                        if (k + 1 < kend) v[1] = p[1];
+                        if (k + 2 < kend) v[2] = p[2];
+                    }
+                }
+            } else {
+                const int k = k0 + 4 * (t >> 6) + e, r = r0 + 4 * (t & 63);
+                const float* p = P + (int64_t)k * s_k + r;
+                if (!GUARD && k0 + 16 <= kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else if (k < kend) {
+                    if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
+                    else {
+                        if (r < rows) v[0] = p[0];
+                        if (r + 1 < rows) v[1] = p[1];
+                        if (r + 2 < rows) v[2] = p[2];
+                    }
+                }
+            }
+            rr[e] = v;
+        }
+    };
+    auto stash = [&](unsigned char* bufp, const f32x4t (&v)[4]) {
+        unsigned char* base = bufp + (mine_b ? 2 * PLANE : 0);
+        if (kfast) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = t + e * 256;
+                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
+                unsigned h0, l0, h1, l1;
+                split_pair_f16x2(x0 * sc, x1 * sc, h0, l0);
+                split_pair_f16x2(x2 * sc, x3 * sc, h1, l1);
+                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(l0, l1);
+            }
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {                       // two k pairs per thread: (4 kq, 4 kq + 1) and (4 kq + 2, 4 kq + 3)
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = v[2 * pp][j], x1 = v[2 * pp + 1][j];
+                    split_pair_f16x2(x0 * sc, x1 * sc, h[j], l[j]);
+                }
+                unsigned char* p = base + ((2 * (t >> 6) + pp) * T + 4 * (t & 63)) * 4;
+                *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+            }
+        }
+    };
+    auto operand = [&](const unsigned char* plane, int row0, bool kf) -> gemm_f16x8 {
+        if (kf) return *reinterpret_cast<const gemm_f16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * T + row0 + (lane & 31);
+        const gemm_u32x4 v = {q[0], q[T], q[2 * T], q[3 * T]};
+        return __builtin_bit_cast(gemm_f16x8, v);
+    };
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(sgemm_x3_lds, rr);
+        fetch(kbeg + 16);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        f32x4t nn[4] = {rr[0], rr[1], rr[2], rr[3]};                                         // tile k + 1, loaded one iteration ago
+        if (k0 + 32 < kend) fetch(k0 + 32);
+        const unsigned char* b = sgemm_x3_lds + buf * BUF;
+        gemm_f16x8 a[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};             // lo hi, hi lo, hi hi: smallest first
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gemm_f16x8 bb[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bb[p] = operand(b + (2 + p) * PLANE, wn + 32 * j, B_KFAST);
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[tt]], bb[PB[tt]], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(sgemm_x3_lds + (buf ^ 1) * BUF, nn);
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
+                if (!GUARD || (gm < g.M && gn < g.N)) {
+                    float* c = g.C + (int64_t)gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[i][j][r] * unscale : acc[i][j][r] * unscale;
+                }
+            }
+}
+
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(512) void sgemm_f16x2v_kernel(GemmArgs g) {
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const bool interior = (int)blockIdx.y * 256 + 256 <= g.M && (int)blockIdx.x * 256 + 256 <= g.N && kend > kbeg;
+    if (interior) sgemm_f16x2v_body<A_KFAST, B_KFAST, false>(g);
+    else sgemm_f16x2v_body<A_KFAST, B_KFAST, true>(g);
+}
+
 // 256x256 tiles when both output dimensions fill them and there are enough of them for one per CU
 static inline bool sgemm_wide_ok(const GemmArgs& g, int slices) {
     if (g.M <= 192 || g.N <= 192) return false;
@@ -642,6 +856,22 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
                     }
                     hipLaunchKernelGGL(kernel, wgrid, dim3(512), lw, st, g);
                 };
+                if (g.amax_a && g.amax_b) {
+                    constexpr size_t lh = (size_t)2 * 4 * 256 * 48;
+                    auto goh = [&](auto kernel) {
+                        static bool raised = false;
+                        if (!raised) {
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lh);
+                            raised = true;
+                        }
+                        hipLaunchKernelGGL(kernel, wgrid, dim3(512), lh, st, g);
+                    };
+                    if (ak && bk) goh(sgemm_f16x2v_kernel<true, true>);
+                    else if (ak) goh(sgemm_f16x2v_kernel<true, false>);
+                    else if (bk) goh(sgemm_f16x2v_kernel<false, true>);
+                    else goh(sgemm_f16x2v_kernel<false, false>);
+                    return;
+                }
                 if (ak && bk) gow(sgemm_bf16x3v_kernel<true, true>);
                 else if (ak) gow(sgemm_bf16x3v_kernel<true, false>);
                 else if (bk) gow(sgemm_bf16x3v_kernel<false, true>);
@@ -812,7 +1042,7 @@ static inline bool sgemm_is_skinny(int64_t sAk, int M, int N, int K) { return sA
 
 // `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies (sgemm_rows_bf16_ok), fp32 paths otherwise
 int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16) {
+                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16, const float* amax_a, int amax_na, const float* amax_b, int amax_nb) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
     if (bf16 && sgemm_rows_bf16_ok(sAk, M, N, K)) {
         const GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K};
@@ -829,7 +1059,7 @@ int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn,
         else hipLaunchKernelGGL(sgemm_skinny_kernel<32>, grid, dim3(256), lds, st, g);
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? (K + 15) & ~15 : 16};
+    GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K > 0 ? (K + 15) & ~15 : 16, amax_a, amax_b, amax_na, amax_nb};
     (void)hipGetLastError();
     sgemm_launch_tiles(g, 1, st);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
@@ -1146,7 +1376,8 @@ static __global__ __launch_bounds__(256) void sgemm_vecmat_kernel(const float* _
 static inline bool sgemm_vecmat_ok(int M, int N, int K, int64_t sBn) { return M == 1 && sBn == 1 && N >= 64 && K >= 256; }
 
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                        int M, int N, int K, bool accumulate, float* partial, hipStream_t st) {
+                        int M, int N, int K, bool accumulate, float* partial, hipStream_t st, const float* amax_a, int amax_na, const float* amax_b,
+                        int amax_nb) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
     // (also in front of the one-workgroup kernel: ASTGCNN's d fc.weight, [1 x 512] . [512 x 64], took 23.6 us there)
     if (!accumulate && (sgemm_tiny_ok(M, N, K) || sgemm_longk_blocks(M, N, K) == 0) && sgemm_vecmat_ok(M, N, K, sBn)) {
@@ -1186,11 +1417,11 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
     const int slices = sgemm_splitk_slices(M, N, K);
-    if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st);
+    if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st, 0, amax_a, amax_na, amax_b, amax_nb);
     int kchunk = (K + slices - 1) / slices;
     kchunk = (kchunk + 15) & ~15;
     const int used = (K + kchunk - 1) / kchunk;
-    GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk};
+    GemmArgs g{A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, 0, kchunk, amax_a, amax_b, amax_na, amax_nb};
     (void)hipGetLastError();
     sgemm_launch_tiles(g, used, st);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;

@@ -16,12 +16,17 @@ int& sgemm_big_mode();
 // C[m][n] (+)= sum_k A(m,k) * B(n,k) with element strides (sAm, sAk), (sBn, sBk); picks the tile / tall-and-skinny / big-tile kernel.
 // `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies, fp32 paths otherwise.
 int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-          int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0);
+          int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0, const float* amax_a = nullptr, int amax_na = 0,
+          const float* amax_b = nullptr, int amax_nb = 0);
+// (amax_a / amax_b, both or neither: amax_na / amax_nb floats each whose maximum is max |A| / max |B| over the FINITE elements -- one partial
+// maximum per workgroup of the kernels that produced the operands.  With them, outputs that fill the 256 x 256 tiles run the two-plane f16
+// split (three matrix instructions per product instead of six; csrc/sgemm.hip: sgemm_f16x2v_kernel).)
 
 // The same product as a deterministic split-K reduction (weight gradients: K = all rows of the batch); `partial` is caller-provided
 // scratch of sgemm_splitk_need_floats(M, N, K) floats.
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, float* partial, hipStream_t st);
+                 int M, int N, int K, bool accumulate, float* partial, hipStream_t st, const float* amax_a = nullptr, int amax_na = 0,
+                 const float* amax_b = nullptr, int amax_nb = 0);
 
 // ... and colsum[m] = sum_k A(m, k) from the same pass (weight gradient + the bias gradient over the same rows); `ones`: K ones for
 // the shapes that take two calls; `partial`: sgemm_splitk_need_floats(M, N + 1, K) floats

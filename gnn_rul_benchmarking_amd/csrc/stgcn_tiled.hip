@@ -115,11 +115,40 @@ __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X
     }
 }
 
+// The operands of the large GEMMs carry their largest finite magnitude with them (the two-plane f16 split of csrc/sgemm.hip scales each
+// operand by a power of two): the kernel that writes an operand stores its workgroup's max |v| as one float of the tensor's partial-maximum
+// row, and the GEMM's workgroups take the maximum of that row on their way in.  No atomics: an atomicMax per workgroup (256 on each of 16
+// replica addresses at XJTU batch 1024) cost the aggregation kernel 40 us, a pre-checked one with an agent-scope load 45.
+// 256 threads, whole wavefronts, every thread calls.
+constexpr int T_AMAX_MAX = 4096;            // partial maxima per tensor: the workgroups of the producing launch (capped by its grid)
+__device__ __forceinline__ float t_finite_abs(float v) {
+    const float m = __builtin_fabsf(v);
+    return m <= 3.0e38f ? m : 0.f;          // (NaN and Inf do not set the scale: they propagate through the product on their own)
+}
+__device__ __forceinline__ void t_amax_store(float m, float* part, float* lds4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
+}
+// ... and for a parameter matrix (theta of every layer: blockIdx.y = layer, gridDim.x partial maxima per layer)
+__global__ __launch_bounds__(256) void t_absmax_kernel(const float* __restrict__ prm, int64_t layer_stride_, int64_t off, int64_t n, float* part) {
+    __shared__ float l4[4];
+    const float* p = prm + blockIdx.y * layer_stride_ + off;
+    float m = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) m = fmaxf(m, t_finite_abs(p[e]));
+    t_amax_store(m, part + (size_t)blockIdx.y * T_AMAX_MAX, l4);
+}
+
 // out[b][c][t] = sum_c' A[b][c][c'] in[b][c'][t] (+ add[b][c][t])          (torch.bmm(A, X), Model.py:87)
-__global__ void t_aggregate_kernel(const float* __restrict__ A, const float* __restrict__ in, const float* add, float* out,
-                                   TArgs a) {      // add may alias out (in-place residual accumulation)
+// (amax: slot block of `out` when it feeds a large GEMM, else null)
+__global__ __launch_bounds__(256) void t_aggregate_kernel(const float* __restrict__ A, const float* __restrict__ in, const float* add, float* out,
+                                                          TArgs a, float* amax) {      // add may alias out (in-place residual accumulation)
+    __shared__ float l4[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * a.N) return;
+    float m = 0.f;
+    if (i < a.B * a.N) {
     const int64_t b = i / a.N;
     const int t = (int)(i % a.N);
     const float* Ab = A + b * F * F;
@@ -142,6 +171,12 @@ __global__ void t_aggregate_kernel(const float* __restrict__ A, const float* __r
     }
 #pragma unroll
     for (int c = 0; c < F; ++c) out[(b * F + c) * a.N + t] = r[c];
+    if (amax) {                                                     // (uniform over the launch)
+#pragma unroll
+        for (int c = 0; c < F; ++c) m = fmaxf(m, t_finite_abs(r[c]));
+    }
+    }
+    if (amax) t_amax_store(m, amax, l4);                            // (whole wavefronts: the lanes behind the last position carry 0)
 }
 
 // eval-mode TCN block of one layer after the theta GEMM (BatchNorm folded), Model.py:134-170,187-195:
@@ -312,7 +347,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* Xout = Xb;
     for (int l = 0; l < L; ++l) {
         const float* pl = prm + l * LS;
-        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a);
+        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, (float*)nullptr);
         int rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);   // (A.X) theta^T
         if (rc != RULGNN_OK) return rc;
         T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a);
@@ -496,12 +531,15 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
 // aggregation A.Xout (AXnext) or, behind the last layer, the channel max-pool (pooled) -- both were launches that re-read Xout
 __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ Xin,
                                                            const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a,
-                                                           const float* __restrict__ A, float* __restrict__ AXnext, float* __restrict__ pooled) {
+                                                           const float* __restrict__ A, float* __restrict__ AXnext, float* __restrict__ pooled,
+                                                           float* amax_next) {
     __shared__ float bnc[7 * F];
+    __shared__ float l4[4];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * a.N) return;
+    float mx = 0.f;
+    if (i < a.B * a.N) {
     const int64_t b = i / a.N;
     const int t = (int)(i % a.N), N = a.N;
     const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
@@ -530,6 +568,7 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
 #pragma unroll
             for (int q = 0; q < F; ++q) acc = fmaf(Ab[c * F + q], xv[q], acc);
             AXnext[(b * F + c) * N + t] = acc;
+            mx = fmaxf(mx, t_finite_abs(acc));
         }
     }
     if (pooled) {                                                    // (t_pool_kernel)
@@ -538,6 +577,8 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
         for (int c = 1; c < F; ++c) m = (xv[c] > m || xv[c] != xv[c]) ? xv[c] : m;
         pooled[i] = m;
     }
+    }
+    if (AXnext && amax_next) t_amax_store(mx, amax_next, l4);       // (whole wavefronts)
 }
 
 // head: y1 = relu(y1pre + b1) (stored), pred, loss, dpred, dy1pre.  One block per sample.
@@ -816,7 +857,7 @@ __device__ __forceinline__ void t_dz1_at(const float* __restrict__ gsum0, const 
 // conv_block1 backward: weight gradient partials, dHpre = (convT1(dz1) + gsum0) * leaky'(H)
 __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restrict__ gsum0, const float* __restrict__ z1, const float* __restrict__ H,
                                                           const float* __restrict__ prm_l, float* __restrict__ dHpre, float* __restrict__ gpart,
-                                                          int bn_index, TTrain a) {
+                                                          int bn_index, TTrain a, float* amax_dh) {
     __shared__ __attribute__((aligned(16))) float tile[4][TTR * TTS];
     __shared__ float bnc[7 * F];
     __shared__ float red[8 * 64];
@@ -826,6 +867,7 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
     const int64_t total = a.B * a.N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4tt acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float dhmax = 0.f;
     for (int64_t base = (int64_t)blockIdx.x * 256; base < total; base += (int64_t)gridDim.x * 256) {
     const int64_t i = base + threadIdx.x;
     const bool ok = i < total;
@@ -848,10 +890,14 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
         for (int c = 0; c < F; ++c) {
             const int64_t idx = (b * F + c) * N + t;
             const float g = dH[c] + gsum0[idx];
-            dHpre[idx] = h[c] > 0.f ? g : g * LEAKY;
+            const float dv = h[c] > 0.f ? g : g * LEAKY;
+            dHpre[idx] = dv;
+            dhmax = fmaxf(dhmax, t_finite_abs(dv));
         }
     }
     }
+    if (amax_dh) t_amax_store(dhmax, amax_dh, red);
+    __syncthreads();
     t_wgrad_store(red, acc0, acc1, gpart + (size_t)blockIdx.x * CONVW);
 }
 
@@ -918,6 +964,7 @@ struct TWs {
     size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
     size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
     size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split;
+    size_t off_amax;            // [3][L][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l|, |d Hpre_l| (the large GEMMs' operand scales)
     size_t cells_bytes;
     int grid;
 };
@@ -952,6 +999,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_cells = o; o += al256(w->cells_bytes);
     w->off_gpart = o; o += al256((size_t)2 * L * w->grid * CONVW * 4);
     w->off_one = o; o += 256;
+    w->off_amax = o; o += al256((size_t)3 * L * T_AMAX_MAX * sizeof(float));
     // partial products of the split-K weight / bias gradient GEMMs (reductions over batch * 10 or batch rows)
     {
         const int R = (int)(B * F), Bi = (int)B;
@@ -996,6 +1044,14 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     float* one = reinterpret_cast<float*>(ws + w.off_one);
     float* split = reinterpret_cast<float*>(ws + w.off_split);
     const float* prm = ar->params;
+    // operand scales of the large GEMMs: partial maxima rows, one float per workgroup of the producing launch.  The scaled form only where
+    // the producers' grids fit a row (every reference wiring does: <= 4096 chunks of 256 positions)
+    float* amax = reinterpret_cast<float*>(ws + w.off_amax);
+    const int n_pos = (int)((BN_ + 255) / 256), n_dh = t_pgrid(BN_), n_th = 64;
+    const bool scaled = n_pos <= T_AMAX_MAX;
+    auto am_ax = [&](int l) { return scaled ? amax + (size_t)(0 * L + l) * T_AMAX_MAX : (float*)nullptr; };
+    auto am_th = [&](int l) { return scaled ? amax + (size_t)(1 * L + l) * T_AMAX_MAX : (float*)nullptr; };
+    auto am_dh = [&](int l) { return scaled ? amax + (size_t)(2 * L + l) * T_AMAX_MAX : (float*)nullptr; };
 
     TArgs a{B, N, s->patch_size, L};
     TTrain t;
@@ -1022,6 +1078,11 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (rc != RULGNN_OK) return rc;
         }
         if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        if (scaled) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N, am_th(0));
+            if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+        }
         T_STATS(ar->x, TP(w.off_X, 0));
         (void)hipGetLastError();
         hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, TP(w.off_X, 0), A, a);
@@ -1030,14 +1091,15 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             const float* pl = prm + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
-            if (l == 0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a);
-            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);
+            if (l == 0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a, am_ax(0));
+            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l), n_pos, am_th(l), n_th);
             if (rc != RULGNN_OK) return rc;
             T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
             T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
             // (+ the next layer's A.X, or the channel max-pool behind the last layer)
             T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t,
-                     (const float*)A, l + 1 < L ? TP(w.off_AX, l + 1) : (float*)nullptr, l + 1 < L ? (float*)nullptr : pooled);
+                     (const float*)A, l + 1 < L ? TP(w.off_AX, l + 1) : (float*)nullptr, l + 1 < L ? (float*)nullptr : pooled,
+                     l + 1 < L ? am_ax(l + 1) : (float*)nullptr);
         }
         // (through the split-K pair: [batch x N] has too few output tiles to fill the chip -- at XJTU batch 1024, 64 tiles of 128 x 128)
         rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);
@@ -1080,9 +1142,9 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             T_LAUNCH_P(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,
                      gpart + (size_t)(2 * l + 1) * w.grid * CONVW, 2 * l + 1, t);
             T_LAUNCH_P(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
-                     gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t);
+                     gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t, am_dh(l));
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
-            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream);
+            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream, am_dh(l), n_dh, am_ax(l), n_pos);
             if (rc != RULGNN_OK) return rc;
             rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
             if (rc != RULGNN_OK) return rc;
@@ -1091,11 +1153,11 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, stream) != 0)
                 return RULGNN_ECALLBACK;
             if (l > 0) {
-                rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream);      // dHpre . theta
+                rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream, 0, am_dh(l), n_dh, am_th(l), n_th);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;
                 // (A^T dAX + dXn, A symmetric.  Folded into the tail kernel of the layer below it cost more there -- 100 adjacency loads and
                 // 100 FMAs per position inside the persistent loop: +22 us -- than this launch takes)
-                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a);
+                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a, (float*)nullptr);
             }
         }
     }
