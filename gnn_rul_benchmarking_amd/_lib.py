@@ -145,7 +145,7 @@ class RgcnuArgs(C.Structure):
 
 
 DTYPE_F32, DTYPE_BF16 = 0, 1      # include/rulgnn.h RULGNN_DTYPE_*
-GEMM_F32, GEMM_BF16X3 = 0, 1      # include/rulgnn.h RULGNN_GEMM_*
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X3_ONLY = 0, 1, 2      # include/rulgnn.h RULGNN_GEMM_*
 HAGCN_TOPK_SLOTS = 16
 
 
@@ -189,6 +189,9 @@ _SIGNATURES = {
     "rulgnn_sgemm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p]),
     "rulgnn_sgemm_mode": (C.c_int, [C.c_int32]),
+    "rulgnn_sgemm_scaled_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rulgnn_absmax_partials_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "rulgnn_sgemm_splitk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rulgnn_sgemm_splitk_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -805,7 +805,7 @@ int rulgnn_sagcn_fwdbwd_f32(const rulgnn_sagcn_shape* shape, const rulgnn_sagcn_
 
 int rulgnn_sgemm_mode(int32_t mode) {
     const int prev = sgemm_big_mode();
-    if (mode == RULGNN_GEMM_F32 || mode == RULGNN_GEMM_BF16X3) sgemm_big_mode() = mode;
+    if (mode == RULGNN_GEMM_F32 || mode == RULGNN_GEMM_BF16X3 || mode == RULGNN_GEMM_BF16X3_ONLY) sgemm_big_mode() = mode;
     return prev;
 }
 
@@ -868,6 +868,19 @@ int rulgnn_sgemm_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, i
     if (M == 0 || N == 0) return RULGNN_OK;
     if (!A || !B || !C) return RULGNN_EINVAL;
     return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, static_cast<hipStream_t>(stream));
+}
+
+int rulgnn_absmax_partials_f32(const float* x, int64_t n, float* partials, int32_t nparts, void* stream) {
+    if (n < 0 || nparts <= 0 || nparts > 65535 || !partials || (n > 0 && !x)) return RULGNN_EINVAL;
+    return absmax_partials(x, n, partials, nparts, static_cast<hipStream_t>(stream));
+}
+int rulgnn_sgemm_scaled_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int32_t M,
+                            int32_t N, int32_t K, int32_t accumulate, const float* amax_a, int32_t amax_na, const float* amax_b, int32_t amax_nb,
+                            void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldc < N) return RULGNN_EINVAL;
+    if (M == 0 || N == 0) return RULGNN_OK;
+    if (!A || !B || !C || !amax_a || !amax_b || amax_na <= 0 || amax_nb <= 0) return RULGNN_EINVAL;
+    return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, static_cast<hipStream_t>(stream), 0, amax_a, amax_na, amax_b, amax_nb);
 }
 
 static size_t splitk_part_floats(int32_t M, int32_t N, int32_t K) {

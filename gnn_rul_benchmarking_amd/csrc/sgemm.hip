@@ -604,9 +604,10 @@ static __global__ __launch_bounds__(512) void sgemm_bf16x3v_kernel(GemmArgs g) {
 // lo = f16(a s - hi); a b = (hi hi + hi lo + lo hi) / (sa sb) + terms below 2^-22 |a b| -- three v_mfma_f32_32x32x16_f16 per fp32
 // product instead of the six of the bf16 split, the arithmetic of the fused ST_GCN kernels (stgcn_mx.hpp).  f16 has five exponent bits:
 // the caller passes max |A| and max |B| (GemmArgs::amax_*, produced by the kernels that wrote the operands) and each operand is scaled
-// by a power of two so that its largest element lands in [2^11, 2^12); elements more than 2^25 below the largest lose precision
-// (their hi part goes subnormal) -- invisible in a product that also contains the large ones, and the reason this form is opt-in:
-// the generic entry points keep the range-free bf16 split.  Same tiles, LDS layout (two planes: 96 KB double-buffered) and pipeline.
+// by a power of two so that its largest element lands in [2^11, 2^12); an element more than 2^15 below the largest keeps fewer than 22
+// bits (its lo part goes subnormal: absolute error 2^-37 of the largest) -- invisible in a product that also contains the large ones,
+// ~4e-5 relative in an output only such elements touch, and the reason this form is opt-in: the generic entry points keep the
+// range-free bf16 split.  Same tiles, LDS layout (two planes: 96 KB double-buffered) and pipeline.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 gemm_f16x8 __attribute__((ext_vector_type(8)));
 static __device__ __forceinline__ float sgemm_f16_scale_of(float amax) {
@@ -807,6 +808,28 @@ static __global__ __launch_bounds__(512) void sgemm_f16x2v_kernel(GemmArgs g) {
     else sgemm_f16x2v_body<A_KFAST, B_KFAST, true>(g);
 }
 
+// partial maxima of |x| over the finite elements, one float per workgroup (the operand scales of the f16 split for tensors whose
+// producer is not one of this library's kernels)
+static __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+    __shared__ float l4[4];
+    float m = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float a = __builtin_fabsf(x[e]);
+        m = fmaxf(m, a <= 3.0e38f ? a : 0.f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) l4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(l4[0], l4[1]), fmaxf(l4[2], l4[3]));
+}
+int absmax_partials(const float* x, int64_t n, float* part, int nparts, hipStream_t st) {
+    if (nparts <= 0) return RULGNN_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(absmax_partials_kernel, dim3(nparts), dim3(256), 0, st, x, n, part);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
 // 256x256 tiles when both output dimensions fill them and there are enough of them for one per CU
 static inline bool sgemm_wide_ok(const GemmArgs& g, int slices) {
     if (g.M <= 192 || g.N <= 192) return false;
@@ -835,7 +858,7 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
     if (sgemm_big_ok(g, slices)) {
         const dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, slices);
         const bool ak = g.sAk == 1, bk = g.sBk == 1;
-        if (sgemm_big_mode() == 1) {
+        if (sgemm_big_mode() >= 1) {                                 // (1: bf16 x 3, f16 x 2 where the caller passes scales; 2: bf16 x 3 only)
             constexpr size_t lx = (size_t)2 * 6 * 128 * 48;
             auto gox = [&](auto kernel) {
                 static bool raised = false;                          // once per instantiation and process
@@ -856,7 +879,7 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
                     }
                     hipLaunchKernelGGL(kernel, wgrid, dim3(512), lw, st, g);
                 };
-                if (g.amax_a && g.amax_b) {
+                if (g.amax_a && g.amax_b && sgemm_big_mode() == 1) {
                     constexpr size_t lh = (size_t)2 * 4 * 256 * 48;
                     auto goh = [&](auto kernel) {
                         static bool raised = false;

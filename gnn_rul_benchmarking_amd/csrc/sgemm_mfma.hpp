@@ -22,6 +22,9 @@ int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn,
 // maximum per workgroup of the kernels that produced the operands.  With them, outputs that fill the 256 x 256 tiles run the two-plane f16
 // split (three matrix instructions per product instead of six; csrc/sgemm.hip: sgemm_f16x2v_kernel).)
 
+// nparts partial maxima of |x| over the finite elements of x[0..n) (one per workgroup): an operand's scale row for the arguments above
+int absmax_partials(const float* x, int64_t n, float* part, int nparts, hipStream_t st);
+
 // The same product as a deterministic split-K reduction (weight gradients: K = all rows of the batch); `partial` is caller-provided
 // scratch of sgemm_splitk_need_floats(M, N, K) floats.
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,

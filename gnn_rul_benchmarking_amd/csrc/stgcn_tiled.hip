@@ -295,9 +295,9 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
     const size_t T = (size_t)s->batch * F * s->num_patch * sizeof(float);
-    // X (ping), X (pong), AX, Hpre  +  A, pooled, y1pre, bnfold
+    // X (ping), X (pong), AX, Hpre  +  A, pooled, y1pre, bnfold, the large GEMMs' operand scales (partial maxima of A.X and of theta_l)
     return 4 * al256(T) + al256((size_t)s->batch * F * F * 4) + 2 * al256((size_t)s->batch * s->num_patch * 4) +
-           al256((size_t)s->num_layers * 4 * F * 4);
+           al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(1 + s->num_layers) * T_AMAX_MAX * sizeof(float));
 }
 
 // (persistent kernels: at most T_PGRID workgroups)
@@ -336,9 +336,18 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* A = reinterpret_cast<float*>(w); w += al256((size_t)B * F * F * 4);
     float* pooled = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* y1pre = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
-    float* bnf = reinterpret_cast<float*>(w);
+    float* bnf = reinterpret_cast<float*>(w); w += al256((size_t)L * 4 * F * 4);
+    float* amax = reinterpret_cast<float*>(w);                          // [1 + L][T_AMAX_MAX]: A.X of the current layer, theta of every layer
+    const int n_pos = (int)((BN_ + 255) / 256), n_th = 64;
+    const bool scaled = n_pos <= T_AMAX_MAX;
 
     T_LAUNCH(t_bnfold_kernel, L * 2 * F, prm, bn, bnf, N, L);
+    if (scaled) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N,
+                           amax + T_AMAX_MAX);
+        if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    }
     T_STATS(x, Xa);
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a);
@@ -347,8 +356,9 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* Xout = Xb;
     for (int l = 0; l < L; ++l) {
         const float* pl = prm + l * LS;
-        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, (float*)nullptr);
-        int rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream);   // (A.X) theta^T
+        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, scaled ? amax : (float*)nullptr);
+        int rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
+                       n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);   // (A.X) theta^T
         if (rc != RULGNN_OK) return rc;
         T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a);
         float* tmp = Xin; Xin = Xout; Xout = tmp;

@@ -750,6 +750,21 @@ int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stag
  */
 int rulgnn_sgemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t accumulate, void *stream);
+/* The same product with per-operand scales (round 5): `amax_a` / `amax_b` = amax_na / amax_nb floats each whose maximum is max |A| / max |B|
+ * over the FINITE elements (rulgnn_absmax_partials_f32 below, or the partial maxima a producing kernel left).  Outputs that fill 256 x 256 tiles
+ * (M, N > 192 and enough tiles for the chip) then run the two-plane f16 split: every operand is scaled by a power of two so that its largest
+ * element lands in [2^11, 2^12), split exactly into hi (11 significant bits) + lo (f16 of the rest), three f16 matrix instructions per
+ * product block with fp32 accumulation, the result unscaled exactly -- 22 significant bits per operand, half the matrix work of
+ * RULGNN_GEMM_BF16X3; an element more than 2^15 below its tensor's largest keeps fewer bits (its lo part goes subnormal: absolute error
+ * 2^-37 of the largest -- invisible in a sum that also contains large elements, ~4e-5 relative in an output only such elements touch:
+ * the reason this form is opt-in).  Other shapes
+ * and RULGNN_GEMM_F32 ignore the scales.  This is the large contraction of the reference's ST_GCN wirings with num_patch > 64
+ * (theta(A.X), models/ST_GCN/Model.py:88, configs/hparams.py:349: [batch * 10, 1024] x [1024, 1024]) and its two gradients. */
+int rulgnn_sgemm_scaled_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
+                            int32_t M, int32_t N, int32_t K, int32_t accumulate, const float *amax_a, int32_t amax_na, const float *amax_b,
+                            int32_t amax_nb, void *stream);
+/* partials[i] = max |x[e]| over the finite elements e = i * 256 + t (mod nparts * 256 strides) of x[0..n): nparts (1..65535) partial maxima. */
+int rulgnn_absmax_partials_f32(const float *x, int64_t n, float *partials, int32_t nparts, void *stream);
 /* The same product as a deterministic split-K reduction -- the weight gradients of the families: C[m][n] = sum over the K rows of the
  * batch of dY(k, m) X(k, n), e.g. nn.Linear's weight.grad (models/FC_STGNN/Model_Base.py:44-107, models/HAGCN/Model.py:26-73) -- and,
  * with `colsum` != NULL, colsum[m] = sum_k A(m, k) from the same pass (the bias gradient over the same rows).  `workspace`: at least
@@ -766,6 +781,10 @@ int rulgnn_sgemm_splitk_f32(const float *A, int64_t sAm, int64_t sAk, const floa
  * kernel.  Returns the previous mode; any other value only queries. */
 #define RULGNN_GEMM_F32 0
 #define RULGNN_GEMM_BF16X3 1
+/* ... RULGNN_GEMM_BF16X3_ONLY: the same, and products whose caller passes operand scales (rulgnn_sgemm_scaled_f32; the tiled ST_GCN path's
+ * five large contractions) ALSO stay on the three-plane bf16 split instead of the two-plane f16 one: range-free fp32-class products at
+ * twice the matrix work. */
+#define RULGNN_GEMM_BF16X3_ONLY 2
 int rulgnn_sgemm_mode(int32_t mode);
 
 /* ------------------------------------------------------------------------------------------------

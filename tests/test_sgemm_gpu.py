@@ -134,3 +134,81 @@ def test_splitk_weight_gradient_matches_numpy(M, N, K, layout, colsum):
     # deterministic: same bits on a second run
     got2, cs2 = run_splitk(A, B, M, N, K, layout, layout, colsum)
     assert np.array_equal(got, got2) and (not colsum or np.array_equal(cs, cs2))
+
+
+def run_scaled(A, B, M, N, K, a_layout, b_layout, nparts=(37, 5)):
+    """rulgnn_sgemm_scaled_f32 with the operand scale rows from rulgnn_absmax_partials_f32 (A: logical [M, K], B: logical [N, K])."""
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    At = torch.from_numpy(np.ascontiguousarray(A if a_layout == "k" else A.T)).to(DEV)
+    Bt = torch.from_numpy(np.ascontiguousarray(B if b_layout == "k" else B.T)).to(DEV)
+    sAm, sAk = (K, 1) if a_layout == "k" else (1, M)
+    sBn, sBk = (K, 1) if b_layout == "k" else (1, N)
+    Ct = torch.zeros(M, N, device=DEV)
+    pa, pb = torch.zeros(nparts[0], device=DEV), torch.zeros(nparts[1], device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rulgnn_absmax_partials_f32(At.data_ptr(), At.numel(), pa.data_ptr(), nparts[0], st), "absmax")
+    _lib.check(lib.rulgnn_absmax_partials_f32(Bt.data_ptr(), Bt.numel(), pb.data_ptr(), nparts[1], st), "absmax")
+    _lib.check(lib.rulgnn_sgemm_scaled_f32(At.data_ptr(), sAm, sAk, Bt.data_ptr(), sBn, sBk, Ct.data_ptr(), N, M, N, K, 0, pa.data_ptr(), nparts[0],
+                                           pb.data_ptr(), nparts[1], st), "sgemm_scaled")
+    return Ct.cpu().numpy(), pa.cpu().numpy(), pb.cpu().numpy()
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1.0, 1.0), (3e-7, 40.0), (2.5e5, 1e-9), (1e-30, 1e20)])
+@pytest.mark.parametrize("a_layout,b_layout", [("k", "k"), ("k", "r"), ("r", "r")])
+def test_two_plane_f16_split_with_operand_scales(scale_a, scale_b, a_layout, b_layout):
+    """The 256 x 256 kernel on two f16 planes per operand (csrc/sgemm.hip: sgemm_f16x2v_kernel) at the shape of the tiled ST_GCN path's theta
+    product, with operands far outside the f16 range in both directions: the power-of-two scales from the partial maxima keep the error at
+    the 2^-22-per-operand class whatever the magnitudes (gradient-sized 1e-7 values, 1e5-sized activations)."""
+    M, N, K = 2560, 1024, 1024 + 16 * 3 + 5                       # 40 tiles x ... >= 160 tiles needs M >= 10240: the split-K-free wide grid
+    M = 10240
+    rng = np.random.default_rng(int(1e3 * np.log10(scale_a * 7 + scale_b)) % 1000)
+    A = (rng.standard_normal((M, K)) * scale_a).astype(np.float32)
+    B = (rng.standard_normal((N, K)) * scale_b).astype(np.float32)
+    got, pa, pb = run_scaled(A, B, M, N, K, a_layout, b_layout)
+    assert pa.max() == np.abs(A).max() and pb.max() == np.abs(B).max()
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    f32 = np.abs((A @ B.T).astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 4e-6, (err, f32)                                  # (fp32 accumulation itself: ~1e-6 at K = 1000)
+    assert np.isfinite(got).all()
+
+
+def test_two_plane_f16_split_special_values_and_small_elements():
+    """NaN / Inf elements do not set the scale and propagate like in fp32 (rows without them stay finite and right).  The stated limit of the
+    form: an element 2^20 below its tensor's largest has lost the low bits of its lo part (f16 subnormals: absolute error 2^-25 after scaling,
+    i.e. <= 2^-37 of the largest) -- a column that only such elements touch is right to ~4e-5 of ITS magnitude, not to 1e-6."""
+    M, N, K = 10240, 1024, 512
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    A[7, 3] = np.nan
+    A[9, 100] = np.inf
+    B[5, :] *= 2.0 ** -20                                          # a whole row of B far below the rest
+    got, pa, pb = run_scaled(A, B, M, N, K, "k", "k")
+    assert np.isfinite(pa).all() and pa.max() < 10
+    ref = np.where(np.isfinite(A), A, 0).astype(np.float64) @ B.astype(np.float64).T
+    ok = np.ones(M, bool); ok[[7, 9]] = False
+    assert np.isnan(got[7]).all() and not np.isfinite(got[9]).any()
+    assert np.abs(got[ok] - ref[ok]).max() < 4e-6 * np.abs(ref[ok]).max()
+    col = np.abs(got[ok, 5] - ref[ok, 5]).max() / np.abs(ref[ok, 5]).max()
+    assert col < 1e-4, col
+
+
+def test_bf16x3_only_mode_ignores_the_operand_scales():
+    """RULGNN_GEMM_BF16X3_ONLY: the scaled entry runs the three-plane bf16 kernel -- the same bits as the plain entry."""
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    M, N, K = 10240, 1024, 256
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    plain = run(A, B, M, N, K, "k", "k")
+    prev = lib.rulgnn_sgemm_mode(_lib.GEMM_BF16X3_ONLY)
+    try:
+        only, _, _ = run_scaled(A, B, M, N, K, "k", "k")
+    finally:
+        lib.rulgnn_sgemm_mode(prev)
+    scaled, _, _ = run_scaled(A, B, M, N, K, "k", "k")
+    assert np.array_equal(only, plain)
+    assert not np.array_equal(scaled, plain) and np.abs(scaled - plain).max() < 1e-5 * np.abs(plain).max()
