@@ -777,12 +777,17 @@ static __device__ __forceinline__ void sgemm_f16x2v_body(GemmArgs g) {
                 for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[tt]], bb[PB[tt]], acc[i][j], 0, 0, 0);
         }
         if (more) stash(sgemm_x3_lds + (buf ^ 1) * BUF, nn);
+#ifndef F16X2_VALU
+#define F16X2_VALU 4
+#endif
+#if F16X2_VALU > 0
 #pragma unroll
         for (int q = 0; q < 24; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, F16X2_VALU, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
+#endif
         __syncthreads();
         buf ^= 1;
     }

@@ -338,7 +338,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* y1pre = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* bnf = reinterpret_cast<float*>(w); w += al256((size_t)L * 4 * F * 4);
     float* amax = reinterpret_cast<float*>(w);                          // [1 + L][T_AMAX_MAX]: A.X of the current layer, theta of every layer
-    const int n_pos = (int)((BN_ + 255) / 256), n_th = 64;
+    const int n_pos = (int)((BN_ + 255) / 256), n_th = 256;
     const bool scaled = n_pos <= T_AMAX_MAX;
 
     T_LAUNCH(t_bnfold_kernel, L * 2 * F, prm, bn, bnf, N, L);
@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
 // head: y1 = relu(y1pre + b1) (stored), pred, loss, dpred, dy1pre.  One block per sample.
 __global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restrict__ y1pre, const float* __restrict__ prm, const float* __restrict__ gy,
                                                            int has_dpred, float* __restrict__ y1, float* __restrict__ pred,
-                                                           float* __restrict__ dpred_out, float* __restrict__ dy1pre, TTrain a) {
+                                                           float* __restrict__ dpred_out, float* __restrict__ dy1pre, TTrain a,
+                                                           float* __restrict__ one) {
     __shared__ float red[4];
     __shared__ float dp;
     const int64_t b = blockIdx.x;
@@ -621,6 +622,9 @@ __global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restri
             d = 2.f * diff / (float)a.global_batch;
             atomicAdd(a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + tc_sf(a.L), (double)diff * (double)diff);
         }
+        // d fc2.bias = sum_b dpred[b]: the cell behind the loss (it was a launch of its own, 13 us); and the constant the bias column sums read
+        atomicAdd(a.cells_bwd + (blockIdx.x % T_REP) * tc_sb(a.L) + tc_sf(a.L) + 1, (double)d);
+        if (blockIdx.x == 0) one[0] = 1.f;
         dpred_out[b] = d;
         dp = d;
     }
@@ -964,6 +968,7 @@ __global__ __launch_bounds__(256) void t_finalize_kernel(TFin f) {
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && f.write_loss)
         f.loss[0] = (float)(tc_sum(f.cells_bwd, tc_sb(L), tc_sf(L)) / (double)f.global_batch);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && f.write_grads) f.grads[off_fc2_b(N, L)] = (float)tc_sum(f.cells_bwd, tc_sb(L), tc_sf(L) + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1029,7 +1034,6 @@ size_t stgcn_tiled_train_workspace_bytes(const rulgnn_stgcn_shape* s) {
     return w.total;
 }
 
-__global__ void t_fill_one_kernel(float* p) { p[0] = 1.f; }
 
 int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args* ar, int mode /* 0 fwd, 1 bwd, 2 both */,
                       hipStream_t stream, const GradReadyHook* ready) {
@@ -1057,7 +1061,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     // operand scales of the large GEMMs: partial maxima rows, one float per workgroup of the producing launch.  The scaled form only where
     // the producers' grids fit a row (every reference wiring does: <= 4096 chunks of 256 positions)
     float* amax = reinterpret_cast<float*>(ws + w.off_amax);
-    const int n_pos = (int)((BN_ + 255) / 256), n_dh = t_pgrid(BN_), n_th = 64;
+    const int n_pos = (int)((BN_ + 255) / 256), n_dh = t_pgrid(BN_), n_th = 256;
     const bool scaled = n_pos <= T_AMAX_MAX;
     auto am_ax = [&](int l) { return scaled ? amax + (size_t)(0 * L + l) * T_AMAX_MAX : (float*)nullptr; };
     auto am_th = [&](int l) { return scaled ? amax + (size_t)(1 * L + l) * T_AMAX_MAX : (float*)nullptr; };
@@ -1120,17 +1124,15 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     // head (also recomputed by a backward-only call: cheap, gives dpred for the incoming gradient)
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_head_train_kernel, dim3((unsigned)B), dim3(256), 0, stream, y1pre, prm, gy, has_dpred, y1, ar->pred, dpredb,
-                       dy1, t);
+                       dy1, t, one);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
 
     if (mode != 0) {
         float* g = ar->grads;
-        T_LAUNCH(t_fill_one_kernel, 1, one);
         // fc2: dW2[j] = sum_b dpred[b] y1[b][j];  db2 = sum_b dpred[b]
         rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
-        rc = sgemm_splitk(dpredb, 0, 1, one, 0, 0, g + off_fc2_b(N, L), 1, 1, 1, (int)B, false, split, stream);
-        if (rc != RULGNN_OK) return rc;
+        // (db2 = sum_b dpred[b]: accumulated by the head kernel, written by the finalize kernel)
         // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
         rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
@@ -1138,7 +1140,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         if (rc != RULGNN_OK) return rc;
         // data parallel with overlap: the head's gradients (fc1 is N x N: 4 MB at XJTU-SY) are final here, with the whole layer
         // stack still to run -- the caller may start their all-reduce on another stream (include/rulgnn.h: rulgnn_grad_ready_fn)
-        if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(param_count(N, L) - off_fc1_w(N, L)), stream) != 0)
+        // (without fc2.bias, the last parameter: its gradient comes out of the finalize kernel with the convolution / BatchNorm ones)
+        if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(off_fc2_b(N, L) - off_fc1_w(N, L)), stream) != 0)
             return RULGNN_ECALLBACK;
         rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream);
         if (rc != RULGNN_OK) return rc;

@@ -413,14 +413,15 @@ class ST_GCN_model(FlatModule):
 
     def ready_regions(self):
         """(offset, count) of the bucket regions ``fused_mse_step(grad_ready=...)`` reports, in the order it reports them
-        (include/rulgnn.h, rulgnn_stgcn_train_fwdbwd_ready_f32): the head (fc1 | fc2), then theta (weight | bias) of every layer but the
+        (include/rulgnn.h, rulgnn_stgcn_train_fwdbwd_ready_f32): the head (fc1 | fc2.weight), then theta (weight | bias) of every layer but the
         first, top layer first.  A function of the shape alone -- dp.py lets a rank with an empty shard replay the same collectives."""
         if not self.reports_ready_gradients:
             return []
         N, L = self.num_patch, self.num_layers
         LS = PL.layer_stride(N)
         head = PL.param_count(N, L) - (N * N + 2 * N + 1)
-        return [(head, N * N + 2 * N + 1)] + [(l * LS, N * N + N) for l in range(L - 1, 0, -1)]
+        # (fc1.weight | fc1.bias | fc2.weight; fc2.bias, the last parameter, comes out of the finalize kernel at the end of the step)
+        return [(head, N * N + 2 * N)] + [(l * LS, N * N + N) for l in range(L - 1, 0, -1)]
 
     SYNC_BN_PAIRS_PER_LAYER = 4      # all-reduces per layer and step under synchronised BatchNorm: 2 forward + 2 backward pairs
 

@@ -183,7 +183,7 @@ int rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(const rulgnn_stgcn_shape *shape, c
  * backward").  `ready(user, grads, offset, count, stream)` is called from the launching thread right after the kernels that finalise
  * args->grads[offset, offset + count) were enqueued on `stream`; the callback must order whatever it starts after the work queued
  * on `stream` so far (record an event there and make its own stream wait for it) and must not touch the rest of args->grads.  Regions
- * are disjoint and reported in backward order: the head (fc1 | fc2 at the tail of the flat buffer) first, then theta (weight | bias) of
+ * are disjoint and reported in backward order: the head (fc1 | fc2.weight near the tail of the flat buffer; not fc2.bias, the last element) first, then theta (weight | bias) of
  * every layer but the first; everything that is not reported (the first layer, the convolution and BatchNorm gradients, the loss) is
  * final when the call returns and its work has drained, as with the plain entry.  Shapes of the fused kernels (num_patch <= 64:
  * buckets of a few KB) make no callback.  Returns RULGNN_ECALLBACK when `ready` returns non-zero. */

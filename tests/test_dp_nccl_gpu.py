@@ -130,7 +130,7 @@ def test_large_bucket_step_overlaps_the_all_reduce_in_gradient_ready_order(nccl_
     fc1 = L * LS
     total = dp.model.bucket.numel()
     regs = ctx.last_overlap_regions
-    assert (fc1, fc1 + N * N + N + N + 1) in regs                        # the head: fc1 | fc2, reported first
+    assert (fc1, fc1 + N * N + N + N) in regs                            # the head: fc1 | fc2.weight, reported first (fc2.bias: finalize kernel)
     assert (1 * LS, 1 * LS + N * N + N) in regs                           # theta of layer 1
     assert regs[0][0] == 0 and regs[-1][1] == total                      # and the complement: every element exactly once
     assert all(a[1] == b[0] for a, b in zip(regs, regs[1:]))
