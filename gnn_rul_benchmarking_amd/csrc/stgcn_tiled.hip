@@ -64,19 +64,25 @@ __global__ __launch_bounds__(256) void t_stats_lds_kernel(const float* __restric
 }
 
 // Pearson adjacency -- Model.py:53-71.  One block per sample.  A: [B][10][10]
+// Means first (two passes like the reference), then the Gram matrix of the centred rows on the fp32 matrix cores: D = Xc Xc^T is one
+// 16 x 16 tile (ten live rows), K = N patches -- v_mfma_f32_16x16x4_f32 with the same register as A and B operand (lane (i, kq): row i at
+// patch t0 + 4 kq + s in step s: a lane's four steps are one 16-byte load), a quarter of the patches per wavefront, the four partial tiles
+// summed through LDS.  As 55 pair sums per thread with a 6-step shuffle reduction each it took 30 us at XJTU batch 1024.
+typedef float tg_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X0, float* __restrict__ A, TArgs a) {
-    __shared__ float red[NPAIR][4];
-    __shared__ float mean[F];
-    __shared__ float dots[NPAIR];
+    __shared__ float red[F][4];
+    __shared__ float mean[16];
+    __shared__ float part[4][16][17];
+    __shared__ float dots[16][17];
     const int64_t b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* xb = X0 + b * F * a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4, N = a.N;
+    const float* xb = X0 + b * F * N;
     float s[F];
 #pragma unroll
     for (int c = 0; c < F; ++c) s[c] = 0.f;
-    for (int t = tid; t < a.N; t += 256)
+    for (int t = tid; t < N; t += 256)
 #pragma unroll
-        for (int c = 0; c < F; ++c) s[c] += xb[c * a.N + t];
+        for (int c = 0; c < F; ++c) s[c] += xb[c * N + t];
 #pragma unroll
     for (int c = 0; c < F; ++c) {
         float v = s[c];
@@ -85,33 +91,42 @@ __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X
         if (lane == 0) red[c][wave] = v;
     }
     __syncthreads();
-    if (tid < F) mean[tid] = (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)a.N;
+    if (tid < 16) mean[tid] = tid < F ? (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)N : 0.f;
     __syncthreads();
-    float d[NPAIR];
+    // this lane's row (rows 10..15 of the tile are zero), centred; patches in chunks of 16, the chunks dealt round-robin to the wavefronts
+    const float mu = mean[li];
+    const float* row = xb + (li < F ? li : 0) * N;
+    tg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (N & 3) == 0;
+    for (int t0 = 16 * wave; t0 < N; t0 += 64) {
+        const int t = t0 + 4 * kq;
+        float v[4];
+        if (vec && t + 3 < N) {
+            const float4 q = *reinterpret_cast<const float4*>(row + t);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
 #pragma unroll
-    for (int i = 0; i < NPAIR; ++i) d[i] = 0.f;
-    for (int t = tid; t < a.N; t += 256) {
-        float cx[F];
+            for (int e = 0; e < 4; ++e) v[e] = row[t + e < N ? t + e : N - 1];
+        }
 #pragma unroll
-        for (int c = 0; c < F; ++c) cx[c] = xb[c * a.N + t] - mean[c];
-#pragma unroll
-        for (int p = 0; p < F; ++p)
-#pragma unroll
-            for (int q = p; q < F; ++q) d[sym(p, q)] = fmaf(cx[p], cx[q], d[sym(p, q)]);
+        for (int e = 0; e < 4; ++e) {
+            const float c = (li < F && t + e < N) ? v[e] - mu : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(c, c, acc, 0, 0, 0);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < NPAIR; ++i) {
-        float v = d[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) red[i][wave] = v;
-    }
+    for (int r = 0; r < 4; ++r) part[wave][4 * kq + r][li] = acc[r];
     __syncthreads();
-    if (tid < NPAIR) dots[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    {
+        const int p = tid >> 4, q = tid & 15;
+        dots[p][q] = (part[0][p][q] + part[1][p][q]) + (part[2][p][q] + part[3][p][q]);
+    }
     __syncthreads();
     if (tid < F * F) {
         const int p = tid / F, q = tid % F;
-        A[b * F * F + tid] = dots[sym(p, q)] / (sqrtf(dots[sym(p, p)]) * sqrtf(dots[sym(q, q)]));   // 0/0 -> NaN as the reference
+        // (the upper triangle's value for both orders: the tile is symmetric up to the matrix cores' summation order inside a row)
+        const float d = p <= q ? dots[p][q] : dots[q][p];
+        A[b * F * F + tid] = d / (sqrtf(dots[p][p]) * sqrtf(dots[q][q]));   // 0/0 -> NaN as the reference
     }
 }
 
