@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void t_stats_lds_kernel(const float* __restric
 // patch t0 + 4 kq + s in step s: a lane's four steps are one 16-byte load), a quarter of the patches per wavefront, the four partial tiles
 // summed through LDS.  As 55 pair sums per thread with a 6-step shuffle reduction each it took 30 us at XJTU batch 1024.
 typedef float tg_f4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X0, float* __restrict__ A, TArgs a) {
+// With `AX0`: the first layer's aggregation A.X0 of this sample right behind its adjacency (the rows are in L2 from the two passes above; it
+// was a launch of its own re-reading them), and the sample's max |A.X0| as its entry of the operand-scale row `amax0`.
+__global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X0, float* __restrict__ A, TArgs a, float* __restrict__ AX0,
+                                                     float* __restrict__ amax0) {
     __shared__ float red[F][4];
+    __shared__ float As[F * F];
     __shared__ float mean[16];
     __shared__ float part[4][16][17];
     __shared__ float dots[16][17];
@@ -126,7 +130,34 @@ __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X
         const int p = tid / F, q = tid % F;
         // (the upper triangle's value for both orders: the tile is symmetric up to the matrix cores' summation order inside a row)
         const float d = p <= q ? dots[p][q] : dots[q][p];
-        A[b * F * F + tid] = d / (sqrtf(dots[p][p]) * sqrtf(dots[q][q]));   // 0/0 -> NaN as the reference
+        const float av = d / (sqrtf(dots[p][p]) * sqrtf(dots[q][q]));       // 0/0 -> NaN as the reference
+        A[b * F * F + tid] = av;
+        As[tid] = av;
+    }
+    if (!AX0) return;
+    __syncthreads();
+    float* ob = AX0 + b * F * N;
+    float m = 0.f;
+    for (int t = tid; t < N; t += 256) {                                    // (same sums in the same order as t_aggregate_kernel)
+        float x[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) x[c] = xb[c * N + t];
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < F; ++q) acc = fmaf(As[c * F + q], x[q], acc);
+            ob[c * N + t] = acc;
+            const float ab = __builtin_fabsf(acc);
+            m = fmaxf(m, ab <= 3.0e38f ? ab : 0.f);
+        }
+    }
+    if (amax0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) red[0][wave] = m;
+        __syncthreads();
+        if (tid == 0) amax0[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
     }
 }
 
@@ -365,7 +396,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     }
     T_STATS(x, Xa);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a);
+    hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a, (float*)nullptr, (float*)nullptr);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     float* Xin = Xa;
     float* Xout = Xb;
@@ -1078,6 +1109,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     float* amax = reinterpret_cast<float*>(ws + w.off_amax);
     const int n_pos = (int)((BN_ + 255) / 256), n_dh = t_pgrid(BN_), n_th = 256;
     const bool scaled = n_pos <= T_AMAX_MAX;
+    const int n_ax0 = (scaled && B <= T_AMAX_MAX) ? (int)B : 0;            // layer 0's row is written per SAMPLE by the Gram kernel (else per chunk)
     auto am_ax = [&](int l) { return scaled ? amax + (size_t)(0 * L + l) * T_AMAX_MAX : (float*)nullptr; };
     auto am_th = [&](int l) { return scaled ? amax + (size_t)(1 * L + l) * T_AMAX_MAX : (float*)nullptr; };
     auto am_dh = [&](int l) { return scaled ? amax + (size_t)(2 * L + l) * T_AMAX_MAX : (float*)nullptr; };
@@ -1114,14 +1146,18 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         }
         T_STATS(ar->x, TP(w.off_X, 0));
         (void)hipGetLastError();
-        hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, TP(w.off_X, 0), A, a);
+        // (+ the first layer's aggregation and its operand-scale row, one entry per sample, where the batch fits a row)
+        const bool agg0 = scaled && B <= T_AMAX_MAX;
+        hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, TP(w.off_X, 0), A, a, agg0 ? TP(w.off_AX, 0) : (float*)nullptr,
+                           agg0 ? am_ax(0) : (float*)nullptr);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         for (int l = 0; l < L; ++l) {
             const float* pl = prm + l * LS;
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
-            if (l == 0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a, am_ax(0));
-            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l), n_pos, am_th(l), n_th);
+            if (l == 0 && !agg0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a, am_ax(0));
+            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l),
+                       l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
             if (rc != RULGNN_OK) return rc;
             T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
             T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
@@ -1172,7 +1208,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             T_LAUNCH_P(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
                      gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t, am_dh(l));
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
-            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream, am_dh(l), n_dh, am_ax(l), n_pos);
+            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream, am_dh(l), n_dh, am_ax(l),
+                              l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
             if (rc != RULGNN_OK) return rc;
             rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
             if (rc != RULGNN_OK) return rc;
