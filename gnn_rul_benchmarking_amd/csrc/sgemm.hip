@@ -618,12 +618,13 @@ static __device__ __forceinline__ float sgemm_f16_scale_of(float amax) {
     se = se < 1 ? 1 : (se > 254 ? 254 : se);
     return __builtin_bit_cast(float, (unsigned)se << 23);
 }
-// the two operand scales from the producers' partial maxima (512 threads; a few thousand floats out of L2: ~1 us per workgroup)
+// the two operand scales from the producers' partial maxima (256 or 512 threads; a few thousand floats out of L2: ~1 us per workgroup)
 static __device__ __forceinline__ void sgemm_f16_scales(const GemmArgs& g, float& sa, float& sb) {
     __shared__ float part[2][8];
     float ma = 0.f, mb = 0.f;
-    for (int i = threadIdx.x; i < g.amax_na; i += 512) ma = fmaxf(ma, g.amax_a[i]);
-    for (int i = threadIdx.x; i < g.amax_nb; i += 512) mb = fmaxf(mb, g.amax_b[i]);
+    const int nthr = blockDim.x, nwave = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < g.amax_na; i += nthr) ma = fmaxf(ma, g.amax_a[i]);
+    for (int i = threadIdx.x; i < g.amax_nb; i += nthr) mb = fmaxf(mb, g.amax_b[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         ma = fmaxf(ma, __shfl_xor(ma, o, 64));
@@ -632,8 +633,7 @@ static __device__ __forceinline__ void sgemm_f16_scales(const GemmArgs& g, float
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = ma; part[1][threadIdx.x >> 6] = mb; }
     __syncthreads();
     ma = mb = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { ma = fmaxf(ma, part[0][w]); mb = fmaxf(mb, part[1][w]); }
+    for (int w = 0; w < nwave; ++w) { ma = fmaxf(ma, part[0][w]); mb = fmaxf(mb, part[1][w]); }
     sa = sgemm_f16_scale_of(ma);
     sb = sgemm_f16_scale_of(mb);
 }
@@ -813,6 +813,186 @@ static __global__ __launch_bounds__(512) void sgemm_f16x2v_kernel(GemmArgs g) {
     else sgemm_f16x2v_body<A_KFAST, B_KFAST, true>(g);
 }
 
+// The 128 x 128 kernel (sgemm_bf16x3_kernel) on two f16 planes, for scaled products with too few 256 x 256 tiles (the tiled ST_GCN path at
+// the reference protocol's batch of 100: [1000 x 1024] x [1024 x 1024] as 64 tiles x 4 k slices).  256 threads here: the scale reduction
+// strides accordingly.
+template <bool A_KFAST, bool B_KFAST, bool GUARD>
+static __device__ __forceinline__ void sgemm_f16x2_body(GemmArgs g) {
+    constexpr int ROWB = 48;                       // bytes per LDS row of the k-contiguous form
+    constexpr int PLANE = 128 * ROWB;              // one bf16 plane of one operand tile
+    constexpr int BUF = 4 * PLANE;                 // A: h, l ; B: h, l
+    extern __shared__ __attribute__((aligned(16))) unsigned char sgemm_x3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    float sa, sb;
+    sgemm_f16_scales(g, sa, sb);
+    const float unscale = 1.0f / (sa * sb);
+    f32x4t ra[2], rb[2];
+    // k-contiguous: float4 e of a thread = row (tid + 256 e) >> 2, k = 4 ((tid + 256 e) & 3)
+    // row-contiguous: float4 e of a thread = rows 4 (tid & 31) .. + 3 at k = 2 (tid >> 5) + e
+    auto fetch_one = [&](const float* __restrict__ P, int64_t s_row, int64_t s_k, int rows, int r0, int k0, int e, bool kfast) -> f32x4t {
+        f32x4t v = {0.f, 0.f, 0.f, 0.f};
+        if (!GUARD && k0 + 16 <= kend) {          // interior tile, whole K step (wave-uniform): every 16-byte load is in bounds
+            if (kfast) {
+                const int idx = tid + e * 256;
+                return *reinterpret_cast<const f32x4t*>(P + (int64_t)(r0 + (idx >> 2)) * s_row + k0 + 4 * (idx & 3));
+            }
+            return *reinterpret_cast<const f32x4t*>(P + (int64_t)(k0 + 2 * (tid >> 5) + e) * s_k + r0 + 4 * (tid & 31));
+        }
+        if (kfast) {
+            const int idx = tid + e * 256;
+            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+            if (r < rows) {
+                const float* p = P + (int64_t)r * s_row + k;
+                if (k + 3 < kend) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (k < kend) v[0] = p[0];
+                    if (k + 1 < kend) v[1] = p[1];
+                    if (k + 2 < kend) v[2] = p[2];
+                }
+            }
+        } else {
+            const int k = k0 + 2 * (tid >> 5) + e, r = r0 + 4 * (tid & 31);
+            if (k < kend) {
+                const float* p = P + (int64_t)k * s_k + r;
+                if (r + 3 < rows) v = *reinterpret_cast<const f32x4t*>(p);
+                else {
+                    if (r < rows) v[0] = p[0];
+                    if (r + 1 < rows) v[1] = p[1];
+                    if (r + 2 < rows) v[2] = p[2];
+                }
+            }
+        }
+        return v;
+    };
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            ra[e] = fetch_one(g.A, g.sAm, g.sAk, g.M, m0, k0, e, A_KFAST);
+            rb[e] = fetch_one(g.B, g.sBn, g.sBk, g.N, n0, k0, e, B_KFAST);
+        }
+    };
+    auto stash_one = [&](unsigned char* base, const f32x4t (&v)[2], bool kfast, float sc) {
+        if (kfast) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int idx = tid + e * 256;
+                const float x0 = v[e][0], x1 = v[e][1], x2 = v[e][2], x3 = v[e][3];
+                unsigned h0, l0, h1, l1;
+                split_pair_f16x2(x0 * sc, x1 * sc, h0, l0);
+                split_pair_f16x2(x2 * sc, x3 * sc, h1, l1);
+                unsigned char* p = base + (idx >> 2) * ROWB + 8 * (idx & 3);
+                *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(l0, l1);
+            }
+        } else {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x0 = v[0][j], x1 = v[1][j];
+                split_pair_f16x2(x0 * sc, x1 * sc, h[j], l[j]);
+            }
+            unsigned char* p = base + ((tid >> 5) * 128 + 4 * (tid & 31)) * 4;
+            *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(p + PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    auto stash = [&](int buf) {
+        unsigned char* b = sgemm_x3_lds + buf * BUF;
+        stash_one(b, ra, A_KFAST, sa);
+        stash_one(b + 2 * PLANE, rb, B_KFAST, sb);
+    };
+    // the MFMA operand of this lane: 8 consecutive k (k half lane >> 5) of row `row0 + (lane & 31)` of one plane
+    auto operand = [&](const unsigned char* plane, int row0, bool kfast) -> gemm_f16x8 {
+        if (kfast) return *reinterpret_cast<const gemm_f16x8*>(plane + (row0 + (lane & 31)) * ROWB + (lane >> 5) * 16);
+        const unsigned* q = reinterpret_cast<const unsigned*>(plane) + (4 * (lane >> 5)) * 128 + row0 + (lane & 31);
+        const gemm_u32x4 v = {q[0], q[128], q[256], q[384]};
+        return __builtin_bit_cast(gemm_f16x8, v);
+    };
+    // Software pipeline, two K steps deep: while the matrix cores work on tile k (LDS buffer `buf`), the registers loaded during the
+    // PREVIOUS iteration (tile k + 1: a full iteration of latency cover) are split and written to the other buffer, and the loads of
+    // tile k + 2 are issued.  The split's VALU work is interleaved with the MFMAs by the scheduling hints at the end of the body: an
+    // in-order wavefront hides ~5 other instructions behind each 32-cycle MFMA, or none at all if they sit behind the whole chain.
+    int buf = 0;
+    if (kbeg < kend) {
+        fetch(kbeg);
+        stash(0);
+        fetch(kbeg + 16);                     // tile 1 (past the end the guarded loads return zeros)
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const bool more = k0 + 16 < kend;
+        f32x4t na[2], nb[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { na[e] = ra[e]; nb[e] = rb[e]; }          // tile k + 1, loaded one iteration ago
+        if (k0 + 32 < kend) fetch(k0 + 32);                                      // tile k + 2 into ra / rb
+        const unsigned char* b = sgemm_x3_lds + buf * BUF;
+        gemm_f16x8 a[2][2], bb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                a[i][p] = operand(b + p * PLANE, wm + 32 * i, A_KFAST);
+                bb[i][p] = operand(b + (2 + p) * PLANE, wn + 32 * i, B_KFAST);
+            }
+        // the three product terms, smallest first; consecutive MFMAs go to different accumulators (independent: back-to-back issue)
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][PA[t]], bb[j][PB[t]], acc[i][j], 0, 0, 0);
+        if (more) {
+            unsigned char* nbuf = sgemm_x3_lds + (buf ^ 1) * BUF;
+            stash_one(nbuf, na, A_KFAST, sa);
+            stash_one(nbuf + 2 * PLANE, nb, B_KFAST, sb);
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);      // eight VALU (the split)
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one LDS write
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D layout of the 32x32 result: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), gn = n0 + wn + 32 * j + (lane & 31);
+                if (!GUARD || (gm < g.M && gn < g.N)) {
+                    float* c = g.C + (int64_t)gm * g.ldc + gn;
+                    *c = g.accumulate ? *c + acc[i][j][r] * unscale : acc[i][j][r] * unscale;
+                }
+            }
+}
+
+template <bool A_KFAST, bool B_KFAST>
+static __global__ __launch_bounds__(256, 2) void sgemm_f16x2_kernel(GemmArgs g) {
+    // interior tiles take the body whose whole K steps load without bounds checks (a third of its non-MFMA instructions were guards)
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const bool interior = (int)blockIdx.y * 128 + 128 <= g.M && (int)blockIdx.x * 128 + 128 <= g.N && kend > kbeg;
+    if (interior) sgemm_f16x2_body<A_KFAST, B_KFAST, false>(g);
+    else sgemm_f16x2_body<A_KFAST, B_KFAST, true>(g);
+}
+
+
 // partial maxima of |x| over the finite elements, one float per workgroup (the operand scales of the f16 split for tensors whose
 // producer is not one of this library's kernels)
 static __global__ __launch_bounds__(256) void absmax_partials_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
@@ -904,6 +1084,22 @@ static inline void sgemm_launch_tiles(const GemmArgs& g, int slices, hipStream_t
                 else if (ak) gow(sgemm_bf16x3v_kernel<true, false>);
                 else if (bk) gow(sgemm_bf16x3v_kernel<false, true>);
                 else gow(sgemm_bf16x3v_kernel<false, false>);
+                return;
+            }
+            if (g.amax_a && g.amax_b && sgemm_big_mode() == 1) {
+                constexpr size_t l2 = (size_t)2 * 4 * 128 * 48;
+                auto goh = [&](auto kernel) {
+                    static bool raised = false;
+                    if (!raised) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                        raised = true;
+                    }
+                    hipLaunchKernelGGL(kernel, grid, dim3(256), l2, st, g);
+                };
+                if (ak && bk) goh(sgemm_f16x2_kernel<true, true>);
+                else if (ak) goh(sgemm_f16x2_kernel<true, false>);
+                else if (bk) goh(sgemm_f16x2_kernel<false, true>);
+                else goh(sgemm_f16x2_kernel<false, false>);
                 return;
             }
             if (ak && bk) gox(sgemm_bf16x3_kernel<true, true>);

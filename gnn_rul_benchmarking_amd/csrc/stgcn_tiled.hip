@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
 __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restrict__ z2, const float* __restrict__ o0, const float* __restrict__ Xin,
                                                            const float* __restrict__ prm_l, float* __restrict__ Xout, int bn_index, TTrain a,
                                                            const float* __restrict__ A, float* __restrict__ AXnext, float* __restrict__ pooled,
-                                                           float* amax_next) {
+                                                           float* amax_next /* row of AXnext, or of pooled behind the last layer */) {
     __shared__ float bnc[7 * F];
     __shared__ float l4[4];
     t_bn_consts(a.cells_fwd, a.cells_bwd, prm_l, a.N, a.L, 1, bn_index, a.cnt, false, bnc);
@@ -632,16 +632,17 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
 #pragma unroll
         for (int c = 1; c < F; ++c) m = (xv[c] > m || xv[c] != xv[c]) ? xv[c] : m;
         pooled[i] = m;
+        mx = t_finite_abs(m);
     }
     }
-    if (AXnext && amax_next) t_amax_store(mx, amax_next, l4);       // (whole wavefronts)
+    if (amax_next) t_amax_store(mx, amax_next, l4);                 // (whole wavefronts)
 }
 
 // head: y1 = relu(y1pre + b1) (stored), pred, loss, dpred, dy1pre.  One block per sample.
 __global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restrict__ y1pre, const float* __restrict__ prm, const float* __restrict__ gy,
                                                            int has_dpred, float* __restrict__ y1, float* __restrict__ pred,
                                                            float* __restrict__ dpred_out, float* __restrict__ dy1pre, TTrain a,
-                                                           float* __restrict__ one) {
+                                                           float* __restrict__ one, float* __restrict__ amax_dy1 /* [B] or null */) {
     __shared__ float red[4];
     __shared__ float dp;
     const int64_t b = blockIdx.x;
@@ -676,7 +677,16 @@ __global__ __launch_bounds__(256) void t_head_train_kernel(const float* __restri
     }
     __syncthreads();
     const float d = dp;
-    for (int j = tid; j < N; j += 256) dy1pre[b * N + j] = (y1[b * N + j] > 0.f) ? d * w2[j] : 0.f;
+    float mx = 0.f;
+    for (int j = tid; j < N; j += 256) {
+        const float v = (y1[b * N + j] > 0.f) ? d * w2[j] : 0.f;
+        dy1pre[b * N + j] = v;
+        mx = fmaxf(mx, t_finite_abs(v));
+    }
+    if (amax_dy1) {
+        __syncthreads();
+        t_amax_store(mx, amax_dy1, red);
+    }
 }
 
 // ---- backward --------------------------------------------------------------------------------------
@@ -1025,7 +1035,8 @@ struct TWs {
     size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
     size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
     size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split;
-    size_t off_amax;            // [3][L][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l|, |d Hpre_l| (the large GEMMs' operand scales)
+    size_t off_amax;            // [3 L + 3][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l| and |fc1.weight|, |d Hpre_l|, |pooled|, |d y1|
+                                // (the operand scales of the GEMMs)
     size_t cells_bytes;
     int grid;
 };
@@ -1060,14 +1071,15 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_cells = o; o += al256(w->cells_bytes);
     w->off_gpart = o; o += al256((size_t)2 * L * w->grid * CONVW * 4);
     w->off_one = o; o += 256;
-    w->off_amax = o; o += al256((size_t)3 * L * T_AMAX_MAX * sizeof(float));
+    w->off_amax = o; o += al256((size_t)(3 * L + 3) * T_AMAX_MAX * sizeof(float));
     // partial products of the split-K weight / bias gradient GEMMs (reductions over batch * 10 or batch rows)
     {
         const int R = (int)(B * F), Bi = (int)B;
         size_t need = 1024;
         if (B > 0)
             for (size_t v : {sgemm_splitk_need_floats(N, N, R), sgemm_splitk_need_floats(1, N, R), sgemm_splitk_need_floats(N, N, Bi),
-                             sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi), sgemm_splitk_need_floats(Bi, N, N)})
+                             sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi), sgemm_splitk_need_floats(Bi, N, N),
+                             R < 2048 ? sgemm_splitk_need_floats(R, N, N) : (size_t)0})
                 need = v > need ? v : need;
         w->off_split = o; o += al256(need * sizeof(float));
     }
@@ -1111,8 +1123,13 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     const bool scaled = n_pos <= T_AMAX_MAX;
     const int n_ax0 = (scaled && B <= T_AMAX_MAX) ? (int)B : 0;            // layer 0's row is written per SAMPLE by the Gram kernel (else per chunk)
     auto am_ax = [&](int l) { return scaled ? amax + (size_t)(0 * L + l) * T_AMAX_MAX : (float*)nullptr; };
-    auto am_th = [&](int l) { return scaled ? amax + (size_t)(1 * L + l) * T_AMAX_MAX : (float*)nullptr; };
-    auto am_dh = [&](int l) { return scaled ? amax + (size_t)(2 * L + l) * T_AMAX_MAX : (float*)nullptr; };
+    auto am_th = [&](int l) { return scaled ? amax + (size_t)(1 * L + l) * T_AMAX_MAX : (float*)nullptr; };          // (l = L: fc1.weight)
+    auto am_dh = [&](int l) { return scaled ? amax + (size_t)(2 * L + 1 + l) * T_AMAX_MAX : (float*)nullptr; };
+    float* am_pool = scaled ? amax + (size_t)(3 * L + 1) * T_AMAX_MAX : (float*)nullptr;                             // n_pos entries (tail kernel)
+    float* am_dy1 = (scaled && B <= T_AMAX_MAX) ? amax + (size_t)(3 * L + 2) * T_AMAX_MAX : (float*)nullptr;         // B entries (head kernel)
+    // rows of [batch * 10, N] too few for the large tiles (the reference protocol's batch of 100): the theta products through the split-K
+    // pair as well, like fc1
+    const bool few_rows = B * F < 2048;
 
     TArgs a{B, N, s->patch_size, L};
     TTrain t;
@@ -1141,7 +1158,9 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
         if (scaled) {
             (void)hipGetLastError();
-            hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N, am_th(0));
+            // (theta of every layer and, as "layer L" of the same stride, fc1.weight)
+            static_assert(off_theta_w(1) == 0 && off_fc1_w(7, 3) == 3 * layer_stride(7), "fc1.weight sits where a layer-L theta would");
+            hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L + 1), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N, am_th(0));
             if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         }
         T_STATS(ar->x, TP(w.off_X, 0));
@@ -1156,6 +1175,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
             if (l == 0 && !agg0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a, am_ax(0));
+            if (few_rows)
+                rc = sgemm_splitk(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, split, stream, am_ax(l),
+                                  l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
+            else
             rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l),
                        l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
             if (rc != RULGNN_OK) return rc;
@@ -1164,10 +1187,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             // (+ the next layer's A.X, or the channel max-pool behind the last layer)
             T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t,
                      (const float*)A, l + 1 < L ? TP(w.off_AX, l + 1) : (float*)nullptr, l + 1 < L ? (float*)nullptr : pooled,
-                     l + 1 < L ? am_ax(l + 1) : (float*)nullptr);
+                     l + 1 < L ? am_ax(l + 1) : am_pool);
         }
         // (through the split-K pair: [batch x N] has too few output tiles to fill the chip -- at XJTU batch 1024, 64 tiles of 128 x 128)
-        rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);
+        rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream, am_pool, n_pos, am_th(L), n_th);
         if (rc != RULGNN_OK) return rc;
     } else {
         if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * T_REP * tc_sb(L), stream) != hipSuccess) return RULGNN_EHIP;
@@ -1175,7 +1198,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     // head (also recomputed by a backward-only call: cheap, gives dpred for the incoming gradient)
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_head_train_kernel, dim3((unsigned)B), dim3(256), 0, stream, y1pre, prm, gy, has_dpred, y1, ar->pred, dpredb,
-                       dy1, t, one);
+                       dy1, t, one, am_dy1);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
 
     if (mode != 0) {
@@ -1185,7 +1208,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         if (rc != RULGNN_OK) return rc;
         // (db2 = sum_b dpred[b]: accumulated by the head kernel, written by the finalize kernel)
         // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
-        rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split, stream);
+        rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split, stream, am_dy1, (int)B,
+                          am_dy1 ? am_pool : (float*)nullptr, n_pos);
         if (rc != RULGNN_OK) return rc;
         rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split, stream);
         if (rc != RULGNN_OK) return rc;
@@ -1194,7 +1218,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         // (without fc2.bias, the last parameter: its gradient comes out of the finalize kernel with the convolution / BatchNorm ones)
         if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(off_fc2_b(N, L) - off_fc1_w(N, L)), stream) != 0)
             return RULGNN_ECALLBACK;
-        rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream);
+        rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream, am_dy1, (int)B,
+                          am_dy1 ? am_th(L) : (float*)nullptr, n_th);
         if (rc != RULGNN_OK) return rc;
         for (int l = L - 1; l >= 0; --l) {
             const float* pl = prm + l * LS;
@@ -1218,6 +1243,9 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, stream) != 0)
                 return RULGNN_ECALLBACK;
             if (l > 0) {
+                if (few_rows)
+                    rc = sgemm_splitk(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, split, stream, am_dh(l), n_dh, am_th(l), n_th);
+                else
                 rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream, 0, am_dh(l), n_dh, am_th(l), n_th);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;
                 // (A^T dAX + dXn, A symmetric.  Folded into the tail kernel of the layer below it cost more there -- 100 adjacency loads and
