@@ -1597,7 +1597,7 @@ static __global__ __launch_bounds__(256) void sgemm_vecmat_kernel(const float* _
     __syncthreads();
     if (wave == 0 && n < N) partial[(int64_t)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
-static inline bool sgemm_vecmat_ok(int M, int N, int K, int64_t sBn) { return M == 1 && sBn == 1 && N >= 64 && K >= 256; }
+static inline bool sgemm_vecmat_ok(int M, int N, int K, int64_t sBn) { return M == 1 && sBn == 1 && N >= 64 && K >= 64; }
 
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st, const float* amax_a, int amax_na, const float* amax_b,
@@ -1612,6 +1612,7 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         ks = ks > 32 ? 32 : ks;                                                        // (rows_sum_kernel: 32 row slices)
         const int fit = (int)(sgemm_splitk_need_floats(M, N, K) / (size_t)N);          // (whichever path sized the caller's scratch)
         ks = ks > fit ? (fit > 0 ? fit : 1) : ks;
+        if (K < 512) ks = 1;                                                           // (a batch-100-sized reduction: one launch straight into C)
         int kper = (K + ks - 1) / ks;
         kper = (kper + 31) & ~31;
         ks = (K + kper - 1) / kper;
