@@ -85,7 +85,8 @@ def stgcn_tiled_shapes(dev, steps=10):
             del algo, X, y
         out[name] = entry
     out["profile"] = "profiles/r05_stgcn_tiled_xjtu_bs1024_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/time_tiled_one.py: 5 large GEMMs at " \
-                     "124-172 TFLOP/s = 45 % of the step's kernel time, the position-parallel kernels between them most of the rest; kernel by kernel: " \
+                     "185-236 TFLOP/s (two-plane f16 split with operand scales) = 37 % of the step's kernel time, the position-parallel kernels between them " \
+                     "most of the rest; kernel by kernel: " \
                      "profiles/r05_tiled_path_and_load_chains.md)"
     return out
 
