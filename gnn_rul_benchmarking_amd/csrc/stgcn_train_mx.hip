@@ -475,6 +475,9 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         if constexpr (KIND == PH_TOP) {
             // ===== last layer, head, loss, head backward ===================================================================================
             float xh1[4][3], y2[4][3];
+            // (this row's label, requested before the last layer's forward: read where it is used -- `if (rowok) ... a.y[s0 + g]`, a load
+            // under a condition -- it was a memory round trip per tile in the middle of the kernel)
+            const float ylab = a.y[s0 + (g < ns ? g : ns - 1)];
             layer_full(X, adjB, kc, dkey[LY], sbase, &xh1, &y2, nullptr, &pend_m);
             // max over the ten channels with its arg-max: per lane over its (up to three) channels, then across the four lane groups
             float pm[4], pa[4];
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
             const float pred = Row<16>::allsum(y1 * fc2w) + fc2b;
             float dpred = 0.f;                                             // x S
             if (rowok) {
-                const float diff = pred - a.y[s0 + g];
+                const float diff = pred - ylab;
                 dpred = 2.f * diff * inv_gb * a.gscale;
                 if (col == 0) acc_loss = fmaf(diff, diff, acc_loss);
             }
