@@ -1857,9 +1857,39 @@ __global__ void fc_bn_running_kernel(FcGeom g, float* __restrict__ bn, const flo
 
 __global__ void fc_fill_one_kernel(float* p) { p[0] = 1.f; }
 
+// the head of the side stream in one launch (it was three): the constant for the bias column sums, the batch statistics for the caller's
+// bucket, and -- when the caller keeps plain (mean, var) there -- the running-statistics update from the same cells
+__global__ void fc_side_head_kernel(FcGeom g, const Cells* cells, float* __restrict__ one, float* __restrict__ bn_batch, float weight,
+                                    float* __restrict__ bn_running, float momentum) {
+    if (threadIdx.x == 0) one[0] = 1.f;
+    for (int id = 0; id < NBN; ++id)
+        for (int c = threadIdx.x; c < g.bn_ch[id]; c += blockDim.x) {
+            const double m = cell_fwd(cells, id, c, 0) / g.cnt[id], q = cell_fwd(cells, id, c, 1) / g.cnt[id];
+            float* mean = bn_batch + g.bn_off[id] + c;
+            float* var = mean + g.bn_ch[id];
+            if (weight > 0.f) {
+                *mean = (float)(weight * m);
+                *var = (float)(weight * q);
+            } else {
+                const double v = q - m * m;
+                const float mf = (float)m, vf = (float)(v < 0.0 ? 0.0 : v);
+                *mean = mf;
+                *var = vf;
+                if (bn_running) {                                   // (fc_bn_running_kernel's arithmetic on the values just written)
+                    const double n = g.cnt[id];
+                    const float unbiased = n > 1.0 ? (float)(vf * (n / (n - 1.0))) : vf;
+                    float* rm = bn_running + g.bn_off[id] + c;
+                    float* rv = rm + g.bn_ch[id];
+                    *rm = (1.0f - momentum) * *rm + momentum * mf;
+                    *rv = (1.0f - momentum) * *rv + momentum * unbiased;
+                }
+            }
+        }
+}
+
 struct FcWs {
     size_t cells, one, z1, z2, a2, z3, F, Mm[2], P[2], AX[2], z5[2], feat, h1, h2, h3, dpred, sqerr;
-    size_t dh3, dh2, dh1, dfeat, dAX[2], dz5[2], gX[2], gM[2], dMb[2], dF, da2, dy1, gp1, gp2, split, total;
+    size_t dh3, dh2, dh1, dfeat, dAX[2], dz5[2], gX[2], gM[2], dMb[2], dF, da2, dy1, gp1, gp2, split, total, split_floats;
     int rows;
 };
 
@@ -1913,6 +1943,15 @@ void fc_ws_layout(const FcGeom& g, FcWs* w) {
     for (int b = 0; b < 2; ++b) { need(g.HD, g.D2, g.G[b] * g.Q); need(g.HD, g.D2 + 1, g.G[b] * g.Q); need(1, g.HD, g.G[b] * g.Q); }
     need(g.D2, g.D2, g.M); need(g.D2, g.D2 + 1, g.M); need(1, g.D2, g.M); need(g.D2, g.CL, g.M); need(g.D2, g.CL + 1, g.M);
     need((int)g.B, g.D2, g.FIN);                        // fc1 forward
+    {   // the five batched weight-gradient products of the backward keep their partial rows side by side
+        SplitKColsumJob j[5] = {};
+        for (int b = 0; b < 2; ++b) { j[b].M = g.HD; j[b].N = g.D2; j[b].K = (int)(g.G[b] * g.Q); }
+        for (int b = 0; b < 2; ++b) { j[2 + b].M = g.D2; j[2 + b].N = g.D2; j[2 + b].K = (int)g.M; }
+        j[4].M = g.D2; j[4].N = g.CL; j[4].K = (int)g.M;
+        const size_t v = sgemm_splitk_colsum_batch_floats(j, 5);
+        if (v > mx) mx = v;
+    }
+    w->split_floats = mx;
     w->split = take(mx);
     w->total = o;
 }
@@ -2104,6 +2143,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         float* gr = a->grads;
         float* split = P_(w.split);
         float* one = P_(w.one);
+        SplitKColsumJob wjobs[5];
+        int nwj = 0;
         // Weight / bias gradient GEMMs: nothing in this call reads their results, and each is a ~6-19 us launch at its latency floor.
         // With a second stream of the caller (args->aux_stream, aux_stream.hpp) they leave the critical path; they share the split-K
         // scratch and therefore one stream.
@@ -2118,12 +2159,11 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         // (the host enqueues in program order: the MAIN stream's next kernel goes out before the dozen side-stream launches behind this fork
         // -- with the side launches first the main queue sat empty for ~30 us while the host enqueued them; same at every fork below)
         if (mlp_fused) FC_RC(sgemm(P_(w.dh1), D2, 1, prm + g.o_f1w, 1, FIN, P_(w.dfeat), FIN, Bi, FIN, D2, false, st, bf));
-        hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, wst, one);
-        if ((mode & 1) && training && a->bn_batch) {
-            hipLaunchKernelGGL(fc_bn_batch_kernel, dim3(1), dim3(64), 0, wst, g, (const Cells*)cells, a->bn_batch, a->bn_moment_weight);
-            if (bn_running_out && a->bn_moment_weight == 0.f)
-                hipLaunchKernelGGL(fc_bn_running_kernel, dim3(1), dim3(64), 0, wst, g, bn_running_out, (const float*)a->bn_batch, bn_momentum, 0);
-        }
+        if ((mode & 1) && training && a->bn_batch)
+            hipLaunchKernelGGL(fc_side_head_kernel, dim3(1), dim3(64), 0, wst, g, (const Cells*)cells, one, a->bn_batch, a->bn_moment_weight,
+                               (bn_running_out && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr, bn_momentum);
+        else
+            hipLaunchKernelGGL(fc_fill_one_kernel, dim3(1), dim3(1), 0, wst, one);
         // (batches of the reference protocol's size: every MLP parameter gradient and the loss sum in one launch, fc_mlp_wgrad_kernel)
         const bool mlp_wgrad_fused = mlp_fused && g.B <= FC_MLPW_MAXB && D2 <= 64;
         if (!a->dpred && a->loss && !mlp_wgrad_fused) (void)block_sum((const float*)P_(w.sqerr), (int64_t)g.B, a->loss, wst);
@@ -2190,7 +2230,6 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             FC_RC(sync_pair(1, 6));
             hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(Gmax * g.Q * HD), 2), dim3(FB), 0, st, g, 4, prm, (const Cells*)cells, z5p, dz5p,
                                GQ0, GQ1);
-            fork();
             const bool bwd_fused = graph_mx && D2 == 2 * HD;          // d AX = d z5 W_theta inside the graph kernel
             if (!bwd_fused)
                 for (int b = 0; b < 2; ++b)
@@ -2224,13 +2263,12 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             }
             hipLaunchKernelGGL(fc_graph_gather_kernel, dim3(grid_for(g.M * D2), 2), dim3(FB), 0, st, g, CPtr2{{P_(w.dAX[0]), P_(w.dAX[1])}},
                                CPtr2{{P_(w.dMb[0]), P_(w.dMb[1])}}, Ptr2{{P_(w.gX[0]), P_(w.gX[1])}}, Ptr2{{P_(w.gM[0]), P_(w.gM[1])}});
-            // (weight gradient and the bias gradient over the same rows: one split-K pass, sgemm_splitk_colsum; enqueued behind the main
-            // stream's graph kernels, which it runs beside)
+            // (weight gradient and the bias gradient over the same rows: one split-K pass with the bias sums as an extra column.  The five
+            // such products of the backward -- theta and mapping of both window blocks, the projection -- are collected and go out as ONE
+            // pair of launches behind the last of their inputs (sgemm_splitk_colsum_batch): they were ten launches, the tail of the side stream)
             for (int b = 0; b < 2; ++b)
-                FC_RC(sgemm_splitk_colsum(P_(w.dz5[b]), 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, (int)(g.G[b] * g.Q), gr + g.o_thb[b], one,
-                                          split, wst));
+                wjobs[nwj++] = SplitKColsumJob{P_(w.dz5[b]), 1, HD, P_(w.AX[b]), 1, D2, gr + g.o_th[b], D2, HD, D2, (int)(g.G[b] * g.Q), gr + g.o_thb[b]};
         }
-        fork();
         hipLaunchKernelGGL(fc_feat_stats_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.F),
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]));
         FC_RC(sync_pair(1, 3));
@@ -2240,7 +2278,7 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                            (const float*)P_(w.gX[0]), (const float*)P_(w.gX[1]), (const float*)P_(w.gM[0]), (const float*)P_(w.gM[1]),
                            (const float*)P_(w.z3), P_(w.dF), thr, dscale, key, key_dev, row_off);
         for (int b = 0; b < 2; ++b)
-            FC_RC(sgemm_splitk_colsum(P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b], one, split, wst));
+            wjobs[nwj++] = SplitKColsumJob{P_(w.gM[b]), 1, D2, P_(w.F), 1, D2, gr + g.o_map[b], D2, D2, D2, Mi, gr + g.o_bmap[b]};
         FC_RC(sync_pair(1, 2));
         hipLaunchKernelGGL(fc_bn_rows_bwd_kernel, dim3(grid_for(g.M * D2)), dim3(FB), 0, st, g, 2, prm, (const Cells*)cells,
                            CPtr2{{P_(w.z3), nullptr}}, Ptr2{{P_(w.dF), nullptr}}, g.M, (int64_t)0);
@@ -2254,7 +2292,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             hipLaunchKernelGGL(fc_act2_bwd_kernel, dim3(grid_for(g.M * CL)), dim3(FB), 0, st, g, prm, cells, (const float*)P_(w.z2),
                                (const float*)P_(w.a2), P_(w.da2));
         }
-        FC_RC(sgemm_splitk_colsum(P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3, one, split, wst));
+        wjobs[nwj++] = SplitKColsumJob{P_(w.dF), 1, D2, P_(w.a2), 1, CL, gr + g.o_W3, CL, D2, CL, Mi, gr + g.o_b3};
+        FC_RC(sgemm_splitk_colsum_batch(wjobs, nwj, one, split, w.split_floats, wst));
         FC_RC(sync_pair(1, 1));
         // (BatchNorm 1's and BatchNorm 0's channel-major backward passes ride in the loads of the kernels that consume them)
         // the second convolution's weight gradient needs d z2 (final here) and the forward statistics only: beside the rest of the chain

@@ -1429,7 +1429,7 @@ static __global__ __launch_bounds__(256) void sgemm_longk_kernel(GemmArgs g, int
 // barrier.  The LDS kernel above ran 18-44 us per launch beside the families' backward chains (FC_STGNN: five of them were the step's
 // critical path); this one is bound by the rows it reads.
 template <int MT, int NT>
-static __global__ __launch_bounds__(256) void sgemm_longk_mfma_kernel(GemmArgs g, int kper, int ones, int nwaves) {
+static __device__ __forceinline__ void sgemm_longk_mfma_body(const GemmArgs& g, int kper, int ones, int nwaves) {
     const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= nwaves) return;
     const int li = lane & 15, kq = lane >> 4;
@@ -1488,6 +1488,22 @@ static __global__ __launch_bounds__(256) void sgemm_longk_mfma_kernel(GemmArgs g
                 const int m = 16 * i + 4 * kq + r, n = 16 * j + li;
                 if (m < g.M && n < g.N) out[m * g.N + n] = acc[i][j][r];
             }
+}
+template <int MT, int NT>
+static __global__ __launch_bounds__(256) void sgemm_longk_mfma_kernel(GemmArgs g, int kper, int ones, int nwaves) {
+    sgemm_longk_mfma_body<MT, NT>(g, kper, ones, nwaves);
+}
+// several such products of ONE tile shape in one launch (blockIdx.y = product): FC_STGNN's five weight-gradient pairs were ten launches at
+// the tail of its side stream
+constexpr int LONGK_BATCH_MAX = 6;
+struct LongkBatch {
+    GemmArgs g[LONGK_BATCH_MAX];
+    int kper[LONGK_BATCH_MAX], nwaves[LONGK_BATCH_MAX];
+};
+template <int MT, int NT>
+static __global__ __launch_bounds__(256) void sgemm_longk_mfma_batch_kernel(LongkBatch b, int ones) {
+    const int j = blockIdx.y;
+    sgemm_longk_mfma_body<MT, NT>(b.g[j], b.kper[j], ones, b.nwaves[j]);
 }
 static bool sgemm_longk_mfma_ok(const GemmArgs& g) { return g.sAm == 1 && g.sBn == 1 && g.M <= 32 && g.N <= 64; }
 static void sgemm_longk_mfma_launch(const GemmArgs& g, int kper, int ones, int nwaves, hipStream_t st) {
@@ -1676,6 +1692,93 @@ int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B
     const int rc = sgemm_splitk(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, false, partial, st);
     if (rc != RULGNN_OK) return rc;
     return sgemm_splitk(ones, 0, 0, A, sAm, sAk, colsum, M, 1, M, K, false, partial, st);
+}
+
+struct LongkReduceBatch {
+    const float* partial[LONGK_BATCH_MAX];
+    float* C[LONGK_BATCH_MAX];
+    float* colsum[LONGK_BATCH_MAX];
+    int64_t ldc[LONGK_BATCH_MAX];
+    int M[LONGK_BATCH_MAX], N[LONGK_BATCH_MAX], nblk[LONGK_BATCH_MAX];
+};
+static __global__ __launch_bounds__(256) void sgemm_longk_reduce_batch_kernel(LongkReduceBatch r) {
+    const int j = blockIdx.y;
+    const int M = r.M[j], N = r.N[j], nblk = r.nblk[j];
+    const int o = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (o >= M * N) return;
+    const float* partial = r.partial[j];
+    float a = 0.f;
+    for (int b = lane; b < nblk; b += 64) a += partial[(int64_t)b * M * N + o];                      // (same order as sgemm_longk_reduce_kernel)
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+    if (lane == 0) {
+        const int mi = o / N, nj = o % N;
+        if (nj == N - 1) r.colsum[j][mi] = a;
+        else r.C[j][(int64_t)mi * r.ldc[j] + nj] = a;
+    }
+}
+// sgemm_splitk_colsum for several products at once: where every one of them is a long-k product of the same matrix-core tile shape (and the
+// scratch holds all their partial rows) two launches serve them all -- bit-identical to the separate calls; otherwise the calls one by one
+size_t sgemm_splitk_colsum_batch_floats(const SplitKColsumJob* jobs, int n) {
+    size_t tot = 0, mx = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t v = sgemm_splitk_need_floats(jobs[i].M, jobs[i].N + 1, jobs[i].K), w = sgemm_splitk_need_floats(jobs[i].M, jobs[i].N, jobs[i].K);
+        const size_t u = sgemm_splitk_need_floats(jobs[i].M, 1, jobs[i].K);
+        tot += v;
+        mx = mx > v ? mx : v; mx = mx > w ? mx : w; mx = mx > u ? mx : u;
+    }
+    return tot > mx ? tot : mx;
+}
+int sgemm_splitk_colsum_batch(const SplitKColsumJob* jobs, int n, const float* ones, float* partial, size_t partial_floats, hipStream_t st) {
+    bool batch = n >= 2 && n <= LONGK_BATCH_MAX;
+    int MT0 = 0, NT0 = 0;
+    size_t tot = 0;
+    for (int i = 0; i < n && batch; ++i) {
+        const SplitKColsumJob& q = jobs[i];
+        const int NE = q.N + 1;
+        if (q.M <= 0 || q.N <= 0 || sgemm_tiny_ok(q.M, q.N, q.K) || sgemm_longk_blocks(q.M, NE, q.K) <= 0 || q.sAm != 1 || q.sBn != 1 || q.M > 32 || NE > 64) {
+            batch = false;
+            break;
+        }
+        const int MT = (q.M + 15) / 16, NT = (NE + 15) / 16;
+        if (i == 0) { MT0 = MT; NT0 = NT; }
+        else if (MT != MT0 || NT != NT0) batch = false;
+        tot += sgemm_splitk_need_floats(q.M, NE, q.K);
+    }
+    if (!batch || tot > partial_floats) {
+        for (int i = 0; i < n; ++i) {
+            const SplitKColsumJob& q = jobs[i];
+            const int rc = sgemm_splitk_colsum(q.A, q.sAm, q.sAk, q.B, q.sBn, q.sBk, q.C, q.ldc, q.M, q.N, q.K, q.colsum, ones, partial, st);
+            if (rc != RULGNN_OK) return rc;
+        }
+        return RULGNN_OK;
+    }
+    LongkBatch lb{};
+    LongkReduceBatch rb{};
+    float* part = partial;
+    int maxw = 0, maxo = 0;
+    for (int i = 0; i < n; ++i) {
+        const SplitKColsumJob& q = jobs[i];
+        const int NE = q.N + 1;
+        int nblk = sgemm_longk_blocks(q.M, NE, q.K);
+        int kper = (q.K + nblk - 1) / nblk;
+        kper = (kper + SKT_ROWS - 1) / SKT_ROWS * SKT_ROWS;
+        nblk = (q.K + kper - 1) / kper;
+        lb.g[i] = GemmArgs{q.A, q.sAm, q.sAk, q.B, q.sBn, q.sBk, part, NE, q.M, NE, q.K, 0, kper};
+        lb.kper[i] = kper; lb.nwaves[i] = nblk;
+        rb.partial[i] = part; rb.C[i] = q.C; rb.colsum[i] = q.colsum; rb.ldc[i] = q.ldc; rb.M[i] = q.M; rb.N[i] = NE; rb.nblk[i] = nblk;
+        part += sgemm_splitk_need_floats(q.M, NE, q.K);
+        maxw = nblk > maxw ? nblk : maxw;
+        maxo = q.M * NE > maxo ? q.M * NE : maxo;
+    }
+    (void)hipGetLastError();
+    const dim3 grid((maxw + 3) / 4, n), block(256);
+#define RULGNN_LKB(mt, nt) hipLaunchKernelGGL((sgemm_longk_mfma_batch_kernel<mt, nt>), grid, block, 0, st, lb, 1)
+    if (MT0 == 1) { if (NT0 == 1) RULGNN_LKB(1, 1); else if (NT0 == 2) RULGNN_LKB(1, 2); else if (NT0 == 3) RULGNN_LKB(1, 3); else RULGNN_LKB(1, 4); }
+    else { if (NT0 == 1) RULGNN_LKB(2, 1); else if (NT0 == 2) RULGNN_LKB(2, 2); else if (NT0 == 3) RULGNN_LKB(2, 3); else RULGNN_LKB(2, 4); }
+#undef RULGNN_LKB
+    hipLaunchKernelGGL(sgemm_longk_reduce_batch_kernel, dim3((maxo + 3) / 4, n), dim3(256), 0, st, rb);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
 // out[e] = sum_r part[r][e] over `rows` per-workgroup partial rows of n values (row stride ld): 32 columns x 32 row slices per

@@ -36,6 +36,18 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
 int sgemm_splitk_colsum(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, float* colsum, const float* ones, float* partial, hipStream_t st);
 
+// ... for several (A, B) pairs at once (the same results; two launches for all of them where every pair is a long-k product of one tile
+// shape); `partial`: sgemm_splitk_colsum_batch_floats(jobs, n) floats
+struct SplitKColsumJob {
+    const float* A; int64_t sAm, sAk;
+    const float* B; int64_t sBn, sBk;
+    float* C; int64_t ldc;
+    int M, N, K;
+    float* colsum;
+};
+size_t sgemm_splitk_colsum_batch_floats(const SplitKColsumJob* jobs, int n);
+int sgemm_splitk_colsum_batch(const SplitKColsumJob* jobs, int n, const float* ones, float* partial, size_t partial_floats, hipStream_t st);
+
 // out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
 int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st);
