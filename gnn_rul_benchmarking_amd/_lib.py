@@ -29,7 +29,7 @@ class StgcnTrainArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("global_batch", C.c_int64), ("sample_offset", C.c_int64),
                 ("dropout_p", C.c_float), ("seed", C.c_uint64), ("step", C.c_uint64),
-                ("bn_moment_weight", C.c_float), ("step_state", C.c_void_p), ("flags", C.c_uint32)]
+                ("bn_moment_weight", C.c_float), ("step_state", C.c_void_p), ("flags", C.c_uint32), ("aux_stream", C.c_void_p)]
 
 
 class AdamArgs(C.Structure):

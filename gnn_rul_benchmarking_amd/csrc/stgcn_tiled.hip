@@ -10,6 +10,7 @@
 #include "stgcn_device.hpp"
 #include "stgcn_host.hpp"
 #include "sgemm_mfma.hpp"
+#include "aux_stream.hpp"
 
 namespace rulgnn {
 
@@ -1034,7 +1035,7 @@ struct TWs {
     size_t T, total;
     size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
     size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
-    size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split;
+    size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split, off_split2;
     size_t off_amax;            // [3 L + 3][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l| and |fc1.weight|, |d Hpre_l|, |pooled|, |d y1|
                                 // (the operand scales of the GEMMs)
     size_t cells_bytes;
@@ -1056,7 +1057,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_Hpre = o; o += w->T;
     w->off_gsum = o; o += w->T;
     w->off_gsum0 = o; o += w->T;
-    w->off_dH = o; o += w->T;
+    w->off_dH = o; o += (size_t)L * w->T;          // per layer: the side stream's d theta product of layer l reads it while layer l - 1 runs
     w->off_dAX = o; o += w->T;
     w->off_dX = o; o += w->T;
     const size_t BNb = al256((size_t)B * N * 4);
@@ -1082,6 +1083,7 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
                              R < 2048 ? sgemm_splitk_need_floats(R, N, N) : (size_t)0})
                 need = v > need ? v : need;
         w->off_split = o; o += al256(need * sizeof(float));
+        w->off_split2 = o; o += al256(need * sizeof(float));          // the side stream's own (parameter-gradient products)
     }
     w->total = o;
 }
@@ -1103,7 +1105,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     char* ws = static_cast<char*>(ar->workspace);
     auto TP = [&](size_t off, int l) { return reinterpret_cast<float*>(ws + off + (size_t)l * w.T); };
     float* Hpre = TP(w.off_Hpre, 0); float* gsum = TP(w.off_gsum, 0); float* gsum0 = TP(w.off_gsum0, 0);
-    float* dHp = TP(w.off_dH, 0); float* dAX = TP(w.off_dAX, 0); float* dX = TP(w.off_dX, 0);
+    float* dAX = TP(w.off_dAX, 0); float* dX = TP(w.off_dX, 0);
     float* A = reinterpret_cast<float*>(ws + w.off_A);
     float* pooled = reinterpret_cast<float*>(ws + w.off_pooled);
     float* y1pre = reinterpret_cast<float*>(ws + w.off_y1pre);
@@ -1115,7 +1117,16 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     float* gpart = reinterpret_cast<float*>(ws + w.off_gpart);
     float* one = reinterpret_cast<float*>(ws + w.off_one);
     float* split = reinterpret_cast<float*>(ws + w.off_split);
+    float* split2 = reinterpret_cast<float*>(ws + w.off_split2);
     const float* prm = ar->params;
+    // Parameter-gradient products (d fc1 / fc2, d theta of every layer and their bias sums: ~290 us of matrix-core work per step at XJTU-SY
+    // batch 1024) feed nothing downstream in this call: with a second stream of the caller (args->aux_stream) they run BESIDE the
+    // position-parallel chain, which is bound by HBM while they are bound by the matrix pipe and LDS.  Not with a gradient-ready callback
+    // (data parallel with overlap): its contract orders the caller's all-reduces against `stream`.
+    // ... nor at batch-100-sized row counts: there every launch sits at its latency floor and the fork / join events cost more than the
+    // overlap returns (XJTU-SY batch 100: 0.38 -> 0.40 ms with it, batch 1024: 1.24 -> 1.22 ms).
+    AuxFork fk(stream, (ready || B * F < 2048) ? nullptr : ar->aux_stream);
+    hipStream_t wst = fk.side();
     // operand scales of the large GEMMs: partial maxima rows, one float per workgroup of the producing launch.  The scaled form only where
     // the producers' grids fit a row (every reference wiring does: <= 4096 chunks of 256 positions)
     float* amax = reinterpret_cast<float*>(ws + w.off_amax);
@@ -1203,20 +1214,21 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
 
     if (mode != 0) {
         float* g = ar->grads;
+        fk.fork();
         // fc2: dW2[j] = sum_b dpred[b] y1[b][j];  db2 = sum_b dpred[b]
-        rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split, stream);
+        rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split2, wst);
         if (rc != RULGNN_OK) return rc;
         // (db2 = sum_b dpred[b]: accumulated by the head kernel, written by the finalize kernel)
         // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
-        rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split, stream, am_dy1, (int)B,
+        rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split2, wst, am_dy1, (int)B,
                           am_dy1 ? am_pool : (float*)nullptr, n_pos);
         if (rc != RULGNN_OK) return rc;
-        rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split, stream);
+        rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split2, wst);
         if (rc != RULGNN_OK) return rc;
         // data parallel with overlap: the head's gradients (fc1 is N x N: 4 MB at XJTU-SY) are final here, with the whole layer
         // stack still to run -- the caller may start their all-reduce on another stream (include/rulgnn.h: rulgnn_grad_ready_fn)
         // (without fc2.bias, the last parameter: its gradient comes out of the finalize kernel with the convolution / BatchNorm ones)
-        if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(off_fc2_b(N, L) - off_fc1_w(N, L)), stream) != 0)
+        if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(off_fc2_b(N, L) - off_fc1_w(N, L)), wst) != 0)
             return RULGNN_ECALLBACK;
         rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream, am_dy1, (int)B,
                           am_dy1 ? am_th(L) : (float*)nullptr, n_th);
@@ -1230,30 +1242,37 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                      l == L - 1 ? 1 : 0, t);
             T_LAUNCH_P(t_conv2_bwd_kernel, BN_, gsum, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_z1, l), pl, gsum0,
                      gpart + (size_t)(2 * l + 1) * w.grid * CONVW, 2 * l + 1, t);
+            float* dHp = TP(w.off_dH, l);
             T_LAUNCH_P(t_conv1_bwd_kernel, BN_, gsum0, TP(w.off_z1, l), TP(w.off_H, l), pl, dHp,
                      gpart + (size_t)(2 * l) * w.grid * CONVW, 2 * l, t, am_dh(l));
-            // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
-            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split, stream, am_dh(l), n_dh, am_ax(l),
-                              l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
-            if (rc != RULGNN_OK) return rc;
-            rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
-            if (rc != RULGNN_OK) return rc;
-            // theta of this layer (weight + bias, contiguous at the head of the layer's block) is final; the convolution and
-            // BatchNorm gradients behind it (2 x 220 floats) come out of t_finalize_kernel at the end of the step
-            if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, stream) != 0)
-                return RULGNN_ECALLBACK;
+            fk.fork();
+            // (the main stream's next product first: the host enqueues in program order.  The side stream's d theta product then runs
+            // beside d(A.X); started behind it instead -- beside the HBM-bound kernels of the layer below -- the step is 4 % SLOWER)
             if (l > 0) {
                 if (few_rows)
                     rc = sgemm_splitk(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, split, stream, am_dh(l), n_dh, am_th(l), n_th);
                 else
                 rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream, 0, am_dh(l), n_dh, am_th(l), n_th);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;
+            }
+            // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
+            rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split2, wst, am_dh(l), n_dh, am_ax(l),
+                              l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
+            if (rc != RULGNN_OK) return rc;
+            rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split2, wst);
+            if (rc != RULGNN_OK) return rc;
+            // theta of this layer (weight + bias, contiguous at the head of the layer's block) is final; the convolution and
+            // BatchNorm gradients behind it (2 x 220 floats) come out of t_finalize_kernel at the end of the step
+            if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, wst) != 0)
+                return RULGNN_ECALLBACK;
+            if (l > 0) {
                 // (A^T dAX + dXn, A symmetric.  Folded into the tail kernel of the layer below it cost more there -- 100 adjacency loads and
                 // 100 FMAs per position inside the persistent loop: +22 us -- than this launch takes)
                 T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a, (float*)nullptr);
             }
         }
     }
+    if (fk.join() != RULGNN_OK) return RULGNN_EHIP;            // the parameter gradients are final in `stream` order from here
     TFin f;
     f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd;
     f.grads = ar->grads; f.loss = ar->loss; f.bn_batch = ar->bn_batch;

@@ -109,6 +109,7 @@ class ST_GCN_model(FlatModule):
         self._last_chain = _lib.STEP_CHAIN   # what the latest whole step resolved to (guard_tensor / retry_on_fp32_chain)
         self._clean_ws = None                # the workspace a matrix-core whole step left clean (see _train_args)
         self._tape_step = {}            # batch size -> step whose activations its workspace holds (autograd-path hazard check)
+        self.side_stream = PL.SideStream()   # tiled path: parameter-gradient products beside the backward chain (aux_stream)
         self.k = int(k)
         in_features = NUM_STATS
         # same construction order as the reference => same RNG consumption => same initial weights
@@ -222,6 +223,8 @@ class ST_GCN_model(FlatModule):
         # RULGNN_TRAIN_WS_CLEAN: a whole step on the matrix-core chain leaves the reduction cells zero; when the LAST use of this very
         # workspace was such a step, the next one runs without its prepare launch (any other use of the workspace drops the claim)
         a.flags = _lib.TRAIN_WS_CLEAN if (whole_step and self._clean_ws is ws and self._step_state is None) else 0
+        # the tiled path's parameter-gradient products beside its backward chain (include/rulgnn.h: aux_stream; the fused chains ignore it)
+        a.aux_stream = self.side_stream.pointer(self._flat.device, True) if (self.num_patch > 64 and self._flat.is_cuda) else None
         self._clean_ws = None
         return a
 

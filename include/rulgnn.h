@@ -126,6 +126,11 @@ typedef struct rulgnn_stgcn_train_args {
                                 w*(E[z], E[z^2]) so that a SUM all-reduce over ranks yields the global-batch moments */
     void *step_state;        /* optional device step state (see rulgnn_step_state_set); NULL = use `step` above */
     uint32_t flags;          /* RULGNN_TRAIN_* bits, 0 = none */
+    void *aux_stream;        /* optional second HIP stream of the caller (NULL: everything on `stream`).  The tiled path (num_patch > 64) runs its
+                                parameter-gradient products (d fc1 / fc2, d theta of every layer, their bias sums) on it beside the
+                                position-parallel backward chain and makes `stream` wait for it before the call's last kernel: the caller's
+                                stream semantics do not change.  Ignored by the fused chains and when a gradient-ready callback is given.
+                                (round 5; the struct grew: rulgnn_stgcn_train_args_size()) */
 } rulgnn_stgcn_train_args;
 /* rulgnn_stgcn_train_step*_f32 / _fwdbwd*_f32 on the matrix-core chain (RULGNN_STEP_MX, also through RULGNN_STEP_AUTO) end with a finalize
  * kernel that leaves the workspace's reduction cells ZERO.  A caller that sets this bit vouches that the previous call that used
