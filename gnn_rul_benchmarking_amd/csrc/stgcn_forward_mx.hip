@@ -275,7 +275,10 @@ __global__ __launch_bounds__(64, MX_WAVES_PER_SIMD) void stgcn_forward_mx_kernel
                 wc[r] = ok ? taps2.y * wsc : 0.f;     // tap at t
                 wd[r] = ok ? taps2.x * wsc : 0.f;     // tap at t - d
             }
-            if (g == 0) wc[3] = co >= 0 ? shift : 0.f;    // x the constant 1 that rides in slot 3 of the data operand
+            // x the constant 1 that rides in slot 3 of the data operand.  (A select, not `if (g == 0)`: mean and beta only feed `shift`,
+            // and under the `if` the compiler sank their two loads into the branch behind a wait of their own -- four extra dependent
+            // memory round trips in front of the first tile.)
+            wc[3] = g == 0 ? (co >= 0 ? shift : 0.f) : wc[3];
             const Split2 c01 = split2(wc[0], wc[1]), c23 = split2(wc[2], wc[3]), d01 = split2(wd[0], wd[1]), d23 = split2(wd[2], wd[3]);
             ops[l].w_hi[blk] = u32x4{c01.hi, c23.hi, d01.hi, d23.hi};
             ops[l].w_lo[blk] = u32x4{c01.lo, c23.lo, d01.lo, d23.lo};
