@@ -343,8 +343,11 @@ static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
     const size_t T = (size_t)s->batch * F * s->num_patch * sizeof(float);
     // X (ping), X (pong), AX, Hpre  +  A, pooled, y1pre, bnfold, the large GEMMs' operand scales (partial maxima of A.X and of theta_l)
+    // (+ split-K scratch of the theta / fc1 products at batch-100-sized row counts: too few output tiles for the large kernels otherwise)
+    const int64_t R = s->batch * F;
+    const size_t sk = R > 0 && R < 2048 ? sgemm_splitk_need_floats((int)R, s->num_patch, s->num_patch) : 0;
     return 4 * al256(T) + al256((size_t)s->batch * F * F * 4) + 2 * al256((size_t)s->batch * s->num_patch * 4) +
-           al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(1 + s->num_layers) * T_AMAX_MAX * sizeof(float));
+           al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(1 + s->num_layers) * T_AMAX_MAX * sizeof(float)) + al256(sk * sizeof(float));
 }
 
 // (persistent kernels: at most T_PGRID workgroups)
@@ -384,7 +387,9 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* pooled = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* y1pre = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* bnf = reinterpret_cast<float*>(w); w += al256((size_t)L * 4 * F * 4);
-    float* amax = reinterpret_cast<float*>(w);                          // [1 + L][T_AMAX_MAX]: A.X of the current layer, theta of every layer
+    float* amax = reinterpret_cast<float*>(w); w += al256((size_t)(1 + L) * T_AMAX_MAX * sizeof(float));   // A.X of the current layer, theta of every layer
+    float* split = reinterpret_cast<float*>(w);
+    const bool few_rows = B * F < 2048;
     const int n_pos = (int)((BN_ + 255) / 256), n_th = 256;
     const bool scaled = n_pos <= T_AMAX_MAX;
 
@@ -404,8 +409,13 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     for (int l = 0; l < L; ++l) {
         const float* pl = prm + l * LS;
         T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, scaled ? amax : (float*)nullptr);
-        int rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
-                       n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);   // (A.X) theta^T
+        int rc;                                                                                  // (A.X) theta^T
+        if (few_rows)
+            rc = sgemm_splitk(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, split, stream, scaled ? amax : (float*)nullptr,
+                              n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);
+        else
+            rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
+                       n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);
         if (rc != RULGNN_OK) return rc;
         T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a);
         float* tmp = Xin; Xin = Xout; Xout = tmp;
