@@ -1269,7 +1269,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split2, wst, am_dh(l), n_dh, am_ax(l),
                               l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
             if (rc != RULGNN_OK) return rc;
-            rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split2, wst);
+            // (the first layer's bias sums on the MAIN stream: it has nothing left to do there while the side stream works through that
+            // layer's d theta, the last product of the step)
+            if (l == 0) rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
+            else rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split2, wst);
             if (rc != RULGNN_OK) return rc;
             // theta of this layer (weight + bias, contiguous at the head of the layer's block) is final; the convolution and
             // BatchNorm gradients behind it (2 x 220 floats) come out of t_finalize_kernel at the end of the step
@@ -1282,7 +1285,6 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             }
         }
     }
-    if (fk.join() != RULGNN_OK) return RULGNN_EHIP;            // the parameter gradients are final in `stream` order from here
     TFin f;
     f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd;
     f.grads = ar->grads; f.loss = ar->loss; f.bn_batch = ar->bn_batch;
@@ -1292,7 +1294,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     f.write_grads = mode != 0;          // forward only: just the batch statistics for the running-stat update
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L * TFIN_SUB), dim3(256), 0, stream, f);
-    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+    if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
+    // (the finalize kernel reads the chain's partial rows and cells only: it runs beside the side stream's last products; the parameter
+    // gradients are final in `stream` order from here)
+    return fk.join();
 }
 
 }  // namespace rulgnn
