@@ -703,11 +703,13 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)
         AST_RC(rows_sum3(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, F(w.thb), gr + g.o_thb, gr + g.o_gb,
                          bwd_rows, (int64_t)E, E, st));
-        AST_RC(fk.join());
+        // (the finalize kernel reads the cells and the squared errors only -- nothing the side stream writes: it runs in front of the join,
+        // beside the side stream's last product, instead of behind the wake-up of a stream that sat waiting)
         hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
                            ((mode & 1) && training) ? a->bn_batch : (float*)nullptr, a->bn_moment_weight, (const float*)F(w.sqerr),
                            (mse && a->loss) ? a->loss : (float*)nullptr,
                            ((mode & 1) && training && a->bn_batch && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr, bn_momentum);
+        AST_RC(fk.join());
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

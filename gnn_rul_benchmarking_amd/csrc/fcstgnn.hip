@@ -2313,11 +2313,12 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
         else
             hipLaunchKernelGGL((fc_conv_wgrad_both_kernel<>), dim3(rows, 2), dim3(FB), 0, st, g, a->x, prm, (const Cells*)cells,
                                (const float*)P_(w.z1), (const float*)P_(w.z2), (const float*)P_(w.dy1), (const float*)P_(w.da2), P_(w.gp1), P_(w.gp2));
-        FC_RC(fk.join());                                    // the gradient GEMMs are done before the call's last kernel
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
+        // (reads the convolutions' partial rows and the cells only: in front of the join, beside whatever the side stream still runs)
         hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
                            (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
+        FC_RC(fk.join());                                    // the gradient GEMMs are done when the call's work has drained
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
