@@ -6,17 +6,48 @@
 
 namespace rulgnn {
 
+__device__ __forceinline__ void adam_value(float& pi, float g, float& mi, float& vi, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
+                                           float beta2, float eps, float wd, float gscale) {
+    const float gi = fmaf(wd, pi, g * gscale);
+    mi = fmaf(beta1, mi, (1.f - beta1) * gi);
+    vi = fmaf(beta2, vi, (1.f - beta2) * gi * gi);
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi = pi - lr_over_bc1 * (mi / denom);
+}
 __device__ __forceinline__ void adam_element(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, int64_t i, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
                                              float beta2, float eps, float wd, float gscale) {
-    const float pi = p[i];
-    const float gi = fmaf(wd, pi, g[i] * gscale);
-    const float mi = fmaf(beta1, m[i], (1.f - beta1) * gi);
-    const float vi = fmaf(beta2, v[i], (1.f - beta2) * gi * gi);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_value(pi, g[i], mi, vi, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = pi - lr_over_bc1 * (mi / denom);
+    p[i] = pi;
+}
+
+// elements [0, n) among `stride` threads, this one being `tid`: 16-byte accesses where the four buffers allow (3.1 M parameters of the
+// XJTU-SY wiring: 16 us with 4-byte accesses), the same arithmetic per element either way
+__device__ __forceinline__ void adam_range(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                           int64_t n, int64_t tid, int64_t stride, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
+                                           float beta2, float eps, float wd, float gscale) {
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* m4 = reinterpret_cast<float4*>(m);
+        float4* v4 = reinterpret_cast<float4*>(v);
+        for (int64_t i = tid; i < n4; i += stride) {
+            float4 pp = p4[i], mm = m4[i], vv = v4[i];
+            const float4 gg = g4[i];
+            adam_value(pp.x, gg.x, mm.x, vv.x, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+            adam_value(pp.y, gg.y, mm.y, vv.y, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+            adam_value(pp.z, gg.z, mm.z, vv.z, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+            adam_value(pp.w, gg.w, mm.w, vv.w, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += stride) adam_element(p, g, m, v, i, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
 }
 
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -30,8 +61,8 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
         lr_over_bc1 = st->lr_over_bc1;
         inv_sqrt_bc2 = st->inv_sqrt_bc2;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        adam_element(p, g, m, v, i, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+    adam_range(p, g, m, v, n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, lr_over_bc1, inv_sqrt_bc2, beta1,
+               beta2, eps, wd, gscale);
 }
 
 __device__ __forceinline__ void bn_running_entry(float* __restrict__ bn, const float* __restrict__ batch, int i, float momentum,
@@ -68,9 +99,8 @@ __global__ void adam_bn_step_kernel(float* __restrict__ p, const float* __restri
         for (int i = threadIdx.x; i < n_bn * 2 * F; i += blockDim.x) bn_running_entry(bn, batch, i, momentum, unbias, from_moments);
         return;
     }
-    const int64_t stride = (int64_t)(gridDim.x - 1) * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        adam_element(p, g, m, v, i, lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale);
+    adam_range(p, g, m, v, n, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)(gridDim.x - 1) * blockDim.x, lr_over_bc1, inv_sqrt_bc2,
+               beta1, beta2, eps, wd, gscale);
 }
 
 __global__ void step_state_set_kernel(StepState* s, uint64_t dropout_step, int64_t adam_step) {

@@ -206,9 +206,14 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape* shape, const rulg
     if (rc != RULGNN_OK) return rc;
     if (opt->bn_stats && (reinterpret_cast<uintptr_t>(opt->bn_stats) & 3)) return RULGNN_EALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (tiled(shape)) {                                    // tiled path: same call, optimizer as separate kernels
+    if (tiled(shape)) {                                    // tiled path: same call, optimizer (+ running statistics) as one more kernel
         rc = stgcn_tiled_train(shape, args, 2, st);
         if (rc != RULGNN_OK) return rc;
+        if (opt->bn_stats && !opt->step_state)
+            return adam_bn_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, param_count(shape->num_patch, shape->num_layers),
+                                opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, opt->bn_stats, args->bn_batch,
+                                shape->num_layers, shape->batch * (int64_t)shape->num_patch, opt->bn_momentum,
+                                args->bn_moment_weight > 0.f ? 1 : 0, nullptr, st);
         rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq,
                        param_count(shape->num_patch, shape->num_layers), opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps,
                        opt->weight_decay, 1.0f, st, opt->step_state);

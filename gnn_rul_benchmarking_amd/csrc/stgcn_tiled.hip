@@ -180,8 +180,12 @@ __device__ __forceinline__ void t_amax_store(float m, float* part, float* lds4) 
     if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(lds4[0], lds4[1]), fmaxf(lds4[2], lds4[3]));
 }
 // ... and for a parameter matrix (theta of every layer: blockIdx.y = layer, gridDim.x partial maxima per layer)
-__global__ __launch_bounds__(256) void t_absmax_kernel(const float* __restrict__ prm, int64_t layer_stride_, int64_t off, int64_t n, float* part) {
+// (+ `nzero` doubles at `zero` cleared by the first row of workgroups: the step's reduction cells, which were a memset launch of their own)
+__global__ __launch_bounds__(256) void t_absmax_kernel(const float* __restrict__ prm, int64_t layer_stride_, int64_t off, int64_t n, float* part,
+                                                       double* __restrict__ zero, int nzero) {
     __shared__ float l4[4];
+    if (blockIdx.y == 0)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nzero; i += gridDim.x * 256) zero[i] = 0.0;
     const float* p = prm + blockIdx.y * layer_stride_ + off;
     float m = 0.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) m = fmaxf(m, t_finite_abs(p[e]));
@@ -397,7 +401,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     if (scaled) {
         (void)hipGetLastError();
         hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N,
-                           amax + T_AMAX_MAX);
+                           amax + T_AMAX_MAX, (double*)nullptr, 0);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
     T_STATS(x, Xa);
@@ -996,22 +1000,39 @@ struct TFin {
     float moment_weight;
     int write_loss, write_grads;
 };
-constexpr int TFIN_SUB = (CONVW + 3) / 4;      // workgroups per (layer, conv block): four weights each, one per wavefront
-__global__ __launch_bounds__(256) void t_finalize_kernel(TFin f) {
+constexpr int TFIN_SUB = (CONVW + 31) / 32;     // workgroups per (layer, conv block): 32 weights each
+__global__ __launch_bounds__(1024) void t_finalize_kernel(TFin f) {
     const int N = f.N, L = f.L, LS = layer_stride(N);
-    // (layer, conv block) x sub: 200 conv weights -- a wavefront per weight, lanes striding over the partial rows (one thread
-    // walking all of them took 1.5 ms at XJTU batch 1024), fixed-order butterfly -- and, in sub 0, the 20 BatchNorm parameters
+    // (layer, conv block) x sub: 200 conv weights -- lanes along the weights (the partial rows are read in 128-byte pieces), 32 row slices
+    // across the workgroup with four loads in flight each, combined through LDS in a fixed order (a wavefront per weight with its lanes
+    // striding over the rows was 18 us at the end of every step of the XJTU-SY wiring; one thread walking all rows 1.5 ms) -- and, in sub 0,
+    // the 20 BatchNorm parameters
+    __shared__ float red[32][33];
     const int bnidx = blockIdx.x / TFIN_SUB, sub = blockIdx.x % TFIN_SUB;
     const int l = bnidx / 2, blk = bnidx % 2;
     const float* gp = f.gpart + (size_t)bnidx * f.grid * CONVW;
     if (f.write_grads) {
-        const int p = sub * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int p = sub * 32 + col;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (p < CONVW) {
+            const float* q = gp + p;
+            int r = sl;
+            for (; r + 96 < f.grid; r += 128) {
+                a0 += q[(size_t)r * CONVW];
+                a1 += q[(size_t)(r + 32) * CONVW];
+                a2 += q[(size_t)(r + 64) * CONVW];
+                a3 += q[(size_t)(r + 96) * CONVW];
+            }
+            for (; r < f.grid; r += 32) a0 += q[(size_t)r * CONVW];
+        }
+        red[sl][col] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (sl == 0 && p < CONVW) {
             float v = 0.f;
-            for (int b = lane; b < f.grid; b += 64) v += gp[(size_t)b * CONVW + p];
 #pragma unroll
-            for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-            if (lane == 0) f.grads[l * LS + off_conv_w(N, blk) + p] = v;
+            for (int s2 = 0; s2 < 32; ++s2) v += red[s2][col];
+            f.grads[l * LS + off_conv_w(N, blk) + p] = v;
         }
     }
     if (sub != 0) return;
@@ -1176,12 +1197,13 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             rc = step_prepare_dropout(ar->step_state, ar->seed, L, stream);
             if (rc != RULGNN_OK) return rc;
         }
-        if (hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
+        if (!scaled && hipMemsetAsync(cells, 0, w.cells_bytes, stream) != hipSuccess) return RULGNN_EHIP;
         if (scaled) {
             (void)hipGetLastError();
             // (theta of every layer and, as "layer L" of the same stride, fc1.weight)
             static_assert(off_theta_w(1) == 0 && off_fc1_w(7, 3) == 3 * layer_stride(7), "fc1.weight sits where a layer-L theta would");
-            hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L + 1), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N, am_th(0));
+            hipLaunchKernelGGL(t_absmax_kernel, dim3(n_th, L + 1), dim3(256), 0, stream, prm, (int64_t)LS, (int64_t)off_theta_w(N), (int64_t)N * N, am_th(0),
+                               cells, (int)(w.cells_bytes / sizeof(double)));
             if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
         }
         T_STATS(ar->x, TP(w.off_X, 0));
@@ -1293,7 +1315,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     f.write_loss = (has_dpred == 0) && ar->loss && mode != 0;
     f.write_grads = mode != 0;          // forward only: just the batch statistics for the running-stat update
     (void)hipGetLastError();
-    hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L * TFIN_SUB), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL(t_finalize_kernel, dim3(2 * L * TFIN_SUB), dim3(1024), 0, stream, f);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     // (the finalize kernel reads the chain's partial rows and cells only: it runs beside the side stream's last products; the parameter
     // gradients are final in `stream` order from here)

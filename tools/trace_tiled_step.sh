@@ -8,7 +8,7 @@ import csv, glob
 f = glob.glob("gpurun_out/cp/**/k_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "adam_step" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "adam_" in r["Kernel_Name"]]
 lo, hi = idx[-2] + 1, idx[-1] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:hi]:
