@@ -75,6 +75,17 @@ constexpr int TP = MAXT + 4;
 __device__ __forceinline__ void fma4(float (&acc)[4], float a, const float4& b) {
     acc[0] = fmaf(a, b.x, acc[0]); acc[1] = fmaf(a, b.y, acc[1]); acc[2] = fmaf(a, b.z, acc[2]); acc[3] = fmaf(a, b.w, acc[3]);
 }
+// n <= CNT AB values src[tid + j AB] as ONE batch of loads: every load is issued before the first use.  A `for (e = tid; e < n; e += AB)
+// lds[...] = src[e]` loop waits for each load before its store -- ten L2 round trips of ~0.7 us in a row for a [50 x 50] weight matrix,
+// twenty in ast_front_kernel's prologue: half of that kernel's 27 us (profiles/r05_tiled_path_and_load_chains.md, section 1b).
+template <int CNT>
+__device__ __forceinline__ void load_batch(float (&v)[CNT], const float* __restrict__ src, int n, int tid) {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        const int e = tid + j * AB;
+        v[j] = src[e < n ? e : n - 1];
+    }
+}
 // (<SN, SE, SO>: nodes, time steps / features (E == T) and output width as compile-time constants, 0 = generic)
 template <int SN, int SE, int SO>
 __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* __restrict__ x, const float* __restrict__ prm,
@@ -96,20 +107,72 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
     __shared__ BnCoef co2[MAXN];
     const int N = SN ? SN : g.N, T = SE ? SE : g.T, E = SE ? SE : g.E, KE = g.K * E, O = SO ? SO : g.O, tid = threadIdx.x;
     const int Q = (E + 3) / 4;                    // column quads (E == T)
-    for (int e = tid; e < MAXT * TP; e += AB) { (&THt[0][0])[e] = 0.f; (&PWt[0][0])[e] = 0.f; }
-    for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&G[0][0])[e] = 0.f; (&T1[0][0])[e] = 0.f; }
-    __syncthreads();
-    for (int e = tid; e < E * T; e += AB) THt[e % T][e / T] = prm[g.o_thw + e];
-    for (int e = tid; e < E * E; e += AB) PWt[e % E][e / E] = prm[g.o_pw + e];
-    for (int e = tid; e < E; e += AB) gbias[e] = prm[g.o_thb + e] + prm[g.o_gb + e];
-    if (tid < N) co2[tid] = bn_coef(cells, bn_running, training, 1, tid, N, (double)g.BG * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    constexpr int WL = ((SE ? SE * SE : MAXT * MAXT) + AB - 1) / AB;           // loads per thread of a weight matrix
+    constexpr int XL = ((SN ? SN : MAXN) * (SE ? SE : MAXT) + AB - 1) / AB;     // ... of a sample's [N x T] tile
+    // The filter column of this thread's (k stripe, output) and the head's weights: requested with the prologue's batch and kept in
+    // registers -- in the pooled stage they were two more round trips per sample, in the head three (one instantiated output width only).
+    constexpr bool PRE = SO != 0 && 4 * SO <= AB && SO <= 64;
+    constexpr int FK = PRE ? (3 * (SE ? SE : MAXT) + 3) / 4 : 1;
+    float fv[FK];
+    float fcw0 = 0.f, fcb0 = 0.f;
+    if constexpr (PRE) {
+        const int st = tid / O, o = tid - st * O;
+#pragma unroll
+        for (int q = 0; q < FK; ++q) {
+            const int k = st + 4 * q;
+            fv[q] = prm[g.o_f + (k < KE ? k : KE - 1) * O + (tid < 4 * O ? o : 0)];
+        }
+        fcw0 = prm[g.o_fcw + (tid < O ? tid : O - 1)];
+        fcb0 = prm[g.o_fcb];
+    }
+    {
+        float wv[WL], pv[WL], xv[XL];
+        load_batch(wv, prm + g.o_thw, E * T, tid);
+        load_batch(pv, prm + g.o_pw, E * E, tid);
+        load_batch(xv, x + (int64_t)blockIdx.x * N * T, N * T, tid);            // (the first sample's tile with them)
+        // (... and the gate bias, the BatchNorm coefficients' sums: one round trip for the whole prologue)
+        const float gb0 = prm[g.o_thb + (tid < E ? tid : E - 1)] + prm[g.o_gb + (tid < E ? tid : E - 1)];
+        if (tid < N) co2[tid] = bn_coef(cells, bn_running, training, 1, tid, N, (double)g.BG * T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+        if (tid < E) gbias[tid] = gb0;
+        for (int e = tid + AB; e < E; e += AB) gbias[e] = prm[g.o_thb + e] + prm[g.o_gb + e];
+        for (int e = tid; e < MAXT * TP; e += AB) { (&THt[0][0])[e] = 0.f; (&PWt[0][0])[e] = 0.f; }
+        for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&G[0][0])[e] = 0.f; (&T1[0][0])[e] = 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int e = tid + j * AB;
+            if (e < E * T) THt[e % T][e / T] = wv[j];
+            if (e < E * E) PWt[e % E][e / E] = pv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            const int e = tid + j * AB;
+            if (e < N * T) T1[e / T][e % T] = xv[j];
+        }
+    }
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         float* tc = tcat + b * N * KE;
-        for (int e = tid; e < N * T; e += AB) T1[e / T][e % T] = x[b * N * T + e];
-        __syncthreads();
+        if (b != blockIdx.x) {
+            float xv[XL];
+            load_batch(xv, x + b * N * T, N * T, tid);
+#pragma unroll
+            for (int j = 0; j < XL; ++j) {
+                const int e = tid + j * AB;
+                if (e < N * T) T1[e / T][e % T] = xv[j];
+            }
+            __syncthreads();
+        }
         for (int w = tid; w < N * Q; w += AB) {                  // gate: four columns t per thread
             const int c = w / Q, t0 = 4 * (w - c * Q);
+            // (z2 / out0 of the four columns requested in front of the product: behind it, inside `if (t < T)`, they were four round trips)
+            float zv[4], ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t idx = b * N * T + c * T + (t0 + r < T ? t0 + r : T - 1);
+                zv[r] = z2[idx];
+                ov[r] = out0[idx];
+            }
             float zp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 10
             for (int k = 0; k < T; ++k) fma4(zp, T1[c][k], *reinterpret_cast<const float4*>(&THt[k][t0]));
@@ -118,8 +181,8 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                 const int t = t0 + r;
                 if (t < T) {
                     const int64_t idx = b * N * T + c * T + t;
-                    const float y = fmaf(z2[idx], co2[c].sc, co2[c].sh);
-                    const float o1 = fmaxf(fmaxf(y, 0.f) + out0[idx], 0.f);
+                    const float y = fmaf(zv[r], co2[c].sc, co2[c].sh);
+                    const float o1 = fmaxf(fmaxf(y, 0.f) + ov[r], 0.f);
                     const float zg = tanhf(zp[r] + gbias[t]);
                     out1[idx] = o1;
                     zg_out[idx] = zg;
@@ -182,25 +245,44 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                 for (int j = 0; j < N; ++j) fma4(a, A[i][j], *reinterpret_cast<const float4*>(&T1[j][c0]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (c0 + r < E) tc[i * KE + 2 * E + c0 + r] = 2.0f * a[r] - G[i][c0 + r];
+                    if (c0 + r < E) {
+                        const float v = 2.0f * a[r] - G[i][c0 + r];
+                        tc[i * KE + 2 * E + c0 + r] = v;
+                        P[i][c0 + r] = v;                        // (P is dead behind the adjacency: the third Chebyshev term's LDS copy)
+                    }
             }
             __syncthreads();
         }
-        for (int e = tid; e < KE; e += AB) {                    // node sums (tc rows were written by this workgroup)
+        for (int e = tid; e < KE; e += AB) {                    // node sums over the LDS copies of the three terms (G | T1 | P): the rows
+            const int part = e / E, c = e - part * E;           // of tc this workgroup just wrote were a store drain + a round trip away
+            const float (*src)[TP] = part == 0 ? G : (part == 1 ? T1 : P);
             float sum = 0.f;
-            for (int i = 0; i < N; ++i) sum += tc[i * KE + e];
+            for (int i = 0; i < N; ++i) sum += src[i][c];
             scat[b * KE + e] = sum;
             SC[e] = sum;
         }
         __syncthreads();
         {                                                        // pooled N = Scat Fcat: four k-stripes per output, combined in fixed order
             float* PL = &T1[0][0];                               // [4][O] partial sums over the T1 tile (dead by now; O <= 256 <= MAXN TP / 4)
+            if constexpr (PRE) {
+                if (tid < 4 * O) {
+                    const int st = tid / O;
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < FK; ++q) {
+                        const int k = st + 4 * q;
+                        if (k < KE) a = fmaf(SC[k], fv[q], a);
+                    }
+                    PL[tid] = a;
+                }
+            } else {
             for (int it = tid; it < 4 * O; it += AB) {
                 const int st = it / O, o = it - st * O;
                 float a = 0.f;
 #pragma unroll 8
                 for (int k = st; k < KE; k += 4) a = fmaf(SC[k], prm[g.o_f + k * O + o], a);
                 PL[st * O + o] = a;
+            }
             }
             __syncthreads();
             // head (ast_head_kernel's arithmetic, wavefront 0): pooled / N, pred = pooled fc^T + b, MSE pieces, D = dpred fc.weight / N
@@ -210,10 +292,10 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                 for (int o = tid; o < O; o += 64) {
                     const float v = ((PL[o] + PL[O + o]) + (PL[2 * O + o] + PL[3 * O + o])) / (float)N;
                     pooled[b * O + o] = v;
-                    a = fmaf(v, prm[g.o_fcw + o], a);
+                    a = fmaf(v, PRE ? fcw0 : prm[g.o_fcw + o], a);
                 }
                 for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
-                const float pr = a + prm[g.o_fcb];
+                const float pr = a + (PRE ? fcb0 : prm[g.o_fcb]);
                 if (tid == 0) pred[b] = pr;
                 if (y) {
                     const float d = pr - y[b];
@@ -222,7 +304,7 @@ __global__ __launch_bounds__(AB) void ast_front_kernel(AstGeom g, const float* _
                         dpred[b] = dp;
                         sqerr[b] = d * d * inv_gb;
                     }
-                    for (int o = tid; o < O; o += 64) dmat[b * O + o] = dp * prm[g.o_fcw + o] * inv_n;
+                    for (int o = tid; o < O; o += 64) dmat[b * O + o] = dp * (PRE ? fcw0 : prm[g.o_fcw + o]) * inv_n;
                 }
             }
         }
@@ -301,28 +383,83 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
     __shared__ float u[MAXN], v[MAXN], w[MAXN], cs[MAXN], acs[MAXN];
     const int N = SN ? SN : g.N, E = SE ? SE : g.E, KE = g.K * E, O = SO ? SO : g.O, tid = threadIdx.x;
     const int Q = (E + 3) / 4;
-    for (int e = tid; e < MAXT * TP; e += AB) (&PW[0][0])[e] = 0.f;
-    for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&DPX[0][0])[e] = 0.f; }
-    __syncthreads();
-    for (int e = tid; e < E * E; e += AB) PW[e / E][e % E] = prm[g.o_pw + e];
-    if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * g.T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+    constexpr int WL = ((SE ? SE * SE : MAXT * MAXT) + AB - 1) / AB;           // loads per thread of a weight matrix (load_batch)
+    constexpr int XL = ((SN ? SN : MAXN) * (SE ? SE : MAXT) + AB - 1) / AB;     // ... of a sample's [N x E] tile
+    constexpr int AL = ((SN ? SN * SN : MAXN * MAXN) + AB - 1) / AB;            // ... of its [N x N] matrices
+    // the filter values of this thread's (o stripe, row) items of the D Fcat^T stage: requested with the prologue's batch and kept in
+    // registers (they were two round trips per pass of that stage; instantiated shapes only)
+    constexpr bool PRE = SO != 0 && SE != 0 && SO % 4 == 0;
+    constexpr int DTN = PRE ? (4 * 3 * SE + AB - 1) / AB : 1, DTQ = PRE ? SO / 4 : 1;
+    float frv[DTN][DTQ];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int ps = 0; ps < DTN; ++ps) {
+            const int it = tid + ps * AB < 4 * KE ? tid + ps * AB : 4 * KE - 1;
+            const int st = it / KE, e = it - st * KE;
+#pragma unroll
+            for (int q = 0; q < DTQ; ++q) frv[ps][q] = prm[g.o_f + e * O + st + 4 * q];
+        }
+    }
+    {
+        float pv[WL];
+        load_batch(pv, prm + g.o_pw, E * E, tid);
+        if (tid < N) co2[tid] = bn_coef(cells, nullptr, 1, 1, tid, N, (double)g.BG * g.T, prm[g.o_g2 + tid], prm[g.o_b2 + tid]);
+        for (int e = tid; e < MAXT * TP; e += AB) (&PW[0][0])[e] = 0.f;
+        for (int e = tid; e < MAXN * TP; e += AB) { (&P[0][0])[e] = 0.f; (&DPX[0][0])[e] = 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WL; ++j) {
+            const int e = tid + j * AB;
+            if (e < E * E) PW[e / E][e % E] = pv[j];
+        }
+    }
     float a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
         const float* tc = tcat + b * N * KE;
-        for (int e = tid; e < N * E; e += AB) P[e / E][e % E] = px[b * N * E + e];
-        for (int e = tid; e < N * N; e += AB) {
-            A[e / N][e % N] = adj[b * N * N + e];
-            Cs[e / N][e % N] = distm[b * N * N + e];
+        {   // the sample's tiles: one batch of loads (they were nine round trips in a row)
+            float pv[XL], av[AL], cv[AL];
+            load_batch(pv, px + b * N * E, N * E, tid);
+            load_batch(av, adj + b * N * N, N * N, tid);
+            load_batch(cv, distm + b * N * N, N * N, tid);
+            const float dm = dmat[b * O + (tid < O ? tid : O - 1)];
+#pragma unroll
+            for (int j = 0; j < XL; ++j) {
+                const int e = tid + j * AB;
+                if (e < N * E) P[e / E][e % E] = pv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < AL; ++j) {
+                const int e = tid + j * AB;
+                if (e < N * N) {
+                    A[e / N][e % N] = av[j];
+                    Cs[e / N][e % N] = cv[j];
+                }
+            }
+            if (tid < O) DM[tid] = dm;
+            for (int e = tid + AB; e < O; e += AB) DM[e] = dmat[b * O + e];
         }
-        for (int e = tid; e < O; e += AB) DM[e] = dmat[b * O + e];
         __syncthreads();
-        for (int it = tid; it < 4 * KE; it += AB) {             // DT = D Fcat^T: row e of the filters viewed as [K E, O], four o-stripes
+        if constexpr (PRE) {                                     // DT = D Fcat^T: row e of the filters viewed as [K E, O], four o-stripes
+#pragma unroll
+            for (int ps = 0; ps < DTN; ++ps) {
+                const int it = tid + ps * AB;
+                if (it < 4 * KE) {
+                    const int st = it / KE, e = it - st * KE;
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < DTQ; ++q) a = fmaf(DM[st + 4 * q], frv[ps][q], a);
+                    DTP[st][e] = a;
+                }
+            }
+        } else {
+        for (int it = tid; it < 4 * KE; it += AB) {
             const int st = it / KE, e = it - st * KE;
             const float* fr = prm + g.o_f + e * O;
             float a = 0.f;
 #pragma unroll 8
             for (int o = st; o < O; o += 4) a = fmaf(DM[o], fr[o], a);
             DTP[st][e] = a;
+        }
         }
         __syncthreads();
         for (int e = tid; e < 3 * E; e += AB) {
@@ -337,11 +474,22 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
             const int j = tid >> 3, l8 = tid & 7;
             if (j < N) {
                 float uu = 0.f, vv = 0.f, ww = 0.f, c = 0.f;
-                for (int e = l8; e < E; e += 8) {
-                    const float gj = tc[j * KE + e];
-                    vv = fmaf(d1[e], gj, vv);
-                    ww = fmaf(d2v[e], gj, ww);
-                    if (g.K > 2) uu = fmaf(d2v[e], tc[j * KE + E + e], uu);
+                constexpr int EL = ((SE ? SE : MAXT) + 7) / 8;                 // (every load of the lane first: one round trip, not EL)
+                float gj[EL], g1[EL];
+#pragma unroll
+                for (int q = 0; q < EL; ++q) {
+                    const int e = l8 + 8 * q < E ? l8 + 8 * q : E - 1;
+                    gj[q] = tc[j * KE + e];
+                    g1[q] = g.K > 2 ? tc[j * KE + E + e] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < EL; ++q) {
+                    const int e = l8 + 8 * q;
+                    if (e < E) {
+                        vv = fmaf(d1[e], gj[q], vv);
+                        ww = fmaf(d2v[e], gj[q], ww);
+                        if (g.K > 2) uu = fmaf(d2v[e], g1[q], uu);
+                    }
                 }
                 for (int i = l8; i < N; i += 8) c += A[i][j];
 #pragma unroll
@@ -390,6 +538,16 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
         __syncthreads();
         for (int wk = tid; wk < N * Q; wk += AB) {               // dG = dG_cheb + dPX P
             const int i = wk / Q, c0 = 4 * (wk - i * Q);
+            // (the saved values of the four columns requested in front of the product, not inside `if (c < E)` behind it: every load there
+            // was a round trip of its own, and the stores in between kept the next ones from being issued early)
+            float zgv[4], o1v[4], zzv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t idx = b * N * E + i * E + (c0 + r < E ? c0 + r : E - 1);
+                zgv[r] = zg_dzpre[idx];
+                o1v[r] = out1[idx];
+                zzv[r] = z2[idx];
+            }
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 10
             for (int k = 0; k < E; ++k) fma4(a, DPX[i][k], *reinterpret_cast<const float4*>(&PW[k][c0]));
@@ -402,13 +560,13 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
                     if (g.K > 2) gch += (2.0f * acs[i] - 1.0f) * d2v[c];
                     const float gg = gch + a[r];
                     const int64_t idx = b * N * E + i * E + c;               // (E == T: node i is the BatchNorm channel, c the time step)
-                    const float zg = zg_dzpre[idx], o1 = out1[idx];
+                    const float zg = zgv[r], o1 = o1v[r];
                     const float dzp = gg * o1 * (1.0f - zg * zg);
                     zg_dzpre[idx] = dzp;
                     DPX2[i][c] = dzp;
                     const float sv = o1 > 0.f ? gg * zg : 0.f;
                     ds1[idx] = sv;
-                    const float zz = z2[idx];
+                    const float zz = zzv[r];
                     const float yv = fmaf(zz, co2[i].sc, co2[i].sh);
                     const float dy = yv > 0.f ? sv : 0.f;
                     dy2[idx] = dy;
@@ -640,6 +798,11 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         double* buf = bwd ? &cells[0].bwd[blk][0][0] : &cells[0].fwd[blk][0][0];
         return sync->fn(sync->user, buf, 2 * MAXN, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
     };
+    // The parameter-gradient GEMMs of the backward feed nothing in this call: with a second stream of the caller (args->aux_stream,
+    // aux_stream.hpp) they run beside the data-gradient chain.  In a whole step the side stream starts behind the FRONT kernel's own
+    // completion signal: an event recorded between it and the graph backward put a marker packet into the main queue, ~5 us of bubble.
+    AuxFork fk(st, (mode & 2) ? a->aux_stream : nullptr);
+    hipEvent_t front_done = nullptr;
     if (mode & 1) {
         hipLaunchKernelGGL(ast_prepare_kernel, dim3(1), dim3(1024), 0, st, cells, F(w.one));
         const int rows = resident_rows((tcn_conv_kernel<1, AstGeom, SN, SE, TTB>), g.B, 1 << 20, TTB);
@@ -650,7 +813,8 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
         // gate, P projection, graph, Chebyshev terms, node sums, the filter product and the head: one launch (ast_front_kernel)
-        hipLaunchKernelGGL((ast_front_kernel<SN, SE, SO>), dim3(resident_rows((ast_front_kernel<SN, SE, SO>), g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
+        if ((mode & 2) && !a->dpred) front_done = fk.stop_event();
+        RULGNN_LAUNCH_EV(front_done, (ast_front_kernel<SN, SE, SO>), dim3(resident_rows((ast_front_kernel<SN, SE, SO>), g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
                            (const Cells*)cells, (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat), F(w.px), F(w.adj),
                            F(w.dist), F(w.scat), F(w.pooled), a->y, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb);
         if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
@@ -662,18 +826,16 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
                                F(w.pooled), (const float*)nullptr, a->dpred, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 1);
         float* gr = a->grads;
         float* split = F(w.split);
-        // The parameter-gradient GEMMs feed nothing in this call: with a second stream of the caller (args->aux_stream, aux_stream.hpp)
-        // they run beside the data-gradient chain.  They share the split-K scratch and therefore one stream.  (The small launches
-        // nothing on the chain waits for -- batch moments, loss sum, the constant of the column sums -- stay on the main stream: the side
-        // chain is the longer one here, measured 0.283 vs 0.257 ms per step with them on it.)
-        AuxFork fk(st, a->aux_stream);
+        // The side stream's products share the split-K scratch and therefore one stream.  (The small launches nothing on the chain waits
+        // for -- batch moments, loss sum, the constant of the column sums -- stay on the main stream: the side chain is the longer one
+        // here, measured 0.283 vs 0.257 ms per step with them on it.)
         hipStream_t wst = fk.side();
         const bool mse = a->dpred == nullptr;
         // the constant 1 the side stream's bias reductions read: written IN FRONT of the fork (behind it the side stream's split-K over
         // `one` was ordered against nothing that wrote it -- garbage from a fresh workspace on the first step)
         // (with a forward in the same call ast_prepare_kernel wrote it; batch statistics and the loss sum ride in the finalize kernel)
         if (!(mode & 1)) hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
-        fk.fork();
+        fk.fork_after(front_done);           // (null -- no forward in this call, a capture, an external d pred: a plain fork here)
         // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
         const int bwd_rows = resident_rows((ast_graph_bwd_kernel<SN, SE, SO>), g.B, AST_BWD_ROWS);
         hipEvent_t bwd_done = fk.stop_event();                       // (the second fork point: behind this kernel)

@@ -85,6 +85,18 @@ __device__ __forceinline__ float tcn_row16_sum(float v) {  // sum over the 16 la
 }
 
 // ---------------------------------------------------------------------------------------------------
+// n <= CNT TBK values src[tid + j TBK] as ONE batch of loads: every load is issued before the first use.  A `for (e = tid; e < n; e += TBK)
+// lds[...] = src[e]` loop waits for each load before its store: ten L2 round trips in a row for the [20 x 120] weight rows of a
+// convolution, four more for a sample's tile -- half of a 12-us launch (profiles/r05_tiled_path_and_load_chains.md, section 1b).
+template <int CNT, int TBK>
+__device__ __forceinline__ void tcn_load_batch(float (&v)[CNT], const float* __restrict__ src, int n, int tid) {
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        const int e = tid + j * TBK;
+        v[j] = src[e < n ? e : n - 1];
+    }
+}
+
 // TCN forward.  STAGE 1: z1 = conv1(x).  STAGE 2: out0 = relu(relu(bn1(z1)) + x); z2 = conv2_dil2(out0).
 // One sample per workgroup iteration; per-channel sums of z accumulate in registers and go to the cells once.
 // ---------------------------------------------------------------------------------------------------
@@ -107,7 +119,20 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_kernel(Geom g, const floa
     const float* wsrc = prm + (STAGE == 1 ? g.o_w1 : g.o_w2);
     // (through LDS with coalesced loads: fetched by the lanes straight into their operand registers every load instruction touched 16
     // rows of the matrix -- 60 such instructions per lane took 7 of the kernel's 17 us)
-    for (int e = tid; e < N * NK; e += TBK) wl[(e / NK) * NKP + e % NK] = wsrc[e];
+    constexpr int WLC = ((SN ? SN * SN : MAXN * MAXN) * KT + TBK - 1) / TBK;      // loads per thread: the weights ...
+    constexpr int XLC = ((SN ? SN : MAXN) * (ST ? ST : MAXT) + TBK - 1) / TBK;     // ... a sample's [N x T] tile
+    float xv[XLC], zv[STAGE == 2 ? XLC : 1];
+    {
+        float wv[WLC];
+        tcn_load_batch<WLC, TBK>(wv, wsrc, N * NK, tid);
+        tcn_load_batch<XLC, TBK>(xv, x + (int64_t)blockIdx.x * N * T, N * T, tid);          // (the first sample's tile with them)
+        if constexpr (STAGE == 2) tcn_load_batch<XLC, TBK>(zv, z1 + (int64_t)blockIdx.x * N * T, N * T, tid);
+#pragma unroll
+        for (int j = 0; j < WLC; ++j) {
+            const int e = tid + j * TBK;
+            if (e < N * NK) wl[(e / NK) * NKP + e % NK] = wv[j];
+        }
+    }
     __syncthreads();
     float wa[2][KSC];
     int boff[KSC];
@@ -134,16 +159,23 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_kernel(Geom g, const floa
     const float* xsf = &xs[0][0];
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
-        const float* xb = x + b * N * T;
-        for (int e = tid; e < N * T; e += TBK) {
-            const int c = e / T, tt = e - c * T;
-            float v = xb[e];
-            if (STAGE == 2) {
-                const float y = fmaf(z1[b * N * T + e], co1[c].sc, co1[c].sh);
-                v = fmaxf(fmaxf(y, 0.f) + v, 0.f);
-                out0[b * N * T + e] = v;
+        if (b != blockIdx.x) {
+            tcn_load_batch<XLC, TBK>(xv, x + b * N * T, N * T, tid);
+            if constexpr (STAGE == 2) tcn_load_batch<XLC, TBK>(zv, z1 + b * N * T, N * T, tid);
+        }
+#pragma unroll
+        for (int j = 0; j < XLC; ++j) {
+            const int e = tid + j * TBK;
+            if (e < N * T) {
+                const int c = e / T, tt = e - c * T;
+                float v = xv[j];
+                if constexpr (STAGE == 2) {
+                    const float y = fmaf(zv[j], co1[c].sc, co1[c].sh);
+                    v = fmaxf(fmaxf(y, 0.f) + v, 0.f);
+                    out0[b * N * T + e] = v;
+                }
+                xs[c][PADL + tt] = v;
             }
-            xs[c][PADL + tt] = v;
         }
         __syncthreads();
         if (16 * wave < T) {                                             // (wave-uniform)
@@ -200,6 +232,9 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_kernel(Geom g, const floa
 //                                                                    the A operand (W seen by input channel) in registers
 // One partial weight-gradient row per workgroup, as before.
 // ---------------------------------------------------------------------------------------------------
+// (Measured and dropped: two wavefronts per SIMD asked of the compiler, __launch_bounds__(TBK, 2).  STAGE 2 at 20 nodes needs 264-280
+// registers, so ONE workgroup fits a CU and the 512 samples of the N-CMAPSS batch run as two rounds of 256; at 255 registers the kernel itself
+// is 1 us faster and the ASTGCNN step 10 us SLOWER -- the parameter-gradient products of the side stream run beside this kernel and starve.)
 template <int STAGE, typename Geom, int SN = 0, int ST = 0, int TBK = AB>
 static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const float* __restrict__ prm, Cells* cells,
                                                          const float* __restrict__ zin, const float* __restrict__ dyin,
@@ -229,7 +264,14 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
     float wt[STAGE == 2 ? 2 : 1][STAGE == 2 ? KSC : 1];
     int doff[STAGE == 2 ? KSC : 1];
     if constexpr (STAGE == 2) {
-        for (int e = tid; e < N * NK; e += TBK) wl[(e / NK) * NKP + e % NK] = prm[g.o_w2 + e];
+        constexpr int WLC = ((SN ? SN * SN : MAXN * MAXN) * KT + TBK - 1) / TBK;
+        float wv[WLC];
+        tcn_load_batch<WLC, TBK>(wv, prm + g.o_w2, N * NK, tid);
+#pragma unroll
+        for (int j = 0; j < WLC; ++j) {
+            const int e = tid + j * TBK;
+            if (e < N * NK) wl[(e / NK) * NKP + e % NK] = wv[j];
+        }
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < KSC; ++s) {
@@ -272,12 +314,22 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
     const int t = 16 * wave + li;
     __syncthreads();
     for (int64_t b = blockIdx.x; b < g.B; b += gridDim.x) {
-        for (int e = tid; e < N * T; e += TBK) {
-            const int c = e / T, tt = e - c * T;
-            const int64_t idx = b * N * T + e;
-            const float xh = (zin[idx] - cz[c].mean) * cz[c].inv;
-            dz[c][tt] = cz[c].sc * (dyin[idx] - bsum[c][0] - xh * bsum[c][1]);
-            xs[c][PAD + tt] = src[idx];
+        {   // the sample's three tiles as one batch of loads (they were a round trip per pass of this loop)
+            constexpr int XLC = ((SN ? SN : MAXN) * (ST ? ST : MAXT) + TBK - 1) / TBK;
+            float zi[XLC], dyv[XLC], sv[XLC];
+            tcn_load_batch<XLC, TBK>(zi, zin + b * N * T, N * T, tid);
+            tcn_load_batch<XLC, TBK>(dyv, dyin + b * N * T, N * T, tid);
+            tcn_load_batch<XLC, TBK>(sv, src + b * N * T, N * T, tid);
+#pragma unroll
+            for (int j = 0; j < XLC; ++j) {
+                const int e = tid + j * TBK;
+                if (e < N * T) {
+                    const int c = e / T, tt = e - c * T;
+                    const float xh = (zi[j] - cz[c].mean) * cz[c].inv;
+                    dz[c][tt] = cz[c].sc * (dyv[j] - bsum[c][0] - xh * bsum[c][1]);
+                    xs[c][PAD + tt] = sv[j];
+                }
+            }
         }
         __syncthreads();
         // d W[co][(ci, tap)] += sum_t dz[co][t] * in[ci][t - (KT-1-tap) D]      (column PAD + that = t + tap D; d z = 0 behind T)
@@ -295,6 +347,18 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
         if constexpr (STAGE == 2) {
             // d out0[ci][t] = ds1 + sum_co sum_k W[co][ci][k] dz[co][t + (KT-1-k) D]
             if (16 * wave < T) {
+                // (d s1 / z1 of this lane's eight outputs requested in front of the products: inside `if (ci < N && t < T)` behind them each
+                // pair was a round trip of its own)
+                float dsv[2][4], z1v[2][4];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = 16 * mt + 4 * kq + r;
+                        const int64_t idx = b * N * T + (ci < N ? ci : N - 1) * T + (t < T ? t : T - 1);
+                        dsv[mt][r] = ds1[idx];
+                        z1v[mt][r] = z1[idx];
+                    }
                 tcn_f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                 for (int s = 0; s < KSC; ++s) {
@@ -309,10 +373,10 @@ static __global__ __launch_bounds__(TBK) void tcn_conv_bwd_kernel(Geom g, const 
                         const int ci = 16 * mt + 4 * kq + r;
                         if (ci < N && t < T) {
                             const int64_t idx = b * N * T + ci * T + t;
-                            const float a = acc[mt][r] + ds1[idx];
+                            const float a = acc[mt][r] + dsv[mt][r];
                             const float o0 = xs[ci][PAD + t];
                             const float s0 = o0 > 0.f ? a : 0.f;
-                            const float zz = z1[idx];
+                            const float zz = z1v[mt][r];
                             const float y = fmaf(zz, c1[ci].sc, c1[ci].sh);
                             const float dy = y > 0.f ? s0 : 0.f;
                             dy1[idx] = dy;

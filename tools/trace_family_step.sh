@@ -1,26 +1,19 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/trace_family_step.sh <FAMILY> <tag>  -- kernel trace (start / end / queue) of bench.py --family steps; prints the last step's timeline
-fam=${1:-FC_STGNN}; tag=${2:-trace}
+# development aid (GPU box, repo root): kernel timeline of one step of a family's update(): tools/trace_family_step.sh FAMILY
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/$tag
-rocprofv3 --kernel-trace -d gpurun_out/$tag/kt -o k --output-format csv -- python bench.py --family $fam --steps 6 --warmup 3 --no-roofline --no-cpu-baseline > gpurun_out/$tag/run.log 2>&1
-python - <<PY
+mkdir -p gpurun_out/cpf
+rocprofv3 --kernel-trace -d gpurun_out/cpf -o k --output-format csv -- python tools/host_vs_gpu.py ${1:-ASTGCNN} 60 > /dev/null 2>&1
+python - <<'PY'
 import csv, glob
-f = glob.glob("gpurun_out/$tag/kt/**/k_kernel_trace.csv", recursive=True)[0]
+f = glob.glob("gpurun_out/cpf/**/k_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# last occurrence of the step's last kernel (adam) marks a step end; take the rows between the two last adam kernels
-idx = [i for i, r in enumerate(rows) if "adam_step" in r["Kernel_Name"] or "multi_tensor" in r["Kernel_Name"]]
-lo, hi = idx[-2] + 1, idx[-1] + 1
+idx = [i for i, r in enumerate(rows) if "adam_" in r["Kernel_Name"]]
+# a step from the steady-state loop (the second timed loop of host_vs_gpu.py): ten steps before the end
+lo, hi = idx[-12] + 1, idx[-11] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
-out = open("gpurun_out/$tag/timeline.txt", "w")
-prev_end = {}
 for r in rows[lo:hi]:
     s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-    q = r.get("Queue_Id", "?")
-    name = r["Kernel_Name"].replace("rulgnn::", "").replace("(anonymous namespace)::", "")[:60]
-    out.write(f"{s/1e3:9.1f} {e/1e3:9.1f} {(e-s)/1e3:7.1f} q{q} {name}\n")
-out.close()
-print(open("gpurun_out/$tag/timeline.txt").read())
+    print("%8.1f %8.1f %7.1f q%s %s" % (s / 1e3, e / 1e3, (e - s) / 1e3, r.get("Queue_Id"), r["Kernel_Name"].replace("rulgnn::", "").replace("(anonymous namespace)::", "")[:70]))
 PY
-find gpurun_out/$tag -name "*.csv" -delete
+find gpurun_out/cpf -name "*.csv" -delete
