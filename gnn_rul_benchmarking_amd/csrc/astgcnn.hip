@@ -694,8 +694,18 @@ __global__ void ast_prepare_kernel(Cells* cells, float* one) {
 struct AstWs {
     size_t cells, one, z1, out0, z2, zpre, out1, tcat, px, adj, dist, scat, pooled, dpred, sqerr, dmat, dpx, ds1, dy2, dy1, thb, gp1, gp2,
         split, total;
+    size_t split_floats;
     int rows;
 };
+// output shapes and reduction lengths of the step's parameter-gradient products (fc.weight, fc.bias, filters, P.weight, theta.weight)
+static void ast_pgrad_dims(const AstGeom& g, SplitKJob* j) {
+    const int M = (int)(g.B * g.N), B = (int)g.B;
+    const int mnk[5][3] = {{1, g.O, B}, {1, 1, B}, {g.KE, g.O, B}, {g.E, g.E, M}, {g.E, g.T, M}};
+    for (int i = 0; i < 5; ++i) {
+        j[i] = SplitKJob{};
+        j[i].M = mnk[i][0]; j[i].N = mnk[i][1]; j[i].K = mnk[i][2] > 0 ? mnk[i][2] : 1;
+    }
+}
 
 void ast_ws_layout(const AstGeom& g, AstWs* w) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -726,7 +736,14 @@ void ast_ws_layout(const AstGeom& g, AstWs* w) {
     w->gp1 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
     w->gp2 = o; o = al(o + (size_t)w->rows * g.N * g.N * KT * sizeof(float));
     const int mx = g.KE > g.E ? g.KE : g.E;
-    w->split = o; o = al(o + sgemm_splitk_partial_floats(mx, g.O > g.E ? g.O : g.E) * sizeof(float));
+    // (... or the five parameter-gradient products of a step at once: ast_pgrad_jobs)
+    SplitKJob dims[5];
+    ast_pgrad_dims(g, dims);
+    size_t sf = sgemm_splitk_partial_floats(mx, g.O > g.E ? g.O : g.E);
+    const size_t bf = sgemm_splitk_batch_floats(dims, 5);
+    sf = sf > bf ? sf : bf;
+    w->split_floats = sf;
+    w->split = o; o = al(o + sf * sizeof(float));
     w->total = o;
 }
 
@@ -798,11 +815,9 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         double* buf = bwd ? &cells[0].bwd[blk][0][0] : &cells[0].fwd[blk][0][0];
         return sync->fn(sync->user, buf, 2 * MAXN, st) == 0 ? RULGNN_OK : RULGNN_ECALLBACK;
     };
-    // The parameter-gradient GEMMs of the backward feed nothing in this call: with a second stream of the caller (args->aux_stream,
-    // aux_stream.hpp) they run beside the data-gradient chain.  In a whole step the side stream starts behind the FRONT kernel's own
-    // completion signal: an event recorded between it and the graph backward put a marker packet into the main queue, ~5 us of bubble.
+    // The parameter-gradient products of the backward feed nothing in this call: with a second stream of the caller (args->aux_stream,
+    // aux_stream.hpp) they run beside the TCN backward, forked behind the graph-backward kernel's own completion signal.
     AuxFork fk(st, (mode & 2) ? a->aux_stream : nullptr);
-    hipEvent_t front_done = nullptr;
     if (mode & 1) {
         hipLaunchKernelGGL(ast_prepare_kernel, dim3(1), dim3(1024), 0, st, cells, F(w.one));
         const int rows = resident_rows((tcn_conv_kernel<1, AstGeom, SN, SE, TTB>), g.B, 1 << 20, TTB);
@@ -813,8 +828,7 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
                            F(w.z2), F(w.out0), cells);
         AST_RC(sync_pair(0, 1));
         // gate, P projection, graph, Chebyshev terms, node sums, the filter product and the head: one launch (ast_front_kernel)
-        if ((mode & 2) && !a->dpred) front_done = fk.stop_event();
-        RULGNN_LAUNCH_EV(front_done, (ast_front_kernel<SN, SE, SO>), dim3(resident_rows((ast_front_kernel<SN, SE, SO>), g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
+        hipLaunchKernelGGL((ast_front_kernel<SN, SE, SO>), dim3(resident_rows((ast_front_kernel<SN, SE, SO>), g.B, 1 << 20)), dim3(AB), 0, st, g, a->x, prm, a->bn_stats, training,
                            (const Cells*)cells, (const float*)F(w.z2), (const float*)F(w.out0), F(w.zpre), F(w.out1), F(w.tcat), F(w.px), F(w.adj),
                            F(w.dist), F(w.scat), F(w.pooled), a->y, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb);
         if (training && a->bn_batch && !(mode & 2))            // (with a backward in the same call: beside its chain, below)
@@ -826,41 +840,42 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
                                F(w.pooled), (const float*)nullptr, a->dpred, a->pred, F(w.dpred), F(w.sqerr), F(w.dmat), inv_gb, 1);
         float* gr = a->grads;
         float* split = F(w.split);
-        // The side stream's products share the split-K scratch and therefore one stream.  (The small launches nothing on the chain waits
-        // for -- batch moments, loss sum, the constant of the column sums -- stay on the main stream: the side chain is the longer one
-        // here, measured 0.283 vs 0.257 ms per step with them on it.)
         hipStream_t wst = fk.side();
         const bool mse = a->dpred == nullptr;
-        // the constant 1 the side stream's bias reductions read: written IN FRONT of the fork (behind it the side stream's split-K over
-        // `one` was ordered against nothing that wrote it -- garbage from a fresh workspace on the first step)
+        // the constant 1 the bias reduction reads: written IN FRONT of the fork (behind it the side stream's product over `one` was
+        // ordered against nothing that wrote it -- garbage from a fresh workspace on the first step)
         // (with a forward in the same call ast_prepare_kernel wrote it; batch statistics and the loss sum ride in the finalize kernel)
         if (!(mode & 1)) hipLaunchKernelGGL(ast_fill_one_kernel, dim3(1), dim3(1), 0, st, F(w.one));
-        fk.fork_after(front_done);           // (null -- no forward in this call, a capture, an external d pred: a plain fork here)
         // DT = D Fcat^T, the graph backward, dG = dG_cheb + dPX P and the gate backward (BatchNorm-2 sums): one launch
         const int bwd_rows = resident_rows((ast_graph_bwd_kernel<SN, SE, SO>), g.B, AST_BWD_ROWS);
-        hipEvent_t bwd_done = fk.stop_event();                       // (the second fork point: behind this kernel)
+        hipEvent_t bwd_done = fk.stop_event();                       // (the fork point: behind this kernel)
         RULGNN_LAUNCH_EV(bwd_done, (ast_graph_bwd_kernel<SN, SE, SO>), dim3(bwd_rows), dim3(AB), 0, st, g, prm,
                          (const float*)F(w.px), (const float*)F(w.tcat), (const float*)F(w.adj), (const float*)F(w.dist), (const float*)F(w.dmat),
                          F(w.dpx), cells, (const float*)F(w.z2), (const float*)F(w.out1), F(w.zpre), F(w.ds1), F(w.dy2), F(w.thb));
-        // (the side stream's launches are enqueued BEHIND the main stream's kernel they run beside: the host enqueues in program order)
-        // fc: d fc.weight[o] = sum_b dpred[b] pooled[b][o]; d fc.bias = sum_b dpred[b]
-        AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.pooled), 1, O, gr + g.o_fcw, O, 1, O, (int)g.B, false, split, wst));
-        if (cols_sum_small_ok(g.B, 1)) AST_RC(cols_sum_small(F(w.dpred), (int)g.B, 1, gr + g.o_fcb, wst));
-        else AST_RC(sgemm_splitk(F(w.dpred), 0, 1, F(w.one), 0, 0, gr + g.o_fcb, 1, 1, 1, (int)g.B, false, split, wst));
-        // d filters = Scat^T D ; DT = D Fcat^T
-        AST_RC(sgemm_splitk(F(w.scat), 1, KE, F(w.dmat), 1, O, gr + g.o_f, O, KE, O, (int)g.B, false, split, wst));
-        // d P = dPX^T G
-        fk.fork_after(bwd_done);
+        // The five parameter-gradient products -- d fc.weight[o] = sum_b dpred[b] pooled[b][o], d fc.bias = sum_b dpred[b],
+        // d filters = Scat^T D, d P = dPX^T G, d theta.weight = dZpre^T x -- as ONE split-K launch + ONE reduction (sgemm_splitk_batch).
+        // As nine launches (5-8 us each, at their latency floor) they needed a side stream from the front kernel on -- two forks and a join,
+        // each a 5-8 us bubble in the main queue, and 0.10 ms of host time per step to enqueue it all.  One stream, the pair behind the
+        // backward chain: 0.119 ms per step; the pair on a side stream beside the TCN backward: 0.122; the nine launches: 0.130.
+        SplitKJob jobs[5];
+        ast_pgrad_dims(g, jobs);
+        jobs[0].A = F(w.dpred); jobs[0].sAm = 0; jobs[0].sAk = 1; jobs[0].B = F(w.pooled); jobs[0].sBn = 1; jobs[0].sBk = O; jobs[0].C = gr + g.o_fcw; jobs[0].ldc = O;
+        jobs[1].A = F(w.dpred); jobs[1].sAm = 0; jobs[1].sAk = 1; jobs[1].B = F(w.one); jobs[1].sBn = 0; jobs[1].sBk = 0; jobs[1].C = gr + g.o_fcb; jobs[1].ldc = 1;
+        jobs[2].A = F(w.scat); jobs[2].sAm = 1; jobs[2].sAk = KE; jobs[2].B = F(w.dmat); jobs[2].sBn = 1; jobs[2].sBk = O; jobs[2].C = gr + g.o_f; jobs[2].ldc = O;
+        jobs[3].A = F(w.dpx); jobs[3].sAm = 1; jobs[3].sAk = E; jobs[3].B = F(w.tcat); jobs[3].sBn = 1; jobs[3].sBk = KE; jobs[3].C = gr + g.o_pw; jobs[3].ldc = E;
+        jobs[4].A = F(w.zpre); jobs[4].sAm = 1; jobs[4].sAk = E; jobs[4].B = a->x; jobs[4].sBn = 1; jobs[4].sBk = T; jobs[4].C = gr + g.o_thw; jobs[4].ldc = T;
+        if (fk.active()) {
+            fk.fork_after(bwd_done);
+            AST_RC(sgemm_splitk_batch(jobs, 5, split, w.split_floats, wst));
+        }
         const int rows = resident_rows((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), g.B, w.rows, TTB);
         AST_RC(sync_pair(1, 1));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<2, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z2), (const float*)F(w.dy2),
                            (const float*)F(w.out0), (const float*)F(w.ds1), (const float*)F(w.z1), F(w.dy1), F(w.gp2));
-        AST_RC(sgemm_splitk(F(w.dpx), 1, E, F(w.tcat), 1, KE, gr + g.o_pw, E, E, E, M, false, split, wst));
-        // gate parameters: d theta.weight = dZpre^T x ; d theta.bias = d gate.bias = column sums of dZpre
-        AST_RC(sgemm_splitk(F(w.zpre), 1, E, a->x, 1, T, gr + g.o_thw, T, E, T, M, false, split, wst));
         AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
+        if (!fk.active()) AST_RC(sgemm_splitk_batch(jobs, 5, split, w.split_floats, st));
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
         // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)
         AST_RC(rows_sum3(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, F(w.thb), gr + g.o_thb, gr + g.o_gb,

@@ -23,11 +23,12 @@ struct GemmArgs {
     int amax_na, amax_nb;
 };
 
-static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
+// (bx, by, bz: the tile's column / row index and its k slice -- blockIdx of the plain launch, decoded from a linear index by the batched one)
+static __device__ __forceinline__ void sgemm_mfma_body(GemmArgs g, int bx, int by, int bz) {
     __shared__ float As[16][64 + 4];      // [k][m]
     __shared__ float Bs[16][64 + 4];      // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int m0 = by * 64, n0 = bx * 64;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     f32x4t acc[2][2];
 #pragma unroll
@@ -35,8 +36,8 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4t){0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, kq = lane >> 4;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    g.C += (int64_t)blockIdx.z * g.M * g.ldc;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    g.C += (int64_t)bz * g.M * g.ldc;
     // Cooperative tile load: 64 x 16 elements of A and of B (4 + 4 per thread).  The lane -> element mapping follows the
     // operand's contiguous dimension (k-fastest when the k stride is 1, else m-fastest) so that wavefront loads coalesce, and
     // the next k-step's elements are fetched into registers while the matrix cores work on the current one.
@@ -100,6 +101,25 @@ static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) {
                     *c = g.accumulate ? *c + acc[i][j][r] : acc[i][j][r];
                 }
             }
+}
+static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) { sgemm_mfma_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+// several split-K products of the 64 x 64 tile kernel as ONE launch (blockIdx.x: the jobs' tiles x slices back to back) and their slice
+// reductions as one more: the parameter gradients of a small model are five to ten launch pairs of 5-8 us each, at their latency floor
+constexpr int GEMM_BATCH_MAX = 6;
+struct GemmBatch {
+    GemmArgs g[GEMM_BATCH_MAX];          // C = the job's partial buffer, ldc = N, kchunk set
+    int first[GEMM_BATCH_MAX + 1];       // first workgroup of each job
+    int nx[GEMM_BATCH_MAX], ny[GEMM_BATCH_MAX];
+    int n;
+};
+static __global__ __launch_bounds__(256) void sgemm_mfma_batch_kernel(GemmBatch b) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_BATCH_MAX; ++q)
+        if (q < b.n && (int)blockIdx.x >= b.first[q]) j = q;
+    const int local = blockIdx.x - b.first[j];
+    const int bx = local % b.nx[j], by = (local / b.nx[j]) % b.ny[j], bz = local / (b.nx[j] * b.ny[j]);
+    sgemm_mfma_body(b.g[j], bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1312,6 +1332,72 @@ static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_kernel(const 
     }
 }
 
+// ... of several products in one launch (sgemm_splitk_batch)
+struct ReduceBatch {
+    const float* partial[GEMM_BATCH_MAX];
+    float* C[GEMM_BATCH_MAX];
+    int64_t ldc[GEMM_BATCH_MAX];
+    int M[GEMM_BATCH_MAX], N[GEMM_BATCH_MAX], slices[GEMM_BATCH_MAX];
+    int first[GEMM_BATCH_MAX + 1];
+    int n;
+};
+static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_batch_kernel(ReduceBatch b) {
+    __shared__ float part[16][64];
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < GEMM_BATCH_MAX; ++q)
+        if (q < b.n && (int)blockIdx.x >= b.first[q]) j = q;
+    const float* __restrict__ partial = b.partial[j];
+    const int M = b.M[j], N = b.N[j], slices = b.slices[j];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = (blockIdx.x - b.first[j]) * 64 + lane;
+    float a = 0.f;
+    if (e < M * N)
+        for (int z = q; z < slices; z += 16) a += partial[(int64_t)z * M * N + e];
+    part[q][lane] = a;
+    __syncthreads();
+    if (q == 0 && e < M * N) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) v += (part[r][lane] + part[r + 1][lane]) + (part[r + 2][lane] + part[r + 3][lane]);
+        b.C[j][(int64_t)(e / N) * b.ldc[j] + (e % N)] = v;
+    }
+}
+size_t sgemm_splitk_batch_floats(const SplitKJob* jobs, int n) {
+    size_t f = 0;
+    for (int j = 0; j < n; ++j) f += (size_t)sgemm_splitk_slices(jobs[j].M, jobs[j].N, jobs[j].K) * jobs[j].M * jobs[j].N;
+    return f;
+}
+int sgemm_splitk_batch(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st) {
+    if (n < 1 || n > GEMM_BATCH_MAX) return RULGNN_EINVAL;
+    if (partial_floats < sgemm_splitk_batch_floats(jobs, n)) return RULGNN_EWORKSPACE;
+    GemmBatch gb{};
+    ReduceBatch rb{};
+    gb.n = rb.n = n;
+    size_t off = 0;
+    int wg = 0, rwg = 0;
+    for (int j = 0; j < n; ++j) {
+        const SplitKJob& q = jobs[j];
+        if (q.M <= 0 || q.N <= 0 || q.K <= 0) return RULGNN_EINVAL;
+        const int slices = sgemm_splitk_slices(q.M, q.N, q.K);
+        int kchunk = (q.K + slices - 1) / slices;
+        kchunk = (kchunk + 15) & ~15;
+        const int used = (q.K + kchunk - 1) / kchunk;
+        gb.g[j] = GemmArgs{q.A, q.sAm, q.sAk, q.B, q.sBn, q.sBk, partial + off, q.N, q.M, q.N, q.K, 0, kchunk};
+        gb.nx[j] = (q.N + 63) / 64; gb.ny[j] = (q.M + 63) / 64;
+        gb.first[j] = wg;
+        wg += gb.nx[j] * gb.ny[j] * used;
+        rb.partial[j] = partial + off; rb.C[j] = q.C; rb.ldc[j] = q.ldc; rb.M[j] = q.M; rb.N[j] = q.N; rb.slices[j] = used;
+        rb.first[j] = rwg;
+        rwg += (q.M * q.N + 63) / 64;
+        off += (size_t)used * q.M * q.N;
+    }
+    gb.first[n] = wg; rb.first[n] = rwg;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(sgemm_mfma_batch_kernel, dim3(wg), dim3(256), 0, st, gb);
+    hipLaunchKernelGGL(sgemm_reduce_slices_batch_kernel, dim3(rwg), dim3(1024), 0, st, rb);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
 
 // ... for large contiguous outputs (M N a multiple of 4, ldc == N: the [N x N] weight gradients of the tiled ST_GCN path, 4 MB per slice):
 // a thread owns four consecutive outputs and walks the slices with 16-byte loads, four slices in flight -- the form above issues one

@@ -48,6 +48,18 @@ struct SplitKColsumJob {
 size_t sgemm_splitk_colsum_batch_floats(const SplitKColsumJob* jobs, int n);
 int sgemm_splitk_colsum_batch(const SplitKColsumJob* jobs, int n, const float* ones, float* partial, size_t partial_floats, hipStream_t st);
 
+// Up to six products C_j = A_j B_j^T (element strides as in sgemm) as one split-K launch of the 64 x 64 tile kernel + one reduction launch:
+// the parameter gradients of a small model, each of which is a 5-8 us launch pair at its latency floor.  Deterministic (fixed slices,
+// fixed-order sums); `partial`: sgemm_splitk_batch_floats(jobs, n) floats.
+struct SplitKJob {
+    const float* A; int64_t sAm, sAk;
+    const float* B; int64_t sBn, sBk;
+    float* C; int64_t ldc;
+    int M, N, K;
+};
+size_t sgemm_splitk_batch_floats(const SplitKJob* jobs, int n);
+int sgemm_splitk_batch(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st);
+
 // out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
 int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st);

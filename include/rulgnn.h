@@ -409,7 +409,9 @@ typedef struct rulgnn_astgcnn_args {
     int64_t global_batch;     /* MSE denominator */
     float bn_moment_weight;
     int32_t training;         /* != 0: BatchNorm batch statistics (model.train()), else running statistics */
-    void *aux_stream;         /* optional second HIP stream of the caller for the parameter-gradient GEMMs (see rulgnn_fcstgnn_args) */
+    void *aux_stream;         /* optional second HIP stream of the caller (see rulgnn_fcstgnn_args): the step's parameter-gradient products (one
+                               * launch pair) then run beside the TCN backward.  Measured slower than NULL at the reference's shapes (the fork /
+                               * join events cost more than the overlap returns): the Python model passes NULL. */
 } rulgnn_astgcnn_args;
 
 int64_t rulgnn_astgcnn_param_count(const rulgnn_astgcnn_shape *shape);      /* < 0: invalid / unsupported */

@@ -15,6 +15,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 algo = get_algorithm_class(fam)(hp.alg_hparams[fam], hp.train_params[fam], dev)
 algo.to(dev); algo.train(); algo.sync_loss = False
+if os.environ.get("NO_SIDE") == "1" and hasattr(algo.model, "side_stream"):      # (one stream: the caller passes no aux_stream)
+    algo.model.side_stream.enabled = False
 g = torch.Generator(device=dev).manual_seed(1)
 X = torch.rand(B, *shape, device=dev, generator=g); y = torch.rand(B, 1, device=dev, generator=g)
 for _ in range(20): algo.update(X, y, 1)
