@@ -105,7 +105,7 @@ static __device__ __forceinline__ void sgemm_mfma_body(GemmArgs g, int bx, int b
 static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) { sgemm_mfma_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
 // several split-K products of the 64 x 64 tile kernel as ONE launch (blockIdx.x: the jobs' tiles x slices back to back) and their slice
 // reductions as one more: the parameter gradients of a small model are five to ten launch pairs of 5-8 us each, at their latency floor
-constexpr int GEMM_BATCH_MAX = 6;
+constexpr int GEMM_BATCH_MAX = 10;
 struct GemmBatch {
     GemmArgs g[GEMM_BATCH_MAX];          // C = the job's partial buffer, ldc = N, kchunk set
     int first[GEMM_BATCH_MAX + 1];       // first workgroup of each job

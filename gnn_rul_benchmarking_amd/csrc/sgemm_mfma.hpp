@@ -48,7 +48,7 @@ struct SplitKColsumJob {
 size_t sgemm_splitk_colsum_batch_floats(const SplitKColsumJob* jobs, int n);
 int sgemm_splitk_colsum_batch(const SplitKColsumJob* jobs, int n, const float* ones, float* partial, size_t partial_floats, hipStream_t st);
 
-// Up to six products C_j = A_j B_j^T (element strides as in sgemm) as one split-K launch of the 64 x 64 tile kernel + one reduction launch:
+// Up to ten products C_j = A_j B_j^T (element strides as in sgemm) as one split-K launch of the 64 x 64 tile kernel + one reduction launch:
 // the parameter gradients of a small model, each of which is a 5-8 us launch pair at its latency floor.  Deterministic (fixed slices,
 // fixed-order sums); `partial`: sgemm_splitk_batch_floats(jobs, n) floats.
 struct SplitKJob {

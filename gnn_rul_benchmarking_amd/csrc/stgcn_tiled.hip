@@ -1070,8 +1070,22 @@ struct TWs {
     size_t off_amax;            // [3 L + 3][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l| and |fc1.weight|, |d Hpre_l|, |pooled|, |d y1|
                                 // (the operand scales of the GEMMs)
     size_t cells_bytes;
+    size_t split_floats;
     int grid;
 };
+// Small wirings (PHM2012 c2: 160 patches): every parameter-gradient product of the step -- fc2.weight, fc1.weight, fc1.bias, theta and its
+// bias of every layer -- is a few 64 x 64 tiles over a long reduction, a launch pair of 5-10 us each at its latency floor: 14 launches of
+// a 44-launch step.  They feed nothing in the call and run as ONE split-K launch + ONE reduction behind the backward chain
+// (sgemm_splitk_batch; 3 + 2 L jobs).  Larger wirings keep the scaled 128 / 256-tile kernels and the side stream.
+static inline bool t_pgrad_batched(int N, int L) { return N <= 256 && 3 + 2 * L <= 10; }
+// (M, N, K) of the jobs in launch order: fc2.weight, fc1.weight, fc1.bias, then (theta, theta bias) of layers L-1 .. 0
+static int t_pgrad_dims(int N, int L, int Bi, int R, SplitKJob* j) {
+    int n = 0;
+    auto add = [&](int M, int Nn, int K) { j[n] = SplitKJob{}; j[n].M = M; j[n].N = Nn; j[n].K = K > 0 ? K : 1; ++n; };
+    add(1, N, Bi); add(N, N, Bi); add(1, N, Bi);
+    for (int l = 0; l < L; ++l) { add(N, N, R); add(1, N, R); }
+    return n;
+}
 
 static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     const int N = s->num_patch, L = s->num_layers;
@@ -1113,6 +1127,14 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
                              sgemm_splitk_need_floats(1, N, Bi), sgemm_splitk_need_floats(1, 1, Bi), sgemm_splitk_need_floats(Bi, N, N),
                              R < 2048 ? sgemm_splitk_need_floats(R, N, N) : (size_t)0})
                 need = v > need ? v : need;
+        // (... or every parameter-gradient product of a step at once: t_pgrad_batched)
+        if (B > 0 && t_pgrad_batched(N, L)) {
+            SplitKJob dims[3 + 2 * 8];
+            const int nj = t_pgrad_dims(N, L, Bi, R, dims);
+            const size_t bf = sgemm_splitk_batch_floats(dims, nj);
+            need = bf > need ? bf : need;
+        }
+        w->split_floats = need;
         w->off_split = o; o += al256(need * sizeof(float));
         w->off_split2 = o; o += al256(need * sizeof(float));          // the side stream's own (parameter-gradient products)
     }
@@ -1156,7 +1178,15 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     // (data parallel with overlap): its contract orders the caller's all-reduces against `stream`.
     // ... nor at batch-100-sized row counts: there every launch sits at its latency floor and the fork / join events cost more than the
     // overlap returns (XJTU-SY batch 100: 0.38 -> 0.40 ms with it, batch 1024: 1.24 -> 1.22 ms).
-    AuxFork fk(stream, (ready || B * F < 2048) ? nullptr : ar->aux_stream);
+    // (every parameter-gradient product as one launch pair at the end of the chain where the wiring is small: no side stream then)
+    const bool pg_batch = !ready && t_pgrad_batched(N, L);
+    SplitKJob pjobs[3 + 2 * 8];
+    int npj = 0;
+    auto pjob = [&](const float* A, int64_t sAm, int64_t sAk, const float* Bm, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int M, int Nn, int K) {
+        pjobs[npj] = SplitKJob{A, sAm, sAk, Bm, sBn, sBk, C, ldc, M, Nn, K};
+        ++npj;
+    };
+    AuxFork fk(stream, (ready || pg_batch || B * F < 2048) ? nullptr : ar->aux_stream);
     hipStream_t wst = fk.side();
     // operand scales of the large GEMMs: partial maxima rows, one float per workgroup of the producing launch.  The scaled form only where
     // the producers' grids fit a row (every reference wiring does: <= 4096 chunks of 256 positions)
@@ -1190,7 +1220,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     t.cells_fwd = cells; t.cells_bwd = cells + T_REP * tc_sf(L);
     const int has_dpred = ar->dpred ? 1 : (ar->y ? 0 : 2);
     const float* gy = ar->dpred ? ar->dpred : ar->y;
-    int rc;
+    int rc = RULGNN_OK;
 
     if (mode == 0 || mode == 2) {
         if (ar->step_state) {
@@ -1248,15 +1278,21 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         float* g = ar->grads;
         fk.fork();
         // fc2: dW2[j] = sum_b dpred[b] y1[b][j];  db2 = sum_b dpred[b]
-        rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split2, wst);
+        if (pg_batch) pjob(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B);
+        else rc = sgemm_splitk(dpredb, 0, 1, y1, 1, N, g + off_fc2_w(N, L), N, 1, N, (int)B, false, split2, wst);
         if (rc != RULGNN_OK) return rc;
         // (db2 = sum_b dpred[b]: accumulated by the head kernel, written by the finalize kernel)
         // fc1: dW1[j][t] = sum_b dy1[b][j] pooled[b][t];  db1[j] = sum_b dy1[b][j];  dpooled = dy1 . W1
+        if (pg_batch) {
+            pjob(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B);
+            pjob(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B);
+        } else {
         rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split2, wst, am_dy1, (int)B,
                           am_dy1 ? am_pool : (float*)nullptr, n_pos);
         if (rc != RULGNN_OK) return rc;
         rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split2, wst);
         if (rc != RULGNN_OK) return rc;
+        }
         // data parallel with overlap: the head's gradients (fc1 is N x N: 4 MB at XJTU-SY) are final here, with the whole layer
         // stack still to run -- the caller may start their all-reduce on another stream (include/rulgnn.h: rulgnn_grad_ready_fn)
         // (without fc2.bias, the last parameter: its gradient comes out of the finalize kernel with the convolution / BatchNorm ones)
@@ -1288,6 +1324,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                 if (rc != RULGNN_OK) return rc;
             }
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
+            if (pg_batch) {
+                pjob(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F));
+                pjob(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F));
+            } else {
             rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split2, wst, am_dh(l), n_dh, am_ax(l),
                               l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
             if (rc != RULGNN_OK) return rc;
@@ -1296,6 +1336,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (l == 0) rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split, stream);
             else rc = sgemm_splitk(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F), false, split2, wst);
             if (rc != RULGNN_OK) return rc;
+            }
             // theta of this layer (weight + bias, contiguous at the head of the layer's block) is final; the convolution and
             // BatchNorm gradients behind it (2 x 220 floats) come out of t_finalize_kernel at the end of the step
             if (ready && l > 0 && ready->fn(ready->user, g, (int64_t)l * LS + off_theta_w(N), (int64_t)N * N + N, wst) != 0)
@@ -1306,6 +1347,10 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                 T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a, (float*)nullptr);
             }
         }
+    }
+    if (npj > 0) {
+        rc = sgemm_splitk_batch(pjobs, npj, split2, w.split_floats, stream);
+        if (rc != RULGNN_OK) return rc;
     }
     TFin f;
     f.gpart = gpart; f.cells_fwd = t.cells_fwd; f.cells_bwd = t.cells_bwd;
