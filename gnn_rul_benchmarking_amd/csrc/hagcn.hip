@@ -44,6 +44,33 @@ struct HgGeom {
     int64_t t_kl, t_topk, t_one, t_split, total_floats;
 };
 
+// The parameter-gradient products of the graph backward -- per level six (weight = dZ^T In, bias = column sums of dZ) pairs and the GIN
+// eps sum: 39 products, each a launch pair of 5-18 us at its latency floor (66 launches, 0.55 ms of an 11-ms step, all in front of the
+// LSTM stack's BPTT).  They feed nothing in the call: ten at a time they are jobs of one split-K launch + one reduction
+// (sgemm_splitk_batch).  ws == nullptr: shapes only (scratch sizing).
+constexpr int HG_PGRAD_JOBS = NLV * 13, HG_PGRAD_BATCH = 10;
+static int hg_pgrad_jobs(const HgGeom& g, float* ws, float* gr, SplitKJob* jobs) {
+    int n = 0;
+    float* one = ws ? ws + g.t_one : nullptr;
+    auto P = [&](int64_t off) -> const float* { return ws ? ws + off : nullptr; };
+    auto G_ = [&](int off) -> float* { return gr ? gr + off : nullptr; };
+    for (int l = 0; l < NLV; ++l) {
+        const int R = (int)(g.rows[l] > 0 ? g.rows[l] : 1), Fin = g.fin[l], Hd = g.Hd, Hh = g.Hh;
+        auto wgrad = [&](const float* dz, int O, const float* in, int K, float* dw, float* db) {
+            jobs[n++] = SplitKJob{dz, 1, O, in, 1, K, dw, K, O, K, R};
+            jobs[n++] = SplitKJob{one, 0, 0, dz, 1, O, db, O, 1, O, R};
+        };
+        wgrad(P(g.d_za[l]), Hd, P(g.t_u[l]), Fin, G_(g.o_w0[l]), G_(g.o_b0[l]));
+        wgrad(P(g.d_zb[l]), Hd, P(g.t_h[l]), Hd, G_(g.o_w2[l]), G_(g.o_b2[l]));
+        wgrad(P(g.d_zm[l]), Hd, P(g.t_axs[l]), Hd, G_(g.o_mw[l]), G_(g.o_mb[l]));
+        wgrad(P(g.d_zp0[l]), Hh, P(g.t_g[l]), Hd, G_(g.o_pw0[l]), G_(g.o_pb0[l]));
+        wgrad(P(g.d_zp1[l]), 1, P(g.t_pm[l]), Hh, G_(g.o_pw2[l]), G_(g.o_pb2[l]));
+        wgrad(P(g.d_zr[l]), 1, P(g.t_axs[l]), Hd, G_(g.o_rw[l]), G_(g.o_rb[l]));
+        jobs[n++] = SplitKJob{P(g.d_eps[l]), 0, 1, one, 0, 0, G_(g.o_eps[l]), 1, 1, 1, (int)(g.G > 0 ? g.G : 1)};      // sum over the graphs
+    }
+    return n;
+}
+
 __host__ int hg_geometry(const rulgnn_hagcn_shape* s, HgGeom* g) {
     if (!s) return RULGNN_EINVAL;
     if (s->graphs < 0 || s->num_node < 1 || s->enc_dim < 1 || s->hidden_dim < 2) return RULGNN_EINVAL;
@@ -84,10 +111,13 @@ __host__ int hg_geometry(const rulgnn_hagcn_shape* s, HgGeom* g) {
     g->t_topk = tk(g->G * TOPK_SLOTS);
     g->t_one = tk(64);
     size_t mx = 1;
-    for (int l = 0; l < NLV; ++l) {
-        const int widest = g->fin[l] > g->Hd ? g->fin[l] : g->Hd;          // gin.mlp.0.weight is [Hd x fin]
-        const size_t v = sgemm_splitk_bound_floats(g->Hd, widest, (int)g->rows[l]);
-        if (v > mx) mx = v;
+    {   // scratch of the parameter-gradient products: launched ten jobs at a time (hg_pgrad_jobs / sgemm_splitk_batch)
+        SplitKJob jobs[HG_PGRAD_JOBS];
+        const int nj = hg_pgrad_jobs(*g, nullptr, nullptr, jobs);
+        for (int j0 = 0; j0 < nj; j0 += HG_PGRAD_BATCH) {
+            const size_t v = sgemm_splitk_batch_floats(jobs + j0, nj - j0 < HG_PGRAD_BATCH ? nj - j0 : HG_PGRAD_BATCH);
+            if (v > mx) mx = v;
+        }
     }
     g->t_split = tk((int64_t)mx);
     g->total_floats = t;
@@ -540,23 +570,15 @@ int hagcn_graph_backward(const rulgnn_hagcn_shape* s, const rulgnn_hagcn_args* a
                        a->dfeats, a->dkl, a->dnodes);
     float* one = ws + g.t_one;
     float* split = ws + g.t_split;
-    float* gr = a->grads;
     hipLaunchKernelGGL(hg_fill_one_kernel, dim3(1), dim3(1), 0, st, one);
-    const int Hd = g.Hd, Hh = g.Hh;
-    for (int l = 0; l < NLV; ++l) {
-        const int R = (int)g.rows[l], Fin = g.fin[l];
-        // weight = dZ^T In ; bias = column sums of dZ
-        auto wgrad = [&](const float* dz, int O, const float* in, int K, float* dw, float* db) {
-            HG_RC(sgemm_splitk(dz, 1, O, in, 1, K, dw, K, O, K, R, false, split, st));
-            return sgemm_splitk(one, 0, 0, dz, 1, O, db, O, 1, O, R, false, split, st);
-        };
-        HG_RC(wgrad(ws + g.d_za[l], Hd, ws + g.t_u[l], Fin, gr + g.o_w0[l], gr + g.o_b0[l]));
-        HG_RC(wgrad(ws + g.d_zb[l], Hd, ws + g.t_h[l], Hd, gr + g.o_w2[l], gr + g.o_b2[l]));
-        HG_RC(wgrad(ws + g.d_zm[l], Hd, ws + g.t_axs[l], Hd, gr + g.o_mw[l], gr + g.o_mb[l]));
-        HG_RC(wgrad(ws + g.d_zp0[l], Hh, ws + g.t_g[l], Hd, gr + g.o_pw0[l], gr + g.o_pb0[l]));
-        HG_RC(wgrad(ws + g.d_zp1[l], 1, ws + g.t_pm[l], Hh, gr + g.o_pw2[l], gr + g.o_pb2[l]));
-        HG_RC(wgrad(ws + g.d_zr[l], 1, ws + g.t_axs[l], Hd, gr + g.o_rw[l], gr + g.o_rb[l]));
-        (void)block_sum((const float*)(ws + g.d_eps[l]), g.G, gr + g.o_eps[l], st);
+    if (g.G > 0) {
+        SplitKJob jobs[HG_PGRAD_JOBS];
+        const int nj = hg_pgrad_jobs(g, ws, a->grads, jobs);
+        const size_t split_floats = (size_t)(g.total_floats - g.t_split);
+        for (int j0 = 0; j0 < nj; j0 += HG_PGRAD_BATCH)
+            HG_RC(sgemm_splitk_batch(jobs + j0, nj - j0 < HG_PGRAD_BATCH ? nj - j0 : HG_PGRAD_BATCH, split, split_floats, st));
+    } else if (hipMemsetAsync(a->grads, 0, sizeof(float) * (size_t)g.nparam, st) != hipSuccess) {      // (no graphs: every sum is empty)
+        return RULGNN_EHIP;
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }

@@ -9,6 +9,8 @@ f = glob.glob("gpurun_out/cpf/**/k_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adam_" in r["Kernel_Name"]]
+if len(idx) < 12:        # (HAGCN steps torch.optim.Adam: the fused multi-tensor kernel, two launches per step -- take every second one)
+    idx = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]][1::2]
 # a step from the steady-state loop (the second timed loop of host_vs_gpu.py): ten steps before the end
 lo, hi = idx[-12] + 1, idx[-11] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
