@@ -26,7 +26,7 @@ struct LstmGeom {
     int Bq, I, H, H4;           // sequences, input width, hidden width
     int64_t rows;               // Bq * T
     // workspace offsets (floats); every per-direction tensor is [dir][q][t][.]
-    int64_t o_gi, o_gates, o_c, o_tc, o_h, o_hprev, o_dgates, o_one, o_split, total;
+    int64_t o_gi, o_gates, o_c, o_tc, o_h, o_hprev, o_dgates, o_one, o_split, o_split_floats, total;
 };
 
 __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
@@ -55,6 +55,18 @@ __host__ int lstm_geometry(const rulgnn_bilstm_shape* s, LstmGeom* g) {
         const int64_t v = (int64_t)sgemm_splitk_need_floats(mn.first, mn.second, (int)g->rows);
         if (v > mx) mx = v;
     }
+    {   // ... or the layer's eight parameter-gradient products at once (bilstm_backward: sgemm_splitk_batch)
+        const int R = (int)(g->rows > 0 ? g->rows : 1);
+        SplitKJob dims[8];
+        for (int d = 0; d < 2; ++d) {
+            dims[4 * d + 0] = SplitKJob{nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, g->H4, g->I, R};
+            dims[4 * d + 1] = SplitKJob{nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, g->H4, g->H, R};
+            dims[4 * d + 2] = dims[4 * d + 3] = SplitKJob{nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 1, g->H4, R};
+        }
+        const int64_t v = (int64_t)sgemm_splitk_batch_floats(dims, 8);
+        if (v > mx) mx = v;
+    }
+    g->o_split_floats = mx;
     g->o_split = tk(mx);
     g->total = o;
     return RULGNN_OK;
@@ -414,14 +426,21 @@ int bilstm_backward(const rulgnn_bilstm_shape* s, const rulgnn_bilstm_args* a, h
         hipEvent_t ev = aux_pooled_event();
         if (!ev || hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(wst, ev, 0) != hipSuccess) return RULGNN_EHIP;
     }
+    // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db_ih = db_hh = column sums of dG -- of both directions: ONE split-K launch + ONE reduction
+    // (they were seven launches per direction, 5-8 us each; behind the first layer's BPTT nothing is left to hide them under)
+    SplitKJob jobs[8];
+    int nj = 0;
     for (int d = 0; d < ndir; ++d) {
         const float* dg = ws + g.o_dgates + (int64_t)d * g.rows * H4;
-        // dW_ih = dG^T x ; dW_hh = dG^T h_prev ; db = column sums
-        LS_RC(sgemm_splitk(dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R, false, split, wst));
-        LS_RC(sgemm_splitk(dg, 1, H4, ws + g.o_hprev + (int64_t)d * g.rows * H, 1, H, a->dw_hh[d], H, H4, H, R, false, split, wst));
-        LS_RC(sgemm_splitk(one, 0, 0, dg, 1, H4, a->db_ih[d], H4, 1, H4, R, false, split, wst));
-        hipLaunchKernelGGL(lstm_copy_kernel, dim3((H4 + 255) / 256), dim3(256), 0, wst, (const float*)a->db_ih[d], a->db_hh[d], H4);
+        jobs[nj++] = SplitKJob{dg, 1, H4, a->x, 1, I, a->dw_ih[d], I, H4, I, R};
+        jobs[nj++] = SplitKJob{dg, 1, H4, ws + g.o_hprev + (int64_t)d * g.rows * H, 1, H, a->dw_hh[d], H, H4, H, R};
+        jobs[nj++] = SplitKJob{one, 0, 0, dg, 1, H4, a->db_ih[d], H4, 1, H4, R};
+        jobs[nj++] = SplitKJob{one, 0, 0, dg, 1, H4, a->db_hh[d], H4, 1, H4, R};
     }
+    if (R > 0) LS_RC(sgemm_splitk_batch(jobs, nj, split, (size_t)g.o_split_floats, wst));
+    else
+        for (int j = 0; j < nj; ++j)
+            if (hipMemsetAsync(jobs[j].C, 0, sizeof(float) * (size_t)jobs[j].M * jobs[j].N, wst) != hipSuccess) return RULGNN_EHIP;
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
