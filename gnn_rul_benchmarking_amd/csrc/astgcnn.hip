@@ -12,6 +12,7 @@
 // Node mean and Chebyshev projection commute, so the [batch*nodes, K*E] x [K*E, O] product is done on the node sums
 // ([batch, K*E]) -- nodes times less work, same result up to summation order.
 #include "aux_stream.hpp"
+#include "reduce_device.hpp"
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
 #include "tcn_nodes.hpp"
@@ -596,10 +597,26 @@ __global__ __launch_bounds__(AB) void ast_graph_bwd_kernel(AstGeom g, const floa
 // (x bn_scale: under synchronised BatchNorm the cells hold GLOBAL sums on every rank and only one rank may contribute them)
 // (one workgroup; round 4: also the batch statistics out and the loss sum -- two launches less on the chain)
 __device__ __forceinline__ void ast_bn_batch_body(const AstGeom& g, const Cells* cells, float* __restrict__ bn_batch, float weight, int e);
-__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells* cells, float* __restrict__ grads, float bn_scale,
-                                                         float* __restrict__ bn_batch, float bn_weight, const float* __restrict__ sqerr,
-                                                         float* __restrict__ loss, float* __restrict__ bn_running, float bn_momentum) {
-    __shared__ float red[AB];
+struct AstFin {
+    const Cells* cells;
+    float* grads;
+    float bn_scale;
+    float* bn_batch;
+    float bn_weight;
+    const float* sqerr;
+    float* loss;
+    float* bn_running;
+    float bn_momentum;
+};
+// (the first AB threads of the workgroup work; every thread of it must call: barriers inside)
+__device__ __forceinline__ void ast_finalize_body(const AstGeom& g, const AstFin& f, float (&red)[AB]) {
+    const Cells* cells = f.cells;
+    float* __restrict__ grads = f.grads;
+    float* __restrict__ bn_batch = f.bn_batch;
+    float* __restrict__ bn_running = f.bn_running;
+    const float* __restrict__ sqerr = f.sqerr;
+    float* __restrict__ loss = f.loss;
+    const float bn_scale = f.bn_scale, bn_weight = f.bn_weight, bn_momentum = f.bn_momentum;
     const int c = threadIdx.x;
     if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
         grads[g.o_g1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
@@ -621,9 +638,11 @@ __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells
         }
     }
     if (loss) {             // strided partial sums, then a fixed-order tree (block_sum's arithmetic at 256 threads)
-        float a = 0.f;
-        for (int64_t i = threadIdx.x; i < g.B; i += AB) a += sqerr[i];
-        red[threadIdx.x] = a;
+        if (threadIdx.x < AB) {
+            float a = 0.f;
+            for (int64_t i = threadIdx.x; i < g.B; i += AB) a += sqerr[i];
+            red[threadIdx.x] = a;
+        }
         __syncthreads();
         for (int m = AB / 2; m > 0; m >>= 1) {
             if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
@@ -631,6 +650,25 @@ __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, const Cells
         }
         if (threadIdx.x == 0) loss[0] = red[0];
     }
+}
+__global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, AstFin f) {
+    __shared__ float red[AB];
+    ast_finalize_body(g, f, red);
+}
+// The end of a one-stream step as ONE launch: the slice sums of the five parameter-gradient products (reduce_slices_batch_body), the
+// partial-row sums of both convolutions' weights and of the gate bias (rows_sum_job_body) and, in one more workgroup, the finalize body --
+// three dependent launches of ~5 us each on a chain whose every launch counts.
+__global__ __launch_bounds__(1024) void ast_tail_kernel(AstGeom g, AstFin f, RowsSumJobs jb, int nb0, int nb1, int nb2, ReduceBatch rb) {
+    __shared__ float red[32][33];
+    __shared__ float part[16][64];
+    __shared__ float fred[AB];
+    const int nr = rb.first[rb.n];
+    const int b = blockIdx.x;
+    if (b < nr) reduce_slices_batch_body(rb, b, part);
+    else if (b - nr < nb0) rows_sum_job_body(jb, 0, b - nr, red);
+    else if (b - nr - nb0 < nb1) rows_sum_job_body(jb, 1, b - nr - nb0, red);
+    else if (b - nr - nb0 - nb1 < nb2) rows_sum_job_body(jb, 2, b - nr - nb0 - nb1, red);
+    else ast_finalize_body(g, f, fred);
 }
 
 // Synchronised BatchNorm: the 16 replicas of one reduction pair (2 MAXN contiguous doubles) collapsed into replica 0, the
@@ -875,17 +913,33 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
         AST_RC(sync_pair(1, 0));
         hipLaunchKernelGGL((tcn_conv_bwd_kernel<1, AstGeom, SN, SE, TTB>), dim3(rows), dim3(TTB), 0, st, g, prm, cells, (const float*)F(w.z1), (const float*)F(w.dy1),
                            a->x, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, F(w.gp1));
-        if (!fk.active()) AST_RC(sgemm_splitk_batch(jobs, 5, split, w.split_floats, st));
+        AstFin fin;
+        fin.cells = cells; fin.grads = gr; fin.bn_scale = sync ? sync->bn_param_grad_scale : 1.0f;
+        fin.bn_batch = ((mode & 1) && training) ? a->bn_batch : (float*)nullptr;
+        fin.bn_weight = a->bn_moment_weight; fin.sqerr = F(w.sqerr);
+        fin.loss = (mse && a->loss) ? a->loss : (float*)nullptr;
+        fin.bn_running = ((mode & 1) && training && a->bn_batch && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr;
+        fin.bn_momentum = bn_momentum;
+        if (!fk.active()) {
+            // one stream: the products' slice sums, both convolutions' partial weight rows, the gate's bias gradient (the graph backward's
+            // partial rows; theta.bias and gate.bias share it) and the finalize body in ONE launch behind the product launch
+            ReduceBatch rb;
+            AST_RC(sgemm_splitk_batch_products(jobs, 5, split, w.split_floats, st, &rb));
+            RowsSumJobs jb{};
+            jb.part[0] = F(w.gp1); jb.out[0] = gr + g.o_w1; jb.rows[0] = rows; jb.n[0] = N * N * KT; jb.ld[0] = (int64_t)N * N * KT;
+            jb.part[1] = F(w.gp2); jb.out[1] = gr + g.o_w2; jb.rows[1] = rows; jb.n[1] = N * N * KT; jb.ld[1] = (int64_t)N * N * KT;
+            jb.part[2] = F(w.thb); jb.out[2] = gr + g.o_thb; jb.out2[2] = gr + g.o_gb; jb.rows[2] = bwd_rows; jb.n[2] = E; jb.ld[2] = E;
+            const int nb01 = (N * N * KT + 31) / 32, nb2 = (E + 31) / 32;
+            hipLaunchKernelGGL(ast_tail_kernel, dim3(rb.first[rb.n] + 2 * nb01 + nb2 + 1), dim3(1024), 0, st, g, fin, jb, nb01, nb01, nb2, rb);
+            return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+        }
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
         // ... and the gate's bias gradient (the graph backward's partial rows; theta.bias and gate.bias share it)
         AST_RC(rows_sum3(F(w.gp1), gr + g.o_w1, F(w.gp2), gr + g.o_w2, rows, (int64_t)N * N * KT, N * N * KT, F(w.thb), gr + g.o_thb, gr + g.o_gb,
                          bwd_rows, (int64_t)E, E, st));
         // (the finalize kernel reads the cells and the squared errors only -- nothing the side stream writes: it runs in front of the join,
         // beside the side stream's last product, instead of behind the wake-up of a stream that sat waiting)
-        hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
-                           ((mode & 1) && training) ? a->bn_batch : (float*)nullptr, a->bn_moment_weight, (const float*)F(w.sqerr),
-                           (mse && a->loss) ? a->loss : (float*)nullptr,
-                           ((mode & 1) && training && a->bn_batch && a->bn_moment_weight == 0.f) ? bn_running_out : (float*)nullptr, bn_momentum);
+        hipLaunchKernelGGL(ast_finalize_kernel, dim3(1), dim3(AB), 0, st, g, fin);
         AST_RC(fk.join());
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;

@@ -1,6 +1,7 @@
 // SGEMM on the gfx950 matrix cores, shared by every family (interface: sgemm_mfma.hpp).  ONE translation unit: the kernels used
 // to live in the header and were instantiated in every unit that included it (most of the library size and build time).
 #include "sgemm_mfma.hpp"
+#include "reduce_device.hpp"
 
 namespace rulgnn {
 
@@ -105,7 +106,6 @@ static __device__ __forceinline__ void sgemm_mfma_body(GemmArgs g, int bx, int b
 static __global__ __launch_bounds__(256) void sgemm_mfma_kernel(GemmArgs g) { sgemm_mfma_body(g, blockIdx.x, blockIdx.y, blockIdx.z); }
 // several split-K products of the 64 x 64 tile kernel as ONE launch (blockIdx.x: the jobs' tiles x slices back to back) and their slice
 // reductions as one more: the parameter gradients of a small model are five to ten launch pairs of 5-8 us each, at their latency floor
-constexpr int GEMM_BATCH_MAX = 10;
 struct GemmBatch {
     GemmArgs g[GEMM_BATCH_MAX];          // C = the job's partial buffer, ldc = N, kchunk set
     int first[GEMM_BATCH_MAX + 1];       // first workgroup of each job
@@ -1333,35 +1333,9 @@ static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_kernel(const 
 }
 
 // ... of several products in one launch (sgemm_splitk_batch)
-struct ReduceBatch {
-    const float* partial[GEMM_BATCH_MAX];
-    float* C[GEMM_BATCH_MAX];
-    int64_t ldc[GEMM_BATCH_MAX];
-    int M[GEMM_BATCH_MAX], N[GEMM_BATCH_MAX], slices[GEMM_BATCH_MAX];
-    int first[GEMM_BATCH_MAX + 1];
-    int n;
-};
 static __global__ __launch_bounds__(1024) void sgemm_reduce_slices_batch_kernel(ReduceBatch b) {
     __shared__ float part[16][64];
-    int j = 0;
-#pragma unroll
-    for (int q = 1; q < GEMM_BATCH_MAX; ++q)
-        if (q < b.n && (int)blockIdx.x >= b.first[q]) j = q;
-    const float* __restrict__ partial = b.partial[j];
-    const int M = b.M[j], N = b.N[j], slices = b.slices[j];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int e = (blockIdx.x - b.first[j]) * 64 + lane;
-    float a = 0.f;
-    if (e < M * N)
-        for (int z = q; z < slices; z += 16) a += partial[(int64_t)z * M * N + e];
-    part[q][lane] = a;
-    __syncthreads();
-    if (q == 0 && e < M * N) {
-        float v = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) v += (part[r][lane] + part[r + 1][lane]) + (part[r + 2][lane] + part[r + 3][lane]);
-        b.C[j][(int64_t)(e / N) * b.ldc[j] + (e % N)] = v;
-    }
+    reduce_slices_batch_body(b, blockIdx.x, part);
 }
 size_t sgemm_splitk_batch_floats(const SplitKJob* jobs, int n) {
     size_t f = 0;
@@ -1369,6 +1343,9 @@ size_t sgemm_splitk_batch_floats(const SplitKJob* jobs, int n) {
     return f;
 }
 int sgemm_splitk_batch(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st) {
+    return sgemm_splitk_batch_products(jobs, n, partial, partial_floats, st, nullptr);
+}
+int sgemm_splitk_batch_products(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st, ReduceBatch* reduce_out) {
     if (n < 1 || n > GEMM_BATCH_MAX) return RULGNN_EINVAL;
     if (partial_floats < sgemm_splitk_batch_floats(jobs, n)) return RULGNN_EWORKSPACE;
     GemmBatch gb{};
@@ -1395,7 +1372,8 @@ int sgemm_splitk_batch(const SplitKJob* jobs, int n, float* partial, size_t part
     gb.first[n] = wg; rb.first[n] = rwg;
     (void)hipGetLastError();
     hipLaunchKernelGGL(sgemm_mfma_batch_kernel, dim3(wg), dim3(256), 0, st, gb);
-    hipLaunchKernelGGL(sgemm_reduce_slices_batch_kernel, dim3(rwg), dim3(1024), 0, st, rb);
+    if (reduce_out) *reduce_out = rb;          // (the caller runs the slice sums inside a launch of its own: reduce_slices_batch_body)
+    else hipLaunchKernelGGL(sgemm_reduce_slices_batch_kernel, dim3(rwg), dim3(1024), 0, st, rb);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 
@@ -1898,44 +1876,11 @@ static __global__ __launch_bounds__(1024) void rows_sum_kernel(const float* __re
         out[e] = v;
     }
 }
-// up to three such sums in one launch (blockIdx.y picks the job; a job may write its result twice: out and out2)
-struct RowsSumJobs {
-    const float* part[3];
-    float* out[3];
-    float* out2[3];
-    int rows[3], n[3];
-    int64_t ld[3];
-};
+// up to three such sums in one launch (blockIdx.y picks the job; reduce_device.hpp)
 static __global__ __launch_bounds__(1024) void rows_sum_multi_kernel(RowsSumJobs jb) {
     __shared__ float red[32][33];
-    const int job = blockIdx.y;
-    const float* part = jb.part[job];
-    const int rows = jb.rows[job], n = jb.n[job];
-    const int64_t ld = jb.ld[job];
-    const int lane = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int e = blockIdx.x * 32 + lane;
-    if (blockIdx.x * 32 >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (e < n) {
-        const float* p = part + e;
-        int r = sl;
-        for (; r + 96 < rows; r += 128) {
-            a0 += p[(int64_t)r * ld];
-            a1 += p[(int64_t)(r + 32) * ld];
-            a2 += p[(int64_t)(r + 64) * ld];
-            a3 += p[(int64_t)(r + 96) * ld];
-        }
-        for (; r < rows; r += 32) a0 += p[(int64_t)r * ld];
-    }
-    red[sl][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (sl == 0 && e < n) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) v += red[q][lane];
-        jb.out[job][e] = v;
-        if (jb.out2[job]) jb.out2[job][e] = v;
-    }
+    if ((int)blockIdx.x * 32 >= jb.n[blockIdx.y]) return;
+    rows_sum_job_body(jb, blockIdx.y, blockIdx.x, red);
 }
 int rows_sum2(const float* partA, float* outA, const float* partB, float* outB, int rows, int64_t ld, int n, hipStream_t st) {
     return rows_sum3(partA, outA, partB, outB, rows, ld, n, nullptr, nullptr, nullptr, 0, 0, 0, st);

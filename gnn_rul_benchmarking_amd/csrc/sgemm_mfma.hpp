@@ -59,6 +59,10 @@ struct SplitKJob {
 };
 size_t sgemm_splitk_batch_floats(const SplitKJob* jobs, int n);
 int sgemm_splitk_batch(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st);
+// ... the product launch alone; *reduce (reduce_device.hpp: ReduceBatch, reduce->first[n] workgroups of 1024 threads) describes the slice sums
+// for a kernel of the caller that runs reduce_slices_batch_body beside its own last reductions
+struct ReduceBatch;
+int sgemm_splitk_batch_products(const SplitKJob* jobs, int n, float* partial, size_t partial_floats, hipStream_t st, ReduceBatch* reduce);
 
 // out[e] = sum_r part[r * ld + e] over `rows` partial rows (fixed order); out[0] = sum(v[0..n)) with one workgroup (fixed order)
 int rows_sum(const float* part, int rows, int64_t ld, int n, float* out, hipStream_t st);
