@@ -11,6 +11,7 @@
 //   conv1 | conv2 | gate -> graph -> head | gate_bwd (BN2 sums) | conv2_bwd (BN1 sums) | conv1_bwd | finalize.
 // Node mean and Chebyshev projection commute, so the [batch*nodes, K*E] x [K*E, O] product is done on the node sums
 // ([batch, K*E]) -- nodes times less work, same result up to summation order.
+#include "adam_device.hpp"
 #include "aux_stream.hpp"
 #include "reduce_device.hpp"
 #include "sgemm_mfma.hpp"
@@ -608,8 +609,10 @@ struct AstFin {
     float* bn_running;
     float bn_momentum;
 };
-// (the first AB threads of the workgroup work; every thread of it must call: barriers inside)
-__device__ __forceinline__ void ast_finalize_body(const AstGeom& g, const AstFin& f, float (&red)[AB]) {
+// (the first AB threads of the workgroup work; every thread of it must call: barriers inside.  epi(dst, value): behind every gradient
+// element stored -- the optimizer update of that element in a whole step, adam_device.hpp)
+template <class Epi>
+__device__ __forceinline__ void ast_finalize_body(const AstGeom& g, const AstFin& f, float (&red)[AB], const Epi& epi) {
     const Cells* cells = f.cells;
     float* __restrict__ grads = f.grads;
     float* __restrict__ bn_batch = f.bn_batch;
@@ -619,10 +622,14 @@ __device__ __forceinline__ void ast_finalize_body(const AstGeom& g, const AstFin
     const float bn_scale = f.bn_scale, bn_weight = f.bn_weight, bn_momentum = f.bn_momentum;
     const int c = threadIdx.x;
     if (c < g.N) {          // the conv weight rows are summed by rows_sum (sgemm_mfma.hpp)
-        grads[g.o_g1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 1);
-        grads[g.o_b1 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 0);
-        grads[g.o_g2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 1);
-        grads[g.o_b2 + c] = bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 0);
+        const float v4[4] = {bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 1), bn_scale * (float)cell_sum(cells, &Cells::bwd, 0, c, 0),
+                             bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 1), bn_scale * (float)cell_sum(cells, &Cells::bwd, 1, c, 0)};
+        const int o4[4] = {g.o_g1, g.o_b1, g.o_g2, g.o_b2};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            grads[o4[q] + c] = v4[q];
+            epi(grads + o4[q] + c, v4[q]);
+        }
     }
     if (bn_batch && c >= 64 && c < 64 + 2 * g.N) {
         ast_bn_batch_body(g, cells, bn_batch, bn_weight, c - 64);
@@ -653,22 +660,24 @@ __device__ __forceinline__ void ast_finalize_body(const AstGeom& g, const AstFin
 }
 __global__ __launch_bounds__(AB) void ast_finalize_kernel(AstGeom g, AstFin f) {
     __shared__ float red[AB];
-    ast_finalize_body(g, f, red);
+    ast_finalize_body(g, f, red, NoEpilogue{});
 }
 // The end of a one-stream step as ONE launch: the slice sums of the five parameter-gradient products (reduce_slices_batch_body), the
 // partial-row sums of both convolutions' weights and of the gate bias (rows_sum_job_body) and, in one more workgroup, the finalize body --
-// three dependent launches of ~5 us each on a chain whose every launch counts.
-__global__ __launch_bounds__(1024) void ast_tail_kernel(AstGeom g, AstFin f, RowsSumJobs jb, int nb0, int nb1, int nb2, ReduceBatch rb) {
+// three dependent launches of ~5 us each on a chain whose every launch counts.  In a whole step also the optimizer: every element of the
+// gradient (13 parameter groups) is finalised here by exactly one thread, which applies Adam to that parameter on the spot (`ad`,
+// adam_device.hpp: the arithmetic of adam_step_kernel) -- no optimizer launch.
+__global__ __launch_bounds__(1024) void ast_tail_kernel(AstGeom g, AstFin f, RowsSumJobs jb, int nb0, int nb1, int nb2, ReduceBatch rb, AdamFuse ad) {
     __shared__ float red[32][33];
     __shared__ float part[16][64];
     __shared__ float fred[AB];
     const int nr = rb.first[rb.n];
     const int b = blockIdx.x;
-    if (b < nr) reduce_slices_batch_body(rb, b, part);
-    else if (b - nr < nb0) rows_sum_job_body(jb, 0, b - nr, red);
-    else if (b - nr - nb0 < nb1) rows_sum_job_body(jb, 1, b - nr - nb0, red);
-    else if (b - nr - nb0 - nb1 < nb2) rows_sum_job_body(jb, 2, b - nr - nb0 - nb1, red);
-    else ast_finalize_body(g, f, fred);
+    if (b < nr) reduce_slices_batch_body(rb, b, part, ad);
+    else if (b - nr < nb0) rows_sum_job_body(jb, 0, b - nr, red, ad);
+    else if (b - nr - nb0 < nb1) rows_sum_job_body(jb, 1, b - nr - nb0, red, ad);
+    else if (b - nr - nb0 - nb1 < nb2) rows_sum_job_body(jb, 2, b - nr - nb0 - nb1, red, ad);
+    else ast_finalize_body(g, f, fred, ad);
 }
 
 // Synchronised BatchNorm: the 16 replicas of one reduction pair (2 MAXN contiguous doubles) collapsed into replica 0, the
@@ -825,7 +834,7 @@ size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s) {
 // shapes as compile-time constants, anything else runs the generic <0, 0, 0>
 template <int SN, int SE, int SO>
 static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync,
-                         float* bn_running_out, float bn_momentum) {
+                         float* bn_running_out, float bn_momentum, AdamFuse* adam) {
     // threads of the TCN kernels: 20 nodes x 50 steps are 260 / 400 work items per sample -- one round of 448 threads (tcn_nodes.hpp)
     constexpr int TTB = AB;             // (the matrix-core convolution kernels: four wavefronts, a 16-step column tile each)
     AstGeom g;
@@ -930,7 +939,13 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
             jb.part[1] = F(w.gp2); jb.out[1] = gr + g.o_w2; jb.rows[1] = rows; jb.n[1] = N * N * KT; jb.ld[1] = (int64_t)N * N * KT;
             jb.part[2] = F(w.thb); jb.out[2] = gr + g.o_thb; jb.out2[2] = gr + g.o_gb; jb.rows[2] = bwd_rows; jb.n[2] = E; jb.ld[2] = E;
             const int nb01 = (N * N * KT + 31) / 32, nb2 = (E + 31) / 32;
-            hipLaunchKernelGGL(ast_tail_kernel, dim3(rb.first[rb.n] + 2 * nb01 + nb2 + 1), dim3(1024), 0, st, g, fin, jb, nb01, nb01, nb2, rb);
+            AdamFuse ad{};
+            if (adam && mode == 3 && !sync) {             // (a whole step: applied here; the caller launches no optimizer kernel)
+                ad = *adam;
+                ad.gbase = gr;
+                adam->gbase = gr;
+            }
+            hipLaunchKernelGGL(ast_tail_kernel, dim3(rb.first[rb.n] + 2 * nb01 + nb2 + 1), dim3(1024), 0, st, g, fin, jb, nb01, nb01, nb2, rb, ad);
             return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
         }
         // both convolutions' partial weight rows in one launch (the second used to sit between the two backward kernels)
@@ -946,12 +961,13 @@ static int astgcnn_run_t(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_arg
 }
 
 int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t st, const BnSyncHook* sync, float* bn_running_out,
-                float bn_momentum) {
+                float bn_momentum, AdamFuse* adam) {
+    if (adam) adam->gbase = nullptr;          // (set by the path that applies the update: see stgcn_host.hpp)
     if (s && s->time_length == 50 && s->output_dim == 64) {
-        if (s->num_nodes == 20) return astgcnn_run_t<20, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum);
-        if (s->num_nodes == 14) return astgcnn_run_t<14, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum);
+        if (s->num_nodes == 20) return astgcnn_run_t<20, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum, adam);
+        if (s->num_nodes == 14) return astgcnn_run_t<14, 50, 64>(s, a, mode, st, sync, bn_running_out, bn_momentum, adam);
     }
-    return astgcnn_run_t<0, 0, 0>(s, a, mode, st, sync, bn_running_out, bn_momentum);
+    return astgcnn_run_t<0, 0, 0>(s, a, mode, st, sync, bn_running_out, bn_momentum, adam);
 }
 
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,

@@ -3,17 +3,10 @@
 //                       L2 weight decay folded into the gradient, bias-corrected, no amsgrad.
 //   bn_running_update:  nn.BatchNorm1d running statistics (momentum 0.1, unbiased running variance).
 #include "stgcn_host.hpp"
+#include "adam_device.hpp"
 
 namespace rulgnn {
 
-__device__ __forceinline__ void adam_value(float& pi, float g, float& mi, float& vi, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
-                                           float beta2, float eps, float wd, float gscale) {
-    const float gi = fmaf(wd, pi, g * gscale);
-    mi = fmaf(beta1, mi, (1.f - beta1) * gi);
-    vi = fmaf(beta2, vi, (1.f - beta2) * gi * gi);
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    pi = pi - lr_over_bc1 * (mi / denom);
-}
 __device__ __forceinline__ void adam_element(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, int64_t i, float lr_over_bc1, float inv_sqrt_bc2, float beta1,
                                              float beta2, float eps, float wd, float gscale) {
@@ -173,6 +166,17 @@ int bn_running_update(float* bn, const float* batch, int num_layers, int64_t cou
     hipLaunchKernelGGL(bn_running_update_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, bn, batch, n_bn,
                        momentum, unbias, from_moments, guard);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+
+// the constants adam_step passes to its kernel, for a step kernel that applies the update itself (adam_device.hpp: AdamFuse)
+void adam_fuse_args(AdamFuse* t, float* p, float* m, float* v, const float* gbase, int64_t step, float lr, float beta1, float beta2, float eps,
+                    float wd) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    t->p = p; t->m = m; t->v = v; t->gbase = gbase;
+    t->lr_over_bc1 = (float)((double)lr / bc1);
+    t->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    t->beta1 = beta1; t->beta2 = beta2; t->eps = eps; t->wd = wd;
 }
 
 int adam_bn_step(float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,

@@ -18,7 +18,9 @@ struct RowsSumJobs {
 };
 // columns [32 bx, 32 bx + 32) of job `job`: 32 columns x 32 row slices, four loads in flight per thread, the slices combined through LDS
 // in a fixed order (deterministic)
-__device__ __forceinline__ void rows_sum_job_body(const RowsSumJobs& jb, int job, int bx, float (&red)[32][33]) {
+// (epi(dst, value): called by the thread that stored `value` at `dst` -- e.g. the optimizer update of that element, adam_device.hpp)
+template <class Epi>
+__device__ __forceinline__ void rows_sum_job_body(const RowsSumJobs& jb, int job, int bx, float (&red)[32][33], const Epi& epi) {
     const float* part = jb.part[job];
     const int rows = jb.rows[job], n = jb.n[job];
     const int64_t ld = jb.ld[job];
@@ -43,8 +45,18 @@ __device__ __forceinline__ void rows_sum_job_body(const RowsSumJobs& jb, int job
 #pragma unroll
         for (int q = 0; q < 32; ++q) v += red[q][lane];
         jb.out[job][e] = v;
-        if (jb.out2[job]) jb.out2[job][e] = v;
+        epi(jb.out[job] + e, v);
+        if (jb.out2[job]) {
+            jb.out2[job][e] = v;
+            epi(jb.out2[job] + e, v);
+        }
     }
+}
+struct ReduceNoEpilogue {
+    __device__ __forceinline__ void operator()(float*, float) const {}
+};
+__device__ __forceinline__ void rows_sum_job_body(const RowsSumJobs& jb, int job, int bx, float (&red)[32][33]) {
+    rows_sum_job_body(jb, job, bx, red, ReduceNoEpilogue{});
 }
 
 // the slice sums of up to GEMM_BATCH_MAX split-K products (sgemm_splitk_batch): job j owns workgroups [first[j], first[j + 1])
@@ -57,7 +69,8 @@ struct ReduceBatch {
     int n;
 };
 // workgroup `block` of the batch: 64 outputs, sixteen threads per output each summing every sixteenth slice, combined in a fixed order
-__device__ __forceinline__ void reduce_slices_batch_body(const ReduceBatch& b, int block, float (&part)[16][64]) {
+template <class Epi>
+__device__ __forceinline__ void reduce_slices_batch_body(const ReduceBatch& b, int block, float (&part)[16][64], const Epi& epi) {
     int j = 0;
 #pragma unroll
     for (int q = 1; q < GEMM_BATCH_MAX; ++q)
@@ -75,8 +88,13 @@ __device__ __forceinline__ void reduce_slices_batch_body(const ReduceBatch& b, i
         float v = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r += 4) v += (part[r][lane] + part[r + 1][lane]) + (part[r + 2][lane] + part[r + 3][lane]);
-        b.C[j][(int64_t)(e / N) * b.ldc[j] + (e % N)] = v;
+        float* dst = b.C[j] + (int64_t)(e / N) * b.ldc[j] + (e % N);
+        *dst = v;
+        epi(dst, v);
     }
+}
+__device__ __forceinline__ void reduce_slices_batch_body(const ReduceBatch& b, int block, float (&part)[16][64]) {
+    reduce_slices_batch_body(b, block, part, ReduceNoEpilogue{});
 }
 
 }  // namespace rulgnn

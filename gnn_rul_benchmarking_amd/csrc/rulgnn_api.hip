@@ -3,6 +3,7 @@
 
 #include "sgemm_mfma.hpp"
 #include "stgcn_host.hpp"
+#include "adam_device.hpp"
 #include "stgcn_train_mx.hpp"
 
 using namespace rulgnn;
@@ -410,10 +411,17 @@ int rulgnn_astgcnn_fwdbwd_f32(const rulgnn_astgcnn_shape* shape, const rulgnn_as
     hipStream_t st = static_cast<hipStream_t>(stream);
     // (plain batch statistics: the running-statistics update rides in the step's finalize kernel)
     const bool tail_bn = opt && opt->bn_stats && args->training && args->bn_moment_weight == 0.f;
-    rc = astgcnn_run(shape, args, 3, st, nullptr, tail_bn ? opt->bn_stats : nullptr, tail_bn ? opt->bn_momentum : 0.f);
+    // (host-side step count: the step's last kernel may apply the optimizer itself -- adam_device.hpp)
+    AdamFuse fuse{};
+    const bool try_fuse = opt && !opt->step_state;
+    if (try_fuse)
+        adam_fuse_args(&fuse, opt->params, opt->exp_avg, opt->exp_avg_sq, nullptr, opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                       opt->weight_decay);
+    rc = astgcnn_run(shape, args, 3, st, nullptr, tail_bn ? opt->bn_stats : nullptr, tail_bn ? opt->bn_momentum : 0.f, try_fuse ? &fuse : nullptr);
     if (rc != RULGNN_OK || !opt) return rc;
-    rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, astgcnn_param_count(shape), opt->step, opt->lr,
-                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+    if (!(try_fuse && fuse.gbase))
+        rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, astgcnn_param_count(shape), opt->step, opt->lr,
+                       opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
     if (rc != RULGNN_OK || !opt->bn_stats || tail_bn) return rc;
     return astgcnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, shape->batch * (int64_t)shape->time_length,
                                      opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);

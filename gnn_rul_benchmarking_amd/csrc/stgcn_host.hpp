@@ -138,9 +138,14 @@ int stmsgcn_run(const rulgnn_stmsgcn_shape* s, const rulgnn_stmsgcn_args* a, int
 int64_t astgcnn_param_count(const rulgnn_astgcnn_shape* s);
 size_t astgcnn_workspace_bytes(const rulgnn_astgcnn_shape* s);
 struct BnSyncHook;
-// (`bn_running_out` != nullptr, whole training steps with plain batch statistics: the finalize kernel also updates the running statistics)
+struct AdamFuse;          // adam_device.hpp
+// (`bn_running_out` != nullptr, whole training steps with plain batch statistics: the finalize kernel also updates the running statistics;
+// `adam` != nullptr, whole training steps: the constants of the optimizer update (adam_fuse_args) -- on return adam->gbase != nullptr says
+// the step's last kernel applied it, else the caller launches adam_step)
 int astgcnn_run(const rulgnn_astgcnn_shape* s, const rulgnn_astgcnn_args* a, int mode, hipStream_t stream, const BnSyncHook* sync = nullptr,
-                float* bn_running_out = nullptr, float bn_momentum = 0.f);
+                float* bn_running_out = nullptr, float bn_momentum = 0.f, AdamFuse* adam = nullptr);
+void adam_fuse_args(AdamFuse* t, float* p, float* m, float* v, const float* gbase, int64_t step, float lr, float beta1, float beta2, float eps,
+                    float wd);
 int astgcnn_bn_running_update(const rulgnn_astgcnn_shape* s, float* bn_stats, const float* bn_batch, int64_t count, float momentum,
                               int from_moments, hipStream_t stream);
 int64_t fcstgnn_param_count(const rulgnn_fcstgnn_shape* s);
