@@ -234,6 +234,7 @@ _SIGNATURES = {
                                                              C.c_void_p, C.c_int32, C.c_void_p]),
     "rulgnn_stgcn_train_guard_counter_offset": (C.c_int64, [C.POINTER(StgcnShape)]),
     "rulgnn_stgcn_train_args_size": (C.c_size_t, []),
+    "rulgnn_struct_size": (C.c_size_t, [C.c_int32]),
     "rulgnn_stgcn_train_phase_count": (C.c_int, [C.c_int32]),
     "rulgnn_stgcn_train_phase_f32": (C.c_int, [C.POINTER(StgcnShape), C.POINTER(StgcnTrainArgs), C.c_int32, C.c_void_p]),
     "rulgnn_adam_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
@@ -311,6 +312,9 @@ _SIGNATURES = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+# index -> ctypes mirror, in the order of the RULGNN_STRUCT_* constants of include/rulgnn.h (rulgnn_struct_size)
+STRUCTS = (StgcnShape, StgcnTrainArgs, AdamArgs, StmsgcnShape, StmsgcnArgs, AstgcnnShape, AstgcnnArgs, FcstgnnShape, FcstgnnArgs, RgcnuShape, RgcnuArgs, StnetShape, StnetArgs, SagcnShape, SagcnArgs, StagnnShape, StagnnArgs, HagcnShape, HagcnArgs, BilstmShape, BilstmArgs, StconvShape, StgnnShape, GruShape, GruArgs)
+
 _lib = None
 
 
@@ -341,6 +345,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the .so is stale: loud by design
         fn.restype = res
         fn.argtypes = args
+    for which, mirror in enumerate(STRUCTS):       # a stale .so (or a stale binding) would read past the end of a shorter struct
+        if lib.rulgnn_struct_size(which) != C.sizeof(mirror):
+            raise RuntimeError(f"{LIB_PATH}: sizeof(struct #{which}) is {lib.rulgnn_struct_size(which)} in the library, {C.sizeof(mirror)} in "
+                               f"this binding ({mirror.__name__}): rebuild with `python -m gnn_rul_benchmarking_amd.build --force`")
     _lib = lib
     return lib
 

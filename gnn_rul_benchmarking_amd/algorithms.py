@@ -198,6 +198,7 @@ class HAGCN(Algorithm):
     data-parallel sharding for this model."""
 
     supports_graphs = False
+    model_class = HAGCN_model
 
     def __init__(self, configs, hparams, device):
         super(HAGCN, self).__init__(configs)

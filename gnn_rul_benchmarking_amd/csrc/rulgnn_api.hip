@@ -186,6 +186,37 @@ int64_t rulgnn_stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape* shape)
 
 size_t rulgnn_stgcn_train_args_size(void) { return sizeof(rulgnn_stgcn_train_args); }
 
+size_t rulgnn_struct_size(int32_t which) {
+    switch (which) {
+    case RULGNN_STRUCT_STGCN_SHAPE: return sizeof(rulgnn_stgcn_shape);
+    case RULGNN_STRUCT_STGCN_TRAIN_ARGS: return sizeof(rulgnn_stgcn_train_args);
+    case RULGNN_STRUCT_ADAM_ARGS: return sizeof(rulgnn_adam_args);
+    case RULGNN_STRUCT_STMSGCN_SHAPE: return sizeof(rulgnn_stmsgcn_shape);
+    case RULGNN_STRUCT_STMSGCN_ARGS: return sizeof(rulgnn_stmsgcn_args);
+    case RULGNN_STRUCT_ASTGCNN_SHAPE: return sizeof(rulgnn_astgcnn_shape);
+    case RULGNN_STRUCT_ASTGCNN_ARGS: return sizeof(rulgnn_astgcnn_args);
+    case RULGNN_STRUCT_FCSTGNN_SHAPE: return sizeof(rulgnn_fcstgnn_shape);
+    case RULGNN_STRUCT_FCSTGNN_ARGS: return sizeof(rulgnn_fcstgnn_args);
+    case RULGNN_STRUCT_RGCNU_SHAPE: return sizeof(rulgnn_rgcnu_shape);
+    case RULGNN_STRUCT_RGCNU_ARGS: return sizeof(rulgnn_rgcnu_args);
+    case RULGNN_STRUCT_STNET_SHAPE: return sizeof(rulgnn_stnet_shape);
+    case RULGNN_STRUCT_STNET_ARGS: return sizeof(rulgnn_stnet_args);
+    case RULGNN_STRUCT_SAGCN_SHAPE: return sizeof(rulgnn_sagcn_shape);
+    case RULGNN_STRUCT_SAGCN_ARGS: return sizeof(rulgnn_sagcn_args);
+    case RULGNN_STRUCT_STAGNN_SHAPE: return sizeof(rulgnn_stagnn_shape);
+    case RULGNN_STRUCT_STAGNN_ARGS: return sizeof(rulgnn_stagnn_args);
+    case RULGNN_STRUCT_HAGCN_SHAPE: return sizeof(rulgnn_hagcn_shape);
+    case RULGNN_STRUCT_HAGCN_ARGS: return sizeof(rulgnn_hagcn_args);
+    case RULGNN_STRUCT_BILSTM_SHAPE: return sizeof(rulgnn_bilstm_shape);
+    case RULGNN_STRUCT_BILSTM_ARGS: return sizeof(rulgnn_bilstm_args);
+    case RULGNN_STRUCT_STCONV_SHAPE: return sizeof(rulgnn_stconv_shape);
+    case RULGNN_STRUCT_STGNN_SHAPE: return sizeof(rulgnn_stgnn_shape);
+    case RULGNN_STRUCT_GRU_SHAPE: return sizeof(rulgnn_gru_shape);
+    case RULGNN_STRUCT_GRU_ARGS: return sizeof(rulgnn_gru_args);
+    default: return 0;
+    }
+}
+
 int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape* shape, const rulgnn_stgcn_train_args* args,
                                 const rulgnn_adam_args* opt, void* stream) {
     if (!opt) return RULGNN_EINVAL;

@@ -47,7 +47,10 @@ class DeviceBatchLoader:
             from .dp import shard_bounds
             lo, hi = shard_bounds(X.shape[0], world_size, rank)
             X, y, self.shard = X[lo:hi], y[lo:hi], (lo, hi)
-            rank, world_size = 0, 1            # inside the shard this rank is on its own
+        if shard_samples:
+            # a TEST set: either this rank's own shard (above) or -- when the set cannot be sharded -- the whole set in the
+            # reference's batches; never a per-batch slice (a slice made rank 0 report metrics of 1 / world of the set)
+            rank, world_size = 0, 1
         self.x_data, self.y_data = X.to(device), y.to(device)
         self.batch_size, self.shuffle, self.drop_last = batch_size, shuffle, drop_last
         self.device, self.rank, self.world_size = device, rank, world_size
@@ -74,18 +77,21 @@ class DeviceBatchLoader:
             yield self.x_data[ids], self.y_data[ids], gb, lo
 
 
-def data_generator(data_path, dataset_configs, hparams, device="cpu", rank=0, world_size=1):
+def data_generator(data_path, dataset_configs, hparams, device="cpu", rank=0, world_size=1, shard_test_sets=True):
+    """``shard_test_sets=False``: every rank evaluates every test set whole, in the reference's batches -- for a model whose eval
+    forward depends on the composition of the batch (``eval_sample_independent = False`` on the model class, e.g. RGCNU)."""
     train = torch.load(os.path.join(data_path, "train.pt"), weights_only=False)
     test = torch.load(os.path.join(data_path, "test.pt"), weights_only=False)
     bs = hparams["batch_size"]
     Xtr, ytr = _normalise(train['samples'], train['labels'])
     train_loader = DeviceBatchLoader(Xtr, ytr, bs, dataset_configs.shuffle, dataset_configs.drop_last, device, rank, world_size)
+    tw = (rank, world_size) if shard_test_sets else (0, 1)
     if isinstance(test['samples'], dict):
         test_loader = {}
         for key in test['samples']:
             Xt, yt = _normalise(test['samples'][key], test['labels'][key])
-            test_loader[key] = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, rank, world_size, shard_samples=True)
+            test_loader[key] = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, *tw, shard_samples=True)
     else:
         Xt, yt = _normalise(test['samples'], test['labels'])
-        test_loader = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, rank, world_size, shard_samples=True)
+        test_loader = DeviceBatchLoader(Xt, yt, bs, False, dataset_configs.drop_last, device, *tw, shard_samples=True)
     return train_loader, test_loader, train['max_ruls']

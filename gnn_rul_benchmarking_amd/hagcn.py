@@ -78,6 +78,17 @@ class deferred_weight_gradients:
         return False
 
 
+def _accumulate_grad_steals(leaves):
+    """True when autograd's AccumulateGrad will adopt a fresh gradient tensor of every leaf untouched: ``.grad is None``, no tensor or
+    post-accumulate hooks, and the backward is not itself recorded (``create_graph``: grad mode is on inside it)."""
+    if torch.is_grad_enabled():
+        return False
+    for p in leaves:
+        if p.grad is not None or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
 class _BiLstmSum(torch.autograd.Function):
     """out = LSTM_forward(x) + LSTM_reverse(x) for one nn.LSTM(bidirectional=True, batch_first=True) (Model.py:58-61)."""
 
@@ -120,6 +131,13 @@ class _BiLstmSum(torch.autograd.Function):
                                                               grads[4 * d + 2].data_ptr(), grads[4 * d + 3].data_ptr())
         a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
         side = _DEFERRED[0]
+        # The deferred gradients are handed to autograd BEFORE the side stream has written them: sound only when AccumulateGrad
+        # takes the tensor as it is (first gradient of the parameter, no hooks, no graph through the backward).  With
+        # ``zero_grad(set_to_none=False)``, gradient accumulation or hooks it would read (``grad += new``, ``clone()``) on the main
+        # stream ahead of the GEMMs -- so in those cases nothing is deferred.
+        leaves = (w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        if side is not None and not _accumulate_grad_steals(leaves):
+            side = None
         if side is not None and side.device == x.device:
             a.aux_stream = side.cuda_stream
             for t in (ctx.ws, x, *grads):          # the side stream reads / writes them after this function has returned
@@ -186,6 +204,9 @@ class _GraphFunction(torch.autograd.Function):
 
 
 class HAGCN_model(nn.Module):
+    # the Bi-LSTM recurs along batch x nodes (Model.py:153-157): a sample's prediction depends on the samples in front of it in the batch
+    eval_sample_independent = False
+
     def __init__(self, patch_size, num_patch, encoder_hidden_dim, hidden_dim, output_dim):
         super().__init__()
         self.patch_size, self.num_patch = int(patch_size), int(num_patch)

@@ -95,6 +95,9 @@ class _Function(torch.autograd.Function):
 
 class RGCNU_model(FlatModule):
     dropout_by_sample_offset = True          # dp.py: pass the shard's first global sample index to fused_mse_step
+    # graph (b, l) meets the adjacency of sample (b * T + l) % bs: the eval forward depends on WHICH samples share a batch, so a test
+    # set must be walked in the reference's batches on every rank, never re-batched per shard (trainer.py / dataloader.data_generator)
+    eval_sample_independent = False
 
     def __init__(self, num_nodes, time_length, hidden_dim, encoder_hidden_dim, kernel_size, alpha):
         super().__init__()

@@ -191,6 +191,7 @@ class ST_GCN_model(FlatModule):
             self._guard_off[batch] = off
             if off >= 0:
                 self._ws[off:off + 4].zero_()
+            self._guard_seen.pop(batch, None)     # a re-created workspace counts from zero again (the old total stayed)
         return self._ws
 
     def _train_args(self, shp, x2d, y, dpred, step, global_batch=None, sample_offset=0, moments_to_bucket=False, whole_step=False):
@@ -262,7 +263,7 @@ class ST_GCN_model(FlatModule):
             if off >= 0:
                 total = int(ent[0][off:off + 4].view(torch.int32).item())
                 if self._guard_dp is None:       # data parallel counts the all-reduced loss instead (every rank sees the same number)
-                    n += total - self._guard_seen.get(batch, 0)
+                    n += max(total - self._guard_seen.get(batch, 0), 0)
                 self._guard_seen[batch] = total
         if self._guard_dp is not None:
             n += int(self._guard_dp.item())

@@ -88,14 +88,18 @@ class GNN_RUL_trainer(object):
             self.logger, self.log_dir = starting_logs(self.dataset, self.GNN_method, self.exp_log_dir, self.dataset_id,
                                                       self.bearing_id, run_id, to_stdout=self.rank == 0) \
                 if self.rank == 0 else (_NullLogger(), None)
+            # a model whose eval forward depends on which samples share a batch (RGCNU's adjacency pairing, HAGCN's recurrence along
+            # batch x nodes) declares ``eval_sample_independent = False``: its test sets stay whole on every rank, in the reference's batches
+            algorithm_class = get_algorithm_class(self.GNN_method)
+            shard_test = getattr(getattr(algorithm_class, "model_class", None), "eval_sample_independent", True)
             self.train_dl, self.test_dl, self.max_ruls = data_generator(
-                self.data_path, self.dataset_configs, self.train_configs, self.device, self.rank, self.world_size)
+                self.data_path, self.dataset_configs, self.train_configs, self.device, self.rank, self.world_size,
+                shard_test_sets=shard_test)
             if isinstance(self.test_dl, dict):
                 self.best_result = {key: [[np.inf], [np.inf], [np.inf], [np.inf]] for key in self.test_dl.keys()}
             else:
                 self.best_result = [[np.inf], [np.inf], [np.inf], [np.inf]]
 
-            algorithm_class = get_algorithm_class(self.GNN_method)
             algorithm = algorithm_class(self.model_configs, self.train_configs, self.device)
             algorithm.to(self.device)
             if self.dp is not None:

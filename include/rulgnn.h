@@ -265,6 +265,37 @@ int64_t rulgnn_stgcn_train_guard_counter_offset(const rulgnn_stgcn_shape *shape)
 /* sizeof(rulgnn_stgcn_train_args) as this library was built: the struct has grown by trailing fields (`flags`, round 4); a caller
  * built against another header compares this with its own sizeof before the first call. */
 size_t rulgnn_stgcn_train_args_size(void);
+/* sizeof() of every struct of this header as the library was built, by index (0 for an unknown index).  Argument structs grow by
+ * TRAILING fields (`flags`, `aux_stream`, ...) which the library reads unconditionally: a caller built against another header compares
+ * these with its own sizeof before the first call (the Python binding does, at load time: gnn_rul_benchmarking_amd/_lib.py), and every
+ * caller ZERO-INITIALISES an argument struct before filling it in (a zero / NULL trailing field always means "the behaviour before the
+ * field existed"). */
+#define RULGNN_STRUCT_STGCN_SHAPE 0
+#define RULGNN_STRUCT_STGCN_TRAIN_ARGS 1
+#define RULGNN_STRUCT_ADAM_ARGS 2
+#define RULGNN_STRUCT_STMSGCN_SHAPE 3
+#define RULGNN_STRUCT_STMSGCN_ARGS 4
+#define RULGNN_STRUCT_ASTGCNN_SHAPE 5
+#define RULGNN_STRUCT_ASTGCNN_ARGS 6
+#define RULGNN_STRUCT_FCSTGNN_SHAPE 7
+#define RULGNN_STRUCT_FCSTGNN_ARGS 8
+#define RULGNN_STRUCT_RGCNU_SHAPE 9
+#define RULGNN_STRUCT_RGCNU_ARGS 10
+#define RULGNN_STRUCT_STNET_SHAPE 11
+#define RULGNN_STRUCT_STNET_ARGS 12
+#define RULGNN_STRUCT_SAGCN_SHAPE 13
+#define RULGNN_STRUCT_SAGCN_ARGS 14
+#define RULGNN_STRUCT_STAGNN_SHAPE 15
+#define RULGNN_STRUCT_STAGNN_ARGS 16
+#define RULGNN_STRUCT_HAGCN_SHAPE 17
+#define RULGNN_STRUCT_HAGCN_ARGS 18
+#define RULGNN_STRUCT_BILSTM_SHAPE 19
+#define RULGNN_STRUCT_BILSTM_ARGS 20
+#define RULGNN_STRUCT_STCONV_SHAPE 21
+#define RULGNN_STRUCT_STGNN_SHAPE 22
+#define RULGNN_STRUCT_GRU_SHAPE 23
+#define RULGNN_STRUCT_GRU_ARGS 24
+size_t rulgnn_struct_size(int32_t which);
 
 /* Profiling aid: the training step is a chain of 4*num_layers+1 phase kernels:
  * phases 0..2L-1 = F_i (forward to BatchNorm i, batch statistics), 2L = TOP (prediction, loss, head

@@ -20,26 +20,134 @@ def rel(a, b):
 
 
 # ---- BASELINE.json metric: "training samples/sec ... C-MAPSS FD004 ST_GCN" at the bench batch (65 536 per GPU) ---------------------------
-def test_config_ST_GCN_cmapss_fd004_shaped_14x30_train_batch_65536_matches_fp64_oracle():
-    """The headline workload of bench.py, whole batch: train-mode predictions, loss, the four BatchNorm batch statistics and EVERY
-    gradient tensor vs the fp64 oracle -- exercises the multi-tile persistent loop, the 16 cell replicas and the [grid][1525]
-    partial rows at the size they are benchmarked at; then the eval forward (matrix-core kernel) of the same batch."""
-    import gpu_util as G
+def _headline_case(N, P, B, L, seed):
     from gnn_rul_benchmarking_amd import params as PL
     from oracle import stgcn_oracle as O
-    from test_train_gpu import check_grads, oracle_step
-    N, P, B, L, p = 14, 30, 65536, 2, 0.2
-    rng = np.random.default_rng(65536)
+    rng = np.random.default_rng(seed)
     prm = O.random_params(N, L, seed=21)
     x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
     y = rng.uniform(0, 1, (B,)).astype(np.float32)
     flat, bn = PL.pack_numpy(prm, N, L)
-    r = G.abi_train(x, y, flat, N, P, L=L, dropout=p, seed=7, step=3)
-    pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, 7, 3)
+    return prm, x, y, flat, bn
+
+
+def _check_step_against_oracle(r, prm, x, y, N, P, L, p, seed, step, **shard):
+    import gpu_util as G
+    from test_train_gpu import check_grads, oracle_step
+    pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, seed, step, **shard)
+    assert np.isfinite(r["loss"]), "the f16 range guard rejected the step"
     assert G.rel_err(r["pred"], pred) < TOL
     assert abs(r["loss"] - loss) < TOL * abs(loss)
     assert G.rel_err(r["bn_batch"], bnb) < TOL
     check_grads(r["grads"], gref, N, L)
+    return gref
+
+
+def test_headline_ST_GCN_14x30_batch_65536_matrix_core_chain_matches_fp64_oracle():
+    """The workload AND the launch form bench.py's headline times: ``ST_GCN.update`` -> RULGNN_STEP_AUTO -> the f16x2-split matrix-core
+    chain (csrc/stgcn_train_mx.hip), dropout 0.2, whole batch of 65 536: train-mode predictions, loss, the four BatchNorm batch
+    statistics and EVERY gradient tensor vs the fp64 oracle (gradients ride the f16 range scaled by 2^(16 + 3) at this batch, DESIGN
+    section 4).  Reference step: algorithms/algorithms.py:481-490, models/ST_GCN/Model.py:187-222."""
+    from gnn_rul_benchmarking_amd import _lib
+    from test_train_mx_gpu import abi_step
+    N, P, B, L, p = 14, 30, 65536, 2, 0.2
+    prm, x, y, flat, _ = _headline_case(N, P, B, L, 65536)
+    lib = _lib.load()
+    import ctypes as C
+    import gpu_util as G
+    xd = torch.from_numpy(x.reshape(B, -1)).to(DEV)
+    assert lib.rulgnn_stgcn_train_step_resolve(C.byref(G.shape_struct(B, N, P, L)), xd.data_ptr(), _lib.STEP_AUTO) == _lib.STEP_MX
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=7, step=3)
+    assert rc == 0
+    _check_step_against_oracle(r, prm, x, y, N, P, L, p, 7, 3)
+
+
+def test_headline_ST_GCN_14x30_batch_65536_matrix_core_step_with_fused_adam_matches_oracle_adam():
+    """The same launch with the optimizer folded into its last kernel (what ``ST_GCN.update`` runs on one GPU): parameters, both Adam
+    moments and the BatchNorm running statistics after one step vs the oracle's ``adam_update`` / ``bn_running_update`` on the
+    oracle's own gradients (torch.optim.Adam with L2 decay, algorithms/algorithms.py:474-478,488)."""
+    import ctypes as C
+    import gpu_util as G
+    from gnn_rul_benchmarking_amd import _lib, params as PL
+    from oracle import stgcn_oracle as O
+    from test_train_gpu import oracle_step
+    N, P, B, L, p = 14, 30, 65536, 2, 0.2
+    lr, wd, k = 1e-3, 1e-4, 4
+    prm, x, y, flat, bn0 = _headline_case(N, P, B, L, 65537)
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(3)
+    xd = torch.from_numpy(x.reshape(B, -1)).to(dev); yd = torch.from_numpy(y).to(dev)
+    pd = torch.from_numpy(flat.copy()).to(dev)
+    m0 = (rng.normal(0, 1e-3, flat.shape)).astype(np.float32); v0 = (rng.uniform(0, 1e-5, flat.shape)).astype(np.float32)
+    md, vd, bnd = torch.from_numpy(m0.copy()).to(dev), torch.from_numpy(v0.copy()).to(dev), torch.from_numpy(bn0.copy()).to(dev)
+    grads = torch.full_like(pd, float("nan")); pred = torch.full((B,), float("nan"), device=dev)
+    loss = torch.full((1,), float("nan"), device=dev); bnb = torch.full((L * 40,), float("nan"), device=dev)
+    shp = G.shape_struct(B, N, P, L)
+    nbytes = lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a = _lib.StgcnTrainArgs()
+    a.x = xd.data_ptr(); a.y = yd.data_ptr(); a.dpred = None
+    a.params = pd.data_ptr(); a.grads = grads.data_ptr(); a.pred = pred.data_ptr(); a.loss = loss.data_ptr()
+    a.bn_batch = bnb.data_ptr(); a.workspace = ws.data_ptr(); a.workspace_bytes = nbytes
+    a.global_batch = B; a.sample_offset = 0; a.dropout_p = p; a.seed = 7; a.step = k
+    opt = _lib.AdamArgs(pd.data_ptr(), md.data_ptr(), vd.data_ptr(), bnd.data_ptr(), k, lr, 0.9, 0.999, 1e-8, wd, 0.1, None)
+    _lib.check(lib.rulgnn_stgcn_train_step_path_f32(C.byref(shp), C.byref(a), C.byref(opt), _lib.STEP_MX, G.stream_ptr()), "step")
+    torch.cuda.synchronize()
+    _, lref, gref, _ = oracle_step(prm, x, y, N, P, L, p, 7, k)
+    assert abs(float(loss.item()) - lref) < TOL * abs(lref)
+    keys = [O.dropout_layer_key(7, k, l) for l in range(L)]
+    fc = O.forward(prm, x.astype(np.float64), N, P, L, train=True, dropout=p, dropout_keys=keys)
+    want_p, want_m, want_v = O.adam_update(flat.astype(np.float64), gref, m0.astype(np.float64), v0.astype(np.float64), k, lr, wd)
+    live = np.zeros(flat.shape, bool)
+    for _, (off, shape) in PL.live_param_layout(N, L).items():
+        live[off:off + int(np.prod(shape))] = True
+    gp, gm, gv = pd.cpu().numpy(), md.cpu().numpy(), vd.cpu().numpy()
+    assert G.rel_err(gm[live], want_m[live]) < GTOL
+    assert G.rel_err(gv[live], want_v[live]) < 2 * GTOL
+    # one Adam step moves a weight by <= lr (1e-3): the parameter gate is on the UPDATE, not on the parameter
+    assert G.rel_err((gp - flat)[live], (want_p - flat)[live]) < 5e-3
+    assert G.rel_err(gp[live], want_p[live]) < 1e-5
+    _, want_bn = PL.pack_numpy({**prm, **O.bn_running_update(prm, fc, L)}, N, L)
+    assert G.rel_err(bnd.cpu().numpy(), want_bn) < TOL
+
+
+def test_headline_ST_GCN_14x30_rank_3_of_8_shard_of_global_batch_524288_matrix_core_chain():
+    """The 8-GPU weak-scaling shard of the headline (BASELINE.json: "at 1/2/4/8 MI355X"): rank 3's 65 536 samples of a global batch of
+    524 288 -- the MSE gradient is 2 (pred - y) / 524 288 and rides the f16 range scaled by 2^(19 + 3); dropout counters start at
+    sample 3 x 65 536."""
+    from gnn_rul_benchmarking_amd import _lib
+    from test_train_mx_gpu import abi_step
+    N, P, B, L, p = 14, 30, 65536, 2, 0.2
+    prm, x, y, flat, _ = _headline_case(N, P, B, L, 524288)
+    shard = dict(global_batch=8 * B, sample_offset=3 * B)
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=7, step=3, **shard)
+    assert rc == 0
+    _check_step_against_oracle(r, prm, x, y, N, P, L, p, 7, 3, **shard)
+
+
+def test_ST_GCN_phm2012_40x64_batch_16384_wide_matrix_core_chain_matches_fp64_oracle():
+    """bench.py's ``train_phm2012_40x64`` leg (the reference's PHM2012 wiring, configs/hparams.py:223,238) on the launch form it times:
+    csrc/stgcn_train_mxw.hip at batch 16 384."""
+    from gnn_rul_benchmarking_amd import _lib
+    from test_train_mx_gpu import abi_step
+    N, P, B, L, p = 40, 64, 16384, 2, 0.2
+    prm, x, y, flat, _ = _headline_case(N, P, B, L, 16384)
+    rc, r = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=7, step=3)
+    assert rc == 0
+    _check_step_against_oracle(r, prm, x, y, N, P, L, p, 7, 3)
+
+
+def test_ST_GCN_cmapss_fd004_shaped_14x30_train_batch_65536_fp32_chain_matches_fp64_oracle():
+    """The fp32 phase chain (RULGNN_STEP_CHAIN; what the split entry rulgnn_stgcn_train_fwdbwd_f32 always runs, and what a step the f16
+    range guard rejected is repeated on) at the bench batch, whole batch: exercises the multi-tile persistent loop, the 16 cell replicas
+    and the [grid][1525] partial rows; then the eval forward (matrix-core kernel) of the same batch."""
+    import gpu_util as G
+    from oracle import stgcn_oracle as O
+    N, P, B, L, p = 14, 30, 65536, 2, 0.2
+    prm, x, y, flat, bn = _headline_case(N, P, B, L, 65536)
+    r = G.abi_train(x, y, flat, N, P, L=L, dropout=p, seed=7, step=3)
+    _check_step_against_oracle(r, prm, x, y, N, P, L, p, 7, 3)
     ev = O.forward(prm, x.astype(np.float64), N, P, L, train=False).pred[:, 0]
     assert G.rel_err(G.abi_forward(x, flat, bn, N, P, L=L), ev) < TOL
 

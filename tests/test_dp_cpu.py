@@ -903,3 +903,36 @@ def test_sharded_test_set_metrics_equal_the_single_process_metrics_world2_gloo(n
     assert np.allclose(out[0]["metrics"], want, rtol=1e-12, atol=0)
     assert out[0]["full_equal"] and out[1]["full_equal"]
     assert out[0]["shard"][1] == out[1]["shard"][0] and out[1]["shard"][1] == n
+
+
+@pytest.mark.parametrize("drop_last", [True, False])
+def test_a_test_set_that_cannot_be_sharded_is_walked_whole_on_every_rank(drop_last, tmp_path):
+    """a test loader that was asked to shard but cannot (``drop_last=True``), or a model whose eval forward
+    depends on the batch composition (``eval_sample_independent = False``: RGCNU, HAGCN -> ``shard_test_sets=False``), must give EVERY
+    rank the reference's batches of the whole set -- never a per-batch slice (rank 0 would report metrics of 1 / world of the set)."""
+    from types import SimpleNamespace
+    from gnn_rul_benchmarking_amd.dataloader import DeviceBatchLoader, data_generator
+    from gnn_rul_benchmarking_amd.algorithms import HAGCN, RGCNU, ST_GCN
+    g = torch.Generator().manual_seed(5)
+    n, bs = 11, 4
+    X, y = torch.rand(n, 3, 4, generator=g), torch.rand(n, 1, generator=g)
+    one = [yb.clone() for _, yb, _, _ in DeviceBatchLoader(X, y, bs, False, drop_last, "cpu")]
+    for rank in range(2):
+        dl = DeviceBatchLoader(X, y, bs, False, drop_last, "cpu", rank, 2, shard_samples=True)
+        got = [(yb, gb, lo) for _, yb, gb, lo in dl]
+        if drop_last:                     # not shardable: the whole set, in the single-process batches
+            assert not dl.shard_samples and dl.shard == (0, n)
+            assert len(got) == len(one) and all(torch.equal(a[0], b) and a[1] == bs and a[2] == 0 for a, b in zip(got, one))
+        else:                             # sharded: this rank's contiguous shard only
+            assert dl.shard_samples and sum(a[0].shape[0] for a in got) == dl.shard[1] - dl.shard[0] in (5, 6)
+    # the model-level opt-out, through data_generator
+    assert getattr(ST_GCN.model_class, "eval_sample_independent", True)
+    assert RGCNU.model_class.eval_sample_independent is False and HAGCN.model_class.eval_sample_independent is False
+    torch.save({"samples": X.numpy(), "labels": y.view(-1).numpy(), "max_ruls": 125.0}, tmp_path / "train.pt")
+    torch.save({"samples": X.numpy(), "labels": y.view(-1).numpy(), "max_ruls": 125.0}, tmp_path / "test.pt")
+    cfg = SimpleNamespace(shuffle=False, drop_last=False)
+    for rank in range(2):
+        _, whole, _ = data_generator(str(tmp_path), cfg, {"batch_size": bs}, "cpu", rank, 2, shard_test_sets=False)
+        assert not whole.shard_samples and whole.n == n and [b[0].shape[0] for b in whole] == [4, 4, 3]
+        _, sharded, _ = data_generator(str(tmp_path), cfg, {"batch_size": bs}, "cpu", rank, 2)
+        assert sharded.shard_samples and sharded.n in (5, 6)

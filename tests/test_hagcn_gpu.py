@@ -247,3 +247,44 @@ def test_deferred_lstm_weight_gradients_give_the_same_step():
     assert all(np.isfinite(la)) and np.allclose(la, lb, rtol=1e-6, atol=0)
     for k in sa:                 # (a gradient read before the side stream had written it would be garbage, not round-off)
         assert torch.allclose(sa[k].float(), sb[k].float(), rtol=0, atol=2e-6), k
+
+
+def test_deferred_lstm_weight_gradients_are_not_deferred_when_autograd_would_read_them():
+    """with ``zero_grad(set_to_none=False)`` (``.grad`` tensors already there), gradient accumulation or a parameter hook,
+    AccumulateGrad reads the new gradient on the main stream as soon as ``backward`` returns it -- ahead of a side stream's GEMMs.  In
+    those cases the LSTM backward keeps everything on the caller's stream: accumulating two backward passes inside a
+    ``deferred_weight_gradients`` block equals the sum of two separate ones."""
+    from gnn_rul_benchmarking_amd import hagcn as H
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    lstm = torch.nn.LSTM(12, 20, batch_first=True, bidirectional=True).to(dev)
+    x = torch.rand(1, 700, 12, device=dev)
+    params = list(lstm.parameters())
+    assert H._accumulate_grad_steals(params) is False          # grad mode is on out here: a recorded backward never defers
+    with torch.no_grad():
+        assert H._accumulate_grad_steals(params) is True
+        params[0].grad = torch.zeros_like(params[0])
+        assert H._accumulate_grad_steals(params) is False
+        params[0].grad = None
+        h = params[1].register_hook(lambda g: g)
+        assert H._accumulate_grad_steals(params) is False
+        h.remove()
+
+    def grads(deferred_block, passes, preset):
+        for p in params:
+            p.grad = torch.zeros_like(p) if preset else None
+        for _ in range(passes):
+            out = H.bilstm_sum(lstm, x)
+            if deferred_block:
+                with H.deferred_weight_gradients(dev):
+                    out.square().sum().backward()
+            else:
+                out.square().sum().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    once = grads(False, 1, False)
+    for preset, passes in ((True, 1), (False, 2), (True, 2)):
+        got = grads(True, passes, preset)
+        for a, b in zip(got, once):
+            assert torch.allclose(a, b * passes, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
