@@ -191,6 +191,10 @@ _SIGNATURES = {
     "rulgnn_sgemm_mode": (C.c_int, [C.c_int32]),
     "rulgnn_sgemm_scaled_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                           C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rulgnn_sgemm_scaled_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "rulgnn_sgemm_scaled_ws_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                             C.POINTER(C.c_int32), C.c_void_p]),
     "rulgnn_absmax_partials_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "rulgnn_sgemm_splitk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rulgnn_sgemm_splitk_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -927,6 +927,32 @@ int rulgnn_sgemm_scaled_f32(const float* A, int64_t sAm, int64_t sAk, const floa
     return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, static_cast<hipStream_t>(stream), 0, amax_a, amax_na, amax_b, amax_nb);
 }
 
+static size_t scaled_plane_bytes(int32_t M, int32_t N, int32_t K) { return (sgemm_planes_ws_bytes(M, N, K) + 255) & ~(size_t)255; }
+size_t rulgnn_sgemm_scaled_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return scaled_plane_bytes(M, N, K) + (split_k ? sgemm_splitk_need_floats(M, N, K) * sizeof(float) : 0);
+}
+int rulgnn_sgemm_scaled_ws_f32(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int32_t M,
+                               int32_t N, int32_t K, int32_t accumulate, const float* amax_a, int32_t amax_na, const float* amax_b, int32_t amax_nb,
+                               int32_t split_k, void* workspace, size_t workspace_bytes, int32_t* used_planes, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || ldc < N) return RULGNN_EINVAL;
+    if (used_planes) *used_planes = 0;
+    if (M == 0 || N == 0) return RULGNN_OK;
+    if (!A || !B || !C || !amax_a || !amax_b || amax_na <= 0 || amax_nb <= 0 || !workspace) return RULGNN_EINVAL;
+    if (workspace_bytes < rulgnn_sgemm_scaled_workspace_bytes(M, N, K, split_k)) return RULGNN_EWORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t pb = scaled_plane_bytes(M, N, K);
+    if (used_planes) {
+        const int s = sgemm_planes_slices(M, N, K, split_k != 0);
+        const bool split_ok = !split_k || (s >= 2 && s <= sgemm_splitk_slices(M, N, K));
+        *used_planes = (sgemm_big_mode() == 1 && s >= 1 && split_ok && sgemm_planes_ok(A, sAm, sAk, B, sBn, sBk, M, N, K, s)) ? 1 : 0;
+    }
+    if (split_k)
+        return sgemm_splitk(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + pb),
+                            st, amax_a, amax_na, amax_b, amax_nb, workspace, pb);
+    return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate != 0, st, 0, amax_a, amax_na, amax_b, amax_nb, workspace, pb);
+}
+
 static size_t splitk_part_floats(int32_t M, int32_t N, int32_t K) {
     const size_t a = sgemm_splitk_need_floats(M, N, K), b = sgemm_splitk_need_floats(M, N + 1, K), c = sgemm_splitk_need_floats(M, 1, K);
     const size_t v = a > b ? a : b;

@@ -1286,8 +1286,12 @@ static inline bool sgemm_is_skinny(int64_t sAk, int M, int N, int K) { return sA
 
 // `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies (sgemm_rows_bf16_ok), fp32 paths otherwise
 int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
-                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16, const float* amax_a, int amax_na, const float* amax_b, int amax_nb) {
+                 int M, int N, int K, bool accumulate, hipStream_t st, int bf16, const float* amax_a, int amax_na, const float* amax_b, int amax_nb,
+                 void* plane_ws, size_t plane_ws_bytes) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
+    if (amax_a && amax_b && plane_ws && sgemm_big_mode() == 1 && sgemm_planes_slices(M, N, K, false) == 1 &&
+        plane_ws_bytes >= sgemm_planes_ws_bytes(M, N, K) && sgemm_planes_ok(A, sAm, sAk, B, sBn, sBk, M, N, K, 1))
+        return sgemm_planes(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, 1, amax_a, amax_na, amax_b, amax_nb, plane_ws, plane_ws_bytes, st);
     if (bf16 && sgemm_rows_bf16_ok(sAk, M, N, K)) {
         const GemmArgs g{A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate ? 1 : 0, K};
         return sgemm_rows_bf16(g, st);
@@ -1681,7 +1685,7 @@ static inline bool sgemm_vecmat_ok(int M, int N, int K, int64_t sBn) { return M 
 
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                         int M, int N, int K, bool accumulate, float* partial, hipStream_t st, const float* amax_a, int amax_na, const float* amax_b,
-                        int amax_nb) {
+                        int amax_nb, void* plane_ws, size_t plane_ws_bytes) {
     if (M <= 0 || N <= 0) return RULGNN_OK;
     // (also in front of the one-workgroup kernel: ASTGCNN's d fc.weight, [1 x 512] . [512 x 64], took 23.6 us there)
     if (!accumulate && (sgemm_tiny_ok(M, N, K) || sgemm_longk_blocks(M, N, K) == 0) && sgemm_vecmat_ok(M, N, K, sBn)) {
@@ -1722,7 +1726,17 @@ int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
         return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
     }
     const int slices = sgemm_splitk_slices(M, N, K);
-    if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st, 0, amax_a, amax_na, amax_b, amax_nb);
+    if (slices <= 1) return sgemm(A, sAm, sAk, B, sBn, sBk, C, ldc, M, N, K, accumulate, st, 0, amax_a, amax_na, amax_b, amax_nb, plane_ws, plane_ws_bytes);
+    if (amax_a && amax_b && plane_ws && sgemm_big_mode() == 1) {
+        // the pre-split kernel with its own slice count (never more slices than `partial` was sized for)
+        const int ps = sgemm_planes_slices(M, N, K, true);
+        if (ps >= 2 && ps <= slices && plane_ws_bytes >= sgemm_planes_ws_bytes(M, N, K) && sgemm_planes_ok(A, sAm, sAk, B, sBn, sBk, M, N, K, ps)) {
+            const int rc = sgemm_planes(A, sAm, sAk, B, sBn, sBk, partial, N, M, N, K, false, ps, amax_a, amax_na, amax_b, amax_nb, plane_ws,
+                                        plane_ws_bytes, st);
+            if (rc != RULGNN_OK) return rc;
+            return sgemm_reduce_slices(partial, C, ldc, M, N, ps, accumulate, st);
+        }
+    }
     int kchunk = (K + slices - 1) / slices;
     kchunk = (kchunk + 15) & ~15;
     const int used = (K + kchunk - 1) / kchunk;

@@ -17,7 +17,16 @@ int& sgemm_big_mode();
 // `bf16` != 0: operands rounded to bf16 on the matrix cores where the shape qualifies, fp32 paths otherwise.
 int sgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
           int M, int N, int K, bool accumulate, hipStream_t st, int bf16 = 0, const float* amax_a = nullptr, int amax_na = 0,
-          const float* amax_b = nullptr, int amax_nb = 0);
+          const float* amax_b = nullptr, int amax_nb = 0, void* plane_ws = nullptr, size_t plane_ws_bytes = 0);
+// (plane_ws: optional scratch of sgemm_planes_ws_bytes(M, N, K) bytes.  With it -- and with the maxima -- products whose shape
+// fits run on PRE-SPLIT operands: a split pass writes each operand once as two k-contiguous f16 planes, the product kernel copies
+// them HBM -> LDS by DMA (csrc/sgemm_planes.hip); everything else stays on the kernels of csrc/sgemm.hip.)
+size_t sgemm_planes_ws_bytes(int M, int N, int K);
+int sgemm_planes_slices(int M, int N, int K, bool want_split);       // 0: this shape does not run on the pre-split kernel
+bool sgemm_planes_ok(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, int M, int N, int K, int slices);
+int sgemm_planes(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int M, int N, int K,
+                 bool accumulate, int slices, const float* amax_a, int amax_na, const float* amax_b, int amax_nb, void* ws, size_t ws_bytes,
+                 hipStream_t st);
 // (amax_a / amax_b, both or neither: amax_na / amax_nb floats each whose maximum is max |A| / max |B| over the FINITE elements -- one partial
 // maximum per workgroup of the kernels that produced the operands.  With them, outputs that fill the 256 x 256 tiles run the two-plane f16
 // split (three matrix instructions per product instead of six; csrc/sgemm.hip: sgemm_f16x2v_kernel).)
@@ -29,7 +38,7 @@ int absmax_partials(const float* x, int64_t n, float* part, int nparts, hipStrea
 // scratch of sgemm_splitk_need_floats(M, N, K) floats.
 int sgemm_splitk(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc,
                  int M, int N, int K, bool accumulate, float* partial, hipStream_t st, const float* amax_a = nullptr, int amax_na = 0,
-                 const float* amax_b = nullptr, int amax_nb = 0);
+                 const float* amax_b = nullptr, int amax_nb = 0, void* plane_ws = nullptr, size_t plane_ws_bytes = 0);
 
 // ... and colsum[m] = sum_k A(m, k) from the same pass (weight gradient + the bias gradient over the same rows); `ones`: K ones for
 // the shapes that take two calls; `partial`: sgemm_splitk_need_floats(M, N + 1, K) floats

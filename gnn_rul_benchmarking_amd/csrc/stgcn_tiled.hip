@@ -343,14 +343,30 @@ __global__ __launch_bounds__(256) void t_head_kernel(const float* __restrict__ y
 // host: eval forward
 // ------------------------------------------------------------------------------------------------
 static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+// split-K scratch of the eval forward: fc1 ([batch x N] . [N x N]: 64 tiles of 128 x 128 at batch 1024 -- through the split-K pair like
+// the training forward; as one launch of the 64 x 64 kernel it was 56 us of the 0.43-ms forward) and, at batch-100-sized row counts, theta
+static inline size_t t_eval_split_floats(int N, int64_t B) {
+    if (B <= 0) return 0;
+    const int64_t R = B * F;
+    const size_t a = R < 2048 ? sgemm_splitk_need_floats((int)R, N, N) : 0, b = sgemm_splitk_need_floats((int)B, N, N);
+    return a > b ? a : b;
+}
+// scratch of the large products' pre-split operands (two f16 planes per operand, csrc/sgemm_planes.hip) for R = batch * 10 rows: the theta
+// products hold [R x N] + [N x N], the weight gradient d theta = dH^T (A.X) two [N x R] operands (`with_grad`)
+static inline size_t t_plane_bytes(int N, int64_t R, bool with_grad) {
+    if (N % 256 != 0 || R < 2048 || R > (1 << 24)) return 0;
+    const size_t fwd = sgemm_planes_ws_bytes((int)R, N, N), grad = with_grad ? sgemm_planes_ws_bytes(N, N, (int)R) : 0;
+    return al256(fwd > grad ? fwd : grad);
+}
 
 size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
     const size_t T = (size_t)s->batch * F * s->num_patch * sizeof(float);
     // X (ping), X (pong), AX, Hpre  +  A, pooled, y1pre, bnfold, the large GEMMs' operand scales (partial maxima of A.X and of theta_l)
     // (+ split-K scratch of the theta / fc1 products at batch-100-sized row counts: too few output tiles for the large kernels otherwise)
     const int64_t R = s->batch * F;
-    const size_t sk = R > 0 && R < 2048 ? sgemm_splitk_need_floats((int)R, s->num_patch, s->num_patch) : 0;
-    return 4 * al256(T) + al256((size_t)s->batch * F * F * 4) + 2 * al256((size_t)s->batch * s->num_patch * 4) +
+    const size_t sk = t_eval_split_floats(s->num_patch, s->batch);
+    // (+ the pre-split operand planes of the theta products, csrc/sgemm_planes.hip)
+    return t_plane_bytes(s->num_patch, R, false) + 4 * al256(T) + al256((size_t)s->batch * F * F * 4) + 2 * al256((size_t)s->batch * s->num_patch * 4) +
            al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(1 + s->num_layers) * T_AMAX_MAX * sizeof(float)) + al256(sk * sizeof(float));
 }
 
@@ -392,7 +408,9 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* y1pre = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* bnf = reinterpret_cast<float*>(w); w += al256((size_t)L * 4 * F * 4);
     float* amax = reinterpret_cast<float*>(w); w += al256((size_t)(1 + L) * T_AMAX_MAX * sizeof(float));   // A.X of the current layer, theta of every layer
-    float* split = reinterpret_cast<float*>(w);
+    float* split = reinterpret_cast<float*>(w); w += al256(t_eval_split_floats(N, B) * sizeof(float));
+    const size_t plane_bytes = t_plane_bytes(N, B * F, false);
+    void* planes = plane_bytes ? static_cast<void*>(w) : nullptr;
     const bool few_rows = B * F < 2048;
     const int n_pos = (int)((BN_ + 255) / 256), n_th = 256;
     const bool scaled = n_pos <= T_AMAX_MAX;
@@ -419,13 +437,13 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
                               n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);
         else
             rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
-                       n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);
+                       n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th, planes, plane_bytes);
         if (rc != RULGNN_OK) return rc;
         T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a);
         float* tmp = Xin; Xin = Xout; Xout = tmp;
     }
     T_LAUNCH(t_pool_kernel, BN_, Xin, pooled, a);
-    int rc = sgemm(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, stream);          // fc1
+    int rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);          // fc1
     if (rc != RULGNN_OK) return rc;
     (void)hipGetLastError();
     hipLaunchKernelGGL(t_head_kernel, dim3((unsigned)B), dim3(256), 0, stream, y1pre, prm, pred, a);
@@ -1067,6 +1085,7 @@ struct TWs {
     size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
     size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
     size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split, off_split2;
+    size_t off_planes, off_planes2, plane_bytes;      // pre-split operand planes of the large products: main stream, side stream
     size_t off_amax;            // [3 L + 3][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l| and |fc1.weight|, |d Hpre_l|, |pooled|, |d y1|
                                 // (the operand scales of the GEMMs)
     size_t cells_bytes;
@@ -1138,6 +1157,9 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
         w->off_split = o; o += al256(need * sizeof(float));
         w->off_split2 = o; o += al256(need * sizeof(float));          // the side stream's own (parameter-gradient products)
     }
+    w->plane_bytes = t_plane_bytes(N, B * F, false);
+    w->off_planes = o; o += w->plane_bytes;
+    w->off_planes2 = o;                                                  // (the side stream's products stay on the in-loop split: no second area)
     w->total = o;
 }
 
@@ -1171,6 +1193,15 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     float* one = reinterpret_cast<float*>(ws + w.off_one);
     float* split = reinterpret_cast<float*>(ws + w.off_split);
     float* split2 = reinterpret_cast<float*>(ws + w.off_split2);
+    void* planes = w.plane_bytes ? static_cast<void*>(ws + w.off_planes) : nullptr;
+    void* planes2 = nullptr;
+    // Which of the step's products run on pre-split operands (csrc/sgemm_planes.hip), measured at XJTU-SY batch 1024 on one box
+    // (tools/time_tiled_step.py): none 1.1945 ms; theta(A.X) 1.1878; + d(A.X) 1.1857 (kept); + d theta 1.2109; + the fc1 products 1.2192.
+    // The product kernel alone is 64 us against 105-111 (324 against 193 TFLOP/s), but every operand costs a split pass (17 us per
+    // [10 240 x 1024] activation: 42 MB in, 42 MB out), d theta needs BOTH operands transposed, and the 256-workgroup / 156-KB kernel
+    // leaves the side stream's product no CU to run beside it (the 160-workgroup round-5 kernel does).
+    const size_t plane_bytes = w.plane_bytes;
+    const size_t pb_fwd = plane_bytes, pb_dax = plane_bytes, pb_dth = 0, pb_fc = 0;
     const float* prm = ar->params;
     // Parameter-gradient products (d fc1 / fc2, d theta of every layer and their bias sums: ~290 us of matrix-core work per step at XJTU-SY
     // batch 1024) feed nothing downstream in this call: with a second stream of the caller (args->aux_stream) they run BESIDE the
@@ -1253,7 +1284,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                                   l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
             else
             rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l),
-                       l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
+                       l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th, pb_fwd ? planes : nullptr, pb_fwd);
             if (rc != RULGNN_OK) return rc;
             T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
             T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
@@ -1263,7 +1294,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                      l + 1 < L ? am_ax(l + 1) : am_pool);
         }
         // (through the split-K pair: [batch x N] has too few output tiles to fill the chip -- at XJTU batch 1024, 64 tiles of 128 x 128)
-        rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream, am_pool, n_pos, am_th(L), n_th);
+        rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream, am_pool, n_pos, am_th(L), n_th,
+                          pb_fc ? planes : nullptr, pb_fc);
         if (rc != RULGNN_OK) return rc;
     } else {
         if (hipMemsetAsync(t.cells_bwd, 0, sizeof(double) * T_REP * tc_sb(L), stream) != hipSuccess) return RULGNN_EHIP;
@@ -1288,7 +1320,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             pjob(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B);
         } else {
         rc = sgemm_splitk(dy1, 1, N, pooled, 1, N, g + off_fc1_w(N, L), N, N, N, (int)B, false, split2, wst, am_dy1, (int)B,
-                          am_dy1 ? am_pool : (float*)nullptr, n_pos);
+                          am_dy1 ? am_pool : (float*)nullptr, n_pos, pb_fc ? planes2 : nullptr, pb_fc);
         if (rc != RULGNN_OK) return rc;
         rc = sgemm_splitk(one, 0, 0, dy1, 1, N, g + off_fc1_b(N, L), N, 1, N, (int)B, false, split2, wst);
         if (rc != RULGNN_OK) return rc;
@@ -1299,7 +1331,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
         if (ready && ready->fn(ready->user, g, (int64_t)off_fc1_w(N, L), (int64_t)(off_fc2_b(N, L) - off_fc1_w(N, L)), wst) != 0)
             return RULGNN_ECALLBACK;
         rc = sgemm_splitk(dy1, N, 1, prm + off_fc1_w(N, L), 1, N, dpool, N, (int)B, N, N, false, split, stream, am_dy1, (int)B,
-                          am_dy1 ? am_th(L) : (float*)nullptr, n_th);
+                          am_dy1 ? am_th(L) : (float*)nullptr, n_th, pb_fc ? planes : nullptr, pb_fc);
         if (rc != RULGNN_OK) return rc;
         for (int l = L - 1; l >= 0; --l) {
             const float* pl = prm + l * LS;
@@ -1320,7 +1352,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                 if (few_rows)
                     rc = sgemm_splitk(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, split, stream, am_dh(l), n_dh, am_th(l), n_th);
                 else
-                rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream, 0, am_dh(l), n_dh, am_th(l), n_th);      // dHpre . theta
+                rc = sgemm(dHp, N, 1, pl + off_theta_w(N), 1, N, dAX, N, (int)(B * F), N, N, false, stream, 0, am_dh(l), n_dh, am_th(l), n_th,
+                           pb_dax ? planes : nullptr, pb_dax);      // dHpre . theta
                 if (rc != RULGNN_OK) return rc;
             }
             // theta: dW[j][k] = sum_r dHpre[r][j] AX[r][k];  db[j] = sum_r dHpre[r][j]
@@ -1329,7 +1362,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
                 pjob(one, 0, 0, dHp, 1, N, gl + off_theta_b(N), N, 1, N, (int)(B * F));
             } else {
             rc = sgemm_splitk(dHp, 1, N, TP(w.off_AX, l), 1, N, gl + off_theta_w(N), N, N, N, (int)(B * F), false, split2, wst, am_dh(l), n_dh, am_ax(l),
-                              l == 0 && n_ax0 > 0 ? n_ax0 : n_pos);
+                              l == 0 && n_ax0 > 0 ? n_ax0 : n_pos, pb_dth ? planes2 : nullptr, pb_dth);
             if (rc != RULGNN_OK) return rc;
             // (the first layer's bias sums on the MAIN stream: it has nothing left to do there while the side stream works through that
             // layer's d theta, the last product of the step)

@@ -801,6 +801,19 @@ int rulgnn_sgemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, i
 int rulgnn_sgemm_scaled_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
                             int32_t M, int32_t N, int32_t K, int32_t accumulate, const float *amax_a, int32_t amax_na, const float *amax_b,
                             int32_t amax_nb, void *stream);
+/* The scaled product on PRE-SPLIT operands (round 6; csrc/sgemm_planes.hip): with `workspace` (rulgnn_sgemm_scaled_workspace_bytes) a
+ * split pass writes each operand ONCE as two k-contiguous f16 planes (hi | lo, scaled as above; a transposing pass when the operand is
+ * row-contiguous) and the product kernel copies operand tiles HBM -> LDS by DMA (global_load_lds_dwordx4: no VGPR round trip, no split in
+ * the product loop) into a three-stage ring, one workgroup barrier per 32 k, 160 x 256 or 128 x 256 output tiles (one per CU for
+ * [10 240 x 1024] . [1024 x 1024]).  Same arithmetic and error class as rulgnn_sgemm_scaled_f32.  Shapes: M a multiple of 160 or 128,
+ * N of 256, K of 32 (split_k: of 32 x the slice count), 16-byte aligned operands with unit stride along k or along the row index;
+ * other shapes (and RULGNN_GEMM_F32 / _BF16X3_ONLY) run exactly what rulgnn_sgemm_scaled_f32 / rulgnn_sgemm_splitk_f32 run.
+ * split_k != 0: the product as a deterministic split-K reduction (the weight gradient d theta = dH^T (A.X): K = batch x 10 rows);
+ * the workspace then also holds the partial slices.  Returns in *used_planes (may be NULL) whether the pre-split kernel ran. */
+size_t rulgnn_sgemm_scaled_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t split_k);
+int rulgnn_sgemm_scaled_ws_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C, int64_t ldc,
+                               int32_t M, int32_t N, int32_t K, int32_t accumulate, const float *amax_a, int32_t amax_na, const float *amax_b,
+                               int32_t amax_nb, int32_t split_k, void *workspace, size_t workspace_bytes, int32_t *used_planes, void *stream);
 /* partials[i] = max |x[e]| over the finite elements e = i * 256 + t (mod nparts * 256 strides) of x[0..n): nparts (1..65535) partial maxima. */
 int rulgnn_absmax_partials_f32(const float *x, int64_t n, float *partials, int32_t nparts, void *stream);
 /* The same product as a deterministic split-K reduction -- the weight gradients of the families: C[m][n] = sum over the K rows of the

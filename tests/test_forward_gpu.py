@@ -28,7 +28,9 @@ def test_forward_matches_reference_golden(name):
                                    (16, 30, 65), (3, 6, 9), (5, 7, 33), (14, 31, 19), (16, 16, 40),
                                    (24, 20, 37), (32, 8, 11), (40, 64, 9), (64, 10, 6),
                                    # num_patch > 64: tiled path (PHM2012 Condition_2, XJTU-SY shapes)
-                                   (65, 8, 5), (160, 16, 7), (200, 6, 3), (1024, 32, 4), (2048, 16, 2)])
+                                   (65, 8, 5), (160, 16, 7), (200, 6, 3), (1024, 32, 4), (2048, 16, 2),
+                                   # ... with batch x 10 rows enough for the pre-split product kernel (csrc/sgemm_planes.hip: 160 x 256 / 128 x 256 tiles)
+                                   (1024, 32, 512), (256, 8, 1024)])
 def test_forward_matches_oracle_seeded(N, P, B):
     import gpu_util as G
     rng = np.random.default_rng(N * 1000 + P * 10 + B)

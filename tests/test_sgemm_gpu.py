@@ -212,3 +212,110 @@ def test_bf16x3_only_mode_ignores_the_operand_scales():
     scaled, _, _ = run_scaled(A, B, M, N, K, "k", "k")
     assert np.array_equal(only, plain)
     assert not np.array_equal(scaled, plain) and np.abs(scaled - plain).max() < 1e-5 * np.abs(plain).max()
+
+
+# ---- the scaled product on PRE-SPLIT operands (csrc/sgemm_planes.hip: split pass + LDS-DMA product kernel; rulgnn_sgemm_scaled_ws_f32) -----
+def run_scaled_ws(A, B, M, N, K, a_layout, b_layout, split_k=False, accumulate=False, C0=None, nparts=(37, 5)):
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    At = torch.from_numpy(np.ascontiguousarray(A if a_layout == "k" else A.T)).to(DEV)
+    Bt = torch.from_numpy(np.ascontiguousarray(B if b_layout == "k" else B.T)).to(DEV)
+    sAm, sAk = (K, 1) if a_layout == "k" else (1, M)
+    sBn, sBk = (K, 1) if b_layout == "k" else (1, N)
+    Ct = torch.full((M, N), float("nan"), device=DEV) if C0 is None else torch.from_numpy(C0.copy()).to(DEV)
+    pa, pb = torch.zeros(nparts[0], device=DEV), torch.zeros(nparts[1], device=DEV)
+    nbytes = lib.rulgnn_sgemm_scaled_workspace_bytes(M, N, K, 1 if split_k else 0)
+    ws = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device=DEV)               # garbage: nothing may rely on a zeroed workspace
+    used = C.c_int32(-1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.rulgnn_absmax_partials_f32(At.data_ptr(), At.numel(), pa.data_ptr(), nparts[0], st), "absmax")
+    _lib.check(lib.rulgnn_absmax_partials_f32(Bt.data_ptr(), Bt.numel(), pb.data_ptr(), nparts[1], st), "absmax")
+    _lib.check(lib.rulgnn_sgemm_scaled_ws_f32(At.data_ptr(), sAm, sAk, Bt.data_ptr(), sBn, sBk, Ct.data_ptr(), N, M, N, K, 1 if accumulate else 0,
+                                              pa.data_ptr(), nparts[0], pb.data_ptr(), nparts[1], 1 if split_k else 0, ws.data_ptr(), nbytes,
+                                              C.byref(used), st), "sgemm_scaled_ws")
+    torch.cuda.synchronize()
+    return Ct.cpu().numpy(), int(used.value)
+
+
+@pytest.mark.parametrize("scale_a,scale_b", [(1.0, 1.0), (3e-7, 40.0), (2.5e5, 1e-9), (1e-30, 1e20)])
+@pytest.mark.parametrize("a_layout,b_layout", [("k", "k"), ("k", "r"), ("r", "k"), ("r", "r")])
+def test_presplit_product_at_the_theta_shape_over_the_operand_range(scale_a, scale_b, a_layout, b_layout):
+    """[10 240 x 1024] . [1024 x 1024] -- theta(A.X) of the reference's XJTU-SY ST_GCN wiring at batch 1024 (models/ST_GCN/Model.py:88,
+    configs/hparams.py:334,349) and, with a row-contiguous B, its data gradient d(A.X) = dH theta: 64 x 4 tiles of 160 x 256, every layout
+    of the split pass, operands from 1e-30 to 1e20: the same 2^-22-per-operand error class as the in-loop split."""
+    M, N, K = 10240, 1024, 1024
+    rng = np.random.default_rng(int(1e3 * np.log10(scale_a * 7 + scale_b)) % 1000 + 1)
+    A = (rng.standard_normal((M, K)) * scale_a).astype(np.float32)
+    B = (rng.standard_normal((N, K)) * scale_b).astype(np.float32)
+    got, used = run_scaled_ws(A, B, M, N, K, a_layout, b_layout)
+    assert used == 1
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 4e-6
+    old, _, _ = run_scaled(A, B, M, N, K, a_layout, b_layout)                           # the in-loop split of round 5: same class, other summation order
+    assert np.abs(got - old).max() / np.abs(ref).max() < 4e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(5120, 1024, 96), (5120, 1024, 32), (5120, 1024, 64), (10240, 512, 160), (20480, 256, 256), (4160, 2048, 128)])
+def test_presplit_product_tile_forms_and_short_k(M, N, K):
+    """128 x 256 tiles (M = 5120 = 40 x 128 fills the chip better than 32 x 160), one / two / three / more k stages of the ring, other panel
+    counts; integer operands come out EXACT (|sum| < 2^24: every partial sum is an exact fp32 and the split of an integer < 2^11 has lo = 0)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got, used = run_scaled_ws(A, B, M, N, K, "k", "k")
+    assert used == 1
+    assert np.abs(got - ref).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-6
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    b_layout = "r" if K % 64 == 0 else "k"            # (the transposing split pass works in 64 x 64 tiles)
+    acc, used = run_scaled_ws(A, B, M, N, K, "k", b_layout, accumulate=True, C0=C0)
+    assert used == 1 and np.abs(acc - (ref + C0)).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max() + 1e-5
+    Ai = rng.integers(-300, 300, (M, K)).astype(np.float32)
+    Bi = rng.integers(-300, 300, (N, K)).astype(np.float32)
+    got, _ = run_scaled_ws(Ai, Bi, M, N, K, "r" if K % 64 == 0 else "k", "k")
+    assert np.array_equal(got, Ai.astype(np.float64) @ Bi.astype(np.float64).T)
+
+
+@pytest.mark.parametrize("M,N,K,layout", [(1024, 1024, 10240, "r"), (1024, 1024, 10240, "k"), (1280, 512, 20480, "r"), (640, 256, 40960, "r")])
+def test_presplit_split_k_weight_gradient(M, N, K, layout):
+    """d theta = dH^T (A.X): [1024 x 1024] over K = batch x 10 = 10 240 rows, both operands row-contiguous (the transposing split pass),
+    32 tiles of 128 x 256 x 8 k slices = 256 workgroups + the fixed-order slice sum: right, and the same bits on a second run."""
+    rng = np.random.default_rng(M + K)
+    A = (rng.standard_normal((M, K)) * 1e-6).astype(np.float32)                       # gradient-sized
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got, used = run_scaled_ws(A, B, M, N, K, layout, layout, split_k=True)
+    assert used == 1
+    assert np.abs(got - ref).max() < 2e-6 * np.sqrt(K) * np.abs(ref).max()
+    got2, _ = run_scaled_ws(A, B, M, N, K, layout, layout, split_k=True)
+    assert np.array_equal(got, got2)
+
+
+def test_presplit_entry_falls_back_for_other_shapes_and_modes_and_propagates_special_values():
+    """A shape the pre-split kernel does not take (M = 10 250) runs the round-5 kernels through the same entry; RULGNN_GEMM_BF16X3_ONLY
+    keeps every product on the range-free bf16 split; NaN / Inf elements do not set the scale and propagate as in fp32."""
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    M, N, K = 10250, 1024, 256
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    got, used = run_scaled_ws(A, B, M, N, K, "k", "k")
+    assert used == 0 and np.abs(got - ref).max() < 4e-6 * np.abs(ref).max()
+    M = 10240
+    A = A[:M].copy()
+    ref = ref[:M]
+    prev = lib.rulgnn_sgemm_mode(_lib.GEMM_BF16X3_ONLY)
+    try:
+        only, used = run_scaled_ws(A, B, M, N, K, "k", "k")
+    finally:
+        lib.rulgnn_sgemm_mode(prev)
+    assert used == 0 and np.array_equal(only, run(A, B, M, N, K, "k", "k"))
+    A[7, 3] = np.nan
+    A[9, 100] = np.inf
+    got, used = run_scaled_ws(A, B, M, N, K, "k", "k")
+    ok = np.ones(M, bool); ok[[7, 9]] = False
+    assert used == 1 and np.isnan(got[7]).all() and not np.isfinite(got[9]).any()
+    assert np.abs(got[ok] - ref[ok]).max() < 4e-6 * np.abs(ref[ok]).max()

@@ -65,7 +65,9 @@ def test_train_matches_reference_autograd(name, mode):
                                        (64, 10, 6, 2, 0.2), (33, 16, 5, 1, 0.2),
                                        # num_patch > 64: tiled path (PHM2012 Condition_2 160x16, XJTU-SY 1024x32 / 2048x16)
                                        (65, 8, 5, 2, 0.0), (160, 16, 7, 2, 0.2), (200, 6, 3, 1, 0.3), (300, 5, 4, 3, 0.2),
-                                       (1024, 32, 3, 2, 0.3), (2048, 16, 2, 2, 0.2)])
+                                       (1024, 32, 3, 2, 0.3), (2048, 16, 2, 2, 0.2),
+                                       # ... the five large products on pre-split operands (csrc/sgemm_planes.hip; batch x 10 >= 5120 rows)
+                                       (1024, 32, 512, 2, 0.3), (256, 8, 1024, 2, 0.2)])
 def test_train_matches_oracle_seeded(N, P, B, L, p):
     import gpu_util as G
     rng = np.random.default_rng(N * 1000 + P * 10 + B)
