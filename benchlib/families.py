@@ -198,7 +198,8 @@ def family_line(args, family, world, rank, dev, use_dist, dist, batch=None, cpu_
         algo.model.compute_dtype = args.dtype
         err = float((preds[args.dtype] - preds["f32"]).abs().max() / preds["f32"].abs().max())
         variant_error = {"pred_max_rel_error_vs_f32": err, "meets_1e-4_gate": bool(err < 1e-4),
-                         "note": "bf16 operands on the row projections only; tests/test_fcstgnn_gpu.py bounds it against the fp64 oracle"}
+                         "note": "bf16 operands on every product of the window-graph kernels (forward and backward) and on the GEMM-launch row projections; fp32 "
+                                 "accumulate / softmax / BatchNorm / weight gradients / Adam; tests/test_fcstgnn_gpu.py bounds it against the fp64 oracle at full size"}
     last = None
     for i in range(args.warmup):
         last = algo.update(Xs[i % 2], ys[i % 2], 1)["loss"]

@@ -570,6 +570,45 @@ __device__ __forceinline__ float fc_swap32(float v) {                 // the val
 }
 constexpr int FC_MX_WAVES = 4;
 
+// A whole product of the window-graph kernels: acc += sum over the NS k slots (slot, half) of a[slot] b[slot].
+//   BF = false: NS x v_mfma_f32_32x32x2_f32 (one k pair per instruction, exact fp32 operands);
+//   BF = true (compute_dtype = bf16, BASELINE.json "FC_STGNN ... bf16"): the operands rounded to bf16 (v_cvt_pk_bf16_f32, nearest-even)
+//   and eight slots per v_mfma_f32_32x32x16_bf16 -- a-operand lane l = A[l & 31][8 (l >> 5) + j], b-operand lane l = B[8 (l >> 5) + j][l & 31]:
+//   slot j of half h is k = 8 h + j, the same (slot, half) pairing of the two operands as the fp32 form, so the register forms of the
+//   kernels carry over unchanged; fp32 accumulation, fp32 softmax / BatchNorm / statistics around it.  NS = 8: one instruction instead of
+//   eight (32 instead of 512 matrix-pipe cycles), NS = 16: two; NS = 4 pads four zero slots.
+typedef __bf16 fc_bf16x8 __attribute__((ext_vector_type(8)));
+// (the compiler's own conversion, not inline asm: the result feeds a matrix instruction directly and the hazard recogniser must see the
+// VALU write -- with `asm("v_cvt_pk_bf16_f32")` the backward kernel read the operand registers too early: NaN gradients)
+__device__ __forceinline__ unsigned fc_pk_bf16(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+template <bool BF, int NS>
+__device__ __forceinline__ fc_f32x16 fc_prod(const float (&a)[NS], const float (&b)[NS], fc_f32x16 acc) {
+    if constexpr (!BF) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc = fc_mfma(a[s], b[s], acc);
+        return acc;
+    } else {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += 8) {
+            u32x4 pa, pb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = s0 + 2 * q;
+                pa[q] = fc_pk_bf16(s < NS ? a[s < NS ? s : 0] : 0.f, s + 1 < NS ? a[s + 1 < NS ? s + 1 : 0] : 0.f);
+                pb[q] = fc_pk_bf16(s < NS ? b[s < NS ? s : 0] : 0.f, s + 1 < NS ? b[s + 1 < NS ? s + 1 : 0] : 0.f);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(fc_bf16x8, pa), __builtin_bit_cast(fc_bf16x8, pb), acc, 0, 0, 0);
+        }
+        return acc;
+    }
+}
+
 // forward: S = M' M'^T, P = softmax(leaky(S - 1e8 I)) by rows, AX = ((P + I) o decay mask) X'   (Model_Base.py:44-78)
 template <int D2T>
 __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_graph_mx_kernel(FcGeom g, int blk, const float* __restrict__ prm, const float* __restrict__ running,
@@ -1055,7 +1094,7 @@ __global__ __launch_bounds__(FB) void fc_graph_bwd_kernel(FcGeom g, int blk, con
 // feature krow(r, h): exactly the operand form of S = M' M'^T, whose k order is free because both operands are the same registers) and
 // the block's Linear z5 = AX W_theta^T + b with its BatchNorm statistics behind (AX^T is already the a-operand form).  Replaces
 // [mapping GEMM, graph kernel, theta GEMM, bias + statistics kernel]: three launches and the Mm / AX round trips less per block.
-template <int D2T>
+template <int D2T, bool BF>
 __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g, const float* __restrict__ prm, const float* __restrict__ running,
                                                                        Cells* cells, int training, const float* __restrict__ F, Ptr2 Mmp, Ptr2 Pp,
                                                                        Ptr2 AXp, Ptr2 z5p) {
@@ -1108,20 +1147,16 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
             xk[s] = (c < D2T && node < Q) ? fmaf(fv, sc, sh) : 0.f;
         }
         // M^T = W_map F^T: lane = node, register = mapped feature krow(r, h)
-        fc_f32x16 M = zero;
-#pragma unroll
-        for (int s = 0; s < HK; ++s) M = fc_mfma(wm[s], fh[s], M);
+        const fc_f32x16 M = fc_prod<BF, HK>(wm, fh, zero);
         if (c < Q) {                                                   // the backward reads the mapping (overlapping windows write the same values)
             float* mr = Mm + (row0 + c) * D2T + 4 * h;
 #pragma unroll
             for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(mr + 8 * m) = make_float4(M[4 * m], M[4 * m + 1], M[4 * m + 2], M[4 * m + 3]);
         }
-        fc_f32x16 S = zero;
+        float mb[HK];
 #pragma unroll
-        for (int s = 0; s < HK; ++s) {
-            const float v = M[s] + bm[fc_krow(s, h)];
-            S = fc_mfma(v, v, S);
-        }
+        for (int s = 0; s < HK; ++s) mb[s] = M[s] + bm[fc_krow(s, h)];
+        const fc_f32x16 S = fc_prod<BF, HK>(mb, mb, zero);
         float t[16], mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1146,22 +1181,24 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
                 if (8 * m + 4 * h < Q)
                     *reinterpret_cast<float4*>(pr + 8 * m) = make_float4(t[4 * m] * inv, t[4 * m + 1] * inv, t[4 * m + 2] * inv, t[4 * m + 3] * inv);
         }
-        fc_f32x16 A = zero;
+        float adjr[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int j = fc_krow(s, h);
             const float adj = (t[s] * inv + (j == c ? 1.f : 0.f)) * (((c < N) == (j < N)) ? 1.f : DECAY);
-            A = fc_mfma(xk[s], j < Q ? adj : 0.f, A);
+            adjr[s] = j < Q ? adj : 0.f;
         }
+        const fc_f32x16 A = fc_prod<BF, 16>(xk, adjr, zero);
         if (c < Q) {
             float* ar = AX + (gi * Q + c) * D2T + 4 * h;
 #pragma unroll
             for (int m = 0; m < D2T / 8; ++m) *reinterpret_cast<float4*>(ar + 8 * m) = make_float4(A[4 * m], A[4 * m + 1], A[4 * m + 2], A[4 * m + 3]);
         }
         // z5^T = W_theta AX^T: lane = node, register = output channel krow(r, h)
-        fc_f32x16 Z = zero;
+        float ak[HK];
 #pragma unroll
-        for (int s = 0; s < HK; ++s) Z = fc_mfma(wt[s], A[s], Z);
+        for (int s = 0; s < HK; ++s) ak[s] = A[s];
+        const fc_f32x16 Z = fc_prod<BF, HK>(wt, ak, zero);
         if (c < Q) {
             float zv[HDT / 2];
 #pragma unroll
@@ -1208,7 +1245,7 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES) void fc_block_mx_kernel(FcGeom g,
 // in both orientations, and dS^T comes from one product with the identity (a-operand dS: the result's register <-> lane roles swap).
 // FUSED: the gradient arrives as d z5 and d AX = d z5 W_theta is formed here in both register forms (eight more products, K = D2 / 2)
 // instead of a GEMM launch and two reads of its result; the half rows of X' are then read in the order krow(step, half) of that form.
-template <int D2T, bool FUSED>
+template <int D2T, bool FUSED, bool BF>
 __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(FcGeom g, const float* __restrict__ prm, const Cells* cells,
                                                                            const float* __restrict__ F, CPtr2 Mmp, CPtr2 Pp, CPtr2 dz5p,
                                                                            Ptr2 dAXp /* in (not FUSED): d AX; out: cX */, Ptr2 cMp) {
@@ -1263,12 +1300,8 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
                 const float4 z4 = zs[v];
                 zo[4 * v] = z4.x; zo[4 * v + 1] = z4.y; zo[4 * v + 2] = z4.z; zo[4 * v + 3] = z4.w;
             }
-            fc_f32x16 DH = zero, DK = zero;
-#pragma unroll
-            for (int s = 0; s < HO; ++s) {
-                DH = fc_mfma(wth[s], zo[s], DH);                        // (register -> feature krow, lane -> node)
-                DK = fc_mfma(zo[s], wth[s], DK);                        // (register -> node krow, lane -> feature)
-            }
+            const fc_f32x16 DH = fc_prod<BF, HO>(wth, zo, zero);          // (register -> feature krow, lane -> node)
+            const fc_f32x16 DK = fc_prod<BF, HO>(zo, wth, zero);          // (register -> node krow, lane -> feature)
 #pragma unroll
             for (int s = 0; s < HK; ++s) dh[s] = DH[s];
 #pragma unroll
@@ -1291,12 +1324,8 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
         // barrier between the stages: hoisted to the top (what the scheduler does on its own) the operands of all five products are
         // live at once -- 308 registers, one wavefront per SIMD and nothing to hide its ~70 loads per graph behind.  This way two fit
         // (205 registers; three spill and are slower): 0.692 -> 0.681 ms per step.
-        fc_f32x16 Tt = zero, Sm = zero;
-#pragma unroll
-        for (int s = 0; s < HK; ++s) {
-            Tt = fc_mfma(xh[s], dh[s], Tt);                             // (register -> j, lane -> i): sum_d X'[j][d] dAX[i][d]
-            Sm = fc_mfma(mh[s], mh[s], Sm);
-        }
+        const fc_f32x16 Tt = fc_prod<BF, HK>(xh, dh, zero);               // (register -> j, lane -> i): sum_d X'[j][d] dAX[i][d]
+        const fc_f32x16 Sm = fc_prod<BF, HK>(mh, mh, zero);
         asm volatile("" ::: "memory");
         // softmax backward of row c (P by rows: this lane's row), then the leaky slope of the pre-activation
         float ds_[16];
@@ -1338,8 +1367,9 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
             for (int s = 0; s < 16; ++s) {
                 const int i = fc_krow(s, h);
                 const float adj = (pc[s] + (i == c ? 1.f : 0.f)) * (((i < N) == (c < N)) ? 1.f : DECAY);
-                CX = fc_mfma(dk[s], i < Q ? adj : 0.f, CX);
+                pc[s] = i < Q ? adj : 0.f;
             }
+            CX = fc_prod<BF, 16>(dk, pc, CX);
             if (c < Q) {                                                // (all loads of this graph's dAX block are behind us)
                 float* xr = dAX + (gi * Q + c) * D2T + 4 * h;
 #pragma unroll
@@ -1367,12 +1397,14 @@ __global__ __launch_bounds__(64 * FC_MX_WAVES, 2) void fc_graph_bwd_mx_kernel(Fc
             const int node = fc_krow(s, h);
             mk[s] = Mm[(row0 + (node < Q ? node : Q - 1)) * D2T + cf];
         }
+        float dsum[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int node = fc_krow(s, h);
-            const float mks = (c < D2T && node < Q) ? mk[s] + bc : 0.f;
-            CM = fc_mfma(mks, ds_[s] + St[s], CM);
+            mk[s] = (c < D2T && node < Q) ? mk[s] + bc : 0.f;
+            dsum[s] = ds_[s] + St[s];
         }
+        CM = fc_prod<BF, 16>(mk, dsum, CM);
         if (c < Q) {
             float* mr = cM + (gi * Q + c) * D2T + 4 * h;
 #pragma unroll
@@ -2093,8 +2125,9 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                    (const float*)P_(w.F), Ptr2{{P_(w.Mm[0]), P_(w.Mm[1])}}, Ptr2{{P_(w.P[0]), P_(w.P[1])}},
                                    Ptr2{{P_(w.AX[0]), P_(w.AX[1])}}, Ptr2{{P_(w.z5[0]), P_(w.z5[1])}});
             };
-            if (D2 == 16) go(fc_block_mx_kernel<16>);
-            else go(fc_block_mx_kernel<32>);
+            // (compute_dtype = bf16: the four products of a window graph on bf16 matrix instructions, fc_prod)
+            if (D2 == 16) { if (bf) go(fc_block_mx_kernel<16, true>); else go(fc_block_mx_kernel<16, false>); }
+            else { if (bf) go(fc_block_mx_kernel<32, true>); else go(fc_block_mx_kernel<32, false>); }
             FC_RC(sync_pair(0, 4));
             FC_RC(sync_pair(0, 6));
         }
@@ -2244,11 +2277,11 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                        Ptr2{{P_(w.dMb[0]), P_(w.dMb[1])}});
                 };
                 if (bwd_fused) {
-                    if (D2 == 16) go(fc_graph_bwd_mx_kernel<16, true>);
-                    else go(fc_graph_bwd_mx_kernel<32, true>);
+                    if (D2 == 16) { if (bf) go(fc_graph_bwd_mx_kernel<16, true, true>); else go(fc_graph_bwd_mx_kernel<16, true, false>); }
+                    else { if (bf) go(fc_graph_bwd_mx_kernel<32, true, true>); else go(fc_graph_bwd_mx_kernel<32, true, false>); }
                 } else {
-                    if (D2 == 16) go(fc_graph_bwd_mx_kernel<16, false>);
-                    else go(fc_graph_bwd_mx_kernel<32, false>);
+                    if (D2 == 16) { if (bf) go(fc_graph_bwd_mx_kernel<16, false, true>); else go(fc_graph_bwd_mx_kernel<16, false, false>); }
+                    else { if (bf) go(fc_graph_bwd_mx_kernel<32, false, true>); else go(fc_graph_bwd_mx_kernel<32, false, false>); }
                 }
             } else {
             for (int b = 0; b < 2; ++b) {

@@ -126,9 +126,9 @@ class FC_STGNN_RUL(FlatModule):
         self._step = 0
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.dropout_p = PE_DROPOUT
-        # "f32" (default; meets the 1e-4 parity gate) or "bf16": bf16 operands on the row-projection matrix-core GEMMs, fp32
-        # accumulation / BatchNorm / graphs / weight gradients / optimizer -- BASELINE.json's "FC_STGNN ... bf16" variant, reported
-        # separately (rulgnn.h: rulgnn_fcstgnn_args.compute_dtype)
+        # "f32" (default; meets the 1e-4 parity gate) or "bf16": bf16 operands on every product of the window-graph kernels (forward and
+        # backward: v_mfma_f32_32x32x16_bf16) and on the row-projection GEMMs; fp32 accumulation / softmax / BatchNorm / weight gradients /
+        # optimizer -- BASELINE.json's "FC_STGNN ... bf16" variant, reported separately (rulgnn.h: rulgnn_fcstgnn_args.compute_dtype)
         self.compute_dtype = "f32"
         self._track_batchnorm_counters()
         self._init_flat()

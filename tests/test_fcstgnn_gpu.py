@@ -159,11 +159,13 @@ def test_eval_batch_split_invariance_and_abi_errors():
 
 
 def test_bf16_variant_error_is_bounded():
-    """BASELINE.json config "FC_STGNN on C-MAPSS FD004, batch=256, bf16": compute_dtype="bf16" rounds the operands of the row
-    projections that run as GEMM launches to bf16 (fp32 accumulate; fp32 BatchNorm / graphs / weight gradients / fused projections).
-    It is a separate, reported variant: its error against the fp64 oracle is bounded here (1e-2 on predictions and loss, gradients
-    within 5 % and pointing the same way).  Since round 3 every forward projection of this wiring is fused into an fp32 kernel, so the
-    predictions sit at fp32 level; the default and every parity claim stay fp32."""
+    """BASELINE.json config "FC_STGNN on C-MAPSS FD004, batch=256, bf16", full size: compute_dtype="bf16" runs the products of the
+    window-graph kernels -- the mapping M = F W_map^T, S = M' M'^T, A.X and the block's 16 -> 8 projection forward; d z5 W_theta, T = X' dAX^T,
+    S, Adj^T dAX and (dS + dS^T) M' backward (csrc/fcstgnn.hip: fc_prod<true>, v_mfma_f32_32x32x16_bf16) -- and the row projections that
+    run as GEMM launches on bf16 operands; fp32 accumulation, softmax, BatchNorm cells, weight gradients and Adam (reference shapes:
+    models/FC_STGNN/Model_Base.py:44-107,175-225).  It is a separate, reported variant that does NOT meet the 1e-4 gate: its error against
+    the fp64 oracle is bounded here (1e-2 on predictions and loss, gradients within 5 % and pointing the same way) and must be REAL
+    (> 1e-5: the switch changes the kernels of this very wiring); the default and every parity claim stay fp32."""
     from gnn_rul_benchmarking_amd.hparams import get_hparams_class
     cfg = O.Config(**get_hparams_class("CMAPSS")("FD004").alg_hparams["FC_STGNN"])
     bs = 256
@@ -188,7 +190,8 @@ def test_bf16_variant_error_is_bounded():
     ref_flat = np.concatenate([np.asarray(grads[k], np.float64).reshape(-1) for k in O.param_names(cfg) if k not in ZERO_GRAD])
     e32, e16 = rel(res["f32"][0], fw.pred), rel(res["bf16"][0], fw.pred)
     assert e32 < TOL
-    assert e16 < 1e-2, e16
+    assert 1e-5 < e16 < 1e-2, e16                     # bf16 operands are visible (8 significant bits) and bounded
+    assert not np.array_equal(res["bf16"][2], res["f32"][2])
     assert abs(res["bf16"][1] - loss) < 1e-2 * abs(loss)
     gerr = np.abs(res["bf16"][2] - ref_flat).max() / np.abs(ref_flat).max()
     cos = float(res["bf16"][2] @ ref_flat / (np.linalg.norm(res["bf16"][2]) * np.linalg.norm(ref_flat)))
