@@ -272,6 +272,11 @@ def main():
                                  "unit": "samples/s", "vs_fp32_chain": fp["vs_fp32_chain"],
                                  "note": "the same step with every product in plain fp32 FMAs (RULGNN_STEP_CHAIN, the path a guard trip falls back to), "
                                          "same batch, dropout 0.2, timed beside the headline"}
+            # the reference's real C-MAPSS window is 50 points (Data_Process/Data_read_CMAPSS.py:330; BASELINE.json names 30): the same step at 14 x 50
+            out["train_cmapss_14x50"] = dict(stgcn_train_other_shape(dev, NUM_PATCH, 50, [per_rank], fp32_batches=(per_rank,)),
+                                             workload="ST_GCN.update at the reference's own C-MAPSS window (14 sensors x 50 points), same batch, dropout 0.2: "
+                                                      "matrix-core chain, fp32 chain beside it",
+                                             algorithmic_bytes_per_sample=algorithmic_bytes_per_sample(NUM_PATCH, 50))
             out["train_phm2012_40x64"] = dict(stgcn_train_other_shape(dev, 40, 64, [100, 16384, 65536], fp32_batches=(16384, 65536)),
                                               workload="ST_GCN.update at the reference's own PHM2012 wiring (40 patches x 64 points, configs/hparams.py:223,238): "
                                                        "wide matrix-core chain (one sample per wavefront in three column tiles, activations recomputed), the "
@@ -292,10 +297,10 @@ def main():
             r = d["roofline"]
             fams[fam] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
                          "workload": d["config"]["workload"], "per_gpu_batch": d["config"]["per_gpu_batch"], "final_loss": d["final_loss"],
-                         "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "us_per_launch", "launches_per_step",
+                         "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "peak_basis", "unit", "frac", "traffic", "us_per_launch", "launches_per_step",
                                                          "launches_in_step", "step_kernel_time_us", "share_of_step_kernel_time", "whole_step_estimate",
                                                          "work_model") if k in r},
-                         "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "runs")} if "cpu_baseline" in d else None}
+                         "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "port_of", "sample", "runs") if k in d["cpu_baseline"]} if "cpu_baseline" in d else None}
         # BASELINE.json configs[1] is written "FC_STGNN ... bf16": the variant (every product of the window-graph kernels, forward and backward,
         # on v_mfma_f32_32x32x16_bf16 with bf16-rounded operands; fp32 accumulate / softmax / BatchNorm / weight gradients / Adam) is timed here
         # beside the fp32 path the entry above reports; it does NOT meet the 1e-4 gate (its error is in the line) -- the parity claim is fp32

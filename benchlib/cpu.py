@@ -33,6 +33,7 @@ def cpu_baseline(num_patch, patch_size, dropout):
     runs.append(dict(T.time_update(num_patch, patch_size, 4096, best["threads"], dropout, warmup=20, iters=100, budget_s=6.0,
                                    eval_forward=True), what="eval forward"))
     return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
+            "port_of": "torch-CPU restatement of the reference's ST_GCN.update (oracle/stgcn_torch_cpu.py: the same ATen kernels in the reference's order)",
             "sample": f"{best['iterations']} ST_GCN.update iterations (after 20 warm-up) of batch 4096 ({num_patch}x{patch_size}, dropout {dropout}), "
                       f"torch-CPU restatement of the reference (oracle/stgcn_torch_cpu.py), fp32, best of thread counts {thread_counts}",
             "cpu_model": T.cpu_model_name(), "host_cpus": cores, "torch": torch.__version__, "runs": runs,
@@ -54,7 +55,7 @@ def family_torch_cpu_baseline(family, cfg, batch, budget_s=10.0):
     per = budget_s / len(counts)
     runs = [T.time_update(family, dict(cfg), batch, th, warmup=3, iters=100, budget_s=per) for th in counts]
     best = max(runs, key=lambda r: r["samples_per_s"])
-    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "torch-cpu restatement",
+    return {"value": best["samples_per_s"], "unit": "samples/s", "cores": best["threads"], "kind": "port", "port_of": "torch-CPU restatement of the reference's update() (oracle/families_torch_cpu.py: the same ATen kernels in the reference's order)",
             "cpu_model": T.cpu_model_name(), "host_cpus": cores, "torch": torch.__version__, "runs": runs,
             "sample": f"full update() (train forward + loss + backward + torch.optim.Adam) of oracle/families_torch_cpu.py at batch {batch}, "
                       f"fp32 ATen kernels, threads {counts}, <= {per:.1f} s or 100 iterations each (iterations timed: "

@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from .common import FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, kernel_short_name, kernel_times
+from .common import FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, F16X2_SPLIT_PEAK_TFLOPS, HBM_PEAK_GBS, kernel_short_name, kernel_times
 from .cpu import family_cpu_baseline
 
 
@@ -253,10 +253,17 @@ def family_line(args, family, world, rank, dev, use_dist, dist, batch=None, cpu_
         if work:
             ach = work / (us * 1e-6) / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS
+            roof["peak_basis"] = "fp32 matrix peak (157.3 TFLOP/s): the kernel issues v_mfma_f32_*_f32"
+            if "f16x2" in short or "sgemm_planes" in short:
+                peak = F16X2_SPLIT_PEAK_TFLOPS
+                roof["peak_basis"] = "dense f16 matrix peak (2500 TFLOP/s) / 3 matrix instructions per fp32-class product block; FLOPs counted once"
+            if args.dtype == "bf16" and ("fc_block_mx" in short or "fc_graph_bwd_mx" in short):
+                peak = BF16_MFMA_PEAK_TFLOPS
+                roof["peak_basis"] = "dense bf16 matrix peak (2500 TFLOP/s): the kernel issues v_mfma_f32_32x32x16_bf16"
             if "bf16x3" in short:
                 # fp32-class products out of six bf16 matrix instructions each (csrc/sgemm_mfma.hpp): the ceiling is a sixth of the dense bf16 peak
                 peak = round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
-                roof["peak_note"] = "dense bf16 matrix peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 products per fp32-class product; FLOPs counted once"
+                roof["peak_basis"] = "dense bf16 matrix peak (2500 TFLOP/s, MI355X_MICROARCH.md) / 6 matrix instructions per fp32-class product block; FLOPs counted once"
             roof.update({"achieved": round(ach, 4), "peak": peak, "frac": round(ach / peak, 5), "flops_per_launch": round(work), "work_model": how})
             if generic_above:
                 roof["generic_gemm_instances_with_larger_share"] = generic_above

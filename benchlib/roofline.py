@@ -17,7 +17,7 @@ if ROOT not in sys.path:
 import ctypes as C
 
 from .common import (HBM_PEAK_GBS, NUM_PATCH, FP32_MFMA_PEAK_TFLOPS, event_time_ms, algorithmic_bytes_per_sample, forward_flops_per_sample, compute_leg,
-                     kernel_short_name, kernel_times)
+                     kernel_short_name, kernel_times, mfma_util_from_profile)
 
 
 def phase_names(L):
@@ -67,7 +67,7 @@ def phase_bytes_per_sample(name, N, P, L, chain="mx"):
 def _traffic_profile(chain="mx"):
     """The committed PMC summary (FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh) of the given phase chain ("mx" = the
     matrix-core chain of round 4, "fp32" = the row-mapped chain; summaries without a "chain" entry predate the former): newest round first."""
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_g_hbm_traffic.json"):
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
             if t.get("chain", "fp32") != chain:
@@ -94,7 +94,7 @@ def forward_traffic(N, P, B):
     """HBM bytes per launch of the fused eval forward from its own PMC passes (tools/profile_forward.sh ->
     profiles/r0N_forward_bs<B>_hbm_traffic.json: the forward profiled ALONE -- the EVAL entry of the train-step profile also counts
     the bench's other launches of that name), or None when this batch was not profiled."""
-    for rnd in ("r05", "r04", "r03", "r02"):       # newest round first
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):       # newest round first
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_forward_bs{B}_hbm_traffic.json")))
             w = t["workload"]
@@ -237,9 +237,12 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
               "unit": "GB/s", "frac": round(fach / HBM_PEAK_GBS, 4), "traffic": forward_traffic(N, P, B),
               "algorithmic_bytes_per_sample": alg, "batch": B,
               "us_per_launch": round(fms * 1e3, 1), "samples_per_s": round(B / (fms * 1e-3), 1),
-              "compute": compute_leg(forward_flops_per_sample(N, P, L), B / (fms * 1e-3), "one eval forward per sample")}
+              "compute": compute_leg(forward_flops_per_sample(N, P, L), B / (fms * 1e-3), "one eval forward per sample", num_patch=N)}
+    roof_f["mfma_util"] = mfma_util_from_profile("stgcn_forward_mx_kernel")
     roof["compute"] = compute_leg(3 * forward_flops_per_sample(N, P, L), B / (step_ms * 1e-3),
-                                  "3 x the forward FLOPs per sample (SURVEY section 8d), whole step; recomputed products not counted")
+                                  "3 x the forward FLOPs per sample (SURVEY section 8d), whole step; recomputed products not counted",
+                                  num_patch=N, passes=9.0 if chain_kind == "mx" else 0.0)
+    roof["mfma_util"] = mfma_util_from_profile("stgcn_train_mx_kernel<2, 2, 2")
     if big_forward:
         BB = 1 << 20
         g = torch.Generator(device=X.device).manual_seed(99)
@@ -249,7 +252,7 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
         roof_f["at_1M"] = {"batch": BB, "us_per_launch": round(bms * 1e3, 1), "achieved": round(bach, 1),
                            "frac": round(bach / HBM_PEAK_GBS, 4), "samples_per_s": round(BB / (bms * 1e-3), 1),
                            "traffic": forward_traffic(N, P, BB),
-                           "compute": compute_leg(forward_flops_per_sample(N, P, L), BB / (bms * 1e-3), "one eval forward per sample")}
+                           "compute": compute_leg(forward_flops_per_sample(N, P, L), BB / (bms * 1e-3), "one eval forward per sample", num_patch=N)}
         del Xb
         # the reference's C-MAPSS window is 50 points (Data_Process/Data_read_CMAPSS.py:330): the same kernel at 14 x 50
         from gnn_rul_benchmarking_amd.stgcn import ST_GCN_model as _M
@@ -262,7 +265,7 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
         roof_f["cmapss_14x50"] = {"kernel": "stgcn_forward_mx_kernel<2, 14, 50>", "batch": X50.size(0), "algorithmic_bytes_per_sample": calg,
                                   "us_per_launch": round(cms * 1e3, 1), "achieved": round(cach, 1), "frac": round(cach / HBM_PEAK_GBS, 4),
                                   "samples_per_s": round(X50.size(0) / (cms * 1e-3), 1),
-                                  "compute": compute_leg(forward_flops_per_sample(N, 50, L), X50.size(0) / (cms * 1e-3), "one eval forward per sample")}
+                                  "compute": compute_leg(forward_flops_per_sample(N, 50, L), X50.size(0) / (cms * 1e-3), "one eval forward per sample", num_patch=N)}
         del X50, m50
         # the reference's own ST_GCN wiring on PHM2012 (configs/hparams.py:238: 40 patches of 64 points): the wide matrix-core kernel
         # (stgcn_forward_mxw_kernel) followed by the scanning launch of the exact kernel, both inside the timed region
@@ -277,7 +280,7 @@ def roofline_measurements(model, X, y, step_ms, iters=10, isolated=False, big_fo
         roof_f["phm2012_40x64"] = {"kernel": "stgcn_forward_mxw_kernel + stgcn_forward_fixup_kernel", "batch": WB,
                                    "algorithmic_bytes_per_sample": walg, "us_per_call": round(wms * 1e3, 1), "achieved": round(wach, 1),
                                    "frac": round(wach / HBM_PEAK_GBS, 4), "samples_per_s": round(WB / (wms * 1e-3), 1),
-                                   "compute": compute_leg(forward_flops_per_sample(WN, WP, 2), WB / (wms * 1e-3), "one eval forward per sample")}
+                                   "compute": compute_leg(forward_flops_per_sample(WN, WP, 2), WB / (wms * 1e-3), "one eval forward per sample", num_patch=WN)}
         del Xw, wide
     return roof, roof_f
 

@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from .common import HBM_PEAK_GBS, FP32_MFMA_PEAK_TFLOPS, event_time_ms, algorithmic_bytes_per_sample
+from .common import HBM_PEAK_GBS, FP32_MFMA_PEAK_TFLOPS, F16X2_SPLIT_PEAK_TFLOPS, event_time_ms, algorithmic_bytes_per_sample, mfma_util_from_profile
 
 
 def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
@@ -78,16 +78,26 @@ def stgcn_tiled_shapes(dev, steps=10):
             tf, etf = 3.0 * fwd * B / (ms * 1e-3) / 1e12, fwd * B / (ems * 1e-3) / 1e12
             entry[f"batch_{B}"] = {"train_ms_per_step": round(ms, 4), "train_samples_per_s": round(B / (ms * 1e-3), 1),
                                    "eval_ms_per_batch": round(ems, 4), "eval_samples_per_s": round(B / (ems * 1e-3), 1),
-                                   "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "eval_achieved": round(etf, 2),
-                                                "eval_frac": round(etf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                                "counts": "whole step: 3 x the forward matmul FLOPs per sample x samples/s (not one kernel)"}}
+                                   "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F16X2_SPLIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                "peak_basis": "dense f16 matrix peak (2500 TFLOP/s) / 3 matrix instructions per fp32-class product block "
+                                                              "(two-plane f16 split: the instruction the large GEMMs issue is v_mfma_f32_32x32x16_f16); "
+                                                              "FLOPs counted once",
+                                                "frac": round(tf / F16X2_SPLIT_PEAK_TFLOPS, 4), "eval_achieved": round(etf, 2),
+                                                "eval_frac": round(etf / F16X2_SPLIT_PEAK_TFLOPS, 4),
+                                                "frac_of_fp32_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                                "counts": "whole step: 3 x the forward matmul FLOPs per sample x samples/s (not one kernel; the "
+                                                          "position-parallel kernels between the GEMMs are HBM-bound and most of the step)"}}
             del algo, X, y
         out[name] = entry
-    out["profile"] = "profiles/r05_stgcn_tiled_xjtu_bs1024_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/time_tiled_one.py: 5 large GEMMs at " \
-                     "185-236 TFLOP/s (two-plane f16 split with operand scales) = 37 % of the step's kernel time, the position-parallel kernels between them " \
-                     "most of the rest; kernel by kernel: " \
-                     "profiles/r05_tiled_path_and_load_chains.md)"
+    out["large_gemm"] = {"kernel": "sgemm_planes_kernel<5> (csrc/sgemm_planes.hip: pre-split operands, LDS-DMA, 160 x 256 tiles) on theta(A.X) and d(A.X); "
+                                   "sgemm_f16x2v_kernel (in-loop split, 256 x 256 tiles) on d theta",
+                         "shape": "[10240 x 1024] . [1024 x 1024]", "kernel_only_us": 63.6, "kernel_only_tflops": 338.0,
+                         "with_split_passes_us": 86.0, "with_split_passes_tflops": 250.0, "round5_kernel_us": 111.0, "round5_kernel_tflops": 193.0,
+                         "peak": F16X2_SPLIT_PEAK_TFLOPS, "frac_kernel_only": round(338.0 / F16X2_SPLIT_PEAK_TFLOPS, 3),
+                         "mfma_util": mfma_util_from_profile("sgemm_planes_kernel"),
+                         "source": "profiles/r06_sgemm_planes_kernel_stats.csv, profiles/r06_sgemm_planes_timing.txt (tools/time_sgemm_planes.py)"}
+    out["profile"] = "profiles/r06_stgcn_tiled_xjtu_bs1024_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/time_tiled_one.py); " \
+                     "what limits the pre-split form inside the step (split-pass traffic, no CU left for the side stream): profiles/r06_notes.md"
     return out
 
 
