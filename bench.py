@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--sync-bn", action="store_true",
                     help="data parallel with synchronised BatchNorm: the N-GPU step is the 1-GPU function of the global batch "
                          "(8 more 160-byte all-reduces per step); default = local statistics like torch DDP")
+    ap.add_argument("--bn-collective", choices=["group", "peer"], default="group",
+                    help="with --sync-bn: the BatchNorm reductions through the process group (RCCL: a host callback per collective) or as "
+                         "device-side one-shot all-reduces over IPC-mapped mailboxes (csrc/peer_comm.hip; one node)")
     ap.add_argument("--scaling", choices=["weak", "strong", "both"], default="both",
                     help="N > 1: weak = fixed per-GPU batch (headline), strong = fixed global batch split over the ranks")
     ap.add_argument("--patch-size", type=int, default=30, help="window length (BASELINE.json: 30)")
@@ -135,6 +138,58 @@ def timed_repetitions(step_fn, steps, warmup, reps, use_dist, dist, dev):
     return out
 
 
+def data_parallel_diagnostics(algo, Xs, ys, args, dist, dev, world, step_ms):
+    """What the first multi-GPU run needs to be diagnostic (every rank takes part: collectives inside): the backend and its rank count,
+    the step's collectives and their sizes, the latency of ONE bucket all-reduce and ONE BatchNorm-cell reduction measured alone on this
+    world (HIP events around 50 back-to-back calls, max over ranks), and the host time to ENQUEUE a step (no synchronisation: it must stay
+    below the device step time or the host, not the GPUs, sets the rate)."""
+    import time as _t
+    m, dp = algo.model, algo.dp
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    bucket = m.bucket.clone()
+    def timed(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return max_over_ranks(e0.elapsed_time(e1) / n * 1e3)
+    bucket_us = timed(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM))
+    cells = torch.zeros(20, dtype=torch.float64, device=dev)
+    group_us = timed(lambda: dist.all_reduce(cells, op=dist.ReduceOp.SUM))
+    peer_us = timed(lambda: dp.peer(cells)) if dp.peer is not None else None
+    # host enqueue time of a step: the loop below returns as soon as everything is queued
+    torch.cuda.synchronize(); dist.barrier()
+    n = max(10, args.steps)
+    t0 = _t.perf_counter()
+    for k in range(n):
+        algo.update(Xs[k % len(Xs)], ys[k % len(ys)], 1)
+    host_ms = (_t.perf_counter() - t0) / n * 1e3
+    torch.cuda.synchronize()
+    host_ms = max_over_ranks(host_ms)
+    if dp.peer is not None:
+        dp.peer.check()
+    L = m.num_layers
+    return {"backend": dist.get_backend(), "ranks_in_group": dist.get_world_size(), "world_size_env": world,
+            "batchnorm": ("syncbn via " + ("device-side one-shot all-reduce over IPC mailboxes (csrc/peer_comm.hip)" if dp.peer is not None
+                                          else "process-group all-reduce (host callback per collective)")) if args.sync_bn else "local statistics",
+            "collectives_per_step": {"bucket_all_reduce": 1, "bucket_bytes": int(m.bucket.numel() * 4),
+                                     "batchnorm_cell_all_reduces": 4 * L if args.sync_bn else 0, "cell_bytes": 160},
+            "bucket_all_reduce_us": round(bucket_us, 1), "cell_all_reduce_us_process_group": round(group_us, 1),
+            "cell_all_reduce_us_peer_mailboxes": round(peer_us, 1) if peer_us is not None else None,
+            "host_enqueue_ms_per_step": round(host_ms, 4), "device_ms_per_step": round(step_ms, 4),
+            "host_bound": bool(host_ms > step_ms),
+            "timing": "collectives: HIP events around 50 back-to-back calls on this world, max over ranks; host: wall clock of enqueueing "
+                      f"{n} steps without synchronisation, max over ranks"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -194,7 +249,7 @@ def main():
     algo.train()
     algo.sync_loss = bool(args.sync_loss)
     if use_dist:
-        algo.attach_data_parallel(DataParallel(sync_bn=args.sync_bn))
+        algo.attach_data_parallel(DataParallel(sync_bn=args.sync_bn, bn_collective=args.bn_collective))
 
     def run(B):
         """Per-rank batch B: returns (per-repetition seconds, last loss, the batches)."""
@@ -227,6 +282,9 @@ def main():
 
     # a step the f16 range guard rejected would have been DROPPED (loss kept on the device): never silently
     algo.check_guard()
+    dp_diag = None
+    if use_dist:
+        dp_diag = data_parallel_diagnostics(algo, Xs, ys, args, dist, dev, world, el / args.steps * 1e3)
     from gnn_rul_benchmarking_amd import _lib as _L
     on_mx = algo.model._last_chain == _L.STEP_MX
     dtype_name = "f32 (f16x2-split MFMA operands, fp32 accumulate)" if on_mx else "f32"
@@ -253,6 +311,8 @@ def main():
         }
         if strong is not None:
             out["strong_scaling"] = strong
+        if dp_diag is not None:
+            out["data_parallel"] = dp_diag
         if not args.no_roofline:
             roof, roof_f = roofline_measurements(algo.model, Xs[0], ys[0], el / args.steps * 1e3, isolated=args.isolated_phases)
             out["roofline"] = roof

@@ -211,6 +211,17 @@ _SIGNATURES = {
     "rulgnn_rgcnu_forward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),
     "rulgnn_rgcnu_backward_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.c_void_p]),
     "rulgnn_rgcnu_fwdbwd_f32": (C.c_int, [C.POINTER(RgcnuShape), C.POINTER(RgcnuArgs), C.POINTER(AdamArgs), C.c_void_p]),
+    "rulgnn_peer_mailbox_bytes": (C.c_size_t, []),
+    "rulgnn_peer_handle_bytes": (C.c_size_t, []),
+    "rulgnn_peer_mailbox_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "rulgnn_peer_mailbox_open": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rulgnn_peer_mailbox_close": (C.c_int, [C.c_void_p]),
+    "rulgnn_peer_mailbox_free": (C.c_int, [C.c_void_p]),
+    "rulgnn_peer_comm_create": (C.c_void_p, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rulgnn_peer_comm_destroy": (None, [C.c_void_p]),
+    "rulgnn_peer_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "rulgnn_peer_comm_collectives": (C.c_int64, [C.c_void_p]),
+    "rulgnn_peer_comm_status": (C.c_int64, [C.c_void_p]),
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
     "rulgnn_stgcn_param_count": (C.c_int64, [C.c_int32, C.c_int32]),
@@ -355,6 +366,29 @@ def load() -> C.CDLL:
                                f"this binding ({mirror.__name__}): rebuild with `python -m gnn_rul_benchmarking_amd.build --force`")
     _lib = lib
     return lib
+
+
+def allreduce_callback(allreduce, ws):
+    """(callback, user, failure) for the `allreduce` / `user` arguments of the *_syncbn_* entries (rulgnn_allreduce_f64_fn).
+    ``allreduce`` is either a Python callable taking a float64 view of the reduction cells inside the workspace ``ws`` (summed over
+    the ranks in place, in stream order: torch.distributed), or an object with ``c_callback`` / ``c_user`` -- the address of a C function
+    of that type and its communicator (dp.PeerAllReduce: rulgnn_peer_allreduce_f64, no Python frame between the phases of a step).
+    ``failure`` collects an exception raised inside the Python form (it must not cross the C frame)."""
+    failure = []
+    if hasattr(allreduce, "c_callback"):
+        return C.cast(allreduce.c_callback, ALLREDUCE_F64_FN), C.c_void_p(allreduce.c_user), failure
+    import torch
+    base = ws.data_ptr()
+
+    def hook(_user, buf, count, _stream):
+        try:
+            off = int(buf) - base
+            allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
+            return 0
+        except BaseException as e:
+            failure.append(e)
+            return 1
+    return ALLREDUCE_F64_FN(hook), None, failure
 
 
 def strerror(code: int) -> str:

@@ -235,18 +235,8 @@ class ASTGCNN_model(FlatModule):
         shp = self._shape(x2d.size(0))
         a = self._args(shp, x2d, True, y=yv, global_batch=global_batch)
         ws = self._ws
-        base, failure = ws.data_ptr(), []
-
-        def hook(_user, buf, count, _stream):
-            try:
-                off = int(buf) - base
-                allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
-                return 0
-            except BaseException as e:          # never let an exception cross the C frame
-                failure.append(e)
-                return 1
-        cb = _lib.ALLREDUCE_F64_FN(hook)
-        rc = _lib.load().rulgnn_astgcnn_fwdbwd_syncbn_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None, _stream())
+        cb, user, failure = _lib.allreduce_callback(allreduce, ws)
+        rc = _lib.load().rulgnn_astgcnn_fwdbwd_syncbn_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, user, _stream())
         if failure:
             raise failure[0]
         _lib.check(rc, "rulgnn_astgcnn_fwdbwd_syncbn_f32")

@@ -14,7 +14,7 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "librulgnn.so")
-SOURCES = ["sgemm.hip", "sgemm_planes.hip", "stgcn_forward.hip", "stgcn_forward_mx.hip", "stgcn_train.hip", "stgcn_train_mx.hip", "stgcn_train_mxw.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "rgcnu.hip", "stnet.hip", "sagcn.hip", "stagnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
+SOURCES = ["sgemm.hip", "sgemm_planes.hip", "peer_comm.hip", "stgcn_forward.hip", "stgcn_forward_mx.hip", "stgcn_train.hip", "stgcn_train_mx.hip", "stgcn_train_mxw.hip", "stgcn_tiled.hip", "stmsgcn.hip", "astgcnn.hip", "stconv.hip", "stgnn.hip", "rgcnu.hip", "stnet.hip", "sagcn.hip", "stagnn.hip", "fcstgnn.hip", "hagcn.hip", "bilstm.hip", "gru.hip", "metrics.hip", "optim.hip", "rulgnn_api.hip"]
 
 
 def _hipcc() -> str:

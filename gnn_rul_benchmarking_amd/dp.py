@@ -34,14 +34,85 @@ def shard_bounds(n: int, world_size: int, rank: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class PeerAllReduce:
+    """The synchronised-BatchNorm collectives as one-shot all-reduces over peer-mapped mailboxes (csrc/peer_comm.hip,
+    include/rulgnn.h "One-shot all-reduce ..."): one single-workgroup launch per collective on the compute stream, NO host callback
+    between the phases of a step -- through ``torch.distributed`` each of the 4 L collectives of a step is a ctypes -> Python -> RCCL
+    round trip (~50 us of a 350-us step).  Sums in rank order: bit-identical on every rank.
+
+    Set-up exchanges the mailboxes' IPC handles through ``torch.distributed`` (any backend); the ranks must be on one node with peer
+    access between their devices (or on one device).  An instance is passed to ``fused_mse_step_syncbn`` in place of the Python
+    all-reduce (``c_callback`` / ``c_user``: _lib.allreduce_callback) and is itself callable on a float64 device tensor."""
+
+    def __init__(self, process_group=None):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        self._lib, self._C = lib, C
+        self.rank, self.world_size = dist.get_rank(process_group), dist.get_world_size(process_group)
+        hb = lib.rulgnn_peer_handle_bytes()
+        handle = (C.c_ubyte * hb)()
+        self._box = C.c_void_p()
+        _lib.check(lib.rulgnn_peer_mailbox_alloc(C.byref(self._box), handle), "rulgnn_peer_mailbox_alloc")
+        handles = [None] * self.world_size
+        dist.all_gather_object(handles, bytes(handle), group=process_group)
+        ptrs = (C.c_void_p * self.world_size)()
+        self._opened = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs[r] = self._box.value
+                continue
+            peer = C.c_void_p()
+            _lib.check(lib.rulgnn_peer_mailbox_open((C.c_ubyte * hb).from_buffer_copy(h), C.byref(peer)), "rulgnn_peer_mailbox_open")
+            self._opened.append(peer)
+            ptrs[r] = peer.value
+        self.c_user = lib.rulgnn_peer_comm_create(self.rank, self.world_size, ptrs)
+        if not self.c_user:
+            raise RuntimeError("rulgnn_peer_comm_create failed")
+        self.c_callback = C.cast(lib.rulgnn_peer_allreduce_f64, C.c_void_p).value
+        dist.barrier(group=process_group)              # every mailbox is mapped everywhere before the first push
+
+    def __call__(self, cells: torch.Tensor) -> None:
+        from . import _lib
+        if cells.dtype != torch.float64 or not cells.is_cuda or not cells.is_contiguous():
+            raise RuntimeError("PeerAllReduce sums contiguous float64 device tensors")
+        st = self._C.c_void_p(torch.cuda.current_stream(cells.device).cuda_stream)
+        _lib.check(self._lib.rulgnn_peer_allreduce_f64(self.c_user, cells.data_ptr(), cells.numel(), st), "rulgnn_peer_allreduce_f64")
+
+    def collectives(self) -> int:
+        return int(self._lib.rulgnn_peer_comm_collectives(self.c_user))
+
+    def check(self) -> None:
+        """Raise if a collective of this rank gave up waiting for a peer (synchronises with the device)."""
+        e = int(self._lib.rulgnn_peer_comm_status(self.c_user))
+        if e != 0:
+            raise RuntimeError(f"one-shot all-reduce number {e} timed out waiting for a peer rank (the step's results are NaN)")
+
+    def close(self) -> None:
+        if getattr(self, "c_user", None):
+            torch.cuda.synchronize()
+            self._lib.rulgnn_peer_comm_destroy(self.c_user)
+            self.c_user = None
+            for p in self._opened:
+                self._lib.rulgnn_peer_mailbox_close(p)
+            self._lib.rulgnn_peer_mailbox_free(self._box)
+
+
 class DataParallel:
-    def __init__(self, process_group=None, sync_bn=False):
+    def __init__(self, process_group=None, sync_bn=False, bn_collective="group"):
+        """``bn_collective`` (with ``sync_bn=True``): "group" = every BatchNorm reduction through ``torch.distributed.all_reduce`` on the
+        process group (RCCL on GPUs: a host callback per collective), "peer" = the device-side one-shot all-reduce of ``PeerAllReduce``
+        (one node, peer access; no host work between the phases of a step)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if bn_collective not in ("group", "peer"):
+            raise ValueError("bn_collective is 'group' or 'peer'")
         self.group = process_group
         self.sync_bn = bool(sync_bn)
         self.rank = dist.get_rank(process_group)
         self.world_size = dist.get_world_size(process_group)
+        self.bn_collective = bn_collective
+        self.peer = PeerAllReduce(process_group) if (self.sync_bn and bn_collective == "peer") else None
 
     def broadcast_model(self, model) -> None:
         """Make every replica identical to rank 0 (parameters and BatchNorm statistics)."""
@@ -171,17 +242,17 @@ class DataParallel:
         # gradients.  A violation is raised AFTER this rank has joined every collective of the step with zeros -- raising here would
         # leave the other ranks waiting in theirs forever.
         violated = b == 0 and self.rank == 0 and global_batch > 0
+        reduce_cells = self.peer if self.peer is not None else (lambda cells: dist.all_reduce(cells, op=dist.ReduceOp.SUM, group=self.group))
         if b == 0:
             for n in schedule:
                 zero = torch.zeros(n, dtype=torch.float64, device=model.bucket.device)
-                dist.all_reduce(zero, op=dist.ReduceOp.SUM, group=self.group)
+                reduce_cells(zero)
             model.bucket.zero_()
             self._empty_shard_bookkeeping(model, global_batch)
         else:
             # the BatchNorm scale / shift gradients come out of the all-reduced cells, i.e. they are already the global sums on every
             # rank: rank 0 (never empty under shard_bounds) contributes them to the bucket, the others contribute zero
-            model.fused_mse_step_syncbn(X_shard, y_shard, global_batch, sample_offset, 1.0 if self.rank == 0 else 0.0,
-                                        lambda cells: dist.all_reduce(cells, op=dist.ReduceOp.SUM, group=self.group))
+            model.fused_mse_step_syncbn(X_shard, y_shard, global_batch, sample_offset, 1.0 if self.rank == 0 else 0.0, reduce_cells)
             # every rank holds the same global (mean, variance); weighted by the shard fraction they SUM to themselves over the
             # ranks, which also hands them to a rank whose shard was empty -- one bucket all-reduce as in the local-BN step
             tail = model.bucket[model.num_live + 1:model.num_live + 1 + model._bn_batch.numel()]

@@ -449,19 +449,9 @@ class ST_GCN_model(FlatModule):
         a = self._train_args(shp, x2d, yv, None, self._step, global_batch, sample_offset, False, whole_step=True)
         self._resolve_chain(shp, x2d)
         ws = self._ws
-        base, failure = ws.data_ptr(), []
-
-        def hook(_user, buf, count, _stream):
-            try:
-                off = int(buf) - base
-                allreduce(ws[off:off + 8 * int(count)].view(torch.float64))
-                return 0
-            except BaseException as e:          # never let an exception cross the C frame
-                failure.append(e)
-                return 1
-        cb = _lib.ALLREDUCE_F64_FN(hook)
+        cb, user, failure = _lib.allreduce_callback(allreduce, ws)
         # the launch form is the model's (step_path): after a guard trip retry_on_fp32_chain() must really land on the fp32 phases
-        rc = _lib.load().rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, None,
+        rc = _lib.load().rulgnn_stgcn_train_fwdbwd_syncbn_path_f32(C.byref(shp), C.byref(a), float(bn_param_grad_scale), cb, user,
                                                                    int(self.step_path), _stream())
         if failure:
             raise failure[0]

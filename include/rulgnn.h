@@ -781,6 +781,34 @@ int rulgnn_stagnn_backward_f32(const rulgnn_stagnn_shape *shape, const rulgnn_st
 int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stagnn_args *args, const rulgnn_adam_args *opt, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * One-shot all-reduce of up to RULGNN_PEER_MAX_COUNT doubles over peer-mapped mailboxes (round 6; csrc/peer_comm.hip): the
+ * synchronised-BatchNorm collectives of a data-parallel step (sum x, sum x^2 / sum dy, sum dy xhat per BatchNorm
+ * layer; the reference itself is single-process) as ONE single-workgroup launch each on the compute stream, no host work in between.
+ * rulgnn_peer_allreduce_f64 has the signature of rulgnn_allreduce_f64_fn: pass its address and the communicator as the
+ * (allreduce, user) pair of rulgnn_stgcn_train_fwdbwd_syncbn[_path]_f32 / rulgnn_fcstgnn_fwdbwd_syncbn_f32 /
+ * rulgnn_astgcnn_fwdbwd_syncbn_f32.  The result is the sum in RANK ORDER on every rank (bit-identical across ranks).
+ *
+ * Set-up (once per process; these calls allocate -- the only entries of this header that do): every rank allocates a mailbox
+ * (fine-grained device memory) and gets its IPC handle (rulgnn_peer_handle_bytes() bytes: hipIpcMemHandle_t), the ranks exchange the
+ * handles by whatever means they have (torch.distributed.all_gather_object in gnn_rul_benchmarking_amd/dp.py), open each other's
+ * mailboxes and build a communicator from the world's pointers (mailboxes[rank] = the own one).  Every rank must issue the same
+ * sequence of collectives.  A collective whose peers do not arrive within ~3 s leaves NaN in the buffer and a sticky error in the
+ * mailbox (rulgnn_peer_comm_status) instead of spinning forever.  Requires peer access between the devices (one node, xGMI or PCIe
+ * P2P) and HSA_ENABLE_IPC_MODE_LEGACY=0 on this image (dmabuf IPC). */
+#define RULGNN_PEER_MAX_COUNT 128
+size_t rulgnn_peer_mailbox_bytes(void);
+size_t rulgnn_peer_handle_bytes(void);
+int rulgnn_peer_mailbox_alloc(void **mailbox, void *handle_out);
+int rulgnn_peer_mailbox_open(const void *handle, void **mailbox);
+int rulgnn_peer_mailbox_close(void *mailbox);
+int rulgnn_peer_mailbox_free(void *mailbox);
+void *rulgnn_peer_comm_create(int32_t rank, int32_t world, void *const *mailboxes);
+void rulgnn_peer_comm_destroy(void *comm);
+int rulgnn_peer_allreduce_f64(void *comm, double *device_buf, int32_t count, void *stream);
+int64_t rulgnn_peer_comm_collectives(void *comm);
+int64_t rulgnn_peer_comm_status(void *comm);
+
+/* ------------------------------------------------------------------------------------------------
  * The fp32 matrix product behind every nn.Linear / torch.matmul / torch.bmm of the reference models that runs as a GEMM here
  * (e.g. models/SAGCN/Model.py:107-108, models/STNet/Model.py:31-38, models/ST_GCN/Model.py:88): C[m][n] (+)= sum_k A(m,k) B(n,k) with
  * element strides (A(m,k) = A[m * sAm + k * sAk], B(n,k) = B[n * sBn + k * sBk], C row stride ldc), exact fp32 on the matrix cores

@@ -43,7 +43,7 @@ def _data(cfg_shape, B, dev, label_scale=1.0):
     return X, y
 
 
-def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out, scale=1.0, sync_loss=True):
+def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out, scale=1.0, sync_loss=True, bn_collective="group"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,7 +52,7 @@ def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out,
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         algo = _make(family, cfg, dev)
-        dp = DataParallel(sync_bn=sync_bn)
+        dp = DataParallel(sync_bn=sync_bn, bn_collective=bn_collective)
         if overlap_min is not None:
             dp.OVERLAP_MIN_BYTES = overlap_min
         algo.attach_data_parallel(dp)
@@ -67,7 +67,11 @@ def _worker(rank, world, port, family, cfg, shape, B, sync_bn, overlap_min, out,
                      "bn": bn.detach().cpu().numpy() if bn is not None else np.zeros(1, np.float32),
                      "shard": hi - lo, "regions": getattr(dp, "last_overlap_regions", None),
                      "step_path": int(getattr(algo.model, "step_path", -1)),
-                     "trips": algo.model.guard_trips() if hasattr(algo.model, "guard_trips") else 0}
+                     "trips": algo.model.guard_trips() if hasattr(algo.model, "guard_trips") else 0,
+                     "peer_collectives": dp.peer.collectives() if dp.peer is not None else 0}
+        if dp.peer is not None:
+            dp.peer.check()
+            dp.peer.close()
     finally:
         dist.destroy_process_group()
 
@@ -295,3 +299,28 @@ def test_local_batchnorm_families_two_processes(family, B):
     """DDP's default (rank-local batch statistics, moments averaged for the running statistics) for the other two BatchNorm families."""
     r0, r1, ref = _run(_hp_case(family), B, False)
     _check(r0, r1, ref, 3e-4)
+
+
+# ---- device-side one-shot all-reduce of the BatchNorm cells (csrc/peer_comm.hip): no host callback between the phases of a step ----------
+def _run_peer(case, B):
+    family, cfg, shape = case
+    mgr = mp.Manager()
+    out_g, out_p = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), family, cfg, shape, B, True, None, out_g), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), family, cfg, shape, B, True, None, out_p, 1.0, True, "peer"), nprocs=2, join=True)
+    return out_g, out_p
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("case,B,collectives_per_step", [(STGCN_MX, 37, 8), (STGCN_MX, 1, 8), (STGCN_MXW40, 6, 8), (STGCN_FP32, 23, 8),
+                                                         (_hp_case("FC_STGNN"), 9, 14), (_hp_case("ASTGCNN"), 11, 4)])
+def test_peer_mailbox_all_reduce_equals_the_process_group_collectives(case, B, collectives_per_step):
+    """``DataParallel(sync_bn=True, bn_collective="peer")``: the 4 L (ST_GCN), 14 (FC_STGNN), 4 (ASTGCNN) BatchNorm reductions of a step
+    as single-workgroup launches over IPC-mapped mailboxes (two processes on one GPU here) -- BIT-equal to the same two-rank step through
+    the process group's all-reduce (two ranks: a + b in either order is the same double), replicas identical, an empty shard (B = 1) joins
+    with zeros, and no collective timed out."""
+    g, p = _run_peer(case, B)
+    for r in (0, 1):
+        assert np.array_equal(p[r]["flat"], g[r]["flat"]) and np.array_equal(p[r]["bn"], g[r]["bn"]) and p[r]["loss"] == g[r]["loss"]
+        assert p[r]["peer_collectives"] == 2 * collectives_per_step and g[r]["peer_collectives"] == 0
+    assert np.array_equal(p[0]["flat"], p[1]["flat"])
