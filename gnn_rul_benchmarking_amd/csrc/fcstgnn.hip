@@ -2121,7 +2121,11 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             // mapping, window graphs, the block's Linear and its BatchNorm statistics: one launch for both window blocks
             const unsigned wgs = (unsigned)((Gmax + FC_MX_WAVES - 1) / FC_MX_WAVES);
             auto go = [&](auto kernel) {
-                hipLaunchKernelGGL(kernel, dim3(wgs < 1024 ? wgs : 1024, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, run, cells, training,
+                // (one workgroup per CU and window block: 2 x 256 = the resident count, each wavefront walks ~4.5 graphs.  With a workgroup per four
+                // graphs -- 2304 workgroups, 4.5 rounds -- every wavefront paid the prologue (BatchNorm table, weights, a barrier) for ONE graph:
+                // FD004 batch 256 0.352 -> 0.336 ms with both graph kernels capped; 128: 0.373, 192: 0.343, 384: 0.343, 512: 0.340)
+                constexpr unsigned capf = 256u;
+                hipLaunchKernelGGL(kernel, dim3(wgs < capf ? wgs : capf, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, run, cells, training,
                                    (const float*)P_(w.F), Ptr2{{P_(w.Mm[0]), P_(w.Mm[1])}}, Ptr2{{P_(w.P[0]), P_(w.P[1])}},
                                    Ptr2{{P_(w.AX[0]), P_(w.AX[1])}}, Ptr2{{P_(w.z5[0]), P_(w.z5[1])}});
             };
@@ -2271,7 +2275,8 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
             if (graph_mx) {
                 const unsigned wgs = (unsigned)((Gmax + FC_MX_WAVES - 1) / FC_MX_WAVES);
                 auto go = [&](auto kernel) {
-                    hipLaunchKernelGGL(kernel, dim3(wgs < 4096 ? wgs : 4096, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, (const Cells*)cells,
+                    constexpr unsigned capb = 256u;                      // (as the forward block kernel: one workgroup per CU and window block)
+                    hipLaunchKernelGGL(kernel, dim3(wgs < capb ? wgs : capb, 2), dim3(64 * FC_MX_WAVES), 0, st, g, prm, (const Cells*)cells,
                                        (const float*)P_(w.F), CPtr2{{P_(w.Mm[0]), P_(w.Mm[1])}}, CPtr2{{P_(w.P[0]), P_(w.P[1])}},
                                        CPtr2{{P_(w.dz5[0]), P_(w.dz5[1])}}, Ptr2{{P_(w.dAX[0]), P_(w.dAX[1])}},
                                        Ptr2{{P_(w.dMb[0]), P_(w.dMb[1])}});
