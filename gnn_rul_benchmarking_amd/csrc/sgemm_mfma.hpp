@@ -26,7 +26,10 @@ int sgemm_planes_slices(int M, int N, int K, bool want_split);       // 0: this 
 bool sgemm_planes_ok(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, int M, int N, int K, int slices);
 int sgemm_planes(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int M, int N, int K,
                  bool accumulate, int slices, const float* amax_a, int amax_na, const float* amax_b, int amax_nb, void* ws, size_t ws_bytes,
-                 hipStream_t st);
+                 hipStream_t st, bool a_presplit = false);
+// operand A split by the kernel that PRODUCES it (no split pass, no fp32 copy): where it writes inside `ws` -- f16 planes [M][K], k
+// contiguous, hi = the top 11 significant bits of a s, lo = f16(a s - hi), s = *scale a power of two with max |a s| < 2^15
+void sgemm_planes_a_slots(void* ws, int M, int K, void** hi, void** lo, float** scale);
 // (amax_a / amax_b, both or neither: amax_na / amax_nb floats each whose maximum is max |A| / max |B| over the FINITE elements -- one partial
 // maximum per workgroup of the kernels that produced the operands.  With them, outputs that fill the 256 x 256 tiles run the two-plane f16
 // split (three matrix instructions per product instead of six; csrc/sgemm.hip: sgemm_f16x2v_kernel).)

@@ -346,9 +346,18 @@ bool sgemm_planes_ok(const float* A, int64_t sAm, int64_t sAk, const float* B, i
 }
 
 // C (slice z at C + z M ldc) (+)= the product, operands split into `ws` first.  The caller has checked sgemm_planes_ok.
+// where a producer that splits operand A itself writes: planes [M][K] (k contiguous) and the power of two it multiplied by
+void sgemm_planes_a_slots(void* ws, int M, int K, void** hi, void** lo, float** scale) {
+    unsigned char* w = static_cast<unsigned char*>(ws);
+    *scale = reinterpret_cast<float*>(w);
+    *hi = w + 1024;
+    *lo = w + 1024 + (size_t)M * K * sizeof(_Float16);
+}
+// (`a_presplit`: operand A already sits in `ws` as planes -- written by the kernel that produced it, sgemm_planes_a_slots -- and A /
+// amax_a are ignored)
 int sgemm_planes(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBn, int64_t sBk, float* C, int64_t ldc, int M, int N, int K,
                  bool accumulate, int slices, const float* amax_a, int amax_na, const float* amax_b, int amax_nb, void* ws, size_t ws_bytes,
-                 hipStream_t st) {
+                 hipStream_t st, bool a_presplit) {
     if (ws_bytes < sgemm_planes_ws_bytes(M, N, K)) return RULGNN_EWORKSPACE;
     unsigned char* w = static_cast<unsigned char*>(ws);
     float* scales = reinterpret_cast<float*>(w);
@@ -357,7 +366,7 @@ int sgemm_planes(const float* A, int64_t sAm, int64_t sAk, const float* B, int64
     _Float16* Bhi = Alo + (size_t)M * K;
     _Float16* Blo = Bhi + (size_t)N * K;
     (void)hipGetLastError();
-    int rc = pl_split_operand(A, sAm, sAk, M, K, amax_a, amax_na, Ahi, Alo, scales, st);
+    int rc = a_presplit ? RULGNN_OK : pl_split_operand(A, sAm, sAk, M, K, amax_a, amax_na, Ahi, Alo, scales, st);
     if (rc != RULGNN_OK) return rc;
     rc = pl_split_operand(B, sBn, sBk, N, K, amax_b, amax_nb, Bhi, Blo, scales + 64, st);
     if (rc != RULGNN_OK) return rc;

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void t_stats_lds_kernel(const float* __restric
 typedef float tg_f4 __attribute__((ext_vector_type(4)));
 // With `AX0`: the first layer's aggregation A.X0 of this sample right behind its adjacency (the rows are in L2 from the two passes above; it
 // was a launch of its own re-reading them), and the sample's max |A.X0| as its entry of the operand-scale row `amax0`.
+// With `amaxX`: the sample's max |X0| as its entry of the row the plane-writing aggregation takes its scale bound from.
 __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X0, float* __restrict__ A, TArgs a, float* __restrict__ AX0,
-                                                     float* __restrict__ amax0) {
+                                                     float* __restrict__ amax0, float* __restrict__ amaxX = nullptr) {
     __shared__ float red[F][4];
     __shared__ float As[F * F];
     __shared__ float mean[16];
@@ -83,17 +84,31 @@ __global__ __launch_bounds__(256) void t_gram_kernel(const float* __restrict__ X
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4, N = a.N;
     const float* xb = X0 + b * F * N;
     float s[F];
+    float mxx = 0.f;
 #pragma unroll
     for (int c = 0; c < F; ++c) s[c] = 0.f;
     for (int t = tid; t < N; t += 256)
 #pragma unroll
-        for (int c = 0; c < F; ++c) s[c] += xb[c * N + t];
+        for (int c = 0; c < F; ++c) {
+            const float xv = xb[c * N + t];
+            s[c] += xv;
+            const float ab = __builtin_fabsf(xv);
+            mxx = fmaxf(mxx, ab <= 3.0e38f ? ab : 0.f);
+        }
 #pragma unroll
     for (int c = 0; c < F; ++c) {
         float v = s[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) red[c][wave] = v;
+    }
+    if (amaxX) {                                                            // (uniform over the launch)
+        __shared__ float mxr[4];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64));
+        if (lane == 0) mxr[wave] = mxx;
+        __syncthreads();
+        if (tid == 0) amaxX[b] = fmaxf(fmaxf(mxr[0], mxr[1]), fmaxf(mxr[2], mxr[3]));
     }
     __syncthreads();
     if (tid < 16) mean[tid] = tid < F ? (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)N : 0.f;
@@ -230,6 +245,54 @@ __global__ __launch_bounds__(256) void t_aggregate_kernel(const float* __restric
     if (amax) t_amax_store(m, amax, l4);                            // (whole wavefronts: the lanes behind the last position carry 0)
 }
 
+// The same aggregation written straight as the GEMM's A operand: two f16 planes hi | lo of (A.X) s instead of fp32 (csrc/sgemm_planes.hip:
+// no split pass, no fp32 copy of A.X).  The scale must be known BEFORE the first value is written, and the tensor's largest element is not:
+// it comes from a BOUND -- |A.X| <= sum_c' |A[c][c']| |X[c']| <= 10 max |X| (Pearson entries lie in [-1, 1]; 16 covers their fp32
+// round-off), with max |X| left behind as partial maxima by the launch that produced X (`amaxX`, n_amax floats).  s puts 16 max |X| into
+// [2^11, 2^12): no element can leave the f16 range, and one within 2^-8 of the bound still has all 22 bits; smaller ones carry an absolute
+// error of 2^-25 / s, i.e. <= 2^-33 of max |X| (fp32's own epsilon relative to it: 2^-24).  NaN / Inf entries propagate through hi.
+__global__ __launch_bounds__(256) void t_aggregate_planes_kernel(const float* __restrict__ A, const float* __restrict__ in, _Float16* __restrict__ hi,
+                                                                 _Float16* __restrict__ lo, float* __restrict__ scale_out,
+                                                                 const float* __restrict__ amaxX, int n_amax, TArgs a) {
+    __shared__ float l4[4];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < n_amax; e += 256) m = fmaxf(m, amaxX[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) l4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = 16.0f * fmaxf(fmaxf(l4[0], l4[1]), fmaxf(l4[2], l4[3]));
+    float s = 1.0f;
+    {
+        const unsigned u = __builtin_bit_cast(unsigned, m);
+        const int ex = (int)((u >> 23) & 0xFFu);
+        if (m > 0.f && ex != 0 && ex != 255) {
+            int se = 127 + 11 - (ex - 127);
+            se = se < 1 ? 1 : (se > 254 ? 254 : se);
+            s = __builtin_bit_cast(float, (unsigned)se << 23);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B * a.N) return;
+    const int64_t b = i / a.N;
+    const int t = (int)(i % a.N);
+    const float* Ab = A + b * F * F;
+    float x[F];
+#pragma unroll
+    for (int c = 0; c < F; ++c) x[c] = in[(b * F + c) * a.N + t];
+#pragma unroll
+    for (int c = 0; c < F; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < F; ++q) acc = fmaf(Ab[c * F + q], x[q], acc);       // (same sums in the same order as t_aggregate_kernel)
+        const float v = acc * s;
+        const float hv = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0xFFFFE000u);
+        hi[(b * F + c) * a.N + t] = (_Float16)hv;
+        lo[(b * F + c) * a.N + t] = (_Float16)(v - hv);
+    }
+}
+
 // eval-mode TCN block of one layer after the theta GEMM (BatchNorm folded), Model.py:134-170,187-195:
 //   H = leaky(Hpre + bias[t]);  o0 = relu(relu(bn1(conv1(H))) + H);  o1 = relu(relu(bn2(conv2(o0))) + o0);  Xn = o1 + X
 // The causal taps need H at t-1 and o0 at t-2, t-3: recomputed from Hpre of the neighbours (cheap, no halo exchange).
@@ -275,11 +338,14 @@ __device__ __forceinline__ void t_o0_at(const float* __restrict__ Hpre, const fl
     for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z[c], sc1[c], sh1[c])) + H[c]);
 }
 
-__global__ void t_tcn_eval_kernel(const float* __restrict__ Hpre, const float* __restrict__ Xin, const float* __restrict__ prm_l,
-                                  const float* __restrict__ bnf, float* __restrict__ Xout, TArgs a) {
+// (amaxX: the workgroup's max |Xout| as its entry of the next layer's scale-bound row, or null; 256 threads, whole wavefronts)
+__global__ __launch_bounds__(256) void t_tcn_eval_kernel(const float* __restrict__ Hpre, const float* __restrict__ Xin, const float* __restrict__ prm_l,
+                                                         const float* __restrict__ bnf, float* __restrict__ Xout, TArgs a, float* __restrict__ amaxX) {
     // prm_l: this layer's parameters (flat layout); bnf: [2][2][F] folded scale/shift of this layer
+    __shared__ float l4[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * a.N) return;
+    float m = 0.f;
+    if (i < a.B * a.N) {
     const int64_t b = i / a.N;
     const int t = (int)(i % a.N), N = a.N;
     const float* tb = prm_l + off_theta_b(N);
@@ -292,8 +358,12 @@ __global__ void t_tcn_eval_kernel(const float* __restrict__ Hpre, const float* _
 #pragma unroll
     for (int c = 0; c < F; ++c) {
         const float o1 = relu(relu(fmaf(z[c], bnf[2 * F + c], bnf[3 * F + c])) + o0[c]);
-        Xout[(b * F + c) * N + t] = o1 + Xin[(b * F + c) * N + t];
+        const float xo = o1 + Xin[(b * F + c) * N + t];
+        Xout[(b * F + c) * N + t] = xo;
+        m = fmaxf(m, t_finite_abs(xo));
     }
+    }
+    if (amaxX) t_amax_store(m, amaxX, l4);                          // (uniform over the launch)
 }
 
 __global__ void t_bnfold_kernel(const float* __restrict__ prm, const float* __restrict__ bn, float* __restrict__ bnf, int N, int L) {
@@ -367,7 +437,7 @@ size_t stgcn_tiled_forward_workspace_bytes(const rulgnn_stgcn_shape* s) {
     const size_t sk = t_eval_split_floats(s->num_patch, s->batch);
     // (+ the pre-split operand planes of the theta products, csrc/sgemm_planes.hip)
     return t_plane_bytes(s->num_patch, R, false) + 4 * al256(T) + al256((size_t)s->batch * F * F * 4) + 2 * al256((size_t)s->batch * s->num_patch * 4) +
-           al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(1 + s->num_layers) * T_AMAX_MAX * sizeof(float)) + al256(sk * sizeof(float));
+           al256((size_t)s->num_layers * 4 * F * 4) + al256((size_t)(2 + s->num_layers) * T_AMAX_MAX * sizeof(float)) + al256(sk * sizeof(float));
 }
 
 // (persistent kernels: at most T_PGRID workgroups)
@@ -407,7 +477,8 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
     float* pooled = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* y1pre = reinterpret_cast<float*>(w); w += al256((size_t)B * N * 4);
     float* bnf = reinterpret_cast<float*>(w); w += al256((size_t)L * 4 * F * 4);
-    float* amax = reinterpret_cast<float*>(w); w += al256((size_t)(1 + L) * T_AMAX_MAX * sizeof(float));   // A.X of the current layer, theta of every layer
+    float* amax = reinterpret_cast<float*>(w); w += al256((size_t)(2 + L) * T_AMAX_MAX * sizeof(float));   // A.X of the current layer, theta of every layer, X of the current layer
+    float* amaxX = amax + (size_t)(1 + L) * T_AMAX_MAX;
     float* split = reinterpret_cast<float*>(w); w += al256(t_eval_split_floats(N, B) * sizeof(float));
     const size_t plane_bytes = t_plane_bytes(N, B * F, false);
     void* planes = plane_bytes ? static_cast<void*>(w) : nullptr;
@@ -422,16 +493,35 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
                            amax + T_AMAX_MAX, (double*)nullptr, 0);
         if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     }
+    // theta(A.X) on pre-split operands with the A planes written by the aggregation itself (t_aggregate_planes_kernel: no split pass, no
+    // fp32 A.X; XJTU-SY batch 1024: 2 x (22 + 17) us of aggregation + split pass become 2 x ~25): needs max |X_l| from the launch in front
+    const bool fused_planes = planes && scaled && !few_rows && B <= T_AMAX_MAX && sgemm_big_mode() == 1 &&
+                              sgemm_planes_slices((int)(B * F), N, N, false) == 1 &&
+                              sgemm_planes_ok(AX, N, 1, prm + off_theta_w(N), N, 1, (int)(B * F), N, N, 1);
     T_STATS(x, Xa);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(t_gram_kernel, dim3((unsigned)B), dim3(256), 0, stream, Xa, A, a, (float*)nullptr, (float*)nullptr,
+                       fused_planes ? amaxX : (float*)nullptr);
     if (hipGetLastError() != hipSuccess) return RULGNN_EHIP;
     float* Xin = Xa;
     float* Xout = Xb;
     for (int l = 0; l < L; ++l) {
         const float* pl = prm + l * LS;
-        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, scaled ? amax : (float*)nullptr);
         int rc;                                                                                  // (A.X) theta^T
+        if (fused_planes) {
+            void *ph, *plo;
+            float* psc;
+            sgemm_planes_a_slots(planes, (int)(B * F), N, &ph, &plo, &psc);
+            T_LAUNCH(t_aggregate_planes_kernel, BN_, A, Xin, static_cast<_Float16*>(ph), static_cast<_Float16*>(plo), psc, (const float*)amaxX,
+                     l == 0 ? (int)B : n_pos, a);
+            rc = sgemm_planes(nullptr, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, 1, nullptr, 0,
+                              amax + (size_t)(1 + l) * T_AMAX_MAX, n_th, planes, plane_bytes, stream, true);
+            if (rc != RULGNN_OK) return rc;
+            T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, l + 1 < L ? amaxX : (float*)nullptr);
+            float* tmp = Xin; Xin = Xout; Xout = tmp;
+            continue;
+        }
+        T_LAUNCH(t_aggregate_kernel, BN_, A, Xin, (const float*)nullptr, AX, a, scaled ? amax : (float*)nullptr);
         if (few_rows)
             rc = sgemm_splitk(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, split, stream, scaled ? amax : (float*)nullptr,
                               n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th);
@@ -439,7 +529,7 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
             rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
                        n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th, planes, plane_bytes);
         if (rc != RULGNN_OK) return rc;
-        T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a);
+        T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, (float*)nullptr);
         float* tmp = Xin; Xin = Xout; Xout = tmp;
     }
     T_LAUNCH(t_pool_kernel, BN_, Xin, pooled, a);

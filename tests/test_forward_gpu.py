@@ -73,3 +73,25 @@ def test_forward_rejects_unsupported():
     assert rc == -3          # tiled path without its workspace
     shp = G.shape_struct(4, 14, 30)
     assert lib.rulgnn_stgcn_forward_f32(C.byref(shp), None, t.data_ptr(), t.data_ptr(), t.data_ptr(), None, 0, G.stream_ptr()) == -1
+
+
+def test_tiled_forward_with_plane_writing_aggregation_agrees_with_the_split_pass_form_and_places_nan_alike():
+    """XJTU-SY 1024 x 32 at batch 512 (5 120 rows: the pre-split product kernel with the A planes written by the aggregation itself,
+    scale from the bound 16 max |X|) against the same windows run as two batches of 256 (too few tiles: the in-loop split of round 5):
+    same function to 1e-4, and a window with a constant patch -- NaN statistics, models/ST_GCN/Model.py:7-52 -- gives NaN for exactly
+    that sample in both."""
+    import gpu_util as G
+    N, P, B = 1024, 32, 512
+    rng = np.random.default_rng(99)
+    prm = O.random_params(N, 2, seed=4)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    x[7, 100, :] = 0.25                                           # a constant patch
+    x[300] *= 40.0                                                # one window far above the others (the scale bound follows it)
+    flat, bn = PL.pack_numpy(prm, N, 2)
+    fused = G.abi_forward(x, flat, bn, N, P)
+    halves = np.concatenate([G.abi_forward(x[:256], flat, bn, N, P), G.abi_forward(x[256:], flat, bn, N, P)])
+    assert np.isnan(fused[7]) and np.isnan(halves[7])
+    ok = np.ones(B, bool); ok[7] = False
+    assert np.isfinite(fused[ok]).all() and np.isfinite(halves[ok]).all()
+    assert G.rel_err(fused[ok], halves[ok]) < TOL
+    assert G.elem_gate(fused[ok], halves[ok], rtol=1e-4, floor=1e-5) <= 1.0
