@@ -357,7 +357,7 @@ def main():
             r = d["roofline"]
             fams[fam] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
                          "workload": d["config"]["workload"], "per_gpu_batch": d["config"]["per_gpu_batch"], "final_loss": d["final_loss"],
-                         "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "peak_basis", "unit", "frac", "traffic", "us_per_launch", "launches_per_step",
+                         "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "peak_basis", "mfma_util", "unit", "frac", "traffic", "us_per_launch", "launches_per_step",
                                                          "launches_in_step", "step_kernel_time_us", "share_of_step_kernel_time", "whole_step_estimate",
                                                          "work_model") if k in r},
                          "cpu_baseline": {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "port_of", "sample", "runs") if k in d["cpu_baseline"]} if "cpu_baseline" in d else None}

@@ -14,7 +14,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-from .common import FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, F16X2_SPLIT_PEAK_TFLOPS, HBM_PEAK_GBS, kernel_short_name, kernel_times
+from .common import (FP32_MFMA_PEAK_TFLOPS, BF16_MFMA_PEAK_TFLOPS, F16X2_SPLIT_PEAK_TFLOPS, HBM_PEAK_GBS, kernel_short_name, kernel_times,
+                     mfma_util_from_profile)
 from .cpu import family_cpu_baseline
 
 
@@ -267,6 +268,9 @@ def family_line(args, family, world, rank, dev, use_dist, dist, batch=None, cpu_
             roof.update({"achieved": round(ach, 4), "peak": peak, "frac": round(ach / peak, 5), "flops_per_launch": round(work), "work_model": how})
             if generic_above:
                 roof["generic_gemm_instances_with_larger_share"] = generic_above
+            mu = mfma_util_from_profile(short.split("<")[0]) if args.dtype == "f32" else None
+            if mu:
+                roof["mfma_util"] = mu
         else:
             roof.update({"achieved": whole["achieved"], "frac": whole["frac"],
                          "work_model": "no per-kernel FLOP model for this kernel (a generic GEMM serving several shapes): the whole-step estimate is quoted"})
