@@ -936,3 +936,27 @@ def test_a_test_set_that_cannot_be_sharded_is_walked_whole_on_every_rank(drop_la
         assert not whole.shard_samples and whole.n == n and [b[0].shape[0] for b in whole] == [4, 4, 3]
         _, sharded, _ = data_generator(str(tmp_path), cfg, {"batch_size": bs}, "cpu", rank, 2)
         assert sharded.shard_samples and sharded.n in (5, 6)
+
+
+def test_data_parallel_options_are_validated_and_the_peer_collective_is_opt_in(tmp_path):
+    """``DataParallel(bn_collective=...)``: only "group" (default: every collective through torch.distributed) and "peer" (the device-side
+    one-shot all-reduce of csrc/peer_comm.hip, built only together with ``sync_bn=True``); anything else raises before any collective;
+    the C entry that the "peer" form hands to the library has the callback's signature and rejects bad arguments without a GPU."""
+    import ctypes as C
+    from gnn_rul_benchmarking_amd import _lib
+    from gnn_rul_benchmarking_amd.dp import DataParallel
+    store = str(tmp_path / "store")
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=0, world_size=1)
+    try:
+        with pytest.raises(ValueError):
+            DataParallel(bn_collective="ring")
+        assert DataParallel().peer is None and DataParallel(sync_bn=True).peer is None          # "group" never touches the mailboxes
+        assert DataParallel(sync_bn=False, bn_collective="peer").peer is None                   # ... nor does "peer" without sync_bn
+    finally:
+        dist.destroy_process_group()
+    lib = _lib.load()
+    assert lib.rulgnn_peer_handle_bytes() == 64 and lib.rulgnn_peer_mailbox_bytes() > 2 * 8 * 128 * 8
+    assert lib.rulgnn_peer_comm_create(0, 9, (C.c_void_p * 9)()) is None                           # world beyond 8
+    assert lib.rulgnn_peer_comm_create(0, 2, (C.c_void_p * 2)()) is None                           # null mailboxes
+    assert lib.rulgnn_peer_allreduce_f64(None, None, 4, None) == _lib.EINVAL
+    assert lib.rulgnn_peer_comm_collectives(None) == -1
