@@ -383,6 +383,9 @@ def main():
         # (after the family lines: the torch-CPU halves of these legs leave the host's thread pool warm and spinning, which the
         # launch-bound FC_STGNN step right behind them paid for with 1.4 instead of 0.43 ms)
         line_out["rmse"] = rmse_teacher_task(dev)
+        # ... and with dropout ON (the reference's protocol trains with dropout 0.2: configs/hparams.py), both paths under the same masks
+        rd = rmse_teacher_task(dev, epochs=10, checkpoints=(36, 120), dropout=0.2)
+        line_out["rmse"]["with_dropout"] = {k: rd[k] for k in ("task", "rmse_hip", "rmse_torch_cpu", "abs_diff", "within_1e-3", "after_steps", "steps")}
         line_out["rmse"]["bn_free_family"] = rmse_teacher_task_stmsgcn(dev)
     if rank == 0:
         line = json.dumps(line_out)

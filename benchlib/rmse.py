@@ -17,16 +17,19 @@ if ROOT not in sys.path:
 from .common import NUM_PATCH
 
 
-def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, max_rul=125.0, checkpoints=(36, 120, 240)):
+def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, max_rul=125.0, checkpoints=(36, 120, 240), dropout=0.0):
     """The RMSE half of BASELINE.json's metric on SURVEY section 8(d)'s synthetic task: a fixed random "teacher" ST_GCN (14 x 30, eval
     mode) labels ~49 k uniform windows (about FD004's training-set size); a student with another initialisation is trained for `epochs`
     passes in batches of `batch`, dropout off, (a) on the HIP path (ST_GCN.update) and (b) by the torch-CPU restatement of the reference's
-    update (oracle/stgcn_torch_cpu.py) from the SAME initial weights on the same batches; both are scored on held-out windows with
+    update (oracle/stgcn_torch_cpu.py) from the SAME initial weights on the same batches -- with ``dropout`` > 0 both under the SAME
+    dropout masks (the HIP path's counter hash, imposed on the restatement: the reference's CPU Bernoulli stream cannot be matched by
+    any GPU path); both are scored on held-out windows with
     the reference's formula RMSE = sqrt(mean((pred - y)^2)) * max_rul (utils.py:148-151) after 36, 120 and 240 optimizer steps (drift
     shows as a growing difference).  The north star asks |RMSE_hip - RMSE_cpu| <= 1e-3."""
     from gnn_rul_benchmarking_amd.algorithms import ST_GCN
     from gnn_rul_benchmarking_amd.stgcn import ST_GCN_model
     from oracle import stgcn_torch_cpu as T
+    from oracle import stgcn_oracle as O
     N, P = NUM_PATCH, 30
     g = torch.Generator(device="cpu").manual_seed(4242)
     Xtr, Xte = torch.rand(n_train, N, P, generator=g), torch.rand(n_test, N, P, generator=g)
@@ -35,7 +38,7 @@ def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, ma
     with torch.no_grad():
         ytr, yte = teacher(Xtr.to(dev)).cpu(), teacher(Xte.to(dev)).cpu()
     torch.manual_seed(7)
-    algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=0.0), {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
+    algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=dropout), {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
     algo.to(dev)
     init = {k: v.detach().cpu().numpy().copy() for k, v in algo.state_dict().items()}
     st = T.State(init, num_layers=2, lr=1e-3, weight_decay=1e-4)
@@ -48,13 +51,18 @@ def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, ma
     step, marks = 0, []
     for _ in range(epochs):
         for lo in range(0, n_train, batch):
+            masks = None
+            if dropout > 0.0:        # the masks the kernels are about to use: a function of (seed, step, layer, element) alone
+                nb = min(batch, n_train - lo)
+                masks = [torch.from_numpy(O.dropout_keep_mask(nb, N, O.dropout_layer_key(algo.model._seed, algo.model._step + 1, l), dropout))
+                         for l in range(2)]
             t0 = time.perf_counter()
             algo.train()
             hip_loss = algo.update(Xd[lo:lo + batch], yd[lo:lo + batch], 1)["loss"]
             t_hip += time.perf_counter() - t0
             t0 = time.perf_counter()
             torch.set_num_threads(min(16, os.cpu_count() or 1))
-            cpu_loss = T.update(st, Xtr[lo:lo + batch], ytr[lo:lo + batch], N, P, 0.0)
+            cpu_loss = T.update(st, Xtr[lo:lo + batch], ytr[lo:lo + batch], N, P, dropout, masks)
             t_cpu += time.perf_counter() - t0
             step += 1
             if step in checkpoints:
@@ -68,7 +76,8 @@ def rmse_teacher_task(dev, epochs=20, n_train=49152, n_test=8192, batch=4096, ma
     torch.set_num_threads(threads)
     base = float(torch.sqrt(torch.mean((yt.mean() - yt) ** 2)) * max_rul)
     last = marks[-1]
-    return {"task": f"teacher ST_GCN({N}, {P}) labels {n_train} uniform windows; student trained {epochs} epochs, batch {batch}, dropout off, "
+    return {"task": f"teacher ST_GCN({N}, {P}) labels {n_train} uniform windows; student trained {epochs} epochs, batch {batch}, "
+                    + (f"dropout {dropout} (the same masks on both paths), " if dropout > 0 else "dropout off, ") +
                     f"Adam lr 1e-3 wd 1e-4; scored on {n_test} held-out windows, RMSE x max_rul {max_rul:g} (reference utils.py:148-151)",
             "rmse_hip": last["rmse_hip"], "rmse_torch_cpu": last["rmse_torch_cpu"], "abs_diff": last["abs_diff"],
             "within_1e-3": bool(all(m["abs_diff"] <= 1e-3 for m in marks)), "after_steps": marks, "rmse_of_predicting_the_mean": round(base, 4),

@@ -77,7 +77,11 @@ def _tcn_block(h, w, gamma, beta, rmean, rvar, dil, train):
     return torch.relu(Fn.batch_norm(z, rmean, rvar, gamma, beta, train, 0.1, 1e-5))
 
 
-def forward(st: State, x: torch.Tensor, num_patch: int, patch_size: int, train: bool, dropout: float = 0.0) -> torch.Tensor:
+def forward(st: State, x: torch.Tensor, num_patch: int, patch_size: int, train: bool, dropout: float = 0.0, keep_masks=None) -> torch.Tensor:
+    """``keep_masks`` (train mode, one bool / float tensor [B, 10, num_patch] per layer): the dropout masks IMPOSED instead of drawn from
+    torch's generator -- nn.Dropout's arithmetic (kept elements x 1 / (1 - p)) on the masks of the HIP path's counter hash
+    (oracle/stgcn_oracle.py: dropout_keep_mask), so that the two paths train the same function with dropout ON (torch's CPU Bernoulli
+    stream cannot be reproduced by any GPU path)."""
     B = x.shape[0]
     feat = patch_statistics(x.reshape(B, num_patch, patch_size))
     adj = pearson(feat)
@@ -91,15 +95,18 @@ def forward(st: State, x: torch.Tensor, num_patch: int, patch_size: int, train: 
         q = f"{p}.1.conv_block2"
         o1 = torch.relu(_tcn_block(o0, st.p[f"{q}.0.weight"], st.p[f"{q}.2.weight"], st.p[f"{q}.2.bias"],
                                    st.buf[f"{q}.2.running_mean"], st.buf[f"{q}.2.running_var"], 2, train) + o0)
-        X = Fn.dropout(o1, dropout, train) + X
+        if keep_masks is not None and train and dropout > 0.0:
+            X = o1 * (keep_masks[l].to(o1.dtype) * (1.0 / (1.0 - dropout))) + X
+        else:
+            X = Fn.dropout(o1, dropout, train) + X
     pooled = X.amax(dim=1) if not train else X.max(dim=1).values       # max over the ten statistic channels
     y1 = torch.relu(Fn.linear(pooled, st.p["fc1.weight"], st.p["fc1.bias"]))
     return Fn.linear(y1, st.p["fc2.weight"], st.p["fc2.bias"])
 
 
-def update(st: State, x: torch.Tensor, y: torch.Tensor, num_patch: int, patch_size: int, dropout: float = 0.0) -> float:
+def update(st: State, x: torch.Tensor, y: torch.Tensor, num_patch: int, patch_size: int, dropout: float = 0.0, keep_masks=None) -> float:
     """One training step; returns the loss like the reference's ``{'loss': loss.item()}``."""
-    pred = forward(st, x, num_patch, patch_size, True, dropout)
+    pred = forward(st, x, num_patch, patch_size, True, dropout, keep_masks)
     loss = Fn.mse_loss(pred, y.reshape(pred.shape))
     st.opt.zero_grad()
     loss.backward()

@@ -18,6 +18,16 @@ def test_teacher_task_rmse_within_1e_3_of_the_torch_cpu_restatement():
     assert abs(r["final_train_loss_hip"] - r["final_train_loss_torch_cpu"]) <= 1e-4 * abs(r["final_train_loss_torch_cpu"]) + 1e-7, r
 
 
+def test_teacher_task_rmse_with_dropout_on_under_the_same_masks():
+    """The same experiment with dropout 0.2 (the reference's protocol trains with dropout): both paths under the SAME masks -- the HIP
+    path's counter hash imposed on the torch-CPU restatement (tests/test_torch_cpu_baseline.py pins that form to the fp64 oracle)."""
+    import bench
+    r = bench.rmse_teacher_task(torch.device("cuda:0"), epochs=2, n_train=16384, n_test=4096, batch=2048, checkpoints=(4, 16), dropout=0.2)
+    assert "dropout 0.2" in r["task"] and r["steps"] == 16 and r["within_1e-3"]
+    assert r["abs_diff"] <= 1e-3, r
+    assert abs(r["final_train_loss_hip"] - r["final_train_loss_torch_cpu"]) <= 1e-4 * abs(r["final_train_loss_torch_cpu"]) + 1e-7, r
+
+
 def test_bn_free_family_teacher_task_tracks_the_torch_cpu_restatement():
     """STMSGCN (no BatchNorm, no dropout) at the reference's PHM2012 wiring and protocol batch: HIP path vs the torch-CPU restatement of the
     reference's update from the same weights on the same batches; the held-out RMSE stays within 1e-3 relative at every checkpoint."""
