@@ -13,6 +13,7 @@
 // adjacency / softmax / aggregation in LDS, the rest is elementwise.  Seven BatchNorms cut the step into phases; batch
 // statistics go through fp64 reduction cells in stream order.  BatchNorms on the unfolded windows are computed on the
 // rows with multiplicity weights (how many windows contain a patch).
+#include "adam_device.hpp"
 #include "async_mem.hpp"
 #include "aux_stream.hpp"
 #include "sgemm_mfma.hpp"
@@ -1825,11 +1826,26 @@ __global__ void fc_cells_collapse_kernel(Cells* cells, int bwd, int id) {
 
 // conv partial rows -> gradients; BatchNorm gamma / beta gradients from the cells (x bn_scale: under synchronised BatchNorm the
 // cells hold GLOBAL sums on every rank and only one rank may contribute them to the all-reduced gradient)
+// (`fuse.p` != nullptr: the thread that finalises a gradient element applies Adam to that parameter on the spot, and the workgroups from
+// `nfin` on apply it to every parameter whose gradient was final before this launch -- the GEMM-produced ones; the launch then sits behind
+// the join with the side stream and the step has no optimizer launch)
 __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* __restrict__ gp1, const float* __restrict__ gp2, int rows,
-                                                        const Cells* cells, float* __restrict__ grads, float bn_scale) {
+                                                        const Cells* cells, float* __restrict__ grads, float bn_scale, AdamFuse fuse, int nfin) {
+    const int n1 = g.H1 * g.K, n2 = g.CO * g.H1 * g.K;
+    if ((int)blockIdx.x >= nfin) {
+        // parameters this launch does not finalise itself: everything but the two convolution weights and the BatchNorm scales / shifts
+        const int stride = ((int)gridDim.x - nfin) * FB;
+        for (int i = ((int)blockIdx.x - nfin) * FB + threadIdx.x; i < g.nparam; i += stride) {
+            bool mine = (i >= g.o_w1 && i < g.o_w1 + n1) || (i >= g.o_w2 && i < g.o_w2 + n2);
+#pragma unroll
+            for (int id = 0; id < NBN; ++id)
+                mine = mine || (i >= g.bn_g[id] && i < g.bn_g[id] + g.bn_ch[id]) || (i >= g.bn_b[id] && i < g.bn_b[id] + g.bn_ch[id]);
+            if (!mine) fuse(grads + i, grads[i]);
+        }
+        return;
+    }
     // one wavefront per value: lanes stride over the partial rows, then a fixed-order butterfly (deterministic)
     const int e = (blockIdx.x * FB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int n1 = g.H1 * g.K, n2 = g.CO * g.H1 * g.K;
     if (e < n1 + n2) {
         const float* src = e < n1 ? gp1 + e : gp2 + (e - n1);
         const int n = e < n1 ? n1 : n2;
@@ -1837,13 +1853,20 @@ __global__ __launch_bounds__(FB) void fc_finalize_kernel(FcGeom g, const float* 
         for (int r = lane; r < rows; r += 64) a += src[(int64_t)r * n];
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
-        if (lane == 0) grads[(e < n1 ? g.o_w1 + e : g.o_w2 + (e - n1))] = a;
+        if (lane == 0) {
+            float* dst = grads + (e < n1 ? g.o_w1 + e : g.o_w2 + (e - n1));
+            *dst = a;
+            fuse(dst, a);
+        }
     } else if (lane == 0) {
         int c = e - n1 - n2;
         for (int id = 0; id < NBN; ++id) {
             if (c < g.bn_ch[id]) {
-                grads[g.bn_g[id] + c] = bn_scale * (float)cell_bwd(cells, id, c, 1);
-                grads[g.bn_b[id] + c] = bn_scale * (float)cell_bwd(cells, id, c, 0);
+                const float gg = bn_scale * (float)cell_bwd(cells, id, c, 1), gb = bn_scale * (float)cell_bwd(cells, id, c, 0);
+                grads[g.bn_g[id] + c] = gg;
+                grads[g.bn_b[id] + c] = gb;
+                fuse(grads + g.bn_g[id] + c, gg);
+                fuse(grads + g.bn_b[id] + c, gb);
                 return;
             }
             c -= g.bn_ch[id];
@@ -2025,7 +2048,7 @@ size_t fcstgnn_workspace_bytes(const rulgnn_fcstgnn_shape* s) {
 
 // mode bit 0: forward (args->training selects batch / running statistics), bit 1: backward
 int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t st, const FcstgnnSync* sync, float* bn_running_out,
-                float bn_momentum) {
+                float bn_momentum, const AdamFuse* fuse) {
     FcGeom g;
     FC_RC(fc_geometry(s, &g));
     if (sync) {
@@ -2353,9 +2376,16 @@ int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int
                                (const float*)P_(w.z1), (const float*)P_(w.z2), (const float*)P_(w.dy1), (const float*)P_(w.da2), P_(w.gp1), P_(w.gp2));
         int nbn = 0;
         for (int i = 0; i < NBN; ++i) nbn += g.bn_ch[i];
-        // (reads the convolutions' partial rows and the cells only: in front of the join, beside whatever the side stream still runs)
-        hipLaunchKernelGGL(fc_finalize_kernel, dim3((g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4), dim3(FB), 0, st, g,
-                           (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f);
+        // (reads the convolutions' partial rows and the cells only: in front of the join, beside whatever the side stream still runs --
+        // unless it also applies the optimizer: then every gradient must be final, and it is the step's last launch behind the join)
+        const int nfin = (g.H1 * g.K + g.CO * g.H1 * g.K + nbn + 3) / 4;
+        const bool with_adam = fuse && fuse->p && !sync;
+        AdamFuse none{};
+        none.p = nullptr;
+        if (with_adam) FC_RC(fk.join());
+        hipLaunchKernelGGL(fc_finalize_kernel, dim3(nfin + (with_adam ? (g.nparam + FB - 1) / FB : 0)), dim3(FB), 0, st, g,
+                           (const float*)P_(w.gp1), (const float*)P_(w.gp2), rows, (const Cells*)cells, gr, sync ? sync->bn_param_grad_scale : 1.0f,
+                           with_adam ? *fuse : none, nfin);
         FC_RC(fk.join());                                    // the gradient GEMMs are done when the call's work has drained
     }
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;

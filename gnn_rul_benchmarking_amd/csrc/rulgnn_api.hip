@@ -547,10 +547,18 @@ int rulgnn_fcstgnn_fwdbwd_f32(const rulgnn_fcstgnn_shape* shape, const rulgnn_fc
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tail_bn = opt && opt->bn_stats && args->training && args->bn_moment_weight == 0.f;
-    rc = fcstgnn_run(shape, args, 3, st, nullptr, tail_bn ? opt->bn_stats : nullptr, tail_bn ? opt->bn_momentum : 0.f);
+    // (host-side step count: the step's last kernel applies the optimizer itself -- adam_device.hpp; a device step state keeps the launch)
+    AdamFuse fuse{};
+    fuse.p = nullptr;
+    const bool fused_adam = opt && !opt->step_state && opt->step >= 1;
+    if (fused_adam)
+        adam_fuse_args(&fuse, opt->params, opt->exp_avg, opt->exp_avg_sq, args->grads, opt->step, opt->lr, opt->beta1, opt->beta2, opt->eps,
+                       opt->weight_decay);
+    rc = fcstgnn_run(shape, args, 3, st, nullptr, tail_bn ? opt->bn_stats : nullptr, tail_bn ? opt->bn_momentum : 0.f, fused_adam ? &fuse : nullptr);
     if (rc != RULGNN_OK || !opt) return rc;
-    rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, fcstgnn_param_count(shape), opt->step, opt->lr,
-                   opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
+    if (!fused_adam)
+        rc = adam_step(opt->params, args->grads, opt->exp_avg, opt->exp_avg_sq, fcstgnn_param_count(shape), opt->step, opt->lr,
+                       opt->beta1, opt->beta2, opt->eps, opt->weight_decay, 1.0f, st, opt->step_state);
     if (rc != RULGNN_OK || !opt->bn_stats || tail_bn) return rc;
     return fcstgnn_bn_running_update(shape, opt->bn_stats, args->bn_batch, opt->bn_momentum, args->bn_moment_weight > 0.f ? 1 : 0, st);
 }

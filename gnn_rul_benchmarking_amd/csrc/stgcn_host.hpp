@@ -160,8 +160,11 @@ struct BnSyncHook {
 typedef BnSyncHook FcstgnnSync;
 // (`bn_running_out` != nullptr, whole training steps with plain batch statistics: the running-statistics update rides on the side stream
 // behind the batch-statistics kernel instead of closing the step)
+// (`fuse` != nullptr, whole training steps on one rank: the step's last launch -- the finalize kernel, then behind the join with the side
+// stream -- applies torch.optim.Adam to every parameter: adam_device.hpp; no optimizer launch)
+struct AdamFuse;
 int fcstgnn_run(const rulgnn_fcstgnn_shape* s, const rulgnn_fcstgnn_args* a, int mode, hipStream_t stream, const FcstgnnSync* sync = nullptr,
-                float* bn_running_out = nullptr, float bn_momentum = 0.f);
+                float* bn_running_out = nullptr, float bn_momentum = 0.f, const AdamFuse* fuse = nullptr);
 int fcstgnn_bn_running_update(const rulgnn_fcstgnn_shape* s, float* bn_stats, const float* bn_batch, float momentum, int from_moments,
                               hipStream_t stream);
 int64_t hagcn_graph_param_count(const rulgnn_hagcn_shape* s);
