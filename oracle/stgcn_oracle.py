@@ -16,7 +16,7 @@ container by ``tests/golden/make_golden.py`` and committed as ``tests/golden/*.n
 Reference map (paths relative to the reference repo root):
   patch_statistics      <- models/ST_GCN/Model.py:7-52   (segment_and_compute_features, skew, kurtosis)
   pearson_adjacency     <- models/ST_GCN/Model.py:53-71  (pcc_graph_construction)
-  _mpnn / layer fwd     <- models/ST_GCN/Model.py:74-90  (MPNN_mk, k=1), :99-173 (TemporalConvNet,
+  _mpnn / layer fwd     <- models/ST_GCN/Model.py:74-90  (MPNN_mk, any order k), :99-173 (TemporalConvNet,
                            only conv_block1/conv_block2 are live), :176-195 (SG_TCN)
   forward               <- models/ST_GCN/Model.py:197-222 (ST_GCN_model.forward)
   mse_train_step        <- algorithms/algorithms.py:481-490 (ST_GCN.update: MSE, backward, Adam)
@@ -40,15 +40,24 @@ BN_MOMENTUM = 0.1
 # ----------------------------------------------------------------------------------------
 # parameter bookkeeping
 # ----------------------------------------------------------------------------------------
-def live_param_names(num_layers: int) -> list[str]:
+def mpnn_order(prm: dict) -> int:
+    """MPNN order k of a parameter dictionary: the number of theta.<kk> Linear layers of layer 0 (Model.py:77)."""
+    k = 0
+    while f"sg_tcn.layers.0.0.theta.{k}.weight" in prm:
+        k += 1
+    return k
+
+
+def live_param_names(num_layers: int, k: int = 1) -> list[str]:
     """Names (reference state_dict keys without the ``model.`` prefix) of the parameters that
     receive gradients, in the flat-buffer order used by the HIP path.  ``net0``/``net1`` are
     constructed by the reference but never called (Model.py:110-131), so they are not live."""
     names = []
     for l in range(num_layers):
         p = f"sg_tcn.layers.{l}"
-        names += [f"{p}.0.theta.0.weight", f"{p}.0.theta.0.bias",
-                  f"{p}.1.conv_block1.0.weight", f"{p}.1.conv_block1.2.weight", f"{p}.1.conv_block1.2.bias",
+        for kk in range(k):
+            names += [f"{p}.0.theta.{kk}.weight", f"{p}.0.theta.{kk}.bias"]
+        names += [f"{p}.1.conv_block1.0.weight", f"{p}.1.conv_block1.2.weight", f"{p}.1.conv_block1.2.bias",
                   f"{p}.1.conv_block2.0.weight", f"{p}.1.conv_block2.2.weight", f"{p}.1.conv_block2.2.bias"]
     names += ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
     return names
@@ -63,7 +72,7 @@ def bn_buffer_names(num_layers: int) -> list[tuple[str, str]]:
     return out
 
 
-def random_params(num_patch: int, num_layers: int = 2, seed: int = 0, dtype=np.float32) -> dict:
+def random_params(num_patch: int, num_layers: int = 2, seed: int = 0, dtype=np.float32, k: int = 1) -> dict:
     """Random (not reference-initialised) live parameters + BN buffers, for tests/bench."""
     rng = np.random.default_rng(seed)
     N, F = num_patch, NUM_STATS
@@ -71,8 +80,9 @@ def random_params(num_patch: int, num_layers: int = 2, seed: int = 0, dtype=np.f
     prm = {}
     for l in range(num_layers):
         p = f"sg_tcn.layers.{l}"
-        prm[f"{p}.0.theta.0.weight"] = rng.uniform(-s, s, (N, N))
-        prm[f"{p}.0.theta.0.bias"] = rng.uniform(-s, s, (N,))
+        for kk in range(k):
+            prm[f"{p}.0.theta.{kk}.weight"] = rng.uniform(-s, s, (N, N))
+            prm[f"{p}.0.theta.{kk}.bias"] = rng.uniform(-s, s, (N,))
         for blk in (1, 2):
             q = f"{p}.1.conv_block{blk}"
             prm[f"{q}.0.weight"] = rng.uniform(-0.22, 0.22, (F, F, TCN_KERNEL))
@@ -184,7 +194,9 @@ def _relu(x):
 @dataclass
 class LayerCache:
     X: np.ndarray = None
-    AX: np.ndarray = None
+    AX: np.ndarray = None          # A X (order 1); AXk / Apow: every order of MPNN_mk
+    AXk: list = None
+    Apow: list = None
     Hpre: np.ndarray = None
     H: np.ndarray = None
     z1: np.ndarray = None
@@ -252,13 +264,22 @@ def forward(prm: dict, x: np.ndarray, num_patch: int, patch_size: int, num_layer
     feat = patch_statistics(x.reshape(B * N, P)).reshape(B, N, F).transpose(0, 2, 1)   # [B,10,N]
     fc.feat = feat
     fc.adj = pearson_adjacency(feat)
+    K = mpnn_order(prm)
     X = feat
     for l in range(num_layers):
         p = f"sg_tcn.layers.{l}"
         lc = LayerCache()
         lc.X = X
-        lc.AX = fc.adj @ X
-        lc.Hpre = lc.AX @ prm[f"{p}.0.theta.0.weight"].T + prm[f"{p}.0.theta.0.bias"]
+        # MPNN_mk, Model.py:81-90: sum over kk of theta_kk(A^(kk+1) X); A_ = bmm(A_, A) is the running power
+        lc.Apow, lc.AXk, lc.Hpre = [], [], 0
+        A_ = fc.adj
+        for kk in range(K):
+            if kk > 0:
+                A_ = A_ @ fc.adj
+            lc.Apow.append(A_)
+            lc.AXk.append(A_ @ X)
+            lc.Hpre = lc.Hpre + lc.AXk[kk] @ prm[f"{p}.0.theta.{kk}.weight"].T + prm[f"{p}.0.theta.{kk}.bias"]
+        lc.AX = lc.AXk[0]
         lc.H = _leaky(lc.Hpre)
         lc.z1 = causal_conv(lc.H, prm[f"{p}.1.conv_block1.0.weight"], 1)
         y, lc.xhat1, lc.istd1 = _bn(lc.z1, prm, f"{p}.1.conv_block1.2", train, lc.bn_mean, lc.bn_var, stat_reduce, stat_count)
@@ -340,10 +361,10 @@ def backward(prm: dict, fc: FwdCache, dpred: np.ndarray, dropout: float = 0.0, s
         dH, g[f"{p}.1.conv_block1.0.weight"] = _conv_backward(dz1, lc.H, prm[f"{p}.1.conv_block1.0.weight"], 1)
         dH = dH + gsum0
         dHpre = dH * np.where(lc.Hpre > 0, dt.type(1), dt.type(LEAKY_SLOPE))
-        g[f"{p}.0.theta.0.weight"] = np.einsum("bcj,bck->jk", dHpre, lc.AX)
-        g[f"{p}.0.theta.0.bias"] = dHpre.sum(axis=(0, 1))
-        dAX = dHpre @ prm[f"{p}.0.theta.0.weight"]
-        dX = fc.adj.transpose(0, 2, 1) @ dAX + dX
+        for kk in range(len(lc.AXk)):
+            g[f"{p}.0.theta.{kk}.weight"] = np.einsum("bcj,bck->jk", dHpre, lc.AXk[kk])
+            g[f"{p}.0.theta.{kk}.bias"] = dHpre.sum(axis=(0, 1))
+            dX = lc.Apow[kk].transpose(0, 2, 1) @ (dHpre @ prm[f"{p}.0.theta.{kk}.weight"]) + dX
     return g
 
 
@@ -391,7 +412,7 @@ def train_step(prm, opt_state, x, y, num_patch, patch_size, num_layers=2, dropou
     new = dict(prm)
     new.update(bn_running_update(prm, fc, num_layers))
     m, v = dict(opt_state["m"]), dict(opt_state["v"])
-    for name in live_param_names(num_layers):
+    for name in live_param_names(num_layers, mpnn_order(prm)):
         g = grads[name].reshape(prm[name].shape)
         m0 = m.get(name, np.zeros_like(prm[name]))
         v0 = v.get(name, np.zeros_like(prm[name]))

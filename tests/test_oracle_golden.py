@@ -13,7 +13,8 @@ from oracle import stgcn_oracle as O
 from conftest import GOLDEN
 
 FB_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stgcn_*x*_bs*.npz"))
-                  if "train_curve" not in p and "layers" not in p)
+                  if "train_curve" not in p and "layers" not in p and "order" not in p)
+ORDER_CASES = ["stgcn_order2_14x30_bs19", "stgcn_order3_14x30_bs10", "stgcn_order2_40x64_bs5", "stgcn_order3_9x21_layers3_bs7"]
 
 
 def load_case(name):
@@ -84,6 +85,50 @@ def test_other_layer_counts_match_reference(name, L):
     g = O.backward(sd, fc, dpred)
     for n in O.live_param_names(L):
         assert rel_err(g[n].reshape(z["grad:" + n].shape), z["grad:" + n]) < 2e-4, n
+
+
+@pytest.mark.parametrize("name", ORDER_CASES)
+def test_mpnn_order_above_one_matches_reference(name):
+    """MPNN_mk with k = 2, 3 (Model.py:81-90: theta_kk on A^(kk+1) X, summed): fixtures of tests/golden/make_golden_order.py."""
+    z, sd = load_case(name)
+    N, P, L, K = int(z["num_patch"]), int(z["patch_size"]), int(z["num_layers"]), int(z["k"])
+    assert O.mpnn_order(sd) == K
+    # the flat order of the live parameters is the reference's named_parameters() order (the dead net0 / net1 branches dropped)
+    live = [n for n in z["key_order"].tolist() if ".net0." not in n and ".net1." not in n]
+    assert live == O.live_param_names(L, K)
+    x = z["x"].astype(np.float64)
+    fc = O.forward(sd, x, N, P, L, train=False)
+    assert rel_err(fc.pred, z["eval_pred"]) < 2e-5
+    fc = O.forward(sd, x, N, P, L, train=True)
+    assert rel_err(fc.pred, z["train_pred"]) < 2e-5
+    loss, dpred = O.mse_loss_and_grad(fc.pred, z["y"].astype(np.float64))
+    assert abs(loss - float(z["train_loss"])) < 2e-5 * abs(float(z["train_loss"]))
+    g = O.backward(sd, fc, dpred)
+    assert sorted(O.live_param_names(L, K)) == sorted(k[5:] for k in z.files if k.startswith("grad:"))
+    for n in O.live_param_names(L, K):
+        assert rel_err(g[n].reshape(z["grad:" + n].shape), z["grad:" + n]) < 3e-4, n
+    for k, v in O.bn_running_update(sd, fc, L).items():
+        assert rel_err(v, z["sd_after:" + k]) < 1e-5, k
+
+
+def test_mpnn_order_two_training_curve_matches_reference_update():
+    z = np.load(os.path.join(GOLDEN, "stgcn_order2_train_curve_14x30_bs16.npz"))
+    N, P, steps = int(z["num_patch"]), int(z["patch_size"]), int(z["steps"])
+    prm = {k[len("sd0:model."):]: z[k].astype(np.float64) for k in z.files if k.startswith("sd0:model.")}
+    assert O.mpnn_order(prm) == 2
+    opt = {"step": 0, "m": {}, "v": {}}
+    losses = []
+    for s in range(steps):
+        loss, prm, opt, _, _ = O.train_step(prm, opt, z["xs"][s].astype(np.float64), z["ys"][s].astype(np.float64),
+                                            N, P, lr=float(z["lr"]), weight_decay=float(z["wd"]))
+        losses.append(loss)
+    ref = z["losses"]
+    assert np.max(np.abs(np.array(losses) - ref) / ref) < 2e-3
+    assert np.max(np.abs(np.array(losses[:3]) - ref[:3]) / ref[:3]) < 5e-5
+    for n in O.live_param_names(2, 2):
+        assert rel_err(prm[n], z["sdK:model." + n]) < 5e-3, n
+    fc = O.forward(prm, z["xs"][0].astype(np.float64), N, P, train=False)
+    assert rel_err(fc.pred, z["eval_pred_after"]) < 5e-3
 
 
 def test_training_curve_matches_reference_update():
