@@ -225,6 +225,7 @@ _SIGNATURES = {
     "rulgnn_version": (C.c_int, []),
     "rulgnn_strerror": (C.c_char_p, [C.c_int]),
     "rulgnn_stgcn_param_count": (C.c_int64, [C.c_int32, C.c_int32]),
+    "rulgnn_stgcn_param_count_order": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "rulgnn_stgcn_forward_workspace_bytes": (C.c_size_t, [C.POINTER(StgcnShape)]),
     "rulgnn_stgcn_forward_path_f32": (C.c_int, [C.POINTER(StgcnShape), C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),

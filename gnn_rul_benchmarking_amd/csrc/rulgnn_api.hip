@@ -36,6 +36,10 @@ int64_t rulgnn_stgcn_param_count(int32_t num_patch, int32_t num_layers) {
     if (num_patch < 1 || num_layers < 1) return -1;
     return param_count(num_patch, num_layers);
 }
+int64_t rulgnn_stgcn_param_count_order(int32_t num_patch, int32_t num_layers, int32_t mpnn_k) {
+    if (num_patch < 1 || num_layers < 1 || mpnn_k < 1) return -1;
+    return param_count(num_patch, num_layers, mpnn_k);
+}
 
 static int check_ptrs(std::initializer_list<const void*> ps) {
     for (const void* p : ps) {
@@ -260,6 +264,7 @@ int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape* shape, const float
     const int rc = validate_shape(shape);
     if (rc != RULGNN_OK) return rc;
     if (tiled(shape)) return RULGNN_EUNSUPPORTED;
+    if (path == RULGNN_STEP_COOP && shape->mpnn_k != 1) return RULGNN_EUNSUPPORTED;      // the single launch is built for order 1
     if (path == RULGNN_STEP_CHAIN || path == RULGNN_STEP_COOP) return path;
     if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
     if (stgcn_train_mx_kind(shape, x) != 0) return RULGNN_STEP_MX;

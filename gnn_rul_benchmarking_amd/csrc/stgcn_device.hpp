@@ -27,18 +27,21 @@ __host__ __device__ constexpr int sym(int a, int b) {
     return (a < b ? a : b) * F - (a < b ? a : b) * ((a < b ? a : b) - 1) / 2 + ((a < b ? b : a) - (a < b ? a : b));
 }
 
-// flat parameter layout (see include/rulgnn.h)
-__host__ __device__ constexpr int layer_stride(int N) { return N * N + N + 2 * (CONVW + 2 * F); }
-__host__ __device__ constexpr int off_theta_w(int) { return 0; }
-__host__ __device__ constexpr int off_theta_b(int N) { return N * N; }
-__host__ __device__ constexpr int off_conv_w(int N, int blk) { return N * N + N + blk * (CONVW + 2 * F); }
-__host__ __device__ constexpr int off_bn_g(int N, int blk) { return off_conv_w(N, blk) + CONVW; }
-__host__ __device__ constexpr int off_bn_b(int N, int blk) { return off_conv_w(N, blk) + CONVW + F; }
-__host__ __device__ constexpr int off_fc1_w(int N, int L) { return L * layer_stride(N); }
-__host__ __device__ constexpr int off_fc1_b(int N, int L) { return off_fc1_w(N, L) + N * N; }
-__host__ __device__ constexpr int off_fc2_w(int N, int L) { return off_fc1_b(N, L) + N; }
-__host__ __device__ constexpr int off_fc2_b(int N, int L) { return off_fc2_w(N, L) + N; }
-__host__ __device__ constexpr int param_count(int N, int L) { return off_fc2_b(N, L) + 1; }
+// flat parameter layout (see include/rulgnn.h).  K = MPNN order (Model.py:74-79: theta is a ModuleList of K Linear(N, N), stored as
+// weight | bias per order, in named_parameters() order); every K defaults to 1, the reference's wiring and the only order the
+// matrix-core and the tiled kernels take.
+constexpr int MAX_MPNN_ORDER = 3;
+__host__ __device__ constexpr int layer_stride(int N, int K = 1) { return K * (N * N + N) + 2 * (CONVW + 2 * F); }
+__host__ __device__ constexpr int off_theta_w(int N, int kk = 0) { return kk * (N * N + N); }
+__host__ __device__ constexpr int off_theta_b(int N, int kk = 0) { return kk * (N * N + N) + N * N; }
+__host__ __device__ constexpr int off_conv_w(int N, int blk, int K = 1) { return K * (N * N + N) + blk * (CONVW + 2 * F); }
+__host__ __device__ constexpr int off_bn_g(int N, int blk, int K = 1) { return off_conv_w(N, blk, K) + CONVW; }
+__host__ __device__ constexpr int off_bn_b(int N, int blk, int K = 1) { return off_conv_w(N, blk, K) + CONVW + F; }
+__host__ __device__ constexpr int off_fc1_w(int N, int L, int K = 1) { return L * layer_stride(N, K); }
+__host__ __device__ constexpr int off_fc1_b(int N, int L, int K = 1) { return off_fc1_w(N, L, K) + N * N; }
+__host__ __device__ constexpr int off_fc2_w(int N, int L, int K = 1) { return off_fc1_b(N, L, K) + N; }
+__host__ __device__ constexpr int off_fc2_b(int N, int L, int K = 1) { return off_fc2_w(N, L, K) + N; }
+__host__ __device__ constexpr int param_count(int N, int L, int K = 1) { return off_fc2_b(N, L, K) + 1; }
 
 // ---------------------------------------------------------------------------------------------
 // DPP primitives.  bound_ctrl = true: lanes shifted in from outside the 16-lane row read 0,

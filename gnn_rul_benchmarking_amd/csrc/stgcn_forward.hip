@@ -16,6 +16,7 @@ struct FwdArgs {
     int64_t B;
     int64_t ntiles;
     int N, P, Ppad, L;
+    int K;              // MPNN order
     uint32_t magicP;
     int vec4;
     int stage_floats;   // per-wave LDS staging floats
@@ -33,10 +34,11 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SPW = Row<RW>::SPW;
     const int N = NFIX ? NFIX : a.N, L = LFIX ? LFIX : a.L, P = PFIX ? PFIX : a.P;
+    const int K = NFIX ? 1 : a.K;                 // (the compile-time shapes are the reference's wirings: order 1)
     EvalWeightsLds<RW> w;
-    w.bind(smem, L);
-    float* stage_all = smem + EvalWeightsLds<RW>::floats(L);
-    eval_weights_fill<RW>(w, prm, bn, N, L, threadIdx.x, BLOCK);
+    w.bind(smem, L, K);
+    float* stage_all = smem + EvalWeightsLds<RW>::floats(L, K);
+    eval_weights_fill<RW>(w, prm, bn, N, L, threadIdx.x, BLOCK, K);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_eval_kernel(const float* 
         __builtin_amdgcn_wave_barrier();
         stage_tile(gx + s0 * sampleNP, stage, ns * (int)sampleNP, P, a.Ppad, a.magicP, a.vec4, lane);
         __builtin_amdgcn_wave_barrier();
-        const float pred = eval_tile_valu<RW>(stage, ns, N, P, a.Ppad, L, w, prm, lane);
+        const float pred = eval_tile_valu<RW>(stage, ns, N, P, a.Ppad, L, w, prm, lane, K);
         if (t == 0 && srow < ns) out[s0 + srow] = pred;
     }
 }
@@ -61,9 +63,10 @@ static int launch_forward_fix(const TileGeom& g, const rulgnn_stgcn_shape* s, co
                           const float* bn, float* out, hipStream_t stream) {
     FwdArgs a;
     a.B = s->batch; a.ntiles = g.ntiles; a.N = s->num_patch; a.P = s->patch_size; a.Ppad = g.Ppad; a.L = s->num_layers;
+    a.K = s->mpnn_k;
     a.magicP = g.magicP; a.vec4 = g.vec4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.stage_floats = g.stage_floats;
-    const size_t lds = sizeof(float) * ((size_t)EvalWeightsLds<RW>::floats(a.L) + (size_t)WAVES_PER_BLOCK * g.stage_floats);
+    const size_t lds = sizeof(float) * ((size_t)EvalWeightsLds<RW>::floats(a.L, a.K) + (size_t)WAVES_PER_BLOCK * g.stage_floats);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stgcn_forward_eval_kernel<RW, NFIX, PFIX, LFIX>),
@@ -80,8 +83,8 @@ template <int RW>
 static int launch_forward(const TileGeom& g, const rulgnn_stgcn_shape* s, const float* x, const float* prm,
                           const float* bn, float* out, hipStream_t stream) {
     if constexpr (RW == 16) {
-        if (s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 30) return launch_forward_fix<RW, 14, 30, 2>(g, s, x, prm, bn, out, stream);
-        if (s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 50) return launch_forward_fix<RW, 14, 50, 2>(g, s, x, prm, bn, out, stream);
+        if (s->mpnn_k == 1 && s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 30) return launch_forward_fix<RW, 14, 30, 2>(g, s, x, prm, bn, out, stream);
+        if (s->mpnn_k == 1 && s->num_patch == 14 && s->num_layers == 2 && s->patch_size == 50) return launch_forward_fix<RW, 14, 50, 2>(g, s, x, prm, bn, out, stream);
     }
     return launch_forward_fix<RW, 0, 0, 0>(g, s, x, prm, bn, out, stream);
 }
@@ -134,6 +137,7 @@ static int launch_fixup(const TileGeom& g, const rulgnn_stgcn_shape* s, const fl
                         hipStream_t stream) {
     FwdArgs a;
     a.B = s->batch; a.ntiles = g.ntiles; a.N = s->num_patch; a.P = s->patch_size; a.Ppad = g.Ppad; a.L = s->num_layers;
+    a.K = 1;                                      // (the matrix-core kernels this scan follows are order 1 only)
     a.magicP = g.magicP; a.vec4 = g.vec4 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.stage_floats = g.stage_floats;
     const size_t lds = sizeof(float) * ((size_t)EvalWeightsLds<RW>::floats(a.L) + (size_t)WAVES_PER_BLOCK * g.stage_floats);

@@ -21,7 +21,10 @@ struct TileGeom {
 inline int validate_shape(const rulgnn_stgcn_shape* s) {
     if (!s) return RULGNN_EINVAL;
     if (s->batch < 0 || s->num_patch < 2 || s->patch_size < 2 || s->num_layers < 1) return RULGNN_EINVAL;
-    if (s->mpnn_k != 1) return RULGNN_EUNSUPPORTED;          // only the reference default k = 1
+    if (s->mpnn_k < 1) return RULGNN_EINVAL;
+    // MPNN order (Model.py:74-90): every wiring of the reference leaves the constructor default 1; 2 and 3 run on the row-mapped fp32
+    // kernels (num_patch <= 64), not on the matrix-core or tiled ones
+    if (s->mpnn_k > MAX_MPNN_ORDER || (s->mpnn_k > 1 && s->num_patch > 64)) return RULGNN_EUNSUPPORTED;
     if (s->num_patch > 4096 || s->num_layers > 8 || s->patch_size > 4096) return RULGNN_EUNSUPPORTED;
     if (s->batch > (int64_t)400000000 / ((int64_t)F * s->num_patch)) return RULGNN_EUNSUPPORTED;  // 32-bit dropout counter
     return RULGNN_OK;

@@ -87,6 +87,7 @@ struct TrainK {
     float dropout_p, drop_scale;
     uint32_t drop_thr;
     int pcount;
+    int K;                // MPNN order (Model.py:74-90): theta matrices per layer; the layout offsets take it
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -208,7 +209,10 @@ constexpr int phase_min_waves(int RW, int KIND, int IDX) {
 // tile and the scalar registers that carried them disappear.
 // The body is a device function so that the same code runs as one kernel per phase (the chain, below) and as the stages of the
 // single cooperative launch that small batches use (stgcn_train_coop_kernel).
-template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0>
+// KORD: MPNN order of the phases that contain the theta projection (F_{2l}) or its backward (G_{2l}) -- compile-time there, because the
+// weight-gradient accumulators of every order live in registers; every other phase is instantiated with KORD = 1 and takes the order
+// from a.K for the parameter offsets only.
+template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0, int KORD = 1>
 __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, const float* __restrict__ prm,
                                                  const float* __restrict__ gy,   // y or dpred (TOP only)
                                                  const TrainK& a) {
@@ -219,7 +223,10 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     constexpr int NBN = 2 * L;
     // BatchNorm layers whose forward statistics this kernel needs: F_i applies BN 0..i-1.
     constexpr int NFWD = KIND == PH_F ? IDX : NBN;
-    const int N = NFIX ? NFIX : a.N, LS = layer_stride(N);
+    static_assert(KORD == 1 || ((KIND == PH_F || KIND == PH_G) && IDX % 2 == 0), "only the theta phases are specialised on the order");
+    static_assert(KORD == 1 || NFIX == 0, "the compile-time shapes are order 1");
+    const int K = NFIX ? 1 : (KORD > 1 ? KORD : a.K);
+    const int N = NFIX ? NFIX : a.N, LS = layer_stride(N, K);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int srow = lane / RW, t = lane % RW;
     // dropout keys, read ONCE from the step scratch (kept out of the tile loops: the compiler will not hoist a load through a
@@ -248,14 +255,18 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     // ---- LDS carve --------------------------------------------------------------------------------
     // three zero-padded [RW][TWS] weight slots: theta of layer LY | theta of layer LY-1 (F_{2l}) or fc1 (TOP) |
     // the transposed matrix the backward needs (theta^T for G_{2l}, fc1^T for TOP)
+    // Order KORD > 1 (F_{2l} / G_{2l} only): KORD slots in all -- theta_kk for F_{2l}, theta_kk^T for G_{2l}.
     constexpr int CS = cell_stride(L);
+    constexpr int NCUR = KORD == 1 ? 1 : (KIND == PH_F ? KORD : 0), NAUX = KORD == 1 ? 1 : 0, NTR = KORD == 1 ? 1 : (KIND == PH_G ? KORD : 0);
     double* cellsum = reinterpret_cast<double*>(smem);     // [CS] the reduction cells, replicas summed
     float* w_cur = smem + 2 * CS;
-    float* w_aux = w_cur + TRW * TWS;
-    float* w_tr = w_aux + TRW * TWS;
-    float* vecs = w_tr + TRW * TWS;                       // [L+2][RW]        theta bias, fc1 bias, fc2 weight
+    float* w_aux = w_cur + NCUR * TRW * TWS;
+    float* w_tr = w_aux + NAUX * TRW * TWS;
+    float* vecs = w_tr + NTR * TRW * TWS;                 // [L+2][RW]        theta bias (summed over the orders), fc1 bias, fc2 weight
     float* bnc = vecs + (L + 2) * TRW;                    // [NBN][BNC][F] (+pad to 4)
-    constexpr int RED_K = 15 + (RW == 16 ? 0 : 4 * NTH);
+    constexpr int RED_TH = RW == 16 ? 4 : 4 * NTH;        // rows of one [N][N] weight-gradient accumulator in the block reduction
+    constexpr int RED_K1 = 15 + (RW == 16 ? 0 : 4 * NTH);
+    constexpr int RED_K = RED_K1 + (KORD - 1) * RED_TH;   // orders 2.. behind the rows of order 1
     float* red = bnc + ((NBN * BNC * F + 3) & ~3);        // [RED_K][64] block reduction of the gradient accumulators
     float* redp = red + RED_K * 64;                       // [4 waves][24] BatchNorm pair / loss partials
     float* convT = redp + WAVES_PER_BLOCK * 24;           // [F][2F] conv_block1 weights of layer LY as [ci][co][tap] (G_{2l} only)
@@ -264,10 +275,10 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     float* mywave = wave_area + wave * wave_area_floats;
 
     // ---- prologue: weights to LDS, BatchNorm constants from the reduction cells ---------------------
-    {
+    if constexpr (KORD == 1) {
         const float* th_cur = prm + LY * LS + off_theta_w(N);
-        const float* aux = KIND == PH_TOP ? prm + off_fc1_w(N, L) : prm + (LY >= 1 ? LY - 1 : 0) * LS + off_theta_w(N);
-        const float* trs = KIND == PH_TOP ? prm + off_fc1_w(N, L) : th_cur;
+        const float* aux = KIND == PH_TOP ? prm + off_fc1_w(N, L, K) : prm + (LY >= 1 ? LY - 1 : 0) * LS + off_theta_w(N);
+        const float* trs = KIND == PH_TOP ? prm + off_fc1_w(N, L, K) : th_cur;
         for (int i = threadIdx.x; i < TRW * TRW; i += BLOCK) {
             const int j = i / TRW, k = i % TRW;
             const bool in = j < N && k < N;
@@ -275,14 +286,28 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             w_aux[j * TWS + k] = in ? aux[j * N + k] : 0.f;
             w_tr[k * TWS + j] = in ? trs[j * N + k] : 0.f;
         }
+    } else {
+        for (int i = threadIdx.x; i < KORD * TRW * TRW; i += BLOCK) {
+            const int kk = i / (TRW * TRW), j = (i / TRW) % TRW, k = i % TRW;
+            const float v = (j < N && k < N) ? prm[LY * LS + off_theta_w(N, kk) + j * N + k] : 0.f;
+            if constexpr (KIND == PH_F) w_cur[(kk * TRW + j) * TWS + k] = v;
+            else w_tr[(kk * TRW + k) * TWS + j] = v;
+        }
     }
     for (int i = threadIdx.x; i < (L + 2) * TRW; i += BLOCK) {
         const int m = i / TRW, j = i % TRW;
-        const float* src = m < L ? prm + m * LS + off_theta_b(N) : (m == L ? prm + off_fc1_b(N, L) : prm + off_fc2_w(N, L));
-        vecs[i] = j < N ? src[j] : 0.f;
+        float v = 0.f;
+        if (j < N) {
+            if (m < L) {
+                for (int kk = 0; kk < K; ++kk) v += prm[m * LS + off_theta_b(N, kk) + j];       // one bias row: the sum over the orders
+            } else {
+                v = m == L ? prm[off_fc1_b(N, L, K) + j] : prm[off_fc2_w(N, L, K) + j];
+            }
+        }
+        vecs[i] = v;
     }
     if constexpr (CONV_FROM_LDS) {                        // this phase's ONE convolution reads its weights from LDS
-        const float* cw = prm + (IDX / 2) * LS + off_conv_w(N, IDX % 2);
+        const float* cw = prm + (IDX / 2) * LS + off_conv_w(N, IDX % 2, K);
         for (int i = threadIdx.x; i < F * F * 2; i += BLOCK) {
             const int tap = i & 1, ci = (i >> 1) % F, co = (i >> 1) / F;
             convT[KIND == PH_G ? ci * 2 * F + co * 2 + tap : i] = cw[i];      // backward: [ci][co][tap]; forward: as stored
@@ -303,7 +328,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             double var = s2 / cnt - mean * mean;
             var = var < 0.0 ? 0.0 : var;
             const double istd = 1.0 / sqrt(var + (double)BN_EPS);
-            const double g = prm[l * LS + off_bn_g(N, blk) + c], be = prm[l * LS + off_bn_b(N, blk) + c];
+            const double g = prm[l * LS + off_bn_g(N, blk, K) + c], be = prm[l * LS + off_bn_b(N, blk, K) + c];
             o[0 * F + c] = (float)mean;
             o[1 * F + c] = (float)istd;
             o[2 * F + c] = (float)(g * istd);
@@ -329,9 +354,17 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
     f32x4 acc_thg[NTH];                                                    // same, tiled, for the generic row width
 #pragma unroll
     for (int i = 0; i < NTH; ++i) acc_thg[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int KX = KORD > 1 ? KORD - 1 : 1;                            // theta gradients of the orders 2.. (G_{2l}, KORD > 1)
+    f32x4 acc_thk[KX], acc_thgk[KX][NTH];
+#pragma unroll
+    for (int q = 0; q < KX; ++q) {
+        acc_thk[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NTH; ++i) acc_thgk[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     float acc_b = 0.f, acc_w2 = 0.f, acc_b2 = 0.f, acc_loss = 0.f;         // theta/fc1 bias, fc2 weight, fc2 bias, loss
 
-    const float fc2_b = prm[off_fc2_b(N, L)];
+    const float fc2_b = prm[off_fc2_b(N, L, K)];
     const int P = PFIX ? PFIX : a.P;                      // compile-time window length: the F_0 statistics passes unroll fully
     const int64_t sampleNP = (int64_t)N * P;
     const float inv_gb = 1.0f / (float)a.global_batch;
@@ -492,10 +525,22 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = tb;
             R16::project10(H, AX, w_cur + t * TWS, N);
+            if constexpr (KORD > 1) {                   // orders 2..: theta_kk(A^(kk+1) X), Model.py:82-88, as A (A^kk X)
+                float AXa[F], AXb[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) AXa[c] = AX[c];
+#pragma unroll
+                for (int kk = 1; kk < KORD; ++kk) {
+                    if constexpr (RW == 16) adj_aggregate_mfma(A, AXa, AXb); else adj_aggregate(A, AXa, AXb);
+                    R16::project10(H, AXb, w_cur + (kk * TRW + t) * TWS, N);
+#pragma unroll
+                    for (int c = 0; c < F; ++c) AXa[c] = AXb[c];
+                }
+            }
 #pragma unroll
             for (int c = 0; c < F; ++c) H[c] = leaky(H[c]);
             if constexpr (CONV_FROM_LDS) causal_conv_lds<TRW, 1>(H, convT, t, z1);
-            else causal_conv<TRW, 1>(H, conv_weights<true, 5>(lp + off_conv_w(N, 0), (int)tile), t, z1);
+            else causal_conv<TRW, 1>(H, conv_weights<true, 5>(lp + off_conv_w(N, 0, K), (int)tile), t, z1);
             store_tile(slot(SV::H(LY)), H);
             store_tile(slot(SV::Z1(LY)), z1);
 #pragma unroll
@@ -533,7 +578,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             }
             float dH[F];
             if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 1>(dz, convT, t, dH);
-            else causal_conv_T<RW, 1>(dz, conv_weights<false, 1>(lp + off_conv_w(N, 0), (int)tile), t, dH);
+            else causal_conv_T<RW, 1>(dz, conv_weights<false, 1>(lp + off_conv_w(N, 0, K), (int)tile), t, dH);
 #pragma unroll
             for (int c = 0; c < F; ++c) {
                 const float g = dH[c] + g0[c];
@@ -542,11 +587,41 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
                 acc_b += dH[c];
             }
             if constexpr (RW != 16) outer_grad_mfma<RW, F>(mywave, dH, AX, lane, acc_thg);
+            if constexpr (KORD > 1) {                   // d theta_kk = d Hpre^T (A^(kk+1) X)
+                float AXa[F], AXb[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) AXa[c] = AX[c];
+#pragma unroll
+                for (int kk = 1; kk < KORD; ++kk) {
+                    if constexpr (RW == 16) adj_aggregate_mfma(A, AXa, AXb); else adj_aggregate(A, AXa, AXb);
+                    if constexpr (RW == 16) {
+#pragma unroll
+                        for (int c = 0; c < F; ++c) acc_thk[kk - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dH[c], AXb[c], acc_thk[kk - 1], 0, 0, 0);
+                    } else {
+                        outer_grad_mfma<RW, F>(mywave, dH, AXb, lane, acc_thgk[kk - 1]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < F; ++c) AXa[c] = AXb[c];
+                }
+            }
             if constexpr (LY > 0) {
                 float dAX[F], dXl[F];
 #pragma unroll
                 for (int c = 0; c < F; ++c) dAX[c] = 0.f;
+                if constexpr (KORD > 1) {
+                    // d X = sum_kk A^(kk+1) (d Hpre theta_kk) = A (u_0 + A (u_1 + A u_2 ...)), u_kk = d Hpre theta_kk (A symmetric)
+                    R16::project10(dAX, dH, w_tr + ((KORD - 1) * TRW + t) * TWS, N);
+#pragma unroll
+                    for (int kk = KORD - 2; kk >= 0; --kk) {
+                        float nxt[F];
+                        if constexpr (RW == 16) adj_aggregate_mfma(A, dAX, nxt); else adj_aggregate(A, dAX, nxt);
+                        R16::project10(nxt, dH, w_tr + (kk * TRW + t) * TWS, N);
+#pragma unroll
+                        for (int c = 0; c < F; ++c) dAX[c] = nxt[c];
+                    }
+                } else {
                 R16::project10(dAX, dH, w_tr + t * TWS, N);                         // dHpre . theta
+                }
                 if constexpr (RW == 16) adj_aggregate_mfma(A, dAX, dXl); else adj_aggregate(A, dAX, dXl);   // A is symmetric: A^T = A
                 float* rb = a.rbuf + tile * tile_floats + loff;
                 constexpr int lq = LY - 1;
@@ -582,7 +657,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
 #pragma unroll
             for (int c = 0; c < F; ++c) o0[c] = relu(relu(fmaf(z1[c], b1[2 * F + c], b1[3 * F + c])) + H[c]);
             if constexpr (CONV_FROM_LDS) causal_conv_lds<TRW, 2>(o0, convT, t, z2);
-            else causal_conv<TRW, 2>(o0, conv_weights<true, 6>(lp + off_conv_w(N, 1), (int)tile), t, z2);
+            else causal_conv<TRW, 2>(o0, conv_weights<true, 6>(lp + off_conv_w(N, 1, K), (int)tile), t, z2);
             store_tile(slot(SV::O0(LY)), o0);
             store_tile(slot(SV::Z2(LY)), z2);
 #pragma unroll
@@ -696,7 +771,7 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             }
             float d_o0[F];
             if constexpr (CONV_FROM_LDS) causal_conv_T_lds<RW, 2>(dz, convT, t, d_o0);
-            else causal_conv_T<RW, 2>(dz, conv_weights<true, 2>(lp + off_conv_w(N, 1), (int)tile), t, d_o0);
+            else causal_conv_T<RW, 2>(dz, conv_weights<true, 2>(lp + off_conv_w(N, 1, K), (int)tile), t, d_o0);
             float sbv[F];
 #pragma unroll
             for (int c = 0; c < F; ++c) {
@@ -768,38 +843,52 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
                         r[k * 64] = (w == 0) ? acc_thg[q][e] : r[k * 64] + acc_thg[q][e];
                     }
             }
+            if constexpr (KORD > 1 && KIND == PH_G) {
+#pragma unroll
+                for (int kk = 1; kk < KORD; ++kk)
+#pragma unroll
+                    for (int q = 0; q < (RW == 16 ? 1 : NTH); ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = RED_K1 + (kk - 1) * RED_TH + q * 4 + e;
+                            const float v2 = RW == 16 ? acc_thk[kk - 1][e] : acc_thgk[kk - 1][q][e];
+                            r[k * 64] = (w == 0) ? v2 : r[k * 64] + v2;
+                        }
+            }
         }
         __syncthreads();
     }
     // [N][N] matrix gradient (theta or fc1): MFMA D layout -> row j = 16m + 4*(lane>>4) + reg, column k = 16n + (lane & 15)
-    auto write_matrix = [&](float* dst) {
+    // (`first`: the accumulator's first row in `red`: 0 (RW 16) / 15 (generic) for order 1 and fc1, RED_K1 + ... for the orders 2..)
+    auto write_matrix = [&](float* dst, int first) {
         if constexpr (RW == 16) {
             for (int i = threadIdx.x; i < 4 * 64; i += BLOCK) {
                 const int rg = i / 64, ln = i % 64, j = 4 * (ln >> 4) + rg, k = ln & 15;
-                if (j < N && k < N) dst[j * N + k] = red[rg * 64 + ln];
+                if (j < N && k < N) dst[j * N + k] = red[(first + rg) * 64 + ln];
             }
         } else {
             constexpr int NT = RW / 16;
             for (int i = threadIdx.x; i < NTH * 4 * 64; i += BLOCK) {
                 const int q = i / 256, rg = (i / 64) % 4, ln = i % 64;
                 const int j = 16 * (q / NT) + 4 * (ln >> 4) + rg, k = 16 * (q % NT) + (ln & 15);
-                if (j < N && k < N) dst[j * N + k] = red[(15 + q * 4 + rg) * 64 + ln];
+                if (j < N && k < N) dst[j * N + k] = red[(first + q * 4 + rg) * 64 + ln];
             }
         }
     };
+    constexpr int RED_FIRST = RW == 16 ? 0 : 15;
     if (KIND == PH_TOP) {
-        write_matrix(row + off_fc1_w(N, L));
+        write_matrix(row + off_fc1_w(N, L, K), RED_FIRST);
         if (threadIdx.x < N) {
             const int j = threadIdx.x;
             float vb = 0.f, vw = 0.f;
             for (int s = 0; s < TSPW; ++s) { vb += red[12 * 64 + s * TRW + j]; vw += red[13 * 64 + s * TRW + j]; }
-            row[off_fc1_b(N, L) + j] = vb;
-            row[off_fc2_w(N, L) + j] = vw;
+            row[off_fc1_b(N, L, K) + j] = vb;
+            row[off_fc2_w(N, L, K) + j] = vw;
         }
         if (threadIdx.x == 0) {
             float v = 0.f;
             for (int s = 0; s < TSPW; ++s) v += red[14 * 64 + s * TRW];
-            row[off_fc2_b(N, L)] = v;
+            row[off_fc2_b(N, L, K)] = v;
         }
     }
     if (KIND == PH_G) {
@@ -813,24 +902,28 @@ __device__ __forceinline__ void train_phase_body(const float* __restrict__ gx, c
             if (which == 0) { ci = j < F ? j : j - F; tap = j < F ? 1 : 0; }
             else { ci = 6 + j; tap = 0; }
             if (co < F && ci < F && (which == 0 || j < 4))
-                lrow[off_conv_w(N, blk) + (co * F + ci) * 2 + tap] = red[(4 + which * 4 + rg) * 64 + ln];
+                lrow[off_conv_w(N, blk, K) + (co * F + ci) * 2 + tap] = red[(4 + which * 4 + rg) * 64 + ln];
         }
         if (blk == 0) {
-            write_matrix(lrow + off_theta_w(N));
+            write_matrix(lrow + off_theta_w(N), RED_FIRST);
+            if constexpr (KORD > 1) {
+#pragma unroll
+                for (int kk = 1; kk < KORD; ++kk) write_matrix(lrow + off_theta_w(N, kk), RED_K1 + (kk - 1) * RED_TH);
+            }
             if (threadIdx.x < N) {
                 float vb = 0.f;
                 for (int s = 0; s < TSPW; ++s) vb += red[12 * 64 + s * TRW + threadIdx.x];
-                lrow[off_theta_b(N) + threadIdx.x] = vb;
+                for (int kk = 0; kk < KORD; ++kk) lrow[off_theta_b(N, kk) + threadIdx.x] = vb;       // every order's bias sees d Hpre summed
             }
         }
     }
 }
 
-template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0>
-__global__ __launch_bounds__(BLOCK, phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
+template <int RW, int L, int KIND, int IDX, int NFIX = 0, int PFIX = 0, int KORD = 1>
+__global__ __launch_bounds__(BLOCK, KORD > 1 ? 1 : phase_min_waves(RW, KIND, IDX)) void stgcn_train_phase_kernel(const float* __restrict__ gx,
                                                                   const float* __restrict__ prm,
                                                                   const float* __restrict__ gy, TrainK a) {
-    train_phase_body<RW, L, KIND, IDX, NFIX, PFIX>(gx, prm, gy, a);
+    train_phase_body<RW, L, KIND, IDX, NFIX, PFIX, KORD>(gx, prm, gy, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,6 +938,7 @@ struct FinalizeK {
     int grid_top;
     int grid_g[16];       // grid of G_i, i = BatchNorm index
     int N, L, pcount;
+    int K;                // MPNN order (parameter offsets)
     int64_t B, global_batch;
     int write_grads, write_loss;
     float moment_weight;
@@ -875,7 +969,7 @@ constexpr int FIN_COLS = 64, FIN_SLICES = 16;
 // fixed order, so both launch forms produce the same bits.
 template <int SPW>
 __device__ __forceinline__ void finalize_unit(const FinalizeK& f, int unit, float (*part)[FIN_COLS], int lane, int wave) {
-    const int N = f.N, L = f.L, LS = layer_stride(N);
+    const int N = f.N, L = f.L, K = f.K, LS = layer_stride(N, K);
     const float lr_over_bc1 = step_scratch(f.cells, L)->lr_over_bc1, inv_sqrt_bc2 = step_scratch(f.cells, L)->inv_sqrt_bc2;
     const int p = unit * FIN_COLS + lane;
     const bool valid = p < f.pcount;
@@ -897,10 +991,10 @@ __device__ __forceinline__ void finalize_unit(const FinalizeK& f, int unit, floa
             nblk = f.grid_top;
         } else {
             const int l = p / LS, o = p % LS;
-            if (o < off_conv_w(N, 0)) nblk = f.grid_g[2 * l];                     // theta w/b
+            if (o < off_conv_w(N, 0, K)) nblk = f.grid_g[2 * l];                  // theta w/b
             else {
-                const int blk = o >= off_conv_w(N, 1) ? 1 : 0;
-                const int oo = o - off_conv_w(N, blk);
+                const int blk = o >= off_conv_w(N, 1, K) ? 1 : 0;
+                const int oo = o - off_conv_w(N, blk, K);
                 nblk = f.grid_g[2 * l + blk];
                 if (oo >= CONVW) { from_cells = true; bn = 2 * l + blk; which = (oo - CONVW) / F; c = (oo - CONVW) % F; }
             }
@@ -1053,7 +1147,7 @@ static void ws_layout(const rulgnn_stgcn_shape* s, const TileGeom& g, WsLayout* 
     w->cells_bytes = sizeof(double) * (size_t)CELL_REPLICAS * cell_stride(L) + sizeof(StepScratch) + 64;   // + grid-barrier counter
     w->off_cells = o; o = al(o + w->cells_bytes);
     w->max_grid = 2048;
-    w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L) * sizeof(float));
+    w->off_gpart = o; o = al(o + (size_t)w->max_grid * param_count(N, L, s->mpnn_k) * sizeof(float));
     const size_t tile_bytes = (size_t)g.ntiles * F * 64 * sizeof(float);
     w->off_saved = o; o = al(o + (size_t)saved_slots(L) * tile_bytes);
     w->off_rbuf = o; o = al(o + tile_bytes);
@@ -1076,20 +1170,23 @@ static int wave_area_for(int kind, int idx, const TileGeom& g) {
     return g.RW == 16 ? 0 : TT_ROWS * TT_STRIDE;          // TOP, generic row width: fc1 gradient through the transpose tile
 }
 
-static size_t train_lds_bytes(int RW, int L, int wave_area) {
+// (kord: the order a theta phase is specialised on -- 1 for every other phase; mirrors the LDS carve of train_phase_body)
+static size_t train_lds_bytes(int RW, int L, int wave_area, int kord = 1) {
     const int tws = RW + 4, nth = RW == 16 ? 0 : (RW / 16) * (RW / 16);
-    const size_t fl = (size_t)2 * cell_stride(L) + (size_t)3 * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
-                      (size_t)(15 + 4 * nth) * 64 + (size_t)WAVES_PER_BLOCK * 24 + CONVT_FLOATS + (size_t)WAVES_PER_BLOCK * wave_area;
+    const int slots = kord == 1 ? 3 : kord, red_th = RW == 16 ? 4 : 4 * nth;
+    const size_t fl = (size_t)2 * cell_stride(L) + (size_t)slots * RW * tws + (size_t)(L + 2) * RW + (size_t)((2 * L * BNC * F + 3) & ~3) +
+                      (size_t)(15 + 4 * nth + (kord - 1) * red_th) * 64 + (size_t)WAVES_PER_BLOCK * 24 + CONVT_FLOATS +
+                      (size_t)WAVES_PER_BLOCK * wave_area;
     return fl * sizeof(float);
 }
 
-template <int RW, int L, int KIND, int IDX, int NFIX, int PFIX = 0>
+template <int RW, int L, int KIND, int IDX, int NFIX, int PFIX = 0, int KORD = 1>
 static int launch_phase_n(const TrainK& k_in, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                           hipStream_t stream, int* grid_out) {
-    auto kern = stgcn_train_phase_kernel<RW, L, KIND, IDX, NFIX, PFIX>;
+    auto kern = stgcn_train_phase_kernel<RW, L, KIND, IDX, NFIX, PFIX, KORD>;
     TrainK k = k_in;
     k.wave_area_floats = wave_area_for(KIND, IDX, g);
-    const size_t lds = train_lds_bytes(RW, L, k.wave_area_floats);
+    const size_t lds = train_lds_bytes(RW, L, k.wave_area_floats, KORD);
     if (lds > 160 * 1024) return RULGNN_EUNSUPPORTED;
     if (lds > 48 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -1107,6 +1204,15 @@ static int launch_phase_n(const TrainK& k_in, const float* x, const float* prm, 
 template <int RW, int L, int KIND, int IDX>
 static int launch_phase(const TrainK& k, const float* x, const float* prm, const float* gy, const TileGeom& g, int max_grid,
                         hipStream_t stream, int* grid_out) {
+    if (k.K > 1) {
+        // MPNN order 2, 3: the theta phases (F_{2l}, G_{2l}) specialised on the order, the others as they are (offsets from k.K)
+        if constexpr ((KIND == PH_F || KIND == PH_G) && IDX % 2 == 0) {
+            if (k.K == 2) return launch_phase_n<RW, L, KIND, IDX, 0, 0, 2>(k, x, prm, gy, g, max_grid, stream, grid_out);
+            if (k.K == 3) return launch_phase_n<RW, L, KIND, IDX, 0, 0, 3>(k, x, prm, gy, g, max_grid, stream, grid_out);
+            return RULGNN_EUNSUPPORTED;
+        }
+        return launch_phase_n<RW, L, KIND, IDX, 0>(k, x, prm, gy, g, max_grid, stream, grid_out);
+    }
     if constexpr (RW == 16 && KIND == PH_F && IDX == 0) {
         // F_0 on the f16 matrix cores (stgcn_forward_mx.hip: the eval kernel's front end and the first half of layer 0) where its
         // shape rules hold (num_patch <= 15, 16-byte pieces); the row-mapped fp32 phase kernel below otherwise
@@ -1223,7 +1329,8 @@ static int setup_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
         const uint64_t ti = (uint64_t)(thr + 0.5);
         k.drop_thr = ti > 4294967295ull ? 4294967295u : (uint32_t)ti;
     }
-    k.pcount = param_count(N, L);
+    k.K = s->mpnn_k;
+    k.pcount = param_count(N, L, k.K);
     k.wave_area_floats = 0;
     return RULGNN_OK;
 }
@@ -1390,7 +1497,7 @@ static int launch_coop(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_arg
     f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
     f.grid_top = (int)grid;
     for (int i = 0; i < 16; ++i) f.grid_g[i] = (int)grid;
-    f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.N = k.N; f.L = L; f.K = 1; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.cell_grad_scale = 1.0f;
     f.guard = 0;
@@ -1470,7 +1577,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     // 97 vs 89 us, batch 4096: 275 vs 104 us) -- a phase costs its prologue plus one single-wavefront pass (~2000 instructions at one
     // issue per ~5 cycles), not its launch, and eleven grid barriers cost more than the ten launches they replace
     if (path == RULGNN_STEP_COOP) {
-        if (mode != TM_FWDBWD || hook) return RULGNN_EUNSUPPORTED;
+        if (mode != TM_FWDBWD || hook || k.K != 1) return RULGNN_EUNSUPPORTED;
         return run_train_coop<RW, L>(s, a, stream, k, w, lds, opt, bn_count);
     }
     const float* gy = a->dpred ? a->dpred : a->y;
@@ -1550,7 +1657,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     f.grads = a->grads; f.loss = a->loss; f.bn_batch = a->bn_batch;
     f.grid_top = grid_top;
     for (int i = 0; i < 16; ++i) f.grid_g[i] = grids[i];
-    f.N = k.N; f.L = L; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
+    f.N = k.N; f.L = L; f.K = k.K; f.pcount = k.pcount; f.B = s->batch; f.global_batch = a->global_batch;
     f.moment_weight = a->bn_moment_weight;
     f.cell_grad_scale = hook ? hook->bn_param_grad_scale : 1.0f;
     f.guard = use_mx ? 1 : 0;

@@ -13,16 +13,19 @@ NUM_STATS = 10       # channels / graph nodes
 TCN_KERNEL = 2
 
 
-def layer_stride(num_patch: int) -> int:
-    return num_patch * num_patch + num_patch + 2 * (NUM_STATS * NUM_STATS * TCN_KERNEL + 2 * NUM_STATS)
+def layer_stride(num_patch: int, k: int = 1) -> int:
+    """``k``: MPNN order -- theta is a ModuleList of k Linear(N, N) (models/ST_GCN/Model.py:74-79)."""
+    return k * (num_patch * num_patch + num_patch) + 2 * (NUM_STATS * NUM_STATS * TCN_KERNEL + 2 * NUM_STATS)
 
 
-def param_count(num_patch: int, num_layers: int) -> int:
-    return num_layers * layer_stride(num_patch) + num_patch * num_patch + 2 * num_patch + 1
+def param_count(num_patch: int, num_layers: int, k: int = 1) -> int:
+    return num_layers * layer_stride(num_patch, k) + num_patch * num_patch + 2 * num_patch + 1
 
 
-def live_param_layout(num_patch: int, num_layers: int) -> "OrderedDict[str, tuple[int, tuple[int, ...]]]":
-    """name (reference key without ``model.``) -> (offset in floats, shape), in buffer order."""
+def live_param_layout(num_patch: int, num_layers: int, k: int = 1) -> "OrderedDict[str, tuple[int, tuple[int, ...]]]":
+    """name (reference key without ``model.``) -> (offset in floats, shape), in buffer order = the reference's
+    ``named_parameters()`` order without the dead ``net0`` / ``net1`` branches."""
+    order = k
     N, F, K = num_patch, NUM_STATS, TCN_KERNEL
     out: "OrderedDict[str, tuple[int, tuple[int, ...]]]" = OrderedDict()
     off = 0
@@ -37,8 +40,9 @@ def live_param_layout(num_patch: int, num_layers: int) -> "OrderedDict[str, tupl
 
     for l in range(num_layers):
         p = f"sg_tcn.layers.{l}"
-        add(f"{p}.0.theta.0.weight", (N, N))
-        add(f"{p}.0.theta.0.bias", (N,))
+        for kk in range(order):
+            add(f"{p}.0.theta.{kk}.weight", (N, N))
+            add(f"{p}.0.theta.{kk}.bias", (N,))
         for blk in (1, 2):
             add(f"{p}.1.conv_block{blk}.0.weight", (F, F, K))
             add(f"{p}.1.conv_block{blk}.2.weight", (F,))
@@ -47,7 +51,7 @@ def live_param_layout(num_patch: int, num_layers: int) -> "OrderedDict[str, tupl
     add("fc1.bias", (N,))
     add("fc2.weight", (1, N))
     add("fc2.bias", (1,))
-    assert off == param_count(N, num_layers)
+    assert off == param_count(N, num_layers, order)
     return out
 
 
@@ -67,12 +71,12 @@ def bn_buffer_count(num_layers: int) -> int:
     return num_layers * 2 * 2 * NUM_STATS
 
 
-def pack_numpy(state: dict, num_patch: int, num_layers: int, prefix: str = ""):
+def pack_numpy(state: dict, num_patch: int, num_layers: int, prefix: str = "", k: int = 1):
     """state_dict-like mapping of numpy arrays -> (flat params, flat bn) float32 numpy arrays."""
     import numpy as np
 
-    flat = np.zeros(param_count(num_patch, num_layers), np.float32)
-    for name, (off, shape) in live_param_layout(num_patch, num_layers).items():
+    flat = np.zeros(param_count(num_patch, num_layers, k), np.float32)
+    for name, (off, shape) in live_param_layout(num_patch, num_layers, k).items():
         a = np.asarray(state[prefix + name], np.float32)
         assert tuple(a.shape) == shape, (name, a.shape, shape)
         flat[off:off + a.size] = a.reshape(-1)
@@ -82,9 +86,9 @@ def pack_numpy(state: dict, num_patch: int, num_layers: int, prefix: str = ""):
     return flat, bn
 
 
-def unpack_numpy(flat, num_patch: int, num_layers: int) -> dict:
+def unpack_numpy(flat, num_patch: int, num_layers: int, k: int = 1) -> dict:
     return {name: flat[off:off + int(__import__("numpy").prod(shape))].reshape(shape)
-            for name, (off, shape) in live_param_layout(num_patch, num_layers).items()}
+            for name, (off, shape) in live_param_layout(num_patch, num_layers, k).items()}
 
 
 # ---- flat-buffer view bookkeeping shared by every model module --------------------------------------------------------

@@ -127,7 +127,7 @@ class ST_GCN_model(FlatModule):
         self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module.check_guard())
         # _bufs: batch size -> (training workspace, prediction buffer), several sizes stay alive; _pin_bufs (graphs.py): captured
         # hipGraphs hold these pointers, never evict; _step_state: device step state (graphs.py), else the host counters are used
-        self._init_flat(PL.live_param_layout(self.num_patch, self.num_layers), PL.param_count(self.num_patch, self.num_layers))
+        self._init_flat(PL.live_param_layout(self.num_patch, self.num_layers, self.k), PL.param_count(self.num_patch, self.num_layers, self.k))
         self._live_slices = self._slices
 
     # ---- flat storage --------------------------------------------------------------------------
@@ -183,7 +183,8 @@ class ST_GCN_model(FlatModule):
             self._guard_unchecked = True
         ent = self._workspace_entry(batch, lambda: _lib.load().rulgnn_stgcn_train_workspace_bytes(C.byref(shp)),
                                     f"ST_GCN training kernels do not cover num_patch={self.num_patch}, num_layers={self.num_layers} "
-                                    "(num_patch 2..4096, patch_size 2..4096, num_layers 1..8, MPNN order k = 1)",
+                                    f"at MPNN order k={self.k} (num_patch 2..4096, patch_size 2..4096, num_layers 1..8; k = 2, 3 for "
+                                    "num_patch <= 64 only)",
                                     make=lambda dev: (torch.empty(batch, dtype=torch.float32, device=dev),))
         self._ws, self._pred_buf = ent
         if fresh:            # the sticky count of guard-rejected steps lives in the workspace and is only ever ADDED to by the kernels
@@ -422,8 +423,8 @@ class ST_GCN_model(FlatModule):
         if not self.reports_ready_gradients:
             return []
         N, L = self.num_patch, self.num_layers
-        LS = PL.layer_stride(N)
-        head = PL.param_count(N, L) - (N * N + 2 * N + 1)
+        LS = PL.layer_stride(N, self.k)
+        head = PL.param_count(N, L, self.k) - (N * N + 2 * N + 1)
         # (fc1.weight | fc1.bias | fc2.weight; fc2.bias, the last parameter, comes out of the finalize kernel at the end of the step)
         return [(head, N * N + 2 * N)] + [(l * LS, N * N + N) for l in range(L - 1, 0, -1)]
 

@@ -45,15 +45,21 @@ typedef struct rulgnn_stgcn_shape {
     int32_t num_patch;    /* N: patches per sample (C-MAPSS view: sensors), 2..4096 (fused kernels up to 64) */
     int32_t patch_size;   /* P: samples per patch (C-MAPSS view: window), 2..4096 */
     int32_t num_layers;   /* L: SG_TCN layers, 1..8 (reference default 2) */
-    int32_t mpnn_k;       /* MPNN order k; only 1 is implemented (the reference's default) */
+    int32_t mpnn_k;       /* MPNN order k (Model.py:74-90): 1 (the reference's default and every hparams row) on every path; 2 and 3 on the
+                           * row-mapped fp32 kernels (num_patch <= 64; eval forward, the phase chain incl. synchronised BatchNorm);
+                           * RULGNN_EUNSUPPORTED beyond, and for RULGNN_STEP_MX / RULGNN_STEP_COOP / RULGNN_EVAL_MX at k > 1 */
 } rulgnn_stgcn_shape;
 
 /* Library / ABI version: major*10000 + minor*100 + patch. */
 int rulgnn_version(void);
 const char *rulgnn_strerror(int code);
 
-/* Number of floats in the flat live-parameter buffer for (num_patch, num_layers). */
+/* Number of floats in the flat live-parameter buffer for (num_patch, num_layers) at MPNN order 1. */
 int64_t rulgnn_stgcn_param_count(int32_t num_patch, int32_t num_layers);
+/* The same for MPNN order mpnn_k (models/ST_GCN/Model.py:74-79: theta is a ModuleList of k Linear(num_patch, num_patch)): per layer
+ * theta.0.weight | theta.0.bias | ... | theta.<k-1>.weight | theta.<k-1>.bias, then the convolution / BatchNorm tensors as at k = 1 --
+ * the reference's named_parameters() order without the dead net0 / net1 branches. */
+int64_t rulgnn_stgcn_param_count_order(int32_t num_patch, int32_t num_layers, int32_t mpnn_k);
 
 /* Eval-mode forward: replaces ST_GCN_model.forward under model.eval()/no_grad
  * (reference models/ST_GCN/Model.py:208-222, called from trainer.py:144).

@@ -18,7 +18,7 @@ def load_case(name):
 
 
 FB_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stgcn_*x*_bs*.npz"))
-                  if "train_curve" not in p and "layers" not in p)
+                  if "train_curve" not in p and "layers" not in p and "order" not in p)
 
 
 def stream_ptr():
@@ -29,7 +29,7 @@ def shape_struct(batch, N, P, L=2, k=1):  # noqa: E741
     return _lib.StgcnShape(batch, N, P, L, k)
 
 
-def abi_forward(x_np, flat_np, bn_np, N, P, L=2):
+def abi_forward(x_np, flat_np, bn_np, N, P, L=2, k=1, path=None):
     """rulgnn_stgcn_forward_f32 on cuda:0; returns pred as numpy [B]."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -38,11 +38,15 @@ def abi_forward(x_np, flat_np, bn_np, N, P, L=2):
     prm = torch.from_numpy(flat_np).to(dev)
     bn = torch.from_numpy(bn_np).to(dev)
     out = torch.full((B,), float("nan"), device=dev)
-    shp = shape_struct(B, N, P, L)
+    shp = shape_struct(B, N, P, L, k)
     nbytes = lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(shp))
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
-    rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(),
-                                      ws.data_ptr() if nbytes else None, nbytes, stream_ptr())
+    if path is None:
+        rc = lib.rulgnn_stgcn_forward_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(),
+                                          ws.data_ptr() if nbytes else None, nbytes, stream_ptr())
+    else:
+        rc = lib.rulgnn_stgcn_forward_path_f32(C.byref(shp), x.data_ptr(), prm.data_ptr(), bn.data_ptr(), out.data_ptr(),
+                                               ws.data_ptr() if nbytes else None, nbytes, path, stream_ptr())
     _lib.check(rc, "rulgnn_stgcn_forward_f32")
     torch.cuda.synchronize()
     return out.cpu().numpy()
@@ -64,7 +68,7 @@ def elem_gate(got, ref, rtol=1e-4, floor=1e-6):
 
 
 def abi_train(x_np, y_np, flat_np, N, P, L=2, mode="fwdbwd", dropout=0.0, seed=0, step=1, dpred_np=None,
-              global_batch=None, sample_offset=0):
+              global_batch=None, sample_offset=0, k=1):
     """Train-mode entry points on cuda:0.  Returns dict(pred, loss, grads, bn_batch) as numpy."""
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -77,7 +81,7 @@ def abi_train(x_np, y_np, flat_np, N, P, L=2, mode="fwdbwd", dropout=0.0, seed=0
     pred = torch.full((B,), float("nan"), device=dev)
     loss = torch.full((1,), float("nan"), device=dev)
     bnb = torch.full((L * 2 * 2 * 10,), float("nan"), device=dev)
-    shp = shape_struct(B, N, P, L)
+    shp = shape_struct(B, N, P, L, k)
     nbytes = lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp))
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

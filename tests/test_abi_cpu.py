@@ -28,6 +28,8 @@ def test_param_count_and_layout_agree_with_library():
     lib = _lib.load()
     for N, L in [(14, 2), (40, 2), (16, 3), (2, 1)]:
         assert lib.rulgnn_stgcn_param_count(N, L) == PL.param_count(N, L)
+        for k in (1, 2, 3):
+            assert lib.rulgnn_stgcn_param_count_order(N, L, k) == PL.param_count(N, L, k)
         lay = PL.live_param_layout(N, L)
         last_off, last_shape = list(lay.values())[-1]
         assert last_off + 1 == PL.param_count(N, L)
@@ -47,8 +49,11 @@ def test_shape_validation_without_gpu():
     big = _lib.StgcnShape(4, 1024, 32, 2, 1)          # XJTU-sized num_patch: tiled path, needs a workspace
     assert lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(big)) > 0
     assert lib.rulgnn_stgcn_forward_workspace_bytes(C.byref(_lib.StgcnShape(4, 14, 30, 2, 1))) == 0
-    bad = _lib.StgcnShape(4, 14, 30, 2, 3)            # MPNN order k != 1
+    bad = _lib.StgcnShape(4, 14, 30, 2, 4)            # MPNN order: 1..3 (2, 3 on the row-mapped kernels, num_patch <= 64)
     assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None, 0, None) == -2
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 160, 16, 2, 2)), None, None, None, None, None, 0, None) == -2
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 14, 30, 2, 0)), None, None, None, None, None, 0, None) == -1
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 14, 30, 2, 3)), None, None, None, None, None, 0, None) == -1   # valid shape, null pointers
     ok = _lib.StgcnShape(4, 14, 30, 2, 1)
     assert lib.rulgnn_stgcn_forward_f32(C.byref(ok), None, None, None, None, None, 0, None) == -1   # null pointers
     empty = _lib.StgcnShape(0, 14, 30, 2, 1)

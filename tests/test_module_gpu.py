@@ -111,8 +111,10 @@ def test_phm2012_shape_trains_and_unsupported_shape_raises_clearly():
     algo.eval()
     with torch.no_grad():
         assert algo.model(x).shape == (50, 1)
-    with pytest.raises(RuntimeError):                 # MPNN order k = 2 is not implemented: loud, no fallback
-        ST_GCN_model(14, 30, k=2).to(DEV).eval()(torch.rand(8, 14, 30, device=DEV))
+    with pytest.raises(RuntimeError):                 # MPNN order k = 4 (and k > 1 on the tiled shapes) is not implemented: loud, no fallback
+        ST_GCN_model(14, 30, k=4).to(DEV).eval()(torch.rand(8, 14, 30, device=DEV))
+    with pytest.raises(RuntimeError):
+        ST_GCN_model(160, 16, k=2).to(DEV).eval()(torch.rand(8, 160, 16, device=DEV))
 
 
 def test_xjtu_and_phm_c2_shapes_train_on_the_tiled_path():
