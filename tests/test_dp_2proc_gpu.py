@@ -120,6 +120,8 @@ STGCN_MXW = ("ST_GCN", dict(num_patch=20, patch_size=30, dropout=0.2), (20, 30))
 STGCN_MXW40 = ("ST_GCN", dict(num_patch=40, patch_size=64, dropout=0.2), (40, 64))        # PHM2012's wiring (three column tiles)
 STGCN_FP32 = ("ST_GCN", dict(num_patch=21, patch_size=30, dropout=0.2), (21, 30))         # 630 floats per window: not 16-byte pieces -> fp32 chain
 STGCN_TILED = ("ST_GCN", dict(num_patch=72, patch_size=8, dropout=0.2), (72, 8))
+STGCN_ORDER2 = ("ST_GCN", dict(num_patch=14, patch_size=30, dropout=0.2, k=2), (14, 30))  # MPNN order 2 (Model.py:74-90): fp32 chain, larger bucket
+STGCN_ORDER3_W = ("ST_GCN", dict(num_patch=24, patch_size=16, dropout=0.2, k=3), (24, 16))  # order 3 on the 64-lane row mapping
 def _hp_case(family):
     """The reference's FD004 wiring of the family (configs/hparams.py), as this package restates it."""
     from gnn_rul_benchmarking_amd import hparams as HP
@@ -155,6 +157,14 @@ def test_stgcn_two_processes_equal_the_single_process_step(B, sync_bn):
 @pytest.mark.parametrize("sync_bn", [False, True])
 def test_stgcn_fp32_chain_two_processes(sync_bn):
     r0, r1, ref = _run(STGCN_FP32, 23, sync_bn)
+    _check(r0, r1, ref, 2e-4)
+
+
+@pytest.mark.parametrize("case,B", [(STGCN_ORDER2, 37), (STGCN_ORDER2, 1), (STGCN_ORDER3_W, 11)])
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_stgcn_mpnn_order_above_one_two_processes(case, B, sync_bn):
+    """k = 2, 3: the bucket grows by (k - 1)(N^2 + N) floats per layer; everything else as at k = 1."""
+    r0, r1, ref = _run(case, B, sync_bn)
     _check(r0, r1, ref, 2e-4)
 
 

@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _replica(N, P, L, dropout, state=None, seed=5):
+def _replica(N, P, L, dropout, state=None, seed=5, k=1):
     from gnn_rul_benchmarking_amd.stgcn import ST_GCN_model
     torch.manual_seed(3)
-    m = ST_GCN_model(N, P, num_layers=L, dropout=dropout)
+    m = ST_GCN_model(N, P, num_layers=L, dropout=dropout, k=k)
     if state is not None:
         m.load_state_dict(state)
     m = m.to(DEV).train()
@@ -45,19 +45,20 @@ class TwoPartySum:
         self.calls[rank] += 1
 
 
-@pytest.mark.parametrize("N,P,L,B,split,p", [(14, 30, 2, 96, 48, 0.2), (14, 30, 2, 4099, 1500, 0.2), (14, 30, 1, 37, 36, 0.0),
-                                             (40, 64, 2, 21, 8, 0.2), (14, 50, 3, 130, 64, 0.1)])
-def test_two_shards_with_synchronised_batchnorm_equal_the_full_batch_step(N, P, L, B, split, p):
+@pytest.mark.parametrize("N,P,L,B,split,p,K", [(14, 30, 2, 96, 48, 0.2, 1), (14, 30, 2, 4099, 1500, 0.2, 1), (14, 30, 1, 37, 36, 0.0, 1),
+                                               (40, 64, 2, 21, 8, 0.2, 1), (14, 50, 3, 130, 64, 0.1, 1),
+                                               (14, 30, 2, 96, 40, 0.2, 2), (40, 64, 2, 21, 8, 0.2, 3)])
+def test_two_shards_with_synchronised_batchnorm_equal_the_full_batch_step(N, P, L, B, split, p, K):
     g = torch.Generator(device=DEV).manual_seed(B)
     x = torch.rand(B, N, P, device=DEV, generator=g)
     y = torch.rand(B, 1, device=DEV, generator=g)
-    full = _replica(N, P, L, p)
+    full = _replica(N, P, L, p, k=K)
     state = {k: v.clone() for k, v in full.state_dict().items()}
     pred_f, loss_f = full.fused_mse_step(x, y)
     pred_f, loss_f = pred_f.clone(), float(loss_f)
     grad_f, bn_f = full.bucket[:full.num_live].clone(), full._bn_batch.clone()
 
-    ranks = [_replica(N, P, L, p, state), _replica(N, P, L, p, state)]
+    ranks = [_replica(N, P, L, p, state, k=K), _replica(N, P, L, p, state, k=K)]
     bounds = [(0, split), (split, B)]
     comm = TwoPartySum()
     errors = []
@@ -91,7 +92,7 @@ def test_two_shards_with_synchronised_batchnorm_equal_the_full_batch_step(N, P, 
         assert torch.allclose(r._bn_batch, bn_f, rtol=1e-5, atol=1e-7)
     grad = ranks[0].bucket[:nl] + ranks[1].bucket[:nl]
     from gnn_rul_benchmarking_amd import params as PL
-    for name, (off, shape) in PL.live_param_layout(N, L).items():
+    for name, (off, shape) in PL.live_param_layout(N, L, K).items():
         n = int(np.prod(shape))
         ref, got = grad_f[off:off + n], grad[off:off + n]
         assert float((got - ref).abs().max()) < 2e-5 * max(float(ref.abs().max()), 1e-6), name
