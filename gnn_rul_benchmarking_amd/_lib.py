@@ -219,6 +219,7 @@ _SIGNATURES = {
     "rulgnn_peer_mailbox_free": (C.c_int, [C.c_void_p]),
     "rulgnn_peer_comm_create": (C.c_void_p, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "rulgnn_peer_comm_destroy": (None, [C.c_void_p]),
+    "rulgnn_peer_comm_set_timeout_ms": (C.c_int, [C.c_void_p, C.c_int64]),
     "rulgnn_peer_allreduce_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "rulgnn_peer_comm_collectives": (C.c_int64, [C.c_void_p]),
     "rulgnn_peer_comm_status": (C.c_int64, [C.c_void_p]),

@@ -141,6 +141,8 @@ class ST_GCN(_FusedAlgorithm):
         if not self.sync_loss:
             return {'loss': loss}
         value = loss.item()                                   # the ONE host read-back of the step
+        if not math.isfinite(value) and self.dp is not None and getattr(self.dp, "peer", None) is not None:
+            self.dp.peer.check()                              # a one-shot BatchNorm collective that gave up on a peer: say so, do not retry
         graphed = self.dp is None and getattr(self, "_graphed", None) is not None
         if not math.isfinite(value) and getattr(model, "guard_tensor", None) is not None:
             if graphed:                                       # a captured graph replays one path: no retry from here

@@ -16,8 +16,10 @@
 //
 // The entry rulgnn_peer_allreduce_f64 has the signature of rulgnn_allreduce_f64_fn: its address and the communicator are passed as the
 // (callback, user) pair of the *_syncbn_* entries -- no Python frame between two phases of a step.  A spin is bounded by wall-clock
-// (PEER_TIMEOUT_TICKS of the 100 MHz counter): a missing peer ends as a sticky error word in the mailbox (reported by
-// rulgnn_peer_comm_status) and garbage in the buffer, never as a hung GPU.
+// (the communicator's timeout, in ticks of the 100 MHz counter; 20 s unless rulgnn_peer_comm_set_timeout_ms says otherwise -- long
+// enough for a peer whose host thread was descheduled or is still loading code objects, short enough to end a job whose peer died): a
+// missing peer ends as a sticky error word in the mailbox (reported by rulgnn_peer_comm_status) and NaN in the buffer, never as a hung
+// GPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -30,7 +32,8 @@ namespace {
 
 constexpr int PEER_MAX_WORLD = 8;
 constexpr int PEER_MAX_COUNT = RULGNN_PEER_MAX_COUNT;
-constexpr unsigned long long PEER_TIMEOUT_TICKS = 300000000ull;       // 3 s of the 100 MHz wall clock
+constexpr unsigned long long PEER_TICKS_PER_MS = 100000ull;           // the 100 MHz wall clock
+constexpr unsigned long long PEER_TIMEOUT_TICKS = 20000ull * PEER_TICKS_PER_MS;      // default: 20 s
 
 struct PeerSlot {
     unsigned long long flag;                 // number of the last collective whose data is complete in this slot
@@ -49,10 +52,11 @@ struct PeerComm {
     int rank, world;
     PeerPtrs peers;                          // peers.box[rank] = the own mailbox
     unsigned long long seq;                  // collectives issued so far
+    unsigned long long timeout_ticks;
 };
 
 __global__ __launch_bounds__(PEER_MAX_COUNT) void peer_allreduce_kernel(double* __restrict__ buf, int n, PeerPtrs p, int rank, int world,
-                                                                         unsigned long long seq) {
+                                                                         unsigned long long seq, unsigned long long timeout_ticks) {
     const int t = threadIdx.x, par = (int)(seq & 1ull);
     if (t < n) {
         const double v = buf[t];
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(PEER_MAX_COUNT) void peer_allreduce_kernel(double* 
         PeerMailbox* mine = p.box[rank];
         while (__hip_atomic_load(&mine->slot[par][t].flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > timeout_ticks) {
                 failed = 1;
                 __hip_atomic_store(&mine->error, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
@@ -120,13 +124,18 @@ void* rulgnn_peer_comm_create(int32_t rank, int32_t world, void* const* mailboxe
     if (rank < 0 || world < 1 || world > PEER_MAX_WORLD || rank >= world || !mailboxes) return nullptr;
     PeerComm* c = new (std::nothrow) PeerComm();
     if (!c) return nullptr;
-    c->rank = rank; c->world = world; c->seq = 0;
+    c->rank = rank; c->world = world; c->seq = 0; c->timeout_ticks = PEER_TIMEOUT_TICKS;
     for (int q = 0; q < PEER_MAX_WORLD; ++q) c->peers.box[q] = q < world ? static_cast<PeerMailbox*>(mailboxes[q]) : nullptr;
     for (int q = 0; q < world; ++q)
         if (!c->peers.box[q]) { delete c; return nullptr; }
     return c;
 }
 void rulgnn_peer_comm_destroy(void* comm) { delete static_cast<PeerComm*>(comm); }
+int rulgnn_peer_comm_set_timeout_ms(void* comm, int64_t ms) {
+    if (!comm || ms < 1 || ms > 600000) return RULGNN_EINVAL;
+    static_cast<PeerComm*>(comm)->timeout_ticks = (unsigned long long)ms * PEER_TICKS_PER_MS;
+    return RULGNN_OK;
+}
 
 // rulgnn_allreduce_f64_fn: device_buf[0..count) summed over the ranks in place, in stream order
 int rulgnn_peer_allreduce_f64(void* comm, double* device_buf, int32_t count, void* stream) {
@@ -136,7 +145,7 @@ int rulgnn_peer_allreduce_f64(void* comm, double* device_buf, int32_t count, voi
     ++c->seq;
     (void)hipGetLastError();
     hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(PEER_MAX_COUNT), 0, static_cast<hipStream_t>(stream), device_buf, (int)count, c->peers,
-                       c->rank, c->world, c->seq);
+                       c->rank, c->world, c->seq, c->timeout_ticks);
     return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
 }
 int64_t rulgnn_peer_comm_collectives(void* comm) { return comm ? (int64_t)static_cast<PeerComm*>(comm)->seq : -1; }

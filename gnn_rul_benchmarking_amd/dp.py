@@ -42,9 +42,12 @@ class PeerAllReduce:
 
     Set-up exchanges the mailboxes' IPC handles through ``torch.distributed`` (any backend); the ranks must be on one node with peer
     access between their devices (or on one device).  An instance is passed to ``fused_mse_step_syncbn`` in place of the Python
-    all-reduce (``c_callback`` / ``c_user``: _lib.allreduce_callback) and is itself callable on a float64 device tensor."""
+    all-reduce (``c_callback`` / ``c_user``: _lib.allreduce_callback) and is itself callable on a float64 device tensor.
 
-    def __init__(self, process_group=None):
+    ``timeout_s``: how long a collective spins for a peer before it gives up (NaN in the buffer -> a NaN loss on every rank through the
+    bucket all-reduce, and ``check()`` raises on the rank that waited)."""
+
+    def __init__(self, process_group=None, timeout_s: float = 20.0):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
@@ -69,6 +72,7 @@ class PeerAllReduce:
         self.c_user = lib.rulgnn_peer_comm_create(self.rank, self.world_size, ptrs)
         if not self.c_user:
             raise RuntimeError("rulgnn_peer_comm_create failed")
+        _lib.check(lib.rulgnn_peer_comm_set_timeout_ms(self.c_user, int(round(timeout_s * 1000.0))), "rulgnn_peer_comm_set_timeout_ms")
         self.c_callback = C.cast(lib.rulgnn_peer_allreduce_f64, C.c_void_p).value
         dist.barrier(group=process_group)              # every mailbox is mapped everywhere before the first push
 

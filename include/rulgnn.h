@@ -798,7 +798,8 @@ int rulgnn_stagnn_fwdbwd_f32(const rulgnn_stagnn_shape *shape, const rulgnn_stag
  * (fine-grained device memory) and gets its IPC handle (rulgnn_peer_handle_bytes() bytes: hipIpcMemHandle_t), the ranks exchange the
  * handles by whatever means they have (torch.distributed.all_gather_object in gnn_rul_benchmarking_amd/dp.py), open each other's
  * mailboxes and build a communicator from the world's pointers (mailboxes[rank] = the own one).  Every rank must issue the same
- * sequence of collectives.  A collective whose peers do not arrive within ~3 s leaves NaN in the buffer and a sticky error in the
+ * sequence of collectives.  A collective whose peers do not arrive within the communicator's timeout (20 s unless
+ * rulgnn_peer_comm_set_timeout_ms set another, 1 ms .. 10 min) leaves NaN in the buffer and a sticky error in the
  * mailbox (rulgnn_peer_comm_status) instead of spinning forever.  Requires peer access between the devices (one node, xGMI or PCIe
  * P2P) and HSA_ENABLE_IPC_MODE_LEGACY=0 on this image (dmabuf IPC). */
 #define RULGNN_PEER_MAX_COUNT 128
@@ -810,6 +811,7 @@ int rulgnn_peer_mailbox_close(void *mailbox);
 int rulgnn_peer_mailbox_free(void *mailbox);
 void *rulgnn_peer_comm_create(int32_t rank, int32_t world, void *const *mailboxes);
 void rulgnn_peer_comm_destroy(void *comm);
+int rulgnn_peer_comm_set_timeout_ms(void *comm, int64_t milliseconds);
 int rulgnn_peer_allreduce_f64(void *comm, double *device_buf, int32_t count, void *stream);
 int64_t rulgnn_peer_comm_collectives(void *comm);
 int64_t rulgnn_peer_comm_status(void *comm);

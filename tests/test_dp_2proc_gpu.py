@@ -373,3 +373,37 @@ def test_peer_mailbox_all_reduce_hundreds_of_back_to_back_collectives():
     out = mgr.dict()
     mp.spawn(_peer_stress_worker, args=(2, _free_port(), 600, out), nprocs=2, join=True)
     assert out[0] == {"bad": 0, "collectives": 600} and out[1] == {"bad": 0, "collectives": 600}
+
+
+def test_peer_mailbox_all_reduce_gives_up_on_a_missing_peer_within_its_timeout():
+    """A world of two whose second rank never arrives (its mailbox is a second local allocation nobody writes): with a 50-ms timeout
+    the collective returns NaN -- not a hung GPU -- and the communicator reports which collective gave up; the next one (the peer still
+    missing) does the same; the argument checks of the timeout setter."""
+    import ctypes as C
+    import time
+    from gnn_rul_benchmarking_amd import _lib
+    lib = _lib.load()
+    torch.cuda.set_device(0)
+    hb = lib.rulgnn_peer_handle_bytes()
+    boxes = (C.c_void_p * 2)()
+    for r in range(2):
+        box, handle = C.c_void_p(), (C.c_ubyte * hb)()
+        _lib.check(lib.rulgnn_peer_mailbox_alloc(C.byref(box), handle), "rulgnn_peer_mailbox_alloc")
+        boxes[r] = box.value
+    comm = lib.rulgnn_peer_comm_create(0, 2, boxes)
+    assert comm
+    assert lib.rulgnn_peer_comm_set_timeout_ms(comm, 0) == _lib.EINVAL and lib.rulgnn_peer_comm_set_timeout_ms(comm, 10 ** 7) == _lib.EINVAL
+    assert lib.rulgnn_peer_comm_set_timeout_ms(comm, 50) == _lib.OK
+    buf = torch.arange(20, dtype=torch.float64, device="cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t0 = time.perf_counter()
+    for q in (1, 2):
+        assert lib.rulgnn_peer_allreduce_f64(comm, buf.data_ptr(), 20, st) == _lib.OK
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(buf).all())
+        assert lib.rulgnn_peer_comm_status(comm) == q
+        buf.copy_(torch.arange(20, dtype=torch.float64))
+    assert time.perf_counter() - t0 < 5.0
+    lib.rulgnn_peer_comm_destroy(comm)
+    for r in range(2):
+        assert lib.rulgnn_peer_mailbox_free(boxes[r]) == _lib.OK
