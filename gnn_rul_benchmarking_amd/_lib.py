@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RULGNN_LIB") or os.path.join(_PKG_DIR, "librulgnn.so"
 OK = 0
 EINVAL, EUNSUPPORTED, EWORKSPACE, EHIP, EALIGN, ECALLBACK = -1, -2, -3, -4, -5, -6      # include/rulgnn.h RULGNN_E*
 EVAL_AUTO, EVAL_EXACT, EVAL_MX = 0, 1, 2      # include/rulgnn.h RULGNN_EVAL_*
-STEP_AUTO, STEP_CHAIN, STEP_COOP, STEP_MX = 0, 1, 2, 3    # include/rulgnn.h RULGNN_STEP_*
+STEP_AUTO, STEP_CHAIN, STEP_COOP, STEP_MX, STEP_MX_PERSIST = 0, 1, 2, 3, 4    # include/rulgnn.h RULGNN_STEP_*
 TRAIN_WS_CLEAN = 1                                        # include/rulgnn.h RULGNN_TRAIN_WS_CLEAN
 NUM_STATS = 10
 

@@ -231,7 +231,8 @@ int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape* shape, const rulg
                                      const rulgnn_adam_args* opt, int32_t path, void* stream) {
     int rc = check_train(shape, args, true);
     if (rc != RULGNN_OK) return rc;
-    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_COOP && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_CHAIN && path != RULGNN_STEP_COOP && path != RULGNN_STEP_MX && path != RULGNN_STEP_MX_PERSIST)
+        return RULGNN_EINVAL;
     if (!opt) {                                            // forward + backward only
         if (tiled(shape)) return stgcn_tiled_train(shape, args, 2, static_cast<hipStream_t>(stream));
         return stgcn_train_step(shape, args, nullptr, static_cast<hipStream_t>(stream), path);
@@ -266,9 +267,12 @@ int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape* shape, const float
     if (tiled(shape)) return RULGNN_EUNSUPPORTED;
     if (path == RULGNN_STEP_COOP && shape->mpnn_k != 1) return RULGNN_EUNSUPPORTED;      // the single launch is built for order 1
     if (path == RULGNN_STEP_CHAIN || path == RULGNN_STEP_COOP) return path;
-    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX) return RULGNN_EINVAL;
-    if (stgcn_train_mx_kind(shape, x) != 0) return RULGNN_STEP_MX;
-    return path == RULGNN_STEP_MX ? RULGNN_EUNSUPPORTED : RULGNN_STEP_CHAIN;
+    if (path != RULGNN_STEP_AUTO && path != RULGNN_STEP_MX && path != RULGNN_STEP_MX_PERSIST) return RULGNN_EINVAL;
+    const int kind = stgcn_train_mx_kind(shape, x);
+    if (path == RULGNN_STEP_MX_PERSIST)          // the small-batch single launch: the 4-sample-tile chain, two layers, a workgroup per CU
+        return kind == 1 && stgcn_train_mx_persistent_grid(shape->batch, shape->num_layers, 2048) > 0 ? RULGNN_STEP_MX : RULGNN_EUNSUPPORTED;
+    if (kind != 0) return RULGNN_STEP_MX;
+    return path != RULGNN_STEP_AUTO ? RULGNN_EUNSUPPORTED : RULGNN_STEP_CHAIN;
 }
 
 int rulgnn_stgcn_train_phase_count(int32_t num_layers) { return num_layers >= 1 ? 4 * num_layers + 1 : -1; }

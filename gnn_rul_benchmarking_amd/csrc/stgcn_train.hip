@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_SLICES) void stgcn_train_finalize_ke
         if (last) {
             const int stride = cell_stride(f.L);
             for (int i = threadIdx.x; i < stride * CELL_REPLICAS; i += blockDim.x) f.cells[i] = 0.0;
-            if (threadIdx.x == 0) { sc->pad[0] = 0u; sc->pad[2] = 0u; sc->pad[1] = WS_CLEAN_TOKEN; }
+            if (threadIdx.x == 0) { sc->pad[0] = 0u; sc->pad[2] = 0u; sc->pad[1] = WS_CLEAN_TOKEN; *step_barrier(f.cells, f.L) = 0u; }
         }
     }
 }
@@ -1374,6 +1374,7 @@ __global__ void stgcn_prepare_kernel(double* cells, int zero_from, int nzero, in
                                      uint64_t step, int L, int new_forward, int has_adam, int64_t adam_step, float lr, float beta1,
                                      float beta2, double bn_count) {
     prepare_body(cells, zero_from, nzero, stride, sc, st, seed, step, L, new_forward, has_adam, adam_step, lr, beta1, beta2, bn_count);
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sc) + sizeof(StepScratch)) = 0u;      // step_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1587,7 +1588,7 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     const int mx_kind = mx_step ? stgcn_train_mx_kind(s, a->x) : 0;                         // the ONE predicate rulgnn_stgcn_train_step_resolve uses
     const bool use_mxw = mx_kind == 2;                                                      // 16 <= num_patch <= 47: the wide chain
     const bool use_mx = mx_kind != 0;
-    if (path == RULGNN_STEP_MX && !use_mx) return RULGNN_EUNSUPPORTED;
+    if ((path == RULGNN_STEP_MX || path == RULGNN_STEP_MX_PERSIST) && !use_mx) return RULGNN_EUNSUPPORTED;
 
     StepScratch* sc = step_scratch(k.cells, L);
     const bool fused_adam = opt && mode == TM_FWDBWD;
@@ -1627,7 +1628,12 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
     int grids[16] = {0};
     if (use_mx) {
         const MxTrainArgs m = mx_args<L>(s, a, k, use_mxw);
-        for (int ph = 0; ph <= 4 * L; ++ph) {
+        // RULGNN_STEP_MX_PERSIST, small batches (every workgroup of the phases' grid on a CU of its own): F_1 .. G_0 as ONE launch
+        // behind F_0 -- the BatchNorm reductions behind arrival counters instead of kernel boundaries (stgcn_train_mx.hip; measured
+        // SLOWER than the launches, hence explicit only).  Not under synchronised BatchNorm: the collectives sit between the phases.
+        const bool persist = path == RULGNN_STEP_MX_PERSIST;
+        if (persist && (use_mxw || hook || stgcn_train_mx_persistent_grid(s->batch, L, w.max_grid) == 0)) return RULGNN_EUNSUPPORTED;
+        for (int ph = 0; ph <= (persist ? 0 : 4 * L); ++ph) {
             int grid = 0;
             rc = mx_phase<L>(s, a, k, m, ph, stream, w.max_grid, &grid, use_mxw, ph == 0 && skip_prepare ? &head : nullptr);
             if (rc != RULGNN_OK) return rc;
@@ -1641,6 +1647,13 @@ static int run_train_rw(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_ar
                 if (i > 0) rc = sync_pair<L>(k, cell_bwd(L) + (i - 1) * 2 * F, hook, stream);
             }
             if (rc != RULGNN_OK) return rc;
+        }
+        if (persist) {
+            int grid = 0;
+            rc = stgcn_train_mx_persistent(m, stream, w.max_grid, &grid);
+            if (rc != RULGNN_OK) return rc;
+            grid_top = grid;
+            for (int i = 0; i < 2 * L; ++i) grids[i] = grid;
         }
     } else {
     rc = launch_phase<RW, L, PH_TOP, 0>(k, a->x, a->params, gy, lds, w.max_grid, stream, &grid_top);

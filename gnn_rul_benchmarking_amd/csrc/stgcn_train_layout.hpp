@@ -66,6 +66,11 @@ __host__ __device__ constexpr int cell_stride(int L) { return 2 * (2 * L * 2 * F
 __host__ __device__ __forceinline__ StepScratch* step_scratch(double* cells, int L) {
     return reinterpret_cast<StepScratch*>(cells + CELL_REPLICAS * cell_stride(L));
 }
+// the arrival counter of the single-launch step forms (one 32-bit word behind the step scratch; zero between steps: the prepare kernel
+// and the finalize kernel of a matrix-core step leave it so)
+__host__ __device__ __forceinline__ unsigned* step_barrier(double* cells, int L) {
+    return reinterpret_cast<unsigned*>(reinterpret_cast<char*>(step_scratch(cells, L)) + sizeof(StepScratch));
+}
 __device__ __forceinline__ double cell_sum(const double* cells, int L, int i) {
     double v = 0.0;
 #pragma unroll
@@ -83,14 +88,25 @@ __device__ __forceinline__ double cell_sum(const double* cells, int L, int i) {
 // and published through a flag cost four round trips on the critical path of every workgroup (device-scope stores / loads: the XCDs' L2s
 // are not coherent with each other); a last-arriver ticket at the end of the producing kernel needs a device-scope release fence, which
 // writes the L2 back: ~40 us per kernel.
+// COHERENT (the persistent small-batch launch, stgcn_train_mx.hip): the cells were completed by OTHER workgroups of this same launch
+// (agent-scope atomics, then a counter) -- read them with agent-scope atomic loads (L1-bypassing `sc1` loads: atomics on both sides).
 constexpr int BN_TABLE_ROWS = 7;        // mean, istd, gamma, beta, gamma istd, mean(dy), mean(dy xhat)
+template <bool COHERENT = false>
 __device__ __forceinline__ void bn_pair_to_lds(const double* cells, const float* prm, float* bnc, int L, int N, bool fwd, int b, int lane) {
     const int CS = cell_stride(L);
     const int base = (fwd ? cell_fwd(L) : cell_bwd(L)) + b * 2 * F;
     double v = 0.0;
     if (lane < 2 * F) {
+        if constexpr (COHERENT) {
+            double t[CELL_REPLICAS];
+#pragma unroll
+            for (int r = 0; r < CELL_REPLICAS; ++r) t[r] = __hip_atomic_load(&cells[r * CS + base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int r = 0; r < CELL_REPLICAS; ++r) v += t[r];
+        } else {
 #pragma unroll
         for (int r = 0; r < CELL_REPLICAS; ++r) v += cells[r * CS + base + lane];
+        }
     }
     const double s1 = v, s2 = __shfl(v, (lane + F) & 63, 64);
     if (lane < F) {

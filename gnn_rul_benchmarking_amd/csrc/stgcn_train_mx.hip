@@ -39,6 +39,7 @@
 //
 // Memory.  Inputs arrive by LDS-DMA one tile ahead (each record is requested again as soon as its last LDS read has retired), outputs
 // leave one tile late, right behind the s_waitcnt vmcnt(0) that also counts stores (stgcn_forward_mx.hip, round 3).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -53,9 +54,21 @@ namespace rulgnn {
 // =====================================================================================================================
 // the phase kernel (everything but F_0)
 // =====================================================================================================================
-template <int L, int KIND, int IDX, int NFIX>
-__global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_mx_kernel(MxTrainK a) {
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+// The body of a phase.  PERSIST: the phase runs inside the single small-batch launch (stgcn_train_mx_persist_kernel below): the sums its
+// BatchNorm constants come from were completed by the other workgroups of the SAME launch -- it waits for their arrivals (`target` on the
+// step's counter) right in front of the cell reads, i.e. behind its first tile's requests and the BatchNorm-independent half of the
+// prologue, and reads the cells with agent-scope atomic loads.  Everything else a phase reads was written by the wavefront itself (tile
+// t belongs to the same wavefront in every phase of a launch) or by an earlier launch.
+#ifdef MXP_TRACE
+__device__ unsigned mxp_ts[128];
+__device__ int mxp_n;
+#define MXP_MARK() do { if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0 && mxp_n < 128) mxp_ts[mxp_n++] = (unsigned)wall_clock64(); } while (0)
+#else
+#define MXP_MARK() do {} while (0)
+#endif
+template <int L, int KIND, int IDX, int NFIX, bool PERSIST>
+__device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_all, unsigned target) {
+    MXP_MARK();                                                                    // 0: phase entry
     const int N = NFIX ? NFIX : a.N;
     const int LS = layer_stride(N);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,14 +161,31 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         constexpr int FW0 = WITH_PREV ? 2 * LY - 2 : 2 * LY;                       // first forward pair
         constexpr int NFW = (KIND == PH_F && BLK == 1) || (KIND == PH_G && BLK == 0) ? 1 : 2;
         static_assert(NFW + (KIND == PH_G ? 1 : 0) <= MXT_WAVES, "one reduction pair per wavefront");
-        if (wave < NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
-        if (KIND == PH_G && wave == NFW) bn_pair_to_lds(a.cells, a.prm, bnc, L, N, false, IDX, lane);
+        MXP_MARK();                                                                // 1: independent prologue done
+        if constexpr (PERSIST) {
+            if (threadIdx.x == 0) {
+                unsigned* const ctr = step_barrier(a.cells, L);
+                // (a workgroup that never arrives -- a grid that is not co-resident -- must not hang the GPU: after ~2^22 polls, seconds,
+                // the step is rejected like a guard trip)
+                unsigned spins = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { atomicOr(&step_scratch(a.cells, L)->pad[0], 4u); break; }
+                }
+            }
+            __syncthreads();
+        }
+        constexpr bool COH = PERSIST;
+        MXP_MARK();                                                                // 2: barrier passed
+        if (wave < NFW) bn_pair_to_lds<COH>(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
+        if (KIND == PH_G && wave == NFW) bn_pair_to_lds<COH>(a.cells, a.prm, bnc, L, N, false, IDX, lane);
         if constexpr (KIND == PH_G) {
             wT = conv_bwd_pack(wT_raw);
             if constexpr (BLK == 0 && LY >= 1) thN = theta_pack(thN_raw);
         }
         __syncthreads();
     }
+    MXP_MARK();                                                                    // 3: BatchNorm table in LDS
     LayerK kc;                                   // layer LY
     layer_constants(kc, rc, bnc, LY, g, col, M0_LY, M1_LY);
     LayerK kp;                                   // layer LY - 1 (F_{2l}, l >= 1)
@@ -367,6 +397,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
 #pragma unroll
         for (int r = 0; r < 3; ++r) pend_v[s][r] = pend_q[s][r] = 0.f;
 
+    MXP_MARK();                                                                    // 4: constants ready
     for (; tile < a.ntiles; tile += tstride) {
         const int64_t s0 = tile * 4;
         const int ns_tile = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
@@ -813,6 +844,7 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
         else tile_body(std::false_type{});
     }
 
+    MXP_MARK();                                                                    // 5: tile loop done
     // ---- the last tile's outputs ---------------------------------------------------------------------------------------------------------
     if (pend) {
         if constexpr (WITH_PREV) {
@@ -947,6 +979,69 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     if (__any(bad) && lane == 0) atomicOr(&sc->pad[0], 1u);
 }
 
+template <int L, int KIND, int IDX, int NFIX>
+__global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_mx_kernel(MxTrainK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    mxt_phase_body<L, KIND, IDX, NFIX, false>(a, smem_all, 0u);
+}
+
+// =====================================================================================================================
+// Small batches: F_1 .. G_0 as ONE launch (RULGNN_STEP_MX_PERSIST; an experiment kept as an explicit, tested option -- it does NOT pay:
+// 85 us per step at batch 100 against 77 us for the ten launches, profiles/r06_notes.md section 4).  At the reference protocol's batch
+// (100: configs/hparams.py:16-27) a phase is one tile per wavefront on seven workgroups and the ten-launch chain is ten dispatches + ten
+// prologues at their latency floor.  Here every workgroup walks the phases itself; between two phases stands an arrival counter instead
+// of a kernel boundary:
+//   * arrive: the workgroup's cell atomics (agent scope) and its own record stores are drained (s_waitcnt vmcnt(0)), the wavefronts meet,
+//     one agent-scope atomic add;
+//   * wait: in the NEXT phase's prologue, right in front of the cell reads (mxt_phase_body<PERSIST>): the first tile's LDS-DMA requests
+//     and the parameter loads / operand conversions that need no BatchNorm are in flight by then.
+// No fence on either side: the only data that crosses a workgroup inside the launch are the fp64 cells -- atomics on the producing and
+// the consuming side (MI355X_MICROARCH.md, inter-workgroup visibility: "8-B agent atomics both sides"); tiles stay on the wavefront that
+// owns them (same grid, same tile -> wavefront map in every phase), the gradient rows and the status word are read by the finalize
+// LAUNCH.  F_0 stays its own launch (other translation unit; it also carries the head-of-step scalars).
+// The grid must be co-resident: the host launches it only when every workgroup has a CU of its own.
+// =====================================================================================================================
+// (inlined: as calls -- 80 callee-saved registers through scratch per phase -- the step measured 94 us instead of 85)
+template <int L, int KIND, int IDX, int NFIX>
+__device__ __forceinline__ void mxt_persist_phase(const MxTrainK& a, float* smem_all, unsigned& arrived_phases) {
+    mxt_phase_body<L, KIND, IDX, NFIX, true>(a, smem_all, arrived_phases * gridDim.x);
+    constexpr bool PERSIST = true;
+    MXP_MARK();                                                                    // 6: body returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MXP_MARK();                                                                    // 7: drained
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(step_barrier(a.cells, L), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++arrived_phases;
+}
+template <int L, int NFIX, int I>
+struct MxtPersistChain {
+    static __device__ __forceinline__ void forward(const MxTrainK& a, float* smem_all, unsigned& n) {
+        if constexpr (I > 1) MxtPersistChain<L, NFIX, I - 1>::forward(a, smem_all, n);
+        mxt_persist_phase<L, PH_F, I, NFIX>(a, smem_all, n);
+    }
+    static __device__ __forceinline__ void backward(const MxTrainK& a, float* smem_all, unsigned& n) {
+        mxt_persist_phase<L, PH_G, I, NFIX>(a, smem_all, n);
+        if constexpr (I > 0) MxtPersistChain<L, NFIX, I - 1>::backward(a, smem_all, n);
+    }
+};
+template <int L, int NFIX>
+__global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train_mx_persist_kernel(MxTrainK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    unsigned n = 0;                                   // phases this workgroup has arrived at; F_1 reads what F_0's LAUNCH left: target 0
+    MxtPersistChain<L, NFIX, 2 * L - 1>::forward(a, smem_all, n);
+    mxt_persist_phase<L, PH_TOP, 0, NFIX>(a, smem_all, n);
+    MxtPersistChain<L, NFIX, 2 * L - 1>::backward(a, smem_all, n);
+#ifdef MXP_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < mxp_n; i += 8)
+            printf("phase %d: pro %u wait %u cells %u const %u tiles %u epi %u drain %u | next %u\n", i / 8, mxp_ts[i + 1] - mxp_ts[i], mxp_ts[i + 2] - mxp_ts[i + 1],
+                   mxp_ts[i + 3] - mxp_ts[i + 2], mxp_ts[i + 4] - mxp_ts[i + 3], mxp_ts[i + 5] - mxp_ts[i + 4], mxp_ts[i + 6] - mxp_ts[i + 5],
+                   mxp_ts[i + 7] - mxp_ts[i + 6], i + 8 < mxp_n ? mxp_ts[i + 8] - mxp_ts[i + 7] : 0u);
+        mxp_n = 0;
+    }
+#endif
+}
+
 // =====================================================================================================================
 // host side
 // =====================================================================================================================
@@ -1020,7 +1115,7 @@ float stgcn_train_mx_grad_scale(int64_t global_batch) {
     return ldexpf(1.0f, e + 3);
 }
 
-int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out) {
+static MxTrainK mxt_kernel_args(const MxTrainArgs& m) {
     MxTrainK k;
     k.prm = m.prm; k.y = m.y; k.pred = m.pred; k.cells = m.cells; k.gpart = m.gpart;
     for (int l = 0; l < MX_MAX_LAYERS; ++l) { k.xrec[l] = m.xrec[l]; k.qrec[l] = m.qrec[l]; k.mrec[l] = m.mrec[l]; }
@@ -1031,6 +1126,48 @@ int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t st
     k.gscale = stgcn_train_mx_grad_scale(m.global_batch);
     k.inv_gscale = 1.0f / k.gscale;
     k.do_backward = m.do_backward;
+    return k;
+}
+
+// F_1 .. G_0 of a whole step as one launch (stgcn_train_mx_persist_kernel): two layers, a batch small enough that every workgroup of
+// the phases' common grid (one tile per wavefront) has a CU of its own -- RULGNN_EUNSUPPORTED otherwise, and the caller runs the phases
+// as launches.  *grid_out = the grid: every phase's partial gradient rows (finalize).
+template <int NFIX>
+static int mxt_persist_launch(const MxTrainK& k, hipStream_t stream, int64_t grid) {
+    constexpr int L = 2;
+    auto kern = &stgcn_train_mx_persist_kernel<L, NFIX>;
+    size_t lds = 0;
+    for (int i = 1; i < 2 * L; ++i) lds = std::max(lds, mxt_lds_bytes(L, PH_F, i, k.N));
+    lds = std::max(lds, mxt_lds_bytes(L, PH_TOP, 0, k.N));
+    for (int i = 0; i < 2 * L; ++i) lds = std::max(lds, mxt_lds_bytes(L, PH_G, i, k.N));
+    if (lds > 80 * 1024) return RULGNN_EUNSUPPORTED;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return RULGNN_EHIP;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * MXT_WAVES), lds, stream, k);
+    return hipGetLastError() == hipSuccess ? RULGNN_OK : RULGNN_EHIP;
+}
+int stgcn_train_mx_persistent_grid(int64_t batch, int num_layers, int max_grid) {
+    if (num_layers != 2 || batch <= 0) return 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int64_t grid = ((batch + 3) / 4 + MXT_WAVES - 1) / MXT_WAVES;
+    return grid <= cus && grid <= max_grid ? (int)grid : 0;              // one workgroup per CU: co-resident whatever else runs
+}
+int stgcn_train_mx_persistent(const MxTrainArgs& m, hipStream_t stream, int max_grid, int* grid_out) {
+    const int grid = m.do_backward ? stgcn_train_mx_persistent_grid(m.B, m.L, max_grid) : 0;
+    if (grid == 0) return RULGNN_EUNSUPPORTED;
+    const MxTrainK k = mxt_kernel_args(m);
+    if (grid_out) *grid_out = grid;
+    return k.N == 14 ? mxt_persist_launch<14>(k, stream, grid) : mxt_persist_launch<0>(k, stream, grid);
+}
+
+int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out) {
+    const MxTrainK k = mxt_kernel_args(m);
     if (m.B == 0) { if (grid_out) *grid_out = 0; return RULGNN_OK; }
     const int L = m.L;
     if (kind == PH_TOP) {

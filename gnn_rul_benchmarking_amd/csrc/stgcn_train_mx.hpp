@@ -33,6 +33,11 @@ bool stgcn_train_mx_shape_ok(const rulgnn_stgcn_shape* s, const float* x);
 float stgcn_train_mx_grad_scale(int64_t global_batch);
 // one phase: kind 0 = F_idx (idx >= 1), 1 = TOP, 2 = G_idx
 int stgcn_train_mx_phase(const MxTrainArgs& m, int kind, int idx, hipStream_t stream, int max_grid, int* grid_out);
+// F_1 .. G_0 of a whole two-layer step as ONE launch, for batches whose common phase grid gives every workgroup a CU of its own
+// (stgcn_train_mx.hip: "Small batches"; RULGNN_STEP_MX_PERSIST); RULGNN_EUNSUPPORTED (nothing launched) otherwise.  *grid_out: the
+// workgroups = partial rows.  _grid: that grid for a batch, 0 where the form does not apply.
+int stgcn_train_mx_persistent_grid(int64_t batch, int num_layers, int max_grid);
+int stgcn_train_mx_persistent(const MxTrainArgs& m, hipStream_t stream, int max_grid, int* grid_out);
 // F_0 of the chain (stgcn_forward_mx.hip): windows -> X_0 tiles, packed adjacency tiles, BatchNorm-0 sums
 // (`head` != nullptr: the step runs without its prepare launch, workgroup 0 writes the head-of-step scalars: stgcn_train_layout.hpp)
 struct HeadScalars;

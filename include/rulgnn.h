@@ -246,6 +246,14 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
  *                      A rejected step also increments a STICKY counter inside the workspace
  *                      (rulgnn_stgcn_train_guard_counter_offset) that no kernel ever clears: a caller that does not read the loss
  *                      back every step checks it at its own pace (once per epoch) and so cannot lose a step silently.
+ *   RULGNN_STEP_MX_PERSIST  RULGNN_STEP_MX with F_1 .. G_0 as ONE launch behind F_0, the BatchNorm reductions behind arrival counters
+ *                      instead of kernel boundaries (no fence: the fp64 cells are agent-scope atomics on both sides, a tile stays on
+ *                      the wavefront that owns it) -- same arithmetic, partial rows and finalize as RULGNN_STEP_MX.  num_patch <= 15,
+ *                      two layers, every workgroup of the phases' grid on a CU of its own (up to 16 x #CUs samples), not under
+ *                      synchronised BatchNorm: RULGNN_EUNSUPPORTED otherwise.  Built for the reference protocol's batch (100) and
+ *                      measured SLOWER there (85 us per step against 77 us for the ten launches: the in-kernel breakdown is in
+ *                      profiles/r06_notes.md section 4), so it is an explicit option only.  Its workgroups wait for each other
+ *                      (bounded: ~2^22 polls, then the step is rejected like a guard trip).
  *   RULGNN_STEP_AUTO   = RULGNN_STEP_MX where it applies, else RULGNN_STEP_CHAIN.
  * num_patch > 64 (tiled path) ignores `path`.
  *
@@ -259,10 +267,11 @@ int rulgnn_stgcn_train_step_f32(const rulgnn_stgcn_shape *shape, const rulgnn_st
 #define RULGNN_STEP_CHAIN 1
 #define RULGNN_STEP_COOP  2
 #define RULGNN_STEP_MX    3
+#define RULGNN_STEP_MX_PERSIST 4
 int rulgnn_stgcn_train_step_path_f32(const rulgnn_stgcn_shape *shape, const rulgnn_stgcn_train_args *args,
                                      const rulgnn_adam_args *opt, int32_t path, void *stream);
 /* Which form a whole MSE step (args->y) with `path` runs for this shape and input pointer: RULGNN_STEP_CHAIN, RULGNN_STEP_COOP or
- * RULGNN_STEP_MX; RULGNN_EUNSUPPORTED for the tiled path (num_patch > 64) and for an explicit form the shape does not allow.  No launch. */
+ * RULGNN_STEP_MX (also for RULGNN_STEP_MX_PERSIST: the same chain and guard protocol); RULGNN_EUNSUPPORTED for the tiled path (num_patch > 64) and for an explicit form the shape does not allow.  No launch. */
 int rulgnn_stgcn_train_step_resolve(const rulgnn_stgcn_shape *shape, const float *x, int32_t path);
 /* Byte offset, inside a training workspace of this shape, of a uint32 that counts the steps the f16 range guard rejected since the
  * caller last zeroed it (the library only ever adds to it; a caller that wants the count zeroes these four bytes when it allocates the

@@ -336,3 +336,89 @@ def test_update_claims_a_clean_workspace_only_after_a_matrix_core_step(N, P):
     assert claimed[0] == 0 and claimed[1] == claimed[2] == 1      # first step: nothing to claim; then the claim
     assert claimed[-3] == 0 and claimed[-2] == claimed[-1] == 1   # dropped behind the autograd-path calls, back one step later
     assert torch.allclose(a.model.flat_params, b.model.flat_params, rtol=1e-4, atol=1e-6)
+
+
+# ---- small batches: F_1 .. G_0 as one launch (RULGNN_STEP_MX_PERSIST, stgcn_train_mx_persist_kernel) -------------------------------------
+@pytest.mark.parametrize("B,p", [(1, 0.0), (3, 0.2), (100, 0.2), (257, 0.2), (1027, 0.0), (4096, 0.2)])
+def test_small_batch_single_launch_equals_the_phase_launches_and_the_oracle(B, p):
+    """RULGNN_STEP_MX_PERSIST runs F_1 .. G_0 as ONE launch (arrival counters instead of kernel boundaries) where the phase grid is at
+    most one workgroup per CU; RULGNN_STEP_MX is the same arithmetic as ten launches.  Same tiles, same partial rows, same finalize:
+    equal up to the order of the fp64 cell atomics."""
+    import gpu_util as G
+    N, P, L = 14, 30, 2
+    rng = np.random.default_rng(B)
+    prm = O.random_params(N, L, seed=B)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    flat, _ = PL.pack_numpy(prm, N, L)
+    rc, one = abi_step(x, y, flat, N, P, L, _lib.STEP_MX_PERSIST, dropout=p, seed=7, step=3)
+    assert rc == 0
+    rc, ten = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=7, step=3)
+    assert rc == 0
+    assert np.isfinite(one["loss"]) and abs(one["loss"] - ten["loss"]) <= 1e-6 * abs(ten["loss"])
+    assert G.rel_err(one["pred"], ten["pred"]) < 1e-6 and G.rel_err(one["bn_batch"], ten["bn_batch"]) < 1e-6
+    check_grads(one["grads"], ten["grads"], N, L, 1e-5)
+    if B <= 1100:
+        pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, p, 7, 3)
+        assert G.rel_err(one["pred"], pred) < TOL and abs(one["loss"] - loss) < TOL * abs(loss) and G.rel_err(one["bn_batch"], bnb) < TOL
+        check_grads(one["grads"], gref, N, L)
+    # with the fused optimizer
+    rc, a1 = abi_step(x, y, flat, N, P, L, _lib.STEP_MX_PERSIST, dropout=p, seed=7, step=3, adam=True)
+    rc2, a10 = abi_step(x, y, flat, N, P, L, _lib.STEP_MX, dropout=p, seed=7, step=3, adam=True)
+    assert rc == 0 and rc2 == 0
+    assert G.rel_err(a1["params"], a10["params"]) < 1e-6 and G.rel_err(a1["m"], a10["m"]) < 1e-5
+
+
+@pytest.mark.parametrize("N,P", [(14, 50), (9, 20)])
+def test_small_batch_single_launch_other_windows(N, P):
+    import gpu_util as G
+    L, B = 2, 100
+    rng = np.random.default_rng(N)
+    prm = O.random_params(N, L, seed=N)
+    x = rng.uniform(0, 1, (B, N, P)).astype(np.float32)
+    y = rng.uniform(0, 1, (B,)).astype(np.float32)
+    flat, _ = PL.pack_numpy(prm, N, L)
+    rc, one = abi_step(x, y, flat, N, P, L, _lib.STEP_MX_PERSIST, dropout=0.2, seed=1, step=2)
+    assert rc == 0
+    pred, loss, gref, bnb = oracle_step(prm, x, y, N, P, L, 0.2, 1, 2)
+    assert G.rel_err(one["pred"], pred) < TOL and abs(one["loss"] - loss) < TOL * abs(loss)
+    check_grads(one["grads"], gref, N, L)
+
+
+def test_small_batch_single_launch_applies_where_it_says():
+    """Beyond one workgroup per CU (4 100 samples on 256 CUs: 257 workgroups), with three layers, on the wide chain: RULGNN_EUNSUPPORTED
+    from the resolver and from the step (nothing launched)."""
+    import gpu_util as G
+    lib = _lib.load()
+    x = torch.zeros(64, device="cuda:0")
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    ok = G.shape_struct(16 * cus, 14, 30, 2)
+    assert lib.rulgnn_stgcn_train_step_resolve(C.byref(ok), C.c_void_p(x.data_ptr()), _lib.STEP_MX_PERSIST) == _lib.STEP_MX
+    for shp in (G.shape_struct(16 * cus + 1, 14, 30, 2), G.shape_struct(100, 14, 30, 3), G.shape_struct(100, 40, 64, 2), G.shape_struct(100, 21, 30, 2)):
+        assert lib.rulgnn_stgcn_train_step_resolve(C.byref(shp), C.c_void_p(x.data_ptr()), _lib.STEP_MX_PERSIST) == _lib.EUNSUPPORTED
+    rng = np.random.default_rng(0)
+    prm = O.random_params(14, 3, seed=0)
+    flat, _ = PL.pack_numpy(prm, 14, 3)
+    rc, _r = abi_step(rng.uniform(0, 1, (8, 14, 30)).astype(np.float32), rng.uniform(0, 1, (8,)).astype(np.float32), flat, 14, 30, 3, _lib.STEP_MX_PERSIST)
+    assert rc == _lib.EUNSUPPORTED
+
+
+def test_small_batch_single_launch_trains_like_the_phase_launches_over_many_steps():
+    """Sixty ``ST_GCN.update`` calls at the reference protocol's batch (100) on one workspace (prepare-free steps: the finalize kernel
+    leaves the cells AND the arrival counter zero) in both launch forms from the same initial state: the loss curves agree."""
+    from gnn_rul_benchmarking_amd.algorithms import ST_GCN
+    dev = torch.device("cuda:0")
+    curves = []
+    for path in (_lib.STEP_MX_PERSIST, _lib.STEP_AUTO):
+        torch.manual_seed(4)
+        algo = ST_GCN({"num_patch": 14, "patch_size": 30, "dropout": 0.2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
+        algo.to(dev).train()
+        algo.model.step_path = path
+        algo.model._seed = 11
+        g = torch.Generator(device="cpu").manual_seed(1)
+        X, y = torch.rand(100, 14, 30, generator=g).to(dev), torch.rand(100, 1, generator=g).to(dev)
+        curves.append([algo.update(X, y, 1)["loss"] for _ in range(60)])
+        algo.check_guard()
+    a, b = np.array(curves[0]), np.array(curves[1])
+    assert np.all(np.isfinite(a)) and a[-1] < a[0]
+    assert np.max(np.abs(a - b) / b) < 1e-4

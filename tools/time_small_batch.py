@@ -1,4 +1,5 @@
-"""ST_GCN.update at small batches: phase chain vs the cooperative single launch (us per step)."""
+"""ST_GCN.update at small batches (us per step): auto (the matrix-core chain as ten launches), the same with F_1 .. G_0 as one launch
+(mx_persist), both also replayed from a hipGraph, the fp32 chain and its cooperative single launch."""
 import sys
 import time
 
@@ -13,7 +14,8 @@ dev = torch.device("cuda:0")
 NP, PS = int(os.environ.get("NP", 14)), int(os.environ.get("PS", 30))      # NP=40 PS=64: the PHM2012 wiring
 for B in [int(v) for v in sys.argv[1:]] or [100, 256, 1024, 2048, 4096]:
     row = []
-    for name, path in (("auto", _lib.STEP_AUTO), ("auto+graph", _lib.STEP_AUTO), ("chain", _lib.STEP_CHAIN), ("coop", _lib.STEP_COOP)):
+    for name, path in (("auto", _lib.STEP_AUTO), ("auto+graph", _lib.STEP_AUTO), ("mx_persist", _lib.STEP_MX_PERSIST),
+                       ("mx_persist+graph", _lib.STEP_MX_PERSIST), ("chain", _lib.STEP_CHAIN), ("coop", _lib.STEP_COOP)):
         torch.manual_seed(0)
         a = ST_GCN({"num_patch": NP, "patch_size": PS, "dropout": 0.2}, {"learning_rate": 1e-4, "weight_decay": 1e-4}, dev)
         a.to(dev).train()
