@@ -62,13 +62,16 @@ namespace rulgnn {
 #ifdef MXP_TRACE
 __device__ unsigned mxp_ts[128];
 __device__ int mxp_n;
-#define MXP_MARK() do { if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0 && mxp_n < 128) mxp_ts[mxp_n++] = (unsigned)wall_clock64(); } while (0)
+__device__ unsigned mxp_id[128];
+#define MXP_MARKI(ID) do { if (PERSIST && blockIdx.x == 0 && threadIdx.x == 0 && mxp_n < 128) { mxp_id[mxp_n] = ID; mxp_ts[mxp_n++] = (unsigned)wall_clock64(); } } while (0)
+#define MXP_MARK() MXP_MARKI(0)
 #else
 #define MXP_MARK() do {} while (0)
+#define MXP_MARKI(ID) do {} while (0)
 #endif
 template <int L, int KIND, int IDX, int NFIX, bool PERSIST>
 __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_all, unsigned target) {
-    MXP_MARK();                                                                    // 0: phase entry
+    MXP_MARKI(100 + KIND * 10 + IDX);                                              // phase entry
     const int N = NFIX ? NFIX : a.N;
     const int LS = layer_stride(N);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -138,6 +141,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
     // which convolutions of the main layer / the previous layer this phase runs, and how
     constexpr int M0_LY = (KIND == PH_F && BLK == 0) ? 1 : 2;                          // conv_block1 of layer LY
     constexpr int M1_LY = (KIND == PH_F && BLK == 0) ? 0 : ((KIND == PH_F) ? 1 : ((KIND == PH_G && BLK == 0) ? 0 : 2));   // conv_block2
+    MXP_MARKI(1);
     LayerRaw rc, rp;
     layer_raw(rc, a.prm, LY, N, g, col, M0_LY, M1_LY);
     if constexpr (WITH_PREV) layer_raw(rp, a.prm, LY - 1, N, g, col, 2, 2);
@@ -161,7 +165,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         constexpr int FW0 = WITH_PREV ? 2 * LY - 2 : 2 * LY;                       // first forward pair
         constexpr int NFW = (KIND == PH_F && BLK == 1) || (KIND == PH_G && BLK == 0) ? 1 : 2;
         static_assert(NFW + (KIND == PH_G ? 1 : 0) <= MXT_WAVES, "one reduction pair per wavefront");
-        MXP_MARK();                                                                // 1: independent prologue done
+        MXP_MARKI(2);                                                              // independent prologue done
         if constexpr (PERSIST) {
             if (threadIdx.x == 0) {
                 unsigned* const ctr = step_barrier(a.cells, L);
@@ -176,7 +180,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
             __syncthreads();
         }
         constexpr bool COH = PERSIST;
-        MXP_MARK();                                                                // 2: barrier passed
+        MXP_MARKI(3);                                                              // barrier passed
         if (wave < NFW) bn_pair_to_lds<COH>(a.cells, a.prm, bnc, L, N, true, FW0 + wave, lane);
         if (KIND == PH_G && wave == NFW) bn_pair_to_lds<COH>(a.cells, a.prm, bnc, L, N, false, IDX, lane);
         if constexpr (KIND == PH_G) {
@@ -185,7 +189,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         }
         __syncthreads();
     }
-    MXP_MARK();                                                                    // 3: BatchNorm table in LDS
+    MXP_MARKI(4);                                                                  // BatchNorm table in LDS
     LayerK kc;                                   // layer LY
     layer_constants(kc, rc, bnc, LY, g, col, M0_LY, M1_LY);
     LayerK kp;                                   // layer LY - 1 (F_{2l}, l >= 1)
@@ -397,7 +401,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
 #pragma unroll
         for (int r = 0; r < 3; ++r) pend_v[s][r] = pend_q[s][r] = 0.f;
 
-    MXP_MARK();                                                                    // 4: constants ready
+    MXP_MARKI(5);                                                                  // constants ready
     for (; tile < a.ntiles; tile += tstride) {
         const int64_t s0 = tile * 4;
         const int ns_tile = (int)((a.B - s0) < 4 ? (a.B - s0) : 4);
@@ -844,7 +848,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         else tile_body(std::false_type{});
     }
 
-    MXP_MARK();                                                                    // 5: tile loop done
+    MXP_MARKI(6);                                                                  // tile loop done
     // ---- the last tile's outputs ---------------------------------------------------------------------------------------------------------
     if (pend) {
         if constexpr (WITH_PREV) {
@@ -865,6 +869,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         }
     }
 
+    MXP_MARKI(7);                                                                  // last tile's stores issued
     // ---- epilogue: the four wavefronts meet here.  BatchNorm pair: fp64 from the 16-lane reduction on, the wavefronts' sums combined in
     // a fixed order, one atomic per channel and workgroup ---------------------------------------------------------------------------------
     StepScratch* const sc = step_scratch(a.cells, L);
@@ -893,6 +898,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         if (lane == 0) pairbuf[wave * PBW + 2 * F] = (double)vl;
     }
     __syncthreads();
+    MXP_MARKI(8);                                                                  // pair sums in LDS
     if (has_pair && threadIdx.x < 2 * F) {
         double* cell = a.cells + (int64_t)(blockIdx.x % CELL_REPLICAS) * CS;
         if (KIND == PH_F) cell += cell_fwd(L) + IDX * 2 * F;
@@ -916,6 +922,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         return;
     }
 
+    MXP_MARKI(9);                                                                  // atomics issued
     // ---- the workgroup's row of partial gradients: the wavefronts add their accumulators into an LDS image of the phase's contiguous
     // parameter range in a fixed order, then the image leaves in coalesced stores -------------------------------------------------------------
     const float us = a.inv_gscale;
@@ -967,6 +974,7 @@ __device__ __forceinline__ void mxt_phase_body(const MxTrainK& a, float* smem_al
         }
         __syncthreads();
     }
+    MXP_MARKI(10);                                                                 // gradient image complete
     if constexpr (KIND == PH_TOP) { rbase = off_fc1_w(N, L); rlen = NN + 2 * N + 1; }
     else if constexpr (BLK == 0) { rbase = LY * LS + off_theta_w(N); rlen = NN + N + CONVW; }
     else { rbase = LY * LS + off_conv_w(N, 1); rlen = CONVW; }
@@ -1006,9 +1014,9 @@ template <int L, int KIND, int IDX, int NFIX>
 __device__ __forceinline__ void mxt_persist_phase(const MxTrainK& a, float* smem_all, unsigned& arrived_phases) {
     mxt_phase_body<L, KIND, IDX, NFIX, true>(a, smem_all, arrived_phases * gridDim.x);
     constexpr bool PERSIST = true;
-    MXP_MARK();                                                                    // 6: body returned
+    MXP_MARKI(11);                                                                 // body returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    MXP_MARK();                                                                    // 7: drained
+    MXP_MARKI(12);                                                                 // drained
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(step_barrier(a.cells, L), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ++arrived_phases;
@@ -1033,10 +1041,11 @@ __global__ __launch_bounds__(64 * MXT_WAVES, MX_WAVES_PER_SIMD) void stgcn_train
     MxtPersistChain<L, NFIX, 2 * L - 1>::backward(a, smem_all, n);
 #ifdef MXP_TRACE
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        for (int i = 0; i < mxp_n; i += 8)
-            printf("phase %d: pro %u wait %u cells %u const %u tiles %u epi %u drain %u | next %u\n", i / 8, mxp_ts[i + 1] - mxp_ts[i], mxp_ts[i + 2] - mxp_ts[i + 1],
-                   mxp_ts[i + 3] - mxp_ts[i + 2], mxp_ts[i + 4] - mxp_ts[i + 3], mxp_ts[i + 5] - mxp_ts[i + 4], mxp_ts[i + 6] - mxp_ts[i + 5],
-                   mxp_ts[i + 7] - mxp_ts[i + 6], i + 8 < mxp_n ? mxp_ts[i + 8] - mxp_ts[i + 7] : 0u);
+        for (int i = 0; i < mxp_n; ++i) {
+            if (mxp_id[i] >= 100) printf("\nphase %u:", mxp_id[i]);
+            else printf(" [%u] +%u", mxp_id[i], mxp_ts[i] - mxp_ts[i - 1]);
+        }
+        printf("\n");
         mxp_n = 0;
     }
 #endif
@@ -1156,7 +1165,9 @@ int stgcn_train_mx_persistent_grid(int64_t batch, int num_layers, int max_grid) 
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int64_t grid = ((batch + 3) / 4 + MXT_WAVES - 1) / MXT_WAVES;
-    return grid <= cus && grid <= max_grid ? (int)grid : 0;              // one workgroup per CU: co-resident whatever else runs
+    // one workgroup per CU: co-resident whatever else runs.  (Measured with a 512-workgroup grid at the headline batch: 0.44 ms against
+    // 0.345 for the launches, 0.23 against 0.14 at 16 384 -- one register allocation for eight bodies spills in the tile loops.)
+    return grid <= cus && grid <= max_grid ? (int)grid : 0;
 }
 int stgcn_train_mx_persistent(const MxTrainArgs& m, hipStream_t stream, int max_grid, int* grid_out) {
     const int grid = m.do_backward ? stgcn_train_mx_persistent_grid(m.B, m.L, max_grid) : 0;
