@@ -332,6 +332,12 @@ def main():
                                  "unit": "samples/s", "vs_fp32_chain": fp["vs_fp32_chain"],
                                  "note": "the same step with every product in plain fp32 FMAs (RULGNN_STEP_CHAIN, the path a guard trip falls back to), "
                                          "same batch, dropout 0.2, timed beside the headline"}
+            # the reference protocol's batch (configs/hparams.py:16-27: batch_size 100): ten dependent launches at their latency floor
+            out["train_batch_100"] = dict(stgcn_train_other_shape(dev, NUM_PATCH, args.patch_size, [100], steps=50, fp32_batches=(100,),
+                                                                   single_launch_batches=(100,)),
+                                          workload="ST_GCN.update at the reference protocol's batch (100) at 14 x 30, dropout 0.2: the matrix-core chain as ten "
+                                                   "launches (what RULGNN_STEP_AUTO runs), the fp32 chain, and F_1 .. G_0 as ONE launch behind arrival counters "
+                                                   "(RULGNN_STEP_MX_PERSIST: built, measured slower, explicit option only -- profiles/r06_notes.md section 4)")
             # the reference's real C-MAPSS window is 50 points (Data_Process/Data_read_CMAPSS.py:330; BASELINE.json names 30): the same step at 14 x 50
             out["train_cmapss_14x50"] = dict(stgcn_train_other_shape(dev, NUM_PATCH, 50, [per_rank], fp32_batches=(per_rank,)),
                                              workload="ST_GCN.update at the reference's own C-MAPSS window (14 sensors x 50 points), same batch, dropout 0.2: "

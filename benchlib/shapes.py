@@ -17,7 +17,7 @@ if ROOT not in sys.path:
 from .common import HBM_PEAK_GBS, FP32_MFMA_PEAK_TFLOPS, F16X2_SPLIT_PEAK_TFLOPS, event_time_ms, algorithmic_bytes_per_sample, mfma_util_from_profile
 
 
-def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
+def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=(), single_launch_batches=()):
     """ST_GCN.update at another wiring (the reference's own PHM2012 40 x 64, configs/hparams.py:223,238): ms per step and samples/s per batch
     on the chain AUTO resolves to (the wide matrix-core chain, csrc/stgcn_train_mxw.hip), and -- for ``fp32_batches`` -- on the fp32 phase chain
     (RULGNN_STEP_CHAIN, the row-mapped path of rounds 1-3) in the same run."""
@@ -28,8 +28,10 @@ def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
         g = torch.Generator(device=dev).manual_seed(5)
         X, y = torch.rand(B, N, P, device=dev, generator=g), torch.rand(B, 1, device=dev, generator=g)
         entry = {}
-        for name, path in (("auto", _lib.STEP_AUTO), ("fp32_chain", _lib.STEP_CHAIN)):
+        for name, path in (("auto", _lib.STEP_AUTO), ("fp32_chain", _lib.STEP_CHAIN), ("single_launch", _lib.STEP_MX_PERSIST)):
             if name == "fp32_chain" and B not in fp32_batches:
+                continue
+            if name == "single_launch" and B not in single_launch_batches:
                 continue
             torch.manual_seed(0)
             algo = ST_GCN(dict(num_patch=N, patch_size=P, dropout=0.2), {"learning_rate": 1e-3, "weight_decay": 1e-4}, dev)
@@ -45,6 +47,8 @@ def stgcn_train_other_shape(dev, N, P, batches, steps=10, fp32_batches=()):
                              "step_algorithmic_frac": round(alg * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if "fp32_chain" in entry:
             out[f"batch_{B}"].update(fp32_chain_ms_per_step=round(entry["fp32_chain"], 4), vs_fp32_chain=round(entry["fp32_chain"] / ms, 2))
+        if "single_launch" in entry:      # RULGNN_STEP_MX_PERSIST: F_1 .. G_0 as one launch behind arrival counters (built, slower: explicit option)
+            out[f"batch_{B}"].update(single_launch_ms_per_step=round(entry["single_launch"], 4))
         del X, y
     return out
 
