@@ -58,8 +58,14 @@ static bool tiled_eval(const rulgnn_stgcn_shape* shape) {
 }
 static bool tiled(const rulgnn_stgcn_shape* shape) { return stgcn_train_workspace_bytes(shape) == 0; }
 
+// MPNN order k > 1 exists on the fused row-mapped kernels only: a shape they cannot hold (a window beyond a wavefront's LDS staging area,
+// more layers than the phase chain is instantiated for) must NOT fall through to the tiled kernels, which read the order-1 layout.
+static bool order_needs_tiled(const rulgnn_stgcn_shape* shape, bool train) {
+    return shape->mpnn_k != 1 && (train ? tiled(shape) : tiled_eval(shape));
+}
+
 size_t rulgnn_stgcn_forward_workspace_bytes(const rulgnn_stgcn_shape* shape) {
-    if (validate_shape(shape) != RULGNN_OK) return 0;
+    if (validate_shape(shape) != RULGNN_OK || order_needs_tiled(shape, false)) return 0;
     return tiled_eval(shape) ? stgcn_tiled_forward_workspace_bytes(shape) : 0;
 }
 
@@ -69,6 +75,7 @@ int rulgnn_stgcn_forward_path_f32(const rulgnn_stgcn_shape* shape, const float* 
     int rc = validate_shape(shape);
     if (rc != RULGNN_OK) return rc;
     if (path != RULGNN_EVAL_AUTO && path != RULGNN_EVAL_EXACT && path != RULGNN_EVAL_MX) return RULGNN_EINVAL;
+    if (order_needs_tiled(shape, false)) return RULGNN_EUNSUPPORTED;
     if (shape->batch == 0) return RULGNN_OK;
     rc = check_ptrs({x, params, bn_stats, pred});
     if (rc != RULGNN_OK) return rc;
@@ -96,6 +103,7 @@ int rulgnn_stgcn_forward_mx_taps_f32(const rulgnn_stgcn_shape* shape, const floa
 }
 
 static size_t train_ws_bytes(const rulgnn_stgcn_shape* shape) {
+    if (order_needs_tiled(shape, true)) return 0;
     return tiled(shape) ? stgcn_tiled_train_workspace_bytes(shape) : stgcn_train_workspace_bytes(shape);
 }
 

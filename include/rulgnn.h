@@ -46,7 +46,8 @@ typedef struct rulgnn_stgcn_shape {
     int32_t patch_size;   /* P: samples per patch (C-MAPSS view: window), 2..4096 */
     int32_t num_layers;   /* L: SG_TCN layers, 1..8 (reference default 2) */
     int32_t mpnn_k;       /* MPNN order k (Model.py:74-90): 1 (the reference's default and every hparams row) on every path; 2 and 3 on the
-                           * row-mapped fp32 kernels (num_patch <= 64; eval forward, the phase chain incl. synchronised BatchNorm);
+                           * row-mapped fp32 kernels (num_patch <= 64 and a shape those kernels hold -- not the tiled fallback; eval forward, the phase chain incl.
+                           * synchronised BatchNorm);
                            * RULGNN_EUNSUPPORTED beyond, and for RULGNN_STEP_MX / RULGNN_STEP_COOP / RULGNN_EVAL_MX at k > 1 */
 } rulgnn_stgcn_shape;
 

@@ -52,6 +52,11 @@ def test_shape_validation_without_gpu():
     bad = _lib.StgcnShape(4, 14, 30, 2, 4)            # MPNN order: 1..3 (2, 3 on the row-mapped kernels, num_patch <= 64)
     assert lib.rulgnn_stgcn_forward_f32(C.byref(bad), None, None, None, None, None, 0, None) == -2
     assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 160, 16, 2, 2)), None, None, None, None, None, 0, None) == -2
+    # k > 1 on a shape the fused kernels cannot hold (a 4096-point window; four layers) must not fall through to the tiled kernels
+    for shp in (_lib.StgcnShape(4, 14, 4096, 2, 2), _lib.StgcnShape(4, 14, 30, 4, 2)):
+        assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(shp)) == 0
+    assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 14, 4096, 2, 2)), None, None, None, None, None, 0, None) == -2
+    assert lib.rulgnn_stgcn_train_workspace_bytes(C.byref(_lib.StgcnShape(4, 14, 4096, 2, 1))) > 0
     assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 14, 30, 2, 0)), None, None, None, None, None, 0, None) == -1
     assert lib.rulgnn_stgcn_forward_f32(C.byref(_lib.StgcnShape(4, 14, 30, 2, 3)), None, None, None, None, None, 0, None) == -1   # valid shape, null pointers
     ok = _lib.StgcnShape(4, 14, 30, 2, 1)
