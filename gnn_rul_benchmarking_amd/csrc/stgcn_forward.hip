@@ -100,9 +100,10 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_fixup_kernel(const float*
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SPW = Row<RW>::SPW;
     const int N = a.N, L = a.L, P = a.P;
+    const int K = a.K;                            // 1 -- passed like the exact kernel passes it: the two must stay the SAME code, bit for bit
     EvalWeightsLds<RW> w;
-    w.bind(smem, L);
-    float* stage = smem + EvalWeightsLds<RW>::floats(L) + (threadIdx.x >> 6) * a.stage_floats;
+    w.bind(smem, L, K);
+    float* stage = smem + EvalWeightsLds<RW>::floats(L, K) + (threadIdx.x >> 6) * a.stage_floats;
     const int lane = threadIdx.x & 63;
     const int srow = lane / RW, t = lane % RW;
     const int64_t sampleNP = (int64_t)N * P;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_fixup_kernel(const float*
         const bool bad = mine < a.B && !(__builtin_fabsf(out[mine]) <= 3.0e38f);
         if (!__syncthreads_or(bad)) continue;
         if (!filled) {
-            eval_weights_fill<RW>(w, prm, bn, N, L, threadIdx.x, BLOCK);
+            eval_weights_fill<RW>(w, prm, bn, N, L, threadIdx.x, BLOCK, K);
             __syncthreads();
             filled = true;
         }
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(BLOCK) void stgcn_forward_fixup_kernel(const float*
             __builtin_amdgcn_wave_barrier();
             stage_tile(gx + s0 * sampleNP, stage, ns * (int)sampleNP, P, a.Ppad, a.magicP, a.vec4, lane);
             __builtin_amdgcn_wave_barrier();
-            const float pred = eval_tile_valu<RW>(stage, ns, N, P, a.Ppad, L, w, prm, lane);
+            const float pred = eval_tile_valu<RW>(stage, ns, N, P, a.Ppad, L, w, prm, lane, K);
             if (t == 0 && s0 + srow == smp) out[smp] = pred;
         }
     }
