@@ -15,6 +15,8 @@ def make(name, seed):
     torch.manual_seed(seed)
     if name == "ST_GCN":
         cfg, hp, shape = {"num_patch": 14, "patch_size": 30, "dropout": 0.2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 30)
+    elif name == "ST_GCN_order2":       # MPNN order 2 (Model.py:74-90): the fp32 phase chain, a larger flat buffer
+        name, cfg, hp, shape = "ST_GCN", {"num_patch": 14, "patch_size": 30, "dropout": 0.2, "k": 2}, {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 30)
     elif name == "ASTGCNN":
         cfg = dict(num_nodes=14, time_length=50, encoder_out_dim=50, output_dim=64, K=3)
         hp, shape = {"learning_rate": 1e-3, "weight_decay": 1e-4}, (14, 50)
@@ -32,7 +34,7 @@ def make(name, seed):
     return algo, shape
 
 
-@pytest.mark.parametrize("name", ["ST_GCN", "ASTGCNN", "STMSGCN", "FC_STGNN", "ST_Conv"])
+@pytest.mark.parametrize("name", ["ST_GCN", "ST_GCN_order2", "ASTGCNN", "STMSGCN", "FC_STGNN", "ST_Conv"])
 def test_graph_replay_equals_eager_steps(name):
     eager, shape = make(name, 3)
     graphed, _ = make(name, 3)
