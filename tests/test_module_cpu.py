@@ -132,3 +132,27 @@ def test_forward_tape_tokens():
     del bufs[4]
     with pytest.raises(RuntimeError, match="evicted"):
         tape.check(4, t4, bufs, "M")
+
+
+@pytest.mark.parametrize("name", ["stgcn_order2_14x30_bs19", "stgcn_order3_9x21_layers3_bs7"])
+def test_mpnn_order_above_one_module_surface_matches_the_reference(name):
+    """ST_GCN_model(..., k = 2 / 3): the parameters, their order and shapes are the reference's (``named_parameters()`` of its own model,
+    tests/golden/make_golden_order.py); the live ones are views of the flat buffer in that order; its state_dict loads strictly."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    N, P, L, K = int(z["num_patch"]), int(z["patch_size"]), int(z["num_layers"]), int(z["k"])
+    m = ST_GCN_model(N, P, num_layers=L, dropout=0.2, k=K)
+    assert [n for n, _ in m.named_parameters()] == [str(k) for k in z["key_order"]]
+    table = dict(m.named_parameters())
+    assert m.flat_params.numel() == PL.param_count(N, L, K)
+    off_prev = -1
+    for pname, (off, shape) in PL.live_param_layout(N, L, K).items():
+        p = table[pname]
+        assert p.data_ptr() == m.flat_params.data_ptr() + 4 * off and tuple(p.shape) == shape and off > off_prev
+        off_prev = off
+    live = [n for n in z["key_order"].tolist() if ".net0." not in n and ".net1." not in n]
+    assert live == list(PL.live_param_layout(N, L, K).keys())
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")}
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for pname in live:
+        assert np.array_equal(table[pname].detach().numpy(), z["sd:" + pname]), pname
