@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--no-families", action="store_true", help="skip the other four BASELINE.json configurations in the default line")
     ap.add_argument("--no-rmse", action="store_true", help="skip the teacher-task RMSE leg (the other half of BASELINE.json's metric)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-shapes", action="store_true",
+                    help="skip the legs at other batches / windows (batch 100, 14 x 50, 40 x 64, the tiled wirings): a rocprofv3 --stats summary of such a "
+                         "run averages every kernel over the headline batch only (tools/profile_r06.sh)")
     ap.add_argument("--isolated-phases", action="store_true", help="also time every phase kernel re-run back to back (MALL-warm)")
     ap.add_argument("--sync-loss", action="store_true", help="loss.item() every step like the reference")
     ap.add_argument("--force-dp", action="store_true", help="use the data-parallel step even for world_size 1 (exercises RCCL)")
@@ -332,6 +335,7 @@ def main():
                                  "unit": "samples/s", "vs_fp32_chain": fp["vs_fp32_chain"],
                                  "note": "the same step with every product in plain fp32 FMAs (RULGNN_STEP_CHAIN, the path a guard trip falls back to), "
                                          "same batch, dropout 0.2, timed beside the headline"}
+        if world == 1 and not args.no_roofline and not args.no_other_shapes:
             # the reference protocol's batch (configs/hparams.py:16-27: batch_size 100): ten dependent launches at their latency floor
             out["train_batch_100"] = dict(stgcn_train_other_shape(dev, NUM_PATCH, args.patch_size, [100], steps=50, fp32_batches=(100,),
                                                                    single_launch_batches=(100,)),

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T="timeout 420"
 if [[ $parts == *round* ]]; then
   mkdir -p gpurun_out/$tag
-  $T rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o s --output-format csv -- python bench.py --steps 20 --warmup 5 --no-families --no-rmse > gpurun_out/$tag/bench.log 2>&1
+  $T rocprofv3 --kernel-trace --stats -d gpurun_out/$tag/stats -o s --output-format csv -- python bench.py --steps 20 --warmup 5 --no-families --no-rmse --no-other-shapes > gpurun_out/$tag/bench.log 2>&1
   $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/$tag/fetch -o f --output-format csv -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-families --no-rmse --no-roofline > /dev/null 2>&1
   $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/$tag/write -o w --output-format csv -- python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-families --no-rmse --no-roofline > /dev/null 2>&1
   python tools/hbm_traffic_report.py gpurun_out/$tag gpurun_out/$tag/hbm_traffic.json 65536
