@@ -339,29 +339,54 @@ __device__ __forceinline__ void t_o0_at(const float* __restrict__ Hpre, const fl
 }
 
 // (amaxX: the workgroup's max |Xout| as its entry of the next layer's scale-bound row, or null; 256 threads, whole wavefronts)
+// conv_block2 reads o0 at t and t - 2: every position's o0 (a conv_block1 point: twenty loads, 200 FMAs) is computed ONCE, by its own
+// thread, and handed to the thread two positions on through LDS; the two positions in front of the workgroup's 256 are computed by its
+// first two lanes.  (Each thread computing both points itself was 600 FMAs and fifty loads per position: 49.5 us at XJTU-SY batch 1024.)
 __global__ __launch_bounds__(256) void t_tcn_eval_kernel(const float* __restrict__ Hpre, const float* __restrict__ Xin, const float* __restrict__ prm_l,
                                                          const float* __restrict__ bnf, float* __restrict__ Xout, TArgs a, float* __restrict__ amaxX) {
     // prm_l: this layer's parameters (flat layout); bnf: [2][2][F] folded scale/shift of this layer
     __shared__ float l4[4];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float m = 0.f;
-    if (i < a.B * a.N) {
-    const int64_t b = i / a.N;
-    const int t = (int)(i % a.N), N = a.N;
+    __shared__ float so[F][256 + 2];
+    const int N = a.N;
+    const int64_t total = a.B * a.N, i0 = (int64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
     const float* tb = prm_l + off_theta_b(N);
     const float* w1 = prm_l + off_conv_w(N, 0);
     const float* w2 = prm_l + off_conv_w(N, 1);
-    float o0[F], o0m[F], z[F];
-    t_o0_at(Hpre, tb, w1, bnf, bnf + F, b, t, N, o0);
-    t_o0_at(Hpre, tb, w1, bnf, bnf + F, b, t - 2, N, o0m);
-    t_conv_point(o0m, o0, w2, z);
+    const bool in = i < total;
+    const int64_t b = in ? i / N : 0;
+    const int t = in ? (int)(i - b * N) : 0;
+    float o0[F];
 #pragma unroll
-    for (int c = 0; c < F; ++c) {
-        const float o1 = relu(relu(fmaf(z[c], bnf[2 * F + c], bnf[3 * F + c])) + o0[c]);
-        const float xo = o1 + Xin[(b * F + c) * N + t];
-        Xout[(b * F + c) * N + t] = xo;
-        m = fmaxf(m, t_finite_abs(xo));
+    for (int c = 0; c < F; ++c) o0[c] = 0.f;
+    if (in) t_o0_at(Hpre, tb, w1, bnf, bnf + F, b, t, N, o0);
+#pragma unroll
+    for (int c = 0; c < F; ++c) so[c][threadIdx.x + 2] = o0[c];
+    if (threadIdx.x < 2) {
+        const int64_t ih = i0 - 2 + threadIdx.x;
+        float oh[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) oh[c] = 0.f;
+        if (ih >= 0 && ih < total) {
+            const int64_t bh = ih / N;
+            t_o0_at(Hpre, tb, w1, bnf, bnf + F, bh, (int)(ih - bh * N), N, oh);
+        }
+#pragma unroll
+        for (int c = 0; c < F; ++c) so[c][threadIdx.x] = oh[c];
     }
+    __syncthreads();
+    float m = 0.f;
+    if (in) {
+        float o0m[F], z[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) o0m[c] = t >= 2 ? so[c][threadIdx.x] : 0.f;       // (position i - 2 is t - 2 of the same sample)
+        t_conv_point(o0m, o0, w2, z);
+#pragma unroll
+        for (int c = 0; c < F; ++c) {
+            const float o1 = relu(relu(fmaf(z[c], bnf[2 * F + c], bnf[3 * F + c])) + o0[c]);
+            const float xo = o1 + Xin[(b * F + c) * N + t];
+            Xout[(b * F + c) * N + t] = xo;
+            m = fmaxf(m, t_finite_abs(xo));
+        }
     }
     if (amaxX) t_amax_store(m, amaxX, l4);                          // (uniform over the launch)
 }
