@@ -342,8 +342,11 @@ __device__ __forceinline__ void t_o0_at(const float* __restrict__ Hpre, const fl
 // conv_block2 reads o0 at t and t - 2: every position's o0 (a conv_block1 point: twenty loads, 200 FMAs) is computed ONCE, by its own
 // thread, and handed to the thread two positions on through LDS; the two positions in front of the workgroup's 256 are computed by its
 // first two lanes.  (Each thread computing both points itself was 600 FMAs and fifty loads per position: 49.5 us at XJTU-SY batch 1024.)
+// `pooled` (behind the last layer): the channel max-pool of the position (AdaptiveMaxPool1d over the ten channels, NaN-propagating like torch: Model.py:218-219) INSTEAD of the layer's output tensor,
+// which only the pool would read -- a 42-MB write and a launch that read it back at XJTU-SY batch 1024.
 __global__ __launch_bounds__(256) void t_tcn_eval_kernel(const float* __restrict__ Hpre, const float* __restrict__ Xin, const float* __restrict__ prm_l,
-                                                         const float* __restrict__ bnf, float* __restrict__ Xout, TArgs a, float* __restrict__ amaxX) {
+                                                         const float* __restrict__ bnf, float* __restrict__ Xout, TArgs a, float* __restrict__ amaxX,
+                                                         float* __restrict__ pooled = nullptr) {
     // prm_l: this layer's parameters (flat layout); bnf: [2][2][F] folded scale/shift of this layer
     __shared__ float l4[4];
     __shared__ float so[F][256 + 2];
@@ -380,12 +383,21 @@ __global__ __launch_bounds__(256) void t_tcn_eval_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < F; ++c) o0m[c] = t >= 2 ? so[c][threadIdx.x] : 0.f;       // (position i - 2 is t - 2 of the same sample)
         t_conv_point(o0m, o0, w2, z);
+        float xo[F];
 #pragma unroll
         for (int c = 0; c < F; ++c) {
             const float o1 = relu(relu(fmaf(z[c], bnf[2 * F + c], bnf[3 * F + c])) + o0[c]);
-            const float xo = o1 + Xin[(b * F + c) * N + t];
-            Xout[(b * F + c) * N + t] = xo;
-            m = fmaxf(m, t_finite_abs(xo));
+            xo[c] = o1 + Xin[(b * F + c) * N + t];
+            m = fmaxf(m, t_finite_abs(xo[c]));
+        }
+        if (pooled) {
+            float pm = xo[0];
+#pragma unroll
+            for (int c = 1; c < F; ++c) pm = (xo[c] > pm || xo[c] != xo[c]) ? xo[c] : pm;
+            pooled[i] = pm;
+        } else {
+#pragma unroll
+            for (int c = 0; c < F; ++c) Xout[(b * F + c) * N + t] = xo[c];
         }
     }
     if (amaxX) t_amax_store(m, amaxX, l4);                          // (uniform over the launch)
@@ -400,21 +412,6 @@ __global__ void t_bnfold_kernel(const float* __restrict__ prm, const float* __re
     const float sc = g / sqrtf(var + BN_EPS);
     bnf[((l * 2 + blk) * 2 + 0) * F + c] = sc;
     bnf[((l * 2 + blk) * 2 + 1) * F + c] = be - mean * sc;
-}
-
-// channel max-pool (NaN-propagating), Model.py:218-219.  pooled: [B][N]
-__global__ void t_pool_kernel(const float* __restrict__ X, float* __restrict__ pooled, TArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B * a.N) return;
-    const int64_t b = i / a.N;
-    const int t = (int)(i % a.N);
-    float m = X[(b * F) * a.N + t];
-#pragma unroll
-    for (int c = 1; c < F; ++c) {
-        const float v = X[(b * F + c) * a.N + t];
-        m = (v > m || v != v) ? v : m;
-    }
-    pooled[i] = m;
 }
 
 // head after the fc1 GEMM: pred[b] = fc2.b + sum_j fc2.w[j] relu(y1pre[b][j] + fc1.b[j]).  One block per sample.
@@ -542,7 +539,8 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
             rc = sgemm_planes(nullptr, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, 1, nullptr, 0,
                               amax + (size_t)(1 + l) * T_AMAX_MAX, n_th, planes, plane_bytes, stream, true);
             if (rc != RULGNN_OK) return rc;
-            T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, l + 1 < L ? amaxX : (float*)nullptr);
+            T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, l + 1 < L ? amaxX : (float*)nullptr,
+                     l + 1 == L ? pooled : (float*)nullptr);
             float* tmp = Xin; Xin = Xout; Xout = tmp;
             continue;
         }
@@ -554,10 +552,9 @@ int stgcn_tiled_forward_eval(const rulgnn_stgcn_shape* s, const float* x, const 
             rc = sgemm(AX, N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, scaled ? amax : (float*)nullptr,
                        n_pos, scaled ? amax + (size_t)(1 + l) * T_AMAX_MAX : (float*)nullptr, n_th, planes, plane_bytes);
         if (rc != RULGNN_OK) return rc;
-        T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, (float*)nullptr);
+        T_LAUNCH(t_tcn_eval_kernel, BN_, Hpre, Xin, pl, bnf + l * 4 * F, Xout, a, (float*)nullptr, l + 1 == L ? pooled : (float*)nullptr);
         float* tmp = Xin; Xin = Xout; Xout = tmp;
     }
-    T_LAUNCH(t_pool_kernel, BN_, Xin, pooled, a);
     int rc = sgemm_splitk(pooled, N, 1, prm + off_fc1_w(N, L), N, 1, y1pre, N, (int)B, N, N, false, split, stream);          // fc1
     if (rc != RULGNN_OK) return rc;
     (void)hipGetLastError();
@@ -775,7 +772,7 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
             mx = fmaxf(mx, t_finite_abs(acc));
         }
     }
-    if (pooled) {                                                    // (t_pool_kernel)
+    if (pooled) {                                                    // (the channel max-pool, as in t_tcn_eval_kernel)
         float m = xv[0];
 #pragma unroll
         for (int c = 1; c < F; ++c) m = (xv[c] > m || xv[c] != xv[c]) ? xv[c] : m;
