@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
             o1 = h >= a.drop_thr ? o1 * a.drop_scale : 0.f;
         }
         xv[c] = o1 + xv[c];
-        Xout[(b * F + c) * N + t] = xv[c];
+        if (!pooled) Xout[(b * F + c) * N + t] = xv[c];
     }
     if (AXnext) {                                                    // (same sums, in the same order, as t_aggregate_kernel)
         const float* Ab = A + b * F * F;
@@ -778,6 +778,18 @@ __global__ __launch_bounds__(256) void t_tail_train_kernel(const float* __restri
         for (int c = 1; c < F; ++c) m = (xv[c] > m || xv[c] != xv[c]) ? xv[c] : m;
         pooled[i] = m;
         mx = t_finite_abs(m);
+        // The last layer's output is read by nobody but the backward's arg-max (t_tail_bwd_kernel, top): the channel it routes d pooled
+        // to travels as ONE row -- row 0 of the output tensor -- instead of the ten rows it would re-derive it from (76 MB less traffic
+        // per step at XJTU-SY batch 1024).  Same rule as there: the first maximum, the first NaN.
+        int arg = 0;
+        float am = xv[0];
+#pragma unroll
+        for (int c = 1; c < F; ++c) {
+            const bool take = (xv[c] > am) || (xv[c] != xv[c] && am == am);
+            am = take ? xv[c] : am;
+            arg = take ? c : arg;
+        }
+        Xout[(b * F) * N + t] = __builtin_bit_cast(float, arg);
     }
     }
     if (amax_next) t_amax_store(mx, amax_next, l4);                 // (whole wavefronts)
@@ -858,20 +870,12 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int c = 0; c < F; ++c) {
             const int64_t idx = (b * F + c) * N + t;
-            gin[c] = top ? Xout[idx] : dXn[idx];
+            gin[c] = top ? 0.f : dXn[idx];
             zv[c] = z2[idx];
             ov[c] = o0[idx];
         }
         if (top) {
-            int arg = 0;
-            float m = gin[0];
-#pragma unroll
-            for (int c = 1; c < F; ++c) {
-                const float v = gin[c];
-                const bool take = (v > m) || (v != v && m == m);
-                m = take ? v : m;
-                arg = take ? c : arg;
-            }
+            const int arg = __builtin_bit_cast(int, Xout[(b * F) * N + t]);      // (row 0 of the last layer's output: t_tail_train_kernel)
             const float dp = dpooled[b * N + t];
 #pragma unroll
             for (int c = 0; c < F; ++c) gin[c] = (c == arg) ? dp : 0.f;
