@@ -665,8 +665,10 @@ __device__ __forceinline__ void t_st10(float* __restrict__ T, int64_t b, int t, 
 }
 
 // ---- forward --------------------------------------------------------------------------------------
-// H = leaky(Hpre + bias); z1 = conv1(H); sums of z1
-__global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restrict__ Hpre, const float* __restrict__ prm_l, float* __restrict__ H,
+// H = leaky(Hpre + bias); z1 = conv1(H); sums of z1.  H is NOT stored: the layer keeps the product's output Hpre (the GEMM writes it into the
+// layer's slot) and every reader re-derives H from it -- one add and one select per element instead of a 42-MB tensor per layer written
+// here and read three times (XJTU-SY batch 1024).
+__global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restrict__ Hpre, const float* __restrict__ prm_l,
                                                             float* __restrict__ z1, int bn_index, TTrain a) {
     __shared__ float lds[4 * 2 * F];
     const int N = a.N;
@@ -681,7 +683,6 @@ __global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restr
         t_load_H(Hpre, prm_l + off_theta_b(N), b, t, N, h);
         t_load_H(Hpre, prm_l + off_theta_b(N), b, t - 1, N, hm);
         t_conv_point(hm, h, prm_l + off_conv_w(N, 0), z);
-        t_st10(H, b, t, N, h);
         t_st10(z1, b, t, N, z);
 #pragma unroll
         for (int c = 0; c < F; ++c) { sa[c] += z[c]; sb[c] = fmaf(z[c], z[c], sb[c]); }
@@ -690,19 +691,20 @@ __global__ __launch_bounds__(256) void t_conv1_train_kernel(const float* __restr
 }
 
 // o0 = relu(relu(bn1(z1)) + H); z2 = conv2(o0); sums of z2
-__device__ __forceinline__ void t_o0_from(const float* __restrict__ z1, const float* __restrict__ H, const float* bnc, int64_t b, int t, int N,
-                                          float (&o0)[F]) {
+__device__ __forceinline__ void t_o0_from(const float* __restrict__ z1, const float* __restrict__ Hpre, const float* __restrict__ tb, const float* bnc,
+                                          int64_t b, int t, int N, float (&o0)[F]) {
     if (t < 0 || t >= N) {
 #pragma unroll
         for (int c = 0; c < F; ++c) o0[c] = 0.f;
         return;
     }
+    const float bias = tb[t];
 #pragma unroll
     for (int c = 0; c < F; ++c)
-        o0[c] = relu(relu(fmaf(z1[(b * F + c) * N + t], bnc[2 * F + c], bnc[3 * F + c])) + H[(b * F + c) * N + t]);
+        o0[c] = relu(relu(fmaf(z1[(b * F + c) * N + t], bnc[2 * F + c], bnc[3 * F + c])) + leaky(Hpre[(b * F + c) * N + t] + bias));
 }
 
-__global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restrict__ z1, const float* __restrict__ H, const float* __restrict__ prm_l,
+__global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restrict__ z1, const float* __restrict__ Hpre, const float* __restrict__ prm_l,
                                                             float* __restrict__ o0, float* __restrict__ z2, int bn_index, TTrain a) {
     __shared__ float lds[4 * 2 * F];
     __shared__ float bnc[7 * F];
@@ -717,8 +719,8 @@ __global__ __launch_bounds__(256) void t_conv2_train_kernel(const float* __restr
         const int64_t b = i / N;
         const int t = (int)(i - b * N);
         float v[F], vm[F], z[F];
-        t_o0_from(z1, H, bnc, b, t, N, v);
-        t_o0_from(z1, H, bnc, b, t - 2, N, vm);
+        t_o0_from(z1, Hpre, prm_l + off_theta_b(N), bnc, b, t, N, v);
+        t_o0_from(z1, Hpre, prm_l + off_theta_b(N), bnc, b, t - 2, N, vm);
         t_conv_point(vm, v, prm_l + off_conv_w(N, 1), z);
         t_st10(o0, b, t, N, v);
         t_st10(z2, b, t, N, z);
@@ -1074,7 +1076,7 @@ __device__ __forceinline__ void t_dz1_at(const float* __restrict__ gsum0, const 
 }
 
 // conv_block1 backward: weight gradient partials, dHpre = (convT1(dz1) + gsum0) * leaky'(H)
-__global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restrict__ gsum0, const float* __restrict__ z1, const float* __restrict__ H,
+__global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restrict__ gsum0, const float* __restrict__ z1, const float* __restrict__ Hpre,
                                                           const float* __restrict__ prm_l, float* __restrict__ dHpre, float* __restrict__ gpart,
                                                           int bn_index, TTrain a, float* amax_dh) {
     __shared__ __attribute__((aligned(16))) float tile[4][TTR * TTS];
@@ -1098,8 +1100,8 @@ __global__ __launch_bounds__(256) void t_conv1_bwd_kernel(const float* __restric
     if (ok) {
         t_dz1_at(gsum0, z1, bnc, b, t, N, dz);
         t_dz1_at(gsum0, z1, bnc, b, t + 1, N, dzs);
-        t_ld10(H, b, t, N, h);
-        t_ld10(H, b, t - 1, N, hs);
+        t_load_H(Hpre, prm_l + off_theta_b(N), b, t, N, h);               // (H = leaky(Hpre + bias): not stored, t_conv1_train_kernel)
+        t_load_H(Hpre, prm_l + off_theta_b(N), b, t - 1, N, hs);
     }
     t_wgrad_mfma(tile[wave], dz, h, hs, lane, acc0, acc1);
     if (ok) {
@@ -1198,8 +1200,8 @@ __global__ __launch_bounds__(1024) void t_finalize_kernel(TFin f) {
 // ------------------------------------------------------------------------------------------------
 struct TWs {
     size_t T, total;
-    size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each
-    size_t off_Hpre, off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
+    size_t off_X, off_AX, off_H, off_z1, off_o0, off_z2;      // per layer, L (+1 for X) tensors each; off_H holds Hpre = theta(A.X) (H is re-derived)
+    size_t off_gsum, off_gsum0, off_dH, off_dAX, off_dX;
     size_t off_A, off_pooled, off_y1pre, off_y1, off_dy1, off_dpool, off_dpred, off_cells, off_gpart, off_one, off_split, off_split2;
     size_t off_planes, off_planes2, plane_bytes;      // pre-split operand planes of the large products: main stream, side stream
     size_t off_amax;            // [3 L + 3][T_AMAX_MAX] floats: partial maxima of |A.X_l|, |theta_l| and |fc1.weight|, |d Hpre_l|, |pooled|, |d y1|
@@ -1234,7 +1236,6 @@ static void tws_layout(const rulgnn_stgcn_shape* s, TWs* w) {
     w->off_z1 = o; o += (size_t)L * w->T;
     w->off_o0 = o; o += (size_t)L * w->T;
     w->off_z2 = o; o += (size_t)L * w->T;
-    w->off_Hpre = o; o += w->T;
     w->off_gsum = o; o += w->T;
     w->off_gsum0 = o; o += w->T;
     w->off_dH = o; o += (size_t)L * w->T;          // per layer: the side stream's d theta product of layer l reads it while layer l - 1 runs
@@ -1295,7 +1296,7 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
     const int64_t B = s->batch, BN_ = B * N;
     char* ws = static_cast<char*>(ar->workspace);
     auto TP = [&](size_t off, int l) { return reinterpret_cast<float*>(ws + off + (size_t)l * w.T); };
-    float* Hpre = TP(w.off_Hpre, 0); float* gsum = TP(w.off_gsum, 0); float* gsum0 = TP(w.off_gsum0, 0);
+    float* gsum = TP(w.off_gsum, 0); float* gsum0 = TP(w.off_gsum0, 0);
     float* dAX = TP(w.off_dAX, 0); float* dX = TP(w.off_dX, 0);
     float* A = reinterpret_cast<float*>(ws + w.off_A);
     float* pooled = reinterpret_cast<float*>(ws + w.off_pooled);
@@ -1395,15 +1396,16 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             t.drop_key = dropout_layer_key(ar->seed, ar->step, l);
             t.key_dev = sstate ? &sstate->drop_key[l] : nullptr;
             if (l == 0 && !agg0) T_LAUNCH(t_aggregate_kernel, BN_, A, TP(w.off_X, l), (const float*)nullptr, TP(w.off_AX, l), a, am_ax(0));
+            float* const Hpl = TP(w.off_H, l);             // the layer's slot keeps the product's output: H = leaky(Hpre + bias) is re-derived by its readers
             if (few_rows)
-                rc = sgemm_splitk(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, split, stream, am_ax(l),
+                rc = sgemm_splitk(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpl, N, (int)(B * F), N, N, false, split, stream, am_ax(l),
                                   l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th);
             else
-            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpre, N, (int)(B * F), N, N, false, stream, 0, am_ax(l),
+            rc = sgemm(TP(w.off_AX, l), N, 1, pl + off_theta_w(N), N, 1, Hpl, N, (int)(B * F), N, N, false, stream, 0, am_ax(l),
                        l == 0 && agg0 ? (int)B : n_pos, am_th(l), n_th, pb_fwd ? planes : nullptr, pb_fwd);
             if (rc != RULGNN_OK) return rc;
-            T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpre, pl, TP(w.off_H, l), TP(w.off_z1, l), 2 * l, t);
-            T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), TP(w.off_H, l), pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
+            T_LAUNCH_P(t_conv1_train_kernel, BN_, Hpl, pl, TP(w.off_z1, l), 2 * l, t);
+            T_LAUNCH_P(t_conv2_train_kernel, BN_, TP(w.off_z1, l), Hpl, pl, TP(w.off_o0, l), TP(w.off_z2, l), 2 * l + 1, t);
             // (+ the next layer's A.X, or the channel max-pool behind the last layer)
             T_LAUNCH(t_tail_train_kernel, BN_, TP(w.off_z2, l), TP(w.off_o0, l), TP(w.off_X, l), pl, TP(w.off_X, l + 1), 2 * l + 1, t,
                      (const float*)A, l + 1 < L ? TP(w.off_AX, l + 1) : (float*)nullptr, l + 1 < L ? (float*)nullptr : pooled,
