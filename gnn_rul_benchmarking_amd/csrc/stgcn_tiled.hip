@@ -209,8 +209,12 @@ __global__ __launch_bounds__(256) void t_absmax_kernel(const float* __restrict__
 
 // out[b][c][t] = sum_c' A[b][c][c'] in[b][c'][t] (+ add[b][c][t])          (torch.bmm(A, X), Model.py:87)
 // (amax: slot block of `out` when it feeds a large GEMM, else null)
+// (`sp_val` / `sp_arg`: the addend in its SPARSE form -- behind the last layer d X_L is d pooled at the arg-max channel and zero elsewhere:
+// the value per position and the channel (row 0 of the last layer's output slot, t_tail_train_kernel) instead of a ten-row tensor that
+// t_tail_bwd_kernel would write, nine rows of zeros, for this kernel to read back)
 __global__ __launch_bounds__(256) void t_aggregate_kernel(const float* __restrict__ A, const float* __restrict__ in, const float* add, float* out,
-                                                          TArgs a, float* amax) {      // add may alias out (in-place residual accumulation)
+                                                          TArgs a, float* amax, const float* __restrict__ sp_val = nullptr,
+                                                          const float* __restrict__ sp_arg = nullptr) {      // add may alias out (in-place residual accumulation)
     __shared__ float l4[4];
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float m = 0.f;
@@ -224,7 +228,12 @@ __global__ __launch_bounds__(256) void t_aggregate_kernel(const float* __restric
     for (int c = 0; c < F; ++c) x[c] = in[(b * F + c) * a.N + t];
 #pragma unroll
     for (int c = 0; c < F; ++c) r[c] = 0.f;
-    if (add) {
+    if (sp_val) {
+        const float dp = sp_val[i];
+        const int arg = __builtin_bit_cast(int, sp_arg[(b * F) * a.N + t]);
+#pragma unroll
+        for (int c = 0; c < F; ++c) r[c] = c == arg ? dp : 0.f;
+    } else if (add) {
 #pragma unroll
         for (int c = 0; c < F; ++c) r[c] = add[(b * F + c) * a.N + t];
     }
@@ -880,9 +889,7 @@ __global__ __launch_bounds__(256) void t_tail_bwd_kernel(const float* __restrict
             const int arg = __builtin_bit_cast(int, Xout[(b * F) * N + t]);      // (row 0 of the last layer's output: t_tail_train_kernel)
             const float dp = dpooled[b * N + t];
 #pragma unroll
-            for (int c = 0; c < F; ++c) gin[c] = (c == arg) ? dp : 0.f;
-#pragma unroll
-            for (int c = 0; c < F; ++c) dXn[(b * F + c) * N + t] = gin[c];
+            for (int c = 0; c < F; ++c) gin[c] = (c == arg) ? dp : 0.f;      // (d X_L itself is not written: t_aggregate_kernel takes (d pooled, arg))
         }
         const uint32_t ctr = (uint32_t)((a.sample_offset + b) * F) * (uint32_t)N + (uint32_t)t;
         const uint32_t key = a.key_dev ? *a.key_dev : a.drop_key;
@@ -1495,7 +1502,8 @@ int stgcn_tiled_train(const rulgnn_stgcn_shape* s, const rulgnn_stgcn_train_args
             if (l > 0) {
                 // (A^T dAX + dXn, A symmetric.  Folded into the tail kernel of the layer below it cost more there -- 100 adjacency loads and
                 // 100 FMAs per position inside the persistent loop: +22 us -- than this launch takes)
-                T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a, (float*)nullptr);
+                if (l == L - 1) T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, (const float*)nullptr, dX, a, (float*)nullptr, (const float*)dpool, (const float*)TP(w.off_X, L));
+                else T_LAUNCH(t_aggregate_kernel, BN_, A, dAX, dX, dX, a, (float*)nullptr);
             }
         }
     }
